@@ -1,0 +1,124 @@
+"""PredictionModelSDENet -- the glue module of the hot path, MI355X build.
+
+Mirrors the reference's `PredictionModelSDENet` (models/model_base_mix_sde.py:22-207) at the boundary:
+built from the same YAML dict, stages resolved through the same {file_path, module_name, kwargs}
+registry (MODEL:38-45), `forward(data) -> dict` with the same keys and the same in-place side effects
+on `data` (MODEL:83-85), `validation_step/test_step` feeding the same metric formulas.  It is a plain
+nn.Module (pytorch_lightning is not in the image); the step methods keep Lightning's signatures so the
+class also drops into a Lightning Trainer where one exists.
+"""
+import os
+from copy import deepcopy
+from importlib.machinery import SourceFileLoader
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from trajsde_amd import runtime
+
+_REPO_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def resolve_class(file_path: str, module_name: str):
+    """The reference's registry: getattr(SourceFileLoader(name, path).load_module(name), name)."""
+    path = file_path if os.path.isfile(file_path) else os.path.join(_REPO_ROOT, file_path)
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f"stage file '{file_path}' not found (cwd or {_REPO_ROOT})")
+    return getattr(SourceFileLoader(module_name, path).load_module(module_name), module_name)
+
+
+class PredictionModelSDENet(nn.Module):
+    def __init__(self, **kwargs) -> None:
+        super().__init__()
+        self.hparams = deepcopy({k: v for k, v in kwargs.items() if k != "init_seed"})
+        init_seed: Optional[int] = kwargs.get("init_seed")
+        for key, value in kwargs.items():
+            if key == "training_specific":
+                for k, v in value.items():
+                    setattr(self, k, v)
+            elif key == "model_specific":
+                for k, v in value["kwargs"].items():
+                    setattr(self, k, v)
+
+        def build(section, offset):
+            args = kwargs[section]
+            kw = dict(args["kwargs"])
+            if init_seed is not None:
+                kw["init_seed"] = init_seed + offset
+            return resolve_class(args["file_path"], args["module_name"])(**kw)
+
+        self.encoder = build("encoder", 1)
+        self.aggregator = build("aggregator", 2)
+        self.decoder = build("decoder", 3)
+
+        self.losses, self.loss_names = [], []
+        for i, path in enumerate(kwargs.get("losses", [])):
+            name = kwargs["losses_module"][i]
+            self.losses.append(resolve_class(path, name)(**dict(kwargs["loss_args"][i])))
+            self.loss_names.append(name)
+        self.loss_weights = kwargs.get("loss_weights", [])
+        self.metrics_tr, self.metrics_vl, self.metric_names = [], [], []
+        for i, path in enumerate(kwargs.get("metrics", [])):
+            name = kwargs["metrics_module"][i]
+            metric = resolve_class(path, name)(**dict(kwargs["metric_args"][i]))
+            self.metrics_tr.append(metric)
+            self.metrics_vl.append(deepcopy(metric))
+            self.metric_names.append(name)
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def forward(self, data, noise: Optional["runtime.NoiseSpec"] = None):
+        """MODEL:74-102.  `noise` (optional, ours) selects the Philox seed or injected normals; the default
+        draws a fresh Philox seed from torch's global generator, like the reference draws fresh noise."""
+        if getattr(self, "ood", False):
+            raise NotImplementedError("ood=True / forward_ood is a 'next' row (SURVEY.md 8(f))")
+        noise = runtime.NoiseSpec.resolve(noise)
+        if self.rotate:
+            rotate_mat, y_rot = runtime.rotate_inputs(data)          # MODEL:76-85
+            if y_rot is not None:
+                data.y = y_rot
+            data["rotate_mat"] = rotate_mat
+        else:
+            raise NotImplementedError("rotate=False is not built (shipped config: rotate: true, CFG:18)")
+        local_embed, diff_in, diff_out, label_in, label_out = self.encoder(data=data, noise=noise)
+        global_embed = self.aggregator(data=data, local_embed=local_embed)
+        out = self.decoder(data=data, local_embed=local_embed, global_embed=global_embed, noise=noise)
+        out["diff_in"], out["diff_out"], out["label_in"], out["label_out"] = diff_in, diff_out, label_in, label_out
+        return out
+
+    # -- Lightning-style hooks (MODEL:104-148) ------------------------------------------------------
+    def training_step(self, data, batch_idx):
+        raise NotImplementedError("training needs the backward kernels: SURVEY.md 8(f) rank 1, not built yet")
+
+    def _agent_eval_tensors(self, data, output):
+        idx = data["agent_index"]
+        return output["loc"][:, idx, :, :2], data.y[idx], output["reg_mask"][idx], data["source"]
+
+    def validation_step(self, data, batch_idx):
+        output = self(data)
+        y_hat, y, mask, source = self._agent_eval_tensors(data, output)
+        if not self.is_gtabs:
+            y_hat, y = torch.cumsum(y_hat, dim=-2), torch.cumsum(y, dim=-2)
+        for metric in self.metrics_vl:
+            metric.update(y_hat.detach(), y.detach(), mask.detach(), source.detach())
+        return output
+
+    def test_step(self, data, batch_idx):
+        output = self(data)
+        if data.y is not None:
+            y_hat, y, mask, source = self._agent_eval_tensors(data, output)
+            for metric in self.metrics_vl:
+                metric.update(y_hat.detach(), y.detach(), mask.detach(), source.detach())
+        return output
+
+    def metric_results(self):
+        return {n: float(m.compute()) for n, m in zip(self.metric_names, self.metrics_vl)}
+
+    def configure_optimizers(self):
+        """AdamW + per-epoch cosine annealing (MODEL:204-207)."""
+        self.optimizer = torch.optim.AdamW(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=self.T_max, eta_min=0.0)
+        return [self.optimizer], [self.scheduler]

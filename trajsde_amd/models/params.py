@@ -1,0 +1,135 @@
+"""Parameter containers whose state_dict keys equal the reference's.
+
+The stage modules own plain nn.Parameters -- the optimiser and checkpoints see exactly the names a
+reference checkpoint has -- but no nn.Linear/LayerNorm *compute* modules: all arithmetic happens in
+the HIP kernels, which read packed copies of these tensors.  `ParamTree` registers parameters under
+dotted paths by creating nested anonymous containers ("a.b.0.weight" -> self.a.b.0.weight).
+
+Initial values follow the reference's distributions (models/utils/util.py:94-159 init_weights:
+xavier-uniform Linear weights, zero biases, LayerNorm ones/zeros; models/utils/ode_utils.py:211-215:
+N(0, 0.1) for the GRU unit; N(0, 0.02) for tokens / hidden vectors).
+"""
+import math
+from typing import Dict, Iterator, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+
+class _Node(nn.Module):
+    """Anonymous container; exists only to shape state_dict key names."""
+
+
+class ParamTree(nn.Module):
+    def __init__(self) -> None:
+        super().__init__()
+        self._gen: Optional[torch.Generator] = None
+
+    def set_init_seed(self, seed: Optional[int]) -> None:
+        """Initialise from a private CPU generator (reproducible, independent of the global RNG state;
+        golden fixtures store only this seed).  None -> use the global RNG like the reference does."""
+        self._gen = None if seed is None else torch.Generator().manual_seed(int(seed))
+
+    # -- registration ---------------------------------------------------------------------------
+    def _leaf_parent(self, path: str) -> Tuple[nn.Module, str]:
+        parts = path.split(".")
+        mod: nn.Module = self
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, _Node())
+            mod = mod._modules[p]
+        return mod, parts[-1]
+
+    def add_param(self, path: str, value: torch.Tensor, requires_grad: bool = True) -> nn.Parameter:
+        mod, leaf = self._leaf_parent(path)
+        p = nn.Parameter(value, requires_grad=requires_grad)
+        mod.register_parameter(leaf, p)
+        return p
+
+    def p(self, path: str) -> nn.Parameter:
+        mod: nn.Module = self
+        parts = path.split(".")
+        for q in parts[:-1]:
+            mod = mod._modules[q]
+        return mod._parameters[parts[-1]]
+
+    # -- initialisers ---------------------------------------------------------------------------
+    def _uniform(self, shape, bound):
+        return (torch.rand(shape, generator=self._gen) * 2 - 1) * bound
+
+    def _normal(self, shape, std):
+        return torch.randn(shape, generator=self._gen) * std
+
+    def linear(self, path: str, out_f: int, in_f: int, init: str = "xavier") -> None:
+        if init == "xavier":
+            w = self._uniform((out_f, in_f), math.sqrt(6.0 / (in_f + out_f)))
+        elif init == "normal0.1":
+            w = self._normal((out_f, in_f), 0.1)
+        else:
+            raise ValueError(init)
+        self.add_param(path + ".weight", w)
+        self.add_param(path + ".bias", torch.zeros(out_f))
+
+    def layernorm(self, path: str, dim: int) -> None:
+        self.add_param(path + ".weight", torch.ones(dim))
+        self.add_param(path + ".bias", torch.zeros(dim))
+
+    def token(self, path: str, *shape: int) -> None:
+        self.add_param(path, self._normal(shape, 0.02))
+
+    def constant(self, path: str, value: float) -> None:
+        self.add_param(path, torch.tensor([[float(value)]]), requires_grad=False)
+
+    # -- composite blocks shared by the stages ------------------------------------------------------
+    def single_input_embedding(self, path: str, in_c: int, d: int) -> None:
+        """keys of models/utils/embedding.py:22-40"""
+        self.linear(f"{path}.embed.0", d, in_c)
+        self.layernorm(f"{path}.embed.1", d)
+        self.linear(f"{path}.embed.3", d, d)
+        self.layernorm(f"{path}.embed.4", d)
+        self.linear(f"{path}.embed.6", d, d)
+        self.layernorm(f"{path}.embed.7", d)
+
+    def multiple_input_embedding(self, path: str, in_cs, d: int) -> None:
+        """keys of models/utils/embedding.py:43-70"""
+        for i, c in enumerate(in_cs):
+            self.linear(f"{path}.module_list.{i}.0", d, c)
+            self.layernorm(f"{path}.module_list.{i}.1", d)
+            self.linear(f"{path}.module_list.{i}.3", d, d)
+        self.layernorm(f"{path}.aggr_embed.0", d)
+        self.linear(f"{path}.aggr_embed.2", d, d)
+        self.layernorm(f"{path}.aggr_embed.3", d)
+
+    def attention_block(self, path: str, d: int, qkv=("lin_q", "lin_k", "lin_v")) -> None:
+        """projection / gate / FFN parameters common to AAEncoder, ALEncoder, GlobalInteractorLayer."""
+        for name in (*qkv, "lin_self", "lin_ih", "lin_hh", "out_proj"):
+            self.linear(f"{path}.{name}", d, d)
+        self.layernorm(f"{path}.norm1", d)
+        self.layernorm(f"{path}.norm2", d)
+        self.linear(f"{path}.mlp.0", 4 * d, d)
+        self.linear(f"{path}.mlp.3", d, 4 * d)
+
+    def sde_nets(self, path: str, d: int, g_names) -> None:
+        """drift f (66-64-64-64), diffusion nets (66-64-64-1) and the frozen prior constants."""
+        self.linear(f"{path}.f_func.net.0", d, d + 2)
+        self.linear(f"{path}.f_func.net.2", d, d)
+        self.linear(f"{path}.f_func.net.4", d, d)
+        for g in g_names:
+            self.linear(f"{path}.{g}.net.0", d, d + 2)
+            self.linear(f"{path}.{g}.net.2", d, d)
+            self.linear(f"{path}.{g}.net.4", 1, d)
+        self.constant(f"{path}.h_func.theta", 1.0)
+        self.constant(f"{path}.h_func.mu", 0.0)
+
+    def head(self, path: str, in_f: int, d: int, out_f: int) -> None:
+        self.linear(f"{path}.0", d, in_f)
+        self.layernorm(f"{path}.1", d)
+        self.linear(f"{path}.3", out_f, d)
+
+    # -- bookkeeping used by the weight packers -------------------------------------------------
+    def version_stamp(self) -> int:
+        """Changes whenever any parameter is modified in place or re-assigned (optimizer step, load)."""
+        s = 0
+        for p in self.parameters():
+            s = (s * 1000003 + p._version + (p.data_ptr() & 0xFFFF)) & 0xFFFFFFFFFFFF
+        return s
