@@ -1,0 +1,166 @@
+/* trajsde_hip.h -- C-ABI of libtrajsde_hip.so: the MI355X (gfx950) kernels of TrajSDE's forward hot path.
+ *
+ * Boundary: the reference is pure Python; its stage modules
+ *   models/encoders/enc_hivt_nusargo_sde_sep2.py   LocalEncoderSDESepPara2.forward   :66-202
+ *   models/aggregators/agg_hivt.py                 GlobalInteractor.forward          :38-58
+ *   models/decoders/dec_hivt_nusargo_sde.py        SDEDecoder.forward                :77-105
+ *   models/model_base_mix_sde.py                   rotate_mat / y rotation           :75-85
+ * are what a maintainer re-points (YAML file_path) at trajsde_amd/models/...; those Python classes bind the
+ * entry points below with ctypes.  Every entry point
+ *   - takes plain device pointers + sizes + a hipStream_t (passed as void*), no torch types;
+ *   - BORROWS its pointers for the duration of the enqueued work, allocates nothing persistent and writes
+ *     only into caller-provided buffers (workspace sizes come from the *_ws_bytes queries);
+ *   - returns 0 on success or a negative trajsde_status; trajsde_last_error() gives the message
+ *     (thread-local).  No exception crosses this boundary.
+ * All floating point is fp32; bool tensors are 1 byte per element; index tensors are int64 as in the
+ * reference's batch and are narrowed to int32 on device.
+ */
+#ifndef TRAJSDE_HIP_H
+#define TRAJSDE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  TRAJSDE_OK = 0,
+  TRAJSDE_ERR_INVALID = -1,   /* bad argument (null pointer, unsupported size)           */
+  TRAJSDE_ERR_HIP = -2,       /* a HIP runtime call or kernel launch failed              */
+  TRAJSDE_ERR_WORKSPACE = -3, /* caller workspace too small                              */
+  TRAJSDE_ERR_UNSUPPORTED = -4
+} trajsde_status;
+
+const char* trajsde_last_error(void);
+int trajsde_abi_version(void);
+
+/* ---- weights ----------------------------------------------------------------------------------
+ * Parameters stay owned by the Python modules (nn.Parameter).  Each stage hands the library an array
+ * of device pointers in the order given by trajsde_param_name(stage, i) (state_dict key relative to
+ * the stage) and gets back one packed fp32 blob laid out as the kernels' LDS images
+ * (MFMA-fragment order for matrices).  Re-pack whenever a parameter changes. */
+typedef enum { TRAJSDE_STAGE_ENCODER = 0, TRAJSDE_STAGE_AGGREGATOR = 1, TRAJSDE_STAGE_DECODER = 2 } trajsde_stage;
+
+int trajsde_param_count(int stage, int num_layers /*aggregator*/, int num_modes);
+const char* trajsde_param_name(int stage, int index, int num_layers, int num_modes);
+int64_t trajsde_blob_floats(int stage, int num_layers, int num_modes);
+int trajsde_pack_weights(int stage, int num_layers, int num_modes, const float* const* params, int n_params,
+                         float* blob, int64_t blob_floats, void* stream);
+
+/* ---- the batch ------------------------------------------------------------ */
+typedef struct {
+  int32_t N;            /* actors                                   */
+  int32_t A;            /* target agents (= scenes)                 */
+  int32_t E;            /* columns of edge_index                    */
+  int32_t L;            /* lane segments                            */
+  int32_t E_al;         /* columns of lane_actor_index              */
+  int32_t H;            /* historical steps (21)                    */
+  int32_t TT;           /* time slots in positions/padding_mask (21+F_data) */
+  int32_t lane_pts;     /* points per lane segment (10)             */
+  const float* x;                  /* [N,H,2]            */
+  const float* positions;          /* [N,TT,2]           */
+  const uint8_t* padding_mask;     /* [N,TT]  1 = missing */
+  const uint8_t* bos_mask;         /* [N,H]              */
+  const float* rotate_angles;      /* [N]                */
+  const int64_t* edge_index;       /* [2,E]  row0 src, row1 dst */
+  const int64_t* agent_index;      /* [A]    ascending   */
+  const int64_t* batch;            /* [N]    scene id    */
+  const int64_t* source;           /* [A]    0 = nuScenes, 1 = Argoverse */
+  const float* lane_positions;     /* [L,lane_pts,2]     */
+  const float* lane_paddings;      /* [L,lane_pts] 1 = pad */
+  const int64_t* lane_actor_index; /* [2,E_al] row0 lane, row1 actor */
+  const float* lane_actor_vectors; /* [E_al,2]           */
+} trajsde_batch;
+
+/* ---- noise: injected standard normals or in-kernel Philox4x32-10 (curand-free) ------------------
+ * Philox counter = (row id, step, stream, column/4), key = seed; row ids are GLOBAL ids when row_ids
+ * is given, else the local row index (host twin: trajsde_amd/philox.py). */
+typedef struct {
+  uint64_t seed;
+  const float* z;            /* if non-null: injected N(0,1) values, layout documented per call */
+  const int32_t* row_ids;    /* optional global row ids for the Philox counter                  */
+} trajsde_noise;
+
+/* ---- MODEL:75-85  rotate_mat[n] = [[cos,-sin],[sin,cos]],  y_rot = y @ R_n ---------------------- */
+int trajsde_rotate(const float* rotate_angles, int32_t N, const float* y /*[N,F,2] or null*/, int32_t F,
+                   float* rotate_mat /*[N,2,2]*/, float* y_rot /*[N,F,2] or null*/, void* stream);
+
+/* ---- graph preparation (ENC:88-118 fake agents + per-step subgraph + radius drop; AGG:41; ENC:198;
+ *      UTIL:83-92).  Builds, on device: CSR-by-target of edge_index, the virtual rows of the fake
+ *      agents, the compacted (t, edge) list of the 21 agent-agent snapshots with pre-rotated geometry,
+ *      the compacted global and lane-actor edge lists, and their segment pointers.
+ *      Synchronises the stream once to return the three edge counts. */
+typedef struct {
+  int32_t Nt;        /* N + A                                   */
+  int32_t E_ext;     /* edges incl. duplicated agent in-edges   */
+  int32_t E_aa;      /* surviving (t,edge) pairs over 21 steps  */
+  int32_t E_g;       /* global-interactor edges                 */
+  int32_t E_la;      /* lane-actor edges within the radius      */
+  /* device pointers into the caller's graph workspace (valid while it lives) */
+  const int32_t* orig;        /* [Nt] original actor of each extended row         */
+  const uint8_t* nus_mask;    /* [Nt]                                              */
+  const int32_t* eos_idx;     /* [Nt] recurrence iteration whose state is kept    */
+  const int32_t* pick_slot;   /* [Nt] row of diff_pick [2A,64] or -1              */
+  const float* x_fake;        /* [A,H,2]                                           */
+  const float* aa_geom;       /* [E_aa,4] (x_j R_i, edge_attr R_i)                 */
+  const int32_t* aa_dst;      /* [E_aa] snapshot node id t*Nt+i                    */
+  const int32_t* aa_segptr;   /* [H*Nt+1]                                          */
+  const float* g_geom;        /* [E_g,4] (rel_pos R_i, cos dtheta, sin dtheta)     */
+  const int32_t* g_src;       /* [E_g]                                             */
+  const int32_t* g_dst;       /* [E_g]                                             */
+  const int32_t* g_segptr;    /* [N+1]                                             */
+  const float* la_geom;       /* [E_la,4] (lane_feat R_i, lane_actor_vector R_i)   */
+  const int32_t* la_dst;      /* [E_la]                                            */
+  const int32_t* la_segptr;   /* [N+1]                                             */
+} trajsde_graph;
+
+/* Two phases, because the sizes of the compacted lists are data dependent:
+ *   prepare : sort/CSR, fake-agent rows, validity+radius flags, prefix sums; fills the counts and the
+ *             per-node arrays of `out`; synchronises the stream to return the counts.
+ *   compact : writes the compacted edge lists / geometry / segment pointers into `edges_ws`
+ *             (trajsde_graph_edges_ws_bytes(out) bytes) and fills the remaining pointers of `out`.
+ * Both workspaces must stay alive while `out` is in use. */
+int64_t trajsde_graph_ws_bytes(const trajsde_batch* b);
+int trajsde_graph_prepare(const trajsde_batch* b, const float* rotate_mat, float local_radius,
+                          const trajsde_noise* fake_noise /* z: [A,H,2] */, void* ws, int64_t ws_bytes,
+                          trajsde_graph* out, void* stream);
+int64_t trajsde_graph_edges_ws_bytes(const trajsde_batch* b, const trajsde_graph* g);
+int trajsde_graph_compact(const trajsde_batch* b, const float* rotate_mat, void* ws, int64_t ws_bytes,
+                          void* edges_ws, int64_t edges_ws_bytes, trajsde_graph* out, void* stream);
+
+/* ---- encoder stage: AAEncoder (ENC:538-614) -> SDE+GRU recurrence (ENC:128-182, SDEINT:477-485,
+ *      ODEU:136-152) -> ALEncoder (ENC:732-797). */
+int64_t trajsde_encoder_ws_bytes(const trajsde_batch* b, const trajsde_graph* g);
+int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, const float* rotate_mat,
+                            const float* blob, const float* enc_step_table /*HOST memory, [H,8] (t0,dt,sqrt_h,sin,cos,..)*/,
+                            const trajsde_noise* noise /* z: [H,Nt,64] */, void* ws, int64_t ws_bytes,
+                            float* local_embed /*[N,64]*/, float* diff_pick /*[2A,64]*/,
+                            float* aa_out /*[H,Nt,64] or null*/, float* latent_ys /*[H,N,64] or null*/,
+                            void* stream);
+
+/* ---- aggregator stage: GlobalInteractor (AGG:38-58, 92-135) ------------------------------------ */
+int64_t trajsde_aggregator_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int num_modes);
+int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers,
+                               int num_modes, const float* local_embed /*[N,64]*/, void* ws, int64_t ws_bytes,
+                               float* global_embed /*[K,N,64]*/, void* stream);
+
+/* ---- decoder stage: SDEDecoder (DEC:77-105) with the stock Euler-Maruyama solve over the float32
+ *      schedule tables of SURVEY.md App. D (trajsde_amd/schedule.py). */
+int64_t trajsde_decoder_ws_bytes(int32_t N, int num_modes);
+int trajsde_decoder_forward(int32_t N, int num_modes, int future_steps, const float* blob,
+                            const float* local_embed /*[N,64]*/, const float* global_embed /*[K,N,64]*/,
+                            const float* step_table /*[n_euler,8]*/, int n_euler,
+                            const float* out_table /*[T,4] (steps_done,w0,w1,0)*/, float min_scale,
+                            const trajsde_noise* noise /* z: [n_euler,K*N,64] */, void* ws, int64_t ws_bytes,
+                            float* loc /*[K,N,T,4]*/, float* pi /*[N,K]*/, void* stream);
+
+/* ---- step-granular decoder SDE step (state round-trips HBM every step): the 512 B/path-step variant
+ *      of SURVEY.md 8(d), kept for the HBM-roofline measurement the north star asks for. */
+int trajsde_sde_step(int32_t rows, const float* blob, const float* y_in, float* y_out,
+                     const float* step_entry /*[8] host values*/, int step, const trajsde_noise* noise, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAJSDE_HIP_H */

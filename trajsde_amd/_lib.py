@@ -1,0 +1,81 @@
+"""ctypes binding of libtrajsde_hip.so (include/trajsde_hip.h).  There is no fallback: if the HIP library
+is missing or fails to load, every stage raises."""
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtrajsde_hip.so")
+
+STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER = 0, 1, 2
+
+
+class TrajsdeError(RuntimeError):
+    pass
+
+
+class Batch(C.Structure):
+    _fields_ = [("N", C.c_int32), ("A", C.c_int32), ("E", C.c_int32), ("L", C.c_int32), ("E_al", C.c_int32),
+                ("H", C.c_int32), ("TT", C.c_int32), ("lane_pts", C.c_int32),
+                ("x", C.c_void_p), ("positions", C.c_void_p), ("padding_mask", C.c_void_p), ("bos_mask", C.c_void_p),
+                ("rotate_angles", C.c_void_p), ("edge_index", C.c_void_p), ("agent_index", C.c_void_p),
+                ("batch", C.c_void_p), ("source", C.c_void_p), ("lane_positions", C.c_void_p),
+                ("lane_paddings", C.c_void_p), ("lane_actor_index", C.c_void_p), ("lane_actor_vectors", C.c_void_p)]
+
+
+class Noise(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("z", C.c_void_p), ("row_ids", C.c_void_p)]
+
+
+class Graph(C.Structure):
+    _fields_ = [("Nt", C.c_int32), ("E_ext", C.c_int32), ("E_aa", C.c_int32), ("E_g", C.c_int32), ("E_la", C.c_int32),
+                ("orig", C.c_void_p), ("nus_mask", C.c_void_p), ("eos_idx", C.c_void_p), ("pick_slot", C.c_void_p),
+                ("x_fake", C.c_void_p), ("aa_geom", C.c_void_p), ("aa_dst", C.c_void_p), ("aa_segptr", C.c_void_p),
+                ("g_geom", C.c_void_p), ("g_src", C.c_void_p), ("g_dst", C.c_void_p), ("g_segptr", C.c_void_p),
+                ("la_geom", C.c_void_p), ("la_dst", C.c_void_p), ("la_segptr", C.c_void_p)]
+
+
+_lib: Optional[C.CDLL] = None
+
+# every symbol include/trajsde_hip.h declares: (restype, argtypes)
+P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SIGNATURES = {
+    "trajsde_last_error": (C.c_char_p, []),
+    "trajsde_abi_version": (C.c_int, []),
+    "trajsde_param_count": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "trajsde_param_name": (C.c_char_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "trajsde_blob_floats": (I64, [C.c_int, C.c_int, C.c_int]),
+    "trajsde_pack_weights": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(P), C.c_int, P, I64, P]),
+    "trajsde_rotate": (C.c_int, [P, I32, P, I32, P, P, P]),
+    "trajsde_graph_ws_bytes": (I64, [C.POINTER(Batch)]),
+    "trajsde_graph_prepare": (C.c_int, [C.POINTER(Batch), P, F32, C.POINTER(Noise), P, I64, C.POINTER(Graph), P]),
+    "trajsde_graph_edges_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
+    "trajsde_graph_compact": (C.c_int, [C.POINTER(Batch), P, P, I64, P, I64, C.POINTER(Graph), P]),
+    "trajsde_encoder_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
+    "trajsde_encoder_forward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, C.POINTER(Noise), P, I64, P, P, P, P, P]),
+    "trajsde_aggregator_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph), C.c_int]),
+    "trajsde_aggregator_forward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, C.c_int, C.c_int, P, P, I64, P, P]),
+    "trajsde_decoder_ws_bytes": (I64, [I32, C.c_int]),
+    "trajsde_decoder_forward": (C.c_int, [I32, C.c_int, C.c_int, P, P, P, P, C.c_int, P, F32, C.POINTER(Noise), P, I64, P, P, P]),
+    "trajsde_sde_step": (C.c_int, [I32, P, P, P, C.POINTER(F32), C.c_int, C.POINTER(Noise), P]),
+}
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise TrajsdeError(f"{LIB_PATH} is missing: build it with `python -m trajsde_amd.build` "
+                               "(there is no CPU/PyTorch fallback for the hot path)")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)       # AttributeError here = header/library mismatch: fail loudly
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = lib().trajsde_last_error().decode()
+        raise TrajsdeError(f"{what or 'trajsde call'} failed ({status}): {msg}")

@@ -1,0 +1,320 @@
+// attn.hip -- the graph-attention family shared by AAEncoder (ENC:498-614), ALEncoder (ENC:693-797) and
+// GlobalInteractorLayer (AGG:61-135), decomposed for gfx950 as
+//   node kernel   : embeddings / norm1 / q (and k_node, v_node) per node           -> MFMA, 16 nodes per wave
+//   edge kernel   : neighbour embedding (3 GEMMs) + k,v + per-head logits per edge -> MFMA, 16 edges per wave
+//   segment kernel: per-target softmax + weighted sum over the CSR segment          -> one wave per target, lane = feature
+//   update kernel : gate, lin_self, out_proj, residual, norm2                       -> MFMA
+//   ffn kernel    : 64 -> 256 -> 64 + residual                                      -> MFMA
+// Edges arrive sorted by target (prep.hip), so a target's messages are one contiguous slab: the segment
+// softmax needs no atomics and is bitwise deterministic.  q is computed once per target instead of once
+// per edge as the reference does (ENC:586, AGG:108); same values, 1/deg of the work.
+#include "common.hpp"
+#include "kernels.hpp"
+#include "layouts.hpp"
+#include "tile.hpp"
+
+namespace tsde {
+
+constexpr float INV_SQRT_DH = 0.35355339059327373f;   // 1/sqrt(64/8)  (ENC:589-590)
+
+// ------------------------------------------------------------------------------------------------ AA node
+__global__ __launch_bounds__(512) void k_aa_center(const float* __restrict__ img_g, const float* __restrict__ x,
+                                                   const float* __restrict__ x_fake, const float* __restrict__ rot,
+                                                   const uint8_t* __restrict__ bos, const int32_t* __restrict__ orig,
+                                                   int N, int Nt, int H, float* __restrict__ center,
+                                                   float* __restrict__ cn, float* __restrict__ q) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img_g, AaCenterL::SIZE);
+  using A = AaCenterL;
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t rows = int64_t(H) * Nt, ntiles = (rows + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < rows ? row : rows - 1;
+    const int t = int(r / Nt), i = int(r - int64_t(t) * Nt), o = orig[i];
+    const float* xp = i < N ? x + (int64_t(i) * H + t) * 2 : x_fake + (int64_t(i - N) * H + t) * 2;
+    const f4 R = *reinterpret_cast<const f4*>(rot + 4 * o);
+    const float x0 = xp[0], x1 = xp[1];
+    const float r0 = x0 * R[0] + x1 * R[2], r1 = x0 * R[1] + x1 * R[3];          // x_t @ R_n  (ENC:550-552)
+    f4 a[4], b[4];
+    linear_in2(a, r0, r1, lds + A::W0, lds + A::B0, L.g);
+    layer_norm<4>(a, lds + A::G1, lds + A::E1, L.g);
+    relu<4>(a);
+    linear<4, 4>(b, a, lds + A::W3, lds + A::B3, L);
+    layer_norm<4>(b, lds + A::G4, lds + A::E4, L.g);
+    relu<4>(b);
+    linear<4, 4>(a, b, lds + A::W6, lds + A::B6, L);
+    layer_norm<4>(a, lds + A::G7, lds + A::E7, L.g);
+    if (bos[int64_t(o) * H + t]) load_vec<4>(a, lds + A::BOS + t * 64, L.g);      // ENC:554-556
+    if (row < rows) store_row(a, center, row, L.g);
+    layer_norm<4>(a, lds + A::N1G, lds + A::N1B, L.g);                            // norm1 (ENC:563)
+    if (row < rows) store_row(a, cn, row, L.g);
+    linear<4, 4>(b, a, lds + A::WQ, lds + A::BQ, L);
+    if (row < rows) store_row(b, q, row, L.g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ edges
+// MultipleInputEmbedding on the two pre-rotated 2-vectors of an edge (EMB:62-70) -> emb
+__device__ __forceinline__ void edge_embed(f4 (&emb)[4], const f4 geom, const float* lds, const Lane& L) {
+  using E = EdgeL;
+  f4 h0[4], h1[4], s[4];
+  linear_in2(h0, geom[0], geom[1], lds + E::A_W0, lds + E::A_B0, L.g);
+  layer_norm<4>(h0, lds + E::A_G, lds + E::A_E, L.g);
+  relu<4>(h0);
+  linear_in2(h1, geom[2], geom[3], lds + E::B_W0, lds + E::B_B0, L.g);
+  layer_norm<4>(h1, lds + E::B_G, lds + E::B_E, L.g);
+  relu<4>(h1);
+  load_vec<4>(s, lds + E::B3, L.g);                       // b0.3 + b1.3
+  linear_acc<4, 4>(s, h0, lds + E::WA3, L.lane);
+  linear_acc<4, 4>(s, h1, lds + E::WB3, L.lane);          // sum of the two branches = one K=128 contraction
+  layer_norm<4>(s, lds + E::AG0, lds + E::AE0, L.g);
+  relu<4>(s);
+  linear<4, 4>(emb, s, lds + E::W2, lds + E::B2, L);
+  layer_norm<4>(emb, lds + E::AG3, lds + E::AE3, L.g);
+}
+
+// per-head logits of 16 edges: q.k over the 8 dims of each head / sqrt(8); heads sit pairwise on lane
+// groups (g, g^1).  Stored as logits[e][slot], slot = 4*(head&1) + (head>>1): one 16-B store per lane pair.
+__device__ __forceinline__ void store_logits(const f4 (&qv)[4], const f4 (&k)[4], float* __restrict__ logits, int64_t e,
+                                             bool valid, const Lane& L) {
+  f4 lg;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    float p = qv[jt][0] * k[jt][0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) p = fmaf(qv[jt][c], k[jt][c], p);
+    p += __shfl_xor(p, 16);
+    lg[jt] = p * INV_SQRT_DH;
+  }
+  if (valid && (L.g & 1) == 0) *reinterpret_cast<f4*>(logits + e * 8 + 4 * (L.g >> 1)) = lg;
+}
+
+// AA / AL: embedding -> lin_k | lin_v -> logits with q[dst], v
+__global__ __launch_bounds__(768) void k_edge_kv(const float* __restrict__ img_g, const float* __restrict__ geom,
+                                                 const int32_t* __restrict__ dst, const float* __restrict__ q, int64_t E,
+                                                 float* __restrict__ logits, float* __restrict__ v) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img_g, EdgeL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (E + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
+    const f4 ge = *reinterpret_cast<const f4*>(geom + 4 * ec);
+    const int d = dst[ec];
+    f4 emb[4], kv[8], qv[4];
+    load_row(qv, q, d, L.g);
+    edge_embed(emb, ge, lds, L);
+    linear<8, 4>(kv, emb, lds + EdgeL::WKV, lds + EdgeL::BKV, L);
+    f4 k[4] = {kv[0], kv[1], kv[2], kv[3]};
+    f4 vv[4] = {kv[4], kv[5], kv[6], kv[7]};
+    store_logits(qv, k, logits, e, e < E, L);
+    if (e < E) store_row(vv, v, e, L.g);
+  }
+}
+
+// global interactor: relative-pose embedding only (AGG:42-51), reused by all layers
+__global__ __launch_bounds__(768) void k_edge_embed(const float* __restrict__ img_g, const float* __restrict__ geom, int64_t E,
+                                                    float* __restrict__ emb_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img_g, EdgeL::EMB_SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (E + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
+    const f4 ge = *reinterpret_cast<const f4*>(geom + 4 * ec);
+    f4 emb[4];
+    edge_embed(emb, ge, lds, L);
+    if (e < E) store_row(emb, emb_out, e, L.g);
+  }
+}
+
+// global layer: k = k_node[src] + lin_k_edge(rel), v = v_node[src] + lin_v_edge(rel)  (AGG:108-117)
+__global__ __launch_bounds__(768) void k_global_edge(const float* __restrict__ img_g, const float* __restrict__ rel,
+                                                     const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                     const float* __restrict__ q, const float* __restrict__ kn,
+                                                     const float* __restrict__ vn, int64_t E, float* __restrict__ logits,
+                                                     float* __restrict__ v) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img_g, GEdgeL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (E + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
+    const int s = src[ec], d = dst[ec];
+    f4 r[4], kv[8], qv[4], kns[4], vns[4];
+    load_row(r, rel, ec, L.g);
+    load_row(qv, q, d, L.g);
+    load_row(kns, kn, s, L.g);
+    load_row(vns, vn, s, L.g);
+    linear<8, 4>(kv, r, lds + GEdgeL::WKV, lds + GEdgeL::BKV, L);
+    f4 k[4], vv[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      k[jt] = kns[jt] + kv[jt];
+      vv[jt] = vns[jt] + kv[4 + jt];
+    }
+    store_logits(qv, k, logits, e, e < E, L);
+    if (e < E) store_row(vv, v, e, L.g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ segment softmax
+// torch_geometric.utils.softmax + add-aggregate: alpha = exp(l - max_seg) / (sum_seg + 1e-16); out = sum alpha * v
+__global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restrict__ segptr, const float* __restrict__ logits,
+                                                         const float* __restrict__ v, int64_t R, float* __restrict__ agg) {
+  const int lane = threadIdx.x & 63;
+  const int head = lane >> 3, slot = 4 * (head & 1) + (head >> 1);
+  const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (node >= R) return;
+  const int beg = segptr[node], end = segptr[node + 1];
+  float m = -INFINITY;
+  for (int e = beg; e < end; ++e) m = fmaxf(m, logits[int64_t(e) * 8 + slot]);
+  float s = 0.f, acc = 0.f;
+  int e = beg;
+  for (; e + 4 <= end; e += 4) {
+    float p[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      p[u] = logits[int64_t(e + u) * 8 + slot];
+      vv[u] = v[int64_t(e + u) * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float ex = fast_exp(p[u] - m);
+      s += ex;
+      acc = fmaf(ex, vv[u], acc);
+    }
+  }
+  for (; e < end; ++e) {
+    const float ex = fast_exp(logits[int64_t(e) * 8 + slot] - m);
+    s += ex;
+    acc = fmaf(ex, v[int64_t(e) * 64 + lane], acc);
+  }
+  agg[node * 64 + lane] = end > beg ? acc / (s + 1e-16f) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------ update + FFN
+// gate = sigmoid(lin_ih(agg) + lin_hh(xn)); upd = agg + gate*(lin_self(xn) - agg); x1 = x + out_proj(upd); xn2 = norm2(x1)
+__global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ img_g, const float* __restrict__ agg,
+                                                     const float* __restrict__ xn, const float* __restrict__ x, int64_t R,
+                                                     float* __restrict__ x1, float* __restrict__ xn2) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img_g, UpdL::SIZE);
+  using U = UpdL;
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (R + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
+    f4 a[4], n[4], g[4], s[4];
+    load_row(a, agg, r, L.g);
+    load_row(n, xn, r, L.g);
+    load_vec<4>(g, lds + U::BIH, L.g);
+    linear_acc<4, 4>(g, a, lds + U::WIH, L.lane);
+    {
+      f4 h[4];
+      linear<4, 4>(h, n, lds + U::WHH, lds + U::BHH, L);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) g[jt] += h[jt];
+    }
+    sigmoid_<4>(g);
+    linear<4, 4>(s, n, lds + U::WSELF, lds + U::BSELF, L);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[jt][c] = a[jt][c] + g[jt][c] * (s[jt][c] - a[jt][c]);
+    linear<4, 4>(s, a, lds + U::WOUT, lds + U::BOUT, L);
+    load_row(n, x, r, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) n[jt] += s[jt];
+    if (row < R) store_row(n, x1, row, L.g);
+    layer_norm<4>(n, lds + U::N2G, lds + U::N2B, L.g);
+    if (row < R) store_row(n, xn2, row, L.g);
+  }
+}
+
+// out = x1 + mlp.3(relu(mlp.0(xn2)))
+__global__ __launch_bounds__(512) void k_ffn(const float* __restrict__ img_g, const float* __restrict__ x1,
+                                             const float* __restrict__ xn2, int64_t R, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img_g, FfnL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (R + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
+    f4 n[4], hid[16], o[4];
+    load_row(n, xn2, r, L.g);
+    linear<16, 4>(hid, n, lds + FfnL::W1, lds + FfnL::B1, L);
+    relu<16>(hid);
+    linear<4, 16>(o, hid, lds + FfnL::W2, lds + FfnL::B2, L);
+    load_row(n, x1, r, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) o[jt] += n[jt];
+    if (row < R) store_row(o, out, row, L.g);
+  }
+}
+
+// xn = norm1(x); NQ stacked projections of xn (AL: q; global layer: q, k_node, v_node)
+template <int NQ>
+__global__ __launch_bounds__(512) void k_node_proj(const float* __restrict__ img_g, const float* __restrict__ x, int64_t R,
+                                                   float* __restrict__ xn_out, float* __restrict__ p0, float* __restrict__ p1,
+                                                   float* __restrict__ p2) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using P = NodeProjL<NQ>;
+  stage_blob(lds, img_g, P::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (R + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
+    f4 a[4], pr[4 * NQ];
+    load_row(a, x, r, L.g);
+    layer_norm<4>(a, lds + P::N1G, lds + P::N1B, L.g);
+    if (row < R) store_row(a, xn_out, row, L.g);
+    linear<4 * NQ, 4>(pr, a, lds + P::W, lds + P::B, L);
+    float* outs[3] = {p0, p1, p2};
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      f4 t4[4] = {pr[4 * j], pr[4 * j + 1], pr[4 * j + 2], pr[4 * j + 3]};
+      if (row < R) store_row(t4, outs[j], row, L.g);
+    }
+  }
+}
+
+// global_embed[k] = multihead_proj_k(norm(x))   (AGG:55-57); blockIdx.y = mode
+__global__ __launch_bounds__(512) void k_mode_proj(const float* __restrict__ norm_g, const float* __restrict__ proj_g,
+                                                   const float* __restrict__ x, int64_t N, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int k = blockIdx.y;
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) lds[i] = norm_g[i];
+  stage_blob(lds + 128, proj_g + int64_t(k) * (MAT64 + 64), MAT64 + 64);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (N + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < N ? row : N - 1;
+    f4 a[4], o[4];
+    load_row(a, x, r, L.g);
+    layer_norm<4>(a, lds, lds + 64, L.g);
+    linear<4, 4>(o, a, lds + 128, lds + 128 + MAT64, L);
+    if (row < N) store_row(o, out + int64_t(k) * N * 64, row, L.g);
+  }
+}
+
+template __global__ void k_node_proj<1>(const float*, const float*, int64_t, float*, float*, float*, float*);
+template __global__ void k_node_proj<3>(const float*, const float*, int64_t, float*, float*, float*, float*);
+
+}  // namespace tsde

@@ -1,0 +1,55 @@
+// common.hpp -- host-side helpers shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <string>
+
+#include "../../include/trajsde_hip.h"
+
+namespace tsde {
+
+std::string& last_error_ref();
+int fail(int code, const std::string& msg);
+
+#define TS_HIP(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess)                                                                             \
+      return ::tsde::fail(TRAJSDE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+  } while (0)
+
+#define TS_LAUNCH_CHECK(name)                                                                         \
+  do {                                                                                                \
+    hipError_t _e = hipGetLastError();                                                                \
+    if (_e != hipSuccess)                                                                             \
+      return ::tsde::fail(TRAJSDE_ERR_HIP, std::string("launch ") + name + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+#define TS_REQUIRE(cond, msg)                                                 \
+  do {                                                                        \
+    if (!(cond)) return ::tsde::fail(TRAJSDE_ERR_INVALID, std::string(msg));  \
+  } while (0)
+
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// bump allocator over a caller-provided workspace
+struct Carver {
+  char* base;
+  int64_t size, off;
+  bool ok;
+  Carver(void* p, int64_t n) : base(static_cast<char*>(p)), size(n), off(0), ok(true) {}
+  template <typename T>
+  T* take(int64_t count) {
+    off = align_up(off, 256);
+    T* p = reinterpret_cast<T*>(base + off);
+    off += count * int64_t(sizeof(T));
+    if (base != nullptr && off > size) ok = false;
+    return p;
+  }
+};
+
+inline int cdiv(int64_t a, int64_t b) { return int((a + b - 1) / b); }
+
+}  // namespace tsde

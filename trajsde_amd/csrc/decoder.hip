@@ -1,0 +1,194 @@
+// decoder.hip -- SDEDecoder (reference models/decoders/dec_hivt_nusargo_sde.py:77-105) for gfx950.
+//
+//   k_dec_init    y0 = ReLU(LN(Linear(128->64)(cat(global, local))))  (DEC:82)   and   pi head (DEC:93-94)
+//   k_sde_decode  the whole Euler-Maruyama solve of stock torchsde.sdeint (DEC:88) fused with the loc/scale
+//                 heads (DEC:95-98): one 16-path tile per wave, state in registers for all steps, drift and
+//                 diffusion MLP weights + heads resident in LDS (~120 KB, fragment order), noise from
+//                 in-kernel Philox (or injected), time bookkeeping replayed from the float32 schedule table
+//                  so the micro-step of T in {30,50,60} is reproduced.
+//   k_sde_step    the same step with the state round-tripping HBM (512 B / path-step), for the roofline report.
+#include "common.hpp"
+#include "layouts.hpp"
+#include "philox.hpp"
+#include "sde_funcs.hpp"
+#include "tile.hpp"
+
+namespace tsde {
+
+// Linear(64,64)-LN-ReLU-Linear(64,2) head on state s -> (o0, o1)
+__device__ __forceinline__ void head_eval(float& o0, float& o1, const f4 (&s)[4], const float* img, const Lane& L) {
+  f4 h[4];
+  linear<4, 4>(h, s, img + HeadL::W0, img + HeadL::B0, L);
+  layer_norm<4>(h, img + HeadL::G, img + HeadL::E, L.g);
+  relu<4>(h);
+  o0 = row_dot(h, img + HeadL::W3, L.g) + img[HeadL::B3];
+  o1 = row_dot(h, img + HeadL::W3 + 64, L.g) + img[HeadL::B3 + 1];
+}
+
+__global__ __launch_bounds__(1024) void k_dec_init(const float* __restrict__ blob, const float* __restrict__ local,
+                                                   const float* __restrict__ global, int N, int K,
+                                                   float* __restrict__ y0, float* __restrict__ pi) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, blob, DecInitL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t rows = int64_t(N) * K;
+  const int64_t ntiles = (rows + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n;
+    const int64_t r = row < rows ? row : rows - 1;
+    f4 gl[4], lo[4], a[4];
+    load_row(gl, global, r, L.g);
+    load_row(lo, local, r % N, L.g);
+    load_vec<4>(a, lds + DecInitL::BA, L.g);
+    linear_acc<4, 4>(a, gl, lds + DecInitL::WA_G, L.lane);
+    linear_acc<4, 4>(a, lo, lds + DecInitL::WA_L, L.lane);
+    layer_norm<4>(a, lds + DecInitL::AG, lds + DecInitL::AE, L.g);
+    relu<4>(a);
+    if (row < rows) store_row(a, y0, row, L.g);
+    load_vec<4>(a, lds + DecInitL::BP, L.g);
+    linear_acc<4, 4>(a, lo, lds + DecInitL::WP_L, L.lane);
+    linear_acc<4, 4>(a, gl, lds + DecInitL::WP_G, L.lane);
+    layer_norm<4>(a, lds + DecInitL::PG, lds + DecInitL::PE, L.g);
+    relu<4>(a);
+    const float p = row_dot(a, lds + DecInitL::WP3, L.g) + lds[DecInitL::BP3];
+    if (row < rows && L.g == 0) pi[(r % N) * K + (r / N)] = p;          // pi is [N, K]  (.t() at DEC:94)
+  }
+}
+
+__global__ __launch_bounds__(768) void k_sde_decode(const float* __restrict__ blob, const float* __restrict__ y0,
+                                                     int64_t rows, int T, int n_euler,
+                                                     const float* __restrict__ step_tab, const float* __restrict__ out_tab,
+                                                     float min_scale, NoiseArg na, float* __restrict__ loc) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, blob, DecSdeL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (rows + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    const int64_t row = tile * 16 + L.n;
+    const int64_t r = row < rows ? row : rows - 1;
+    f4 y[4], prev[4];
+    load_row(y, y0, r, L.g);
+    int o = 0;
+    for (int k = 0; k < n_euler; ++k) {
+      keep_lds_reads_here();
+      const float dt = step_tab[k * 8 + 1], sq = step_tab[k * 8 + 2], sn = step_tab[k * 8 + 3], cs = step_tab[k * 8 + 4];
+      f4 f[4], z[4];
+      drift_eval(f, y, lds + DecSdeL::F, sn, cs, L);
+      const float gs = diff_eval(y, lds + DecSdeL::G, sn, cs, L);
+      noise_row(z, na, STREAM_DECODER, k, r, rows, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) prev[jt] = y[jt];
+      em_update(y, f, gs, z, dt, sq);
+      // emit every output whose interpolation bracket closes with this step (linear_interp of the solver)
+      while (o < T && int(out_tab[o * 4]) == k + 1) {
+        keep_lds_reads_here();
+        const float w0 = out_tab[o * 4 + 1], w1 = out_tab[o * 4 + 2];
+        f4 s[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) s[jt][c] = w0 * prev[jt][c] + w1 * y[jt][c];
+        float lx, ly, sx, sy;
+        head_eval(lx, ly, s, lds + DecSdeL::LOC, L);
+        head_eval(sx, sy, s, lds + DecSdeL::SCALE, L);
+        sx = (sx > 0.f ? sx : fast_exp(sx) - 1.0f) + 1.0f + min_scale;       // ELU(alpha=1) + 1 + min_scale (DEC:97-98)
+        sy = (sy > 0.f ? sy : fast_exp(sy) - 1.0f) + 1.0f + min_scale;
+        if (row < rows && L.g == 0) {
+          f4 v = {lx, ly, sx, sy};
+          *reinterpret_cast<f4*>(loc + (row * T + o) * 4) = v;
+        }
+        ++o;
+      }
+    }
+  }
+}
+
+// step-granular variant: one Euler-Maruyama step, state read from and written to HBM (no heads)
+__global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blob, const float* __restrict__ y_in,
+                                                   float* __restrict__ y_out, int64_t rows, float dt, float sq, float sn,
+                                                   float cs, int step, NoiseArg na) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, blob, DecSdeL::LOC);   // F and G images only
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (rows + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    const int64_t row = tile * 16 + L.n;
+    keep_lds_reads_here();
+    const int64_t r = row < rows ? row : rows - 1;
+    f4 y[4], f[4], z[4];
+    load_row(y, y_in, r, L.g);
+    drift_eval(f, y, lds + DecSdeL::F, sn, cs, L);
+    const float gs = diff_eval(y, lds + DecSdeL::G, sn, cs, L);
+    noise_row(z, na, STREAM_DECODER, step, r, rows, L.g);
+    em_update(y, f, gs, z, dt, sq);
+    if (row < rows) store_row(y, y_out, row, L.g);
+  }
+}
+
+int pick_grid(int64_t ntiles, int waves_per_wg) {
+  int64_t wgs = (ntiles + waves_per_wg - 1) / waves_per_wg;
+  return int(wgs < 1 ? 1 : (wgs > 256 ? 256 : wgs));   // one resident workgroup per CU (LDS-bound), grid-stride beyond
+}
+
+}  // namespace tsde
+
+using namespace tsde;
+
+static NoiseArg to_arg(const trajsde_noise* n) {
+  NoiseArg a{0, nullptr, nullptr};
+  if (n) { a.seed = n->seed; a.z = n->z; a.row_ids = n->row_ids; }
+  return a;
+}
+
+extern "C" {
+
+int64_t trajsde_decoder_ws_bytes(int32_t N, int num_modes) { return align_up(int64_t(N) * num_modes * 64 * 4, 256) + 256; }
+
+int trajsde_decoder_forward(int32_t N, int num_modes, int future_steps, const float* blob, const float* local_embed,
+                            const float* global_embed, const float* step_table, int n_euler, const float* out_table,
+                            float min_scale, const trajsde_noise* noise, void* ws, int64_t ws_bytes, float* loc,
+                            float* pi, void* stream_) {
+  TS_REQUIRE(blob && local_embed && global_embed && step_table && out_table && loc && pi && ws, "decoder_forward: null pointer");
+  TS_REQUIRE(N > 0 && num_modes > 0 && future_steps > 0 && n_euler > 0, "decoder_forward: empty problem");
+  if (ws_bytes < trajsde_decoder_ws_bytes(N, num_modes)) return fail(TRAJSDE_ERR_WORKSPACE, "decoder_forward: workspace too small");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  Carver cv(ws, ws_bytes);
+  const int64_t rows = int64_t(N) * num_modes;
+  float* y0 = cv.take<float>(rows * 64);
+  const int64_t ntiles = (rows + 15) / 16;
+  {
+    const int threads = 512;
+    static bool attr = false;
+    if (!attr) { TS_HIP(hipFuncSetAttribute((const void*)k_dec_init, hipFuncAttributeMaxDynamicSharedMemorySize, DecInitL::SIZE * 4)); attr = true; }
+    k_dec_init<<<pick_grid(ntiles, threads / 64), threads, DecInitL::SIZE * 4, stream>>>(blob + DecBlob::INIT, local_embed, global_embed, N, num_modes, y0, pi);
+    TS_LAUNCH_CHECK("k_dec_init");
+  }
+  {
+    const int threads = 768;   // 12 waves = 3 per SIMD: 168 VGPRs each, no spills; 256 CUs x 12 = 3072 tiles in flight
+    static bool attr = false;
+    if (!attr) { TS_HIP(hipFuncSetAttribute((const void*)k_sde_decode, hipFuncAttributeMaxDynamicSharedMemorySize, DecSdeL::SIZE * 4)); attr = true; }
+    k_sde_decode<<<pick_grid(ntiles, threads / 64), threads, DecSdeL::SIZE * 4, stream>>>(
+        blob + DecBlob::SDE, y0, rows, future_steps, n_euler, step_table, out_table, min_scale, to_arg(noise), loc);
+    TS_LAUNCH_CHECK("k_sde_decode");
+  }
+  return TRAJSDE_OK;
+}
+
+int trajsde_sde_step(int32_t rows, const float* blob, const float* y_in, float* y_out, const float* e, int step,
+                     const trajsde_noise* noise, void* stream_) {
+  TS_REQUIRE(blob && y_in && y_out && e && rows > 0, "sde_step: bad argument");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int threads = 1024;
+  static bool attr = false;
+  if (!attr) { TS_HIP(hipFuncSetAttribute((const void*)k_sde_step, hipFuncAttributeMaxDynamicSharedMemorySize, DecSdeL::LOC * 4)); attr = true; }
+  const int64_t ntiles = (int64_t(rows) + 15) / 16;
+  k_sde_step<<<pick_grid(ntiles, threads / 64), threads, DecSdeL::LOC * 4, stream>>>(blob + DecBlob::SDE, y_in, y_out, rows, e[1], e[2], e[3], e[4], step, to_arg(noise));
+  TS_LAUNCH_CHECK("k_sde_step");
+  return TRAJSDE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+// kernels.hpp -- declarations of the __global__ entry points defined in attn.hip / recur.hip, launched from stages.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "philox.hpp"
+
+namespace tsde {
+
+__global__ void k_aa_center(const float* img, const float* x, const float* x_fake, const float* rot, const uint8_t* bos,
+                            const int32_t* orig, int N, int Nt, int H, float* center, float* cn, float* q);
+__global__ void k_edge_kv(const float* img, const float* geom, const int32_t* dst, const float* q, int64_t E, float* logits, float* v);
+__global__ void k_edge_embed(const float* img, const float* geom, int64_t E, float* emb_out);
+__global__ void k_global_edge(const float* img, const float* rel, const int32_t* src, const int32_t* dst, const float* q,
+                              const float* kn, const float* vn, int64_t E, float* logits, float* v);
+__global__ void k_seg_softmax_agg(const int32_t* segptr, const float* logits, const float* v, int64_t R, float* agg);
+__global__ void k_node_update(const float* img, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2);
+__global__ void k_ffn(const float* img, const float* x1, const float* xn2, int64_t R, float* out);
+template <int NQ>
+__global__ void k_node_proj(const float* img, const float* x, int64_t R, float* xn_out, float* p0, float* p1, float* p2);
+__global__ void k_mode_proj(const float* norm_g, const float* proj_g, const float* x, int64_t N, float* out);
+
+__global__ void k_enc_sde_step(const float* img, const float* h_in, const float* hidden0, int Nt, float dt, float sq, float sn, float cs,
+                               int idx, NoiseArg na, const uint8_t* nus, const int32_t* eos, const int32_t* pick_slot, float* h_ode,
+                               float* diff_pick);
+__global__ void k_enc_gru_step(const float* img, const float* h_ode, const float* x_t, int Nt, int N, int t, int TT, int idx,
+                               const uint8_t* pad, const int32_t* orig, const int32_t* eos, float* h_out, float* local_out,
+                               float* latent_t);
+
+}  // namespace tsde

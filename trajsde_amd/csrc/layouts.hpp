@@ -1,0 +1,172 @@
+// layouts.hpp -- offsets (in floats) of every kernel's LDS weight image, and of the images inside the three
+// stage blobs.  Matrices are stored in MFMA fragment order [jo][q][lane][4] (tile.hpp), vectors plainly.
+// The pack recipes in pack.hip fill exactly these offsets; the kernels read exactly these offsets.
+#pragma once
+
+namespace tsde {
+
+#define TS_FIELD(name, size, prev) name = prev##_END, name##_END = name + (size)
+
+constexpr int MAT64 = 64 * 64;
+
+// k_aa_center: SingleInputEmbedding (EMB:22-40) + bos token + norm1 + lin_q  (ENC:546-556, 563, 586)
+struct AaCenterL {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(W0, 128, S), TS_FIELD(B0, 64, W0), TS_FIELD(G1, 64, B0), TS_FIELD(E1, 64, G1),
+    TS_FIELD(W3, MAT64, E1), TS_FIELD(B3, 64, W3), TS_FIELD(G4, 64, B3), TS_FIELD(E4, 64, G4),
+    TS_FIELD(W6, MAT64, E4), TS_FIELD(B6, 64, W6), TS_FIELD(G7, 64, B6), TS_FIELD(E7, 64, G7),
+    TS_FIELD(BOS, 21 * 64, E7), TS_FIELD(N1G, 64, BOS), TS_FIELD(N1B, 64, N1G),
+    TS_FIELD(WQ, MAT64, N1B), TS_FIELD(BQ, 64, WQ),
+    SIZE = BQ_END
+  };
+};
+
+// edge kernels: MultipleInputEmbedding (EMB:43-70) [+ lin_k | lin_v] (ENC:577-588, 759-767; AGG:51)
+struct EdgeL {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(A_W0, 128, S), TS_FIELD(A_B0, 64, A_W0), TS_FIELD(A_G, 64, A_B0), TS_FIELD(A_E, 64, A_G),
+    TS_FIELD(B_W0, 128, A_E), TS_FIELD(B_B0, 64, B_W0), TS_FIELD(B_G, 64, B_B0), TS_FIELD(B_E, 64, B_G),
+    TS_FIELD(WA3, MAT64, B_E), TS_FIELD(WB3, MAT64, WA3), TS_FIELD(B3, 64, WB3),
+    TS_FIELD(AG0, 64, B3), TS_FIELD(AE0, 64, AG0), TS_FIELD(W2, MAT64, AE0), TS_FIELD(B2, 64, W2),
+    TS_FIELD(AG3, 64, B2), TS_FIELD(AE3, 64, AG3),
+    EMB_SIZE = AE3_END,
+    TS_FIELD(WKV, 2 * MAT64, AE3), TS_FIELD(BKV, 128, WKV),
+    SIZE = BKV_END
+  };
+};
+
+// k_node_update: gate / self / out_proj / norm2 (ENC:595-600, 609; AGG:119-124, 131)
+struct UpdL {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(WIH, MAT64, S), TS_FIELD(BIH, 64, WIH), TS_FIELD(WHH, MAT64, BIH), TS_FIELD(BHH, 64, WHH),
+    TS_FIELD(WSELF, MAT64, BHH), TS_FIELD(BSELF, 64, WSELF), TS_FIELD(WOUT, MAT64, BSELF), TS_FIELD(BOUT, 64, WOUT),
+    TS_FIELD(N2G, 64, BOUT), TS_FIELD(N2B, 64, N2G),
+    SIZE = N2B_END
+  };
+};
+
+// k_ffn: mlp.0 (64->256) ReLU mlp.3 (256->64)
+struct FfnL {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(W1, 4 * MAT64, S), TS_FIELD(B1, 256, W1), TS_FIELD(W2, 4 * MAT64, B1), TS_FIELD(B2, 64, W2),
+    SIZE = B2_END
+  };
+};
+
+// k_node_proj<NQ>: norm1 + NQ stacked 64x64 projections (AL: q; global layers: q | k_node | v_node)
+template <int NQ>
+struct NodeProjL {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(N1G, 64, S), TS_FIELD(N1B, 64, N1G), TS_FIELD(W, NQ * MAT64, N1B), TS_FIELD(B, NQ * 64, W),
+    SIZE = B_END
+  };
+};
+
+// global edge kernel: lin_k_edge | lin_v_edge (AGG:110-112)
+struct GEdgeL {
+  enum : int { S_END = 0, TS_FIELD(WKV, 2 * MAT64, S), TS_FIELD(BKV, 128, WKV), SIZE = BKV_END };
+};
+
+// one drift/diffusion pair (FFunc / GFunc: ENC:372-440, DEC:107-158); WS/WC = columns 64/65 (sin t, cos t)
+struct DriftL {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(W0, MAT64, S), TS_FIELD(WS, 64, W0), TS_FIELD(WC, 64, WS), TS_FIELD(B0, 64, WC),
+    TS_FIELD(W2, MAT64, B0), TS_FIELD(B2, 64, W2), TS_FIELD(W4, MAT64, B2), TS_FIELD(B4, 64, W4),
+    SIZE = B4_END
+  };
+};
+struct DiffL {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(W0, MAT64, S), TS_FIELD(WS, 64, W0), TS_FIELD(WC, 64, WS), TS_FIELD(B0, 64, WC),
+    TS_FIELD(W2, MAT64, B0), TS_FIELD(B2, 64, W2), TS_FIELD(W4, 64, B2), TS_FIELD(B4, 4, W4),
+    SIZE = B4_END
+  };
+};
+
+struct EncSdeL {
+  enum : int { F = 0, GN = F + DriftL::SIZE, GA = GN + DiffL::SIZE, SIZE = GA + DiffL::SIZE };
+};
+
+// GRU_Unit (ODEU:111-152).  y_concat = [h, x] (cols 0..63 = h); combined = [x, r*h] (cols 0..63 = x)
+struct EncGruL {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(WUR_H, 2 * MAT64, S), TS_FIELD(WUR_X, 2 * MAT64, WUR_H), TS_FIELD(BUR, 128, WUR_X),
+    TS_FIELD(WU2, MAT64, BUR), TS_FIELD(BU2, 64, WU2), TS_FIELD(WR2, MAT64, BU2), TS_FIELD(BR2, 64, WR2),
+    TS_FIELD(WN_X, MAT64, BR2), TS_FIELD(WN_H, MAT64, WN_X), TS_FIELD(BN0, 64, WN_H),
+    TS_FIELD(WN2, MAT64, BN0), TS_FIELD(BN2, 64, WN2),
+    SIZE = BN2_END
+  };
+};
+
+// encoder stage blob
+struct EncBlob {
+  enum : int {
+    AA_CENTER = 0,
+    AA_EDGE = AA_CENTER + AaCenterL::SIZE,
+    AA_UPD = AA_EDGE + EdgeL::SIZE,
+    AA_FFN = AA_UPD + UpdL::SIZE,
+    SDE = AA_FFN + FfnL::SIZE,
+    GRU = SDE + EncSdeL::SIZE,
+    HIDDEN = GRU + EncGruL::SIZE,
+    AL_Q = HIDDEN + 64,
+    AL_EDGE = AL_Q + NodeProjL<1>::SIZE,
+    AL_UPD = AL_EDGE + EdgeL::SIZE,
+    AL_FFN = AL_UPD + UpdL::SIZE,
+    SIZE = AL_FFN + FfnL::SIZE
+  };
+};
+
+// aggregator stage blob: rel_embed, then per layer {qkv, edge, upd, ffn}, then norm + per-mode projection
+struct AggLayerL {
+  enum : int {
+    QKV = 0, EDGE = QKV + NodeProjL<3>::SIZE, UPD = EDGE + GEdgeL::SIZE, FFN = UPD + UpdL::SIZE, SIZE = FFN + FfnL::SIZE
+  };
+};
+struct AggBlob {
+  static constexpr int REL = 0;
+  static constexpr int layer(int i) { return EdgeL::EMB_SIZE + i * AggLayerL::SIZE; }
+  static constexpr int norm(int nl) { return layer(nl); }                       // gamma | beta
+  static constexpr int proj(int nl, int k) { return norm(nl) + 128 + k * (MAT64 + 64); }  // W_k frag | b_k
+  static constexpr int size(int nl, int K) { return proj(nl, K); }
+};
+
+// decoder stage blob
+struct DecInitL {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(WA_G, MAT64, S), TS_FIELD(WA_L, MAT64, WA_G), TS_FIELD(BA, 64, WA_L), TS_FIELD(AG, 64, BA), TS_FIELD(AE, 64, AG),
+    TS_FIELD(WP_L, MAT64, AE), TS_FIELD(WP_G, MAT64, WP_L), TS_FIELD(BP, 64, WP_G), TS_FIELD(PG, 64, BP), TS_FIELD(PE, 64, PG),
+    TS_FIELD(WP3, 64, PE), TS_FIELD(BP3, 4, WP3),
+    SIZE = BP3_END
+  };
+};
+struct HeadL {   // Linear(64,64) LN ReLU Linear(64,2)   (DEC:50-61)
+  enum : int {
+    S_END = 0,
+    TS_FIELD(W0, MAT64, S), TS_FIELD(B0, 64, W0), TS_FIELD(G, 64, B0), TS_FIELD(E, 64, G), TS_FIELD(W3, 128, E), TS_FIELD(B3, 4, W3),
+    SIZE = B3_END
+  };
+};
+struct DecSdeL {
+  enum : int { F = 0, G = F + DriftL::SIZE, LOC = G + DiffL::SIZE, SCALE = LOC + HeadL::SIZE, SIZE = SCALE + HeadL::SIZE };
+};
+struct DecBlob {
+  enum : int { INIT = 0, SDE = INIT + DecInitL::SIZE, SIZE = SDE + DecSdeL::SIZE };
+};
+
+static_assert(EdgeL::SIZE * 4 <= 160 * 1024, "edge image must fit LDS");
+static_assert(FfnL::SIZE * 4 <= 160 * 1024, "ffn image must fit LDS");
+static_assert(EncSdeL::SIZE * 4 <= 160 * 1024, "encoder SDE image must fit LDS");
+static_assert(EncGruL::SIZE * 4 <= 160 * 1024, "GRU image must fit LDS");
+static_assert(DecSdeL::SIZE * 4 <= 160 * 1024, "decoder SDE image must fit LDS");
+static_assert(EncBlob::AL_Q % 4 == 0 && EncBlob::SDE % 4 == 0 && DecBlob::SDE % 4 == 0, "16-byte aligned images");
+
+}  // namespace tsde

@@ -1,0 +1,296 @@
+// pack.hip -- weight packing: state_dict tensors -> the kernels' LDS images (layouts.hpp), plus the
+// parameter-name tables of the C-ABI.  One recipe per stage is the single source of truth: run "dry" it
+// yields the ordered parameter names (trajsde_param_name), run "wet" it launches the pack kernels.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "layouts.hpp"
+
+namespace tsde {
+
+std::string& last_error_ref() {
+  static thread_local std::string e;
+  return e;
+}
+int fail(int code, const std::string& msg) {
+  last_error_ref() = msg;
+  return code;
+}
+
+// dst[i] (+)= src[i]
+__global__ void k_pack_vec(const float* __restrict__ src, float* __restrict__ dst, int n, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
+}
+// dst[r] = src[r*ld + col]
+__global__ void k_pack_col(const float* __restrict__ src, float* __restrict__ dst, int rows, int ld, int col) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) dst[i] = src[i * ld + col];
+}
+// MFMA fragment order: dst[((jo*JTI + q)*64 + lane)*4 + c] = W[16jo + (lane&15)][col0 + 16q + 4(lane>>4) + c]
+__global__ void k_pack_mat(const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld, int col0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= jto * jti * 256) return;
+  const int c = i & 3, lane = (i >> 2) & 63, q = (i >> 8) % jti, jo = (i >> 8) / jti;
+  dst[i] = src[(16 * jo + (lane & 15)) * ld + col0 + 16 * q + 4 * (lane >> 4) + c];
+}
+
+struct Packer {
+  bool dry;
+  std::vector<std::string> names;          // dry: collected in order of first use
+  const float* const* params = nullptr;    // wet
+  float* blob = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  int index(const std::string& n) {
+    for (size_t i = 0; i < names.size(); ++i)
+      if (names[i] == n) return int(i);
+    names.push_back(n);
+    return int(names.size()) - 1;
+  }
+  const float* src(const std::string& n) {
+    const int i = index(n);
+    return dry ? nullptr : params[i];
+  }
+  void vec(const std::string& n, int dst, int count, bool accumulate = false) {
+    const float* s = src(n);
+    if (dry) return;
+    k_pack_vec<<<cdiv(count, 256), 256, 0, stream>>>(s, blob + dst, count, accumulate ? 1 : 0);
+  }
+  void col(const std::string& n, int dst, int rows, int ld, int c) {
+    const float* s = src(n);
+    if (dry) return;
+    k_pack_col<<<cdiv(rows, 256), 256, 0, stream>>>(s, blob + dst, rows, ld, c);
+  }
+  // rows x cols sub-matrix starting at column col0 of a row-major [rows x ld] weight
+  void mat(const std::string& n, int dst, int rows, int cols, int ld, int col0 = 0) {
+    const float* s = src(n);
+    if (dry) return;
+    const int jto = rows / 16, jti = cols / 16;
+    k_pack_mat<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, col0);
+  }
+  void lin(const std::string& p, int w, int b, int rows = 64, int cols = 64) {
+    mat(p + ".weight", w, rows, cols, cols);
+    vec(p + ".bias", b, rows);
+  }
+  void ln(const std::string& p, int g, int e) {
+    vec(p + ".weight", g, 64);
+    vec(p + ".bias", e, 64);
+  }
+};
+
+static void recipe_edge_embed(Packer& P, const std::string& p, int base) {   // MultipleInputEmbedding
+  using E = EdgeL;
+  P.vec(p + ".module_list.0.0.weight", base + E::A_W0, 128);
+  P.vec(p + ".module_list.0.0.bias", base + E::A_B0, 64);
+  P.ln(p + ".module_list.0.1", base + E::A_G, base + E::A_E);
+  P.vec(p + ".module_list.1.0.weight", base + E::B_W0, 128);
+  P.vec(p + ".module_list.1.0.bias", base + E::B_B0, 64);
+  P.ln(p + ".module_list.1.1", base + E::B_G, base + E::B_E);
+  P.mat(p + ".module_list.0.3.weight", base + E::WA3, 64, 64, 64);
+  P.mat(p + ".module_list.1.3.weight", base + E::WB3, 64, 64, 64);
+  P.vec(p + ".module_list.0.3.bias", base + E::B3, 64);
+  P.vec(p + ".module_list.1.3.bias", base + E::B3, 64, /*accumulate=*/true);
+  P.ln(p + ".aggr_embed.0", base + E::AG0, base + E::AE0);
+  P.lin(p + ".aggr_embed.2", base + E::W2, base + E::B2);
+  P.ln(p + ".aggr_embed.3", base + E::AG3, base + E::AE3);
+}
+static void recipe_upd_ffn(Packer& P, const std::string& p, int upd, int ffn) {
+  P.lin(p + ".lin_ih", upd + UpdL::WIH, upd + UpdL::BIH);
+  P.lin(p + ".lin_hh", upd + UpdL::WHH, upd + UpdL::BHH);
+  P.lin(p + ".lin_self", upd + UpdL::WSELF, upd + UpdL::BSELF);
+  P.lin(p + ".out_proj", upd + UpdL::WOUT, upd + UpdL::BOUT);
+  P.ln(p + ".norm2", upd + UpdL::N2G, upd + UpdL::N2B);
+  P.lin(p + ".mlp.0", ffn + FfnL::W1, ffn + FfnL::B1, 256, 64);
+  P.lin(p + ".mlp.3", ffn + FfnL::W2, ffn + FfnL::B2, 64, 256);
+}
+static void recipe_drift(Packer& P, const std::string& p, int base) {
+  using L = DriftL;
+  P.mat(p + ".net.0.weight", base + L::W0, 64, 64, 66, 0);
+  P.col(p + ".net.0.weight", base + L::WS, 64, 66, 64);
+  P.col(p + ".net.0.weight", base + L::WC, 64, 66, 65);
+  P.vec(p + ".net.0.bias", base + L::B0, 64);
+  P.lin(p + ".net.2", base + L::W2, base + L::B2);
+  P.lin(p + ".net.4", base + L::W4, base + L::B4);
+}
+static void recipe_diff(Packer& P, const std::string& p, int base) {
+  using L = DiffL;
+  P.mat(p + ".net.0.weight", base + L::W0, 64, 64, 66, 0);
+  P.col(p + ".net.0.weight", base + L::WS, 64, 66, 64);
+  P.col(p + ".net.0.weight", base + L::WC, 64, 66, 65);
+  P.vec(p + ".net.0.bias", base + L::B0, 64);
+  P.lin(p + ".net.2", base + L::W2, base + L::B2);
+  P.vec(p + ".net.4.weight", base + L::W4, 64);
+  P.vec(p + ".net.4.bias", base + L::B4, 1);
+}
+
+static void recipe_encoder(Packer& P) {
+  using B = EncBlob;
+  {  // AAEncoder node path
+    using L = AaCenterL;
+    const std::string c = "aa_encoder.center_embed.embed.";
+    P.vec(c + "0.weight", B::AA_CENTER + L::W0, 128);
+    P.vec(c + "0.bias", B::AA_CENTER + L::B0, 64);
+    P.ln(c + "1", B::AA_CENTER + L::G1, B::AA_CENTER + L::E1);
+    P.lin(c + "3", B::AA_CENTER + L::W3, B::AA_CENTER + L::B3);
+    P.ln(c + "4", B::AA_CENTER + L::G4, B::AA_CENTER + L::E4);
+    P.lin(c + "6", B::AA_CENTER + L::W6, B::AA_CENTER + L::B6);
+    P.ln(c + "7", B::AA_CENTER + L::G7, B::AA_CENTER + L::E7);
+    P.vec("aa_encoder.bos_token", B::AA_CENTER + L::BOS, 21 * 64);
+    P.ln("aa_encoder.norm1", B::AA_CENTER + L::N1G, B::AA_CENTER + L::N1B);
+    P.lin("aa_encoder.lin_q", B::AA_CENTER + L::WQ, B::AA_CENTER + L::BQ);
+  }
+  recipe_edge_embed(P, "aa_encoder.nbr_embed", B::AA_EDGE);
+  P.mat("aa_encoder.lin_k.weight", B::AA_EDGE + EdgeL::WKV, 64, 64, 64);
+  P.mat("aa_encoder.lin_v.weight", B::AA_EDGE + EdgeL::WKV + MAT64, 64, 64, 64);
+  P.vec("aa_encoder.lin_k.bias", B::AA_EDGE + EdgeL::BKV, 64);
+  P.vec("aa_encoder.lin_v.bias", B::AA_EDGE + EdgeL::BKV + 64, 64);
+  recipe_upd_ffn(P, "aa_encoder", B::AA_UPD, B::AA_FFN);
+  recipe_drift(P, "lsde_func.f_func", B::SDE + EncSdeL::F);
+  recipe_diff(P, "lsde_func.g_nus", B::SDE + EncSdeL::GN);
+  recipe_diff(P, "lsde_func.g_argo", B::SDE + EncSdeL::GA);
+  {  // GRU_Unit
+    using L = EncGruL;
+    const int g = B::GRU;
+    P.mat("gru_unit.update_gate.0.weight", g + L::WUR_H, 64, 64, 128, 0);
+    P.mat("gru_unit.reset_gate.0.weight", g + L::WUR_H + MAT64, 64, 64, 128, 0);
+    P.mat("gru_unit.update_gate.0.weight", g + L::WUR_X, 64, 64, 128, 64);
+    P.mat("gru_unit.reset_gate.0.weight", g + L::WUR_X + MAT64, 64, 64, 128, 64);
+    P.vec("gru_unit.update_gate.0.bias", g + L::BUR, 64);
+    P.vec("gru_unit.reset_gate.0.bias", g + L::BUR + 64, 64);
+    P.lin("gru_unit.update_gate.2", g + L::WU2, g + L::BU2);
+    P.lin("gru_unit.reset_gate.2", g + L::WR2, g + L::BR2);
+    P.mat("gru_unit.new_state_net.0.weight", g + L::WN_X, 64, 64, 128, 0);
+    P.mat("gru_unit.new_state_net.0.weight", g + L::WN_H, 64, 64, 128, 64);
+    P.vec("gru_unit.new_state_net.0.bias", g + L::BN0, 64);
+    P.lin("gru_unit.new_state_net.2", g + L::WN2, g + L::BN2);
+  }
+  P.vec("hidden", B::HIDDEN, 64);
+  P.ln("al_encoder.norm1", B::AL_Q + NodeProjL<1>::N1G, B::AL_Q + NodeProjL<1>::N1B);
+  P.lin("al_encoder.lin_q", B::AL_Q + NodeProjL<1>::W, B::AL_Q + NodeProjL<1>::B);
+  recipe_edge_embed(P, "al_encoder.lane_embed", B::AL_EDGE);
+  P.mat("al_encoder.lin_k.weight", B::AL_EDGE + EdgeL::WKV, 64, 64, 64);
+  P.mat("al_encoder.lin_v.weight", B::AL_EDGE + EdgeL::WKV + MAT64, 64, 64, 64);
+  P.vec("al_encoder.lin_k.bias", B::AL_EDGE + EdgeL::BKV, 64);
+  P.vec("al_encoder.lin_v.bias", B::AL_EDGE + EdgeL::BKV + 64, 64);
+  recipe_upd_ffn(P, "al_encoder", B::AL_UPD, B::AL_FFN);
+}
+
+static void recipe_aggregator(Packer& P, int nl, int K) {
+  recipe_edge_embed(P, "rel_embed", AggBlob::REL);
+  for (int i = 0; i < nl; ++i) {
+    const std::string p = "global_interactor_layers." + std::to_string(i);
+    const int b = AggBlob::layer(i);
+    using Q = NodeProjL<3>;
+    P.ln(p + ".norm1", b + AggLayerL::QKV + Q::N1G, b + AggLayerL::QKV + Q::N1B);
+    const char* qkv[3] = {".lin_q_node", ".lin_k_node", ".lin_v_node"};
+    for (int j = 0; j < 3; ++j) {
+      P.mat(p + qkv[j] + ".weight", b + AggLayerL::QKV + Q::W + j * MAT64, 64, 64, 64);
+      P.vec(p + qkv[j] + ".bias", b + AggLayerL::QKV + Q::B + j * 64, 64);
+    }
+    P.mat(p + ".lin_k_edge.weight", b + AggLayerL::EDGE + GEdgeL::WKV, 64, 64, 64);
+    P.mat(p + ".lin_v_edge.weight", b + AggLayerL::EDGE + GEdgeL::WKV + MAT64, 64, 64, 64);
+    P.vec(p + ".lin_k_edge.bias", b + AggLayerL::EDGE + GEdgeL::BKV, 64);
+    P.vec(p + ".lin_v_edge.bias", b + AggLayerL::EDGE + GEdgeL::BKV + 64, 64);
+    recipe_upd_ffn(P, p, b + AggLayerL::UPD, b + AggLayerL::FFN);
+  }
+  P.ln("norm", AggBlob::norm(nl), AggBlob::norm(nl) + 64);
+  // multihead_proj [K*64, 64]: mode k owns rows 64k..64k+63 (AGG:56 view(-1, K, 64))
+  const float* w = P.src("multihead_proj.weight");
+  const float* bsrc = P.src("multihead_proj.bias");
+  if (!P.dry)
+    for (int k = 0; k < K; ++k) {
+      k_pack_mat<<<cdiv(16 * 256, 256), 256, 0, P.stream>>>(w + int64_t(k) * MAT64, P.blob + AggBlob::proj(nl, k), 4, 4, 64, 0);
+      k_pack_vec<<<1, 64, 0, P.stream>>>(bsrc + k * 64, P.blob + AggBlob::proj(nl, k) + MAT64, 64, 0);
+    }
+}
+
+static void recipe_head(Packer& P, const std::string& p, int base) {
+  P.lin(p + ".0", base + HeadL::W0, base + HeadL::B0);
+  P.ln(p + ".1", base + HeadL::G, base + HeadL::E);
+  P.vec(p + ".3.weight", base + HeadL::W3, 128);
+  P.vec(p + ".3.bias", base + HeadL::B3, 2);
+}
+static void recipe_decoder(Packer& P) {
+  using I = DecInitL;
+  const int b = DecBlob::INIT;
+  P.mat("aggr_embed.0.weight", b + I::WA_G, 64, 64, 128, 0);     // cat(global, local): DEC:82
+  P.mat("aggr_embed.0.weight", b + I::WA_L, 64, 64, 128, 64);
+  P.vec("aggr_embed.0.bias", b + I::BA, 64);
+  P.ln("aggr_embed.1", b + I::AG, b + I::AE);
+  P.mat("pi.0.weight", b + I::WP_L, 64, 64, 128, 0);             // cat(local, global): DEC:93-94
+  P.mat("pi.0.weight", b + I::WP_G, 64, 64, 128, 64);
+  P.vec("pi.0.bias", b + I::BP, 64);
+  P.ln("pi.1", b + I::PG, b + I::PE);
+  P.vec("pi.3.weight", b + I::WP3, 64);
+  P.vec("pi.3.bias", b + I::BP3, 1);
+  recipe_drift(P, "lsde_func.f_func", DecBlob::SDE + DecSdeL::F);
+  recipe_diff(P, "lsde_func.g_func", DecBlob::SDE + DecSdeL::G);
+  recipe_head(P, "decoder", DecBlob::SDE + DecSdeL::LOC);
+  recipe_head(P, "scale", DecBlob::SDE + DecSdeL::SCALE);
+}
+
+static bool run_recipe(Packer& P, int stage, int nl, int K) {
+  switch (stage) {
+    case TRAJSDE_STAGE_ENCODER: recipe_encoder(P); return true;
+    case TRAJSDE_STAGE_AGGREGATOR: recipe_aggregator(P, nl, K); return true;
+    case TRAJSDE_STAGE_DECODER: recipe_decoder(P); return true;
+  }
+  return false;
+}
+
+}  // namespace tsde
+
+using namespace tsde;
+
+extern "C" {
+
+const char* trajsde_last_error(void) { return last_error_ref().c_str(); }
+int trajsde_abi_version(void) { return 1; }
+
+int trajsde_param_count(int stage, int num_layers, int num_modes) {
+  Packer P{true};
+  if (!run_recipe(P, stage, num_layers, num_modes)) return fail(TRAJSDE_ERR_INVALID, "unknown stage");
+  return int(P.names.size());
+}
+
+const char* trajsde_param_name(int stage, int index, int num_layers, int num_modes) {
+  static thread_local std::string out;
+  Packer P{true};
+  if (!run_recipe(P, stage, num_layers, num_modes) || index < 0 || index >= int(P.names.size())) return nullptr;
+  out = P.names[index];
+  return out.c_str();
+}
+
+int64_t trajsde_blob_floats(int stage, int num_layers, int num_modes) {
+  switch (stage) {
+    case TRAJSDE_STAGE_ENCODER: return EncBlob::SIZE;
+    case TRAJSDE_STAGE_AGGREGATOR: return AggBlob::size(num_layers, num_modes);
+    case TRAJSDE_STAGE_DECODER: return DecBlob::SIZE;
+  }
+  return fail(TRAJSDE_ERR_INVALID, "unknown stage");
+}
+
+int trajsde_pack_weights(int stage, int num_layers, int num_modes, const float* const* params, int n_params,
+                         float* blob, int64_t blob_floats, void* stream) {
+  TS_REQUIRE(params && blob, "pack_weights: null pointer");
+  Packer dry{true};
+  if (!run_recipe(dry, stage, num_layers, num_modes)) return fail(TRAJSDE_ERR_INVALID, "unknown stage");
+  TS_REQUIRE(n_params == int(dry.names.size()), "pack_weights: parameter count does not match trajsde_param_count");
+  TS_REQUIRE(blob_floats >= trajsde_blob_floats(stage, num_layers, num_modes), "pack_weights: blob too small");
+  for (int i = 0; i < n_params; ++i) TS_REQUIRE(params[i] != nullptr, "pack_weights: null parameter " + dry.names[i]);
+  TS_HIP(hipMemsetAsync(blob, 0, size_t(blob_floats) * sizeof(float), static_cast<hipStream_t>(stream)));
+  Packer wet{false};
+  wet.names = dry.names;
+  wet.params = params;
+  wet.blob = blob;
+  wet.stream = static_cast<hipStream_t>(stream);
+  run_recipe(wet, stage, num_layers, num_modes);
+  TS_LAUNCH_CHECK("pack");
+  return TRAJSDE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// philox.hpp -- in-kernel Philox4x32-10 + Box-Muller (curand-free).  Bit-exact uint32 stream vs the host
+// twin trajsde_amd/philox.py; counter = (row id, step, stream, column/4), key = 64-bit seed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tile.hpp"
+
+namespace tsde {
+
+constexpr uint32_t STREAM_FAKE_AGENT = 1, STREAM_ENCODER = 2, STREAM_DECODER = 3;
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return (float(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// four standard normals for columns 4*quad .. 4*quad+3 of (stream, step, row)
+__device__ __forceinline__ f4 philox_normal4(uint64_t seed, uint32_t stream, uint32_t step, uint32_t row, uint32_t quad) {
+  uint32_t w[4];
+  philox4x32_10(row, step, stream, quad, uint32_t(seed), uint32_t(seed >> 32), w);
+  f4 z;
+#pragma unroll
+  for (int a = 0; a < 4; a += 2) {
+    const float r = sqrtf(-2.0f * __logf(u01(w[a])));
+    const float u = u01(w[a + 1]);                       // angle in revolutions: v_sin/v_cos take x/(2*pi)
+    z[a] = r * __builtin_amdgcn_cosf(u);
+    z[a + 1] = r * __builtin_amdgcn_sinf(u);
+  }
+  return z;
+}
+
+struct NoiseArg {
+  uint64_t seed;
+  const float* z;          // injected normals or nullptr
+  const int32_t* row_ids;  // global ids or nullptr
+};
+
+// z for the 16 features (4 quads: jt*4+g) of `row` at `step`; injected layout [steps][rows][64]
+__device__ __forceinline__ void noise_row(f4 (&z)[4], const NoiseArg& na, uint32_t stream, int step, int64_t row,
+                                          int64_t rows_total, int g) {
+  if (na.z != nullptr) {
+    const float* p = na.z + (int64_t(step) * rows_total + row) * D + 4 * g;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) z[jt] = *reinterpret_cast<const f4*>(p + 16 * jt);
+  } else {
+    const uint32_t rid = na.row_ids ? uint32_t(na.row_ids[row]) : uint32_t(row);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) z[jt] = philox_normal4(na.seed, stream, uint32_t(step), rid, uint32_t(4 * jt + g));
+  }
+}
+
+}  // namespace tsde

@@ -1,0 +1,52 @@
+// sde_funcs.hpp -- drift / diffusion networks and the Euler-Maruyama update shared by the encoder
+// recurrence (ENC:372-482 via SDEINT:477-485) and the decoder solve (DEC:107-195 via stock torchsde Euler).
+#pragma once
+#include "layouts.hpp"
+#include "tile.hpp"
+
+namespace tsde {
+
+// first SDE layer: 66 -> 64 with the (sin t, cos t) columns folded into the bias
+__device__ __forceinline__ void sde_layer0(f4 (&out)[4], const f4 (&y)[4], const float* img, int W0, int WS, int WC, int B0,
+                                           float sn, float cs, const Lane& L) {
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    const int f0 = 16 * jt + 4 * L.g;
+    const f4 b = *reinterpret_cast<const f4*>(img + B0 + f0);
+    const f4 s = *reinterpret_cast<const f4*>(img + WS + f0);
+    const f4 c = *reinterpret_cast<const f4*>(img + WC + f0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[jt][e] = fmaf(c[e], cs, fmaf(s[e], sn, b[e]));
+  }
+  linear_acc<4, 4>(out, y, img + W0, L.lane);
+}
+
+// drift f(t, y) (FFunc) -> f[4];  img points at a DriftL image
+__device__ __forceinline__ void drift_eval(f4 (&f)[4], const f4 (&y)[4], const float* img, float sn, float cs, const Lane& L) {
+  f4 h1[4], h2[4];
+  sde_layer0(h1, y, img, DriftL::W0, DriftL::WS, DriftL::WC, DriftL::B0, sn, cs, L);
+  tanh_<4>(h1);
+  linear<4, 4>(h2, h1, img + DriftL::W2, img + DriftL::B2, L);
+  tanh_<4>(h2);
+  linear<4, 4>(f, h2, img + DriftL::W4, img + DriftL::B4, L);
+}
+
+// diffusion g(t, y) (GFunc): one sigmoid scalar per row, broadcast over the 64 state channels
+__device__ __forceinline__ float diff_eval(const f4 (&y)[4], const float* img, float sn, float cs, const Lane& L) {
+  f4 h1[4], h2[4];
+  sde_layer0(h1, y, img, DiffL::W0, DiffL::WS, DiffL::WC, DiffL::B0, sn, cs, L);
+  tanh_<4>(h1);
+  linear<4, 4>(h2, h1, img + DiffL::W2, img + DiffL::B2, L);
+  tanh_<4>(h2);
+  return fast_sigmoid(row_dot(h2, img + DiffL::W4, L.g) + img[DiffL::B4]);
+}
+
+// y1 = (y0 + f*dt) + g*(z*sqrt_h)      (Euler.step: y0 + f*dt + g_prod)
+__device__ __forceinline__ void em_update(f4 (&y)[4], const f4 (&f)[4], float gs, const f4 (&z)[4], float dt, float sq) {
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) y[jt][c] = (y[jt][c] + f[jt][c] * dt) + gs * (z[jt][c] * sq);
+}
+
+}  // namespace tsde

@@ -1,0 +1,182 @@
+// stages.hip -- C-ABI entry points of the encoder and aggregator stages: workspace carving and the launch
+// sequences over the kernels of attn.hip / recur.hip.  Everything is enqueued on the caller's stream; nothing
+// is allocated and nothing synchronises here.
+#include "common.hpp"
+#include "kernels.hpp"
+#include "layouts.hpp"
+
+namespace tsde {
+
+#define TS_LAUNCH(kern, grid, threads, lds, st, ...)                                                              \
+  do {                                                                                                            \
+    static bool _attr_done = false;                                                                               \
+    if (!_attr_done) {                                                                                            \
+      TS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));       \
+      _attr_done = true;                                                                                          \
+    }                                                                                                             \
+    kern<<<grid, threads, lds, st>>>(__VA_ARGS__);                                                                \
+    TS_LAUNCH_CHECK(#kern);                                                                                       \
+  } while (0)
+
+// grid for a tile kernel whose workgroups each hold an LDS weight image: as many workgroups as fit on the
+// chip at once (LDS- and thread-limited), grid-stride beyond that, never more than the work needs
+static int tile_grid(int64_t ntiles, int threads, int lds_bytes) {
+  const int waves = threads / 64;
+  int per_cu = int((160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1));
+  const int by_threads = 2048 / threads;
+  if (per_cu > by_threads) per_cu = by_threads;
+  if (per_cu < 1) per_cu = 1;
+  int64_t want = (ntiles + waves - 1) / waves;
+  const int64_t cap = 256 * int64_t(per_cu);
+  if (want > cap) want = cap;
+  return int(want < 1 ? 1 : want);
+}
+
+struct EncWs {
+  float *center, *cn, *q, *logits, *v, *agg, *x1, *xn2, *aa_out, *hA, *hB, *lat, *al_xn, *al_q, *al_logits, *al_v, *al_agg, *al_x1,
+      *al_xn2;
+  int64_t total;
+  bool ok;
+  EncWs(const trajsde_batch* b, const trajsde_graph* g, void* ws, int64_t bytes) {
+    Carver c(ws, bytes);
+    const int64_t R = int64_t(b->H) * g->Nt, N = b->N;
+    center = c.take<float>(R * 64); cn = c.take<float>(R * 64); q = c.take<float>(R * 64);
+    logits = c.take<float>(int64_t(g->E_aa) * 8 + 8); v = c.take<float>(int64_t(g->E_aa) * 64 + 64);
+    agg = c.take<float>(R * 64); x1 = c.take<float>(R * 64); xn2 = c.take<float>(R * 64); aa_out = c.take<float>(R * 64);
+    hA = c.take<float>(int64_t(g->Nt) * 64); hB = c.take<float>(int64_t(g->Nt) * 64); lat = c.take<float>(N * 64);
+    al_xn = c.take<float>(N * 64); al_q = c.take<float>(N * 64);
+    al_logits = c.take<float>(int64_t(g->E_la) * 8 + 8); al_v = c.take<float>(int64_t(g->E_la) * 64 + 64);
+    al_agg = c.take<float>(N * 64); al_x1 = c.take<float>(N * 64); al_xn2 = c.take<float>(N * 64);
+    total = c.off + 256;
+    ok = c.ok;
+  }
+};
+
+struct AggWs {
+  float *rel, *xn, *q, *kn, *vn, *logits, *v, *agg, *x1, *xn2, *xa, *xb;
+  int64_t total;
+  bool ok;
+  AggWs(const trajsde_batch* b, const trajsde_graph* g, void* ws, int64_t bytes) {
+    Carver c(ws, bytes);
+    const int64_t N = b->N, E = g->E_g;
+    rel = c.take<float>(E * 64 + 64);
+    xn = c.take<float>(N * 64); q = c.take<float>(N * 64); kn = c.take<float>(N * 64); vn = c.take<float>(N * 64);
+    logits = c.take<float>(E * 8 + 8); v = c.take<float>(E * 64 + 64);
+    agg = c.take<float>(N * 64); x1 = c.take<float>(N * 64); xn2 = c.take<float>(N * 64); xa = c.take<float>(N * 64); xb = c.take<float>(N * 64);
+    total = c.off + 256;
+    ok = c.ok;
+  }
+};
+
+// one attention block over an edge list already reduced to (logits, v): softmax-aggregate, gated update, FFN
+static int attention_tail(const float* upd_img, const float* ffn_img, const int32_t* segptr, const float* logits, const float* v,
+                          const float* xn, const float* x, int64_t R, float* agg, float* x1, float* xn2, float* out, hipStream_t st) {
+  k_seg_softmax_agg<<<cdiv(R, 4), 256, 0, st>>>(segptr, logits, v, R, agg);
+  TS_LAUNCH_CHECK("k_seg_softmax_agg");
+  const int64_t ntiles = (R + 15) / 16;
+  TS_LAUNCH(k_node_update, tile_grid(ntiles, 512, UpdL::SIZE * 4), 512, UpdL::SIZE * 4, st, upd_img, agg, xn, x, R, x1, xn2);
+  TS_LAUNCH(k_ffn, tile_grid(ntiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, ffn_img, x1, xn2, R, out);
+  return TRAJSDE_OK;
+}
+
+}  // namespace tsde
+
+using namespace tsde;
+
+extern "C" {
+
+int64_t trajsde_encoder_ws_bytes(const trajsde_batch* b, const trajsde_graph* g) {
+  if (!b || !g) return -1;
+  EncWs w(b, g, nullptr, 0);
+  return w.total;
+}
+
+int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob,
+                            const float* step_tab /*HOST [H,8]*/, const trajsde_noise* noise, void* ws, int64_t ws_bytes,
+                            float* local_embed, float* diff_pick, float* aa_out_user, float* latent_ys, void* stream_) {
+  TS_REQUIRE(b && g && rot && blob && step_tab && ws && local_embed && diff_pick, "encoder_forward: null pointer");
+  TS_REQUIRE(g->aa_segptr && g->la_segptr && g->orig, "encoder_forward: graph not compacted (call trajsde_graph_compact)");
+  EncWs w(b, g, ws, ws_bytes);
+  if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_forward: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  const int N = b->N, Nt = g->Nt, H = b->H, A = b->A;
+  const int64_t R = int64_t(H) * Nt;
+  float* aa_out = aa_out_user ? aa_out_user : w.aa_out;
+  NoiseArg na{0, nullptr, nullptr};
+  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
+
+  // ---- AAEncoder on the 21 snapshots at once (ENC:112-121, 538-566)
+  TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob + EncBlob::AA_CENTER,
+            b->x, g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
+  if (g->E_aa > 0)
+    TS_LAUNCH(k_edge_kv, tile_grid((int64_t(g->E_aa) + 15) / 16, 768, EdgeL::SIZE * 4), 768, EdgeL::SIZE * 4, st,
+              blob + EncBlob::AA_EDGE, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v);
+  if (int rc = attention_tail(blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg,
+                              w.x1, w.xn2, aa_out, st))
+    return rc;
+
+  // ---- latent SDE + GRU recurrence, iteration idx consumes history step t = H-1-idx (ENC:128-182)
+  TS_HIP(hipMemsetAsync(diff_pick, 0, size_t(2) * A * 64 * sizeof(float), st));
+  const int64_t rtiles = (int64_t(Nt) + 15) / 16;
+  for (int idx = 0; idx < H; ++idx) {
+    const int t = H - 1 - idx;
+    const float* e = step_tab + 8 * idx;
+    TS_LAUNCH(k_enc_sde_step, tile_grid(rtiles, 256, EncSdeL::SIZE * 4), 256, EncSdeL::SIZE * 4, st, blob + EncBlob::SDE,
+              idx == 0 ? nullptr : w.hA, blob + EncBlob::HIDDEN, Nt, e[1], e[2], e[3], e[4], idx, na, g->nus_mask, g->eos_idx,
+              g->pick_slot, w.hB, diff_pick);
+    TS_LAUNCH(k_enc_gru_step, tile_grid(rtiles, 256, EncGruL::SIZE * 4), 256, EncGruL::SIZE * 4, st, blob + EncBlob::GRU, w.hB,
+              aa_out + int64_t(t) * Nt * 64, Nt, N, t, b->TT, idx, b->padding_mask, g->orig, g->eos_idx, w.hA, w.lat,
+              latent_ys ? latent_ys + int64_t(idx) * N * 64 : nullptr);
+  }
+
+  // ---- ALEncoder (ENC:198-200, 732-797)
+  TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
+            blob + EncBlob::AL_Q, w.lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
+  if (g->E_la > 0)
+    TS_LAUNCH(k_edge_kv, tile_grid((int64_t(g->E_la) + 15) / 16, 768, EdgeL::SIZE * 4), 768, EdgeL::SIZE * 4, st,
+              blob + EncBlob::AL_EDGE, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v);
+  return attention_tail(blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, g->la_segptr, w.al_logits, w.al_v, w.al_xn, w.lat, N,
+                        w.al_agg, w.al_x1, w.al_xn2, local_embed, st);
+}
+
+int64_t trajsde_aggregator_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int num_modes) {
+  if (!b || !g) return -1;
+  (void)num_modes;
+  AggWs w(b, g, nullptr, 0);
+  return w.total;
+}
+
+int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers, int num_modes,
+                               const float* local_embed, void* ws, int64_t ws_bytes, float* global_embed, void* stream_) {
+  TS_REQUIRE(b && g && blob && local_embed && ws && global_embed, "aggregator_forward: null pointer");
+  TS_REQUIRE(g->g_segptr, "aggregator_forward: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(num_layers >= 0 && num_modes > 0, "aggregator_forward: bad layer/mode count");
+  AggWs w(b, g, ws, ws_bytes);
+  if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "aggregator_forward: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  const int64_t N = b->N, E = g->E_g, ntiles = (N + 15) / 16, etiles = (E + 15) / 16;
+  if (E > 0)
+    TS_LAUNCH(k_edge_embed, tile_grid(etiles, 768, EdgeL::EMB_SIZE * 4), 768, EdgeL::EMB_SIZE * 4, st, blob + AggBlob::REL, g->g_geom,
+              E, w.rel);
+  const float* x = local_embed;
+  float* bufs[2] = {w.xa, w.xb};
+  for (int i = 0; i < num_layers; ++i) {
+    const float* lb = blob + AggBlob::layer(i);
+    TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
+              w.xn, w.q, w.kn, w.vn);
+    if (E > 0)
+      TS_LAUNCH(k_global_edge, tile_grid(etiles, 768, GEdgeL::SIZE * 4), 768, GEdgeL::SIZE * 4, st, lb + AggLayerL::EDGE, w.rel, g->g_src,
+                g->g_dst, w.q, w.kn, w.vn, E, w.logits, w.v);
+    float* out = bufs[i & 1];
+    if (int rc = attention_tail(lb + AggLayerL::UPD, lb + AggLayerL::FFN, g->g_segptr, w.logits, w.v, w.xn, x, N, w.agg, w.x1, w.xn2,
+                                out, st))
+      return rc;
+    x = out;
+  }
+  const int lds = (128 + MAT64 + 64) * 4;
+  dim3 grid(tile_grid(ntiles, 512, lds), num_modes);
+  TS_LAUNCH(k_mode_proj, grid, 512, lds, st, blob + AggBlob::norm(num_layers), blob + AggBlob::proj(num_layers, 0), x, N, global_embed);
+  return TRAJSDE_OK;
+}
+
+}  // extern "C"

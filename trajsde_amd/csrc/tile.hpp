@@ -1,0 +1,181 @@
+// tile.hpp -- the wave-level building blocks shared by every kernel of the path (gfx950 / CDNA4 only).
+//
+// Design: "row on lane".  A wave owns a tile of 16 rows (agent-samples, edges or nodes).  Lane l holds
+// row n = l & 15 and, of that row's features, the quads selected by g = l >> 4: a 64-feature activation
+// is   f4 a[4]   with   a[jt][c] = X[row n][16*jt + 4*g + c].
+// A linear layer is computed TRANSPOSED on the matrix cores, Y^T = W * X^T, with the exact-fp32
+// v_mfma_f32_16x16x4_f32 (A = 16 output features x 4 k, B = 4 k x 16 rows, D = 16 features x 16 rows):
+//   - the D fragment (col = lane&15 = row, row = 4*(lane>>4)+reg = feature) is *already* the
+//     activation layout above, so chains of layers never leave registers: no LDS transpose,
+//     no cross-lane traffic (cf. cdna_hip_programming.md section 3, accumulator tile as next operand);
+//   - the k index consumed by instruction (q, c) on lane group g is k = 16q + 4g + c, i.e. exactly
+//     a[q][c]; the matching weight element for lane (i, g) is W[16*jo + i][16q + 4g + c], four
+//     contiguous floats of the row-major nn.Linear weight -> one ds_read_b128 per 4 MFMAs.
+// Weights live in LDS in "fragment order" (pack.hip): [jo][q][lane][4], conflict-free b128 reads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tsde {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int D = 64;          // embed width of every stage (CFG:32)
+constexpr int TILE_ROWS = 16;  // rows per wave tile
+
+struct Lane {
+  int lane, n, g;
+  __device__ __forceinline__ Lane() {
+    lane = threadIdx.x & 63;
+    n = lane & 15;
+    g = lane >> 4;
+  }
+};
+
+// ---------------------------------------------------------------- matrix-core linear layers
+// acc[jo] += W[16jo.., :] * in   for a weight stored in fragment order at `w` (LDS or global).
+template <int JT_OUT, int JT_IN>
+__device__ __forceinline__ void linear_acc(f4 (&acc)[JT_OUT], const f4 (&in)[JT_IN], const float* w, int lane) {
+#pragma unroll
+  for (int q = 0; q < JT_IN; ++q) {
+    f4 wf[JT_OUT];
+#pragma unroll
+    for (int jo = 0; jo < JT_OUT; ++jo) wf[jo] = *reinterpret_cast<const f4*>(w + ((jo * JT_IN + q) * 64 + lane) * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int jo = 0; jo < JT_OUT; ++jo)
+        acc[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[jo][c], in[q][c], acc[jo], 0, 0, 0);
+  }
+}
+
+// per-feature vector (bias, LayerNorm gamma/beta, ...) stored plainly: v[16*jt + 4*g + c]
+template <int JT>
+__device__ __forceinline__ void load_vec(f4 (&out)[JT], const float* v, int g) {
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) out[jt] = *reinterpret_cast<const f4*>(v + 16 * jt + 4 * g);
+}
+
+template <int JT_OUT, int JT_IN>
+__device__ __forceinline__ void linear(f4 (&out)[JT_OUT], const f4 (&in)[JT_IN], const float* w, const float* bias,
+                                       const Lane& L) {
+  load_vec<JT_OUT>(out, bias, L.g);
+  linear_acc<JT_OUT, JT_IN>(out, in, w, L.lane);
+}
+
+// ---------------------------------------------------------------- row reductions (4 lanes hold one row)
+__device__ __forceinline__ float row_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <int JT>
+__device__ __forceinline__ void layer_norm(f4 (&a)[JT], const float* gamma, const float* beta, int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) s += (a[jt][0] + a[jt][1]) + (a[jt][2] + a[jt][3]);
+  const float mean = row_sum(s) * (1.0f / (16 * JT));
+  float v = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = a[jt][c] - mean;
+      a[jt][c] = d;
+      v += d * d;
+    }
+  const float rstd = 1.0f / sqrtf(row_sum(v) * (1.0f / (16 * JT)) + 1e-5f);
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) {
+    const f4 ga = *reinterpret_cast<const f4*>(gamma + 16 * jt + 4 * g);
+    const f4 be = *reinterpret_cast<const f4*>(beta + 16 * jt + 4 * g);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[jt][c] = a[jt][c] * rstd * ga[c] + be[c];
+  }
+}
+
+// dot of a 64-feature activation with a plain vector, reduced over the row
+__device__ __forceinline__ float row_dot(const f4 (&a)[4], const float* w, int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    const f4 wv = *reinterpret_cast<const f4*>(w + 16 * jt + 4 * g);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s = fmaf(a[jt][c], wv[c], s);
+  }
+  return row_sum(s);
+}
+
+// ---------------------------------------------------------------- pointwise
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_tanh(float x) {
+  // 1 - 2/(e^{2x}+1): v_exp_f32 + v_rcp_f32, abs error ~2e-7; saturates correctly at +-inf
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+
+template <int JT>
+__device__ __forceinline__ void relu(f4 (&a)[JT]) {
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[jt][c] = fmaxf(a[jt][c], 0.f);
+}
+template <int JT>
+__device__ __forceinline__ void tanh_(f4 (&a)[JT]) {
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[jt][c] = fast_tanh(a[jt][c]);
+}
+template <int JT>
+__device__ __forceinline__ void sigmoid_(f4 (&a)[JT]) {
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[jt][c] = fast_sigmoid(a[jt][c]);
+}
+
+// first layer of the 2-d input embeddings: out[f] = W[f][0]*x0 + W[f][1]*x1 + b[f], W row-major [64][2]
+__device__ __forceinline__ void linear_in2(f4 (&out)[4], float x0, float x1, const float* w, const float* b, int g) {
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    const int f0 = 16 * jt + 4 * g;
+    const f4 wa = *reinterpret_cast<const f4*>(w + 2 * f0);
+    const f4 wb = *reinterpret_cast<const f4*>(w + 2 * f0 + 4);
+    const f4 bb = *reinterpret_cast<const f4*>(b + f0);
+    out[jt][0] = fmaf(x1, wa[1], fmaf(x0, wa[0], bb[0]));
+    out[jt][1] = fmaf(x1, wa[3], fmaf(x0, wa[2], bb[1]));
+    out[jt][2] = fmaf(x1, wb[1], fmaf(x0, wb[0], bb[2]));
+    out[jt][3] = fmaf(x1, wb[3], fmaf(x0, wb[2], bb[3]));
+  }
+}
+
+// ---------------------------------------------------------------- HBM <-> activation tiles ([rows][64] fp32)
+__device__ __forceinline__ void load_row(f4 (&a)[4], const float* base, int64_t row, int g) {
+  const float* p = base + row * D + 4 * g;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) a[jt] = *reinterpret_cast<const f4*>(p + 16 * jt);
+}
+__device__ __forceinline__ void store_row(const f4 (&a)[4], float* base, int64_t row, int g) {
+  float* p = base + row * D + 4 * g;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(p + 16 * jt) = a[jt];
+}
+
+// Weights in LDS are loop-invariant, so LICM would hoist every fragment read out of the tile / time loops
+// and spill hundreds of VGPRs; a compiler-only memory barrier at the top of each loop body keeps the
+// ds_reads next to their MFMAs (no instruction is emitted).
+__device__ __forceinline__ void keep_lds_reads_here() { asm volatile("" ::: "memory"); }
+
+// stage a packed weight blob into LDS (whole workgroup), then barrier
+__device__ __forceinline__ void stage_blob(float* lds, const float* blob, int n_floats) {
+  const f4* src = reinterpret_cast<const f4*>(blob);
+  f4* dst = reinterpret_cast<f4*>(lds);
+  for (int i = threadIdx.x; i < (n_floats >> 2); i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+}
+
+}  // namespace tsde

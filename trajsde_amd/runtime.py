@@ -1,6 +1,297 @@
-"""placeholder, replaced below"""
-class NoiseSpec:  # noqa
-    pass
-class StageRuntime:  # noqa
-    def __init__(self, module, stage):
-        self.module, self.stage = module, stage
+"""Host-side runtime of the stage modules: weight packing, workspaces, noise selection and the ctypes
+calls into libtrajsde_hip.so.  PyTorch is used for device memory and streams only."""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from trajsde_amd import _lib
+from trajsde_amd.schedule import EulerSchedule, decoder_schedule, encoder_schedule
+
+D = 64
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise _lib.TrajsdeError(f"{what} must live on the GPU: the hot path has no CPU implementation "
+                                "(oracle/ is test infrastructure, not a fallback)")
+
+
+@dataclass
+class NoiseSpec:
+    """Where the path's randomness comes from (SURVEY.md App. F draw order).
+
+    seed            in-kernel Philox4x32-10 key; host twin: trajsde_amd/philox.py
+    z_fake/z_enc/z_dec   injected standard normals [A,21,2] / [21,Nt,64] / [n_euler,K*N,64] (parity tests)
+    *_row_ids       int32 global row ids for the Philox counter (resharding-invariant streams)
+    """
+    seed: int = 0
+    z_fake: Optional[torch.Tensor] = None
+    z_enc: Optional[torch.Tensor] = None
+    z_dec: Optional[torch.Tensor] = None
+    fake_row_ids: Optional[torch.Tensor] = None
+    enc_row_ids: Optional[torch.Tensor] = None
+    dec_row_ids: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def resolve(noise: Optional["NoiseSpec"]) -> "NoiseSpec":
+        if noise is not None:
+            return noise
+        return NoiseSpec(seed=int(torch.randint(0, 2 ** 62, (1,)).item()))   # fresh stream per forward, like the reference
+
+    def c_noise(self, z: Optional[torch.Tensor], row_ids: Optional[torch.Tensor]) -> _lib.Noise:
+        if z is not None:
+            assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()
+        if row_ids is not None:
+            assert row_ids.is_cuda and row_ids.dtype == torch.int32 and row_ids.is_contiguous()
+        return _lib.Noise(C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF), _ptr(z), _ptr(row_ids))
+
+
+def rotate_inputs(data) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """MODEL:75-85 on the GPU: rotate_mat [N,2,2] and y @ rotate_mat."""
+    ang = data["rotate_angles"]
+    _require_gpu(ang, "data['rotate_angles']")
+    N = ang.shape[0]
+    y = data.y
+    rot = torch.empty(N, 2, 2, device=ang.device, dtype=torch.float32)
+    y_rot = torch.empty_like(y) if y is not None else None
+    F = y.shape[1] if y is not None else 0
+    _lib.check(_lib.lib().trajsde_rotate(_ptr(ang.contiguous()), N, _ptr(y.contiguous()) if y is not None else None, F,
+                                         _ptr(rot), _ptr(y_rot), _stream()), "trajsde_rotate")
+    return rot, y_rot
+
+
+class _TableCache:
+    """float32 schedule tables (host replay of the solver's time bookkeeping) resident on the device."""
+
+    def __init__(self) -> None:
+        self._c: Dict[tuple, tuple] = {}
+
+    def get(self, key: tuple, make, device) -> Tuple[EulerSchedule, torch.Tensor, torch.Tensor]:
+        k = key + (str(device),)
+        if k not in self._c:
+            s: EulerSchedule = make()
+            self._c[k] = (s, torch.from_numpy(s.step_table()).to(device), torch.from_numpy(s.out_table()).to(device))
+        return self._c[k]
+
+
+_TABLES = _TableCache()
+
+
+class StageRuntime:
+    """Per-stage glue owned by a stage module (encoder / aggregator / decoder)."""
+
+    STAGE_ID = {"encoder": _lib.STAGE_ENCODER, "aggregator": _lib.STAGE_AGGREGATOR, "decoder": _lib.STAGE_DECODER}
+
+    def __init__(self, module, stage: str) -> None:
+        object.__setattr__(self, "module", module)
+        self.stage = stage
+        self.stage_id = self.STAGE_ID[stage]
+        self._blob: Optional[torch.Tensor] = None
+        self._blob_stamp = None
+        self._names = None
+
+    # ---------------------------------------------------------------- weights
+    def _dims(self) -> Tuple[int, int]:
+        m = self.module
+        return int(getattr(m, "num_layers", 0)), int(getattr(m, "num_modes", 0))
+
+    def param_names(self):
+        if self._names is None:
+            L = _lib.lib()
+            nl, K = self._dims()
+            n = L.trajsde_param_count(self.stage_id, nl, K)
+            self._names = [L.trajsde_param_name(self.stage_id, i, nl, K).decode() for i in range(n)]
+        return self._names
+
+    def blob(self) -> torch.Tensor:
+        """Packed LDS images of this stage's weights; re-packed whenever a parameter changed."""
+        m = self.module
+        first = next(m.parameters())
+        _require_gpu(first, f"{self.stage} parameters")
+        stamp = (m.version_stamp(), str(first.device))
+        if self._blob is None or stamp != self._blob_stamp:
+            L = _lib.lib()
+            nl, K = self._dims()
+            names = self.param_names()
+            tensors = []
+            for n in names:
+                p = m.p(n)
+                if p.dtype != torch.float32 or not p.is_contiguous() or p.device != first.device:
+                    raise _lib.TrajsdeError(f"parameter {self.stage}.{n} must be contiguous fp32 on {first.device}")
+                tensors.append(p)
+            n_floats = L.trajsde_blob_floats(self.stage_id, nl, K)
+            blob = torch.empty(n_floats, device=first.device, dtype=torch.float32)
+            arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+            with torch.cuda.device(first.device):
+                _lib.check(L.trajsde_pack_weights(self.stage_id, nl, K, arr, len(tensors), blob.data_ptr(), n_floats, _stream()),
+                           "trajsde_pack_weights")
+            self._blob, self._blob_stamp = blob, stamp
+        return self._blob
+
+    # ---------------------------------------------------------------- decoder
+    def decoder_forward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor,
+                        noise: Optional[NoiseSpec] = None) -> Dict[str, torch.Tensor]:
+        m = self.module
+        noise = NoiseSpec.resolve(noise)
+        _require_gpu(local_embed, "local_embed")
+        dev = local_embed.device
+        K, T = int(m.num_modes), int(m.future_steps)
+        N = local_embed.shape[0]
+        sched, step_tab, out_tab = _TABLES.get(("dec", T, float(m.max_fut_t), float(m.min_stepsize)),
+                                               lambda: decoder_schedule(T, float(m.max_fut_t), float(m.min_stepsize)), dev)
+        if noise.z_dec is not None and tuple(noise.z_dec.shape) != (sched.n_euler, K * N, D):
+            raise _lib.TrajsdeError(f"z_dec must be [{sched.n_euler},{K * N},{D}] (one increment per Euler step, App. D)")
+        L = _lib.lib()
+        blob = self.blob()
+        loc = torch.empty(K, N, T, 4, device=dev, dtype=torch.float32)
+        pi = torch.empty(N, K, device=dev, dtype=torch.float32)
+        ws_bytes = L.trajsde_decoder_ws_bytes(N, K)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        cn = noise.c_noise(noise.z_dec, noise.dec_row_ids)
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_decoder_forward(N, K, T, blob.data_ptr(), local_embed.contiguous().data_ptr(),
+                                                 global_embed.contiguous().data_ptr(), step_tab.data_ptr(), sched.n_euler,
+                                                 out_tab.data_ptr(), float(m.min_scale), C.byref(cn), ws.data_ptr(), ws_bytes,
+                                                 loc.data_ptr(), pi.data_ptr(), _stream()), "trajsde_decoder_forward")
+        out = {"loc": loc, "pi": pi, "reg_mask": ~data["padding_mask"][:, -T:]}          # DEC:104
+        return out
+
+    # ---------------------------------------------------------------- encoder
+    def encoder_forward(self, data, noise: Optional[NoiseSpec] = None):
+        """LocalEncoderSDESepPara2.forward (ENC:66-202) -> (local_embed, diff_in, diff_out, label_in, label_out)."""
+        m = self.module
+        noise = NoiseSpec.resolve(noise)
+        gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), noise)
+        dev = gc.device
+        L = _lib.lib()
+        blob = self.blob()
+        H, N, A, Nt = gc.batch.H, gc.batch.N, gc.batch.A, gc.graph.Nt
+        sched = encoder_schedule(H, float(m.max_past_t), float(m.minimum_step), bool(m.run_backwards))
+        if sched.n_euler != H or not np.all(sched.out_w1 == 1.0):
+            raise _lib.TrajsdeError("encoder schedule is not one Euler step per interval (SURVEY App. D)")
+        tab = np.ascontiguousarray(sched.step_table())
+        if noise.z_enc is not None and tuple(noise.z_enc.shape) != (H, Nt, D):
+            raise _lib.TrajsdeError(f"z_enc must be [{H},{Nt},{D}]")
+        local = torch.empty(N, D, device=dev, dtype=torch.float32)
+        diff_pick = torch.empty(2 * A, D, device=dev, dtype=torch.float32)
+        cap = bool(getattr(m, "capture_intermediates", False))
+        aa_out = torch.empty(H, Nt, D, device=dev, dtype=torch.float32) if cap else None
+        latent = torch.empty(H, N, D, device=dev, dtype=torch.float32) if cap else None
+        ws_bytes = L.trajsde_encoder_ws_bytes(C.byref(gc.batch), C.byref(gc.graph))
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        cn = noise.c_noise(noise.z_enc, noise.enc_row_ids)
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_encoder_forward(C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), blob.data_ptr(),
+                                                 tab.ctypes.data_as(C.c_void_p), C.byref(cn), ws.data_ptr(), ws_bytes,
+                                                 local.data_ptr(), diff_pick.data_ptr(), _ptr(aa_out), _ptr(latent), _stream()),
+                       "trajsde_encoder_forward")
+        if cap:
+            m.last_intermediates = {"aa_out": aa_out, "latent_ys": latent, "E_aa": gc.graph.E_aa, "E_g": gc.graph.E_g,
+                                    "E_la": gc.graph.E_la}
+        diff_in, diff_out = torch.chunk(diff_pick, 2, 0)                                    # ENC:194
+        return (local, diff_in, diff_out, torch.full_like(diff_in, m.real_label), torch.full_like(diff_out, m.fake_label))
+
+    # ---------------------------------------------------------------- aggregator
+    def aggregator_forward(self, data, local_embed: torch.Tensor) -> torch.Tensor:
+        """GlobalInteractor.forward (AGG:38-58) -> [K, N, 64]."""
+        m = self.module
+        _require_gpu(local_embed, "local_embed")
+        gc = GraphContext.get(data, None, int(m.historical_steps), None)
+        dev = gc.device
+        L = _lib.lib()
+        blob = self.blob()
+        K, N = int(m.num_modes), gc.batch.N
+        out = torch.empty(K, N, D, device=dev, dtype=torch.float32)
+        ws_bytes = L.trajsde_aggregator_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), K)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_aggregator_forward(C.byref(gc.batch), C.byref(gc.graph), blob.data_ptr(), int(m.num_layers), K,
+                                                    local_embed.contiguous().data_ptr(), ws.data_ptr(), ws_bytes, out.data_ptr(),
+                                                    _stream()), "trajsde_aggregator_forward")
+        return out
+
+
+class GraphContext:
+    """Device-side graph structures of one batch (CSR, compacted edge lists, segment pointers), built once per
+    forward by the first stage that needs them and parked on the batch object for the next stage."""
+
+    KEY = "_trajsde_graph"
+    DEFAULT_RADIUS = 50.0
+
+    def __init__(self, data, radius: float, H: int, noise: Optional[NoiseSpec]) -> None:
+        L = _lib.lib()
+        x = data["x"]
+        _require_gpu(x, "data['x']")
+        self.device = dev = x.device
+        keep = self._keep = []
+
+        def f32(t):
+            t = t.to(torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def u8(t):
+            t = t.contiguous()
+            t = t.view(torch.uint8) if t.dtype == torch.bool else t.to(torch.uint8)
+            keep.append(t)
+            return t.data_ptr()
+
+        def i64(t):
+            t = t.to(torch.int64).contiguous()
+            keep.append(t)
+            return t.data_ptr() if t.numel() else None
+
+        N, Hx = x.shape[0], x.shape[1]
+        if Hx != H:
+            raise _lib.TrajsdeError(f"data['x'] has {Hx} history steps, the stage was built for {H}")
+        if "rotate_mat" not in data or data["rotate_mat"] is None or data["rotate_mat"] is False:
+            raise _lib.TrajsdeError("data['rotate_mat'] is missing: call the model's forward (MODEL:75-85) or runtime.rotate_inputs")
+        self.rot = data["rotate_mat"].to(torch.float32).contiguous()
+        ei, lai = data["edge_index"], data["lane_actor_index"]
+        lp = data["lane_positions"]
+        self.batch = _lib.Batch(N, data["agent_index"].numel(), ei.shape[1], lp.shape[0], lai.shape[1], H,
+                                data["positions"].shape[1], lp.shape[1] if lp.dim() > 1 else 0,
+                                f32(x), f32(data["positions"]), u8(data["padding_mask"]), u8(data["bos_mask"]),
+                                f32(data["rotate_angles"]), i64(ei), i64(data["agent_index"]), i64(data["batch"]),
+                                i64(data["source"]), f32(lp), f32(data["lane_paddings"]), i64(lai),
+                                f32(data["lane_actor_vectors"]))
+        if data["padding_mask"].shape[1] != data["positions"].shape[1]:
+            raise _lib.TrajsdeError("padding_mask and positions must cover the same time slots")
+        self.graph = _lib.Graph()
+        noise = NoiseSpec.resolve(noise)
+        z_fake = noise.z_fake
+        if z_fake is not None and tuple(z_fake.shape) != (self.batch.A, H, 2):
+            raise _lib.TrajsdeError(f"z_fake must be [{self.batch.A},{H},2]")
+        cn = noise.c_noise(z_fake, noise.fake_row_ids)
+        with torch.cuda.device(dev):
+            ws_bytes = L.trajsde_graph_ws_bytes(C.byref(self.batch))
+            if ws_bytes < 0:
+                raise _lib.TrajsdeError("graph workspace query failed: " + L.trajsde_last_error().decode())
+            self.ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+            _lib.check(L.trajsde_graph_prepare(C.byref(self.batch), self.rot.data_ptr(), float(radius), C.byref(cn),
+                                               self.ws.data_ptr(), ws_bytes, C.byref(self.graph), _stream()), "trajsde_graph_prepare")
+            ews_bytes = L.trajsde_graph_edges_ws_bytes(C.byref(self.batch), C.byref(self.graph))
+            self.edges_ws = torch.empty(ews_bytes, device=dev, dtype=torch.uint8)
+            _lib.check(L.trajsde_graph_compact(C.byref(self.batch), self.rot.data_ptr(), self.ws.data_ptr(), ws_bytes,
+                                               self.edges_ws.data_ptr(), ews_bytes, C.byref(self.graph), _stream()),
+                       "trajsde_graph_compact")
+
+    @classmethod
+    def get(cls, data, radius: Optional[float], H: int, noise: Optional[NoiseSpec]) -> "GraphContext":
+        gc = data[cls.KEY] if cls.KEY in data else None
+        if gc is None or (radius is not None and noise is not None):
+            # the encoder (which owns the radius and the fake-agent noise) always rebuilds; the aggregator reuses
+            gc = cls(data, cls.DEFAULT_RADIUS if radius is None else radius, H, noise)
+            data[cls.KEY] = gc
+        return gc
