@@ -1,0 +1,204 @@
+"""bench.py -- scenes/sec of PredictionModelSDENet.forward on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]           # N=1: plain process
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one forward pass (graph preparation + encoder + global interactor + SDE decoder, inference,
+fp32, fresh Philox seed) over one synthetic batch of BASELINE config 2: 64 scenes x 128 agents, K=6,
+20 SDE steps (SURVEY.md 8(d) generator), inputs resident in HBM before the timed region.  Scenes
+shard over ranks with no data-path collective: every rank runs the same-sized batch
+(weak scaling); the only collectives are the timing barrier and the max-over-ranks of the elapsed time.
+
+Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel (HIP events recorded
+inside the library on the launch stream during the timed region) and the CPU baseline (the oracle --
+oracle/restate.py, the bit-exact restatement of the reference -- timed on this box's host cores on a
+bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from trajsde_amd import _lib  # noqa: E402
+from trajsde_amd.models.model_base_mix_sde import PredictionModelSDENet  # noqa: E402
+from trajsde_amd.runtime import NoiseSpec  # noqa: E402
+from trajsde_amd.synth import CONFIGS, synth  # noqa: E402
+
+WORKLOAD = "config2"                 # "Synthetic batch of 64 scenes x 128 agents, K=6, 20 steps, 1xMI355X inference-only"
+FLOP_PER_EDGE = 41.7e3               # neighbour embed 25.1k + k,v 16.4k + dot 0.256k per (t, edge)
+MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak (no xf32 on gfx950)
+CPU_SAMPLE_SCENES = 16
+
+
+def build_cfg(spec):
+    import yaml
+    with open(os.path.join(ROOT, "trajsde_amd/configs/nusargo/hivt_nuSArgo_sdesepenc_sdedec.yml")) as f:
+        cfg = yaml.safe_load(f)
+    K, T, mt = spec["num_modes"], spec["future_steps"], spec["max_fut_t"]
+    cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)
+    cfg["aggregator"]["kwargs"]["num_modes"] = K
+    cfg["decoder"]["kwargs"].update(num_modes=K, future_steps=T, max_fut_t=mt)
+    return cfg
+
+
+def cpu_baseline(model, cfg, spec, gpu_loc_fn):
+    """Oracle timed on the host cores: CPU_SAMPLE_SCENES scenes of the same generator, 1 warm-up + 3 timed
+    forwards; also the 'minADE match' leg: GPU vs oracle on that very sample with the same Philox seed."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import restate
+    from trajsde_amd.metrics import ADE_T, FDE_T
+    skw = dict(spec["synth"], S=CPU_SAMPLE_SCENES)
+    batch = synth(**skw)
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    seed = 1234
+    times = []
+    out = None
+    for i in range(4):
+        t0 = time.perf_counter()
+        out = restate.forward(P, cfg, batch, restate.PhiloxNoise(seed))
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times[1:]))
+    o_gpu, data_gpu = gpu_loc_fn(batch, seed)
+    idx = batch["agent_index"]
+    res = {}
+    for name, src in (("gpu", (o_gpu["loc"].cpu(), o_gpu["reg_mask"].cpu(), data_gpu.y.cpu())), ("cpu", (out["loc"], out["reg_mask"], out["y"]))):
+        loc, mask, y = src
+        ade, fde = ADE_T("nuScenes", [T_END(loc), T_END(loc)]), FDE_T("nuScenes", [T_END(loc), T_END(loc)])
+        args = (loc[:, idx, :, :2], y[idx], mask[idx], batch["source"])
+        ade.update(*args)
+        fde.update(*args)
+        res[name] = (float(ade.compute()), float(fde.compute()))
+    match = {"minADE_gpu": res["gpu"][0], "minADE_cpu_oracle": res["cpu"][0], "minFDE_gpu": res["gpu"][1],
+             "minFDE_cpu_oracle": res["cpu"][1], "max_abs_loc_diff": float((o_gpu["loc"].cpu() - out["loc"]).abs().max()),
+             "tolerance": 1e-4}
+    base = {"value": CPU_SAMPLE_SCENES / med, "unit": "scenes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{CPU_SAMPLE_SCENES} of the 64 scenes of {WORKLOAD} (same generator and seed), oracle/restate.py, "
+                      f"1 warm-up + 3 timed forwards, median {med:.3f} s/forward, torch {torch.__version__} fp32"}
+    return base, match
+
+
+def T_END(loc):
+    return loc.shape[2] - 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="extra untimed pass timing every kernel (stderr)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    lib = _lib.lib()
+
+    spec = CONFIGS[WORKLOAD]
+    cfg = build_cfg(spec)
+    model = PredictionModelSDENet(**cfg, init_seed=0).eval().to(dev)        # random-init weights of the named architecture
+    skw = dict(spec["synth"])
+    skw["seed"] = skw["seed"] + 1000 * rank                                   # every rank owns different scenes
+    batch_cpu = synth(**skw)
+    scenes = skw["S"]
+    batch = batch_cpu.to(dev)
+    y0 = batch.y.clone()
+
+    def step(i):
+        batch.y = y0                                                          # forward rotates y in place (MODEL:83-84)
+        return model(batch, noise=NoiseSpec(seed=10_000 * (rank + 1) + i))
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        sync_all()
+        lib.trajsde_profile_mode(1)                                           # events around the dominant kernel only
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(args.warmup + i)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        lib.trajsde_profile_mode(0)
+    prof = _lib.profile_report()
+    e_aa = batch[ "_trajsde_graph"].graph.E_aa
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        n_launch, total_ms, _ = prof.get("k_edge_kv[aa]", (0, 0.0, True))
+        avg_s = (total_ms / max(n_launch, 1)) * 1e-3
+        achieved = (FLOP_PER_EDGE * e_aa / avg_s) * 1e-12 if avg_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.isfile(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("k_edge_kv[aa]", {}).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "scenes/sec (K=6, 20 SDE steps, ~256 agents) at 1/2/4/8 MI355X; minADE match",
+            "value": world * scenes * args.steps / elapsed, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic batch of 64 scenes x 128 agents, K=6, 20 SDE steps, "
+                                   "inference-only forward (graph prep + encoder + global interactor + SDE decoder), "
+                                   "synth(S=64,n=128,L=64,F=20,box=200,seed=2,mixed_source)",
+                       "scenes_per_gpu": scenes, "agents_per_scene": skw["n"], "num_modes": spec["num_modes"],
+                       "future_steps": spec["future_steps"], "aa_edges_per_step": int(e_aa), "parallelism": f"scene-shard x{world}"},
+            "roofline": {"kernel": "k_edge_kv[aa] (agent-agent edge embedding + k,v + logits, fp32 MFMA 16x16x4)",
+                         "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                         "avg_launch_ms": avg_s * 1e3, "launches": n_launch, "flop_per_edge": FLOP_PER_EDGE},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            def gpu_fn(b_cpu, seed):
+                b = b_cpu.to(dev)
+                with torch.no_grad():
+                    o = model(b, noise=NoiseSpec(seed=seed))
+                return o, b
+            base, match = cpu_baseline(model, cfg, spec, gpu_fn)
+            line["cpu_baseline"] = base
+            line["minade_match"] = match
+        if args.kernel_table:
+            lib.trajsde_profile_mode(2)
+            with torch.no_grad():
+                for i in range(3):
+                    step(900 + i)
+            torch.cuda.synchronize()
+            lib.trajsde_profile_mode(0)
+            tab = _lib.profile_report()
+            tot = sum(v[1] for v in tab.values())
+            print(f"# per-kernel device time over 3 forwards (HIP events), total {tot / 3:.3f} ms/forward", file=sys.stderr)
+            for tag, (n, ms, dom) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+                print(f"#   {tag:24s} launches/fwd {n / 3:6.1f}  ms/fwd {ms / 3:8.3f}  {100 * ms / tot:5.1f}%", file=sys.stderr)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -160,6 +160,13 @@ int trajsde_decoder_forward(int32_t N, int num_modes, int future_steps, const fl
 int trajsde_sde_step(int32_t rows, const float* blob, const float* y_in, float* y_out,
                      const float* step_entry /*[8] host values*/, int step, const trajsde_noise* noise, void* stream);
 
+/* ---- measurement hooks: HIP events recorded on the launch stream around the library's own kernel
+ *      launches (bench.py's roofline leg).  mode 0 = off, 1 = only the dominant kernel (k_edge_kv on the
+ *      agent-agent snapshots), 2 = every launch.  The report is text, one line per kernel tag:
+ *      "<tag> <launches> <total_ms> <dominant>"; it waits for the events and resets the recorder. */
+int trajsde_profile_mode(int mode);
+int64_t trajsde_profile_report(char* buf, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,8 @@ SIGNATURES = {
     "trajsde_aggregator_forward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, C.c_int, C.c_int, P, P, I64, P, P]),
     "trajsde_decoder_ws_bytes": (I64, [I32, C.c_int]),
     "trajsde_decoder_forward": (C.c_int, [I32, C.c_int, C.c_int, P, P, P, P, C.c_int, P, F32, C.POINTER(Noise), P, I64, P, P, P]),
+    "trajsde_profile_mode": (C.c_int, [C.c_int]),
+    "trajsde_profile_report": (I64, [C.c_char_p, I64]),
     "trajsde_sde_step": (C.c_int, [I32, P, P, P, C.POINTER(F32), C.c_int, C.POINTER(Noise), P]),
 }
 
@@ -67,6 +69,10 @@ def lib() -> C.CDLL:
         if not os.path.isfile(LIB_PATH):
             raise TrajsdeError(f"{LIB_PATH} is missing: build it with `python -m trajsde_amd.build` "
                                "(there is no CPU/PyTorch fallback for the hot path)")
+        # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Load torch's first so that this library
+        # binds to the runtime that owns torch's device context and streams; loaded the other way round the process
+        # ends up with two HIP runtimes and ours reports "no ROCm-capable device".
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)       # AttributeError here = header/library mismatch: fail loudly
@@ -79,3 +85,15 @@ def check(status: int, what: str = "") -> None:
     if status != 0:
         msg = lib().trajsde_last_error().decode()
         raise TrajsdeError(f"{what or 'trajsde call'} failed ({status}): {msg}")
+
+
+def profile_report() -> dict:
+    """{tag: (launches, total_ms, dominant)} of the events recorded since the last report."""
+    L = lib()
+    buf = C.create_string_buffer(1 << 16)
+    L.trajsde_profile_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        tag, n, ms, dom = line.rsplit(" ", 3)
+        out[tag] = (int(n), float(ms), bool(int(dom)))
+    return out

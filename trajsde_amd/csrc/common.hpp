@@ -52,4 +52,39 @@ struct Carver {
 
 inline int cdiv(int64_t a, int64_t b) { return int((a + b - 1) / b); }
 
+// ---- optional per-kernel timing with HIP events on the launch stream (trajsde_profile_mode / _report).
+// mode 0: off (no events are created or recorded); 1: only launches tagged as "dominant"; 2: every launch.
+int profile_mode();
+void profile_begin(const char* tag, hipStream_t st, bool dominant);
+void profile_end(const char* tag, hipStream_t st, bool dominant);
+struct ProfScope {
+  const char* tag;
+  hipStream_t st;
+  bool dom, on;
+  ProfScope(const char* t, hipStream_t s, bool dominant = false) : tag(t), st(s), dom(dominant) {
+    const int m = profile_mode();
+    on = m == 2 || (m == 1 && dominant);
+    if (on) profile_begin(tag, st, dom);
+  }
+  ~ProfScope() {
+    if (on) profile_end(tag, st, dom);
+  }
+};
+
+// launch a kernel that needs `lds` bytes of dynamic LDS (the >64 KB opt-in is done once per kernel)
+#define TS_LAUNCH_TAG(tag, dominant, kern, grid, threads, lds, st, ...)                                           \
+  do {                                                                                                            \
+    static bool _attr_done = false;                                                                               \
+    if (!_attr_done) {                                                                                            \
+      TS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));       \
+      _attr_done = true;                                                                                          \
+    }                                                                                                             \
+    {                                                                                                             \
+      ::tsde::ProfScope _ps(tag, st, dominant);                                                                   \
+      kern<<<grid, threads, lds, st>>>(__VA_ARGS__);                                                              \
+    }                                                                                                             \
+    TS_LAUNCH_CHECK(tag);                                                                                         \
+  } while (0)
+#define TS_LAUNCH(kern, grid, threads, lds, st, ...) TS_LAUNCH_TAG(#kern, false, kern, grid, threads, lds, st, __VA_ARGS__)
+
 }  // namespace tsde

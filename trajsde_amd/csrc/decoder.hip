@@ -160,21 +160,11 @@ int trajsde_decoder_forward(int32_t N, int num_modes, int future_steps, const fl
   const int64_t rows = int64_t(N) * num_modes;
   float* y0 = cv.take<float>(rows * 64);
   const int64_t ntiles = (rows + 15) / 16;
-  {
-    const int threads = 512;
-    static bool attr = false;
-    if (!attr) { TS_HIP(hipFuncSetAttribute((const void*)k_dec_init, hipFuncAttributeMaxDynamicSharedMemorySize, DecInitL::SIZE * 4)); attr = true; }
-    k_dec_init<<<pick_grid(ntiles, threads / 64), threads, DecInitL::SIZE * 4, stream>>>(blob + DecBlob::INIT, local_embed, global_embed, N, num_modes, y0, pi);
-    TS_LAUNCH_CHECK("k_dec_init");
-  }
-  {
-    const int threads = 768;   // 12 waves = 3 per SIMD: 168 VGPRs each, no spills; 256 CUs x 12 = 3072 tiles in flight
-    static bool attr = false;
-    if (!attr) { TS_HIP(hipFuncSetAttribute((const void*)k_sde_decode, hipFuncAttributeMaxDynamicSharedMemorySize, DecSdeL::SIZE * 4)); attr = true; }
-    k_sde_decode<<<pick_grid(ntiles, threads / 64), threads, DecSdeL::SIZE * 4, stream>>>(
-        blob + DecBlob::SDE, y0, rows, future_steps, n_euler, step_table, out_table, min_scale, to_arg(noise), loc);
-    TS_LAUNCH_CHECK("k_sde_decode");
-  }
+  TS_LAUNCH(k_dec_init, pick_grid(ntiles, 8), 512, DecInitL::SIZE * 4, stream, blob + DecBlob::INIT, local_embed, global_embed, N,
+            num_modes, y0, pi);
+  // 768 threads = 12 waves = 3 per SIMD (168 VGPRs each); 256 CUs x 12 waves = 3072 path tiles in flight
+  TS_LAUNCH(k_sde_decode, pick_grid(ntiles, 12), 768, DecSdeL::SIZE * 4, stream, blob + DecBlob::SDE, y0, rows, future_steps, n_euler,
+            step_table, out_table, min_scale, to_arg(noise), loc);
   return TRAJSDE_OK;
 }
 
@@ -182,12 +172,9 @@ int trajsde_sde_step(int32_t rows, const float* blob, const float* y_in, float* 
                      const trajsde_noise* noise, void* stream_) {
   TS_REQUIRE(blob && y_in && y_out && e && rows > 0, "sde_step: bad argument");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int threads = 1024;
-  static bool attr = false;
-  if (!attr) { TS_HIP(hipFuncSetAttribute((const void*)k_sde_step, hipFuncAttributeMaxDynamicSharedMemorySize, DecSdeL::LOC * 4)); attr = true; }
   const int64_t ntiles = (int64_t(rows) + 15) / 16;
-  k_sde_step<<<pick_grid(ntiles, threads / 64), threads, DecSdeL::LOC * 4, stream>>>(blob + DecBlob::SDE, y_in, y_out, rows, e[1], e[2], e[3], e[4], step, to_arg(noise));
-  TS_LAUNCH_CHECK("k_sde_step");
+  TS_LAUNCH(k_sde_step, pick_grid(ntiles, 16), 1024, DecSdeL::LOC * 4, stream, blob + DecBlob::SDE, y_in, y_out, int64_t(rows), e[1], e[2],
+            e[3], e[4], step, to_arg(noise));
   return TRAJSDE_OK;
 }
 

@@ -242,11 +242,72 @@ static bool run_recipe(Packer& P, int stage, int nl, int K) {
   return false;
 }
 
+// ---- event profiler (see common.hpp)
+struct ProfRec {
+  std::string tag;
+  bool dominant;
+  std::vector<hipEvent_t> beg, end;
+};
+static int g_prof_mode = 0;
+static std::vector<ProfRec> g_prof;
+int profile_mode() { return g_prof_mode; }
+static ProfRec& prof_rec(const char* tag, bool dominant) {
+  for (auto& r : g_prof)
+    if (r.tag == tag) return r;
+  g_prof.push_back(ProfRec{tag, dominant, {}, {}});
+  return g_prof.back();
+}
+void profile_begin(const char* tag, hipStream_t st, bool dominant) {
+  ProfRec& r = prof_rec(tag, dominant);
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, st);
+  r.beg.push_back(e);
+}
+void profile_end(const char* tag, hipStream_t st, bool dominant) {
+  ProfRec& r = prof_rec(tag, dominant);
+  if (r.end.size() >= r.beg.size()) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, st);
+  r.end.push_back(e);
+}
+
 }  // namespace tsde
 
 using namespace tsde;
 
 extern "C" {
+
+int trajsde_profile_mode(int mode) {
+  g_prof_mode = mode;
+  return TRAJSDE_OK;
+}
+
+// "tag count total_ms dominant\n" per kernel tag; waits for the recorded events, then forgets them
+int64_t trajsde_profile_report(char* buf, int64_t cap) {
+  std::string out;
+  for (auto& r : g_prof) {
+    double total = 0;
+    size_t n = r.end.size() < r.beg.size() ? r.end.size() : r.beg.size();
+    for (size_t i = 0; i < n; ++i) {
+      float ms = 0;
+      if (hipEventSynchronize(r.end[i]) == hipSuccess && hipEventElapsedTime(&ms, r.beg[i], r.end[i]) == hipSuccess) total += ms;
+    }
+    for (auto e : r.beg) (void)hipEventDestroy(e);
+    for (auto e : r.end) (void)hipEventDestroy(e);
+    char line[256];
+    snprintf(line, sizeof(line), "%s %zu %.6f %d\n", r.tag.c_str(), n, total, r.dominant ? 1 : 0);
+    out += line;
+  }
+  g_prof.clear();
+  if (buf && cap > 0) {
+    const size_t n = out.size() < size_t(cap - 1) ? out.size() : size_t(cap - 1);
+    std::memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return int64_t(out.size());
+}
 
 const char* trajsde_last_error(void) { return last_error_ref().c_str(); }
 int trajsde_abi_version(void) { return 1; }

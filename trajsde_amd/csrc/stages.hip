@@ -7,17 +7,6 @@
 
 namespace tsde {
 
-#define TS_LAUNCH(kern, grid, threads, lds, st, ...)                                                              \
-  do {                                                                                                            \
-    static bool _attr_done = false;                                                                               \
-    if (!_attr_done) {                                                                                            \
-      TS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));       \
-      _attr_done = true;                                                                                          \
-    }                                                                                                             \
-    kern<<<grid, threads, lds, st>>>(__VA_ARGS__);                                                                \
-    TS_LAUNCH_CHECK(#kern);                                                                                       \
-  } while (0)
-
 // grid for a tile kernel whose workgroups each hold an LDS weight image: as many workgroups as fit on the
 // chip at once (LDS- and thread-limited), grid-stride beyond that, never more than the work needs
 static int tile_grid(int64_t ntiles, int threads, int lds_bytes) {
@@ -71,8 +60,7 @@ struct AggWs {
 // one attention block over an edge list already reduced to (logits, v): softmax-aggregate, gated update, FFN
 static int attention_tail(const float* upd_img, const float* ffn_img, const int32_t* segptr, const float* logits, const float* v,
                           const float* xn, const float* x, int64_t R, float* agg, float* x1, float* xn2, float* out, hipStream_t st) {
-  k_seg_softmax_agg<<<cdiv(R, 4), 256, 0, st>>>(segptr, logits, v, R, agg);
-  TS_LAUNCH_CHECK("k_seg_softmax_agg");
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, segptr, logits, v, R, agg);
   const int64_t ntiles = (R + 15) / 16;
   TS_LAUNCH(k_node_update, tile_grid(ntiles, 512, UpdL::SIZE * 4), 512, UpdL::SIZE * 4, st, upd_img, agg, xn, x, R, x1, xn2);
   TS_LAUNCH(k_ffn, tile_grid(ntiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, ffn_img, x1, xn2, R, out);
@@ -109,7 +97,7 @@ int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, cons
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob + EncBlob::AA_CENTER,
             b->x, g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
   if (g->E_aa > 0)
-    TS_LAUNCH(k_edge_kv, tile_grid((int64_t(g->E_aa) + 15) / 16, 768, EdgeL::SIZE * 4), 768, EdgeL::SIZE * 4, st,
+    TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv, tile_grid((int64_t(g->E_aa) + 15) / 16, 768, EdgeL::SIZE * 4), 768, EdgeL::SIZE * 4, st,
               blob + EncBlob::AA_EDGE, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v);
   if (int rc = attention_tail(blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg,
                               w.x1, w.xn2, aa_out, st))
@@ -133,7 +121,7 @@ int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, cons
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob + EncBlob::AL_Q, w.lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
   if (g->E_la > 0)
-    TS_LAUNCH(k_edge_kv, tile_grid((int64_t(g->E_la) + 15) / 16, 768, EdgeL::SIZE * 4), 768, EdgeL::SIZE * 4, st,
+    TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv, tile_grid((int64_t(g->E_la) + 15) / 16, 768, EdgeL::SIZE * 4), 768, EdgeL::SIZE * 4, st,
               blob + EncBlob::AL_EDGE, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v);
   return attention_tail(blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, g->la_segptr, w.al_logits, w.al_v, w.al_xn, w.lat, N,
                         w.al_agg, w.al_x1, w.al_xn2, local_embed, st);
