@@ -1,0 +1,89 @@
+"""N>1 path on CPU: world_size-2 gloo processes each own a round-robin shard of the scenes.  Checked without a
+GPU: (a) shards are a disjoint cover, (b) with global Philox row ids a rank's outputs equal the corresponding
+rows of the single-process run (the oracle stands in for the kernels here -- it consumes the same NoiseSpec row
+ids through the Philox host twin), (c) metric states all-reduce to the single-process value."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers as H
+
+SCENES = [dict(S=1, n=5, L=3, F=5, box=60.0, seed=41), dict(S=1, n=8, L=4, F=5, box=60.0, seed=42),
+          dict(S=1, n=6, L=2, F=5, box=60.0, seed=43), dict(S=1, n=7, L=5, F=5, box=60.0, seed=44)]
+K, T, MAXT, SEED = 2, 5, 0.5, 321
+
+
+def _run_oracle(model, cfg, batch, spec):
+    import restate
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    noise = restate.PhiloxNoise(spec.seed, enc_row_ids=spec.enc_row_ids.numpy(), dec_row_ids=spec.dec_row_ids.numpy(),
+                                fake_row_ids=spec.fake_row_ids.numpy())
+    return restate.forward(P, cfg, batch, noise)
+
+
+def _metrics(out, batch):
+    from trajsde_amd.metrics import ADE_T, FDE_T
+    idx = batch["agent_index"]
+    ade, fde = ADE_T("nuScenes", [T - 1, T - 1]), FDE_T("nuScenes", [T - 1, T - 1])
+    for m in (ade, fde):
+        m.update(out["loc"][:, idx, :, :2], out["y"][idx], out["reg_mask"][idx], batch["source"])
+    return ade, fde
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from trajsde_amd.data import collate
+        from trajsde_amd.shard import global_noise_spec, shard_scenes
+        from trajsde_amd.synth import synth
+        torch.set_num_threads(1)
+        mine = shard_scenes(len(SCENES), rank, world)
+        batch = collate([synth(**SCENES[s]) for s in mine])
+        model, cfg = H.build_model(K, T, MAXT, init_seed=3)
+        spec = global_noise_spec(SEED, mine, [s["n"] for s in SCENES], K)
+        out = _run_oracle(model, cfg, batch, spec)
+        ade, fde = _metrics(out, batch)
+        q.put((rank, mine, out["loc"].numpy(), float(ade.compute()), float(fde.compute())))   # compute() all-reduces
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_scene_sharding_matches_single_process():
+    from trajsde_amd.data import collate
+    from trajsde_amd.shard import global_noise_spec, shard_scenes
+    from trajsde_amd.synth import synth
+    world = 2
+    assert sorted(sum((shard_scenes(len(SCENES), r, world) for r in range(world)), [])) == list(range(len(SCENES)))
+    # single process, all scenes
+    full = collate([synth(**s) for s in SCENES])
+    model, cfg = H.build_model(K, T, MAXT, init_seed=3)
+    counts = [s["n"] for s in SCENES]
+    want = _run_oracle(model, cfg, full, global_noise_spec(SEED, range(len(SCENES)), counts, K))
+    ade, fde = _metrics(want, full)
+    want_ade, want_fde = float(ade.compute()), float(fde.compute())
+    offs = np.cumsum([0] + counts)
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, mine, loc, ade_r, fde_r in results:
+        rows = np.concatenate([np.arange(offs[s], offs[s + 1]) for s in mine])
+        assert np.abs(loc - want["loc"].numpy()[:, rows]).max() <= 1e-5
+        assert abs(ade_r - want_ade) <= 1e-5 and abs(fde_r - want_fde) <= 1e-5
