@@ -118,6 +118,68 @@ def test_scene_independence_and_sharding_invariance(dev):
     assert H.maxdiff(o2["pi"][na:].cpu(), o1["pi"].cpu()) <= 1e-5
 
 
+def test_full_size_config2_properties(dev):
+    """BASELINE config 2 at full size (64 scenes x 128 agents, K=6, T=20), where the oracle is too slow to run whole:
+    (1) scene independence: a scene taken out of the big batch and run alone (same global Philox row ids) gives
+    the same trajectories; (2) that scene alone matches the oracle; (3) outputs are finite, scales > min_scale."""
+    from trajsde_amd.data import TemporalData, collate
+    from trajsde_amd.shard import global_noise_spec
+    from trajsde_amd.synth import CONFIGS, synth
+    spec = CONFIGS["config2"]
+    K, T = spec["num_modes"], spec["future_steps"]
+    S, n, L = spec["synth"]["S"], spec["synth"]["n"], spec["synth"]["L"]
+    model, cfg = H.build_model(K, T, spec["max_fut_t"], init_seed=0)
+    big = synth(**spec["synth"])
+    counts = [n] * S
+    gpu = model.to(dev)
+    o_big = gpu(big.to(dev), noise=global_noise_spec(4242, range(S), counts, K, device=dev))
+    assert torch.isfinite(o_big["loc"]).all() and torch.isfinite(o_big["pi"]).all()
+    assert float(o_big["loc"][..., 2:].min()) > cfg["decoder"]["kwargs"]["min_scale"]
+    assert tuple(o_big["loc"].shape) == (K, S * n, T, 4)
+    for s in (0, 37):
+        lo, hi = s * n, (s + 1) * n
+        ei = big["edge_index"]
+        keep = (ei[1] >= lo) & (ei[1] < hi)
+        lai = big["lane_actor_index"]
+        lkeep = (lai[1] >= lo) & (lai[1] < hi)
+        one = TemporalData(x=big["x"][lo:hi], positions=big["positions"][lo:hi], padding_mask=big["padding_mask"][lo:hi],
+                           bos_mask=big["bos_mask"][lo:hi], rotate_angles=big["rotate_angles"][lo:hi], y=big["y"][lo:hi],
+                           edge_index=ei[:, keep] - lo, lane_positions=big["lane_positions"][s * L:(s + 1) * L],
+                           lane_paddings=big["lane_paddings"][s * L:(s + 1) * L],
+                           lane_actor_index=lai[:, lkeep] - torch.tensor([[s * L], [lo]]),
+                           lane_actor_vectors=big["lane_actor_vectors"][lkeep], agent_index=big["agent_index"][s:s + 1] - lo,
+                           av_index=big["av_index"][s:s + 1] - lo, batch=torch.zeros(n, dtype=torch.long),
+                           source=big["source"][s:s + 1], num_nodes=n)
+        ns = global_noise_spec(4242, [s], counts, K, device=dev)
+        o_one = gpu(one.to(dev), noise=ns)
+        assert H.maxdiff(o_one["loc"].cpu(), o_big["loc"][:, lo:hi].cpu()) <= 1e-5
+        assert H.maxdiff(o_one["pi"].cpu(), o_big["pi"][lo:hi].cpu()) <= 1e-5
+        import restate
+        P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        want = restate.forward(P, cfg, H.clone_batch(one), restate.PhiloxNoise(
+            4242, enc_row_ids=ns.enc_row_ids.cpu().numpy(), dec_row_ids=ns.dec_row_ids.cpu().numpy(),
+            fake_row_ids=ns.fake_row_ids.cpu().numpy()))
+        assert H.maxdiff(o_one["loc"].cpu(), want["loc"]) <= TOL
+        assert H.maxdiff(o_one["pi"].cpu(), want["pi"]) <= TOL
+
+
+def test_dense_scene_1024_agents(dev):
+    """stress shape of BASELINE config 5 (one 1024-agent scene, in-degree up to 1023, K=20, 50 -> 51 Euler steps):
+    the segment softmax / CSR paths at maximum fan-in, checked against the oracle."""
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    K, T, max_t = 20, 50, 5.0
+    batch = synth(S=1, n=1024, L=64, F=T, box=80.0, seed=77, history_dropout=0.2)     # 80 m box: everyone within the radius
+    model, cfg = H.build_model(K, T, max_t, init_seed=11)
+    want = H.oracle_forward(model, cfg, batch, noise_seed=5, want_intermediates=True)
+    model = model.to(dev)
+    model.encoder.capture_intermediates = True
+    o = model(batch.to(dev), noise=NoiseSpec(seed=5))
+    assert model.encoder.last_intermediates["E_aa"] == want["aa_edges"]
+    assert H.maxdiff(o["loc"].cpu(), want["loc"]) <= TOL
+    assert H.maxdiff(o["pi"].cpu(), want["pi"]) <= TOL
+
+
 def test_errors_are_loud(dev):
     from trajsde_amd import _lib
     from trajsde_amd.synth import synth

@@ -92,7 +92,7 @@ __device__ __forceinline__ void store_logits(const f4 (&qv)[4], const f4 (&k)[4]
 }
 
 // AA / AL: embedding -> lin_k | lin_v -> logits with q[dst], v
-__global__ __launch_bounds__(768) void k_edge_kv(const float* __restrict__ img_g, const float* __restrict__ geom,
+__global__ __launch_bounds__(1024) void k_edge_kv(const float* __restrict__ img_g, const float* __restrict__ geom,
                                                  const int32_t* __restrict__ dst, const float* __restrict__ q, int64_t E,
                                                  float* __restrict__ logits, float* __restrict__ v) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(768) void k_edge_kv(const float* __restrict__ img_g
 }
 
 // global interactor: relative-pose embedding only (AGG:42-51), reused by all layers
-__global__ __launch_bounds__(768) void k_edge_embed(const float* __restrict__ img_g, const float* __restrict__ geom, int64_t E,
+__global__ __launch_bounds__(1024) void k_edge_embed(const float* __restrict__ img_g, const float* __restrict__ geom, int64_t E,
                                                     float* __restrict__ emb_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, img_g, EdgeL::EMB_SIZE);
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(768) void k_edge_embed(const float* __restrict__ im
 }
 
 // global layer: k = k_node[src] + lin_k_edge(rel), v = v_node[src] + lin_v_edge(rel)  (AGG:108-117)
-__global__ __launch_bounds__(768) void k_global_edge(const float* __restrict__ img_g, const float* __restrict__ rel,
+__global__ __launch_bounds__(1024) void k_global_edge(const float* __restrict__ img_g, const float* __restrict__ rel,
                                                      const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                                      const float* __restrict__ q, const float* __restrict__ kn,
                                                      const float* __restrict__ vn, int64_t E, float* __restrict__ logits,

@@ -7,6 +7,8 @@
 //                 in-kernel Philox (or injected), time bookkeeping replayed from the float32 schedule table
 //                  so the micro-step of T in {30,50,60} is reproduced.
 //   k_sde_step    the same step with the state round-tripping HBM (512 B / path-step), for the roofline report.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "layouts.hpp"
 #include "philox.hpp"
@@ -163,7 +165,8 @@ int trajsde_decoder_forward(int32_t N, int num_modes, int future_steps, const fl
   TS_LAUNCH(k_dec_init, pick_grid(ntiles, 8), 512, DecInitL::SIZE * 4, stream, blob + DecBlob::INIT, local_embed, global_embed, N,
             num_modes, y0, pi);
   // 768 threads = 12 waves = 3 per SIMD (168 VGPRs each); 256 CUs x 12 waves = 3072 path tiles in flight
-  TS_LAUNCH(k_sde_decode, pick_grid(ntiles, 12), 768, DecSdeL::SIZE * 4, stream, blob + DecBlob::SDE, y0, rows, future_steps, n_euler,
+  static const int dthreads = []() { const char* v = getenv("TRAJSDE_THREADS_DECODE"); const int t = v ? atoi(v) : 768; return (t >= 64 && t <= 768 && t % 64 == 0) ? t : 768; }();
+  TS_LAUNCH(k_sde_decode, pick_grid(ntiles, dthreads / 64), dthreads, DecSdeL::SIZE * 4, stream, blob + DecBlob::SDE, y0, rows, future_steps, n_euler,
             step_table, out_table, min_scale, to_arg(noise), loc);
   return TRAJSDE_OK;
 }

@@ -129,25 +129,28 @@ __device__ __forceinline__ EdgeRef resolve_ext_edge(int p, int N, int A, int E, 
   return r;
 }
 
-__global__ void k_aa_flags(int N, int A, int E, int H, int TT, int64_t f_ub, const int32_t* __restrict__ counts,
+// One thread per extended edge, looping over the H snapshots: the edge is resolved once and the H positions /
+// padding bytes of both endpoints are contiguous in memory.  flags is zero-filled beforehand (memset).
+__global__ void k_aa_flags(int N, int A, int E, int H, int TT, const int32_t* __restrict__ counts,
                            const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_dst,
                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ext_rowptr,
                            const int32_t* __restrict__ orig, const uint8_t* __restrict__ pad,
                            const float* __restrict__ pos, float radius, uint8_t* __restrict__ flags) {
   const int E_ext = counts[0];
-  const int64_t total = int64_t(H) * E_ext;
-  for (int64_t f = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; f <= f_ub; f += int64_t(gridDim.x) * blockDim.x) {
-    uint8_t keep = 0;
-    if (f < total) {
-      const int t = int(f / E_ext), p = int(f - int64_t(t) * E_ext);
-      const EdgeRef r = resolve_ext_edge(p, N, A, E, csr_src, csr_dst, rowptr, ext_rowptr, orig);
-      if (!pad[int64_t(r.src) * TT + t] && !pad[int64_t(r.o) * TT + t]) {            // subgraph, ENC:108
-        const float dx = pos[(int64_t(r.src) * TT + t) * 2] - pos[(int64_t(r.o) * TT + t) * 2];
-        const float dy = pos[(int64_t(r.src) * TT + t) * 2 + 1] - pos[(int64_t(r.o) * TT + t) * 2 + 1];
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < E_ext; p += gridDim.x * blockDim.x) {
+    const EdgeRef r = resolve_ext_edge(p, N, A, E, csr_src, csr_dst, rowptr, ext_rowptr, orig);
+    const uint8_t* ps = pad + int64_t(r.src) * TT;
+    const uint8_t* pd = pad + int64_t(r.o) * TT;
+    const float* xs = pos + int64_t(r.src) * TT * 2;
+    const float* xd = pos + int64_t(r.o) * TT * 2;
+    for (int t = 0; t < H; ++t) {
+      uint8_t keep = 0;
+      if (!ps[t] && !pd[t]) {                                                        // subgraph, ENC:108
+        const float dx = xs[2 * t] - xd[2 * t], dy = xs[2 * t + 1] - xd[2 * t + 1];
         keep = sqrtf(dx * dx + dy * dy) < radius;                                     // UTIL:88
       }
+      flags[int64_t(t) * E_ext + p] = keep;
     }
-    flags[f] = keep;
   }
 }
 
@@ -159,19 +162,22 @@ __global__ void k_aa_compact(int N, int A, int E, int H, int TT, const int32_t* 
                              const int32_t* __restrict__ cpos, int32_t* __restrict__ aa_dst, float* __restrict__ geom) {
   const int E_ext = counts[0];
   const int Nt = N + A;
-  const int64_t total = int64_t(H) * E_ext;
-  for (int64_t f = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; f < total; f += int64_t(gridDim.x) * blockDim.x) {
-    if (!flags[f]) continue;
-    const int t = int(f / E_ext), p = int(f - int64_t(t) * E_ext);
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < E_ext; p += gridDim.x * blockDim.x) {
     const EdgeRef r = resolve_ext_edge(p, N, A, E, csr_src, csr_dst, rowptr, ext_rowptr, orig);
-    const int q = cpos[f];
     const f4 R = *reinterpret_cast<const f4*>(rot + 4 * r.o);          // [[R0,R1],[R2,R3]]
-    const float x0 = x[(int64_t(r.src) * H + t) * 2], x1 = x[(int64_t(r.src) * H + t) * 2 + 1];   // senders are real actors
-    const float dx = pos[(int64_t(r.src) * TT + t) * 2] - pos[(int64_t(r.o) * TT + t) * 2];
-    const float dy = pos[(int64_t(r.src) * TT + t) * 2 + 1] - pos[(int64_t(r.o) * TT + t) * 2 + 1];
-    f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
-    *reinterpret_cast<f4*>(geom + 4 * int64_t(q)) = g;
-    aa_dst[q] = t * Nt + r.i;
+    const float* xs = x + int64_t(r.src) * H * 2;                      // senders are real actors
+    const float* ps = pos + int64_t(r.src) * TT * 2;
+    const float* pd = pos + int64_t(r.o) * TT * 2;
+    for (int t = 0; t < H; ++t) {
+      const int64_t f = int64_t(t) * E_ext + p;
+      if (!flags[f]) continue;
+      const int q = cpos[f];
+      const float x0 = xs[2 * t], x1 = xs[2 * t + 1];
+      const float dx = ps[2 * t] - pd[2 * t], dy = ps[2 * t + 1] - pd[2 * t + 1];
+      f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
+      *reinterpret_cast<f4*>(geom + 4 * int64_t(q)) = g;
+      aa_dst[q] = t * Nt + r.i;
+    }
   }
 }
 
@@ -382,8 +388,9 @@ int trajsde_graph_prepare(const trajsde_batch* b, const float* rot, float radius
   k_fake_x<<<cdiv(A * ((2 * H + 3) / 4), 256), 256, 0, st>>>(A, H, b->x, b->agent_index, na, w.x_fake);
   k_ext_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, A, E, w.rowptr, b->agent_index, w.ext_rowptr, w.counts);
   // 21 snapshots: flags + prefix sum
-  k_aa_flags<<<2048, 256, 0, st>>>(N, A, E, H, TT, w.f_ub, w.counts, w.csr_src, w.csr_dst, w.rowptr, w.ext_rowptr, w.orig,
-                                   b->padding_mask, b->positions, radius, w.flags_aa);
+  TS_HIP(hipMemsetAsync(w.flags_aa, 0, size_t(w.f_ub + 1), st));
+  k_aa_flags<<<cdiv(2 * int64_t(E) + 1, 256), 256, 0, st>>>(N, A, E, H, TT, w.counts, w.csr_src, w.csr_dst, w.rowptr, w.ext_rowptr,
+                                                            w.orig, b->padding_mask, b->positions, radius, w.flags_aa);
   {
     size_t tmp = size_t(w.cub_bytes);
     TS_HIP(scan_flags(w.cub_tmp, tmp, w.flags_aa, w.cpos_aa, int(w.f_ub + 1), st));
@@ -433,7 +440,7 @@ int trajsde_graph_compact(const trajsde_batch* b, const float* rot, void* ws, in
   if (!w.ok || !e.ok) return fail(TRAJSDE_ERR_WORKSPACE, "graph_compact: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int N = b->N, A = b->A, E = b->E, H = b->H, TT = b->TT, Ea = b->E_al, Nt = N + A;
-  k_aa_compact<<<2048, 256, 0, st>>>(N, A, E, H, TT, w.counts, w.csr_src, w.csr_dst, w.rowptr, w.ext_rowptr, w.orig, b->x,
+  k_aa_compact<<<cdiv(int64_t(out->E_ext) + 1, 256), 256, 0, st>>>(N, A, E, H, TT, w.counts, w.csr_src, w.csr_dst, w.rowptr, w.ext_rowptr, w.orig, b->x,
                                      b->positions, rot, w.flags_aa, w.cpos_aa, e.aa_dst, e.aa_geom);
   k_aa_segptr<<<cdiv(int64_t(H) * Nt + 1, 256), 256, 0, st>>>(Nt, H, w.counts, w.ext_rowptr, w.cpos_aa, e.aa_segptr);
   if (E > 0)

@@ -13,7 +13,7 @@
 
 namespace tsde {
 
-__global__ __launch_bounds__(256) void k_enc_sde_step(const float* __restrict__ img_g, const float* __restrict__ h_in,
+__global__ __launch_bounds__(512) void k_enc_sde_step(const float* __restrict__ img_g, const float* __restrict__ h_in,
                                                       const float* __restrict__ hidden0, int Nt, float dt, float sq, float sn,
                                                       float cs, int idx, NoiseArg na, const uint8_t* __restrict__ nus,
                                                       const int32_t* __restrict__ eos, const int32_t* __restrict__ pick_slot,
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_enc_sde_step(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void k_enc_gru_step(const float* __restrict__ img_g, const float* __restrict__ h_ode,
+__global__ __launch_bounds__(512) void k_enc_gru_step(const float* __restrict__ img_g, const float* __restrict__ h_ode,
                                                       const float* __restrict__ x_t, int Nt, int N, int t, int TT, int idx,
                                                       const uint8_t* __restrict__ pad, const int32_t* __restrict__ orig,
                                                       const int32_t* __restrict__ eos, float* __restrict__ h_out,

@@ -5,7 +5,20 @@
 #include "kernels.hpp"
 #include "layouts.hpp"
 
+#include <cstdlib>
+
 namespace tsde {
+
+// workgroup sizes; overridable for sweeps: TRAJSDE_THREADS_EDGE / _NODE / _RECUR (multiples of 64)
+static int env_threads(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (!v) return dflt;
+  const int t = atoi(v);
+  return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : dflt;
+}
+static int threads_edge() { static int t = env_threads("TRAJSDE_THREADS_EDGE", 1024); return t; }
+static int threads_node() { static int t = env_threads("TRAJSDE_THREADS_NODE", 512); return t; }
+static int threads_recur() { static int t = env_threads("TRAJSDE_THREADS_RECUR", 256); return t; }
 
 // grid for a tile kernel whose workgroups each hold an LDS weight image: as many workgroups as fit on the
 // chip at once (LDS- and thread-limited), grid-stride beyond that, never more than the work needs
@@ -62,8 +75,8 @@ static int attention_tail(const float* upd_img, const float* ffn_img, const int3
                           const float* xn, const float* x, int64_t R, float* agg, float* x1, float* xn2, float* out, hipStream_t st) {
   TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, segptr, logits, v, R, agg);
   const int64_t ntiles = (R + 15) / 16;
-  TS_LAUNCH(k_node_update, tile_grid(ntiles, 512, UpdL::SIZE * 4), 512, UpdL::SIZE * 4, st, upd_img, agg, xn, x, R, x1, xn2);
-  TS_LAUNCH(k_ffn, tile_grid(ntiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, ffn_img, x1, xn2, R, out);
+  TS_LAUNCH(k_node_update, tile_grid(ntiles, threads_node(), UpdL::SIZE * 4), threads_node(), UpdL::SIZE * 4, st, upd_img, agg, xn, x, R, x1, xn2);
+  TS_LAUNCH(k_ffn, tile_grid(ntiles, threads_node(), FfnL::SIZE * 4), threads_node(), FfnL::SIZE * 4, st, ffn_img, x1, xn2, R, out);
   return TRAJSDE_OK;
 }
 
@@ -97,7 +110,7 @@ int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, cons
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob + EncBlob::AA_CENTER,
             b->x, g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
   if (g->E_aa > 0)
-    TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv, tile_grid((int64_t(g->E_aa) + 15) / 16, 768, EdgeL::SIZE * 4), 768, EdgeL::SIZE * 4, st,
+    TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv, tile_grid((int64_t(g->E_aa) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(), EdgeL::SIZE * 4, st,
               blob + EncBlob::AA_EDGE, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v);
   if (int rc = attention_tail(blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg,
                               w.x1, w.xn2, aa_out, st))
@@ -109,10 +122,10 @@ int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, cons
   for (int idx = 0; idx < H; ++idx) {
     const int t = H - 1 - idx;
     const float* e = step_tab + 8 * idx;
-    TS_LAUNCH(k_enc_sde_step, tile_grid(rtiles, 256, EncSdeL::SIZE * 4), 256, EncSdeL::SIZE * 4, st, blob + EncBlob::SDE,
+    TS_LAUNCH(k_enc_sde_step, tile_grid(rtiles, threads_recur(), EncSdeL::SIZE * 4), threads_recur(), EncSdeL::SIZE * 4, st, blob + EncBlob::SDE,
               idx == 0 ? nullptr : w.hA, blob + EncBlob::HIDDEN, Nt, e[1], e[2], e[3], e[4], idx, na, g->nus_mask, g->eos_idx,
               g->pick_slot, w.hB, diff_pick);
-    TS_LAUNCH(k_enc_gru_step, tile_grid(rtiles, 256, EncGruL::SIZE * 4), 256, EncGruL::SIZE * 4, st, blob + EncBlob::GRU, w.hB,
+    TS_LAUNCH(k_enc_gru_step, tile_grid(rtiles, threads_recur(), EncGruL::SIZE * 4), threads_recur(), EncGruL::SIZE * 4, st, blob + EncBlob::GRU, w.hB,
               aa_out + int64_t(t) * Nt * 64, Nt, N, t, b->TT, idx, b->padding_mask, g->orig, g->eos_idx, w.hA, w.lat,
               latent_ys ? latent_ys + int64_t(idx) * N * 64 : nullptr);
   }
@@ -121,7 +134,7 @@ int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, cons
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob + EncBlob::AL_Q, w.lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
   if (g->E_la > 0)
-    TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv, tile_grid((int64_t(g->E_la) + 15) / 16, 768, EdgeL::SIZE * 4), 768, EdgeL::SIZE * 4, st,
+    TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv, tile_grid((int64_t(g->E_la) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(), EdgeL::SIZE * 4, st,
               blob + EncBlob::AL_EDGE, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v);
   return attention_tail(blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, g->la_segptr, w.al_logits, w.al_v, w.al_xn, w.lat, N,
                         w.al_agg, w.al_x1, w.al_xn2, local_embed, st);
@@ -144,7 +157,7 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int64_t N = b->N, E = g->E_g, ntiles = (N + 15) / 16, etiles = (E + 15) / 16;
   if (E > 0)
-    TS_LAUNCH(k_edge_embed, tile_grid(etiles, 768, EdgeL::EMB_SIZE * 4), 768, EdgeL::EMB_SIZE * 4, st, blob + AggBlob::REL, g->g_geom,
+    TS_LAUNCH(k_edge_embed, tile_grid(etiles, threads_edge(), EdgeL::EMB_SIZE * 4), threads_edge(), EdgeL::EMB_SIZE * 4, st, blob + AggBlob::REL, g->g_geom,
               E, w.rel);
   const float* x = local_embed;
   float* bufs[2] = {w.xa, w.xb};
@@ -153,7 +166,7 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
     TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
               w.xn, w.q, w.kn, w.vn);
     if (E > 0)
-      TS_LAUNCH(k_global_edge, tile_grid(etiles, 768, GEdgeL::SIZE * 4), 768, GEdgeL::SIZE * 4, st, lb + AggLayerL::EDGE, w.rel, g->g_src,
+      TS_LAUNCH(k_global_edge, tile_grid(etiles, threads_edge(), GEdgeL::SIZE * 4), threads_edge(), GEdgeL::SIZE * 4, st, lb + AggLayerL::EDGE, w.rel, g->g_src,
                 g->g_dst, w.q, w.kn, w.vn, E, w.logits, w.v);
     float* out = bufs[i & 1];
     if (int rc = attention_tail(lb + AggLayerL::UPD, lb + AggLayerL::FFN, g->g_segptr, w.logits, w.v, w.xn, x, N, w.agg, w.x1, w.xn2,
