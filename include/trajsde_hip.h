@@ -139,6 +139,16 @@ int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, cons
                             float* aa_out /*[H,Nt,64] or null*/, float* latent_ys /*[H,N,64] or null*/,
                             void* stream);
 
+/* ---- LocalEncoderSDESepPara2.forward_ood (ENC:204-370): graph prepared with b->A = 0 (no fake agents);
+ *      n_samples (reference: 10) stochastic recurrences from a zero state; stds[n] = std over samples of
+ *      the kept latent state (unbiased), averaged over the 64 channels; local_embed from the sample mean.
+ *      Noise layout when injected: z [n_samples*H, N, 64]; Philox step index = sample*H + iteration. */
+int64_t trajsde_encoder_ood_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int n_samples);
+int trajsde_encoder_forward_ood(const trajsde_batch* b, const trajsde_graph* g, const float* rotate_mat,
+                                const float* blob, const float* enc_step_table /*HOST memory, [H,8]*/,
+                                const trajsde_noise* noise, int n_samples, void* ws, int64_t ws_bytes,
+                                float* local_embed /*[N,64]*/, float* stds /*[N]*/, void* stream);
+
 /* ---- aggregator stage: GlobalInteractor (AGG:38-58, 92-135) ------------------------------------ */
 int64_t trajsde_aggregator_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int num_modes);
 int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers,

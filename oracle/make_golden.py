@@ -53,6 +53,43 @@ def philox_noise(seed, A, Nt, KN, n_euler, H=21):
     return z_fake, z_enc, z_dec
 
 
+OOD_CASES = {
+    "ood_k3_t5": (dict(S=2, n=7, L=5, F=5, box=70.0, seed=15, mixed_source=True, history_dropout=0.4), 3, 5, 0.5, 4, 105),
+}
+
+
+def make_ood(name):
+    """MODEL:89-98 with ood=True: encoder.forward_ood (10 stochastic recurrences) -> stds."""
+    skw, K, T, max_t, init_seed, noise_seed = OOD_CASES[name]
+    batch = synth(**skw)
+    ours = PredictionModelSDENet(**our_cfg(K, T, max_t), init_seed=init_seed)
+    sd = {k: v.detach().clone() for k, v in ours.state_dict().items()}
+    ref = R.build_reference_model(R.load_reference_cfg(num_modes=K, future_steps=T, max_fut_t=max_t))
+    ref.load_state_dict(sd)
+    ref.ood = True
+    N = batch.num_nodes
+    sched = decoder_schedule(T, max_t)
+    z_enc = [philox.normals(noise_seed, philox.STREAM_ENCODER, s, np.arange(N), 64) for s in range(10 * 21)]
+    z_dec = [philox.normals(noise_seed, philox.STREAM_DECODER, k, np.arange(K * N), 64) for k in range(sched.n_euler)]
+    caps = {}
+    hook = ref.aggregator.register_forward_hook(lambda m, a, o: caps.__setitem__("global_embed", o))
+    out, data, rec = R.run_reference_forward(ref, batch, replay=[torch.from_numpy(z) for z in z_enc + z_dec])
+    hook.remove()
+    assert len(rec) == 210 + sched.n_euler
+    fx = {f"in.{k}": v.numpy() for k, v in batch.as_dict().items() if torch.is_tensor(v)}
+    fx["meta.num_modes"], fx["meta.future_steps"], fx["meta.max_fut_t"] = K, T, max_t
+    fx["meta.init_seed"], fx["meta.noise_seed"] = init_seed, noise_seed
+    fx["meta.state_checksum"] = state_checksum(sd)
+    fx["meta.n_euler"] = sched.n_euler
+    for k in ("loc", "pi", "reg_mask", "stds"):
+        fx[f"out.{k}"] = out[k].numpy()
+    fx["mid.global_embed"] = caps["global_embed"].numpy()
+    path = os.path.join(ROOT, "tests", "golden_ood", name + ".npz")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez_compressed(path, **fx)
+    print(f"{name}: N={N} K={K} T={T} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def make(name):
     skw, K, T, max_t, init_seed, noise_seed = CASES[name]
     batch = synth(**skw)
@@ -97,5 +134,5 @@ def make(name):
 if __name__ == "__main__":
     if not R.reference_available():
         sys.exit("reference tree not found; golden vectors can only be generated in the build container")
-    for name in (sys.argv[1:] or CASES):
-        make(name)
+    for name in (sys.argv[1:] or list(CASES) + list(OOD_CASES)):
+        make_ood(name) if name in OOD_CASES else make(name)

@@ -118,6 +118,21 @@ def test_scene_independence_and_sharding_invariance(dev):
     assert H.maxdiff(o2["pi"][na:].cpu(), o1["pi"].cpu()) <= 1e-5
 
 
+def test_forward_ood_matches_reference_golden(dev):
+    """the OOD path (MODEL:89-98, ENC:204-370): 10 stochastic encoder passes -> per-actor std"""
+    from test_oracle_golden import _load_ood
+    from trajsde_amd.runtime import NoiseSpec
+    batch, meta, out = _load_ood()
+    model, cfg = H.build_model(meta)
+    model = model.to(dev)
+    model.ood = True
+    o = model(batch.to(dev), noise=NoiseSpec(seed=int(meta["noise_seed"])))
+    assert "stds" in o and "diff_in" not in o
+    assert H.maxdiff(o["stds"].cpu(), out["stds"]) <= TOL
+    assert H.maxdiff(o["loc"].cpu(), out["loc"]) <= TOL
+    assert H.maxdiff(o["pi"].cpu(), out["pi"]) <= TOL
+
+
 def test_full_size_config2_properties(dev):
     """BASELINE config 2 at full size (64 scenes x 128 agents, K=6, T=20), where the oracle is too slow to run whole:
     (1) scene independence: a scene taken out of the big batch and run alone (same global Philox row ids) gives

@@ -24,6 +24,28 @@ def test_restatement_matches_reference_golden(name):
         assert H.maxdiff(mine[key], mid[key]) <= tol, key
 
 
+def _load_ood(name="ood_k3_t5"):
+    import os
+    from trajsde_amd.data import TemporalData
+    z = np.load(os.path.join(H.ROOT, "tests", "golden_ood", name + ".npz"))
+    batch = TemporalData(**{k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in.")})
+    batch["num_nodes"] = batch["x"].shape[0]
+    meta = {k[5:]: z[k].item() for k in z.files if k.startswith("meta.")}
+    out = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out.")}
+    return batch, meta, out
+
+
+def test_restatement_matches_reference_golden_ood():
+    """MODEL:89-98 with ood=True (forward_ood, ENC:204-370), golden from the reference itself."""
+    import restate
+    batch, meta, out = _load_ood()
+    model, cfg = H.build_model(meta)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    mine = restate.forward(P, cfg, H.clone_batch(batch), restate.PhiloxNoise(int(meta["noise_seed"])), ood=True)
+    for key in ("loc", "pi", "stds"):
+        assert H.maxdiff(mine[key], out[key]) <= 1e-5, key
+
+
 def test_oracle_detects_a_wrong_radius():
     """negative control: the comparison is not vacuous."""
     batch, meta, out, mid = H.load_fixture("mixed_k6_t20")

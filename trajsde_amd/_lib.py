@@ -53,6 +53,8 @@ SIGNATURES = {
     "trajsde_graph_compact": (C.c_int, [C.POINTER(Batch), P, P, I64, P, I64, C.POINTER(Graph), P]),
     "trajsde_encoder_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
     "trajsde_encoder_forward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, C.POINTER(Noise), P, I64, P, P, P, P, P]),
+    "trajsde_encoder_ood_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph), C.c_int]),
+    "trajsde_encoder_forward_ood": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, C.POINTER(Noise), C.c_int, P, I64, P, P, P]),
     "trajsde_aggregator_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph), C.c_int]),
     "trajsde_aggregator_forward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, C.c_int, C.c_int, P, P, I64, P, P]),
     "trajsde_decoder_ws_bytes": (I64, [I32, C.c_int]),

@@ -21,10 +21,12 @@ __global__ void k_node_proj(const float* img, const float* x, int64_t R, float* 
 __global__ void k_mode_proj(const float* norm_g, const float* proj_g, const float* x, int64_t N, float* out);
 
 __global__ void k_enc_sde_step(const float* img, const float* h_in, const float* hidden0, int Nt, float dt, float sq, float sn, float cs,
-                               int idx, NoiseArg na, const uint8_t* nus, const int32_t* eos, const int32_t* pick_slot, float* h_ode,
+                               int idx, int noise_step0, NoiseArg na, const uint8_t* nus, const int32_t* eos, const int32_t* pick_slot, float* h_ode,
                                float* diff_pick);
 __global__ void k_enc_gru_step(const float* img, const float* h_ode, const float* x_t, int Nt, int N, int t, int TT, int idx,
                                const uint8_t* pad, const int32_t* orig, const int32_t* eos, float* h_out, float* local_out,
                                float* latent_t);
+
+__global__ void k_ood_stats(const float* samples, int S, int N, float* mean, float* stds);
 
 }  // namespace tsde

@@ -302,7 +302,7 @@ struct PrepWs {
     la_rowptr = c.take<int32_t>(N + 1);
     nus = c.take<uint8_t>(Nt); flags_aa = c.take<uint8_t>(f_ub + 1); flags_g = c.take<uint8_t>(E + 1); flags_la = c.take<uint8_t>(Ea + 1);
     cpos_aa = c.take<int32_t>(f_ub + 1); cpos_g = c.take<int32_t>(E + 1); cpos_la = c.take<int32_t>(Ea + 1);
-    x_fake = c.take<float>(A * H * 2); lane_feat = c.take<float>(int64_t(b->L) * 2);
+    x_fake = c.take<float>(A * H * 2 + 4); lane_feat = c.take<float>(int64_t(b->L) * 2);
     size_t s1 = 0, s2 = 0, s3 = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s1, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
                                        int(E > Ea ? E : Ea), 0, 32, (hipStream_t)0);
@@ -334,11 +334,12 @@ struct EdgeWs {
 
 static int check_batch(const trajsde_batch* b) {
   TS_REQUIRE(b != nullptr, "batch: null");
-  TS_REQUIRE(b->N > 0 && b->A > 0 && b->H > 0 && b->TT >= b->H, "batch: bad sizes");
+  TS_REQUIRE(b->N > 0 && b->A >= 0 && b->H > 0 && b->TT >= b->H, "batch: bad sizes");
   TS_REQUIRE(b->E >= 0 && b->E_al >= 0 && b->L >= 0, "batch: negative sizes");
   TS_REQUIRE(int64_t(b->H) * 2 * b->E < (int64_t(1) << 31) - 2, "batch: too many (t, edge) candidates for int32 positions");
-  TS_REQUIRE(b->x && b->positions && b->padding_mask && b->bos_mask && b->rotate_angles && b->agent_index && b->batch && b->source,
+  TS_REQUIRE(b->x && b->positions && b->padding_mask && b->bos_mask && b->rotate_angles && b->batch && b->source,
              "batch: null actor tensor");
+  TS_REQUIRE(b->A == 0 || b->agent_index, "batch: null agent_index");   // A == 0: no fake agents (forward_ood, ENC:204-370)
   TS_REQUIRE(b->E == 0 || b->edge_index, "batch: null edge_index");
   TS_REQUIRE(b->E_al == 0 || (b->lane_actor_index && b->lane_actor_vectors && b->lane_positions && b->lane_paddings),
              "batch: null lane tensor");
@@ -384,8 +385,10 @@ int trajsde_graph_prepare(const trajsde_batch* b, const float* rot, float radius
   }
   k_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(w.csr_dst, E, N, w.rowptr);
   k_ext_nodes<<<cdiv(Nt, 256), 256, 0, st>>>(N, A, H, b->agent_index, b->batch, b->source, b->bos_mask, w.orig, w.nus, w.eos, w.pick_slot);
-  k_agent_slots<<<cdiv(A, 256), 256, 0, st>>>(A, b->agent_index, w.pick_slot);
-  k_fake_x<<<cdiv(A * ((2 * H + 3) / 4), 256), 256, 0, st>>>(A, H, b->x, b->agent_index, na, w.x_fake);
+  if (A > 0) {
+    k_agent_slots<<<cdiv(A, 256), 256, 0, st>>>(A, b->agent_index, w.pick_slot);
+    k_fake_x<<<cdiv(A * ((2 * H + 3) / 4), 256), 256, 0, st>>>(A, H, b->x, b->agent_index, na, w.x_fake);
+  }
   k_ext_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, A, E, w.rowptr, b->agent_index, w.ext_rowptr, w.counts);
   // 21 snapshots: flags + prefix sum
   TS_HIP(hipMemsetAsync(w.flags_aa, 0, size_t(w.f_ub + 1), st));

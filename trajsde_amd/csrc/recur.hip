@@ -15,7 +15,7 @@ namespace tsde {
 
 __global__ __launch_bounds__(512) void k_enc_sde_step(const float* __restrict__ img_g, const float* __restrict__ h_in,
                                                       const float* __restrict__ hidden0, int Nt, float dt, float sq, float sn,
-                                                      float cs, int idx, NoiseArg na, const uint8_t* __restrict__ nus,
+                                                      float cs, int idx, int noise_step0, NoiseArg na, const uint8_t* __restrict__ nus,
                                                       const int32_t* __restrict__ eos, const int32_t* __restrict__ pick_slot,
                                                       float* __restrict__ h_ode, float* __restrict__ diff_pick) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -40,12 +40,12 @@ __global__ __launch_bounds__(512) void k_enc_sde_step(const float* __restrict__ 
       const float b = diff_eval(y, lds + EncSdeL::GA, sn, cs, L);
       gs = is_nus ? a : b;
     }
-    noise_row(z, na, STREAM_ENCODER, idx, r, Nt, L.g);
+    noise_row(z, na, STREAM_ENCODER, noise_step0 + idx, r, Nt, L.g);
     em_update(y, f, gs, z, dt, sq);
     if (row < Nt) {
       store_row(y, h_ode, row, L.g);
       const int slot = pick_slot[r];
-      if (slot >= 0 && eos[r] == idx) {                               // ENC:171,190-191 diffusion of the kept step
+      if (diff_pick != nullptr && slot >= 0 && eos[r] == idx) {                               // ENC:171,190-191 diffusion of the kept step
         f4 gv[4];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) gv[jt] = f4{gs, gs, gs, gs};
@@ -105,6 +105,27 @@ __global__ __launch_bounds__(512) void k_enc_gru_step(const float* __restrict__ 
       }
     }
   }
+}
+
+// forward_ood (ENC:311-313): outs [S,N,64] -> mean over samples [N,64] and std(0).mean(-1) [N] (unbiased std)
+__global__ __launch_bounds__(256) void k_ood_stats(const float* __restrict__ samples, int S, int N, float* __restrict__ mean,
+                                                   float* __restrict__ stds) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float m = 0.f;
+  for (int s = 0; s < S; ++s) m += samples[(int64_t(s) * N + row) * 64 + lane];
+  m /= float(S);
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float d = samples[(int64_t(s) * N + row) * 64 + lane] - m;
+    v += d * d;
+  }
+  float sd = S > 1 ? sqrtf(v / float(S - 1)) : 0.f;
+  mean[row * 64 + lane] = m;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) sd += __shfl_xor(sd, o);
+  if (lane == 0) stds[row] = sd * (1.0f / 64.0f);
 }
 
 }  // namespace tsde

@@ -92,52 +92,102 @@ int64_t trajsde_encoder_ws_bytes(const trajsde_batch* b, const trajsde_graph* g)
   return w.total;
 }
 
-int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob,
-                            const float* step_tab /*HOST [H,8]*/, const trajsde_noise* noise, void* ws, int64_t ws_bytes,
-                            float* local_embed, float* diff_pick, float* aa_out_user, float* latent_ys, void* stream_) {
-  TS_REQUIRE(b && g && rot && blob && step_tab && ws && local_embed && diff_pick, "encoder_forward: null pointer");
-  TS_REQUIRE(g->aa_segptr && g->la_segptr && g->orig, "encoder_forward: graph not compacted (call trajsde_graph_compact)");
-  EncWs w(b, g, ws, ws_bytes);
-  if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_forward: workspace too small");
-  hipStream_t st = static_cast<hipStream_t>(stream_);
-  const int N = b->N, Nt = g->Nt, H = b->H, A = b->A;
+// AAEncoder on the H snapshots at once (ENC:112-121, 538-566) -> aa_out [H, Nt, 64]
+static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob, EncWs& w, float* aa_out,
+                          hipStream_t st) {
+  const int N = b->N, Nt = g->Nt, H = b->H;
   const int64_t R = int64_t(H) * Nt;
-  float* aa_out = aa_out_user ? aa_out_user : w.aa_out;
-  NoiseArg na{0, nullptr, nullptr};
-  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
-
-  // ---- AAEncoder on the 21 snapshots at once (ENC:112-121, 538-566)
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob + EncBlob::AA_CENTER,
             b->x, g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
   if (g->E_aa > 0)
     TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv, tile_grid((int64_t(g->E_aa) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(), EdgeL::SIZE * 4, st,
               blob + EncBlob::AA_EDGE, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v);
-  if (int rc = attention_tail(blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg,
-                              w.x1, w.xn2, aa_out, st))
-    return rc;
+  return attention_tail(blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg, w.x1,
+                        w.xn2, aa_out, st);
+}
 
-  // ---- latent SDE + GRU recurrence, iteration idx consumes history step t = H-1-idx (ENC:128-182)
-  TS_HIP(hipMemsetAsync(diff_pick, 0, size_t(2) * A * 64 * sizeof(float), st));
+// one pass of the latent SDE + GRU recurrence; iteration idx consumes history step t = H-1-idx (ENC:128-182)
+static int run_recurrence(const trajsde_batch* b, const trajsde_graph* g, const float* blob, const float* step_tab, const float* h0,
+                          int noise_step0, NoiseArg na, EncWs& w, const float* aa_out, float* kept, float* diff_pick,
+                          float* latent_ys, hipStream_t st) {
+  const int N = b->N, Nt = g->Nt, H = b->H;
   const int64_t rtiles = (int64_t(Nt) + 15) / 16;
   for (int idx = 0; idx < H; ++idx) {
     const int t = H - 1 - idx;
     const float* e = step_tab + 8 * idx;
     TS_LAUNCH(k_enc_sde_step, tile_grid(rtiles, threads_recur(), EncSdeL::SIZE * 4), threads_recur(), EncSdeL::SIZE * 4, st, blob + EncBlob::SDE,
-              idx == 0 ? nullptr : w.hA, blob + EncBlob::HIDDEN, Nt, e[1], e[2], e[3], e[4], idx, na, g->nus_mask, g->eos_idx,
+              idx == 0 ? nullptr : w.hA, h0, Nt, e[1], e[2], e[3], e[4], idx, noise_step0, na, g->nus_mask, g->eos_idx,
               g->pick_slot, w.hB, diff_pick);
     TS_LAUNCH(k_enc_gru_step, tile_grid(rtiles, threads_recur(), EncGruL::SIZE * 4), threads_recur(), EncGruL::SIZE * 4, st, blob + EncBlob::GRU, w.hB,
-              aa_out + int64_t(t) * Nt * 64, Nt, N, t, b->TT, idx, b->padding_mask, g->orig, g->eos_idx, w.hA, w.lat,
+              aa_out + int64_t(t) * Nt * 64, Nt, N, t, b->TT, idx, b->padding_mask, g->orig, g->eos_idx, w.hA, kept,
               latent_ys ? latent_ys + int64_t(idx) * N * 64 : nullptr);
   }
+  return TRAJSDE_OK;
+}
 
-  // ---- ALEncoder (ENC:198-200, 732-797)
+// ALEncoder (ENC:198-200, 732-797): lat [N,64] -> local_embed [N,64]
+static int run_al_encoder(const trajsde_batch* b, const trajsde_graph* g, const float* blob, EncWs& w, const float* lat,
+                          float* local_embed, hipStream_t st) {
+  const int N = b->N;
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
-            blob + EncBlob::AL_Q, w.lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
+            blob + EncBlob::AL_Q, lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
   if (g->E_la > 0)
     TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv, tile_grid((int64_t(g->E_la) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(), EdgeL::SIZE * 4, st,
               blob + EncBlob::AL_EDGE, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v);
-  return attention_tail(blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, g->la_segptr, w.al_logits, w.al_v, w.al_xn, w.lat, N,
-                        w.al_agg, w.al_x1, w.al_xn2, local_embed, st);
+  return attention_tail(blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, g->la_segptr, w.al_logits, w.al_v, w.al_xn, lat, N, w.al_agg,
+                        w.al_x1, w.al_xn2, local_embed, st);
+}
+
+int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob,
+                            const float* step_tab /*HOST [H,8]*/, const trajsde_noise* noise, void* ws, int64_t ws_bytes,
+                            float* local_embed, float* diff_pick, float* aa_out_user, float* latent_ys, void* stream_) {
+  TS_REQUIRE(b && g && rot && blob && step_tab && ws && local_embed && diff_pick, "encoder_forward: null pointer");
+  TS_REQUIRE(g->aa_segptr && g->la_segptr && g->orig, "encoder_forward: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(b->A > 0 && g->Nt == b->N + b->A, "encoder_forward: graph was prepared without the fake-agent rows");
+  EncWs w(b, g, ws, ws_bytes);
+  if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_forward: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  float* aa_out = aa_out_user ? aa_out_user : w.aa_out;
+  NoiseArg na{0, nullptr, nullptr};
+  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
+  if (int rc = run_aa_encoder(b, g, rot, blob, w, aa_out, st)) return rc;
+  TS_HIP(hipMemsetAsync(diff_pick, 0, size_t(2) * b->A * 64 * sizeof(float), st));
+  if (int rc = run_recurrence(b, g, blob, step_tab, blob + EncBlob::HIDDEN, 0, na, w, aa_out, w.lat, diff_pick, latent_ys, st)) return rc;
+  return run_al_encoder(b, g, blob, w, w.lat, local_embed, st);
+}
+
+// LocalEncoderSDESepPara2.forward_ood (ENC:204-370): the batch/graph carry no fake agents (A = 0); `n_samples`
+// stochastic recurrences from a zero state, per-actor std of the kept latent, AL encoder on the mean.
+int64_t trajsde_encoder_ood_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int n_samples) {
+  if (!b || !g || n_samples < 1) return -1;
+  EncWs w(b, g, nullptr, 0);
+  return w.total + align_up(int64_t(n_samples) * b->N * 64 * 4, 256) + align_up(int64_t(b->N) * 64 * 4, 256) + 1024;
+}
+
+int trajsde_encoder_forward_ood(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob,
+                                const float* step_tab /*HOST [H,8]*/, const trajsde_noise* noise, int n_samples, void* ws,
+                                int64_t ws_bytes, float* local_embed, float* stds, void* stream_) {
+  TS_REQUIRE(b && g && rot && blob && step_tab && ws && local_embed && stds, "encoder_forward_ood: null pointer");
+  TS_REQUIRE(g->aa_segptr && g->la_segptr && g->orig, "encoder_forward_ood: graph not compacted");
+  TS_REQUIRE(b->A == 0 && g->Nt == b->N, "encoder_forward_ood: prepare the graph with A = 0 (no fake agents)");
+  TS_REQUIRE(n_samples >= 1, "encoder_forward_ood: n_samples < 1");
+  if (ws_bytes < trajsde_encoder_ood_ws_bytes(b, g, n_samples)) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_forward_ood: workspace too small");
+  EncWs w(b, g, ws, ws_bytes);
+  Carver extra(static_cast<char*>(ws) + align_up(w.total, 256), ws_bytes - align_up(w.total, 256));
+  float* samples = extra.take<float>(int64_t(n_samples) * b->N * 64);
+  float* mean = extra.take<float>(int64_t(b->N) * 64);
+  float* zero = extra.take<float>(64);
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  NoiseArg na{0, nullptr, nullptr};
+  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
+  if (int rc = run_aa_encoder(b, g, rot, blob, w, w.aa_out, st)) return rc;
+  TS_HIP(hipMemsetAsync(zero, 0, 64 * sizeof(float), st));                         // ENC:257 prev_hidden = zeros
+  for (int j = 0; j < n_samples; ++j)
+    if (int rc = run_recurrence(b, g, blob, step_tab, zero, j * b->H, na, w, w.aa_out, samples + int64_t(j) * b->N * 64, nullptr,
+                                nullptr, st))
+      return rc;
+  TS_LAUNCH(k_ood_stats, cdiv(b->N, 4), 256, 0, st, samples, n_samples, b->N, mean, stds);
+  return run_al_encoder(b, g, blob, w, mean, local_embed, st);
 }
 
 int64_t trajsde_aggregator_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int num_modes) {

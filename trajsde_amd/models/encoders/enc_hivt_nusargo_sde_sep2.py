@@ -50,5 +50,6 @@ class LocalEncoderSDESepPara2(ParamTree):
     def forward(self, data, noise: Optional["runtime.NoiseSpec"] = None):
         return self._rt.encoder_forward(data, noise)
 
-    def forward_ood(self, data):
-        raise NotImplementedError("forward_ood (ENC:204-370) is a 'next' row of SURVEY.md 8(f); not built yet")
+    def forward_ood(self, data, noise: Optional["runtime.NoiseSpec"] = None):
+        """ENC:204-370: 10 stochastic recurrences from a zero state -> (local_embed, per-actor std)."""
+        return self._rt.encoder_forward_ood(data, noise, n_samples=10)

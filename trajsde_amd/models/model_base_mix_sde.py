@@ -73,8 +73,7 @@ class PredictionModelSDENet(nn.Module):
     def forward(self, data, noise: Optional["runtime.NoiseSpec"] = None):
         """MODEL:74-102.  `noise` (optional, ours) selects the Philox seed or injected normals; the default
         draws a fresh Philox seed from torch's global generator, like the reference draws fresh noise."""
-        if getattr(self, "ood", False):
-            raise NotImplementedError("ood=True / forward_ood is a 'next' row (SURVEY.md 8(f))")
+        ood = bool(getattr(self, "ood", False))                              # test.py --ood injects this flag (test.py:45-46)
         noise = runtime.NoiseSpec.resolve(noise)
         if self.rotate:
             rotate_mat, y_rot = runtime.rotate_inputs(data)          # MODEL:76-85
@@ -83,10 +82,16 @@ class PredictionModelSDENet(nn.Module):
             data["rotate_mat"] = rotate_mat
         else:
             raise NotImplementedError("rotate=False is not built (shipped config: rotate: true, CFG:18)")
-        local_embed, diff_in, diff_out, label_in, label_out = self.encoder(data=data, noise=noise)
+        if ood:
+            local_embed, stds = self.encoder.forward_ood(data=data, noise=noise)            # MODEL:89-90
+        else:
+            local_embed, diff_in, diff_out, label_in, label_out = self.encoder(data=data, noise=noise)
         global_embed = self.aggregator(data=data, local_embed=local_embed)
         out = self.decoder(data=data, local_embed=local_embed, global_embed=global_embed, noise=noise)
-        out["diff_in"], out["diff_out"], out["label_in"], out["label_out"] = diff_in, diff_out, label_in, label_out
+        if ood:
+            out["stds"] = stds                                                                 # MODEL:97-98
+        else:
+            out["diff_in"], out["diff_out"], out["label_in"], out["label_out"] = diff_in, diff_out, label_in, label_out
         return out
 
     # -- Lightning-style hooks (MODEL:104-148) ------------------------------------------------------

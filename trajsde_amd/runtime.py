@@ -178,13 +178,7 @@ class StageRuntime:
         L = _lib.lib()
         blob = self.blob()
         H, N, A, Nt = gc.batch.H, gc.batch.N, gc.batch.A, gc.graph.Nt
-        key = (H, float(m.max_past_t), float(m.minimum_step), bool(m.run_backwards))
-        if key not in _ENC_TABLES:               # host replay of the solver's float32 time bookkeeping: once per config
-            sched = encoder_schedule(*key)
-            if sched.n_euler != H or not np.all(sched.out_w1 == 1.0):
-                raise _lib.TrajsdeError("encoder schedule is not one Euler step per interval (SURVEY App. D)")
-            _ENC_TABLES[key] = np.ascontiguousarray(sched.step_table())
-        tab = _ENC_TABLES[key]
+        tab = self._enc_table()
         if noise.z_enc is not None and tuple(noise.z_enc.shape) != (H, Nt, D):
             raise _lib.TrajsdeError(f"z_enc must be [{H},{Nt},{D}]")
         local = torch.empty(N, D, device=dev, dtype=torch.float32)
@@ -205,6 +199,39 @@ class StageRuntime:
                                     "E_la": gc.graph.E_la}
         diff_in, diff_out = torch.chunk(diff_pick, 2, 0)                                    # ENC:194
         return (local, diff_in, diff_out, torch.full_like(diff_in, m.real_label), torch.full_like(diff_out, m.fake_label))
+
+    def _enc_table(self) -> np.ndarray:
+        m = self.module
+        key = (int(m.historical_steps), float(m.max_past_t), float(m.minimum_step), bool(m.run_backwards))
+        if key not in _ENC_TABLES:               # host replay of the solver's float32 time bookkeeping: once per config
+            sched = encoder_schedule(*key)
+            if sched.n_euler != key[0] or not np.all(sched.out_w1 == 1.0):
+                raise _lib.TrajsdeError("encoder schedule is not one Euler step per interval (SURVEY App. D)")
+            _ENC_TABLES[key] = np.ascontiguousarray(sched.step_table())
+        return _ENC_TABLES[key]
+
+    def encoder_forward_ood(self, data, noise: Optional[NoiseSpec] = None, n_samples: int = 10):
+        """LocalEncoderSDESepPara2.forward_ood (ENC:204-370) -> (local_embed, actors_std)."""
+        m = self.module
+        noise = NoiseSpec.resolve(noise)
+        gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), noise, fake_agents=False)
+        dev = gc.device
+        L = _lib.lib()
+        blob = self.blob()
+        H, N = gc.batch.H, gc.batch.N
+        tab = self._enc_table()
+        if noise.z_enc is not None and tuple(noise.z_enc.shape) != (n_samples * H, N, D):
+            raise _lib.TrajsdeError(f"z_enc must be [{n_samples * H},{N},{D}] for forward_ood")
+        local = torch.empty(N, D, device=dev, dtype=torch.float32)
+        stds = torch.empty(N, device=dev, dtype=torch.float32)
+        ws_bytes = L.trajsde_encoder_ood_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), n_samples)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        cn = noise.c_noise(noise.z_enc, noise.enc_row_ids)
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_encoder_forward_ood(C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), blob.data_ptr(),
+                                                     tab.ctypes.data_as(C.c_void_p), C.byref(cn), n_samples, ws.data_ptr(), ws_bytes,
+                                                     local.data_ptr(), stds.data_ptr(), _stream()), "trajsde_encoder_forward_ood")
+        return local, stds
 
     # ---------------------------------------------------------------- aggregator
     def aggregator_forward(self, data, local_embed: torch.Tensor) -> torch.Tensor:
@@ -233,8 +260,9 @@ class GraphContext:
     KEY = "_trajsde_graph"
     DEFAULT_RADIUS = 50.0
 
-    def __init__(self, data, radius: float, H: int, noise: Optional[NoiseSpec]) -> None:
+    def __init__(self, data, radius: float, H: int, noise: Optional[NoiseSpec], fake_agents: bool = True) -> None:
         L = _lib.lib()
+        self.fake_agents = fake_agents
         x = data["x"]
         _require_gpu(x, "data['x']")
         self.device = dev = x.device
@@ -264,17 +292,18 @@ class GraphContext:
         self.rot = data["rotate_mat"].to(torch.float32).contiguous()
         ei, lai = data["edge_index"], data["lane_actor_index"]
         lp = data["lane_positions"]
-        self.batch = _lib.Batch(N, data["agent_index"].numel(), ei.shape[1], lp.shape[0], lai.shape[1], H,
+        n_agents = data["agent_index"].numel() if fake_agents else 0      # A = 0: no fake rows (forward_ood, ENC:204-370)
+        self.batch = _lib.Batch(N, n_agents, ei.shape[1], lp.shape[0], lai.shape[1], H,
                                 data["positions"].shape[1], lp.shape[1] if lp.dim() > 1 else 0,
                                 f32(x), f32(data["positions"]), u8(data["padding_mask"]), u8(data["bos_mask"]),
-                                f32(data["rotate_angles"]), i64(ei), i64(data["agent_index"]), i64(data["batch"]),
+                                f32(data["rotate_angles"]), i64(ei), i64(data["agent_index"]) if fake_agents else None, i64(data["batch"]),
                                 i64(data["source"]), f32(lp), f32(data["lane_paddings"]), i64(lai),
                                 f32(data["lane_actor_vectors"]))
         if data["padding_mask"].shape[1] != data["positions"].shape[1]:
             raise _lib.TrajsdeError("padding_mask and positions must cover the same time slots")
         self.graph = _lib.Graph()
         noise = NoiseSpec.resolve(noise)
-        z_fake = noise.z_fake
+        z_fake = noise.z_fake if fake_agents else None
         if z_fake is not None and tuple(z_fake.shape) != (self.batch.A, H, 2):
             raise _lib.TrajsdeError(f"z_fake must be [{self.batch.A},{H},2]")
         cn = noise.c_noise(z_fake, noise.fake_row_ids)
@@ -292,10 +321,10 @@ class GraphContext:
                        "trajsde_graph_compact")
 
     @classmethod
-    def get(cls, data, radius: Optional[float], H: int, noise: Optional[NoiseSpec]) -> "GraphContext":
+    def get(cls, data, radius: Optional[float], H: int, noise: Optional[NoiseSpec], fake_agents: bool = True) -> "GraphContext":
         gc = data[cls.KEY] if cls.KEY in data else None
         if gc is None or (radius is not None and noise is not None):
             # the encoder (which owns the radius and the fake-agent noise) always rebuilds; the aggregator reuses
-            gc = cls(data, cls.DEFAULT_RADIUS if radius is None else radius, H, noise)
+            gc = cls(data, cls.DEFAULT_RADIUS if radius is None else radius, H, noise, fake_agents)
             data[cls.KEY] = gc
         return gc
