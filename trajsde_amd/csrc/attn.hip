@@ -13,6 +13,8 @@
 #include "layouts.hpp"
 #include "tile.hpp"
 
+#include <type_traits>
+
 namespace tsde {
 
 constexpr float INV_SQRT_DH = 0.35355339059327373f;   // 1/sqrt(64/8)  (ENC:589-590)
@@ -57,8 +59,9 @@ __global__ __launch_bounds__(512) void k_aa_center(const float* __restrict__ img
 
 // ------------------------------------------------------------------------------------------------ edges
 // MultipleInputEmbedding on the two pre-rotated 2-vectors of an edge (EMB:62-70) -> emb
+template <bool X6>
 __device__ __forceinline__ void edge_embed(f4 (&emb)[4], const f4 geom, const float* lds, const Lane& L) {
-  using E = EdgeL;
+  using E = typename std::conditional<X6, EdgeL6, EdgeL>::type;
   f4 h0[4], h1[4], s[4];
   linear_in2(h0, geom[0], geom[1], lds + E::A_W0, lds + E::A_B0, L.g);
   layer_norm<4>(h0, lds + E::A_G, lds + E::A_E, L.g);
@@ -67,11 +70,17 @@ __device__ __forceinline__ void edge_embed(f4 (&emb)[4], const f4 geom, const fl
   layer_norm<4>(h1, lds + E::B_G, lds + E::B_E, L.g);
   relu<4>(h1);
   load_vec<4>(s, lds + E::B3, L.g);                       // b0.3 + b1.3
-  linear_acc<4, 4>(s, h0, lds + E::WA3, L.lane);
-  linear_acc<4, 4>(s, h1, lds + E::WB3, L.lane);          // sum of the two branches = one K=128 contraction
+  if constexpr (X6) {
+    linear_acc_x6<4, 4>(s, h0, lds + E::WA3, L.lane);
+    linear_acc_x6<4, 4>(s, h1, lds + E::WB3, L.lane);
+  } else {
+    linear_acc<4, 4>(s, h0, lds + E::WA3, L.lane);
+    linear_acc<4, 4>(s, h1, lds + E::WB3, L.lane);        // sum of the two branches = one K=128 contraction
+  }
   layer_norm<4>(s, lds + E::AG0, lds + E::AE0, L.g);
   relu<4>(s);
-  linear<4, 4>(emb, s, lds + E::W2, lds + E::B2, L);
+  if constexpr (X6) linear_x6<4, 4>(emb, s, lds + E::W2, lds + E::B2, L);
+  else linear<4, 4>(emb, s, lds + E::W2, lds + E::B2, L);
   layer_norm<4>(emb, lds + E::AG3, lds + E::AE3, L.g);
 }
 
@@ -91,12 +100,14 @@ __device__ __forceinline__ void store_logits(const f4 (&qv)[4], const f4 (&k)[4]
   if (valid && (L.g & 1) == 0) *reinterpret_cast<f4*>(logits + e * 8 + 4 * (L.g >> 1)) = lg;
 }
 
-// AA / AL: embedding -> lin_k | lin_v -> logits with q[dst], v
+// AA / AL: embedding -> lin_k | lin_v -> logits with q[dst], v.   X6: bf16x6 split-precision matrix products
+template <bool X6>
 __global__ __launch_bounds__(1024) void k_edge_kv(const float* __restrict__ img_g, const float* __restrict__ geom,
                                                  const int32_t* __restrict__ dst, const float* __restrict__ q, int64_t E,
                                                  float* __restrict__ logits, float* __restrict__ v) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_blob(lds, img_g, EdgeL::SIZE);
+  using EL = typename std::conditional<X6, EdgeL6, EdgeL>::type;
+  stage_blob(lds, img_g, EL::SIZE);
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (E + 15) / 16;
@@ -107,8 +118,9 @@ __global__ __launch_bounds__(1024) void k_edge_kv(const float* __restrict__ img_
     const int d = dst[ec];
     f4 emb[4], kv[8], qv[4];
     load_row(qv, q, d, L.g);
-    edge_embed(emb, ge, lds, L);
-    linear<8, 4>(kv, emb, lds + EdgeL::WKV, lds + EdgeL::BKV, L);
+    edge_embed<X6>(emb, ge, lds, L);
+    if constexpr (X6) linear_x6<8, 4>(kv, emb, lds + EL::WKV, lds + EL::BKV, L);
+    else linear<8, 4>(kv, emb, lds + EL::WKV, lds + EL::BKV, L);
     f4 k[4] = {kv[0], kv[1], kv[2], kv[3]};
     f4 vv[4] = {kv[4], kv[5], kv[6], kv[7]};
     store_logits(qv, k, logits, e, e < E, L);
@@ -117,10 +129,11 @@ __global__ __launch_bounds__(1024) void k_edge_kv(const float* __restrict__ img_
 }
 
 // global interactor: relative-pose embedding only (AGG:42-51), reused by all layers
+template <bool X6>
 __global__ __launch_bounds__(1024) void k_edge_embed(const float* __restrict__ img_g, const float* __restrict__ geom, int64_t E,
                                                     float* __restrict__ emb_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_blob(lds, img_g, EdgeL::EMB_SIZE);
+  stage_blob(lds, img_g, X6 ? int(EdgeL6::EMB_SIZE) : int(EdgeL::EMB_SIZE));
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (E + 15) / 16;
@@ -129,19 +142,21 @@ __global__ __launch_bounds__(1024) void k_edge_embed(const float* __restrict__ i
     const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
     const f4 ge = *reinterpret_cast<const f4*>(geom + 4 * ec);
     f4 emb[4];
-    edge_embed(emb, ge, lds, L);
+    edge_embed<X6>(emb, ge, lds, L);
     if (e < E) store_row(emb, emb_out, e, L.g);
   }
 }
 
 // global layer: k = k_node[src] + lin_k_edge(rel), v = v_node[src] + lin_v_edge(rel)  (AGG:108-117)
+template <bool X6>
 __global__ __launch_bounds__(1024) void k_global_edge(const float* __restrict__ img_g, const float* __restrict__ rel,
                                                      const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                                      const float* __restrict__ q, const float* __restrict__ kn,
                                                      const float* __restrict__ vn, int64_t E, float* __restrict__ logits,
                                                      float* __restrict__ v) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_blob(lds, img_g, GEdgeL::SIZE);
+  using GL = typename std::conditional<X6, GEdgeL6, GEdgeL>::type;
+  stage_blob(lds, img_g, GL::SIZE);
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (E + 15) / 16;
@@ -154,7 +169,8 @@ __global__ __launch_bounds__(1024) void k_global_edge(const float* __restrict__ 
     load_row(qv, q, d, L.g);
     load_row(kns, kn, s, L.g);
     load_row(vns, vn, s, L.g);
-    linear<8, 4>(kv, r, lds + GEdgeL::WKV, lds + GEdgeL::BKV, L);
+    if constexpr (X6) linear_x6<8, 4>(kv, r, lds + GL::WKV, lds + GL::BKV, L);
+    else linear<8, 4>(kv, r, lds + GL::WKV, lds + GL::BKV, L);
     f4 k[4], vv[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
@@ -314,6 +330,12 @@ __global__ __launch_bounds__(512) void k_mode_proj(const float* __restrict__ nor
   }
 }
 
+template __global__ void k_edge_kv<false>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*);
+template __global__ void k_edge_kv<true>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*);
+template __global__ void k_edge_embed<false>(const float*, const float*, int64_t, float*);
+template __global__ void k_edge_embed<true>(const float*, const float*, int64_t, float*);
+template __global__ void k_global_edge<false>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
+template __global__ void k_global_edge<true>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
 template __global__ void k_node_proj<1>(const float*, const float*, int64_t, float*, float*, float*, float*);
 template __global__ void k_node_proj<3>(const float*, const float*, int64_t, float*, float*, float*, float*);
 

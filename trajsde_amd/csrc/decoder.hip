@@ -8,6 +8,7 @@
 //                  so the micro-step of T in {30,50,60} is reproduced.
 //   k_sde_step    the same step with the state round-tripping HBM (512 B / path-step), for the roofline report.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 #include "layouts.hpp"
@@ -59,12 +60,14 @@ __global__ __launch_bounds__(1024) void k_dec_init(const float* __restrict__ blo
   }
 }
 
-__global__ __launch_bounds__(768) void k_sde_decode(const float* __restrict__ blob, const float* __restrict__ y0,
+template <bool X6, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_sde_decode(const float* __restrict__ blob, const float* __restrict__ y0,
                                                      int64_t rows, int T, int n_euler,
                                                      const float* __restrict__ step_tab, const float* __restrict__ out_tab,
                                                      float min_scale, NoiseArg na, float* __restrict__ loc) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_blob(lds, blob, DecSdeL::SIZE);
+  using DL = typename std::conditional<X6, DecSdeL6, DecSdeL>::type;
+  stage_blob(lds, blob, DL::SIZE);
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (rows + 15) / 16;
@@ -78,8 +81,14 @@ __global__ __launch_bounds__(768) void k_sde_decode(const float* __restrict__ bl
       keep_lds_reads_here();
       const float dt = step_tab[k * 8 + 1], sq = step_tab[k * 8 + 2], sn = step_tab[k * 8 + 3], cs = step_tab[k * 8 + 4];
       f4 f[4], z[4];
-      drift_eval(f, y, lds + DecSdeL::F, sn, cs, L);
-      const float gs = diff_eval(y, lds + DecSdeL::G, sn, cs, L);
+      float gs;
+      if constexpr (X6) {
+        drift_eval_x6(f, y, lds + DL::F, sn, cs, L);
+        gs = diff_eval_x6(y, lds + DL::G, sn, cs, L);
+      } else {
+        drift_eval(f, y, lds + DL::F, sn, cs, L);
+        gs = diff_eval(y, lds + DL::G, sn, cs, L);
+      }
       noise_row(z, na, STREAM_DECODER, k, r, rows, L.g);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) prev[jt] = y[jt];
@@ -94,8 +103,8 @@ __global__ __launch_bounds__(768) void k_sde_decode(const float* __restrict__ bl
 #pragma unroll
           for (int c = 0; c < 4; ++c) s[jt][c] = w0 * prev[jt][c] + w1 * y[jt][c];
         float lx, ly, sx, sy;
-        head_eval(lx, ly, s, lds + DecSdeL::LOC, L);
-        head_eval(sx, sy, s, lds + DecSdeL::SCALE, L);
+        head_eval(lx, ly, s, lds + DL::LOC, L);
+        head_eval(sx, sy, s, lds + DL::SCALE, L);
         sx = (sx > 0.f ? sx : fast_exp(sx) - 1.0f) + 1.0f + min_scale;       // ELU(alpha=1) + 1 + min_scale (DEC:97-98)
         sy = (sy > 0.f ? sy : fast_exp(sy) - 1.0f) + 1.0f + min_scale;
         if (row < rows && L.g == 0) {
@@ -166,8 +175,16 @@ int trajsde_decoder_forward(int32_t N, int num_modes, int future_steps, const fl
             num_modes, y0, pi);
   // 768 threads = 12 waves = 3 per SIMD (168 VGPRs each); 256 CUs x 12 waves = 3072 path tiles in flight
   static const int dthreads = []() { const char* v = getenv("TRAJSDE_THREADS_DECODE"); const int t = v ? atoi(v) : 768; return (t >= 64 && t <= 768 && t % 64 == 0) ? t : 768; }();
-  TS_LAUNCH(k_sde_decode, pick_grid(ntiles, dthreads / 64), dthreads, DecSdeL::SIZE * 4, stream, blob + DecBlob::SDE, y0, rows, future_steps, n_euler,
-            step_table, out_table, min_scale, to_arg(noise), loc);
+  static const bool x6 = []() { const char* e = getenv("TRAJSDE_DECODE_FP32"); return !(e && atoi(e) != 0); }();
+  // <=512 threads: the 256-VGPR build (no spills, 2 waves/SIMD); above: the 168-VGPR build (3 waves/SIMD)
+#define TS_DECODE(X6, MAXT, IMG, OFF)                                                                                          \
+  TS_LAUNCH((k_sde_decode<X6, MAXT>), pick_grid(ntiles, dthreads / 64), dthreads, IMG::SIZE * 4, stream, blob + OFF, y0, rows, \
+            future_steps, n_euler, step_table, out_table, min_scale, to_arg(noise), loc)
+  if (x6 && dthreads <= 512) TS_DECODE(true, 512, DecSdeL6, DecBlob::SDE6);
+  else if (x6) TS_DECODE(true, 768, DecSdeL6, DecBlob::SDE6);
+  else if (dthreads <= 512) TS_DECODE(false, 512, DecSdeL, DecBlob::SDE);
+  else TS_DECODE(false, 768, DecSdeL, DecBlob::SDE);
+#undef TS_DECODE
   return TRAJSDE_OK;
 }
 

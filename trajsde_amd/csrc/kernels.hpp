@@ -9,8 +9,11 @@ namespace tsde {
 
 __global__ void k_aa_center(const float* img, const float* x, const float* x_fake, const float* rot, const uint8_t* bos,
                             const int32_t* orig, int N, int Nt, int H, float* center, float* cn, float* q);
+template <bool X6>
 __global__ void k_edge_kv(const float* img, const float* geom, const int32_t* dst, const float* q, int64_t E, float* logits, float* v);
+template <bool X6>
 __global__ void k_edge_embed(const float* img, const float* geom, int64_t E, float* emb_out);
+template <bool X6>
 __global__ void k_global_edge(const float* img, const float* rel, const int32_t* src, const int32_t* dst, const float* q,
                               const float* kn, const float* vn, int64_t E, float* logits, float* v);
 __global__ void k_seg_softmax_agg(const int32_t* segptr, const float* logits, const float* v, int64_t R, float* agg);

@@ -37,6 +37,27 @@ struct EdgeL {
   };
 };
 
+// the same two images with the matrices as three bf16 planes (bf16x6 split precision, tile.hpp): a 64x64
+// matrix takes 3 * 4096 * 2 B = 6144 floats
+constexpr int MAT64X6 = 6144;
+struct EdgeL6 {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(A_W0, 128, S), TS_FIELD(A_B0, 64, A_W0), TS_FIELD(A_G, 64, A_B0), TS_FIELD(A_E, 64, A_G),
+    TS_FIELD(B_W0, 128, A_E), TS_FIELD(B_B0, 64, B_W0), TS_FIELD(B_G, 64, B_B0), TS_FIELD(B_E, 64, B_G),
+    TS_FIELD(WA3, MAT64X6, B_E), TS_FIELD(WB3, MAT64X6, WA3), TS_FIELD(B3, 64, WB3),
+    TS_FIELD(AG0, 64, B3), TS_FIELD(AE0, 64, AG0), TS_FIELD(W2, MAT64X6, AE0), TS_FIELD(B2, 64, W2),
+    TS_FIELD(AG3, 64, B2), TS_FIELD(AE3, 64, AG3),
+    EMB_SIZE = AE3_END,
+    TS_FIELD(WKV, 2 * MAT64X6, AE3), TS_FIELD(BKV, 128, WKV),
+    SIZE = BKV_END
+  };
+};
+struct GEdgeL6 {
+  enum : int { S_END = 0, TS_FIELD(WKV, 2 * MAT64X6, S), TS_FIELD(BKV, 128, WKV), SIZE = BKV_END };
+};
+static_assert(EdgeL6::SIZE * 4 <= 160 * 1024, "split-precision edge image must fit LDS");
+
 // k_node_update: gate / self / out_proj / norm2 (ENC:595-600, 609; AGG:119-124, 131)
 struct UpdL {
   enum : int {
@@ -90,6 +111,23 @@ struct DiffL {
   };
 };
 
+struct DriftL6 {   // the three 64x64 matrices as bf16x6 planes
+  enum : int {
+    S_END = 0,
+    TS_FIELD(W0, MAT64X6, S), TS_FIELD(WS, 64, W0), TS_FIELD(WC, 64, WS), TS_FIELD(B0, 64, WC),
+    TS_FIELD(W2, MAT64X6, B0), TS_FIELD(B2, 64, W2), TS_FIELD(W4, MAT64X6, B2), TS_FIELD(B4, 64, W4),
+    SIZE = B4_END
+  };
+};
+struct DiffL6 {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(W0, MAT64X6, S), TS_FIELD(WS, 64, W0), TS_FIELD(WC, 64, WS), TS_FIELD(B0, 64, WC),
+    TS_FIELD(W2, MAT64X6, B0), TS_FIELD(B2, 64, W2), TS_FIELD(W4, 64, B2), TS_FIELD(B4, 4, W4),
+    SIZE = B4_END
+  };
+};
+
 struct EncSdeL {
   enum : int { F = 0, GN = F + DriftL::SIZE, GA = GN + DiffL::SIZE, SIZE = GA + DiffL::SIZE };
 };
@@ -120,19 +158,23 @@ struct EncBlob {
     AL_EDGE = AL_Q + NodeProjL<1>::SIZE,
     AL_UPD = AL_EDGE + EdgeL::SIZE,
     AL_FFN = AL_UPD + UpdL::SIZE,
-    SIZE = AL_FFN + FfnL::SIZE
+    AA_EDGE6 = AL_FFN + FfnL::SIZE,
+    AL_EDGE6 = AA_EDGE6 + EdgeL6::SIZE,
+    SIZE = AL_EDGE6 + EdgeL6::SIZE
   };
 };
 
 // aggregator stage blob: rel_embed, then per layer {qkv, edge, upd, ffn}, then norm + per-mode projection
 struct AggLayerL {
   enum : int {
-    QKV = 0, EDGE = QKV + NodeProjL<3>::SIZE, UPD = EDGE + GEdgeL::SIZE, FFN = UPD + UpdL::SIZE, SIZE = FFN + FfnL::SIZE
+    QKV = 0, EDGE = QKV + NodeProjL<3>::SIZE, UPD = EDGE + GEdgeL::SIZE, FFN = UPD + UpdL::SIZE, EDGE6 = FFN + FfnL::SIZE,
+    SIZE = EDGE6 + GEdgeL6::SIZE
   };
 };
 struct AggBlob {
   static constexpr int REL = 0;
-  static constexpr int layer(int i) { return EdgeL::EMB_SIZE + i * AggLayerL::SIZE; }
+  static constexpr int REL6 = EdgeL::EMB_SIZE;
+  static constexpr int layer(int i) { return EdgeL::EMB_SIZE + EdgeL6::EMB_SIZE + i * AggLayerL::SIZE; }
   static constexpr int norm(int nl) { return layer(nl); }                       // gamma | beta
   static constexpr int proj(int nl, int k) { return norm(nl) + 128 + k * (MAT64 + 64); }  // W_k frag | b_k
   static constexpr int size(int nl, int K) { return proj(nl, K); }
@@ -158,8 +200,13 @@ struct HeadL {   // Linear(64,64) LN ReLU Linear(64,2)   (DEC:50-61)
 struct DecSdeL {
   enum : int { F = 0, G = F + DriftL::SIZE, LOC = G + DiffL::SIZE, SCALE = LOC + HeadL::SIZE, SIZE = SCALE + HeadL::SIZE };
 };
+// fused decode kernel image: drift + diffusion in split precision, the two heads in plain fp32 (fits the 160 KB LDS)
+struct DecSdeL6 {
+  enum : int { F = 0, G = F + DriftL6::SIZE, LOC = G + DiffL6::SIZE, SCALE = LOC + HeadL::SIZE, SIZE = SCALE + HeadL::SIZE };
+};
+static_assert(DecSdeL6::SIZE * 4 <= 160 * 1024, "split-precision decoder image must fit LDS");
 struct DecBlob {
-  enum : int { INIT = 0, SDE = INIT + DecInitL::SIZE, SIZE = SDE + DecSdeL::SIZE };
+  enum : int { INIT = 0, SDE = INIT + DecInitL::SIZE, SDE6 = SDE + DecSdeL::SIZE, SIZE = SDE6 + DecSdeL6::SIZE };
 };
 
 static_assert(EdgeL::SIZE * 4 <= 160 * 1024, "edge image must fit LDS");

@@ -37,6 +37,24 @@ __global__ void k_pack_mat(const float* __restrict__ src, float* __restrict__ ds
   dst[i] = src[(16 * jo + (lane & 15)) * ld + col0 + 16 * q + 4 * (lane >> 4) + c];
 }
 
+// bf16x6 planes: dst (as bf16) [plane][jo][s][lane][8]; element j of lane (i,g) in k-step s is the plane-th exact
+// truncation piece of W[16jo + i][col0 + 32s + 16(j>>2) + 4g + (j&3)]   (tile.hpp linear_acc_x6)
+__global__ void k_pack_mat6(const float* __restrict__ src, unsigned short* __restrict__ dst, int jto, int ks, int ld, int col0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_plane = jto * ks * 512;
+  if (i >= per_plane) return;
+  const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % ks, jo = (i >> 9) / ks;
+  const float x = src[(16 * jo + (lane & 15)) * ld + col0 + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)];
+  const unsigned M = 0xFFFF0000u;
+  const float h = __uint_as_float(__float_as_uint(x) & M);
+  const float r = x - h;
+  const float m = __uint_as_float(__float_as_uint(r) & M);
+  const float l = r - m;
+  dst[i] = (unsigned short)(__float_as_uint(h) >> 16);
+  dst[per_plane + i] = (unsigned short)(__float_as_uint(m) >> 16);
+  dst[2 * per_plane + i] = (unsigned short)(__float_as_uint(l) >> 16);
+}
+
 struct Packer {
   bool dry;
   std::vector<std::string> names;          // dry: collected in order of first use
@@ -72,6 +90,12 @@ struct Packer {
     const int jto = rows / 16, jti = cols / 16;
     k_pack_mat<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, col0);
   }
+  void mat6(const std::string& n, int dst, int rows, int cols, int ld, int col0 = 0) {
+    const float* s = src(n);
+    if (dry) return;
+    const int jto = rows / 16, ks = cols / 32;
+    k_pack_mat6<<<cdiv(jto * ks * 512, 256), 256, 0, stream>>>(s, reinterpret_cast<unsigned short*>(blob + dst), jto, ks, ld, col0);
+  }
   void lin(const std::string& p, int w, int b, int rows = 64, int cols = 64) {
     mat(p + ".weight", w, rows, cols, cols);
     vec(p + ".bias", b, rows);
@@ -98,6 +122,48 @@ static void recipe_edge_embed(Packer& P, const std::string& p, int base) {   // 
   P.lin(p + ".aggr_embed.2", base + E::W2, base + E::B2);
   P.ln(p + ".aggr_embed.3", base + E::AG3, base + E::AE3);
 }
+static void recipe_edge_embed6(Packer& P, const std::string& p, int base) {   // split-precision twin of the above
+  using E = EdgeL6;
+  P.vec(p + ".module_list.0.0.weight", base + E::A_W0, 128);
+  P.vec(p + ".module_list.0.0.bias", base + E::A_B0, 64);
+  P.ln(p + ".module_list.0.1", base + E::A_G, base + E::A_E);
+  P.vec(p + ".module_list.1.0.weight", base + E::B_W0, 128);
+  P.vec(p + ".module_list.1.0.bias", base + E::B_B0, 64);
+  P.ln(p + ".module_list.1.1", base + E::B_G, base + E::B_E);
+  P.mat6(p + ".module_list.0.3.weight", base + E::WA3, 64, 64, 64);
+  P.mat6(p + ".module_list.1.3.weight", base + E::WB3, 64, 64, 64);
+  P.vec(p + ".module_list.0.3.bias", base + E::B3, 64);
+  P.vec(p + ".module_list.1.3.bias", base + E::B3, 64, /*accumulate=*/true);
+  P.ln(p + ".aggr_embed.0", base + E::AG0, base + E::AE0);
+  P.mat6(p + ".aggr_embed.2.weight", base + E::W2, 64, 64, 64);
+  P.vec(p + ".aggr_embed.2.bias", base + E::B2, 64);
+  P.ln(p + ".aggr_embed.3", base + E::AG3, base + E::AE3);
+}
+// lin_k | lin_v as ONE 128-row split-precision matrix: planes are [plane][jo 0..7][s][lane][8]
+__global__ void k_pack_mat6_stack2(const float* __restrict__ wk, const float* __restrict__ wv, unsigned short* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_plane = 8 * 2 * 512;
+  if (i >= per_plane) return;
+  const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % 2, jo = (i >> 9) / 2;
+  const float* src = jo < 4 ? wk : wv;
+  const float x = src[(16 * (jo & 3) + (lane & 15)) * 64 + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)];
+  const unsigned M = 0xFFFF0000u;
+  const float h = __uint_as_float(__float_as_uint(x) & M);
+  const float r = x - h;
+  const float m = __uint_as_float(__float_as_uint(r) & M);
+  const float l = r - m;
+  dst[i] = (unsigned short)(__float_as_uint(h) >> 16);
+  dst[per_plane + i] = (unsigned short)(__float_as_uint(m) >> 16);
+  dst[2 * per_plane + i] = (unsigned short)(__float_as_uint(l) >> 16);
+}
+static void pack_kv6(Packer& P, const std::string& k, const std::string& v, int w, int b) {
+  const float* wk = P.src(k + ".weight");
+  const float* wv = P.src(v + ".weight");
+  if (!P.dry) k_pack_mat6_stack2<<<cdiv(8 * 2 * 512, 256), 256, 0, P.stream>>>(wk, wv, reinterpret_cast<unsigned short*>(P.blob + w));
+  P.vec(k + ".bias", b, 64);
+  P.vec(v + ".bias", b + 64, 64);
+}
+
 static void recipe_upd_ffn(Packer& P, const std::string& p, int upd, int ffn) {
   P.lin(p + ".lin_ih", upd + UpdL::WIH, upd + UpdL::BIH);
   P.lin(p + ".lin_hh", upd + UpdL::WHH, upd + UpdL::BHH);
@@ -123,6 +189,29 @@ static void recipe_diff(Packer& P, const std::string& p, int base) {
   P.col(p + ".net.0.weight", base + L::WC, 64, 66, 65);
   P.vec(p + ".net.0.bias", base + L::B0, 64);
   P.lin(p + ".net.2", base + L::W2, base + L::B2);
+  P.vec(p + ".net.4.weight", base + L::W4, 64);
+  P.vec(p + ".net.4.bias", base + L::B4, 1);
+}
+
+static void recipe_drift6(Packer& P, const std::string& p, int base) {
+  using L = DriftL6;
+  P.mat6(p + ".net.0.weight", base + L::W0, 64, 64, 66, 0);
+  P.col(p + ".net.0.weight", base + L::WS, 64, 66, 64);
+  P.col(p + ".net.0.weight", base + L::WC, 64, 66, 65);
+  P.vec(p + ".net.0.bias", base + L::B0, 64);
+  P.mat6(p + ".net.2.weight", base + L::W2, 64, 64, 64);
+  P.vec(p + ".net.2.bias", base + L::B2, 64);
+  P.mat6(p + ".net.4.weight", base + L::W4, 64, 64, 64);
+  P.vec(p + ".net.4.bias", base + L::B4, 64);
+}
+static void recipe_diff6(Packer& P, const std::string& p, int base) {
+  using L = DiffL6;
+  P.mat6(p + ".net.0.weight", base + L::W0, 64, 64, 66, 0);
+  P.col(p + ".net.0.weight", base + L::WS, 64, 66, 64);
+  P.col(p + ".net.0.weight", base + L::WC, 64, 66, 65);
+  P.vec(p + ".net.0.bias", base + L::B0, 64);
+  P.mat6(p + ".net.2.weight", base + L::W2, 64, 64, 64);
+  P.vec(p + ".net.2.bias", base + L::B2, 64);
   P.vec(p + ".net.4.weight", base + L::W4, 64);
   P.vec(p + ".net.4.bias", base + L::B4, 1);
 }
@@ -177,10 +266,15 @@ static void recipe_encoder(Packer& P) {
   P.vec("al_encoder.lin_k.bias", B::AL_EDGE + EdgeL::BKV, 64);
   P.vec("al_encoder.lin_v.bias", B::AL_EDGE + EdgeL::BKV + 64, 64);
   recipe_upd_ffn(P, "al_encoder", B::AL_UPD, B::AL_FFN);
+  recipe_edge_embed6(P, "aa_encoder.nbr_embed", B::AA_EDGE6);
+  pack_kv6(P, "aa_encoder.lin_k", "aa_encoder.lin_v", B::AA_EDGE6 + EdgeL6::WKV, B::AA_EDGE6 + EdgeL6::BKV);
+  recipe_edge_embed6(P, "al_encoder.lane_embed", B::AL_EDGE6);
+  pack_kv6(P, "al_encoder.lin_k", "al_encoder.lin_v", B::AL_EDGE6 + EdgeL6::WKV, B::AL_EDGE6 + EdgeL6::BKV);
 }
 
 static void recipe_aggregator(Packer& P, int nl, int K) {
   recipe_edge_embed(P, "rel_embed", AggBlob::REL);
+  recipe_edge_embed6(P, "rel_embed", AggBlob::REL6);
   for (int i = 0; i < nl; ++i) {
     const std::string p = "global_interactor_layers." + std::to_string(i);
     const int b = AggBlob::layer(i);
@@ -196,6 +290,7 @@ static void recipe_aggregator(Packer& P, int nl, int K) {
     P.vec(p + ".lin_k_edge.bias", b + AggLayerL::EDGE + GEdgeL::BKV, 64);
     P.vec(p + ".lin_v_edge.bias", b + AggLayerL::EDGE + GEdgeL::BKV + 64, 64);
     recipe_upd_ffn(P, p, b + AggLayerL::UPD, b + AggLayerL::FFN);
+    pack_kv6(P, p + ".lin_k_edge", p + ".lin_v_edge", b + AggLayerL::EDGE6 + GEdgeL6::WKV, b + AggLayerL::EDGE6 + GEdgeL6::BKV);
   }
   P.ln("norm", AggBlob::norm(nl), AggBlob::norm(nl) + 64);
   // multihead_proj [K*64, 64]: mode k owns rows 64k..64k+63 (AGG:56 view(-1, K, 64))
@@ -231,6 +326,10 @@ static void recipe_decoder(Packer& P) {
   recipe_diff(P, "lsde_func.g_func", DecBlob::SDE + DecSdeL::G);
   recipe_head(P, "decoder", DecBlob::SDE + DecSdeL::LOC);
   recipe_head(P, "scale", DecBlob::SDE + DecSdeL::SCALE);
+  recipe_drift6(P, "lsde_func.f_func", DecBlob::SDE6 + DecSdeL6::F);
+  recipe_diff6(P, "lsde_func.g_func", DecBlob::SDE6 + DecSdeL6::G);
+  recipe_head(P, "decoder", DecBlob::SDE6 + DecSdeL6::LOC);
+  recipe_head(P, "scale", DecBlob::SDE6 + DecSdeL6::SCALE);
 }
 
 static bool run_recipe(Packer& P, int stage, int nl, int K) {

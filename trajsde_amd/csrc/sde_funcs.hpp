@@ -49,4 +49,35 @@ __device__ __forceinline__ void em_update(f4 (&y)[4], const f4 (&f)[4], float gs
     for (int c = 0; c < 4; ++c) y[jt][c] = (y[jt][c] + f[jt][c] * dt) + gs * (z[jt][c] * sq);
 }
 
+// ---- split-precision (bf16x6, tile.hpp) twins used by the fused decoder kernel
+__device__ __forceinline__ void sde_layer0_x6(f4 (&out)[4], const f4 (&y)[4], const float* img, int W0, int WS, int WC, int B0,
+                                              float sn, float cs, const Lane& L) {
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    const int f0 = 16 * jt + 4 * L.g;
+    const f4 b = *reinterpret_cast<const f4*>(img + B0 + f0);
+    const f4 s = *reinterpret_cast<const f4*>(img + WS + f0);
+    const f4 c = *reinterpret_cast<const f4*>(img + WC + f0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[jt][e] = fmaf(c[e], cs, fmaf(s[e], sn, b[e]));
+  }
+  linear_acc_x6<4, 4>(out, y, img + W0, L.lane);
+}
+__device__ __forceinline__ void drift_eval_x6(f4 (&f)[4], const f4 (&y)[4], const float* img, float sn, float cs, const Lane& L) {
+  f4 h1[4], h2[4];
+  sde_layer0_x6(h1, y, img, DriftL6::W0, DriftL6::WS, DriftL6::WC, DriftL6::B0, sn, cs, L);
+  tanh_<4>(h1);
+  linear_x6<4, 4>(h2, h1, img + DriftL6::W2, img + DriftL6::B2, L);
+  tanh_<4>(h2);
+  linear_x6<4, 4>(f, h2, img + DriftL6::W4, img + DriftL6::B4, L);
+}
+__device__ __forceinline__ float diff_eval_x6(const f4 (&y)[4], const float* img, float sn, float cs, const Lane& L) {
+  f4 h1[4], h2[4];
+  sde_layer0_x6(h1, y, img, DiffL6::W0, DiffL6::WS, DiffL6::WC, DiffL6::B0, sn, cs, L);
+  tanh_<4>(h1);
+  linear_x6<4, 4>(h2, h1, img + DiffL6::W2, img + DiffL6::B2, L);
+  tanh_<4>(h2);
+  return fast_sigmoid(row_dot(h2, img + DiffL6::W4, L.g) + img[DiffL6::B4]);
+}
+
 }  // namespace tsde

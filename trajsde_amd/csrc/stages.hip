@@ -16,6 +16,7 @@ static int env_threads(const char* name, int dflt) {
   const int t = atoi(v);
   return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : dflt;
 }
+static bool edge_x6() { static bool v = []() { const char* e = getenv("TRAJSDE_EDGE_FP32"); return !(e && atoi(e) != 0); }(); return v; }
 static int threads_edge() { static int t = env_threads("TRAJSDE_THREADS_EDGE", 1024); return t; }
 static int threads_node() { static int t = env_threads("TRAJSDE_THREADS_NODE", 512); return t; }
 static int threads_recur() { static int t = env_threads("TRAJSDE_THREADS_RECUR", 256); return t; }
@@ -99,9 +100,14 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
   const int64_t R = int64_t(H) * Nt;
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob + EncBlob::AA_CENTER,
             b->x, g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
-  if (g->E_aa > 0)
-    TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv, tile_grid((int64_t(g->E_aa) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(), EdgeL::SIZE * 4, st,
-              blob + EncBlob::AA_EDGE, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v);
+  if (g->E_aa > 0) {
+    if (edge_x6())
+      TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv<true>, tile_grid((int64_t(g->E_aa) + 15) / 16, threads_edge(), EdgeL6::SIZE * 4), threads_edge(),
+                    EdgeL6::SIZE * 4, st, blob + EncBlob::AA_EDGE6, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v);
+    else
+      TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv<false>, tile_grid((int64_t(g->E_aa) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(),
+                    EdgeL::SIZE * 4, st, blob + EncBlob::AA_EDGE, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v);
+  }
   return attention_tail(blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg, w.x1,
                         w.xn2, aa_out, st);
 }
@@ -131,9 +137,14 @@ static int run_al_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
   const int N = b->N;
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob + EncBlob::AL_Q, lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
-  if (g->E_la > 0)
-    TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv, tile_grid((int64_t(g->E_la) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(), EdgeL::SIZE * 4, st,
-              blob + EncBlob::AL_EDGE, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v);
+  if (g->E_la > 0) {
+    if (edge_x6())
+      TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv<true>, tile_grid((int64_t(g->E_la) + 15) / 16, threads_edge(), EdgeL6::SIZE * 4), threads_edge(),
+                    EdgeL6::SIZE * 4, st, blob + EncBlob::AL_EDGE6, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v);
+    else
+      TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv<false>, tile_grid((int64_t(g->E_la) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(),
+                    EdgeL::SIZE * 4, st, blob + EncBlob::AL_EDGE, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v);
+  }
   return attention_tail(blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, g->la_segptr, w.al_logits, w.al_v, w.al_xn, lat, N, w.al_agg,
                         w.al_x1, w.al_xn2, local_embed, st);
 }
@@ -206,18 +217,28 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
   if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "aggregator_forward: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int64_t N = b->N, E = g->E_g, ntiles = (N + 15) / 16, etiles = (E + 15) / 16;
-  if (E > 0)
-    TS_LAUNCH(k_edge_embed, tile_grid(etiles, threads_edge(), EdgeL::EMB_SIZE * 4), threads_edge(), EdgeL::EMB_SIZE * 4, st, blob + AggBlob::REL, g->g_geom,
-              E, w.rel);
+  if (E > 0) {
+    if (edge_x6())
+      TS_LAUNCH(k_edge_embed<true>, tile_grid(etiles, threads_edge(), EdgeL6::EMB_SIZE * 4), threads_edge(), EdgeL6::EMB_SIZE * 4, st,
+                blob + AggBlob::REL6, g->g_geom, E, w.rel);
+    else
+      TS_LAUNCH(k_edge_embed<false>, tile_grid(etiles, threads_edge(), EdgeL::EMB_SIZE * 4), threads_edge(), EdgeL::EMB_SIZE * 4, st,
+                blob + AggBlob::REL, g->g_geom, E, w.rel);
+  }
   const float* x = local_embed;
   float* bufs[2] = {w.xa, w.xb};
   for (int i = 0; i < num_layers; ++i) {
     const float* lb = blob + AggBlob::layer(i);
     TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
               w.xn, w.q, w.kn, w.vn);
-    if (E > 0)
-      TS_LAUNCH(k_global_edge, tile_grid(etiles, threads_edge(), GEdgeL::SIZE * 4), threads_edge(), GEdgeL::SIZE * 4, st, lb + AggLayerL::EDGE, w.rel, g->g_src,
-                g->g_dst, w.q, w.kn, w.vn, E, w.logits, w.v);
+    if (E > 0) {
+      if (edge_x6())
+        TS_LAUNCH(k_global_edge<true>, tile_grid(etiles, threads_edge(), GEdgeL6::SIZE * 4), threads_edge(), GEdgeL6::SIZE * 4, st,
+                  lb + AggLayerL::EDGE6, w.rel, g->g_src, g->g_dst, w.q, w.kn, w.vn, E, w.logits, w.v);
+      else
+        TS_LAUNCH(k_global_edge<false>, tile_grid(etiles, threads_edge(), GEdgeL::SIZE * 4), threads_edge(), GEdgeL::SIZE * 4, st,
+                  lb + AggLayerL::EDGE, w.rel, g->g_src, g->g_dst, w.q, w.kn, w.vn, E, w.logits, w.v);
+    }
     float* out = bufs[i & 1];
     if (int rc = attention_tail(lb + AggLayerL::UPD, lb + AggLayerL::FFN, g->g_segptr, w.logits, w.v, w.xn, x, N, w.agg, w.x1, w.xn2,
                                 out, st))
