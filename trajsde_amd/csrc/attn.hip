@@ -94,7 +94,7 @@ __device__ __forceinline__ void store_logits(const f4 (&qv)[4], const f4 (&k)[4]
     float p = qv[jt][0] * k[jt][0];
 #pragma unroll
     for (int c = 1; c < 4; ++c) p = fmaf(qv[jt][c], k[jt][c], p);
-    p += __shfl_xor(p, 16);
+    p = xor16_sum(p);
     lg[jt] = p * INV_SQRT_DH;
   }
   if (valid && (L.g & 1) == 0) *reinterpret_cast<f4*>(logits + e * 8 + 4 * (L.g >> 1)) = lg;
@@ -148,8 +148,13 @@ __global__ __launch_bounds__(1024) void k_edge_embed(const float* __restrict__ i
 }
 
 // global layer: k = k_node[src] + lin_k_edge(rel), v = v_node[src] + lin_v_edge(rel)  (AGG:108-117)
+// The kernel is latency-bound (ids -> dependent row gathers -> little compute), so it is software-pipelined by
+// hand: while tile i is on the matrix cores, the rows of tile i+1 are in flight and the ids of tile i+2 are loading.
+struct GEdgeIn {
+  f4 r[4], qv[4], kns[4], vns[4];
+};
 template <bool X6>
-__global__ __launch_bounds__(1024) void k_global_edge(const float* __restrict__ img_g, const float* __restrict__ rel,
+__global__ __launch_bounds__(512) void k_global_edge(const float* __restrict__ img_g, const float* __restrict__ rel,
                                                      const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                                      const float* __restrict__ q, const float* __restrict__ kn,
                                                      const float* __restrict__ vn, int64_t E, float* __restrict__ logits,
@@ -160,25 +165,59 @@ __global__ __launch_bounds__(1024) void k_global_edge(const float* __restrict__ 
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (E + 15) / 16;
-  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
-    keep_lds_reads_here();
-    const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
-    const int s = src[ec], d = dst[ec];
-    f4 r[4], kv[8], qv[4], kns[4], vns[4];
-    load_row(r, rel, ec, L.g);
-    load_row(qv, q, d, L.g);
-    load_row(kns, kn, s, L.g);
-    load_row(vns, vn, s, L.g);
-    if constexpr (X6) linear_x6<8, 4>(kv, r, lds + GL::WKV, lds + GL::BKV, L);
-    else linear<8, 4>(kv, r, lds + GL::WKV, lds + GL::BKV, L);
+  const int64_t stride = int64_t(gridDim.x) * waves;
+  auto edge_of = [&](int64_t tile) {
+    const int64_t e = tile * 16 + L.n;
+    return e < E ? e : E - 1;
+  };
+  auto issue = [&](GEdgeIn& in, int64_t ec, int s, int d) {
+    load_row(in.r, rel, ec, L.g);
+    load_row(in.qv, q, d, L.g);
+    load_row(in.kns, kn, s, L.g);
+    load_row(in.vns, vn, s, L.g);
+  };
+  auto compute = [&](const GEdgeIn& in, int64_t tile) {
+    const int64_t e = tile * 16 + L.n;
+    f4 kv[8];
+    if constexpr (X6) linear_x6<8, 4>(kv, in.r, lds + GL::WKV, lds + GL::BKV, L);
+    else linear<8, 4>(kv, in.r, lds + GL::WKV, lds + GL::BKV, L);
     f4 k[4], vv[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
-      k[jt] = kns[jt] + kv[jt];
-      vv[jt] = vns[jt] + kv[4 + jt];
+      k[jt] = in.kns[jt] + kv[jt];
+      vv[jt] = in.vns[jt] + kv[4 + jt];
     }
-    store_logits(qv, k, logits, e, e < E, L);
+    store_logits(in.qv, k, logits, e, e < E, L);
     if (e < E) store_row(vv, v, e, L.g);
+  };
+  int64_t t0 = int64_t(blockIdx.x) * waves + wave;
+  if (t0 >= ntiles) return;
+  GEdgeIn A, B;
+  int64_t t1 = t0 + stride, t2 = t1 + stride;
+  {
+    const int64_t e0 = edge_of(t0);
+    issue(A, e0, src[e0], dst[e0]);
+  }
+  int s1 = 0, d1 = 0;
+  if (t1 < ntiles) { const int64_t e1 = edge_of(t1); s1 = src[e1]; d1 = dst[e1]; }
+  while (true) {
+    // ---- A holds tile t0 (in flight or landed), (s1, d1) are the ids of t1
+    keep_lds_reads_here();
+    int s2 = 0, d2 = 0;
+    if (t1 < ntiles) issue(B, edge_of(t1), s1, d1);
+    if (t2 < ntiles) { const int64_t e2 = edge_of(t2); s2 = src[e2]; d2 = dst[e2]; }
+    compute(A, t0);
+    if (t1 >= ntiles) break;
+    // ---- roles swapped: B holds tile t1, (s2, d2) are the ids of t2
+    keep_lds_reads_here();
+    const int64_t t3 = t2 + stride;
+    int s3 = 0, d3 = 0;
+    if (t2 < ntiles) issue(A, edge_of(t2), s2, d2);
+    if (t3 < ntiles) { const int64_t e3 = edge_of(t3); s3 = src[e3]; d3 = dst[e3]; }
+    compute(B, t1);
+    if (t2 >= ntiles) break;
+    t0 = t2; t1 = t3; t2 = t3 + stride;
+    s1 = s3; d1 = d3;
   }
 }
 

@@ -233,10 +233,10 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
               w.xn, w.q, w.kn, w.vn);
     if (E > 0) {
       if (edge_x6())
-        TS_LAUNCH(k_global_edge<true>, tile_grid(etiles, threads_edge(), GEdgeL6::SIZE * 4), threads_edge(), GEdgeL6::SIZE * 4, st,
+        TS_LAUNCH(k_global_edge<true>, tile_grid(etiles, 512, GEdgeL6::SIZE * 4), 512, GEdgeL6::SIZE * 4, st,
                   lb + AggLayerL::EDGE6, w.rel, g->g_src, g->g_dst, w.q, w.kn, w.vn, E, w.logits, w.v);
       else
-        TS_LAUNCH(k_global_edge<false>, tile_grid(etiles, threads_edge(), GEdgeL::SIZE * 4), threads_edge(), GEdgeL::SIZE * 4, st,
+        TS_LAUNCH(k_global_edge<false>, tile_grid(etiles, 512, GEdgeL::SIZE * 4), 512, GEdgeL::SIZE * 4, st,
                   lb + AggLayerL::EDGE, w.rel, g->g_src, g->g_dst, w.q, w.kn, w.vn, E, w.logits, w.v);
     }
     float* out = bufs[i & 1];

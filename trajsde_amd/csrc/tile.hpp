@@ -115,9 +115,6 @@ __device__ __forceinline__ void linear_acc_x6(f4 (&acc)[JT_OUT], const f4 (&in)[
   u4 b1[KS], b2[KS], b3[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) split_kstep(in[2 * s], in[2 * s + 1], b1[s], b2[s], b3[s]);
-  f4 small[JT_OUT];
-#pragma unroll
-  for (int jo = 0; jo < JT_OUT; ++jo) small[jo] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -127,16 +124,15 @@ __device__ __forceinline__ void linear_acc_x6(f4 (&acc)[JT_OUT], const f4 (&in)[
       const bf8 a2 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p + PLANE));
       const bf8 a3 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p + 2 * PLANE));
       const bf8 x1 = __builtin_bit_cast(bf8, b1[s]), x2 = __builtin_bit_cast(bf8, b2[s]), x3 = __builtin_bit_cast(bf8, b3[s]);
-      small[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, x3, small[jo], 0, 0, 0);
-      small[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, x2, small[jo], 0, 0, 0);
-      small[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, x1, small[jo], 0, 0, 0);
-      small[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, x2, small[jo], 0, 0, 0);
-      small[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, x1, small[jo], 0, 0, 0);
+      // one fp32 accumulation chain; each add rounds at 2^-24 of the running sum, like an fp32 fma chain would
       acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, x1, acc[jo], 0, 0, 0);
+      acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, x2, acc[jo], 0, 0, 0);
+      acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, x1, acc[jo], 0, 0, 0);
+      acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, x3, acc[jo], 0, 0, 0);
+      acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, x2, acc[jo], 0, 0, 0);
+      acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, x1, acc[jo], 0, 0, 0);
     }
   }
-#pragma unroll
-  for (int jo = 0; jo < JT_OUT; ++jo) acc[jo] += small[jo];
 }
 
 // per-feature vector (bias, LayerNorm gamma/beta, ...) stored plainly: v[16*jt + 4*g + c]
@@ -160,11 +156,18 @@ __device__ __forceinline__ void linear_x6(f4 (&out)[JT_OUT], const f4 (&in)[JT_I
 }
 
 // ---------------------------------------------------------------- row reductions (4 lanes hold one row)
-__device__ __forceinline__ float row_sum(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
+// all-reduce over the 4 lanes {n, n+16, n+32, n+48} that hold one row, without touching LDS:
+// v_permlane16_swap exchanges odd 16-lane rows of its first operand with even rows of the second, so swapping a
+// register with a copy of itself yields (r0,r0,r2,r2) and (r1,r1,r3,r3); v_permlane32_swap does the same for halves.
+__device__ __forceinline__ float xor16_sum(float v) {
+  const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(p[0]) + __uint_as_float(p[1]);
 }
+__device__ __forceinline__ float xor32_sum(float v) {
+  const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
+__device__ __forceinline__ float row_sum(float v) { return xor32_sum(xor16_sum(v)); }
 
 template <int JT>
 __device__ __forceinline__ void layer_norm(f4 (&a)[JT], const float* gamma, const float* beta, int g) {
