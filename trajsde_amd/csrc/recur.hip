@@ -107,6 +107,253 @@ __global__ __launch_bounds__(512) void k_enc_gru_step(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Cooperative persistent recurrence: ALL H iterations in one launch.
+//   * a workgroup = 4 waves owns up to COOP_TMAX row tiles; wave w computes output features [16w, 16w+16) of every
+//     layer, so its share of the 66 K weights is 256 VGPRs -- the whole drift / dual diffusion / GRU parameter set
+//     lives in the register file (512 VGPRs per lane at one wave per SIMD) for all H steps: no LDS image, no
+//     re-staging, no weight traffic after the prologue;
+//   * activations are exchanged between the four waves through LDS (one 16x64 tile per layer, 7 barriers per step);
+//     the hidden state never leaves LDS between steps; elementwise work (tanh, Philox, gates) is split four ways too;
+//   * the matrix fragments are the plain fp32 fragment order of the stage blob: wave w simply reads slice jo = w.
+// (COOP_TMAX, COOP_RS, COOP_TILE and StepTab are declared in kernels.hpp)
+
+struct WSlice {   // one wave's 16 output rows of a 64x64 matrix: 4 k-chunks of A fragments
+  f4 q[4];
+};
+__device__ __forceinline__ WSlice load_slice(const float* mat_frag, int jo, int lane) {
+  WSlice s;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s.q[q] = *reinterpret_cast<const f4*>(mat_frag + ((jo * 4 + q) * 64 + lane) * 4);
+  return s;
+}
+__device__ __forceinline__ void slice_mma(f4& acc, const WSlice& w, const f4 (&in)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.q[q][c], in[q][c], acc, 0, 0, 0);
+}
+// full 16x64 activation tile from LDS as B operands / one wave's 16-feature slice to LDS
+__device__ __forceinline__ void lds_read_tile(f4 (&in)[4], const float* tile, const Lane& L) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) in[q] = *reinterpret_cast<const f4*>(tile + L.n * COOP_RS + 16 * q + 4 * L.g);
+}
+__device__ __forceinline__ void lds_write_slice(float* tile, const f4& v, int w, const Lane& L) {
+  *reinterpret_cast<f4*>(tile + L.n * COOP_RS + 16 * w + 4 * L.g) = v;
+}
+__device__ __forceinline__ f4 vec_slice(const float* v, int w, int g) { return *reinterpret_cast<const f4*>(v + 16 * w + 4 * g); }
+__device__ __forceinline__ f4 tanh4(f4 a) { return f4{fast_tanh(a[0]), fast_tanh(a[1]), fast_tanh(a[2]), fast_tanh(a[3])}; }
+__device__ __forceinline__ f4 sigm4(f4 a) { return f4{fast_sigmoid(a[0]), fast_sigmoid(a[1]), fast_sigmoid(a[2]), fast_sigmoid(a[3])}; }
+
+__global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict__ sde_img, const float* __restrict__ gru_img,
+                                                        const float* __restrict__ h0, const float* __restrict__ aa_out,
+                                                        int Nt, int N, int H, int TT, int tiles_per_wg, StepTab tab, int noise_step0,
+                                                        NoiseArg na, const uint8_t* __restrict__ nus,
+                                                        const uint8_t* __restrict__ pad, const int32_t* __restrict__ orig,
+                                                        const int32_t* __restrict__ eos, const int32_t* __restrict__ pick_slot,
+                                                        float* __restrict__ kept, float* __restrict__ diff_pick,
+                                                        float* __restrict__ latent_ys) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const Lane L;
+  const int w = threadIdx.x >> 6;
+  const int64_t ntiles = (int64_t(Nt) + 15) / 16;
+  // tiles of this workgroup: blockIdx.x + k * gridDim.x
+  int T = 0;
+  for (int k = 0; k < tiles_per_wg; ++k)
+    if (int64_t(blockIdx.x) + int64_t(k) * gridDim.x < ntiles) T = k + 1;
+  if (T == 0) return;
+  auto Yb = [&](int k) { return lds + (4 * k + 0) * COOP_TILE; };
+  auto Ab = [&](int k) { return lds + (4 * k + 1) * COOP_TILE; };
+  auto Bb = [&](int k) { return lds + (4 * k + 2) * COOP_TILE; };
+  auto Cb = [&](int k) { return lds + (4 * k + 3) * COOP_TILE; };
+  float* GP = lds + 4 * tiles_per_wg * COOP_TILE;              // [tile][wave][16]
+
+  // ---- register-resident weights: this wave's slice of every matrix
+  const float* F = sde_img + EncSdeL::F;
+  const float* GN = sde_img + EncSdeL::GN;
+  const float* GA = sde_img + EncSdeL::GA;
+  const WSlice wf0 = load_slice(F + DriftL::W0, w, L.lane), wf2 = load_slice(F + DriftL::W2, w, L.lane), wf4 = load_slice(F + DriftL::W4, w, L.lane);
+  const WSlice wn0 = load_slice(GN + DiffL::W0, w, L.lane), wn2 = load_slice(GN + DiffL::W2, w, L.lane);
+  const WSlice wa0 = load_slice(GA + DiffL::W0, w, L.lane), wa2 = load_slice(GA + DiffL::W2, w, L.lane);
+  using G = EncGruL;
+  const WSlice wuh = load_slice(gru_img + G::WUR_H, w, L.lane), wrh = load_slice(gru_img + G::WUR_H, 4 + w, L.lane);
+  const WSlice wux = load_slice(gru_img + G::WUR_X, w, L.lane), wrx = load_slice(gru_img + G::WUR_X, 4 + w, L.lane);
+  const WSlice wu2 = load_slice(gru_img + G::WU2, w, L.lane), wr2 = load_slice(gru_img + G::WR2, w, L.lane);
+  const WSlice wnx = load_slice(gru_img + G::WN_X, w, L.lane), wnh = load_slice(gru_img + G::WN_H, w, L.lane);
+  const WSlice wn2g = load_slice(gru_img + G::WN2, w, L.lane);
+
+  // ---- per-tile row bookkeeping and the initial state
+  int64_t rowk[COOP_TMAX];
+  bool inb[COOP_TMAX], is_nus[COOP_TMAX];
+  int eosk[COOP_TMAX], slotk[COOP_TMAX], origk[COOP_TMAX];
+  unsigned long long nusmask[COOP_TMAX];
+#pragma unroll
+  for (int k = 0; k < COOP_TMAX; ++k) {
+    if (k < T) {
+      const int64_t row = (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * 16 + L.n;
+      inb[k] = row < Nt;
+      rowk[k] = inb[k] ? row : Nt - 1;
+      is_nus[k] = nus[rowk[k]] != 0;
+      nusmask[k] = __ballot(is_nus[k]);
+      eosk[k] = eos[rowk[k]];
+      slotk[k] = pick_slot[rowk[k]];
+      origk[k] = orig[rowk[k]];
+      const f4 y = h0 ? vec_slice(h0, w, L.g) : f4{0.f, 0.f, 0.f, 0.f};      // same initial vector for every row (ENC:78 / :257)
+      lds_write_slice(Yb(k), y, w, L);
+    }
+  }
+  __syncthreads();
+
+  for (int idx = 0; idx < H; ++idx) {
+    const int t = H - 1 - idx;
+    const float dt = tab.dt[idx], sq = tab.sq[idx], sn = tab.sn[idx], cs = tab.cs[idx];
+    // first-layer biases with the (sin t, cos t) columns folded in
+    const f4 bf0 = vec_slice(F + DriftL::B0, w, L.g) + vec_slice(F + DriftL::WS, w, L.g) * sn + vec_slice(F + DriftL::WC, w, L.g) * cs;
+    const f4 bn0 = vec_slice(GN + DiffL::B0, w, L.g) + vec_slice(GN + DiffL::WS, w, L.g) * sn + vec_slice(GN + DiffL::WC, w, L.g) * cs;
+    const f4 ba0 = vec_slice(GA + DiffL::B0, w, L.g) + vec_slice(GA + DiffL::WS, w, L.g) * sn + vec_slice(GA + DiffL::WC, w, L.g) * cs;
+    f4 xin[COOP_TMAX][4];
+    // ---- P1: first layers of f and g
+#pragma unroll
+    for (int k = 0; k < COOP_TMAX; ++k)
+      if (k < T) {
+        f4 y[4];
+        lds_read_tile(y, Yb(k), L);
+        load_row(xin[k], aa_out + int64_t(t) * Nt * 64, rowk[k], L.g);           // x_t rows for the GRU, in flight early
+        f4 a = bf0;
+        slice_mma(a, wf0, y);
+        lds_write_slice(Ab(k), tanh4(a), w, L);
+        f4 gsel;
+        if (nusmask[k] == ~0ull) { gsel = bn0; slice_mma(gsel, wn0, y); }
+        else if (nusmask[k] == 0ull) { gsel = ba0; slice_mma(gsel, wa0, y); }
+        else {
+          f4 gn = bn0, ga = ba0;
+          slice_mma(gn, wn0, y);
+          slice_mma(ga, wa0, y);
+          gsel = is_nus[k] ? gn : ga;
+        }
+        lds_write_slice(Bb(k), tanh4(gsel), w, L);
+      }
+    __syncthreads();
+    // ---- P2: second layers; partial dot of the diffusion head
+#pragma unroll
+    for (int k = 0; k < COOP_TMAX; ++k)
+      if (k < T) {
+        f4 f1[4], g1[4];
+        lds_read_tile(f1, Ab(k), L);
+        lds_read_tile(g1, Bb(k), L);
+        f4 a = vec_slice(F + DriftL::B2, w, L.g);
+        slice_mma(a, wf2, f1);
+        lds_write_slice(Cb(k), tanh4(a), w, L);
+        f4 g2;
+        float part;
+        auto head = [&](const f4& h2, const float* img) {
+          const f4 wv = vec_slice(img + DiffL::W4, w, L.g);
+          return row_sum(h2[0] * wv[0] + h2[1] * wv[1] + h2[2] * wv[2] + h2[3] * wv[3]);
+        };
+        if (nusmask[k] == ~0ull) { g2 = vec_slice(GN + DiffL::B2, w, L.g); slice_mma(g2, wn2, g1); part = head(tanh4(g2), GN); }
+        else if (nusmask[k] == 0ull) { g2 = vec_slice(GA + DiffL::B2, w, L.g); slice_mma(g2, wa2, g1); part = head(tanh4(g2), GA); }
+        else {
+          f4 gn = vec_slice(GN + DiffL::B2, w, L.g), ga = vec_slice(GA + DiffL::B2, w, L.g);
+          slice_mma(gn, wn2, g1);
+          slice_mma(ga, wa2, g1);
+          const float pn = head(tanh4(gn), GN), pa = head(tanh4(ga), GA);
+          part = is_nus[k] ? pn : pa;
+        }
+        if (L.g == 0) GP[(k * 4 + w) * 16 + L.n] = part;
+      }
+    __syncthreads();
+    // ---- P3: drift output, diffusion scalar, Euler-Maruyama update of this wave's 16 state channels
+#pragma unroll
+    for (int k = 0; k < COOP_TMAX; ++k)
+      if (k < T) {
+        f4 f2[4];
+        lds_read_tile(f2, Cb(k), L);
+        f4 f = vec_slice(F + DriftL::B4, w, L.g);
+        slice_mma(f, wf4, f2);
+        const float b4 = is_nus[k] ? GN[DiffL::B4] : GA[DiffL::B4];
+        const float gs = fast_sigmoid(GP[(k * 4 + 0) * 16 + L.n] + GP[(k * 4 + 1) * 16 + L.n] + GP[(k * 4 + 2) * 16 + L.n] +
+                                      GP[(k * 4 + 3) * 16 + L.n] + b4);
+        f4 z;
+        if (na.z != nullptr) z = *reinterpret_cast<const f4*>(na.z + (int64_t(noise_step0 + idx) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g);
+        else z = philox_normal4(na.seed, STREAM_ENCODER, uint32_t(noise_step0 + idx),
+                                na.row_ids ? uint32_t(na.row_ids[rowk[k]]) : uint32_t(rowk[k]), uint32_t(4 * w + L.g));
+        f4 y = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[c] = (y[c] + f[c] * dt) + gs * (z[c] * sq);       // SDEINT:483
+        lds_write_slice(Yb(k), y, w, L);                                                  // Y now holds h' (all P1 reads are behind two barriers)
+        if (diff_pick != nullptr && inb[k] && slotk[k] >= 0 && eosk[k] == idx)
+          *reinterpret_cast<f4*>(diff_pick + int64_t(slotk[k]) * 64 + 16 * w + 4 * L.g) = f4{gs, gs, gs, gs};
+      }
+    __syncthreads();
+    // ---- P4: GRU gates, first layers (y_concat = [h', x])
+#pragma unroll
+    for (int k = 0; k < COOP_TMAX; ++k)
+      if (k < T) {
+        f4 hp[4];
+        lds_read_tile(hp, Yb(k), L);
+        f4 u1 = vec_slice(gru_img + G::BUR, w, L.g), r1 = vec_slice(gru_img + G::BUR + 64, w, L.g);
+        slice_mma(u1, wuh, hp);
+        slice_mma(u1, wux, xin[k]);
+        slice_mma(r1, wrh, hp);
+        slice_mma(r1, wrx, xin[k]);
+        lds_write_slice(Ab(k), tanh4(u1), w, L);
+        lds_write_slice(Bb(k), tanh4(r1), w, L);
+      }
+    __syncthreads();
+    // ---- P5: gates; reset * h'
+    f4 ug[COOP_TMAX];
+#pragma unroll
+    for (int k = 0; k < COOP_TMAX; ++k)
+      if (k < T) {
+        f4 u1[4], r1[4];
+        lds_read_tile(u1, Ab(k), L);
+        lds_read_tile(r1, Bb(k), L);
+        f4 u = vec_slice(gru_img + G::BU2, w, L.g), r = vec_slice(gru_img + G::BR2, w, L.g);
+        slice_mma(u, wu2, u1);
+        slice_mma(r, wr2, r1);
+        ug[k] = sigm4(u);
+        const f4 hs = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
+        lds_write_slice(Cb(k), sigm4(r) * hs, w, L);
+      }
+    __syncthreads();
+    // ---- P6: candidate state, first layer (combined = [x, r*h'])
+#pragma unroll
+    for (int k = 0; k < COOP_TMAX; ++k)
+      if (k < T) {
+        f4 rh[4];
+        lds_read_tile(rh, Cb(k), L);
+        f4 n1 = vec_slice(gru_img + G::BN0, w, L.g);
+        slice_mma(n1, wnx, xin[k]);
+        slice_mma(n1, wnh, rh);
+        lds_write_slice(Ab(k), tanh4(n1), w, L);
+      }
+    __syncthreads();
+    // ---- P7: candidate state, second layer; gated blend; masked update; picks
+#pragma unroll
+    for (int k = 0; k < COOP_TMAX; ++k)
+      if (k < T) {
+        f4 n1[4];
+        lds_read_tile(n1, Ab(k), L);
+        f4 nw = vec_slice(gru_img + G::BN2, w, L.g);
+        slice_mma(nw, wn2g, n1);
+        f4 hs = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
+        const bool valid = !pad[int64_t(origk[k]) * TT + t];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float hn = (1.0f - ug[k][c]) * nw[c] + ug[k][c] * hs[c];
+          hs[c] = valid ? hn : hs[c];
+        }
+        lds_write_slice(Yb(k), hs, w, L);
+        const int64_t row = rowk[k];
+        if (inb[k] && row < N) {
+          if (eosk[k] == idx) *reinterpret_cast<f4*>(kept + row * 64 + 16 * w + 4 * L.g) = hs;
+          if (latent_ys != nullptr) *reinterpret_cast<f4*>(latent_ys + (int64_t(idx) * N + row) * 64 + 16 * w + 4 * L.g) = hs;
+        }
+      }
+    __syncthreads();
+  }
+}
+
 // forward_ood (ENC:311-313): outs [S,N,64] -> mean over samples [N,64] and std(0).mean(-1) [N] (unbiased std)
 __global__ __launch_bounds__(256) void k_ood_stats(const float* __restrict__ samples, int S, int N, float* __restrict__ mean,
                                                    float* __restrict__ stds) {

@@ -118,6 +118,20 @@ static int run_recurrence(const trajsde_batch* b, const trajsde_graph* g, const 
                           float* latent_ys, hipStream_t st) {
   const int N = b->N, Nt = g->Nt, H = b->H;
   const int64_t rtiles = (int64_t(Nt) + 15) / 16;
+  // cooperative persistent kernel: all H iterations in one launch, weights resident in the register file
+  static const bool legacy = []() { const char* e = getenv("TRAJSDE_RECUR_LEGACY"); return e && atoi(e) != 0; }();
+  const int tiles_per_wg = int((rtiles + 255) / 256);
+  if (!legacy && tiles_per_wg <= COOP_TMAX && H <= 32) {
+    StepTab tab;
+    for (int i = 0; i < H; ++i) {
+      tab.dt[i] = step_tab[8 * i + 1]; tab.sq[i] = step_tab[8 * i + 2]; tab.sn[i] = step_tab[8 * i + 3]; tab.cs[i] = step_tab[8 * i + 4];
+    }
+    const int grid = int((rtiles + tiles_per_wg - 1) / tiles_per_wg);
+    const int lds = (4 * tiles_per_wg * COOP_TILE + tiles_per_wg * 64) * 4;
+    TS_LAUNCH(k_enc_recur_coop, grid, 256, lds, st, blob + EncBlob::SDE, blob + EncBlob::GRU, h0, aa_out, Nt, N, H, b->TT, tiles_per_wg, tab,
+              noise_step0, na, g->nus_mask, b->padding_mask, g->orig, g->eos_idx, g->pick_slot, kept, diff_pick, latent_ys);
+    return TRAJSDE_OK;
+  }
   for (int idx = 0; idx < H; ++idx) {
     const int t = H - 1 - idx;
     const float* e = step_tab + 8 * idx;
