@@ -256,6 +256,105 @@ __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restri
   agg[node * 64 + lane] = end > beg ? acc / (s + 1e-16f) : 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------ fused global attention
+// One wave per target actor: the whole message/softmax/aggregate of a GlobalInteractorLayer (AGG:101-117) without
+// any per-edge GEMM and without materialising per-edge k / v / logits:
+//   logit_h(e) = [ q_h . k_node[src]_h  +  (Wke_h^T q_h) . rel_e  +  q_h . bke_h ] / sqrt(8)
+//   out        = sum_e alpha_e v_node[src]  +  Wve ( sum_e alpha_{e,h} rel_e )  +  bve * sum_e alpha_e
+// i.e. lin_k_edge is folded into the query once per target (U_h = Wke_h^T q_h, 8 x 64) and lin_v_edge is applied
+// once per target after the aggregation.  Per edge the wave streams one rel row (256 B) and gathers two node rows.
+// Lane l is feature l of the node rows (head l>>3) and holds slice 8*(l&7).. of the rel row / of U for head l>>3.
+__device__ __forceinline__ float dpp_add(float v, int ctrl_tag) {
+  // ctrl_tag 0: xor 1, 1: xor 2 (quad permutes), 2: mirror within 8 lanes
+  int r;
+  if (ctrl_tag == 0) r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);
+  else if (ctrl_tag == 1) r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);
+  else r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true);
+  return v + __int_as_float(r);
+}
+__device__ __forceinline__ float head_sum(float v) { return dpp_add(dpp_add(dpp_add(v, 0), 1), 2); }   // over the 8 lanes of a head
+
+__global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ img, const int32_t* __restrict__ segptr,
+                                                     const int32_t* __restrict__ src, const float* __restrict__ rel,
+                                                     const float* __restrict__ q, const float* __restrict__ kn,
+                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ agg) {
+  __shared__ __attribute__((aligned(16))) float sbuf[4][8][64 + 4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = lane >> 3, j = lane & 7;
+  const int64_t node = int64_t(blockIdx.x) * 4 + wv;
+  const int64_t nc = node < N ? node : N - 1;
+  const float* wke = img + GAttnL::WKE;
+  const float* wve = img + GAttnL::WVE;
+  const float ql = q[nc * 64 + lane];
+  const float cb = head_sum(ql * img[GAttnL::BKE + lane]);
+  float U[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) U[e] = 0.f;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const float qd = __shfl(ql, 8 * h + d);
+    const f4 w0 = *reinterpret_cast<const f4*>(wke + (8 * h + d) * 64 + 8 * j);
+    const f4 w1 = *reinterpret_cast<const f4*>(wke + (8 * h + d) * 64 + 8 * j + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { U[e] = fmaf(w0[e], qd, U[e]); U[4 + e] = fmaf(w1[e], qd, U[4 + e]); }
+  }
+  const int beg = segptr[nc], end = node < N ? segptr[nc + 1] : beg;
+  float m = -INFINITY, s = 0.f, accv = 0.f, accr[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) accr[e] = 0.f;
+  for (int e0 = beg; e0 < end; e0 += 8) {
+    f4 ra[8], rb[8];
+    float knv[8], vnv[8], lg[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u < end ? e0 + u : end - 1;
+      const int sidx = src[e];
+      ra[u] = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + 8 * j);
+      rb[u] = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + 8 * j + 4);
+      knv[u] = kn[int64_t(sidx) * 64 + lane];
+      vnv[u] = vn[int64_t(sidx) * 64 + lane];
+    }
+    float cm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float p = ql * knv[u];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { p = fmaf(ra[u][e], U[e], p); p = fmaf(rb[u][e], U[4 + e], p); }
+      p = (head_sum(p) + cb) * INV_SQRT_DH;
+      lg[u] = e0 + u < end ? p : -INFINITY;
+      cm = fmaxf(cm, lg[u]);
+    }
+    const float mn = fmaxf(m, cm);
+    const float sc = fast_exp(m - mn);          // m = -inf on the first chunk -> 0
+    m = mn;
+    s *= sc;
+    accv *= sc;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) accr[e] *= sc;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float ex = fast_exp(lg[u] - m);     // masked lanes: exp(-inf) = 0
+      s += ex;
+      accv = fmaf(ex, vnv[u], accv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { accr[e] = fmaf(ex, ra[u][e], accr[e]); accr[4 + e] = fmaf(ex, rb[u][e], accr[4 + e]); }
+    }
+  }
+  const float inv = 1.0f / (s + 1e-16f);          // PyG softmax denominator
+  // S_h = sum_e alpha_{e,h} rel_e, spread over the 8 lanes of head h -> LDS so every lane of the head sees all 64
+  *reinterpret_cast<f4*>(&sbuf[wv][h][8 * j]) = f4{accr[0] * inv, accr[1] * inv, accr[2] * inv, accr[3] * inv};
+  *reinterpret_cast<f4*>(&sbuf[wv][h][8 * j + 4]) = f4{accr[4] * inv, accr[5] * inv, accr[6] * inv, accr[7] * inv};
+  float out = fmaf(img[GAttnL::BVE + lane], s * inv, accv * inv);
+#pragma unroll
+  for (int k4 = 0; k4 < 16; ++k4) {
+    const f4 wr = *reinterpret_cast<const f4*>(wve + lane * 64 + 4 * k4);
+    const f4 sv = *reinterpret_cast<const f4*>(&sbuf[wv][h][4 * k4]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out = fmaf(wr[e], sv[e], out);
+  }
+  if (node < N) agg[node * 64 + lane] = out;
+}
+
 // ------------------------------------------------------------------------------------------------ update + FFN
 // gate = sigmoid(lin_ih(agg) + lin_hh(xn)); upd = agg + gate*(lin_self(xn) - agg); x1 = x + out_proj(upd); xn2 = norm2(x1)
 __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ img_g, const float* __restrict__ agg,

@@ -16,6 +16,8 @@ __global__ void k_edge_embed(const float* img, const float* geom, int64_t E, flo
 template <bool X6>
 __global__ void k_global_edge(const float* img, const float* rel, const int32_t* src, const int32_t* dst, const float* q,
                               const float* kn, const float* vn, int64_t E, float* logits, float* v);
+__global__ void k_global_attn(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
+                              const float* vn, int64_t N, float* agg);
 __global__ void k_seg_softmax_agg(const int32_t* segptr, const float* logits, const float* v, int64_t R, float* agg);
 __global__ void k_node_update(const float* img, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2);
 __global__ void k_ffn(const float* img, const float* x1, const float* xn2, int64_t R, float* out);

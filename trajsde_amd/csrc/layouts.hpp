@@ -165,10 +165,14 @@ struct EncBlob {
 };
 
 // aggregator stage blob: rel_embed, then per layer {qkv, edge, upd, ffn}, then norm + per-mode projection
+// fused global attention (k_global_attn): lin_k_edge / lin_v_edge as plain row-major matrices
+struct GAttnL {
+  enum : int { S_END = 0, TS_FIELD(WKE, MAT64, S), TS_FIELD(BKE, 64, WKE), TS_FIELD(WVE, MAT64, BKE), TS_FIELD(BVE, 64, WVE), SIZE = BVE_END };
+};
 struct AggLayerL {
   enum : int {
     QKV = 0, EDGE = QKV + NodeProjL<3>::SIZE, UPD = EDGE + GEdgeL::SIZE, FFN = UPD + UpdL::SIZE, EDGE6 = FFN + FfnL::SIZE,
-    SIZE = EDGE6 + GEdgeL6::SIZE
+    ATTN = EDGE6 + GEdgeL6::SIZE, SIZE = ATTN + GAttnL::SIZE
   };
 };
 struct AggBlob {

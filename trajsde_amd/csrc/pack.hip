@@ -291,6 +291,10 @@ static void recipe_aggregator(Packer& P, int nl, int K) {
     P.vec(p + ".lin_v_edge.bias", b + AggLayerL::EDGE + GEdgeL::BKV + 64, 64);
     recipe_upd_ffn(P, p, b + AggLayerL::UPD, b + AggLayerL::FFN);
     pack_kv6(P, p + ".lin_k_edge", p + ".lin_v_edge", b + AggLayerL::EDGE6 + GEdgeL6::WKV, b + AggLayerL::EDGE6 + GEdgeL6::BKV);
+    P.vec(p + ".lin_k_edge.weight", b + AggLayerL::ATTN + GAttnL::WKE, MAT64);
+    P.vec(p + ".lin_k_edge.bias", b + AggLayerL::ATTN + GAttnL::BKE, 64);
+    P.vec(p + ".lin_v_edge.weight", b + AggLayerL::ATTN + GAttnL::WVE, MAT64);
+    P.vec(p + ".lin_v_edge.bias", b + AggLayerL::ATTN + GAttnL::BVE, 64);
   }
   P.ln("norm", AggBlob::norm(nl), AggBlob::norm(nl) + 64);
   // multihead_proj [K*64, 64]: mode k owns rows 64k..64k+63 (AGG:56 view(-1, K, 64))

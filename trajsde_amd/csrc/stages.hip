@@ -245,6 +245,18 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
     const float* lb = blob + AggBlob::layer(i);
     TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
               w.xn, w.q, w.kn, w.vn);
+    float* out = bufs[i & 1];
+    static const bool fused = []() { const char* e = getenv("TRAJSDE_GLOBAL_UNFUSED"); return !(e && atoi(e) != 0); }();
+    if (fused) {
+      // one wave per target: logits, softmax and aggregation in one pass over the rel rows (no per-edge GEMM)
+      TS_LAUNCH(k_global_attn, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg);
+      const int64_t nt = (N + 15) / 16;
+      TS_LAUNCH(k_node_update, tile_grid(nt, threads_node(), UpdL::SIZE * 4), threads_node(), UpdL::SIZE * 4, st, lb + AggLayerL::UPD, w.agg,
+                w.xn, x, N, w.x1, w.xn2);
+      TS_LAUNCH(k_ffn, tile_grid(nt, threads_node(), FfnL::SIZE * 4), threads_node(), FfnL::SIZE * 4, st, lb + AggLayerL::FFN, w.x1, w.xn2, N, out);
+      x = out;
+      continue;
+    }
     if (E > 0) {
       if (edge_x6())
         TS_LAUNCH(k_global_edge<true>, tile_grid(etiles, 512, GEdgeL6::SIZE * 4), 512, GEdgeL6::SIZE * 4, st,
@@ -253,7 +265,6 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
         TS_LAUNCH(k_global_edge<false>, tile_grid(etiles, 512, GEdgeL::SIZE * 4), 512, GEdgeL::SIZE * 4, st,
                   lb + AggLayerL::EDGE, w.rel, g->g_src, g->g_dst, w.q, w.kn, w.vn, E, w.logits, w.v);
     }
-    float* out = bufs[i & 1];
     if (int rc = attention_tail(lb + AggLayerL::UPD, lb + AggLayerL::FFN, g->g_segptr, w.logits, w.v, w.xn, x, N, w.agg, w.x1, w.xn2,
                                 out, st))
       return rc;
