@@ -357,12 +357,18 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
 
 // ------------------------------------------------------------------------------------------------ update + FFN
 // gate = sigmoid(lin_ih(agg) + lin_hh(xn)); upd = agg + gate*(lin_self(xn) - agg); x1 = x + out_proj(upd); xn2 = norm2(x1)
+template <bool X6>
 __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ img_g, const float* __restrict__ agg,
                                                      const float* __restrict__ xn, const float* __restrict__ x, int64_t R,
                                                      float* __restrict__ x1, float* __restrict__ xn2) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_blob(lds, img_g, UpdL::SIZE);
-  using U = UpdL;
+  using U = typename std::conditional<X6, UpdL6, UpdL>::type;
+  stage_blob(lds, img_g, U::SIZE);
+  const Lane L_;
+  auto lin = [&](f4 (&out)[4], const f4 (&in)[4], int wo, int bo) {
+    if constexpr (X6) linear_x6<4, 4>(out, in, lds + wo, lds + bo, L_);
+    else linear<4, 4>(out, in, lds + wo, lds + bo, L_);
+  };
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (R + 15) / 16;
@@ -372,21 +378,20 @@ __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ i
     f4 a[4], n[4], g[4], s[4];
     load_row(a, agg, r, L.g);
     load_row(n, xn, r, L.g);
-    load_vec<4>(g, lds + U::BIH, L.g);
-    linear_acc<4, 4>(g, a, lds + U::WIH, L.lane);
+    lin(g, a, U::WIH, U::BIH);
     {
       f4 h[4];
-      linear<4, 4>(h, n, lds + U::WHH, lds + U::BHH, L);
+      lin(h, n, U::WHH, U::BHH);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) g[jt] += h[jt];
     }
     sigmoid_<4>(g);
-    linear<4, 4>(s, n, lds + U::WSELF, lds + U::BSELF, L);
+    lin(s, n, U::WSELF, U::BSELF);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
       for (int c = 0; c < 4; ++c) a[jt][c] = a[jt][c] + g[jt][c] * (s[jt][c] - a[jt][c]);
-    linear<4, 4>(s, a, lds + U::WOUT, lds + U::BOUT, L);
+    lin(s, a, U::WOUT, U::BOUT);
     load_row(n, x, r, L.g);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) n[jt] += s[jt];
@@ -416,6 +421,40 @@ __global__ __launch_bounds__(512) void k_ffn(const float* __restrict__ img_g, co
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) o[jt] += n[jt];
     if (row < R) store_row(o, out, row, L.g);
+  }
+}
+
+// split-precision FFN in two passes over this workgroup's tiles, one per half of the 256 hidden units:
+//   pass 0: out = x1 + b2 + W2[:, :128] relu(W1[:128] xn2 + b1[:128]);   pass 1: out += W2[:, 128:] relu(W1[128:] xn2 + b1[128:])
+__global__ __launch_bounds__(512) void k_ffn6(const float* __restrict__ img_g, const float* __restrict__ x1,
+                                              const float* __restrict__ xn2, int64_t R, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (R + 15) / 16;
+  for (int hf = 0; hf < 2; ++hf) {
+    if (hf) __syncthreads();                                   // everyone is done reading the first half image
+    stage_blob(lds, img_g + hf * FfnL6::HALF, FfnL6::HALF);
+    for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+      keep_lds_reads_here();
+      const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
+      f4 n[4], hid[8], o[4];
+      load_row(n, xn2, r, L.g);
+      linear_x6<8, 4>(hid, n, lds + FfnL6::W1, lds + FfnL6::B1, L);
+      relu<8>(hid);
+      if (hf == 0) {
+        load_vec<4>(o, lds + FfnL6::B2, L.g);
+        load_row(n, x1, r, L.g);
+      } else {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) o[jt] = f4{0.f, 0.f, 0.f, 0.f};
+        load_row(n, out, r, L.g);                              // partial sum of pass 0 (same wave wrote it)
+      }
+      linear_acc_x6<4, 8>(o, hid, lds + FfnL6::W2, L.lane);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) o[jt] += n[jt];
+      if (row < R) store_row(o, out, row, L.g);
+    }
   }
 }
 
@@ -474,6 +513,8 @@ template __global__ void k_edge_embed<false>(const float*, const float*, int64_t
 template __global__ void k_edge_embed<true>(const float*, const float*, int64_t, float*);
 template __global__ void k_global_edge<false>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
 template __global__ void k_global_edge<true>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
+template __global__ void k_node_update<false>(const float*, const float*, const float*, const float*, int64_t, float*, float*);
+template __global__ void k_node_update<true>(const float*, const float*, const float*, const float*, int64_t, float*, float*);
 template __global__ void k_node_proj<1>(const float*, const float*, int64_t, float*, float*, float*, float*);
 template __global__ void k_node_proj<3>(const float*, const float*, int64_t, float*, float*, float*, float*);
 

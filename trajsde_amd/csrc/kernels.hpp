@@ -19,7 +19,9 @@ __global__ void k_global_edge(const float* img, const float* rel, const int32_t*
 __global__ void k_global_attn(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
                               const float* vn, int64_t N, float* agg);
 __global__ void k_seg_softmax_agg(const int32_t* segptr, const float* logits, const float* v, int64_t R, float* agg);
+template <bool X6>
 __global__ void k_node_update(const float* img, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2);
+__global__ void k_ffn6(const float* img, const float* x1, const float* xn2, int64_t R, float* out);
 __global__ void k_ffn(const float* img, const float* x1, const float* xn2, int64_t R, float* out);
 template <int NQ>
 __global__ void k_node_proj(const float* img, const float* x, int64_t R, float* xn_out, float* p0, float* p1, float* p2);

@@ -69,6 +69,26 @@ struct UpdL {
   };
 };
 
+struct UpdL6 {   // split-precision twin of UpdL
+  enum : int {
+    S_END = 0,
+    TS_FIELD(WIH, MAT64X6, S), TS_FIELD(BIH, 64, WIH), TS_FIELD(WHH, MAT64X6, BIH), TS_FIELD(BHH, 64, WHH),
+    TS_FIELD(WSELF, MAT64X6, BHH), TS_FIELD(BSELF, 64, WSELF), TS_FIELD(WOUT, MAT64X6, BSELF), TS_FIELD(BOUT, 64, WOUT),
+    TS_FIELD(N2G, 64, BOUT), TS_FIELD(N2B, 64, N2G),
+    SIZE = N2B_END
+  };
+};
+// split-precision FFN: the 256 hidden units are processed in two halves of 128 so that each half's image
+// (W1 half 128x64 + W2 half 64x128 as bf16x6 planes, 98 KB) fits LDS; HALF = size of one half image
+struct FfnL6 {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(W1, 2 * MAT64X6, S), TS_FIELD(B1, 128, W1), TS_FIELD(W2, 2 * MAT64X6, B1), TS_FIELD(B2, 64, W2),
+    HALF = B2_END, SIZE = 2 * B2_END
+  };
+};
+static_assert(UpdL6::SIZE * 4 <= 160 * 1024 && FfnL6::HALF * 4 <= 160 * 1024, "split-precision node images must fit LDS");
+
 // k_ffn: mlp.0 (64->256) ReLU mlp.3 (256->64)
 struct FfnL {
   enum : int {
@@ -160,7 +180,11 @@ struct EncBlob {
     AL_FFN = AL_UPD + UpdL::SIZE,
     AA_EDGE6 = AL_FFN + FfnL::SIZE,
     AL_EDGE6 = AA_EDGE6 + EdgeL6::SIZE,
-    SIZE = AL_EDGE6 + EdgeL6::SIZE
+    AA_UPD6 = AL_EDGE6 + EdgeL6::SIZE,
+    AA_FFN6 = AA_UPD6 + UpdL6::SIZE,
+    AL_UPD6 = AA_FFN6 + FfnL6::SIZE,
+    AL_FFN6 = AL_UPD6 + UpdL6::SIZE,
+    SIZE = AL_FFN6 + FfnL6::SIZE
   };
 };
 
@@ -172,7 +196,7 @@ struct GAttnL {
 struct AggLayerL {
   enum : int {
     QKV = 0, EDGE = QKV + NodeProjL<3>::SIZE, UPD = EDGE + GEdgeL::SIZE, FFN = UPD + UpdL::SIZE, EDGE6 = FFN + FfnL::SIZE,
-    ATTN = EDGE6 + GEdgeL6::SIZE, SIZE = ATTN + GAttnL::SIZE
+    ATTN = EDGE6 + GEdgeL6::SIZE, UPD6 = ATTN + GAttnL::SIZE, FFN6 = UPD6 + UpdL6::SIZE, SIZE = FFN6 + FfnL6::SIZE
   };
 };
 struct AggBlob {

@@ -173,6 +173,32 @@ static void recipe_upd_ffn(Packer& P, const std::string& p, int upd, int ffn) {
   P.lin(p + ".mlp.0", ffn + FfnL::W1, ffn + FfnL::B1, 256, 64);
   P.lin(p + ".mlp.3", ffn + FfnL::W2, ffn + FfnL::B2, 64, 256);
 }
+static void recipe_upd_ffn6(Packer& P, const std::string& p, int upd, int ffn) {
+  using U = UpdL6;
+  P.mat6(p + ".lin_ih.weight", upd + U::WIH, 64, 64, 64);
+  P.vec(p + ".lin_ih.bias", upd + U::BIH, 64);
+  P.mat6(p + ".lin_hh.weight", upd + U::WHH, 64, 64, 64);
+  P.vec(p + ".lin_hh.bias", upd + U::BHH, 64);
+  P.mat6(p + ".lin_self.weight", upd + U::WSELF, 64, 64, 64);
+  P.vec(p + ".lin_self.bias", upd + U::BSELF, 64);
+  P.mat6(p + ".out_proj.weight", upd + U::WOUT, 64, 64, 64);
+  P.vec(p + ".out_proj.bias", upd + U::BOUT, 64);
+  P.ln(p + ".norm2", upd + U::N2G, upd + U::N2B);
+  // FFN halves: hidden units [128*hf, 128*hf+128): rows of mlp.0, columns of mlp.3
+  const float* w1 = P.src(p + ".mlp.0.weight");     // [256, 64]
+  const float* b1 = P.src(p + ".mlp.0.bias");
+  const float* w2 = P.src(p + ".mlp.3.weight");     // [64, 256]
+  const float* b2 = P.src(p + ".mlp.3.bias");
+  if (!P.dry)
+    for (int hf = 0; hf < 2; ++hf) {
+      const int base = ffn + hf * FfnL6::HALF;
+      k_pack_mat6<<<cdiv(8 * 2 * 512, 256), 256, 0, P.stream>>>(w1 + hf * 128 * 64, reinterpret_cast<unsigned short*>(P.blob + base + FfnL6::W1), 8, 2, 64, 0);
+      k_pack_vec<<<1, 128, 0, P.stream>>>(b1 + hf * 128, P.blob + base + FfnL6::B1, 128, 0);
+      k_pack_mat6<<<cdiv(4 * 4 * 512, 256), 256, 0, P.stream>>>(w2, reinterpret_cast<unsigned short*>(P.blob + base + FfnL6::W2), 4, 4, 256, hf * 128);
+      k_pack_vec<<<1, 64, 0, P.stream>>>(b2, P.blob + base + FfnL6::B2, 64, 0);
+    }
+}
+
 static void recipe_drift(Packer& P, const std::string& p, int base) {
   using L = DriftL;
   P.mat(p + ".net.0.weight", base + L::W0, 64, 64, 66, 0);
@@ -270,6 +296,8 @@ static void recipe_encoder(Packer& P) {
   pack_kv6(P, "aa_encoder.lin_k", "aa_encoder.lin_v", B::AA_EDGE6 + EdgeL6::WKV, B::AA_EDGE6 + EdgeL6::BKV);
   recipe_edge_embed6(P, "al_encoder.lane_embed", B::AL_EDGE6);
   pack_kv6(P, "al_encoder.lin_k", "al_encoder.lin_v", B::AL_EDGE6 + EdgeL6::WKV, B::AL_EDGE6 + EdgeL6::BKV);
+  recipe_upd_ffn6(P, "aa_encoder", B::AA_UPD6, B::AA_FFN6);
+  recipe_upd_ffn6(P, "al_encoder", B::AL_UPD6, B::AL_FFN6);
 }
 
 static void recipe_aggregator(Packer& P, int nl, int K) {
@@ -291,6 +319,7 @@ static void recipe_aggregator(Packer& P, int nl, int K) {
     P.vec(p + ".lin_v_edge.bias", b + AggLayerL::EDGE + GEdgeL::BKV + 64, 64);
     recipe_upd_ffn(P, p, b + AggLayerL::UPD, b + AggLayerL::FFN);
     pack_kv6(P, p + ".lin_k_edge", p + ".lin_v_edge", b + AggLayerL::EDGE6 + GEdgeL6::WKV, b + AggLayerL::EDGE6 + GEdgeL6::BKV);
+    recipe_upd_ffn6(P, p, b + AggLayerL::UPD6, b + AggLayerL::FFN6);
     P.vec(p + ".lin_k_edge.weight", b + AggLayerL::ATTN + GAttnL::WKE, MAT64);
     P.vec(p + ".lin_k_edge.bias", b + AggLayerL::ATTN + GAttnL::BKE, 64);
     P.vec(p + ".lin_v_edge.weight", b + AggLayerL::ATTN + GAttnL::WVE, MAT64);

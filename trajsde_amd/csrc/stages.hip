@@ -72,13 +72,30 @@ struct AggWs {
 };
 
 // one attention block over an edge list already reduced to (logits, v): softmax-aggregate, gated update, FFN
-static int attention_tail(const float* upd_img, const float* ffn_img, const int32_t* segptr, const float* logits, const float* v,
-                          const float* xn, const float* x, int64_t R, float* agg, float* x1, float* xn2, float* out, hipStream_t st) {
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, segptr, logits, v, R, agg);
+static bool node_x6() { static bool v = []() { const char* e = getenv("TRAJSDE_NODE_FP32"); return !(e && atoi(e) != 0); }(); return v; }
+
+// gated update + FFN of one attention block; `upd6/ffn6` are the split-precision images, `upd/ffn` the plain fp32 ones
+struct NodeImgs {
+  const float *upd, *ffn, *upd6, *ffn6;
+};
+static int update_ffn(const NodeImgs& im, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2, float* out,
+                      hipStream_t st) {
   const int64_t ntiles = (R + 15) / 16;
-  TS_LAUNCH(k_node_update, tile_grid(ntiles, threads_node(), UpdL::SIZE * 4), threads_node(), UpdL::SIZE * 4, st, upd_img, agg, xn, x, R, x1, xn2);
-  TS_LAUNCH(k_ffn, tile_grid(ntiles, threads_node(), FfnL::SIZE * 4), threads_node(), FfnL::SIZE * 4, st, ffn_img, x1, xn2, R, out);
+  if (node_x6()) {
+    TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, threads_node(), UpdL6::SIZE * 4), threads_node(), UpdL6::SIZE * 4, st, im.upd6, agg, xn, x,
+              R, x1, xn2);
+    TS_LAUNCH(k_ffn6, tile_grid(ntiles, threads_node(), FfnL6::HALF * 4), threads_node(), FfnL6::HALF * 4, st, im.ffn6, x1, xn2, R, out);
+  } else {
+    TS_LAUNCH(k_node_update<false>, tile_grid(ntiles, threads_node(), UpdL::SIZE * 4), threads_node(), UpdL::SIZE * 4, st, im.upd, agg, xn, x, R,
+              x1, xn2);
+    TS_LAUNCH(k_ffn, tile_grid(ntiles, threads_node(), FfnL::SIZE * 4), threads_node(), FfnL::SIZE * 4, st, im.ffn, x1, xn2, R, out);
+  }
   return TRAJSDE_OK;
+}
+static int attention_tail(const NodeImgs& im, const int32_t* segptr, const float* logits, const float* v, const float* xn, const float* x,
+                          int64_t R, float* agg, float* x1, float* xn2, float* out, hipStream_t st) {
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, segptr, logits, v, R, agg);
+  return update_ffn(im, agg, xn, x, R, x1, xn2, out, st);
 }
 
 }  // namespace tsde
@@ -108,8 +125,8 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
       TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv<false>, tile_grid((int64_t(g->E_aa) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(),
                     EdgeL::SIZE * 4, st, blob + EncBlob::AA_EDGE, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v);
   }
-  return attention_tail(blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg, w.x1,
-                        w.xn2, aa_out, st);
+  const NodeImgs im{blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, blob + EncBlob::AA_UPD6, blob + EncBlob::AA_FFN6};
+  return attention_tail(im, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg, w.x1, w.xn2, aa_out, st);
 }
 
 // one pass of the latent SDE + GRU recurrence; iteration idx consumes history step t = H-1-idx (ENC:128-182)
@@ -159,8 +176,8 @@ static int run_al_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
       TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv<false>, tile_grid((int64_t(g->E_la) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(),
                     EdgeL::SIZE * 4, st, blob + EncBlob::AL_EDGE, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v);
   }
-  return attention_tail(blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, g->la_segptr, w.al_logits, w.al_v, w.al_xn, lat, N, w.al_agg,
-                        w.al_x1, w.al_xn2, local_embed, st);
+  const NodeImgs im{blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, blob + EncBlob::AL_UPD6, blob + EncBlob::AL_FFN6};
+  return attention_tail(im, g->la_segptr, w.al_logits, w.al_v, w.al_xn, lat, N, w.al_agg, w.al_x1, w.al_xn2, local_embed, st);
 }
 
 int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob,
@@ -246,14 +263,12 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
     TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
               w.xn, w.q, w.kn, w.vn);
     float* out = bufs[i & 1];
+    const NodeImgs im{lb + AggLayerL::UPD, lb + AggLayerL::FFN, lb + AggLayerL::UPD6, lb + AggLayerL::FFN6};
     static const bool fused = []() { const char* e = getenv("TRAJSDE_GLOBAL_UNFUSED"); return !(e && atoi(e) != 0); }();
     if (fused) {
       // one wave per target: logits, softmax and aggregation in one pass over the rel rows (no per-edge GEMM)
       TS_LAUNCH(k_global_attn, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg);
-      const int64_t nt = (N + 15) / 16;
-      TS_LAUNCH(k_node_update, tile_grid(nt, threads_node(), UpdL::SIZE * 4), threads_node(), UpdL::SIZE * 4, st, lb + AggLayerL::UPD, w.agg,
-                w.xn, x, N, w.x1, w.xn2);
-      TS_LAUNCH(k_ffn, tile_grid(nt, threads_node(), FfnL::SIZE * 4), threads_node(), FfnL::SIZE * 4, st, lb + AggLayerL::FFN, w.x1, w.xn2, N, out);
+      if (int rc = update_ffn(im, w.agg, w.xn, x, N, w.x1, w.xn2, out, st)) return rc;
       x = out;
       continue;
     }
@@ -265,9 +280,7 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
         TS_LAUNCH(k_global_edge<false>, tile_grid(etiles, 512, GEdgeL::SIZE * 4), 512, GEdgeL::SIZE * 4, st,
                   lb + AggLayerL::EDGE, w.rel, g->g_src, g->g_dst, w.q, w.kn, w.vn, E, w.logits, w.v);
     }
-    if (int rc = attention_tail(lb + AggLayerL::UPD, lb + AggLayerL::FFN, g->g_segptr, w.logits, w.v, w.xn, x, N, w.agg, w.x1, w.xn2,
-                                out, st))
-      return rc;
+    if (int rc = attention_tail(im, g->g_segptr, w.logits, w.v, w.xn, x, N, w.agg, w.x1, w.xn2, out, st)) return rc;
     x = out;
   }
   const int lds = (128 + MAT64 + 64) * 4;
