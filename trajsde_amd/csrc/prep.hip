@@ -33,24 +33,56 @@ __global__ void k_rotate(const float* __restrict__ ang, int N, const float* __re
     }
 }
 
-__global__ void k_split_edges(const int64_t* __restrict__ ei, int E, int row_key, int32_t* __restrict__ keys,
-                              int32_t* __restrict__ vals, int vals_are_ids) {
+// ---------------------------------------------------------------------------------------------- CSR by target
+// counting sort on the target id (deterministic counts via integer atomics), then every row is put into canonical
+// order (ascending source / edge id) by an in-LDS bitonic sort, so the result does not depend on atomic arrival
+// order -- nor on the order of the input edge list.
+__global__ void k_degree(const int64_t* __restrict__ ei, int E, int32_t* __restrict__ deg) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E) atomicAdd(&deg[int(ei[int64_t(E) + e])], 1);                 // row 1 = target
+}
+__global__ void k_scatter(const int64_t* __restrict__ ei, int E, int32_t* __restrict__ cursor, int32_t* __restrict__ out,
+                          int store_edge_id) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  keys[e] = int32_t(ei[int64_t(row_key) * E + e]);
-  vals[e] = vals_are_ids ? e : int32_t(ei[int64_t(1 - row_key) * E + e]);
+  const int p = atomicAdd(&cursor[int(ei[int64_t(E) + e])], 1);
+  out[p] = store_edge_id ? e : int32_t(ei[e]);                             // row 0 = source
 }
-
-// rowptr[i] = first position whose key >= i   (i in [0, n])
-__global__ void k_rowptr(const int32_t* __restrict__ keys, int E, int n, int32_t* __restrict__ rowptr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i > n) return;
-  int lo = 0, hi = E;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (keys[mid] < i) lo = mid + 1; else hi = mid;
+// ascending sort of every CSR row; one workgroup per row (grid-stride), bitonic network in LDS (rows up to 4096
+// entries) or in place in global memory for longer rows
+__global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ rowptr, int n_rows, int32_t* __restrict__ vals) {
+  __shared__ int32_t buf[4096];
+  for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+    const int beg = rowptr[row], n = rowptr[row + 1] - beg;
+    if (n <= 1) continue;
+    int P = 2;
+    while (P < n) P <<= 1;
+    const bool in_lds = P <= 4096;
+    int32_t* a = in_lds ? buf : vals + beg;
+    if (in_lds) {
+      for (int i = threadIdx.x; i < P; i += blockDim.x) buf[i] = i < n ? vals[beg + i] : INT32_MAX;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; i < P; i += blockDim.x) {
+          const int l = i ^ j;
+          if (l > i) {
+            // virtual padding with +inf for the global-memory variant
+            const int32_t vi = (in_lds || i < n) ? a[i] : INT32_MAX, vl = (in_lds || l < n) ? a[l] : INT32_MAX;
+            const bool up = (i & k) == 0;
+            if ((vi > vl) == up) {
+              if (in_lds || i < n) a[i] = vl;
+              if (in_lds || l < n) a[l] = vi;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    if (in_lds)
+      for (int i = threadIdx.x; i < n; i += blockDim.x) vals[beg + i] = buf[i];
+    __syncthreads();
   }
-  rowptr[i] = lo;
 }
 
 // per extended node: original actor, source mask, recurrence iteration to keep; slots of the agent rows
@@ -94,108 +126,72 @@ __global__ void k_fake_x(int A, int H, const float* __restrict__ x, const int64_
   }
 }
 
-// ext_rowptr: rows 0..N as rowptr, rows of the fake agents appended (copies of their agents' in-edges)
-__global__ void k_ext_rowptr(int N, int A, int E, const int32_t* __restrict__ rowptr, const int64_t* __restrict__ agent_index,
-                             int32_t* __restrict__ ext_rowptr, int32_t* __restrict__ counts) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i <= N) ext_rowptr[i] = rowptr[i];
-  if (i == 0) {
-    int acc = E;
-    for (int k = 0; k < A; ++k) {
-      const int a = int(agent_index[k]);
-      acc += rowptr[a + 1] - rowptr[a];
-      ext_rowptr[N + k + 1] = acc;
-    }
-    counts[0] = acc;   // E_ext
+// ---------------------------------------------------------------------------------------------- 21 snapshots
+// 32 lanes per extended node, lane = history step t: one pass counts the surviving in-edges of snapshot node (t, i)
+// (both endpoints valid at t, ENC:108; closer than the radius, UTIL:88), a prefix sum over the H*Nt counts gives the
+// segment pointers, a second identical pass writes the compacted records.  For a fixed in-edge the H lanes read the
+// H contiguous positions / padding bytes of the sender: coalesced, and no per-candidate flag array or 44M-entry scan.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_aa_pass(int N, int Nt, int H, int TT, const int32_t* __restrict__ rowptr,
+                                                 const int32_t* __restrict__ csr_src, const int32_t* __restrict__ orig,
+                                                 const uint8_t* __restrict__ pad, const float* __restrict__ pos,
+                                                 const float* __restrict__ x, const float* __restrict__ rot, float radius_val,
+                                                 const float* __restrict__ radius_dev, int32_t* __restrict__ cnt_or_ptr, int32_t* __restrict__ aa_dst,
+                                                 float* __restrict__ geom) {
+  const int t = threadIdx.x & 31;
+  const int64_t node = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 5;
+  if (node >= Nt) return;
+  const float radius = radius_dev ? radius_dev[0] : radius_val;            // the fill pass re-reads what the count pass used
+  const int o = orig[node];
+  const bool tv = t < H;
+  const int tc = tv ? t : 0;
+  const bool dst_ok = tv && !pad[int64_t(o) * TT + tc];
+  const float px = pos[(int64_t(o) * TT + tc) * 2], py = pos[(int64_t(o) * TT + tc) * 2 + 1];
+  f4 R = f4{0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  if (FILL) {
+    R = *reinterpret_cast<const f4*>(rot + 4 * o);
+    k = tv ? cnt_or_ptr[int64_t(tc) * Nt + node] : 0;
   }
-}
-
-struct EdgeRef { int i, o, src; };
-// candidate p of the extended CSR -> (extended dst node i, its original actor o, source actor)
-__device__ __forceinline__ EdgeRef resolve_ext_edge(int p, int N, int A, int E, const int32_t* csr_src, const int32_t* csr_dst,
-                                                    const int32_t* rowptr, const int32_t* ext_rowptr, const int32_t* orig) {
-  EdgeRef r;
-  if (p < E) {
-    r.i = csr_dst[p]; r.o = r.i; r.src = csr_src[p];
-  } else {
-    int lo = N, hi = N + A - 1;                       // last fake row whose start <= p
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (ext_rowptr[mid] <= p) lo = mid; else hi = mid - 1;
-    }
-    r.i = lo; r.o = orig[lo];
-    r.src = csr_src[rowptr[r.o] + (p - ext_rowptr[lo])];
-  }
-  return r;
-}
-
-// One thread per extended edge, looping over the H snapshots: the edge is resolved once and the H positions /
-// padding bytes of both endpoints are contiguous in memory.  flags is zero-filled beforehand (memset).
-__global__ void k_aa_flags(int N, int A, int E, int H, int TT, const int32_t* __restrict__ counts,
-                           const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_dst,
-                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ext_rowptr,
-                           const int32_t* __restrict__ orig, const uint8_t* __restrict__ pad,
-                           const float* __restrict__ pos, float radius, uint8_t* __restrict__ flags) {
-  const int E_ext = counts[0];
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < E_ext; p += gridDim.x * blockDim.x) {
-    const EdgeRef r = resolve_ext_edge(p, N, A, E, csr_src, csr_dst, rowptr, ext_rowptr, orig);
-    const uint8_t* ps = pad + int64_t(r.src) * TT;
-    const uint8_t* pd = pad + int64_t(r.o) * TT;
-    const float* xs = pos + int64_t(r.src) * TT * 2;
-    const float* xd = pos + int64_t(r.o) * TT * 2;
-    for (int t = 0; t < H; ++t) {
-      uint8_t keep = 0;
-      if (!ps[t] && !pd[t]) {                                                        // subgraph, ENC:108
-        const float dx = xs[2 * t] - xd[2 * t], dy = xs[2 * t + 1] - xd[2 * t + 1];
-        keep = sqrtf(dx * dx + dy * dy) < radius;                                     // UTIL:88
+  const int beg = rowptr[o], end = rowptr[o + 1];
+  for (int p0 = beg; p0 < end; p0 += 32) {
+    const int mine = p0 + t < end ? csr_src[p0 + t] : 0;                   // coalesced chunk of sender ids
+    const int m = end - p0 < 32 ? end - p0 : 32;
+    for (int u = 0; u < m; ++u) {
+      const int s = __shfl(mine, u, 32);
+      const bool ok = dst_ok && !pad[int64_t(s) * TT + tc];
+      const float dx = pos[(int64_t(s) * TT + tc) * 2] - px, dy = pos[(int64_t(s) * TT + tc) * 2 + 1] - py;
+      if (ok && sqrtf(dx * dx + dy * dy) < radius) {
+        if (FILL) {
+          const float x0 = x[(int64_t(s) * H + tc) * 2], x1 = x[(int64_t(s) * H + tc) * 2 + 1];   // senders are real actors
+          f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
+          *reinterpret_cast<f4*>(geom + 4 * int64_t(k)) = g;
+          aa_dst[k] = tc * Nt + int(node);
+        }
+        ++k;
       }
-      flags[int64_t(t) * E_ext + p] = keep;
     }
   }
+  if (!FILL && tv) cnt_or_ptr[int64_t(tc) * Nt + node] = k;
 }
 
-__global__ void k_aa_compact(int N, int A, int E, int H, int TT, const int32_t* __restrict__ counts,
-                             const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_dst,
-                             const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ext_rowptr,
-                             const int32_t* __restrict__ orig, const float* __restrict__ x, const float* __restrict__ pos,
-                             const float* __restrict__ rot, const uint8_t* __restrict__ flags,
-                             const int32_t* __restrict__ cpos, int32_t* __restrict__ aa_dst, float* __restrict__ geom) {
-  const int E_ext = counts[0];
-  const int Nt = N + A;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < E_ext; p += gridDim.x * blockDim.x) {
-    const EdgeRef r = resolve_ext_edge(p, N, A, E, csr_src, csr_dst, rowptr, ext_rowptr, orig);
-    const f4 R = *reinterpret_cast<const f4*>(rot + 4 * r.o);          // [[R0,R1],[R2,R3]]
-    const float* xs = x + int64_t(r.src) * H * 2;                      // senders are real actors
-    const float* ps = pos + int64_t(r.src) * TT * 2;
-    const float* pd = pos + int64_t(r.o) * TT * 2;
-    for (int t = 0; t < H; ++t) {
-      const int64_t f = int64_t(t) * E_ext + p;
-      if (!flags[f]) continue;
-      const int q = cpos[f];
-      const float x0 = xs[2 * t], x1 = xs[2 * t + 1];
-      const float dx = ps[2 * t] - pd[2 * t], dy = ps[2 * t + 1] - pd[2 * t + 1];
-      f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
-      *reinterpret_cast<f4*>(geom + 4 * int64_t(q)) = g;
-      aa_dst[q] = t * Nt + r.i;
-    }
-  }
-}
-
-__global__ void k_aa_segptr(int Nt, int H, const int32_t* __restrict__ counts, const int32_t* __restrict__ ext_rowptr,
-                            const int32_t* __restrict__ cpos, int32_t* __restrict__ segptr) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r > H * Nt) return;
-  const int E_ext = counts[0];
-  const int t = r / Nt, i = r - t * Nt;
-  segptr[r] = (r == H * Nt) ? cpos[int64_t(H) * E_ext] : cpos[int64_t(t) * E_ext + ext_rowptr[i]];
-}
-
+// ---------------------------------------------------------------------------------------------- global / lane edges
 // global interactor edges: both endpoints valid at the reference step (AGG:41)
-__global__ void k_g_flags(int E, int TT, int tref, const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_dst,
-                          const uint8_t* __restrict__ pad, uint8_t* __restrict__ flags) {
+__global__ void k_g_flags(int E, int N, int TT, int tref, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_src,
+                          const uint8_t* __restrict__ pad, int32_t* __restrict__ csr_dst, uint8_t* __restrict__ flags) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > E) return;
-  flags[p] = (p < E) && !pad[int64_t(csr_src[p]) * TT + tref] && !pad[int64_t(csr_dst[p]) * TT + tref];
+  uint8_t keep = 0;
+  if (p < E) {
+    int lo = 0, hi = N;                                                    // row of position p: last i with rowptr[i] <= p
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (rowptr[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    csr_dst[p] = lo;
+    keep = !pad[int64_t(csr_src[p]) * TT + tref] && !pad[int64_t(lo) * TT + tref];
+  }
+  flags[p] = keep;
 }
 __global__ void k_g_compact(int E, int TT, int tref, const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_dst,
                             const float* __restrict__ pos, const float* __restrict__ rot, const float* __restrict__ ang,
@@ -230,12 +226,18 @@ __global__ void k_lane_feat(int L, int P, const float* __restrict__ lp, const fl
   feat[2 * l] = lp[(int64_t(l) * P + last) * 2] - lp[int64_t(l) * P * 2];
   feat[2 * l + 1] = lp[(int64_t(l) * P + last) * 2 + 1] - lp[int64_t(l) * P * 2 + 1];
 }
-__global__ void k_la_flags(int E_al, const int32_t* __restrict__ eid, const float* __restrict__ vec, float radius,
-                           uint8_t* __restrict__ flags) {
+__global__ void k_la_flags(int E_al, int N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ eid,
+                           const float* __restrict__ vec, float radius, int32_t* __restrict__ actor, uint8_t* __restrict__ flags) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > E_al) return;
   uint8_t keep = 0;
   if (p < E_al) {
+    int lo = 0, hi = N;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (rowptr[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    actor[p] = lo;
     const float vx = vec[2 * int64_t(eid[p])], vy = vec[2 * int64_t(eid[p]) + 1];
     keep = sqrtf(vx * vx + vy * vy) < radius;                                                 // ENC:198
   }
@@ -256,10 +258,12 @@ __global__ void k_la_compact(int E_al, const int32_t* __restrict__ actor, const 
   *reinterpret_cast<f4*>(geom + 4 * int64_t(q)) = g;
   la_dst[q] = i;
 }
-__global__ void k_collect_counts(int H, int E, int E_al, const int32_t* __restrict__ cpos_aa, const int32_t* __restrict__ cpos_g,
-                                 const int32_t* __restrict__ cpos_la, int32_t* __restrict__ counts) {
+__global__ void k_collect_counts(int64_t n_aa, int E, int E_al, const int32_t* __restrict__ aa_segptr, const int32_t* __restrict__ cpos_g,
+                                 const int32_t* __restrict__ cpos_la, float radius, int32_t* __restrict__ counts) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    counts[1] = cpos_aa[int64_t(H) * counts[0]];
+    counts[0] = 0;
+    reinterpret_cast<float*>(counts)[4] = radius;
+    counts[1] = aa_segptr[n_aa];
     counts[2] = cpos_g[E];
     counts[3] = cpos_la[E_al];
   }
@@ -274,40 +278,33 @@ static hipError_t scan_flags(void* tmp, size_t& tmp_bytes, const uint8_t* flags,
   return hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, FlagIter(flags, ByteToInt()), out, n, st);
 }
 
-static int bits_for(int n) {
-  int b = 1;
-  while ((int64_t(1) << b) <= n) ++b;
-  return b;
-}
-
 // phase-1 workspace layout, derived from the batch sizes alone (so both phases agree on it)
 struct PrepWs {
-  int32_t *k_in, *v_in, *csr_dst, *csr_src, *rowptr, *ext_rowptr, *orig, *eos, *pick_slot, *counts;
-  int32_t *la_k_in, *la_v_in, *la_actor, *la_eid, *la_rowptr;
-  uint8_t *nus, *flags_aa, *flags_g, *flags_la;
-  int32_t *cpos_aa, *cpos_g, *cpos_la;
+  int32_t *deg, *rowptr, *cursor, *csr_src, *csr_dst, *orig, *eos, *pick_slot, *counts;
+  int32_t *la_deg, *la_rowptr, *la_cursor, *la_eid, *la_actor;
+  int32_t *aa_segptr, *g_segptr, *la_segptr, *cpos_g, *cpos_la;
+  uint8_t *nus, *flags_g, *flags_la;
   float *x_fake, *lane_feat;
   void* cub_tmp;
-  int64_t cub_bytes, f_ub;
+  int64_t cub_bytes, n_aa;
   int64_t total;
   bool ok;
   PrepWs(const trajsde_batch* b, void* ws, int64_t ws_bytes) {
     Carver c(ws, ws_bytes);
     const int64_t N = b->N, A = b->A, E = b->E, Nt = N + A, H = b->H, Ea = b->E_al;
-    f_ub = H * 2 * E;                       // E_ext <= 2E
-    k_in = c.take<int32_t>(E); v_in = c.take<int32_t>(E); csr_dst = c.take<int32_t>(E); csr_src = c.take<int32_t>(E);
-    rowptr = c.take<int32_t>(N + 1); ext_rowptr = c.take<int32_t>(Nt + 1);
+    n_aa = H * Nt;
+    deg = c.take<int32_t>(N + 1); rowptr = c.take<int32_t>(N + 1); cursor = c.take<int32_t>(N + 1);
+    csr_src = c.take<int32_t>(E + 1); csr_dst = c.take<int32_t>(E + 1);
     orig = c.take<int32_t>(Nt); eos = c.take<int32_t>(Nt); pick_slot = c.take<int32_t>(Nt); counts = c.take<int32_t>(8);
-    la_k_in = c.take<int32_t>(Ea); la_v_in = c.take<int32_t>(Ea); la_actor = c.take<int32_t>(Ea); la_eid = c.take<int32_t>(Ea);
-    la_rowptr = c.take<int32_t>(N + 1);
-    nus = c.take<uint8_t>(Nt); flags_aa = c.take<uint8_t>(f_ub + 1); flags_g = c.take<uint8_t>(E + 1); flags_la = c.take<uint8_t>(Ea + 1);
-    cpos_aa = c.take<int32_t>(f_ub + 1); cpos_g = c.take<int32_t>(E + 1); cpos_la = c.take<int32_t>(Ea + 1);
-    x_fake = c.take<float>(A * H * 2 + 4); lane_feat = c.take<float>(int64_t(b->L) * 2);
-    size_t s1 = 0, s2 = 0, s3 = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s1, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
-                                       int(E > Ea ? E : Ea), 0, 32, (hipStream_t)0);
-    (void)scan_flags(nullptr, s2, nullptr, nullptr, int(f_ub + 1), (hipStream_t)0);
-    (void)s3;
+    la_deg = c.take<int32_t>(N + 1); la_rowptr = c.take<int32_t>(N + 1); la_cursor = c.take<int32_t>(N + 1);
+    la_eid = c.take<int32_t>(Ea + 1); la_actor = c.take<int32_t>(Ea + 1);
+    aa_segptr = c.take<int32_t>(n_aa + 1); g_segptr = c.take<int32_t>(N + 1); la_segptr = c.take<int32_t>(N + 1);
+    cpos_g = c.take<int32_t>(E + 1); cpos_la = c.take<int32_t>(Ea + 1);
+    nus = c.take<uint8_t>(Nt); flags_g = c.take<uint8_t>(E + 1); flags_la = c.take<uint8_t>(Ea + 1);
+    x_fake = c.take<float>(A * H * 2 + 4); lane_feat = c.take<float>(int64_t(b->L) * 2 + 4);
+    size_t s1 = 0, s2 = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, s1, (int32_t*)nullptr, (int32_t*)nullptr, int(n_aa + 1), (hipStream_t)0);
+    (void)scan_flags(nullptr, s2, nullptr, nullptr, int((E > Ea ? E : Ea) + 1), (hipStream_t)0);
     cub_bytes = int64_t(s1 > s2 ? s1 : s2) + 256;
     cub_tmp = c.take<uint8_t>(cub_bytes);
     total = c.off + 256;
@@ -317,16 +314,15 @@ struct PrepWs {
 
 struct EdgeWs {
   float *aa_geom, *g_geom, *la_geom;
-  int32_t *aa_dst, *aa_segptr, *g_src, *g_dst, *g_segptr, *la_dst, *la_segptr;
+  int32_t *aa_dst, *g_src, *g_dst, *la_dst;
   int64_t total;
   bool ok;
   EdgeWs(const trajsde_batch* b, const trajsde_graph* g, void* ws, int64_t ws_bytes) {
     Carver c(ws, ws_bytes);
+    (void)b;
     aa_geom = c.take<float>(4 * int64_t(g->E_aa) + 4); aa_dst = c.take<int32_t>(g->E_aa + 1);
-    aa_segptr = c.take<int32_t>(int64_t(b->H) * g->Nt + 1);
     g_geom = c.take<float>(4 * int64_t(g->E_g) + 4); g_src = c.take<int32_t>(g->E_g + 1); g_dst = c.take<int32_t>(g->E_g + 1);
-    g_segptr = c.take<int32_t>(b->N + 1);
-    la_geom = c.take<float>(4 * int64_t(g->E_la) + 4); la_dst = c.take<int32_t>(g->E_la + 1); la_segptr = c.take<int32_t>(b->N + 1);
+    la_geom = c.take<float>(4 * int64_t(g->E_la) + 4); la_dst = c.take<int32_t>(g->E_la + 1);
     total = c.off + 256;
     ok = c.ok;
   }
@@ -334,15 +330,31 @@ struct EdgeWs {
 
 static int check_batch(const trajsde_batch* b) {
   TS_REQUIRE(b != nullptr, "batch: null");
-  TS_REQUIRE(b->N > 0 && b->A >= 0 && b->H > 0 && b->TT >= b->H, "batch: bad sizes");
+  TS_REQUIRE(b->N > 0 && b->A >= 0 && b->H > 0 && b->H <= 32 && b->TT >= b->H, "batch: bad sizes (H <= 32)");
   TS_REQUIRE(b->E >= 0 && b->E_al >= 0 && b->L >= 0, "batch: negative sizes");
-  TS_REQUIRE(int64_t(b->H) * 2 * b->E < (int64_t(1) << 31) - 2, "batch: too many (t, edge) candidates for int32 positions");
+  TS_REQUIRE(int64_t(b->H) * b->E < (int64_t(1) << 31) - 2, "batch: too many (t, edge) candidates for int32 positions");
   TS_REQUIRE(b->x && b->positions && b->padding_mask && b->bos_mask && b->rotate_angles && b->batch && b->source,
              "batch: null actor tensor");
   TS_REQUIRE(b->A == 0 || b->agent_index, "batch: null agent_index");   // A == 0: no fake agents (forward_ood, ENC:204-370)
   TS_REQUIRE(b->E == 0 || b->edge_index, "batch: null edge_index");
   TS_REQUIRE(b->E_al == 0 || (b->lane_actor_index && b->lane_actor_vectors && b->lane_positions && b->lane_paddings),
              "batch: null lane tensor");
+  return TRAJSDE_OK;
+}
+
+// CSR by target: degree histogram -> exclusive scan -> scatter -> canonical row order
+static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* rowptr, int32_t* cursor, int32_t* out, bool edge_ids,
+                     void* cub_tmp, int64_t cub_bytes, hipStream_t st) {
+  TS_HIP(hipMemsetAsync(deg, 0, size_t(N + 1) * sizeof(int32_t), st));
+  if (E > 0) k_degree<<<cdiv(E, 256), 256, 0, st>>>(ei, E, deg);
+  size_t tmp = size_t(cub_bytes);
+  TS_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, deg, rowptr, N + 1, st));
+  TS_HIP(hipMemcpyAsync(cursor, rowptr, size_t(N + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  if (E > 0) {
+    k_scatter<<<cdiv(E, 256), 256, 0, st>>>(ei, E, cursor, out, edge_ids ? 1 : 0);
+    k_row_sort<<<N < 4096 ? N : 4096, 256, 0, st>>>(rowptr, N, out);
+  }
+  TS_LAUNCH_CHECK("build_csr");
   return TRAJSDE_OK;
 }
 
@@ -377,54 +389,45 @@ int trajsde_graph_prepare(const trajsde_batch* b, const float* rot, float radius
   NoiseArg na{0, nullptr, nullptr};
   if (fake_noise) { na.seed = fake_noise->seed; na.z = fake_noise->z; na.row_ids = fake_noise->row_ids; }
 
-  // CSR by target of edge_index
-  if (E > 0) {
-    k_split_edges<<<cdiv(E, 256), 256, 0, st>>>(b->edge_index, E, /*row_key=*/1, w.k_in, w.v_in, 0);
-    size_t tmp = size_t(w.cub_bytes);
-    TS_HIP(hipcub::DeviceRadixSort::SortPairs(w.cub_tmp, tmp, w.k_in, w.csr_dst, w.v_in, w.csr_src, E, 0, bits_for(N), st));
-  }
-  k_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(w.csr_dst, E, N, w.rowptr);
+  if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.cursor, w.csr_src, false, w.cub_tmp, w.cub_bytes, st)) return rc;
   k_ext_nodes<<<cdiv(Nt, 256), 256, 0, st>>>(N, A, H, b->agent_index, b->batch, b->source, b->bos_mask, w.orig, w.nus, w.eos, w.pick_slot);
   if (A > 0) {
     k_agent_slots<<<cdiv(A, 256), 256, 0, st>>>(A, b->agent_index, w.pick_slot);
     k_fake_x<<<cdiv(A * ((2 * H + 3) / 4), 256), 256, 0, st>>>(A, H, b->x, b->agent_index, na, w.x_fake);
   }
-  k_ext_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, A, E, w.rowptr, b->agent_index, w.ext_rowptr, w.counts);
-  // 21 snapshots: flags + prefix sum
-  TS_HIP(hipMemsetAsync(w.flags_aa, 0, size_t(w.f_ub + 1), st));
-  k_aa_flags<<<cdiv(2 * int64_t(E) + 1, 256), 256, 0, st>>>(N, A, E, H, TT, w.counts, w.csr_src, w.csr_dst, w.rowptr, w.ext_rowptr,
-                                                            w.orig, b->padding_mask, b->positions, radius, w.flags_aa);
+  // 21 snapshots: count pass + prefix sum -> segment pointers
+  k_aa_pass<false><<<cdiv(int64_t(Nt) * 32, 256), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, b->padding_mask, b->positions,
+                                                                b->x, rot, radius, nullptr, w.aa_segptr, nullptr, nullptr);
+  TS_HIP(hipMemsetAsync(w.aa_segptr + w.n_aa, 0, sizeof(int32_t), st));
   {
     size_t tmp = size_t(w.cub_bytes);
-    TS_HIP(scan_flags(w.cub_tmp, tmp, w.flags_aa, w.cpos_aa, int(w.f_ub + 1), st));
+    TS_HIP(hipcub::DeviceScan::ExclusiveSum(w.cub_tmp, tmp, w.aa_segptr, w.aa_segptr, int(w.n_aa + 1), st));
   }
   // global interactor edges
-  k_g_flags<<<cdiv(E + 1, 256), 256, 0, st>>>(E, TT, H - 1, w.csr_src, w.csr_dst, b->padding_mask, w.flags_g);
+  k_g_flags<<<cdiv(E + 1, 256), 256, 0, st>>>(E, N, TT, H - 1, w.rowptr, w.csr_src, b->padding_mask, w.csr_dst, w.flags_g);
   {
     size_t tmp = size_t(w.cub_bytes);
     TS_HIP(scan_flags(w.cub_tmp, tmp, w.flags_g, w.cpos_g, E + 1, st));
   }
-  // lane-actor edges sorted by actor
+  k_segptr_from_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, w.rowptr, w.cpos_g, w.g_segptr);
+  // lane-actor edges grouped by actor
   if (b->L > 0) k_lane_feat<<<cdiv(b->L, 256), 256, 0, st>>>(b->L, b->lane_pts, b->lane_positions, b->lane_paddings, w.lane_feat);
-  if (Ea > 0) {
-    k_split_edges<<<cdiv(Ea, 256), 256, 0, st>>>(b->lane_actor_index, Ea, /*row_key=*/1, w.la_k_in, w.la_v_in, 1);
-    size_t tmp = size_t(w.cub_bytes);
-    TS_HIP(hipcub::DeviceRadixSort::SortPairs(w.cub_tmp, tmp, w.la_k_in, w.la_actor, w.la_v_in, w.la_eid, Ea, 0, bits_for(N), st));
-  }
-  k_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(w.la_actor, Ea, N, w.la_rowptr);
-  k_la_flags<<<cdiv(Ea + 1, 256), 256, 0, st>>>(Ea, w.la_eid, b->lane_actor_vectors, radius, w.flags_la);
+  if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_cursor, w.la_eid, true, w.cub_tmp, w.cub_bytes, st)) return rc;
+  k_la_flags<<<cdiv(Ea + 1, 256), 256, 0, st>>>(Ea, N, w.la_rowptr, w.la_eid, b->lane_actor_vectors, radius, w.la_actor, w.flags_la);
   {
     size_t tmp = size_t(w.cub_bytes);
     TS_HIP(scan_flags(w.cub_tmp, tmp, w.flags_la, w.cpos_la, Ea + 1, st));
   }
-  k_collect_counts<<<1, 64, 0, st>>>(H, E, Ea, w.cpos_aa, w.cpos_g, w.cpos_la, w.counts);
+  k_segptr_from_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, w.la_rowptr, w.cpos_la, w.la_segptr);
+  k_collect_counts<<<1, 64, 0, st>>>(w.n_aa, E, Ea, w.aa_segptr, w.cpos_g, w.cpos_la, radius, w.counts);
   TS_LAUNCH_CHECK("graph_prepare kernels");
   int32_t h[4];
   TS_HIP(hipMemcpyAsync(h, w.counts, sizeof(h), hipMemcpyDeviceToHost, st));
   TS_HIP(hipStreamSynchronize(st));
   std::memset(out, 0, sizeof(*out));
-  out->Nt = Nt; out->E_ext = h[0]; out->E_aa = h[1]; out->E_g = h[2]; out->E_la = h[3];
+  out->Nt = Nt; out->E_ext = E; out->E_aa = h[1]; out->E_g = h[2]; out->E_la = h[3];
   out->orig = w.orig; out->nus_mask = w.nus; out->eos_idx = w.eos; out->pick_slot = w.pick_slot; out->x_fake = w.x_fake;
+  out->aa_segptr = w.aa_segptr; out->g_segptr = w.g_segptr; out->la_segptr = w.la_segptr;
   return TRAJSDE_OK;
 }
 
@@ -443,21 +446,18 @@ int trajsde_graph_compact(const trajsde_batch* b, const float* rot, void* ws, in
   if (!w.ok || !e.ok) return fail(TRAJSDE_ERR_WORKSPACE, "graph_compact: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int N = b->N, A = b->A, E = b->E, H = b->H, TT = b->TT, Ea = b->E_al, Nt = N + A;
-  k_aa_compact<<<cdiv(int64_t(out->E_ext) + 1, 256), 256, 0, st>>>(N, A, E, H, TT, w.counts, w.csr_src, w.csr_dst, w.rowptr, w.ext_rowptr, w.orig, b->x,
-                                     b->positions, rot, w.flags_aa, w.cpos_aa, e.aa_dst, e.aa_geom);
-  k_aa_segptr<<<cdiv(int64_t(H) * Nt + 1, 256), 256, 0, st>>>(Nt, H, w.counts, w.ext_rowptr, w.cpos_aa, e.aa_segptr);
+  k_aa_pass<true><<<cdiv(int64_t(Nt) * 32, 256), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, b->padding_mask, b->positions,
+                                                               b->x, rot, 0.f, reinterpret_cast<const float*>(w.counts) + 4, w.aa_segptr, e.aa_dst, e.aa_geom);
   if (E > 0)
     k_g_compact<<<cdiv(E, 256), 256, 0, st>>>(E, TT, H - 1, w.csr_src, w.csr_dst, b->positions, rot, b->rotate_angles, w.flags_g,
                                               w.cpos_g, e.g_src, e.g_dst, e.g_geom);
-  k_segptr_from_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, w.rowptr, w.cpos_g, e.g_segptr);
   if (Ea > 0)
     k_la_compact<<<cdiv(Ea, 256), 256, 0, st>>>(Ea, w.la_actor, w.la_eid, b->lane_actor_index, b->lane_actor_vectors, w.lane_feat,
                                                 rot, w.flags_la, w.cpos_la, e.la_dst, e.la_geom);
-  k_segptr_from_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, w.la_rowptr, w.cpos_la, e.la_segptr);
   TS_LAUNCH_CHECK("graph_compact kernels");
-  out->aa_geom = e.aa_geom; out->aa_dst = e.aa_dst; out->aa_segptr = e.aa_segptr;
-  out->g_geom = e.g_geom; out->g_src = e.g_src; out->g_dst = e.g_dst; out->g_segptr = e.g_segptr;
-  out->la_geom = e.la_geom; out->la_dst = e.la_dst; out->la_segptr = e.la_segptr;
+  out->aa_geom = e.aa_geom; out->aa_dst = e.aa_dst;
+  out->g_geom = e.g_geom; out->g_src = e.g_src; out->g_dst = e.g_dst;
+  out->la_geom = e.la_geom; out->la_dst = e.la_dst;
   return TRAJSDE_OK;
 }
 

@@ -184,7 +184,7 @@ int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, cons
                             const float* step_tab /*HOST [H,8]*/, const trajsde_noise* noise, void* ws, int64_t ws_bytes,
                             float* local_embed, float* diff_pick, float* aa_out_user, float* latent_ys, void* stream_) {
   TS_REQUIRE(b && g && rot && blob && step_tab && ws && local_embed && diff_pick, "encoder_forward: null pointer");
-  TS_REQUIRE(g->aa_segptr && g->la_segptr && g->orig, "encoder_forward: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_forward: graph not compacted (call trajsde_graph_compact)");
   TS_REQUIRE(b->A > 0 && g->Nt == b->N + b->A, "encoder_forward: graph was prepared without the fake-agent rows");
   EncWs w(b, g, ws, ws_bytes);
   if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_forward: workspace too small");
@@ -210,7 +210,7 @@ int trajsde_encoder_forward_ood(const trajsde_batch* b, const trajsde_graph* g, 
                                 const float* step_tab /*HOST [H,8]*/, const trajsde_noise* noise, int n_samples, void* ws,
                                 int64_t ws_bytes, float* local_embed, float* stds, void* stream_) {
   TS_REQUIRE(b && g && rot && blob && step_tab && ws && local_embed && stds, "encoder_forward_ood: null pointer");
-  TS_REQUIRE(g->aa_segptr && g->la_segptr && g->orig, "encoder_forward_ood: graph not compacted");
+  TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_forward_ood: graph not compacted");
   TS_REQUIRE(b->A == 0 && g->Nt == b->N, "encoder_forward_ood: prepare the graph with A = 0 (no fake agents)");
   TS_REQUIRE(n_samples >= 1, "encoder_forward_ood: n_samples < 1");
   if (ws_bytes < trajsde_encoder_ood_ws_bytes(b, g, n_samples)) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_forward_ood: workspace too small");
@@ -242,7 +242,7 @@ int64_t trajsde_aggregator_ws_bytes(const trajsde_batch* b, const trajsde_graph*
 int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers, int num_modes,
                                const float* local_embed, void* ws, int64_t ws_bytes, float* global_embed, void* stream_) {
   TS_REQUIRE(b && g && blob && local_embed && ws && global_embed, "aggregator_forward: null pointer");
-  TS_REQUIRE(g->g_segptr, "aggregator_forward: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(g->g_src && g->g_segptr, "aggregator_forward: graph not compacted (call trajsde_graph_compact)");
   TS_REQUIRE(num_layers >= 0 && num_modes > 0, "aggregator_forward: bad layer/mode count");
   AggWs w(b, g, ws, ws_bytes);
   if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "aggregator_forward: workspace too small");
