@@ -33,7 +33,12 @@ from trajsde_amd.synth import CONFIGS, synth  # noqa: E402
 
 WORKLOAD = "config2"                 # "Synthetic batch of 64 scenes x 128 agents, K=6, 20 steps, 1xMI355X inference-only"
 FLOP_PER_EDGE = 41.7e3               # neighbour embed 25.1k + k,v 16.4k + dot 0.256k per (t, edge)
-MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak (no xf32 on gfx950)
+# The edge kernel evaluates its fp32 GEMMs as bf16x6 split products on the bf16 matrix cores (csrc/tile.hpp): six
+# v_mfma_f32_16x16x32_bf16 per fp32 product, fp32-accurate.  Its roofline is therefore the dense bf16 MFMA peak of
+# MI355X_MICROARCH.md (2.5 PFLOP/s) divided by 6, expressed in algorithmic (fp32) FLOP/s.
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+SPLIT_PRODUCTS = 6
+PEAK_FP32_EQUIV_TFLOPS = MFMA_BF16_PEAK_TFLOPS / SPLIT_PRODUCTS
 CPU_SAMPLE_SCENES = 16
 
 
@@ -70,7 +75,8 @@ def cpu_baseline(model, cfg, spec, gpu_loc_fn):
     res = {}
     for name, src in (("gpu", (o_gpu["loc"].cpu(), o_gpu["reg_mask"].cpu(), data_gpu.y.cpu())), ("cpu", (out["loc"], out["reg_mask"], out["y"]))):
         loc, mask, y = src
-        ade, fde = ADE_T("nuScenes", [T_END(loc), T_END(loc)]), FDE_T("nuScenes", [T_END(loc), T_END(loc)])
+        last = loc.shape[2] - 1
+        ade, fde = ADE_T("nuScenes", [last, last]), FDE_T("nuScenes", [last, last])
         args = (loc[:, idx, :, :2], y[idx], mask[idx], batch["source"])
         ade.update(*args)
         fde.update(*args)
@@ -82,10 +88,6 @@ def cpu_baseline(model, cfg, spec, gpu_loc_fn):
             "sample": f"{CPU_SAMPLE_SCENES} of the 64 scenes of {WORKLOAD} (same generator and seed), oracle/restate.py, "
                       f"1 warm-up + 3 timed forwards, median {med:.3f} s/forward, torch {torch.__version__} fp32"}
     return base, match
-
-
-def T_END(loc):
-    return loc.shape[2] - 1
 
 
 def main():
@@ -134,8 +136,8 @@ def main():
             y0s.append(b.y.clone())
     batch = batches[0]
 
-    def step(i):
-        k = i % n_streams
+    def step(i, single_stream=False):
+        k = 0 if single_stream else i % n_streams
         b = batches[k]
         with torch.cuda.stream(streams[k]):
             b.y = y0s[k]                                                      # forward rotates y in place (MODEL:83-84)
@@ -169,7 +171,7 @@ def main():
         avg_s = (total_ms / max(n_launch, 1)) * 1e-3
         achieved = (FLOP_PER_EDGE * e_aa / avg_s) * 1e-12 if avg_s > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
         if os.path.isfile(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get("k_edge_kv[aa]", {}).get("hbm_bytes_per_launch")
@@ -184,10 +186,14 @@ def main():
                        "scenes_per_gpu": scenes, "agents_per_scene": skw["n"], "num_modes": spec["num_modes"],
                        "future_steps": spec["future_steps"], "aa_edges_per_step": int(e_aa), "parallelism": f"scene-shard x{world}",
                        "streams_per_gpu": n_streams},
-            "roofline": {"kernel": "k_edge_kv[aa] (agent-agent edge embedding + k,v + logits, fp32 MFMA 16x16x4)",
-                         "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                         "avg_launch_ms": avg_s * 1e3, "launches": n_launch, "flop_per_edge": FLOP_PER_EDGE},
+            "roofline": {"kernel": "k_edge_kv[aa] (agent-agent edge embedding + k,v + logits; bf16x6 split-precision MFMA 16x16x32, fp32-accurate)",
+                         "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_EQUIV_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_EQUIV_TFLOPS, "traffic": traffic,
+                         "avg_launch_ms": avg_s * 1e3, "launches": n_launch, "flop_per_edge": FLOP_PER_EDGE,
+                         "peak_note": "algorithmic fp32 FLOP/s; peak = 2500 TFLOP/s dense bf16 MFMA / 6 bf16 products per fp32 product "
+                                      "(the same kernel on exact fp32 MFMA, TRAJSDE_EDGE_FP32=1, ran at 110-113 TFLOP/s = 0.70-0.72 of the "
+                                      "157.3 TFLOP/s fp32 matrix peak)",
+                         "bf16_mfma_tflops": achieved * SPLIT_PRODUCTS * (40960.0 / 41700.0)},
         }
         if not args.no_cpu_baseline and world == 1:
             def gpu_fn(b_cpu, seed):
@@ -198,11 +204,25 @@ def main():
             base, match = cpu_baseline(model, cfg, spec, gpu_fn)
             line["cpu_baseline"] = base
             line["minade_match"] = match
+        # the same kernel measured alone (one stream, nothing overlapping it): the figure to hold against the rocprof
+        # kernel-trace summary of a --streams 1 run; with several streams the events above also see co-running kernels
+        lib.trajsde_profile_mode(1)
+        with torch.no_grad():
+            for i in range(5):
+                step(800 + i, single_stream=True)
+        torch.cuda.synchronize()
+        lib.trajsde_profile_mode(0)
+        iso_n, iso_ms, _ = _lib.profile_report().get("k_edge_kv[aa]", (0, 0.0, True))
+        if iso_n:
+            iso = FLOP_PER_EDGE * e_aa / (iso_ms / iso_n * 1e-3) * 1e-12
+            line["roofline_isolated"] = {"kernel": "k_edge_kv[aa]", "streams": 1, "achieved": iso, "peak": PEAK_FP32_EQUIV_TFLOPS,
+                                         "unit": "TFLOP/s", "frac": iso / PEAK_FP32_EQUIV_TFLOPS, "avg_launch_ms": iso_ms / iso_n,
+                                         "launches": iso_n}
         if args.kernel_table:
             lib.trajsde_profile_mode(2)
             with torch.no_grad():
                 for i in range(3):
-                    step(900 + i)
+                    step(900 + i, single_stream=True)
             torch.cuda.synchronize()
             lib.trajsde_profile_mode(0)
             tab = _lib.profile_report()
