@@ -87,13 +87,14 @@ int trajsde_rotate(const float* rotate_angles, int32_t N, const float* y /*[N,F,
                    float* rotate_mat /*[N,2,2]*/, float* y_rot /*[N,F,2] or null*/, void* stream);
 
 /* ---- graph preparation (ENC:88-118 fake agents + per-step subgraph + radius drop; AGG:41; ENC:198;
- *      UTIL:83-92).  Builds, on device: CSR-by-target of edge_index, the virtual rows of the fake
- *      agents, the compacted (t, edge) list of the 21 agent-agent snapshots with pre-rotated geometry,
- *      the compacted global and lane-actor edge lists, and their segment pointers.
+ *      UTIL:83-92).  Builds, on device: CSR-by-target of edge_index (counting sort, rows in canonical
+ *      ascending-source order), the virtual rows of the fake agents, the compacted (t, edge) list of the
+ *      21 agent-agent snapshots with pre-rotated geometry (count pass, prefix sum, fill pass), the
+ *      compacted global and lane-actor edge lists, and their segment pointers.
  *      Synchronises the stream once to return the three edge counts. */
 typedef struct {
   int32_t Nt;        /* N + A                                   */
-  int32_t E_ext;     /* edges incl. duplicated agent in-edges   */
+  int32_t E_ext;     /* = E (the fake agents' in-edges are virtual) */
   int32_t E_aa;      /* surviving (t,edge) pairs over 21 steps  */
   int32_t E_g;       /* global-interactor edges                 */
   int32_t E_la;      /* lane-actor edges within the radius      */
