@@ -104,16 +104,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("TRAJSDE_BENCH_FORCE_DIST") == "1":      # the latter: exercise the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if dist is not None else 0)
     lib = _lib.lib()
 
     spec = CONFIGS[WORKLOAD]
@@ -230,10 +233,12 @@ def main():
             print(f"# per-kernel device time over 3 forwards (HIP events), total {tot / 3:.3f} ms/forward", file=sys.stderr)
             for tag, (n, ms, dom) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
                 print(f"#   {tag:24s} launches/fwd {n / 3:6.1f}  ms/fwd {ms / 3:8.3f}  {100 * ms / tot:5.1f}%", file=sys.stderr)
-        print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)                                   # the one JSON line, last on stdout
 
 
 if __name__ == "__main__":

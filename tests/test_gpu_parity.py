@@ -90,6 +90,46 @@ def test_forward_matches_oracle_on_synthetic(S, n, L, K, T, max_t, kw, dev):
     assert torch.equal(o["reg_mask"].cpu(), want["reg_mask"])
 
 
+def test_degenerate_graphs(dev):
+    """no agent-agent edges at all (every scene has a single actor), no lane-actor edges, duplicated edges"""
+    from trajsde_amd.data import collate
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    K, T = 2, 5
+    model, cfg = H.build_model(K, T, 0.5, init_seed=4)
+    lonely = collate([synth(S=1, n=1, L=2, F=T, box=30.0, seed=60 + i) for i in range(3)])          # E = 0
+    far = synth(S=2, n=5, L=3, F=T, box=40.0, seed=70)
+    far["lane_actor_vectors"] = far["lane_actor_vectors"] + 1000.0                                    # every lane beyond the radius
+    dup = synth(S=1, n=6, L=3, F=T, box=40.0, seed=71)
+    dup["edge_index"] = torch.cat([dup["edge_index"], dup["edge_index"][:, :7]], dim=1)               # repeated edges count twice
+    dup["edge_index"] = dup["edge_index"][:, torch.randperm(dup["edge_index"].shape[1], generator=torch.Generator().manual_seed(3))]
+    gpu = None
+    for batch in (lonely, far, dup):
+        want = H.oracle_forward(model, cfg, batch, noise_seed=8)
+        gpu = gpu or model.to(dev)
+        o = gpu(batch.to(dev), noise=NoiseSpec(seed=8))
+        for key in ("loc", "pi", "diff_in", "diff_out"):
+            assert H.maxdiff(o[key].cpu(), want[key]) <= TOL, key
+
+
+def test_edge_order_invariance(dev):
+    """the CSR rows are put in canonical order, so permuting the input edge list changes nothing, bit for bit"""
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    K, T = 2, 5
+    model, cfg = H.build_model(K, T, 0.5, init_seed=4)
+    model = model.to(dev)
+    a = synth(S=3, n=12, L=5, F=T, box=60.0, seed=81, history_dropout=0.3)
+    b = H.clone_batch(a)
+    g = torch.Generator().manual_seed(5)
+    b["edge_index"] = a["edge_index"][:, torch.randperm(a["edge_index"].shape[1], generator=g)]
+    perm = torch.randperm(a["lane_actor_index"].shape[1], generator=g)
+    b["lane_actor_index"], b["lane_actor_vectors"] = a["lane_actor_index"][:, perm], a["lane_actor_vectors"][perm]
+    oa = model(a.to(dev), noise=NoiseSpec(seed=3))
+    ob = model(b.to(dev), noise=NoiseSpec(seed=3))
+    assert torch.equal(oa["loc"], ob["loc"]) and torch.equal(oa["pi"], ob["pi"])
+
+
 def test_scene_independence_and_sharding_invariance(dev):
     """scenes never interact; with global row ids the Philox stream survives re-sharding"""
     from trajsde_amd.data import collate

@@ -222,7 +222,9 @@ __global__ __launch_bounds__(512) void k_global_edge(const float* __restrict__ i
 }
 
 // ------------------------------------------------------------------------------------------------ segment softmax
-// torch_geometric.utils.softmax + add-aggregate: alpha = exp(l - max_seg) / (sum_seg + 1e-16); out = sum alpha * v
+// torch_geometric.utils.softmax + add-aggregate: alpha = exp(l - max_seg) / (sum_seg + 1e-16); out = sum alpha * v.
+// Single pass over the slab with an online softmax in chunks of 8 edges (8 logits + 8 value rows in flight per
+// lane); the running maximum is the segment maximum at the end, so the result equals the two-pass form up to rounding.
 __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restrict__ segptr, const float* __restrict__ logits,
                                                          const float* __restrict__ v, int64_t R, float* __restrict__ agg) {
   const int lane = threadIdx.x & 63;
@@ -230,28 +232,32 @@ __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restri
   const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (node >= R) return;
   const int beg = segptr[node], end = segptr[node + 1];
-  float m = -INFINITY;
-  for (int e = beg; e < end; ++e) m = fmaxf(m, logits[int64_t(e) * 8 + slot]);
-  float s = 0.f, acc = 0.f;
-  int e = beg;
-  for (; e + 4 <= end; e += 4) {
-    float p[4], vv[4];
+  float m = -INFINITY, s = 0.f, acc = 0.f;
+  for (int e0 = beg; e0 < end; e0 += 8) {
+    float p[8], vv[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      p[u] = logits[int64_t(e + u) * 8 + slot];
-      vv[u] = v[int64_t(e + u) * 64 + lane];
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u < end ? e0 + u : end - 1;
+      p[u] = logits[int64_t(e) * 8 + slot];
+      vv[u] = v[int64_t(e) * 64 + lane];
     }
+    float cm = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
+      p[u] = e0 + u < end ? p[u] : -INFINITY;
+      cm = fmaxf(cm, p[u]);
+    }
+    const float mn = fmaxf(m, cm);
+    const float sc = fast_exp(m - mn);
+    m = mn;
+    s *= sc;
+    acc *= sc;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
       const float ex = fast_exp(p[u] - m);
       s += ex;
       acc = fmaf(ex, vv[u], acc);
     }
-  }
-  for (; e < end; ++e) {
-    const float ex = fast_exp(logits[int64_t(e) * 8 + slot] - m);
-    s += ex;
-    acc = fmaf(ex, v[int64_t(e) * 64 + lane], acc);
   }
   agg[node * 64 + lane] = end > beg ? acc / (s + 1e-16f) : 0.f;
 }

@@ -48,19 +48,33 @@ __global__ void k_scatter(const int64_t* __restrict__ ei, int E, int32_t* __rest
   const int p = atomicAdd(&cursor[int(ei[int64_t(E) + e])], 1);
   out[p] = store_edge_id ? e : int32_t(ei[e]);                             // row 0 = source
 }
+// lane-actor edges: value = (lane id << 32) | edge id, so that rows sort by lane first (canonical under permutations
+// of the input list) and the edge id is still at hand for the vector lookup
+__global__ void k_scatter_lane(const int64_t* __restrict__ lai, int E, int32_t* __restrict__ cursor, int64_t* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int p = atomicAdd(&cursor[int(lai[int64_t(E) + e])], 1);
+  out[p] = (lai[e] << 32) | int64_t(e);
+}
+__global__ void k_unpack_eid(const int64_t* __restrict__ packed, int E, int32_t* __restrict__ eid) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E) eid[e] = int32_t(packed[e] & 0xFFFFFFFFll);
+}
 // ascending sort of every CSR row; one workgroup per row (grid-stride), bitonic network in LDS (rows up to 4096
 // entries) or in place in global memory for longer rows
-__global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ rowptr, int n_rows, int32_t* __restrict__ vals) {
-  __shared__ int32_t buf[4096];
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals) {
+  __shared__ T buf[4096];
+  const T INF = sizeof(T) == 8 ? T(INT64_MAX) : T(INT32_MAX);
   for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
     const int beg = rowptr[row], n = rowptr[row + 1] - beg;
     if (n <= 1) continue;
     int P = 2;
     while (P < n) P <<= 1;
     const bool in_lds = P <= 4096;
-    int32_t* a = in_lds ? buf : vals + beg;
+    T* a = in_lds ? buf : vals + beg;
     if (in_lds) {
-      for (int i = threadIdx.x; i < P; i += blockDim.x) buf[i] = i < n ? vals[beg + i] : INT32_MAX;
+      for (int i = threadIdx.x; i < P; i += blockDim.x) buf[i] = i < n ? vals[beg + i] : INF;
     }
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1)
@@ -69,7 +83,7 @@ __global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ ro
           const int l = i ^ j;
           if (l > i) {
             // virtual padding with +inf for the global-memory variant
-            const int32_t vi = (in_lds || i < n) ? a[i] : INT32_MAX, vl = (in_lds || l < n) ? a[l] : INT32_MAX;
+            const T vi = (in_lds || i < n) ? a[i] : INF, vl = (in_lds || l < n) ? a[l] : INF;
             const bool up = (i & k) == 0;
             if ((vi > vl) == up) {
               if (in_lds || i < n) a[i] = vl;
@@ -282,6 +296,7 @@ static hipError_t scan_flags(void* tmp, size_t& tmp_bytes, const uint8_t* flags,
 struct PrepWs {
   int32_t *deg, *rowptr, *cursor, *csr_src, *csr_dst, *orig, *eos, *pick_slot, *counts;
   int32_t *la_deg, *la_rowptr, *la_cursor, *la_eid, *la_actor;
+  int64_t* la_pack;
   int32_t *aa_segptr, *g_segptr, *la_segptr, *cpos_g, *cpos_la;
   uint8_t *nus, *flags_g, *flags_la;
   float *x_fake, *lane_feat;
@@ -297,7 +312,7 @@ struct PrepWs {
     csr_src = c.take<int32_t>(E + 1); csr_dst = c.take<int32_t>(E + 1);
     orig = c.take<int32_t>(Nt); eos = c.take<int32_t>(Nt); pick_slot = c.take<int32_t>(Nt); counts = c.take<int32_t>(8);
     la_deg = c.take<int32_t>(N + 1); la_rowptr = c.take<int32_t>(N + 1); la_cursor = c.take<int32_t>(N + 1);
-    la_eid = c.take<int32_t>(Ea + 1); la_actor = c.take<int32_t>(Ea + 1);
+    la_eid = c.take<int32_t>(Ea + 1); la_actor = c.take<int32_t>(Ea + 1); la_pack = c.take<int64_t>(Ea + 1);
     aa_segptr = c.take<int32_t>(n_aa + 1); g_segptr = c.take<int32_t>(N + 1); la_segptr = c.take<int32_t>(N + 1);
     cpos_g = c.take<int32_t>(E + 1); cpos_la = c.take<int32_t>(Ea + 1);
     nus = c.take<uint8_t>(Nt); flags_g = c.take<uint8_t>(E + 1); flags_la = c.take<uint8_t>(Ea + 1);
@@ -343,16 +358,20 @@ static int check_batch(const trajsde_batch* b) {
 }
 
 // CSR by target: degree histogram -> exclusive scan -> scatter -> canonical row order
-static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* rowptr, int32_t* cursor, int32_t* out, bool edge_ids,
+static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* rowptr, int32_t* cursor, int32_t* out, int64_t* lane_pack,
                      void* cub_tmp, int64_t cub_bytes, hipStream_t st) {
   TS_HIP(hipMemsetAsync(deg, 0, size_t(N + 1) * sizeof(int32_t), st));
   if (E > 0) k_degree<<<cdiv(E, 256), 256, 0, st>>>(ei, E, deg);
   size_t tmp = size_t(cub_bytes);
   TS_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, deg, rowptr, N + 1, st));
   TS_HIP(hipMemcpyAsync(cursor, rowptr, size_t(N + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-  if (E > 0) {
-    k_scatter<<<cdiv(E, 256), 256, 0, st>>>(ei, E, cursor, out, edge_ids ? 1 : 0);
-    k_row_sort<<<N < 4096 ? N : 4096, 256, 0, st>>>(rowptr, N, out);
+  if (E > 0 && lane_pack == nullptr) {
+    k_scatter<<<cdiv(E, 256), 256, 0, st>>>(ei, E, cursor, out, 0);
+    k_row_sort<int32_t><<<N < 4096 ? N : 4096, 256, 0, st>>>(rowptr, N, out);
+  } else if (E > 0) {
+    k_scatter_lane<<<cdiv(E, 256), 256, 0, st>>>(ei, E, cursor, lane_pack);
+    k_row_sort<int64_t><<<N < 4096 ? N : 4096, 256, 0, st>>>(rowptr, N, lane_pack);
+    k_unpack_eid<<<cdiv(E, 256), 256, 0, st>>>(lane_pack, E, out);
   }
   TS_LAUNCH_CHECK("build_csr");
   return TRAJSDE_OK;
@@ -389,7 +408,7 @@ int trajsde_graph_prepare(const trajsde_batch* b, const float* rot, float radius
   NoiseArg na{0, nullptr, nullptr};
   if (fake_noise) { na.seed = fake_noise->seed; na.z = fake_noise->z; na.row_ids = fake_noise->row_ids; }
 
-  if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.cursor, w.csr_src, false, w.cub_tmp, w.cub_bytes, st)) return rc;
+  if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.cursor, w.csr_src, nullptr, w.cub_tmp, w.cub_bytes, st)) return rc;
   k_ext_nodes<<<cdiv(Nt, 256), 256, 0, st>>>(N, A, H, b->agent_index, b->batch, b->source, b->bos_mask, w.orig, w.nus, w.eos, w.pick_slot);
   if (A > 0) {
     k_agent_slots<<<cdiv(A, 256), 256, 0, st>>>(A, b->agent_index, w.pick_slot);
@@ -412,7 +431,7 @@ int trajsde_graph_prepare(const trajsde_batch* b, const float* rot, float radius
   k_segptr_from_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, w.rowptr, w.cpos_g, w.g_segptr);
   // lane-actor edges grouped by actor
   if (b->L > 0) k_lane_feat<<<cdiv(b->L, 256), 256, 0, st>>>(b->L, b->lane_pts, b->lane_positions, b->lane_paddings, w.lane_feat);
-  if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_cursor, w.la_eid, true, w.cub_tmp, w.cub_bytes, st)) return rc;
+  if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_cursor, w.la_eid, w.la_pack, w.cub_tmp, w.cub_bytes, st)) return rc;
   k_la_flags<<<cdiv(Ea + 1, 256), 256, 0, st>>>(Ea, N, w.la_rowptr, w.la_eid, b->lane_actor_vectors, radius, w.la_actor, w.flags_la);
   {
     size_t tmp = size_t(w.cub_bytes);
