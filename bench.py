@@ -44,7 +44,7 @@ CPU_SAMPLE_SCENES = 16
 
 def build_cfg(spec):
     import yaml
-    with open(os.path.join(ROOT, "trajsde_amd/configs/nusargo/hivt_nuSArgo_sdesepenc_sdedec.yml")) as f:
+    with open(os.path.join(ROOT, "trajsde_amd/configs/mi355x_sde_encoder_decoder.yml")) as f:
         cfg = yaml.safe_load(f)
     K, T, mt = spec["num_modes"], spec["future_steps"], spec["max_fut_t"]
     cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)

@@ -11,7 +11,7 @@ GOLDEN = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(ROOT, "
 
 
 def our_cfg(num_modes, future_steps, max_fut_t):
-    with open(os.path.join(ROOT, "trajsde_amd/configs/nusargo/hivt_nuSArgo_sdesepenc_sdedec.yml")) as f:
+    with open(os.path.join(ROOT, "trajsde_amd/configs/mi355x_sde_encoder_decoder.yml")) as f:
         cfg = yaml.safe_load(f)
     cfg["model_specific"]["kwargs"].update(num_modes=num_modes, future_steps=future_steps)
     cfg["aggregator"]["kwargs"]["num_modes"] = num_modes
