@@ -84,9 +84,19 @@ def cpu_baseline(model, cfg, spec, gpu_loc_fn):
     match = {"minADE_gpu": res["gpu"][0], "minADE_cpu_oracle": res["cpu"][0], "minFDE_gpu": res["gpu"][1],
              "minFDE_cpu_oracle": res["cpu"][1], "max_abs_loc_diff": float((o_gpu["loc"].cpu() - out["loc"]).abs().max()),
              "tolerance": 1e-4}
-    base = {"value": CPU_SAMPLE_SCENES / med, "unit": "scenes/s", "cores": torch.get_num_threads(), "kind": "port",
+    # one-thread figure on a smaller sample (SURVEY 8(d) asks for both)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    small = synth(**dict(spec["synth"], S=2))
+    restate.forward(P, cfg, small, restate.PhiloxNoise(seed))
+    t0 = time.perf_counter()
+    restate.forward(P, cfg, small, restate.PhiloxNoise(seed))
+    one = 2 / (time.perf_counter() - t0)
+    torch.set_num_threads(nthreads)
+    base = {"value": CPU_SAMPLE_SCENES / med, "unit": "scenes/s", "cores": nthreads, "kind": "port",
             "sample": f"{CPU_SAMPLE_SCENES} of the 64 scenes of {WORKLOAD} (same generator and seed), oracle/restate.py, "
-                      f"1 warm-up + 3 timed forwards, median {med:.3f} s/forward, torch {torch.__version__} fp32"}
+                      f"1 warm-up + 3 timed forwards, median {med:.3f} s/forward, torch {torch.__version__} fp32",
+            "value_1_thread": one, "sample_1_thread": "2 scenes of the same generator, 1 warm-up + 1 timed forward"}
     return base, match
 
 

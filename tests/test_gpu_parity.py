@@ -235,6 +235,20 @@ def test_dense_scene_1024_agents(dev):
     assert H.maxdiff(o["pi"].cpu(), want["pi"]) <= TOL
 
 
+def test_edge_snapshot_helper_matches_reference_side_effect(dev):
+    """ENC:107-110 leaves edge_index_t / edge_attr_t on the batch; the helper reproduces them on request"""
+    from trajsde_amd.runtime import edge_snapshot
+    batch, meta, out, mid = H.load_fixture("mixed_k6_t20")
+    data = batch.to(dev)
+    for t in (0, 10, 20):
+        e, attr = edge_snapshot(data, t)
+        valid = ~batch["padding_mask"][:, t]
+        keep = valid[batch["edge_index"][0]] & valid[batch["edge_index"][1]]
+        want = batch["edge_index"][:, keep]
+        assert torch.equal(e.cpu(), want)
+        assert H.maxdiff(attr.cpu(), batch["positions"][want[0], t] - batch["positions"][want[1], t]) == 0
+
+
 def test_errors_are_loud(dev):
     from trajsde_amd import _lib
     from trajsde_amd.synth import synth

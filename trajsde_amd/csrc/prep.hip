@@ -10,6 +10,7 @@
 // The compacted lists carry the pre-rotated 2-d geometry the edge kernels consume (16 B per edge).
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -63,7 +64,7 @@ __global__ void k_unpack_eid(const int64_t* __restrict__ packed, int E, int32_t*
 // ascending sort of every CSR row; one workgroup per row (grid-stride), bitonic network in LDS (rows up to 4096
 // entries) or in place in global memory for longer rows
 template <typename T>
-__global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals) {
+__global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals) {   // 64 or 256 threads
   __shared__ T buf[4096];
   const T INF = sizeof(T) == 8 ? T(INT64_MAX) : T(INT32_MAX);
   for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
@@ -367,10 +368,15 @@ static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* row
   TS_HIP(hipMemcpyAsync(cursor, rowptr, size_t(N + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   if (E > 0 && lane_pack == nullptr) {
     k_scatter<<<cdiv(E, 256), 256, 0, st>>>(ei, E, cursor, out, 0);
-    k_row_sort<int32_t><<<N < 4096 ? N : 4096, 256, 0, st>>>(rowptr, N, out);
+    // short rows: one wave per row and many rows in flight; long rows: a full workgroup per row
+    static const int rs_env = []() { const char* e = getenv("TRAJSDE_ROWSORT_THREADS"); return e ? atoi(e) : 0; }();
+    const int rs_threads = rs_env ? rs_env : (int64_t(E) <= int64_t(N) * 256 ? 64 : 256);
+    k_row_sort<int32_t><<<N < 16384 ? N : 16384, rs_threads, 0, st>>>(rowptr, N, out);
   } else if (E > 0) {
     k_scatter_lane<<<cdiv(E, 256), 256, 0, st>>>(ei, E, cursor, lane_pack);
-    k_row_sort<int64_t><<<N < 4096 ? N : 4096, 256, 0, st>>>(rowptr, N, lane_pack);
+    static const int rs_env = []() { const char* e = getenv("TRAJSDE_ROWSORT_THREADS"); return e ? atoi(e) : 0; }();
+    const int rs_threads = rs_env ? rs_env : (int64_t(E) <= int64_t(N) * 256 ? 64 : 256);
+    k_row_sort<int64_t><<<N < 16384 ? N : 16384, rs_threads, 0, st>>>(rowptr, N, lane_pack);
     k_unpack_eid<<<cdiv(E, 256), 256, 0, st>>>(lane_pack, E, out);
   }
   TS_LAUNCH_CHECK("build_csr");

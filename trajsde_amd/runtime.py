@@ -71,6 +71,20 @@ def rotate_inputs(data) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     return rot, y_rot
 
 
+def edge_snapshot(data, t: int, local_radius: float = 50.0, fake_agents: bool = False):
+    """`data['edge_index_{t}']`, `data['edge_attr_{t}']` as the reference's encoder leaves them on the batch
+    (ENC:107-110: subgraph of the nodes valid at step t, attr = pos[src] - pos[dst]; the radius filter of ENC:115 is
+    applied only to the copies fed to the AA encoder, not to these).  The HIP path never materialises the 21 lists
+    (DESIGN.md 3); this helper rebuilds one on request with plain tensor indexing for callers that want to look at it."""
+    ei, pad, pos = data["edge_index"], data["padding_mask"], data["positions"]
+    if fake_agents:
+        raise NotImplementedError("snapshots of the fake-agent copies are internal to the encoder")
+    valid = ~pad[:, t]
+    keep = valid[ei[0]] & valid[ei[1]]
+    e = ei[:, keep]
+    return e, pos[e[0], t] - pos[e[1], t]
+
+
 class _TableCache:
     """float32 schedule tables (host replay of the solver's time bookkeeping) resident on the device."""
 
