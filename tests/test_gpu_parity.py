@@ -249,6 +249,54 @@ def test_edge_snapshot_helper_matches_reference_side_effect(dev):
         assert H.maxdiff(attr.cpu(), batch["positions"][want[0], t] - batch["positions"][want[1], t]) == 0
 
 
+def test_driver_metrics_match_oracle(dev):
+    """the test.py-like loop (YAML -> registry -> test_step -> metrics) against the oracle's trajectories"""
+    from trajsde_amd import driver
+    from trajsde_amd.metrics import ADE_T, FDE_T, MR_T
+    from trajsde_amd.synth import CONFIGS, synth
+    spec = CONFIGS["config1"]
+    K, T = spec["num_modes"], spec["future_steps"]
+    cfg = H.our_cfg(K, T, spec["max_fut_t"])
+    for m in cfg["metric_args"]:
+        m["end_idcs"] = [T - 1, T - 1]
+    model = driver.build_model(cfg, None, dev, init_seed=0)
+    batches = [synth(**dict(spec["synth"], seed=500 + i)) for i in range(3)]
+    got = driver.evaluate(model, [b.to(dev) for b in batches], seed=40)
+    cpu_model, _ = H.build_model(K, T, spec["max_fut_t"], init_seed=0)
+    want = [ADE_T("nuScenes", [T - 1] * 2), FDE_T("nuScenes", [T - 1] * 2), MR_T("nuScenes", [T - 1] * 2)]
+    for i, b in enumerate(batches):
+        o = H.oracle_forward(cpu_model, cfg, b, noise_seed=40 + i, want_intermediates=False)
+        idx = b["agent_index"]
+        for m in want:
+            m.update(o["loc"][:, idx, :, :2], o["y"][idx], o["reg_mask"][idx], b["source"])
+    for name, m in zip(("ADE_T", "FDE_T", "MR_T"), want):
+        assert abs(got[name] - float(m.compute())) <= 1e-4, name
+
+
+def test_split_precision_and_exact_fp32_paths_agree(dev, tmp_path):
+    """the bf16x6 split-precision kernels (default) against the exact-fp32 MFMA kernels (TRAJSDE_*_FP32=1); the
+    switches are read once per process, so each mode runs in its own interpreter"""
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import sys, torch; sys.path[:0] = [%r, %r]\n"
+        "import helpers as H\n"
+        "from trajsde_amd.runtime import NoiseSpec\n"
+        "from trajsde_amd.synth import synth\n"
+        "m, cfg = H.build_model(6, 20, 2.0, init_seed=2)\n"
+        "o = m.to('cuda')(synth(S=3, n=20, L=8, F=20, box=90.0, seed=9, mixed_source=True).to('cuda'), noise=NoiseSpec(seed=6))\n"
+        "torch.save({k: v.cpu() for k, v in o.items()}, sys.argv[1])\n") % (H.ROOT, os.path.join(H.ROOT, "tests"))
+    outs = {}
+    for mode, env in (("split", {}), ("fp32", {"TRAJSDE_EDGE_FP32": "1", "TRAJSDE_NODE_FP32": "1", "TRAJSDE_DECODE_FP32": "1",
+                                               "TRAJSDE_RECUR_LEGACY": "1", "TRAJSDE_GLOBAL_UNFUSED": "1"})):
+        path = str(tmp_path / (mode + ".pt"))
+        subprocess.run([sys.executable, "-c", script, path], check=True, env={**os.environ, **env}, timeout=600)
+        outs[mode] = torch.load(path)
+    for key in ("loc", "pi", "diff_in", "diff_out"):
+        assert H.maxdiff(outs["split"][key], outs["fp32"][key]) <= 2e-5, key
+
+
 def test_errors_are_loud(dev):
     from trajsde_amd import _lib
     from trajsde_amd.synth import synth
