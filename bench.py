@@ -63,13 +63,24 @@ def cpu_baseline(model, cfg, spec, gpu_loc_fn):
     batch = synth(**skw)
     P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     seed = 1234
-    times = []
+    # the oracle is many small torch ops: more threads is not monotonically faster, so a few thread counts are timed
+    # (1 warm-up + 2 timed forwards each) and the best one is the reported baseline
+    all_threads = torch.get_num_threads()
+    table = {}
     out = None
-    for i in range(4):
-        t0 = time.perf_counter()
-        out = restate.forward(P, cfg, batch, restate.PhiloxNoise(seed))
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times[1:]))
+    for nt in sorted({1, 8, 32, all_threads}):
+        if nt > all_threads:
+            continue
+        torch.set_num_threads(nt)
+        times = []
+        for i in range(3):
+            t0 = time.perf_counter()
+            out = restate.forward(P, cfg, batch, restate.PhiloxNoise(seed))
+            times.append(time.perf_counter() - t0)
+        table[nt] = float(np.mean(times[1:]))
+    torch.set_num_threads(all_threads)
+    best_nt = min(table, key=table.get)
+    med = table[best_nt]
     o_gpu, data_gpu = gpu_loc_fn(batch, seed)
     idx = batch["agent_index"]
     res = {}
@@ -84,19 +95,11 @@ def cpu_baseline(model, cfg, spec, gpu_loc_fn):
     match = {"minADE_gpu": res["gpu"][0], "minADE_cpu_oracle": res["cpu"][0], "minFDE_gpu": res["gpu"][1],
              "minFDE_cpu_oracle": res["cpu"][1], "max_abs_loc_diff": float((o_gpu["loc"].cpu() - out["loc"]).abs().max()),
              "tolerance": 1e-4}
-    # one-thread figure on a smaller sample (SURVEY 8(d) asks for both)
-    nthreads = torch.get_num_threads()
-    torch.set_num_threads(1)
-    small = synth(**dict(spec["synth"], S=2))
-    restate.forward(P, cfg, small, restate.PhiloxNoise(seed))
-    t0 = time.perf_counter()
-    restate.forward(P, cfg, small, restate.PhiloxNoise(seed))
-    one = 2 / (time.perf_counter() - t0)
-    torch.set_num_threads(nthreads)
-    base = {"value": CPU_SAMPLE_SCENES / med, "unit": "scenes/s", "cores": nthreads, "kind": "port",
+    base = {"value": CPU_SAMPLE_SCENES / med, "unit": "scenes/s", "cores": best_nt, "kind": "port",
             "sample": f"{CPU_SAMPLE_SCENES} of the 64 scenes of {WORKLOAD} (same generator and seed), oracle/restate.py, "
-                      f"1 warm-up + 3 timed forwards, median {med:.3f} s/forward, torch {torch.__version__} fp32",
-            "value_1_thread": one, "sample_1_thread": "2 scenes of the same generator, 1 warm-up + 1 timed forward"}
+                      f"1 warm-up + 2 timed forwards per thread count, best = {best_nt} threads at {med:.3f} s/forward, "
+                      f"torch {torch.__version__} fp32, host has {os.cpu_count()} logical cores",
+            "scenes_per_s_by_threads": {str(k): CPU_SAMPLE_SCENES / v for k, v in table.items()}}
     return base, match
 
 

@@ -1,0 +1,84 @@
+"""CPU suite: host-side mirrors of the reference interface (losses, metrics, collate, schedule helpers) against the
+formulas of the reference, evaluated on the oracle's outputs."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+
+def _oracle_case():
+    batch, meta, out, mid = H.load_fixture("mixed_k6_t20")
+    model, cfg = H.build_model(meta)
+    o = H.oracle_forward(model, cfg, batch, meta["noise_seed"], want_intermediates=False)
+    return batch, o
+
+
+def test_losses_match_reference_formulas():
+    from trajsde_amd.losses import L2, DiffBCE
+    batch, o = _oracle_case()
+    data = {"y": o["y"]}
+    # losses/L2.py:10-27 spelled out literally
+    loc, target, reg_mask = o["loc"][..., :2], o["y"], o["reg_mask"]
+    l2 = torch.norm(target.unsqueeze(0) - loc, p=2, dim=-1)
+    ade = l2.clone()
+    ade[:, ~reg_mask] = 0
+    idx = torch.argmin(ade.mean(-1), dim=0)
+    want = l2[idx, torch.arange(l2.size(1))][reg_mask].mean()
+    assert abs(float(L2()(data, o)) - float(want)) < 1e-6
+    bce = torch.nn.BCELoss()
+    want = bce(o["diff_in"], o["label_in"]) + bce(o["diff_out"], o["label_out"])
+    assert abs(float(DiffBCE()(data, o)) - float(want)) < 1e-6
+
+
+def test_metrics_match_reference_formulas():
+    from trajsde_amd.metrics import ADE_T, FDE_T, MR_T
+    batch, o = _oracle_case()
+    idx = batch["agent_index"]
+    pred, target, mask, source = o["loc"][:, idx, :, :2], o["y"][idx], o["reg_mask"][idx], batch["source"]
+    T = pred.shape[2]
+    # metrics/ade_t.py:39-66 (nuScenes branch), metrics/fde_t.py:39-57, metrics/mr_t.py:41-53 spelled out
+    l2 = torch.norm(pred - target.unsqueeze(0), p=2, dim=-1)
+    any_valid = mask.any(-1)
+    l2v, mv = l2[:, any_valid].clone(), mask[any_valid]
+    l2v[:, ~mv] = 0
+    ade = l2v.sum(-1) / mv.sum(-1).unsqueeze(0)
+    want_ade = ade[torch.argmin(ade, 0), torch.arange(int(any_valid.sum()))].sum() / any_valid.sum()
+    end = torch.full((pred.shape[1],), T - 1)
+    ar = torch.arange(pred.shape[1])
+    fl2 = torch.norm(pred[:, ar, end] - target[ar, end].unsqueeze(0), p=2, dim=-1)
+    fv = mask[ar, end]
+    want_fde = fl2[:, fv].min(0).values.sum() / fv.sum() if int(fv.sum()) else torch.tensor(float("nan"))
+    want_mr = (l2v.max(-1)[0].min(0)[0] > 2.0).sum() / any_valid.sum()
+    m = [ADE_T("nuScenes", [T - 1, T - 1]), FDE_T("nuScenes", [T - 1, T - 1]), MR_T("nuScenes", [T - 1, T - 1])]
+    for x in m:
+        x.update(pred, target, mask, source)
+    assert abs(float(m[0].compute()) - float(want_ade)) < 1e-6
+    if int(fv.sum()):
+        assert abs(float(m[1].compute()) - float(want_fde)) < 1e-6
+    assert abs(float(m[2].compute()) - float(want_mr)) < 1e-6
+
+
+def test_collate_offsets_like_pyg():
+    """index keys offset by the running actor count, lane_actor_index by [lanes; actors] (UTIL:67-75)"""
+    from trajsde_amd.data import collate
+    from trajsde_amd.synth import synth
+    a, b = synth(S=1, n=4, L=3, F=5, box=30.0, seed=1), synth(S=1, n=6, L=2, F=5, box=30.0, seed=2)
+    c = collate([a, b])
+    assert c.num_nodes == 10 and c["x"].shape[0] == 10
+    assert torch.equal(c["edge_index"][:, a["edge_index"].shape[1]:], b["edge_index"] + 4)
+    assert torch.equal(c["lane_actor_index"][:, a["lane_actor_index"].shape[1]:], b["lane_actor_index"] + torch.tensor([[3], [4]]))
+    assert torch.equal(c["agent_index"], torch.tensor([0, 4])) and torch.equal(c["batch"], torch.tensor([0] * 4 + [1] * 6))
+    assert c["source"].shape == (2,) and c["lane_positions"].shape[0] == 5
+
+
+def test_oracle_is_invariant_to_edge_order():
+    """permutation-equivariance over edge order: reordering edge_index leaves the oracle's output unchanged up
+    to fp32 summation order"""
+    batch, o = _oracle_case()
+    model, cfg = H.build_model(6, 20, 2.0, init_seed=0)
+    b2 = H.clone_batch(batch)
+    g = torch.Generator().manual_seed(0)
+    b2["edge_index"] = batch["edge_index"][:, torch.randperm(batch["edge_index"].shape[1], generator=g)]
+    o2 = H.oracle_forward(model, cfg, b2, 101, want_intermediates=False)
+    assert H.maxdiff(o2["loc"], o["loc"]) < 1e-4

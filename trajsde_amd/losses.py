@@ -1,0 +1,34 @@
+"""Loss values of the reference's SDE config, computed on the device tensors the forward returns
+(losses/L2.py:10-27 winner-takes-all min-ADE regression; losses/diff_BCE.py:11-16 BCE on the encoder's diffusion
+outputs, real = 0, perturbed = 1).  Forward values only -- used for validation-time reporting; training needs the
+backward kernels, so these are not wired into `training_step`.
+"""
+import torch
+import torch.nn.functional as F
+
+
+class L2:
+    def __init__(self, reduction: str = "mean") -> None:
+        if reduction != "mean":
+            raise ValueError(f"{reduction} is not a valid value for reduction")
+        self.reduction = reduction
+
+    def __call__(self, data, output) -> torch.Tensor:
+        target = data["y"]                                               # already rotated by forward (MODEL:83-84)
+        loc = output["loc"][..., :2]
+        reg_mask = output["reg_mask"]
+        l2 = torch.norm(target.unsqueeze(0) - loc, p=2, dim=-1)         # [K, N, T]
+        ade = (l2 * reg_mask.unsqueeze(0)).mean(-1)                      # masked steps count as zero, mean over all T
+        best = ade.argmin(0)                                             # winner per actor
+        min_l2 = l2.gather(0, best.view(1, -1, 1).expand(1, -1, l2.size(-1))).squeeze(0)
+        n = reg_mask.sum()
+        return (min_l2 * reg_mask).sum() / n if int(n) > 0 else min_l2.sum() * 0
+
+
+class DiffBCE:
+    def __init__(self, reduction: str = "mean") -> None:
+        self.reduction = reduction
+
+    def __call__(self, data, output) -> torch.Tensor:
+        return (F.binary_cross_entropy(output["diff_in"], output["label_in"], reduction=self.reduction) +
+                F.binary_cross_entropy(output["diff_out"], output["label_out"], reduction=self.reduction))
