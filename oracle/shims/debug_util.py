@@ -11,3 +11,7 @@ viz_result_batch_ood_load = viz_data_goal = _noop
 
 def __getattr__(name):
     return _noop
+
+
+__all__ = ["save_modules", "viz_result_batch_base", "viz_result_batch_goalpred", "viz_result_batch_ood",
+           "viz_result_batch_ood_load", "viz_data_goal"]

@@ -38,6 +38,9 @@ class Data:
     def __delitem__(self, key):
         del self._store[key]
 
+    def __delattr__(self, key):
+        del self._store[key]
+
     def __contains__(self, key):
         return key in self._store
 
@@ -98,6 +101,10 @@ class Batch(Data):
 class Dataset(torch.utils.data.Dataset):
     def __init__(self, root=None, transform=None, pre_transform=None, pre_filter=None):
         self.root, self.transform = root, transform
+        if hasattr(self, "_download"):
+            self._download()
+        if hasattr(self, "_process"):
+            self._process()
 
     def __len__(self):
         return self.len()

@@ -1,0 +1,151 @@
+"""Flat scene shards + the mixed-grid dataset against what the reference's `nuArgoDataset.get` returned for the
+same stored scenes (tests/golden_data/mixds.npz, made by oracle/make_golden_dataset.py).  Bit-exact."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from trajsde_amd.data import collate
+from trajsde_amd.dataset import DataModuleNuArgoMix, SceneLoader, nuArgoDataset
+from trajsde_amd.scene_store import SceneShard, SceneStore, write_shard
+
+FIX = os.path.join(os.path.dirname(__file__), "golden_data", "mixds.npz")
+
+
+def _groups(z, prefix):
+    """{scene index: {key: value}} of the arrays stored under `prefix/<i>/<key>`"""
+    out = {}
+    for name in z.files:
+        if name.startswith(prefix + "/"):
+            i, k = name[len(prefix) + 1:].split("/", 1)
+            v = z[name]
+            if v.dtype.kind == "U":
+                v = str(v)
+            elif v.ndim == 0 and k in ("seq_id", "av_index", "agent_index", "num_nodes", "source"):
+                v = int(v)
+            else:
+                v = torch.from_numpy(np.array(v))
+            out.setdefault(int(i), {})[k] = v
+    return [out[i] for i in sorted(out)]
+
+
+@pytest.fixture(scope="module")
+def fixture():
+    return np.load(FIX)
+
+
+@pytest.fixture(scope="module")
+def roots(fixture, tmp_path_factory):
+    root = tmp_path_factory.mktemp("scenes")
+    nus, argo = _groups(fixture, "raw/nus"), _groups(fixture, "raw/argo")
+    for sub in ("train", "val"):
+        os.makedirs(root / "nu" / sub)
+        # two shards per split: the dataset must walk them in name order
+        write_shard(str(root / "nu" / sub / "part0.safetensors"), nus[:2])
+        write_shard(str(root / "nu" / sub / "part1.safetensors"), nus[2:])
+    os.makedirs(root / "argo" / "train")
+    write_shard(str(root / "argo" / "train" / "all.safetensors"), argo)
+    return str(root / "nu"), str(root / "argo")
+
+
+def _same(a, b, key):
+    if torch.is_tensor(b):
+        assert torch.is_tensor(a), key
+        assert a.dtype == b.dtype and a.shape == b.shape, (key, a.dtype, b.dtype, a.shape, b.shape)
+        assert torch.equal(a, b), key
+    else:
+        a = a.item() if torch.is_tensor(a) else a
+        assert a == b, (key, a, b)
+
+
+def _check(ds, expected):
+    assert len(ds) == len(expected)
+    for i, exp in enumerate(expected):
+        got = ds.get(i)
+        exp = {k: v for k, v in exp.items() if k != "num_nodes"}
+        assert sorted(k for k in got.keys) == sorted(exp), (sorted(got.keys), sorted(exp))
+        assert got.num_nodes == exp["x"].shape[0]
+        for k, v in exp.items():
+            _same(got[k], v, f"scene {i} {k}")
+
+
+BASE = dict(nus=True, Argo=True, type="grid", is_gtabs=True, random_flip=False)
+
+
+def test_shard_roundtrip(fixture, tmp_path):
+    nus, argo = _groups(fixture, "raw/nus"), _groups(fixture, "raw/argo")
+    p = str(tmp_path / "mixed.safetensors")
+    with pytest.raises(ValueError):
+        write_shard(p, nus + argo)                 # 5+12 vs 20+30 stored slots: one source per shard
+    partial = {k: v for k, v in nus[0].items() if k not in ("category", "goal_idcs")}
+    scenes = nus + argo[:0] + [partial] + nus[:2]  # a key missing from some scenes: `.has` masks
+    write_shard(p, scenes)
+    sh = SceneShard(p)
+    assert len(sh) == 6
+    for i, src in enumerate(scenes):
+        got = sh.scene(i)
+        want = {k: v for k, v in src.items() if k != "num_nodes"}
+        assert sorted(got) == sorted(want)
+        for k, v in want.items():
+            _same(got[k], v, k)
+    with pytest.raises(IndexError):
+        sh.scene(6)
+    st = SceneStore([p, p])
+    assert len(st) == 12 and torch.equal(st.scene(7)["x"], sh.scene(1)["x"])
+
+
+def test_val_split_matches_reference(fixture, roots):
+    _check(nuArgoDataset("val", None, None, *roots, spec_args=BASE), _groups(fixture, "val"))
+
+
+def test_relative_targets_match_reference(fixture, roots):
+    _check(nuArgoDataset("val", None, None, *roots, spec_args={**BASE, "is_gtabs": False}), _groups(fixture, "val_rel"))
+
+
+def test_single_source_matches_reference(fixture, roots):
+    _check(nuArgoDataset("val", None, None, *roots, spec_args={**BASE, "nus": False}), _groups(fixture, "val_argo_only"))
+
+
+def test_train_flips_match_reference(fixture, roots):
+    ds = nuArgoDataset("train", None, None, *roots, spec_args={**BASE, "random_flip": True})
+    for seed in fixture["meta/flip_seeds"].tolist():
+        random.seed(seed)
+        _check(ds, _groups(fixture, f"train_seed{seed}"))
+
+
+def test_missing_shards_fail_loudly(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        nuArgoDataset("val", None, None, str(tmp_path), str(tmp_path), spec_args=BASE)
+
+
+def test_loader_shards_scenes_across_ranks(roots):
+    ds = nuArgoDataset("val", None, None, *roots, spec_args=BASE)
+    whole = [b for b in SceneLoader(ds, batch_size=4)]
+    assert [int(b["batch"].max()) + 1 for b in whole] == [4, 2]
+    ref = collate(ds[i] for i in range(4))
+    for k in ("x", "edge_index", "lane_actor_index", "padding_mask", "agent_index"):
+        assert torch.equal(whole[0][k], ref[k])
+    seen = []
+    for rank in range(2):
+        ld = SceneLoader(ds, batch_size=2, rank=rank, world_size=2)
+        assert ld.scene_ids() == list(range(rank, len(ds), 2))
+        seen += [s for b in ld for s in b["seq_id"]]
+    assert sorted(seen) == sorted(ds.get(i)["seq_id"] for i in range(len(ds)))
+    a = SceneLoader(ds, 2, shuffle=True, seed=3)
+    b = SceneLoader(ds, 2, shuffle=True, seed=3)
+    assert a.scene_ids() == b.scene_ids()
+    b.set_epoch(1)
+    assert sorted(b.scene_ids()) == list(range(len(ds)))
+
+
+def test_datamodule_mirror(roots):
+    dm = DataModuleNuArgoMix(nu_root=None, Argo_root=None, nu_dir=roots[0], Argo_dir=roots[1],
+                             tr_dataset_args={**BASE, "random_flip": True}, val_dataset_args=BASE,
+                             test_dataset_args=BASE, train_batch_size=3, val_batch_size=6, shuffle=False)
+    dm.setup()
+    assert len(dm.train_dataset) == len(dm.val_dataset) == 6
+    batch = next(iter(dm.val_dataloader()))
+    assert batch["x"].shape[1:] == (21, 2) and batch["y"].shape[1:] == (60, 2)
+    assert batch["padding_mask"].shape[1] == 81 and batch["source"].tolist() == [0, 0, 0, 1, 1, 1]

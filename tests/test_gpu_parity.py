@@ -1,6 +1,8 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against (a) the golden vectors made
 from the reference and (b) the CPU oracle on seeded synthetic batches.  Tolerance: the north star's 1e-4
 max-abs on predicted trajectories; intermediates are held to the same bound."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -271,6 +273,41 @@ def test_driver_metrics_match_oracle(dev):
             m.update(o["loc"][:, idx, :, :2], o["y"][idx], o["reg_mask"][idx], b["source"])
     for name, m in zip(("ADE_T", "FDE_T", "MR_T"), want):
         assert abs(got[name] - float(m.compute())) <= 1e-4, name
+
+
+def test_dataset_fed_batches_match_oracle(dev, tmp_path):
+    """flat scene shards -> mixed-grid dataset -> loader -> forward, against the oracle on the same batch; the
+    HBM-resident store must give the same batch as the host one"""
+    import numpy as np
+    from test_dataset import BASE, _groups
+    from trajsde_amd import driver
+    from trajsde_amd.dataset import SceneLoader, nuArgoDataset
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.scene_store import write_shard
+    z = np.load(os.path.join(H.ROOT, "tests", "golden_data", "mixds.npz"))
+    for sub, name, group in (("nu/val", "a", "raw/nus"), ("argo/train", "b", "raw/argo")):
+        os.makedirs(tmp_path / sub)
+        write_shard(str(tmp_path / sub / f"{name}.safetensors"), _groups(z, group))
+    roots = (str(tmp_path / "nu"), str(tmp_path / "argo"))
+    host = nuArgoDataset("val", None, None, *roots, spec_args=BASE)
+    resident = nuArgoDataset("val", None, None, *roots, spec_args=BASE, device=str(dev))
+    (hb,) = list(SceneLoader(host, batch_size=6, device=dev))
+    (rb,) = list(SceneLoader(resident, batch_size=6, device=dev))
+    for k in hb.keys:
+        if torch.is_tensor(hb[k]):
+            assert rb[k].device.type == "cuda" and torch.equal(hb[k], rb[k]), k
+    K, T, max_t = 3, 60, 6.0
+    model, cfg = H.build_model(K, T, max_t, init_seed=5)
+    want = H.oracle_forward(model, cfg, hb.to("cpu"), noise_seed=77, want_intermediates=False)
+    o = model.to(dev)(hb, noise=NoiseSpec(seed=77))
+    for key in ("loc", "pi"):
+        assert H.maxdiff(o[key].cpu(), want[key]) <= TOL, key
+    assert torch.equal(o["reg_mask"].cpu(), want["reg_mask"])
+    cfg["datamodule_specific"]["kwargs"].update(val_batch_size=4, test_dataset_args={**BASE})
+    batches = list(driver.datamodule_batches(cfg, dev, 0, 1, *roots))
+    assert [int(b["batch"].max()) + 1 for b in batches] == [4, 2]
+    res = driver.evaluate(model, batches)
+    assert all(np.isfinite(v) for v in res.values()), res
 
 
 def test_split_precision_and_exact_fp32_paths_agree(dev, tmp_path):

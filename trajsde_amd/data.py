@@ -88,7 +88,8 @@ def collate(scenes: Iterable[TemporalData]) -> TemporalData:
     for k, parts in acc.items():
         v0 = parts[0]
         if not torch.is_tensor(v0):
-            out[k] = parts
+            # PyG turns per-scene Python numbers into one tensor (e.g. `source`), anything else into a list
+            out[k] = torch.tensor(parts) if isinstance(v0, (bool, int, float)) else parts
         elif k in _PER_SCENE_SCALARS or v0.dim() == 0:
             out[k] = torch.stack([p.reshape(()) for p in parts])
         elif "index" in k and v0.dim() == 2:          # [2, E] edge lists

@@ -5,6 +5,10 @@ so the loop is spelled out; the model class keeps Lightning's hook signatures an
 
     python -m trajsde_amd.driver --config trajsde_amd/configs/mi355x_sde_encoder_decoder.yml \
         --synthetic config1 [--batches 4] [--ckpt path.ckpt] [--ood] [--gpus N via torch.distributed.run]
+    python -m trajsde_amd.driver --config ... --data [--nu_dir D --argo_dir D]      # the YAML's data module
+
+With `--data` the `datamodule_specific` section is resolved like `test.py:54-58` does and the model is evaluated on
+its `test_dataloader()` (flat scene shards, trajsde_amd/dataset.py); ranks take disjoint scene sets.
 
 Training (`train.py:42-66`) needs the backward kernels and is not built yet.
 """
@@ -58,6 +62,19 @@ def synthetic_batches(name: str, n: int, device, rank: int = 0, world: int = 1):
         yield synth(**dict(spec["synth"], seed=spec["synth"]["seed"] + 97 * i)).to(device)
 
 
+def datamodule_batches(cfg: dict, device, rank: int = 0, world: int = 1, nu_dir=None, argo_dir=None):
+    """test.py:54-58: resolve the data module through the registry, iterate its test loader"""
+    dm_cfg = cfg["datamodule_specific"]
+    kwargs = dict(dm_cfg["kwargs"], rank=rank, world_size=world, device=device)
+    if nu_dir:
+        kwargs["nu_dir"] = nu_dir
+    if argo_dir:
+        kwargs["Argo_dir"] = argo_dir
+    dm = resolve_class(dm_cfg["file_path"], dm_cfg["module_name"])(**kwargs)
+    dm.setup("test")
+    return dm.test_dataloader()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("-c", "--config", required=True)
@@ -65,6 +82,9 @@ def main() -> None:
     ap.add_argument("--synthetic", default="config1", choices=sorted(CONFIGS))
     ap.add_argument("--batches", type=int, default=4)
     ap.add_argument("--ood", action="store_true")
+    ap.add_argument("--data", action="store_true", help="evaluate on the YAML's data module instead of synthetic batches")
+    ap.add_argument("--nu_dir", default=None)
+    ap.add_argument("--argo_dir", default=None)
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,18 +96,23 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     with open(args.config) as f:
         cfg = yaml.safe_load(f)
-    spec = CONFIGS[args.synthetic]
-    K, T = spec["num_modes"], spec["future_steps"]
-    cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)
-    cfg["aggregator"]["kwargs"]["num_modes"] = K
-    cfg["decoder"]["kwargs"].update(num_modes=K, future_steps=T, max_fut_t=spec["max_fut_t"])
-    for m in cfg["metric_args"]:
-        m["end_idcs"] = [T - 1, T - 1]
+    if not args.data:
+        spec = CONFIGS[args.synthetic]
+        K, T = spec["num_modes"], spec["future_steps"]
+        cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)
+        cfg["aggregator"]["kwargs"]["num_modes"] = K
+        cfg["decoder"]["kwargs"].update(num_modes=K, future_steps=T, max_fut_t=spec["max_fut_t"])
+        for m in cfg["metric_args"]:
+            m["end_idcs"] = [T - 1, T - 1]
     if args.ood:
         cfg["model_specific"]["kwargs"]["ood"] = True                                # test.py:45-46
     dev = torch.device("cuda", local_rank)
     model = build_model(cfg, args.ckpt, dev, init_seed=0 if args.ckpt is None else None)
-    res = evaluate(model, synthetic_batches(args.synthetic, args.batches, dev, rank, world))   # metric states all-reduce in compute()
+    if args.data:
+        batches = datamodule_batches(cfg, dev, rank, world, args.nu_dir, args.argo_dir)
+    else:
+        batches = synthetic_batches(args.synthetic, args.batches, dev, rank, world)
+    res = evaluate(model, batches)                                                    # metric states all-reduce in compute()
     if rank == 0:
         text = json.dumps(res)
         if args.out:
