@@ -40,7 +40,13 @@ int trajsde_abi_version(void);
  * of device pointers in the order given by trajsde_param_name(stage, i) (state_dict key relative to
  * the stage) and gets back one packed fp32 blob laid out as the kernels' LDS images
  * (MFMA-fragment order for matrices).  Re-pack whenever a parameter changes. */
-typedef enum { TRAJSDE_STAGE_ENCODER = 0, TRAJSDE_STAGE_AGGREGATOR = 1, TRAJSDE_STAGE_DECODER = 2 } trajsde_stage;
+typedef enum {
+  TRAJSDE_STAGE_ENCODER = 0,
+  TRAJSDE_STAGE_AGGREGATOR = 1,
+  TRAJSDE_STAGE_DECODER = 2,
+  TRAJSDE_STAGE_DECODER_BWD = 3 /* transposed images for trajsde_decoder_l2_backward; its parameter list is the
+                                   subset of the decoder's that receives a gradient */
+} trajsde_stage;
 
 int trajsde_param_count(int stage, int num_layers /*aggregator*/, int num_modes);
 const char* trajsde_param_name(int stage, int index, int num_layers, int num_modes);
@@ -165,6 +171,22 @@ int trajsde_decoder_forward(int32_t N, int num_modes, int future_steps, const fl
                             const float* out_table /*[T,4] (steps_done,w0,w1,0)*/, float min_scale,
                             const trajsde_noise* noise /* z: [n_euler,K*N,64] */, void* ws, int64_t ws_bytes,
                             float* loc /*[K,N,T,4]*/, float* pi /*[N,K]*/, void* stream);
+
+/* ---- winner-takes-all L2 regression loss (losses/L2.py:10-27) + backward of the decoder stage: gradients of
+ *      loss = mean over valid (actor, step) of |y - loc[best mode]| w.r.t. the decoder parameters and the stage
+ *      inputs.  `loc` is the forward output, `noise` the same noise (seed or z) the forward used; the winning
+ *      paths are replayed and differentiated through every Euler-Maruyama step.  `grads[i]` is a buffer shaped
+ *      like parameter trajsde_param_name(TRAJSDE_STAGE_DECODER_BWD, i) and is overwritten; `blob_bwd` is that
+ *      stage's packed image, `blob_fwd` the TRAJSDE_STAGE_DECODER one.  The pi and scale heads get no gradient
+ *      from this loss.  best_mode may be null. */
+int64_t trajsde_decoder_backward_ws_bytes(int32_t N, int num_modes, int future_steps, int n_euler);
+int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, const float* blob_fwd, const float* blob_bwd,
+                                const float* local_embed /*[N,64]*/, const float* global_embed /*[K,N,64]*/,
+                                const float* step_table /*[n_euler,8]*/, int n_euler, const float* out_table /*[T,4]*/,
+                                const trajsde_noise* noise, const float* loc /*[K,N,T,4]*/, const float* y /*[N,T,2]*/,
+                                const uint8_t* reg_mask /*[N,T]*/, void* ws, int64_t ws_bytes, float* loss /*[1] device*/,
+                                int32_t* best_mode /*[N] device or null*/, float* const* grads, int n_grads,
+                                float* d_local /*[N,64]*/, float* d_global /*[K,N,64]*/, void* stream);
 
 /* ---- step-granular decoder SDE step (state round-trips HBM every step): the 512 B/path-step variant
  *      of SURVEY.md 8(d), kept for the HBM-roofline measurement the north star asks for. */

@@ -1,0 +1,123 @@
+"""GPU tests (-m gpu) of the backward kernels: the winner-takes-all L2 loss + decoder-stage backward through the
+C-ABI against torch.autograd run over the CPU oracle's restatement of the same stage (oracle/restate.py, which is
+pinned against the reference by the golden vectors).  Tolerances are relative to the largest entry of each
+gradient tensor: fp32 sums over ~1e5 rows on both sides."""
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+REL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from trajsde_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _reference_l2(y, loc, reg_mask):
+    """losses/L2.py:10-27 spelled out on tensors (mean reduction)"""
+    l2 = torch.norm(y.unsqueeze(0) - loc, p=2, dim=-1)
+    ade = l2.clone()
+    ade[:, ~reg_mask] = 0
+    best = torch.argmin(ade.mean(-1), dim=0)
+    minl2 = l2[best, torch.arange(l2.size(1))]
+    return minl2[reg_mask].mean(), best
+
+
+def _oracle_grads(model, cfg, batch_cpu, local, glob, y_rot, seed):
+    import restate
+    from trajsde_amd.schedule import decoder_schedule
+    c = restate.flat_cfg(cfg)
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    names = [k for k in P if k.startswith("decoder.")]
+    for k in names:
+        P[k].requires_grad_(True)
+    local = local.detach().cpu().clone().requires_grad_(True)
+    glob = glob.detach().cpu().clone().requires_grad_(True)
+    sched = decoder_schedule(c["future_steps"], c["max_fut_t"], c["min_stepsize"])
+    with torch.enable_grad():
+        out = restate.sde_decoder(P, c, batch_cpu, local, glob, restate.PhiloxNoise(seed), sched)
+        loss, best = _reference_l2(y_rot.cpu(), out["loc"][..., :2], out["reg_mask"])
+        loss.backward()
+    grads = {k[len("decoder."):]: (P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])) for k in names}
+    return float(loss.detach()), best, grads, local.grad, glob.grad
+
+
+def _rel(a, b):
+    scale = max(float(b.abs().max()), 1e-12)
+    return float((a.double().cpu() - b.double()).abs().max()) / scale
+
+
+@pytest.mark.parametrize("S,n,K,T,max_t,kw", [
+    (3, 20, 4, 20, 2.0, dict(mixed_source=True, history_dropout=0.3)),
+    (2, 13, 3, 30, 3.0, dict(source=1)),            # T=30: the solver's extra micro-step, outputs interpolated
+    (2, 9, 1, 5, 0.5, dict(nus_sparsity=True)),     # a single mode, ragged masks
+])
+def test_decoder_l2_backward_matches_autograd(S, n, K, T, max_t, kw, dev):
+    from trajsde_amd import runtime
+    from trajsde_amd.synth import synth
+    batch = synth(S=S, n=n, L=6, F=T, box=80.0, seed=300 + n, **kw)
+    model, cfg = H.build_model(K, T, max_t, init_seed=11)
+    model = model.to(dev)
+    data = batch.to(dev)
+    noise = runtime.NoiseSpec(seed=91)
+    rot, y_rot = runtime.rotate_inputs(data)
+    data.y, data["rotate_mat"] = y_rot, rot
+    local, *_ = model.encoder(data=data, noise=noise)
+    glob = model.aggregator(data=data, local_embed=local)
+    out = model.decoder(data=data, local_embed=local, global_embed=glob, noise=noise)
+    res = model.decoder._rt.decoder_l2_backward(data, local, glob, out, noise)
+    torch.cuda.synchronize()
+
+    want_loss, want_best, want, d_local, d_glob = _oracle_grads(model, cfg, batch, local, glob, y_rot, 91)
+    assert torch.equal(res["best_mode"].cpu().long(), want_best)
+    assert abs(float(res["loss"]) - want_loss) <= 1e-5 * max(1.0, abs(want_loss))
+    # the loss the kernels report is losses.L2 on the forward output
+    from trajsde_amd.losses import L2
+    assert abs(float(L2()(data, out)) - float(res["loss"])) <= 1e-5 * max(1.0, abs(want_loss))
+    got = res["grads"]
+    for k in set(want) - set(got):
+        assert float(want[k].abs().max()) == 0.0, k               # pi / scale heads, unused buffers: no gradient path
+    assert set(got) <= set(want)
+    for k, g in got.items():
+        assert g.shape == want[k].shape, k
+        assert torch.isfinite(g).all(), k
+        assert _rel(g, want[k]) <= REL, (k, _rel(g, want[k]))
+    assert _rel(res["d_local_embed"], d_local) <= REL
+    assert _rel(res["d_global_embed"], d_glob) <= REL
+    # only the winning mode of each actor receives gradient
+    dg = res["d_global_embed"].cpu()
+    lose = torch.ones(K, dg.shape[1], dtype=torch.bool)
+    lose[want_best, torch.arange(dg.shape[1])] = False
+    assert float(dg[lose].abs().max()) == 0.0 if lose.any() else True
+
+
+def test_decoder_backward_is_deterministic_and_checks_arguments(dev):
+    from trajsde_amd import _lib, runtime
+    from trajsde_amd.synth import synth
+    batch = synth(S=2, n=24, L=6, F=20, box=80.0, seed=5, mixed_source=True)
+    model, _ = H.build_model(3, 20, 2.0, init_seed=2)
+    model = model.to(dev)
+    data = batch.to(dev)
+    noise = runtime.NoiseSpec(seed=7)
+    rot, y_rot = runtime.rotate_inputs(data)
+    data.y, data["rotate_mat"] = y_rot, rot
+    local, *_ = model.encoder(data=data, noise=noise)
+    glob = model.aggregator(data=data, local_embed=local)
+    out = model.decoder(data=data, local_embed=local, global_embed=glob, noise=noise)
+    a = model.decoder._rt.decoder_l2_backward(data, local, glob, out, noise)
+    b = model.decoder._rt.decoder_l2_backward(data, local, glob, out, noise)
+    for k in a["grads"]:
+        assert torch.equal(a["grads"][k], b["grads"][k]), k        # two-stage reductions, no atomics
+    assert torch.equal(a["d_local_embed"], b["d_local_embed"])
+    with pytest.raises(_lib.TrajsdeError):
+        model.decoder._rt.decoder_l2_backward(data, local, glob, out, None)
+    data.y = y_rot[:, :10]
+    with pytest.raises(_lib.TrajsdeError):
+        model.decoder._rt.decoder_l2_backward(data, local, glob, out, noise)

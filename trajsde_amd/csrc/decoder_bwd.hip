@@ -1,0 +1,760 @@
+// decoder_bwd.hip -- winner-takes-all L2 regression loss (reference losses/L2.py:10-27) and the backward pass of the
+// SDEDecoder stage (DEC:77-105) for gfx950: gradients w.r.t. the decoder's parameters and w.r.t. its two inputs
+// (local_embed, global_embed).  First family of SURVEY.md 8(f) rank 1.
+//
+// Only the winning mode of each actor carries gradient, so everything below runs on N rows (path r_i = best_i*N + i),
+// not K*N.  The Euler-Maruyama solve is differentiated "discretise-then-optimise": the forward trajectory of the
+// N winning paths is replayed once (same Philox counters, so the same noise) keeping every state and hidden
+// activation, then a reverse sweep propagates dL/dy_k through the step map y' = y + f(y,t) dt + g(y,t) z sqrt(h).
+//
+//   k_l2_wta / k_l2_finalize   best mode per actor, loss value, 1/count
+//   k_init_sel                 y0 of the winning paths                      (aggr_embed, DEC:82)
+//   k_sde_replay               forward replay, keeps y_k, tanh activations and g  [step][row][64]
+//   k_head_bwd                 loc head forward + backward per (row, output step): dL/ds_o, saves (s, du)
+//   k_sde_bwd                  the reverse sweep; saves the pre-activation gradients of the five linears
+//   k_dec_init_bwd             aggr_embed backward: d local_embed, d global_embed, saves (input, da)
+//   k_wgrad / k_reduce_partials   dW = sum_rows delta^T a  as MFMA outer products over saved rows (deterministic
+//                              two-stage reduction), bias = column sums, time-feature columns = step-weighted sums
+//
+// Matrix products use the exact-fp32 MFMA path (tile.hpp linear_acc) on transposed fragment images (layouts.hpp
+// SweepL / HeadBwdL / InitBwdL): dX^T = W^T dY^T has the same "row on lane" operand/result layout as the forward.
+#include <cstdlib>
+
+#include "common.hpp"
+#include "layouts.hpp"
+#include "philox.hpp"
+#include "sde_funcs.hpp"
+#include "tile.hpp"
+
+namespace tsde {
+
+// ------------------------------------------------------------------ tile helpers used only by backward kernels
+// x -> x_hat in place (the normalisation of tile.hpp layer_norm without the affine part); returns 1/std
+__device__ __forceinline__ float ln_normalize(f4 (&a)[4]) {
+  float s = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) s += (a[jt][0] + a[jt][1]) + (a[jt][2] + a[jt][3]);
+  const float mean = row_sum(s) * (1.0f / 64);
+  float v = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = a[jt][c] - mean;
+      a[jt][c] = d;
+      v += d * d;
+    }
+  const float rstd = 1.0f / sqrtf(row_sum(v) * (1.0f / 64) + 1e-5f);
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[jt][c] *= rstd;
+  return rstd;
+}
+
+// dy (grad w.r.t. gamma*x_hat+beta) -> grad w.r.t. the LayerNorm input, in place; accumulates dgamma, dbeta
+__device__ __forceinline__ void ln_backward(f4 (&dy)[4], const f4 (&xh)[4], float rstd, const float* gamma, int g,
+                                            f4 (&dgam)[4], f4 (&dbet)[4]) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    const f4 ga = *reinterpret_cast<const f4*>(gamma + 16 * jt + 4 * g);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      dgam[jt][c] = fmaf(dy[jt][c], xh[jt][c], dgam[jt][c]);
+      dbet[jt][c] += dy[jt][c];
+      const float gm = ga[c] * dy[jt][c];
+      dy[jt][c] = gm;
+      s1 += gm;
+      s2 = fmaf(gm, xh[jt][c], s2);
+    }
+  }
+  const float m1 = row_sum(s1) * (1.0f / 64), m2 = row_sum(s2) * (1.0f / 64);
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dy[jt][c] = rstd * (dy[jt][c] - m1 - xh[jt][c] * m2);
+}
+
+__device__ __forceinline__ void zero4(f4 (&a)[4]) {
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) a[jt] = f4{0.f, 0.f, 0.f, 0.f};
+}
+
+// out = W^T-image * in  (no bias)
+__device__ __forceinline__ void linear_t(f4 (&out)[4], const f4 (&in)[4], const float* wt, const Lane& L) {
+  zero4(out);
+  linear_acc<4, 4>(out, in, wt, L.lane);
+}
+
+// sum a per-lane accumulator over the 16 rows of the wave's tiles (lanes with equal g) -> 64 floats at dst
+__device__ __forceinline__ void flush_vec(const f4 (&acc)[4], float* dst, const Lane& L) {
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    f4 v = acc[jt];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float x = v[c];
+      x += __shfl_xor(x, 1);
+      x += __shfl_xor(x, 2);
+      x += __shfl_xor(x, 4);
+      x += __shfl_xor(x, 8);
+      v[c] = x;
+    }
+    if (L.n == 0) *reinterpret_cast<f4*>(dst + 16 * jt + 4 * L.g) = v;
+  }
+}
+// the same for a value that is already equal on the 4 lanes of a row
+__device__ __forceinline__ void flush_scalar(float x, float* dst, const Lane& L) {
+  x += __shfl_xor(x, 1);
+  x += __shfl_xor(x, 2);
+  x += __shfl_xor(x, 4);
+  x += __shfl_xor(x, 8);
+  if (L.lane == 0) *dst = x;
+}
+
+// ------------------------------------------------------------------ loss
+// one thread per actor: masked L2 per mode, first minimum wins (L2.py:19-22)
+__global__ void k_l2_wta(const float* __restrict__ loc, const float* __restrict__ y, const uint8_t* __restrict__ mask, int N, int K,
+                         int T, int32_t* __restrict__ best, float* __restrict__ minsum, int32_t* __restrict__ cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int c = 0;
+  for (int t = 0; t < T; ++t) c += mask[int64_t(i) * T + t] ? 1 : 0;
+  int bk = 0;
+  float bs = 0.f;
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) {
+      if (!mask[int64_t(i) * T + t]) continue;
+      const f4 l = *reinterpret_cast<const f4*>(loc + ((int64_t(k) * N + i) * T + t) * 4);
+      const float dx = y[(int64_t(i) * T + t) * 2] - l[0], dy = y[(int64_t(i) * T + t) * 2 + 1] - l[1];
+      s += sqrtf(dx * dx + dy * dy);
+    }
+    if (k == 0 || s < bs) {
+      bs = s;
+      bk = k;
+    }
+  }
+  best[i] = bk;
+  minsum[i] = bs;
+  cnt[i] = c;
+}
+
+// scal[0] = loss = sum(minsum) / count, scal[1] = 1/count (0 when nothing is valid); fixed summation order
+__global__ __launch_bounds__(1024) void k_l2_finalize(const float* __restrict__ minsum, const int32_t* __restrict__ cnt, int N,
+                                                      float* __restrict__ scal) {
+  __shared__ double ssum[1024];
+  __shared__ long long scnt[1024];
+  double s = 0.0;
+  long long c = 0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    s += double(minsum[i]);
+    c += cnt[i];
+  }
+  ssum[threadIdx.x] = s;
+  scnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if (int(threadIdx.x) < w) {
+      ssum[threadIdx.x] += ssum[threadIdx.x + w];
+      scnt[threadIdx.x] += scnt[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    scal[0] = scnt[0] > 0 ? float(ssum[0] / double(scnt[0])) : 0.f;
+    scal[1] = scnt[0] > 0 ? float(1.0 / double(scnt[0])) : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ forward replay of the winning paths
+__global__ __launch_bounds__(128) void k_init_sel(const float* __restrict__ img, const float* __restrict__ local,
+                                                  const float* __restrict__ global, const int32_t* __restrict__ best, int N,
+                                                  float* __restrict__ y0, float* __restrict__ gsel) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img, InitBwdL::AE_END);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int ntiles = (N + 15) / 16;
+  for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
+    keep_lds_reads_here();
+    const int row = tile * 16 + L.n;
+    const int i = row < N ? row : N - 1;
+    f4 gl[4], lo[4], a[4];
+    load_row(gl, global, int64_t(best[i]) * N + i, L.g);
+    load_row(lo, local, i, L.g);
+    load_vec<4>(a, lds + InitBwdL::BA, L.g);
+    linear_acc<4, 4>(a, gl, lds + InitBwdL::WA_G, L.lane);
+    linear_acc<4, 4>(a, lo, lds + InitBwdL::WA_L, L.lane);
+    layer_norm<4>(a, lds + InitBwdL::AG, lds + InitBwdL::AE, L.g);
+    relu<4>(a);
+    if (row < N) {
+      store_row(a, y0, row, L.g);
+      store_row(gl, gsel, row, L.g);
+    }
+  }
+}
+
+// states [n_euler+1][N][64] (slab 0 = y0 on entry); H1,H2,G1,G2 [n_euler][N][64]; GS [n_euler][N]
+__global__ __launch_bounds__(128) void k_sde_replay(const float* __restrict__ img, const int32_t* __restrict__ best, int N, int K,
+                                                    int n_euler, const float* __restrict__ step_tab, NoiseArg na,
+                                                    float* __restrict__ states, float* __restrict__ H1, float* __restrict__ H2,
+                                                    float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ GS) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img, DecSdeL::LOC);                      // drift + diffusion images
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int ntiles = (N + 15) / 16;
+  const int64_t slab = int64_t(N) * D;
+  for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
+    const int row = tile * 16 + L.n;
+    const int i = row < N ? row : N - 1;
+    const int64_t r = int64_t(best[i]) * N + i;
+    f4 y[4];
+    load_row(y, states, i, L.g);
+    for (int k = 0; k < n_euler; ++k) {
+      keep_lds_reads_here();
+      const float dt = step_tab[k * 8 + 1], sq = step_tab[k * 8 + 2], sn = step_tab[k * 8 + 3], cs = step_tab[k * 8 + 4];
+      const float* F = lds + DecSdeL::F;
+      const float* G = lds + DecSdeL::G;
+      f4 h1[4], h2[4], f[4], z[4];
+      sde_layer0(h1, y, F, DriftL::W0, DriftL::WS, DriftL::WC, DriftL::B0, sn, cs, L);
+      tanh_<4>(h1);
+      linear<4, 4>(h2, h1, F + DriftL::W2, F + DriftL::B2, L);
+      tanh_<4>(h2);
+      linear<4, 4>(f, h2, F + DriftL::W4, F + DriftL::B4, L);
+      if (row < N) {
+        store_row(h1, H1 + k * slab, row, L.g);
+        store_row(h2, H2 + k * slab, row, L.g);
+      }
+      sde_layer0(h1, y, G, DiffL::W0, DiffL::WS, DiffL::WC, DiffL::B0, sn, cs, L);
+      tanh_<4>(h1);
+      linear<4, 4>(h2, h1, G + DiffL::W2, G + DiffL::B2, L);
+      tanh_<4>(h2);
+      const float gs = fast_sigmoid(row_dot(h2, G + DiffL::W4, L.g) + G[DiffL::B4]);
+      if (row < N) {
+        store_row(h1, G1 + k * slab, row, L.g);
+        store_row(h2, G2 + k * slab, row, L.g);
+        if (L.g == 0) GS[int64_t(k) * N + row] = gs;
+      }
+      noise_row(z, na, STREAM_DECODER, k, r, int64_t(N) * K, L.g);
+      em_update(y, f, gs, z, dt, sq);
+      if (row < N) store_row(y, states + (k + 1) * slab, row, L.g);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ loc head: forward + backward per (row, output)
+// vector-gradient slots of one wave in `vpart` (floats)
+struct HeadV { enum : int { DGAM = 0, DBET = 64, DW3X = 128, DW3Y = 192, DB3 = 256, SIZE = 264 }; };
+
+// rows are (o, i): o = output step, i = actor.  S_in / DU / DS are [T][N][64]
+__global__ __launch_bounds__(128) void k_head_bwd(const float* __restrict__ img, const float* __restrict__ states,
+                                                  const float* __restrict__ out_tab, const float* __restrict__ y,
+                                                  const uint8_t* __restrict__ mask, const float* __restrict__ scal, int N, int T,
+                                                  float* __restrict__ S_in, float* __restrict__ DU, float* __restrict__ DS,
+                                                  float* __restrict__ vpart) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img, HeadBwdL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int tiles_per_o = (N + 15) / 16;
+  const int ntiles = tiles_per_o * T;
+  const int64_t slab = int64_t(N) * D;
+  const float inv_count = scal[1];
+  const float* H = lds + HeadBwdL::FWD;
+  f4 dgam[4], dbet[4], dw3x[4], dw3y[4];
+  zero4(dgam); zero4(dbet); zero4(dw3x); zero4(dw3y);
+  float db3x = 0.f, db3y = 0.f;
+  for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
+    keep_lds_reads_here();
+    const int o = tile / tiles_per_o;
+    const int row = (tile - o * tiles_per_o) * 16 + L.n;
+    const int i = row < N ? row : N - 1;
+    const int ko = int(out_tab[o * 4]);
+    const float w0 = out_tab[o * 4 + 1], w1 = out_tab[o * 4 + 2];
+    f4 s[4], u[4], v[4];
+    {
+      f4 a[4], b[4];
+      load_row(a, states + (ko - 1) * slab, i, L.g);
+      load_row(b, states + ko * slab, i, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[jt][c] = w0 * a[jt][c] + w1 * b[jt][c];
+    }
+    linear<4, 4>(u, s, H + HeadL::W0, H + HeadL::B0, L);
+    const float rstd = ln_normalize(u);                     // u = x_hat
+    bool pos[16];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const f4 ga = *reinterpret_cast<const f4*>(H + HeadL::G + 16 * jt + 4 * L.g);
+      const f4 be = *reinterpret_cast<const f4*>(H + HeadL::E + 16 * jt + 4 * L.g);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float pre = u[jt][c] * ga[c] + be[c];
+        pos[jt * 4 + c] = pre > 0.f;
+        v[jt][c] = fmaxf(pre, 0.f);
+      }
+    }
+    const float lx = row_dot(v, H + HeadL::W3, L.g) + H[HeadL::B3];
+    const float ly = row_dot(v, H + HeadL::W3 + 64, L.g) + H[HeadL::B3 + 1];
+    // dL/dl = (l - y) / |l - y| / count on valid steps (L2.py:16,25)
+    float gx = 0.f, gy = 0.f;
+    if (row < N && mask[int64_t(i) * T + o]) {
+      const float dx = lx - y[(int64_t(i) * T + o) * 2], dy = ly - y[(int64_t(i) * T + o) * 2 + 1];
+      const float nrm = sqrtf(dx * dx + dy * dy);
+      if (nrm > 0.f) {
+        gx = dx / nrm * inv_count;
+        gy = dy / nrm * inv_count;
+      }
+    }
+    db3x += gx;
+    db3y += gy;
+    f4 dv[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const f4 wx = *reinterpret_cast<const f4*>(H + HeadL::W3 + 16 * jt + 4 * L.g);
+      const f4 wy = *reinterpret_cast<const f4*>(H + HeadL::W3 + 64 + 16 * jt + 4 * L.g);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        dw3x[jt][c] = fmaf(gx, v[jt][c], dw3x[jt][c]);
+        dw3y[jt][c] = fmaf(gy, v[jt][c], dw3y[jt][c]);
+        dv[jt][c] = pos[jt * 4 + c] ? fmaf(gx, wx[c], gy * wy[c]) : 0.f;
+      }
+    }
+    ln_backward(dv, u, rstd, H + HeadL::G, L.g, dgam, dbet);      // dv := du
+    f4 ds[4];
+    linear_t(ds, dv, lds + HeadBwdL::W0T, L);
+    if (row < N) {
+      store_row(s, S_in + o * slab, row, L.g);
+      store_row(dv, DU + o * slab, row, L.g);
+      store_row(ds, DS + o * slab, row, L.g);
+    }
+  }
+  float* vp = vpart + int64_t(blockIdx.x * waves + wave) * HeadV::SIZE;
+  flush_vec(dgam, vp + HeadV::DGAM, L);
+  flush_vec(dbet, vp + HeadV::DBET, L);
+  flush_vec(dw3x, vp + HeadV::DW3X, L);
+  flush_vec(dw3y, vp + HeadV::DW3Y, L);
+  flush_scalar(db3x, vp + HeadV::DB3, L);
+  flush_scalar(db3y, vp + HeadV::DB3 + 1, L);
+}
+
+// ------------------------------------------------------------------ reverse sweep through the Euler-Maruyama steps
+struct SweepV { enum : int { DV4 = 0, DC4 = 64, SIZE = 68 }; };
+
+__global__ __launch_bounds__(128) void k_sde_bwd(const float* __restrict__ img, const int32_t* __restrict__ best, int N, int K, int T,
+                                                 int n_euler, const float* __restrict__ step_tab, const float* __restrict__ out_tab,
+                                                 NoiseArg na, const float* __restrict__ H1, const float* __restrict__ H2,
+                                                 const float* __restrict__ G1, const float* __restrict__ G2,
+                                                 const float* __restrict__ GS, const float* __restrict__ DS,
+                                                 float* __restrict__ DH1, float* __restrict__ DH2, float* __restrict__ DF,
+                                                 float* __restrict__ DG1, float* __restrict__ DG2, float* __restrict__ DY0,
+                                                 float* __restrict__ vpart) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img, SweepL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int ntiles = (N + 15) / 16;
+  const int64_t slab = int64_t(N) * D;
+  f4 dv4[4];
+  zero4(dv4);
+  float dc4 = 0.f;
+  for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
+    const int row = tile * 16 + L.n;
+    const int i = row < N ? row : N - 1;
+    const bool live = row < N;
+    const int64_t r = int64_t(best[i]) * N + i;
+    f4 dy[4];                                             // dL/dy_{k+1} on entry of iteration k
+    zero4(dy);
+    int o = T - 1;
+    for (int k = n_euler - 1; k >= 0; --k) {
+      keep_lds_reads_here();
+      const float dt = step_tab[k * 8 + 1], sq = step_tab[k * 8 + 2];
+      // outputs interpolated between y_k and y_{k+1}: s_o = w0 y_k + w1 y_{k+1}
+      f4 dprev[4];
+      zero4(dprev);
+      while (o >= 0 && int(out_tab[o * 4]) == k + 1) {
+        const float w0 = out_tab[o * 4 + 1], w1 = out_tab[o * 4 + 2];
+        f4 ds[4];
+        load_row(ds, DS + o * slab, i, L.g);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            dy[jt][c] = fmaf(w1, ds[jt][c], dy[jt][c]);
+            dprev[jt][c] = fmaf(w0, ds[jt][c], dprev[jt][c]);
+          }
+        --o;
+      }
+      f4 a[4], d[4], t[4];
+      // ---- drift net: y' gets f*dt
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[jt][c] = dt * dy[jt][c];
+      if (live) store_row(d, DF + k * slab, row, L.g);
+      linear_t(t, d, lds + SweepL::F_W4T, L);
+      load_row(a, H2 + k * slab, i, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - a[jt][c] * a[jt][c]);
+      if (live) store_row(d, DH2 + k * slab, row, L.g);
+      linear_t(t, d, lds + SweepL::F_W2T, L);
+      load_row(a, H1 + k * slab, i, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - a[jt][c] * a[jt][c]);
+      if (live) store_row(d, DH1 + k * slab, row, L.g);
+      f4 dyn[4];                                          // dL/dy_k being assembled
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) dyn[jt] = dy[jt] + dprev[jt];
+      linear_acc<4, 4>(dyn, d, lds + SweepL::F_W0T, L.lane);
+      // ---- diffusion net: y' gets g * (z sqrt(h)), g one scalar per row
+      f4 z[4];
+      noise_row(z, na, STREAM_DECODER, k, r, int64_t(N) * K, L.g);
+      float cdot = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cdot = fmaf(z[jt][c] * sq, dy[jt][c], cdot);
+      const float gs = GS[int64_t(k) * N + i];
+      const float dgp = row_sum(cdot) * gs * (1.0f - gs);
+      load_row(a, G2 + k * slab, i, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const f4 w4 = *reinterpret_cast<const f4*>(lds + SweepL::G_W4 + 16 * jt + 4 * L.g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (live) dv4[jt][c] = fmaf(dgp, a[jt][c], dv4[jt][c]);
+          d[jt][c] = dgp * w4[c] * (1.0f - a[jt][c] * a[jt][c]);
+        }
+      }
+      if (live) {
+        dc4 += dgp;
+        store_row(d, DG2 + k * slab, row, L.g);
+      }
+      linear_t(t, d, lds + SweepL::G_W2T, L);
+      load_row(a, G1 + k * slab, i, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - a[jt][c] * a[jt][c]);
+      if (live) store_row(d, DG1 + k * slab, row, L.g);
+      linear_acc<4, 4>(dyn, d, lds + SweepL::G_W0T, L.lane);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) dy[jt] = dyn[jt];
+    }
+    if (live) store_row(dy, DY0, row, L.g);
+  }
+  float* vp = vpart + int64_t(blockIdx.x * waves + wave) * SweepV::SIZE;
+  flush_vec(dv4, vp + SweepV::DV4, L);
+  flush_scalar(dc4, vp + SweepV::DC4, L);
+}
+
+// ------------------------------------------------------------------ aggr_embed backward
+struct InitV { enum : int { DGAM = 0, DBET = 64, SIZE = 128 }; };
+
+__global__ __launch_bounds__(128) void k_dec_init_bwd(const float* __restrict__ img, const float* __restrict__ local,
+                                                      const float* __restrict__ gsel, const float* __restrict__ DY0,
+                                                      const int32_t* __restrict__ best, int N, float* __restrict__ DA,
+                                                      float* __restrict__ d_local, float* __restrict__ d_global,
+                                                      float* __restrict__ vpart) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img, InitBwdL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int ntiles = (N + 15) / 16;
+  f4 dgam[4], dbet[4];
+  zero4(dgam); zero4(dbet);
+  for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
+    keep_lds_reads_here();
+    const int row = tile * 16 + L.n;
+    const int i = row < N ? row : N - 1;
+    f4 gl[4], lo[4], a[4], d[4];
+    load_row(gl, gsel, i, L.g);
+    load_row(lo, local, i, L.g);
+    load_vec<4>(a, lds + InitBwdL::BA, L.g);
+    linear_acc<4, 4>(a, gl, lds + InitBwdL::WA_G, L.lane);
+    linear_acc<4, 4>(a, lo, lds + InitBwdL::WA_L, L.lane);
+    const float rstd = ln_normalize(a);
+    load_row(d, DY0, i, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const f4 ga = *reinterpret_cast<const f4*>(lds + InitBwdL::AG + 16 * jt + 4 * L.g);
+      const f4 be = *reinterpret_cast<const f4*>(lds + InitBwdL::AE + 16 * jt + 4 * L.g);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (!(a[jt][c] * ga[c] + be[c] > 0.f) || row >= N) d[jt][c] = 0.f;
+    }
+    ln_backward(d, a, rstd, lds + InitBwdL::AG, L.g, dgam, dbet);   // d := d a_pre
+    f4 t[4];
+    if (row < N) store_row(d, DA, row, L.g);
+    linear_t(t, d, lds + InitBwdL::WA_GT, L);
+    if (row < N) store_row(t, d_global, int64_t(best[i]) * N + i, L.g);
+    linear_t(t, d, lds + InitBwdL::WA_LT, L);
+    if (row < N) store_row(t, d_local, row, L.g);
+  }
+  float* vp = vpart + int64_t(blockIdx.x * waves + wave) * InitV::SIZE;
+  flush_vec(dgam, vp + InitV::DGAM, L);
+  flush_vec(dbet, vp + InitV::DBET, L);
+}
+
+// ------------------------------------------------------------------ weight gradients from saved rows
+// part[p] = sum_{rows of chunk p} delta[r][:]^T a[r][:]  (64x64, [o][i]),  cs[p][o] = sum delta[r][o].
+// Chunks never straddle a group (= one Euler step of rows_per_group rows), so the reducer can weight them per step.
+__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ delta, const float* __restrict__ a, int64_t R,
+                                               int64_t rows_per_group, int chunk, int chunks_per_group,
+                                               float* __restrict__ part, float* __restrict__ cs) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  float (*red)[4096] = reinterpret_cast<float (*)[4096]>(dyn);                  // [4 waves][64x64]
+  float (*csr)[4][64] = reinterpret_cast<float (*)[4][64]>(dyn + 4 * 4096);      // [4 waves][4 k-groups][64]
+  const int p = blockIdx.x;
+  const int group = p / chunks_per_group, sub = p - group * chunks_per_group;
+  const int64_t row0 = group * rows_per_group + int64_t(sub) * chunk;
+  int64_t row1 = row0 + chunk;
+  if (row1 > (group + 1) * rows_per_group) row1 = (group + 1) * rows_per_group;
+  if (row1 > R) row1 = R;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, idx = lane & 15, kg = lane >> 4;
+  f4 acc[4][4];
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) acc[ot][it] = f4{0.f, 0.f, 0.f, 0.f};
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t rb = row0 + 4 * wave; rb < row1; rb += 16) {
+    const int64_t r = rb + kg;
+    float A[4], B[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      A[q] = r < row1 ? delta[r * D + 16 * q + idx] : 0.f;
+      B[q] = r < row1 ? a[r * D + 16 * q + idx] : 0.f;
+      csum[q] += A[q];
+    }
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ot], B[it], acc[ot][it], 0, 0, 0);
+  }
+  // D fragment: lane holds dW[16ot + 4kg + reg][16it + idx]
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) red[wave][(16 * ot + 4 * kg + reg) * 64 + 16 * it + idx] = acc[ot][it][reg];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) csr[wave][kg][16 * q + idx] = csum[q];
+  __syncthreads();
+  for (int j = threadIdx.x; j < 4096; j += 256)
+    part[int64_t(p) * 4096 + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) s += csr[w][g][threadIdx.x];
+    cs[int64_t(p) * 64 + threadIdx.x] = s;
+  }
+}
+
+// W[o*ldw + col0 + i] = sum_p part[p][o][i];  bias[o] = sum_p cs[p][o];  with time_cols the (sin t, cos t) input
+// columns 64 / 65 of the 66-wide first SDE layer: W[o*ldw + 64] = sum_p sin(t_group(p)) cs[p][o], likewise cos
+__global__ void k_reduce_partials(const float* __restrict__ part, const float* __restrict__ cs, int P, int chunks_per_group,
+                                  const float* __restrict__ step_tab, float* __restrict__ W, int ldw, int col0,
+                                  float* __restrict__ bias, int time_cols) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < 4096) {
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[int64_t(p) * 4096 + j];
+    W[(j >> 6) * ldw + col0 + (j & 63)] = s;
+  } else if (j < 4096 + 64) {
+    const int o = j - 4096;
+    float b = 0.f, ws = 0.f, wc = 0.f;
+    for (int p = 0; p < P; ++p) {
+      const float v = cs[int64_t(p) * 64 + o];
+      b += v;
+      if (time_cols) {
+        const int k = p / chunks_per_group;
+        ws = fmaf(step_tab[k * 8 + 3], v, ws);
+        wc = fmaf(step_tab[k * 8 + 4], v, wc);
+      }
+    }
+    if (bias) bias[o] = b;
+    if (time_cols) {
+      W[o * ldw + 64] = ws;
+      W[o * ldw + 65] = wc;
+    }
+  }
+}
+
+// dst[j] = sum_w src[w*stride + j], j < n   (per-wave vector partials -> one vector)
+__global__ void k_colsum(const float* __restrict__ src, int rows, int stride, int n, float* __restrict__ dst) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.f;
+  for (int w = 0; w < rows; ++w) s += src[int64_t(w) * stride + j];
+  dst[j] = s;
+}
+
+}  // namespace tsde
+
+using namespace tsde;
+
+namespace {
+
+// gradient slots, in the order of trajsde_param_name(TRAJSDE_STAGE_DECODER_BWD, i)  (pack.hip recipe_decoder_bwd)
+enum GradSlot {
+  F0W = 0, F2W, F4W, G0W, G2W, G4W, D0W, D0B, D1W, D1B, D3W, D3B, A0W, A0B, A1W, A1B, F0B, F2B, F4B, G0B, G2B, G4B, N_GRADS
+};
+constexpr int WGRAD_CHUNK = 512;
+constexpr int BWD_THREADS = 128;
+
+struct BwdWs {
+  int32_t *best, *cnt;
+  float *minsum, *scal, *states, *H1, *H2, *G1, *G2, *GS, *DH1, *DH2, *DF, *DG1, *DG2, *S_in, *DU, *DS, *gsel, *DA, *DY0, *part, *cs,
+      *vpart;
+  int64_t bytes;
+};
+
+BwdWs carve_bwd(void* ws, int64_t ws_bytes, int N, int T, int n_euler, bool& ok) {
+  Carver cv(ws, ws_bytes);
+  BwdWs w;
+  const int64_t slab = int64_t(N) * 64;
+  w.best = cv.take<int32_t>(N);
+  w.cnt = cv.take<int32_t>(N);
+  w.minsum = cv.take<float>(N);
+  w.scal = cv.take<float>(4);
+  w.states = cv.take<float>(slab * (n_euler + 1));
+  w.H1 = cv.take<float>(slab * n_euler);
+  w.H2 = cv.take<float>(slab * n_euler);
+  w.G1 = cv.take<float>(slab * n_euler);
+  w.G2 = cv.take<float>(slab * n_euler);
+  w.GS = cv.take<float>(int64_t(N) * n_euler);
+  w.DH1 = cv.take<float>(slab * n_euler);
+  w.DH2 = cv.take<float>(slab * n_euler);
+  w.DF = cv.take<float>(slab * n_euler);
+  w.DG1 = cv.take<float>(slab * n_euler);
+  w.DG2 = cv.take<float>(slab * n_euler);
+  w.S_in = cv.take<float>(slab * T);
+  w.DU = cv.take<float>(slab * T);
+  w.DS = cv.take<float>(slab * T);
+  w.gsel = cv.take<float>(slab);
+  w.DA = cv.take<float>(slab);
+  w.DY0 = cv.take<float>(slab);
+  const int64_t max_rows = int64_t(N) * (n_euler > T ? n_euler : T);
+  const int64_t max_parts = (max_rows + WGRAD_CHUNK - 1) / WGRAD_CHUNK + (n_euler > T ? n_euler : T);
+  w.part = cv.take<float>(max_parts * 4096);
+  w.cs = cv.take<float>(max_parts * 64);
+  w.vpart = cv.take<float>(int64_t(256) * (BWD_THREADS / 64) * 512);
+  w.bytes = cv.off + 256;
+  ok = cv.ok;
+  return w;
+}
+
+int bwd_grid(int ntiles) {
+  const int waves = BWD_THREADS / 64;
+  const int g = (ntiles + waves - 1) / waves;
+  return g < 1 ? 1 : (g > 256 ? 256 : g);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t trajsde_decoder_backward_ws_bytes(int32_t N, int num_modes, int future_steps, int n_euler) {
+  (void)num_modes;
+  bool ok;
+  return carve_bwd(nullptr, 0, N, future_steps, n_euler, ok).bytes;
+}
+
+int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, const float* blob_fwd, const float* blob_bwd,
+                                const float* local_embed, const float* global_embed, const float* step_table, int n_euler,
+                                const float* out_table, const trajsde_noise* noise, const float* loc, const float* y,
+                                const uint8_t* reg_mask, void* ws, int64_t ws_bytes, float* loss, int32_t* best_mode,
+                                float* const* grads, int n_grads, float* d_local, float* d_global, void* stream_) {
+  TS_REQUIRE(blob_fwd && blob_bwd && local_embed && global_embed && step_table && out_table && loc && y && reg_mask && ws && loss &&
+                 grads && d_local && d_global,
+             "decoder_l2_backward: null pointer");
+  TS_REQUIRE(N > 0 && num_modes > 0 && future_steps > 0 && n_euler > 0, "decoder_l2_backward: empty problem");
+  TS_REQUIRE(n_grads == N_GRADS, "decoder_l2_backward: gradient count does not match trajsde_param_count(DECODER_BWD)");
+  for (int i = 0; i < N_GRADS; ++i) TS_REQUIRE(grads[i] != nullptr, "decoder_l2_backward: null gradient buffer");
+  if (ws_bytes < trajsde_decoder_backward_ws_bytes(N, num_modes, future_steps, n_euler))
+    return fail(TRAJSDE_ERR_WORKSPACE, "decoder_l2_backward: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  bool ok;
+  const int K = num_modes, T = future_steps;
+  BwdWs w = carve_bwd(ws, ws_bytes, N, T, n_euler, ok);
+  NoiseArg na{0, nullptr, nullptr};
+  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
+  const int ntiles = (N + 15) / 16;
+  const int waves = BWD_THREADS / 64;
+  const int64_t slab = int64_t(N) * 64;
+
+  // ---- loss, winner per actor
+  TS_LAUNCH(k_l2_wta, cdiv(N, 256), 256, 0, st, loc, y, reg_mask, N, K, T, w.best, w.minsum, w.cnt);
+  TS_LAUNCH(k_l2_finalize, 1, 1024, 0, st, w.minsum, w.cnt, N, w.scal);
+  TS_HIP(hipMemcpyAsync(loss, w.scal, sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (best_mode) TS_HIP(hipMemcpyAsync(best_mode, w.best, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st));
+
+  // ---- replay of the winning paths
+  const float* init_img = blob_bwd + DecBwdBlob::INIT;
+  TS_LAUNCH(k_init_sel, bwd_grid(ntiles), BWD_THREADS, InitBwdL::AE_END * 4, st, init_img, local_embed, global_embed, w.best, N,
+            w.states, w.gsel);
+  TS_LAUNCH(k_sde_replay, bwd_grid(ntiles), BWD_THREADS, DecSdeL::LOC * 4, st, blob_fwd + DecBlob::SDE, w.best, N, K, n_euler,
+            step_table, na, w.states, w.H1, w.H2, w.G1, w.G2, w.GS);
+
+  // ---- backward: head, sweep, init
+  const int head_grid = bwd_grid(ntiles * T);
+  TS_LAUNCH(k_head_bwd, head_grid, BWD_THREADS, HeadBwdL::SIZE * 4, st, blob_bwd + DecBwdBlob::HEAD, w.states, out_table, y, reg_mask,
+            w.scal, N, T, w.S_in, w.DU, w.DS, w.vpart);
+  const int head_waves = head_grid * waves;
+  auto colsum = [&](const float* src, int rows, int stride, int n, float* dst) { k_colsum<<<cdiv(n, 64), 64, 0, st>>>(src, rows, stride, n, dst); };
+  colsum(w.vpart + HeadV::DGAM, head_waves, HeadV::SIZE, 64, grads[D1W]);
+  colsum(w.vpart + HeadV::DBET, head_waves, HeadV::SIZE, 64, grads[D1B]);
+  colsum(w.vpart + HeadV::DW3X, head_waves, HeadV::SIZE, 128, grads[D3W]);      // rows x, y of decoder.3.weight [2,64]
+  colsum(w.vpart + HeadV::DB3, head_waves, HeadV::SIZE, 2, grads[D3B]);
+  TS_LAUNCH_CHECK("k_colsum(head)");
+
+  const int sweep_grid = bwd_grid(ntiles);
+  TS_LAUNCH(k_sde_bwd, sweep_grid, BWD_THREADS, SweepL::SIZE * 4, st, blob_bwd + DecBwdBlob::SWEEP, w.best, N, K, T, n_euler, step_table,
+            out_table, na, w.H1, w.H2, w.G1, w.G2, w.GS, w.DS, w.DH1, w.DH2, w.DF, w.DG1, w.DG2, w.DY0, w.vpart);
+  colsum(w.vpart + SweepV::DV4, sweep_grid * waves, SweepV::SIZE, 64, grads[G4W]);
+  colsum(w.vpart + SweepV::DC4, sweep_grid * waves, SweepV::SIZE, 1, grads[G4B]);
+  TS_LAUNCH_CHECK("k_colsum(sweep)");
+
+  TS_HIP(hipMemsetAsync(d_global, 0, size_t(K) * N * 64 * sizeof(float), st));
+  TS_LAUNCH(k_dec_init_bwd, sweep_grid, BWD_THREADS, InitBwdL::SIZE * 4, st, init_img, local_embed, w.gsel, w.DY0, w.best, N, w.DA, d_local,
+            d_global, w.vpart);
+  colsum(w.vpart + InitV::DGAM, sweep_grid * waves, InitV::SIZE, 64, grads[A1W]);
+  colsum(w.vpart + InitV::DBET, sweep_grid * waves, InitV::SIZE, 64, grads[A1B]);
+  TS_LAUNCH_CHECK("k_colsum(init)");
+
+  // ---- weight gradients: (delta rows, input rows, rows, rows per step) -> W (+ column offset), bias, time columns
+  auto wgrad = [&](const float* delta, const float* a, int64_t R, int64_t rows_per_group, float* W, int ldw, int col0, float* bias,
+                   int time_cols) -> int {
+    const int cpg = int((rows_per_group + WGRAD_CHUNK - 1) / WGRAD_CHUNK);
+    const int groups = int((R + rows_per_group - 1) / rows_per_group);
+    const int P = cpg * groups;
+    TS_LAUNCH(k_wgrad, P, 256, (4 * 4096 + 4 * 4 * 64) * 4, st, delta, a, R, rows_per_group, WGRAD_CHUNK, cpg, w.part, w.cs);
+    TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 256), 256, 0, st, w.part, w.cs, P, cpg, step_table, W, ldw, col0, bias, time_cols);
+    return TRAJSDE_OK;
+  };
+  const int64_t RS = slab / 64 * n_euler, RT = slab / 64 * T;
+  int rc;
+  if ((rc = wgrad(w.DH1, w.states, RS, N, grads[F0W], 66, 0, grads[F0B], 1))) return rc;
+  if ((rc = wgrad(w.DH2, w.H1, RS, N, grads[F2W], 64, 0, grads[F2B], 0))) return rc;
+  if ((rc = wgrad(w.DF, w.H2, RS, N, grads[F4W], 64, 0, grads[F4B], 0))) return rc;
+  if ((rc = wgrad(w.DG1, w.states, RS, N, grads[G0W], 66, 0, grads[G0B], 1))) return rc;
+  if ((rc = wgrad(w.DG2, w.G1, RS, N, grads[G2W], 64, 0, grads[G2B], 0))) return rc;
+  if ((rc = wgrad(w.DU, w.S_in, RT, RT, grads[D0W], 64, 0, grads[D0B], 0))) return rc;
+  if ((rc = wgrad(w.DA, w.gsel, N, N, grads[A0W], 128, 0, grads[A0B], 0))) return rc;      // cat(global, local): DEC:82
+  if ((rc = wgrad(w.DA, local_embed, N, N, grads[A0W], 128, 64, nullptr, 0))) return rc;
+  return TRAJSDE_OK;
+}
+
+}  // extern "C"

@@ -237,6 +237,33 @@ struct DecBlob {
   enum : int { INIT = 0, SDE = INIT + DecInitL::SIZE, SDE6 = SDE + DecSdeL::SIZE, SIZE = SDE6 + DecSdeL6::SIZE };
 };
 
+// ---- backward images of the decoder stage (decoder_bwd.hip): `*T` fields hold the TRANSPOSED matrix in
+// fragment order, so dX^T = W^T dY^T runs through the same linear_acc as the forward pass
+struct SweepL {       // reverse Euler-Maruyama sweep: drift and diffusion nets
+  enum : int {
+    S_END = 0,
+    TS_FIELD(F_W0T, MAT64, S), TS_FIELD(F_W2T, MAT64, F_W0T), TS_FIELD(F_W4T, MAT64, F_W2T),
+    TS_FIELD(G_W0T, MAT64, F_W4T), TS_FIELD(G_W2T, MAT64, G_W0T), TS_FIELD(G_W4, 64, G_W2T),
+    SIZE = G_W4_END
+  };
+};
+struct HeadBwdL {     // loc head: forward image + W0 transposed
+  enum : int { FWD = 0, W0T = HeadL::SIZE, SIZE = W0T + MAT64 };
+};
+struct InitBwdL {     // aggr_embed: forward fields + the two halves transposed
+  enum : int {
+    S_END = 0,
+    TS_FIELD(WA_G, MAT64, S), TS_FIELD(WA_L, MAT64, WA_G), TS_FIELD(BA, 64, WA_L), TS_FIELD(AG, 64, BA), TS_FIELD(AE, 64, AG),
+    TS_FIELD(WA_GT, MAT64, AE), TS_FIELD(WA_LT, MAT64, WA_GT),
+    SIZE = WA_LT_END
+  };
+};
+struct DecBwdBlob {
+  enum : int { SWEEP = 0, HEAD = SWEEP + SweepL::SIZE, INIT = HEAD + HeadBwdL::SIZE, SIZE = INIT + InitBwdL::SIZE };
+};
+static_assert(SweepL::SIZE * 4 <= 160 * 1024, "sweep image must fit LDS");
+static_assert(DecBwdBlob::HEAD % 4 == 0 && DecBwdBlob::INIT % 4 == 0, "16-byte aligned images");
+
 static_assert(EdgeL::SIZE * 4 <= 160 * 1024, "edge image must fit LDS");
 static_assert(FfnL::SIZE * 4 <= 160 * 1024, "ffn image must fit LDS");
 static_assert(EncSdeL::SIZE * 4 <= 160 * 1024, "encoder SDE image must fit LDS");

@@ -37,6 +37,15 @@ __global__ void k_pack_mat(const float* __restrict__ src, float* __restrict__ ds
   dst[i] = src[(16 * jo + (lane & 15)) * ld + col0 + 16 * q + 4 * (lane >> 4) + c];
 }
 
+// fragment image of the TRANSPOSE of the 64x64 block at column col0: element [i][o] = W[o][col0 + i]
+__global__ void k_pack_matT(const float* __restrict__ src, float* __restrict__ dst, int ld, int col0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 16 * 256) return;
+  const int c = i & 3, lane = (i >> 2) & 63, q = (i >> 8) % 4, jo = (i >> 8) / 4;
+  const int row_t = 16 * jo + (lane & 15), col_t = 16 * q + 4 * (lane >> 4) + c;      // element of W^T
+  dst[i] = src[col_t * ld + col0 + row_t];
+}
+
 // bf16x6 planes: dst (as bf16) [plane][jo][s][lane][8]; element j of lane (i,g) in k-step s is the plane-th exact
 // truncation piece of W[16jo + i][col0 + 32s + 16(j>>2) + 4g + (j&3)]   (tile.hpp linear_acc_x6)
 __global__ void k_pack_mat6(const float* __restrict__ src, unsigned short* __restrict__ dst, int jto, int ks, int ld, int col0) {
@@ -89,6 +98,11 @@ struct Packer {
     if (dry) return;
     const int jto = rows / 16, jti = cols / 16;
     k_pack_mat<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, col0);
+  }
+  void matT(const std::string& n, int dst, int ld, int col0 = 0) {
+    const float* s = src(n);
+    if (dry) return;
+    k_pack_matT<<<cdiv(16 * 256, 256), 256, 0, stream>>>(s, blob + dst, ld, col0);
   }
   void mat6(const std::string& n, int dst, int rows, int cols, int ld, int col0 = 0) {
     const float* s = src(n);
@@ -365,11 +379,38 @@ static void recipe_decoder(Packer& P) {
   recipe_head(P, "scale", DecBlob::SDE6 + DecSdeL6::SCALE);
 }
 
+// backward images of the decoder stage (loc head, drift/diffusion nets, aggr_embed); `pi` and `scale` receive no
+// gradient from the L2 regression loss and are not packed
+static void recipe_decoder_bwd(Packer& P) {
+  const int s = DecBwdBlob::SWEEP, h = DecBwdBlob::HEAD, b = DecBwdBlob::INIT;
+  P.matT("lsde_func.f_func.net.0.weight", s + SweepL::F_W0T, 66);
+  P.matT("lsde_func.f_func.net.2.weight", s + SweepL::F_W2T, 64);
+  P.matT("lsde_func.f_func.net.4.weight", s + SweepL::F_W4T, 64);
+  P.matT("lsde_func.g_func.net.0.weight", s + SweepL::G_W0T, 66);
+  P.matT("lsde_func.g_func.net.2.weight", s + SweepL::G_W2T, 64);
+  P.vec("lsde_func.g_func.net.4.weight", s + SweepL::G_W4, 64);
+  recipe_head(P, "decoder", h + HeadBwdL::FWD);
+  P.matT("decoder.0.weight", h + HeadBwdL::W0T, 64);
+  using I = InitBwdL;
+  P.mat("aggr_embed.0.weight", b + I::WA_G, 64, 64, 128, 0);
+  P.mat("aggr_embed.0.weight", b + I::WA_L, 64, 64, 128, 64);
+  P.vec("aggr_embed.0.bias", b + I::BA, 64);
+  P.ln("aggr_embed.1", b + I::AG, b + I::AE);
+  P.matT("aggr_embed.0.weight", b + I::WA_GT, 128, 0);
+  P.matT("aggr_embed.0.weight", b + I::WA_LT, 128, 64);
+  // not packed, but they receive a gradient: listed so that the gradient slots of trajsde_decoder_l2_backward
+  // follow this parameter table
+  for (const char* n : {"lsde_func.f_func.net.0.bias", "lsde_func.f_func.net.2.bias", "lsde_func.f_func.net.4.bias",
+                        "lsde_func.g_func.net.0.bias", "lsde_func.g_func.net.2.bias", "lsde_func.g_func.net.4.bias"})
+    P.index(n);
+}
+
 static bool run_recipe(Packer& P, int stage, int nl, int K) {
   switch (stage) {
     case TRAJSDE_STAGE_ENCODER: recipe_encoder(P); return true;
     case TRAJSDE_STAGE_AGGREGATOR: recipe_aggregator(P, nl, K); return true;
     case TRAJSDE_STAGE_DECODER: recipe_decoder(P); return true;
+    case TRAJSDE_STAGE_DECODER_BWD: recipe_decoder_bwd(P); return true;
   }
   return false;
 }
@@ -463,6 +504,7 @@ int64_t trajsde_blob_floats(int stage, int num_layers, int num_modes) {
     case TRAJSDE_STAGE_ENCODER: return EncBlob::SIZE;
     case TRAJSDE_STAGE_AGGREGATOR: return AggBlob::size(num_layers, num_modes);
     case TRAJSDE_STAGE_DECODER: return DecBlob::SIZE;
+    case TRAJSDE_STAGE_DECODER_BWD: return DecBwdBlob::SIZE;
   }
   return fail(TRAJSDE_ERR_INVALID, "unknown stage");
 }

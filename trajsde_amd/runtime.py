@@ -112,47 +112,50 @@ class StageRuntime:
         object.__setattr__(self, "module", module)
         self.stage = stage
         self.stage_id = self.STAGE_ID[stage]
-        self._blob: Optional[torch.Tensor] = None
-        self._blob_stamp = None
-        self._names = None
+        self._blobs: Dict[int, Tuple[torch.Tensor, object]] = {}
+        self._names: Dict[int, list] = {}
 
     # ---------------------------------------------------------------- weights
     def _dims(self) -> Tuple[int, int]:
         m = self.module
         return int(getattr(m, "num_layers", 0)), int(getattr(m, "num_modes", 0))
 
-    def param_names(self):
-        if self._names is None:
+    def param_names(self, stage_id: Optional[int] = None):
+        stage_id = self.stage_id if stage_id is None else stage_id
+        if stage_id not in self._names:
             L = _lib.lib()
             nl, K = self._dims()
-            n = L.trajsde_param_count(self.stage_id, nl, K)
-            self._names = [L.trajsde_param_name(self.stage_id, i, nl, K).decode() for i in range(n)]
-        return self._names
+            n = L.trajsde_param_count(stage_id, nl, K)
+            self._names[stage_id] = [L.trajsde_param_name(stage_id, i, nl, K).decode() for i in range(n)]
+        return self._names[stage_id]
 
-    def blob(self) -> torch.Tensor:
-        """Packed LDS images of this stage's weights; re-packed whenever a parameter changed."""
+    def blob(self, stage_id: Optional[int] = None) -> torch.Tensor:
+        """Packed LDS images of this stage's weights (`stage_id`: the forward images by default, or the
+        stage's backward images); re-packed whenever a parameter changed."""
         m = self.module
+        stage_id = self.stage_id if stage_id is None else stage_id
         first = next(m.parameters())
         _require_gpu(first, f"{self.stage} parameters")
         stamp = (m.version_stamp(), str(first.device))
-        if self._blob is None or stamp != self._blob_stamp:
+        cached = self._blobs.get(stage_id)
+        if cached is None or stamp != cached[1]:
             L = _lib.lib()
             nl, K = self._dims()
-            names = self.param_names()
+            names = self.param_names(stage_id)
             tensors = []
             for n in names:
                 p = m.p(n)
                 if p.dtype != torch.float32 or not p.is_contiguous() or p.device != first.device:
                     raise _lib.TrajsdeError(f"parameter {self.stage}.{n} must be contiguous fp32 on {first.device}")
                 tensors.append(p)
-            n_floats = L.trajsde_blob_floats(self.stage_id, nl, K)
+            n_floats = L.trajsde_blob_floats(stage_id, nl, K)
             blob = torch.empty(n_floats, device=first.device, dtype=torch.float32)
             arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
             with torch.cuda.device(first.device):
-                _lib.check(L.trajsde_pack_weights(self.stage_id, nl, K, arr, len(tensors), blob.data_ptr(), n_floats, _stream()),
+                _lib.check(L.trajsde_pack_weights(stage_id, nl, K, arr, len(tensors), blob.data_ptr(), n_floats, _stream()),
                            "trajsde_pack_weights")
-            self._blob, self._blob_stamp = blob, stamp
-        return self._blob
+            self._blobs[stage_id] = (blob, stamp)
+        return self._blobs[stage_id][0]
 
     # ---------------------------------------------------------------- decoder
     def decoder_forward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor,
@@ -181,6 +184,46 @@ class StageRuntime:
                                                  loc.data_ptr(), pi.data_ptr(), _stream()), "trajsde_decoder_forward")
         out = {"loc": loc, "pi": pi, "reg_mask": ~data["padding_mask"][:, -T:]}          # DEC:104
         return out
+
+    def decoder_l2_backward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor, out: Dict[str, torch.Tensor],
+                            noise: NoiseSpec) -> Dict[str, object]:
+        """Winner-takes-all L2 loss (losses/L2.py:10-27) on `out` = decoder_forward(...) and its gradients w.r.t.
+        this stage's parameters and inputs.  `noise` must be the NoiseSpec the forward ran with (same seed / z), so
+        that the replayed winning paths are the forward's.  Returns {"loss", "best_mode", "grads": {param name:
+        tensor}, "d_local_embed", "d_global_embed"}; `pi.*` and `scale.*` get no gradient from this loss."""
+        m = self.module
+        if noise is None:
+            raise _lib.TrajsdeError("decoder_l2_backward needs the NoiseSpec of the forward pass (seed or z_dec)")
+        _require_gpu(local_embed, "local_embed")
+        dev = local_embed.device
+        K, T = int(m.num_modes), int(m.future_steps)
+        N = local_embed.shape[0]
+        sched, step_tab, out_tab = _TABLES.get(("dec", T, float(m.max_fut_t), float(m.min_stepsize)),
+                                               lambda: decoder_schedule(T, float(m.max_fut_t), float(m.min_stepsize)), dev)
+        y = data["y"]
+        if y is None or tuple(y.shape) != (N, T, 2):
+            raise _lib.TrajsdeError(f"data['y'] must be [{N},{T},2] (rotated targets, MODEL:83-84)")
+        y = y.to(torch.float32).contiguous()
+        mask = out["reg_mask"].contiguous().view(torch.uint8)
+        L = _lib.lib()
+        names = self.param_names(_lib.STAGE_DECODER_BWD)
+        grads = {n: torch.empty_like(m.p(n)) for n in names}
+        arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        best = torch.empty(N, device=dev, dtype=torch.int32)
+        d_local = torch.empty(N, D, device=dev, dtype=torch.float32)
+        d_global = torch.empty(K, N, D, device=dev, dtype=torch.float32)
+        ws_bytes = L.trajsde_decoder_backward_ws_bytes(N, K, T, sched.n_euler)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        cn = noise.c_noise(noise.z_dec, noise.dec_row_ids)
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_decoder_l2_backward(
+                N, K, T, self.blob().data_ptr(), self.blob(_lib.STAGE_DECODER_BWD).data_ptr(),
+                local_embed.contiguous().data_ptr(), global_embed.contiguous().data_ptr(), step_tab.data_ptr(), sched.n_euler,
+                out_tab.data_ptr(), C.byref(cn), out["loc"].contiguous().data_ptr(), y.data_ptr(), mask.data_ptr(),
+                ws.data_ptr(), ws_bytes, loss.data_ptr(), best.data_ptr(), arr, len(names), d_local.data_ptr(),
+                d_global.data_ptr(), _stream()), "trajsde_decoder_l2_backward")
+        return {"loss": loss[0], "best_mode": best, "grads": grads, "d_local_embed": d_local, "d_global_embed": d_global}
 
     # ---------------------------------------------------------------- encoder
     def encoder_forward(self, data, noise: Optional[NoiseSpec] = None):
