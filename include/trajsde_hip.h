@@ -46,6 +46,8 @@ typedef enum {
   TRAJSDE_STAGE_DECODER = 2,
   TRAJSDE_STAGE_DECODER_BWD = 3 /* transposed images for trajsde_decoder_l2_backward; its parameter list is the
                                    subset of the decoder's that receives a gradient */
+  ,
+  TRAJSDE_STAGE_AGGREGATOR_BWD = 4 /* images for trajsde_aggregator_backward (same parameters as the aggregator) */
 } trajsde_stage;
 
 int trajsde_param_count(int stage, int num_layers /*aggregator*/, int num_modes);
@@ -187,6 +189,16 @@ int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, cons
                                 const uint8_t* reg_mask /*[N,T]*/, void* ws, int64_t ws_bytes, float* loss /*[1] device*/,
                                 int32_t* best_mode /*[N] device or null*/, float* const* grads, int n_grads,
                                 float* d_local /*[N,64]*/, float* d_global /*[K,N,64]*/, void* stream);
+
+/* ---- backward of the aggregator stage (AGG:38-58, 92-135): dL/d global_embed -> dL/d local_embed (overwritten;
+ *      the caller adds the decoder's own d local_embed) and one gradient per aggregator parameter, grads[i] shaped
+ *      like parameter trajsde_param_name(TRAJSDE_STAGE_AGGREGATOR_BWD, i) and overwritten (pre-zero them: with no
+ *      global edges the rel_embed entries are left untouched).  The forward is recomputed internally in fp32. */
+int64_t trajsde_aggregator_backward_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int num_layers, int num_modes);
+int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, const float* blob_bwd,
+                                int num_layers, int num_modes, const float* local_embed /*[N,64]*/,
+                                const float* d_global /*[K,N,64]*/, void* ws, int64_t ws_bytes, float* const* grads, int n_grads,
+                                float* d_local /*[N,64]*/, void* stream);
 
 /* ---- step-granular decoder SDE step (state round-trips HBM every step): the 512 B/path-step variant
  *      of SURVEY.md 8(d), kept for the HBM-roofline measurement the north star asks for. */

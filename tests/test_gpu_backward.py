@@ -98,6 +98,61 @@ def test_decoder_l2_backward_matches_autograd(S, n, K, T, max_t, kw, dev):
     assert float(dg[lose].abs().max()) == 0.0 if lose.any() else True
 
 
+def _oracle_aggregator_grads(model, cfg, batch_cpu, local, d_glob):
+    import restate
+    c = restate.flat_cfg(cfg)
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    names = [k for k in P if k.startswith("aggregator.")]
+    for k in names:
+        P[k].requires_grad_(True)
+    local = local.detach().cpu().clone().requires_grad_(True)
+    rot, _ = restate.rotate_inputs(batch_cpu)
+    with torch.enable_grad():
+        glob = restate.global_interactor(P, c, batch_cpu, rot, local)
+        (glob * d_glob.cpu()).sum().backward()
+    grads = {k[len("aggregator."):]: (P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])) for k in names}
+    return grads, local.grad
+
+
+@pytest.mark.parametrize("S,n,K,kw", [
+    (3, 20, 4, dict(mixed_source=True, history_dropout=0.3)),
+    (2, 33, 2, dict(source=1)),
+    (2, 1, 3, dict()),                               # single-actor scenes: no global edges at all
+])
+def test_aggregator_backward_matches_autograd(S, n, K, kw, dev):
+    from trajsde_amd import runtime
+    from trajsde_amd.synth import synth
+    T = 5
+    batch = synth(S=S, n=n, L=6, F=T, box=80.0, seed=400 + n, **kw)
+    model, cfg = H.build_model(K, T, 0.5, init_seed=13)
+    model = model.to(dev)
+    data = batch.to(dev)
+    noise = runtime.NoiseSpec(seed=17)
+    rot, y_rot = runtime.rotate_inputs(data)
+    data.y, data["rotate_mat"] = y_rot, rot
+    local, *_ = model.encoder(data=data, noise=noise)
+    N = local.shape[0]
+    g = torch.Generator().manual_seed(3)
+    d_glob = torch.randn(K, N, 64, generator=g)
+    res = model.aggregator._rt.aggregator_backward(data, local, d_glob.to(dev))
+    torch.cuda.synchronize()
+    want, d_local = _oracle_aggregator_grads(model, cfg, batch, local, d_glob)
+    got = res["grads"]
+    assert set(got) == set(want)
+    for k in sorted(got):
+        assert got[k].shape == want[k].shape, k
+        assert torch.isfinite(got[k]).all(), k
+        # relative to the tensor's largest entry; key biases shift all logits of a target alike, so their gradient
+        # is zero in exact arithmetic and what either side reports is cancellation noise: absolute bound there
+        scale = float(want[k].abs().max())
+        err = float((got[k].cpu().double() - want[k].double()).abs().max())
+        if k.endswith("lin_k_node.bias") or k.endswith("lin_k_edge.bias"):
+            assert scale <= 5e-5 and err <= 5e-5, (k, err, scale)
+        else:
+            assert err <= REL * scale + 1e-7, (k, err, scale)
+    assert _rel(res["d_local_embed"], d_local) <= REL
+
+
 def test_decoder_backward_is_deterministic_and_checks_arguments(dev):
     from trajsde_amd import _lib, runtime
     from trajsde_amd.synth import synth

@@ -7,7 +7,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtrajsde_hip.so")
 
-STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD = 0, 1, 2, 3
+STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGATOR_BWD = 0, 1, 2, 3, 4
 
 
 class TrajsdeError(RuntimeError):
@@ -62,6 +62,9 @@ SIGNATURES = {
     "trajsde_decoder_backward_ws_bytes": (I64, [I32, C.c_int, C.c_int, C.c_int]),
     "trajsde_decoder_l2_backward": (C.c_int, [I32, C.c_int, C.c_int, P, P, P, P, P, C.c_int, P, C.POINTER(Noise), P, P, P, P, I64,
                                               P, P, C.POINTER(P), C.c_int, P, P, P]),
+    "trajsde_aggregator_backward_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph), C.c_int, C.c_int]),
+    "trajsde_aggregator_backward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, C.c_int, C.c_int, P, P, P, I64,
+                                              C.POINTER(P), C.c_int, P, P]),
     "trajsde_profile_mode": (C.c_int, [C.c_int]),
     "trajsde_profile_report": (I64, [C.c_char_p, I64]),
     "trajsde_sde_step": (C.c_int, [I32, P, P, P, C.POINTER(F32), C.c_int, C.POINTER(Noise), P]),

@@ -1,0 +1,332 @@
+// aggregator_bwd.hip -- backward of the GlobalInteractor stage (reference models/aggregators/agg_hivt.py:38-58,
+// 92-135): given dL/d global_embed [K,N,64] it returns dL/d local_embed and the gradients of every aggregator
+// parameter.  Second family of SURVEY.md 8(f) rank 1.
+//
+// The stage's forward is recomputed here in exact fp32 with one buffer per layer (the "tape"), then walked backwards:
+//   multihead_proj / norm            k_lin_t_acc x K  ->  k_node_proj_bwd<0>
+//   per layer, last to first         node_block_backward (FFN, gated update)  ->  k_gattn_bwd  ->  k_node_proj_bwd<3>
+//   rel_embed                        edge_embed_backward on the summed d rel rows
+//
+// k_gattn_bwd mirrors the fused forward (attn.hip k_global_attn): one wave per target actor, lin_k_edge folded into
+// the query (U_h = Wke_h^T q_h), lin_v_edge folded into the incoming gradient (Z_h = Wve_h^T dagg_h), softmax
+// statistics recomputed in a first pass over the segment.  With alpha the attention weights,
+//   d alpha_e,h = dagg_h . (v_node[src] + lin_v_edge(rel_e))_h,   d logit_e,h = alpha (d alpha - dagg_h . agg_h)
+// Per-target sums  RL_h = sum_e dlogit/sqrt(dh) rel_e  and  SS_h = sum_e alpha rel_e  give the lin_k_edge / lin_v_edge
+// weight gradients as node-level outer products (k_headwise_outer) instead of per-edge ones.  Gradients of the
+// source rows (k_node, v_node) are scattered with float atomics: their summation order, and so their last bits, can
+// differ from run to run; everything else is reduced in a fixed order.
+#include <string>
+#include <unordered_map>
+
+#include "bwd.hpp"
+#include "common.hpp"
+#include "kernels.hpp"
+#include "layouts.hpp"
+#include "tile.hpp"
+
+namespace tsde {
+
+namespace {
+constexpr float INV_SQRT_DH_B = 0.35355339059327373f;   // 1/sqrt(64/8)
+
+__device__ __forceinline__ float dpp_add_b(float v, int tag) {
+  int r;
+  if (tag == 0) r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);
+  else if (tag == 1) r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);
+  else r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true);
+  return v + __int_as_float(r);
+}
+__device__ __forceinline__ float head_sum_b(float v) { return dpp_add_b(dpp_add_b(dpp_add_b(v, 0), 1), 2); }
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img, const int32_t* __restrict__ segptr,
+                                                   const int32_t* __restrict__ src, const float* __restrict__ rel,
+                                                   const float* __restrict__ q, const float* __restrict__ kn,
+                                                   const float* __restrict__ vn, const float* __restrict__ agg,
+                                                   const float* __restrict__ dagg, int64_t N, float* __restrict__ DQ,
+                                                   float* __restrict__ DKN, float* __restrict__ DVN, float* __restrict__ DREL,
+                                                   float* __restrict__ RL, float* __restrict__ SS, float* __restrict__ DAGGM) {
+  __shared__ __attribute__((aligned(16))) float sbuf[4][8][64 + 4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = lane >> 3, j = lane & 7;
+  const int64_t node = int64_t(blockIdx.x) * 4 + wv;
+  const int64_t nc = node < N ? node : N - 1;
+  const float* wke = img + GAttnL::WKE;
+  const float* wve = img + GAttnL::WVE;
+  const float ql = q[nc * 64 + lane];
+  const float da = node < N ? dagg[nc * 64 + lane] : 0.f;
+  const float cb = head_sum_b(ql * img[GAttnL::BKE + lane]);
+  const float cz = head_sum_b(da * img[GAttnL::BVE + lane]);
+  const float dlt = head_sum_b(da * agg[nc * 64 + lane]);
+  float U[8], Z[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) U[e] = Z[e] = 0.f;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const float qd = __shfl(ql, 8 * h + d), dd = __shfl(da, 8 * h + d);
+    const f4 k0 = *reinterpret_cast<const f4*>(wke + (8 * h + d) * 64 + 8 * j);
+    const f4 k1 = *reinterpret_cast<const f4*>(wke + (8 * h + d) * 64 + 8 * j + 4);
+    const f4 v0 = *reinterpret_cast<const f4*>(wve + (8 * h + d) * 64 + 8 * j);
+    const f4 v1 = *reinterpret_cast<const f4*>(wve + (8 * h + d) * 64 + 8 * j + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      U[e] = fmaf(k0[e], qd, U[e]); U[4 + e] = fmaf(k1[e], qd, U[4 + e]);
+      Z[e] = fmaf(v0[e], dd, Z[e]); Z[4 + e] = fmaf(v1[e], dd, Z[4 + e]);
+    }
+  }
+  const int beg = segptr[nc], end = node < N ? segptr[nc + 1] : beg;
+  auto logit = [&](const f4& ra, const f4& rb, float knv) {
+    float p = ql * knv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p = fmaf(ra[e], U[e], p); p = fmaf(rb[e], U[4 + e], p); }
+    return (head_sum_b(p) + cb) * INV_SQRT_DH_B;
+  };
+  // pass 1: softmax statistics of the segment
+  float m = -INFINITY, s = 0.f;
+  for (int e = beg; e < end; ++e) {
+    const f4 ra = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + 8 * j);
+    const f4 rb = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + 8 * j + 4);
+    const float p = logit(ra, rb, kn[int64_t(src[e]) * 64 + lane]);
+    const float mn = fmaxf(m, p);
+    s = s * fast_exp(m - mn) + fast_exp(p - mn);
+    m = mn;
+  }
+  const float inv = 1.0f / (s + 1e-16f);
+  // pass 2: gradients
+  float dqe = 0.f, Rl[8], Sa[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) Rl[e] = Sa[e] = 0.f;
+  for (int e = beg; e < end; ++e) {
+    const int sidx = src[e];
+    const f4 ra = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + 8 * j);
+    const f4 rb = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + 8 * j + 4);
+    const float knv = kn[int64_t(sidx) * 64 + lane], vnv = vn[int64_t(sidx) * 64 + lane];
+    const float alpha = fast_exp(logit(ra, rb, knv) - m) * inv;
+    float t = da * vnv;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { t = fmaf(ra[c], Z[c], t); t = fmaf(rb[c], Z[4 + c], t); }
+    const float dal = head_sum_b(t) + cz;
+    const float dls = alpha * (dal - dlt) * INV_SQRT_DH_B;
+    dqe = fmaf(dls, knv, dqe);
+    atomicAdd(DKN + int64_t(sidx) * 64 + lane, dls * ql);
+    atomicAdd(DVN + int64_t(sidx) * 64 + lane, alpha * da);
+    float dr[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      Rl[c] = fmaf(dls, ra[c], Rl[c]); Rl[4 + c] = fmaf(dls, rb[c], Rl[4 + c]);
+      Sa[c] = fmaf(alpha, ra[c], Sa[c]); Sa[4 + c] = fmaf(alpha, rb[c], Sa[4 + c]);
+      dr[c] = fmaf(dls, U[c], alpha * Z[c]);
+      dr[4 + c] = fmaf(dls, U[4 + c], alpha * Z[4 + c]);
+    }
+    // d rel_e = sum over heads: lanes j, j+8, ..., j+56 hold the same 8 columns
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float x = dr[c];
+      x += __shfl_xor(x, 8);
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      dr[c] = x;
+    }
+    if (h == 0) {
+      float* p = DREL + int64_t(e) * 64 + 8 * j;
+      f4 a = *reinterpret_cast<f4*>(p), b = *reinterpret_cast<f4*>(p + 4);
+      a += f4{dr[0], dr[1], dr[2], dr[3]};
+      b += f4{dr[4], dr[5], dr[6], dr[7]};
+      *reinterpret_cast<f4*>(p) = a;
+      *reinterpret_cast<f4*>(p + 4) = b;
+    }
+  }
+  *reinterpret_cast<f4*>(&sbuf[wv][h][8 * j]) = f4{Rl[0], Rl[1], Rl[2], Rl[3]};
+  *reinterpret_cast<f4*>(&sbuf[wv][h][8 * j + 4]) = f4{Rl[4], Rl[5], Rl[6], Rl[7]};
+  if (node < N) {
+    float* rp = RL + (node * 8 + h) * 64 + 8 * j;
+    float* sp = SS + (node * 8 + h) * 64 + 8 * j;
+    *reinterpret_cast<f4*>(rp) = f4{Rl[0], Rl[1], Rl[2], Rl[3]};
+    *reinterpret_cast<f4*>(rp + 4) = f4{Rl[4], Rl[5], Rl[6], Rl[7]};
+    *reinterpret_cast<f4*>(sp) = f4{Sa[0], Sa[1], Sa[2], Sa[3]};
+    *reinterpret_cast<f4*>(sp + 4) = f4{Sa[4], Sa[5], Sa[6], Sa[7]};
+  }
+  // d q[d] = sum_e dlogit/sqrt(dh) (k_node[src][d] + lin_k_edge(rel_e)[d]) = dqe + Wke[d] . RL_head(d)
+  float dq = dqe;
+#pragma unroll
+  for (int k4 = 0; k4 < 16; ++k4) {
+    const f4 wr = *reinterpret_cast<const f4*>(wke + lane * 64 + 4 * k4);
+    const f4 rv = *reinterpret_cast<const f4*>(&sbuf[wv][h][4 * k4]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dq = fmaf(wr[e], rv[e], dq);
+  }
+  if (node < N) {
+    DQ[node * 64 + lane] = dq;
+    DAGGM[node * 64 + lane] = da * (s * inv);        // lin_v_edge.bias sees sum_e alpha = 1 where the target has edges
+  }
+}
+
+// ---- workspace
+struct AggBwdWs {
+  // forward tape
+  float *rel, *xn[8], *q[8], *kn[8], *vn[8], *agg[8], *x1[8], *xn2[8], *out[8];
+  // backward scratch
+  float *dcur, *dnext, *dagg, *dxn, *DQ, *DKN, *DVN, *DREL, *RL, *SS, *DAGGM, *XF, *part, *cs;
+  NodeBlockScratch nb;
+  EdgeEmbedScratch ee;
+  int64_t total;
+  bool ok;
+  AggBwdWs(int64_t N, int64_t E, int nl, int K, void* ws, int64_t bytes) {
+    Carver c(ws, bytes);
+    rel = c.take<float>(E * 64 + 64);
+    for (int l = 0; l < nl; ++l) {
+      xn[l] = c.take<float>(N * 64); q[l] = c.take<float>(N * 64); kn[l] = c.take<float>(N * 64); vn[l] = c.take<float>(N * 64);
+      agg[l] = c.take<float>(N * 64); x1[l] = c.take<float>(N * 64); xn2[l] = c.take<float>(N * 64); out[l] = c.take<float>(N * 64);
+    }
+    float** singles[] = {&dcur, &dnext, &dagg, &dxn, &DQ, &DKN, &DVN, &DAGGM, &XF, &nb.dx1, &nb.UPD, &nb.DGP, &nb.DS};
+    for (float** p : singles) *p = c.take<float>(N * 64);
+    nb.H = c.take<float>(N * 256);
+    nb.DH = c.take<float>(N * 256);
+    RL = c.take<float>(N * 512);
+    SS = c.take<float>(N * 512);
+    DREL = c.take<float>(E * 64 + 64);
+    float** edge[] = {&ee.S, &ee.DEP, &ee.DSP, &ee.A0, &ee.B0};
+    for (float** p : edge) *p = c.take<float>(E * 64 + 64);
+    nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
+    const int64_t rows = E > N ? E : N;
+    const int64_t parts = wgrad_max_parts(rows, 1);
+    part = c.take<float>(parts * 4096);
+    cs = c.take<float>(parts * 64);
+    (void)K;
+    total = c.off + 256;
+    ok = c.ok;
+  }
+};
+
+}  // namespace tsde
+
+using namespace tsde;
+
+extern "C" {
+
+int64_t trajsde_aggregator_backward_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int num_layers, int num_modes) {
+  if (!b || !g || num_layers < 0 || num_layers > 8) return -1;
+  AggBwdWs w(b->N, g->E_g, num_layers, num_modes, nullptr, 0);
+  return w.total;
+}
+
+int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, const float* blob_bwd,
+                                int num_layers, int num_modes, const float* local_embed, const float* d_global, void* ws,
+                                int64_t ws_bytes, float* const* grads, int n_grads, float* d_local, void* stream_) {
+  TS_REQUIRE(b && g && blob_fwd && blob_bwd && local_embed && d_global && ws && grads && d_local, "aggregator_backward: null pointer");
+  TS_REQUIRE(g->g_src && g->g_segptr, "aggregator_backward: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(num_layers >= 1 && num_layers <= 8 && num_modes > 0, "aggregator_backward: bad layer/mode count");
+  const std::vector<std::string> names = stage_param_names(TRAJSDE_STAGE_AGGREGATOR_BWD, num_layers, num_modes);
+  TS_REQUIRE(n_grads == int(names.size()), "aggregator_backward: gradient count does not match trajsde_param_count(AGGREGATOR_BWD)");
+  std::unordered_map<std::string, float*> slot;
+  for (int i = 0; i < n_grads; ++i) {
+    TS_REQUIRE(grads[i] != nullptr, "aggregator_backward: null gradient buffer " + names[i]);
+    slot[names[i]] = grads[i];
+  }
+  bool missing = false;
+  auto G = [&](const std::string& n) -> float* {
+    auto it = slot.find(n);
+    if (it == slot.end()) { missing = true; return nullptr; }
+    return it->second;
+  };
+  AggBwdWs w(b->N, g->E_g, num_layers, num_modes, ws, ws_bytes);
+  if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "aggregator_backward: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  const int64_t N = b->N, E = g->E_g, ntiles = (N + 15) / 16, etiles = (E + 15) / 16;
+  const int nl = num_layers, K = num_modes;
+  const WgradCtx wc{st, w.part, w.cs, nullptr};
+
+  // ---- forward recompute in exact fp32, one buffer per layer
+  if (E > 0)
+    TS_LAUNCH(k_edge_embed<false>, tile_grid(etiles, 1024, EdgeL::EMB_SIZE * 4), 1024, EdgeL::EMB_SIZE * 4, st, blob_fwd + AggBlob::REL,
+              g->g_geom, E, w.rel);
+  const float* x = local_embed;
+  for (int l = 0; l < nl; ++l) {
+    const float* lb = blob_fwd + AggBlob::layer(l);
+    TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
+              w.xn[l], w.q[l], w.kn[l], w.vn[l]);
+    TS_LAUNCH(k_global_attn, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
+              w.agg[l]);
+    TS_LAUNCH(k_node_update<false>, tile_grid(ntiles, 512, UpdL::SIZE * 4), 512, UpdL::SIZE * 4, st, lb + AggLayerL::UPD, w.agg[l], w.xn[l], x,
+              N, w.x1[l], w.xn2[l]);
+    TS_LAUNCH(k_ffn, tile_grid(ntiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + AggLayerL::FFN, w.x1[l], w.xn2[l], N, w.out[l]);
+    x = w.out[l];
+  }
+
+  // ---- multihead_proj + final norm
+  for (int k = 0; k < K; ++k)
+    TS_LAUNCH(k_lin_t_acc, tile_grid(ntiles, 256, MAT64 * 4), 256, MAT64 * 4, st, blob_bwd + AggBwdBlob::proj(nl, k),
+              d_global + int64_t(k) * N * 64, N, w.dxn, k > 0 ? 1 : 0);
+  {
+    const int gp = tile_grid(ntiles, 256, ProjBwdL<0>::SIZE * 4);
+    TS_LAUNCH(k_node_proj_bwd<0>, gp, 256, ProjBwdL<0>::SIZE * 4, st, blob_bwd + AggBwdBlob::norm(nl), w.out[nl - 1], nullptr, w.dxn,
+              nullptr, nullptr, nullptr, N, w.dcur, w.XF, w.nb.vpart);
+    if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, G("norm.weight"))) return rc;
+    if (int rc = run_colsum(st, w.nb.vpart + 64, gp * 4, 128, 64, G("norm.bias"))) return rc;
+    float* pw = G("multihead_proj.weight");
+    float* pb = G("multihead_proj.bias");
+    TS_REQUIRE(!missing, "aggregator_backward: parameter table lacks norm / multihead_proj");
+    for (int k = 0; k < K; ++k)
+      if (int rc = run_wgrad(wc, d_global + int64_t(k) * N * 64, 64, w.XF, 64, N, N, pw + int64_t(k) * MAT64, 64, 0, pb + 64 * k, 0)) return rc;
+  }
+
+  // ---- layers, last to first
+  TS_HIP(hipMemsetAsync(w.DREL, 0, size_t(E * 64 + 64) * sizeof(float), st));
+  float* dcur = w.dcur;
+  float* dnext = w.dnext;
+  for (int l = nl - 1; l >= 0; --l) {
+    const std::string p = "global_interactor_layers." + std::to_string(l);
+    const float* lb = blob_bwd + AggBwdBlob::layer(l);
+    const float* x_in = l == 0 ? local_embed : w.out[l - 1];
+    NodeBlockGrads gr{G(p + ".lin_ih.weight"), G(p + ".lin_ih.bias"), G(p + ".lin_hh.weight"), G(p + ".lin_hh.bias"),
+                      G(p + ".lin_self.weight"), G(p + ".lin_self.bias"), G(p + ".out_proj.weight"), G(p + ".out_proj.bias"),
+                      G(p + ".norm2.weight"), G(p + ".norm2.bias"), G(p + ".mlp.0.weight"), G(p + ".mlp.0.bias"),
+                      G(p + ".mlp.3.weight"), G(p + ".mlp.3.bias")};
+    float* wke = G(p + ".lin_k_edge.weight");
+    float* bke = G(p + ".lin_k_edge.bias");
+    float* wve = G(p + ".lin_v_edge.weight");
+    float* bve = G(p + ".lin_v_edge.bias");
+    float* n1g = G(p + ".norm1.weight");
+    float* n1b = G(p + ".norm1.bias");
+    float* qkv_w[3] = {G(p + ".lin_q_node.weight"), G(p + ".lin_k_node.weight"), G(p + ".lin_v_node.weight")};
+    float* qkv_b[3] = {G(p + ".lin_q_node.bias"), G(p + ".lin_k_node.bias"), G(p + ".lin_v_node.bias")};
+    TS_REQUIRE(!missing, "aggregator_backward: parameter table lacks an entry of " + p);
+    const NodeBlockTape tp{w.agg[l], w.xn[l], w.x1[l], w.xn2[l]};
+    if (int rc = node_block_backward(lb + AggLayerBwdL::NODE, tp, dcur, N, w.nb, wc, gr, w.dagg, w.dxn, st)) return rc;
+    TS_HIP(hipMemsetAsync(w.DKN, 0, size_t(N) * 64 * sizeof(float), st));
+    TS_HIP(hipMemsetAsync(w.DVN, 0, size_t(N) * 64 * sizeof(float), st));
+    TS_LAUNCH(k_gattn_bwd, cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], w.agg[l],
+              w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM);
+    TS_LAUNCH(k_headwise_outer, 64, 256, 0, st, w.q[l], w.RL, N, wke);
+    TS_LAUNCH(k_headwise_outer, 64, 256, 0, st, w.dagg, w.SS, N, wve);
+    TS_HIP(hipMemsetAsync(bke, 0, 64 * sizeof(float), st));          // a key bias shifts every logit of a target alike
+    if (int rc = run_colsum(st, w.DAGGM, N, 64, 64, bve)) return rc;
+    const int gp = tile_grid(ntiles, 256, ProjBwdL<3>::SIZE * 4);
+    TS_LAUNCH(k_node_proj_bwd<3>, gp, 256, ProjBwdL<3>::SIZE * 4, st, lb + AggLayerBwdL::PROJ, x_in, w.nb.dx1, w.dxn, w.DQ, w.DKN, w.DVN, N,
+              dnext, nullptr, w.nb.vpart);
+    if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, n1g)) return rc;
+    if (int rc = run_colsum(st, w.nb.vpart + 64, gp * 4, 128, 64, n1b)) return rc;
+    const float* dps[3] = {w.DQ, w.DKN, w.DVN};
+    for (int j = 0; j < 3; ++j)
+      if (int rc = run_wgrad(wc, dps[j], 64, w.xn[l], 64, N, N, qkv_w[j], 64, 0, qkv_b[j], 0)) return rc;
+    float* t = dcur; dcur = dnext; dnext = t;
+  }
+  TS_HIP(hipMemcpyAsync(d_local, dcur, size_t(N) * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+
+  // ---- rel_embed (shared by every layer: DREL is the sum of their d rel rows)
+  {
+    const std::string p = "rel_embed";
+    EdgeEmbedGrads eg{G(p + ".module_list.0.0.weight"), G(p + ".module_list.0.0.bias"), G(p + ".module_list.0.1.weight"),
+                      G(p + ".module_list.0.1.bias"), G(p + ".module_list.1.0.weight"), G(p + ".module_list.1.0.bias"),
+                      G(p + ".module_list.1.1.weight"), G(p + ".module_list.1.1.bias"), G(p + ".module_list.0.3.weight"),
+                      G(p + ".module_list.0.3.bias"), G(p + ".module_list.1.3.weight"), G(p + ".module_list.1.3.bias"),
+                      G(p + ".aggr_embed.0.weight"), G(p + ".aggr_embed.0.bias"), G(p + ".aggr_embed.2.weight"),
+                      G(p + ".aggr_embed.2.bias"), G(p + ".aggr_embed.3.weight"), G(p + ".aggr_embed.3.bias")};
+    TS_REQUIRE(!missing, "aggregator_backward: parameter table lacks an entry of rel_embed");
+    // E == 0: the embedding never ran and its gradients stay as the caller initialised them (zeros)
+    if (int rc = edge_embed_backward(blob_bwd + AggBwdBlob::REL, g->g_geom, w.DREL, E, w.ee, wc, eg, st)) return rc;
+  }
+  return TRAJSDE_OK;
+}
+
+}  // extern "C"

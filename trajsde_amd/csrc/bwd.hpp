@@ -1,0 +1,65 @@
+// bwd.hpp -- pieces of the backward pass shared across translation units: the weight-gradient reduction kernels
+// (defined in decoder_bwd.hip) and the node-level backward kernels (node_bwd.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace tsde {
+
+constexpr int WGRAD_CHUNK = 512;           // rows one k_wgrad workgroup reduces
+inline int64_t wgrad_max_parts(int64_t rows, int64_t groups) { return (rows + WGRAD_CHUNK - 1) / WGRAD_CHUNK + groups + 1; }
+
+__global__ void k_wgrad(const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, int chunk,
+                        int chunks_per_group, float* part, float* cs);
+__global__ void k_reduce_partials(const float* part, const float* cs, int P, int chunks_per_group, const float* step_tab, float* W,
+                                  int ldw, int col0, float* bias, int time_cols);
+__global__ void k_colsum(const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride);
+
+struct WgradCtx {
+  hipStream_t st;
+  float *part, *cs;            // scratch for wgrad_max_parts(...) partials of 4096 / 64 floats
+  const float* step_tab;       // only read when time_cols is set
+};
+// W[o*ldw + col0 + i] = sum_r delta[r*ldd + o] * a[r*lda + i]  (o, i < 64);  bias[o] = sum_r delta[r*ldd + o] (or null)
+int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, float* W,
+              int ldw, int col0, float* bias, int time_cols);
+int run_colsum(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride = 1);
+
+// ---- node-level backward blocks (node_bwd.hip)
+__global__ void k_ffn_bwd_a(const float* img, const float* dout, const float* xn2, int64_t R, float* H, float* DH);
+__global__ void k_ffn_bwd_b(const float* img, const float* DH, const float* dout, const float* x1, int64_t R, float* dx1, float* vpart);
+__global__ void k_upd_bwd(const float* img, const float* dx1, const float* agg, const float* xn, int64_t R, float* UPD, float* DGP,
+                          float* DS, float* DAGG, float* DXN);
+template <int NQ>
+__global__ void k_node_proj_bwd(const float* img, const float* x, const float* dres, const float* dxn_part, const float* dp0,
+                                const float* dp1, const float* dp2, int64_t R, float* dx_out, float* xn_out, float* vpart);
+__global__ void k_lin_t_acc(const float* wt, const float* d, int64_t R, float* out, int accumulate);
+__global__ void k_headwise_outer(const float* X, const float* Y, int64_t N, float* W);
+
+constexpr int64_t VPART_FLOATS = int64_t(2048) * 4 * 320;     // per-wave vector partials of the widest kernel at the largest grid
+
+struct NodeBlockTape { const float *agg, *xn, *x1, *xn2; };                      // forward activations [R,64]
+struct NodeBlockScratch { float *H, *DH, *dx1, *UPD, *DGP, *DS, *vpart; };        // [R,256] x2, [R,64] x4, VPART_FLOATS
+struct NodeBlockGrads {                                                           // parameter-shaped gradient buffers
+  float *w_ih, *b_ih, *w_hh, *b_hh, *w_self, *b_self, *w_out, *b_out, *n2g, *n2b, *w1, *b1, *w2, *b2;
+};
+// backward of  x1 = x + out_proj(gated update(agg, xn)),  out = x1 + mlp(norm2(x1))  given dout [R,64]:
+// writes dagg, dxn (the block's contribution to d xn) and sc.dx1 (= d x1, also the residual gradient of x)
+int node_block_backward(const float* img /*NodeBlockBwdL*/, const NodeBlockTape& tp, const float* dout, int64_t R,
+                        const NodeBlockScratch& sc, const WgradCtx& wc, const NodeBlockGrads& gr, float* dagg, float* dxn,
+                        hipStream_t st);
+
+struct EdgeEmbedScratch { float *S, *DEP, *DSP, *A0, *B0, *vpart; };             // [E,64] x5
+struct EdgeEmbedGrads {
+  float *a_w0, *a_b0, *a_g, *a_e, *b_w0, *b_b0, *b_g, *b_e, *wa3, *ba3, *wb3, *bb3, *ag0, *ae0, *w2, *b2, *ag3, *ae3;
+};
+int edge_embed_backward(const float* img /*EdgeBwdL*/, const float* geom, const float* demb, int64_t E, const EdgeEmbedScratch& sc,
+                        const WgradCtx& wc, const EdgeEmbedGrads& gr, hipStream_t st);
+
+// ordered parameter names of a stage (the dry run of its pack recipe, pack.hip)
+std::vector<std::string> stage_param_names(int stage, int num_layers, int num_modes);
+
+}  // namespace tsde

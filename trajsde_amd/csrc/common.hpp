@@ -52,6 +52,21 @@ struct Carver {
 
 inline int cdiv(int64_t a, int64_t b) { return int((a + b - 1) / b); }
 
+// grid for a tile kernel whose workgroups each hold an LDS weight image: as many workgroups as fit on the
+// chip at once (LDS- and thread-limited), grid-stride beyond that, never more than the work needs
+inline int tile_grid(int64_t ntiles, int threads, int lds_bytes) {
+  const int waves = threads / 64;
+  int per_cu = int((160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1));
+  const int by_threads = 2048 / threads;
+  if (per_cu > by_threads) per_cu = by_threads;
+  if (per_cu < 1) per_cu = 1;
+  int64_t want = (ntiles + waves - 1) / waves;
+  const int64_t cap = 256 * int64_t(per_cu);
+  if (want > cap) want = cap;
+  return int(want < 1 ? 1 : want);
+}
+
+
 // ---- optional per-kernel timing with HIP events on the launch stream (trajsde_profile_mode / _report).
 // mode 0: off (no events are created or recorded); 1: only launches tagged as "dominant"; 2: every launch.
 int profile_mode();

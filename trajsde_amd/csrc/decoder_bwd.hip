@@ -25,93 +25,10 @@
 #include "philox.hpp"
 #include "sde_funcs.hpp"
 #include "tile.hpp"
+#include "tile_bwd.hpp"
+#include "bwd.hpp"
 
 namespace tsde {
-
-// ------------------------------------------------------------------ tile helpers used only by backward kernels
-// x -> x_hat in place (the normalisation of tile.hpp layer_norm without the affine part); returns 1/std
-__device__ __forceinline__ float ln_normalize(f4 (&a)[4]) {
-  float s = 0.f;
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) s += (a[jt][0] + a[jt][1]) + (a[jt][2] + a[jt][3]);
-  const float mean = row_sum(s) * (1.0f / 64);
-  float v = 0.f;
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float d = a[jt][c] - mean;
-      a[jt][c] = d;
-      v += d * d;
-    }
-  const float rstd = 1.0f / sqrtf(row_sum(v) * (1.0f / 64) + 1e-5f);
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) a[jt][c] *= rstd;
-  return rstd;
-}
-
-// dy (grad w.r.t. gamma*x_hat+beta) -> grad w.r.t. the LayerNorm input, in place; accumulates dgamma, dbeta
-__device__ __forceinline__ void ln_backward(f4 (&dy)[4], const f4 (&xh)[4], float rstd, const float* gamma, int g,
-                                            f4 (&dgam)[4], f4 (&dbet)[4]) {
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    const f4 ga = *reinterpret_cast<const f4*>(gamma + 16 * jt + 4 * g);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      dgam[jt][c] = fmaf(dy[jt][c], xh[jt][c], dgam[jt][c]);
-      dbet[jt][c] += dy[jt][c];
-      const float gm = ga[c] * dy[jt][c];
-      dy[jt][c] = gm;
-      s1 += gm;
-      s2 = fmaf(gm, xh[jt][c], s2);
-    }
-  }
-  const float m1 = row_sum(s1) * (1.0f / 64), m2 = row_sum(s2) * (1.0f / 64);
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dy[jt][c] = rstd * (dy[jt][c] - m1 - xh[jt][c] * m2);
-}
-
-__device__ __forceinline__ void zero4(f4 (&a)[4]) {
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) a[jt] = f4{0.f, 0.f, 0.f, 0.f};
-}
-
-// out = W^T-image * in  (no bias)
-__device__ __forceinline__ void linear_t(f4 (&out)[4], const f4 (&in)[4], const float* wt, const Lane& L) {
-  zero4(out);
-  linear_acc<4, 4>(out, in, wt, L.lane);
-}
-
-// sum a per-lane accumulator over the 16 rows of the wave's tiles (lanes with equal g) -> 64 floats at dst
-__device__ __forceinline__ void flush_vec(const f4 (&acc)[4], float* dst, const Lane& L) {
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    f4 v = acc[jt];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float x = v[c];
-      x += __shfl_xor(x, 1);
-      x += __shfl_xor(x, 2);
-      x += __shfl_xor(x, 4);
-      x += __shfl_xor(x, 8);
-      v[c] = x;
-    }
-    if (L.n == 0) *reinterpret_cast<f4*>(dst + 16 * jt + 4 * L.g) = v;
-  }
-}
-// the same for a value that is already equal on the 4 lanes of a row
-__device__ __forceinline__ void flush_scalar(float x, float* dst, const Lane& L) {
-  x += __shfl_xor(x, 1);
-  x += __shfl_xor(x, 2);
-  x += __shfl_xor(x, 4);
-  x += __shfl_xor(x, 8);
-  if (L.lane == 0) *dst = x;
-}
 
 // ------------------------------------------------------------------ loss
 // one thread per actor: masked L2 per mode, first minimum wins (L2.py:19-22)
@@ -507,7 +424,7 @@ __global__ __launch_bounds__(128) void k_dec_init_bwd(const float* __restrict__ 
 // ------------------------------------------------------------------ weight gradients from saved rows
 // part[p] = sum_{rows of chunk p} delta[r][:]^T a[r][:]  (64x64, [o][i]),  cs[p][o] = sum delta[r][o].
 // Chunks never straddle a group (= one Euler step of rows_per_group rows), so the reducer can weight them per step.
-__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ delta, const float* __restrict__ a, int64_t R,
+__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ delta, int ldd, const float* __restrict__ a, int lda, int64_t R,
                                                int64_t rows_per_group, int chunk, int chunks_per_group,
                                                float* __restrict__ part, float* __restrict__ cs) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];
@@ -531,8 +448,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ delta, 
     float A[4], B[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      A[q] = r < row1 ? delta[r * D + 16 * q + idx] : 0.f;
-      B[q] = r < row1 ? a[r * D + 16 * q + idx] : 0.f;
+      A[q] = r < row1 ? delta[r * ldd + 16 * q + idx] : 0.f;
+      B[q] = r < row1 ? a[r * lda + 16 * q + idx] : 0.f;
       csum[q] += A[q];
     }
 #pragma unroll
@@ -592,13 +509,32 @@ __global__ void k_reduce_partials(const float* __restrict__ part, const float* _
   }
 }
 
-// dst[j] = sum_w src[w*stride + j], j < n   (per-wave vector partials -> one vector)
-__global__ void k_colsum(const float* __restrict__ src, int rows, int stride, int n, float* __restrict__ dst) {
+// dst[j*dst_stride] = sum_w src[w*stride + j], j < n   (per-wave vector partials -> one vector)
+__global__ void k_colsum(const float* __restrict__ src, int64_t rows, int stride, int n, float* __restrict__ dst, int dst_stride) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   float s = 0.f;
-  for (int w = 0; w < rows; ++w) s += src[int64_t(w) * stride + j];
-  dst[j] = s;
+  for (int64_t w = 0; w < rows; ++w) s += src[w * stride + j];
+  dst[int64_t(j) * dst_stride] = s;
+}
+
+int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, float* W,
+              int ldw, int col0, float* bias, int time_cols) {
+  if (R <= 0) {   // nothing to sum: the gradient block is zero
+    TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 256), 256, 0, c.st, c.part, c.cs, 0, 1, c.step_tab, W, ldw, col0, bias, time_cols);
+    return TRAJSDE_OK;
+  }
+  const int cpg = int((rows_per_group + WGRAD_CHUNK - 1) / WGRAD_CHUNK);
+  const int groups = int((R + rows_per_group - 1) / rows_per_group);
+  const int P = cpg * groups;
+  TS_LAUNCH(k_wgrad, P, 256, (4 * 4096 + 4 * 4 * 64) * 4, c.st, delta, ldd, a, lda, R, rows_per_group, WGRAD_CHUNK, cpg, c.part, c.cs);
+  TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 256), 256, 0, c.st, c.part, c.cs, P, cpg, c.step_tab, W, ldw, col0, bias, time_cols);
+  return TRAJSDE_OK;
+}
+int run_colsum(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride) {
+  k_colsum<<<cdiv(n, 64), 64, 0, st>>>(src, rows, stride, n, dst, dst_stride);
+  TS_LAUNCH_CHECK("k_colsum");
+  return TRAJSDE_OK;
 }
 
 }  // namespace tsde
@@ -611,7 +547,6 @@ namespace {
 enum GradSlot {
   F0W = 0, F2W, F4W, G0W, G2W, G4W, D0W, D0B, D1W, D1B, D3W, D3B, A0W, A0B, A1W, A1B, F0B, F2B, F4B, G0B, G2B, G4B, N_GRADS
 };
-constexpr int WGRAD_CHUNK = 512;
 constexpr int BWD_THREADS = 128;
 
 struct BwdWs {
@@ -647,7 +582,7 @@ BwdWs carve_bwd(void* ws, int64_t ws_bytes, int N, int T, int n_euler, bool& ok)
   w.DA = cv.take<float>(slab);
   w.DY0 = cv.take<float>(slab);
   const int64_t max_rows = int64_t(N) * (n_euler > T ? n_euler : T);
-  const int64_t max_parts = (max_rows + WGRAD_CHUNK - 1) / WGRAD_CHUNK + (n_euler > T ? n_euler : T);
+  const int64_t max_parts = wgrad_max_parts(max_rows, n_euler > T ? n_euler : T);
   w.part = cv.take<float>(max_parts * 4096);
   w.cs = cv.take<float>(max_parts * 64);
   w.vpart = cv.take<float>(int64_t(256) * (BWD_THREADS / 64) * 512);
@@ -713,7 +648,7 @@ int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, cons
   TS_LAUNCH(k_head_bwd, head_grid, BWD_THREADS, HeadBwdL::SIZE * 4, st, blob_bwd + DecBwdBlob::HEAD, w.states, out_table, y, reg_mask,
             w.scal, N, T, w.S_in, w.DU, w.DS, w.vpart);
   const int head_waves = head_grid * waves;
-  auto colsum = [&](const float* src, int rows, int stride, int n, float* dst) { k_colsum<<<cdiv(n, 64), 64, 0, st>>>(src, rows, stride, n, dst); };
+  auto colsum = [&](const float* src, int rows, int stride, int n, float* dst) { k_colsum<<<cdiv(n, 64), 64, 0, st>>>(src, rows, stride, n, dst, 1); };
   colsum(w.vpart + HeadV::DGAM, head_waves, HeadV::SIZE, 64, grads[D1W]);
   colsum(w.vpart + HeadV::DBET, head_waves, HeadV::SIZE, 64, grads[D1B]);
   colsum(w.vpart + HeadV::DW3X, head_waves, HeadV::SIZE, 128, grads[D3W]);      // rows x, y of decoder.3.weight [2,64]
@@ -735,15 +670,9 @@ int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, cons
   TS_LAUNCH_CHECK("k_colsum(init)");
 
   // ---- weight gradients: (delta rows, input rows, rows, rows per step) -> W (+ column offset), bias, time columns
+  const WgradCtx wc{st, w.part, w.cs, step_table};
   auto wgrad = [&](const float* delta, const float* a, int64_t R, int64_t rows_per_group, float* W, int ldw, int col0, float* bias,
-                   int time_cols) -> int {
-    const int cpg = int((rows_per_group + WGRAD_CHUNK - 1) / WGRAD_CHUNK);
-    const int groups = int((R + rows_per_group - 1) / rows_per_group);
-    const int P = cpg * groups;
-    TS_LAUNCH(k_wgrad, P, 256, (4 * 4096 + 4 * 4 * 64) * 4, st, delta, a, R, rows_per_group, WGRAD_CHUNK, cpg, w.part, w.cs);
-    TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 256), 256, 0, st, w.part, w.cs, P, cpg, step_table, W, ldw, col0, bias, time_cols);
-    return TRAJSDE_OK;
-  };
+                   int time_cols) -> int { return run_wgrad(wc, delta, 64, a, 64, R, rows_per_group, W, ldw, col0, bias, time_cols); };
   const int64_t RS = slab / 64 * n_euler, RT = slab / 64 * T;
   int rc;
   if ((rc = wgrad(w.DH1, w.states, RS, N, grads[F0W], 66, 0, grads[F0B], 1))) return rc;

@@ -261,6 +261,46 @@ struct InitBwdL {     // aggr_embed: forward fields + the two halves transposed
 struct DecBwdBlob {
   enum : int { SWEEP = 0, HEAD = SWEEP + SweepL::SIZE, INIT = HEAD + HeadBwdL::SIZE, SIZE = INIT + InitBwdL::SIZE };
 };
+// ---- backward images of the node-level blocks shared by the three attention families (node_bwd.hip)
+struct FfnBwdAL {     // recompute h = relu(W1 xn2 + b1), dh = (W2^T dout) * (h > 0)
+  enum : int { S_END = 0, TS_FIELD(W1, 4 * MAT64, S), TS_FIELD(B1, 256, W1), TS_FIELD(W2T, 4 * MAT64, B1), SIZE = W2T_END };
+};
+struct FfnBwdBL {     // dxn2 = W1^T dh, then norm2 backward
+  enum : int { S_END = 0, TS_FIELD(W1T, 4 * MAT64, S), TS_FIELD(N2G, 64, W1T), SIZE = N2G_END };
+};
+struct UpdBwdL {      // gated update: forward matrices for the recompute + the four transposes
+  enum : int {
+    S_END = 0,
+    TS_FIELD(WIH, MAT64, S), TS_FIELD(BIH, 64, WIH), TS_FIELD(WHH, MAT64, BIH), TS_FIELD(BHH, 64, WHH),
+    TS_FIELD(WSELF, MAT64, BHH), TS_FIELD(BSELF, 64, WSELF),
+    TS_FIELD(WOUT_T, MAT64, BSELF), TS_FIELD(WIH_T, MAT64, WOUT_T), TS_FIELD(WHH_T, MAT64, WIH_T), TS_FIELD(WSELF_T, MAT64, WHH_T),
+    SIZE = WSELF_T_END
+  };
+};
+template <int NQ>
+struct ProjBwdL {     // norm1 + NQ transposed projections (NQ = 0: a bare LayerNorm backward)
+  enum : int { S_END = 0, TS_FIELD(N1G, 64, S), TS_FIELD(N1B, 64, N1G), TS_FIELD(WT, NQ * MAT64, N1B), SIZE = WT_END };
+};
+struct EdgeBwdL {     // MultipleInputEmbedding: forward image (EdgeL up to EMB_SIZE) + the three transposes
+  enum : int { FWD = 0, W2T = EdgeL::EMB_SIZE, WA3T = W2T + MAT64, WB3T = WA3T + MAT64, SIZE = WB3T + MAT64 };
+};
+struct NodeBlockBwdL {   // one attention block's node-level backward images
+  enum : int { FFN_A = 0, FFN_B = FFN_A + FfnBwdAL::SIZE, UPD = FFN_B + FfnBwdBL::SIZE, SIZE = UPD + UpdBwdL::SIZE };
+};
+// aggregator backward blob: rel_embed, per layer {node block, qkv projections, lin_k_edge | lin_v_edge plain}, final norm,
+// per-mode transposed projections
+struct AggLayerBwdL {
+  enum : int { NODE = 0, PROJ = NODE + NodeBlockBwdL::SIZE, ATTN = PROJ + ProjBwdL<3>::SIZE, SIZE = ATTN + GAttnL::SIZE };
+};
+struct AggBwdBlob {
+  static constexpr int REL = 0;
+  static constexpr int layer(int i) { return EdgeBwdL::SIZE + i * AggLayerBwdL::SIZE; }
+  static constexpr int norm(int nl) { return layer(nl); }                        // ProjBwdL<0>: gamma | beta
+  static constexpr int proj(int nl, int k) { return norm(nl) + 128 + k * MAT64; }  // W_k^T fragment image
+  static constexpr int size(int nl, int K) { return proj(nl, K); }
+};
+static_assert(FfnBwdAL::SIZE * 4 <= 160 * 1024 && UpdBwdL::SIZE * 4 <= 160 * 1024 && EdgeBwdL::SIZE * 4 <= 160 * 1024,
+              "node backward images must fit LDS");
 static_assert(SweepL::SIZE * 4 <= 160 * 1024, "sweep image must fit LDS");
 static_assert(DecBwdBlob::HEAD % 4 == 0 && DecBwdBlob::INIT % 4 == 0, "16-byte aligned images");
 

@@ -1,0 +1,430 @@
+// node_bwd.hip -- backward of the node-level blocks every attention family of the path shares (AAEncoder ENC:595-613,
+// ALEncoder ENC:778-797, GlobalInteractorLayer AGG:119-135), plus the MultipleInputEmbedding backward (EMB:43-70):
+//
+//   k_ffn_bwd_a / k_ffn_bwd_b   out = x1 + W2 relu(W1 norm2(x1) + b1) + b2      -> dx1, saves (h, dh)
+//   k_upd_bwd                   gate / lin_self / out_proj (+ residual)          -> dagg, dxn, saves (upd, dgate_pre, ds)
+//   k_node_proj_bwd<NQ>         xn = norm1(x), NQ projections of xn              -> dx
+//   k_lin_t_acc                 out (+)= W^T d   for one transposed image
+//   k_edge_embed_bwd_tail / _branch   MultipleInputEmbedding over edge rows      -> saves the (delta, input) rows
+//   k_headwise_outer            W[d][c] = sum_i X[i][d] Y[i][head(d)][c]
+//
+// All matrix products are exact-fp32 MFMA (tile.hpp) on forward or transposed fragment images; parameter gradients
+// that are matrices come from the saved rows through run_wgrad (decoder_bwd.hip), vectors from per-wave accumulators.
+#include "bwd.hpp"
+#include "common.hpp"
+#include "layouts.hpp"
+#include "tile.hpp"
+#include "tile_bwd.hpp"
+
+namespace tsde {
+
+__device__ __forceinline__ void load_row256(f4 (&a)[16], const float* base, int64_t row, int g) {
+  const float* p = base + row * 256 + 4 * g;
+#pragma unroll
+  for (int jt = 0; jt < 16; ++jt) a[jt] = *reinterpret_cast<const f4*>(p + 16 * jt);
+}
+__device__ __forceinline__ void store_row256(const f4 (&a)[16], float* base, int64_t row, int g) {
+  float* p = base + row * 256 + 4 * g;
+#pragma unroll
+  for (int jt = 0; jt < 16; ++jt) *reinterpret_cast<f4*>(p + 16 * jt) = a[jt];
+}
+
+// H = relu(W1 xn2 + b1)  [R,256];  DH = (W2^T dout) * (H > 0)
+__global__ __launch_bounds__(256) void k_ffn_bwd_a(const float* __restrict__ img, const float* __restrict__ dout,
+                                                   const float* __restrict__ xn2, int64_t R, float* __restrict__ H,
+                                                   float* __restrict__ DH) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img, FfnBwdAL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (R + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
+    f4 n[4], hid[16], dh[16];
+    load_row(n, xn2, r, L.g);
+    linear<16, 4>(hid, n, lds + FfnBwdAL::W1, lds + FfnBwdAL::B1, L);
+    relu<16>(hid);
+    load_row(n, dout, r, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 16; ++jt) dh[jt] = f4{0.f, 0.f, 0.f, 0.f};
+    linear_acc<16, 4>(dh, n, lds + FfnBwdAL::W2T, L.lane);
+#pragma unroll
+    for (int jt = 0; jt < 16; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (!(hid[jt][c] > 0.f)) dh[jt][c] = 0.f;
+    if (row < R) {
+      store_row256(hid, H, row, L.g);
+      store_row256(dh, DH, row, L.g);
+    }
+  }
+}
+
+// dx1 = dout + norm2-backward(W1^T dh);  per-wave (dgamma2 | dbeta2) -> vpart[wave][128]
+__global__ __launch_bounds__(256) void k_ffn_bwd_b(const float* __restrict__ img, const float* __restrict__ DH,
+                                                   const float* __restrict__ dout, const float* __restrict__ x1, int64_t R,
+                                                   float* __restrict__ dx1, float* __restrict__ vpart) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img, FfnBwdBL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (R + 15) / 16;
+  f4 dgam[4], dbet[4];
+  zero4(dgam); zero4(dbet);
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
+    f4 dh[16], t[4], x[4];
+    load_row256(dh, DH, r, L.g);
+    zero4(t);
+    linear_acc<4, 16>(t, dh, lds + FfnBwdBL::W1T, L.lane);
+    if (row >= R) zero4(t);
+    load_row(x, x1, r, L.g);
+    const float rstd = ln_normalize(x);
+    ln_backward(t, x, rstd, lds + FfnBwdBL::N2G, L.g, dgam, dbet);
+    load_row(x, dout, r, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) t[jt] += x[jt];
+    if (row < R) store_row(t, dx1, row, L.g);
+  }
+  float* vp = vpart + int64_t(blockIdx.x * waves + wave) * 128;
+  flush_vec(dgam, vp, L);
+  flush_vec(dbet, vp + 64, L);
+}
+
+// gate = sigmoid(Wih agg + Whh xn + b); s = Wself xn + b; upd = agg + gate (s - agg); x1 = x + Wout upd + b
+// given dx1:  UPD, DGP (d gate pre-activation), DS (d s), DAGG (d agg), DXN (d xn from this block)
+__global__ __launch_bounds__(256) void k_upd_bwd(const float* __restrict__ img, const float* __restrict__ dx1,
+                                                 const float* __restrict__ agg, const float* __restrict__ xn, int64_t R,
+                                                 float* __restrict__ UPD, float* __restrict__ DGP, float* __restrict__ DS,
+                                                 float* __restrict__ DAGG, float* __restrict__ DXN) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using U = UpdBwdL;
+  stage_blob(lds, img, U::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (R + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
+    f4 a[4], n[4], g[4], s[4], d[4], t[4];
+    load_row(a, agg, r, L.g);
+    load_row(n, xn, r, L.g);
+    linear<4, 4>(g, a, lds + U::WIH, lds + U::BIH, L);
+    linear<4, 4>(t, n, lds + U::WHH, lds + U::BHH, L);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) g[jt] += t[jt];
+    sigmoid_<4>(g);
+    linear<4, 4>(s, n, lds + U::WSELF, lds + U::BSELF, L);
+    load_row(d, dx1, r, L.g);
+    linear_t(t, d, lds + U::WOUT_T, L);                                 // t = d upd
+    f4 upd[4], dgp[4], ds[4], dagg[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float gg = g[jt][c], diff = s[jt][c] - a[jt][c];
+        upd[jt][c] = a[jt][c] + gg * diff;
+        dagg[jt][c] = t[jt][c] * (1.0f - gg);
+        ds[jt][c] = t[jt][c] * gg;
+        dgp[jt][c] = t[jt][c] * diff * gg * (1.0f - gg);
+      }
+    linear_acc<4, 4>(dagg, dgp, lds + U::WIH_T, L.lane);
+    linear_t(t, dgp, lds + U::WHH_T, L);
+    linear_acc<4, 4>(t, ds, lds + U::WSELF_T, L.lane);
+    if (row < R) {
+      store_row(upd, UPD, row, L.g);
+      store_row(dgp, DGP, row, L.g);
+      store_row(ds, DS, row, L.g);
+      store_row(dagg, DAGG, row, L.g);
+      store_row(t, DXN, row, L.g);
+    }
+  }
+}
+
+// dx = dres + norm1-backward(dxn_part + sum_j Wj^T dp_j);  optional xn_out = norm1(x);  per-wave (dgamma | dbeta)
+template <int NQ>
+__global__ __launch_bounds__(256) void k_node_proj_bwd(const float* __restrict__ img, const float* __restrict__ x,
+                                                       const float* __restrict__ dres, const float* __restrict__ dxn_part,
+                                                       const float* __restrict__ dp0, const float* __restrict__ dp1,
+                                                       const float* __restrict__ dp2, int64_t R, float* __restrict__ dx_out,
+                                                       float* __restrict__ xn_out, float* __restrict__ vpart) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using P = ProjBwdL<NQ>;
+  stage_blob(lds, img, P::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (R + 15) / 16;
+  f4 dgam[4], dbet[4];
+  zero4(dgam); zero4(dbet);
+  const float* dps[3] = {dp0, dp1, dp2};
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
+    f4 t[4], d[4], xh[4];
+    if (dxn_part) load_row(t, dxn_part, r, L.g);
+    else zero4(t);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      load_row(d, dps[j], r, L.g);
+      linear_acc<4, 4>(t, d, lds + P::WT + j * MAT64, L.lane);
+    }
+    if (row >= R) zero4(t);
+    load_row(xh, x, r, L.g);
+    const float rstd = ln_normalize(xh);
+    if (xn_out && row < R) {
+      f4 o[4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const f4 ga = *reinterpret_cast<const f4*>(lds + P::N1G + 16 * jt + 4 * L.g);
+        const f4 be = *reinterpret_cast<const f4*>(lds + P::N1B + 16 * jt + 4 * L.g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[jt][c] = xh[jt][c] * ga[c] + be[c];
+      }
+      store_row(o, xn_out, row, L.g);
+    }
+    ln_backward(t, xh, rstd, lds + P::N1G, L.g, dgam, dbet);
+    if (dres) {
+      load_row(d, dres, r, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) t[jt] += d[jt];
+    }
+    if (row < R) store_row(t, dx_out, row, L.g);
+  }
+  float* vp = vpart + int64_t(blockIdx.x * waves + wave) * 128;
+  flush_vec(dgam, vp, L);
+  flush_vec(dbet, vp + 64, L);
+}
+template __global__ void k_node_proj_bwd<0>(const float*, const float*, const float*, const float*, const float*, const float*,
+                                            const float*, int64_t, float*, float*, float*);
+template __global__ void k_node_proj_bwd<1>(const float*, const float*, const float*, const float*, const float*, const float*,
+                                            const float*, int64_t, float*, float*, float*);
+template __global__ void k_node_proj_bwd<3>(const float*, const float*, const float*, const float*, const float*, const float*,
+                                            const float*, int64_t, float*, float*, float*);
+
+// out (+)= W^T d  for the transposed 64x64 image `wt`
+__global__ __launch_bounds__(256) void k_lin_t_acc(const float* __restrict__ wt, const float* __restrict__ d, int64_t R,
+                                                   float* __restrict__ out, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, wt, MAT64);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (R + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
+    f4 a[4], t[4];
+    load_row(a, d, r, L.g);
+    if (accumulate) load_row(t, out, r, L.g);
+    else zero4(t);
+    linear_acc<4, 4>(t, a, lds, L.lane);
+    if (row < R) store_row(t, out, row, L.g);
+  }
+}
+
+// ------------------------------------------------------------------ MultipleInputEmbedding backward (EMB:62-70)
+// forward: a0 = relu(LN(A_W0 in0 + b)), b0 likewise from in1; sp = WA3 a0 + WB3 b0 + b3; s = relu(LN0(sp));
+//          ep = W2 s + b2; emb = LN3(ep).
+// tail: given demb rows -> saves S (= s), DEP (d ep), DSP (d sp), A0, B0 (branch activations); per-wave vectors
+//       (dgamma3 | dbeta3 | dgamma0 | dbeta0) -> vpart[wave][256]
+__device__ __forceinline__ void branch_fwd(f4 (&xh)[4], f4 (&act)[4], float& rstd, float i0, float i1, const float* w0,
+                                           const float* b0, const float* gam, const float* bet, const Lane& L) {
+  linear_in2(xh, i0, i1, w0, b0, L.g);
+  rstd = ln_normalize(xh);
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    const f4 ga = *reinterpret_cast<const f4*>(gam + 16 * jt + 4 * L.g);
+    const f4 be = *reinterpret_cast<const f4*>(bet + 16 * jt + 4 * L.g);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) act[jt][c] = fmaxf(xh[jt][c] * ga[c] + be[c], 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_edge_embed_bwd_tail(const float* __restrict__ img, const float* __restrict__ geom,
+                                                             const float* __restrict__ demb, int64_t E, float* __restrict__ S,
+                                                             float* __restrict__ DEP, float* __restrict__ DSP,
+                                                             float* __restrict__ A0, float* __restrict__ B0,
+                                                             float* __restrict__ vpart) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img, EdgeBwdL::WA3T);                   // forward image + W2^T
+  using EL = EdgeL;
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (E + 15) / 16;
+  f4 dg3[4], db3[4], dg0[4], db0[4];
+  zero4(dg3); zero4(db3); zero4(dg0); zero4(db0);
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
+    const f4 ge = *reinterpret_cast<const f4*>(geom + 4 * ec);
+    f4 xh[4], a0[4], b0[4], sp[4], s[4], ep[4], d[4];
+    float r_;
+    branch_fwd(xh, a0, r_, ge[0], ge[1], lds + EL::A_W0, lds + EL::A_B0, lds + EL::A_G, lds + EL::A_E, L);
+    branch_fwd(xh, b0, r_, ge[2], ge[3], lds + EL::B_W0, lds + EL::B_B0, lds + EL::B_G, lds + EL::B_E, L);
+    load_vec<4>(sp, lds + EL::B3, L.g);
+    linear_acc<4, 4>(sp, a0, lds + EL::WA3, L.lane);
+    linear_acc<4, 4>(sp, b0, lds + EL::WB3, L.lane);
+    const float rs0 = ln_normalize(sp);                   // sp = s_hat
+    bool pos[16];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const f4 ga = *reinterpret_cast<const f4*>(lds + EL::AG0 + 16 * jt + 4 * L.g);
+      const f4 be = *reinterpret_cast<const f4*>(lds + EL::AE0 + 16 * jt + 4 * L.g);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float pre = sp[jt][c] * ga[c] + be[c];
+        pos[4 * jt + c] = pre > 0.f;
+        s[jt][c] = fmaxf(pre, 0.f);
+      }
+    }
+    linear<4, 4>(ep, s, lds + EL::W2, lds + EL::B2, L);
+    const float rs3 = ln_normalize(ep);                   // ep = e_hat
+    load_row(d, demb, ec, L.g);
+    if (e >= E) zero4(d);
+    ln_backward(d, ep, rs3, lds + EL::AG3, L.g, dg3, db3);   // d := d ep
+    f4 t[4];
+    linear_t(t, d, lds + EdgeBwdL::W2T, L);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (!pos[4 * jt + c]) t[jt][c] = 0.f;
+    ln_backward(t, sp, rs0, lds + EL::AG0, L.g, dg0, db0);   // t := d sp
+    if (e < E) {
+      store_row(s, S, e, L.g);
+      store_row(d, DEP, e, L.g);
+      store_row(t, DSP, e, L.g);
+      store_row(a0, A0, e, L.g);
+      store_row(b0, B0, e, L.g);
+    }
+  }
+  float* vp = vpart + int64_t(blockIdx.x * waves + wave) * 256;
+  flush_vec(dg3, vp, L);
+  flush_vec(db3, vp + 64, L);
+  flush_vec(dg0, vp + 128, L);
+  flush_vec(db0, vp + 192, L);
+}
+
+// branch BR (0: first input, 1: second): d act = W{A,B}3^T dsp * (act > 0) -> LN backward -> the 2-wide input linear.
+// per-wave vectors (dgamma | dbeta | dW0[:,0] | dW0[:,1] | db0) -> vpart[wave][320]
+template <int BR>
+__global__ __launch_bounds__(256) void k_edge_embed_bwd_branch(const float* __restrict__ img, const float* __restrict__ geom,
+                                                               const float* __restrict__ DSP, int64_t E,
+                                                               float* __restrict__ vpart) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using EL = EdgeL;
+  constexpr int W0 = BR ? EL::B_W0 : EL::A_W0, B0_ = BR ? EL::B_B0 : EL::A_B0, G_ = BR ? EL::B_G : EL::A_G, E_ = BR ? EL::B_E : EL::A_E;
+  // stage the input-embedding vectors and this branch's transposed matrix only
+  for (int i = threadIdx.x; i < EL::WA3; i += blockDim.x) lds[i] = img[i];
+  {
+    const float* src = img + (BR ? EdgeBwdL::WB3T : EdgeBwdL::WA3T);
+    for (int i = threadIdx.x; i < MAT64; i += blockDim.x) lds[EL::WA3 + i] = src[i];
+  }
+  __syncthreads();
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (E + 15) / 16;
+  f4 dg[4], db[4], dwx[4], dwy[4], dbb[4];
+  zero4(dg); zero4(db); zero4(dwx); zero4(dwy); zero4(dbb);
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
+    const f4 ge = *reinterpret_cast<const f4*>(geom + 4 * ec);
+    const float i0 = BR ? ge[2] : ge[0], i1 = BR ? ge[3] : ge[1];
+    f4 xh[4], act[4], d[4], t[4];
+    float rstd;
+    branch_fwd(xh, act, rstd, i0, i1, lds + W0, lds + B0_, lds + G_, lds + E_, L);
+    load_row(d, DSP, ec, L.g);
+    if (e >= E) zero4(d);
+    linear_t(t, d, lds + EL::WA3, L);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (!(act[jt][c] > 0.f)) t[jt][c] = 0.f;
+    ln_backward(t, xh, rstd, lds + G_, L.g, dg, db);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        dwx[jt][c] = fmaf(t[jt][c], i0, dwx[jt][c]);
+        dwy[jt][c] = fmaf(t[jt][c], i1, dwy[jt][c]);
+        dbb[jt][c] += t[jt][c];
+      }
+  }
+  float* vp = vpart + int64_t(blockIdx.x * waves + wave) * 320;
+  flush_vec(dg, vp, L);
+  flush_vec(db, vp + 64, L);
+  flush_vec(dwx, vp + 128, L);
+  flush_vec(dwy, vp + 192, L);
+  flush_vec(dbb, vp + 256, L);
+}
+template __global__ void k_edge_embed_bwd_branch<0>(const float*, const float*, const float*, int64_t, float*);
+template __global__ void k_edge_embed_bwd_branch<1>(const float*, const float*, const float*, int64_t, float*);
+
+// W[d][c] = sum_i X[i][d] * Y[i][d>>3][c]    (X [N,64], Y [N,8,64]); one workgroup per output row d
+__global__ __launch_bounds__(256) void k_headwise_outer(const float* __restrict__ X, const float* __restrict__ Y, int64_t N,
+                                                        float* __restrict__ W) {
+  __shared__ float red[4][64];
+  const int d = blockIdx.x, c = threadIdx.x & 63, part = threadIdx.x >> 6, h = d >> 3;
+  float s = 0.f;
+  for (int64_t i = part; i < N; i += 4) s = fmaf(X[i * 64 + d], Y[(i * 8 + h) * 64 + c], s);
+  red[part][c] = s;
+  __syncthreads();
+  if (part == 0) W[d * 64 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// ------------------------------------------------------------------ host drivers
+int node_block_backward(const float* img, const NodeBlockTape& tp, const float* dout, int64_t R, const NodeBlockScratch& sc,
+                        const WgradCtx& wc, const NodeBlockGrads& gr, float* dagg, float* dxn, hipStream_t st) {
+  const int64_t ntiles = (R + 15) / 16;
+  const int ga = tile_grid(ntiles, 256, FfnBwdAL::SIZE * 4), gb = tile_grid(ntiles, 256, FfnBwdBL::SIZE * 4),
+            gu = tile_grid(ntiles, 256, UpdBwdL::SIZE * 4);
+  TS_LAUNCH(k_ffn_bwd_a, ga, 256, FfnBwdAL::SIZE * 4, st, img + NodeBlockBwdL::FFN_A, dout, tp.xn2, R, sc.H, sc.DH);
+  TS_LAUNCH(k_ffn_bwd_b, gb, 256, FfnBwdBL::SIZE * 4, st, img + NodeBlockBwdL::FFN_B, sc.DH, dout, tp.x1, R, sc.dx1, sc.vpart);
+  if (int rc = run_colsum(st, sc.vpart, gb * 4, 128, 64, gr.n2g)) return rc;
+  if (int rc = run_colsum(st, sc.vpart + 64, gb * 4, 128, 64, gr.n2b)) return rc;
+  // mlp.0 [256,64] (four 64-row blocks) and mlp.3 [64,256] (four 64-column blocks)
+  for (int b = 0; b < 4; ++b) {
+    if (int rc = run_wgrad(wc, sc.DH + 64 * b, 256, tp.xn2, 64, R, R, gr.w1 + b * MAT64, 64, 0, gr.b1 + 64 * b, 0)) return rc;
+    if (int rc = run_wgrad(wc, dout, 64, sc.H + 64 * b, 256, R, R, gr.w2, 256, 64 * b, b == 0 ? gr.b2 : nullptr, 0)) return rc;
+  }
+  TS_LAUNCH(k_upd_bwd, gu, 256, UpdBwdL::SIZE * 4, st, img + NodeBlockBwdL::UPD, sc.dx1, tp.agg, tp.xn, R, sc.UPD, sc.DGP, sc.DS, dagg, dxn);
+  if (int rc = run_wgrad(wc, sc.dx1, 64, sc.UPD, 64, R, R, gr.w_out, 64, 0, gr.b_out, 0)) return rc;
+  if (int rc = run_wgrad(wc, sc.DGP, 64, tp.agg, 64, R, R, gr.w_ih, 64, 0, gr.b_ih, 0)) return rc;
+  if (int rc = run_wgrad(wc, sc.DGP, 64, tp.xn, 64, R, R, gr.w_hh, 64, 0, gr.b_hh, 0)) return rc;
+  if (int rc = run_wgrad(wc, sc.DS, 64, tp.xn, 64, R, R, gr.w_self, 64, 0, gr.b_self, 0)) return rc;
+  return TRAJSDE_OK;
+}
+
+int edge_embed_backward(const float* img, const float* geom, const float* demb, int64_t E, const EdgeEmbedScratch& sc,
+                        const WgradCtx& wc, const EdgeEmbedGrads& gr, hipStream_t st) {
+  if (E <= 0) return TRAJSDE_OK;
+  const int64_t ntiles = (E + 15) / 16;
+  const int lds_tail = EdgeBwdL::WA3T * 4, lds_br = (EdgeL::WA3 + MAT64) * 4;
+  const int gt = tile_grid(ntiles, 256, lds_tail), gb = tile_grid(ntiles, 256, lds_br);
+  TS_LAUNCH(k_edge_embed_bwd_tail, gt, 256, lds_tail, st, img, geom, demb, E, sc.S, sc.DEP, sc.DSP, sc.A0, sc.B0, sc.vpart);
+  float* const tail_vec[4] = {gr.ag3, gr.ae3, gr.ag0, gr.ae0};
+  for (int i = 0; i < 4; ++i)
+    if (int rc = run_colsum(st, sc.vpart + 64 * i, gt * 4, 256, 64, tail_vec[i])) return rc;
+  if (int rc = run_wgrad(wc, sc.DEP, 64, sc.S, 64, E, E, gr.w2, 64, 0, gr.b2, 0)) return rc;
+  if (int rc = run_wgrad(wc, sc.DSP, 64, sc.A0, 64, E, E, gr.wa3, 64, 0, gr.ba3, 0)) return rc;
+  if (int rc = run_wgrad(wc, sc.DSP, 64, sc.B0, 64, E, E, gr.wb3, 64, 0, gr.bb3, 0)) return rc;
+  for (int br = 0; br < 2; ++br) {
+    if (br == 0) TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, img, geom, sc.DSP, E, sc.vpart);
+    else TS_LAUNCH(k_edge_embed_bwd_branch<1>, gb, 256, lds_br, st, img, geom, sc.DSP, E, sc.vpart);
+    float* g_ = br ? gr.b_g : gr.a_g;
+    float* e_ = br ? gr.b_e : gr.a_e;
+    float* w0 = br ? gr.b_w0 : gr.a_w0;
+    float* b0 = br ? gr.b_b0 : gr.a_b0;
+    if (int rc = run_colsum(st, sc.vpart, gb * 4, 320, 64, g_)) return rc;
+    if (int rc = run_colsum(st, sc.vpart + 64, gb * 4, 320, 64, e_)) return rc;
+    if (int rc = run_colsum(st, sc.vpart + 128, gb * 4, 320, 64, w0, 2)) return rc;        // [64,2] weight, column 0
+    if (int rc = run_colsum(st, sc.vpart + 192, gb * 4, 320, 64, w0 + 1, 2)) return rc;    // column 1
+    if (int rc = run_colsum(st, sc.vpart + 256, gb * 4, 320, 64, b0)) return rc;
+  }
+  return TRAJSDE_OK;
+}
+
+}  // namespace tsde

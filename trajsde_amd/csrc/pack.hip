@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 
+#include "bwd.hpp"
 #include "common.hpp"
 #include "layouts.hpp"
 
@@ -37,13 +38,13 @@ __global__ void k_pack_mat(const float* __restrict__ src, float* __restrict__ ds
   dst[i] = src[(16 * jo + (lane & 15)) * ld + col0 + 16 * q + 4 * (lane >> 4) + c];
 }
 
-// fragment image of the TRANSPOSE of the 64x64 block at column col0: element [i][o] = W[o][col0 + i]
-__global__ void k_pack_matT(const float* __restrict__ src, float* __restrict__ dst, int ld, int col0) {
+// fragment image [jo < jto][q < jti][lane][4] of a TRANSPOSED weight: element [r][c] = W[c][col0 + r] (W row-major, ld)
+__global__ void k_pack_matT(const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld, int col0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 16 * 256) return;
-  const int c = i & 3, lane = (i >> 2) & 63, q = (i >> 8) % 4, jo = (i >> 8) / 4;
+  if (i >= jto * jti * 256) return;
+  const int c = i & 3, lane = (i >> 2) & 63, q = (i >> 8) % jti, jo = (i >> 8) / jti;
   const int row_t = 16 * jo + (lane & 15), col_t = 16 * q + 4 * (lane >> 4) + c;      // element of W^T
-  dst[i] = src[col_t * ld + col0 + row_t];
+  dst[i] = src[int64_t(col_t) * ld + col0 + row_t];
 }
 
 // bf16x6 planes: dst (as bf16) [plane][jo][s][lane][8]; element j of lane (i,g) in k-step s is the plane-th exact
@@ -99,10 +100,11 @@ struct Packer {
     const int jto = rows / 16, jti = cols / 16;
     k_pack_mat<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, col0);
   }
-  void matT(const std::string& n, int dst, int ld, int col0 = 0) {
+  // transposed image of the [16*jti x 16*jto] block of W starting at column col0 (default: a 64x64 block)
+  void matT(const std::string& n, int dst, int ld, int col0 = 0, int jto = 4, int jti = 4) {
     const float* s = src(n);
     if (dry) return;
-    k_pack_matT<<<cdiv(16 * 256, 256), 256, 0, stream>>>(s, blob + dst, ld, col0);
+    k_pack_matT<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, col0);
   }
   void mat6(const std::string& n, int dst, int rows, int cols, int ld, int col0 = 0) {
     const float* s = src(n);
@@ -405,14 +407,69 @@ static void recipe_decoder_bwd(Packer& P) {
     P.index(n);
 }
 
+// node-level backward images of one attention block (layouts.hpp NodeBlockBwdL); `p` = the block's parameter prefix
+static void recipe_node_block_bwd(Packer& P, const std::string& p, int base) {
+  const int a = base + NodeBlockBwdL::FFN_A, b = base + NodeBlockBwdL::FFN_B, u = base + NodeBlockBwdL::UPD;
+  P.lin(p + ".mlp.0", a + FfnBwdAL::W1, a + FfnBwdAL::B1, 256, 64);
+  P.matT(p + ".mlp.3.weight", a + FfnBwdAL::W2T, 256, 0, 16, 4);         // (W2 [64,256])^T as a 256x64 image
+  P.matT(p + ".mlp.0.weight", b + FfnBwdBL::W1T, 64, 0, 4, 16);          // (W1 [256,64])^T as a 64x256 image
+  P.vec(p + ".norm2.weight", b + FfnBwdBL::N2G, 64);
+  P.lin(p + ".lin_ih", u + UpdBwdL::WIH, u + UpdBwdL::BIH);
+  P.lin(p + ".lin_hh", u + UpdBwdL::WHH, u + UpdBwdL::BHH);
+  P.lin(p + ".lin_self", u + UpdBwdL::WSELF, u + UpdBwdL::BSELF);
+  P.matT(p + ".out_proj.weight", u + UpdBwdL::WOUT_T, 64);
+  P.matT(p + ".lin_ih.weight", u + UpdBwdL::WIH_T, 64);
+  P.matT(p + ".lin_hh.weight", u + UpdBwdL::WHH_T, 64);
+  P.matT(p + ".lin_self.weight", u + UpdBwdL::WSELF_T, 64);
+  for (const char* n : {".mlp.3.bias", ".out_proj.bias", ".norm2.bias"}) P.index(p + n);
+}
+static void recipe_edge_embed_bwd(Packer& P, const std::string& p, int base) {
+  recipe_edge_embed(P, p, base + EdgeBwdL::FWD);
+  P.matT(p + ".aggr_embed.2.weight", base + EdgeBwdL::W2T, 64);
+  P.matT(p + ".module_list.0.3.weight", base + EdgeBwdL::WA3T, 64);
+  P.matT(p + ".module_list.1.3.weight", base + EdgeBwdL::WB3T, 64);
+}
+static void recipe_aggregator_bwd(Packer& P, int nl, int K) {
+  recipe_edge_embed_bwd(P, "rel_embed", AggBwdBlob::REL);
+  for (int i = 0; i < nl; ++i) {
+    const std::string p = "global_interactor_layers." + std::to_string(i);
+    const int b = AggBwdBlob::layer(i);
+    recipe_node_block_bwd(P, p, b + AggLayerBwdL::NODE);
+    using Q = ProjBwdL<3>;
+    P.ln(p + ".norm1", b + AggLayerBwdL::PROJ + Q::N1G, b + AggLayerBwdL::PROJ + Q::N1B);
+    const char* qkv[3] = {".lin_q_node", ".lin_k_node", ".lin_v_node"};
+    for (int j = 0; j < 3; ++j) {
+      P.matT(p + qkv[j] + ".weight", b + AggLayerBwdL::PROJ + Q::WT + j * MAT64, 64);
+      P.index(p + qkv[j] + ".bias");
+    }
+    P.vec(p + ".lin_k_edge.weight", b + AggLayerBwdL::ATTN + GAttnL::WKE, MAT64);
+    P.vec(p + ".lin_k_edge.bias", b + AggLayerBwdL::ATTN + GAttnL::BKE, 64);
+    P.vec(p + ".lin_v_edge.weight", b + AggLayerBwdL::ATTN + GAttnL::WVE, MAT64);
+    P.vec(p + ".lin_v_edge.bias", b + AggLayerBwdL::ATTN + GAttnL::BVE, 64);
+  }
+  P.ln("norm", AggBwdBlob::norm(nl), AggBwdBlob::norm(nl) + 64);
+  const float* w = P.src("multihead_proj.weight");
+  P.index("multihead_proj.bias");
+  if (!P.dry)
+    for (int k = 0; k < K; ++k)
+      k_pack_matT<<<cdiv(16 * 256, 256), 256, 0, P.stream>>>(w + int64_t(k) * MAT64, P.blob + AggBwdBlob::proj(nl, k), 4, 4, 64, 0);
+}
+
 static bool run_recipe(Packer& P, int stage, int nl, int K) {
   switch (stage) {
     case TRAJSDE_STAGE_ENCODER: recipe_encoder(P); return true;
     case TRAJSDE_STAGE_AGGREGATOR: recipe_aggregator(P, nl, K); return true;
     case TRAJSDE_STAGE_DECODER: recipe_decoder(P); return true;
     case TRAJSDE_STAGE_DECODER_BWD: recipe_decoder_bwd(P); return true;
+    case TRAJSDE_STAGE_AGGREGATOR_BWD: recipe_aggregator_bwd(P, nl, K); return true;
   }
   return false;
+}
+
+std::vector<std::string> stage_param_names(int stage, int num_layers, int num_modes) {
+  Packer P{true};
+  if (!run_recipe(P, stage, num_layers, num_modes)) return {};
+  return P.names;
 }
 
 // ---- event profiler (see common.hpp)
@@ -505,6 +562,7 @@ int64_t trajsde_blob_floats(int stage, int num_layers, int num_modes) {
     case TRAJSDE_STAGE_AGGREGATOR: return AggBlob::size(num_layers, num_modes);
     case TRAJSDE_STAGE_DECODER: return DecBlob::SIZE;
     case TRAJSDE_STAGE_DECODER_BWD: return DecBwdBlob::SIZE;
+    case TRAJSDE_STAGE_AGGREGATOR_BWD: return AggBwdBlob::size(num_layers, num_modes);
   }
   return fail(TRAJSDE_ERR_INVALID, "unknown stage");
 }

@@ -21,20 +21,6 @@ static int threads_edge() { static int t = env_threads("TRAJSDE_THREADS_EDGE", 1
 static int threads_node() { static int t = env_threads("TRAJSDE_THREADS_NODE", 512); return t; }
 static int threads_recur() { static int t = env_threads("TRAJSDE_THREADS_RECUR", 256); return t; }
 
-// grid for a tile kernel whose workgroups each hold an LDS weight image: as many workgroups as fit on the
-// chip at once (LDS- and thread-limited), grid-stride beyond that, never more than the work needs
-static int tile_grid(int64_t ntiles, int threads, int lds_bytes) {
-  const int waves = threads / 64;
-  int per_cu = int((160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1));
-  const int by_threads = 2048 / threads;
-  if (per_cu > by_threads) per_cu = by_threads;
-  if (per_cu < 1) per_cu = 1;
-  int64_t want = (ntiles + waves - 1) / waves;
-  const int64_t cap = 256 * int64_t(per_cu);
-  if (want > cap) want = cap;
-  return int(want < 1 ? 1 : want);
-}
-
 struct EncWs {
   float *center, *cn, *q, *logits, *v, *agg, *x1, *xn2, *aa_out, *hA, *hB, *lat, *al_xn, *al_q, *al_logits, *al_v, *al_agg, *al_x1,
       *al_xn2;

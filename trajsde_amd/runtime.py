@@ -310,6 +310,32 @@ class StageRuntime:
         return out
 
 
+    def aggregator_backward(self, data, local_embed: torch.Tensor, d_global: torch.Tensor) -> Dict[str, object]:
+        """Backward of GlobalInteractor.forward: dL/d global_embed [K,N,64] -> {"grads": {param name: tensor},
+        "d_local_embed": [N,64]} (the aggregator's own contribution; the decoder's d local_embed is added by the
+        caller).  The forward is recomputed inside the call."""
+        m = self.module
+        _require_gpu(local_embed, "local_embed")
+        gc = GraphContext.get(data, None, int(m.historical_steps), None)
+        dev = gc.device
+        L = _lib.lib()
+        K, N, nl = int(m.num_modes), gc.batch.N, int(m.num_layers)
+        if tuple(d_global.shape) != (K, N, D):
+            raise _lib.TrajsdeError(f"d_global must be [{K},{N},{D}]")
+        names = self.param_names(_lib.STAGE_AGGREGATOR_BWD)
+        grads = {n: torch.zeros_like(m.p(n)) for n in names}
+        arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
+        d_local = torch.empty(N, D, device=dev, dtype=torch.float32)
+        ws_bytes = L.trajsde_aggregator_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), nl, K)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_aggregator_backward(
+                C.byref(gc.batch), C.byref(gc.graph), self.blob().data_ptr(), self.blob(_lib.STAGE_AGGREGATOR_BWD).data_ptr(), nl, K,
+                local_embed.contiguous().data_ptr(), d_global.to(torch.float32).contiguous().data_ptr(), ws.data_ptr(), ws_bytes,
+                arr, len(names), d_local.data_ptr(), _stream()), "trajsde_aggregator_backward")
+        return {"grads": grads, "d_local_embed": d_local}
+
+
 class GraphContext:
     """Device-side graph structures of one batch (CSR, compacted edge lists, segment pointers), built once per
     forward by the first stage that needs them and parked on the batch object for the next stage."""
