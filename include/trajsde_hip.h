@@ -44,10 +44,11 @@ typedef enum {
   TRAJSDE_STAGE_ENCODER = 0,
   TRAJSDE_STAGE_AGGREGATOR = 1,
   TRAJSDE_STAGE_DECODER = 2,
-  TRAJSDE_STAGE_DECODER_BWD = 3 /* transposed images for trajsde_decoder_l2_backward; its parameter list is the
-                                   subset of the decoder's that receives a gradient */
-  ,
-  TRAJSDE_STAGE_AGGREGATOR_BWD = 4 /* images for trajsde_aggregator_backward (same parameters as the aggregator) */
+  /* backward images: the parameter list of a *_BWD stage names the parameters that receive a gradient, in the
+   * order of the gradient buffers the stage's backward entry point takes */
+  TRAJSDE_STAGE_DECODER_BWD = 3,    /* trajsde_decoder_l2_backward (pi / scale heads get no gradient from that loss) */
+  TRAJSDE_STAGE_AGGREGATOR_BWD = 4, /* trajsde_aggregator_backward */
+  TRAJSDE_STAGE_ENCODER_BWD = 5     /* trajsde_encoder_backward */
 } trajsde_stage;
 
 int trajsde_param_count(int stage, int num_layers /*aggregator*/, int num_modes);
@@ -199,6 +200,21 @@ int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, 
                                 int num_layers, int num_modes, const float* local_embed /*[N,64]*/,
                                 const float* d_global /*[K,N,64]*/, void* ws, int64_t ws_bytes, float* const* grads, int n_grads,
                                 float* d_local /*[N,64]*/, void* stream);
+
+/* ---- backward of the encoder stage (ENC:66-202) + the DiffBCE loss on its diffusion outputs (losses/diff_BCE.py):
+ *      d_local = dL/d local_embed (decoder + aggregator contributions); diff_weight = weight of the DiffBCE term in
+ *      the total loss (0 skips it); *diff_loss receives diff_weight * DiffBCE.  `noise` must be the forward's.
+ *      grads[i] is shaped like parameter trajsde_param_name(TRAJSDE_STAGE_ENCODER_BWD, i) (pre-zeroed by the caller,
+ *      overwritten where the batch reaches the parameter).  d_latent [N,64] / d_aa_out [H,Nt,64] are optional
+ *      outputs (null to skip) of the gradients at the two internal stage boundaries.  The step table is passed
+ *      twice: host copy (scalars for the launches) and device copy (time-feature column reductions). */
+int64_t trajsde_encoder_backward_ws_bytes(const trajsde_batch* b, const trajsde_graph* g);
+int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rotate_mat, const float* blob_fwd,
+                             const float* blob_bwd, const float* enc_step_table /*HOST [H,8]*/,
+                             const float* enc_step_table_dev /*device [H,8]*/, const trajsde_noise* noise,
+                             const float* d_local /*[N,64]*/, float diff_weight, void* ws, int64_t ws_bytes,
+                             float* diff_loss /*[1] device*/, float* const* grads, int n_grads, float* d_latent, float* d_aa_out,
+                             void* stream);
 
 /* ---- step-granular decoder SDE step (state round-trips HBM every step): the 512 B/path-step variant
  *      of SURVEY.md 8(d), kept for the HBM-roofline measurement the north star asks for. */

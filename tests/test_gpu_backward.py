@@ -153,6 +153,86 @@ def test_aggregator_backward_matches_autograd(S, n, K, kw, dev):
     assert _rel(res["d_local_embed"], d_local) <= REL
 
 
+def _oracle_encoder_grads(model, cfg, batch_cpu, d_local, seed, diff_weight):
+    """autograd over the oracle's encoder restatement, evaluated in float64: several encoder gradients (LayerNorm
+    chains summed over every edge of 21 snapshots) are ill-conditioned enough that the float32 autograd result is
+    itself ~2e-4 away from the float64 one, so the higher-precision run of the same code is the reference here"""
+    import restate
+    import torch.nn.functional as F
+    from trajsde_amd.schedule import encoder_schedule
+    c = restate.flat_cfg(cfg)
+    sched = encoder_schedule(c["historical_steps"], c["max_past_t"], c["minimum_step"])
+    dt = torch.float64
+    P = {k: (v.detach().cpu().to(dt) if v.is_floating_point() else v.detach().cpu().clone()) for k, v in model.state_dict().items()}
+    names = [k for k in P if k.startswith("encoder.") and P[k].is_floating_point()]
+    for k in names:
+        P[k].requires_grad_(True)
+    b = H.clone_batch(batch_cpu)
+    for k in b.keys:
+        if torch.is_tensor(b[k]) and b[k].is_floating_point():
+            b[k] = b[k].to(dt)
+
+    class Noise64(restate.PhiloxNoise):
+        def fake_agent(self, shape):
+            return super().fake_agent(shape).to(dt)
+
+        def encoder(self, idx, shape):
+            return super().encoder(idx, shape).to(dt)
+
+    torch.set_default_dtype(dt)
+    try:
+        rot, _ = restate.rotate_inputs(b)
+        with torch.enable_grad():
+            local, diff_in, diff_out, inter = restate.local_encoder(P, c, b, rot, Noise64(seed), sched, True)
+            inter["aa_out"].retain_grad()
+            bce = (F.binary_cross_entropy(diff_in, torch.zeros_like(diff_in)) +
+                   F.binary_cross_entropy(diff_out, torch.ones_like(diff_out)))
+            ((local * d_local.cpu().to(dt)).sum() + diff_weight * bce).backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    grads = {k[len("encoder."):]: (P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])) for k in names}
+    return grads, float(bce.detach()), inter["aa_out"].grad
+
+
+@pytest.mark.parametrize("S,n,kw,diff_weight", [
+    (3, 14, dict(mixed_source=True, history_dropout=0.4), 1.0),
+    (2, 9, dict(source=1, history_dropout=0.2), 0.5),
+    (2, 6, dict(nus_sparsity=True), 0.0),
+])
+def test_encoder_backward_matches_autograd(S, n, kw, diff_weight, dev):
+    from trajsde_amd import runtime
+    from trajsde_amd.synth import synth
+    T, K = 5, 2
+    batch = synth(S=S, n=n, L=6, F=T, box=60.0, seed=500 + n, **kw)
+    model, cfg = H.build_model(K, T, 0.5, init_seed=17)
+    model = model.to(dev)
+    data = batch.to(dev)
+    noise = runtime.NoiseSpec(seed=23)
+    rot, y_rot = runtime.rotate_inputs(data)
+    data.y, data["rotate_mat"] = y_rot, rot
+    local, *_ = model.encoder(data=data, noise=noise)
+    g = torch.Generator().manual_seed(5)
+    d_local = torch.randn(local.shape, generator=g)
+    res = model.encoder._rt.encoder_backward(data, d_local.to(dev), noise, diff_weight=diff_weight, want_boundaries=True)
+    torch.cuda.synchronize()
+    want, bce, d_aa = _oracle_encoder_grads(model, cfg, batch, d_local, 23, diff_weight)
+    assert abs(float(res["diff_loss"]) - diff_weight * bce) <= 1e-5 * max(1.0, bce)
+    assert _rel(res["d_aa_out"], d_aa) <= REL
+    got = res["grads"]
+    for k in set(want) - set(got):
+        assert float(want[k].abs().max()) == 0.0, k
+    assert set(got) <= set(want)
+    bad = []
+    for k in sorted(got):
+        assert got[k].shape == want[k].shape, k
+        scale = float(want[k].abs().max())
+        err = float((got[k].cpu().double() - want[k].double()).abs().max())
+        zero_by_symmetry = k.endswith("lin_k.bias")            # a key bias shifts every logit of a target alike
+        if (err > 5e-5 or scale > 5e-5) if zero_by_symmetry else (err > REL * scale + 1e-7):
+            bad.append((k, err, scale))
+    assert not bad, bad
+
+
 def test_decoder_backward_is_deterministic_and_checks_arguments(dev):
     from trajsde_amd import _lib, runtime
     from trajsde_amd.synth import synth

@@ -7,7 +7,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtrajsde_hip.so")
 
-STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGATOR_BWD = 0, 1, 2, 3, 4
+STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGATOR_BWD, STAGE_ENCODER_BWD = 0, 1, 2, 3, 4, 5
 
 
 class TrajsdeError(RuntimeError):
@@ -65,6 +65,9 @@ SIGNATURES = {
     "trajsde_aggregator_backward_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph), C.c_int, C.c_int]),
     "trajsde_aggregator_backward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, C.c_int, C.c_int, P, P, P, I64,
                                               C.POINTER(P), C.c_int, P, P]),
+    "trajsde_encoder_backward_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
+    "trajsde_encoder_backward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, P, P, C.POINTER(Noise), P, F32, P, I64, P,
+                                           C.POINTER(P), C.c_int, P, P, P]),
     "trajsde_profile_mode": (C.c_int, [C.c_int]),
     "trajsde_profile_report": (I64, [C.c_char_p, I64]),
     "trajsde_sde_step": (C.c_int, [I32, P, P, P, C.POINTER(F32), C.c_int, C.POINTER(Noise), P]),

@@ -18,6 +18,7 @@
 #include <string>
 #include <unordered_map>
 
+#include "attn_common.hpp"
 #include "bwd.hpp"
 #include "common.hpp"
 #include "kernels.hpp"
@@ -25,19 +26,6 @@
 #include "tile.hpp"
 
 namespace tsde {
-
-namespace {
-constexpr float INV_SQRT_DH_B = 0.35355339059327373f;   // 1/sqrt(64/8)
-
-__device__ __forceinline__ float dpp_add_b(float v, int tag) {
-  int r;
-  if (tag == 0) r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);
-  else if (tag == 1) r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);
-  else r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true);
-  return v + __int_as_float(r);
-}
-__device__ __forceinline__ float head_sum_b(float v) { return dpp_add_b(dpp_add_b(dpp_add_b(v, 0), 1), 2); }
-}  // namespace
 
 __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                    const int32_t* __restrict__ src, const float* __restrict__ rel,
@@ -55,9 +43,9 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
   const float* wve = img + GAttnL::WVE;
   const float ql = q[nc * 64 + lane];
   const float da = node < N ? dagg[nc * 64 + lane] : 0.f;
-  const float cb = head_sum_b(ql * img[GAttnL::BKE + lane]);
-  const float cz = head_sum_b(da * img[GAttnL::BVE + lane]);
-  const float dlt = head_sum_b(da * agg[nc * 64 + lane]);
+  const float cb = head_sum(ql * img[GAttnL::BKE + lane]);
+  const float cz = head_sum(da * img[GAttnL::BVE + lane]);
+  const float dlt = head_sum(da * agg[nc * 64 + lane]);
   float U[8], Z[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) U[e] = Z[e] = 0.f;
@@ -79,7 +67,7 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
     float p = ql * knv;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { p = fmaf(ra[e], U[e], p); p = fmaf(rb[e], U[4 + e], p); }
-    return (head_sum_b(p) + cb) * INV_SQRT_DH_B;
+    return (head_sum(p) + cb) * INV_SQRT_DH;
   };
   // pass 1: softmax statistics of the segment
   float m = -INFINITY, s = 0.f;
@@ -105,8 +93,8 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
     float t = da * vnv;
 #pragma unroll
     for (int c = 0; c < 4; ++c) { t = fmaf(ra[c], Z[c], t); t = fmaf(rb[c], Z[4 + c], t); }
-    const float dal = head_sum_b(t) + cz;
-    const float dls = alpha * (dal - dlt) * INV_SQRT_DH_B;
+    const float dal = head_sum(t) + cz;
+    const float dls = alpha * (dal - dlt) * INV_SQRT_DH;
     dqe = fmaf(dls, knv, dqe);
     atomicAdd(DKN + int64_t(sidx) * 64 + lane, dls * ql);
     atomicAdd(DVN + int64_t(sidx) * 64 + lane, alpha * da);

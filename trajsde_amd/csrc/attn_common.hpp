@@ -1,0 +1,67 @@
+// attn_common.hpp -- device pieces shared by the forward attention kernels (attn.hip) and their backward twins
+// (encoder_bwd.hip, aggregator_bwd.hip): the edge embedding, the per-head logit layout, head-wise lane sums.
+#pragma once
+#include <type_traits>
+
+#include "layouts.hpp"
+#include "tile.hpp"
+
+namespace tsde {
+
+constexpr float INV_SQRT_DH = 0.35355339059327373f;   // 1/sqrt(64/8)  (ENC:589-590)
+
+// MultipleInputEmbedding on the two pre-rotated 2-vectors of an edge (EMB:62-70) -> emb
+template <bool X6>
+__device__ __forceinline__ void edge_embed(f4 (&emb)[4], const f4 geom, const float* lds, const Lane& L) {
+  using E = typename std::conditional<X6, EdgeL6, EdgeL>::type;
+  f4 h0[4], h1[4], s[4];
+  linear_in2(h0, geom[0], geom[1], lds + E::A_W0, lds + E::A_B0, L.g);
+  layer_norm<4>(h0, lds + E::A_G, lds + E::A_E, L.g);
+  relu<4>(h0);
+  linear_in2(h1, geom[2], geom[3], lds + E::B_W0, lds + E::B_B0, L.g);
+  layer_norm<4>(h1, lds + E::B_G, lds + E::B_E, L.g);
+  relu<4>(h1);
+  load_vec<4>(s, lds + E::B3, L.g);                       // b0.3 + b1.3
+  if constexpr (X6) {
+    linear_acc_x6<4, 4>(s, h0, lds + E::WA3, L.lane);
+    linear_acc_x6<4, 4>(s, h1, lds + E::WB3, L.lane);
+  } else {
+    linear_acc<4, 4>(s, h0, lds + E::WA3, L.lane);
+    linear_acc<4, 4>(s, h1, lds + E::WB3, L.lane);        // sum of the two branches = one K=128 contraction
+  }
+  layer_norm<4>(s, lds + E::AG0, lds + E::AE0, L.g);
+  relu<4>(s);
+  if constexpr (X6) linear_x6<4, 4>(emb, s, lds + E::W2, lds + E::B2, L);
+  else linear<4, 4>(emb, s, lds + E::W2, lds + E::B2, L);
+  layer_norm<4>(emb, lds + E::AG3, lds + E::AE3, L.g);
+}
+
+// per-head logits of 16 edges: q.k over the 8 dims of each head / sqrt(8); heads sit pairwise on lane
+// groups (g, g^1).  Stored as logits[e][slot], slot = 4*(head&1) + (head>>1): one 16-B store per lane pair.
+__device__ __forceinline__ void store_logits(const f4 (&qv)[4], const f4 (&k)[4], float* __restrict__ logits, int64_t e,
+                                             bool valid, const Lane& L) {
+  f4 lg;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    float p = qv[jt][0] * k[jt][0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) p = fmaf(qv[jt][c], k[jt][c], p);
+    p = xor16_sum(p);
+    lg[jt] = p * INV_SQRT_DH;
+  }
+  if (valid && (L.g & 1) == 0) *reinterpret_cast<f4*>(logits + e * 8 + 4 * (L.g >> 1)) = lg;
+}
+
+// sums over the 8 lanes that hold one head when lane = feature (segment / fused-attention kernels)
+__device__ __forceinline__ float dpp_add(float v, int ctrl_tag) {
+  // ctrl_tag 0: xor 1, 1: xor 2 (quad permutes), 2: mirror within 8 lanes
+  int r;
+  if (ctrl_tag == 0) r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);
+  else if (ctrl_tag == 1) r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);
+  else r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true);
+  return v + __int_as_float(r);
+}
+__device__ __forceinline__ float head_sum(float v) { return dpp_add(dpp_add(dpp_add(v, 0), 1), 2); }   // over the 8 lanes of a head
+
+
+}  // namespace tsde

@@ -36,6 +36,8 @@ __global__ void k_upd_bwd(const float* img, const float* dx1, const float* agg, 
 template <int NQ>
 __global__ void k_node_proj_bwd(const float* img, const float* x, const float* dres, const float* dxn_part, const float* dp0,
                                 const float* dp1, const float* dp2, int64_t R, float* dx_out, float* xn_out, float* vpart);
+template <int BR>
+__global__ void k_edge_embed_bwd_branch(const float* img, const float* geom, const float* DSP, int64_t E, float* vpart);
 __global__ void k_lin_t_acc(const float* wt, const float* d, int64_t R, float* out, int accumulate);
 __global__ void k_headwise_outer(const float* X, const float* Y, int64_t N, float* W);
 

@@ -1,0 +1,858 @@
+// encoder_bwd.hip -- backward of the LocalEncoderSDESepPara2 stage (reference models/encoders/
+// enc_hivt_nusargo_sde_sep2.py:66-202) for gfx950, and the DiffBCE loss on its diffusion outputs
+// (losses/diff_BCE.py:11-16).  Third family of SURVEY.md 8(f) rank 1.
+//
+// Inputs: dL/d local_embed [N,64] (decoder + aggregator) and the weight of the DiffBCE term.  The forward is
+// recomputed in exact fp32 keeping a tape, then walked backwards:
+//   ALEncoder     node block -> segment-attention backward -> edge (lane embedding, k, v) backward -> norm1/lin_q
+//   recurrence    21 x { GRU_Unit backward, Euler-Maruyama step backward (drift + the source's diffusion net) },
+//                 d latent enters at each actor's kept iteration, d DiffBCE/d g at the picked diffusion values
+//   AAEncoder     the same attention chain over the 21 snapshots, then the centre embedding / bos tokens
+// Matrix weight gradients come from saved (delta, input) rows through run_wgrad; everything is reduced in a fixed
+// order (no atomics in this stage).
+#include <string>
+#include <unordered_map>
+
+#include "attn_common.hpp"
+#include "bwd.hpp"
+#include "common.hpp"
+#include "kernels.hpp"
+#include "layouts.hpp"
+#include "philox.hpp"
+#include "sde_funcs.hpp"
+#include "tile.hpp"
+#include "tile_bwd.hpp"
+
+namespace tsde {
+
+// ------------------------------------------------------------------ segment attention backward (AA / AL)
+// wave per target row, lane = feature (head = lane >> 3).  alpha recomputed from the saved logits;
+// DV[e] = alpha_h dagg,  DLG[e][slot(h)] = alpha_h (dagg_h . v_e,h - dagg_h . agg_h)   (w.r.t. the stored, scaled logit)
+__global__ __launch_bounds__(256) void k_seg_attn_bwd(const int32_t* __restrict__ segptr, const float* __restrict__ logits,
+                                                      const float* __restrict__ v, const float* __restrict__ agg,
+                                                      const float* __restrict__ dagg, int64_t R, float* __restrict__ DV,
+                                                      float* __restrict__ DLG) {
+  const int lane = threadIdx.x & 63;
+  const int head = lane >> 3, slot = 4 * (head & 1) + (head >> 1);
+  const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (node >= R) return;
+  const int beg = segptr[node], end = segptr[node + 1];
+  if (end <= beg) return;
+  float m = -INFINITY, s = 0.f;
+  for (int e = beg; e < end; ++e) {
+    const float p = logits[int64_t(e) * 8 + slot];
+    const float mn = fmaxf(m, p);
+    s = s * fast_exp(m - mn) + fast_exp(p - mn);
+    m = mn;
+  }
+  const float inv = 1.0f / (s + 1e-16f);
+  const float da = dagg[node * 64 + lane];
+  const float dlt = head_sum(da * agg[node * 64 + lane]);
+  for (int e = beg; e < end; ++e) {
+    const float alpha = fast_exp(logits[int64_t(e) * 8 + slot] - m) * inv;
+    const float dal = head_sum(da * v[int64_t(e) * 64 + lane]);
+    DV[int64_t(e) * 64 + lane] = alpha * da;
+    if ((lane & 7) == 0) DLG[int64_t(e) * 8 + slot] = alpha * (dal - dlt);
+  }
+}
+
+// DQ[r] = sum of the DQE rows of segment r (edges are sorted by target)
+__global__ __launch_bounds__(256) void k_seg_sum(const int32_t* __restrict__ segptr, const float* __restrict__ DQE, int64_t R,
+                                                 float* __restrict__ DQ) {
+  const int lane = threadIdx.x & 63;
+  const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (node >= R) return;
+  float s = 0.f;
+  for (int e = segptr[node]; e < segptr[node + 1]; ++e) s += DQE[int64_t(e) * 64 + lane];
+  DQ[node * 64 + lane] = s;
+}
+
+// edge rows: recompute emb, k;  dk = dlogit * q[dst] / sqrt(dh) (the stored logit is already scaled),
+// DQE = dlogit * k,  DEMB = Wk^T dk + Wv^T dv;  saves EMB and DK for the lin_k / lin_v weight gradients
+__global__ __launch_bounds__(512) void k_edge_kv_bwd(const float* __restrict__ img, const float* __restrict__ geom,
+                                                     const int32_t* __restrict__ dst, const float* __restrict__ q,
+                                                     const float* __restrict__ DLG, const float* __restrict__ DV, int64_t E,
+                                                     float* __restrict__ EMB, float* __restrict__ DK, float* __restrict__ DQE,
+                                                     float* __restrict__ DEMB) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img, EdgeKvBwdL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (E + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
+    const f4 ge = *reinterpret_cast<const f4*>(geom + 4 * ec);
+    f4 emb[4], k[4], qv[4], dk[4], dqe[4], dv[4], de[4];
+    load_row(qv, q, dst[ec], L.g);
+    edge_embed<false>(emb, ge, lds, L);
+    linear<4, 4>(k, emb, lds + EdgeL::WKV, lds + EdgeL::BKV, L);
+    const f4 dl = *reinterpret_cast<const f4*>(DLG + ec * 8 + 4 * (L.g >> 1));      // heads 2jt + (g>>1), jt = 0..3
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        dk[jt][c] = dl[jt] * qv[jt][c] * INV_SQRT_DH;
+        dqe[jt][c] = dl[jt] * k[jt][c] * INV_SQRT_DH;
+      }
+    load_row(dv, DV, ec, L.g);
+    linear_t(de, dk, lds + EdgeKvBwdL::WKT, L);
+    linear_acc<4, 4>(de, dv, lds + EdgeKvBwdL::WVT, L.lane);
+    if (e < E) {
+      store_row(emb, EMB, e, L.g);
+      store_row(dk, DK, e, L.g);
+      store_row(dqe, DQE, e, L.g);
+      store_row(de, DEMB, e, L.g);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ centre embedding (SingleInputEmbedding, EMB:22-40)
+// forward: a1 = relu(LN1(W0 xr + b0)); a2 = relu(LN4(W3 a1 + b3)); centre = LN7(W6 a2 + b6), replaced by the bos token
+// where bos.  tail: LN7 / W6 / LN4 backward; saves A2, DA3P (for W6), A1, DA2P (for W3), XR (rotated inputs, [R,4]).
+__global__ __launch_bounds__(256) void k_aa_center_bwd_tail(const float* __restrict__ img, const float* __restrict__ x,
+                                                            const float* __restrict__ x_fake, const float* __restrict__ rot,
+                                                            const uint8_t* __restrict__ bos, const int32_t* __restrict__ orig, int N,
+                                                            int Nt, int H, const float* __restrict__ dcenter,
+                                                            float* __restrict__ A1, float* __restrict__ A2, float* __restrict__ DA3P,
+                                                            float* __restrict__ DA2P, float* __restrict__ XR,
+                                                            float* __restrict__ vpart) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img, CenterTailL::SIZE);
+  using A = AaCenterL;
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t rows = int64_t(H) * Nt, ntiles = (rows + 15) / 16;
+  f4 dg7[4], db7[4], dg4[4], db4[4];
+  zero4(dg7); zero4(db7); zero4(dg4); zero4(db4);
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < rows ? row : rows - 1;
+    const int t = int(r / Nt), i = int(r - int64_t(t) * Nt), o = orig[i];
+    const float* xp = i < N ? x + (int64_t(i) * H + t) * 2 : x_fake + (int64_t(i - N) * H + t) * 2;
+    const f4 Rm = *reinterpret_cast<const f4*>(rot + 4 * o);
+    const float x0 = xp[0], x1 = xp[1];
+    const float r0 = x0 * Rm[0] + x1 * Rm[2], r1 = x0 * Rm[1] + x1 * Rm[3];
+    f4 a1[4], a2[4], a3[4], d[4], t4[4];
+    linear_in2(a1, r0, r1, lds + A::W0, lds + A::B0, L.g);
+    layer_norm<4>(a1, lds + A::G1, lds + A::E1, L.g);
+    relu<4>(a1);
+    linear<4, 4>(a2, a1, lds + A::W3, lds + A::B3, L);
+    const float rs4 = ln_normalize(a2);                    // a2 = x_hat of LN4
+    f4 act2[4];
+    bool pos[16];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const f4 ga = *reinterpret_cast<const f4*>(lds + A::G4 + 16 * jt + 4 * L.g);
+      const f4 be = *reinterpret_cast<const f4*>(lds + A::E4 + 16 * jt + 4 * L.g);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float pre = a2[jt][c] * ga[c] + be[c];
+        pos[4 * jt + c] = pre > 0.f;
+        act2[jt][c] = fmaxf(pre, 0.f);
+      }
+    }
+    linear<4, 4>(a3, act2, lds + A::W6, lds + A::B6, L);
+    const float rs7 = ln_normalize(a3);                    // a3 = x_hat of LN7
+    load_row(d, dcenter, r, L.g);
+    if (row >= rows || bos[int64_t(o) * H + t]) zero4(d);  // bos rows take the token, not the embedding
+    ln_backward(d, a3, rs7, lds + A::G7, L.g, dg7, db7);   // d := d a3p
+    linear_t(t4, d, lds + CenterTailL::W6T, L);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (!pos[4 * jt + c]) t4[jt][c] = 0.f;
+    ln_backward(t4, a2, rs4, lds + A::G4, L.g, dg4, db4);  // t4 := d a2p
+    if (row < rows) {
+      store_row(a1, A1, row, L.g);
+      store_row(act2, A2, row, L.g);
+      store_row(d, DA3P, row, L.g);
+      store_row(t4, DA2P, row, L.g);
+      if (L.g == 0) *reinterpret_cast<f4*>(XR + 4 * row) = f4{r0, r1, 0.f, 0.f};
+    }
+  }
+  float* vp = vpart + int64_t(blockIdx.x * waves + wave) * 256;
+  flush_vec(dg7, vp, L);
+  flush_vec(db7, vp + 64, L);
+  flush_vec(dg4, vp + 128, L);
+  flush_vec(db4, vp + 192, L);
+}
+
+// d bos_token[t][c] = sum over the rows (t, i) that took the token of dcentre; one workgroup per t
+__global__ __launch_bounds__(256) void k_bos_grad(const float* __restrict__ dcenter, const uint8_t* __restrict__ bos,
+                                                  const int32_t* __restrict__ orig, int Nt, int H, float* __restrict__ dtok) {
+  __shared__ float red[4][64];
+  const int t = blockIdx.x, c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  float s = 0.f;
+  for (int i = part; i < Nt; i += 4)
+    if (bos[int64_t(orig[i]) * H + t]) s += dcenter[(int64_t(t) * Nt + i) * 64 + c];
+  red[part][c] = s;
+  __syncthreads();
+  if (part == 0) dtok[t * 64 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// ------------------------------------------------------------------ recurrence: forward replay with saves
+// one Euler-Maruyama step of iteration idx; slabs are [H][Nt][64] (GS, [H][Nt])
+__global__ __launch_bounds__(256) void k_enc_sde_save(const float* __restrict__ img_g, const float* __restrict__ h_in,
+                                                      const float* __restrict__ hidden0, int Nt, float dt, float sq, float sn,
+                                                      float cs, int idx, NoiseArg na, const uint8_t* __restrict__ nus,
+                                                      float* __restrict__ HIN, float* __restrict__ H1, float* __restrict__ H2,
+                                                      float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ GS,
+                                                      float* __restrict__ HODE) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img_g, EncSdeL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (int64_t(Nt) + 15) / 16;
+  const int64_t off = int64_t(idx) * Nt;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < Nt ? row : Nt - 1;
+    const bool live = row < Nt;
+    f4 y[4], h1[4], h2[4], f[4], z[4];
+    if (h_in != nullptr) load_row(y, h_in, r, L.g);
+    else load_vec<4>(y, hidden0, L.g);
+    if (live) store_row(y, HIN, off + row, L.g);
+    const float* F = lds + EncSdeL::F;
+    sde_layer0(h1, y, F, DriftL::W0, DriftL::WS, DriftL::WC, DriftL::B0, sn, cs, L);
+    tanh_<4>(h1);
+    linear<4, 4>(h2, h1, F + DriftL::W2, F + DriftL::B2, L);
+    tanh_<4>(h2);
+    linear<4, 4>(f, h2, F + DriftL::W4, F + DriftL::B4, L);
+    if (live) {
+      store_row(h1, H1, off + row, L.g);
+      store_row(h2, H2, off + row, L.g);
+    }
+    const bool is_nus = nus[r] != 0;
+    f4 g1[4], g2[4];
+    float gs = 0.f;
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {                        // per-row selection of g_nus / g_argo (ENC:470-482)
+      const float* G = lds + (net == 0 ? EncSdeL::GN : EncSdeL::GA);
+      f4 a[4], b[4];
+      sde_layer0(a, y, G, DiffL::W0, DiffL::WS, DiffL::WC, DiffL::B0, sn, cs, L);
+      tanh_<4>(a);
+      linear<4, 4>(b, a, G + DiffL::W2, G + DiffL::B2, L);
+      tanh_<4>(b);
+      const float gv = fast_sigmoid(row_dot(b, G + DiffL::W4, L.g) + G[DiffL::B4]);
+      if (is_nus == (net == 0)) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) { g1[jt] = a[jt]; g2[jt] = b[jt]; }
+        gs = gv;
+      }
+    }
+    if (live) {
+      store_row(g1, G1, off + row, L.g);
+      store_row(g2, G2, off + row, L.g);
+      if (L.g == 0) GS[off + row] = gs;
+    }
+    noise_row(z, na, STREAM_ENCODER, idx, r, Nt, L.g);
+    em_update(y, f, gs, z, dt, sq);
+    if (live) store_row(y, HODE, off + row, L.g);
+  }
+}
+
+// GRU_Unit of iteration idx with every activation kept; h_out = next state (not a slab)
+__global__ __launch_bounds__(256) void k_enc_gru_save(const float* __restrict__ img_g, const float* __restrict__ x_t, int Nt,
+                                                      int t, int TT, int idx, const uint8_t* __restrict__ pad,
+                                                      const int32_t* __restrict__ orig, const float* __restrict__ HODE,
+                                                      float* __restrict__ XS, float* __restrict__ U1, float* __restrict__ R1,
+                                                      float* __restrict__ UU, float* __restrict__ RR, float* __restrict__ RH,
+                                                      float* __restrict__ N1, float* __restrict__ NW, float* __restrict__ h_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img_g, EncGruL::SIZE);
+  using G = EncGruL;
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (int64_t(Nt) + 15) / 16;
+  const int64_t off = int64_t(idx) * Nt;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < Nt ? row : Nt - 1;
+    f4 h[4], x[4], ur[8];
+    load_row(h, HODE, off + r, L.g);
+    load_row(x, x_t, r, L.g);
+    load_vec<8>(ur, lds + G::BUR, L.g);
+    linear_acc<8, 4>(ur, h, lds + G::WUR_H, L.lane);
+    linear_acc<8, 4>(ur, x, lds + G::WUR_X, L.lane);
+    tanh_<8>(ur);
+    f4 u1[4] = {ur[0], ur[1], ur[2], ur[3]}, r1[4] = {ur[4], ur[5], ur[6], ur[7]};
+    f4 u[4], rg[4], rh[4], n1[4], nw[4];
+    linear<4, 4>(u, u1, lds + G::WU2, lds + G::BU2, L);
+    sigmoid_<4>(u);
+    linear<4, 4>(rg, r1, lds + G::WR2, lds + G::BR2, L);
+    sigmoid_<4>(rg);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) rh[jt] = rg[jt] * h[jt];
+    load_vec<4>(n1, lds + G::BN0, L.g);
+    linear_acc<4, 4>(n1, x, lds + G::WN_X, L.lane);
+    linear_acc<4, 4>(n1, rh, lds + G::WN_H, L.lane);
+    tanh_<4>(n1);
+    linear<4, 4>(nw, n1, lds + G::WN2, lds + G::BN2, L);
+    const bool valid = !pad[int64_t(orig[r]) * TT + t];
+    if (row < Nt) {
+      const int64_t o = off + row;
+      store_row(x, XS, o, L.g);
+      store_row(u1, U1, o, L.g);
+      store_row(r1, R1, o, L.g);
+      store_row(u, UU, o, L.g);
+      store_row(rg, RR, o, L.g);
+      store_row(rh, RH, o, L.g);
+      store_row(n1, N1, o, L.g);
+      store_row(nw, NW, o, L.g);
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float hn = (1.0f - u[jt][c]) * nw[jt][c] + u[jt][c] * h[jt][c];
+        h[jt][c] = valid ? hn : h[jt][c];
+      }
+    if (row < Nt) store_row(h, h_out, row, L.g);
+  }
+}
+
+// ------------------------------------------------------------------ recurrence: backward of one iteration
+// dh [Nt,64] = gradient w.r.t. this iteration's output state (without the kept-latent term, added here);
+// writes DHO (d h_ode), DX (d aa_out[t]) and the GRU deltas of slab idx
+__global__ __launch_bounds__(256) void k_enc_gru_bwd(const float* __restrict__ img, int Nt, int N, int t, int TT, int idx,
+                                                     const uint8_t* __restrict__ pad, const int32_t* __restrict__ orig,
+                                                     const int32_t* __restrict__ eos, const float* __restrict__ dh,
+                                                     const float* __restrict__ dlat, const float* __restrict__ HODE,
+                                                     const float* __restrict__ U1, const float* __restrict__ R1,
+                                                     const float* __restrict__ UU, const float* __restrict__ RR,
+                                                     const float* __restrict__ N1, const float* __restrict__ NW,
+                                                     float* __restrict__ DNW, float* __restrict__ DN1P, float* __restrict__ DUP,
+                                                     float* __restrict__ DRP, float* __restrict__ DU1, float* __restrict__ DR1,
+                                                     float* __restrict__ DHO, float* __restrict__ DX) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img, GruBwdL::SIZE);
+  using G = GruBwdL;
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (int64_t(Nt) + 15) / 16;
+  const int64_t off = int64_t(idx) * Nt;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < Nt ? row : Nt - 1;
+    const bool valid = !pad[int64_t(orig[r]) * TT + t] && row < Nt;
+    f4 d[4], h[4], u[4], a[4];
+    if (dh != nullptr) load_row(d, dh, r, L.g);
+    else zero4(d);
+    if (r < N && eos[r] == idx) {                              // ENC:187-188: this iteration's state is the kept latent
+      load_row(a, dlat, r, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) d[jt] += a[jt];
+    }
+    load_row(h, HODE, off + r, L.g);
+    load_row(u, UU, off + r, L.g);
+    load_row(a, NW, off + r, L.g);
+    f4 dnw[4], du[4], dho[4], dx[4], t4[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float dd = valid ? d[jt][c] : 0.f, uu = u[jt][c];
+        dnw[jt][c] = dd * (1.0f - uu);
+        du[jt][c] = dd * (h[jt][c] - a[jt][c]) * uu * (1.0f - uu);          // through the sigmoid: d u_pre
+        dho[jt][c] = valid ? dd * uu : d[jt][c];                            // masked rows pass the state through
+      }
+    // new_state_net
+    linear_t(t4, dnw, lds + G::WN2T, L);
+    load_row(a, N1, off + r, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t4[jt][c] *= (1.0f - a[jt][c] * a[jt][c]);  // t4 = d n1_pre
+    linear_t(dx, t4, lds + G::WNXT, L);
+    f4 drh[4], rr[4], drp[4];
+    linear_t(drh, t4, lds + G::WNHT, L);
+    load_row(rr, RR, off + r, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float rv = rr[jt][c];
+        dho[jt][c] = fmaf(drh[jt][c], rv, dho[jt][c]);
+        drp[jt][c] = drh[jt][c] * h[jt][c] * rv * (1.0f - rv);                // d r_pre
+      }
+    if (row < Nt) {
+      store_row(dnw, DNW, off + row, L.g);
+      store_row(t4, DN1P, off + row, L.g);
+      store_row(du, DUP, off + row, L.g);
+      store_row(drp, DRP, off + row, L.g);
+    }
+    // gates: second layers, tanh, first layers on [h, x]
+    f4 du1[4], dr1[4];
+    linear_t(du1, du, lds + G::WU2T, L);
+    load_row(a, U1, off + r, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) du1[jt][c] *= (1.0f - a[jt][c] * a[jt][c]);
+    linear_t(dr1, drp, lds + G::WR2T, L);
+    load_row(a, R1, off + r, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dr1[jt][c] *= (1.0f - a[jt][c] * a[jt][c]);
+    linear_acc<4, 4>(dho, du1, lds + G::UHT, L.lane);
+    linear_acc<4, 4>(dho, dr1, lds + G::RHT, L.lane);
+    linear_acc<4, 4>(dx, du1, lds + G::UXT, L.lane);
+    linear_acc<4, 4>(dx, dr1, lds + G::RXT, L.lane);
+    if (row < Nt) {
+      store_row(du1, DU1, off + row, L.g);
+      store_row(dr1, DR1, off + row, L.g);
+      store_row(dho, DHO, row, L.g);
+      store_row(dx, DX, row, L.g);
+    }
+  }
+}
+
+// d h_in of iteration idx from DHO (d h_ode) and the DiffBCE gradient on the picked diffusion values
+__global__ __launch_bounds__(256) void k_enc_sde_bwd(const float* __restrict__ img, int Nt, float dt, float sq, int idx, NoiseArg na,
+                                                     const uint8_t* __restrict__ nus, const int32_t* __restrict__ eos,
+                                                     const float* __restrict__ DLDG, const float* __restrict__ DHO,
+                                                     const float* __restrict__ H1, const float* __restrict__ H2,
+                                                     const float* __restrict__ G1, const float* __restrict__ G2,
+                                                     const float* __restrict__ GS, float* __restrict__ DF, float* __restrict__ DH2,
+                                                     float* __restrict__ DH1, float* __restrict__ DG2N, float* __restrict__ DG1N,
+                                                     float* __restrict__ DG2A, float* __restrict__ DG1A, float* __restrict__ DGPN,
+                                                     float* __restrict__ DGPA, float* __restrict__ dh_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_blob(lds, img, EncSdeBwdL::SIZE);
+  using S = EncSdeBwdL;
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (int64_t(Nt) + 15) / 16;
+  const int64_t off = int64_t(idx) * Nt;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t row = tile * 16 + L.n, r = row < Nt ? row : Nt - 1;
+    const bool live = row < Nt;
+    f4 dy[4], a[4], d[4], t[4], dyn[4];
+    load_row(dy, DHO, r, L.g);
+    if (!live) zero4(dy);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d[jt][c] = dt * dy[jt][c];
+    if (live) store_row(d, DF, off + row, L.g);
+    linear_t(t, d, lds + S::F_W4T, L);
+    load_row(a, H2, off + r, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - a[jt][c] * a[jt][c]);
+    if (live) store_row(d, DH2, off + row, L.g);
+    linear_t(t, d, lds + S::F_W2T, L);
+    load_row(a, H1, off + r, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - a[jt][c] * a[jt][c]);
+    if (live) store_row(d, DH1, off + row, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) dyn[jt] = dy[jt];
+    linear_acc<4, 4>(dyn, d, lds + S::F_W0T, L.lane);
+    // diffusion: g (z sqrt h) with g one scalar per row, from the row's source net
+    f4 z[4];
+    noise_row(z, na, STREAM_ENCODER, idx, r, Nt, L.g);
+    float cdot = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cdot = fmaf(z[jt][c] * sq, dy[jt][c], cdot);
+    const float gs = GS[off + r];
+    float dg = row_sum(cdot);
+    if (live && eos[r] == idx) dg += DLDG[r];                   // ENC:171,190-191: the diffusion value DiffBCE sees
+    const float dgp = live ? dg * gs * (1.0f - gs) : 0.f;
+    const bool is_nus = nus[r] != 0;
+    f4 g1[4], g2[4];
+    load_row(g2, G2, off + r, L.g);
+    load_row(g1, G1, off + r, L.g);
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+      const float sel = (is_nus == (net == 0)) ? dgp : 0.f;
+      const float* w4 = lds + (net == 0 ? S::GN_W4 : S::GA_W4);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const f4 wv = *reinterpret_cast<const f4*>(w4 + 16 * jt + 4 * L.g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[jt][c] = sel * wv[c] * (1.0f - g2[jt][c] * g2[jt][c]);
+      }
+      if (live) {
+        store_row(d, net == 0 ? DG2N : DG2A, off + row, L.g);
+        if (L.g == 0) (net == 0 ? DGPN : DGPA)[off + row] = sel;
+      }
+      linear_t(t, d, lds + (net == 0 ? S::GN_W2T : S::GA_W2T), L);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - g1[jt][c] * g1[jt][c]);
+      if (live) store_row(d, net == 0 ? DG1N : DG1A, off + row, L.g);
+      linear_acc<4, 4>(dyn, d, lds + (net == 0 ? S::GN_W0T : S::GA_W0T), L.lane);
+    }
+    if (live) store_row(dyn, dh_out, row, L.g);
+  }
+}
+
+// out[c] = sum_r s[r] * A[r][c]  (c < 64),  out[64] = sum_r s[r];  one workgroup, fixed order
+__global__ __launch_bounds__(1024) void k_rowscale_colsum(const float* __restrict__ A, const float* __restrict__ s, int64_t R,
+                                                          float* __restrict__ out_vec, float* __restrict__ out_sum) {
+  __shared__ float red[16][65];
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  float acc = 0.f, ss = 0.f;
+  for (int64_t r = part; r < R; r += 16) {
+    const float sv = s[r];
+    acc = fmaf(sv, A[r * 64 + c], acc);
+    ss += sv;
+  }
+  red[part][c] = acc;
+  if (c == 0) red[part][64] = ss;
+  __syncthreads();
+  if (part == 0) {
+    float t = 0.f;
+    for (int p = 0; p < 16; ++p) t += red[p][c];
+    out_vec[c] = t;
+    if (c == 0) {
+      float u = 0.f;
+      for (int p = 0; p < 16; ++p) u += red[p][64];
+      *out_sum = u;
+    }
+  }
+}
+
+// DiffBCE (diff_BCE.py:11-16, mean reduction): label 0 for the real target agents' picked diffusion, 1 for their
+// perturbed copies.  DLDG[r] = weight * dL/dg of row r (0 for rows that are not picked); loss[0] = weight * L
+__global__ __launch_bounds__(1024) void k_diffbce(const float* __restrict__ GS, const int32_t* __restrict__ eos,
+                                                  const int32_t* __restrict__ pick_slot, int Nt, int A, float weight,
+                                                  float* __restrict__ DLDG, float* __restrict__ loss) {
+  __shared__ double red[1024];
+  double acc = 0.0;
+  for (int r = threadIdx.x; r < Nt; r += 1024) {
+    const int slot = pick_slot[r];
+    float g_ = 0.f;
+    if (slot >= 0) {
+      const float g = GS[int64_t(eos[r]) * Nt + r];
+      if (slot < A) {                                        // diff_in, target 0: -log(1 - g)
+        acc += double(-fmaxf(logf(1.0f - g), -100.0f));
+        g_ = 1.0f / (1.0f - g);
+      } else {                                               // diff_out, target 1: -log(g)
+        acc += double(-fmaxf(logf(g), -100.0f));
+        g_ = -1.0f / g;
+      }
+    }
+    DLDG[r] = A > 0 ? weight * g_ / float(A) : 0.f;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if (int(threadIdx.x) < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = A > 0 ? float(double(weight) * red[0] / double(A)) : 0.f;
+}
+
+// lat[r] = state after iteration eos[r]: valid ? (1-u) nw + u h_ode : h_ode, from the saved slabs
+__global__ void k_gather_latent(const float* __restrict__ HODE, const float* __restrict__ UU, const float* __restrict__ NW,
+                                const int32_t* __restrict__ eos, const uint8_t* __restrict__ pad, const int32_t* __restrict__ orig, int N,
+                                int Nt, int H, int TT, float* __restrict__ lat) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= int64_t(N) * 64) return;
+  const int r = int(i >> 6), c = int(i & 63), idx = eos[r], t = H - 1 - idx;
+  const int64_t o = (int64_t(idx) * Nt + r) * 64 + c;
+  const bool valid = !pad[int64_t(orig[r]) * TT + t];
+  const float h = HODE[o], u = UU[o];
+  lat[i] = valid ? (1.0f - u) * NW[o] + u * h : h;
+}
+
+// ------------------------------------------------------------------ workspace
+struct EncBwdWs {
+  // AA tape
+  float *center, *cn, *q, *logits, *v, *agg, *x1, *xn2, *aa_out;
+  // recurrence tape (slabs [H][Nt][64]) and running states
+  float *HIN, *H1, *H2, *G1, *G2, *GS, *HODE, *XS, *U1, *R1, *UU, *RR, *RH, *N1, *NW, *hcur, *lat;
+  // AL tape
+  float *al_xn, *al_q, *al_logits, *al_v, *al_agg, *al_x1, *al_xn2, *al_out;
+  // backward: recurrence deltas
+  float *DF, *DH2, *DH1, *DG2N, *DG1N, *DG2A, *DG1A, *DGPN, *DGPA, *DNW, *DN1P, *DUP, *DRP, *DU1, *DR1, *DHO, *dhA, *dhB, *DLDG, *DLAT, *DAA;
+  // backward: attention chain scratch (sized for the larger of the AA / AL problems)
+  float *dagg, *dxn, *DQ, *DCENTER, *DV, *DLG, *EMB, *DK, *DQE, *DEMB, *A1, *A2, *DA3P, *DA2P, *XR, *part, *cs, *scal;
+  NodeBlockScratch nb;
+  EdgeEmbedScratch ee;
+  int64_t total;
+  bool ok;
+  EncBwdWs(const trajsde_batch* b, const trajsde_graph* g, void* ws, int64_t bytes) {
+    Carver c(ws, bytes);
+    const int64_t H = b->H, Nt = g->Nt, N = b->N, R = H * Nt, Eaa = g->E_aa, Ela = g->E_la, E = (Eaa > Ela ? Eaa : Ela) + 1;
+    float** rows_R[] = {&center, &cn, &q, &agg, &x1, &xn2, &aa_out, &HIN, &H1, &H2, &G1, &G2, &HODE, &XS, &U1, &R1, &UU, &RR, &RH, &N1,
+                        &NW, &DF, &DH2, &DH1, &DG2N, &DG1N, &DG2A, &DG1A, &DNW, &DN1P, &DUP, &DRP, &DU1, &DR1, &DAA, &dagg, &dxn, &DQ,
+                        &DCENTER, &A1, &A2, &DA3P, &DA2P, &nb.dx1, &nb.UPD, &nb.DGP, &nb.DS};
+    for (float** p : rows_R) *p = c.take<float>(R * 64);
+    float** rows_Rs[] = {&GS, &DGPN, &DGPA};
+    for (float** p : rows_Rs) *p = c.take<float>(R);
+    XR = c.take<float>(R * 4);
+    nb.H = c.take<float>(R * 256);
+    nb.DH = c.take<float>(R * 256);
+    float** rows_Nt[] = {&hcur, &DHO, &dhA, &dhB};
+    for (float** p : rows_Nt) *p = c.take<float>(Nt * 64);
+    DLDG = c.take<float>(Nt);
+    float** rows_N[] = {&lat, &al_xn, &al_q, &al_agg, &al_x1, &al_xn2, &al_out, &DLAT};
+    for (float** p : rows_N) *p = c.take<float>(N * 64);
+    logits = c.take<float>(Eaa * 8 + 8);
+    v = c.take<float>(Eaa * 64 + 64);
+    al_logits = c.take<float>(Ela * 8 + 8);
+    al_v = c.take<float>(Ela * 64 + 64);
+    DLG = c.take<float>(E * 8);
+    float** rows_E[] = {&DV, &EMB, &DK, &DQE, &DEMB, &ee.S, &ee.DEP, &ee.DSP, &ee.A0, &ee.B0};
+    for (float** p : rows_E) *p = c.take<float>(E * 64);
+    nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
+    const int64_t rows = E > R ? E : R;
+    const int64_t parts = wgrad_max_parts(rows, H);
+    part = c.take<float>(parts * 4096);
+    cs = c.take<float>(parts * 64);
+    scal = c.take<float>(64);
+    total = c.off + 256;
+    ok = c.ok;
+  }
+};
+
+// attention chain of one encoder (AA or AL) given d out rows: node block, segment softmax, edge kernel, projection.
+// Returns d x (the block's input rows) in `dx_out`.
+struct AttnChain {
+  const float *img_node, *img_proj, *img_kv, *img_emb;            // backward images
+  const float *geom, *q, *logits, *v, *x;                         // graph + tape
+  const int32_t *dst, *segptr;
+  NodeBlockTape tp;
+  int64_t R, E;
+  std::string prefix, embed;                                      // parameter names: <prefix>.lin_k..., <prefix>.<embed>...
+};
+
+}  // namespace tsde
+
+using namespace tsde;
+
+namespace {
+
+struct GradTable {
+  std::unordered_map<std::string, float*> slot;
+  bool missing = false;
+  std::string missing_name;
+  float* operator()(const std::string& n) {
+    auto it = slot.find(n);
+    if (it == slot.end()) {
+      if (!missing) missing_name = n;
+      missing = true;
+      return nullptr;
+    }
+    return it->second;
+  }
+};
+
+int run_attn_chain(const AttnChain& c, const float* dout, EncBwdWs& w, const WgradCtx& wc, GradTable& G, float* dx_out,
+                   hipStream_t st) {
+  const std::string& p = c.prefix;
+  NodeBlockGrads gr{G(p + ".lin_ih.weight"), G(p + ".lin_ih.bias"), G(p + ".lin_hh.weight"), G(p + ".lin_hh.bias"),
+                    G(p + ".lin_self.weight"), G(p + ".lin_self.bias"), G(p + ".out_proj.weight"), G(p + ".out_proj.bias"),
+                    G(p + ".norm2.weight"), G(p + ".norm2.bias"), G(p + ".mlp.0.weight"), G(p + ".mlp.0.bias"),
+                    G(p + ".mlp.3.weight"), G(p + ".mlp.3.bias")};
+  const std::string e = p + "." + c.embed;
+  EdgeEmbedGrads eg{G(e + ".module_list.0.0.weight"), G(e + ".module_list.0.0.bias"), G(e + ".module_list.0.1.weight"),
+                    G(e + ".module_list.0.1.bias"), G(e + ".module_list.1.0.weight"), G(e + ".module_list.1.0.bias"),
+                    G(e + ".module_list.1.1.weight"), G(e + ".module_list.1.1.bias"), G(e + ".module_list.0.3.weight"),
+                    G(e + ".module_list.0.3.bias"), G(e + ".module_list.1.3.weight"), G(e + ".module_list.1.3.bias"),
+                    G(e + ".aggr_embed.0.weight"), G(e + ".aggr_embed.0.bias"), G(e + ".aggr_embed.2.weight"),
+                    G(e + ".aggr_embed.2.bias"), G(e + ".aggr_embed.3.weight"), G(e + ".aggr_embed.3.bias")};
+  float *wk = G(p + ".lin_k.weight"), *bk = G(p + ".lin_k.bias"), *wv = G(p + ".lin_v.weight"), *bv = G(p + ".lin_v.bias");
+  float *wq = G(p + ".lin_q.weight"), *bq = G(p + ".lin_q.bias"), *n1g = G(p + ".norm1.weight"), *n1b = G(p + ".norm1.bias");
+  TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
+  const int64_t R = c.R, E = c.E;
+  if (int rc = node_block_backward(c.img_node, c.tp, dout, R, w.nb, wc, gr, w.dagg, w.dxn, st)) return rc;
+  TS_HIP(hipMemsetAsync(w.DQ, 0, size_t(R) * 64 * sizeof(float), st));
+  if (E > 0) {
+    TS_LAUNCH(k_seg_attn_bwd, cdiv(R, 4), 256, 0, st, c.segptr, c.logits, c.v, c.tp.agg, w.dagg, R, w.DV, w.DLG);
+    TS_LAUNCH(k_edge_kv_bwd, tile_grid((E + 15) / 16, 512, EdgeKvBwdL::SIZE * 4), 512, EdgeKvBwdL::SIZE * 4, st, c.img_kv, c.geom, c.dst, c.q,
+              w.DLG, w.DV, E, w.EMB, w.DK, w.DQE, w.DEMB);
+    TS_LAUNCH(k_seg_sum, cdiv(R, 4), 256, 0, st, c.segptr, w.DQE, R, w.DQ);
+    if (int rc = run_wgrad(wc, w.DK, 64, w.EMB, 64, E, E, wk, 64, 0, bk, 0)) return rc;
+    if (int rc = run_wgrad(wc, w.DV, 64, w.EMB, 64, E, E, wv, 64, 0, bv, 0)) return rc;
+    if (int rc = edge_embed_backward(c.img_emb, c.geom, w.DEMB, E, w.ee, wc, eg, st)) return rc;
+  }
+  const int gp = tile_grid((R + 15) / 16, 256, ProjBwdL<1>::SIZE * 4);
+  TS_LAUNCH(k_node_proj_bwd<1>, gp, 256, ProjBwdL<1>::SIZE * 4, st, c.img_proj, c.x, w.nb.dx1, w.dxn, w.DQ, nullptr, nullptr, R, dx_out,
+            nullptr, w.nb.vpart);
+  if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, n1g)) return rc;
+  if (int rc = run_colsum(st, w.nb.vpart + 64, gp * 4, 128, 64, n1b)) return rc;
+  return run_wgrad(wc, w.DQ, 64, c.tp.xn, 64, R, R, wq, 64, 0, bq, 0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t trajsde_encoder_backward_ws_bytes(const trajsde_batch* b, const trajsde_graph* g) {
+  if (!b || !g) return -1;
+  EncBwdWs w(b, g, nullptr, 0);
+  return w.total;
+}
+
+int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_fwd,
+                             const float* blob_bwd, const float* step_tab /*HOST [H,8]*/, const float* step_tab_dev,
+                             const trajsde_noise* noise, const float* d_local, float diff_weight, void* ws, int64_t ws_bytes,
+                             float* diff_loss, float* const* grads, int n_grads, float* d_latent, float* d_aa_out,
+                             void* stream_) {
+  TS_REQUIRE(b && g && rot && blob_fwd && blob_bwd && step_tab && step_tab_dev && d_local && ws && diff_loss && grads,
+             "encoder_backward: null pointer");
+  TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_backward: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(b->A > 0 && g->Nt == b->N + b->A, "encoder_backward: graph was prepared without the fake-agent rows");
+  const std::vector<std::string> names = stage_param_names(TRAJSDE_STAGE_ENCODER_BWD, 0, 0);
+  TS_REQUIRE(n_grads == int(names.size()), "encoder_backward: gradient count does not match trajsde_param_count(ENCODER_BWD)");
+  GradTable G;
+  for (int i = 0; i < n_grads; ++i) {
+    TS_REQUIRE(grads[i] != nullptr, "encoder_backward: null gradient buffer " + names[i]);
+    G.slot[names[i]] = grads[i];
+  }
+  EncBwdWs w(b, g, ws, ws_bytes);
+  if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_backward: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  const int N = b->N, Nt = g->Nt, H = b->H, A = b->A;
+  const int64_t R = int64_t(H) * Nt, Eaa = g->E_aa, Ela = g->E_la;
+  const int64_t rtiles = (int64_t(Nt) + 15) / 16;
+  NoiseArg na{0, nullptr, nullptr};
+  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
+  const WgradCtx wc{st, w.part, w.cs, step_tab_dev};
+  using FB = EncBlob;
+  using BB = EncBwdBlob;
+
+  // ================= forward recompute (exact fp32) =================
+  TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob_fwd + FB::AA_CENTER, b->x,
+            g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
+  if (Eaa > 0)
+    TS_LAUNCH(k_edge_kv<false>, tile_grid((Eaa + 15) / 16, 1024, EdgeL::SIZE * 4), 1024, EdgeL::SIZE * 4, st, blob_fwd + FB::AA_EDGE,
+              g->aa_geom, g->aa_dst, w.q, Eaa, w.logits, w.v);
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, g->aa_segptr, w.logits, w.v, R, w.agg);
+  TS_LAUNCH(k_node_update<false>, tile_grid((R + 15) / 16, 512, UpdL::SIZE * 4), 512, UpdL::SIZE * 4, st, blob_fwd + FB::AA_UPD, w.agg, w.cn,
+            w.center, R, w.x1, w.xn2);
+  TS_LAUNCH(k_ffn, tile_grid((R + 15) / 16, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, blob_fwd + FB::AA_FFN, w.x1, w.xn2, R, w.aa_out);
+  for (int idx = 0; idx < H; ++idx) {
+    const int t = H - 1 - idx;
+    const float* e = step_tab + 8 * idx;
+    TS_LAUNCH(k_enc_sde_save, tile_grid(rtiles, 256, EncSdeL::SIZE * 4), 256, EncSdeL::SIZE * 4, st, blob_fwd + FB::SDE,
+              idx == 0 ? nullptr : w.hcur, blob_fwd + FB::HIDDEN, Nt, e[1], e[2], e[3], e[4], idx, na, g->nus_mask, w.HIN, w.H1, w.H2, w.G1,
+              w.G2, w.GS, w.HODE);
+    TS_LAUNCH(k_enc_gru_save, tile_grid(rtiles, 256, EncGruL::SIZE * 4), 256, EncGruL::SIZE * 4, st, blob_fwd + FB::GRU,
+              w.aa_out + int64_t(t) * Nt * 64, Nt, t, b->TT, idx, b->padding_mask, g->orig, w.HODE, w.XS, w.U1, w.R1, w.UU, w.RR, w.RH, w.N1,
+              w.NW, w.hcur);
+  }
+  // the kept latent of actor r is the state after iteration eos[r] (ENC:187-188): rebuilt from the saved slabs
+  k_gather_latent<<<cdiv(int64_t(N) * 64, 256), 256, 0, st>>>(w.HODE, w.UU, w.NW, g->eos_idx, b->padding_mask, g->orig, N, Nt, H, b->TT, w.lat);
+  TS_LAUNCH_CHECK("k_gather_latent");
+  TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
+            blob_fwd + FB::AL_Q, w.lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
+  if (Ela > 0)
+    TS_LAUNCH(k_edge_kv<false>, tile_grid((Ela + 15) / 16, 1024, EdgeL::SIZE * 4), 1024, EdgeL::SIZE * 4, st, blob_fwd + FB::AL_EDGE,
+              g->la_geom, g->la_dst, w.al_q, Ela, w.al_logits, w.al_v);
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(N, 4), 256, 0, st, g->la_segptr, w.al_logits, w.al_v, int64_t(N), w.al_agg);
+  TS_LAUNCH(k_node_update<false>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL::SIZE * 4), 512, UpdL::SIZE * 4, st, blob_fwd + FB::AL_UPD,
+            w.al_agg, w.al_xn, w.lat, int64_t(N), w.al_x1, w.al_xn2);
+
+  // ================= backward =================
+  // ---- ALEncoder: d local_embed -> d latent
+  {
+    AttnChain c{blob_bwd + BB::AL_NODE, blob_bwd + BB::AL_PROJ, blob_bwd + BB::AL_EDGEKV, blob_bwd + BB::AL_EDGEEMB,
+                g->la_geom, w.al_q, w.al_logits, w.al_v, w.lat, g->la_dst, g->la_segptr,
+                NodeBlockTape{w.al_agg, w.al_xn, w.al_x1, w.al_xn2}, int64_t(N), Ela, "al_encoder", "lane_embed"};
+    if (int rc = run_attn_chain(c, d_local, w, wc, G, w.DLAT, st)) return rc;
+    if (d_latent) TS_HIP(hipMemcpyAsync(d_latent, w.DLAT, size_t(N) * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  // ---- DiffBCE on the picked diffusion values
+  TS_LAUNCH(k_diffbce, 1, 1024, 0, st, w.GS, g->eos_idx, g->pick_slot, Nt, A, diff_weight, w.DLDG, w.scal);
+  TS_HIP(hipMemcpyAsync(diff_loss, w.scal, sizeof(float), hipMemcpyDeviceToDevice, st));
+  // ---- recurrence, last iteration first
+  {
+    const float* dh = nullptr;                 // nothing reads the final state except through the kept latents
+    float* bufs[2] = {w.dhA, w.dhB};
+    for (int idx = H - 1; idx >= 0; --idx) {
+      const int t = H - 1 - idx;
+      const float* e = step_tab + 8 * idx;
+      TS_LAUNCH(k_enc_gru_bwd, tile_grid(rtiles, 256, GruBwdL::SIZE * 4), 256, GruBwdL::SIZE * 4, st, blob_bwd + BB::GRU, Nt, N, t, b->TT, idx,
+                b->padding_mask, g->orig, g->eos_idx, dh, w.DLAT, w.HODE, w.U1, w.R1, w.UU, w.RR, w.N1, w.NW, w.DNW, w.DN1P, w.DUP, w.DRP,
+                w.DU1, w.DR1, w.DHO, w.DAA + int64_t(t) * Nt * 64);
+      float* out = bufs[idx & 1];
+      TS_LAUNCH(k_enc_sde_bwd, tile_grid(rtiles, 256, EncSdeBwdL::SIZE * 4), 256, EncSdeBwdL::SIZE * 4, st, blob_bwd + BB::SDE, Nt, e[1], e[2],
+                idx, na, g->nus_mask, g->eos_idx, w.DLDG, w.DHO, w.H1, w.H2, w.G1, w.G2, w.GS, w.DF, w.DH2, w.DH1, w.DG2N, w.DG1N, w.DG2A,
+                w.DG1A, w.DGPN, w.DGPA, out);
+      dh = out;
+    }
+    // iteration 0 started from the learned initial state, broadcast to every row (ENC:78)
+    if (int rc = run_colsum(st, dh, Nt, 64, 64, G("hidden"))) return rc;
+    const std::string lf = "lsde_func.", gu = "gru_unit.";
+    struct WG { const float* d; const float* a; const char* w; const char* bias; int ldw, col0, tc; };
+    const WG jobs[] = {
+        {w.DH1, w.HIN, "lsde_func.f_func.net.0.weight", "lsde_func.f_func.net.0.bias", 66, 0, 1},
+        {w.DH2, w.H1, "lsde_func.f_func.net.2.weight", "lsde_func.f_func.net.2.bias", 64, 0, 0},
+        {w.DF, w.H2, "lsde_func.f_func.net.4.weight", "lsde_func.f_func.net.4.bias", 64, 0, 0},
+        {w.DG1N, w.HIN, "lsde_func.g_nus.net.0.weight", "lsde_func.g_nus.net.0.bias", 66, 0, 1},
+        {w.DG2N, w.G1, "lsde_func.g_nus.net.2.weight", "lsde_func.g_nus.net.2.bias", 64, 0, 0},
+        {w.DG1A, w.HIN, "lsde_func.g_argo.net.0.weight", "lsde_func.g_argo.net.0.bias", 66, 0, 1},
+        {w.DG2A, w.G1, "lsde_func.g_argo.net.2.weight", "lsde_func.g_argo.net.2.bias", 64, 0, 0},
+        {w.DNW, w.N1, "gru_unit.new_state_net.2.weight", "gru_unit.new_state_net.2.bias", 64, 0, 0},
+        {w.DN1P, w.XS, "gru_unit.new_state_net.0.weight", "gru_unit.new_state_net.0.bias", 128, 0, 0},
+        {w.DN1P, w.RH, "gru_unit.new_state_net.0.weight", nullptr, 128, 64, 0},
+        {w.DUP, w.U1, "gru_unit.update_gate.2.weight", "gru_unit.update_gate.2.bias", 64, 0, 0},
+        {w.DRP, w.R1, "gru_unit.reset_gate.2.weight", "gru_unit.reset_gate.2.bias", 64, 0, 0},
+        {w.DU1, w.HODE, "gru_unit.update_gate.0.weight", "gru_unit.update_gate.0.bias", 128, 0, 0},
+        {w.DU1, w.XS, "gru_unit.update_gate.0.weight", nullptr, 128, 64, 0},
+        {w.DR1, w.HODE, "gru_unit.reset_gate.0.weight", "gru_unit.reset_gate.0.bias", 128, 0, 0},
+        {w.DR1, w.XS, "gru_unit.reset_gate.0.weight", nullptr, 128, 64, 0},
+    };
+    for (const WG& j : jobs) {
+      float* W = G(j.w);
+      float* bias = j.bias ? G(j.bias) : nullptr;
+      TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
+      if (int rc = run_wgrad(wc, j.d, 64, j.a, 64, R, Nt, W, j.ldw, j.col0, bias, j.tc)) return rc;
+    }
+    // last diffusion layers (64 -> 1): d w4 = sum dgp * g2, d b4 = sum dgp, per net (rows of the other source carry 0)
+    float *n4w = G("lsde_func.g_nus.net.4.weight"), *n4b = G("lsde_func.g_nus.net.4.bias");
+    float *a4w = G("lsde_func.g_argo.net.4.weight"), *a4b = G("lsde_func.g_argo.net.4.bias");
+    TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
+    TS_LAUNCH(k_rowscale_colsum, 1, 1024, 0, st, w.G2, w.DGPN, R, n4w, n4b);
+    TS_LAUNCH(k_rowscale_colsum, 1, 1024, 0, st, w.G2, w.DGPA, R, a4w, a4b);
+  }
+  if (d_aa_out) TS_HIP(hipMemcpyAsync(d_aa_out, w.DAA, size_t(R) * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // ---- AAEncoder over the H snapshots
+  {
+    AttnChain c{blob_bwd + BB::AA_NODE, blob_bwd + BB::AA_PROJ, blob_bwd + BB::AA_EDGEKV, blob_bwd + BB::AA_EDGEEMB,
+                g->aa_geom, w.q, w.logits, w.v, w.center, g->aa_dst, g->aa_segptr, NodeBlockTape{w.agg, w.cn, w.x1, w.xn2}, R, Eaa,
+                "aa_encoder", "nbr_embed"};
+    if (int rc = run_attn_chain(c, w.DAA, w, wc, G, w.DCENTER, st)) return rc;
+    const std::string ce = "aa_encoder.center_embed.embed.";
+    float *w0 = G(ce + "0.weight"), *b0 = G(ce + "0.bias"), *g1 = G(ce + "1.weight"), *e1 = G(ce + "1.bias");
+    float *w3 = G(ce + "3.weight"), *b3 = G(ce + "3.bias"), *g4 = G(ce + "4.weight"), *e4 = G(ce + "4.bias");
+    float *w6 = G(ce + "6.weight"), *b6 = G(ce + "6.bias"), *g7 = G(ce + "7.weight"), *e7 = G(ce + "7.bias");
+    float* tok = G("aa_encoder.bos_token");
+    TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
+    const int gt = tile_grid((R + 15) / 16, 256, CenterTailL::SIZE * 4);
+    TS_LAUNCH(k_aa_center_bwd_tail, gt, 256, CenterTailL::SIZE * 4, st, blob_bwd + BB::AA_CTAIL, b->x, g->x_fake, rot, b->bos_mask, g->orig, N,
+              Nt, H, w.DCENTER, w.A1, w.A2, w.DA3P, w.DA2P, w.XR, w.nb.vpart);
+    float* const tv[4] = {g7, e7, g4, e4};
+    for (int i = 0; i < 4; ++i)
+      if (int rc = run_colsum(st, w.nb.vpart + 64 * i, gt * 4, 256, 64, tv[i])) return rc;
+    if (int rc = run_wgrad(wc, w.DA3P, 64, w.A2, 64, R, R, w6, 64, 0, b6, 0)) return rc;
+    if (int rc = run_wgrad(wc, w.DA2P, 64, w.A1, 64, R, R, w3, 64, 0, b3, 0)) return rc;
+    const int lds_br = (EdgeL::WA3 + MAT64) * 4;
+    const int gb = tile_grid((R + 15) / 16, 256, lds_br);
+    TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, blob_bwd + BB::AA_CHEAD, w.XR, w.DA2P, R, w.nb.vpart);
+    if (int rc = run_colsum(st, w.nb.vpart, gb * 4, 320, 64, g1)) return rc;
+    if (int rc = run_colsum(st, w.nb.vpart + 64, gb * 4, 320, 64, e1)) return rc;
+    if (int rc = run_colsum(st, w.nb.vpart + 128, gb * 4, 320, 64, w0, 2)) return rc;
+    if (int rc = run_colsum(st, w.nb.vpart + 192, gb * 4, 320, 64, w0 + 1, 2)) return rc;
+    if (int rc = run_colsum(st, w.nb.vpart + 256, gb * 4, 320, 64, b0)) return rc;
+    TS_LAUNCH(k_bos_grad, H, 256, 0, st, w.DCENTER, b->bos_mask, g->orig, Nt, H, tok);
+  }
+  return TRAJSDE_OK;
+}
+
+}  // extern "C"

@@ -299,6 +299,50 @@ struct AggBwdBlob {
   static constexpr int proj(int nl, int k) { return norm(nl) + 128 + k * MAT64; }  // W_k^T fragment image
   static constexpr int size(int nl, int K) { return proj(nl, K); }
 };
+// ---- encoder backward images (encoder_bwd.hip)
+struct EdgeKvBwdL {   // AA / AL edge kernel: forward image (embedding + lin_k | lin_v) and the two transposes
+  enum : int { FWD = 0, WKT = EdgeL::SIZE, WVT = WKT + MAT64, SIZE = WVT + MAT64 };
+};
+struct CenterTailL {  // center_embed (SingleInputEmbedding): forward fields in AaCenterL order up to the last LayerNorm, + W6^T
+  enum : int { FWD = 0, W6T = AaCenterL::E7_END, SIZE = W6T + MAT64 };
+};
+struct GruBwdL {      // GRU_Unit: every matrix transposed, 64x64 blocks (h / x halves of the 128-wide inputs apart)
+  enum : int {
+    S_END = 0,
+    TS_FIELD(WN2T, MAT64, S), TS_FIELD(WNXT, MAT64, WN2T), TS_FIELD(WNHT, MAT64, WNXT), TS_FIELD(WU2T, MAT64, WNHT),
+    TS_FIELD(WR2T, MAT64, WU2T), TS_FIELD(UHT, MAT64, WR2T), TS_FIELD(RHT, MAT64, UHT), TS_FIELD(UXT, MAT64, RHT),
+    TS_FIELD(RXT, MAT64, UXT),
+    SIZE = RXT_END
+  };
+};
+struct EncSdeBwdL {   // drift + the two diffusion nets, transposed
+  enum : int {
+    S_END = 0,
+    TS_FIELD(F_W0T, MAT64, S), TS_FIELD(F_W2T, MAT64, F_W0T), TS_FIELD(F_W4T, MAT64, F_W2T),
+    TS_FIELD(GN_W0T, MAT64, F_W4T), TS_FIELD(GN_W2T, MAT64, GN_W0T), TS_FIELD(GA_W0T, MAT64, GN_W2T), TS_FIELD(GA_W2T, MAT64, GA_W0T),
+    TS_FIELD(GN_W4, 64, GA_W2T), TS_FIELD(GA_W4, 64, GN_W4),
+    SIZE = GA_W4_END
+  };
+};
+struct EncBwdBlob {
+  enum : int {
+    AA_EDGEKV = 0,
+    AA_EDGEEMB = AA_EDGEKV + EdgeKvBwdL::SIZE,
+    AA_NODE = AA_EDGEEMB + EdgeBwdL::SIZE,
+    AA_PROJ = AA_NODE + NodeBlockBwdL::SIZE,
+    AA_CTAIL = AA_PROJ + ProjBwdL<1>::SIZE,
+    AA_CHEAD = AA_CTAIL + CenterTailL::SIZE,           // EdgeBwdL-shaped: first embedding layer in the A_* slots, W3^T in WA3T
+    SDE = AA_CHEAD + EdgeBwdL::SIZE,
+    GRU = SDE + EncSdeBwdL::SIZE,
+    AL_PROJ = GRU + GruBwdL::SIZE,
+    AL_EDGEKV = AL_PROJ + ProjBwdL<1>::SIZE,
+    AL_EDGEEMB = AL_EDGEKV + EdgeKvBwdL::SIZE,
+    AL_NODE = AL_EDGEEMB + EdgeBwdL::SIZE,
+    SIZE = AL_NODE + NodeBlockBwdL::SIZE
+  };
+};
+static_assert(GruBwdL::SIZE * 4 <= 160 * 1024 && EncSdeBwdL::SIZE * 4 <= 160 * 1024 && EdgeKvBwdL::SIZE * 4 <= 160 * 1024,
+              "encoder backward images must fit LDS");
 static_assert(FfnBwdAL::SIZE * 4 <= 160 * 1024 && UpdBwdL::SIZE * 4 <= 160 * 1024 && EdgeBwdL::SIZE * 4 <= 160 * 1024,
               "node backward images must fit LDS");
 static_assert(SweepL::SIZE * 4 <= 160 * 1024, "sweep image must fit LDS");

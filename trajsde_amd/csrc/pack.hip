@@ -455,6 +455,80 @@ static void recipe_aggregator_bwd(Packer& P, int nl, int K) {
       k_pack_matT<<<cdiv(16 * 256, 256), 256, 0, P.stream>>>(w + int64_t(k) * MAT64, P.blob + AggBwdBlob::proj(nl, k), 4, 4, 64, 0);
 }
 
+static void recipe_edge_kv_bwd(Packer& P, const std::string& p, const std::string& embed, int kv, int emb) {
+  recipe_edge_embed(P, p + "." + embed, kv + EdgeKvBwdL::FWD);
+  P.mat(p + ".lin_k.weight", kv + EdgeL::WKV, 64, 64, 64);
+  P.mat(p + ".lin_v.weight", kv + EdgeL::WKV + MAT64, 64, 64, 64);
+  P.vec(p + ".lin_k.bias", kv + EdgeL::BKV, 64);
+  P.vec(p + ".lin_v.bias", kv + EdgeL::BKV + 64, 64);
+  P.matT(p + ".lin_k.weight", kv + EdgeKvBwdL::WKT, 64);
+  P.matT(p + ".lin_v.weight", kv + EdgeKvBwdL::WVT, 64);
+  recipe_edge_embed_bwd(P, p + "." + embed, emb);
+}
+static void recipe_proj1_bwd(Packer& P, const std::string& p, int base) {
+  P.ln(p + ".norm1", base + ProjBwdL<1>::N1G, base + ProjBwdL<1>::N1B);
+  P.matT(p + ".lin_q.weight", base + ProjBwdL<1>::WT, 64);
+  P.index(p + ".lin_q.bias");
+}
+static void recipe_encoder_bwd(Packer& P) {
+  using B = EncBwdBlob;
+  recipe_edge_kv_bwd(P, "aa_encoder", "nbr_embed", B::AA_EDGEKV, B::AA_EDGEEMB);
+  recipe_node_block_bwd(P, "aa_encoder", B::AA_NODE);
+  recipe_proj1_bwd(P, "aa_encoder", B::AA_PROJ);
+  {
+    using L = AaCenterL;
+    const std::string c = "aa_encoder.center_embed.embed.";
+    const int t = B::AA_CTAIL, h = B::AA_CHEAD;
+    P.vec(c + "0.weight", t + L::W0, 128);
+    P.vec(c + "0.bias", t + L::B0, 64);
+    P.ln(c + "1", t + L::G1, t + L::E1);
+    P.lin(c + "3", t + L::W3, t + L::B3);
+    P.ln(c + "4", t + L::G4, t + L::E4);
+    P.lin(c + "6", t + L::W6, t + L::B6);
+    P.ln(c + "7", t + L::G7, t + L::E7);
+    P.matT(c + "6.weight", t + CenterTailL::W6T, 64);
+    P.vec(c + "0.weight", h + EdgeL::A_W0, 128);
+    P.vec(c + "0.bias", h + EdgeL::A_B0, 64);
+    P.ln(c + "1", h + EdgeL::A_G, h + EdgeL::A_E);
+    P.matT(c + "3.weight", h + EdgeBwdL::WA3T, 64);
+    P.index("aa_encoder.bos_token");
+  }
+  {
+    using L = EncSdeBwdL;
+    const int s = B::SDE;
+    P.matT("lsde_func.f_func.net.0.weight", s + L::F_W0T, 66);
+    P.matT("lsde_func.f_func.net.2.weight", s + L::F_W2T, 64);
+    P.matT("lsde_func.f_func.net.4.weight", s + L::F_W4T, 64);
+    P.matT("lsde_func.g_nus.net.0.weight", s + L::GN_W0T, 66);
+    P.matT("lsde_func.g_nus.net.2.weight", s + L::GN_W2T, 64);
+    P.matT("lsde_func.g_argo.net.0.weight", s + L::GA_W0T, 66);
+    P.matT("lsde_func.g_argo.net.2.weight", s + L::GA_W2T, 64);
+    P.vec("lsde_func.g_nus.net.4.weight", s + L::GN_W4, 64);
+    P.vec("lsde_func.g_argo.net.4.weight", s + L::GA_W4, 64);
+    for (const char* net : {"f_func", "g_nus", "g_argo"})
+      for (const char* l : {"0", "2", "4"}) P.index(std::string("lsde_func.") + net + ".net." + l + ".bias");
+  }
+  {
+    using L = GruBwdL;
+    const int g = B::GRU;
+    P.matT("gru_unit.new_state_net.2.weight", g + L::WN2T, 64);
+    P.matT("gru_unit.new_state_net.0.weight", g + L::WNXT, 128, 0);
+    P.matT("gru_unit.new_state_net.0.weight", g + L::WNHT, 128, 64);
+    P.matT("gru_unit.update_gate.2.weight", g + L::WU2T, 64);
+    P.matT("gru_unit.reset_gate.2.weight", g + L::WR2T, 64);
+    P.matT("gru_unit.update_gate.0.weight", g + L::UHT, 128, 0);
+    P.matT("gru_unit.reset_gate.0.weight", g + L::RHT, 128, 0);
+    P.matT("gru_unit.update_gate.0.weight", g + L::UXT, 128, 64);
+    P.matT("gru_unit.reset_gate.0.weight", g + L::RXT, 128, 64);
+    for (const char* n : {"update_gate.0", "update_gate.2", "reset_gate.0", "reset_gate.2", "new_state_net.0", "new_state_net.2"})
+      P.index(std::string("gru_unit.") + n + ".bias");
+  }
+  P.index("hidden");
+  recipe_proj1_bwd(P, "al_encoder", B::AL_PROJ);
+  recipe_edge_kv_bwd(P, "al_encoder", "lane_embed", B::AL_EDGEKV, B::AL_EDGEEMB);
+  recipe_node_block_bwd(P, "al_encoder", B::AL_NODE);
+}
+
 static bool run_recipe(Packer& P, int stage, int nl, int K) {
   switch (stage) {
     case TRAJSDE_STAGE_ENCODER: recipe_encoder(P); return true;
@@ -462,6 +536,7 @@ static bool run_recipe(Packer& P, int stage, int nl, int K) {
     case TRAJSDE_STAGE_DECODER: recipe_decoder(P); return true;
     case TRAJSDE_STAGE_DECODER_BWD: recipe_decoder_bwd(P); return true;
     case TRAJSDE_STAGE_AGGREGATOR_BWD: recipe_aggregator_bwd(P, nl, K); return true;
+    case TRAJSDE_STAGE_ENCODER_BWD: recipe_encoder_bwd(P); return true;
   }
   return false;
 }
@@ -563,6 +638,7 @@ int64_t trajsde_blob_floats(int stage, int num_layers, int num_modes) {
     case TRAJSDE_STAGE_DECODER: return DecBlob::SIZE;
     case TRAJSDE_STAGE_DECODER_BWD: return DecBwdBlob::SIZE;
     case TRAJSDE_STAGE_AGGREGATOR_BWD: return AggBwdBlob::size(num_layers, num_modes);
+    case TRAJSDE_STAGE_ENCODER_BWD: return EncBwdBlob::SIZE;
   }
   return fail(TRAJSDE_ERR_INVALID, "unknown stage");
 }

@@ -101,6 +101,8 @@ class _TableCache:
 
 _TABLES = _TableCache()
 _ENC_TABLES: Dict[tuple, np.ndarray] = {}
+_TABLES_DEV: Dict[tuple, torch.Tensor] = {}          # device copies of the host step tables
+
 
 
 class StageRuntime:
@@ -256,6 +258,42 @@ class StageRuntime:
                                     "E_la": gc.graph.E_la}
         diff_in, diff_out = torch.chunk(diff_pick, 2, 0)                                    # ENC:194
         return (local, diff_in, diff_out, torch.full_like(diff_in, m.real_label), torch.full_like(diff_out, m.fake_label))
+
+    def encoder_backward(self, data, d_local: torch.Tensor, noise: NoiseSpec, diff_weight: float = 1.0,
+                         want_boundaries: bool = False) -> Dict[str, object]:
+        """Backward of LocalEncoderSDESepPara2.forward plus the DiffBCE term: `d_local` = dL/d local_embed [N,64],
+        `noise` the forward's NoiseSpec.  Returns {"grads": {param name: tensor}, "diff_loss": diff_weight * DiffBCE}
+        (+ "d_latent" [N,64], "d_aa_out" [H,Nt,64] with want_boundaries).  The forward is recomputed inside."""
+        m = self.module
+        if noise is None:
+            raise _lib.TrajsdeError("encoder_backward needs the NoiseSpec of the forward pass")
+        gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), noise)
+        dev = gc.device
+        L = _lib.lib()
+        H, N, Nt = gc.batch.H, gc.batch.N, gc.graph.Nt
+        if tuple(d_local.shape) != (N, D):
+            raise _lib.TrajsdeError(f"d_local must be [{N},{D}]")
+        tab = self._enc_table()
+        tab_dev = _TABLES_DEV.setdefault((id(tab), str(dev)), torch.from_numpy(tab).to(dev))
+        names = self.param_names(_lib.STAGE_ENCODER_BWD)
+        grads = {n: torch.zeros_like(m.p(n)) for n in names}
+        arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        d_lat = torch.empty(N, D, device=dev, dtype=torch.float32) if want_boundaries else None
+        d_aa = torch.empty(H, Nt, D, device=dev, dtype=torch.float32) if want_boundaries else None
+        ws_bytes = L.trajsde_encoder_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph))
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        cn = noise.c_noise(noise.z_enc, noise.enc_row_ids)
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_encoder_backward(
+                C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), self.blob().data_ptr(),
+                self.blob(_lib.STAGE_ENCODER_BWD).data_ptr(), tab.ctypes.data_as(C.c_void_p), tab_dev.data_ptr(), C.byref(cn),
+                d_local.to(torch.float32).contiguous().data_ptr(), float(diff_weight), ws.data_ptr(), ws_bytes, loss.data_ptr(),
+                arr, len(names), _ptr(d_lat), _ptr(d_aa), _stream()), "trajsde_encoder_backward")
+        out = {"grads": grads, "diff_loss": loss[0]}
+        if want_boundaries:
+            out.update(d_latent=d_lat, d_aa_out=d_aa)
+        return out
 
     def _enc_table(self) -> np.ndarray:
         m = self.module
