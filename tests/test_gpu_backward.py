@@ -256,3 +256,91 @@ def test_decoder_backward_is_deterministic_and_checks_arguments(dev):
     data.y = y_rot[:, :10]
     with pytest.raises(_lib.TrajsdeError):
         model.decoder._rt.decoder_l2_backward(data, local, glob, out, noise)
+
+
+def _oracle_full_grads(model, cfg, batch_cpu, seed, w_l2, w_diff):
+    """end-to-end autograd over the oracle (float64): encoder -> aggregator -> decoder -> w_l2 L2 + w_diff DiffBCE"""
+    import restate
+    import torch.nn.functional as F
+    from trajsde_amd.schedule import decoder_schedule, encoder_schedule
+    c = restate.flat_cfg(cfg)
+    es = encoder_schedule(c["historical_steps"], c["max_past_t"], c["minimum_step"])
+    ds = decoder_schedule(c["future_steps"], c["max_fut_t"], c["min_stepsize"])
+    dt = torch.float64
+    P = {k: (v.detach().cpu().to(dt) if v.is_floating_point() else v.detach().cpu().clone()) for k, v in model.state_dict().items()}
+    names = [k for k in P if P[k].is_floating_point()]
+    for k in names:
+        P[k].requires_grad_(True)
+    b = H.clone_batch(batch_cpu)
+    for k in b.keys:
+        if torch.is_tensor(b[k]) and b[k].is_floating_point():
+            b[k] = b[k].to(dt)
+
+    class Noise64(restate.PhiloxNoise):
+        def fake_agent(self, shape):
+            return super().fake_agent(shape).to(dt)
+
+        def encoder(self, idx, shape):
+            return super().encoder(idx, shape).to(dt)
+
+        def decoder(self, k, shape):
+            return super().decoder(k, shape).to(dt)
+
+    torch.set_default_dtype(dt)
+    try:
+        rot, y_rot = restate.rotate_inputs(b)
+        noise = Noise64(seed)
+        with torch.enable_grad():
+            local, diff_in, diff_out, _ = restate.local_encoder(P, c, b, rot, noise, es, False)
+            glob = restate.global_interactor(P, c, b, rot, local)
+            out = restate.sde_decoder(P, c, b, local, glob, noise, ds)
+            l2, _ = _reference_l2(y_rot, out["loc"][..., :2], out["reg_mask"])
+            bce = (F.binary_cross_entropy(diff_in, torch.zeros_like(diff_in)) +
+                   F.binary_cross_entropy(diff_out, torch.ones_like(diff_out)))
+            loss = w_l2 * l2 + w_diff * bce
+            loss.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return float(loss.detach()), {k: P[k].grad for k in names}
+
+
+def test_training_step_gradients_match_end_to_end_autograd(dev):
+    """`training_step(...).backward()` fills .grad like autograd over the whole reference graph would"""
+    from trajsde_amd import runtime
+    from trajsde_amd.synth import synth
+    K, T = 3, 20
+    batch = synth(S=3, n=12, L=6, F=T, box=70.0, seed=77, mixed_source=True, history_dropout=0.3)
+    model, cfg = H.build_model(K, T, 2.0, init_seed=19)
+    model.loss_weights = [1.0, 0.5]
+    model = model.to(dev).train()
+    loss = model.training_step(batch.to(dev), 0, noise=runtime.NoiseSpec(seed=31))
+    loss.backward()
+    torch.cuda.synchronize()
+    want_loss, want = _oracle_full_grads(model, cfg, batch, 31, 1.0, 0.5)
+    assert abs(float(loss) - want_loss) <= 1e-5 * max(1.0, abs(want_loss))
+    reached = {id(p) for p in model.params_with_gradient()}
+    bad = []
+    for n, p in model.named_parameters():
+        w = want[n]
+        if id(p) not in reached:
+            assert p.grad is None and (w is None or float(w.abs().max()) == 0.0), n
+            continue
+        scale = float(w.abs().max())
+        err = float((p.grad.cpu().double() - w).abs().max())
+        zero_by_symmetry = n.endswith("lin_k.bias") or n.endswith("lin_k_node.bias") or n.endswith("lin_k_edge.bias")
+        if (err > 5e-5 or scale > 5e-5) if zero_by_symmetry else (err > REL * scale + 1e-7):
+            bad.append((n, err, scale))
+    assert not bad, bad
+
+
+def test_a_few_optimizer_steps_reduce_the_loss(dev):
+    from trajsde_amd import driver
+    from trajsde_amd.synth import synth
+    batch = synth(S=4, n=16, L=6, F=20, box=70.0, seed=78, mixed_source=True).to(dev)
+    model, _ = H.build_model(3, 20, 2.0, init_seed=21)
+    model.lr, model.weight_decay, model.T_max = 2e-3, 1e-4, 10
+    model = model.to(dev)
+    hist = driver.train(model, lambda epoch: [batch] * 6, epochs=2, seed=0)
+    assert len(hist) == 12 and all(torch.isfinite(torch.tensor(hist)))
+    assert sum(hist[-3:]) < sum(hist[:3]), hist
+    assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("decoder.pi.") or n.startswith("decoder.scale."))

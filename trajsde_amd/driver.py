@@ -10,7 +10,12 @@ so the loop is spelled out; the model class keeps Lightning's hook signatures an
 With `--data` the `datamodule_specific` section is resolved like `test.py:54-58` does and the model is evaluated on
 its `test_dataloader()` (flat scene shards, trajsde_amd/dataset.py); ranks take disjoint scene sets.
 
-Training (`train.py:42-66`) needs the backward kernels and is not built yet.
+    python -m trajsde_amd.driver --config ... --train --synthetic config1 --batches 8 --epochs 2    # train.py:42-66
+
+`--train` runs the reference's optimisation recipe (AdamW + per-epoch cosine annealing, MODEL:204-207) over
+`training_step`; with WORLD_SIZE > 1 every rank trains on its own scenes and the gradients are averaged with ONE
+all-reduce per step over a flat bucket that the parameters' `.grad` tensors are views of (RCCL over xGMI: ~1.4 MB,
+latency-bound, so a single collective beats bucketing).
 """
 import argparse
 import json
@@ -56,6 +61,53 @@ def _seeded_test_step(model, data, batch_idx, seed):
     return output
 
 
+class FlatGrads:
+    """One contiguous gradient buffer; every parameter's `.grad` is a view into it, so zeroing is one memset and
+    the data-parallel gradient sync is one all-reduce (the only collective of the training path)."""
+
+    def __init__(self, params) -> None:
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(total, device=ref.device, dtype=ref.dtype)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self) -> None:
+        self.flat.zero_()
+
+    def all_reduce_mean(self) -> None:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+
+
+def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None) -> list:
+    """trainer.fit(...) spelled out (train.py:60-66): per batch zero -> training_step -> backward -> gradient
+    all-reduce -> AdamW step; scheduler step per epoch.  `batches_per_epoch(epoch)` yields this rank's batches.
+    Returns the per-step loss values of this rank."""
+    model.train()
+    (optimizer,), (scheduler,) = model.configure_optimizers()
+    flat = FlatGrads(model.params_with_gradient())
+    history, step = [], 0
+    for epoch in range(epochs):
+        for i, batch in enumerate(batches_per_epoch(epoch)):
+            flat.zero()
+            loss = model.training_step(batch, i, noise=NoiseSpec(seed=seed + step))
+            loss.backward()
+            flat.all_reduce_mean()
+            optimizer.step()
+            history.append(float(loss))
+            if log:
+                log(epoch, i, history[-1], model.last_losses)
+            step += 1
+        scheduler.step()
+    return history
+
+
 def synthetic_batches(name: str, n: int, device, rank: int = 0, world: int = 1):
     spec = CONFIGS[name]
     for i in range(rank, n, world):                                                   # scene-batches shard over ranks
@@ -82,6 +134,8 @@ def main() -> None:
     ap.add_argument("--synthetic", default="config1", choices=sorted(CONFIGS))
     ap.add_argument("--batches", type=int, default=4)
     ap.add_argument("--ood", action="store_true")
+    ap.add_argument("--train", action="store_true", help="run the optimisation loop instead of the evaluation loop")
+    ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--data", action="store_true", help="evaluate on the YAML's data module instead of synthetic batches")
     ap.add_argument("--nu_dir", default=None)
     ap.add_argument("--argo_dir", default=None)
@@ -108,6 +162,31 @@ def main() -> None:
         cfg["model_specific"]["kwargs"]["ood"] = True                                # test.py:45-46
     dev = torch.device("cuda", local_rank)
     model = build_model(cfg, args.ckpt, dev, init_seed=0 if args.ckpt is None else None)
+    if args.train:
+        if args.data:
+            dm_cfg = cfg["datamodule_specific"]
+            kwargs = dict(dm_cfg["kwargs"], rank=rank, world_size=world, device=dev)
+            if args.nu_dir:
+                kwargs["nu_dir"] = args.nu_dir
+            if args.argo_dir:
+                kwargs["Argo_dir"] = args.argo_dir
+            dm = resolve_class(dm_cfg["file_path"], dm_cfg["module_name"])(**kwargs)
+            dm.setup("fit")
+            loader = dm.train_dataloader()
+
+            def per_epoch(epoch):
+                loader.set_epoch(epoch)
+                return iter(loader)
+        else:
+            def per_epoch(epoch):
+                return synthetic_batches(args.synthetic, args.batches, dev, rank, world)
+        hist = train(model, per_epoch, args.epochs,
+                     log=(lambda e, i, l, parts: print(f"epoch {e} step {i} loss {l:.5f}")) if rank == 0 else None)
+        if rank == 0:
+            print(json.dumps({"steps": len(hist), "first_loss": hist[0], "last_loss": hist[-1]}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.data:
         batches = datamodule_batches(cfg, dev, rank, world, args.nu_dir, args.argo_dir)
     else:

@@ -28,6 +28,40 @@ def resolve_class(file_path: str, module_name: str):
     return getattr(SourceFileLoader(module_name, path).load_module(module_name), module_name)
 
 
+class _PathLoss(torch.autograd.Function):
+    """loss = sum_i w_i * loss_i over the configured {L2, DiffBCE} set as ONE autograd node whose inputs are the model
+    parameters: forward runs the HIP forward and, right behind it, the three stage backward entry points of the
+    C-ABI (decoder -> aggregator -> encoder); backward hands the gradients to autograd, so `loss.backward()`,
+    optimizers, gradient accumulation and torch DDP hooks behave as with the reference's autograd graph."""
+
+    @staticmethod
+    def forward(ctx, model, data, noise, w_l2, w_diff, *params):
+        with torch.no_grad():
+            out, local, glob = model._forward_stages(data, noise)
+            enc_rt, agg_rt, dec_rt = model.encoder._rt, model.aggregator._rt, model.decoder._rt
+            dec = dec_rt.decoder_l2_backward(data, local, glob, out, noise)
+            d_glob, d_local = dec["d_global_embed"], dec["d_local_embed"]
+            if w_l2 != 1.0:
+                d_glob, d_local = d_glob * w_l2, d_local * w_l2
+            agg = agg_rt.aggregator_backward(data, local, d_glob)
+            enc = enc_rt.encoder_backward(data, d_local + agg["d_local_embed"], noise, diff_weight=w_diff)
+            by_name = {}
+            for n, g in dec["grads"].items():
+                by_name["decoder." + n] = g if w_l2 == 1.0 else g * w_l2
+            for n, g in agg["grads"].items():
+                by_name["aggregator." + n] = g
+            for n, g in enc["grads"].items():
+                by_name["encoder." + n] = g
+            ctx.grads = [by_name.get(n) for n in model._param_names]          # None: no path from these losses
+            model.last_output = out
+            model.last_losses = {"L2": dec["loss"].detach(), "DiffBCE": enc["diff_loss"].detach() / w_diff if w_diff else None}
+            return (w_l2 * dec["loss"] + enc["diff_loss"]).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, None, None, None) + tuple(None if x is None else x * g for x in ctx.grads)
+
+
 class PredictionModelSDENet(nn.Module):
     def __init__(self, **kwargs) -> None:
         super().__init__()
@@ -94,9 +128,48 @@ class PredictionModelSDENet(nn.Module):
             out["diff_in"], out["diff_out"], out["label_in"], out["label_out"] = diff_in, diff_out, label_in, label_out
         return out
 
+    def params_with_gradient(self):
+        """the parameters the configured losses reach (everything except the decoder's pi / scale heads and unused
+        buffers-as-parameters): the reference's autograd leaves the others' `.grad` at None, so AdamW skips them"""
+        from trajsde_amd import _lib
+        reached = set()
+        for stage, sid in (("encoder", _lib.STAGE_ENCODER_BWD), ("aggregator", _lib.STAGE_AGGREGATOR_BWD),
+                           ("decoder", _lib.STAGE_DECODER_BWD)):
+            reached |= {f"{stage}.{n}" for n in getattr(self, stage)._rt.param_names(sid)}
+        return [p for n, p in self.named_parameters() if n in reached]
+
+    def _forward_stages(self, data, noise):
+        """forward() that also hands back the two stage boundaries the backward entry points need"""
+        rotate_mat, y_rot = runtime.rotate_inputs(data)
+        if y_rot is not None:
+            data.y = y_rot
+        data["rotate_mat"] = rotate_mat
+        local_embed, diff_in, diff_out, label_in, label_out = self.encoder(data=data, noise=noise)
+        global_embed = self.aggregator(data=data, local_embed=local_embed)
+        out = self.decoder(data=data, local_embed=local_embed, global_embed=global_embed, noise=noise)
+        out["diff_in"], out["diff_out"], out["label_in"], out["label_out"] = diff_in, diff_out, label_in, label_out
+        return out, local_embed, global_embed
+
     # -- Lightning-style hooks (MODEL:104-148) ------------------------------------------------------
-    def training_step(self, data, batch_idx):
-        raise NotImplementedError("training needs the backward kernels: SURVEY.md 8(f) rank 1, not built yet")
+    def training_step(self, data, batch_idx, noise: Optional["runtime.NoiseSpec"] = None):
+        """MODEL:104-116: forward, the weighted sum of the configured losses, as a tensor whose `.backward()` fills
+        `.grad` through the HIP backward kernels.  The kernels implement the shipped loss set (losses/L2.py +
+        losses/diff_BCE.py, CFG:78-83); any other loss is refused rather than silently differentiated elsewhere."""
+        if not self.rotate:
+            raise NotImplementedError("rotate=False is not built (shipped config: rotate: true, CFG:18)")
+        weights = dict(zip(self.loss_names, self.loss_weights))
+        unknown = set(self.loss_names) - {"L2", "DiffBCE"}
+        if unknown or "L2" not in weights:
+            raise NotImplementedError(f"training_step differentiates L2 (+ DiffBCE) through the HIP kernels; configured: {self.loss_names}")
+        if data.y is None:
+            raise ValueError("training_step needs targets (data.y)")
+        noise = runtime.NoiseSpec.resolve(noise)
+        if not hasattr(self, "_param_names"):
+            self._param_names = [n for n, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        loss = _PathLoss.apply(self, data, noise, float(weights["L2"]), float(weights.get("DiffBCE", 0.0)), *params)
+        self.log_dict = {f"train/{k}": v for k, v in self.last_losses.items() if v is not None}
+        return loss
 
     def _agent_eval_tensors(self, data, output):
         idx = data["agent_index"]
