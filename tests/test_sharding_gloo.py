@@ -87,3 +87,55 @@ def test_two_rank_scene_sharding_matches_single_process():
         rows = np.concatenate([np.arange(offs[s], offs[s + 1]) for s in mine])
         assert np.abs(loc - want["loc"].numpy()[:, rows]).max() <= 1e-5
         assert abs(ade_r - want_ade) <= 1e-5 and abs(fde_r - want_fde) <= 1e-5
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from trajsde_amd.driver import FlatGrads
+        torch.set_num_threads(1)
+        model, _ = H.build_model(K, T, MAXT, init_seed=3)
+        params = [p for n, p in model.named_parameters() if p.requires_grad and not n.startswith("decoder.pi.")]
+        flat = FlatGrads(params)
+        flat.zero()
+        with torch.no_grad():
+            for p in params:
+                p.grad.add_(p.detach() * float(rank + 1))          # stand-in for a rank's backward: accumulates in place
+        views_ok = all(p.grad.data_ptr() >= flat.flat.data_ptr() for p in params)
+        flat.all_reduce_mean()                                       # the one collective of a training step
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.0)
+        before = [p.detach().clone() for p in model.parameters()]
+        opt.step()
+        moved = [float((p.detach() - b).abs().max()) for p, b in zip(model.parameters(), before)]
+        q.put((rank, views_ok, flat.flat.clone().numpy(), torch.cat([p.detach().reshape(-1) for p in params]).numpy(),
+               [n for (n, p), m in zip(model.named_parameters(), moved) if m == 0.0]))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_all_reduce_over_flat_bucket():
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    model, _ = H.build_model(K, T, MAXT, init_seed=3)
+    want = torch.cat([p.detach().reshape(-1) for n, p in model.named_parameters()
+                      if p.requires_grad and not n.startswith("decoder.pi.")]).numpy() * 1.5
+    for rank, views_ok, flat, new_params, frozen in got:
+        assert views_ok
+        np.testing.assert_allclose(flat, want, rtol=1e-6, atol=1e-7)       # mean of (1x, 2x) on both ranks
+        assert any(n.startswith("decoder.pi.") for n in frozen)                # grad None -> AdamW leaves them alone
+        assert "decoder.decoder.0.weight" not in frozen and "encoder.gru_unit.update_gate.0.weight" not in frozen
+    np.testing.assert_array_equal(got[0][3], got[1][3])                        # replicas stay bit-identical after the step
