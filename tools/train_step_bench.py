@@ -1,0 +1,73 @@
+"""Time `training_step + backward + AdamW` at a BASELINE.json synthetic configuration (default config2: 64 scenes x 128
+agents, K=6, 20 steps) and print the library's per-kernel HIP-event table for one step.
+
+    python tools/train_step_bench.py [--config config2] [--steps 5] [--warmup 2]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import yaml
+    from trajsde_amd import _lib, driver
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import CONFIGS, synth
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="config2")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    a = ap.parse_args()
+    spec = CONFIGS[a.config]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "trajsde_amd/configs/mi355x_sde_encoder_decoder.yml")) as f:
+        cfg = yaml.safe_load(f)
+    K, T = spec["num_modes"], spec["future_steps"]
+    cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)
+    cfg["aggregator"]["kwargs"]["num_modes"] = K
+    cfg["decoder"]["kwargs"].update(num_modes=K, future_steps=T, max_fut_t=spec["max_fut_t"])
+    dev = torch.device("cuda:0")
+    model = driver.build_model(cfg, None, dev, init_seed=0).train()
+    (opt,), _ = model.configure_optimizers()
+    flat = driver.FlatGrads(model.params_with_gradient())
+    batch = synth(**spec["synth"]).to(dev)
+
+    def step(i):
+        flat.zero()
+        loss = model.training_step(batch, i, noise=NoiseSpec(seed=100 + i))
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / a.steps * 1e3
+    torch.cuda.reset_peak_memory_stats()
+    _lib.lib().trajsde_profile_mode(2)
+    step(999)
+    torch.cuda.synchronize()
+    table = _lib.profile_report()
+    _lib.lib().trajsde_profile_mode(0)
+    rows = sorted(((v[1], k, v[0]) for k, v in table.items()), reverse=True)
+    print(json.dumps({"config": a.config, "scenes": spec["synth"]["S"], "ms_per_train_step": ms,
+                      "scenes_per_s": spec["synth"]["S"] / ms * 1e3, "loss": float(loss),
+                      "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
+    tot = sum(r[0] for r in rows)
+    print(f"kernel time of one step (HIP events, serial): {tot:.2f} ms")
+    for ms_k, name, n in rows[:28]:
+        print(f"  {ms_k:8.3f} ms  x{n:<4d} {name}")
+
+
+if __name__ == "__main__":
+    main()

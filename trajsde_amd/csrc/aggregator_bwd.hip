@@ -285,8 +285,8 @@ int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, 
     TS_HIP(hipMemsetAsync(w.DVN, 0, size_t(N) * 64 * sizeof(float), st));
     TS_LAUNCH(k_gattn_bwd, cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], w.agg[l],
               w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM);
-    TS_LAUNCH(k_headwise_outer, 64, 256, 0, st, w.q[l], w.RL, N, wke);
-    TS_LAUNCH(k_headwise_outer, 64, 256, 0, st, w.dagg, w.SS, N, wve);
+    if (int rc = run_headwise_outer(wc, w.q[l], w.RL, N, wke)) return rc;
+    if (int rc = run_headwise_outer(wc, w.dagg, w.SS, N, wve)) return rc;
     TS_HIP(hipMemsetAsync(bke, 0, 64 * sizeof(float), st));          // a key bias shifts every logit of a target alike
     if (int rc = run_colsum(st, w.DAGGM, N, 64, 64, bve)) return rc;
     const int gp = tile_grid(ntiles, 256, ProjBwdL<3>::SIZE * 4);

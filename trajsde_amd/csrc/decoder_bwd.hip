@@ -509,13 +509,24 @@ __global__ void k_reduce_partials(const float* __restrict__ part, const float* _
   }
 }
 
-// dst[j*dst_stride] = sum_w src[w*stride + j], j < n   (per-wave vector partials -> one vector)
-__global__ void k_colsum(const float* __restrict__ src, int64_t rows, int stride, int n, float* __restrict__ dst, int dst_stride) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+// dst[j*dst_stride] = sum_w src[w*stride + j], j < n   (per-wave vector partials -> one vector).
+// One workgroup per 64 columns, 16 row slices per workgroup, fixed summation order.
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, int64_t rows, int stride, int n, float* __restrict__ dst,
+                                                 int dst_stride) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int64_t w = 0; w < rows; ++w) s += src[w * stride + j];
-  dst[int64_t(j) * dst_stride] = s;
+  if (j < n)
+    for (int64_t w = part; w < rows; w += 16) s += src[w * stride + j];
+  red[part][c] = s;
+  __syncthreads();
+  if (part == 0 && j < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += red[p][c];
+    dst[int64_t(j) * dst_stride] = t;
+  }
 }
 
 int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, float* W,
@@ -524,15 +535,19 @@ int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, in
     TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 256), 256, 0, c.st, c.part, c.cs, 0, 1, c.step_tab, W, ldw, col0, bias, time_cols);
     return TRAJSDE_OK;
   }
-  const int cpg = int((rows_per_group + WGRAD_CHUNK - 1) / WGRAD_CHUNK);
+  // rows per workgroup: at least WGRAD_CHUNK, and few enough partials (<= ~512) that the second stage stays short
   const int groups = int((R + rows_per_group - 1) / rows_per_group);
+  int64_t chunk = WGRAD_CHUNK;
+  const int64_t want_parts = groups > 512 ? groups : 512;
+  while ((rows_per_group + chunk - 1) / chunk * groups > want_parts) chunk *= 2;
+  const int cpg = int((rows_per_group + chunk - 1) / chunk);
   const int P = cpg * groups;
-  TS_LAUNCH(k_wgrad, P, 256, (4 * 4096 + 4 * 4 * 64) * 4, c.st, delta, ldd, a, lda, R, rows_per_group, WGRAD_CHUNK, cpg, c.part, c.cs);
+  TS_LAUNCH(k_wgrad, P, 256, (4 * 4096 + 4 * 4 * 64) * 4, c.st, delta, ldd, a, lda, R, rows_per_group, int(chunk), cpg, c.part, c.cs);
   TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 256), 256, 0, c.st, c.part, c.cs, P, cpg, c.step_tab, W, ldw, col0, bias, time_cols);
   return TRAJSDE_OK;
 }
 int run_colsum(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride) {
-  k_colsum<<<cdiv(n, 64), 64, 0, st>>>(src, rows, stride, n, dst, dst_stride);
+  k_colsum<<<cdiv(n, 64), 1024, 0, st>>>(src, rows, stride, n, dst, dst_stride);
   TS_LAUNCH_CHECK("k_colsum");
   return TRAJSDE_OK;
 }
@@ -648,7 +663,7 @@ int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, cons
   TS_LAUNCH(k_head_bwd, head_grid, BWD_THREADS, HeadBwdL::SIZE * 4, st, blob_bwd + DecBwdBlob::HEAD, w.states, out_table, y, reg_mask,
             w.scal, N, T, w.S_in, w.DU, w.DS, w.vpart);
   const int head_waves = head_grid * waves;
-  auto colsum = [&](const float* src, int rows, int stride, int n, float* dst) { k_colsum<<<cdiv(n, 64), 64, 0, st>>>(src, rows, stride, n, dst, 1); };
+  auto colsum = [&](const float* src, int rows, int stride, int n, float* dst) { k_colsum<<<cdiv(n, 64), 1024, 0, st>>>(src, rows, stride, n, dst, 1); };
   colsum(w.vpart + HeadV::DGAM, head_waves, HeadV::SIZE, 64, grads[D1W]);
   colsum(w.vpart + HeadV::DBET, head_waves, HeadV::SIZE, 64, grads[D1B]);
   colsum(w.vpart + HeadV::DW3X, head_waves, HeadV::SIZE, 128, grads[D3W]);      // rows x, y of decoder.3.weight [2,64]

@@ -180,16 +180,20 @@ __global__ __launch_bounds__(256) void k_aa_center_bwd_tail(const float* __restr
 }
 
 // d bos_token[t][c] = sum over the rows (t, i) that took the token of dcentre; one workgroup per t
-__global__ __launch_bounds__(256) void k_bos_grad(const float* __restrict__ dcenter, const uint8_t* __restrict__ bos,
-                                                  const int32_t* __restrict__ orig, int Nt, int H, float* __restrict__ dtok) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void k_bos_grad(const float* __restrict__ dcenter, const uint8_t* __restrict__ bos,
+                                                   const int32_t* __restrict__ orig, int Nt, int H, float* __restrict__ dtok) {
+  __shared__ float red[16][64];
   const int t = blockIdx.x, c = threadIdx.x & 63, part = threadIdx.x >> 6;
   float s = 0.f;
-  for (int i = part; i < Nt; i += 4)
+  for (int i = part; i < Nt; i += 16)
     if (bos[int64_t(orig[i]) * H + t]) s += dcenter[(int64_t(t) * Nt + i) * 64 + c];
   red[part][c] = s;
   __syncthreads();
-  if (part == 0) dtok[t * 64 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  if (part == 0) {
+    float u = 0.f;
+    for (int p = 0; p < 16; ++p) u += red[p][c];
+    dtok[t * 64 + c] = u;
+  }
 }
 
 // ------------------------------------------------------------------ recurrence: forward replay with saves
@@ -498,28 +502,29 @@ __global__ __launch_bounds__(256) void k_enc_sde_bwd(const float* __restrict__ i
   }
 }
 
-// out[c] = sum_r s[r] * A[r][c]  (c < 64),  out[64] = sum_r s[r];  one workgroup, fixed order
+// part[b][c] = sum over row slice b of s[r] * A[r][c]  (c < 64),  part[b][64] = sum s[r];  summed by k_colsum afterwards
 __global__ __launch_bounds__(1024) void k_rowscale_colsum(const float* __restrict__ A, const float* __restrict__ s, int64_t R,
-                                                          float* __restrict__ out_vec, float* __restrict__ out_sum) {
+                                                          float* __restrict__ part) {
   __shared__ float red[16][65];
-  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int64_t per = (R + gridDim.x - 1) / gridDim.x, lo = int64_t(blockIdx.x) * per, hi = lo + per < R ? lo + per : R;
   float acc = 0.f, ss = 0.f;
-  for (int64_t r = part; r < R; r += 16) {
+  for (int64_t r = lo + sub; r < hi; r += 16) {
     const float sv = s[r];
     acc = fmaf(sv, A[r * 64 + c], acc);
     ss += sv;
   }
-  red[part][c] = acc;
-  if (c == 0) red[part][64] = ss;
+  red[sub][c] = acc;
+  if (c == 0) red[sub][64] = ss;
   __syncthreads();
-  if (part == 0) {
+  if (sub == 0) {
     float t = 0.f;
     for (int p = 0; p < 16; ++p) t += red[p][c];
-    out_vec[c] = t;
+    part[blockIdx.x * 128 + c] = t;
     if (c == 0) {
       float u = 0.f;
       for (int p = 0; p < 16; ++p) u += red[p][64];
-      *out_sum = u;
+      part[blockIdx.x * 128 + 64] = u;
     }
   }
 }
@@ -818,8 +823,12 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
     float *n4w = G("lsde_func.g_nus.net.4.weight"), *n4b = G("lsde_func.g_nus.net.4.bias");
     float *a4w = G("lsde_func.g_argo.net.4.weight"), *a4b = G("lsde_func.g_argo.net.4.bias");
     TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
-    TS_LAUNCH(k_rowscale_colsum, 1, 1024, 0, st, w.G2, w.DGPN, R, n4w, n4b);
-    TS_LAUNCH(k_rowscale_colsum, 1, 1024, 0, st, w.G2, w.DGPA, R, a4w, a4b);
+    for (int net = 0; net < 2; ++net) {
+      const int blocks = R >= 65536 ? 128 : 8;
+      TS_LAUNCH(k_rowscale_colsum, blocks, 1024, 0, st, w.G2, net == 0 ? w.DGPN : w.DGPA, R, w.nb.vpart);
+      if (int rc = run_colsum(st, w.nb.vpart, blocks, 128, 64, net == 0 ? n4w : a4w)) return rc;
+      if (int rc = run_colsum(st, w.nb.vpart + 64, blocks, 128, 1, net == 0 ? n4b : a4b)) return rc;
+    }
   }
   if (d_aa_out) TS_HIP(hipMemcpyAsync(d_aa_out, w.DAA, size_t(R) * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
   // ---- AAEncoder over the H snapshots
@@ -850,7 +859,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
     if (int rc = run_colsum(st, w.nb.vpart + 128, gb * 4, 320, 64, w0, 2)) return rc;
     if (int rc = run_colsum(st, w.nb.vpart + 192, gb * 4, 320, 64, w0 + 1, 2)) return rc;
     if (int rc = run_colsum(st, w.nb.vpart + 256, gb * 4, 320, 64, b0)) return rc;
-    TS_LAUNCH(k_bos_grad, H, 256, 0, st, w.DCENTER, b->bos_mask, g->orig, Nt, H, tok);
+    TS_LAUNCH(k_bos_grad, H, 1024, 0, st, w.DCENTER, b->bos_mask, g->orig, Nt, H, tok);
   }
   return TRAJSDE_OK;
 }
