@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TRAJSDE_BENCH_STREAMS", "3")),
                     help="HIP streams the K steps are dealt over (each step is still one complete forward of one batch)")
     ap.add_argument("--kernel-table", action="store_true", help="extra untimed pass timing every kernel (stderr)")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the secondary training-step figure")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -234,6 +235,36 @@ def main():
             line["roofline_isolated"] = {"kernel": "k_edge_kv[aa]", "streams": 1, "achieved": iso, "peak": PEAK_FP32_EQUIV_TFLOPS,
                                          "unit": "TFLOP/s", "frac": iso / PEAK_FP32_EQUIV_TFLOPS, "avg_launch_ms": iso_ms / iso_n,
                                          "launches": iso_n}
+        if world == 1 and not args.no_train_step:
+            # secondary figure (not `value`): the training step of the same workload -- forward + L2/DiffBCE + the three
+            # stage backward calls + AdamW, reported next to the inference metric
+            try:
+                from trajsde_amd.driver import FlatGrads
+                model.train()
+                (opt,), _ = model.configure_optimizers()
+                flat = FlatGrads(model.params_with_gradient())
+                tb = batches[0]
+
+                def tstep(i):
+                    flat.zero()
+                    tb.y = y0s[0]                                               # forward rotates y in place (MODEL:83-84)
+                    model.training_step(tb, i, noise=NoiseSpec(seed=5000 + i)).backward()
+                    opt.step()
+                tstep(0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(3):
+                    tstep(1 + i)
+                torch.cuda.synchronize()
+                tms = (time.perf_counter() - t0) / 3 * 1e3
+                line["train_step"] = {"ms_per_step": tms, "scenes_per_s": spec["synth"]["S"] / tms * 1e3, "steps": 3,
+                                      "what": "training_step + backward (HIP backward kernels of all three stages) + AdamW on one "
+                                              "batch of the same workload, fp32 gradients, 1 stream; weights are updated, so this "
+                                              "runs after every inference measurement",
+                                      "loss_L2": float(model.last_losses["L2"]), "loss_DiffBCE": float(model.last_losses["DiffBCE"])}
+                model.eval()
+            except Exception as e:                                              # never let the secondary figure cost the main line
+                line["train_step"] = {"error": repr(e)[:300]}
         if args.kernel_table:
             lib.trajsde_profile_mode(2)
             with torch.no_grad():

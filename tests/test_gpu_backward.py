@@ -340,7 +340,13 @@ def test_a_few_optimizer_steps_reduce_the_loss(dev):
     model, _ = H.build_model(3, 20, 2.0, init_seed=21)
     model.lr, model.weight_decay, model.T_max = 2e-3, 1e-4, 10
     model = model.to(dev)
-    hist = driver.train(model, lambda epoch: [batch] * 6, epochs=2, seed=0)
+    y0 = batch.y.clone()
+
+    def fresh(epoch):                                   # forward rotates y in place (MODEL:83-84): hand out fresh targets
+        for _ in range(6):
+            batch.y = y0
+            yield batch
+    hist = driver.train(model, fresh, epochs=2, seed=0)
     assert len(hist) == 12 and all(torch.isfinite(torch.tensor(hist)))
     assert sum(hist[-3:]) < sum(hist[:3]), hist
     assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("decoder.pi.") or n.startswith("decoder.scale."))

@@ -37,9 +37,11 @@ def main():
     (opt,), _ = model.configure_optimizers()
     flat = driver.FlatGrads(model.params_with_gradient())
     batch = synth(**spec["synth"]).to(dev)
+    y0 = batch.y.clone()
 
     def step(i):
         flat.zero()
+        batch.y = y0                                   # forward rotates y in place (MODEL:83-84)
         loss = model.training_step(batch, i, noise=NoiseSpec(seed=100 + i))
         loss.backward()
         opt.step()

@@ -443,19 +443,31 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ delta, 
 #pragma unroll
     for (int it = 0; it < 4; ++it) acc[ot][it] = f4{0.f, 0.f, 0.f, 0.f};
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t rb = row0 + 4 * wave; rb < row1; rb += 16) {
+  // software-pipelined over 4-row k-steps: the operands of step i+1 are in flight while step i is on the matrix cores
+  auto fetch = [&](int64_t rb, float (&A)[4], float (&B)[4]) {
     const int64_t r = rb + kg;
-    float A[4], B[4];
+    const bool ok = r < row1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      A[q] = r < row1 ? delta[r * ldd + 16 * q + idx] : 0.f;
-      B[q] = r < row1 ? a[r * lda + 16 * q + idx] : 0.f;
-      csum[q] += A[q];
+      A[q] = ok ? delta[r * ldd + 16 * q + idx] : 0.f;
+      B[q] = ok ? a[r * lda + 16 * q + idx] : 0.f;
     }
+  };
+  float A0[4], B0[4], A1[4], B1[4];
+  int64_t rb = row0 + 4 * wave;
+  if (rb < row1) fetch(rb, A0, B0);
+  while (rb < row1) {
+    const int64_t nb = rb + 16;
+    if (nb < row1) fetch(nb, A1, B1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) csum[q] += A0[q];
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
-      for (int it = 0; it < 4; ++it) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ot], B[it], acc[ot][it], 0, 0, 0);
+      for (int it = 0; it < 4; ++it) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[ot], B0[it], acc[ot][it], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { A0[q] = A1[q]; B0[q] = B1[q]; }
+    rb = nb;
   }
   // D fragment: lane holds dW[16ot + 4kg + reg][16it + idx]
 #pragma unroll
@@ -480,31 +492,48 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ delta, 
 }
 
 // W[o*ldw + col0 + i] = sum_p part[p][o][i];  bias[o] = sum_p cs[p][o];  with time_cols the (sin t, cos t) input
-// columns 64 / 65 of the 66-wide first SDE layer: W[o*ldw + 64] = sum_p sin(t_group(p)) cs[p][o], likewise cos
-__global__ void k_reduce_partials(const float* __restrict__ part, const float* __restrict__ cs, int P, int chunks_per_group,
-                                  const float* __restrict__ step_tab, float* __restrict__ W, int ldw, int col0,
-                                  float* __restrict__ bias, int time_cols) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+// columns 64 / 65 of the 66-wide first SDE layer: W[o*ldw + 64] = sum_p sin(t_group(p)) cs[p][o], likewise cos.
+// A workgroup owns 32 outputs; its 8 thread groups each sum every 8th partial, then combine in a fixed order.
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ part, const float* __restrict__ cs, int P,
+                                                         int chunks_per_group, const float* __restrict__ step_tab,
+                                                         float* __restrict__ W, int ldw, int col0, float* __restrict__ bias,
+                                                         int time_cols) {
+  __shared__ float red[3][8][32];
+  const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + lane;
+  float s = 0.f, ws = 0.f, wc = 0.f;
   if (j < 4096) {
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[int64_t(p) * 4096 + j];
-    W[(j >> 6) * ldw + col0 + (j & 63)] = s;
+    for (int p = sl; p < P; p += 8) s += part[int64_t(p) * 4096 + j];
   } else if (j < 4096 + 64) {
     const int o = j - 4096;
-    float b = 0.f, ws = 0.f, wc = 0.f;
-    for (int p = 0; p < P; ++p) {
+    for (int p = sl; p < P; p += 8) {
       const float v = cs[int64_t(p) * 64 + o];
-      b += v;
+      s += v;
       if (time_cols) {
         const int k = p / chunks_per_group;
         ws = fmaf(step_tab[k * 8 + 3], v, ws);
         wc = fmaf(step_tab[k * 8 + 4], v, wc);
       }
     }
-    if (bias) bias[o] = b;
+  }
+  red[0][sl][lane] = s;
+  red[1][sl][lane] = ws;
+  red[2][sl][lane] = wc;
+  __syncthreads();
+  if (sl != 0) return;
+  float t[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t[q] += red[q][g][lane];
+  if (j < 4096) {
+    W[(j >> 6) * ldw + col0 + (j & 63)] = t[0];
+  } else if (j < 4096 + 64) {
+    const int o = j - 4096;
+    if (bias) bias[o] = t[0];
     if (time_cols) {
-      W[o * ldw + 64] = ws;
-      W[o * ldw + 65] = wc;
+      W[o * ldw + 64] = t[1];
+      W[o * ldw + 65] = t[2];
     }
   }
 }
@@ -532,7 +561,7 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, 
 int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, float* W,
               int ldw, int col0, float* bias, int time_cols) {
   if (R <= 0) {   // nothing to sum: the gradient block is zero
-    TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 256), 256, 0, c.st, c.part, c.cs, 0, 1, c.step_tab, W, ldw, col0, bias, time_cols);
+    TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 32), 256, 0, c.st, c.part, c.cs, 0, 1, c.step_tab, W, ldw, col0, bias, time_cols);
     return TRAJSDE_OK;
   }
   // rows per workgroup: at least WGRAD_CHUNK, and few enough partials (<= ~512) that the second stage stays short
@@ -543,7 +572,7 @@ int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, in
   const int cpg = int((rows_per_group + chunk - 1) / chunk);
   const int P = cpg * groups;
   TS_LAUNCH(k_wgrad, P, 256, (4 * 4096 + 4 * 4 * 64) * 4, c.st, delta, ldd, a, lda, R, rows_per_group, int(chunk), cpg, c.part, c.cs);
-  TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 256), 256, 0, c.st, c.part, c.cs, P, cpg, c.step_tab, W, ldw, col0, bias, time_cols);
+  TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 32), 256, 0, c.st, c.part, c.cs, P, cpg, c.step_tab, W, ldw, col0, bias, time_cols);
   return TRAJSDE_OK;
 }
 int run_colsum(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride) {

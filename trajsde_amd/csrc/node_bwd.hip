@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void k_headwise_outer(const float* __restrict_
 int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64_t N, float* W) {
   const int S = N >= 4096 ? 32 : (N >= 256 ? 8 : 1);
   TS_LAUNCH(k_headwise_outer, dim3(64, S), 256, 0, wc.st, X, Y, N, wc.part);
-  TS_LAUNCH(k_reduce_partials, cdiv(4096, 256), 256, 0, wc.st, wc.part, wc.cs, S, 1, nullptr, W, 64, 0, nullptr, 0);
+  TS_LAUNCH(k_reduce_partials, cdiv(4096, 32), 256, 0, wc.st, wc.part, wc.cs, S, 1, nullptr, W, 64, 0, nullptr, 0);
   return TRAJSDE_OK;
 }
 

@@ -55,6 +55,13 @@ def _grid_slots(source: int):
     return past, fut
 
 
+def _div5(v: torch.Tensor) -> torch.Tensor:
+    """v / 5 with the host's correctly rounded float32 result also for HBM-resident stores: the device's float32
+    division may differ in the last bit, the float64 quotient rounded to float32 cannot (a quotient by 5 is never
+    within 2^-27 of a rounding boundary)"""
+    return (v.double() / 5.0).to(v.dtype) if v.is_cuda else v / 5
+
+
 def _shards(root: str, sub: str) -> List[str]:
     files = sorted(glob.glob(os.path.join(root, sub, "*.safetensors")))
     if not files:
@@ -111,11 +118,10 @@ class nuArgoDataset(torch.utils.data.Dataset):
         for k in ("agent_index", "av_index"):
             sc[k] = torch.as_tensor(sc[k]).to(torch.long).reshape(())
         x, y = sc["x"], sc.get("y")
-        per_step = 5.0 if source == 0 else 1.0        # nuScenes steps span 5 grid slots
-        x = x / per_step if source == 0 else x
+        x = _div5(x) if source == 0 else x            # nuScenes steps span 5 grid slots
         if not self.is_gtabs:
             y = torch.diff(y, dim=1, prepend=torch.zeros_like(y[:, :1]))
-            y = y / per_step if source == 0 else y
+            y = _div5(y) if source == 0 else y
         pad = sc["padding_mask"].clone()
         if "category" in sc:
             cat = sc.pop("category").float()
@@ -247,9 +253,13 @@ class DataModuleNuArgoMix:
         extra = {"device": self.resident_device} if getattr(self, "resident_device", None) else {}
         mk = lambda split, args: self.dataset_module(split, self.nu_root, self.Argo_root, self.nu_dir,
                                                      self.Argo_dir, spec_args=args, **extra)
-        self.train_dataset = mk("train", self.tr_dataset_args)
-        self.val_dataset = mk("val", self.val_dataset_args)
-        self.test_dataset = mk("val", self.test_dataset_args)     # Datamodule_nuargo_mix.py:31
+        # the reference builds all three regardless of `stage`; with stage given only what that stage reads is opened
+        if stage in (None, "fit"):
+            self.train_dataset = mk("train", self.tr_dataset_args)
+        if stage in (None, "fit", "validate"):
+            self.val_dataset = mk("val", self.val_dataset_args)
+        if stage in (None, "test"):
+            self.test_dataset = mk("val", self.test_dataset_args)     # Datamodule_nuargo_mix.py:31
 
     def _loader(self, ds, bs, shuffle):
         return SceneLoader(ds, bs, shuffle=shuffle, device=self.device, rank=self.rank, world_size=self.world_size)

@@ -1,7 +1,8 @@
 """Loss values of the reference's SDE config, computed on the device tensors the forward returns
 (losses/L2.py:10-27 winner-takes-all min-ADE regression; losses/diff_BCE.py:11-16 BCE on the encoder's diffusion
-outputs, real = 0, perturbed = 1).  Forward values only -- used for validation-time reporting; training needs the
-backward kernels, so these are not wired into `training_step`.
+outputs, real = 0, perturbed = 1).  These classes are what the YAML's `losses:` entries resolve to: they give the
+loss *values* (validation-time reporting, tests); `training_step` takes their names and weights and differentiates
+the same two losses inside the HIP backward entry points (trajsde_decoder_l2_backward, trajsde_encoder_backward).
 """
 import torch
 import torch.nn.functional as F

@@ -444,8 +444,13 @@ class GraphContext:
     @classmethod
     def get(cls, data, radius: Optional[float], H: int, noise: Optional[NoiseSpec], fake_agents: bool = True) -> "GraphContext":
         gc = data[cls.KEY] if cls.KEY in data else None
-        if gc is None or (radius is not None and noise is not None):
-            # the encoder (which owns the radius and the fake-agent noise) always rebuilds; the aggregator reuses
+        key = None
+        if radius is not None and noise is not None:
+            key = (float(radius), int(noise.seed), id(noise.z_fake), id(noise.fake_row_ids), bool(fake_agents), id(data["x"]))
+        if gc is None or (key is not None and getattr(gc, "build_key", None) != key):
+            # the encoder (which owns the radius and the fake-agent noise) builds; the aggregator and the backward
+            # entry points of the same step (same noise) reuse
             gc = cls(data, cls.DEFAULT_RADIUS if radius is None else radius, H, noise, fake_agents)
+            gc.build_key = key
             data[cls.KEY] = gc
         return gc
