@@ -246,7 +246,7 @@ int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, 
     TS_LAUNCH(k_lin_t_acc, tile_grid(ntiles, 256, MAT64 * 4), 256, MAT64 * 4, st, blob_bwd + AggBwdBlob::proj(nl, k),
               d_global + int64_t(k) * N * 64, N, w.dxn, k > 0 ? 1 : 0);
   {
-    const int gp = tile_grid(ntiles, 256, ProjBwdL<0>::SIZE * 4);
+    const int gp = vec_grid(ntiles, 256, ProjBwdL<0>::SIZE * 4);
     TS_LAUNCH(k_node_proj_bwd<0>, gp, 256, ProjBwdL<0>::SIZE * 4, st, blob_bwd + AggBwdBlob::norm(nl), w.out[nl - 1], nullptr, w.dxn,
               nullptr, nullptr, nullptr, N, w.dcur, w.XF, w.nb.vpart);
     if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, G("norm.weight"))) return rc;
@@ -289,7 +289,7 @@ int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, 
     if (int rc = run_headwise_outer(wc, w.dagg, w.SS, N, wve)) return rc;
     TS_HIP(hipMemsetAsync(bke, 0, 64 * sizeof(float), st));          // a key bias shifts every logit of a target alike
     if (int rc = run_colsum(st, w.DAGGM, N, 64, 64, bve)) return rc;
-    const int gp = tile_grid(ntiles, 256, ProjBwdL<3>::SIZE * 4);
+    const int gp = vec_grid(ntiles, 256, ProjBwdL<3>::SIZE * 4);
     TS_LAUNCH(k_node_proj_bwd<3>, gp, 256, ProjBwdL<3>::SIZE * 4, st, lb + AggLayerBwdL::PROJ, x_in, w.nb.dx1, w.dxn, w.DQ, w.DKN, w.DVN, N,
               dnext, nullptr, w.nb.vpart);
     if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, n1g)) return rc;

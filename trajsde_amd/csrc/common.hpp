@@ -54,6 +54,12 @@ inline int cdiv(int64_t a, int64_t b) { return int((a + b - 1) / b); }
 
 // grid for a tile kernel whose workgroups each hold an LDS weight image: as many workgroups as fit on the
 // chip at once (LDS- and thread-limited), grid-stride beyond that, never more than the work needs
+// same, for kernels that flush per-wave vector-gradient partials: capped so that the partial slab stays small
+inline int tile_grid(int64_t ntiles, int threads, int lds_bytes);
+inline int vec_grid(int64_t ntiles, int threads, int lds_bytes) {
+  const int g = tile_grid(ntiles, threads, lds_bytes);
+  return g > 512 ? 512 : g;
+}
 inline int tile_grid(int64_t ntiles, int threads, int lds_bytes) {
   const int waves = threads / 64;
   int per_cu = int((160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1));

@@ -546,8 +546,19 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, 
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + c;
   float s = 0.f;
-  if (j < n)
-    for (int64_t w = part; w < rows; w += 16) s += src[w * stride + j];
+  if (j < n) {
+    // four independent partial sums keep several loads in flight (a single workgroup streams the whole slab)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t w = part;
+    for (; w + 48 < rows; w += 64) {
+      s0 += src[w * stride + j];
+      s1 += src[(w + 16) * stride + j];
+      s2 += src[(w + 32) * stride + j];
+      s3 += src[(w + 48) * stride + j];
+    }
+    for (; w < rows; w += 16) s0 += src[w * stride + j];
+    s = (s0 + s1) + (s2 + s3);
+  }
   red[part][c] = s;
   __syncthreads();
   if (part == 0 && j < n) {

@@ -685,7 +685,7 @@ int run_attn_chain(const AttnChain& c, const float* dout, EncBwdWs& w, const Wgr
     if (int rc = run_wgrad(wc, w.DV, 64, w.EMB, 64, E, E, wv, 64, 0, bv, 0)) return rc;
     if (int rc = edge_embed_backward(c.img_emb, c.geom, w.DEMB, E, w.ee, wc, eg, st)) return rc;
   }
-  const int gp = tile_grid((R + 15) / 16, 256, ProjBwdL<1>::SIZE * 4);
+  const int gp = vec_grid((R + 15) / 16, 256, ProjBwdL<1>::SIZE * 4);
   TS_LAUNCH(k_node_proj_bwd<1>, gp, 256, ProjBwdL<1>::SIZE * 4, st, c.img_proj, c.x, w.nb.dx1, w.dxn, w.DQ, nullptr, nullptr, R, dx_out,
             nullptr, w.nb.vpart);
   if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, n1g)) return rc;
@@ -843,7 +843,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
     float *w6 = G(ce + "6.weight"), *b6 = G(ce + "6.bias"), *g7 = G(ce + "7.weight"), *e7 = G(ce + "7.bias");
     float* tok = G("aa_encoder.bos_token");
     TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
-    const int gt = tile_grid((R + 15) / 16, 256, CenterTailL::SIZE * 4);
+    const int gt = vec_grid((R + 15) / 16, 256, CenterTailL::SIZE * 4);
     TS_LAUNCH(k_aa_center_bwd_tail, gt, 256, CenterTailL::SIZE * 4, st, blob_bwd + BB::AA_CTAIL, b->x, g->x_fake, rot, b->bos_mask, g->orig, N,
               Nt, H, w.DCENTER, w.A1, w.A2, w.DA3P, w.DA2P, w.XR, w.nb.vpart);
     float* const tv[4] = {g7, e7, g4, e4};
@@ -852,7 +852,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
     if (int rc = run_wgrad(wc, w.DA3P, 64, w.A2, 64, R, R, w6, 64, 0, b6, 0)) return rc;
     if (int rc = run_wgrad(wc, w.DA2P, 64, w.A1, 64, R, R, w3, 64, 0, b3, 0)) return rc;
     const int lds_br = (EdgeL::WA3 + MAT64) * 4;
-    const int gb = tile_grid((R + 15) / 16, 256, lds_br);
+    const int gb = vec_grid((R + 15) / 16, 256, lds_br);
     TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, blob_bwd + BB::AA_CHEAD, w.XR, w.DA2P, R, w.nb.vpart);
     if (int rc = run_colsum(st, w.nb.vpart, gb * 4, 320, 64, g1)) return rc;
     if (int rc = run_colsum(st, w.nb.vpart + 64, gb * 4, 320, 64, e1)) return rc;

@@ -388,7 +388,7 @@ int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64
 int node_block_backward(const float* img, const NodeBlockTape& tp, const float* dout, int64_t R, const NodeBlockScratch& sc,
                         const WgradCtx& wc, const NodeBlockGrads& gr, float* dagg, float* dxn, hipStream_t st) {
   const int64_t ntiles = (R + 15) / 16;
-  const int ga = tile_grid(ntiles, 256, FfnBwdAL::SIZE * 4), gb = tile_grid(ntiles, 256, FfnBwdBL::SIZE * 4),
+  const int ga = tile_grid(ntiles, 256, FfnBwdAL::SIZE * 4), gb = vec_grid(ntiles, 256, FfnBwdBL::SIZE * 4),
             gu = tile_grid(ntiles, 256, UpdBwdL::SIZE * 4);
   TS_LAUNCH(k_ffn_bwd_a, ga, 256, FfnBwdAL::SIZE * 4, st, img + NodeBlockBwdL::FFN_A, dout, tp.xn2, R, sc.H, sc.DH);
   TS_LAUNCH(k_ffn_bwd_b, gb, 256, FfnBwdBL::SIZE * 4, st, img + NodeBlockBwdL::FFN_B, sc.DH, dout, tp.x1, R, sc.dx1, sc.vpart);
@@ -412,7 +412,7 @@ int edge_embed_backward(const float* img, const float* geom, const float* demb, 
   if (E <= 0) return TRAJSDE_OK;
   const int64_t ntiles = (E + 15) / 16;
   const int lds_tail = EdgeBwdL::WA3T * 4, lds_br = (EdgeL::WA3 + MAT64) * 4;
-  const int gt = tile_grid(ntiles, 256, lds_tail), gb = tile_grid(ntiles, 256, lds_br);
+  const int gt = vec_grid(ntiles, 256, lds_tail), gb = vec_grid(ntiles, 256, lds_br);
   TS_LAUNCH(k_edge_embed_bwd_tail, gt, 256, lds_tail, st, img, geom, demb, E, sc.S, sc.DEP, sc.DSP, sc.A0, sc.B0, sc.vpart);
   float* const tail_vec[4] = {gr.ag3, gr.ae3, gr.ag0, gr.ae0};
   for (int i = 0; i < 4; ++i)

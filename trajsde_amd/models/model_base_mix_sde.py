@@ -59,7 +59,9 @@ class _PathLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (None, None, None, None, None) + tuple(None if x is None else x * g for x in ctx.grads)
+        have = [x for x in ctx.grads if x is not None]
+        scaled = iter(torch._foreach_mul(have, g))                          # a handful of fused launches, not one per tensor
+        return (None, None, None, None, None) + tuple(None if x is None else next(scaled) for x in ctx.grads)
 
 
 class PredictionModelSDENet(nn.Module):

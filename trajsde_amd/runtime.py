@@ -131,6 +131,22 @@ class StageRuntime:
             self._names[stage_id] = [L.trajsde_param_name(stage_id, i, nl, K).decode() for i in range(n)]
         return self._names[stage_id]
 
+    def _grad_buffers(self, stage_id: int) -> Dict[str, torch.Tensor]:
+        """zero-initialised gradient buffers of a *_BWD stage as views of ONE flat tensor (one fill instead of one per
+        parameter), keyed and ordered like param_names(stage_id)"""
+        m = self.module
+        names = self.param_names(stage_id)
+        shapes = [m.p(n).shape for n in names]
+        sizes = [int(np.prod(sh)) if len(sh) else 1 for sh in shapes]
+        # 16-byte aligned slices: kernels store float4 rows into some of them
+        offs, total = [], 0
+        for sz in sizes:
+            offs.append(total)
+            total += (sz + 3) // 4 * 4
+        first = next(m.parameters())
+        flat = torch.zeros(total, device=first.device, dtype=torch.float32)
+        return {n: flat[o:o + sz].view(sh) for n, o, sz, sh in zip(names, offs, sizes, shapes)}
+
     def blob(self, stage_id: Optional[int] = None) -> torch.Tensor:
         """Packed LDS images of this stage's weights (`stage_id`: the forward images by default, or the
         stage's backward images); re-packed whenever a parameter changed."""
@@ -209,7 +225,7 @@ class StageRuntime:
         mask = out["reg_mask"].contiguous().view(torch.uint8)
         L = _lib.lib()
         names = self.param_names(_lib.STAGE_DECODER_BWD)
-        grads = {n: torch.empty_like(m.p(n)) for n in names}
+        grads = self._grad_buffers(_lib.STAGE_DECODER_BWD)
         arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
         loss = torch.empty(1, device=dev, dtype=torch.float32)
         best = torch.empty(N, device=dev, dtype=torch.int32)
@@ -276,7 +292,7 @@ class StageRuntime:
         tab = self._enc_table()
         tab_dev = _TABLES_DEV.setdefault((id(tab), str(dev)), torch.from_numpy(tab).to(dev))
         names = self.param_names(_lib.STAGE_ENCODER_BWD)
-        grads = {n: torch.zeros_like(m.p(n)) for n in names}
+        grads = self._grad_buffers(_lib.STAGE_ENCODER_BWD)
         arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
         loss = torch.empty(1, device=dev, dtype=torch.float32)
         d_lat = torch.empty(N, D, device=dev, dtype=torch.float32) if want_boundaries else None
@@ -361,7 +377,7 @@ class StageRuntime:
         if tuple(d_global.shape) != (K, N, D):
             raise _lib.TrajsdeError(f"d_global must be [{K},{N},{D}]")
         names = self.param_names(_lib.STAGE_AGGREGATOR_BWD)
-        grads = {n: torch.zeros_like(m.p(n)) for n in names}
+        grads = self._grad_buffers(_lib.STAGE_AGGREGATOR_BWD)
         arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
         d_local = torch.empty(N, D, device=dev, dtype=torch.float32)
         ws_bytes = L.trajsde_aggregator_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), nl, K)
