@@ -48,7 +48,11 @@ typedef enum {
    * order of the gradient buffers the stage's backward entry point takes */
   TRAJSDE_STAGE_DECODER_BWD = 3,    /* trajsde_decoder_l2_backward (pi / scale heads get no gradient from that loss) */
   TRAJSDE_STAGE_AGGREGATOR_BWD = 4, /* trajsde_aggregator_backward */
-  TRAJSDE_STAGE_ENCODER_BWD = 5     /* trajsde_encoder_backward */
+  TRAJSDE_STAGE_ENCODER_BWD = 5,    /* trajsde_encoder_backward */
+  /* vanilla HiVT variant (configs/nusargo/hivt_nuSArgo_trmenc_mlpdec.yml): `num_layers` carries the number of
+   * temporal layers for ENCODER_GRID and the number of future steps for DECODER_MLP */
+  TRAJSDE_STAGE_ENCODER_GRID = 6,
+  TRAJSDE_STAGE_DECODER_MLP = 7
 } trajsde_stage;
 
 int trajsde_param_count(int stage, int num_layers /*aggregator*/, int num_modes);
@@ -165,6 +169,11 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
                                int num_modes, const float* local_embed /*[N,64]*/, void* ws, int64_t ws_bytes,
                                float* global_embed /*[K,N,64]*/, void* stream);
 
+/* the same with the head count of the attention spelled out (8: the SDE config, 4: the vanilla HiVT config) */
+int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers,
+                                     int num_modes, int num_heads, const float* local_embed, void* ws, int64_t ws_bytes,
+                                     float* global_embed, void* stream);
+
 /* ---- decoder stage: SDEDecoder (DEC:77-105) with the stock Euler-Maruyama solve over the float32
  *      schedule tables of SURVEY.md App. D (trajsde_amd/schedule.py). */
 int64_t trajsde_decoder_ws_bytes(int32_t N, int num_modes);
@@ -174,6 +183,18 @@ int trajsde_decoder_forward(int32_t N, int num_modes, int future_steps, const fl
                             const float* out_table /*[T,4] (steps_done,w0,w1,0)*/, float min_scale,
                             const trajsde_noise* noise /* z: [n_euler,K*N,64] */, void* ws, int64_t ws_bytes,
                             float* loc /*[K,N,T,4]*/, float* pi /*[N,K]*/, void* stream);
+
+/* ---- vanilla HiVT variant (configs/nusargo/hivt_nuSArgo_trmenc_mlpdec.yml): LocalEncoder.forward
+ *      (enc_hivt_nusargo_grid.py:52-93: AAEncoder, TemporalEncoder :225-292, ALEncoder; graph prepared with A = 0) and
+ *      MLPDecoder.forward (dec_hivt_nusargo_grid.py:47-63).  Blobs: TRAJSDE_STAGE_ENCODER_GRID / _DECODER_MLP. */
+int64_t trajsde_encoder_grid_ws_bytes(const trajsde_batch* b, const trajsde_graph* g);
+int trajsde_encoder_grid_forward(const trajsde_batch* b, const trajsde_graph* g, const float* rotate_mat, const float* blob,
+                                 int num_heads, int num_temporal_layers, void* ws, int64_t ws_bytes,
+                                 float* local_embed /*[N,64]*/, void* stream);
+int64_t trajsde_mlp_decoder_ws_bytes(int32_t N, int num_modes);
+int trajsde_mlp_decoder_forward(int32_t N, int num_modes, int future_steps, const float* blob,
+                                const float* local_embed /*[N,64]*/, const float* global_embed /*[K,N,64]*/, float min_scale,
+                                void* ws, int64_t ws_bytes, float* loc /*[K,N,T,4]*/, float* pi /*[N,K]*/, void* stream);
 
 /* ---- winner-takes-all L2 regression loss (losses/L2.py:10-27) + backward of the decoder stage: gradients of
  *      loss = mean over valid (actor, step) of |y - loc[best mode]| w.r.t. the decoder parameters and the stage

@@ -335,7 +335,7 @@ def global_interactor(P, cfg, batch, rot, local_embed):
         xn = _ln(P, g + ".norm1", x)
         k_e = _lin(P, g + ".lin_k_node", xn)[src] + _lin(P, g + ".lin_k_edge", rel)
         v_e = _lin(P, g + ".lin_v_node", xn)[src] + _lin(P, g + ".lin_v_edge", rel)
-        agg = attention_aggregate(_lin(P, g + ".lin_q_node", xn), k_e, v_e, dst, n)
+        agg = attention_aggregate(_lin(P, g + ".lin_q_node", xn), k_e, v_e, dst, n, heads=cfg.get("num_heads", 8))
         x = x + _lin(P, g + ".out_proj", gated_update(P, g, agg, xn))
         x = x + ff_block(P, g, _ln(P, g + ".norm2", x))
     x = _ln(P, pre + ".norm", x)

@@ -1,0 +1,116 @@
+"""CPU restatement of the vanilla-HiVT variant of the path: `PredictionModel.forward`
+(models/model_base_mix.py:74-92) = LocalEncoder (models/encoders/enc_hivt_nusargo_grid.py: AAEncoder over 21 snapshots,
+TemporalEncoder, ALEncoder) -> GlobalInteractor -> MLPDecoder (models/decoders/dec_hivt_nusargo_grid.py).
+TEST INFRASTRUCTURE ONLY, same rules as restate.py; pinned by tests/golden_grid/*.npz (oracle/make_golden_grid.py).
+Abbreviations: GENC = enc_hivt_nusargo_grid.py, GDEC = dec_hivt_nusargo_grid.py.
+"""
+import torch
+import torch.nn.functional as F
+
+from restate import (D, _lin, _ln, attention_aggregate, ff_block, gated_update, global_interactor, multiple_input_embedding,
+                     rotate2, rotate_inputs, single_input_embedding)
+
+
+def flat_cfg(cfg):
+    e, a, d = cfg["encoder"]["kwargs"], cfg["aggregator"]["kwargs"], cfg["decoder"]["kwargs"]
+    return dict(historical_steps=e["historical_steps"], local_radius=e["local_radius"], num_heads=e["num_heads"],
+                num_temporal_layers=e["num_temporal_layers"], input_diff=e["input_diff"], num_modes=d["num_modes"],
+                future_steps=d["future_steps"], min_scale=d["min_scale"], num_global_layers=a["num_layers"])
+
+
+def temporal_encoder(P, pre, x, padding_mask, heads, layers):
+    """TemporalEncoder.forward GENC:241-249 over nn.TransformerEncoder of pre-norm TemporalEncoderLayers (GENC:258-292),
+    causal mask GENC:251-255; nn.MultiheadAttention semantics: q scaled by dh^-0.5, softmax over keys j <= i."""
+    S, N, _ = x.shape                                                        # [21, N, 64]
+    x = torch.where(padding_mask.t().unsqueeze(-1), P[pre + ".padding_token"], x)
+    x = torch.cat((x, P[pre + ".cls_token"].expand(-1, N, -1)), 0) + P[pre + ".pos_embed"]
+    S += 1
+    dh = D // heads
+    causal = torch.tril(torch.ones(S, S, dtype=torch.bool))
+    for i in range(layers):
+        l = f"{pre}.transformer_encoder.layers.{i}"
+        xn = _ln(P, l + ".norm1", x)
+        qkv = F.linear(xn, P[l + ".self_attn.in_proj_weight"], P[l + ".self_attn.in_proj_bias"])
+        q, k, v = (t.reshape(S, N, heads, dh).permute(1, 2, 0, 3) for t in qkv.chunk(3, -1))    # [N, h, S, dh]
+        att = (q * dh ** -0.5) @ k.transpose(-1, -2)
+        att = att.masked_fill(~causal, float("-inf")).softmax(-1)
+        o = (att @ v).permute(2, 0, 1, 3).reshape(S, N, D)
+        x = x + _lin(P, l + ".self_attn.out_proj", o)
+        x = x + _lin(P, l + ".linear2", F.relu(_lin(P, l + ".linear1", _ln(P, l + ".norm2", x))))
+    return _ln(P, pre + ".transformer_encoder.norm", x)[-1]
+
+
+def local_encoder_grid(P, cfg, batch, rot):
+    """LocalEncoder.forward GENC:52-93"""
+    pre = "encoder"
+    H, radius, heads = cfg["historical_steps"], cfg["local_radius"], cfg["num_heads"]
+    x, pos, pad = batch["x"], batch["positions"], batch["padding_mask"]
+    N = x.shape[0]
+    valid = ~pad[:, :H]
+    src, dst = batch["edge_index"]
+    srcs, dsts, attrs = [], [], []
+    for t in range(H):                                                      # GENC:57-67
+        keep = valid[src, t] & valid[dst, t]
+        s_t, d_t = src[keep], dst[keep]
+        attr = pos[s_t, t] - pos[d_t, t]
+        near = torch.norm(attr, p=2, dim=-1) < radius
+        srcs.append(s_t[near] + t * N)
+        dsts.append(d_t[near] + t * N)
+        attrs.append(attr[near])
+    e_src, e_dst, e_attr = torch.cat(srcs), torch.cat(dsts), torch.cat(attrs)
+    a = pre + ".aa_encoder"                                                 # AAEncoder.forward GENC:135-166
+    xt = x.transpose(0, 1).reshape(H * N, 2)
+    rot_rep = rot.repeat(H, 1, 1)
+    center = single_input_embedding(P, a + ".center_embed", rotate2(xt, rot_rep))
+    if cfg["input_diff"]:
+        center = torch.where(batch["bos_mask"].t().reshape(H * N).unsqueeze(-1), P[a + ".bos_token"].repeat_interleave(N, 0), center)
+    cn = _ln(P, a + ".norm1", center)
+    r_e = rot_rep[e_dst]
+    nbr = multiple_input_embedding(P, a + ".nbr_embed", [rotate2(xt[e_src], r_e), rotate2(e_attr, r_e)])
+    agg = attention_aggregate(_lin(P, a + ".lin_q", cn), _lin(P, a + ".lin_k", nbr), _lin(P, a + ".lin_v", nbr), e_dst, H * N, heads)
+    center = center + _lin(P, a + ".out_proj", gated_update(P, a, agg, cn))
+    center = center + ff_block(P, a, _ln(P, a + ".norm2", center))
+    out = temporal_encoder(P, pre + ".temporal_encoder", center.view(H, N, D), pad[:, :H], heads, cfg["num_temporal_layers"])
+    l = pre + ".al_encoder"                                                 # GENC:80-93 + ALEncoder
+    la, lav = batch["lane_actor_index"], batch["lane_actor_vectors"]
+    near = torch.norm(lav, p=2, dim=-1) < radius
+    l_src, l_dst, lav = la[0][near], la[1][near], lav[near]
+    lane_len = (1 - batch["lane_paddings"]).sum(-1)
+    lp = batch["lane_positions"]
+    ar = torch.arange(lp.size(0))
+    lane_feat = lp[ar, (lane_len - 1).long()] - lp[ar, 0]
+    xn = _ln(P, l + ".norm1", out)
+    r_e = rot[l_dst]
+    lane = multiple_input_embedding(P, l + ".lane_embed", [rotate2(lane_feat[l_src], r_e), rotate2(lav, r_e)])
+    agg = attention_aggregate(_lin(P, l + ".lin_q", xn), _lin(P, l + ".lin_k", lane), _lin(P, l + ".lin_v", lane), l_dst, N, heads)
+    out = out + _lin(P, l + ".out_proj", gated_update(P, l, agg, xn))
+    return out + ff_block(P, l, _ln(P, l + ".norm2", out))
+
+
+def mlp_decoder(P, cfg, batch, local_embed, global_embed):
+    """MLPDecoder.forward GDEC:47-63"""
+    pre = "decoder"
+    K, T = cfg["num_modes"], cfg["future_steps"]
+    N = local_embed.shape[0]
+    loc_exp = local_embed.expand(K, N, D)
+    h = F.relu(_ln(P, pre + ".pi.1", _lin(P, pre + ".pi.0", torch.cat((loc_exp, global_embed), -1))))
+    pi = _lin(P, pre + ".pi.6", F.relu(_ln(P, pre + ".pi.4", _lin(P, pre + ".pi.3", h)))).squeeze(-1).t()
+    out = F.relu(_ln(P, pre + ".aggr_embed.1", _lin(P, pre + ".aggr_embed.0", torch.cat((global_embed, loc_exp), -1))))
+    loc = _lin(P, pre + ".loc.3", F.relu(_ln(P, pre + ".loc.1", _lin(P, pre + ".loc.0", out)))).view(K, N, T, 2)
+    sc = _lin(P, pre + ".scale.3", F.relu(_ln(P, pre + ".scale.1", _lin(P, pre + ".scale.0", out))))
+    sc = F.elu(sc, alpha=1.0).view(K, N, T, 2) + 1.0 + cfg["min_scale"]
+    return {"loc": torch.cat((loc, sc), -1), "pi": pi, "reg_mask": ~batch["padding_mask"][:, -T:]}
+
+
+@torch.no_grad()
+def forward(P, cfg, batch, want_intermediates=False):
+    """PredictionModel.forward, models/model_base_mix.py:74-92 (eval mode)"""
+    c = flat_cfg(cfg) if "encoder" in cfg else cfg
+    rot, y_rot = rotate_inputs(batch)
+    local = local_encoder_grid(P, c, batch, rot)
+    glob = global_interactor(P, dict(c, historical_steps=c["historical_steps"]), batch, rot, local)
+    out = mlp_decoder(P, c, batch, local, glob)
+    out.update(rotate_mat=rot, y=y_rot)
+    if want_intermediates:
+        out.update(local_embed=local, global_embed=glob)
+    return out

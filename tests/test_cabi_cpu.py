@@ -47,3 +47,38 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.TrajsdeError):
         _lib.lib()
+
+
+def test_param_tables_of_backward_and_vanilla_stages():
+    """every *_BWD stage names a subset of its stage's parameters; the vanilla-variant stages cover theirs"""
+    import yaml
+    import helpers as H
+    from trajsde_amd import _lib
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    lib = _lib.lib()
+    model, _ = H.build_model(6, 20, 2.0)
+
+    def names(stage, nl, K):
+        return [lib.trajsde_param_name(stage, i, nl, K).decode() for i in range(lib.trajsde_param_count(stage, nl, K))]
+
+    for stage, mod, nl, K in ((_lib.STAGE_DECODER_BWD, model.decoder, 0, 6), (_lib.STAGE_AGGREGATOR_BWD, model.aggregator, 3, 6),
+                              (_lib.STAGE_ENCODER_BWD, model.encoder, 0, 0)):
+        sd = dict(mod.named_parameters())
+        got = names(stage, nl, K)
+        assert len(set(got)) == len(got) and all(n in sd for n in got)
+    # the aggregator and encoder losses reach everything the forward uses; the decoder's pi / scale heads are not reached
+    assert set(names(_lib.STAGE_AGGREGATOR_BWD, 3, 6)) == set(names(_lib.STAGE_AGGREGATOR, 3, 6))
+    assert set(names(_lib.STAGE_ENCODER_BWD, 0, 0)) == set(names(_lib.STAGE_ENCODER, 0, 0))
+    missing = set(names(_lib.STAGE_DECODER, 0, 6)) - set(names(_lib.STAGE_DECODER_BWD, 0, 6))
+    assert missing and all(n.startswith("pi.") or n.startswith("scale.") for n in missing)
+
+    with open(os.path.join(H.ROOT, "trajsde_amd/configs/mi355x_trmenc_mlpdec.yml")) as f:
+        cfg = yaml.safe_load(f)
+    van = PredictionModel(**cfg, init_seed=0)
+    enc = dict(van.encoder.named_parameters())
+    got = names(_lib.STAGE_ENCODER_GRID, 4, 0)
+    assert all(n in enc for n in got)
+    assert set(enc) - set(got) == {"al_encoder.is_intersection_embed", "al_encoder.turn_direction_embed", "al_encoder.traffic_control_embed"}
+    dec = dict(van.decoder.named_parameters())
+    assert set(names(_lib.STAGE_DECODER_MLP, 60, 10)) == set(dec)
+    assert lib.trajsde_blob_floats(_lib.STAGE_ENCODER_GRID, 4, 0) > lib.trajsde_blob_floats(_lib.STAGE_ENCODER, 0, 0)

@@ -1,5 +1,8 @@
 """CPU suite: the oracle (oracle/restate.py) against the golden vectors made from the reference, plus
 known-answer tests for the third-party semantics it restates."""
+import glob
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -44,6 +47,37 @@ def test_restatement_matches_reference_golden_ood():
     mine = restate.forward(P, cfg, H.clone_batch(batch), restate.PhiloxNoise(int(meta["noise_seed"])), ood=True)
     for key in ("loc", "pi", "stds"):
         assert H.maxdiff(mine[key], out[key]) <= 1e-5, key
+
+
+GRID = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(H.ROOT, "tests", "golden_grid", "*.npz")))
+
+
+@pytest.mark.parametrize("name", GRID)
+def test_vanilla_restatement_matches_reference_golden(name):
+    """oracle/restate_grid.py against the reference's vanilla HiVT model (tests/golden_grid, oracle/make_golden_grid.py).
+    torch's fused multi-head attention orders its sums differently, so the pin is 1e-5 here, not bit-exact."""
+    import restate_grid
+    import yaml
+    from trajsde_amd.data import TemporalData
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    z = np.load(os.path.join(H.ROOT, "tests", "golden_grid", name + ".npz"))
+    batch = TemporalData(**{k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in.")})
+    with open(os.path.join(H.ROOT, "trajsde_amd/configs/mi355x_trmenc_mlpdec.yml")) as f:
+        cfg = yaml.safe_load(f)
+    K, T, heads, layers = (int(z["meta." + k]) for k in ("num_modes", "future_steps", "num_heads", "num_temporal_layers"))
+    cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)
+    cfg["encoder"]["kwargs"].update(num_heads=heads, num_temporal_layers=layers)
+    cfg["aggregator"]["kwargs"].update(num_modes=K, num_heads=heads)
+    cfg["decoder"]["kwargs"].update(num_modes=K, future_steps=T)
+    model = PredictionModel(**cfg, init_seed=int(z["meta.init_seed"]))
+    sd = model.state_dict()
+    assert abs(sum(float(v.double().abs().sum()) for v in sd.values() if torch.isfinite(v).all()) - float(z["meta.state_checksum"])) < 1e-6 * float(z["meta.state_checksum"])
+    out = restate_grid.forward({k: v.detach() for k, v in sd.items()}, cfg, batch, want_intermediates=True)
+    for k in ("loc", "pi"):
+        assert H.maxdiff(out[k], torch.from_numpy(z["out." + k])) <= 1e-5, k
+    assert torch.equal(out["reg_mask"], torch.from_numpy(z["out.reg_mask"]))
+    for k in ("local_embed", "global_embed"):
+        assert H.maxdiff(out[k], torch.from_numpy(z["mid." + k])) <= 1e-5, k
 
 
 def test_oracle_detects_a_wrong_radius():

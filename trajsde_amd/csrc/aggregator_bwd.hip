@@ -233,7 +233,7 @@ int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, 
     const float* lb = blob_fwd + AggBlob::layer(l);
     TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
               w.xn[l], w.q[l], w.kn[l], w.vn[l]);
-    TS_LAUNCH(k_global_attn, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
+    TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
               w.agg[l]);
     TS_LAUNCH(k_node_update<false>, tile_grid(ntiles, 512, UpdL::SIZE * 4), 512, UpdL::SIZE * 4, st, lb + AggLayerL::UPD, w.agg[l], w.xn[l], x,
               N, w.x1[l], w.xn2[l]);

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512) void k_aa_center(const float* __restrict__ img
 template <bool X6>
 __global__ __launch_bounds__(1024) void k_edge_kv(const float* __restrict__ img_g, const float* __restrict__ geom,
                                                  const int32_t* __restrict__ dst, const float* __restrict__ q, int64_t E,
-                                                 float* __restrict__ logits, float* __restrict__ v) {
+                                                 float* __restrict__ logits, float* __restrict__ v, int heads) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using EL = typename std::conditional<X6, EdgeL6, EdgeL>::type;
   stage_blob(lds, img_g, EL::SIZE);
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(1024) void k_edge_kv(const float* __restrict__ img_
     else linear<8, 4>(kv, emb, lds + EL::WKV, lds + EL::BKV, L);
     f4 k[4] = {kv[0], kv[1], kv[2], kv[3]};
     f4 vv[4] = {kv[4], kv[5], kv[6], kv[7]};
-    store_logits(qv, k, logits, e, e < E, L);
+    store_logits(qv, k, logits, e, e < E, L, heads);
     if (e < E) store_row(vv, v, e, L.g);
   }
 }
@@ -184,9 +184,9 @@ __global__ __launch_bounds__(512) void k_global_edge(const float* __restrict__ i
 // Single pass over the slab with an online softmax in chunks of 8 edges (8 logits + 8 value rows in flight per
 // lane); the running maximum is the segment maximum at the end, so the result equals the two-pass form up to rounding.
 __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restrict__ segptr, const float* __restrict__ logits,
-                                                         const float* __restrict__ v, int64_t R, float* __restrict__ agg) {
+                                                         const float* __restrict__ v, int64_t R, float* __restrict__ agg, int heads) {
   const int lane = threadIdx.x & 63;
-  const int head = lane >> 3, slot = 4 * (head & 1) + (head >> 1);
+  const int head = heads == 4 ? lane >> 4 : lane >> 3, slot = heads == 4 ? head : 4 * (head & 1) + (head >> 1);
   const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (node >= R) return;
   const int beg = segptr[node], end = segptr[node + 1];
@@ -228,43 +228,50 @@ __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restri
 // i.e. lin_k_edge is folded into the query once per target (U_h = Wke_h^T q_h, 8 x 64) and lin_v_edge is applied
 // once per target after the aggregation.  Per edge the wave streams one rel row (256 B) and gathers two node rows.
 // Lane l is feature l of the node rows (head l>>3) and holds slice 8*(l&7).. of the rel row / of U for head l>>3.
+template <int HEADS>
 __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                      const int32_t* __restrict__ src, const float* __restrict__ rel,
                                                      const float* __restrict__ q, const float* __restrict__ kn,
                                                      const float* __restrict__ vn, int64_t N, float* __restrict__ agg) {
-  __shared__ __attribute__((aligned(16))) float sbuf[4][8][64 + 4];
+  constexpr int LPH = 64 / HEADS;          // lanes (= head dims) per head: 8, or 16 with 4 heads
+  constexpr int SL = 64 / LPH;             // rel-row columns per lane: a head's 64-wide row is spread over its LPH lanes
+  constexpr int NV = SL / 4;               // ... as float4s
+  constexpr float INV = HEADS == 4 ? 0.25f : INV_SQRT_DH;
+  __shared__ __attribute__((aligned(16))) float sbuf[4][HEADS][64 + 4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int h = lane >> 3, j = lane & 7;
+  const int h = lane / LPH, j = lane % LPH;
   const int64_t node = int64_t(blockIdx.x) * 4 + wv;
   const int64_t nc = node < N ? node : N - 1;
   const float* wke = img + GAttnL::WKE;
   const float* wve = img + GAttnL::WVE;
   const float ql = q[nc * 64 + lane];
-  const float cb = head_sum(ql * img[GAttnL::BKE + lane]);
-  float U[8];
+  const float cb = head_sum_n<HEADS>(ql * img[GAttnL::BKE + lane]);
+  float U[SL];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) U[e] = 0.f;
+  for (int e = 0; e < SL; ++e) U[e] = 0.f;
 #pragma unroll
-  for (int d = 0; d < 8; ++d) {
-    const float qd = __shfl(ql, 8 * h + d);
-    const f4 w0 = *reinterpret_cast<const f4*>(wke + (8 * h + d) * 64 + 8 * j);
-    const f4 w1 = *reinterpret_cast<const f4*>(wke + (8 * h + d) * 64 + 8 * j + 4);
+  for (int d = 0; d < LPH; ++d) {
+    const float qd = __shfl(ql, LPH * h + d);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { U[e] = fmaf(w0[e], qd, U[e]); U[4 + e] = fmaf(w1[e], qd, U[4 + e]); }
+    for (int v4 = 0; v4 < NV; ++v4) {
+      const f4 w = *reinterpret_cast<const f4*>(wke + (LPH * h + d) * 64 + SL * j + 4 * v4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) U[4 * v4 + e] = fmaf(w[e], qd, U[4 * v4 + e]);
+    }
   }
   const int beg = segptr[nc], end = node < N ? segptr[nc + 1] : beg;
-  float m = -INFINITY, s = 0.f, accv = 0.f, accr[8];
+  float m = -INFINITY, s = 0.f, accv = 0.f, accr[SL];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) accr[e] = 0.f;
+  for (int e = 0; e < SL; ++e) accr[e] = 0.f;
   for (int e0 = beg; e0 < end; e0 += 8) {
-    f4 ra[8], rb[8];
+    f4 r[8][NV];
     float knv[8], vnv[8], lg[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u < end ? e0 + u : end - 1;
       const int sidx = src[e];
-      ra[u] = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + 8 * j);
-      rb[u] = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + 8 * j + 4);
+#pragma unroll
+      for (int v4 = 0; v4 < NV; ++v4) r[u][v4] = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + SL * j + 4 * v4);
       knv[u] = kn[int64_t(sidx) * 64 + lane];
       vnv[u] = vn[int64_t(sidx) * 64 + lane];
     }
@@ -273,8 +280,10 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
     for (int u = 0; u < 8; ++u) {
       float p = ql * knv[u];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { p = fmaf(ra[u][e], U[e], p); p = fmaf(rb[u][e], U[4 + e], p); }
-      p = (head_sum(p) + cb) * INV_SQRT_DH;
+      for (int v4 = 0; v4 < NV; ++v4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p = fmaf(r[u][v4][e], U[4 * v4 + e], p);
+      p = (head_sum_n<HEADS>(p) + cb) * INV;
       lg[u] = e0 + u < end ? p : -INFINITY;
       cm = fmaxf(cm, lg[u]);
     }
@@ -284,20 +293,24 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
     s *= sc;
     accv *= sc;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) accr[e] *= sc;
+    for (int e = 0; e < SL; ++e) accr[e] *= sc;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float ex = fast_exp(lg[u] - m);     // masked lanes: exp(-inf) = 0
       s += ex;
       accv = fmaf(ex, vnv[u], accv);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { accr[e] = fmaf(ex, ra[u][e], accr[e]); accr[4 + e] = fmaf(ex, rb[u][e], accr[4 + e]); }
+      for (int v4 = 0; v4 < NV; ++v4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accr[4 * v4 + e] = fmaf(ex, r[u][v4][e], accr[4 * v4 + e]);
     }
   }
   const float inv = 1.0f / (s + 1e-16f);          // PyG softmax denominator
-  // S_h = sum_e alpha_{e,h} rel_e, spread over the 8 lanes of head h -> LDS so every lane of the head sees all 64
-  *reinterpret_cast<f4*>(&sbuf[wv][h][8 * j]) = f4{accr[0] * inv, accr[1] * inv, accr[2] * inv, accr[3] * inv};
-  *reinterpret_cast<f4*>(&sbuf[wv][h][8 * j + 4]) = f4{accr[4] * inv, accr[5] * inv, accr[6] * inv, accr[7] * inv};
+  // S_h = sum_e alpha_{e,h} rel_e, spread over the lanes of head h -> LDS so every lane of the head sees all 64
+#pragma unroll
+  for (int v4 = 0; v4 < NV; ++v4)
+    *reinterpret_cast<f4*>(&sbuf[wv][h][SL * j + 4 * v4]) =
+        f4{accr[4 * v4] * inv, accr[4 * v4 + 1] * inv, accr[4 * v4 + 2] * inv, accr[4 * v4 + 3] * inv};
   float out = fmaf(img[GAttnL::BVE + lane], s * inv, accv * inv);
 #pragma unroll
   for (int k4 = 0; k4 < 16; ++k4) {
@@ -308,6 +321,10 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
   }
   if (node < N) agg[node * 64 + lane] = out;
 }
+template __global__ void k_global_attn<8>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                          const float*, int64_t, float*);
+template __global__ void k_global_attn<4>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                          const float*, int64_t, float*);
 
 // ------------------------------------------------------------------------------------------------ update + FFN
 // gate = sigmoid(lin_ih(agg) + lin_hh(xn)); upd = agg + gate*(lin_self(xn) - agg); x1 = x + out_proj(upd); xn2 = norm2(x1)
@@ -461,8 +478,8 @@ __global__ __launch_bounds__(512) void k_mode_proj(const float* __restrict__ nor
   }
 }
 
-template __global__ void k_edge_kv<false>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*);
-template __global__ void k_edge_kv<true>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*);
+template __global__ void k_edge_kv<false>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*, int);
+template __global__ void k_edge_kv<true>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*, int);
 template __global__ void k_edge_embed<false>(const float*, const float*, int64_t, float*);
 template __global__ void k_edge_embed<true>(const float*, const float*, int64_t, float*);
 template __global__ void k_global_edge<false>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);

@@ -36,10 +36,12 @@ __device__ __forceinline__ void edge_embed(f4 (&emb)[4], const f4 geom, const fl
   layer_norm<4>(emb, lds + E::AG3, lds + E::AE3, L.g);
 }
 
-// per-head logits of 16 edges: q.k over the 8 dims of each head / sqrt(8); heads sit pairwise on lane
-// groups (g, g^1).  Stored as logits[e][slot], slot = 4*(head&1) + (head>>1): one 16-B store per lane pair.
+// per-head logits of 16 edges: q.k over the dims of each head / sqrt(dh).
+// 8 heads (dh = 8): heads sit pairwise on lane groups (g, g^1); stored as logits[e][slot], slot = 4*(head&1) + (head>>1),
+//                   one 16-B store per lane pair.
+// 4 heads (dh = 16): head jt spans all four lane groups; slots 0..3 = heads 0..3 (slots 4..7 unused).
 __device__ __forceinline__ void store_logits(const f4 (&qv)[4], const f4 (&k)[4], float* __restrict__ logits, int64_t e,
-                                             bool valid, const Lane& L) {
+                                             bool valid, const Lane& L, int heads = 8) {
   f4 lg;
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
@@ -47,9 +49,14 @@ __device__ __forceinline__ void store_logits(const f4 (&qv)[4], const f4 (&k)[4]
 #pragma unroll
     for (int c = 1; c < 4; ++c) p = fmaf(qv[jt][c], k[jt][c], p);
     p = xor16_sum(p);
-    lg[jt] = p * INV_SQRT_DH;
+    if (heads == 4) p = xor32_sum(p);
+    lg[jt] = p * (heads == 4 ? 0.25f : INV_SQRT_DH);
   }
-  if (valid && (L.g & 1) == 0) *reinterpret_cast<f4*>(logits + e * 8 + 4 * (L.g >> 1)) = lg;
+  if (heads == 4) {
+    if (valid && L.g == 0) *reinterpret_cast<f4*>(logits + e * 8) = lg;
+  } else if (valid && (L.g & 1) == 0) {
+    *reinterpret_cast<f4*>(logits + e * 8 + 4 * (L.g >> 1)) = lg;
+  }
 }
 
 // sums over the 8 lanes that hold one head when lane = feature (segment / fused-attention kernels)
@@ -62,6 +69,13 @@ __device__ __forceinline__ float dpp_add(float v, int ctrl_tag) {
   return v + __int_as_float(r);
 }
 __device__ __forceinline__ float head_sum(float v) { return dpp_add(dpp_add(dpp_add(v, 0), 1), 2); }   // over the 8 lanes of a head
+__device__ __forceinline__ float head_sum16(float v) {                                                  // over the 16 lanes of a head (4 heads)
+  v = head_sum(v);
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true);              // row_mirror: joins the two halves
+  return v + __int_as_float(r);
+}
+template <int HEADS>
+__device__ __forceinline__ float head_sum_n(float v) { return HEADS == 4 ? head_sum16(v) : head_sum(v); }
 
 
 }  // namespace tsde

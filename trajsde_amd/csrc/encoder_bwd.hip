@@ -736,8 +736,8 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
             g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
   if (Eaa > 0)
     TS_LAUNCH(k_edge_kv<false>, tile_grid((Eaa + 15) / 16, 1024, EdgeL::SIZE * 4), 1024, EdgeL::SIZE * 4, st, blob_fwd + FB::AA_EDGE,
-              g->aa_geom, g->aa_dst, w.q, Eaa, w.logits, w.v);
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, g->aa_segptr, w.logits, w.v, R, w.agg);
+              g->aa_geom, g->aa_dst, w.q, Eaa, w.logits, w.v, 8);
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, g->aa_segptr, w.logits, w.v, R, w.agg, 8);
   TS_LAUNCH(k_node_update<false>, tile_grid((R + 15) / 16, 512, UpdL::SIZE * 4), 512, UpdL::SIZE * 4, st, blob_fwd + FB::AA_UPD, w.agg, w.cn,
             w.center, R, w.x1, w.xn2);
   TS_LAUNCH(k_ffn, tile_grid((R + 15) / 16, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, blob_fwd + FB::AA_FFN, w.x1, w.xn2, R, w.aa_out);
@@ -758,8 +758,8 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
             blob_fwd + FB::AL_Q, w.lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
   if (Ela > 0)
     TS_LAUNCH(k_edge_kv<false>, tile_grid((Ela + 15) / 16, 1024, EdgeL::SIZE * 4), 1024, EdgeL::SIZE * 4, st, blob_fwd + FB::AL_EDGE,
-              g->la_geom, g->la_dst, w.al_q, Ela, w.al_logits, w.al_v);
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(N, 4), 256, 0, st, g->la_segptr, w.al_logits, w.al_v, int64_t(N), w.al_agg);
+              g->la_geom, g->la_dst, w.al_q, Ela, w.al_logits, w.al_v, 8);
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(N, 4), 256, 0, st, g->la_segptr, w.al_logits, w.al_v, int64_t(N), w.al_agg, 8);
   TS_LAUNCH(k_node_update<false>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL::SIZE * 4), 512, UpdL::SIZE * 4, st, blob_fwd + FB::AL_UPD,
             w.al_agg, w.al_xn, w.lat, int64_t(N), w.al_x1, w.al_xn2);
 

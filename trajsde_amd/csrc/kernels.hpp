@@ -10,15 +10,17 @@ namespace tsde {
 __global__ void k_aa_center(const float* img, const float* x, const float* x_fake, const float* rot, const uint8_t* bos,
                             const int32_t* orig, int N, int Nt, int H, float* center, float* cn, float* q);
 template <bool X6>
-__global__ void k_edge_kv(const float* img, const float* geom, const int32_t* dst, const float* q, int64_t E, float* logits, float* v);
+__global__ void k_edge_kv(const float* img, const float* geom, const int32_t* dst, const float* q, int64_t E, float* logits, float* v,
+                          int heads);
 template <bool X6>
 __global__ void k_edge_embed(const float* img, const float* geom, int64_t E, float* emb_out);
 template <bool X6>
 __global__ void k_global_edge(const float* img, const float* rel, const int32_t* src, const int32_t* dst, const float* q,
                               const float* kn, const float* vn, int64_t E, float* logits, float* v);
+template <int HEADS>
 __global__ void k_global_attn(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
                               const float* vn, int64_t N, float* agg);
-__global__ void k_seg_softmax_agg(const int32_t* segptr, const float* logits, const float* v, int64_t R, float* agg);
+__global__ void k_seg_softmax_agg(const int32_t* segptr, const float* logits, const float* v, int64_t R, float* agg, int heads);
 template <bool X6>
 __global__ void k_node_update(const float* img, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2);
 __global__ void k_ffn6(const float* img, const float* x1, const float* xn2, int64_t R, float* out);
@@ -44,6 +46,13 @@ __global__ void k_enc_recur_coop(const float* sde_img, const float* gru_img, con
                                  int TT, int tiles_per_wg, StepTab tab, int noise_step0, NoiseArg na, const uint8_t* nus, const uint8_t* pad,
                                  const int32_t* orig, const int32_t* eos, const int32_t* pick_slot, float* kept, float* diff_pick,
                                  float* latent_ys);
+// vanilla HiVT variant (grid.hip)
+__global__ void k_tr_prep(const float* aa_out, const uint8_t* pad, const float* tok, int N, int TT, float* X);
+template <int HEADS>
+__global__ void k_tr_attention(const float* q, const float* k, const float* v, int N, float* o);
+__global__ void k_tr_outproj(const float* img, const float* o, const float* x, int64_t R, float* x1, float* xn2);
+__global__ void k_tr_final(const float* norm, const float* x, int N, float* out);
+
 __global__ void k_ood_stats(const float* samples, int S, int N, float* mean, float* stds);
 
 }  // namespace tsde

@@ -237,6 +237,45 @@ struct DecBlob {
   enum : int { INIT = 0, SDE = INIT + DecInitL::SIZE, SDE6 = SDE + DecSdeL::SIZE, SIZE = SDE6 + DecSdeL6::SIZE };
 };
 
+// ---- vanilla HiVT variant (grid.hip): TemporalEncoder (GENC:241-292) and MLPDecoder (GDEC:11-63)
+struct TrOutL {       // self_attn.out_proj + norm2
+  enum : int { S_END = 0, TS_FIELD(WOUT, MAT64, S), TS_FIELD(BOUT, 64, WOUT), TS_FIELD(N2G, 64, BOUT), TS_FIELD(N2B, 64, N2G), SIZE = N2B_END };
+};
+struct TrLayerL {     // norm1 + in_proj (q | k | v), out_proj + norm2, linear1 / linear2
+  enum : int { QKV = 0, OUT = QKV + NodeProjL<3>::SIZE, FFN = OUT + TrOutL::SIZE, SIZE = FFN + FfnL::SIZE };
+};
+struct EncGridBlob {  // the AA / AL images at their EncBlob offsets (SDE / GRU regions unused), then the temporal encoder
+  static constexpr int TOK = EncBlob::SIZE;                      // padding_token [21][64] | cls_token [64] | pos_embed [22][64]
+  static constexpr int TOK_PAD = 0, TOK_CLS = 21 * 64, TOK_POS = 22 * 64, TOK_SIZE = 44 * 64;
+  static constexpr int layer(int i) { return TOK + TOK_SIZE + i * TrLayerL::SIZE; }
+  static constexpr int norm(int nl) { return layer(nl); }        // gamma | beta of transformer_encoder.norm
+  static constexpr int size(int nl) { return norm(nl) + 128; }
+};
+struct MlpInitL {     // aggr_embed (-> out) and the three-layer pi head
+  enum : int {
+    S_END = 0,
+    TS_FIELD(WA_G, MAT64, S), TS_FIELD(WA_L, MAT64, WA_G), TS_FIELD(BA, 64, WA_L), TS_FIELD(AG, 64, BA), TS_FIELD(AE, 64, AG),
+    TS_FIELD(WP_L, MAT64, AE), TS_FIELD(WP_G, MAT64, WP_L), TS_FIELD(BP, 64, WP_G), TS_FIELD(PG, 64, BP), TS_FIELD(PE, 64, PG),
+    TS_FIELD(WP3, MAT64, PE), TS_FIELD(BP3, 64, WP3), TS_FIELD(PG4, 64, BP3), TS_FIELD(PE4, 64, PG4),
+    TS_FIELD(WP6, 64, PE4), TS_FIELD(BP6, 4, WP6),
+    SIZE = BP6_END
+  };
+};
+struct MlpHeadsL {    // loc and scale: Linear LN ReLU Linear(64, 2T), the last matrix zero-padded to 128 rows
+  enum : int {
+    S_END = 0,
+    TS_FIELD(L_W0, MAT64, S), TS_FIELD(L_B0, 64, L_W0), TS_FIELD(L_G, 64, L_B0), TS_FIELD(L_E, 64, L_G),
+    TS_FIELD(L_W3, 2 * MAT64, L_E), TS_FIELD(L_B3, 128, L_W3),
+    TS_FIELD(S_W0, MAT64, L_B3), TS_FIELD(S_B0, 64, S_W0), TS_FIELD(S_G, 64, S_B0), TS_FIELD(S_E, 64, S_G),
+    TS_FIELD(S_W3, 2 * MAT64, S_E), TS_FIELD(S_B3, 128, S_W3),
+    SIZE = S_B3_END
+  };
+};
+struct MlpDecBlob {
+  enum : int { INIT = 0, HEADS = MlpInitL::SIZE, SIZE = HEADS + MlpHeadsL::SIZE };
+};
+static_assert(MlpInitL::SIZE * 4 <= 160 * 1024 && MlpHeadsL::SIZE * 4 <= 160 * 1024, "MLP decoder images must fit LDS");
+
 // ---- backward images of the decoder stage (decoder_bwd.hip): `*T` fields hold the TRANSPOSED matrix in
 // fragment order, so dX^T = W^T dY^T runs through the same linear_acc as the forward pass
 struct SweepL {       // reverse Euler-Maruyama sweep: drift and diffusion nets

@@ -38,6 +38,15 @@ __global__ void k_pack_mat(const float* __restrict__ src, float* __restrict__ ds
   dst[i] = src[(16 * jo + (lane & 15)) * ld + col0 + 16 * q + 4 * (lane >> 4) + c];
 }
 
+// k_pack_mat with the rows >= rows_valid written as zeros (a weight whose row count is not a multiple of 16)
+__global__ void k_pack_mat_pad(const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld, int rows_valid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= jto * jti * 256) return;
+  const int c = i & 3, lane = (i >> 2) & 63, q = (i >> 8) % jti, jo = (i >> 8) / jti;
+  const int row = 16 * jo + (lane & 15);
+  dst[i] = row < rows_valid ? src[row * ld + 16 * q + 4 * (lane >> 4) + c] : 0.f;
+}
+
 // fragment image [jo < jto][q < jti][lane][4] of a TRANSPOSED weight: element [r][c] = W[c][col0 + r] (W row-major, ld)
 __global__ void k_pack_matT(const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld, int col0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,6 +108,11 @@ struct Packer {
     if (dry) return;
     const int jto = rows / 16, jti = cols / 16;
     k_pack_mat<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, col0);
+  }
+  void mat_pad(const std::string& n, int dst, int jto, int jti, int ld, int rows_valid) {
+    const float* s = src(n);
+    if (dry) return;
+    k_pack_mat_pad<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, rows_valid);
   }
   // transposed image of the [16*jti x 16*jto] block of W starting at column col0 (default: a 64x64 block)
   void matT(const std::string& n, int dst, int ld, int col0 = 0, int jto = 4, int jti = 4) {
@@ -258,7 +272,8 @@ static void recipe_diff6(Packer& P, const std::string& p, int base) {
   P.vec(p + ".net.4.bias", base + L::B4, 1);
 }
 
-static void recipe_encoder(Packer& P) {
+// AAEncoder + ALEncoder images (shared by the SDE encoder and the vanilla one)
+static void recipe_encoder_attention(Packer& P) {
   using B = EncBlob;
   {  // AAEncoder node path
     using L = AaCenterL;
@@ -280,6 +295,25 @@ static void recipe_encoder(Packer& P) {
   P.vec("aa_encoder.lin_k.bias", B::AA_EDGE + EdgeL::BKV, 64);
   P.vec("aa_encoder.lin_v.bias", B::AA_EDGE + EdgeL::BKV + 64, 64);
   recipe_upd_ffn(P, "aa_encoder", B::AA_UPD, B::AA_FFN);
+  P.ln("al_encoder.norm1", B::AL_Q + NodeProjL<1>::N1G, B::AL_Q + NodeProjL<1>::N1B);
+  P.lin("al_encoder.lin_q", B::AL_Q + NodeProjL<1>::W, B::AL_Q + NodeProjL<1>::B);
+  recipe_edge_embed(P, "al_encoder.lane_embed", B::AL_EDGE);
+  P.mat("al_encoder.lin_k.weight", B::AL_EDGE + EdgeL::WKV, 64, 64, 64);
+  P.mat("al_encoder.lin_v.weight", B::AL_EDGE + EdgeL::WKV + MAT64, 64, 64, 64);
+  P.vec("al_encoder.lin_k.bias", B::AL_EDGE + EdgeL::BKV, 64);
+  P.vec("al_encoder.lin_v.bias", B::AL_EDGE + EdgeL::BKV + 64, 64);
+  recipe_upd_ffn(P, "al_encoder", B::AL_UPD, B::AL_FFN);
+  recipe_edge_embed6(P, "aa_encoder.nbr_embed", B::AA_EDGE6);
+  pack_kv6(P, "aa_encoder.lin_k", "aa_encoder.lin_v", B::AA_EDGE6 + EdgeL6::WKV, B::AA_EDGE6 + EdgeL6::BKV);
+  recipe_edge_embed6(P, "al_encoder.lane_embed", B::AL_EDGE6);
+  pack_kv6(P, "al_encoder.lin_k", "al_encoder.lin_v", B::AL_EDGE6 + EdgeL6::WKV, B::AL_EDGE6 + EdgeL6::BKV);
+  recipe_upd_ffn6(P, "aa_encoder", B::AA_UPD6, B::AA_FFN6);
+  recipe_upd_ffn6(P, "al_encoder", B::AL_UPD6, B::AL_FFN6);
+}
+
+static void recipe_encoder(Packer& P) {
+  using B = EncBlob;
+  recipe_encoder_attention(P);
   recipe_drift(P, "lsde_func.f_func", B::SDE + EncSdeL::F);
   recipe_diff(P, "lsde_func.g_nus", B::SDE + EncSdeL::GN);
   recipe_diff(P, "lsde_func.g_argo", B::SDE + EncSdeL::GA);
@@ -300,20 +334,58 @@ static void recipe_encoder(Packer& P) {
     P.lin("gru_unit.new_state_net.2", g + L::WN2, g + L::BN2);
   }
   P.vec("hidden", B::HIDDEN, 64);
-  P.ln("al_encoder.norm1", B::AL_Q + NodeProjL<1>::N1G, B::AL_Q + NodeProjL<1>::N1B);
-  P.lin("al_encoder.lin_q", B::AL_Q + NodeProjL<1>::W, B::AL_Q + NodeProjL<1>::B);
-  recipe_edge_embed(P, "al_encoder.lane_embed", B::AL_EDGE);
-  P.mat("al_encoder.lin_k.weight", B::AL_EDGE + EdgeL::WKV, 64, 64, 64);
-  P.mat("al_encoder.lin_v.weight", B::AL_EDGE + EdgeL::WKV + MAT64, 64, 64, 64);
-  P.vec("al_encoder.lin_k.bias", B::AL_EDGE + EdgeL::BKV, 64);
-  P.vec("al_encoder.lin_v.bias", B::AL_EDGE + EdgeL::BKV + 64, 64);
-  recipe_upd_ffn(P, "al_encoder", B::AL_UPD, B::AL_FFN);
-  recipe_edge_embed6(P, "aa_encoder.nbr_embed", B::AA_EDGE6);
-  pack_kv6(P, "aa_encoder.lin_k", "aa_encoder.lin_v", B::AA_EDGE6 + EdgeL6::WKV, B::AA_EDGE6 + EdgeL6::BKV);
-  recipe_edge_embed6(P, "al_encoder.lane_embed", B::AL_EDGE6);
-  pack_kv6(P, "al_encoder.lin_k", "al_encoder.lin_v", B::AL_EDGE6 + EdgeL6::WKV, B::AL_EDGE6 + EdgeL6::BKV);
-  recipe_upd_ffn6(P, "aa_encoder", B::AA_UPD6, B::AA_FFN6);
-  recipe_upd_ffn6(P, "al_encoder", B::AL_UPD6, B::AL_FFN6);
+}
+
+// vanilla LocalEncoder (GENC:52-93): AA / AL as above + TemporalEncoder with `nl` layers
+static void recipe_encoder_grid(Packer& P, int nl) {
+  recipe_encoder_attention(P);
+  const std::string t = "temporal_encoder.";
+  const int tok = EncGridBlob::TOK;
+  P.vec(t + "padding_token", tok + EncGridBlob::TOK_PAD, 21 * 64);
+  P.vec(t + "cls_token", tok + EncGridBlob::TOK_CLS, 64);
+  P.vec(t + "pos_embed", tok + EncGridBlob::TOK_POS, 22 * 64);
+  for (int i = 0; i < nl; ++i) {
+    const std::string l = t + "transformer_encoder.layers." + std::to_string(i);
+    const int b = EncGridBlob::layer(i);
+    using Q = NodeProjL<3>;
+    P.ln(l + ".norm1", b + TrLayerL::QKV + Q::N1G, b + TrLayerL::QKV + Q::N1B);
+    P.mat(l + ".self_attn.in_proj_weight", b + TrLayerL::QKV + Q::W, 192, 64, 64);     // rows q | k | v
+    P.vec(l + ".self_attn.in_proj_bias", b + TrLayerL::QKV + Q::B, 192);
+    P.lin(l + ".self_attn.out_proj", b + TrLayerL::OUT + TrOutL::WOUT, b + TrLayerL::OUT + TrOutL::BOUT);
+    P.ln(l + ".norm2", b + TrLayerL::OUT + TrOutL::N2G, b + TrLayerL::OUT + TrOutL::N2B);
+    P.lin(l + ".linear1", b + TrLayerL::FFN + FfnL::W1, b + TrLayerL::FFN + FfnL::B1, 256, 64);
+    P.lin(l + ".linear2", b + TrLayerL::FFN + FfnL::W2, b + TrLayerL::FFN + FfnL::B2, 64, 256);
+  }
+  P.ln(t + "transformer_encoder.norm", EncGridBlob::norm(nl), EncGridBlob::norm(nl) + 64);
+}
+
+// MLPDecoder (GDEC:11-63) for T future steps (2T <= 128 outputs per head)
+static void recipe_decoder_mlp(Packer& P, int T) {
+  using I = MlpInitL;
+  using H = MlpHeadsL;
+  const int b = MlpDecBlob::INIT, h = MlpDecBlob::HEADS;
+  P.mat("aggr_embed.0.weight", b + I::WA_G, 64, 64, 128, 0);      // cat(global, local)
+  P.mat("aggr_embed.0.weight", b + I::WA_L, 64, 64, 128, 64);
+  P.vec("aggr_embed.0.bias", b + I::BA, 64);
+  P.ln("aggr_embed.1", b + I::AG, b + I::AE);
+  P.mat("pi.0.weight", b + I::WP_L, 64, 64, 128, 0);              // cat(local, global)
+  P.mat("pi.0.weight", b + I::WP_G, 64, 64, 128, 64);
+  P.vec("pi.0.bias", b + I::BP, 64);
+  P.ln("pi.1", b + I::PG, b + I::PE);
+  P.lin("pi.3", b + I::WP3, b + I::BP3);
+  P.ln("pi.4", b + I::PG4, b + I::PE4);
+  P.vec("pi.6.weight", b + I::WP6, 64);
+  P.vec("pi.6.bias", b + I::BP6, 1);
+  const char* heads[2] = {"loc", "scale"};
+  const int w0[2] = {H::L_W0, H::S_W0}, b0[2] = {H::L_B0, H::S_B0}, g[2] = {H::L_G, H::S_G}, e[2] = {H::L_E, H::S_E},
+            w3[2] = {H::L_W3, H::S_W3}, b3[2] = {H::L_B3, H::S_B3};
+  for (int k = 0; k < 2; ++k) {
+    const std::string p = heads[k];
+    P.lin(p + ".0", h + w0[k], h + b0[k]);
+    P.ln(p + ".1", h + g[k], h + e[k]);
+    P.mat_pad(p + ".3.weight", h + w3[k], 8, 4, 64, 2 * T);       // [2T, 64] zero-padded to 128 rows
+    P.vec(p + ".3.bias", h + b3[k], 2 * T);
+  }
 }
 
 static void recipe_aggregator(Packer& P, int nl, int K) {
@@ -537,6 +609,8 @@ static bool run_recipe(Packer& P, int stage, int nl, int K) {
     case TRAJSDE_STAGE_DECODER_BWD: recipe_decoder_bwd(P); return true;
     case TRAJSDE_STAGE_AGGREGATOR_BWD: recipe_aggregator_bwd(P, nl, K); return true;
     case TRAJSDE_STAGE_ENCODER_BWD: recipe_encoder_bwd(P); return true;
+    case TRAJSDE_STAGE_ENCODER_GRID: recipe_encoder_grid(P, nl); return true;
+    case TRAJSDE_STAGE_DECODER_MLP: recipe_decoder_mlp(P, nl); return true;
   }
   return false;
 }
@@ -639,6 +713,8 @@ int64_t trajsde_blob_floats(int stage, int num_layers, int num_modes) {
     case TRAJSDE_STAGE_DECODER_BWD: return DecBwdBlob::SIZE;
     case TRAJSDE_STAGE_AGGREGATOR_BWD: return AggBwdBlob::size(num_layers, num_modes);
     case TRAJSDE_STAGE_ENCODER_BWD: return EncBwdBlob::SIZE;
+    case TRAJSDE_STAGE_ENCODER_GRID: return EncGridBlob::size(num_layers);
+    case TRAJSDE_STAGE_DECODER_MLP: return MlpDecBlob::SIZE;
   }
   return fail(TRAJSDE_ERR_INVALID, "unknown stage");
 }

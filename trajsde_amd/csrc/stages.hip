@@ -79,8 +79,8 @@ static int update_ffn(const NodeImgs& im, const float* agg, const float* xn, con
   return TRAJSDE_OK;
 }
 static int attention_tail(const NodeImgs& im, const int32_t* segptr, const float* logits, const float* v, const float* xn, const float* x,
-                          int64_t R, float* agg, float* x1, float* xn2, float* out, hipStream_t st) {
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, segptr, logits, v, R, agg);
+                          int64_t R, float* agg, float* x1, float* xn2, float* out, hipStream_t st, int heads = 8) {
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, segptr, logits, v, R, agg, heads);
   return update_ffn(im, agg, xn, x, R, x1, xn2, out, st);
 }
 
@@ -98,7 +98,7 @@ int64_t trajsde_encoder_ws_bytes(const trajsde_batch* b, const trajsde_graph* g)
 
 // AAEncoder on the H snapshots at once (ENC:112-121, 538-566) -> aa_out [H, Nt, 64]
 static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob, EncWs& w, float* aa_out,
-                          hipStream_t st) {
+                          hipStream_t st, int heads = 8) {
   const int N = b->N, Nt = g->Nt, H = b->H;
   const int64_t R = int64_t(H) * Nt;
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob + EncBlob::AA_CENTER,
@@ -106,13 +106,13 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
   if (g->E_aa > 0) {
     if (edge_x6())
       TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv<true>, tile_grid((int64_t(g->E_aa) + 15) / 16, threads_edge(), EdgeL6::SIZE * 4), threads_edge(),
-                    EdgeL6::SIZE * 4, st, blob + EncBlob::AA_EDGE6, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v);
+                    EdgeL6::SIZE * 4, st, blob + EncBlob::AA_EDGE6, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v, heads);
     else
       TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv<false>, tile_grid((int64_t(g->E_aa) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(),
-                    EdgeL::SIZE * 4, st, blob + EncBlob::AA_EDGE, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v);
+                    EdgeL::SIZE * 4, st, blob + EncBlob::AA_EDGE, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v, heads);
   }
   const NodeImgs im{blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, blob + EncBlob::AA_UPD6, blob + EncBlob::AA_FFN6};
-  return attention_tail(im, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg, w.x1, w.xn2, aa_out, st);
+  return attention_tail(im, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg, w.x1, w.xn2, aa_out, st, heads);
 }
 
 // one pass of the latent SDE + GRU recurrence; iteration idx consumes history step t = H-1-idx (ENC:128-182)
@@ -150,20 +150,20 @@ static int run_recurrence(const trajsde_batch* b, const trajsde_graph* g, const 
 
 // ALEncoder (ENC:198-200, 732-797): lat [N,64] -> local_embed [N,64]
 static int run_al_encoder(const trajsde_batch* b, const trajsde_graph* g, const float* blob, EncWs& w, const float* lat,
-                          float* local_embed, hipStream_t st) {
+                          float* local_embed, hipStream_t st, int heads = 8) {
   const int N = b->N;
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob + EncBlob::AL_Q, lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
   if (g->E_la > 0) {
     if (edge_x6())
       TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv<true>, tile_grid((int64_t(g->E_la) + 15) / 16, threads_edge(), EdgeL6::SIZE * 4), threads_edge(),
-                    EdgeL6::SIZE * 4, st, blob + EncBlob::AL_EDGE6, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v);
+                    EdgeL6::SIZE * 4, st, blob + EncBlob::AL_EDGE6, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v, heads);
     else
       TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv<false>, tile_grid((int64_t(g->E_la) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(),
-                    EdgeL::SIZE * 4, st, blob + EncBlob::AL_EDGE, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v);
+                    EdgeL::SIZE * 4, st, blob + EncBlob::AL_EDGE, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v, heads);
   }
   const NodeImgs im{blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, blob + EncBlob::AL_UPD6, blob + EncBlob::AL_FFN6};
-  return attention_tail(im, g->la_segptr, w.al_logits, w.al_v, w.al_xn, lat, N, w.al_agg, w.al_x1, w.al_xn2, local_embed, st);
+  return attention_tail(im, g->la_segptr, w.al_logits, w.al_v, w.al_xn, lat, N, w.al_agg, w.al_x1, w.al_xn2, local_embed, st, heads);
 }
 
 int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob,
@@ -218,6 +218,49 @@ int trajsde_encoder_forward_ood(const trajsde_batch* b, const trajsde_graph* g, 
   return run_al_encoder(b, g, blob, w, mean, local_embed, st);
 }
 
+// vanilla LocalEncoder.forward (GENC:52-93): AAEncoder on the 21 snapshots (no fake agents: graph prepared with A = 0),
+// TemporalEncoder per actor, ALEncoder.
+int64_t trajsde_encoder_grid_ws_bytes(const trajsde_batch* b, const trajsde_graph* g) {
+  if (!b || !g) return -1;
+  EncWs w(b, g, nullptr, 0);
+  return w.total + 9 * align_up(int64_t(b->N) * 22 * 64 * 4, 256) + align_up(int64_t(b->N) * 64 * 4, 256) + 1024;
+}
+
+int trajsde_encoder_grid_forward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob, int num_heads,
+                                 int num_temporal_layers, void* ws, int64_t ws_bytes, float* local_embed, void* stream_) {
+  TS_REQUIRE(b && g && rot && blob && ws && local_embed, "encoder_grid_forward: null pointer");
+  TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_grid_forward: graph not compacted");
+  TS_REQUIRE(b->A == 0 && g->Nt == b->N, "encoder_grid_forward: prepare the graph with A = 0 (no fake agents)");
+  TS_REQUIRE(b->H == 21, "encoder_grid_forward: the temporal kernels are built for historical_steps = 21");
+  TS_REQUIRE(num_heads == 8 || num_heads == 4, "encoder_grid_forward: num_heads must be 8 or 4");
+  TS_REQUIRE(num_temporal_layers >= 1, "encoder_grid_forward: no temporal layers");
+  if (ws_bytes < trajsde_encoder_grid_ws_bytes(b, g)) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_grid_forward: workspace too small");
+  EncWs w(b, g, ws, ws_bytes);
+  Carver extra(static_cast<char*>(ws) + align_up(w.total, 256), ws_bytes - align_up(w.total, 256));
+  const int N = b->N;
+  const int64_t R = int64_t(N) * 22, rtiles = (R + 15) / 16;
+  float *xa = extra.take<float>(R * 64), *xb = extra.take<float>(R * 64), *xn = extra.take<float>(R * 64), *q = extra.take<float>(R * 64),
+        *k = extra.take<float>(R * 64), *v = extra.take<float>(R * 64), *o = extra.take<float>(R * 64), *x1 = extra.take<float>(R * 64),
+        *xn2 = extra.take<float>(R * 64), *tout = extra.take<float>(int64_t(N) * 64);
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (int rc = run_aa_encoder(b, g, rot, blob, w, w.aa_out, st, num_heads)) return rc;
+  TS_LAUNCH(k_tr_prep, cdiv(R * 64, 256), 256, 0, st, w.aa_out, b->padding_mask, blob + EncGridBlob::TOK, N, b->TT, xa);
+  float* x = xa;
+  float* nx = xb;
+  for (int l = 0; l < num_temporal_layers; ++l) {
+    const float* lb = blob + EncGridBlob::layer(l);
+    TS_LAUNCH(k_node_proj<3>, tile_grid(rtiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + TrLayerL::QKV, x, R, xn, q, k,
+              v);
+    if (num_heads == 4) TS_LAUNCH(k_tr_attention<4>, cdiv(N, 4), 256, 0, st, q, k, v, N, o);
+    else TS_LAUNCH(k_tr_attention<8>, cdiv(N, 4), 256, 0, st, q, k, v, N, o);
+    TS_LAUNCH(k_tr_outproj, tile_grid(rtiles, 512, TrOutL::SIZE * 4), 512, TrOutL::SIZE * 4, st, lb + TrLayerL::OUT, o, x, R, x1, xn2);
+    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, x1, xn2, R, nx);
+    float* t = x; x = nx; nx = t;
+  }
+  TS_LAUNCH(k_tr_final, tile_grid((int64_t(N) + 15) / 16, 256, 0), 256, 0, st, blob + EncGridBlob::norm(num_temporal_layers), x, N, tout);
+  return run_al_encoder(b, g, blob, w, tout, local_embed, st, num_heads);
+}
+
 int64_t trajsde_aggregator_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int num_modes) {
   if (!b || !g) return -1;
   (void)num_modes;
@@ -227,7 +270,14 @@ int64_t trajsde_aggregator_ws_bytes(const trajsde_batch* b, const trajsde_graph*
 
 int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers, int num_modes,
                                const float* local_embed, void* ws, int64_t ws_bytes, float* global_embed, void* stream_) {
+  return trajsde_aggregator_forward_heads(b, g, blob, num_layers, num_modes, 8, local_embed, ws, ws_bytes, global_embed, stream_);
+}
+
+int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers, int num_modes,
+                                     int num_heads, const float* local_embed, void* ws, int64_t ws_bytes, float* global_embed,
+                                     void* stream_) {
   TS_REQUIRE(b && g && blob && local_embed && ws && global_embed, "aggregator_forward: null pointer");
+  TS_REQUIRE(num_heads == 8 || num_heads == 4, "aggregator_forward: num_heads must be 8 or 4");
   TS_REQUIRE(g->g_src && g->g_segptr, "aggregator_forward: graph not compacted (call trajsde_graph_compact)");
   TS_REQUIRE(num_layers >= 0 && num_modes > 0, "aggregator_forward: bad layer/mode count");
   AggWs w(b, g, ws, ws_bytes);
@@ -250,10 +300,14 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
               w.xn, w.q, w.kn, w.vn);
     float* out = bufs[i & 1];
     const NodeImgs im{lb + AggLayerL::UPD, lb + AggLayerL::FFN, lb + AggLayerL::UPD6, lb + AggLayerL::FFN6};
-    static const bool fused = []() { const char* e = getenv("TRAJSDE_GLOBAL_UNFUSED"); return !(e && atoi(e) != 0); }();
+    static const bool fused_env = []() { const char* e = getenv("TRAJSDE_GLOBAL_UNFUSED"); return !(e && atoi(e) != 0); }();
+    const bool fused = fused_env || num_heads != 8;           // the unfused edge kernel exists for 8 heads only
     if (fused) {
       // one wave per target: logits, softmax and aggregation in one pass over the rel rows (no per-edge GEMM)
-      TS_LAUNCH(k_global_attn, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg);
+      if (num_heads == 4)
+        TS_LAUNCH(k_global_attn<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg);
+      else
+        TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg);
       if (int rc = update_ffn(im, w.agg, w.xn, x, N, w.x1, w.xn2, out, st)) return rc;
       x = out;
       continue;

@@ -18,6 +18,7 @@ all-reduce per step over a flat bucket that the parameters' `.grad` tensors are 
 latency-bound, so a single collective beats bucketing).
 """
 import argparse
+import inspect
 import json
 import os
 from typing import Iterable, Optional
@@ -47,8 +48,9 @@ def evaluate(model, batches: Iterable, seed: int = 0) -> dict:
     """trainer.test(...): test_step per batch, then the epoch-end metric dump (MODEL:133-165)."""
     for metric in model.metrics_vl:
         metric.reset()
+    stochastic = "noise" in inspect.signature(model.forward).parameters      # the vanilla HiVT variant has no noise to seed
     for i, batch in enumerate(batches):
-        model.test_step(batch, i) if seed is None else _seeded_test_step(model, batch, i, seed + i)
+        model.test_step(batch, i) if (seed is None or not stochastic) else _seeded_test_step(model, batch, i, seed + i)
     return model.metric_results()
 
 
@@ -155,7 +157,9 @@ def main() -> None:
         K, T = spec["num_modes"], spec["future_steps"]
         cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)
         cfg["aggregator"]["kwargs"]["num_modes"] = K
-        cfg["decoder"]["kwargs"].update(num_modes=K, future_steps=T, max_fut_t=spec["max_fut_t"])
+        cfg["decoder"]["kwargs"].update(num_modes=K, future_steps=T)
+        if "max_fut_t" in cfg["decoder"]["kwargs"]:
+            cfg["decoder"]["kwargs"]["max_fut_t"] = spec["max_fut_t"]
         for m in cfg["metric_args"]:
             m["end_idcs"] = [T - 1, T - 1]
     if args.ood:

@@ -17,8 +17,8 @@ class GlobalInteractor(ParamTree):
         d = self.embed_dim
         if not self.rotate:
             raise NotImplementedError("rotate=False is not built (the shipped config rotates, CFG:59)")
-        if d != 64 or self.num_heads != 8 or self.edge_dim != 2:
-            raise NotImplementedError("kernels are specialised for embed_dim=64, 8 heads, 2-d edges")
+        if d != 64 or self.num_heads not in (4, 8) or self.edge_dim != 2:
+            raise NotImplementedError("kernels are specialised for embed_dim=64, 4 or 8 heads, 2-d edges")
         self.multiple_input_embedding("rel_embed", [self.edge_dim, self.edge_dim], d)
         for i in range(self.num_layers):
             self.attention_block(f"global_interactor_layers.{i}", d,

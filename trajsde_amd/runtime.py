@@ -108,7 +108,8 @@ _TABLES_DEV: Dict[tuple, torch.Tensor] = {}          # device copies of the host
 class StageRuntime:
     """Per-stage glue owned by a stage module (encoder / aggregator / decoder)."""
 
-    STAGE_ID = {"encoder": _lib.STAGE_ENCODER, "aggregator": _lib.STAGE_AGGREGATOR, "decoder": _lib.STAGE_DECODER}
+    STAGE_ID = {"encoder": _lib.STAGE_ENCODER, "aggregator": _lib.STAGE_AGGREGATOR, "decoder": _lib.STAGE_DECODER,
+                "encoder_grid": _lib.STAGE_ENCODER_GRID, "decoder_mlp": _lib.STAGE_DECODER_MLP}
 
     def __init__(self, module, stage: str) -> None:
         object.__setattr__(self, "module", module)
@@ -120,6 +121,8 @@ class StageRuntime:
     # ---------------------------------------------------------------- weights
     def _dims(self) -> Tuple[int, int]:
         m = self.module
+        if self.stage == "encoder_grid":             # this recipe takes the number of temporal layers
+            return int(m.num_temporal_layers), 0
         return int(getattr(m, "num_layers", 0)), int(getattr(m, "num_modes", 0))
 
     def param_names(self, stage_id: Optional[int] = None):
@@ -358,10 +361,49 @@ class StageRuntime:
         ws_bytes = L.trajsde_aggregator_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), K)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         with torch.cuda.device(dev):
-            _lib.check(L.trajsde_aggregator_forward(C.byref(gc.batch), C.byref(gc.graph), blob.data_ptr(), int(m.num_layers), K,
-                                                    local_embed.contiguous().data_ptr(), ws.data_ptr(), ws_bytes, out.data_ptr(),
-                                                    _stream()), "trajsde_aggregator_forward")
+            _lib.check(L.trajsde_aggregator_forward_heads(C.byref(gc.batch), C.byref(gc.graph), blob.data_ptr(), int(m.num_layers), K,
+                                                          int(m.num_heads), local_embed.contiguous().data_ptr(), ws.data_ptr(),
+                                                          ws_bytes, out.data_ptr(), _stream()), "trajsde_aggregator_forward")
         return out
+
+    # ---------------------------------------------------------------- vanilla HiVT variant
+    def encoder_grid_forward(self, data) -> torch.Tensor:
+        """LocalEncoder.forward (enc_hivt_nusargo_grid.py:52-93) -> local_embed [N,64]"""
+        m = self.module
+        noise = NoiseSpec(seed=0)                                      # no fake agents, no noise: the graph only
+        gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), noise, fake_agents=False)
+        dev = gc.device
+        L = _lib.lib()
+        blob = self.blob()
+        N = gc.batch.N
+        local = torch.empty(N, D, device=dev, dtype=torch.float32)
+        ws_bytes = L.trajsde_encoder_grid_ws_bytes(C.byref(gc.batch), C.byref(gc.graph))
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_encoder_grid_forward(C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), blob.data_ptr(),
+                                                      int(m.num_heads), int(m.num_temporal_layers), ws.data_ptr(), ws_bytes,
+                                                      local.data_ptr(), _stream()), "trajsde_encoder_grid_forward")
+        return local
+
+    def mlp_decoder_forward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """MLPDecoder.forward (dec_hivt_nusargo_grid.py:47-63)"""
+        m = self.module
+        _require_gpu(local_embed, "local_embed")
+        dev = local_embed.device
+        K, T, N = int(m.num_modes), int(m.future_steps), local_embed.shape[0]
+        L = _lib.lib()
+        blob = self.blob()
+        loc = torch.empty(K, N, T, 4, device=dev, dtype=torch.float32)
+        pi = torch.empty(N, K, device=dev, dtype=torch.float32)
+        ws_bytes = L.trajsde_mlp_decoder_ws_bytes(N, K)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_mlp_decoder_forward(N, K, T, blob.data_ptr(), local_embed.contiguous().data_ptr(),
+                                                     global_embed.contiguous().data_ptr(), float(m.min_scale), ws.data_ptr(),
+                                                     ws_bytes, loc.data_ptr(), pi.data_ptr(), _stream()),
+                       "trajsde_mlp_decoder_forward")
+        return {"loc": loc, "pi": pi, "local_embed": local_embed, "global_embed": global_embed,
+                "reg_mask": ~data["padding_mask"][:, -T:]}
 
 
     def aggregator_backward(self, data, local_embed: torch.Tensor, d_global: torch.Tensor) -> Dict[str, object]:
