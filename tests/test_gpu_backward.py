@@ -2,6 +2,8 @@
 C-ABI against torch.autograd run over the CPU oracle's restatement of the same stage (oracle/restate.py, which is
 pinned against the reference by the golden vectors).  Tolerances are relative to the largest entry of each
 gradient tensor: fp32 sums over ~1e5 rows on both sides."""
+import os
+
 import pytest
 import torch
 
@@ -350,3 +352,33 @@ def test_a_few_optimizer_steps_reduce_the_loss(dev):
     assert len(hist) == 12 and all(torch.isfinite(torch.tensor(hist)))
     assert sum(hist[-3:]) < sum(hist[:3]), hist
     assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("decoder.pi.") or n.startswith("decoder.scale."))
+
+
+def test_training_loop_over_scene_shards(dev, tmp_path):
+    """the train.py-like loop end to end: flat scene shards -> mixed-grid dataset (train split, flips) -> scene loader ->
+    training_step / backward / AdamW, through the YAML registry like `python -m trajsde_amd.driver --train --data`"""
+    import numpy as np
+    from test_dataset import _groups
+    from trajsde_amd import driver
+    from trajsde_amd.scene_store import write_shard
+    z = np.load(os.path.join(H.ROOT, "tests", "golden_data", "mixds.npz"))
+    for sub, group in (("nu/train", "raw/nus"), ("nu/val", "raw/nus"), ("argo/train", "raw/argo")):
+        os.makedirs(tmp_path / sub)
+        write_shard(str(tmp_path / sub / "a.safetensors"), _groups(z, group))
+    cfg = H.our_cfg(3, 60, 6.0)
+    cfg["datamodule_specific"]["kwargs"].update(nu_dir=str(tmp_path / "nu"), Argo_dir=str(tmp_path / "argo"), train_batch_size=3,
+                                                 shuffle=True, device=dev)
+    model = driver.build_model(cfg, None, dev, init_seed=4)
+    model.lr = 1e-3
+    dm_cfg = cfg["datamodule_specific"]
+    from trajsde_amd.models.model_base_mix_sde import resolve_class
+    dm = resolve_class(dm_cfg["file_path"], dm_cfg["module_name"])(**dm_cfg["kwargs"])
+    dm.setup("fit")
+    loader = dm.train_dataloader()
+
+    def per_epoch(epoch):
+        loader.set_epoch(epoch)
+        return iter(loader)
+    hist = driver.train(model, per_epoch, epochs=3, seed=1)
+    assert len(hist) == 6 and all(np.isfinite(hist))
+    assert all(torch.isfinite(p).all() for p in model.parameters())

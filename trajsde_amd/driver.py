@@ -102,7 +102,7 @@ def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None) -> lis
             loss.backward()
             flat.all_reduce_mean()
             optimizer.step()
-            history.append(float(loss))
+            history.append(float(loss.detach()))
             if log:
                 log(epoch, i, history[-1], model.last_losses)
             step += 1
