@@ -2,7 +2,7 @@
 // 92-135): given dL/d global_embed [K,N,64] it returns dL/d local_embed and the gradients of every aggregator
 // parameter.  Second family of SURVEY.md 8(f) rank 1.
 //
-// The stage's forward is recomputed here in exact fp32 with one buffer per layer (the "tape"), then walked backwards:
+// The stage's forward is recomputed here with one buffer per layer (the "tape"), then walked backwards:
 //   multihead_proj / norm            k_lin_t_acc x K  ->  k_node_proj_bwd<0>
 //   per layer, last to first         node_block_backward (FFN, gated update)  ->  k_gattn_bwd  ->  k_node_proj_bwd<3>
 //   rel_embed                        edge_embed_backward on the summed d rel rows
@@ -224,9 +224,9 @@ int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, 
   const int nl = num_layers, K = num_modes;
   const WgradCtx wc{st, w.part, w.cs, nullptr};
 
-  // ---- forward recompute in exact fp32, one buffer per layer
+  // ---- forward recompute (the kernels the forward itself runs), one buffer per layer
   if (E > 0)
-    TS_LAUNCH(k_edge_embed<false>, tile_grid(etiles, 1024, EdgeL::EMB_SIZE * 4), 1024, EdgeL::EMB_SIZE * 4, st, blob_fwd + AggBlob::REL,
+    TS_LAUNCH(k_edge_embed<true>, tile_grid(etiles, 1024, EdgeL6::EMB_SIZE * 4), 1024, EdgeL6::EMB_SIZE * 4, st, blob_fwd + AggBlob::REL6,
               g->g_geom, E, w.rel);
   const float* x = local_embed;
   for (int l = 0; l < nl; ++l) {
@@ -235,9 +235,9 @@ int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, 
               w.xn[l], w.q[l], w.kn[l], w.vn[l]);
     TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
               w.agg[l]);
-    TS_LAUNCH(k_node_update<false>, tile_grid(ntiles, 512, UpdL::SIZE * 4), 512, UpdL::SIZE * 4, st, lb + AggLayerL::UPD, w.agg[l], w.xn[l], x,
+    TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, lb + AggLayerL::UPD6, w.agg[l], w.xn[l], x,
               N, w.x1[l], w.xn2[l]);
-    TS_LAUNCH(k_ffn, tile_grid(ntiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + AggLayerL::FFN, w.x1[l], w.xn2[l], N, w.out[l]);
+    TS_LAUNCH(k_ffn6, tile_grid(ntiles, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, lb + AggLayerL::FFN6, w.x1[l], w.xn2[l], N, w.out[l]);
     x = w.out[l];
   }
 

@@ -443,32 +443,44 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ delta, 
 #pragma unroll
     for (int it = 0; it < 4; ++it) acc[ot][it] = f4{0.f, 0.f, 0.f, 0.f};
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
-  // software-pipelined over 4-row k-steps: the operands of step i+1 are in flight while step i is on the matrix cores
-  auto fetch = [&](int64_t rb, float (&A)[4], float (&B)[4]) {
-    const int64_t r = rb + kg;
-    const bool ok = r < row1;
+  // 64-row blocks of delta and a are staged in LDS with coalesced 16-B loads (row stride 80 floats: the four k-groups
+  // of an operand read land in four different bank quarters), then every wave takes every 4th 4-row k-step
+  constexpr int RS = 80;
+  float* ds_ = dyn;                       // [64][RS]   (the staging area is reused for the cross-wave reduction below)
+  float* as_ = dyn + 64 * RS;             // [64][RS]
+  for (int64_t blk = row0; blk < row1; blk += 64) {
+    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      A[q] = ok ? delta[r * ldd + 16 * q + idx] : 0.f;
-      B[q] = ok ? a[r * lda + 16 * q + idx] : 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const int f = threadIdx.x + 256 * u;            // float4 index within the 64 x 16 block
+      const int r = f >> 4, c4 = f & 15;
+      const int64_t row = blk + r;
+      f4 dv = f4{0.f, 0.f, 0.f, 0.f}, av = dv;
+      if (row < row1) {
+        dv = *reinterpret_cast<const f4*>(delta + row * ldd + 4 * c4);
+        av = *reinterpret_cast<const f4*>(a + row * lda + 4 * c4);
+      }
+      *reinterpret_cast<f4*>(ds_ + r * RS + 4 * c4) = dv;
+      *reinterpret_cast<f4*>(as_ + r * RS + 4 * c4) = av;
     }
-  };
-  float A0[4], B0[4], A1[4], B1[4];
-  int64_t rb = row0 + 4 * wave;
-  if (rb < row1) fetch(rb, A0, B0);
-  while (rb < row1) {
-    const int64_t nb = rb + 16;
-    if (nb < row1) fetch(nb, A1, B1);
+    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) csum[q] += A0[q];
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int r = 4 * (wave + 4 * s4) + kg;
+      float A[4], B[4];
 #pragma unroll
-    for (int ot = 0; ot < 4; ++ot)
+      for (int q = 0; q < 4; ++q) {
+        A[q] = ds_[r * RS + 16 * q + idx];
+        B[q] = as_[r * RS + 16 * q + idx];
+        csum[q] += A[q];
+      }
 #pragma unroll
-      for (int it = 0; it < 4; ++it) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[ot], B0[it], acc[ot][it], 0, 0, 0);
+      for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { A0[q] = A1[q]; B0[q] = B1[q]; }
-    rb = nb;
+        for (int it = 0; it < 4; ++it) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ot], B[it], acc[ot][it], 0, 0, 0);
+    }
   }
+  __syncthreads();
   // D fragment: lane holds dW[16ot + 4kg + reg][16it + idx]
 #pragma unroll
   for (int ot = 0; ot < 4; ++ot)

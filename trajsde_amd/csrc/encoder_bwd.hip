@@ -3,7 +3,7 @@
 // (losses/diff_BCE.py:11-16).  Third family of SURVEY.md 8(f) rank 1.
 //
 // Inputs: dL/d local_embed [N,64] (decoder + aggregator) and the weight of the DiffBCE term.  The forward is
-// recomputed in exact fp32 keeping a tape, then walked backwards:
+// recomputed keeping a tape, then walked backwards:
 //   ALEncoder     node block -> segment-attention backward -> edge (lane embedding, k, v) backward -> norm1/lin_q
 //   recurrence    21 x { GRU_Unit backward, Euler-Maruyama step backward (drift + the source's diffusion net) },
 //                 d latent enters at each actor's kept iteration, d DiffBCE/d g at the picked diffusion values
@@ -731,16 +731,16 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   using FB = EncBlob;
   using BB = EncBwdBlob;
 
-  // ================= forward recompute (exact fp32) =================
+  // ================= forward recompute (the split-precision kernels the forward itself runs; recurrence in fp32) =================
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob_fwd + FB::AA_CENTER, b->x,
             g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
   if (Eaa > 0)
-    TS_LAUNCH(k_edge_kv<false>, tile_grid((Eaa + 15) / 16, 1024, EdgeL::SIZE * 4), 1024, EdgeL::SIZE * 4, st, blob_fwd + FB::AA_EDGE,
+    TS_LAUNCH(k_edge_kv<true>, tile_grid((Eaa + 15) / 16, 1024, EdgeL6::SIZE * 4), 1024, EdgeL6::SIZE * 4, st, blob_fwd + FB::AA_EDGE6,
               g->aa_geom, g->aa_dst, w.q, Eaa, w.logits, w.v, 8);
   TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, g->aa_segptr, w.logits, w.v, R, w.agg, 8);
-  TS_LAUNCH(k_node_update<false>, tile_grid((R + 15) / 16, 512, UpdL::SIZE * 4), 512, UpdL::SIZE * 4, st, blob_fwd + FB::AA_UPD, w.agg, w.cn,
+  TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
             w.center, R, w.x1, w.xn2);
-  TS_LAUNCH(k_ffn, tile_grid((R + 15) / 16, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, blob_fwd + FB::AA_FFN, w.x1, w.xn2, R, w.aa_out);
+  TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out);
   for (int idx = 0; idx < H; ++idx) {
     const int t = H - 1 - idx;
     const float* e = step_tab + 8 * idx;
@@ -757,10 +757,10 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob_fwd + FB::AL_Q, w.lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
   if (Ela > 0)
-    TS_LAUNCH(k_edge_kv<false>, tile_grid((Ela + 15) / 16, 1024, EdgeL::SIZE * 4), 1024, EdgeL::SIZE * 4, st, blob_fwd + FB::AL_EDGE,
+    TS_LAUNCH(k_edge_kv<true>, tile_grid((Ela + 15) / 16, 1024, EdgeL6::SIZE * 4), 1024, EdgeL6::SIZE * 4, st, blob_fwd + FB::AL_EDGE6,
               g->la_geom, g->la_dst, w.al_q, Ela, w.al_logits, w.al_v, 8);
   TS_LAUNCH(k_seg_softmax_agg, cdiv(N, 4), 256, 0, st, g->la_segptr, w.al_logits, w.al_v, int64_t(N), w.al_agg, 8);
-  TS_LAUNCH(k_node_update<false>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL::SIZE * 4), 512, UpdL::SIZE * 4, st, blob_fwd + FB::AL_UPD,
+  TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
             w.al_agg, w.al_xn, w.lat, int64_t(N), w.al_x1, w.al_xn2);
 
   // ================= backward =================
