@@ -237,6 +237,11 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
                              float* diff_loss /*[1] device*/, float* const* grads, int n_grads, float* d_latent, float* d_aa_out,
                              void* stream);
 
+int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, const float* blob_bwd,
+                                      int num_layers, int num_modes, int num_heads, const float* local_embed,
+                                      const float* d_global, void* ws, int64_t ws_bytes, float* const* grads, int n_grads,
+                                      float* d_local, void* stream);
+
 /* ---- step-granular decoder SDE step (state round-trips HBM every step): the 512 B/path-step variant
  *      of SURVEY.md 8(d), kept for the HBM-roofline measurement the north star asks for. */
 int trajsde_sde_step(int32_t rows, const float* blob, const float* y_in, float* y_out,

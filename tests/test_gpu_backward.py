@@ -100,9 +100,9 @@ def test_decoder_l2_backward_matches_autograd(S, n, K, T, max_t, kw, dev):
     assert float(dg[lose].abs().max()) == 0.0 if lose.any() else True
 
 
-def _oracle_aggregator_grads(model, cfg, batch_cpu, local, d_glob):
+def _oracle_aggregator_grads(model, cfg, batch_cpu, local, d_glob, heads=8):
     import restate
-    c = restate.flat_cfg(cfg)
+    c = dict(restate.flat_cfg(cfg), num_heads=heads)
     P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     names = [k for k in P if k.startswith("aggregator.")]
     for k in names:
@@ -116,17 +116,21 @@ def _oracle_aggregator_grads(model, cfg, batch_cpu, local, d_glob):
     return grads, local.grad
 
 
-@pytest.mark.parametrize("S,n,K,kw", [
-    (3, 20, 4, dict(mixed_source=True, history_dropout=0.3)),
-    (2, 33, 2, dict(source=1)),
-    (2, 1, 3, dict()),                               # single-actor scenes: no global edges at all
+@pytest.mark.parametrize("S,n,K,heads,kw", [
+    (3, 20, 4, 8, dict(mixed_source=True, history_dropout=0.3)),
+    (2, 33, 2, 8, dict(source=1)),
+    (2, 1, 3, 8, dict()),                            # single-actor scenes: no global edges at all
+    (3, 18, 3, 4, dict(mixed_source=True)),          # the vanilla configuration's head count
 ])
-def test_aggregator_backward_matches_autograd(S, n, K, kw, dev):
+def test_aggregator_backward_matches_autograd(S, n, K, heads, kw, dev):
     from trajsde_amd import runtime
+    from trajsde_amd.models.model_base_mix_sde import PredictionModelSDENet
     from trajsde_amd.synth import synth
     T = 5
     batch = synth(S=S, n=n, L=6, F=T, box=80.0, seed=400 + n, **kw)
-    model, cfg = H.build_model(K, T, 0.5, init_seed=13)
+    cfg = H.our_cfg(K, T, 0.5)
+    cfg["aggregator"]["kwargs"]["num_heads"] = heads
+    model = PredictionModelSDENet(**cfg, init_seed=13).eval()
     model = model.to(dev)
     data = batch.to(dev)
     noise = runtime.NoiseSpec(seed=17)
@@ -138,7 +142,7 @@ def test_aggregator_backward_matches_autograd(S, n, K, kw, dev):
     d_glob = torch.randn(K, N, 64, generator=g)
     res = model.aggregator._rt.aggregator_backward(data, local, d_glob.to(dev))
     torch.cuda.synchronize()
-    want, d_local = _oracle_aggregator_grads(model, cfg, batch, local, d_glob)
+    want, d_local = _oracle_aggregator_grads(model, cfg, batch, local, d_glob, heads)
     got = res["grads"]
     assert set(got) == set(want)
     for k in sorted(got):

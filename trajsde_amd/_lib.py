@@ -66,6 +66,8 @@ SIGNATURES = {
     "trajsde_aggregator_backward_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph), C.c_int, C.c_int]),
     "trajsde_aggregator_backward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, C.c_int, C.c_int, P, P, P, I64,
                                               C.POINTER(P), C.c_int, P, P]),
+    "trajsde_aggregator_backward_heads": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, C.c_int, C.c_int, C.c_int, P, P, P, I64,
+                                                    C.POINTER(P), C.c_int, P, P]),
     "trajsde_encoder_backward_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
     "trajsde_encoder_backward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, P, P, C.POINTER(Noise), P, F32, P, I64, P,
                                            C.POINTER(P), C.c_int, P, P, P]),

@@ -27,6 +27,7 @@
 
 namespace tsde {
 
+template <int HEADS>
 __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                    const int32_t* __restrict__ src, const float* __restrict__ rel,
                                                    const float* __restrict__ q, const float* __restrict__ kn,
@@ -34,105 +35,117 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
                                                    const float* __restrict__ dagg, int64_t N, float* __restrict__ DQ,
                                                    float* __restrict__ DKN, float* __restrict__ DVN, float* __restrict__ DREL,
                                                    float* __restrict__ RL, float* __restrict__ SS, float* __restrict__ DAGGM) {
-  __shared__ __attribute__((aligned(16))) float sbuf[4][8][64 + 4];
+  constexpr int LPH = 64 / HEADS, SL = 64 / LPH, NV = SL / 4;     // as in k_global_attn<HEADS>
+  constexpr float INV = HEADS == 4 ? 0.25f : INV_SQRT_DH;
+  __shared__ __attribute__((aligned(16))) float sbuf[4][HEADS][64 + 4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int h = lane >> 3, j = lane & 7;
+  const int h = lane / LPH, j = lane % LPH;
   const int64_t node = int64_t(blockIdx.x) * 4 + wv;
   const int64_t nc = node < N ? node : N - 1;
   const float* wke = img + GAttnL::WKE;
   const float* wve = img + GAttnL::WVE;
   const float ql = q[nc * 64 + lane];
   const float da = node < N ? dagg[nc * 64 + lane] : 0.f;
-  const float cb = head_sum(ql * img[GAttnL::BKE + lane]);
-  const float cz = head_sum(da * img[GAttnL::BVE + lane]);
-  const float dlt = head_sum(da * agg[nc * 64 + lane]);
-  float U[8], Z[8];
+  const float cb = head_sum_n<HEADS>(ql * img[GAttnL::BKE + lane]);
+  const float cz = head_sum_n<HEADS>(da * img[GAttnL::BVE + lane]);
+  const float dlt = head_sum_n<HEADS>(da * agg[nc * 64 + lane]);
+  float U[SL], Z[SL];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) U[e] = Z[e] = 0.f;
+  for (int e = 0; e < SL; ++e) U[e] = Z[e] = 0.f;
 #pragma unroll
-  for (int d = 0; d < 8; ++d) {
-    const float qd = __shfl(ql, 8 * h + d), dd = __shfl(da, 8 * h + d);
-    const f4 k0 = *reinterpret_cast<const f4*>(wke + (8 * h + d) * 64 + 8 * j);
-    const f4 k1 = *reinterpret_cast<const f4*>(wke + (8 * h + d) * 64 + 8 * j + 4);
-    const f4 v0 = *reinterpret_cast<const f4*>(wve + (8 * h + d) * 64 + 8 * j);
-    const f4 v1 = *reinterpret_cast<const f4*>(wve + (8 * h + d) * 64 + 8 * j + 4);
+  for (int d = 0; d < LPH; ++d) {
+    const float qd = __shfl(ql, LPH * h + d), dd = __shfl(da, LPH * h + d);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      U[e] = fmaf(k0[e], qd, U[e]); U[4 + e] = fmaf(k1[e], qd, U[4 + e]);
-      Z[e] = fmaf(v0[e], dd, Z[e]); Z[4 + e] = fmaf(v1[e], dd, Z[4 + e]);
+    for (int v4 = 0; v4 < NV; ++v4) {
+      const f4 kw = *reinterpret_cast<const f4*>(wke + (LPH * h + d) * 64 + SL * j + 4 * v4);
+      const f4 vw = *reinterpret_cast<const f4*>(wve + (LPH * h + d) * 64 + SL * j + 4 * v4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        U[4 * v4 + e] = fmaf(kw[e], qd, U[4 * v4 + e]);
+        Z[4 * v4 + e] = fmaf(vw[e], dd, Z[4 * v4 + e]);
+      }
     }
   }
   const int beg = segptr[nc], end = node < N ? segptr[nc + 1] : beg;
-  auto logit = [&](const f4& ra, const f4& rb, float knv) {
+  auto load_rel = [&](int e, f4 (&r)[NV]) {
+#pragma unroll
+    for (int v4 = 0; v4 < NV; ++v4) r[v4] = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + SL * j + 4 * v4);
+  };
+  auto logit = [&](const f4 (&r)[NV], float knv) {
     float p = ql * knv;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { p = fmaf(ra[e], U[e], p); p = fmaf(rb[e], U[4 + e], p); }
-    return (head_sum(p) + cb) * INV_SQRT_DH;
+    for (int v4 = 0; v4 < NV; ++v4)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p = fmaf(r[v4][e], U[4 * v4 + e], p);
+    return (head_sum_n<HEADS>(p) + cb) * INV;
   };
   // pass 1: softmax statistics of the segment
   float m = -INFINITY, s = 0.f;
   for (int e = beg; e < end; ++e) {
-    const f4 ra = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + 8 * j);
-    const f4 rb = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + 8 * j + 4);
-    const float p = logit(ra, rb, kn[int64_t(src[e]) * 64 + lane]);
+    f4 r[NV];
+    load_rel(e, r);
+    const float p = logit(r, kn[int64_t(src[e]) * 64 + lane]);
     const float mn = fmaxf(m, p);
     s = s * fast_exp(m - mn) + fast_exp(p - mn);
     m = mn;
   }
   const float inv = 1.0f / (s + 1e-16f);
   // pass 2: gradients
-  float dqe = 0.f, Rl[8], Sa[8];
+  float dqe = 0.f, Rl[SL], Sa[SL];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) Rl[e] = Sa[e] = 0.f;
+  for (int e = 0; e < SL; ++e) Rl[e] = Sa[e] = 0.f;
   for (int e = beg; e < end; ++e) {
     const int sidx = src[e];
-    const f4 ra = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + 8 * j);
-    const f4 rb = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + 8 * j + 4);
+    f4 r[NV];
+    load_rel(e, r);
     const float knv = kn[int64_t(sidx) * 64 + lane], vnv = vn[int64_t(sidx) * 64 + lane];
-    const float alpha = fast_exp(logit(ra, rb, knv) - m) * inv;
+    const float alpha = fast_exp(logit(r, knv) - m) * inv;
     float t = da * vnv;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { t = fmaf(ra[c], Z[c], t); t = fmaf(rb[c], Z[4 + c], t); }
-    const float dal = head_sum(t) + cz;
-    const float dls = alpha * (dal - dlt) * INV_SQRT_DH;
+    for (int v4 = 0; v4 < NV; ++v4)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t = fmaf(r[v4][c], Z[4 * v4 + c], t);
+    const float dal = head_sum_n<HEADS>(t) + cz;
+    const float dls = alpha * (dal - dlt) * INV;
     dqe = fmaf(dls, knv, dqe);
     atomicAdd(DKN + int64_t(sidx) * 64 + lane, dls * ql);
     atomicAdd(DVN + int64_t(sidx) * 64 + lane, alpha * da);
-    float dr[8];
+    float dr[SL];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      Rl[c] = fmaf(dls, ra[c], Rl[c]); Rl[4 + c] = fmaf(dls, rb[c], Rl[4 + c]);
-      Sa[c] = fmaf(alpha, ra[c], Sa[c]); Sa[4 + c] = fmaf(alpha, rb[c], Sa[4 + c]);
-      dr[c] = fmaf(dls, U[c], alpha * Z[c]);
-      dr[4 + c] = fmaf(dls, U[4 + c], alpha * Z[4 + c]);
-    }
-    // d rel_e = sum over heads: lanes j, j+8, ..., j+56 hold the same 8 columns
+    for (int v4 = 0; v4 < NV; ++v4)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < 4; ++c) {
+        const int i = 4 * v4 + c;
+        Rl[i] = fmaf(dls, r[v4][c], Rl[i]);
+        Sa[i] = fmaf(alpha, r[v4][c], Sa[i]);
+        dr[i] = fmaf(dls, U[i], alpha * Z[i]);
+      }
+    // d rel_e = sum over heads: lanes j, j + LPH, ... hold the same SL columns
+#pragma unroll
+    for (int c = 0; c < SL; ++c) {
       float x = dr[c];
-      x += __shfl_xor(x, 8);
-      x += __shfl_xor(x, 16);
-      x += __shfl_xor(x, 32);
+#pragma unroll
+      for (int o = LPH; o < 64; o <<= 1) x += __shfl_xor(x, o);
       dr[c] = x;
     }
     if (h == 0) {
-      float* p = DREL + int64_t(e) * 64 + 8 * j;
-      f4 a = *reinterpret_cast<f4*>(p), b = *reinterpret_cast<f4*>(p + 4);
-      a += f4{dr[0], dr[1], dr[2], dr[3]};
-      b += f4{dr[4], dr[5], dr[6], dr[7]};
-      *reinterpret_cast<f4*>(p) = a;
-      *reinterpret_cast<f4*>(p + 4) = b;
+      float* p = DREL + int64_t(e) * 64 + SL * j;
+#pragma unroll
+      for (int v4 = 0; v4 < NV; ++v4) {
+        f4 a = *reinterpret_cast<f4*>(p + 4 * v4);
+        a += f4{dr[4 * v4], dr[4 * v4 + 1], dr[4 * v4 + 2], dr[4 * v4 + 3]};
+        *reinterpret_cast<f4*>(p + 4 * v4) = a;
+      }
     }
   }
-  *reinterpret_cast<f4*>(&sbuf[wv][h][8 * j]) = f4{Rl[0], Rl[1], Rl[2], Rl[3]};
-  *reinterpret_cast<f4*>(&sbuf[wv][h][8 * j + 4]) = f4{Rl[4], Rl[5], Rl[6], Rl[7]};
-  if (node < N) {
-    float* rp = RL + (node * 8 + h) * 64 + 8 * j;
-    float* sp = SS + (node * 8 + h) * 64 + 8 * j;
-    *reinterpret_cast<f4*>(rp) = f4{Rl[0], Rl[1], Rl[2], Rl[3]};
-    *reinterpret_cast<f4*>(rp + 4) = f4{Rl[4], Rl[5], Rl[6], Rl[7]};
-    *reinterpret_cast<f4*>(sp) = f4{Sa[0], Sa[1], Sa[2], Sa[3]};
-    *reinterpret_cast<f4*>(sp + 4) = f4{Sa[4], Sa[5], Sa[6], Sa[7]};
+#pragma unroll
+  for (int v4 = 0; v4 < NV; ++v4) {
+    const f4 rv = f4{Rl[4 * v4], Rl[4 * v4 + 1], Rl[4 * v4 + 2], Rl[4 * v4 + 3]};
+    *reinterpret_cast<f4*>(&sbuf[wv][h][SL * j + 4 * v4]) = rv;
+    if (node < N) {
+      *reinterpret_cast<f4*>(RL + (node * HEADS + h) * 64 + SL * j + 4 * v4) = rv;
+      *reinterpret_cast<f4*>(SS + (node * HEADS + h) * 64 + SL * j + 4 * v4) = f4{Sa[4 * v4], Sa[4 * v4 + 1], Sa[4 * v4 + 2], Sa[4 * v4 + 3]};
+    }
   }
   // d q[d] = sum_e dlogit/sqrt(dh) (k_node[src][d] + lin_k_edge(rel_e)[d]) = dqe + Wke[d] . RL_head(d)
   float dq = dqe;
@@ -201,7 +214,15 @@ int64_t trajsde_aggregator_backward_ws_bytes(const trajsde_batch* b, const trajs
 int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, const float* blob_bwd,
                                 int num_layers, int num_modes, const float* local_embed, const float* d_global, void* ws,
                                 int64_t ws_bytes, float* const* grads, int n_grads, float* d_local, void* stream_) {
+  return trajsde_aggregator_backward_heads(b, g, blob_fwd, blob_bwd, num_layers, num_modes, 8, local_embed, d_global, ws, ws_bytes, grads,
+                                           n_grads, d_local, stream_);
+}
+
+int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, const float* blob_bwd,
+                                      int num_layers, int num_modes, int num_heads, const float* local_embed, const float* d_global,
+                                      void* ws, int64_t ws_bytes, float* const* grads, int n_grads, float* d_local, void* stream_) {
   TS_REQUIRE(b && g && blob_fwd && blob_bwd && local_embed && d_global && ws && grads && d_local, "aggregator_backward: null pointer");
+  TS_REQUIRE(num_heads == 8 || num_heads == 4, "aggregator_backward: num_heads must be 8 or 4");
   TS_REQUIRE(g->g_src && g->g_segptr, "aggregator_backward: graph not compacted (call trajsde_graph_compact)");
   TS_REQUIRE(num_layers >= 1 && num_layers <= 8 && num_modes > 0, "aggregator_backward: bad layer/mode count");
   const std::vector<std::string> names = stage_param_names(TRAJSDE_STAGE_AGGREGATOR_BWD, num_layers, num_modes);
@@ -233,8 +254,12 @@ int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, 
     const float* lb = blob_fwd + AggBlob::layer(l);
     TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
               w.xn[l], w.q[l], w.kn[l], w.vn[l]);
-    TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
-              w.agg[l]);
+    if (num_heads == 4)
+      TS_LAUNCH(k_global_attn<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
+                w.agg[l]);
+    else
+      TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
+                w.agg[l]);
     TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, lb + AggLayerL::UPD6, w.agg[l], w.xn[l], x,
               N, w.x1[l], w.xn2[l]);
     TS_LAUNCH(k_ffn6, tile_grid(ntiles, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, lb + AggLayerL::FFN6, w.x1[l], w.xn2[l], N, w.out[l]);
@@ -283,10 +308,14 @@ int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, 
     if (int rc = node_block_backward(lb + AggLayerBwdL::NODE, tp, dcur, N, w.nb, wc, gr, w.dagg, w.dxn, st)) return rc;
     TS_HIP(hipMemsetAsync(w.DKN, 0, size_t(N) * 64 * sizeof(float), st));
     TS_HIP(hipMemsetAsync(w.DVN, 0, size_t(N) * 64 * sizeof(float), st));
-    TS_LAUNCH(k_gattn_bwd, cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], w.agg[l],
-              w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM);
-    if (int rc = run_headwise_outer(wc, w.q[l], w.RL, N, wke)) return rc;
-    if (int rc = run_headwise_outer(wc, w.dagg, w.SS, N, wve)) return rc;
+    if (num_heads == 4)
+      TS_LAUNCH(k_gattn_bwd<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
+                w.agg[l], w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM);
+    else
+      TS_LAUNCH(k_gattn_bwd<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
+                w.agg[l], w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM);
+    if (int rc = run_headwise_outer(wc, w.q[l], w.RL, N, wke, num_heads)) return rc;
+    if (int rc = run_headwise_outer(wc, w.dagg, w.SS, N, wve, num_heads)) return rc;
     TS_HIP(hipMemsetAsync(bke, 0, 64 * sizeof(float), st));          // a key bias shifts every logit of a target alike
     if (int rc = run_colsum(st, w.DAGGM, N, 64, 64, bve)) return rc;
     const int gp = vec_grid(ntiles, 256, ProjBwdL<3>::SIZE * 4);

@@ -27,8 +27,8 @@ struct WgradCtx {
 int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, float* W,
               int ldw, int col0, float* bias, int time_cols);
 int run_colsum(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride = 1);
-// W[d][c] = sum_i X[i][d] * Y[i][d>>3][c]   (X [N,64], Y [N,8,64]) through wc.part
-int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64_t N, float* W);
+// W[d][c] = sum_i X[i][d] * Y[i][head(d)][c]   (X [N,64], Y [N,heads,64]) through wc.part
+int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64_t N, float* W, int heads = 8);
 
 // ---- node-level backward blocks (node_bwd.hip)
 __global__ void k_ffn_bwd_a(const float* img, const float* dout, const float* xn2, int64_t R, float* H, float* DH);
@@ -41,7 +41,7 @@ __global__ void k_node_proj_bwd(const float* img, const float* x, const float* d
 template <int BR>
 __global__ void k_edge_embed_bwd_branch(const float* img, const float* geom, const float* DSP, int64_t E, float* vpart);
 __global__ void k_lin_t_acc(const float* wt, const float* d, int64_t R, float* out, int accumulate);
-__global__ void k_headwise_outer(const float* X, const float* Y, int64_t N, float* part);
+__global__ void k_headwise_outer(const float* X, const float* Y, int64_t N, float* part, int heads);
 
 constexpr int64_t VPART_FLOATS = int64_t(2048) * 4 * 320;     // per-wave vector partials of the widest kernel at the largest grid
 

@@ -31,9 +31,10 @@ namespace tsde {
 __global__ __launch_bounds__(256) void k_seg_attn_bwd(const int32_t* __restrict__ segptr, const float* __restrict__ logits,
                                                       const float* __restrict__ v, const float* __restrict__ agg,
                                                       const float* __restrict__ dagg, int64_t R, float* __restrict__ DV,
-                                                      float* __restrict__ DLG) {
+                                                      float* __restrict__ DLG, int heads) {
   const int lane = threadIdx.x & 63;
-  const int head = lane >> 3, slot = 4 * (head & 1) + (head >> 1);
+  const int head = heads == 4 ? lane >> 4 : lane >> 3, slot = heads == 4 ? head : 4 * (head & 1) + (head >> 1);
+  const int lph_mask = heads == 4 ? 15 : 7;
   const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (node >= R) return;
   const int beg = segptr[node], end = segptr[node + 1];
@@ -47,12 +48,14 @@ __global__ __launch_bounds__(256) void k_seg_attn_bwd(const int32_t* __restrict_
   }
   const float inv = 1.0f / (s + 1e-16f);
   const float da = dagg[node * 64 + lane];
-  const float dlt = head_sum(da * agg[node * 64 + lane]);
+  const float t0 = da * agg[node * 64 + lane];
+  const float dlt = heads == 4 ? head_sum16(t0) : head_sum(t0);
   for (int e = beg; e < end; ++e) {
     const float alpha = fast_exp(logits[int64_t(e) * 8 + slot] - m) * inv;
-    const float dal = head_sum(da * v[int64_t(e) * 64 + lane]);
+    const float t1 = da * v[int64_t(e) * 64 + lane];
+    const float dal = heads == 4 ? head_sum16(t1) : head_sum(t1);
     DV[int64_t(e) * 64 + lane] = alpha * da;
-    if ((lane & 7) == 0) DLG[int64_t(e) * 8 + slot] = alpha * (dal - dlt);
+    if ((lane & lph_mask) == 0) DLG[int64_t(e) * 8 + slot] = alpha * (dal - dlt);
   }
 }
 
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(512) void k_edge_kv_bwd(const float* __restrict__ i
                                                      const int32_t* __restrict__ dst, const float* __restrict__ q,
                                                      const float* __restrict__ DLG, const float* __restrict__ DV, int64_t E,
                                                      float* __restrict__ EMB, float* __restrict__ DK, float* __restrict__ DQE,
-                                                     float* __restrict__ DEMB) {
+                                                     float* __restrict__ DEMB, int heads) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, img, EdgeKvBwdL::SIZE);
   const Lane L;
@@ -87,13 +90,15 @@ __global__ __launch_bounds__(512) void k_edge_kv_bwd(const float* __restrict__ i
     load_row(qv, q, dst[ec], L.g);
     edge_embed<false>(emb, ge, lds, L);
     linear<4, 4>(k, emb, lds + EdgeL::WKV, lds + EdgeL::BKV, L);
-    const f4 dl = *reinterpret_cast<const f4*>(DLG + ec * 8 + 4 * (L.g >> 1));      // heads 2jt + (g>>1), jt = 0..3
+    // 8 heads: lane group g holds heads 2jt + (g>>1) at slots 4(g>>1) + jt; 4 heads: head jt at slot jt for every g
+    const f4 dl = *reinterpret_cast<const f4*>(DLG + ec * 8 + (heads == 4 ? 0 : 4 * (L.g >> 1)));
+    const float sc = heads == 4 ? 0.25f : INV_SQRT_DH;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        dk[jt][c] = dl[jt] * qv[jt][c] * INV_SQRT_DH;
-        dqe[jt][c] = dl[jt] * k[jt][c] * INV_SQRT_DH;
+        dk[jt][c] = dl[jt] * qv[jt][c] * sc;
+        dqe[jt][c] = dl[jt] * k[jt][c] * sc;
       }
     load_row(dv, DV, ec, L.g);
     linear_t(de, dk, lds + EdgeKvBwdL::WKT, L);
@@ -633,6 +638,7 @@ struct AttnChain {
   NodeBlockTape tp;
   int64_t R, E;
   std::string prefix, embed;                                      // parameter names: <prefix>.lin_k..., <prefix>.<embed>...
+  int heads = 8;
 };
 
 }  // namespace tsde
@@ -677,9 +683,9 @@ int run_attn_chain(const AttnChain& c, const float* dout, EncBwdWs& w, const Wgr
   if (int rc = node_block_backward(c.img_node, c.tp, dout, R, w.nb, wc, gr, w.dagg, w.dxn, st)) return rc;
   TS_HIP(hipMemsetAsync(w.DQ, 0, size_t(R) * 64 * sizeof(float), st));
   if (E > 0) {
-    TS_LAUNCH(k_seg_attn_bwd, cdiv(R, 4), 256, 0, st, c.segptr, c.logits, c.v, c.tp.agg, w.dagg, R, w.DV, w.DLG);
+    TS_LAUNCH(k_seg_attn_bwd, cdiv(R, 4), 256, 0, st, c.segptr, c.logits, c.v, c.tp.agg, w.dagg, R, w.DV, w.DLG, c.heads);
     TS_LAUNCH(k_edge_kv_bwd, tile_grid((E + 15) / 16, 512, EdgeKvBwdL::SIZE * 4), 512, EdgeKvBwdL::SIZE * 4, st, c.img_kv, c.geom, c.dst, c.q,
-              w.DLG, w.DV, E, w.EMB, w.DK, w.DQE, w.DEMB);
+              w.DLG, w.DV, E, w.EMB, w.DK, w.DQE, w.DEMB, c.heads);
     TS_LAUNCH(k_seg_sum, cdiv(R, 4), 256, 0, st, c.segptr, w.DQE, R, w.DQ);
     if (int rc = run_wgrad(wc, w.DK, 64, w.EMB, 64, E, E, wk, 64, 0, bk, 0)) return rc;
     if (int rc = run_wgrad(wc, w.DV, 64, w.EMB, 64, E, E, wv, 64, 0, bv, 0)) return rc;

@@ -363,23 +363,23 @@ __global__ __launch_bounds__(256) void k_edge_embed_bwd_branch(const float* __re
 template __global__ void k_edge_embed_bwd_branch<0>(const float*, const float*, const float*, int64_t, float*);
 template __global__ void k_edge_embed_bwd_branch<1>(const float*, const float*, const float*, int64_t, float*);
 
-// part[s][d][c] = sum over row slice s of X[i][d] * Y[i][d>>3][c]    (X [N,64], Y [N,8,64]); grid (64 rows d, S slices);
+// part[s][d][c] = sum over row slice s of X[i][d] * Y[i][head(d)][c]    (X [N,64], Y [N,heads,64]); grid (64 rows d, S slices);
 // the S partial 64x64 blocks are then summed by k_reduce_partials
 __global__ __launch_bounds__(256) void k_headwise_outer(const float* __restrict__ X, const float* __restrict__ Y, int64_t N,
-                                                        float* __restrict__ part) {
+                                                        float* __restrict__ part, int heads) {
   __shared__ float red[4][64];
-  const int d = blockIdx.x, c = threadIdx.x & 63, sub = threadIdx.x >> 6, h = d >> 3;
+  const int d = blockIdx.x, c = threadIdx.x & 63, sub = threadIdx.x >> 6, h = d / (64 / heads);
   const int S = gridDim.y, sl = blockIdx.y;
   const int64_t per = (N + S - 1) / S, lo = sl * per, hi = lo + per < N ? lo + per : N;
   float s = 0.f;
-  for (int64_t i = lo + sub; i < hi; i += 4) s = fmaf(X[i * 64 + d], Y[(i * 8 + h) * 64 + c], s);
+  for (int64_t i = lo + sub; i < hi; i += 4) s = fmaf(X[i * 64 + d], Y[(i * heads + h) * 64 + c], s);
   red[sub][c] = s;
   __syncthreads();
   if (sub == 0) part[int64_t(sl) * 4096 + d * 64 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
-int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64_t N, float* W) {
+int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64_t N, float* W, int heads) {
   const int S = N >= 4096 ? 32 : (N >= 256 ? 8 : 1);
-  TS_LAUNCH(k_headwise_outer, dim3(64, S), 256, 0, wc.st, X, Y, N, wc.part);
+  TS_LAUNCH(k_headwise_outer, dim3(64, S), 256, 0, wc.st, X, Y, N, wc.part, heads);
   TS_LAUNCH(k_reduce_partials, cdiv(4096, 32), 256, 0, wc.st, wc.part, wc.cs, S, 1, nullptr, W, 64, 0, nullptr, 0);
   return TRAJSDE_OK;
 }

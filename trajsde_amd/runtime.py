@@ -425,9 +425,9 @@ class StageRuntime:
         ws_bytes = L.trajsde_aggregator_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), nl, K)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         with torch.cuda.device(dev):
-            _lib.check(L.trajsde_aggregator_backward(
+            _lib.check(L.trajsde_aggregator_backward_heads(
                 C.byref(gc.batch), C.byref(gc.graph), self.blob().data_ptr(), self.blob(_lib.STAGE_AGGREGATOR_BWD).data_ptr(), nl, K,
-                local_embed.contiguous().data_ptr(), d_global.to(torch.float32).contiguous().data_ptr(), ws.data_ptr(), ws_bytes,
+                int(m.num_heads), local_embed.contiguous().data_ptr(), d_global.to(torch.float32).contiguous().data_ptr(), ws.data_ptr(), ws_bytes,
                 arr, len(names), d_local.data_ptr(), _stream()), "trajsde_aggregator_backward")
         return {"grads": grads, "d_local_embed": d_local}
 
