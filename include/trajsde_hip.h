@@ -52,7 +52,9 @@ typedef enum {
   /* vanilla HiVT variant (configs/nusargo/hivt_nuSArgo_trmenc_mlpdec.yml): `num_layers` carries the number of
    * temporal layers for ENCODER_GRID and the number of future steps for DECODER_MLP */
   TRAJSDE_STAGE_ENCODER_GRID = 6,
-  TRAJSDE_STAGE_DECODER_MLP = 7
+  TRAJSDE_STAGE_DECODER_MLP = 7,
+  TRAJSDE_STAGE_DECODER_MLP_BWD = 8, /* trajsde_mlp_decoder_l2_backward; num_layers = future steps */
+  TRAJSDE_STAGE_ENCODER_GRID_BWD = 9 /* trajsde_encoder_grid_backward; num_layers = temporal layers */
 } trajsde_stage;
 
 int trajsde_param_count(int stage, int num_layers /*aggregator*/, int num_modes);
@@ -195,6 +197,15 @@ int64_t trajsde_mlp_decoder_ws_bytes(int32_t N, int num_modes);
 int trajsde_mlp_decoder_forward(int32_t N, int num_modes, int future_steps, const float* blob,
                                 const float* local_embed /*[N,64]*/, const float* global_embed /*[K,N,64]*/, float min_scale,
                                 void* ws, int64_t ws_bytes, float* loc /*[K,N,T,4]*/, float* pi /*[N,K]*/, void* stream);
+
+/* backward of MLPDecoder under the winner-takes-all L2 loss (the vanilla configuration's only loss): like
+ * trajsde_decoder_l2_backward without noise; grads follow trajsde_param_name(TRAJSDE_STAGE_DECODER_MLP_BWD, i). */
+int64_t trajsde_mlp_decoder_backward_ws_bytes(int32_t N);
+int trajsde_mlp_decoder_l2_backward(int32_t N, int num_modes, int future_steps, const float* blob_bwd, const float* local_embed,
+                                    const float* global_embed, const float* loc /*[K,N,T,4]*/, const float* y /*[N,T,2]*/,
+                                    const uint8_t* reg_mask /*[N,T]*/, void* ws, int64_t ws_bytes, float* loss,
+                                    int32_t* best_mode, float* const* grads, int n_grads, float* d_local, float* d_global,
+                                    void* stream);
 
 /* ---- winner-takes-all L2 regression loss (losses/L2.py:10-27) + backward of the decoder stage: gradients of
  *      loss = mean over valid (actor, step) of |y - loc[best mode]| w.r.t. the decoder parameters and the stage

@@ -85,3 +85,51 @@ def test_vanilla_variant_is_inference_only_and_loud(dev):
         model.training_step(batch, 0)
     with pytest.raises(NotImplementedError):
         PredictionModel(**_cfg(3, 80, 4, 2), init_seed=1)          # 2T > 128 outputs per head
+
+
+def _l2(y, loc, reg_mask):
+    l2 = torch.norm(y.unsqueeze(0) - loc, p=2, dim=-1)
+    ade = l2.clone()
+    ade[:, ~reg_mask] = 0
+    best = torch.argmin(ade.mean(-1), dim=0)
+    return l2[best, torch.arange(l2.size(1))][reg_mask].mean(), best
+
+
+@pytest.mark.parametrize("S,n,K,T", [(3, 14, 4, 30), (2, 9, 1, 64), (2, 21, 10, 60)])
+def test_mlp_decoder_l2_backward_matches_autograd(S, n, K, T, dev):
+    import restate_grid
+    from trajsde_amd import runtime
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    from trajsde_amd.synth import synth
+    batch = synth(S=S, n=n, L=5, F=T, box=80.0, seed=800 + n, mixed_source=True, history_dropout=0.3)
+    cfg = _cfg(K, T, 4, 2)
+    model = PredictionModel(**cfg, init_seed=3).to(dev)
+    data = batch.to(dev)
+    with torch.no_grad():
+        out = model(data)                                           # rotates data.y
+    local, glob = out["local_embed"], out["global_embed"]
+    res = model.decoder._rt.mlp_decoder_l2_backward(data, local, glob, out)
+    torch.cuda.synchronize()
+    c = restate_grid.flat_cfg(cfg)
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    names = [k for k in P if k.startswith("decoder.")]
+    for k in names:
+        P[k].requires_grad_(True)
+    lo, gl = local.detach().cpu().clone().requires_grad_(True), glob.detach().cpu().clone().requires_grad_(True)
+    with torch.enable_grad():
+        o = restate_grid.mlp_decoder(P, c, batch, lo, gl)
+        loss, best = _l2(data.y.cpu(), o["loc"][..., :2], o["reg_mask"])
+        loss.backward()
+    assert torch.equal(res["best_mode"].cpu().long(), best)
+    assert abs(float(res["loss"]) - float(loss.detach())) <= 1e-5 * max(1.0, float(loss.detach()))
+    got = res["grads"]
+    for k in names:
+        short = k[len("decoder."):]
+        want = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        if short not in got:
+            assert float(want.abs().max()) == 0.0, k                 # scale / pi heads
+            continue
+        scale = float(want.abs().max())
+        assert float((got[short].cpu().double() - want.double()).abs().max()) <= 2e-4 * scale + 1e-7, k
+    for a, b in ((res["d_local_embed"], lo.grad), (res["d_global_embed"], gl.grad)):
+        assert float((a.cpu() - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7

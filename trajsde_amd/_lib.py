@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtrajsde_hip.so")
 
 STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGATOR_BWD, STAGE_ENCODER_BWD = 0, 1, 2, 3, 4, 5
-STAGE_ENCODER_GRID, STAGE_DECODER_MLP = 6, 7
+STAGE_ENCODER_GRID, STAGE_DECODER_MLP, STAGE_DECODER_MLP_BWD, STAGE_ENCODER_GRID_BWD = 6, 7, 8, 9
 
 
 class TrajsdeError(RuntimeError):
@@ -76,6 +76,8 @@ SIGNATURES = {
     "trajsde_encoder_grid_forward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, C.c_int, C.c_int, P, I64, P, P]),
     "trajsde_mlp_decoder_ws_bytes": (I64, [I32, C.c_int]),
     "trajsde_mlp_decoder_forward": (C.c_int, [I32, C.c_int, C.c_int, P, P, P, F32, P, I64, P, P, P]),
+    "trajsde_mlp_decoder_backward_ws_bytes": (I64, [I32]),
+    "trajsde_mlp_decoder_l2_backward": (C.c_int, [I32, C.c_int, C.c_int, P, P, P, P, P, P, P, I64, P, P, C.POINTER(P), C.c_int, P, P, P]),
     "trajsde_profile_mode": (C.c_int, [C.c_int]),
     "trajsde_profile_report": (I64, [C.c_char_p, I64]),
     "trajsde_sde_step": (C.c_int, [I32, P, P, P, C.POINTER(F32), C.c_int, C.POINTER(Noise), P]),

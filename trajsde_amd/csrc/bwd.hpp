@@ -18,6 +18,15 @@ __global__ void k_reduce_partials(const float* part, const float* cs, int P, int
                                   int ldw, int col0, float* bias, int time_cols);
 __global__ void k_colsum(const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride);
 
+// ---- pieces of the SDE decoder backward reused by the MLP decoder backward (decoder_bwd.hip)
+struct InitV { enum : int { DGAM = 0, DBET = 64, SIZE = 128 }; };               // per-wave vector slots of k_dec_init_bwd
+__global__ void k_l2_wta(const float* loc, const float* y, const uint8_t* mask, int N, int K, int T, int32_t* best, float* minsum,
+                         int32_t* cnt);
+__global__ void k_l2_finalize(const float* minsum, const int32_t* cnt, int N, float* scal);
+__global__ void k_init_sel(const float* img, const float* local, const float* global, const int32_t* best, int N, float* y0, float* gsel);
+__global__ void k_dec_init_bwd(const float* img, const float* local, const float* gsel, const float* DY0, const int32_t* best, int N,
+                               float* DA, float* d_local, float* d_global, float* vpart);
+
 struct WgradCtx {
   hipStream_t st;
   float *part, *cs;            // scratch for wgrad_max_parts(...) partials of 4096 / 64 floats

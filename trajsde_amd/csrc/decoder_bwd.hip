@@ -374,7 +374,6 @@ __global__ __launch_bounds__(128) void k_sde_bwd(const float* __restrict__ img, 
 }
 
 // ------------------------------------------------------------------ aggr_embed backward
-struct InitV { enum : int { DGAM = 0, DBET = 64, SIZE = 128 }; };
 
 __global__ __launch_bounds__(128) void k_dec_init_bwd(const float* __restrict__ img, const float* __restrict__ local,
                                                       const float* __restrict__ gsel, const float* __restrict__ DY0,

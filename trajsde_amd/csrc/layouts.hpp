@@ -276,6 +276,15 @@ struct MlpDecBlob {
 };
 static_assert(MlpInitL::SIZE * 4 <= 160 * 1024 && MlpHeadsL::SIZE * 4 <= 160 * 1024, "MLP decoder images must fit LDS");
 
+struct MlpHeadBwdL {   // loc head of the MLP decoder: forward fields + W3^T (zero-padded to 128 columns) + W0^T
+  enum : int {
+    S_END = 0,
+    TS_FIELD(W0, MAT64, S), TS_FIELD(B0, 64, W0), TS_FIELD(G, 64, B0), TS_FIELD(E, 64, G), TS_FIELD(W3, 2 * MAT64, E),
+    TS_FIELD(B3, 128, W3), TS_FIELD(W3T, 2 * MAT64, B3), TS_FIELD(W0T, MAT64, W3T),
+    SIZE = W0T_END
+  };
+};
+
 // ---- backward images of the decoder stage (decoder_bwd.hip): `*T` fields hold the TRANSPOSED matrix in
 // fragment order, so dX^T = W^T dY^T runs through the same linear_acc as the forward pass
 struct SweepL {       // reverse Euler-Maruyama sweep: drift and diffusion nets
@@ -384,6 +393,9 @@ static_assert(GruBwdL::SIZE * 4 <= 160 * 1024 && EncSdeBwdL::SIZE * 4 <= 160 * 1
               "encoder backward images must fit LDS");
 static_assert(FfnBwdAL::SIZE * 4 <= 160 * 1024 && UpdBwdL::SIZE * 4 <= 160 * 1024 && EdgeBwdL::SIZE * 4 <= 160 * 1024,
               "node backward images must fit LDS");
+struct MlpDecBwdBlob {
+  enum : int { HEAD = 0, INIT = MlpHeadBwdL::SIZE, SIZE = INIT + InitBwdL::SIZE };
+};
 static_assert(SweepL::SIZE * 4 <= 160 * 1024, "sweep image must fit LDS");
 static_assert(DecBwdBlob::HEAD % 4 == 0 && DecBwdBlob::INIT % 4 == 0, "16-byte aligned images");
 

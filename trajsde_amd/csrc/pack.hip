@@ -48,12 +48,13 @@ __global__ void k_pack_mat_pad(const float* __restrict__ src, float* __restrict_
 }
 
 // fragment image [jo < jto][q < jti][lane][4] of a TRANSPOSED weight: element [r][c] = W[c][col0 + r] (W row-major, ld)
-__global__ void k_pack_matT(const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld, int col0) {
+__global__ void k_pack_matT(const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld, int col0,
+                            int rows_valid) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= jto * jti * 256) return;
   const int c = i & 3, lane = (i >> 2) & 63, q = (i >> 8) % jti, jo = (i >> 8) / jti;
   const int row_t = 16 * jo + (lane & 15), col_t = 16 * q + 4 * (lane >> 4) + c;      // element of W^T
-  dst[i] = src[int64_t(col_t) * ld + col0 + row_t];
+  dst[i] = col_t < rows_valid ? src[int64_t(col_t) * ld + col0 + row_t] : 0.f;      // rows of W beyond rows_valid read as 0
 }
 
 // bf16x6 planes: dst (as bf16) [plane][jo][s][lane][8]; element j of lane (i,g) in k-step s is the plane-th exact
@@ -115,10 +116,10 @@ struct Packer {
     k_pack_mat_pad<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, rows_valid);
   }
   // transposed image of the [16*jti x 16*jto] block of W starting at column col0 (default: a 64x64 block)
-  void matT(const std::string& n, int dst, int ld, int col0 = 0, int jto = 4, int jti = 4) {
+  void matT(const std::string& n, int dst, int ld, int col0 = 0, int jto = 4, int jti = 4, int rows_valid = 1 << 30) {
     const float* s = src(n);
     if (dry) return;
-    k_pack_matT<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, col0);
+    k_pack_matT<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, col0, rows_valid);
   }
   void mat6(const std::string& n, int dst, int rows, int cols, int ld, int col0 = 0) {
     const float* s = src(n);
@@ -453,6 +454,28 @@ static void recipe_decoder(Packer& P) {
   recipe_head(P, "scale", DecBlob::SDE6 + DecSdeL6::SCALE);
 }
 
+static void recipe_aggr_embed_bwd(Packer& P, int b) {      // aggr_embed of either decoder: forward halves + transposes
+  using I = InitBwdL;
+  P.mat("aggr_embed.0.weight", b + I::WA_G, 64, 64, 128, 0);
+  P.mat("aggr_embed.0.weight", b + I::WA_L, 64, 64, 128, 64);
+  P.vec("aggr_embed.0.bias", b + I::BA, 64);
+  P.ln("aggr_embed.1", b + I::AG, b + I::AE);
+  P.matT("aggr_embed.0.weight", b + I::WA_GT, 128, 0);
+  P.matT("aggr_embed.0.weight", b + I::WA_LT, 128, 64);
+}
+// MLPDecoder backward (L2 on loc): loc head + aggr_embed; `scale` and `pi` get no gradient from that loss
+static void recipe_decoder_mlp_bwd(Packer& P, int T) {
+  using H = MlpHeadBwdL;
+  const int h = MlpDecBwdBlob::HEAD;
+  P.lin("loc.0", h + H::W0, h + H::B0);
+  P.ln("loc.1", h + H::G, h + H::E);
+  P.mat_pad("loc.3.weight", h + H::W3, 8, 4, 64, 2 * T);
+  P.vec("loc.3.bias", h + H::B3, 2 * T);
+  P.matT("loc.3.weight", h + H::W3T, 64, 0, 4, 8, 2 * T);          // (W3 [2T,64])^T as a 64 x 128 image
+  P.matT("loc.0.weight", h + H::W0T, 64);
+  recipe_aggr_embed_bwd(P, MlpDecBwdBlob::INIT);
+}
+
 // backward images of the decoder stage (loc head, drift/diffusion nets, aggr_embed); `pi` and `scale` receive no
 // gradient from the L2 regression loss and are not packed
 static void recipe_decoder_bwd(Packer& P) {
@@ -465,13 +488,7 @@ static void recipe_decoder_bwd(Packer& P) {
   P.vec("lsde_func.g_func.net.4.weight", s + SweepL::G_W4, 64);
   recipe_head(P, "decoder", h + HeadBwdL::FWD);
   P.matT("decoder.0.weight", h + HeadBwdL::W0T, 64);
-  using I = InitBwdL;
-  P.mat("aggr_embed.0.weight", b + I::WA_G, 64, 64, 128, 0);
-  P.mat("aggr_embed.0.weight", b + I::WA_L, 64, 64, 128, 64);
-  P.vec("aggr_embed.0.bias", b + I::BA, 64);
-  P.ln("aggr_embed.1", b + I::AG, b + I::AE);
-  P.matT("aggr_embed.0.weight", b + I::WA_GT, 128, 0);
-  P.matT("aggr_embed.0.weight", b + I::WA_LT, 128, 64);
+  recipe_aggr_embed_bwd(P, b);
   // not packed, but they receive a gradient: listed so that the gradient slots of trajsde_decoder_l2_backward
   // follow this parameter table
   for (const char* n : {"lsde_func.f_func.net.0.bias", "lsde_func.f_func.net.2.bias", "lsde_func.f_func.net.4.bias",
@@ -524,7 +541,7 @@ static void recipe_aggregator_bwd(Packer& P, int nl, int K) {
   P.index("multihead_proj.bias");
   if (!P.dry)
     for (int k = 0; k < K; ++k)
-      k_pack_matT<<<cdiv(16 * 256, 256), 256, 0, P.stream>>>(w + int64_t(k) * MAT64, P.blob + AggBwdBlob::proj(nl, k), 4, 4, 64, 0);
+      k_pack_matT<<<cdiv(16 * 256, 256), 256, 0, P.stream>>>(w + int64_t(k) * MAT64, P.blob + AggBwdBlob::proj(nl, k), 4, 4, 64, 0, 1 << 30);
 }
 
 static void recipe_edge_kv_bwd(Packer& P, const std::string& p, const std::string& embed, int kv, int emb) {
@@ -611,6 +628,7 @@ static bool run_recipe(Packer& P, int stage, int nl, int K) {
     case TRAJSDE_STAGE_ENCODER_BWD: recipe_encoder_bwd(P); return true;
     case TRAJSDE_STAGE_ENCODER_GRID: recipe_encoder_grid(P, nl); return true;
     case TRAJSDE_STAGE_DECODER_MLP: recipe_decoder_mlp(P, nl); return true;
+    case TRAJSDE_STAGE_DECODER_MLP_BWD: recipe_decoder_mlp_bwd(P, nl); return true;
   }
   return false;
 }
@@ -715,6 +733,7 @@ int64_t trajsde_blob_floats(int stage, int num_layers, int num_modes) {
     case TRAJSDE_STAGE_ENCODER_BWD: return EncBwdBlob::SIZE;
     case TRAJSDE_STAGE_ENCODER_GRID: return EncGridBlob::size(num_layers);
     case TRAJSDE_STAGE_DECODER_MLP: return MlpDecBlob::SIZE;
+    case TRAJSDE_STAGE_DECODER_MLP_BWD: return MlpDecBwdBlob::SIZE;
   }
   return fail(TRAJSDE_ERR_INVALID, "unknown stage");
 }

@@ -432,6 +432,36 @@ class StageRuntime:
         return {"grads": grads, "d_local_embed": d_local}
 
 
+    def mlp_decoder_l2_backward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor,
+                                out: Dict[str, torch.Tensor]) -> Dict[str, object]:
+        """L2 (winner takes all) on `out` = mlp_decoder_forward(...) and its gradients, like decoder_l2_backward"""
+        m = self.module
+        dev = local_embed.device
+        K, T, N = int(m.num_modes), int(m.future_steps), local_embed.shape[0]
+        y = data["y"]
+        if y is None or tuple(y.shape) != (N, T, 2):
+            raise _lib.TrajsdeError(f"data['y'] must be [{N},{T},2] (rotated targets)")
+        y = y.to(torch.float32).contiguous()
+        mask = out["reg_mask"].contiguous().view(torch.uint8)
+        L = _lib.lib()
+        names = self.param_names(_lib.STAGE_DECODER_MLP_BWD)
+        grads = self._grad_buffers(_lib.STAGE_DECODER_MLP_BWD)
+        arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        best = torch.empty(N, device=dev, dtype=torch.int32)
+        d_local = torch.empty(N, D, device=dev, dtype=torch.float32)
+        d_global = torch.empty(K, N, D, device=dev, dtype=torch.float32)
+        ws_bytes = L.trajsde_mlp_decoder_backward_ws_bytes(N)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_mlp_decoder_l2_backward(
+                N, K, T, self.blob(_lib.STAGE_DECODER_MLP_BWD).data_ptr(), local_embed.contiguous().data_ptr(),
+                global_embed.contiguous().data_ptr(), out["loc"].contiguous().data_ptr(), y.data_ptr(), mask.data_ptr(), ws.data_ptr(),
+                ws_bytes, loss.data_ptr(), best.data_ptr(), arr, len(names), d_local.data_ptr(), d_global.data_ptr(), _stream()),
+                "trajsde_mlp_decoder_l2_backward")
+        return {"loss": loss[0], "best_mode": best, "grads": grads, "d_local_embed": d_local, "d_global_embed": d_global}
+
+
 class GraphContext:
     """Device-side graph structures of one batch (CSR, compacted edge lists, segment pointers), built once per
     forward by the first stage that needs them and parked on the batch object for the next stage."""
