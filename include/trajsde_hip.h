@@ -207,6 +207,13 @@ int trajsde_mlp_decoder_l2_backward(int32_t N, int num_modes, int future_steps, 
                                     int32_t* best_mode, float* const* grads, int n_grads, float* d_local, float* d_global,
                                     void* stream);
 
+/* backward of the vanilla LocalEncoder: dL/d local_embed -> one gradient per parameter of
+ * trajsde_param_name(TRAJSDE_STAGE_ENCODER_GRID_BWD, i) (buffers pre-zeroed by the caller); forward recomputed inside. */
+int64_t trajsde_encoder_grid_backward_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int num_temporal_layers);
+int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rotate_mat, const float* blob_fwd,
+                                  const float* blob_bwd, int num_heads, int num_temporal_layers, const float* d_local /*[N,64]*/,
+                                  void* ws, int64_t ws_bytes, float* const* grads, int n_grads, void* stream);
+
 /* ---- winner-takes-all L2 regression loss (losses/L2.py:10-27) + backward of the decoder stage: gradients of
  *      loss = mean over valid (actor, step) of |y - loc[best mode]| w.r.t. the decoder parameters and the stage
  *      inputs.  `loc` is the forward output, `noise` the same noise (seed or z) the forward used; the winning

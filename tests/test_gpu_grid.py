@@ -76,13 +76,15 @@ def test_vanilla_forward_matches_oracle_on_synthetic(S, n, K, T, heads, layers, 
     assert torch.equal(out["reg_mask"].cpu(), want["reg_mask"])
 
 
-def test_vanilla_variant_is_inference_only_and_loud(dev):
+def test_vanilla_variant_refuses_what_it_does_not_build(dev):
     from trajsde_amd.models.model_base_mix import PredictionModel
     from trajsde_amd.synth import synth
-    model = PredictionModel(**_cfg(3, 12, 4, 2), init_seed=1).to(dev)
+    cfg = _cfg(3, 12, 4, 2)
+    cfg["model_specific"]["kwargs"]["ts_drop"] = 0.1
+    model = PredictionModel(**cfg, init_seed=1).to(dev)
     batch = synth(S=1, n=5, L=3, F=12, box=50.0, seed=1).to(dev)
     with pytest.raises(NotImplementedError):
-        model.training_step(batch, 0)
+        model.training_step(batch, 0)                               # ts_drop augmentation
     with pytest.raises(NotImplementedError):
         PredictionModel(**_cfg(3, 80, 4, 2), init_seed=1)          # 2T > 128 outputs per head
 
@@ -133,3 +135,101 @@ def test_mlp_decoder_l2_backward_matches_autograd(S, n, K, T, dev):
         assert float((got[short].cpu().double() - want.double()).abs().max()) <= 2e-4 * scale + 1e-7, k
     for a, b in ((res["d_local_embed"], lo.grad), (res["d_global_embed"], gl.grad)):
         assert float((a.cpu() - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7
+
+
+def _oracle_full(model, cfg, batch_cpu, d_local=None):
+    """float64 autograd over oracle/restate_grid.py: whole model under L2, or the encoder alone under sum(local * d_local)"""
+    import restate
+    import restate_grid
+    c = restate_grid.flat_cfg(cfg)
+    dt = torch.float64
+    P = {k: (v.detach().cpu().to(dt) if v.is_floating_point() else v.detach().cpu().clone()) for k, v in model.state_dict().items()}
+    names = [k for k in P if P[k].is_floating_point() and not k.endswith("attn_mask")]
+    for k in names:
+        P[k].requires_grad_(True)
+    b = H.clone_batch(batch_cpu)
+    for k in b.keys:
+        if torch.is_tensor(b[k]) and b[k].is_floating_point():
+            b[k] = b[k].to(dt)
+    torch.set_default_dtype(dt)
+    try:
+        rot, y_rot = restate.rotate_inputs(b)
+        with torch.enable_grad():
+            local = restate_grid.local_encoder_grid(P, c, b, rot)
+            if d_local is not None:
+                loss = (local * d_local.cpu().to(dt)).sum()
+            else:
+                glob = restate.global_interactor(P, c, b, rot, local)
+                out = restate_grid.mlp_decoder(P, c, b, local, glob)
+                loss, _ = _l2(y_rot, out["loc"][..., :2], out["reg_mask"])
+            loss.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return float(loss.detach()), {k: P[k].grad for k in names}
+
+
+def _compare(named_grads, want, prefix=""):
+    bad = []
+    for n, g in named_grads:
+        w = want[prefix + n]
+        if g is None:
+            assert w is None or float(w.abs().max()) == 0.0, n
+            continue
+        scale = float(w.abs().max())
+        err = float((g.cpu().double() - w).abs().max())
+        zero_by_symmetry = n.endswith("lin_k.bias") or n.endswith("lin_k_node.bias") or n.endswith("lin_k_edge.bias")
+        if (err > 5e-5 or scale > 5e-5) if zero_by_symmetry else (err > 2e-4 * scale + 1e-7):
+            bad.append((n, err, scale))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("S,n,heads,layers,kw", [
+    (3, 12, 4, 2, dict(mixed_source=True, history_dropout=0.4)),
+    (2, 9, 8, 1, dict(source=1, history_dropout=0.2)),
+])
+def test_vanilla_encoder_backward_matches_autograd(S, n, heads, layers, kw, dev):
+    from trajsde_amd import runtime
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    from trajsde_amd.synth import synth
+    batch = synth(S=S, n=n, L=6, F=5, box=60.0, seed=900 + n, **kw)
+    cfg = _cfg(2, 5, heads, layers)
+    model = PredictionModel(**cfg, init_seed=5).to(dev)
+    data = batch.to(dev)
+    rot, y_rot = runtime.rotate_inputs(data)
+    data.y, data["rotate_mat"] = y_rot, rot
+    with torch.no_grad():
+        local = model.encoder(data=data)
+    d_local = torch.randn(local.shape, generator=torch.Generator().manual_seed(2))
+    res = model.encoder._rt.encoder_grid_backward(data, d_local.to(dev))
+    torch.cuda.synchronize()
+    _, want = _oracle_full(model, cfg, batch, d_local)
+    _compare(res["grads"].items(), want, "encoder.")
+
+
+def test_vanilla_training_step_matches_end_to_end_autograd_and_trains(dev):
+    from trajsde_amd import driver
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    from trajsde_amd.synth import synth
+    K, T = 3, 12
+    batch = synth(S=3, n=11, L=6, F=T, box=70.0, seed=91, mixed_source=True, history_dropout=0.3)
+    cfg = _cfg(K, T, 4, 2)
+    model = PredictionModel(**cfg, init_seed=7).to(dev).train()
+    data = batch.to(dev)
+    y0 = data.y.clone()
+    loss = model.training_step(data, 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    want_loss, want = _oracle_full(model, cfg, batch)
+    assert abs(float(loss.detach()) - want_loss) <= 1e-5 * max(1.0, want_loss)
+    reached = {id(p) for p in model.params_with_gradient()}
+    _compare(((n, p.grad) for n, p in model.named_parameters() if id(p) in reached), want)
+    assert all(p.grad is None for n, p in model.named_parameters() if id(p) not in reached)
+    model.zero_grad(set_to_none=True)
+    model.lr, model.weight_decay, model.T_max = 2e-3, 1e-4, 10
+
+    def fresh(epoch):
+        for _ in range(6):
+            data.y = y0
+            yield data
+    hist = driver.train(model, fresh, epochs=2)
+    assert len(hist) == 12 and sum(hist[-3:]) < sum(hist[:3]), hist

@@ -78,6 +78,9 @@ SIGNATURES = {
     "trajsde_mlp_decoder_forward": (C.c_int, [I32, C.c_int, C.c_int, P, P, P, F32, P, I64, P, P, P]),
     "trajsde_mlp_decoder_backward_ws_bytes": (I64, [I32]),
     "trajsde_mlp_decoder_l2_backward": (C.c_int, [I32, C.c_int, C.c_int, P, P, P, P, P, P, P, I64, P, P, C.POINTER(P), C.c_int, P, P, P]),
+    "trajsde_encoder_grid_backward_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph), C.c_int]),
+    "trajsde_encoder_grid_backward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, C.c_int, C.c_int, P, P, I64, C.POINTER(P),
+                                                C.c_int, P]),
     "trajsde_profile_mode": (C.c_int, [C.c_int]),
     "trajsde_profile_report": (I64, [C.c_char_p, I64]),
     "trajsde_sde_step": (C.c_int, [I32, P, P, P, C.POINTER(F32), C.c_int, C.POINTER(Noise), P]),

@@ -65,12 +65,24 @@ int node_block_backward(const float* img /*NodeBlockBwdL*/, const NodeBlockTape&
                         const NodeBlockScratch& sc, const WgradCtx& wc, const NodeBlockGrads& gr, float* dagg, float* dxn,
                         hipStream_t st);
 
+// the FFN half alone (TemporalEncoderLayer: linear1 / linear2 / norm2); uses gr.w1, b1, w2, b2, n2g, n2b only
+int ffn_block_backward(const float* img_a /*FfnBwdAL*/, const float* img_b /*FfnBwdBL*/, const float* xn2, const float* x1,
+                       const float* dout, int64_t R, const NodeBlockScratch& sc, const WgradCtx& wc, const NodeBlockGrads& gr,
+                       hipStream_t st);
+
 struct EdgeEmbedScratch { float *S, *DEP, *DSP, *A0, *B0, *vpart; };             // [E,64] x5
 struct EdgeEmbedGrads {
   float *a_w0, *a_b0, *a_g, *a_e, *b_w0, *b_b0, *b_g, *b_e, *wa3, *ba3, *wb3, *bb3, *ag0, *ae0, *w2, *b2, *ag3, *ae3;
 };
 int edge_embed_backward(const float* img /*EdgeBwdL*/, const float* geom, const float* demb, int64_t E, const EdgeEmbedScratch& sc,
                         const WgradCtx& wc, const EdgeEmbedGrads& gr, hipStream_t st);
+
+// ---- TemporalEncoder backward kernels (grid_bwd.hip)
+__global__ void k_tr_final_bwd(const float* norm, const float* x, const float* dtout, int N, float* DX, float* vpart);
+template <int HEADS>
+__global__ void k_tr_attention_bwd(const float* q, const float* k, const float* v, const float* dO, int N, float* dq, float* dk, float* dv);
+__global__ void k_tr_prep_bwd(const float* DX0, const uint8_t* pad, int N, int TT, float* DAA);
+__global__ void k_tr_tok_grad(const float* DX0, const uint8_t* pad, int N, int TT, float* dpad, float* dcls, float* dpos);
 
 // ordered parameter names of a stage (the dry run of its pack recipe, pack.hip)
 std::vector<std::string> stage_param_names(int stage, int num_layers, int num_modes);

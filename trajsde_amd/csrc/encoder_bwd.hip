@@ -699,6 +699,42 @@ int run_attn_chain(const AttnChain& c, const float* dout, EncBwdWs& w, const Wgr
   return run_wgrad(wc, w.DQ, 64, c.tp.xn, 64, R, R, wq, 64, 0, bq, 0);
 }
 
+// AAEncoder backward over the H snapshots: w.DAA = d aa_out [H,Nt,64] on entry; attention chain, centre embedding, bos tokens
+int aa_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_bwd, EncBwdWs& w,
+                        const WgradCtx& wc, GradTable& G, int heads, hipStream_t st) {
+  using BB = EncBwdBlob;
+  const int N = b->N, Nt = g->Nt, H = b->H;
+  const int64_t R = int64_t(H) * Nt, Eaa = g->E_aa;
+    AttnChain c{blob_bwd + BB::AA_NODE, blob_bwd + BB::AA_PROJ, blob_bwd + BB::AA_EDGEKV, blob_bwd + BB::AA_EDGEEMB,
+                g->aa_geom, w.q, w.logits, w.v, w.center, g->aa_dst, g->aa_segptr, NodeBlockTape{w.agg, w.cn, w.x1, w.xn2}, R, Eaa,
+                "aa_encoder", "nbr_embed", heads};
+    if (int rc = run_attn_chain(c, w.DAA, w, wc, G, w.DCENTER, st)) return rc;
+    const std::string ce = "aa_encoder.center_embed.embed.";
+    float *w0 = G(ce + "0.weight"), *b0 = G(ce + "0.bias"), *g1 = G(ce + "1.weight"), *e1 = G(ce + "1.bias");
+    float *w3 = G(ce + "3.weight"), *b3 = G(ce + "3.bias"), *g4 = G(ce + "4.weight"), *e4 = G(ce + "4.bias");
+    float *w6 = G(ce + "6.weight"), *b6 = G(ce + "6.bias"), *g7 = G(ce + "7.weight"), *e7 = G(ce + "7.bias");
+    float* tok = G("aa_encoder.bos_token");
+    TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
+    const int gt = vec_grid((R + 15) / 16, 256, CenterTailL::SIZE * 4);
+    TS_LAUNCH(k_aa_center_bwd_tail, gt, 256, CenterTailL::SIZE * 4, st, blob_bwd + BB::AA_CTAIL, b->x, g->x_fake, rot, b->bos_mask, g->orig, N,
+              Nt, H, w.DCENTER, w.A1, w.A2, w.DA3P, w.DA2P, w.XR, w.nb.vpart);
+    float* const tv[4] = {g7, e7, g4, e4};
+    for (int i = 0; i < 4; ++i)
+      if (int rc = run_colsum(st, w.nb.vpart + 64 * i, gt * 4, 256, 64, tv[i])) return rc;
+    if (int rc = run_wgrad(wc, w.DA3P, 64, w.A2, 64, R, R, w6, 64, 0, b6, 0)) return rc;
+    if (int rc = run_wgrad(wc, w.DA2P, 64, w.A1, 64, R, R, w3, 64, 0, b3, 0)) return rc;
+    const int lds_br = (EdgeL::WA3 + MAT64) * 4;
+    const int gb = vec_grid((R + 15) / 16, 256, lds_br);
+    TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, blob_bwd + BB::AA_CHEAD, w.XR, w.DA2P, R, w.nb.vpart);
+    if (int rc = run_colsum(st, w.nb.vpart, gb * 4, 320, 64, g1)) return rc;
+    if (int rc = run_colsum(st, w.nb.vpart + 64, gb * 4, 320, 64, e1)) return rc;
+    if (int rc = run_colsum(st, w.nb.vpart + 128, gb * 4, 320, 64, w0, 2)) return rc;
+    if (int rc = run_colsum(st, w.nb.vpart + 192, gb * 4, 320, 64, w0 + 1, 2)) return rc;
+    if (int rc = run_colsum(st, w.nb.vpart + 256, gb * 4, 320, 64, b0)) return rc;
+    TS_LAUNCH(k_bos_grad, H, 1024, 0, st, w.DCENTER, b->bos_mask, g->orig, Nt, H, tok);
+  return TRAJSDE_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -837,37 +873,160 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
     }
   }
   if (d_aa_out) TS_HIP(hipMemcpyAsync(d_aa_out, w.DAA, size_t(R) * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
-  // ---- AAEncoder over the H snapshots
-  {
-    AttnChain c{blob_bwd + BB::AA_NODE, blob_bwd + BB::AA_PROJ, blob_bwd + BB::AA_EDGEKV, blob_bwd + BB::AA_EDGEEMB,
-                g->aa_geom, w.q, w.logits, w.v, w.center, g->aa_dst, g->aa_segptr, NodeBlockTape{w.agg, w.cn, w.x1, w.xn2}, R, Eaa,
-                "aa_encoder", "nbr_embed"};
-    if (int rc = run_attn_chain(c, w.DAA, w, wc, G, w.DCENTER, st)) return rc;
-    const std::string ce = "aa_encoder.center_embed.embed.";
-    float *w0 = G(ce + "0.weight"), *b0 = G(ce + "0.bias"), *g1 = G(ce + "1.weight"), *e1 = G(ce + "1.bias");
-    float *w3 = G(ce + "3.weight"), *b3 = G(ce + "3.bias"), *g4 = G(ce + "4.weight"), *e4 = G(ce + "4.bias");
-    float *w6 = G(ce + "6.weight"), *b6 = G(ce + "6.bias"), *g7 = G(ce + "7.weight"), *e7 = G(ce + "7.bias");
-    float* tok = G("aa_encoder.bos_token");
-    TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
-    const int gt = vec_grid((R + 15) / 16, 256, CenterTailL::SIZE * 4);
-    TS_LAUNCH(k_aa_center_bwd_tail, gt, 256, CenterTailL::SIZE * 4, st, blob_bwd + BB::AA_CTAIL, b->x, g->x_fake, rot, b->bos_mask, g->orig, N,
-              Nt, H, w.DCENTER, w.A1, w.A2, w.DA3P, w.DA2P, w.XR, w.nb.vpart);
-    float* const tv[4] = {g7, e7, g4, e4};
-    for (int i = 0; i < 4; ++i)
-      if (int rc = run_colsum(st, w.nb.vpart + 64 * i, gt * 4, 256, 64, tv[i])) return rc;
-    if (int rc = run_wgrad(wc, w.DA3P, 64, w.A2, 64, R, R, w6, 64, 0, b6, 0)) return rc;
-    if (int rc = run_wgrad(wc, w.DA2P, 64, w.A1, 64, R, R, w3, 64, 0, b3, 0)) return rc;
-    const int lds_br = (EdgeL::WA3 + MAT64) * 4;
-    const int gb = vec_grid((R + 15) / 16, 256, lds_br);
-    TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, blob_bwd + BB::AA_CHEAD, w.XR, w.DA2P, R, w.nb.vpart);
-    if (int rc = run_colsum(st, w.nb.vpart, gb * 4, 320, 64, g1)) return rc;
-    if (int rc = run_colsum(st, w.nb.vpart + 64, gb * 4, 320, 64, e1)) return rc;
-    if (int rc = run_colsum(st, w.nb.vpart + 128, gb * 4, 320, 64, w0, 2)) return rc;
-    if (int rc = run_colsum(st, w.nb.vpart + 192, gb * 4, 320, 64, w0 + 1, 2)) return rc;
-    if (int rc = run_colsum(st, w.nb.vpart + 256, gb * 4, 320, 64, b0)) return rc;
-    TS_LAUNCH(k_bos_grad, H, 1024, 0, st, w.DCENTER, b->bos_mask, g->orig, Nt, H, tok);
-  }
+  if (int rc = aa_encoder_backward(b, g, rot, blob_bwd, w, wc, G, 8, st)) return rc;
   return TRAJSDE_OK;
+}
+
+// ------------------------------------------------------------------ vanilla LocalEncoder backward (GENC:52-93)
+namespace {
+struct TrLayerTape { float *xn, *q, *k, *v, *o, *x1, *xn2, *out; };
+struct GridBwdExtra {      // buffers of the vanilla encoder backward beyond EncBwdWs: the temporal tape and its gradients
+  float *x0, *dxa, *dxb, *dq, *dk, *dv, *dO, *tout, *dtout, *H, *DH, *dx1;
+  std::vector<TrLayerTape> tp;
+  int64_t bytes;
+  bool ok;
+  GridBwdExtra(void* base, int64_t size, int64_t N, int nl) : tp(nl) {
+    Carver ex(base, size);
+    const int64_t RT = N * 22;
+    x0 = ex.take<float>(RT * 64);
+    for (auto& l : tp) {
+      l.xn = ex.take<float>(RT * 64); l.q = ex.take<float>(RT * 64); l.k = ex.take<float>(RT * 64); l.v = ex.take<float>(RT * 64);
+      l.o = ex.take<float>(RT * 64); l.x1 = ex.take<float>(RT * 64); l.xn2 = ex.take<float>(RT * 64); l.out = ex.take<float>(RT * 64);
+    }
+    float** slabs[] = {&dxa, &dxb, &dq, &dk, &dv, &dO, &dx1};
+    for (float** p : slabs) *p = ex.take<float>(RT * 64);
+    tout = ex.take<float>(N * 64);
+    dtout = ex.take<float>(N * 64);
+    H = ex.take<float>(RT * 256);           // the temporal rows (22 N) outnumber the snapshot rows EncBwdWs sizes its node scratch for
+    DH = ex.take<float>(RT * 256);
+    bytes = ex.off + 256;
+    ok = ex.ok;
+  }
+};
+}  // namespace
+
+int64_t trajsde_encoder_grid_backward_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int num_temporal_layers) {
+  if (!b || !g || num_temporal_layers < 1 || num_temporal_layers > 16) return -1;
+  EncBwdWs w(b, g, nullptr, 0);
+  return align_up(w.total, 256) + GridBwdExtra(nullptr, 0, b->N, num_temporal_layers).bytes;
+}
+
+int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_fwd,
+                                  const float* blob_bwd, int num_heads, int num_temporal_layers, const float* d_local, void* ws,
+                                  int64_t ws_bytes, float* const* grads, int n_grads, void* stream_) {
+  TS_REQUIRE(b && g && rot && blob_fwd && blob_bwd && d_local && ws && grads, "encoder_grid_backward: null pointer");
+  TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_grid_backward: graph not compacted");
+  TS_REQUIRE(b->A == 0 && g->Nt == b->N && b->H == 21, "encoder_grid_backward: graph with A = 0 and 21 history steps expected");
+  TS_REQUIRE(num_heads == 8 || num_heads == 4, "encoder_grid_backward: num_heads must be 8 or 4");
+  const int nl = num_temporal_layers;
+  TS_REQUIRE(nl >= 1 && nl <= 16, "encoder_grid_backward: 1..16 temporal layers");
+  const std::vector<std::string> names = stage_param_names(TRAJSDE_STAGE_ENCODER_GRID_BWD, nl, 0);
+  TS_REQUIRE(n_grads == int(names.size()), "encoder_grid_backward: gradient count does not match trajsde_param_count(ENCODER_GRID_BWD)");
+  GradTable G;
+  for (int i = 0; i < n_grads; ++i) {
+    TS_REQUIRE(grads[i] != nullptr, "encoder_grid_backward: null gradient buffer " + names[i]);
+    G.slot[names[i]] = grads[i];
+  }
+  if (ws_bytes < trajsde_encoder_grid_backward_ws_bytes(b, g, nl)) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_grid_backward: workspace too small");
+  EncBwdWs w(b, g, ws, ws_bytes);
+  GridBwdExtra ex(static_cast<char*>(ws) + align_up(w.total, 256), ws_bytes - align_up(w.total, 256), b->N, nl);
+  TS_REQUIRE(w.ok && ex.ok, "encoder_grid_backward: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  const int N = b->N, H = b->H;
+  const int64_t R = int64_t(H) * N, RT = int64_t(N) * 22, Eaa = g->E_aa, Ela = g->E_la, rtiles = (RT + 15) / 16;
+  std::vector<TrLayerTape>& tp = ex.tp;
+  float *x0 = ex.x0, *dxa = ex.dxa, *dxb = ex.dxb, *dq = ex.dq, *dk = ex.dk, *dv = ex.dv, *dO = ex.dO, *tout = ex.tout, *dtout = ex.dtout;
+  const WgradCtx wc{st, w.part, w.cs, nullptr};
+  using FB = EncBlob;
+  using BB = EncBwdBlob;
+  // ================= forward recompute =================
+  TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob_fwd + FB::AA_CENTER, b->x,
+            g->x_fake, rot, b->bos_mask, g->orig, N, N, H, w.center, w.cn, w.q);
+  if (Eaa > 0)
+    TS_LAUNCH(k_edge_kv<true>, tile_grid((Eaa + 15) / 16, 1024, EdgeL6::SIZE * 4), 1024, EdgeL6::SIZE * 4, st, blob_fwd + FB::AA_EDGE6,
+              g->aa_geom, g->aa_dst, w.q, Eaa, w.logits, w.v, num_heads);
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, g->aa_segptr, w.logits, w.v, R, w.agg, num_heads);
+  TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
+            w.center, R, w.x1, w.xn2);
+  TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out);
+  TS_LAUNCH(k_tr_prep, cdiv(RT * 64, 256), 256, 0, st, w.aa_out, b->padding_mask, blob_fwd + EncGridBlob::TOK, N, b->TT, x0);
+  const float* x = x0;
+  for (int l = 0; l < nl; ++l) {
+    const float* lb = blob_fwd + EncGridBlob::layer(l);
+    TS_LAUNCH(k_node_proj<3>, tile_grid(rtiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + TrLayerL::QKV, x, RT,
+              tp[l].xn, tp[l].q, tp[l].k, tp[l].v);
+    if (num_heads == 4) TS_LAUNCH(k_tr_attention<4>, cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, N, tp[l].o);
+    else TS_LAUNCH(k_tr_attention<8>, cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, N, tp[l].o);
+    TS_LAUNCH(k_tr_outproj, tile_grid(rtiles, 512, TrOutL::SIZE * 4), 512, TrOutL::SIZE * 4, st, lb + TrLayerL::OUT, tp[l].o, x, RT, tp[l].x1,
+              tp[l].xn2);
+    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, tp[l].x1, tp[l].xn2, RT, tp[l].out);
+    x = tp[l].out;
+  }
+  TS_LAUNCH(k_tr_final, tile_grid((int64_t(N) + 15) / 16, 256, 0), 256, 0, st, blob_fwd + EncGridBlob::norm(nl), x, N, tout);
+  TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
+            blob_fwd + FB::AL_Q, tout, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
+  if (Ela > 0)
+    TS_LAUNCH(k_edge_kv<true>, tile_grid((Ela + 15) / 16, 1024, EdgeL6::SIZE * 4), 1024, EdgeL6::SIZE * 4, st, blob_fwd + FB::AL_EDGE6,
+              g->la_geom, g->la_dst, w.al_q, Ela, w.al_logits, w.al_v, num_heads);
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(N, 4), 256, 0, st, g->la_segptr, w.al_logits, w.al_v, int64_t(N), w.al_agg, num_heads);
+  TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
+            w.al_agg, w.al_xn, tout, int64_t(N), w.al_x1, w.al_xn2);
+  // ================= backward =================
+  {
+    AttnChain c{blob_bwd + BB::AL_NODE, blob_bwd + BB::AL_PROJ, blob_bwd + BB::AL_EDGEKV, blob_bwd + BB::AL_EDGEEMB,
+                g->la_geom, w.al_q, w.al_logits, w.al_v, tout, g->la_dst, g->la_segptr,
+                NodeBlockTape{w.al_agg, w.al_xn, w.al_x1, w.al_xn2}, int64_t(N), Ela, "al_encoder", "lane_embed", num_heads};
+    if (int rc = run_attn_chain(c, d_local, w, wc, G, dtout, st)) return rc;
+  }
+  const std::string te = "temporal_encoder.";
+  float* dcur = dxa;
+  float* dnext = dxb;
+  TS_HIP(hipMemsetAsync(dcur, 0, size_t(RT) * 64 * sizeof(float), st));
+  {
+    const int gf = vec_grid((int64_t(N) + 15) / 16, 256, 0);
+    float *ng = G(te + "transformer_encoder.norm.weight"), *nb = G(te + "transformer_encoder.norm.bias");
+    TS_REQUIRE(!G.missing, "encoder_grid_backward: parameter table lacks " + G.missing_name);
+    TS_LAUNCH(k_tr_final_bwd, gf, 256, 0, st, blob_bwd + EncGridBwdBlob::norm(nl), x, dtout, N, dcur, w.nb.vpart);
+    if (int rc = run_colsum(st, w.nb.vpart, gf * 4, 128, 64, ng)) return rc;
+    if (int rc = run_colsum(st, w.nb.vpart + 64, gf * 4, 128, 64, nb)) return rc;
+  }
+  NodeBlockScratch sc = w.nb;
+  sc.H = ex.H;
+  sc.DH = ex.DH;
+  sc.dx1 = ex.dx1;
+  for (int l = nl - 1; l >= 0; --l) {
+    const std::string p = te + "transformer_encoder.layers." + std::to_string(l);
+    const float* lb = blob_bwd + EncGridBwdBlob::layer(l);
+    const float* x_in = l == 0 ? x0 : tp[l - 1].out;
+    NodeBlockGrads gr{};
+    gr.w1 = G(p + ".linear1.weight"); gr.b1 = G(p + ".linear1.bias"); gr.w2 = G(p + ".linear2.weight"); gr.b2 = G(p + ".linear2.bias");
+    gr.n2g = G(p + ".norm2.weight"); gr.n2b = G(p + ".norm2.bias");
+    float *wo = G(p + ".self_attn.out_proj.weight"), *bo = G(p + ".self_attn.out_proj.bias");
+    float *wi = G(p + ".self_attn.in_proj_weight"), *bi = G(p + ".self_attn.in_proj_bias");
+    float *n1g = G(p + ".norm1.weight"), *n1b = G(p + ".norm1.bias");
+    TS_REQUIRE(!G.missing, "encoder_grid_backward: parameter table lacks " + G.missing_name);
+    if (int rc = ffn_block_backward(lb + TrLayerBwdL::FFN_A, lb + TrLayerBwdL::FFN_B, tp[l].xn2, tp[l].x1, dcur, RT, sc, wc, gr, st)) return rc;
+    TS_LAUNCH(k_lin_t_acc, tile_grid(rtiles, 256, MAT64 * 4), 256, MAT64 * 4, st, lb + TrLayerBwdL::WOUT_T, sc.dx1, RT, dO, 0);
+    if (int rc = run_wgrad(wc, sc.dx1, 64, tp[l].o, 64, RT, RT, wo, 64, 0, bo, 0)) return rc;
+    if (num_heads == 4) TS_LAUNCH(k_tr_attention_bwd<4>, cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, dO, N, dq, dk, dv);
+    else TS_LAUNCH(k_tr_attention_bwd<8>, cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, dO, N, dq, dk, dv);
+    const int gp = vec_grid(rtiles, 256, ProjBwdL<3>::SIZE * 4);
+    TS_LAUNCH(k_node_proj_bwd<3>, gp, 256, ProjBwdL<3>::SIZE * 4, st, lb + TrLayerBwdL::PROJ, x_in, sc.dx1, nullptr, dq, dk, dv, RT, dnext,
+              nullptr, w.nb.vpart);
+    if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, n1g)) return rc;
+    if (int rc = run_colsum(st, w.nb.vpart + 64, gp * 4, 128, 64, n1b)) return rc;
+    const float* dps[3] = {dq, dk, dv};
+    for (int j = 0; j < 3; ++j)
+      if (int rc = run_wgrad(wc, dps[j], 64, tp[l].xn, 64, RT, RT, wi + int64_t(j) * MAT64, 64, 0, bi + 64 * j, 0)) return rc;
+    float* t = dcur; dcur = dnext; dnext = t;
+  }
+  {
+    float *gpad = G(te + "padding_token"), *gcls = G(te + "cls_token"), *gpos = G(te + "pos_embed");
+    TS_REQUIRE(!G.missing, "encoder_grid_backward: parameter table lacks " + G.missing_name);
+    TS_LAUNCH(k_tr_tok_grad, 22, 1024, 0, st, dcur, b->padding_mask, N, b->TT, gpad, gcls, gpos);
+    TS_LAUNCH(k_tr_prep_bwd, cdiv(R * 64, 256), 256, 0, st, dcur, b->padding_mask, N, b->TT, w.DAA);
+  }
+  return aa_encoder_backward(b, g, rot, blob_bwd, w, wc, G, num_heads, st);
 }
 
 }  // extern "C"

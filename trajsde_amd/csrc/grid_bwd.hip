@@ -93,6 +93,129 @@ __global__ __launch_bounds__(256) void k_mlp_heads_bwd(const float* __restrict__
   flush_vec(dbet, vp + 64, L);
 }
 
+// ------------------------------------------------------------------ TemporalEncoder backward (GENC:241-292)
+constexpr int TRB_S = 22;
+
+// d of transformer_encoder.norm on the cls rows: DX[n][21] = LN-backward(dtout[n]) (DX zeroed by the caller);
+// per-wave (dgamma | dbeta) -> vpart[wave][128]
+__global__ __launch_bounds__(256) void k_tr_final_bwd(const float* __restrict__ norm, const float* __restrict__ x,
+                                                      const float* __restrict__ dtout, int N, float* __restrict__ DX,
+                                                      float* __restrict__ vpart) {
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int ntiles = (N + 15) / 16;
+  f4 dgam[4], dbet[4];
+  zero4(dgam); zero4(dbet);
+  for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
+    const int row = tile * 16 + L.n, r = row < N ? row : N - 1;
+    f4 xh[4], d[4];
+    load_row(xh, x, int64_t(r) * TRB_S + (TRB_S - 1), L.g);
+    const float rstd = ln_normalize(xh);
+    load_row(d, dtout, r, L.g);
+    if (row >= N) zero4(d);
+    ln_backward(d, xh, rstd, norm, L.g, dgam, dbet);
+    if (row < N) store_row(d, DX, int64_t(row) * TRB_S + (TRB_S - 1), L.g);
+  }
+  float* vp = vpart + int64_t(blockIdx.x * waves + wave) * 128;
+  flush_vec(dgam, vp, L);
+  flush_vec(dbet, vp + 64, L);
+}
+
+// causal self-attention backward, one wave per actor (lane = feature): given dO -> dQ, dK, dV (rows [n][s][64]).
+// Recomputes the softmax per query; with alpha the weights, d alpha_j = dO_i . v_j (head-wise), d logit_j =
+// alpha_j (d alpha_j - dO_i . o_i), and the logit is (q * dh^-0.5) . k.
+template <int HEADS>
+__global__ __launch_bounds__(256) void k_tr_attention_bwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, const float* __restrict__ dO, int N,
+                                                          float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  constexpr float SCALE = HEADS == 4 ? 0.25f : INV_SQRT_DH;
+  const int64_t base = int64_t(n) * TRB_S * 64 + lane;
+  float kr[TRB_S], vr[TRB_S], dkr[TRB_S], dvr[TRB_S];
+#pragma unroll
+  for (int j = 0; j < TRB_S; ++j) {
+    kr[j] = k[base + j * 64];
+    vr[j] = v[base + j * 64];
+    dkr[j] = 0.f;
+    dvr[j] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < TRB_S; ++i) {
+    const float qd = q[base + i * 64] * SCALE;
+    const float go = dO[base + i * 64];
+    float p[TRB_S];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      p[j] = head_sum_n<HEADS>(qd * kr[j]);
+      m = fmaxf(m, p[j]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      p[j] = fast_exp(p[j] - m);
+      s += p[j];
+    }
+    const float inv = 1.0f / s;
+    float dal[TRB_S], dlt = 0.f;
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      p[j] *= inv;                                            // alpha_j
+      dal[j] = head_sum_n<HEADS>(go * vr[j]);
+      dlt = fmaf(p[j], dal[j], dlt);
+    }
+    float dqi = 0.f;
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      const float dl = p[j] * (dal[j] - dlt);
+      dqi = fmaf(dl, kr[j], dqi);
+      dkr[j] = fmaf(dl, qd, dkr[j]);
+      dvr[j] = fmaf(p[j], go, dvr[j]);
+    }
+    dq[base + i * 64] = dqi * SCALE;
+  }
+#pragma unroll
+  for (int j = 0; j < TRB_S; ++j) {
+    dk[base + j * 64] = dkr[j];
+    dv[base + j * 64] = dvr[j];
+  }
+}
+template __global__ void k_tr_attention_bwd<4>(const float*, const float*, const float*, const float*, int, float*, float*, float*);
+template __global__ void k_tr_attention_bwd<8>(const float*, const float*, const float*, const float*, int, float*, float*, float*);
+
+// d aa_out[t][n] = padded ? 0 : dX0[n][t]
+__global__ void k_tr_prep_bwd(const float* __restrict__ DX0, const uint8_t* __restrict__ pad, int N, int TT, float* __restrict__ DAA) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= int64_t(N) * (TRB_S - 1) * 64) return;
+  const int c = int(i & 63), n = int((i >> 6) % N), t = int((i >> 6) / N);
+  DAA[i] = pad[int64_t(n) * TT + t] ? 0.f : DX0[(int64_t(n) * TRB_S + t) * 64 + c];
+}
+
+// token gradients, one workgroup per token s: dpos[s] = sum_n dX0[n][s]; dpad[s] = sum over padded n (s < 21); dcls = sum (s = 21)
+__global__ __launch_bounds__(1024) void k_tr_tok_grad(const float* __restrict__ DX0, const uint8_t* __restrict__ pad, int N, int TT,
+                                                      float* __restrict__ dpad, float* __restrict__ dcls, float* __restrict__ dpos) {
+  __shared__ float red[2][16][64];
+  const int s = blockIdx.x, c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  float all = 0.f, pd = 0.f;
+  for (int n = part; n < N; n += 16) {
+    const float v = DX0[(int64_t(n) * TRB_S + s) * 64 + c];
+    all += v;
+    if (s < TRB_S - 1 && pad[int64_t(n) * TT + s]) pd += v;
+  }
+  red[0][part][c] = all;
+  red[1][part][c] = pd;
+  __syncthreads();
+  if (part == 0) {
+    float a = 0.f, b = 0.f;
+    for (int p = 0; p < 16; ++p) { a += red[0][p][c]; b += red[1][p][c]; }
+    dpos[s * 64 + c] = a;
+    if (s < TRB_S - 1) dpad[s * 64 + c] = b;
+    else dcls[c] = a;
+  }
+}
+
 }  // namespace tsde
 
 using namespace tsde;

@@ -393,6 +393,15 @@ static_assert(GruBwdL::SIZE * 4 <= 160 * 1024 && EncSdeBwdL::SIZE * 4 <= 160 * 1
               "encoder backward images must fit LDS");
 static_assert(FfnBwdAL::SIZE * 4 <= 160 * 1024 && UpdBwdL::SIZE * 4 <= 160 * 1024 && EdgeBwdL::SIZE * 4 <= 160 * 1024,
               "node backward images must fit LDS");
+struct TrLayerBwdL {   // TemporalEncoderLayer backward: FFN (a, b), out_proj^T, norm1 + in_proj^T (q | k | v)
+  enum : int { FFN_A = 0, FFN_B = FFN_A + FfnBwdAL::SIZE, WOUT_T = FFN_B + FfnBwdBL::SIZE, PROJ = WOUT_T + MAT64, SIZE = PROJ + ProjBwdL<3>::SIZE };
+};
+struct EncGridBwdBlob {   // EncBwdBlob's AA / AL images at their offsets (recurrence regions unused), then the temporal encoder
+  static constexpr int TR = EncBwdBlob::SIZE;
+  static constexpr int layer(int i) { return TR + i * TrLayerBwdL::SIZE; }
+  static constexpr int norm(int nl) { return layer(nl); }          // ProjBwdL<0>: gamma | beta of transformer_encoder.norm
+  static constexpr int size(int nl) { return norm(nl) + 128; }
+};
 struct MlpDecBwdBlob {
   enum : int { HEAD = 0, INIT = MlpHeadBwdL::SIZE, SIZE = INIT + InitBwdL::SIZE };
 };

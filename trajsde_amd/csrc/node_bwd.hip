@@ -385,20 +385,28 @@ int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64
 }
 
 // ------------------------------------------------------------------ host drivers
+// out = x1 + W2 relu(W1 norm2(x1) + b1) + b2 given dout: sc.dx1 = d x1 (residual + through norm2), FFN / norm2 gradients
+int ffn_block_backward(const float* img_a, const float* img_b, const float* xn2, const float* x1, const float* dout, int64_t R,
+                       const NodeBlockScratch& sc, const WgradCtx& wc, const NodeBlockGrads& gr, hipStream_t st) {
+  const int64_t ntiles = (R + 15) / 16;
+  const int ga = tile_grid(ntiles, 256, FfnBwdAL::SIZE * 4), gb = vec_grid(ntiles, 256, FfnBwdBL::SIZE * 4);
+  TS_LAUNCH(k_ffn_bwd_a, ga, 256, FfnBwdAL::SIZE * 4, st, img_a, dout, xn2, R, sc.H, sc.DH);
+  TS_LAUNCH(k_ffn_bwd_b, gb, 256, FfnBwdBL::SIZE * 4, st, img_b, sc.DH, dout, x1, R, sc.dx1, sc.vpart);
+  if (int rc = run_colsum(st, sc.vpart, gb * 4, 128, 64, gr.n2g)) return rc;
+  if (int rc = run_colsum(st, sc.vpart + 64, gb * 4, 128, 64, gr.n2b)) return rc;
+  // first layer [256,64] (four 64-row blocks) and second layer [64,256] (four 64-column blocks)
+  for (int b = 0; b < 4; ++b) {
+    if (int rc = run_wgrad(wc, sc.DH + 64 * b, 256, xn2, 64, R, R, gr.w1 + b * MAT64, 64, 0, gr.b1 + 64 * b, 0)) return rc;
+    if (int rc = run_wgrad(wc, dout, 64, sc.H + 64 * b, 256, R, R, gr.w2, 256, 64 * b, b == 0 ? gr.b2 : nullptr, 0)) return rc;
+  }
+  return TRAJSDE_OK;
+}
+
 int node_block_backward(const float* img, const NodeBlockTape& tp, const float* dout, int64_t R, const NodeBlockScratch& sc,
                         const WgradCtx& wc, const NodeBlockGrads& gr, float* dagg, float* dxn, hipStream_t st) {
   const int64_t ntiles = (R + 15) / 16;
-  const int ga = tile_grid(ntiles, 256, FfnBwdAL::SIZE * 4), gb = vec_grid(ntiles, 256, FfnBwdBL::SIZE * 4),
-            gu = tile_grid(ntiles, 256, UpdBwdL::SIZE * 4);
-  TS_LAUNCH(k_ffn_bwd_a, ga, 256, FfnBwdAL::SIZE * 4, st, img + NodeBlockBwdL::FFN_A, dout, tp.xn2, R, sc.H, sc.DH);
-  TS_LAUNCH(k_ffn_bwd_b, gb, 256, FfnBwdBL::SIZE * 4, st, img + NodeBlockBwdL::FFN_B, sc.DH, dout, tp.x1, R, sc.dx1, sc.vpart);
-  if (int rc = run_colsum(st, sc.vpart, gb * 4, 128, 64, gr.n2g)) return rc;
-  if (int rc = run_colsum(st, sc.vpart + 64, gb * 4, 128, 64, gr.n2b)) return rc;
-  // mlp.0 [256,64] (four 64-row blocks) and mlp.3 [64,256] (four 64-column blocks)
-  for (int b = 0; b < 4; ++b) {
-    if (int rc = run_wgrad(wc, sc.DH + 64 * b, 256, tp.xn2, 64, R, R, gr.w1 + b * MAT64, 64, 0, gr.b1 + 64 * b, 0)) return rc;
-    if (int rc = run_wgrad(wc, dout, 64, sc.H + 64 * b, 256, R, R, gr.w2, 256, 64 * b, b == 0 ? gr.b2 : nullptr, 0)) return rc;
-  }
+  const int gu = tile_grid(ntiles, 256, UpdBwdL::SIZE * 4);
+  if (int rc = ffn_block_backward(img + NodeBlockBwdL::FFN_A, img + NodeBlockBwdL::FFN_B, tp.xn2, tp.x1, dout, R, sc, wc, gr, st)) return rc;
   TS_LAUNCH(k_upd_bwd, gu, 256, UpdBwdL::SIZE * 4, st, img + NodeBlockBwdL::UPD, sc.dx1, tp.agg, tp.xn, R, sc.UPD, sc.DGP, sc.DS, dagg, dxn);
   if (int rc = run_wgrad(wc, sc.dx1, 64, sc.UPD, 64, R, R, gr.w_out, 64, 0, gr.b_out, 0)) return rc;
   if (int rc = run_wgrad(wc, sc.DGP, 64, tp.agg, 64, R, R, gr.w_ih, 64, 0, gr.b_ih, 0)) return rc;

@@ -559,7 +559,8 @@ static void recipe_proj1_bwd(Packer& P, const std::string& p, int base) {
   P.matT(p + ".lin_q.weight", base + ProjBwdL<1>::WT, 64);
   P.index(p + ".lin_q.bias");
 }
-static void recipe_encoder_bwd(Packer& P) {
+// AA / AL backward images (shared by the SDE encoder and the vanilla one)
+static void recipe_encoder_attention_bwd(Packer& P) {
   using B = EncBwdBlob;
   recipe_edge_kv_bwd(P, "aa_encoder", "nbr_embed", B::AA_EDGEKV, B::AA_EDGEEMB);
   recipe_node_block_bwd(P, "aa_encoder", B::AA_NODE);
@@ -582,6 +583,14 @@ static void recipe_encoder_bwd(Packer& P) {
     P.matT(c + "3.weight", h + EdgeBwdL::WA3T, 64);
     P.index("aa_encoder.bos_token");
   }
+  recipe_proj1_bwd(P, "al_encoder", B::AL_PROJ);
+  recipe_edge_kv_bwd(P, "al_encoder", "lane_embed", B::AL_EDGEKV, B::AL_EDGEEMB);
+  recipe_node_block_bwd(P, "al_encoder", B::AL_NODE);
+}
+
+static void recipe_encoder_bwd(Packer& P) {
+  using B = EncBwdBlob;
+  recipe_encoder_attention_bwd(P);
   {
     using L = EncSdeBwdL;
     const int s = B::SDE;
@@ -613,9 +622,32 @@ static void recipe_encoder_bwd(Packer& P) {
       P.index(std::string("gru_unit.") + n + ".bias");
   }
   P.index("hidden");
-  recipe_proj1_bwd(P, "al_encoder", B::AL_PROJ);
-  recipe_edge_kv_bwd(P, "al_encoder", "lane_embed", B::AL_EDGEKV, B::AL_EDGEEMB);
-  recipe_node_block_bwd(P, "al_encoder", B::AL_NODE);
+}
+
+// vanilla LocalEncoder backward: AA / AL as above + the temporal transformer
+static void recipe_encoder_grid_bwd(Packer& P, int nl) {
+  recipe_encoder_attention_bwd(P);
+  const std::string t = "temporal_encoder.";
+  for (int i = 0; i < nl; ++i) {
+    const std::string l = t + "transformer_encoder.layers." + std::to_string(i);
+    const int b = EncGridBwdBlob::layer(i);
+    const int a = b + TrLayerBwdL::FFN_A, bb = b + TrLayerBwdL::FFN_B, pr = b + TrLayerBwdL::PROJ;
+    P.lin(l + ".linear1", a + FfnBwdAL::W1, a + FfnBwdAL::B1, 256, 64);
+    P.matT(l + ".linear2.weight", a + FfnBwdAL::W2T, 256, 0, 16, 4);
+    P.matT(l + ".linear1.weight", bb + FfnBwdBL::W1T, 64, 0, 4, 16);
+    P.vec(l + ".norm2.weight", bb + FfnBwdBL::N2G, 64);
+    P.matT(l + ".self_attn.out_proj.weight", b + TrLayerBwdL::WOUT_T, 64);
+    P.ln(l + ".norm1", pr + ProjBwdL<3>::N1G, pr + ProjBwdL<3>::N1B);
+    // in_proj_weight [192,64] = q | k | v row blocks: three transposed 64x64 images
+    const float* w = P.src(l + ".self_attn.in_proj_weight");
+    if (!P.dry)
+      for (int j = 0; j < 3; ++j)
+        k_pack_matT<<<cdiv(16 * 256, 256), 256, 0, P.stream>>>(w + int64_t(j) * MAT64, P.blob + pr + ProjBwdL<3>::WT + j * MAT64, 4, 4, 64, 0,
+                                                              1 << 30);
+    for (const char* n : {".self_attn.in_proj_bias", ".self_attn.out_proj.bias", ".linear2.bias", ".norm2.bias"}) P.index(l + n);
+  }
+  P.ln(t + "transformer_encoder.norm", EncGridBwdBlob::norm(nl), EncGridBwdBlob::norm(nl) + 64);
+  for (const char* n : {"padding_token", "cls_token", "pos_embed"}) P.index(t + n);
 }
 
 static bool run_recipe(Packer& P, int stage, int nl, int K) {
@@ -629,6 +661,7 @@ static bool run_recipe(Packer& P, int stage, int nl, int K) {
     case TRAJSDE_STAGE_ENCODER_GRID: recipe_encoder_grid(P, nl); return true;
     case TRAJSDE_STAGE_DECODER_MLP: recipe_decoder_mlp(P, nl); return true;
     case TRAJSDE_STAGE_DECODER_MLP_BWD: recipe_decoder_mlp_bwd(P, nl); return true;
+    case TRAJSDE_STAGE_ENCODER_GRID_BWD: recipe_encoder_grid_bwd(P, nl); return true;
   }
   return false;
 }
@@ -734,6 +767,7 @@ int64_t trajsde_blob_floats(int stage, int num_layers, int num_modes) {
     case TRAJSDE_STAGE_ENCODER_GRID: return EncGridBlob::size(num_layers);
     case TRAJSDE_STAGE_DECODER_MLP: return MlpDecBlob::SIZE;
     case TRAJSDE_STAGE_DECODER_MLP_BWD: return MlpDecBwdBlob::SIZE;
+    case TRAJSDE_STAGE_ENCODER_GRID_BWD: return EncGridBwdBlob::size(num_layers);
   }
   return fail(TRAJSDE_ERR_INVALID, "unknown stage");
 }

@@ -1,8 +1,10 @@
 """PredictionModel -- glue module of the vanilla HiVT variant of the path (reference models/model_base_mix.py:22-209):
 same YAML registry, `forward(data) -> dict`, the same in-place side effects on `data` (rotate_mat, rotated y) and the
 same validation / test step bookkeeping as the SDE model; the stages are the HIP-backed LocalEncoder,
-GlobalInteractor and MLPDecoder.  Deterministic (no SDE noise).  Inference only: the backward kernels cover the SDE
-configuration (8 heads), so `training_step` raises here instead of differentiating anything elsewhere.
+GlobalInteractor and MLPDecoder.  Deterministic (no SDE noise).  `training_step` differentiates the shipped loss of
+this configuration (L2, configs/nusargo/hivt_nuSArgo_trmenc_mlpdec.yml:62-66) through the HIP backward entry points
+(trajsde_mlp_decoder_l2_backward -> trajsde_aggregator_backward_heads -> trajsde_encoder_grid_backward); `ts_drop`
+augmentation (models/model_base_mix.py:95-100) is not built and is refused.
 """
 from copy import deepcopy
 from typing import Optional
@@ -12,6 +14,33 @@ import torch.nn as nn
 
 from trajsde_amd import runtime
 from trajsde_amd.models.model_base_mix_sde import resolve_class
+
+
+class _GridPathLoss(torch.autograd.Function):
+    """w * L2 as one autograd node over the parameters (see model_base_mix_sde._PathLoss)"""
+
+    @staticmethod
+    def forward(ctx, model, data, w_l2, *params):
+        with torch.no_grad():
+            out = model(data)
+            local, glob = out["local_embed"], out["global_embed"]
+            dec = model.decoder._rt.mlp_decoder_l2_backward(data, local, glob, out)
+            agg = model.aggregator._rt.aggregator_backward(data, local, dec["d_global_embed"])
+            enc = model.encoder._rt.encoder_grid_backward(data, dec["d_local_embed"] + agg["d_local_embed"])
+            by_name = {"decoder." + n: g for n, g in dec["grads"].items()}
+            by_name.update({"aggregator." + n: g for n, g in agg["grads"].items()})
+            by_name.update({"encoder." + n: g for n, g in enc["grads"].items()})
+            ctx.grads = [by_name.get(n) for n in model._param_names]
+            ctx.w = w_l2
+            model.last_output = out
+            model.last_losses = {"L2": dec["loss"].detach()}
+            return (w_l2 * dec["loss"]).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        have = [x for x in ctx.grads if x is not None]
+        scaled = iter(torch._foreach_mul(have, g * ctx.w))
+        return (None, None, None) + tuple(None if x is None else next(scaled) for x in ctx.grads)
 
 
 class PredictionModel(nn.Module):
@@ -37,6 +66,12 @@ class PredictionModel(nn.Module):
         self.encoder = build("encoder", 1)
         self.aggregator = build("aggregator", 2)
         self.decoder = build("decoder", 3)
+        self.losses, self.loss_names = [], []
+        for i, path in enumerate(kwargs.get("losses", [])):
+            name = kwargs["losses_module"][i]
+            self.losses.append(resolve_class(path, name)(**dict(kwargs["loss_args"][i])))
+            self.loss_names.append(name)
+        self.loss_weights = kwargs.get("loss_weights", [])
         self.metrics_tr, self.metrics_vl, self.metric_names = [], [], []
         for i, path in enumerate(kwargs.get("metrics", [])):
             name = kwargs["metrics_module"][i]
@@ -61,8 +96,36 @@ class PredictionModel(nn.Module):
         global_embed = self.aggregator(data=data, local_embed=local_embed)
         return self.decoder(data=data, local_embed=local_embed, global_embed=global_embed)
 
-    def training_step(self, data, batch_idx):
-        raise NotImplementedError("the vanilla HiVT variant is inference-only here; train the SDE configuration")
+    def params_with_gradient(self):
+        from trajsde_amd import _lib
+        reached = set()
+        for stage, sid in (("encoder", _lib.STAGE_ENCODER_GRID_BWD), ("aggregator", _lib.STAGE_AGGREGATOR_BWD),
+                           ("decoder", _lib.STAGE_DECODER_MLP_BWD)):
+            reached |= {f"{stage}.{n}" for n in getattr(self, stage)._rt.param_names(sid)}
+        return [p for n, p in self.named_parameters() if n in reached]
+
+    def training_step(self, data, batch_idx, noise=None):
+        """models/model_base_mix.py:94-114 for the shipped loss (L2)"""
+        if getattr(self, "ts_drop", False):
+            raise NotImplementedError("ts_drop augmentation is not built")
+        if self.loss_names != ["L2"]:
+            raise NotImplementedError(f"training_step differentiates L2 through the HIP kernels; configured: {self.loss_names}")
+        if data.y is None:
+            raise ValueError("training_step needs targets (data.y)")
+        if not hasattr(self, "_param_names"):
+            self._param_names = [n for n, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        return _GridPathLoss.apply(self, data, float(self.loss_weights[0]), *params)
+
+    def configure_optimizers(self):
+        """models/model_base_mix.py:205-208: AdamW + StepLR(scheduler_step, scheduler_gamma).  The shipped YAML does not
+        define those two keys (the reference would fail there); without them the SDE model's cosine schedule is used."""
+        self.optimizer = torch.optim.AdamW(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        if hasattr(self, "scheduler_step"):
+            self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=self.scheduler_step, gamma=self.scheduler_gamma)
+        else:
+            self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=self.T_max, eta_min=0.0)
+        return [self.optimizer], [self.scheduler]
 
     def _agent_eval_tensors(self, data, output):
         idx = data["agent_index"]

@@ -385,6 +385,28 @@ class StageRuntime:
                                                       local.data_ptr(), _stream()), "trajsde_encoder_grid_forward")
         return local
 
+    def encoder_grid_backward(self, data, d_local: torch.Tensor) -> Dict[str, object]:
+        """backward of the vanilla LocalEncoder: dL/d local_embed [N,64] -> {"grads": {param name: tensor}}"""
+        m = self.module
+        gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), NoiseSpec(seed=0), fake_agents=False)
+        dev = gc.device
+        L = _lib.lib()
+        N, nl = gc.batch.N, int(m.num_temporal_layers)
+        if tuple(d_local.shape) != (N, D):
+            raise _lib.TrajsdeError(f"d_local must be [{N},{D}]")
+        names = self.param_names(_lib.STAGE_ENCODER_GRID_BWD)
+        grads = self._grad_buffers(_lib.STAGE_ENCODER_GRID_BWD)
+        arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
+        ws_bytes = L.trajsde_encoder_grid_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), nl)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_encoder_grid_backward(
+                C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), self.blob().data_ptr(),
+                self.blob(_lib.STAGE_ENCODER_GRID_BWD).data_ptr(), int(m.num_heads), nl,
+                d_local.to(torch.float32).contiguous().data_ptr(), ws.data_ptr(), ws_bytes, arr, len(names), _stream()),
+                "trajsde_encoder_grid_backward")
+        return {"grads": grads}
+
     def mlp_decoder_forward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor) -> Dict[str, torch.Tensor]:
         """MLPDecoder.forward (dec_hivt_nusargo_grid.py:47-63)"""
         m = self.module
