@@ -118,11 +118,13 @@ __global__ __launch_bounds__(MAXT) void k_sde_decode(const float* __restrict__ b
 }
 
 // step-granular variant: one Euler-Maruyama step, state read from and written to HBM (no heads)
+template <bool X6>
 __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blob, const float* __restrict__ y_in,
                                                    float* __restrict__ y_out, int64_t rows, float dt, float sq, float sn,
                                                    float cs, int step, NoiseArg na) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_blob(lds, blob, DecSdeL::LOC);   // F and G images only
+  using DL = typename std::conditional<X6, DecSdeL6, DecSdeL>::type;
+  stage_blob(lds, blob, DL::LOC);   // F and G images only
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (rows + 15) / 16;
@@ -132,8 +134,14 @@ __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blo
     const int64_t r = row < rows ? row : rows - 1;
     f4 y[4], f[4], z[4];
     load_row(y, y_in, r, L.g);
-    drift_eval(f, y, lds + DecSdeL::F, sn, cs, L);
-    const float gs = diff_eval(y, lds + DecSdeL::G, sn, cs, L);
+    float gs;
+    if constexpr (X6) {
+      drift_eval_x6(f, y, lds + DL::F, sn, cs, L);
+      gs = diff_eval_x6(y, lds + DL::G, sn, cs, L);
+    } else {
+      drift_eval(f, y, lds + DL::F, sn, cs, L);
+      gs = diff_eval(y, lds + DL::G, sn, cs, L);
+    }
     noise_row(z, na, STREAM_DECODER, step, r, rows, L.g);
     em_update(y, f, gs, z, dt, sq);
     if (row < rows) store_row(y, y_out, row, L.g);
@@ -193,8 +201,13 @@ int trajsde_sde_step(int32_t rows, const float* blob, const float* y_in, float* 
   TS_REQUIRE(blob && y_in && y_out && e && rows > 0, "sde_step: bad argument");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int64_t ntiles = (int64_t(rows) + 15) / 16;
-  TS_LAUNCH(k_sde_step, pick_grid(ntiles, 16), 1024, DecSdeL::LOC * 4, stream, blob + DecBlob::SDE, y_in, y_out, int64_t(rows), e[1], e[2],
-            e[3], e[4], step, to_arg(noise));
+  static const bool x6 = []() { const char* v = getenv("TRAJSDE_DECODE_FP32"); return !(v && atoi(v) != 0); }();
+  if (x6)
+    TS_LAUNCH(k_sde_step<true>, pick_grid(ntiles, 16), 1024, DecSdeL6::LOC * 4, stream, blob + DecBlob::SDE6, y_in, y_out, int64_t(rows), e[1],
+              e[2], e[3], e[4], step, to_arg(noise));
+  else
+    TS_LAUNCH(k_sde_step<false>, pick_grid(ntiles, 16), 1024, DecSdeL::LOC * 4, stream, blob + DecBlob::SDE, y_in, y_out, int64_t(rows), e[1],
+              e[2], e[3], e[4], step, to_arg(noise));
   return TRAJSDE_OK;
 }
 
