@@ -124,9 +124,11 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
 #pragma unroll
     for (int c = 0; c < SL; ++c) {
       float x = dr[c];
-#pragma unroll
-      for (int o = LPH; o < 64; o <<= 1) x += __shfl_xor(x, o);
-      dr[c] = x;
+      if (LPH == 8) {                                       // lane ^ 8 inside the 16-lane row: DPP row_ror:8
+        const int rr = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xF, 0xF, true);
+        x += __int_as_float(rr);
+      }
+      dr[c] = xor32_sum(xor16_sum(x));                      // lanes ^ 16, ^ 32: permlane swaps, no LDS crossbar
     }
     if (h == 0) {
       float* p = DREL + int64_t(e) * 64 + SL * j;
