@@ -13,8 +13,9 @@
 //   d alpha_e,h = dagg_h . (v_node[src] + lin_v_edge(rel_e))_h,   d logit_e,h = alpha (d alpha - dagg_h . agg_h)
 // Per-target sums  RL_h = sum_e dlogit/sqrt(dh) rel_e  and  SS_h = sum_e alpha rel_e  give the lin_k_edge / lin_v_edge
 // weight gradients as node-level outer products (k_headwise_outer) instead of per-edge ones.  Gradients of the
-// source rows (k_node, v_node) are scattered with float atomics: their summation order, and so their last bits, can
-// differ from run to run; everything else is reduced in a fixed order.
+// source rows (k_node, v_node): the global graph of a scene is symmetric, so they are gathered per source in a fixed
+// order from per-edge (alpha, dlogit) scalars through a reverse-edge index (k_reverse_edges, k_gattn_src_bwd); only for
+// an asymmetric edge list (not produced by the reference's datasets) are they scattered with float atomics.
 #include <string>
 #include <unordered_map>
 
@@ -34,7 +35,10 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
                                                    const float* __restrict__ vn, const float* __restrict__ agg,
                                                    const float* __restrict__ dagg, int64_t N, float* __restrict__ DQ,
                                                    float* __restrict__ DKN, float* __restrict__ DVN, float* __restrict__ DREL,
-                                                   float* __restrict__ RL, float* __restrict__ SS, float* __restrict__ DAGGM) {
+                                                   float* __restrict__ RL, float* __restrict__ SS, float* __restrict__ DAGGM,
+                                                   float* __restrict__ EA, float* __restrict__ ED) {
+  // EA / ED non-null: the source-row gradients are gathered afterwards by k_gattn_src_bwd from the per-edge (alpha, dlogit)
+  // scalars written here (symmetric graph, fixed summation order); null: scattered right here with float atomics
   constexpr int LPH = 64 / HEADS, SL = 64 / LPH, NV = SL / 4;     // as in k_global_attn<HEADS>
   constexpr float INV = HEADS == 4 ? 0.25f : INV_SQRT_DH;
   __shared__ __attribute__((aligned(16))) float sbuf[4][HEADS][64 + 4];
@@ -108,8 +112,15 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
     const float dal = head_sum_n<HEADS>(t) + cz;
     const float dls = alpha * (dal - dlt) * INV;
     dqe = fmaf(dls, knv, dqe);
-    atomicAdd(DKN + int64_t(sidx) * 64 + lane, dls * ql);
-    atomicAdd(DVN + int64_t(sidx) * 64 + lane, alpha * da);
+    if (EA != nullptr) {
+      if (j == 0) {
+        EA[int64_t(e) * HEADS + h] = alpha;
+        ED[int64_t(e) * HEADS + h] = dls;
+      }
+    } else {
+      atomicAdd(DKN + int64_t(sidx) * 64 + lane, dls * ql);
+      atomicAdd(DVN + int64_t(sidx) * 64 + lane, alpha * da);
+    }
     float dr[SL];
 #pragma unroll
     for (int v4 = 0; v4 < NV; ++v4)
@@ -164,12 +175,48 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
   }
 }
 
+// REV[e'] = index of the reverse edge (dst -> src) of e' = (src -> dst), or -1; *asym is raised when one is missing
+__global__ void k_reverse_edges(const int32_t* __restrict__ segptr, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                int64_t E, int32_t* __restrict__ REV, int32_t* __restrict__ asym) {
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int i = src[e], jn = dst[e];
+  int found = -1;
+  for (int r = segptr[i]; r < segptr[i + 1]; ++r)
+    if (src[r] == jn) { found = r; break; }
+  REV[e] = found;
+  if (found < 0) atomicOr(asym, 1);
+}
+
+// gradients of the source rows, one wave per source node jn (lane = feature): for every incoming edge e' = (i -> jn) the
+// outgoing edge (jn -> i) = REV[e'] carries the scalars:  d k_node[jn] += dlogit q[i],  d v_node[jn] += alpha dagg[i]
+template <int HEADS>
+__global__ __launch_bounds__(256) void k_gattn_src_bwd(const int32_t* __restrict__ segptr, const int32_t* __restrict__ src,
+                                                       const int32_t* __restrict__ REV, const float* __restrict__ EA,
+                                                       const float* __restrict__ ED, const float* __restrict__ q,
+                                                       const float* __restrict__ dagg, int64_t N, float* __restrict__ DKN,
+                                                       float* __restrict__ DVN) {
+  const int lane = threadIdx.x & 63, h = lane / (64 / HEADS);
+  const int64_t node = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (node >= N) return;
+  float dk = 0.f, dv = 0.f;
+  for (int ep = segptr[node]; ep < segptr[node + 1]; ++ep) {
+    const int e = REV[ep], i = src[ep];
+    const float a = EA[int64_t(e) * HEADS + h], d = ED[int64_t(e) * HEADS + h];
+    dk = fmaf(d, q[int64_t(i) * 64 + lane], dk);
+    dv = fmaf(a, dagg[int64_t(i) * 64 + lane], dv);
+  }
+  DKN[node * 64 + lane] = dk;
+  DVN[node * 64 + lane] = dv;
+}
+
 // ---- workspace
 struct AggBwdWs {
   // forward tape
   float *rel, *xn[8], *q[8], *kn[8], *vn[8], *agg[8], *x1[8], *xn2[8], *out[8];
   // backward scratch
-  float *dcur, *dnext, *dagg, *dxn, *DQ, *DKN, *DVN, *DREL, *RL, *SS, *DAGGM, *XF, *part, *cs;
+  float *dcur, *dnext, *dagg, *dxn, *DQ, *DKN, *DVN, *DREL, *RL, *SS, *DAGGM, *XF, *part, *cs, *EA, *ED;
+  int32_t *REV, *asym;
   NodeBlockScratch nb;
   EdgeEmbedScratch ee;
   int64_t total;
@@ -188,6 +235,10 @@ struct AggBwdWs {
     RL = c.take<float>(N * 512);
     SS = c.take<float>(N * 512);
     DREL = c.take<float>(E * 64 + 64);
+    EA = c.take<float>(E * 8 + 8);
+    ED = c.take<float>(E * 8 + 8);
+    REV = c.take<int32_t>(E + 1);
+    asym = c.take<int32_t>(4);
     float** edge[] = {&ee.S, &ee.DEP, &ee.DSP, &ee.A0, &ee.B0};
     for (float** p : edge) *p = c.take<float>(E * 64 + 64);
     nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
@@ -286,6 +337,19 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
   }
 
   // ---- layers, last to first
+  // the global graph of a scene is symmetric (all ordered pairs of its valid actors), which lets the source-row
+  // gradients be gathered in a fixed order instead of scattered with atomics; checked here, one 4-byte read back
+  bool symmetric = false;
+  if (E > 0) {
+    TS_HIP(hipMemsetAsync(w.asym, 0, sizeof(int32_t), st));
+    TS_LAUNCH(k_reverse_edges, cdiv(E, 256), 256, 0, st, g->g_segptr, g->g_src, g->g_dst, E, w.REV, w.asym);
+    int32_t flag = 1;
+    TS_HIP(hipMemcpyAsync(&flag, w.asym, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TS_HIP(hipStreamSynchronize(st));
+    symmetric = flag == 0;
+  }
+  float* const ea = symmetric ? w.EA : nullptr;
+  float* const ed = symmetric ? w.ED : nullptr;
   TS_HIP(hipMemsetAsync(w.DREL, 0, size_t(E * 64 + 64) * sizeof(float), st));
   float* dcur = w.dcur;
   float* dnext = w.dnext;
@@ -312,10 +376,16 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     TS_HIP(hipMemsetAsync(w.DVN, 0, size_t(N) * 64 * sizeof(float), st));
     if (num_heads == 4)
       TS_LAUNCH(k_gattn_bwd<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
-                w.agg[l], w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM);
+                w.agg[l], w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM, ea, ed);
     else
       TS_LAUNCH(k_gattn_bwd<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
-                w.agg[l], w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM);
+                w.agg[l], w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM, ea, ed);
+    if (symmetric) {
+      if (num_heads == 4)
+        TS_LAUNCH(k_gattn_src_bwd<4>, cdiv(N, 4), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA, w.ED, w.q[l], w.dagg, N, w.DKN, w.DVN);
+      else
+        TS_LAUNCH(k_gattn_src_bwd<8>, cdiv(N, 4), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA, w.ED, w.q[l], w.dagg, N, w.DKN, w.DVN);
+    }
     if (int rc = run_headwise_outer(wc, w.q[l], w.RL, N, wke, num_heads)) return rc;
     if (int rc = run_headwise_outer(wc, w.dagg, w.SS, N, wve, num_heads)) return rc;
     TS_HIP(hipMemsetAsync(bke, 0, 64 * sizeof(float), st));          // a key bias shifts every logit of a target alike
