@@ -207,7 +207,9 @@ def main():
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_EQUIV_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_EQUIV_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": avg_s * 1e3, "launches": n_launch, "flop_per_edge": FLOP_PER_EDGE,
-                         "peak_note": "algorithmic fp32 FLOP/s; peak = 2500 TFLOP/s dense bf16 MFMA / 6 bf16 products per fp32 product "
+                         "peak_note": "algorithmic fp32 FLOP/s; the kernel is instruction-issue bound (SQ counters: ~1060 VALU + 240 MFMA + ~190 "
+                                      "LDS instructions per 16-edge tile, issue port saturated, MFMA pipe busy ~45 %); "
+                                      "peak = 2500 TFLOP/s dense bf16 MFMA / 6 bf16 products per fp32 product "
                                       "(the same kernel on exact fp32 MFMA, TRAJSDE_EDGE_FP32=1, ran at 110-113 TFLOP/s = 0.70-0.72 of the "
                                       "157.3 TFLOP/s fp32 matrix peak)",
                          "bf16_mfma_tflops": achieved * SPLIT_PRODUCTS * (40960.0 / 41700.0)},

@@ -16,6 +16,10 @@
 
 #include <type_traits>
 
+#ifndef TSDE_SKEW_SLEEPS
+#define TSDE_SKEW_SLEEPS 2      // x s_sleep(32) = 2 x 2048 cycles, about half of a tile's VALU + matrix time
+#endif
+
 namespace tsde {
 
 
@@ -69,6 +73,12 @@ __global__ __launch_bounds__(1024) void k_edge_kv(const float* __restrict__ img_
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (E + 15) / 16;
+  // The waves of a SIMD (wave, wave+4, ...) run the same VALU-stage / matrix-stage stream; started together they stay in
+  // phase and the two pipes take turns.  Every other one of them starts about half a tile late, once: from then on one is in
+  // a VALU stage while its neighbour is on the matrix cores.
+  if ((wave >> 2) & 1) {
+    for (int i = 0; i < TSDE_SKEW_SLEEPS; ++i) __builtin_amdgcn_s_sleep(32);
+  }
   for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
     keep_lds_reads_here();
     const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
@@ -85,6 +95,56 @@ __global__ __launch_bounds__(1024) void k_edge_kv(const float* __restrict__ img_
     if (e < E) store_row(vv, v, e, L.g);
   }
 }
+
+// The split-precision edge kernel with two 16-edge tiles per wave (32 rows): every LDS weight fragment feeds both tiles'
+// matrix-core instructions (linear_acc_x6_2), halving the ds_read_b128 issue slots per tile.  SQ counters say the one-tile
+// kernel is instruction-issue bound (per SIMD ~1.0 instruction-issue utilisation summed over its waves: ~1060 VALU, 240
+// MFMA and 192 LDS instructions per tile), so the saved slots are the gain.  Per tile the arithmetic and its order are
+// those of k_edge_kv<true>: same bits.  (A variant that ran the two tiles half a stage apart with sched_group_barrier
+// interleaving was slower: 256 VGPRs with spills, 2 waves per SIMD.)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_edge_kv2(const float* __restrict__ img_g, const float* __restrict__ geom,
+                                                      const int32_t* __restrict__ dst, const float* __restrict__ q, int64_t E,
+                                                      float* __restrict__ logits, float* __restrict__ v, int heads) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using EL = EdgeL6;
+  stage_blob(lds, img_g, EL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t npairs = (E + 31) / 32;
+  if ((wave >> 2) & 1) {                                   // see k_edge_kv: start every other wave of a SIMD half a tile late
+    for (int i = 0; i < 2 * TSDE_SKEW_SLEEPS; ++i) __builtin_amdgcn_s_sleep(32);
+  }
+  for (int64_t pair = int64_t(blockIdx.x) * waves + wave; pair < npairs; pair += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    const int64_t e0 = pair * 32 + L.n, e1 = e0 + 16;
+    const int64_t c0 = e0 < E ? e0 : E - 1, c1 = e1 < E ? e1 : E - 1;
+    const f4 g0 = *reinterpret_cast<const f4*>(geom + 4 * c0);
+    const f4 g1 = *reinterpret_cast<const f4*>(geom + 4 * c1);
+    const int d0 = dst[c0], d1 = dst[c1];
+    f4 emb0[4], emb1[4], kv0[8], kv1[8], qv[4];
+    edge_embed2_x6(emb0, emb1, g0, g1, lds, L);
+    load_vec<8>(kv0, lds + EL::BKV, L.g);
+    load_vec<8>(kv1, lds + EL::BKV, L.g);
+    linear_acc_x6_2<8, 4>(kv0, kv1, emb0, emb1, lds + EL::WKV, L.lane);
+    {
+      load_row(qv, q, d0, L.g);
+      f4 k[4] = {kv0[0], kv0[1], kv0[2], kv0[3]};
+      f4 vv[4] = {kv0[4], kv0[5], kv0[6], kv0[7]};
+      store_logits(qv, k, logits, e0, e0 < E, L, heads);
+      if (e0 < E) store_row(vv, v, e0, L.g);
+    }
+    {
+      load_row(qv, q, d1, L.g);
+      f4 k[4] = {kv1[0], kv1[1], kv1[2], kv1[3]};
+      f4 vv[4] = {kv1[4], kv1[5], kv1[6], kv1[7]};
+      store_logits(qv, k, logits, e1, e1 < E, L, heads);
+      if (e1 < E) store_row(vv, v, e1, L.g);
+    }
+  }
+}
+template __global__ void k_edge_kv2<512>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*, int);
+template __global__ void k_edge_kv2<768>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*, int);
 
 // global interactor: relative-pose embedding only (AGG:42-51), reused by all layers
 template <bool X6>

@@ -36,6 +36,38 @@ __device__ __forceinline__ void edge_embed(f4 (&emb)[4], const f4 geom, const fl
   layer_norm<4>(emb, lds + E::AG3, lds + E::AE3, L.g);
 }
 
+// the split-precision embedding for two edge tiles of one wave at once (linear_acc_x6_2: weight fragments read once)
+__device__ __forceinline__ void edge_embed2_x6(f4 (&emb0)[4], f4 (&emb1)[4], const f4 ge0, const f4 ge1, const float* lds,
+                                               const Lane& L) {
+  using E = EdgeL6;
+  f4 a0[4], a1[4], b0[4], b1[4], s0[4], s1[4];
+  linear_in2(a0, ge0[0], ge0[1], lds + E::A_W0, lds + E::A_B0, L.g);
+  layer_norm<4>(a0, lds + E::A_G, lds + E::A_E, L.g);
+  relu<4>(a0);
+  linear_in2(a1, ge1[0], ge1[1], lds + E::A_W0, lds + E::A_B0, L.g);
+  layer_norm<4>(a1, lds + E::A_G, lds + E::A_E, L.g);
+  relu<4>(a1);
+  load_vec<4>(s0, lds + E::B3, L.g);
+  load_vec<4>(s1, lds + E::B3, L.g);
+  linear_acc_x6_2<4, 4>(s0, s1, a0, a1, lds + E::WA3, L.lane);
+  linear_in2(b0, ge0[2], ge0[3], lds + E::B_W0, lds + E::B_B0, L.g);
+  layer_norm<4>(b0, lds + E::B_G, lds + E::B_E, L.g);
+  relu<4>(b0);
+  linear_in2(b1, ge1[2], ge1[3], lds + E::B_W0, lds + E::B_B0, L.g);
+  layer_norm<4>(b1, lds + E::B_G, lds + E::B_E, L.g);
+  relu<4>(b1);
+  linear_acc_x6_2<4, 4>(s0, s1, b0, b1, lds + E::WB3, L.lane);
+  layer_norm<4>(s0, lds + E::AG0, lds + E::AE0, L.g);
+  relu<4>(s0);
+  layer_norm<4>(s1, lds + E::AG0, lds + E::AE0, L.g);
+  relu<4>(s1);
+  load_vec<4>(emb0, lds + E::B2, L.g);
+  load_vec<4>(emb1, lds + E::B2, L.g);
+  linear_acc_x6_2<4, 4>(emb0, emb1, s0, s1, lds + E::W2, L.lane);
+  layer_norm<4>(emb0, lds + E::AG3, lds + E::AE3, L.g);
+  layer_norm<4>(emb1, lds + E::AG3, lds + E::AE3, L.g);
+}
+
 // per-head logits of 16 edges: q.k over the dims of each head / sqrt(dh).
 // 8 heads (dh = 8): heads sit pairwise on lane groups (g, g^1); stored as logits[e][slot], slot = 4*(head&1) + (head>>1),
 //                   one 16-B store per lane pair.

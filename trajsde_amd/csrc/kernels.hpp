@@ -12,6 +12,9 @@ __global__ void k_aa_center(const float* img, const float* x, const float* x_fak
 template <bool X6>
 __global__ void k_edge_kv(const float* img, const float* geom, const int32_t* dst, const float* q, int64_t E, float* logits, float* v,
                           int heads);
+template <int THREADS>
+__global__ void k_edge_kv2(const float* img, const float* geom, const int32_t* dst, const float* q, int64_t E, float* logits, float* v,
+                           int heads);
 template <bool X6>
 __global__ void k_edge_embed(const float* img, const float* geom, int64_t E, float* emb_out);
 template <bool X6>

@@ -17,6 +17,8 @@ static int env_threads(const char* name, int dflt) {
   return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : dflt;
 }
 static bool edge_x6() { static bool v = []() { const char* e = getenv("TRAJSDE_EDGE_FP32"); return !(e && atoi(e) != 0); }(); return v; }
+static bool edge_pair() { static bool v = []() { const char* e = getenv("TRAJSDE_EDGE_PAIR"); return !(e && atoi(e) == 0); }(); return v; }   // two tiles per wave (default on)
+static int pair_threads() { static int t = []() { const char* e = getenv("TRAJSDE_PAIR_THREADS"); const int v = e ? atoi(e) : 768; return v == 512 ? 512 : 768; }(); return t; }
 static int threads_edge() { static int t = env_threads("TRAJSDE_THREADS_EDGE", 1024); return t; }
 static int threads_node() { static int t = env_threads("TRAJSDE_THREADS_NODE", 512); return t; }
 static int threads_recur() { static int t = env_threads("TRAJSDE_THREADS_RECUR", 256); return t; }
@@ -104,7 +106,16 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob + EncBlob::AA_CENTER,
             b->x, g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
   if (g->E_aa > 0) {
-    if (edge_x6())
+    if (edge_x6() && edge_pair())
+    {
+      if (pair_threads() == 768)
+        TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv2<768>, tile_grid((int64_t(g->E_aa) + 31) / 32, 768, EdgeL6::SIZE * 4), 768, EdgeL6::SIZE * 4,
+                      st, blob + EncBlob::AA_EDGE6, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v, heads);
+      else
+        TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv2<512>, tile_grid((int64_t(g->E_aa) + 31) / 32, 512, EdgeL6::SIZE * 4), 512, EdgeL6::SIZE * 4,
+                      st, blob + EncBlob::AA_EDGE6, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v, heads);
+    }
+    else if (edge_x6())
       TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv<true>, tile_grid((int64_t(g->E_aa) + 15) / 16, threads_edge(), EdgeL6::SIZE * 4), threads_edge(),
                     EdgeL6::SIZE * 4, st, blob + EncBlob::AA_EDGE6, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v, heads);
     else
@@ -155,7 +166,10 @@ static int run_al_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob + EncBlob::AL_Q, lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
   if (g->E_la > 0) {
-    if (edge_x6())
+    if (edge_x6() && edge_pair())
+      TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv2<512>, tile_grid((int64_t(g->E_la) + 31) / 32, 512, EdgeL6::SIZE * 4), 512, EdgeL6::SIZE * 4, st,
+                    blob + EncBlob::AL_EDGE6, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v, heads);
+    else if (edge_x6())
       TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv<true>, tile_grid((int64_t(g->E_la) + 15) / 16, threads_edge(), EdgeL6::SIZE * 4), threads_edge(),
                     EdgeL6::SIZE * 4, st, blob + EncBlob::AL_EDGE6, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v, heads);
     else

@@ -135,6 +135,49 @@ __device__ __forceinline__ void linear_acc_x6(f4 (&acc)[JT_OUT], const f4 (&in)[
   }
 }
 
+// The same contraction for TWO row tiles of the wave at once: every weight fragment read from LDS feeds both tiles'
+// matrix-core instructions, which halves the LDS traffic per tile.  (LDS bandwidth, 128 B/clk/CU, is what bounds the
+// edge kernels: a 64x64 bf16x6 product reads 24 KB of fragments per wave.)  Per tile the arithmetic and its order are
+// those of linear_acc_x6, so the results are bitwise the same.
+template <int JT_OUT, int JT_IN>
+__device__ __forceinline__ void linear_acc_x6_2(f4 (&acc0)[JT_OUT], f4 (&acc1)[JT_OUT], const f4 (&in0)[JT_IN], const f4 (&in1)[JT_IN],
+                                                const float* w, int lane) {
+  static_assert(JT_IN % 2 == 0, "k-steps cover 32 features");
+  constexpr int KS = JT_IN / 2;
+  constexpr int PLANE = JT_OUT * KS * 256;
+  u4 p1[KS], p2[KS], p3[KS], q1[KS], q2[KS], q3[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    split_kstep(in0[2 * s], in0[2 * s + 1], p1[s], p2[s], p3[s]);
+    split_kstep(in1[2 * s], in1[2 * s + 1], q1[s], q2[s], q3[s]);
+  }
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+#pragma unroll
+    for (int jo = 0; jo < JT_OUT; ++jo) {
+      const float* p = w + (jo * KS + s) * 256 + lane * 4;
+      const bf8 a1 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p));
+      const bf8 a2 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p + PLANE));
+      const bf8 a3 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p + 2 * PLANE));
+      const bf8 x1 = __builtin_bit_cast(bf8, p1[s]), x2 = __builtin_bit_cast(bf8, p2[s]), x3 = __builtin_bit_cast(bf8, p3[s]);
+      const bf8 y1 = __builtin_bit_cast(bf8, q1[s]), y2 = __builtin_bit_cast(bf8, q2[s]), y3 = __builtin_bit_cast(bf8, q3[s]);
+      // the two tiles' chains are independent: interleaving them also hides the matrix-core latency of each chain
+      acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, x1, acc0[jo], 0, 0, 0);
+      acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, y1, acc1[jo], 0, 0, 0);
+      acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, x2, acc0[jo], 0, 0, 0);
+      acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, y2, acc1[jo], 0, 0, 0);
+      acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, x1, acc0[jo], 0, 0, 0);
+      acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, y1, acc1[jo], 0, 0, 0);
+      acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, x3, acc0[jo], 0, 0, 0);
+      acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, y3, acc1[jo], 0, 0, 0);
+      acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, x2, acc0[jo], 0, 0, 0);
+      acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, y2, acc1[jo], 0, 0, 0);
+      acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, x1, acc0[jo], 0, 0, 0);
+      acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, y1, acc1[jo], 0, 0, 0);
+    }
+  }
+}
+
 // per-feature vector (bias, LayerNorm gamma/beta, ...) stored plainly: v[16*jt + 4*g + c]
 template <int JT>
 __device__ __forceinline__ void load_vec(f4 (&out)[JT], const float* v, int g) {
