@@ -420,3 +420,34 @@ def test_aggregator_backward_is_bitwise_reproducible_and_handles_asymmetric_grap
             assert torch.equal(a["d_local_embed"], b["d_local_embed"])
             for k in a["grads"]:
                 assert torch.equal(a["grads"][k], b["grads"][k]), k
+
+
+def test_checkpoint_resume_retraces_the_uninterrupted_run(dev, tmp_path):
+    """every reduction of the backward runs in a fixed order, so training is bitwise reproducible: a run resumed from the
+    epoch-1 checkpoint ends on exactly the parameters of the run that was never interrupted"""
+    from trajsde_amd import driver
+    from trajsde_amd.synth import synth
+    batch = synth(S=3, n=12, L=6, F=20, box=70.0, seed=79, mixed_source=True).to(dev)
+    y0 = batch.y.clone()
+
+    def fresh(epoch):
+        for _ in range(3):
+            batch.y = y0
+            yield batch
+
+    def make():
+        m, _ = H.build_model(3, 20, 2.0, init_seed=23)
+        m.lr, m.weight_decay, m.T_max = 1e-3, 1e-4, 4
+        return m.to(dev)
+    a = make()
+    hist_a = driver.train(a, fresh, epochs=3, seed=5)
+    b = make()
+    ck = str(tmp_path / "ck.pt")
+    driver.train(b, fresh, epochs=2, seed=5, ckpt_path=ck)
+    c = make()
+    hist_c = driver.train(c, fresh, epochs=3, seed=5, resume=ck)
+    assert hist_c == hist_a[6:]
+    for (n, p), (_, q) in zip(a.named_parameters(), c.named_parameters()):
+        assert torch.equal(p, q), n
+    ref_style = torch.load(ck, map_location="cpu")
+    assert set(ref_style["state_dict"]) == set(a.state_dict())           # loads into the reference model key for key

@@ -87,15 +87,35 @@ class FlatGrads:
             self.flat.div_(dist.get_world_size())
 
 
-def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None) -> list:
+def save_checkpoint(path: str, model, optimizer, scheduler, epoch: int, step: int) -> None:
+    """A Lightning-shaped checkpoint (`state_dict` at the top level like the reference's `ModelCheckpoint` files, so
+    either side loads the other's weights with `load_state_dict`), plus what the loop needs to resume."""
+    tmp = path + ".tmp"
+    torch.save({"state_dict": model.state_dict(), "optimizer_states": [optimizer.state_dict()],
+                "lr_schedulers": [scheduler.state_dict()], "epoch": epoch, "global_step": step}, tmp)
+    os.replace(tmp, path)
+
+
+def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None, ckpt_path: Optional[str] = None,
+          resume: Optional[str] = None) -> list:
     """trainer.fit(...) spelled out (train.py:60-66): per batch zero -> training_step -> backward -> gradient
     all-reduce -> AdamW step; scheduler step per epoch.  `batches_per_epoch(epoch)` yields this rank's batches.
-    Returns the per-step loss values of this rank."""
+    `ckpt_path`: rank 0 writes a checkpoint after every epoch; `resume`: continue from such a file (weights, AdamW
+    moments, schedule, epoch and step counters -- the noise seeds continue where they stopped, so a resumed run
+    retraces the uninterrupted one).  Returns the per-step loss values of this rank."""
     model.train()
     (optimizer,), (scheduler,) = model.configure_optimizers()
+    first_epoch, step = 0, 0
+    if resume is not None:
+        state = torch.load(resume, map_location=model.device)
+        model.load_state_dict(state["state_dict"])
+        optimizer.load_state_dict(state["optimizer_states"][0])
+        scheduler.load_state_dict(state["lr_schedulers"][0])
+        first_epoch, step = int(state["epoch"]) + 1, int(state["global_step"])
     flat = FlatGrads(model.params_with_gradient())
-    history, step = [], 0
-    for epoch in range(epochs):
+    rank0 = not (torch.distributed.is_available() and torch.distributed.is_initialized()) or torch.distributed.get_rank() == 0
+    history = []
+    for epoch in range(first_epoch, epochs):
         for i, batch in enumerate(batches_per_epoch(epoch)):
             flat.zero()
             loss = model.training_step(batch, i, noise=NoiseSpec(seed=seed + step))
@@ -107,6 +127,8 @@ def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None) -> lis
                 log(epoch, i, history[-1], model.last_losses)
             step += 1
         scheduler.step()
+        if ckpt_path is not None and rank0:
+            save_checkpoint(ckpt_path, model, optimizer, scheduler, epoch, step)
     return history
 
 
@@ -138,6 +160,8 @@ def main() -> None:
     ap.add_argument("--ood", action="store_true")
     ap.add_argument("--train", action="store_true", help="run the optimisation loop instead of the evaluation loop")
     ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--save", default=None, help="--train: checkpoint written after every epoch")
+    ap.add_argument("--resume", default=None, help="--train: continue from a checkpoint written by --save")
     ap.add_argument("--data", action="store_true", help="evaluate on the YAML's data module instead of synthetic batches")
     ap.add_argument("--nu_dir", default=None)
     ap.add_argument("--argo_dir", default=None)
@@ -184,7 +208,7 @@ def main() -> None:
         else:
             def per_epoch(epoch):
                 return synthetic_batches(args.synthetic, args.batches, dev, rank, world)
-        hist = train(model, per_epoch, args.epochs,
+        hist = train(model, per_epoch, args.epochs, ckpt_path=args.save, resume=args.resume,
                      log=(lambda e, i, l, parts: print(f"epoch {e} step {i} loss {l:.5f}")) if rank == 0 else None)
         if rank == 0:
             print(json.dumps({"steps": len(hist), "first_loss": hist[0], "last_loss": hist[-1]}))
