@@ -118,6 +118,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:
+        os.dup2(2, 1)       # only rank 0 owns stdout (the JSON line); anything other ranks' libraries print goes to stderr
     if world > 1 or os.environ.get("TRAJSDE_BENCH_FORCE_DIST") == "1":      # the latter: exercise the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -324,6 +326,11 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
+        try:                                                                  # RCCL writes its version banner through C stdio,
+            import ctypes                                                     # buffered until exit when stdout is a pipe: push it
+            ctypes.CDLL(None).fflush(None)                                    # out now so that the JSON line really is the last one
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)                                   # the one JSON line, last on stdout
 
 
