@@ -88,8 +88,8 @@ __global__ __launch_bounds__(512) void k_edge_kv_bwd(const float* __restrict__ i
     const f4 ge = *reinterpret_cast<const f4*>(geom + 4 * ec);
     f4 emb[4], k[4], qv[4], dk[4], dqe[4], dv[4], de[4];
     load_row(qv, q, dst[ec], L.g);
-    edge_embed<false>(emb, ge, lds, L);
-    linear<4, 4>(k, emb, lds + EdgeL::WKV, lds + EdgeL::BKV, L);
+    edge_embed<true>(emb, ge, lds, L);
+    linear_x6<4, 4>(k, emb, lds + EdgeKvBwdL::WK6, lds + EdgeKvBwdL::BK, L);
     // 8 heads: lane group g holds heads 2jt + (g>>1) at slots 4(g>>1) + jt; 4 heads: head jt at slot jt for every g
     const f4 dl = *reinterpret_cast<const f4*>(DLG + ec * 8 + (heads == 4 ? 0 : 4 * (L.g >> 1)));
     const float sc = heads == 4 ? 0.25f : INV_SQRT_DH;
@@ -585,7 +585,7 @@ struct EncBwdWs {
   // recurrence tape (slabs [H][Nt][64]) and running states
   float *HIN, *H1, *H2, *G1, *G2, *GS, *HODE, *XS, *U1, *R1, *UU, *RR, *RH, *N1, *NW, *hcur, *lat;
   // AL tape
-  float *al_xn, *al_q, *al_logits, *al_v, *al_agg, *al_x1, *al_xn2, *al_out;
+  float *al_xn, *al_q, *al_logits, *al_v, *al_agg, *al_x1, *al_xn2;
   // backward: recurrence deltas
   float *DF, *DH2, *DH1, *DG2N, *DG1N, *DG2A, *DG1A, *DGPN, *DGPA, *DNW, *DN1P, *DUP, *DRP, *DU1, *DR1, *DHO, *dhA, *dhB, *DLDG, *DLAT, *DAA;
   // backward: attention chain scratch (sized for the larger of the AA / AL problems)
@@ -609,7 +609,7 @@ struct EncBwdWs {
     float** rows_Nt[] = {&hcur, &DHO, &dhA, &dhB};
     for (float** p : rows_Nt) *p = c.take<float>(Nt * 64);
     DLDG = c.take<float>(Nt);
-    float** rows_N[] = {&lat, &al_xn, &al_q, &al_agg, &al_x1, &al_xn2, &al_out, &DLAT};
+    float** rows_N[] = {&lat, &al_xn, &al_q, &al_agg, &al_x1, &al_xn2, &DLAT};
     for (float** p : rows_N) *p = c.take<float>(N * 64);
     logits = c.take<float>(Eaa * 8 + 8);
     v = c.take<float>(Eaa * 64 + 64);
@@ -705,33 +705,33 @@ int aa_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const fl
   using BB = EncBwdBlob;
   const int N = b->N, Nt = g->Nt, H = b->H;
   const int64_t R = int64_t(H) * Nt, Eaa = g->E_aa;
-    AttnChain c{blob_bwd + BB::AA_NODE, blob_bwd + BB::AA_PROJ, blob_bwd + BB::AA_EDGEKV, blob_bwd + BB::AA_EDGEEMB,
-                g->aa_geom, w.q, w.logits, w.v, w.center, g->aa_dst, g->aa_segptr, NodeBlockTape{w.agg, w.cn, w.x1, w.xn2}, R, Eaa,
-                "aa_encoder", "nbr_embed", heads};
-    if (int rc = run_attn_chain(c, w.DAA, w, wc, G, w.DCENTER, st)) return rc;
-    const std::string ce = "aa_encoder.center_embed.embed.";
-    float *w0 = G(ce + "0.weight"), *b0 = G(ce + "0.bias"), *g1 = G(ce + "1.weight"), *e1 = G(ce + "1.bias");
-    float *w3 = G(ce + "3.weight"), *b3 = G(ce + "3.bias"), *g4 = G(ce + "4.weight"), *e4 = G(ce + "4.bias");
-    float *w6 = G(ce + "6.weight"), *b6 = G(ce + "6.bias"), *g7 = G(ce + "7.weight"), *e7 = G(ce + "7.bias");
-    float* tok = G("aa_encoder.bos_token");
-    TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
-    const int gt = vec_grid((R + 15) / 16, 256, CenterTailL::SIZE * 4);
-    TS_LAUNCH(k_aa_center_bwd_tail, gt, 256, CenterTailL::SIZE * 4, st, blob_bwd + BB::AA_CTAIL, b->x, g->x_fake, rot, b->bos_mask, g->orig, N,
-              Nt, H, w.DCENTER, w.A1, w.A2, w.DA3P, w.DA2P, w.XR, w.nb.vpart);
-    float* const tv[4] = {g7, e7, g4, e4};
-    for (int i = 0; i < 4; ++i)
-      if (int rc = run_colsum(st, w.nb.vpart + 64 * i, gt * 4, 256, 64, tv[i])) return rc;
-    if (int rc = run_wgrad(wc, w.DA3P, 64, w.A2, 64, R, R, w6, 64, 0, b6, 0)) return rc;
-    if (int rc = run_wgrad(wc, w.DA2P, 64, w.A1, 64, R, R, w3, 64, 0, b3, 0)) return rc;
-    const int lds_br = (EdgeL::WA3 + MAT64) * 4;
-    const int gb = vec_grid((R + 15) / 16, 256, lds_br);
-    TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, blob_bwd + BB::AA_CHEAD, w.XR, w.DA2P, R, w.nb.vpart);
-    if (int rc = run_colsum(st, w.nb.vpart, gb * 4, 320, 64, g1)) return rc;
-    if (int rc = run_colsum(st, w.nb.vpart + 64, gb * 4, 320, 64, e1)) return rc;
-    if (int rc = run_colsum(st, w.nb.vpart + 128, gb * 4, 320, 64, w0, 2)) return rc;
-    if (int rc = run_colsum(st, w.nb.vpart + 192, gb * 4, 320, 64, w0 + 1, 2)) return rc;
-    if (int rc = run_colsum(st, w.nb.vpart + 256, gb * 4, 320, 64, b0)) return rc;
-    TS_LAUNCH(k_bos_grad, H, 1024, 0, st, w.DCENTER, b->bos_mask, g->orig, Nt, H, tok);
+  AttnChain c{blob_bwd + BB::AA_NODE, blob_bwd + BB::AA_PROJ, blob_bwd + BB::AA_EDGEKV, blob_bwd + BB::AA_EDGEEMB,
+              g->aa_geom, w.q, w.logits, w.v, w.center, g->aa_dst, g->aa_segptr, NodeBlockTape{w.agg, w.cn, w.x1, w.xn2}, R, Eaa,
+              "aa_encoder", "nbr_embed", heads};
+  if (int rc = run_attn_chain(c, w.DAA, w, wc, G, w.DCENTER, st)) return rc;
+  const std::string ce = "aa_encoder.center_embed.embed.";
+  float *w0 = G(ce + "0.weight"), *b0 = G(ce + "0.bias"), *g1 = G(ce + "1.weight"), *e1 = G(ce + "1.bias");
+  float *w3 = G(ce + "3.weight"), *b3 = G(ce + "3.bias"), *g4 = G(ce + "4.weight"), *e4 = G(ce + "4.bias");
+  float *w6 = G(ce + "6.weight"), *b6 = G(ce + "6.bias"), *g7 = G(ce + "7.weight"), *e7 = G(ce + "7.bias");
+  float* tok = G("aa_encoder.bos_token");
+  TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
+  const int gt = vec_grid((R + 15) / 16, 256, CenterTailL::SIZE * 4);
+  TS_LAUNCH(k_aa_center_bwd_tail, gt, 256, CenterTailL::SIZE * 4, st, blob_bwd + BB::AA_CTAIL, b->x, g->x_fake, rot, b->bos_mask, g->orig, N,
+            Nt, H, w.DCENTER, w.A1, w.A2, w.DA3P, w.DA2P, w.XR, w.nb.vpart);
+  float* const tv[4] = {g7, e7, g4, e4};
+  for (int i = 0; i < 4; ++i)
+    if (int rc = run_colsum(st, w.nb.vpart + 64 * i, gt * 4, 256, 64, tv[i])) return rc;
+  if (int rc = run_wgrad(wc, w.DA3P, 64, w.A2, 64, R, R, w6, 64, 0, b6, 0)) return rc;
+  if (int rc = run_wgrad(wc, w.DA2P, 64, w.A1, 64, R, R, w3, 64, 0, b3, 0)) return rc;
+  const int lds_br = (EdgeL::WA3 + MAT64) * 4;
+  const int gb = vec_grid((R + 15) / 16, 256, lds_br);
+  TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, blob_bwd + BB::AA_CHEAD, w.XR, w.DA2P, R, w.nb.vpart);
+  if (int rc = run_colsum(st, w.nb.vpart, gb * 4, 320, 64, g1)) return rc;
+  if (int rc = run_colsum(st, w.nb.vpart + 64, gb * 4, 320, 64, e1)) return rc;
+  if (int rc = run_colsum(st, w.nb.vpart + 128, gb * 4, 320, 64, w0, 2)) return rc;
+  if (int rc = run_colsum(st, w.nb.vpart + 192, gb * 4, 320, 64, w0 + 1, 2)) return rc;
+  if (int rc = run_colsum(st, w.nb.vpart + 256, gb * 4, 320, 64, b0)) return rc;
+  TS_LAUNCH(k_bos_grad, H, 1024, 0, st, w.DCENTER, b->bos_mask, g->orig, Nt, H, tok);
   return TRAJSDE_OK;
 }
 

@@ -329,9 +329,11 @@ template <int NQ>
 struct ProjBwdL {     // norm1 + NQ transposed projections (NQ = 0: a bare LayerNorm backward)
   enum : int { S_END = 0, TS_FIELD(N1G, 64, S), TS_FIELD(N1B, 64, N1G), TS_FIELD(WT, NQ * MAT64, N1B), SIZE = WT_END };
 };
-struct EdgeBwdL {     // MultipleInputEmbedding: forward image (EdgeL up to EMB_SIZE) + the three transposes
-  enum : int { FWD = 0, W2T = EdgeL::EMB_SIZE, WA3T = W2T + MAT64, WB3T = WA3T + MAT64, SIZE = WB3T + MAT64 };
+struct EdgeBwdL {     // MultipleInputEmbedding: split-precision forward image (EdgeL6 up to EMB_SIZE, for the recompute) + the three
+                      // fp32 transposes; the small per-feature vectors sit at the same offsets as in EdgeL
+  enum : int { FWD = 0, W2T = EdgeL6::EMB_SIZE, WA3T = W2T + MAT64, WB3T = WA3T + MAT64, SIZE = WB3T + MAT64 };
 };
+static_assert(int(EdgeL6::WA3) == int(EdgeL::WA3), "the input-layer vectors of both edge images share offsets");
 struct NodeBlockBwdL {   // one attention block's node-level backward images
   enum : int { FFN_A = 0, FFN_B = FFN_A + FfnBwdAL::SIZE, UPD = FFN_B + FfnBwdBL::SIZE, SIZE = UPD + UpdBwdL::SIZE };
 };
@@ -348,8 +350,8 @@ struct AggBwdBlob {
   static constexpr int size(int nl, int K) { return proj(nl, K); }
 };
 // ---- encoder backward images (encoder_bwd.hip)
-struct EdgeKvBwdL {   // AA / AL edge kernel: forward image (embedding + lin_k | lin_v) and the two transposes
-  enum : int { FWD = 0, WKT = EdgeL::SIZE, WVT = WKT + MAT64, SIZE = WVT + MAT64 };
+struct EdgeKvBwdL {   // AA / AL edge kernel: split-precision embedding image + lin_k (for the recompute of emb and k), lin_k^T, lin_v^T
+  enum : int { FWD = 0, WK6 = EdgeL6::EMB_SIZE, BK = WK6 + MAT64X6, WKT = BK + 64, WVT = WKT + MAT64, SIZE = WVT + MAT64 };
 };
 struct CenterTailL {  // center_embed (SingleInputEmbedding): forward fields in AaCenterL order up to the last LayerNorm, + W6^T
   enum : int { FWD = 0, W6T = AaCenterL::E7_END, SIZE = W6T + MAT64 };

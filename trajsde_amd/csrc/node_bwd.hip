@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_edge_embed_bwd_tail(const float* __rest
                                                              float* __restrict__ vpart) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, img, EdgeBwdL::WA3T);                   // forward image + W2^T
-  using EL = EdgeL;
+  using EL = EdgeL6;                                     // split-precision recompute, fp32 transposes for the gradients
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (E + 15) / 16;
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void k_edge_embed_bwd_tail(const float* __rest
     branch_fwd(xh, a0, r_, ge[0], ge[1], lds + EL::A_W0, lds + EL::A_B0, lds + EL::A_G, lds + EL::A_E, L);
     branch_fwd(xh, b0, r_, ge[2], ge[3], lds + EL::B_W0, lds + EL::B_B0, lds + EL::B_G, lds + EL::B_E, L);
     load_vec<4>(sp, lds + EL::B3, L.g);
-    linear_acc<4, 4>(sp, a0, lds + EL::WA3, L.lane);
-    linear_acc<4, 4>(sp, b0, lds + EL::WB3, L.lane);
+    linear_acc_x6<4, 4>(sp, a0, lds + EL::WA3, L.lane);
+    linear_acc_x6<4, 4>(sp, b0, lds + EL::WB3, L.lane);
     const float rs0 = ln_normalize(sp);                   // sp = s_hat
     bool pos[16];
 #pragma unroll
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_edge_embed_bwd_tail(const float* __rest
         s[jt][c] = fmaxf(pre, 0.f);
       }
     }
-    linear<4, 4>(ep, s, lds + EL::W2, lds + EL::B2, L);
+    linear_x6<4, 4>(ep, s, lds + EL::W2, lds + EL::B2, L);
     const float rs3 = ln_normalize(ep);                   // ep = e_hat
     load_row(d, demb, ec, L.g);
     if (e >= E) zero4(d);

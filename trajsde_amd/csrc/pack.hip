@@ -513,7 +513,7 @@ static void recipe_node_block_bwd(Packer& P, const std::string& p, int base) {
   for (const char* n : {".mlp.3.bias", ".out_proj.bias", ".norm2.bias"}) P.index(p + n);
 }
 static void recipe_edge_embed_bwd(Packer& P, const std::string& p, int base) {
-  recipe_edge_embed(P, p, base + EdgeBwdL::FWD);
+  recipe_edge_embed6(P, p, base + EdgeBwdL::FWD);
   P.matT(p + ".aggr_embed.2.weight", base + EdgeBwdL::W2T, 64);
   P.matT(p + ".module_list.0.3.weight", base + EdgeBwdL::WA3T, 64);
   P.matT(p + ".module_list.1.3.weight", base + EdgeBwdL::WB3T, 64);
@@ -545,11 +545,10 @@ static void recipe_aggregator_bwd(Packer& P, int nl, int K) {
 }
 
 static void recipe_edge_kv_bwd(Packer& P, const std::string& p, const std::string& embed, int kv, int emb) {
-  recipe_edge_embed(P, p + "." + embed, kv + EdgeKvBwdL::FWD);
-  P.mat(p + ".lin_k.weight", kv + EdgeL::WKV, 64, 64, 64);
-  P.mat(p + ".lin_v.weight", kv + EdgeL::WKV + MAT64, 64, 64, 64);
-  P.vec(p + ".lin_k.bias", kv + EdgeL::BKV, 64);
-  P.vec(p + ".lin_v.bias", kv + EdgeL::BKV + 64, 64);
+  recipe_edge_embed6(P, p + "." + embed, kv + EdgeKvBwdL::FWD);
+  P.mat6(p + ".lin_k.weight", kv + EdgeKvBwdL::WK6, 64, 64, 64);
+  P.vec(p + ".lin_k.bias", kv + EdgeKvBwdL::BK, 64);
+  P.index(p + ".lin_v.bias");
   P.matT(p + ".lin_k.weight", kv + EdgeKvBwdL::WKT, 64);
   P.matT(p + ".lin_v.weight", kv + EdgeKvBwdL::WVT, 64);
   recipe_edge_embed_bwd(P, p + "." + embed, emb);
