@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ delta, 
                                                int64_t rows_per_group, int chunk, int chunks_per_group,
                                                float* __restrict__ part, float* __restrict__ cs) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];
-  float (*red)[4096] = reinterpret_cast<float (*)[4096]>(dyn);                  // [4 waves][64x64]
-  float (*csr)[4][64] = reinterpret_cast<float (*)[4][64]>(dyn + 4 * 4096);      // [4 waves][4 k-groups][64]
+  float (*red)[2048] = reinterpret_cast<float (*)[2048]>(dyn);                  // [4 waves][32 x 64]: half of the output rows
+  float (*csr)[4][64] = reinterpret_cast<float (*)[4][64]>(dyn + 64 * 80 * 2);   // [4 waves][4 k-groups][64], behind the staging area
   const int p = blockIdx.x;
   const int group = p / chunks_per_group, sub = p - group * chunks_per_group;
   const int64_t row0 = group * rows_per_group + int64_t(sub) * chunk;
@@ -480,18 +480,23 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ delta, 
     }
   }
   __syncthreads();
-  // D fragment: lane holds dW[16ot + 4kg + reg][16it + idx]
-#pragma unroll
-  for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) red[wave][(16 * ot + 4 * kg + reg) * 64 + 16 * it + idx] = acc[ot][it][reg];
+  // D fragment: lane holds dW[16ot + 4kg + reg][16it + idx].  The four waves' tiles are combined through LDS in two
+  // halves of 32 output rows, so that the reduction fits the 40 KB staging area (4 workgroups per CU stay resident)
 #pragma unroll
   for (int q = 0; q < 4; ++q) csr[wave][kg][16 * q + idx] = csum[q];
-  __syncthreads();
-  for (int j = threadIdx.x; j < 4096; j += 256)
-    part[int64_t(p) * 4096 + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[wave][(16 * ot + 4 * kg + reg) * 64 + 16 * it + idx] = acc[2 * half + ot][it][reg];
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2048; j += 256)
+      part[int64_t(p) * 4096 + 2048 * half + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+  }
   if (threadIdx.x < 64) {
     float s = 0.f;
 #pragma unroll
@@ -586,14 +591,15 @@ int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, in
     TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 32), 256, 0, c.st, c.part, c.cs, 0, 1, c.step_tab, W, ldw, col0, bias, time_cols);
     return TRAJSDE_OK;
   }
-  // rows per workgroup: at least WGRAD_CHUNK, and few enough partials (<= ~512) that the second stage stays short
+  // rows per workgroup: at least WGRAD_CHUNK; enough partials to fill the chip several times over (a workgroup walks its
+  // rows 64 at a time with a barrier in between), few enough (<= ~2048) that the second stage stays short
   const int groups = int((R + rows_per_group - 1) / rows_per_group);
   int64_t chunk = WGRAD_CHUNK;
-  const int64_t want_parts = groups > 512 ? groups : 512;
+  const int64_t want_parts = groups > 2048 ? groups : 2048;
   while ((rows_per_group + chunk - 1) / chunk * groups > want_parts) chunk *= 2;
   const int cpg = int((rows_per_group + chunk - 1) / chunk);
   const int P = cpg * groups;
-  TS_LAUNCH(k_wgrad, P, 256, (4 * 4096 + 4 * 4 * 64) * 4, c.st, delta, ldd, a, lda, R, rows_per_group, int(chunk), cpg, c.part, c.cs);
+  TS_LAUNCH(k_wgrad, P, 256, (64 * 80 * 2 + 4 * 4 * 64) * 4, c.st, delta, ldd, a, lda, R, rows_per_group, int(chunk), cpg, c.part, c.cs);
   TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 32), 256, 0, c.st, c.part, c.cs, P, cpg, c.step_tab, W, ldw, col0, bias, time_cols);
   return TRAJSDE_OK;
 }
