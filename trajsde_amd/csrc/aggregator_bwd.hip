@@ -219,7 +219,7 @@ struct AggBwdWs {
   int32_t *REV, *asym;
   NodeBlockScratch nb;
   EdgeEmbedScratch ee;
-  int64_t total;
+  int64_t total, parts;
   bool ok;
   AggBwdWs(int64_t N, int64_t E, int nl, int K, void* ws, int64_t bytes) {
     Carver c(ws, bytes);
@@ -243,7 +243,7 @@ struct AggBwdWs {
     for (float** p : edge) *p = c.take<float>(E * 64 + 64);
     nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
     const int64_t rows = E > N ? E : N;
-    const int64_t parts = wgrad_max_parts(rows, 1);
+    parts = wgrad_max_parts(rows, 1);
     part = c.take<float>(parts * 4096);
     cs = c.take<float>(parts * 64);
     (void)K;
@@ -296,7 +296,7 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int64_t N = b->N, E = g->E_g, ntiles = (N + 15) / 16, etiles = (E + 15) / 16;
   const int nl = num_layers, K = num_modes;
-  const WgradCtx wc{st, w.part, w.cs, nullptr};
+  const WgradCtx wc{st, w.part, w.cs, nullptr, w.parts};
 
   // ---- forward recompute (the kernels the forward itself runs), one buffer per layer
   if (E > 0)
@@ -332,8 +332,10 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     float* pw = G("multihead_proj.weight");
     float* pb = G("multihead_proj.bias");
     TS_REQUIRE(!missing, "aggregator_backward: parameter table lacks norm / multihead_proj");
+    WgradBatch wb(wc, N, N);
     for (int k = 0; k < K; ++k)
-      if (int rc = run_wgrad(wc, d_global + int64_t(k) * N * 64, 64, w.XF, 64, N, N, pw + int64_t(k) * MAT64, 64, 0, pb + 64 * k, 0)) return rc;
+      if (int rc = wb.add(d_global + int64_t(k) * N * 64, 64, w.XF, 64, pw + int64_t(k) * MAT64, 64, 0, pb + 64 * k, 0)) return rc;
+    if (int rc = wb.flush()) return rc;
   }
 
   // ---- layers, last to first
@@ -396,8 +398,10 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, n1g)) return rc;
     if (int rc = run_colsum(st, w.nb.vpart + 64, gp * 4, 128, 64, n1b)) return rc;
     const float* dps[3] = {w.DQ, w.DKN, w.DVN};
+    WgradBatch wb(wc, N, N);
     for (int j = 0; j < 3; ++j)
-      if (int rc = run_wgrad(wc, dps[j], 64, w.xn[l], 64, N, N, qkv_w[j], 64, 0, qkv_b[j], 0)) return rc;
+      if (int rc = wb.add(dps[j], 64, w.xn[l], 64, qkv_w[j], 64, 0, qkv_b[j], 0)) return rc;
+    if (int rc = wb.flush()) return rc;
     float* t = dcur; dcur = dnext; dnext = t;
   }
   TS_HIP(hipMemcpyAsync(d_local, dcur, size_t(N) * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -10,12 +10,21 @@
 namespace tsde {
 
 constexpr int WGRAD_CHUNK = 512;           // rows one k_wgrad workgroup reduces
-inline int64_t wgrad_max_parts(int64_t rows, int64_t groups) { return (rows + WGRAD_CHUNK - 1) / WGRAD_CHUNK + groups + 33; }   // +32: run_headwise_outer slices
+constexpr int WGRAD_MAX_JOBS = 16;         // weight-gradient problems over the same rows that share one launch
+// partial slots of a workspace: the largest single problem (+32: run_headwise_outer slices) plus room for batching small ones
+inline int64_t wgrad_max_parts(int64_t rows, int64_t groups) { return (rows + WGRAD_CHUNK - 1) / WGRAD_CHUNK + groups + 33 + 2048; }
 
-__global__ void k_wgrad(const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, int chunk,
-                        int chunks_per_group, float* part, float* cs);
-__global__ void k_reduce_partials(const float* part, const float* cs, int P, int chunks_per_group, const float* step_tab, float* W,
-                                  int ldw, int col0, float* bias, int time_cols);
+struct WgradJob {              // W[o*ldw + col0 + i] = sum_r delta[r*ldd + o] * a[r*lda + i];  bias[o] = sum_r delta[r*ldd + o] (or null)
+  const float *delta, *a;
+  float *W, *bias;
+  int ldd, lda, ldw, col0, time_cols;
+};
+struct WgradJobs {
+  WgradJob j[WGRAD_MAX_JOBS];
+  int n;
+};
+__global__ void k_wgrad(WgradJobs jobs, int64_t R, int64_t rows_per_group, int chunk, int chunks_per_group, int P, float* part, float* cs);
+__global__ void k_reduce_partials(WgradJobs jobs, const float* part, const float* cs, int P, int chunks_per_group, const float* step_tab);
 __global__ void k_colsum(const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride);
 
 // ---- pieces of the SDE decoder backward reused by the MLP decoder backward (decoder_bwd.hip)
@@ -29,8 +38,18 @@ __global__ void k_dec_init_bwd(const float* img, const float* local, const float
 
 struct WgradCtx {
   hipStream_t st;
-  float *part, *cs;            // scratch for wgrad_max_parts(...) partials of 4096 / 64 floats
+  float *part, *cs;            // scratch for `cap` partials of 4096 / 64 floats
   const float* step_tab;       // only read when time_cols is set
+  int64_t cap;                 // = wgrad_max_parts(...) the workspace was carved with
+};
+// several weight-gradient problems over the SAME rows (R, rows_per_group) in one pair of launches (grid.y = problem)
+struct WgradBatch {
+  const WgradCtx& c;
+  int64_t R, rows_per_group;
+  WgradJobs jobs;
+  WgradBatch(const WgradCtx& ctx, int64_t R_, int64_t rpg) : c(ctx), R(R_), rows_per_group(rpg) { jobs.n = 0; }
+  int add(const float* delta, int ldd, const float* a, int lda, float* W, int ldw, int col0, float* bias, int time_cols);
+  int flush();
 };
 // W[o*ldw + col0 + i] = sum_r delta[r*ldd + o] * a[r*lda + i]  (o, i < 64);  bias[o] = sum_r delta[r*ldd + o] (or null)
 int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, float* W,

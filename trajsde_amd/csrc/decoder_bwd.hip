@@ -423,9 +423,14 @@ __global__ __launch_bounds__(128) void k_dec_init_bwd(const float* __restrict__ 
 // ------------------------------------------------------------------ weight gradients from saved rows
 // part[p] = sum_{rows of chunk p} delta[r][:]^T a[r][:]  (64x64, [o][i]),  cs[p][o] = sum delta[r][o].
 // Chunks never straddle a group (= one Euler step of rows_per_group rows), so the reducer can weight them per step.
-__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ delta, int ldd, const float* __restrict__ a, int lda, int64_t R,
-                                               int64_t rows_per_group, int chunk, int chunks_per_group,
+__global__ __launch_bounds__(256) void k_wgrad(WgradJobs jobs, int64_t R, int64_t rows_per_group, int chunk, int chunks_per_group, int P,
                                                float* __restrict__ part, float* __restrict__ cs) {
+  const WgradJob& job = jobs.j[blockIdx.y];
+  const float* __restrict__ delta = job.delta;
+  const float* __restrict__ a = job.a;
+  const int ldd = job.ldd, lda = job.lda;
+  part += int64_t(blockIdx.y) * P * 4096;
+  cs += int64_t(blockIdx.y) * P * 64;
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   float (*red)[2048] = reinterpret_cast<float (*)[2048]>(dyn);                  // [4 waves][32 x 64]: half of the output rows
   float (*csr)[4][64] = reinterpret_cast<float (*)[4][64]>(dyn + 64 * 80 * 2);   // [4 waves][4 k-groups][64], behind the staging area
@@ -510,10 +515,14 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ delta, 
 // W[o*ldw + col0 + i] = sum_p part[p][o][i];  bias[o] = sum_p cs[p][o];  with time_cols the (sin t, cos t) input
 // columns 64 / 65 of the 66-wide first SDE layer: W[o*ldw + 64] = sum_p sin(t_group(p)) cs[p][o], likewise cos.
 // A workgroup owns 32 outputs; its 8 thread groups each sum every 8th partial, then combine in a fixed order.
-__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ part, const float* __restrict__ cs, int P,
-                                                         int chunks_per_group, const float* __restrict__ step_tab,
-                                                         float* __restrict__ W, int ldw, int col0, float* __restrict__ bias,
-                                                         int time_cols) {
+__global__ __launch_bounds__(256) void k_reduce_partials(WgradJobs jobs, const float* __restrict__ part, const float* __restrict__ cs, int P,
+                                                         int chunks_per_group, const float* __restrict__ step_tab) {
+  const WgradJob& job = jobs.j[blockIdx.y];
+  float* __restrict__ W = job.W;
+  float* __restrict__ bias = job.bias;
+  const int ldw = job.ldw, col0 = job.col0, time_cols = job.time_cols;
+  part += int64_t(blockIdx.y) * P * 4096;
+  cs += int64_t(blockIdx.y) * P * 64;
   __shared__ float red[3][8][32];
   const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + lane;
@@ -585,10 +594,21 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, 
   }
 }
 
-int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, float* W,
-              int ldw, int col0, float* bias, int time_cols) {
-  if (R <= 0) {   // nothing to sum: the gradient block is zero
-    TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 32), 256, 0, c.st, c.part, c.cs, 0, 1, c.step_tab, W, ldw, col0, bias, time_cols);
+int WgradBatch::add(const float* delta, int ldd, const float* a, int lda, float* W, int ldw, int col0, float* bias, int time_cols) {
+  if (jobs.n == WGRAD_MAX_JOBS)
+    if (int rc = flush()) return rc;
+  jobs.j[jobs.n++] = WgradJob{delta, a, W, bias, ldd, lda, ldw, col0, time_cols};
+  return TRAJSDE_OK;
+}
+
+int WgradBatch::flush() {
+  if (jobs.n == 0) return TRAJSDE_OK;
+  const int n = jobs.n;
+  jobs.n = 0;
+  if (R <= 0) {   // nothing to sum: the gradient blocks are zero
+    WgradJobs all = jobs;
+    all.n = n;
+    TS_LAUNCH(k_reduce_partials, dim3(cdiv(4096 + 64, 32), n), 256, 0, c.st, all, c.part, c.cs, 0, 1, c.step_tab);
     return TRAJSDE_OK;
   }
   // rows per workgroup: at least WGRAD_CHUNK; enough partials to fill the chip several times over (a workgroup walks its
@@ -599,9 +619,23 @@ int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, in
   while ((rows_per_group + chunk - 1) / chunk * groups > want_parts) chunk *= 2;
   const int cpg = int((rows_per_group + chunk - 1) / chunk);
   const int P = cpg * groups;
-  TS_LAUNCH(k_wgrad, P, 256, (64 * 80 * 2 + 4 * 4 * 64) * 4, c.st, delta, ldd, a, lda, R, rows_per_group, int(chunk), cpg, c.part, c.cs);
-  TS_LAUNCH(k_reduce_partials, cdiv(4096 + 64, 32), 256, 0, c.st, c.part, c.cs, P, cpg, c.step_tab, W, ldw, col0, bias, time_cols);
+  int per_launch = int(c.cap / P);
+  if (per_launch < 1) return fail(TRAJSDE_ERR_WORKSPACE, "wgrad: partial buffer too small");
+  for (int first = 0; first < n; first += per_launch) {
+    WgradJobs sub;
+    sub.n = n - first < per_launch ? n - first : per_launch;
+    for (int i = 0; i < sub.n; ++i) sub.j[i] = jobs.j[first + i];
+    TS_LAUNCH(k_wgrad, dim3(P, sub.n), 256, (64 * 80 * 2 + 4 * 4 * 64) * 4, c.st, sub, R, rows_per_group, int(chunk), cpg, P, c.part, c.cs);
+    TS_LAUNCH(k_reduce_partials, dim3(cdiv(4096 + 64, 32), sub.n), 256, 0, c.st, sub, c.part, c.cs, P, cpg, c.step_tab);
+  }
   return TRAJSDE_OK;
+}
+
+int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, float* W,
+              int ldw, int col0, float* bias, int time_cols) {
+  WgradBatch b(c, R, rows_per_group);
+  if (int rc = b.add(delta, ldd, a, lda, W, ldw, col0, bias, time_cols)) return rc;
+  return b.flush();
 }
 int run_colsum(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride) {
   k_colsum<<<cdiv(n, 64), 1024, 0, st>>>(src, rows, stride, n, dst, dst_stride);
@@ -625,7 +659,7 @@ struct BwdWs {
   int32_t *best, *cnt;
   float *minsum, *scal, *states, *H1, *H2, *G1, *G2, *GS, *DH1, *DH2, *DF, *DG1, *DG2, *S_in, *DU, *DS, *gsel, *DA, *DY0, *part, *cs,
       *vpart;
-  int64_t bytes;
+  int64_t bytes, parts;
 };
 
 BwdWs carve_bwd(void* ws, int64_t ws_bytes, int N, int T, int n_euler, bool& ok) {
@@ -654,7 +688,7 @@ BwdWs carve_bwd(void* ws, int64_t ws_bytes, int N, int T, int n_euler, bool& ok)
   w.DA = cv.take<float>(slab);
   w.DY0 = cv.take<float>(slab);
   const int64_t max_rows = int64_t(N) * (n_euler > T ? n_euler : T);
-  const int64_t max_parts = wgrad_max_parts(max_rows, n_euler > T ? n_euler : T);
+  const int64_t max_parts = w.parts = wgrad_max_parts(max_rows, n_euler > T ? n_euler : T);
   w.part = cv.take<float>(max_parts * 4096);
   w.cs = cv.take<float>(max_parts * 64);
   w.vpart = cv.take<float>(int64_t(256) * (BWD_THREADS / 64) * 512);
@@ -742,19 +776,27 @@ int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, cons
   TS_LAUNCH_CHECK("k_colsum(init)");
 
   // ---- weight gradients: (delta rows, input rows, rows, rows per step) -> W (+ column offset), bias, time columns
-  const WgradCtx wc{st, w.part, w.cs, step_table};
+  const WgradCtx wc{st, w.part, w.cs, step_table, w.parts};
   auto wgrad = [&](const float* delta, const float* a, int64_t R, int64_t rows_per_group, float* W, int ldw, int col0, float* bias,
                    int time_cols) -> int { return run_wgrad(wc, delta, 64, a, 64, R, rows_per_group, W, ldw, col0, bias, time_cols); };
   const int64_t RS = slab / 64 * n_euler, RT = slab / 64 * T;
   int rc;
-  if ((rc = wgrad(w.DH1, w.states, RS, N, grads[F0W], 66, 0, grads[F0B], 1))) return rc;
-  if ((rc = wgrad(w.DH2, w.H1, RS, N, grads[F2W], 64, 0, grads[F2B], 0))) return rc;
-  if ((rc = wgrad(w.DF, w.H2, RS, N, grads[F4W], 64, 0, grads[F4B], 0))) return rc;
-  if ((rc = wgrad(w.DG1, w.states, RS, N, grads[G0W], 66, 0, grads[G0B], 1))) return rc;
-  if ((rc = wgrad(w.DG2, w.G1, RS, N, grads[G2W], 64, 0, grads[G2B], 0))) return rc;
+  {
+    WgradBatch sde(wc, RS, N);                              // the five SDE matrices over the same (step, path) rows: one launch pair
+    if ((rc = sde.add(w.DH1, 64, w.states, 64, grads[F0W], 66, 0, grads[F0B], 1))) return rc;
+    if ((rc = sde.add(w.DH2, 64, w.H1, 64, grads[F2W], 64, 0, grads[F2B], 0))) return rc;
+    if ((rc = sde.add(w.DF, 64, w.H2, 64, grads[F4W], 64, 0, grads[F4B], 0))) return rc;
+    if ((rc = sde.add(w.DG1, 64, w.states, 64, grads[G0W], 66, 0, grads[G0B], 1))) return rc;
+    if ((rc = sde.add(w.DG2, 64, w.G1, 64, grads[G2W], 64, 0, grads[G2B], 0))) return rc;
+    if ((rc = sde.flush())) return rc;
+  }
   if ((rc = wgrad(w.DU, w.S_in, RT, RT, grads[D0W], 64, 0, grads[D0B], 0))) return rc;
-  if ((rc = wgrad(w.DA, w.gsel, N, N, grads[A0W], 128, 0, grads[A0B], 0))) return rc;      // cat(global, local): DEC:82
-  if ((rc = wgrad(w.DA, local_embed, N, N, grads[A0W], 128, 64, nullptr, 0))) return rc;
+  {
+    WgradBatch init(wc, N, N);                              // aggr_embed.0 [64,128] = cat(global, local): DEC:82
+    if ((rc = init.add(w.DA, 64, w.gsel, 64, grads[A0W], 128, 0, grads[A0B], 0))) return rc;
+    if ((rc = init.add(w.DA, 64, local_embed, 64, grads[A0W], 128, 64, nullptr, 0))) return rc;
+    if ((rc = init.flush())) return rc;
+  }
   return TRAJSDE_OK;
 }
 

@@ -592,7 +592,7 @@ struct EncBwdWs {
   float *dagg, *dxn, *DQ, *DCENTER, *DV, *DLG, *EMB, *DK, *DQE, *DEMB, *A1, *A2, *DA3P, *DA2P, *XR, *part, *cs, *scal;
   NodeBlockScratch nb;
   EdgeEmbedScratch ee;
-  int64_t total;
+  int64_t total, parts;
   bool ok;
   EncBwdWs(const trajsde_batch* b, const trajsde_graph* g, void* ws, int64_t bytes) {
     Carver c(ws, bytes);
@@ -620,7 +620,7 @@ struct EncBwdWs {
     for (float** p : rows_E) *p = c.take<float>(E * 64);
     nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
     const int64_t rows = E > R ? E : R;
-    const int64_t parts = wgrad_max_parts(rows, H);
+    parts = wgrad_max_parts(rows, H);
     part = c.take<float>(parts * 4096);
     cs = c.take<float>(parts * 64);
     scal = c.take<float>(64);
@@ -687,8 +687,12 @@ int run_attn_chain(const AttnChain& c, const float* dout, EncBwdWs& w, const Wgr
     TS_LAUNCH(k_edge_kv_bwd, tile_grid((E + 15) / 16, 512, EdgeKvBwdL::SIZE * 4), 512, EdgeKvBwdL::SIZE * 4, st, c.img_kv, c.geom, c.dst, c.q,
               w.DLG, w.DV, E, w.EMB, w.DK, w.DQE, w.DEMB, c.heads);
     TS_LAUNCH(k_seg_sum, cdiv(R, 4), 256, 0, st, c.segptr, w.DQE, R, w.DQ);
-    if (int rc = run_wgrad(wc, w.DK, 64, w.EMB, 64, E, E, wk, 64, 0, bk, 0)) return rc;
-    if (int rc = run_wgrad(wc, w.DV, 64, w.EMB, 64, E, E, wv, 64, 0, bv, 0)) return rc;
+    {
+      WgradBatch wb(wc, E, E);
+      if (int rc = wb.add(w.DK, 64, w.EMB, 64, wk, 64, 0, bk, 0)) return rc;
+      if (int rc = wb.add(w.DV, 64, w.EMB, 64, wv, 64, 0, bv, 0)) return rc;
+      if (int rc = wb.flush()) return rc;
+    }
     if (int rc = edge_embed_backward(c.img_emb, c.geom, w.DEMB, E, w.ee, wc, eg, st)) return rc;
   }
   const int gp = vec_grid((R + 15) / 16, 256, ProjBwdL<1>::SIZE * 4);
@@ -769,7 +773,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   const int64_t rtiles = (int64_t(Nt) + 15) / 16;
   NoiseArg na{0, nullptr, nullptr};
   if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
-  const WgradCtx wc{st, w.part, w.cs, step_tab_dev};
+  const WgradCtx wc{st, w.part, w.cs, step_tab_dev, w.parts};
   using FB = EncBlob;
   using BB = EncBwdBlob;
 
@@ -855,12 +859,14 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
         {w.DR1, w.HODE, "gru_unit.reset_gate.0.weight", "gru_unit.reset_gate.0.bias", 128, 0, 0},
         {w.DR1, w.XS, "gru_unit.reset_gate.0.weight", nullptr, 128, 64, 0},
     };
+    WgradBatch wb(wc, R, Nt);                                  // sixteen problems over the same (iteration, row) slabs
     for (const WG& j : jobs) {
       float* W = G(j.w);
       float* bias = j.bias ? G(j.bias) : nullptr;
       TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
-      if (int rc = run_wgrad(wc, j.d, 64, j.a, 64, R, Nt, W, j.ldw, j.col0, bias, j.tc)) return rc;
+      if (int rc = wb.add(j.d, 64, j.a, 64, W, j.ldw, j.col0, bias, j.tc)) return rc;
     }
+    if (int rc = wb.flush()) return rc;
     // last diffusion layers (64 -> 1): d w4 = sum dgp * g2, d b4 = sum dgp, per net (rows of the other source carry 0)
     float *n4w = G("lsde_func.g_nus.net.4.weight"), *n4b = G("lsde_func.g_nus.net.4.bias");
     float *a4w = G("lsde_func.g_argo.net.4.weight"), *a4b = G("lsde_func.g_argo.net.4.bias");
@@ -936,7 +942,7 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
   const int64_t R = int64_t(H) * N, RT = int64_t(N) * 22, Eaa = g->E_aa, Ela = g->E_la, rtiles = (RT + 15) / 16;
   std::vector<TrLayerTape>& tp = ex.tp;
   float *x0 = ex.x0, *dxa = ex.dxa, *dxb = ex.dxb, *dq = ex.dq, *dk = ex.dk, *dv = ex.dv, *dO = ex.dO, *tout = ex.tout, *dtout = ex.dtout;
-  const WgradCtx wc{st, w.part, w.cs, nullptr};
+  const WgradCtx wc{st, w.part, w.cs, nullptr, w.parts};
   using FB = EncBlob;
   using BB = EncBwdBlob;
   // ================= forward recompute =================
@@ -1016,8 +1022,10 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
     if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, n1g)) return rc;
     if (int rc = run_colsum(st, w.nb.vpart + 64, gp * 4, 128, 64, n1b)) return rc;
     const float* dps[3] = {dq, dk, dv};
+    WgradBatch wb(wc, RT, RT);
     for (int j = 0; j < 3; ++j)
-      if (int rc = run_wgrad(wc, dps[j], 64, tp[l].xn, 64, RT, RT, wi + int64_t(j) * MAT64, 64, 0, bi + 64 * j, 0)) return rc;
+      if (int rc = wb.add(dps[j], 64, tp[l].xn, 64, wi + int64_t(j) * MAT64, 64, 0, bi + 64 * j, 0)) return rc;
+    if (int rc = wb.flush()) return rc;
     float* t = dcur; dcur = dnext; dnext = t;
   }
   {

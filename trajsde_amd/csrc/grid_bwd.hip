@@ -226,7 +226,7 @@ enum MlpGradSlot { L0W = 0, L0B, L1W, L1B, L3W, L3B, A0W, A0B, A1W, A1B, N_MLP_G
 struct MlpBwdWs {
   int32_t *best, *cnt;
   float *minsum, *scal, *out, *gsel, *H, *DL, *DU, *DOUT, *DA, *w3tmp, *b3tmp, *part, *cs, *vpart;
-  int64_t bytes;
+  int64_t bytes, parts;
   bool ok;
   MlpBwdWs(void* ws, int64_t n, int N) {
     Carver c(ws, n);
@@ -235,7 +235,7 @@ struct MlpBwdWs {
     out = c.take<float>(slab); gsel = c.take<float>(slab); H = c.take<float>(slab); DL = c.take<float>(slab * 2);
     DU = c.take<float>(slab); DOUT = c.take<float>(slab); DA = c.take<float>(slab);
     w3tmp = c.take<float>(128 * 64); b3tmp = c.take<float>(128);
-    const int64_t parts = wgrad_max_parts(N, 1);
+    parts = wgrad_max_parts(N, 1);
     part = c.take<float>(parts * 4096); cs = c.take<float>(parts * 64);
     vpart = c.take<float>(int64_t(512) * 4 * 128);
     bytes = c.off + 256;
@@ -263,7 +263,7 @@ int trajsde_mlp_decoder_l2_backward(int32_t N, int num_modes, int future_steps, 
   const int K = num_modes, T = future_steps;
   const int ntiles = (N + 15) / 16;
   const float* init_img = blob_bwd + MlpDecBwdBlob::INIT;
-  const WgradCtx wc{st, w.part, w.cs, nullptr};
+  const WgradCtx wc{st, w.part, w.cs, nullptr, w.parts};
   TS_LAUNCH(k_l2_wta, cdiv(N, 256), 256, 0, st, loc, y, reg_mask, N, K, T, w.best, w.minsum, w.cnt);
   TS_LAUNCH(k_l2_finalize, 1, 1024, 0, st, w.minsum, w.cnt, N, w.scal);
   TS_HIP(hipMemcpyAsync(loss, w.scal, sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -380,7 +380,10 @@ __global__ __launch_bounds__(256) void k_headwise_outer(const float* __restrict_
 int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64_t N, float* W, int heads) {
   const int S = N >= 4096 ? 32 : (N >= 256 ? 8 : 1);
   TS_LAUNCH(k_headwise_outer, dim3(64, S), 256, 0, wc.st, X, Y, N, wc.part, heads);
-  TS_LAUNCH(k_reduce_partials, cdiv(4096, 32), 256, 0, wc.st, wc.part, wc.cs, S, 1, nullptr, W, 64, 0, nullptr, 0);
+  WgradJobs one;
+  one.n = 1;
+  one.j[0] = WgradJob{nullptr, nullptr, W, nullptr, 0, 0, 64, 0, 0};
+  TS_LAUNCH(k_reduce_partials, dim3(cdiv(4096, 32), 1), 256, 0, wc.st, one, wc.part, wc.cs, S, 1, nullptr);
   return TRAJSDE_OK;
 }
 
@@ -394,12 +397,13 @@ int ffn_block_backward(const float* img_a, const float* img_b, const float* xn2,
   TS_LAUNCH(k_ffn_bwd_b, gb, 256, FfnBwdBL::SIZE * 4, st, img_b, sc.DH, dout, x1, R, sc.dx1, sc.vpart);
   if (int rc = run_colsum(st, sc.vpart, gb * 4, 128, 64, gr.n2g)) return rc;
   if (int rc = run_colsum(st, sc.vpart + 64, gb * 4, 128, 64, gr.n2b)) return rc;
-  // first layer [256,64] (four 64-row blocks) and second layer [64,256] (four 64-column blocks)
+  // first layer [256,64] (four 64-row blocks) and second layer [64,256] (four 64-column blocks): eight problems, one launch pair
+  WgradBatch wb(wc, R, R);
   for (int b = 0; b < 4; ++b) {
-    if (int rc = run_wgrad(wc, sc.DH + 64 * b, 256, xn2, 64, R, R, gr.w1 + b * MAT64, 64, 0, gr.b1 + 64 * b, 0)) return rc;
-    if (int rc = run_wgrad(wc, dout, 64, sc.H + 64 * b, 256, R, R, gr.w2, 256, 64 * b, b == 0 ? gr.b2 : nullptr, 0)) return rc;
+    if (int rc = wb.add(sc.DH + 64 * b, 256, xn2, 64, gr.w1 + b * MAT64, 64, 0, gr.b1 + 64 * b, 0)) return rc;
+    if (int rc = wb.add(dout, 64, sc.H + 64 * b, 256, gr.w2, 256, 64 * b, b == 0 ? gr.b2 : nullptr, 0)) return rc;
   }
-  return TRAJSDE_OK;
+  return wb.flush();
 }
 
 int node_block_backward(const float* img, const NodeBlockTape& tp, const float* dout, int64_t R, const NodeBlockScratch& sc,
@@ -408,11 +412,12 @@ int node_block_backward(const float* img, const NodeBlockTape& tp, const float* 
   const int gu = tile_grid(ntiles, 256, UpdBwdL::SIZE * 4);
   if (int rc = ffn_block_backward(img + NodeBlockBwdL::FFN_A, img + NodeBlockBwdL::FFN_B, tp.xn2, tp.x1, dout, R, sc, wc, gr, st)) return rc;
   TS_LAUNCH(k_upd_bwd, gu, 256, UpdBwdL::SIZE * 4, st, img + NodeBlockBwdL::UPD, sc.dx1, tp.agg, tp.xn, R, sc.UPD, sc.DGP, sc.DS, dagg, dxn);
-  if (int rc = run_wgrad(wc, sc.dx1, 64, sc.UPD, 64, R, R, gr.w_out, 64, 0, gr.b_out, 0)) return rc;
-  if (int rc = run_wgrad(wc, sc.DGP, 64, tp.agg, 64, R, R, gr.w_ih, 64, 0, gr.b_ih, 0)) return rc;
-  if (int rc = run_wgrad(wc, sc.DGP, 64, tp.xn, 64, R, R, gr.w_hh, 64, 0, gr.b_hh, 0)) return rc;
-  if (int rc = run_wgrad(wc, sc.DS, 64, tp.xn, 64, R, R, gr.w_self, 64, 0, gr.b_self, 0)) return rc;
-  return TRAJSDE_OK;
+  WgradBatch wb(wc, R, R);
+  if (int rc = wb.add(sc.dx1, 64, sc.UPD, 64, gr.w_out, 64, 0, gr.b_out, 0)) return rc;
+  if (int rc = wb.add(sc.DGP, 64, tp.agg, 64, gr.w_ih, 64, 0, gr.b_ih, 0)) return rc;
+  if (int rc = wb.add(sc.DGP, 64, tp.xn, 64, gr.w_hh, 64, 0, gr.b_hh, 0)) return rc;
+  if (int rc = wb.add(sc.DS, 64, tp.xn, 64, gr.w_self, 64, 0, gr.b_self, 0)) return rc;
+  return wb.flush();
 }
 
 int edge_embed_backward(const float* img, const float* geom, const float* demb, int64_t E, const EdgeEmbedScratch& sc,
@@ -425,9 +430,13 @@ int edge_embed_backward(const float* img, const float* geom, const float* demb, 
   float* const tail_vec[4] = {gr.ag3, gr.ae3, gr.ag0, gr.ae0};
   for (int i = 0; i < 4; ++i)
     if (int rc = run_colsum(st, sc.vpart + 64 * i, gt * 4, 256, 64, tail_vec[i])) return rc;
-  if (int rc = run_wgrad(wc, sc.DEP, 64, sc.S, 64, E, E, gr.w2, 64, 0, gr.b2, 0)) return rc;
-  if (int rc = run_wgrad(wc, sc.DSP, 64, sc.A0, 64, E, E, gr.wa3, 64, 0, gr.ba3, 0)) return rc;
-  if (int rc = run_wgrad(wc, sc.DSP, 64, sc.B0, 64, E, E, gr.wb3, 64, 0, gr.bb3, 0)) return rc;
+  {
+    WgradBatch wb(wc, E, E);
+    if (int rc = wb.add(sc.DEP, 64, sc.S, 64, gr.w2, 64, 0, gr.b2, 0)) return rc;
+    if (int rc = wb.add(sc.DSP, 64, sc.A0, 64, gr.wa3, 64, 0, gr.ba3, 0)) return rc;
+    if (int rc = wb.add(sc.DSP, 64, sc.B0, 64, gr.wb3, 64, 0, gr.bb3, 0)) return rc;
+    if (int rc = wb.flush()) return rc;
+  }
   for (int br = 0; br < 2; ++br) {
     if (br == 0) TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, img, geom, sc.DSP, E, sc.vpart);
     else TS_LAUNCH(k_edge_embed_bwd_branch<1>, gb, 256, lds_br, st, img, geom, sc.DSP, E, sc.vpart);
