@@ -20,27 +20,40 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+// Packing runs as launches over job tables passed BY VALUE in the kernel arguments (64 jobs per launch; jobs that
+// accumulate onto another's output go in a later launch): a stage has a few hundred small tensors and is re-packed after
+// every optimizer step, so per-tensor launches were ~700 launches per training step.  Element i of a job is handled by
+// the device functions below.
+struct PackJob {
+  int kind, count, pass;
+  int p0, p1, p2, p3, p4;
+  const float *src, *src2;
+  float* dst;
+};
+enum PackKind { PK_VEC = 0, PK_COL, PK_MAT, PK_MAT_PAD, PK_MATT, PK_MAT6, PK_MAT6_STACK2 };
+constexpr int PACK_JOBS_PER_LAUNCH = 64;        // 64 x 56 B: under the 4 KB kernel-argument limit
+struct PackJobs {
+  PackJob j[PACK_JOBS_PER_LAUNCH];
+};
+
 // dst[i] (+)= src[i]
-__global__ void k_pack_vec(const float* __restrict__ src, float* __restrict__ dst, int n, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_pack_vec(int i, const float* __restrict__ src, float* __restrict__ dst, int n, int accumulate) {
   if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
 }
 // dst[r] = src[r*ld + col]
-__global__ void k_pack_col(const float* __restrict__ src, float* __restrict__ dst, int rows, int ld, int col) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_pack_col(int i, const float* __restrict__ src, float* __restrict__ dst, int rows, int ld, int col) {
   if (i < rows) dst[i] = src[i * ld + col];
 }
 // MFMA fragment order: dst[((jo*JTI + q)*64 + lane)*4 + c] = W[16jo + (lane&15)][col0 + 16q + 4(lane>>4) + c]
-__global__ void k_pack_mat(const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld, int col0) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_pack_mat(int i, const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld, int col0) {
   if (i >= jto * jti * 256) return;
   const int c = i & 3, lane = (i >> 2) & 63, q = (i >> 8) % jti, jo = (i >> 8) / jti;
   dst[i] = src[(16 * jo + (lane & 15)) * ld + col0 + 16 * q + 4 * (lane >> 4) + c];
 }
 
 // k_pack_mat with the rows >= rows_valid written as zeros (a weight whose row count is not a multiple of 16)
-__global__ void k_pack_mat_pad(const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld, int rows_valid) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_pack_mat_pad(int i, const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld,
+                                               int rows_valid) {
   if (i >= jto * jti * 256) return;
   const int c = i & 3, lane = (i >> 2) & 63, q = (i >> 8) % jti, jo = (i >> 8) / jti;
   const int row = 16 * jo + (lane & 15);
@@ -48,9 +61,8 @@ __global__ void k_pack_mat_pad(const float* __restrict__ src, float* __restrict_
 }
 
 // fragment image [jo < jto][q < jti][lane][4] of a TRANSPOSED weight: element [r][c] = W[c][col0 + r] (W row-major, ld)
-__global__ void k_pack_matT(const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld, int col0,
-                            int rows_valid) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_pack_matT(int i, const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld,
+                                            int col0, int rows_valid) {
   if (i >= jto * jti * 256) return;
   const int c = i & 3, lane = (i >> 2) & 63, q = (i >> 8) % jti, jo = (i >> 8) / jti;
   const int row_t = 16 * jo + (lane & 15), col_t = 16 * q + 4 * (lane >> 4) + c;      // element of W^T
@@ -59,8 +71,8 @@ __global__ void k_pack_matT(const float* __restrict__ src, float* __restrict__ d
 
 // bf16x6 planes: dst (as bf16) [plane][jo][s][lane][8]; element j of lane (i,g) in k-step s is the plane-th exact
 // truncation piece of W[16jo + i][col0 + 32s + 16(j>>2) + 4g + (j&3)]   (tile.hpp linear_acc_x6)
-__global__ void k_pack_mat6(const float* __restrict__ src, unsigned short* __restrict__ dst, int jto, int ks, int ld, int col0) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_pack_mat6(int i, const float* __restrict__ src, unsigned short* __restrict__ dst, int jto, int ks,
+                                            int ld, int col0) {
   const int per_plane = jto * ks * 512;
   if (i >= per_plane) return;
   const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % ks, jo = (i >> 9) / ks;
@@ -75,8 +87,54 @@ __global__ void k_pack_mat6(const float* __restrict__ src, unsigned short* __res
   dst[2 * per_plane + i] = (unsigned short)(__float_as_uint(l) >> 16);
 }
 
+// lin_k | lin_v as ONE 128-row split-precision matrix: planes are [plane][jo 0..7][s][lane][8]
+__device__ __forceinline__ void k_pack_mat6_stack2(int i, const float* __restrict__ wk, const float* __restrict__ wv,
+                                                   unsigned short* __restrict__ dst) {
+  const int per_plane = 8 * 2 * 512;
+  if (i >= per_plane) return;
+  const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % 2, jo = (i >> 9) / 2;
+  const float* src = jo < 4 ? wk : wv;
+  const float x = src[(16 * (jo & 3) + (lane & 15)) * 64 + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)];
+  const unsigned M = 0xFFFF0000u;
+  const float h = __uint_as_float(__float_as_uint(x) & M);
+  const float r = x - h;
+  const float m = __uint_as_float(__float_as_uint(r) & M);
+  const float l = r - m;
+  dst[i] = (unsigned short)(__float_as_uint(h) >> 16);
+  dst[per_plane + i] = (unsigned short)(__float_as_uint(m) >> 16);
+  dst[2 * per_plane + i] = (unsigned short)(__float_as_uint(l) >> 16);
+}
+
+// one thread per element; blockIdx.y = job
+__global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
+  const PackJob& J = jobs.j[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= J.count) return;
+  switch (J.kind) {
+    case PK_VEC: k_pack_vec(i, J.src, J.dst, J.count, J.p0); break;
+    case PK_COL: k_pack_col(i, J.src, J.dst, J.count, J.p0, J.p1); break;
+    case PK_MAT: k_pack_mat(i, J.src, J.dst, J.p0, J.p1, J.p2, J.p3); break;
+    case PK_MAT_PAD: k_pack_mat_pad(i, J.src, J.dst, J.p0, J.p1, J.p2, J.p3); break;
+    case PK_MATT: k_pack_matT(i, J.src, J.dst, J.p0, J.p1, J.p2, J.p3, J.p4); break;
+    case PK_MAT6: k_pack_mat6(i, J.src, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1, J.p2, J.p3); break;
+    case PK_MAT6_STACK2: k_pack_mat6_stack2(i, J.src, J.src2, reinterpret_cast<unsigned short*>(J.dst)); break;
+  }
+}
+
 struct Packer {
   bool dry;
+  std::vector<PackJob> jobs;               // wet: filled by the recipe, launched once by trajsde_pack_weights
+  void emit(int kind, int count, const float* s, float* d, int p0 = 0, int p1 = 0, int p2 = 0, int p3 = 0, int p4 = 0,
+            const float* s2 = nullptr, int pass = 0) {
+    jobs.push_back(PackJob{kind, count, pass, p0, p1, p2, p3, p4, s, s2, d});
+  }
+  // raw-pointer forms for recipes that slice a parameter themselves
+  void vec_raw(const float* s, float* d, int count) { emit(PK_VEC, count, s, d, 0); }
+  void mat_raw(const float* s, float* d, int jto, int jti, int ld, int col0) { emit(PK_MAT, jto * jti * 256, s, d, jto, jti, ld, col0); }
+  void matT_raw(const float* s, float* d, int jto, int jti, int ld, int col0, int rows_valid) {
+    emit(PK_MATT, jto * jti * 256, s, d, jto, jti, ld, col0, rows_valid);
+  }
+  void mat6_raw(const float* s, float* d, int jto, int ks, int ld, int col0) { emit(PK_MAT6, jto * ks * 512, s, d, jto, ks, ld, col0); }
   std::vector<std::string> names;          // dry: collected in order of first use
   const float* const* params = nullptr;    // wet
   float* blob = nullptr;
@@ -96,36 +154,36 @@ struct Packer {
   void vec(const std::string& n, int dst, int count, bool accumulate = false) {
     const float* s = src(n);
     if (dry) return;
-    k_pack_vec<<<cdiv(count, 256), 256, 0, stream>>>(s, blob + dst, count, accumulate ? 1 : 0);
+    emit(PK_VEC, count, s, blob + dst, accumulate ? 1 : 0, 0, 0, 0, 0, nullptr, accumulate ? 1 : 0);
   }
   void col(const std::string& n, int dst, int rows, int ld, int c) {
     const float* s = src(n);
     if (dry) return;
-    k_pack_col<<<cdiv(rows, 256), 256, 0, stream>>>(s, blob + dst, rows, ld, c);
+    emit(PK_COL, rows, s, blob + dst, ld, c);
   }
   // rows x cols sub-matrix starting at column col0 of a row-major [rows x ld] weight
   void mat(const std::string& n, int dst, int rows, int cols, int ld, int col0 = 0) {
     const float* s = src(n);
     if (dry) return;
     const int jto = rows / 16, jti = cols / 16;
-    k_pack_mat<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, col0);
+    mat_raw(s, blob + dst, jto, jti, ld, col0);
   }
   void mat_pad(const std::string& n, int dst, int jto, int jti, int ld, int rows_valid) {
     const float* s = src(n);
     if (dry) return;
-    k_pack_mat_pad<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, rows_valid);
+    emit(PK_MAT_PAD, jto * jti * 256, s, blob + dst, jto, jti, ld, rows_valid);
   }
   // transposed image of the [16*jti x 16*jto] block of W starting at column col0 (default: a 64x64 block)
   void matT(const std::string& n, int dst, int ld, int col0 = 0, int jto = 4, int jti = 4, int rows_valid = 1 << 30) {
     const float* s = src(n);
     if (dry) return;
-    k_pack_matT<<<cdiv(jto * jti * 256, 256), 256, 0, stream>>>(s, blob + dst, jto, jti, ld, col0, rows_valid);
+    matT_raw(s, blob + dst, jto, jti, ld, col0, rows_valid);
   }
   void mat6(const std::string& n, int dst, int rows, int cols, int ld, int col0 = 0) {
     const float* s = src(n);
     if (dry) return;
     const int jto = rows / 16, ks = cols / 32;
-    k_pack_mat6<<<cdiv(jto * ks * 512, 256), 256, 0, stream>>>(s, reinterpret_cast<unsigned short*>(blob + dst), jto, ks, ld, col0);
+    mat6_raw(s, blob + dst, jto, ks, ld, col0);
   }
   void lin(const std::string& p, int w, int b, int rows = 64, int cols = 64) {
     mat(p + ".weight", w, rows, cols, cols);
@@ -170,27 +228,10 @@ static void recipe_edge_embed6(Packer& P, const std::string& p, int base) {   //
   P.vec(p + ".aggr_embed.2.bias", base + E::B2, 64);
   P.ln(p + ".aggr_embed.3", base + E::AG3, base + E::AE3);
 }
-// lin_k | lin_v as ONE 128-row split-precision matrix: planes are [plane][jo 0..7][s][lane][8]
-__global__ void k_pack_mat6_stack2(const float* __restrict__ wk, const float* __restrict__ wv, unsigned short* __restrict__ dst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int per_plane = 8 * 2 * 512;
-  if (i >= per_plane) return;
-  const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % 2, jo = (i >> 9) / 2;
-  const float* src = jo < 4 ? wk : wv;
-  const float x = src[(16 * (jo & 3) + (lane & 15)) * 64 + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)];
-  const unsigned M = 0xFFFF0000u;
-  const float h = __uint_as_float(__float_as_uint(x) & M);
-  const float r = x - h;
-  const float m = __uint_as_float(__float_as_uint(r) & M);
-  const float l = r - m;
-  dst[i] = (unsigned short)(__float_as_uint(h) >> 16);
-  dst[per_plane + i] = (unsigned short)(__float_as_uint(m) >> 16);
-  dst[2 * per_plane + i] = (unsigned short)(__float_as_uint(l) >> 16);
-}
 static void pack_kv6(Packer& P, const std::string& k, const std::string& v, int w, int b) {
   const float* wk = P.src(k + ".weight");
   const float* wv = P.src(v + ".weight");
-  if (!P.dry) k_pack_mat6_stack2<<<cdiv(8 * 2 * 512, 256), 256, 0, P.stream>>>(wk, wv, reinterpret_cast<unsigned short*>(P.blob + w));
+  if (!P.dry) P.emit(PK_MAT6_STACK2, 8 * 2 * 512, wk, P.blob + w, 0, 0, 0, 0, 0, wv);
   P.vec(k + ".bias", b, 64);
   P.vec(v + ".bias", b + 64, 64);
 }
@@ -223,10 +264,10 @@ static void recipe_upd_ffn6(Packer& P, const std::string& p, int upd, int ffn) {
   if (!P.dry)
     for (int hf = 0; hf < 2; ++hf) {
       const int base = ffn + hf * FfnL6::HALF;
-      k_pack_mat6<<<cdiv(8 * 2 * 512, 256), 256, 0, P.stream>>>(w1 + hf * 128 * 64, reinterpret_cast<unsigned short*>(P.blob + base + FfnL6::W1), 8, 2, 64, 0);
-      k_pack_vec<<<1, 128, 0, P.stream>>>(b1 + hf * 128, P.blob + base + FfnL6::B1, 128, 0);
-      k_pack_mat6<<<cdiv(4 * 4 * 512, 256), 256, 0, P.stream>>>(w2, reinterpret_cast<unsigned short*>(P.blob + base + FfnL6::W2), 4, 4, 256, hf * 128);
-      k_pack_vec<<<1, 64, 0, P.stream>>>(b2, P.blob + base + FfnL6::B2, 64, 0);
+      P.mat6_raw(w1 + hf * 128 * 64, P.blob + base + FfnL6::W1, 8, 2, 64, 0);
+      P.vec_raw(b1 + hf * 128, P.blob + base + FfnL6::B1, 128);
+      P.mat6_raw(w2, P.blob + base + FfnL6::W2, 4, 4, 256, hf * 128);
+      P.vec_raw(b2, P.blob + base + FfnL6::B2, 64);
     }
 }
 
@@ -420,8 +461,8 @@ static void recipe_aggregator(Packer& P, int nl, int K) {
   const float* bsrc = P.src("multihead_proj.bias");
   if (!P.dry)
     for (int k = 0; k < K; ++k) {
-      k_pack_mat<<<cdiv(16 * 256, 256), 256, 0, P.stream>>>(w + int64_t(k) * MAT64, P.blob + AggBlob::proj(nl, k), 4, 4, 64, 0);
-      k_pack_vec<<<1, 64, 0, P.stream>>>(bsrc + k * 64, P.blob + AggBlob::proj(nl, k) + MAT64, 64, 0);
+      P.mat_raw(w + int64_t(k) * MAT64, P.blob + AggBlob::proj(nl, k), 4, 4, 64, 0);
+      P.vec_raw(bsrc + k * 64, P.blob + AggBlob::proj(nl, k) + MAT64, 64);
     }
 }
 
@@ -541,7 +582,7 @@ static void recipe_aggregator_bwd(Packer& P, int nl, int K) {
   P.index("multihead_proj.bias");
   if (!P.dry)
     for (int k = 0; k < K; ++k)
-      k_pack_matT<<<cdiv(16 * 256, 256), 256, 0, P.stream>>>(w + int64_t(k) * MAT64, P.blob + AggBwdBlob::proj(nl, k), 4, 4, 64, 0, 1 << 30);
+      P.matT_raw(w + int64_t(k) * MAT64, P.blob + AggBwdBlob::proj(nl, k), 4, 4, 64, 0, 1 << 30);
 }
 
 static void recipe_edge_kv_bwd(Packer& P, const std::string& p, const std::string& embed, int kv, int emb) {
@@ -641,8 +682,7 @@ static void recipe_encoder_grid_bwd(Packer& P, int nl) {
     const float* w = P.src(l + ".self_attn.in_proj_weight");
     if (!P.dry)
       for (int j = 0; j < 3; ++j)
-        k_pack_matT<<<cdiv(16 * 256, 256), 256, 0, P.stream>>>(w + int64_t(j) * MAT64, P.blob + pr + ProjBwdL<3>::WT + j * MAT64, 4, 4, 64, 0,
-                                                              1 << 30);
+        P.matT_raw(w + int64_t(j) * MAT64, P.blob + pr + ProjBwdL<3>::WT + j * MAT64, 4, 4, 64, 0, 1 << 30);
     for (const char* n : {".self_attn.in_proj_bias", ".self_attn.out_proj.bias", ".linear2.bias", ".norm2.bias"}) P.index(l + n);
   }
   P.ln(t + "transformer_encoder.norm", EncGridBwdBlob::norm(nl), EncGridBwdBlob::norm(nl) + 64);
@@ -786,6 +826,21 @@ int trajsde_pack_weights(int stage, int num_layers, int num_modes, const float* 
   wet.blob = blob;
   wet.stream = static_cast<hipStream_t>(stream);
   run_recipe(wet, stage, num_layers, num_modes);
+  for (int pass = 0; pass < 2; ++pass) {
+    PackJobs tab;
+    int n = 0, max_count = 0;
+    auto launch = [&] {
+      if (n) k_pack_jobs<<<dim3(cdiv(max_count, 256), n), 256, 0, wet.stream>>>(tab);
+      n = max_count = 0;
+    };
+    for (const PackJob& j : wet.jobs) {
+      if (j.pass != pass) continue;
+      tab.j[n++] = j;
+      max_count = j.count > max_count ? j.count : max_count;
+      if (n == PACK_JOBS_PER_LAUNCH) launch();
+    }
+    launch();
+  }
   TS_LAUNCH_CHECK("pack");
   return TRAJSDE_OK;
 }
