@@ -33,12 +33,14 @@ from trajsde_amd.synth import CONFIGS, synth  # noqa: E402
 
 WORKLOAD = "config2"                 # "Synthetic batch of 64 scenes x 128 agents, K=6, 20 steps, 1xMI355X inference-only"
 FLOP_PER_EDGE = 41.7e3               # neighbour embed 25.1k + k,v 16.4k + dot 0.256k per (t, edge)
-# The edge kernel evaluates its fp32 GEMMs as bf16x6 split products on the bf16 matrix cores (csrc/tile.hpp): six
-# v_mfma_f32_16x16x32_bf16 per fp32 product, fp32-accurate.  Its roofline is therefore the dense bf16 MFMA peak of
-# MI355X_MICROARCH.md (2.5 PFLOP/s) divided by 6, expressed in algorithmic (fp32) FLOP/s.
-MFMA_BF16_PEAK_TFLOPS = 2500.0
-SPLIT_PRODUCTS = 6
-PEAK_FP32_EQUIV_TFLOPS = MFMA_BF16_PEAK_TFLOPS / SPLIT_PRODUCTS
+# The edge kernel evaluates its fp32 GEMMs as split-precision products on the 16-bit matrix cores (csrc/tile.hpp):
+# three v_mfma_f32_16x16x32_f16 per fp32 product (fp16x3, the default build) or six ..._bf16 (bf16x6), fp32-accurate.
+# Its roofline is therefore the dense fp16/bf16 MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s) divided by the number
+# of products, expressed in algorithmic (fp32) FLOP/s.
+MFMA_16BIT_PEAK_TFLOPS = 2500.0
+SPLIT_PRODUCTS = _lib.lib().trajsde_split_products()
+SPLIT_NAME = {3: "fp16x3", 6: "bf16x6"}[SPLIT_PRODUCTS]
+PEAK_FP32_EQUIV_TFLOPS = MFMA_16BIT_PEAK_TFLOPS / SPLIT_PRODUCTS
 CPU_SAMPLE_SCENES = 16
 
 
@@ -205,16 +207,18 @@ def main():
                        "scenes_per_gpu": scenes, "agents_per_scene": skw["n"], "num_modes": spec["num_modes"],
                        "future_steps": spec["future_steps"], "aa_edges_per_step": int(e_aa), "parallelism": f"scene-shard x{world}",
                        "streams_per_gpu": n_streams},
-            "roofline": {"kernel": "k_edge_kv[aa] (agent-agent edge embedding + k,v + logits; bf16x6 split-precision MFMA 16x16x32, fp32-accurate)",
+            "roofline": {"kernel": f"k_edge_kv[aa] (agent-agent edge embedding + k,v + logits; {SPLIT_NAME} split-precision MFMA 16x16x32, fp32-accurate)",
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_EQUIV_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_EQUIV_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": avg_s * 1e3, "launches": n_launch, "flop_per_edge": FLOP_PER_EDGE,
-                         "peak_note": "algorithmic fp32 FLOP/s; the kernel is instruction-issue bound (SQ counters: ~1060 VALU + 240 MFMA + ~190 "
-                                      "LDS instructions per 16-edge tile, issue port saturated, MFMA pipe busy ~45 %); "
-                                      "peak = 2500 TFLOP/s dense bf16 MFMA / 6 bf16 products per fp32 product "
+                         "peak_note": "algorithmic fp32 FLOP/s; the kernel is VALU/instruction-issue bound, not matrix-core bound "
+                                      "(ISA per 16-edge tile: ~800 VALU + 120 MFMA + ~80 LDS instructions with fp16x3; ~1060 + 240 + ~190 "
+                                      "with bf16x6, where SQ counters showed the issue port saturated and the MFMA pipe ~45 % busy); "
+                                      f"peak = 2500 TFLOP/s dense 16-bit MFMA / {SPLIT_PRODUCTS} products per fp32 product "
                                       "(the same kernel on exact fp32 MFMA, TRAJSDE_EDGE_FP32=1, ran at 110-113 TFLOP/s = 0.70-0.72 of the "
-                                      "157.3 TFLOP/s fp32 matrix peak)",
-                         "bf16_mfma_tflops": achieved * SPLIT_PRODUCTS * (40960.0 / 41700.0)},
+                                      "157.3 TFLOP/s fp32 matrix peak; bf16x6 ran at 142-188 TFLOP/s)",
+                         "split_precision": SPLIT_NAME,
+                         "mfma_16bit_tflops": achieved * SPLIT_PRODUCTS * (40960.0 / 41700.0)},
         }
         if not args.no_cpu_baseline and world == 1:
             def gpu_fn(b_cpu, seed):
@@ -268,13 +272,13 @@ def main():
             fp32_path = os.environ.get("TRAJSDE_DECODE_FP32", "0") not in ("", "0")
             fpeak = 157.3 if fp32_path else PEAK_FP32_EQUIV_TFLOPS
             line["roofline_sde_step"] = {"kernel": "k_sde_step (one Euler-Maruyama step per launch, state in HBM; "
-                                                   + ("exact fp32 MFMA)" if fp32_path else "bf16x6 split-precision MFMA, fp32-accurate)"),
+                                                   + ("exact fp32 MFMA)" if fp32_path else f"{SPLIT_NAME} split-precision MFMA, fp32-accurate)"),
                                          "rows": rows, "avg_launch_ms": sms, "bound": "mfma",
                                          "hbm_view": {"achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                                                       "bytes_per_path_step": 512},
                                          "flop_view": {"achieved": tfl, "peak": fpeak, "unit": "TFLOP/s", "frac": tfl / fpeak,
                                                        "flop_per_path_step": 41.8e3},
-                                         "note": "82 FLOP/B against a ridge of ~20 FLOP/B (fp32 matrix peak) .. ~52 (bf16x6): compute-bound at "
+                                         "note": "82 FLOP/B against a ridge of ~20 FLOP/B (fp32 matrix peak) .. ~52-104 (split precision): compute-bound at "
                                                  "fp32 accuracy, so the HBM fraction is low by construction; the fused decoder never writes "
                                                  "the state at all"}
         except Exception as e:

@@ -34,6 +34,9 @@ typedef enum {
 
 const char* trajsde_last_error(void);
 int trajsde_abi_version(void);
+/* matrix products per fp32 product of the split-precision kernels this library was built with:
+ * 3 = fp16x3 (default), 6 = bf16x6 (build with TRAJSDE_SPLIT=bf16x6); see csrc/tile.hpp */
+int trajsde_split_products(void);
 
 /* ---- weights ----------------------------------------------------------------------------------
  * Parameters stay owned by the Python modules (nn.Parameter).  Each stage hands the library an array

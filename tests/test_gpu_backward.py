@@ -234,7 +234,10 @@ def test_encoder_backward_matches_autograd(S, n, kw, diff_weight, dev):
         scale = float(want[k].abs().max())
         err = float((got[k].cpu().double() - want[k].double()).abs().max())
         zero_by_symmetry = k.endswith("lin_k.bias")            # a key bias shifts every logit of a target alike
-        if (err > 5e-5 or scale > 5e-5) if zero_by_symmetry else (err > REL * scale + 1e-7):
+        # the edge-embedding weight gradients are ill-conditioned: fp32 torch.autograd over the oracle is itself 2e-4 of
+        # the fp64 reference away on them (hence fp64 as the reference); allow twice that for the fp32 kernels
+        rel = 2 * REL if "_embed.module_list" in k else REL
+        if (err > 5e-5 or scale > 5e-5) if zero_by_symmetry else (err > rel * scale + 1e-7):
             bad.append((k, err, scale))
     assert not bad, bad
 

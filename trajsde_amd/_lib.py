@@ -42,6 +42,7 @@ _lib: Optional[C.CDLL] = None
 P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "trajsde_last_error": (C.c_char_p, []),
+    "trajsde_split_products": (C.c_int, []),
     "trajsde_abi_version": (C.c_int, []),
     "trajsde_param_count": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trajsde_param_name": (C.c_char_p, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -1,6 +1,7 @@
 """Build libtrajsde_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
     python -m trajsde_amd.build [--force]
+    TRAJSDE_SPLIT=bf16x6 python -m trajsde_amd.build --force     # three bf16 pieces / six products instead of fp16x3
 """
 import os
 import subprocess
@@ -11,6 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtrajsde_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# split-precision flavour of the matrix products (csrc/tile.hpp): fp16x3 (default) or the older bf16x6
+if os.environ.get("TRAJSDE_SPLIT", "fp16x3") == "bf16x6":
+    FLAGS.append("-DTSDE_SPLIT_H3=0")
 
 
 def sources():

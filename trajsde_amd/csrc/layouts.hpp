@@ -2,6 +2,9 @@
 // stage blobs.  Matrices are stored in MFMA fragment order [jo][q][lane][4] (tile.hpp), vectors plainly.
 // The pack recipes in pack.hip fill exactly these offsets; the kernels read exactly these offsets.
 #pragma once
+#ifndef TSDE_SPLIT_H3
+#define TSDE_SPLIT_H3 1   // 1: fp16x3 split precision, 0: bf16x6 (three exact bf16 pieces, six products)
+#endif
 
 namespace tsde {
 
@@ -39,7 +42,11 @@ struct EdgeL {
 
 // the same two images with the matrices as three bf16 planes (bf16x6 split precision, tile.hpp): a 64x64
 // matrix takes 3 * 4096 * 2 B = 6144 floats
+#if TSDE_SPLIT_H3
+constexpr int MAT64X6 = 4096;   // two fp16 planes
+#else
 constexpr int MAT64X6 = 6144;
+#endif
 struct EdgeL6 {
   enum : int {
     S_END = 0,

@@ -69,14 +69,15 @@ __device__ __forceinline__ void k_pack_matT(int i, const float* __restrict__ src
   dst[i] = col_t < rows_valid ? src[int64_t(col_t) * ld + col0 + row_t] : 0.f;      // rows of W beyond rows_valid read as 0
 }
 
-// bf16x6 planes: dst (as bf16) [plane][jo][s][lane][8]; element j of lane (i,g) in k-step s is the plane-th exact
-// truncation piece of W[16jo + i][col0 + 32s + 16(j>>2) + 4g + (j&3)]   (tile.hpp linear_acc_x6)
-__device__ __forceinline__ void k_pack_mat6(int i, const float* __restrict__ src, unsigned short* __restrict__ dst, int jto, int ks,
-                                            int ld, int col0) {
-  const int per_plane = jto * ks * 512;
-  if (i >= per_plane) return;
-  const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % ks, jo = (i >> 9) / ks;
-  const float x = src[(16 * jo + (lane & 15)) * ld + col0 + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)];
+// the split-precision pieces of one weight element (tile.hpp): fp16x3 = two fp16 planes, round to nearest (the
+// second piece then carries the signed remainder); bf16x6 = three exact bf16 truncation pieces
+__device__ __forceinline__ void store_split(float x, unsigned short* __restrict__ dst, int i, int per_plane) {
+#if TSDE_SPLIT_H3
+  const _Float16 h = _Float16(x);
+  const _Float16 l = _Float16(x - float(h));
+  dst[i] = __builtin_bit_cast(unsigned short, h);
+  dst[per_plane + i] = __builtin_bit_cast(unsigned short, l);
+#else
   const unsigned M = 0xFFFF0000u;
   const float h = __uint_as_float(__float_as_uint(x) & M);
   const float r = x - h;
@@ -85,6 +86,18 @@ __device__ __forceinline__ void k_pack_mat6(int i, const float* __restrict__ src
   dst[i] = (unsigned short)(__float_as_uint(h) >> 16);
   dst[per_plane + i] = (unsigned short)(__float_as_uint(m) >> 16);
   dst[2 * per_plane + i] = (unsigned short)(__float_as_uint(l) >> 16);
+#endif
+}
+
+// bf16x6 planes: dst (as bf16) [plane][jo][s][lane][8]; element j of lane (i,g) in k-step s is the plane-th exact
+// truncation piece of W[16jo + i][col0 + 32s + 16(j>>2) + 4g + (j&3)]   (tile.hpp linear_acc_x6)
+__device__ __forceinline__ void k_pack_mat6(int i, const float* __restrict__ src, unsigned short* __restrict__ dst, int jto, int ks,
+                                            int ld, int col0) {
+  const int per_plane = jto * ks * 512;
+  if (i >= per_plane) return;
+  const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % ks, jo = (i >> 9) / ks;
+  const float x = src[(16 * jo + (lane & 15)) * ld + col0 + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)];
+  store_split(x, dst, i, per_plane);
 }
 
 // lin_k | lin_v as ONE 128-row split-precision matrix: planes are [plane][jo 0..7][s][lane][8]
@@ -95,14 +108,7 @@ __device__ __forceinline__ void k_pack_mat6_stack2(int i, const float* __restric
   const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % 2, jo = (i >> 9) / 2;
   const float* src = jo < 4 ? wk : wv;
   const float x = src[(16 * (jo & 3) + (lane & 15)) * 64 + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)];
-  const unsigned M = 0xFFFF0000u;
-  const float h = __uint_as_float(__float_as_uint(x) & M);
-  const float r = x - h;
-  const float m = __uint_as_float(__float_as_uint(r) & M);
-  const float l = r - m;
-  dst[i] = (unsigned short)(__float_as_uint(h) >> 16);
-  dst[per_plane + i] = (unsigned short)(__float_as_uint(m) >> 16);
-  dst[2 * per_plane + i] = (unsigned short)(__float_as_uint(l) >> 16);
+  store_split(x, dst, i, per_plane);
 }
 
 // one thread per element; blockIdx.y = job
@@ -779,6 +785,7 @@ int64_t trajsde_profile_report(char* buf, int64_t cap) {
 }
 
 const char* trajsde_last_error(void) { return last_error_ref().c_str(); }
+int trajsde_split_products(void) { return TSDE_SPLIT_H3 ? 3 : 6; }
 int trajsde_abi_version(void) { return 1; }
 
 int trajsde_param_count(int stage, int num_layers, int num_modes) {

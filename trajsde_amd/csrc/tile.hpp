@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "layouts.hpp"   // TSDE_SPLIT_H3
+
 namespace tsde {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -83,6 +85,90 @@ __device__ __forceinline__ void linear_acc(f4 (&acc)[JT_OUT], const f4 (&in)[JT_
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
+#if TSDE_SPLIT_H3
+// fp16x3: x = h + l with h = fp16(x) (round toward zero, v_cvt_pkrtz_f16_f32) and l = fp16(x - h): 22 significant bits,
+// the residual x - h is exact in fp32 and is formed by v_fma_mix_f32 straight from the packed half.  a*b ~= a_h b_h +
+// a_h b_l + a_l b_h (three v_mfma_f32_16x16x32_f16; the dropped a_l b_l is 2^-22 relative).  2 VALU per value to split
+// against 5.5 for three bf16 pieces, and half the matrix instructions.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const hp2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  float r0, r1;                                                                    // x - h, exact
+  const unsigned hb = __builtin_bit_cast(unsigned, h);
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
+  const hp2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+  hi = hb;
+  lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void split_kstep(const f4& qa, const f4& qb, u4& hi, u4& lo) {
+  unsigned h[4], l[4];
+  split_pair(qa[0], qa[1], h[0], l[0]);
+  split_pair(qa[2], qa[3], h[1], l[1]);
+  split_pair(qb[0], qb[1], h[2], l[2]);
+  split_pair(qb[2], qb[3], h[3], l[3]);
+  hi = u4{h[0], h[1], h[2], h[3]};
+  lo = u4{l[0], l[1], l[2], l[3]};
+}
+
+// acc[jo] += W * in with W stored as two fp16 planes in fragment order [plane][jo][s][lane][8] (pack.hip MAT6)
+template <int JT_OUT, int JT_IN>
+__device__ __forceinline__ void linear_acc_x6(f4 (&acc)[JT_OUT], const f4 (&in)[JT_IN], const float* w, int lane) {
+  static_assert(JT_IN % 2 == 0, "k-steps cover 32 features");
+  constexpr int KS = JT_IN / 2;
+  constexpr int PLANE = JT_OUT * KS * 256;                       // floats per plane
+  u4 b1[KS], b2[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) split_kstep(in[2 * s], in[2 * s + 1], b1[s], b2[s]);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+#pragma unroll
+    for (int jo = 0; jo < JT_OUT; ++jo) {
+      const float* p = w + (jo * KS + s) * 256 + lane * 4;
+      const h8 a1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p));
+      const h8 a2 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p + PLANE));
+      const h8 x1 = __builtin_bit_cast(h8, b1[s]), x2 = __builtin_bit_cast(h8, b2[s]);
+      acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1, acc[jo], 0, 0, 0);
+      acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x2, acc[jo], 0, 0, 0);
+      acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, x1, acc[jo], 0, 0, 0);
+    }
+  }
+}
+
+// the same contraction for TWO row tiles of the wave at once (weight fragments read from LDS once)
+template <int JT_OUT, int JT_IN>
+__device__ __forceinline__ void linear_acc_x6_2(f4 (&acc0)[JT_OUT], f4 (&acc1)[JT_OUT], const f4 (&in0)[JT_IN], const f4 (&in1)[JT_IN],
+                                                const float* w, int lane) {
+  static_assert(JT_IN % 2 == 0, "k-steps cover 32 features");
+  constexpr int KS = JT_IN / 2;
+  constexpr int PLANE = JT_OUT * KS * 256;
+  u4 p1[KS], p2[KS], q1[KS], q2[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    split_kstep(in0[2 * s], in0[2 * s + 1], p1[s], p2[s]);
+    split_kstep(in1[2 * s], in1[2 * s + 1], q1[s], q2[s]);
+  }
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+#pragma unroll
+    for (int jo = 0; jo < JT_OUT; ++jo) {
+      const float* p = w + (jo * KS + s) * 256 + lane * 4;
+      const h8 a1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p));
+      const h8 a2 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p + PLANE));
+      const h8 x1 = __builtin_bit_cast(h8, p1[s]), x2 = __builtin_bit_cast(h8, p2[s]);
+      const h8 y1 = __builtin_bit_cast(h8, q1[s]), y2 = __builtin_bit_cast(h8, q2[s]);
+      acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1, acc0[jo], 0, 0, 0);
+      acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, y1, acc1[jo], 0, 0, 0);
+      acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x2, acc0[jo], 0, 0, 0);
+      acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, y2, acc1[jo], 0, 0, 0);
+      acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, x1, acc0[jo], 0, 0, 0);
+      acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, y1, acc1[jo], 0, 0, 0);
+    }
+  }
+}
+#else
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
   const unsigned M = 0xFFFF0000u;
   const float h0 = __uint_as_float(__float_as_uint(x0) & M), h1 = __uint_as_float(__float_as_uint(x1) & M);
@@ -177,6 +263,8 @@ __device__ __forceinline__ void linear_acc_x6_2(f4 (&acc0)[JT_OUT], f4 (&acc1)[J
     }
   }
 }
+
+#endif   // TSDE_SPLIT_H3
 
 // per-feature vector (bias, LayerNorm gamma/beta, ...) stored plainly: v[16*jt + 4*g + c]
 template <int JT>
