@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restri
                                                          const float* __restrict__ v, int64_t R, float* __restrict__ agg, int heads) {
   const int lane = threadIdx.x & 63;
   const int head = heads == 4 ? lane >> 4 : lane >> 3, slot = heads == 4 ? head : 4 * (head & 1) + (head >> 1);
-  const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // the wave index is uniform: saying so keeps the segment bounds, the edge index and every row address in SGPRs
+  const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (node >= R) return;
   const int beg = segptr[node], end = segptr[node + 1];
   float m = -INFINITY, s = 0.f, acc = 0.f;
@@ -256,8 +257,10 @@ __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restri
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u < end ? e0 + u : end - 1;
-      p[u] = logits[int64_t(e) * 8 + slot];
-      vv[u] = v[int64_t(e) * 64 + lane];
+      const float* lrow = logits + int64_t(e) * 8;
+      const float* vrow = v + int64_t(e) * 64;
+      p[u] = lrow[slot];
+      vv[u] = vrow[lane];
     }
     float cm = -INFINITY;
 #pragma unroll
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
   constexpr int NV = SL / 4;               // ... as float4s
   constexpr float INV = HEADS == 4 ? 0.25f : INV_SQRT_DH;
   __shared__ __attribute__((aligned(16))) float sbuf[4][HEADS][64 + 4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: addresses in SGPRs
   const int h = lane / LPH, j = lane % LPH;
   const int64_t node = int64_t(blockIdx.x) * 4 + wv;
   const int64_t nc = node < N ? node : N - 1;
@@ -326,14 +329,20 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
   for (int e0 = beg; e0 < end; e0 += 8) {
     f4 r[8][NV];
     float knv[8], vnv[8], lg[8];
+    // the chunk's 8 source indices in one coalesced load, handed out as scalars: every row address below is an SGPR
+    // base plus a per-lane constant offset, so the loop spends no VALU cycles on address arithmetic
+    const int sv = src[e0 + (lane & 7) < end ? e0 + (lane & 7) : end - 1];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u < end ? e0 + u : end - 1;
-      const int sidx = src[e];
+      const int sidx = __builtin_amdgcn_readlane(sv, u);
+      const float* rrow = rel + int64_t(e) * 64;
+      const float* krow = kn + int64_t(sidx) * 64;
+      const float* vrow = vn + int64_t(sidx) * 64;
 #pragma unroll
-      for (int v4 = 0; v4 < NV; ++v4) r[u][v4] = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + SL * j + 4 * v4);
-      knv[u] = kn[int64_t(sidx) * 64 + lane];
-      vnv[u] = vn[int64_t(sidx) * 64 + lane];
+      for (int v4 = 0; v4 < NV; ++v4) r[u][v4] = *reinterpret_cast<const f4*>(rrow + SL * j + 4 * v4);
+      knv[u] = krow[lane];
+      vnv[u] = vrow[lane];
     }
     float cm = -INFINITY;
 #pragma unroll

@@ -28,6 +28,25 @@ __device__ __forceinline__ void head_eval(float& o0, float& o1, const f4 (&s)[4]
   o1 = row_dot(h, img + HeadL::W3 + 64, L.g) + img[HeadL::B3 + 1];
 }
 
+#if TSDE_SPLIT_H3
+// both heads of the fused kernel on one split of s: stacked first layers (HeadPairL6), fp16x3 matrix products
+__device__ __forceinline__ void head_pair_eval(float& lx, float& ly, float& sx, float& sy, const f4 (&s)[4], const float* img,
+                                               const Lane& L) {
+  using HP = HeadPairL6;
+  f4 h[8];
+  linear_x6<8, 4>(h, s, img + HP::W0, img + HP::B0, L);
+  f4 a[4] = {h[0], h[1], h[2], h[3]}, b[4] = {h[4], h[5], h[6], h[7]};
+  layer_norm<4>(a, img + HP::G_LOC, img + HP::E_LOC, L.g);
+  relu<4>(a);
+  lx = row_dot(a, img + HP::W3_LOC, L.g) + img[HP::B3_LOC];
+  ly = row_dot(a, img + HP::W3_LOC + 64, L.g) + img[HP::B3_LOC + 1];
+  layer_norm<4>(b, img + HP::G_SC, img + HP::E_SC, L.g);
+  relu<4>(b);
+  sx = row_dot(b, img + HP::W3_SC, L.g) + img[HP::B3_SC];
+  sy = row_dot(b, img + HP::W3_SC + 64, L.g) + img[HP::B3_SC + 1];
+}
+#endif
+
 __global__ __launch_bounds__(1024) void k_dec_init(const float* __restrict__ blob, const float* __restrict__ local,
                                                    const float* __restrict__ global, int N, int K,
                                                    float* __restrict__ y0, float* __restrict__ pi) {
@@ -103,8 +122,14 @@ __global__ __launch_bounds__(MAXT) void k_sde_decode(const float* __restrict__ b
 #pragma unroll
           for (int c = 0; c < 4; ++c) s[jt][c] = w0 * prev[jt][c] + w1 * y[jt][c];
         float lx, ly, sx, sy;
-        head_eval(lx, ly, s, lds + DL::LOC, L);
-        head_eval(sx, sy, s, lds + DL::SCALE, L);
+#if TSDE_SPLIT_H3
+        if constexpr (X6) head_pair_eval(lx, ly, sx, sy, s, lds + DL::LOC, L);
+        else
+#endif
+        {
+          head_eval(lx, ly, s, lds + DL::LOC, L);
+          head_eval(sx, sy, s, lds + DL::SCALE, L);
+        }
         sx = (sx > 0.f ? sx : fast_exp(sx) - 1.0f) + 1.0f + min_scale;       // ELU(alpha=1) + 1 + min_scale (DEC:97-98)
         sy = (sy > 0.f ? sy : fast_exp(sy) - 1.0f) + 1.0f + min_scale;
         if (row < rows && L.g == 0) {

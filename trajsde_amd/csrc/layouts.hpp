@@ -171,6 +171,12 @@ struct EncGruL {
   };
 };
 
+// the 16 matrices of one recurrence iteration as split-precision images, for the register-resident cooperative kernel
+// (recur.hip): index m -> offset m * MAT64X6.  Vectors (biases, time columns, diffusion head) stay in EncSdeL / EncGruL.
+struct EncCoopL6 {
+  enum : int { F0 = 0, F2, F4, N0, N2, A0, A2, UH, RH, UX, RX, U2, R2, NX, NH, N2G, COUNT, SIZE = COUNT * MAT64X6 };
+};
+
 // encoder stage blob
 struct EncBlob {
   enum : int {
@@ -191,7 +197,8 @@ struct EncBlob {
     AA_FFN6 = AA_UPD6 + UpdL6::SIZE,
     AL_UPD6 = AA_FFN6 + FfnL6::SIZE,
     AL_FFN6 = AL_UPD6 + UpdL6::SIZE,
-    SIZE = AL_FFN6 + FfnL6::SIZE
+    COOP6 = AL_FFN6 + FfnL6::SIZE,
+    SIZE = COOP6 + EncCoopL6::SIZE
   };
 };
 
@@ -235,9 +242,26 @@ struct HeadL {   // Linear(64,64) LN ReLU Linear(64,2)   (DEC:50-61)
 struct DecSdeL {
   enum : int { F = 0, G = F + DriftL::SIZE, LOC = G + DiffL::SIZE, SCALE = LOC + HeadL::SIZE, SIZE = SCALE + HeadL::SIZE };
 };
-// fused decode kernel image: drift + diffusion in split precision, the two heads in plain fp32 (fits the 160 KB LDS)
+// the loc and scale heads of the fused decode kernel as ONE pair: their first layers stacked into a 128x64 split-
+// precision matrix (one split of the state feeds both), then each head's LayerNorm and Linear(64,2).  Only with fp16x3,
+// where the pair is as large as two fp32 heads; the bf16x6 planes would not fit the 160 KB LDS next to drift+diffusion.
+struct HeadPairL6 {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(W0, 2 * MAT64X6, S), TS_FIELD(B0, 128, W0),
+    TS_FIELD(G_LOC, 64, B0), TS_FIELD(E_LOC, 64, G_LOC), TS_FIELD(W3_LOC, 128, E_LOC), TS_FIELD(B3_LOC, 4, W3_LOC),
+    TS_FIELD(G_SC, 64, B3_LOC), TS_FIELD(E_SC, 64, G_SC), TS_FIELD(W3_SC, 128, E_SC), TS_FIELD(B3_SC, 4, W3_SC),
+    SIZE = B3_SC_END
+  };
+};
+// fused decode kernel image: drift + diffusion in split precision; the heads as HeadPairL6 at LOC (fp16x3) or as two
+// plain fp32 heads (bf16x6)
 struct DecSdeL6 {
+#if TSDE_SPLIT_H3
+  enum : int { F = 0, G = F + DriftL6::SIZE, LOC = G + DiffL6::SIZE, SIZE = LOC + HeadPairL6::SIZE };
+#else
   enum : int { F = 0, G = F + DriftL6::SIZE, LOC = G + DiffL6::SIZE, SCALE = LOC + HeadL::SIZE, SIZE = SCALE + HeadL::SIZE };
+#endif
 };
 static_assert(DecSdeL6::SIZE * 4 <= 160 * 1024, "split-precision decoder image must fit LDS");
 struct DecBlob {

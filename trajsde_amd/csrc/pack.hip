@@ -382,6 +382,26 @@ static void recipe_encoder(Packer& P) {
     P.lin("gru_unit.new_state_net.2", g + L::WN2, g + L::BN2);
   }
   P.vec("hidden", B::HIDDEN, 64);
+  {  // the same matrices once more as split-precision images for k_enc_recur_coop
+    using C = EncCoopL6;
+    auto at = [](int m) { return B::COOP6 + m * MAT64X6; };
+    P.mat6("lsde_func.f_func.net.0.weight", at(C::F0), 64, 64, 66, 0);
+    P.mat6("lsde_func.f_func.net.2.weight", at(C::F2), 64, 64, 64);
+    P.mat6("lsde_func.f_func.net.4.weight", at(C::F4), 64, 64, 64);
+    P.mat6("lsde_func.g_nus.net.0.weight", at(C::N0), 64, 64, 66, 0);
+    P.mat6("lsde_func.g_nus.net.2.weight", at(C::N2), 64, 64, 64);
+    P.mat6("lsde_func.g_argo.net.0.weight", at(C::A0), 64, 64, 66, 0);
+    P.mat6("lsde_func.g_argo.net.2.weight", at(C::A2), 64, 64, 64);
+    P.mat6("gru_unit.update_gate.0.weight", at(C::UH), 64, 64, 128, 0);
+    P.mat6("gru_unit.reset_gate.0.weight", at(C::RH), 64, 64, 128, 0);
+    P.mat6("gru_unit.update_gate.0.weight", at(C::UX), 64, 64, 128, 64);
+    P.mat6("gru_unit.reset_gate.0.weight", at(C::RX), 64, 64, 128, 64);
+    P.mat6("gru_unit.update_gate.2.weight", at(C::U2), 64, 64, 64);
+    P.mat6("gru_unit.reset_gate.2.weight", at(C::R2), 64, 64, 64);
+    P.mat6("gru_unit.new_state_net.0.weight", at(C::NX), 64, 64, 128, 0);
+    P.mat6("gru_unit.new_state_net.0.weight", at(C::NH), 64, 64, 128, 64);
+    P.mat6("gru_unit.new_state_net.2.weight", at(C::N2G), 64, 64, 64);
+  }
 }
 
 // vanilla LocalEncoder (GENC:52-93): AA / AL as above + TemporalEncoder with `nl` layers
@@ -497,8 +517,22 @@ static void recipe_decoder(Packer& P) {
   recipe_head(P, "scale", DecBlob::SDE + DecSdeL::SCALE);
   recipe_drift6(P, "lsde_func.f_func", DecBlob::SDE6 + DecSdeL6::F);
   recipe_diff6(P, "lsde_func.g_func", DecBlob::SDE6 + DecSdeL6::G);
+#if TSDE_SPLIT_H3
+  {
+    using HP = HeadPairL6;
+    const int h = DecBlob::SDE6 + DecSdeL6::LOC;
+    pack_kv6(P, "decoder.0", "scale.0", h + HP::W0, h + HP::B0);      // stacked first layers + both biases
+    P.ln("decoder.1", h + HP::G_LOC, h + HP::E_LOC);
+    P.vec("decoder.3.weight", h + HP::W3_LOC, 128);
+    P.vec("decoder.3.bias", h + HP::B3_LOC, 2);
+    P.ln("scale.1", h + HP::G_SC, h + HP::E_SC);
+    P.vec("scale.3.weight", h + HP::W3_SC, 128);
+    P.vec("scale.3.bias", h + HP::B3_SC, 2);
+  }
+#else
   recipe_head(P, "decoder", DecBlob::SDE6 + DecSdeL6::LOC);
   recipe_head(P, "scale", DecBlob::SDE6 + DecSdeL6::SCALE);
+#endif
 }
 
 static void recipe_aggr_embed_bwd(Packer& P, int b) {      // aggr_embed of either decoder: forward halves + transposes

@@ -115,9 +115,45 @@ __global__ __launch_bounds__(512) void k_enc_gru_step(const float* __restrict__ 
 //     re-staging, no weight traffic after the prologue;
 //   * activations are exchanged between the four waves through LDS (one 16x64 tile per layer, 7 barriers per step);
 //     the hidden state never leaves LDS between steps; elementwise work (tanh, Philox, gates) is split four ways too;
-//   * the matrix fragments are the plain fp32 fragment order of the stage blob: wave w simply reads slice jo = w.
+//   * fp16x3 build: the matrices come from the EncCoopL6 image (two fp16 planes per matrix, tile.hpp), a wave's slice is
+//     still 16 VGPRs per matrix, and a 64-k product is 6 dependent v_mfma_f32_16x16x32_f16 instead of 16 dependent
+//     v_mfma_f32_16x16x4_f32 -- the recurrence is one wave per SIMD, so the length of that chain is what a step costs;
+//     an activation tile is split into its two fp16 pieces once per wave after it is read from LDS (Opnd);
+//   * bf16x6 build: plain fp32 fragments of the stage blob (three planes would not fit the register file).
 // (COOP_TMAX, COOP_RS, COOP_TILE and StepTab are declared in kernels.hpp)
 
+#if TSDE_SPLIT_H3
+struct WSlice {   // one wave's 16 output rows of a 64x64 matrix: [plane][k-step] fp16x8 A fragments
+  u4 p[2][2];
+};
+__device__ __forceinline__ WSlice load_slice(const float* mat6, int jo, int lane) {
+  WSlice s;
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) s.p[pl][ks] = *reinterpret_cast<const u4*>(mat6 + pl * 2048 + (jo * 2 + ks) * 256 + lane * 4);
+  return s;
+}
+struct Opnd {     // a 16x64 activation tile as B operands: [k-step] fp16x8 high and low pieces
+  u4 hi[2], lo[2];
+};
+__device__ __forceinline__ Opnd make_opnd(const f4 (&in)[4]) {
+  Opnd o;
+  split_kstep(in[0], in[1], o.hi[0], o.lo[0]);
+  split_kstep(in[2], in[3], o.hi[1], o.lo[1]);
+  return o;
+}
+__device__ __forceinline__ void slice_mma(f4& acc, const WSlice& w, const Opnd& x) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const h8 a1 = __builtin_bit_cast(h8, w.p[0][ks]), a2 = __builtin_bit_cast(h8, w.p[1][ks]);
+    const h8 x1 = __builtin_bit_cast(h8, x.hi[ks]), x2 = __builtin_bit_cast(h8, x.lo[ks]);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, x1, acc, 0, 0, 0);
+  }
+}
+#else
 struct WSlice {   // one wave's 16 output rows of a 64x64 matrix: 4 k-chunks of A fragments
   f4 q[4];
 };
@@ -127,12 +163,17 @@ __device__ __forceinline__ WSlice load_slice(const float* mat_frag, int jo, int 
   for (int q = 0; q < 4; ++q) s.q[q] = *reinterpret_cast<const f4*>(mat_frag + ((jo * 4 + q) * 64 + lane) * 4);
   return s;
 }
-__device__ __forceinline__ void slice_mma(f4& acc, const WSlice& w, const f4 (&in)[4]) {
+struct Opnd {
+  f4 q[4];
+};
+__device__ __forceinline__ Opnd make_opnd(const f4 (&in)[4]) { return Opnd{{in[0], in[1], in[2], in[3]}}; }
+__device__ __forceinline__ void slice_mma(f4& acc, const WSlice& w, const Opnd& x) {
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.q[q][c], in[q][c], acc, 0, 0, 0);
+    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.q[q][c], x.q[q][c], acc, 0, 0, 0);
 }
+#endif
 // full 16x64 activation tile from LDS as B operands / one wave's 16-feature slice to LDS
 __device__ __forceinline__ void lds_read_tile(f4 (&in)[4], const float* tile, const Lane& L) {
 #pragma unroll
@@ -146,7 +187,7 @@ __device__ __forceinline__ f4 tanh4(f4 a) { return f4{fast_tanh(a[0]), fast_tanh
 __device__ __forceinline__ f4 sigm4(f4 a) { return f4{fast_sigmoid(a[0]), fast_sigmoid(a[1]), fast_sigmoid(a[2]), fast_sigmoid(a[3])}; }
 
 __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict__ sde_img, const float* __restrict__ gru_img,
-                                                        const float* __restrict__ h0, const float* __restrict__ aa_out,
+                                                        const float* __restrict__ coop6, const float* __restrict__ h0, const float* __restrict__ aa_out,
                                                         int Nt, int N, int H, int TT, int tiles_per_wg, StepTab tab, int noise_step0,
                                                         NoiseArg na, const uint8_t* __restrict__ nus,
                                                         const uint8_t* __restrict__ pad, const int32_t* __restrict__ orig,
@@ -172,15 +213,23 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
   const float* F = sde_img + EncSdeL::F;
   const float* GN = sde_img + EncSdeL::GN;
   const float* GA = sde_img + EncSdeL::GA;
+  using G = EncGruL;
+#if TSDE_SPLIT_H3
+  using C6 = EncCoopL6;
+  auto sl = [&](int m) { return load_slice(coop6 + m * MAT64X6, w, L.lane); };
+  const WSlice wf0 = sl(C6::F0), wf2 = sl(C6::F2), wf4 = sl(C6::F4), wn0 = sl(C6::N0), wn2 = sl(C6::N2), wa0 = sl(C6::A0), wa2 = sl(C6::A2);
+  const WSlice wuh = sl(C6::UH), wrh = sl(C6::RH), wux = sl(C6::UX), wrx = sl(C6::RX), wu2 = sl(C6::U2), wr2 = sl(C6::R2);
+  const WSlice wnx = sl(C6::NX), wnh = sl(C6::NH), wn2g = sl(C6::N2G);
+#else
   const WSlice wf0 = load_slice(F + DriftL::W0, w, L.lane), wf2 = load_slice(F + DriftL::W2, w, L.lane), wf4 = load_slice(F + DriftL::W4, w, L.lane);
   const WSlice wn0 = load_slice(GN + DiffL::W0, w, L.lane), wn2 = load_slice(GN + DiffL::W2, w, L.lane);
   const WSlice wa0 = load_slice(GA + DiffL::W0, w, L.lane), wa2 = load_slice(GA + DiffL::W2, w, L.lane);
-  using G = EncGruL;
   const WSlice wuh = load_slice(gru_img + G::WUR_H, w, L.lane), wrh = load_slice(gru_img + G::WUR_H, 4 + w, L.lane);
   const WSlice wux = load_slice(gru_img + G::WUR_X, w, L.lane), wrx = load_slice(gru_img + G::WUR_X, 4 + w, L.lane);
   const WSlice wu2 = load_slice(gru_img + G::WU2, w, L.lane), wr2 = load_slice(gru_img + G::WR2, w, L.lane);
   const WSlice wnx = load_slice(gru_img + G::WN_X, w, L.lane), wnh = load_slice(gru_img + G::WN_H, w, L.lane);
   const WSlice wn2g = load_slice(gru_img + G::WN2, w, L.lane);
+#endif
 
   // ---- per-tile row bookkeeping and the initial state
   int64_t rowk[COOP_TMAX];
@@ -211,14 +260,16 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
     const f4 bf0 = vec_slice(F + DriftL::B0, w, L.g) + vec_slice(F + DriftL::WS, w, L.g) * sn + vec_slice(F + DriftL::WC, w, L.g) * cs;
     const f4 bn0 = vec_slice(GN + DiffL::B0, w, L.g) + vec_slice(GN + DiffL::WS, w, L.g) * sn + vec_slice(GN + DiffL::WC, w, L.g) * cs;
     const f4 ba0 = vec_slice(GA + DiffL::B0, w, L.g) + vec_slice(GA + DiffL::WS, w, L.g) * sn + vec_slice(GA + DiffL::WC, w, L.g) * cs;
-    f4 xin[COOP_TMAX][4];
+    Opnd xin[COOP_TMAX];
     // ---- P1: first layers of f and g
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 y[4];
-        lds_read_tile(y, Yb(k), L);
-        load_row(xin[k], aa_out + int64_t(t) * Nt * 64, rowk[k], L.g);           // x_t rows for the GRU, in flight early
+        f4 yf[4], xf[4];
+        lds_read_tile(yf, Yb(k), L);
+        load_row(xf, aa_out + int64_t(t) * Nt * 64, rowk[k], L.g);               // x_t rows for the GRU, in flight early
+        const Opnd y = make_opnd(yf);
+        xin[k] = make_opnd(xf);
         f4 a = bf0;
         slice_mma(a, wf0, y);
         lds_write_slice(Ab(k), tanh4(a), w, L);
@@ -238,9 +289,10 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 f1[4], g1[4];
-        lds_read_tile(f1, Ab(k), L);
-        lds_read_tile(g1, Bb(k), L);
+        f4 f1f[4], g1f[4];
+        lds_read_tile(f1f, Ab(k), L);
+        lds_read_tile(g1f, Bb(k), L);
+        const Opnd f1 = make_opnd(f1f), g1 = make_opnd(g1f);
         f4 a = vec_slice(F + DriftL::B2, w, L.g);
         slice_mma(a, wf2, f1);
         lds_write_slice(Cb(k), tanh4(a), w, L);
@@ -266,8 +318,9 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 f2[4];
-        lds_read_tile(f2, Cb(k), L);
+        f4 f2f[4];
+        lds_read_tile(f2f, Cb(k), L);
+        const Opnd f2 = make_opnd(f2f);
         f4 f = vec_slice(F + DriftL::B4, w, L.g);
         slice_mma(f, wf4, f2);
         const float b4 = is_nus[k] ? GN[DiffL::B4] : GA[DiffL::B4];
@@ -289,8 +342,9 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 hp[4];
-        lds_read_tile(hp, Yb(k), L);
+        f4 hpf[4];
+        lds_read_tile(hpf, Yb(k), L);
+        const Opnd hp = make_opnd(hpf);
         f4 u1 = vec_slice(gru_img + G::BUR, w, L.g), r1 = vec_slice(gru_img + G::BUR + 64, w, L.g);
         slice_mma(u1, wuh, hp);
         slice_mma(u1, wux, xin[k]);
@@ -305,9 +359,10 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 u1[4], r1[4];
-        lds_read_tile(u1, Ab(k), L);
-        lds_read_tile(r1, Bb(k), L);
+        f4 u1f[4], r1f[4];
+        lds_read_tile(u1f, Ab(k), L);
+        lds_read_tile(r1f, Bb(k), L);
+        const Opnd u1 = make_opnd(u1f), r1 = make_opnd(r1f);
         f4 u = vec_slice(gru_img + G::BU2, w, L.g), r = vec_slice(gru_img + G::BR2, w, L.g);
         slice_mma(u, wu2, u1);
         slice_mma(r, wr2, r1);
@@ -320,8 +375,9 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 rh[4];
-        lds_read_tile(rh, Cb(k), L);
+        f4 rhf[4];
+        lds_read_tile(rhf, Cb(k), L);
+        const Opnd rh = make_opnd(rhf);
         f4 n1 = vec_slice(gru_img + G::BN0, w, L.g);
         slice_mma(n1, wnx, xin[k]);
         slice_mma(n1, wnh, rh);
@@ -332,8 +388,9 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 n1[4];
-        lds_read_tile(n1, Ab(k), L);
+        f4 n1f[4];
+        lds_read_tile(n1f, Ab(k), L);
+        const Opnd n1 = make_opnd(n1f);
         f4 nw = vec_slice(gru_img + G::BN2, w, L.g);
         slice_mma(nw, wn2g, n1);
         f4 hs = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);

@@ -142,7 +142,7 @@ static int run_recurrence(const trajsde_batch* b, const trajsde_graph* g, const 
     }
     const int grid = int((rtiles + tiles_per_wg - 1) / tiles_per_wg);
     const int lds = (4 * tiles_per_wg * COOP_TILE + tiles_per_wg * 64) * 4;
-    TS_LAUNCH(k_enc_recur_coop, grid, 256, lds, st, blob + EncBlob::SDE, blob + EncBlob::GRU, h0, aa_out, Nt, N, H, b->TT, tiles_per_wg, tab,
+    TS_LAUNCH(k_enc_recur_coop, grid, 256, lds, st, blob + EncBlob::SDE, blob + EncBlob::GRU, blob + EncBlob::COOP6, h0, aa_out, Nt, N, H, b->TT, tiles_per_wg, tab,
               noise_step0, na, g->nus_mask, b->padding_mask, g->orig, g->eos_idx, g->pick_slot, kept, diff_pick, latent_ys);
     return TRAJSDE_OK;
   }
