@@ -330,7 +330,7 @@ __global__ __launch_bounds__(128) void k_sde_bwd(const float* __restrict__ img, 
       f4 dyn[4];                                          // dL/dy_k being assembled
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) dyn[jt] = dy[jt] + dprev[jt];
-      linear_acc<4, 4>(dyn, d, lds + SweepL::F_W0T, L.lane);
+      linear_adj<4, 4>(dyn, d, lds + SweepL::F_W0T, L);
       // ---- diffusion net: y' gets g * (z sqrt(h)), g one scalar per row
       f4 z[4];
       noise_row(z, na, STREAM_DECODER, k, r, int64_t(N) * K, L.g);
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(128) void k_sde_bwd(const float* __restrict__ img, 
 #pragma unroll
         for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - a[jt][c] * a[jt][c]);
       if (live) store_row(d, DG1 + k * slab, row, L.g);
-      linear_acc<4, 4>(dyn, d, lds + SweepL::G_W0T, L.lane);
+      linear_adj<4, 4>(dyn, d, lds + SweepL::G_W0T, L);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) dy[jt] = dyn[jt];
     }

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(512) void k_edge_kv_bwd(const float* __restrict__ i
       }
     load_row(dv, DV, ec, L.g);
     linear_t(de, dk, lds + EdgeKvBwdL::WKT, L);
-    linear_acc<4, 4>(de, dv, lds + EdgeKvBwdL::WVT, L.lane);
+    linear_adj<4, 4>(de, dv, lds + EdgeKvBwdL::WVT, L);
     if (e < E) {
       store_row(emb, EMB, e, L.g);
       store_row(dk, DK, e, L.g);
@@ -406,10 +406,10 @@ __global__ __launch_bounds__(256) void k_enc_gru_bwd(const float* __restrict__ i
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
       for (int c = 0; c < 4; ++c) dr1[jt][c] *= (1.0f - a[jt][c] * a[jt][c]);
-    linear_acc<4, 4>(dho, du1, lds + G::UHT, L.lane);
-    linear_acc<4, 4>(dho, dr1, lds + G::RHT, L.lane);
-    linear_acc<4, 4>(dx, du1, lds + G::UXT, L.lane);
-    linear_acc<4, 4>(dx, dr1, lds + G::RXT, L.lane);
+    linear_adj<4, 4>(dho, du1, lds + G::UHT, L);
+    linear_adj<4, 4>(dho, dr1, lds + G::RHT, L);
+    linear_adj<4, 4>(dx, du1, lds + G::UXT, L);
+    linear_adj<4, 4>(dx, dr1, lds + G::RXT, L);
     if (row < Nt) {
       store_row(du1, DU1, off + row, L.g);
       store_row(dr1, DR1, off + row, L.g);
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void k_enc_sde_bwd(const float* __restrict__ i
     if (live) store_row(d, DH1, off + row, L.g);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) dyn[jt] = dy[jt];
-    linear_acc<4, 4>(dyn, d, lds + S::F_W0T, L.lane);
+    linear_adj<4, 4>(dyn, d, lds + S::F_W0T, L);
     // diffusion: g (z sqrt h) with g one scalar per row, from the row's source net
     f4 z[4];
     noise_row(z, na, STREAM_ENCODER, idx, r, Nt, L.g);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void k_enc_sde_bwd(const float* __restrict__ i
 #pragma unroll
         for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - g1[jt][c] * g1[jt][c]);
       if (live) store_row(d, net == 0 ? DG1N : DG1A, off + row, L.g);
-      linear_acc<4, 4>(dyn, d, lds + (net == 0 ? S::GN_W0T : S::GA_W0T), L.lane);
+      linear_adj<4, 4>(dyn, d, lds + (net == 0 ? S::GN_W0T : S::GA_W0T), L);
     }
     if (live) store_row(dyn, dh_out, row, L.g);
   }

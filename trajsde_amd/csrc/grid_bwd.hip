@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_mlp_heads_bwd(const float* __restrict__
     }
     f4 dh[4];
     zero4(dh);
-    linear_acc<4, 8>(dh, dl, lds + M::W3T, L.lane);
+    linear_adj<4, 8>(dh, dl, lds + M::W3T, L);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll

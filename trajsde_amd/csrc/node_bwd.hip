@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_a(const float* __restrict__ img
     load_row(n, dout, r, L.g);
 #pragma unroll
     for (int jt = 0; jt < 16; ++jt) dh[jt] = f4{0.f, 0.f, 0.f, 0.f};
-    linear_acc<16, 4>(dh, n, lds + FfnBwdAL::W2T, L.lane);
+    linear_adj<16, 4>(dh, n, lds + FfnBwdAL::W2T, L);
 #pragma unroll
     for (int jt = 0; jt < 16; ++jt)
 #pragma unroll
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_b(const float* __restrict__ img
     f4 dh[16], t[4], x[4];
     load_row256(dh, DH, r, L.g);
     zero4(t);
-    linear_acc<4, 16>(t, dh, lds + FfnBwdBL::W1T, L.lane);
+    linear_adj<4, 16>(t, dh, lds + FfnBwdBL::W1T, L);
     if (row >= R) zero4(t);
     load_row(x, x1, r, L.g);
     const float rstd = ln_normalize(x);
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(256) void k_upd_bwd(const float* __restrict__ img, 
         ds[jt][c] = t[jt][c] * gg;
         dgp[jt][c] = t[jt][c] * diff * gg * (1.0f - gg);
       }
-    linear_acc<4, 4>(dagg, dgp, lds + U::WIH_T, L.lane);
+    linear_adj<4, 4>(dagg, dgp, lds + U::WIH_T, L);
     linear_t(t, dgp, lds + U::WHH_T, L);
-    linear_acc<4, 4>(t, ds, lds + U::WSELF_T, L.lane);
+    linear_adj<4, 4>(t, ds, lds + U::WSELF_T, L);
     if (row < R) {
       store_row(upd, UPD, row, L.g);
       store_row(dgp, DGP, row, L.g);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_node_proj_bwd(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       load_row(d, dps[j], r, L.g);
-      linear_acc<4, 4>(t, d, lds + P::WT + j * MAT64, L.lane);
+      linear_adj<4, 4>(t, d, lds + P::WT + j * MAT64, L);
     }
     if (row >= R) zero4(t);
     load_row(xh, x, r, L.g);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_lin_t_acc(const float* __restrict__ wt,
     load_row(a, d, r, L.g);
     if (accumulate) load_row(t, out, r, L.g);
     else zero4(t);
-    linear_acc<4, 4>(t, a, lds, L.lane);
+    linear_adj<4, 4>(t, a, lds, L);
     if (row < R) store_row(t, out, row, L.g);
   }
 }

@@ -30,7 +30,7 @@ struct PackJob {
   const float *src, *src2;
   float* dst;
 };
-enum PackKind { PK_VEC = 0, PK_COL, PK_MAT, PK_MAT_PAD, PK_MATT, PK_MAT6, PK_MAT6_STACK2 };
+enum PackKind { PK_VEC = 0, PK_COL, PK_MAT, PK_MAT_PAD, PK_MATT, PK_MAT6, PK_MAT6_STACK2, PK_SPLIT };
 constexpr int PACK_JOBS_PER_LAUNCH = 64;        // 64 x 56 B: under the 4 KB kernel-argument limit
 struct PackJobs {
   PackJob j[PACK_JOBS_PER_LAUNCH];
@@ -71,25 +71,27 @@ __device__ __forceinline__ void k_pack_matT(int i, const float* __restrict__ src
 
 // the split-precision pieces of one weight element (tile.hpp): fp16x3 = two fp16 planes, round to nearest (the
 // second piece then carries the signed remainder); bf16x6 = three exact bf16 truncation pieces
-__device__ __forceinline__ void store_split(float x, unsigned short* __restrict__ dst, int i, int per_plane) {
+__device__ __forceinline__ void store_split(float x, unsigned short* __restrict__ dst, int i, int /*per_plane*/) {
+  // i = ((jo*ks + s)*64 + lane)*8 + j; the pieces of one (jo, s) block sit next to each other: [jo][s][piece][lane][8]
+  const int blk = i >> 9, within = i & 511;
 #if TSDE_SPLIT_H3
   const _Float16 h = _Float16(x);
   const _Float16 l = _Float16(x - float(h));
-  dst[i] = __builtin_bit_cast(unsigned short, h);
-  dst[per_plane + i] = __builtin_bit_cast(unsigned short, l);
+  dst[(blk * 2) * 512 + within] = __builtin_bit_cast(unsigned short, h);
+  dst[(blk * 2 + 1) * 512 + within] = __builtin_bit_cast(unsigned short, l);
 #else
   const unsigned M = 0xFFFF0000u;
   const float h = __uint_as_float(__float_as_uint(x) & M);
   const float r = x - h;
   const float m = __uint_as_float(__float_as_uint(r) & M);
   const float l = r - m;
-  dst[i] = (unsigned short)(__float_as_uint(h) >> 16);
-  dst[per_plane + i] = (unsigned short)(__float_as_uint(m) >> 16);
-  dst[2 * per_plane + i] = (unsigned short)(__float_as_uint(l) >> 16);
+  dst[(blk * 3) * 512 + within] = (unsigned short)(__float_as_uint(h) >> 16);
+  dst[(blk * 3 + 1) * 512 + within] = (unsigned short)(__float_as_uint(m) >> 16);
+  dst[(blk * 3 + 2) * 512 + within] = (unsigned short)(__float_as_uint(l) >> 16);
 #endif
 }
 
-// bf16x6 planes: dst (as bf16) [plane][jo][s][lane][8]; element j of lane (i,g) in k-step s is the plane-th exact
+// split-precision pieces: dst (16-bit) [jo][s][piece][lane][8]; element j of lane (i,g) in k-step s is the piece-th
 // truncation piece of W[16jo + i][col0 + 32s + 16(j>>2) + 4g + (j&3)]   (tile.hpp linear_acc_x6)
 __device__ __forceinline__ void k_pack_mat6(int i, const float* __restrict__ src, unsigned short* __restrict__ dst, int jto, int ks,
                                             int ld, int col0) {
@@ -97,6 +99,21 @@ __device__ __forceinline__ void k_pack_mat6(int i, const float* __restrict__ src
   if (i >= per_plane) return;
   const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % ks, jo = (i >> 9) / ks;
   const float x = src[(16 * jo + (lane & 15)) * ld + col0 + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)];
+  store_split(x, dst, i, per_plane);
+}
+
+// split-precision image of a (possibly transposed, possibly row-padded) matrix, the layout of k_pack_mat6:
+//   plain:      element [r][c] = W[r][col0 + c], rows >= rows_valid read as 0
+//   transposed: element [r][c] = W[c][col0 + r], rows of W >= rows_valid read as 0
+__device__ __forceinline__ void k_pack_split(int i, const float* __restrict__ src, unsigned short* __restrict__ dst, int jto, int ks,
+                                             int ld, int col0, int rows_valid, int transposed) {
+  const int per_plane = jto * ks * 512;
+  if (i >= per_plane) return;
+  const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % ks, jo = (i >> 9) / ks;
+  const int r = 16 * jo + (lane & 15), c = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+  float x;
+  if (transposed) x = c < rows_valid ? src[int64_t(c) * ld + col0 + r] : 0.f;
+  else x = r < rows_valid ? src[int64_t(r) * ld + col0 + c] : 0.f;
   store_split(x, dst, i, per_plane);
 }
 
@@ -124,6 +141,7 @@ __global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
     case PK_MATT: k_pack_matT(i, J.src, J.dst, J.p0, J.p1, J.p2, J.p3, J.p4); break;
     case PK_MAT6: k_pack_mat6(i, J.src, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1, J.p2, J.p3); break;
     case PK_MAT6_STACK2: k_pack_mat6_stack2(i, J.src, J.src2, reinterpret_cast<unsigned short*>(J.dst)); break;
+    case PK_SPLIT: k_pack_split(i, J.src, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1, J.p2, J.p3, J.p4 & 0x3FFFFFFF, J.p4 >> 30); break;
   }
 }
 
@@ -136,9 +154,19 @@ struct Packer {
   }
   // raw-pointer forms for recipes that slice a parameter themselves
   void vec_raw(const float* s, float* d, int count) { emit(PK_VEC, count, s, d, 0); }
-  void mat_raw(const float* s, float* d, int jto, int jti, int ld, int col0) { emit(PK_MAT, jto * jti * 256, s, d, jto, jti, ld, col0); }
+  // general matrix images: fp32 fragment order (bf16x6 build) or, in the fp16x3 build, split-precision planes of the
+  // same size (tile.hpp linear_acc); jti counts 16-column input tiles and is always even
+  void split_raw(const float* s, float* d, int jto, int jti, int ld, int col0, int rows_valid, bool transposed) {
+    const int rv = rows_valid > 0x3FFFFFFF ? 0x3FFFFFFF : rows_valid;
+    emit(PK_SPLIT, jto * (jti / 2) * 512, s, d, jto, jti / 2, ld, col0, rv | (transposed ? 1 << 30 : 0));
+  }
+  void mat_raw(const float* s, float* d, int jto, int jti, int ld, int col0) {
+    if (TSDE_SPLIT_H3) split_raw(s, d, jto, jti, ld, col0, 1 << 30, false);
+    else emit(PK_MAT, jto * jti * 256, s, d, jto, jti, ld, col0);
+  }
   void matT_raw(const float* s, float* d, int jto, int jti, int ld, int col0, int rows_valid) {
-    emit(PK_MATT, jto * jti * 256, s, d, jto, jti, ld, col0, rows_valid);
+    if (TSDE_SPLIT_H3) split_raw(s, d, jto, jti, ld, col0, rows_valid, true);
+    else emit(PK_MATT, jto * jti * 256, s, d, jto, jti, ld, col0, rows_valid);
   }
   void mat6_raw(const float* s, float* d, int jto, int ks, int ld, int col0) { emit(PK_MAT6, jto * ks * 512, s, d, jto, ks, ld, col0); }
   std::vector<std::string> names;          // dry: collected in order of first use
@@ -177,7 +205,8 @@ struct Packer {
   void mat_pad(const std::string& n, int dst, int jto, int jti, int ld, int rows_valid) {
     const float* s = src(n);
     if (dry) return;
-    emit(PK_MAT_PAD, jto * jti * 256, s, blob + dst, jto, jti, ld, rows_valid);
+    if (TSDE_SPLIT_H3) split_raw(s, blob + dst, jto, jti, ld, 0, rows_valid, false);
+    else emit(PK_MAT_PAD, jto * jti * 256, s, blob + dst, jto, jti, ld, rows_valid);
   }
   // transposed image of the [16*jti x 16*jto] block of W starting at column col0 (default: a 64x64 block)
   void matT(const std::string& n, int dst, int ld, int col0 = 0, int jto = 4, int jti = 4, int rows_valid = 1 << 30) {

@@ -131,7 +131,7 @@ __device__ __forceinline__ WSlice load_slice(const float* mat6, int jo, int lane
 #pragma unroll
   for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) s.p[pl][ks] = *reinterpret_cast<const u4*>(mat6 + pl * 2048 + (jo * 2 + ks) * 256 + lane * 4);
+    for (int ks = 0; ks < 2; ++ks) s.p[pl][ks] = *reinterpret_cast<const u4*>(mat6 + ((jo * 2 + ks) * 2 + pl) * 256 + lane * 4);
   return s;
 }
 struct Opnd {     // a 16x64 activation tile as B operands: [k-step] fp16x8 high and low pieces

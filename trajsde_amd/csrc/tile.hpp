@@ -35,9 +35,11 @@ struct Lane {
 };
 
 // ---------------------------------------------------------------- matrix-core linear layers
-// acc[jo] += W[16jo.., :] * in   for a weight stored in fragment order at `w` (LDS or global).
+// acc[jo] += W[16jo.., :] * in   for a weight stored in fp32 fragment order at `w` (LDS or global), exact fp32 MFMA.
+// (Used by the bf16x6 build; in the fp16x3 build every image is a split-precision image and `linear_acc` below
+// forwards to linear_acc_x6.)
 template <int JT_OUT, int JT_IN>
-__device__ __forceinline__ void linear_acc(f4 (&acc)[JT_OUT], const f4 (&in)[JT_IN], const float* w, int lane) {
+__device__ __forceinline__ void linear_acc_f32(f4 (&acc)[JT_OUT], const f4 (&in)[JT_IN], const float* w, int lane) {
 #ifdef TSDE_NO_PREFETCH
 #pragma unroll
   for (int q = 0; q < JT_IN; ++q) {
@@ -113,12 +115,12 @@ __device__ __forceinline__ void split_kstep(const f4& qa, const f4& qb, u4& hi, 
   lo = u4{l[0], l[1], l[2], l[3]};
 }
 
-// acc[jo] += W * in with W stored as two fp16 planes in fragment order [plane][jo][s][lane][8] (pack.hip MAT6)
+// acc[jo] += W * in with W stored as two fp16 pieces in fragment order [jo][s][piece][lane][8] (pack.hip MAT6);
+// jo-major like the fp32 images, so row blocks packed separately concatenate into one taller matrix
 template <int JT_OUT, int JT_IN>
 __device__ __forceinline__ void linear_acc_x6(f4 (&acc)[JT_OUT], const f4 (&in)[JT_IN], const float* w, int lane) {
   static_assert(JT_IN % 2 == 0, "k-steps cover 32 features");
   constexpr int KS = JT_IN / 2;
-  constexpr int PLANE = JT_OUT * KS * 256;                       // floats per plane
   u4 b1[KS], b2[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) split_kstep(in[2 * s], in[2 * s + 1], b1[s], b2[s]);
@@ -126,9 +128,9 @@ __device__ __forceinline__ void linear_acc_x6(f4 (&acc)[JT_OUT], const f4 (&in)[
   for (int s = 0; s < KS; ++s) {
 #pragma unroll
     for (int jo = 0; jo < JT_OUT; ++jo) {
-      const float* p = w + (jo * KS + s) * 256 + lane * 4;
+      const float* p = w + (jo * KS + s) * 512 + lane * 4;
       const h8 a1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p));
-      const h8 a2 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p + PLANE));
+      const h8 a2 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p + 256));
       const h8 x1 = __builtin_bit_cast(h8, b1[s]), x2 = __builtin_bit_cast(h8, b2[s]);
       acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1, acc[jo], 0, 0, 0);
       acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x2, acc[jo], 0, 0, 0);
@@ -143,7 +145,6 @@ __device__ __forceinline__ void linear_acc_x6_2(f4 (&acc0)[JT_OUT], f4 (&acc1)[J
                                                 const float* w, int lane) {
   static_assert(JT_IN % 2 == 0, "k-steps cover 32 features");
   constexpr int KS = JT_IN / 2;
-  constexpr int PLANE = JT_OUT * KS * 256;
   u4 p1[KS], p2[KS], q1[KS], q2[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
@@ -154,9 +155,9 @@ __device__ __forceinline__ void linear_acc_x6_2(f4 (&acc0)[JT_OUT], f4 (&acc1)[J
   for (int s = 0; s < KS; ++s) {
 #pragma unroll
     for (int jo = 0; jo < JT_OUT; ++jo) {
-      const float* p = w + (jo * KS + s) * 256 + lane * 4;
+      const float* p = w + (jo * KS + s) * 512 + lane * 4;
       const h8 a1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p));
-      const h8 a2 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p + PLANE));
+      const h8 a2 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p + 256));
       const h8 x1 = __builtin_bit_cast(h8, p1[s]), x2 = __builtin_bit_cast(h8, p2[s]);
       const h8 y1 = __builtin_bit_cast(h8, q1[s]), y2 = __builtin_bit_cast(h8, q2[s]);
       acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1, acc0[jo], 0, 0, 0);
@@ -192,12 +193,11 @@ __device__ __forceinline__ void split_kstep(const f4& qa, const f4& qb, u4& hi, 
   lo = u4{l[0], l[1], l[2], l[3]};
 }
 
-// acc[jo] += W * in with W stored as three bf16 planes in fragment order [plane][jo][s][lane][8] (pack.hip MAT6)
+// acc[jo] += W * in with W stored as three bf16 pieces in fragment order [jo][s][piece][lane][8] (pack.hip MAT6)
 template <int JT_OUT, int JT_IN>
 __device__ __forceinline__ void linear_acc_x6(f4 (&acc)[JT_OUT], const f4 (&in)[JT_IN], const float* w, int lane) {
   static_assert(JT_IN % 2 == 0, "k-steps cover 32 features");
   constexpr int KS = JT_IN / 2;
-  constexpr int PLANE = JT_OUT * KS * 256;                       // floats per plane
   u4 b1[KS], b2[KS], b3[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) split_kstep(in[2 * s], in[2 * s + 1], b1[s], b2[s], b3[s]);
@@ -205,10 +205,10 @@ __device__ __forceinline__ void linear_acc_x6(f4 (&acc)[JT_OUT], const f4 (&in)[
   for (int s = 0; s < KS; ++s) {
 #pragma unroll
     for (int jo = 0; jo < JT_OUT; ++jo) {
-      const float* p = w + (jo * KS + s) * 256 + lane * 4;
+      const float* p = w + (jo * KS + s) * 768 + lane * 4;
       const bf8 a1 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p));
-      const bf8 a2 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p + PLANE));
-      const bf8 a3 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p + 2 * PLANE));
+      const bf8 a2 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p + 256));
+      const bf8 a3 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p + 512));
       const bf8 x1 = __builtin_bit_cast(bf8, b1[s]), x2 = __builtin_bit_cast(bf8, b2[s]), x3 = __builtin_bit_cast(bf8, b3[s]);
       // one fp32 accumulation chain; each add rounds at 2^-24 of the running sum, like an fp32 fma chain would
       acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, x1, acc[jo], 0, 0, 0);
@@ -230,7 +230,6 @@ __device__ __forceinline__ void linear_acc_x6_2(f4 (&acc0)[JT_OUT], f4 (&acc1)[J
                                                 const float* w, int lane) {
   static_assert(JT_IN % 2 == 0, "k-steps cover 32 features");
   constexpr int KS = JT_IN / 2;
-  constexpr int PLANE = JT_OUT * KS * 256;
   u4 p1[KS], p2[KS], p3[KS], q1[KS], q2[KS], q3[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
@@ -241,10 +240,10 @@ __device__ __forceinline__ void linear_acc_x6_2(f4 (&acc0)[JT_OUT], f4 (&acc1)[J
   for (int s = 0; s < KS; ++s) {
 #pragma unroll
     for (int jo = 0; jo < JT_OUT; ++jo) {
-      const float* p = w + (jo * KS + s) * 256 + lane * 4;
+      const float* p = w + (jo * KS + s) * 768 + lane * 4;
       const bf8 a1 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p));
-      const bf8 a2 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p + PLANE));
-      const bf8 a3 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p + 2 * PLANE));
+      const bf8 a2 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p + 256));
+      const bf8 a3 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(p + 512));
       const bf8 x1 = __builtin_bit_cast(bf8, p1[s]), x2 = __builtin_bit_cast(bf8, p2[s]), x3 = __builtin_bit_cast(bf8, p3[s]);
       const bf8 y1 = __builtin_bit_cast(bf8, q1[s]), y2 = __builtin_bit_cast(bf8, q2[s]), y3 = __builtin_bit_cast(bf8, q3[s]);
       // the two tiles' chains are independent: interleaving them also hides the matrix-core latency of each chain
@@ -265,6 +264,19 @@ __device__ __forceinline__ void linear_acc_x6_2(f4 (&acc0)[JT_OUT], f4 (&acc1)[J
 }
 
 #endif   // TSDE_SPLIT_H3
+
+// The general-purpose contraction of the node-level and backward kernels.  fp16x3 build: a 64x64 split-precision image
+// is exactly as large as the fp32 one (MAT64X6 == MAT64), so pack.hip writes EVERY matrix image as fp16 planes and this
+// is the split-precision product -- a 64-k product costs 6 x 16 matrix-core cycles instead of 16 x 32.  bf16x6 build:
+// fp32 fragment images and the exact fp32 instruction.
+template <int JT_OUT, int JT_IN>
+__device__ __forceinline__ void linear_acc(f4 (&acc)[JT_OUT], const f4 (&in)[JT_IN], const float* w, int lane) {
+#if TSDE_SPLIT_H3
+  linear_acc_x6<JT_OUT, JT_IN>(acc, in, w, lane);
+#else
+  linear_acc_f32<JT_OUT, JT_IN>(acc, in, w, lane);
+#endif
+}
 
 // per-feature vector (bias, LayerNorm gamma/beta, ...) stored plainly: v[16*jt + 4*g + c]
 template <int JT>
@@ -299,6 +311,43 @@ __device__ __forceinline__ float xor32_sum(float v) {
   return __uint_as_float(p[0]) + __uint_as_float(p[1]);
 }
 __device__ __forceinline__ float row_sum(float v) { return xor32_sum(xor16_sum(v)); }
+__device__ __forceinline__ float row_max(float v) {
+  const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(p[0]), __uint_as_float(p[1]));
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+
+// Adjoint product of the backward kernels: acc += W^T d for an adjoint tile d and the transposed image of W.
+// Adjoints are small and span many binades (1e-9 .. 1), outside what fp16 pieces hold, so in the fp16x3 build each ROW
+// of d (a lane's 16 values + its 3 partner lanes) is first scaled by the power of two that brings its largest element
+// into [1, 2) -- exact -- multiplied in split precision, and the result is scaled back while it is accumulated.
+// Relative to the row's largest element this keeps 2^-22; an fp32 product is no better than 2^-24 of the same scale.
+template <int JT_OUT, int JT_IN>
+__device__ __forceinline__ void linear_adj(f4 (&acc)[JT_OUT], const f4 (&d)[JT_IN], const float* wt, const Lane& L) {
+#if TSDE_SPLIT_H3
+  float m = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < JT_IN; ++jt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) m = fmaxf(m, fabsf(d[jt][c]));
+  m = row_max(m);
+  const unsigned e = __float_as_uint(m) & 0x7F800000u;          // 2^floor(log2 m); 0 for an all-zero row
+  const float up = __uint_as_float(0x7F000000u - e), down = __uint_as_float(e);
+  f4 ds[JT_IN], t[JT_OUT];
+#pragma unroll
+  for (int jt = 0; jt < JT_IN; ++jt) ds[jt] = d[jt] * up;
+#pragma unroll
+  for (int jo = 0; jo < JT_OUT; ++jo) t[jo] = f4{0.f, 0.f, 0.f, 0.f};
+  linear_acc_x6<JT_OUT, JT_IN>(t, ds, wt, L.lane);
+#pragma unroll
+  for (int jo = 0; jo < JT_OUT; ++jo)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[jo][c] = fmaf(t[jo][c], down, acc[jo][c]);
+#else
+  linear_acc_f32<JT_OUT, JT_IN>(acc, d, wt, L.lane);
+#endif
+}
 
 template <int JT>
 __device__ __forceinline__ void layer_norm(f4 (&a)[JT], const float* gamma, const float* beta, int g) {

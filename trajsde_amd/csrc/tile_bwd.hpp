@@ -60,7 +60,7 @@ __device__ __forceinline__ void zero4(f4 (&a)[4]) {
 // out = W^T-image * in  (no bias)
 __device__ __forceinline__ void linear_t(f4 (&out)[4], const f4 (&in)[4], const float* wt, const Lane& L) {
   zero4(out);
-  linear_acc<4, 4>(out, in, wt, L.lane);
+  linear_adj<4, 4>(out, in, wt, L);
 }
 
 // sum a per-lane accumulator over the 16 rows of the wave's tiles (lanes with equal g) -> 64 floats at dst
