@@ -310,9 +310,12 @@ def test_dataset_fed_batches_match_oracle(dev, tmp_path):
     assert all(np.isfinite(v) for v in res.values()), res
 
 
-def test_split_precision_and_exact_fp32_paths_agree(dev, tmp_path):
-    """the bf16x6 split-precision kernels (default) against the exact-fp32 MFMA kernels (TRAJSDE_*_FP32=1); the
-    switches are read once per process, so each mode runs in its own interpreter"""
+def test_alternative_kernel_paths_agree(dev, tmp_path):
+    """the default kernels (paired tiles, fused decoder heads, cooperative recurrence, fused global attention) against
+    the alternative kernel structures selected by the TRAJSDE_* switches: the single-tile kernels on the plain images
+    (TRAJSDE_*_FP32=1: exact fp32 MFMA in a bf16x6 build, the same split-precision products in the default fp16x3
+    build), the two-launch recurrence and the unfused global attention.  The switches are read once per process, so
+    each mode runs in its own interpreter"""
     import os
     import subprocess
     import sys

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
   constexpr int LPH = 64 / HEADS, SL = 64 / LPH, NV = SL / 4;     // as in k_global_attn<HEADS>
   constexpr float INV = HEADS == 4 ? 0.25f : INV_SQRT_DH;
   __shared__ __attribute__((aligned(16))) float sbuf[4][HEADS][64 + 4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row addresses in SGPRs
   const int h = lane / LPH, j = lane % LPH;
   const int64_t node = int64_t(blockIdx.x) * 4 + wv;
   const int64_t nc = node < N ? node : N - 1;
@@ -72,9 +72,12 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
   }
   const int beg = segptr[nc], end = node < N ? segptr[nc + 1] : beg;
   auto load_rel = [&](int e, f4 (&r)[NV]) {
+    const float* rrow = rel + int64_t(e) * 64;
 #pragma unroll
-    for (int v4 = 0; v4 < NV; ++v4) r[v4] = *reinterpret_cast<const f4*>(rel + int64_t(e) * 64 + SL * j + 4 * v4);
+    for (int v4 = 0; v4 < NV; ++v4) r[v4] = *reinterpret_cast<const f4*>(rrow + SL * j + 4 * v4);
   };
+  // the source indices of a chunk in one coalesced load, handed out as scalars (k_global_attn does the same)
+  auto chunk_src = [&](int e0, int n) { return src[e0 + (lane & (n - 1)) < end ? e0 + (lane & (n - 1)) : end - 1]; };
   auto logit = [&](const f4 (&r)[NV], float knv) {
     float p = ql * knv;
 #pragma unroll
@@ -85,24 +88,53 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
   };
   // pass 1: softmax statistics of the segment
   float m = -INFINITY, s = 0.f;
-  for (int e = beg; e < end; ++e) {
-    f4 r[NV];
-    load_rel(e, r);
-    const float p = logit(r, kn[int64_t(src[e]) * 64 + lane]);
-    const float mn = fmaxf(m, p);
-    s = s * fast_exp(m - mn) + fast_exp(p - mn);
+  for (int e0 = beg; e0 < end; e0 += 8) {                  // 8 edges in flight per round trip, as in the forward kernel
+    f4 r[8][NV];
+    float knv[8], lg[8];
+    const int sv = chunk_src(e0, 8);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u < end ? e0 + u : end - 1;
+      load_rel(e, r[u]);
+      knv[u] = (kn + int64_t(__builtin_amdgcn_readlane(sv, u)) * 64)[lane];
+    }
+    float cm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      lg[u] = e0 + u < end ? logit(r[u], knv[u]) : -INFINITY;
+      cm = fmaxf(cm, lg[u]);
+    }
+    const float mn = fmaxf(m, cm);
+    s *= fast_exp(m - mn);
     m = mn;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += fast_exp(lg[u] - m);
   }
   const float inv = 1.0f / (s + 1e-16f);
   // pass 2: gradients
   float dqe = 0.f, Rl[SL], Sa[SL];
 #pragma unroll
   for (int e = 0; e < SL; ++e) Rl[e] = Sa[e] = 0.f;
-  for (int e = beg; e < end; ++e) {
-    const int sidx = src[e];
-    f4 r[NV];
-    load_rel(e, r);
-    const float knv = kn[int64_t(sidx) * 64 + lane], vnv = vn[int64_t(sidx) * 64 + lane];
+  for (int e0 = beg; e0 < end; e0 += 4) {                  // loads of 4 edges in flight, then their gradients in order
+   f4 rr4[4][NV];
+   float kn4[4], vn4[4];
+   int sx4[4];
+   const int sv = chunk_src(e0, 4);
+#pragma unroll
+   for (int u = 0; u < 4; ++u) {
+     const int e = e0 + u < end ? e0 + u : end - 1;
+     sx4[u] = __builtin_amdgcn_readlane(sv, u);
+     load_rel(e, rr4[u]);
+     kn4[u] = (kn + int64_t(sx4[u]) * 64)[lane];
+     vn4[u] = (vn + int64_t(sx4[u]) * 64)[lane];
+   }
+#pragma unroll
+   for (int u = 0; u < 4; ++u) {
+    const int e = e0 + u;
+    if (e >= end) break;
+    const int sidx = sx4[u];
+    const f4 (&r)[NV] = rr4[u];
+    const float knv = kn4[u], vnv = vn4[u];
     const float alpha = fast_exp(logit(r, knv) - m) * inv;
     float t = da * vnv;
 #pragma unroll
@@ -150,6 +182,7 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
         *reinterpret_cast<f4*>(p + 4 * v4) = a;
       }
     }
+   }
   }
 #pragma unroll
   for (int v4 = 0; v4 < NV; ++v4) {
@@ -197,14 +230,28 @@ __global__ __launch_bounds__(256) void k_gattn_src_bwd(const int32_t* __restrict
                                                        const float* __restrict__ dagg, int64_t N, float* __restrict__ DKN,
                                                        float* __restrict__ DVN) {
   const int lane = threadIdx.x & 63, h = lane / (64 / HEADS);
-  const int64_t node = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t node = int64_t(blockIdx.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (node >= N) return;
   float dk = 0.f, dv = 0.f;
-  for (int ep = segptr[node]; ep < segptr[node + 1]; ++ep) {
-    const int e = REV[ep], i = src[ep];
-    const float a = EA[int64_t(e) * HEADS + h], d = ED[int64_t(e) * HEADS + h];
-    dk = fmaf(d, q[int64_t(i) * 64 + lane], dk);
-    dv = fmaf(a, dagg[int64_t(i) * 64 + lane], dv);
+  const int beg = segptr[node], end = segptr[node + 1];
+  for (int e0 = beg; e0 < end; e0 += 8) {                  // 8 edges per round trip; indices loaded coalesced, used as scalars
+    const int ec = e0 + (lane & 7) < end ? e0 + (lane & 7) : end - 1;
+    const int rv = REV[ec], sv = src[ec];
+    float a[8], d[8], qv[8], gv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = __builtin_amdgcn_readlane(rv, u), i = __builtin_amdgcn_readlane(sv, u);
+      a[u] = (EA + int64_t(e) * HEADS)[h];
+      d[u] = (ED + int64_t(e) * HEADS)[h];
+      qv[u] = (q + int64_t(i) * 64)[lane];
+      gv[u] = (dagg + int64_t(i) * 64)[lane];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + u < end) {                                  // same summation order as one edge at a time
+        dk = fmaf(d[u], qv[u], dk);
+        dv = fmaf(a[u], gv[u], dv);
+      }
   }
   DKN[node * 64 + lane] = dk;
   DVN[node * 64 + lane] = dv;

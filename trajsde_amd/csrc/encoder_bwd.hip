@@ -35,27 +35,49 @@ __global__ __launch_bounds__(256) void k_seg_attn_bwd(const int32_t* __restrict_
   const int lane = threadIdx.x & 63;
   const int head = heads == 4 ? lane >> 4 : lane >> 3, slot = heads == 4 ? head : 4 * (head & 1) + (head >> 1);
   const int lph_mask = heads == 4 ? 15 : 7;
-  const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform
   if (node >= R) return;
   const int beg = segptr[node], end = segptr[node + 1];
   if (end <= beg) return;
   float m = -INFINITY, s = 0.f;
-  for (int e = beg; e < end; ++e) {
-    const float p = logits[int64_t(e) * 8 + slot];
-    const float mn = fmaxf(m, p);
-    s = s * fast_exp(m - mn) + fast_exp(p - mn);
+  for (int e0 = beg; e0 < end; e0 += 8) {                  // the chunked online softmax of k_seg_softmax_agg (same m, s)
+    float p[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] = (logits + int64_t(e0 + u < end ? e0 + u : end - 1) * 8)[slot];
+    float cm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      p[u] = e0 + u < end ? p[u] : -INFINITY;
+      cm = fmaxf(cm, p[u]);
+    }
+    const float mn = fmaxf(m, cm);
+    s *= fast_exp(m - mn);
     m = mn;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += fast_exp(p[u] - m);
   }
   const float inv = 1.0f / (s + 1e-16f);
   const float da = dagg[node * 64 + lane];
   const float t0 = da * agg[node * 64 + lane];
   const float dlt = heads == 4 ? head_sum16(t0) : head_sum(t0);
-  for (int e = beg; e < end; ++e) {
-    const float alpha = fast_exp(logits[int64_t(e) * 8 + slot] - m) * inv;
-    const float t1 = da * v[int64_t(e) * 64 + lane];
-    const float dal = heads == 4 ? head_sum16(t1) : head_sum(t1);
-    DV[int64_t(e) * 64 + lane] = alpha * da;
-    if ((lane & lph_mask) == 0) DLG[int64_t(e) * 8 + slot] = alpha * (dal - dlt);
+  for (int e0 = beg; e0 < end; e0 += 4) {                  // 4 edges' loads in flight
+    float lg[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u < end ? e0 + u : end - 1;
+      lg[u] = (logits + int64_t(e) * 8)[slot];
+      vv[u] = (v + int64_t(e) * 64)[lane];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u;
+      if (e >= end) break;
+      const float alpha = fast_exp(lg[u] - m) * inv;
+      const float t1 = da * vv[u];
+      const float dal = heads == 4 ? head_sum16(t1) : head_sum(t1);
+      (DV + int64_t(e) * 64)[lane] = alpha * da;
+      if ((lane & lph_mask) == 0) (DLG + int64_t(e) * 8)[slot] = alpha * (dal - dlt);
+    }
   }
 }
 
@@ -63,10 +85,17 @@ __global__ __launch_bounds__(256) void k_seg_attn_bwd(const int32_t* __restrict_
 __global__ __launch_bounds__(256) void k_seg_sum(const int32_t* __restrict__ segptr, const float* __restrict__ DQE, int64_t R,
                                                  float* __restrict__ DQ) {
   const int lane = threadIdx.x & 63;
-  const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (node >= R) return;
   float s = 0.f;
-  for (int e = segptr[node]; e < segptr[node + 1]; ++e) s += DQE[int64_t(e) * 64 + lane];
+  const int beg = segptr[node], end = segptr[node + 1];
+  for (int e0 = beg; e0 < end; e0 += 8) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = (DQE + int64_t(e0 + u < end ? e0 + u : end - 1) * 64)[lane];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += e0 + u < end ? x[u] : 0.f;          // same order as one row at a time
+  }
   DQ[node * 64 + lane] = s;
 }
 
