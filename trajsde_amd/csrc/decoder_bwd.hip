@@ -16,8 +16,9 @@
 //   k_wgrad / k_reduce_partials   dW = sum_rows delta^T a  as MFMA outer products over saved rows (deterministic
 //                              two-stage reduction), bias = column sums, time-feature columns = step-weighted sums
 //
-// Matrix products use the exact-fp32 MFMA path (tile.hpp linear_acc) on transposed fragment images (layouts.hpp
-// SweepL / HeadBwdL / InitBwdL): dX^T = W^T dY^T has the same "row on lane" operand/result layout as the forward.
+// Matrix products run on transposed images (layouts.hpp SweepL / HeadBwdL / InitBwdL): dX^T = W^T dY^T has the same
+// "row on lane" operand/result layout as the forward.  tile.hpp linear_adj: row-scaled split precision in the fp16x3
+// build, the exact fp32 instruction in the bf16x6 build; the weight gradients (k_wgrad) are always exact fp32.
 #include <cstdlib>
 
 #include "common.hpp"

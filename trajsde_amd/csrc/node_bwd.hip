@@ -8,7 +8,8 @@
 //   k_edge_embed_bwd_tail / _branch   MultipleInputEmbedding over edge rows      -> saves the (delta, input) rows
 //   k_headwise_outer            W[d][c] = sum_i X[i][d] Y[i][head(d)][c]
 //
-// All matrix products are exact-fp32 MFMA (tile.hpp) on forward or transposed fragment images; parameter gradients
+// Matrix products: tile.hpp linear_acc on forward images (recomputation) and linear_adj on transposed images (adjoints:
+// row-scaled split precision in the fp16x3 build, exact fp32 in the bf16x6 build); parameter gradients
 // that are matrices come from the saved rows through run_wgrad (decoder_bwd.hip), vectors from per-wave accumulators.
 #include "bwd.hpp"
 #include "common.hpp"

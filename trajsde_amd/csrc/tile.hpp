@@ -3,8 +3,9 @@
 // Design: "row on lane".  A wave owns a tile of 16 rows (agent-samples, edges or nodes).  Lane l holds
 // row n = l & 15 and, of that row's features, the quads selected by g = l >> 4: a 64-feature activation
 // is   f4 a[4]   with   a[jt][c] = X[row n][16*jt + 4*g + c].
-// A linear layer is computed TRANSPOSED on the matrix cores, Y^T = W * X^T, with the exact-fp32
-// v_mfma_f32_16x16x4_f32 (A = 16 output features x 4 k, B = 4 k x 16 rows, D = 16 features x 16 rows):
+// A linear layer is computed TRANSPOSED on the matrix cores, Y^T = W * X^T.  Described here for the exact-fp32
+// v_mfma_f32_16x16x4_f32 (A = 16 output features x 4 k, B = 4 k x 16 rows, D = 16 features x 16 rows); the
+// split-precision products further down (fp16x3 by default, K = 32 per instruction) keep the same D layout:
 //   - the D fragment (col = lane&15 = row, row = 4*(lane>>4)+reg = feature) is *already* the
 //     activation layout above, so chains of layers never leave registers: no LDS transpose,
 //     no cross-lane traffic (cf. cdna_hip_programming.md section 3, accumulator tile as next operand);
