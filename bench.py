@@ -44,6 +44,24 @@ PEAK_FP32_EQUIV_TFLOPS = MFMA_16BIT_PEAK_TFLOPS / SPLIT_PRODUCTS
 CPU_SAMPLE_SCENES = 16
 
 
+# static instruction stream of the pair edge kernel per 16-edge tile (hipcc -S of csrc/attn.hip, k_edge_kv2<768>, counted
+# over the tile loop): VALU incl. the operand splits and LayerNorms, and the 16x16x32 matrix instructions
+EDGE_TILE_VALU = {3: 805, 6: 1060}
+EDGE_TILE_MFMA = {3: 120, 6: 240}
+
+
+def issue_view(e_aa, avg_s):
+    """What actually bounds the dominant kernel: a wave64 VALU instruction occupies its SIMD's VALU for 4 cycles, a
+    16x16x32 matrix instruction the matrix pipe for 16; with 2-3 waves per SIMD the two barely overlap, so the sum of both
+    per tile against the measured SIMD-cycles per tile (at the 2.4 GHz peak clock, 1024 SIMDs) is the fraction of the time
+    the SIMDs spend issuing this kernel's own arithmetic."""
+    tiles = e_aa / 16.0
+    valu, mfma = EDGE_TILE_VALU[SPLIT_PRODUCTS] * 4, EDGE_TILE_MFMA[SPLIT_PRODUCTS] * 16
+    measured = avg_s * 2.4e9 * 1024 / tiles
+    return {"valu_cycles_per_tile": valu, "mfma_cycles_per_tile": mfma, "measured_simd_cycles_per_tile": measured,
+            "frac": (valu + mfma) / measured, "clock_GHz": 2.4, "simds": 1024}
+
+
 def build_cfg(spec):
     import yaml
     with open(os.path.join(ROOT, "trajsde_amd/configs/mi355x_sde_encoder_decoder.yml")) as f:
@@ -218,6 +236,7 @@ def main():
                                       "(the same kernel on exact fp32 MFMA, TRAJSDE_EDGE_FP32=1, ran at 110-113 TFLOP/s = 0.70-0.72 of the "
                                       "157.3 TFLOP/s fp32 matrix peak; bf16x6 ran at 142-188 TFLOP/s)",
                          "split_precision": SPLIT_NAME,
+                         "issue_view": issue_view(e_aa, avg_s),
                          "mfma_16bit_tflops": achieved * SPLIT_PRODUCTS * (40960.0 / 41700.0)},
         }
         if not args.no_cpu_baseline and world == 1:
@@ -242,7 +261,7 @@ def main():
             iso = FLOP_PER_EDGE * e_aa / (iso_ms / iso_n * 1e-3) * 1e-12
             line["roofline_isolated"] = {"kernel": "k_edge_kv[aa]", "streams": 1, "achieved": iso, "peak": PEAK_FP32_EQUIV_TFLOPS,
                                          "unit": "TFLOP/s", "frac": iso / PEAK_FP32_EQUIV_TFLOPS, "avg_launch_ms": iso_ms / iso_n,
-                                         "launches": iso_n}
+                                         "launches": iso_n, "issue_view": issue_view(e_aa, iso_ms / iso_n * 1e-3)}
         # the step-granular decoder SDE step (state round-trips HBM every Euler step: SURVEY 8(d)'s 512 B / path-step
         # variant) in both views: algorithmic HBM GB/s -- the figure the north star names -- and the FLOP/s that binds it
         try:
