@@ -15,12 +15,17 @@ template <bool X6>
 __device__ __forceinline__ void edge_embed(f4 (&emb)[4], const f4 geom, const float* lds, const Lane& L) {
   using E = typename std::conditional<X6, EdgeL6, EdgeL>::type;
   f4 h0[4], h1[4], s[4];
-  linear_in2(h0, geom[0], geom[1], lds + E::A_W0, lds + E::A_B0, L.g);
-  layer_norm<4>(h0, lds + E::A_G, lds + E::A_E, L.g);
-  relu<4>(h0);
-  linear_in2(h1, geom[2], geom[3], lds + E::B_W0, lds + E::B_B0, L.g);
-  layer_norm<4>(h1, lds + E::B_G, lds + E::B_E, L.g);
-  relu<4>(h1);
+  if constexpr (X6) {
+    in2_ln_relu(h0, geom[0], geom[1], lds + EdgeL6::A_C, lds + E::A_E, L.g);
+    in2_ln_relu(h1, geom[2], geom[3], lds + EdgeL6::B_C, lds + E::B_E, L.g);
+  } else {
+    linear_in2(h0, geom[0], geom[1], lds + E::A_W0, lds + E::A_B0, L.g);
+    layer_norm<4>(h0, lds + E::A_G, lds + E::A_E, L.g);
+    relu<4>(h0);
+    linear_in2(h1, geom[2], geom[3], lds + E::B_W0, lds + E::B_B0, L.g);
+    layer_norm<4>(h1, lds + E::B_G, lds + E::B_E, L.g);
+    relu<4>(h1);
+  }
   load_vec<4>(s, lds + E::B3, L.g);                       // b0.3 + b1.3
   if constexpr (X6) {
     linear_acc_x6<4, 4>(s, h0, lds + E::WA3, L.lane);
@@ -41,21 +46,13 @@ __device__ __forceinline__ void edge_embed2_x6(f4 (&emb0)[4], f4 (&emb1)[4], con
                                                const Lane& L) {
   using E = EdgeL6;
   f4 a0[4], a1[4], b0[4], b1[4], s0[4], s1[4];
-  linear_in2(a0, ge0[0], ge0[1], lds + E::A_W0, lds + E::A_B0, L.g);
-  layer_norm<4>(a0, lds + E::A_G, lds + E::A_E, L.g);
-  relu<4>(a0);
-  linear_in2(a1, ge1[0], ge1[1], lds + E::A_W0, lds + E::A_B0, L.g);
-  layer_norm<4>(a1, lds + E::A_G, lds + E::A_E, L.g);
-  relu<4>(a1);
+  in2_ln_relu(a0, ge0[0], ge0[1], lds + E::A_C, lds + E::A_E, L.g);
+  in2_ln_relu(a1, ge1[0], ge1[1], lds + E::A_C, lds + E::A_E, L.g);
   load_vec<4>(s0, lds + E::B3, L.g);
   load_vec<4>(s1, lds + E::B3, L.g);
   linear_acc_x6_2<4, 4>(s0, s1, a0, a1, lds + E::WA3, L.lane);
-  linear_in2(b0, ge0[2], ge0[3], lds + E::B_W0, lds + E::B_B0, L.g);
-  layer_norm<4>(b0, lds + E::B_G, lds + E::B_E, L.g);
-  relu<4>(b0);
-  linear_in2(b1, ge1[2], ge1[3], lds + E::B_W0, lds + E::B_B0, L.g);
-  layer_norm<4>(b1, lds + E::B_G, lds + E::B_E, L.g);
-  relu<4>(b1);
+  in2_ln_relu(b0, ge0[2], ge0[3], lds + E::B_C, lds + E::B_E, L.g);
+  in2_ln_relu(b1, ge1[2], ge1[3], lds + E::B_C, lds + E::B_E, L.g);
   linear_acc_x6_2<4, 4>(s0, s1, b0, b1, lds + E::WB3, L.lane);
   layer_norm<4>(s0, lds + E::AG0, lds + E::AE0, L.g);
   relu<4>(s0);

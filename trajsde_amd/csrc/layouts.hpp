@@ -47,6 +47,13 @@ constexpr int MAT64X6 = 4096;   // two fp16 planes
 #else
 constexpr int MAT64X6 = 6144;
 #endif
+// Linear(2,64) -> LayerNorm with the statistics in closed form (tile.hpp in2_ln): the pre-LN activation is affine in the
+// two inputs, h - mean(h) = w0c x0 + w1c x1 + bc with the feature-centred columns, so
+//   var(h) = |L^T (x0, x1, 1)|^2   for the Cholesky factor L of the 3x3 Gram matrix of (w0c, w1c, bc) / 64
+// -- a sum of three squares, no cancellation -- and LN(h) = rstd (GW0 x0 + GW1 x1 + GB) + beta with gamma folded in.
+struct In2L {
+  enum : int { GW0 = 0, GW1 = 64, GB = 128, CH = 192, SIZE = 200 };   // CH: l00 l10 l20 l11 l21 l22 (+2 pad)
+};
 struct EdgeL6 {
   enum : int {
     S_END = 0,
@@ -55,8 +62,9 @@ struct EdgeL6 {
     TS_FIELD(WA3, MAT64X6, B_E), TS_FIELD(WB3, MAT64X6, WA3), TS_FIELD(B3, 64, WB3),
     TS_FIELD(AG0, 64, B3), TS_FIELD(AE0, 64, AG0), TS_FIELD(W2, MAT64X6, AE0), TS_FIELD(B2, 64, W2),
     TS_FIELD(AG3, 64, B2), TS_FIELD(AE3, 64, AG3),
-    EMB_SIZE = AE3_END,
-    TS_FIELD(WKV, 2 * MAT64X6, AE3), TS_FIELD(BKV, 128, WKV),
+    TS_FIELD(A_C, In2L::SIZE, AE3), TS_FIELD(B_C, In2L::SIZE, A_C),     // closed-form first layers of the two branches
+    EMB_SIZE = B_C_END,
+    TS_FIELD(WKV, 2 * MAT64X6, B_C), TS_FIELD(BKV, 128, WKV),
     SIZE = BKV_END
   };
 };

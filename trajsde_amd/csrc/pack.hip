@@ -27,11 +27,11 @@ int fail(int code, const std::string& msg) {
 struct PackJob {
   int kind, count, pass;
   int p0, p1, p2, p3, p4;
-  const float *src, *src2;
+  const float *src, *src2, *src3;
   float* dst;
 };
-enum PackKind { PK_VEC = 0, PK_COL, PK_MAT, PK_MAT_PAD, PK_MATT, PK_MAT6, PK_MAT6_STACK2, PK_SPLIT };
-constexpr int PACK_JOBS_PER_LAUNCH = 64;        // 64 x 56 B: under the 4 KB kernel-argument limit
+enum PackKind { PK_VEC = 0, PK_COL, PK_MAT, PK_MAT_PAD, PK_MATT, PK_MAT6, PK_MAT6_STACK2, PK_SPLIT, PK_LN2 };
+constexpr int PACK_JOBS_PER_LAUNCH = 48;        // 48 x 64 B: under the 4 KB kernel-argument limit
 struct PackJobs {
   PackJob j[PACK_JOBS_PER_LAUNCH];
 };
@@ -128,6 +128,35 @@ __device__ __forceinline__ void k_pack_mat6_stack2(int i, const float* __restric
   store_split(x, dst, i, per_plane);
 }
 
+// closed-form Linear(2,64)->LayerNorm block (layouts.hpp In2L) from W [64][2], b [64], gamma [64]: thread f < 64 writes
+// the gamma-scaled centred columns, thread 0 the Cholesky factor of their Gram matrix / 64; sums in double
+__device__ __forceinline__ void k_pack_ln2(int i, const float* __restrict__ W, const float* __restrict__ b,
+                                           const float* __restrict__ gamma, float* __restrict__ dst) {
+  if (i >= 64) return;
+  double m0 = 0, m1 = 0, mb = 0;
+  for (int f = 0; f < 64; ++f) { m0 += W[2 * f]; m1 += W[2 * f + 1]; mb += b[f]; }
+  m0 /= 64; m1 /= 64; mb /= 64;
+  dst[In2L::GW0 + i] = float(double(gamma[i]) * (W[2 * i] - m0));
+  dst[In2L::GW1 + i] = float(double(gamma[i]) * (W[2 * i + 1] - m1));
+  dst[In2L::GB + i] = float(double(gamma[i]) * (b[i] - mb));
+  if (i == 0) {
+    double g00 = 0, g01 = 0, g02 = 0, g11 = 0, g12 = 0, g22 = 0;
+    for (int f = 0; f < 64; ++f) {
+      const double a = W[2 * f] - m0, c = W[2 * f + 1] - m1, d = b[f] - mb;
+      g00 += a * a; g01 += a * c; g02 += a * d; g11 += c * c; g12 += c * d; g22 += d * d;
+    }
+    g00 /= 64; g01 /= 64; g02 /= 64; g11 /= 64; g12 /= 64; g22 /= 64;
+    // G = L L^T (lower), rank-deficient columns (e.g. a zero bias) give zero pivots: their rows of L are zero
+    const double l00 = g00 > 0 ? sqrt(g00) : 0, l10 = l00 > 0 ? g01 / l00 : 0, l20 = l00 > 0 ? g02 / l00 : 0;
+    const double p11 = g11 - l10 * l10, l11 = p11 > 0 ? sqrt(p11) : 0, l21 = l11 > 0 ? (g12 - l20 * l10) / l11 : 0;
+    const double p22 = g22 - l20 * l20 - l21 * l21, l22 = p22 > 0 ? sqrt(p22) : 0;
+    // |L^T z|^2 with z = (x0, x1, 1):  (l00 x0 + l10 x1 + l20)^2 + (l11 x1 + l21)^2 + l22^2
+    float* ch = dst + In2L::CH;
+    ch[0] = float(l00); ch[1] = float(l10); ch[2] = float(l20); ch[3] = float(l11); ch[4] = float(l21); ch[5] = float(l22);
+    ch[6] = ch[7] = 0.f;
+  }
+}
+
 // one thread per element; blockIdx.y = job
 __global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
   const PackJob& J = jobs.j[blockIdx.y];
@@ -141,6 +170,7 @@ __global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
     case PK_MATT: k_pack_matT(i, J.src, J.dst, J.p0, J.p1, J.p2, J.p3, J.p4); break;
     case PK_MAT6: k_pack_mat6(i, J.src, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1, J.p2, J.p3); break;
     case PK_MAT6_STACK2: k_pack_mat6_stack2(i, J.src, J.src2, reinterpret_cast<unsigned short*>(J.dst)); break;
+    case PK_LN2: k_pack_ln2(i, J.src, J.src2, J.src3, J.dst); break;
     case PK_SPLIT: k_pack_split(i, J.src, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1, J.p2, J.p3, J.p4 & 0x3FFFFFFF, J.p4 >> 30); break;
   }
 }
@@ -150,7 +180,7 @@ struct Packer {
   std::vector<PackJob> jobs;               // wet: filled by the recipe, launched once by trajsde_pack_weights
   void emit(int kind, int count, const float* s, float* d, int p0 = 0, int p1 = 0, int p2 = 0, int p3 = 0, int p4 = 0,
             const float* s2 = nullptr, int pass = 0) {
-    jobs.push_back(PackJob{kind, count, pass, p0, p1, p2, p3, p4, s, s2, d});
+    jobs.push_back(PackJob{kind, count, pass, p0, p1, p2, p3, p4, s, s2, nullptr, d});
   }
   // raw-pointer forms for recipes that slice a parameter themselves
   void vec_raw(const float* s, float* d, int count) { emit(PK_VEC, count, s, d, 0); }
@@ -220,6 +250,15 @@ struct Packer {
     const int jto = rows / 16, ks = cols / 32;
     mat6_raw(s, blob + dst, jto, ks, ld, col0);
   }
+  // closed-form block of Sequential(Linear(2,64), LayerNorm(64)) `p.0`, `p.1`
+  void ln2(const std::string& p, int dst) {
+    const float* w = src(p + ".0.weight");
+    const float* b = src(p + ".0.bias");
+    const float* g = src(p + ".1.weight");
+    if (dry) return;
+    emit(PK_LN2, 64, w, blob + dst, 0, 0, 0, 0, 0, b);
+    jobs.back().src3 = g;
+  }
   void lin(const std::string& p, int w, int b, int rows = 64, int cols = 64) {
     mat(p + ".weight", w, rows, cols, cols);
     vec(p + ".bias", b, rows);
@@ -258,6 +297,8 @@ static void recipe_edge_embed6(Packer& P, const std::string& p, int base) {   //
   P.mat6(p + ".module_list.1.3.weight", base + E::WB3, 64, 64, 64);
   P.vec(p + ".module_list.0.3.bias", base + E::B3, 64);
   P.vec(p + ".module_list.1.3.bias", base + E::B3, 64, /*accumulate=*/true);
+  P.ln2(p + ".module_list.0", base + E::A_C);
+  P.ln2(p + ".module_list.1", base + E::B_C);
   P.ln(p + ".aggr_embed.0", base + E::AG0, base + E::AE0);
   P.mat6(p + ".aggr_embed.2.weight", base + E::W2, 64, 64, 64);
   P.vec(p + ".aggr_embed.2.bias", base + E::B2, 64);
