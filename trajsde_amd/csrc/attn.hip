@@ -252,10 +252,11 @@ __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restri
   if (node >= R) return;
   const int beg = segptr[node], end = segptr[node + 1];
   float m = -INFINITY, s = 0.f, acc = 0.f;
-  for (int e0 = beg; e0 < end; e0 += 8) {
-    float p[8], vv[8];
+  constexpr int CH = 16;                                   // edges in flight per round trip (a segment's rows are contiguous)
+  for (int e0 = beg; e0 < end; e0 += CH) {
+    float p[CH], vv[CH];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < CH; ++u) {
       const int e = e0 + u < end ? e0 + u : end - 1;
       const float* lrow = logits + int64_t(e) * 8;
       const float* vrow = v + int64_t(e) * 64;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restri
     }
     float cm = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < CH; ++u) {
       p[u] = e0 + u < end ? p[u] : -INFINITY;
       cm = fmaxf(cm, p[u]);
     }
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restri
     s *= sc;
     acc *= sc;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < CH; ++u) {
       const float ex = fast_exp(p[u] - m);
       s += ex;
       acc = fmaf(ex, vv[u], acc);

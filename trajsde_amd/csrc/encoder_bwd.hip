@@ -40,13 +40,13 @@ __global__ __launch_bounds__(256) void k_seg_attn_bwd(const int32_t* __restrict_
   const int beg = segptr[node], end = segptr[node + 1];
   if (end <= beg) return;
   float m = -INFINITY, s = 0.f;
-  for (int e0 = beg; e0 < end; e0 += 8) {                  // the chunked online softmax of k_seg_softmax_agg (same m, s)
-    float p[8];
+  for (int e0 = beg; e0 < end; e0 += 16) {                 // the chunked online softmax of k_seg_softmax_agg (same m, s)
+    float p[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) p[u] = (logits + int64_t(e0 + u < end ? e0 + u : end - 1) * 8)[slot];
+    for (int u = 0; u < 16; ++u) p[u] = (logits + int64_t(e0 + u < end ? e0 + u : end - 1) * 8)[slot];
     float cm = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       p[u] = e0 + u < end ? p[u] : -INFINITY;
       cm = fmaxf(cm, p[u]);
     }
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_seg_attn_bwd(const int32_t* __restrict_
     s *= fast_exp(m - mn);
     m = mn;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += fast_exp(p[u] - m);
+    for (int u = 0; u < 16; ++u) s += fast_exp(p[u] - m);
   }
   const float inv = 1.0f / (s + 1e-16f);
   const float da = dagg[node * 64 + lane];

@@ -172,18 +172,31 @@ __global__ __launch_bounds__(256) void k_aa_pass(int N, int Nt, int H, int TT, c
   for (int p0 = beg; p0 < end; p0 += 32) {
     const int mine = p0 + t < end ? csr_src[p0 + t] : 0;                   // coalesced chunk of sender ids
     const int m = end - p0 < 32 ? end - p0 : 32;
-    for (int u = 0; u < m; ++u) {
-      const int s = __shfl(mine, u, 32);
-      const bool ok = dst_ok && !pad[int64_t(s) * TT + tc];
-      const float dx = pos[(int64_t(s) * TT + tc) * 2] - px, dy = pos[(int64_t(s) * TT + tc) * 2 + 1] - py;
-      if (ok && sqrtf(dx * dx + dy * dy) < radius) {
-        if (FILL) {
-          const float x0 = x[(int64_t(s) * H + tc) * 2], x1 = x[(int64_t(s) * H + tc) * 2 + 1];   // senders are real actors
-          f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
-          *reinterpret_cast<f4*>(geom + 4 * int64_t(k)) = g;
-          aa_dst[k] = tc * Nt + int(node);
+    for (int u0 = 0; u0 < m; u0 += 4) {                                    // 4 senders' loads in flight, then tested in order
+      int sv[4];
+      uint8_t pv[4];
+      float2 qv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sv[j] = __shfl(mine, u0 + j < m ? u0 + j : m - 1, 32);
+        pv[j] = pad[int64_t(sv[j]) * TT + tc];
+        qv[j] = *reinterpret_cast<const float2*>(pos + (int64_t(sv[j]) * TT + tc) * 2);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (u0 + j >= m) break;
+        const int s = sv[j];
+        const bool ok = dst_ok && !pv[j];
+        const float dx = qv[j].x - px, dy = qv[j].y - py;
+        if (ok && sqrtf(dx * dx + dy * dy) < radius) {
+          if (FILL) {
+            const float x0 = x[(int64_t(s) * H + tc) * 2], x1 = x[(int64_t(s) * H + tc) * 2 + 1];   // senders are real actors
+            f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
+            *reinterpret_cast<f4*>(geom + 4 * int64_t(k)) = g;
+            aa_dst[k] = tc * Nt + int(node);
+          }
+          ++k;
         }
-        ++k;
       }
     }
   }

@@ -203,11 +203,12 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
   for (int k = 0; k < tiles_per_wg; ++k)
     if (int64_t(blockIdx.x) + int64_t(k) * gridDim.x < ntiles) T = k + 1;
   if (T == 0) return;
-  auto Yb = [&](int k) { return lds + (4 * k + 0) * COOP_TILE; };
-  auto Ab = [&](int k) { return lds + (4 * k + 1) * COOP_TILE; };
-  auto Bb = [&](int k) { return lds + (4 * k + 2) * COOP_TILE; };
-  auto Cb = [&](int k) { return lds + (4 * k + 3) * COOP_TILE; };
-  float* GP = lds + 4 * tiles_per_wg * COOP_TILE;              // [tile][wave][16]
+  auto Yb = [&](int k) { return lds + (5 * k + 0) * COOP_TILE; };
+  auto Ab = [&](int k) { return lds + (5 * k + 1) * COOP_TILE; };
+  auto Bb = [&](int k) { return lds + (5 * k + 2) * COOP_TILE; };
+  auto Cb = [&](int k) { return lds + (5 * k + 3) * COOP_TILE; };
+  auto Xb = [&](int k) { return lds + (5 * k + 4) * COOP_TILE; };   // x_t tile of the step, each wave brings a quarter
+  float* GP = lds + 5 * tiles_per_wg * COOP_TILE;              // [tile][wave][16]
 
   // ---- register-resident weights: this wave's slice of every matrix
   const float* F = sde_img + EncSdeL::F;
@@ -260,16 +261,15 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
     const f4 bf0 = vec_slice(F + DriftL::B0, w, L.g) + vec_slice(F + DriftL::WS, w, L.g) * sn + vec_slice(F + DriftL::WC, w, L.g) * cs;
     const f4 bn0 = vec_slice(GN + DiffL::B0, w, L.g) + vec_slice(GN + DiffL::WS, w, L.g) * sn + vec_slice(GN + DiffL::WC, w, L.g) * cs;
     const f4 ba0 = vec_slice(GA + DiffL::B0, w, L.g) + vec_slice(GA + DiffL::WS, w, L.g) * sn + vec_slice(GA + DiffL::WC, w, L.g) * cs;
-    Opnd xin[COOP_TMAX];
+    f4 xq[COOP_TMAX];                                        // this wave's quarter of the x_t rows: loaded in P1, to LDS in P3
     // ---- P1: first layers of f and g
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 yf[4], xf[4];
+        f4 yf[4];
         lds_read_tile(yf, Yb(k), L);
-        load_row(xf, aa_out + int64_t(t) * Nt * 64, rowk[k], L.g);               // x_t rows for the GRU, in flight early
+        xq[k] = *reinterpret_cast<const f4*>(aa_out + (int64_t(t) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g);   // in flight early
         const Opnd y = make_opnd(yf);
-        xin[k] = make_opnd(xf);
         f4 a = bf0;
         slice_mma(a, wf0, y);
         lds_write_slice(Ab(k), tanh4(a), w, L);
@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
 #pragma unroll
         for (int c = 0; c < 4; ++c) y[c] = (y[c] + f[c] * dt) + gs * (z[c] * sq);       // SDEINT:483
         lds_write_slice(Yb(k), y, w, L);                                                  // Y now holds h' (all P1 reads are behind two barriers)
+        lds_write_slice(Xb(k), xq[k], w, L);
         if (diff_pick != nullptr && inb[k] && slotk[k] >= 0 && eosk[k] == idx)
           *reinterpret_cast<f4*>(diff_pick + int64_t(slotk[k]) * 64 + 16 * w + 4 * L.g) = f4{gs, gs, gs, gs};
       }
@@ -345,11 +346,14 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
         f4 hpf[4];
         lds_read_tile(hpf, Yb(k), L);
         const Opnd hp = make_opnd(hpf);
+        f4 xf[4];
+        lds_read_tile(xf, Xb(k), L);
+        const Opnd xin = make_opnd(xf);
         f4 u1 = vec_slice(gru_img + G::BUR, w, L.g), r1 = vec_slice(gru_img + G::BUR + 64, w, L.g);
         slice_mma(u1, wuh, hp);
-        slice_mma(u1, wux, xin[k]);
+        slice_mma(u1, wux, xin);
         slice_mma(r1, wrh, hp);
-        slice_mma(r1, wrx, xin[k]);
+        slice_mma(r1, wrx, xin);
         lds_write_slice(Ab(k), tanh4(u1), w, L);
         lds_write_slice(Bb(k), tanh4(r1), w, L);
       }
@@ -378,8 +382,11 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
         f4 rhf[4];
         lds_read_tile(rhf, Cb(k), L);
         const Opnd rh = make_opnd(rhf);
+        f4 xf[4];
+        lds_read_tile(xf, Xb(k), L);                       // the x_t tile again (not kept live across the phases)
+        const Opnd xin = make_opnd(xf);
         f4 n1 = vec_slice(gru_img + G::BN0, w, L.g);
-        slice_mma(n1, wnx, xin[k]);
+        slice_mma(n1, wnx, xin);
         slice_mma(n1, wnh, rh);
         lds_write_slice(Ab(k), tanh4(n1), w, L);
       }

@@ -60,7 +60,15 @@ struct AggWs {
 };
 
 // one attention block over an edge list already reduced to (logits, v): softmax-aggregate, gated update, FFN
-static bool node_x6() { static bool v = []() { const char* e = getenv("TRAJSDE_NODE_FP32"); return !(e && atoi(e) != 0); }(); return v; }
+// fp16x3 build: the plain images are split-precision images of the same size, so the one-pass FFN (k_ffn, 128 KB image)
+// replaces the two-half k_ffn6 that the 1.5x larger bf16x6 planes needed; TRAJSDE_NODE_FP32=0/1 forces either pair
+static bool node_x6() {
+  static bool v = []() {
+    const char* e = getenv("TRAJSDE_NODE_FP32");
+    return e ? atoi(e) == 0 : !TSDE_SPLIT_H3;
+  }();
+  return v;
+}
 
 // gated update + FFN of one attention block; `upd6/ffn6` are the split-precision images, `upd/ffn` the plain fp32 ones
 struct NodeImgs {
@@ -141,7 +149,7 @@ static int run_recurrence(const trajsde_batch* b, const trajsde_graph* g, const 
       tab.dt[i] = step_tab[8 * i + 1]; tab.sq[i] = step_tab[8 * i + 2]; tab.sn[i] = step_tab[8 * i + 3]; tab.cs[i] = step_tab[8 * i + 4];
     }
     const int grid = int((rtiles + tiles_per_wg - 1) / tiles_per_wg);
-    const int lds = (4 * tiles_per_wg * COOP_TILE + tiles_per_wg * 64) * 4;
+    const int lds = (5 * tiles_per_wg * COOP_TILE + tiles_per_wg * 64) * 4;
     TS_LAUNCH(k_enc_recur_coop, grid, 256, lds, st, blob + EncBlob::SDE, blob + EncBlob::GRU, blob + EncBlob::COOP6, h0, aa_out, Nt, N, H, b->TT, tiles_per_wg, tab,
               noise_step0, na, g->nus_mask, b->padding_mask, g->orig, g->eos_idx, g->pick_slot, kept, diff_pick, latent_ys);
     return TRAJSDE_OK;
