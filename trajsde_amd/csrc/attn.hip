@@ -302,6 +302,7 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
   constexpr int NV = SL / 4;               // ... as float4s
   constexpr float INV = HEADS == 4 ? 0.25f : INV_SQRT_DH;
   __shared__ __attribute__((aligned(16))) float sbuf[4][HEADS][64 + 4];
+  __shared__ __attribute__((aligned(16))) float srel[4][8][64];   // a wave's chunk of rel rows (wave-private, no block barrier)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: addresses in SGPRs
   const int h = lane / LPH, j = lane % LPH;
   const int64_t node = int64_t(blockIdx.x) * 4 + wv;
@@ -333,6 +334,10 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
     // the chunk's 8 source indices in one coalesced load, handed out as scalars: every row address below is an SGPR
     // base plus a per-lane constant offset, so the loop spends no VALU cycles on address arithmetic
     const int sv = src[e0 + (lane & 7) < end ? e0 + (lane & 7) : end - 1];
+    // every head needs the whole 64-wide rel row, so a per-lane 32-B load would fetch each row HEADS times through the
+    // texture-address unit (16 cycles per 16-B wave load): the wave loads each row once, one dword per lane, and the
+    // lanes pick their slices out of LDS (same-address reads across the heads broadcast)
+    float rl[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u < end ? e0 + u : end - 1;
@@ -340,11 +345,19 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
       const float* rrow = rel + int64_t(e) * 64;
       const float* krow = kn + int64_t(sidx) * 64;
       const float* vrow = vn + int64_t(sidx) * 64;
-#pragma unroll
-      for (int v4 = 0; v4 < NV; ++v4) r[u][v4] = *reinterpret_cast<const f4*>(rrow + SL * j + 4 * v4);
+      rl[u] = rrow[lane];
       knv[u] = krow[lane];
       vnv[u] = vrow[lane];
     }
+    __builtin_amdgcn_wave_barrier();                      // the previous chunk's slice reads are done (same wave, in order)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) srel[wv][u][lane] = rl[u];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int v4 = 0; v4 < NV; ++v4) r[u][v4] = *reinterpret_cast<const f4*>(&srel[wv][u][SL * j + 4 * v4]);
     float cm = -INFINITY;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
