@@ -454,3 +454,42 @@ def test_checkpoint_resume_retraces_the_uninterrupted_run(dev, tmp_path):
         assert torch.equal(p, q), n
     ref_style = torch.load(ck, map_location="cpu")
     assert set(ref_style["state_dict"]) == set(a.state_dict())           # loads into the reference model key for key
+
+
+@pytest.mark.parametrize("scale", [1e-7, 1e3])
+def test_backward_is_linear_in_the_upstream_gradient_over_many_binades(scale, dev):
+    """the adjoint products run in split precision on fp16 pieces (tile.hpp linear_adj): each adjoint row is scaled by a
+    power of two into fp16's range first.  Gradients must therefore be exactly as accurate for an upstream gradient of
+    1e-7 (where an unscaled fp16 split would flush everything below 6e-8 to zero) or 1e3 as for one of order 1."""
+    from trajsde_amd import runtime
+    from trajsde_amd.synth import synth
+    K, T = 3, 5
+    model, cfg = H.build_model(K, T, 0.5, init_seed=13)
+    model = model.to(dev)
+    data = synth(S=3, n=16, L=6, F=T, box=80.0, seed=77, mixed_source=True).to(dev)
+    noise = runtime.NoiseSpec(seed=17)
+    rot, y_rot = runtime.rotate_inputs(data)
+    data.y, data["rotate_mat"] = y_rot, rot
+    local, *_ = model.encoder(data=data, noise=noise)
+    g = torch.Generator().manual_seed(3)
+    d_glob = torch.randn(K, local.shape[0], 64, generator=g).to(dev)
+    one = model.aggregator._rt.aggregator_backward(data, local, d_glob)
+    one = {k: v.clone() for k, v in one["grads"].items()} | {"d_local_embed": one["d_local_embed"].clone()}
+    many = model.aggregator._rt.aggregator_backward(data, local, d_glob * scale)
+    many = dict(many["grads"]) | {"d_local_embed": many["d_local_embed"]}
+    for k in sorted(one):
+        a, b = one[k].double() * scale, many[k].double()
+        ref = float(a.abs().max())
+        if ref < 1e-4 * scale:                       # zero-by-symmetry gradients (key biases): noise on both sides
+            continue
+        assert float((a - b).abs().max()) <= 2e-5 * ref, (k, float((a - b).abs().max()), ref)
+    d_local = torch.randn(local.shape, generator=g).to(dev)
+    e1 = model.encoder._rt.encoder_backward(data, d_local, noise, diff_weight=0.0, want_boundaries=False)
+    e1 = {k: v.clone() for k, v in e1["grads"].items()}
+    e2 = model.encoder._rt.encoder_backward(data, d_local * scale, noise, diff_weight=0.0, want_boundaries=False)["grads"]
+    for k in sorted(e1):
+        a, b = e1[k].double() * scale, e2[k].double()
+        ref = float(a.abs().max())
+        if ref < 1e-4 * scale:
+            continue
+        assert float((a - b).abs().max()) <= 2e-5 * ref, (k, float((a - b).abs().max()), ref)
