@@ -341,6 +341,42 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
         assert torch.equal(outs["split"][key], outs["one_tile"][key]), key             # two tiles per wave: the same bits
 
 
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 30.0])
+def test_sde_step_matches_float64_over_state_magnitudes(scale, dev):
+    """one Euler-Maruyama step through the C-ABI (trajsde_sde_step, the split-precision drift/diffusion MLPs) against the
+    oracle's drift/diffusion evaluated in float64, for hidden states of very different magnitude and a ragged row count:
+    the fp16 pieces of the split must not lose small states (fp16 subnormals) nor large ones"""
+    import ctypes as C
+    import restate
+    from trajsde_amd import _lib
+    from trajsde_amd.schedule import decoder_schedule
+    model, cfg = H.build_model(6, 20, 2.0, init_seed=4)
+    for p_ in model.decoder.lsde_func.parameters():                   # not the initial weights: biases are zero there
+        with torch.no_grad():
+            p_.add_(0.05 * torch.randn(p_.shape, generator=torch.Generator().manual_seed(p_.numel())))
+    model = model.to(dev)
+    rows = 16 * 7 + 5
+    g = torch.Generator().manual_seed(11)
+    y = torch.randn(rows, 64, generator=g) * scale
+    z = torch.randn(1, rows, 64, generator=g)
+    tab = np.ascontiguousarray(decoder_schedule(20, 2.0).step_table())
+    k = 3
+    t0, dt, sq, sn, cs = (float(v) for v in tab[k, :5])
+    yd, zd, out = y.to(dev), z.to(dev).contiguous(), torch.empty(rows, 64, device=dev)
+    nz = _lib.Noise(C.c_uint64(0), zd.data_ptr(), None)
+    e = tab[k].ctypes.data_as(C.POINTER(C.c_float))
+    _lib.check(_lib.lib().trajsde_sde_step(rows, model.decoder._rt.blob().data_ptr(), yd.data_ptr(), out.data_ptr(), e, 0, C.byref(nz),
+                                           torch.cuda.current_stream().cuda_stream), "trajsde_sde_step")
+    torch.cuda.synchronize()
+    P = {k_: v.detach().cpu().double() for k_, v in model.decoder.state_dict().items()}
+    y64 = y.double()
+    f = restate.drift(P, "lsde_func.f_func", y64, sn, cs)
+    gs = restate.diffusion(P, "lsde_func.g_func", y64, sn, cs)
+    want = y64 + f * dt + gs * (z[0].double() * sq)                    # SDEINT:483
+    err = float((out.cpu().double() - want).abs().max())
+    assert err <= 5e-6 * max(1.0, scale), (scale, err)
+
+
 def test_errors_are_loud(dev):
     from trajsde_amd import _lib
     from trajsde_amd.synth import synth
