@@ -76,6 +76,7 @@ def test_stages_in_isolation_match_golden(name, dev):
     (3, 40, 20, 3, 30, 3.0, dict(source=1)),
     (2, 17, 5, 2, 5, 0.5, dict(nus_sparsity=True)),
     (1, 1, 3, 2, 5, 0.5, dict()),                 # a scene with a single actor: no edges at all
+    (2, 11, 4, 20, 50, 5.0, dict(mixed_source=True)),   # the stress configuration's K=20 modes and 51 Euler steps
 ])
 def test_forward_matches_oracle_on_synthetic(S, n, L, K, T, max_t, kw, dev):
     from trajsde_amd.runtime import NoiseSpec
