@@ -132,14 +132,14 @@ __global__ __launch_bounds__(THREADS) void k_edge_kv2(const float* __restrict__ 
       f4 k[4] = {kv0[0], kv0[1], kv0[2], kv0[3]};
       f4 vv[4] = {kv0[4], kv0[5], kv0[6], kv0[7]};
       store_logits(qv, k, logits, e0, e0 < E, L, heads);
-      if (e0 < E) store_row_stream(vv, v, e0, L.g);
+      if (e0 < E) store_row(vv, v, e0, L.g);
     }
     {
       load_row(qv, q, d1, L.g);
       f4 k[4] = {kv1[0], kv1[1], kv1[2], kv1[3]};
       f4 vv[4] = {kv1[4], kv1[5], kv1[6], kv1[7]};
       store_logits(qv, k, logits, e1, e1 < E, L, heads);
-      if (e1 < E) store_row_stream(vv, v, e1, L.g);
+      if (e1 < E) store_row(vv, v, e1, L.g);
     }
   }
 }

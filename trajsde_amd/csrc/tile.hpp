@@ -462,13 +462,6 @@ __device__ __forceinline__ void store_row(const f4 (&a)[4], float* base, int64_t
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(p + 16 * jt) = a[jt];
 }
-// the same store for rows that are read exactly once by a later kernel and are far larger than the caches (the v rows of
-// the agent-agent edges): non-temporal, so they do not push the gathered q rows and the weights out of L2
-__device__ __forceinline__ void store_row_stream(const f4 (&a)[4], float* base, int64_t row, int g) {
-  float* p = base + row * D + 4 * g;
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) __builtin_nontemporal_store(a[jt], reinterpret_cast<f4*>(p + 16 * jt));
-}
 
 // Weights in LDS are loop-invariant, so LICM would hoist every fragment read out of the tile / time loops
 // and spill hundreds of VGPRs; a compiler-only memory barrier at the top of each loop body keeps the
