@@ -46,7 +46,7 @@ CPU_SAMPLE_SCENES = 16
 
 # static instruction stream of the pair edge kernel per 16-edge tile (hipcc -S of csrc/attn.hip, k_edge_kv2<768>, counted
 # over the tile loop): VALU incl. the operand splits and LayerNorms, and the 16x16x32 matrix instructions
-EDGE_TILE_VALU = {3: 640, 6: 1060}
+EDGE_TILE_VALU = {3: 552, 6: 1060}
 EDGE_TILE_MFMA = {3: 120, 6: 240}
 
 
@@ -230,7 +230,7 @@ def main():
                          "frac": achieved / PEAK_FP32_EQUIV_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": avg_s * 1e3, "launches": n_launch, "flop_per_edge": FLOP_PER_EDGE,
                          "peak_note": "algorithmic fp32 FLOP/s; the kernel is VALU/instruction-issue bound, not matrix-core bound "
-                                      "(ISA per 16-edge tile: ~640 VALU + 120 MFMA + ~76 LDS instructions with fp16x3; ~1060 + 240 + ~190 "
+                                      "(ISA per 16-edge tile: ~550 VALU + 120 MFMA + ~76 LDS instructions with fp16x3; ~1060 + 240 + ~190 "
                                       "with bf16x6, where SQ counters showed the issue port saturated and the MFMA pipe ~45 % busy); "
                                       f"peak = 2500 TFLOP/s dense 16-bit MFMA / {SPLIT_PRODUCTS} products per fp32 product "
                                       "(the same kernel on exact fp32 MFMA, TRAJSDE_EDGE_FP32=1, ran at 110-113 TFLOP/s = 0.70-0.72 of the "

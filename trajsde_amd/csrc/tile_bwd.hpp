@@ -20,7 +20,7 @@ __device__ __forceinline__ float ln_normalize(f4 (&a)[4]) {
       a[jt][c] = d;
       v += d * d;
     }
-  const float rstd = 1.0f / sqrtf(row_sum(v) * (1.0f / 64) + 1e-5f);
+  const float rstd = rsqrt_nr(row_sum(v) * (1.0f / 64) + 1e-5f);
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
