@@ -286,7 +286,7 @@ struct AggBwdWs {
     ED = c.take<float>(E * 8 + 8);
     REV = c.take<int32_t>(E + 1);
     asym = c.take<int32_t>(4);
-    float** edge[] = {&ee.S, &ee.DEP, &ee.DSP, &ee.A0, &ee.B0};
+    float** edge[] = {&ee.S, &ee.DEP, &ee.DSP};
     for (float** p : edge) *p = c.take<float>(E * 64 + 64);
     nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
     const int64_t rows = E > N ? E : N;

@@ -18,6 +18,11 @@ struct WgradJob {              // W[o*ldw + col0 + i] = sum_r delta[r*ldd + o] *
   const float *delta, *a;
   float *W, *bias;
   int ldd, lda, ldw, col0, time_cols;
+  // computed operand: when in2 is set, row r of `a` is ReLU(LN(Linear(2,64)(geom[r][pair], geom[r][pair+1]))) evaluated
+  // on the fly from the 16-byte geometry record `a + 4r` with the closed-form block `in2` (layouts.hpp In2L) and `beta`
+  // -- the activation rows of the two embedding branches are never written to or read from HBM
+  const float *in2, *beta;
+  int pair;
 };
 struct WgradJobs {
   WgradJob j[WGRAD_MAX_JOBS];
@@ -49,6 +54,7 @@ struct WgradBatch {
   WgradJobs jobs;
   WgradBatch(const WgradCtx& ctx, int64_t R_, int64_t rpg) : c(ctx), R(R_), rows_per_group(rpg) { jobs.n = 0; }
   int add(const float* delta, int ldd, const float* a, int lda, float* W, int ldw, int col0, float* bias, int time_cols);
+  int add_in2(const float* delta, int ldd, const float* geom, int pair, const float* in2, const float* beta, float* W, int ldw, float* bias);
   int flush();
 };
 // W[o*ldw + col0 + i] = sum_r delta[r*ldd + o] * a[r*lda + i]  (o, i < 64);  bias[o] = sum_r delta[r*ldd + o] (or null)
@@ -89,7 +95,7 @@ int ffn_block_backward(const float* img_a /*FfnBwdAL*/, const float* img_b /*Ffn
                        const float* dout, int64_t R, const NodeBlockScratch& sc, const WgradCtx& wc, const NodeBlockGrads& gr,
                        hipStream_t st);
 
-struct EdgeEmbedScratch { float *S, *DEP, *DSP, *A0, *B0, *vpart; };             // [E,64] x5
+struct EdgeEmbedScratch { float *S, *DEP, *DSP, *vpart; };                       // [E,64] x3
 struct EdgeEmbedGrads {
   float *a_w0, *a_b0, *a_g, *a_e, *b_w0, *b_b0, *b_g, *b_e, *wa3, *ba3, *wb3, *bb3, *ag0, *ae0, *w2, *b2, *ag3, *ae3;
 };

@@ -453,8 +453,10 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradJobs jobs, int64_t R, int64_
   constexpr int RS = 80;
   float* ds_ = dyn;                       // [64][RS]   (the staging area is reused for the cross-wave reduction below)
   float* as_ = dyn + 64 * RS;             // [64][RS]
-  for (int64_t blk = row0; blk < row1; blk += 64) {
-    __syncthreads();
+  // software pipeline: the global loads (or the computed operand) of block k+1 are issued before the matrix work of block
+  // k, so their latency hides behind it; registers -> LDS happens after the barrier that retires block k's reads
+  f4 dreg[4], areg[4];
+  auto fetch = [&](int64_t blk) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int f = threadIdx.x + 256 * u;            // float4 index within the 64 x 16 block
@@ -463,12 +465,31 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradJobs jobs, int64_t R, int64_
       f4 dv = f4{0.f, 0.f, 0.f, 0.f}, av = dv;
       if (row < row1) {
         dv = *reinterpret_cast<const f4*>(delta + row * ldd + 4 * c4);
-        av = *reinterpret_cast<const f4*>(a + row * lda + 4 * c4);
+        if (job.in2 != nullptr) {                       // computed operand (uniform per launch slice: blockIdx.y)
+          const f4 ge = *reinterpret_cast<const f4*>(a + row * 4);
+          const float x0 = job.pair ? ge[2] : ge[0], x1 = job.pair ? ge[3] : ge[1];
+          const float rstd = in2_rstd(x0, x1, job.in2);
+          av = in2_ln_relu4(x0 * rstd, x1 * rstd, rstd, job.in2, job.beta, 4 * c4);
+        } else {
+          av = *reinterpret_cast<const f4*>(a + row * lda + 4 * c4);
+        }
       }
-      *reinterpret_cast<f4*>(ds_ + r * RS + 4 * c4) = dv;
-      *reinterpret_cast<f4*>(as_ + r * RS + 4 * c4) = av;
+      dreg[u] = dv;
+      areg[u] = av;
+    }
+  };
+  if (row0 < row1) fetch(row0);
+  for (int64_t blk = row0; blk < row1; blk += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = threadIdx.x + 256 * u;
+      const int r = f >> 4, c4 = f & 15;
+      *reinterpret_cast<f4*>(ds_ + r * RS + 4 * c4) = dreg[u];
+      *reinterpret_cast<f4*>(as_ + r * RS + 4 * c4) = areg[u];
     }
     __syncthreads();
+    if (blk + 64 < row1) fetch(blk + 64);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const int r = 4 * (wave + 4 * s4) + kg;
@@ -598,7 +619,14 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, 
 int WgradBatch::add(const float* delta, int ldd, const float* a, int lda, float* W, int ldw, int col0, float* bias, int time_cols) {
   if (jobs.n == WGRAD_MAX_JOBS)
     if (int rc = flush()) return rc;
-  jobs.j[jobs.n++] = WgradJob{delta, a, W, bias, ldd, lda, ldw, col0, time_cols};
+  jobs.j[jobs.n++] = WgradJob{delta, a, W, bias, ldd, lda, ldw, col0, time_cols, nullptr, nullptr, 0};
+  return TRAJSDE_OK;
+}
+int WgradBatch::add_in2(const float* delta, int ldd, const float* geom, int pair, const float* in2, const float* beta, float* W, int ldw,
+                        float* bias) {
+  if (jobs.n == WGRAD_MAX_JOBS)
+    if (int rc = flush()) return rc;
+  jobs.j[jobs.n++] = WgradJob{delta, geom, W, bias, ldd, 4, ldw, 0, 0, in2, beta, pair};
   return TRAJSDE_OK;
 }
 

@@ -645,7 +645,7 @@ struct EncBwdWs {
     al_logits = c.take<float>(Ela * 8 + 8);
     al_v = c.take<float>(Ela * 64 + 64);
     DLG = c.take<float>(E * 8);
-    float** rows_E[] = {&DV, &EMB, &DK, &DQE, &DEMB, &ee.S, &ee.DEP, &ee.DSP, &ee.A0, &ee.B0};
+    float** rows_E[] = {&DV, &EMB, &DK, &DQE, &DEMB, &ee.S, &ee.DEP, &ee.DSP};
     for (float** p : rows_E) *p = c.take<float>(E * 64);
     nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
     const int64_t rows = E > R ? E : R;

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256) void k_lin_t_acc(const float* __restrict__ wt,
 // ------------------------------------------------------------------ MultipleInputEmbedding backward (EMB:62-70)
 // forward: a0 = relu(LN(A_W0 in0 + b)), b0 likewise from in1; sp = WA3 a0 + WB3 b0 + b3; s = relu(LN0(sp));
 //          ep = W2 s + b2; emb = LN3(ep).
-// tail: given demb rows -> saves S (= s), DEP (d ep), DSP (d sp), A0, B0 (branch activations); per-wave vectors
+// tail: given demb rows -> saves S (= s), DEP (d ep), DSP (d sp) (the branch activations a0, b0 are recomputed from the
+//       geometry by the weight-gradient kernel: WgradBatch::add_in2); per-wave vectors
 //       (dgamma3 | dbeta3 | dgamma0 | dbeta0) -> vpart[wave][256]
 __device__ __forceinline__ void branch_fwd(f4 (&xh)[4], f4 (&act)[4], float& rstd, float i0, float i1, const float* w0,
                                            const float* b0, const float* gam, const float* bet, const Lane& L) {
@@ -245,7 +246,6 @@ __device__ __forceinline__ void branch_fwd(f4 (&xh)[4], f4 (&act)[4], float& rst
 __global__ __launch_bounds__(256) void k_edge_embed_bwd_tail(const float* __restrict__ img, const float* __restrict__ geom,
                                                              const float* __restrict__ demb, int64_t E, float* __restrict__ S,
                                                              float* __restrict__ DEP, float* __restrict__ DSP,
-                                                             float* __restrict__ A0, float* __restrict__ B0,
                                                              float* __restrict__ vpart) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, img, EdgeBwdL::WA3T);                   // forward image + W2^T
@@ -296,8 +296,6 @@ __global__ __launch_bounds__(256) void k_edge_embed_bwd_tail(const float* __rest
       store_row(s, S, e, L.g);
       store_row(d, DEP, e, L.g);
       store_row(t, DSP, e, L.g);
-      store_row(a0, A0, e, L.g);
-      store_row(b0, B0, e, L.g);
     }
   }
   float* vp = vpart + int64_t(blockIdx.x * waves + wave) * 256;
@@ -427,15 +425,15 @@ int edge_embed_backward(const float* img, const float* geom, const float* demb, 
   const int64_t ntiles = (E + 15) / 16;
   const int lds_tail = EdgeBwdL::WA3T * 4, lds_br = (EdgeL::WA3 + MAT64) * 4;
   const int gt = vec_grid(ntiles, 256, lds_tail), gb = vec_grid(ntiles, 256, lds_br);
-  TS_LAUNCH(k_edge_embed_bwd_tail, gt, 256, lds_tail, st, img, geom, demb, E, sc.S, sc.DEP, sc.DSP, sc.A0, sc.B0, sc.vpart);
+  TS_LAUNCH(k_edge_embed_bwd_tail, gt, 256, lds_tail, st, img, geom, demb, E, sc.S, sc.DEP, sc.DSP, sc.vpart);
   float* const tail_vec[4] = {gr.ag3, gr.ae3, gr.ag0, gr.ae0};
   for (int i = 0; i < 4; ++i)
     if (int rc = run_colsum(st, sc.vpart + 64 * i, gt * 4, 256, 64, tail_vec[i])) return rc;
   {
     WgradBatch wb(wc, E, E);
     if (int rc = wb.add(sc.DEP, 64, sc.S, 64, gr.w2, 64, 0, gr.b2, 0)) return rc;
-    if (int rc = wb.add(sc.DSP, 64, sc.A0, 64, gr.wa3, 64, 0, gr.ba3, 0)) return rc;
-    if (int rc = wb.add(sc.DSP, 64, sc.B0, 64, gr.wb3, 64, 0, gr.bb3, 0)) return rc;
+    if (int rc = wb.add_in2(sc.DSP, 64, geom, 0, img + EdgeL6::A_C, img + EdgeL6::A_E, gr.wa3, 64, gr.ba3)) return rc;
+    if (int rc = wb.add_in2(sc.DSP, 64, geom, 1, img + EdgeL6::B_C, img + EdgeL6::B_E, gr.wb3, 64, gr.bb3)) return rc;
     if (int rc = wb.flush()) return rc;
   }
   for (int br = 0; br < 2; ++br) {

@@ -443,20 +443,26 @@ __device__ __forceinline__ void linear_in2(f4 (&out)[4], float x0, float x1, con
 
 // ReLU(LayerNorm(Linear(2,64)(x))) with the LayerNorm statistics in closed form (layouts.hpp In2L; pack.hip PK_LN2):
 // 3 fma + 1 max per element instead of 2 fma for the layer, two row reductions and 3 more per element for the LayerNorm.
-__device__ __forceinline__ void in2_ln_relu(f4 (&out)[4], float x0, float x1, const float* c, const float* beta, int g) {
+// rstd of the layer's LayerNorm for inputs (x0, x1): var = |L^T (x0, x1, 1)|^2
+__device__ __forceinline__ float in2_rstd(float x0, float x1, const float* c) {
   const f4 ch0 = *reinterpret_cast<const f4*>(c + 192), ch1 = *reinterpret_cast<const f4*>(c + 196);
   const float a = fmaf(ch0[0], x0, fmaf(ch0[1], x1, ch0[2])), b = fmaf(ch0[3], x1, ch1[0]);
-  const float var = fmaf(a, a, fmaf(b, b, ch1[1] * ch1[1]));
-  const float rstd = rsqrt_nr(var + 1e-5f);
+  return rsqrt_nr(fmaf(a, a, fmaf(b, b, ch1[1] * ch1[1])) + 1e-5f);
+}
+// features f0 .. f0+3 of ReLU(LayerNorm(Linear(2,64)(x))), given x * rstd and rstd
+__device__ __forceinline__ f4 in2_ln_relu4(float x0r, float x1r, float rstd, const float* c, const float* beta, int f0) {
+  const f4 w0 = *reinterpret_cast<const f4*>(c + f0), w1 = *reinterpret_cast<const f4*>(c + 64 + f0);
+  const f4 gb = *reinterpret_cast<const f4*>(c + 128 + f0), be = *reinterpret_cast<const f4*>(beta + f0);
+  f4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = fmaxf(fmaf(w0[k], x0r, fmaf(w1[k], x1r, fmaf(gb[k], rstd, be[k]))), 0.f);
+  return o;
+}
+__device__ __forceinline__ void in2_ln_relu(f4 (&out)[4], float x0, float x1, const float* c, const float* beta, int g) {
+  const float rstd = in2_rstd(x0, x1, c);
   const float x0r = x0 * rstd, x1r = x1 * rstd;
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    const int f0 = 16 * jt + 4 * g;
-    const f4 w0 = *reinterpret_cast<const f4*>(c + f0), w1 = *reinterpret_cast<const f4*>(c + 64 + f0);
-    const f4 gb = *reinterpret_cast<const f4*>(c + 128 + f0), be = *reinterpret_cast<const f4*>(beta + f0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[jt][k] = fmaxf(fmaf(w0[k], x0r, fmaf(w1[k], x1r, fmaf(gb[k], rstd, be[k]))), 0.f);
-  }
+  for (int jt = 0; jt < 4; ++jt) out[jt] = in2_ln_relu4(x0r, x1r, rstd, c, beta, 16 * jt + 4 * g);
 }
 
 // ---------------------------------------------------------------- HBM <-> activation tiles ([rows][64] fp32)
