@@ -1,0 +1,105 @@
+"""Generate tests/golden_train/*.npz: the REFERENCE's own training loss and parameter gradients on small synthetic batches.
+
+    python oracle/make_golden_train.py            # build container only (needs /root/reference)
+
+The reference model (imported from /root/reference over oracle/shims, our state_dict loaded key for key) runs its
+`forward` with injected noise, its own loss modules (`losses/L2.py`, `losses/diff_BCE.py`, weighted as
+`training_step` does, `models/model_base_mix_sde.py:104-111`) and torch.autograd.  Dropout is switched off
+(`model.eval()`, which changes nothing else: the path has no BatchNorm): the MI355X path differentiates the network
+without dropout, so that is the function both sides are compared on.
+
+A fixture holds data only: the batch, the init / noise seeds, the two loss values, and every parameter gradient.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path[:0] = [ROOT, HERE]
+
+import ref_loader as R                                        # noqa: E402
+from make_golden import our_cfg, philox_noise, state_checksum  # noqa: E402
+from trajsde_amd.models.model_base_mix_sde import PredictionModelSDENet  # noqa: E402
+from trajsde_amd.schedule import decoder_schedule            # noqa: E402
+from trajsde_amd.synth import synth                          # noqa: E402
+
+CASES = {
+    # name: (synth kwargs, num_modes, future_steps, max_fut_t, init_seed, noise_seed, full)
+    # last field: store every gradient tensor (True) or a digest per tensor (False) -- keeps the fixtures small
+    "train_mixed_k3_t5": (dict(S=3, n=9, L=5, F=5, box=70.0, seed=21, mixed_source=True, history_dropout=0.3), 3, 5, 0.5, 5, 201, True),
+    "train_argo_k6_t30": (dict(S=2, n=7, L=6, F=30, box=90.0, seed=22, source=1, history_dropout=0.2), 6, 30, 3.0, 6, 202, False),
+}
+
+
+def digest_signs(key, n):
+    """the +-1 vector a gradient digest is projected on: seeded by the parameter name, shared with the tests"""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(key.encode()))
+    return (torch.randint(0, 2, (n,), generator=g) * 2 - 1).double()
+
+
+def make(name):
+    skw, K, T, max_t, init_seed, noise_seed, full = CASES[name]
+    batch = synth(**skw)
+    ours = PredictionModelSDENet(**our_cfg(K, T, max_t), init_seed=init_seed)
+    g = torch.Generator().manual_seed(1000 + init_seed)
+    with torch.no_grad():                                     # leave the initial point: zero biases hide bias-gradient bugs
+        for p in ours.parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn(p.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in ours.state_dict().items()}
+    ref = R.build_reference_model(R.load_reference_cfg(num_modes=K, future_steps=T, max_fut_t=max_t))
+    ref.load_state_dict(sd)
+    ref.eval()                                                # dropout off (see the module docstring)
+    # (a float64 run of the reference is not the same function: the solver's time bookkeeping is float32 arithmetic and
+    # takes a different number of Euler steps in double, SURVEY App. D -- so the fixture is the reference's float32
+    # autograd result, whose own rounding noise on the ill-conditioned encoder gradients is ~1e-3 for T=30)
+    N, A = batch.num_nodes, batch["agent_index"].numel()
+    sched = decoder_schedule(T, max_t)
+    z_fake, z_enc, z_dec = philox_noise(noise_seed, A, N + A, K * N, sched.n_euler)
+    replay = [torch.from_numpy(z_fake)] + [torch.from_numpy(z) for z in z_enc] + [torch.from_numpy(z) for z in z_dec]
+
+    R._install_paths()
+    from noise_source import SOURCE
+    SOURCE.reset(seed=None, replay=replay)
+    data = R.to_reference_data(batch)
+    with R.reference_cwd(), R.injected_randn_like(), torch.enable_grad():
+        out = ref(data)
+        parts = [fn(data, out) for fn in ref.losses]                                  # MODEL:108-110
+        loss = sum(w * l for w, l in zip(ref.loss_weights, parts))
+        loss.backward()
+    assert len(SOURCE.record) == 1 + 21 + sched.n_euler
+    fx = {f"in.{k}": v.numpy() for k, v in batch.as_dict().items() if torch.is_tensor(v)}
+    fx["meta.num_modes"], fx["meta.future_steps"], fx["meta.max_fut_t"] = K, T, max_t
+    fx["meta.init_seed"], fx["meta.noise_seed"], fx["meta.perturb_seed"] = init_seed, noise_seed, 1000 + init_seed
+    fx["meta.state_checksum"] = state_checksum(sd)
+    for nm, w, l in zip(ref.loss_names, ref.loss_weights, parts):
+        fx[f"loss.{nm}"] = np.float64(float(l))
+        fx[f"weight.{nm}"] = np.float64(float(w))
+    fx["loss.total"] = np.float64(float(loss))
+    n_grad = 0
+    for k, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        gr = p.grad.detach().double().reshape(-1)
+        n_grad += 1
+        if full:
+            fx[f"grad.{k}"] = p.grad.detach().numpy().astype(np.float32)
+        else:                                                 # digest: norm, a seeded +-1 projection, the leading entries
+            fx[f"digest.{k}"] = np.array([float(gr.norm()), float((gr * digest_signs(k, gr.numel())).sum())] +
+                                         gr[:30].tolist(), dtype=np.float64)
+    path = os.path.join(ROOT, "tests", "golden_train", name + ".npz")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez_compressed(path, **fx)
+    print(f"{name}: N={N} K={K} T={T} losses={[(n, round(float(l), 6)) for n, l in zip(ref.loss_names, parts)]} "
+          f"grads={n_grad} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    if not R.reference_available():
+        sys.exit("reference tree not found; golden vectors can only be generated in the build container")
+    for name in (sys.argv[1:] or list(CASES)):
+        make(name)

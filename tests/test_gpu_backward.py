@@ -267,50 +267,7 @@ def test_decoder_backward_is_deterministic_and_checks_arguments(dev):
         model.decoder._rt.decoder_l2_backward(data, local, glob, out, noise)
 
 
-def _oracle_full_grads(model, cfg, batch_cpu, seed, w_l2, w_diff):
-    """end-to-end autograd over the oracle (float64): encoder -> aggregator -> decoder -> w_l2 L2 + w_diff DiffBCE"""
-    import restate
-    import torch.nn.functional as F
-    from trajsde_amd.schedule import decoder_schedule, encoder_schedule
-    c = restate.flat_cfg(cfg)
-    es = encoder_schedule(c["historical_steps"], c["max_past_t"], c["minimum_step"])
-    ds = decoder_schedule(c["future_steps"], c["max_fut_t"], c["min_stepsize"])
-    dt = torch.float64
-    P = {k: (v.detach().cpu().to(dt) if v.is_floating_point() else v.detach().cpu().clone()) for k, v in model.state_dict().items()}
-    names = [k for k in P if P[k].is_floating_point()]
-    for k in names:
-        P[k].requires_grad_(True)
-    b = H.clone_batch(batch_cpu)
-    for k in b.keys:
-        if torch.is_tensor(b[k]) and b[k].is_floating_point():
-            b[k] = b[k].to(dt)
-
-    class Noise64(restate.PhiloxNoise):
-        def fake_agent(self, shape):
-            return super().fake_agent(shape).to(dt)
-
-        def encoder(self, idx, shape):
-            return super().encoder(idx, shape).to(dt)
-
-        def decoder(self, k, shape):
-            return super().decoder(k, shape).to(dt)
-
-    torch.set_default_dtype(dt)
-    try:
-        rot, y_rot = restate.rotate_inputs(b)
-        noise = Noise64(seed)
-        with torch.enable_grad():
-            local, diff_in, diff_out, _ = restate.local_encoder(P, c, b, rot, noise, es, False)
-            glob = restate.global_interactor(P, c, b, rot, local)
-            out = restate.sde_decoder(P, c, b, local, glob, noise, ds)
-            l2, _ = _reference_l2(y_rot, out["loc"][..., :2], out["reg_mask"])
-            bce = (F.binary_cross_entropy(diff_in, torch.zeros_like(diff_in)) +
-                   F.binary_cross_entropy(diff_out, torch.ones_like(diff_out)))
-            loss = w_l2 * l2 + w_diff * bce
-            loss.backward()
-    finally:
-        torch.set_default_dtype(torch.float32)
-    return float(loss.detach()), {k: P[k].grad for k in names}
+_oracle_full_grads = H.oracle_full_grads
 
 
 def test_training_step_gradients_match_end_to_end_autograd(dev):
@@ -493,3 +450,24 @@ def test_backward_is_linear_in_the_upstream_gradient_over_many_binades(scale, de
         if ref < 1e-4 * scale:
             continue
         assert float((a - b).abs().max()) <= 2e-5 * ref, (k, float((a - b).abs().max()), ref)
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in
+                                        __import__("glob").glob(os.path.join(H.ROOT, "tests", "golden_train", "*.npz"))))
+def test_training_step_matches_the_reference_training_step(name, dev):
+    """loss and every parameter gradient of the HIP training step against what the REFERENCE's own model, loss modules and
+    torch.autograd produced for the same weights, batch and injected noise (tests/golden_train, dropout off)"""
+    from trajsde_amd import runtime
+    batch, meta, losses, weights, grads, digests = H.load_train_fixture(name)
+    model, cfg = H.build_model(int(meta["num_modes"]), int(meta["future_steps"]), float(meta["max_fut_t"]), init_seed=int(meta["init_seed"]))
+    H.perturb_parameters(model, int(meta["perturb_seed"]))
+    assert abs(H.state_checksum(model.state_dict()) - meta["state_checksum"]) <= 1e-6 * meta["state_checksum"]
+    model.loss_weights = [weights["L2"], weights["DiffBCE"]]
+    model = model.to(dev).train()
+    loss = model.training_step(batch.to(dev), 0, noise=runtime.NoiseSpec(seed=int(meta["noise_seed"])))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - losses["total"]) <= 1e-5 * max(1.0, abs(losses["total"]))
+    got = {n: p.grad for n, p in model.named_parameters()}
+    bad = H.check_grads_against_train_fixture(got, grads, digests, rel=REL if grads else 2e-3)
+    assert not bad, bad[:8]

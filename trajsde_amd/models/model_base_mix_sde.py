@@ -165,6 +165,14 @@ class PredictionModelSDENet(nn.Module):
             raise NotImplementedError(f"training_step differentiates L2 (+ DiffBCE) through the HIP kernels; configured: {self.loss_names}")
         if data.y is None:
             raise ValueError("training_step needs targets (data.y)")
+        if not getattr(self, "_dropout_warned", False):
+            self._dropout_warned = True
+            p_drop = max(float(getattr(m, "dropout", 0.0) or 0.0) for m in (self.encoder, self.aggregator))
+            if p_drop > 0:
+                import warnings
+                warnings.warn(f"dropout={p_drop} of the YAML is accepted but NOT applied: the HIP training step differentiates the "
+                              "network without dropout (the reference applies it to attention weights, projections and the FFNs "
+                              "in train mode, ENC:538-614, AGG:92-135); DESIGN.md section 7")
         noise = runtime.NoiseSpec.resolve(noise)
         if not hasattr(self, "_param_names"):
             self._param_names = [n for n, _ in self.named_parameters()]
