@@ -82,3 +82,21 @@ def test_oracle_is_invariant_to_edge_order():
     b2["edge_index"] = batch["edge_index"][:, torch.randperm(batch["edge_index"].shape[1], generator=g)]
     o2 = H.oracle_forward(model, cfg, b2, 101, want_intermediates=False)
     assert H.maxdiff(o2["loc"], o["loc"]) < 1e-4
+
+
+def test_metrics_match_the_reference_metric_classes():
+    """trajsde_amd.metrics against values produced by the reference's own ADE_T / FDE_T / MR_T classes
+    (tests/golden_metrics/metrics.npz, oracle/make_golden_metrics.py): both `dataset` switches, two accumulated updates,
+    mixed sources, agents without valid steps, masked end indices"""
+    import os
+    import numpy as np
+    from trajsde_amd import metrics as M
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_metrics", "metrics.npz"))
+    batches = [[torch.from_numpy(z[f"in{i}.{k}"]) for k in ("pred", "target", "mask", "source")] for i in range(2)]
+    for ds in ("nuScenes", "Argoverse"):
+        for cls in ("ADE_T", "FDE_T", "MR_T"):
+            m = getattr(M, cls)(dataset=ds, end_idcs=[59, 29], sources=[0, 1])
+            m.update(*batches[0])
+            assert abs(float(m.compute()) - float(z[f"out.{ds}.{cls}.after1"])) <= 2e-6, (ds, cls, 1)
+            m.update(*batches[1])
+            assert abs(float(m.compute()) - float(z[f"out.{ds}.{cls}.after2"])) <= 2e-6, (ds, cls, 2)

@@ -58,9 +58,10 @@ class ADE_T(_MinOverModes):
         if self.dataset == "nuScenes":
             best = ade.argmin(0)
         elif self.dataset == "Argoverse":
+            # the reference picks the mode on the MASKED distances (ade_t.py:45,58: l2[:, ~reg_mask] = 0 comes first), so an
+            # agent whose end step is invalid sees fde = 0 for every mode and keeps mode 0
             end = self._end_index(source, l2.size(-1))
-            fde = torch.norm(pred - target.unsqueeze(0), p=2, dim=-1).gather(
-                2, end.view(1, -1, 1).expand(l2.size(0), -1, 1)).squeeze(-1)
+            fde = l2.gather(2, end.view(1, -1, 1).expand(l2.size(0), -1, 1)).squeeze(-1)
             best = fde.argmin(0)
         else:
             raise NotImplementedError("other dataset is not implemented")
