@@ -98,8 +98,68 @@ def make(name):
           f"grads={n_grad} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+GRID_CASES = {
+    # name: (synth kwargs, num_modes, future_steps, num_heads, temporal layers, init_seed)
+    "train_grid_k3_t12_h4": (dict(S=3, n=9, L=6, F=12, box=70.0, seed=23, mixed_source=True, history_dropout=0.3), 3, 12, 4, 2, 7),
+}
+
+
+def make_grid(name):
+    """the vanilla HiVT variant (models/model_base_mix.py PredictionModel, L2 only): deterministic, so the reference's float32
+    autograd is a clean yardstick; stored as per-tensor digests"""
+    import yaml
+    import make_golden_grid as G
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    skw, K, T, heads, layers, init_seed = GRID_CASES[name]
+    batch = synth(**skw)
+    with open(os.path.join(ROOT, "trajsde_amd/configs/mi355x_trmenc_mlpdec.yml")) as f:
+        ours_cfg = G.edit(yaml.safe_load(f), K, T, heads, layers)
+    ours = PredictionModel(**ours_cfg, init_seed=init_seed)
+    g = torch.Generator().manual_seed(1000 + init_seed)
+    with torch.no_grad():
+        for p in ours.parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn(p.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in ours.state_dict().items()}
+    with open(os.path.join(R.REFERENCE_ROOT, G.REF_CFG)) as f:
+        ref_cfg = G.edit(yaml.safe_load(f), K, T, heads, layers)
+    ref = R.build_reference_model(ref_cfg)
+    ref.load_state_dict(sd)
+    ref.eval()                                                # dropout off
+    data = R.to_reference_data(batch)
+    stock = torch.nn.TransformerEncoder.forward
+    torch.nn.TransformerEncoder.forward = G.torch1_transformer_encoder_forward
+    try:
+        with R.reference_cwd(), torch.enable_grad():
+            out = ref(data)
+            parts = [fn(data, out) for fn in ref.losses]
+            loss = sum(w * l for w, l in zip(ref.loss_weights, parts))
+            loss.backward()
+    finally:
+        torch.nn.TransformerEncoder.forward = stock
+    fx = {f"in.{k}": v.numpy() for k, v in batch.as_dict().items() if torch.is_tensor(v)}
+    fx.update({"meta.num_modes": K, "meta.future_steps": T, "meta.num_heads": heads, "meta.num_temporal_layers": layers,
+               "meta.init_seed": init_seed, "meta.perturb_seed": 1000 + init_seed, "meta.state_checksum": G.state_checksum(sd)})
+    for nm, w, l in zip(ref.loss_names, ref.loss_weights, parts):
+        fx[f"loss.{nm}"] = np.float64(float(l))
+        fx[f"weight.{nm}"] = np.float64(float(w))
+    fx["loss.total"] = np.float64(float(loss))
+    n_grad = 0
+    for k, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        gr = p.grad.detach().double().reshape(-1)
+        n_grad += 1
+        fx[f"digest.{k}"] = np.array([float(gr.norm()), float((gr * digest_signs(k, gr.numel())).sum())] + gr[:30].tolist(),
+                                     dtype=np.float64)
+    path = os.path.join(ROOT, "tests", "golden_train", name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"{name}: N={batch.num_nodes} K={K} T={T} losses={[(n, round(float(l), 6)) for n, l in zip(ref.loss_names, parts)]} "
+          f"grads={n_grad} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
     if not R.reference_available():
         sys.exit("reference tree not found; golden vectors can only be generated in the build container")
-    for name in (sys.argv[1:] or list(CASES)):
-        make(name)
+    for name in (sys.argv[1:] or list(CASES) + list(GRID_CASES)):
+        make_grid(name) if name in GRID_CASES else make(name)

@@ -186,3 +186,44 @@ def check_grads_against_train_fixture(got, grads, digests, rel):
         if float((gd[:m] - lead[:m]).abs().max()) > r * max(float(lead[:m].abs().max()), norm) + 1e-7:
             bad.append((k, "lead", float((gd[:m] - lead[:m]).abs().max())))
     return bad
+
+
+def grid_cfg(K, T, heads, layers):
+    with open(os.path.join(ROOT, "trajsde_amd/configs/mi355x_trmenc_mlpdec.yml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)
+    cfg["encoder"]["kwargs"].update(num_heads=heads, num_temporal_layers=layers)
+    cfg["aggregator"]["kwargs"].update(num_modes=K, num_heads=heads)
+    cfg["decoder"]["kwargs"].update(num_modes=K, future_steps=T)
+    return cfg
+
+
+def oracle_grid_full_grads(model, cfg, batch_cpu, d_local=None):
+    """float64 autograd over oracle/restate_grid.py: whole model under L2, or the encoder alone under sum(local * d_local)"""
+    import restate
+    import restate_grid
+    c = restate_grid.flat_cfg(cfg)
+    dt = torch.float64
+    P = {k: (v.detach().cpu().to(dt) if v.is_floating_point() else v.detach().cpu().clone()) for k, v in model.state_dict().items()}
+    names = [k for k in P if P[k].is_floating_point() and not k.endswith("attn_mask")]
+    for k in names:
+        P[k].requires_grad_(True)
+    b = clone_batch(batch_cpu)
+    for k in b.keys:
+        if torch.is_tensor(b[k]) and b[k].is_floating_point():
+            b[k] = b[k].to(dt)
+    torch.set_default_dtype(dt)
+    try:
+        rot, y_rot = restate.rotate_inputs(b)
+        with torch.enable_grad():
+            local = restate_grid.local_encoder_grid(P, c, b, rot)
+            if d_local is not None:
+                loss = (local * d_local.cpu().to(dt)).sum()
+            else:
+                glob = restate.global_interactor(P, c, b, rot, local)
+                out = restate_grid.mlp_decoder(P, c, b, local, glob)
+                loss, _ = reference_l2(y_rot, out["loc"][..., :2], out["reg_mask"])
+            loss.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return float(loss.detach()), {k: P[k].grad for k in names}

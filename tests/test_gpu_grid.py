@@ -137,35 +137,7 @@ def test_mlp_decoder_l2_backward_matches_autograd(S, n, K, T, dev):
         assert float((a.cpu() - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7
 
 
-def _oracle_full(model, cfg, batch_cpu, d_local=None):
-    """float64 autograd over oracle/restate_grid.py: whole model under L2, or the encoder alone under sum(local * d_local)"""
-    import restate
-    import restate_grid
-    c = restate_grid.flat_cfg(cfg)
-    dt = torch.float64
-    P = {k: (v.detach().cpu().to(dt) if v.is_floating_point() else v.detach().cpu().clone()) for k, v in model.state_dict().items()}
-    names = [k for k in P if P[k].is_floating_point() and not k.endswith("attn_mask")]
-    for k in names:
-        P[k].requires_grad_(True)
-    b = H.clone_batch(batch_cpu)
-    for k in b.keys:
-        if torch.is_tensor(b[k]) and b[k].is_floating_point():
-            b[k] = b[k].to(dt)
-    torch.set_default_dtype(dt)
-    try:
-        rot, y_rot = restate.rotate_inputs(b)
-        with torch.enable_grad():
-            local = restate_grid.local_encoder_grid(P, c, b, rot)
-            if d_local is not None:
-                loss = (local * d_local.cpu().to(dt)).sum()
-            else:
-                glob = restate.global_interactor(P, c, b, rot, local)
-                out = restate_grid.mlp_decoder(P, c, b, local, glob)
-                loss, _ = _l2(y_rot, out["loc"][..., :2], out["reg_mask"])
-            loss.backward()
-    finally:
-        torch.set_default_dtype(torch.float32)
-    return float(loss.detach()), {k: P[k].grad for k in names}
+_oracle_full = H.oracle_grid_full_grads
 
 
 def _compare(named_grads, want, prefix=""):
@@ -233,3 +205,20 @@ def test_vanilla_training_step_matches_end_to_end_autograd_and_trains(dev):
             yield data
     hist = driver.train(model, fresh, epochs=2)
     assert len(hist) == 12 and sum(hist[-3:]) < sum(hist[:3]), hist
+
+
+def test_vanilla_training_step_matches_the_reference_training_step(dev):
+    """loss and parameter-gradient digests of the HIP training step of the vanilla variant against the REFERENCE's own model
+    (models/model_base_mix.py), L2 module and torch.autograd (tests/golden_train/train_grid_*.npz, dropout off)"""
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    batch, meta, losses, weights, grads, digests = H.load_train_fixture("train_grid_k3_t12_h4")
+    cfg = _cfg(int(meta["num_modes"]), int(meta["future_steps"]), int(meta["num_heads"]), int(meta["num_temporal_layers"]))
+    model = PredictionModel(**cfg, init_seed=int(meta["init_seed"]))
+    H.perturb_parameters(model, int(meta["perturb_seed"]))
+    model = model.to(dev).train()
+    loss = model.training_step(batch.to(dev), 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - losses["total"]) <= 1e-5 * max(1.0, abs(losses["total"]))
+    bad = H.check_grads_against_train_fixture({n: p.grad for n, p in model.named_parameters()}, grads, digests, rel=2e-4)
+    assert not bad, bad[:8]
