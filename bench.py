@@ -229,7 +229,7 @@ def main():
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_EQUIV_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_EQUIV_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": avg_s * 1e3, "launches": n_launch, "flop_per_edge": FLOP_PER_EDGE,
-                         "peak_note": "algorithmic fp32 FLOP/s; the kernel is VALU/instruction-issue bound, not matrix-core bound "
+                         "peak_note": "algorithmic fp32 FLOP/s; the kernel is bound by VALU issue and LDS fragment reads, not by the matrix cores "
                                       "(ISA per 16-edge tile: ~550 VALU + 120 MFMA + ~76 LDS instructions with fp16x3; ~1060 + 240 + ~190 "
                                       "with bf16x6, where SQ counters showed the issue port saturated and the MFMA pipe ~45 % busy); "
                                       f"peak = 2500 TFLOP/s dense 16-bit MFMA / {SPLIT_PRODUCTS} products per fp32 product "
