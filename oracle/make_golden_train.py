@@ -31,6 +31,9 @@ CASES = {
     # last field: store every gradient tensor (True) or a digest per tensor (False) -- keeps the fixtures small
     "train_mixed_k3_t5": (dict(S=3, n=9, L=5, F=5, box=70.0, seed=21, mixed_source=True, history_dropout=0.3), 3, 5, 0.5, 5, 201, True),
     "train_argo_k6_t30": (dict(S=2, n=7, L=6, F=30, box=90.0, seed=22, source=1, history_dropout=0.2), 6, 30, 3.0, 6, 202, False),
+    # BASELINE configs[3]: the shipped training shape (K=10 modes, T=60 future steps = 61 Euler steps, mixed sources; CFG:9-22)
+    "train_shipped_k10_t60": (dict(S=4, n=6, L=5, F=60, box=80.0, seed=24, mixed_source=True, history_dropout=0.3, nus_sparsity=False),
+                              10, 60, 6.0, 8, 204, False),
 }
 
 

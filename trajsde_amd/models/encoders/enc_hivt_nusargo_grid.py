@@ -31,7 +31,8 @@ class LocalEncoder(ParamTree):
         t = "temporal_encoder"
         for i in range(self.num_temporal_layers):
             l = f"{t}.transformer_encoder.layers.{i}"
-            self.add_param(f"{l}.self_attn.in_proj_weight", self._uniform((3 * d, d), (6.0 / (4 * d)) ** 0.5))
+            # init_weights' nn.MultiheadAttention branch (UTIL:114-120): fan_in = fan_out = embed_dim, not the [3d, d] shape
+            self.add_param(f"{l}.self_attn.in_proj_weight", self._uniform((3 * d, d), (6.0 / (2 * d)) ** 0.5))
             self.add_param(f"{l}.self_attn.in_proj_bias", torch.zeros(3 * d))
             self.linear(f"{l}.self_attn.out_proj", d, d)
             self.linear(f"{l}.linear1", 4 * d, d)

@@ -40,8 +40,10 @@ class LocalEncoderSDESepPara2(ParamTree):
         for name, rows in (("is_intersection_embed", 2), ("turn_direction_embed", 3), ("traffic_control_embed", 2)):
             self.token(f"al_encoder.{name}", rows, d)          # present in checkpoints, unused (ENC:724-729)
         for gate in ("update_gate", "reset_gate", "new_state_net"):
-            self.linear(f"gru_unit.{gate}.0", d, 2 * d, init="normal0.1")
-            self.linear(f"gru_unit.{gate}.2", d, d, init="normal0.1")
+            # GRU_Unit draws N(0, 0.1) (ODEU:211-215) when it is built (ENC:49), but the encoder's closing
+            # `self.apply(init_weights)` (ENC:64) re-initialises every nn.Linear, these included: xavier-uniform, zero bias
+            self.linear(f"gru_unit.{gate}.0", d, 2 * d)
+            self.linear(f"gru_unit.{gate}.2", d, d)
         self.sde_nets("lsde_func", d, ("g_nus", "g_argo"))
         self.token("hidden", d)
         self.set_init_seed(None)

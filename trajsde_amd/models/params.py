@@ -6,8 +6,10 @@ the HIP kernels, which read packed copies of these tensors.  `ParamTree` registe
 dotted paths by creating nested anonymous containers ("a.b.0.weight" -> self.a.b.0.weight).
 
 Initial values follow the reference's distributions (models/utils/util.py:94-159 init_weights:
-xavier-uniform Linear weights, zero biases, LayerNorm ones/zeros; models/utils/ode_utils.py:211-215:
-N(0, 0.1) for the GRU unit; N(0, 0.02) for tokens / hidden vectors).
+xavier-uniform Linear weights, zero biases, LayerNorm ones/zeros -- the GRU unit included: its own N(0, 0.1) of
+models/utils/ode_utils.py:211-215 is overwritten by the encoder's closing `self.apply(init_weights)`, ENC:49 then ENC:64;
+N(0, 0.02) for tokens / hidden vectors).  tests/test_init_golden.py holds every family to moments taken from freshly
+constructed reference models (oracle/make_golden_init.py).
 """
 import math
 from typing import Dict, Iterator, Optional, Tuple
