@@ -132,6 +132,10 @@ typedef struct {
   const float* la_geom;       /* [E_la,4] (lane_feat R_i, lane_actor_vector R_i)   */
   const int32_t* la_dst;      /* [E_la]                                            */
   const int32_t* la_segptr;   /* [N+1]                                             */
+  /* ABI 2: the sender of every compacted record (the kernels do not read these: the geometry above already carries what a
+   * sender contributes; they make the index work of ENC:107-118 / ENC:198 checkable edge for edge) */
+  const int32_t* aa_src;      /* [E_aa] sending actor (a real actor, < N)          */
+  const int32_t* la_lane;     /* [E_la] lane segment                               */
 } trajsde_graph;
 
 /* Two phases, because the sizes of the compacted lists are data dependent:

@@ -126,6 +126,9 @@ def make(name):
     fx["mid.global_embed"] = caps["global_embed"].numpy()
     fx["mid.aa_out"] = caps["aa_out"].view(21, N + A, 64).numpy()
     fx["mid.latent_ys"] = torch.stack(caps["gru"])[:, :N].numpy()
+    for t in range(21):                                       # the encoder's side effect on the batch (ENC:107-110)
+        fx[f"mid.edge_index_{t}"] = data[f"edge_index_{t}"].numpy()
+        fx[f"mid.edge_attr_{t}"] = data[f"edge_attr_{t}"].numpy()
     path = os.path.join(ROOT, "tests", "golden", name + ".npz")
     np.savez_compressed(path, **fx)
     print(f"{name}: N={N} A={A} K={K} T={T} euler={sched.n_euler} -> {os.path.getsize(path) / 1024:.0f} KiB")

@@ -181,6 +181,8 @@ def local_encoder(P, cfg, batch, rot, noise, enc_sched, want_intermediates=False
         attrs.append(attr[near])
     e_src, e_dst, e_attr = torch.cat(srcs), torch.cat(dsts), torch.cat(attrs)
     inter["aa_edges"] = int(e_src.numel())
+    if want_intermediates:
+        inter["aa_edge_list"] = torch.stack((e_src, e_dst))    # snapshot-node ids t*Nt + n, the reference's order
 
     # AAEncoder.forward ENC:546-566 on the 21*Nt snapshot nodes (node id = t*Nt + n)
     a = pre + ".aa_encoder"
@@ -235,6 +237,8 @@ def local_encoder(P, cfg, batch, rot, noise, enc_sched, want_intermediates=False
     la, lav = batch["lane_actor_index"], batch["lane_actor_vectors"]
     near = torch.norm(lav, p=2, dim=-1) < radius
     l_src, l_dst, lav = la[0][near], la[1][near], lav[near]
+    if want_intermediates:
+        inter["al_edge_list"] = torch.stack((l_src, l_dst))    # (lane, actor)
     xn = _ln(P, l + ".norm1", out)
     r_e = rot[l_dst]
     lane = multiple_input_embedding(P, l + ".lane_embed", [rotate2(lane_feat[l_src], r_e), rotate2(lav, r_e)])
@@ -315,7 +319,7 @@ def local_encoder_ood(P, cfg, batch, rot, noise, enc_sched, eval_iter=10):
     return out, actors_std
 
 
-def global_interactor(P, cfg, batch, rot, local_embed):
+def global_interactor(P, cfg, batch, rot, local_embed, inter=None):
     """GlobalInteractor.forward AGG:38-58 with GlobalInteractorLayer AGG:92-135."""
     pre = "aggregator"
     K = cfg["num_modes"]
@@ -324,6 +328,8 @@ def global_interactor(P, cfg, batch, rot, local_embed):
     src, dst = batch["edge_index"]
     keep = valid[src] & valid[dst]
     src, dst = src[keep], dst[keep]
+    if inter is not None:
+        inter["g_edge_list"] = torch.stack((src, dst))
     pos = batch["positions"][:, t_ref]
     rel_pos = rotate2(pos[src] - pos[dst], rot[dst])
     th = batch["rotate_angles"][src] - batch["rotate_angles"][dst]
@@ -449,7 +455,7 @@ def forward(P: Dict[str, torch.Tensor], cfg: dict, batch, noise, want_intermedia
             out.update(local_embed=local, global_embed=glob)
         return out
     local, diff_in, diff_out, inter = local_encoder(P, c, batch, rot, noise, enc_sched, want_intermediates)
-    glob = global_interactor(P, c, batch, rot, local)
+    glob = global_interactor(P, c, batch, rot, local, inter if want_intermediates else None)
     out = sde_decoder(P, c, batch, local, glob, noise, dec_sched, want_intermediates)
     out.update(diff_in=diff_in, diff_out=diff_out, label_in=torch.zeros_like(diff_in),
                label_out=torch.ones_like(diff_out), rotate_mat=rot, y=y_rot)

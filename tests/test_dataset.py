@@ -133,6 +133,11 @@ def test_loader_shards_scenes_across_ranks(roots):
         assert ld.scene_ids() == list(range(rank, len(ds), 2))
         seen += [s for b in ld for s in b["seq_id"]]
     assert sorted(seen) == sorted(ds.get(i)["seq_id"] for i in range(len(ds)))
+    # 6 scenes on 4 ranks: padded by wrapping to 8 so that every rank runs the same number of steps (DistributedSampler
+    # rule); evaluation loaders (even=False) leave the tail ranks short instead of counting a scene twice
+    even = [SceneLoader(ds, 1, rank=r, world_size=4).scene_ids() for r in range(4)]
+    assert even == [[0, 4], [1, 5], [2, 0], [3, 1]] and len({len(SceneLoader(ds, 1, rank=r, world_size=4)) for r in range(4)}) == 1
+    assert [SceneLoader(ds, 1, rank=r, world_size=4, even=False).scene_ids() for r in range(4)] == [[0, 4], [1, 5], [2], [3]]
     a = SceneLoader(ds, 2, shuffle=True, seed=3)
     b = SceneLoader(ds, 2, shuffle=True, seed=3)
     assert a.scene_ids() == b.scene_ids()

@@ -238,18 +238,105 @@ def test_dense_scene_1024_agents(dev):
     assert H.maxdiff(o["pi"].cpu(), want["pi"]) <= TOL
 
 
-def test_edge_snapshot_helper_matches_reference_side_effect(dev):
-    """ENC:107-110 leaves edge_index_t / edge_attr_t on the batch; the helper reproduces them on request"""
-    from trajsde_amd.runtime import edge_snapshot
-    batch, meta, out, mid = H.load_fixture("mixed_k6_t20")
+@pytest.mark.parametrize("name", H.GOLDEN)
+def test_preserve_side_effects_leaves_the_reference_edge_snapshots_on_the_batch(name, dev):
+    """ENC:107-110 leaves edge_index_t / edge_attr_t (extended edge list incl. the fake agents' in-edges, no radius filter) on
+    the batch; with preserve_side_effects=True so does this build -- compared with what the reference's own forward left"""
+    from trajsde_amd.runtime import NoiseSpec
+    batch, meta, out, mid = H.load_fixture(name)
+    model, cfg = H.build_model(meta)
+    model = model.to(dev)
     data = batch.to(dev)
-    for t in (0, 10, 20):
-        e, attr = edge_snapshot(data, t)
-        valid = ~batch["padding_mask"][:, t]
-        keep = valid[batch["edge_index"][0]] & valid[batch["edge_index"][1]]
-        want = batch["edge_index"][:, keep]
-        assert torch.equal(e.cpu(), want)
-        assert H.maxdiff(attr.cpu(), batch["positions"][want[0], t] - batch["positions"][want[1], t]) == 0
+    model(data, noise=NoiseSpec(seed=int(meta["noise_seed"])))
+    assert "edge_index_0" not in data                                   # opt-in: the default forward does not spend time on them
+    data = batch.to(dev)
+    model(data, noise=NoiseSpec(seed=int(meta["noise_seed"])), preserve_side_effects=True)
+    for t in range(21):
+        assert torch.equal(data[f"edge_index_{t}"].cpu(), mid[f"edge_index_{t}"]), t
+        assert H.maxdiff(data[f"edge_attr_{t}"].cpu(), mid[f"edge_attr_{t}"]) == 0, t
+
+
+def _sorted_cols(*rows):
+    """columns of an index matrix in lexicographic order (multiset comparison of edge lists)"""
+    m = torch.stack([r.to(torch.int64).cpu() for r in rows])
+    key = torch.zeros(m.shape[1], dtype=torch.int64)
+    for r in m:
+        key = key * (int(m.max()) + 1 if m.numel() else 1) + r
+    return m[:, torch.argsort(key, stable=True)]
+
+
+@pytest.mark.parametrize("S,n,L,kw", [
+    (3, 14, 6, dict(mixed_source=True, history_dropout=0.4)),
+    (2, 33, 9, dict(nus_sparsity=True)),
+    (1, 1, 2, dict()),
+    (4, 20, 5, dict(history_dropout=0.7)),
+])
+def test_compacted_edge_lists_equal_the_oracle_edge_sets_exactly(S, n, L, kw, dev):
+    """index work is exact: the compacted agent-agent (t, src, dst), global (src, dst) and lane-actor (lane, actor) lists are
+    the oracle's lists as multisets, the rows are in canonical order, and the segment pointers are the CSR of the targets"""
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    K, T = 2, 5
+    batch = synth(S=S, n=n, L=L, F=T, box=130.0, seed=300 + n, **kw)
+    if n > 1:                                                            # duplicated and shuffled input edges too
+        g = torch.Generator().manual_seed(n)
+        ei = torch.cat([batch["edge_index"], batch["edge_index"][:, :5]], dim=1)
+        batch["edge_index"] = ei[:, torch.randperm(ei.shape[1], generator=g)]
+    model, cfg = H.build_model(K, T, 0.5, init_seed=2)
+    want = H.oracle_forward(model, cfg, batch, noise_seed=9)
+    model = model.to(dev)
+    model.encoder.capture_intermediates = True
+    model(batch.to(dev), noise=NoiseSpec(seed=9))
+    im = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in model.encoder.last_intermediates.items()}
+    N, A = batch.num_nodes, batch["agent_index"].numel()
+    Nt = N + A
+    # agent-agent: ours = (sender actor, snapshot node t*Nt+i); oracle = (t*Nt + sender, t*Nt + i)
+    t_of = torch.div(im["aa_dst"], Nt, rounding_mode="floor")
+    ours = _sorted_cols(t_of * Nt + im["aa_src"], im["aa_dst"])
+    assert torch.equal(ours, _sorted_cols(*want["aa_edge_list"]))
+    assert torch.equal(_sorted_cols(im["g_src"], im["g_dst"]), _sorted_cols(*want["g_edge_list"]))
+    assert torch.equal(_sorted_cols(im["la_lane"], im["la_dst"]), _sorted_cols(*want["al_edge_list"]))
+    for dst, src, segptr, rows in ((im["aa_dst"], im["aa_src"], im["aa_segptr"], 21 * Nt), (im["g_dst"], im["g_src"], im["g_segptr"], N),
+                                   (im["la_dst"], im["la_lane"], im["la_segptr"], N)):
+        assert segptr.numel() == rows + 1 and int(segptr[0]) == 0 and int(segptr[-1]) == dst.numel()
+        counts = torch.bincount(dst.to(torch.int64), minlength=rows)
+        assert torch.equal(segptr[1:] - segptr[:-1], counts.to(torch.int32))      # CSR of the targets
+        assert bool((dst[1:] >= dst[:-1]).all())                                   # target-major
+        same = dst[1:] == dst[:-1]
+        assert bool((src[1:][same] >= src[:-1][same]).all())                       # senders ascending inside a row
+
+
+def test_csr_rows_longer_than_the_lds_sort_buffer(dev):
+    """a target with more than 4096 in-edges (and an actor near more than 4096 lanes) takes the global-memory path of the
+    canonical row sort; the row length is not a power of two"""
+    from trajsde_amd.data import TemporalData
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    K, T, n, L = 2, 5, 4200, 4300
+    batch = synth(S=1, n=n, L=L, F=T, box=30.0, seed=91)             # everyone within the radius of everyone
+    g = torch.Generator().manual_seed(17)
+    star = torch.stack([torch.arange(1, n), torch.zeros(n - 1, dtype=torch.int64)])          # every actor -> actor 0
+    ring = torch.stack([torch.arange(n), (torch.arange(n) + 1) % n])
+    ei = torch.cat([star, ring], dim=1)
+    batch["edge_index"] = ei[:, torch.randperm(ei.shape[1], generator=g)]
+    la = torch.stack([torch.arange(L), torch.zeros(L, dtype=torch.int64)])                   # every lane -> actor 0
+    la = la[:, torch.randperm(L, generator=g)]
+    batch["lane_actor_index"] = la
+    batch["lane_actor_vectors"] = batch["lane_positions"][la[0], -1] - batch["positions"][la[1], 20]
+    model, cfg = H.build_model(K, T, 0.5, init_seed=2)
+    want = H.oracle_forward(model, cfg, batch, noise_seed=4)
+    model = model.to(dev)
+    model.encoder.capture_intermediates = True
+    o = model(batch.to(dev), noise=NoiseSpec(seed=4))
+    im = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in model.encoder.last_intermediates.items()}
+    Nt = n + 1
+    t_of = torch.div(im["aa_dst"], Nt, rounding_mode="floor")
+    assert torch.equal(_sorted_cols(t_of * Nt + im["aa_src"], im["aa_dst"]), _sorted_cols(*want["aa_edge_list"]))
+    assert torch.equal(_sorted_cols(im["la_lane"], im["la_dst"]), _sorted_cols(*want["al_edge_list"]))
+    for dst, src in ((im["aa_dst"], im["aa_src"]), (im["la_dst"], im["la_lane"])):
+        same = dst[1:] == dst[:-1]
+        assert bool((src[1:][same] >= src[:-1][same]).all())
+    assert H.maxdiff(o["loc"].cpu(), want["loc"]) <= TOL
 
 
 def test_driver_metrics_match_oracle(dev):

@@ -139,3 +139,96 @@ def test_two_rank_gradient_all_reduce_over_flat_bucket():
         assert any(n.startswith("decoder.pi.") for n in frozen)                # grad None -> AdamW leaves them alone
         assert "decoder.decoder.0.weight" not in frozen and "encoder.gru_unit.update_gate.0.weight" not in frozen
     np.testing.assert_array_equal(got[0][3], got[1][3])                        # replicas stay bit-identical after the step
+
+
+class _ToyModel(torch.nn.Module):
+    """stands in for PredictionModelSDENet in the training LOOP test (the kernels need a GPU): same hook names, a loss whose
+    gradient depends on the batch and on the noise seed, so that the all-reduced mean is checkable"""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(3))
+        self.seen = []
+
+    @property
+    def device(self):
+        return self.w.device
+
+    def params_with_gradient(self):
+        return [self.w]
+
+    def configure_optimizers(self):
+        opt = torch.optim.SGD(self.parameters(), lr=1.0)
+        return [opt], [torch.optim.lr_scheduler.LambdaLR(opt, lambda e: 1.0)]
+
+    def training_step(self, batch, batch_idx, noise=None):
+        self.seen.append((int(batch["tag"]), int(noise.seed)))
+        self.last_losses = {}
+        c = torch.tensor([float(batch["tag"]), float(noise.seed % 1000), 1.0])
+        return (self.w * c).sum()
+
+
+class _TaggedBatches:
+    def __init__(self, ids):
+        self.ids = ids
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __iter__(self):
+        return iter({"tag": torch.tensor(i)} for i in self.ids)
+
+
+def _loop_worker(rank, world, port, q, even):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from trajsde_amd import driver
+        torch.set_num_threads(1)
+        sb = driver.synthetic_batches("config1", 5, "cpu", rank, world, even=even)       # 5 batches on 2 ranks
+        model = _ToyModel()
+        try:
+            driver.train(model, lambda epoch: _TaggedBatches(sb.ids), epochs=2, seed=100)
+            q.put((rank, "ok", sb.ids, model.seen, model.w.detach().numpy()))
+        except RuntimeError as e:
+            q.put((rank, "error", sb.ids, str(e), None))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("even", [True, False])
+def test_training_loop_with_a_batch_count_not_divisible_by_the_world_size(even):
+    """5 batches on 2 ranks.  even=True (what `driver --train` and the train loader use): padded by wrapping to 3 steps per
+    rank, every step's gradients are averaged by one all-reduce, replicas stay identical, ranks draw different noise seeds.
+    even=False: the loop refuses up front (RuntimeError on every rank) instead of hanging in the 3rd all-reduce."""
+    from trajsde_amd.driver import RANK_SEED_STRIDE
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_loop_worker, args=(r, world, port, q, even)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    if not even:
+        assert [g[1] for g in got] == ["error", "error"] and "number of steps" in got[0][3]
+        assert [g[2] for g in got] == [[0, 2, 4], [1, 3]]
+        return
+    assert [g[1] for g in got] == ["ok", "ok"]
+    assert [g[2] for g in got] == [[0, 2, 4], [1, 3, 0]]                       # wrapped: batch 0 closes rank 1's epoch
+    seeds = [[sd for _, sd in g[3]] for g in got]
+    assert seeds[0] == [100 + k for k in range(6)] and seeds[1] == [100 + k + RANK_SEED_STRIDE for k in range(6)]
+    # SGD with lr 1 on sum(w * c): w = -sum over steps of mean over ranks of c
+    want = np.zeros(3)
+    for k in range(6):
+        cs = [np.array([float(got[r][3][k][0]), float(got[r][3][k][1] % 1000), 1.0]) for r in range(world)]
+        want -= np.mean(cs, axis=0)
+    for g in got:
+        np.testing.assert_allclose(g[4], want, rtol=1e-6)

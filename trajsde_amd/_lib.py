@@ -11,6 +11,9 @@ STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGA
 STAGE_ENCODER_GRID, STAGE_DECODER_MLP, STAGE_DECODER_MLP_BWD, STAGE_ENCODER_GRID_BWD = 6, 7, 8, 9
 
 
+ABI_VERSION = 2          # include/trajsde_hip.h: trajsde_graph grew aa_src / la_lane
+
+
 class TrajsdeError(RuntimeError):
     pass
 
@@ -33,7 +36,8 @@ class Graph(C.Structure):
                 ("orig", C.c_void_p), ("nus_mask", C.c_void_p), ("eos_idx", C.c_void_p), ("pick_slot", C.c_void_p),
                 ("x_fake", C.c_void_p), ("aa_geom", C.c_void_p), ("aa_dst", C.c_void_p), ("aa_segptr", C.c_void_p),
                 ("g_geom", C.c_void_p), ("g_src", C.c_void_p), ("g_dst", C.c_void_p), ("g_segptr", C.c_void_p),
-                ("la_geom", C.c_void_p), ("la_dst", C.c_void_p), ("la_segptr", C.c_void_p)]
+                ("la_geom", C.c_void_p), ("la_dst", C.c_void_p), ("la_segptr", C.c_void_p),
+                ("aa_src", C.c_void_p), ("la_lane", C.c_void_p)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -102,6 +106,9 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)       # AttributeError here = header/library mismatch: fail loudly
             fn.restype, fn.argtypes = res, args
+        if handle.trajsde_abi_version() != ABI_VERSION:
+            raise TrajsdeError(f"{LIB_PATH} has ABI version {handle.trajsde_abi_version()}, this binding expects {ABI_VERSION}: "
+                               "rebuild with `python -m trajsde_amd.build --force`")
         _lib = handle
     return _lib
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstdio>
 #include <string>
 
@@ -31,6 +32,13 @@ int fail(int code, const std::string& msg);
   do {                                                                        \
     if (!(cond)) return ::tsde::fail(TRAJSDE_ERR_INVALID, std::string(msg));  \
   } while (0)
+
+constexpr int MAX_DEVICES = 64;
+inline int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return (d >= 0 && d < MAX_DEVICES) ? d : 0;
+}
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -92,13 +100,16 @@ struct ProfScope {
   }
 };
 
-// launch a kernel that needs `lds` bytes of dynamic LDS (the >64 KB opt-in is done once per kernel)
+// launch a kernel that needs `lds` bytes of dynamic LDS.  The >64 KB opt-in is raised whenever a call site asks for more
+// than it has asked before ON THE CURRENT DEVICE (a kernel whose LDS size depends on the batch, e.g. k_enc_recur_coop, must
+// not stay latched at its first call's size; the attribute is per device).  `_attr_lds[dev]` holds bytes + 1, 0 = unset.
 #define TS_LAUNCH_TAG(tag, dominant, kern, grid, threads, lds, st, ...)                                           \
   do {                                                                                                            \
-    static bool _attr_done = false;                                                                               \
-    if (!_attr_done) {                                                                                            \
+    static std::atomic<int> _attr_lds[::tsde::MAX_DEVICES];                                                       \
+    const int _dev = ::tsde::current_device();                                                                    \
+    if (int(lds) + 1 > _attr_lds[_dev].load(std::memory_order_relaxed)) {                                         \
       TS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));       \
-      _attr_done = true;                                                                                          \
+      _attr_lds[_dev].store(int(lds) + 1, std::memory_order_relaxed);                                             \
     }                                                                                                             \
     {                                                                                                             \
       ::tsde::ProfScope _ps(tag, st, dominant);                                                                   \

@@ -890,7 +890,7 @@ int64_t trajsde_profile_report(char* buf, int64_t cap) {
 
 const char* trajsde_last_error(void) { return last_error_ref().c_str(); }
 int trajsde_split_products(void) { return TSDE_SPLIT_H3 ? 3 : 6; }
-int trajsde_abi_version(void) { return 1; }
+int trajsde_abi_version(void) { return 2; }
 
 int trajsde_param_count(int stage, int num_layers, int num_modes) {
   Packer P{true};

@@ -61,8 +61,11 @@ __global__ void k_unpack_eid(const int64_t* __restrict__ packed, int E, int32_t*
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < E) eid[e] = int32_t(packed[e] & 0xFFFFFFFFll);
 }
-// ascending sort of every CSR row; one workgroup per row (grid-stride), bitonic network in LDS (rows up to 4096
-// entries) or in place in global memory for longer rows
+// ascending sort of every CSR row; one workgroup per row (grid-stride).  Rows of up to 4096 entries: bitonic network in LDS
+// on the row padded to a power of two with +inf.  Longer rows: in place in global memory with the "flip" form of the network
+// (first sub-step of stage k pairs i with i ^ (k - 1), the others i with i ^ j), in which EVERY compare-exchange puts the
+// minimum at the lower index -- so the virtual +inf padding above the row's end never moves and a pair whose upper index lies
+// beyond the row is a no-op: correct for any row length without materialising the padding.
 template <typename T>
 __global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals) {   // 64 or 256 threads
   __shared__ T buf[4096];
@@ -72,31 +75,45 @@ __global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ ro
     if (n <= 1) continue;
     int P = 2;
     while (P < n) P <<= 1;
-    const bool in_lds = P <= 4096;
-    T* a = in_lds ? buf : vals + beg;
-    if (in_lds) {
+    if (P <= 4096) {
       for (int i = threadIdx.x; i < P; i += blockDim.x) buf[i] = i < n ? vals[beg + i] : INF;
-    }
-    __syncthreads();
-    for (int k = 2; k <= P; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = threadIdx.x; i < P; i += blockDim.x) {
-          const int l = i ^ j;
-          if (l > i) {
-            // virtual padding with +inf for the global-memory variant
-            const T vi = (in_lds || i < n) ? a[i] : INF, vl = (in_lds || l < n) ? a[l] : INF;
-            const bool up = (i & k) == 0;
-            if ((vi > vl) == up) {
-              if (in_lds || i < n) a[i] = vl;
-              if (in_lds || l < n) a[l] = vi;
+      __syncthreads();
+      for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int i = threadIdx.x; i < P; i += blockDim.x) {
+            const int l = i ^ j;
+            if (l > i) {
+              const T vi = buf[i], vl = buf[l];
+              const bool up = (i & k) == 0;
+              if ((vi > vl) == up) {
+                buf[i] = vl;
+                buf[l] = vi;
+              }
             }
           }
+          __syncthreads();
         }
-        __syncthreads();
-      }
-    if (in_lds)
       for (int i = threadIdx.x; i < n; i += blockDim.x) vals[beg + i] = buf[i];
-    __syncthreads();
+      __syncthreads();
+    } else {
+      T* a = vals + beg;
+      for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          const int mask = (j == (k >> 1)) ? k - 1 : j;      // flip on the first sub-step of a stage
+          for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int l = i ^ mask;
+            if (l > i && l < n) {
+              const T vi = a[i], vl = a[l];
+              if (vi > vl) {
+                a[i] = vl;
+                a[l] = vi;
+              }
+            }
+          }
+          __threadfence_block();
+          __syncthreads();
+        }
+    }
   }
 }
 
@@ -152,7 +169,7 @@ __global__ __launch_bounds__(256) void k_aa_pass(int N, int Nt, int H, int TT, c
                                                  const uint8_t* __restrict__ pad, const float* __restrict__ pos,
                                                  const float* __restrict__ x, const float* __restrict__ rot, float radius_val,
                                                  const float* __restrict__ radius_dev, int32_t* __restrict__ cnt_or_ptr, int32_t* __restrict__ aa_dst,
-                                                 float* __restrict__ geom) {
+                                                 int32_t* __restrict__ aa_src, float* __restrict__ geom) {
   const int t = threadIdx.x & 31;
   const int64_t node = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 5;
   if (node >= Nt) return;
@@ -194,6 +211,7 @@ __global__ __launch_bounds__(256) void k_aa_pass(int N, int Nt, int H, int TT, c
             f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
             *reinterpret_cast<f4*>(geom + 4 * int64_t(k)) = g;
             aa_dst[k] = tc * Nt + int(node);
+            aa_src[k] = s;
           }
           ++k;
         }
@@ -275,7 +293,7 @@ __global__ void k_la_compact(int E_al, const int32_t* __restrict__ actor, const 
                              const int64_t* __restrict__ la_index, const float* __restrict__ vec,
                              const float* __restrict__ lane_feat, const float* __restrict__ rot,
                              const uint8_t* __restrict__ flags, const int32_t* __restrict__ cpos, int32_t* __restrict__ la_dst,
-                             float* __restrict__ geom) {
+                             int32_t* __restrict__ la_lane, float* __restrict__ geom) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= E_al || !flags[p]) return;
   const int i = actor[p], e = eid[p], q = cpos[p];
@@ -285,6 +303,7 @@ __global__ void k_la_compact(int E_al, const int32_t* __restrict__ actor, const 
   f4 g = {fx * R[0] + fy * R[2], fx * R[1] + fy * R[3], vx * R[0] + vy * R[2], vx * R[1] + vy * R[3]};   // ENC:763-764
   *reinterpret_cast<f4*>(geom + 4 * int64_t(q)) = g;
   la_dst[q] = i;
+  la_lane[q] = lane;
 }
 __global__ void k_collect_counts(int64_t n_aa, int E, int E_al, const int32_t* __restrict__ aa_segptr, const int32_t* __restrict__ cpos_g,
                                  const int32_t* __restrict__ cpos_la, float radius, int32_t* __restrict__ counts) {
@@ -343,15 +362,15 @@ struct PrepWs {
 
 struct EdgeWs {
   float *aa_geom, *g_geom, *la_geom;
-  int32_t *aa_dst, *g_src, *g_dst, *la_dst;
+  int32_t *aa_dst, *aa_src, *g_src, *g_dst, *la_dst, *la_lane;
   int64_t total;
   bool ok;
   EdgeWs(const trajsde_batch* b, const trajsde_graph* g, void* ws, int64_t ws_bytes) {
     Carver c(ws, ws_bytes);
     (void)b;
-    aa_geom = c.take<float>(4 * int64_t(g->E_aa) + 4); aa_dst = c.take<int32_t>(g->E_aa + 1);
+    aa_geom = c.take<float>(4 * int64_t(g->E_aa) + 4); aa_dst = c.take<int32_t>(g->E_aa + 1); aa_src = c.take<int32_t>(g->E_aa + 1);
     g_geom = c.take<float>(4 * int64_t(g->E_g) + 4); g_src = c.take<int32_t>(g->E_g + 1); g_dst = c.take<int32_t>(g->E_g + 1);
-    la_geom = c.take<float>(4 * int64_t(g->E_la) + 4); la_dst = c.take<int32_t>(g->E_la + 1);
+    la_geom = c.take<float>(4 * int64_t(g->E_la) + 4); la_dst = c.take<int32_t>(g->E_la + 1); la_lane = c.take<int32_t>(g->E_la + 1);
     total = c.off + 256;
     ok = c.ok;
   }
@@ -435,7 +454,7 @@ int trajsde_graph_prepare(const trajsde_batch* b, const float* rot, float radius
   }
   // 21 snapshots: count pass + prefix sum -> segment pointers
   k_aa_pass<false><<<cdiv(int64_t(Nt) * 32, 256), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, b->padding_mask, b->positions,
-                                                                b->x, rot, radius, nullptr, w.aa_segptr, nullptr, nullptr);
+                                                                b->x, rot, radius, nullptr, w.aa_segptr, nullptr, nullptr, nullptr);
   TS_HIP(hipMemsetAsync(w.aa_segptr + w.n_aa, 0, sizeof(int32_t), st));
   {
     size_t tmp = size_t(w.cub_bytes);
@@ -485,15 +504,15 @@ int trajsde_graph_compact(const trajsde_batch* b, const float* rot, void* ws, in
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int N = b->N, A = b->A, E = b->E, H = b->H, TT = b->TT, Ea = b->E_al, Nt = N + A;
   k_aa_pass<true><<<cdiv(int64_t(Nt) * 32, 256), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, b->padding_mask, b->positions,
-                                                               b->x, rot, 0.f, reinterpret_cast<const float*>(w.counts) + 4, w.aa_segptr, e.aa_dst, e.aa_geom);
+                                                               b->x, rot, 0.f, reinterpret_cast<const float*>(w.counts) + 4, w.aa_segptr, e.aa_dst, e.aa_src, e.aa_geom);
   if (E > 0)
     k_g_compact<<<cdiv(E, 256), 256, 0, st>>>(E, TT, H - 1, w.csr_src, w.csr_dst, b->positions, rot, b->rotate_angles, w.flags_g,
                                               w.cpos_g, e.g_src, e.g_dst, e.g_geom);
   if (Ea > 0)
     k_la_compact<<<cdiv(Ea, 256), 256, 0, st>>>(Ea, w.la_actor, w.la_eid, b->lane_actor_index, b->lane_actor_vectors, w.lane_feat,
-                                                rot, w.flags_la, w.cpos_la, e.la_dst, e.la_geom);
+                                                rot, w.flags_la, w.cpos_la, e.la_dst, e.la_lane, e.la_geom);
   TS_LAUNCH_CHECK("graph_compact kernels");
-  out->aa_geom = e.aa_geom; out->aa_dst = e.aa_dst;
+  out->aa_geom = e.aa_geom; out->aa_dst = e.aa_dst; out->aa_src = e.aa_src; out->la_lane = e.la_lane;
   out->g_geom = e.g_geom; out->g_src = e.g_src; out->g_dst = e.g_dst;
   out->la_geom = e.la_geom; out->la_dst = e.la_dst;
   return TRAJSDE_OK;

@@ -175,10 +175,14 @@ class SceneLoader:
     on a side stream one batch ahead of the consumer."""
 
     def __init__(self, dataset, batch_size: int, shuffle: bool = False, device: Optional[str] = None,
-                 rank: int = 0, world_size: int = 1, seed: int = 0, drop_last: bool = False):
+                 rank: int = 0, world_size: int = 1, seed: int = 0, drop_last: bool = False, even: bool = True):
+        """`even` (default): every rank gets the same number of scenes -- the order is padded by wrapping around to a
+        multiple of world_size, like torch's DistributedSampler that Lightning installs for the reference (train.py:54) --
+        so that every rank runs the same number of steps and the per-step gradient all-reduce cannot be left waiting.
+        Evaluation loaders pass even=False: no per-step collective there, and no scene is counted twice in the metrics."""
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
         self.device = torch.device(device) if device is not None else None
-        self.rank, self.world_size, self.seed, self.drop_last = rank, world_size, seed, drop_last
+        self.rank, self.world_size, self.seed, self.drop_last, self.even = rank, world_size, seed, drop_last, even
         self.epoch = 0
 
     def set_epoch(self, epoch: int) -> None:
@@ -191,6 +195,9 @@ class SceneLoader:
             order = torch.randperm(n, generator=g).tolist()
         else:
             order = list(range(n))
+        if self.even and self.world_size > 1 and n % self.world_size:
+            pad = self.world_size - n % self.world_size
+            order += (order * (pad // max(n, 1) + 1))[:pad]
         return order[self.rank::self.world_size]
 
     def __len__(self) -> int:
@@ -220,14 +227,20 @@ class SceneLoader:
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             if pending is not None:
-                done, pev, keep = pending
-                torch.cuda.current_stream(self.device).wait_event(pev)
-                yield done
+                yield self._hand_over(*pending)
             pending = (dev, ev, staged)
         if pending is not None:
-            done, pev, keep = pending
-            torch.cuda.current_stream(self.device).wait_event(pev)
-            yield done
+            yield self._hand_over(*pending)
+
+    def _hand_over(self, done, copied, staged):
+        """the batch was allocated and filled on the copy stream: make the consumer's stream wait for the copy and tell the
+        caching allocator that the consumer's stream uses these blocks (so they are not recycled under its kernels)"""
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(copied)
+        for v in done.as_dict().values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+        return done
 
 
 class DataModuleNuArgoMix:
@@ -261,14 +274,14 @@ class DataModuleNuArgoMix:
         if stage in (None, "test"):
             self.test_dataset = mk("val", self.test_dataset_args)     # Datamodule_nuargo_mix.py:31
 
-    def _loader(self, ds, bs, shuffle):
-        return SceneLoader(ds, bs, shuffle=shuffle, device=self.device, rank=self.rank, world_size=self.world_size)
+    def _loader(self, ds, bs, shuffle, even):
+        return SceneLoader(ds, bs, shuffle=shuffle, device=self.device, rank=self.rank, world_size=self.world_size, even=even)
 
     def train_dataloader(self):
-        return self._loader(self.train_dataset, self.train_batch_size, self.shuffle)
+        return self._loader(self.train_dataset, self.train_batch_size, self.shuffle, True)     # equal step counts per rank
 
     def val_dataloader(self):
-        return self._loader(self.val_dataset, self.val_batch_size, False)
+        return self._loader(self.val_dataset, self.val_batch_size, False, False)
 
     def test_dataloader(self):
-        return self._loader(self.test_dataset, self.val_batch_size, False)
+        return self._loader(self.test_dataset, self.val_batch_size, False, False)

@@ -49,8 +49,12 @@ def evaluate(model, batches: Iterable, seed: int = 0) -> dict:
     for metric in model.metrics_vl:
         metric.reset()
     stochastic = "noise" in inspect.signature(model.forward).parameters      # the vanilla HiVT variant has no noise to seed
+    rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
     for i, batch in enumerate(batches):
-        model.test_step(batch, i) if (seed is None or not stochastic) else _seeded_test_step(model, batch, i, seed + i)
+        if seed is None or not stochastic:
+            model.test_step(batch, i)
+        else:
+            _seeded_test_step(model, batch, i, seed + i + RANK_SEED_STRIDE * rank)
     return model.metric_results()
 
 
@@ -87,6 +91,24 @@ class FlatGrads:
             self.flat.div_(dist.get_world_size())
 
 
+RANK_SEED_STRIDE = 1_000_003          # noise seeds of rank r: base + step + r * stride (distinct streams per rank)
+
+
+def assert_equal_step_counts(batches) -> None:
+    """One blocking gradient all-reduce per step means every rank must run the same number of steps: check it before the
+    first one instead of hanging in RCCL after the last.  Needs `len(batches)` (SceneLoader and synthetic_batches have it)."""
+    import torch.distributed as dist
+    if not hasattr(batches, "__len__"):
+        raise ValueError("multi-rank training needs a sized batch source (len()) so that step counts can be checked up front")
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    n = torch.tensor([len(batches), -len(batches)], dtype=torch.int64, device=dev)
+    dist.all_reduce(n, op=dist.ReduceOp.MAX)
+    hi, lo = int(n[0]), -int(n[1])
+    if hi != lo:
+        raise RuntimeError(f"ranks disagree on the number of steps per epoch ({lo}..{hi}): pad the scene list to a multiple "
+                           "of the world size (SceneLoader(even=True), synthetic_batches(even=True)) or drop the tail")
+
+
 def save_checkpoint(path: str, model, optimizer, scheduler, epoch: int, step: int) -> None:
     """A Lightning-shaped checkpoint (`state_dict` at the top level like the reference's `ModelCheckpoint` files, so
     either side loads the other's weights with `load_state_dict`), plus what the loop needs to resume."""
@@ -113,12 +135,18 @@ def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None, ckpt_p
         scheduler.load_state_dict(state["lr_schedulers"][0])
         first_epoch, step = int(state["epoch"]) + 1, int(state["global_step"])
     flat = FlatGrads(model.params_with_gradient())
-    rank0 = not (torch.distributed.is_available() and torch.distributed.is_initialized()) or torch.distributed.get_rank() == 0
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    rank = torch.distributed.get_rank() if dist_on else 0
+    rank0 = rank == 0
     history = []
     for epoch in range(first_epoch, epochs):
-        for i, batch in enumerate(batches_per_epoch(epoch)):
+        batches = batches_per_epoch(epoch)
+        if dist_on:
+            assert_equal_step_counts(batches)
+        for i, batch in enumerate(batches):
             flat.zero()
-            loss = model.training_step(batch, i, noise=NoiseSpec(seed=seed + step))
+            # every rank draws its own Philox streams (rank folded into the key); rank 0's are those of a single-GPU run
+            loss = model.training_step(batch, i, noise=NoiseSpec(seed=seed + step + RANK_SEED_STRIDE * rank))
             loss.backward()
             flat.all_reduce_mean()
             optimizer.step()
@@ -132,10 +160,26 @@ def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None, ckpt_p
     return history
 
 
-def synthetic_batches(name: str, n: int, device, rank: int = 0, world: int = 1):
-    spec = CONFIGS[name]
-    for i in range(rank, n, world):                                                   # scene-batches shard over ranks
-        yield synth(**dict(spec["synth"], seed=spec["synth"]["seed"] + 97 * i)).to(device)
+class synthetic_batches:
+    """`n` synthetic scene-batches of BASELINE configuration `name`, sharded round-robin over the ranks.  `even` (the
+    training loop): the batch list is padded by wrapping around to a multiple of `world`, so every rank runs the same
+    number of steps (the DistributedSampler rule Lightning applies for the reference) -- 5 batches on 2 ranks are 3 steps
+    each, batch 0 twice.  Evaluation passes even=False: no per-step collective, no batch counted twice."""
+
+    def __init__(self, name: str, n: int, device, rank: int = 0, world: int = 1, even: bool = False):
+        self.spec, self.device = CONFIGS[name], device
+        order = list(range(n))
+        if even and world > 1 and n % world:
+            pad = world - n % world
+            order += (order * (pad // max(n, 1) + 1))[:pad]
+        self.ids = order[rank::world]
+
+    def __len__(self) -> int:
+        return len(self.ids)
+
+    def __iter__(self):
+        for i in self.ids:
+            yield synth(**dict(self.spec["synth"], seed=self.spec["synth"]["seed"] + 97 * i)).to(self.device)
 
 
 def datamodule_batches(cfg: dict, device, rank: int = 0, world: int = 1, nu_dir=None, argo_dir=None):
@@ -207,7 +251,7 @@ def main() -> None:
                 return iter(loader)
         else:
             def per_epoch(epoch):
-                return synthetic_batches(args.synthetic, args.batches, dev, rank, world)
+                return synthetic_batches(args.synthetic, args.batches, dev, rank, world, even=True)
         hist = train(model, per_epoch, args.epochs, ckpt_path=args.save, resume=args.resume,
                      log=(lambda e, i, l, parts: print(f"epoch {e} step {i} loss {l:.5f}")) if rank == 0 else None)
         if rank == 0:

@@ -49,8 +49,12 @@ class LocalEncoderSDESepPara2(ParamTree):
         self.set_init_seed(None)
         self._rt = runtime.StageRuntime(self, "encoder")
 
-    def forward(self, data, noise: Optional["runtime.NoiseSpec"] = None):
-        return self._rt.encoder_forward(data, noise)
+    def forward(self, data, noise: Optional["runtime.NoiseSpec"] = None, preserve_side_effects: Optional[bool] = None):
+        """`preserve_side_effects` (default: the `preserve_side_effects` constructor kwarg, else False): also leave
+        `data['edge_index_{t}']` / `data['edge_attr_{t}']` on the batch as the reference's forward does (ENC:107-110)."""
+        if preserve_side_effects is None:
+            preserve_side_effects = bool(getattr(self, "preserve_side_effects", False))
+        return self._rt.encoder_forward(data, noise, preserve_side_effects=preserve_side_effects)
 
     def forward_ood(self, data, noise: Optional["runtime.NoiseSpec"] = None):
         """ENC:204-370: 10 stochastic recurrences from a zero state -> (local_embed, per-actor std)."""

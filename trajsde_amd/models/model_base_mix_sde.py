@@ -106,9 +106,14 @@ class PredictionModelSDENet(nn.Module):
     def device(self) -> torch.device:
         return next(self.parameters()).device
 
-    def forward(self, data, noise: Optional["runtime.NoiseSpec"] = None):
+    def forward(self, data, noise: Optional["runtime.NoiseSpec"] = None, preserve_side_effects: Optional[bool] = None):
         """MODEL:74-102.  `noise` (optional, ours) selects the Philox seed or injected normals; the default
-        draws a fresh Philox seed from torch's global generator, like the reference draws fresh noise."""
+        draws a fresh Philox seed from torch's global generator, like the reference draws fresh noise.
+        `preserve_side_effects=True` (or `preserve_side_effects: true` among the model / encoder kwargs of the YAML) makes
+        the encoder also write `data['edge_index_{t}']`, `data['edge_attr_{t}']` (ENC:107-110); `rotate_mat` and the rotated
+        `y` (MODEL:83-85) are always written."""
+        if preserve_side_effects is None:
+            preserve_side_effects = getattr(self, "preserve_side_effects", None)
         ood = bool(getattr(self, "ood", False))                              # test.py --ood injects this flag (test.py:45-46)
         noise = runtime.NoiseSpec.resolve(noise)
         if self.rotate:
@@ -121,7 +126,8 @@ class PredictionModelSDENet(nn.Module):
         if ood:
             local_embed, stds = self.encoder.forward_ood(data=data, noise=noise)            # MODEL:89-90
         else:
-            local_embed, diff_in, diff_out, label_in, label_out = self.encoder(data=data, noise=noise)
+            local_embed, diff_in, diff_out, label_in, label_out = self.encoder(data=data, noise=noise,
+                                                                               preserve_side_effects=preserve_side_effects)
         global_embed = self.aggregator(data=data, local_embed=local_embed)
         out = self.decoder(data=data, local_embed=local_embed, global_embed=global_embed, noise=noise)
         if ood:

@@ -71,18 +71,25 @@ def rotate_inputs(data) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     return rot, y_rot
 
 
-def edge_snapshot(data, t: int, local_radius: float = 50.0, fake_agents: bool = False):
-    """`data['edge_index_{t}']`, `data['edge_attr_{t}']` as the reference's encoder leaves them on the batch
-    (ENC:107-110: subgraph of the nodes valid at step t, attr = pos[src] - pos[dst]; the radius filter of ENC:115 is
-    applied only to the copies fed to the AA encoder, not to these).  The HIP path never materialises the 21 lists
-    (DESIGN.md 3); this helper rebuilds one on request with plain tensor indexing for callers that want to look at it."""
-    ei, pad, pos = data["edge_index"], data["padding_mask"], data["positions"]
-    if fake_agents:
-        raise NotImplementedError("snapshots of the fake-agent copies are internal to the encoder")
-    valid = ~pad[:, t]
-    keep = valid[ei[0]] & valid[ei[1]]
-    e = ei[:, keep]
-    return e, pos[e[0], t] - pos[e[1], t]
+def edge_snapshots(data, historical_steps: int) -> None:
+    """The encoder's side effect on the batch (ENC:88-99, 107-110): `data['edge_index_{t}']` = the edges of the EXTENDED
+    edge list (edge_index plus the in-edges of the target agents re-pointed at their fake copies, node ids N..N+A-1) whose
+    two endpoints are valid at step t, in the order of the input list, and `data['edge_attr_{t}']` = pos[src,t] - pos[dst,t]
+    (no radius filter: ENC:115 applies it only to the copies fed to the AA encoder).  The HIP path never materialises these
+    21 lists (it works on one target-sorted, radius-filtered list); stages write them only when asked to
+    (`preserve_side_effects=True`), with plain device-side tensor indexing -- they feed nothing on the hot path."""
+    ei, pad, pos, agent = data["edge_index"], data["padding_mask"], data["positions"], data["agent_index"]
+    N = data["x"].shape[0]
+    to_agent = torch.isin(ei[1], agent)
+    _, inv = torch.unique(ei[1][to_agent], return_inverse=True)
+    new_edge = torch.cat((ei, torch.stack((ei[0][to_agent], inv + N))), dim=-1)
+    orig = torch.cat((torch.arange(N, device=ei.device), agent))
+    valid, pos_ext = ~pad[orig][:, :historical_steps], pos[orig]
+    for t in range(historical_steps):
+        keep = valid[new_edge[0], t] & valid[new_edge[1], t]
+        e = new_edge[:, keep]
+        data[f"edge_index_{t}"] = e
+        data[f"edge_attr_{t}"] = pos_ext[e[0], t] - pos_ext[e[1], t]
 
 
 class _TableCache:
@@ -115,7 +122,7 @@ class StageRuntime:
         object.__setattr__(self, "module", module)
         self.stage = stage
         self.stage_id = self.STAGE_ID[stage]
-        self._blobs: Dict[int, Tuple[torch.Tensor, object]] = {}
+        self._blobs: Dict[int, tuple] = {}          # stage id -> (blob, parameter stamp, pack-done event, packing stream)
         self._names: Dict[int, list] = {}
 
     # ---------------------------------------------------------------- weights
@@ -175,8 +182,18 @@ class StageRuntime:
             with torch.cuda.device(first.device):
                 _lib.check(L.trajsde_pack_weights(stage_id, nl, K, arr, len(tensors), blob.data_ptr(), n_floats, _stream()),
                            "trajsde_pack_weights")
-            self._blobs[stage_id] = (blob, stamp)
-        return self._blobs[stage_id][0]
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+            self._blobs[stage_id] = (blob, stamp, ev, torch.cuda.current_stream(first.device).cuda_stream)
+        blob, stamp_, ev, packed_on = self._blobs[stage_id]
+        if ev is not None:
+            if ev.query():
+                self._blobs[stage_id] = (blob, stamp_, None, packed_on)        # pack finished: nothing left to order against
+            else:
+                cur = torch.cuda.current_stream(first.device)
+                if cur.cuda_stream != packed_on:
+                    cur.wait_event(ev)      # packed on another stream (multi-stream drivers): order the reads behind the pack
+        return blob
 
     # ---------------------------------------------------------------- decoder
     def decoder_forward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor,
@@ -247,8 +264,9 @@ class StageRuntime:
         return {"loss": loss[0], "best_mode": best, "grads": grads, "d_local_embed": d_local, "d_global_embed": d_global}
 
     # ---------------------------------------------------------------- encoder
-    def encoder_forward(self, data, noise: Optional[NoiseSpec] = None):
-        """LocalEncoderSDESepPara2.forward (ENC:66-202) -> (local_embed, diff_in, diff_out, label_in, label_out)."""
+    def encoder_forward(self, data, noise: Optional[NoiseSpec] = None, preserve_side_effects: bool = False):
+        """LocalEncoderSDESepPara2.forward (ENC:66-202) -> (local_embed, diff_in, diff_out, label_in, label_out).
+        `preserve_side_effects`: also leave `edge_index_{t}` / `edge_attr_{t}` on the batch like ENC:107-110 does."""
         m = self.module
         noise = NoiseSpec.resolve(noise)
         gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), noise)
@@ -274,7 +292,9 @@ class StageRuntime:
                        "trajsde_encoder_forward")
         if cap:
             m.last_intermediates = {"aa_out": aa_out, "latent_ys": latent, "E_aa": gc.graph.E_aa, "E_g": gc.graph.E_g,
-                                    "E_la": gc.graph.E_la}
+                                    "E_la": gc.graph.E_la, **gc.edge_lists()}
+        if preserve_side_effects:
+            edge_snapshots(data, H)                                                         # ENC:107-110
         diff_in, diff_out = torch.chunk(diff_pick, 2, 0)                                    # ENC:194
         return (local, diff_in, diff_out, torch.full_like(diff_in, m.real_label), torch.full_like(diff_out, m.fake_label))
 
@@ -551,12 +571,45 @@ class GraphContext:
                                                self.edges_ws.data_ptr(), ews_bytes, C.byref(self.graph), _stream()),
                        "trajsde_graph_compact")
 
+    def _i32(self, buf: torch.Tensor, ptr: Optional[int], n: int) -> torch.Tensor:
+        """int32 view of `n` entries at device address `ptr` inside the workspace tensor `buf`"""
+        if not ptr or n <= 0:
+            return torch.empty(0, dtype=torch.int32, device=self.device)
+        off = ptr - buf.data_ptr()
+        assert 0 <= off and off + 4 * n <= buf.numel() and off % 4 == 0
+        return buf[off:off + 4 * n].view(torch.int32)
+
+    def edge_lists(self) -> Dict[str, torch.Tensor]:
+        """the compacted lists as tensors (copies): what ENC:107-118, AGG:41 and ENC:198 leave of the input edge lists, in
+        this build's canonical order (target-major, senders ascending) -- for edge-for-edge comparison with the oracle"""
+        g, b = self.graph, self.batch
+        n_aa = b.H * g.Nt
+        return {"aa_src": self._i32(self.edges_ws, g.aa_src, g.E_aa).clone(), "aa_dst": self._i32(self.edges_ws, g.aa_dst, g.E_aa).clone(),
+                "aa_segptr": self._i32(self.ws, g.aa_segptr, n_aa + 1).clone(),
+                "g_src": self._i32(self.edges_ws, g.g_src, g.E_g).clone(), "g_dst": self._i32(self.edges_ws, g.g_dst, g.E_g).clone(),
+                "g_segptr": self._i32(self.ws, g.g_segptr, b.N + 1).clone(),
+                "la_lane": self._i32(self.edges_ws, g.la_lane, g.E_la).clone(), "la_dst": self._i32(self.edges_ws, g.la_dst, g.E_la).clone(),
+                "la_segptr": self._i32(self.ws, g.la_segptr, b.N + 1).clone()}
+
+    @staticmethod
+    def _input_stamp(data) -> tuple:
+        """identity AND in-place version of every batch tensor the graph is derived from: an edited batch never reuses a
+        stale graph, even under a repeated noise seed"""
+        out = []
+        for k in ("x", "positions", "padding_mask", "bos_mask", "rotate_angles", "edge_index", "agent_index", "batch", "source",
+                  "lane_positions", "lane_paddings", "lane_actor_index", "lane_actor_vectors", "rotate_mat"):
+            t = data[k] if k in data else None
+            out.append((t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else None)
+        return tuple(out)
+
     @classmethod
     def get(cls, data, radius: Optional[float], H: int, noise: Optional[NoiseSpec], fake_agents: bool = True) -> "GraphContext":
         gc = data[cls.KEY] if cls.KEY in data else None
         key = None
         if radius is not None and noise is not None:
-            key = (float(radius), int(noise.seed), id(noise.z_fake), id(noise.fake_row_ids), bool(fake_agents), id(data["x"]))
+            key = (float(radius), int(noise.seed), id(noise.z_fake), id(noise.fake_row_ids), bool(fake_agents), cls._input_stamp(data))
+        elif gc is not None and getattr(gc, "build_key", None) is not None and gc.build_key[-1] != cls._input_stamp(data):
+            gc = None                                                     # the batch was edited since the encoder built the graph
         if gc is None or (key is not None and getattr(gc, "build_key", None) != key):
             # the encoder (which owns the radius and the fake-agent noise) builds; the aggregator and the backward
             # entry points of the same step (same noise) reuse
