@@ -37,6 +37,13 @@ int trajsde_abi_version(void);
 /* matrix products per fp32 product of the split-precision kernels this library was built with:
  * 3 = fp16x3 (default), 6 = bf16x6 (build with TRAJSDE_SPLIT=bf16x6); see csrc/tile.hpp */
 int trajsde_split_products(void);
+/* fp16 range guard of the split-precision products (csrc/range.hpp).  Kernels that feed a data-dependent, unnormalised
+ * tensor (SDE states, rows entering the recurrence / the decoder, attention aggregates, FFN hidden units) or a weight to an
+ * fp16x3 product set a sticky per-device bit when a magnitude reaches 65504, where the fp16 pieces would saturate.  This call
+ * synchronises `stream`, reads (and with reset != 0 clears) the bits and returns TRAJSDE_OK or TRAJSDE_ERR_UNSUPPORTED with
+ * the affected sites in trajsde_last_error(); *sites_out (optional) receives the bit mask.  Call it where the host
+ * synchronises anyway (end of an evaluation epoch, when a loss value is read); always 0 in a bf16x6 build. */
+int trajsde_range_status(int reset, uint32_t* sites_out, void* stream);
 
 /* ---- weights ----------------------------------------------------------------------------------
  * Parameters stay owned by the Python modules (nn.Parameter).  Each stage hands the library an array

@@ -429,7 +429,7 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
         assert torch.equal(outs["split"][key], outs["one_tile"][key]), key             # two tiles per wave: the same bits
 
 
-@pytest.mark.parametrize("scale", [1e-3, 1.0, 30.0])
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 30.0, 1e3, 2e4])
 def test_sde_step_matches_float64_over_state_magnitudes(scale, dev):
     """one Euler-Maruyama step through the C-ABI (trajsde_sde_step, the split-precision drift/diffusion MLPs) against the
     oracle's drift/diffusion evaluated in float64, for hidden states of very different magnitude and a ragged row count:
@@ -463,6 +463,56 @@ def test_sde_step_matches_float64_over_state_magnitudes(scale, dev):
     want = y64 + f * dt + gs * (z[0].double() * sq)                    # SDEINT:483
     err = float((out.cpu().double() - want).abs().max())
     assert err <= 5e-6 * max(1.0, scale), (scale, err)
+    _lib.check_range()                                                  # in range: the guard stays quiet
+
+
+def test_fp16_range_guard_is_loud(dev):
+    """magnitudes the fp16 pieces cannot hold (>= 65504) are refused with TRAJSDE_ERR_UNSUPPORTED instead of saturating
+    silently: a hidden state of 7e4 through trajsde_sde_step, an aggregate of 7e4 through the node block of the aggregator,
+    a weight of 1e5; and the flag is sticky until it is read"""
+    import ctypes as C
+    from trajsde_amd import _lib
+    from trajsde_amd.runtime import NoiseSpec, rotate_inputs
+    from trajsde_amd.schedule import decoder_schedule
+    from trajsde_amd.synth import synth
+    _lib.check_range()                                                  # start clean
+    model, cfg = H.build_model(2, 5, 0.5, init_seed=4)
+    model = model.to(dev)
+    rows = 40
+    tab = np.ascontiguousarray(decoder_schedule(5, 0.5).step_table())
+    e = tab[1].ctypes.data_as(C.POINTER(C.c_float))
+    nz = _lib.Noise(C.c_uint64(3), None, None)
+    st = torch.cuda.current_stream().cuda_stream
+    for scale, ok in ((6.0e4, True), (7.0e4, False)):
+        y = torch.full((rows, 64), scale, device=dev)
+        y[:, ::2] *= -1
+        out = torch.empty_like(y)
+        _lib.check(_lib.lib().trajsde_sde_step(rows, model.decoder._rt.blob().data_ptr(), y.data_ptr(), out.data_ptr(), e, 0, C.byref(nz), st))
+        if ok:
+            _lib.check_range()
+        else:
+            with pytest.raises(_lib.TrajsdeError, match="decoder SDE state"):
+                _lib.check_range()
+            _lib.check_range()                                          # reading cleared it
+    # whole forward on a sane batch: quiet
+    batch = synth(S=2, n=6, L=3, F=5, box=50.0, seed=5).to(dev)
+    model(batch, noise=NoiseSpec(seed=1))
+    _lib.check_range()
+    # the decoder fed with an embedding row of 1e5
+    batch["rotate_mat"], _ = rotate_inputs(batch)
+    N = batch.num_nodes
+    local = torch.randn(N, 64, device=dev)
+    glob = torch.randn(2, N, 64, device=dev)
+    glob[1, 3, 7] = 1.0e5
+    model.decoder(data=batch, local_embed=local, global_embed=glob, noise=NoiseSpec(seed=1))
+    with pytest.raises(_lib.TrajsdeError, match="decoder embedding inputs"):
+        _lib.check_range()
+    # a weight without an fp16 image
+    with torch.no_grad():
+        model.decoder.p("lsde_func.f_func.net.2.weight")[5, 5] = 1.0e5
+    model.decoder(data=batch, local_embed=local, global_embed=glob[:, :, :].clamp(-10, 10), noise=NoiseSpec(seed=1))
+    with pytest.raises(_lib.TrajsdeError, match="weight"):
+        _lib.check_range()
 
 
 def test_errors_are_loud(dev):

@@ -48,6 +48,7 @@ SIGNATURES = {
     "trajsde_last_error": (C.c_char_p, []),
     "trajsde_split_products": (C.c_int, []),
     "trajsde_abi_version": (C.c_int, []),
+    "trajsde_range_status": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), P]),
     "trajsde_param_count": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trajsde_param_name": (C.c_char_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "trajsde_blob_floats": (I64, [C.c_int, C.c_int, C.c_int]),
@@ -117,6 +118,14 @@ def check(status: int, what: str = "") -> None:
     if status != 0:
         msg = lib().trajsde_last_error().decode()
         raise TrajsdeError(f"{what or 'trajsde call'} failed ({status}): {msg}")
+
+
+def check_range(stream: Optional[int] = None, reset: bool = True) -> None:
+    """raise TrajsdeError if a launch since the last check fed a magnitude >= 65504 to an fp16x3 product (csrc/range.hpp);
+    synchronises `stream` (default: torch's current stream)"""
+    import torch
+    st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    check(lib().trajsde_range_status(1 if reset else 0, None, st), "trajsde_range_status")
 
 
 def profile_report() -> dict:

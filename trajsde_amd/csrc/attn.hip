@@ -12,6 +12,7 @@
 #include "kernels.hpp"
 #include "layouts.hpp"
 #include "attn_common.hpp"
+#include "range.hpp"
 #include "tile.hpp"
 
 #include <type_traits>
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ i
     f4 a[4], n[4], g[4], s[4];
     load_row(a, agg, r, L.g);
     load_row(n, xn, r, L.g);
+    range_note(absmax<4>(a), RS_NODE_AGG);
     lin(g, a, U::WIH, U::BIH);
     {
       f4 h[4];
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ i
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
       for (int c = 0; c < 4; ++c) a[jt][c] = a[jt][c] + g[jt][c] * (s[jt][c] - a[jt][c]);
+    range_note(absmax<4>(a), RS_NODE_AGG);
     lin(s, a, U::WOUT, U::BOUT);
     load_row(n, x, r, L.g);
 #pragma unroll
@@ -470,6 +473,7 @@ __global__ __launch_bounds__(512) void k_ffn(const float* __restrict__ img_g, co
     load_row(n, xn2, r, L.g);
     linear<16, 4>(hid, n, lds + FfnL::W1, lds + FfnL::B1, L);
     relu<16>(hid);
+    range_note(absmax<16>(hid), RS_FFN_HIDDEN);
     linear<4, 16>(o, hid, lds + FfnL::W2, lds + FfnL::B2, L);
     load_row(n, x1, r, L.g);
 #pragma unroll

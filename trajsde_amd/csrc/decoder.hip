@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "layouts.hpp"
 #include "philox.hpp"
+#include "range.hpp"
 #include "sde_funcs.hpp"
 #include "tile.hpp"
 
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(1024) void k_dec_init(const float* __restrict__ blo
     f4 gl[4], lo[4], a[4];
     load_row(gl, global, r, L.g);
     load_row(lo, local, r % N, L.g);
+    range_note(fmaxf(absmax<4>(gl), absmax<4>(lo)), RS_DEC_INPUT);
     load_vec<4>(a, lds + DecInitL::BA, L.g);
     linear_acc<4, 4>(a, gl, lds + DecInitL::WA_G, L.lane);
     linear_acc<4, 4>(a, lo, lds + DecInitL::WA_L, L.lane);
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(MAXT) void k_sde_decode(const float* __restrict__ b
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) prev[jt] = y[jt];
       em_update(y, f, gs, z, dt, sq);
+      range_note(absmax<4>(y), RS_DEC_STATE);                 // the state is the next step's (and the heads') split operand
       // emit every output whose interpolation bracket closes with this step (linear_interp of the solver)
       while (o < T && int(out_tab[o * 4]) == k + 1) {
         keep_lds_reads_here();
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blo
     const int64_t r = row < rows ? row : rows - 1;
     f4 y[4], f[4], z[4];
     load_row(y, y_in, r, L.g);
+    range_note(absmax<4>(y), RS_DEC_STATE);
     float gs;
     if constexpr (X6) {
       drift_eval_x6(f, y, lds + DL::F, sn, cs, L);

@@ -8,6 +8,7 @@
 #include "bwd.hpp"
 #include "common.hpp"
 #include "layouts.hpp"
+#include "range.hpp"
 
 namespace tsde {
 
@@ -19,6 +20,13 @@ int fail(int code, const std::string& msg) {
   last_error_ref() = msg;
   return code;
 }
+
+// registry of the per-translation-unit range flag words (range.hpp); function-local static: safe during static initialisation
+std::vector<RangeReader>& range_readers() {
+  static std::vector<RangeReader> v;
+  return v;
+}
+void register_range_reader(RangeReader r) { range_readers().push_back(r); }
 
 // Packing runs as launches over job tables passed BY VALUE in the kernel arguments (64 jobs per launch; jobs that
 // accumulate onto another's output go in a later launch): a stage has a few hundred small tensors and is re-packed after
@@ -75,6 +83,7 @@ __device__ __forceinline__ void store_split(float x, unsigned short* __restrict_
   // i = ((jo*ks + s)*64 + lane)*8 + j; the pieces of one (jo, s) block sit next to each other: [jo][s][piece][lane][8]
   const int blk = i >> 9, within = i & 511;
 #if TSDE_SPLIT_H3
+  range_note(fabsf(x), RS_WEIGHT);                        // |w| >= 65504 has no fp16 image
   const _Float16 h = _Float16(x);
   const _Float16 l = _Float16(x - float(h));
   dst[(blk * 2) * 512 + within] = __builtin_bit_cast(unsigned short, h);
@@ -890,6 +899,26 @@ int64_t trajsde_profile_report(char* buf, int64_t cap) {
 
 const char* trajsde_last_error(void) { return last_error_ref().c_str(); }
 int trajsde_split_products(void) { return TSDE_SPLIT_H3 ? 3 : 6; }
+
+int trajsde_range_status(int reset, uint32_t* sites_out, void* stream) {
+  static const char* const names[tsde::RS_SITES] = {"decoder SDE state", "decoder embedding inputs", "encoder latent state",
+                                                    "aa_out rows entering the GRU", "attention aggregate / gated update",
+                                                    "FFN hidden units", "a weight (no fp16 image)"};
+  unsigned all = 0;
+  for (tsde::RangeReader r : tsde::range_readers()) {
+    unsigned w = 0;
+    TS_HIP(r(&w, reset != 0, static_cast<hipStream_t>(stream)));
+    all |= w;
+  }
+  if (sites_out) *sites_out = all;
+  if (all == 0) return TRAJSDE_OK;
+  std::string msg = "fp16x3 split-precision range exceeded (|value| >= 65504) in: ";
+  bool first = true;
+  for (unsigned i = 0; i < tsde::RS_SITES; ++i)
+    if (all & (1u << i)) { msg += (first ? "" : ", "); msg += names[i]; first = false; }
+  msg += " -- the results of the affected launches are not valid; rebuild with TRAJSDE_SPLIT=bf16x6 for fp32's exponent range";
+  return tsde::fail(TRAJSDE_ERR_UNSUPPORTED, msg);
+}
 int trajsde_abi_version(void) { return 2; }
 
 int trajsde_param_count(int stage, int num_layers, int num_modes) {

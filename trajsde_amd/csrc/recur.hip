@@ -8,6 +8,7 @@
 #include "kernels.hpp"
 #include "layouts.hpp"
 #include "philox.hpp"
+#include "range.hpp"
 #include "sde_funcs.hpp"
 #include "tile.hpp"
 
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(512) void k_enc_sde_step(const float* __restrict__ 
     f4 y[4], f[4], z[4];
     if (h_in != nullptr) load_row(y, h_in, r, L.g);
     else load_vec<4>(y, hidden0, L.g);                               // ENC:78 learned initial state
+    range_note(absmax<4>(y), RS_ENC_STATE);
     drift_eval(f, y, lds + EncSdeL::F, sn, cs, L);
     const bool is_nus = nus[r] != 0;
     const unsigned long long m = __ballot(is_nus);
@@ -72,6 +74,8 @@ __global__ __launch_bounds__(512) void k_enc_gru_step(const float* __restrict__ 
     f4 h[4], x[4], ur[8];
     load_row(h, h_ode, r, L.g);
     load_row(x, x_t, r, L.g);
+    range_note(absmax<4>(h), RS_ENC_STATE);
+    range_note(absmax<4>(x), RS_ENC_INPUT);
     load_vec<8>(ur, lds + G::BUR, L.g);
     linear_acc<8, 4>(ur, h, lds + G::WUR_H, L.lane);                  // y_concat = [h, x]
     linear_acc<8, 4>(ur, x, lds + G::WUR_X, L.lane);
@@ -249,6 +253,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
       slotk[k] = pick_slot[rowk[k]];
       origk[k] = orig[rowk[k]];
       const f4 y = h0 ? vec_slice(h0, w, L.g) : f4{0.f, 0.f, 0.f, 0.f};      // same initial vector for every row (ENC:78 / :257)
+      range_note(absmax4(y), RS_ENC_STATE);
       lds_write_slice(Yb(k), y, w, L);
     }
   }
@@ -333,6 +338,8 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
         f4 y = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
 #pragma unroll
         for (int c = 0; c < 4; ++c) y[c] = (y[c] + f[c] * dt) + gs * (z[c] * sq);       // SDEINT:483
+        range_note(absmax4(y), RS_ENC_STATE);                                             // operands of the GRU's split products
+        range_note(absmax4(xq[k]), RS_ENC_INPUT);
         lds_write_slice(Yb(k), y, w, L);                                                  // Y now holds h' (all P1 reads are behind two barriers)
         lds_write_slice(Xb(k), xq[k], w, L);
         if (diff_pick != nullptr && inb[k] && slotk[k] >= 0 && eosk[k] == idx)

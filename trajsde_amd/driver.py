@@ -55,6 +55,8 @@ def evaluate(model, batches: Iterable, seed: int = 0) -> dict:
             model.test_step(batch, i)
         else:
             _seeded_test_step(model, batch, i, seed + i + RANK_SEED_STRIDE * rank)
+    if hasattr(model, "check_range"):
+        model.check_range()                                   # no silently saturated fp16x3 operand in this epoch
     return model.metric_results()
 
 
@@ -155,6 +157,8 @@ def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None, ckpt_p
                 log(epoch, i, history[-1], model.last_losses)
             step += 1
         scheduler.step()
+        if hasattr(model, "check_range"):
+            model.check_range()
         if ckpt_path is not None and rank0:
             save_checkpoint(ckpt_path, model, optimizer, scheduler, epoch, step)
     return history

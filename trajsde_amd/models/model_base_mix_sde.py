@@ -136,6 +136,13 @@ class PredictionModelSDENet(nn.Module):
             out["diff_in"], out["diff_out"], out["label_in"], out["label_out"] = diff_in, diff_out, label_in, label_out
         return out
 
+    @staticmethod
+    def check_range() -> None:
+        """raise if a launch since the last check left the fp16 range of the split-precision products (csrc/range.hpp);
+        synchronises the current stream -- call it where the host waits anyway (epoch end, when a loss is read)"""
+        from trajsde_amd import _lib
+        _lib.check_range()
+
     def params_with_gradient(self):
         """the parameters the configured losses reach (everything except the decoder's pi / scale heads and unused
         buffers-as-parameters): the reference's autograd leaves the others' `.grad` at None, so AdamW skips them"""

@@ -95,6 +95,10 @@ CONFIGS = {
     # BASELINE configs[3]: mixed nuScenes+Argoverse training as shipped (K=10, T=60, 128 scenes per GPU: CFG:9-22,106)
     "config4": dict(synth=dict(S=128, n=48, L=150, F=60, box=150.0, seed=4, mixed_source=True),
                     num_modes=10, future_steps=60, max_fut_t=6.0),
+    # the workload BASELINE.json's metric is quoted on (K=6, 20 SDE steps, ~256 agents), batched to fill one GPU: 32 scenes
+    # of 256 agents (N = 8192 actors, ~7.6 M surviving (t, edge) pairs per forward)
+    "metric256": dict(synth=dict(S=32, n=256, L=64, F=20, box=200.0, seed=2, mixed_source=True),
+                      num_modes=6, future_steps=20, max_fut_t=2.0),
     "scene256": dict(synth=dict(S=1, n=256, L=64, F=20, box=200.0, seed=2),
                      num_modes=6, future_steps=20, max_fut_t=2.0),
     "config5": dict(synth=dict(S=8, n=1024, L=256, F=50, box=600.0, seed=5, mixed_source=True),
