@@ -159,7 +159,7 @@ def test_aggregator_backward_matches_autograd(S, n, K, heads, kw, dev):
     assert _rel(res["d_local_embed"], d_local) <= REL
 
 
-def _oracle_encoder_grads(model, cfg, batch_cpu, d_local, seed, diff_weight):
+def _oracle_encoder_grads(model, cfg, batch_cpu, d_local, seed, diff_weight, dt=torch.float64):
     """autograd over the oracle's encoder restatement, evaluated in float64: several encoder gradients (LayerNorm
     chains summed over every edge of 21 snapshots) are ill-conditioned enough that the float32 autograd result is
     itself ~2e-4 away from the float64 one, so the higher-precision run of the same code is the reference here"""
@@ -168,7 +168,6 @@ def _oracle_encoder_grads(model, cfg, batch_cpu, d_local, seed, diff_weight):
     from trajsde_amd.schedule import encoder_schedule
     c = restate.flat_cfg(cfg)
     sched = encoder_schedule(c["historical_steps"], c["max_past_t"], c["minimum_step"])
-    dt = torch.float64
     P = {k: (v.detach().cpu().to(dt) if v.is_floating_point() else v.detach().cpu().clone()) for k, v in model.state_dict().items()}
     names = [k for k in P if k.startswith("encoder.") and P[k].is_floating_point()]
     for k in names:
@@ -222,6 +221,9 @@ def test_encoder_backward_matches_autograd(S, n, kw, diff_weight, dev):
     res = model.encoder._rt.encoder_backward(data, d_local.to(dev), noise, diff_weight=diff_weight, want_boundaries=True)
     torch.cuda.synchronize()
     want, bce, d_aa = _oracle_encoder_grads(model, cfg, batch, d_local, 23, diff_weight)
+    # the yardstick for "ill-conditioned": how far torch.autograd over the SAME oracle code lands from the float64 result when
+    # it runs in float32 -- a float32 kernel cannot be asked to do better than about that
+    want32, _, _ = _oracle_encoder_grads(model, cfg, batch, d_local, 23, diff_weight, dt=torch.float32)
     assert abs(float(res["diff_loss"]) - diff_weight * bce) <= 1e-5 * max(1.0, bce)
     assert _rel(res["d_aa_out"], d_aa) <= REL
     got = res["grads"]
@@ -237,8 +239,9 @@ def test_encoder_backward_matches_autograd(S, n, kw, diff_weight, dev):
         # the edge-embedding weight gradients are ill-conditioned: fp32 torch.autograd over the oracle is itself 2e-4 of
         # the fp64 reference away on them (hence fp64 as the reference); allow twice that for the fp32 kernels
         rel = 2 * REL if "_embed.module_list" in k else REL
-        if (err > 5e-5 or scale > 5e-5) if zero_by_symmetry else (err > rel * scale + 1e-7):
-            bad.append((k, err, scale))
+        noise32 = float((want32[k].double() - want[k].double()).abs().max())           # float32 autograd's own deviation
+        if (err > 5e-5 or scale > 5e-5) if zero_by_symmetry else (err > max(rel * scale, 2 * noise32) + 1e-7):
+            bad.append((k, err, scale, noise32))
     assert not bad, bad
 
 
