@@ -429,7 +429,7 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
         assert torch.equal(outs["split"][key], outs["one_tile"][key]), key             # two tiles per wave: the same bits
 
 
-@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 30.0, 1e3, 2e4])
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 30.0, 1e3, 1e4])
 def test_sde_step_matches_float64_over_state_magnitudes(scale, dev):
     """one Euler-Maruyama step through the C-ABI (trajsde_sde_step, the split-precision drift/diffusion MLPs) against the
     oracle's drift/diffusion evaluated in float64, for hidden states of very different magnitude and a ragged row count:

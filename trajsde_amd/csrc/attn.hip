@@ -147,6 +147,161 @@ __global__ __launch_bounds__(THREADS) void k_edge_kv2(const float* __restrict__ 
 template __global__ void k_edge_kv2<512>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*, int);
 template __global__ void k_edge_kv2<768>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*, int);
 
+// ------------------------------------------------------------------------------------------------ fused edge attention
+// k_edge_attn2: the edge kernel above with the segment softmax + aggregation folded in, so that the per-edge v rows and
+// logits (288 B per edge, written once and read once: 2 x 2 GB per forward at 32 scenes x 256 agents) never reach HBM.
+//
+// Layout ("one edge stream per tile row").  The compacted edge list is sorted by target.  It is cut into `nstreams` chunks
+// of exactly C consecutive edges (the last one shorter); row n of a wave's tile walks chunk `stream(n)` front to back, one
+// edge per tile iteration.  A tile iteration is the same 16-row matrix work as before (embedding, lin_k | lin_v), but its 16
+// rows are 16 DIFFERENT streams -- so the online softmax of a row is lane-local: lane (n, g) owns features 16jt+4g+c of row n,
+// which belong to head 2jt + (g>>1), and keeps the running (m, s) of those heads and the running weighted sum of its 16 value
+// features in registers across iterations.  No cross-lane reduction beyond the per-head dot product that the logits always
+// needed, no segmented scan, no atomics.  Every stream has the same length, so all rows of all waves run the same number of
+// iterations: balanced by construction, whatever the in-degree distribution.
+//
+// When a row's target changes (and at the end of its chunk) the row flushes one RECORD -- acc[64] | m[16] | s[16], 384 B -- to
+// slot (target + stream): along the edge list either the target or the stream advances between consecutive records, so the
+// slot is unique and the records of a target sit at consecutive slots target + (first stream .. last stream).  A target whose
+// segment lies inside one chunk produces one record; one that straddles a chunk boundary produces one per chunk it touches.
+// k_seg_merge (one wave per target, lane = feature) combines them in stream order and normalises like PyG's softmax
+// (sum + 1e-16).  The chunking depends only on E, so results are bitwise reproducible and independent of the input edge order.
+struct SegState {
+  f4 acc[4], m, s;
+};
+__device__ __forceinline__ void seg_reset(SegState& S) {
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) S.acc[jt] = f4{0.f, 0.f, 0.f, 0.f};
+  S.m = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  S.s = f4{0.f, 0.f, 0.f, 0.f};
+}
+// per-head logits of the 16 rows of a tile: lane (n, g) gets, for jt = 0..3, the logit of the head its features 16jt+4g+c
+// belong to (8 heads: head 2jt + (g>>1), completed by the partner lane group g^1; 4 heads: head jt, all four groups)
+__device__ __forceinline__ f4 head_logits(const f4 (&qv)[4], const f4 (&k)[4], int heads) {
+  f4 lg;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    float p = qv[jt][0] * k[jt][0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) p = fmaf(qv[jt][c], k[jt][c], p);
+    p = xor16_sum(p);
+    if (heads == 4) p = xor32_sum(p);
+    lg[jt] = p * (heads == 4 ? 0.25f : INV_SQRT_DH);
+  }
+  return lg;
+}
+__device__ __forceinline__ void seg_update(SegState& S, const f4& lg, const f4 (&v)[4]) {
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    const float mn = fmaxf(S.m[jt], lg[jt]);
+    const float sc = fast_exp(S.m[jt] - mn);             // first edge of a segment: exp(-inf) = 0
+    const float ex = fast_exp(lg[jt] - mn);
+    S.m[jt] = mn;
+    S.s[jt] = fmaf(S.s[jt], sc, ex);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) S.acc[jt][c] = fmaf(S.acc[jt][c], sc, ex * v[jt][c]);
+  }
+}
+__device__ __forceinline__ void seg_flush(const SegState& S, float* __restrict__ rec, int64_t slot, int g) {
+  float* r = rec + slot * SEG_REC;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(r + 16 * jt + 4 * g) = S.acc[jt];
+  *reinterpret_cast<f4*>(r + 64 + 4 * g) = S.m;           // m / s of lane group g at [4g + jt]
+  *reinterpret_cast<f4*>(r + 80 + 4 * g) = S.s;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict__ img_g, const float* __restrict__ geom,
+                                                        const int32_t* __restrict__ dst, const float* __restrict__ q, int64_t E, int C,
+                                                        float* __restrict__ rec, int heads) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using EL = EdgeL6;
+  stage_blob(lds, img_g, EL::SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t nstreams = (E + C - 1) / C;
+  const int64_t s0 = (int64_t(blockIdx.x) * waves + wave) * 32 + L.n, s1 = s0 + 16;      // the two tiles' streams of this lane's rows
+  if ((int64_t(blockIdx.x) * waves + wave) * 32 >= nstreams) return;                       // whole wave beyond the list (uniform)
+  if ((wave >> 2) & 1) {                                   // see k_edge_kv: start every other wave of a SIMD half a tile late
+    for (int i = 0; i < 2 * TSDE_SKEW_SLEEPS; ++i) __builtin_amdgcn_s_sleep(32);
+  }
+  SegState S0, S1;
+  seg_reset(S0);
+  seg_reset(S1);
+  int cur0 = -1, cur1 = -1;
+  const int64_t b0 = s0 * C, b1 = s1 * C;
+  for (int it = 0; it < C; ++it) {
+    keep_lds_reads_here();
+    const int64_t e0 = b0 + it, e1 = b1 + it;
+    const bool ok0 = e0 < E, ok1 = e1 < E;                 // only the last stream is short; streams >= nstreams are empty
+    const int64_t c0 = ok0 ? e0 : E - 1, c1 = ok1 ? e1 : E - 1;
+    const f4 g0 = *reinterpret_cast<const f4*>(geom + 4 * c0);
+    const f4 g1 = *reinterpret_cast<const f4*>(geom + 4 * c1);
+    const int d0 = dst[c0], d1 = dst[c1];
+    if (ok0 && d0 != cur0) {                               // the row's target changes: its finished segment part leaves
+      if (cur0 >= 0) seg_flush(S0, rec, int64_t(cur0) + s0, L.g);
+      seg_reset(S0);
+      cur0 = d0;
+    }
+    if (ok1 && d1 != cur1) {
+      if (cur1 >= 0) seg_flush(S1, rec, int64_t(cur1) + s1, L.g);
+      seg_reset(S1);
+      cur1 = d1;
+    }
+    f4 emb0[4], emb1[4], kv0[8], kv1[8], qv[4];
+    edge_embed2_x6(emb0, emb1, g0, g1, lds, L);
+    load_vec<8>(kv0, lds + EL::BKV, L.g);
+    load_vec<8>(kv1, lds + EL::BKV, L.g);
+    linear_acc_x6_2<8, 4>(kv0, kv1, emb0, emb1, lds + EL::WKV, L.lane);
+    {
+      load_row(qv, q, d0, L.g);
+      const f4 k[4] = {kv0[0], kv0[1], kv0[2], kv0[3]};
+      const f4 vv[4] = {kv0[4], kv0[5], kv0[6], kv0[7]};
+      const f4 lg = head_logits(qv, k, heads);
+      if (ok0) seg_update(S0, lg, vv);
+    }
+    {
+      load_row(qv, q, d1, L.g);
+      const f4 k[4] = {kv1[0], kv1[1], kv1[2], kv1[3]};
+      const f4 vv[4] = {kv1[4], kv1[5], kv1[6], kv1[7]};
+      const f4 lg = head_logits(qv, k, heads);
+      if (ok1) seg_update(S1, lg, vv);
+    }
+  }
+  if (cur0 >= 0) seg_flush(S0, rec, int64_t(cur0) + s0, L.g);
+  if (cur1 >= 0) seg_flush(S1, rec, int64_t(cur1) + s1, L.g);
+}
+template __global__ void k_edge_attn2<512>(const float*, const float*, const int32_t*, const float*, int64_t, int, float*, int);
+template __global__ void k_edge_attn2<768>(const float*, const float*, const int32_t*, const float*, int64_t, int, float*, int);
+
+// records of one target -> agg row.  One wave per target, lane = feature f (jt = f>>4, g = (f>>2)&3); a target's records sit
+// at slots target + (first stream .. last stream) of its segment and are combined in that order.
+__global__ __launch_bounds__(256) void k_seg_merge(const int32_t* __restrict__ segptr, const float* __restrict__ rec, int C, int64_t R,
+                                                   float* __restrict__ agg) {
+  const int lane = threadIdx.x & 63;
+  const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (node >= R) return;
+  const int beg = segptr[node], end = segptr[node + 1];
+  float out = 0.f;
+  if (end > beg) {
+    const int c0 = beg / C, c1 = (end - 1) / C;
+    const int ms = 4 * ((lane >> 2) & 3) + (lane >> 4);    // index of this feature's (m, s) inside a record
+    const float* r = rec + (node + c0) * SEG_REC;
+    float m = r[64 + ms], s = r[80 + ms], acc = r[lane];
+    for (int c = c0 + 1; c <= c1; ++c) {
+      r += SEG_REC;
+      const float mp = r[64 + ms], sp = r[80 + ms], ap = r[lane];
+      const float mn = fmaxf(m, mp);
+      const float a = fast_exp(m - mn), b = fast_exp(mp - mn);
+      s = s * a + sp * b;
+      acc = acc * a + ap * b;
+      m = mn;
+    }
+    out = acc / (s + 1e-16f);                              // torch_geometric.utils.softmax denominator
+  }
+  agg[node * 64 + lane] = out;
+}
+
 // global interactor: relative-pose embedding only (AGG:42-51), reused by all layers
 template <bool X6>
 __global__ __launch_bounds__(1024) void k_edge_embed(const float* __restrict__ img_g, const float* __restrict__ geom, int64_t E,

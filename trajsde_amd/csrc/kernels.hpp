@@ -15,6 +15,25 @@ __global__ void k_edge_kv(const float* img, const float* geom, const int32_t* ds
 template <int THREADS>
 __global__ void k_edge_kv2(const float* img, const float* geom, const int32_t* dst, const float* q, int64_t E, float* logits, float* v,
                            int heads);
+// fused edge attention (attn.hip): edge streams of C consecutive edges, one per tile row; records of SEG_REC floats per
+// (target, stream) pair at slot target + stream
+constexpr int SEG_REC = 96;                       // acc[64] | m[16] | s[16]
+constexpr int SEG_STREAMS_512 = 256 * 8 * 32;     // 256 CUs x 8 waves x 32 rows: every wave of a resident 512-thread grid owns 32 streams
+struct AttnPlan {
+  int C;                                          // edges per stream
+  int64_t nstreams;                               // ceil(E / C)
+  int64_t rec_slots(int64_t targets) const { return targets + nstreams + 1; }
+};
+inline AttnPlan attn_plan(int64_t E, int streams_target = SEG_STREAMS_512) {
+  AttnPlan p;
+  p.C = int((E + streams_target - 1) / streams_target);
+  if (p.C < 1) p.C = 1;
+  p.nstreams = (E + p.C - 1) / p.C;
+  return p;
+}
+template <int THREADS>
+__global__ void k_edge_attn2(const float* img, const float* geom, const int32_t* dst, const float* q, int64_t E, int C, float* rec, int heads);
+__global__ void k_seg_merge(const int32_t* segptr, const float* rec, int C, int64_t R, float* agg);
 template <bool X6>
 __global__ void k_edge_embed(const float* img, const float* geom, int64_t E, float* emb_out);
 template <bool X6>

@@ -19,6 +19,11 @@ static int env_threads(const char* name, int dflt) {
 static bool edge_x6() { static bool v = []() { const char* e = getenv("TRAJSDE_EDGE_FP32"); return !(e && atoi(e) != 0); }(); return v; }
 static bool edge_pair() { static bool v = []() { const char* e = getenv("TRAJSDE_EDGE_PAIR"); return !(e && atoi(e) == 0); }(); return v; }   // two tiles per wave (default on)
 static int pair_threads() { static int t = []() { const char* e = getenv("TRAJSDE_PAIR_THREADS"); const int v = e ? atoi(e) : 768; return v == 512 ? 512 : 768; }(); return t; }
+// fused edge attention (k_edge_attn2 + k_seg_merge: no per-edge v / logits in HBM): default; TRAJSDE_ATTN_FUSED=0 runs the
+// two-kernel form (k_edge_kv2 -> HBM -> k_seg_softmax_agg) that the backward's recomputation still uses
+static bool attn_fused() { static bool v = []() { const char* e = getenv("TRAJSDE_ATTN_FUSED"); return !(e && atoi(e) == 0); }(); return v && edge_x6() && edge_pair(); }
+static int fused_threads() { static int t = []() { const char* e = getenv("TRAJSDE_FUSED_THREADS"); const int v = e ? atoi(e) : 512; return v == 768 ? 768 : 512; }(); return t; }
+static AttnPlan fused_plan(int64_t E) { return attn_plan(E, 256 * 32 * (fused_threads() / 64)); }
 static int threads_edge() { static int t = env_threads("TRAJSDE_THREADS_EDGE", 1024); return t; }
 static int threads_node() { static int t = env_threads("TRAJSDE_THREADS_NODE", 512); return t; }
 static int threads_recur() { static int t = env_threads("TRAJSDE_THREADS_RECUR", 256); return t; }
@@ -26,17 +31,21 @@ static int threads_recur() { static int t = env_threads("TRAJSDE_THREADS_RECUR",
 struct EncWs {
   float *center, *cn, *q, *logits, *v, *agg, *x1, *xn2, *aa_out, *hA, *hB, *lat, *al_xn, *al_q, *al_logits, *al_v, *al_agg, *al_x1,
       *al_xn2;
+  float *rec, *al_rec;          // fused form: (target, stream) records instead of per-edge logits / v
   int64_t total;
   bool ok;
   EncWs(const trajsde_batch* b, const trajsde_graph* g, void* ws, int64_t bytes) {
     Carver c(ws, bytes);
     const int64_t R = int64_t(b->H) * g->Nt, N = b->N;
+    const bool fused = attn_fused();
     center = c.take<float>(R * 64); cn = c.take<float>(R * 64); q = c.take<float>(R * 64);
-    logits = c.take<float>(int64_t(g->E_aa) * 8 + 8); v = c.take<float>(int64_t(g->E_aa) * 64 + 64);
+    rec = c.take<float>(fused ? fused_plan(g->E_aa).rec_slots(R) * SEG_REC : 4);
+    al_rec = c.take<float>(fused ? fused_plan(g->E_la).rec_slots(N) * SEG_REC : 4);
+    logits = c.take<float>(fused ? 8 : int64_t(g->E_aa) * 8 + 8); v = c.take<float>(fused ? 64 : int64_t(g->E_aa) * 64 + 64);
     agg = c.take<float>(R * 64); x1 = c.take<float>(R * 64); xn2 = c.take<float>(R * 64); aa_out = c.take<float>(R * 64);
     hA = c.take<float>(int64_t(g->Nt) * 64); hB = c.take<float>(int64_t(g->Nt) * 64); lat = c.take<float>(N * 64);
     al_xn = c.take<float>(N * 64); al_q = c.take<float>(N * 64);
-    al_logits = c.take<float>(int64_t(g->E_la) * 8 + 8); al_v = c.take<float>(int64_t(g->E_la) * 64 + 64);
+    al_logits = c.take<float>(fused ? 8 : int64_t(g->E_la) * 8 + 8); al_v = c.take<float>(fused ? 64 : int64_t(g->E_la) * 64 + 64);
     al_agg = c.take<float>(N * 64); al_x1 = c.take<float>(N * 64); al_xn2 = c.take<float>(N * 64);
     total = c.off + 256;
     ok = c.ok;
@@ -94,6 +103,23 @@ static int attention_tail(const NodeImgs& im, const int32_t* segptr, const float
   return update_ffn(im, agg, xn, x, R, x1, xn2, out, st);
 }
 
+// embedding + lin_k|lin_v + softmax-aggregate of one edge list in the fused form: records, then one merged agg row per target
+static int fused_edge_attention(const char* tag, bool dominant, const float* img, const float* geom, const int32_t* dst, const float* q,
+                                int64_t E, const int32_t* segptr, int64_t R, float* rec, float* agg, int heads, hipStream_t st) {
+  const AttnPlan pl = fused_plan(E);
+  if (E > 0) {
+    const int threads = fused_threads();
+    const int64_t waves = (pl.nstreams + 31) / 32;
+    const int grid = int((waves + threads / 64 - 1) / (threads / 64));
+    if (threads == 768)
+      TS_LAUNCH_TAG(tag, dominant, k_edge_attn2<768>, grid, 768, EdgeL6::SIZE * 4, st, img, geom, dst, q, E, pl.C, rec, heads);
+    else
+      TS_LAUNCH_TAG(tag, dominant, k_edge_attn2<512>, grid, 512, EdgeL6::SIZE * 4, st, img, geom, dst, q, E, pl.C, rec, heads);
+  }
+  TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, pl.C, R, agg);
+  return TRAJSDE_OK;
+}
+
 }  // namespace tsde
 
 using namespace tsde;
@@ -113,6 +139,13 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
   const int64_t R = int64_t(H) * Nt;
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob + EncBlob::AA_CENTER,
             b->x, g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
+  const NodeImgs im{blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, blob + EncBlob::AA_UPD6, blob + EncBlob::AA_FFN6};
+  if (attn_fused()) {
+    if (int rc = fused_edge_attention("k_edge_kv[aa]", true, blob + EncBlob::AA_EDGE6, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), g->aa_segptr, R,
+                                      w.rec, w.agg, heads, st))
+      return rc;
+    return update_ffn(im, w.agg, w.cn, w.center, R, w.x1, w.xn2, aa_out, st);
+  }
   if (g->E_aa > 0) {
     if (edge_x6() && edge_pair())
     {
@@ -130,7 +163,6 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
       TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv<false>, tile_grid((int64_t(g->E_aa) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(),
                     EdgeL::SIZE * 4, st, blob + EncBlob::AA_EDGE, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v, heads);
   }
-  const NodeImgs im{blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, blob + EncBlob::AA_UPD6, blob + EncBlob::AA_FFN6};
   return attention_tail(im, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg, w.x1, w.xn2, aa_out, st, heads);
 }
 
@@ -173,6 +205,13 @@ static int run_al_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
   const int N = b->N;
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob + EncBlob::AL_Q, lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
+  const NodeImgs im{blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, blob + EncBlob::AL_UPD6, blob + EncBlob::AL_FFN6};
+  if (attn_fused()) {
+    if (int rc = fused_edge_attention("k_edge_kv[al]", false, blob + EncBlob::AL_EDGE6, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), g->la_segptr,
+                                      int64_t(N), w.al_rec, w.al_agg, heads, st))
+      return rc;
+    return update_ffn(im, w.al_agg, w.al_xn, lat, N, w.al_x1, w.al_xn2, local_embed, st);
+  }
   if (g->E_la > 0) {
     if (edge_x6() && edge_pair())
       TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv2<512>, tile_grid((int64_t(g->E_la) + 31) / 32, 512, EdgeL6::SIZE * 4), 512, EdgeL6::SIZE * 4, st,
@@ -184,7 +223,6 @@ static int run_al_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
       TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv<false>, tile_grid((int64_t(g->E_la) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(),
                     EdgeL::SIZE * 4, st, blob + EncBlob::AL_EDGE, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v, heads);
   }
-  const NodeImgs im{blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, blob + EncBlob::AL_UPD6, blob + EncBlob::AL_FFN6};
   return attention_tail(im, g->la_segptr, w.al_logits, w.al_v, w.al_xn, lat, N, w.al_agg, w.al_x1, w.al_xn2, local_embed, st, heads);
 }
 
