@@ -107,6 +107,17 @@ typedef struct {
   const int32_t* row_ids;    /* optional global row ids for the Philox counter                  */
 } trajsde_noise;
 
+/* ---- train-mode dropout of the attention blocks (AAEncoder ENC:521-533,592,611; ALEncoder ENC:711-723,771,794;
+ *      GlobalInteractorLayer AGG:78-90,116,132): nn.Dropout(p) on the attention weights, on out_proj's output and on the two
+ *      activations of the FFN.  Masks are cut from the same counter-based Philox stream as the SDE noise (csrc/dropout.hpp;
+ *      host twin trajsde_amd/philox.py), keyed by (seed, block, site, element) -- so the forward, the forward recomputation
+ *      inside the backward entry points and the backward kernels all see the same mask when they are handed the same struct.
+ *      Pass null (or p = 0) for eval mode. */
+typedef struct {
+  float p;          /* drop probability in [0, 1); kept elements are scaled by 1 / (1 - p) */
+  uint64_t seed;
+} trajsde_dropout;
+
 /* ---- MODEL:75-85  rotate_mat[n] = [[cos,-sin],[sin,cos]],  y_rot = y @ R_n ---------------------- */
 int trajsde_rotate(const float* rotate_angles, int32_t N, const float* y /*[N,F,2] or null*/, int32_t F,
                    float* rotate_mat /*[N,2,2]*/, float* y_rot /*[N,F,2] or null*/, void* stream);
@@ -141,9 +152,14 @@ typedef struct {
   const int32_t* la_segptr;   /* [N+1]                                             */
   /* ABI 2: the sender of every compacted record (the kernels do not read these: the geometry above already carries what a
    * sender contributes; they make the index work of ENC:107-118 / ENC:198 checkable edge for edge) */
-  const int32_t* aa_src;      /* [E_aa] sending actor (a real actor, < N)          */
-  const int32_t* la_lane;     /* [E_la] lane segment                               */
+  const int32_t* aa_src;      /* [E_aa] sending actor (a real actor, < N); null unless trajsde_export_senders(1) */
+  const int32_t* la_lane;     /* [E_la] lane segment; null unless trajsde_export_senders(1)                      */
 } trajsde_graph;
+
+/* Process-wide switch: have trajsde_graph_compact also write the sender of every compacted record (aa_src / la_lane above).
+ * Off by default -- the kernels never read them, they exist so that tests can compare the index work edge for edge.
+ * Returns the previous setting. */
+int trajsde_export_senders(int on);
 
 /* Two phases, because the sizes of the compacted lists are data dependent:
  *   prepare : sort/CSR, fake-agent rows, validity+radius flags, prefix sums; fills the counts and the
@@ -167,7 +183,7 @@ int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, cons
                             const trajsde_noise* noise /* z: [H,Nt,64] */, void* ws, int64_t ws_bytes,
                             float* local_embed /*[N,64]*/, float* diff_pick /*[2A,64]*/,
                             float* aa_out /*[H,Nt,64] or null*/, float* latent_ys /*[H,N,64] or null*/,
-                            void* stream);
+                            const trajsde_dropout* dropout /* null = eval mode */, void* stream);
 
 /* ---- LocalEncoderSDESepPara2.forward_ood (ENC:204-370): graph prepared with b->A = 0 (no fake agents);
  *      n_samples (reference: 10) stochastic recurrences from a zero state; stds[n] = std over samples of
@@ -188,7 +204,7 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
 /* the same with the head count of the attention spelled out (8: the SDE config, 4: the vanilla HiVT config) */
 int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers,
                                      int num_modes, int num_heads, const float* local_embed, void* ws, int64_t ws_bytes,
-                                     float* global_embed, void* stream);
+                                     float* global_embed, const trajsde_dropout* dropout /* null = eval mode */, void* stream);
 
 /* ---- decoder stage: SDEDecoder (DEC:77-105) with the stock Euler-Maruyama solve over the float32
  *      schedule tables of SURVEY.md App. D (trajsde_amd/schedule.py). */
@@ -267,12 +283,12 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
                              const float* enc_step_table_dev /*device [H,8]*/, const trajsde_noise* noise,
                              const float* d_local /*[N,64]*/, float diff_weight, void* ws, int64_t ws_bytes,
                              float* diff_loss /*[1] device*/, float* const* grads, int n_grads, float* d_latent, float* d_aa_out,
-                             void* stream);
+                             const trajsde_dropout* dropout /* the forward's, or null */, void* stream);
 
 int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, const float* blob_bwd,
                                       int num_layers, int num_modes, int num_heads, const float* local_embed,
                                       const float* d_global, void* ws, int64_t ws_bytes, float* const* grads, int n_grads,
-                                      float* d_local, void* stream);
+                                      float* d_local, const trajsde_dropout* dropout /* the forward's, or null */, void* stream);
 
 /* ---- step-granular decoder SDE step (state round-trips HBM every step): the 512 B/path-step variant
  *      of SURVEY.md 8(d), kept for the HBM-roofline measurement the north star asks for. */

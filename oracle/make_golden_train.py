@@ -3,12 +3,14 @@
     python oracle/make_golden_train.py            # build container only (needs /root/reference)
 
 The reference model (imported from /root/reference over oracle/shims, our state_dict loaded key for key) runs its
-`forward` with injected noise, its own loss modules (`losses/L2.py`, `losses/diff_BCE.py`, weighted as
-`training_step` does, `models/model_base_mix_sde.py:104-111`) and torch.autograd.  Dropout is switched off
-(`model.eval()`, which changes nothing else: the path has no BatchNorm): the MI355X path differentiates the network
-without dropout, so that is the function both sides are compared on.
+`forward` in TRAIN mode with injected noise, its own loss modules (`losses/L2.py`, `losses/diff_BCE.py`, weighted as
+`training_step` does, `models/model_base_mix_sde.py:104-111`) and torch.autograd.  Its dropout (p = 0.1 at four sites of
+each of the five attention blocks, ENC:521-533,592,611, ENC:711-723,771,794, AGG:78-90,116,132) is served from injected
+masks: the masks the HIP kernels cut from their Philox stream (host twin trajsde_amd/philox.py), laid out in the
+reference's own element order (`ref_loader.injected_dropout`) -- so both sides differentiate the same function.
+(The vanilla-variant case stays in eval mode: that variant's HIP training step refuses dropout.)
 
-A fixture holds data only: the batch, the init / noise seeds, the two loss values, and every parameter gradient.
+A fixture holds data only: the batch, the init / noise / dropout seeds, the two loss values, and every parameter gradient.
 """
 import os
 import sys
@@ -54,9 +56,13 @@ def make(name):
             if p.requires_grad:
                 p.add_(0.02 * torch.randn(p.shape, generator=g))
     sd = {k: v.detach().clone() for k, v in ours.state_dict().items()}
-    ref = R.build_reference_model(R.load_reference_cfg(num_modes=K, future_steps=T, max_fut_t=max_t))
+    ref_cfg = R.load_reference_cfg(num_modes=K, future_steps=T, max_fut_t=max_t)
+    ref = R.build_reference_model(ref_cfg)
     ref.load_state_dict(sd)
-    ref.eval()                                                # dropout off (see the module docstring)
+    ref.train()                                               # dropout on, served from injected masks (module docstring)
+    p_drop = float(ref_cfg["encoder"]["kwargs"]["dropout"])
+    assert p_drop == float(ref_cfg["aggregator"]["kwargs"]["dropout"]) == float(our_cfg(K, T, max_t)["encoder"]["kwargs"]["dropout"])
+    dropout_seed = 7000 + noise_seed
     # (a float64 run of the reference is not the same function: the solver's time bookkeeping is float32 arithmetic and
     # takes a different number of Euler steps in double, SURVEY App. D -- so the fixture is the reference's float32
     # autograd result, whose own rounding noise on the ill-conditioned encoder gradients is ~1e-3 for T=30)
@@ -65,11 +71,24 @@ def make(name):
     z_fake, z_enc, z_dec = philox_noise(noise_seed, A, N + A, K * N, sched.n_euler)
     replay = [torch.from_numpy(z_fake)] + [torch.from_numpy(z) for z in z_enc] + [torch.from_numpy(z) for z in z_dec]
 
+    # the dropout masks in the reference's call order and element order; the edge orders come from the oracle, whose lists
+    # are the reference's (bit-exact restatement, tests/test_oracle_golden.py)
+    import restate
+    from trajsde_amd import philox
+    orc = restate.forward({k: v.clone() for k, v in sd.items()}, our_cfg(K, T, max_t), batch, restate.PhiloxNoise(noise_seed),
+                          want_intermediates=True)
+    drop = restate.PhiloxDropout(dropout_seed, p_drop)
+    Rn = 21 * (N + A)
+    masks = []
+    for block, (edges, rows) in enumerate([(orc["aa_edge_list"], Rn), (orc["al_edge_list"], N)] + [(orc["g_edge_list"], N)] * 3):
+        like = torch.empty(rows, 64)
+        masks += [drop.attn(block, edges[0], edges[1], 8, like), drop.feat(block, philox.DK_PROJ, like),
+                  drop.feat(block, philox.DK_HIDDEN, torch.empty(rows, 256)), drop.feat(block, philox.DK_OUT, like)]
     R._install_paths()
     from noise_source import SOURCE
     SOURCE.reset(seed=None, replay=replay)
     data = R.to_reference_data(batch)
-    with R.reference_cwd(), R.injected_randn_like(), torch.enable_grad():
+    with R.reference_cwd(), R.injected_randn_like(), R.injected_dropout(masks) as served, torch.enable_grad():
         out = ref(data)
         parts = [fn(data, out) for fn in ref.losses]                                  # MODEL:108-110
         loss = sum(w * l for w, l in zip(ref.loss_weights, parts))
@@ -77,7 +96,9 @@ def make(name):
     assert len(SOURCE.record) == 1 + 21 + sched.n_euler
     fx = {f"in.{k}": v.numpy() for k, v in batch.as_dict().items() if torch.is_tensor(v)}
     fx["meta.num_modes"], fx["meta.future_steps"], fx["meta.max_fut_t"] = K, T, max_t
+    assert len(served) == 20, served
     fx["meta.init_seed"], fx["meta.noise_seed"], fx["meta.perturb_seed"] = init_seed, noise_seed, 1000 + init_seed
+    fx["meta.dropout_p"], fx["meta.dropout_seed"] = p_drop, dropout_seed
     fx["meta.state_checksum"] = state_checksum(sd)
     for nm, w, l in zip(ref.loss_names, ref.loss_weights, parts):
         fx[f"loss.{nm}"] = np.float64(float(l))

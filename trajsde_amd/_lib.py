@@ -11,7 +11,7 @@ STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGA
 STAGE_ENCODER_GRID, STAGE_DECODER_MLP, STAGE_DECODER_MLP_BWD, STAGE_ENCODER_GRID_BWD = 6, 7, 8, 9
 
 
-ABI_VERSION = 2          # include/trajsde_hip.h: trajsde_graph grew aa_src / la_lane
+ABI_VERSION = 3          # include/trajsde_hip.h: trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3)
 
 
 class TrajsdeError(RuntimeError):
@@ -31,6 +31,10 @@ class Noise(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("z", C.c_void_p), ("row_ids", C.c_void_p)]
 
 
+class Dropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("seed", C.c_uint64)]
+
+
 class Graph(C.Structure):
     _fields_ = [("Nt", C.c_int32), ("E_ext", C.c_int32), ("E_aa", C.c_int32), ("E_g", C.c_int32), ("E_la", C.c_int32),
                 ("orig", C.c_void_p), ("nus_mask", C.c_void_p), ("eos_idx", C.c_void_p), ("pick_slot", C.c_void_p),
@@ -48,6 +52,7 @@ SIGNATURES = {
     "trajsde_last_error": (C.c_char_p, []),
     "trajsde_split_products": (C.c_int, []),
     "trajsde_abi_version": (C.c_int, []),
+    "trajsde_export_senders": (C.c_int, [C.c_int]),
     "trajsde_range_status": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), P]),
     "trajsde_param_count": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trajsde_param_name": (C.c_char_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -59,7 +64,8 @@ SIGNATURES = {
     "trajsde_graph_edges_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
     "trajsde_graph_compact": (C.c_int, [C.POINTER(Batch), P, P, I64, P, I64, C.POINTER(Graph), P]),
     "trajsde_encoder_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
-    "trajsde_encoder_forward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, C.POINTER(Noise), P, I64, P, P, P, P, P]),
+    "trajsde_encoder_forward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, C.POINTER(Noise), P, I64, P, P, P, P,
+                                          C.POINTER(Dropout), P]),
     "trajsde_encoder_ood_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph), C.c_int]),
     "trajsde_encoder_forward_ood": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, C.POINTER(Noise), C.c_int, P, I64, P, P, P]),
     "trajsde_aggregator_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph), C.c_int]),
@@ -73,11 +79,12 @@ SIGNATURES = {
     "trajsde_aggregator_backward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, C.c_int, C.c_int, P, P, P, I64,
                                               C.POINTER(P), C.c_int, P, P]),
     "trajsde_aggregator_backward_heads": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, C.c_int, C.c_int, C.c_int, P, P, P, I64,
-                                                    C.POINTER(P), C.c_int, P, P]),
+                                                    C.POINTER(P), C.c_int, P, C.POINTER(Dropout), P]),
     "trajsde_encoder_backward_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
     "trajsde_encoder_backward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, P, P, C.POINTER(Noise), P, F32, P, I64, P,
-                                           C.POINTER(P), C.c_int, P, P, P]),
-    "trajsde_aggregator_forward_heads": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, C.c_int, C.c_int, C.c_int, P, P, I64, P, P]),
+                                           C.POINTER(P), C.c_int, P, P, C.POINTER(Dropout), P]),
+    "trajsde_aggregator_forward_heads": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, C.c_int, C.c_int, C.c_int, P, P, I64, P,
+                                                   C.POINTER(Dropout), P]),
     "trajsde_encoder_grid_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
     "trajsde_encoder_grid_forward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, C.c_int, C.c_int, P, I64, P, P]),
     "trajsde_mlp_decoder_ws_bytes": (I64, [I32, C.c_int]),

@@ -22,6 +22,7 @@
 #include "attn_common.hpp"
 #include "bwd.hpp"
 #include "common.hpp"
+#include "dropout.hpp"
 #include "kernels.hpp"
 #include "layouts.hpp"
 #include "tile.hpp"
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
                                                    const float* __restrict__ dagg, int64_t N, float* __restrict__ DQ,
                                                    float* __restrict__ DKN, float* __restrict__ DVN, float* __restrict__ DREL,
                                                    float* __restrict__ RL, float* __restrict__ SS, float* __restrict__ DAGGM,
-                                                   float* __restrict__ EA, float* __restrict__ ED) {
+                                                   float* __restrict__ EA, float* __restrict__ ED, DropArg drop) {
   // EA / ED non-null: the source-row gradients are gathered afterwards by k_gattn_src_bwd from the per-edge (alpha, dlogit)
   // scalars written here (symmetric graph, fixed summation order); null: scattered right here with float atomics
   constexpr int LPH = 64 / HEADS, SL = 64 / LPH, NV = SL / 4;     // as in k_global_attn<HEADS>
@@ -111,7 +112,11 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
     for (int u = 0; u < 8; ++u) s += fast_exp(lg[u] - m);
   }
   const float inv = 1.0f / (s + 1e-16f);
-  // pass 2: gradients
+  // pass 2: gradients.  Attention dropout (AGG:116): agg_h = sum_e alpha_e d_e (v_node[src] + lin_v_edge(rel_e) )_h with
+  // d_e = keep_e / (1 - p): every "alpha" that multiplies a VALUE below becomes alpha d_e, d alpha_e = d_e (dagg . value_e),
+  // and lin_v_edge.bias sees sum_e alpha_e d_e instead of 1
+  const bool dropping = drop.p > 0.f;
+  float sad = 0.f;
   float dqe = 0.f, Rl[SL], Sa[SL];
 #pragma unroll
   for (int e = 0; e < SL; ++e) Rl[e] = Sa[e] = 0.f;
@@ -119,6 +124,8 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
    f4 rr4[4][NV];
    float kn4[4], vn4[4];
    int sx4[4];
+   float kp[4] = {1.f, 1.f, 1.f, 1.f};
+   if (dropping) drop_attn_chunk<4>(kp, drop, uint32_t(nc), uint32_t(e0 - beg), lane, h);
    const int sv = chunk_src(e0, 4);
 #pragma unroll
    for (int u = 0; u < 4; ++u) {
@@ -136,22 +143,24 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
     const f4 (&r)[NV] = rr4[u];
     const float knv = kn4[u], vnv = vn4[u];
     const float alpha = fast_exp(logit(r, knv) - m) * inv;
+    const float alk = alpha * kp[u];                       // the weight the values were summed with
+    sad += alk;
     float t = da * vnv;
 #pragma unroll
     for (int v4 = 0; v4 < NV; ++v4)
 #pragma unroll
       for (int c = 0; c < 4; ++c) t = fmaf(r[v4][c], Z[4 * v4 + c], t);
-    const float dal = head_sum_n<HEADS>(t) + cz;
+    const float dal = (head_sum_n<HEADS>(t) + cz) * kp[u];
     const float dls = alpha * (dal - dlt) * INV;
     dqe = fmaf(dls, knv, dqe);
     if (EA != nullptr) {
       if (j == 0) {
-        EA[int64_t(e) * HEADS + h] = alpha;
+        EA[int64_t(e) * HEADS + h] = alk;
         ED[int64_t(e) * HEADS + h] = dls;
       }
     } else {
       atomicAdd(DKN + int64_t(sidx) * 64 + lane, dls * ql);
-      atomicAdd(DVN + int64_t(sidx) * 64 + lane, alpha * da);
+      atomicAdd(DVN + int64_t(sidx) * 64 + lane, alk * da);
     }
     float dr[SL];
 #pragma unroll
@@ -160,8 +169,8 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
       for (int c = 0; c < 4; ++c) {
         const int i = 4 * v4 + c;
         Rl[i] = fmaf(dls, r[v4][c], Rl[i]);
-        Sa[i] = fmaf(alpha, r[v4][c], Sa[i]);
-        dr[i] = fmaf(dls, U[i], alpha * Z[i]);
+        Sa[i] = fmaf(alk, r[v4][c], Sa[i]);
+        dr[i] = fmaf(dls, U[i], alk * Z[i]);
       }
     // d rel_e = sum over heads: lanes j, j + LPH, ... hold the same SL columns
 #pragma unroll
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
   }
   if (node < N) {
     DQ[node * 64 + lane] = dq;
-    DAGGM[node * 64 + lane] = da * (s * inv);        // lin_v_edge.bias sees sum_e alpha = 1 where the target has edges
+    DAGGM[node * 64 + lane] = da * (dropping ? sad : s * inv);        // lin_v_edge.bias sees sum_e alpha d_e (= 1 without dropout)
   }
 }
 
@@ -315,13 +324,16 @@ int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, 
                                 int num_layers, int num_modes, const float* local_embed, const float* d_global, void* ws,
                                 int64_t ws_bytes, float* const* grads, int n_grads, float* d_local, void* stream_) {
   return trajsde_aggregator_backward_heads(b, g, blob_fwd, blob_bwd, num_layers, num_modes, 8, local_embed, d_global, ws, ws_bytes, grads,
-                                           n_grads, d_local, stream_);
+                                           n_grads, d_local, nullptr, stream_);
 }
 
 int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, const float* blob_bwd,
                                       int num_layers, int num_modes, int num_heads, const float* local_embed, const float* d_global,
-                                      void* ws, int64_t ws_bytes, float* const* grads, int n_grads, float* d_local, void* stream_) {
+                                      void* ws, int64_t ws_bytes, float* const* grads, int n_grads, float* d_local,
+                                      const trajsde_dropout* dropout, void* stream_) {
   TS_REQUIRE(b && g && blob_fwd && blob_bwd && local_embed && d_global && ws && grads && d_local, "aggregator_backward: null pointer");
+  TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "aggregator_backward: dropout p must be in [0, 1)");
+  auto drop_of = [&](int layer) { return dropout ? make_drop(dropout->p, dropout->seed, 2 + layer) : no_drop(); };   // dropout.hpp block ids
   TS_REQUIRE(num_heads == 8 || num_heads == 4, "aggregator_backward: num_heads must be 8 or 4");
   TS_REQUIRE(g->g_src && g->g_segptr, "aggregator_backward: graph not compacted (call trajsde_graph_compact)");
   TS_REQUIRE(num_layers >= 1 && num_layers <= 8 && num_modes > 0, "aggregator_backward: bad layer/mode count");
@@ -356,13 +368,14 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
               w.xn[l], w.q[l], w.kn[l], w.vn[l]);
     if (num_heads == 4)
       TS_LAUNCH(k_global_attn<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
-                w.agg[l]);
+                w.agg[l], drop_of(l));
     else
       TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
-                w.agg[l]);
+                w.agg[l], drop_of(l));
     TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, lb + AggLayerL::UPD6, w.agg[l], w.xn[l], x,
-              N, w.x1[l], w.xn2[l]);
-    TS_LAUNCH(k_ffn6, tile_grid(ntiles, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, lb + AggLayerL::FFN6, w.x1[l], w.xn2[l], N, w.out[l]);
+              N, w.x1[l], w.xn2[l], drop_of(l));
+    TS_LAUNCH(k_ffn6, tile_grid(ntiles, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, lb + AggLayerL::FFN6, w.x1[l], w.xn2[l], N, w.out[l],
+              drop_of(l));
     x = w.out[l];
   }
 
@@ -420,15 +433,15 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     float* qkv_b[3] = {G(p + ".lin_q_node.bias"), G(p + ".lin_k_node.bias"), G(p + ".lin_v_node.bias")};
     TS_REQUIRE(!missing, "aggregator_backward: parameter table lacks an entry of " + p);
     const NodeBlockTape tp{w.agg[l], w.xn[l], w.x1[l], w.xn2[l]};
-    if (int rc = node_block_backward(lb + AggLayerBwdL::NODE, tp, dcur, N, w.nb, wc, gr, w.dagg, w.dxn, st)) return rc;
+    if (int rc = node_block_backward(lb + AggLayerBwdL::NODE, tp, dcur, N, w.nb, wc, gr, w.dagg, w.dxn, st, drop_of(l))) return rc;
     TS_HIP(hipMemsetAsync(w.DKN, 0, size_t(N) * 64 * sizeof(float), st));
     TS_HIP(hipMemsetAsync(w.DVN, 0, size_t(N) * 64 * sizeof(float), st));
     if (num_heads == 4)
       TS_LAUNCH(k_gattn_bwd<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
-                w.agg[l], w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM, ea, ed);
+                w.agg[l], w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM, ea, ed, drop_of(l));
     else
       TS_LAUNCH(k_gattn_bwd<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
-                w.agg[l], w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM, ea, ed);
+                w.agg[l], w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM, ea, ed, drop_of(l));
     if (symmetric) {
       if (num_heads == 4)
         TS_LAUNCH(k_gattn_src_bwd<4>, cdiv(N, 4), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA, w.ED, w.q[l], w.dagg, N, w.DKN, w.DVN);

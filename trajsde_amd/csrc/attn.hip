@@ -12,6 +12,7 @@
 #include "kernels.hpp"
 #include "layouts.hpp"
 #include "attn_common.hpp"
+#include "dropout.hpp"
 #include "range.hpp"
 #include "tile.hpp"
 
@@ -190,7 +191,9 @@ __device__ __forceinline__ f4 head_logits(const f4 (&qv)[4], const f4 (&k)[4], i
   }
   return lg;
 }
-__device__ __forceinline__ void seg_update(SegState& S, const f4& lg, const f4 (&v)[4]) {
+// `keep`: attention dropout (ENC:592): the softmax is normalised over ALL edges (s), the weighted sum takes the kept ones
+// scaled by 1/(1-p); f4{1,1,1,1} when dropout is off
+__device__ __forceinline__ void seg_update(SegState& S, const f4& lg, const f4 (&v)[4], const f4& keep) {
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
     const float mn = fmaxf(S.m[jt], lg[jt]);
@@ -198,8 +201,9 @@ __device__ __forceinline__ void seg_update(SegState& S, const f4& lg, const f4 (
     const float ex = fast_exp(lg[jt] - mn);
     S.m[jt] = mn;
     S.s[jt] = fmaf(S.s[jt], sc, ex);
+    const float exk = ex * keep[jt];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) S.acc[jt][c] = fmaf(S.acc[jt][c], sc, ex * v[jt][c]);
+    for (int c = 0; c < 4; ++c) S.acc[jt][c] = fmaf(S.acc[jt][c], sc, exk * v[jt][c]);
   }
 }
 __device__ __forceinline__ void seg_flush(const SegState& S, float* __restrict__ rec, int64_t slot, int g) {
@@ -210,10 +214,10 @@ __device__ __forceinline__ void seg_flush(const SegState& S, float* __restrict__
   *reinterpret_cast<f4*>(r + 80 + 4 * g) = S.s;
 }
 
-template <int THREADS>
+template <int THREADS, bool DROP>
 __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict__ img_g, const float* __restrict__ geom,
                                                         const int32_t* __restrict__ dst, const float* __restrict__ q, int64_t E, int C,
-                                                        float* __restrict__ rec, int heads) {
+                                                        float* __restrict__ rec, int heads, const int32_t* __restrict__ segptr, DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using EL = EdgeL6;
   stage_blob(lds, img_g, EL::SIZE);
@@ -229,6 +233,8 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
   seg_reset(S0);
   seg_reset(S1);
   int cur0 = -1, cur1 = -1;
+  int base0 = 0, base1 = 0;                                // DROP: first edge of the rows' current targets (mask counter = rank)
+  const f4 one4 = f4{1.f, 1.f, 1.f, 1.f};
   const int64_t b0 = s0 * C, b1 = s1 * C;
   for (int it = 0; it < C; ++it) {
     keep_lds_reads_here();
@@ -242,11 +248,13 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
       if (cur0 >= 0) seg_flush(S0, rec, int64_t(cur0) + s0, L.g);
       seg_reset(S0);
       cur0 = d0;
+      if (DROP) base0 = segptr[d0];
     }
     if (ok1 && d1 != cur1) {
       if (cur1 >= 0) seg_flush(S1, rec, int64_t(cur1) + s1, L.g);
       seg_reset(S1);
       cur1 = d1;
+      if (DROP) base1 = segptr[d1];
     }
     f4 emb0[4], emb1[4], kv0[8], kv1[8], qv[4];
     edge_embed2_x6(emb0, emb1, g0, g1, lds, L);
@@ -258,21 +266,22 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
       const f4 k[4] = {kv0[0], kv0[1], kv0[2], kv0[3]};
       const f4 vv[4] = {kv0[4], kv0[5], kv0[6], kv0[7]};
       const f4 lg = head_logits(qv, k, heads);
-      if (ok0) seg_update(S0, lg, vv);
+      if (ok0) seg_update(S0, lg, vv, DROP ? drop_attn_row(drop, uint32_t(d0), uint32_t(int(e0) - base0), L.g, heads) : one4);
     }
     {
       load_row(qv, q, d1, L.g);
       const f4 k[4] = {kv1[0], kv1[1], kv1[2], kv1[3]};
       const f4 vv[4] = {kv1[4], kv1[5], kv1[6], kv1[7]};
       const f4 lg = head_logits(qv, k, heads);
-      if (ok1) seg_update(S1, lg, vv);
+      if (ok1) seg_update(S1, lg, vv, DROP ? drop_attn_row(drop, uint32_t(d1), uint32_t(int(e1) - base1), L.g, heads) : one4);
     }
   }
   if (cur0 >= 0) seg_flush(S0, rec, int64_t(cur0) + s0, L.g);
   if (cur1 >= 0) seg_flush(S1, rec, int64_t(cur1) + s1, L.g);
 }
-template __global__ void k_edge_attn2<512>(const float*, const float*, const int32_t*, const float*, int64_t, int, float*, int);
-template __global__ void k_edge_attn2<768>(const float*, const float*, const int32_t*, const float*, int64_t, int, float*, int);
+template __global__ void k_edge_attn2<512, false>(const float*, const float*, const int32_t*, const float*, int64_t, int, float*, int, const int32_t*, DropArg);
+template __global__ void k_edge_attn2<768, false>(const float*, const float*, const int32_t*, const float*, int64_t, int, float*, int, const int32_t*, DropArg);
+template __global__ void k_edge_attn2<512, true>(const float*, const float*, const int32_t*, const float*, int64_t, int, float*, int, const int32_t*, DropArg);
 
 // records of one target -> agg row.  One wave per target, lane = feature f (jt = f>>4, g = (f>>2)&3); a target's records sit
 // at slots target + (first stream .. last stream) of its segment and are combined in that order.
@@ -400,7 +409,8 @@ __global__ __launch_bounds__(512) void k_global_edge(const float* __restrict__ i
 // Single pass over the slab with an online softmax in chunks of 8 edges (8 logits + 8 value rows in flight per
 // lane); the running maximum is the segment maximum at the end, so the result equals the two-pass form up to rounding.
 __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restrict__ segptr, const float* __restrict__ logits,
-                                                         const float* __restrict__ v, int64_t R, float* __restrict__ agg, int heads) {
+                                                         const float* __restrict__ v, int64_t R, float* __restrict__ agg, int heads,
+                                                         DropArg drop) {
   const int lane = threadIdx.x & 63;
   const int head = heads == 4 ? lane >> 4 : lane >> 3, slot = heads == 4 ? head : 4 * (head & 1) + (head >> 1);
   // the wave index is uniform: saying so keeps the segment bounds, the edge index and every row address in SGPRs
@@ -430,11 +440,22 @@ __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restri
     m = mn;
     s *= sc;
     acc *= sc;
+    if (drop.p > 0.f) {                                      // attention dropout: kept edges only, scaled, in the weighted sum
+      float kp[CH];
+      drop_attn_chunk<CH>(kp, drop, uint32_t(node), uint32_t(e0 - beg), lane, head);
 #pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      const float ex = fast_exp(p[u] - m);
-      s += ex;
-      acc = fmaf(ex, vv[u], acc);
+      for (int u = 0; u < CH; ++u) {
+        const float ex = fast_exp(p[u] - m);
+        s += ex;
+        acc = fmaf(ex * kp[u], vv[u], acc);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const float ex = fast_exp(p[u] - m);
+        s += ex;
+        acc = fmaf(ex, vv[u], acc);
+      }
     }
   }
   agg[node * 64 + lane] = end > beg ? acc / (s + 1e-16f) : 0.f;
@@ -452,7 +473,7 @@ template <int HEADS>
 __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                      const int32_t* __restrict__ src, const float* __restrict__ rel,
                                                      const float* __restrict__ q, const float* __restrict__ kn,
-                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ agg) {
+                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ agg, DropArg drop) {
   constexpr int LPH = 64 / HEADS;          // lanes (= head dims) per head: 8, or 16 with 4 heads
   constexpr int SL = 64 / LPH;             // rel-row columns per lane: a head's 64-wide row is spread over its LPH lanes
   constexpr int NV = SL / 4;               // ... as float4s
@@ -481,12 +502,14 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
     }
   }
   const int beg = segptr[nc], end = node < N ? segptr[nc + 1] : beg;
-  float m = -INFINITY, s = 0.f, accv = 0.f, accr[SL];
+  float m = -INFINITY, s = 0.f, sk = 0.f, accv = 0.f, accr[SL];      // sk: sum of the KEPT, scaled weights (= s without dropout)
 #pragma unroll
   for (int e = 0; e < SL; ++e) accr[e] = 0.f;
+  const bool dropping = drop.p > 0.f;
   for (int e0 = beg; e0 < end; e0 += 8) {
     f4 r[8][NV];
-    float knv[8], vnv[8], lg[8];
+    float knv[8], vnv[8], lg[8], kp[8];
+    if (dropping) drop_attn_chunk<8>(kp, drop, uint32_t(nc), uint32_t(e0 - beg), lane, h);
     // the chunk's 8 source indices in one coalesced load, handed out as scalars: every row address below is an SGPR
     // base plus a per-lane constant offset, so the loop spends no VALU cycles on address arithmetic
     const int sv = src[e0 + (lane & 7) < end ? e0 + (lane & 7) : end - 1];
@@ -530,13 +553,16 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
     const float sc = fast_exp(m - mn);          // m = -inf on the first chunk -> 0
     m = mn;
     s *= sc;
+    sk *= sc;
     accv *= sc;
 #pragma unroll
     for (int e = 0; e < SL; ++e) accr[e] *= sc;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const float ex = fast_exp(lg[u] - m);     // masked lanes: exp(-inf) = 0
+      float ex = fast_exp(lg[u] - m);           // masked lanes: exp(-inf) = 0
       s += ex;
+      if (dropping) ex *= kp[u];                // attention dropout (AGG:116): the softmax sum keeps every edge
+      sk += ex;
       accv = fmaf(ex, vnv[u], accv);
 #pragma unroll
       for (int v4 = 0; v4 < NV; ++v4)
@@ -550,7 +576,7 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
   for (int v4 = 0; v4 < NV; ++v4)
     *reinterpret_cast<f4*>(&sbuf[wv][h][SL * j + 4 * v4]) =
         f4{accr[4 * v4] * inv, accr[4 * v4 + 1] * inv, accr[4 * v4 + 2] * inv, accr[4 * v4 + 3] * inv};
-  float out = fmaf(img[GAttnL::BVE + lane], s * inv, accv * inv);
+  float out = fmaf(img[GAttnL::BVE + lane], sk * inv, accv * inv);
 #pragma unroll
   for (int k4 = 0; k4 < 16; ++k4) {
     const f4 wr = *reinterpret_cast<const f4*>(wve + lane * 64 + 4 * k4);
@@ -561,16 +587,16 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
   if (node < N) agg[node * 64 + lane] = out;
 }
 template __global__ void k_global_attn<8>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                          const float*, int64_t, float*);
+                                          const float*, int64_t, float*, DropArg);
 template __global__ void k_global_attn<4>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                          const float*, int64_t, float*);
+                                          const float*, int64_t, float*, DropArg);
 
 // ------------------------------------------------------------------------------------------------ update + FFN
 // gate = sigmoid(lin_ih(agg) + lin_hh(xn)); upd = agg + gate*(lin_self(xn) - agg); x1 = x + out_proj(upd); xn2 = norm2(x1)
 template <bool X6>
 __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ img_g, const float* __restrict__ agg,
                                                      const float* __restrict__ xn, const float* __restrict__ x, int64_t R,
-                                                     float* __restrict__ x1, float* __restrict__ xn2) {
+                                                     float* __restrict__ x1, float* __restrict__ xn2, DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using U = typename std::conditional<X6, UpdL6, UpdL>::type;
   stage_blob(lds, img_g, U::SIZE);
@@ -604,6 +630,12 @@ __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ i
       for (int c = 0; c < 4; ++c) a[jt][c] = a[jt][c] + g[jt][c] * (s[jt][c] - a[jt][c]);
     range_note(absmax<4>(a), RS_NODE_AGG);
     lin(s, a, U::WOUT, U::BOUT);
+    if (drop.p > 0.f) {                                       // proj_drop(out_proj(..)) (ENC:611, AGG:132)
+      f4 mk[4];
+      drop_feat16(mk, drop, DK_PROJ, uint32_t(r), 0, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) s[jt] *= mk[jt];
+    }
     load_row(n, x, r, L.g);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) n[jt] += s[jt];
@@ -615,7 +647,7 @@ __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ i
 
 // out = x1 + mlp.3(relu(mlp.0(xn2)))
 __global__ __launch_bounds__(512) void k_ffn(const float* __restrict__ img_g, const float* __restrict__ x1,
-                                             const float* __restrict__ xn2, int64_t R, float* __restrict__ out) {
+                                             const float* __restrict__ xn2, int64_t R, float* __restrict__ out, DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, img_g, FfnL::SIZE);
   const Lane L;
@@ -628,8 +660,23 @@ __global__ __launch_bounds__(512) void k_ffn(const float* __restrict__ img_g, co
     load_row(n, xn2, r, L.g);
     linear<16, 4>(hid, n, lds + FfnL::W1, lds + FfnL::B1, L);
     relu<16>(hid);
+    if (drop.p > 0.f) {                                       // mlp: Linear - ReLU - Dropout - Linear - Dropout (ENC:529-533)
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        f4 mk[4];
+        drop_feat16(mk, drop, DK_HIDDEN, uint32_t(r), blk, L.g);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) hid[4 * blk + jt] *= mk[jt];
+      }
+    }
     range_note(absmax<16>(hid), RS_FFN_HIDDEN);
     linear<4, 16>(o, hid, lds + FfnL::W2, lds + FfnL::B2, L);
+    if (drop.p > 0.f) {
+      f4 mk[4];
+      drop_feat16(mk, drop, DK_OUT, uint32_t(r), 0, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) o[jt] *= mk[jt];
+    }
     load_row(n, x1, r, L.g);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) o[jt] += n[jt];
@@ -640,7 +687,7 @@ __global__ __launch_bounds__(512) void k_ffn(const float* __restrict__ img_g, co
 // split-precision FFN in two passes over this workgroup's tiles, one per half of the 256 hidden units:
 //   pass 0: out = x1 + b2 + W2[:, :128] relu(W1[:128] xn2 + b1[:128]);   pass 1: out += W2[:, 128:] relu(W1[128:] xn2 + b1[128:])
 __global__ __launch_bounds__(512) void k_ffn6(const float* __restrict__ img_g, const float* __restrict__ x1,
-                                              const float* __restrict__ xn2, int64_t R, float* __restrict__ out) {
+                                              const float* __restrict__ xn2, int64_t R, float* __restrict__ out, DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -655,6 +702,17 @@ __global__ __launch_bounds__(512) void k_ffn6(const float* __restrict__ img_g, c
       load_row(n, xn2, r, L.g);
       linear_x6<8, 4>(hid, n, lds + FfnL6::W1, lds + FfnL6::B1, L);
       relu<8>(hid);
+      f4 mo[4];
+      if (drop.p > 0.f) {                                      // hidden units 128*hf .. +127 = 64-blocks 2*hf, 2*hf + 1
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+          f4 mk[4];
+          drop_feat16(mk, drop, DK_HIDDEN, uint32_t(r), 2 * hf + b2, L.g);
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt) hid[4 * b2 + jt] *= mk[jt];
+        }
+        drop_feat16(mo, drop, DK_OUT, uint32_t(r), 0, L.g);
+      }
       if (hf == 0) {
         load_vec<4>(o, lds + FfnL6::B2, L.g);
         load_row(n, x1, r, L.g);
@@ -664,6 +722,10 @@ __global__ __launch_bounds__(512) void k_ffn6(const float* __restrict__ img_g, c
         load_row(n, out, r, L.g);                              // partial sum of pass 0 (same wave wrote it)
       }
       linear_acc_x6<4, 8>(o, hid, lds + FfnL6::W2, L.lane);
+      if (drop.p > 0.f) {                                      // the output mask distributes over the two half sums
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) o[jt] *= mo[jt];
+      }
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) o[jt] += n[jt];
       if (row < R) store_row(o, out, row, L.g);
@@ -726,8 +788,8 @@ template __global__ void k_edge_embed<false>(const float*, const float*, int64_t
 template __global__ void k_edge_embed<true>(const float*, const float*, int64_t, float*);
 template __global__ void k_global_edge<false>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
 template __global__ void k_global_edge<true>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
-template __global__ void k_node_update<false>(const float*, const float*, const float*, const float*, int64_t, float*, float*);
-template __global__ void k_node_update<true>(const float*, const float*, const float*, const float*, int64_t, float*, float*);
+template __global__ void k_node_update<false>(const float*, const float*, const float*, const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_node_update<true>(const float*, const float*, const float*, const float*, int64_t, float*, float*, DropArg);
 template __global__ void k_node_proj<1>(const float*, const float*, int64_t, float*, float*, float*, float*);
 template __global__ void k_node_proj<3>(const float*, const float*, int64_t, float*, float*, float*, float*);
 

@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 
+#include "dropout.hpp"
+
 namespace tsde {
 
 constexpr int WGRAD_CHUNK = 512;           // rows one k_wgrad workgroup reduces
@@ -65,10 +67,10 @@ int run_colsum(hipStream_t st, const float* src, int64_t rows, int stride, int n
 int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64_t N, float* W, int heads = 8);
 
 // ---- node-level backward blocks (node_bwd.hip)
-__global__ void k_ffn_bwd_a(const float* img, const float* dout, const float* xn2, int64_t R, float* H, float* DH);
+__global__ void k_ffn_bwd_a(const float* img, const float* dout, const float* xn2, int64_t R, float* H, float* DH, float* DOUT2, DropArg drop);
 __global__ void k_ffn_bwd_b(const float* img, const float* DH, const float* dout, const float* x1, int64_t R, float* dx1, float* vpart);
 __global__ void k_upd_bwd(const float* img, const float* dx1, const float* agg, const float* xn, int64_t R, float* UPD, float* DGP,
-                          float* DS, float* DAGG, float* DXN);
+                          float* DS, float* DAGG, float* DXN, float* DX1M, DropArg drop);
 template <int NQ>
 __global__ void k_node_proj_bwd(const float* img, const float* x, const float* dres, const float* dxn_part, const float* dp0,
                                 const float* dp1, const float* dp2, int64_t R, float* dx_out, float* xn_out, float* vpart);
@@ -88,12 +90,12 @@ struct NodeBlockGrads {                                                         
 // writes dagg, dxn (the block's contribution to d xn) and sc.dx1 (= d x1, also the residual gradient of x)
 int node_block_backward(const float* img /*NodeBlockBwdL*/, const NodeBlockTape& tp, const float* dout, int64_t R,
                         const NodeBlockScratch& sc, const WgradCtx& wc, const NodeBlockGrads& gr, float* dagg, float* dxn,
-                        hipStream_t st);
+                        hipStream_t st, const DropArg& drop);
 
 // the FFN half alone (TemporalEncoderLayer: linear1 / linear2 / norm2); uses gr.w1, b1, w2, b2, n2g, n2b only
 int ffn_block_backward(const float* img_a /*FfnBwdAL*/, const float* img_b /*FfnBwdBL*/, const float* xn2, const float* x1,
                        const float* dout, int64_t R, const NodeBlockScratch& sc, const WgradCtx& wc, const NodeBlockGrads& gr,
-                       hipStream_t st);
+                       hipStream_t st, const DropArg& drop);
 
 struct EdgeEmbedScratch { float *S, *DEP, *DSP, *vpart; };                       // [E,64] x3
 struct EdgeEmbedGrads {

@@ -31,7 +31,7 @@ namespace tsde {
 __global__ __launch_bounds__(256) void k_seg_attn_bwd(const int32_t* __restrict__ segptr, const float* __restrict__ logits,
                                                       const float* __restrict__ v, const float* __restrict__ agg,
                                                       const float* __restrict__ dagg, int64_t R, float* __restrict__ DV,
-                                                      float* __restrict__ DLG, int heads) {
+                                                      float* __restrict__ DLG, int heads, DropArg drop) {
   const int lane = threadIdx.x & 63;
   const int head = heads == 4 ? lane >> 4 : lane >> 3, slot = heads == 4 ? head : 4 * (head & 1) + (head >> 1);
   const int lph_mask = heads == 4 ? 15 : 7;
@@ -60,22 +60,26 @@ __global__ __launch_bounds__(256) void k_seg_attn_bwd(const int32_t* __restrict_
   const float da = dagg[node * 64 + lane];
   const float t0 = da * agg[node * 64 + lane];
   const float dlt = heads == 4 ? head_sum16(t0) : head_sum(t0);
+  // attention dropout (ENC:592): agg = sum_e alpha_e d_e v_e with d_e = keep_e / (1 - p), so d v_e = alpha_e d_e dagg and
+  // d alpha_e = d_e (dagg . v_e); `dlt` = dagg . agg is already the dropped aggregate's
   for (int e0 = beg; e0 < end; e0 += 4) {                  // 4 edges' loads in flight
-    float lg[4], vv[4];
+    float lg[4], vv[4], kp[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = e0 + u < end ? e0 + u : end - 1;
       lg[u] = (logits + int64_t(e) * 8)[slot];
       vv[u] = (v + int64_t(e) * 64)[lane];
+      kp[u] = 1.0f;
     }
+    if (drop.p > 0.f) drop_attn_chunk<4>(kp, drop, uint32_t(node), uint32_t(e0 - beg), lane, head);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = e0 + u;
       if (e >= end) break;
       const float alpha = fast_exp(lg[u] - m) * inv;
       const float t1 = da * vv[u];
-      const float dal = heads == 4 ? head_sum16(t1) : head_sum(t1);
-      (DV + int64_t(e) * 64)[lane] = alpha * da;
+      const float dal = (heads == 4 ? head_sum16(t1) : head_sum(t1)) * kp[u];
+      (DV + int64_t(e) * 64)[lane] = alpha * kp[u] * da;
       if ((lane & lph_mask) == 0) (DLG + int64_t(e) * 8)[slot] = alpha * (dal - dlt);
     }
   }
@@ -668,6 +672,7 @@ struct AttnChain {
   int64_t R, E;
   std::string prefix, embed;                                      // parameter names: <prefix>.lin_k..., <prefix>.<embed>...
   int heads = 8;
+  DropArg drop = no_drop();                                       // train-mode dropout of this block (dropout.hpp)
 };
 
 }  // namespace tsde
@@ -709,10 +714,10 @@ int run_attn_chain(const AttnChain& c, const float* dout, EncBwdWs& w, const Wgr
   float *wq = G(p + ".lin_q.weight"), *bq = G(p + ".lin_q.bias"), *n1g = G(p + ".norm1.weight"), *n1b = G(p + ".norm1.bias");
   TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
   const int64_t R = c.R, E = c.E;
-  if (int rc = node_block_backward(c.img_node, c.tp, dout, R, w.nb, wc, gr, w.dagg, w.dxn, st)) return rc;
+  if (int rc = node_block_backward(c.img_node, c.tp, dout, R, w.nb, wc, gr, w.dagg, w.dxn, st, c.drop)) return rc;
   TS_HIP(hipMemsetAsync(w.DQ, 0, size_t(R) * 64 * sizeof(float), st));
   if (E > 0) {
-    TS_LAUNCH(k_seg_attn_bwd, cdiv(R, 4), 256, 0, st, c.segptr, c.logits, c.v, c.tp.agg, w.dagg, R, w.DV, w.DLG, c.heads);
+    TS_LAUNCH(k_seg_attn_bwd, cdiv(R, 4), 256, 0, st, c.segptr, c.logits, c.v, c.tp.agg, w.dagg, R, w.DV, w.DLG, c.heads, c.drop);
     TS_LAUNCH(k_edge_kv_bwd, tile_grid((E + 15) / 16, 512, EdgeKvBwdL::SIZE * 4), 512, EdgeKvBwdL::SIZE * 4, st, c.img_kv, c.geom, c.dst, c.q,
               w.DLG, w.DV, E, w.EMB, w.DK, w.DQE, w.DEMB, c.heads);
     TS_LAUNCH(k_seg_sum, cdiv(R, 4), 256, 0, st, c.segptr, w.DQE, R, w.DQ);
@@ -734,13 +739,14 @@ int run_attn_chain(const AttnChain& c, const float* dout, EncBwdWs& w, const Wgr
 
 // AAEncoder backward over the H snapshots: w.DAA = d aa_out [H,Nt,64] on entry; attention chain, centre embedding, bos tokens
 int aa_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_bwd, EncBwdWs& w,
-                        const WgradCtx& wc, GradTable& G, int heads, hipStream_t st) {
+                        const WgradCtx& wc, GradTable& G, int heads, hipStream_t st, const DropArg& drop = no_drop()) {
   using BB = EncBwdBlob;
   const int N = b->N, Nt = g->Nt, H = b->H;
   const int64_t R = int64_t(H) * Nt, Eaa = g->E_aa;
   AttnChain c{blob_bwd + BB::AA_NODE, blob_bwd + BB::AA_PROJ, blob_bwd + BB::AA_EDGEKV, blob_bwd + BB::AA_EDGEEMB,
               g->aa_geom, w.q, w.logits, w.v, w.center, g->aa_dst, g->aa_segptr, NodeBlockTape{w.agg, w.cn, w.x1, w.xn2}, R, Eaa,
               "aa_encoder", "nbr_embed", heads};
+  c.drop = drop;
   if (int rc = run_attn_chain(c, w.DAA, w, wc, G, w.DCENTER, st)) return rc;
   const std::string ce = "aa_encoder.center_embed.embed.";
   float *w0 = G(ce + "0.weight"), *b0 = G(ce + "0.bias"), *g1 = G(ce + "1.weight"), *e1 = G(ce + "1.bias");
@@ -782,9 +788,12 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
                              const float* blob_bwd, const float* step_tab /*HOST [H,8]*/, const float* step_tab_dev,
                              const trajsde_noise* noise, const float* d_local, float diff_weight, void* ws, int64_t ws_bytes,
                              float* diff_loss, float* const* grads, int n_grads, float* d_latent, float* d_aa_out,
-                             void* stream_) {
+                             const trajsde_dropout* dropout, void* stream_) {
   TS_REQUIRE(b && g && rot && blob_fwd && blob_bwd && step_tab && step_tab_dev && d_local && ws && diff_loss && grads,
              "encoder_backward: null pointer");
+  TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "encoder_backward: dropout p must be in [0, 1)");
+  const DropArg drop_aa = dropout ? make_drop(dropout->p, dropout->seed, 0) : no_drop();     // block ids of dropout.hpp
+  const DropArg drop_al = dropout ? make_drop(dropout->p, dropout->seed, 1) : no_drop();
   TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_backward: graph not compacted (call trajsde_graph_compact)");
   TS_REQUIRE(b->A > 0 && g->Nt == b->N + b->A, "encoder_backward: graph was prepared without the fake-agent rows");
   const std::vector<std::string> names = stage_param_names(TRAJSDE_STAGE_ENCODER_BWD, 0, 0);
@@ -812,10 +821,10 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   if (Eaa > 0)
     TS_LAUNCH(k_edge_kv<true>, tile_grid((Eaa + 15) / 16, 1024, EdgeL6::SIZE * 4), 1024, EdgeL6::SIZE * 4, st, blob_fwd + FB::AA_EDGE6,
               g->aa_geom, g->aa_dst, w.q, Eaa, w.logits, w.v, 8);
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, g->aa_segptr, w.logits, w.v, R, w.agg, 8);
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, g->aa_segptr, w.logits, w.v, R, w.agg, 8, drop_aa);
   TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
-            w.center, R, w.x1, w.xn2);
-  TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out);
+            w.center, R, w.x1, w.xn2, drop_aa);
+  TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out, drop_aa);
   for (int idx = 0; idx < H; ++idx) {
     const int t = H - 1 - idx;
     const float* e = step_tab + 8 * idx;
@@ -834,9 +843,9 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   if (Ela > 0)
     TS_LAUNCH(k_edge_kv<true>, tile_grid((Ela + 15) / 16, 1024, EdgeL6::SIZE * 4), 1024, EdgeL6::SIZE * 4, st, blob_fwd + FB::AL_EDGE6,
               g->la_geom, g->la_dst, w.al_q, Ela, w.al_logits, w.al_v, 8);
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(N, 4), 256, 0, st, g->la_segptr, w.al_logits, w.al_v, int64_t(N), w.al_agg, 8);
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(N, 4), 256, 0, st, g->la_segptr, w.al_logits, w.al_v, int64_t(N), w.al_agg, 8, drop_al);
   TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
-            w.al_agg, w.al_xn, w.lat, int64_t(N), w.al_x1, w.al_xn2);
+            w.al_agg, w.al_xn, w.lat, int64_t(N), w.al_x1, w.al_xn2, drop_al);
 
   // ================= backward =================
   // ---- ALEncoder: d local_embed -> d latent
@@ -844,6 +853,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
     AttnChain c{blob_bwd + BB::AL_NODE, blob_bwd + BB::AL_PROJ, blob_bwd + BB::AL_EDGEKV, blob_bwd + BB::AL_EDGEEMB,
                 g->la_geom, w.al_q, w.al_logits, w.al_v, w.lat, g->la_dst, g->la_segptr,
                 NodeBlockTape{w.al_agg, w.al_xn, w.al_x1, w.al_xn2}, int64_t(N), Ela, "al_encoder", "lane_embed"};
+    c.drop = drop_al;
     if (int rc = run_attn_chain(c, d_local, w, wc, G, w.DLAT, st)) return rc;
     if (d_latent) TS_HIP(hipMemcpyAsync(d_latent, w.DLAT, size_t(N) * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
@@ -908,7 +918,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
     }
   }
   if (d_aa_out) TS_HIP(hipMemcpyAsync(d_aa_out, w.DAA, size_t(R) * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
-  if (int rc = aa_encoder_backward(b, g, rot, blob_bwd, w, wc, G, 8, st)) return rc;
+  if (int rc = aa_encoder_backward(b, g, rot, blob_bwd, w, wc, G, 8, st, drop_aa)) return rc;
   return TRAJSDE_OK;
 }
 
@@ -980,10 +990,10 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
   if (Eaa > 0)
     TS_LAUNCH(k_edge_kv<true>, tile_grid((Eaa + 15) / 16, 1024, EdgeL6::SIZE * 4), 1024, EdgeL6::SIZE * 4, st, blob_fwd + FB::AA_EDGE6,
               g->aa_geom, g->aa_dst, w.q, Eaa, w.logits, w.v, num_heads);
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, g->aa_segptr, w.logits, w.v, R, w.agg, num_heads);
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, g->aa_segptr, w.logits, w.v, R, w.agg, num_heads, no_drop());
   TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
-            w.center, R, w.x1, w.xn2);
-  TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out);
+            w.center, R, w.x1, w.xn2, no_drop());
+  TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out, no_drop());
   TS_LAUNCH(k_tr_prep, cdiv(RT * 64, 256), 256, 0, st, w.aa_out, b->padding_mask, blob_fwd + EncGridBlob::TOK, N, b->TT, x0);
   const float* x = x0;
   for (int l = 0; l < nl; ++l) {
@@ -994,7 +1004,7 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
     else TS_LAUNCH(k_tr_attention<8>, cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, N, tp[l].o);
     TS_LAUNCH(k_tr_outproj, tile_grid(rtiles, 512, TrOutL::SIZE * 4), 512, TrOutL::SIZE * 4, st, lb + TrLayerL::OUT, tp[l].o, x, RT, tp[l].x1,
               tp[l].xn2);
-    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, tp[l].x1, tp[l].xn2, RT, tp[l].out);
+    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, tp[l].x1, tp[l].xn2, RT, tp[l].out, no_drop());
     x = tp[l].out;
   }
   TS_LAUNCH(k_tr_final, tile_grid((int64_t(N) + 15) / 16, 256, 0), 256, 0, st, blob_fwd + EncGridBlob::norm(nl), x, N, tout);
@@ -1003,9 +1013,9 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
   if (Ela > 0)
     TS_LAUNCH(k_edge_kv<true>, tile_grid((Ela + 15) / 16, 1024, EdgeL6::SIZE * 4), 1024, EdgeL6::SIZE * 4, st, blob_fwd + FB::AL_EDGE6,
               g->la_geom, g->la_dst, w.al_q, Ela, w.al_logits, w.al_v, num_heads);
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(N, 4), 256, 0, st, g->la_segptr, w.al_logits, w.al_v, int64_t(N), w.al_agg, num_heads);
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(N, 4), 256, 0, st, g->la_segptr, w.al_logits, w.al_v, int64_t(N), w.al_agg, num_heads, no_drop());
   TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
-            w.al_agg, w.al_xn, tout, int64_t(N), w.al_x1, w.al_xn2);
+            w.al_agg, w.al_xn, tout, int64_t(N), w.al_x1, w.al_xn2, no_drop());
   // ================= backward =================
   {
     AttnChain c{blob_bwd + BB::AL_NODE, blob_bwd + BB::AL_PROJ, blob_bwd + BB::AL_EDGEKV, blob_bwd + BB::AL_EDGEEMB,
@@ -1040,7 +1050,7 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
     float *wi = G(p + ".self_attn.in_proj_weight"), *bi = G(p + ".self_attn.in_proj_bias");
     float *n1g = G(p + ".norm1.weight"), *n1b = G(p + ".norm1.bias");
     TS_REQUIRE(!G.missing, "encoder_grid_backward: parameter table lacks " + G.missing_name);
-    if (int rc = ffn_block_backward(lb + TrLayerBwdL::FFN_A, lb + TrLayerBwdL::FFN_B, tp[l].xn2, tp[l].x1, dcur, RT, sc, wc, gr, st)) return rc;
+    if (int rc = ffn_block_backward(lb + TrLayerBwdL::FFN_A, lb + TrLayerBwdL::FFN_B, tp[l].xn2, tp[l].x1, dcur, RT, sc, wc, gr, st, no_drop())) return rc;
     TS_LAUNCH(k_lin_t_acc, tile_grid(rtiles, 256, MAT64 * 4), 256, MAT64 * 4, st, lb + TrLayerBwdL::WOUT_T, sc.dx1, RT, dO, 0);
     if (int rc = run_wgrad(wc, sc.dx1, 64, tp[l].o, 64, RT, RT, wo, 64, 0, bo, 0)) return rc;
     if (num_heads == 4) TS_LAUNCH(k_tr_attention_bwd<4>, cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, dO, N, dq, dk, dv);

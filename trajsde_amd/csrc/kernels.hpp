@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dropout.hpp"
 #include "philox.hpp"
 
 namespace tsde {
@@ -31,8 +32,9 @@ inline AttnPlan attn_plan(int64_t E, int streams_target = SEG_STREAMS_512) {
   p.nstreams = (E + p.C - 1) / p.C;
   return p;
 }
-template <int THREADS>
-__global__ void k_edge_attn2(const float* img, const float* geom, const int32_t* dst, const float* q, int64_t E, int C, float* rec, int heads);
+template <int THREADS, bool DROP>
+__global__ void k_edge_attn2(const float* img, const float* geom, const int32_t* dst, const float* q, int64_t E, int C, float* rec, int heads,
+                             const int32_t* segptr, DropArg drop);
 __global__ void k_seg_merge(const int32_t* segptr, const float* rec, int C, int64_t R, float* agg);
 template <bool X6>
 __global__ void k_edge_embed(const float* img, const float* geom, int64_t E, float* emb_out);
@@ -41,12 +43,12 @@ __global__ void k_global_edge(const float* img, const float* rel, const int32_t*
                               const float* kn, const float* vn, int64_t E, float* logits, float* v);
 template <int HEADS>
 __global__ void k_global_attn(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
-                              const float* vn, int64_t N, float* agg);
-__global__ void k_seg_softmax_agg(const int32_t* segptr, const float* logits, const float* v, int64_t R, float* agg, int heads);
+                              const float* vn, int64_t N, float* agg, DropArg drop);
+__global__ void k_seg_softmax_agg(const int32_t* segptr, const float* logits, const float* v, int64_t R, float* agg, int heads, DropArg drop);
 template <bool X6>
-__global__ void k_node_update(const float* img, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2);
-__global__ void k_ffn6(const float* img, const float* x1, const float* xn2, int64_t R, float* out);
-__global__ void k_ffn(const float* img, const float* x1, const float* xn2, int64_t R, float* out);
+__global__ void k_node_update(const float* img, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2, DropArg drop);
+__global__ void k_ffn6(const float* img, const float* x1, const float* xn2, int64_t R, float* out, DropArg drop);
+__global__ void k_ffn(const float* img, const float* x1, const float* xn2, int64_t R, float* out, DropArg drop);
 template <int NQ>
 __global__ void k_node_proj(const float* img, const float* x, int64_t R, float* xn_out, float* p0, float* p1, float* p2);
 __global__ void k_mode_proj(const float* norm_g, const float* proj_g, const float* x, int64_t N, float* out);

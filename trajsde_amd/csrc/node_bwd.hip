@@ -13,6 +13,7 @@
 // that are matrices come from the saved rows through run_wgrad (decoder_bwd.hip), vectors from per-wave accumulators.
 #include "bwd.hpp"
 #include "common.hpp"
+#include "dropout.hpp"
 #include "layouts.hpp"
 #include "tile.hpp"
 #include "tile_bwd.hpp"
@@ -31,9 +32,11 @@ __device__ __forceinline__ void store_row256(const f4 (&a)[16], float* base, int
 }
 
 // H = relu(W1 xn2 + b1)  [R,256];  DH = (W2^T dout) * (H > 0)
+// with dropout (mlp: Linear - ReLU - Dropout(m1) - Linear - Dropout(m2)): H = relu(..) m1 is what mlp.3 saw, the gradient
+// entering mlp.3 is DOUT2 = dout m2 (saved: it is the delta of the mlp.3 weight gradient), DH = (W2^T DOUT2) m1 (pre > 0)
 __global__ __launch_bounds__(256) void k_ffn_bwd_a(const float* __restrict__ img, const float* __restrict__ dout,
                                                    const float* __restrict__ xn2, int64_t R, float* __restrict__ H,
-                                                   float* __restrict__ DH) {
+                                                   float* __restrict__ DH, float* __restrict__ DOUT2, DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, img, FfnBwdAL::SIZE);
   const Lane L;
@@ -47,14 +50,34 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_a(const float* __restrict__ img
     linear<16, 4>(hid, n, lds + FfnBwdAL::W1, lds + FfnBwdAL::B1, L);
     relu<16>(hid);
     load_row(n, dout, r, L.g);
+    const bool dropping = drop.p > 0.f;
+    f4 m1[16];
+    if (dropping) {
+      f4 mk[4];
+      drop_feat16(mk, drop, DK_OUT, uint32_t(r), 0, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) n[jt] *= mk[jt];
+      if (row < R) store_row(n, DOUT2, row, L.g);
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        drop_feat16(mk, drop, DK_HIDDEN, uint32_t(r), blk, L.g);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          m1[4 * blk + jt] = mk[jt];
+          hid[4 * blk + jt] *= mk[jt];
+        }
+      }
+    }
 #pragma unroll
     for (int jt = 0; jt < 16; ++jt) dh[jt] = f4{0.f, 0.f, 0.f, 0.f};
     linear_adj<16, 4>(dh, n, lds + FfnBwdAL::W2T, L);
 #pragma unroll
     for (int jt = 0; jt < 16; ++jt)
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (!(hid[jt][c] > 0.f)) dh[jt][c] = 0.f;
+      for (int c = 0; c < 4; ++c) {
+        if (!(hid[jt][c] > 0.f)) dh[jt][c] = 0.f;              // pre <= 0, or dropped
+        else if (dropping) dh[jt][c] *= m1[jt][c];
+      }
     if (row < R) {
       store_row256(hid, H, row, L.g);
       store_row256(dh, DH, row, L.g);
@@ -96,10 +119,11 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_b(const float* __restrict__ img
 
 // gate = sigmoid(Wih agg + Whh xn + b); s = Wself xn + b; upd = agg + gate (s - agg); x1 = x + Wout upd + b
 // given dx1:  UPD, DGP (d gate pre-activation), DS (d s), DAGG (d agg), DXN (d xn from this block)
+// with dropout x1 = x + m3 (Wout upd + b): the gradient entering out_proj is DX1M = dx1 m3 (saved: delta of its weight gradient)
 __global__ __launch_bounds__(256) void k_upd_bwd(const float* __restrict__ img, const float* __restrict__ dx1,
                                                  const float* __restrict__ agg, const float* __restrict__ xn, int64_t R,
                                                  float* __restrict__ UPD, float* __restrict__ DGP, float* __restrict__ DS,
-                                                 float* __restrict__ DAGG, float* __restrict__ DXN) {
+                                                 float* __restrict__ DAGG, float* __restrict__ DXN, float* __restrict__ DX1M, DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using U = UpdBwdL;
   stage_blob(lds, img, U::SIZE);
@@ -119,6 +143,13 @@ __global__ __launch_bounds__(256) void k_upd_bwd(const float* __restrict__ img, 
     sigmoid_<4>(g);
     linear<4, 4>(s, n, lds + U::WSELF, lds + U::BSELF, L);
     load_row(d, dx1, r, L.g);
+    if (drop.p > 0.f) {
+      f4 mk[4];
+      drop_feat16(mk, drop, DK_PROJ, uint32_t(r), 0, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) d[jt] *= mk[jt];
+      if (row < R) store_row(d, DX1M, row, L.g);
+    }
     linear_t(t, d, lds + U::WOUT_T, L);                                 // t = d upd
     f4 upd[4], dgp[4], ds[4], dagg[4];
 #pragma unroll
@@ -389,10 +420,13 @@ int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64
 // ------------------------------------------------------------------ host drivers
 // out = x1 + W2 relu(W1 norm2(x1) + b1) + b2 given dout: sc.dx1 = d x1 (residual + through norm2), FFN / norm2 gradients
 int ffn_block_backward(const float* img_a, const float* img_b, const float* xn2, const float* x1, const float* dout, int64_t R,
-                       const NodeBlockScratch& sc, const WgradCtx& wc, const NodeBlockGrads& gr, hipStream_t st) {
+                       const NodeBlockScratch& sc, const WgradCtx& wc, const NodeBlockGrads& gr, hipStream_t st, const DropArg& drop) {
   const int64_t ntiles = (R + 15) / 16;
   const int ga = tile_grid(ntiles, 256, FfnBwdAL::SIZE * 4), gb = vec_grid(ntiles, 256, FfnBwdBL::SIZE * 4);
-  TS_LAUNCH(k_ffn_bwd_a, ga, 256, FfnBwdAL::SIZE * 4, st, img_a, dout, xn2, R, sc.H, sc.DH);
+  // dropout: the masked gradient rows entering mlp.3 live in sc.UPD until this function's weight gradients are enqueued
+  // (k_upd_bwd, which owns that buffer, runs after them on the same stream)
+  const float* dout2 = drop.p > 0.f ? sc.UPD : dout;
+  TS_LAUNCH(k_ffn_bwd_a, ga, 256, FfnBwdAL::SIZE * 4, st, img_a, dout, xn2, R, sc.H, sc.DH, sc.UPD, drop);
   TS_LAUNCH(k_ffn_bwd_b, gb, 256, FfnBwdBL::SIZE * 4, st, img_b, sc.DH, dout, x1, R, sc.dx1, sc.vpart);
   if (int rc = run_colsum(st, sc.vpart, gb * 4, 128, 64, gr.n2g)) return rc;
   if (int rc = run_colsum(st, sc.vpart + 64, gb * 4, 128, 64, gr.n2b)) return rc;
@@ -400,19 +434,22 @@ int ffn_block_backward(const float* img_a, const float* img_b, const float* xn2,
   WgradBatch wb(wc, R, R);
   for (int b = 0; b < 4; ++b) {
     if (int rc = wb.add(sc.DH + 64 * b, 256, xn2, 64, gr.w1 + b * MAT64, 64, 0, gr.b1 + 64 * b, 0)) return rc;
-    if (int rc = wb.add(dout, 64, sc.H + 64 * b, 256, gr.w2, 256, 64 * b, b == 0 ? gr.b2 : nullptr, 0)) return rc;
+    if (int rc = wb.add(dout2, 64, sc.H + 64 * b, 256, gr.w2, 256, 64 * b, b == 0 ? gr.b2 : nullptr, 0)) return rc;
   }
   return wb.flush();
 }
 
 int node_block_backward(const float* img, const NodeBlockTape& tp, const float* dout, int64_t R, const NodeBlockScratch& sc,
-                        const WgradCtx& wc, const NodeBlockGrads& gr, float* dagg, float* dxn, hipStream_t st) {
+                        const WgradCtx& wc, const NodeBlockGrads& gr, float* dagg, float* dxn, hipStream_t st, const DropArg& drop) {
   const int64_t ntiles = (R + 15) / 16;
   const int gu = tile_grid(ntiles, 256, UpdBwdL::SIZE * 4);
-  if (int rc = ffn_block_backward(img + NodeBlockBwdL::FFN_A, img + NodeBlockBwdL::FFN_B, tp.xn2, tp.x1, dout, R, sc, wc, gr, st)) return rc;
-  TS_LAUNCH(k_upd_bwd, gu, 256, UpdBwdL::SIZE * 4, st, img + NodeBlockBwdL::UPD, sc.dx1, tp.agg, tp.xn, R, sc.UPD, sc.DGP, sc.DS, dagg, dxn);
+  if (int rc = ffn_block_backward(img + NodeBlockBwdL::FFN_A, img + NodeBlockBwdL::FFN_B, tp.xn2, tp.x1, dout, R, sc, wc, gr, st, drop)) return rc;
+  // dropout: the masked gradient rows entering out_proj go to sc.H (the FFN's weight gradients, its last readers, are enqueued)
+  const float* dx1m = drop.p > 0.f ? sc.H : sc.dx1;
+  TS_LAUNCH(k_upd_bwd, gu, 256, UpdBwdL::SIZE * 4, st, img + NodeBlockBwdL::UPD, sc.dx1, tp.agg, tp.xn, R, sc.UPD, sc.DGP, sc.DS, dagg, dxn, sc.H,
+            drop);
   WgradBatch wb(wc, R, R);
-  if (int rc = wb.add(sc.dx1, 64, sc.UPD, 64, gr.w_out, 64, 0, gr.b_out, 0)) return rc;
+  if (int rc = wb.add(dx1m, 64, sc.UPD, 64, gr.w_out, 64, 0, gr.b_out, 0)) return rc;
   if (int rc = wb.add(sc.DGP, 64, tp.agg, 64, gr.w_ih, 64, 0, gr.b_ih, 0)) return rc;
   if (int rc = wb.add(sc.DGP, 64, tp.xn, 64, gr.w_hh, 64, 0, gr.b_hh, 0)) return rc;
   if (int rc = wb.add(sc.DS, 64, tp.xn, 64, gr.w_self, 64, 0, gr.b_self, 0)) return rc;

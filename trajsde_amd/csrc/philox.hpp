@@ -28,6 +28,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// the four raw words of counter (row, step, stream, quad): what the dropout masks are cut from (dropout.hpp)
+__device__ __forceinline__ void philox_words(uint64_t seed, uint32_t stream, uint32_t step, uint32_t row, uint32_t quad, uint32_t (&w)[4]) {
+  philox4x32_10(row, step, stream, quad, uint32_t(seed), uint32_t(seed >> 32), w);
+}
+
 __device__ __forceinline__ float u01(uint32_t x) { return (float(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 // four standard normals for columns 4*quad .. 4*quad+3 of (stream, step, row)

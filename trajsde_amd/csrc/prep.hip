@@ -10,6 +10,7 @@
 // The compacted lists carry the pre-rotated 2-d geometry the edge kernels consume (16 B per edge).
 #include <hipcub/hipcub.hpp>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -159,10 +160,15 @@ __global__ void k_fake_x(int A, int H, const float* __restrict__ x, const int64_
 }
 
 // ---------------------------------------------------------------------------------------------- 21 snapshots
-// 32 lanes per extended node, lane = history step t: one pass counts the surviving in-edges of snapshot node (t, i)
-// (both endpoints valid at t, ENC:108; closer than the radius, UTIL:88), a prefix sum over the H*Nt counts gives the
-// segment pointers, a second identical pass writes the compacted records.  For a fixed in-edge the H lanes read the
-// H contiguous positions / padding bytes of the sender: coalesced, and no per-candidate flag array or 44M-entry scan.
+// Lane = (extended node, history step t): a wave holds 64 / H nodes (3 for H = 21), the H lanes of a node walk the node's
+// CSR row together, so for one in-edge they read the sender's H contiguous positions / padding bytes: coalesced.  One pass
+// counts the surviving in-edges of snapshot node (t, i) (both endpoints valid at t, ENC:108; closer than the radius,
+// UTIL:88), a prefix sum over the H*Nt counts gives the segment pointers, a second identical pass writes the compacted
+// records.  A lane's survivors are consecutive entries of its own segment, so the fill pass buffers four of them in registers
+// and writes 64 B of geometry + one 16-byte vector of targets (+ one of senders) at a time: the pass is bound by the number of
+// store instructions (every lane of one hits a different cache line), and this cuts them from 12 to 6 per four survivors.
+// (A ballot-compaction form -- lanes = 64 candidate senders at a fixed t, survivors written 64 at a time -- was measured
+// slower: its position reads are 64-line gathers, 0.22 ms for the count pass alone against 0.09 ms.)
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_aa_pass(int N, int Nt, int H, int TT, const int32_t* __restrict__ rowptr,
                                                  const int32_t* __restrict__ csr_src, const int32_t* __restrict__ orig,
@@ -170,55 +176,85 @@ __global__ __launch_bounds__(256) void k_aa_pass(int N, int Nt, int H, int TT, c
                                                  const float* __restrict__ x, const float* __restrict__ rot, float radius_val,
                                                  const float* __restrict__ radius_dev, int32_t* __restrict__ cnt_or_ptr, int32_t* __restrict__ aa_dst,
                                                  int32_t* __restrict__ aa_src, float* __restrict__ geom) {
-  const int t = threadIdx.x & 31;
-  const int64_t node = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 5;
-  if (node >= Nt) return;
+  const int lane = threadIdx.x & 63, per = 64 / H;                         // nodes per wave
+  const int sub = lane / H, t = lane - sub * H;                            // sub >= per: idle tail lanes of the wave
+  const int64_t wave = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t node = wave * per + sub;
+  const bool live = sub < per && node < Nt;
   const float radius = radius_dev ? radius_dev[0] : radius_val;            // the fill pass re-reads what the count pass used
-  const int o = orig[node];
-  const bool tv = t < H;
-  const int tc = tv ? t : 0;
-  const bool dst_ok = tv && !pad[int64_t(o) * TT + tc];
-  const float px = pos[(int64_t(o) * TT + tc) * 2], py = pos[(int64_t(o) * TT + tc) * 2 + 1];
+  const int o = live ? orig[node] : 0;
+  const bool dst_ok = live && !pad[int64_t(o) * TT + t];
+  const float px = pos[(int64_t(o) * TT + t) * 2], py = pos[(int64_t(o) * TT + t) * 2 + 1];
   f4 R = f4{0.f, 0.f, 0.f, 0.f};
   int k = 0;
-  if (FILL) {
+  if (FILL && live) {
     R = *reinterpret_cast<const f4*>(rot + 4 * o);
-    k = tv ? cnt_or_ptr[int64_t(tc) * Nt + node] : 0;
+    k = cnt_or_ptr[int64_t(t) * Nt + node];
   }
-  const int beg = rowptr[o], end = rowptr[o + 1];
-  for (int p0 = beg; p0 < end; p0 += 32) {
-    const int mine = p0 + t < end ? csr_src[p0 + t] : 0;                   // coalesced chunk of sender ids
-    const int m = end - p0 < 32 ? end - p0 : 32;
-    for (int u0 = 0; u0 < m; u0 += 4) {                                    // 4 senders' loads in flight, then tested in order
+  const int beg = live ? rowptr[o] : 0, end = live ? rowptr[o + 1] : 0;
+  const int first = sub * H;                                               // lane of this node's t = 0
+  f4 gbuf[4];
+  int sbuf[4];
+  int nb = 0;                                                              // survivors waiting in gbuf / sbuf
+  const int tgt = t * Nt + int(node);
+  auto flush4 = [&]() {                                                    // k already counts the four buffered survivors
+    float* gp = geom + 4 * int64_t(k - 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(gp + 4 * j) = gbuf[j];
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    typedef i4 __attribute__((aligned(4))) i4u;                           // segments start at any 4-byte position
+    *reinterpret_cast<i4u*>(aa_dst + (k - 4)) = i4{tgt, tgt, tgt, tgt};
+    if (aa_src != nullptr) *reinterpret_cast<i4u*>(aa_src + (k - 4)) = i4{sbuf[0], sbuf[1], sbuf[2], sbuf[3]};
+  };
+  // the nodes of a wave have rows of different lengths: every lane runs to the longest, past its own end it idles
+  int longest = end - beg;
+  for (int off = 1; off < 64; off <<= 1) longest = max(longest, __shfl_xor(longest, off));
+  for (int p0 = 0; p0 < longest; p0 += H) {
+    const int mine = (p0 + t < end - beg) ? csr_src[beg + p0 + t] : 0;     // coalesced chunk of H sender ids per node
+    const int m = min(max(end - beg - p0, 0), H);
+    for (int u0 = 0; u0 < H; u0 += 4) {                                    // 4 senders' loads in flight, then tested in order
       int sv[4];
       uint8_t pv[4];
       float2 qv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        sv[j] = __shfl(mine, u0 + j < m ? u0 + j : m - 1, 32);
-        pv[j] = pad[int64_t(sv[j]) * TT + tc];
-        qv[j] = *reinterpret_cast<const float2*>(pos + (int64_t(sv[j]) * TT + tc) * 2);
+        const int u = u0 + j < m ? u0 + j : (m > 0 ? m - 1 : 0);
+        sv[j] = __shfl(mine, first + u);
+        pv[j] = pad[int64_t(sv[j]) * TT + t];
+        qv[j] = *reinterpret_cast<const float2*>(pos + (int64_t(sv[j]) * TT + t) * 2);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (u0 + j >= m) break;
-        const int s = sv[j];
-        const bool ok = dst_ok && !pv[j];
+        const int sdr = sv[j];
+        const bool ok = dst_ok && u0 + j < m && !pv[j];
         const float dx = qv[j].x - px, dy = qv[j].y - py;
         if (ok && sqrtf(dx * dx + dy * dy) < radius) {
           if (FILL) {
-            const float x0 = x[(int64_t(s) * H + tc) * 2], x1 = x[(int64_t(s) * H + tc) * 2 + 1];   // senders are real actors
-            f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
-            *reinterpret_cast<f4*>(geom + 4 * int64_t(k)) = g;
-            aa_dst[k] = tc * Nt + int(node);
-            aa_src[k] = s;
+            const float x0 = x[(int64_t(sdr) * H + t) * 2], x1 = x[(int64_t(sdr) * H + t) * 2 + 1];   // senders are real actors
+            const f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              if (nb == b) { gbuf[b] = g; sbuf[b] = sdr; }                 // static register indices
+            ++nb;
           }
           ++k;
+          if (FILL && nb == 4) { flush4(); nb = 0; }
         }
       }
     }
   }
-  if (!FILL && tv) cnt_or_ptr[int64_t(tc) * Nt + node] = k;
+  if (FILL) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      if (b < nb) {
+        const int64_t w = k - nb + b;
+        *reinterpret_cast<f4*>(geom + 4 * w) = gbuf[b];
+        aa_dst[w] = tgt;
+        if (aa_src != nullptr) aa_src[w] = sbuf[b];
+      }
+  } else if (live) {
+    cnt_or_ptr[int64_t(t) * Nt + node] = k;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- global / lane edges
@@ -303,7 +339,7 @@ __global__ void k_la_compact(int E_al, const int32_t* __restrict__ actor, const 
   f4 g = {fx * R[0] + fy * R[2], fx * R[1] + fy * R[3], vx * R[0] + vy * R[2], vx * R[1] + vy * R[3]};   // ENC:763-764
   *reinterpret_cast<f4*>(geom + 4 * int64_t(q)) = g;
   la_dst[q] = i;
-  la_lane[q] = lane;
+  if (la_lane != nullptr) la_lane[q] = lane;
 }
 __global__ void k_collect_counts(int64_t n_aa, int E, int E_al, const int32_t* __restrict__ aa_segptr, const int32_t* __restrict__ cpos_g,
                                  const int32_t* __restrict__ cpos_la, float radius, int32_t* __restrict__ counts) {
@@ -402,12 +438,12 @@ static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* row
     k_scatter<<<cdiv(E, 256), 256, 0, st>>>(ei, E, cursor, out, 0);
     // short rows: one wave per row and many rows in flight; long rows: a full workgroup per row
     static const int rs_env = []() { const char* e = getenv("TRAJSDE_ROWSORT_THREADS"); return e ? atoi(e) : 0; }();
-    const int rs_threads = rs_env ? rs_env : (int64_t(E) <= int64_t(N) * 256 ? 64 : 256);
+    const int rs_threads = rs_env ? rs_env : (int64_t(E) <= int64_t(N) * 64 ? 64 : 256);
     k_row_sort<int32_t><<<N < 16384 ? N : 16384, rs_threads, 0, st>>>(rowptr, N, out);
   } else if (E > 0) {
     k_scatter_lane<<<cdiv(E, 256), 256, 0, st>>>(ei, E, cursor, lane_pack);
     static const int rs_env = []() { const char* e = getenv("TRAJSDE_ROWSORT_THREADS"); return e ? atoi(e) : 0; }();
-    const int rs_threads = rs_env ? rs_env : (int64_t(E) <= int64_t(N) * 256 ? 64 : 256);
+    const int rs_threads = rs_env ? rs_env : (int64_t(E) <= int64_t(N) * 64 ? 64 : 256);
     k_row_sort<int64_t><<<N < 16384 ? N : 16384, rs_threads, 0, st>>>(rowptr, N, lane_pack);
     k_unpack_eid<<<cdiv(E, 256), 256, 0, st>>>(lane_pack, E, out);
   }
@@ -419,7 +455,14 @@ static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* row
 
 using namespace tsde;
 
+static std::atomic<int> g_export_senders{0};
+
 extern "C" {
+
+int trajsde_export_senders(int on) {
+  const int prev = g_export_senders.exchange(on ? 1 : 0);
+  return prev;
+}
 
 int trajsde_rotate(const float* rotate_angles, int32_t N, const float* y, int32_t F, float* rotate_mat, float* y_rot, void* stream) {
   TS_REQUIRE(rotate_angles && rotate_mat && N > 0, "rotate: bad argument");
@@ -446,15 +489,19 @@ int trajsde_graph_prepare(const trajsde_batch* b, const float* rot, float radius
   NoiseArg na{0, nullptr, nullptr};
   if (fake_noise) { na.seed = fake_noise->seed; na.z = fake_noise->z; na.row_ids = fake_noise->row_ids; }
 
-  if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.cursor, w.csr_src, nullptr, w.cub_tmp, w.cub_bytes, st)) return rc;
+  {
+    ProfScope ps("build_csr[actors]", st);
+    if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.cursor, w.csr_src, nullptr, w.cub_tmp, w.cub_bytes, st)) return rc;
+  }
   k_ext_nodes<<<cdiv(Nt, 256), 256, 0, st>>>(N, A, H, b->agent_index, b->batch, b->source, b->bos_mask, w.orig, w.nus, w.eos, w.pick_slot);
   if (A > 0) {
     k_agent_slots<<<cdiv(A, 256), 256, 0, st>>>(A, b->agent_index, w.pick_slot);
     k_fake_x<<<cdiv(A * ((2 * H + 3) / 4), 256), 256, 0, st>>>(A, H, b->x, b->agent_index, na, w.x_fake);
   }
   // 21 snapshots: count pass + prefix sum -> segment pointers
-  k_aa_pass<false><<<cdiv(int64_t(Nt) * 32, 256), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, b->padding_mask, b->positions,
-                                                                b->x, rot, radius, nullptr, w.aa_segptr, nullptr, nullptr, nullptr);
+  { ProfScope ps("k_aa_pass<count>", st);
+  k_aa_pass<false><<<cdiv(Nt, 4 * (64 / H)), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, b->padding_mask, b->positions,
+                                                                b->x, rot, radius, nullptr, w.aa_segptr, nullptr, nullptr, nullptr); }
   TS_HIP(hipMemsetAsync(w.aa_segptr + w.n_aa, 0, sizeof(int32_t), st));
   {
     size_t tmp = size_t(w.cub_bytes);
@@ -469,7 +516,10 @@ int trajsde_graph_prepare(const trajsde_batch* b, const float* rot, float radius
   k_segptr_from_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, w.rowptr, w.cpos_g, w.g_segptr);
   // lane-actor edges grouped by actor
   if (b->L > 0) k_lane_feat<<<cdiv(b->L, 256), 256, 0, st>>>(b->L, b->lane_pts, b->lane_positions, b->lane_paddings, w.lane_feat);
-  if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_cursor, w.la_eid, w.la_pack, w.cub_tmp, w.cub_bytes, st)) return rc;
+  {
+    ProfScope ps("build_csr[lanes]", st);
+    if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_cursor, w.la_eid, w.la_pack, w.cub_tmp, w.cub_bytes, st)) return rc;
+  }
   k_la_flags<<<cdiv(Ea + 1, 256), 256, 0, st>>>(Ea, N, w.la_rowptr, w.la_eid, b->lane_actor_vectors, radius, w.la_actor, w.flags_la);
   {
     size_t tmp = size_t(w.cub_bytes);
@@ -503,16 +553,19 @@ int trajsde_graph_compact(const trajsde_batch* b, const float* rot, void* ws, in
   if (!w.ok || !e.ok) return fail(TRAJSDE_ERR_WORKSPACE, "graph_compact: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int N = b->N, A = b->A, E = b->E, H = b->H, TT = b->TT, Ea = b->E_al, Nt = N + A;
-  k_aa_pass<true><<<cdiv(int64_t(Nt) * 32, 256), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, b->padding_mask, b->positions,
-                                                               b->x, rot, 0.f, reinterpret_cast<const float*>(w.counts) + 4, w.aa_segptr, e.aa_dst, e.aa_src, e.aa_geom);
+  const bool want_src = g_export_senders.load() != 0;                      // sender ids are for checking the index work only
+  { ProfScope ps("k_aa_pass<fill>", st);
+  k_aa_pass<true><<<cdiv(Nt, 4 * (64 / H)), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, b->padding_mask, b->positions,
+                                                               b->x, rot, 0.f, reinterpret_cast<const float*>(w.counts) + 4, w.aa_segptr, e.aa_dst, want_src ? e.aa_src : nullptr, e.aa_geom); }
   if (E > 0)
     k_g_compact<<<cdiv(E, 256), 256, 0, st>>>(E, TT, H - 1, w.csr_src, w.csr_dst, b->positions, rot, b->rotate_angles, w.flags_g,
                                               w.cpos_g, e.g_src, e.g_dst, e.g_geom);
   if (Ea > 0)
     k_la_compact<<<cdiv(Ea, 256), 256, 0, st>>>(Ea, w.la_actor, w.la_eid, b->lane_actor_index, b->lane_actor_vectors, w.lane_feat,
-                                                rot, w.flags_la, w.cpos_la, e.la_dst, e.la_lane, e.la_geom);
+                                                rot, w.flags_la, w.cpos_la, e.la_dst, want_src ? e.la_lane : nullptr, e.la_geom);
   TS_LAUNCH_CHECK("graph_compact kernels");
-  out->aa_geom = e.aa_geom; out->aa_dst = e.aa_dst; out->aa_src = e.aa_src; out->la_lane = e.la_lane;
+  out->aa_geom = e.aa_geom; out->aa_dst = e.aa_dst;
+  out->aa_src = want_src ? e.aa_src : nullptr; out->la_lane = want_src ? e.la_lane : nullptr;
   out->g_geom = e.g_geom; out->g_src = e.g_src; out->g_dst = e.g_dst;
   out->la_geom = e.la_geom; out->la_dst = e.la_dst;
   return TRAJSDE_OK;

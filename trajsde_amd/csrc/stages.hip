@@ -84,37 +84,41 @@ struct NodeImgs {
   const float *upd, *ffn, *upd6, *ffn6;
 };
 static int update_ffn(const NodeImgs& im, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2, float* out,
-                      hipStream_t st) {
+                      hipStream_t st, const DropArg& drop = no_drop()) {
   const int64_t ntiles = (R + 15) / 16;
   if (node_x6()) {
     TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, threads_node(), UpdL6::SIZE * 4), threads_node(), UpdL6::SIZE * 4, st, im.upd6, agg, xn, x,
-              R, x1, xn2);
-    TS_LAUNCH(k_ffn6, tile_grid(ntiles, threads_node(), FfnL6::HALF * 4), threads_node(), FfnL6::HALF * 4, st, im.ffn6, x1, xn2, R, out);
+              R, x1, xn2, drop);
+    TS_LAUNCH(k_ffn6, tile_grid(ntiles, threads_node(), FfnL6::HALF * 4), threads_node(), FfnL6::HALF * 4, st, im.ffn6, x1, xn2, R, out, drop);
   } else {
     TS_LAUNCH(k_node_update<false>, tile_grid(ntiles, threads_node(), UpdL::SIZE * 4), threads_node(), UpdL::SIZE * 4, st, im.upd, agg, xn, x, R,
-              x1, xn2);
-    TS_LAUNCH(k_ffn, tile_grid(ntiles, threads_node(), FfnL::SIZE * 4), threads_node(), FfnL::SIZE * 4, st, im.ffn, x1, xn2, R, out);
+              x1, xn2, drop);
+    TS_LAUNCH(k_ffn, tile_grid(ntiles, threads_node(), FfnL::SIZE * 4), threads_node(), FfnL::SIZE * 4, st, im.ffn, x1, xn2, R, out, drop);
   }
   return TRAJSDE_OK;
 }
 static int attention_tail(const NodeImgs& im, const int32_t* segptr, const float* logits, const float* v, const float* xn, const float* x,
-                          int64_t R, float* agg, float* x1, float* xn2, float* out, hipStream_t st, int heads = 8) {
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, segptr, logits, v, R, agg, heads);
-  return update_ffn(im, agg, xn, x, R, x1, xn2, out, st);
+                          int64_t R, float* agg, float* x1, float* xn2, float* out, hipStream_t st, int heads = 8,
+                          const DropArg& drop = no_drop()) {
+  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, segptr, logits, v, R, agg, heads, drop);
+  return update_ffn(im, agg, xn, x, R, x1, xn2, out, st, drop);
 }
 
 // embedding + lin_k|lin_v + softmax-aggregate of one edge list in the fused form: records, then one merged agg row per target
 static int fused_edge_attention(const char* tag, bool dominant, const float* img, const float* geom, const int32_t* dst, const float* q,
-                                int64_t E, const int32_t* segptr, int64_t R, float* rec, float* agg, int heads, hipStream_t st) {
+                                int64_t E, const int32_t* segptr, int64_t R, float* rec, float* agg, int heads, hipStream_t st,
+                                const DropArg& drop = no_drop()) {
   const AttnPlan pl = fused_plan(E);
   if (E > 0) {
-    const int threads = fused_threads();
+    const int threads = drop.p > 0.f ? 512 : fused_threads();             // the dropout form is built for 512 threads
     const int64_t waves = (pl.nstreams + 31) / 32;
     const int grid = int((waves + threads / 64 - 1) / (threads / 64));
-    if (threads == 768)
-      TS_LAUNCH_TAG(tag, dominant, k_edge_attn2<768>, grid, 768, EdgeL6::SIZE * 4, st, img, geom, dst, q, E, pl.C, rec, heads);
+    if (drop.p > 0.f)
+      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, true>), grid, 512, EdgeL6::SIZE * 4, st, img, geom, dst, q, E, pl.C, rec, heads, segptr, drop);
+    else if (threads == 768)
+      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<768, false>), grid, 768, EdgeL6::SIZE * 4, st, img, geom, dst, q, E, pl.C, rec, heads, segptr, drop);
     else
-      TS_LAUNCH_TAG(tag, dominant, k_edge_attn2<512>, grid, 512, EdgeL6::SIZE * 4, st, img, geom, dst, q, E, pl.C, rec, heads);
+      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, false>), grid, 512, EdgeL6::SIZE * 4, st, img, geom, dst, q, E, pl.C, rec, heads, segptr, drop);
   }
   TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, pl.C, R, agg);
   return TRAJSDE_OK;
@@ -134,7 +138,7 @@ int64_t trajsde_encoder_ws_bytes(const trajsde_batch* b, const trajsde_graph* g)
 
 // AAEncoder on the H snapshots at once (ENC:112-121, 538-566) -> aa_out [H, Nt, 64]
 static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob, EncWs& w, float* aa_out,
-                          hipStream_t st, int heads = 8) {
+                          hipStream_t st, int heads = 8, const DropArg& drop = no_drop()) {
   const int N = b->N, Nt = g->Nt, H = b->H;
   const int64_t R = int64_t(H) * Nt;
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob + EncBlob::AA_CENTER,
@@ -142,9 +146,9 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
   const NodeImgs im{blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, blob + EncBlob::AA_UPD6, blob + EncBlob::AA_FFN6};
   if (attn_fused()) {
     if (int rc = fused_edge_attention("k_edge_kv[aa]", true, blob + EncBlob::AA_EDGE6, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), g->aa_segptr, R,
-                                      w.rec, w.agg, heads, st))
+                                      w.rec, w.agg, heads, st, drop))
       return rc;
-    return update_ffn(im, w.agg, w.cn, w.center, R, w.x1, w.xn2, aa_out, st);
+    return update_ffn(im, w.agg, w.cn, w.center, R, w.x1, w.xn2, aa_out, st, drop);
   }
   if (g->E_aa > 0) {
     if (edge_x6() && edge_pair())
@@ -163,7 +167,7 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
       TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv<false>, tile_grid((int64_t(g->E_aa) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(),
                     EdgeL::SIZE * 4, st, blob + EncBlob::AA_EDGE, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v, heads);
   }
-  return attention_tail(im, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg, w.x1, w.xn2, aa_out, st, heads);
+  return attention_tail(im, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg, w.x1, w.xn2, aa_out, st, heads, drop);
 }
 
 // one pass of the latent SDE + GRU recurrence; iteration idx consumes history step t = H-1-idx (ENC:128-182)
@@ -201,16 +205,16 @@ static int run_recurrence(const trajsde_batch* b, const trajsde_graph* g, const 
 
 // ALEncoder (ENC:198-200, 732-797): lat [N,64] -> local_embed [N,64]
 static int run_al_encoder(const trajsde_batch* b, const trajsde_graph* g, const float* blob, EncWs& w, const float* lat,
-                          float* local_embed, hipStream_t st, int heads = 8) {
+                          float* local_embed, hipStream_t st, int heads = 8, const DropArg& drop = no_drop()) {
   const int N = b->N;
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob + EncBlob::AL_Q, lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
   const NodeImgs im{blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, blob + EncBlob::AL_UPD6, blob + EncBlob::AL_FFN6};
   if (attn_fused()) {
     if (int rc = fused_edge_attention("k_edge_kv[al]", false, blob + EncBlob::AL_EDGE6, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), g->la_segptr,
-                                      int64_t(N), w.al_rec, w.al_agg, heads, st))
+                                      int64_t(N), w.al_rec, w.al_agg, heads, st, drop))
       return rc;
-    return update_ffn(im, w.al_agg, w.al_xn, lat, N, w.al_x1, w.al_xn2, local_embed, st);
+    return update_ffn(im, w.al_agg, w.al_xn, lat, N, w.al_x1, w.al_xn2, local_embed, st, drop);
   }
   if (g->E_la > 0) {
     if (edge_x6() && edge_pair())
@@ -223,13 +227,17 @@ static int run_al_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
       TS_LAUNCH_TAG("k_edge_kv[al]", false, k_edge_kv<false>, tile_grid((int64_t(g->E_la) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(),
                     EdgeL::SIZE * 4, st, blob + EncBlob::AL_EDGE, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), w.al_logits, w.al_v, heads);
   }
-  return attention_tail(im, g->la_segptr, w.al_logits, w.al_v, w.al_xn, lat, N, w.al_agg, w.al_x1, w.al_xn2, local_embed, st, heads);
+  return attention_tail(im, g->la_segptr, w.al_logits, w.al_v, w.al_xn, lat, N, w.al_agg, w.al_x1, w.al_xn2, local_embed, st, heads, drop);
 }
 
 int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob,
                             const float* step_tab /*HOST [H,8]*/, const trajsde_noise* noise, void* ws, int64_t ws_bytes,
-                            float* local_embed, float* diff_pick, float* aa_out_user, float* latent_ys, void* stream_) {
+                            float* local_embed, float* diff_pick, float* aa_out_user, float* latent_ys, const trajsde_dropout* dropout,
+                            void* stream_) {
   TS_REQUIRE(b && g && rot && blob && step_tab && ws && local_embed && diff_pick, "encoder_forward: null pointer");
+  TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "encoder_forward: dropout p must be in [0, 1)");
+  const DropArg drop_aa = dropout ? make_drop(dropout->p, dropout->seed, 0) : no_drop();     // block ids of dropout.hpp
+  const DropArg drop_al = dropout ? make_drop(dropout->p, dropout->seed, 1) : no_drop();
   TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_forward: graph not compacted (call trajsde_graph_compact)");
   TS_REQUIRE(b->A > 0 && g->Nt == b->N + b->A, "encoder_forward: graph was prepared without the fake-agent rows");
   EncWs w(b, g, ws, ws_bytes);
@@ -238,10 +246,10 @@ int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, cons
   float* aa_out = aa_out_user ? aa_out_user : w.aa_out;
   NoiseArg na{0, nullptr, nullptr};
   if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
-  if (int rc = run_aa_encoder(b, g, rot, blob, w, aa_out, st)) return rc;
+  if (int rc = run_aa_encoder(b, g, rot, blob, w, aa_out, st, 8, drop_aa)) return rc;
   TS_HIP(hipMemsetAsync(diff_pick, 0, size_t(2) * b->A * 64 * sizeof(float), st));
   if (int rc = run_recurrence(b, g, blob, step_tab, blob + EncBlob::HIDDEN, 0, na, w, aa_out, w.lat, diff_pick, latent_ys, st)) return rc;
-  return run_al_encoder(b, g, blob, w, w.lat, local_embed, st);
+  return run_al_encoder(b, g, blob, w, w.lat, local_embed, st, 8, drop_al);
 }
 
 // LocalEncoderSDESepPara2.forward_ood (ENC:204-370): the batch/graph carry no fake agents (A = 0); `n_samples`
@@ -314,7 +322,7 @@ int trajsde_encoder_grid_forward(const trajsde_batch* b, const trajsde_graph* g,
     if (num_heads == 4) TS_LAUNCH(k_tr_attention<4>, cdiv(N, 4), 256, 0, st, q, k, v, N, o);
     else TS_LAUNCH(k_tr_attention<8>, cdiv(N, 4), 256, 0, st, q, k, v, N, o);
     TS_LAUNCH(k_tr_outproj, tile_grid(rtiles, 512, TrOutL::SIZE * 4), 512, TrOutL::SIZE * 4, st, lb + TrLayerL::OUT, o, x, R, x1, xn2);
-    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, x1, xn2, R, nx);
+    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, x1, xn2, R, nx, no_drop());
     float* t = x; x = nx; nx = t;
   }
   TS_LAUNCH(k_tr_final, tile_grid((int64_t(N) + 15) / 16, 256, 0), 256, 0, st, blob + EncGridBlob::norm(num_temporal_layers), x, N, tout);
@@ -330,13 +338,14 @@ int64_t trajsde_aggregator_ws_bytes(const trajsde_batch* b, const trajsde_graph*
 
 int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers, int num_modes,
                                const float* local_embed, void* ws, int64_t ws_bytes, float* global_embed, void* stream_) {
-  return trajsde_aggregator_forward_heads(b, g, blob, num_layers, num_modes, 8, local_embed, ws, ws_bytes, global_embed, stream_);
+  return trajsde_aggregator_forward_heads(b, g, blob, num_layers, num_modes, 8, local_embed, ws, ws_bytes, global_embed, nullptr, stream_);
 }
 
 int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers, int num_modes,
                                      int num_heads, const float* local_embed, void* ws, int64_t ws_bytes, float* global_embed,
-                                     void* stream_) {
+                                     const trajsde_dropout* dropout, void* stream_) {
   TS_REQUIRE(b && g && blob && local_embed && ws && global_embed, "aggregator_forward: null pointer");
+  TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "aggregator_forward: dropout p must be in [0, 1)");
   TS_REQUIRE(num_heads == 8 || num_heads == 4, "aggregator_forward: num_heads must be 8 or 4");
   TS_REQUIRE(g->g_src && g->g_segptr, "aggregator_forward: graph not compacted (call trajsde_graph_compact)");
   TS_REQUIRE(num_layers >= 0 && num_modes > 0, "aggregator_forward: bad layer/mode count");
@@ -362,13 +371,15 @@ int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph
     const NodeImgs im{lb + AggLayerL::UPD, lb + AggLayerL::FFN, lb + AggLayerL::UPD6, lb + AggLayerL::FFN6};
     static const bool fused_env = []() { const char* e = getenv("TRAJSDE_GLOBAL_UNFUSED"); return !(e && atoi(e) != 0); }();
     const bool fused = fused_env || num_heads != 8;           // the unfused edge kernel exists for 8 heads only
+    const DropArg drop = dropout ? make_drop(dropout->p, dropout->seed, 2 + i) : no_drop();   // block ids of dropout.hpp
+    TS_REQUIRE(fused || drop.p == 0.f, "aggregator_forward: dropout needs the fused global attention (unset TRAJSDE_GLOBAL_UNFUSED)");
     if (fused) {
       // one wave per target: logits, softmax and aggregation in one pass over the rel rows (no per-edge GEMM)
       if (num_heads == 4)
-        TS_LAUNCH(k_global_attn<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg);
+        TS_LAUNCH(k_global_attn<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, drop);
       else
-        TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg);
-      if (int rc = update_ffn(im, w.agg, w.xn, x, N, w.x1, w.xn2, out, st)) return rc;
+        TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, drop);
+      if (int rc = update_ffn(im, w.agg, w.xn, x, N, w.x1, w.xn2, out, st, drop)) return rc;
       x = out;
       continue;
     }

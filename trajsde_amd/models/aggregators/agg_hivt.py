@@ -28,5 +28,6 @@ class GlobalInteractor(ParamTree):
         self.set_init_seed(None)
         self._rt = runtime.StageRuntime(self, "aggregator")
 
-    def forward(self, data, local_embed):
-        return self._rt.aggregator_forward(data, local_embed)
+    def forward(self, data, local_embed, noise=None):
+        """`noise` (ours, optional): the NoiseSpec whose dropout key seeds this stage's train-mode dropout masks"""
+        return self._rt.aggregator_forward(data, local_embed, noise)

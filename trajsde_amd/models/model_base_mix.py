@@ -112,6 +112,12 @@ class PredictionModel(nn.Module):
             raise NotImplementedError(f"training_step differentiates L2 through the HIP kernels; configured: {self.loss_names}")
         if data.y is None:
             raise ValueError("training_step needs targets (data.y)")
+        p_drop = max(float(getattr(m, "dropout", 0.0) or 0.0) for m in (self.encoder, self.aggregator))
+        if self.training and p_drop > 0:
+            raise NotImplementedError(
+                f"dropout={p_drop}: the vanilla variant's TemporalEncoder has dropout sites (attention weights, dropout1/2, the FFN) "
+                "whose HIP training kernels are not built; train this variant with `dropout: 0.0` (the shipped "
+                "trajsde_amd/configs/mi355x_trmenc_mlpdec.yml does) -- the SDE model applies its dropout (csrc/dropout.hpp)")
         if not hasattr(self, "_param_names"):
             self._param_names = [n for n, _ in self.named_parameters()]
         params = [p for _, p in self.named_parameters()]

@@ -43,7 +43,7 @@ class _PathLoss(torch.autograd.Function):
             d_glob, d_local = dec["d_global_embed"], dec["d_local_embed"]
             if w_l2 != 1.0:
                 d_glob, d_local = d_glob * w_l2, d_local * w_l2
-            agg = agg_rt.aggregator_backward(data, local, d_glob)
+            agg = agg_rt.aggregator_backward(data, local, d_glob, noise)
             enc = enc_rt.encoder_backward(data, d_local + agg["d_local_embed"], noise, diff_weight=w_diff)
             by_name = {}
             for n, g in dec["grads"].items():
@@ -128,7 +128,7 @@ class PredictionModelSDENet(nn.Module):
         else:
             local_embed, diff_in, diff_out, label_in, label_out = self.encoder(data=data, noise=noise,
                                                                                preserve_side_effects=preserve_side_effects)
-        global_embed = self.aggregator(data=data, local_embed=local_embed)
+        global_embed = self.aggregator(data=data, local_embed=local_embed, noise=noise)
         out = self.decoder(data=data, local_embed=local_embed, global_embed=global_embed, noise=noise)
         if ood:
             out["stds"] = stds                                                                 # MODEL:97-98
@@ -160,7 +160,7 @@ class PredictionModelSDENet(nn.Module):
             data.y = y_rot
         data["rotate_mat"] = rotate_mat
         local_embed, diff_in, diff_out, label_in, label_out = self.encoder(data=data, noise=noise)
-        global_embed = self.aggregator(data=data, local_embed=local_embed)
+        global_embed = self.aggregator(data=data, local_embed=local_embed, noise=noise)
         out = self.decoder(data=data, local_embed=local_embed, global_embed=global_embed, noise=noise)
         out["diff_in"], out["diff_out"], out["label_in"], out["label_out"] = diff_in, diff_out, label_in, label_out
         return out, local_embed, global_embed
@@ -168,7 +168,9 @@ class PredictionModelSDENet(nn.Module):
     # -- Lightning-style hooks (MODEL:104-148) ------------------------------------------------------
     def training_step(self, data, batch_idx, noise: Optional["runtime.NoiseSpec"] = None):
         """MODEL:104-116: forward, the weighted sum of the configured losses, as a tensor whose `.backward()` fills
-        `.grad` through the HIP backward kernels.  The kernels implement the shipped loss set (losses/L2.py +
+        `.grad` through the HIP backward kernels.  In train mode (`model.train()`) the stages' `dropout` is applied at the
+        reference's sites (attention weights, out_proj output, the two FFN activations of every attention block) with masks
+        cut from the Philox stream of `noise` (csrc/dropout.hpp); `model.eval()` switches it off, as in the reference.  The kernels implement the shipped loss set (losses/L2.py +
         losses/diff_BCE.py, CFG:78-83); any other loss is refused rather than silently differentiated elsewhere."""
         if not self.rotate:
             raise NotImplementedError("rotate=False is not built (shipped config: rotate: true, CFG:18)")
@@ -178,14 +180,6 @@ class PredictionModelSDENet(nn.Module):
             raise NotImplementedError(f"training_step differentiates L2 (+ DiffBCE) through the HIP kernels; configured: {self.loss_names}")
         if data.y is None:
             raise ValueError("training_step needs targets (data.y)")
-        if not getattr(self, "_dropout_warned", False):
-            self._dropout_warned = True
-            p_drop = max(float(getattr(m, "dropout", 0.0) or 0.0) for m in (self.encoder, self.aggregator))
-            if p_drop > 0:
-                import warnings
-                warnings.warn(f"dropout={p_drop} of the YAML is accepted but NOT applied: the HIP training step differentiates the "
-                              "network without dropout (the reference applies it to attention weights, projections and the FFNs "
-                              "in train mode, ENC:538-614, AGG:92-135); DESIGN.md section 7")
         noise = runtime.NoiseSpec.resolve(noise)
         if not hasattr(self, "_param_names"):
             self._param_names = [n for n, _ in self.named_parameters()]

@@ -63,3 +63,73 @@ def normals(seed: int, stream: int, step: int, rows: np.ndarray, ncols: int) -> 
         out[..., a] = r * np.cos(th).astype(np.float32)
         out[..., a + 1] = r * np.sin(th).astype(np.float32)
     return out.reshape(rows.shape[0], ncols)
+
+
+# ---------------------------------------------------------------------------------------------- dropout masks
+# Host twin of trajsde_amd/csrc/dropout.hpp (bit-exact: integer comparisons on the Philox words).  A mask element is a 16-bit
+# field of a Philox block, kept when field >= round(p * 65536), then scaled by 1 / (1 - p).
+STREAM_DROPOUT = 16
+DK_ATTN, DK_PROJ, DK_HIDDEN, DK_OUT = 0, 1, 2, 3
+BLOCK_AA, BLOCK_AL, BLOCK_GLOBAL0 = 0, 1, 2            # attention block ids: AAEncoder, ALEncoder, global layer i -> 2 + i
+
+
+def words(seed: int, stream: int, step, rows, quad: int = 0) -> np.ndarray:
+    """raw Philox words [n, 4] of the counters (row, step, stream, quad); `step` and `rows` broadcast"""
+    rows = np.asarray(rows, dtype=np.uint32)
+    step = np.broadcast_to(np.asarray(step, dtype=np.uint32), rows.shape)
+    ctr = np.zeros(rows.shape + (4,), dtype=np.uint32)
+    ctr[..., 0], ctr[..., 1], ctr[..., 2], ctr[..., 3] = rows, step, np.uint32(stream), np.uint32(quad)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
+    return philox4x32_10(ctr, key)
+
+
+def dropout_threshold(p: float) -> int:
+    return int(float(p) * 65536.0 + 0.5)
+
+
+def dropout_scale(p: float) -> np.float32:
+    return np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+
+
+def _fields(w: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """16-bit field `idx` (0..7) of each 4-word block w[..., 4]"""
+    word = np.take_along_axis(w, (idx >> 1)[..., None].astype(np.int64), axis=-1)[..., 0]
+    return (word >> (np.uint32(16) * (idx & 1).astype(np.uint32))) & np.uint32(0xFFFF)
+
+
+def dropout_feature_mask(seed: int, block: int, kind: int, n_rows: int, n_feat: int, p: float) -> np.ndarray:
+    """[n_rows, n_feat] float32 of {0, 1/(1-p)}: feature f = 64 blk + 16 jt + 4 g + c of row r comes from the block of counter
+    (r, 8 blk + 2 g + (jt >> 1), stream, 0), field 4 (jt & 1) + c"""
+    f = np.arange(n_feat)
+    blk, within = f >> 6, f & 63
+    jt, g, c = within >> 4, (within >> 2) & 3, within & 3
+    call, idx = blk * 8 + 2 * g + (jt >> 1), 4 * (jt & 1) + c
+    rows = np.repeat(np.arange(n_rows, dtype=np.uint32)[:, None], n_feat, axis=1)
+    w = words(seed, STREAM_DROPOUT + 4 * block + kind, np.broadcast_to(call[None, :], rows.shape), rows)
+    keep = _fields(w, np.broadcast_to(idx[None, :], rows.shape)) >= np.uint32(dropout_threshold(p))
+    return np.where(keep, dropout_scale(p), np.float32(0.0)).astype(np.float32)
+
+
+def dropout_attn_mask(seed: int, block: int, dst, rank, heads: int, p: float) -> np.ndarray:
+    """[E, heads] float32 of {0, 1/(1-p)} for edges given by their target node and their rank inside the target's segment of the
+    canonical (ascending sender) order: counter (dst, rank, stream, 0), field = head"""
+    dst = np.asarray(dst, dtype=np.uint32)
+    w = words(seed, STREAM_DROPOUT + 4 * block + DK_ATTN, np.asarray(rank, dtype=np.uint32), dst)
+    h = np.arange(heads)
+    wrep = np.repeat(w[:, None, :], heads, axis=1)
+    keep = _fields(wrep, np.broadcast_to(h[None, :], (dst.shape[0], heads))) >= np.uint32(dropout_threshold(p))
+    return np.where(keep, dropout_scale(p), np.float32(0.0)).astype(np.float32)
+
+
+def segment_ranks(src, dst) -> np.ndarray:
+    """rank of every edge inside its target's segment when segments are ordered by ascending sender (ties: input order) --
+    the order of the compacted lists of csrc/prep.hip"""
+    src, dst = np.asarray(src, dtype=np.int64), np.asarray(dst, dtype=np.int64)
+    n = src.shape[0]
+    order = np.lexsort((np.arange(n), src, dst))
+    ds = dst[order]
+    first = np.r_[0, np.flatnonzero(ds[1:] != ds[:-1]) + 1] if n else np.zeros(0, dtype=np.int64)
+    start = np.repeat(first, np.diff(np.r_[first, n])) if n else first
+    rank = np.empty(n, dtype=np.int64)
+    rank[order] = np.arange(n) - start
+    return rank

@@ -36,6 +36,7 @@ class NoiseSpec:
     *_row_ids       int32 global row ids for the Philox counter (resharding-invariant streams)
     """
     seed: int = 0
+    dropout_seed: Optional[int] = None       # key of the train-mode dropout masks (csrc/dropout.hpp); default: `seed`
     z_fake: Optional[torch.Tensor] = None
     z_enc: Optional[torch.Tensor] = None
     z_dec: Optional[torch.Tensor] = None
@@ -48,6 +49,14 @@ class NoiseSpec:
         if noise is not None:
             return noise
         return NoiseSpec(seed=int(torch.randint(0, 2 ** 62, (1,)).item()))   # fresh stream per forward, like the reference
+
+    def c_dropout(self, module) -> Optional[_lib.Dropout]:
+        """the stage's `dropout` kwarg as the C struct while the module is in train mode, else None (eval: no dropout)"""
+        p = float(getattr(module, "dropout", 0.0) or 0.0)
+        if not getattr(module, "training", False) or p <= 0.0:
+            return None
+        ds = self.seed if self.dropout_seed is None else self.dropout_seed
+        return _lib.Dropout(C.c_float(p), C.c_uint64(int(ds) & 0xFFFFFFFFFFFFFFFF))
 
     def c_noise(self, z: Optional[torch.Tensor], row_ids: Optional[torch.Tensor]) -> _lib.Noise:
         if z is not None:
@@ -269,9 +278,15 @@ class StageRuntime:
         `preserve_side_effects`: also leave `edge_index_{t}` / `edge_attr_{t}` on the batch like ENC:107-110 does."""
         m = self.module
         noise = NoiseSpec.resolve(noise)
-        gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), noise)
-        dev = gc.device
+        cap = bool(getattr(m, "capture_intermediates", False))
         L = _lib.lib()
+        prev = L.trajsde_export_senders(1) if cap else 0                  # edge lists with their senders, for the tests
+        try:
+            gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), noise, want_senders=cap)
+        finally:
+            if cap:
+                L.trajsde_export_senders(prev)
+        dev = gc.device
         blob = self.blob()
         H, N, A, Nt = gc.batch.H, gc.batch.N, gc.batch.A, gc.graph.Nt
         tab = self._enc_table()
@@ -279,16 +294,17 @@ class StageRuntime:
             raise _lib.TrajsdeError(f"z_enc must be [{H},{Nt},{D}]")
         local = torch.empty(N, D, device=dev, dtype=torch.float32)
         diff_pick = torch.empty(2 * A, D, device=dev, dtype=torch.float32)
-        cap = bool(getattr(m, "capture_intermediates", False))
         aa_out = torch.empty(H, Nt, D, device=dev, dtype=torch.float32) if cap else None
         latent = torch.empty(H, N, D, device=dev, dtype=torch.float32) if cap else None
         ws_bytes = L.trajsde_encoder_ws_bytes(C.byref(gc.batch), C.byref(gc.graph))
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         cn = noise.c_noise(noise.z_enc, noise.enc_row_ids)
+        dr = noise.c_dropout(m)
         with torch.cuda.device(dev):
             _lib.check(L.trajsde_encoder_forward(C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), blob.data_ptr(),
                                                  tab.ctypes.data_as(C.c_void_p), C.byref(cn), ws.data_ptr(), ws_bytes,
-                                                 local.data_ptr(), diff_pick.data_ptr(), _ptr(aa_out), _ptr(latent), _stream()),
+                                                 local.data_ptr(), diff_pick.data_ptr(), _ptr(aa_out), _ptr(latent),
+                                                 C.byref(dr) if dr is not None else None, _stream()),
                        "trajsde_encoder_forward")
         if cap:
             m.last_intermediates = {"aa_out": aa_out, "latent_ys": latent, "E_aa": gc.graph.E_aa, "E_g": gc.graph.E_g,
@@ -323,12 +339,14 @@ class StageRuntime:
         ws_bytes = L.trajsde_encoder_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph))
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         cn = noise.c_noise(noise.z_enc, noise.enc_row_ids)
+        dr = noise.c_dropout(m)                                            # the forward's masks, regenerated from the same key
         with torch.cuda.device(dev):
             _lib.check(L.trajsde_encoder_backward(
                 C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), self.blob().data_ptr(),
                 self.blob(_lib.STAGE_ENCODER_BWD).data_ptr(), tab.ctypes.data_as(C.c_void_p), tab_dev.data_ptr(), C.byref(cn),
                 d_local.to(torch.float32).contiguous().data_ptr(), float(diff_weight), ws.data_ptr(), ws_bytes, loss.data_ptr(),
-                arr, len(names), _ptr(d_lat), _ptr(d_aa), _stream()), "trajsde_encoder_backward")
+                arr, len(names), _ptr(d_lat), _ptr(d_aa), C.byref(dr) if dr is not None else None, _stream()),
+                "trajsde_encoder_backward")
         out = {"grads": grads, "diff_loss": loss[0]}
         if want_boundaries:
             out.update(d_latent=d_lat, d_aa_out=d_aa)
@@ -368,9 +386,10 @@ class StageRuntime:
         return local, stds
 
     # ---------------------------------------------------------------- aggregator
-    def aggregator_forward(self, data, local_embed: torch.Tensor) -> torch.Tensor:
-        """GlobalInteractor.forward (AGG:38-58) -> [K, N, 64]."""
+    def aggregator_forward(self, data, local_embed: torch.Tensor, noise: Optional[NoiseSpec] = None) -> torch.Tensor:
+        """GlobalInteractor.forward (AGG:38-58) -> [K, N, 64].  `noise`: only its dropout key is used, in train mode."""
         m = self.module
+        dr = NoiseSpec.resolve(noise).c_dropout(m) if (m.training and float(getattr(m, "dropout", 0.0) or 0.0) > 0) else None
         _require_gpu(local_embed, "local_embed")
         gc = GraphContext.get(data, None, int(m.historical_steps), None)
         dev = gc.device
@@ -383,7 +402,8 @@ class StageRuntime:
         with torch.cuda.device(dev):
             _lib.check(L.trajsde_aggregator_forward_heads(C.byref(gc.batch), C.byref(gc.graph), blob.data_ptr(), int(m.num_layers), K,
                                                           int(m.num_heads), local_embed.contiguous().data_ptr(), ws.data_ptr(),
-                                                          ws_bytes, out.data_ptr(), _stream()), "trajsde_aggregator_forward")
+                                                          ws_bytes, out.data_ptr(), C.byref(dr) if dr is not None else None, _stream()),
+                       "trajsde_aggregator_forward")
         return out
 
     # ---------------------------------------------------------------- vanilla HiVT variant
@@ -448,7 +468,8 @@ class StageRuntime:
                 "reg_mask": ~data["padding_mask"][:, -T:]}
 
 
-    def aggregator_backward(self, data, local_embed: torch.Tensor, d_global: torch.Tensor) -> Dict[str, object]:
+    def aggregator_backward(self, data, local_embed: torch.Tensor, d_global: torch.Tensor,
+                            noise: Optional[NoiseSpec] = None) -> Dict[str, object]:
         """Backward of GlobalInteractor.forward: dL/d global_embed [K,N,64] -> {"grads": {param name: tensor},
         "d_local_embed": [N,64]} (the aggregator's own contribution; the decoder's d local_embed is added by the
         caller).  The forward is recomputed inside the call."""
@@ -466,11 +487,14 @@ class StageRuntime:
         d_local = torch.empty(N, D, device=dev, dtype=torch.float32)
         ws_bytes = L.trajsde_aggregator_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), nl, K)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        dr = noise.c_dropout(m) if noise is not None else None            # the forward's masks
+        if dr is None and m.training and float(getattr(m, "dropout", 0.0) or 0.0) > 0:
+            raise _lib.TrajsdeError("aggregator_backward in train mode needs the NoiseSpec of the forward pass (dropout key)")
         with torch.cuda.device(dev):
             _lib.check(L.trajsde_aggregator_backward_heads(
                 C.byref(gc.batch), C.byref(gc.graph), self.blob().data_ptr(), self.blob(_lib.STAGE_AGGREGATOR_BWD).data_ptr(), nl, K,
                 int(m.num_heads), local_embed.contiguous().data_ptr(), d_global.to(torch.float32).contiguous().data_ptr(), ws.data_ptr(), ws_bytes,
-                arr, len(names), d_local.data_ptr(), _stream()), "trajsde_aggregator_backward")
+                arr, len(names), d_local.data_ptr(), C.byref(dr) if dr is not None else None, _stream()), "trajsde_aggregator_backward")
         return {"grads": grads, "d_local_embed": d_local}
 
 
@@ -603,8 +627,11 @@ class GraphContext:
         return tuple(out)
 
     @classmethod
-    def get(cls, data, radius: Optional[float], H: int, noise: Optional[NoiseSpec], fake_agents: bool = True) -> "GraphContext":
+    def get(cls, data, radius: Optional[float], H: int, noise: Optional[NoiseSpec], fake_agents: bool = True,
+            want_senders: bool = False) -> "GraphContext":
         gc = data[cls.KEY] if cls.KEY in data else None
+        if gc is not None and want_senders and not gc.graph.aa_src and gc.graph.E_aa > 0:
+            gc = None                                                     # built without the sender ids: rebuild
         key = None
         if radius is not None and noise is not None:
             key = (float(radius), int(noise.seed), id(noise.z_fake), id(noise.fake_row_ids), bool(fake_agents), cls._input_stamp(data))
