@@ -41,7 +41,7 @@ def main():
     run(20)
     torch.cuda.synchronize()
     beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 200
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     beg.record()
     run(n)
     end.record()
