@@ -37,6 +37,14 @@ int trajsde_abi_version(void);
 /* matrix products per fp32 product of the split-precision kernels this library was built with:
  * 3 = fp16x3 (default), 6 = bf16x6 (build with TRAJSDE_SPLIT=bf16x6); see csrc/tile.hpp */
 int trajsde_split_products(void);
+/* Storage of the [rows][64] activations that stay INSIDE a stage between its kernels -- the relative-pose embeddings of the
+ * global interactor [E_g,64], aa_out [H,Nt,64] entering the recurrence, the decoder's initial states y0 [K*N,64], and the
+ * state of trajsde_sde_step: mode 0 = fp32 (default), 1 = bf16 ("bf16 hidden state" of the stress configuration: rows are
+ * rounded to nearest-even when stored and widened exactly when loaded; all arithmetic stays fp32 in registers; stage
+ * boundaries -- local_embed, global_embed, loc, pi -- stay fp32).  Process-wide; returns the previous mode.  Inference only:
+ * the backward entry points keep their tape in fp32 and refuse to run in mode 1.  In mode 1 the buffers trajsde_sde_step
+ * reads and writes hold bf16 elements. */
+int trajsde_state_storage(int mode);
 /* fp16 range guard of the split-precision products (csrc/range.hpp).  Kernels that feed a data-dependent, unnormalised
  * tensor (SDE states, rows entering the recurrence / the decoder, attention aggregates, FFN hidden units) or a weight to an
  * fp16x3 product set a sticky per-device bit when a magnitude reaches 65504, where the fp16 pieces would saturate.  This call

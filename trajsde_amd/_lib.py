@@ -53,6 +53,7 @@ SIGNATURES = {
     "trajsde_split_products": (C.c_int, []),
     "trajsde_abi_version": (C.c_int, []),
     "trajsde_export_senders": (C.c_int, [C.c_int]),
+    "trajsde_state_storage": (C.c_int, [C.c_int]),
     "trajsde_range_status": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), P]),
     "trajsde_param_count": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trajsde_param_name": (C.c_char_p, [C.c_int, C.c_int, C.c_int, C.c_int]),

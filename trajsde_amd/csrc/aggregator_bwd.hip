@@ -332,6 +332,7 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
                                       void* ws, int64_t ws_bytes, float* const* grads, int n_grads, float* d_local,
                                       const trajsde_dropout* dropout, void* stream_) {
   TS_REQUIRE(b && g && blob_fwd && blob_bwd && local_embed && d_global && ws && grads && d_local, "aggregator_backward: null pointer");
+  TS_REQUIRE(!state_bf16(), "aggregator_backward: the backward pass keeps its tape in fp32; switch trajsde_state_storage(0) for training");
   TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "aggregator_backward: dropout p must be in [0, 1)");
   auto drop_of = [&](int layer) { return dropout ? make_drop(dropout->p, dropout->seed, 2 + layer) : no_drop(); };   // dropout.hpp block ids
   TS_REQUIRE(num_heads == 8 || num_heads == 4, "aggregator_backward: num_heads must be 8 or 4");
@@ -360,7 +361,7 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
   // ---- forward recompute (the kernels the forward itself runs), one buffer per layer
   if (E > 0)
     TS_LAUNCH(k_edge_embed<true>, tile_grid(etiles, 1024, EdgeL6::EMB_SIZE * 4), 1024, EdgeL6::EMB_SIZE * 4, st, blob_fwd + AggBlob::REL6,
-              g->g_geom, E, w.rel);
+              g->g_geom, E, w.rel, 0);
   const float* x = local_embed;
   for (int l = 0; l < nl; ++l) {
     const float* lb = blob_fwd + AggBlob::layer(l);
@@ -368,10 +369,10 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
               w.xn[l], w.q[l], w.kn[l], w.vn[l]);
     if (num_heads == 4)
       TS_LAUNCH(k_global_attn<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
-                w.agg[l], drop_of(l));
+                w.agg[l], drop_of(l), 0);
     else
       TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
-                w.agg[l], drop_of(l));
+                w.agg[l], drop_of(l), 0);
     TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, lb + AggLayerL::UPD6, w.agg[l], w.xn[l], x,
               N, w.x1[l], w.xn2[l], drop_of(l));
     TS_LAUNCH(k_ffn6, tile_grid(ntiles, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, lb + AggLayerL::FFN6, w.x1[l], w.xn2[l], N, w.out[l],

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_seg_merge(const int32_t* __restrict__ s
 // global interactor: relative-pose embedding only (AGG:42-51), reused by all layers
 template <bool X6>
 __global__ __launch_bounds__(1024) void k_edge_embed(const float* __restrict__ img_g, const float* __restrict__ geom, int64_t E,
-                                                    float* __restrict__ emb_out) {
+                                                    float* __restrict__ emb_out, int st_bf16) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, img_g, X6 ? int(EdgeL6::EMB_SIZE) : int(EdgeL::EMB_SIZE));
   const Lane L;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(1024) void k_edge_embed(const float* __restrict__ i
     const f4 ge = *reinterpret_cast<const f4*>(geom + 4 * ec);
     f4 emb[4];
     edge_embed<X6>(emb, ge, lds, L);
-    if (e < E) store_row(emb, emb_out, e, L.g);
+    if (e < E) store_row_st(emb, emb_out, e, L.g, st_bf16 != 0);
   }
 }
 
@@ -473,7 +473,8 @@ template <int HEADS>
 __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                      const int32_t* __restrict__ src, const float* __restrict__ rel,
                                                      const float* __restrict__ q, const float* __restrict__ kn,
-                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ agg, DropArg drop) {
+                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ agg, DropArg drop,
+                                                     int st_bf16) {
   constexpr int LPH = 64 / HEADS;          // lanes (= head dims) per head: 8, or 16 with 4 heads
   constexpr int SL = 64 / LPH;             // rel-row columns per lane: a head's 64-wide row is spread over its LPH lanes
   constexpr int NV = SL / 4;               // ... as float4s
@@ -513,24 +514,33 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
     // the chunk's 8 source indices in one coalesced load, handed out as scalars: every row address below is an SGPR
     // base plus a per-lane constant offset, so the loop spends no VALU cycles on address arithmetic
     const int sv = src[e0 + (lane & 7) < end ? e0 + (lane & 7) : end - 1];
-    // every head needs the whole 64-wide rel row, so a per-lane 32-B load would fetch each row HEADS times through the
-    // texture-address unit (16 cycles per 16-B wave load): the wave loads each row once, one dword per lane, and the
-    // lanes pick their slices out of LDS (same-address reads across the heads broadcast)
-    float rl[8];
+    // every head needs the whole 64-wide rel row, so a per-lane 32-B slice load would fetch each row HEADS times through the
+    // texture-address unit: the wave loads the chunk's 8 rows ONCE, parks them in wave-private LDS and the lanes pick their
+    // slices out of LDS (same-address reads across the heads broadcast)
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u < end ? e0 + u : end - 1;
       const int sidx = __builtin_amdgcn_readlane(sv, u);
-      const float* rrow = rel + int64_t(e) * 64;
       const float* krow = kn + int64_t(sidx) * 64;
       const float* vrow = vn + int64_t(sidx) * 64;
-      rl[u] = rrow[lane];
       knv[u] = krow[lane];
       vnv[u] = vrow[lane];
     }
-    __builtin_amdgcn_wave_barrier();                      // the previous chunk's slice reads are done (same wave, in order)
+    if (st_bf16) {                                            // bf16 storage: 8 lanes per row, 16 B (8 elements) per lane, widened here
+      const int ur = lane >> 3, uc = lane & 7;
+      const int64_t er = e0 + ur < end ? e0 + ur : end - 1;
+      const bf4* p = reinterpret_cast<const bf4*>(reinterpret_cast<const __bf16*>(rel) + er * 64 + 8 * uc);
+      const f4 ra = widen4(p[0]), rb = widen4(p[1]);
+      __builtin_amdgcn_wave_barrier();                        // the previous chunk's slice reads are done (same wave, in order)
+      *reinterpret_cast<f4*>(&srel[wv][ur][8 * uc]) = ra;
+      *reinterpret_cast<f4*>(&srel[wv][ur][8 * uc + 4]) = rb;
+    } else {                                                  // fp32: one dword per lane and row (measured faster than 2 x 16 B per lane)
+      float rl[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) srel[wv][u][lane] = rl[u];
+      for (int u = 0; u < 8; ++u) rl[u] = (rel + int64_t(e0 + u < end ? e0 + u : end - 1) * 64)[lane];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int u = 0; u < 8; ++u) srel[wv][u][lane] = rl[u];
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -587,9 +597,9 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
   if (node < N) agg[node * 64 + lane] = out;
 }
 template __global__ void k_global_attn<8>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                          const float*, int64_t, float*, DropArg);
+                                          const float*, int64_t, float*, DropArg, int);
 template __global__ void k_global_attn<4>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                          const float*, int64_t, float*, DropArg);
+                                          const float*, int64_t, float*, DropArg, int);
 
 // ------------------------------------------------------------------------------------------------ update + FFN
 // gate = sigmoid(lin_ih(agg) + lin_hh(xn)); upd = agg + gate*(lin_self(xn) - agg); x1 = x + out_proj(upd); xn2 = norm2(x1)
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ i
 
 // out = x1 + mlp.3(relu(mlp.0(xn2)))
 __global__ __launch_bounds__(512) void k_ffn(const float* __restrict__ img_g, const float* __restrict__ x1,
-                                             const float* __restrict__ xn2, int64_t R, float* __restrict__ out, DropArg drop) {
+                                             const float* __restrict__ xn2, int64_t R, float* __restrict__ out, DropArg drop, int out_bf16) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, img_g, FfnL::SIZE);
   const Lane L;
@@ -680,7 +690,7 @@ __global__ __launch_bounds__(512) void k_ffn(const float* __restrict__ img_g, co
     load_row(n, x1, r, L.g);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) o[jt] += n[jt];
-    if (row < R) store_row(o, out, row, L.g);
+    if (row < R) store_row_st(o, out, row, L.g, out_bf16 != 0);
   }
 }
 
@@ -784,8 +794,8 @@ __global__ __launch_bounds__(512) void k_mode_proj(const float* __restrict__ nor
 
 template __global__ void k_edge_kv<false>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*, int);
 template __global__ void k_edge_kv<true>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*, int);
-template __global__ void k_edge_embed<false>(const float*, const float*, int64_t, float*);
-template __global__ void k_edge_embed<true>(const float*, const float*, int64_t, float*);
+template __global__ void k_edge_embed<false>(const float*, const float*, int64_t, float*, int);
+template __global__ void k_edge_embed<true>(const float*, const float*, int64_t, float*, int);
 template __global__ void k_global_edge<false>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
 template __global__ void k_global_edge<true>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
 template __global__ void k_node_update<false>(const float*, const float*, const float*, const float*, int64_t, float*, float*, DropArg);

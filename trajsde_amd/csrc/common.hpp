@@ -81,6 +81,9 @@ inline int tile_grid(int64_t ntiles, int threads, int lds_bytes) {
 }
 
 
+// storage of the [rows][64] activations that stay inside a stage (trajsde_state_storage): false = fp32, true = bf16
+bool state_bf16();
+
 // ---- optional per-kernel timing with HIP events on the launch stream (trajsde_profile_mode / _report).
 // mode 0: off (no events are created or recorded); 1: only launches tagged as "dominant"; 2: every launch.
 int profile_mode();

@@ -50,7 +50,7 @@ __device__ __forceinline__ void head_pair_eval(float& lx, float& ly, float& sx, 
 
 __global__ __launch_bounds__(1024) void k_dec_init(const float* __restrict__ blob, const float* __restrict__ local,
                                                    const float* __restrict__ global, int N, int K,
-                                                   float* __restrict__ y0, float* __restrict__ pi) {
+                                                   float* __restrict__ y0, float* __restrict__ pi, int st_bf16) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, blob, DecInitL::SIZE);
   const Lane L;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(1024) void k_dec_init(const float* __restrict__ blo
     linear_acc<4, 4>(a, lo, lds + DecInitL::WA_L, L.lane);
     layer_norm<4>(a, lds + DecInitL::AG, lds + DecInitL::AE, L.g);
     relu<4>(a);
-    if (row < rows) store_row(a, y0, row, L.g);
+    if (row < rows) store_row_st(a, y0, row, L.g, st_bf16 != 0);
     load_vec<4>(a, lds + DecInitL::BP, L.g);
     linear_acc<4, 4>(a, lo, lds + DecInitL::WP_L, L.lane);
     linear_acc<4, 4>(a, gl, lds + DecInitL::WP_G, L.lane);
@@ -85,7 +85,7 @@ template <bool X6, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_sde_decode(const float* __restrict__ blob, const float* __restrict__ y0,
                                                      int64_t rows, int T, int n_euler,
                                                      const float* __restrict__ step_tab, const float* __restrict__ out_tab,
-                                                     float min_scale, NoiseArg na, float* __restrict__ loc) {
+                                                     float min_scale, NoiseArg na, float* __restrict__ loc, int st_bf16) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using DL = typename std::conditional<X6, DecSdeL6, DecSdeL>::type;
   stage_blob(lds, blob, DL::SIZE);
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(MAXT) void k_sde_decode(const float* __restrict__ b
     const int64_t row = tile * 16 + L.n;
     const int64_t r = row < rows ? row : rows - 1;
     f4 y[4], prev[4];
-    load_row(y, y0, r, L.g);
+    load_row_st(y, y0, r, L.g, st_bf16 != 0);
     int o = 0;
     for (int k = 0; k < n_euler; ++k) {
       keep_lds_reads_here();
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(MAXT) void k_sde_decode(const float* __restrict__ b
 template <bool X6>
 __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blob, const float* __restrict__ y_in,
                                                    float* __restrict__ y_out, int64_t rows, float dt, float sq, float sn,
-                                                   float cs, int step, NoiseArg na) {
+                                                   float cs, int step, NoiseArg na, int st_bf16) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using DL = typename std::conditional<X6, DecSdeL6, DecSdeL>::type;
   stage_blob(lds, blob, DL::LOC);   // F and G images only
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blo
     keep_lds_reads_here();
     const int64_t r = row < rows ? row : rows - 1;
     f4 y[4], f[4], z[4];
-    load_row(y, y_in, r, L.g);
+    load_row_st(y, y_in, r, L.g, st_bf16 != 0);
     range_note(absmax<4>(y), RS_DEC_STATE);
     float gs;
     if constexpr (X6) {
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blo
     }
     noise_row(z, na, STREAM_DECODER, step, r, rows, L.g);
     em_update(y, f, gs, z, dt, sq);
-    if (row < rows) store_row(y, y_out, row, L.g);
+    if (row < rows) store_row_st(y, y_out, row, L.g, st_bf16 != 0);
   }
 }
 
@@ -209,14 +209,14 @@ int trajsde_decoder_forward(int32_t N, int num_modes, int future_steps, const fl
   float* y0 = cv.take<float>(rows * 64);
   const int64_t ntiles = (rows + 15) / 16;
   TS_LAUNCH(k_dec_init, pick_grid(ntiles, 8), 512, DecInitL::SIZE * 4, stream, blob + DecBlob::INIT, local_embed, global_embed, N,
-            num_modes, y0, pi);
+            num_modes, y0, pi, state_bf16() ? 1 : 0);
   // 768 threads = 12 waves = 3 per SIMD (168 VGPRs each); 256 CUs x 12 waves = 3072 path tiles in flight
   static const int dthreads = []() { const char* v = getenv("TRAJSDE_THREADS_DECODE"); const int t = v ? atoi(v) : 768; return (t >= 64 && t <= 768 && t % 64 == 0) ? t : 768; }();
   static const bool x6 = []() { const char* e = getenv("TRAJSDE_DECODE_FP32"); return !(e && atoi(e) != 0); }();
   // <=512 threads: the 256-VGPR build (no spills, 2 waves/SIMD); above: the 168-VGPR build (3 waves/SIMD)
 #define TS_DECODE(X6, MAXT, IMG, OFF)                                                                                          \
   TS_LAUNCH((k_sde_decode<X6, MAXT>), pick_grid(ntiles, dthreads / 64), dthreads, IMG::SIZE * 4, stream, blob + OFF, y0, rows, \
-            future_steps, n_euler, step_table, out_table, min_scale, to_arg(noise), loc)
+            future_steps, n_euler, step_table, out_table, min_scale, to_arg(noise), loc, state_bf16() ? 1 : 0)
   if (x6 && dthreads <= 512) TS_DECODE(true, 512, DecSdeL6, DecBlob::SDE6);
   else if (x6) TS_DECODE(true, 768, DecSdeL6, DecBlob::SDE6);
   else if (dthreads <= 512) TS_DECODE(false, 512, DecSdeL, DecBlob::SDE);
@@ -233,10 +233,10 @@ int trajsde_sde_step(int32_t rows, const float* blob, const float* y_in, float* 
   static const bool x6 = []() { const char* v = getenv("TRAJSDE_DECODE_FP32"); return !(v && atoi(v) != 0); }();
   if (x6)
     TS_LAUNCH(k_sde_step<true>, pick_grid(ntiles, 16), 1024, DecSdeL6::LOC * 4, stream, blob + DecBlob::SDE6, y_in, y_out, int64_t(rows), e[1],
-              e[2], e[3], e[4], step, to_arg(noise));
+              e[2], e[3], e[4], step, to_arg(noise), state_bf16() ? 1 : 0);
   else
     TS_LAUNCH(k_sde_step<false>, pick_grid(ntiles, 16), 1024, DecSdeL::LOC * 4, stream, blob + DecBlob::SDE, y_in, y_out, int64_t(rows), e[1],
-              e[2], e[3], e[4], step, to_arg(noise));
+              e[2], e[3], e[4], step, to_arg(noise), state_bf16() ? 1 : 0);
   return TRAJSDE_OK;
 }
 

@@ -792,6 +792,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   TS_REQUIRE(b && g && rot && blob_fwd && blob_bwd && step_tab && step_tab_dev && d_local && ws && diff_loss && grads,
              "encoder_backward: null pointer");
   TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "encoder_backward: dropout p must be in [0, 1)");
+  TS_REQUIRE(!state_bf16(), "encoder_backward: the backward pass keeps its tape in fp32; switch trajsde_state_storage(0) for training");
   const DropArg drop_aa = dropout ? make_drop(dropout->p, dropout->seed, 0) : no_drop();     // block ids of dropout.hpp
   const DropArg drop_al = dropout ? make_drop(dropout->p, dropout->seed, 1) : no_drop();
   TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_backward: graph not compacted (call trajsde_graph_compact)");
@@ -1004,7 +1005,7 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
     else TS_LAUNCH(k_tr_attention<8>, cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, N, tp[l].o);
     TS_LAUNCH(k_tr_outproj, tile_grid(rtiles, 512, TrOutL::SIZE * 4), 512, TrOutL::SIZE * 4, st, lb + TrLayerL::OUT, tp[l].o, x, RT, tp[l].x1,
               tp[l].xn2);
-    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, tp[l].x1, tp[l].xn2, RT, tp[l].out, no_drop());
+    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, tp[l].x1, tp[l].xn2, RT, tp[l].out, no_drop(), 0);
     x = tp[l].out;
   }
   TS_LAUNCH(k_tr_final, tile_grid((int64_t(N) + 15) / 16, 256, 0), 256, 0, st, blob_fwd + EncGridBlob::norm(nl), x, N, tout);

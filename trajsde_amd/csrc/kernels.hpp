@@ -37,18 +37,18 @@ __global__ void k_edge_attn2(const float* img, const float* geom, const int32_t*
                              const int32_t* segptr, DropArg drop);
 __global__ void k_seg_merge(const int32_t* segptr, const float* rec, int C, int64_t R, float* agg);
 template <bool X6>
-__global__ void k_edge_embed(const float* img, const float* geom, int64_t E, float* emb_out);
+__global__ void k_edge_embed(const float* img, const float* geom, int64_t E, float* emb_out, int st_bf16);
 template <bool X6>
 __global__ void k_global_edge(const float* img, const float* rel, const int32_t* src, const int32_t* dst, const float* q,
                               const float* kn, const float* vn, int64_t E, float* logits, float* v);
 template <int HEADS>
 __global__ void k_global_attn(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
-                              const float* vn, int64_t N, float* agg, DropArg drop);
+                              const float* vn, int64_t N, float* agg, DropArg drop, int st_bf16);
 __global__ void k_seg_softmax_agg(const int32_t* segptr, const float* logits, const float* v, int64_t R, float* agg, int heads, DropArg drop);
 template <bool X6>
 __global__ void k_node_update(const float* img, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2, DropArg drop);
 __global__ void k_ffn6(const float* img, const float* x1, const float* xn2, int64_t R, float* out, DropArg drop);
-__global__ void k_ffn(const float* img, const float* x1, const float* xn2, int64_t R, float* out, DropArg drop);
+__global__ void k_ffn(const float* img, const float* x1, const float* xn2, int64_t R, float* out, DropArg drop, int out_bf16);
 template <int NQ>
 __global__ void k_node_proj(const float* img, const float* x, int64_t R, float* xn_out, float* p0, float* p1, float* p2);
 __global__ void k_mode_proj(const float* norm_g, const float* proj_g, const float* x, int64_t N, float* out);
@@ -69,7 +69,7 @@ struct StepTab {                                              // per-iteration (
 __global__ void k_enc_recur_coop(const float* sde_img, const float* gru_img, const float* coop6, const float* h0, const float* aa_out, int Nt, int N, int H,
                                  int TT, int tiles_per_wg, StepTab tab, int noise_step0, NoiseArg na, const uint8_t* nus, const uint8_t* pad,
                                  const int32_t* orig, const int32_t* eos, const int32_t* pick_slot, float* kept, float* diff_pick,
-                                 float* latent_ys);
+                                 float* latent_ys, int aa_bf16);
 // vanilla HiVT variant (grid.hip)
 __global__ void k_tr_prep(const float* aa_out, const uint8_t* pad, const float* tok, int N, int TT, float* X);
 template <int HEADS>

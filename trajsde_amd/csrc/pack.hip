@@ -1,6 +1,7 @@
 // pack.hip -- weight packing: state_dict tensors -> the kernels' LDS images (layouts.hpp), plus the
 // parameter-name tables of the C-ABI.  One recipe per stage is the single source of truth: run "dry" it
 // yields the ordered parameter names (trajsde_param_name), run "wet" it launches the pack kernels.
+#include <atomic>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,6 +21,9 @@ int fail(int code, const std::string& msg) {
   last_error_ref() = msg;
   return code;
 }
+
+std::atomic<int> g_state_bf16{0};
+bool state_bf16() { return g_state_bf16.load(std::memory_order_relaxed) != 0; }
 
 // registry of the per-translation-unit range flag words (range.hpp); function-local static: safe during static initialisation
 std::vector<RangeReader>& range_readers() {
@@ -899,6 +903,11 @@ int64_t trajsde_profile_report(char* buf, int64_t cap) {
 
 const char* trajsde_last_error(void) { return last_error_ref().c_str(); }
 int trajsde_split_products(void) { return TSDE_SPLIT_H3 ? 3 : 6; }
+
+int trajsde_state_storage(int mode) {
+  const int prev = tsde::g_state_bf16.exchange(mode == 1 ? 1 : 0);
+  return prev;
+}
 
 int trajsde_range_status(int reset, uint32_t* sites_out, void* stream) {
   static const char* const names[tsde::RS_SITES] = {"decoder SDE state", "decoder embedding inputs", "encoder latent state",

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
                                                         const uint8_t* __restrict__ pad, const int32_t* __restrict__ orig,
                                                         const int32_t* __restrict__ eos, const int32_t* __restrict__ pick_slot,
                                                         float* __restrict__ kept, float* __restrict__ diff_pick,
-                                                        float* __restrict__ latent_ys) {
+                                                        float* __restrict__ latent_ys, int aa_bf16) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const Lane L;
   const int w = threadIdx.x >> 6;
@@ -273,7 +273,11 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
       if (k < T) {
         f4 yf[4];
         lds_read_tile(yf, Yb(k), L);
-        xq[k] = *reinterpret_cast<const f4*>(aa_out + (int64_t(t) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g);   // in flight early
+        {                                                      // in flight early; fp32 or bf16 storage (tile.hpp)
+          const int64_t at = (int64_t(t) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g;
+          xq[k] = aa_bf16 ? widen4(*reinterpret_cast<const bf4*>(reinterpret_cast<const __bf16*>(aa_out) + at))
+                          : *reinterpret_cast<const f4*>(aa_out + at);
+        }
         const Opnd y = make_opnd(yf);
         f4 a = bf0;
         slice_mma(a, wf0, y);

@@ -84,8 +84,9 @@ struct NodeImgs {
   const float *upd, *ffn, *upd6, *ffn6;
 };
 static int update_ffn(const NodeImgs& im, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2, float* out,
-                      hipStream_t st, const DropArg& drop = no_drop()) {
+                      hipStream_t st, const DropArg& drop = no_drop(), bool out_bf16 = false) {
   const int64_t ntiles = (R + 15) / 16;
+  TS_REQUIRE(!(out_bf16 && node_x6()), "bf16 state storage needs the one-pass FFN kernel (default fp16x3 build, TRAJSDE_NODE_FP32 unset)");
   if (node_x6()) {
     TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, threads_node(), UpdL6::SIZE * 4), threads_node(), UpdL6::SIZE * 4, st, im.upd6, agg, xn, x,
               R, x1, xn2, drop);
@@ -93,7 +94,7 @@ static int update_ffn(const NodeImgs& im, const float* agg, const float* xn, con
   } else {
     TS_LAUNCH(k_node_update<false>, tile_grid(ntiles, threads_node(), UpdL::SIZE * 4), threads_node(), UpdL::SIZE * 4, st, im.upd, agg, xn, x, R,
               x1, xn2, drop);
-    TS_LAUNCH(k_ffn, tile_grid(ntiles, threads_node(), FfnL::SIZE * 4), threads_node(), FfnL::SIZE * 4, st, im.ffn, x1, xn2, R, out, drop);
+    TS_LAUNCH(k_ffn, tile_grid(ntiles, threads_node(), FfnL::SIZE * 4), threads_node(), FfnL::SIZE * 4, st, im.ffn, x1, xn2, R, out, drop, out_bf16 ? 1 : 0);
   }
   return TRAJSDE_OK;
 }
@@ -148,7 +149,7 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
     if (int rc = fused_edge_attention("k_edge_kv[aa]", true, blob + EncBlob::AA_EDGE6, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), g->aa_segptr, R,
                                       w.rec, w.agg, heads, st, drop))
       return rc;
-    return update_ffn(im, w.agg, w.cn, w.center, R, w.x1, w.xn2, aa_out, st, drop);
+    return update_ffn(im, w.agg, w.cn, w.center, R, w.x1, w.xn2, aa_out, st, drop, state_bf16());      // aa_out in the state storage type
   }
   if (g->E_aa > 0) {
     if (edge_x6() && edge_pair())
@@ -167,6 +168,7 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
       TS_LAUNCH_TAG("k_edge_kv[aa]", true, k_edge_kv<false>, tile_grid((int64_t(g->E_aa) + 15) / 16, threads_edge(), EdgeL::SIZE * 4), threads_edge(),
                     EdgeL::SIZE * 4, st, blob + EncBlob::AA_EDGE, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), w.logits, w.v, heads);
   }
+  TS_REQUIRE(!state_bf16(), "bf16 state storage needs the fused edge attention (default)");
   return attention_tail(im, g->aa_segptr, w.logits, w.v, w.cn, w.center, R, w.agg, w.x1, w.xn2, aa_out, st, heads, drop);
 }
 
@@ -179,6 +181,8 @@ static int run_recurrence(const trajsde_batch* b, const trajsde_graph* g, const 
   // cooperative persistent kernel: all H iterations in one launch, weights resident in the register file
   static const bool legacy = []() { const char* e = getenv("TRAJSDE_RECUR_LEGACY"); return e && atoi(e) != 0; }();
   const int tiles_per_wg = int((rtiles + 255) / 256);
+  TS_REQUIRE(!state_bf16() || (!legacy && tiles_per_wg <= COOP_TMAX && H <= 32),
+             "bf16 state storage needs the cooperative recurrence kernel (at most 16384 extended rows)");
   if (!legacy && tiles_per_wg <= COOP_TMAX && H <= 32) {
     StepTab tab;
     for (int i = 0; i < H; ++i) {
@@ -187,7 +191,7 @@ static int run_recurrence(const trajsde_batch* b, const trajsde_graph* g, const 
     const int grid = int((rtiles + tiles_per_wg - 1) / tiles_per_wg);
     const int lds = (5 * tiles_per_wg * COOP_TILE + tiles_per_wg * 64) * 4;
     TS_LAUNCH(k_enc_recur_coop, grid, 256, lds, st, blob + EncBlob::SDE, blob + EncBlob::GRU, blob + EncBlob::COOP6, h0, aa_out, Nt, N, H, b->TT, tiles_per_wg, tab,
-              noise_step0, na, g->nus_mask, b->padding_mask, g->orig, g->eos_idx, g->pick_slot, kept, diff_pick, latent_ys);
+              noise_step0, na, g->nus_mask, b->padding_mask, g->orig, g->eos_idx, g->pick_slot, kept, diff_pick, latent_ys, state_bf16() ? 1 : 0);
     return TRAJSDE_OK;
   }
   for (int idx = 0; idx < H; ++idx) {
@@ -322,7 +326,7 @@ int trajsde_encoder_grid_forward(const trajsde_batch* b, const trajsde_graph* g,
     if (num_heads == 4) TS_LAUNCH(k_tr_attention<4>, cdiv(N, 4), 256, 0, st, q, k, v, N, o);
     else TS_LAUNCH(k_tr_attention<8>, cdiv(N, 4), 256, 0, st, q, k, v, N, o);
     TS_LAUNCH(k_tr_outproj, tile_grid(rtiles, 512, TrOutL::SIZE * 4), 512, TrOutL::SIZE * 4, st, lb + TrLayerL::OUT, o, x, R, x1, xn2);
-    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, x1, xn2, R, nx, no_drop());
+    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, x1, xn2, R, nx, no_drop(), 0);
     float* t = x; x = nx; nx = t;
   }
   TS_LAUNCH(k_tr_final, tile_grid((int64_t(N) + 15) / 16, 256, 0), 256, 0, st, blob + EncGridBlob::norm(num_temporal_layers), x, N, tout);
@@ -356,10 +360,10 @@ int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph
   if (E > 0) {
     if (edge_x6())
       TS_LAUNCH(k_edge_embed<true>, tile_grid(etiles, threads_edge(), EdgeL6::EMB_SIZE * 4), threads_edge(), EdgeL6::EMB_SIZE * 4, st,
-                blob + AggBlob::REL6, g->g_geom, E, w.rel);
+                blob + AggBlob::REL6, g->g_geom, E, w.rel, state_bf16() ? 1 : 0);
     else
       TS_LAUNCH(k_edge_embed<false>, tile_grid(etiles, threads_edge(), EdgeL::EMB_SIZE * 4), threads_edge(), EdgeL::EMB_SIZE * 4, st,
-                blob + AggBlob::REL, g->g_geom, E, w.rel);
+                blob + AggBlob::REL, g->g_geom, E, w.rel, state_bf16() ? 1 : 0);
   }
   const float* x = local_embed;
   float* bufs[2] = {w.xa, w.xb};
@@ -373,12 +377,13 @@ int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph
     const bool fused = fused_env || num_heads != 8;           // the unfused edge kernel exists for 8 heads only
     const DropArg drop = dropout ? make_drop(dropout->p, dropout->seed, 2 + i) : no_drop();   // block ids of dropout.hpp
     TS_REQUIRE(fused || drop.p == 0.f, "aggregator_forward: dropout needs the fused global attention (unset TRAJSDE_GLOBAL_UNFUSED)");
+    TS_REQUIRE(fused || !state_bf16(), "aggregator_forward: bf16 state storage needs the fused global attention");
     if (fused) {
       // one wave per target: logits, softmax and aggregation in one pass over the rel rows (no per-edge GEMM)
       if (num_heads == 4)
-        TS_LAUNCH(k_global_attn<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, drop);
+        TS_LAUNCH(k_global_attn<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, drop, state_bf16() ? 1 : 0);
       else
-        TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, drop);
+        TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, drop, state_bf16() ? 1 : 0);
       if (int rc = update_ffn(im, w.agg, w.xn, x, N, w.x1, w.xn2, out, st, drop)) return rc;
       x = out;
       continue;

@@ -477,6 +477,35 @@ __device__ __forceinline__ void store_row(const f4 (&a)[4], float* base, int64_t
   for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(p + 16 * jt) = a[jt];
 }
 
+// ---- "hidden state stored bf16 between kernels" (BASELINE configs[4]): the same [rows][64] activations with 2-byte elements.
+// Arithmetic stays fp32 in registers; a row is rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32) when it is stored and
+// widened exactly when it is loaded.  `bf16` is uniform per launch (trajsde_state_storage), so the branch is a scalar one.
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 widen4(const bf4 v) { return f4{float(v[0]), float(v[1]), float(v[2]), float(v[3])}; }
+__device__ __forceinline__ bf4 narrow4(const f4 v) { return bf4{__bf16(v[0]), __bf16(v[1]), __bf16(v[2]), __bf16(v[3])}; }
+__device__ __forceinline__ void load_row_st(f4 (&a)[4], const void* base, int64_t row, int g, bool bf16) {
+  if (bf16) {
+    const __bf16* p = static_cast<const __bf16*>(base) + row * D + 4 * g;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) a[jt] = widen4(*reinterpret_cast<const bf4*>(p + 16 * jt));
+  } else {
+    load_row(a, static_cast<const float*>(base), row, g);
+  }
+}
+__device__ __forceinline__ void store_row_st(const f4 (&a)[4], void* base, int64_t row, int g, bool bf16) {
+  if (bf16) {
+    __bf16* p = static_cast<__bf16*>(base) + row * D + 4 * g;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<bf4*>(p + 16 * jt) = narrow4(a[jt]);
+  } else {
+    store_row(a, static_cast<float*>(base), row, g);
+  }
+}
+// one element of a row (kernels with lane = feature)
+__device__ __forceinline__ float load_elem_st(const void* base, int64_t idx, bool bf16) {
+  return bf16 ? float(static_cast<const __bf16*>(base)[idx]) : static_cast<const float*>(base)[idx];
+}
+
 // Weights in LDS are loop-invariant, so LICM would hoist every fragment read out of the tile / time loops
 // and spill hundreds of VGPRs; a compiler-only memory barrier at the top of each loop body keeps the
 // ds_reads next to their MFMAs (no instruction is emitted).

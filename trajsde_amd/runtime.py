@@ -66,6 +66,22 @@ class NoiseSpec:
         return _lib.Noise(C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF), _ptr(z), _ptr(row_ids))
 
 
+def set_state_storage(kind: str) -> str:
+    """"fp32" (default) or "bf16": how the [rows][64] activations that stay inside a stage are stored between its kernels
+    (include/trajsde_hip.h trajsde_state_storage; BASELINE configs[4] "bf16 hidden state").  Inference only.  Returns the
+    previous setting."""
+    if kind not in ("fp32", "bf16"):
+        raise ValueError("state storage is 'fp32' or 'bf16'")
+    return "bf16" if _lib.lib().trajsde_state_storage(1 if kind == "bf16" else 0) else "fp32"
+
+
+def state_storage() -> str:
+    L = _lib.lib()
+    prev = L.trajsde_state_storage(0)
+    L.trajsde_state_storage(prev)
+    return "bf16" if prev else "fp32"
+
+
 def rotate_inputs(data) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """MODEL:75-85 on the GPU: rotate_mat [N,2,2] and y @ rotate_mat."""
     ang = data["rotate_angles"]
@@ -307,6 +323,8 @@ class StageRuntime:
                                                  C.byref(dr) if dr is not None else None, _stream()),
                        "trajsde_encoder_forward")
         if cap:
+            if state_storage() == "bf16":                                  # aa_out was written with 2-byte elements
+                aa_out = aa_out.view(-1).view(torch.bfloat16)[:H * Nt * D].view(H, Nt, D).float()
             m.last_intermediates = {"aa_out": aa_out, "latent_ys": latent, "E_aa": gc.graph.E_aa, "E_g": gc.graph.E_g,
                                     "E_la": gc.graph.E_la, **gc.edge_lists()}
         if preserve_side_effects:
