@@ -367,12 +367,10 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     const float* lb = blob_fwd + AggBlob::layer(l);
     TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
               w.xn[l], w.q[l], w.kn[l], w.vn[l]);
-    if (num_heads == 4)
-      TS_LAUNCH(k_global_attn<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
-                w.agg[l], drop_of(l), 0);
-    else
-      TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N,
-                w.agg[l], drop_of(l), 0);
+    {
+      const DropArg dl = drop_of(l);
+      TS_GLOBAL_ATTN(num_heads, false, dl, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N, w.agg[l]);
+    }
     TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, lb + AggLayerL::UPD6, w.agg[l], w.xn[l], x,
               N, w.x1[l], w.xn2[l], drop_of(l));
     TS_LAUNCH(k_ffn6, tile_grid(ntiles, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, lb + AggLayerL::FFN6, w.x1[l], w.xn2[l], N, w.out[l],

@@ -232,6 +232,11 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
   SegState S0, S1;
   seg_reset(S0);
   seg_reset(S1);
+  // The query row of a tile row changes only when the row's target does (every ~deg iterations), but 2 x 16 registers to keep
+  // it do not fit beside the softmax state at two waves per SIMD, and re-gathering 256 B per row and iteration from L2 was
+  // 1.4 GB of fabric reads per launch (FETCH_SIZE).  So each lane parks ITS 16 query values in LDS -- a private slot,
+  // [tile][jt][lane][4], conflict-free b128 -- when its row's target changes, and reads them back every iteration.
+  float* qs = lds + EL::SIZE + wave * (2 * 4 * 64 * 4);
   int cur0 = -1, cur1 = -1;
   int base0 = 0, base1 = 0;                                // DROP: first edge of the rows' current targets (mask counter = rank)
   const f4 one4 = f4{1.f, 1.f, 1.f, 1.f};
@@ -249,12 +254,20 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
       seg_reset(S0);
       cur0 = d0;
       if (DROP) base0 = segptr[d0];
+      f4 qn[4];
+      load_row(qn, q, d0, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(qs + (jt * 64 + L.lane) * 4) = qn[jt];
     }
     if (ok1 && d1 != cur1) {
       if (cur1 >= 0) seg_flush(S1, rec, int64_t(cur1) + s1, L.g);
       seg_reset(S1);
       cur1 = d1;
       if (DROP) base1 = segptr[d1];
+      f4 qn[4];
+      load_row(qn, q, d1, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(qs + ((4 + jt) * 64 + L.lane) * 4) = qn[jt];
     }
     f4 emb0[4], emb1[4], kv0[8], kv1[8], qv[4];
     edge_embed2_x6(emb0, emb1, g0, g1, lds, L);
@@ -262,14 +275,16 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
     load_vec<8>(kv1, lds + EL::BKV, L.g);
     linear_acc_x6_2<8, 4>(kv0, kv1, emb0, emb1, lds + EL::WKV, L.lane);
     {
-      load_row(qv, q, d0, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) qv[jt] = *reinterpret_cast<const f4*>(qs + (jt * 64 + L.lane) * 4);
       const f4 k[4] = {kv0[0], kv0[1], kv0[2], kv0[3]};
       const f4 vv[4] = {kv0[4], kv0[5], kv0[6], kv0[7]};
       const f4 lg = head_logits(qv, k, heads);
       if (ok0) seg_update(S0, lg, vv, DROP ? drop_attn_row(drop, uint32_t(d0), uint32_t(int(e0) - base0), L.g, heads) : one4);
     }
     {
-      load_row(qv, q, d1, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) qv[jt] = *reinterpret_cast<const f4*>(qs + ((4 + jt) * 64 + L.lane) * 4);
       const f4 k[4] = {kv1[0], kv1[1], kv1[2], kv1[3]};
       const f4 vv[4] = {kv1[4], kv1[5], kv1[6], kv1[7]};
       const f4 lg = head_logits(qv, k, heads);
@@ -280,7 +295,6 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
   if (cur1 >= 0) seg_flush(S1, rec, int64_t(cur1) + s1, L.g);
 }
 template __global__ void k_edge_attn2<512, false>(const float*, const float*, const int32_t*, const float*, int64_t, int, float*, int, const int32_t*, DropArg);
-template __global__ void k_edge_attn2<768, false>(const float*, const float*, const int32_t*, const float*, int64_t, int, float*, int, const int32_t*, DropArg);
 template __global__ void k_edge_attn2<512, true>(const float*, const float*, const int32_t*, const float*, int64_t, int, float*, int, const int32_t*, DropArg);
 
 // records of one target -> agg row.  One wave per target, lane = feature f (jt = f>>4, g = (f>>2)&3); a target's records sit
@@ -469,12 +483,11 @@ __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restri
 // i.e. lin_k_edge is folded into the query once per target (U_h = Wke_h^T q_h, 8 x 64) and lin_v_edge is applied
 // once per target after the aggregation.  Per edge the wave streams one rel row (256 B) and gathers two node rows.
 // Lane l is feature l of the node rows (head l>>3) and holds slice 8*(l&7).. of the rel row / of U for head l>>3.
-template <int HEADS>
+template <int HEADS, bool ST_BF16, bool DROP>
 __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                      const int32_t* __restrict__ src, const float* __restrict__ rel,
                                                      const float* __restrict__ q, const float* __restrict__ kn,
-                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ agg, DropArg drop,
-                                                     int st_bf16) {
+                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ agg, DropArg drop) {
   constexpr int LPH = 64 / HEADS;          // lanes (= head dims) per head: 8, or 16 with 4 heads
   constexpr int SL = 64 / LPH;             // rel-row columns per lane: a head's 64-wide row is spread over its LPH lanes
   constexpr int NV = SL / 4;               // ... as float4s
@@ -506,7 +519,7 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
   float m = -INFINITY, s = 0.f, sk = 0.f, accv = 0.f, accr[SL];      // sk: sum of the KEPT, scaled weights (= s without dropout)
 #pragma unroll
   for (int e = 0; e < SL; ++e) accr[e] = 0.f;
-  const bool dropping = drop.p > 0.f;
+  constexpr bool dropping = DROP;                             // train-mode instantiation (attention dropout, AGG:116)
   for (int e0 = beg; e0 < end; e0 += 8) {
     f4 r[8][NV];
     float knv[8], vnv[8], lg[8], kp[8];
@@ -517,27 +530,30 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
     // every head needs the whole 64-wide rel row, so a per-lane 32-B slice load would fetch each row HEADS times through the
     // texture-address unit: the wave loads the chunk's 8 rows ONCE, parks them in wave-private LDS and the lanes pick their
     // slices out of LDS (same-address reads across the heads broadcast)
+    float rl[8];
+    f4 ra, rb;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u < end ? e0 + u : end - 1;
       const int sidx = __builtin_amdgcn_readlane(sv, u);
+      const float* rrow = rel + int64_t(e) * 64;
       const float* krow = kn + int64_t(sidx) * 64;
       const float* vrow = vn + int64_t(sidx) * 64;
+      if (!ST_BF16) rl[u] = rrow[lane];                       // fp32 rows: one dword per lane
       knv[u] = krow[lane];
       vnv[u] = vrow[lane];
     }
-    if (st_bf16) {                                            // bf16 storage: 8 lanes per row, 16 B (8 elements) per lane, widened here
-      const int ur = lane >> 3, uc = lane & 7;
-      const int64_t er = e0 + ur < end ? e0 + ur : end - 1;
-      const bf4* p = reinterpret_cast<const bf4*>(reinterpret_cast<const __bf16*>(rel) + er * 64 + 8 * uc);
-      const f4 ra = widen4(p[0]), rb = widen4(p[1]);
-      __builtin_amdgcn_wave_barrier();                        // the previous chunk's slice reads are done (same wave, in order)
-      *reinterpret_cast<f4*>(&srel[wv][ur][8 * uc]) = ra;
-      *reinterpret_cast<f4*>(&srel[wv][ur][8 * uc + 4]) = rb;
-    } else {                                                  // fp32: one dword per lane and row (measured faster than 2 x 16 B per lane)
-      float rl[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) rl[u] = (rel + int64_t(e0 + u < end ? e0 + u : end - 1) * 64)[lane];
-      __builtin_amdgcn_wave_barrier();
+    if (ST_BF16) {                                            // bf16 storage: 8 lanes per row, 16 B (8 elements) per lane, widened here
+      const int64_t er = e0 + (lane >> 3) < end ? e0 + (lane >> 3) : end - 1;
+      const bf4* p = reinterpret_cast<const bf4*>(reinterpret_cast<const __bf16*>(rel) + er * 64 + 8 * (lane & 7));
+      ra = widen4(p[0]);
+      rb = widen4(p[1]);
+    }
+    __builtin_amdgcn_wave_barrier();                          // the previous chunk's slice reads are done (same wave, in order)
+    if (ST_BF16) {
+      *reinterpret_cast<f4*>(&srel[wv][lane >> 3][8 * (lane & 7)]) = ra;
+      *reinterpret_cast<f4*>(&srel[wv][lane >> 3][8 * (lane & 7) + 4]) = rb;
+    } else {
 #pragma unroll
       for (int u = 0; u < 8; ++u) srel[wv][u][lane] = rl[u];
     }
@@ -596,10 +612,22 @@ __global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ i
   }
   if (node < N) agg[node * 64 + lane] = out;
 }
-template __global__ void k_global_attn<8>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                          const float*, int64_t, float*, DropArg, int);
-template __global__ void k_global_attn<4>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                          const float*, int64_t, float*, DropArg, int);
+template __global__ void k_global_attn<8, false, false>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, DropArg);
+template __global__ void k_global_attn<8, false, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, DropArg);
+template __global__ void k_global_attn<8, true, false>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, DropArg);
+template __global__ void k_global_attn<8, true, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, DropArg);
+template __global__ void k_global_attn<4, false, false>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, DropArg);
+template __global__ void k_global_attn<4, false, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, DropArg);
+template __global__ void k_global_attn<4, true, false>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, DropArg);
+template __global__ void k_global_attn<4, true, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, DropArg);
 
 // ------------------------------------------------------------------------------------------------ update + FFN
 // gate = sigmoid(lin_ih(agg) + lin_hh(xn)); upd = agg + gate*(lin_self(xn) - agg); x1 = x + out_proj(upd); xn2 = norm2(x1)

@@ -35,15 +35,27 @@ inline AttnPlan attn_plan(int64_t E, int streams_target = SEG_STREAMS_512) {
 template <int THREADS, bool DROP>
 __global__ void k_edge_attn2(const float* img, const float* geom, const int32_t* dst, const float* q, int64_t E, int C, float* rec, int heads,
                              const int32_t* segptr, DropArg drop);
+// launch the instantiation selected by (heads, bf16 state storage, dropout)
+#define TS_GLOBAL_ATTN(heads, bf16, drop, ...)                                                                       \
+  do {                                                                                                              \
+    const bool _d = (drop).p > 0.f;                                                                                 \
+    if ((heads) == 4) {                                                                                             \
+      if (bf16) { if (_d) TS_LAUNCH_TAG("k_global_attn<4>", false, (k_global_attn<4, true, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<4>", false, (k_global_attn<4, true, false>), __VA_ARGS__, drop); } \
+      else { if (_d) TS_LAUNCH_TAG("k_global_attn<4>", false, (k_global_attn<4, false, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<4>", false, (k_global_attn<4, false, false>), __VA_ARGS__, drop); } \
+    } else {                                                                                                        \
+      if (bf16) { if (_d) TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, true, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, true, false>), __VA_ARGS__, drop); } \
+      else { if (_d) TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, false, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, false, false>), __VA_ARGS__, drop); } \
+    }                                                                                                               \
+  } while (0)
 __global__ void k_seg_merge(const int32_t* segptr, const float* rec, int C, int64_t R, float* agg);
 template <bool X6>
 __global__ void k_edge_embed(const float* img, const float* geom, int64_t E, float* emb_out, int st_bf16);
 template <bool X6>
 __global__ void k_global_edge(const float* img, const float* rel, const int32_t* src, const int32_t* dst, const float* q,
                               const float* kn, const float* vn, int64_t E, float* logits, float* v);
-template <int HEADS>
+template <int HEADS, bool ST_BF16, bool DROP>
 __global__ void k_global_attn(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
-                              const float* vn, int64_t N, float* agg, DropArg drop, int st_bf16);
+                              const float* vn, int64_t N, float* agg, DropArg drop);
 __global__ void k_seg_softmax_agg(const int32_t* segptr, const float* logits, const float* v, int64_t R, float* agg, int heads, DropArg drop);
 template <bool X6>
 __global__ void k_node_update(const float* img, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2, DropArg drop);

@@ -22,7 +22,7 @@ static int pair_threads() { static int t = []() { const char* e = getenv("TRAJSD
 // fused edge attention (k_edge_attn2 + k_seg_merge: no per-edge v / logits in HBM): default; TRAJSDE_ATTN_FUSED=0 runs the
 // two-kernel form (k_edge_kv2 -> HBM -> k_seg_softmax_agg) that the backward's recomputation still uses
 static bool attn_fused() { static bool v = []() { const char* e = getenv("TRAJSDE_ATTN_FUSED"); return !(e && atoi(e) == 0); }(); return v && edge_x6() && edge_pair(); }
-static int fused_threads() { static int t = []() { const char* e = getenv("TRAJSDE_FUSED_THREADS"); const int v = e ? atoi(e) : 512; return v == 768 ? 768 : 512; }(); return t; }
+static int fused_threads() { return 512; }   // 2 waves per SIMD: 196 VGPRs, weight image + 8 x 8 KB of parked query rows = 147 KB of LDS
 static AttnPlan fused_plan(int64_t E) { return attn_plan(E, 256 * 32 * (fused_threads() / 64)); }
 static int threads_edge() { static int t = env_threads("TRAJSDE_THREADS_EDGE", 1024); return t; }
 static int threads_node() { static int t = env_threads("TRAJSDE_THREADS_NODE", 512); return t; }
@@ -114,12 +114,11 @@ static int fused_edge_attention(const char* tag, bool dominant, const float* img
     const int threads = drop.p > 0.f ? 512 : fused_threads();             // the dropout form is built for 512 threads
     const int64_t waves = (pl.nstreams + 31) / 32;
     const int grid = int((waves + threads / 64 - 1) / (threads / 64));
+    const int lds = (EdgeL6::SIZE + (threads / 64) * 2048) * 4;              // weight image + every wave's parked query rows (8 KB)
     if (drop.p > 0.f)
-      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, true>), grid, 512, EdgeL6::SIZE * 4, st, img, geom, dst, q, E, pl.C, rec, heads, segptr, drop);
-    else if (threads == 768)
-      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<768, false>), grid, 768, EdgeL6::SIZE * 4, st, img, geom, dst, q, E, pl.C, rec, heads, segptr, drop);
+      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, true>), grid, 512, lds, st, img, geom, dst, q, E, pl.C, rec, heads, segptr, drop);
     else
-      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, false>), grid, 512, EdgeL6::SIZE * 4, st, img, geom, dst, q, E, pl.C, rec, heads, segptr, drop);
+      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, false>), grid, 512, lds, st, img, geom, dst, q, E, pl.C, rec, heads, segptr, drop);
   }
   TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, pl.C, R, agg);
   return TRAJSDE_OK;
@@ -380,10 +379,7 @@ int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph
     TS_REQUIRE(fused || !state_bf16(), "aggregator_forward: bf16 state storage needs the fused global attention");
     if (fused) {
       // one wave per target: logits, softmax and aggregation in one pass over the rel rows (no per-edge GEMM)
-      if (num_heads == 4)
-        TS_LAUNCH(k_global_attn<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, drop, state_bf16() ? 1 : 0);
-      else
-        TS_LAUNCH(k_global_attn<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, drop, state_bf16() ? 1 : 0);
+      TS_GLOBAL_ATTN(num_heads, state_bf16(), drop, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg);
       if (int rc = update_ffn(im, w.agg, w.xn, x, N, w.x1, w.xn2, out, st, drop)) return rc;
       x = out;
       continue;
