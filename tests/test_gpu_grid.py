@@ -79,14 +79,48 @@ def test_vanilla_forward_matches_oracle_on_synthetic(S, n, K, T, heads, layers, 
 def test_vanilla_variant_refuses_what_it_does_not_build(dev):
     from trajsde_amd.models.model_base_mix import PredictionModel
     from trajsde_amd.synth import synth
-    cfg = _cfg(3, 12, 4, 2)
-    cfg["model_specific"]["kwargs"]["ts_drop"] = 0.1
-    model = PredictionModel(**cfg, init_seed=1).to(dev)
-    batch = synth(S=1, n=5, L=3, F=12, box=50.0, seed=1).to(dev)
-    with pytest.raises(NotImplementedError):
-        model.training_step(batch, 0)                               # ts_drop augmentation
     with pytest.raises(NotImplementedError):
         PredictionModel(**_cfg(3, 80, 4, 2), init_seed=1)          # 2T > 128 outputs per head
+    cfg = _cfg(3, 12, 4, 2)
+    cfg["encoder"]["kwargs"]["dropout"] = 0.1                      # the TemporalEncoder's dropout sites have no training kernels
+    model = PredictionModel(**cfg, init_seed=1).to(dev).train()
+    batch = synth(S=1, n=5, L=3, F=12, box=50.0, seed=1).to(dev)
+    with pytest.raises(NotImplementedError, match="dropout"):
+        model.training_step(batch, 0)
+
+
+def test_ts_drop_augmentation_masks_history_steps_like_the_reference(dev):
+    """models/model_base_mix.py:96-100: a dropped step loses its input and becomes padding; bos steps and the current step
+    are never dropped.  ts_drop = 1 drops every droppable step, which makes the augmented batch predictable: the training
+    step on it equals the training step of a model without ts_drop on the hand-masked batch."""
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    from trajsde_amd.synth import synth
+    cfg = _cfg(3, 12, 4, 2)
+    batch = synth(S=2, n=7, L=4, F=12, box=60.0, seed=4, history_dropout=0.3)
+    plain = PredictionModel(**cfg, init_seed=3).to(dev).train()
+    cfg_ts = _cfg(3, 12, 4, 2)
+    cfg_ts["model_specific"]["kwargs"]["ts_drop"] = 1.0
+    aug = PredictionModel(**cfg_ts, init_seed=3).to(dev).train()
+    a = batch.to(dev)
+    loss_aug = aug.training_step(a, 0)
+    mask = torch.ones(batch["x"].shape[0], 21, dtype=torch.bool)
+    mask[batch["bos_mask"]] = False
+    mask[:, -1] = False
+    assert torch.equal(a["padding_mask"][:, :21].cpu(), batch["padding_mask"][:, :21] | mask)      # in place, like the reference
+    assert float(a["x"].cpu()[mask].abs().max()) == 0.0
+    b = H.clone_batch(batch)
+    b["x"][mask] = 0
+    b["padding_mask"][:, :21] |= mask
+    loss_plain = plain.training_step(b.to(dev), 0)
+    assert torch.equal(loss_aug.detach(), loss_plain.detach())
+    # a fractional rate drops about that fraction of the droppable steps
+    cfg_ts["model_specific"]["kwargs"]["ts_drop"] = 0.3
+    frac = PredictionModel(**cfg_ts, init_seed=3).to(dev).train()
+    big = synth(S=4, n=60, L=4, F=12, box=90.0, seed=5).to(dev)
+    before = big["padding_mask"][:, :21].clone()
+    frac.apply_ts_drop(big, generator=torch.Generator(device=dev).manual_seed(1))
+    dropped = (big["padding_mask"][:, :21] & ~before).float().mean().item() * 21 / 19          # 19 of 21 steps are droppable here
+    assert 0.25 < dropped < 0.35
 
 
 def _l2(y, loc, reg_mask):

@@ -3,8 +3,9 @@ same YAML registry, `forward(data) -> dict`, the same in-place side effects on `
 same validation / test step bookkeeping as the SDE model; the stages are the HIP-backed LocalEncoder,
 GlobalInteractor and MLPDecoder.  Deterministic (no SDE noise).  `training_step` differentiates the shipped loss of
 this configuration (L2, configs/nusargo/hivt_nuSArgo_trmenc_mlpdec.yml:62-66) through the HIP backward entry points
-(trajsde_mlp_decoder_l2_backward -> trajsde_aggregator_backward_heads -> trajsde_encoder_grid_backward); `ts_drop`
-augmentation (models/model_base_mix.py:95-100) is not built and is refused.
+(trajsde_mlp_decoder_l2_backward -> trajsde_aggregator_backward_heads -> trajsde_encoder_grid_backward); the `ts_drop`
+augmentation (models/model_base_mix.py:95-100) masks history steps of the batch before the forward, as there.  The YAML's
+`nodecay` flag is stored and, as in the reference (no code reads it), has no effect: AdamW runs over all parameters.
 """
 from copy import deepcopy
 from typing import Optional
@@ -104,10 +105,22 @@ class PredictionModel(nn.Module):
             reached |= {f"{stage}.{n}" for n in getattr(self, stage)._rt.param_names(sid)}
         return [p for n, p in self.named_parameters() if n in reached]
 
+    def apply_ts_drop(self, data, generator: Optional[torch.Generator] = None) -> None:
+        """models/model_base_mix.py:96-100: drop history steps at random (probability `ts_drop`), never a step that begins a
+        track (bos) nor the current one: the inputs of a dropped step are zeroed and the step is marked as padding -- in place,
+        on the batch, like the reference does.  Index plumbing on the inputs; the kernels see an ordinary batch."""
+        h = int(self.historical_steps)
+        x = data.x
+        mask = torch.rand(x.size(0), h, device=x.device, generator=generator) > (1 - float(self.ts_drop))
+        mask[data.bos_mask] = False
+        mask[:, -1] = False
+        x[mask] = 0
+        data.padding_mask[:, :h] = data.padding_mask[:, :h] | mask
+
     def training_step(self, data, batch_idx, noise=None):
         """models/model_base_mix.py:94-114 for the shipped loss (L2)"""
         if getattr(self, "ts_drop", False):
-            raise NotImplementedError("ts_drop augmentation is not built")
+            self.apply_ts_drop(data)
         if self.loss_names != ["L2"]:
             raise NotImplementedError(f"training_step differentiates L2 through the HIP kernels; configured: {self.loss_names}")
         if data.y is None:
