@@ -291,12 +291,29 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
                              const float* enc_step_table_dev /*device [H,8]*/, const trajsde_noise* noise,
                              const float* d_local /*[N,64]*/, float diff_weight, void* ws, int64_t ws_bytes,
                              float* diff_loss /*[1] device*/, float* const* grads, int n_grads, float* d_latent, float* d_aa_out,
-                             const trajsde_dropout* dropout /* the forward's, or null */, void* stream);
+                             const trajsde_dropout* dropout /* the forward's, or null */,
+                             int tape_valid /* 1: `ws` still holds the tape trajsde_encoder_forward_train left in it */, void* stream);
+
+/* Training forward of the encoder stage: the same function as trajsde_encoder_forward (same weights, noise, dropout), run
+ * through the kernels that KEEP every activation the backward needs, in `ws` (sized by trajsde_encoder_backward_ws_bytes).
+ * Hand the SAME `ws` to trajsde_encoder_backward with tape_valid = 1 and the backward skips its own recomputation of the
+ * forward (one forward per training step instead of two).  Outputs as trajsde_encoder_forward. */
+int trajsde_encoder_forward_train(const trajsde_batch* b, const trajsde_graph* g, const float* rotate_mat, const float* blob_fwd,
+                                  const float* enc_step_table /*HOST [H,8]*/, const trajsde_noise* noise, void* ws,
+                                  int64_t ws_bytes, float* local_embed /*[N,64]*/, float* diff_pick /*[2A,64]*/,
+                                  const trajsde_dropout* dropout, void* stream);
 
 int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, const float* blob_bwd,
                                       int num_layers, int num_modes, int num_heads, const float* local_embed,
                                       const float* d_global, void* ws, int64_t ws_bytes, float* const* grads, int n_grads,
-                                      float* d_local, const trajsde_dropout* dropout /* the forward's, or null */, void* stream);
+                                      float* d_local, const trajsde_dropout* dropout /* the forward's, or null */,
+                                      int tape_valid /* 1: `ws` holds the tape of trajsde_aggregator_forward_train */, void* stream);
+
+/* Training forward of the aggregator stage (see trajsde_encoder_forward_train): keeps its per-layer activations in `ws`
+ * (trajsde_aggregator_backward_ws_bytes) for trajsde_aggregator_backward_heads(..., tape_valid = 1). */
+int trajsde_aggregator_forward_train(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, int num_layers,
+                                     int num_modes, int num_heads, const float* local_embed, void* ws, int64_t ws_bytes,
+                                     float* global_embed /*[K,N,64]*/, const trajsde_dropout* dropout, void* stream);
 
 /* ---- step-granular decoder SDE step (state round-trips HBM every step): the 512 B/path-step variant
  *      of SURVEY.md 8(d), kept for the HBM-roofline measurement the north star asks for. */

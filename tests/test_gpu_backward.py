@@ -491,3 +491,40 @@ def test_training_step_matches_the_reference_training_step(name, dev):
     got = {n: p.grad for n, p in model.named_parameters()}
     bad = H.check_grads_against_train_fixture(got, grads, digests, rel=REL if grads else 2e-3)
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+def test_training_forward_keeps_a_tape_the_backward_walks(train_mode, dev):
+    """one forward per training step: *_forward_train compute the stage outputs with the tape-keeping kernels (same function as
+    the inference forward, to rounding), and the backward entry points given that tape return bit for bit what they return
+    when they recompute the forward themselves"""
+    from trajsde_amd import runtime
+    from trajsde_amd.synth import synth
+    K, T = 3, 5
+    batch = synth(S=3, n=13, L=6, F=T, box=70.0, seed=61, mixed_source=True, history_dropout=0.3)
+    model, cfg = H.build_model(K, T, 0.5, init_seed=23)
+    model = model.to(dev)
+    model.train() if train_mode else model.eval()
+    data = batch.to(dev)
+    noise = runtime.NoiseSpec(seed=41)
+    rot, y_rot = runtime.rotate_inputs(data)
+    data.y, data["rotate_mat"] = y_rot, rot
+    local, di, do, _, _ = model.encoder(data=data, noise=noise)
+    glob = model.aggregator(data=data, local_embed=local, noise=noise)
+    (local_t, di_t, do_t, _, _), enc_tape = model.encoder._rt.encoder_forward_train(data, noise)
+    glob_t, agg_tape = model.aggregator._rt.aggregator_forward_train(data, local, noise)
+    assert H.maxdiff(local_t, local) <= 2e-5 and H.maxdiff(di_t, di) <= 2e-6 and H.maxdiff(do_t, do) <= 2e-6
+    assert H.maxdiff(glob_t, glob) <= 2e-5
+    g = torch.Generator().manual_seed(3)
+    d_local = torch.randn(local.shape, generator=g).to(dev)
+    d_glob = torch.randn(glob.shape, generator=g).to(dev)
+    with_tape = model.encoder._rt.encoder_backward(data, d_local, noise, diff_weight=0.7, tape=enc_tape)
+    without = model.encoder._rt.encoder_backward(data, d_local, noise, diff_weight=0.7)
+    assert torch.equal(with_tape["diff_loss"], without["diff_loss"])
+    for k in without["grads"]:
+        assert torch.equal(with_tape["grads"][k], without["grads"][k]), k
+    a_with = model.aggregator._rt.aggregator_backward(data, local, d_glob, noise, tape=agg_tape)
+    a_without = model.aggregator._rt.aggregator_backward(data, local, d_glob, noise)
+    assert torch.equal(a_with["d_local_embed"], a_without["d_local_embed"])
+    for k in a_without["grads"]:
+        assert torch.equal(a_with["grads"][k], a_without["grads"][k]), k

@@ -312,6 +312,34 @@ struct AggBwdWs {
 
 using namespace tsde;
 
+// The aggregator's forward with one activation buffer per layer kept in `w` (the tape the backward walks): run once per
+// training step, by trajsde_aggregator_forward_train or by the backward itself when no tape was handed over.
+template <typename DropOf>
+static int aggregator_tape(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, int nl, int num_heads,
+                           const float* local_embed, AggBwdWs& w, DropOf drop_of, hipStream_t st) {
+  const int64_t N = b->N, E = g->E_g, ntiles = (N + 15) / 16, etiles = (E + 15) / 16;
+  if (E > 0)
+    TS_LAUNCH(k_edge_embed<true>, tile_grid(etiles, 1024, EdgeL6::EMB_SIZE * 4), 1024, EdgeL6::EMB_SIZE * 4, st, blob_fwd + AggBlob::REL6,
+              g->g_geom, E, w.rel, 0);
+  const float* x = local_embed;
+  for (int l = 0; l < nl; ++l) {
+    const float* lb = blob_fwd + AggBlob::layer(l);
+    TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
+              w.xn[l], w.q[l], w.kn[l], w.vn[l]);
+    {
+      const DropArg dl = drop_of(l);
+      TS_GLOBAL_ATTN(num_heads, false, dl, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N, w.agg[l]);
+    }
+    TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, lb + AggLayerL::UPD6, w.agg[l], w.xn[l], x,
+              N, w.x1[l], w.xn2[l], drop_of(l));
+    TS_LAUNCH(k_ffn6, tile_grid(ntiles, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, lb + AggLayerL::FFN6, w.x1[l], w.xn2[l], N, w.out[l],
+              drop_of(l));
+    x = w.out[l];
+  }
+
+  return TRAJSDE_OK;
+}
+
 extern "C" {
 
 int64_t trajsde_aggregator_backward_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int num_layers, int num_modes) {
@@ -324,13 +352,35 @@ int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, 
                                 int num_layers, int num_modes, const float* local_embed, const float* d_global, void* ws,
                                 int64_t ws_bytes, float* const* grads, int n_grads, float* d_local, void* stream_) {
   return trajsde_aggregator_backward_heads(b, g, blob_fwd, blob_bwd, num_layers, num_modes, 8, local_embed, d_global, ws, ws_bytes, grads,
-                                           n_grads, d_local, nullptr, stream_);
+                                           n_grads, d_local, nullptr, 0, stream_);
+}
+
+int trajsde_aggregator_forward_train(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, int num_layers, int num_modes,
+                                     int num_heads, const float* local_embed, void* ws, int64_t ws_bytes, float* global_embed,
+                                     const trajsde_dropout* dropout, void* stream_) {
+  TS_REQUIRE(b && g && blob_fwd && local_embed && ws && global_embed, "aggregator_forward_train: null pointer");
+  TS_REQUIRE(num_heads == 8 || num_heads == 4, "aggregator_forward_train: num_heads must be 8 or 4");
+  TS_REQUIRE(g->g_src && g->g_segptr, "aggregator_forward_train: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(num_layers >= 1 && num_layers <= 8 && num_modes > 0, "aggregator_forward_train: bad layer/mode count");
+  TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "aggregator_forward_train: dropout p must be in [0, 1)");
+  TS_REQUIRE(!state_bf16(), "aggregator_forward_train: the training tape is fp32; switch trajsde_state_storage(0)");
+  auto drop_of = [&](int layer) { return dropout ? make_drop(dropout->p, dropout->seed, 2 + layer) : no_drop(); };
+  AggBwdWs w(b->N, g->E_g, num_layers, num_modes, ws, ws_bytes);
+  if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "aggregator_forward_train: workspace too small (trajsde_aggregator_backward_ws_bytes)");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (int rc = aggregator_tape(b, g, blob_fwd, num_layers, num_heads, local_embed, w, drop_of, st)) return rc;
+  const int64_t N = b->N, ntiles = (N + 15) / 16;
+  const int lds = (128 + MAT64 + 64) * 4;
+  dim3 grid(tile_grid(ntiles, 512, lds), num_modes);
+  TS_LAUNCH(k_mode_proj, grid, 512, lds, st, blob_fwd + AggBlob::norm(num_layers), blob_fwd + AggBlob::proj(num_layers, 0), w.out[num_layers - 1], N,
+            global_embed);
+  return TRAJSDE_OK;
 }
 
 int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, const float* blob_bwd,
                                       int num_layers, int num_modes, int num_heads, const float* local_embed, const float* d_global,
                                       void* ws, int64_t ws_bytes, float* const* grads, int n_grads, float* d_local,
-                                      const trajsde_dropout* dropout, void* stream_) {
+                                      const trajsde_dropout* dropout, int tape_valid, void* stream_) {
   TS_REQUIRE(b && g && blob_fwd && blob_bwd && local_embed && d_global && ws && grads && d_local, "aggregator_backward: null pointer");
   TS_REQUIRE(!state_bf16(), "aggregator_backward: the backward pass keeps its tape in fp32; switch trajsde_state_storage(0) for training");
   TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "aggregator_backward: dropout p must be in [0, 1)");
@@ -358,25 +408,9 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
   const int nl = num_layers, K = num_modes;
   const WgradCtx wc{st, w.part, w.cs, nullptr, w.parts};
 
-  // ---- forward recompute (the kernels the forward itself runs), one buffer per layer
-  if (E > 0)
-    TS_LAUNCH(k_edge_embed<true>, tile_grid(etiles, 1024, EdgeL6::EMB_SIZE * 4), 1024, EdgeL6::EMB_SIZE * 4, st, blob_fwd + AggBlob::REL6,
-              g->g_geom, E, w.rel, 0);
-  const float* x = local_embed;
-  for (int l = 0; l < nl; ++l) {
-    const float* lb = blob_fwd + AggBlob::layer(l);
-    TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
-              w.xn[l], w.q[l], w.kn[l], w.vn[l]);
-    {
-      const DropArg dl = drop_of(l);
-      TS_GLOBAL_ATTN(num_heads, false, dl, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N, w.agg[l]);
-    }
-    TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, lb + AggLayerL::UPD6, w.agg[l], w.xn[l], x,
-              N, w.x1[l], w.xn2[l], drop_of(l));
-    TS_LAUNCH(k_ffn6, tile_grid(ntiles, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, lb + AggLayerL::FFN6, w.x1[l], w.xn2[l], N, w.out[l],
-              drop_of(l));
-    x = w.out[l];
-  }
+  if (!tape_valid)
+    if (int rc = aggregator_tape(b, g, blob_fwd, nl, num_heads, local_embed, w, drop_of, st)) return rc;
+  (void)etiles;
 
   // ---- multihead_proj + final norm
   for (int k = 0; k < K; ++k)

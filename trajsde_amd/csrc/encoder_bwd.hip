@@ -776,47 +776,17 @@ int aa_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const fl
 
 }  // namespace
 
-extern "C" {
-
-int64_t trajsde_encoder_backward_ws_bytes(const trajsde_batch* b, const trajsde_graph* g) {
-  if (!b || !g) return -1;
-  EncBwdWs w(b, g, nullptr, 0);
-  return w.total;
-}
-
-int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_fwd,
-                             const float* blob_bwd, const float* step_tab /*HOST [H,8]*/, const float* step_tab_dev,
-                             const trajsde_noise* noise, const float* d_local, float diff_weight, void* ws, int64_t ws_bytes,
-                             float* diff_loss, float* const* grads, int n_grads, float* d_latent, float* d_aa_out,
-                             const trajsde_dropout* dropout, void* stream_) {
-  TS_REQUIRE(b && g && rot && blob_fwd && blob_bwd && step_tab && step_tab_dev && d_local && ws && diff_loss && grads,
-             "encoder_backward: null pointer");
-  TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "encoder_backward: dropout p must be in [0, 1)");
-  TS_REQUIRE(!state_bf16(), "encoder_backward: the backward pass keeps its tape in fp32; switch trajsde_state_storage(0) for training");
-  const DropArg drop_aa = dropout ? make_drop(dropout->p, dropout->seed, 0) : no_drop();     // block ids of dropout.hpp
-  const DropArg drop_al = dropout ? make_drop(dropout->p, dropout->seed, 1) : no_drop();
-  TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_backward: graph not compacted (call trajsde_graph_compact)");
-  TS_REQUIRE(b->A > 0 && g->Nt == b->N + b->A, "encoder_backward: graph was prepared without the fake-agent rows");
-  const std::vector<std::string> names = stage_param_names(TRAJSDE_STAGE_ENCODER_BWD, 0, 0);
-  TS_REQUIRE(n_grads == int(names.size()), "encoder_backward: gradient count does not match trajsde_param_count(ENCODER_BWD)");
-  GradTable G;
-  for (int i = 0; i < n_grads; ++i) {
-    TS_REQUIRE(grads[i] != nullptr, "encoder_backward: null gradient buffer " + names[i]);
-    G.slot[names[i]] = grads[i];
-  }
-  EncBwdWs w(b, g, ws, ws_bytes);
-  if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_backward: workspace too small");
-  hipStream_t st = static_cast<hipStream_t>(stream_);
-  const int N = b->N, Nt = g->Nt, H = b->H, A = b->A;
+// The encoder's forward with every activation the backward needs kept in `w` (the "tape"): the split-precision kernels the
+// inference forward runs, in their two-kernel attention form (per-edge logits / v are needed by the softmax backward), the
+// recurrence as 21 x (SDE step, GRU) launches that save their intermediates.  Run once per training step: by
+// trajsde_encoder_forward_train (which also finishes local_embed / diff_pick), or by trajsde_encoder_backward itself when no
+// tape was handed over.
+static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_fwd, const float* step_tab,
+                        const NoiseArg& na, EncBwdWs& w, const DropArg& drop_aa, const DropArg& drop_al, hipStream_t st) {
+  const int N = b->N, Nt = g->Nt, H = b->H;
   const int64_t R = int64_t(H) * Nt, Eaa = g->E_aa, Ela = g->E_la;
   const int64_t rtiles = (int64_t(Nt) + 15) / 16;
-  NoiseArg na{0, nullptr, nullptr};
-  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
-  const WgradCtx wc{st, w.part, w.cs, step_tab_dev, w.parts};
   using FB = EncBlob;
-  using BB = EncBwdBlob;
-
-  // ================= forward recompute (the split-precision kernels the forward itself runs; recurrence in fp32) =================
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob_fwd + FB::AA_CENTER, b->x,
             g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
   if (Eaa > 0)
@@ -847,6 +817,86 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   TS_LAUNCH(k_seg_softmax_agg, cdiv(N, 4), 256, 0, st, g->la_segptr, w.al_logits, w.al_v, int64_t(N), w.al_agg, 8, drop_al);
   TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
             w.al_agg, w.al_xn, w.lat, int64_t(N), w.al_x1, w.al_xn2, drop_al);
+
+  return TRAJSDE_OK;
+}
+
+// diff_pick[slot] = the diffusion value of the kept iteration of the rows that have a slot (ENC:171,190-191), broadcast over
+// the 64 channels -- from the tape's GS [H][Nt]
+__global__ void k_pick_diff(const float* __restrict__ GS, const int32_t* __restrict__ eos, const int32_t* __restrict__ pick_slot, int Nt,
+                            float* __restrict__ diff_pick) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int slot = pick_slot[r];
+  if (slot >= 0) diff_pick[int64_t(slot) * 64 + lane] = GS[int64_t(eos[r]) * Nt + r];
+}
+
+extern "C" {
+
+int64_t trajsde_encoder_backward_ws_bytes(const trajsde_batch* b, const trajsde_graph* g) {
+  if (!b || !g) return -1;
+  EncBwdWs w(b, g, nullptr, 0);
+  return w.total;
+}
+
+int trajsde_encoder_forward_train(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_fwd,
+                                  const float* step_tab /*HOST [H,8]*/, const trajsde_noise* noise, void* ws, int64_t ws_bytes,
+                                  float* local_embed, float* diff_pick, const trajsde_dropout* dropout, void* stream_) {
+  TS_REQUIRE(b && g && rot && blob_fwd && step_tab && ws && local_embed && diff_pick, "encoder_forward_train: null pointer");
+  TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_forward_train: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(b->A > 0 && g->Nt == b->N + b->A, "encoder_forward_train: graph was prepared without the fake-agent rows");
+  TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "encoder_forward_train: dropout p must be in [0, 1)");
+  TS_REQUIRE(!state_bf16(), "encoder_forward_train: the training tape is fp32; switch trajsde_state_storage(0)");
+  const DropArg drop_aa = dropout ? make_drop(dropout->p, dropout->seed, 0) : no_drop();
+  const DropArg drop_al = dropout ? make_drop(dropout->p, dropout->seed, 1) : no_drop();
+  EncBwdWs w(b, g, ws, ws_bytes);
+  if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_forward_train: workspace too small (trajsde_encoder_backward_ws_bytes)");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  NoiseArg na{0, nullptr, nullptr};
+  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
+  if (int rc = encoder_tape(b, g, rot, blob_fwd, step_tab, na, w, drop_aa, drop_al, st)) return rc;
+  const int N = b->N;
+  TS_LAUNCH(k_ffn6, tile_grid((int64_t(N) + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + EncBlob::AL_FFN6, w.al_x1, w.al_xn2,
+            int64_t(N), local_embed, drop_al);
+  TS_HIP(hipMemsetAsync(diff_pick, 0, size_t(2) * b->A * 64 * sizeof(float), st));
+  k_pick_diff<<<g->Nt, 64, 0, st>>>(w.GS, g->eos_idx, g->pick_slot, g->Nt, diff_pick);
+  TS_LAUNCH_CHECK("k_pick_diff");
+  return TRAJSDE_OK;
+}
+
+int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_fwd,
+                             const float* blob_bwd, const float* step_tab /*HOST [H,8]*/, const float* step_tab_dev,
+                             const trajsde_noise* noise, const float* d_local, float diff_weight, void* ws, int64_t ws_bytes,
+                             float* diff_loss, float* const* grads, int n_grads, float* d_latent, float* d_aa_out,
+                             const trajsde_dropout* dropout, int tape_valid, void* stream_) {
+  TS_REQUIRE(b && g && rot && blob_fwd && blob_bwd && step_tab && step_tab_dev && d_local && ws && diff_loss && grads,
+             "encoder_backward: null pointer");
+  TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "encoder_backward: dropout p must be in [0, 1)");
+  TS_REQUIRE(!state_bf16(), "encoder_backward: the backward pass keeps its tape in fp32; switch trajsde_state_storage(0) for training");
+  const DropArg drop_aa = dropout ? make_drop(dropout->p, dropout->seed, 0) : no_drop();     // block ids of dropout.hpp
+  const DropArg drop_al = dropout ? make_drop(dropout->p, dropout->seed, 1) : no_drop();
+  TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_backward: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(b->A > 0 && g->Nt == b->N + b->A, "encoder_backward: graph was prepared without the fake-agent rows");
+  const std::vector<std::string> names = stage_param_names(TRAJSDE_STAGE_ENCODER_BWD, 0, 0);
+  TS_REQUIRE(n_grads == int(names.size()), "encoder_backward: gradient count does not match trajsde_param_count(ENCODER_BWD)");
+  GradTable G;
+  for (int i = 0; i < n_grads; ++i) {
+    TS_REQUIRE(grads[i] != nullptr, "encoder_backward: null gradient buffer " + names[i]);
+    G.slot[names[i]] = grads[i];
+  }
+  EncBwdWs w(b, g, ws, ws_bytes);
+  if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_backward: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  const int N = b->N, Nt = g->Nt, H = b->H, A = b->A;
+  const int64_t R = int64_t(H) * Nt, Eaa = g->E_aa, Ela = g->E_la;
+  const int64_t rtiles = (int64_t(Nt) + 15) / 16;
+  NoiseArg na{0, nullptr, nullptr};
+  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
+  const WgradCtx wc{st, w.part, w.cs, step_tab_dev, w.parts};
+  using FB = EncBlob;
+  using BB = EncBwdBlob;
+
+  if (!tape_valid)
+    if (int rc = encoder_tape(b, g, rot, blob_fwd, step_tab, na, w, drop_aa, drop_al, st)) return rc;
 
   // ================= backward =================
   // ---- ALEncoder: d local_embed -> d latent

@@ -37,14 +37,18 @@ class _PathLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, data, noise, w_l2, w_diff, *params):
         with torch.no_grad():
-            out, local, glob = model._forward_stages(data, noise)
+            # one forward per step: the encoder and aggregator run their tape-keeping forward, the backward entry points
+            # then walk those tapes instead of recomputing the stage (runtime.*_forward_train)
+            out, local, glob, enc_tape, agg_tape = model._forward_stages(data, noise, keep_tapes=True)
             enc_rt, agg_rt, dec_rt = model.encoder._rt, model.aggregator._rt, model.decoder._rt
             dec = dec_rt.decoder_l2_backward(data, local, glob, out, noise)
             d_glob, d_local = dec["d_global_embed"], dec["d_local_embed"]
             if w_l2 != 1.0:
                 d_glob, d_local = d_glob * w_l2, d_local * w_l2
-            agg = agg_rt.aggregator_backward(data, local, d_glob, noise)
-            enc = enc_rt.encoder_backward(data, d_local + agg["d_local_embed"], noise, diff_weight=w_diff)
+            agg = agg_rt.aggregator_backward(data, local, d_glob, noise, tape=agg_tape)
+            del agg_tape
+            enc = enc_rt.encoder_backward(data, d_local + agg["d_local_embed"], noise, diff_weight=w_diff, tape=enc_tape)
+            del enc_tape
             by_name = {}
             for n, g in dec["grads"].items():
                 by_name["decoder." + n] = g if w_l2 == 1.0 else g * w_l2
@@ -153,16 +157,24 @@ class PredictionModelSDENet(nn.Module):
             reached |= {f"{stage}.{n}" for n in getattr(self, stage)._rt.param_names(sid)}
         return [p for n, p in self.named_parameters() if n in reached]
 
-    def _forward_stages(self, data, noise):
-        """forward() that also hands back the two stage boundaries the backward entry points need"""
+    def _forward_stages(self, data, noise, keep_tapes: bool = False):
+        """forward() that also hands back the two stage boundaries the backward entry points need; with `keep_tapes` the
+        encoder and the aggregator run their tape-keeping forward and the tapes are returned too"""
         rotate_mat, y_rot = runtime.rotate_inputs(data)
         if y_rot is not None:
             data.y = y_rot
         data["rotate_mat"] = rotate_mat
-        local_embed, diff_in, diff_out, label_in, label_out = self.encoder(data=data, noise=noise)
-        global_embed = self.aggregator(data=data, local_embed=local_embed, noise=noise)
+        enc_tape = agg_tape = None
+        if keep_tapes:
+            (local_embed, diff_in, diff_out, label_in, label_out), enc_tape = self.encoder._rt.encoder_forward_train(data, noise)
+            global_embed, agg_tape = self.aggregator._rt.aggregator_forward_train(data, local_embed, noise)
+        else:
+            local_embed, diff_in, diff_out, label_in, label_out = self.encoder(data=data, noise=noise)
+            global_embed = self.aggregator(data=data, local_embed=local_embed, noise=noise)
         out = self.decoder(data=data, local_embed=local_embed, global_embed=global_embed, noise=noise)
         out["diff_in"], out["diff_out"], out["label_in"], out["label_out"] = diff_in, diff_out, label_in, label_out
+        if keep_tapes:
+            return out, local_embed, global_embed, enc_tape, agg_tape
         return out, local_embed, global_embed
 
     # -- Lightning-style hooks (MODEL:104-148) ------------------------------------------------------

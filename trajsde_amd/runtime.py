@@ -332,11 +332,37 @@ class StageRuntime:
         diff_in, diff_out = torch.chunk(diff_pick, 2, 0)                                    # ENC:194
         return (local, diff_in, diff_out, torch.full_like(diff_in, m.real_label), torch.full_like(diff_out, m.fake_label))
 
+    def encoder_forward_train(self, data, noise: NoiseSpec):
+        """The encoder's forward for a training step: same outputs as encoder_forward (same weights, noise, dropout), computed
+        by the kernels that keep the tape the backward needs.  Returns (outputs tuple, tape) -- hand `tape` to encoder_backward
+        and the backward does not recompute the forward."""
+        m = self.module
+        gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), noise)
+        dev = gc.device
+        L = _lib.lib()
+        N, A = gc.batch.N, gc.batch.A
+        tab = self._enc_table()
+        local = torch.empty(N, D, device=dev, dtype=torch.float32)
+        diff_pick = torch.empty(2 * A, D, device=dev, dtype=torch.float32)
+        ws_bytes = L.trajsde_encoder_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph))
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        cn = noise.c_noise(noise.z_enc, noise.enc_row_ids)
+        dr = noise.c_dropout(m)
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_encoder_forward_train(C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), self.blob().data_ptr(),
+                                                       tab.ctypes.data_as(C.c_void_p), C.byref(cn), ws.data_ptr(), ws_bytes, local.data_ptr(),
+                                                       diff_pick.data_ptr(), C.byref(dr) if dr is not None else None, _stream()),
+                       "trajsde_encoder_forward_train")
+        diff_in, diff_out = torch.chunk(diff_pick, 2, 0)
+        outs = (local, diff_in, diff_out, torch.full_like(diff_in, m.real_label), torch.full_like(diff_out, m.fake_label))
+        return outs, (ws, ws_bytes)
+
     def encoder_backward(self, data, d_local: torch.Tensor, noise: NoiseSpec, diff_weight: float = 1.0,
-                         want_boundaries: bool = False) -> Dict[str, object]:
+                         want_boundaries: bool = False, tape=None) -> Dict[str, object]:
         """Backward of LocalEncoderSDESepPara2.forward plus the DiffBCE term: `d_local` = dL/d local_embed [N,64],
         `noise` the forward's NoiseSpec.  Returns {"grads": {param name: tensor}, "diff_loss": diff_weight * DiffBCE}
-        (+ "d_latent" [N,64], "d_aa_out" [H,Nt,64] with want_boundaries).  The forward is recomputed inside."""
+        (+ "d_latent" [N,64], "d_aa_out" [H,Nt,64] with want_boundaries).  `tape`: what encoder_forward_train returned for
+        this very step; without it the forward is recomputed inside."""
         m = self.module
         if noise is None:
             raise _lib.TrajsdeError("encoder_backward needs the NoiseSpec of the forward pass")
@@ -354,8 +380,11 @@ class StageRuntime:
         loss = torch.empty(1, device=dev, dtype=torch.float32)
         d_lat = torch.empty(N, D, device=dev, dtype=torch.float32) if want_boundaries else None
         d_aa = torch.empty(H, Nt, D, device=dev, dtype=torch.float32) if want_boundaries else None
-        ws_bytes = L.trajsde_encoder_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph))
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        if tape is not None:
+            ws, ws_bytes = tape
+        else:
+            ws_bytes = L.trajsde_encoder_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph))
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         cn = noise.c_noise(noise.z_enc, noise.enc_row_ids)
         dr = noise.c_dropout(m)                                            # the forward's masks, regenerated from the same key
         with torch.cuda.device(dev):
@@ -363,7 +392,7 @@ class StageRuntime:
                 C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), self.blob().data_ptr(),
                 self.blob(_lib.STAGE_ENCODER_BWD).data_ptr(), tab.ctypes.data_as(C.c_void_p), tab_dev.data_ptr(), C.byref(cn),
                 d_local.to(torch.float32).contiguous().data_ptr(), float(diff_weight), ws.data_ptr(), ws_bytes, loss.data_ptr(),
-                arr, len(names), _ptr(d_lat), _ptr(d_aa), C.byref(dr) if dr is not None else None, _stream()),
+                arr, len(names), _ptr(d_lat), _ptr(d_aa), C.byref(dr) if dr is not None else None, 1 if tape is not None else 0, _stream()),
                 "trajsde_encoder_backward")
         out = {"grads": grads, "diff_loss": loss[0]}
         if want_boundaries:
@@ -486,8 +515,28 @@ class StageRuntime:
                 "reg_mask": ~data["padding_mask"][:, -T:]}
 
 
+    def aggregator_forward_train(self, data, local_embed: torch.Tensor, noise: Optional[NoiseSpec] = None):
+        """GlobalInteractor.forward for a training step -> (global_embed [K,N,64], tape for aggregator_backward)"""
+        m = self.module
+        _require_gpu(local_embed, "local_embed")
+        gc = GraphContext.get(data, None, int(m.historical_steps), None)
+        dev = gc.device
+        L = _lib.lib()
+        K, N, nl = int(m.num_modes), gc.batch.N, int(m.num_layers)
+        out = torch.empty(K, N, D, device=dev, dtype=torch.float32)
+        ws_bytes = L.trajsde_aggregator_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), nl, K)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        dr = noise.c_dropout(m) if noise is not None else None
+        if dr is None and m.training and float(getattr(m, "dropout", 0.0) or 0.0) > 0:
+            raise _lib.TrajsdeError("aggregator_forward_train in train mode needs a NoiseSpec (dropout key)")
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_aggregator_forward_train(C.byref(gc.batch), C.byref(gc.graph), self.blob().data_ptr(), nl, K, int(m.num_heads),
+                                                          local_embed.contiguous().data_ptr(), ws.data_ptr(), ws_bytes, out.data_ptr(),
+                                                          C.byref(dr) if dr is not None else None, _stream()), "trajsde_aggregator_forward_train")
+        return out, (ws, ws_bytes)
+
     def aggregator_backward(self, data, local_embed: torch.Tensor, d_global: torch.Tensor,
-                            noise: Optional[NoiseSpec] = None) -> Dict[str, object]:
+                            noise: Optional[NoiseSpec] = None, tape=None) -> Dict[str, object]:
         """Backward of GlobalInteractor.forward: dL/d global_embed [K,N,64] -> {"grads": {param name: tensor},
         "d_local_embed": [N,64]} (the aggregator's own contribution; the decoder's d local_embed is added by the
         caller).  The forward is recomputed inside the call."""
@@ -503,8 +552,11 @@ class StageRuntime:
         grads = self._grad_buffers(_lib.STAGE_AGGREGATOR_BWD)
         arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
         d_local = torch.empty(N, D, device=dev, dtype=torch.float32)
-        ws_bytes = L.trajsde_aggregator_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), nl, K)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        if tape is not None:
+            ws, ws_bytes = tape
+        else:
+            ws_bytes = L.trajsde_aggregator_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), nl, K)
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         dr = noise.c_dropout(m) if noise is not None else None            # the forward's masks
         if dr is None and m.training and float(getattr(m, "dropout", 0.0) or 0.0) > 0:
             raise _lib.TrajsdeError("aggregator_backward in train mode needs the NoiseSpec of the forward pass (dropout key)")
@@ -512,7 +564,8 @@ class StageRuntime:
             _lib.check(L.trajsde_aggregator_backward_heads(
                 C.byref(gc.batch), C.byref(gc.graph), self.blob().data_ptr(), self.blob(_lib.STAGE_AGGREGATOR_BWD).data_ptr(), nl, K,
                 int(m.num_heads), local_embed.contiguous().data_ptr(), d_global.to(torch.float32).contiguous().data_ptr(), ws.data_ptr(), ws_bytes,
-                arr, len(names), d_local.data_ptr(), C.byref(dr) if dr is not None else None, _stream()), "trajsde_aggregator_backward")
+                arr, len(names), d_local.data_ptr(), C.byref(dr) if dr is not None else None, 1 if tape is not None else 0, _stream()),
+                "trajsde_aggregator_backward")
         return {"grads": grads, "d_local_embed": d_local}
 
 
