@@ -649,8 +649,11 @@ struct EncBwdWs {
     al_logits = c.take<float>(Ela * 8 + 8);
     al_v = c.take<float>(Ela * 64 + 64);
     DLG = c.take<float>(E * 8);
-    float** rows_E[] = {&DV, &EMB, &DK, &DQE, &DEMB, &ee.S, &ee.DEP, &ee.DSP};
+    float** rows_E[] = {&DV, &EMB, &DK, &DQE, &DEMB};
     for (float** p : rows_E) *p = c.take<float>(E * 64);
+    // the embedding backward starts after the lin_k / lin_v weight gradients (the last readers of DK, DV, EMB, DQE) are
+    // enqueued on the same stream, so its three per-edge slabs reuse those buffers: 3 x E x 256 B less workspace
+    ee.S = DK; ee.DEP = DV; ee.DSP = DQE;
     nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
     const int64_t rows = E > R ? E : R;
     parts = wgrad_max_parts(rows, H);
