@@ -24,12 +24,21 @@ for set in "$A" "$Bc" "$Cc" "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_fwd_$i -- python3 $P > $O/pmc_fwd_$i.log 2>&1
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_sde_$i -- python3 $S > $O/pmc_sde_$i.log 2>&1
 done
+# BASELINE configs[4] (stress shape, bf16 hidden state): kernel stats + HBM counters of tools/stress_forward.py
+T="$R/tools/stress_forward.py --storage bf16 --iters 3"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kst -- python3 $T > $O/kst.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_stress_4 -- python3 $T > $O/pmc_stress_4.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_stress_5 -- python3 $T > $O/pmc_stress_5.log 2>&1
+python3 $R/tools/stress_forward.py --check > $O/stress_forward.json 2> $O/stress_forward.err
+python3 $R/tools/train_step_bench.py > $O/train_step.log 2>&1
+python3 $R/tools/train_step_bench.py --config config4 > $O/train_step_config4.log 2>&1
 cd $R
+cp $(find $O/kst -name "*kernel_stats.csv" | head -1) $O/kernel_stats_stress_bf16.csv
 cp $(find $O/ks1 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_streams1.csv
 cp $(find $O/ks3 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_default_streams3.csv
 cp $(find $O/kss -name "*kernel_stats.csv" | head -1) $O/kernel_stats_sde_step.csv
 python3 tools/counter_summary.py $O $O/sq_counters.md $O/traffic.json
-rm -rf $O/ks1 $O/ks3 $O/kss
+rm -rf $O/ks1 $O/ks3 $O/kss $O/kst
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*agent_info.csv" -delete
 tail -3 $O/sq_counters.md

@@ -66,13 +66,20 @@ def table(title, cmd, data, order_key="SQ_WAVE_CYCLES", top=14):
 
 def main():
     root, md_path, json_path = sys.argv[1:4]
-    fwd, sde = collect(root, "pmc_fwd_"), collect(root, "pmc_sde_")
+    fwd, sde, stress = collect(root, "pmc_fwd_"), collect(root, "pmc_sde_"), collect(root, "pmc_stress_")
     lines = ["# SQ / TCC counters, round 2 build (fp16x3 split precision, fused edge attention)", ""]
     lines += table("forward, 32 scenes x 256 agents, K=6, 20 steps, one stream",
                    "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --windows 1 "
                    "--no-cpu-baseline --no-train-step --no-secondary --streams 1   (one pass per counter set)", fwd)
     lines += [""] + table("step-granular SDE step, 786 432 rows", "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- "
                           "python3 tools/sde_step_bench.py 786432 30", sde)
+    if stress:
+        lines += ["", "## stress shape (BASELINE configs[4]): 8 scenes x 1024 agents, K=20, 50 steps, bf16 state storage -- HBM counters", "",
+                  "    rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 tools/stress_forward.py --storage bf16 --iters 3", "",
+                  "| kernel | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes (2 x FETCH + WRITE) |", "|---|---|---|---|"]
+        for n in sorted(stress, key=lambda k: -(2 * stress[k].get("FETCH_SIZE", 0) + stress[k].get("WRITE_SIZE", 0)))[:12]:
+            fr, wr = stress[n].get("FETCH_SIZE", 0.0), stress[n].get("WRITE_SIZE", 0.0)
+            lines.append(f"| {n} | {fr:.0f} | {wr:.0f} | {(2 * fr + wr) * 1024:.4g} |")
     with open(md_path, "w") as f:
         f.write("\n".join(lines) + "\n")
     doc = {}
