@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restri
 // once per target after the aggregation.  Per edge the wave streams one rel row (256 B) and gathers two node rows.
 // Lane l is feature l of the node rows (head l>>3) and holds slice 8*(l&7).. of the rel row / of U for head l>>3.
 template <int HEADS, bool ST_BF16, bool DROP>
-__global__ __launch_bounds__(256) void k_global_attn(const float* __restrict__ img, const int32_t* __restrict__ segptr,
+__global__ __launch_bounds__(256, 4) void k_global_attn(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                      const int32_t* __restrict__ src, const float* __restrict__ rel,
                                                      const float* __restrict__ q, const float* __restrict__ kn,
                                                      const float* __restrict__ vn, int64_t N, float* __restrict__ agg, DropArg drop) {
