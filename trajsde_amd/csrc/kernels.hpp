@@ -78,6 +78,7 @@ constexpr int COOP_TILE = 16 * COOP_RS;
 struct StepTab {                                              // per-iteration (dt, sqrt_h, sin t0, cos t0), H <= 32
   float dt[32], sq[32], sn[32], cs[32];
 };
+template <int TW>
 __global__ void k_enc_recur_coop(const float* sde_img, const float* gru_img, const float* coop6, const float* h0, const float* aa_out, int Nt, int N, int H,
                                  int TT, int tiles_per_wg, StepTab tab, int noise_step0, NoiseArg na, const uint8_t* nus, const uint8_t* pad,
                                  const int32_t* orig, const int32_t* eos, const int32_t* pick_slot, float* kept, float* diff_pick,

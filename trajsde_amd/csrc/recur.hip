@@ -190,6 +190,7 @@ __device__ __forceinline__ f4 vec_slice(const float* v, int w, int g) { return *
 __device__ __forceinline__ f4 tanh4(f4 a) { return f4{fast_tanh(a[0]), fast_tanh(a[1]), fast_tanh(a[2]), fast_tanh(a[3])}; }
 __device__ __forceinline__ f4 sigm4(f4 a) { return f4{fast_sigmoid(a[0]), fast_sigmoid(a[1]), fast_sigmoid(a[2]), fast_sigmoid(a[3])}; }
 
+template <int TW>
 __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict__ sde_img, const float* __restrict__ gru_img,
                                                         const float* __restrict__ coop6, const float* __restrict__ h0, const float* __restrict__ aa_out,
                                                         int Nt, int N, int H, int TT, int tiles_per_wg, StepTab tab, int noise_step0,
@@ -202,11 +203,13 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
   const Lane L;
   const int w = threadIdx.x >> 6;
   const int64_t ntiles = (int64_t(Nt) + 15) / 16;
-  // tiles of this workgroup: blockIdx.x + k * gridDim.x
-  int T = 0;
-  for (int k = 0; k < tiles_per_wg; ++k)
-    if (int64_t(blockIdx.x) + int64_t(k) * gridDim.x < ntiles) T = k + 1;
-  if (T == 0) return;
+  // tiles of this workgroup: blockIdx.x + k * gridDim.x, k < TW.  TW is a compile-time constant so that the per-phase code of
+  // the TW tiles is straight-line and the scheduler interleaves their LDS reads, splits and matrix chains (a runtime tile
+  // count put every tile behind its own branch: one dependency chain at a time on a one-wave-per-SIMD kernel); tiles past
+  // the end of the rows are computed on clamped rows and never stored (inb)
+  constexpr int T = TW;
+  (void)ntiles;
+  (void)tiles_per_wg;
   auto Yb = [&](int k) { return lds + (5 * k + 0) * COOP_TILE; };
   auto Ab = [&](int k) { return lds + (5 * k + 1) * COOP_TILE; };
   auto Bb = [&](int k) { return lds + (5 * k + 2) * COOP_TILE; };
@@ -428,6 +431,13 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
     __syncthreads();
   }
 }
+
+#define TS_COOP_INST(TW)                                                                                                          \
+  template __global__ void k_enc_recur_coop<TW>(const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, \
+                                                StepTab, int, NoiseArg, const uint8_t*, const uint8_t*, const int32_t*, const int32_t*,      \
+                                                const int32_t*, float*, float*, float*, int);
+TS_COOP_INST(1) TS_COOP_INST(2) TS_COOP_INST(3) TS_COOP_INST(4)
+#undef TS_COOP_INST
 
 // forward_ood (ENC:311-313): outs [S,N,64] -> mean over samples [N,64] and std(0).mean(-1) [N] (unbiased std)
 __global__ __launch_bounds__(256) void k_ood_stats(const float* __restrict__ samples, int S, int N, float* __restrict__ mean,

@@ -189,8 +189,15 @@ static int run_recurrence(const trajsde_batch* b, const trajsde_graph* g, const 
     }
     const int grid = int((rtiles + tiles_per_wg - 1) / tiles_per_wg);
     const int lds = (5 * tiles_per_wg * COOP_TILE + tiles_per_wg * 64) * 4;
-    TS_LAUNCH(k_enc_recur_coop, grid, 256, lds, st, blob + EncBlob::SDE, blob + EncBlob::GRU, blob + EncBlob::COOP6, h0, aa_out, Nt, N, H, b->TT, tiles_per_wg, tab,
-              noise_step0, na, g->nus_mask, b->padding_mask, g->orig, g->eos_idx, g->pick_slot, kept, diff_pick, latent_ys, state_bf16() ? 1 : 0);
+#define TS_COOP(TW) TS_LAUNCH_TAG("k_enc_recur_coop", false, k_enc_recur_coop<TW>, grid, 256, lds, st, blob + EncBlob::SDE, blob + EncBlob::GRU, blob + EncBlob::COOP6, h0, aa_out, Nt, N, H, b->TT, tiles_per_wg, tab, \
+              noise_step0, na, g->nus_mask, b->padding_mask, g->orig, g->eos_idx, g->pick_slot, kept, diff_pick, latent_ys, state_bf16() ? 1 : 0)
+    switch (tiles_per_wg) {
+      case 1: TS_COOP(1); break;
+      case 2: TS_COOP(2); break;
+      case 3: TS_COOP(3); break;
+      default: TS_COOP(4); break;
+    }
+#undef TS_COOP
     return TRAJSDE_OK;
   }
   for (int idx = 0; idx < H; ++idx) {
