@@ -186,6 +186,40 @@ __device__ __forceinline__ void lds_read_tile(f4 (&in)[4], const float* tile, co
 __device__ __forceinline__ void lds_write_slice(float* tile, const f4& v, int w, const Lane& L) {
   *reinterpret_cast<f4*>(tile + L.n * COOP_RS + 16 * w + 4 * L.g) = v;
 }
+// Operand tiles: activations that only ever feed a matrix product.  fp16x3 build: the PRODUCING wave splits its 4 values per
+// lane into the two fp16 pieces and stores them in operand order -- [piece][k-step][lane][8 halves], 4 KB per tile -- so a
+// consumer's B fragments are four conflict-free 16-byte reads and nobody re-splits the tile (every one of the four waves used
+// to split all 16 values per lane of every tile it read: ~40 % of the kernel's vector instructions).  A wave's output features
+// 16w + 4g + c are the halves 4(w&1) .. +3 of k-step w>>1 in the SAME lane's fragment, so producer and consumer lanes coincide.
+#if TSDE_SPLIT_H3
+constexpr int COOP_OT = 1024;                                 // floats per operand tile
+__device__ __forceinline__ void opnd_write(float* tile, const f4& v, int w, const Lane& L) {
+  unsigned h0, l0, h1, l1;
+  split_pair(v[0], v[1], h0, l0);
+  split_pair(v[2], v[3], h1, l1);
+  uint2* base = reinterpret_cast<uint2*>(tile);
+  const int ks = w >> 1, half = w & 1;
+  base[((0 * 2 + ks) * 64 + L.lane) * 2 + half] = uint2{h0, h1};
+  base[((1 * 2 + ks) * 64 + L.lane) * 2 + half] = uint2{l0, l1};
+}
+__device__ __forceinline__ Opnd opnd_read(const float* tile, const Lane& L) {
+  const u4* b = reinterpret_cast<const u4*>(tile);
+  Opnd o;
+  o.hi[0] = b[0 * 64 + L.lane];
+  o.hi[1] = b[1 * 64 + L.lane];
+  o.lo[0] = b[2 * 64 + L.lane];
+  o.lo[1] = b[3 * 64 + L.lane];
+  return o;
+}
+#else
+constexpr int COOP_OT = COOP_TILE;
+__device__ __forceinline__ void opnd_write(float* tile, const f4& v, int w, const Lane& L) { lds_write_slice(tile, v, w, L); }
+__device__ __forceinline__ Opnd opnd_read(const float* tile, const Lane& L) {
+  f4 t[4];
+  lds_read_tile(t, tile, L);
+  return make_opnd(t);
+}
+#endif
 __device__ __forceinline__ f4 vec_slice(const float* v, int w, int g) { return *reinterpret_cast<const f4*>(v + 16 * w + 4 * g); }
 __device__ __forceinline__ f4 tanh4(f4 a) { return f4{fast_tanh(a[0]), fast_tanh(a[1]), fast_tanh(a[2]), fast_tanh(a[3])}; }
 __device__ __forceinline__ f4 sigm4(f4 a) { return f4{fast_sigmoid(a[0]), fast_sigmoid(a[1]), fast_sigmoid(a[2]), fast_sigmoid(a[3])}; }
@@ -210,12 +244,14 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
   constexpr int T = TW;
   (void)ntiles;
   (void)tiles_per_wg;
-  auto Yb = [&](int k) { return lds + (5 * k + 0) * COOP_TILE; };
-  auto Ab = [&](int k) { return lds + (5 * k + 1) * COOP_TILE; };
-  auto Bb = [&](int k) { return lds + (5 * k + 2) * COOP_TILE; };
-  auto Cb = [&](int k) { return lds + (5 * k + 3) * COOP_TILE; };
-  auto Xb = [&](int k) { return lds + (5 * k + 4) * COOP_TILE; };   // x_t tile of the step, each wave brings a quarter
-  float* GP = lds + 5 * tiles_per_wg * COOP_TILE;              // [tile][wave][16]
+  constexpr int PER = COOP_TILE + 5 * COOP_OT;                  // per tile: the fp32 state + five operand tiles
+  auto Yb = [&](int k) { return lds + k * PER; };                                   // hidden state, fp32 (the update reads its own slice)
+  auto Ys = [&](int k) { return lds + k * PER + COOP_TILE; };                       // the same state as a matrix operand
+  auto Ab = [&](int k) { return lds + k * PER + COOP_TILE + 1 * COOP_OT; };
+  auto Bb = [&](int k) { return lds + k * PER + COOP_TILE + 2 * COOP_OT; };
+  auto Cb = [&](int k) { return lds + k * PER + COOP_TILE + 3 * COOP_OT; };
+  auto Xb = [&](int k) { return lds + k * PER + COOP_TILE + 4 * COOP_OT; };         // x_t tile of the step, each wave brings a quarter
+  float* GP = lds + tiles_per_wg * PER;                         // [tile][wave][16]
 
   // ---- register-resident weights: this wave's slice of every matrix
   const float* F = sde_img + EncSdeL::F;
@@ -258,6 +294,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
       const f4 y = h0 ? vec_slice(h0, w, L.g) : f4{0.f, 0.f, 0.f, 0.f};      // same initial vector for every row (ENC:78 / :257)
       range_note(absmax4(y), RS_ENC_STATE);
       lds_write_slice(Yb(k), y, w, L);
+      opnd_write(Ys(k), y, w, L);
     }
   }
   __syncthreads();
@@ -274,17 +311,15 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 yf[4];
-        lds_read_tile(yf, Yb(k), L);
         {                                                      // in flight early; fp32 or bf16 storage (tile.hpp)
           const int64_t at = (int64_t(t) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g;
           xq[k] = aa_bf16 ? widen4(*reinterpret_cast<const bf4*>(reinterpret_cast<const __bf16*>(aa_out) + at))
                           : *reinterpret_cast<const f4*>(aa_out + at);
         }
-        const Opnd y = make_opnd(yf);
+        const Opnd y = opnd_read(Ys(k), L);
         f4 a = bf0;
         slice_mma(a, wf0, y);
-        lds_write_slice(Ab(k), tanh4(a), w, L);
+        opnd_write(Ab(k), tanh4(a), w, L);
         f4 gsel;
         if (nusmask[k] == ~0ull) { gsel = bn0; slice_mma(gsel, wn0, y); }
         else if (nusmask[k] == 0ull) { gsel = ba0; slice_mma(gsel, wa0, y); }
@@ -294,20 +329,17 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
           slice_mma(ga, wa0, y);
           gsel = is_nus[k] ? gn : ga;
         }
-        lds_write_slice(Bb(k), tanh4(gsel), w, L);
+        opnd_write(Bb(k), tanh4(gsel), w, L);
       }
     __syncthreads();
     // ---- P2: second layers; partial dot of the diffusion head
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 f1f[4], g1f[4];
-        lds_read_tile(f1f, Ab(k), L);
-        lds_read_tile(g1f, Bb(k), L);
-        const Opnd f1 = make_opnd(f1f), g1 = make_opnd(g1f);
+        const Opnd f1 = opnd_read(Ab(k), L), g1 = opnd_read(Bb(k), L);
         f4 a = vec_slice(F + DriftL::B2, w, L.g);
         slice_mma(a, wf2, f1);
-        lds_write_slice(Cb(k), tanh4(a), w, L);
+        opnd_write(Cb(k), tanh4(a), w, L);
         f4 g2;
         float part;
         auto head = [&](const f4& h2, const float* img) {
@@ -330,9 +362,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 f2f[4];
-        lds_read_tile(f2f, Cb(k), L);
-        const Opnd f2 = make_opnd(f2f);
+        const Opnd f2 = opnd_read(Cb(k), L);
         f4 f = vec_slice(F + DriftL::B4, w, L.g);
         slice_mma(f, wf4, f2);
         const float b4 = is_nus[k] ? GN[DiffL::B4] : GA[DiffL::B4];
@@ -348,7 +378,8 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
         range_note(absmax4(y), RS_ENC_STATE);                                             // operands of the GRU's split products
         range_note(absmax4(xq[k]), RS_ENC_INPUT);
         lds_write_slice(Yb(k), y, w, L);                                                  // Y now holds h' (all P1 reads are behind two barriers)
-        lds_write_slice(Xb(k), xq[k], w, L);
+        opnd_write(Ys(k), y, w, L);
+        opnd_write(Xb(k), xq[k], w, L);
         if (diff_pick != nullptr && inb[k] && slotk[k] >= 0 && eosk[k] == idx)
           *reinterpret_cast<f4*>(diff_pick + int64_t(slotk[k]) * 64 + 16 * w + 4 * L.g) = f4{gs, gs, gs, gs};
       }
@@ -357,19 +388,15 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 hpf[4];
-        lds_read_tile(hpf, Yb(k), L);
-        const Opnd hp = make_opnd(hpf);
-        f4 xf[4];
-        lds_read_tile(xf, Xb(k), L);
-        const Opnd xin = make_opnd(xf);
+        const Opnd hp = opnd_read(Ys(k), L);
+        const Opnd xin = opnd_read(Xb(k), L);
         f4 u1 = vec_slice(gru_img + G::BUR, w, L.g), r1 = vec_slice(gru_img + G::BUR + 64, w, L.g);
         slice_mma(u1, wuh, hp);
         slice_mma(u1, wux, xin);
         slice_mma(r1, wrh, hp);
         slice_mma(r1, wrx, xin);
-        lds_write_slice(Ab(k), tanh4(u1), w, L);
-        lds_write_slice(Bb(k), tanh4(r1), w, L);
+        opnd_write(Ab(k), tanh4(u1), w, L);
+        opnd_write(Bb(k), tanh4(r1), w, L);
       }
     __syncthreads();
     // ---- P5: gates; reset * h'
@@ -377,41 +404,32 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 u1f[4], r1f[4];
-        lds_read_tile(u1f, Ab(k), L);
-        lds_read_tile(r1f, Bb(k), L);
-        const Opnd u1 = make_opnd(u1f), r1 = make_opnd(r1f);
+        const Opnd u1 = opnd_read(Ab(k), L), r1 = opnd_read(Bb(k), L);
         f4 u = vec_slice(gru_img + G::BU2, w, L.g), r = vec_slice(gru_img + G::BR2, w, L.g);
         slice_mma(u, wu2, u1);
         slice_mma(r, wr2, r1);
         ug[k] = sigm4(u);
         const f4 hs = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
-        lds_write_slice(Cb(k), sigm4(r) * hs, w, L);
+        opnd_write(Cb(k), sigm4(r) * hs, w, L);
       }
     __syncthreads();
     // ---- P6: candidate state, first layer (combined = [x, r*h'])
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 rhf[4];
-        lds_read_tile(rhf, Cb(k), L);
-        const Opnd rh = make_opnd(rhf);
-        f4 xf[4];
-        lds_read_tile(xf, Xb(k), L);                       // the x_t tile again (not kept live across the phases)
-        const Opnd xin = make_opnd(xf);
+        const Opnd rh = opnd_read(Cb(k), L);
+        const Opnd xin = opnd_read(Xb(k), L);              // the x_t tile again (not kept live across the phases)
         f4 n1 = vec_slice(gru_img + G::BN0, w, L.g);
         slice_mma(n1, wnx, xin);
         slice_mma(n1, wnh, rh);
-        lds_write_slice(Ab(k), tanh4(n1), w, L);
+        opnd_write(Ab(k), tanh4(n1), w, L);
       }
     __syncthreads();
     // ---- P7: candidate state, second layer; gated blend; masked update; picks
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
       if (k < T) {
-        f4 n1f[4];
-        lds_read_tile(n1f, Ab(k), L);
-        const Opnd n1 = make_opnd(n1f);
+        const Opnd n1 = opnd_read(Ab(k), L);
         f4 nw = vec_slice(gru_img + G::BN2, w, L.g);
         slice_mma(nw, wn2g, n1);
         f4 hs = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
@@ -422,6 +440,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
           hs[c] = valid ? hn : hs[c];
         }
         lds_write_slice(Yb(k), hs, w, L);
+        opnd_write(Ys(k), hs, w, L);
         const int64_t row = rowk[k];
         if (inb[k] && row < N) {
           if (eosk[k] == idx) *reinterpret_cast<f4*>(kept + row * 64 + 16 * w + 4 * L.g) = hs;
