@@ -152,6 +152,7 @@ def main():
     import torch
     from trajsde_amd import _lib
     from trajsde_amd.models.model_base_mix_sde import PredictionModelSDENet
+    from trajsde_amd import runtime as runtime_mod
     from trajsde_amd.runtime import NoiseSpec
     from trajsde_amd.synth import CONFIGS, synth
 
@@ -206,9 +207,9 @@ def main():
                     self.y0s.append(b.y.clone())
             torch.cuda.synchronize()
 
-        # Steps are dealt round-robin over the streams so that the host-side part of step i+1 (graph preparation incl. its
-        # one stream sync, launches) and its latency-bound kernels overlap the tail of step i.  Every step is a complete
-        # forward of one batch.
+        # Steps are dealt round-robin over the streams so that the latency-bound kernels of step i+1 overlap the tail of
+        # step i.  The forward is sync-free (runtime.sync_free: list lengths stay on the device), so the host only
+        # enqueues.  Every step is a complete forward of one batch.
         def step(self, i, single_stream=False):
             k = 0 if single_stream else i % n_streams
             b = self.batches[k]
@@ -217,7 +218,7 @@ def main():
                 return model(b, noise=NoiseSpec(seed=10_000 * (rank + 1) + i))
 
         def e_aa(self):
-            return self.batches[0]["_trajsde_graph"].graph.E_aa
+            return self.batches[0]["_trajsde_graph"].true_counts()["E_aa"]       # (reads the device-side count: outside timed regions)
 
     def sync_all():
         if dist is not None:
@@ -280,7 +281,7 @@ def main():
                                    f"SDE decoder), synth({', '.join(f'{k}={v}' for k, v in spec['synth'].items())})",
                        "scenes_per_gpu": wl.scenes, "agents_per_scene": wl.skw["n"], "num_modes": spec["num_modes"],
                        "future_steps": spec["future_steps"], "aa_edges_per_step": int(e_aa), "parallelism": f"scene-shard x{world}",
-                       "streams_per_gpu": n_streams, "rccl_ranks_seen": rccl_ranks},
+                       "streams_per_gpu": n_streams, "rccl_ranks_seen": rccl_ranks, "sync_free_forward": bool(runtime_mod.sync_free())},
             "timing": {"windows_ms": [1e3 * w for w in windows], "reported": "median window", "steps_per_window": args.steps},
             "roofline": roof,
         }

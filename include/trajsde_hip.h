@@ -162,6 +162,11 @@ typedef struct {
    * sender contributes; they make the index work of ENC:107-118 / ENC:198 checkable edge for edge) */
   const int32_t* aa_src;      /* [E_aa] sending actor (a real actor, < N); null unless trajsde_export_senders(1) */
   const int32_t* la_lane;     /* [E_la] lane segment; null unless trajsde_export_senders(1)                      */
+  /* ABI 5: the three list lengths on the DEVICE (counts[1] = E_aa, [2] = E_g, [3] = E_la).  With exact = 0
+   * (trajsde_graph_prepare_async) the E_* fields above are UPPER BOUNDS that size buffers and grids, the kernels of the
+   * inference forward read the true lengths here, and no host synchronisation happens anywhere in the forward. */
+  const int32_t* counts;
+  int32_t exact;              /* 1: E_aa / E_g / E_la are the true lengths (trajsde_graph_prepare) */
 } trajsde_graph;
 
 /* Process-wide switch: have trajsde_graph_compact also write the sender of every compacted record (aa_src / la_lane above).
@@ -179,6 +184,16 @@ int64_t trajsde_graph_ws_bytes(const trajsde_batch* b);
 int trajsde_graph_prepare(const trajsde_batch* b, const float* rotate_mat, float local_radius,
                           const trajsde_noise* fake_noise /* z: [A,H,2] */, void* ws, int64_t ws_bytes,
                           trajsde_graph* out, void* stream);
+/* trajsde_graph_prepare without the stream synchronisation: the counts stay on the device (out->counts), the E_* fields
+ * are upper bounds (E_aa <= 2 * H * E, E_g <= E, E_la <= E_al) and out->exact = 0.  Accepted by
+ * trajsde_graph_compact and by the inference entry points trajsde_encoder_forward / trajsde_aggregator_forward_heads in
+ * their default (fused) kernel forms; every other entry point (backward, training, OOD, vanilla variant) needs an exact
+ * graph and says so. */
+int trajsde_graph_prepare_async(const trajsde_batch* b, const float* rotate_mat, float radius, const trajsde_noise* fake_noise,
+                                void* ws, int64_t ws_bytes, trajsde_graph* out, void* stream);
+/* 1 when the kernel forms this process selected (environment switches of csrc/stages.hip) accept a graph from
+ * trajsde_graph_prepare_async, i.e. the default build and environment */
+int trajsde_sync_free_supported(void);
 int64_t trajsde_graph_edges_ws_bytes(const trajsde_batch* b, const trajsde_graph* g);
 int trajsde_graph_compact(const trajsde_batch* b, const float* rotate_mat, void* ws, int64_t ws_bytes,
                           void* edges_ws, int64_t edges_ws_bytes, trajsde_graph* out, void* stream);

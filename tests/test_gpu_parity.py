@@ -581,3 +581,67 @@ def test_errors_are_loud(dev):
     L = _lib.lib()
     assert L.trajsde_decoder_forward(0, 1, 1, None, None, None, None, 0, None, 0.0, None, None, 0, None, None, None) != 0
     assert b"null" in L.trajsde_last_error() or b"empty" in L.trajsde_last_error()
+
+
+@pytest.mark.parametrize("S,n,L,kw", [
+    (3, 14, 6, dict(mixed_source=True, history_dropout=0.4)),
+    (1, 1, 2, dict()),                                                   # no agent-agent edge at all
+    (6, 90, 40, dict(nus_sparsity=True)),                                # E_aa > 65536: streams of more than one edge
+])
+def test_sync_free_forward_is_bitwise_the_exact_forward(S, n, L, kw, dev):
+    """trajsde_graph_prepare_async leaves the list lengths on the device and hands the kernels bounds; the kernels derive the
+    same stream cut from the device-side count, so the outputs are bit-identical -- and the graph can still be made exact
+    for an entry point that needs host-side lengths"""
+    from trajsde_amd import runtime
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    K, T = 3, 6
+    batch = synth(S=S, n=n, L=L, F=T, box=60.0, seed=5, **kw)
+    model, cfg = H.build_model(K, T, 0.5, init_seed=3)
+    model = model.to(dev).eval()
+    assert runtime.sync_free()                                           # the default
+    outs = {}
+    for mode in (True, False):
+        prev = runtime.set_sync_free(mode)
+        try:
+            data = batch.to(dev)
+            with torch.no_grad():
+                o = model(data, noise=NoiseSpec(seed=12))
+            gc = data["_trajsde_graph"]
+            assert bool(gc.graph.exact) == (not mode)
+            outs[mode] = ({k: v.clone() for k, v in o.items() if torch.is_tensor(v)}, gc.true_counts(), gc)
+        finally:
+            runtime.set_sync_free(prev)
+    assert outs[True][1] == outs[False][1]
+    assert {"loc", "pi", "diff_in", "diff_out"} <= set(outs[True][0])
+    for k in outs[True][0]:
+        assert torch.equal(outs[True][0][k], outs[False][0][k]), k
+    gc = outs[True][2]
+    bound = gc.graph.E_aa
+    gc.make_exact()
+    assert gc.graph.exact and gc.graph.E_aa == outs[False][1]["E_aa"] <= bound
+    lists = gc.edge_lists()
+    assert lists["aa_dst"].numel() == gc.graph.E_aa
+    model.check_range()
+
+
+def test_training_after_a_sync_free_forward_of_the_same_batch(dev):
+    """the training entry points need exact list lengths: they make a graph left by a sync-free forward exact themselves"""
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    K, T = 2, 5
+    batch = synth(S=2, n=12, L=5, F=T, box=40.0, seed=8)
+    model, cfg = H.build_model(K, T, 0.5, init_seed=4)
+    model = model.to(dev)
+    data = batch.to(dev)
+    y0 = data.y.clone()
+    model.eval()
+    with torch.no_grad():
+        model(data, noise=NoiseSpec(seed=3))
+    assert not data["_trajsde_graph"].graph.exact
+    model.train()
+    data.y = y0
+    loss = model.training_step(data, 0, noise=NoiseSpec(seed=3))
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert data["_trajsde_graph"].graph.exact

@@ -11,7 +11,8 @@ STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGA
 STAGE_ENCODER_GRID, STAGE_DECODER_MLP, STAGE_DECODER_MLP_BWD, STAGE_ENCODER_GRID_BWD = 6, 7, 8, 9
 
 
-ABI_VERSION = 4          # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4)
+ABI_VERSION = 5          # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4);
+                         # device-side list lengths + trajsde_graph_prepare_async (5)
 
 
 class TrajsdeError(RuntimeError):
@@ -41,7 +42,7 @@ class Graph(C.Structure):
                 ("x_fake", C.c_void_p), ("aa_geom", C.c_void_p), ("aa_dst", C.c_void_p), ("aa_segptr", C.c_void_p),
                 ("g_geom", C.c_void_p), ("g_src", C.c_void_p), ("g_dst", C.c_void_p), ("g_segptr", C.c_void_p),
                 ("la_geom", C.c_void_p), ("la_dst", C.c_void_p), ("la_segptr", C.c_void_p),
-                ("aa_src", C.c_void_p), ("la_lane", C.c_void_p)]
+                ("aa_src", C.c_void_p), ("la_lane", C.c_void_p), ("counts", C.c_void_p), ("exact", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -62,6 +63,8 @@ SIGNATURES = {
     "trajsde_rotate": (C.c_int, [P, I32, P, I32, P, P, P]),
     "trajsde_graph_ws_bytes": (I64, [C.POINTER(Batch)]),
     "trajsde_graph_prepare": (C.c_int, [C.POINTER(Batch), P, F32, C.POINTER(Noise), P, I64, C.POINTER(Graph), P]),
+    "trajsde_graph_prepare_async": (C.c_int, [C.POINTER(Batch), P, F32, C.POINTER(Noise), P, I64, C.POINTER(Graph), P]),
+    "trajsde_sync_free_supported": (C.c_int, []),
     "trajsde_graph_edges_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
     "trajsde_graph_compact": (C.c_int, [C.POINTER(Batch), P, P, I64, P, I64, C.POINTER(Graph), P]),
     "trajsde_encoder_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),

@@ -320,7 +320,7 @@ static int aggregator_tape(const trajsde_batch* b, const trajsde_graph* g, const
   const int64_t N = b->N, E = g->E_g, ntiles = (N + 15) / 16, etiles = (E + 15) / 16;
   if (E > 0)
     TS_LAUNCH(k_edge_embed<true>, tile_grid(etiles, 1024, EdgeL6::EMB_SIZE * 4), 1024, EdgeL6::EMB_SIZE * 4, st, blob_fwd + AggBlob::REL6,
-              g->g_geom, E, w.rel, 0);
+              g->g_geom, EdgeCount{E, nullptr, 0}, w.rel, 0);
   const float* x = local_embed;
   for (int l = 0; l < nl; ++l) {
     const float* lb = blob_fwd + AggBlob::layer(l);
@@ -361,6 +361,7 @@ int trajsde_aggregator_forward_train(const trajsde_batch* b, const trajsde_graph
   TS_REQUIRE(b && g && blob_fwd && local_embed && ws && global_embed, "aggregator_forward_train: null pointer");
   TS_REQUIRE(num_heads == 8 || num_heads == 4, "aggregator_forward_train: num_heads must be 8 or 4");
   TS_REQUIRE(g->g_src && g->g_segptr, "aggregator_forward_train: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(g->exact, "aggregator_forward_train: needs exact list lengths (trajsde_graph_prepare, not _async)");
   TS_REQUIRE(num_layers >= 1 && num_layers <= 8 && num_modes > 0, "aggregator_forward_train: bad layer/mode count");
   TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "aggregator_forward_train: dropout p must be in [0, 1)");
   TS_REQUIRE(!state_bf16(), "aggregator_forward_train: the training tape is fp32; switch trajsde_state_storage(0)");
@@ -387,6 +388,7 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
   auto drop_of = [&](int layer) { return dropout ? make_drop(dropout->p, dropout->seed, 2 + layer) : no_drop(); };   // dropout.hpp block ids
   TS_REQUIRE(num_heads == 8 || num_heads == 4, "aggregator_backward: num_heads must be 8 or 4");
   TS_REQUIRE(g->g_src && g->g_segptr, "aggregator_backward: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(g->exact, "aggregator_backward: needs exact list lengths (trajsde_graph_prepare, not _async)");
   TS_REQUIRE(num_layers >= 1 && num_layers <= 8 && num_modes > 0, "aggregator_backward: bad layer/mode count");
   const std::vector<std::string> names = stage_param_names(TRAJSDE_STAGE_AGGREGATOR_BWD, num_layers, num_modes);
   TS_REQUIRE(n_grads == int(names.size()), "aggregator_backward: gradient count does not match trajsde_param_count(AGGREGATOR_BWD)");

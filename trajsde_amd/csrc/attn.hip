@@ -216,10 +216,13 @@ __device__ __forceinline__ void seg_flush(const SegState& S, float* __restrict__
 
 template <int THREADS, bool DROP>
 __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict__ img_g, const float* __restrict__ geom,
-                                                        const int32_t* __restrict__ dst, const float* __restrict__ q, int64_t E, int C,
+                                                        const int32_t* __restrict__ dst, const float* __restrict__ q, EdgeCount ec, int C_host,
                                                         float* __restrict__ rec, int heads, const int32_t* __restrict__ segptr, DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using EL = EdgeL6;
+  const int64_t E = edge_count(ec);
+  const int C = stream_len(ec, E, C_host);
+  if (E <= 0) return;                                      // (only reachable when the count lives on the device)
   stage_blob(lds, img_g, EL::SIZE);
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -294,13 +297,14 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
   if (cur0 >= 0) seg_flush(S0, rec, int64_t(cur0) + s0, L.g);
   if (cur1 >= 0) seg_flush(S1, rec, int64_t(cur1) + s1, L.g);
 }
-template __global__ void k_edge_attn2<512, false>(const float*, const float*, const int32_t*, const float*, int64_t, int, float*, int, const int32_t*, DropArg);
-template __global__ void k_edge_attn2<512, true>(const float*, const float*, const int32_t*, const float*, int64_t, int, float*, int, const int32_t*, DropArg);
+template __global__ void k_edge_attn2<512, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg);
+template __global__ void k_edge_attn2<512, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg);
 
 // records of one target -> agg row.  One wave per target, lane = feature f (jt = f>>4, g = (f>>2)&3); a target's records sit
 // at slots target + (first stream .. last stream) of its segment and are combined in that order.
-__global__ __launch_bounds__(256) void k_seg_merge(const int32_t* __restrict__ segptr, const float* __restrict__ rec, int C, int64_t R,
-                                                   float* __restrict__ agg) {
+__global__ __launch_bounds__(256) void k_seg_merge(const int32_t* __restrict__ segptr, const float* __restrict__ rec, EdgeCount ec, int C_host,
+                                                   int64_t R, float* __restrict__ agg) {
+  const int C = stream_len(ec, edge_count(ec), C_host);
   const int lane = threadIdx.x & 63;
   const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (node >= R) return;
@@ -327,9 +331,10 @@ __global__ __launch_bounds__(256) void k_seg_merge(const int32_t* __restrict__ s
 
 // global interactor: relative-pose embedding only (AGG:42-51), reused by all layers
 template <bool X6>
-__global__ __launch_bounds__(1024) void k_edge_embed(const float* __restrict__ img_g, const float* __restrict__ geom, int64_t E,
+__global__ __launch_bounds__(1024) void k_edge_embed(const float* __restrict__ img_g, const float* __restrict__ geom, EdgeCount ec,
                                                     float* __restrict__ emb_out, int st_bf16) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int64_t E = edge_count(ec);
   stage_blob(lds, img_g, X6 ? int(EdgeL6::EMB_SIZE) : int(EdgeL::EMB_SIZE));
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -822,8 +827,8 @@ __global__ __launch_bounds__(512) void k_mode_proj(const float* __restrict__ nor
 
 template __global__ void k_edge_kv<false>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*, int);
 template __global__ void k_edge_kv<true>(const float*, const float*, const int32_t*, const float*, int64_t, float*, float*, int);
-template __global__ void k_edge_embed<false>(const float*, const float*, int64_t, float*, int);
-template __global__ void k_edge_embed<true>(const float*, const float*, int64_t, float*, int);
+template __global__ void k_edge_embed<false>(const float*, const float*, EdgeCount, float*, int);
+template __global__ void k_edge_embed<true>(const float*, const float*, EdgeCount, float*, int);
 template __global__ void k_global_edge<false>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
 template __global__ void k_global_edge<true>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
 template __global__ void k_node_update<false>(const float*, const float*, const float*, const float*, int64_t, float*, float*, DropArg);

@@ -846,6 +846,7 @@ int trajsde_encoder_forward_train(const trajsde_batch* b, const trajsde_graph* g
                                   float* local_embed, float* diff_pick, const trajsde_dropout* dropout, void* stream_) {
   TS_REQUIRE(b && g && rot && blob_fwd && step_tab && ws && local_embed && diff_pick, "encoder_forward_train: null pointer");
   TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_forward_train: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(g->exact, "encoder_forward_train: needs exact list lengths (trajsde_graph_prepare, not _async)");
   TS_REQUIRE(b->A > 0 && g->Nt == b->N + b->A, "encoder_forward_train: graph was prepared without the fake-agent rows");
   TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "encoder_forward_train: dropout p must be in [0, 1)");
   TS_REQUIRE(!state_bf16(), "encoder_forward_train: the training tape is fp32; switch trajsde_state_storage(0)");
@@ -878,6 +879,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   const DropArg drop_aa = dropout ? make_drop(dropout->p, dropout->seed, 0) : no_drop();     // block ids of dropout.hpp
   const DropArg drop_al = dropout ? make_drop(dropout->p, dropout->seed, 1) : no_drop();
   TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_backward: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(g->exact, "encoder_backward: needs exact list lengths (trajsde_graph_prepare, not _async)");
   TS_REQUIRE(b->A > 0 && g->Nt == b->N + b->A, "encoder_backward: graph was prepared without the fake-agent rows");
   const std::vector<std::string> names = stage_param_names(TRAJSDE_STAGE_ENCODER_BWD, 0, 0);
   TS_REQUIRE(n_grads == int(names.size()), "encoder_backward: gradient count does not match trajsde_param_count(ENCODER_BWD)");
@@ -1015,6 +1017,7 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
                                   int64_t ws_bytes, float* const* grads, int n_grads, void* stream_) {
   TS_REQUIRE(b && g && rot && blob_fwd && blob_bwd && d_local && ws && grads, "encoder_grid_backward: null pointer");
   TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_grid_backward: graph not compacted");
+  TS_REQUIRE(g->exact, "encoder_grid_backward: needs exact list lengths (trajsde_graph_prepare, not _async)");
   TS_REQUIRE(b->A == 0 && g->Nt == b->N && b->H == 21, "encoder_grid_backward: graph with A = 0 and 21 history steps expected");
   TS_REQUIRE(num_heads == 8 || num_heads == 4, "encoder_grid_backward: num_heads must be 8 or 4");
   const int nl = num_temporal_layers;

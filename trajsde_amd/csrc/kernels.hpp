@@ -26,6 +26,19 @@ struct AttnPlan {
   int64_t nstreams;                               // ceil(E / C)
   int64_t rec_slots(int64_t targets) const { return targets + nstreams + 1; }
 };
+// the list length of a launch: known on the host (dev == null), or only an upper bound `E` with the true value on the device
+// (the sync-free forward, trajsde_graph_prepare_async) -- the kernels then derive the same C from it that attn_plan would
+struct EdgeCount {
+  int64_t E;
+  const int32_t* dev;
+  int streams_target;
+};
+__device__ __forceinline__ int64_t edge_count(const EdgeCount& c) { return c.dev ? int64_t(*c.dev) : c.E; }
+__device__ __forceinline__ int stream_len(const EdgeCount& c, int64_t E, int C_host) {
+  if (!c.dev) return C_host;
+  const int C = int((E + c.streams_target - 1) / c.streams_target);
+  return C < 1 ? 1 : C;
+}
 inline AttnPlan attn_plan(int64_t E, int streams_target = SEG_STREAMS_512) {
   AttnPlan p;
   p.C = int((E + streams_target - 1) / streams_target);
@@ -34,7 +47,7 @@ inline AttnPlan attn_plan(int64_t E, int streams_target = SEG_STREAMS_512) {
   return p;
 }
 template <int THREADS, bool DROP>
-__global__ void k_edge_attn2(const float* img, const float* geom, const int32_t* dst, const float* q, int64_t E, int C, float* rec, int heads,
+__global__ void k_edge_attn2(const float* img, const float* geom, const int32_t* dst, const float* q, EdgeCount ec, int C, float* rec, int heads,
                              const int32_t* segptr, DropArg drop);
 // launch the instantiation selected by (heads, bf16 state storage, dropout)
 #define TS_GLOBAL_ATTN(heads, bf16, drop, ...)                                                                       \
@@ -48,9 +61,9 @@ __global__ void k_edge_attn2(const float* img, const float* geom, const int32_t*
       else { if (_d) TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, false, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, false, false>), __VA_ARGS__, drop); } \
     }                                                                                                               \
   } while (0)
-__global__ void k_seg_merge(const int32_t* segptr, const float* rec, int C, int64_t R, float* agg);
+__global__ void k_seg_merge(const int32_t* segptr, const float* rec, EdgeCount ec, int C, int64_t R, float* agg);
 template <bool X6>
-__global__ void k_edge_embed(const float* img, const float* geom, int64_t E, float* emb_out, int st_bf16);
+__global__ void k_edge_embed(const float* img, const float* geom, EdgeCount ec, float* emb_out, int st_bf16);
 template <bool X6>
 __global__ void k_global_edge(const float* img, const float* rel, const int32_t* src, const int32_t* dst, const float* q,
                               const float* kn, const float* vn, int64_t E, float* logits, float* v);

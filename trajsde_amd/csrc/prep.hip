@@ -10,6 +10,7 @@
 // The compacted lists carry the pre-rotated 2-d geometry the edge kernels consume (16 B per edge).
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -478,8 +479,8 @@ int64_t trajsde_graph_ws_bytes(const trajsde_batch* b) {
   return w.total;
 }
 
-int trajsde_graph_prepare(const trajsde_batch* b, const float* rot, float radius, const trajsde_noise* fake_noise, void* ws,
-                          int64_t ws_bytes, trajsde_graph* out, void* stream_) {
+static int graph_prepare(const trajsde_batch* b, const float* rot, float radius, const trajsde_noise* fake_noise, void* ws,
+                         int64_t ws_bytes, trajsde_graph* out, void* stream_, bool sync) {
   if (int rc = check_batch(b)) return rc;
   TS_REQUIRE(rot && ws && out, "graph_prepare: null pointer");
   PrepWs w(b, ws, ws_bytes);
@@ -528,14 +529,34 @@ int trajsde_graph_prepare(const trajsde_batch* b, const float* rot, float radius
   k_segptr_from_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, w.la_rowptr, w.cpos_la, w.la_segptr);
   k_collect_counts<<<1, 64, 0, st>>>(w.n_aa, E, Ea, w.aa_segptr, w.cpos_g, w.cpos_la, radius, w.counts);
   TS_LAUNCH_CHECK("graph_prepare kernels");
-  int32_t h[4];
-  TS_HIP(hipMemcpyAsync(h, w.counts, sizeof(h), hipMemcpyDeviceToHost, st));
-  TS_HIP(hipStreamSynchronize(st));
+  int32_t h[4] = {0, 0, 0, 0};
+  if (sync) {
+    TS_HIP(hipMemcpyAsync(h, w.counts, sizeof(h), hipMemcpyDeviceToHost, st));
+    TS_HIP(hipStreamSynchronize(st));
+  } else {
+    // upper bounds: every (t, in-edge) candidate of every extended node survives.  The fake rows alias their agents' CSR
+    // rows, whose in-degrees sum to at most E (repeated input edges count, so A * (N - 1) is NOT a bound)
+    const int64_t aa_max = int64_t(H) * 2 * int64_t(E);
+    (void)A;
+    TS_REQUIRE(aa_max < (int64_t(1) << 31) - 2, "graph_prepare_async: too many (t, edge) candidates for int32 positions");
+    h[1] = int32_t(aa_max); h[2] = E; h[3] = Ea;
+  }
   std::memset(out, 0, sizeof(*out));
+  out->counts = w.counts; out->exact = sync ? 1 : 0;
   out->Nt = Nt; out->E_ext = E; out->E_aa = h[1]; out->E_g = h[2]; out->E_la = h[3];
   out->orig = w.orig; out->nus_mask = w.nus; out->eos_idx = w.eos; out->pick_slot = w.pick_slot; out->x_fake = w.x_fake;
   out->aa_segptr = w.aa_segptr; out->g_segptr = w.g_segptr; out->la_segptr = w.la_segptr;
   return TRAJSDE_OK;
+}
+
+int trajsde_graph_prepare(const trajsde_batch* b, const float* rot, float radius, const trajsde_noise* fake_noise, void* ws,
+                          int64_t ws_bytes, trajsde_graph* out, void* stream_) {
+  return graph_prepare(b, rot, radius, fake_noise, ws, ws_bytes, out, stream_, true);
+}
+
+int trajsde_graph_prepare_async(const trajsde_batch* b, const float* rot, float radius, const trajsde_noise* fake_noise, void* ws,
+                                int64_t ws_bytes, trajsde_graph* out, void* stream_) {
+  return graph_prepare(b, rot, radius, fake_noise, ws, ws_bytes, out, stream_, false);
 }
 
 int64_t trajsde_graph_edges_ws_bytes(const trajsde_batch* b, const trajsde_graph* g) {

@@ -5,6 +5,7 @@
 #include "kernels.hpp"
 #include "layouts.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace tsde {
@@ -23,7 +24,17 @@ static int pair_threads() { static int t = []() { const char* e = getenv("TRAJSD
 // two-kernel form (k_edge_kv2 -> HBM -> k_seg_softmax_agg) that the backward's recomputation still uses
 static bool attn_fused() { static bool v = []() { const char* e = getenv("TRAJSDE_ATTN_FUSED"); return !(e && atoi(e) == 0); }(); return v && edge_x6() && edge_pair(); }
 static int fused_threads() { return 512; }   // 2 waves per SIMD: 196 VGPRs, weight image + 8 x 8 KB of parked query rows = 147 KB of LDS
-static AttnPlan fused_plan(int64_t E) { return attn_plan(E, 256 * 32 * (fused_threads() / 64)); }
+static bool global_fused_env() { static const bool v = []() { const char* e = getenv("TRAJSDE_GLOBAL_UNFUSED"); return !(e && atoi(e) != 0); }(); return v; }
+static int fused_streams() { return 256 * 32 * (fused_threads() / 64); }
+static AttnPlan fused_plan(int64_t E) { return attn_plan(E, fused_streams()); }
+// record slots of a list whose length is only bounded by E: any E' <= E cuts into at most min(E, streams) streams
+static int64_t fused_rec_slots(int64_t E, bool exact, int64_t targets) {
+  return exact ? fused_plan(E).rec_slots(targets) : targets + std::min<int64_t>(E, fused_streams()) + 1;
+}
+// an inexact graph (trajsde_graph_prepare_async) carries its list lengths on the device
+static EdgeCount count_of(const trajsde_graph* g, int which, int64_t E) {
+  return EdgeCount{E, g->exact ? nullptr : g->counts + which, fused_streams()};
+}
 static int threads_edge() { static int t = env_threads("TRAJSDE_THREADS_EDGE", 1024); return t; }
 static int threads_node() { static int t = env_threads("TRAJSDE_THREADS_NODE", 512); return t; }
 static int threads_recur() { static int t = env_threads("TRAJSDE_THREADS_RECUR", 256); return t; }
@@ -39,8 +50,8 @@ struct EncWs {
     const int64_t R = int64_t(b->H) * g->Nt, N = b->N;
     const bool fused = attn_fused();
     center = c.take<float>(R * 64); cn = c.take<float>(R * 64); q = c.take<float>(R * 64);
-    rec = c.take<float>(fused ? fused_plan(g->E_aa).rec_slots(R) * SEG_REC : 4);
-    al_rec = c.take<float>(fused ? fused_plan(g->E_la).rec_slots(N) * SEG_REC : 4);
+    rec = c.take<float>(fused ? fused_rec_slots(g->E_aa, g->exact != 0, R) * SEG_REC : 4);
+    al_rec = c.take<float>(fused ? fused_rec_slots(g->E_la, g->exact != 0, N) * SEG_REC : 4);
     logits = c.take<float>(fused ? 8 : int64_t(g->E_aa) * 8 + 8); v = c.take<float>(fused ? 64 : int64_t(g->E_aa) * 64 + 64);
     agg = c.take<float>(R * 64); x1 = c.take<float>(R * 64); xn2 = c.take<float>(R * 64); aa_out = c.take<float>(R * 64);
     hA = c.take<float>(int64_t(g->Nt) * 64); hB = c.take<float>(int64_t(g->Nt) * 64); lat = c.take<float>(N * 64);
@@ -107,20 +118,22 @@ static int attention_tail(const NodeImgs& im, const int32_t* segptr, const float
 
 // embedding + lin_k|lin_v + softmax-aggregate of one edge list in the fused form: records, then one merged agg row per target
 static int fused_edge_attention(const char* tag, bool dominant, const float* img, const float* geom, const int32_t* dst, const float* q,
-                                int64_t E, const int32_t* segptr, int64_t R, float* rec, float* agg, int heads, hipStream_t st,
+                                const EdgeCount& ec, const int32_t* segptr, int64_t R, float* rec, float* agg, int heads, hipStream_t st,
                                 const DropArg& drop = no_drop()) {
+  const int64_t E = ec.E;
   const AttnPlan pl = fused_plan(E);
   if (E > 0) {
     const int threads = drop.p > 0.f ? 512 : fused_threads();             // the dropout form is built for 512 threads
-    const int64_t waves = (pl.nstreams + 31) / 32;
+    // a bounded list: enough waves for the most streams any E' <= E cuts into; the ones beyond the true count leave at once
+    const int64_t waves = ((ec.dev ? std::min<int64_t>(E, fused_streams()) : pl.nstreams) + 31) / 32;
     const int grid = int((waves + threads / 64 - 1) / (threads / 64));
     const int lds = (EdgeL6::SIZE + (threads / 64) * 2048) * 4;              // weight image + every wave's parked query rows (8 KB)
     if (drop.p > 0.f)
-      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, true>), grid, 512, lds, st, img, geom, dst, q, E, pl.C, rec, heads, segptr, drop);
+      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, true>), grid, 512, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop);
     else
-      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, false>), grid, 512, lds, st, img, geom, dst, q, E, pl.C, rec, heads, segptr, drop);
+      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, false>), grid, 512, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop);
   }
-  TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, pl.C, R, agg);
+  TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, ec, pl.C, R, agg);
   return TRAJSDE_OK;
 }
 
@@ -129,6 +142,8 @@ static int fused_edge_attention(const char* tag, bool dominant, const float* img
 using namespace tsde;
 
 extern "C" {
+
+int trajsde_sync_free_supported(void) { return attn_fused() && global_fused_env() ? 1 : 0; }
 
 int64_t trajsde_encoder_ws_bytes(const trajsde_batch* b, const trajsde_graph* g) {
   if (!b || !g) return -1;
@@ -145,7 +160,7 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
             b->x, g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
   const NodeImgs im{blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, blob + EncBlob::AA_UPD6, blob + EncBlob::AA_FFN6};
   if (attn_fused()) {
-    if (int rc = fused_edge_attention("k_edge_kv[aa]", true, blob + EncBlob::AA_EDGE6, g->aa_geom, g->aa_dst, w.q, int64_t(g->E_aa), g->aa_segptr, R,
+    if (int rc = fused_edge_attention("k_edge_kv[aa]", true, blob + EncBlob::AA_EDGE6, g->aa_geom, g->aa_dst, w.q, count_of(g, 1, g->E_aa), g->aa_segptr, R,
                                       w.rec, w.agg, heads, st, drop))
       return rc;
     return update_ffn(im, w.agg, w.cn, w.center, R, w.x1, w.xn2, aa_out, st, drop, state_bf16());      // aa_out in the state storage type
@@ -221,7 +236,7 @@ static int run_al_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
             blob + EncBlob::AL_Q, lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
   const NodeImgs im{blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, blob + EncBlob::AL_UPD6, blob + EncBlob::AL_FFN6};
   if (attn_fused()) {
-    if (int rc = fused_edge_attention("k_edge_kv[al]", false, blob + EncBlob::AL_EDGE6, g->la_geom, g->la_dst, w.al_q, int64_t(g->E_la), g->la_segptr,
+    if (int rc = fused_edge_attention("k_edge_kv[al]", false, blob + EncBlob::AL_EDGE6, g->la_geom, g->la_dst, w.al_q, count_of(g, 3, g->E_la), g->la_segptr,
                                       int64_t(N), w.al_rec, w.al_agg, heads, st, drop))
       return rc;
     return update_ffn(im, w.al_agg, w.al_xn, lat, N, w.al_x1, w.al_xn2, local_embed, st, drop);
@@ -249,6 +264,7 @@ int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, cons
   const DropArg drop_aa = dropout ? make_drop(dropout->p, dropout->seed, 0) : no_drop();     // block ids of dropout.hpp
   const DropArg drop_al = dropout ? make_drop(dropout->p, dropout->seed, 1) : no_drop();
   TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_forward: graph not compacted (call trajsde_graph_compact)");
+  TS_REQUIRE(g->exact || (attn_fused() && g->counts), "encoder_forward: a graph from trajsde_graph_prepare_async needs the fused edge attention");
   TS_REQUIRE(b->A > 0 && g->Nt == b->N + b->A, "encoder_forward: graph was prepared without the fake-agent rows");
   EncWs w(b, g, ws, ws_bytes);
   if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_forward: workspace too small");
@@ -275,6 +291,7 @@ int trajsde_encoder_forward_ood(const trajsde_batch* b, const trajsde_graph* g, 
                                 int64_t ws_bytes, float* local_embed, float* stds, void* stream_) {
   TS_REQUIRE(b && g && rot && blob && step_tab && ws && local_embed && stds, "encoder_forward_ood: null pointer");
   TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_forward_ood: graph not compacted");
+  TS_REQUIRE(g->exact, "encoder_forward_ood: needs exact list lengths (trajsde_graph_prepare, not _async)");
   TS_REQUIRE(b->A == 0 && g->Nt == b->N, "encoder_forward_ood: prepare the graph with A = 0 (no fake agents)");
   TS_REQUIRE(n_samples >= 1, "encoder_forward_ood: n_samples < 1");
   if (ws_bytes < trajsde_encoder_ood_ws_bytes(b, g, n_samples)) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_forward_ood: workspace too small");
@@ -308,6 +325,7 @@ int trajsde_encoder_grid_forward(const trajsde_batch* b, const trajsde_graph* g,
                                  int num_temporal_layers, void* ws, int64_t ws_bytes, float* local_embed, void* stream_) {
   TS_REQUIRE(b && g && rot && blob && ws && local_embed, "encoder_grid_forward: null pointer");
   TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_grid_forward: graph not compacted");
+  TS_REQUIRE(g->exact, "encoder_grid_forward: needs exact list lengths (trajsde_graph_prepare, not _async)");
   TS_REQUIRE(b->A == 0 && g->Nt == b->N, "encoder_grid_forward: prepare the graph with A = 0 (no fake agents)");
   TS_REQUIRE(b->H == 21, "encoder_grid_forward: the temporal kernels are built for historical_steps = 21");
   TS_REQUIRE(num_heads == 8 || num_heads == 4, "encoder_grid_forward: num_heads must be 8 or 4");
@@ -366,10 +384,10 @@ int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph
   if (E > 0) {
     if (edge_x6())
       TS_LAUNCH(k_edge_embed<true>, tile_grid(etiles, threads_edge(), EdgeL6::EMB_SIZE * 4), threads_edge(), EdgeL6::EMB_SIZE * 4, st,
-                blob + AggBlob::REL6, g->g_geom, E, w.rel, state_bf16() ? 1 : 0);
+                blob + AggBlob::REL6, g->g_geom, count_of(g, 2, E), w.rel, state_bf16() ? 1 : 0);
     else
       TS_LAUNCH(k_edge_embed<false>, tile_grid(etiles, threads_edge(), EdgeL::EMB_SIZE * 4), threads_edge(), EdgeL::EMB_SIZE * 4, st,
-                blob + AggBlob::REL, g->g_geom, E, w.rel, state_bf16() ? 1 : 0);
+                blob + AggBlob::REL, g->g_geom, count_of(g, 2, E), w.rel, state_bf16() ? 1 : 0);
   }
   const float* x = local_embed;
   float* bufs[2] = {w.xa, w.xb};
@@ -379,11 +397,11 @@ int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph
               w.xn, w.q, w.kn, w.vn);
     float* out = bufs[i & 1];
     const NodeImgs im{lb + AggLayerL::UPD, lb + AggLayerL::FFN, lb + AggLayerL::UPD6, lb + AggLayerL::FFN6};
-    static const bool fused_env = []() { const char* e = getenv("TRAJSDE_GLOBAL_UNFUSED"); return !(e && atoi(e) != 0); }();
-    const bool fused = fused_env || num_heads != 8;           // the unfused edge kernel exists for 8 heads only
+    const bool fused = global_fused_env() || num_heads != 8;           // the unfused edge kernel exists for 8 heads only
     const DropArg drop = dropout ? make_drop(dropout->p, dropout->seed, 2 + i) : no_drop();   // block ids of dropout.hpp
     TS_REQUIRE(fused || drop.p == 0.f, "aggregator_forward: dropout needs the fused global attention (unset TRAJSDE_GLOBAL_UNFUSED)");
     TS_REQUIRE(fused || !state_bf16(), "aggregator_forward: bf16 state storage needs the fused global attention");
+    TS_REQUIRE(fused || g->exact, "aggregator_forward: a graph from trajsde_graph_prepare_async needs the fused global attention");
     if (fused) {
       // one wave per target: logits, softmax and aggregation in one pass over the rel rows (no per-edge GEMM)
       TS_GLOBAL_ATTN(num_heads, state_bf16(), drop, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg);

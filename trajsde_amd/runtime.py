@@ -1,6 +1,7 @@
 """Host-side runtime of the stage modules: weight packing, workspaces, noise selection and the ctypes
 calls into libtrajsde_hip.so.  PyTorch is used for device memory and streams only."""
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -73,6 +74,23 @@ def set_state_storage(kind: str) -> str:
     if kind not in ("fp32", "bf16"):
         raise ValueError("state storage is 'fp32' or 'bf16'")
     return "bf16" if _lib.lib().trajsde_state_storage(1 if kind == "bf16" else 0) else "fp32"
+
+
+_SYNC_FREE = os.environ.get("TRAJSDE_SYNC_FREE", "1") != "0"
+
+
+def set_sync_free(on: bool) -> bool:
+    """Sync-free inference forward (default on): the graph stage leaves the compacted lists' lengths on the device
+    (trajsde_graph_prepare_async) and sizes buffers and grids from bounds, so a forward never waits on the GPU.  Entry points
+    that need the lengths on the host (training, backward, captures) make the graph exact themselves.  Returns the previous
+    setting."""
+    global _SYNC_FREE
+    prev, _SYNC_FREE = _SYNC_FREE, bool(on)
+    return prev
+
+
+def sync_free() -> bool:
+    return _SYNC_FREE and bool(_lib.lib().trajsde_sync_free_supported())
 
 
 def state_storage() -> str:
@@ -298,7 +316,8 @@ class StageRuntime:
         L = _lib.lib()
         prev = L.trajsde_export_senders(1) if cap else 0                  # edge lists with their senders, for the tests
         try:
-            gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), noise, want_senders=cap)
+            gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), noise, want_senders=cap,
+                                  exact=True if cap else not sync_free())
         finally:
             if cap:
                 L.trajsde_export_senders(prev)
@@ -325,8 +344,7 @@ class StageRuntime:
         if cap:
             if state_storage() == "bf16":                                  # aa_out was written with 2-byte elements
                 aa_out = aa_out.view(-1).view(torch.bfloat16)[:H * Nt * D].view(H, Nt, D).float()
-            m.last_intermediates = {"aa_out": aa_out, "latent_ys": latent, "E_aa": gc.graph.E_aa, "E_g": gc.graph.E_g,
-                                    "E_la": gc.graph.E_la, **gc.edge_lists()}
+            m.last_intermediates = {"aa_out": aa_out, "latent_ys": latent, **gc.true_counts(), **gc.edge_lists()}
         if preserve_side_effects:
             edge_snapshots(data, H)                                                         # ENC:107-110
         diff_in, diff_out = torch.chunk(diff_pick, 2, 0)                                    # ENC:194
@@ -438,7 +456,7 @@ class StageRuntime:
         m = self.module
         dr = NoiseSpec.resolve(noise).c_dropout(m) if (m.training and float(getattr(m, "dropout", 0.0) or 0.0) > 0) else None
         _require_gpu(local_embed, "local_embed")
-        gc = GraphContext.get(data, None, int(m.historical_steps), None)
+        gc = GraphContext.get(data, None, int(m.historical_steps), None, exact=None)
         dev = gc.device
         L = _lib.lib()
         blob = self.blob()
@@ -606,7 +624,8 @@ class GraphContext:
     KEY = "_trajsde_graph"
     DEFAULT_RADIUS = 50.0
 
-    def __init__(self, data, radius: float, H: int, noise: Optional[NoiseSpec], fake_agents: bool = True) -> None:
+    def __init__(self, data, radius: float, H: int, noise: Optional[NoiseSpec], fake_agents: bool = True,
+                 exact: bool = True) -> None:
         L = _lib.lib()
         self.fake_agents = fake_agents
         x = data["x"]
@@ -658,8 +677,13 @@ class GraphContext:
             if ws_bytes < 0:
                 raise _lib.TrajsdeError("graph workspace query failed: " + L.trajsde_last_error().decode())
             self.ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-            _lib.check(L.trajsde_graph_prepare(C.byref(self.batch), self.rot.data_ptr(), float(radius), C.byref(cn),
-                                               self.ws.data_ptr(), ws_bytes, C.byref(self.graph), _stream()), "trajsde_graph_prepare")
+            # sync-free form: list lengths stay on the device, the E_* fields are bounds (int32 positions must hold them)
+            b = self.batch
+            if not exact and 2 * b.H * b.E >= 2 ** 31 - 2:
+                exact = True
+            prepare = L.trajsde_graph_prepare if exact else L.trajsde_graph_prepare_async
+            _lib.check(prepare(C.byref(self.batch), self.rot.data_ptr(), float(radius), C.byref(cn),
+                               self.ws.data_ptr(), ws_bytes, C.byref(self.graph), _stream()), "trajsde_graph_prepare")
             ews_bytes = L.trajsde_graph_edges_ws_bytes(C.byref(self.batch), C.byref(self.graph))
             self.edges_ws = torch.empty(ews_bytes, device=dev, dtype=torch.uint8)
             _lib.check(L.trajsde_graph_compact(C.byref(self.batch), self.rot.data_ptr(), self.ws.data_ptr(), ws_bytes,
@@ -674,9 +698,28 @@ class GraphContext:
         assert 0 <= off and off + 4 * n <= buf.numel() and off % 4 == 0
         return buf[off:off + 4 * n].view(torch.int32)
 
+    def true_counts(self) -> Dict[str, int]:
+        """the list lengths (a host synchronisation when the graph was built sync-free)"""
+        g = self.graph
+        if g.exact:
+            return {"E_aa": g.E_aa, "E_g": g.E_g, "E_la": g.E_la}
+        c = self._i32(self.ws, g.counts, 4).tolist()
+        return {"E_aa": c[1], "E_g": c[2], "E_la": c[3]}
+
+    def make_exact(self) -> "GraphContext":
+        """turn a sync-free graph into an exact one in place: read the counts (synchronises) and store them in the E_* fields.
+        The buffers keep their bound-sized allocation; every entry point accepts the graph afterwards."""
+        g = self.graph
+        if not g.exact:
+            c = self.true_counts()
+            assert c["E_aa"] <= g.E_aa and c["E_g"] <= g.E_g and c["E_la"] <= g.E_la, "edge-count bound violated"
+            g.E_aa, g.E_g, g.E_la, g.exact = c["E_aa"], c["E_g"], c["E_la"], 1
+        return self
+
     def edge_lists(self) -> Dict[str, torch.Tensor]:
         """the compacted lists as tensors (copies): what ENC:107-118, AGG:41 and ENC:198 leave of the input edge lists, in
         this build's canonical order (target-major, senders ascending) -- for edge-for-edge comparison with the oracle"""
+        self.make_exact()
         g, b = self.graph, self.batch
         n_aa = b.H * g.Nt
         return {"aa_src": self._i32(self.edges_ws, g.aa_src, g.E_aa).clone(), "aa_dst": self._i32(self.edges_ws, g.aa_dst, g.E_aa).clone(),
@@ -699,7 +742,9 @@ class GraphContext:
 
     @classmethod
     def get(cls, data, radius: Optional[float], H: int, noise: Optional[NoiseSpec], fake_agents: bool = True,
-            want_senders: bool = False) -> "GraphContext":
+            want_senders: bool = False, exact: Optional[bool] = True) -> "GraphContext":
+        """`exact`: True -- the caller's entry point needs the list lengths on the host (training, backward, OOD, vanilla
+        variant, captures); False -- build sync-free if a build is needed; None -- take whatever the encoder left."""
         gc = data[cls.KEY] if cls.KEY in data else None
         if gc is not None and want_senders and not gc.graph.aa_src and gc.graph.E_aa > 0:
             gc = None                                                     # built without the sender ids: rebuild
@@ -711,7 +756,9 @@ class GraphContext:
         if gc is None or (key is not None and getattr(gc, "build_key", None) != key):
             # the encoder (which owns the radius and the fake-agent noise) builds; the aggregator and the backward
             # entry points of the same step (same noise) reuse
-            gc = cls(data, cls.DEFAULT_RADIUS if radius is None else radius, H, noise, fake_agents)
+            gc = cls(data, cls.DEFAULT_RADIUS if radius is None else radius, H, noise, fake_agents, exact=exact is not False)
             gc.build_key = key
             data[cls.KEY] = gc
+        if exact:
+            gc.make_exact()
         return gc
