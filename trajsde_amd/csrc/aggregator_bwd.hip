@@ -9,7 +9,7 @@
 //
 // k_gattn_bwd mirrors the fused forward (attn.hip k_global_attn): one wave per target actor, lin_k_edge folded into
 // the query (U_h = Wke_h^T q_h), lin_v_edge folded into the incoming gradient (Z_h = Wve_h^T dagg_h), softmax
-// statistics recomputed in a first pass over the segment.  With alpha the attention weights,
+// statistics taken from the forward's tape (one pass over the segment).  With alpha the attention weights,
 //   d alpha_e,h = dagg_h . (v_node[src] + lin_v_edge(rel_e))_h,   d logit_e,h = alpha (d alpha - dagg_h . agg_h)
 // Per-target sums  RL_h = sum_e dlogit/sqrt(dh) rel_e  and  SS_h = sum_e alpha rel_e  give the lin_k_edge / lin_v_edge
 // weight gradients as node-level outer products (k_headwise_outer) instead of per-edge ones.  Gradients of the
@@ -29,20 +29,28 @@
 
 namespace tsde {
 
-template <int HEADS>
+// NODE = false: attention over edge rows alone (the AA / AL encoders: k = lin_k(emb_e), v = lin_v(emb_e), `rel` = the stored
+// embedding rows): no kn / vn / src, nothing to scatter; UZ may be null (k_gattn_drel then rebuilds U, Z from q and dagg).
+template <int HEADS, bool NODE>
 __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                    const int32_t* __restrict__ src, const float* __restrict__ rel,
                                                    const float* __restrict__ q, const float* __restrict__ kn,
                                                    const float* __restrict__ vn, const float* __restrict__ agg,
-                                                   const float* __restrict__ dagg, int64_t N, float* __restrict__ DQ,
-                                                   float* __restrict__ DKN, float* __restrict__ DVN, float* __restrict__ DREL,
+                                                   const float* __restrict__ dagg, const float* __restrict__ stats, int64_t N,
+                                                   float* __restrict__ DQ, float* __restrict__ DKN, float* __restrict__ DVN,
                                                    float* __restrict__ RL, float* __restrict__ SS, float* __restrict__ DAGGM,
-                                                   float* __restrict__ EA, float* __restrict__ ED, DropArg drop) {
-  // EA / ED non-null: the source-row gradients are gathered afterwards by k_gattn_src_bwd from the per-edge (alpha, dlogit)
-  // scalars written here (symmetric graph, fixed summation order); null: scattered right here with float atomics
+                                                   float* __restrict__ EA, float* __restrict__ ED, float* __restrict__ UZ,
+                                                   const int32_t* __restrict__ asym, DropArg drop) {
+  // One pass over the segment: the softmax statistics come from the forward's tape (stats).  Per edge and head the kernel
+  // leaves the two scalars everything else is made of -- EA = alpha d_e (the weight the values were summed with) and
+  // ED = d logit / sqrt(dh) -- and per target the vectors U_h = Wke_h^T q_h, Z_h = Wve_h^T dagg_h (UZ):
+  //   d rel_e          = sum_layers sum_h ED U_h + EA Z_h             (k_gattn_drel, once for all layers)
+  //   d k_node[src], d v_node[src]: gathered per source in a fixed order (k_gattn_src_bwd; symmetric graph, *asym == 0),
+  //                                 or scattered right here with float atomics (*asym != 0)
   constexpr int LPH = 64 / HEADS, SL = 64 / LPH, NV = SL / 4;     // as in k_global_attn<HEADS>
   constexpr float INV = HEADS == 4 ? 0.25f : INV_SQRT_DH;
   __shared__ __attribute__((aligned(16))) float sbuf[4][HEADS][64 + 4];
+  __shared__ __attribute__((aligned(16))) float srel[4][8][64];   // a wave's chunk of rel rows (wave-private, as in the forward)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row addresses in SGPRs
   const int h = lane / LPH, j = lane % LPH;
   const int64_t node = int64_t(blockIdx.x) * 4 + wv;
@@ -71,127 +79,85 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
       }
     }
   }
-  const int beg = segptr[nc], end = node < N ? segptr[nc + 1] : beg;
-  auto load_rel = [&](int e, f4 (&r)[NV]) {
-    const float* rrow = rel + int64_t(e) * 64;
+  if (node < N && UZ != nullptr) {
 #pragma unroll
-    for (int v4 = 0; v4 < NV; ++v4) r[v4] = *reinterpret_cast<const f4*>(rrow + SL * j + 4 * v4);
-  };
-  // the source indices of a chunk in one coalesced load, handed out as scalars (k_global_attn does the same)
-  auto chunk_src = [&](int e0, int n) { return src[e0 + (lane & (n - 1)) < end ? e0 + (lane & (n - 1)) : end - 1]; };
-  auto logit = [&](const f4 (&r)[NV], float knv) {
-    float p = ql * knv;
-#pragma unroll
-    for (int v4 = 0; v4 < NV; ++v4)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) p = fmaf(r[v4][e], U[4 * v4 + e], p);
-    return (head_sum_n<HEADS>(p) + cb) * INV;
-  };
-  // pass 1: softmax statistics of the segment
-  float m = -INFINITY, s = 0.f;
-  for (int e0 = beg; e0 < end; e0 += 8) {                  // 8 edges in flight per round trip, as in the forward kernel
-    f4 r[8][NV];
-    float knv[8], lg[8];
-    const int sv = chunk_src(e0, 8);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u < end ? e0 + u : end - 1;
-      load_rel(e, r[u]);
-      knv[u] = (kn + int64_t(__builtin_amdgcn_readlane(sv, u)) * 64)[lane];
+    for (int v4 = 0; v4 < NV; ++v4) {
+      *reinterpret_cast<f4*>(UZ + ((node * HEADS + h) * 2 + 0) * 64 + SL * j + 4 * v4) = f4{U[4 * v4], U[4 * v4 + 1], U[4 * v4 + 2], U[4 * v4 + 3]};
+      *reinterpret_cast<f4*>(UZ + ((node * HEADS + h) * 2 + 1) * 64 + SL * j + 4 * v4) = f4{Z[4 * v4], Z[4 * v4 + 1], Z[4 * v4 + 2], Z[4 * v4 + 3]};
     }
-    float cm = -INFINITY;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      lg[u] = e0 + u < end ? logit(r[u], knv[u]) : -INFINITY;
-      cm = fmaxf(cm, lg[u]);
-    }
-    const float mn = fmaxf(m, cm);
-    s *= fast_exp(m - mn);
-    m = mn;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += fast_exp(lg[u] - m);
   }
-  const float inv = 1.0f / (s + 1e-16f);
-  // pass 2: gradients.  Attention dropout (AGG:116): agg_h = sum_e alpha_e d_e (v_node[src] + lin_v_edge(rel_e) )_h with
-  // d_e = keep_e / (1 - p): every "alpha" that multiplies a VALUE below becomes alpha d_e, d alpha_e = d_e (dagg . value_e),
-  // and lin_v_edge.bias sees sum_e alpha_e d_e instead of 1
+  const int beg = segptr[nc], end = node < N ? segptr[nc + 1] : beg;
+  const float m = stats[(nc * HEADS + h) * 2], inv = stats[(nc * HEADS + h) * 2 + 1];
+  const bool scatter = NODE && *asym != 0;
+  // Attention dropout (AGG:116): agg_h = sum_e alpha_e d_e (v_node[src] + lin_v_edge(rel_e))_h with d_e = keep_e / (1 - p):
+  // every "alpha" that multiplies a VALUE below becomes alpha d_e, d alpha_e = d_e (dagg . value_e), and lin_v_edge.bias
+  // sees sum_e alpha_e d_e instead of 1
   const bool dropping = drop.p > 0.f;
-  float sad = 0.f;
+  float sad = 0.f, sal = 0.f;
   float dqe = 0.f, Rl[SL], Sa[SL];
 #pragma unroll
   for (int e = 0; e < SL; ++e) Rl[e] = Sa[e] = 0.f;
-  for (int e0 = beg; e0 < end; e0 += 4) {                  // loads of 4 edges in flight, then their gradients in order
-   f4 rr4[4][NV];
-   float kn4[4], vn4[4];
-   int sx4[4];
-   float kp[4] = {1.f, 1.f, 1.f, 1.f};
-   if (dropping) drop_attn_chunk<4>(kp, drop, uint32_t(nc), uint32_t(e0 - beg), lane, h);
-   const int sv = chunk_src(e0, 4);
+  for (int e0 = beg; e0 < end; e0 += 8) {                  // 8 edges in flight per round trip, as in the forward kernel
+    f4 r[8][NV];
+    float knv[8], vnv[8], rl[8];
+    float kp[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (dropping) drop_attn_chunk<8>(kp, drop, uint32_t(nc), uint32_t(e0 - beg), lane, h);
+    const int sv = NODE ? src[e0 + (lane & 7) < end ? e0 + (lane & 7) : end - 1] : 0;   // coalesced, handed out as scalars
+    int sx[8];
 #pragma unroll
-   for (int u = 0; u < 4; ++u) {
-     const int e = e0 + u < end ? e0 + u : end - 1;
-     sx4[u] = __builtin_amdgcn_readlane(sv, u);
-     load_rel(e, rr4[u]);
-     kn4[u] = (kn + int64_t(sx4[u]) * 64)[lane];
-     vn4[u] = (vn + int64_t(sx4[u]) * 64)[lane];
-   }
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u < end ? e0 + u : end - 1;
+      sx[u] = __builtin_amdgcn_readlane(sv, u);
+      rl[u] = (rel + int64_t(e) * 64)[lane];               // the row once per wave, slices picked out of LDS below
+      knv[u] = NODE ? (kn + int64_t(sx[u]) * 64)[lane] : 0.f;
+      vnv[u] = NODE ? (vn + int64_t(sx[u]) * 64)[lane] : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();                        // the previous chunk's slice reads are done (same wave, in order)
 #pragma unroll
-   for (int u = 0; u < 4; ++u) {
-    const int e = e0 + u;
-    if (e >= end) break;
-    const int sidx = sx4[u];
-    const f4 (&r)[NV] = rr4[u];
-    const float knv = kn4[u], vnv = vn4[u];
-    const float alpha = fast_exp(logit(r, knv) - m) * inv;
-    const float alk = alpha * kp[u];                       // the weight the values were summed with
-    sad += alk;
-    float t = da * vnv;
+    for (int u = 0; u < 8; ++u) srel[wv][u][lane] = rl[u];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int v4 = 0; v4 < NV; ++v4)
+    for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) t = fmaf(r[v4][c], Z[4 * v4 + c], t);
-    const float dal = (head_sum_n<HEADS>(t) + cz) * kp[u];
-    const float dls = alpha * (dal - dlt) * INV;
-    dqe = fmaf(dls, knv, dqe);
-    if (EA != nullptr) {
+      for (int v4 = 0; v4 < NV; ++v4) r[u][v4] = *reinterpret_cast<const f4*>(&srel[wv][u][SL * j + 4 * v4]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u;
+      if (e >= end) break;
+      float p = ql * knv[u];
+      float t = da * vnv[u];
+#pragma unroll
+      for (int v4 = 0; v4 < NV; ++v4)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          p = fmaf(r[u][v4][c], U[4 * v4 + c], p);
+          t = fmaf(r[u][v4][c], Z[4 * v4 + c], t);
+        }
+      const float lg = (head_sum_n<HEADS>(p) + cb) * INV;
+      const float alpha = fast_exp(lg - m) * inv;
+      const float alk = alpha * kp[u];                     // the weight the values were summed with
+      sad += alk;
+      sal += alpha;
+      const float dal = (head_sum_n<HEADS>(t) + cz) * kp[u];
+      const float dls = alpha * (dal - dlt) * INV;
+      dqe = fmaf(dls, knv[u], dqe);
       if (j == 0) {
         EA[int64_t(e) * HEADS + h] = alk;
         ED[int64_t(e) * HEADS + h] = dls;
       }
-    } else {
-      atomicAdd(DKN + int64_t(sidx) * 64 + lane, dls * ql);
-      atomicAdd(DVN + int64_t(sidx) * 64 + lane, alk * da);
-    }
-    float dr[SL];
-#pragma unroll
-    for (int v4 = 0; v4 < NV; ++v4)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int i = 4 * v4 + c;
-        Rl[i] = fmaf(dls, r[v4][c], Rl[i]);
-        Sa[i] = fmaf(alk, r[v4][c], Sa[i]);
-        dr[i] = fmaf(dls, U[i], alk * Z[i]);
+      if (scatter) {
+        atomicAdd(DKN + int64_t(sx[u]) * 64 + lane, dls * ql);
+        atomicAdd(DVN + int64_t(sx[u]) * 64 + lane, alk * da);
       }
-    // d rel_e = sum over heads: lanes j, j + LPH, ... hold the same SL columns
 #pragma unroll
-    for (int c = 0; c < SL; ++c) {
-      float x = dr[c];
-      if (LPH == 8) {                                       // lane ^ 8 inside the 16-lane row: DPP row_ror:8
-        const int rr = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xF, 0xF, true);
-        x += __int_as_float(rr);
-      }
-      dr[c] = xor32_sum(xor16_sum(x));                      // lanes ^ 16, ^ 32: permlane swaps, no LDS crossbar
-    }
-    if (h == 0) {
-      float* p = DREL + int64_t(e) * 64 + SL * j;
+      for (int v4 = 0; v4 < NV; ++v4)
 #pragma unroll
-      for (int v4 = 0; v4 < NV; ++v4) {
-        f4 a = *reinterpret_cast<f4*>(p + 4 * v4);
-        a += f4{dr[4 * v4], dr[4 * v4 + 1], dr[4 * v4 + 2], dr[4 * v4 + 3]};
-        *reinterpret_cast<f4*>(p + 4 * v4) = a;
-      }
+        for (int c = 0; c < 4; ++c) {
+          Rl[4 * v4 + c] = fmaf(dls, r[u][v4][c], Rl[4 * v4 + c]);
+          Sa[4 * v4 + c] = fmaf(alk, r[u][v4][c], Sa[4 * v4 + c]);
+        }
     }
-   }
   }
 #pragma unroll
   for (int v4 = 0; v4 < NV; ++v4) {
@@ -213,19 +179,130 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
   }
   if (node < N) {
     DQ[node * 64 + lane] = dq;
-    DAGGM[node * 64 + lane] = da * (dropping ? sad : s * inv);        // lin_v_edge.bias sees sum_e alpha d_e (= 1 without dropout)
+    DAGGM[node * 64 + lane] = da * (dropping ? sad : sal);            // lin_v_edge.bias sees sum_e alpha d_e (= 1 without dropout)
   }
 }
 
-// REV[e'] = index of the reverse edge (dst -> src) of e' = (src -> dst), or -1; *asym is raised when one is missing
+// d rel_e = sum over the layers l and heads h of  ED_l[e][h] U_l[tgt][h] + EA_l[e][h] Z_l[tgt][h]  -- the relative-pose embedding
+// is shared by every layer (AGG:42-51), so its gradient is assembled ONCE from the per-edge scalars and per-target vectors the
+// layers' k_gattn_bwd left, instead of a read-modify-write of the [E,64] rows per layer.  One wave per target, lane = column;
+// a chunk's 64 / HEADS edges x HEADS scalars arrive in one coalesced load per (layer, EA | ED) and are handed out as scalars.
+// FROM_ROWS (NL = 1): U, Z are rebuilt from the target's q / dagg rows and the GAttnL image instead of read from UZ (the AA
+// encoder has H x Nt targets of ~20 edges each: storing 4 KB of (U, Z) per target would cost more than it saves).
+template <int HEADS, int NL, bool FROM_ROWS>
+__global__ __launch_bounds__(256) void k_gattn_drel(DrelArgs a, const int32_t* __restrict__ segptr, int64_t N, float* __restrict__ DREL,
+                                                    int accumulate) {
+  constexpr int EPC = 64 / HEADS, LPH = 64 / HEADS;
+  const int lane = threadIdx.x & 63;
+  const int64_t node = int64_t(blockIdx.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (node >= N) return;
+  float U[NL][HEADS], Z[NL][HEADS];
+  if (FROM_ROWS) {
+    static_assert(!FROM_ROWS || NL == 1, "FROM_ROWS handles one layer");
+    const float ql = a.q[node * 64 + lane], dl = a.dagg[node * 64 + lane];
+    const float* wke = a.img + GAttnL::WKE;
+    const float* wve = a.img + GAttnL::WVE;
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+      float u = 0.f, z = 0.f;
+#pragma unroll
+      for (int d = 0; d < LPH; ++d) {
+        const float qd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ql), LPH * h + d));
+        const float dd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl), LPH * h + d));
+        u = fmaf(wke[(LPH * h + d) * 64 + lane], qd, u);
+        z = fmaf(wve[(LPH * h + d) * 64 + lane], dd, z);
+      }
+      U[0][h] = u;
+      Z[0][h] = z;
+    }
+  } else {
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int h = 0; h < HEADS; ++h) {
+        U[l][h] = a.UZ[l][((node * HEADS + h) * 2 + 0) * 64 + lane];
+        Z[l][h] = a.UZ[l][((node * HEADS + h) * 2 + 1) * 64 + lane];
+      }
+  }
+  const int beg = segptr[node], end = segptr[node + 1];
+  for (int e0 = beg; e0 < end; e0 += EPC) {
+    float eav[NL], edv[NL];
+    const int64_t idx = int64_t(e0) * HEADS + lane;
+    const bool ok = idx < int64_t(end) * HEADS;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      eav[l] = ok ? a.EA[l][idx] : 0.f;
+      edv[l] = ok ? a.ED[l][idx] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < EPC; ++u) {
+      if (e0 + u >= end) break;
+      float dr = 0.f;
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+          const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(edv[l]), u * HEADS + h));
+          const float al = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eav[l]), u * HEADS + h));
+          dr = fmaf(d, U[l][h], dr);
+          dr = fmaf(al, Z[l][h], dr);
+        }
+      float* out = DREL + int64_t(e0 + u) * 64 + lane;
+      *out = accumulate ? *out + dr : dr;
+    }
+  }
+}
+
+int run_gattn_drel(hipStream_t st, int heads, int nl, bool from_rows, const DrelArgs& da, const int32_t* segptr, int64_t N, float* DREL,
+                   int accumulate) {
+#define TS_DREL(H_, N_, F_) TS_LAUNCH((k_gattn_drel<H_, N_, F_>), cdiv(N, 4), 256, 0, st, da, segptr, N, DREL, accumulate)
+  if (from_rows) {
+    if (heads == 4) TS_DREL(4, 1, true);
+    else TS_DREL(8, 1, true);
+  } else if (heads == 4) {
+    switch (nl) { case 1: TS_DREL(4, 1, false); break; case 2: TS_DREL(4, 2, false); break; case 3: TS_DREL(4, 3, false); break; default: TS_DREL(4, 4, false); }
+  } else {
+    switch (nl) { case 1: TS_DREL(8, 1, false); break; case 2: TS_DREL(8, 2, false); break; case 3: TS_DREL(8, 3, false); break; default: TS_DREL(8, 4, false); }
+  }
+#undef TS_DREL
+  return TRAJSDE_OK;
+}
+
+// the encoders' attention backward over stored embedding rows (NODE = false), see bwd.hpp
+int run_edge_attn_bwd(hipStream_t st, int heads, const float* img, const int32_t* segptr, const float* emb, const float* q, const float* agg,
+                      const float* dagg, const float* stats, int64_t R, float* DQ, float* RL, float* SS, float* DAGGM, float* EA, float* ED,
+                      const DropArg& drop) {
+  const int32_t* ns = nullptr;
+  const float* nf = nullptr;
+  float* nw = nullptr;
+  if (heads == 4)
+    TS_LAUNCH_TAG("k_edge_attn_rows_bwd<4>", false, (k_gattn_bwd<4, false>), cdiv(R, 4), 256, 0, st, img, segptr, ns, emb, q, nf, nf, agg, dagg, stats,
+                  R, DQ, nw, nw, RL, SS, DAGGM, EA, ED, nw, ns, drop);
+  else
+    TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_gattn_bwd<8, false>), cdiv(R, 4), 256, 0, st, img, segptr, ns, emb, q, nf, nf, agg, dagg, stats,
+                  R, DQ, nw, nw, RL, SS, DAGGM, EA, ED, nw, ns, drop);
+  return TRAJSDE_OK;
+}
+
+// REV[e'] = index of the reverse edge (dst -> src) of e' = (src -> dst), or -1; *asym is raised when one is missing.
+// The compacted rows list their senders in ascending order (prep.hip), so a binary search finds it; a row that is not sorted
+// (a caller's own edge order) falls back to the scan.
 __global__ void k_reverse_edges(const int32_t* __restrict__ segptr, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                 int64_t E, int32_t* __restrict__ REV, int32_t* __restrict__ asym) {
   const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const int i = src[e], jn = dst[e];
-  int found = -1;
-  for (int r = segptr[i]; r < segptr[i + 1]; ++r)
-    if (src[r] == jn) { found = r; break; }
+  const int r0 = segptr[i], r1 = segptr[i + 1];
+  int lo = r0, hi = r1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (src[mid] < jn) lo = mid + 1;
+    else hi = mid;
+  }
+  int found = lo < r1 && src[lo] == jn ? lo : -1;
+  if (found < 0)
+    for (int r = r0; r < r1; ++r)
+      if (src[r] == jn) { found = r; break; }
   REV[e] = found;
   if (found < 0) atomicOr(asym, 1);
 }
@@ -237,10 +314,10 @@ __global__ __launch_bounds__(256) void k_gattn_src_bwd(const int32_t* __restrict
                                                        const int32_t* __restrict__ REV, const float* __restrict__ EA,
                                                        const float* __restrict__ ED, const float* __restrict__ q,
                                                        const float* __restrict__ dagg, int64_t N, float* __restrict__ DKN,
-                                                       float* __restrict__ DVN) {
+                                                       float* __restrict__ DVN, const int32_t* __restrict__ asym) {
   const int lane = threadIdx.x & 63, h = lane / (64 / HEADS);
   const int64_t node = int64_t(blockIdx.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (node >= N) return;
+  if (node >= N || *asym != 0) return;                     // asymmetric list: k_gattn_bwd scattered the rows with atomics
   float dk = 0.f, dv = 0.f;
   const int beg = segptr[node], end = segptr[node + 1];
   for (int e0 = beg; e0 < end; e0 += 8) {                  // 8 edges per round trip; indices loaded coalesced, used as scalars
@@ -270,8 +347,10 @@ __global__ __launch_bounds__(256) void k_gattn_src_bwd(const int32_t* __restrict
 struct AggBwdWs {
   // forward tape
   float *rel, *xn[8], *q[8], *kn[8], *vn[8], *agg[8], *x1[8], *xn2[8], *out[8];
+  float* stats[8];               // softmax statistics (max logit, 1 / sum) per (target, head) of every layer
   // backward scratch
-  float *dcur, *dnext, *dagg, *dxn, *DQ, *DKN, *DVN, *DREL, *RL, *SS, *DAGGM, *XF, *part, *cs, *EA, *ED;
+  float *dcur, *dnext, *dagg, *dxn, *DQ, *DKN, *DVN, *DREL, *RL, *SS, *DAGGM, *XF, *part, *cs;
+  float *EA[8], *ED[8], *UZ[8];  // per layer: the per-edge (alpha d, d logit) scalars and per-target (U, Z) vectors (k_gattn_drel)
   int32_t *REV, *asym;
   NodeBlockScratch nb;
   EdgeEmbedScratch ee;
@@ -283,6 +362,7 @@ struct AggBwdWs {
     for (int l = 0; l < nl; ++l) {
       xn[l] = c.take<float>(N * 64); q[l] = c.take<float>(N * 64); kn[l] = c.take<float>(N * 64); vn[l] = c.take<float>(N * 64);
       agg[l] = c.take<float>(N * 64); x1[l] = c.take<float>(N * 64); xn2[l] = c.take<float>(N * 64); out[l] = c.take<float>(N * 64);
+      stats[l] = c.take<float>(N * 16);
     }
     float** singles[] = {&dcur, &dnext, &dagg, &dxn, &DQ, &DKN, &DVN, &DAGGM, &XF, &nb.dx1, &nb.UPD, &nb.DGP, &nb.DS};
     for (float** p : singles) *p = c.take<float>(N * 64);
@@ -291,8 +371,11 @@ struct AggBwdWs {
     RL = c.take<float>(N * 512);
     SS = c.take<float>(N * 512);
     DREL = c.take<float>(E * 64 + 64);
-    EA = c.take<float>(E * 8 + 8);
-    ED = c.take<float>(E * 8 + 8);
+    for (int l = 0; l < nl; ++l) {
+      EA[l] = c.take<float>(E * 8 + 64);
+      ED[l] = c.take<float>(E * 8 + 64);
+      UZ[l] = c.take<float>(N * 1024);
+    }
     REV = c.take<int32_t>(E + 1);
     asym = c.take<int32_t>(4);
     float** edge[] = {&ee.S, &ee.DEP, &ee.DSP};
@@ -328,7 +411,7 @@ static int aggregator_tape(const trajsde_batch* b, const trajsde_graph* g, const
               w.xn[l], w.q[l], w.kn[l], w.vn[l]);
     {
       const DropArg dl = drop_of(l);
-      TS_GLOBAL_ATTN(num_heads, false, dl, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N, w.agg[l]);
+      TS_GLOBAL_ATTN(num_heads, false, dl, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N, w.agg[l], w.stats[l]);
     }
     TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, lb + AggLayerL::UPD6, w.agg[l], w.xn[l], x,
               N, w.x1[l], w.xn2[l], drop_of(l));
@@ -422,8 +505,12 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     const int gp = vec_grid(ntiles, 256, ProjBwdL<0>::SIZE * 4);
     TS_LAUNCH(k_node_proj_bwd<0>, gp, 256, ProjBwdL<0>::SIZE * 4, st, blob_bwd + AggBwdBlob::norm(nl), w.out[nl - 1], nullptr, w.dxn,
               nullptr, nullptr, nullptr, N, w.dcur, w.XF, w.nb.vpart);
-    if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, G("norm.weight"))) return rc;
-    if (int rc = run_colsum(st, w.nb.vpart + 64, gp * 4, 128, 64, G("norm.bias"))) return rc;
+    {
+      ColsumBatch cb(st, gp * 4, 128);
+      cb.add(w.nb.vpart, 64, G("norm.weight"));
+      cb.add(w.nb.vpart + 64, 64, G("norm.bias"));
+      if (int rc = cb.flush()) return rc;
+    }
     float* pw = G("multihead_proj.weight");
     float* pb = G("multihead_proj.bias");
     TS_REQUIRE(!missing, "aggregator_backward: parameter table lacks norm / multihead_proj");
@@ -435,19 +522,9 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
 
   // ---- layers, last to first
   // the global graph of a scene is symmetric (all ordered pairs of its valid actors), which lets the source-row
-  // gradients be gathered in a fixed order instead of scattered with atomics; checked here, one 4-byte read back
-  bool symmetric = false;
-  if (E > 0) {
-    TS_HIP(hipMemsetAsync(w.asym, 0, sizeof(int32_t), st));
-    TS_LAUNCH(k_reverse_edges, cdiv(E, 256), 256, 0, st, g->g_segptr, g->g_src, g->g_dst, E, w.REV, w.asym);
-    int32_t flag = 1;
-    TS_HIP(hipMemcpyAsync(&flag, w.asym, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    TS_HIP(hipStreamSynchronize(st));
-    symmetric = flag == 0;
-  }
-  float* const ea = symmetric ? w.EA : nullptr;
-  float* const ed = symmetric ? w.ED : nullptr;
-  TS_HIP(hipMemsetAsync(w.DREL, 0, size_t(E * 64 + 64) * sizeof(float), st));
+  // gradients be gathered in a fixed order instead of scattered with atomics; checked on the device (w.asym), no read back
+  TS_HIP(hipMemsetAsync(w.asym, 0, sizeof(int32_t), st));
+  if (E > 0) TS_LAUNCH(k_reverse_edges, cdiv(E, 256), 256, 0, st, g->g_segptr, g->g_src, g->g_dst, E, w.REV, w.asym);
   float* dcur = w.dcur;
   float* dnext = w.dnext;
   for (int l = nl - 1; l >= 0; --l) {
@@ -471,17 +548,16 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     if (int rc = node_block_backward(lb + AggLayerBwdL::NODE, tp, dcur, N, w.nb, wc, gr, w.dagg, w.dxn, st, drop_of(l))) return rc;
     TS_HIP(hipMemsetAsync(w.DKN, 0, size_t(N) * 64 * sizeof(float), st));
     TS_HIP(hipMemsetAsync(w.DVN, 0, size_t(N) * 64 * sizeof(float), st));
-    if (num_heads == 4)
-      TS_LAUNCH(k_gattn_bwd<4>, cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
-                w.agg[l], w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM, ea, ed, drop_of(l));
-    else
-      TS_LAUNCH(k_gattn_bwd<8>, cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
-                w.agg[l], w.dagg, N, w.DQ, w.DKN, w.DVN, w.DREL, w.RL, w.SS, w.DAGGM, ea, ed, drop_of(l));
-    if (symmetric) {
-      if (num_heads == 4)
-        TS_LAUNCH(k_gattn_src_bwd<4>, cdiv(N, 4), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA, w.ED, w.q[l], w.dagg, N, w.DKN, w.DVN);
-      else
-        TS_LAUNCH(k_gattn_src_bwd<8>, cdiv(N, 4), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA, w.ED, w.q[l], w.dagg, N, w.DKN, w.DVN);
+    if (num_heads == 4) {
+      TS_LAUNCH((k_gattn_bwd<4, true>), cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
+                w.agg[l], w.dagg, w.stats[l], N, w.DQ, w.DKN, w.DVN, w.RL, w.SS, w.DAGGM, w.EA[l], w.ED[l], w.UZ[l], w.asym, drop_of(l));
+      TS_LAUNCH(k_gattn_src_bwd<4>, cdiv(N, 4), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA[l], w.ED[l], w.q[l], w.dagg, N, w.DKN, w.DVN,
+                w.asym);
+    } else {
+      TS_LAUNCH((k_gattn_bwd<8, true>), cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
+                w.agg[l], w.dagg, w.stats[l], N, w.DQ, w.DKN, w.DVN, w.RL, w.SS, w.DAGGM, w.EA[l], w.ED[l], w.UZ[l], w.asym, drop_of(l));
+      TS_LAUNCH(k_gattn_src_bwd<8>, cdiv(N, 4), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA[l], w.ED[l], w.q[l], w.dagg, N, w.DKN, w.DVN,
+                w.asym);
     }
     if (int rc = run_headwise_outer(wc, w.q[l], w.RL, N, wke, num_heads)) return rc;
     if (int rc = run_headwise_outer(wc, w.dagg, w.SS, N, wve, num_heads)) return rc;
@@ -490,8 +566,12 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     const int gp = vec_grid(ntiles, 256, ProjBwdL<3>::SIZE * 4);
     TS_LAUNCH(k_node_proj_bwd<3>, gp, 256, ProjBwdL<3>::SIZE * 4, st, lb + AggLayerBwdL::PROJ, x_in, w.nb.dx1, w.dxn, w.DQ, w.DKN, w.DVN, N,
               dnext, nullptr, w.nb.vpart);
-    if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, n1g)) return rc;
-    if (int rc = run_colsum(st, w.nb.vpart + 64, gp * 4, 128, 64, n1b)) return rc;
+    {
+      ColsumBatch cb(st, gp * 4, 128);
+      cb.add(w.nb.vpart, 64, n1g);
+      cb.add(w.nb.vpart + 64, 64, n1b);
+      if (int rc = cb.flush()) return rc;
+    }
     const float* dps[3] = {w.DQ, w.DKN, w.DVN};
     WgradBatch wb(wc, N, N);
     for (int j = 0; j < 3; ++j)
@@ -501,7 +581,17 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
   }
   TS_HIP(hipMemcpyAsync(d_local, dcur, size_t(N) * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
 
-  // ---- rel_embed (shared by every layer: DREL is the sum of their d rel rows)
+  // ---- rel_embed (shared by every layer: DREL is the sum of their d rel rows, assembled here in one pass)
+  if (E > 0)
+    for (int l0 = 0; l0 < nl; l0 += 4) {
+      const int cnt = nl - l0 < 4 ? nl - l0 : 4;
+      DrelArgs da{};
+      for (int i = 0; i < 4; ++i) {
+        const int l = l0 + (i < cnt ? i : 0);
+        da.EA[i] = w.EA[l]; da.ED[i] = w.ED[l]; da.UZ[i] = w.UZ[l];
+      }
+      if (int rc = run_gattn_drel(st, num_heads, cnt, false, da, g->g_segptr, N, w.DREL, l0 > 0 ? 1 : 0)) return rc;
+    }
   {
     const std::string p = "rel_embed";
     EdgeEmbedGrads eg{G(p + ".module_list.0.0.weight"), G(p + ".module_list.0.0.bias"), G(p + ".module_list.0.1.weight"),

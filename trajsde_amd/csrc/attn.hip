@@ -488,11 +488,16 @@ __global__ __launch_bounds__(256) void k_seg_softmax_agg(const int32_t* __restri
 // i.e. lin_k_edge is folded into the query once per target (U_h = Wke_h^T q_h, 8 x 64) and lin_v_edge is applied
 // once per target after the aggregation.  Per edge the wave streams one rel row (256 B) and gathers two node rows.
 // Lane l is feature l of the node rows (head l>>3) and holds slice 8*(l&7).. of the rel row / of U for head l>>3.
-template <int HEADS, bool ST_BF16, bool DROP>
+// NODE = false: the same attention over edge rows alone (k = lin_k(row), v = lin_v(row): the AA / AL encoders' attention on
+// stored embedding rows, training path) -- kn / vn are not read.
+template <int HEADS, bool ST_BF16, bool DROP, bool NODE>
 __global__ __launch_bounds__(256, 4) void k_global_attn(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                      const int32_t* __restrict__ src, const float* __restrict__ rel,
                                                      const float* __restrict__ q, const float* __restrict__ kn,
-                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ agg, DropArg drop) {
+                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ agg,
+                                                     float* __restrict__ stats, DropArg drop) {
+  // stats (training tape, or null): the softmax statistics (max logit, 1 / (sum + 1e-16)) of every (target, head), so that
+  // the backward does not need a first pass over the segment to rebuild them
   constexpr int LPH = 64 / HEADS;          // lanes (= head dims) per head: 8, or 16 with 4 heads
   constexpr int SL = 64 / LPH;             // rel-row columns per lane: a head's 64-wide row is spread over its LPH lanes
   constexpr int NV = SL / 4;               // ... as float4s
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(256, 4) void k_global_attn(const float* __restrict_
     if (dropping) drop_attn_chunk<8>(kp, drop, uint32_t(nc), uint32_t(e0 - beg), lane, h);
     // the chunk's 8 source indices in one coalesced load, handed out as scalars: every row address below is an SGPR
     // base plus a per-lane constant offset, so the loop spends no VALU cycles on address arithmetic
-    const int sv = src[e0 + (lane & 7) < end ? e0 + (lane & 7) : end - 1];
+    const int sv = NODE ? src[e0 + (lane & 7) < end ? e0 + (lane & 7) : end - 1] : 0;
     // every head needs the whole 64-wide rel row, so a per-lane 32-B slice load would fetch each row HEADS times through the
     // texture-address unit: the wave loads the chunk's 8 rows ONCE, parks them in wave-private LDS and the lanes pick their
     // slices out of LDS (same-address reads across the heads broadcast)
@@ -545,8 +550,8 @@ __global__ __launch_bounds__(256, 4) void k_global_attn(const float* __restrict_
       const float* krow = kn + int64_t(sidx) * 64;
       const float* vrow = vn + int64_t(sidx) * 64;
       if (!ST_BF16) rl[u] = rrow[lane];                       // fp32 rows: one dword per lane
-      knv[u] = krow[lane];
-      vnv[u] = vrow[lane];
+      knv[u] = NODE ? krow[lane] : 0.f;
+      vnv[u] = NODE ? vrow[lane] : 0.f;
     }
     if (ST_BF16) {                                            // bf16 storage: 8 lanes per row, 16 B (8 elements) per lane, widened here
       const int64_t er = e0 + (lane >> 3) < end ? e0 + (lane >> 3) : end - 1;
@@ -616,23 +621,32 @@ __global__ __launch_bounds__(256, 4) void k_global_attn(const float* __restrict_
     for (int e = 0; e < 4; ++e) out = fmaf(wr[e], sv[e], out);
   }
   if (node < N) agg[node * 64 + lane] = out;
+  if (stats != nullptr && node < N && j == 0) *reinterpret_cast<float2*>(stats + (node * HEADS + h) * 2) = float2{m, inv};
 }
-template __global__ void k_global_attn<8, false, false>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                                       const float*, int64_t, float*, DropArg);
-template __global__ void k_global_attn<8, false, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                                       const float*, int64_t, float*, DropArg);
-template __global__ void k_global_attn<8, true, false>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                                       const float*, int64_t, float*, DropArg);
-template __global__ void k_global_attn<8, true, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                                       const float*, int64_t, float*, DropArg);
-template __global__ void k_global_attn<4, false, false>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                                       const float*, int64_t, float*, DropArg);
-template __global__ void k_global_attn<4, false, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                                       const float*, int64_t, float*, DropArg);
-template __global__ void k_global_attn<4, true, false>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                                       const float*, int64_t, float*, DropArg);
-template __global__ void k_global_attn<4, true, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
-                                                       const float*, int64_t, float*, DropArg);
+template __global__ void k_global_attn<8, false, false, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_global_attn<8, false, true, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_global_attn<8, true, false, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_global_attn<8, true, true, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_global_attn<4, false, false, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_global_attn<4, false, true, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_global_attn<4, true, false, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_global_attn<4, true, true, true>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_global_attn<8, false, false, false>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_global_attn<8, false, true, false>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_global_attn<4, false, false, false>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_global_attn<4, false, true, false>(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                                                       const float*, int64_t, float*, float*, DropArg);
 
 // ------------------------------------------------------------------------------------------------ update + FFN
 // gate = sigmoid(lin_ih(agg) + lin_hh(xn)); upd = agg + gate*(lin_self(xn) - agg); x1 = x + out_proj(upd); xn2 = norm2(x1)

@@ -32,7 +32,17 @@ struct WgradJobs {
 };
 __global__ void k_wgrad(WgradJobs jobs, int64_t R, int64_t rows_per_group, int chunk, int chunks_per_group, int P, float* part, float* cs);
 __global__ void k_reduce_partials(WgradJobs jobs, const float* part, const float* cs, int P, int chunks_per_group, const float* step_tab);
-__global__ void k_colsum(const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride);
+constexpr int COLSUM_MAX_JOBS = 8;         // vectors cut from the same slab of per-wave partials that share one launch
+struct ColsumJob {
+  const float* src;            // first column of the vector inside the slab
+  float* dst;
+  int n, dst_stride;
+};
+struct ColsumJobs {
+  ColsumJob j[COLSUM_MAX_JOBS];
+  int n;
+};
+__global__ void k_colsum(ColsumJobs jobs, int64_t rows, int stride);
 
 // ---- pieces of the SDE decoder backward reused by the MLP decoder backward (decoder_bwd.hip)
 struct InitV { enum : int { DGAM = 0, DBET = 64, SIZE = 128 }; };               // per-wave vector slots of k_dec_init_bwd
@@ -63,6 +73,17 @@ struct WgradBatch {
 int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, float* W,
               int ldw, int col0, float* bias, int time_cols);
 int run_colsum(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride = 1);
+int run_colsum_tall(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, float* scratch /* 256 x n floats */);
+// several vectors of the same slab (rows x stride floats of per-wave partials) in one launch
+struct ColsumBatch {
+  hipStream_t st;
+  int64_t rows;
+  int stride;
+  ColsumJobs jobs;
+  ColsumBatch(hipStream_t st_, int64_t rows_, int stride_) : st(st_), rows(rows_), stride(stride_) { jobs.n = 0; }
+  int add(const float* src, int n, float* dst, int dst_stride = 1);
+  int flush();
+};
 // W[d][c] = sum_i X[i][d] * Y[i][head(d)][c]   (X [N,64], Y [N,heads,64]) through wc.part
 int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64_t N, float* W, int heads = 8);
 
@@ -77,7 +98,6 @@ __global__ void k_node_proj_bwd(const float* img, const float* x, const float* d
 template <int BR>
 __global__ void k_edge_embed_bwd_branch(const float* img, const float* geom, const float* DSP, int64_t E, float* vpart);
 __global__ void k_lin_t_acc(const float* wt, const float* d, int64_t R, float* out, int accumulate);
-__global__ void k_headwise_outer(const float* X, const float* Y, int64_t N, float* part, int heads);
 
 constexpr int64_t VPART_FLOATS = int64_t(2048) * 4 * 320;     // per-wave vector partials of the widest kernel at the largest grid
 
@@ -101,8 +121,34 @@ struct EdgeEmbedScratch { float *S, *DEP, *DSP, *vpart; };                      
 struct EdgeEmbedGrads {
   float *a_w0, *a_b0, *a_g, *a_e, *b_w0, *b_b0, *b_g, *b_e, *wa3, *ba3, *wb3, *bb3, *ag0, *ae0, *w2, *b2, *ag3, *ae3;
 };
+// what the attention backward over stored embedding rows leaves per edge (run_edge_attn_bwd), for the embedding backward to
+// build d emb from: the edges' targets, the targets' q / dagg rows, the (alpha d, d logit) scalars and lin_k^T | lin_v^T
+struct EdgeAttnGrad {
+  const int32_t* dst;
+  const float *q, *dagg, *EA, *ED;
+  const float* wkvt;           // [2][64][64]: lin_k.weight^T | lin_v.weight^T (EdgeKvBwdL::WKT, WVT)
+  int heads;
+};
+// `demb`: d emb rows [E,64], or (ag != null) built inside the kernel from the attention scalars
 int edge_embed_backward(const float* img /*EdgeBwdL*/, const float* geom, const float* demb, int64_t E, const EdgeEmbedScratch& sc,
-                        const WgradCtx& wc, const EdgeEmbedGrads& gr, hipStream_t st);
+                        const WgradCtx& wc, const EdgeEmbedGrads& gr, hipStream_t st, const EdgeAttnGrad* ag = nullptr);
+
+// ---- wave-per-target attention backward (aggregator_bwd.hip), shared by the global interactor and the AA / AL encoders
+struct DrelArgs {
+  const float* EA[4];          // per layer: [E][HEADS] alpha d_e (the weight the values were summed with)
+  const float* ED[4];          // per layer: [E][HEADS] d logit / sqrt(dh)
+  const float* UZ[4];          // per layer: [N][HEADS][2][64] (U_h, Z_h) of every target, or (from_rows) unused
+  const float *img, *q, *dagg; // from_rows: GAttnL image and the targets' q / dagg rows
+};
+// DREL[e] (+)= sum over the `nl` <= 4 layers and heads of ED U_h + EA Z_h
+int run_gattn_drel(hipStream_t st, int heads, int nl, bool from_rows, const DrelArgs& da, const int32_t* segptr, int64_t N, float* DREL,
+                   int accumulate);
+// attention over stored edge rows `emb` [E,64] (k = lin_k(emb), v = lin_v(emb); img = GAttnL): given dagg [R,64] and the forward's
+// (max, 1/sum) statistics, writes DQ [R,64], RL / SS [R,heads,64] (lin_k / lin_v weight gradients as headwise outer products
+// with q / dagg), DAGGM [R,64] (column sum = lin_v bias gradient) and the per-edge scalars EA / ED [E,heads]
+int run_edge_attn_bwd(hipStream_t st, int heads, const float* img, const int32_t* segptr, const float* emb, const float* q, const float* agg,
+                      const float* dagg, const float* stats, int64_t R, float* DQ, float* RL, float* SS, float* DAGGM, float* EA, float* ED,
+                      const DropArg& drop);
 
 // ---- TemporalEncoder backward kernels (grid_bwd.hip)
 __global__ void k_tr_final_bwd(const float* norm, const float* x, const float* dtout, int N, float* DX, float* vpart);

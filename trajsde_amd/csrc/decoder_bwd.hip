@@ -585,26 +585,28 @@ __global__ __launch_bounds__(256) void k_reduce_partials(WgradJobs jobs, const f
   }
 }
 
-// dst[j*dst_stride] = sum_w src[w*stride + j], j < n   (per-wave vector partials -> one vector).
-// One workgroup per 64 columns, 16 row slices per workgroup, fixed summation order.
-__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, int64_t rows, int stride, int n, float* __restrict__ dst,
-                                                 int dst_stride) {
+// dst[j*dst_stride] = sum_w src[w*stride + j], j < n   (per-wave vector partials -> one vector), for up to COLSUM_MAX_JOBS
+// vectors cut from the same slab of partials in one launch (grid.y = job).  One workgroup per 64 columns, 16 row slices per
+// workgroup, fixed summation order.
+__global__ __launch_bounds__(1024) void k_colsum(ColsumJobs jobs, int64_t rows, int stride) {
   __shared__ float red[16][64];
+  const ColsumJob& job = jobs.j[blockIdx.y];
+  const float* __restrict__ src = job.src;
+  const int n = job.n;
+  if (blockIdx.x * 64 >= n) return;                   // (uniform) a narrower job of the same launch
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + c;
   float s = 0.f;
   if (j < n) {
-    // four independent partial sums keep several loads in flight (a single workgroup streams the whole slab)
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // eight independent partial sums keep several loads in flight (a single workgroup streams the whole slab)
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int64_t w = part;
-    for (; w + 48 < rows; w += 64) {
-      s0 += src[w * stride + j];
-      s1 += src[(w + 16) * stride + j];
-      s2 += src[(w + 32) * stride + j];
-      s3 += src[(w + 48) * stride + j];
+    for (; w + 112 < rows; w += 128) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += src[(w + 16 * u) * stride + j];
     }
-    for (; w < rows; w += 16) s0 += src[w * stride + j];
-    s = (s0 + s1) + (s2 + s3);
+    for (; w < rows; w += 16) a[0] += src[w * stride + j];
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   red[part][c] = s;
   __syncthreads();
@@ -612,8 +614,23 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, 
     float t = 0.f;
 #pragma unroll
     for (int p = 0; p < 16; ++p) t += red[p][c];
-    dst[int64_t(j) * dst_stride] = t;
+    job.dst[int64_t(j) * job.dst_stride] = t;
   }
+}
+
+int ColsumBatch::add(const float* src, int n, float* dst, int dst_stride) {
+  if (jobs.n == COLSUM_MAX_JOBS)
+    if (int rc = flush()) return rc;
+  jobs.j[jobs.n++] = ColsumJob{src, dst, n, dst_stride};
+  return TRAJSDE_OK;
+}
+int ColsumBatch::flush() {
+  if (jobs.n == 0) return TRAJSDE_OK;
+  int widest = 0;
+  for (int i = 0; i < jobs.n; ++i) widest = jobs.j[i].n > widest ? jobs.j[i].n : widest;
+  TS_LAUNCH(k_colsum, dim3(cdiv(widest, 64), jobs.n), 1024, 0, st, jobs, rows, stride);
+  jobs.n = 0;
+  return TRAJSDE_OK;
 }
 
 int WgradBatch::add(const float* delta, int ldd, const float* a, int lda, float* W, int ldw, int col0, float* bias, int time_cols) {
@@ -666,10 +683,43 @@ int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, in
   if (int rc = b.add(delta, ldd, a, lda, W, ldw, col0, bias, time_cols)) return rc;
   return b.flush();
 }
+// a tall slab (rows >> the 16 row slices of one workgroup): `slices` workgroups per 64 columns each sum a contiguous share of the
+// rows into scratch[slice][n], a second launch sums the slices -- fixed order, no atomics
+__global__ __launch_bounds__(1024) void k_colsum_slices(const float* __restrict__ src, int64_t rows, int stride, int n, float* __restrict__ scratch) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  const int64_t per = (rows + gridDim.y - 1) / gridDim.y, lo = blockIdx.y * per, hi = lo + per < rows ? lo + per : rows;
+  float s = 0.f;
+  if (j < n) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t w = lo + part;
+    for (; w + 48 < hi; w += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] += src[(w + 16 * u) * stride + j];
+    }
+    for (; w < hi; w += 16) a[0] += src[w * stride + j];
+    s = (a[0] + a[1]) + (a[2] + a[3]);
+  }
+  red[part][c] = s;
+  __syncthreads();
+  if (part == 0 && j < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += red[p][c];
+    scratch[int64_t(blockIdx.y) * n + j] = t;
+  }
+}
+int run_colsum_tall(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, float* scratch /* 256 x n floats */) {
+  if (rows < 16384) return run_colsum(st, src, rows, stride, n, dst, 1);
+  const int slices = 256;
+  TS_LAUNCH(k_colsum_slices, dim3(cdiv(n, 64), slices), 1024, 0, st, src, rows, stride, n, scratch);
+  return run_colsum(st, scratch, slices, n, n, dst, 1);
+}
 int run_colsum(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride) {
-  k_colsum<<<cdiv(n, 64), 1024, 0, st>>>(src, rows, stride, n, dst, dst_stride);
-  TS_LAUNCH_CHECK("k_colsum");
-  return TRAJSDE_OK;
+  ColsumBatch b(st, rows, stride);
+  if (int rc = b.add(src, n, dst, dst_stride)) return rc;
+  return b.flush();
 }
 
 }  // namespace tsde
@@ -783,26 +833,34 @@ int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, cons
   TS_LAUNCH(k_head_bwd, head_grid, BWD_THREADS, HeadBwdL::SIZE * 4, st, blob_bwd + DecBwdBlob::HEAD, w.states, out_table, y, reg_mask,
             w.scal, N, T, w.S_in, w.DU, w.DS, w.vpart);
   const int head_waves = head_grid * waves;
-  auto colsum = [&](const float* src, int rows, int stride, int n, float* dst) { k_colsum<<<cdiv(n, 64), 1024, 0, st>>>(src, rows, stride, n, dst, 1); };
-  colsum(w.vpart + HeadV::DGAM, head_waves, HeadV::SIZE, 64, grads[D1W]);
-  colsum(w.vpart + HeadV::DBET, head_waves, HeadV::SIZE, 64, grads[D1B]);
-  colsum(w.vpart + HeadV::DW3X, head_waves, HeadV::SIZE, 128, grads[D3W]);      // rows x, y of decoder.3.weight [2,64]
-  colsum(w.vpart + HeadV::DB3, head_waves, HeadV::SIZE, 2, grads[D3B]);
-  TS_LAUNCH_CHECK("k_colsum(head)");
+  {
+    ColsumBatch cb(st, head_waves, HeadV::SIZE);
+    cb.add(w.vpart + HeadV::DGAM, 64, grads[D1W]);
+    cb.add(w.vpart + HeadV::DBET, 64, grads[D1B]);
+    cb.add(w.vpart + HeadV::DW3X, 128, grads[D3W]);      // rows x, y of decoder.3.weight [2,64]
+    cb.add(w.vpart + HeadV::DB3, 2, grads[D3B]);
+    if (int rc = cb.flush()) return rc;
+  }
 
   const int sweep_grid = bwd_grid(ntiles);
   TS_LAUNCH(k_sde_bwd, sweep_grid, BWD_THREADS, SweepL::SIZE * 4, st, blob_bwd + DecBwdBlob::SWEEP, w.best, N, K, T, n_euler, step_table,
             out_table, na, w.H1, w.H2, w.G1, w.G2, w.GS, w.DS, w.DH1, w.DH2, w.DF, w.DG1, w.DG2, w.DY0, w.vpart);
-  colsum(w.vpart + SweepV::DV4, sweep_grid * waves, SweepV::SIZE, 64, grads[G4W]);
-  colsum(w.vpart + SweepV::DC4, sweep_grid * waves, SweepV::SIZE, 1, grads[G4B]);
-  TS_LAUNCH_CHECK("k_colsum(sweep)");
+  {
+    ColsumBatch cb(st, sweep_grid * waves, SweepV::SIZE);
+    cb.add(w.vpart + SweepV::DV4, 64, grads[G4W]);
+    cb.add(w.vpart + SweepV::DC4, 1, grads[G4B]);
+    if (int rc = cb.flush()) return rc;
+  }
 
   TS_HIP(hipMemsetAsync(d_global, 0, size_t(K) * N * 64 * sizeof(float), st));
   TS_LAUNCH(k_dec_init_bwd, sweep_grid, BWD_THREADS, InitBwdL::SIZE * 4, st, init_img, local_embed, w.gsel, w.DY0, w.best, N, w.DA, d_local,
             d_global, w.vpart);
-  colsum(w.vpart + InitV::DGAM, sweep_grid * waves, InitV::SIZE, 64, grads[A1W]);
-  colsum(w.vpart + InitV::DBET, sweep_grid * waves, InitV::SIZE, 64, grads[A1B]);
-  TS_LAUNCH_CHECK("k_colsum(init)");
+  {
+    ColsumBatch cb(st, sweep_grid * waves, InitV::SIZE);
+    cb.add(w.vpart + InitV::DGAM, 64, grads[A1W]);
+    cb.add(w.vpart + InitV::DBET, 64, grads[A1B]);
+    if (int rc = cb.flush()) return rc;
+  }
 
   // ---- weight gradients: (delta rows, input rows, rows, rows per step) -> W (+ column offset), bias, time columns
   const WgradCtx wc{st, w.part, w.cs, step_table, w.parts};

@@ -4,7 +4,8 @@
 //
 // Inputs: dL/d local_embed [N,64] (decoder + aggregator) and the weight of the DiffBCE term.  The forward is
 // recomputed keeping a tape, then walked backwards:
-//   ALEncoder     node block -> segment-attention backward -> edge (lane embedding, k, v) backward -> norm1/lin_q
+//   ALEncoder     node block -> attention backward over the stored embedding rows (one wave per target) -> lane embedding
+//                 backward -> norm1/lin_q
 //   recurrence    21 x { GRU_Unit backward, Euler-Maruyama step backward (drift + the source's diffusion net) },
 //                 d latent enters at each actor's kept iteration, d DiffBCE/d g at the picked diffusion values
 //   AAEncoder     the same attention chain over the 21 snapshots, then the centre embedding / bos tokens
@@ -24,126 +25,6 @@
 #include "tile_bwd.hpp"
 
 namespace tsde {
-
-// ------------------------------------------------------------------ segment attention backward (AA / AL)
-// wave per target row, lane = feature (head = lane >> 3).  alpha recomputed from the saved logits;
-// DV[e] = alpha_h dagg,  DLG[e][slot(h)] = alpha_h (dagg_h . v_e,h - dagg_h . agg_h)   (w.r.t. the stored, scaled logit)
-__global__ __launch_bounds__(256) void k_seg_attn_bwd(const int32_t* __restrict__ segptr, const float* __restrict__ logits,
-                                                      const float* __restrict__ v, const float* __restrict__ agg,
-                                                      const float* __restrict__ dagg, int64_t R, float* __restrict__ DV,
-                                                      float* __restrict__ DLG, int heads, DropArg drop) {
-  const int lane = threadIdx.x & 63;
-  const int head = heads == 4 ? lane >> 4 : lane >> 3, slot = heads == 4 ? head : 4 * (head & 1) + (head >> 1);
-  const int lph_mask = heads == 4 ? 15 : 7;
-  const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform
-  if (node >= R) return;
-  const int beg = segptr[node], end = segptr[node + 1];
-  if (end <= beg) return;
-  float m = -INFINITY, s = 0.f;
-  for (int e0 = beg; e0 < end; e0 += 16) {                 // the chunked online softmax of k_seg_softmax_agg (same m, s)
-    float p[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) p[u] = (logits + int64_t(e0 + u < end ? e0 + u : end - 1) * 8)[slot];
-    float cm = -INFINITY;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      p[u] = e0 + u < end ? p[u] : -INFINITY;
-      cm = fmaxf(cm, p[u]);
-    }
-    const float mn = fmaxf(m, cm);
-    s *= fast_exp(m - mn);
-    m = mn;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s += fast_exp(p[u] - m);
-  }
-  const float inv = 1.0f / (s + 1e-16f);
-  const float da = dagg[node * 64 + lane];
-  const float t0 = da * agg[node * 64 + lane];
-  const float dlt = heads == 4 ? head_sum16(t0) : head_sum(t0);
-  // attention dropout (ENC:592): agg = sum_e alpha_e d_e v_e with d_e = keep_e / (1 - p), so d v_e = alpha_e d_e dagg and
-  // d alpha_e = d_e (dagg . v_e); `dlt` = dagg . agg is already the dropped aggregate's
-  for (int e0 = beg; e0 < end; e0 += 4) {                  // 4 edges' loads in flight
-    float lg[4], vv[4], kp[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u < end ? e0 + u : end - 1;
-      lg[u] = (logits + int64_t(e) * 8)[slot];
-      vv[u] = (v + int64_t(e) * 64)[lane];
-      kp[u] = 1.0f;
-    }
-    if (drop.p > 0.f) drop_attn_chunk<4>(kp, drop, uint32_t(node), uint32_t(e0 - beg), lane, head);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u;
-      if (e >= end) break;
-      const float alpha = fast_exp(lg[u] - m) * inv;
-      const float t1 = da * vv[u];
-      const float dal = (heads == 4 ? head_sum16(t1) : head_sum(t1)) * kp[u];
-      (DV + int64_t(e) * 64)[lane] = alpha * kp[u] * da;
-      if ((lane & lph_mask) == 0) (DLG + int64_t(e) * 8)[slot] = alpha * (dal - dlt);
-    }
-  }
-}
-
-// DQ[r] = sum of the DQE rows of segment r (edges are sorted by target)
-__global__ __launch_bounds__(256) void k_seg_sum(const int32_t* __restrict__ segptr, const float* __restrict__ DQE, int64_t R,
-                                                 float* __restrict__ DQ) {
-  const int lane = threadIdx.x & 63;
-  const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (node >= R) return;
-  float s = 0.f;
-  const int beg = segptr[node], end = segptr[node + 1];
-  for (int e0 = beg; e0 < end; e0 += 8) {
-    float x[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) x[u] = (DQE + int64_t(e0 + u < end ? e0 + u : end - 1) * 64)[lane];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += e0 + u < end ? x[u] : 0.f;          // same order as one row at a time
-  }
-  DQ[node * 64 + lane] = s;
-}
-
-// edge rows: recompute emb, k;  dk = dlogit * q[dst] / sqrt(dh) (the stored logit is already scaled),
-// DQE = dlogit * k,  DEMB = Wk^T dk + Wv^T dv;  saves EMB and DK for the lin_k / lin_v weight gradients
-__global__ __launch_bounds__(512) void k_edge_kv_bwd(const float* __restrict__ img, const float* __restrict__ geom,
-                                                     const int32_t* __restrict__ dst, const float* __restrict__ q,
-                                                     const float* __restrict__ DLG, const float* __restrict__ DV, int64_t E,
-                                                     float* __restrict__ EMB, float* __restrict__ DK, float* __restrict__ DQE,
-                                                     float* __restrict__ DEMB, int heads) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_blob(lds, img, EdgeKvBwdL::SIZE);
-  const Lane L;
-  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
-  const int64_t ntiles = (E + 15) / 16;
-  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
-    keep_lds_reads_here();
-    const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
-    const f4 ge = *reinterpret_cast<const f4*>(geom + 4 * ec);
-    f4 emb[4], k[4], qv[4], dk[4], dqe[4], dv[4], de[4];
-    load_row(qv, q, dst[ec], L.g);
-    edge_embed<true>(emb, ge, lds, L);
-    linear_x6<4, 4>(k, emb, lds + EdgeKvBwdL::WK6, lds + EdgeKvBwdL::BK, L);
-    // 8 heads: lane group g holds heads 2jt + (g>>1) at slots 4(g>>1) + jt; 4 heads: head jt at slot jt for every g
-    const f4 dl = *reinterpret_cast<const f4*>(DLG + ec * 8 + (heads == 4 ? 0 : 4 * (L.g >> 1)));
-    const float sc = heads == 4 ? 0.25f : INV_SQRT_DH;
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        dk[jt][c] = dl[jt] * qv[jt][c] * sc;
-        dqe[jt][c] = dl[jt] * k[jt][c] * sc;
-      }
-    load_row(dv, DV, ec, L.g);
-    linear_t(de, dk, lds + EdgeKvBwdL::WKT, L);
-    linear_adj<4, 4>(de, dv, lds + EdgeKvBwdL::WVT, L);
-    if (e < E) {
-      store_row(emb, EMB, e, L.g);
-      store_row(dk, DK, e, L.g);
-      store_row(dqe, DQE, e, L.g);
-      store_row(de, DEMB, e, L.g);
-    }
-  }
-}
 
 // ------------------------------------------------------------------ centre embedding (SingleInputEmbedding, EMB:22-40)
 // forward: a1 = relu(LN1(W0 xr + b0)); a2 = relu(LN4(W3 a1 + b3)); centre = LN7(W6 a2 + b6), replaced by the bos token
@@ -217,14 +98,35 @@ __global__ __launch_bounds__(256) void k_aa_center_bwd_tail(const float* __restr
   flush_vec(db4, vp + 192, L);
 }
 
-// d bos_token[t][c] = sum over the rows (t, i) that took the token of dcentre; one workgroup per t
+// d bos_token[t][c] = sum over the rows (t, i) that took the token of dcentre; one workgroup per t.  Few rows take the token
+// (an actor's first valid step), so each wave scans its contiguous share of the rows 64 at a time for the flag and only then
+// loads the flagged rows, in ascending order (fixed summation order).
 __global__ __launch_bounds__(1024) void k_bos_grad(const float* __restrict__ dcenter, const uint8_t* __restrict__ bos,
                                                    const int32_t* __restrict__ orig, int Nt, int H, float* __restrict__ dtok) {
   __shared__ float red[16][64];
   const int t = blockIdx.x, c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int per = (((Nt + 15) / 16) + 63) & ~63;
+  const int r0 = part * per, r1 = r0 + per < Nt ? r0 + per : Nt;
   float s = 0.f;
-  for (int i = part; i < Nt; i += 16)
-    if (bos[int64_t(orig[i]) * H + t]) s += dcenter[(int64_t(t) * Nt + i) * 64 + c];
+  for (int base = r0; base < r1; base += 64) {
+    const int i = base + c;
+    const bool f = i < r1 && bos[int64_t(orig[i]) * H + t] != 0;
+    unsigned long long m = __ballot(f);
+    while (m) {                                              // eight flagged rows in flight, added in ascending order
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k] = 0.f;
+        if (m) {
+          const int b = __ffsll(m) - 1;
+          m &= m - 1;
+          v[k] = dcenter[(int64_t(t) * Nt + base + b) * 64 + c];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+  }
   red[part][c] = s;
   __syncthreads();
   if (part == 0) {
@@ -614,15 +516,15 @@ __global__ void k_gather_latent(const float* __restrict__ HODE, const float* __r
 // ------------------------------------------------------------------ workspace
 struct EncBwdWs {
   // AA tape
-  float *center, *cn, *q, *logits, *v, *agg, *x1, *xn2, *aa_out;
+  float *center, *cn, *q, *emb, *stats, *agg, *x1, *xn2, *aa_out;      // emb [E_aa,64]: nbr_embed rows; stats [R,8,2]: softmax (max, 1/sum)
   // recurrence tape (slabs [H][Nt][64]) and running states
   float *HIN, *H1, *H2, *G1, *G2, *GS, *HODE, *XS, *U1, *R1, *UU, *RR, *RH, *N1, *NW, *hcur, *lat;
   // AL tape
-  float *al_xn, *al_q, *al_logits, *al_v, *al_agg, *al_x1, *al_xn2;
+  float *al_xn, *al_q, *al_emb, *al_stats, *al_agg, *al_x1, *al_xn2;
   // backward: recurrence deltas
   float *DF, *DH2, *DH1, *DG2N, *DG1N, *DG2A, *DG1A, *DGPN, *DGPA, *DNW, *DN1P, *DUP, *DRP, *DU1, *DR1, *DHO, *dhA, *dhB, *DLDG, *DLAT, *DAA;
   // backward: attention chain scratch (sized for the larger of the AA / AL problems)
-  float *dagg, *dxn, *DQ, *DCENTER, *DV, *DLG, *EMB, *DK, *DQE, *DEMB, *A1, *A2, *DA3P, *DA2P, *XR, *part, *cs, *scal;
+  float *dagg, *dxn, *DQ, *DCENTER, *EA, *ED, *RL, *SS, *DAGGM, *A1, *A2, *DA3P, *DA2P, *XR, *part, *cs, *scal;
   NodeBlockScratch nb;
   EdgeEmbedScratch ee;
   int64_t total, parts;
@@ -632,7 +534,7 @@ struct EncBwdWs {
     const int64_t H = b->H, Nt = g->Nt, N = b->N, R = H * Nt, Eaa = g->E_aa, Ela = g->E_la, E = (Eaa > Ela ? Eaa : Ela) + 1;
     float** rows_R[] = {&center, &cn, &q, &agg, &x1, &xn2, &aa_out, &HIN, &H1, &H2, &G1, &G2, &HODE, &XS, &U1, &R1, &UU, &RR, &RH, &N1,
                         &NW, &DF, &DH2, &DH1, &DG2N, &DG1N, &DG2A, &DG1A, &DNW, &DN1P, &DUP, &DRP, &DU1, &DR1, &DAA, &dagg, &dxn, &DQ,
-                        &DCENTER, &A1, &A2, &DA3P, &DA2P, &nb.dx1, &nb.UPD, &nb.DGP, &nb.DS};
+                        &DCENTER, &DAGGM, &A1, &A2, &DA3P, &DA2P, &nb.dx1, &nb.UPD, &nb.DGP, &nb.DS};
     for (float** p : rows_R) *p = c.take<float>(R * 64);
     float** rows_Rs[] = {&GS, &DGPN, &DGPA};
     for (float** p : rows_Rs) *p = c.take<float>(R);
@@ -644,16 +546,16 @@ struct EncBwdWs {
     DLDG = c.take<float>(Nt);
     float** rows_N[] = {&lat, &al_xn, &al_q, &al_agg, &al_x1, &al_xn2, &DLAT};
     for (float** p : rows_N) *p = c.take<float>(N * 64);
-    logits = c.take<float>(Eaa * 8 + 8);
-    v = c.take<float>(Eaa * 64 + 64);
-    al_logits = c.take<float>(Ela * 8 + 8);
-    al_v = c.take<float>(Ela * 64 + 64);
-    DLG = c.take<float>(E * 8);
-    float** rows_E[] = {&DV, &EMB, &DK, &DQE, &DEMB};
+    emb = c.take<float>(Eaa * 64 + 64);
+    stats = c.take<float>(R * 16);
+    al_emb = c.take<float>(Ela * 64 + 64);
+    al_stats = c.take<float>(N * 16);
+    EA = c.take<float>(E * 8 + 64);
+    ED = c.take<float>(E * 8 + 64);
+    RL = c.take<float>(R * 512);                              // per (target, head) sums of the embedding rows (run_edge_attn_bwd)
+    SS = c.take<float>(R * 512);
+    float** rows_E[] = {&ee.S, &ee.DEP, &ee.DSP};
     for (float** p : rows_E) *p = c.take<float>(E * 64);
-    // the embedding backward starts after the lin_k / lin_v weight gradients (the last readers of DK, DV, EMB, DQE) are
-    // enqueued on the same stream, so its three per-edge slabs reuse those buffers: 3 x E x 256 B less workspace
-    ee.S = DK; ee.DEP = DV; ee.DSP = DQE;
     nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
     const int64_t rows = E > R ? E : R;
     parts = wgrad_max_parts(rows, H);
@@ -668,14 +570,15 @@ struct EncBwdWs {
 // attention chain of one encoder (AA or AL) given d out rows: node block, segment softmax, edge kernel, projection.
 // Returns d x (the block's input rows) in `dx_out`.
 struct AttnChain {
-  const float *img_node, *img_proj, *img_kv, *img_emb;            // backward images
-  const float *geom, *q, *logits, *v, *x;                         // graph + tape
+  const float *img_node, *img_proj, *img_attn, *img_emb;          // backward images (img_attn: GAttnL of lin_k / lin_v, forward blob)
+  const float *geom, *q, *emb, *stats, *x;                        // graph + tape (emb: embedding rows, stats: softmax max | 1/sum)
   const int32_t *dst, *segptr;
   NodeBlockTape tp;
   int64_t R, E;
   std::string prefix, embed;                                      // parameter names: <prefix>.lin_k..., <prefix>.<embed>...
   int heads = 8;
   DropArg drop = no_drop();                                       // train-mode dropout of this block (dropout.hpp)
+  const float* img_kvt = nullptr;                                 // lin_k^T | lin_v^T (EdgeKvBwdL::WKT of the backward blob)
 };
 
 }  // namespace tsde
@@ -718,38 +621,46 @@ int run_attn_chain(const AttnChain& c, const float* dout, EncBwdWs& w, const Wgr
   TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
   const int64_t R = c.R, E = c.E;
   if (int rc = node_block_backward(c.img_node, c.tp, dout, R, w.nb, wc, gr, w.dagg, w.dxn, st, c.drop)) return rc;
-  TS_HIP(hipMemsetAsync(w.DQ, 0, size_t(R) * 64 * sizeof(float), st));
+  // Attention over the stored embedding rows, one wave per target (aggregator_bwd.hip k_gattn_bwd<.., NODE = false>): with
+  // k_e = lin_k(emb_e), v_e = lin_v(emb_e) the per-edge matrices drop out --
+  //   d lin_k.weight = headwise outer(q, RL),  RL_h = sum_e dlogit_e,h emb_e        d lin_k.bias = 0 (shifts a target's logits alike)
+  //   d lin_v.weight = headwise outer(dagg, SS), SS_h = sum_e alpha_e,h emb_e       d lin_v.bias = column sum of DAGGM
+  //   d emb_e        = Wk^T (dlogit_e,h q) + Wv^T (alpha_e,h dagg)   built inside the embedding backward (EdgeAttnGrad)
+  // so no [E,64] row of k, v, d k, d v or d emb is ever written.  A target without edges gets DQ = 0, RL = SS = 0 from the kernel.
+  if (int rc = run_edge_attn_bwd(st, c.heads, c.img_attn, c.segptr, c.emb, c.q, c.tp.agg, w.dagg, c.stats, R, w.DQ, w.RL, w.SS, w.DAGGM,
+                                 w.EA, w.ED, c.drop))
+    return rc;
+  if (int rc = run_headwise_outer(wc, c.q, w.RL, R, wk, c.heads)) return rc;
+  if (int rc = run_headwise_outer(wc, w.dagg, w.SS, R, wv, c.heads)) return rc;
+  TS_HIP(hipMemsetAsync(bk, 0, 64 * sizeof(float), st));
+  if (int rc = run_colsum_tall(st, w.DAGGM, R, 64, 64, bv, w.nb.vpart)) return rc;
   if (E > 0) {
-    TS_LAUNCH(k_seg_attn_bwd, cdiv(R, 4), 256, 0, st, c.segptr, c.logits, c.v, c.tp.agg, w.dagg, R, w.DV, w.DLG, c.heads, c.drop);
-    TS_LAUNCH(k_edge_kv_bwd, tile_grid((E + 15) / 16, 512, EdgeKvBwdL::SIZE * 4), 512, EdgeKvBwdL::SIZE * 4, st, c.img_kv, c.geom, c.dst, c.q,
-              w.DLG, w.DV, E, w.EMB, w.DK, w.DQE, w.DEMB, c.heads);
-    TS_LAUNCH(k_seg_sum, cdiv(R, 4), 256, 0, st, c.segptr, w.DQE, R, w.DQ);
-    {
-      WgradBatch wb(wc, E, E);
-      if (int rc = wb.add(w.DK, 64, w.EMB, 64, wk, 64, 0, bk, 0)) return rc;
-      if (int rc = wb.add(w.DV, 64, w.EMB, 64, wv, 64, 0, bv, 0)) return rc;
-      if (int rc = wb.flush()) return rc;
-    }
-    if (int rc = edge_embed_backward(c.img_emb, c.geom, w.DEMB, E, w.ee, wc, eg, st)) return rc;
+    const EdgeAttnGrad ag{c.dst, c.q, w.dagg, w.EA, w.ED, c.img_kvt, c.heads};
+    if (int rc = edge_embed_backward(c.img_emb, c.geom, nullptr, E, w.ee, wc, eg, st, &ag)) return rc;
   }
   const int gp = vec_grid((R + 15) / 16, 256, ProjBwdL<1>::SIZE * 4);
   TS_LAUNCH(k_node_proj_bwd<1>, gp, 256, ProjBwdL<1>::SIZE * 4, st, c.img_proj, c.x, w.nb.dx1, w.dxn, w.DQ, nullptr, nullptr, R, dx_out,
             nullptr, w.nb.vpart);
-  if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, n1g)) return rc;
-  if (int rc = run_colsum(st, w.nb.vpart + 64, gp * 4, 128, 64, n1b)) return rc;
+  {
+    ColsumBatch cb(st, gp * 4, 128);
+    cb.add(w.nb.vpart, 64, n1g);
+    cb.add(w.nb.vpart + 64, 64, n1b);
+    if (int rc = cb.flush()) return rc;
+  }
   return run_wgrad(wc, w.DQ, 64, c.tp.xn, 64, R, R, wq, 64, 0, bq, 0);
 }
 
 // AAEncoder backward over the H snapshots: w.DAA = d aa_out [H,Nt,64] on entry; attention chain, centre embedding, bos tokens
-int aa_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_bwd, EncBwdWs& w,
+int aa_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_fwd, const float* blob_bwd, EncBwdWs& w,
                         const WgradCtx& wc, GradTable& G, int heads, hipStream_t st, const DropArg& drop = no_drop()) {
   using BB = EncBwdBlob;
   const int N = b->N, Nt = g->Nt, H = b->H;
   const int64_t R = int64_t(H) * Nt, Eaa = g->E_aa;
-  AttnChain c{blob_bwd + BB::AA_NODE, blob_bwd + BB::AA_PROJ, blob_bwd + BB::AA_EDGEKV, blob_bwd + BB::AA_EDGEEMB,
-              g->aa_geom, w.q, w.logits, w.v, w.center, g->aa_dst, g->aa_segptr, NodeBlockTape{w.agg, w.cn, w.x1, w.xn2}, R, Eaa,
+  AttnChain c{blob_bwd + BB::AA_NODE, blob_bwd + BB::AA_PROJ, blob_fwd + EncBlob::AA_ATTN, blob_bwd + BB::AA_EDGEEMB,
+              g->aa_geom, w.q, w.emb, w.stats, w.center, g->aa_dst, g->aa_segptr, NodeBlockTape{w.agg, w.cn, w.x1, w.xn2}, R, Eaa,
               "aa_encoder", "nbr_embed", heads};
   c.drop = drop;
+  c.img_kvt = blob_bwd + BB::AA_EDGEKV + EdgeKvBwdL::WKT;
   if (int rc = run_attn_chain(c, w.DAA, w, wc, G, w.DCENTER, st)) return rc;
   const std::string ce = "aa_encoder.center_embed.embed.";
   float *w0 = G(ce + "0.weight"), *b0 = G(ce + "0.bias"), *g1 = G(ce + "1.weight"), *e1 = G(ce + "1.bias");
@@ -761,23 +672,42 @@ int aa_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const fl
   TS_LAUNCH(k_aa_center_bwd_tail, gt, 256, CenterTailL::SIZE * 4, st, blob_bwd + BB::AA_CTAIL, b->x, g->x_fake, rot, b->bos_mask, g->orig, N,
             Nt, H, w.DCENTER, w.A1, w.A2, w.DA3P, w.DA2P, w.XR, w.nb.vpart);
   float* const tv[4] = {g7, e7, g4, e4};
-  for (int i = 0; i < 4; ++i)
-    if (int rc = run_colsum(st, w.nb.vpart + 64 * i, gt * 4, 256, 64, tv[i])) return rc;
+  {
+    ColsumBatch cb(st, gt * 4, 256);
+    for (int i = 0; i < 4; ++i) cb.add(w.nb.vpart + 64 * i, 64, tv[i]);
+    if (int rc = cb.flush()) return rc;
+  }
   if (int rc = run_wgrad(wc, w.DA3P, 64, w.A2, 64, R, R, w6, 64, 0, b6, 0)) return rc;
   if (int rc = run_wgrad(wc, w.DA2P, 64, w.A1, 64, R, R, w3, 64, 0, b3, 0)) return rc;
   const int lds_br = (EdgeL::WA3 + MAT64) * 4;
   const int gb = vec_grid((R + 15) / 16, 256, lds_br);
   TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, blob_bwd + BB::AA_CHEAD, w.XR, w.DA2P, R, w.nb.vpart);
-  if (int rc = run_colsum(st, w.nb.vpart, gb * 4, 320, 64, g1)) return rc;
-  if (int rc = run_colsum(st, w.nb.vpart + 64, gb * 4, 320, 64, e1)) return rc;
-  if (int rc = run_colsum(st, w.nb.vpart + 128, gb * 4, 320, 64, w0, 2)) return rc;
-  if (int rc = run_colsum(st, w.nb.vpart + 192, gb * 4, 320, 64, w0 + 1, 2)) return rc;
-  if (int rc = run_colsum(st, w.nb.vpart + 256, gb * 4, 320, 64, b0)) return rc;
+  {
+    ColsumBatch cb(st, gb * 4, 320);
+    cb.add(w.nb.vpart, 64, g1);
+    cb.add(w.nb.vpart + 64, 64, e1);
+    cb.add(w.nb.vpart + 128, 64, w0, 2);
+    cb.add(w.nb.vpart + 192, 64, w0 + 1, 2);
+    cb.add(w.nb.vpart + 256, 64, b0);
+    if (int rc = cb.flush()) return rc;
+  }
   TS_LAUNCH(k_bos_grad, H, 1024, 0, st, w.DCENTER, b->bos_mask, g->orig, Nt, H, tok);
   return TRAJSDE_OK;
 }
 
 }  // namespace
+
+// training-path attention of an encoder (AA / AL): the edge embedding rows are computed once and KEPT (the tape), the attention
+// itself runs one wave per target over those rows (k_global_attn<.., NODE = false>: lin_k / lin_v folded into per-target
+// vectors) and leaves the softmax statistics for the backward
+static int edge_attention_tape(const float* img_edge6, const float* img_attn, const float* geom, int64_t E, const int32_t* segptr, const float* q,
+                               int64_t R, float* emb, float* stats, float* agg, int heads, const DropArg& drop, hipStream_t st) {
+  if (E > 0)
+    TS_LAUNCH(k_edge_embed<true>, tile_grid((E + 15) / 16, 1024, EdgeL6::EMB_SIZE * 4), 1024, EdgeL6::EMB_SIZE * 4, st, img_edge6, geom,
+              EdgeCount{E, nullptr, 0}, emb, 0);
+  TS_EDGE_ATTN(heads, drop, cdiv(R, 4), 256, 0, st, img_attn, segptr, emb, q, R, agg, stats);
+  return TRAJSDE_OK;
+}
 
 // The encoder's forward with every activation the backward needs kept in `w` (the "tape"): the split-precision kernels the
 // inference forward runs, in their two-kernel attention form (per-edge logits / v are needed by the softmax backward), the
@@ -792,10 +722,9 @@ static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const fl
   using FB = EncBlob;
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob_fwd + FB::AA_CENTER, b->x,
             g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
-  if (Eaa > 0)
-    TS_LAUNCH(k_edge_kv<true>, tile_grid((Eaa + 15) / 16, 1024, EdgeL6::SIZE * 4), 1024, EdgeL6::SIZE * 4, st, blob_fwd + FB::AA_EDGE6,
-              g->aa_geom, g->aa_dst, w.q, Eaa, w.logits, w.v, 8);
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, g->aa_segptr, w.logits, w.v, R, w.agg, 8, drop_aa);
+  if (int rc = edge_attention_tape(blob_fwd + FB::AA_EDGE6, blob_fwd + FB::AA_ATTN, g->aa_geom, Eaa, g->aa_segptr, w.q, R, w.emb, w.stats, w.agg,
+                                   8, drop_aa, st))
+    return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
             w.center, R, w.x1, w.xn2, drop_aa);
   TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out, drop_aa);
@@ -814,10 +743,9 @@ static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const fl
   TS_LAUNCH_CHECK("k_gather_latent");
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob_fwd + FB::AL_Q, w.lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
-  if (Ela > 0)
-    TS_LAUNCH(k_edge_kv<true>, tile_grid((Ela + 15) / 16, 1024, EdgeL6::SIZE * 4), 1024, EdgeL6::SIZE * 4, st, blob_fwd + FB::AL_EDGE6,
-              g->la_geom, g->la_dst, w.al_q, Ela, w.al_logits, w.al_v, 8);
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(N, 4), 256, 0, st, g->la_segptr, w.al_logits, w.al_v, int64_t(N), w.al_agg, 8, drop_al);
+  if (int rc = edge_attention_tape(blob_fwd + FB::AL_EDGE6, blob_fwd + FB::AL_ATTN, g->la_geom, Ela, g->la_segptr, w.al_q, int64_t(N), w.al_emb,
+                                   w.al_stats, w.al_agg, 8, drop_al, st))
+    return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
             w.al_agg, w.al_xn, w.lat, int64_t(N), w.al_x1, w.al_xn2, drop_al);
 
@@ -906,10 +834,11 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   // ================= backward =================
   // ---- ALEncoder: d local_embed -> d latent
   {
-    AttnChain c{blob_bwd + BB::AL_NODE, blob_bwd + BB::AL_PROJ, blob_bwd + BB::AL_EDGEKV, blob_bwd + BB::AL_EDGEEMB,
-                g->la_geom, w.al_q, w.al_logits, w.al_v, w.lat, g->la_dst, g->la_segptr,
+    AttnChain c{blob_bwd + BB::AL_NODE, blob_bwd + BB::AL_PROJ, blob_fwd + EncBlob::AL_ATTN, blob_bwd + BB::AL_EDGEEMB,
+                g->la_geom, w.al_q, w.al_emb, w.al_stats, w.lat, g->la_dst, g->la_segptr,
                 NodeBlockTape{w.al_agg, w.al_xn, w.al_x1, w.al_xn2}, int64_t(N), Ela, "al_encoder", "lane_embed"};
     c.drop = drop_al;
+    c.img_kvt = blob_bwd + BB::AL_EDGEKV + EdgeKvBwdL::WKT;
     if (int rc = run_attn_chain(c, d_local, w, wc, G, w.DLAT, st)) return rc;
     if (d_latent) TS_HIP(hipMemcpyAsync(d_latent, w.DLAT, size_t(N) * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
@@ -969,12 +898,16 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
     for (int net = 0; net < 2; ++net) {
       const int blocks = R >= 65536 ? 128 : 8;
       TS_LAUNCH(k_rowscale_colsum, blocks, 1024, 0, st, w.G2, net == 0 ? w.DGPN : w.DGPA, R, w.nb.vpart);
-      if (int rc = run_colsum(st, w.nb.vpart, blocks, 128, 64, net == 0 ? n4w : a4w)) return rc;
-      if (int rc = run_colsum(st, w.nb.vpart + 64, blocks, 128, 1, net == 0 ? n4b : a4b)) return rc;
+      {
+        ColsumBatch cb(st, blocks, 128);
+        cb.add(w.nb.vpart, 64, net == 0 ? n4w : a4w);
+        cb.add(w.nb.vpart + 64, 1, net == 0 ? n4b : a4b);
+        if (int rc = cb.flush()) return rc;
+      }
     }
   }
   if (d_aa_out) TS_HIP(hipMemcpyAsync(d_aa_out, w.DAA, size_t(R) * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
-  if (int rc = aa_encoder_backward(b, g, rot, blob_bwd, w, wc, G, 8, st, drop_aa)) return rc;
+  if (int rc = aa_encoder_backward(b, g, rot, blob_fwd, blob_bwd, w, wc, G, 8, st, drop_aa)) return rc;
   return TRAJSDE_OK;
 }
 
@@ -1044,10 +977,9 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
   // ================= forward recompute =================
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob_fwd + FB::AA_CENTER, b->x,
             g->x_fake, rot, b->bos_mask, g->orig, N, N, H, w.center, w.cn, w.q);
-  if (Eaa > 0)
-    TS_LAUNCH(k_edge_kv<true>, tile_grid((Eaa + 15) / 16, 1024, EdgeL6::SIZE * 4), 1024, EdgeL6::SIZE * 4, st, blob_fwd + FB::AA_EDGE6,
-              g->aa_geom, g->aa_dst, w.q, Eaa, w.logits, w.v, num_heads);
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(R, 4), 256, 0, st, g->aa_segptr, w.logits, w.v, R, w.agg, num_heads, no_drop());
+  if (int rc = edge_attention_tape(blob_fwd + FB::AA_EDGE6, blob_fwd + FB::AA_ATTN, g->aa_geom, Eaa, g->aa_segptr, w.q, R, w.emb, w.stats, w.agg,
+                                   num_heads, no_drop(), st))
+    return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
             w.center, R, w.x1, w.xn2, no_drop());
   TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out, no_drop());
@@ -1067,17 +999,17 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
   TS_LAUNCH(k_tr_final, tile_grid((int64_t(N) + 15) / 16, 256, 0), 256, 0, st, blob_fwd + EncGridBlob::norm(nl), x, N, tout);
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob_fwd + FB::AL_Q, tout, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
-  if (Ela > 0)
-    TS_LAUNCH(k_edge_kv<true>, tile_grid((Ela + 15) / 16, 1024, EdgeL6::SIZE * 4), 1024, EdgeL6::SIZE * 4, st, blob_fwd + FB::AL_EDGE6,
-              g->la_geom, g->la_dst, w.al_q, Ela, w.al_logits, w.al_v, num_heads);
-  TS_LAUNCH(k_seg_softmax_agg, cdiv(N, 4), 256, 0, st, g->la_segptr, w.al_logits, w.al_v, int64_t(N), w.al_agg, num_heads, no_drop());
+  if (int rc = edge_attention_tape(blob_fwd + FB::AL_EDGE6, blob_fwd + FB::AL_ATTN, g->la_geom, Ela, g->la_segptr, w.al_q, int64_t(N), w.al_emb,
+                                   w.al_stats, w.al_agg, num_heads, no_drop(), st))
+    return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
             w.al_agg, w.al_xn, tout, int64_t(N), w.al_x1, w.al_xn2, no_drop());
   // ================= backward =================
   {
-    AttnChain c{blob_bwd + BB::AL_NODE, blob_bwd + BB::AL_PROJ, blob_bwd + BB::AL_EDGEKV, blob_bwd + BB::AL_EDGEEMB,
-                g->la_geom, w.al_q, w.al_logits, w.al_v, tout, g->la_dst, g->la_segptr,
+    AttnChain c{blob_bwd + BB::AL_NODE, blob_bwd + BB::AL_PROJ, blob_fwd + EncBlob::AL_ATTN, blob_bwd + BB::AL_EDGEEMB,
+                g->la_geom, w.al_q, w.al_emb, w.al_stats, tout, g->la_dst, g->la_segptr,
                 NodeBlockTape{w.al_agg, w.al_xn, w.al_x1, w.al_xn2}, int64_t(N), Ela, "al_encoder", "lane_embed", num_heads};
+    c.img_kvt = blob_bwd + BB::AL_EDGEKV + EdgeKvBwdL::WKT;
     if (int rc = run_attn_chain(c, d_local, w, wc, G, dtout, st)) return rc;
   }
   const std::string te = "temporal_encoder.";
@@ -1089,8 +1021,12 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
     float *ng = G(te + "transformer_encoder.norm.weight"), *nb = G(te + "transformer_encoder.norm.bias");
     TS_REQUIRE(!G.missing, "encoder_grid_backward: parameter table lacks " + G.missing_name);
     TS_LAUNCH(k_tr_final_bwd, gf, 256, 0, st, blob_bwd + EncGridBwdBlob::norm(nl), x, dtout, N, dcur, w.nb.vpart);
-    if (int rc = run_colsum(st, w.nb.vpart, gf * 4, 128, 64, ng)) return rc;
-    if (int rc = run_colsum(st, w.nb.vpart + 64, gf * 4, 128, 64, nb)) return rc;
+    {
+      ColsumBatch cb(st, gf * 4, 128);
+      cb.add(w.nb.vpart, 64, ng);
+      cb.add(w.nb.vpart + 64, 64, nb);
+      if (int rc = cb.flush()) return rc;
+    }
   }
   NodeBlockScratch sc = w.nb;
   sc.H = ex.H;
@@ -1115,8 +1051,12 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
     const int gp = vec_grid(rtiles, 256, ProjBwdL<3>::SIZE * 4);
     TS_LAUNCH(k_node_proj_bwd<3>, gp, 256, ProjBwdL<3>::SIZE * 4, st, lb + TrLayerBwdL::PROJ, x_in, sc.dx1, nullptr, dq, dk, dv, RT, dnext,
               nullptr, w.nb.vpart);
-    if (int rc = run_colsum(st, w.nb.vpart, gp * 4, 128, 64, n1g)) return rc;
-    if (int rc = run_colsum(st, w.nb.vpart + 64, gp * 4, 128, 64, n1b)) return rc;
+    {
+      ColsumBatch cb(st, gp * 4, 128);
+      cb.add(w.nb.vpart, 64, n1g);
+      cb.add(w.nb.vpart + 64, 64, n1b);
+      if (int rc = cb.flush()) return rc;
+    }
     const float* dps[3] = {dq, dk, dv};
     WgradBatch wb(wc, RT, RT);
     for (int j = 0; j < 3; ++j)
@@ -1130,7 +1070,7 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
     TS_LAUNCH(k_tr_tok_grad, 22, 1024, 0, st, dcur, b->padding_mask, N, b->TT, gpad, gcls, gpos);
     TS_LAUNCH(k_tr_prep_bwd, cdiv(R * 64, 256), 256, 0, st, dcur, b->padding_mask, N, b->TT, w.DAA);
   }
-  return aa_encoder_backward(b, g, rot, blob_bwd, w, wc, G, num_heads, st);
+  return aa_encoder_backward(b, g, rot, blob_fwd, blob_bwd, w, wc, G, num_heads, st);
 }
 
 }  // extern "C"

@@ -273,8 +273,12 @@ int trajsde_mlp_decoder_l2_backward(int32_t N, int num_modes, int future_steps, 
   const int gh = vec_grid(ntiles, 256, MlpHeadBwdL::SIZE * 4);
   TS_LAUNCH(k_mlp_heads_bwd, gh, 256, MlpHeadBwdL::SIZE * 4, st, blob_bwd + MlpDecBwdBlob::HEAD, w.out, y, reg_mask, w.scal, N, T, w.H, w.DL,
             w.DU, w.DOUT, w.vpart);
-  if (int rc = run_colsum(st, w.vpart, gh * 4, 128, 64, grads[L1W])) return rc;
-  if (int rc = run_colsum(st, w.vpart + 64, gh * 4, 128, 64, grads[L1B])) return rc;
+  {
+    ColsumBatch cb(st, gh * 4, 128);
+    cb.add(w.vpart, 64, grads[L1W]);
+    cb.add(w.vpart + 64, 64, grads[L1B]);
+    if (int rc = cb.flush()) return rc;
+  }
   // loc.3 [2T, 64]: two 64-row blocks into a 128-row scratch, the first 2T rows are the gradient
   for (int b = 0; b < 2; ++b)
     if (int rc = run_wgrad(wc, w.DL + 64 * b, 128, w.H, 64, N, N, w.w3tmp + b * MAT64, 64, 0, w.b3tmp + 64 * b, 0)) return rc;
@@ -284,8 +288,12 @@ int trajsde_mlp_decoder_l2_backward(int32_t N, int num_modes, int future_steps, 
   TS_HIP(hipMemsetAsync(d_global, 0, size_t(K) * N * 64 * sizeof(float), st));
   TS_LAUNCH(k_dec_init_bwd, g128, 128, InitBwdL::SIZE * 4, st, init_img, local_embed, w.gsel, w.DOUT, w.best, N, w.DA, d_local, d_global,
             w.vpart);
-  if (int rc = run_colsum(st, w.vpart + InitV::DGAM, g128 * 2, InitV::SIZE, 64, grads[A1W])) return rc;
-  if (int rc = run_colsum(st, w.vpart + InitV::DBET, g128 * 2, InitV::SIZE, 64, grads[A1B])) return rc;
+  {
+    ColsumBatch cb(st, g128 * 2, InitV::SIZE);
+    cb.add(w.vpart + InitV::DGAM, 64, grads[A1W]);
+    cb.add(w.vpart + InitV::DBET, 64, grads[A1B]);
+    if (int rc = cb.flush()) return rc;
+  }
   if (int rc = run_wgrad(wc, w.DA, 64, w.gsel, 64, N, N, grads[A0W], 128, 0, grads[A0B], 0)) return rc;      // cat(global, local)
   return run_wgrad(wc, w.DA, 64, local_embed, 64, N, N, grads[A0W], 128, 64, nullptr, 0);
 }

@@ -54,11 +54,26 @@ __global__ void k_edge_attn2(const float* img, const float* geom, const int32_t*
   do {                                                                                                              \
     const bool _d = (drop).p > 0.f;                                                                                 \
     if ((heads) == 4) {                                                                                             \
-      if (bf16) { if (_d) TS_LAUNCH_TAG("k_global_attn<4>", false, (k_global_attn<4, true, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<4>", false, (k_global_attn<4, true, false>), __VA_ARGS__, drop); } \
-      else { if (_d) TS_LAUNCH_TAG("k_global_attn<4>", false, (k_global_attn<4, false, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<4>", false, (k_global_attn<4, false, false>), __VA_ARGS__, drop); } \
+      if (bf16) { if (_d) TS_LAUNCH_TAG("k_global_attn<4>", false, (k_global_attn<4, true, true, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<4>", false, (k_global_attn<4, true, false, true>), __VA_ARGS__, drop); } \
+      else { if (_d) TS_LAUNCH_TAG("k_global_attn<4>", false, (k_global_attn<4, false, true, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<4>", false, (k_global_attn<4, false, false, true>), __VA_ARGS__, drop); } \
     } else {                                                                                                        \
-      if (bf16) { if (_d) TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, true, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, true, false>), __VA_ARGS__, drop); } \
-      else { if (_d) TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, false, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, false, false>), __VA_ARGS__, drop); } \
+      if (bf16) { if (_d) TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, true, true, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, true, false, true>), __VA_ARGS__, drop); } \
+      else { if (_d) TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, false, true, true>), __VA_ARGS__, drop); else TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn<8, false, false, true>), __VA_ARGS__, drop); } \
+    }                                                                                                               \
+  } while (0)
+// the same kernel over edge rows alone (NODE = false: AA / AL attention on stored embedding rows, training path):
+// TS_EDGE_ATTN(heads, drop, grid, block, lds, stream, img /*GAttnL*/, segptr, emb, q, R, agg, stats)
+#define TS_EDGE_ATTN(heads, drop, grid, block, lds, st, img, segptr, emb, q, R, agg, stats)                          \
+  do {                                                                                                              \
+    const bool _d = (drop).p > 0.f;                                                                                 \
+    const int32_t* _ns = nullptr;                                                                                   \
+    const float* _nf = nullptr;                                                                                     \
+    if ((heads) == 4) {                                                                                             \
+      if (_d) TS_LAUNCH_TAG("k_edge_attn_rows<4>", false, (k_global_attn<4, false, true, false>), grid, block, lds, st, img, segptr, _ns, emb, q, _nf, _nf, R, agg, stats, drop); \
+      else TS_LAUNCH_TAG("k_edge_attn_rows<4>", false, (k_global_attn<4, false, false, false>), grid, block, lds, st, img, segptr, _ns, emb, q, _nf, _nf, R, agg, stats, drop); \
+    } else {                                                                                                        \
+      if (_d) TS_LAUNCH_TAG("k_edge_attn_rows<8>", false, (k_global_attn<8, false, true, false>), grid, block, lds, st, img, segptr, _ns, emb, q, _nf, _nf, R, agg, stats, drop); \
+      else TS_LAUNCH_TAG("k_edge_attn_rows<8>", false, (k_global_attn<8, false, false, false>), grid, block, lds, st, img, segptr, _ns, emb, q, _nf, _nf, R, agg, stats, drop); \
     }                                                                                                               \
   } while (0)
 __global__ void k_seg_merge(const int32_t* segptr, const float* rec, EdgeCount ec, int C, int64_t R, float* agg);
@@ -67,9 +82,9 @@ __global__ void k_edge_embed(const float* img, const float* geom, EdgeCount ec, 
 template <bool X6>
 __global__ void k_global_edge(const float* img, const float* rel, const int32_t* src, const int32_t* dst, const float* q,
                               const float* kn, const float* vn, int64_t E, float* logits, float* v);
-template <int HEADS, bool ST_BF16, bool DROP>
+template <int HEADS, bool ST_BF16, bool DROP, bool NODE>
 __global__ void k_global_attn(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
-                              const float* vn, int64_t N, float* agg, DropArg drop);
+                              const float* vn, int64_t N, float* agg, float* stats, DropArg drop);
 __global__ void k_seg_softmax_agg(const int32_t* segptr, const float* logits, const float* v, int64_t R, float* agg, int heads, DropArg drop);
 template <bool X6>
 __global__ void k_node_update(const float* img, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2, DropArg drop);

@@ -186,6 +186,11 @@ struct EncCoopL6 {
 };
 
 // encoder stage blob
+// wave-per-target attention (k_global_attn and its backward): the key / value maps of the EDGE rows as plain row-major
+// matrices -- lin_k_edge / lin_v_edge of a global layer, lin_k / lin_v of the AA and AL encoders (training path)
+struct GAttnL {
+  enum : int { S_END = 0, TS_FIELD(WKE, MAT64, S), TS_FIELD(BKE, 64, WKE), TS_FIELD(WVE, MAT64, BKE), TS_FIELD(BVE, 64, WVE), SIZE = BVE_END };
+};
 struct EncBlob {
   enum : int {
     AA_CENTER = 0,
@@ -206,15 +211,13 @@ struct EncBlob {
     AL_UPD6 = AA_FFN6 + FfnL6::SIZE,
     AL_FFN6 = AL_UPD6 + UpdL6::SIZE,
     COOP6 = AL_FFN6 + FfnL6::SIZE,
-    SIZE = COOP6 + EncCoopL6::SIZE
+    AA_ATTN = COOP6 + EncCoopL6::SIZE,
+    AL_ATTN = AA_ATTN + GAttnL::SIZE,
+    SIZE = AL_ATTN + GAttnL::SIZE
   };
 };
 
 // aggregator stage blob: rel_embed, then per layer {qkv, edge, upd, ffn}, then norm + per-mode projection
-// fused global attention (k_global_attn): lin_k_edge / lin_v_edge as plain row-major matrices
-struct GAttnL {
-  enum : int { S_END = 0, TS_FIELD(WKE, MAT64, S), TS_FIELD(BKE, 64, WKE), TS_FIELD(WVE, MAT64, BKE), TS_FIELD(BVE, 64, WVE), SIZE = BVE_END };
-};
 struct AggLayerL {
   enum : int {
     QKV = 0, EDGE = QKV + NodeProjL<3>::SIZE, UPD = EDGE + GEdgeL::SIZE, FFN = UPD + UpdL::SIZE, EDGE6 = FFN + FfnL::SIZE,

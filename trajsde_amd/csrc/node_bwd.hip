@@ -274,12 +274,21 @@ __device__ __forceinline__ void branch_fwd(f4 (&xh)[4], f4 (&act)[4], float& rst
   }
 }
 
-__global__ __launch_bounds__(256) void k_edge_embed_bwd_tail(const float* __restrict__ img, const float* __restrict__ geom,
-                                                             const float* __restrict__ demb, int64_t E, float* __restrict__ S,
-                                                             float* __restrict__ DEP, float* __restrict__ DSP,
+// ATTN: d emb is not read from `demb` but built here from the attention backward's per-edge scalars (bwd.hpp EdgeAttnGrad):
+//   d emb_e = Wk^T (ED_e,h q[dst_e]) + Wv^T (EA_e,h dagg[dst_e])        (h = the head of each feature)
+// -- two more transposed products per tile instead of a [E,64] row written by one kernel and read by this one.
+template <bool ATTN>
+__global__ __launch_bounds__(512) void k_edge_embed_bwd_tail(const float* __restrict__ img, const float* __restrict__ geom,
+                                                             const float* __restrict__ demb, EdgeAttnGrad ag, int64_t E,
+                                                             float* __restrict__ S, float* __restrict__ DEP, float* __restrict__ DSP,
                                                              float* __restrict__ vpart) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, img, EdgeBwdL::WA3T);                   // forward image + W2^T
+  if (ATTN) {                                             // lin_k^T | lin_v^T behind it
+    for (int i = threadIdx.x; i < 2 * MAT64 / 4; i += blockDim.x)
+      reinterpret_cast<f4*>(lds + EdgeBwdL::WA3T)[i] = reinterpret_cast<const f4*>(ag.wkvt)[i];
+    __syncthreads();
+  }
   using EL = EdgeL6;                                     // split-precision recompute, fp32 transposes for the gradients
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -312,7 +321,43 @@ __global__ __launch_bounds__(256) void k_edge_embed_bwd_tail(const float* __rest
     }
     linear_x6<4, 4>(ep, s, lds + EL::W2, lds + EL::B2, L);
     const float rs3 = ln_normalize(ep);                   // ep = e_hat
-    load_row(d, demb, ec, L.g);
+    if (ATTN) {
+      const int tgt = ag.dst[ec];
+      f4 qv[4], gv[4];
+      load_row(qv, ag.q, tgt, L.g);
+      load_row(gv, ag.dagg, tgt, L.g);
+      // lane group g holds the features of heads 2jt + (g >> 1) (8 heads) or jt (4 heads)
+      const f4 d0 = *reinterpret_cast<const f4*>(ag.ED + ec * ag.heads), a0_ = *reinterpret_cast<const f4*>(ag.EA + ec * ag.heads);
+      f4 d1 = d0, a1_ = a0_;
+      if (ag.heads == 8) {
+        d1 = *reinterpret_cast<const f4*>(ag.ED + ec * 8 + 4);
+        a1_ = *reinterpret_cast<const f4*>(ag.EA + ec * 8 + 4);
+      }
+      const int odd = L.g >> 1;
+      f4 dk[4], dv[4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        float sd, sa;
+        if (ag.heads == 8) {
+          const f4& dd = jt < 2 ? d0 : d1;
+          const f4& aa = jt < 2 ? a0_ : a1_;
+          sd = odd ? dd[2 * (jt & 1) + 1] : dd[2 * (jt & 1)];
+          sa = odd ? aa[2 * (jt & 1) + 1] : aa[2 * (jt & 1)];
+        } else {
+          sd = d0[jt];
+          sa = a0_[jt];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          dk[jt][c] = sd * qv[jt][c];
+          dv[jt][c] = sa * gv[jt][c];
+        }
+      }
+      linear_t(d, dk, lds + EdgeBwdL::WA3T, L);
+      linear_adj<4, 4>(d, dv, lds + EdgeBwdL::WA3T + MAT64, L);
+    } else {
+      load_row(d, demb, ec, L.g);
+    }
     if (e >= E) zero4(d);
     ln_backward(d, ep, rs3, lds + EL::AG3, L.g, dg3, db3);   // d := d ep
     f4 t[4];
@@ -393,23 +438,50 @@ __global__ __launch_bounds__(256) void k_edge_embed_bwd_branch(const float* __re
 template __global__ void k_edge_embed_bwd_branch<0>(const float*, const float*, const float*, int64_t, float*);
 template __global__ void k_edge_embed_bwd_branch<1>(const float*, const float*, const float*, int64_t, float*);
 
-// part[s][d][c] = sum over row slice s of X[i][d] * Y[i][head(d)][c]    (X [N,64], Y [N,heads,64]); grid (64 rows d, S slices);
-// the S partial 64x64 blocks are then summed by k_reduce_partials
-__global__ __launch_bounds__(256) void k_headwise_outer(const float* __restrict__ X, const float* __restrict__ Y, int64_t N,
-                                                        float* __restrict__ part, int heads) {
-  __shared__ float red[4][64];
-  const int d = blockIdx.x, c = threadIdx.x & 63, sub = threadIdx.x >> 6, h = d / (64 / heads);
+// part[s][d][c] = sum over row slice s of X[i][d] * Y[i][head(d)][c]    (X [N,64], Y [N,heads,64]); grid (heads, S slices): a
+// workgroup owns one head -- its 64 / heads output rows d share the Y rows, which are therefore read exactly once.  The four
+// waves of a workgroup take every 4th row of the slice; the S partial 64x64 blocks are then summed by k_reduce_partials.
+template <int HEADS>
+__global__ __launch_bounds__(256) void k_headwise_outer_t(const float* __restrict__ X, const float* __restrict__ Y, int64_t N,
+                                                          float* __restrict__ part) {
+  constexpr int LPH = 64 / HEADS;
+  __shared__ float red[4][LPH][64];
+  const int h = blockIdx.x, c = threadIdx.x & 63, sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int S = gridDim.y, sl = blockIdx.y;
   const int64_t per = (N + S - 1) / S, lo = sl * per, hi = lo + per < N ? lo + per : N;
-  float s = 0.f;
-  for (int64_t i = lo + sub; i < hi; i += 4) s = fmaf(X[i * 64 + d], Y[(i * heads + h) * 64 + c], s);
-  red[sub][c] = s;
+  float acc[LPH];
+#pragma unroll
+  for (int d = 0; d < LPH; ++d) acc[d] = 0.f;
+  for (int64_t i0 = lo + sub; i0 < hi; i0 += 16) {          // four rows of this wave in flight
+    float y[4], x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + 4 * u < hi ? i0 + 4 * u : hi - 1;
+      y[u] = Y[(i * HEADS + h) * 64 + c];
+      x[u] = c < LPH ? X[i * 64 + LPH * h + c] : 0.f;        // the head's LPH inputs of the row, handed out as scalars below
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i0 + 4 * u >= hi) break;
+#pragma unroll
+      for (int d = 0; d < LPH; ++d)
+        acc[d] = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[u]), d)), y[u], acc[d]);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < LPH; ++d) red[sub][d][c] = acc[d];
   __syncthreads();
-  if (sub == 0) part[int64_t(sl) * 4096 + d * 64 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  if (sub == 0) {
+#pragma unroll
+    for (int d = 0; d < LPH; ++d)
+      part[int64_t(sl) * 4096 + (LPH * h + d) * 64 + c] = (red[0][d][c] + red[1][d][c]) + (red[2][d][c] + red[3][d][c]);
+  }
 }
 int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64_t N, float* W, int heads) {
-  const int S = N >= 4096 ? 32 : (N >= 256 ? 8 : 1);
-  TS_LAUNCH(k_headwise_outer, dim3(64, S), 256, 0, wc.st, X, Y, N, wc.part, heads);
+  const int S = N >= 65536 ? 128 : (N >= 4096 ? 32 : (N >= 256 ? 8 : 1));
+  if (int64_t(S) > wc.cap) return fail(TRAJSDE_ERR_WORKSPACE, "headwise_outer: partial buffer too small");
+  if (heads == 4) TS_LAUNCH_TAG("k_headwise_outer", false, k_headwise_outer_t<4>, dim3(4, S), 256, 0, wc.st, X, Y, N, wc.part);
+  else TS_LAUNCH_TAG("k_headwise_outer", false, k_headwise_outer_t<8>, dim3(8, S), 256, 0, wc.st, X, Y, N, wc.part);
   WgradJobs one;
   one.n = 1;
   one.j[0] = WgradJob{nullptr, nullptr, W, nullptr, 0, 0, 64, 0, 0};
@@ -428,8 +500,12 @@ int ffn_block_backward(const float* img_a, const float* img_b, const float* xn2,
   const float* dout2 = drop.p > 0.f ? sc.UPD : dout;
   TS_LAUNCH(k_ffn_bwd_a, ga, 256, FfnBwdAL::SIZE * 4, st, img_a, dout, xn2, R, sc.H, sc.DH, sc.UPD, drop);
   TS_LAUNCH(k_ffn_bwd_b, gb, 256, FfnBwdBL::SIZE * 4, st, img_b, sc.DH, dout, x1, R, sc.dx1, sc.vpart);
-  if (int rc = run_colsum(st, sc.vpart, gb * 4, 128, 64, gr.n2g)) return rc;
-  if (int rc = run_colsum(st, sc.vpart + 64, gb * 4, 128, 64, gr.n2b)) return rc;
+  {
+    ColsumBatch cb(st, gb * 4, 128);
+    cb.add(sc.vpart, 64, gr.n2g);
+    cb.add(sc.vpart + 64, 64, gr.n2b);
+    if (int rc = cb.flush()) return rc;
+  }
   // first layer [256,64] (four 64-row blocks) and second layer [64,256] (four 64-column blocks): eight problems, one launch pair
   WgradBatch wb(wc, R, R);
   for (int b = 0; b < 4; ++b) {
@@ -457,15 +533,23 @@ int node_block_backward(const float* img, const NodeBlockTape& tp, const float* 
 }
 
 int edge_embed_backward(const float* img, const float* geom, const float* demb, int64_t E, const EdgeEmbedScratch& sc,
-                        const WgradCtx& wc, const EdgeEmbedGrads& gr, hipStream_t st) {
+                        const WgradCtx& wc, const EdgeEmbedGrads& gr, hipStream_t st, const EdgeAttnGrad* ag) {
   if (E <= 0) return TRAJSDE_OK;
   const int64_t ntiles = (E + 15) / 16;
-  const int lds_tail = EdgeBwdL::WA3T * 4, lds_br = (EdgeL::WA3 + MAT64) * 4;
-  const int gt = vec_grid(ntiles, 256, lds_tail), gb = vec_grid(ntiles, 256, lds_br);
-  TS_LAUNCH(k_edge_embed_bwd_tail, gt, 256, lds_tail, st, img, geom, demb, E, sc.S, sc.DEP, sc.DSP, sc.vpart);
+  const int lds_tail = (EdgeBwdL::WA3T + (ag ? 2 * MAT64 : 0)) * 4, lds_br = (EdgeL::WA3 + MAT64) * 4;
+  const int tail_threads = ag ? 512 : 256;                 // one workgroup per CU with the two extra matrices: make it a bigger one
+  const int gt = vec_grid(ntiles, tail_threads, lds_tail), gb = vec_grid(ntiles, 256, lds_br);
+  const int tail_waves = tail_threads / 64;
+  if (ag) TS_LAUNCH_TAG("k_edge_embed_bwd_tail<attn>", false, k_edge_embed_bwd_tail<true>, gt, tail_threads, lds_tail, st, img, geom, demb, *ag, E,
+                        sc.S, sc.DEP, sc.DSP, sc.vpart);
+  else TS_LAUNCH_TAG("k_edge_embed_bwd_tail", false, k_edge_embed_bwd_tail<false>, gt, tail_threads, lds_tail, st, img, geom, demb, EdgeAttnGrad{}, E,
+                     sc.S, sc.DEP, sc.DSP, sc.vpart);
   float* const tail_vec[4] = {gr.ag3, gr.ae3, gr.ag0, gr.ae0};
-  for (int i = 0; i < 4; ++i)
-    if (int rc = run_colsum(st, sc.vpart + 64 * i, gt * 4, 256, 64, tail_vec[i])) return rc;
+  {
+    ColsumBatch cb(st, gt * tail_waves, 256);
+    for (int i = 0; i < 4; ++i) cb.add(sc.vpart + 64 * i, 64, tail_vec[i]);
+    if (int rc = cb.flush()) return rc;
+  }
   {
     WgradBatch wb(wc, E, E);
     if (int rc = wb.add(sc.DEP, 64, sc.S, 64, gr.w2, 64, 0, gr.b2, 0)) return rc;
@@ -480,11 +564,15 @@ int edge_embed_backward(const float* img, const float* geom, const float* demb, 
     float* e_ = br ? gr.b_e : gr.a_e;
     float* w0 = br ? gr.b_w0 : gr.a_w0;
     float* b0 = br ? gr.b_b0 : gr.a_b0;
-    if (int rc = run_colsum(st, sc.vpart, gb * 4, 320, 64, g_)) return rc;
-    if (int rc = run_colsum(st, sc.vpart + 64, gb * 4, 320, 64, e_)) return rc;
-    if (int rc = run_colsum(st, sc.vpart + 128, gb * 4, 320, 64, w0, 2)) return rc;        // [64,2] weight, column 0
-    if (int rc = run_colsum(st, sc.vpart + 192, gb * 4, 320, 64, w0 + 1, 2)) return rc;    // column 1
-    if (int rc = run_colsum(st, sc.vpart + 256, gb * 4, 320, 64, b0)) return rc;
+    {
+      ColsumBatch cb(st, gb * 4, 320);
+      cb.add(sc.vpart, 64, g_);
+      cb.add(sc.vpart + 64, 64, e_);
+      cb.add(sc.vpart + 128, 64, w0, 2);        // [64,2] weight, column 0
+      cb.add(sc.vpart + 192, 64, w0 + 1, 2);    // column 1
+      cb.add(sc.vpart + 256, 64, b0);
+      if (int rc = cb.flush()) return rc;
+    }
   }
   return TRAJSDE_OK;
 }

@@ -440,6 +440,16 @@ static void recipe_encoder_attention(Packer& P) {
   pack_kv6(P, "al_encoder.lin_k", "al_encoder.lin_v", B::AL_EDGE6 + EdgeL6::WKV, B::AL_EDGE6 + EdgeL6::BKV);
   recipe_upd_ffn6(P, "aa_encoder", B::AA_UPD6, B::AA_FFN6);
   recipe_upd_ffn6(P, "al_encoder", B::AL_UPD6, B::AL_FFN6);
+  // training path: wave-per-target attention over stored embedding rows (k_global_attn<.., NODE = false> and its backward)
+  const char* enc[2] = {"aa_encoder", "al_encoder"};
+  const int at[2] = {B::AA_ATTN, B::AL_ATTN};
+  for (int i = 0; i < 2; ++i) {
+    const std::string e = enc[i];
+    P.vec(e + ".lin_k.weight", at[i] + GAttnL::WKE, MAT64);
+    P.vec(e + ".lin_k.bias", at[i] + GAttnL::BKE, 64);
+    P.vec(e + ".lin_v.weight", at[i] + GAttnL::WVE, MAT64);
+    P.vec(e + ".lin_v.bias", at[i] + GAttnL::BVE, 64);
+  }
 }
 
 static void recipe_encoder(Packer& P) {

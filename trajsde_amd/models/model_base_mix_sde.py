@@ -57,6 +57,8 @@ class _PathLoss(torch.autograd.Function):
             for n, g in enc["grads"].items():
                 by_name["encoder." + n] = g
             ctx.grads = [by_name.get(n) for n in model._param_names]          # None: no path from these losses
+            ctx.direct = bool(getattr(model, "direct_grad_accumulation", True))
+            ctx.params = params if ctx.direct else None
             model.last_output = out
             model.last_losses = {"L2": dec["loss"].detach(), "DiffBCE": enc["diff_loss"].detach() / w_diff if w_diff else None}
             return (w_l2 * dec["loss"] + enc["diff_loss"]).clone()
@@ -64,6 +66,24 @@ class _PathLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         have = [x for x in ctx.grads if x is not None]
+        if ctx.direct:
+            # Leaf accumulation done here in two fused launches instead of one AccumulateGrad node (an add kernel and ~5 us of
+            # host time) per parameter: `.grad += g * grad`, or `.grad = ...` where there is none yet -- what autograd's
+            # accumulation would have left.  The parameters then receive no gradient THROUGH autograd, so per-parameter
+            # hooks (torch DDP's reducer) do not fire: `model.direct_grad_accumulation = False` restores the plain route.
+            torch._foreach_mul_(have, g)                                     # our own buffers, fresh every step
+            dst, src = [], []
+            for p, x in zip(ctx.params, ctx.grads):
+                if x is None or not p.requires_grad:
+                    continue
+                if p.grad is None:
+                    p.grad = x
+                else:
+                    dst.append(p.grad)
+                    src.append(x)
+            if dst:
+                torch._foreach_add_(dst, src)
+            return (None,) * (5 + len(ctx.grads))
         scaled = iter(torch._foreach_mul(have, g))                          # a handful of fused launches, not one per tensor
         return (None, None, None, None, None) + tuple(None if x is None else next(scaled) for x in ctx.grads)
 
