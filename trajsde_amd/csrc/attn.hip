@@ -214,10 +214,12 @@ __device__ __forceinline__ void seg_flush(const SegState& S, float* __restrict__
   *reinterpret_cast<f4*>(r + 80 + 4 * g) = S.s;
 }
 
-template <int THREADS, bool DROP>
+// SAVE (training path): the embedding rows are also written to emb_out [E,64] -- the tape of the attention backward.
+template <int THREADS, bool DROP, bool SAVE>
 __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict__ img_g, const float* __restrict__ geom,
                                                         const int32_t* __restrict__ dst, const float* __restrict__ q, EdgeCount ec, int C_host,
-                                                        float* __restrict__ rec, int heads, const int32_t* __restrict__ segptr, DropArg drop) {
+                                                        float* __restrict__ rec, int heads, const int32_t* __restrict__ segptr, DropArg drop,
+                                                        float* __restrict__ emb_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using EL = EdgeL6;
   const int64_t E = edge_count(ec);
@@ -274,6 +276,10 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
     }
     f4 emb0[4], emb1[4], kv0[8], kv1[8], qv[4];
     edge_embed2_x6(emb0, emb1, g0, g1, lds, L);
+    if (SAVE) {
+      if (ok0) store_row(emb0, emb_out, e0, L.g);
+      if (ok1) store_row(emb1, emb_out, e1, L.g);
+    }
     load_vec<8>(kv0, lds + EL::BKV, L.g);
     load_vec<8>(kv1, lds + EL::BKV, L.g);
     linear_acc_x6_2<8, 4>(kv0, kv1, emb0, emb1, lds + EL::WKV, L.lane);
@@ -297,19 +303,22 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
   if (cur0 >= 0) seg_flush(S0, rec, int64_t(cur0) + s0, L.g);
   if (cur1 >= 0) seg_flush(S1, rec, int64_t(cur1) + s1, L.g);
 }
-template __global__ void k_edge_attn2<512, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg);
-template __global__ void k_edge_attn2<512, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg);
+template __global__ void k_edge_attn2<512, false, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<512, true, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<512, false, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<512, true, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 
 // records of one target -> agg row.  One wave per target, lane = feature f (jt = f>>4, g = (f>>2)&3); a target's records sit
 // at slots target + (first stream .. last stream) of its segment and are combined in that order.
+// stats (training path, or null): the merged (max logit, 1 / (sum + 1e-16)) of every (target, head), [R][heads][2]
 __global__ __launch_bounds__(256) void k_seg_merge(const int32_t* __restrict__ segptr, const float* __restrict__ rec, EdgeCount ec, int C_host,
-                                                   int64_t R, float* __restrict__ agg) {
+                                                   int64_t R, float* __restrict__ agg, float* __restrict__ stats, int heads) {
   const int C = stream_len(ec, edge_count(ec), C_host);
   const int lane = threadIdx.x & 63;
   const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (node >= R) return;
   const int beg = segptr[node], end = segptr[node + 1];
-  float out = 0.f;
+  float out = 0.f, m_out = 0.f, inv_out = 0.f;
   if (end > beg) {
     const int c0 = beg / C, c1 = (end - 1) / C;
     const int ms = 4 * ((lane >> 2) & 3) + (lane >> 4);    // index of this feature's (m, s) inside a record
@@ -325,8 +334,14 @@ __global__ __launch_bounds__(256) void k_seg_merge(const int32_t* __restrict__ s
       m = mn;
     }
     out = acc / (s + 1e-16f);                              // torch_geometric.utils.softmax denominator
+    m_out = m;
+    inv_out = 1.0f / (s + 1e-16f);
   }
   agg[node * 64 + lane] = out;
+  if (stats != nullptr) {                                  // lane = feature: the first lane of every head writes its pair
+    const int lph = 64 / heads;
+    if ((lane & (lph - 1)) == 0) *reinterpret_cast<float2*>(stats + (node * heads + lane / lph) * 2) = float2{m_out, inv_out};
+  }
 }
 
 // global interactor: relative-pose embedding only (AGG:42-51), reused by all layers

@@ -524,6 +524,7 @@ struct EncBwdWs {
   // backward: recurrence deltas
   float *DF, *DH2, *DH1, *DG2N, *DG1N, *DG2A, *DG1A, *DGPN, *DGPA, *DNW, *DN1P, *DUP, *DRP, *DU1, *DR1, *DHO, *dhA, *dhB, *DLDG, *DLAT, *DAA;
   // backward: attention chain scratch (sized for the larger of the AA / AL problems)
+  float* rec;                  // (target, stream) records of the fused forward attention
   float *dagg, *dxn, *DQ, *DCENTER, *EA, *ED, *RL, *SS, *DAGGM, *A1, *A2, *DA3P, *DA2P, *XR, *part, *cs, *scal;
   NodeBlockScratch nb;
   EdgeEmbedScratch ee;
@@ -550,6 +551,10 @@ struct EncBwdWs {
     stats = c.take<float>(R * 16);
     al_emb = c.take<float>(Ela * 64 + 64);
     al_stats = c.take<float>(N * 16);
+    {
+      const int64_t ra = fused_rec_floats(Eaa, true, R), rl = fused_rec_floats(Ela, true, N);
+      rec = c.take<float>(ra > rl ? ra : rl);
+    }
     EA = c.take<float>(E * 8 + 64);
     ED = c.take<float>(E * 8 + 64);
     RL = c.take<float>(R * 512);                              // per (target, head) sums of the embedding rows (run_edge_attn_bwd)
@@ -700,8 +705,11 @@ int aa_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const fl
 // training-path attention of an encoder (AA / AL): the edge embedding rows are computed once and KEPT (the tape), the attention
 // itself runs one wave per target over those rows (k_global_attn<.., NODE = false>: lin_k / lin_v folded into per-target
 // vectors) and leaves the softmax statistics for the backward
-static int edge_attention_tape(const float* img_edge6, const float* img_attn, const float* geom, int64_t E, const int32_t* segptr, const float* q,
-                               int64_t R, float* emb, float* stats, float* agg, int heads, const DropArg& drop, hipStream_t st) {
+static int edge_attention_tape(const char* tag, const float* img_edge6, const float* img_attn, const float* geom, const int32_t* dst, int64_t E,
+                               const int32_t* segptr, const float* q, int64_t R, float* emb, float* stats, float* agg, float* rec, int heads,
+                               const DropArg& drop, hipStream_t st) {
+  if (attn_fused_enabled())     // the inference forward's own kernels, which also write the embedding rows and the statistics
+    return fused_edge_attention(tag, false, img_edge6, geom, dst, q, EdgeCount{E, nullptr, 0}, segptr, R, rec, agg, heads, st, drop, emb, stats);
   if (E > 0)
     TS_LAUNCH(k_edge_embed<true>, tile_grid((E + 15) / 16, 1024, EdgeL6::EMB_SIZE * 4), 1024, EdgeL6::EMB_SIZE * 4, st, img_edge6, geom,
               EdgeCount{E, nullptr, 0}, emb, 0);
@@ -722,8 +730,8 @@ static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const fl
   using FB = EncBlob;
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob_fwd + FB::AA_CENTER, b->x,
             g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
-  if (int rc = edge_attention_tape(blob_fwd + FB::AA_EDGE6, blob_fwd + FB::AA_ATTN, g->aa_geom, Eaa, g->aa_segptr, w.q, R, w.emb, w.stats, w.agg,
-                                   8, drop_aa, st))
+  if (int rc = edge_attention_tape("k_edge_kv[aa]+emb", blob_fwd + FB::AA_EDGE6, blob_fwd + FB::AA_ATTN, g->aa_geom, g->aa_dst, Eaa, g->aa_segptr, w.q, R,
+                                   w.emb, w.stats, w.agg, w.rec, 8, drop_aa, st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
             w.center, R, w.x1, w.xn2, drop_aa);
@@ -743,8 +751,8 @@ static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const fl
   TS_LAUNCH_CHECK("k_gather_latent");
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob_fwd + FB::AL_Q, w.lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
-  if (int rc = edge_attention_tape(blob_fwd + FB::AL_EDGE6, blob_fwd + FB::AL_ATTN, g->la_geom, Ela, g->la_segptr, w.al_q, int64_t(N), w.al_emb,
-                                   w.al_stats, w.al_agg, 8, drop_al, st))
+  if (int rc = edge_attention_tape("k_edge_kv[al]+emb", blob_fwd + FB::AL_EDGE6, blob_fwd + FB::AL_ATTN, g->la_geom, g->la_dst, Ela, g->la_segptr, w.al_q,
+                                   int64_t(N), w.al_emb, w.al_stats, w.al_agg, w.rec, 8, drop_al, st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
             w.al_agg, w.al_xn, w.lat, int64_t(N), w.al_x1, w.al_xn2, drop_al);
@@ -977,8 +985,8 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
   // ================= forward recompute =================
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob_fwd + FB::AA_CENTER, b->x,
             g->x_fake, rot, b->bos_mask, g->orig, N, N, H, w.center, w.cn, w.q);
-  if (int rc = edge_attention_tape(blob_fwd + FB::AA_EDGE6, blob_fwd + FB::AA_ATTN, g->aa_geom, Eaa, g->aa_segptr, w.q, R, w.emb, w.stats, w.agg,
-                                   num_heads, no_drop(), st))
+  if (int rc = edge_attention_tape("k_edge_kv[aa]+emb", blob_fwd + FB::AA_EDGE6, blob_fwd + FB::AA_ATTN, g->aa_geom, g->aa_dst, Eaa, g->aa_segptr, w.q, R,
+                                   w.emb, w.stats, w.agg, w.rec, num_heads, no_drop(), st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
             w.center, R, w.x1, w.xn2, no_drop());
@@ -999,8 +1007,8 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
   TS_LAUNCH(k_tr_final, tile_grid((int64_t(N) + 15) / 16, 256, 0), 256, 0, st, blob_fwd + EncGridBlob::norm(nl), x, N, tout);
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob_fwd + FB::AL_Q, tout, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
-  if (int rc = edge_attention_tape(blob_fwd + FB::AL_EDGE6, blob_fwd + FB::AL_ATTN, g->la_geom, Ela, g->la_segptr, w.al_q, int64_t(N), w.al_emb,
-                                   w.al_stats, w.al_agg, num_heads, no_drop(), st))
+  if (int rc = edge_attention_tape("k_edge_kv[al]+emb", blob_fwd + FB::AL_EDGE6, blob_fwd + FB::AL_ATTN, g->la_geom, g->la_dst, Ela, g->la_segptr, w.al_q,
+                                   int64_t(N), w.al_emb, w.al_stats, w.al_agg, w.rec, num_heads, no_drop(), st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
             w.al_agg, w.al_xn, tout, int64_t(N), w.al_x1, w.al_xn2, no_drop());

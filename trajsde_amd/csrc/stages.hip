@@ -117,25 +117,30 @@ static int attention_tail(const NodeImgs& im, const int32_t* segptr, const float
 }
 
 // embedding + lin_k|lin_v + softmax-aggregate of one edge list in the fused form: records, then one merged agg row per target
-static int fused_edge_attention(const char* tag, bool dominant, const float* img, const float* geom, const int32_t* dst, const float* q,
-                                const EdgeCount& ec, const int32_t* segptr, int64_t R, float* rec, float* agg, int heads, hipStream_t st,
-                                const DropArg& drop = no_drop()) {
+int fused_edge_attention(const char* tag, bool dominant, const float* img, const float* geom, const int32_t* dst, const float* q,
+                         const EdgeCount& ec, const int32_t* segptr, int64_t R, float* rec, float* agg, int heads, hipStream_t st,
+                         const DropArg& drop, float* emb_out, float* stats) {
   const int64_t E = ec.E;
   const AttnPlan pl = fused_plan(E);
   if (E > 0) {
-    const int threads = drop.p > 0.f ? 512 : fused_threads();             // the dropout form is built for 512 threads
+    const int threads = 512;
     // a bounded list: enough waves for the most streams any E' <= E cuts into; the ones beyond the true count leave at once
     const int64_t waves = ((ec.dev ? std::min<int64_t>(E, fused_streams()) : pl.nstreams) + 31) / 32;
     const int grid = int((waves + threads / 64 - 1) / (threads / 64));
     const int lds = (EdgeL6::SIZE + (threads / 64) * 2048) * 4;              // weight image + every wave's parked query rows (8 KB)
-    if (drop.p > 0.f)
-      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, true>), grid, 512, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop);
-    else
-      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, false>), grid, 512, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop);
+    const bool d = drop.p > 0.f, sv = emb_out != nullptr;
+#define TS_EA2(D_, S_) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, D_, S_>), grid, 512, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
+    if (d && sv) TS_EA2(true, true);
+    else if (d) TS_EA2(true, false);
+    else if (sv) TS_EA2(false, true);
+    else TS_EA2(false, false);
+#undef TS_EA2
   }
-  TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, ec, pl.C, R, agg);
+  TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, ec, pl.C, R, agg, stats, heads);
   return TRAJSDE_OK;
 }
+bool attn_fused_enabled() { return attn_fused(); }
+int64_t fused_rec_floats(int64_t E, bool exact, int64_t targets) { return fused_rec_slots(E, exact, targets) * SEG_REC; }
 
 }  // namespace tsde
 
