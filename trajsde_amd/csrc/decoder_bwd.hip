@@ -456,6 +456,20 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradJobs jobs, int64_t R, int64_
   // software pipeline: the global loads (or the computed operand) of block k+1 are issued before the matrix work of block
   // k, so their latency hides behind it; registers -> LDS happens after the barrier that retires block k's reads
   f4 dreg[4], areg[4];
+  // computed operand: a thread always produces the same four features (4 * (threadIdx.x & 15)), so the closed-form constants
+  // of those features are loaded once, not with every row
+  const bool computed = job.in2 != nullptr;             // uniform per launch slice (blockIdx.y)
+  f4 kw0, kw1, kgb, kbe, kc0, kc1;
+  if (computed) {
+    const int f0 = 4 * (threadIdx.x & 15);
+    kw0 = *reinterpret_cast<const f4*>(job.in2 + f0);
+    kw1 = *reinterpret_cast<const f4*>(job.in2 + 64 + f0);
+    kgb = *reinterpret_cast<const f4*>(job.in2 + 128 + f0);
+    kbe = *reinterpret_cast<const f4*>(job.beta + f0);
+    kc0 = *reinterpret_cast<const f4*>(job.in2 + 192);
+    kc1 = *reinterpret_cast<const f4*>(job.in2 + 196);
+  }
+  const int pair = job.pair;
   auto fetch = [&](int64_t blk) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -465,11 +479,14 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradJobs jobs, int64_t R, int64_
       f4 dv = f4{0.f, 0.f, 0.f, 0.f}, av = dv;
       if (row < row1) {
         dv = *reinterpret_cast<const f4*>(delta + row * ldd + 4 * c4);
-        if (job.in2 != nullptr) {                       // computed operand (uniform per launch slice: blockIdx.y)
+        if (computed) {                                 // in2_rstd / in2_ln_relu4 (tile.hpp) on the hoisted constants
           const f4 ge = *reinterpret_cast<const f4*>(a + row * 4);
-          const float x0 = job.pair ? ge[2] : ge[0], x1 = job.pair ? ge[3] : ge[1];
-          const float rstd = in2_rstd(x0, x1, job.in2);
-          av = in2_ln_relu4(x0 * rstd, x1 * rstd, rstd, job.in2, job.beta, 4 * c4);
+          const float x0 = pair ? ge[2] : ge[0], x1 = pair ? ge[3] : ge[1];
+          const float ca = fmaf(kc0[0], x0, fmaf(kc0[1], x1, kc0[2])), cb = fmaf(kc0[3], x1, kc1[0]);
+          const float rstd = rsqrt_nr(fmaf(ca, ca, fmaf(cb, cb, kc1[1] * kc1[1])) + 1e-5f);
+          const float x0r = x0 * rstd, x1r = x1 * rstd;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) av[k] = fmaxf(fmaf(kw0[k], x0r, fmaf(kw1[k], x1r, fmaf(kgb[k], rstd, kbe[k]))), 0.f);
         } else {
           av = *reinterpret_cast<const f4*>(a + row * lda + 4 * c4);
         }
@@ -658,10 +675,12 @@ int WgradBatch::flush() {
     return TRAJSDE_OK;
   }
   // rows per workgroup: at least WGRAD_CHUNK; enough partials to fill the chip several times over (a workgroup walks its
-  // rows 64 at a time with a barrier in between), few enough (<= ~2048) that the second stage stays short
+  // rows 64 at a time with a barrier in between), few enough (<= ~1024) that the second stage stays short
   const int groups = int((R + rows_per_group - 1) / rows_per_group);
   int64_t chunk = WGRAD_CHUNK;
-  const int64_t want_parts = groups > 2048 ? groups : 2048;
+  static const int parts_env = []() { const char* e = getenv("TRAJSDE_WGRAD_PARTS"); return e ? atoi(e) : 0; }();
+  const int64_t base_parts = parts_env > 0 ? parts_env : 1024;      // 2048 -> 1024: k_reduce_partials 0.60 -> 0.44 ms per training step
+  const int64_t want_parts = groups > base_parts ? groups : base_parts;
   while ((rows_per_group + chunk - 1) / chunk * groups > want_parts) chunk *= 2;
   const int cpg = int((rows_per_group + chunk - 1) / chunk);
   const int P = cpg * groups;
