@@ -53,6 +53,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.warmup + i)
+    enq = (time.perf_counter() - t0) / a.steps * 1e3            # host time to enqueue a step (the graph stage's one sync included)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.steps * 1e3
     torch.cuda.reset_peak_memory_stats()
@@ -62,7 +63,7 @@ def main():
     table = _lib.profile_report()
     _lib.lib().trajsde_profile_mode(0)
     rows = sorted(((v[1], k, v[0]) for k, v in table.items()), reverse=True)
-    print(json.dumps({"config": a.config, "scenes": spec["synth"]["S"], "ms_per_train_step": ms,
+    print(json.dumps({"config": a.config, "scenes": spec["synth"]["S"], "ms_per_train_step": ms, "host_enqueue_ms": enq,
                       "scenes_per_s": spec["synth"]["S"] / ms * 1e3, "loss": float(loss),
                       "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
     tot = sum(r[0] for r in rows)

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <cstdio>
 #include <string>
 
@@ -64,6 +65,12 @@ inline int cdiv(int64_t a, int64_t b) { return int((a + b - 1) / b); }
 // chip at once (LDS- and thread-limited), grid-stride beyond that, never more than the work needs
 // same, for kernels that flush per-wave vector-gradient partials: capped so that the partial slab stays small
 inline int tile_grid(int64_t ntiles, int threads, int lds_bytes);
+inline int env_threads(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (!v) return dflt;
+  const int t = atoi(v);
+  return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : dflt;
+}
 inline int vec_grid(int64_t ntiles, int threads, int lds_bytes) {
   const int g = tile_grid(ntiles, threads, lds_bytes);
   return g > 512 ? 512 : g;

@@ -138,14 +138,12 @@ __global__ __launch_bounds__(1024) void k_bos_grad(const float* __restrict__ dce
 
 // ------------------------------------------------------------------ recurrence: forward replay with saves
 // one Euler-Maruyama step of iteration idx; slabs are [H][Nt][64] (GS, [H][Nt])
-__global__ __launch_bounds__(256) void k_enc_sde_save(const float* __restrict__ img_g, const float* __restrict__ h_in,
+static __device__ __forceinline__ void enc_sde_save_body(const float* lds, const float* __restrict__ h_in,
                                                       const float* __restrict__ hidden0, int Nt, float dt, float sq, float sn,
                                                       float cs, int idx, NoiseArg na, const uint8_t* __restrict__ nus,
                                                       float* __restrict__ HIN, float* __restrict__ H1, float* __restrict__ H2,
                                                       float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ GS,
                                                       float* __restrict__ HODE) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_blob(lds, img_g, EncSdeL::SIZE);
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (int64_t(Nt) + 15) / 16;
@@ -198,14 +196,12 @@ __global__ __launch_bounds__(256) void k_enc_sde_save(const float* __restrict__ 
 }
 
 // GRU_Unit of iteration idx with every activation kept; h_out = next state (not a slab)
-__global__ __launch_bounds__(256) void k_enc_gru_save(const float* __restrict__ img_g, const float* __restrict__ x_t, int Nt,
+static __device__ __forceinline__ void enc_gru_save_body(const float* lds, const float* __restrict__ x_t, int Nt,
                                                       int t, int TT, int idx, const uint8_t* __restrict__ pad,
                                                       const int32_t* __restrict__ orig, const float* __restrict__ HODE,
                                                       float* __restrict__ XS, float* __restrict__ U1, float* __restrict__ R1,
                                                       float* __restrict__ UU, float* __restrict__ RR, float* __restrict__ RH,
                                                       float* __restrict__ N1, float* __restrict__ NW, float* __restrict__ h_out) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_blob(lds, img_g, EncGruL::SIZE);
   using G = EncGruL;
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -260,7 +256,7 @@ __global__ __launch_bounds__(256) void k_enc_gru_save(const float* __restrict__ 
 // ------------------------------------------------------------------ recurrence: backward of one iteration
 // dh [Nt,64] = gradient w.r.t. this iteration's output state (without the kept-latent term, added here);
 // writes DHO (d h_ode), DX (d aa_out[t]) and the GRU deltas of slab idx
-__global__ __launch_bounds__(256) void k_enc_gru_bwd(const float* __restrict__ img, int Nt, int N, int t, int TT, int idx,
+static __device__ __forceinline__ void enc_gru_bwd_body(const float* lds, int Nt, int N, int t, int TT, int idx,
                                                      const uint8_t* __restrict__ pad, const int32_t* __restrict__ orig,
                                                      const int32_t* __restrict__ eos, const float* __restrict__ dh,
                                                      const float* __restrict__ dlat, const float* __restrict__ HODE,
@@ -270,8 +266,6 @@ __global__ __launch_bounds__(256) void k_enc_gru_bwd(const float* __restrict__ i
                                                      float* __restrict__ DNW, float* __restrict__ DN1P, float* __restrict__ DUP,
                                                      float* __restrict__ DRP, float* __restrict__ DU1, float* __restrict__ DR1,
                                                      float* __restrict__ DHO, float* __restrict__ DX) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_blob(lds, img, GruBwdL::SIZE);
   using G = GruBwdL;
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -355,7 +349,7 @@ __global__ __launch_bounds__(256) void k_enc_gru_bwd(const float* __restrict__ i
 }
 
 // d h_in of iteration idx from DHO (d h_ode) and the DiffBCE gradient on the picked diffusion values
-__global__ __launch_bounds__(256) void k_enc_sde_bwd(const float* __restrict__ img, int Nt, float dt, float sq, int idx, NoiseArg na,
+static __device__ __forceinline__ void enc_sde_bwd_body(const float* lds, int Nt, float dt, float sq, int idx, NoiseArg na,
                                                      const uint8_t* __restrict__ nus, const int32_t* __restrict__ eos,
                                                      const float* __restrict__ DLDG, const float* __restrict__ DHO,
                                                      const float* __restrict__ H1, const float* __restrict__ H2,
@@ -364,8 +358,6 @@ __global__ __launch_bounds__(256) void k_enc_sde_bwd(const float* __restrict__ i
                                                      float* __restrict__ DH1, float* __restrict__ DG2N, float* __restrict__ DG1N,
                                                      float* __restrict__ DG2A, float* __restrict__ DG1A, float* __restrict__ DGPN,
                                                      float* __restrict__ DGPA, float* __restrict__ dh_out) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_blob(lds, img, EncSdeBwdL::SIZE);
   using S = EncSdeBwdL;
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -439,6 +431,63 @@ __global__ __launch_bounds__(256) void k_enc_sde_bwd(const float* __restrict__ i
       linear_adj<4, 4>(dyn, d, lds + (net == 0 ? S::GN_W0T : S::GA_W0T), L);
     }
     if (live) store_row(dyn, dh_out, row, L.g);
+  }
+}
+
+// ------------------------------------------------------------------ the recurrence as two persistent kernels
+// Rows never talk to each other inside the recurrence, so a wave can walk ITS tiles through all H iterations: one launch instead
+// of 2 H.  The two weight images of an iteration do not fit LDS together (SDE 7 + GRU 9 matrices), so the workgroup re-stages
+// them from L2 every half iteration (256 KB per workgroup and iteration).  A wave reads back only rows it wrote itself (running
+// state, d h), in program order.  Measured (64 x 128 agents): 42 + 42 launches of 0.81 + 1.07 ms -> 0.71 + 0.83 ms; what remains is
+// the dependent chain of ~30 products per iteration at one tile per wave (35-40 us per iteration), not launches or staging --
+// wider workgroups (faster staging) do not help, only splitting a tile's products across waves would (the inference kernel
+// k_enc_recur_coop does that; it keeps no tape).
+struct RecurTab { float v[32][4]; };            // per iteration: dt, sqrt(dt), sin t, cos t  (H <= 32, trajsde_batch)
+struct RecurSaveArgs {
+  const float *img_sde, *img_gru, *hidden0, *aa_out;
+  int Nt, H, TT;
+  NoiseArg na;
+  const uint8_t *nus, *pad;
+  const int32_t* orig;
+  float *HIN, *H1, *H2, *G1, *G2, *GS, *HODE, *XS, *U1, *R1, *UU, *RR, *RH, *N1, *NW, *hcur;
+};
+__global__ __launch_bounds__(256) void k_enc_recur_save(RecurSaveArgs a, RecurTab tab) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int idx = 0; idx < a.H; ++idx) {
+    const int t = a.H - 1 - idx;
+    if (idx) __syncthreads();                               // every wave is done with the GRU image
+    stage_blob(lds, a.img_sde, EncSdeL::SIZE);
+    enc_sde_save_body(lds, idx == 0 ? nullptr : a.hcur, a.hidden0, a.Nt, tab.v[idx][0], tab.v[idx][1], tab.v[idx][2], tab.v[idx][3], idx, a.na,
+                      a.nus, a.HIN, a.H1, a.H2, a.G1, a.G2, a.GS, a.HODE);
+    __syncthreads();
+    stage_blob(lds, a.img_gru, EncGruL::SIZE);
+    enc_gru_save_body(lds, a.aa_out + int64_t(t) * a.Nt * 64, a.Nt, t, a.TT, idx, a.pad, a.orig, a.HODE, a.XS, a.U1, a.R1, a.UU, a.RR, a.RH, a.N1,
+                      a.NW, a.hcur);
+  }
+}
+struct RecurBwdArgs {
+  const float *img_gru, *img_sde;
+  int Nt, N, H, TT;
+  NoiseArg na;
+  const uint8_t *pad, *nus;
+  const int32_t *orig, *eos;
+  const float *dlat, *DLDG, *HODE, *U1, *R1, *UU, *RR, *N1, *NW, *H1, *H2, *G1, *G2, *GS;
+  float *DNW, *DN1P, *DUP, *DRP, *DU1, *DR1, *DHO, *DAA, *DF, *DH2, *DH1, *DG2N, *DG1N, *DG2A, *DG1A, *DGPN, *DGPA, *dh;
+};
+// last iteration first; a.dh [Nt,64] carries d h between iterations (nothing reads the final state except through the kept
+// latents, so the first one starts from zero) and holds d h of iteration 0's input on exit
+__global__ __launch_bounds__(256) void k_enc_recur_bwd(RecurBwdArgs a, RecurTab tab) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int idx = a.H - 1; idx >= 0; --idx) {
+    const int t = a.H - 1 - idx;
+    if (idx != a.H - 1) __syncthreads();
+    stage_blob(lds, a.img_gru, GruBwdL::SIZE);
+    enc_gru_bwd_body(lds, a.Nt, a.N, t, a.TT, idx, a.pad, a.orig, a.eos, idx == a.H - 1 ? nullptr : a.dh, a.dlat, a.HODE, a.U1, a.R1, a.UU, a.RR,
+                     a.N1, a.NW, a.DNW, a.DN1P, a.DUP, a.DRP, a.DU1, a.DR1, a.DHO, a.DAA + int64_t(t) * a.Nt * 64);
+    __syncthreads();
+    stage_blob(lds, a.img_sde, EncSdeBwdL::SIZE);
+    enc_sde_bwd_body(lds, a.Nt, tab.v[idx][0], tab.v[idx][1], idx, a.na, a.nus, a.eos, a.DLDG, a.DHO, a.H1, a.H2, a.G1, a.G2, a.GS, a.DF, a.DH2,
+                     a.DH1, a.DG2N, a.DG1N, a.DG2A, a.DG1A, a.DGPN, a.DGPA, a.dh);
   }
 }
 
@@ -736,15 +785,16 @@ static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const fl
   TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
             w.center, R, w.x1, w.xn2, drop_aa);
   TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out, drop_aa);
-  for (int idx = 0; idx < H; ++idx) {
-    const int t = H - 1 - idx;
-    const float* e = step_tab + 8 * idx;
-    TS_LAUNCH(k_enc_sde_save, tile_grid(rtiles, 256, EncSdeL::SIZE * 4), 256, EncSdeL::SIZE * 4, st, blob_fwd + FB::SDE,
-              idx == 0 ? nullptr : w.hcur, blob_fwd + FB::HIDDEN, Nt, e[1], e[2], e[3], e[4], idx, na, g->nus_mask, w.HIN, w.H1, w.H2, w.G1,
-              w.G2, w.GS, w.HODE);
-    TS_LAUNCH(k_enc_gru_save, tile_grid(rtiles, 256, EncGruL::SIZE * 4), 256, EncGruL::SIZE * 4, st, blob_fwd + FB::GRU,
-              w.aa_out + int64_t(t) * Nt * 64, Nt, t, b->TT, idx, b->padding_mask, g->orig, w.HODE, w.XS, w.U1, w.R1, w.UU, w.RR, w.RH, w.N1,
-              w.NW, w.hcur);
+  {
+    RecurTab tab;
+    for (int idx = 0; idx < H; ++idx) {
+      const float* e = step_tab + 8 * idx;
+      tab.v[idx][0] = e[1]; tab.v[idx][1] = e[2]; tab.v[idx][2] = e[3]; tab.v[idx][3] = e[4];
+    }
+    const RecurSaveArgs ra{blob_fwd + FB::SDE, blob_fwd + FB::GRU, blob_fwd + FB::HIDDEN, w.aa_out, Nt, H, b->TT, na, g->nus_mask, b->padding_mask,
+                           g->orig, w.HIN, w.H1, w.H2, w.G1, w.G2, w.GS, w.HODE, w.XS, w.U1, w.R1, w.UU, w.RR, w.RH, w.N1, w.NW, w.hcur};
+    const int lds_r = (EncSdeL::SIZE > EncGruL::SIZE ? EncSdeL::SIZE : EncGruL::SIZE) * 4;
+    TS_LAUNCH(k_enc_recur_save, tile_grid(rtiles, 256, lds_r), 256, lds_r, st, ra, tab);
   }
   // the kept latent of actor r is the state after iteration eos[r] (ENC:187-188): rebuilt from the saved slabs
   k_gather_latent<<<cdiv(int64_t(N) * 64, 256), 256, 0, st>>>(w.HODE, w.UU, w.NW, g->eos_idx, b->padding_mask, g->orig, N, Nt, H, b->TT, w.lat);
@@ -855,20 +905,18 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   TS_HIP(hipMemcpyAsync(diff_loss, w.scal, sizeof(float), hipMemcpyDeviceToDevice, st));
   // ---- recurrence, last iteration first
   {
-    const float* dh = nullptr;                 // nothing reads the final state except through the kept latents
-    float* bufs[2] = {w.dhA, w.dhB};
-    for (int idx = H - 1; idx >= 0; --idx) {
-      const int t = H - 1 - idx;
+    RecurTab tab;
+    for (int idx = 0; idx < H; ++idx) {
       const float* e = step_tab + 8 * idx;
-      TS_LAUNCH(k_enc_gru_bwd, tile_grid(rtiles, 256, GruBwdL::SIZE * 4), 256, GruBwdL::SIZE * 4, st, blob_bwd + BB::GRU, Nt, N, t, b->TT, idx,
-                b->padding_mask, g->orig, g->eos_idx, dh, w.DLAT, w.HODE, w.U1, w.R1, w.UU, w.RR, w.N1, w.NW, w.DNW, w.DN1P, w.DUP, w.DRP,
-                w.DU1, w.DR1, w.DHO, w.DAA + int64_t(t) * Nt * 64);
-      float* out = bufs[idx & 1];
-      TS_LAUNCH(k_enc_sde_bwd, tile_grid(rtiles, 256, EncSdeBwdL::SIZE * 4), 256, EncSdeBwdL::SIZE * 4, st, blob_bwd + BB::SDE, Nt, e[1], e[2],
-                idx, na, g->nus_mask, g->eos_idx, w.DLDG, w.DHO, w.H1, w.H2, w.G1, w.G2, w.GS, w.DF, w.DH2, w.DH1, w.DG2N, w.DG1N, w.DG2A,
-                w.DG1A, w.DGPN, w.DGPA, out);
-      dh = out;
+      tab.v[idx][0] = e[1]; tab.v[idx][1] = e[2]; tab.v[idx][2] = e[3]; tab.v[idx][3] = e[4];
     }
+    const RecurBwdArgs rb{blob_bwd + BB::GRU, blob_bwd + BB::SDE, Nt, N, H, b->TT, na, b->padding_mask, g->nus_mask, g->orig, g->eos_idx,
+                          w.DLAT, w.DLDG, w.HODE, w.U1, w.R1, w.UU, w.RR, w.N1, w.NW, w.H1, w.H2, w.G1, w.G2, w.GS,
+                          w.DNW, w.DN1P, w.DUP, w.DRP, w.DU1, w.DR1, w.DHO, w.DAA, w.DF, w.DH2, w.DH1, w.DG2N, w.DG1N, w.DG2A, w.DG1A,
+                          w.DGPN, w.DGPA, w.dhA};
+    const int lds_r = (GruBwdL::SIZE > EncSdeBwdL::SIZE ? GruBwdL::SIZE : EncSdeBwdL::SIZE) * 4;
+    TS_LAUNCH(k_enc_recur_bwd, tile_grid(rtiles, 256, lds_r), 256, lds_r, st, rb, tab);
+    const float* dh = w.dhA;
     // iteration 0 started from the learned initial state, broadcast to every row (ENC:78)
     if (int rc = run_colsum(st, dh, Nt, 64, 64, G("hidden"))) return rc;
     const std::string lf = "lsde_func.", gu = "gru_unit.";

@@ -10,13 +10,7 @@
 
 namespace tsde {
 
-// workgroup sizes; overridable for sweeps: TRAJSDE_THREADS_EDGE / _NODE / _RECUR (multiples of 64)
-static int env_threads(const char* name, int dflt) {
-  const char* v = getenv(name);
-  if (!v) return dflt;
-  const int t = atoi(v);
-  return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : dflt;
-}
+// workgroup sizes; overridable for sweeps: TRAJSDE_THREADS_EDGE / _NODE / _RECUR (multiples of 64); env_threads: common.hpp
 static bool edge_x6() { static bool v = []() { const char* e = getenv("TRAJSDE_EDGE_FP32"); return !(e && atoi(e) != 0); }(); return v; }
 static bool edge_pair() { static bool v = []() { const char* e = getenv("TRAJSDE_EDGE_PAIR"); return !(e && atoi(e) == 0); }(); return v; }   // two tiles per wave (default on)
 static int pair_threads() { static int t = []() { const char* e = getenv("TRAJSDE_PAIR_THREADS"); const int v = e ? atoi(e) : 768; return v == 512 ? 512 : 768; }(); return t; }
