@@ -378,8 +378,9 @@ struct AggBwdWs {
     }
     REV = c.take<int32_t>(E + 1);
     asym = c.take<int32_t>(4);
-    float** edge[] = {&ee.S, &ee.DEP, &ee.DSP};
+    float** edge[] = {&ee.DEP, &ee.DSP};
     for (float** p : edge) *p = c.take<float>(E * 64 + 64);
+    ee.S = rel;                                             // the rel rows are dead once every layer's k_gattn_bwd has run
     nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
     const int64_t rows = E > N ? E : N;
     parts = wgrad_max_parts(rows, 1);

@@ -608,8 +608,9 @@ struct EncBwdWs {
     ED = c.take<float>(E * 8 + 64);
     RL = c.take<float>(R * 512);                              // per (target, head) sums of the embedding rows (run_edge_attn_bwd)
     SS = c.take<float>(R * 512);
-    float** rows_E[] = {&ee.S, &ee.DEP, &ee.DSP};
+    float** rows_E[] = {&ee.DEP, &ee.DSP};               // (ee.S: the chain's embedding slab, dead by then -- run_attn_chain)
     for (float** p : rows_E) *p = c.take<float>(E * 64);
+    ee.S = nullptr;
     nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
     const int64_t rows = E > R ? E : R;
     parts = wgrad_max_parts(rows, H);
@@ -690,7 +691,10 @@ int run_attn_chain(const AttnChain& c, const float* dout, EncBwdWs& w, const Wgr
   if (int rc = run_colsum_tall(st, w.DAGGM, R, 64, 64, bv, w.nb.vpart)) return rc;
   if (E > 0) {
     const EdgeAttnGrad ag{c.dst, c.q, w.dagg, w.EA, w.ED, c.img_kvt, c.heads};
-    if (int rc = edge_embed_backward(c.img_emb, c.geom, nullptr, E, w.ee, wc, eg, st, &ag)) return rc;
+    // the embedding rows were last read by the attention backward above: their slab becomes the embedding backward's S slab
+    EdgeEmbedScratch ee = w.ee;
+    ee.S = const_cast<float*>(c.emb);
+    if (int rc = edge_embed_backward(c.img_emb, c.geom, nullptr, E, ee, wc, eg, st, &ag)) return rc;
   }
   const int gp = vec_grid((R + 15) / 16, 256, ProjBwdL<1>::SIZE * 4);
   TS_LAUNCH(k_node_proj_bwd<1>, gp, 256, ProjBwdL<1>::SIZE * 4, st, c.img_proj, c.x, w.nb.dx1, w.dxn, w.DQ, nullptr, nullptr, R, dx_out,

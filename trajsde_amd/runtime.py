@@ -77,6 +77,7 @@ def set_state_storage(kind: str) -> str:
 
 
 _SYNC_FREE = os.environ.get("TRAJSDE_SYNC_FREE", "1") != "0"
+SYNC_FREE_MAX_BYTES = 4 << 30
 
 
 def set_sync_free(on: bool) -> bool:
@@ -679,7 +680,9 @@ class GraphContext:
             self.ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
             # sync-free form: list lengths stay on the device, the E_* fields are bounds (int32 positions must hold them)
             b = self.batch
-            if not exact and 2 * b.H * b.E >= 2 ** 31 - 2:
+            # ... and the agent-agent list is allocated for the bound 2 H E (24 B per slot): past SYNC_FREE_MAX_BYTES the
+            # one synchronisation is the better deal (8 scenes x 1024 agents would reserve 8 GB for 90 MB of edges)
+            if not exact and (2 * b.H * b.E >= 2 ** 31 - 2 or 24 * 2 * b.H * b.E > SYNC_FREE_MAX_BYTES):
                 exact = True
             prepare = L.trajsde_graph_prepare if exact else L.trajsde_graph_prepare_async
             _lib.check(prepare(C.byref(self.batch), self.rot.data_ptr(), float(radius), C.byref(cn),
