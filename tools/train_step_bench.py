@@ -66,6 +66,18 @@ def main():
     print(json.dumps({"config": a.config, "scenes": spec["synth"]["S"], "ms_per_train_step": ms, "host_enqueue_ms": enq,
                       "scenes_per_s": spec["synth"]["S"] / ms * 1e3, "loss": float(loss),
                       "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
+    # roofline of the HBM-bound weight-gradient launch: the three embedding problems of every edge list (AA, AL, global)
+    gc = batch["_trajsde_graph"]
+    cnt = gc.true_counts()
+    edges = cnt["E_aa"] + cnt["E_la"] + cnt["E_g"]
+    if "k_wgrad[edge-embed]" in table:
+        n, ms_w = table["k_wgrad[edge-embed]"]
+        by = edges * (512 + 2 * 272)
+        print(json.dumps({"roofline_k_wgrad_edge_embed": {"bound": "hbm", "algorithmic_bytes_per_step": by, "ms_per_step": ms_w, "launches": n,
+                                                          "achieved_GBps": by / (ms_w * 1e-3) * 1e-9, "peak_GBps": 8000.0,
+                                                          "frac": by / (ms_w * 1e-3) * 1e-9 / 8000.0,
+                                                          "rows": {"E_aa": cnt["E_aa"], "E_la": cnt["E_la"], "E_g": cnt["E_g"]},
+                                                          "bytes_per_row": "(d e_pre, s) 2 x 256 B + 2 x (d s_pre 256 B + geometry 16 B)"}}))
     tot = sum(r[0] for r in rows)
     print(f"kernel time of one step (HIP events, serial): {tot:.2f} ms")
     for ms_k, name, n in rows[:28]:

@@ -64,7 +64,8 @@ struct WgradBatch {
   const WgradCtx& c;
   int64_t R, rows_per_group;
   WgradJobs jobs;
-  WgradBatch(const WgradCtx& ctx, int64_t R_, int64_t rpg) : c(ctx), R(R_), rows_per_group(rpg) { jobs.n = 0; }
+  const char* tag;             // name of the launch in the profile table (the edge-embedding batch carries its own: its roofline)
+  WgradBatch(const WgradCtx& ctx, int64_t R_, int64_t rpg, const char* tag_ = "k_wgrad") : c(ctx), R(R_), rows_per_group(rpg), tag(tag_) { jobs.n = 0; }
   int add(const float* delta, int ldd, const float* a, int lda, float* W, int ldw, int col0, float* bias, int time_cols);
   int add_in2(const float* delta, int ldd, const float* geom, int pair, const float* in2, const float* beta, float* W, int ldw, float* bias);
   int flush();

@@ -690,7 +690,7 @@ int WgradBatch::flush() {
     WgradJobs sub;
     sub.n = n - first < per_launch ? n - first : per_launch;
     for (int i = 0; i < sub.n; ++i) sub.j[i] = jobs.j[first + i];
-    TS_LAUNCH(k_wgrad, dim3(P, sub.n), 256, (64 * 80 * 2 + 4 * 4 * 64) * 4, c.st, sub, R, rows_per_group, int(chunk), cpg, P, c.part, c.cs);
+    TS_LAUNCH_TAG(tag, false, k_wgrad, dim3(P, sub.n), 256, (64 * 80 * 2 + 4 * 4 * 64) * 4, c.st, sub, R, rows_per_group, int(chunk), cpg, P, c.part, c.cs);
     TS_LAUNCH(k_reduce_partials, dim3(cdiv(4096 + 64, 32), sub.n), 256, 0, c.st, sub, c.part, c.cs, P, cpg, c.step_tab);
   }
   return TRAJSDE_OK;

@@ -551,7 +551,9 @@ int edge_embed_backward(const float* img, const float* geom, const float* demb, 
     if (int rc = cb.flush()) return rc;
   }
   {
-    WgradBatch wb(wc, E, E);
+    // three problems over the E rows: (DEP, S) 512 B per row, 2 x (DSP, geometry) 272 B per row -- the HBM-bound launch whose
+    // roofline tools/train_step_bench.py reports
+    WgradBatch wb(wc, E, E, "k_wgrad[edge-embed]");
     if (int rc = wb.add(sc.DEP, 64, sc.S, 64, gr.w2, 64, 0, gr.b2, 0)) return rc;
     if (int rc = wb.add_in2(sc.DSP, 64, geom, 0, img + EdgeL6::A_C, img + EdgeL6::A_E, gr.wa3, 64, gr.ba3)) return rc;
     if (int rc = wb.add_in2(sc.DSP, 64, geom, 1, img + EdgeL6::B_C, img + EdgeL6::B_E, gr.wb3, 64, gr.bb3)) return rc;
