@@ -11,6 +11,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
+#include <limits>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -161,100 +163,178 @@ __global__ void k_fake_x(int A, int H, const float* __restrict__ x, const int64_
 }
 
 // ---------------------------------------------------------------------------------------------- 21 snapshots
-// Lane = (extended node, history step t): a wave holds 64 / H nodes (3 for H = 21), the H lanes of a node walk the node's
-// CSR row together, so for one in-edge they read the sender's H contiguous positions / padding bytes: coalesced.  One pass
-// counts the surviving in-edges of snapshot node (t, i) (both endpoints valid at t, ENC:108; closer than the radius,
-// UTIL:88), a prefix sum over the H*Nt counts gives the segment pointers, a second identical pass writes the compacted
-// records.  A lane's survivors are consecutive entries of its own segment, so the fill pass buffers four of them in registers
-// and writes 64 B of geometry + one 16-byte vector of targets (+ one of senders) at a time: the pass is bound by the number of
-// store instructions (every lane of one hits a different cache line), and this cuts them from 12 to 6 per four survivors.
-// (A ballot-compaction form -- lanes = 64 candidate senders at a fixed t, survivors written 64 at a time -- was measured
-// slower: its position reads are 64-line gathers, 0.22 ms for the count pass alone against 0.09 ms.)
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_aa_pass(int N, int Nt, int H, int TT, const int32_t* __restrict__ rowptr,
-                                                 const int32_t* __restrict__ csr_src, const int32_t* __restrict__ orig,
-                                                 const uint8_t* __restrict__ pad, const float* __restrict__ pos,
-                                                 const float* __restrict__ x, const float* __restrict__ rot, float radius_val,
-                                                 const float* __restrict__ radius_dev, int32_t* __restrict__ cnt_or_ptr, int32_t* __restrict__ aa_dst,
-                                                 int32_t* __restrict__ aa_src, float* __restrict__ geom) {
-  const int lane = threadIdx.x & 63, per = 64 / H;                         // nodes per wave
-  const int sub = lane / H, t = lane - sub * H;                            // sub >= per: idle tail lanes of the wave
-  const int64_t wave = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int64_t node = wave * per + sub;
-  const bool live = sub < per && node < Nt;
-  const float radius = radius_dev ? radius_dev[0] : radius_val;            // the fill pass re-reads what the count pass used
-  const int o = live ? orig[node] : 0;
-  const bool dst_ok = live && !pad[int64_t(o) * TT + t];
-  const float px = pos[(int64_t(o) * TT + t) * 2], py = pos[(int64_t(o) * TT + t) * 2 + 1];
-  f4 R = f4{0.f, 0.f, 0.f, 0.f};
-  int k = 0;
-  if (FILL && live) {
-    R = *reinterpret_cast<const f4*>(rot + 4 * o);
-    k = cnt_or_ptr[int64_t(t) * Nt + node];
-  }
-  const int beg = live ? rowptr[o] : 0, end = live ? rowptr[o + 1] : 0;
-  const int first = sub * H;                                               // lane of this node's t = 0
-  f4 gbuf[4];
-  int sbuf[4];
-  int nb = 0;                                                              // survivors waiting in gbuf / sbuf
-  const int tgt = t * Nt + int(node);
-  auto flush4 = [&]() {                                                    // k already counts the four buffered survivors
-    float* gp = geom + 4 * int64_t(k - 4);
+// The agent-agent list of snapshot t keeps the in-edge (j -> i) when both ends are valid at t (ENC:108) and closer than the
+// radius (UTIL:88).  Three steps, none of which evaluates a candidate twice or leaves lanes idle on non-survivors:
+//   k_aa_ballots   a wave tests 64 consecutive CSR positions (in-edges of REAL actors) at every t and stores, per t, the 64-bit
+//                  ballot of the survivors -- 8 H bytes per 64 candidates x H.  The rows of the fake agents alias their actors'
+//                  (same positions, same padding), so their candidates are the same bits.
+//   k_aa_count     one thread per snapshot node (t, i): popcounts of its row's stretch of the ballots -> segment lengths; a prefix
+//                  sum (hipcub) turns them into the segment pointers.
+//   k_aa_fill      one wave per extended node: for every t the survivors of the row are handed to the lanes by rank (lane r takes the
+//                  r-th set bit of the row's ballots), so a segment's records are computed and written 64 at a time, contiguously
+//                  -- the pass is as long as the output, not as long as the candidate list.
+// Results are identical to evaluating every (t, in-edge) candidate in row order: same predicate, same order (ascending CSR
+// position = ascending sender), same arithmetic for the geometry.
+// The reference's test is  sqrt(dx^2 + dy^2) < radius  in float32 (UTIL:88).  sqrtf is correctly rounded and monotone, so that is
+// exactly  dx^2 + dy^2 < T  with T the smallest float whose square root reaches the radius (radius2_threshold, host): same
+// survivors for every input, without a 25-instruction IEEE square root per candidate.
+__device__ __forceinline__ bool within_radius2(float dx, float dy, float thr2) { return dx * dx + dy * dy < thr2; }
+static float radius2_threshold(float radius) {
+  if (!(radius > 0.f)) return 0.f;                                       // sqrt(x) < r <= 0 never holds (x >= 0)
+  if (std::isinf(radius)) return radius;
+  float t = radius * radius;
+  if (std::isinf(t)) t = std::numeric_limits<float>::max();
+  while (t > 0.f && std::sqrt(t) >= radius) t = std::nextafter(t, 0.f);                                            // sqrt(t) < radius
+  while (std::sqrt(t) < radius) t = std::nextafter(t, std::numeric_limits<float>::infinity());                      // smallest t with sqrt(t) >= radius
+  return t;
+}
+
+// vmask[i]: bit t set when actor i is valid (not padded) at history step t
+__global__ void k_valid_mask(int N, int H, int TT, const uint8_t* __restrict__ pad, uint32_t* __restrict__ vmask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  uint32_t m = 0;
+  uint8_t v[32];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(gp + 4 * j) = gbuf[j];
-    typedef int i4 __attribute__((ext_vector_type(4)));
-    typedef i4 __attribute__((aligned(4))) i4u;                           // segments start at any 4-byte position
-    *reinterpret_cast<i4u*>(aa_dst + (k - 4)) = i4{tgt, tgt, tgt, tgt};
-    if (aa_src != nullptr) *reinterpret_cast<i4u*>(aa_src + (k - 4)) = i4{sbuf[0], sbuf[1], sbuf[2], sbuf[3]};
-  };
-  // the nodes of a wave have rows of different lengths: every lane runs to the longest, past its own end it idles
-  int longest = end - beg;
-  for (int off = 1; off < 64; off <<= 1) longest = max(longest, __shfl_xor(longest, off));
-  for (int p0 = 0; p0 < longest; p0 += H) {
-    const int mine = (p0 + t < end - beg) ? csr_src[beg + p0 + t] : 0;     // coalesced chunk of H sender ids per node
-    const int m = min(max(end - beg - p0, 0), H);
-    for (int u0 = 0; u0 < H; u0 += 4) {                                    // 4 senders' loads in flight, then tested in order
-      int sv[4];
-      uint8_t pv[4];
-      float2 qv[4];
+  for (int t = 0; t < 32; ++t) v[t] = pad[int64_t(i) * TT + (t < H ? t : H - 1)];     // all loads in flight (H <= 32)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int u = u0 + j < m ? u0 + j : (m > 0 ? m - 1 : 0);
-        sv[j] = __shfl(mine, first + u);
-        pv[j] = pad[int64_t(sv[j]) * TT + t];
-        qv[j] = *reinterpret_cast<const float2*>(pos + (int64_t(sv[j]) * TT + t) * 2);
-      }
+  for (int t = 0; t < 32; ++t) m |= uint32_t(t < H && !v[t]) << t;
+  vmask[i] = m;
+}
+
+// A wave owns 64 consecutive CSR positions.  Phase 1, lane = (candidate, t) the way the rows lie in memory: the senders' position
+// rows are read coalesced (64 / H rows of 8 H bytes per instruction; one lane per candidate looping over t would make every load
+// a 64-line gather) and parked in wave-private LDS.  Phase 2, lane = candidate: for every t the lane tests its pair (sender row
+// from LDS, target row from the one or two rows the block's candidates share) and the wave's ballot IS the stored word.
+__global__ __launch_bounds__(256) void k_aa_ballots(int E, int H, int TT, const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_dst,
+                                                    const uint32_t* __restrict__ vmask, const float* __restrict__ pos, float thr2,
+                                                    unsigned long long* __restrict__ bal) {
+  extern __shared__ __attribute__((aligned(16))) float2 rows[];                            // [4 waves][64 rows][H | 1]: odd stride, 2-way LDS conflicts at most
+  const int AA_ROW = H | 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t blk = int64_t(blockIdx.x) * (blockDim.x >> 6) + wv;                       // 64 consecutive CSR positions
+  if (blk * 64 >= E) return;                                                               // (uniform)
+  const int per = 64 / H, j = lane / H, t = lane - j * H;
+  const float2* pos2 = reinterpret_cast<const float2*>(pos);
+  const int64_t pl = blk * 64 + lane;
+  const bool live = pl < E;
+  const int s_all = live ? csr_src[pl] : 0, o_all = live ? csr_dst[pl] : 0;
+  const uint32_t m = live ? (vmask[s_all] & vmask[o_all]) : 0u;
+  float2* mine_rows = rows + wv * 64 * AA_ROW;
+  for (int q0 = 0; q0 < 64; q0 += 8 * per) {                                               // eight row groups in flight
+    float2 v[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int sdr = sv[j];
-        const bool ok = dst_ok && u0 + j < m && !pv[j];
-        const float dx = qv[j].x - px, dy = qv[j].y - py;
-        if (ok && sqrtf(dx * dx + dy * dy) < radius) {
-          if (FILL) {
-            const float x0 = x[(int64_t(sdr) * H + t) * 2], x1 = x[(int64_t(sdr) * H + t) * 2 + 1];   // senders are real actors
-            const f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u * per + j;
+      const int su = __shfl(s_all, q & 63);
+      v[u] = pos2[int64_t(su) * TT + t];
+    }
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-              if (nb == b) { gbuf[b] = g; sbuf[b] = sdr; }                 // static register indices
-            ++nb;
-          }
-          ++k;
-          if (FILL && nb == 4) { flush4(); nb = 0; }
-        }
-      }
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u * per + j;
+      if (j < per && q < 64) mine_rows[q * AA_ROW + t] = v[u];
     }
   }
-  if (FILL) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const float2* pd = pos2 + int64_t(o_all) * TT;
+  unsigned long long mine = 0;
+  for (int t0 = 0; t0 < H; t0 += 8) {
+    float2 d[8];
 #pragma unroll
-    for (int b = 0; b < 3; ++b)
-      if (b < nb) {
-        const int64_t w = k - nb + b;
-        *reinterpret_cast<f4*>(geom + 4 * w) = gbuf[b];
-        aa_dst[w] = tgt;
-        if (aa_src != nullptr) aa_src[w] = sbuf[b];
+    for (int u = 0; u < 8; ++u) d[u] = pd[t0 + u < H ? t0 + u : H - 1];                     // one or two distinct rows per wave: broadcast
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int tt = t0 + u;
+      if (tt >= H) break;                                                                  // (uniform)
+      const float2 q = mine_rows[lane * AA_ROW + tt];
+      const bool ok = ((m >> tt) & 1u) && within_radius2(q.x - d[u].x, q.y - d[u].y, thr2);
+      const unsigned long long B = __ballot(ok);
+      if (lane == tt) mine = B;
+    }
+  }
+  if (lane < H) bal[blk * H + lane] = mine;
+}
+
+// bits [lo, hi) of a 64-bit word
+__device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
+  const unsigned long long upto_hi = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+  return upto_hi & ~((1ull << lo) - 1ull);
+}
+// the part of ballot block b that belongs to the CSR row [beg, end)
+__device__ __forceinline__ unsigned long long row_part(int b, int beg, int end) {
+  const int lo = beg > 64 * b ? beg - 64 * b : 0, hi = end < 64 * b + 64 ? end - 64 * b : 64;
+  return bit_range(lo, hi);
+}
+
+__global__ void k_aa_count(int Nt, int H, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ orig,
+                           const unsigned long long* __restrict__ bal, int32_t* __restrict__ cnt) {
+  const int64_t id = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;                       // = t * Nt + node
+  if (id >= int64_t(H) * Nt) return;
+  const int t = int(id / Nt), node = int(id - int64_t(t) * Nt), o = orig[node];
+  const int beg = rowptr[o], end = rowptr[o + 1];
+  int c = 0;
+  if (end > beg)
+    for (int b = beg >> 6; b <= (end - 1) >> 6; ++b) c += __popcll(bal[int64_t(b) * H + t] & row_part(b, beg, end));
+  cnt[id] = c;
+}
+
+// index of the r-th (0-based) set bit of w (r < popcount(w))
+__device__ __forceinline__ int nth_set_bit(unsigned long long w, int r) {
+  int posn = 0;
+#pragma unroll
+  for (int width = 32; width >= 1; width >>= 1) {
+    const int c = __popcll((w >> posn) & ((1ull << width) - 1ull));
+    if (r >= c) { r -= c; posn += width; }
+  }
+  return posn;
+}
+
+__global__ __launch_bounds__(256) void k_aa_fill(int N, int Nt, int H, int TT, const int32_t* __restrict__ rowptr,
+                                                 const int32_t* __restrict__ csr_src, const int32_t* __restrict__ orig,
+                                                 const unsigned long long* __restrict__ bal, const int32_t* __restrict__ segptr,
+                                                 const float* __restrict__ pos, const float* __restrict__ x, const float* __restrict__ rot,
+                                                 int32_t* __restrict__ aa_dst, int32_t* __restrict__ aa_src, float* __restrict__ geom) {
+  // one wave per extended node; for every t its survivors are handed out to the lanes by rank (lane r takes the r-th set bit of
+  // the row's ballots), so the records of segment (t, node) are written 64 at a time, contiguously
+  const int lane = threadIdx.x & 63;
+  const int node = __builtin_amdgcn_readfirstlane(int(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  (void)N;
+  if (node >= Nt) return;
+  const int o = orig[node];
+  const int beg = rowptr[o], end = rowptr[o + 1];
+  if (end <= beg) return;
+  const int b0 = beg >> 6, b1 = (end - 1) >> 6;
+  const f4 R = *reinterpret_cast<const f4*>(rot + 4 * o);
+  const float2* pd_row = reinterpret_cast<const float2*>(pos) + int64_t(o) * TT;
+  for (int t = 0; t < H; ++t) {
+    const int seg = t * Nt + node;
+    const int base = segptr[seg], n = segptr[seg + 1] - base;
+    if (n == 0) continue;                                                  // (uniform)
+    const float2 pd = pd_row[t];
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const int r = c0 + lane;
+      unsigned long long selw = 0;
+      int selb = b0, rr = 0, cum = 0;
+      for (int b = b0; b <= b1; ++b) {                                     // the row's ballot words are wave-uniform
+        const unsigned long long w = bal[int64_t(b) * H + t] & row_part(b, beg, end);
+        const int c = __popcll(w);
+        if (r >= cum && r < cum + c) { selw = w; selb = b; rr = r - cum; }
+        cum += c;
+        if (cum >= c0 + 64) break;                                         // (uniform) every lane of this chunk is served
       }
-  } else if (live) {
-    cnt_or_ptr[int64_t(t) * Nt + node] = k;
+      if (r < n) {
+        const int sdr = csr_src[64 * selb + nth_set_bit(selw, rr)];        // senders are real actors
+        const float2 ps = reinterpret_cast<const float2*>(pos)[int64_t(sdr) * TT + t];
+        const float dx = ps.x - pd.x, dy = ps.y - pd.y;
+        const float x0 = x[(int64_t(sdr) * H + t) * 2], x1 = x[(int64_t(sdr) * H + t) * 2 + 1];
+        const f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
+        const int64_t k = int64_t(base) + r;
+        *reinterpret_cast<f4*>(geom + 4 * k) = g;
+        aa_dst[k] = seg;
+        if (aa_src != nullptr) aa_src[k] = sdr;
+      }
+    }
   }
 }
 
@@ -369,6 +449,8 @@ struct PrepWs {
   int64_t* la_pack;
   int32_t *aa_segptr, *g_segptr, *la_segptr, *cpos_g, *cpos_la;
   uint8_t *nus, *flags_g, *flags_la;
+  uint32_t* vmask;               // per actor: bit t = valid at history step t
+  unsigned long long* bal;       // [ceil(E / 64)][H]: survivors of 64 consecutive CSR positions at step t (k_aa_ballots)
   float *x_fake, *lane_feat;
   void* cub_tmp;
   int64_t cub_bytes, n_aa;
@@ -387,6 +469,8 @@ struct PrepWs {
     cpos_g = c.take<int32_t>(E + 1); cpos_la = c.take<int32_t>(Ea + 1);
     nus = c.take<uint8_t>(Nt); flags_g = c.take<uint8_t>(E + 1); flags_la = c.take<uint8_t>(Ea + 1);
     x_fake = c.take<float>(A * H * 2 + 4); lane_feat = c.take<float>(int64_t(b->L) * 2 + 4);
+    vmask = c.take<uint32_t>(N + 1);
+    bal = c.take<unsigned long long>(((E + 63) / 64 + 1) * H);
     size_t s1 = 0, s2 = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, s1, (int32_t*)nullptr, (int32_t*)nullptr, int(n_aa + 1), (hipStream_t)0);
     (void)scan_flags(nullptr, s2, nullptr, nullptr, int((E > Ea ? E : Ea) + 1), (hipStream_t)0);
@@ -499,17 +583,20 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
     k_agent_slots<<<cdiv(A, 256), 256, 0, st>>>(A, b->agent_index, w.pick_slot);
     k_fake_x<<<cdiv(A * ((2 * H + 3) / 4), 256), 256, 0, st>>>(A, H, b->x, b->agent_index, na, w.x_fake);
   }
-  // 21 snapshots: count pass + prefix sum -> segment pointers
-  { ProfScope ps("k_aa_pass<count>", st);
-  k_aa_pass<false><<<cdiv(Nt, 4 * (64 / H)), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, b->padding_mask, b->positions,
-                                                                b->x, rot, radius, nullptr, w.aa_segptr, nullptr, nullptr, nullptr); }
+  // global interactor edges (also names the target of every CSR position: csr_dst)
+  k_g_flags<<<cdiv(E + 1, 256), 256, 0, st>>>(E, N, TT, H - 1, w.rowptr, w.csr_src, b->padding_mask, w.csr_dst, w.flags_g);
+  // 21 snapshots: survivor ballots -> segment lengths -> prefix sum -> segment pointers
+  if (E > 0) { ProfScope ps("k_aa_ballots", st);
+    k_valid_mask<<<cdiv(N, 256), 256, 0, st>>>(N, H, TT, b->padding_mask, w.vmask);
+    k_aa_ballots<<<cdiv(cdiv(E, 64), 4), 256, size_t(4) * 64 * (H | 1) * sizeof(float2), st>>>(E, H, TT, w.csr_src, w.csr_dst, w.vmask, b->positions,
+                                                                                            radius2_threshold(radius), w.bal); }
+  { ProfScope ps("k_aa_count", st);
+  k_aa_count<<<cdiv(int64_t(H) * Nt, 256), 256, 0, st>>>(Nt, H, w.rowptr, w.orig, w.bal, w.aa_segptr); }
   TS_HIP(hipMemsetAsync(w.aa_segptr + w.n_aa, 0, sizeof(int32_t), st));
   {
     size_t tmp = size_t(w.cub_bytes);
     TS_HIP(hipcub::DeviceScan::ExclusiveSum(w.cub_tmp, tmp, w.aa_segptr, w.aa_segptr, int(w.n_aa + 1), st));
   }
-  // global interactor edges
-  k_g_flags<<<cdiv(E + 1, 256), 256, 0, st>>>(E, N, TT, H - 1, w.rowptr, w.csr_src, b->padding_mask, w.csr_dst, w.flags_g);
   {
     size_t tmp = size_t(w.cub_bytes);
     TS_HIP(scan_flags(w.cub_tmp, tmp, w.flags_g, w.cpos_g, E + 1, st));
@@ -575,9 +662,9 @@ int trajsde_graph_compact(const trajsde_batch* b, const float* rot, void* ws, in
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int N = b->N, A = b->A, E = b->E, H = b->H, TT = b->TT, Ea = b->E_al, Nt = N + A;
   const bool want_src = g_export_senders.load() != 0;                      // sender ids are for checking the index work only
-  { ProfScope ps("k_aa_pass<fill>", st);
-  k_aa_pass<true><<<cdiv(Nt, 4 * (64 / H)), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, b->padding_mask, b->positions,
-                                                               b->x, rot, 0.f, reinterpret_cast<const float*>(w.counts) + 4, w.aa_segptr, e.aa_dst, want_src ? e.aa_src : nullptr, e.aa_geom); }
+  { ProfScope ps("k_aa_fill", st);
+  k_aa_fill<<<cdiv(Nt, 4), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, w.bal, w.aa_segptr, b->positions, b->x, rot, e.aa_dst,
+                                   want_src ? e.aa_src : nullptr, e.aa_geom); }
   if (E > 0)
     k_g_compact<<<cdiv(E, 256), 256, 0, st>>>(E, TT, H - 1, w.csr_src, w.csr_dst, b->positions, rot, b->rotate_angles, w.flags_g,
                                               w.cpos_g, e.g_src, e.g_dst, e.g_geom);
