@@ -300,17 +300,25 @@ int trajsde_aggregator_backward(const trajsde_batch* b, const trajsde_graph* g, 
  *      overwritten where the batch reaches the parameter).  d_latent [N,64] / d_aa_out [H,Nt,64] are optional
  *      outputs (null to skip) of the gradients at the two internal stage boundaries.  The step table is passed
  *      twice: host copy (scalars for the launches) and device copy (time-feature column reductions). */
+/*      Workspaces (ABI 6): the stage's memory is the forward TAPE (trajsde_encoder_tape_bytes: what the training forward writes
+ *      and the backward reads) plus the backward's own SCRATCH (trajsde_encoder_backward_scratch_bytes).  Either hand both in one
+ *      buffer `ws` of trajsde_encoder_backward_ws_bytes (tape first; scratch = null), or hand the tape as `ws` and a separate
+ *      `scratch` buffer: a training step then holds only the tape between its forward and this call, and can allocate the scratch
+ *      after the decoder's and aggregator's workspaces are released (peak memory of a step: max, not sum). */
 int64_t trajsde_encoder_backward_ws_bytes(const trajsde_batch* b, const trajsde_graph* g);
+int64_t trajsde_encoder_tape_bytes(const trajsde_batch* b, const trajsde_graph* g);
+int64_t trajsde_encoder_backward_scratch_bytes(const trajsde_batch* b, const trajsde_graph* g);
 int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rotate_mat, const float* blob_fwd,
                              const float* blob_bwd, const float* enc_step_table /*HOST [H,8]*/,
                              const float* enc_step_table_dev /*device [H,8]*/, const trajsde_noise* noise,
                              const float* d_local /*[N,64]*/, float diff_weight, void* ws, int64_t ws_bytes,
                              float* diff_loss /*[1] device*/, float* const* grads, int n_grads, float* d_latent, float* d_aa_out,
                              const trajsde_dropout* dropout /* the forward's, or null */,
-                             int tape_valid /* 1: `ws` still holds the tape trajsde_encoder_forward_train left in it */, void* stream);
+                             int tape_valid /* 1: `ws` still holds the tape trajsde_encoder_forward_train left in it */,
+                             void* scratch /* or null: scratch follows the tape inside `ws` */, int64_t scratch_bytes, void* stream);
 
 /* Training forward of the encoder stage: the same function as trajsde_encoder_forward (same weights, noise, dropout), run
- * through the kernels that KEEP every activation the backward needs, in `ws` (sized by trajsde_encoder_backward_ws_bytes).
+ * through the kernels that KEEP every activation the backward needs, in `ws` (at least trajsde_encoder_tape_bytes).
  * Hand the SAME `ws` to trajsde_encoder_backward with tape_valid = 1 and the backward skips its own recomputation of the
  * forward (one forward per training step instead of two).  Outputs as trajsde_encoder_forward. */
 int trajsde_encoder_forward_train(const trajsde_batch* b, const trajsde_graph* g, const float* rotate_mat, const float* blob_fwd,

@@ -11,8 +11,8 @@ STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGA
 STAGE_ENCODER_GRID, STAGE_DECODER_MLP, STAGE_DECODER_MLP_BWD, STAGE_ENCODER_GRID_BWD = 6, 7, 8, 9
 
 
-ABI_VERSION = 5          # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4);
-                         # device-side list lengths + trajsde_graph_prepare_async (5)
+ABI_VERSION = 6          # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4);
+                         # device-side list lengths + trajsde_graph_prepare_async (5); encoder tape / scratch split (6)
 
 
 class TrajsdeError(RuntimeError):
@@ -87,8 +87,10 @@ SIGNATURES = {
     "trajsde_aggregator_forward_train": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, C.c_int, C.c_int, C.c_int, P, P, I64, P,
                                                    C.POINTER(Dropout), P]),
     "trajsde_encoder_backward_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
+    "trajsde_encoder_tape_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
+    "trajsde_encoder_backward_scratch_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
     "trajsde_encoder_backward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, P, P, C.POINTER(Noise), P, F32, P, I64, P,
-                                           C.POINTER(P), C.c_int, P, P, C.POINTER(Dropout), C.c_int, P]),
+                                           C.POINTER(P), C.c_int, P, P, C.POINTER(Dropout), C.c_int, P, I64, P]),
     "trajsde_encoder_forward_train": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, C.POINTER(Noise), P, I64, P, P,
                                                 C.POINTER(Dropout), P]),
     "trajsde_aggregator_forward_heads": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, C.c_int, C.c_int, C.c_int, P, P, I64, P,

@@ -577,36 +577,53 @@ struct EncBwdWs {
   float *dagg, *dxn, *DQ, *DCENTER, *EA, *ED, *RL, *SS, *DAGGM, *A1, *A2, *DA3P, *DA2P, *XR, *part, *cs, *scal;
   NodeBlockScratch nb;
   EdgeEmbedScratch ee;
-  int64_t total, parts;
+  int64_t total, tape_total, scratch_total, parts;
   bool ok;
-  EncBwdWs(const trajsde_batch* b, const trajsde_graph* g, void* ws, int64_t bytes) {
-    Carver c(ws, bytes);
+  // The forward tape (what trajsde_encoder_forward_train writes and the backward reads) is carved first, the backward's own
+  // scratch after it.  With `scratch` given the two live in separate buffers: a training step then holds only the tape between
+  // its forward and the encoder backward, and the scratch is allocated when the decoder's and aggregator's workspaces are gone.
+  EncBwdWs(const trajsde_batch* b, const trajsde_graph* g, void* ws, int64_t bytes, void* scratch = nullptr, int64_t scratch_bytes = 0) {
+    Carver t(ws, bytes);
     const int64_t H = b->H, Nt = g->Nt, N = b->N, R = H * Nt, Eaa = g->E_aa, Ela = g->E_la, E = (Eaa > Ela ? Eaa : Ela) + 1;
-    float** rows_R[] = {&center, &cn, &q, &agg, &x1, &xn2, &aa_out, &HIN, &H1, &H2, &G1, &G2, &HODE, &XS, &U1, &R1, &UU, &RR, &RH, &N1,
-                        &NW, &DF, &DH2, &DH1, &DG2N, &DG1N, &DG2A, &DG1A, &DNW, &DN1P, &DUP, &DRP, &DU1, &DR1, &DAA, &dagg, &dxn, &DQ,
-                        &DCENTER, &DAGGM, &A1, &A2, &DA3P, &DA2P, &nb.dx1, &nb.UPD, &nb.DGP, &nb.DS};
+    // ---- tape
+    float** tape_R[] = {&center, &cn, &q, &agg, &x1, &xn2, &aa_out, &HIN, &H1, &H2, &G1, &G2, &HODE, &XS, &U1, &R1, &UU, &RR, &RH, &N1, &NW};
+    for (float** p : tape_R) *p = t.take<float>(R * 64);
+    GS = t.take<float>(R);
+    hcur = t.take<float>(Nt * 64);
+    float** tape_N[] = {&lat, &al_xn, &al_q, &al_agg, &al_x1, &al_xn2};
+    for (float** p : tape_N) *p = t.take<float>(N * 64);
+    emb = t.take<float>(Eaa * 64 + 64);
+    stats = t.take<float>(R * 16);
+    al_emb = t.take<float>(Ela * 64 + 64);
+    al_stats = t.take<float>(N * 16);
+    {
+      const int64_t ra = fused_rec_floats(Eaa, true, R), rl = fused_rec_floats(Ela, true, N);
+      rec = t.take<float>(ra > rl ? ra : rl);                // (forward only)
+    }
+    tape_total = t.off + 256;
+    // ---- backward scratch
+    Carver c = scratch ? Carver(scratch, scratch_bytes) : t;
+    const int64_t s_begin = scratch ? 0 : t.off;
+    float** rows_R[] = {&DF, &DH2, &DH1, &DG2N, &DG1N, &DG2A, &DG1A, &DNW, &DN1P, &DUP, &DRP, &DU1, &DR1, &DAA, &dagg, &dxn, &DQ,
+                        &DCENTER, &DAGGM, &nb.dx1, &nb.UPD, &nb.DGP, &nb.DS};
     for (float** p : rows_R) *p = c.take<float>(R * 64);
-    float** rows_Rs[] = {&GS, &DGPN, &DGPA};
+    // the centre-embedding backward runs last, after the recurrence's weight gradients (the last readers of its delta slabs)
+    // were enqueued on the same stream: its four slabs reuse four of those
+    A1 = DF; A2 = DH2; DA3P = DH1; DA2P = DG2N;
+    float** rows_Rs[] = {&DGPN, &DGPA};
     for (float** p : rows_Rs) *p = c.take<float>(R);
     XR = c.take<float>(R * 4);
     nb.H = c.take<float>(R * 256);
     nb.DH = c.take<float>(R * 256);
-    float** rows_Nt[] = {&hcur, &DHO, &dhA, &dhB};
+    float** rows_Nt[] = {&DHO, &dhA, &dhB};
     for (float** p : rows_Nt) *p = c.take<float>(Nt * 64);
     DLDG = c.take<float>(Nt);
-    float** rows_N[] = {&lat, &al_xn, &al_q, &al_agg, &al_x1, &al_xn2, &DLAT};
-    for (float** p : rows_N) *p = c.take<float>(N * 64);
-    emb = c.take<float>(Eaa * 64 + 64);
-    stats = c.take<float>(R * 16);
-    al_emb = c.take<float>(Ela * 64 + 64);
-    al_stats = c.take<float>(N * 16);
-    {
-      const int64_t ra = fused_rec_floats(Eaa, true, R), rl = fused_rec_floats(Ela, true, N);
-      rec = c.take<float>(ra > rl ? ra : rl);
-    }
+    DLAT = c.take<float>(N * 64);
     EA = c.take<float>(E * 8 + 64);
     ED = c.take<float>(E * 8 + 64);
-    RL = c.take<float>(R * 512);                              // per (target, head) sums of the embedding rows (run_edge_attn_bwd)
+    // per (target, head) sums of the embedding rows (run_edge_attn_bwd), [R,8,64] each.  RL lives in the node block's two
+    // [R,256] slabs (contiguous), which the block's own kernels and weight gradients have finished with by then
+    RL = nb.H;
     SS = c.take<float>(R * 512);
     float** rows_E[] = {&ee.DEP, &ee.DSP};               // (ee.S: the chain's embedding slab, dead by then -- run_attn_chain)
     for (float** p : rows_E) *p = c.take<float>(E * 64);
@@ -617,8 +634,9 @@ struct EncBwdWs {
     part = c.take<float>(parts * 4096);
     cs = c.take<float>(parts * 64);
     scal = c.take<float>(64);
-    total = c.off + 256;
-    ok = c.ok;
+    scratch_total = c.off - s_begin + 256;
+    total = scratch ? tape_total : c.off + 256;               // single-buffer form: tape and scratch in one workspace
+    ok = t.ok && c.ok;
   }
 };
 
@@ -830,6 +848,16 @@ int64_t trajsde_encoder_backward_ws_bytes(const trajsde_batch* b, const trajsde_
   EncBwdWs w(b, g, nullptr, 0);
   return w.total;
 }
+int64_t trajsde_encoder_tape_bytes(const trajsde_batch* b, const trajsde_graph* g) {
+  if (!b || !g) return -1;
+  EncBwdWs w(b, g, nullptr, 0);
+  return w.tape_total;
+}
+int64_t trajsde_encoder_backward_scratch_bytes(const trajsde_batch* b, const trajsde_graph* g) {
+  if (!b || !g) return -1;
+  EncBwdWs w(b, g, nullptr, 0);
+  return w.scratch_total;
+}
 
 int trajsde_encoder_forward_train(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_fwd,
                                   const float* step_tab /*HOST [H,8]*/, const trajsde_noise* noise, void* ws, int64_t ws_bytes,
@@ -842,8 +870,8 @@ int trajsde_encoder_forward_train(const trajsde_batch* b, const trajsde_graph* g
   TS_REQUIRE(!state_bf16(), "encoder_forward_train: the training tape is fp32; switch trajsde_state_storage(0)");
   const DropArg drop_aa = dropout ? make_drop(dropout->p, dropout->seed, 0) : no_drop();
   const DropArg drop_al = dropout ? make_drop(dropout->p, dropout->seed, 1) : no_drop();
-  EncBwdWs w(b, g, ws, ws_bytes);
-  if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_forward_train: workspace too small (trajsde_encoder_backward_ws_bytes)");
+  EncBwdWs w(b, g, ws, int64_t(1) << 60);                 // only the tape fields are touched here
+  if (ws_bytes < w.tape_total) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_forward_train: workspace too small (trajsde_encoder_tape_bytes)");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   NoiseArg na{0, nullptr, nullptr};
   if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
@@ -861,7 +889,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
                              const float* blob_bwd, const float* step_tab /*HOST [H,8]*/, const float* step_tab_dev,
                              const trajsde_noise* noise, const float* d_local, float diff_weight, void* ws, int64_t ws_bytes,
                              float* diff_loss, float* const* grads, int n_grads, float* d_latent, float* d_aa_out,
-                             const trajsde_dropout* dropout, int tape_valid, void* stream_) {
+                             const trajsde_dropout* dropout, int tape_valid, void* scratch, int64_t scratch_bytes, void* stream_) {
   TS_REQUIRE(b && g && rot && blob_fwd && blob_bwd && step_tab && step_tab_dev && d_local && ws && diff_loss && grads,
              "encoder_backward: null pointer");
   TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "encoder_backward: dropout p must be in [0, 1)");
@@ -878,7 +906,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
     TS_REQUIRE(grads[i] != nullptr, "encoder_backward: null gradient buffer " + names[i]);
     G.slot[names[i]] = grads[i];
   }
-  EncBwdWs w(b, g, ws, ws_bytes);
+  EncBwdWs w(b, g, ws, ws_bytes, scratch, scratch_bytes);
   if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_backward: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int N = b->N, Nt = g->Nt, H = b->H, A = b->A;

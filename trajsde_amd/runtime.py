@@ -363,7 +363,7 @@ class StageRuntime:
         tab = self._enc_table()
         local = torch.empty(N, D, device=dev, dtype=torch.float32)
         diff_pick = torch.empty(2 * A, D, device=dev, dtype=torch.float32)
-        ws_bytes = L.trajsde_encoder_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph))
+        ws_bytes = L.trajsde_encoder_tape_bytes(C.byref(gc.batch), C.byref(gc.graph))
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         cn = noise.c_noise(noise.z_enc, noise.enc_row_ids)
         dr = noise.c_dropout(m)
@@ -402,8 +402,12 @@ class StageRuntime:
         if tape is not None:
             ws, ws_bytes = tape
         else:
-            ws_bytes = L.trajsde_encoder_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph))
+            ws_bytes = L.trajsde_encoder_tape_bytes(C.byref(gc.batch), C.byref(gc.graph))
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        # the backward's own scratch is a separate buffer, allocated only now: between the training forward and this call the
+        # step holds the tape alone, and the decoder's / aggregator's workspaces have been released by the time this one is taken
+        sc_bytes = L.trajsde_encoder_backward_scratch_bytes(C.byref(gc.batch), C.byref(gc.graph))
+        scratch = torch.empty(sc_bytes, device=dev, dtype=torch.uint8)
         cn = noise.c_noise(noise.z_enc, noise.enc_row_ids)
         dr = noise.c_dropout(m)                                            # the forward's masks, regenerated from the same key
         with torch.cuda.device(dev):
@@ -411,7 +415,8 @@ class StageRuntime:
                 C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), self.blob().data_ptr(),
                 self.blob(_lib.STAGE_ENCODER_BWD).data_ptr(), tab.ctypes.data_as(C.c_void_p), tab_dev.data_ptr(), C.byref(cn),
                 d_local.to(torch.float32).contiguous().data_ptr(), float(diff_weight), ws.data_ptr(), ws_bytes, loss.data_ptr(),
-                arr, len(names), _ptr(d_lat), _ptr(d_aa), C.byref(dr) if dr is not None else None, 1 if tape is not None else 0, _stream()),
+                arr, len(names), _ptr(d_lat), _ptr(d_aa), C.byref(dr) if dr is not None else None, 1 if tape is not None else 0,
+                scratch.data_ptr(), sc_bytes, _stream()),
                 "trajsde_encoder_backward")
         out = {"grads": grads, "diff_loss": loss[0]}
         if want_boundaries:
