@@ -586,10 +586,12 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
   // global interactor edges (also names the target of every CSR position: csr_dst)
   k_g_flags<<<cdiv(E + 1, 256), 256, 0, st>>>(E, N, TT, H - 1, w.rowptr, w.csr_src, b->padding_mask, w.csr_dst, w.flags_g);
   // 21 snapshots: survivor ballots -> segment lengths -> prefix sum -> segment pointers
-  if (E > 0) { ProfScope ps("k_aa_ballots", st);
+  if (E > 0) {
     k_valid_mask<<<cdiv(N, 256), 256, 0, st>>>(N, H, TT, b->padding_mask, w.vmask);
-    k_aa_ballots<<<cdiv(cdiv(E, 64), 4), 256, size_t(4) * 64 * (H | 1) * sizeof(float2), st>>>(E, H, TT, w.csr_src, w.csr_dst, w.vmask, b->positions,
-                                                                                            radius2_threshold(radius), w.bal); }
+    const int lds_b = 4 * 64 * (H | 1) * int(sizeof(float2));              // (67 KB at H = 32: TS_LAUNCH raises the dynamic-LDS limit)
+    TS_LAUNCH(k_aa_ballots, cdiv(cdiv(E, 64), 4), 256, lds_b, st, E, H, TT, w.csr_src, w.csr_dst, w.vmask, b->positions, radius2_threshold(radius),
+              w.bal);
+  }
   { ProfScope ps("k_aa_count", st);
   k_aa_count<<<cdiv(int64_t(H) * Nt, 256), 256, 0, st>>>(Nt, H, w.rowptr, w.orig, w.bal, w.aa_segptr); }
   TS_HIP(hipMemsetAsync(w.aa_segptr + w.n_aa, 0, sizeof(int32_t), st));
