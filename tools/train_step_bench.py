@@ -71,7 +71,7 @@ def main():
     cnt = gc.true_counts()
     edges = cnt["E_aa"] + cnt["E_la"] + cnt["E_g"]
     if "k_wgrad[edge-embed]" in table:
-        n, ms_w = table["k_wgrad[edge-embed]"]
+        n, ms_w = table["k_wgrad[edge-embed]"][0], table["k_wgrad[edge-embed]"][1]
         by = edges * (512 + 2 * 272)
         print(json.dumps({"roofline_k_wgrad_edge_embed": {"bound": "hbm", "algorithmic_bytes_per_step": by, "ms_per_step": ms_w, "launches": n,
                                                           "achieved_GBps": by / (ms_w * 1e-3) * 1e-9, "peak_GBps": 8000.0,

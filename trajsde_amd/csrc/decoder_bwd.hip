@@ -433,8 +433,6 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradJobs jobs, int64_t R, int64_
   part += int64_t(blockIdx.y) * P * 4096;
   cs += int64_t(blockIdx.y) * P * 64;
   extern __shared__ __attribute__((aligned(16))) float dyn[];
-  float (*red)[2048] = reinterpret_cast<float (*)[2048]>(dyn);                  // [4 waves][32 x 64]: half of the output rows
-  float (*csr)[4][64] = reinterpret_cast<float (*)[4][64]>(dyn + 64 * 80 * 2);   // [4 waves][4 k-groups][64], behind the staging area
   const int p = blockIdx.x;
   const int group = p / chunks_per_group, sub = p - group * chunks_per_group;
   const int64_t row0 = group * rows_per_group + int64_t(sub) * chunk;
@@ -442,12 +440,14 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradJobs jobs, int64_t R, int64_
   if (row1 > (group + 1) * rows_per_group) row1 = (group + 1) * rows_per_group;
   if (row1 > R) row1 = R;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, idx = lane & 15, kg = lane >> 4;
-  f4 acc[4][4];
+  // Wave `ot` owns output rows 16 ot .. 16 ot + 15 of the 64 x 64 block and walks ALL 4-row k-steps of a staged block: 16
+  // accumulator registers per lane instead of 64 (every wave holding the whole block and taking every 4th k-step), so four
+  // workgroups fit a CU between the barriers instead of two, and no cross-wave reduction at the end.
+  const int ot = wave;
+  f4 acc[4];
 #pragma unroll
-  for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-    for (int it = 0; it < 4; ++it) acc[ot][it] = f4{0.f, 0.f, 0.f, 0.f};
-  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < 4; ++it) acc[it] = f4{0.f, 0.f, 0.f, 0.f};
+  float csum = 0.f;
   // 64-row blocks of delta and a are staged in LDS with coalesced 16-B loads (row stride 80 floats: the four k-groups
   // of an operand read land in four different bank quarters), then every wave takes every 4th 4-row k-step
   constexpr int RS = 80;
@@ -507,48 +507,27 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradJobs jobs, int64_t R, int64_
     }
     __syncthreads();
     if (blk + 64 < row1) fetch(blk + 64);
+#pragma unroll 8
+    for (int ks = 0; ks < 16; ++ks) {
+      const int r = 4 * ks + kg;
+      const float A = ds_[r * RS + 16 * ot + idx];
+      float B[4];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int r = 4 * (wave + 4 * s4) + kg;
-      float A[4], B[4];
+      for (int q = 0; q < 4; ++q) B[q] = as_[r * RS + 16 * q + idx];
+      csum += A;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        A[q] = ds_[r * RS + 16 * q + idx];
-        B[q] = as_[r * RS + 16 * q + idx];
-        csum[q] += A[q];
-      }
-#pragma unroll
-      for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ot], B[it], acc[ot][it], 0, 0, 0);
+      for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B[it], acc[it], 0, 0, 0);
     }
   }
-  __syncthreads();
-  // D fragment: lane holds dW[16ot + 4kg + reg][16it + idx].  The four waves' tiles are combined through LDS in two
-  // halves of 32 output rows, so that the reduction fits the 40 KB staging area (4 workgroups per CU stay resident)
+  // D fragment: lane holds dW[16 ot + 4 kg + reg][16 it + idx]
+  float* out = part + int64_t(p) * 4096;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) csr[wave][kg][16 * q + idx] = csum[q];
+  for (int it = 0; it < 4; ++it)
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (half) __syncthreads();
-#pragma unroll
-    for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-      for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) red[wave][(16 * ot + 4 * kg + reg) * 64 + 16 * it + idx] = acc[2 * half + ot][it][reg];
-    __syncthreads();
-    for (int j = threadIdx.x; j < 2048; j += 256)
-      part[int64_t(p) * 4096 + 2048 * half + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
-  }
-  if (threadIdx.x < 64) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) s += csr[w][g][threadIdx.x];
-    cs[int64_t(p) * 64 + threadIdx.x] = s;
-  }
+    for (int reg = 0; reg < 4; ++reg) out[(16 * ot + 4 * kg + reg) * 64 + 16 * it + idx] = acc[it][reg];
+  csum += __shfl_xor(csum, 16);                             // the four k-groups of column 16 ot + idx
+  csum += __shfl_xor(csum, 32);
+  if (kg == 0) cs[int64_t(p) * 64 + 16 * ot + idx] = csum;
 }
 
 // W[o*ldw + col0 + i] = sum_p part[p][o][i];  bias[o] = sum_p cs[p][o];  with time_cols the (sin t, cos t) input
@@ -681,7 +660,12 @@ int WgradBatch::flush() {
   static const int parts_env = []() { const char* e = getenv("TRAJSDE_WGRAD_PARTS"); return e ? atoi(e) : 0; }();
   const int64_t base_parts = parts_env > 0 ? parts_env : 1024;      // 2048 -> 1024: k_reduce_partials 0.60 -> 0.44 ms per training step
   const int64_t want_parts = groups > base_parts ? groups : base_parts;
-  while ((rows_per_group + chunk - 1) / chunk * groups > want_parts) chunk *= 2;
+  if ((rows_per_group + chunk - 1) / chunk * groups > want_parts) {
+    // the smallest multiple of 64 rows that stays within the partial budget: P lands just under it (1024 = one full round of
+    // the chip's 4 x 256 resident workgroups per problem), not at whatever a doubling of the chunk happens to give
+    const int64_t per_group = want_parts / groups > 0 ? want_parts / groups : 1;
+    chunk = ((rows_per_group + per_group - 1) / per_group + 63) / 64 * 64;
+  }
   const int cpg = int((rows_per_group + chunk - 1) / chunk);
   const int P = cpg * groups;
   int per_launch = int(c.cap / P);
@@ -690,7 +674,7 @@ int WgradBatch::flush() {
     WgradJobs sub;
     sub.n = n - first < per_launch ? n - first : per_launch;
     for (int i = 0; i < sub.n; ++i) sub.j[i] = jobs.j[first + i];
-    TS_LAUNCH_TAG(tag, false, k_wgrad, dim3(P, sub.n), 256, (64 * 80 * 2 + 4 * 4 * 64) * 4, c.st, sub, R, rows_per_group, int(chunk), cpg, P, c.part, c.cs);
+    TS_LAUNCH_TAG(tag, false, k_wgrad, dim3(P, sub.n), 256, (64 * 80 * 2) * 4, c.st, sub, R, rows_per_group, int(chunk), cpg, P, c.part, c.cs);
     TS_LAUNCH(k_reduce_partials, dim3(cdiv(4096 + 64, 32), sub.n), 256, 0, c.st, sub, c.part, c.cs, P, cpg, c.step_tab);
   }
   return TRAJSDE_OK;
