@@ -392,7 +392,9 @@ class StageRuntime:
         if tuple(d_local.shape) != (N, D):
             raise _lib.TrajsdeError(f"d_local must be [{N},{D}]")
         tab = self._enc_table()
-        tab_dev = _TABLES_DEV.setdefault((id(tab), str(dev)), torch.from_numpy(tab).to(dev))
+        tab_dev = _TABLES_DEV.get((id(tab), str(dev)))                     # (not setdefault: its default would be built -- a blocking
+        if tab_dev is None:                                                #  pageable host-to-device copy -- on every call)
+            tab_dev = _TABLES_DEV[(id(tab), str(dev))] = torch.from_numpy(tab).to(dev)
         names = self.param_names(_lib.STAGE_ENCODER_BWD)
         grads = self._grad_buffers(_lib.STAGE_ENCODER_BWD)
         arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
