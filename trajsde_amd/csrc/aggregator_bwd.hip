@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
   const float* wve = img + GAttnL::WVE;
   const float ql = q[nc * 64 + lane];
   const float da = node < N ? dagg[nc * 64 + lane] : 0.f;
-  const float cb = head_sum_n<HEADS>(ql * img[GAttnL::BKE + lane]);
+  const float cb = NODE ? 0.f : head_sum_n<HEADS>(ql * img[GAttnL::BKE + lane]);   // (the forward drops it with node rows: attn.hip)
   const float cz = head_sum_n<HEADS>(da * img[GAttnL::BVE + lane]);
   const float dlt = head_sum_n<HEADS>(da * agg[nc * 64 + lane]);
   float U[SL], Z[SL];

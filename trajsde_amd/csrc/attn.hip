@@ -525,8 +525,10 @@ __global__ __launch_bounds__(256, 4) void k_global_attn(const float* __restrict_
   const int64_t nc = node < N ? node : N - 1;
   const float* wke = img + GAttnL::WKE;
   const float* wve = img + GAttnL::WVE;
-  const float ql = q[nc * 64 + lane];
-  const float cb = head_sum_n<HEADS>(ql * img[GAttnL::BKE + lane]);
+  // The logits' 1 / sqrt(dh) is folded into the query (ql, U) once per target.  With node rows (the global interactor) the
+  // key bias term q_h . bke_h is dropped: it shifts every logit of a (target, head) alike, and the softmax does not see it.
+  const float ql = q[nc * 64 + lane] * INV;
+  const float cb = NODE ? 0.f : head_sum_n<HEADS>(ql * img[GAttnL::BKE + lane]);
   float U[SL];
 #pragma unroll
   for (int e = 0; e < SL; ++e) U[e] = 0.f;
@@ -596,7 +598,8 @@ __global__ __launch_bounds__(256, 4) void k_global_attn(const float* __restrict_
       for (int v4 = 0; v4 < NV; ++v4)
 #pragma unroll
         for (int e = 0; e < 4; ++e) p = fmaf(r[u][v4][e], U[4 * v4 + e], p);
-      p = (head_sum_n<HEADS>(p) + cb) * INV;
+      p = head_sum_n<HEADS>(p);
+      if (!NODE) p += cb;
       lg[u] = e0 + u < end ? p : -INFINITY;
       cm = fmaxf(cm, lg[u]);
     }
