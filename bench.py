@@ -359,19 +359,18 @@ def main():
         # secondary figure (not `value`): the training step of BASELINE configs[1] -- forward + L2/DiffBCE + the three
         # stage backward calls + AdamW, reported next to the inference metric
         try:
-            from trajsde_amd.driver import FlatGrads
+            from trajsde_amd.driver import FlatTraining
             twl = Workload(SECONDARY)
             tspec = CONFIGS[SECONDARY]
             tmodel = PredictionModelSDENet(**build_cfg(tspec), init_seed=0).to(dev).train()
-            (opt,), _ = tmodel.configure_optimizers()
-            flat = FlatGrads(tmodel.params_with_gradient())
+            flat = FlatTraining(tmodel)                                       # the training loop's handle (driver.train)
             tb = twl.batches[0]
 
             def tstep(i):
                 flat.zero()
                 tb.y = twl.y0s[0]                                             # forward rotates y in place (MODEL:83-84)
                 tmodel.training_step(tb, i, noise=NoiseSpec(seed=5000 + i)).backward()
-                opt.step()
+                flat.step()
             for i in range(2):                                                 # optimizer state, allocator pools
                 tstep(i)
             torch.cuda.synchronize()

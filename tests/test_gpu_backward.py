@@ -528,3 +528,38 @@ def test_training_forward_keeps_a_tape_the_backward_walks(train_mode, dev):
     assert torch.equal(a_with["d_local_embed"], a_without["d_local_embed"])
     for k in a_without["grads"]:
         assert torch.equal(a_with["grads"][k], a_without["grads"][k]), k
+
+
+def test_flat_training_is_the_per_parameter_adamw_bit_for_bit(dev):
+    """driver.FlatTraining runs AdamW over ONE tensor that every optimised parameter is a slice of; AdamW is element-wise, so
+    three training steps end on exactly the parameters of torch's per-parameter AdamW over the same model -- and the weight
+    images are re-packed although the slices' version counters never move (StageParams.touch)"""
+    from trajsde_amd import driver
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    batch = synth(S=2, n=10, L=5, F=6, box=50.0, seed=21, mixed_source=True).to(dev)
+    y0 = batch.y.clone()
+
+    def make():
+        m, _ = H.build_model(3, 6, 0.5, init_seed=9)
+        m.lr, m.weight_decay, m.T_max = 1e-3, 1e-4, 4
+        return m.to(dev).train()
+
+    a = make()
+    (opt,), _ = a.configure_optimizers()
+    fa = driver.FlatGrads(a.params_with_gradient())
+    b = make()
+    fb = driver.FlatTraining(b)
+    losses = []
+    for i in range(3):
+        for m, zero, step in ((a, fa.zero, opt.step), (b, fb.zero, fb.step)):
+            zero()
+            batch.y = y0
+            loss = m.training_step(batch, i, noise=NoiseSpec(seed=40 + i))
+            loss.backward()
+            step()
+            losses.append(float(loss.detach()))
+    assert losses[0::2] == losses[1::2]                    # same losses step by step: the re-packed weights were the updated ones
+    assert losses[0] != losses[4]                          # ... and they did change
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert na == nb and torch.equal(pa.detach(), pb.detach()), na

@@ -33,8 +33,7 @@ def main():
     cfg["decoder"]["kwargs"].update(num_modes=K, future_steps=T, max_fut_t=spec["max_fut_t"])
     dev = torch.device("cuda:0")
     model = driver.build_model(cfg, None, dev, init_seed=0).train()
-    (opt,), _ = model.configure_optimizers()
-    flat = driver.FlatGrads(model.params_with_gradient())
+    flat = driver.FlatTraining(model)                  # what driver.train uses: AdamW over one flat parameter tensor
     batch = synth(**spec["synth"]).to(dev)
     y0 = batch.y.clone()
 
@@ -43,7 +42,7 @@ def main():
         batch.y = y0
         loss = model.training_step(batch, i, noise=NoiseSpec(seed=100 + i))
         loss.backward()
-        opt.step()
+        flat.step()
 
     for i in range(3):
         step(i)

@@ -452,16 +452,16 @@ __global__ __launch_bounds__(256) void k_headwise_outer_t(const float* __restric
   float acc[LPH];
 #pragma unroll
   for (int d = 0; d < LPH; ++d) acc[d] = 0.f;
-  for (int64_t i0 = lo + sub; i0 < hi; i0 += 16) {          // four rows of this wave in flight
-    float y[4], x[4];
+  for (int64_t i0 = lo + sub; i0 < hi; i0 += 32) {          // eight rows of this wave in flight (the kernel waits on memory)
+    float y[8], x[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int64_t i = i0 + 4 * u < hi ? i0 + 4 * u : hi - 1;
       y[u] = Y[(i * HEADS + h) * 64 + c];
       x[u] = c < LPH ? X[i * 64 + LPH * h + c] : 0.f;        // the head's LPH inputs of the row, handed out as scalars below
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       if (i0 + 4 * u >= hi) break;
 #pragma unroll
       for (int d = 0; d < LPH; ++d)
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void k_headwise_outer_t(const float* __restric
   }
 }
 int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64_t N, float* W, int heads) {
-  const int S = N >= 65536 ? 128 : (N >= 4096 ? 32 : (N >= 256 ? 8 : 1));
+  const int S = N >= 65536 ? 256 : (N >= 4096 ? 32 : (N >= 256 ? 8 : 1));
   if (int64_t(S) > wc.cap) return fail(TRAJSDE_ERR_WORKSPACE, "headwise_outer: partial buffer too small");
   if (heads == 4) TS_LAUNCH_TAG("k_headwise_outer", false, k_headwise_outer_t<4>, dim3(4, S), 256, 0, wc.st, X, Y, N, wc.part);
   else TS_LAUNCH_TAG("k_headwise_outer", false, k_headwise_outer_t<8>, dim3(8, S), 256, 0, wc.st, X, Y, N, wc.part);

@@ -47,14 +47,21 @@ class ParamTree(nn.Module):
         p = nn.Parameter(value, requires_grad=requires_grad)
         mod.register_parameter(leaf, p)
         self.__dict__.pop("_stamp_slots", None)
+        self.__dict__.pop("_p_slots", None)
         return p
 
     def p(self, path: str) -> nn.Parameter:
-        mod: nn.Module = self
-        parts = path.split(".")
-        for q in parts[:-1]:
-            mod = mod._modules[q]
-        return mod._parameters[parts[-1]]
+        slots = self.__dict__.get("_p_slots")                               # path -> (container dict, leaf): survives re-assignment
+        if slots is None:
+            slots = self.__dict__["_p_slots"] = {}
+        hit = slots.get(path)
+        if hit is None:
+            mod: nn.Module = self
+            parts = path.split(".")
+            for q in parts[:-1]:
+                mod = mod._modules[q]
+            hit = slots[path] = (mod._parameters, parts[-1])
+        return hit[0][hit[1]]
 
     # -- initialisers ---------------------------------------------------------------------------
     def _uniform(self, shape, bound):
@@ -130,6 +137,11 @@ class ParamTree(nn.Module):
         self.linear(f"{path}.3", out_f, d)
 
     # -- bookkeeping used by the weight packers -------------------------------------------------
+    def touch(self) -> None:
+        """Say that parameter storage was modified through an alias the version counters do not see (driver.FlatTraining
+        updates every parameter through one flat tensor they are slices of): the next forward re-packs the weight images."""
+        self.__dict__["_touched"] = self.__dict__.get("_touched", 0) + 1
+
     def version_stamp(self) -> int:
         """Changes whenever any parameter is modified in place or re-assigned (optimizer step, load, .to()).
         Called once per stage per forward, so it walks a cached list of (container dict, leaf name) slots instead of
@@ -138,7 +150,7 @@ class ParamTree(nn.Module):
         if slots is None:
             slots = [(mod._parameters, leaf) for mod in self.modules() for leaf in mod._parameters]
             self.__dict__["_stamp_slots"] = slots
-        s = 0
+        s = self.__dict__.get("_touched", 0)
         for d, leaf in slots:
             p = d[leaf]
             s = (s * 1000003 + p._version + (p.data_ptr() & 0xFFFF)) & 0xFFFFFFFFFFFF

@@ -189,14 +189,21 @@ class StageRuntime:
         """zero-initialised gradient buffers of a *_BWD stage as views of ONE flat tensor (one fill instead of one per
         parameter), keyed and ordered like param_names(stage_id)"""
         m = self.module
-        names = self.param_names(stage_id)
-        shapes = [m.p(n).shape for n in names]
-        sizes = [int(np.prod(sh)) if len(sh) else 1 for sh in shapes]
-        # 16-byte aligned slices: kernels store float4 rows into some of them
-        offs, total = [], 0
-        for sz in sizes:
-            offs.append(total)
-            total += (sz + 3) // 4 * 4
+        lay = self._grad_layouts.get(stage_id) if hasattr(self, "_grad_layouts") else None
+        if lay is None:                                                     # names / shapes / offsets do not change: computed once
+            names = self.param_names(stage_id)
+            shapes = [tuple(m.p(n).shape) for n in names]
+            sizes = [int(np.prod(sh)) if len(sh) else 1 for sh in shapes]
+            # 16-byte aligned slices: kernels store float4 rows into some of them
+            offs, total = [], 0
+            for sz in sizes:
+                offs.append(total)
+                total += (sz + 3) // 4 * 4
+            lay = (names, shapes, sizes, offs, total)
+            if not hasattr(self, "_grad_layouts"):
+                self._grad_layouts = {}
+            self._grad_layouts[stage_id] = lay
+        names, shapes, sizes, offs, total = lay
         first = next(m.parameters())
         flat = torch.zeros(total, device=first.device, dtype=torch.float32)
         return {n: flat[o:o + sz].view(sh) for n, o, sz, sh in zip(names, offs, sizes, shapes)}
