@@ -6,8 +6,8 @@
 // recomputed keeping a tape, then walked backwards:
 //   ALEncoder     node block -> attention backward over the stored embedding rows (one wave per target) -> lane embedding
 //                 backward -> norm1/lin_q
-//   recurrence    21 x { GRU_Unit backward, Euler-Maruyama step backward (drift + the source's diffusion net) },
-//                 d latent enters at each actor's kept iteration, d DiffBCE/d g at the picked diffusion values
+//   recurrence    21 x { GRU_Unit backward, Euler-Maruyama step backward (drift + the source's diffusion net) } in one
+//                 persistent launch; d latent enters at each actor's kept iteration, d DiffBCE/d g at the picked diffusion values
 //   AAEncoder     the same attention chain over the 21 snapshots, then the centre embedding / bos tokens
 // Matrix weight gradients come from saved (delta, input) rows through run_wgrad; everything is reduced in a fixed
 // order (no atomics in this stage).
@@ -789,8 +789,8 @@ static int edge_attention_tape(const char* tag, const float* img_edge6, const fl
 }
 
 // The encoder's forward with every activation the backward needs kept in `w` (the "tape"): the split-precision kernels the
-// inference forward runs, in their two-kernel attention form (per-edge logits / v are needed by the softmax backward), the
-// recurrence as 21 x (SDE step, GRU) launches that save their intermediates.  Run once per training step: by
+// inference forward runs -- the fused edge attention also writes the embedding rows and the softmax statistics, which is all
+// the attention backward needs -- and the recurrence as one persistent launch that saves its intermediates.  Run once per training step: by
 // trajsde_encoder_forward_train (which also finishes local_embed / diff_pick), or by trajsde_encoder_backward itself when no
 // tape was handed over.
 static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_fwd, const float* step_tab,

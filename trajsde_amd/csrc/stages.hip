@@ -14,8 +14,8 @@ namespace tsde {
 static bool edge_x6() { static bool v = []() { const char* e = getenv("TRAJSDE_EDGE_FP32"); return !(e && atoi(e) != 0); }(); return v; }
 static bool edge_pair() { static bool v = []() { const char* e = getenv("TRAJSDE_EDGE_PAIR"); return !(e && atoi(e) == 0); }(); return v; }   // two tiles per wave (default on)
 static int pair_threads() { static int t = []() { const char* e = getenv("TRAJSDE_PAIR_THREADS"); const int v = e ? atoi(e) : 768; return v == 512 ? 512 : 768; }(); return t; }
-// fused edge attention (k_edge_attn2 + k_seg_merge: no per-edge v / logits in HBM): default; TRAJSDE_ATTN_FUSED=0 runs the
-// two-kernel form (k_edge_kv2 -> HBM -> k_seg_softmax_agg) that the backward's recomputation still uses
+// fused edge attention (k_edge_attn2 + k_seg_merge: no per-edge v / logits in HBM): default, inference and training forward
+// alike; TRAJSDE_ATTN_FUSED=0 runs the older two-kernel form (k_edge_kv2 -> HBM -> k_seg_softmax_agg), kept as a cross-check
 static bool attn_fused() { static bool v = []() { const char* e = getenv("TRAJSDE_ATTN_FUSED"); return !(e && atoi(e) == 0); }(); return v && edge_x6() && edge_pair(); }
 static int fused_threads() { return 512; }   // 2 waves per SIMD: 196 VGPRs, weight image + 8 x 8 KB of parked query rows = 147 KB of LDS
 static bool global_fused_env() { static const bool v = []() { const char* e = getenv("TRAJSDE_GLOBAL_UNFUSED"); return !(e && atoi(e) != 0); }(); return v; }
