@@ -307,6 +307,37 @@ def main():
             el1 = float(np.median(w1))
             line["streams1"] = {"value": wl.scenes * args.steps / el1, "ms_per_step": 1e3 * el1 / args.steps, "windows_ms": [1e3 * w for w in w1],
                                 "roofline": edge_roofline(iso_n, iso_ms, e_aa, 1)}
+            # the same steps as HIP-graph replays (runtime.GraphedForward: the whole forward incl. the graph stage captured per
+            # stream, the Philox key read from device memory so every replay draws fresh noise): the GPU side is unchanged --
+            # the forward is GPU-bound -- what it removes is the host's ~0.4 ms of launches per forward
+            try:
+                gfs = []
+                for k, st in enumerate(streams):
+                    with torch.cuda.stream(st):
+                        wl.batches[k].y = wl.y0s[k]
+                        gfs.append(runtime_mod.GraphedForward(model, wl.batches[k]))
+                torch.cuda.synchronize()
+
+                def graph_window(first):
+                    sync_all()
+                    t0 = time.perf_counter()
+                    for i in range(args.steps):
+                        k = (first + i) % n_streams
+                        with torch.cuda.stream(streams[k]):
+                            gfs[k](seed=10_000 * (rank + 1) + first + i)
+                    t_enq = time.perf_counter() - t0
+                    sync_all()
+                    return time.perf_counter() - t0, t_enq
+                graph_window(0)
+                gw = [graph_window(900 + w * args.steps) for w in range(3)]
+                elg = float(np.median([g[0] for g in gw]))
+                line["graph_replay"] = {"value": wl.scenes * args.steps / elg, "ms_per_step": 1e3 * elg / args.steps,
+                                        "host_enqueue_ms_per_step": 1e3 * float(np.median([g[1] for g in gw])) / args.steps,
+                                        "streams_per_gpu": n_streams, "windows_ms": [1e3 * g[0] for g in gw],
+                                        "what": "hipGraph replay of the full forward (graph stage + encoder + interactor + decoder) per stream"}
+                del gfs
+            except Exception as e:                                          # a secondary figure never costs the main line
+                line["graph_replay"] = {"error": repr(e)[:300]}
             # BASELINE configs[1] (64 scenes x 128 agents), the round-1 headline, as a secondary figure
             if SECONDARY != args.workload:
                 w2l = Workload(SECONDARY)

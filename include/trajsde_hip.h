@@ -113,6 +113,8 @@ typedef struct {
   uint64_t seed;
   const float* z;            /* if non-null: injected N(0,1) values, layout documented per call */
   const int32_t* row_ids;    /* optional global row ids for the Philox counter                  */
+  const uint64_t* seed_dev;  /* ABI 7, optional: the key is read from this DEVICE word when the kernel runs (`seed` is then
+                              * ignored), so a captured hipGraph of the forward draws fresh noise on every replay           */
 } trajsde_noise;
 
 /* ---- train-mode dropout of the attention blocks (AAEncoder ENC:521-533,592,611; ALEncoder ENC:711-723,771,794;

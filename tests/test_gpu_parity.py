@@ -645,3 +645,36 @@ def test_training_after_a_sync_free_forward_of_the_same_batch(dev):
     loss.backward()
     assert torch.isfinite(loss)
     assert data["_trajsde_graph"].graph.exact
+
+
+def test_graph_replay_is_the_eager_forward(dev):
+    """runtime.GraphedForward: the whole inference forward (graph stage included) captured once and replayed; the Philox key is
+    read from device memory, so a replay with seed s is bit-for-bit the eager forward with NoiseSpec(seed=s), and an in-place
+    edit of the batch is seen by the next replay"""
+    from trajsde_amd import runtime
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    K, T = 3, 6
+    batch = synth(S=4, n=40, L=12, F=T, box=80.0, seed=31, mixed_source=True)
+    model, cfg = H.build_model(K, T, 0.5, init_seed=6)
+    model = model.to(dev).eval()
+    data = batch.to(dev)
+    gf = runtime.GraphedForward(model, data)
+    keys = ("loc", "pi", "diff_in", "diff_out")
+    for seed in (5, 77):
+        got = {k: gf(seed=seed)[k].clone() for k in keys}
+        ref = batch.to(dev)
+        with torch.no_grad():
+            want = model(ref, noise=NoiseSpec(seed=seed))
+        for k in keys:
+            assert torch.equal(got[k], want[k]), (seed, k)
+    a = gf(seed=5)["loc"].clone()
+    assert not torch.equal(a, gf(seed=6)["loc"])
+    # an edited batch (same shapes, same addresses): one actor steps aside at the last observed step
+    data["positions"][0, 20] += 3.0
+    edited = H.clone_batch(batch)
+    edited["positions"][0, 20] += 3.0
+    got = gf(seed=5)["loc"].clone()
+    with torch.no_grad():
+        want = model(edited.to(dev), noise=NoiseSpec(seed=5))["loc"]
+    assert torch.equal(got, want) and not torch.equal(got, a)

@@ -11,8 +11,9 @@ STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGA
 STAGE_ENCODER_GRID, STAGE_DECODER_MLP, STAGE_DECODER_MLP_BWD, STAGE_ENCODER_GRID_BWD = 6, 7, 8, 9
 
 
-ABI_VERSION = 6          # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4);
-                         # device-side list lengths + trajsde_graph_prepare_async (5); encoder tape / scratch split (6)
+ABI_VERSION = 7          # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4);
+                         # device-side list lengths + trajsde_graph_prepare_async (5); encoder tape / scratch split (6);
+                         # trajsde_noise.seed_dev: Philox key read on the device (7)
 
 
 class TrajsdeError(RuntimeError):
@@ -29,7 +30,7 @@ class Batch(C.Structure):
 
 
 class Noise(C.Structure):
-    _fields_ = [("seed", C.c_uint64), ("z", C.c_void_p), ("row_ids", C.c_void_p)]
+    _fields_ = [("seed", C.c_uint64), ("z", C.c_void_p), ("row_ids", C.c_void_p), ("seed_dev", C.c_void_p)]
 
 
 class Dropout(C.Structure):

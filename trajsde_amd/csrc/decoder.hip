@@ -188,7 +188,7 @@ using namespace tsde;
 
 static NoiseArg to_arg(const trajsde_noise* n) {
   NoiseArg a{0, nullptr, nullptr};
-  if (n) { a.seed = n->seed; a.z = n->z; a.row_ids = n->row_ids; }
+  if (n) { a.seed = n->seed; a.z = n->z; a.row_ids = n->row_ids; a.seed_dev = n->seed_dev; }
   return a;
 }
 

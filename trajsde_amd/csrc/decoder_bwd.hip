@@ -813,7 +813,7 @@ int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, cons
   const int K = num_modes, T = future_steps;
   BwdWs w = carve_bwd(ws, ws_bytes, N, T, n_euler, ok);
   NoiseArg na{0, nullptr, nullptr};
-  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
+  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; na.seed_dev = noise->seed_dev; }
   const int ntiles = (N + 15) / 16;
   const int waves = BWD_THREADS / 64;
   const int64_t slab = int64_t(N) * 64;

@@ -874,7 +874,7 @@ int trajsde_encoder_forward_train(const trajsde_batch* b, const trajsde_graph* g
   if (ws_bytes < w.tape_total) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_forward_train: workspace too small (trajsde_encoder_tape_bytes)");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   NoiseArg na{0, nullptr, nullptr};
-  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
+  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; na.seed_dev = noise->seed_dev; }
   if (int rc = encoder_tape(b, g, rot, blob_fwd, step_tab, na, w, drop_aa, drop_al, st)) return rc;
   const int N = b->N;
   TS_LAUNCH(k_ffn6, tile_grid((int64_t(N) + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + EncBlob::AL_FFN6, w.al_x1, w.al_xn2,
@@ -913,7 +913,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   const int64_t R = int64_t(H) * Nt, Eaa = g->E_aa, Ela = g->E_la;
   const int64_t rtiles = (int64_t(Nt) + 15) / 16;
   NoiseArg na{0, nullptr, nullptr};
-  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
+  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; na.seed_dev = noise->seed_dev; }
   const WgradCtx wc{st, w.part, w.cs, step_tab_dev, w.parts};
   using FB = EncBlob;
   using BB = EncBwdBlob;

@@ -55,7 +55,9 @@ struct NoiseArg {
   uint64_t seed;
   const float* z;          // injected normals or nullptr
   const int32_t* row_ids;  // global ids or nullptr
+  const uint64_t* seed_dev = nullptr;   // the key lives in device memory (graph replays): read when the kernel runs
 };
+__device__ __forceinline__ uint64_t noise_key(const NoiseArg& na) { return na.seed_dev ? *na.seed_dev : na.seed; }
 
 // z for the 16 features (4 quads: jt*4+g) of `row` at `step`; injected layout [steps][rows][64]
 __device__ __forceinline__ void noise_row(f4 (&z)[4], const NoiseArg& na, uint32_t stream, int step, int64_t row,
@@ -66,8 +68,9 @@ __device__ __forceinline__ void noise_row(f4 (&z)[4], const NoiseArg& na, uint32
     for (int jt = 0; jt < 4; ++jt) z[jt] = *reinterpret_cast<const f4*>(p + 16 * jt);
   } else {
     const uint32_t rid = na.row_ids ? uint32_t(na.row_ids[row]) : uint32_t(row);
+    const uint64_t key = noise_key(na);
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) z[jt] = philox_normal4(na.seed, stream, uint32_t(step), rid, uint32_t(4 * jt + g));
+    for (int jt = 0; jt < 4; ++jt) z[jt] = philox_normal4(key, stream, uint32_t(step), rid, uint32_t(4 * jt + g));
   }
 }
 

@@ -153,7 +153,7 @@ __global__ void k_fake_x(int A, int H, const float* __restrict__ x, const int64_
   if (na.z != nullptr) {
     for (int c = 0; c < 4; ++c) z[c] = (4 * q + c < 2 * H) ? na.z[int64_t(k) * 2 * H + 4 * q + c] : 0.f;
   } else {
-    z = philox_normal4(na.seed, STREAM_FAKE_AGENT, 0u, na.row_ids ? uint32_t(na.row_ids[k]) : uint32_t(k), uint32_t(q));
+    z = philox_normal4(noise_key(na), STREAM_FAKE_AGENT, 0u, na.row_ids ? uint32_t(na.row_ids[k]) : uint32_t(k), uint32_t(q));
   }
   const int64_t a = agent_index[k];
   for (int c = 0; c < 4; ++c) {
@@ -572,7 +572,7 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int N = b->N, A = b->A, E = b->E, H = b->H, TT = b->TT, Ea = b->E_al, Nt = N + A;
   NoiseArg na{0, nullptr, nullptr};
-  if (fake_noise) { na.seed = fake_noise->seed; na.z = fake_noise->z; na.row_ids = fake_noise->row_ids; }
+  if (fake_noise) { na.seed = fake_noise->seed; na.z = fake_noise->z; na.row_ids = fake_noise->row_ids; na.seed_dev = fake_noise->seed_dev; }
 
   {
     ProfScope ps("build_csr[actors]", st);

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
                                       GP[(k * 4 + 3) * 16 + L.n] + b4);
         f4 z;
         if (na.z != nullptr) z = *reinterpret_cast<const f4*>(na.z + (int64_t(noise_step0 + idx) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g);
-        else z = philox_normal4(na.seed, STREAM_ENCODER, uint32_t(noise_step0 + idx),
+        else z = philox_normal4(noise_key(na), STREAM_ENCODER, uint32_t(noise_step0 + idx),
                                 na.row_ids ? uint32_t(na.row_ids[rowk[k]]) : uint32_t(rowk[k]), uint32_t(4 * w + L.g));
         f4 y = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
 #pragma unroll

@@ -270,7 +270,7 @@ int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, cons
   hipStream_t st = static_cast<hipStream_t>(stream_);
   float* aa_out = aa_out_user ? aa_out_user : w.aa_out;
   NoiseArg na{0, nullptr, nullptr};
-  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
+  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; na.seed_dev = noise->seed_dev; }
   if (int rc = run_aa_encoder(b, g, rot, blob, w, aa_out, st, 8, drop_aa)) return rc;
   TS_HIP(hipMemsetAsync(diff_pick, 0, size_t(2) * b->A * 64 * sizeof(float), st));
   if (int rc = run_recurrence(b, g, blob, step_tab, blob + EncBlob::HIDDEN, 0, na, w, aa_out, w.lat, diff_pick, latent_ys, st)) return rc;
@@ -301,7 +301,7 @@ int trajsde_encoder_forward_ood(const trajsde_batch* b, const trajsde_graph* g, 
   float* zero = extra.take<float>(64);
   hipStream_t st = static_cast<hipStream_t>(stream_);
   NoiseArg na{0, nullptr, nullptr};
-  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; }
+  if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; na.seed_dev = noise->seed_dev; }
   if (int rc = run_aa_encoder(b, g, rot, blob, w, w.aa_out, st)) return rc;
   TS_HIP(hipMemsetAsync(zero, 0, 64 * sizeof(float), st));                         // ENC:257 prev_hidden = zeros
   for (int j = 0; j < n_samples; ++j)

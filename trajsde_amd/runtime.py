@@ -37,6 +37,8 @@ class NoiseSpec:
     *_row_ids       int32 global row ids for the Philox counter (resharding-invariant streams)
     """
     seed: int = 0
+    seed_dev: Optional[torch.Tensor] = None  # one uint64 (as int64) on the device: the key is read THERE when the kernels run
+                                             # (`seed` ignored) -- what lets a captured graph of the forward draw fresh noise
     dropout_seed: Optional[int] = None       # key of the train-mode dropout masks (csrc/dropout.hpp); default: `seed`
     z_fake: Optional[torch.Tensor] = None
     z_enc: Optional[torch.Tensor] = None
@@ -64,7 +66,53 @@ class NoiseSpec:
             assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()
         if row_ids is not None:
             assert row_ids.is_cuda and row_ids.dtype == torch.int32 and row_ids.is_contiguous()
-        return _lib.Noise(C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF), _ptr(z), _ptr(row_ids))
+        if self.seed_dev is not None:
+            assert self.seed_dev.is_cuda and self.seed_dev.dtype == torch.int64 and self.seed_dev.numel() == 1
+        return _lib.Noise(C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF), _ptr(z), _ptr(row_ids), _ptr(self.seed_dev))
+
+
+class GraphedForward:
+    """The inference forward of one batch captured in a HIP graph (torch.cuda.CUDAGraph) and replayed.
+
+    Possible because the forward is sync-free (trajsde_graph_prepare_async: list lengths stay on the device, buffers and grids are
+    sized from bounds) and the Philox key can live in device memory (NoiseSpec.seed_dev): a replay re-runs graph preparation,
+    encoder, global interactor and decoder on whatever the batch tensors hold NOW, with the key written before the replay.
+    The batch tensors must keep their shapes and addresses (update them in place); outputs are the captured tensors.
+
+        gf = GraphedForward(model, batch)          # warm-up + capture
+        out = gf(seed=123)                         # one graph launch; out["loc"] etc. are overwritten by the next call
+    """
+
+    def __init__(self, model, data, warmup: int = 2) -> None:
+        x = data["x"]
+        _require_gpu(x, "data['x']")
+        if not sync_free():
+            raise _lib.TrajsdeError("GraphedForward needs the sync-free forward (TRAJSDE_SYNC_FREE, default kernel forms)")
+        if model.training:
+            raise _lib.TrajsdeError("GraphedForward captures the inference forward: call model.eval() first")
+        self.model, self.data = model, data
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=x.device)
+        self.noise = NoiseSpec(seed=0, seed_dev=self.seed_dev)
+        self._y = data.y                                                    # the forward REBINDS data.y to the rotated copy (MODEL:83-84):
+        side = torch.cuda.Stream(device=x.device)                          # the captured kernels keep reading this tensor
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(max(1, warmup)):                                  # weight images packed, LDS limits raised, pools warm
+                data.y = self._y
+                model(data, noise=self.noise)
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        torch.cuda.synchronize(x.device)
+        if GraphContext.KEY in data:                                         # the capture must contain the graph stage itself
+            del data[GraphContext.KEY]
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            data.y = self._y
+            self.out = model(data, noise=self.noise)
+
+    def __call__(self, seed: int):
+        self.seed_dev.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        self.graph.replay()
+        return self.out
 
 
 def set_state_storage(kind: str) -> str:
