@@ -29,6 +29,17 @@ import subprocess
 import sys
 import time
 
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -125,7 +136,7 @@ def cpu_baseline(model, cfg, spec, gpu_loc_fn):
             "sample": f"{CPU_SAMPLE_SCENES} scene x {skw['n']} agents of {WORKLOAD} (same generator and seed, K=6, 20 steps), "
                       f"oracle/restate.py (bit-exact restatement of the reference), 2 warm-ups + median of 5 timed forwards per "
                       f"thread count, best = {best_nt} threads at {med:.3f} s/forward, torch {torch.__version__} fp32, "
-                      f"host has {os.cpu_count()} logical cores",
+                      f"host: {cpu_model()}, {os.cpu_count()} logical cores",
             "scenes_per_s_by_threads": {str(k): CPU_SAMPLE_SCENES / v for k, v in table.items()}}
     return base, match
 
