@@ -105,7 +105,7 @@ def cpu_baseline(model, cfg, spec, gpu_loc_fn):
     # best one is the reported baseline
     all_threads = torch.get_num_threads()
     table, out = {}, None
-    for nt in sorted({1, 8, 16, 32}):
+    for nt in sorted({1, 8, 16, 32, all_threads}):           # incl. torch's own default (all physical cores)
         if nt > max(all_threads, 1):
             continue
         torch.set_num_threads(nt)
