@@ -270,6 +270,8 @@ def _sorted_cols(*rows):
     (2, 33, 9, dict(nus_sparsity=True)),
     (1, 1, 2, dict()),
     (4, 20, 5, dict(history_dropout=0.7)),
+    (1, 160, 8, dict(mixed_source=True)),                                # rows of 159 in-edges: three ballot blocks, > 64 survivors per segment
+    (5, 70, 12, dict(history_dropout=0.3, nus_sparsity=True)),           # rows straddling ballot-block boundaries at every offset
 ])
 def test_compacted_edge_lists_equal_the_oracle_edge_sets_exactly(S, n, L, kw, dev):
     """index work is exact: the compacted agent-agent (t, src, dst), global (src, dst) and lane-actor (lane, actor) lists are
