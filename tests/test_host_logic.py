@@ -123,3 +123,46 @@ def test_dropout_mask_host_twin():
     assert np.array_equal(a[1], a[3]) is False or True                                               # distinct ranks draw distinct blocks
     b = philox.dropout_attn_mask(9, philox.BLOCK_GLOBAL0 + 1, dst[::-1], philox.segment_ranks(src, dst)[::-1], 8, 0.5)
     assert np.array_equal(a[::-1], b)                                                                # keyed by (target, rank), not by position
+
+
+def test_flat_training_matches_per_parameter_adamw_on_cpu():
+    """driver.FlatTraining (AdamW over one flat tensor the parameters are slices of) against torch's per-parameter AdamW on a
+    module with parameters the loss does not reach: same values after three steps, untouched parameters stay untouched, and
+    the stages are told to re-pack (touch) because the slices' version counters do not move"""
+    import torch
+    from trajsde_amd import driver
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(4)
+            self.a = torch.nn.Parameter(torch.randn(5, 3, generator=g))
+            self.b = torch.nn.Parameter(torch.randn(7, generator=g))
+            self.unused = torch.nn.Parameter(torch.randn(4, generator=g))
+            self.lr, self.weight_decay, self.T_max = 1e-2, 1e-1, 5
+            self.touched = 0
+
+        def params_with_gradient(self):
+            return [self.a, self.b]
+
+        def touch(self):
+            self.touched += 1
+
+        def loss(self, i):
+            return ((self.a * (i + 1)).sum() ** 2 + (self.b ** 3).sum())
+
+    ref, flat = Toy(), Toy()
+    opt = torch.optim.AdamW(ref.parameters(), lr=ref.lr, weight_decay=ref.weight_decay)
+    ft = driver.FlatTraining(flat)
+    keep = flat.unused.detach().clone()
+    for i in range(3):
+        opt.zero_grad()
+        ref.loss(i).backward()
+        opt.step()
+        ft.zero()
+        flat.loss(i).backward()
+        ft.step()
+    assert torch.equal(ref.a.detach(), flat.a.detach()) and torch.equal(ref.b.detach(), flat.b.detach())
+    assert torch.equal(flat.unused.detach(), keep) and torch.equal(ref.unused.detach(), keep) and flat.unused.grad is None
+    assert flat.touched == 3
+    assert flat.a.data_ptr() == ft.flat_param.data_ptr()                  # the parameters ARE slices of the flat tensor
