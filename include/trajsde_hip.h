@@ -193,6 +193,10 @@ int trajsde_graph_prepare(const trajsde_batch* b, const float* rotate_mat, float
  * graph and says so. */
 int trajsde_graph_prepare_async(const trajsde_batch* b, const float* rotate_mat, float radius, const trajsde_noise* fake_noise,
                                 void* ws, int64_t ws_bytes, trajsde_graph* out, void* stream);
+/* The radius test of the snapshot lists is  dx*dx + dy*dy < T  with T = the smallest float whose correctly rounded square root
+ * reaches `radius`: exactly the survivors of the reference's  sqrt(dx*dx + dy*dy) < radius  (utils/util.py:88).  Exported so
+ * that the equivalence can be checked on the host (tests/test_host_logic.py). */
+float trajsde_radius2_threshold(float radius);
 /* 1 when the kernel forms this process selected (environment switches of csrc/stages.hip) accept a graph from
  * trajsde_graph_prepare_async, i.e. the default build and environment */
 int trajsde_sync_free_supported(void);

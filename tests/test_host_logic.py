@@ -166,3 +166,23 @@ def test_flat_training_matches_per_parameter_adamw_on_cpu():
     assert torch.equal(flat.unused.detach(), keep) and torch.equal(ref.unused.detach(), keep) and flat.unused.grad is None
     assert flat.touched == 3
     assert flat.a.data_ptr() == ft.flat_param.data_ptr()                  # the parameters ARE slices of the flat tensor
+
+
+def test_squared_radius_threshold_selects_exactly_the_sqrt_survivors():
+    """the snapshot pass tests  d2 < T  instead of  sqrt(d2) < radius  (UTIL:88): T is the smallest float32 whose correctly
+    rounded square root reaches the radius, so both tests agree for EVERY float32 d2 -- checked on all values within a few
+    thousand ulps of radius^2 and on random ones, for several radii"""
+    import numpy as np
+    from trajsde_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    for radius in (50.0, 1.0, 0.3, 49.99999, 123.456, 1e-3, 7e4):
+        r = np.float32(radius)
+        T = np.float32(L.trajsde_radius2_threshold(float(r)))
+        centre = np.float32(r * r)
+        bits = np.array([centre], dtype=np.float32).view(np.uint32)[0]
+        near = (np.arange(-4096, 4097, dtype=np.int64) + int(bits)).astype(np.uint32).view(np.float32)
+        far = (rng.random(20000).astype(np.float32) * np.float32(4.0) * centre)
+        for d2 in (near, far):
+            assert np.array_equal(np.sqrt(d2, dtype=np.float32) < r, d2 < T), radius
+    assert L.trajsde_radius2_threshold(0.0) == 0.0 and L.trajsde_radius2_threshold(-1.0) == 0.0

@@ -66,6 +66,7 @@ SIGNATURES = {
     "trajsde_graph_prepare": (C.c_int, [C.POINTER(Batch), P, F32, C.POINTER(Noise), P, I64, C.POINTER(Graph), P]),
     "trajsde_graph_prepare_async": (C.c_int, [C.POINTER(Batch), P, F32, C.POINTER(Noise), P, I64, C.POINTER(Graph), P]),
     "trajsde_sync_free_supported": (C.c_int, []),
+    "trajsde_radius2_threshold": (C.c_float, [C.c_float]),
     "trajsde_graph_edges_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
     "trajsde_graph_compact": (C.c_int, [C.POINTER(Batch), P, P, I64, P, I64, C.POINTER(Graph), P]),
     "trajsde_encoder_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),

@@ -544,6 +544,8 @@ static std::atomic<int> g_export_senders{0};
 
 extern "C" {
 
+float trajsde_radius2_threshold(float radius) { return radius2_threshold(radius); }
+
 int trajsde_export_senders(int on) {
   const int prev = g_export_senders.exchange(on ? 1 : 0);
   return prev;
