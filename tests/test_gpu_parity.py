@@ -680,3 +680,35 @@ def test_graph_replay_is_the_eager_forward(dev):
     with torch.no_grad():
         want = model(edited.to(dev), noise=NoiseSpec(seed=5))["loc"]
     assert torch.equal(got, want) and not torch.equal(got, a)
+
+
+def test_radius_test_on_borderline_pairs_follows_torch_norm(dev):
+    """pairs whose distance sits within an ulp of the radius: the three ways of forming dx^2 + dy^2 in float32 (two fma
+    contraction orders, no contraction) disagree about them.  The kernel forms it like torch.norm does on the reference's
+    side (fma(dy, dy, fl(dx * dx))), so the edge lists still equal the oracle's exactly"""
+    import numpy as np
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    offs = np.array([[37.32516098022461, 33.26908874511719], [-35.689231872558594, -35.01826095581055],
+                     [-33.735321044921875, -36.9043083190918], [2.910139560699463, -49.91523742675781],
+                     [-48.656944274902344, -11.51093578338623], [-29.218093872070312, -40.57465744018555]], dtype=np.float32)
+    K, T = 2, 5
+    batch = synth(S=1, n=7, L=3, F=T, box=10.0, seed=5)
+    pos = torch.zeros_like(batch["positions"])
+    pos[1:7] = torch.from_numpy(offs)[:, None, :]                       # actor 0 at the origin, nobody moves
+    batch["positions"] = pos
+    batch["x"] = torch.zeros_like(batch["x"])
+    batch["padding_mask"] = torch.zeros_like(batch["padding_mask"])
+    batch["bos_mask"] = torch.zeros_like(batch["bos_mask"])
+    batch["bos_mask"][:, 0] = True
+    d = torch.norm(pos[1:7, 0] - pos[0:1, 0], dim=-1)
+    assert 0 < int((d < 50.0).sum()) < 6                                 # the oracle's own test splits these pairs
+    model, cfg = H.build_model(K, T, 0.5, init_seed=2)
+    want = H.oracle_forward(model, cfg, batch, noise_seed=3)
+    model = model.to(dev)
+    model.encoder.capture_intermediates = True
+    model(batch.to(dev), noise=NoiseSpec(seed=3))
+    im = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in model.encoder.last_intermediates.items()}
+    Nt = batch.num_nodes + batch["agent_index"].numel()
+    t_of = torch.div(im["aa_dst"], Nt, rounding_mode="floor")
+    assert torch.equal(_sorted_cols(t_of * Nt + im["aa_src"], im["aa_dst"]), _sorted_cols(*want["aa_edge_list"]))

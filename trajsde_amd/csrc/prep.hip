@@ -178,7 +178,11 @@ __global__ void k_fake_x(int A, int H, const float* __restrict__ x, const int64_
 // The reference's test is  sqrt(dx^2 + dy^2) < radius  in float32 (UTIL:88).  sqrtf is correctly rounded and monotone, so that is
 // exactly  dx^2 + dy^2 < T  with T the smallest float whose square root reaches the radius (radius2_threshold, host): same
 // survivors for every input, without a 25-instruction IEEE square root per candidate.
-__device__ __forceinline__ bool within_radius2(float dx, float dy, float thr2) { return dx * dx + dy * dy < thr2; }
+// The sum of squares is formed the way torch.norm forms it on the reference's side (measured: acc = fl(dx * dx), then
+// fma(dy, dy, acc) -- 0 mismatches in 2 M random pairs, against 8 % for the other contraction order), spelled out so that the
+// compiler's choice of contraction cannot move a borderline pair.
+__device__ __forceinline__ float norm2_sq(float dx, float dy) { return fmaf(dy, dy, __fmul_rn(dx, dx)); }
+__device__ __forceinline__ bool within_radius2(float dx, float dy, float thr2) { return norm2_sq(dx, dy) < thr2; }
 static float radius2_threshold(float radius) {
   if (!(radius > 0.f)) return 0.f;                                       // sqrt(x) < r <= 0 never holds (x >= 0)
   if (std::isinf(radius)) return radius;
@@ -402,7 +406,7 @@ __global__ void k_la_flags(int E_al, int N, const int32_t* __restrict__ rowptr, 
     }
     actor[p] = lo;
     const float vx = vec[2 * int64_t(eid[p])], vy = vec[2 * int64_t(eid[p]) + 1];
-    keep = sqrtf(vx * vx + vy * vy) < radius;                                                 // ENC:198
+    keep = sqrtf(norm2_sq(vx, vy)) < radius;                                                  // ENC:198
   }
   flags[p] = keep;
 }
