@@ -82,3 +82,9 @@ def test_param_tables_of_backward_and_vanilla_stages():
     dec = dict(van.decoder.named_parameters())
     assert set(names(_lib.STAGE_DECODER_MLP, 60, 10)) == set(dec)
     assert lib.trajsde_blob_floats(_lib.STAGE_ENCODER_GRID, 4, 0) > lib.trajsde_blob_floats(_lib.STAGE_ENCODER, 0, 0)
+
+
+def test_build_hook_post_check_passes_on_the_built_library():
+    """__graft_entry__.build()'s own check after compiling (it once compared against a stale ABI literal)"""
+    import __graft_entry__ as g
+    g.check_loaded()
