@@ -5,7 +5,7 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtrajsde_hip.so")
+LIB_PATH = os.environ.get("TRAJSDE_LIB") or os.path.join(HERE, "libtrajsde_hip.so")   # TRAJSDE_LIB: another build of the same ABI (A/B runs)
 
 STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGATOR_BWD, STAGE_ENCODER_BWD = 0, 1, 2, 3, 4, 5
 STAGE_ENCODER_GRID, STAGE_DECODER_MLP, STAGE_DECODER_MLP_BWD, STAGE_ENCODER_GRID_BWD = 6, 7, 8, 9

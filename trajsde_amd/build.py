@@ -15,6 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # split-precision flavour of the matrix products (csrc/tile.hpp): fp16x3 (default) or the older bf16x6
 if os.environ.get("TRAJSDE_SPLIT", "fp16x3") == "bf16x6":
     FLAGS.append("-DTSDE_SPLIT_H3=0")
+FLAGS += os.environ.get("TRAJSDE_CXXFLAGS", "").split()       # experiments: extra -D switches of the kernels
 
 
 def sources():

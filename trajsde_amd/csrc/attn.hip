@@ -221,11 +221,11 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
                                                         float* __restrict__ rec, int heads, const int32_t* __restrict__ segptr, DropArg drop,
                                                         float* __restrict__ emb_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  using EL = EdgeL6;
+  using EL = EdgeL6F;
   const int64_t E = edge_count(ec);
   const int C = stream_len(ec, E, C_host);
   if (E <= 0) return;                                      // (only reachable when the count lives on the device)
-  stage_blob(lds, img_g, EL::SIZE);
+  stage_blob(lds, img_g, EL::LDS_SIZE);
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t nstreams = (E + C - 1) / C;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
   // it do not fit beside the softmax state at two waves per SIMD, and re-gathering 256 B per row and iteration from L2 was
   // 1.4 GB of fabric reads per launch (FETCH_SIZE).  So each lane parks ITS 16 query values in LDS -- a private slot,
   // [tile][jt][lane][4], conflict-free b128 -- when its row's target changes, and reads them back every iteration.
-  float* qs = lds + EL::SIZE + wave * (2 * 4 * 64 * 4);
+  float* qs = lds + EL::LDS_SIZE + wave * (2 * 4 * 64 * 4);
   int cur0 = -1, cur1 = -1;
   int base0 = 0, base1 = 0;                                // DROP: first edge of the rows' current targets (mask counter = rank)
   const f4 one4 = f4{1.f, 1.f, 1.f, 1.f};
@@ -275,13 +275,30 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
       for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(qs + ((4 + jt) * 64 + L.lane) * 4) = qn[jt];
     }
     f4 emb0[4], emb1[4], kv0[8], kv1[8], qv[4];
-    edge_embed2_x6(emb0, emb1, g0, g1, lds, L);
-    if (SAVE) {
-      if (ok0) store_row(emb0, emb_out, e0, L.g);
-      if (ok1) store_row(emb1, emb_out, e1, L.g);
+    edge_embed2_fused(emb0, emb1, g0, g1, lds, L);         // (y - mean) * rstd of the last LayerNorm; gamma / beta live downstream
+    if (SAVE) {                                            // the tape holds the embedding rows proper
+      f4 t0[4], t1[4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const f4 ga = *reinterpret_cast<const f4*>(lds + EL::AG3 + 16 * jt + 4 * L.g);
+        const f4 be = *reinterpret_cast<const f4*>(lds + EL::AE3 + 16 * jt + 4 * L.g);
+        t0[jt] = emb0[jt] * ga + be;
+        t1[jt] = emb1[jt] * ga + be;
+      }
+      if (ok0) store_row(t0, emb_out, e0, L.g);
+      if (ok1) store_row(t1, emb_out, e1, L.g);
     }
-    load_vec<8>(kv0, lds + EL::BKV, L.g);
-    load_vec<8>(kv1, lds + EL::BKV, L.g);
+    // k / v without their constant parts (EdgeL6F): q . CK shifts all logits of a (target, head) alike, and sum_e alpha_e CV = CV
+    // is added by k_seg_merge.  With attention dropout the kept weights do not sum to one, so v carries CV here.
+#pragma unroll
+    for (int jo = 0; jo < 8; ++jo) {
+      kv0[jo] = f4{0.f, 0.f, 0.f, 0.f};
+      kv1[jo] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (DROP) {
+      load_vec<4>(reinterpret_cast<f4(&)[4]>(kv0[4]), img_g + EL::CV, L.g);
+      load_vec<4>(reinterpret_cast<f4(&)[4]>(kv1[4]), img_g + EL::CV, L.g);
+    }
     linear_acc_x6_2<8, 4>(kv0, kv1, emb0, emb1, lds + EL::WKV, L.lane);
     {
 #pragma unroll
@@ -311,8 +328,12 @@ template __global__ void k_edge_attn2<512, true, true>(const float*, const float
 // records of one target -> agg row.  One wave per target, lane = feature f (jt = f>>4, g = (f>>2)&3); a target's records sit
 // at slots target + (first stream .. last stream) of its segment and are combined in that order.
 // stats (training path, or null): the merged (max logit, 1 / (sum + 1e-16)) of every (target, head), [R][heads][2]
+// img (EdgeL6F): the constant parts the edge kernel left out -- CV joins the aggregate of every non-empty target (add_cv; not
+// when the edge kernel ran with attention dropout and carried it itself), q . CK / sqrt(dh) joins the saved maximum, which the
+// backward compares with logits that contain it
 __global__ __launch_bounds__(256) void k_seg_merge(const int32_t* __restrict__ segptr, const float* __restrict__ rec, EdgeCount ec, int C_host,
-                                                   int64_t R, float* __restrict__ agg, float* __restrict__ stats, int heads) {
+                                                   int64_t R, float* __restrict__ agg, float* __restrict__ stats, int heads,
+                                                   const float* __restrict__ img, const float* __restrict__ q, int add_cv) {
   const int C = stream_len(ec, edge_count(ec), C_host);
   const int lane = threadIdx.x & 63;
   const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -334,12 +355,15 @@ __global__ __launch_bounds__(256) void k_seg_merge(const int32_t* __restrict__ s
       m = mn;
     }
     out = acc / (s + 1e-16f);                              // torch_geometric.utils.softmax denominator
+    if (add_cv) out += img[EdgeL6F::CV + lane];
     m_out = m;
     inv_out = 1.0f / (s + 1e-16f);
   }
   agg[node * 64 + lane] = out;
   if (stats != nullptr) {                                  // lane = feature: the first lane of every head writes its pair
     const int lph = 64 / heads;
+    const float ck = q[node * 64 + lane] * img[EdgeL6F::CK + lane];
+    if (end > beg) m_out += (heads == 4 ? head_sum16(ck) * 0.25f : head_sum(ck) * INV_SQRT_DH);
     if ((lane & (lph - 1)) == 0) *reinterpret_cast<float2*>(stats + (node * heads + lane / lph) * 2) = float2{m_out, inv_out};
   }
 }

@@ -776,11 +776,11 @@ int aa_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const fl
 // training-path attention of an encoder (AA / AL): the edge embedding rows are computed once and KEPT (the tape), the attention
 // itself runs one wave per target over those rows (k_global_attn<.., NODE = false>: lin_k / lin_v folded into per-target
 // vectors) and leaves the softmax statistics for the backward
-static int edge_attention_tape(const char* tag, const float* img_edge6, const float* img_attn, const float* geom, const int32_t* dst, int64_t E,
+static int edge_attention_tape(const char* tag, const float* img_fused, const float* img_edge6, const float* img_attn, const float* geom, const int32_t* dst, int64_t E,
                                const int32_t* segptr, const float* q, int64_t R, float* emb, float* stats, float* agg, float* rec, int heads,
                                const DropArg& drop, hipStream_t st) {
   if (attn_fused_enabled())     // the inference forward's own kernels, which also write the embedding rows and the statistics
-    return fused_edge_attention(tag, false, img_edge6, geom, dst, q, EdgeCount{E, nullptr, 0}, segptr, R, rec, agg, heads, st, drop, emb, stats);
+    return fused_edge_attention(tag, false, img_fused, geom, dst, q, EdgeCount{E, nullptr, 0}, segptr, R, rec, agg, heads, st, drop, emb, stats);
   if (E > 0)
     TS_LAUNCH(k_edge_embed<true>, tile_grid((E + 15) / 16, 1024, EdgeL6::EMB_SIZE * 4), 1024, EdgeL6::EMB_SIZE * 4, st, img_edge6, geom,
               EdgeCount{E, nullptr, 0}, emb, 0);
@@ -801,7 +801,7 @@ static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const fl
   using FB = EncBlob;
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob_fwd + FB::AA_CENTER, b->x,
             g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
-  if (int rc = edge_attention_tape("k_edge_kv[aa]+emb", blob_fwd + FB::AA_EDGE6, blob_fwd + FB::AA_ATTN, g->aa_geom, g->aa_dst, Eaa, g->aa_segptr, w.q, R,
+  if (int rc = edge_attention_tape("k_edge_kv[aa]+emb", blob_fwd + FB::AA_EDGE6F, blob_fwd + FB::AA_EDGE6, blob_fwd + FB::AA_ATTN, g->aa_geom, g->aa_dst, Eaa, g->aa_segptr, w.q, R,
                                    w.emb, w.stats, w.agg, w.rec, 8, drop_aa, st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
@@ -823,7 +823,7 @@ static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const fl
   TS_LAUNCH_CHECK("k_gather_latent");
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob_fwd + FB::AL_Q, w.lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
-  if (int rc = edge_attention_tape("k_edge_kv[al]+emb", blob_fwd + FB::AL_EDGE6, blob_fwd + FB::AL_ATTN, g->la_geom, g->la_dst, Ela, g->la_segptr, w.al_q,
+  if (int rc = edge_attention_tape("k_edge_kv[al]+emb", blob_fwd + FB::AL_EDGE6F, blob_fwd + FB::AL_EDGE6, blob_fwd + FB::AL_ATTN, g->la_geom, g->la_dst, Ela, g->la_segptr, w.al_q,
                                    int64_t(N), w.al_emb, w.al_stats, w.al_agg, w.rec, 8, drop_al, st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
@@ -1065,7 +1065,7 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
   // ================= forward recompute =================
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob_fwd + FB::AA_CENTER, b->x,
             g->x_fake, rot, b->bos_mask, g->orig, N, N, H, w.center, w.cn, w.q);
-  if (int rc = edge_attention_tape("k_edge_kv[aa]+emb", blob_fwd + FB::AA_EDGE6, blob_fwd + FB::AA_ATTN, g->aa_geom, g->aa_dst, Eaa, g->aa_segptr, w.q, R,
+  if (int rc = edge_attention_tape("k_edge_kv[aa]+emb", blob_fwd + FB::AA_EDGE6F, blob_fwd + FB::AA_EDGE6, blob_fwd + FB::AA_ATTN, g->aa_geom, g->aa_dst, Eaa, g->aa_segptr, w.q, R,
                                    w.emb, w.stats, w.agg, w.rec, num_heads, no_drop(), st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
@@ -1087,7 +1087,7 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
   TS_LAUNCH(k_tr_final, tile_grid((int64_t(N) + 15) / 16, 256, 0), 256, 0, st, blob_fwd + EncGridBlob::norm(nl), x, N, tout);
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob_fwd + FB::AL_Q, tout, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
-  if (int rc = edge_attention_tape("k_edge_kv[al]+emb", blob_fwd + FB::AL_EDGE6, blob_fwd + FB::AL_ATTN, g->la_geom, g->la_dst, Ela, g->la_segptr, w.al_q,
+  if (int rc = edge_attention_tape("k_edge_kv[al]+emb", blob_fwd + FB::AL_EDGE6F, blob_fwd + FB::AL_EDGE6, blob_fwd + FB::AL_ATTN, g->la_geom, g->la_dst, Ela, g->la_segptr, w.al_q,
                                    int64_t(N), w.al_emb, w.al_stats, w.al_agg, w.rec, num_heads, no_drop(), st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,

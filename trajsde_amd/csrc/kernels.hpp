@@ -50,7 +50,7 @@ template <int THREADS, bool DROP, bool SAVE>
 __global__ void k_edge_attn2(const float* img, const float* geom, const int32_t* dst, const float* q, EdgeCount ec, int C, float* rec, int heads,
                              const int32_t* segptr, DropArg drop, float* emb_out);
 // host side of the fused edge attention (stages.hip): k_edge_attn2 + k_seg_merge -> agg [R,64]; the training path also asks
-// for the embedding rows (emb_out [E,64]) and the softmax statistics (stats [R,heads,2])
+// for the embedding rows (emb_out [E,64]) and the softmax statistics (stats [R,heads,2]).  img: the stage blob's EdgeL6F image
 bool attn_fused_enabled();
 int64_t fused_rec_floats(int64_t E, bool exact, int64_t targets);
 int fused_edge_attention(const char* tag, bool dominant, const float* img, const float* geom, const int32_t* dst, const float* q,
@@ -83,7 +83,8 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
       else TS_LAUNCH_TAG("k_edge_attn_rows<8>", false, (k_global_attn<8, false, false, false>), grid, block, lds, st, img, segptr, _ns, emb, q, _nf, _nf, R, agg, stats, drop); \
     }                                                                                                               \
   } while (0)
-__global__ void k_seg_merge(const int32_t* segptr, const float* rec, EdgeCount ec, int C, int64_t R, float* agg, float* stats, int heads);
+__global__ void k_seg_merge(const int32_t* segptr, const float* rec, EdgeCount ec, int C, int64_t R, float* agg, float* stats, int heads,
+                            const float* img, const float* q, int add_cv);
 template <bool X6>
 __global__ void k_edge_embed(const float* img, const float* geom, EdgeCount ec, float* emb_out, int st_bf16);
 template <bool X6>

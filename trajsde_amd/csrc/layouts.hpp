@@ -68,6 +68,28 @@ struct EdgeL6 {
     SIZE = BKV_END
   };
 };
+// image of the fused edge-attention kernel (attn.hip k_edge_attn2).  The embedding of EdgeL6 with the LayerNorm algebra
+// moved into the weights (pack.hip recipe_edge_fused):
+//   WA3 | WB3 | B3 and W2 | B2 are FEATURE-CENTRED (the mean over the 64 outputs removed), so the rows that leave the matrix
+//     cores are already y - mean(y): the LayerNorms behind them reduce the variance only;
+//   WKV = [lin_k | lin_v] diag(gamma3): the last LayerNorm's gamma rides in the consumer, the kernel multiplies by rstd only;
+//   CK = lin_k(beta3), CV = lin_v(beta3) (biases included) are the constant parts of k and v.  q . CK is the same for every
+//     edge of a (target, head): the softmax does not see it (it is added back to the saved maximum of the training tape),
+//     and sum_e alpha_e CV = CV is added once per target by k_seg_merge.  Both are read from the blob in global memory.
+struct EdgeL6F {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(A_E, 64, S), TS_FIELD(B_E, 64, A_E),
+    TS_FIELD(WA3, MAT64X6, B_E), TS_FIELD(WB3, MAT64X6, WA3), TS_FIELD(B3, 64, WB3),
+    TS_FIELD(AG0, 64, B3), TS_FIELD(AE0, 64, AG0), TS_FIELD(W2, MAT64X6, AE0), TS_FIELD(B2, 64, W2),
+    TS_FIELD(AG3, 64, B2), TS_FIELD(AE3, 64, AG3),                      // the embedding rows of the training tape only
+    TS_FIELD(A_C, In2L::SIZE, AE3), TS_FIELD(B_C, In2L::SIZE, A_C),
+    TS_FIELD(WKV, 2 * MAT64X6, B_C),
+    LDS_SIZE = WKV_END,
+    TS_FIELD(CK, 64, WKV), TS_FIELD(CV, 64, CK),
+    SIZE = CV_END
+  };
+};
 struct GEdgeL6 {
   enum : int { S_END = 0, TS_FIELD(WKV, 2 * MAT64X6, S), TS_FIELD(BKV, 128, WKV), SIZE = BKV_END };
 };
@@ -213,7 +235,9 @@ struct EncBlob {
     COOP6 = AL_FFN6 + FfnL6::SIZE,
     AA_ATTN = COOP6 + EncCoopL6::SIZE,
     AL_ATTN = AA_ATTN + GAttnL::SIZE,
-    SIZE = AL_ATTN + GAttnL::SIZE
+    AA_EDGE6F = AL_ATTN + GAttnL::SIZE,
+    AL_EDGE6F = AA_EDGE6F + EdgeL6F::SIZE,
+    SIZE = AL_EDGE6F + EdgeL6F::SIZE
   };
 };
 

@@ -42,7 +42,7 @@ struct PackJob {
   const float *src, *src2, *src3;
   float* dst;
 };
-enum PackKind { PK_VEC = 0, PK_COL, PK_MAT, PK_MAT_PAD, PK_MATT, PK_MAT6, PK_MAT6_STACK2, PK_SPLIT, PK_LN2 };
+enum PackKind { PK_VEC = 0, PK_COL, PK_MAT, PK_MAT_PAD, PK_MATT, PK_MAT6, PK_MAT6_STACK2, PK_SPLIT, PK_LN2, PK_MAT6_CENTRED, PK_VEC_CENTRED, PK_AFFINE };
 constexpr int PACK_JOBS_PER_LAUNCH = 48;        // 48 x 64 B: under the 4 KB kernel-argument limit
 struct PackJobs {
   PackJob j[PACK_JOBS_PER_LAUNCH];
@@ -131,14 +131,46 @@ __device__ __forceinline__ void k_pack_split(int i, const float* __restrict__ sr
 }
 
 // lin_k | lin_v as ONE 128-row split-precision matrix: planes are [plane][jo 0..7][s][lane][8]
+// colscale (or null): the matrix times diag(colscale) -- a LayerNorm's gamma folded into the layer that consumes its output
 __device__ __forceinline__ void k_pack_mat6_stack2(int i, const float* __restrict__ wk, const float* __restrict__ wv,
-                                                   unsigned short* __restrict__ dst) {
+                                                   const float* __restrict__ colscale, unsigned short* __restrict__ dst) {
   const int per_plane = 8 * 2 * 512;
   if (i >= per_plane) return;
   const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % 2, jo = (i >> 9) / 2;
   const float* src = jo < 4 ? wk : wv;
-  const float x = src[(16 * (jo & 3) + (lane & 15)) * 64 + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)];
+  const int col = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+  float x = src[(16 * (jo & 3) + (lane & 15)) * 64 + col];
+  if (colscale != nullptr) x *= colscale[col];
   store_split(x, dst, i, per_plane);
+}
+
+// 64x64 weight with the mean over its OUTPUT features removed from every column: W_c = W - 1 (1^T W) / 64.  A LayerNorm
+// that follows y = W x + b only ever sees y - mean(y) = W_c x + (b - mean(b)), so the kernel that multiplies by W_c gets the
+// centred row straight out of the matrix cores (tile.hpp centred_rstd)
+__device__ __forceinline__ void k_pack_mat6_centred(int i, const float* __restrict__ src, unsigned short* __restrict__ dst) {
+  const int per_plane = 4 * 2 * 512;
+  if (i >= per_plane) return;
+  const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % 2, jo = (i >> 9) / 2;
+  const int col = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+  double m = 0;
+  for (int r = 0; r < 64; ++r) m += src[r * 64 + col];
+  const float x = float(double(src[(16 * jo + (lane & 15)) * 64 + col]) - m / 64);
+  store_split(x, dst, i, per_plane);
+}
+// dst = (a [+ b]) - mean(a [+ b]), 64 elements
+__device__ __forceinline__ void k_pack_vec_centred(int i, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst) {
+  if (i >= 64) return;
+  double m = 0;
+  for (int f = 0; f < 64; ++f) m += double(a[f]) + (b ? double(b[f]) : 0.0);
+  dst[i] = float(double(a[i]) + (b ? double(b[i]) : 0.0) - m / 64);
+}
+// dst = W beta + bias (W [64][64] row-major): what a linear layer makes of the LayerNorm's beta in front of it
+__device__ __forceinline__ void k_pack_affine(int i, const float* __restrict__ W, const float* __restrict__ beta,
+                                              const float* __restrict__ bias, float* __restrict__ dst) {
+  if (i >= 64) return;
+  double acc = bias[i];
+  for (int c = 0; c < 64; ++c) acc += double(W[i * 64 + c]) * beta[c];
+  dst[i] = float(acc);
 }
 
 // closed-form Linear(2,64)->LayerNorm block (layouts.hpp In2L) from W [64][2], b [64], gamma [64]: thread f < 64 writes
@@ -182,7 +214,10 @@ __global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
     case PK_MAT_PAD: k_pack_mat_pad(i, J.src, J.dst, J.p0, J.p1, J.p2, J.p3); break;
     case PK_MATT: k_pack_matT(i, J.src, J.dst, J.p0, J.p1, J.p2, J.p3, J.p4); break;
     case PK_MAT6: k_pack_mat6(i, J.src, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1, J.p2, J.p3); break;
-    case PK_MAT6_STACK2: k_pack_mat6_stack2(i, J.src, J.src2, reinterpret_cast<unsigned short*>(J.dst)); break;
+    case PK_MAT6_STACK2: k_pack_mat6_stack2(i, J.src, J.src2, J.src3, reinterpret_cast<unsigned short*>(J.dst)); break;
+    case PK_MAT6_CENTRED: k_pack_mat6_centred(i, J.src, reinterpret_cast<unsigned short*>(J.dst)); break;
+    case PK_VEC_CENTRED: k_pack_vec_centred(i, J.src, J.src2, J.dst); break;
+    case PK_AFFINE: k_pack_affine(i, J.src, J.src2, J.src3, J.dst); break;
     case PK_LN2: k_pack_ln2(i, J.src, J.src2, J.src3, J.dst); break;
     case PK_SPLIT: k_pack_split(i, J.src, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1, J.p2, J.p3, J.p4 & 0x3FFFFFFF, J.p4 >> 30); break;
   }
@@ -317,6 +352,42 @@ static void recipe_edge_embed6(Packer& P, const std::string& p, int base) {   //
   P.vec(p + ".aggr_embed.2.bias", base + E::B2, 64);
   P.ln(p + ".aggr_embed.3", base + E::AG3, base + E::AE3);
 }
+// image of the fused edge-attention kernel (layouts.hpp EdgeL6F): the embedding of recipe_edge_embed6 with the LayerNorm
+// algebra folded into the matrices, lin_k | lin_v scaled by the last LayerNorm's gamma, no k / v bias rows
+static void recipe_edge_fused(Packer& P, const std::string& p, const std::string& att, int base) {
+  using E = EdgeL6F;
+  const float* wa = P.src(p + ".module_list.0.3.weight");
+  const float* wb = P.src(p + ".module_list.1.3.weight");
+  const float* ba = P.src(p + ".module_list.0.3.bias");
+  const float* bb = P.src(p + ".module_list.1.3.bias");
+  const float* w2 = P.src(p + ".aggr_embed.2.weight");
+  const float* b2 = P.src(p + ".aggr_embed.2.bias");
+  const float* g3 = P.src(p + ".aggr_embed.3.weight");
+  const float* e3 = P.src(p + ".aggr_embed.3.bias");
+  const float* wk = P.src(att + ".lin_k.weight");
+  const float* wv = P.src(att + ".lin_v.weight");
+  const float* bk = P.src(att + ".lin_k.bias");
+  const float* bv = P.src(att + ".lin_v.bias");
+  P.vec(p + ".module_list.0.1.bias", base + E::A_E, 64);
+  P.vec(p + ".module_list.1.1.bias", base + E::B_E, 64);
+  P.ln2(p + ".module_list.0", base + E::A_C);
+  P.ln2(p + ".module_list.1", base + E::B_C);
+  P.ln(p + ".aggr_embed.0", base + E::AG0, base + E::AE0);
+  P.ln(p + ".aggr_embed.3", base + E::AG3, base + E::AE3);
+  if (P.dry) return;
+  float* d = P.blob + base;
+  P.emit(PK_MAT6_CENTRED, 4 * 2 * 512, wa, d + E::WA3);
+  P.emit(PK_MAT6_CENTRED, 4 * 2 * 512, wb, d + E::WB3);
+  P.emit(PK_VEC_CENTRED, 64, ba, d + E::B3, 0, 0, 0, 0, 0, bb);
+  P.emit(PK_MAT6_CENTRED, 4 * 2 * 512, w2, d + E::W2);
+  P.emit(PK_VEC_CENTRED, 64, b2, d + E::B2);
+  P.emit(PK_MAT6_STACK2, 8 * 2 * 512, wk, d + E::WKV, 0, 0, 0, 0, 0, wv);
+  P.jobs.back().src3 = g3;
+  P.emit(PK_AFFINE, 64, wk, d + E::CK, 0, 0, 0, 0, 0, e3);
+  P.jobs.back().src3 = bk;
+  P.emit(PK_AFFINE, 64, wv, d + E::CV, 0, 0, 0, 0, 0, e3);
+  P.jobs.back().src3 = bv;
+}
 static void pack_kv6(Packer& P, const std::string& k, const std::string& v, int w, int b) {
   const float* wk = P.src(k + ".weight");
   const float* wv = P.src(v + ".weight");
@@ -438,6 +509,8 @@ static void recipe_encoder_attention(Packer& P) {
   pack_kv6(P, "aa_encoder.lin_k", "aa_encoder.lin_v", B::AA_EDGE6 + EdgeL6::WKV, B::AA_EDGE6 + EdgeL6::BKV);
   recipe_edge_embed6(P, "al_encoder.lane_embed", B::AL_EDGE6);
   pack_kv6(P, "al_encoder.lin_k", "al_encoder.lin_v", B::AL_EDGE6 + EdgeL6::WKV, B::AL_EDGE6 + EdgeL6::BKV);
+  recipe_edge_fused(P, "aa_encoder.nbr_embed", "aa_encoder", B::AA_EDGE6F);
+  recipe_edge_fused(P, "al_encoder.lane_embed", "al_encoder", B::AL_EDGE6F);
   recipe_upd_ffn6(P, "aa_encoder", B::AA_UPD6, B::AA_FFN6);
   recipe_upd_ffn6(P, "al_encoder", B::AL_UPD6, B::AL_FFN6);
   // training path: wave-per-target attention over stored embedding rows (k_global_attn<.., NODE = false> and its backward)

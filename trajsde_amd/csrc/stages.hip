@@ -121,7 +121,7 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
     // a bounded list: enough waves for the most streams any E' <= E cuts into; the ones beyond the true count leave at once
     const int64_t waves = ((ec.dev ? std::min<int64_t>(E, fused_streams()) : pl.nstreams) + 31) / 32;
     const int grid = int((waves + threads / 64 - 1) / (threads / 64));
-    const int lds = (EdgeL6::SIZE + (threads / 64) * 2048) * 4;              // weight image + every wave's parked query rows (8 KB)
+    const int lds = (EdgeL6F::LDS_SIZE + (threads / 64) * 2048) * 4;         // weight image + every wave's parked query rows (8 KB)
     const bool d = drop.p > 0.f, sv = emb_out != nullptr;
 #define TS_EA2(D_, S_) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, D_, S_>), grid, 512, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
     if (d && sv) TS_EA2(true, true);
@@ -130,7 +130,7 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
     else TS_EA2(false, false);
 #undef TS_EA2
   }
-  TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, ec, pl.C, R, agg, stats, heads);
+  TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, ec, pl.C, R, agg, stats, heads, img, q, drop.p > 0.f ? 0 : 1);
   return TRAJSDE_OK;
 }
 bool attn_fused_enabled() { return attn_fused(); }
@@ -159,7 +159,7 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
             b->x, g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
   const NodeImgs im{blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, blob + EncBlob::AA_UPD6, blob + EncBlob::AA_FFN6};
   if (attn_fused()) {
-    if (int rc = fused_edge_attention("k_edge_kv[aa]", true, blob + EncBlob::AA_EDGE6, g->aa_geom, g->aa_dst, w.q, count_of(g, 1, g->E_aa), g->aa_segptr, R,
+    if (int rc = fused_edge_attention("k_edge_kv[aa]", true, blob + EncBlob::AA_EDGE6F, g->aa_geom, g->aa_dst, w.q, count_of(g, 1, g->E_aa), g->aa_segptr, R,
                                       w.rec, w.agg, heads, st, drop))
       return rc;
     return update_ffn(im, w.agg, w.cn, w.center, R, w.x1, w.xn2, aa_out, st, drop, state_bf16());      // aa_out in the state storage type
@@ -235,7 +235,7 @@ static int run_al_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
             blob + EncBlob::AL_Q, lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
   const NodeImgs im{blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, blob + EncBlob::AL_UPD6, blob + EncBlob::AL_FFN6};
   if (attn_fused()) {
-    if (int rc = fused_edge_attention("k_edge_kv[al]", false, blob + EncBlob::AL_EDGE6, g->la_geom, g->la_dst, w.al_q, count_of(g, 3, g->E_la), g->la_segptr,
+    if (int rc = fused_edge_attention("k_edge_kv[al]", false, blob + EncBlob::AL_EDGE6F, g->la_geom, g->la_dst, w.al_q, count_of(g, 3, g->E_la), g->la_segptr,
                                       int64_t(N), w.al_rec, w.al_agg, heads, st, drop))
       return rc;
     return update_ffn(im, w.al_agg, w.al_xn, lat, N, w.al_x1, w.al_xn2, local_embed, st, drop);

@@ -90,7 +90,7 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 #if TSDE_SPLIT_H3
 // fp16x3: x = h + l with h = fp16(x) (round toward zero, v_cvt_pkrtz_f16_f32) and l = fp16(x - h): 22 significant bits,
-// the residual x - h is exact in fp32 and is formed by v_fma_mix_f32 straight from the packed half.  a*b ~= a_h b_h +
+// the residual x - h is exact in fp32 and is formed (and rounded to fp16) by v_fma_mixlo/mixhi_f16 straight from the packed half.  a*b ~= a_h b_h +
 // a_h b_l + a_l b_h (three v_mfma_f32_16x16x32_f16; the dropped a_l b_l is 2^-22 relative).  2 VALU per value to split
 // against 5.5 for three bf16 pieces, and half the matrix instructions.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -106,7 +106,14 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
   hi = hb;
   lo = __builtin_bit_cast(unsigned, l);
 }
+// The 8 values of one k-step.  The residual x - h (exact in fp32) is rounded to fp16 by the instruction that forms it:
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 write the fp16 result into one half of the destination, so a pair costs cvt_pkrtz + 2
+// instead of cvt_pkrtz + 2 + cvt_pkrtz.  They are 16-bit partial writes: gfx940-class hardware wants a wait state between
+// such a write and a read of the register, which the compiler cannot insert around inline assembly -- so the four pairs are
+// issued as one block, low halves first (three independent instructions between the two writes of a register and between a
+// write and the block's end, except for the last one: one s_nop).
 __device__ __forceinline__ void split_kstep(const f4& qa, const f4& qb, u4& hi, u4& lo) {
+#ifdef TSDE_SPLIT_LO_RTZ
   unsigned h[4], l[4];
   split_pair(qa[0], qa[1], h[0], l[0]);
   split_pair(qa[2], qa[3], h[1], l[1]);
@@ -114,6 +121,26 @@ __device__ __forceinline__ void split_kstep(const f4& qa, const f4& qb, u4& hi, 
   split_pair(qb[2], qb[3], h[3], l[3]);
   hi = u4{h[0], h[1], h[2], h[3]};
   lo = u4{l[0], l[1], l[2], l[3]};
+#else
+  const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(qa[0], qa[1]));
+  const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(qa[2], qa[3]));
+  const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(qb[0], qb[1]));
+  const unsigned h3 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(qb[2], qb[3]));
+  unsigned l0, l1, l2, l3;
+  asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 0"
+      : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+      : "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(qa[0]), "v"(qa[1]), "v"(qa[2]), "v"(qa[3]), "v"(qb[0]), "v"(qb[1]), "v"(qb[2]), "v"(qb[3]));
+  hi = u4{h0, h1, h2, h3};
+  lo = u4{l0, l1, l2, l3};
+#endif
 }
 
 // acc[jo] += W * in with W stored as two fp16 pieces in fragment order [jo][s][piece][lane][8] (pack.hip MAT6);
@@ -381,6 +408,17 @@ __device__ __forceinline__ void layer_norm(f4 (&a)[JT], const float* gamma, cons
 #pragma unroll
     for (int c = 0; c < 4; ++c) a[jt][c] = a[jt][c] * rstd * ga[c] + be[c];
   }
+}
+
+// LayerNorm of a row that arrives FEATURE-CENTRED (its producing matrix and bias had the mean over the 64 outputs removed
+// when they were packed, pack.hip PK_MAT6_CENTRED): the mean is zero by construction, the variance is what is left to reduce
+__device__ __forceinline__ float centred_rstd(const f4 (&d)[4]) {
+  float v = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v = fmaf(d[jt][c], d[jt][c], v);
+  return rsqrt_nr(row_sum(v) * (1.0f / 64) + 1e-5f);
 }
 
 // dot of a 64-feature activation with a plain vector, reduced over the row
