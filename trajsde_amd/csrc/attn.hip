@@ -229,8 +229,9 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t nstreams = (E + C - 1) / C;
-  const int64_t s0 = (int64_t(blockIdx.x) * waves + wave) * 32 + L.n, s1 = s0 + 16;      // the two tiles' streams of this lane's rows
-  if ((int64_t(blockIdx.x) * waves + wave) * 32 >= nstreams) return;                       // whole wave beyond the list (uniform)
+  const int64_t wid = xcd_block() * waves + wave;          // xcd_grid launch: consecutive streams (same snapshot, same scene) share an L2
+  const int64_t s0 = wid * 32 + L.n, s1 = s0 + 16;         // the two tiles' streams of this lane's rows
+  if (wid * 32 >= nstreams) return;                        // whole wave beyond the list (uniform)
   if ((wave >> 2) & 1) {                                   // see k_edge_kv: start every other wave of a SIMD half a tile late
     for (int i = 0; i < 2 * TSDE_SKEW_SLEEPS; ++i) __builtin_amdgcn_s_sleep(32);
   }
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256, 4) void k_global_attn(const float* __restrict_
   __shared__ __attribute__((aligned(16))) float srel[4][8][64];   // a wave's chunk of rel rows (wave-private, no block barrier)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: addresses in SGPRs
   const int h = lane / LPH, j = lane % LPH;
-  const int64_t node = int64_t(blockIdx.x) * 4 + wv;
+  const int64_t node = xcd_block() * 4 + wv;                 // launched with xcd_grid(): a scene's targets share an L2
   const int64_t nc = node < N ? node : N - 1;
   const float* wke = img + GAttnL::WKE;
   const float* wve = img + GAttnL::WVE;

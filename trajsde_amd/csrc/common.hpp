@@ -60,6 +60,14 @@ struct Carver {
 };
 
 inline int cdiv(int64_t a, int64_t b) { return int((a + b - 1) / b); }
+// XCD-aware workgroup order.  The dispatcher deals workgroups round-robin to the 8 XCDs (workgroup b runs on XCD b % 8) and
+// each XCD has its own 4 MB L2.  Kernels whose neighbouring workgroups read the same rows (the targets of one scene gather
+// the same node rows) launch xcd_grid(blocks) workgroups and work on logical block xcd_block(): XCD x then owns the contiguous
+// range [x * per, (x + 1) * per), so a scene's rows live in one L2 instead of being streamed through all eight.
+inline int xcd_grid(int64_t blocks) { return 8 * cdiv(blocks, 8); }
+#ifdef __HIPCC__
+__device__ __forceinline__ int64_t xcd_block() { return int64_t(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+#endif
 
 // grid for a tile kernel whose workgroups each hold an LDS weight image: as many workgroups as fit on the
 // chip at once (LDS- and thread-limited), grid-stride beyond that, never more than the work needs

@@ -784,7 +784,7 @@ static int edge_attention_tape(const char* tag, const float* img_fused, const fl
   if (E > 0)
     TS_LAUNCH(k_edge_embed<true>, tile_grid((E + 15) / 16, 1024, EdgeL6::EMB_SIZE * 4), 1024, EdgeL6::EMB_SIZE * 4, st, img_edge6, geom,
               EdgeCount{E, nullptr, 0}, emb, 0);
-  TS_EDGE_ATTN(heads, drop, cdiv(R, 4), 256, 0, st, img_attn, segptr, emb, q, R, agg, stats);
+  TS_EDGE_ATTN(heads, drop, xcd_grid(cdiv(R, 4)), 256, 0, st, img_attn, segptr, emb, q, R, agg, stats);
   return TRAJSDE_OK;
 }
 

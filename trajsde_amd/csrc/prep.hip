@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_aa_ballots(int E, int H, int TT, const 
   extern __shared__ __attribute__((aligned(16))) float2 rows[];                            // [4 waves][64 rows][H | 1]: odd stride, 2-way LDS conflicts at most
   const int AA_ROW = H | 1;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t blk = int64_t(blockIdx.x) * (blockDim.x >> 6) + wv;                       // 64 consecutive CSR positions
+  const int64_t blk = xcd_block() * (blockDim.x >> 6) + wv;                               // 64 consecutive CSR positions (xcd_grid launch)
   if (blk * 64 >= E) return;                                                               // (uniform)
   const int per = 64 / H, j = lane / H, t = lane - j * H;
   const float2* pos2 = reinterpret_cast<const float2*>(pos);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_aa_fill(int N, int Nt, int H, int TT, c
   // one wave per extended node; for every t its survivors are handed out to the lanes by rank (lane r takes the r-th set bit of
   // the row's ballots), so the records of segment (t, node) are written 64 at a time, contiguously
   const int lane = threadIdx.x & 63;
-  const int node = __builtin_amdgcn_readfirstlane(int(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  const int node = __builtin_amdgcn_readfirstlane(int(xcd_block() * (blockDim.x >> 6) + (threadIdx.x >> 6)));   // xcd_grid launch
   (void)N;
   if (node >= Nt) return;
   const int o = orig[node];
@@ -595,7 +595,7 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
   if (E > 0) {
     k_valid_mask<<<cdiv(N, 256), 256, 0, st>>>(N, H, TT, b->padding_mask, w.vmask);
     const int lds_b = 4 * 64 * (H | 1) * int(sizeof(float2));              // (67 KB at H = 32: TS_LAUNCH raises the dynamic-LDS limit)
-    TS_LAUNCH(k_aa_ballots, cdiv(cdiv(E, 64), 4), 256, lds_b, st, E, H, TT, w.csr_src, w.csr_dst, w.vmask, b->positions, radius2_threshold(radius),
+    TS_LAUNCH(k_aa_ballots, xcd_grid(cdiv(cdiv(E, 64), 4)), 256, lds_b, st, E, H, TT, w.csr_src, w.csr_dst, w.vmask, b->positions, radius2_threshold(radius),
               w.bal);
   }
   { ProfScope ps("k_aa_count", st);
@@ -671,7 +671,7 @@ int trajsde_graph_compact(const trajsde_batch* b, const float* rot, void* ws, in
   const int N = b->N, A = b->A, E = b->E, H = b->H, TT = b->TT, Ea = b->E_al, Nt = N + A;
   const bool want_src = g_export_senders.load() != 0;                      // sender ids are for checking the index work only
   { ProfScope ps("k_aa_fill", st);
-  k_aa_fill<<<cdiv(Nt, 4), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, w.bal, w.aa_segptr, b->positions, b->x, rot, e.aa_dst,
+  k_aa_fill<<<xcd_grid(cdiv(Nt, 4)), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, w.bal, w.aa_segptr, b->positions, b->x, rot, e.aa_dst,
                                    want_src ? e.aa_src : nullptr, e.aa_geom); }
   if (E > 0)
     k_g_compact<<<cdiv(E, 256), 256, 0, st>>>(E, TT, H - 1, w.csr_src, w.csr_dst, b->positions, rot, b->rotate_angles, w.flags_g,

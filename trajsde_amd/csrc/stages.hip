@@ -120,7 +120,7 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
     const int threads = 512;
     // a bounded list: enough waves for the most streams any E' <= E cuts into; the ones beyond the true count leave at once
     const int64_t waves = ((ec.dev ? std::min<int64_t>(E, fused_streams()) : pl.nstreams) + 31) / 32;
-    const int grid = int((waves + threads / 64 - 1) / (threads / 64));
+    const int grid = xcd_grid((waves + threads / 64 - 1) / (threads / 64));
     const int lds = (EdgeL6F::LDS_SIZE + (threads / 64) * 2048) * 4;         // weight image + every wave's parked query rows (8 KB)
     const bool d = drop.p > 0.f, sv = emb_out != nullptr;
 #define TS_EA2(D_, S_) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, D_, S_>), grid, 512, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
@@ -403,7 +403,7 @@ int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph
     TS_REQUIRE(fused || g->exact, "aggregator_forward: a graph from trajsde_graph_prepare_async needs the fused global attention");
     if (fused) {
       // one wave per target: logits, softmax and aggregation in one pass over the rel rows (no per-edge GEMM)
-      TS_GLOBAL_ATTN(num_heads, state_bf16(), drop, cdiv(N, 4), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, static_cast<float*>(nullptr));
+      TS_GLOBAL_ATTN(num_heads, state_bf16(), drop, xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, static_cast<float*>(nullptr));
       if (int rc = update_ffn(im, w.agg, w.xn, x, N, w.x1, w.xn2, out, st, drop)) return rc;
       x = out;
       continue;
