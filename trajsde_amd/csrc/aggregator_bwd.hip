@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
   __shared__ __attribute__((aligned(16))) float srel[4][8][64];   // a wave's chunk of rel rows (wave-private, as in the forward)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row addresses in SGPRs
   const int h = lane / LPH, j = lane % LPH;
-  const int64_t node = int64_t(blockIdx.x) * 4 + wv;
+  const int64_t node = xcd_block() * 4 + wv;
   const int64_t nc = node < N ? node : N - 1;
   const float* wke = img + GAttnL::WKE;
   const float* wve = img + GAttnL::WVE;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_gattn_drel(DrelArgs a, const int32_t* _
                                                     int accumulate) {
   constexpr int EPC = 64 / HEADS, LPH = 64 / HEADS;
   const int lane = threadIdx.x & 63;
-  const int64_t node = int64_t(blockIdx.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t node = xcd_block() * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (node >= N) return;
   float U[NL][HEADS], Z[NL][HEADS];
   if (FROM_ROWS) {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_gattn_drel(DrelArgs a, const int32_t* _
 
 int run_gattn_drel(hipStream_t st, int heads, int nl, bool from_rows, const DrelArgs& da, const int32_t* segptr, int64_t N, float* DREL,
                    int accumulate) {
-#define TS_DREL(H_, N_, F_) TS_LAUNCH((k_gattn_drel<H_, N_, F_>), cdiv(N, 4), 256, 0, st, da, segptr, N, DREL, accumulate)
+#define TS_DREL(H_, N_, F_) TS_LAUNCH((k_gattn_drel<H_, N_, F_>), xcd_grid(cdiv(N, 4)), 256, 0, st, da, segptr, N, DREL, accumulate)
   if (from_rows) {
     if (heads == 4) TS_DREL(4, 1, true);
     else TS_DREL(8, 1, true);
@@ -276,10 +276,10 @@ int run_edge_attn_bwd(hipStream_t st, int heads, const float* img, const int32_t
   const float* nf = nullptr;
   float* nw = nullptr;
   if (heads == 4)
-    TS_LAUNCH_TAG("k_edge_attn_rows_bwd<4>", false, (k_gattn_bwd<4, false>), cdiv(R, 4), 256, 0, st, img, segptr, ns, emb, q, nf, nf, agg, dagg, stats,
+    TS_LAUNCH_TAG("k_edge_attn_rows_bwd<4>", false, (k_gattn_bwd<4, false>), xcd_grid(cdiv(R, 4)), 256, 0, st, img, segptr, ns, emb, q, nf, nf, agg, dagg, stats,
                   R, DQ, nw, nw, RL, SS, DAGGM, EA, ED, nw, ns, drop);
   else
-    TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_gattn_bwd<8, false>), cdiv(R, 4), 256, 0, st, img, segptr, ns, emb, q, nf, nf, agg, dagg, stats,
+    TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_gattn_bwd<8, false>), xcd_grid(cdiv(R, 4)), 256, 0, st, img, segptr, ns, emb, q, nf, nf, agg, dagg, stats,
                   R, DQ, nw, nw, RL, SS, DAGGM, EA, ED, nw, ns, drop);
   return TRAJSDE_OK;
 }
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_gattn_src_bwd(const int32_t* __restrict
                                                        const float* __restrict__ dagg, int64_t N, float* __restrict__ DKN,
                                                        float* __restrict__ DVN, const int32_t* __restrict__ asym) {
   const int lane = threadIdx.x & 63, h = lane / (64 / HEADS);
-  const int64_t node = int64_t(blockIdx.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t node = xcd_block() * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (node >= N || *asym != 0) return;                     // asymmetric list: k_gattn_bwd scattered the rows with atomics
   float dk = 0.f, dv = 0.f;
   const int beg = segptr[node], end = segptr[node + 1];
@@ -550,14 +550,14 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     TS_HIP(hipMemsetAsync(w.DKN, 0, size_t(N) * 64 * sizeof(float), st));
     TS_HIP(hipMemsetAsync(w.DVN, 0, size_t(N) * 64 * sizeof(float), st));
     if (num_heads == 4) {
-      TS_LAUNCH((k_gattn_bwd<4, true>), cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
+      TS_LAUNCH((k_gattn_bwd<4, true>), xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
                 w.agg[l], w.dagg, w.stats[l], N, w.DQ, w.DKN, w.DVN, w.RL, w.SS, w.DAGGM, w.EA[l], w.ED[l], w.UZ[l], w.asym, drop_of(l));
-      TS_LAUNCH(k_gattn_src_bwd<4>, cdiv(N, 4), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA[l], w.ED[l], w.q[l], w.dagg, N, w.DKN, w.DVN,
+      TS_LAUNCH(k_gattn_src_bwd<4>, xcd_grid(cdiv(N, 4)), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA[l], w.ED[l], w.q[l], w.dagg, N, w.DKN, w.DVN,
                 w.asym);
     } else {
-      TS_LAUNCH((k_gattn_bwd<8, true>), cdiv(N, 4), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
+      TS_LAUNCH((k_gattn_bwd<8, true>), xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
                 w.agg[l], w.dagg, w.stats[l], N, w.DQ, w.DKN, w.DVN, w.RL, w.SS, w.DAGGM, w.EA[l], w.ED[l], w.UZ[l], w.asym, drop_of(l));
-      TS_LAUNCH(k_gattn_src_bwd<8>, cdiv(N, 4), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA[l], w.ED[l], w.q[l], w.dagg, N, w.DKN, w.DVN,
+      TS_LAUNCH(k_gattn_src_bwd<8>, xcd_grid(cdiv(N, 4)), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA[l], w.ED[l], w.q[l], w.dagg, N, w.DKN, w.DVN,
                 w.asym);
     }
     if (int rc = run_headwise_outer(wc, w.q[l], w.RL, N, wke, num_heads)) return rc;
