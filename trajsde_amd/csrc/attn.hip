@@ -247,14 +247,30 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
   int base0 = 0, base1 = 0;                                // DROP: first edge of the rows' current targets (mask counter = rank)
   const f4 one4 = f4{1.f, 1.f, 1.f, 1.f};
   const int64_t b0 = s0 * C, b1 = s1 * C;
+  // an iteration's geometry and targets are loaded one iteration ahead: the first thing an iteration does is compare its targets
+  // with the current ones, and with two waves per SIMD nothing would cover that round trip
+  f4 ng0, ng1;
+  int nd0, nd1;
+  {
+    const int64_t c0 = b0 < E ? b0 : E - 1, c1 = b1 < E ? b1 : E - 1;
+    ng0 = *reinterpret_cast<const f4*>(geom + 4 * c0);
+    ng1 = *reinterpret_cast<const f4*>(geom + 4 * c1);
+    nd0 = dst[c0];
+    nd1 = dst[c1];
+  }
   for (int it = 0; it < C; ++it) {
     keep_lds_reads_here();
     const int64_t e0 = b0 + it, e1 = b1 + it;
     const bool ok0 = e0 < E, ok1 = e1 < E;                 // only the last stream is short; streams >= nstreams are empty
-    const int64_t c0 = ok0 ? e0 : E - 1, c1 = ok1 ? e1 : E - 1;
-    const f4 g0 = *reinterpret_cast<const f4*>(geom + 4 * c0);
-    const f4 g1 = *reinterpret_cast<const f4*>(geom + 4 * c1);
-    const int d0 = dst[c0], d1 = dst[c1];
+    const f4 g0 = ng0, g1 = ng1;
+    const int d0 = nd0, d1 = nd1;
+    {
+      const int64_t c0 = e0 + 1 < E ? e0 + 1 : E - 1, c1 = e1 + 1 < E ? e1 + 1 : E - 1;     // (one past a stream's end: loaded, never used)
+      ng0 = *reinterpret_cast<const f4*>(geom + 4 * c0);
+      ng1 = *reinterpret_cast<const f4*>(geom + 4 * c1);
+      nd0 = dst[c0];
+      nd1 = dst[c1];
+    }
     if (ok0 && d0 != cur0) {                               // the row's target changes: its finished segment part leaves
       if (cur0 >= 0) seg_flush(S0, rec, int64_t(cur0) + s0, L.g);
       seg_reset(S0);

@@ -179,22 +179,30 @@ __device__ __forceinline__ void linear_acc_x6_2(f4 (&acc0)[JT_OUT], f4 (&acc1)[J
     split_kstep(in0[2 * s], in0[2 * s + 1], p1[s], p2[s]);
     split_kstep(in1[2 * s], in1[2 * s + 1], q1[s], q2[s]);
   }
+  // the weight fragments of step (s, jo) + 1 are read from LDS while step (s, jo) feeds the matrix cores (two fragment pairs
+  // in registers): the ds_read latency stays off the chain of matrix instructions
+  constexpr int STEPS = KS * JT_OUT;
+  u4 f1[2], f2[2];
+  f1[0] = *reinterpret_cast<const u4*>(w + lane * 4);
+  f2[0] = *reinterpret_cast<const u4*>(w + lane * 4 + 256);
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-#pragma unroll
-    for (int jo = 0; jo < JT_OUT; ++jo) {
-      const float* p = w + (jo * KS + s) * 512 + lane * 4;
-      const h8 a1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p));
-      const h8 a2 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p + 256));
-      const h8 x1 = __builtin_bit_cast(h8, p1[s]), x2 = __builtin_bit_cast(h8, p2[s]);
-      const h8 y1 = __builtin_bit_cast(h8, q1[s]), y2 = __builtin_bit_cast(h8, q2[s]);
-      acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1, acc0[jo], 0, 0, 0);
-      acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, y1, acc1[jo], 0, 0, 0);
-      acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x2, acc0[jo], 0, 0, 0);
-      acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, y2, acc1[jo], 0, 0, 0);
-      acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, x1, acc0[jo], 0, 0, 0);
-      acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, y1, acc1[jo], 0, 0, 0);
+  for (int i = 0; i < STEPS; ++i) {
+    const int s = i / JT_OUT, jo = i % JT_OUT;
+    if (i + 1 < STEPS) {
+      const int s2 = (i + 1) / JT_OUT, jo2 = (i + 1) % JT_OUT;
+      const float* p = w + (jo2 * KS + s2) * 512 + lane * 4;
+      f1[(i + 1) & 1] = *reinterpret_cast<const u4*>(p);
+      f2[(i + 1) & 1] = *reinterpret_cast<const u4*>(p + 256);
     }
+    const h8 a1 = __builtin_bit_cast(h8, f1[i & 1]), a2 = __builtin_bit_cast(h8, f2[i & 1]);
+    const h8 x1 = __builtin_bit_cast(h8, p1[s]), x2 = __builtin_bit_cast(h8, p2[s]);
+    const h8 y1 = __builtin_bit_cast(h8, q1[s]), y2 = __builtin_bit_cast(h8, q2[s]);
+    acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1, acc0[jo], 0, 0, 0);
+    acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, y1, acc1[jo], 0, 0, 0);
+    acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x2, acc0[jo], 0, 0, 0);
+    acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, y2, acc1[jo], 0, 0, 0);
+    acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, x1, acc0[jo], 0, 0, 0);
+    acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, y1, acc1[jo], 0, 0, 0);
   }
 }
 #else
