@@ -193,6 +193,7 @@ __device__ __forceinline__ void linear_acc_x6_2(f4 (&acc0)[JT_OUT], f4 (&acc1)[J
       const float* p = w + (jo2 * KS + s2) * 512 + lane * 4;
       f1[(i + 1) & 1] = *reinterpret_cast<const u4*>(p);
       f2[(i + 1) & 1] = *reinterpret_cast<const u4*>(p + 256);
+      __builtin_amdgcn_sched_barrier(0);                     // (the scheduler would sink the reads to two instructions before their use)
     }
     const h8 a1 = __builtin_bit_cast(h8, f1[i & 1]), a2 = __builtin_bit_cast(h8, f2[i & 1]);
     const h8 x1 = __builtin_bit_cast(h8, p1[s]), x2 = __builtin_bit_cast(h8, p2[s]);
