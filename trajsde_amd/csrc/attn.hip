@@ -215,11 +215,14 @@ __device__ __forceinline__ void seg_flush(const SegState& S, float* __restrict__
 }
 
 // SAVE (training path): the embedding rows are also written to emb_out [E,64] -- the tape of the attention backward.
-template <int THREADS, bool DROP, bool SAVE>
-__global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict__ img_g, const float* __restrict__ geom,
-                                                        const int32_t* __restrict__ dst, const float* __restrict__ q, EdgeCount ec, int C_host,
-                                                        float* __restrict__ rec, int heads, const int32_t* __restrict__ segptr, DropArg drop,
-                                                        float* __restrict__ emb_out) {
+// NT: row tiles per wave (streams per wave = 16 NT); a workgroup walks 256 streams.  Shipped: 8 waves x 2 tiles, two waves per
+// SIMD.  (Measured alternatives, 32 x 256 agents: 4 waves x 4 tiles at one wave per SIMD -- every weight fragment feeding 12
+// matrix instructions, accumulators in AGPRs -- 0.575 ms per launch against 0.47 ms; 4 waves x 2 tiles 0.60 ms.)
+template <int NT, bool DROP, bool SAVE>
+__global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restrict__ img_g, const float* __restrict__ geom,
+                                                          const int32_t* __restrict__ dst, const float* __restrict__ q, EdgeCount ec, int C_host,
+                                                          float* __restrict__ rec, int heads, const int32_t* __restrict__ segptr, DropArg drop,
+                                                          float* __restrict__ emb_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using EL = EdgeL6F;
   const int64_t E = edge_count(ec);
@@ -230,117 +233,112 @@ __global__ __launch_bounds__(THREADS) void k_edge_attn2(const float* __restrict_
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t nstreams = (E + C - 1) / C;
   const int64_t wid = xcd_block() * waves + wave;          // xcd_grid launch: consecutive streams (same snapshot, same scene) share an L2
-  const int64_t s0 = wid * 32 + L.n, s1 = s0 + 16;         // the two tiles' streams of this lane's rows
-  if (wid * 32 >= nstreams) return;                        // whole wave beyond the list (uniform)
-  if ((wave >> 2) & 1) {                                   // see k_edge_kv: start every other wave of a SIMD half a tile late
+  if (wid * (16 * NT) >= nstreams) return;                 // whole wave beyond the list (uniform)
+  if (NT == 2 && ((wave >> 2) & 1)) {                      // see k_edge_kv: start every other wave of a SIMD half a tile late
     for (int i = 0; i < 2 * TSDE_SKEW_SLEEPS; ++i) __builtin_amdgcn_s_sleep(32);
   }
-  SegState S0, S1;
-  seg_reset(S0);
-  seg_reset(S1);
-  // The query row of a tile row changes only when the row's target does (every ~deg iterations), but 2 x 16 registers to keep
-  // it do not fit beside the softmax state at two waves per SIMD, and re-gathering 256 B per row and iteration from L2 was
-  // 1.4 GB of fabric reads per launch (FETCH_SIZE).  So each lane parks ITS 16 query values in LDS -- a private slot,
-  // [tile][jt][lane][4], conflict-free b128 -- when its row's target changes, and reads them back every iteration.
-  float* qs = lds + EL::LDS_SIZE + wave * (2 * 4 * 64 * 4);
-  int cur0 = -1, cur1 = -1;
-  int base0 = 0, base1 = 0;                                // DROP: first edge of the rows' current targets (mask counter = rank)
+  SegState S[NT];
+  int64_t sid[NT], base_e[NT];                             // the tiles' streams of this lane's rows, and their first edges
+  int cur[NT], rank0[NT];                                  // current target; DROP: first edge of that target (mask counter = rank)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    seg_reset(S[t]);
+    sid[t] = wid * (16 * NT) + 16 * t + L.n;
+    base_e[t] = sid[t] * C;
+    cur[t] = -1;
+    rank0[t] = 0;
+  }
+  // The query row of a tile row changes only when the row's target does (every ~deg iterations), but NT x 16 registers to keep
+  // it do not fit beside the softmax state, and re-gathering 256 B per row and iteration from L2 was 1.4 GB of fabric reads per
+  // launch (FETCH_SIZE).  So each lane parks ITS 16 query values in LDS -- a private slot, [tile][jt][lane][4], conflict-free
+  // b128 -- when its row's target changes, and reads them back every iteration.
+  float* qs = lds + EL::LDS_SIZE + wave * (NT * 4 * 64 * 4);
   const f4 one4 = f4{1.f, 1.f, 1.f, 1.f};
-  const int64_t b0 = s0 * C, b1 = s1 * C;
   // an iteration's geometry and targets are loaded one iteration ahead: the first thing an iteration does is compare its targets
-  // with the current ones, and with two waves per SIMD nothing would cover that round trip
-  f4 ng0, ng1;
-  int nd0, nd1;
-  {
-    const int64_t c0 = b0 < E ? b0 : E - 1, c1 = b1 < E ? b1 : E - 1;
-    ng0 = *reinterpret_cast<const f4*>(geom + 4 * c0);
-    ng1 = *reinterpret_cast<const f4*>(geom + 4 * c1);
-    nd0 = dst[c0];
-    nd1 = dst[c1];
+  // with the current ones, and nothing would cover that round trip
+  f4 ng[NT];
+  int nd[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int64_t c = base_e[t] < E ? base_e[t] : E - 1;
+    ng[t] = *reinterpret_cast<const f4*>(geom + 4 * c);
+    nd[t] = dst[c];
   }
   for (int it = 0; it < C; ++it) {
     keep_lds_reads_here();
-    const int64_t e0 = b0 + it, e1 = b1 + it;
-    const bool ok0 = e0 < E, ok1 = e1 < E;                 // only the last stream is short; streams >= nstreams are empty
-    const f4 g0 = ng0, g1 = ng1;
-    const int d0 = nd0, d1 = nd1;
-    {
-      const int64_t c0 = e0 + 1 < E ? e0 + 1 : E - 1, c1 = e1 + 1 < E ? e1 + 1 : E - 1;     // (one past a stream's end: loaded, never used)
-      ng0 = *reinterpret_cast<const f4*>(geom + 4 * c0);
-      ng1 = *reinterpret_cast<const f4*>(geom + 4 * c1);
-      nd0 = dst[c0];
-      nd1 = dst[c1];
-    }
-    if (ok0 && d0 != cur0) {                               // the row's target changes: its finished segment part leaves
-      if (cur0 >= 0) seg_flush(S0, rec, int64_t(cur0) + s0, L.g);
-      seg_reset(S0);
-      cur0 = d0;
-      if (DROP) base0 = segptr[d0];
-      f4 qn[4];
-      load_row(qn, q, d0, L.g);
+    f4 ge[NT];
+    int d[NT];
+    bool ok[NT];
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(qs + (jt * 64 + L.lane) * 4) = qn[jt];
+    for (int t = 0; t < NT; ++t) {
+      const int64_t e = base_e[t] + it;
+      ok[t] = e < E;                                       // only the last stream is short; streams >= nstreams are empty
+      ge[t] = ng[t];
+      d[t] = nd[t];
+      const int64_t c = e + 1 < E ? e + 1 : E - 1;         // (one past a stream's end: loaded, never used)
+      ng[t] = *reinterpret_cast<const f4*>(geom + 4 * c);
+      nd[t] = dst[c];
     }
-    if (ok1 && d1 != cur1) {
-      if (cur1 >= 0) seg_flush(S1, rec, int64_t(cur1) + s1, L.g);
-      seg_reset(S1);
-      cur1 = d1;
-      if (DROP) base1 = segptr[d1];
-      f4 qn[4];
-      load_row(qn, q, d1, L.g);
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(qs + ((4 + jt) * 64 + L.lane) * 4) = qn[jt];
-    }
-    f4 emb0[4], emb1[4], kv0[8], kv1[8], qv[4];
-    edge_embed2_fused(emb0, emb1, g0, g1, lds, L);         // (y - mean) * rstd of the last LayerNorm; gamma / beta live downstream
-    if (SAVE) {                                            // the tape holds the embedding rows proper
-      f4 t0[4], t1[4];
+    for (int t = 0; t < NT; ++t) {
+      if (ok[t] && d[t] != cur[t]) {                       // the row's target changes: its finished segment part leaves
+        if (cur[t] >= 0) seg_flush(S[t], rec, int64_t(cur[t]) + sid[t], L.g);
+        seg_reset(S[t]);
+        cur[t] = d[t];
+        if (DROP) rank0[t] = segptr[d[t]];
+        f4 qn[4];
+        load_row(qn, q, d[t], L.g);
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const f4 ga = *reinterpret_cast<const f4*>(lds + EL::AG3 + 16 * jt + 4 * L.g);
-        const f4 be = *reinterpret_cast<const f4*>(lds + EL::AE3 + 16 * jt + 4 * L.g);
-        t0[jt] = emb0[jt] * ga + be;
-        t1[jt] = emb1[jt] * ga + be;
+        for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(qs + ((4 * t + jt) * 64 + L.lane) * 4) = qn[jt];
       }
-      if (ok0) store_row(t0, emb_out, e0, L.g);
-      if (ok1) store_row(t1, emb_out, e1, L.g);
+    }
+    f4 emb[NT][4], kv[NT][8];
+    edge_embed_fused_n<NT>(emb, ge, lds, L);                // (y - mean) * rstd of the last LayerNorm; gamma / beta live downstream
+    if (SAVE) {                                            // the tape holds the embedding rows proper
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f4 tr[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          const f4 ga = *reinterpret_cast<const f4*>(lds + EL::AG3 + 16 * jt + 4 * L.g);
+          const f4 be = *reinterpret_cast<const f4*>(lds + EL::AE3 + 16 * jt + 4 * L.g);
+          tr[jt] = emb[t][jt] * ga + be;
+        }
+        if (ok[t]) store_row(tr, emb_out, base_e[t] + it, L.g);
+      }
     }
     // k / v without their constant parts (EdgeL6F): q . CK shifts all logits of a (target, head) alike, and sum_e alpha_e CV = CV
     // is added by k_seg_merge.  With attention dropout the kept weights do not sum to one, so v carries CV here.
 #pragma unroll
-    for (int jo = 0; jo < 8; ++jo) {
-      kv0[jo] = f4{0.f, 0.f, 0.f, 0.f};
-      kv1[jo] = f4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (DROP) {
-      load_vec<4>(reinterpret_cast<f4(&)[4]>(kv0[4]), img_g + EL::CV, L.g);
-      load_vec<4>(reinterpret_cast<f4(&)[4]>(kv1[4]), img_g + EL::CV, L.g);
-    }
-    linear_acc_x6_2<8, 4>(kv0, kv1, emb0, emb1, lds + EL::WKV, L.lane);
-    {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) qv[jt] = *reinterpret_cast<const f4*>(qs + (jt * 64 + L.lane) * 4);
-      const f4 k[4] = {kv0[0], kv0[1], kv0[2], kv0[3]};
-      const f4 vv[4] = {kv0[4], kv0[5], kv0[6], kv0[7]};
-      const f4 lg = head_logits(qv, k, heads);
-      if (ok0) seg_update(S0, lg, vv, DROP ? drop_attn_row(drop, uint32_t(d0), uint32_t(int(e0) - base0), L.g, heads) : one4);
-    }
-    {
+      for (int jo = 0; jo < 8; ++jo) kv[t][jo] = f4{0.f, 0.f, 0.f, 0.f};
+      if (DROP) {
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) qv[jt] = *reinterpret_cast<const f4*>(qs + ((4 + jt) * 64 + L.lane) * 4);
-      const f4 k[4] = {kv1[0], kv1[1], kv1[2], kv1[3]};
-      const f4 vv[4] = {kv1[4], kv1[5], kv1[6], kv1[7]};
+        for (int jt = 0; jt < 4; ++jt) kv[t][4 + jt] = *reinterpret_cast<const f4*>(img_g + EL::CV + 16 * jt + 4 * L.g);
+      }
+    }
+    linear_acc_x6_n<NT, 8, 4>(kv, emb, lds + EL::WKV, L.lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f4 qv[4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) qv[jt] = *reinterpret_cast<const f4*>(qs + ((4 * t + jt) * 64 + L.lane) * 4);
+      const f4 k[4] = {kv[t][0], kv[t][1], kv[t][2], kv[t][3]};
+      const f4 vv[4] = {kv[t][4], kv[t][5], kv[t][6], kv[t][7]};
       const f4 lg = head_logits(qv, k, heads);
-      if (ok1) seg_update(S1, lg, vv, DROP ? drop_attn_row(drop, uint32_t(d1), uint32_t(int(e1) - base1), L.g, heads) : one4);
+      if (ok[t])
+        seg_update(S[t], lg, vv, DROP ? drop_attn_row(drop, uint32_t(d[t]), uint32_t(int(base_e[t] + it) - rank0[t]), L.g, heads) : one4);
     }
   }
-  if (cur0 >= 0) seg_flush(S0, rec, int64_t(cur0) + s0, L.g);
-  if (cur1 >= 0) seg_flush(S1, rec, int64_t(cur1) + s1, L.g);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (cur[t] >= 0) seg_flush(S[t], rec, int64_t(cur[t]) + sid[t], L.g);
 }
-template __global__ void k_edge_attn2<512, false, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<512, true, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<512, false, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<512, true, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 
 // records of one target -> agg row.  One wave per target, lane = feature f (jt = f>>4, g = (f>>2)&3); a target's records sit
 // at slots target + (first stream .. last stream) of its segment and are combined in that order.

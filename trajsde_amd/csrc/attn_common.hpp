@@ -65,39 +65,42 @@ __device__ __forceinline__ void edge_embed2_x6(f4 (&emb0)[4], f4 (&emb1)[4], con
   layer_norm<4>(emb1, lds + E::AG3, lds + E::AE3, L.g);
 }
 
-// The embedding for the fused edge-attention kernel, on its own image (layouts.hpp EdgeL6F): the two matrix layers hand out
-// feature-centred rows, so each LayerNorm is one variance reduction, and the last LayerNorm stops at (y - mean) * rstd -- its
-// gamma sits in the lin_k | lin_v image, its beta in the per-target constants.  n0 / n1: those normalised rows.
-__device__ __forceinline__ void edge_embed2_fused(f4 (&n0)[4], f4 (&n1)[4], const f4 ge0, const f4 ge1, const float* lds, const Lane& L) {
+// The embedding for the fused edge-attention kernel, on its own image (layouts.hpp EdgeL6F), for the NT row tiles of one wave: the
+// two matrix layers hand out feature-centred rows, so each LayerNorm is one variance reduction, and the last LayerNorm stops at
+// (y - mean) * rstd -- its gamma sits in the lin_k | lin_v image, its beta in the per-target constants.  nrm: those normalised rows.
+template <int NT>
+__device__ __forceinline__ void edge_embed_fused_n(f4 (&nrm)[NT][4], const f4 (&ge)[NT], const float* lds, const Lane& L) {
   using E = EdgeL6F;
-  f4 a0[4], a1[4], b0[4], b1[4], s0[4], s1[4];
-  in2_ln_relu(a0, ge0[0], ge0[1], lds + E::A_C, lds + E::A_E, L.g);
-  in2_ln_relu(a1, ge1[0], ge1[1], lds + E::A_C, lds + E::A_E, L.g);
-  load_vec<4>(s0, lds + E::B3, L.g);
-  load_vec<4>(s1, lds + E::B3, L.g);
-  linear_acc_x6_2<4, 4>(s0, s1, a0, a1, lds + E::WA3, L.lane);
-  in2_ln_relu(b0, ge0[2], ge0[3], lds + E::B_C, lds + E::B_E, L.g);
-  in2_ln_relu(b1, ge1[2], ge1[3], lds + E::B_C, lds + E::B_E, L.g);
-  linear_acc_x6_2<4, 4>(s0, s1, b0, b1, lds + E::WB3, L.lane);
-  const float r0 = centred_rstd(s0), r1 = centred_rstd(s1);
+  f4 a[NT][4], s[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    in2_ln_relu(a[t], ge[t][0], ge[t][1], lds + E::A_C, lds + E::A_E, L.g);
+    load_vec<4>(s[t], lds + E::B3, L.g);
+  }
+  linear_acc_x6_n<NT, 4, 4>(s, a, lds + E::WA3, L.lane);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) in2_ln_relu(a[t], ge[t][2], ge[t][3], lds + E::B_C, lds + E::B_E, L.g);
+  linear_acc_x6_n<NT, 4, 4>(s, a, lds + E::WB3, L.lane);
+  float r[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) r[t] = centred_rstd(s[t]);
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
     const f4 ga = *reinterpret_cast<const f4*>(lds + E::AG0 + 16 * jt + 4 * L.g);
     const f4 be = *reinterpret_cast<const f4*>(lds + E::AE0 + 16 * jt + 4 * L.g);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      s0[jt][c] = fmaxf(fmaf(s0[jt][c] * r0, ga[c], be[c]), 0.f);
-      s1[jt][c] = fmaxf(fmaf(s1[jt][c] * r1, ga[c], be[c]), 0.f);
-    }
-  }
-  load_vec<4>(n0, lds + E::B2, L.g);
-  load_vec<4>(n1, lds + E::B2, L.g);
-  linear_acc_x6_2<4, 4>(n0, n1, s0, s1, lds + E::W2, L.lane);
-  const float t0 = centred_rstd(n0), t1 = centred_rstd(n1);
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    n0[jt] *= t0;
-    n1[jt] *= t1;
+      for (int c = 0; c < 4; ++c) s[t][jt][c] = fmaxf(fmaf(s[t][jt][c] * r[t], ga[c], be[c]), 0.f);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) load_vec<4>(nrm[t], lds + E::B2, L.g);
+  linear_acc_x6_n<NT, 4, 4>(nrm, s, lds + E::W2, L.lane);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float q = centred_rstd(nrm[t]);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) nrm[t][jt] *= q;
   }
 }
 

@@ -17,9 +17,9 @@ static int pair_threads() { static int t = []() { const char* e = getenv("TRAJSD
 // fused edge attention (k_edge_attn2 + k_seg_merge: no per-edge v / logits in HBM): default, inference and training forward
 // alike; TRAJSDE_ATTN_FUSED=0 runs the older two-kernel form (k_edge_kv2 -> HBM -> k_seg_softmax_agg), kept as a cross-check
 static bool attn_fused() { static bool v = []() { const char* e = getenv("TRAJSDE_ATTN_FUSED"); return !(e && atoi(e) == 0); }(); return v && edge_x6() && edge_pair(); }
-static int fused_threads() { static const int v = env_threads("TRAJSDE_FUSED_THREADS", 512); return v; }   // 2 waves per SIMD: ~200 VGPRs, weight image + 8 x 8 KB of parked query rows = 150 KB of LDS
+static int fused_threads() { return 512; }   // 2 waves per SIMD: ~200 VGPRs, weight image + 8 x 8 KB of parked query rows = 150 KB of LDS
 static bool global_fused_env() { static const bool v = []() { const char* e = getenv("TRAJSDE_GLOBAL_UNFUSED"); return !(e && atoi(e) != 0); }(); return v; }
-static int fused_streams() { return 256 * 32 * (fused_threads() / 64); }
+static int fused_streams() { return 256 * 256; }             // a workgroup walks 256 streams (8 waves x 2 tiles or 4 waves x 4 tiles), one workgroup per CU
 static AttnPlan fused_plan(int64_t E) { return attn_plan(E, fused_streams()); }
 // record slots of a list whose length is only bounded by E: any E' <= E cuts into at most min(E, streams) streams
 static int64_t fused_rec_slots(int64_t E, bool exact, int64_t targets) {
@@ -119,15 +119,15 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
   if (E > 0) {
     const int threads = fused_threads();
     // a bounded list: enough waves for the most streams any E' <= E cuts into; the ones beyond the true count leave at once
-    const int64_t waves = ((ec.dev ? std::min<int64_t>(E, fused_streams()) : pl.nstreams) + 31) / 32;
-    const int grid = xcd_grid((waves + threads / 64 - 1) / (threads / 64));
-    const int lds = (EdgeL6F::LDS_SIZE + (threads / 64) * 2048) * 4;         // weight image + every wave's parked query rows (8 KB)
+    const int64_t streams = ec.dev ? std::min<int64_t>(E, fused_streams()) : pl.nstreams;
+    const int grid = xcd_grid((streams + 255) / 256);
+    const int lds = (EdgeL6F::LDS_SIZE + 256 * 64) * 4;                      // weight image + the parked query rows of 256 streams (64 KB)
     const bool d = drop.p > 0.f, sv = emb_out != nullptr;
-#define TS_EA2(D_, S_) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<512, D_, S_>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
-    if (d && sv) TS_EA2(true, true);
-    else if (d) TS_EA2(true, false);
-    else if (sv) TS_EA2(false, true);
-    else TS_EA2(false, false);
+#define TS_EA2(N_, D_, S_) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<N_, D_, S_>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
+    if (d && sv) TS_EA2(2, true, true);
+    else if (d) TS_EA2(2, true, false);
+    else if (sv) TS_EA2(2, false, true);
+    else TS_EA2(2, false, false);
 #undef TS_EA2
   }
   TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, ec, pl.C, R, agg, stats, heads, img, q, drop.p > 0.f ? 0 : 1);

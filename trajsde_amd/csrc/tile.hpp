@@ -206,6 +206,40 @@ __device__ __forceinline__ void linear_acc_x6_2(f4 (&acc0)[JT_OUT], f4 (&acc1)[J
     acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, y1, acc1[jo], 0, 0, 0);
   }
 }
+// the same contraction for NT row tiles of one wave: every weight fragment read from LDS feeds 3 NT matrix instructions.
+// Per tile the products and their order are those of linear_acc_x6 (same bits).
+template <int NT, int JT_OUT, int JT_IN>
+__device__ __forceinline__ void linear_acc_x6_n(f4 (&acc)[NT][JT_OUT], const f4 (&in)[NT][JT_IN], const float* w, int lane) {
+  static_assert(JT_IN % 2 == 0, "k-steps cover 32 features");
+  constexpr int KS = JT_IN / 2;
+  u4 xh[NT][KS], xl[NT][KS];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) split_kstep(in[t][2 * s], in[t][2 * s + 1], xh[t][s], xl[t][s]);
+  constexpr int STEPS = KS * JT_OUT;
+  u4 f1[2], f2[2];
+  f1[0] = *reinterpret_cast<const u4*>(w + lane * 4);
+  f2[0] = *reinterpret_cast<const u4*>(w + lane * 4 + 256);
+#pragma unroll
+  for (int i = 0; i < STEPS; ++i) {
+    const int s = i / JT_OUT, jo = i % JT_OUT;
+    if (i + 1 < STEPS) {
+      const int s2 = (i + 1) / JT_OUT, jo2 = (i + 1) % JT_OUT;
+      const float* p = w + (jo2 * KS + s2) * 512 + lane * 4;
+      f1[(i + 1) & 1] = *reinterpret_cast<const u4*>(p);
+      f2[(i + 1) & 1] = *reinterpret_cast<const u4*>(p + 256);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const h8 a1 = __builtin_bit_cast(h8, f1[i & 1]), a2 = __builtin_bit_cast(h8, f2[i & 1]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(h8, xh[t][s]), acc[t][jo], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(h8, xl[t][s]), acc[t][jo], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(h8, xh[t][s]), acc[t][jo], 0, 0, 0);
+  }
+}
 #else
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
   const unsigned M = 0xFFFF0000u;
