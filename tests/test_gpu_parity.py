@@ -423,6 +423,8 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
                                                "TRAJSDE_RECUR_LEGACY": "1", "TRAJSDE_GLOBAL_UNFUSED": "1"}),
                       ("one_tile", {"TRAJSDE_EDGE_PAIR": "0"}),
                       ("two_kernel", {"TRAJSDE_ATTN_FUSED": "0"}),
+                      ("tile32", {"TRAJSDE_EDGE_TILE": "32"}),
+                      ("tile32_pingpong", {"TRAJSDE_EDGE_TILE": "32", "TRAJSDE_EDGE_PINGPONG": "1"}),
                       ("fallbacks", {"TRAJSDE_RECUR_LEGACY": "1", "TRAJSDE_GLOBAL_UNFUSED": "1", "TRAJSDE_NODE_FP32": "0"})):
         path = str(tmp_path / (mode + ".pt"))
         subprocess.run([sys.executable, "-c", script, path], check=True, env={**os.environ, **env}, timeout=600)
@@ -434,6 +436,10 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
         # same products, a different order of the softmax accumulation
         assert H.maxdiff(outs["split"][key], outs["two_kernel"][key]) <= 2e-5, key
         assert torch.equal(outs["two_kernel"][key], outs["one_tile"][key]), key        # two tiles per wave: the same bits
+        # the fused edge attention on 32x32x16 matrix tiles (edge32.hip): other fragment order, same algebra; with and without the
+        # phase barriers between the two waves of a SIMD: the same bits
+        assert H.maxdiff(outs["split"][key], outs["tile32"][key]) <= 2e-5, key
+        assert torch.equal(outs["tile32"][key], outs["tile32_pingpong"][key]), key
 
 
 @pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 30.0, 1e3, 1e4])

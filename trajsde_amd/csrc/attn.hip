@@ -348,7 +348,7 @@ template __global__ void k_edge_attn2<2, true, true>(const float*, const float*,
 // backward compares with logits that contain it
 __global__ __launch_bounds__(256) void k_seg_merge(const int32_t* __restrict__ segptr, const float* __restrict__ rec, EdgeCount ec, int C_host,
                                                    int64_t R, float* __restrict__ agg, float* __restrict__ stats, int heads,
-                                                   const float* __restrict__ img, const float* __restrict__ q, int add_cv) {
+                                                   const float* __restrict__ img, const float* __restrict__ q, int add_cv, int rec_layout) {
   const int C = stream_len(ec, edge_count(ec), C_host);
   const int lane = threadIdx.x & 63;
   const int64_t node = int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -357,7 +357,8 @@ __global__ __launch_bounds__(256) void k_seg_merge(const int32_t* __restrict__ s
   float out = 0.f, m_out = 0.f, inv_out = 0.f;
   if (end > beg) {
     const int c0 = beg / C, c1 = (end - 1) / C;
-    const int ms = 4 * ((lane >> 2) & 3) + (lane >> 4);    // index of this feature's (m, s) inside a record
+    // index of this feature's (m, s) inside a record: by lane group and tile quad (k_edge_attn2), or by 8-feature slot (k_edge_attn3)
+    const int ms = rec_layout ? (lane >> 3) : 4 * ((lane >> 2) & 3) + (lane >> 4);
     const float* r = rec + (node + c0) * SEG_REC;
     float m = r[64 + ms], s = r[80 + ms], acc = r[lane];
     for (int c = c0 + 1; c <= c1; ++c) {

@@ -84,7 +84,11 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
     }                                                                                                               \
   } while (0)
 __global__ void k_seg_merge(const int32_t* segptr, const float* rec, EdgeCount ec, int C, int64_t R, float* agg, float* stats, int heads,
-                            const float* img, const float* q, int add_cv);
+                            const float* img, const float* q, int add_cv, int rec_layout);
+// the fused edge attention on 32x32x16 matrix tiles (edge32.hip): same arguments, records in layout 1
+template <bool DROP, bool SAVE, bool PP>
+__global__ void k_edge_attn3(const float* img, const float* geom, const int32_t* dst, const float* q, EdgeCount ec, int C, float* rec, int heads,
+                             const int32_t* segptr, DropArg drop, float* emb_out);
 template <bool X6>
 __global__ void k_edge_embed(const float* img, const float* geom, EdgeCount ec, float* emb_out, int st_bf16);
 template <bool X6>

@@ -235,9 +235,9 @@ struct EncBlob {
     COOP6 = AL_FFN6 + FfnL6::SIZE,
     AA_ATTN = COOP6 + EncCoopL6::SIZE,
     AL_ATTN = AA_ATTN + GAttnL::SIZE,
-    AA_EDGE6F = AL_ATTN + GAttnL::SIZE,
-    AL_EDGE6F = AA_EDGE6F + EdgeL6F::SIZE,
-    SIZE = AL_EDGE6F + EdgeL6F::SIZE
+    AA_EDGE6F = AL_ATTN + GAttnL::SIZE,                    // each followed by its twin in the 32x32x16 fragment order (edge32.hip)
+    AL_EDGE6F = AA_EDGE6F + 2 * EdgeL6F::SIZE,
+    SIZE = AL_EDGE6F + 2 * EdgeL6F::SIZE
   };
 };
 

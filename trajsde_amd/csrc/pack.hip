@@ -42,7 +42,7 @@ struct PackJob {
   const float *src, *src2, *src3;
   float* dst;
 };
-enum PackKind { PK_VEC = 0, PK_COL, PK_MAT, PK_MAT_PAD, PK_MATT, PK_MAT6, PK_MAT6_STACK2, PK_SPLIT, PK_LN2, PK_MAT6_CENTRED, PK_VEC_CENTRED, PK_AFFINE };
+enum PackKind { PK_VEC = 0, PK_COL, PK_MAT, PK_MAT_PAD, PK_MATT, PK_MAT6, PK_MAT6_STACK2, PK_SPLIT, PK_LN2, PK_MAT6_CENTRED, PK_VEC_CENTRED, PK_AFFINE, PK_MAT32 };
 constexpr int PACK_JOBS_PER_LAUNCH = 48;        // 48 x 64 B: under the 4 KB kernel-argument limit
 struct PackJobs {
   PackJob j[PACK_JOBS_PER_LAUNCH];
@@ -157,6 +157,30 @@ __device__ __forceinline__ void k_pack_mat6_centred(int i, const float* __restri
   const float x = float(double(src[(16 * jo + (lane & 15)) * 64 + col]) - m / 64);
   store_split(x, dst, i, per_plane);
 }
+// Split-precision image of a (32 nblk) x 64 matrix for the 32x32x16 matrix instruction (edge32.hip): planes
+// [jo < nblk][k-step s < 4][piece][lane][8], lane (m = lane & 31, hh = lane >> 5) holding row 32 jo + m and, as k slot 8 hh + jj
+// of step s, input feature 32 (s >> 1) + 8 (2 (s & 1) + (jj >> 2)) + 4 hh + (jj & 3).  Rows 64.. come from W1 (lin_k | lin_v
+// stacked).  centred: the mean over the 64 rows of the matrix a row comes from is removed from every column; colscale (or
+// null): columns scaled (a LayerNorm's gamma folded into its consumer).
+__device__ __forceinline__ void k_pack_mat32(int i, const float* __restrict__ W0, const float* __restrict__ W1,
+                                             const float* __restrict__ colscale, unsigned short* __restrict__ dst, int nblk, int centred) {
+  const int per_plane = nblk * 4 * 512;
+  if (i >= per_plane) return;
+  const int jj = i & 7, lane = (i >> 3) & 63, s = (i >> 9) & 3, jo = i >> 11;
+  const int m = lane & 31, hh = lane >> 5, row = 32 * jo + m;
+  const float* src = row < 64 ? W0 : W1;
+  const int r = row & 63;
+  const int col = 32 * (s >> 1) + 8 * (2 * (s & 1) + (jj >> 2)) + 4 * hh + (jj & 3);
+  double x = src[r * 64 + col];
+  if (centred) {
+    double mu = 0;
+    for (int k = 0; k < 64; ++k) mu += src[k * 64 + col];
+    x -= mu / 64;
+  }
+  float xf = float(x);
+  if (colscale != nullptr) xf *= colscale[col];
+  store_split(xf, dst, i, per_plane);
+}
 // dst = (a [+ b]) - mean(a [+ b]), 64 elements
 __device__ __forceinline__ void k_pack_vec_centred(int i, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst) {
   if (i >= 64) return;
@@ -218,6 +242,7 @@ __global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
     case PK_MAT6_CENTRED: k_pack_mat6_centred(i, J.src, reinterpret_cast<unsigned short*>(J.dst)); break;
     case PK_VEC_CENTRED: k_pack_vec_centred(i, J.src, J.src2, J.dst); break;
     case PK_AFFINE: k_pack_affine(i, J.src, J.src2, J.src3, J.dst); break;
+    case PK_MAT32: k_pack_mat32(i, J.src, J.src2, J.src3, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1); break;
     case PK_LN2: k_pack_ln2(i, J.src, J.src2, J.src3, J.dst); break;
     case PK_SPLIT: k_pack_split(i, J.src, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1, J.p2, J.p3, J.p4 & 0x3FFFFFFF, J.p4 >> 30); break;
   }
@@ -354,7 +379,7 @@ static void recipe_edge_embed6(Packer& P, const std::string& p, int base) {   //
 }
 // image of the fused edge-attention kernel (layouts.hpp EdgeL6F): the embedding of recipe_edge_embed6 with the LayerNorm
 // algebra folded into the matrices, lin_k | lin_v scaled by the last LayerNorm's gamma, no k / v bias rows
-static void recipe_edge_fused(Packer& P, const std::string& p, const std::string& att, int base) {
+static void recipe_edge_fused(Packer& P, const std::string& p, const std::string& att, int base, bool tile32 = false) {
   using E = EdgeL6F;
   const float* wa = P.src(p + ".module_list.0.3.weight");
   const float* wb = P.src(p + ".module_list.1.3.weight");
@@ -376,13 +401,21 @@ static void recipe_edge_fused(Packer& P, const std::string& p, const std::string
   P.ln(p + ".aggr_embed.3", base + E::AG3, base + E::AE3);
   if (P.dry) return;
   float* d = P.blob + base;
-  P.emit(PK_MAT6_CENTRED, 4 * 2 * 512, wa, d + E::WA3);
-  P.emit(PK_MAT6_CENTRED, 4 * 2 * 512, wb, d + E::WB3);
+  if (tile32) {                                            // the same matrices in the fragment order of the 32x32x16 instruction
+    P.emit(PK_MAT32, 2 * 4 * 512, wa, d + E::WA3, 2, 1);
+    P.emit(PK_MAT32, 2 * 4 * 512, wb, d + E::WB3, 2, 1);
+    P.emit(PK_MAT32, 2 * 4 * 512, w2, d + E::W2, 2, 1);
+    P.emit(PK_MAT32, 4 * 4 * 512, wk, d + E::WKV, 4, 0, 0, 0, 0, wv);
+    P.jobs.back().src3 = g3;
+  } else {
+    P.emit(PK_MAT6_CENTRED, 4 * 2 * 512, wa, d + E::WA3);
+    P.emit(PK_MAT6_CENTRED, 4 * 2 * 512, wb, d + E::WB3);
+    P.emit(PK_MAT6_CENTRED, 4 * 2 * 512, w2, d + E::W2);
+    P.emit(PK_MAT6_STACK2, 8 * 2 * 512, wk, d + E::WKV, 0, 0, 0, 0, 0, wv);
+    P.jobs.back().src3 = g3;
+  }
   P.emit(PK_VEC_CENTRED, 64, ba, d + E::B3, 0, 0, 0, 0, 0, bb);
-  P.emit(PK_MAT6_CENTRED, 4 * 2 * 512, w2, d + E::W2);
   P.emit(PK_VEC_CENTRED, 64, b2, d + E::B2);
-  P.emit(PK_MAT6_STACK2, 8 * 2 * 512, wk, d + E::WKV, 0, 0, 0, 0, 0, wv);
-  P.jobs.back().src3 = g3;
   P.emit(PK_AFFINE, 64, wk, d + E::CK, 0, 0, 0, 0, 0, e3);
   P.jobs.back().src3 = bk;
   P.emit(PK_AFFINE, 64, wv, d + E::CV, 0, 0, 0, 0, 0, e3);
@@ -511,6 +544,8 @@ static void recipe_encoder_attention(Packer& P) {
   pack_kv6(P, "al_encoder.lin_k", "al_encoder.lin_v", B::AL_EDGE6 + EdgeL6::WKV, B::AL_EDGE6 + EdgeL6::BKV);
   recipe_edge_fused(P, "aa_encoder.nbr_embed", "aa_encoder", B::AA_EDGE6F);
   recipe_edge_fused(P, "al_encoder.lane_embed", "al_encoder", B::AL_EDGE6F);
+  recipe_edge_fused(P, "aa_encoder.nbr_embed", "aa_encoder", B::AA_EDGE6F + EdgeL6F::SIZE, true);
+  recipe_edge_fused(P, "al_encoder.lane_embed", "al_encoder", B::AL_EDGE6F + EdgeL6F::SIZE, true);
   recipe_upd_ffn6(P, "aa_encoder", B::AA_UPD6, B::AA_FFN6);
   recipe_upd_ffn6(P, "al_encoder", B::AL_UPD6, B::AL_FFN6);
   // training path: wave-per-target attention over stored embedding rows (k_global_attn<.., NODE = false> and its backward)

@@ -17,7 +17,13 @@ static int pair_threads() { static int t = []() { const char* e = getenv("TRAJSD
 // fused edge attention (k_edge_attn2 + k_seg_merge: no per-edge v / logits in HBM): default, inference and training forward
 // alike; TRAJSDE_ATTN_FUSED=0 runs the older two-kernel form (k_edge_kv2 -> HBM -> k_seg_softmax_agg), kept as a cross-check
 static bool attn_fused() { static bool v = []() { const char* e = getenv("TRAJSDE_ATTN_FUSED"); return !(e && atoi(e) == 0); }(); return v && edge_x6() && edge_pair(); }
-static int fused_threads() { return 512; }   // 2 waves per SIMD: ~200 VGPRs, weight image + 8 x 8 KB of parked query rows = 150 KB of LDS
+static int fused_threads() { return 512; }   // 2 waves per SIMD: ~220 VGPRs, weight image + 8 x 8 KB of parked query rows = 150 KB of LDS
+// TRAJSDE_EDGE_TILE=32: the fused edge attention on 32x32x16 matrix tiles (edge32.hip) -- half the matrix instructions and 12 %
+// fewer vector instructions, parity-tested, and 5 % slower un-profiled (0.839 against 0.800 ms on one box): the default stays
+// the 16x16x32 form.  TRAJSDE_EDGE_PINGPONG=1 adds its phase barriers that keep the second wave of a SIMD one phase behind the
+// first (edge32.hip phase_sync): slower still, kept as the record of the experiment.
+static bool edge_pingpong() { static const bool v = []() { const char* e = getenv("TRAJSDE_EDGE_PINGPONG"); return e && atoi(e) != 0; }(); return v; }
+static bool edge_tile32() { static const bool v = []() { const char* e = getenv("TRAJSDE_EDGE_TILE"); return e && atoi(e) == 32; }(); return v && TSDE_SPLIT_H3; }
 static bool global_fused_env() { static const bool v = []() { const char* e = getenv("TRAJSDE_GLOBAL_UNFUSED"); return !(e && atoi(e) != 0); }(); return v; }
 static int fused_streams() { return 256 * 256; }             // a workgroup walks 256 streams (8 waves x 2 tiles or 4 waves x 4 tiles), one workgroup per CU
 static AttnPlan fused_plan(int64_t E) { return attn_plan(E, fused_streams()); }
@@ -124,13 +130,24 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
     const int lds = (EdgeL6F::LDS_SIZE + 256 * 64) * 4;                      // weight image + the parked query rows of 256 streams (64 KB)
     const bool d = drop.p > 0.f, sv = emb_out != nullptr;
 #define TS_EA2(N_, D_, S_) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<N_, D_, S_>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
-    if (d && sv) TS_EA2(2, true, true);
-    else if (d) TS_EA2(2, true, false);
-    else if (sv) TS_EA2(2, false, true);
-    else TS_EA2(2, false, false);
+#define TS_EA3(D_, S_) if (edge_pingpong()) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn3<D_, S_, true>), grid, threads, lds, st, img + EdgeL6F::SIZE, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out); else TS_LAUNCH_TAG(tag, dominant, (k_edge_attn3<D_, S_, false>), grid, threads, lds, st, img + EdgeL6F::SIZE, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
+    if (edge_tile32()) {
+#if TSDE_SPLIT_H3
+      if (d && sv) TS_EA3(true, true);
+      else if (d) TS_EA3(true, false);
+      else if (sv) TS_EA3(false, true);
+      else TS_EA3(false, false);
+#endif
+    } else {
+      if (d && sv) TS_EA2(2, true, true);
+      else if (d) TS_EA2(2, true, false);
+      else if (sv) TS_EA2(2, false, true);
+      else TS_EA2(2, false, false);
+    }
 #undef TS_EA2
+#undef TS_EA3
   }
-  TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, ec, pl.C, R, agg, stats, heads, img, q, drop.p > 0.f ? 0 : 1);
+  TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, ec, pl.C, R, agg, stats, heads, img, q, drop.p > 0.f ? 0 : 1, edge_tile32() ? 1 : 0);
   return TRAJSDE_OK;
 }
 bool attn_fused_enabled() { return attn_fused(); }
