@@ -583,6 +583,11 @@ __global__ __launch_bounds__(256, 4) void k_global_attn(const float* __restrict_
     }
   }
   const int beg = segptr[nc], end = node < N ? segptr[nc + 1] : beg;
+  // Row loads go through buffer descriptors: address = descriptor base (SGPRs) + scalar row offset + lane * 4, so a load costs no
+  // vector instruction (plain pointers made the compiler add a 64-bit per-lane address for each of the 24 loads of a chunk:
+  // 11 % of the loop's vector instructions).  Offsets are 32-bit: the rel descriptor starts at the target's segment.
+  const __amdgpu_buffer_rsrc_t rs_rel = row_rsrc(rel + (ST_BF16 ? 0 : int64_t(beg) * 64));
+  const __amdgpu_buffer_rsrc_t rs_kn = row_rsrc(kn), rs_vn = row_rsrc(vn);
   float m = -INFINITY, s = 0.f, sk = 0.f, accv = 0.f, accr[SL];      // sk: sum of the KEPT, scaled weights (= s without dropout)
 #pragma unroll
   for (int e = 0; e < SL; ++e) accr[e] = 0.f;
@@ -603,12 +608,9 @@ __global__ __launch_bounds__(256, 4) void k_global_attn(const float* __restrict_
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u < end ? e0 + u : end - 1;
       const int sidx = __builtin_amdgcn_readlane(sv, u);
-      const float* rrow = rel + int64_t(e) * 64;
-      const float* krow = kn + int64_t(sidx) * 64;
-      const float* vrow = vn + int64_t(sidx) * 64;
-      if (!ST_BF16) rl[u] = rrow[lane];                       // fp32 rows: one dword per lane
-      knv[u] = NODE ? krow[lane] : 0.f;
-      vnv[u] = NODE ? vrow[lane] : 0.f;
+      if (!ST_BF16) rl[u] = row_load(rs_rel, lane, e - beg);  // fp32 rows: one dword per lane
+      knv[u] = NODE ? row_load(rs_kn, lane, sidx) : 0.f;
+      vnv[u] = NODE ? row_load(rs_vn, lane, sidx) : 0.f;
     }
     if (ST_BF16) {                                            // bf16 storage: 8 lanes per row, 16 B (8 elements) per lane, widened here
       const int64_t er = e0 + (lane >> 3) < end ? e0 + (lane >> 3) : end - 1;

@@ -127,6 +127,15 @@ __device__ __forceinline__ void store_logits(const f4 (&qv)[4], const f4 (&k)[4]
   }
 }
 
+// [rows][64] fp32 rows read with lane = feature as  descriptor base (SGPRs) + row * 256 (a scalar) + lane * 4: buffer loads that
+// cost no vector instruction, where a plain pointer makes the compiler form a 64-bit per-lane address for every load
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0xFFFFFFFF, 0x00020000);      // raw buffer, 32-bit data format
+}
+__device__ __forceinline__ float row_load(__amdgpu_buffer_rsrc_t rs, int lane, int row /*uniform, < 2^23*/) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, row * 256, 0));
+}
+
 // sums over the 8 lanes that hold one head when lane = feature (segment / fused-attention kernels)
 __device__ __forceinline__ float dpp_add(float v, int ctrl_tag) {
   // ctrl_tag 0: xor 1, 1: xor 2 (quad permutes), 2: mirror within 8 lanes

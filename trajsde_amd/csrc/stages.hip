@@ -420,6 +420,7 @@ int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph
     TS_REQUIRE(fused || g->exact, "aggregator_forward: a graph from trajsde_graph_prepare_async needs the fused global attention");
     if (fused) {
       // one wave per target: logits, softmax and aggregation in one pass over the rel rows (no per-edge GEMM)
+      TS_REQUIRE(N < (1 << 23), "aggregator_forward: node rows are addressed with 32-bit byte offsets (N < 2^23)");
       TS_GLOBAL_ATTN(num_heads, state_bf16(), drop, xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, static_cast<float*>(nullptr));
       if (int rc = update_ffn(im, w.agg, w.xn, x, N, w.x1, w.xn2, out, st, drop)) return rc;
       x = out;
