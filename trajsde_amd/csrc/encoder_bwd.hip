@@ -910,12 +910,11 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "encoder_backward: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int N = b->N, Nt = g->Nt, H = b->H, A = b->A;
-  const int64_t R = int64_t(H) * Nt, Eaa = g->E_aa, Ela = g->E_la;
+  const int64_t R = int64_t(H) * Nt, Ela = g->E_la;
   const int64_t rtiles = (int64_t(Nt) + 15) / 16;
   NoiseArg na{0, nullptr, nullptr};
   if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; na.seed_dev = noise->seed_dev; }
   const WgradCtx wc{st, w.part, w.cs, step_tab_dev, w.parts};
-  using FB = EncBlob;
   using BB = EncBwdBlob;
 
   if (!tape_valid)
