@@ -46,19 +46,24 @@ __global__ void k_degree(const int64_t* __restrict__ ei, int E, int32_t* __restr
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < E) atomicAdd(&deg[int(ei[int64_t(E) + e])], 1);                 // row 1 = target
 }
-__global__ void k_scatter(const int64_t* __restrict__ ei, int E, int32_t* __restrict__ cursor, int32_t* __restrict__ out,
-                          int store_edge_id) {
+// a row's slots are handed out by counting its degree back down (any order: the rows are sorted afterwards), so no copy of the
+// row pointers is needed as a cursor
+__global__ void k_scatter(const int64_t* __restrict__ ei, int E, const int32_t* __restrict__ rowptr, int32_t* __restrict__ deg,
+                          int32_t* __restrict__ out, int store_edge_id) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  const int p = atomicAdd(&cursor[int(ei[int64_t(E) + e])], 1);
+  const int d = int(ei[int64_t(E) + e]);
+  const int p = rowptr[d] + atomicSub(&deg[d], 1) - 1;
   out[p] = store_edge_id ? e : int32_t(ei[e]);                             // row 0 = source
 }
 // lane-actor edges: value = (lane id << 32) | edge id, so that rows sort by lane first (canonical under permutations
 // of the input list) and the edge id is still at hand for the vector lookup
-__global__ void k_scatter_lane(const int64_t* __restrict__ lai, int E, int32_t* __restrict__ cursor, int64_t* __restrict__ out) {
+__global__ void k_scatter_lane(const int64_t* __restrict__ lai, int E, const int32_t* __restrict__ rowptr, int32_t* __restrict__ deg,
+                               int64_t* __restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  const int p = atomicAdd(&cursor[int(lai[int64_t(E) + e])], 1);
+  const int d = int(lai[int64_t(E) + e]);
+  const int p = rowptr[d] + atomicSub(&deg[d], 1) - 1;
   out[p] = (lai[e] << 32) | int64_t(e);
 }
 __global__ void k_unpack_eid(const int64_t* __restrict__ packed, int E, int32_t* __restrict__ eid) {
@@ -448,8 +453,8 @@ static hipError_t scan_flags(void* tmp, size_t& tmp_bytes, const uint8_t* flags,
 
 // phase-1 workspace layout, derived from the batch sizes alone (so both phases agree on it)
 struct PrepWs {
-  int32_t *deg, *rowptr, *cursor, *csr_src, *csr_dst, *orig, *eos, *pick_slot, *counts;
-  int32_t *la_deg, *la_rowptr, *la_cursor, *la_eid, *la_actor;
+  int32_t *deg, *rowptr, *csr_src, *csr_dst, *orig, *eos, *pick_slot, *counts;
+  int32_t *la_deg, *la_rowptr, *la_eid, *la_actor;
   int64_t* la_pack;
   int32_t *aa_segptr, *g_segptr, *la_segptr, *cpos_g, *cpos_la;
   uint8_t *nus, *flags_g, *flags_la;
@@ -464,10 +469,11 @@ struct PrepWs {
     Carver c(ws, ws_bytes);
     const int64_t N = b->N, A = b->A, E = b->E, Nt = N + A, H = b->H, Ea = b->E_al;
     n_aa = H * Nt;
-    deg = c.take<int32_t>(N + 1); rowptr = c.take<int32_t>(N + 1); cursor = c.take<int32_t>(N + 1);
+    deg = c.take<int32_t>(2 * (N + 1)); la_deg = deg + (N + 1);          // both degree arrays: one memset (graph_prepare)
+    rowptr = c.take<int32_t>(N + 1);
     csr_src = c.take<int32_t>(E + 1); csr_dst = c.take<int32_t>(E + 1);
     orig = c.take<int32_t>(Nt); eos = c.take<int32_t>(Nt); pick_slot = c.take<int32_t>(Nt); counts = c.take<int32_t>(8);
-    la_deg = c.take<int32_t>(N + 1); la_rowptr = c.take<int32_t>(N + 1); la_cursor = c.take<int32_t>(N + 1);
+    la_rowptr = c.take<int32_t>(N + 1);
     la_eid = c.take<int32_t>(Ea + 1); la_actor = c.take<int32_t>(Ea + 1); la_pack = c.take<int64_t>(Ea + 1);
     aa_segptr = c.take<int32_t>(n_aa + 1); g_segptr = c.take<int32_t>(N + 1); la_segptr = c.take<int32_t>(N + 1);
     cpos_g = c.take<int32_t>(E + 1); cpos_la = c.take<int32_t>(Ea + 1);
@@ -516,21 +522,20 @@ static int check_batch(const trajsde_batch* b) {
 }
 
 // CSR by target: degree histogram -> exclusive scan -> scatter -> canonical row order
-static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* rowptr, int32_t* cursor, int32_t* out, int64_t* lane_pack,
+// (deg arrives zeroed)
+static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* rowptr, int32_t* out, int64_t* lane_pack,
                      void* cub_tmp, int64_t cub_bytes, hipStream_t st) {
-  TS_HIP(hipMemsetAsync(deg, 0, size_t(N + 1) * sizeof(int32_t), st));
   if (E > 0) k_degree<<<cdiv(E, 256), 256, 0, st>>>(ei, E, deg);
   size_t tmp = size_t(cub_bytes);
   TS_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, deg, rowptr, N + 1, st));
-  TS_HIP(hipMemcpyAsync(cursor, rowptr, size_t(N + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   if (E > 0 && lane_pack == nullptr) {
-    k_scatter<<<cdiv(E, 256), 256, 0, st>>>(ei, E, cursor, out, 0);
+    k_scatter<<<cdiv(E, 256), 256, 0, st>>>(ei, E, rowptr, deg, out, 0);
     // short rows: one wave per row and many rows in flight; long rows: a full workgroup per row
     static const int rs_env = []() { const char* e = getenv("TRAJSDE_ROWSORT_THREADS"); return e ? atoi(e) : 0; }();
     const int rs_threads = rs_env ? rs_env : (int64_t(E) <= int64_t(N) * 64 ? 64 : 256);
     k_row_sort<int32_t><<<N < 16384 ? N : 16384, rs_threads, 0, st>>>(rowptr, N, out);
   } else if (E > 0) {
-    k_scatter_lane<<<cdiv(E, 256), 256, 0, st>>>(ei, E, cursor, lane_pack);
+    k_scatter_lane<<<cdiv(E, 256), 256, 0, st>>>(ei, E, rowptr, deg, lane_pack);
     static const int rs_env = []() { const char* e = getenv("TRAJSDE_ROWSORT_THREADS"); return e ? atoi(e) : 0; }();
     const int rs_threads = rs_env ? rs_env : (int64_t(E) <= int64_t(N) * 64 ? 64 : 256);
     k_row_sort<int64_t><<<N < 16384 ? N : 16384, rs_threads, 0, st>>>(rowptr, N, lane_pack);
@@ -580,9 +585,10 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
   NoiseArg na{0, nullptr, nullptr};
   if (fake_noise) { na.seed = fake_noise->seed; na.z = fake_noise->z; na.row_ids = fake_noise->row_ids; na.seed_dev = fake_noise->seed_dev; }
 
+  TS_HIP(hipMemsetAsync(w.deg, 0, size_t(2) * (N + 1) * sizeof(int32_t), st));       // actor and lane degree counters
   {
     ProfScope ps("build_csr[actors]", st);
-    if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.cursor, w.csr_src, nullptr, w.cub_tmp, w.cub_bytes, st)) return rc;
+    if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.csr_src, nullptr, w.cub_tmp, w.cub_bytes, st)) return rc;
   }
   k_ext_nodes<<<cdiv(Nt, 256), 256, 0, st>>>(N, A, H, b->agent_index, b->batch, b->source, b->bos_mask, w.orig, w.nus, w.eos, w.pick_slot);
   if (A > 0) {
@@ -614,7 +620,7 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
   if (b->L > 0) k_lane_feat<<<cdiv(b->L, 256), 256, 0, st>>>(b->L, b->lane_pts, b->lane_positions, b->lane_paddings, w.lane_feat);
   {
     ProfScope ps("build_csr[lanes]", st);
-    if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_cursor, w.la_eid, w.la_pack, w.cub_tmp, w.cub_bytes, st)) return rc;
+    if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_eid, w.la_pack, w.cub_tmp, w.cub_bytes, st)) return rc;
   }
   k_la_flags<<<cdiv(Ea + 1, 256), 256, 0, st>>>(Ea, N, w.la_rowptr, w.la_eid, b->lane_actor_vectors, radius, w.la_actor, w.flags_la);
   {
