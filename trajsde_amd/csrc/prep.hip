@@ -127,11 +127,10 @@ __global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ ro
 }
 
 // per extended node: original actor, source mask, recurrence iteration to keep; slots of the agent rows
-__global__ void k_ext_nodes(int N, int A, int H, const int64_t* __restrict__ agent_index, const int64_t* __restrict__ batch,
-                            const int64_t* __restrict__ source, const uint8_t* __restrict__ bos,
-                            int32_t* __restrict__ orig, uint8_t* __restrict__ nus, int32_t* __restrict__ eos,
-                            int32_t* __restrict__ pick_slot) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ext_nodes_body(int i, int N, int A, int H, const int64_t* __restrict__ agent_index,
+                                               const int64_t* __restrict__ batch, const int64_t* __restrict__ source,
+                                               const uint8_t* __restrict__ bos, int32_t* __restrict__ orig, uint8_t* __restrict__ nus,
+                                               int32_t* __restrict__ eos, int32_t* __restrict__ pick_slot) {
   if (i >= N + A) return;
   const int o = i < N ? i : int(agent_index[i - N]);
   orig[i] = o;
@@ -148,9 +147,8 @@ __global__ void k_agent_slots(int A, const int64_t* __restrict__ agent_index, in
 }
 
 // x_fake[k,t,:] = x[agent_k,t,:] + 2*z   (ENC:94-95)
-__global__ void k_fake_x(int A, int H, const float* __restrict__ x, const int64_t* __restrict__ agent_index, NoiseArg na,
-                         float* __restrict__ x_fake) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (k, quad of 4 columns)
+__device__ __forceinline__ void fake_x_body(int idx /* one thread per (k, quad of 4 columns) */, int A, int H, const float* __restrict__ x,
+                                            const int64_t* __restrict__ agent_index, const NoiseArg& na, float* __restrict__ x_fake) {
   const int quads = (2 * H + 3) / 4;
   if (idx >= A * quads) return;
   const int k = idx / quads, q = idx % quads;
@@ -199,8 +197,7 @@ static float radius2_threshold(float radius) {
 }
 
 // vmask[i]: bit t set when actor i is valid (not padded) at history step t
-__global__ void k_valid_mask(int N, int H, int TT, const uint8_t* __restrict__ pad, uint32_t* __restrict__ vmask) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void valid_mask_body(int i, int N, int H, int TT, const uint8_t* __restrict__ pad, uint32_t* __restrict__ vmask) {
   if (i >= N) return;
   uint32_t m = 0;
   uint8_t v[32];
@@ -280,6 +277,7 @@ __global__ void k_aa_count(int Nt, int H, const int32_t* __restrict__ rowptr, co
                            const unsigned long long* __restrict__ bal, int32_t* __restrict__ cnt) {
   const int64_t id = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;                       // = t * Nt + node
   if (id >= int64_t(H) * Nt) return;
+  if (id == 0) cnt[int64_t(H) * Nt] = 0;                                                   // the scan's extra element (total at the end)
   const int t = int(id / Nt), node = int(id - int64_t(t) * Nt), o = orig[node];
   const int beg = rowptr[o], end = rowptr[o + 1];
   int c = 0;
@@ -388,8 +386,8 @@ __global__ void k_segptr_from_rowptr(int n, const int32_t* __restrict__ rowptr, 
 }
 
 // lane feature (ENC:68-71); torch's negative index wraps when a lane is fully padded
-__global__ void k_lane_feat(int L, int P, const float* __restrict__ lp, const float* __restrict__ pad, float* __restrict__ feat) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void lane_feat_body(int l, int L, int P, const float* __restrict__ lp, const float* __restrict__ pad,
+                                               float* __restrict__ feat) {
   if (l >= L) return;
   float len = 0.f;
   for (int j = 0; j < P; ++j) len += 1.0f - pad[int64_t(l) * P + j];
@@ -397,6 +395,27 @@ __global__ void k_lane_feat(int L, int P, const float* __restrict__ lp, const fl
   if (last < 0) last += P;
   feat[2 * l] = lp[(int64_t(l) * P + last) * 2] - lp[int64_t(l) * P * 2];
   feat[2 * l + 1] = lp[(int64_t(l) * P + last) * 2 + 1] - lp[int64_t(l) * P * 2 + 1];
+}
+// The four per-input passes that depend on nothing but the batch -- extended-node table, fake agents' inputs, per-actor validity
+// masks, lane features -- as ONE launch: blocks [0, b1) / [b1, b2) / [b2, b3) / [b3, ..) take one pass each (a 71-kernel forward
+// spends 5 % of its time in launches of a few microseconds).
+struct InputPassArgs {
+  int N, A, H, TT, L, P, b1, b2, b3;
+  const int64_t *agent_index, *batch, *source;
+  const uint8_t *bos, *pad;
+  const float *x, *lane_pos, *lane_pad;
+  int32_t *orig, *eos, *pick_slot;
+  uint8_t* nus;
+  float *x_fake, *lane_feat;
+  uint32_t* vmask;
+  NoiseArg na;
+};
+__global__ __launch_bounds__(256) void k_input_passes(const InputPassArgs a) {
+  const int blk = blockIdx.x;
+  if (blk < a.b1) ext_nodes_body(blk * 256 + threadIdx.x, a.N, a.A, a.H, a.agent_index, a.batch, a.source, a.bos, a.orig, a.nus, a.eos, a.pick_slot);
+  else if (blk < a.b2) fake_x_body((blk - a.b1) * 256 + threadIdx.x, a.A, a.H, a.x, a.agent_index, a.na, a.x_fake);
+  else if (blk < a.b3) valid_mask_body((blk - a.b2) * 256 + threadIdx.x, a.N, a.H, a.TT, a.pad, a.vmask);
+  else lane_feat_body((blk - a.b3) * 256 + threadIdx.x, a.L, a.P, a.lane_pos, a.lane_pad, a.lane_feat);
 }
 __global__ void k_la_flags(int E_al, int N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ eid,
                            const float* __restrict__ vec, float radius, int32_t* __restrict__ actor, uint8_t* __restrict__ flags) {
@@ -590,23 +609,30 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
     ProfScope ps("build_csr[actors]", st);
     if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.csr_src, nullptr, w.cub_tmp, w.cub_bytes, st)) return rc;
   }
-  k_ext_nodes<<<cdiv(Nt, 256), 256, 0, st>>>(N, A, H, b->agent_index, b->batch, b->source, b->bos_mask, w.orig, w.nus, w.eos, w.pick_slot);
-  if (A > 0) {
-    k_agent_slots<<<cdiv(A, 256), 256, 0, st>>>(A, b->agent_index, w.pick_slot);
-    k_fake_x<<<cdiv(A * ((2 * H + 3) / 4), 256), 256, 0, st>>>(A, H, b->x, b->agent_index, na, w.x_fake);
+  {
+    InputPassArgs ia;
+    ia.N = N; ia.A = A; ia.H = H; ia.TT = TT; ia.L = b->L; ia.P = b->lane_pts;
+    ia.b1 = cdiv(Nt, 256);
+    ia.b2 = ia.b1 + (A > 0 ? cdiv(A * ((2 * H + 3) / 4), 256) : 0);
+    ia.b3 = ia.b2 + (E > 0 ? cdiv(N, 256) : 0);
+    const int blocks = ia.b3 + (b->L > 0 ? cdiv(b->L, 256) : 0);
+    ia.agent_index = b->agent_index; ia.batch = b->batch; ia.source = b->source; ia.bos = b->bos_mask; ia.pad = b->padding_mask;
+    ia.x = b->x; ia.lane_pos = b->lane_positions; ia.lane_pad = b->lane_paddings;
+    ia.orig = w.orig; ia.eos = w.eos; ia.pick_slot = w.pick_slot; ia.nus = w.nus; ia.x_fake = w.x_fake; ia.lane_feat = w.lane_feat;
+    ia.vmask = w.vmask; ia.na = na;
+    k_input_passes<<<blocks, 256, 0, st>>>(ia);
   }
+  if (A > 0) k_agent_slots<<<cdiv(A, 256), 256, 0, st>>>(A, b->agent_index, w.pick_slot);    // after the table: overrides its -1 entries
   // global interactor edges (also names the target of every CSR position: csr_dst)
   k_g_flags<<<cdiv(E + 1, 256), 256, 0, st>>>(E, N, TT, H - 1, w.rowptr, w.csr_src, b->padding_mask, w.csr_dst, w.flags_g);
   // 21 snapshots: survivor ballots -> segment lengths -> prefix sum -> segment pointers
   if (E > 0) {
-    k_valid_mask<<<cdiv(N, 256), 256, 0, st>>>(N, H, TT, b->padding_mask, w.vmask);
     const int lds_b = 4 * 64 * (H | 1) * int(sizeof(float2));              // (67 KB at H = 32: TS_LAUNCH raises the dynamic-LDS limit)
     TS_LAUNCH(k_aa_ballots, xcd_grid(cdiv(cdiv(E, 64), 4)), 256, lds_b, st, E, H, TT, w.csr_src, w.csr_dst, w.vmask, b->positions, radius2_threshold(radius),
               w.bal);
   }
   { ProfScope ps("k_aa_count", st);
   k_aa_count<<<cdiv(int64_t(H) * Nt, 256), 256, 0, st>>>(Nt, H, w.rowptr, w.orig, w.bal, w.aa_segptr); }
-  TS_HIP(hipMemsetAsync(w.aa_segptr + w.n_aa, 0, sizeof(int32_t), st));
   {
     size_t tmp = size_t(w.cub_bytes);
     TS_HIP(hipcub::DeviceScan::ExclusiveSum(w.cub_tmp, tmp, w.aa_segptr, w.aa_segptr, int(w.n_aa + 1), st));
@@ -617,7 +643,6 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
   }
   k_segptr_from_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, w.rowptr, w.cpos_g, w.g_segptr);
   // lane-actor edges grouped by actor
-  if (b->L > 0) k_lane_feat<<<cdiv(b->L, 256), 256, 0, st>>>(b->L, b->lane_pts, b->lane_positions, b->lane_paddings, w.lane_feat);
   {
     ProfScope ps("build_csr[lanes]", st);
     if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_eid, w.la_pack, w.cub_tmp, w.cub_bytes, st)) return rc;
