@@ -266,7 +266,8 @@ def main():
     def edge_roofline(n_launch, total_ms, e_aa_, streams_):
         avg_s = (total_ms / max(n_launch, 1)) * 1e-3
         ach = (FLOP_PER_EDGE * e_aa_ / avg_s) * 1e-12 if avg_s > 0 else 0.0
-        return {"kernel": f"k_edge_kv[aa] (agent-agent edge embedding + k,v + logits; {split_name} split-precision MFMA 16x16x32, fp32-accurate)",
+        return {"kernel": f"k_edge_attn2, profile tag k_edge_kv[aa] (fused agent-agent edge attention: embedding + k,v + online segment softmax + "
+                          f"aggregation; {split_name} split-precision MFMA 16x16x32, fp32-accurate)",
                 "bound": "mfma", "achieved": ach, "peak": peak_fp32_equiv, "unit": "TFLOP/s", "frac": ach / peak_fp32_equiv,
                 "avg_launch_ms": avg_s * 1e3, "launches": n_launch, "flop_per_edge": FLOP_PER_EDGE, "edges_per_launch": int(e_aa_),
                 "streams": streams_, "mfma_16bit_tflops": ach * split_products * (40960.0 / 41700.0)}
