@@ -218,9 +218,7 @@ __global__ __launch_bounds__(512) void k_edge_attn3(const float* __restrict__ im
     for (int t = 0; t < 8; ++t) qn[t] = *reinterpret_cast<const f4*>(q + int64_t(nd) * 64 + 32 * (t >> 2) + 8 * (t & 3) + 4 * hh);
     if (DROP) nrank = segptr[nd];
   }
-#ifndef E32_PP_NOSHIFT
   if (PP && (wave & 4)) phase_sync();                      // the second wave of every SIMD runs one phase behind (phase_sync)
-#endif
   for (int it = 0; it < C; ++it) {
     keep_lds_reads_here();
     const int64_t e = base_e + it;
@@ -311,9 +309,7 @@ __global__ __launch_bounds__(512) void k_edge_attn3(const float* __restrict__ im
       }
     }
   }
-#ifndef E32_PP_NOSHIFT
   if (PP && !(wave & 4)) phase_sync();
-#endif
   if (cur >= 0) seg_flush32(S, rec, int64_t(cur) + sid, hh);
 }
 template __global__ void k_edge_attn3<false, false, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
