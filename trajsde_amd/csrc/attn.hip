@@ -336,6 +336,7 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
     if (cur[t] >= 0) seg_flush(S[t], rec, int64_t(cur[t]) + sid[t], L.g);
 }
 template __global__ void k_edge_attn2<2, false, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<1, false, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<2, true, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<2, false, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<2, true, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);

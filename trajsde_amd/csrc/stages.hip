@@ -22,6 +22,9 @@ static int fused_threads() { return 512; }   // 2 waves per SIMD: ~220 VGPRs, we
 // fewer vector instructions, parity-tested, and 5 % slower un-profiled (0.839 against 0.800 ms on one box): the default stays
 // the 16x16x32 form.  TRAJSDE_EDGE_PINGPONG=1 adds its phase barriers that keep the second wave of a SIMD one phase behind the
 // first (edge32.hip phase_sync): slower still, kept as the record of the experiment.
+// TRAJSDE_FUSED_TILES=1: the inference instantiation with one tile per wave and 16 waves per workgroup (4 waves per SIMD, 116
+// VGPRs, weight fragments not shared between tiles): bit-identical, and within the noise of the default (0.85 vs 0.86-0.91 ms)
+static bool fused_one_tile() { static const bool v = []() { const char* e = getenv("TRAJSDE_FUSED_TILES"); return e && atoi(e) == 1; }(); return v; }
 static bool edge_pingpong() { static const bool v = []() { const char* e = getenv("TRAJSDE_EDGE_PINGPONG"); return e && atoi(e) != 0; }(); return v; }
 static bool edge_tile32() { static const bool v = []() { const char* e = getenv("TRAJSDE_EDGE_TILE"); return e && atoi(e) == 32; }(); return v && TSDE_SPLIT_H3; }
 static bool global_fused_env() { static const bool v = []() { const char* e = getenv("TRAJSDE_GLOBAL_UNFUSED"); return !(e && atoi(e) != 0); }(); return v; }
@@ -138,6 +141,8 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
       else if (sv) TS_EA3(false, true);
       else TS_EA3(false, false);
 #endif
+    } else if (fused_one_tile() && !d && !sv) {
+      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<1, false, false>), grid, 1024, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out);
     } else {
       if (d && sv) TS_EA2(2, true, true);
       else if (d) TS_EA2(2, true, false);
