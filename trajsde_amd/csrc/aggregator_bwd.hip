@@ -416,7 +416,7 @@ static int aggregator_tape(const trajsde_batch* b, const trajsde_graph* g, const
       TS_GLOBAL_ATTN(num_heads, false, dl, xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N, w.agg[l], w.stats[l]);
     }
     TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, lb + AggLayerL::UPD6, w.agg[l], w.xn[l], x,
-              N, w.x1[l], w.xn2[l], drop_of(l));
+              N, w.x1[l], w.xn2[l], drop_of(l), no_merge());
     TS_LAUNCH(k_ffn6, tile_grid(ntiles, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, lb + AggLayerL::FFN6, w.x1[l], w.xn2[l], N, w.out[l],
               drop_of(l));
     x = w.out[l];

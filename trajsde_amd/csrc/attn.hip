@@ -714,7 +714,7 @@ template __global__ void k_global_attn<4, false, true, false>(const float*, cons
 template <bool X6>
 __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ img_g, const float* __restrict__ agg,
                                                      const float* __restrict__ xn, const float* __restrict__ x, int64_t R,
-                                                     float* __restrict__ x1, float* __restrict__ xn2, DropArg drop) {
+                                                     float* __restrict__ x1, float* __restrict__ xn2, DropArg drop, SegMerge mg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using U = typename std::conditional<X6, UpdL6, UpdL>::type;
   stage_blob(lds, img_g, U::SIZE);
@@ -730,7 +730,42 @@ __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ i
     keep_lds_reads_here();
     const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
     f4 a[4], n[4], g[4], s[4];
-    load_row(a, agg, r, L.g);
+    if (mg.rec != nullptr) {
+      // the aggregate straight from the fused edge attention's records (k_seg_merge's arithmetic, in the records' own lane layout:
+      // lane (n, g) reads its 16 sums and the (m, s) of its 4 head slots): no agg rows through HBM, one launch less
+      const int C = stream_len(mg.ec, edge_count(mg.ec), mg.C_host);
+      const int beg = mg.segptr[r], end = mg.segptr[r + 1];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) a[jt] = f4{0.f, 0.f, 0.f, 0.f};
+      if (end > beg) {
+        const int c0 = beg / C, c1 = (end - 1) / C;
+        const float* rr = mg.rec + (r + c0) * SEG_REC;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) a[jt] = *reinterpret_cast<const f4*>(rr + 16 * jt + 4 * L.g);
+        f4 m = *reinterpret_cast<const f4*>(rr + 64 + 4 * L.g), sm = *reinterpret_cast<const f4*>(rr + 80 + 4 * L.g);
+        for (int c = c0 + 1; c <= c1; ++c) {
+          rr += SEG_REC;
+          const f4 mp = *reinterpret_cast<const f4*>(rr + 64 + 4 * L.g), sp = *reinterpret_cast<const f4*>(rr + 80 + 4 * L.g);
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt) {
+            const f4 ap = *reinterpret_cast<const f4*>(rr + 16 * jt + 4 * L.g);
+            const float mn = fmaxf(m[jt], mp[jt]);
+            const float wa = fast_exp(m[jt] - mn), wb = fast_exp(mp[jt] - mn);
+            sm[jt] = sm[jt] * wa + sp[jt] * wb;
+            a[jt] = a[jt] * wa + ap * wb;
+            m[jt] = mn;
+          }
+        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          const f4 cv = *reinterpret_cast<const f4*>(mg.cv + 16 * jt + 4 * L.g);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a[jt][c] = a[jt][c] / (sm[jt] + 1e-16f) + cv[c];      // torch_geometric.utils.softmax denominator
+        }
+      }
+    } else {
+      load_row(a, agg, r, L.g);
+    }
     load_row(n, xn, r, L.g);
     range_note(absmax<4>(a), RS_NODE_AGG);
     lin(g, a, U::WIH, U::BIH);
@@ -906,8 +941,8 @@ template __global__ void k_edge_embed<false>(const float*, const float*, EdgeCou
 template __global__ void k_edge_embed<true>(const float*, const float*, EdgeCount, float*, int);
 template __global__ void k_global_edge<false>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
 template __global__ void k_global_edge<true>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
-template __global__ void k_node_update<false>(const float*, const float*, const float*, const float*, int64_t, float*, float*, DropArg);
-template __global__ void k_node_update<true>(const float*, const float*, const float*, const float*, int64_t, float*, float*, DropArg);
+template __global__ void k_node_update<false>(const float*, const float*, const float*, const float*, int64_t, float*, float*, DropArg, SegMerge);
+template __global__ void k_node_update<true>(const float*, const float*, const float*, const float*, int64_t, float*, float*, DropArg, SegMerge);
 template __global__ void k_node_proj<1>(const float*, const float*, int64_t, float*, float*, float*, float*);
 template __global__ void k_node_proj<3>(const float*, const float*, int64_t, float*, float*, float*, float*);
 

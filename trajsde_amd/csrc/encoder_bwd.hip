@@ -805,7 +805,7 @@ static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const fl
                                    w.emb, w.stats, w.agg, w.rec, 8, drop_aa, st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
-            w.center, R, w.x1, w.xn2, drop_aa);
+            w.center, R, w.x1, w.xn2, drop_aa, no_merge());
   TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out, drop_aa);
   {
     RecurTab tab;
@@ -827,7 +827,7 @@ static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const fl
                                    int64_t(N), w.al_emb, w.al_stats, w.al_agg, w.rec, 8, drop_al, st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
-            w.al_agg, w.al_xn, w.lat, int64_t(N), w.al_x1, w.al_xn2, drop_al);
+            w.al_agg, w.al_xn, w.lat, int64_t(N), w.al_x1, w.al_xn2, drop_al, no_merge());
 
   return TRAJSDE_OK;
 }
@@ -1068,7 +1068,7 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
                                    w.emb, w.stats, w.agg, w.rec, num_heads, no_drop(), st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
-            w.center, R, w.x1, w.xn2, no_drop());
+            w.center, R, w.x1, w.xn2, no_drop(), no_merge());
   TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out, no_drop());
   TS_LAUNCH(k_tr_prep, cdiv(RT * 64, 256), 256, 0, st, w.aa_out, b->padding_mask, blob_fwd + EncGridBlob::TOK, N, b->TT, x0);
   const float* x = x0;
@@ -1090,7 +1090,7 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
                                    int64_t(N), w.al_emb, w.al_stats, w.al_agg, w.rec, num_heads, no_drop(), st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
-            w.al_agg, w.al_xn, tout, int64_t(N), w.al_x1, w.al_xn2, no_drop());
+            w.al_agg, w.al_xn, tout, int64_t(N), w.al_x1, w.al_xn2, no_drop(), no_merge());
   // ================= backward =================
   {
     AttnChain c{blob_bwd + BB::AL_NODE, blob_bwd + BB::AL_PROJ, blob_fwd + EncBlob::AL_ATTN, blob_bwd + BB::AL_EDGEEMB,

@@ -39,6 +39,16 @@ __device__ __forceinline__ int stream_len(const EdgeCount& c, int64_t E, int C_h
   const int C = int((E + c.streams_target - 1) / c.streams_target);
   return C < 1 ? 1 : C;
 }
+// The records of the fused edge attention (16-row-tile layout) merged by the kernel that consumes the aggregate (k_node_update)
+// instead of by k_seg_merge: rec == nullptr means "read the agg rows".  cv: the per-target constant of the v rows (EdgeL6F::CV).
+struct SegMerge {
+  const float* rec;
+  const int32_t* segptr;
+  EdgeCount ec;
+  int C_host;
+  const float* cv;
+};
+inline SegMerge no_merge() { return SegMerge{nullptr, nullptr, EdgeCount{0, nullptr, 0}, 0, nullptr}; }
 inline AttnPlan attn_plan(int64_t E, int streams_target = SEG_STREAMS_512) {
   AttnPlan p;
   p.C = int((E + streams_target - 1) / streams_target);
@@ -55,7 +65,7 @@ bool attn_fused_enabled();
 int64_t fused_rec_floats(int64_t E, bool exact, int64_t targets);
 int fused_edge_attention(const char* tag, bool dominant, const float* img, const float* geom, const int32_t* dst, const float* q,
                          const EdgeCount& ec, const int32_t* segptr, int64_t R, float* rec, float* agg, int heads, hipStream_t st,
-                         const DropArg& drop, float* emb_out = nullptr, float* stats = nullptr);
+                         const DropArg& drop, float* emb_out = nullptr, float* stats = nullptr, SegMerge* defer = nullptr);
 // launch the instantiation selected by (heads, bf16 state storage, dropout)
 #define TS_GLOBAL_ATTN(heads, bf16, drop, ...)                                                                       \
   do {                                                                                                              \
@@ -99,7 +109,8 @@ __global__ void k_global_attn(const float* img, const int32_t* segptr, const int
                               const float* vn, int64_t N, float* agg, float* stats, DropArg drop);
 __global__ void k_seg_softmax_agg(const int32_t* segptr, const float* logits, const float* v, int64_t R, float* agg, int heads, DropArg drop);
 template <bool X6>
-__global__ void k_node_update(const float* img, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2, DropArg drop);
+__global__ void k_node_update(const float* img, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2, DropArg drop,
+                              SegMerge mg);
 __global__ void k_ffn6(const float* img, const float* x1, const float* xn2, int64_t R, float* out, DropArg drop);
 __global__ void k_ffn(const float* img, const float* x1, const float* xn2, int64_t R, float* out, DropArg drop, int out_bf16);
 template <int NQ>

@@ -24,6 +24,8 @@ static int fused_threads() { return 512; }   // 2 waves per SIMD: ~220 VGPRs, we
 // first (edge32.hip phase_sync): slower still, kept as the record of the experiment.
 // TRAJSDE_FUSED_TILES=1: the inference instantiation with one tile per wave and 16 waves per workgroup (4 waves per SIMD, 116
 // VGPRs, weight fragments not shared between tiles): bit-identical, and within the noise of the default (0.85 vs 0.86-0.91 ms)
+// TRAJSDE_MERGE_KERNEL=1: the records are merged by k_seg_merge into agg rows (always so in training) instead of inside k_node_update
+static bool merge_in_update() { static const bool v = []() { const char* e = getenv("TRAJSDE_MERGE_KERNEL"); return !(e && atoi(e) != 0); }(); return v; }
 static bool fused_one_tile() { static const bool v = []() { const char* e = getenv("TRAJSDE_FUSED_TILES"); return e && atoi(e) == 1; }(); return v; }
 static bool edge_pingpong() { static const bool v = []() { const char* e = getenv("TRAJSDE_EDGE_PINGPONG"); return e && atoi(e) != 0; }(); return v; }
 static bool edge_tile32() { static const bool v = []() { const char* e = getenv("TRAJSDE_EDGE_TILE"); return e && atoi(e) == 32; }(); return v && TSDE_SPLIT_H3; }
@@ -98,16 +100,16 @@ struct NodeImgs {
   const float *upd, *ffn, *upd6, *ffn6;
 };
 static int update_ffn(const NodeImgs& im, const float* agg, const float* xn, const float* x, int64_t R, float* x1, float* xn2, float* out,
-                      hipStream_t st, const DropArg& drop = no_drop(), bool out_bf16 = false) {
+                      hipStream_t st, const DropArg& drop = no_drop(), bool out_bf16 = false, const SegMerge& mg = no_merge()) {
   const int64_t ntiles = (R + 15) / 16;
   TS_REQUIRE(!(out_bf16 && node_x6()), "bf16 state storage needs the one-pass FFN kernel (default fp16x3 build, TRAJSDE_NODE_FP32 unset)");
   if (node_x6()) {
     TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, threads_node(), UpdL6::SIZE * 4), threads_node(), UpdL6::SIZE * 4, st, im.upd6, agg, xn, x,
-              R, x1, xn2, drop);
+              R, x1, xn2, drop, mg);
     TS_LAUNCH(k_ffn6, tile_grid(ntiles, threads_node(), FfnL6::HALF * 4), threads_node(), FfnL6::HALF * 4, st, im.ffn6, x1, xn2, R, out, drop);
   } else {
     TS_LAUNCH(k_node_update<false>, tile_grid(ntiles, threads_node(), UpdL::SIZE * 4), threads_node(), UpdL::SIZE * 4, st, im.upd, agg, xn, x, R,
-              x1, xn2, drop);
+              x1, xn2, drop, mg);
     TS_LAUNCH(k_ffn, tile_grid(ntiles, threads_node(), FfnL::SIZE * 4), threads_node(), FfnL::SIZE * 4, st, im.ffn, x1, xn2, R, out, drop, out_bf16 ? 1 : 0);
   }
   return TRAJSDE_OK;
@@ -122,7 +124,7 @@ static int attention_tail(const NodeImgs& im, const int32_t* segptr, const float
 // embedding + lin_k|lin_v + softmax-aggregate of one edge list in the fused form: records, then one merged agg row per target
 int fused_edge_attention(const char* tag, bool dominant, const float* img, const float* geom, const int32_t* dst, const float* q,
                          const EdgeCount& ec, const int32_t* segptr, int64_t R, float* rec, float* agg, int heads, hipStream_t st,
-                         const DropArg& drop, float* emb_out, float* stats) {
+                         const DropArg& drop, float* emb_out, float* stats, SegMerge* defer) {
   const int64_t E = ec.E;
   const AttnPlan pl = fused_plan(E);
   if (E > 0) {
@@ -152,6 +154,12 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
 #undef TS_EA2
 #undef TS_EA3
   }
+  // inference with the default record layout: the consumer of the aggregate (k_node_update) merges the records itself
+  if (defer != nullptr && stats == nullptr && emb_out == nullptr && drop.p == 0.f && !edge_tile32() && merge_in_update()) {
+    *defer = SegMerge{rec, segptr, ec, pl.C, img + EdgeL6F::CV};
+    return TRAJSDE_OK;
+  }
+  if (defer != nullptr) *defer = no_merge();
   TS_LAUNCH(k_seg_merge, cdiv(R, 4), 256, 0, st, segptr, rec, ec, pl.C, R, agg, stats, heads, img, q, drop.p > 0.f ? 0 : 1, edge_tile32() ? 1 : 0);
   return TRAJSDE_OK;
 }
@@ -181,10 +189,11 @@ static int run_aa_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
             b->x, g->x_fake, rot, b->bos_mask, g->orig, N, Nt, H, w.center, w.cn, w.q);
   const NodeImgs im{blob + EncBlob::AA_UPD, blob + EncBlob::AA_FFN, blob + EncBlob::AA_UPD6, blob + EncBlob::AA_FFN6};
   if (attn_fused()) {
+    SegMerge mg = no_merge();
     if (int rc = fused_edge_attention("k_edge_kv[aa]", true, blob + EncBlob::AA_EDGE6F, g->aa_geom, g->aa_dst, w.q, count_of(g, 1, g->E_aa), g->aa_segptr, R,
-                                      w.rec, w.agg, heads, st, drop))
+                                      w.rec, w.agg, heads, st, drop, nullptr, nullptr, &mg))
       return rc;
-    return update_ffn(im, w.agg, w.cn, w.center, R, w.x1, w.xn2, aa_out, st, drop, state_bf16());      // aa_out in the state storage type
+    return update_ffn(im, w.agg, w.cn, w.center, R, w.x1, w.xn2, aa_out, st, drop, state_bf16(), mg);  // aa_out in the state storage type
   }
   if (g->E_aa > 0) {
     if (edge_x6() && edge_pair())
@@ -257,10 +266,11 @@ static int run_al_encoder(const trajsde_batch* b, const trajsde_graph* g, const 
             blob + EncBlob::AL_Q, lat, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
   const NodeImgs im{blob + EncBlob::AL_UPD, blob + EncBlob::AL_FFN, blob + EncBlob::AL_UPD6, blob + EncBlob::AL_FFN6};
   if (attn_fused()) {
+    SegMerge mg = no_merge();
     if (int rc = fused_edge_attention("k_edge_kv[al]", false, blob + EncBlob::AL_EDGE6F, g->la_geom, g->la_dst, w.al_q, count_of(g, 3, g->E_la), g->la_segptr,
-                                      int64_t(N), w.al_rec, w.al_agg, heads, st, drop))
+                                      int64_t(N), w.al_rec, w.al_agg, heads, st, drop, nullptr, nullptr, &mg))
       return rc;
-    return update_ffn(im, w.al_agg, w.al_xn, lat, N, w.al_x1, w.al_xn2, local_embed, st, drop);
+    return update_ffn(im, w.al_agg, w.al_xn, lat, N, w.al_x1, w.al_xn2, local_embed, st, drop, false, mg);
   }
   if (g->E_la > 0) {
     if (edge_x6() && edge_pair())
