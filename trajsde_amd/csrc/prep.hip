@@ -66,17 +66,14 @@ __global__ void k_scatter_lane(const int64_t* __restrict__ lai, int E, const int
   const int p = rowptr[d] + atomicSub(&deg[d], 1) - 1;
   out[p] = (lai[e] << 32) | int64_t(e);
 }
-__global__ void k_unpack_eid(const int64_t* __restrict__ packed, int E, int32_t* __restrict__ eid) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < E) eid[e] = int32_t(packed[e] & 0xFFFFFFFFll);
-}
 // ascending sort of the long CSR rows (more than 256 entries; second phase of k_row_sort), one workgroup per row (grid-stride).
 // Rows of up to 4096 entries: bitonic network in LDS on the row padded to a power of two with +inf.  Longer rows: in place in global memory with the "flip" form of the network
 // (first sub-step of stage k pairs i with i ^ (k - 1), the others i with i ^ j), in which EVERY compare-exchange puts the
 // minimum at the lower index -- so the virtual +inf padding above the row's end never moves and a pair whose upper index lies
 // beyond the row is a no-op: correct for any row length without materialising the padding.
 template <typename T>
-__device__ __forceinline__ void sort_long_rows(const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals, T* buf /* LDS, 4096 */) {
+__device__ __forceinline__ void sort_long_rows(const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals, T* buf /* LDS, 4096 */,
+                                               int32_t* __restrict__ low_out) {
   const T INF = sizeof(T) == 8 ? T(INT64_MAX) : T(INT32_MAX);
   for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
     const int beg = rowptr[row], n = rowptr[row + 1] - beg;
@@ -101,7 +98,10 @@ __device__ __forceinline__ void sort_long_rows(const int32_t* __restrict__ rowpt
           }
           __syncthreads();
         }
-      for (int i = threadIdx.x; i < n; i += blockDim.x) vals[beg + i] = buf[i];
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        vals[beg + i] = buf[i];
+        if (low_out != nullptr) low_out[beg + i] = int32_t(int64_t(buf[i]) & 0xFFFFFFFFll);
+      }
       __syncthreads();
     } else {
       T* a = vals + beg;
@@ -121,6 +121,8 @@ __device__ __forceinline__ void sort_long_rows(const int32_t* __restrict__ rowpt
           __threadfence_block();
           __syncthreads();
         }
+      if (low_out != nullptr)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) low_out[beg + i] = int32_t(int64_t(a[i]) & 0xFFFFFFFFll);
     }
   }
 }
@@ -140,14 +142,19 @@ __device__ __forceinline__ T lane_xor(T v, int mask) {
   }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals) {
+__global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals,
+                                                  int32_t* __restrict__ low_out /* or null: the low words of the sorted values (edge ids of packed lane keys) */) {
   __shared__ T buf[4096];
   constexpr int EPL = 4, PMAX = 64 * EPL;
   const T INF = sizeof(T) == 8 ? T(INT64_MAX) : T(INT32_MAX);
   const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
   for (int row = blockIdx.x * waves + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * waves) {
     const int beg = rowptr[row], n = rowptr[row + 1] - beg;
-    if (n <= 1 || n > PMAX) continue;
+    if (n > PMAX) continue;
+    if (n <= 1) {
+      if (n == 1 && low_out != nullptr && lane == 0) low_out[beg] = int32_t(int64_t(vals[beg]) & 0xFFFFFFFFll);
+      continue;
+    }
     T v[EPL];
 #pragma unroll
     for (int r = 0; r < EPL; ++r) v[r] = EPL * lane + r < n ? vals[beg + EPL * lane + r] : INF;
@@ -183,9 +190,12 @@ __global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ ro
     }
 #pragma unroll
     for (int r = 0; r < EPL; ++r)
-      if (EPL * lane + r < n) vals[beg + EPL * lane + r] = v[r];
+      if (EPL * lane + r < n) {
+        vals[beg + EPL * lane + r] = v[r];
+        if (low_out != nullptr) low_out[beg + EPL * lane + r] = int32_t(int64_t(v[r]) & 0xFFFFFFFFll);
+      }
   }
-  sort_long_rows<T>(rowptr, n_rows, vals, buf);             // rows of more than 256 entries, a workgroup per row
+  sort_long_rows<T>(rowptr, n_rows, vals, buf, low_out);    // rows of more than 256 entries, a workgroup per row
 }
 
 // per extended node: original actor, source mask, recurrence iteration to keep; slots of the agent rows
@@ -611,11 +621,10 @@ static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* row
   TS_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, deg, rowptr, N + 1, st));
   if (E > 0 && lane_pack == nullptr) {
     k_scatter<<<cdiv(E, 256), 256, 0, st>>>(ei, E, rowptr, deg, out, 0);
-    k_row_sort<int32_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, out);
+    k_row_sort<int32_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, out, nullptr);
   } else if (E > 0) {
     k_scatter_lane<<<cdiv(E, 256), 256, 0, st>>>(ei, E, rowptr, deg, lane_pack);
-    k_row_sort<int64_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, lane_pack);
-    k_unpack_eid<<<cdiv(E, 256), 256, 0, st>>>(lane_pack, E, out);
+    k_row_sort<int64_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, lane_pack, out);     // also writes the edge ids
   }
   TS_LAUNCH_CHECK("build_csr");
   return TRAJSDE_OK;
