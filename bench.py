@@ -252,7 +252,11 @@ def main():
 
     wl = Workload(args.workload)
     with torch.no_grad():
-        for i in range(args.warmup):
+        # W untimed steps -- and never fewer than two per stream: the first step of a stream sizes its buffers, the second is the
+        # first to run while the previous one's buffers are still alive; leaving that to the timed region put a 100-200 ms
+        # allocator stall into its first window on some boxes
+        warm_steps = max(args.warmup, 2 * n_streams)
+        for i in range(warm_steps):
             wl.step(i)
         sync_all()
         lib.trajsde_profile_mode(1)                                           # events around the dominant kernel only
@@ -294,7 +298,8 @@ def main():
                        "scenes_per_gpu": wl.scenes, "agents_per_scene": wl.skw["n"], "num_modes": spec["num_modes"],
                        "future_steps": spec["future_steps"], "aa_edges_per_step": int(e_aa), "parallelism": f"scene-shard x{world}",
                        "streams_per_gpu": n_streams, "rccl_ranks_seen": rccl_ranks, "sync_free_forward": bool(runtime_mod.sync_free())},
-            "timing": {"windows_ms": [1e3 * w for w in windows], "reported": "median window", "steps_per_window": args.steps},
+            "timing": {"windows_ms": [1e3 * w for w in windows], "reported": "median window", "steps_per_window": args.steps,
+                       "untimed_warmup_steps_run": warm_steps},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
