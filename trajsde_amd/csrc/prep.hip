@@ -451,11 +451,6 @@ __global__ void k_g_compact(int E, int TT, int tref, const int32_t* __restrict__
   g_src[q] = s;
   g_dst[q] = i;
 }
-__global__ void k_segptr_from_rowptr(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cpos,
-                                     int32_t* __restrict__ segptr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i <= n) segptr[i] = cpos[rowptr[i]];
-}
 
 // lane feature (ENC:68-71); torch's negative index wraps when a lane is fully padded
 __device__ __forceinline__ void lane_feat_body(int l, int L, int P, const float* __restrict__ lp, const float* __restrict__ pad,
@@ -522,8 +517,17 @@ __global__ void k_la_compact(int E_al, const int32_t* __restrict__ actor, const 
   la_dst[q] = i;
   if (la_lane != nullptr) la_lane[q] = lane;
 }
+// the last launch of the graph stage: the segment pointers of the global and lane lists (positions of the row starts among the
+// survivors) and the three list lengths
 __global__ void k_collect_counts(int64_t n_aa, int E, int E_al, const int32_t* __restrict__ aa_segptr, const int32_t* __restrict__ cpos_g,
-                                 const int32_t* __restrict__ cpos_la, float radius, int32_t* __restrict__ counts) {
+                                 const int32_t* __restrict__ cpos_la, float radius, int32_t* __restrict__ counts, int N,
+                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ la_rowptr, int32_t* __restrict__ g_segptr,
+                                 int32_t* __restrict__ la_segptr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= N) {
+    g_segptr[i] = cpos_g[rowptr[i]];
+    la_segptr[i] = cpos_la[la_rowptr[i]];
+  }
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     counts[0] = 0;
     reinterpret_cast<float*>(counts)[4] = radius;
@@ -707,7 +711,6 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
     size_t tmp = size_t(w.cub_bytes);
     TS_HIP(scan_flags(w.cub_tmp, tmp, w.flags_g, w.cpos_g, E + 1, st));
   }
-  k_segptr_from_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, w.rowptr, w.cpos_g, w.g_segptr);
   // lane-actor edges grouped by actor
   {
     ProfScope ps("build_csr[lanes]", st);
@@ -718,8 +721,8 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
     size_t tmp = size_t(w.cub_bytes);
     TS_HIP(scan_flags(w.cub_tmp, tmp, w.flags_la, w.cpos_la, Ea + 1, st));
   }
-  k_segptr_from_rowptr<<<cdiv(N + 1, 256), 256, 0, st>>>(N, w.la_rowptr, w.cpos_la, w.la_segptr);
-  k_collect_counts<<<1, 64, 0, st>>>(w.n_aa, E, Ea, w.aa_segptr, w.cpos_g, w.cpos_la, radius, w.counts);
+  k_collect_counts<<<cdiv(N + 1, 256), 256, 0, st>>>(w.n_aa, E, Ea, w.aa_segptr, w.cpos_g, w.cpos_la, radius, w.counts, N, w.rowptr, w.la_rowptr,
+                                                     w.g_segptr, w.la_segptr);
   TS_LAUNCH_CHECK("graph_prepare kernels");
   int32_t h[4] = {0, 0, 0, 0};
   if (sync) {
