@@ -617,12 +617,41 @@ static int check_batch(const trajsde_batch* b) {
 }
 
 // CSR by target: degree histogram -> exclusive scan -> scatter -> canonical row order
+// exclusive prefix sum of up to 32 768 int32 by ONE workgroup (the row pointers of a batch: N + 1 counts) -- one launch of a few
+// microseconds where the device-wide scan is two
+__global__ __launch_bounds__(1024) void k_scan_small(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n) {
+  __shared__ int32_t wsum[16];
+  const int per = (n + 1023) / 1024, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int beg = t * per, end = beg + per < n ? beg + per : n;
+  int32_t s = 0;
+  for (int i = beg; i < end; ++i) s += in[i];
+  int32_t inc = s;                                          // inclusive scan of the threads' sums inside the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int32_t o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  int32_t base = 0;
+  for (int w = 0; w < wv; ++w) base += wsum[w];
+  int32_t run = base + inc - s;                             // exclusive prefix of this thread's first element
+  for (int i = beg; i < end; ++i) {
+    const int32_t v = in[i];
+    out[i] = run;
+    run += v;
+  }
+}
 // (deg arrives zeroed)
 static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* rowptr, int32_t* out, int64_t* lane_pack,
                      void* cub_tmp, int64_t cub_bytes, hipStream_t st) {
   if (E > 0) k_degree<<<cdiv(E, 256), 256, 0, st>>>(ei, E, deg);
-  size_t tmp = size_t(cub_bytes);
-  TS_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, deg, rowptr, N + 1, st));
+  if (N + 1 <= 32768) {
+    k_scan_small<<<1, 1024, 0, st>>>(deg, rowptr, N + 1);
+  } else {
+    size_t tmp = size_t(cub_bytes);
+    TS_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, deg, rowptr, N + 1, st));
+  }
   if (E > 0 && lane_pack == nullptr) {
     k_scatter<<<cdiv(E, 256), 256, 0, st>>>(ei, E, rowptr, deg, out, 0);
     k_row_sort<int32_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, out, nullptr);
