@@ -73,11 +73,13 @@ __global__ void k_scatter_lane(const int64_t* __restrict__ lai, int E, const int
 // beyond the row is a no-op: correct for any row length without materialising the padding.
 template <typename T>
 __device__ __forceinline__ void sort_long_rows(const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals, T* buf /* LDS, 4096 */,
-                                               int32_t* __restrict__ low_out) {
+                                               int32_t* __restrict__ low_out, int32_t* __restrict__ row_out) {
   const T INF = sizeof(T) == 8 ? T(INT64_MAX) : T(INT32_MAX);
   for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
     const int beg = rowptr[row], n = rowptr[row + 1] - beg;
     if (n <= 256) continue;                                 // (sorted by a wave in the first phase)
+    if (row_out != nullptr)
+      for (int i = threadIdx.x; i < n; i += blockDim.x) row_out[beg + i] = row;
     int P = 2;
     while (P < n) P <<= 1;
     if (P <= 4096) {
@@ -143,7 +145,8 @@ __device__ __forceinline__ T lane_xor(T v, int mask) {
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals,
-                                                  int32_t* __restrict__ low_out /* or null: the low words of the sorted values (edge ids of packed lane keys) */) {
+                                                  int32_t* __restrict__ low_out /* or null: the low words of the sorted values (edge ids of packed lane keys) */,
+                                                  int32_t* __restrict__ row_out /* or null: the row of every position (its target) */) {
   __shared__ T buf[4096];
   constexpr int EPL = 4, PMAX = 64 * EPL;
   const T INF = sizeof(T) == 8 ? T(INT64_MAX) : T(INT32_MAX);
@@ -151,6 +154,11 @@ __global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ ro
   for (int row = blockIdx.x * waves + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * waves) {
     const int beg = rowptr[row], n = rowptr[row + 1] - beg;
     if (n > PMAX) continue;
+    if (row_out != nullptr) {
+#pragma unroll
+      for (int r = 0; r < EPL; ++r)
+        if (64 * r + lane < n) row_out[beg + 64 * r + lane] = row;
+    }
     if (n <= 1) {
       if (n == 1 && low_out != nullptr && lane == 0) low_out[beg] = int32_t(int64_t(vals[beg]) & 0xFFFFFFFFll);
       continue;
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ ro
         if (low_out != nullptr) low_out[beg + EPL * lane + r] = int32_t(int64_t(v[r]) & 0xFFFFFFFFll);
       }
   }
-  sort_long_rows<T>(rowptr, n_rows, vals, buf, low_out);    // rows of more than 256 entries, a workgroup per row
+  sort_long_rows<T>(rowptr, n_rows, vals, buf, low_out, row_out);    // rows of more than 256 entries, a workgroup per row
 }
 
 // per extended node: original actor, source mask, recurrence iteration to keep; slots of the agent rows
@@ -419,20 +427,12 @@ __global__ __launch_bounds__(256) void k_aa_fill(int N, int Nt, int H, int TT, c
 
 // ---------------------------------------------------------------------------------------------- global / lane edges
 // global interactor edges: both endpoints valid at the reference step (AGG:41)
-__global__ void k_g_flags(int E, int N, int TT, int tref, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_src,
-                          const uint8_t* __restrict__ pad, int32_t* __restrict__ csr_dst, uint8_t* __restrict__ flags) {
+__global__ void k_g_flags(int E, int TT, int tref, const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_dst,
+                          const uint8_t* __restrict__ pad, uint8_t* __restrict__ flags) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > E) return;
   uint8_t keep = 0;
-  if (p < E) {
-    int lo = 0, hi = N;                                                    // row of position p: last i with rowptr[i] <= p
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (rowptr[mid] <= p) lo = mid; else hi = mid - 1;
-    }
-    csr_dst[p] = lo;
-    keep = !pad[int64_t(csr_src[p]) * TT + tref] && !pad[int64_t(lo) * TT + tref];
-  }
+  if (p < E) keep = !pad[int64_t(csr_src[p]) * TT + tref] && !pad[int64_t(csr_dst[p]) * TT + tref];   // csr_dst: written by the row sort
   flags[p] = keep;
 }
 __global__ void k_g_compact(int E, int TT, int tref, const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_dst,
@@ -643,8 +643,9 @@ __global__ __launch_bounds__(1024) void k_scan_small(const int32_t* __restrict__
   }
 }
 // (deg arrives zeroed)
+// dst_out (or null): the target of every CSR position (the row it lies in), for the passes that walk positions, not rows
 static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* rowptr, int32_t* out, int64_t* lane_pack,
-                     void* cub_tmp, int64_t cub_bytes, hipStream_t st) {
+                     void* cub_tmp, int64_t cub_bytes, hipStream_t st, int32_t* dst_out = nullptr) {
   if (E > 0) k_degree<<<cdiv(E, 256), 256, 0, st>>>(ei, E, deg);
   if (N + 1 <= 32768) {
     k_scan_small<<<1, 1024, 0, st>>>(deg, rowptr, N + 1);
@@ -654,10 +655,10 @@ static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* row
   }
   if (E > 0 && lane_pack == nullptr) {
     k_scatter<<<cdiv(E, 256), 256, 0, st>>>(ei, E, rowptr, deg, out, 0);
-    k_row_sort<int32_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, out, nullptr);
+    k_row_sort<int32_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, out, nullptr, dst_out);
   } else if (E > 0) {
     k_scatter_lane<<<cdiv(E, 256), 256, 0, st>>>(ei, E, rowptr, deg, lane_pack);
-    k_row_sort<int64_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, lane_pack, out);     // also writes the edge ids
+    k_row_sort<int64_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, lane_pack, out, nullptr);   // also writes the edge ids
   }
   TS_LAUNCH_CHECK("build_csr");
   return TRAJSDE_OK;
@@ -706,7 +707,7 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
   TS_HIP(hipMemsetAsync(w.deg, 0, size_t(2) * (N + 1) * sizeof(int32_t), st));       // actor and lane degree counters
   {
     ProfScope ps("build_csr[actors]", st);
-    if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.csr_src, nullptr, w.cub_tmp, w.cub_bytes, st)) return rc;
+    if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.csr_src, nullptr, w.cub_tmp, w.cub_bytes, st, w.csr_dst)) return rc;
   }
   {
     InputPassArgs ia;
@@ -723,7 +724,7 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
   }
   if (A > 0) k_agent_slots<<<cdiv(A, 256), 256, 0, st>>>(A, b->agent_index, w.pick_slot);    // after the table: overrides its -1 entries
   // global interactor edges (also names the target of every CSR position: csr_dst)
-  k_g_flags<<<cdiv(E + 1, 256), 256, 0, st>>>(E, N, TT, H - 1, w.rowptr, w.csr_src, b->padding_mask, w.csr_dst, w.flags_g);
+  k_g_flags<<<cdiv(E + 1, 256), 256, 0, st>>>(E, TT, H - 1, w.csr_src, w.csr_dst, b->padding_mask, w.flags_g);
   // 21 snapshots: survivor ballots -> segment lengths -> prefix sum -> segment pointers
   if (E > 0) {
     const int lds_b = 4 * 64 * (H | 1) * int(sizeof(float2));              // (67 KB at H = 32: TS_LAUNCH raises the dynamic-LDS limit)
