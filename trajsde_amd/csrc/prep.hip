@@ -484,18 +484,11 @@ __global__ __launch_bounds__(256) void k_input_passes(const InputPassArgs a) {
   else if (blk < a.b3) valid_mask_body((blk - a.b2) * 256 + threadIdx.x, a.N, a.H, a.TT, a.pad, a.vmask);
   else lane_feat_body((blk - a.b3) * 256 + threadIdx.x, a.L, a.P, a.lane_pos, a.lane_pad, a.lane_feat);
 }
-__global__ void k_la_flags(int E_al, int N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ eid,
-                           const float* __restrict__ vec, float radius, int32_t* __restrict__ actor, uint8_t* __restrict__ flags) {
+__global__ void k_la_flags(int E_al, const int32_t* __restrict__ eid, const float* __restrict__ vec, float radius, uint8_t* __restrict__ flags) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > E_al) return;
   uint8_t keep = 0;
-  if (p < E_al) {
-    int lo = 0, hi = N;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (rowptr[mid] <= p) lo = mid; else hi = mid - 1;
-    }
-    actor[p] = lo;
+  if (p < E_al) {                                          // (the actor of every position: written by the row sort)
     const float vx = vec[2 * int64_t(eid[p])], vy = vec[2 * int64_t(eid[p]) + 1];
     keep = sqrtf(norm2_sq(vx, vy)) < radius;                                                  // ENC:198
   }
@@ -658,7 +651,7 @@ static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* row
     k_row_sort<int32_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, out, nullptr, dst_out);
   } else if (E > 0) {
     k_scatter_lane<<<cdiv(E, 256), 256, 0, st>>>(ei, E, rowptr, deg, lane_pack);
-    k_row_sort<int64_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, lane_pack, out, nullptr);   // also writes the edge ids
+    k_row_sort<int64_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, lane_pack, out, dst_out);   // also writes the edge ids
   }
   TS_LAUNCH_CHECK("build_csr");
   return TRAJSDE_OK;
@@ -744,9 +737,9 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
   // lane-actor edges grouped by actor
   {
     ProfScope ps("build_csr[lanes]", st);
-    if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_eid, w.la_pack, w.cub_tmp, w.cub_bytes, st)) return rc;
+    if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_eid, w.la_pack, w.cub_tmp, w.cub_bytes, st, w.la_actor)) return rc;
   }
-  k_la_flags<<<cdiv(Ea + 1, 256), 256, 0, st>>>(Ea, N, w.la_rowptr, w.la_eid, b->lane_actor_vectors, radius, w.la_actor, w.flags_la);
+  k_la_flags<<<cdiv(Ea + 1, 256), 256, 0, st>>>(Ea, w.la_eid, b->lane_actor_vectors, radius, w.flags_la);
   {
     size_t tmp = size_t(w.cub_bytes);
     TS_HIP(scan_flags(w.cub_tmp, tmp, w.flags_la, w.cpos_la, Ea + 1, st));
