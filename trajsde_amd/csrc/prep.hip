@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void k_aa_fill(int N, int Nt, int H, int TT, c
   const int b0 = beg >> 6, b1 = (end - 1) >> 6;
   const f4 R = *reinterpret_cast<const f4*>(rot + 4 * o);
   const float2* pd_row = reinterpret_cast<const float2*>(pos) + int64_t(o) * TT;
-  for (int t = 0; t < H; ++t) {
+  for (int t = blockIdx.y; t < H; t += gridDim.y) {                        // gridDim.y waves share a node's snapshots: more gathers in flight
     const int seg = t * Nt + node;
     const int base = segptr[seg], n = segptr[seg + 1] - base;
     if (n == 0) continue;                                                  // (uniform)
@@ -794,7 +794,8 @@ int trajsde_graph_compact(const trajsde_batch* b, const float* rot, void* ws, in
   const int N = b->N, A = b->A, E = b->E, H = b->H, TT = b->TT, Ea = b->E_al, Nt = N + A;
   const bool want_src = g_export_senders.load() != 0;                      // sender ids are for checking the index work only
   { ProfScope ps("k_aa_fill", st);
-  k_aa_fill<<<xcd_grid(cdiv(Nt, 4)), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, w.bal, w.aa_segptr, b->positions, b->x, rot, e.aa_dst,
+  static const int fill_parts = []() { const char* e = getenv("TRAJSDE_FILL_PARTS"); const int v = e ? atoi(e) : 7; return v >= 1 && v <= 32 ? v : 7; }();   // 94 us at 1, 80 at 3, 79 at 7, 84 at 21 (32 x 256 agents)
+  k_aa_fill<<<dim3(xcd_grid(cdiv(Nt, 4)), fill_parts), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, w.bal, w.aa_segptr, b->positions, b->x, rot, e.aa_dst,
                                    want_src ? e.aa_src : nullptr, e.aa_geom); }
   if (E > 0)
     k_g_compact<<<cdiv(E, 256), 256, 0, st>>>(E, TT, H - 1, w.csr_src, w.csr_dst, b->positions, rot, b->rotate_angles, w.flags_g,
