@@ -218,7 +218,9 @@ __device__ __forceinline__ void seg_flush(const SegState& S, float* __restrict__
 // NT: row tiles per wave (streams per wave = 16 NT); a workgroup walks 256 streams.  Shipped: 8 waves x 2 tiles, two waves per
 // SIMD.  (Measured alternatives, 32 x 256 agents: 4 waves x 4 tiles at one wave per SIMD -- every weight fragment feeding 12
 // matrix instructions, accumulators in AGPRs -- 0.575 ms per launch against 0.47 ms; 4 waves x 2 tiles 0.60 ms.)
-template <int NT, bool DROP, bool SAVE>
+// LIST (0: agent-agent, 1: agent-lane) only names the instantiation, so that a kernel trace lists the two launches of a forward
+// -- 6.85 M edges and 0.2 M edges on the metric workload -- separately.
+template <int NT, bool DROP, bool SAVE, int LIST>
 __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restrict__ img_g, const float* __restrict__ geom,
                                                           const int32_t* __restrict__ dst, const float* __restrict__ q, EdgeCount ec, int C_host,
                                                           float* __restrict__ rec, int heads, const int32_t* __restrict__ segptr, DropArg drop,
@@ -335,11 +337,16 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
   for (int t = 0; t < NT; ++t)
     if (cur[t] >= 0) seg_flush(S[t], rec, int64_t(cur[t]) + sid[t], L.g);
 }
-template __global__ void k_edge_attn2<2, false, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<1, false, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<2, true, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<2, false, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<2, true, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, false, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, false, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<1, false, false, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<1, false, false, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, false, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, false, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, true, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, true, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, true, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, true, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 
 // records of one target -> agg row.  One wave per target, lane = feature f (jt = f>>4, g = (f>>2)&3); a target's records sit
 // at slots target + (first stream .. last stream) of its segment and are combined in that order.

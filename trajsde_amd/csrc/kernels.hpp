@@ -56,7 +56,7 @@ inline AttnPlan attn_plan(int64_t E, int streams_target = SEG_STREAMS_512) {
   p.nstreams = (E + p.C - 1) / p.C;
   return p;
 }
-template <int NT, bool DROP, bool SAVE>
+template <int NT, bool DROP, bool SAVE, int LIST>
 __global__ void k_edge_attn2(const float* img, const float* geom, const int32_t* dst, const float* q, EdgeCount ec, int C, float* rec, int heads,
                              const int32_t* segptr, DropArg drop, float* emb_out);
 // host side of the fused edge attention (stages.hip): k_edge_attn2 + k_seg_merge -> agg [R,64]; the training path also asks

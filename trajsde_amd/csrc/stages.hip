@@ -134,7 +134,8 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
     const int grid = xcd_grid((streams + 255) / 256);
     const int lds = (EdgeL6F::LDS_SIZE + 256 * 64) * 4;                      // weight image + the parked query rows of 256 streams (64 KB)
     const bool d = drop.p > 0.f, sv = emb_out != nullptr;
-#define TS_EA2(N_, D_, S_) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<N_, D_, S_>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
+#define TS_EA2L(N_, D_, S_, L_) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<N_, D_, S_, L_>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
+#define TS_EA2(N_, D_, S_) do { if (dominant) TS_EA2L(N_, D_, S_, 0); else TS_EA2L(N_, D_, S_, 1); } while (0)
 #define TS_EA3(D_, S_) if (edge_pingpong()) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn3<D_, S_, true>), grid, threads, lds, st, img + EdgeL6F::SIZE, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out); else TS_LAUNCH_TAG(tag, dominant, (k_edge_attn3<D_, S_, false>), grid, threads, lds, st, img + EdgeL6F::SIZE, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
     if (edge_tile32()) {
 #if TSDE_SPLIT_H3
@@ -144,7 +145,8 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
       else TS_EA3(false, false);
 #endif
     } else if (fused_one_tile() && !d && !sv) {
-      TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<1, false, false>), grid, 1024, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out);
+      if (dominant) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<1, false, false, 0>), grid, 1024, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out);
+      else TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<1, false, false, 1>), grid, 1024, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out);
     } else {
       if (d && sv) TS_EA2(2, true, true);
       else if (d) TS_EA2(2, true, false);
@@ -152,6 +154,7 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
       else TS_EA2(2, false, false);
     }
 #undef TS_EA2
+#undef TS_EA2L
 #undef TS_EA3
   }
   // inference with the default record layout: the consumer of the aggregate (k_node_update) merges the records itself
