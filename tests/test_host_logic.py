@@ -168,6 +168,106 @@ def test_flat_training_matches_per_parameter_adamw_on_cpu():
     assert flat.a.data_ptr() == ft.flat_param.data_ptr()                  # the parameters ARE slices of the flat tensor
 
 
+def test_flat_training_checkpoints_hold_the_reference_optimizer_layout(tmp_path):
+    """`optimizer_states[0]` of a checkpoint written by the loop is what `AdamW(model.parameters())` (MODEL:205) holds after
+    the same steps -- per parameter, indexed in `parameters()` order, no entry for parameters without a gradient -- so a
+    reference / Lightning checkpoint resumes here and ours resumes there; the one-tensor layout written by earlier versions
+    of the loop still loads; a state of another architecture is refused with a clear message"""
+    import torch
+    from trajsde_amd import driver
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(4)
+            self.a = torch.nn.Parameter(torch.randn(5, 3, generator=g))
+            self.unused = torch.nn.Parameter(torch.randn(4, generator=g))       # between the optimised ones in parameters() order
+            self.b = torch.nn.Parameter(torch.randn(7, generator=g))
+            self.lr, self.weight_decay, self.T_max = 1e-2, 1e-1, 5
+
+        def params_with_gradient(self):
+            return [self.a, self.b]
+
+        def loss(self, i):
+            return ((self.a * (i + 1)).sum() ** 2 + (self.b ** 3).sum())
+
+    def run(model, handle, steps, first=0):
+        for i in range(first, first + steps):
+            handle.zero() if hasattr(handle, "zero") else handle.zero_grad()
+            model.loss(i).backward()
+            handle.step()
+
+    ref, ours = Toy(), Toy()
+    opt = torch.optim.AdamW(ref.parameters(), lr=ref.lr, weight_decay=ref.weight_decay)
+    ft = driver.FlatTraining(ours)
+    assert ft.optimizer_state_dict()["state"] == {}                             # nothing stepped yet
+    run(ref, opt, 2)
+    run(ours, ft, 2)
+    want, got = opt.state_dict(), ft.optimizer_state_dict()
+    assert sorted(got["state"]) == sorted(want["state"]) == [0, 2]              # `unused` (index 1) has no state, as in torch
+    assert got["param_groups"][0]["params"] == want["param_groups"][0]["params"] == [0, 1, 2]
+    for i in (0, 2):
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(got["state"][i][k], want["state"][i][k]) and got["state"][i][k].shape == want["state"][i][k].shape
+        assert float(got["state"][i]["step"]) == float(want["state"][i]["step"]) == 2.0
+    # through a file, the way train() does it; then both directions of a resume
+    ck = str(tmp_path / "ck.ckpt")
+    driver.save_checkpoint(ck, ours, ft, ft.scheduler, epoch=0, step=2)
+    saved = torch.load(ck)["optimizer_states"][0]
+    theirs = Toy()
+    theirs.load_state_dict(ours.state_dict())
+    opt2 = torch.optim.AdamW(theirs.parameters(), lr=ref.lr, weight_decay=ref.weight_decay)
+    opt2.load_state_dict(saved)                                                 # the reference's optimizer resumes our file
+    mine = Toy()
+    mine.load_state_dict(ref.state_dict())
+    ft2 = driver.FlatTraining(mine)
+    ft2.load_optimizer_state_dict(want)                                         # our loop resumes the reference's state
+    run(ref, opt, 2, first=2)
+    run(theirs, opt2, 2, first=2)
+    run(mine, ft2, 2, first=2)
+    for m in (theirs, mine):
+        assert torch.equal(m.a.detach(), ref.a.detach()) and torch.equal(m.b.detach(), ref.b.detach())
+    # legacy one-tensor layout
+    import copy
+    legacy = copy.deepcopy(ft.optimizer.state_dict())     # state_dict() hands out the live moment tensors
+    old = Toy()
+    old.load_state_dict(ours.state_dict())
+    ft3 = driver.FlatTraining(old)
+    ft3.load_optimizer_state_dict(legacy)
+    run(ours, ft, 1, first=2)
+    run(old, ft3, 1, first=2)
+    assert torch.equal(old.a.detach(), ours.a.detach()) and torch.equal(old.b.detach(), ours.b.detach())
+    # wrong architecture
+    bad = {"state": {}, "param_groups": [dict(want["param_groups"][0], params=[0, 1])]}
+    with pytest.raises(ValueError, match="not a checkpoint of this architecture"):
+        ft3.load_optimizer_state_dict(bad)
+
+
+def test_graph_stamp_accepts_inference_tensors():
+    """Lightning's validate / test loops run under torch.inference_mode(): the batch tensors moved to the device there (and
+    the rotate_mat the forward writes) track no version counter, and reading `_version` on them raises.  The graph cache's
+    input stamp must not: inference tensors are stamped by identity (version -1), ordinary ones by identity + version."""
+    import torch
+    from trajsde_amd.runtime import GraphContext
+    from trajsde_amd.synth import synth
+    plain = synth(S=1, n=4, L=2, F=5, box=40.0, seed=3)
+    plain["rotate_mat"] = torch.zeros(4, 2, 2)
+    s0 = GraphContext._input_stamp(plain)
+    plain["x"].add_(1.0)
+    s1 = GraphContext._input_stamp(plain)
+    assert s0 != s1 and s0[1:] == s1[1:]                                  # an in-place edit moves the stamp of that tensor only
+    with torch.inference_mode():
+        inf = synth(S=1, n=4, L=2, F=5, box=40.0, seed=3)
+        inf["rotate_mat"] = torch.zeros(4, 2, 2)
+        assert inf["x"].is_inference()
+        with pytest.raises(RuntimeError):
+            inf["x"]._version
+        a = GraphContext._input_stamp(inf)
+        assert all(e is None or e[1] == -1 for e in a)
+        assert a == GraphContext._input_stamp(inf)
+    assert a == GraphContext._input_stamp(inf)                            # also readable outside the mode
+
+
 def test_squared_radius_threshold_selects_exactly_the_sqrt_survivors():
     """the snapshot pass tests  d2 < T  instead of  sqrt(d2) < radius  (UTIL:88): T is the smallest float32 whose correctly
     rounded square root reaches the radius, so both tests agree for EVERY float32 d2 -- checked on all values within a few

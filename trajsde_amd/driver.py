@@ -100,7 +100,8 @@ class FlatTraining:
     host time per step instead of ~2.5 ms of per-tensor bookkeeping -- which is what a slow host otherwise exposes once the
     GPU side of a training step is down to ~13 ms.  Parameters the losses do not reach keep `.grad = None` and are not in the
     optimizer, exactly what torch's AdamW does with them (it skips parameters without a gradient, weight decay included).
-    The optimizer state holds one tensor: it resumes our own checkpoints, not a per-parameter one."""
+    The optimizer state holds one tensor; checkpoints store it cut back into the per-parameter layout of the reference's
+    `AdamW(self.parameters())` (optimizer_state_dict / load_optimizer_state_dict), so either side resumes the other's."""
 
     def __init__(self, model) -> None:
         params = [p for p in model.params_with_gradient() if p.requires_grad]
@@ -112,6 +113,9 @@ class FlatTraining:
             p.data = self.flat_param.data[off:off + p.numel()].view_as(p)
             off += p.numel()
         self.params = params
+        self._named = list(model.named_parameters())
+        self._all_params = [p for _, p in self._named]       # the order of `AdamW(self.parameters())` (MODEL:205)
+        self._index = {id(p): i for i, p in enumerate(self._all_params)}
         self.grads = FlatGrads(params)                       # p.grad: slices of one gradient buffer, in the same order
         self.flat_param.grad = self.grads.flat
         self._stages = [m for m in model.modules() if hasattr(m, "touch")]
@@ -132,6 +136,73 @@ class FlatTraining:
         for m in self._stages:                               # the slices' version counters did not move: tell the weight packers
             m.touch()
 
+    # -- checkpoints: the optimizer state in the layout of `AdamW(model.parameters())` (MODEL:205) ----------------------
+    def optimizer_state_dict(self) -> dict:
+        """The state of the ONE flat tensor cut back into per-parameter entries, indexed like `model.parameters()` -- what
+        the reference's `configure_optimizers` (and a Lightning checkpoint of it) holds.  Parameters the losses do not reach
+        have no entry, as in torch (AdamW creates state on a parameter's first gradient)."""
+        sd = self.optimizer.state_dict()
+        group = dict(sd["param_groups"][0])
+        group["params"] = list(range(len(self._all_params)))
+        state = {}
+        flat_state = sd["state"].get(0)
+        if flat_state is not None:
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                state[self._index[id(p)]] = {
+                    "step": flat_state["step"].clone() if torch.is_tensor(flat_state["step"]) else flat_state["step"],
+                    "exp_avg": flat_state["exp_avg"][off:off + n].view_as(p).clone(),
+                    "exp_avg_sq": flat_state["exp_avg_sq"][off:off + n].view_as(p).clone()}
+                off += n
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        """accepts the per-parameter layout above (ours, the reference's, Lightning's) and the one-tensor layout this loop
+        wrote before it had a converter (one parameter in the group whose state is as long as the flat tensor)"""
+        groups = sd["param_groups"]
+        if len(groups) != 1:
+            raise ValueError(f"optimizer state has {len(groups)} parameter groups; the recipe of MODEL:204-207 has one")
+        n_flat = self.flat_param.numel()
+        legacy = len(groups[0]["params"]) == 1 and len(self._all_params) != 1
+        if legacy:
+            st = sd["state"].get(groups[0]["params"][0])
+            if st is not None and st["exp_avg"].numel() != n_flat:
+                raise ValueError(f"flat optimizer state of {st['exp_avg'].numel()} elements does not fit this model's "
+                                 f"{n_flat} optimised elements")
+            flat_sd = {"state": {} if st is None else {0: st}, "param_groups": [dict(groups[0], params=[0])]}
+            self.optimizer.load_state_dict(flat_sd)
+            return
+        if len(groups[0]["params"]) != len(self._all_params):
+            raise ValueError(f"optimizer state covers {len(groups[0]['params'])} parameters, the model has "
+                             f"{len(self._all_params)}: not a checkpoint of this architecture")
+        ids = groups[0]["params"]                                             # saved id of the i-th parameter
+        have = [ids[self._index[id(p)]] in sd["state"] for p in self.params]
+        if not any(have):
+            state = {}
+        else:
+            if not all(have):
+                missing = [n for n, p in self._named if id(p) in {id(q) for q, h in zip(self.params, have) if not h}]
+                raise ValueError(f"optimizer state lacks moments for optimised parameters: {missing[:4]} ...")
+            ref = self.flat_param
+            exp_avg = torch.empty(n_flat, device=ref.device, dtype=ref.dtype)
+            exp_avg_sq = torch.empty_like(exp_avg)
+            off, steps = 0, set()
+            for p in self.params:
+                st = sd["state"][ids[self._index[id(p)]]]
+                if st["exp_avg"].numel() != p.numel():
+                    raise ValueError("optimizer state shape mismatch for a parameter of %d elements" % p.numel())
+                exp_avg[off:off + p.numel()] = st["exp_avg"].reshape(-1).to(ref.device, ref.dtype)
+                exp_avg_sq[off:off + p.numel()] = st["exp_avg_sq"].reshape(-1).to(ref.device, ref.dtype)
+                steps.add(float(st["step"]))
+                off += p.numel()
+            if len(steps) != 1:
+                raise ValueError(f"parameters were stepped a different number of times ({sorted(steps)}): one flat tensor "
+                                 "has one step counter")
+            step = torch.tensor(steps.pop(), dtype=torch.float32)
+            state = {0: {"step": step, "exp_avg": exp_avg, "exp_avg_sq": exp_avg_sq}}
+        self.optimizer.load_state_dict({"state": state, "param_groups": [dict(groups[0], params=[0])]})
+
 
 class PlainTraining:
     """the same handle over the model's own `configure_optimizers()` (per-parameter optimizer, flat gradient bucket): for
@@ -149,6 +220,12 @@ class PlainTraining:
 
     def step(self) -> None:
         self.optimizer.step()
+
+    def optimizer_state_dict(self) -> dict:
+        return self.optimizer.state_dict()
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        self.optimizer.load_state_dict(sd)
 
 
 RANK_SEED_STRIDE = 1_000_003          # noise seeds of rank r: base + step + r * stride (distinct streams per rank)
@@ -171,9 +248,12 @@ def assert_equal_step_counts(batches) -> None:
 
 def save_checkpoint(path: str, model, optimizer, scheduler, epoch: int, step: int) -> None:
     """A Lightning-shaped checkpoint (`state_dict` at the top level like the reference's `ModelCheckpoint` files, so
-    either side loads the other's weights with `load_state_dict`), plus what the loop needs to resume."""
+    either side loads the other's weights with `load_state_dict`; `optimizer_states[0]` per parameter in the order of
+    `AdamW(self.parameters())`, MODEL:205), plus what the loop needs to resume.  `optimizer`: a FlatTraining /
+    PlainTraining handle (its per-parameter view is stored) or a plain torch optimizer."""
     tmp = path + ".tmp"
-    torch.save({"state_dict": model.state_dict(), "optimizer_states": [optimizer.state_dict()],
+    opt_state = optimizer.optimizer_state_dict() if hasattr(optimizer, "optimizer_state_dict") else optimizer.state_dict()
+    torch.save({"state_dict": model.state_dict(), "optimizer_states": [opt_state],
                 "lr_schedulers": [scheduler.state_dict()], "epoch": epoch, "global_step": step}, tmp)
     os.replace(tmp, path)
 
@@ -194,7 +274,7 @@ def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None, ckpt_p
     flat = FlatTraining(model) if recipe else PlainTraining(model)
     optimizer, scheduler = flat.optimizer, flat.scheduler
     if state is not None:
-        optimizer.load_state_dict(state["optimizer_states"][0])
+        flat.load_optimizer_state_dict(state["optimizer_states"][0])
         scheduler.load_state_dict(state["lr_schedulers"][0])
         first_epoch, step = int(state["epoch"]) + 1, int(state["global_step"])
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
@@ -220,7 +300,7 @@ def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None, ckpt_p
         if hasattr(model, "check_range"):
             model.check_range()
         if ckpt_path is not None and rank0:
-            save_checkpoint(ckpt_path, model, optimizer, scheduler, epoch, step)
+            save_checkpoint(ckpt_path, model, flat, scheduler, epoch, step)
     return history
 
 
@@ -257,6 +337,26 @@ def datamodule_batches(cfg: dict, device, rank: int = 0, world: int = 1, nu_dir=
     dm = resolve_class(dm_cfg["file_path"], dm_cfg["module_name"])(**kwargs)
     dm.setup("test")
     return dm.test_dataloader()
+
+
+def datamodule_train_batches(cfg: dict, device, rank: int = 0, world: int = 1, nu_dir=None, argo_dir=None):
+    """train.py:56-66: the YAML's data module, `setup('fit')`, its train loader.  Returns `per_epoch(epoch)` for `train()`:
+    the loader ITSELF, re-seeded for the epoch -- it is sized (`len()` honours the even padding over the ranks), which
+    `assert_equal_step_counts` needs; `iter(loader)` is a generator and is not."""
+    dm_cfg = cfg["datamodule_specific"]
+    kwargs = dict(dm_cfg["kwargs"], rank=rank, world_size=world, device=device)
+    if nu_dir:
+        kwargs["nu_dir"] = nu_dir
+    if argo_dir:
+        kwargs["Argo_dir"] = argo_dir
+    dm = resolve_class(dm_cfg["file_path"], dm_cfg["module_name"])(**kwargs)
+    dm.setup("fit")
+    loader = dm.train_dataloader()
+
+    def per_epoch(epoch):
+        loader.set_epoch(epoch)
+        return loader
+    return per_epoch
 
 
 def main() -> None:
@@ -300,19 +400,7 @@ def main() -> None:
     model = build_model(cfg, args.ckpt, dev, init_seed=0 if args.ckpt is None else None)
     if args.train:
         if args.data:
-            dm_cfg = cfg["datamodule_specific"]
-            kwargs = dict(dm_cfg["kwargs"], rank=rank, world_size=world, device=dev)
-            if args.nu_dir:
-                kwargs["nu_dir"] = args.nu_dir
-            if args.argo_dir:
-                kwargs["Argo_dir"] = args.argo_dir
-            dm = resolve_class(dm_cfg["file_path"], dm_cfg["module_name"])(**kwargs)
-            dm.setup("fit")
-            loader = dm.train_dataloader()
-
-            def per_epoch(epoch):
-                loader.set_epoch(epoch)
-                return iter(loader)
+            per_epoch = datamodule_train_batches(cfg, dev, rank, world, args.nu_dir, args.argo_dir)
         else:
             def per_epoch(epoch):
                 return synthetic_batches(args.synthetic, args.batches, dev, rank, world, even=True)

@@ -1,6 +1,7 @@
 """Host-side runtime of the stage modules: weight packing, workspaces, noise selection and the ctypes
 calls into libtrajsde_hip.so.  PyTorch is used for device memory and streams only."""
 import ctypes as C
+import itertools
 import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -58,6 +59,9 @@ class NoiseSpec:
         p = float(getattr(module, "dropout", 0.0) or 0.0)
         if not getattr(module, "training", False) or p <= 0.0:
             return None
+        if self.dropout_seed is None and self.seed_dev is not None:
+            raise _lib.TrajsdeError("train-mode dropout with a device-resident Philox key (seed_dev): the mask key is a host "
+                                    "value -- pass NoiseSpec(dropout_seed=...)")
         ds = self.seed if self.dropout_seed is None else self.dropout_seed
         return _lib.Dropout(C.c_float(p), C.c_uint64(int(ds) & 0xFFFFFFFFFFFFFFFF))
 
@@ -102,6 +106,10 @@ class GraphedForward:
                 model(data, noise=self.noise)
         torch.cuda.current_stream(x.device).wait_stream(side)
         torch.cuda.synchronize(x.device)
+        for mod in model.modules():                                          # every weight image is packed and the device is idle:
+            rt = getattr(mod, "_rt", None)                                   # drop the pack-done events, so that blob() does not
+            if isinstance(rt, StageRuntime):                                 # query one inside the capture (not capturable)
+                rt.packs_complete()
         if GraphContext.KEY in data:                                         # the capture must contain the graph stage itself
             del data[GraphContext.KEY]
         self.graph = torch.cuda.CUDAGraph()
@@ -293,6 +301,11 @@ class StageRuntime:
                 if cur.cuda_stream != packed_on:
                     cur.wait_event(ev)      # packed on another stream (multi-stream drivers): order the reads behind the pack
         return blob
+
+    def packs_complete(self) -> None:
+        """the caller has synchronised the device: no pack is in flight, nothing left to order reads against"""
+        for sid, (blob, stamp, ev, packed_on) in list(self._blobs.items()):
+            self._blobs[sid] = (blob, stamp, None, packed_on)
 
     # ---------------------------------------------------------------- decoder
     def decoder_forward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor,
@@ -686,6 +699,7 @@ class GraphContext:
 
     KEY = "_trajsde_graph"
     DEFAULT_RADIUS = 50.0
+    _DEVICE_KEY_TOKENS = itertools.count(1)
 
     def __init__(self, data, radius: float, H: int, noise: Optional[NoiseSpec], fake_agents: bool = True,
                  exact: bool = True) -> None:
@@ -802,7 +816,15 @@ class GraphContext:
         for k in ("x", "positions", "padding_mask", "bos_mask", "rotate_angles", "edge_index", "agent_index", "batch", "source",
                   "lane_positions", "lane_paddings", "lane_actor_index", "lane_actor_vectors", "rotate_mat"):
             t = data[k] if k in data else None
-            out.append((t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else None)
+            if not torch.is_tensor(t):
+                out.append(None)
+                continue
+            # inference tensors (a batch moved to the device under torch.inference_mode(), as Lightning's validate / test loops
+            # do) track no version counter -- reading it raises.  They are stamped by identity alone: the encoder rebuilds the
+            # graph whenever the noise key changes, i.e. on every forward with fresh noise, and the later stages of the SAME
+            # forward reuse it.
+            ver = -1 if t.is_inference() else t._version
+            out.append((t.data_ptr(), ver, tuple(t.shape)))
         return tuple(out)
 
     @classmethod
@@ -815,7 +837,11 @@ class GraphContext:
             gc = None                                                     # built without the sender ids: rebuild
         key = None
         if radius is not None and noise is not None:
-            key = (float(radius), int(noise.seed), id(noise.z_fake), id(noise.fake_row_ids), bool(fake_agents), cls._input_stamp(data))
+            # a device-resident key (NoiseSpec.seed_dev) can change without the host seeing it, and the fake agents' rows are
+            # drawn from it: such a graph is never reused across encoder calls (a fresh token per build request)
+            dev_key = None if noise.seed_dev is None else next(cls._DEVICE_KEY_TOKENS)
+            key = (float(radius), int(noise.seed), dev_key, id(noise.z_fake), id(noise.fake_row_ids), bool(fake_agents),
+                   cls._input_stamp(data))
         elif gc is not None and getattr(gc, "build_key", None) is not None and gc.build_key[-1] != cls._input_stamp(data):
             gc = None                                                     # the batch was edited since the encoder built the graph
         if gc is None or (key is not None and getattr(gc, "build_key", None) != key):
