@@ -105,7 +105,9 @@ def cpu_baseline(model, cfg, spec, gpu_loc_fn):
     # best one is the reported baseline
     all_threads = torch.get_num_threads()
     table, out = {}, None
-    for nt in sorted({1, 8, 16, 32, all_threads}):           # incl. torch's own default (all physical cores)
+    # (torch's own default -- all physical cores, 128 on the pool's hosts -- is NOT timed: it measured 3-4x slower than 16
+    #  threads on this many-small-ops workload and cost ~30 s of every bench run for a number nobody uses)
+    for nt in sorted({1, 8, 16, 32}):
         if nt > max(all_threads, 1):
             continue
         torch.set_num_threads(nt)
@@ -266,6 +268,17 @@ def main():
     e_aa = wl.e_aa()
     elapsed = float(np.median(windows))
     _lib.check_range()                                                        # no saturated fp16x3 operand in the timed forwards
+    # The same workload on ONE stream, on every rank: the dominant kernel's HIP events then bracket that kernel alone -- the
+    # figure a `--streams 1` rocprofv3 kernel trace reproduces (profiles/) and the one `roofline` reports.  With several
+    # streams the events also span whatever co-runs on the chip (`roofline_corun`).
+    with torch.no_grad():
+        for i in range(2):
+            wl.step(700 + i, single_stream=True)
+        lib.trajsde_profile_mode(1)
+        w1 = [timed_window(wl, args.steps, 800 + w * args.steps, single_stream=True) for w in range(3)]
+        lib.trajsde_profile_mode(0)
+    iso_n, iso_ms, _ = _lib.profile_report().get("k_edge_kv[aa]", (0, 0.0, True))
+    el1 = float(np.median(w1))
 
     def edge_roofline(n_launch, total_ms, e_aa_, streams_):
         avg_s = (total_ms / max(n_launch, 1)) * 1e-3
@@ -278,15 +291,19 @@ def main():
 
     if rank == 0:
         n_launch, total_ms, _ = prof.get("k_edge_kv[aa]", (0, 0.0, True))
-        roof = edge_roofline(n_launch, total_ms, e_aa, n_streams)
+        roof = edge_roofline(iso_n, iso_ms, e_aa, 1)                          # the kernel alone (one stream): what profiles/ reproduces
+        roof_corun = edge_roofline(n_launch, total_ms, e_aa, n_streams)       # inside the timed multi-stream region
         roof["traffic"] = None                                                # HBM bytes per launch are a PMC quantity: not measurable in this run
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if os.path.isfile(tpath):
-            with open(tpath) as f:
-                roof["traffic_profiled"] = dict(json.load(f).get("k_edge_kv[aa]", {}), source="profiles/r02_traffic.json (rocprofv3 --pmc "
-                                                "FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; NOT measured in this run)")
+        for tname in ("r03_traffic.json", "r02_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.isfile(tpath):
+                with open(tpath) as f:
+                    roof["traffic_profiled"] = dict(json.load(f).get("k_edge_kv[aa]", {}), source=f"profiles/{tname} (rocprofv3 --pmc "
+                                                    "FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; NOT measured in this run)")
+                break
         roof["peak_note"] = (f"algorithmic fp32 FLOP/s; peak = 2500 TFLOP/s dense 16-bit MFMA / {split_products} products per fp32 product; "
-                             "with several streams the events also see co-running kernels: `streams1.roofline` is the kernel alone")
+                             "HIP events of the one-stream pass of this run (the kernel alone on the chip); `roofline_corun` is the same "
+                             "kernel inside the timed multi-stream region, where the events also span co-running kernels")
         line = {
             "metric": "scenes/sec (K=6, 20 SDE steps, ~256 agents) at 1/2/4/8 MI355X; minADE match",
             "value": world * wl.scenes * args.steps / elapsed, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
@@ -301,7 +318,13 @@ def main():
             "timing": {"windows_ms": [1e3 * w for w in windows], "reported": "median window", "steps_per_window": args.steps,
                        "untimed_warmup_steps_run": warm_steps},
             "roofline": roof,
+            "roofline_corun": roof_corun,
+            "streams1": {"value": world * wl.scenes * args.steps / el1, "ms_per_step": 1e3 * el1 / args.steps,
+                         "windows_ms": [1e3 * w for w in w1], "what": "the same steps on one HIP stream per GPU"},
         }
+        if world > 1:                                                         # world-1-only legs: say so instead of leaving the keys out
+            for k in ("cpu_baseline", "minade_match", "graph_replay", "config2_64x128", "roofline_sde_step", "train_step"):
+                line[k] = "n/a (N>1): measured by the N=1 run"
         if not args.no_cpu_baseline and world == 1:
             def gpu_fn(b_cpu, seed):
                 b = b_cpu.to(dev)
@@ -313,17 +336,6 @@ def main():
             line["minade_match"] = match
     if not args.no_secondary and world == 1:
         with torch.no_grad():
-            # the same workload on ONE stream (host and launch gaps exposed), with the dominant kernel measured alone: the
-            # figure to hold against the rocprof kernel-trace summary of a --streams 1 run
-            for i in range(2):
-                wl.step(700 + i, single_stream=True)
-            lib.trajsde_profile_mode(1)
-            w1 = [timed_window(wl, args.steps, 800 + w * args.steps, single_stream=True) for w in range(3)]
-            lib.trajsde_profile_mode(0)
-            iso_n, iso_ms, _ = _lib.profile_report().get("k_edge_kv[aa]", (0, 0.0, True))
-            el1 = float(np.median(w1))
-            line["streams1"] = {"value": wl.scenes * args.steps / el1, "ms_per_step": 1e3 * el1 / args.steps, "windows_ms": [1e3 * w for w in w1],
-                                "roofline": edge_roofline(iso_n, iso_ms, e_aa, 1)}
             # the same steps as HIP-graph replays (runtime.GraphedForward: the whole forward incl. the graph stage captured per
             # stream, the Philox key read from device memory so every replay draws fresh noise): the GPU side is unchanged --
             # the forward is GPU-bound -- what it removes is the host's ~0.4 ms of launches per forward

@@ -10,7 +10,7 @@ import json, sys
 d = json.loads(sys.stdin.readline())
 s1 = d['streams1']
 print('$which', 'scenes/s %.0f' % d['value'], '| 1 stream %.0f (%.3f ms)' % (s1['value'], s1['ms_per_step']),
-      '| edge kernel alone %.4f ms frac %.3f' % (s1['roofline']['avg_launch_ms'], s1['roofline']['frac']),
+      '| edge kernel alone %.4f ms frac %.3f' % (d['roofline']['avg_launch_ms'], d['roofline']['frac']),
       '| graph %.0f' % d['graph_replay']['value'], '| 64x128 %.0f' % d['config2_64x128']['value'])"
   done
 done

@@ -115,7 +115,12 @@ def main():
                                          "achieved_GBps": rows * 128 * elem / (sms * 1e-3) / 1e9,
                                          "frac_of_8TBps": rows * 128 * elem / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                          "TFLOPps": rows * 41.8e3 / (sms * 1e-3) / 1e12},
-                        "finite": bool(torch.isfinite(out["loc"]).all())}
+                        "finite": bool(torch.isfinite(out["loc"]).all()),
+                        # accuracy class of this storage type against the CPU oracle (what tests/test_gpu_parity.py pins):
+                        # fp32 storage is the 1e-4 north-star path; bf16 storage rounds every intra-stage row to 8 mantissa bits
+                        "parity_level": {"fp32": {"max_abs_loc_vs_oracle_bound": 1e-4, "class": "north-star parity (fp32 state)"},
+                                         "bf16": {"max_abs_loc_vs_oracle_bound": 5e-2, "class": "bf16 state storage: ~200x looser than the "
+                                                  "fp32-state path (measured 2.1e-2 on 3.8 m trajectories at this shape); inference only"}}[storage]}
         del ya, yb
     runtime.set_state_storage("fp32")
     _lib.check_range()
