@@ -167,6 +167,27 @@ template __global__ void k_edge_kv2<768>(const float*, const float*, const int32
 // segment lies inside one chunk produces one record; one that straddles a chunk boundary produces one per chunk it touches.
 // k_seg_merge (one wave per target, lane = feature) combines them in stream order and normalises like PyG's softmax
 // (sum + 1e-16).  The chunking depends only on E, so results are bitwise reproducible and independent of the input edge order.
+#ifdef TSDE_EDGE_STAMPS
+// Diagnostic build only (tools/edge_phase_stamps.py): cycles (s_memtime) that one wave of every workgroup spends in each phase of
+// an iteration of k_edge_attn2, summed over the launch.  The stamp's own s_waitcnt drains the wave's LDS queue at every mark, so
+// the total runs a little slower than the shipped kernel; the shares are what it is for.
+__device__ unsigned long long g_edge_stamps[16];
+__device__ unsigned long long g_edge_wg[4 * 512];
+struct PhaseStamps {
+  unsigned long long last, real0, acc[12];
+  __device__ __forceinline__ void start() {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0;
+    last = __builtin_amdgcn_s_memtime();
+    real0 = __builtin_amdgcn_s_memrealtime();
+  }
+  __device__ __forceinline__ void mark(int i) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    acc[i] += t - last;
+    last = t;
+  }
+};
+#endif
 struct SegState {
   f4 acc[4], m, s;
 };
@@ -266,6 +287,12 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
     ng[t] = *reinterpret_cast<const f4*>(geom + 4 * c);
     nd[t] = dst[c];
   }
+#ifdef TSDE_EDGE_STAMPS
+  PhaseStamps st;
+  st.start();
+#else
+  NoStamps st;
+#endif
   for (int it = 0; it < C; ++it) {
     keep_lds_reads_here();
     f4 ge[NT];
@@ -273,10 +300,16 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
     bool ok[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int64_t e = base_e[t] + it;
-      ok[t] = e < E;                                       // only the last stream is short; streams >= nstreams are empty
+      ok[t] = base_e[t] + it < E;                          // only the last stream is short; streams >= nstreams are empty
       ge[t] = ng[t];
       d[t] = nd[t];
+      // the loads of the previous iteration are consumed HERE, before this iteration issues anything: the compiler's counted
+      // waits further down would otherwise also cover the query-row transfers below, which it does not know about
+      asm volatile("" : "+v"(ge[t]), "+v"(d[t]));
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int64_t e = base_e[t] + it;
       const int64_t c = e + 1 < E ? e + 1 : E - 1;         // (one past a stream's end: loaded, never used)
       ng[t] = *reinterpret_cast<const f4*>(geom + 4 * c);
       nd[t] = dst[c];
@@ -288,14 +321,37 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
         seg_reset(S[t]);
         cur[t] = d[t];
         if (DROP) rank0[t] = segptr[d[t]];
-        f4 qn[4];
-        load_row(qn, q, d[t], L.g);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(qs + ((4 * t + jt) * 64 + L.lane) * 4) = qn[jt];
+        // the new target's query row goes from L2 straight into the lane's LDS slots (global_load_lds_dwordx4: lane l's 16 bytes land
+        // at the wave-uniform base + 16 l, which IS the slot layout [tile][jt][lane][4]): no registers, and nothing waits for it
+        // until the logits at the end of the iteration (s_waitcnt vmcnt there)
+        const float* qrow = q + int64_t(d[t]) * D + 4 * L.g;
+        // (through assembly: given the builtin, the compiler orders every later LDS read of the kernel -- the weight fragments --
+        //  behind the transfer with s_waitcnt vmcnt(0), which is the very wait this is here to remove)
+        const unsigned slot = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>(
+            (__attribute__((address_space(3))) float*)(qs + 4 * t * 256))));
+        unsigned m0_keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %5\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, off\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %3, off\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %4, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(m0_keep)
+                     : "v"(qrow), "v"(qrow + 16), "v"(qrow + 32), "v"(qrow + 48), "s"(slot)
+                     : "memory", "scc");
       }
     }
+    st.mark(0);                                            // loads, target changes (record flush, query row)
     f4 emb[NT][4], kv[NT][8];
-    edge_embed_fused_n<NT>(emb, ge, lds, L);                // (y - mean) * rstd of the last LayerNorm; gamma / beta live downstream
+    edge_embed_fused_n<NT>(emb, ge, lds, L, st);            // (y - mean) * rstd of the last LayerNorm; gamma / beta live downstream
     if (SAVE) {                                            // the tape holds the embedding rows proper
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -321,6 +377,8 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
       }
     }
     linear_acc_x6_n<NT, 8, 4>(kv, emb, lds + EL::WKV, L.lane);
+    st.mark(8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the query rows sent to LDS at the top of the iteration have landed
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f4 qv[4];
@@ -328,15 +386,58 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
       for (int jt = 0; jt < 4; ++jt) qv[jt] = *reinterpret_cast<const f4*>(qs + ((4 * t + jt) * 64 + L.lane) * 4);
       const f4 k[4] = {kv[t][0], kv[t][1], kv[t][2], kv[t][3]};
       const f4 vv[4] = {kv[t][4], kv[t][5], kv[t][6], kv[t][7]};
-      const f4 lg = head_logits(qv, k, heads);
-      if (ok[t])
-        seg_update(S[t], lg, vv, DROP ? drop_attn_row(drop, uint32_t(d[t]), uint32_t(int(base_e[t] + it) - rank0[t]), L.g, heads) : one4);
+      f4 lg = head_logits(qv, k, heads);
+      // Branch-free: a row beyond the list (the tail of the last stream; rows of streams >= nstreams) enters with logit -inf --
+      // weight exp(-inf) = 0, running maximum and scale unchanged -- instead of skipping the update under an exec mask: one basic
+      // block, so the scheduler interleaves the two tiles' dependent chains (dot -> lane swaps -> max -> exp -> fma).  A row that
+      // never had an edge turns its state into NaNs (exp(-inf + inf)); it is never flushed (cur < 0).
+      if (!ok[t]) lg = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      seg_update(S[t], lg, vv, DROP ? drop_attn_row(drop, uint32_t(d[t]), uint32_t(int(base_e[t] + it) - rank0[t]), L.g, heads) : one4);
     }
+    st.mark(9);                                            // logits + online softmax
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t)
     if (cur[t] >= 0) seg_flush(S[t], rec, int64_t(cur[t]) + sid[t], L.g);
+#ifdef TSDE_EDGE_STAMPS
+  if (LIST == 0 && !DROP && !SAVE && (wave == 0 || wave == 5) && L.lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) atomicAdd(&g_edge_stamps[i], st.acc[i]);
+    atomicAdd(&g_edge_stamps[10], (unsigned long long)C);
+    const unsigned long long real = __builtin_amdgcn_s_memrealtime() - st.real0;
+    atomicAdd(&g_edge_stamps[11], real);                   // 100 MHz ticks over the same loop: the clock
+    atomicMax(&g_edge_stamps[12], real);                   // slowest / fastest stamped wave of the launches (10 ns units)
+    atomicMin(&g_edge_stamps[13], real);
+    atomicAdd(&g_edge_stamps[14], 1ull);
+    if (wave == 0) {                                       // per workgroup (last launch): loop time, phase-0 cycles, XCC, CU
+      unsigned xcc, hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      const int b = int(xcd_block()) & 511;
+      g_edge_wg[4 * b + 0] = real;
+      g_edge_wg[4 * b + 1] = st.acc[0];
+      g_edge_wg[4 * b + 2] = xcc;
+      g_edge_wg[4 * b + 3] = hwid;
+    }
+  }
+#endif
 }
+#ifdef TSDE_EDGE_STAMPS
+}  // namespace tsde
+extern "C" int trajsde_debug_edge_stamps(unsigned long long* host16, int reset) {
+  if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(tsde::g_edge_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    z[13] = ~0ull;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(tsde::g_edge_stamps), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+extern "C" int trajsde_debug_edge_wg(unsigned long long* host2048) {
+  return hipMemcpyFromSymbol(host2048, HIP_SYMBOL(tsde::g_edge_wg), 4 * 512 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+namespace tsde {
+#endif
 template __global__ void k_edge_attn2<2, false, false, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<2, false, false, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<1, false, false, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);

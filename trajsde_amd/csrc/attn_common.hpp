@@ -68,10 +68,37 @@ __device__ __forceinline__ void edge_embed2_x6(f4 (&emb0)[4], f4 (&emb1)[4], con
 // The embedding for the fused edge-attention kernel, on its own image (layouts.hpp EdgeL6F), for the NT row tiles of one wave: the
 // two matrix layers hand out feature-centred rows, so each LayerNorm is one variance reduction, and the last LayerNorm stops at
 // (y - mean) * rstd -- its gamma sits in the lin_k | lin_v image, its beta in the per-target constants.  nrm: those normalised rows.
-template <int NT>
-__device__ __forceinline__ void edge_embed_fused_n(f4 (&nrm)[NT][4], const f4 (&ge)[NT], const float* lds, const Lane& L) {
+// ST: phase stamps of a diagnostic build (attn.hip, TSDE_EDGE_STAMPS); NoStamps compiles to nothing
+struct NoStamps {
+  __device__ __forceinline__ void mark(int) {}
+};
+template <int NT, class ST>
+__device__ __forceinline__ void edge_embed_fused_n(f4 (&nrm)[NT][4], const f4 (&ge)[NT], const float* lds, const Lane& L, ST& st) {
   using E = EdgeL6F;
   f4 a[NT][4], s[NT][4];
+#if TSDE_SPLIT_H3 && !defined(TSDE_IN2_VALU)
+  // the two first layers on the matrix cores (layouts.hpp IN2F): 4 matrix instructions per tile and branch instead of 48 fma
+  float xa[NT], xb[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    xa[t] = ge[t][0];
+    xb[t] = ge[t][1];
+    load_vec<4>(s[t], lds + E::B3, L.g);
+  }
+  in2_mfma_relu_n<NT>(a, xa, xb, lds + E::A_C, lds + E::A_F, L.lane);
+  st.mark(1);
+  linear_acc_x6_n<NT, 4, 4>(s, a, lds + E::WA3, L.lane);
+  st.mark(2);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    xa[t] = ge[t][2];
+    xb[t] = ge[t][3];
+  }
+  in2_mfma_relu_n<NT>(a, xa, xb, lds + E::B_C, lds + E::B_F, L.lane);
+  st.mark(3);
+  linear_acc_x6_n<NT, 4, 4>(s, a, lds + E::WB3, L.lane);
+  st.mark(4);
+#else
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     in2_ln_relu(a[t], ge[t][0], ge[t][1], lds + E::A_C, lds + E::A_E, L.g);
@@ -81,6 +108,7 @@ __device__ __forceinline__ void edge_embed_fused_n(f4 (&nrm)[NT][4], const f4 (&
 #pragma unroll
   for (int t = 0; t < NT; ++t) in2_ln_relu(a[t], ge[t][2], ge[t][3], lds + E::B_C, lds + E::B_E, L.g);
   linear_acc_x6_n<NT, 4, 4>(s, a, lds + E::WB3, L.lane);
+#endif
   float r[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) r[t] = centred_rstd(s[t]);
@@ -95,13 +123,21 @@ __device__ __forceinline__ void edge_embed_fused_n(f4 (&nrm)[NT][4], const f4 (&
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) load_vec<4>(nrm[t], lds + E::B2, L.g);
+  st.mark(5);
   linear_acc_x6_n<NT, 4, 4>(nrm, s, lds + E::W2, L.lane);
+  st.mark(6);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const float q = centred_rstd(nrm[t]);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) nrm[t][jt] *= q;
   }
+  st.mark(7);
+}
+template <int NT>
+__device__ __forceinline__ void edge_embed_fused_n(f4 (&nrm)[NT][4], const f4 (&ge)[NT], const float* lds, const Lane& L) {
+  NoStamps st;
+  edge_embed_fused_n<NT, NoStamps>(nrm, ge, lds, L, st);
 }
 
 // per-head logits of 16 edges: q.k over the dims of each head / sqrt(dh).

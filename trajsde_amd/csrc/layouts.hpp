@@ -54,6 +54,14 @@ constexpr int MAT64X6 = 6144;
 struct In2L {
   enum : int { GW0 = 0, GW1 = 64, GB = 128, CH = 192, SIZE = 200 };   // CH: l00 l10 l20 l11 l21 l22 (+2 pad)
 };
+// The same block as ONE matrix-core product per 16 output features (fp16x3 build; tile.hpp in2_mfma_relu_n): the pre-ReLU
+// activation  rstd (GW0 x0 + GW1 x1 + GB) + beta  is an inner product over 14 of the 32 k-slots of a 16x16x32 step,
+//   row operand (every lane of a row alike):  x0r_h x1r_h x0r_l x1r_l r_h r_l 1 1      (x0r = x0 rstd, ..; h / l fp16 pieces)
+//   fragment, lane group 0:                   GW0_h GW1_h GW0_h GW1_h GB_h GB_h be_h be_l
+//   fragment, lane group 1:                   GW0_l GW1_l 0     0     GB_l 0    0    0        groups 2, 3: zeros
+// i.e. the three split-precision products h h + h l + l h of every term, exact in the fp32 accumulator.  4 fragments
+// [jo][lane][8] fp16 = 1024 floats replace 48 fma per 16 x 64 tile by 4 matrix instructions.
+constexpr int IN2F = 1024;
 struct EdgeL6 {
   enum : int {
     S_END = 0,
@@ -85,8 +93,9 @@ struct EdgeL6F {
     TS_FIELD(AG3, 64, B2), TS_FIELD(AE3, 64, AG3),                      // the embedding rows of the training tape only
     TS_FIELD(A_C, In2L::SIZE, AE3), TS_FIELD(B_C, In2L::SIZE, A_C),
     TS_FIELD(WKV, 2 * MAT64X6, B_C),
-    LDS_SIZE = WKV_END,
-    TS_FIELD(CK, 64, WKV), TS_FIELD(CV, 64, CK),
+    TS_FIELD(A_F, IN2F, WKV), TS_FIELD(B_F, IN2F, A_F),                 // the two first layers as matrix-core fragments (below)
+    LDS_SIZE = B_F_END,
+    TS_FIELD(CK, 64, B_F), TS_FIELD(CV, 64, CK),
     SIZE = CV_END
   };
 };

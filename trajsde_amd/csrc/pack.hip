@@ -42,7 +42,7 @@ struct PackJob {
   const float *src, *src2, *src3;
   float* dst;
 };
-enum PackKind { PK_VEC = 0, PK_COL, PK_MAT, PK_MAT_PAD, PK_MATT, PK_MAT6, PK_MAT6_STACK2, PK_SPLIT, PK_LN2, PK_MAT6_CENTRED, PK_VEC_CENTRED, PK_AFFINE, PK_MAT32 };
+enum PackKind { PK_VEC = 0, PK_COL, PK_MAT, PK_MAT_PAD, PK_MATT, PK_MAT6, PK_MAT6_STACK2, PK_SPLIT, PK_LN2, PK_MAT6_CENTRED, PK_VEC_CENTRED, PK_AFFINE, PK_MAT32, PK_IN2F };
 constexpr int PACK_JOBS_PER_LAUNCH = 48;        // 48 x 64 B: under the 4 KB kernel-argument limit
 struct PackJobs {
   PackJob j[PACK_JOBS_PER_LAUNCH];
@@ -226,6 +226,31 @@ __device__ __forceinline__ void k_pack_ln2(int i, const float* __restrict__ W, c
   }
 }
 
+// matrix-core fragments of a closed-form Linear(2,64)->LayerNorm block (layouts.hpp IN2F) from the In2L block `in2` packed by
+// an earlier pass and the LayerNorm's beta; dst (16-bit) [jo][lane][8]
+__device__ __forceinline__ void k_pack_in2f(int i, const float* __restrict__ in2, const float* __restrict__ beta,
+                                            unsigned short* __restrict__ dst) {
+  if (i >= 4 * 512) return;
+  const int j = i & 7, lane = (i >> 3) & 63, jo = i >> 9;
+  const int f = 16 * jo + (lane & 15), g = lane >> 4;
+  const float term[4] = {in2[In2L::GW0 + f], in2[In2L::GW1 + f], in2[In2L::GB + f], beta[f]};
+  float x = 0.f;
+  bool low = false;
+  if (g == 0) {                                            // GW0_h GW1_h GW0_h GW1_h GB_h GB_h be_h be_l
+    x = term[j < 4 ? (j & 1) : j < 6 ? 2 : 3];
+    low = j == 7;
+  } else if (g == 1 && (j < 2 || j == 4)) {                // GW0_l GW1_l 0 0 GB_l 0 0 0
+    x = term[j < 2 ? j : 2];
+    low = true;
+  }
+#if TSDE_SPLIT_H3
+  range_note(fabsf(x), RS_WEIGHT);
+#endif
+  const _Float16 h = _Float16(x);
+  const _Float16 l = _Float16(x - float(h));
+  dst[i] = __builtin_bit_cast(unsigned short, low ? l : h);
+}
+
 // one thread per element; blockIdx.y = job
 __global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
   const PackJob& J = jobs.j[blockIdx.y];
@@ -244,6 +269,7 @@ __global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
     case PK_AFFINE: k_pack_affine(i, J.src, J.src2, J.src3, J.dst); break;
     case PK_MAT32: k_pack_mat32(i, J.src, J.src2, J.src3, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1); break;
     case PK_LN2: k_pack_ln2(i, J.src, J.src2, J.src3, J.dst); break;
+    case PK_IN2F: k_pack_in2f(i, J.src, J.src2, reinterpret_cast<unsigned short*>(J.dst)); break;
     case PK_SPLIT: k_pack_split(i, J.src, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1, J.p2, J.p3, J.p4 & 0x3FFFFFFF, J.p4 >> 30); break;
   }
 }
@@ -332,6 +358,12 @@ struct Packer {
     emit(PK_LN2, 64, w, blob + dst, 0, 0, 0, 0, 0, b);
     jobs.back().src3 = g;
   }
+  // ... and its matrix-core fragments (layouts.hpp IN2F) from that block at `in2` and the LayerNorm's beta: second pass
+  void in2f(const std::string& p, int in2, int dst) {
+    const float* be = src(p + ".1.bias");
+    if (dry) return;
+    emit(PK_IN2F, 4 * 512, blob + in2, blob + dst, 0, 0, 0, 0, 0, be, /*pass=*/1);
+  }
   void lin(const std::string& p, int w, int b, int rows = 64, int cols = 64) {
     mat(p + ".weight", w, rows, cols, cols);
     vec(p + ".bias", b, rows);
@@ -397,6 +429,8 @@ static void recipe_edge_fused(Packer& P, const std::string& p, const std::string
   P.vec(p + ".module_list.1.1.bias", base + E::B_E, 64);
   P.ln2(p + ".module_list.0", base + E::A_C);
   P.ln2(p + ".module_list.1", base + E::B_C);
+  P.in2f(p + ".module_list.0", base + E::A_C, base + E::A_F);
+  P.in2f(p + ".module_list.1", base + E::B_C, base + E::B_F);
   P.ln(p + ".aggr_embed.0", base + E::AG0, base + E::AE0);
   P.ln(p + ".aggr_embed.3", base + E::AG3, base + E::AE3);
   if (P.dry) return;

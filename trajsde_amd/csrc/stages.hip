@@ -17,7 +17,10 @@ static int pair_threads() { static int t = []() { const char* e = getenv("TRAJSD
 // fused edge attention (k_edge_attn2 + k_seg_merge: no per-edge v / logits in HBM): default, inference and training forward
 // alike; TRAJSDE_ATTN_FUSED=0 runs the older two-kernel form (k_edge_kv2 -> HBM -> k_seg_softmax_agg), kept as a cross-check
 static bool attn_fused() { static bool v = []() { const char* e = getenv("TRAJSDE_ATTN_FUSED"); return !(e && atoi(e) == 0); }(); return v && edge_x6() && edge_pair(); }
-static int fused_threads() { return 512; }   // 2 waves per SIMD: ~220 VGPRs, weight image + 8 x 8 KB of parked query rows = 150 KB of LDS
+static int fused_threads() {                 // TRAJSDE_FUSED_THREADS=256: one wave per SIMD (diagnostic runs of the phase stamps)
+  static const int t = [] { const char* e = getenv("TRAJSDE_FUSED_THREADS"); const int v = e ? atoi(e) : 512; return v == 256 ? 256 : 512; }();
+  return t;
+}   // 2 waves per SIMD: ~220 VGPRs, weight image + 8 x 8 KB of parked query rows = 150 KB of LDS
 // TRAJSDE_EDGE_TILE=32: the fused edge attention on 32x32x16 matrix tiles (edge32.hip) -- half the matrix instructions and 12 %
 // fewer vector instructions, parity-tested, and 5 % slower un-profiled (0.839 against 0.800 ms on one box): the default stays
 // the 16x16x32 form.  TRAJSDE_EDGE_PINGPONG=1 adds its phase barriers that keep the second wave of a SIMD one phase behind the
@@ -131,7 +134,8 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
     const int threads = fused_threads();
     // a bounded list: enough waves for the most streams any E' <= E cuts into; the ones beyond the true count leave at once
     const int64_t streams = ec.dev ? std::min<int64_t>(E, fused_streams()) : pl.nstreams;
-    const int grid = xcd_grid((streams + 255) / 256);
+    const int per_wg = (fused_one_tile() ? 1024 : threads) / 64 * (fused_one_tile() ? 16 : 32);      // streams a workgroup walks (256 by default)
+    const int grid = xcd_grid((streams + per_wg - 1) / per_wg);
     const int lds = (EdgeL6F::LDS_SIZE + 256 * 64) * 4;                      // weight image + the parked query rows of 256 streams (64 KB)
     const bool d = drop.p > 0.f, sv = emb_out != nullptr;
 #define TS_EA2L(N_, D_, S_, L_) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<N_, D_, S_, L_>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)

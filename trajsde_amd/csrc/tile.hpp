@@ -206,6 +206,9 @@ __device__ __forceinline__ void linear_acc_x6_2(f4 (&acc0)[JT_OUT], f4 (&acc1)[J
     acc1[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, y1, acc1[jo], 0, 0, 0);
   }
 }
+#ifndef TSDE_FRAG_AHEAD
+#define TSDE_FRAG_AHEAD 1
+#endif
 // the same contraction for NT row tiles of one wave: every weight fragment read from LDS feeds 3 NT matrix instructions.
 // Per tile the products and their order are those of linear_acc_x6 (same bits).
 template <int NT, int JT_OUT, int JT_IN>
@@ -218,20 +221,25 @@ __device__ __forceinline__ void linear_acc_x6_n(f4 (&acc)[NT][JT_OUT], const f4 
 #pragma unroll
     for (int s = 0; s < KS; ++s) split_kstep(in[t][2 * s], in[t][2 * s + 1], xh[t][s], xl[t][s]);
   constexpr int STEPS = KS * JT_OUT;
-  u4 f1[2], f2[2];
-  f1[0] = *reinterpret_cast<const u4*>(w + lane * 4);
-  f2[0] = *reinterpret_cast<const u4*>(w + lane * 4 + 256);
+  constexpr int PF = TSDE_FRAG_AHEAD;                      // matrix steps (6 NT... 3 NT instructions) a fragment pair is read ahead of its use
+  u4 f1[PF + 1], f2[PF + 1];
+#pragma unroll
+  for (int i = 0; i < PF && i < STEPS; ++i) {
+    const float* p = w + ((i % JT_OUT) * KS + i / JT_OUT) * 512 + lane * 4;
+    f1[i] = *reinterpret_cast<const u4*>(p);
+    f2[i] = *reinterpret_cast<const u4*>(p + 256);
+  }
 #pragma unroll
   for (int i = 0; i < STEPS; ++i) {
     const int s = i / JT_OUT, jo = i % JT_OUT;
-    if (i + 1 < STEPS) {
-      const int s2 = (i + 1) / JT_OUT, jo2 = (i + 1) % JT_OUT;
+    if (i + PF < STEPS) {
+      const int s2 = (i + PF) / JT_OUT, jo2 = (i + PF) % JT_OUT;
       const float* p = w + (jo2 * KS + s2) * 512 + lane * 4;
-      f1[(i + 1) & 1] = *reinterpret_cast<const u4*>(p);
-      f2[(i + 1) & 1] = *reinterpret_cast<const u4*>(p + 256);
+      f1[(i + PF) % (PF + 1)] = *reinterpret_cast<const u4*>(p);
+      f2[(i + PF) % (PF + 1)] = *reinterpret_cast<const u4*>(p + 256);
       __builtin_amdgcn_sched_barrier(0);
     }
-    const h8 a1 = __builtin_bit_cast(h8, f1[i & 1]), a2 = __builtin_bit_cast(h8, f2[i & 1]);
+    const h8 a1 = __builtin_bit_cast(h8, f1[i % (PF + 1)]), a2 = __builtin_bit_cast(h8, f2[i % (PF + 1)]);
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t][jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(h8, xh[t][s]), acc[t][jo], 0, 0, 0);
 #pragma unroll
@@ -545,6 +553,58 @@ __device__ __forceinline__ void in2_ln_relu(f4 (&out)[4], float x0, float x1, co
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) out[jt] = in2_ln_relu4(x0r, x1r, rstd, c, beta, 16 * jt + 4 * g);
 }
+
+#if TSDE_SPLIT_H3
+// The same block on the matrix cores (layouts.hpp IN2F): the row operand x0r_h x1r_h | x0r_l x1r_l | r_h r_l | 1 1 of one row,
+// 5 vector instructions (the 16-bit partial writes go through one assembly block like split_kstep's, with wait states between
+// the two writes of a register and before the block's end) ...
+__device__ __forceinline__ u4 in2_operand(float x0r, float x1r, float rstd) {
+  const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0r, x1r));
+  unsigned hr = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(rstd, 0.f));
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %2, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %1, -1.0, %5 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 1\n\t"
+      "v_fma_mixhi_f16 %0, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 1"
+      : "=&v"(l), "+v"(hr)
+      : "v"(h), "v"(x0r), "v"(x1r), "v"(rstd));
+  return u4{h, l, hr, 0x3C003C00u};
+}
+// ... and ReLU(LayerNorm(Linear(2,64)(x))) of NT row tiles: 4 fragments read once, 4 NT matrix instructions, 16 NT max
+template <int NT>
+__device__ __forceinline__ void in2_operands_n(u4 (&b)[NT], const float (&x0)[NT], const float (&x1)[NT], const float* c) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float rstd = in2_rstd(x0[t], x1[t], c);
+    b[t] = in2_operand(x0[t] * rstd, x1[t] * rstd, rstd);
+  }
+}
+template <int NT>
+__device__ __forceinline__ void in2_mfma_relu_n(f4 (&out)[NT][4], const u4 (&b)[NT], const float* frag, int lane);
+template <int NT>
+__device__ __forceinline__ void in2_mfma_relu_n(f4 (&out)[NT][4], const float (&x0)[NT], const float (&x1)[NT], const float* c,
+                                                const float* frag, int lane) {
+  u4 b[NT];
+  in2_operands_n<NT>(b, x0, x1, c);
+  in2_mfma_relu_n<NT>(out, b, frag, lane);
+}
+template <int NT>
+__device__ __forceinline__ void in2_mfma_relu_n(f4 (&out)[NT][4], const u4 (&b)[NT], const float* frag, int lane) {
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(frag + jt * 256 + lane * 4));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f4 y = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, b[t]), f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      // ReLU as an integer max on the bits (negative floats are negative integers): fmaxf on a matrix result makes the
+      // compiler canonicalise it first with a second v_max, and inline assembly would hide the matrix-result hazard from it
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[t][jt][k] = __int_as_float(max(__float_as_int(y[k]), 0));
+    }
+  }
+}
+#endif
 
 // ---------------------------------------------------------------- HBM <-> activation tiles ([rows][64] fp32)
 __device__ __forceinline__ void load_row(f4 (&a)[4], const float* base, int64_t row, int g) {
