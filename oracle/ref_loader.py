@@ -71,6 +71,17 @@ def build_reference_model(cfg, seed=0):
     return model
 
 
+def reference_model_class(cfg_path: str = REF_CFG):
+    """the reference's model CLASS (not an instance) as train.py:49 / test.py:48 resolve it -- for its static helpers"""
+    _install_paths()
+    from importlib.machinery import SourceFileLoader
+    with open(os.path.join(REFERENCE_ROOT, cfg_path)) as f:
+        ms = yaml.safe_load(f)["model_specific"]
+    with reference_cwd():
+        mod = SourceFileLoader(ms["module_name"], ms["file_path"]).load_module(ms["module_name"])
+    return getattr(mod, ms["module_name"])
+
+
 def to_reference_data(batch):
     """Wrap a trajsde_amd.data.TemporalData (or dict) into the reference's own TemporalData class."""
     _install_paths()

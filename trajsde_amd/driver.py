@@ -1,7 +1,8 @@
 """Minimal evaluation driver for the MI355X build, mirroring the reference's `test.py:39-58`
 (YAML load -> class resolve through the {file_path, module_name, kwargs} registry -> optional checkpoint ->
 loop of `test_step` over batches -> metrics JSON; `MODEL:133-165`).  pytorch_lightning / PyG are not in the image,
-so the loop is spelled out; the model class keeps Lightning's hook signatures and also runs under a real Trainer.
+so the loop is spelled out here; where pytorch_lightning IS importable the model classes derive from
+`pl.LightningModule` (models/lightning_base.py) and `pl.Trainer.fit / test` take them as train.py / test.py do.
 
     python -m trajsde_amd.driver --config trajsde_amd/configs/mi355x_sde_encoder_decoder.yml \
         --synthetic config1 [--batches 4] [--ckpt path.ckpt] [--ood] [--gpus N via torch.distributed.run]
@@ -416,6 +417,9 @@ def main() -> None:
     else:
         batches = synthetic_batches(args.synthetic, args.batches, dev, rank, world)
     res = evaluate(model, batches)                                                    # metric states all-reduce in compute()
+    if rank == 0 and args.ckpt is not None:
+        model.result_ckpt_path = args.ckpt                                            # test_epoch_end (MODEL:150-165): the result
+        model.test_epoch_end([])                                                      # JSON next to the tested checkpoint
     if rank == 0:
         text = json.dumps(res)
         if args.out:

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from trajsde_amd import runtime
+from trajsde_amd.models.lightning_base import LightningHooks
 from trajsde_amd.models.model_base_mix_sde import resolve_class
 
 
@@ -44,10 +45,10 @@ class _GridPathLoss(torch.autograd.Function):
         return (None, None, None) + tuple(None if x is None else next(scaled) for x in ctx.grads)
 
 
-class PredictionModel(nn.Module):
+class PredictionModel(LightningHooks):
     def __init__(self, **kwargs) -> None:
         super().__init__()
-        self.hparams = deepcopy({k: v for k, v in kwargs.items() if k != "init_seed"})
+        self._record_hparams(kwargs)                                      # models/model_base_mix.py:28 save_hyperparameters()
         init_seed: Optional[int] = kwargs.get("init_seed")
         for key, value in kwargs.items():
             if key == "training_specific":
@@ -134,7 +135,13 @@ class PredictionModel(nn.Module):
         if not hasattr(self, "_param_names"):
             self._param_names = [n for n, _ in self.named_parameters()]
         params = [p for _, p in self.named_parameters()]
-        return _GridPathLoss.apply(self, data, float(self.loss_weights[0]), *params)
+        loss = _GridPathLoss.apply(self, data, float(self.loss_weights[0]), *params)
+        self.log_value("train/L2", self.last_losses["L2"], prog_bar=True, on_step=True, on_epoch=True,
+                       batch_size=int(self.last_output["loc"].size(1)))          # models/model_base_mix.py:112
+        lr = self.current_lr()
+        if lr is not None:
+            self.log_value("lr", lr, prog_bar=False, on_step=False, on_epoch=True, batch_size=1)
+        return loss
 
     def configure_optimizers(self):
         """models/model_base_mix.py:205-208: AdamW + StepLR(scheduler_step, scheduler_gamma).  The shipped YAML does not
@@ -159,6 +166,8 @@ class PredictionModel(nn.Module):
 
     def test_step(self, data, batch_idx):
         output = self(data)
+        if getattr(self, "only_agent", False):                                # models/model_base_mix.py:136-137
+            self.leave_only_agent(data, output)
         if data.y is not None:
             y_hat, y, mask, source = self._agent_eval_tensors(data, output)
             for metric in self.metrics_vl:

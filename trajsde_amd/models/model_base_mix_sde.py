@@ -3,9 +3,11 @@
 Mirrors the reference's `PredictionModelSDENet` (models/model_base_mix_sde.py:22-207) at the boundary:
 built from the same YAML dict, stages resolved through the same {file_path, module_name, kwargs}
 registry (MODEL:38-45), `forward(data) -> dict` with the same keys and the same in-place side effects
-on `data` (MODEL:83-85), `validation_step/test_step` feeding the same metric formulas.  It is a plain
-nn.Module (pytorch_lightning is not in the image); the step methods keep Lightning's signatures so the
-class also drops into a Lightning Trainer where one exists.
+on `data` (MODEL:83-85), `validation_step/test_step` feeding the same metric formulas.  It is a
+`pytorch_lightning.LightningModule` wherever that package is importable (what `pl.Trainer.fit / test` of train.py:54-66,
+test.py:58 require of the model class) and a plain nn.Module in this image, where it is not and trajsde_amd.driver spells
+the loops out (models/lightning_base.py); `test_epoch_end`, `only_agent` / `leave_only_agent` and the `self.log` calls
+of the reference's steps are there under both.
 """
 import os
 from copy import deepcopy
@@ -16,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from trajsde_amd import runtime
+from trajsde_amd.models.lightning_base import LightningHooks
 
 _REPO_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -88,10 +91,10 @@ class _PathLoss(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(None if x is None else next(scaled) for x in ctx.grads)
 
 
-class PredictionModelSDENet(nn.Module):
+class PredictionModelSDENet(LightningHooks):
     def __init__(self, **kwargs) -> None:
         super().__init__()
-        self.hparams = deepcopy({k: v for k, v in kwargs.items() if k != "init_seed"})
+        self._record_hparams(kwargs)                                      # MODEL:28 save_hyperparameters()
         init_seed: Optional[int] = kwargs.get("init_seed")
         for key, value in kwargs.items():
             if key == "training_specific":
@@ -217,7 +220,13 @@ class PredictionModelSDENet(nn.Module):
             self._param_names = [n for n, _ in self.named_parameters()]
         params = [p for _, p in self.named_parameters()]
         loss = _PathLoss.apply(self, data, noise, float(weights["L2"]), float(weights.get("DiffBCE", 0.0)), *params)
-        self.log_dict = {f"train/{k}": v for k, v in self.last_losses.items() if v is not None}
+        n_rows = int(self.last_output["loc"].size(1))
+        for name in self.loss_names:                                          # MODEL:112: one entry per configured loss
+            if self.last_losses.get(name) is not None:
+                self.log_value(f"train/{name}", self.last_losses[name], prog_bar=True, on_step=True, on_epoch=True, batch_size=n_rows)
+        lr = self.current_lr()
+        if lr is not None:                                                    # MODEL:113 (once configure_optimizers has run)
+            self.log_value("lr", lr, prog_bar=False, on_step=False, on_epoch=True, batch_size=1)
         return loss
 
     def _agent_eval_tensors(self, data, output):
@@ -235,6 +244,8 @@ class PredictionModelSDENet(nn.Module):
 
     def test_step(self, data, batch_idx):
         output = self(data)
+        if getattr(self, "only_agent", False):                                # MODEL:136-137
+            self.leave_only_agent(data, output)
         if data.y is not None:
             y_hat, y, mask, source = self._agent_eval_tensors(data, output)
             for metric in self.metrics_vl:
