@@ -235,6 +235,24 @@ int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph
                                      int num_modes, int num_heads, const float* local_embed, void* ws, int64_t ws_bytes,
                                      float* global_embed, const trajsde_dropout* dropout /* null = eval mode */, void* stream);
 
+/* ABI 8.  The relative-pose embedding of the global edges (AGG:42-51: `rel_embed` of edge_attr, once for all layers) reads
+ * the graph stage's output only, not the encoder's: trajsde_aggregator_prepare runs it alone into the stage's workspace
+ * (same `ws` / `ws_bytes` as the forward call that follows), trajsde_aggregator_forward_prepared is
+ * trajsde_aggregator_forward_heads without it.  A host that enqueues `prepare` on a second stream lets that chip-filling
+ * kernel share the GPU with the encoder's serial recurrence (AGG:38-58 split at AGG:51 | AGG:52; trajsde_encoder_fork_stream
+ * below says where the second stream starts); the caller orders the two streams (an event after `prepare`, waited for before
+ * `forward_prepared`). */
+int trajsde_aggregator_prepare(const trajsde_batch* b, const trajsde_graph* g, const float* blob, void* ws, int64_t ws_bytes,
+                               void* stream);
+/* Where on the encoder's timeline such side work should start: the NEXT trajsde_encoder_forward call of this host thread records
+ * an event on its stream right before it launches the recurrence (ENC:128-200: the 21 SDE + GRU iterations, one persistent kernel
+ * on 2/3 of the CUs at one wave per SIMD) and makes `side_stream` wait for it -- so work enqueued on `side_stream` after that call
+ * returns runs beside the recurrence, not beside the chip-filling attention kernels before it.  One-shot; null disarms. */
+int trajsde_encoder_fork_stream(void* side_stream);
+int trajsde_aggregator_forward_prepared(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers,
+                                        int num_modes, int num_heads, const float* local_embed, void* ws, int64_t ws_bytes,
+                                        float* global_embed, const trajsde_dropout* dropout /* null = eval mode */, void* stream);
+
 /* ---- decoder stage: SDEDecoder (DEC:77-105) with the stock Euler-Maruyama solve over the float32
  *      schedule tables of SURVEY.md App. D (trajsde_amd/schedule.py). */
 int64_t trajsde_decoder_ws_bytes(int32_t N, int num_modes);

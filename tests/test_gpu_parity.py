@@ -806,3 +806,28 @@ def test_radius_test_on_borderline_pairs_follows_torch_norm(dev):
     Nt = batch.num_nodes + batch["agent_index"].numel()
     t_of = torch.div(im["aa_dst"], Nt, rounding_mode="floor")
     assert torch.equal(_sorted_cols(t_of * Nt + im["aa_src"], im["aa_dst"]), _sorted_cols(*want["aa_edge_list"]))
+
+
+def test_relative_pose_prefetch_on_a_side_stream_is_bitwise_the_default_forward(dev):
+    """runtime.arm_rel_prefetch / launch_rel_prefetch (TRAJSDE_OVERLAP_REL=1; C-ABI trajsde_encoder_fork_stream,
+    trajsde_aggregator_prepare, trajsde_aggregator_forward_prepared): the aggregator's relative-pose embedding (AGG:42-51) on a
+    side stream forked where the encoder's recurrence starts -- the same kernels on the same inputs, so the same bits, also
+    when the forwards of two batches alternate (workspaces handed between the streams of the caching allocator)."""
+    from trajsde_amd import runtime
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    model, cfg = H.build_model(6, 20, 2.0, init_seed=2)
+    model = model.to(dev)
+    batches = [synth(S=6, n=40, L=12, F=20, box=120.0, seed=s, mixed_source=True) for s in (3, 4)]
+    want = [{k: v.clone() for k, v in model(H.clone_batch(b).to(dev), noise=NoiseSpec(seed=9 + i)).items()} for i, b in enumerate(batches)]
+    prev = runtime._OVERLAP_REL
+    runtime._OVERLAP_REL = True
+    try:
+        for rep in range(3):
+            for i, b in enumerate(batches):
+                got = model(H.clone_batch(b).to(dev), noise=NoiseSpec(seed=9 + i))
+                for k in ("loc", "pi", "diff_in", "diff_out"):
+                    assert torch.equal(got[k], want[i][k]), (rep, i, k)
+        torch.cuda.synchronize()
+    finally:
+        runtime._OVERLAP_REL = prev

@@ -11,9 +11,10 @@ STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGA
 STAGE_ENCODER_GRID, STAGE_DECODER_MLP, STAGE_DECODER_MLP_BWD, STAGE_ENCODER_GRID_BWD = 6, 7, 8, 9
 
 
-ABI_VERSION = 7          # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4);
+ABI_VERSION = 8          # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4);
                          # device-side list lengths + trajsde_graph_prepare_async (5); encoder tape / scratch split (6);
-                         # trajsde_noise.seed_dev: Philox key read on the device (7)
+                         # trajsde_noise.seed_dev: Philox key read on the device (7); trajsde_aggregator_prepare /
+                         # _forward_prepared: the relative-pose embedding as a call of its own (8)
 
 
 class TrajsdeError(RuntimeError):
@@ -97,6 +98,10 @@ SIGNATURES = {
                                                 C.POINTER(Dropout), P]),
     "trajsde_aggregator_forward_heads": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, C.c_int, C.c_int, C.c_int, P, P, I64, P,
                                                    C.POINTER(Dropout), P]),
+    "trajsde_aggregator_prepare": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, I64, P]),
+    "trajsde_encoder_fork_stream": (C.c_int, [P]),
+    "trajsde_aggregator_forward_prepared": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, C.c_int, C.c_int, C.c_int, P, P, I64, P,
+                                                      C.POINTER(Dropout), P]),
     "trajsde_encoder_grid_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
     "trajsde_encoder_grid_forward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, C.c_int, C.c_int, P, I64, P, P]),
     "trajsde_mlp_decoder_ws_bytes": (I64, [I32, C.c_int]),

@@ -167,6 +167,7 @@ template __global__ void k_edge_kv2<768>(const float*, const float*, const int32
 // segment lies inside one chunk produces one record; one that straddles a chunk boundary produces one per chunk it touches.
 // k_seg_merge (one wave per target, lane = feature) combines them in stream order and normalises like PyG's softmax
 // (sum + 1e-16).  The chunking depends only on E, so results are bitwise reproducible and independent of the input edge order.
+#if TSDE_SPLIT_H3   // the fused kernel exists in the fp16x3 build only: its image + query slots do not fit LDS with three bf16 planes
 #ifdef TSDE_EDGE_STAMPS
 // Diagnostic build only (tools/edge_phase_stamps.py): cycles (s_memtime) that one wave of every workgroup spends in each phase of
 // an iteration of k_edge_attn2, summed over the launch.  The stamp's own s_waitcnt drains the wave's LDS queue at every mark, so
@@ -448,6 +449,7 @@ template __global__ void k_edge_attn2<2, false, true, 0>(const float*, const flo
 template __global__ void k_edge_attn2<2, false, true, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<2, true, true, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<2, true, true, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+#endif   // TSDE_SPLIT_H3
 
 // records of one target -> agg row.  One wave per target, lane = feature f (jt = f>>4, g = (f>>2)&3); a target's records sit
 // at slots target + (first stream .. last stream) of its segment and are combined in that order.

@@ -16,7 +16,7 @@ static bool edge_pair() { static bool v = []() { const char* e = getenv("TRAJSDE
 static int pair_threads() { static int t = []() { const char* e = getenv("TRAJSDE_PAIR_THREADS"); const int v = e ? atoi(e) : 768; return v == 512 ? 512 : 768; }(); return t; }
 // fused edge attention (k_edge_attn2 + k_seg_merge: no per-edge v / logits in HBM): default, inference and training forward
 // alike; TRAJSDE_ATTN_FUSED=0 runs the older two-kernel form (k_edge_kv2 -> HBM -> k_seg_softmax_agg), kept as a cross-check
-static bool attn_fused() { static bool v = []() { const char* e = getenv("TRAJSDE_ATTN_FUSED"); return !(e && atoi(e) == 0); }(); return v && edge_x6() && edge_pair(); }
+static bool attn_fused() { static bool v = []() { const char* e = getenv("TRAJSDE_ATTN_FUSED"); return !(e && atoi(e) == 0); }(); return v && edge_x6() && edge_pair() && TSDE_SPLIT_H3; }
 static int fused_threads() {                 // TRAJSDE_FUSED_THREADS=256: one wave per SIMD (diagnostic runs of the phase stamps)
   static const int t = [] { const char* e = getenv("TRAJSDE_FUSED_THREADS"); const int v = e ? atoi(e) : 512; return v == 256 ? 256 : 512; }();
   return t;
@@ -141,6 +141,10 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
 #define TS_EA2L(N_, D_, S_, L_) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<N_, D_, S_, L_>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
 #define TS_EA2(N_, D_, S_) do { if (dominant) TS_EA2L(N_, D_, S_, 0); else TS_EA2L(N_, D_, S_, 1); } while (0)
 #define TS_EA3(D_, S_) if (edge_pingpong()) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn3<D_, S_, true>), grid, threads, lds, st, img + EdgeL6F::SIZE, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out); else TS_LAUNCH_TAG(tag, dominant, (k_edge_attn3<D_, S_, false>), grid, threads, lds, st, img + EdgeL6F::SIZE, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
+#if !TSDE_SPLIT_H3
+    (void)grid; (void)lds; (void)threads;
+    return fail(TRAJSDE_ERR_UNSUPPORTED, "the fused edge attention (and with it the training forward) exists in the fp16x3 build only");
+#else
     if (edge_tile32()) {
 #if TSDE_SPLIT_H3
       if (d && sv) TS_EA3(true, true);
@@ -157,6 +161,7 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
       else if (sv) TS_EA2(2, false, true);
       else TS_EA2(2, false, false);
     }
+#endif   // TSDE_SPLIT_H3
 #undef TS_EA2
 #undef TS_EA2L
 #undef TS_EA3
@@ -176,6 +181,11 @@ int64_t fused_rec_floats(int64_t E, bool exact, int64_t targets) { return fused_
 }  // namespace tsde
 
 using namespace tsde;
+
+// ---- trajsde_encoder_fork_stream (ABI 8): see include/trajsde_hip.h
+static thread_local hipStream_t t_fork_stream = nullptr;
+static thread_local hipEvent_t t_fork_event = nullptr;
+
 
 extern "C" {
 
@@ -312,6 +322,14 @@ int trajsde_encoder_forward(const trajsde_batch* b, const trajsde_graph* g, cons
   if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; na.seed_dev = noise->seed_dev; }
   if (int rc = run_aa_encoder(b, g, rot, blob, w, aa_out, st, 8, drop_aa)) return rc;
   TS_HIP(hipMemsetAsync(diff_pick, 0, size_t(2) * b->A * 64 * sizeof(float), st));
+  if (t_fork_stream != nullptr) {
+    // trajsde_encoder_fork_stream: whatever the caller enqueues on that stream from now on starts when the recurrence does
+    // (one-shot; an event record + a stream wait, both capturable)
+    if (t_fork_event == nullptr) TS_HIP(hipEventCreateWithFlags(&t_fork_event, hipEventDisableTiming));
+    TS_HIP(hipEventRecord(t_fork_event, st));
+    TS_HIP(hipStreamWaitEvent(t_fork_stream, t_fork_event, 0));
+    t_fork_stream = nullptr;
+  }
   if (int rc = run_recurrence(b, g, blob, step_tab, blob + EncBlob::HIDDEN, 0, na, w, aa_out, w.lat, diff_pick, latent_ys, st)) return rc;
   return run_al_encoder(b, g, blob, w, w.lat, local_embed, st, 8, drop_al);
 }
@@ -407,9 +425,52 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
   return trajsde_aggregator_forward_heads(b, g, blob, num_layers, num_modes, 8, local_embed, ws, ws_bytes, global_embed, nullptr, stream_);
 }
 
+// relative-pose embedding of every global edge (AGG:42-51), once for the layers: depends on the graph stage alone
+static int aggregator_rel_embed(const trajsde_batch* b, const trajsde_graph* g, const float* blob, AggWs& w, hipStream_t st) {
+  const int64_t E = g->E_g, etiles = (E + 15) / 16;
+  if (E > 0) {
+    if (edge_x6())
+      TS_LAUNCH(k_edge_embed<true>, tile_grid(etiles, threads_edge(), EdgeL6::EMB_SIZE * 4), threads_edge(), EdgeL6::EMB_SIZE * 4, st,
+                blob + AggBlob::REL6, g->g_geom, count_of(g, 2, E), w.rel, state_bf16() ? 1 : 0);
+    else
+      TS_LAUNCH(k_edge_embed<false>, tile_grid(etiles, threads_edge(), EdgeL::EMB_SIZE * 4), threads_edge(), EdgeL::EMB_SIZE * 4, st,
+                blob + AggBlob::REL, g->g_geom, count_of(g, 2, E), w.rel, state_bf16() ? 1 : 0);
+  }
+  return TRAJSDE_OK;
+}
+
+int trajsde_encoder_fork_stream(void* side_stream) {
+  t_fork_stream = static_cast<hipStream_t>(side_stream);
+  return TRAJSDE_OK;
+}
+
+int trajsde_aggregator_prepare(const trajsde_batch* b, const trajsde_graph* g, const float* blob, void* ws, int64_t ws_bytes, void* stream_) {
+  TS_REQUIRE(b && g && blob && ws, "aggregator_prepare: null pointer");
+  TS_REQUIRE(g->g_src && g->g_segptr, "aggregator_prepare: graph not compacted (call trajsde_graph_compact)");
+  AggWs w(b, g, ws, ws_bytes);
+  if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "aggregator_prepare: workspace too small");
+  return aggregator_rel_embed(b, g, blob, w, static_cast<hipStream_t>(stream_));
+}
+
+static int aggregator_forward_impl(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers, int num_modes,
+                                   int num_heads, const float* local_embed, void* ws, int64_t ws_bytes, float* global_embed,
+                                   const trajsde_dropout* dropout, void* stream_, bool rel_ready);
+
 int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers, int num_modes,
                                      int num_heads, const float* local_embed, void* ws, int64_t ws_bytes, float* global_embed,
                                      const trajsde_dropout* dropout, void* stream_) {
+  return aggregator_forward_impl(b, g, blob, num_layers, num_modes, num_heads, local_embed, ws, ws_bytes, global_embed, dropout, stream_, false);
+}
+
+int trajsde_aggregator_forward_prepared(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers, int num_modes,
+                                        int num_heads, const float* local_embed, void* ws, int64_t ws_bytes, float* global_embed,
+                                        const trajsde_dropout* dropout, void* stream_) {
+  return aggregator_forward_impl(b, g, blob, num_layers, num_modes, num_heads, local_embed, ws, ws_bytes, global_embed, dropout, stream_, true);
+}
+
+static int aggregator_forward_impl(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers, int num_modes,
+                                   int num_heads, const float* local_embed, void* ws, int64_t ws_bytes, float* global_embed,
+                                   const trajsde_dropout* dropout, void* stream_, bool rel_ready) {
   TS_REQUIRE(b && g && blob && local_embed && ws && global_embed, "aggregator_forward: null pointer");
   TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "aggregator_forward: dropout p must be in [0, 1)");
   TS_REQUIRE(num_heads == 8 || num_heads == 4, "aggregator_forward: num_heads must be 8 or 4");
@@ -419,14 +480,8 @@ int trajsde_aggregator_forward_heads(const trajsde_batch* b, const trajsde_graph
   if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "aggregator_forward: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int64_t N = b->N, E = g->E_g, ntiles = (N + 15) / 16, etiles = (E + 15) / 16;
-  if (E > 0) {
-    if (edge_x6())
-      TS_LAUNCH(k_edge_embed<true>, tile_grid(etiles, threads_edge(), EdgeL6::EMB_SIZE * 4), threads_edge(), EdgeL6::EMB_SIZE * 4, st,
-                blob + AggBlob::REL6, g->g_geom, count_of(g, 2, E), w.rel, state_bf16() ? 1 : 0);
-    else
-      TS_LAUNCH(k_edge_embed<false>, tile_grid(etiles, threads_edge(), EdgeL::EMB_SIZE * 4), threads_edge(), EdgeL::EMB_SIZE * 4, st,
-                blob + AggBlob::REL, g->g_geom, count_of(g, 2, E), w.rel, state_bf16() ? 1 : 0);
-  }
+  if (!rel_ready)
+    if (int rc = aggregator_rel_embed(b, g, blob, w, st)) return rc;
   const float* x = local_embed;
   float* bufs[2] = {w.xa, w.xb};
   for (int i = 0; i < num_layers; ++i) {

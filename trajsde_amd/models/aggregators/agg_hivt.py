@@ -28,6 +28,7 @@ class GlobalInteractor(ParamTree):
         self.set_init_seed(None)
         self._rt = runtime.StageRuntime(self, "aggregator")
 
-    def forward(self, data, local_embed, noise=None):
-        """`noise` (ours, optional): the NoiseSpec whose dropout key seeds this stage's train-mode dropout masks"""
-        return self._rt.aggregator_forward(data, local_embed, noise)
+    def forward(self, data, local_embed, noise=None, prepared=None):
+        """`noise` (ours, optional): the NoiseSpec whose dropout key seeds this stage's train-mode dropout masks;
+        `prepared` (ours, optional): the handle of `runtime.StageRuntime.prefetch_rel_embed` of this forward"""
+        return self._rt.aggregator_forward(data, local_embed, noise, prepared=prepared)

@@ -150,12 +150,19 @@ class PredictionModelSDENet(LightningHooks):
             data["rotate_mat"] = rotate_mat
         else:
             raise NotImplementedError("rotate=False is not built (shipped config: rotate: true, CFG:18)")
+        prepared = None
         if ood:
             local_embed, stds = self.encoder.forward_ood(data=data, noise=noise)            # MODEL:89-90
         else:
+            # the aggregator's relative-pose embedding depends on the graph stage alone: on a side stream that the encoder call
+            # forks where its recurrence starts, it shares the chip with that serial kernel (runtime.arm_rel_prefetch; eval mode only)
+            rt = getattr(self.aggregator, "_rt", None)
+            side = rt.arm_rel_prefetch(data, self.encoder) if (not self.training and rt is not None) else None
             local_embed, diff_in, diff_out, label_in, label_out = self.encoder(data=data, noise=noise,
                                                                                preserve_side_effects=preserve_side_effects)
-        global_embed = self.aggregator(data=data, local_embed=local_embed, noise=noise)
+            prepared = rt.launch_rel_prefetch(data, side) if side is not None else None
+        global_embed = (self.aggregator(data=data, local_embed=local_embed, noise=noise, prepared=prepared) if prepared is not None
+                        else self.aggregator(data=data, local_embed=local_embed, noise=noise))
         out = self.decoder(data=data, local_embed=local_embed, global_embed=global_embed, noise=noise)
         if ood:
             out["stds"] = stds                                                                 # MODEL:97-98

@@ -113,7 +113,9 @@ class GraphedForward:
         if GraphContext.KEY in data:                                         # the capture must contain the graph stage itself
             del data[GraphContext.KEY]
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        cap = torch.cuda.Stream(device=x.device)                             # the capture stream and its side stream (the relative-pose
+        _side_stream(x.device, cap)                                          # prefetch forks onto it) exist before the capture starts
+        with torch.cuda.graph(self.graph, stream=cap), torch.no_grad():
             data.y = self._y
             self.out = model(data, noise=self.noise)
 
@@ -130,6 +132,36 @@ def set_state_storage(kind: str) -> str:
     if kind not in ("fp32", "bf16"):
         raise ValueError("state storage is 'fp32' or 'bf16'")
     return "bf16" if _lib.lib().trajsde_state_storage(1 if kind == "bf16" else 0) else "fp32"
+
+
+# Off by default: measured on the metric workload (32 x 256 agents) the one-stream forward gains 0.6 % (2.781 against 2.798 ms)
+# and the three-stream headline loses 1.2 % -- the recurrence's four waves per CU hold the whole register file of their SIMDs
+# (512 registers each), so the embedding kernel only finds room on the CUs the recurrence leaves empty.
+_OVERLAP_REL = os.environ.get("TRAJSDE_OVERLAP_REL", "0") != "0"
+_SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(dev, cur) -> "torch.cuda.Stream":
+    """one side stream per (device, stream the forward runs on): forwards dealt over several streams keep their own"""
+    key = (str(dev), int(cur.cuda_stream))
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+class RelPrefetch:
+    """the aggregator's relative-pose rows on their way on a side stream (StageRuntime.prefetch_rel_embed)"""
+
+    def __init__(self, gc, ws, ws_bytes, done, dev) -> None:
+        self.gc, self.ws, self.ws_bytes, self.done, self.dev = gc, ws, ws_bytes, done, dev
+        self.joined = False
+
+    def join(self) -> None:
+        """the current stream waits for the side stream's kernel (also what ends a captured fork)"""
+        if not self.joined:
+            torch.cuda.current_stream(self.dev).wait_event(self.done)
+            self.joined = True
 
 
 _SYNC_FREE = os.environ.get("TRAJSDE_SYNC_FREE", "1") != "0"
@@ -527,8 +559,11 @@ class StageRuntime:
         return local, stds
 
     # ---------------------------------------------------------------- aggregator
-    def aggregator_forward(self, data, local_embed: torch.Tensor, noise: Optional[NoiseSpec] = None) -> torch.Tensor:
-        """GlobalInteractor.forward (AGG:38-58) -> [K, N, 64].  `noise`: only its dropout key is used, in train mode."""
+    def aggregator_forward(self, data, local_embed: torch.Tensor, noise: Optional[NoiseSpec] = None,
+                           prepared: Optional["RelPrefetch"] = None) -> torch.Tensor:
+        """GlobalInteractor.forward (AGG:38-58) -> [K, N, 64].  `noise`: only its dropout key is used, in train mode.
+        `prepared`: what `prefetch_rel_embed` returned for this forward -- the relative-pose rows are then already in the
+        workspace (or on their way on the side stream: this stream waits for them) and the call skips that kernel."""
         m = self.module
         dr = NoiseSpec.resolve(noise).c_dropout(m) if (m.training and float(getattr(m, "dropout", 0.0) or 0.0) > 0) else None
         _require_gpu(local_embed, "local_embed")
@@ -538,14 +573,66 @@ class StageRuntime:
         blob = self.blob()
         K, N = int(m.num_modes), gc.batch.N
         out = torch.empty(K, N, D, device=dev, dtype=torch.float32)
-        ws_bytes = L.trajsde_aggregator_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), K)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        if prepared is not None and prepared.gc is not gc:
+            prepared.join()                                               # (the graph was rebuilt in between: the rows are of another list)
+            prepared = None
+        if prepared is not None:
+            ws, ws_bytes = prepared.ws, prepared.ws_bytes
+            prepared.join()
+            entry = L.trajsde_aggregator_forward_prepared
+        else:
+            ws_bytes = L.trajsde_aggregator_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), K)
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+            entry = L.trajsde_aggregator_forward_heads
         with torch.cuda.device(dev):
-            _lib.check(L.trajsde_aggregator_forward_heads(C.byref(gc.batch), C.byref(gc.graph), blob.data_ptr(), int(m.num_layers), K,
-                                                          int(m.num_heads), local_embed.contiguous().data_ptr(), ws.data_ptr(),
-                                                          ws_bytes, out.data_ptr(), C.byref(dr) if dr is not None else None, _stream()),
+            _lib.check(entry(C.byref(gc.batch), C.byref(gc.graph), blob.data_ptr(), int(m.num_layers), K,
+                             int(m.num_heads), local_embed.contiguous().data_ptr(), ws.data_ptr(),
+                             ws_bytes, out.data_ptr(), C.byref(dr) if dr is not None else None, _stream()),
                        "trajsde_aggregator_forward")
         return out
+
+    def arm_rel_prefetch(self, data, encoder_module) -> Optional["torch.cuda.Stream"]:
+        """Called on the AGGREGATOR's runtime before the encoder of an inference forward: names the side stream on which the
+        relative-pose embedding (AGG:42-51; it reads the graph stage's output only) will run, and has the encoder call fork it
+        at the point where its recurrence starts (trajsde_encoder_fork_stream).  That kernel fills the chip for ~0.2 ms and depends
+        on nothing the encoder computes, while the recurrence keeps a third of the CUs idle at one wave per SIMD for about as
+        long.  None when switched off (the default; TRAJSDE_OVERLAP_REL=1 turns it on) or where the split entry points do not apply."""
+        if not _OVERLAP_REL:
+            return None
+        m, enc = self.module, encoder_module
+        if bool(getattr(enc, "capture_intermediates", False)) or m.training or enc.training:
+            return None
+        x = data["x"]
+        _require_gpu(x, "data['x']")
+        side = _side_stream(x.device, torch.cuda.current_stream(x.device))
+        _lib.check(_lib.lib().trajsde_encoder_fork_stream(side.cuda_stream), "trajsde_encoder_fork_stream")
+        return side
+
+    def launch_rel_prefetch(self, data, side) -> Optional["RelPrefetch"]:
+        """after the encoder call returned: the side stream now waits for the fork event; enqueue the embedding on it"""
+        if side is None or GraphContext.KEY not in data:
+            return None
+        m = self.module
+        gc = GraphContext.get(data, None, int(m.historical_steps), None, exact=None)
+        dev = gc.device
+        L = _lib.lib()
+        blob = self.blob()                                                # (packed on the current stream before the side kernel reads it:
+        ws_bytes = L.trajsde_aggregator_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), int(m.num_modes))     # see pack event below)
+        packed = self._blobs[self.stage_id][2]                            # a pack still in flight on another stream: order behind it
+        cur = torch.cuda.current_stream(dev)
+        with torch.cuda.device(dev), torch.cuda.stream(side):
+            # the workspace comes from the SIDE stream's share of the caching allocator: a block of the current stream's could be
+            # the encoder workspace that was released a moment ago on the host while the encoder's kernels -- beside which the
+            # side kernel is about to run -- still use it
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+            if packed is not None:
+                side.wait_event(packed)
+            _lib.check(L.trajsde_aggregator_prepare(C.byref(gc.batch), C.byref(gc.graph), blob.data_ptr(), ws.data_ptr(), ws_bytes,
+                                                    side.cuda_stream), "trajsde_aggregator_prepare")
+            done = torch.cuda.Event()
+            done.record(side)
+        ws.record_stream(cur)                                             # ... and is used on the current stream from the join on
+        return RelPrefetch(gc, ws, ws_bytes, done, dev)
 
     # ---------------------------------------------------------------- vanilla HiVT variant
     def encoder_grid_forward(self, data) -> torch.Tensor:
