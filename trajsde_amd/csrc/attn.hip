@@ -449,7 +449,299 @@ template __global__ void k_edge_attn2<2, false, true, 0>(const float*, const flo
 template __global__ void k_edge_attn2<2, false, true, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<2, true, true, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<2, true, true, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+// ------------------------------------------------------------------------------------------------ pipelined form
+// k_edge_attn2p: the inference kernel above (same streams, same records, the same arithmetic per edge: bit-identical) with the
+// vector work of one tile issued BETWEEN the matrix instructions of the other, by construction.
+//
+// What the measurements say (tools/edge_phase_stamps.py, tools/microbench/coexec.hip): a wave is an in-order stream whose
+// vector stages (LayerNorms, operand splits, softmax) and matrix stages (the five products) alternate and depend on each
+// other, so within a wave nothing overlaps; the SIMD then serves the older of its two waves at nearly the speed of a lone
+// wave, and a lone wave takes ~10.4 k cycles per iteration for 4.1 k cycles of matrix pipe and 3.6 k of vector issue.  One
+// stream that issues a matrix instruction followed by independent vector instructions hides the vector ones in the matrix
+// instruction's 16 cycles (microbenchmark: 48 x (mfma + 4 fma) = 21.5 cycles each, against 16 + 16 issued apart).
+//
+// So the wave's two tiles run ONE STAGE APART: tile B lags tile A by one stage of the chain
+//     V1 in2 operands | M1 in2 layers | V2 relu, split | M2 W_A, W_B | V3 LN, relu, split | M3 W_2 | V4 LN, split | M4 lin_k|lin_v | V5 softmax
+// and every matrix stage of one tile is a cluster whose steps (3 matrix instructions each) are followed by "atoms" of the
+// other tile's vector stage -- small independent pieces (one k-step's split, one head's softmax update, ...), spread evenly
+// over the steps and pinned there (sched_barrier).  A.Vk pairs with B.Mk, B.V(k+1) with A.Mk; the one vector stage left
+// over (A's softmax) runs alone.  The price: the tiles no longer share weight fragments (each fragment pair feeds 3 matrix
+// instructions instead of 6: twice the LDS reads).
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, F, I + 1>(static_cast<F&&>(f));
+  }
+}
+
+struct PipeTile {                                          // what a tile carries from stage to stage
+  f4 ge;
+  int d;
+  bool ok;
+  u4 opA, opB;                                             // V1: the in2 row operands of the two branches
+  f4 a[4], a2[4];                                          // M1: first-layer outputs before the ReLU
+  u4 xah[2], xal[2], xbh[2], xbl[2];                       // V2: their split pieces
+  f4 s[4];                                                 // M2: W_A h_A + W_B h_B + b (feature-centred)
+  u4 uh[2], ul[2];                                         // V3
+  f4 nrm[4];                                               // M3: W_2 u + b_2 (feature-centred)
+  u4 nh[2], nl[2];                                         // V4
+  f4 kv[8];                                                // M4
+};
+
+// one matrix stage: acc[jo] += W x over the two k-steps.  A step covers TWO accumulators (jo, jo + 1) of one k-step: six matrix
+// instructions that alternate between them, so consecutive ones never depend on each other (a chain on one accumulator makes
+// the compiler pad with s_nop whenever it renames the destination); after step i the atoms j with floor(j STEPS / K) == i.
+// Per accumulator the order of the products is that of linear_acc_x6_n: same bits.
+template <int JT_OUT, int K, bool ZERO, class Atoms>
+__device__ __forceinline__ void pipe_cluster(f4 (&acc)[JT_OUT], const u4 (&xh)[2], const u4 (&xl)[2], const float* w, int lane, Atoms&& atoms) {
+  static_assert(JT_OUT % 2 == 0, "steps pair up the output tiles");
+  constexpr int STEPS = JT_OUT;                            // (k-step s, pair p): s-major like linear_acc_x6_n
+  constexpr int PAIRS = JT_OUT / 2;
+  u4 f1[2][2], f2[2][2];                                   // [buffer][which of the pair]: hi and lo piece fragments
+  auto load = [&](int buf, int s, int p) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float* ptr = w + ((2 * p + h) * 2 + s) * 512 + lane * 4;
+      f1[buf][h] = *reinterpret_cast<const u4*>(ptr);
+      f2[buf][h] = *reinterpret_cast<const u4*>(ptr + 256);
+    }
+  };
+  load(0, 0, 0);
+  static_for<STEPS>([&](auto I) {
+    constexpr int i = decltype(I)::value, s = i / PAIRS, p = i % PAIRS, b = i & 1;
+    if constexpr (i + 1 < STEPS) load(b ^ 1, (i + 1) / PAIRS, (i + 1) % PAIRS);
+    const h8 xhs = __builtin_bit_cast(h8, xh[s]), xls = __builtin_bit_cast(h8, xl[s]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const h8 a1 = __builtin_bit_cast(h8, f1[b][h]);
+      if (ZERO && s == 0) acc[2 * p + h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xhs, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      else acc[2 * p + h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xhs, acc[2 * p + h], 0, 0, 0);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      acc[2 * p + h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, f1[b][h]), xls, acc[2 * p + h], 0, 0, 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      acc[2 * p + h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, f2[b][h]), xhs, acc[2 * p + h], 0, 0, 0);
+    static_for<K>([&](auto J) {
+      if constexpr (decltype(J)::value * STEPS / K == i) atoms(J);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+// the two first layers of a tile (layouts.hpp IN2F): 8 single matrix instructions, atoms as above
+template <int K, class Atoms>
+__device__ __forceinline__ void pipe_cluster_in2(PipeTile& T, const float* fragA, const float* fragB, int lane, Atoms&& atoms) {
+  static_for<8>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    const float* fr = (i < 4 ? fragA : fragB) + (i & 3) * 256 + lane * 4;
+    const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(fr));
+    const f4 y = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, i < 4 ? T.opA : T.opB), f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    if constexpr (i < 4) T.a[i] = y;
+    else T.a2[i - 4] = y;
+    static_for<K>([&](auto J) {
+      if constexpr (decltype(J)::value * 8 / K == i) atoms(J);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+template <int LIST>
+__global__ __launch_bounds__(512) void k_edge_attn2p(const float* __restrict__ img_g, const float* __restrict__ geom,
+                                                     const int32_t* __restrict__ dst, const float* __restrict__ q, EdgeCount ec, int C_host,
+                                                     float* __restrict__ rec, int heads) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using EL = EdgeL6F;
+  constexpr int NT = 2;
+  const int64_t E = edge_count(ec);
+  const int C = stream_len(ec, E, C_host);
+  if (E <= 0) return;
+  stage_blob(lds, img_g, EL::LDS_SIZE);
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t nstreams = (E + C - 1) / C;
+  const int64_t wid = xcd_block() * waves + wave;
+  if (wid * (16 * NT) >= nstreams) return;
+  SegState S[NT];
+  int64_t sid[NT], base_e[NT];
+  int cur[NT];
+  f4 ng[NT];
+  int nd[NT];
+  PipeTile T[NT];
+  float* qs = lds + EL::LDS_SIZE + wave * (NT * 4 * 64 * 4);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    seg_reset(S[t]);
+    sid[t] = wid * (16 * NT) + 16 * t + L.n;
+    base_e[t] = sid[t] * C;
+    cur[t] = -1;
+    const int64_t c = base_e[t] < E ? base_e[t] : E - 1;
+    ng[t] = *reinterpret_cast<const f4*>(geom + 4 * c);
+    nd[t] = dst[c];
+  }
+  // ---- the vector stages of tile t, as atoms -------------------------------------------------------------------------------------
+  // adv: edge `nit` of the tile's stream enters: its geometry (loaded one edge ahead), the next edge's loads, and -- when the
+  // row's target changes -- the record of the finished segment part and the new target's query row (k_edge_attn2)
+  auto adv = [&](auto TT, int nit) {
+    constexpr int t = decltype(TT)::value;
+    const int64_t e = base_e[t] + nit;
+    T[t].ok = nit < C && e < E;
+    T[t].ge = ng[t];
+    T[t].d = nd[t];
+    asm volatile("" : "+v"(T[t].ge), "+v"(T[t].d));         // the previous loads are consumed here (see k_edge_attn2)
+    const int64_t c = e + 1 < E ? e + 1 : E - 1;
+    ng[t] = *reinterpret_cast<const f4*>(geom + 4 * c);
+    nd[t] = dst[c];
+    if (T[t].ok && T[t].d != cur[t]) {
+      if (cur[t] >= 0) seg_flush(S[t], rec, int64_t(cur[t]) + sid[t], L.g);
+      seg_reset(S[t]);
+      cur[t] = T[t].d;
+      const float* qrow = q + int64_t(T[t].d) * D + 4 * L.g;
+      const unsigned slot = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>(
+          (__attribute__((address_space(3))) float*)(qs + 4 * t * 256))));
+      unsigned m0_keep;
+      asm volatile("s_mov_b32 %0, m0\n\t"
+                   "s_mov_b32 m0, %5\n\t"
+                   "s_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, off\n\t"
+                   "s_add_u32 m0, m0, 0x400\n\t"
+                   "s_nop 0\n\t"
+                   "global_load_lds_dwordx4 %2, off\n\t"
+                   "s_add_u32 m0, m0, 0x400\n\t"
+                   "s_nop 0\n\t"
+                   "global_load_lds_dwordx4 %3, off\n\t"
+                   "s_add_u32 m0, m0, 0x400\n\t"
+                   "s_nop 0\n\t"
+                   "global_load_lds_dwordx4 %4, off\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(m0_keep)
+                   : "v"(qrow), "v"(qrow + 16), "v"(qrow + 32), "v"(qrow + 48), "s"(slot)
+                   : "memory", "scc");
+    }
+  };
+  auto v1 = [&](auto TT, auto J) {                          // 2 atoms: the row operand of branch J
+    constexpr int t = decltype(TT)::value, j = decltype(J)::value;
+    const float x0 = j == 0 ? T[t].ge[0] : T[t].ge[2], x1 = j == 0 ? T[t].ge[1] : T[t].ge[3];
+    const float rstd = in2_rstd(x0, x1, lds + (j == 0 ? EL::A_C : EL::B_C));
+    const u4 op = in2_operand(x0 * rstd, x1 * rstd, rstd);
+    if constexpr (j == 0) T[t].opA = op;
+    else T[t].opB = op;
+  };
+  auto v2 = [&](auto TT, auto J) {                          // 5 atoms: ReLU + split of (branch, k-step); the bias of the sum
+    constexpr int t = decltype(TT)::value, j = decltype(J)::value;
+    if constexpr (j < 4) {
+      constexpr int br = j >> 1, ks = j & 1;
+      f4(&src)[4] = br == 0 ? T[t].a : T[t].a2;
+      f4 r0, r1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        r0[k] = __int_as_float(max(__float_as_int(src[2 * ks][k]), 0));
+        r1[k] = __int_as_float(max(__float_as_int(src[2 * ks + 1][k]), 0));
+      }
+      if constexpr (br == 0) split_kstep(r0, r1, T[t].xah[ks], T[t].xal[ks]);
+      else split_kstep(r0, r1, T[t].xbh[ks], T[t].xbl[ks]);
+    } else {
+      load_vec<4>(T[t].s, lds + EL::B3, L.g);
+    }
+  };
+  float r3[NT];
+  auto v3 = [&](auto TT, auto J) {                          // 4 atoms: rstd | LN + ReLU + split of k-step 0, 1 | the next bias
+    constexpr int t = decltype(TT)::value, j = decltype(J)::value;
+    if constexpr (j == 0) {
+      r3[t] = centred_rstd(T[t].s);
+    } else if constexpr (j < 3) {
+      constexpr int ks = j - 1;
+      f4 u[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int jt = 2 * ks + h;
+        const f4 ga = *reinterpret_cast<const f4*>(lds + EL::AG0 + 16 * jt + 4 * L.g);
+        const f4 be = *reinterpret_cast<const f4*>(lds + EL::AE0 + 16 * jt + 4 * L.g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) u[h][c] = fmaxf(fmaf(T[t].s[jt][c] * r3[t], ga[c], be[c]), 0.f);
+      }
+      split_kstep(u[0], u[1], T[t].uh[ks], T[t].ul[ks]);
+    } else {
+      load_vec<4>(T[t].nrm, lds + EL::B2, L.g);
+    }
+  };
+  float r4[NT];
+  auto v4 = [&](auto TT, auto J) {                          // 3 atoms: rstd | scale + split of k-step 0, 1
+    constexpr int t = decltype(TT)::value, j = decltype(J)::value;
+    if constexpr (j == 0) {
+      r4[t] = centred_rstd(T[t].nrm);
+    } else {
+      constexpr int ks = j - 1;
+      const f4 n0 = T[t].nrm[2 * ks] * r4[t], n1 = T[t].nrm[2 * ks + 1] * r4[t];
+      split_kstep(n0, n1, T[t].nh[ks], T[t].nl[ks]);
+    }
+  };
+  f4 lg5[NT];
+  auto v5 = [&](auto TT, auto J) {                          // 5 atoms: the four head slots' logits | the softmax update
+    constexpr int t = decltype(TT)::value, j = decltype(J)::value;
+    if constexpr (j == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the query rows sent to LDS have landed
+    if constexpr (j < 4) {
+      const f4 qv = *reinterpret_cast<const f4*>(qs + ((4 * t + j) * 64 + L.lane) * 4);
+      float p = qv[0] * T[t].kv[j][0];
+#pragma unroll
+      for (int c = 1; c < 4; ++c) p = fmaf(qv[c], T[t].kv[j][c], p);
+      p = xor16_sum(p);
+      if (heads == 4) p = xor32_sum(p);
+      lg5[t][j] = p * (heads == 4 ? 0.25f : INV_SQRT_DH);
+    } else {
+      f4 lg = lg5[t];
+      if (!T[t].ok) lg = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      const f4 vv[4] = {T[t].kv[4], T[t].kv[5], T[t].kv[6], T[t].kv[7]};
+      seg_update(S[t], lg, vv, f4{1.f, 1.f, 1.f, 1.f});
+    }
+  };
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  // ---- prologue: both tiles take their first edge; B also runs its first vector stage (it lags A by one stage)
+  adv(T0{}, 0);
+  adv(T1{}, 0);
+  v1(T1{}, std::integral_constant<int, 0>{});
+  v1(T1{}, std::integral_constant<int, 1>{});
+  for (int it = 0; it < C; ++it) {
+    keep_lds_reads_here();
+    // A.V1 | B.M1
+    pipe_cluster_in2<2>(T[1], lds + EL::A_F, lds + EL::B_F, L.lane, [&](auto J) { v1(T0{}, J); });
+    // A.M1 | B.V2
+    pipe_cluster_in2<5>(T[0], lds + EL::A_F, lds + EL::B_F, L.lane, [&](auto J) { v2(T1{}, J); });
+    // A.V2 | B.M2 (W_A then W_B)
+    pipe_cluster<4, 3, false>(T[1].s, T[1].xah, T[1].xal, lds + EL::WA3, L.lane, [&](auto J) { v2(T0{}, J); });
+    pipe_cluster<4, 2, false>(T[1].s, T[1].xbh, T[1].xbl, lds + EL::WB3, L.lane,
+                              [&](auto J) { v2(T0{}, std::integral_constant<int, decltype(J)::value + 3>{}); });
+    // A.M2 | B.V3
+    pipe_cluster<4, 2, false>(T[0].s, T[0].xah, T[0].xal, lds + EL::WA3, L.lane, [&](auto J) { v3(T1{}, J); });
+    pipe_cluster<4, 2, false>(T[0].s, T[0].xbh, T[0].xbl, lds + EL::WB3, L.lane,
+                              [&](auto J) { v3(T1{}, std::integral_constant<int, decltype(J)::value + 2>{}); });
+    // A.V3 | B.M3
+    pipe_cluster<4, 4, false>(T[1].nrm, T[1].uh, T[1].ul, lds + EL::W2, L.lane, [&](auto J) { v3(T0{}, J); });
+    // A.M3 | B.V4
+    pipe_cluster<4, 3, false>(T[0].nrm, T[0].uh, T[0].ul, lds + EL::W2, L.lane, [&](auto J) { v4(T1{}, J); });
+    // A.V4 | B.M4
+    pipe_cluster<8, 3, true>(T[1].kv, T[1].nh, T[1].nl, lds + EL::WKV, L.lane, [&](auto J) { v4(T0{}, J); });
+    // A.M4 | B.V5, B takes its next edge, B.V1 of that edge
+    pipe_cluster<8, 8, true>(T[0].kv, T[0].nh, T[0].nl, lds + EL::WKV, L.lane, [&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (j < 5) v5(T1{}, J);
+      else if constexpr (j == 5) adv(T1{}, it + 1);
+      else v1(T1{}, std::integral_constant<int, j - 6>{});
+    });
+    // A.V5, A takes its next edge
+    static_for<5>([&](auto J) { v5(T0{}, J); });
+    adv(T0{}, it + 1);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (cur[t] >= 0) seg_flush(S[t], rec, int64_t(cur[t]) + sid[t], L.g);
+}
+template __global__ void k_edge_attn2p<0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int);
+template __global__ void k_edge_attn2p<1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int);
 #endif   // TSDE_SPLIT_H3
+
 
 // records of one target -> agg row.  One wave per target, lane = feature f (jt = f>>4, g = (f>>2)&3); a target's records sit
 // at slots target + (first stream .. last stream) of its segment and are combined in that order.

@@ -59,6 +59,8 @@ inline AttnPlan attn_plan(int64_t E, int streams_target = SEG_STREAMS_512) {
 template <int NT, bool DROP, bool SAVE, int LIST>
 __global__ void k_edge_attn2(const float* img, const float* geom, const int32_t* dst, const float* q, EdgeCount ec, int C, float* rec, int heads,
                              const int32_t* segptr, DropArg drop, float* emb_out);
+template <int LIST>
+__global__ void k_edge_attn2p(const float* img, const float* geom, const int32_t* dst, const float* q, EdgeCount ec, int C, float* rec, int heads);
 // host side of the fused edge attention (stages.hip): k_edge_attn2 + k_seg_merge -> agg [R,64]; the training path also asks
 // for the embedding rows (emb_out [E,64]) and the softmax statistics (stats [R,heads,2]).  img: the stage blob's EdgeL6F image
 bool attn_fused_enabled();

@@ -29,6 +29,10 @@ static int fused_threads() {                 // TRAJSDE_FUSED_THREADS=256: one w
 // VGPRs, weight fragments not shared between tiles): bit-identical, and within the noise of the default (0.85 vs 0.86-0.91 ms)
 // TRAJSDE_MERGE_KERNEL=1: the records are merged by k_seg_merge into agg rows (always so in training) instead of inside k_node_update
 static bool merge_in_update() { static const bool v = []() { const char* e = getenv("TRAJSDE_MERGE_KERNEL"); return !(e && atoi(e) != 0); }(); return v; }
+// TRAJSDE_EDGE_PIPE=1: the software-pipelined form of the fused edge attention (k_edge_attn2p: the wave's two tiles one stage apart,
+// vector work issued between the other tile's matrix instructions; bit-identical) for inference.  Measured slower than the lockstep
+// form (0.87 against 0.81 ms per launch; one wave per SIMD 1.12 against 0.98) -- DESIGN.md section 5 -- so it is an alternative.
+static bool edge_pipe() { static const bool v = []() { const char* e = getenv("TRAJSDE_EDGE_PIPE"); return e && atoi(e) == 1; }(); return v; }
 static bool fused_one_tile() { static const bool v = []() { const char* e = getenv("TRAJSDE_FUSED_TILES"); return e && atoi(e) == 1; }(); return v; }
 static bool edge_pingpong() { static const bool v = []() { const char* e = getenv("TRAJSDE_EDGE_PINGPONG"); return e && atoi(e) != 0; }(); return v; }
 static bool edge_tile32() { static const bool v = []() { const char* e = getenv("TRAJSDE_EDGE_TILE"); return e && atoi(e) == 32; }(); return v && TSDE_SPLIT_H3; }
@@ -152,6 +156,10 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
       else if (sv) TS_EA3(false, true);
       else TS_EA3(false, false);
 #endif
+    } else if (edge_pipe() && !d && !sv && !fused_one_tile()) {
+      // inference: the two tiles of a wave one stage apart, vector work issued between the other tile's matrix instructions
+      if (dominant) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2p<0>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads);
+      else TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2p<1>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads);
     } else if (fused_one_tile() && !d && !sv) {
       if (dominant) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<1, false, false, 0>), grid, 1024, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out);
       else TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<1, false, false, 1>), grid, 1024, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out);
