@@ -103,10 +103,24 @@ __global__ __launch_bounds__(MAXT) void k_sde_decode(const float* __restrict__ b
       const float dt = step_tab[k * 8 + 1], sq = step_tab[k * 8 + 2], sn = step_tab[k * 8 + 3], cs = step_tab[k * 8 + 4];
       f4 f[4], z[4];
       float gs;
+#if TSDE_SPLIT_H3
+      if constexpr (X6) {
+        // this step's 128 first-layer biases, once per step in the wave's own LDS slot (they were 64 fma + 24 LDS reads per tile)
+        float* tb = lds + DL::SIZE + wave * 128;
+        __builtin_amdgcn_wave_barrier();                       // the previous step's reads of the slot are done (same wave, in order)
+        sde_time_bias(tb, lds, sn, cs, L.lane);
+        sde_time_bias(tb, lds, sn, cs, L.lane + 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        sde_fg_eval(f, gs, y, lds, tb, L);
+      } else
+#else
       if constexpr (X6) {
         drift_eval_x6(f, y, lds + DL::F, sn, cs, L);
         gs = diff_eval_x6(y, lds + DL::G, sn, cs, L);
-      } else {
+      } else
+#endif
+      {
         drift_eval(f, y, lds + DL::F, sn, cs, L);
         gs = diff_eval(y, lds + DL::G, sn, cs, L);
       }
@@ -153,6 +167,13 @@ __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blo
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using DL = typename std::conditional<X6, DecSdeL6, DecSdeL>::type;
   stage_blob(lds, blob, DL::LOC);   // F and G images only
+#if TSDE_SPLIT_H3
+  float* tb = lds + DL::LOC;        // the step's 128 first-layer biases: constants of the launch
+  if (X6) {
+    if (threadIdx.x < 128) sde_time_bias(tb, lds, sn, cs, threadIdx.x);
+    __syncthreads();
+  }
+#endif
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (rows + 15) / 16;
@@ -164,10 +185,17 @@ __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blo
     load_row_st(y, y_in, r, L.g, st_bf16 != 0);
     range_note(absmax<4>(y), RS_DEC_STATE);
     float gs;
+#if TSDE_SPLIT_H3
+    if constexpr (X6) {
+      sde_fg_eval(f, gs, y, lds, tb, L);
+    } else
+#else
     if constexpr (X6) {
       drift_eval_x6(f, y, lds + DL::F, sn, cs, L);
       gs = diff_eval_x6(y, lds + DL::G, sn, cs, L);
-    } else {
+    } else
+#endif
+    {
       drift_eval(f, y, lds + DL::F, sn, cs, L);
       gs = diff_eval(y, lds + DL::G, sn, cs, L);
     }
@@ -215,7 +243,7 @@ int trajsde_decoder_forward(int32_t N, int num_modes, int future_steps, const fl
   static const bool x6 = []() { const char* e = getenv("TRAJSDE_DECODE_FP32"); return !(e && atoi(e) != 0); }();
   // <=512 threads: the 256-VGPR build (no spills, 2 waves/SIMD); above: the 168-VGPR build (3 waves/SIMD)
 #define TS_DECODE(X6, MAXT, IMG, OFF)                                                                                          \
-  TS_LAUNCH((k_sde_decode<X6, MAXT>), pick_grid(ntiles, dthreads / 64), dthreads, IMG::SIZE * 4, stream, blob + OFF, y0, rows, \
+  TS_LAUNCH((k_sde_decode<X6, MAXT>), pick_grid(ntiles, dthreads / 64), dthreads, (IMG::SIZE + (dthreads / 64) * 128) * 4, stream, blob + OFF, y0, rows, \
             future_steps, n_euler, step_table, out_table, min_scale, to_arg(noise), loc, state_bf16() ? 1 : 0)
   if (x6 && dthreads <= 512) TS_DECODE(true, 512, DecSdeL6, DecBlob::SDE6);
   else if (x6) TS_DECODE(true, 768, DecSdeL6, DecBlob::SDE6);
@@ -232,7 +260,7 @@ int trajsde_sde_step(int32_t rows, const float* blob, const float* y_in, float* 
   const int64_t ntiles = (int64_t(rows) + 15) / 16;
   static const bool x6 = []() { const char* v = getenv("TRAJSDE_DECODE_FP32"); return !(v && atoi(v) != 0); }();
   if (x6)
-    TS_LAUNCH(k_sde_step<true>, pick_grid(ntiles, 16), 1024, DecSdeL6::LOC * 4, stream, blob + DecBlob::SDE6, y_in, y_out, int64_t(rows), e[1],
+    TS_LAUNCH(k_sde_step<true>, pick_grid(ntiles, 16), 1024, (DecSdeL6::LOC + 128) * 4, stream, blob + DecBlob::SDE6, y_in, y_out, int64_t(rows), e[1],
               e[2], e[3], e[4], step, to_arg(noise), state_bf16() ? 1 : 0);
   else
     TS_LAUNCH(k_sde_step<false>, pick_grid(ntiles, 16), 1024, DecSdeL::LOC * 4, stream, blob + DecBlob::SDE, y_in, y_out, int64_t(rows), e[1],

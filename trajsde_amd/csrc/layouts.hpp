@@ -302,7 +302,15 @@ struct HeadPairL6 {
 // plain fp32 heads (bf16x6)
 struct DecSdeL6 {
 #if TSDE_SPLIT_H3
-  enum : int { F = 0, G = F + DriftL6::SIZE, LOC = G + DiffL6::SIZE, SIZE = LOC + HeadPairL6::SIZE };
+  // fp16x3: the first layers of drift and diffusion stacked into ONE 128x64 matrix (rows 0..63 drift, 64..127 diffusion; one split
+  // of the state feeds both) with their bias / sin / cos columns stacked alike, then the rest of the two nets, then the head pair
+  enum : int {
+    S_END = 0,
+    TS_FIELD(W0FG, 2 * MAT64X6, S), TS_FIELD(B0FG, 128, W0FG), TS_FIELD(WSFG, 128, B0FG), TS_FIELD(WCFG, 128, WSFG),
+    TS_FIELD(F_W2, MAT64X6, WCFG), TS_FIELD(F_B2, 64, F_W2), TS_FIELD(F_W4, MAT64X6, F_B2), TS_FIELD(F_B4, 64, F_W4),
+    TS_FIELD(G_W2, MAT64X6, F_B4), TS_FIELD(G_B2, 64, G_W2), TS_FIELD(G_W4, 64, G_B2), TS_FIELD(G_B4, 4, G_W4),
+    LOC = G_B4_END, SIZE = LOC + HeadPairL6::SIZE
+  };
 #else
   enum : int { F = 0, G = F + DriftL6::SIZE, LOC = G + DiffL6::SIZE, SCALE = LOC + HeadL::SIZE, SIZE = SCALE + HeadL::SIZE };
 #endif

@@ -750,8 +750,32 @@ static void recipe_decoder(Packer& P) {
   recipe_diff(P, "lsde_func.g_func", DecBlob::SDE + DecSdeL::G);
   recipe_head(P, "decoder", DecBlob::SDE + DecSdeL::LOC);
   recipe_head(P, "scale", DecBlob::SDE + DecSdeL::SCALE);
+#if TSDE_SPLIT_H3
+  {
+    using D = DecSdeL6;
+    const int d = DecBlob::SDE6;
+    const std::string f = "lsde_func.f_func.net.", g = "lsde_func.g_func.net.";
+    P.mat6(f + "0.weight", d + D::W0FG, 64, 64, 66, 0);                 // jo-major planes: the two row blocks concatenate
+    P.mat6(g + "0.weight", d + D::W0FG + MAT64X6, 64, 64, 66, 0);
+    P.vec(f + "0.bias", d + D::B0FG, 64);
+    P.vec(g + "0.bias", d + D::B0FG + 64, 64);
+    P.col(f + "0.weight", d + D::WSFG, 64, 66, 64);
+    P.col(g + "0.weight", d + D::WSFG + 64, 64, 66, 64);
+    P.col(f + "0.weight", d + D::WCFG, 64, 66, 65);
+    P.col(g + "0.weight", d + D::WCFG + 64, 64, 66, 65);
+    P.mat6(f + "2.weight", d + D::F_W2, 64, 64, 64);
+    P.vec(f + "2.bias", d + D::F_B2, 64);
+    P.mat6(f + "4.weight", d + D::F_W4, 64, 64, 64);
+    P.vec(f + "4.bias", d + D::F_B4, 64);
+    P.mat6(g + "2.weight", d + D::G_W2, 64, 64, 64);
+    P.vec(g + "2.bias", d + D::G_B2, 64);
+    P.vec(g + "4.weight", d + D::G_W4, 64);
+    P.vec(g + "4.bias", d + D::G_B4, 1);
+  }
+#else
   recipe_drift6(P, "lsde_func.f_func", DecBlob::SDE6 + DecSdeL6::F);
   recipe_diff6(P, "lsde_func.g_func", DecBlob::SDE6 + DecSdeL6::G);
+#endif
 #if TSDE_SPLIT_H3
   {
     using HP = HeadPairL6;

@@ -80,4 +80,31 @@ __device__ __forceinline__ float diff_eval_x6(const f4 (&y)[4], const float* img
   return fast_sigmoid(row_dot(h2, img + DiffL6::W4, L.g) + img[DiffL6::B4]);
 }
 
+#if TSDE_SPLIT_H3
+// Drift and diffusion on the fp16x3 decoder image (layouts.hpp DecSdeL6).  The two first layers are ONE 128x64 product on one
+// split of the state (the heads do the same, decoder.hip head_pair_eval); `tb` = their 128 time-conditioned biases
+// b + s sin t + c cos t, which are constants of an Euler step: computed once per step into LDS (sde_time_bias), not once per tile.
+// Per output the arithmetic and its order are those of drift_eval_x6 / diff_eval_x6: same bits.
+__device__ __forceinline__ void sde_time_bias(float* tb, const float* img, float sn, float cs, int i /* 0..127 */) {
+  using DD = DecSdeL6;
+  tb[i] = fmaf(img[DD::WCFG + i], cs, fmaf(img[DD::WSFG + i], sn, img[DD::B0FG + i]));
+}
+__device__ __forceinline__ void sde_fg_eval(f4 (&f)[4], float& gs, const f4 (&y)[4], const float* img, const float* tb, const Lane& L) {
+  using DD = DecSdeL6;
+  f4 h[8];
+#pragma unroll
+  for (int jo = 0; jo < 8; ++jo) h[jo] = *reinterpret_cast<const f4*>(tb + 16 * jo + 4 * L.g);
+  linear_acc_x6<8, 4>(h, y, img + DD::W0FG, L.lane);
+  tanh_<8>(h);
+  const f4 hf[4] = {h[0], h[1], h[2], h[3]}, hg[4] = {h[4], h[5], h[6], h[7]};
+  f4 h2[4];
+  linear_x6<4, 4>(h2, hf, img + DD::F_W2, img + DD::F_B2, L);
+  tanh_<4>(h2);
+  linear_x6<4, 4>(f, h2, img + DD::F_W4, img + DD::F_B4, L);
+  linear_x6<4, 4>(h2, hg, img + DD::G_W2, img + DD::G_B2, L);
+  tanh_<4>(h2);
+  gs = fast_sigmoid(row_dot(h2, img + DD::G_W4, L.g) + img[DD::G_B4]);
+}
+#endif
+
 }  // namespace tsde

@@ -152,6 +152,7 @@ __device__ __forceinline__ void linear_acc_x6(f4 (&acc)[JT_OUT], const f4 (&in)[
   u4 b1[KS], b2[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) split_kstep(in[2 * s], in[2 * s + 1], b1[s], b2[s]);
+#ifdef TSDE_MFMA_CHAIN
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -165,6 +166,38 @@ __device__ __forceinline__ void linear_acc_x6(f4 (&acc)[JT_OUT], const f4 (&in)[
       acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, x1, acc[jo], 0, 0, 0);
     }
   }
+#else
+  // Two output tiles at a time, their three products interleaved: an instruction that takes its accumulator from the one issued
+  // right before it waits for that result (measured: ~27 cycles per instruction in such a chain against 16 when the chain
+  // alternates between two accumulators -- tools/microbench/coexec.hip modes 22 / 14).  Per accumulator the order of the products
+  // is unchanged: same bits.
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const h8 x1 = __builtin_bit_cast(h8, b1[s]), x2 = __builtin_bit_cast(h8, b2[s]);
+#pragma unroll
+    for (int jo = 0; jo < JT_OUT; jo += 2) {
+      const float* p = w + (jo * KS + s) * 512 + lane * 4;
+      const h8 a1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p));
+      const h8 a2 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(p + 256));
+      if (jo + 1 < JT_OUT) {
+        const float* r = w + ((jo + 1) * KS + s) * 512 + lane * 4;
+        const h8 c1 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(r));
+        const h8 c2 = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(r + 256));
+        acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1, acc[jo], 0, 0, 0);
+        acc[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, x1, acc[jo + 1], 0, 0, 0);
+        acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x2, acc[jo], 0, 0, 0);
+        acc[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, x2, acc[jo + 1], 0, 0, 0);
+        acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, x1, acc[jo], 0, 0, 0);
+        acc[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(c2, x1, acc[jo + 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                   // (left alone, the scheduler regroups the six into two chains of three)
+      } else {
+        acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1, acc[jo], 0, 0, 0);
+        acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x2, acc[jo], 0, 0, 0);
+        acc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, x1, acc[jo], 0, 0, 0);
+      }
+    }
+  }
+#endif
 }
 
 // the same contraction for TWO row tiles of the wave at once (weight fragments read from LDS once)
