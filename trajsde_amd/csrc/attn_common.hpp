@@ -16,8 +16,21 @@ __device__ __forceinline__ void edge_embed(f4 (&emb)[4], const f4 geom, const fl
   using E = typename std::conditional<X6, EdgeL6, EdgeL>::type;
   f4 h0[4], h1[4], s[4];
   if constexpr (X6) {
+#if TSDE_SPLIT_H3 && !defined(TSDE_IN2_VALU)
+    // the two first layers on the matrix cores (layouts.hpp IN2F), as in the fused edge attention
+    f4 ha[1][4], hb[1][4];
+    const float xa[1] = {geom[0]}, xb[1] = {geom[1]}, xc[1] = {geom[2]}, xd[1] = {geom[3]};
+    in2_mfma_relu_n<1>(ha, xa, xb, lds + EdgeL6::A_C, lds + EdgeL6::A_F, L.lane);
+    in2_mfma_relu_n<1>(hb, xc, xd, lds + EdgeL6::B_C, lds + EdgeL6::B_F, L.lane);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      h0[jt] = ha[0][jt];
+      h1[jt] = hb[0][jt];
+    }
+#else
     in2_ln_relu(h0, geom[0], geom[1], lds + EdgeL6::A_C, lds + E::A_E, L.g);
     in2_ln_relu(h1, geom[2], geom[3], lds + EdgeL6::B_C, lds + E::B_E, L.g);
+#endif
   } else {
     linear_in2(h0, geom[0], geom[1], lds + E::A_W0, lds + E::A_B0, L.g);
     layer_norm<4>(h0, lds + E::A_G, lds + E::A_E, L.g);
@@ -46,6 +59,22 @@ __device__ __forceinline__ void edge_embed2_x6(f4 (&emb0)[4], f4 (&emb1)[4], con
                                                const Lane& L) {
   using E = EdgeL6;
   f4 a0[4], a1[4], b0[4], b1[4], s0[4], s1[4];
+#if TSDE_SPLIT_H3 && !defined(TSDE_IN2_VALU)
+  {                                                        // the first layers on the matrix cores, like edge_embed<true>: same bits
+    f4 h[2][4];
+    const float xa[2] = {ge0[0], ge1[0]}, xb[2] = {ge0[1], ge1[1]}, xc[2] = {ge0[2], ge1[2]}, xd[2] = {ge0[3], ge1[3]};
+    in2_mfma_relu_n<2>(h, xa, xb, lds + E::A_C, lds + E::A_F, L.lane);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) { a0[jt] = h[0][jt]; a1[jt] = h[1][jt]; }
+    in2_mfma_relu_n<2>(h, xc, xd, lds + E::B_C, lds + E::B_F, L.lane);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) { b0[jt] = h[0][jt]; b1[jt] = h[1][jt]; }
+  }
+  load_vec<4>(s0, lds + E::B3, L.g);
+  load_vec<4>(s1, lds + E::B3, L.g);
+  linear_acc_x6_2<4, 4>(s0, s1, a0, a1, lds + E::WA3, L.lane);
+  linear_acc_x6_2<4, 4>(s0, s1, b0, b1, lds + E::WB3, L.lane);
+#else
   in2_ln_relu(a0, ge0[0], ge0[1], lds + E::A_C, lds + E::A_E, L.g);
   in2_ln_relu(a1, ge1[0], ge1[1], lds + E::A_C, lds + E::A_E, L.g);
   load_vec<4>(s0, lds + E::B3, L.g);
@@ -54,6 +83,7 @@ __device__ __forceinline__ void edge_embed2_x6(f4 (&emb0)[4], f4 (&emb1)[4], con
   in2_ln_relu(b0, ge0[2], ge0[3], lds + E::B_C, lds + E::B_E, L.g);
   in2_ln_relu(b1, ge1[2], ge1[3], lds + E::B_C, lds + E::B_E, L.g);
   linear_acc_x6_2<4, 4>(s0, s1, b0, b1, lds + E::WB3, L.lane);
+#endif
   layer_norm<4>(s0, lds + E::AG0, lds + E::AE0, L.g);
   relu<4>(s0);
   layer_norm<4>(s1, lds + E::AG0, lds + E::AE0, L.g);

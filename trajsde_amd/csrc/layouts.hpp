@@ -71,8 +71,9 @@ struct EdgeL6 {
     TS_FIELD(AG0, 64, B3), TS_FIELD(AE0, 64, AG0), TS_FIELD(W2, MAT64X6, AE0), TS_FIELD(B2, 64, W2),
     TS_FIELD(AG3, 64, B2), TS_FIELD(AE3, 64, AG3),
     TS_FIELD(A_C, In2L::SIZE, AE3), TS_FIELD(B_C, In2L::SIZE, A_C),     // closed-form first layers of the two branches
-    EMB_SIZE = B_C_END,
-    TS_FIELD(WKV, 2 * MAT64X6, B_C), TS_FIELD(BKV, 128, WKV),
+    TS_FIELD(A_F, IN2F, B_C), TS_FIELD(B_F, IN2F, A_F),                 // ... and their matrix-core fragments (IN2F)
+    EMB_SIZE = B_F_END,
+    TS_FIELD(WKV, 2 * MAT64X6, B_F), TS_FIELD(BKV, 128, WKV),
     SIZE = BKV_END
   };
 };

@@ -404,6 +404,8 @@ static void recipe_edge_embed6(Packer& P, const std::string& p, int base) {   //
   P.vec(p + ".module_list.1.3.bias", base + E::B3, 64, /*accumulate=*/true);
   P.ln2(p + ".module_list.0", base + E::A_C);
   P.ln2(p + ".module_list.1", base + E::B_C);
+  P.in2f(p + ".module_list.0", base + E::A_C, base + E::A_F);
+  P.in2f(p + ".module_list.1", base + E::B_C, base + E::B_F);
   P.ln(p + ".aggr_embed.0", base + E::AG0, base + E::AE0);
   P.mat6(p + ".aggr_embed.2.weight", base + E::W2, 64, 64, 64);
   P.vec(p + ".aggr_embed.2.bias", base + E::B2, 64);
