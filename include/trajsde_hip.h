@@ -106,7 +106,7 @@ typedef struct {
   const float* lane_actor_vectors; /* [E_al,2]           */
 } trajsde_batch;
 
-/* ---- noise: injected standard normals or in-kernel Philox4x32-10 (curand-free) ------------------
+/* ---- noise: injected standard normals or in-kernel Philox4x32-7 (curand-free) ------------------
  * Philox counter = (row id, step, stream, column/4), key = seed; row ids are GLOBAL ids when row_ids
  * is given, else the local row index (host twin: trajsde_amd/philox.py). */
 typedef struct {

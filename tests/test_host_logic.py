@@ -31,6 +31,31 @@ def test_losses_match_reference_formulas():
     assert abs(float(DiffBCE()(data, o)) - float(want)) < 1e-6
 
 
+def test_laplace_nll_value_matches_the_reference_class():
+    """losses/laplace_nll_loss.py evaluated by the reference's own class (run from /root/reference where it exists) and by the
+    literal formula otherwise"""
+    import os
+    import sys
+    from trajsde_amd.losses import LaplaceNLLLoss
+    batch, o = _oracle_case()
+    data = {"y": o["y"]}
+    got = float(LaplaceNLLLoss(eps=1e-6)(data, o))
+    loc, scale = o["loc"].chunk(2, dim=-1)
+    diff = torch.norm(o["y"].unsqueeze(0) - loc, dim=-1)
+    d_ = diff.clone()
+    d_[:, ~o["reg_mask"]] = 0
+    best = torch.argmin(d_.mean(-1), dim=0)
+    ar = torch.arange(best.size(0))
+    l, s = loc[best, ar], scale[best, ar].clamp(min=1e-6)
+    want = float((torch.log(2 * s) + torch.abs(o["y"] - l) / s)[o["reg_mask"]].mean())
+    assert abs(got - want) <= 1e-6 * max(1.0, abs(want))
+    ref_file = "/root/reference/losses/laplace_nll_loss.py"
+    if os.path.isfile(ref_file):
+        from importlib.machinery import SourceFileLoader
+        ref = SourceFileLoader("ref_laplace", ref_file).load_module("ref_laplace").LaplaceNLLLoss(eps=1e-6)
+        assert abs(got - float(ref(data, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()}))) <= 1e-6 * max(1.0, abs(want))
+
+
 def test_metrics_match_reference_formulas():
     from trajsde_amd.metrics import ADE_T, FDE_T, MR_T
     batch, o = _oracle_case()

@@ -108,13 +108,22 @@ def test_schedule_table_matches_appendix_d():
 
 def test_philox_known_answers_and_moments():
     from trajsde_amd import philox
-    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
-           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
-           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
-            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]          # Random123 kat_vectors, philox4x32-10
-    for ctr, key, want in kat:
-        got = philox.philox4x32_10(np.array([ctr], np.uint32), np.array(key, np.uint32))[0]
-        assert tuple(int(x) for x in got) == want
+    # Random123 kat_vectors: the same three (counter, key) pairs at the library's default 10 rounds and at the 7 rounds this
+    # build runs (csrc/philox.hpp PHILOX_ROUNDS; trajsde_amd/philox.py is its twin)
+    pi_ctr, pi_key = (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)
+    kat = {10: [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+                ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+                (pi_ctr, pi_key, (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))],
+           7: [((0, 0, 0, 0), (0, 0), (0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48)),
+               ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662)),
+               (pi_ctr, pi_key, (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a))]}
+    assert philox.PHILOX_ROUNDS == 7
+    for rounds, vectors in kat.items():
+        for ctr, key, want in vectors:
+            got = philox.philox4x32(np.array([ctr], np.uint32), np.array(key, np.uint32), rounds=rounds)[0]
+            assert tuple(int(v) for v in got) == want, (rounds, ctr)
+    got = philox.philox4x32(np.array([pi_ctr], np.uint32), np.array(pi_key, np.uint32))[0]        # the default IS the 7-round one
+    assert tuple(int(v) for v in got) == kat[7][2][2]
     z = philox.normals(7, philox.STREAM_DECODER, 3, np.arange(4096), 64)
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
     # keyed by global row id: a shard sees exactly the rows it owns

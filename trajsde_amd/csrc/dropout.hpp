@@ -6,7 +6,7 @@
 //   DK_PROJ    proj_drop(out_proj(...))                   per (node, feature)   ENC:611 / ENC:794 / AGG:132
 //   DK_HIDDEN  mlp: Linear - ReLU - Dropout - ...         per (node, 256 units) ENC:531 / ENC:721 / AGG:88
 //   DK_OUT     mlp: ... - Linear - Dropout                per (node, feature)   ENC:533 / ENC:723 / AGG:90
-// A mask element is a 16-bit field of a Philox4x32-10 block, kept when field >= round(p * 65536) and then scaled by 1/(1-p)
+// A mask element is a 16-bit field of a Philox4x32-7 block (philox.hpp PHILOX_ROUNDS), kept when field >= round(p * 65536) and then scaled by 1/(1-p)
 // like torch's dropout.  The counter identifies the element, never a launch geometry, so the forward, the forward
 // recomputation inside the backward entry points and the backward kernels all regenerate the same mask:
 //   node sites   counter = (row, call, stream, 0)  call = 8*blk + 2g + (jt>>1), field 4(jt&1)+c  for feature 64*blk + 16jt + 4g + c

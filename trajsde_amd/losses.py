@@ -33,3 +33,26 @@ class DiffBCE:
     def __call__(self, data, output) -> torch.Tensor:
         return (F.binary_cross_entropy(output["diff_in"], output["label_in"], reduction=self.reduction) +
                 F.binary_cross_entropy(output["diff_out"], output["label_out"], reduction=self.reduction))
+
+
+class LaplaceNLLLoss:
+    """losses/laplace_nll_loss.py:18-47: Laplace negative log-likelihood of the winner-takes-all mode (the mode with the
+    smallest masked mean L2), scale clamped at `eps`.  No shipped configuration names it (CFG:78-83 use L2 + DiffBCE), so
+    only its VALUE is built -- validation-time reporting on the forward's device tensors; `training_step` refuses it (the
+    HIP backward entry points differentiate L2 and DiffBCE; the scale head gets no gradient from those)."""
+
+    def __init__(self, eps: float = 1e-6, reduction: str = "mean") -> None:
+        if reduction != "mean":
+            raise ValueError("{} is not a valid value for reduction".format(reduction))
+        self.eps, self.reduction = float(eps), reduction
+
+    def __call__(self, data, output) -> torch.Tensor:
+        target = data["y"]
+        loc, scale = output["loc"].chunk(2, dim=-1)
+        reg_mask = output["reg_mask"]
+        diff = torch.norm(target.unsqueeze(0) - loc, dim=-1) * reg_mask.unsqueeze(0)
+        best = diff.mean(-1).argmin(0)
+        idx = torch.arange(best.size(0), device=best.device)
+        loc, scale = loc[best, idx], scale[best, idx].clamp(min=self.eps)
+        nll = torch.log(2 * scale) + torch.abs(target - loc) / scale
+        return nll[reg_mask].mean()

@@ -1,4 +1,4 @@
-"""Philox4x32-10 counter-based normals: the bit-exact host twin of the in-kernel generator
+"""Philox4x32-7 counter-based normals: the bit-exact host twin of the in-kernel generator
 (trajsde_amd/csrc/philox.hpp).  curand-free; the counter is keyed by *global* ids so that the stream
 does not change when scenes are re-sharded across GPUs.
 
@@ -21,13 +21,16 @@ STREAM_ENCODER = 2      # 21 Brownian increments [Nt,64] (sdeint.py:480)
 STREAM_DECODER = 3      # T_euler Brownian increments [K*N,64] (dec_hivt_nusargo_sde.py:88)
 
 
-def philox4x32_10(ctr: np.ndarray, key: np.ndarray) -> np.ndarray:
+PHILOX_ROUNDS = 7      # csrc/philox.hpp: Random123's Philox4x32-7 (the Crush-resistant minimum; 10 is its default with a margin)
+
+
+def philox4x32(ctr: np.ndarray, key: np.ndarray, rounds: int = PHILOX_ROUNDS) -> np.ndarray:
     """ctr [...,4] uint32, key [2] uint32 -> [...,4] uint32."""
     c0, c1, c2, c3 = (ctr[..., i].astype(np.uint32) for i in range(4))
     k0, k1 = np.uint32(key[0]), np.uint32(key[1])
     mask = np.uint64(0xFFFFFFFF)
     with np.errstate(over="ignore"):
-        for _ in range(10):
+        for _ in range(rounds):
             p0 = c0.astype(np.uint64) * PHILOX_M0
             p1 = c2.astype(np.uint64) * PHILOX_M1
             hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & mask).astype(np.uint32)
@@ -53,7 +56,7 @@ def normals(seed: int, stream: int, step: int, rows: np.ndarray, ncols: int) -> 
     ctr[..., 2] = np.uint32(stream)
     ctr[..., 3] = np.arange(nq, dtype=np.uint32)[None, :]
     key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
-    w = philox4x32_10(ctr, key)
+    w = philox4x32(ctr, key)
     u = _uniform(w)
     two_pi = np.float32(6.283185307179586)
     out = np.empty((rows.shape[0], nq, 4), dtype=np.float32)
@@ -80,7 +83,7 @@ def words(seed: int, stream: int, step, rows, quad: int = 0) -> np.ndarray:
     ctr = np.zeros(rows.shape + (4,), dtype=np.uint32)
     ctr[..., 0], ctr[..., 1], ctr[..., 2], ctr[..., 3] = rows, step, np.uint32(stream), np.uint32(quad)
     key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
-    return philox4x32_10(ctr, key)
+    return philox4x32(ctr, key)
 
 
 def dropout_threshold(p: float) -> int:

@@ -33,7 +33,7 @@ def _require_gpu(t: torch.Tensor, what: str) -> None:
 class NoiseSpec:
     """Where the path's randomness comes from (SURVEY.md App. F draw order).
 
-    seed            in-kernel Philox4x32-10 key; host twin: trajsde_amd/philox.py
+    seed            in-kernel Philox4x32-7 key; host twin: trajsde_amd/philox.py
     z_fake/z_enc/z_dec   injected standard normals [A,21,2] / [21,Nt,64] / [n_euler,K*N,64] (parity tests)
     *_row_ids       int32 global row ids for the Philox counter (resharding-invariant streams)
     """
