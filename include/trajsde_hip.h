@@ -72,7 +72,8 @@ typedef enum {
   TRAJSDE_STAGE_ENCODER_GRID = 6,
   TRAJSDE_STAGE_DECODER_MLP = 7,
   TRAJSDE_STAGE_DECODER_MLP_BWD = 8, /* trajsde_mlp_decoder_l2_backward; num_layers = future steps */
-  TRAJSDE_STAGE_ENCODER_GRID_BWD = 9 /* trajsde_encoder_grid_backward; num_layers = temporal layers */
+  TRAJSDE_STAGE_ENCODER_GRID_BWD = 9, /* trajsde_encoder_grid_backward; num_layers = temporal layers */
+  TRAJSDE_STAGE_DECODER_NLL_BWD = 10  /* trajsde_decoder_nll_backward: the DECODER_BWD table followed by the scale head (ABI 8) */
 } trajsde_stage;
 
 int trajsde_param_count(int stage, int num_layers /*aggregator*/, int num_modes);
@@ -306,6 +307,18 @@ int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, cons
                                 const uint8_t* reg_mask /*[N,T]*/, void* ws, int64_t ws_bytes, float* loss /*[1] device*/,
                                 int32_t* best_mode /*[N] device or null*/, float* const* grads, int n_grads,
                                 float* d_local /*[N,64]*/, float* d_global /*[K,N,64]*/, void* stream);
+
+/* The same stage under the Laplace negative log-likelihood (losses/laplace_nll_loss.py:18-47; ABI 8): the winner is still the
+ * mode with the smallest masked L2, the loss is mean over valid steps and both coordinates of log(2 s) + |y - l| / s with
+ * s = max(scale, eps) of that mode -- so the scale head (ELU + 1 + min_scale, DEC:97-98) receives a gradient too.  `grads`
+ * follow trajsde_param_name(TRAJSDE_STAGE_DECODER_NLL_BWD, i): the DECODER_BWD table, then scale.0 / .1 / .3 weight and bias;
+ * `blob_bwd` is that stage's image. */
+int64_t trajsde_decoder_nll_backward_ws_bytes(int32_t N, int num_modes, int future_steps, int n_euler);
+int trajsde_decoder_nll_backward(int32_t N, int num_modes, int future_steps, const float* blob_fwd, const float* blob_bwd,
+                                 const float* local_embed, const float* global_embed, const float* step_table, int n_euler,
+                                 const float* out_table, const trajsde_noise* noise, const float* loc, const float* y,
+                                 const uint8_t* reg_mask, float eps, float min_scale, void* ws, int64_t ws_bytes, float* loss,
+                                 int32_t* best_mode, float* const* grads, int n_grads, float* d_local, float* d_global, void* stream);
 
 /* ---- backward of the aggregator stage (AGG:38-58, 92-135): dL/d global_embed -> dL/d local_embed (overwritten;
  *      the caller adds the decoder's own d local_embed) and one gradient per aggregator parameter, grads[i] shaped

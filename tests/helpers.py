@@ -71,8 +71,25 @@ def reference_l2(y, loc, reg_mask):
     return minl2[reg_mask].mean(), best
 
 
-def oracle_full_grads(model, cfg, batch_cpu, seed, w_l2, w_diff, want_parts=False, drop=None):
-    """end-to-end autograd over the oracle (float64): encoder -> aggregator -> decoder -> w_l2 L2 + w_diff DiffBCE;
+def reference_laplace_nll(y, out_loc4, reg_mask, eps=1e-6):
+    """losses/laplace_nll_loss.py:29-44 spelled out on tensors (mean reduction; the clamp is applied without a gradient)"""
+    loc, scale = out_loc4.chunk(2, dim=-1)
+    diff = torch.norm(y.unsqueeze(0) - loc, dim=-1)
+    d_ = diff.clone()
+    d_[:, ~reg_mask] = 0
+    best = torch.argmin(d_.mean(-1), dim=0)
+    ar = torch.arange(best.size(0))
+    loc, scale = loc[best, ar], scale[best, ar]
+    scale = scale.clone()
+    with torch.no_grad():
+        scale.clamp_(min=eps)
+    nll = torch.log(2 * scale) + torch.abs(y - loc) / scale
+    return nll[reg_mask].mean(), best
+
+
+def oracle_full_grads(model, cfg, batch_cpu, seed, w_l2, w_diff, want_parts=False, drop=None, nll_eps=None):
+    """end-to-end autograd over the oracle (float64): encoder -> aggregator -> decoder -> w_l2 L2 (or, with `nll_eps`, the
+    Laplace NLL) + w_diff DiffBCE;
     `drop`: a restate.PhiloxDropout for train-mode dropout (the masks the HIP kernels cut from their Philox stream)"""
     import restate
     import torch.nn.functional as F
@@ -108,7 +125,10 @@ def oracle_full_grads(model, cfg, batch_cpu, seed, w_l2, w_diff, want_parts=Fals
             local, diff_in, diff_out, _ = restate.local_encoder(P, c, b, rot, noise, es, False, drop)
             glob = restate.global_interactor(P, c, b, rot, local, None, drop)
             out = restate.sde_decoder(P, c, b, local, glob, noise, ds)
-            l2, _ = reference_l2(y_rot, out["loc"][..., :2], out["reg_mask"])
+            if nll_eps is None:
+                l2, _ = reference_l2(y_rot, out["loc"][..., :2], out["reg_mask"])
+            else:                                                    # the regression loss is the Laplace NLL (both heads trained)
+                l2, _ = reference_laplace_nll(y_rot, out["loc"], out["reg_mask"], nll_eps)
             bce = (F.binary_cross_entropy(diff_in, torch.zeros_like(diff_in)) +
                    F.binary_cross_entropy(diff_out, torch.ones_like(diff_out)))
             loss = w_l2 * l2 + w_diff * bce

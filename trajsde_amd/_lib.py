@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("TRAJSDE_LIB") or os.path.join(HERE, "libtrajsde_hip.s
 
 STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGATOR_BWD, STAGE_ENCODER_BWD = 0, 1, 2, 3, 4, 5
 STAGE_ENCODER_GRID, STAGE_DECODER_MLP, STAGE_DECODER_MLP_BWD, STAGE_ENCODER_GRID_BWD = 6, 7, 8, 9
+STAGE_DECODER_NLL_BWD = 10
 
 
 ABI_VERSION = 8          # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4);
@@ -82,6 +83,9 @@ SIGNATURES = {
     "trajsde_decoder_backward_ws_bytes": (I64, [I32, C.c_int, C.c_int, C.c_int]),
     "trajsde_decoder_l2_backward": (C.c_int, [I32, C.c_int, C.c_int, P, P, P, P, P, C.c_int, P, C.POINTER(Noise), P, P, P, P, I64,
                                               P, P, C.POINTER(P), C.c_int, P, P, P]),
+    "trajsde_decoder_nll_backward_ws_bytes": (I64, [I32, C.c_int, C.c_int, C.c_int]),
+    "trajsde_decoder_nll_backward": (C.c_int, [I32, C.c_int, C.c_int, P, P, P, P, P, C.c_int, P, C.POINTER(Noise), P, P, P, F32, F32, P, I64,
+                                               P, P, C.POINTER(P), C.c_int, P, P, P]),
     "trajsde_aggregator_backward_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph), C.c_int, C.c_int]),
     "trajsde_aggregator_backward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, C.c_int, C.c_int, P, P, P, I64,
                                               C.POINTER(P), C.c_int, P, P]),

@@ -59,9 +59,37 @@ __global__ void k_l2_wta(const float* __restrict__ loc, const float* __restrict_
   cnt[i] = c;
 }
 
+__device__ __forceinline__ void k_loss_finalize_body(const float* __restrict__ minsum, const int32_t* __restrict__ cnt, int N,
+                                                      float* __restrict__ scal, int per_step);
+// Laplace NLL of the winning mode (losses/laplace_nll_loss.py:29-44): per actor the sum over its valid steps of
+// log(2 s) + |y - l| / s for both coordinates, s = max(scale, eps); overwrites minsum (the winner is already chosen)
+__global__ void k_nll_value(const float* __restrict__ loc, const float* __restrict__ y, const uint8_t* __restrict__ mask,
+                            const int32_t* __restrict__ best, int N, int T, float eps, float* __restrict__ minsum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) {
+    if (!mask[int64_t(i) * T + t]) continue;
+    const f4 l = *reinterpret_cast<const f4*>(loc + ((int64_t(best[i]) * N + i) * T + t) * 4);
+    const float sx = fmaxf(l[2], eps), sy = fmaxf(l[3], eps);
+    s += logf(2.f * sx) + fabsf(y[(int64_t(i) * T + t) * 2] - l[0]) / sx;
+    s += logf(2.f * sy) + fabsf(y[(int64_t(i) * T + t) * 2 + 1] - l[1]) / sy;
+  }
+  minsum[i] = s;
+}
+
 // scal[0] = loss = sum(minsum) / count, scal[1] = 1/count (0 when nothing is valid); fixed summation order
 __global__ __launch_bounds__(1024) void k_l2_finalize(const float* __restrict__ minsum, const int32_t* __restrict__ cnt, int N,
                                                       float* __restrict__ scal) {
+  k_loss_finalize_body(minsum, cnt, N, scal, 1);
+}
+// the same with `per_step` loss elements per valid step (the Laplace NLL averages over the x and the y term: 2)
+__global__ __launch_bounds__(1024) void k_nll_finalize(const float* __restrict__ minsum, const int32_t* __restrict__ cnt, int N,
+                                                       float* __restrict__ scal) {
+  k_loss_finalize_body(minsum, cnt, N, scal, 2);
+}
+__device__ __forceinline__ void k_loss_finalize_body(const float* __restrict__ minsum, const int32_t* __restrict__ cnt, int N,
+                                                      float* __restrict__ scal, int per_step) {
   __shared__ double ssum[1024];
   __shared__ long long scnt[1024];
   double s = 0.0;
@@ -81,8 +109,9 @@ __global__ __launch_bounds__(1024) void k_l2_finalize(const float* __restrict__ 
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    scal[0] = scnt[0] > 0 ? float(ssum[0] / double(scnt[0])) : 0.f;
-    scal[1] = scnt[0] > 0 ? float(1.0 / double(scnt[0])) : 0.f;
+    const double denom = double(scnt[0]) * per_step;
+    scal[0] = scnt[0] > 0 ? float(ssum[0] / denom) : 0.f;
+    scal[1] = scnt[0] > 0 ? float(1.0 / denom) : 0.f;
   }
 }
 
@@ -168,11 +197,20 @@ __global__ __launch_bounds__(128) void k_sde_replay(const float* __restrict__ im
 struct HeadV { enum : int { DGAM = 0, DBET = 64, DW3X = 128, DW3Y = 192, DB3 = 256, SIZE = 264 }; };
 
 // rows are (o, i): o = output step, i = actor.  S_in / DU / DS are [T][N][64]
+// MODE 0: the loc head under the winner-takes-all L2 loss.  MODE 1 / 2: the loc / the scale head under the Laplace NLL
+// (losses/laplace_nll_loss.py): `nll` carries the forward's outputs of the winning mode (the other head's value enters each
+// head's upstream gradient); the scale head's launch ADDS its state gradient to the loc head's (DS) and writes its own delta rows.
+struct NllArg {
+  const float* loc;        // [K, N, T, 4] forward outputs
+  const int32_t* best;     // winning mode per actor
+  float eps, min_scale;
+};
+template <int MODE>
 __global__ __launch_bounds__(128) void k_head_bwd(const float* __restrict__ img, const float* __restrict__ states,
                                                   const float* __restrict__ out_tab, const float* __restrict__ y,
                                                   const uint8_t* __restrict__ mask, const float* __restrict__ scal, int N, int T,
                                                   float* __restrict__ S_in, float* __restrict__ DU, float* __restrict__ DS,
-                                                  float* __restrict__ vpart) {
+                                                  float* __restrict__ vpart, NllArg nll) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, img, HeadBwdL::SIZE);
   const Lane L;
@@ -218,14 +256,35 @@ __global__ __launch_bounds__(128) void k_head_bwd(const float* __restrict__ img,
     }
     const float lx = row_dot(v, H + HeadL::W3, L.g) + H[HeadL::B3];
     const float ly = row_dot(v, H + HeadL::W3 + 64, L.g) + H[HeadL::B3 + 1];
-    // dL/dl = (l - y) / |l - y| / count on valid steps (L2.py:16,25)
     float gx = 0.f, gy = 0.f;
     if (row < N && mask[int64_t(i) * T + o]) {
-      const float dx = lx - y[(int64_t(i) * T + o) * 2], dy = ly - y[(int64_t(i) * T + o) * 2 + 1];
-      const float nrm = sqrtf(dx * dx + dy * dy);
-      if (nrm > 0.f) {
-        gx = dx / nrm * inv_count;
-        gy = dy / nrm * inv_count;
+      const float yx = y[(int64_t(i) * T + o) * 2], yy = y[(int64_t(i) * T + o) * 2 + 1];
+      if (MODE == 0) {
+        // dL/dl = (l - y) / |l - y| / count on valid steps (L2.py:16,25)
+        const float dx = lx - yx, dy = ly - yy;
+        const float nrm = sqrtf(dx * dx + dy * dy);
+        if (nrm > 0.f) {
+          gx = dx / nrm * inv_count;
+          gy = dy / nrm * inv_count;
+        }
+      } else {
+        const f4 fw = *reinterpret_cast<const f4*>(nll.loc + ((int64_t(nll.best[i]) * N + i) * T + o) * 4);
+        if (MODE == 1) {
+          // d/dl [ |y - l| / s ] = -sign(y - l) / s, s = max(scale, eps) of the forward (no gradient through the clamp's value)
+          const float sx = fmaxf(fw[2], nll.eps), sy = fmaxf(fw[3], nll.eps);
+          const float ex = yx - lx, ey = yy - ly;
+          gx = (ex > 0.f ? -1.f : ex < 0.f ? 1.f : 0.f) / sx * inv_count;
+          gy = (ey > 0.f ? -1.f : ey < 0.f ? 1.f : 0.f) / sy * inv_count;
+        } else {
+          // this head's two outputs are the raw scales: s = ELU(raw) + 1 + min_scale (DEC:97-98), clamped at eps in place, the
+          // gradient passing through (laplace_nll_loss.py:38-40); d/ds [ log 2s + |y - l| / s ] = 1/s - |y - l| / s^2
+          const float sxr = (lx > 0.f ? lx : fast_exp(lx) - 1.0f) + 1.0f + nll.min_scale;
+          const float syr = (ly > 0.f ? ly : fast_exp(ly) - 1.0f) + 1.0f + nll.min_scale;
+          const float sx = fmaxf(sxr, nll.eps), sy = fmaxf(syr, nll.eps);
+          const float ax = fabsf(yx - fw[0]), ay = fabsf(yy - fw[1]);
+          gx = (1.0f / sx - ax / (sx * sx)) * inv_count * (lx > 0.f ? 1.0f : fast_exp(lx));
+          gy = (1.0f / sy - ay / (sy * sy)) * inv_count * (ly > 0.f ? 1.0f : fast_exp(ly));
+        }
       }
     }
     db3x += gx;
@@ -246,7 +305,14 @@ __global__ __launch_bounds__(128) void k_head_bwd(const float* __restrict__ img,
     f4 ds[4];
     linear_t(ds, dv, lds + HeadBwdL::W0T, L);
     if (row < N) {
-      store_row(s, S_in + o * slab, row, L.g);
+      if (MODE == 2) {                                       // the second head of the step: its state gradient joins the first's
+        f4 prev[4];
+        load_row(prev, DS + o * slab, row, L.g);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) ds[jt] += prev[jt];
+      } else {
+        store_row(s, S_in + o * slab, row, L.g);
+      }
       store_row(dv, DU + o * slab, row, L.g);
       store_row(ds, DS + o * slab, row, L.g);
     }
@@ -733,18 +799,20 @@ namespace {
 
 // gradient slots, in the order of trajsde_param_name(TRAJSDE_STAGE_DECODER_BWD, i)  (pack.hip recipe_decoder_bwd)
 enum GradSlot {
-  F0W = 0, F2W, F4W, G0W, G2W, G4W, D0W, D0B, D1W, D1B, D3W, D3B, A0W, A0B, A1W, A1B, F0B, F2B, F4B, G0B, G2B, G4B, N_GRADS
+  F0W = 0, F2W, F4W, G0W, G2W, G4W, D0W, D0B, D1W, D1B, D3W, D3B, A0W, A0B, A1W, A1B, F0B, F2B, F4B, G0B, G2B, G4B, N_GRADS,
+  // TRAJSDE_STAGE_DECODER_NLL_BWD: the same table followed by the scale head (pack.hip recipe_decoder_nll_bwd)
+  S0W = N_GRADS, S0B, S1W, S1B, S3W, S3B, N_GRADS_NLL
 };
 constexpr int BWD_THREADS = 128;
 
 struct BwdWs {
   int32_t *best, *cnt;
   float *minsum, *scal, *states, *H1, *H2, *G1, *G2, *GS, *DH1, *DH2, *DF, *DG1, *DG2, *S_in, *DU, *DS, *gsel, *DA, *DY0, *part, *cs,
-      *vpart;
+      *vpart, *DU2;
   int64_t bytes, parts;
 };
 
-BwdWs carve_bwd(void* ws, int64_t ws_bytes, int N, int T, int n_euler, bool& ok) {
+BwdWs carve_bwd(void* ws, int64_t ws_bytes, int N, int T, int n_euler, bool& ok, bool nll = false) {
   Carver cv(ws, ws_bytes);
   BwdWs w;
   const int64_t slab = int64_t(N) * 64;
@@ -774,6 +842,7 @@ BwdWs carve_bwd(void* ws, int64_t ws_bytes, int N, int T, int n_euler, bool& ok)
   w.part = cv.take<float>(max_parts * 4096);
   w.cs = cv.take<float>(max_parts * 64);
   w.vpart = cv.take<float>(int64_t(256) * (BWD_THREADS / 64) * 512);
+  w.DU2 = nll ? cv.take<float>(slab * T) : nullptr;        // the scale head's delta rows (Laplace NLL)
   w.bytes = cv.off + 256;
   ok = cv.ok;
   return w;
@@ -795,23 +864,57 @@ int64_t trajsde_decoder_backward_ws_bytes(int32_t N, int num_modes, int future_s
   return carve_bwd(nullptr, 0, N, future_steps, n_euler, ok).bytes;
 }
 
+int64_t trajsde_decoder_nll_backward_ws_bytes(int32_t N, int num_modes, int future_steps, int n_euler) {
+  (void)num_modes;
+  bool ok;
+  return carve_bwd(nullptr, 0, N, future_steps, n_euler, ok, true).bytes;
+}
+
+static int decoder_backward_impl(bool nll, float eps, float min_scale, int32_t N, int num_modes, int future_steps, const float* blob_fwd,
+                                 const float* blob_bwd, const float* local_embed, const float* global_embed, const float* step_table,
+                                 int n_euler, const float* out_table, const trajsde_noise* noise, const float* loc, const float* y,
+                                 const uint8_t* reg_mask, void* ws, int64_t ws_bytes, float* loss, int32_t* best_mode, float* const* grads,
+                                 int n_grads, float* d_local, float* d_global, void* stream_);
+
 int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, const float* blob_fwd, const float* blob_bwd,
                                 const float* local_embed, const float* global_embed, const float* step_table, int n_euler,
                                 const float* out_table, const trajsde_noise* noise, const float* loc, const float* y,
                                 const uint8_t* reg_mask, void* ws, int64_t ws_bytes, float* loss, int32_t* best_mode,
                                 float* const* grads, int n_grads, float* d_local, float* d_global, void* stream_) {
+  return decoder_backward_impl(false, 0.f, 0.f, N, num_modes, future_steps, blob_fwd, blob_bwd, local_embed, global_embed, step_table, n_euler,
+                               out_table, noise, loc, y, reg_mask, ws, ws_bytes, loss, best_mode, grads, n_grads, d_local, d_global, stream_);
+}
+
+int trajsde_decoder_nll_backward(int32_t N, int num_modes, int future_steps, const float* blob_fwd, const float* blob_bwd,
+                                 const float* local_embed, const float* global_embed, const float* step_table, int n_euler,
+                                 const float* out_table, const trajsde_noise* noise, const float* loc, const float* y,
+                                 const uint8_t* reg_mask, float eps, float min_scale, void* ws, int64_t ws_bytes, float* loss,
+                                 int32_t* best_mode, float* const* grads, int n_grads, float* d_local, float* d_global, void* stream_) {
+  TS_REQUIRE(eps > 0.f, "decoder_nll_backward: eps must be positive");
+  return decoder_backward_impl(true, eps, min_scale, N, num_modes, future_steps, blob_fwd, blob_bwd, local_embed, global_embed, step_table,
+                               n_euler, out_table, noise, loc, y, reg_mask, ws, ws_bytes, loss, best_mode, grads, n_grads, d_local, d_global,
+                               stream_);
+}
+
+static int decoder_backward_impl(bool nll, float eps, float min_scale, int32_t N, int num_modes, int future_steps, const float* blob_fwd,
+                                 const float* blob_bwd, const float* local_embed, const float* global_embed, const float* step_table,
+                                 int n_euler, const float* out_table, const trajsde_noise* noise, const float* loc, const float* y,
+                                 const uint8_t* reg_mask, void* ws, int64_t ws_bytes, float* loss, int32_t* best_mode, float* const* grads,
+                                 int n_grads, float* d_local, float* d_global, void* stream_) {
   TS_REQUIRE(blob_fwd && blob_bwd && local_embed && global_embed && step_table && out_table && loc && y && reg_mask && ws && loss &&
                  grads && d_local && d_global,
-             "decoder_l2_backward: null pointer");
-  TS_REQUIRE(N > 0 && num_modes > 0 && future_steps > 0 && n_euler > 0, "decoder_l2_backward: empty problem");
-  TS_REQUIRE(n_grads == N_GRADS, "decoder_l2_backward: gradient count does not match trajsde_param_count(DECODER_BWD)");
-  for (int i = 0; i < N_GRADS; ++i) TS_REQUIRE(grads[i] != nullptr, "decoder_l2_backward: null gradient buffer");
-  if (ws_bytes < trajsde_decoder_backward_ws_bytes(N, num_modes, future_steps, n_euler))
-    return fail(TRAJSDE_ERR_WORKSPACE, "decoder_l2_backward: workspace too small");
+             "decoder backward: null pointer");
+  TS_REQUIRE(N > 0 && num_modes > 0 && future_steps > 0 && n_euler > 0, "decoder backward: empty problem");
+  const int want_grads = nll ? int(N_GRADS_NLL) : int(N_GRADS);
+  TS_REQUIRE(n_grads == want_grads, "decoder backward: gradient count does not match trajsde_param_count of the backward stage");
+  for (int i = 0; i < want_grads; ++i) TS_REQUIRE(grads[i] != nullptr, "decoder backward: null gradient buffer");
+  if (ws_bytes < (nll ? trajsde_decoder_nll_backward_ws_bytes(N, num_modes, future_steps, n_euler)
+                      : trajsde_decoder_backward_ws_bytes(N, num_modes, future_steps, n_euler)))
+    return fail(TRAJSDE_ERR_WORKSPACE, "decoder backward: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   bool ok;
   const int K = num_modes, T = future_steps;
-  BwdWs w = carve_bwd(ws, ws_bytes, N, T, n_euler, ok);
+  BwdWs w = carve_bwd(ws, ws_bytes, N, T, n_euler, ok, nll);
   NoiseArg na{0, nullptr, nullptr};
   if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; na.seed_dev = noise->seed_dev; }
   const int ntiles = (N + 15) / 16;
@@ -819,8 +922,13 @@ int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, cons
   const int64_t slab = int64_t(N) * 64;
 
   // ---- loss, winner per actor
-  TS_LAUNCH(k_l2_wta, cdiv(N, 256), 256, 0, st, loc, y, reg_mask, N, K, T, w.best, w.minsum, w.cnt);
-  TS_LAUNCH(k_l2_finalize, 1, 1024, 0, st, w.minsum, w.cnt, N, w.scal);
+  TS_LAUNCH(k_l2_wta, cdiv(N, 256), 256, 0, st, loc, y, reg_mask, N, K, T, w.best, w.minsum, w.cnt);     // the winner is the L2 one in both losses
+  if (nll) {
+    TS_LAUNCH(k_nll_value, cdiv(N, 256), 256, 0, st, loc, y, reg_mask, w.best, N, T, eps, w.minsum);
+    TS_LAUNCH(k_nll_finalize, 1, 1024, 0, st, w.minsum, w.cnt, N, w.scal);
+  } else {
+    TS_LAUNCH(k_l2_finalize, 1, 1024, 0, st, w.minsum, w.cnt, N, w.scal);
+  }
   TS_HIP(hipMemcpyAsync(loss, w.scal, sizeof(float), hipMemcpyDeviceToDevice, st));
   if (best_mode) TS_HIP(hipMemcpyAsync(best_mode, w.best, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st));
 
@@ -833,8 +941,13 @@ int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, cons
 
   // ---- backward: head, sweep, init
   const int head_grid = bwd_grid(ntiles * T);
-  TS_LAUNCH(k_head_bwd, head_grid, BWD_THREADS, HeadBwdL::SIZE * 4, st, blob_bwd + DecBwdBlob::HEAD, w.states, out_table, y, reg_mask,
-            w.scal, N, T, w.S_in, w.DU, w.DS, w.vpart);
+  const NllArg na_nll{loc, w.best, eps, min_scale};
+  if (nll)
+    TS_LAUNCH(k_head_bwd<1>, head_grid, BWD_THREADS, HeadBwdL::SIZE * 4, st, blob_bwd + DecBwdBlob::HEAD, w.states, out_table, y, reg_mask,
+              w.scal, N, T, w.S_in, w.DU, w.DS, w.vpart, na_nll);
+  else
+    TS_LAUNCH(k_head_bwd<0>, head_grid, BWD_THREADS, HeadBwdL::SIZE * 4, st, blob_bwd + DecBwdBlob::HEAD, w.states, out_table, y, reg_mask,
+              w.scal, N, T, w.S_in, w.DU, w.DS, w.vpart, na_nll);
   const int head_waves = head_grid * waves;
   {
     ColsumBatch cb(st, head_waves, HeadV::SIZE);
@@ -842,6 +955,16 @@ int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, cons
     cb.add(w.vpart + HeadV::DBET, 64, grads[D1B]);
     cb.add(w.vpart + HeadV::DW3X, 128, grads[D3W]);      // rows x, y of decoder.3.weight [2,64]
     cb.add(w.vpart + HeadV::DB3, 2, grads[D3B]);
+    if (int rc = cb.flush()) return rc;
+  }
+  if (nll) {                                               // the scale head (its images follow the L2 blob: DecNllBwdBlob)
+    TS_LAUNCH(k_head_bwd<2>, head_grid, BWD_THREADS, HeadBwdL::SIZE * 4, st, blob_bwd + DecNllBwdBlob::HEAD_SC, w.states, out_table, y,
+              reg_mask, w.scal, N, T, w.S_in, w.DU2, w.DS, w.vpart, na_nll);
+    ColsumBatch cb(st, head_waves, HeadV::SIZE);
+    cb.add(w.vpart + HeadV::DGAM, 64, grads[S1W]);
+    cb.add(w.vpart + HeadV::DBET, 64, grads[S1B]);
+    cb.add(w.vpart + HeadV::DW3X, 128, grads[S3W]);
+    cb.add(w.vpart + HeadV::DB3, 2, grads[S3B]);
     if (int rc = cb.flush()) return rc;
   }
 
@@ -881,6 +1004,7 @@ int trajsde_decoder_l2_backward(int32_t N, int num_modes, int future_steps, cons
     if ((rc = sde.flush())) return rc;
   }
   if ((rc = wgrad(w.DU, w.S_in, RT, RT, grads[D0W], 64, 0, grads[D0B], 0))) return rc;
+  if (nll && (rc = wgrad(w.DU2, w.S_in, RT, RT, grads[S0W], 64, 0, grads[S0B], 0))) return rc;
   {
     WgradBatch init(wc, N, N);                              // aggr_embed.0 [64,128] = cat(global, local): DEC:82
     if ((rc = init.add(w.DA, 64, w.gsel, 64, grads[A0W], 128, 0, grads[A0B], 0))) return rc;

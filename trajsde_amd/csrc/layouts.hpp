@@ -393,6 +393,9 @@ struct InitBwdL {     // aggr_embed: forward fields + the two halves transposed
 struct DecBwdBlob {
   enum : int { SWEEP = 0, HEAD = SWEEP + SweepL::SIZE, INIT = HEAD + HeadBwdL::SIZE, SIZE = INIT + InitBwdL::SIZE };
 };
+struct DecNllBwdBlob {   // Laplace NLL: the L2 blob followed by the scale head's images (forward + W0 transposed)
+  enum : int { HEAD_SC = DecBwdBlob::SIZE, SIZE = HEAD_SC + HeadBwdL::SIZE };
+};
 // ---- backward images of the node-level blocks shared by the three attention families (node_bwd.hip)
 struct FfnBwdAL {     // recompute h = relu(W1 xn2 + b1), dh = (W2^T dout) * (h > 0)
   enum : int { S_END = 0, TS_FIELD(W1, 4 * MAT64, S), TS_FIELD(B1, 256, W1), TS_FIELD(W2T, 4 * MAT64, B1), SIZE = W2T_END };

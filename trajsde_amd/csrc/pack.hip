@@ -838,6 +838,14 @@ static void recipe_decoder_bwd(Packer& P) {
     P.index(n);
 }
 
+// Laplace NLL: the L2 table and images, then the scale head's (its gradient slots follow the L2 ones)
+static void recipe_decoder_nll_bwd(Packer& P) {
+  recipe_decoder_bwd(P);
+  const int h = DecNllBwdBlob::HEAD_SC;
+  recipe_head(P, "scale", h + HeadBwdL::FWD);
+  P.matT("scale.0.weight", h + HeadBwdL::W0T, 64);
+}
+
 // node-level backward images of one attention block (layouts.hpp NodeBlockBwdL); `p` = the block's parameter prefix
 static void recipe_node_block_bwd(Packer& P, const std::string& p, int base) {
   const int a = base + NodeBlockBwdL::FFN_A, b = base + NodeBlockBwdL::FFN_B, u = base + NodeBlockBwdL::UPD;
@@ -996,6 +1004,7 @@ static bool run_recipe(Packer& P, int stage, int nl, int K) {
     case TRAJSDE_STAGE_AGGREGATOR: recipe_aggregator(P, nl, K); return true;
     case TRAJSDE_STAGE_DECODER: recipe_decoder(P); return true;
     case TRAJSDE_STAGE_DECODER_BWD: recipe_decoder_bwd(P); return true;
+    case TRAJSDE_STAGE_DECODER_NLL_BWD: recipe_decoder_nll_bwd(P); return true;
     case TRAJSDE_STAGE_AGGREGATOR_BWD: recipe_aggregator_bwd(P, nl, K); return true;
     case TRAJSDE_STAGE_ENCODER_BWD: recipe_encoder_bwd(P); return true;
     case TRAJSDE_STAGE_ENCODER_GRID: recipe_encoder_grid(P, nl); return true;
@@ -1128,6 +1137,7 @@ int64_t trajsde_blob_floats(int stage, int num_layers, int num_modes) {
     case TRAJSDE_STAGE_AGGREGATOR: return AggBlob::size(num_layers, num_modes);
     case TRAJSDE_STAGE_DECODER: return DecBlob::SIZE;
     case TRAJSDE_STAGE_DECODER_BWD: return DecBwdBlob::SIZE;
+    case TRAJSDE_STAGE_DECODER_NLL_BWD: return DecNllBwdBlob::SIZE;
     case TRAJSDE_STAGE_AGGREGATOR_BWD: return AggBwdBlob::size(num_layers, num_modes);
     case TRAJSDE_STAGE_ENCODER_BWD: return EncBwdBlob::SIZE;
     case TRAJSDE_STAGE_ENCODER_GRID: return EncGridBlob::size(num_layers);

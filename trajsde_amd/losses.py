@@ -2,7 +2,8 @@
 (losses/L2.py:10-27 winner-takes-all min-ADE regression; losses/diff_BCE.py:11-16 BCE on the encoder's diffusion
 outputs, real = 0, perturbed = 1).  These classes are what the YAML's `losses:` entries resolve to: they give the
 loss *values* (validation-time reporting, tests); `training_step` takes their names and weights and differentiates
-the same two losses inside the HIP backward entry points (trajsde_decoder_l2_backward, trajsde_encoder_backward).
+the same losses inside the HIP backward entry points (trajsde_decoder_l2_backward / trajsde_decoder_nll_backward,
+trajsde_encoder_backward).
 """
 import torch
 import torch.nn.functional as F
@@ -38,8 +39,8 @@ class DiffBCE:
 class LaplaceNLLLoss:
     """losses/laplace_nll_loss.py:18-47: Laplace negative log-likelihood of the winner-takes-all mode (the mode with the
     smallest masked mean L2), scale clamped at `eps`.  No shipped configuration names it (CFG:78-83 use L2 + DiffBCE), so
-    only its VALUE is built -- validation-time reporting on the forward's device tensors; `training_step` refuses it (the
-    HIP backward entry points differentiate L2 and DiffBCE; the scale head gets no gradient from those)."""
+    this class gives its VALUE on the forward's device tensors; `training_step` differentiates it through
+    trajsde_decoder_nll_backward (the scale head is trained under it, unlike under L2)."""
 
     def __init__(self, eps: float = 1e-6, reduction: str = "mean") -> None:
         if reduction != "mean":

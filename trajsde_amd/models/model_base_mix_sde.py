@@ -39,12 +39,17 @@ class _PathLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, data, noise, w_l2, w_diff, *params):
+        """`w_l2`: the weight of the regression loss -- L2, or LaplaceNLLLoss when the model is configured with it"""
         with torch.no_grad():
             # one forward per step: the encoder and aggregator run their tape-keeping forward, the backward entry points
             # then walk those tapes instead of recomputing the stage (runtime.*_forward_train)
             out, local, glob, enc_tape, agg_tape = model._forward_stages(data, noise, keep_tapes=True)
             enc_rt, agg_rt, dec_rt = model.encoder._rt, model.aggregator._rt, model.decoder._rt
-            dec = dec_rt.decoder_l2_backward(data, local, glob, out, noise)
+            reg = model._regression_loss()
+            if reg[0] == "LaplaceNLLLoss":
+                dec = dec_rt.decoder_nll_backward(data, local, glob, out, noise, eps=reg[1])
+            else:
+                dec = dec_rt.decoder_l2_backward(data, local, glob, out, noise)
             d_glob, d_local = dec["d_global_embed"], dec["d_local_embed"]
             if w_l2 != 1.0:
                 d_glob, d_local = d_glob * w_l2, d_local * w_l2
@@ -63,7 +68,7 @@ class _PathLoss(torch.autograd.Function):
             ctx.direct = bool(getattr(model, "direct_grad_accumulation", True))
             ctx.params = params if ctx.direct else None
             model.last_output = out
-            model.last_losses = {"L2": dec["loss"].detach(), "DiffBCE": enc["diff_loss"].detach() / w_diff if w_diff else None}
+            model.last_losses = {reg[0]: dec["loss"].detach(), "DiffBCE": enc["diff_loss"].detach() / w_diff if w_diff else None}
             return (w_l2 * dec["loss"] + enc["diff_loss"]).clone()
 
     @staticmethod
@@ -177,13 +182,22 @@ class PredictionModelSDENet(LightningHooks):
         from trajsde_amd import _lib
         _lib.check_range()
 
+    def _regression_loss(self):
+        """(name, eps) of the configured regression loss: "L2" (losses/L2.py, the shipped one) or "LaplaceNLLLoss"
+        (losses/laplace_nll_loss.py: the scale head is trained as well)"""
+        for name, fn in zip(self.loss_names, self.losses):
+            if name == "LaplaceNLLLoss":
+                return name, float(getattr(fn, "eps", 1e-6))
+        return "L2", None
+
     def params_with_gradient(self):
         """the parameters the configured losses reach (everything except the decoder's pi / scale heads and unused
         buffers-as-parameters): the reference's autograd leaves the others' `.grad` at None, so AdamW skips them"""
         from trajsde_amd import _lib
         reached = set()
+        dec_stage = _lib.STAGE_DECODER_NLL_BWD if self._regression_loss()[0] == "LaplaceNLLLoss" else _lib.STAGE_DECODER_BWD
         for stage, sid in (("encoder", _lib.STAGE_ENCODER_BWD), ("aggregator", _lib.STAGE_AGGREGATOR_BWD),
-                           ("decoder", _lib.STAGE_DECODER_BWD)):
+                           ("decoder", dec_stage)):
             reached |= {f"{stage}.{n}" for n in getattr(self, stage)._rt.param_names(sid)}
         return [p for n, p in self.named_parameters() if n in reached]
 
@@ -217,16 +231,18 @@ class PredictionModelSDENet(LightningHooks):
         if not self.rotate:
             raise NotImplementedError("rotate=False is not built (shipped config: rotate: true, CFG:18)")
         weights = dict(zip(self.loss_names, self.loss_weights))
-        unknown = set(self.loss_names) - {"L2", "DiffBCE"}
-        if unknown or "L2" not in weights:
-            raise NotImplementedError(f"training_step differentiates L2 (+ DiffBCE) through the HIP kernels; configured: {self.loss_names}")
+        unknown = set(self.loss_names) - {"L2", "LaplaceNLLLoss", "DiffBCE"}
+        reg_name = self._regression_loss()[0]
+        if unknown or reg_name not in weights or ("L2" in weights and "LaplaceNLLLoss" in weights):
+            raise NotImplementedError("training_step differentiates ONE regression loss (L2 or LaplaceNLLLoss) + DiffBCE through the HIP "
+                                      f"kernels; configured: {self.loss_names}")
         if data.y is None:
             raise ValueError("training_step needs targets (data.y)")
         noise = runtime.NoiseSpec.resolve(noise)
         if not hasattr(self, "_param_names"):
             self._param_names = [n for n, _ in self.named_parameters()]
         params = [p for _, p in self.named_parameters()]
-        loss = _PathLoss.apply(self, data, noise, float(weights["L2"]), float(weights.get("DiffBCE", 0.0)), *params)
+        loss = _PathLoss.apply(self, data, noise, float(weights[reg_name]), float(weights.get("DiffBCE", 0.0)), *params)
         n_rows = int(self.last_output["loc"].size(1))
         for name in self.loss_names:                                          # MODEL:112: one entry per configured loss
             if self.last_losses.get(name) is not None:

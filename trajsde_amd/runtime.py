@@ -367,12 +367,24 @@ class StageRuntime:
         out = {"loc": loc, "pi": pi, "reg_mask": ~data["padding_mask"][:, -T:]}          # DEC:104
         return out
 
+    def decoder_nll_backward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor, out: Dict[str, torch.Tensor],
+                             noise: NoiseSpec, eps: float = 1e-6) -> Dict[str, object]:
+        """Laplace negative log-likelihood of the winning mode (losses/laplace_nll_loss.py:18-47) on `out` = decoder_forward(...)
+        and its gradients -- like decoder_l2_backward, with the scale head differentiated as well (grads keyed by
+        param_names(STAGE_DECODER_NLL_BWD))."""
+        return self._decoder_backward(data, local_embed, global_embed, out, noise, nll_eps=float(eps))
+
     def decoder_l2_backward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor, out: Dict[str, torch.Tensor],
                             noise: NoiseSpec) -> Dict[str, object]:
         """Winner-takes-all L2 loss (losses/L2.py:10-27) on `out` = decoder_forward(...) and its gradients w.r.t.
         this stage's parameters and inputs.  `noise` must be the NoiseSpec the forward ran with (same seed / z), so
         that the replayed winning paths are the forward's.  Returns {"loss", "best_mode", "grads": {param name:
         tensor}, "d_local_embed", "d_global_embed"}; `pi.*` and `scale.*` get no gradient from this loss."""
+        return self._decoder_backward(data, local_embed, global_embed, out, noise, nll_eps=None)
+
+    def _decoder_backward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor, out: Dict[str, torch.Tensor],
+                          noise: NoiseSpec, nll_eps: Optional[float]) -> Dict[str, object]:
+        """shared body of decoder_l2_backward / decoder_nll_backward (`nll_eps` None: L2)"""
         m = self.module
         if noise is None:
             raise _lib.TrajsdeError("decoder_l2_backward needs the NoiseSpec of the forward pass (seed or z_dec)")
@@ -388,23 +400,30 @@ class StageRuntime:
         y = y.to(torch.float32).contiguous()
         mask = out["reg_mask"].contiguous().view(torch.uint8)
         L = _lib.lib()
-        names = self.param_names(_lib.STAGE_DECODER_BWD)
-        grads = self._grad_buffers(_lib.STAGE_DECODER_BWD)
+        stage = _lib.STAGE_DECODER_BWD if nll_eps is None else _lib.STAGE_DECODER_NLL_BWD
+        names = self.param_names(stage)
+        grads = self._grad_buffers(stage)
         arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
         loss = torch.empty(1, device=dev, dtype=torch.float32)
         best = torch.empty(N, device=dev, dtype=torch.int32)
         d_local = torch.empty(N, D, device=dev, dtype=torch.float32)
         d_global = torch.empty(K, N, D, device=dev, dtype=torch.float32)
-        ws_bytes = L.trajsde_decoder_backward_ws_bytes(N, K, T, sched.n_euler)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         cn = noise.c_noise(noise.z_dec, noise.dec_row_ids)
-        with torch.cuda.device(dev):
-            _lib.check(L.trajsde_decoder_l2_backward(
-                N, K, T, self.blob().data_ptr(), self.blob(_lib.STAGE_DECODER_BWD).data_ptr(),
+        head = (N, K, T, self.blob().data_ptr(), self.blob(stage).data_ptr(),
                 local_embed.contiguous().data_ptr(), global_embed.contiguous().data_ptr(), step_tab.data_ptr(), sched.n_euler,
-                out_tab.data_ptr(), C.byref(cn), out["loc"].contiguous().data_ptr(), y.data_ptr(), mask.data_ptr(),
-                ws.data_ptr(), ws_bytes, loss.data_ptr(), best.data_ptr(), arr, len(names), d_local.data_ptr(),
-                d_global.data_ptr(), _stream()), "trajsde_decoder_l2_backward")
+                out_tab.data_ptr(), C.byref(cn), out["loc"].contiguous().data_ptr(), y.data_ptr(), mask.data_ptr())
+        with torch.cuda.device(dev):
+            if nll_eps is None:
+                ws_bytes = L.trajsde_decoder_backward_ws_bytes(N, K, T, sched.n_euler)
+                ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+                _lib.check(L.trajsde_decoder_l2_backward(*head, ws.data_ptr(), ws_bytes, loss.data_ptr(), best.data_ptr(), arr, len(names),
+                                                         d_local.data_ptr(), d_global.data_ptr(), _stream()), "trajsde_decoder_l2_backward")
+            else:
+                ws_bytes = L.trajsde_decoder_nll_backward_ws_bytes(N, K, T, sched.n_euler)
+                ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+                _lib.check(L.trajsde_decoder_nll_backward(*head, float(nll_eps), float(m.min_scale), ws.data_ptr(), ws_bytes, loss.data_ptr(),
+                                                          best.data_ptr(), arr, len(names), d_local.data_ptr(), d_global.data_ptr(),
+                                                          _stream()), "trajsde_decoder_nll_backward")
         return {"loss": loss[0], "best_mode": best, "grads": grads, "d_local_embed": d_local, "d_global_embed": d_global}
 
     # ---------------------------------------------------------------- encoder
