@@ -226,8 +226,9 @@ class PredictionModelSDENet(LightningHooks):
         """MODEL:104-116: forward, the weighted sum of the configured losses, as a tensor whose `.backward()` fills
         `.grad` through the HIP backward kernels.  In train mode (`model.train()`) the stages' `dropout` is applied at the
         reference's sites (attention weights, out_proj output, the two FFN activations of every attention block) with masks
-        cut from the Philox stream of `noise` (csrc/dropout.hpp); `model.eval()` switches it off, as in the reference.  The kernels implement the shipped loss set (losses/L2.py +
-        losses/diff_BCE.py, CFG:78-83); any other loss is refused rather than silently differentiated elsewhere."""
+        cut from the Philox stream of `noise` (csrc/dropout.hpp); `model.eval()` switches it off, as in the reference.  The kernels implement the
+        shipped loss set (losses/L2.py + losses/diff_BCE.py, CFG:78-83) and losses/laplace_nll_loss.py in place of L2; any other loss
+        is refused rather than silently differentiated elsewhere."""
         if not self.rotate:
             raise NotImplementedError("rotate=False is not built (shipped config: rotate: true, CFG:18)")
         weights = dict(zip(self.loss_names, self.loss_weights))
