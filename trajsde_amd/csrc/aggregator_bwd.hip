@@ -349,7 +349,7 @@ struct AggBwdWs {
   float *rel, *xn[8], *q[8], *kn[8], *vn[8], *agg[8], *x1[8], *xn2[8], *out[8];
   float* stats[8];               // softmax statistics (max logit, 1 / sum) per (target, head) of every layer
   // backward scratch
-  float *dcur, *dnext, *dagg, *dxn, *DQ, *DKN, *DVN, *DREL, *RL, *SS, *DAGGM, *XF, *part, *cs;
+  float *dcur, *dnext, *dagg, *dxn, *DQ, *DKN, *DVN, *DREL, *RL, *SS, *DAGGM, *XF, *part, *cs, *varena;
   float *EA[8], *ED[8], *UZ[8];  // per layer: the per-edge (alpha d, d logit) scalars and per-target (U, Z) vectors (k_gattn_drel)
   int32_t *REV, *asym;
   NodeBlockScratch nb;
@@ -382,6 +382,7 @@ struct AggBwdWs {
     for (float** p : edge) *p = c.take<float>(E * 64 + 64);
     ee.S = rel;                                             // the rel rows are dead once every layer's k_gattn_bwd has run
     nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
+    varena = c.take<float>(VPART_ARENA_SLABS * VPART_FLOATS);
     const int64_t rows = E > N ? E : N;
     parts = wgrad_max_parts(rows, 1);
     part = c.take<float>(parts * 4096);
@@ -494,6 +495,7 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
   const int64_t N = b->N, E = g->E_g, ntiles = (N + 15) / 16, etiles = (E + 15) / 16;
   const int nl = num_layers, K = num_modes;
   const WgradCtx wc{st, w.part, w.cs, nullptr, w.parts};
+  DeferredSums sums(st, w.part, w.cs, w.parts, nullptr, w.varena, VPART_ARENA_SLABS * VPART_FLOATS);    // this call's reductions: at the end
 
   if (!tape_valid)
     if (int rc = aggregator_tape(b, g, blob_fwd, nl, num_heads, local_embed, w, drop_of, st)) return rc;
@@ -505,12 +507,13 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
               d_global + int64_t(k) * N * 64, N, w.dxn, k > 0 ? 1 : 0);
   {
     const int gp = vec_grid(ntiles, 256, ProjBwdL<0>::SIZE * 4);
+    float* const vp = vpart_slab(w.nb.vpart, int64_t(gp) * 4, 128);
     TS_LAUNCH(k_node_proj_bwd<0>, gp, 256, ProjBwdL<0>::SIZE * 4, st, blob_bwd + AggBwdBlob::norm(nl), w.out[nl - 1], nullptr, w.dxn,
-              nullptr, nullptr, nullptr, N, w.dcur, w.XF, w.nb.vpart);
+              nullptr, nullptr, nullptr, N, w.dcur, w.XF, vp);
     {
       ColsumBatch cb(st, gp * 4, 128);
-      cb.add(w.nb.vpart, 64, G("norm.weight"));
-      cb.add(w.nb.vpart + 64, 64, G("norm.bias"));
+      cb.add(vp, 64, G("norm.weight"));
+      cb.add(vp + 64, 64, G("norm.bias"));
       if (int rc = cb.flush()) return rc;
     }
     float* pw = G("multihead_proj.weight");
@@ -566,12 +569,13 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     TS_HIP(hipMemsetAsync(bke, 0, 64 * sizeof(float), st));          // a key bias shifts every logit of a target alike
     if (int rc = run_colsum(st, w.DAGGM, N, 64, 64, bve)) return rc;
     const int gp = vec_grid(ntiles, 256, ProjBwdL<3>::SIZE * 4);
+    float* const vp = vpart_slab(w.nb.vpart, int64_t(gp) * 4, 128);
     TS_LAUNCH(k_node_proj_bwd<3>, gp, 256, ProjBwdL<3>::SIZE * 4, st, lb + AggLayerBwdL::PROJ, x_in, w.nb.dx1, w.dxn, w.DQ, w.DKN, w.DVN, N,
-              dnext, nullptr, w.nb.vpart);
+              dnext, nullptr, vp);
     {
       ColsumBatch cb(st, gp * 4, 128);
-      cb.add(w.nb.vpart, 64, n1g);
-      cb.add(w.nb.vpart + 64, 64, n1b);
+      cb.add(vp, 64, n1g);
+      cb.add(vp + 64, 64, n1b);
       if (int rc = cb.flush()) return rc;
     }
     const float* dps[3] = {w.DQ, w.DKN, w.DVN};
@@ -606,7 +610,7 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     // E == 0: the embedding never ran and its gradients stay as the caller initialised them (zeros)
     if (int rc = edge_embed_backward(blob_bwd + AggBwdBlob::REL, g->g_geom, w.DREL, E, w.ee, wc, eg, st)) return rc;
   }
-  return TRAJSDE_OK;
+  return sums.finish();
 }
 
 }  // extern "C"

@@ -73,6 +73,65 @@ struct WgradBatch {
 // W[o*ldw + col0 + i] = sum_r delta[r*ldd + o] * a[r*lda + i]  (o, i < 64);  bias[o] = sum_r delta[r*ldd + o] (or null)
 int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, float* W,
               int ldw, int col0, float* bias, int time_cols);
+// ---- deferred sums.  A backward entry point of the SDE path produces ~35 weight-gradient batches and ~33 slabs of per-wave vector
+// partials; summing each with its own launch (two dozen microseconds apiece, a handful of workgroups) cost 0.7 ms of a 12.4 ms step.
+// With a DeferredSums object alive, WgradBatch::flush / run_headwise_outer leave their partials where they are (a bump allocator over
+// the context's partial buffer) and ColsumBatch::flush leaves the slab where it is (vpart_slab hands every producer its own), and the
+// sums of the whole entry point run in a few wide launches at finish() -- or earlier, whenever one of the two areas is full.  Same
+// fixed summation order as the immediate kernels; nothing reads a gradient buffer before the entry point returns.
+struct ReduceJob {             // one 64 x 64 (+ bias / time columns) block: its partials start at slot `base`
+  float *W, *bias;
+  int64_t base;
+  int P, cpg, ldw, col0, time_cols;
+};
+constexpr int REDUCE_MAX_JOBS = 64;
+struct ReduceJobs {
+  ReduceJob j[REDUCE_MAX_JOBS];
+  int n;
+};
+struct ColsumQJob {
+  const float* src;
+  float* dst;
+  int64_t rows;
+  int n, stride, dst_stride;
+};
+constexpr int COLSUMQ_MAX_JOBS = 96;
+struct ColsumQJobs {
+  ColsumQJob j[COLSUMQ_MAX_JOBS];
+  int n;
+};
+struct ReduceQueue {
+  hipStream_t st;
+  float *part, *cs;
+  const float* step_tab;
+  int64_t cap, used;
+  std::vector<ReduceJob> jobs;
+  int64_t take(int64_t slots, int* rc);      // first slot of a fresh run of `slots` partials (drains first when they do not fit)
+  int drain();
+};
+struct ColsumQueue {
+  hipStream_t st;
+  float* arena;
+  int64_t cap, used;
+  std::vector<ColsumQJob> jobs;
+  float* take(int64_t floats);               // null: does not fit even after a drain (the caller falls back to its shared slab)
+  int drain();
+};
+ReduceQueue*& active_reduce_queue();
+ColsumQueue*& active_colsum_queue();
+struct DeferredSums {
+  ReduceQueue rq;
+  ColsumQueue cq;
+  DeferredSums(hipStream_t st, float* part, float* cs, int64_t cap, const float* step_tab, float* arena, int64_t arena_floats);
+  ~DeferredSums();                           // deactivates the queues (error paths); launches nothing
+  int finish();                              // the remaining sums; the queues stay active and empty
+  DeferredSums(const DeferredSums&) = delete;
+};
+// the slab a producer of per-wave vector partials writes ([rows][stride] floats) and the ColsumBatch built on it reads: the
+// caller's shared slab, or -- with deferred sums active -- a slab of its own that stays intact until the sums have run
+float* vpart_slab(float* shared_slab, int64_t rows, int stride);
+constexpr int64_t VPART_ARENA_SLABS = 6;     // the arena of a workspace, in units of VPART_FLOATS
+
 int run_colsum(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, int dst_stride = 1);
 int run_colsum_tall(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, float* scratch /* 256 x n floats */);
 // several vectors of the same slab (rows x stride floats of per-wave partials) in one launch

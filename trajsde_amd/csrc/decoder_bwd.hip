@@ -490,7 +490,7 @@ __global__ __launch_bounds__(128) void k_dec_init_bwd(const float* __restrict__ 
 // ------------------------------------------------------------------ weight gradients from saved rows
 // part[p] = sum_{rows of chunk p} delta[r][:]^T a[r][:]  (64x64, [o][i]),  cs[p][o] = sum delta[r][o].
 // Chunks never straddle a group (= one Euler step of rows_per_group rows), so the reducer can weight them per step.
-__global__ __launch_bounds__(256) void k_wgrad(WgradJobs jobs, int64_t R, int64_t rows_per_group, int chunk, int chunks_per_group, int P,
+__global__ __launch_bounds__(256, 3) void k_wgrad(WgradJobs jobs, int64_t R, int64_t rows_per_group, int chunk, int chunks_per_group, int P,
                                                float* __restrict__ part, float* __restrict__ cs) {
   const WgradJob& job = jobs.j[blockIdx.y];
   const float* __restrict__ delta = job.delta;
@@ -514,28 +514,32 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradJobs jobs, int64_t R, int64_
 #pragma unroll
   for (int it = 0; it < 4; ++it) acc[it] = f4{0.f, 0.f, 0.f, 0.f};
   float csum = 0.f;
-  // 64-row blocks of delta and a are staged in LDS with coalesced 16-B loads (row stride 80 floats: the four k-groups
-  // of an operand read land in four different bank quarters), then every wave takes every 4th 4-row k-step
-  constexpr int RS = 80;
-  float* ds_ = dyn;                       // [64][RS]   (the staging area is reused for the cross-wave reduction below)
-  float* as_ = dyn + 64 * RS;             // [64][RS]
+  // 64-row blocks of delta and a are staged in LDS TRANSPOSED -- [feature][row], the row index XOR-ed with a per-feature multiple
+  // of 4 -- so that a lane's 16 operand values of a block are 4 aligned 16-byte reads, all issued before the block's 64 matrix
+  // instructions (reading them one k-step at a time put an LDS round trip in front of every pair of matrix instructions: the
+  // pipe was 60 % busy).  The contraction index is permuted to make that possible: k-step j sums rows {j, 16+j, 32+j, 48+j} of the
+  // block (lane group kg holds rows 16 kg .. 16 kg + 15), the same permutation for both operands.  The XOR term 4 ((f & 15) ^ (f >> 4))
+  // spreads the 16 features a read instruction touches over all banks, and the 64 scalar writes of a wave over all 32 write banks.
+  float* ds_ = dyn;                       // [64 features][64 rows]
+  float* as_ = dyn + 4096;                // [64 features][64 rows]
+  const int c4w = threadIdx.x & 15;
+  int wofs[4];                            // this thread's four features: f * 64, with the swizzle term kept apart in wswz
+  int wswz[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int f = 4 * c4w + j;
+    wofs[j] = f * 64;
+    wswz[j] = 4 * ((f & 15) ^ (f >> 4));
+  }
+  const float* a_rd = ds_ + (16 * ot + idx) * 64;           // operand reads: feature rows of this lane
+  const int a_sw = 4 * (idx ^ ot);
   // software pipeline: the global loads (or the computed operand) of block k+1 are issued before the matrix work of block
   // k, so their latency hides behind it; registers -> LDS happens after the barrier that retires block k's reads
   f4 dreg[4], areg[4];
-  // computed operand: a thread always produces the same four features (4 * (threadIdx.x & 15)), so the closed-form constants
-  // of those features are loaded once, not with every row
   const bool computed = job.in2 != nullptr;             // uniform per launch slice (blockIdx.y)
-  f4 kw0, kw1, kgb, kbe, kc0, kc1;
-  if (computed) {
-    const int f0 = 4 * (threadIdx.x & 15);
-    kw0 = *reinterpret_cast<const f4*>(job.in2 + f0);
-    kw1 = *reinterpret_cast<const f4*>(job.in2 + 64 + f0);
-    kgb = *reinterpret_cast<const f4*>(job.in2 + 128 + f0);
-    kbe = *reinterpret_cast<const f4*>(job.beta + f0);
-    kc0 = *reinterpret_cast<const f4*>(job.in2 + 192);
-    kc1 = *reinterpret_cast<const f4*>(job.in2 + 196);
-  }
   const int pair = job.pair;
+  // the computed operand is built from the row's geometry AFTER the barrier that opens the next block (`finish`), not where the
+  // geometry is fetched: its consumer would otherwise wait out the load right in front of the matrix loop, every block
   auto fetch = [&](int64_t blk) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -543,47 +547,77 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradJobs jobs, int64_t R, int64_
       const int r = f >> 4, c4 = f & 15;
       const int64_t row = blk + r;
       f4 dv = f4{0.f, 0.f, 0.f, 0.f}, av = dv;
+#if defined(TSDE_WGRAD_NOLOAD)
+      if (row < row1) { dv = f4{1.f, 2.f, 3.f, float(row)}; av = dv; }
+#else
       if (row < row1) {
         dv = *reinterpret_cast<const f4*>(delta + row * ldd + 4 * c4);
-        if (computed) {                                 // in2_rstd / in2_ln_relu4 (tile.hpp) on the hoisted constants
-          const f4 ge = *reinterpret_cast<const f4*>(a + row * 4);
-          const float x0 = pair ? ge[2] : ge[0], x1 = pair ? ge[3] : ge[1];
-          const float ca = fmaf(kc0[0], x0, fmaf(kc0[1], x1, kc0[2])), cb = fmaf(kc0[3], x1, kc1[0]);
-          const float rstd = rsqrt_nr(fmaf(ca, ca, fmaf(cb, cb, kc1[1] * kc1[1])) + 1e-5f);
-          const float x0r = x0 * rstd, x1r = x1 * rstd;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) av[k] = fmaxf(fmaf(kw0[k], x0r, fmaf(kw1[k], x1r, fmaf(kgb[k], rstd, kbe[k]))), 0.f);
-        } else {
-          av = *reinterpret_cast<const f4*>(a + row * lda + 4 * c4);
-        }
+        av = computed ? *reinterpret_cast<const f4*>(a + row * 4) : *reinterpret_cast<const f4*>(a + row * lda + 4 * c4);
       }
+#endif
       dreg[u] = dv;
       areg[u] = av;
     }
   };
-  if (row0 < row1) fetch(row0);
-  for (int64_t blk = row0; blk < row1; blk += 64) {
-    __syncthreads();
+  auto finish = [&](int64_t blk) {                      // in2_rstd / in2_ln_relu4 (tile.hpp)
+    // a thread always produces the same four features (4 * (threadIdx.x & 15)); their closed-form constants are re-read per block
+    // (cache hits) rather than held in 24 registers across the matrix loop
+    const int f0 = 4 * (threadIdx.x & 15);
+    const f4 kw0 = *reinterpret_cast<const f4*>(job.in2 + f0), kw1 = *reinterpret_cast<const f4*>(job.in2 + 64 + f0);
+    const f4 kgb = *reinterpret_cast<const f4*>(job.in2 + 128 + f0), kbe = *reinterpret_cast<const f4*>(job.beta + f0);
+    const f4 kc0 = *reinterpret_cast<const f4*>(job.in2 + 192), kc1 = *reinterpret_cast<const f4*>(job.in2 + 196);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int f = threadIdx.x + 256 * u;
-      const int r = f >> 4, c4 = f & 15;
-      *reinterpret_cast<f4*>(ds_ + r * RS + 4 * c4) = dreg[u];
-      *reinterpret_cast<f4*>(as_ + r * RS + 4 * c4) = areg[u];
+      const int r = (threadIdx.x + 256 * u) >> 4;
+      const f4 ge = areg[u];
+      const float x0 = pair ? ge[2] : ge[0], x1 = pair ? ge[3] : ge[1];
+      const float ca = fmaf(kc0[0], x0, fmaf(kc0[1], x1, kc0[2])), cb = fmaf(kc0[3], x1, kc1[0]);
+      const float rstd = rsqrt_nr(fmaf(ca, ca, fmaf(cb, cb, kc1[1] * kc1[1])) + 1e-5f);
+      const float x0r = x0 * rstd, x1r = x1 * rstd;
+      f4 av;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) av[k] = fmaxf(fmaf(kw0[k], x0r, fmaf(kw1[k], x1r, fmaf(kgb[k], rstd, kbe[k]))), 0.f);
+      areg[u] = blk + r < row1 ? av : f4{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  if (row0 < row1) fetch(row0);
+  for (int64_t blk = row0; blk < row1; blk += 64) {
+#if !defined(TSDE_WGRAD_NOBARRIER)
     __syncthreads();
-    if (blk + 64 < row1) fetch(blk + 64);
-#pragma unroll 8
-    for (int ks = 0; ks < 16; ++ks) {
-      const int r = 4 * ks + kg;
-      const float A = ds_[r * RS + 16 * ot + idx];
-      float B[4];
+#endif
+    if (computed) finish(blk);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) B[q] = as_[r * RS + 16 * q + idx];
-      csum += A;
+    for (int u = 0; u < 4; ++u) {
+      const int r = (threadIdx.x + 256 * u) >> 4;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B[it], acc[it], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        ds_[wofs[j] + (r ^ wswz[j])] = dreg[u][j];
+        as_[wofs[j] + (r ^ wswz[j])] = areg[u][j];
+      }
     }
+#if !defined(TSDE_WGRAD_NOBARRIER)
+    __syncthreads();
+#endif
+    if (blk + 64 < row1) fetch(blk + 64);
+    f4 A[4], B[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) A[m] = *reinterpret_cast<const f4*>(a_rd + ((16 * kg + 4 * m) ^ a_sw));
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) B[q][m] = *reinterpret_cast<const f4*>(as_ + (16 * q + idx) * 64 + ((16 * kg + 4 * m) ^ (4 * (idx ^ q))));
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        csum += A[m][c];
+#pragma unroll
+#if defined(TSDE_WGRAD_NOMFMA)
+        for (int it = 0; it < 4; ++it) acc[it][0] += A[m][c] * B[it][m][c];
+#else
+        for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m][c], B[it][m][c], acc[it], 0, 0, 0);
+#endif
+      }
   }
   // D fragment: lane holds dW[16 ot + 4 kg + reg][16 it + idx]
   float* out = part + int64_t(p) * 4096;
@@ -680,6 +714,163 @@ __global__ __launch_bounds__(1024) void k_colsum(ColsumJobs jobs, int64_t rows, 
   }
 }
 
+
+// ------------------------------------------------------------------ deferred sums (bwd.hpp)
+// k_reduce_partials with per-problem partial runs: grid.y = problem, slots [base, base + P) of the shared partial buffer
+__global__ __launch_bounds__(256) void k_reduce_partials_q(ReduceJobs jobs, const float* __restrict__ part, const float* __restrict__ cs,
+                                                           const float* __restrict__ step_tab) {
+  const ReduceJob& job = jobs.j[blockIdx.y];
+  float* __restrict__ W = job.W;
+  float* __restrict__ bias = job.bias;
+  const int ldw = job.ldw, col0 = job.col0, time_cols = job.time_cols, P = job.P, chunks_per_group = job.cpg;
+  part += job.base * 4096;
+  cs += job.base * 64;
+  __shared__ float red[3][8][32];
+  const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + lane;
+  float s = 0.f, ws = 0.f, wc = 0.f;
+  if (j < 4096) {
+    for (int p = sl; p < P; p += 8) s += part[int64_t(p) * 4096 + j];
+  } else if (j < 4096 + 64 && (bias || time_cols)) {
+    const int o = j - 4096;
+    for (int p = sl; p < P; p += 8) {
+      const float v = cs[int64_t(p) * 64 + o];
+      s += v;
+      if (time_cols) {
+        const int k = p / chunks_per_group;
+        ws = fmaf(step_tab[k * 8 + 3], v, ws);
+        wc = fmaf(step_tab[k * 8 + 4], v, wc);
+      }
+    }
+  }
+  red[0][sl][lane] = s;
+  red[1][sl][lane] = ws;
+  red[2][sl][lane] = wc;
+  __syncthreads();
+  if (sl != 0) return;
+  float t[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t[q] += red[q][g][lane];
+  if (j < 4096) {
+    W[(j >> 6) * ldw + col0 + (j & 63)] = t[0];
+  } else if (j < 4096 + 64) {
+    const int o = j - 4096;
+    if (bias) bias[o] = t[0];
+    if (time_cols) {
+      W[o * ldw + 64] = t[1];
+      W[o * ldw + 65] = t[2];
+    }
+  }
+}
+// k_colsum with per-vector slabs (rows, stride): grid.y = vector
+__global__ __launch_bounds__(1024) void k_colsum_q(ColsumQJobs jobs) {
+  __shared__ float red[16][64];
+  const ColsumQJob& job = jobs.j[blockIdx.y];
+  const float* __restrict__ src = job.src;
+  const int n = job.n, stride = job.stride;
+  const int64_t rows = job.rows;
+  if (blockIdx.x * 64 >= n) return;                   // (uniform) a narrower vector of the same launch
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  float s = 0.f;
+  if (j < n) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int64_t w = part;
+    for (; w + 112 < rows; w += 128) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += src[(w + 16 * u) * stride + j];
+    }
+    for (; w < rows; w += 16) a[0] += src[w * stride + j];
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+  red[part][c] = s;
+  __syncthreads();
+  if (part == 0 && j < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += red[p][c];
+    job.dst[int64_t(j) * job.dst_stride] = t;
+  }
+}
+
+ReduceQueue*& active_reduce_queue() {
+  static thread_local ReduceQueue* q = nullptr;
+  return q;
+}
+ColsumQueue*& active_colsum_queue() {
+  static thread_local ColsumQueue* q = nullptr;
+  return q;
+}
+int ReduceQueue::drain() {
+  for (size_t first = 0; first < jobs.size(); first += REDUCE_MAX_JOBS) {
+    ReduceJobs sub;
+    sub.n = int(jobs.size() - first < size_t(REDUCE_MAX_JOBS) ? jobs.size() - first : size_t(REDUCE_MAX_JOBS));
+    for (int i = 0; i < sub.n; ++i) sub.j[i] = jobs[first + i];
+    TS_LAUNCH(k_reduce_partials_q, dim3(cdiv(4096 + 64, 32), sub.n), 256, 0, st, sub, part, cs, step_tab);
+  }
+  jobs.clear();
+  used = 0;
+  return TRAJSDE_OK;
+}
+int64_t ReduceQueue::take(int64_t slots, int* rc) {
+  *rc = TRAJSDE_OK;
+  if (used + slots > cap) *rc = drain();
+  const int64_t base = used;
+  used += slots;
+  return base;
+}
+int ColsumQueue::drain() {
+  for (size_t first = 0; first < jobs.size(); first += COLSUMQ_MAX_JOBS) {
+    ColsumQJobs sub;
+    sub.n = int(jobs.size() - first < size_t(COLSUMQ_MAX_JOBS) ? jobs.size() - first : size_t(COLSUMQ_MAX_JOBS));
+    int widest = 0;
+    for (int i = 0; i < sub.n; ++i) {
+      sub.j[i] = jobs[first + i];
+      widest = sub.j[i].n > widest ? sub.j[i].n : widest;
+    }
+    TS_LAUNCH(k_colsum_q, dim3(cdiv(widest, 64), sub.n), 1024, 0, st, sub);
+  }
+  jobs.clear();
+  used = 0;
+  return TRAJSDE_OK;
+}
+float* ColsumQueue::take(int64_t floats) {
+  floats = (floats + 63) / 64 * 64;
+  if (floats > cap) return nullptr;
+  if (used + floats > cap && drain() != TRAJSDE_OK) return nullptr;
+  float* p = arena + used;
+  used += floats;
+  return p;
+}
+DeferredSums::DeferredSums(hipStream_t st, float* part, float* cs, int64_t cap, const float* step_tab, float* arena, int64_t arena_floats) {
+  rq.st = st; rq.part = part; rq.cs = cs; rq.step_tab = step_tab; rq.cap = cap; rq.used = 0;
+  cq.st = st; cq.arena = arena; cq.cap = arena_floats; cq.used = 0;
+  static const bool off = []() { const char* e = getenv("TRAJSDE_IMMEDIATE_SUMS"); return e && e[0] == '1'; }();   // A/B switch
+  if (off) return;
+  active_reduce_queue() = &rq;
+  active_colsum_queue() = arena ? &cq : nullptr;
+}
+DeferredSums::~DeferredSums() {
+  if (active_reduce_queue() == &rq) active_reduce_queue() = nullptr;
+  if (active_colsum_queue() == &cq) active_colsum_queue() = nullptr;
+}
+int DeferredSums::finish() {
+  if (int rc = cq.drain()) return rc;
+  return rq.drain();
+}
+float* vpart_slab(float* shared_slab, int64_t rows, int stride) {
+  ColsumQueue* q = active_colsum_queue();
+  if (!q) return shared_slab;
+  float* p = q->take(rows * stride);
+  if (p) return p;
+  // larger than the arena: sum what is queued (the shared slab may be one of its sources) and fall back to the shared slab, whose
+  // own sum then runs immediately (ColsumBatch::flush sees a source outside the arena)
+  q->drain();
+  return shared_slab;
+}
+
 int ColsumBatch::add(const float* src, int n, float* dst, int dst_stride) {
   if (jobs.n == COLSUM_MAX_JOBS)
     if (int rc = flush()) return rc;
@@ -688,6 +879,15 @@ int ColsumBatch::add(const float* src, int n, float* dst, int dst_stride) {
 }
 int ColsumBatch::flush() {
   if (jobs.n == 0) return TRAJSDE_OK;
+  if (ColsumQueue* q = active_colsum_queue()) {
+    bool inside = true;                               // deferred only for slabs that live in the queue's arena
+    for (int i = 0; i < jobs.n; ++i) inside = inside && jobs.j[i].src >= q->arena && jobs.j[i].src < q->arena + q->cap;
+    if (inside) {
+      for (int i = 0; i < jobs.n; ++i) q->jobs.push_back(ColsumQJob{jobs.j[i].src, jobs.j[i].dst, rows, jobs.j[i].n, stride, jobs.j[i].dst_stride});
+      jobs.n = 0;
+      return TRAJSDE_OK;
+    }
+  }
   int widest = 0;
   for (int i = 0; i < jobs.n; ++i) widest = jobs.j[i].n > widest ? jobs.j[i].n : widest;
   TS_LAUNCH(k_colsum, dim3(cdiv(widest, 64), jobs.n), 1024, 0, st, jobs, rows, stride);
@@ -724,7 +924,11 @@ int WgradBatch::flush() {
   const int groups = int((R + rows_per_group - 1) / rows_per_group);
   int64_t chunk = WGRAD_CHUNK;
   static const int parts_env = []() { const char* e = getenv("TRAJSDE_WGRAD_PARTS"); return e ? atoi(e) : 0; }();
-  const int64_t base_parts = parts_env > 0 ? parts_env : 1024;      // 2048 -> 1024: k_reduce_partials 0.60 -> 0.44 ms per training step
+  // One resident round of the chip: 3 workgroups of this kernel fit a CU (40 KB of LDS each), and a workgroup streams its
+  // rows at the same rate however many it has, so 768 workgroups over the launch's problems leave no partial last round and
+  // the fewest partials to reduce (3 problems: 1024 partials each 1.41 ms, 384 1.54 ms, 256 1.35 ms, 128 1.93 ms)
+  const int64_t one_round = (768 + n - 1) / n;
+  const int64_t base_parts = parts_env > 0 ? parts_env : (one_round > 32 ? one_round : 32);
   const int64_t want_parts = groups > base_parts ? groups : base_parts;
   if ((rows_per_group + chunk - 1) / chunk * groups > want_parts) {
     // the smallest multiple of 64 rows that stays within the partial budget: P lands just under it (1024 = one full round of
@@ -736,11 +940,23 @@ int WgradBatch::flush() {
   const int P = cpg * groups;
   int per_launch = int(c.cap / P);
   if (per_launch < 1) return fail(TRAJSDE_ERR_WORKSPACE, "wgrad: partial buffer too small");
+  ReduceQueue* rq = active_reduce_queue();
+  if (rq && rq->part != c.part) rq = nullptr;           // (a context over another partial buffer: immediate)
   for (int first = 0; first < n; first += per_launch) {
     WgradJobs sub;
     sub.n = n - first < per_launch ? n - first : per_launch;
     for (int i = 0; i < sub.n; ++i) sub.j[i] = jobs.j[first + i];
-    TS_LAUNCH_TAG(tag, false, k_wgrad, dim3(P, sub.n), 256, (64 * 80 * 2) * 4, c.st, sub, R, rows_per_group, int(chunk), cpg, P, c.part, c.cs);
+    if (rq) {                                           // partials stay in their slots; summed at DeferredSums::finish (or when full)
+      int rc = TRAJSDE_OK;
+      const int64_t base = rq->take(int64_t(sub.n) * P, &rc);
+      if (rc) return rc;
+      TS_LAUNCH_TAG(tag, false, k_wgrad, dim3(P, sub.n), 256, 2 * 4096 * 4, c.st, sub, R, rows_per_group, int(chunk), cpg, P, c.part + base * 4096,
+                    c.cs + base * 64);
+      for (int i = 0; i < sub.n; ++i)
+        rq->jobs.push_back(ReduceJob{sub.j[i].W, sub.j[i].bias, base + int64_t(i) * P, P, cpg, sub.j[i].ldw, sub.j[i].col0, sub.j[i].time_cols});
+      continue;
+    }
+    TS_LAUNCH_TAG(tag, false, k_wgrad, dim3(P, sub.n), 256, 2 * 4096 * 4, c.st, sub, R, rows_per_group, int(chunk), cpg, P, c.part, c.cs);
     TS_LAUNCH(k_reduce_partials, dim3(cdiv(4096 + 64, 32), sub.n), 256, 0, c.st, sub, c.part, c.cs, P, cpg, c.step_tab);
   }
   return TRAJSDE_OK;
@@ -808,8 +1024,8 @@ constexpr int BWD_THREADS = 128;
 struct BwdWs {
   int32_t *best, *cnt;
   float *minsum, *scal, *states, *H1, *H2, *G1, *G2, *GS, *DH1, *DH2, *DF, *DG1, *DG2, *S_in, *DU, *DS, *gsel, *DA, *DY0, *part, *cs,
-      *vpart, *DU2;
-  int64_t bytes, parts;
+      *vpart, *DU2, *varena;
+  int64_t bytes, parts, varena_floats;
 };
 
 BwdWs carve_bwd(void* ws, int64_t ws_bytes, int N, int T, int n_euler, bool& ok, bool nll = false) {
@@ -842,6 +1058,8 @@ BwdWs carve_bwd(void* ws, int64_t ws_bytes, int N, int T, int n_euler, bool& ok,
   w.part = cv.take<float>(max_parts * 4096);
   w.cs = cv.take<float>(max_parts * 64);
   w.vpart = cv.take<float>(int64_t(256) * (BWD_THREADS / 64) * 512);
+  w.varena_floats = VPART_ARENA_SLABS * int64_t(256) * (BWD_THREADS / 64) * 512;
+  w.varena = cv.take<float>(w.varena_floats);
   w.DU2 = nll ? cv.take<float>(slab * T) : nullptr;        // the scale head's delta rows (Laplace NLL)
   w.bytes = cv.off + 256;
   ok = cv.ok;
@@ -915,6 +1133,7 @@ static int decoder_backward_impl(bool nll, float eps, float min_scale, int32_t N
   bool ok;
   const int K = num_modes, T = future_steps;
   BwdWs w = carve_bwd(ws, ws_bytes, N, T, n_euler, ok, nll);
+  DeferredSums sums(st, w.part, w.cs, w.parts, step_table, w.varena, w.varena_floats);      // every reduction of this call: at the end
   NoiseArg na{0, nullptr, nullptr};
   if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; na.seed_dev = noise->seed_dev; }
   const int ntiles = (N + 15) / 16;
@@ -942,49 +1161,53 @@ static int decoder_backward_impl(bool nll, float eps, float min_scale, int32_t N
   // ---- backward: head, sweep, init
   const int head_grid = bwd_grid(ntiles * T);
   const NllArg na_nll{loc, w.best, eps, min_scale};
+  const int head_waves = head_grid * waves;
+  float* vp = vpart_slab(w.vpart, head_waves, HeadV::SIZE);
   if (nll)
     TS_LAUNCH(k_head_bwd<1>, head_grid, BWD_THREADS, HeadBwdL::SIZE * 4, st, blob_bwd + DecBwdBlob::HEAD, w.states, out_table, y, reg_mask,
-              w.scal, N, T, w.S_in, w.DU, w.DS, w.vpart, na_nll);
+              w.scal, N, T, w.S_in, w.DU, w.DS, vp, na_nll);
   else
     TS_LAUNCH(k_head_bwd<0>, head_grid, BWD_THREADS, HeadBwdL::SIZE * 4, st, blob_bwd + DecBwdBlob::HEAD, w.states, out_table, y, reg_mask,
-              w.scal, N, T, w.S_in, w.DU, w.DS, w.vpart, na_nll);
-  const int head_waves = head_grid * waves;
+              w.scal, N, T, w.S_in, w.DU, w.DS, vp, na_nll);
   {
     ColsumBatch cb(st, head_waves, HeadV::SIZE);
-    cb.add(w.vpart + HeadV::DGAM, 64, grads[D1W]);
-    cb.add(w.vpart + HeadV::DBET, 64, grads[D1B]);
-    cb.add(w.vpart + HeadV::DW3X, 128, grads[D3W]);      // rows x, y of decoder.3.weight [2,64]
-    cb.add(w.vpart + HeadV::DB3, 2, grads[D3B]);
+    cb.add(vp + HeadV::DGAM, 64, grads[D1W]);
+    cb.add(vp + HeadV::DBET, 64, grads[D1B]);
+    cb.add(vp + HeadV::DW3X, 128, grads[D3W]);      // rows x, y of decoder.3.weight [2,64]
+    cb.add(vp + HeadV::DB3, 2, grads[D3B]);
     if (int rc = cb.flush()) return rc;
   }
   if (nll) {                                               // the scale head (its images follow the L2 blob: DecNllBwdBlob)
+    vp = vpart_slab(w.vpart, head_waves, HeadV::SIZE);
     TS_LAUNCH(k_head_bwd<2>, head_grid, BWD_THREADS, HeadBwdL::SIZE * 4, st, blob_bwd + DecNllBwdBlob::HEAD_SC, w.states, out_table, y,
-              reg_mask, w.scal, N, T, w.S_in, w.DU2, w.DS, w.vpart, na_nll);
+              reg_mask, w.scal, N, T, w.S_in, w.DU2, w.DS, vp, na_nll);
     ColsumBatch cb(st, head_waves, HeadV::SIZE);
-    cb.add(w.vpart + HeadV::DGAM, 64, grads[S1W]);
-    cb.add(w.vpart + HeadV::DBET, 64, grads[S1B]);
-    cb.add(w.vpart + HeadV::DW3X, 128, grads[S3W]);
-    cb.add(w.vpart + HeadV::DB3, 2, grads[S3B]);
+    cb.add(vp + HeadV::DGAM, 64, grads[S1W]);
+    cb.add(vp + HeadV::DBET, 64, grads[S1B]);
+    cb.add(vp + HeadV::DW3X, 128, grads[S3W]);
+    cb.add(vp + HeadV::DB3, 2, grads[S3B]);
     if (int rc = cb.flush()) return rc;
   }
 
   const int sweep_grid = bwd_grid(ntiles);
+  vp = vpart_slab(w.vpart, int64_t(sweep_grid) * waves, SweepV::SIZE);
   TS_LAUNCH(k_sde_bwd, sweep_grid, BWD_THREADS, SweepL::SIZE * 4, st, blob_bwd + DecBwdBlob::SWEEP, w.best, N, K, T, n_euler, step_table,
-            out_table, na, w.H1, w.H2, w.G1, w.G2, w.GS, w.DS, w.DH1, w.DH2, w.DF, w.DG1, w.DG2, w.DY0, w.vpart);
+            out_table, na, w.H1, w.H2, w.G1, w.G2, w.GS, w.DS, w.DH1, w.DH2, w.DF, w.DG1, w.DG2, w.DY0, vp);
   {
     ColsumBatch cb(st, sweep_grid * waves, SweepV::SIZE);
-    cb.add(w.vpart + SweepV::DV4, 64, grads[G4W]);
-    cb.add(w.vpart + SweepV::DC4, 1, grads[G4B]);
+    cb.add(vp + SweepV::DV4, 64, grads[G4W]);
+    cb.add(vp + SweepV::DC4, 1, grads[G4B]);
     if (int rc = cb.flush()) return rc;
   }
 
   TS_HIP(hipMemsetAsync(d_global, 0, size_t(K) * N * 64 * sizeof(float), st));
+  vp = vpart_slab(w.vpart, int64_t(sweep_grid) * waves, InitV::SIZE);
   TS_LAUNCH(k_dec_init_bwd, sweep_grid, BWD_THREADS, InitBwdL::SIZE * 4, st, init_img, local_embed, w.gsel, w.DY0, w.best, N, w.DA, d_local,
-            d_global, w.vpart);
+            d_global, vp);
   {
     ColsumBatch cb(st, sweep_grid * waves, InitV::SIZE);
-    cb.add(w.vpart + InitV::DGAM, 64, grads[A1W]);
-    cb.add(w.vpart + InitV::DBET, 64, grads[A1B]);
+    cb.add(vp + InitV::DGAM, 64, grads[A1W]);
+    cb.add(vp + InitV::DBET, 64, grads[A1B]);
     if (int rc = cb.flush()) return rc;
   }
 
@@ -1011,7 +1234,7 @@ static int decoder_backward_impl(bool nll, float eps, float min_scale, int32_t N
     if ((rc = init.add(w.DA, 64, local_embed, 64, grads[A0W], 128, 64, nullptr, 0))) return rc;
     if ((rc = init.flush())) return rc;
   }
-  return TRAJSDE_OK;
+  return sums.finish();
 }
 
 }  // extern "C"

@@ -574,7 +574,7 @@ struct EncBwdWs {
   float *DF, *DH2, *DH1, *DG2N, *DG1N, *DG2A, *DG1A, *DGPN, *DGPA, *DNW, *DN1P, *DUP, *DRP, *DU1, *DR1, *DHO, *dhA, *dhB, *DLDG, *DLAT, *DAA;
   // backward: attention chain scratch (sized for the larger of the AA / AL problems)
   float* rec;                  // (target, stream) records of the fused forward attention
-  float *dagg, *dxn, *DQ, *DCENTER, *EA, *ED, *RL, *SS, *DAGGM, *A1, *A2, *DA3P, *DA2P, *XR, *part, *cs, *scal;
+  float *dagg, *dxn, *DQ, *DCENTER, *EA, *ED, *RL, *SS, *DAGGM, *A1, *A2, *DA3P, *DA2P, *XR, *part, *cs, *scal, *varena;
   NodeBlockScratch nb;
   EdgeEmbedScratch ee;
   int64_t total, tape_total, scratch_total, parts;
@@ -629,6 +629,7 @@ struct EncBwdWs {
     for (float** p : rows_E) *p = c.take<float>(E * 64);
     ee.S = nullptr;
     nb.vpart = ee.vpart = c.take<float>(VPART_FLOATS);
+    varena = c.take<float>(VPART_ARENA_SLABS * VPART_FLOATS);       // the producers' own slabs while the sums are deferred (bwd.hpp)
     const int64_t rows = E > R ? E : R;
     parts = wgrad_max_parts(rows, H);
     part = c.take<float>(parts * 4096);
@@ -715,12 +716,13 @@ int run_attn_chain(const AttnChain& c, const float* dout, EncBwdWs& w, const Wgr
     if (int rc = edge_embed_backward(c.img_emb, c.geom, nullptr, E, ee, wc, eg, st, &ag)) return rc;
   }
   const int gp = vec_grid((R + 15) / 16, 256, ProjBwdL<1>::SIZE * 4);
+  float* const vp = vpart_slab(w.nb.vpart, int64_t(gp) * 4, 128);
   TS_LAUNCH(k_node_proj_bwd<1>, gp, 256, ProjBwdL<1>::SIZE * 4, st, c.img_proj, c.x, w.nb.dx1, w.dxn, w.DQ, nullptr, nullptr, R, dx_out,
-            nullptr, w.nb.vpart);
+            nullptr, vp);
   {
     ColsumBatch cb(st, gp * 4, 128);
-    cb.add(w.nb.vpart, 64, n1g);
-    cb.add(w.nb.vpart + 64, 64, n1b);
+    cb.add(vp, 64, n1g);
+    cb.add(vp + 64, 64, n1b);
     if (int rc = cb.flush()) return rc;
   }
   return run_wgrad(wc, w.DQ, 64, c.tp.xn, 64, R, R, wq, 64, 0, bq, 0);
@@ -745,26 +747,28 @@ int aa_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const fl
   float* tok = G("aa_encoder.bos_token");
   TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
   const int gt = vec_grid((R + 15) / 16, 256, CenterTailL::SIZE * 4);
+  float* vp = vpart_slab(w.nb.vpart, int64_t(gt) * 4, 256);
   TS_LAUNCH(k_aa_center_bwd_tail, gt, 256, CenterTailL::SIZE * 4, st, blob_bwd + BB::AA_CTAIL, b->x, g->x_fake, rot, b->bos_mask, g->orig, N,
-            Nt, H, w.DCENTER, w.A1, w.A2, w.DA3P, w.DA2P, w.XR, w.nb.vpart);
+            Nt, H, w.DCENTER, w.A1, w.A2, w.DA3P, w.DA2P, w.XR, vp);
   float* const tv[4] = {g7, e7, g4, e4};
   {
     ColsumBatch cb(st, gt * 4, 256);
-    for (int i = 0; i < 4; ++i) cb.add(w.nb.vpart + 64 * i, 64, tv[i]);
+    for (int i = 0; i < 4; ++i) cb.add(vp + 64 * i, 64, tv[i]);
     if (int rc = cb.flush()) return rc;
   }
   if (int rc = run_wgrad(wc, w.DA3P, 64, w.A2, 64, R, R, w6, 64, 0, b6, 0)) return rc;
   if (int rc = run_wgrad(wc, w.DA2P, 64, w.A1, 64, R, R, w3, 64, 0, b3, 0)) return rc;
   const int lds_br = (EdgeL::WA3 + MAT64) * 4;
   const int gb = vec_grid((R + 15) / 16, 256, lds_br);
-  TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, blob_bwd + BB::AA_CHEAD, w.XR, w.DA2P, R, w.nb.vpart);
+  vp = vpart_slab(w.nb.vpart, int64_t(gb) * 4, 320);
+  TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, blob_bwd + BB::AA_CHEAD, w.XR, w.DA2P, R, vp);
   {
     ColsumBatch cb(st, gb * 4, 320);
-    cb.add(w.nb.vpart, 64, g1);
-    cb.add(w.nb.vpart + 64, 64, e1);
-    cb.add(w.nb.vpart + 128, 64, w0, 2);
-    cb.add(w.nb.vpart + 192, 64, w0 + 1, 2);
-    cb.add(w.nb.vpart + 256, 64, b0);
+    cb.add(vp, 64, g1);
+    cb.add(vp + 64, 64, e1);
+    cb.add(vp + 128, 64, w0, 2);
+    cb.add(vp + 192, 64, w0 + 1, 2);
+    cb.add(vp + 256, 64, b0);
     if (int rc = cb.flush()) return rc;
   }
   TS_LAUNCH(k_bos_grad, H, 1024, 0, st, w.DCENTER, b->bos_mask, g->orig, Nt, H, tok);
@@ -915,6 +919,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
   NoiseArg na{0, nullptr, nullptr};
   if (noise) { na.seed = noise->seed; na.z = noise->z; na.row_ids = noise->row_ids; na.seed_dev = noise->seed_dev; }
   const WgradCtx wc{st, w.part, w.cs, step_tab_dev, w.parts};
+  DeferredSums sums(st, w.part, w.cs, w.parts, step_tab_dev, w.varena, VPART_ARENA_SLABS * VPART_FLOATS);   // this call's reductions: at the end
   using BB = EncBwdBlob;
 
   if (!tape_valid)
@@ -984,18 +989,19 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
     TS_REQUIRE(!G.missing, "encoder_backward: parameter table lacks " + G.missing_name);
     for (int net = 0; net < 2; ++net) {
       const int blocks = R >= 65536 ? 128 : 8;
-      TS_LAUNCH(k_rowscale_colsum, blocks, 1024, 0, st, w.G2, net == 0 ? w.DGPN : w.DGPA, R, w.nb.vpart);
+      float* const vp = vpart_slab(w.nb.vpart, blocks, 128);
+      TS_LAUNCH(k_rowscale_colsum, blocks, 1024, 0, st, w.G2, net == 0 ? w.DGPN : w.DGPA, R, vp);
       {
         ColsumBatch cb(st, blocks, 128);
-        cb.add(w.nb.vpart, 64, net == 0 ? n4w : a4w);
-        cb.add(w.nb.vpart + 64, 1, net == 0 ? n4b : a4b);
+        cb.add(vp, 64, net == 0 ? n4w : a4w);
+        cb.add(vp + 64, 1, net == 0 ? n4b : a4b);
         if (int rc = cb.flush()) return rc;
       }
     }
   }
   if (d_aa_out) TS_HIP(hipMemcpyAsync(d_aa_out, w.DAA, size_t(R) * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (int rc = aa_encoder_backward(b, g, rot, blob_fwd, blob_bwd, w, wc, G, 8, st, drop_aa)) return rc;
-  return TRAJSDE_OK;
+  return sums.finish();
 }
 
 // ------------------------------------------------------------------ vanilla LocalEncoder backward (GENC:52-93)

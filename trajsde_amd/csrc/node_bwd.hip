@@ -480,8 +480,19 @@ __global__ __launch_bounds__(256) void k_headwise_outer_t(const float* __restric
 int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64_t N, float* W, int heads) {
   const int S = N >= 65536 ? 256 : (N >= 4096 ? 32 : (N >= 256 ? 8 : 1));
   if (int64_t(S) > wc.cap) return fail(TRAJSDE_ERR_WORKSPACE, "headwise_outer: partial buffer too small");
-  if (heads == 4) TS_LAUNCH_TAG("k_headwise_outer", false, k_headwise_outer_t<4>, dim3(4, S), 256, 0, wc.st, X, Y, N, wc.part);
-  else TS_LAUNCH_TAG("k_headwise_outer", false, k_headwise_outer_t<8>, dim3(8, S), 256, 0, wc.st, X, Y, N, wc.part);
+  ReduceQueue* rq = active_reduce_queue();
+  if (rq && rq->part != wc.part) rq = nullptr;
+  float* part = wc.part;
+  if (rq) {                                             // deferred sums (bwd.hpp): the S partials keep their slots until finish()
+    int rc = TRAJSDE_OK;
+    const int64_t base = rq->take(S, &rc);
+    if (rc) return rc;
+    part += base * 4096;
+    rq->jobs.push_back(ReduceJob{W, nullptr, base, S, 1, 64, 0, 0});
+  }
+  if (heads == 4) TS_LAUNCH_TAG("k_headwise_outer", false, k_headwise_outer_t<4>, dim3(4, S), 256, 0, wc.st, X, Y, N, part);
+  else TS_LAUNCH_TAG("k_headwise_outer", false, k_headwise_outer_t<8>, dim3(8, S), 256, 0, wc.st, X, Y, N, part);
+  if (rq) return TRAJSDE_OK;
   WgradJobs one;
   one.n = 1;
   one.j[0] = WgradJob{nullptr, nullptr, W, nullptr, 0, 0, 64, 0, 0};
@@ -499,11 +510,12 @@ int ffn_block_backward(const float* img_a, const float* img_b, const float* xn2,
   // (k_upd_bwd, which owns that buffer, runs after them on the same stream)
   const float* dout2 = drop.p > 0.f ? sc.UPD : dout;
   TS_LAUNCH(k_ffn_bwd_a, ga, 256, FfnBwdAL::SIZE * 4, st, img_a, dout, xn2, R, sc.H, sc.DH, sc.UPD, drop);
-  TS_LAUNCH(k_ffn_bwd_b, gb, 256, FfnBwdBL::SIZE * 4, st, img_b, sc.DH, dout, x1, R, sc.dx1, sc.vpart);
+  float* const vp = vpart_slab(sc.vpart, int64_t(gb) * 4, 128);
+  TS_LAUNCH(k_ffn_bwd_b, gb, 256, FfnBwdBL::SIZE * 4, st, img_b, sc.DH, dout, x1, R, sc.dx1, vp);
   {
     ColsumBatch cb(st, gb * 4, 128);
-    cb.add(sc.vpart, 64, gr.n2g);
-    cb.add(sc.vpart + 64, 64, gr.n2b);
+    cb.add(vp, 64, gr.n2g);
+    cb.add(vp + 64, 64, gr.n2b);
     if (int rc = cb.flush()) return rc;
   }
   // first layer [256,64] (four 64-row blocks) and second layer [64,256] (four 64-column blocks): eight problems, one launch pair
@@ -540,14 +552,15 @@ int edge_embed_backward(const float* img, const float* geom, const float* demb, 
   const int tail_threads = ag ? 512 : 256;                 // one workgroup per CU with the two extra matrices: make it a bigger one
   const int gt = vec_grid(ntiles, tail_threads, lds_tail), gb = vec_grid(ntiles, 256, lds_br);
   const int tail_waves = tail_threads / 64;
+  float* vp = vpart_slab(sc.vpart, int64_t(gt) * tail_waves, 256);
   if (ag) TS_LAUNCH_TAG("k_edge_embed_bwd_tail<attn>", false, k_edge_embed_bwd_tail<true>, gt, tail_threads, lds_tail, st, img, geom, demb, *ag, E,
-                        sc.S, sc.DEP, sc.DSP, sc.vpart);
+                        sc.S, sc.DEP, sc.DSP, vp);
   else TS_LAUNCH_TAG("k_edge_embed_bwd_tail", false, k_edge_embed_bwd_tail<false>, gt, tail_threads, lds_tail, st, img, geom, demb, EdgeAttnGrad{}, E,
-                     sc.S, sc.DEP, sc.DSP, sc.vpart);
+                     sc.S, sc.DEP, sc.DSP, vp);
   float* const tail_vec[4] = {gr.ag3, gr.ae3, gr.ag0, gr.ae0};
   {
     ColsumBatch cb(st, gt * tail_waves, 256);
-    for (int i = 0; i < 4; ++i) cb.add(sc.vpart + 64 * i, 64, tail_vec[i]);
+    for (int i = 0; i < 4; ++i) cb.add(vp + 64 * i, 64, tail_vec[i]);
     if (int rc = cb.flush()) return rc;
   }
   {
@@ -560,19 +573,20 @@ int edge_embed_backward(const float* img, const float* geom, const float* demb, 
     if (int rc = wb.flush()) return rc;
   }
   for (int br = 0; br < 2; ++br) {
-    if (br == 0) TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, img, geom, sc.DSP, E, sc.vpart);
-    else TS_LAUNCH(k_edge_embed_bwd_branch<1>, gb, 256, lds_br, st, img, geom, sc.DSP, E, sc.vpart);
+    vp = vpart_slab(sc.vpart, int64_t(gb) * 4, 320);
+    if (br == 0) TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, img, geom, sc.DSP, E, vp);
+    else TS_LAUNCH(k_edge_embed_bwd_branch<1>, gb, 256, lds_br, st, img, geom, sc.DSP, E, vp);
     float* g_ = br ? gr.b_g : gr.a_g;
     float* e_ = br ? gr.b_e : gr.a_e;
     float* w0 = br ? gr.b_w0 : gr.a_w0;
     float* b0 = br ? gr.b_b0 : gr.a_b0;
     {
       ColsumBatch cb(st, gb * 4, 320);
-      cb.add(sc.vpart, 64, g_);
-      cb.add(sc.vpart + 64, 64, e_);
-      cb.add(sc.vpart + 128, 64, w0, 2);        // [64,2] weight, column 0
-      cb.add(sc.vpart + 192, 64, w0 + 1, 2);    // column 1
-      cb.add(sc.vpart + 256, 64, b0);
+      cb.add(vp, 64, g_);
+      cb.add(vp + 64, 64, e_);
+      cb.add(vp + 128, 64, w0, 2);        // [64,2] weight, column 0
+      cb.add(vp + 192, 64, w0 + 1, 2);    // column 1
+      cb.add(vp + 256, 64, b0);
       if (int rc = cb.flush()) return rc;
     }
   }
