@@ -271,6 +271,13 @@ int64_t trajsde_encoder_grid_ws_bytes(const trajsde_batch* b, const trajsde_grap
 int trajsde_encoder_grid_forward(const trajsde_batch* b, const trajsde_graph* g, const float* rotate_mat, const float* blob,
                                  int num_heads, int num_temporal_layers, void* ws, int64_t ws_bytes,
                                  float* local_embed /*[N,64]*/, void* stream);
+/* The same forward under model.train(): the reference's dropout modules are active (configs/nusargo/hivt_nuSArgo_trmenc_mlpdec.yml
+ * ships dropout 0.1) -- the four sites of the AA and AL attention blocks and, per TemporalEncoder layer, nn.MultiheadAttention's dropout on
+ * the softmax output, dropout1, the feed-forward dropout and dropout2 (enc_hivt_nusargo_grid.py:256-283).  Masks come from the Philox
+ * stream keyed by `dropout` (null or p = 0: identical to trajsde_encoder_grid_forward). */
+int trajsde_encoder_grid_forward_train(const trajsde_batch* b, const trajsde_graph* g, const float* rotate_mat, const float* blob,
+                                       int num_heads, int num_temporal_layers, void* ws, int64_t ws_bytes,
+                                       float* local_embed /*[N,64]*/, const trajsde_dropout* dropout, void* stream);
 int64_t trajsde_mlp_decoder_ws_bytes(int32_t N, int num_modes);
 int trajsde_mlp_decoder_forward(int32_t N, int num_modes, int future_steps, const float* blob,
                                 const float* local_embed /*[N,64]*/, const float* global_embed /*[K,N,64]*/, float min_scale,
@@ -291,6 +298,12 @@ int64_t trajsde_encoder_grid_backward_ws_bytes(const trajsde_batch* b, const tra
 int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rotate_mat, const float* blob_fwd,
                                   const float* blob_bwd, int num_heads, int num_temporal_layers, const float* d_local /*[N,64]*/,
                                   void* ws, int64_t ws_bytes, float* const* grads, int n_grads, void* stream);
+
+/* ... of a forward that ran with dropout (trajsde_encoder_grid_forward_train with the same `dropout`) */
+int trajsde_encoder_grid_backward_train(const trajsde_batch* b, const trajsde_graph* g, const float* rotate_mat, const float* blob_fwd,
+                                        const float* blob_bwd, int num_heads, int num_temporal_layers, const float* d_local /*[N,64]*/,
+                                        void* ws, int64_t ws_bytes, float* const* grads, int n_grads,
+                                        const trajsde_dropout* dropout, void* stream);
 
 /* ---- winner-takes-all L2 regression loss (losses/L2.py:10-27) + backward of the decoder stage: gradients of
  *      loss = mean over valid (actor, step) of |y - loc[best mode]| w.r.t. the decoder parameters and the stage

@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from restate import (D, _lin, _ln, attention_aggregate, ff_block, gated_update, global_interactor, multiple_input_embedding,
-                     rotate2, rotate_inputs, single_input_embedding)
+                     proj_drop, rotate2, rotate_inputs, single_input_embedding)
 
 
 def flat_cfg(cfg):
@@ -18,9 +18,24 @@ def flat_cfg(cfg):
                 future_steps=d["future_steps"], min_scale=d["min_scale"], num_global_layers=a["num_layers"])
 
 
-def temporal_encoder(P, pre, x, padding_mask, heads, layers):
+def temporal_masks(drop, layer, n_actors, heads, like):
+    """the four train-mode dropout masks of TemporalEncoder layer `layer` in THIS file's layouts -- attention weights [N, h, S, S]
+    (nn.MultiheadAttention's dropout on the softmax output), dropout1 [S, N, 64], the FFN's dropout [S, N, 256], dropout2 [S, N, 64]
+    (GENC:262-283) -- from the host twin of csrc/dropout.hpp: block 16 + layer, node sites on the token row n * S + s"""
+    from trajsde_amd import philox
+    S, block = 22, philox.TEMPORAL_BLOCK0 + layer
+    att = torch.from_numpy(philox.dropout_temporal_attn_mask(drop.seed, block, n_actors, heads, drop.p, S)).to(like.dtype)
+
+    def rows(kind, width):
+        m = philox.dropout_feature_mask(drop.seed, block, kind, n_actors * S, width, drop.p)           # row n * S + s
+        return torch.from_numpy(m).to(like.dtype).view(n_actors, S, width).transpose(0, 1)              # -> [S, N, width]
+    return att, rows(philox.DK_PROJ, D), rows(philox.DK_HIDDEN, 4 * D), rows(philox.DK_OUT, D)
+
+
+def temporal_encoder(P, pre, x, padding_mask, heads, layers, drop=None):
     """TemporalEncoder.forward GENC:241-249 over nn.TransformerEncoder of pre-norm TemporalEncoderLayers (GENC:258-292),
-    causal mask GENC:251-255; nn.MultiheadAttention semantics: q scaled by dh^-0.5, softmax over keys j <= i."""
+    causal mask GENC:251-255; nn.MultiheadAttention semantics: q scaled by dh^-0.5, softmax over keys j <= i.
+    `drop`: a restate.PhiloxDropout (train mode: the layers' four dropout sites) or None."""
     S, N, _ = x.shape                                                        # [21, N, 64]
     x = torch.where(padding_mask.t().unsqueeze(-1), P[pre + ".padding_token"], x)
     x = torch.cat((x, P[pre + ".cls_token"].expand(-1, N, -1)), 0) + P[pre + ".pos_embed"]
@@ -34,14 +49,22 @@ def temporal_encoder(P, pre, x, padding_mask, heads, layers):
         q, k, v = (t.reshape(S, N, heads, dh).permute(1, 2, 0, 3) for t in qkv.chunk(3, -1))    # [N, h, S, dh]
         att = (q * dh ** -0.5) @ k.transpose(-1, -2)
         att = att.masked_fill(~causal, float("-inf")).softmax(-1)
+        m_att = m_proj = m_hid = m_out = None
+        if drop is not None:
+            m_att, m_proj, m_hid, m_out = temporal_masks(drop, i, N, heads, x)
+            att = att * m_att
         o = (att @ v).permute(2, 0, 1, 3).reshape(S, N, D)
-        x = x + _lin(P, l + ".self_attn.out_proj", o)
-        x = x + _lin(P, l + ".linear2", F.relu(_lin(P, l + ".linear1", _ln(P, l + ".norm2", x))))
+        sa = _lin(P, l + ".self_attn.out_proj", o)
+        x = x + (sa * m_proj if drop is not None else sa)
+        h = F.relu(_lin(P, l + ".linear1", _ln(P, l + ".norm2", x)))
+        ff = _lin(P, l + ".linear2", h * m_hid if drop is not None else h)
+        x = x + (ff * m_out if drop is not None else ff)
     return _ln(P, pre + ".transformer_encoder.norm", x)[-1]
 
 
-def local_encoder_grid(P, cfg, batch, rot):
-    """LocalEncoder.forward GENC:52-93"""
+def local_encoder_grid(P, cfg, batch, rot, drop=None, inter=None):
+    """LocalEncoder.forward GENC:52-93.  `drop`: a restate.PhiloxDropout (train mode) or None; `inter`: dict that receives the edge
+    lists in the reference's order (the fixture generator lays the injected masks out with them)"""
     pre = "encoder"
     H, radius, heads = cfg["historical_steps"], cfg["local_radius"], cfg["num_heads"]
     x, pos, pad = batch["x"], batch["positions"], batch["padding_mask"]
@@ -67,10 +90,11 @@ def local_encoder_grid(P, cfg, batch, rot):
     cn = _ln(P, a + ".norm1", center)
     r_e = rot_rep[e_dst]
     nbr = multiple_input_embedding(P, a + ".nbr_embed", [rotate2(xt[e_src], r_e), rotate2(e_attr, r_e)])
-    agg = attention_aggregate(_lin(P, a + ".lin_q", cn), _lin(P, a + ".lin_k", nbr), _lin(P, a + ".lin_v", nbr), e_dst, H * N, heads)
-    center = center + _lin(P, a + ".out_proj", gated_update(P, a, agg, cn))
-    center = center + ff_block(P, a, _ln(P, a + ".norm2", center))
-    out = temporal_encoder(P, pre + ".temporal_encoder", center.view(H, N, D), pad[:, :H], heads, cfg["num_temporal_layers"])
+    agg = attention_aggregate(_lin(P, a + ".lin_q", cn), _lin(P, a + ".lin_k", nbr), _lin(P, a + ".lin_v", nbr), e_dst, H * N, heads,
+                              attn_keep=drop.attn(0, e_src, e_dst, heads, cn) if drop is not None else None)
+    center = center + proj_drop(_lin(P, a + ".out_proj", gated_update(P, a, agg, cn)), drop, 0)
+    center = center + ff_block(P, a, _ln(P, a + ".norm2", center), drop, 0)
+    out = temporal_encoder(P, pre + ".temporal_encoder", center.view(H, N, D), pad[:, :H], heads, cfg["num_temporal_layers"], drop)
     l = pre + ".al_encoder"                                                 # GENC:80-93 + ALEncoder
     la, lav = batch["lane_actor_index"], batch["lane_actor_vectors"]
     near = torch.norm(lav, p=2, dim=-1) < radius
@@ -82,9 +106,12 @@ def local_encoder_grid(P, cfg, batch, rot):
     xn = _ln(P, l + ".norm1", out)
     r_e = rot[l_dst]
     lane = multiple_input_embedding(P, l + ".lane_embed", [rotate2(lane_feat[l_src], r_e), rotate2(lav, r_e)])
-    agg = attention_aggregate(_lin(P, l + ".lin_q", xn), _lin(P, l + ".lin_k", lane), _lin(P, l + ".lin_v", lane), l_dst, N, heads)
-    out = out + _lin(P, l + ".out_proj", gated_update(P, l, agg, xn))
-    return out + ff_block(P, l, _ln(P, l + ".norm2", out))
+    agg = attention_aggregate(_lin(P, l + ".lin_q", xn), _lin(P, l + ".lin_k", lane), _lin(P, l + ".lin_v", lane), l_dst, N, heads,
+                              attn_keep=drop.attn(1, l_src, l_dst, heads, xn) if drop is not None else None)
+    out = out + proj_drop(_lin(P, l + ".out_proj", gated_update(P, l, agg, xn)), drop, 1)
+    if inter is not None:
+        inter.update(aa_edge_list=(e_src, e_dst), al_edge_list=(l_src, l_dst))
+    return out + ff_block(P, l, _ln(P, l + ".norm2", out), drop, 1)
 
 
 def mlp_decoder(P, cfg, batch, local_embed, global_embed):
@@ -103,14 +130,15 @@ def mlp_decoder(P, cfg, batch, local_embed, global_embed):
 
 
 @torch.no_grad()
-def forward(P, cfg, batch, want_intermediates=False):
-    """PredictionModel.forward, models/model_base_mix.py:74-92 (eval mode)"""
+def forward(P, cfg, batch, want_intermediates=False, drop=None):
+    """PredictionModel.forward, models/model_base_mix.py:74-92 (eval mode; `drop`: a restate.PhiloxDropout for train mode)"""
     c = flat_cfg(cfg) if "encoder" in cfg else cfg
     rot, y_rot = rotate_inputs(batch)
-    local = local_encoder_grid(P, c, batch, rot)
-    glob = global_interactor(P, dict(c, historical_steps=c["historical_steps"]), batch, rot, local)
+    inter = {} if want_intermediates else None
+    local = local_encoder_grid(P, c, batch, rot, drop, inter)
+    glob = global_interactor(P, dict(c, historical_steps=c["historical_steps"]), batch, rot, local, inter, drop)
     out = mlp_decoder(P, c, batch, local, glob)
     out.update(rotate_mat=rot, y=y_rot)
     if want_intermediates:
-        out.update(local_embed=local, global_embed=glob)
+        out.update(inter, local_embed=local, global_embed=glob)
     return out

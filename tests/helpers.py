@@ -227,8 +227,9 @@ def grid_cfg(K, T, heads, layers):
     return cfg
 
 
-def oracle_grid_full_grads(model, cfg, batch_cpu, d_local=None):
-    """float64 autograd over oracle/restate_grid.py: whole model under L2, or the encoder alone under sum(local * d_local)"""
+def oracle_grid_full_grads(model, cfg, batch_cpu, d_local=None, drop=None):
+    """float64 autograd over oracle/restate_grid.py: whole model under L2, or the encoder alone under sum(local * d_local);
+    `drop`: a restate.PhiloxDropout for train mode (the masks the HIP kernels cut from their Philox stream)"""
     import restate
     import restate_grid
     c = restate_grid.flat_cfg(cfg)
@@ -245,11 +246,11 @@ def oracle_grid_full_grads(model, cfg, batch_cpu, d_local=None):
     try:
         rot, y_rot = restate.rotate_inputs(b)
         with torch.enable_grad():
-            local = restate_grid.local_encoder_grid(P, c, b, rot)
+            local = restate_grid.local_encoder_grid(P, c, b, rot, drop)
             if d_local is not None:
                 loss = (local * d_local.cpu().to(dt)).sum()
             else:
-                glob = restate.global_interactor(P, c, b, rot, local)
+                glob = restate.global_interactor(P, c, b, rot, local, None, drop)
                 out = restate_grid.mlp_decoder(P, c, b, local, glob)
                 loss, _ = reference_l2(y_rot, out["loc"][..., :2], out["reg_mask"])
             loss.backward()

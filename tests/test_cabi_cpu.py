@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol(repo_root):
     lib = _lib.lib()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.trajsde_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.trajsde_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_param_tables_match_state_dict():

@@ -78,15 +78,8 @@ def test_vanilla_forward_matches_oracle_on_synthetic(S, n, K, T, heads, layers, 
 
 def test_vanilla_variant_refuses_what_it_does_not_build(dev):
     from trajsde_amd.models.model_base_mix import PredictionModel
-    from trajsde_amd.synth import synth
     with pytest.raises(NotImplementedError):
         PredictionModel(**_cfg(3, 80, 4, 2), init_seed=1)          # 2T > 128 outputs per head
-    cfg = _cfg(3, 12, 4, 2)
-    cfg["encoder"]["kwargs"]["dropout"] = 0.1                      # the TemporalEncoder's dropout sites have no training kernels
-    model = PredictionModel(**cfg, init_seed=1).to(dev).train()
-    batch = synth(S=1, n=5, L=3, F=12, box=50.0, seed=1).to(dev)
-    with pytest.raises(NotImplementedError, match="dropout"):
-        model.training_step(batch, 0)
 
 
 def test_ts_drop_augmentation_masks_history_steps_like_the_reference(dev):
@@ -210,6 +203,83 @@ def test_vanilla_encoder_backward_matches_autograd(S, n, heads, layers, kw, dev)
     torch.cuda.synchronize()
     _, want = _oracle_full(model, cfg, batch, d_local)
     _compare(res["grads"].items(), want, "encoder.")
+
+
+def _cfg_drop(K, T, heads, layers, p=0.1):
+    cfg = _cfg(K, T, heads, layers)
+    cfg["encoder"]["kwargs"]["dropout"] = p                       # the reference's YAML value (hivt_nuSArgo_trmenc_mlpdec.yml:33)
+    cfg["aggregator"]["kwargs"]["dropout"] = p
+    return cfg
+
+
+@pytest.mark.parametrize("S,n,heads,layers,kw", [
+    (3, 12, 4, 2, dict(mixed_source=True, history_dropout=0.4)),
+    (2, 9, 8, 1, dict(source=1, history_dropout=0.2)),
+])
+def test_vanilla_encoder_train_mode_dropout_forward_and_backward(S, n, heads, layers, kw, dev):
+    """model.train() with the reference's dropout 0.1: the 4 sites of the AA and AL blocks and the 4 of every TemporalEncoder layer
+    (nn.MultiheadAttention's dropout on the softmax output, dropout1, the FFN's dropout, dropout2: GENC:256-283).  Forward against
+    the oracle fed the host twin's masks (1e-4), every encoder gradient against float64 autograd over it; eval mode is untouched
+    by the key, train mode depends on it."""
+    import restate
+    import restate_grid
+    from trajsde_amd import runtime
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    from trajsde_amd.synth import synth
+    batch = synth(S=S, n=n, L=6, F=5, box=60.0, seed=900 + n, **kw)
+    cfg = _cfg_drop(2, 5, heads, layers)
+    model = PredictionModel(**cfg, init_seed=5).to(dev)
+    H.perturb_parameters(model, 78)          # (77 puts an FFN unit of temporal layer 0 on its ReLU kink for the first case: 2e-3 on linear1)
+    data = batch.to(dev)
+    rot, y_rot = runtime.rotate_inputs(data)
+    data.y, data["rotate_mat"] = y_rot, rot
+    noise = runtime.NoiseSpec(seed=3, dropout_seed=4242)
+    with torch.no_grad():
+        model.eval()
+        ev = model.encoder(data=data, noise=noise)
+        assert torch.equal(ev, model.encoder(data=data))                    # eval: no dropout, whatever the key
+        model.train()
+        tr = model.encoder(data=data, noise=noise)
+        assert torch.equal(tr, model.encoder(data=data, noise=noise))       # same key, same masks
+        assert not torch.equal(tr, model.encoder(data=data, noise=runtime.NoiseSpec(seed=3, dropout_seed=4243)))
+        assert float((tr - ev).abs().max()) > 1e-3
+    drop = restate.PhiloxDropout(4242, 0.1)
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    b = H.clone_batch(batch)
+    r_cpu, _ = restate.rotate_inputs(b)
+    with torch.no_grad():
+        want = restate_grid.local_encoder_grid(P, restate_grid.flat_cfg(cfg), b, r_cpu, drop)
+    assert float((tr.cpu() - want).abs().max()) <= 1e-4
+    g = torch.Generator().manual_seed(5)
+    d_local = torch.randn(tr.shape, generator=g).to(dev)
+    res = model.encoder._rt.encoder_grid_backward(data, d_local, noise)
+    torch.cuda.synchronize()
+    _, want_g = _oracle_full(model, cfg, batch, d_local, drop)
+    _compare(res["grads"].items(), want_g, "encoder.")
+
+
+def test_vanilla_training_step_in_train_mode_with_the_reference_dropout(dev):
+    """the whole vanilla training step under model.train() with dropout 0.1 in encoder and aggregator (36 dropout sites):
+    loss and every gradient against float64 autograd over the oracle with the host twin's masks"""
+    import restate
+    from trajsde_amd import runtime
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    from trajsde_amd.synth import synth
+    K, T = 3, 12
+    batch = synth(S=3, n=11, L=6, F=T, box=70.0, seed=93, mixed_source=True, history_dropout=0.3)
+    cfg = _cfg_drop(K, T, 4, 2)
+    model = PredictionModel(**cfg, init_seed=8)
+    H.perturb_parameters(model, 1234)
+    model = model.to(dev).train()
+    loss = model.training_step(batch.to(dev), 0, noise=runtime.NoiseSpec(seed=1, dropout_seed=99))
+    loss.backward()
+    torch.cuda.synchronize()
+    want_loss, want = _oracle_full(model, cfg, batch, None, restate.PhiloxDropout(99, 0.1))
+    assert abs(float(loss.detach()) - want_loss) <= 1e-5 * max(1.0, want_loss)
+    reached = {id(p) for p in model.params_with_gradient()}
+    _compare(((n, p.grad) for n, p in model.named_parameters() if id(p) in reached), want)
+    with pytest.raises(Exception, match="NoiseSpec|dropout"):
+        model.encoder._rt.encoder_grid_forward(batch.to(dev), None)          # train mode without a key is refused, never silently eval
 
 
 def test_vanilla_training_step_matches_end_to_end_autograd_and_trains(dev):

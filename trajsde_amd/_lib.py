@@ -12,10 +12,11 @@ STAGE_ENCODER_GRID, STAGE_DECODER_MLP, STAGE_DECODER_MLP_BWD, STAGE_ENCODER_GRID
 STAGE_DECODER_NLL_BWD = 10
 
 
-ABI_VERSION = 8          # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4);
+ABI_VERSION = 9          # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4);
                          # device-side list lengths + trajsde_graph_prepare_async (5); encoder tape / scratch split (6);
                          # trajsde_noise.seed_dev: Philox key read on the device (7); trajsde_aggregator_prepare /
-                         # _forward_prepared: the relative-pose embedding as a call of its own (8)
+                         # _forward_prepared: the relative-pose embedding as a call of its own (8);
+                         # trajsde_encoder_grid_forward_train / _backward_train: dropout of the vanilla encoder (9)
 
 
 class TrajsdeError(RuntimeError):
@@ -108,6 +109,8 @@ SIGNATURES = {
                                                       C.POINTER(Dropout), P]),
     "trajsde_encoder_grid_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph)]),
     "trajsde_encoder_grid_forward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, C.c_int, C.c_int, P, I64, P, P]),
+    "trajsde_encoder_grid_forward_train": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, C.c_int, C.c_int, P, I64, P,
+                                                     C.POINTER(Dropout), P]),
     "trajsde_mlp_decoder_ws_bytes": (I64, [I32, C.c_int]),
     "trajsde_mlp_decoder_forward": (C.c_int, [I32, C.c_int, C.c_int, P, P, P, F32, P, I64, P, P, P]),
     "trajsde_mlp_decoder_backward_ws_bytes": (I64, [I32]),
@@ -115,6 +118,8 @@ SIGNATURES = {
     "trajsde_encoder_grid_backward_ws_bytes": (I64, [C.POINTER(Batch), C.POINTER(Graph), C.c_int]),
     "trajsde_encoder_grid_backward": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, C.c_int, C.c_int, P, P, I64, C.POINTER(P),
                                                 C.c_int, P]),
+    "trajsde_encoder_grid_backward_train": (C.c_int, [C.POINTER(Batch), C.POINTER(Graph), P, P, P, C.c_int, C.c_int, P, P, I64, C.POINTER(P),
+                                                      C.c_int, C.POINTER(Dropout), P]),
     "trajsde_profile_mode": (C.c_int, [C.c_int]),
     "trajsde_profile_report": (I64, [C.c_char_p, I64]),
     "trajsde_sde_step": (C.c_int, [I32, P, P, P, C.POINTER(F32), C.c_int, C.POINTER(Noise), P]),

@@ -212,8 +212,10 @@ int run_edge_attn_bwd(hipStream_t st, int heads, const float* img, const int32_t
 
 // ---- TemporalEncoder backward kernels (grid_bwd.hip)
 __global__ void k_tr_final_bwd(const float* norm, const float* x, const float* dtout, int N, float* DX, float* vpart);
-template <int HEADS>
-__global__ void k_tr_attention_bwd(const float* q, const float* k, const float* v, const float* dO, int N, float* dq, float* dk, float* dv);
+template <int HEADS, bool DROP>
+__global__ void k_tr_attention_bwd(const float* q, const float* k, const float* v, const float* dO, int N, float* dq, float* dk, float* dv,
+                                   DropArg drop);
+__global__ void k_drop_rows(const float* src, int64_t R, float* dst, DropArg drop, int kind);        // dst = src * factors of (row, feature)
 __global__ void k_tr_prep_bwd(const float* DX0, const uint8_t* pad, int N, int TT, float* DAA);
 __global__ void k_tr_tok_grad(const float* DX0, const uint8_t* pad, int N, int TT, float* dpad, float* dcls, float* dpos);
 

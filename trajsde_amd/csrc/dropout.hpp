@@ -89,4 +89,17 @@ __device__ __forceinline__ void drop_attn_chunk(float (&k)[CH], const DropArg& d
   }
 }
 
+// TemporalEncoder layers of the vanilla variant (grid.hip; GENC:256-283): block id 16 + layer.  Their node sites (dropout1 = DK_PROJ,
+// the FFN's DK_HIDDEN / DK_OUT) use drop_feat16 on the token row n * 22 + s; the attention weights of nn.MultiheadAttention
+// (dropout on the softmax output) are per (actor n, head h, query i, key j): block of counter (n, (i * HEADS + h) * 3 + (j >> 3),
+// stream, 0), field j & 7.  Host twin: philox.py dropout_temporal_attn_mask.
+constexpr int DROP_TEMPORAL_BLOCK0 = 16;    // (global layers take 2 .. 2 + layers - 1)
+template <int HEADS>
+__device__ __forceinline__ void drop_tr_attn8(float* k /*[8]*/, const DropArg& d, uint32_t n, int head, int i, int chunk) {
+  uint32_t w[4];
+  philox_words(d.seed, drop_stream(d, DK_ATTN), uint32_t((i * HEADS + head) * 3 + chunk), n, 0u, w);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) k[u] = drop_pick(w[u >> 1], u & 1, d);
+}
+
 }  // namespace tsde

@@ -1041,7 +1041,20 @@ int64_t trajsde_encoder_grid_backward_ws_bytes(const trajsde_batch* b, const tra
 int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_fwd,
                                   const float* blob_bwd, int num_heads, int num_temporal_layers, const float* d_local, void* ws,
                                   int64_t ws_bytes, float* const* grads, int n_grads, void* stream_) {
+  return trajsde_encoder_grid_backward_train(b, g, rot, blob_fwd, blob_bwd, num_heads, num_temporal_layers, d_local, ws, ws_bytes, grads, n_grads,
+                                             nullptr, stream_);
+}
+
+// the same backward for a forward that ran with dropout (trajsde_encoder_grid_forward_train, the same `dropout`): the masks are
+// regenerated from their counters in the recomputed forward and in every backward kernel that needs them
+int trajsde_encoder_grid_backward_train(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob_fwd,
+                                        const float* blob_bwd, int num_heads, int num_temporal_layers, const float* d_local, void* ws,
+                                        int64_t ws_bytes, float* const* grads, int n_grads, const trajsde_dropout* dropout, void* stream_) {
   TS_REQUIRE(b && g && rot && blob_fwd && blob_bwd && d_local && ws && grads, "encoder_grid_backward: null pointer");
+  TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "encoder_grid_backward: dropout p must be in [0, 1)");
+  const bool dropping = dropout && dropout->p > 0.f;
+  auto drop_of = [&](int block) { return dropping ? make_drop(dropout->p, dropout->seed, block) : no_drop(); };
+  const DropArg drop_aa = drop_of(0), drop_al = drop_of(1);
   TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_grid_backward: graph not compacted");
   TS_REQUIRE(g->exact, "encoder_grid_backward: needs exact list lengths (trajsde_graph_prepare, not _async)");
   TS_REQUIRE(b->A == 0 && g->Nt == b->N && b->H == 21, "encoder_grid_backward: graph with A = 0 and 21 history steps expected");
@@ -1071,38 +1084,39 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
   TS_LAUNCH(k_aa_center, tile_grid((R + 15) / 16, 512, AaCenterL::SIZE * 4), 512, AaCenterL::SIZE * 4, st, blob_fwd + FB::AA_CENTER, b->x,
             g->x_fake, rot, b->bos_mask, g->orig, N, N, H, w.center, w.cn, w.q);
   if (int rc = edge_attention_tape("k_edge_kv[aa]+emb", blob_fwd + FB::AA_EDGE6F, blob_fwd + FB::AA_EDGE6, blob_fwd + FB::AA_ATTN, g->aa_geom, g->aa_dst, Eaa, g->aa_segptr, w.q, R,
-                                   w.emb, w.stats, w.agg, w.rec, num_heads, no_drop(), st))
+                                   w.emb, w.stats, w.agg, w.rec, num_heads, drop_aa, st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((R + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AA_UPD6, w.agg, w.cn,
-            w.center, R, w.x1, w.xn2, no_drop(), no_merge());
-  TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out, no_drop());
+            w.center, R, w.x1, w.xn2, drop_aa, no_merge());
+  TS_LAUNCH(k_ffn6, tile_grid((R + 15) / 16, 512, FfnL6::HALF * 4), 512, FfnL6::HALF * 4, st, blob_fwd + FB::AA_FFN6, w.x1, w.xn2, R, w.aa_out, drop_aa);
   TS_LAUNCH(k_tr_prep, cdiv(RT * 64, 256), 256, 0, st, w.aa_out, b->padding_mask, blob_fwd + EncGridBlob::TOK, N, b->TT, x0);
   const float* x = x0;
   for (int l = 0; l < nl; ++l) {
     const float* lb = blob_fwd + EncGridBlob::layer(l);
     TS_LAUNCH(k_node_proj<3>, tile_grid(rtiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + TrLayerL::QKV, x, RT,
               tp[l].xn, tp[l].q, tp[l].k, tp[l].v);
-    if (num_heads == 4) TS_LAUNCH(k_tr_attention<4>, cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, N, tp[l].o);
-    else TS_LAUNCH(k_tr_attention<8>, cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, N, tp[l].o);
+    const DropArg dl = drop_of(DROP_TEMPORAL_BLOCK0 + l);
+    if (int rc = launch_tr_attention(num_heads, tp[l].q, tp[l].k, tp[l].v, N, tp[l].o, dl, st)) return rc;
     TS_LAUNCH(k_tr_outproj, tile_grid(rtiles, 512, TrOutL::SIZE * 4), 512, TrOutL::SIZE * 4, st, lb + TrLayerL::OUT, tp[l].o, x, RT, tp[l].x1,
-              tp[l].xn2);
-    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, tp[l].x1, tp[l].xn2, RT, tp[l].out, no_drop(), 0);
+              tp[l].xn2, dl);
+    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, tp[l].x1, tp[l].xn2, RT, tp[l].out, dl, 0);
     x = tp[l].out;
   }
   TS_LAUNCH(k_tr_final, tile_grid((int64_t(N) + 15) / 16, 256, 0), 256, 0, st, blob_fwd + EncGridBlob::norm(nl), x, N, tout);
   TS_LAUNCH(k_node_proj<1>, tile_grid((int64_t(N) + 15) / 16, 512, NodeProjL<1>::SIZE * 4), 512, NodeProjL<1>::SIZE * 4, st,
             blob_fwd + FB::AL_Q, tout, int64_t(N), w.al_xn, w.al_q, nullptr, nullptr);
   if (int rc = edge_attention_tape("k_edge_kv[al]+emb", blob_fwd + FB::AL_EDGE6F, blob_fwd + FB::AL_EDGE6, blob_fwd + FB::AL_ATTN, g->la_geom, g->la_dst, Ela, g->la_segptr, w.al_q,
-                                   int64_t(N), w.al_emb, w.al_stats, w.al_agg, w.rec, num_heads, no_drop(), st))
+                                   int64_t(N), w.al_emb, w.al_stats, w.al_agg, w.rec, num_heads, drop_al, st))
     return rc;
   TS_LAUNCH(k_node_update<true>, tile_grid((int64_t(N) + 15) / 16, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, blob_fwd + FB::AL_UPD6,
-            w.al_agg, w.al_xn, tout, int64_t(N), w.al_x1, w.al_xn2, no_drop(), no_merge());
+            w.al_agg, w.al_xn, tout, int64_t(N), w.al_x1, w.al_xn2, drop_al, no_merge());
   // ================= backward =================
   {
     AttnChain c{blob_bwd + BB::AL_NODE, blob_bwd + BB::AL_PROJ, blob_fwd + EncBlob::AL_ATTN, blob_bwd + BB::AL_EDGEEMB,
                 g->la_geom, w.al_q, w.al_emb, w.al_stats, tout, g->la_dst, g->la_segptr,
                 NodeBlockTape{w.al_agg, w.al_xn, w.al_x1, w.al_xn2}, int64_t(N), Ela, "al_encoder", "lane_embed", num_heads};
     c.img_kvt = blob_bwd + BB::AL_EDGEKV + EdgeKvBwdL::WKT;
+    c.drop = drop_al;
     if (int rc = run_attn_chain(c, d_local, w, wc, G, dtout, st)) return rc;
   }
   const std::string te = "temporal_encoder.";
@@ -1136,11 +1150,23 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
     float *wi = G(p + ".self_attn.in_proj_weight"), *bi = G(p + ".self_attn.in_proj_bias");
     float *n1g = G(p + ".norm1.weight"), *n1b = G(p + ".norm1.bias");
     TS_REQUIRE(!G.missing, "encoder_grid_backward: parameter table lacks " + G.missing_name);
-    if (int rc = ffn_block_backward(lb + TrLayerBwdL::FFN_A, lb + TrLayerBwdL::FFN_B, tp[l].xn2, tp[l].x1, dcur, RT, sc, wc, gr, st, no_drop())) return rc;
-    TS_LAUNCH(k_lin_t_acc, tile_grid(rtiles, 256, MAT64 * 4), 256, MAT64 * 4, st, lb + TrLayerBwdL::WOUT_T, sc.dx1, RT, dO, 0);
-    if (int rc = run_wgrad(wc, sc.dx1, 64, tp[l].o, 64, RT, RT, wo, 64, 0, bo, 0)) return rc;
-    if (num_heads == 4) TS_LAUNCH(k_tr_attention_bwd<4>, cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, dO, N, dq, dk, dv);
-    else TS_LAUNCH(k_tr_attention_bwd<8>, cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, dO, N, dq, dk, dv);
+    const DropArg dl = drop_of(DROP_TEMPORAL_BLOCK0 + l);
+    if (int rc = ffn_block_backward(lb + TrLayerBwdL::FFN_A, lb + TrLayerBwdL::FFN_B, tp[l].xn2, tp[l].x1, dcur, RT, sc, wc, gr, st, dl)) return rc;
+    // dropout1: out_proj saw dx1 m, the residual dx1 (k_drop_rows; dq is free until the attention backward writes it)
+    const float* dx1m = sc.dx1;
+    if (dropping) {
+      TS_LAUNCH(k_drop_rows, tile_grid(rtiles, 256, 0), 256, 0, st, sc.dx1, RT, dq, dl, int(DK_PROJ));
+      dx1m = dq;
+    }
+    TS_LAUNCH(k_lin_t_acc, tile_grid(rtiles, 256, MAT64 * 4), 256, MAT64 * 4, st, lb + TrLayerBwdL::WOUT_T, dx1m, RT, dO, 0);
+    if (int rc = run_wgrad(wc, dx1m, 64, tp[l].o, 64, RT, RT, wo, 64, 0, bo, 0)) return rc;
+    if (num_heads == 4) {
+      if (dropping) TS_LAUNCH_TAG("k_tr_attention_bwd<drop>", false, (k_tr_attention_bwd<4, true>), cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, dO, N, dq, dk, dv, dl);
+      else TS_LAUNCH_TAG("k_tr_attention_bwd", false, (k_tr_attention_bwd<4, false>), cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, dO, N, dq, dk, dv, dl);
+    } else {
+      if (dropping) TS_LAUNCH_TAG("k_tr_attention_bwd<drop>", false, (k_tr_attention_bwd<8, true>), cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, dO, N, dq, dk, dv, dl);
+      else TS_LAUNCH_TAG("k_tr_attention_bwd", false, (k_tr_attention_bwd<8, false>), cdiv(N, 4), 256, 0, st, tp[l].q, tp[l].k, tp[l].v, dO, N, dq, dk, dv, dl);
+    }
     const int gp = vec_grid(rtiles, 256, ProjBwdL<3>::SIZE * 4);
     TS_LAUNCH(k_node_proj_bwd<3>, gp, 256, ProjBwdL<3>::SIZE * 4, st, lb + TrLayerBwdL::PROJ, x_in, sc.dx1, nullptr, dq, dk, dv, RT, dnext,
               nullptr, w.nb.vpart);
@@ -1163,7 +1189,7 @@ int trajsde_encoder_grid_backward(const trajsde_batch* b, const trajsde_graph* g
     TS_LAUNCH(k_tr_tok_grad, 22, 1024, 0, st, dcur, b->padding_mask, N, b->TT, gpad, gcls, gpos);
     TS_LAUNCH(k_tr_prep_bwd, cdiv(R * 64, 256), 256, 0, st, dcur, b->padding_mask, N, b->TT, w.DAA);
   }
-  return aa_encoder_backward(b, g, rot, blob_fwd, blob_bwd, w, wc, G, num_heads, st);
+  return aa_encoder_backward(b, g, rot, blob_fwd, blob_bwd, w, wc, G, num_heads, st, drop_aa);
 }
 
 }  // extern "C"

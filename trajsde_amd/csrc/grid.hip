@@ -14,6 +14,7 @@
 //     k_mlp_heads      loc / scale = Linear(relu(LN(Linear(out)))) with 2T outputs, ELU + 1 + min_scale on scale
 #include "attn_common.hpp"
 #include "common.hpp"
+#include "dropout.hpp"
 #include "kernels.hpp"
 #include "layouts.hpp"
 #include "tile.hpp"
@@ -33,14 +34,16 @@ __global__ void k_tr_prep(const float* __restrict__ aa_out, const uint8_t* __res
   X[i] = v + tok[EncGridBlob::TOK_POS + s * 64 + c];
 }
 
-// rows of q, k, v, o are [n][s][64]; nn.MultiheadAttention: q scaled by dh^-0.5, keys j <= i (causal mask GENC:251-255)
-template <int HEADS>
+// rows of q, k, v, o are [n][s][64]; nn.MultiheadAttention: q scaled by dh^-0.5, keys j <= i (causal mask GENC:251-255).
+// DROP: the module's dropout on the softmax output (train mode), factors from dropout.hpp drop_tr_attn8
+template <int HEADS, bool DROP>
 __global__ __launch_bounds__(256) void k_tr_attention(const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, int N, float* __restrict__ o) {
+                                                      const float* __restrict__ v, int N, float* __restrict__ o, DropArg drop) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (n >= N) return;
   constexpr float SCALE = HEADS == 4 ? 0.25f : INV_SQRT_DH;
+  const int head = lane / (64 / HEADS);
   const int64_t base = int64_t(n) * TR_S * 64 + lane;
   float kr[TR_S], vr[TR_S];
 #pragma unroll
@@ -58,22 +61,43 @@ __global__ __launch_bounds__(256) void k_tr_attention(const float* __restrict__ 
       p[j] = head_sum_n<HEADS>(qd * kr[j]);
       m = fmaxf(m, p[j]);
     }
+    float mk[24];
+    if (DROP) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (8 * c <= i) drop_tr_attn8<HEADS>(mk + 8 * c, drop, uint32_t(n), head, i, c);
+    }
     float s = 0.f, acc = 0.f;
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
       const float e = fast_exp(p[j] - m);
       s += e;
-      acc = fmaf(e, vr[j], acc);
+      acc = fmaf(DROP ? e * mk[j] : e, vr[j], acc);
     }
     o[base + i * 64] = acc / s;
   }
 }
-template __global__ void k_tr_attention<4>(const float*, const float*, const float*, int, float*);
-template __global__ void k_tr_attention<8>(const float*, const float*, const float*, int, float*);
+template __global__ void k_tr_attention<4, false>(const float*, const float*, const float*, int, float*, DropArg);
+template __global__ void k_tr_attention<8, false>(const float*, const float*, const float*, int, float*, DropArg);
+template __global__ void k_tr_attention<4, true>(const float*, const float*, const float*, int, float*, DropArg);
+template __global__ void k_tr_attention<8, true>(const float*, const float*, const float*, int, float*, DropArg);
 
+int launch_tr_attention(int heads, const float* q, const float* k, const float* v, int N, float* o, const DropArg& drop, hipStream_t st) {
+  const bool d = drop.p > 0.f;
+  if (heads == 4) {
+    if (d) TS_LAUNCH_TAG("k_tr_attention<drop>", false, (k_tr_attention<4, true>), cdiv(N, 4), 256, 0, st, q, k, v, N, o, drop);
+    else TS_LAUNCH_TAG("k_tr_attention", false, (k_tr_attention<4, false>), cdiv(N, 4), 256, 0, st, q, k, v, N, o, drop);
+  } else {
+    if (d) TS_LAUNCH_TAG("k_tr_attention<drop>", false, (k_tr_attention<8, true>), cdiv(N, 4), 256, 0, st, q, k, v, N, o, drop);
+    else TS_LAUNCH_TAG("k_tr_attention", false, (k_tr_attention<8, false>), cdiv(N, 4), 256, 0, st, q, k, v, N, o, drop);
+  }
+  return TRAJSDE_OK;
+}
+
+// x1 = x + dropout1(out_proj(o)) (GENC:270-276; the dropout in train mode only: DK_PROJ factors of the token row)
 __global__ __launch_bounds__(512) void k_tr_outproj(const float* __restrict__ img, const float* __restrict__ o,
                                                     const float* __restrict__ x, int64_t R, float* __restrict__ x1,
-                                                    float* __restrict__ xn2) {
+                                                    float* __restrict__ xn2, DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, img, TrOutL::SIZE);
   const Lane L;
@@ -85,6 +109,12 @@ __global__ __launch_bounds__(512) void k_tr_outproj(const float* __restrict__ im
     f4 a[4], t[4];
     load_row(a, o, r, L.g);
     linear<4, 4>(t, a, lds + TrOutL::WOUT, lds + TrOutL::BOUT, L);
+    if (drop.p > 0.f) {
+      f4 mk[4];
+      drop_feat16(mk, drop, DK_PROJ, uint32_t(r), 0, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) t[jt] *= mk[jt];
+    }
     load_row(a, x, r, L.g);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) t[jt] += a[jt];

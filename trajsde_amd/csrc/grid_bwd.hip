@@ -7,6 +7,7 @@
 #include "attn_common.hpp"
 #include "bwd.hpp"
 #include "common.hpp"
+#include "dropout.hpp"
 #include "kernels.hpp"
 #include "layouts.hpp"
 #include "tile.hpp"
@@ -123,15 +124,17 @@ __global__ __launch_bounds__(256) void k_tr_final_bwd(const float* __restrict__ 
 
 // causal self-attention backward, one wave per actor (lane = feature): given dO -> dQ, dK, dV (rows [n][s][64]).
 // Recomputes the softmax per query; with alpha the weights, d alpha_j = dO_i . v_j (head-wise), d logit_j =
-// alpha_j (d alpha_j - dO_i . o_i), and the logit is (q * dh^-0.5) . k.
-template <int HEADS>
+// alpha_j (d alpha_j - sum_j' alpha_j' d alpha_j'), and the logit is (q * dh^-0.5) . k.  DROP (train mode): the values were summed
+// with alpha_j m_j (m the dropout factors of dropout.hpp drop_tr_attn8), so d alpha_j = m_j (dO_i . v_j) and d v_j += alpha_j m_j dO_i.
+template <int HEADS, bool DROP>
 __global__ __launch_bounds__(256) void k_tr_attention_bwd(const float* __restrict__ q, const float* __restrict__ k,
                                                           const float* __restrict__ v, const float* __restrict__ dO, int N,
-                                                          float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv) {
+                                                          float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, DropArg drop) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (n >= N) return;
   constexpr float SCALE = HEADS == 4 ? 0.25f : INV_SQRT_DH;
+  const int head = lane / (64 / HEADS);
   const int64_t base = int64_t(n) * TRB_S * 64 + lane;
   float kr[TRB_S], vr[TRB_S], dkr[TRB_S], dvr[TRB_S];
 #pragma unroll
@@ -152,6 +155,12 @@ __global__ __launch_bounds__(256) void k_tr_attention_bwd(const float* __restric
       p[j] = head_sum_n<HEADS>(qd * kr[j]);
       m = fmaxf(m, p[j]);
     }
+    float mk[24];
+    if (DROP) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (8 * c <= i) drop_tr_attn8<HEADS>(mk + 8 * c, drop, uint32_t(n), head, i, c);
+    }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
@@ -164,6 +173,7 @@ __global__ __launch_bounds__(256) void k_tr_attention_bwd(const float* __restric
     for (int j = 0; j <= i; ++j) {
       p[j] *= inv;                                            // alpha_j
       dal[j] = head_sum_n<HEADS>(go * vr[j]);
+      if (DROP) dal[j] *= mk[j];
       dlt = fmaf(p[j], dal[j], dlt);
     }
     float dqi = 0.f;
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(256) void k_tr_attention_bwd(const float* __restric
       const float dl = p[j] * (dal[j] - dlt);
       dqi = fmaf(dl, kr[j], dqi);
       dkr[j] = fmaf(dl, qd, dkr[j]);
-      dvr[j] = fmaf(p[j], go, dvr[j]);
+      dvr[j] = fmaf(DROP ? p[j] * mk[j] : p[j], go, dvr[j]);
     }
     dq[base + i * 64] = dqi * SCALE;
   }
@@ -182,8 +192,28 @@ __global__ __launch_bounds__(256) void k_tr_attention_bwd(const float* __restric
     dv[base + j * 64] = dvr[j];
   }
 }
-template __global__ void k_tr_attention_bwd<4>(const float*, const float*, const float*, const float*, int, float*, float*, float*);
-template __global__ void k_tr_attention_bwd<8>(const float*, const float*, const float*, const float*, int, float*, float*, float*);
+template __global__ void k_tr_attention_bwd<4, false>(const float*, const float*, const float*, const float*, int, float*, float*, float*, DropArg);
+template __global__ void k_tr_attention_bwd<8, false>(const float*, const float*, const float*, const float*, int, float*, float*, float*, DropArg);
+template __global__ void k_tr_attention_bwd<4, true>(const float*, const float*, const float*, const float*, int, float*, float*, float*, DropArg);
+template __global__ void k_tr_attention_bwd<8, true>(const float*, const float*, const float*, const float*, int, float*, float*, float*, DropArg);
+
+// dst[r] = src[r] * (dropout factors of site `kind` on row r): the gradient that enters a Linear whose output went through a
+// node-site dropout (dropout1 of a TemporalEncoder layer: x1 = x + m (Wout o + b), so Wout sees dx1 m, the residual dx1)
+__global__ __launch_bounds__(256) void k_drop_rows(const float* __restrict__ src, int64_t R, float* __restrict__ dst, DropArg drop, int kind) {
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (R + 15) / 16;
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+    const int64_t row = tile * 16 + L.n;
+    if (row >= R) continue;
+    f4 a[4], mk[4];
+    load_row(a, src, row, L.g);
+    drop_feat16(mk, drop, kind, uint32_t(row), 0, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) a[jt] *= mk[jt];
+    store_row(a, dst, row, L.g);
+  }
+}
 
 // d aa_out[t][n] = padded ? 0 : dX0[n][t]
 __global__ void k_tr_prep_bwd(const float* __restrict__ DX0, const uint8_t* __restrict__ pad, int N, int TT, float* __restrict__ DAA) {

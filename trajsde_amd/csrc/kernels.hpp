@@ -142,9 +142,10 @@ __global__ void k_enc_recur_coop(const float* sde_img, const float* gru_img, con
                                  float* latent_ys, int aa_bf16);
 // vanilla HiVT variant (grid.hip)
 __global__ void k_tr_prep(const float* aa_out, const uint8_t* pad, const float* tok, int N, int TT, float* X);
-template <int HEADS>
-__global__ void k_tr_attention(const float* q, const float* k, const float* v, int N, float* o);
-__global__ void k_tr_outproj(const float* img, const float* o, const float* x, int64_t R, float* x1, float* xn2);
+template <int HEADS, bool DROP>
+__global__ void k_tr_attention(const float* q, const float* k, const float* v, int N, float* o, DropArg drop);
+__global__ void k_tr_outproj(const float* img, const float* o, const float* x, int64_t R, float* x1, float* xn2, DropArg drop);
+int launch_tr_attention(int heads, const float* q, const float* k, const float* v, int N, float* o, const DropArg& drop, hipStream_t st);
 __global__ void k_tr_final(const float* norm, const float* x, int N, float* out);
 
 __global__ void k_ood_stats(const float* samples, int S, int N, float* mean, float* stds);

@@ -1115,7 +1115,7 @@ int trajsde_range_status(int reset, uint32_t* sites_out, void* stream) {
   msg += " -- the results of the affected launches are not valid; rebuild with TRAJSDE_SPLIT=bf16x6 for fp32's exponent range";
   return tsde::fail(TRAJSDE_ERR_UNSUPPORTED, msg);
 }
-int trajsde_abi_version(void) { return 8; }
+int trajsde_abi_version(void) { return 9; }
 
 int trajsde_param_count(int stage, int num_layers, int num_modes) {
   Packer P{true};

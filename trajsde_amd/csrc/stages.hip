@@ -387,7 +387,19 @@ int64_t trajsde_encoder_grid_ws_bytes(const trajsde_batch* b, const trajsde_grap
 
 int trajsde_encoder_grid_forward(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob, int num_heads,
                                  int num_temporal_layers, void* ws, int64_t ws_bytes, float* local_embed, void* stream_) {
+  return trajsde_encoder_grid_forward_train(b, g, rot, blob, num_heads, num_temporal_layers, ws, ws_bytes, local_embed, nullptr, stream_);
+}
+
+// the same forward with the train-mode dropout of the reference's modules (GENC:52-93 under model.train()): attention weights,
+// proj_drop and the two FFN sites of the AA / AL blocks (blocks 0 / 1 of dropout.hpp) and, per TemporalEncoder layer l (block 16 + l),
+// nn.MultiheadAttention's dropout on the softmax output, dropout1, the FFN's dropout and dropout2 (GENC:262-283)
+int trajsde_encoder_grid_forward_train(const trajsde_batch* b, const trajsde_graph* g, const float* rot, const float* blob, int num_heads,
+                                       int num_temporal_layers, void* ws, int64_t ws_bytes, float* local_embed,
+                                       const trajsde_dropout* dropout, void* stream_) {
   TS_REQUIRE(b && g && rot && blob && ws && local_embed, "encoder_grid_forward: null pointer");
+  TS_REQUIRE(!dropout || (dropout->p >= 0.f && dropout->p < 1.f), "encoder_grid_forward: dropout p must be in [0, 1)");
+  const bool dropping = dropout && dropout->p > 0.f;
+  auto drop_of = [&](int block) { return dropping ? make_drop(dropout->p, dropout->seed, block) : no_drop(); };
   TS_REQUIRE(g->aa_dst && g->la_dst && g->orig, "encoder_grid_forward: graph not compacted");
   TS_REQUIRE(g->exact, "encoder_grid_forward: needs exact list lengths (trajsde_graph_prepare, not _async)");
   TS_REQUIRE(b->A == 0 && g->Nt == b->N, "encoder_grid_forward: prepare the graph with A = 0 (no fake agents)");
@@ -403,7 +415,7 @@ int trajsde_encoder_grid_forward(const trajsde_batch* b, const trajsde_graph* g,
         *k = extra.take<float>(R * 64), *v = extra.take<float>(R * 64), *o = extra.take<float>(R * 64), *x1 = extra.take<float>(R * 64),
         *xn2 = extra.take<float>(R * 64), *tout = extra.take<float>(int64_t(N) * 64);
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  if (int rc = run_aa_encoder(b, g, rot, blob, w, w.aa_out, st, num_heads)) return rc;
+  if (int rc = run_aa_encoder(b, g, rot, blob, w, w.aa_out, st, num_heads, drop_of(0))) return rc;
   TS_LAUNCH(k_tr_prep, cdiv(R * 64, 256), 256, 0, st, w.aa_out, b->padding_mask, blob + EncGridBlob::TOK, N, b->TT, xa);
   float* x = xa;
   float* nx = xb;
@@ -411,14 +423,14 @@ int trajsde_encoder_grid_forward(const trajsde_batch* b, const trajsde_graph* g,
     const float* lb = blob + EncGridBlob::layer(l);
     TS_LAUNCH(k_node_proj<3>, tile_grid(rtiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + TrLayerL::QKV, x, R, xn, q, k,
               v);
-    if (num_heads == 4) TS_LAUNCH(k_tr_attention<4>, cdiv(N, 4), 256, 0, st, q, k, v, N, o);
-    else TS_LAUNCH(k_tr_attention<8>, cdiv(N, 4), 256, 0, st, q, k, v, N, o);
-    TS_LAUNCH(k_tr_outproj, tile_grid(rtiles, 512, TrOutL::SIZE * 4), 512, TrOutL::SIZE * 4, st, lb + TrLayerL::OUT, o, x, R, x1, xn2);
-    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, x1, xn2, R, nx, no_drop(), 0);
+    const DropArg dl = drop_of(DROP_TEMPORAL_BLOCK0 + l);
+    if (int rc = launch_tr_attention(num_heads, q, k, v, N, o, dl, st)) return rc;
+    TS_LAUNCH(k_tr_outproj, tile_grid(rtiles, 512, TrOutL::SIZE * 4), 512, TrOutL::SIZE * 4, st, lb + TrLayerL::OUT, o, x, R, x1, xn2, dl);
+    TS_LAUNCH(k_ffn, tile_grid(rtiles, 512, FfnL::SIZE * 4), 512, FfnL::SIZE * 4, st, lb + TrLayerL::FFN, x1, xn2, R, nx, dl, 0);
     float* t = x; x = nx; nx = t;
   }
   TS_LAUNCH(k_tr_final, tile_grid((int64_t(N) + 15) / 16, 256, 0), 256, 0, st, blob + EncGridBlob::norm(num_temporal_layers), x, N, tout);
-  return run_al_encoder(b, g, blob, w, tout, local_embed, st, num_heads);
+  return run_al_encoder(b, g, blob, w, tout, local_embed, st, num_heads, drop_of(1));
 }
 
 int64_t trajsde_aggregator_ws_bytes(const trajsde_batch* b, const trajsde_graph* g, int num_modes) {

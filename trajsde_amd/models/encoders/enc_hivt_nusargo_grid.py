@@ -52,5 +52,6 @@ class LocalEncoder(ParamTree):
         self.set_init_seed(None)
         self._rt = runtime.StageRuntime(self, "encoder_grid")
 
-    def forward(self, data):
-        return self._rt.encoder_grid_forward(data)
+    def forward(self, data, noise=None):
+        """`noise` (ours): the NoiseSpec whose key the train-mode dropout masks are cut from (csrc/dropout.hpp); eval mode needs none"""
+        return self._rt.encoder_grid_forward(data, noise)

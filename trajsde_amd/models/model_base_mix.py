@@ -22,13 +22,13 @@ class _GridPathLoss(torch.autograd.Function):
     """w * L2 as one autograd node over the parameters (see model_base_mix_sde._PathLoss)"""
 
     @staticmethod
-    def forward(ctx, model, data, w_l2, *params):
+    def forward(ctx, model, data, noise, w_l2, *params):
         with torch.no_grad():
-            out = model(data)
+            out = model(data, noise=noise)
             local, glob = out["local_embed"], out["global_embed"]
             dec = model.decoder._rt.mlp_decoder_l2_backward(data, local, glob, out)
-            agg = model.aggregator._rt.aggregator_backward(data, local, dec["d_global_embed"])
-            enc = model.encoder._rt.encoder_grid_backward(data, dec["d_local_embed"] + agg["d_local_embed"])
+            agg = model.aggregator._rt.aggregator_backward(data, local, dec["d_global_embed"], noise)
+            enc = model.encoder._rt.encoder_grid_backward(data, dec["d_local_embed"] + agg["d_local_embed"], noise)
             by_name = {"decoder." + n: g for n, g in dec["grads"].items()}
             by_name.update({"aggregator." + n: g for n, g in agg["grads"].items()})
             by_name.update({"encoder." + n: g for n, g in enc["grads"].items()})
@@ -42,7 +42,7 @@ class _GridPathLoss(torch.autograd.Function):
     def backward(ctx, g):
         have = [x for x in ctx.grads if x is not None]
         scaled = iter(torch._foreach_mul(have, g * ctx.w))
-        return (None, None, None) + tuple(None if x is None else next(scaled) for x in ctx.grads)
+        return (None, None, None, None) + tuple(None if x is None else next(scaled) for x in ctx.grads)
 
 
 class PredictionModel(LightningHooks):
@@ -86,16 +86,19 @@ class PredictionModel(LightningHooks):
     def device(self) -> torch.device:
         return next(self.parameters()).device
 
-    def forward(self, data):
-        """models/model_base_mix.py:74-92"""
+    def forward(self, data, noise: Optional["runtime.NoiseSpec"] = None):
+        """models/model_base_mix.py:74-92.  `noise` (optional, ours): the key of the train-mode dropout masks; the default draws a fresh
+        one from torch's global generator, like the reference's dropout draws fresh masks.  Eval mode uses no randomness."""
+        if self.training:
+            noise = runtime.NoiseSpec.resolve(noise)
         if not self.rotate:
             raise NotImplementedError("rotate=False is not built (shipped config: rotate: true)")
         rotate_mat, y_rot = runtime.rotate_inputs(data)
         if y_rot is not None:
             data.y = y_rot
         data["rotate_mat"] = rotate_mat
-        local_embed = self.encoder(data=data)
-        global_embed = self.aggregator(data=data, local_embed=local_embed)
+        local_embed = self.encoder(data=data, noise=noise)
+        global_embed = self.aggregator(data=data, local_embed=local_embed, noise=noise)
         return self.decoder(data=data, local_embed=local_embed, global_embed=global_embed)
 
     def params_with_gradient(self):
@@ -119,23 +122,20 @@ class PredictionModel(LightningHooks):
         data.padding_mask[:, :h] = data.padding_mask[:, :h] | mask
 
     def training_step(self, data, batch_idx, noise=None):
-        """models/model_base_mix.py:94-114 for the shipped loss (L2)"""
+        """models/model_base_mix.py:94-114 for the shipped loss (L2).  In train mode the stages' `dropout` (0.1 in the reference's YAML) is
+        applied at the reference's 36 sites -- the four of every attention block and of every TemporalEncoder layer -- with masks cut
+        from the Philox stream of `noise` (csrc/dropout.hpp); `model.eval()` switches it off."""
         if getattr(self, "ts_drop", False):
             self.apply_ts_drop(data)
         if self.loss_names != ["L2"]:
             raise NotImplementedError(f"training_step differentiates L2 through the HIP kernels; configured: {self.loss_names}")
         if data.y is None:
             raise ValueError("training_step needs targets (data.y)")
-        p_drop = max(float(getattr(m, "dropout", 0.0) or 0.0) for m in (self.encoder, self.aggregator))
-        if self.training and p_drop > 0:
-            raise NotImplementedError(
-                f"dropout={p_drop}: the vanilla variant's TemporalEncoder has dropout sites (attention weights, dropout1/2, the FFN) "
-                "whose HIP training kernels are not built; train this variant with `dropout: 0.0` (the shipped "
-                "trajsde_amd/configs/mi355x_trmenc_mlpdec.yml does) -- the SDE model applies its dropout (csrc/dropout.hpp)")
+        noise = runtime.NoiseSpec.resolve(noise)
         if not hasattr(self, "_param_names"):
             self._param_names = [n for n, _ in self.named_parameters()]
         params = [p for _, p in self.named_parameters()]
-        loss = _GridPathLoss.apply(self, data, float(self.loss_weights[0]), *params)
+        loss = _GridPathLoss.apply(self, data, noise, float(self.loss_weights[0]), *params)
         self.log_value("train/L2", self.last_losses["L2"], prog_bar=True, on_step=True, on_epoch=True,
                        batch_size=int(self.last_output["loc"].size(1)))          # models/model_base_mix.py:112
         lr = self.current_lr()

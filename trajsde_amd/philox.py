@@ -124,6 +124,21 @@ def dropout_attn_mask(seed: int, block: int, dst, rank, heads: int, p: float) ->
     return np.where(keep, dropout_scale(p), np.float32(0.0)).astype(np.float32)
 
 
+TEMPORAL_BLOCK0 = 16         # dropout block ids of the vanilla variant's TemporalEncoder layers: 16 + layer (csrc/dropout.hpp)
+
+
+def dropout_temporal_attn_mask(seed: int, block: int, n_actors: int, heads: int, p: float, tokens: int = 22) -> np.ndarray:
+    """[n_actors, heads, tokens, tokens] float32 of {0, 1/(1-p)}: the factor of attention weight (query i, key j) of head h of actor n in
+    a TemporalEncoder layer (nn.MultiheadAttention's dropout on the softmax output, GENC:262) comes from the block of counter
+    (n, (i * heads + h) * 3 + (j >> 3), stream, 0), field j & 7 -- csrc/dropout.hpp drop_tr_attn"""
+    n, h, i, j = np.meshgrid(np.arange(n_actors, dtype=np.uint32), np.arange(heads, dtype=np.uint32), np.arange(tokens, dtype=np.uint32),
+                             np.arange(tokens, dtype=np.uint32), indexing="ij")
+    call = (i * np.uint32(heads) + h) * np.uint32(3) + (j >> np.uint32(3))
+    w = words(seed, STREAM_DROPOUT + 4 * block + DK_ATTN, call.reshape(-1), n.reshape(-1))
+    keep = _fields(w, (j & np.uint32(7)).reshape(-1)) >= np.uint32(dropout_threshold(p))
+    return np.where(keep, dropout_scale(p), np.float32(0.0)).astype(np.float32).reshape(n_actors, heads, tokens, tokens)
+
+
 def segment_ranks(src, dst) -> np.ndarray:
     """rank of every edge inside its target's segment when segments are ordered by ascending sender (ties: input order) --
     the order of the compacted lists of csrc/prep.hip"""

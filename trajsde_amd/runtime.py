@@ -654,11 +654,14 @@ class StageRuntime:
         return RelPrefetch(gc, ws, ws_bytes, done, dev)
 
     # ---------------------------------------------------------------- vanilla HiVT variant
-    def encoder_grid_forward(self, data) -> torch.Tensor:
-        """LocalEncoder.forward (enc_hivt_nusargo_grid.py:52-93) -> local_embed [N,64]"""
+    def encoder_grid_forward(self, data, noise: Optional[NoiseSpec] = None) -> torch.Tensor:
+        """LocalEncoder.forward (enc_hivt_nusargo_grid.py:52-93) -> local_embed [N,64].  In train mode the module's `dropout` is
+        applied at the reference's sites with masks keyed by `noise` (csrc/dropout.hpp); the variant draws no other noise."""
         m = self.module
-        noise = NoiseSpec(seed=0)                                      # no fake agents, no noise: the graph only
-        gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), noise, fake_agents=False)
+        dr = noise.c_dropout(m) if noise is not None else None
+        if dr is None and m.training and float(getattr(m, "dropout", 0.0) or 0.0) > 0:
+            raise _lib.TrajsdeError("encoder_grid_forward in train mode needs a NoiseSpec (dropout key)")
+        gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), NoiseSpec(seed=0), fake_agents=False)   # no fake agents: the graph only
         dev = gc.device
         L = _lib.lib()
         blob = self.blob()
@@ -667,14 +670,19 @@ class StageRuntime:
         ws_bytes = L.trajsde_encoder_grid_ws_bytes(C.byref(gc.batch), C.byref(gc.graph))
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         with torch.cuda.device(dev):
-            _lib.check(L.trajsde_encoder_grid_forward(C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), blob.data_ptr(),
-                                                      int(m.num_heads), int(m.num_temporal_layers), ws.data_ptr(), ws_bytes,
-                                                      local.data_ptr(), _stream()), "trajsde_encoder_grid_forward")
+            _lib.check(L.trajsde_encoder_grid_forward_train(C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), blob.data_ptr(),
+                                                            int(m.num_heads), int(m.num_temporal_layers), ws.data_ptr(), ws_bytes,
+                                                            local.data_ptr(), C.byref(dr) if dr is not None else None, _stream()),
+                       "trajsde_encoder_grid_forward_train")
         return local
 
-    def encoder_grid_backward(self, data, d_local: torch.Tensor) -> Dict[str, object]:
-        """backward of the vanilla LocalEncoder: dL/d local_embed [N,64] -> {"grads": {param name: tensor}}"""
+    def encoder_grid_backward(self, data, d_local: torch.Tensor, noise: Optional[NoiseSpec] = None) -> Dict[str, object]:
+        """backward of the vanilla LocalEncoder: dL/d local_embed [N,64] -> {"grads": {param name: tensor}}; `noise`: the forward's
+        (train mode: its dropout key -- the masks are regenerated)"""
         m = self.module
+        dr = noise.c_dropout(m) if noise is not None else None
+        if dr is None and m.training and float(getattr(m, "dropout", 0.0) or 0.0) > 0:
+            raise _lib.TrajsdeError("encoder_grid_backward in train mode needs the NoiseSpec of the forward pass (dropout key)")
         gc = GraphContext.get(data, float(m.local_radius), int(m.historical_steps), NoiseSpec(seed=0), fake_agents=False)
         dev = gc.device
         L = _lib.lib()
@@ -687,11 +695,11 @@ class StageRuntime:
         ws_bytes = L.trajsde_encoder_grid_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), nl)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         with torch.cuda.device(dev):
-            _lib.check(L.trajsde_encoder_grid_backward(
+            _lib.check(L.trajsde_encoder_grid_backward_train(
                 C.byref(gc.batch), C.byref(gc.graph), gc.rot.data_ptr(), self.blob().data_ptr(),
                 self.blob(_lib.STAGE_ENCODER_GRID_BWD).data_ptr(), int(m.num_heads), nl,
-                d_local.to(torch.float32).contiguous().data_ptr(), ws.data_ptr(), ws_bytes, arr, len(names), _stream()),
-                "trajsde_encoder_grid_backward")
+                d_local.to(torch.float32).contiguous().data_ptr(), ws.data_ptr(), ws_bytes, arr, len(names),
+                C.byref(dr) if dr is not None else None, _stream()), "trajsde_encoder_grid_backward_train")
         return {"grads": grads}
 
     def mlp_decoder_forward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor) -> Dict[str, torch.Tensor]:
