@@ -139,9 +139,46 @@ def make(name):
 
 
 GRID_CASES = {
-    # name: (synth kwargs, num_modes, future_steps, num_heads, temporal layers, init_seed)
+    # name: (synth kwargs, num_modes, future_steps, num_heads, temporal layers, init_seed[, dropout key])
     "train_grid_k3_t12_h4": (dict(S=3, n=9, L=6, F=12, box=70.0, seed=23, mixed_source=True, history_dropout=0.3), 3, 12, 4, 2, 7),
+    # model.train() with the YAML's dropout 0.1: the reference's 36 dropout calls served from the Philox host twin's masks
+    "train_grid_drop_k3_t12_h4": (dict(S=3, n=9, L=6, F=12, box=70.0, seed=26, mixed_source=True, history_dropout=0.3), 3, 12, 4, 2, 11, 7311),
 }
+
+
+def torch1_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, **_):
+    """what nn.MultiheadAttention computed under the reference's pinned torch 1.x (env.yml) for need_weights=False too: softmax of the
+    masked scaled scores, F.dropout on the WEIGHTS, weights @ v.  torch 2.x routes this call to a fused kernel whose dropout does not
+    pass through F.dropout; the generator puts the explicit form back so that the injected masks reach it."""
+    import math
+    import torch.nn.functional as F
+    w = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(q.size(-1)) if scale is None else scale)
+    if attn_mask is not None:
+        w = w.masked_fill(~attn_mask, float("-inf")) if attn_mask.dtype == torch.bool else w + attn_mask
+    w = torch.softmax(w, dim=-1)
+    if dropout_p > 0.0:
+        w = F.dropout(w, p=dropout_p)
+    return w @ v
+
+
+def grid_dropout_masks(orc, drop, N, heads, layers, global_layers):
+    """the masks of the vanilla reference forward in its call order and element order: AAEncoder (4), every TemporalEncoder layer
+    (attention weights [N, heads, 22, 22], dropout1 / FFN / dropout2 on [22, N, .]), ALEncoder (4), the global layers (4 each)"""
+    import restate_grid
+    from trajsde_amd import philox
+    masks = []
+
+    def block(b, edges, rows):
+        like = torch.empty(rows, 64)
+        return [drop.attn(b, edges[0], edges[1], heads, like), drop.feat(b, philox.DK_PROJ, like),
+                drop.feat(b, philox.DK_HIDDEN, torch.empty(rows, 256)), drop.feat(b, philox.DK_OUT, like)]
+    masks += block(0, orc["aa_edge_list"], 21 * N)
+    for l in range(layers):
+        masks += list(restate_grid.temporal_masks(drop, l, N, heads, torch.empty(1)))
+    masks += block(1, orc["al_edge_list"], N)
+    for i in range(global_layers):
+        masks += block(2 + i, orc["g_edge_list"], N)
+    return masks
 
 
 def make_grid(name):
@@ -150,7 +187,8 @@ def make_grid(name):
     import yaml
     import make_golden_grid as G
     from trajsde_amd.models.model_base_mix import PredictionModel
-    skw, K, T, heads, layers, init_seed = GRID_CASES[name]
+    skw, K, T, heads, layers, init_seed = GRID_CASES[name][:6]
+    dropout_seed = GRID_CASES[name][6] if len(GRID_CASES[name]) > 6 else None
     batch = synth(**skw)
     with open(os.path.join(ROOT, "trajsde_amd/configs/mi355x_trmenc_mlpdec.yml")) as f:
         ours_cfg = G.edit(yaml.safe_load(f), K, T, heads, layers)
@@ -165,21 +203,43 @@ def make_grid(name):
         ref_cfg = G.edit(yaml.safe_load(f), K, T, heads, layers)
     ref = R.build_reference_model(ref_cfg)
     ref.load_state_dict(sd)
-    ref.eval()                                                # dropout off
     data = R.to_reference_data(batch)
     stock = torch.nn.TransformerEncoder.forward
     torch.nn.TransformerEncoder.forward = G.torch1_transformer_encoder_forward
+    import contextlib
+    import torch.nn.functional as F
+    stock_sdpa = F.scaled_dot_product_attention
+    inject = contextlib.nullcontext([])
+    p_drop = 0.0
+    if dropout_seed is None:
+        ref.eval()                                            # dropout off
+    else:
+        import restate
+        import restate_grid
+        ref.train()                                           # dropout on, served from injected masks
+        p_drop = float(ref_cfg["encoder"]["kwargs"]["dropout"])
+        assert p_drop == float(ref_cfg["aggregator"]["kwargs"]["dropout"]) > 0
+        orc = restate_grid.forward({k: v.clone() for k, v in sd.items()}, ours_cfg, batch, want_intermediates=True)
+        masks = grid_dropout_masks(orc, restate.PhiloxDropout(dropout_seed, p_drop), batch.num_nodes, heads, layers,
+                                   int(ref_cfg["aggregator"]["kwargs"]["num_layers"]))
+        inject = R.injected_dropout(masks)
+        F.scaled_dot_product_attention = torch1_attention
     try:
-        with R.reference_cwd(), torch.enable_grad():
+        with R.reference_cwd(), inject as served, torch.enable_grad():
             out = ref(data)
             parts = [fn(data, out) for fn in ref.losses]
             loss = sum(w * l for w, l in zip(ref.loss_weights, parts))
             loss.backward()
     finally:
         torch.nn.TransformerEncoder.forward = stock
+        F.scaled_dot_product_attention = stock_sdpa
+    if dropout_seed is not None:
+        assert len(served) == 8 + 4 * layers + 4 * int(ref_cfg["aggregator"]["kwargs"]["num_layers"]), served
     fx = {f"in.{k}": v.numpy() for k, v in batch.as_dict().items() if torch.is_tensor(v)}
     fx.update({"meta.num_modes": K, "meta.future_steps": T, "meta.num_heads": heads, "meta.num_temporal_layers": layers,
                "meta.init_seed": init_seed, "meta.perturb_seed": 1000 + init_seed, "meta.state_checksum": G.state_checksum(sd)})
+    if dropout_seed is not None:
+        fx.update({"meta.dropout_p": p_drop, "meta.dropout_seed": dropout_seed})
     for nm, w, l in zip(ref.loss_names, ref.loss_weights, parts):
         fx[f"loss.{nm}"] = np.float64(float(l))
         fx[f"weight.{nm}"] = np.float64(float(w))

@@ -217,9 +217,11 @@ def check_grads_against_train_fixture(got, grads, digests, rel):
     return bad
 
 
-def grid_cfg(K, T, heads, layers):
+def grid_cfg(K, T, heads, layers, dropout=0.0):
     with open(os.path.join(ROOT, "trajsde_amd/configs/mi355x_trmenc_mlpdec.yml")) as f:
         cfg = yaml.safe_load(f)
+    cfg["encoder"]["kwargs"]["dropout"] = dropout
+    cfg["aggregator"]["kwargs"]["dropout"] = dropout
     cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)
     cfg["encoder"]["kwargs"].update(num_heads=heads, num_temporal_layers=layers)
     cfg["aggregator"]["kwargs"].update(num_modes=K, num_heads=heads)

@@ -25,9 +25,12 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _cfg(K, T, heads, layers):
+def _cfg(K, T, heads, layers, dropout=0.0):
+    """the shipped YAML (dropout 0.1 as the reference's) with the sizes of a test; `dropout` 0 unless a test is about it"""
     with open(os.path.join(H.ROOT, "trajsde_amd/configs/mi355x_trmenc_mlpdec.yml")) as f:
         cfg = yaml.safe_load(f)
+    cfg["encoder"]["kwargs"]["dropout"] = dropout
+    cfg["aggregator"]["kwargs"]["dropout"] = dropout
     cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)
     cfg["encoder"]["kwargs"].update(num_heads=heads, num_temporal_layers=layers)
     cfg["aggregator"]["kwargs"].update(num_modes=K, num_heads=heads)
@@ -206,10 +209,7 @@ def test_vanilla_encoder_backward_matches_autograd(S, n, heads, layers, kw, dev)
 
 
 def _cfg_drop(K, T, heads, layers, p=0.1):
-    cfg = _cfg(K, T, heads, layers)
-    cfg["encoder"]["kwargs"]["dropout"] = p                       # the reference's YAML value (hivt_nuSArgo_trmenc_mlpdec.yml:33)
-    cfg["aggregator"]["kwargs"]["dropout"] = p
-    return cfg
+    return _cfg(K, T, heads, layers, dropout=p)                   # the reference's YAML value (hivt_nuSArgo_trmenc_mlpdec.yml:33)
 
 
 @pytest.mark.parametrize("S,n,heads,layers,kw", [
@@ -311,16 +311,22 @@ def test_vanilla_training_step_matches_end_to_end_autograd_and_trains(dev):
     assert len(hist) == 12 and sum(hist[-3:]) < sum(hist[:3]), hist
 
 
-def test_vanilla_training_step_matches_the_reference_training_step(dev):
+@pytest.mark.parametrize("name", ["train_grid_k3_t12_h4", "train_grid_drop_k3_t12_h4"])
+def test_vanilla_training_step_matches_the_reference_training_step(name, dev):
     """loss and parameter-gradient digests of the HIP training step of the vanilla variant against the REFERENCE's own model
-    (models/model_base_mix.py), L2 module and torch.autograd (tests/golden_train/train_grid_*.npz, dropout off)"""
+    (models/model_base_mix.py), L2 module and torch.autograd (tests/golden_train/train_grid_*.npz): one fixture with dropout off,
+    one made under model.train() with the YAML's dropout 0.1 and the reference's 28 dropout calls (2 temporal layers) served from the
+    masks of the Philox host twin (oracle/make_golden_train.py make_grid)"""
+    from trajsde_amd import runtime
     from trajsde_amd.models.model_base_mix import PredictionModel
-    batch, meta, losses, weights, grads, digests = H.load_train_fixture("train_grid_k3_t12_h4")
-    cfg = _cfg(int(meta["num_modes"]), int(meta["future_steps"]), int(meta["num_heads"]), int(meta["num_temporal_layers"]))
+    batch, meta, losses, weights, grads, digests = H.load_train_fixture(name)
+    p = float(meta.get("dropout_p", 0.0))
+    cfg = _cfg(int(meta["num_modes"]), int(meta["future_steps"]), int(meta["num_heads"]), int(meta["num_temporal_layers"]), dropout=p)
     model = PredictionModel(**cfg, init_seed=int(meta["init_seed"]))
     H.perturb_parameters(model, int(meta["perturb_seed"]))
     model = model.to(dev).train()
-    loss = model.training_step(batch.to(dev), 0)
+    noise = runtime.NoiseSpec(seed=0, dropout_seed=int(meta["dropout_seed"])) if p > 0 else None
+    loss = model.training_step(batch.to(dev), 0, noise=noise)
     loss.backward()
     torch.cuda.synchronize()
     assert abs(float(loss.detach()) - losses["total"]) <= 1e-5 * max(1.0, abs(losses["total"]))
