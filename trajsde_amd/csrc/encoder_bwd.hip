@@ -817,10 +817,35 @@ static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const fl
       const float* e = step_tab + 8 * idx;
       tab.v[idx][0] = e[1]; tab.v[idx][1] = e[2]; tab.v[idx][2] = e[3]; tab.v[idx][3] = e[4];
     }
-    const RecurSaveArgs ra{blob_fwd + FB::SDE, blob_fwd + FB::GRU, blob_fwd + FB::HIDDEN, w.aa_out, Nt, H, b->TT, na, g->nus_mask, b->padding_mask,
-                           g->orig, w.HIN, w.H1, w.H2, w.G1, w.G2, w.GS, w.HODE, w.XS, w.U1, w.R1, w.UU, w.RR, w.RH, w.N1, w.NW, w.hcur};
-    const int lds_r = (EncSdeL::SIZE > EncGruL::SIZE ? EncSdeL::SIZE : EncGruL::SIZE) * 4;
-    TS_LAUNCH(k_enc_recur_save, tile_grid(rtiles, 256, lds_r), 256, lds_r, st, ra, tab);
+    // The inference kernel (recur.hip k_enc_recur_coop: a tile's products split over four waves, weights in registers) with tape
+    // stores beside it: 0.71 -> ~0.25 ms at 64 x 128 agents against the one-tile-per-wave form below, which stays for shapes the
+    // cooperative kernel does not take (more than COOP_TMAX x 256 row tiles) and under TRAJSDE_RECUR_LEGACY=1.
+    static const bool legacy = []() { const char* e = getenv("TRAJSDE_RECUR_LEGACY"); return e && atoi(e) != 0; }();
+    const int tiles_per_wg = int((rtiles + 255) / 256);
+    if (TSDE_SPLIT_H3 && !legacy && tiles_per_wg <= COOP_TMAX && H <= 32) {
+      StepTab stab;
+      for (int i = 0; i < H; ++i) {
+        stab.dt[i] = step_tab[8 * i + 1]; stab.sq[i] = step_tab[8 * i + 2]; stab.sn[i] = step_tab[8 * i + 3]; stab.cs[i] = step_tab[8 * i + 4];
+      }
+      const RecurTape tp{w.HIN, w.H1, w.H2, w.G1, w.G2, w.GS, w.HODE, w.XS, w.U1, w.R1, w.UU, w.RR, w.RH, w.N1, w.NW};
+      const int grid = int((rtiles + tiles_per_wg - 1) / tiles_per_wg);
+      const int lds = coop_lds_floats(tiles_per_wg) * 4;
+#define TS_COOP_SAVE(TW) TS_LAUNCH_TAG("k_enc_recur_coop<save>", false, (k_enc_recur_coop<TW, true>), grid, 256, lds, st, blob_fwd + FB::SDE, blob_fwd + FB::GRU, \
+              blob_fwd + FB::COOP6, blob_fwd + FB::HIDDEN, w.aa_out, Nt, N, H, b->TT, tiles_per_wg, stab, 0, na, g->nus_mask, b->padding_mask, g->orig, g->eos_idx,     \
+              g->pick_slot, w.lat, nullptr, nullptr, 0, tp)
+      switch (tiles_per_wg) {
+        case 1: TS_COOP_SAVE(1); break;
+        case 2: TS_COOP_SAVE(2); break;
+        case 3: TS_COOP_SAVE(3); break;
+        default: TS_COOP_SAVE(4); break;
+      }
+#undef TS_COOP_SAVE
+    } else {
+      const RecurSaveArgs ra{blob_fwd + FB::SDE, blob_fwd + FB::GRU, blob_fwd + FB::HIDDEN, w.aa_out, Nt, H, b->TT, na, g->nus_mask, b->padding_mask,
+                             g->orig, w.HIN, w.H1, w.H2, w.G1, w.G2, w.GS, w.HODE, w.XS, w.U1, w.R1, w.UU, w.RR, w.RH, w.N1, w.NW, w.hcur};
+      const int lds_r = (EncSdeL::SIZE > EncGruL::SIZE ? EncSdeL::SIZE : EncGruL::SIZE) * 4;
+      TS_LAUNCH(k_enc_recur_save, tile_grid(rtiles, 256, lds_r), 256, lds_r, st, ra, tab);
+    }
   }
   // the kept latent of actor r is the state after iteration eos[r] (ENC:187-188): rebuilt from the saved slabs
   k_gather_latent<<<cdiv(int64_t(N) * 64, 256), 256, 0, st>>>(w.HODE, w.UU, w.NW, g->eos_idx, b->padding_mask, g->orig, N, Nt, H, b->TT, w.lat);

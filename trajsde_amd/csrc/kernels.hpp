@@ -135,11 +135,15 @@ constexpr int coop_lds_floats(int tiles) { return tiles * (COOP_TILE + 5 * (TSDE
 struct StepTab {                                              // per-iteration (dt, sqrt_h, sin t0, cos t0), H <= 32
   float dt[32], sq[32], sn[32], cs[32];
 };
-template <int TW>
+// activation slabs [H][Nt][64] (GS: [H][Nt]) the training forward keeps for the recurrence backward (encoder_bwd.hip EncBwdWs)
+struct RecurTape {
+  float *HIN, *H1, *H2, *G1, *G2, *GS, *HODE, *XS, *U1, *R1, *UU, *RR, *RH, *N1, *NW;
+};
+template <int TW, bool SAVE>
 __global__ void k_enc_recur_coop(const float* sde_img, const float* gru_img, const float* coop6, const float* h0, const float* aa_out, int Nt, int N, int H,
                                  int TT, int tiles_per_wg, StepTab tab, int noise_step0, NoiseArg na, const uint8_t* nus, const uint8_t* pad,
                                  const int32_t* orig, const int32_t* eos, const int32_t* pick_slot, float* kept, float* diff_pick,
-                                 float* latent_ys, int aa_bf16);
+                                 float* latent_ys, int aa_bf16, RecurTape tp);
 // vanilla HiVT variant (grid.hip)
 __global__ void k_tr_prep(const float* aa_out, const uint8_t* pad, const float* tok, int N, int TT, float* X);
 template <int HEADS, bool DROP>

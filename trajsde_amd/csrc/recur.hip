@@ -224,7 +224,7 @@ __device__ __forceinline__ f4 vec_slice(const float* v, int w, int g) { return *
 __device__ __forceinline__ f4 tanh4(f4 a) { return f4{fast_tanh(a[0]), fast_tanh(a[1]), fast_tanh(a[2]), fast_tanh(a[3])}; }
 __device__ __forceinline__ f4 sigm4(f4 a) { return f4{fast_sigmoid(a[0]), fast_sigmoid(a[1]), fast_sigmoid(a[2]), fast_sigmoid(a[3])}; }
 
-template <int TW>
+template <int TW, bool SAVE>
 __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict__ sde_img, const float* __restrict__ gru_img,
                                                         const float* __restrict__ coop6, const float* __restrict__ h0, const float* __restrict__ aa_out,
                                                         int Nt, int N, int H, int TT, int tiles_per_wg, StepTab tab, int noise_step0,
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
                                                         const uint8_t* __restrict__ pad, const int32_t* __restrict__ orig,
                                                         const int32_t* __restrict__ eos, const int32_t* __restrict__ pick_slot,
                                                         float* __restrict__ kept, float* __restrict__ diff_pick,
-                                                        float* __restrict__ latent_ys, int aa_bf16) {
+                                                        float* __restrict__ latent_ys, int aa_bf16, RecurTape tp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const Lane L;
   const int w = threadIdx.x >> 6;
@@ -302,6 +302,11 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
   for (int idx = 0; idx < H; ++idx) {
     const int t = H - 1 - idx;
     const float dt = tab.dt[idx], sq = tab.sq[idx], sn = tab.sn[idx], cs = tab.cs[idx];
+    // SAVE (the training forward): this wave's 16 channels of every activation the backward reads go to the tape slabs
+    // [H][Nt][64] of csrc/encoder_bwd.hip (what k_enc_recur_save wrote one tile per wave) -- fire-and-forget stores
+    auto keep = [&](float* slab, int k, const f4& v) {
+      if (SAVE && inb[k]) *reinterpret_cast<f4*>(slab + (int64_t(idx) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g) = v;
+    };
     // first-layer biases with the (sin t, cos t) columns folded in
     const f4 bf0 = vec_slice(F + DriftL::B0, w, L.g) + vec_slice(F + DriftL::WS, w, L.g) * sn + vec_slice(F + DriftL::WC, w, L.g) * cs;
     const f4 bn0 = vec_slice(GN + DiffL::B0, w, L.g) + vec_slice(GN + DiffL::WS, w, L.g) * sn + vec_slice(GN + DiffL::WC, w, L.g) * cs;
@@ -317,9 +322,12 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
                           : *reinterpret_cast<const f4*>(aa_out + at);
         }
         const Opnd y = opnd_read(Ys(k), L);
+        if (SAVE) keep(tp.HIN, k, *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g));
         f4 a = bf0;
         slice_mma(a, wf0, y);
-        opnd_write(Ab(k), tanh4(a), w, L);
+        a = tanh4(a);
+        keep(tp.H1, k, a);
+        opnd_write(Ab(k), a, w, L);
         f4 gsel;
         if (nusmask[k] == ~0ull) { gsel = bn0; slice_mma(gsel, wn0, y); }
         else if (nusmask[k] == 0ull) { gsel = ba0; slice_mma(gsel, wa0, y); }
@@ -329,7 +337,9 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
           slice_mma(ga, wa0, y);
           gsel = is_nus[k] ? gn : ga;
         }
-        opnd_write(Bb(k), tanh4(gsel), w, L);
+        gsel = tanh4(gsel);
+        keep(tp.G1, k, gsel);
+        opnd_write(Bb(k), gsel, w, L);
       }
     __syncthreads();
     // ---- P2: second layers; partial dot of the diffusion head
@@ -339,22 +349,28 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
         const Opnd f1 = opnd_read(Ab(k), L), g1 = opnd_read(Bb(k), L);
         f4 a = vec_slice(F + DriftL::B2, w, L.g);
         slice_mma(a, wf2, f1);
-        opnd_write(Cb(k), tanh4(a), w, L);
+        a = tanh4(a);
+        keep(tp.H2, k, a);
+        opnd_write(Cb(k), a, w, L);
         f4 g2;
         float part;
         auto head = [&](const f4& h2, const float* img) {
           const f4 wv = vec_slice(img + DiffL::W4, w, L.g);
           return row_sum(h2[0] * wv[0] + h2[1] * wv[1] + h2[2] * wv[2] + h2[3] * wv[3]);
         };
-        if (nusmask[k] == ~0ull) { g2 = vec_slice(GN + DiffL::B2, w, L.g); slice_mma(g2, wn2, g1); part = head(tanh4(g2), GN); }
-        else if (nusmask[k] == 0ull) { g2 = vec_slice(GA + DiffL::B2, w, L.g); slice_mma(g2, wa2, g1); part = head(tanh4(g2), GA); }
+        if (nusmask[k] == ~0ull) { g2 = vec_slice(GN + DiffL::B2, w, L.g); slice_mma(g2, wn2, g1); g2 = tanh4(g2); part = head(g2, GN); }
+        else if (nusmask[k] == 0ull) { g2 = vec_slice(GA + DiffL::B2, w, L.g); slice_mma(g2, wa2, g1); g2 = tanh4(g2); part = head(g2, GA); }
         else {
           f4 gn = vec_slice(GN + DiffL::B2, w, L.g), ga = vec_slice(GA + DiffL::B2, w, L.g);
           slice_mma(gn, wn2, g1);
           slice_mma(ga, wa2, g1);
-          const float pn = head(tanh4(gn), GN), pa = head(tanh4(ga), GA);
+          gn = tanh4(gn);
+          ga = tanh4(ga);
+          const float pn = head(gn, GN), pa = head(ga, GA);
           part = is_nus[k] ? pn : pa;
+          g2 = is_nus[k] ? gn : ga;
         }
+        keep(tp.G2, k, g2);
         if (L.g == 0) GP[(k * 4 + w) * 16 + L.n] = part;
       }
     __syncthreads();
@@ -375,6 +391,9 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
         f4 y = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
 #pragma unroll
         for (int c = 0; c < 4; ++c) y[c] = (y[c] + f[c] * dt) + gs * (z[c] * sq);       // SDEINT:483
+        keep(tp.HODE, k, y);
+        keep(tp.XS, k, xq[k]);
+        if (SAVE && inb[k] && w == 0 && L.g == 0) tp.GS[int64_t(idx) * Nt + rowk[k]] = gs;
         range_note(absmax4(y), RS_ENC_STATE);                                             // operands of the GRU's split products
         range_note(absmax4(xq[k]), RS_ENC_INPUT);
         lds_write_slice(Yb(k), y, w, L);                                                  // Y now holds h' (all P1 reads are behind two barriers)
@@ -395,8 +414,12 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
         slice_mma(u1, wux, xin);
         slice_mma(r1, wrh, hp);
         slice_mma(r1, wrx, xin);
-        opnd_write(Ab(k), tanh4(u1), w, L);
-        opnd_write(Bb(k), tanh4(r1), w, L);
+        u1 = tanh4(u1);
+        r1 = tanh4(r1);
+        keep(tp.U1, k, u1);
+        keep(tp.R1, k, r1);
+        opnd_write(Ab(k), u1, w, L);
+        opnd_write(Bb(k), r1, w, L);
       }
     __syncthreads();
     // ---- P5: gates; reset * h'
@@ -410,7 +433,12 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
         slice_mma(r, wr2, r1);
         ug[k] = sigm4(u);
         const f4 hs = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
-        opnd_write(Cb(k), sigm4(r) * hs, w, L);
+        r = sigm4(r);
+        const f4 rhs = r * hs;
+        keep(tp.UU, k, ug[k]);
+        keep(tp.RR, k, r);
+        keep(tp.RH, k, rhs);
+        opnd_write(Cb(k), rhs, w, L);
       }
     __syncthreads();
     // ---- P6: candidate state, first layer (combined = [x, r*h'])
@@ -422,7 +450,9 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
         f4 n1 = vec_slice(gru_img + G::BN0, w, L.g);
         slice_mma(n1, wnx, xin);
         slice_mma(n1, wnh, rh);
-        opnd_write(Ab(k), tanh4(n1), w, L);
+        n1 = tanh4(n1);
+        keep(tp.N1, k, n1);
+        opnd_write(Ab(k), n1, w, L);
       }
     __syncthreads();
     // ---- P7: candidate state, second layer; gated blend; masked update; picks
@@ -432,6 +462,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
         const Opnd n1 = opnd_read(Ab(k), L);
         f4 nw = vec_slice(gru_img + G::BN2, w, L.g);
         slice_mma(nw, wn2g, n1);
+        keep(tp.NW, k, nw);
         f4 hs = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
         const bool valid = !pad[int64_t(origk[k]) * TT + t];
 #pragma unroll
@@ -451,11 +482,12 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
   }
 }
 
-#define TS_COOP_INST(TW)                                                                                                          \
-  template __global__ void k_enc_recur_coop<TW>(const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, \
-                                                StepTab, int, NoiseArg, const uint8_t*, const uint8_t*, const int32_t*, const int32_t*,      \
-                                                const int32_t*, float*, float*, float*, int);
-TS_COOP_INST(1) TS_COOP_INST(2) TS_COOP_INST(3) TS_COOP_INST(4)
+#define TS_COOP_INST(TW, SV)                                                                                                      \
+  template __global__ void k_enc_recur_coop<TW, SV>(const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, \
+                                                    StepTab, int, NoiseArg, const uint8_t*, const uint8_t*, const int32_t*, const int32_t*,  \
+                                                    const int32_t*, float*, float*, float*, int, RecurTape);
+TS_COOP_INST(1, false) TS_COOP_INST(2, false) TS_COOP_INST(3, false) TS_COOP_INST(4, false)
+TS_COOP_INST(1, true) TS_COOP_INST(2, true) TS_COOP_INST(3, true) TS_COOP_INST(4, true)
 #undef TS_COOP_INST
 
 // forward_ood (ENC:311-313): outs [S,N,64] -> mean over samples [N,64] and std(0).mean(-1) [N] (unbiased std)

@@ -259,8 +259,8 @@ static int run_recurrence(const trajsde_batch* b, const trajsde_graph* g, const 
     }
     const int grid = int((rtiles + tiles_per_wg - 1) / tiles_per_wg);
     const int lds = coop_lds_floats(tiles_per_wg) * 4;
-#define TS_COOP(TW) TS_LAUNCH_TAG("k_enc_recur_coop", false, k_enc_recur_coop<TW>, grid, 256, lds, st, blob + EncBlob::SDE, blob + EncBlob::GRU, blob + EncBlob::COOP6, h0, aa_out, Nt, N, H, b->TT, tiles_per_wg, tab, \
-              noise_step0, na, g->nus_mask, b->padding_mask, g->orig, g->eos_idx, g->pick_slot, kept, diff_pick, latent_ys, state_bf16() ? 1 : 0)
+#define TS_COOP(TW) TS_LAUNCH_TAG("k_enc_recur_coop", false, (k_enc_recur_coop<TW, false>), grid, 256, lds, st, blob + EncBlob::SDE, blob + EncBlob::GRU, blob + EncBlob::COOP6, h0, aa_out, Nt, N, H, b->TT, tiles_per_wg, tab, \
+              noise_step0, na, g->nus_mask, b->padding_mask, g->orig, g->eos_idx, g->pick_slot, kept, diff_pick, latent_ys, state_bf16() ? 1 : 0, RecurTape{})
     switch (tiles_per_wg) {
       case 1: TS_COOP(1); break;
       case 2: TS_COOP(2); break;
