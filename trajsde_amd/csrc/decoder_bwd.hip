@@ -630,6 +630,193 @@ __global__ __launch_bounds__(256, 3) void k_wgrad(WgradJobs jobs, int64_t R, int
   if (kg == 0) cs[int64_t(p) * 64 + 16 * ot + idx] = csum;
 }
 
+#if TSDE_SPLIT_H3
+// ---- the same partial sums on the 16-bit matrix cores (fp16x3: a_h b_h + a_h b_l + a_l b_h, tile.hpp), the default in this build.
+// The fp32 matrix instruction runs at 1/16 of the 16-bit rate: at 8 192 flops per row the exact kernel above is bound by it (0.85 ms
+// of matrix pipe for the 4.55 M edge rows of a 64 x 128 step, the same as streaming their 4.8 GB); three 16-bit products take a fifth of
+// that and leave the kernel to HBM.  Both operands of a block are scaled by a power of two taken from the block's largest magnitude (deltas
+// are tiny, fp16 has 5 exponent bits: the same reason tile.hpp linear_adj scales rows), split into hi / lo halves when the block is
+// staged, and the block's product is scaled back when it joins the fp32 accumulator.  The contraction runs over ROWS, which sit on the
+// lanes' row index in global memory order: the planes are staged row-major ([64 rows][64 halves], 8-byte chunks XOR-swizzled) and read
+// through ds_read_b64_tr_b16, which hands lane i of a 16-lane group column i of four rows -- an operand fragment, no transposing writes
+// (lane map checked on the hardware: tools/microbench/trread.hip).
+typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ int wg6_off(int r, int c) {      // byte offset of chunk c (4 halves) of row r: conflict-free for the stores and the transposed reads
+  return r * 128 + 8 * (c ^ ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 2));
+}
+__device__ __forceinline__ h8 wg6_frag(const char* plane, int off0, int off1) {
+  const s4v x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(plane + off0));
+  const s4v y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(plane + off1));
+  const uint2 a = __builtin_bit_cast(uint2, x), b = __builtin_bit_cast(uint2, y);
+  return __builtin_bit_cast(h8, u4{a.x, a.y, b.x, b.y});
+}
+// 2^(14 - floor(log2 m)) and its inverse for a block whose largest magnitude is m (0 / 0 for an all-zero or sub-2^-113 block)
+__device__ __forceinline__ void wg6_scale(float m, float& up, float& down) {
+  const unsigned e = __float_as_uint(m) & 0x7F800000u;
+  const bool ok = e >= (14u << 23);
+  up = ok ? __uint_as_float(0x86000000u - e) : 0.f;
+  down = ok ? __uint_as_float(e - (14u << 23)) : 0.f;
+}
+#ifndef TSDE_WG6_OCC
+#define TSDE_WG6_OCC 3
+#endif
+__global__ __launch_bounds__(256, TSDE_WG6_OCC) void k_wgrad6(WgradJobs jobs, int64_t R, int64_t rows_per_group, int chunk, int chunks_per_group, int P,
+                                                   float* __restrict__ part, float* __restrict__ cs) {
+  const WgradJob& job = jobs.j[blockIdx.y];
+  const float* __restrict__ delta = job.delta;
+  const float* __restrict__ a = job.a;
+  const int ldd = job.ldd, lda = job.lda;
+  part += int64_t(blockIdx.y) * P * 4096;
+  cs += int64_t(blockIdx.y) * P * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const dh = smem;                               // four [64 rows][64 halves] planes: delta hi / lo, a hi / lo
+  char* const dl = smem + 8192;
+  char* const ah = smem + 16384;
+  char* const al = smem + 24576;
+  float* const slots = reinterpret_cast<float*>(smem + 32768);      // [parity][wave][2]: the block maxima of the two operands
+  const int p = blockIdx.x;
+  const int group = p / chunks_per_group, sub = p - group * chunks_per_group;
+  const int64_t row0 = group * rows_per_group + int64_t(sub) * chunk;
+  int64_t row1 = row0 + chunk;
+  if (row1 > (group + 1) * rows_per_group) row1 = (group + 1) * rows_per_group;
+  if (row1 > R) row1 = R;
+  const int lane = threadIdx.x & 63, ot = threadIdx.x >> 6, idx = lane & 15, kg = lane >> 4;
+  f4 acc[4], csum4 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < 4; ++it) acc[it] = f4{0.f, 0.f, 0.f, 0.f};
+  f4 dreg[4], areg[4];
+  const bool computed = job.in2 != nullptr;
+  const int pair = job.pair;
+  const int c4w = threadIdx.x & 15, r0w = threadIdx.x >> 4;
+  auto fetch = [&](int64_t blk) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t row = blk + r0w + 16 * u;
+      f4 dv = f4{0.f, 0.f, 0.f, 0.f}, av = dv;
+      if (row < row1) {
+        dv = *reinterpret_cast<const f4*>(delta + row * ldd + 4 * c4w);
+        av = computed ? *reinterpret_cast<const f4*>(a + row * 4) : *reinterpret_cast<const f4*>(a + row * lda + 4 * c4w);
+      }
+      dreg[u] = dv;
+      areg[u] = av;
+    }
+  };
+  auto finish = [&](int64_t blk) {                      // the computed operand from the row's geometry (see k_wgrad)
+    const int f0 = 4 * c4w;
+    const f4 kw0 = *reinterpret_cast<const f4*>(job.in2 + f0), kw1 = *reinterpret_cast<const f4*>(job.in2 + 64 + f0);
+    const f4 kgb = *reinterpret_cast<const f4*>(job.in2 + 128 + f0), kbe = *reinterpret_cast<const f4*>(job.beta + f0);
+    const f4 kc0 = *reinterpret_cast<const f4*>(job.in2 + 192), kc1 = *reinterpret_cast<const f4*>(job.in2 + 196);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f4 ge = areg[u];
+      const float x0 = pair ? ge[2] : ge[0], x1 = pair ? ge[3] : ge[1];
+      const float ca = fmaf(kc0[0], x0, fmaf(kc0[1], x1, kc0[2])), cb = fmaf(kc0[3], x1, kc1[0]);
+      const float rstd = rsqrt_nr(fmaf(ca, ca, fmaf(cb, cb, kc1[1] * kc1[1])) + 1e-5f);
+      const float x0r = x0 * rstd, x1r = x1 * rstd;
+      f4 av;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) av[k] = fmaxf(fmaf(kw0[k], x0r, fmaf(kw1[k], x1r, fmaf(kgb[k], rstd, kbe[k]))), 0.f);
+      areg[u] = blk + r0w + 16 * u < row1 ? av : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // this lane's fragment addresses: rows 32 ks + 8 kg + 4 half + q, chunk 4 * (16-column block) + p   (q = idx >> 2, p = idx & 3)
+  const int fq = idx >> 2, fp = idx & 3;
+  if (row0 < row1) fetch(row0);
+  for (int64_t blk = row0; blk < row1; blk += 64) {
+    if (computed) finish(blk);
+    float md = 0.f, ma = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        md = fmaxf(md, fabsf(dreg[u][c]));
+        ma = fmaxf(ma, fabsf(areg[u][c]));
+      }
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      md = fmaxf(md, __shfl_xor(md, sft));
+      ma = fmaxf(ma, __shfl_xor(ma, sft));
+    }
+    float* const sl = slots + 8 * (int((blk - row0) >> 6) & 1);       // two sets by block parity: a set is rewritten two barriers after its last read
+    if (lane == 0) {
+      sl[2 * ot] = md;
+      sl[2 * ot + 1] = ma;
+    }
+    __syncthreads();                                    // every wave is done with the previous block's planes; the maxima are visible
+    md = fmaxf(fmaxf(sl[0], sl[2]), fmaxf(sl[4], sl[6]));
+    ma = fmaxf(fmaxf(sl[1], sl[3]), fmaxf(sl[5], sl[7]));
+    float up_d, down_d, up_a, down_a;
+    wg6_scale(md, up_d, down_d);
+    wg6_scale(ma, up_a, down_a);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int off = wg6_off(r0w + 16 * u, c4w);
+      const f4 dv = dreg[u] * up_d, av = areg[u] * up_a;
+      unsigned h0, l0, h1, l1;
+      split_pair(dv[0], dv[1], h0, l0);
+      split_pair(dv[2], dv[3], h1, l1);
+      *reinterpret_cast<uint2*>(dh + off) = uint2{h0, h1};
+      *reinterpret_cast<uint2*>(dl + off) = uint2{l0, l1};
+      split_pair(av[0], av[1], h0, l0);
+      split_pair(av[2], av[3], h1, l1);
+      *reinterpret_cast<uint2*>(ah + off) = uint2{h0, h1};
+      *reinterpret_cast<uint2*>(al + off) = uint2{l0, l1};
+      csum4 += dreg[u];
+    }
+    __syncthreads();
+    if (blk + 64 < row1) fetch(blk + 64);
+    f4 accb[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) accb[it] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int rA = 32 * ks + 8 * kg + fq;
+      const int oa0 = wg6_off(rA, 4 * ot + fp), oa1 = wg6_off(rA + 4, 4 * ot + fp);
+      const h8 Ah = wg6_frag(dh, oa0, oa1), Al = wg6_frag(dl, oa0, oa1);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int ob0 = wg6_off(rA, 4 * it + fp), ob1 = wg6_off(rA + 4, 4 * it + fp);
+        const h8 Bh = wg6_frag(ah, ob0, ob1), Bl = wg6_frag(al, ob0, ob1);
+        accb[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, accb[it], 0, 0, 0);
+        accb[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, accb[it], 0, 0, 0);
+        accb[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, accb[it], 0, 0, 0);
+      }
+    }
+    const float down = down_d * down_a;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[it][c] = fmaf(accb[it][c], down, acc[it][c]);
+  }
+  // D fragment: lane holds dW[16 ot + 4 kg + reg][16 it + idx]
+  float* out = part + int64_t(p) * 4096;
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) out[(16 * ot + 4 * kg + reg) * 64 + 16 * it + idx] = acc[it][reg];
+  // column sums of delta (exact fp32, from the rows as they were fetched): this thread's four features over its rows -> the block's
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    csum4[c] += __shfl_xor(csum4[c], 16);
+    csum4[c] += __shfl_xor(csum4[c], 32);
+  }
+  __syncthreads();
+  f4* red = reinterpret_cast<f4*>(smem);
+  if (lane < 16) red[ot * 16 + lane] = csum4;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const f4 t = (red[threadIdx.x] + red[16 + threadIdx.x]) + (red[32 + threadIdx.x] + red[48 + threadIdx.x]);
+    *reinterpret_cast<f4*>(cs + int64_t(p) * 64 + 4 * threadIdx.x) = t;
+  }
+}
+static bool wgrad_f32() {          // TRAJSDE_WGRAD_F32=1: the exact fp32 kernel (A/B runs)
+  static const bool v = []() { const char* e = getenv("TRAJSDE_WGRAD_F32"); return e && atoi(e) != 0; }();
+  return v;
+}
+#else
+static bool wgrad_f32() { return true; }
+#endif
+
 // W[o*ldw + col0 + i] = sum_p part[p][o][i];  bias[o] = sum_p cs[p][o];  with time_cols the (sin t, cos t) input
 // columns 64 / 65 of the 66-wide first SDE layer: W[o*ldw + 64] = sum_p sin(t_group(p)) cs[p][o], likewise cos.
 // A workgroup owns 32 outputs; its 8 thread groups each sum every 8th partial, then combine in a fixed order.
@@ -909,6 +1096,23 @@ int WgradBatch::add_in2(const float* delta, int ldd, const float* geom, int pair
   return TRAJSDE_OK;
 }
 
+#if TSDE_SPLIT_H3 && defined(TSDE_WG6_OCC)
+#define TSDE_WG6_OCC_HOST TSDE_WG6_OCC
+#else
+#define TSDE_WG6_OCC_HOST 3
+#endif
+static int launch_wgrad(const char* tag, const WgradJobs& sub, int64_t R, int64_t rows_per_group, int chunk, int cpg, int P, float* part, float* cs,
+                        hipStream_t st) {
+#if TSDE_SPLIT_H3
+  if (!wgrad_f32()) {
+    TS_LAUNCH_TAG(tag, false, k_wgrad6, dim3(P, sub.n), 256, 32768 + 64, st, sub, R, rows_per_group, chunk, cpg, P, part, cs);
+    return TRAJSDE_OK;
+  }
+#endif
+  TS_LAUNCH_TAG(tag, false, k_wgrad, dim3(P, sub.n), 256, 2 * 4096 * 4, st, sub, R, rows_per_group, chunk, cpg, P, part, cs);
+  return TRAJSDE_OK;
+}
+
 int WgradBatch::flush() {
   if (jobs.n == 0) return TRAJSDE_OK;
   const int n = jobs.n;
@@ -927,7 +1131,7 @@ int WgradBatch::flush() {
   // One resident round of the chip: 3 workgroups of this kernel fit a CU (40 KB of LDS each), and a workgroup streams its
   // rows at the same rate however many it has, so 768 workgroups over the launch's problems leave no partial last round and
   // the fewest partials to reduce (3 problems: 1024 partials each 1.41 ms, 384 1.54 ms, 256 1.35 ms, 128 1.93 ms)
-  const int64_t one_round = (768 + n - 1) / n;
+  const int64_t one_round = ((wgrad_f32() ? 768 : 256 * TSDE_WG6_OCC_HOST) + n - 1) / n;
   const int64_t base_parts = parts_env > 0 ? parts_env : (one_round > 32 ? one_round : 32);
   const int64_t want_parts = groups > base_parts ? groups : base_parts;
   if ((rows_per_group + chunk - 1) / chunk * groups > want_parts) {
@@ -950,13 +1154,12 @@ int WgradBatch::flush() {
       int rc = TRAJSDE_OK;
       const int64_t base = rq->take(int64_t(sub.n) * P, &rc);
       if (rc) return rc;
-      TS_LAUNCH_TAG(tag, false, k_wgrad, dim3(P, sub.n), 256, 2 * 4096 * 4, c.st, sub, R, rows_per_group, int(chunk), cpg, P, c.part + base * 4096,
-                    c.cs + base * 64);
+      if (int rc2 = launch_wgrad(tag, sub, R, rows_per_group, int(chunk), cpg, P, c.part + base * 4096, c.cs + base * 64, c.st)) return rc2;
       for (int i = 0; i < sub.n; ++i)
         rq->jobs.push_back(ReduceJob{sub.j[i].W, sub.j[i].bias, base + int64_t(i) * P, P, cpg, sub.j[i].ldw, sub.j[i].col0, sub.j[i].time_cols});
       continue;
     }
-    TS_LAUNCH_TAG(tag, false, k_wgrad, dim3(P, sub.n), 256, 2 * 4096 * 4, c.st, sub, R, rows_per_group, int(chunk), cpg, P, c.part, c.cs);
+    if (int rc2 = launch_wgrad(tag, sub, R, rows_per_group, int(chunk), cpg, P, c.part, c.cs, c.st)) return rc2;
     TS_LAUNCH(k_reduce_partials, dim3(cdiv(4096 + 64, 32), sub.n), 256, 0, c.st, sub, c.part, c.cs, P, cpg, c.step_tab);
   }
   return TRAJSDE_OK;

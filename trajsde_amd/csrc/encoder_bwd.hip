@@ -976,7 +976,8 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
                           w.DNW, w.DN1P, w.DUP, w.DRP, w.DU1, w.DR1, w.DHO, w.DAA, w.DF, w.DH2, w.DH1, w.DG2N, w.DG1N, w.DG2A, w.DG1A,
                           w.DGPN, w.DGPA, w.dhA};
     const int lds_r = (GruBwdL::SIZE > EncSdeBwdL::SIZE ? GruBwdL::SIZE : EncSdeBwdL::SIZE) * 4;
-    TS_LAUNCH(k_enc_recur_bwd, tile_grid(rtiles, 256, lds_r), 256, lds_r, st, rb, tab);
+    static const int bwd_threads = env_threads("TRAJSDE_RECUR_BWD_THREADS", 256);
+    TS_LAUNCH(k_enc_recur_bwd, tile_grid(rtiles, bwd_threads, lds_r), bwd_threads, lds_r, st, rb, tab);
     const float* dh = w.dhA;
     // iteration 0 started from the learned initial state, broadcast to every row (ENC:78)
     if (int rc = run_colsum(st, dh, Nt, 64, 64, G("hidden"))) return rc;
