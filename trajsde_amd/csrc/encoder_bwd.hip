@@ -821,7 +821,8 @@ static int encoder_tape(const trajsde_batch* b, const trajsde_graph* g, const fl
     // stores beside it: 0.71 -> ~0.25 ms at 64 x 128 agents against the one-tile-per-wave form below, which stays for shapes the
     // cooperative kernel does not take (more than COOP_TMAX x 256 row tiles) and under TRAJSDE_RECUR_LEGACY=1.
     static const bool legacy = []() { const char* e = getenv("TRAJSDE_RECUR_LEGACY"); return e && atoi(e) != 0; }();
-    const int tiles_per_wg = int((rtiles + 255) / 256);
+    static const int force_tw = []() { const char* e = getenv("TRAJSDE_RECUR_TW"); return e ? atoi(e) : 0; }();
+    const int tiles_per_wg = force_tw > 0 ? force_tw : int((rtiles + 255) / 256);
     if (TSDE_SPLIT_H3 && !legacy && tiles_per_wg <= COOP_TMAX && H <= 32) {
       StepTab stab;
       for (int i = 0; i < H; ++i) {
@@ -976,8 +977,37 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
                           w.DNW, w.DN1P, w.DUP, w.DRP, w.DU1, w.DR1, w.DHO, w.DAA, w.DF, w.DH2, w.DH1, w.DG2N, w.DG1N, w.DG2A, w.DG1A,
                           w.DGPN, w.DGPA, w.dhA};
     const int lds_r = (GruBwdL::SIZE > EncSdeBwdL::SIZE ? GruBwdL::SIZE : EncSdeBwdL::SIZE) * 4;
-    static const int bwd_threads = env_threads("TRAJSDE_RECUR_BWD_THREADS", 256);
-    TS_LAUNCH(k_enc_recur_bwd, tile_grid(rtiles, bwd_threads, lds_r), bwd_threads, lds_r, st, rb, tab);
+    // the cooperative form (recur.hip k_enc_recur_bwd_coop: the transposed matrices in registers, no staging) where it applies
+    static const bool legacy_bwd = []() { const char* e = getenv("TRAJSDE_RECUR_LEGACY"); return e && atoi(e) != 0; }();
+    // Row tiles per workgroup: unlike the forward kernel, whose three interleaved tiles hide each other's latencies, this one slows
+    // down more than in proportion (measured per pass over 256 workgroups at 21 iterations: 0.146 / 0.27 / 0.70 / 1.26 ms with 1 / 2 /
+    // 3 / 4 tiles: 404 / 508 registers, then 127 / 279 spilled, and a loop body that outgrows the instruction cache), so it runs one
+    // or two tiles and as many rounds of 256 workgroups as that takes -- 515 tiles: 3 rounds of one, 0.44 ms (legacy kernel 0.83)
+    static const int force_tw = []() { const char* e = getenv("TRAJSDE_RECUR_BWD_TW"); return e ? atoi(e) : 0; }();      // experiments
+    const int64_t rounds1 = (rtiles + 255) / 256, rounds2 = (rtiles + 511) / 512;
+    const int tiles_per_wg = force_tw > 0 ? force_tw : (rounds2 * 185 < rounds1 * 100 ? 2 : 1);
+    if (TSDE_SPLIT_H3 && !legacy_bwd && tiles_per_wg <= COOP_TMAX && H <= 32) {
+      RecurBwdCoopArgs ca{};
+      ca.gru_t = blob_bwd + BB::GRU; ca.sde_t = blob_bwd + BB::SDE;
+      ca.Nt = Nt; ca.N = N; ca.H = H; ca.TT = b->TT; ca.na = na;
+      ca.pad = b->padding_mask; ca.nus = g->nus_mask; ca.orig = g->orig; ca.eos = g->eos_idx;
+      ca.dlat = w.DLAT; ca.DLDG = w.DLDG;
+      ca.tp = RecurTape{w.HIN, w.H1, w.H2, w.G1, w.G2, w.GS, w.HODE, w.XS, w.U1, w.R1, w.UU, w.RR, w.RH, w.N1, w.NW};
+      ca.DNW = w.DNW; ca.DN1P = w.DN1P; ca.DUP = w.DUP; ca.DRP = w.DRP; ca.DU1 = w.DU1; ca.DR1 = w.DR1; ca.DAA = w.DAA;
+      ca.DF = w.DF; ca.DH2 = w.DH2; ca.DH1 = w.DH1; ca.DG2N = w.DG2N; ca.DG1N = w.DG1N; ca.DG2A = w.DG2A; ca.DG1A = w.DG1A;
+      ca.DGPN = w.DGPN; ca.DGPA = w.DGPA; ca.dh_out = w.dhA;
+      for (int i = 0; i < H; ++i) { ca.dt[i] = step_tab[8 * i + 1]; ca.sq[i] = step_tab[8 * i + 2]; }
+      const int grid = int((rtiles + tiles_per_wg - 1) / tiles_per_wg);
+      const int lds = coop_bwd_lds_floats(tiles_per_wg) * 4;
+      switch (tiles_per_wg) {
+        case 1: TS_LAUNCH(k_enc_recur_bwd_coop<1>, grid, 256, lds, st, ca); break;
+        case 2: TS_LAUNCH(k_enc_recur_bwd_coop<2>, grid, 256, lds, st, ca); break;
+        case 3: TS_LAUNCH(k_enc_recur_bwd_coop<3>, grid, 256, lds, st, ca); break;
+        default: TS_LAUNCH(k_enc_recur_bwd_coop<4>, grid, 256, lds, st, ca); break;
+      }
+    } else {
+      TS_LAUNCH(k_enc_recur_bwd, tile_grid(rtiles, 256, lds_r), 256, lds_r, st, rb, tab);
+    }
     const float* dh = w.dhA;
     // iteration 0 started from the learned initial state, broadcast to every row (ENC:78)
     if (int rc = run_colsum(st, dh, Nt, 64, 64, G("hidden"))) return rc;

@@ -144,6 +144,22 @@ __global__ void k_enc_recur_coop(const float* sde_img, const float* gru_img, con
                                  int TT, int tiles_per_wg, StepTab tab, int noise_step0, NoiseArg na, const uint8_t* nus, const uint8_t* pad,
                                  const int32_t* orig, const int32_t* eos, const int32_t* pick_slot, float* kept, float* diff_pick,
                                  float* latent_ys, int aa_bf16, RecurTape tp);
+// the recurrence backward in the cooperative form (recur.hip k_enc_recur_bwd_coop)
+struct RecurBwdCoopArgs {
+  const float *gru_t, *sde_t;          // GruBwdL / EncSdeBwdL images: every matrix transposed, split-precision fragments
+  int Nt, N, H, TT;
+  NoiseArg na;
+  const uint8_t *pad, *nus;
+  const int32_t *orig, *eos;
+  const float *dlat, *DLDG;
+  RecurTape tp;                        // the forward's activation slabs
+  float *DNW, *DN1P, *DUP, *DRP, *DU1, *DR1, *DAA, *DF, *DH2, *DH1, *DG2N, *DG1N, *DG2A, *DG1A, *DGPN, *DGPA, *dh_out;
+  float dt[32], sq[32];
+};
+constexpr int COOP_BWD_TILES = 6;                                 // operand tiles per row tile (+ 64 partial dots, 64 row magnitudes)
+constexpr int coop_bwd_lds_floats(int tiles) { return tiles * (COOP_BWD_TILES * (TSDE_SPLIT_H3 ? 1024 : COOP_TILE) + 128); }
+template <int TW>
+__global__ void k_enc_recur_bwd_coop(RecurBwdCoopArgs a);
 // vanilla HiVT variant (grid.hip)
 __global__ void k_tr_prep(const float* aa_out, const uint8_t* pad, const float* tok, int N, int TT, float* X);
 template <int HEADS, bool DROP>

@@ -490,6 +490,258 @@ TS_COOP_INST(1, false) TS_COOP_INST(2, false) TS_COOP_INST(3, false) TS_COOP_INS
 TS_COOP_INST(1, true) TS_COOP_INST(2, true) TS_COOP_INST(3, true) TS_COOP_INST(4, true)
 #undef TS_COOP_INST
 
+// ------------------------------------------------------------------------------------------------------------------
+// The recurrence BACKWARD in the same cooperative form (training; replaces encoder_bwd.hip k_enc_recur_bwd where it applies): the sixteen
+// TRANSPOSED matrices (GruBwdL / EncSdeBwdL images) live in the registers of the four waves, wave w produces channels [16w, 16w+16) of
+// every delta, the deltas that feed a product travel through fp32 LDS tiles, d h stays in registers from iteration to iteration.
+// The one-tile-per-wave kernel re-staged its two 128 KB images every half iteration on 129 workgroups (0.83 ms at 64 x 128 agents).
+// Deltas are tiny and fp16 has five exponent bits (why tile.hpp linear_adj scales the rows of every adjoint product).  Here a row is
+// normalised ONCE per iteration: everything the iteration computes for a row is linear in the gradient entering it (d h of the later
+// iteration, the kept-latent gradient, the DiffBCE gradient of the diffusion value), so the row's largest such magnitude fixes a power of
+// two that is applied at the top of the iteration and taken off again at every store and at the bottom; in between the deltas are O(1)
+// and travel as ordinary pre-split operand tiles (opnd_write / opnd_read) -- one exchange per phase, no per-product maxima.
+// Nine barriers per iteration:  G0 row magnitudes | G1 gate / candidate deltas | G2 new_state.2^T, update.2^T | G3 new_state.0^T |
+// G4 reset.2^T | G5 gate first layers^T -> d x_t, d h';  drift.4 input, diffusion dot | S2 drift.4^T, diffusion heads |
+// S3 drift.2^T, diffusion.2^T | (S4 first layers^T -> d h of the previous iteration: its readers are fenced by the next G0).
+__device__ __forceinline__ f4 zero_mma(const WSlice& w, const Opnd& x) {
+  f4 t = f4{0.f, 0.f, 0.f, 0.f};
+  slice_mma(t, w, x);
+  return t;
+}
+__device__ __forceinline__ f4 dtanh4(const f4& d, const f4& y) { return f4{d[0] * (1.f - y[0] * y[0]), d[1] * (1.f - y[1] * y[1]), d[2] * (1.f - y[2] * y[2]), d[3] * (1.f - y[3] * y[3])}; }
+
+template <int TW>
+__global__ __launch_bounds__(256) void k_enc_recur_bwd_coop(RecurBwdCoopArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const Lane L;
+  const int w = threadIdx.x >> 6;
+  constexpr int T = TW;
+  constexpr int PER = COOP_BWD_TILES * COOP_OT + 128;
+  auto Tb = [&](int k, int i) { return lds + k * PER + i * COOP_OT; };
+  auto GPb = [&](int k) { return lds + k * PER + COOP_BWD_TILES * COOP_OT; };            // [wave][16]: partial diffusion dots
+  auto MXb = [&](int k) { return lds + k * PER + COOP_BWD_TILES * COOP_OT + 64; };       // [wave][16]: row magnitudes
+  const int Nt = a.Nt, N = a.N, H = a.H;
+  using G = GruBwdL;
+  using S = EncSdeBwdL;
+  auto sl = [&](const float* img, int off) { return load_slice(img + off, w, L.lane); };
+  const WSlice wn2 = sl(a.gru_t, G::WN2T), wnx = sl(a.gru_t, G::WNXT), wnh = sl(a.gru_t, G::WNHT), wu2 = sl(a.gru_t, G::WU2T), wr2 = sl(a.gru_t, G::WR2T);
+  const WSlice wuh = sl(a.gru_t, G::UHT), wrh = sl(a.gru_t, G::RHT), wux = sl(a.gru_t, G::UXT), wrx = sl(a.gru_t, G::RXT);
+  const WSlice wf0 = sl(a.sde_t, S::F_W0T), wf2 = sl(a.sde_t, S::F_W2T), wf4 = sl(a.sde_t, S::F_W4T);
+  const WSlice wgn0 = sl(a.sde_t, S::GN_W0T), wgn2 = sl(a.sde_t, S::GN_W2T), wga0 = sl(a.sde_t, S::GA_W0T), wga2 = sl(a.sde_t, S::GA_W2T);
+  const f4 w4n = vec_slice(a.sde_t + S::GN_W4, w, L.g), w4a = vec_slice(a.sde_t + S::GA_W4, w, L.g);
+
+  int64_t rowk[COOP_TMAX];
+  bool inb[COOP_TMAX], is_nus[COOP_TMAX];
+  int eosk[COOP_TMAX], origk[COOP_TMAX];
+  unsigned long long nusmask[COOP_TMAX];
+  f4 dh[COOP_TMAX];
+#pragma unroll
+  for (int k = 0; k < COOP_TMAX; ++k)
+    if (k < T) {
+      const int64_t row = (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * 16 + L.n;
+      inb[k] = row < Nt;
+      rowk[k] = inb[k] ? row : Nt - 1;
+      is_nus[k] = a.nus[rowk[k]] != 0;
+      nusmask[k] = __ballot(is_nus[k]);
+      eosk[k] = a.eos[rowk[k]];
+      origk[k] = a.orig[rowk[k]];
+      dh[k] = f4{0.f, 0.f, 0.f, 0.f};                      // nothing reads the final state except through the kept latents
+    }
+  const int ch = 16 * w + 4 * L.g;                          // this lane's four channels of its row
+  // tape slices are requested ONE PHASE before they are used (a phase is ~1.5 us at one wave per SIMD: a load issued inside it would be
+  // its longest instruction) and held for that phase only -- holding an iteration's twelve slices per tile spilled at two tiles already
+  auto at_i = [&](const float* slab, int k, int i) { return *reinterpret_cast<const f4*>(slab + (int64_t(i) * Nt + rowk[k]) * 64 + ch); };
+  f4 hs[COOP_TMAX], pu[COOP_TMAX], pnw[COOP_TMAX];          // h', u, candidate of the iteration about to run
+#pragma unroll
+  for (int k = 0; k < COOP_TMAX; ++k)
+    if (k < T) {
+      hs[k] = at_i(a.tp.HODE, k, H - 1);
+      pu[k] = at_i(a.tp.UU, k, H - 1);
+      pnw[k] = at_i(a.tp.NW, k, H - 1);
+    }
+
+  for (int idx = H - 1; idx >= 0; --idx) {
+    const int t = H - 1 - idx;
+    const float dt = a.dt[idx], sq = a.sq[idx];
+    auto at = [&](const float* slab, int k) { return at_i(slab, k, idx); };
+    f4 dho[COOP_TMAX], dx[COOP_TMAX], pa[COOP_TMAX], pb[COOP_TMAX], d0[COOP_TMAX];   // pa / pb: the slices fetched for the next phase
+    float pgs[COOP_TMAX], up[COOP_TMAX], down[COOP_TMAX], dldg[COOP_TMAX];
+    auto keep = [&](float* slab, int k, const f4& v) {       // stores carry the true scale
+      if (inb[k]) *reinterpret_cast<f4*>(slab + (int64_t(idx) * Nt + rowk[k]) * 64 + ch) = v * down[k];
+    };
+#define TS_EACH_TILE _Pragma("unroll") for (int k = 0; k < COOP_TMAX; ++k) if (k < T)
+    // ---- G0: the gradient entering the iteration and its magnitude per row
+    TS_EACH_TILE {
+      pa[k] = at(a.tp.N1, k);
+      pb[k] = at(a.tp.U1, k);
+      d0[k] = dh[k];
+      if (rowk[k] < N && eosk[k] == idx) d0[k] += *reinterpret_cast<const f4*>(a.dlat + rowk[k] * 64 + ch);      // ENC:187-188
+      dldg[k] = (inb[k] && eosk[k] == idx) ? a.DLDG[rowk[k]] : 0.f;               // ENC:171,190-191: joins at the diffusion head
+      const float m = fmaxf(row_max(absmax4(d0[k])), fabsf(dldg[k]));
+      if (L.g == 0) MXb(k)[16 * w + L.n] = m;
+    }
+    __syncthreads();
+    // ---- G1: through the gated blend (ODEU:147-151), on the normalised row
+    TS_EACH_TILE {
+      const float* pm = MXb(k) + L.n;
+      const unsigned e = __float_as_uint(fmaxf(fmaxf(pm[0], pm[16]), fmaxf(pm[32], pm[48]))) & 0x7F800000u;   // 0 for an all-zero row
+      up[k] = __uint_as_float(0x7F000000u - e);
+      down[k] = __uint_as_float(e);
+      const bool valid = !a.pad[int64_t(origk[k]) * a.TT + t] && inb[k];
+      f4 dnw, du;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float d = d0[k][c] * up[k];
+        const float dd = valid ? d : 0.f, uu = pu[k][c];
+        dnw[c] = dd * (1.0f - uu);                                                 // d candidate
+        du[c] = dd * (hs[k][c] - pnw[k][c]) * uu * (1.0f - uu);                   // d u_pre
+        dho[k][c] = valid ? dd * uu : d;                                           // masked rows pass the state through
+      }
+      keep(a.DNW, k, dnw);
+      keep(a.DUP, k, du);
+      opnd_write(Tb(k, 0), dnw, w, L);
+      opnd_write(Tb(k, 1), du, w, L);
+    }
+    __syncthreads();
+    // ---- G2: new_state_net.2^T, update_gate.2^T
+    TS_EACH_TILE {
+      const f4 n1 = pa[k], u1 = pb[k];
+      pa[k] = at(a.tp.RR, k);
+      const f4 t4 = dtanh4(zero_mma(wn2, opnd_read(Tb(k, 0), L)), n1);            // d n1_pre
+      const f4 du1 = dtanh4(zero_mma(wu2, opnd_read(Tb(k, 1), L)), u1);           // d u1_pre
+      keep(a.DN1P, k, t4);
+      keep(a.DU1, k, du1);
+      opnd_write(Tb(k, 2), t4, w, L);
+      opnd_write(Tb(k, 3), du1, w, L);
+    }
+    __syncthreads();
+    // ---- G3: new_state_net.0^T on [x, r h']
+    TS_EACH_TILE {
+      const f4 rr = pa[k];
+      pa[k] = at(a.tp.R1, k);
+      const Opnd o = opnd_read(Tb(k, 2), L);
+      dx[k] = zero_mma(wnx, o);
+      const f4 drh = zero_mma(wnh, o);
+      f4 drp;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float rv = rr[c];
+        dho[k][c] = fmaf(drh[c], rv, dho[k][c]);
+        drp[c] = drh[c] * hs[k][c] * rv * (1.0f - rv);                             // d r_pre
+      }
+      keep(a.DRP, k, drp);
+      opnd_write(Tb(k, 0), drp, w, L);
+    }
+    __syncthreads();
+    // ---- G4: reset_gate.2^T
+    TS_EACH_TILE {
+      const f4 dr1 = dtanh4(zero_mma(wr2, opnd_read(Tb(k, 0), L)), pa[k]);
+      keep(a.DR1, k, dr1);
+      opnd_write(Tb(k, 1), dr1, w, L);
+    }
+    __syncthreads();
+    // ---- G5: gate first layers^T on [h', x] -> d x_t and d h'; then the Euler-Maruyama step (SDEINT:483): d f = dt d h', the
+    //      diffusion scalar's gradient is the row dot of d h' with z sqrt(dt)
+    TS_EACH_TILE {
+      pa[k] = at(a.tp.H2, k);
+      pb[k] = at(a.tp.G2, k);
+      pgs[k] = a.tp.GS[int64_t(idx) * Nt + rowk[k]];
+      const Opnd ou = opnd_read(Tb(k, 3), L), orr = opnd_read(Tb(k, 1), L);
+      slice_mma(dho[k], wuh, ou);
+      slice_mma(dho[k], wrh, orr);
+      slice_mma(dx[k], wux, ou);
+      slice_mma(dx[k], wrx, orr);
+      if (inb[k]) *reinterpret_cast<f4*>(a.DAA + (int64_t(t) * Nt + rowk[k]) * 64 + ch) = dx[k] * down[k];
+      if (!inb[k]) dho[k] = f4{0.f, 0.f, 0.f, 0.f};
+      const f4 df = dho[k] * dt;
+      keep(a.DF, k, df);
+      opnd_write(Tb(k, 0), df, w, L);
+      f4 z;
+      if (a.na.z != nullptr) z = *reinterpret_cast<const f4*>(a.na.z + (int64_t(idx) * Nt + rowk[k]) * 64 + ch);
+      else z = philox_normal4(noise_key(a.na), STREAM_ENCODER, uint32_t(idx),
+                              a.na.row_ids ? uint32_t(a.na.row_ids[rowk[k]]) : uint32_t(rowk[k]), uint32_t(4 * w + L.g));
+      float cdot = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cdot = fmaf(z[c] * sq, dho[k][c], cdot);
+      cdot = row_sum(cdot);
+      if (L.g == 0) GPb(k)[16 * w + L.n] = cdot;
+    }
+    __syncthreads();
+    // ---- S2: drift.4^T; the diffusion head (64 -> 1, sigmoid) of the row's own net
+    TS_EACH_TILE {
+      const f4 h2 = pa[k], g2 = pb[k];
+      pa[k] = at(a.tp.H1, k);
+      pb[k] = at(a.tp.G1, k);
+      const f4 dh2 = dtanh4(zero_mma(wf4, opnd_read(Tb(k, 0), L)), h2);
+      keep(a.DH2, k, dh2);
+      opnd_write(Tb(k, 2), dh2, w, L);
+      const float* gp = GPb(k) + L.n;
+      const float dg = ((gp[0] + gp[16]) + (gp[32] + gp[48])) + dldg[k] * up[k];
+      const float gs = pgs[k];
+      const float dgp = inb[k] ? dg * gs * (1.0f - gs) : 0.f;
+      const float seln = is_nus[k] ? dgp : 0.f, sela = is_nus[k] ? 0.f : dgp;
+      f4 dg2n, dg2a;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float gg = 1.0f - g2[c] * g2[c];
+        dg2n[c] = seln * w4n[c] * gg;
+        dg2a[c] = sela * w4a[c] * gg;
+      }
+      keep(a.DG2N, k, dg2n);
+      keep(a.DG2A, k, dg2a);
+      if (inb[k] && w == 0 && L.g == 0) {
+        a.DGPN[int64_t(idx) * Nt + rowk[k]] = seln * down[k];
+        a.DGPA[int64_t(idx) * Nt + rowk[k]] = sela * down[k];
+      }
+      if (nusmask[k] != 0ull) opnd_write(Tb(k, 3), dg2n, w, L);
+      if (nusmask[k] != ~0ull) opnd_write(Tb(k, 4), dg2a, w, L);
+    }
+    __syncthreads();
+    // ---- S3: drift.2^T, diffusion.2^T
+    TS_EACH_TILE {
+      const f4 h1 = pa[k], g1 = pb[k];
+      const f4 dh1 = dtanh4(zero_mma(wf2, opnd_read(Tb(k, 2), L)), h1);
+      keep(a.DH1, k, dh1);
+      opnd_write(Tb(k, 0), dh1, w, L);
+      f4 dg1n = f4{0.f, 0.f, 0.f, 0.f}, dg1a = dg1n;
+      if (nusmask[k] != 0ull) {
+        dg1n = dtanh4(zero_mma(wgn2, opnd_read(Tb(k, 3), L)), g1);
+        opnd_write(Tb(k, 1), dg1n, w, L);
+      }
+      if (nusmask[k] != ~0ull) {
+        dg1a = dtanh4(zero_mma(wga2, opnd_read(Tb(k, 4), L)), g1);
+        opnd_write(Tb(k, 5), dg1a, w, L);
+      }
+      keep(a.DG1N, k, dg1n);
+      keep(a.DG1A, k, dg1a);
+      if (idx > 0) {                                         // the next iteration's blend inputs
+        hs[k] = at_i(a.tp.HODE, k, idx - 1);
+        pu[k] = at_i(a.tp.UU, k, idx - 1);
+        pnw[k] = at_i(a.tp.NW, k, idx - 1);
+      }
+    }
+    __syncthreads();
+    // ---- S4: first layers^T (the 64 state columns of the 66-wide inputs) -> d h entering the previous iteration, true scale.
+    //      No barrier behind it: the next writes to the tiles it reads (0, 1, 5) come after G0's barrier.
+    TS_EACH_TILE {
+      f4 dyn = dho[k];
+      slice_mma(dyn, wf0, opnd_read(Tb(k, 0), L));
+      if (nusmask[k] != 0ull) slice_mma(dyn, wgn0, opnd_read(Tb(k, 1), L));
+      if (nusmask[k] != ~0ull) slice_mma(dyn, wga0, opnd_read(Tb(k, 5), L));
+      dh[k] = dyn * down[k];
+    }
+#undef TS_EACH_TILE
+  }
+#pragma unroll
+  for (int k = 0; k < COOP_TMAX; ++k)
+    if (k < T)
+      if (inb[k]) *reinterpret_cast<f4*>(a.dh_out + rowk[k] * 64 + ch) = dh[k];
+}
+template __global__ void k_enc_recur_bwd_coop<1>(RecurBwdCoopArgs);
+template __global__ void k_enc_recur_bwd_coop<2>(RecurBwdCoopArgs);
+template __global__ void k_enc_recur_bwd_coop<3>(RecurBwdCoopArgs);
+template __global__ void k_enc_recur_bwd_coop<4>(RecurBwdCoopArgs);
+
 // forward_ood (ENC:311-313): outs [S,N,64] -> mean over samples [N,64] and std(0).mean(-1) [N] (unbiased std)
 __global__ __launch_bounds__(256) void k_ood_stats(const float* __restrict__ samples, int S, int N, float* __restrict__ mean,
                                                    float* __restrict__ stds) {

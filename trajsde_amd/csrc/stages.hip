@@ -249,7 +249,8 @@ static int run_recurrence(const trajsde_batch* b, const trajsde_graph* g, const 
   const int64_t rtiles = (int64_t(Nt) + 15) / 16;
   // cooperative persistent kernel: all H iterations in one launch, weights resident in the register file
   static const bool legacy = []() { const char* e = getenv("TRAJSDE_RECUR_LEGACY"); return e && atoi(e) != 0; }();
-  const int tiles_per_wg = int((rtiles + 255) / 256);
+  static const int force_tw = []() { const char* e = getenv("TRAJSDE_RECUR_TW"); return e ? atoi(e) : 0; }();      // experiments
+  const int tiles_per_wg = force_tw > 0 ? force_tw : int((rtiles + 255) / 256);
   TS_REQUIRE(!state_bf16() || (!legacy && tiles_per_wg <= COOP_TMAX && H <= 32),
              "bf16 state storage needs the cooperative recurrence kernel (at most 16384 extended rows)");
   if (!legacy && tiles_per_wg <= COOP_TMAX && H <= 32) {
