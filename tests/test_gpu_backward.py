@@ -273,6 +273,39 @@ def test_decoder_backward_is_deterministic_and_checks_arguments(dev):
 _oracle_full_grads = H.oracle_full_grads
 
 
+@pytest.mark.parametrize("log2_scale", [-40, -20, 12])
+def test_gradients_scale_with_the_loss_weights(log2_scale, dev):
+    """size-independent property of the backward: it is linear in the loss weights.  The 16-bit matrix products of the backward see
+    power-of-two-normalised deltas (rows in tile.hpp linear_adj, 64-row blocks in k_wgrad6, a row per iteration in
+    k_enc_recur_bwd_coop), so gradients 2^-40 ... 2^12 times the usual ones must come out as exactly scaled copies up to fp32
+    rounding -- an fp16 range problem (flushed deltas, saturated blocks) would show as a broken ratio."""
+    from trajsde_amd import runtime
+    from trajsde_amd.synth import synth
+    K, T = 3, 20
+    batch = synth(S=3, n=12, L=6, F=T, box=70.0, seed=79, mixed_source=True, history_dropout=0.3)
+    model, cfg = H.build_model(K, T, 2.0, init_seed=23)
+    H.perturb_parameters(model, 41)
+    model = model.to(dev).train()
+
+    def grads(w_l2, w_diff):
+        model.zero_grad(set_to_none=True)
+        model.loss_weights = [w_l2, w_diff]
+        loss = model.training_step(H.clone_batch(batch).to(dev), 0, noise=runtime.NoiseSpec(seed=5, dropout_seed=6))
+        loss.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    s = 2.0 ** log2_scale
+    base, scaled = grads(1.0, 0.5), grads(s, 0.5 * s)
+    assert base.keys() == scaled.keys()
+    bad = []
+    for n, g in base.items():
+        ref = float(g.abs().max())
+        err = float((scaled[n] / s - g).abs().max())
+        if err > 2e-6 * ref + 1e-12:
+            bad.append((n, err, ref))
+    assert not bad, bad[:6]
+
+
 @pytest.mark.parametrize("mode", ["train: dropout 0.1", "train: dropout 0.3, own key", "eval"])
 def test_training_step_gradients_match_end_to_end_autograd(mode, dev):
     """`training_step(...).backward()` fills .grad like autograd over the whole reference graph would -- in train mode with
