@@ -273,6 +273,38 @@ def test_decoder_backward_is_deterministic_and_checks_arguments(dev):
 _oracle_full_grads = H.oracle_full_grads
 
 
+def test_full_size_training_step_agrees_between_kernel_forms(dev):
+    """BASELINE configs[1] (64 scenes x 128 agents: 3.4 M agent-agent edges, 4.55 M embedding rows) is far beyond what the float64 oracle
+    can differentiate, so the full-size check is a cross-check: the same training step in two child processes, once with this round's
+    kernel forms (k_wgrad6 on block-scaled 16-bit products, deferred sums, the cooperative recurrence kernels) and once with the forms
+    they replaced (exact fp32 weight-gradient products, one reduction per batch, one tile per wave: TRAJSDE_WGRAD_F32 /
+    TRAJSDE_IMMEDIATE_SUMS / TRAJSDE_RECUR_LEGACY).  Same loss to 1e-6, every one of the 252 - 8 gradients finite and equal in norm and in
+    a seeded +-1 projection to 2e-5 of its norm."""
+    import json
+    import subprocess
+    import sys
+
+    def run(extra):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, os.path.join(H.ROOT, "tests", "grad_digest_child.py"), "config2"], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    new = run({})
+    old = run({"TRAJSDE_WGRAD_F32": "1", "TRAJSDE_IMMEDIATE_SUMS": "1", "TRAJSDE_RECUR_LEGACY": "1"})
+    assert abs(new["loss"] - old["loss"]) <= 1e-6 * max(1.0, abs(old["loss"]))
+    assert new["digests"].keys() == old["digests"].keys() and len(new["digests"]) >= 240
+    bad = []
+    for n, (norm, proj, finite) in new["digests"].items():
+        o_norm, o_proj, o_finite = old["digests"][n]
+        assert finite and o_finite, n
+        zero_by_symmetry = n.endswith("lin_k.bias") or n.endswith("lin_k_node.bias") or n.endswith("lin_k_edge.bias")
+        tol = 2e-5 * max(o_norm, 1e-12)
+        if not zero_by_symmetry and (abs(norm - o_norm) > tol or abs(proj - o_proj) > tol * 8):
+            bad.append((n, norm, o_norm, proj, o_proj))
+    assert not bad, bad[:6]
+
+
 @pytest.mark.parametrize("log2_scale", [-40, -20, 12])
 def test_gradients_scale_with_the_loss_weights(log2_scale, dev):
     """size-independent property of the backward: it is linear in the loss weights.  The 16-bit matrix products of the backward see
