@@ -547,14 +547,10 @@ __global__ __launch_bounds__(256, 3) void k_wgrad(WgradJobs jobs, int64_t R, int
       const int r = f >> 4, c4 = f & 15;
       const int64_t row = blk + r;
       f4 dv = f4{0.f, 0.f, 0.f, 0.f}, av = dv;
-#if defined(TSDE_WGRAD_NOLOAD)
-      if (row < row1) { dv = f4{1.f, 2.f, 3.f, float(row)}; av = dv; }
-#else
       if (row < row1) {
         dv = *reinterpret_cast<const f4*>(delta + row * ldd + 4 * c4);
         av = computed ? *reinterpret_cast<const f4*>(a + row * 4) : *reinterpret_cast<const f4*>(a + row * lda + 4 * c4);
       }
-#endif
       dreg[u] = dv;
       areg[u] = av;
     }
@@ -582,9 +578,7 @@ __global__ __launch_bounds__(256, 3) void k_wgrad(WgradJobs jobs, int64_t R, int
   };
   if (row0 < row1) fetch(row0);
   for (int64_t blk = row0; blk < row1; blk += 64) {
-#if !defined(TSDE_WGRAD_NOBARRIER)
     __syncthreads();
-#endif
     if (computed) finish(blk);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -595,9 +589,7 @@ __global__ __launch_bounds__(256, 3) void k_wgrad(WgradJobs jobs, int64_t R, int
         as_[wofs[j] + (r ^ wswz[j])] = areg[u][j];
       }
     }
-#if !defined(TSDE_WGRAD_NOBARRIER)
     __syncthreads();
-#endif
     if (blk + 64 < row1) fetch(blk + 64);
     f4 A[4], B[4][4];
 #pragma unroll
@@ -612,11 +604,7 @@ __global__ __launch_bounds__(256, 3) void k_wgrad(WgradJobs jobs, int64_t R, int
       for (int c = 0; c < 4; ++c) {
         csum += A[m][c];
 #pragma unroll
-#if defined(TSDE_WGRAD_NOMFMA)
-        for (int it = 0; it < 4; ++it) acc[it][0] += A[m][c] * B[it][m][c];
-#else
         for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m][c], B[it][m][c], acc[it], 0, 0, 0);
-#endif
       }
   }
   // D fragment: lane holds dW[16 ot + 4 kg + reg][16 it + idx]
