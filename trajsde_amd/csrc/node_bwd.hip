@@ -45,11 +45,13 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_a(const float* __restrict__ img
   for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
     keep_lds_reads_here();
     const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
-    f4 n[4], hid[16], dh[16];
+    f4 n[4], hid[16], dh[16], dn[4];
     load_row(n, xn2, r, L.g);
+    load_row(dn, dout, r, L.g);                                  // requested with the tile's first row, not after the first product
     linear<16, 4>(hid, n, lds + FfnBwdAL::W1, lds + FfnBwdAL::B1, L);
     relu<16>(hid);
-    load_row(n, dout, r, L.g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) n[jt] = dn[jt];
     const bool dropping = drop.p > 0.f;
     f4 m1[16];
     if (dropping) {
@@ -99,17 +101,17 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_b(const float* __restrict__ img
   for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
     keep_lds_reads_here();
     const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
-    f4 dh[16], t[4], x[4];
+    f4 dh[16], t[4], x[4], dres[4];
     load_row256(dh, DH, r, L.g);
+    load_row(x, x1, r, L.g);                                     // all three rows of the tile are requested up front
+    load_row(dres, dout, r, L.g);
     zero4(t);
     linear_adj<4, 16>(t, dh, lds + FfnBwdBL::W1T, L);
     if (row >= R) zero4(t);
-    load_row(x, x1, r, L.g);
     const float rstd = ln_normalize(x);
     ln_backward(t, x, rstd, lds + FfnBwdBL::N2G, L.g, dgam, dbet);
-    load_row(x, dout, r, L.g);
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) t[jt] += x[jt];
+    for (int jt = 0; jt < 4; ++jt) t[jt] += dres[jt];
     if (row < R) store_row(t, dx1, row, L.g);
   }
   float* vp = vpart + int64_t(blockIdx.x * waves + wave) * 128;
@@ -136,13 +138,13 @@ __global__ __launch_bounds__(256) void k_upd_bwd(const float* __restrict__ img, 
     f4 a[4], n[4], g[4], s[4], d[4], t[4];
     load_row(a, agg, r, L.g);
     load_row(n, xn, r, L.g);
+    load_row(d, dx1, r, L.g);                                    // (ahead of the three forward products that do not need it)
     linear<4, 4>(g, a, lds + U::WIH, lds + U::BIH, L);
     linear<4, 4>(t, n, lds + U::WHH, lds + U::BHH, L);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) g[jt] += t[jt];
     sigmoid_<4>(g);
     linear<4, 4>(s, n, lds + U::WSELF, lds + U::BSELF, L);
-    load_row(d, dx1, r, L.g);
     if (drop.p > 0.f) {
       f4 mk[4];
       drop_feat16(mk, drop, DK_PROJ, uint32_t(r), 0, L.g);
@@ -194,16 +196,17 @@ __global__ __launch_bounds__(256) void k_node_proj_bwd(const float* __restrict__
   for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
     keep_lds_reads_here();
     const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
-    f4 t[4], d[4], xh[4];
+    f4 t[4], d[4], xh[4], dq[NQ > 0 ? NQ : 1][4], dr[4];
     if (dxn_part) load_row(t, dxn_part, r, L.g);
     else zero4(t);
+    // every row of the tile is requested before the first product (they used to be loaded one product at a time)
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-      load_row(d, dps[j], r, L.g);
-      linear_adj<4, 4>(t, d, lds + P::WT + j * MAT64, L);
-    }
-    if (row >= R) zero4(t);
+    for (int j = 0; j < NQ; ++j) load_row(dq[j], dps[j], r, L.g);
     load_row(xh, x, r, L.g);
+    if (dres) load_row(dr, dres, r, L.g);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) linear_adj<4, 4>(t, dq[j], lds + P::WT + j * MAT64, L);
+    if (row >= R) zero4(t);
     const float rstd = ln_normalize(xh);
     if (xn_out && row < R) {
       f4 o[4];
@@ -218,9 +221,8 @@ __global__ __launch_bounds__(256) void k_node_proj_bwd(const float* __restrict__
     }
     ln_backward(t, xh, rstd, lds + P::N1G, L.g, dgam, dbet);
     if (dres) {
-      load_row(d, dres, r, L.g);
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) t[jt] += d[jt];
+      for (int jt = 0; jt < 4; ++jt) t[jt] += dr[jt];
     }
     if (row < R) store_row(t, dx_out, row, L.g);
   }
@@ -300,6 +302,23 @@ __global__ __launch_bounds__(512) void k_edge_embed_bwd_tail(const float* __rest
     const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
     const f4 ge = *reinterpret_cast<const f4*>(geom + 4 * ec);
     f4 xh[4], a0[4], b0[4], sp[4], s[4], ep[4], d[4];
+    // ATTN: the target's q / dagg rows and the edge's scalars are requested HERE, ahead of the forward recompute that does not
+    // need them (index -> row is two dependent latencies; left where they are used, they stalled every tile at two waves per SIMD)
+    f4 qv[4], gv[4], d0, a0_, d1, a1_;
+    if (!ATTN) load_row(d, demb, ec, L.g);
+    if (ATTN) {
+      const int tgt = ag.dst[ec];
+      load_row(qv, ag.q, tgt, L.g);
+      load_row(gv, ag.dagg, tgt, L.g);
+      d0 = *reinterpret_cast<const f4*>(ag.ED + ec * ag.heads);
+      a0_ = *reinterpret_cast<const f4*>(ag.EA + ec * ag.heads);
+      d1 = d0;
+      a1_ = a0_;
+      if (ag.heads == 8) {
+        d1 = *reinterpret_cast<const f4*>(ag.ED + ec * 8 + 4);
+        a1_ = *reinterpret_cast<const f4*>(ag.EA + ec * 8 + 4);
+      }
+    }
     float r_;
     branch_fwd(xh, a0, r_, ge[0], ge[1], lds + EL::A_W0, lds + EL::A_B0, lds + EL::A_G, lds + EL::A_E, L);
     branch_fwd(xh, b0, r_, ge[2], ge[3], lds + EL::B_W0, lds + EL::B_B0, lds + EL::B_G, lds + EL::B_E, L);
@@ -322,17 +341,7 @@ __global__ __launch_bounds__(512) void k_edge_embed_bwd_tail(const float* __rest
     linear_x6<4, 4>(ep, s, lds + EL::W2, lds + EL::B2, L);
     const float rs3 = ln_normalize(ep);                   // ep = e_hat
     if (ATTN) {
-      const int tgt = ag.dst[ec];
-      f4 qv[4], gv[4];
-      load_row(qv, ag.q, tgt, L.g);
-      load_row(gv, ag.dagg, tgt, L.g);
       // lane group g holds the features of heads 2jt + (g >> 1) (8 heads) or jt (4 heads)
-      const f4 d0 = *reinterpret_cast<const f4*>(ag.ED + ec * ag.heads), a0_ = *reinterpret_cast<const f4*>(ag.EA + ec * ag.heads);
-      f4 d1 = d0, a1_ = a0_;
-      if (ag.heads == 8) {
-        d1 = *reinterpret_cast<const f4*>(ag.ED + ec * 8 + 4);
-        a1_ = *reinterpret_cast<const f4*>(ag.EA + ec * 8 + 4);
-      }
       const int odd = L.g >> 1;
       f4 dk[4], dv[4];
 #pragma unroll
@@ -355,8 +364,6 @@ __global__ __launch_bounds__(512) void k_edge_embed_bwd_tail(const float* __rest
       }
       linear_t(d, dk, lds + EdgeBwdL::WA3T, L);
       linear_adj<4, 4>(d, dv, lds + EdgeBwdL::WA3T + MAT64, L);
-    } else {
-      load_row(d, demb, ec, L.g);
     }
     if (e >= E) zero4(d);
     ln_backward(d, ep, rs3, lds + EL::AG3, L.g, dg3, db3);   // d := d ep
