@@ -1169,6 +1169,8 @@ __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ i
       load_row(a, agg, r, L.g);
     }
     load_row(n, xn, r, L.g);
+    f4 xr[4];
+    load_row(xr, x, r, L.g);                                  // the residual row: requested with the tile's other rows, used last
     range_note(absmax<4>(a), RS_NODE_AGG);
     lin(g, a, U::WIH, U::BIH);
     {
@@ -1191,9 +1193,8 @@ __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ i
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) s[jt] *= mk[jt];
     }
-    load_row(n, x, r, L.g);
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) n[jt] += s[jt];
+    for (int jt = 0; jt < 4; ++jt) n[jt] = xr[jt] + s[jt];
     if (row < R) store_row(n, x1, row, L.g);
     layer_norm<4>(n, lds + U::N2G, lds + U::N2B, L.g);
     if (row < R) store_row(n, xn2, row, L.g);
@@ -1211,8 +1212,9 @@ __global__ __launch_bounds__(512) void k_ffn(const float* __restrict__ img_g, co
   for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
     keep_lds_reads_here();
     const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
-    f4 n[4], hid[16], o[4];
+    f4 n[4], hid[16], o[4], xr[4];
     load_row(n, xn2, r, L.g);
+    load_row(xr, x1, r, L.g);                                 // the residual row, requested up front
     linear<16, 4>(hid, n, lds + FfnL::W1, lds + FfnL::B1, L);
     relu<16>(hid);
     if (drop.p > 0.f) {                                       // mlp: Linear - ReLU - Dropout - Linear - Dropout (ENC:529-533)
@@ -1232,9 +1234,8 @@ __global__ __launch_bounds__(512) void k_ffn(const float* __restrict__ img_g, co
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) o[jt] *= mk[jt];
     }
-    load_row(n, x1, r, L.g);
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) o[jt] += n[jt];
+    for (int jt = 0; jt < 4; ++jt) o[jt] += xr[jt];
     if (row < R) store_row_st(o, out, row, L.g, out_bf16 != 0);
   }
 }
