@@ -97,6 +97,10 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
   float dqe = 0.f, Rl[SL], Sa[SL];
 #pragma unroll
   for (int e = 0; e < SL; ++e) Rl[e] = Sa[e] = 0.f;
+  // row loads through buffer descriptors as in the forward kernel (attn.hip k_global_attn): descriptor base in SGPRs + scalar row
+  // offset + lane * 4 -- no per-lane 64-bit address arithmetic for the 24 loads of a chunk
+  const __amdgpu_buffer_rsrc_t rs_rel = row_rsrc(rel + int64_t(beg) * 64);
+  const __amdgpu_buffer_rsrc_t rs_kn = row_rsrc(kn), rs_vn = row_rsrc(vn);
   for (int e0 = beg; e0 < end; e0 += 8) {                  // 8 edges in flight per round trip, as in the forward kernel
     f4 r[8][NV];
     float knv[8], vnv[8], rl[8];
@@ -108,9 +112,9 @@ __global__ __launch_bounds__(256) void k_gattn_bwd(const float* __restrict__ img
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u < end ? e0 + u : end - 1;
       sx[u] = __builtin_amdgcn_readlane(sv, u);
-      rl[u] = (rel + int64_t(e) * 64)[lane];               // the row once per wave, slices picked out of LDS below
-      knv[u] = NODE ? (kn + int64_t(sx[u]) * 64)[lane] : 0.f;
-      vnv[u] = NODE ? (vn + int64_t(sx[u]) * 64)[lane] : 0.f;
+      rl[u] = row_load(rs_rel, lane, e - beg);             // the row once per wave, slices picked out of LDS below
+      knv[u] = NODE ? row_load(rs_kn, lane, sx[u]) : 0.f;
+      vnv[u] = NODE ? row_load(rs_vn, lane, sx[u]) : 0.f;
     }
     __builtin_amdgcn_wave_barrier();                        // the previous chunk's slice reads are done (same wave, in order)
 #pragma unroll
