@@ -1020,6 +1020,12 @@ float* ColsumQueue::take(int64_t floats) {
   return p;
 }
 DeferredSums::DeferredSums(hipStream_t st, float* part, float* cs, int64_t cap, const float* step_tab, float* arena, int64_t arena_floats) {
+  // TRAJSDE_REDUCE_CAP / TRAJSDE_VPART_ARENA (partial slots / arena floats): smaller areas than the workspace has, so that tests reach
+  // the sum-early-when-full paths at sizes where the real areas never fill
+  static const int64_t cap_env = []() { const char* e = getenv("TRAJSDE_REDUCE_CAP"); return e ? atoll(e) : 0; }();
+  static const int64_t arena_env = []() { const char* e = getenv("TRAJSDE_VPART_ARENA"); return e ? atoll(e) : 0; }();
+  if (cap_env > 0 && cap_env < cap) cap = cap_env;
+  if (arena_env > 0 && arena_env < arena_floats) arena_floats = arena_env;
   rq.st = st; rq.part = part; rq.cs = cs; rq.step_tab = step_tab; rq.cap = cap; rq.used = 0;
   cq.st = st; cq.arena = arena; cq.cap = arena_floats; cq.used = 0;
   static const bool off = []() { const char* e = getenv("TRAJSDE_IMMEDIATE_SUMS"); return e && e[0] == '1'; }();   // A/B switch
@@ -1134,6 +1140,14 @@ int WgradBatch::flush() {
   if (per_launch < 1) return fail(TRAJSDE_ERR_WORKSPACE, "wgrad: partial buffer too small");
   ReduceQueue* rq = active_reduce_queue();
   if (rq && rq->part != c.part) rq = nullptr;           // (a context over another partial buffer: immediate)
+  if (rq && rq->cap < c.cap) {                          // a queue over a smaller area than the context's
+    per_launch = int(rq->cap / P);
+    if (per_launch < 1) {                               // one problem's partials do not fit it: this batch is summed immediately,
+      if (int rc = rq->drain()) return rc;              // from slot 0 of the same buffer -- after what is queued there
+      rq = nullptr;
+      per_launch = int(c.cap / P);
+    }
+  }
   for (int first = 0; first < n; first += per_launch) {
     WgradJobs sub;
     sub.n = n - first < per_launch ? n - first : per_launch;

@@ -90,30 +90,32 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 #if TSDE_SPLIT_H3
 // fp16x3: x = h + l with h = fp16(x) (round toward zero, v_cvt_pkrtz_f16_f32) and l = fp16(x - h): 22 significant bits,
-// the residual x - h is exact in fp32 and is formed (and rounded to fp16) by v_fma_mixlo/mixhi_f16 straight from the packed half.  a*b ~= a_h b_h +
+// the residual x - h is exact in fp32 (v_fma_mix_f32 straight from the packed half) and rounded to nearest.  a*b ~= a_h b_h +
 // a_h b_l + a_l b_h (three v_mfma_f32_16x16x32_f16; the dropped a_l b_l is 2^-22 relative).  2 VALU per value to split
 // against 5.5 for three bf16 pieces, and half the matrix instructions.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
 
+typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
+// fp16x3 operand split of two values: hi = fp16(x) (round toward zero, one v_cvt_pkrtz for the pair), lo = fp16(x - hi) with the
+// residual formed exactly in fp32 by v_fma_mix_f32 (reads the fp16 half in place) and rounded to nearest by v_cvt_pk_f16_f32:
+// four instructions per pair, every one of them visible to the compiler's scheduler and hazard recognizer.
+// (Rounds 2-3 shipped a three-instruction form -- v_fma_mixlo_f16 / v_fma_mixhi_f16 writing the two halves of the lo register from one
+// inline-assembly block per k-step.  It made a few tiles per 10^5 come out different from run to run in their low-order bits -- found
+// by comparing two identical backward calls word for word; 1 to 8 wait states before or after the block did not cure it -- and the
+// rigid nine-instruction block was also SLOWER than these schedulable four: edge attention 0.777 -> 0.766 ms, 14.05 -> 14.3 k scenes/s.)
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
   const hp2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
   float r0, r1;                                                                    // x - h, exact
   const unsigned hb = __builtin_bit_cast(unsigned, h);
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x0));
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
-  const hp2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+  const hf2 l = hf2{_Float16(r0), _Float16(r1)};
   hi = hb;
   lo = __builtin_bit_cast(unsigned, l);
 }
-// The 8 values of one k-step.  The residual x - h (exact in fp32) is rounded to fp16 by the instruction that forms it:
-// v_fma_mixlo_f16 / v_fma_mixhi_f16 write the fp16 result into one half of the destination, so a pair costs cvt_pkrtz + 2
-// instead of cvt_pkrtz + 2 + cvt_pkrtz.  They are 16-bit partial writes: gfx940-class hardware wants a wait state between
-// such a write and a read of the register, which the compiler cannot insert around inline assembly -- so the four pairs are
-// issued as one block, low halves first (three independent instructions between the two writes of a register and between a
-// write and the block's end, except for the last one: one s_nop).
+// The 8 values of one k-step
 __device__ __forceinline__ void split_kstep(const f4& qa, const f4& qb, u4& hi, u4& lo) {
-#ifdef TSDE_SPLIT_LO_RTZ
   unsigned h[4], l[4];
   split_pair(qa[0], qa[1], h[0], l[0]);
   split_pair(qa[2], qa[3], h[1], l[1]);
@@ -121,26 +123,6 @@ __device__ __forceinline__ void split_kstep(const f4& qa, const f4& qb, u4& hi, 
   split_pair(qb[2], qb[3], h[3], l[3]);
   hi = u4{h[0], h[1], h[2], h[3]};
   lo = u4{l[0], l[1], l[2], l[3]};
-#else
-  const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(qa[0], qa[1]));
-  const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(qa[2], qa[3]));
-  const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(qb[0], qb[1]));
-  const unsigned h3 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(qb[2], qb[3]));
-  unsigned l0, l1, l2, l3;
-  asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "s_nop 0"
-      : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
-      : "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(qa[0]), "v"(qa[1]), "v"(qa[2]), "v"(qa[3]), "v"(qb[0]), "v"(qb[1]), "v"(qb[2]), "v"(qb[3]));
-  hi = u4{h0, h1, h2, h3};
-  lo = u4{l0, l1, l2, l3};
-#endif
 }
 
 // acc[jo] += W * in with W stored as two fp16 pieces in fragment order [jo][s][piece][lane][8] (pack.hip MAT6);
@@ -588,20 +570,17 @@ __device__ __forceinline__ void in2_ln_relu(f4 (&out)[4], float x0, float x1, co
 }
 
 #if TSDE_SPLIT_H3
-// The same block on the matrix cores (layouts.hpp IN2F): the row operand x0r_h x1r_h | x0r_l x1r_l | r_h r_l | 1 1 of one row,
-// 5 vector instructions (the 16-bit partial writes go through one assembly block like split_kstep's, with wait states between
-// the two writes of a register and before the block's end) ...
+// The same block on the matrix cores (layouts.hpp IN2F): the row operand x0r_h x1r_h | x0r_l x1r_l | r_h r_l | 1 1 of one row
+// (hi / lo pieces as in split_pair: no 16-bit partial writes, see there) ...
 __device__ __forceinline__ u4 in2_operand(float x0r, float x1r, float rstd) {
-  const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0r, x1r));
-  unsigned hr = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(rstd, 0.f));
-  unsigned l;
-  asm("v_fma_mixlo_f16 %0, %2, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %1, %1, -1.0, %5 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "s_nop 1\n\t"
-      "v_fma_mixhi_f16 %0, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "s_nop 1"
-      : "=&v"(l), "+v"(hr)
-      : "v"(h), "v"(x0r), "v"(x1r), "v"(rstd));
+  unsigned h, l;
+  split_pair(x0r, x1r, h, l);
+  const hp2 rh = __builtin_amdgcn_cvt_pkrtz(rstd, 0.f);
+  const unsigned rhb = __builtin_bit_cast(unsigned, rh);
+  float rr;                                                                        // rstd - fp16(rstd), exact
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rr) : "v"(rhb), "v"(rstd));
+  const hf2 rl = hf2{_Float16(rr), _Float16(0.f)};
+  const unsigned hr = (rhb & 0xFFFFu) | (__builtin_bit_cast(unsigned, rl) << 16);  // r_h | r_l
   return u4{h, l, hr, 0x3C003C00u};
 }
 // ... and ReLU(LayerNorm(Linear(2,64)(x))) of NT row tiles: 4 fragments read once, 4 NT matrix instructions, 16 NT max
