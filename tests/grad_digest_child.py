@@ -26,9 +26,22 @@ def main():
     dev = torch.device("cuda:0")
     model = driver.build_model(cfg, None, dev, init_seed=0).train()
     batch = synth(**spec["synth"]).to(dev)
+    poison = os.environ.get("TRAJSDE_TEST_POISON")             # what the workspaces hold before the kernels write them
+    if poison:
+        junk = torch.empty(3 << 30, device=dev, dtype=torch.float32)          # 12 GB: the step's allocations are carved from this block
+        if poison == "nan":
+            junk.fill_(float("nan"))
+        elif poison == "zero":
+            junk.zero_()
+        else:
+            junk.view(torch.int32).random_(-2 ** 31, 2 ** 31 - 1, generator=torch.Generator(device=dev).manual_seed(int(poison)))
+        del junk
     loss = model.training_step(batch, 0, noise=NoiseSpec(seed=100, dropout_seed=101))
     loss.backward()
     torch.cuda.synchronize()
+    dump = os.environ.get("TRAJSDE_TEST_DUMP")                 # every gradient, word for word, for a cross-process comparison
+    if dump:
+        torch.save({n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}, dump)
     out = {}
     for n, p in model.named_parameters():
         if p.grad is None:

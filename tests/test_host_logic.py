@@ -193,6 +193,50 @@ def test_flat_training_matches_per_parameter_adamw_on_cpu():
     assert flat.a.data_ptr() == ft.flat_param.data_ptr()                  # the parameters ARE slices of the flat tensor
 
 
+def test_flat_grads_accumulate_gathers_stage_buffers_into_the_parameter_order():
+    """driver.FlatGrads.accumulate: gradients that arrive as views of a few flat, padded buffers in another order (the stage
+    backward entry points' layout) land in the parameters' slices scaled by the upstream gradient, added to what is there;
+    layouts it cannot serve (a detached gradient, a re-assigned .grad, a buffer whose parameters are not one block) are
+    refused untouched"""
+    import torch
+    from trajsde_amd import driver
+    g = torch.Generator().manual_seed(5)
+    shapes = [(3, 4), (5,), (2, 2, 2), (7,), (1,)]
+    params = [torch.nn.Parameter(torch.randn(*sh, generator=g)) for sh in shapes]
+    sink = driver.FlatGrads(params)
+    sink.flat.copy_(torch.randn(sink.flat.numel(), generator=g))
+    before = sink.flat.clone()
+
+    def stage_views(order, numel):
+        flat = torch.randn(numel, generator=g)
+        off, out = 0, {}
+        for i in order:                                   # 4-float aligned slices, like runtime._grad_buffers
+            n = params[i].numel()
+            out[i] = flat[off:off + n].view(shapes[i])
+            off += (n + 3) // 4 * 4
+        return out
+    a = stage_views([1, 0], 24)                           # parameters 0, 1 from buffer A (stored in the other order)
+    b = stage_views([4, 2, 3], 24)                        # parameters 2, 3, 4 from buffer B
+    grads = [a[0], a[1], b[2], b[3], b[4]]
+    scale = torch.tensor(0.5)
+    assert sink.accumulate(params, grads, scale)
+    for p, x, off in zip(params, grads, sink.offsets):
+        want = before[off:off + p.numel()].view_as(p) + 0.5 * x
+        assert torch.equal(p.grad, want)
+    assert sink.accumulate(params, grads, scale) and len(sink._gather) == 2          # index tensors are built once
+    now = sink.flat.clone()
+    assert not sink.accumulate(params, [a[0], a[1], b[2], b[3] * 1.0, b[4]], scale)   # a detached gradient: no base buffer
+    assert not sink.accumulate(params, [a[0], b[3].new_zeros(5), b[2], b[3], b[4]][:5], scale)
+    assert not sink.accumulate(params, [a[0], None, b[2], b[3], b[4]], scale)
+    c = stage_views([0, 2], 24)
+    assert not sink.accumulate(params, [c[0], a[1], c[2], b[3], b[4]], scale)        # buffer C, A, C: not one block each
+    keep = params[2].grad
+    params[2].grad = keep.clone()
+    assert not sink.accumulate(params, grads, scale)                                  # someone re-assigned a .grad
+    params[2].grad = keep
+    assert torch.equal(sink.flat, now)
+
+
 def test_flat_training_checkpoints_hold_the_reference_optimizer_layout(tmp_path):
     """`optimizer_states[0]` of a checkpoint written by the loop is what `AdamW(model.parameters())` (MODEL:205) holds after
     the same steps -- per parameter, indexed in `parameters()` order, no entry for parameters without a gradient -- so a

@@ -1,0 +1,180 @@
+// Does a vector instruction that overwrites a SrcA (or SrcB) register of v_mfma_f32_16x16x32_f16 right behind it change the product?
+// The compiler schedules such writes with no wait states (tools/isa_mfma_war_scan.py); csrc/tile.hpp split_pair describes what was seen.
+//   hipcc --offload-arch=gfx950 -O3 mfma_war.hip -o mfma_war && ./mfma_war
+// Per variant: a matrix instruction on fixed registers, W wait states, then v_mov_b32 of junk into the first (or last) register of A or B;
+// the accumulator is compared with the same product left alone.  2 waves per SIMD, 200 rounds per wave.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+#define BODY(NOPS, VICTIM)                                                                                   \
+  asm volatile("v_mov_b32 v40, %1\n\tv_mov_b32 v41, %2\n\tv_mov_b32 v42, %3\n\tv_mov_b32 v43, %4\n\t"        \
+               "v_mov_b32 v44, %5\n\tv_mov_b32 v45, %6\n\tv_mov_b32 v46, %7\n\tv_mov_b32 v47, %8\n\t"        \
+               "v_mov_b32 v48, 0\n\tv_mov_b32 v49, 0\n\tv_mov_b32 v50, 0\n\tv_mov_b32 v51, 0\n\t"            \
+               "s_nop 7\n\ts_nop 7\n\t"                                                                     \
+               "v_mfma_f32_16x16x32_f16 v[48:51], v[40:43], v[44:47], v[48:51]\n\t" NOPS                     \
+               "v_mov_b32 " VICTIM ", 0x7bff7bff\n\t"                                                       \
+               "s_nop 15\n\ts_nop 15\n\t"                                                                   \
+               "v_mov_b32 %0, v48\n\t"                                                                      \
+               : "=v"(got)                                                                                   \
+               : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w)              \
+               : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51");
+
+template <int V>
+__global__ __launch_bounds__(512) void k(const u4* A, const u4* B, unsigned* bad, int rounds) {
+  const int lane = threadIdx.x & 63;
+  unsigned n = 0;
+  for (int r = 0; r < rounds; ++r) {
+    const u4 a = A[(r * 64 + lane) & 4095], b = B[(r * 97 + lane) & 4095];
+    float want, got;
+    asm volatile("v_mov_b32 v40, %1\n\tv_mov_b32 v41, %2\n\tv_mov_b32 v42, %3\n\tv_mov_b32 v43, %4\n\t"
+                 "v_mov_b32 v44, %5\n\tv_mov_b32 v45, %6\n\tv_mov_b32 v46, %7\n\tv_mov_b32 v47, %8\n\t"
+                 "v_mov_b32 v48, 0\n\tv_mov_b32 v49, 0\n\tv_mov_b32 v50, 0\n\tv_mov_b32 v51, 0\n\t"
+                 "s_nop 7\n\ts_nop 7\n\t"
+                 "v_mfma_f32_16x16x32_f16 v[48:51], v[40:43], v[44:47], v[48:51]\n\t"
+                 "s_nop 15\n\ts_nop 15\n\t"
+                 "v_mov_b32 %0, v48\n\t"
+                 : "=v"(want)
+                 : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w)
+                 : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51");
+    if (V == 0) { BODY("", "v40") }
+    if (V == 1) { BODY("s_nop 0\n\t", "v40") }
+    if (V == 2) { BODY("s_nop 1\n\t", "v40") }
+    if (V == 3) { BODY("s_nop 3\n\t", "v40") }
+    if (V == 4) { BODY("s_nop 7\n\t", "v40") }
+    if (V == 5) { BODY("", "v43") }
+    if (V == 6) { BODY("", "v44") }
+    if (V == 7) { BODY("", "v47") }
+    if (V == 8) { BODY("s_nop 3\n\t", "v47") }
+    if (V == 9) { BODY("s_nop 15\n\t", "v40") }
+    n += __float_as_uint(want) != __float_as_uint(got);
+  }
+  if (n) atomicAdd(&bad[V * 64 + lane], n);
+}
+
+// ... and the other direction: how soon behind the matrix instruction may a vector instruction READ its result?  (the compiler leaves
+// 7 wait states for this instruction.)  The accumulator starts from a known value; a stale read returns it.
+#define RBODY(NOPS)                                                                                          \
+  asm volatile("v_mov_b32 v40, %1\n\tv_mov_b32 v41, %2\n\tv_mov_b32 v42, %3\n\tv_mov_b32 v43, %4\n\t"        \
+               "v_mov_b32 v44, %5\n\tv_mov_b32 v45, %6\n\tv_mov_b32 v46, %7\n\tv_mov_b32 v47, %8\n\t"        \
+               "v_mov_b32 v48, 0\n\tv_mov_b32 v49, 0\n\tv_mov_b32 v50, 0\n\tv_mov_b32 v51, 0\n\t"            \
+               "s_nop 7\n\ts_nop 7\n\t"                                                                     \
+               "v_mfma_f32_16x16x32_f16 v[48:51], v[40:43], v[44:47], v[48:51]\n\t"                            \
+               "v_mfma_f32_16x16x32_f16 v[48:51], v[44:47], v[40:43], v[48:51]\n\t" NOPS                       \
+               "v_mov_b32 %0, v48\n\t"                                                                      \
+               "s_nop 15\n\ts_nop 15\n\t"                                                                   \
+               : "=v"(got)                                                                                   \
+               : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w)              \
+               : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51");
+template <int V>
+__global__ __launch_bounds__(512) void kr(const u4* A, const u4* B, unsigned* bad, int rounds) {
+  const int lane = threadIdx.x & 63;
+  unsigned n = 0;
+  for (int r = 0; r < rounds; ++r) {
+    const u4 a = A[(r * 64 + lane) & 4095], b = B[(r * 97 + lane) & 4095];
+    float want, got;
+    RBODY("s_nop 15\n\ts_nop 15\n\t")
+    want = got;
+    if (V == 0) { RBODY("s_nop 2\n\t") }
+    if (V == 1) { RBODY("s_nop 4\n\t") }
+    if (V == 2) { RBODY("s_nop 5\n\t") }
+    if (V == 3) { RBODY("s_nop 6\n\t") }
+    if (V == 4) { RBODY("s_nop 7\n\t") }
+    if (V == 5) { RBODY("s_nop 9\n\t") }
+    if (V == 6) { RBODY("s_nop 11\n\t") }
+    if (V == 7) { RBODY("s_nop 15\n\t") }
+    n += __float_as_uint(want) != __float_as_uint(got);
+  }
+  if (n) atomicAdd(&bad[V * 64 + lane], n);
+}
+
+// ... the same read by a PACKED fp32 instruction (v_pk_mul_f32 by (1, 1) of the pair D0:D1): low and high element checked separately
+#define PBODY(NOPS)                                                                                          \
+  asm volatile("v_mov_b32 v40, %2\n\tv_mov_b32 v41, %3\n\tv_mov_b32 v42, %4\n\tv_mov_b32 v43, %5\n\t"        \
+               "v_mov_b32 v44, %6\n\tv_mov_b32 v45, %7\n\tv_mov_b32 v46, %8\n\tv_mov_b32 v47, %9\n\t"        \
+               "v_mov_b32 v48, 0\n\tv_mov_b32 v49, 0\n\tv_mov_b32 v50, 0\n\tv_mov_b32 v51, 0\n\t"            \
+               "v_mov_b32 v54, 1.0\n\tv_mov_b32 v55, 1.0\n\t"                                                \
+               "s_nop 7\n\ts_nop 7\n\t"                                                                     \
+               "v_mfma_f32_16x16x32_f16 v[48:51], v[40:43], v[44:47], v[48:51]\n\t"                            \
+               "v_mfma_f32_16x16x32_f16 v[48:51], v[44:47], v[40:43], v[48:51]\n\t" NOPS                       \
+               "v_pk_mul_f32 v[52:53], v[48:49], v[54:55]\n\t"                                                \
+               "s_nop 15\n\ts_nop 15\n\t"                                                                   \
+               "v_mov_b32 %0, v52\n\tv_mov_b32 %1, v53\n\t"                                                  \
+               : "=v"(g0), "=v"(g1)                                                                          \
+               : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w)              \
+               : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+template <int V>
+__global__ __launch_bounds__(512) void kp(const u4* A, const u4* B, unsigned* bad, int rounds) {
+  const int lane = threadIdx.x & 63;
+  unsigned n0 = 0, n1 = 0;
+  for (int r = 0; r < rounds; ++r) {
+    const u4 a = A[(r * 64 + lane) & 4095], b = B[(r * 97 + lane) & 4095];
+    float g0, g1, w0, w1;
+    PBODY("s_nop 15\n\ts_nop 15\n\t")
+    w0 = g0; w1 = g1;
+    if (V == 0) { PBODY("s_nop 5\n\t") }
+    if (V == 1) { PBODY("s_nop 6\n\t") }
+    if (V == 2) { PBODY("s_nop 7\n\t") }
+    if (V == 3) { PBODY("s_nop 8\n\t") }
+    if (V == 4) { PBODY("s_nop 10\n\t") }
+    n0 += __float_as_uint(w0) != __float_as_uint(g0);
+    n1 += __float_as_uint(w1) != __float_as_uint(g1);
+  }
+  if (n0) atomicAdd(&bad[V * 128 + lane], n0);
+  if (n1) atomicAdd(&bad[V * 128 + 64 + lane], n1);
+}
+
+int main() {
+  std::vector<u4> a(4096), b(4096);
+  uint64_t s = 88172645463325252ull;
+  auto half = [&]() -> unsigned { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return unsigned(0x3000 + ((s >> 20) & 0x0FFF)) | unsigned((s & 1) << 15); };   // |x| in [0.125, 1)
+  for (auto* v : {&a, &b})
+    for (auto& q : *v) q = u4{half() | (half() << 16), half() | (half() << 16), half() | (half() << 16), half() | (half() << 16)};
+  u4 *dA, *dB; unsigned* dbad;
+  hipMalloc(&dA, 65536); hipMalloc(&dB, 65536); hipMalloc(&dbad, 10 * 64 * 4);
+  hipMemcpy(dA, a.data(), 65536, hipMemcpyHostToDevice); hipMemcpy(dB, b.data(), 65536, hipMemcpyHostToDevice);
+  hipMemset(dbad, 0, 10 * 64 * 4);
+  const int rounds = 200;
+#define RUN(V) k<V><<<1024, 512>>>(dA, dB, dbad, rounds);
+  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9)
+  hipDeviceSynchronize();
+  std::vector<unsigned> bad(640);
+  hipMemcpy(bad.data(), dbad, 2560, hipMemcpyDeviceToHost);
+  const char* names[10] = {"A reg 0, +0 wait", "A reg 0, +1 wait", "A reg 0, +2 wait", "A reg 0, +4 wait", "A reg 0, +8 wait", "A reg 3, +0 wait",
+                           "B reg 0, +0 wait", "B reg 3, +0 wait", "B reg 3, +4 wait", "A reg 0, +16 wait"};
+  const double per_lane = 1024.0 * 8 * rounds;
+  for (int v = 0; v < 10; ++v) {
+    unsigned tot = 0; int lanes = 0, first = -1, last = -1;
+    for (int l = 0; l < 64; ++l) if (bad[v * 64 + l]) { tot += bad[v * 64 + l]; ++lanes; if (first < 0) first = l; last = l; }
+    std::printf("%-18s: %10u wrong accumulator words (D register 0) of %.0f, in %d lanes (%d..%d) -> rate %.2e per lane-product\n", names[v], tot,
+                per_lane * 64, lanes, first, last, tot / (per_lane * 64));
+  }
+  hipMemset(dbad, 0, 10 * 64 * 4);
+#define RUNR(V) kr<V><<<1024, 512>>>(dA, dB, dbad, rounds);
+  RUNR(0) RUNR(1) RUNR(2) RUNR(3) RUNR(4) RUNR(5) RUNR(6) RUNR(7)
+  hipDeviceSynchronize();
+  hipMemcpy(bad.data(), dbad, 2560, hipMemcpyDeviceToHost);
+  const int waits[8] = {3, 5, 6, 7, 8, 10, 12, 16};
+  for (int v = 0; v < 8; ++v) {
+    unsigned tot = 0; int lanes = 0, first = -1, last = -1;
+    for (int l = 0; l < 64; ++l) if (bad[v * 64 + l]) { tot += bad[v * 64 + l]; ++lanes; if (first < 0) first = l; last = l; }
+    std::printf("read of D register 0, %2d wait states behind the 2nd of two chained instructions: %10u stale of %.0f, in %d lanes (%d..%d)\n", waits[v], tot,
+                per_lane * 64, lanes, first, last);
+  }
+  hipMemset(dbad, 0, 10 * 64 * 4);
+#define RUNP(V) kp<V><<<1024, 512>>>(dA, dB, dbad, rounds);
+  RUNP(0) RUNP(1) RUNP(2) RUNP(3) RUNP(4)
+  hipDeviceSynchronize();
+  hipMemcpy(bad.data(), dbad, 2560, hipMemcpyDeviceToHost);
+  const int pw[5] = {6, 7, 8, 9, 11};
+  for (int v = 0; v < 5; ++v)
+    for (int e = 0; e < 2; ++e) {
+      unsigned tot = 0; int lanes = 0, first = -1, last = -1;
+      for (int l = 0; l < 64; ++l) if (bad[v * 128 + e * 64 + l]) { tot += bad[v * 128 + e * 64 + l]; ++lanes; if (first < 0) first = l; last = l; }
+      std::printf("packed read of D0:D1, %2d wait states, element %d: %10u stale of %.0f, in %d lanes (%d..%d)\n", pw[v], e, tot, per_lane * 64, lanes, first, last);
+    }
+  return 0;
+}

@@ -11,7 +11,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtrajsde_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize is a CORRECTNESS flag here, not a tuning one.  With the SLP vectoriser on, the compiler pairs the fp32 arithmetic
+# around the matrix products into packed instructions (v_pk_fma_f32 / v_pk_mul_f32 on register pairs shuffled together by v_pk_mov_b32),
+# and identical launches then disagree in their low-order bits: one element of a pair, in lanes 48-63 of a 16-row tile, off by the size
+# of ONE dropped split-precision term (2^-11 of it), in a few tiles per million, differently every run -- every backward call of the
+# aggregator at 64 x 128 agents, 40 % of the encoder's.  Without it: 0 differing words in 40 calls and across 8 processes; same speed
+# (forward +-0, training step -2 %).  The mechanism is not pinned down: the simple hazards measure as the compiler assumes
+# (tools/microbench/mfma_war.hip: results readable 7 wait states behind the instruction, also by packed reads; operands free at once).
+# Guards: tests/test_gpu_backward.py *_bitwise_identical, test_full_size_training_step_agrees_between_kernel_forms.  DESIGN.md section 5.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # split-precision flavour of the matrix products (csrc/tile.hpp): fp16x3 (default) or the older bf16x6
 if os.environ.get("TRAJSDE_SPLIT", "fp16x3") == "bf16x6":
     FLAGS.append("-DTSDE_SPLIT_H3=0")

@@ -80,12 +80,48 @@ class FlatGrads:
         ref = self.params[0]
         self.flat = torch.zeros(total, device=ref.device, dtype=ref.dtype)
         off = 0
+        self.views, self.offsets = [], []
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(p.grad)
+            self.offsets.append(off)
             off += p.numel()
+        self._gather = {}
 
     def zero(self) -> None:
         self.flat.zero_()
+
+    def accumulate(self, params, grads, scale) -> bool:
+        """`.grad += scale * g` for all parameters at once, when the gradients arrive as views of a few flat buffers (what the
+        stage backward entry points fill: runtime.StageRuntime._grad_buffers) and every parameter still holds the slice of
+        `flat` it was given: per source buffer one gather into this buffer's order and one fused multiply-add on the block of
+        `flat` that buffer's parameters cover -- six launches a step instead of ~250 slice pairs walked by multi-tensor kernels.
+        `params` / `grads`: parallel lists (a gradient may be None); `scale`: 0-dim tensor.  Returns False, having done
+        nothing, whenever the layout is not that simple (the caller then accumulates parameter by parameter)."""
+        by_id = {id(p): g for p, g in zip(params, grads) if g is not None}
+        if len(by_id) != len(self.params):
+            return False
+        runs = []                                        # (source flat, first offset in self.flat, [(offset in source, numel)])
+        for p, view, off in zip(self.params, self.views, self.offsets):
+            g = by_id.get(id(p))
+            if g is None or p.grad is not view or g._base is None or not g.is_contiguous() or g.numel() != p.numel() \
+                    or g.dtype != self.flat.dtype or g._base.dim() != 1:
+                return False
+            if not runs or runs[-1][0] is not g._base:
+                if any(r[0] is g._base for r in runs):
+                    return False                         # a source buffer's parameters are not one block of `flat`
+                runs.append((g._base, off, []))
+            runs[-1][2].append((g.storage_offset() - g._base.storage_offset(), p.numel()))
+        for src, first, pieces in runs:
+            key = (first, src.numel(), tuple(pieces))
+            idx = self._gather.get(key)
+            if idx is None:
+                idx = torch.cat([torch.arange(o, o + n, dtype=torch.int64) for o, n in pieces]).to(self.flat.device)
+                if len(self._gather) > 8:
+                    self._gather.clear()
+                self._gather[key] = idx
+            self.flat[first:first + idx.numel()].addcmul_(src.index_select(0, idx), scale)
+        return True
 
     def all_reduce_mean(self) -> None:
         import torch.distributed as dist
@@ -119,7 +155,10 @@ class FlatTraining:
         self._index = {id(p): i for i, p in enumerate(self._all_params)}
         self.grads = FlatGrads(params)                       # p.grad: slices of one gradient buffer, in the same order
         self.flat_param.grad = self.grads.flat
+        model._grad_sink = self.grads                        # the path loss hands its gradients over in a few launches (accumulate)
         self._stages = [m for m in model.modules() if hasattr(m, "touch")]
+        # (torch's single-kernel `fused=True` form is no gain here: its multi-tensor launch cuts ONE tensor into 64 K-element
+        # chunks, eight workgroups for this model, 109 us against 64 us for the six launches of the default form)
         self.optimizer = torch.optim.AdamW([self.flat_param], lr=model.lr, weight_decay=model.weight_decay)
         if hasattr(model, "scheduler_step"):
             self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=model.scheduler_step, gamma=model.scheduler_gamma)
@@ -212,6 +251,7 @@ class PlainTraining:
     def __init__(self, model) -> None:
         (self.optimizer,), (self.scheduler,) = model.configure_optimizers()
         self.grads = FlatGrads(model.params_with_gradient())
+        model._grad_sink = self.grads
 
     def zero(self) -> None:
         self.grads.zero()

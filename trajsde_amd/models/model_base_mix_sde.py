@@ -41,11 +41,11 @@ class _PathLoss(torch.autograd.Function):
     def forward(ctx, model, data, noise, w_l2, w_diff, *params):
         """`w_l2`: the weight of the regression loss -- L2, or LaplaceNLLLoss when the model is configured with it"""
         with torch.no_grad():
+            enc_rt, agg_rt, dec_rt = model.encoder._rt, model.aggregator._rt, model.decoder._rt
+            reg = model._regression_loss()
             # one forward per step: the encoder and aggregator run their tape-keeping forward, the backward entry points
             # then walk those tapes instead of recomputing the stage (runtime.*_forward_train)
             out, local, glob, enc_tape, agg_tape = model._forward_stages(data, noise, keep_tapes=True)
-            enc_rt, agg_rt, dec_rt = model.encoder._rt, model.aggregator._rt, model.decoder._rt
-            reg = model._regression_loss()
             if reg[0] == "LaplaceNLLLoss":
                 dec = dec_rt.decoder_nll_backward(data, local, glob, out, noise, eps=reg[1])
             else:
@@ -67,6 +67,7 @@ class _PathLoss(torch.autograd.Function):
             ctx.grads = [by_name.get(n) for n in model._param_names]          # None: no path from these losses
             ctx.direct = bool(getattr(model, "direct_grad_accumulation", True))
             ctx.params = params if ctx.direct else None
+            ctx.sink = getattr(model, "_grad_sink", None) if ctx.direct else None
             model.last_output = out
             model.last_losses = {reg[0]: dec["loss"].detach(), "DiffBCE": enc["diff_loss"].detach() / w_diff if w_diff else None}
             return (w_l2 * dec["loss"] + enc["diff_loss"]).clone()
@@ -79,6 +80,9 @@ class _PathLoss(torch.autograd.Function):
             # host time) per parameter: `.grad += g * grad`, or `.grad = ...` where there is none yet -- what autograd's
             # accumulation would have left.  The parameters then receive no gradient THROUGH autograd, so per-parameter
             # hooks (torch DDP's reducer) do not fire: `model.direct_grad_accumulation = False` restores the plain route.
+            sink = ctx.sink                                                  # driver.FlatGrads: all of it in six launches
+            if sink is not None and sink.accumulate(ctx.params, ctx.grads, g):
+                return (None,) * (5 + len(ctx.grads))
             torch._foreach_mul_(have, g)                                     # our own buffers, fresh every step
             dst, src = [], []
             for p, x in zip(ctx.params, ctx.grads):

@@ -496,11 +496,12 @@ class StageRuntime:
         return outs, (ws, ws_bytes)
 
     def encoder_backward(self, data, d_local: torch.Tensor, noise: NoiseSpec, diff_weight: float = 1.0,
-                         want_boundaries: bool = False, tape=None) -> Dict[str, object]:
+                         want_boundaries: bool = False, tape=None, keep_scratch: bool = False) -> Dict[str, object]:
         """Backward of LocalEncoderSDESepPara2.forward plus the DiffBCE term: `d_local` = dL/d local_embed [N,64],
         `noise` the forward's NoiseSpec.  Returns {"grads": {param name: tensor}, "diff_loss": diff_weight * DiffBCE}
         (+ "d_latent" [N,64], "d_aa_out" [H,Nt,64] with want_boundaries).  `tape`: what encoder_forward_train returned for
-        this very step; without it the forward is recomputed inside."""
+        this very step; without it the forward is recomputed inside.  `keep_scratch` (reproducibility checks): the backward's
+        scratch buffer starts zeroed and is returned as "_scratch"."""
         m = self.module
         if noise is None:
             raise _lib.TrajsdeError("encoder_backward needs the NoiseSpec of the forward pass")
@@ -528,7 +529,7 @@ class StageRuntime:
         # the backward's own scratch is a separate buffer, allocated only now: between the training forward and this call the
         # step holds the tape alone, and the decoder's / aggregator's workspaces have been released by the time this one is taken
         sc_bytes = L.trajsde_encoder_backward_scratch_bytes(C.byref(gc.batch), C.byref(gc.graph))
-        scratch = torch.empty(sc_bytes, device=dev, dtype=torch.uint8)
+        scratch = (torch.zeros if keep_scratch else torch.empty)(sc_bytes, device=dev, dtype=torch.uint8)
         cn = noise.c_noise(noise.z_enc, noise.enc_row_ids)
         dr = noise.c_dropout(m)                                            # the forward's masks, regenerated from the same key
         with torch.cuda.device(dev):
@@ -542,6 +543,8 @@ class StageRuntime:
         out = {"grads": grads, "diff_loss": loss[0]}
         if want_boundaries:
             out.update(d_latent=d_lat, d_aa_out=d_aa)
+        if keep_scratch:
+            out["_scratch"] = scratch
         return out
 
     def _enc_table(self) -> np.ndarray:
