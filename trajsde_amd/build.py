@@ -18,6 +18,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # aggregator at 64 x 128 agents, 40 % of the encoder's.  Without it: 0 differing words in 40 calls and across 8 processes; same speed
 # (forward +-0, training step -2 %).  The mechanism is not pinned down: the simple hazards measure as the compiler assumes
 # (tools/microbench/mfma_war.hip: results readable 7 wait states behind the instruction, also by packed reads; operands free at once).
+# (It is also what lets the operand split compile to three instructions per pair: csrc/tile.hpp split_pair.)
 # Guards: tests/test_gpu_backward.py *_bitwise_identical, test_full_size_training_step_agrees_between_kernel_forms.  DESIGN.md section 5.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # split-precision flavour of the matrix products (csrc/tile.hpp): fp16x3 (default) or the older bf16x6

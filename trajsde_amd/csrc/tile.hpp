@@ -97,34 +97,45 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
 
 typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
-// fp16x3 operand split of two values: hi = fp16(x) (round toward zero, one v_cvt_pkrtz for the pair), lo = fp16(x - hi): the residual by
-// v_dot2c_f32_f16 of the packed halves with the constant (-1, 0) / (0, -1) -- one instruction per value, reads the half in place -- rounded
-// to nearest by v_cvt_pk_f16_f32.  Four instructions per pair and NO inline assembly: every instruction is visible to the compiler's
-// scheduler and hazard recognizer.  (The dot product is exact while the fp16 piece is a normal number; below 2^-14 it is off by up to
-// 2^-13 of the residual, a quarter of what rounding lo to fp16 loses anyway: tools/microbench/dot2.hip.)
-// History, because both earlier forms were WRONG in a way no parity test sees:
-//  * rounds 2-3: v_cvt_pkrtz + v_fma_mixlo_f16 / v_fma_mixhi_f16 writing the two halves of the lo register, one inline-assembly block per
-//    k-step.  A few tiles per 10^5 came out different from run to run in their low-order bits.
-//  * then: v_cvt_pkrtz, two v_fma_mix_f32 in inline assembly (x - h straight from the packed half), v_cvt_pk_f16_f32.  Ten times rarer,
-//    still there: one column of a 16-row tile off by ~2^-11 of its smallest term in ~40 % of the encoder backward calls at 64 x 128 agents.
-//    The compiler cannot see what an asm block writes: it hands the block a result register that was an operand of a matrix instruction
-//    issued three instructions earlier (the dead weight fragment), and inserts none of the wait states it puts in front of its own
-//    instructions in that position.  Wait states inside the block do not help (8 before: same rate; after, or the result tied to an
-//    input: every call differs); the compiler-visible forms are clean in 40 calls of 40.
-//  Found by comparing identical backward calls word for word (tests/test_gpu_backward.py ..._bitwise_identical, tools/encoder_bwd_repeat.py).
-//  Cost of being right: edge attention 0.777 -> 0.795 ms (the form with two converts and a packed subtract, -DTSDE_SPLIT_SUB: 0.81-0.86).
+// fp16x3 operand split of two values: hi = fp16(x) (round toward zero, one v_cvt_pkrtz for the pair), lo = fp16(x - hi): the residual is
+// an fma of the fp16 half (extended), -1 and x -- exact in fp32 -- rounded to nearest into the lo half.  Written as plain arithmetic, the
+// compiler selects v_fma_mixlo_f16 / v_fma_mixhi_f16 for it (the half read in place, the fp32 fma and the rounding in ONE instruction
+// per value): three instructions per pair, none of them inline assembly, so all of them are seen by the scheduler and the hazard
+// recognizer.  Two things make the selection happen: the multiplier is opaque (a literal -1 folds the fma into convert + subtract), and
+// the library is built with -fno-slp-vectorize (otherwise the two fmas of a pair become one v_pk_fma_f32 behind two converts).
+// History, because the earlier forms were WRONG in a way no parity test sees (identical launches disagreeing in low-order bits; found by
+// comparing repeated backward calls word for word: tests/test_gpu_backward.py *_bitwise_identical, tools/encoder_bwd_repeat.py):
+//  * rounds 2-3: the same three instructions as ONE inline-assembly block per k-step; a few tiles per 10^5 differed from run to run.
+//  * then v_cvt_pkrtz, two inline-assembly v_fma_mix_f32, v_cvt_pk_f16_f32: ten times rarer, still there (a column of a 16-row tile off by
+//    2^-11 of its smallest term in 40 % of the encoder backward calls at 64 x 128 agents).
+//  * what all failing builds share is the SLP vectoriser (trajsde_amd/build.py FLAGS): with it off, the inline-assembly form is clean too
+//    (-DTSDE_SPLIT_ASM, 0 differing words in 40 calls) -- but an asm block stays invisible to the hazard recognizer, so it is not shipped.
+//  Edge attention alone, one box: this form 0.777 ms, the assembly form 0.771, v_dot2c_f32_f16 (-DTSDE_SPLIT_DOT2: inexact below 2^-14,
+//  tools/microbench/dot2.hip) 0.788, converts + subtract (-DTSDE_SPLIT_SUB) 0.81-0.86.
+__device__ __forceinline__ float opaque_minus_one() {
+  float m = -1.0f;
+  asm("" : "+s"(m));             // no instruction, a scalar register: nothing a vector hazard could involve
+  return m;
+}
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
   const hp2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
   float r0, r1;                                                                    // x - h, exact
   const unsigned hb = __builtin_bit_cast(unsigned, h);
   const hf2 hh = __builtin_bit_cast(hf2, h);
-#if defined(TSDE_SPLIT_SUB)
-  r0 = x0 - float(hh[0]);                                                          // two converts + a packed subtract: 5 instructions per pair
+#if defined(TSDE_SPLIT_ASM)                                                        // (experiments only: see the history above)
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
+#elif defined(TSDE_SPLIT_SUB)
+  r0 = x0 - float(hh[0]);                                                          // two converts + two subtracts
   r1 = x1 - float(hh[1]);
-#else
+#elif defined(TSDE_SPLIT_DOT2)
   const hf2 e0 = __builtin_bit_cast(hf2, 0x0000BC00u), e1 = __builtin_bit_cast(hf2, 0xBC000000u);      // (-1, 0), (0, -1)
   r0 = __builtin_amdgcn_fdot2(hh, e0, x0, false);                                  // v_dot2c_f32_f16: x0 - h[0]
   r1 = __builtin_amdgcn_fdot2(hh, e1, x1, false);
+#else
+  const float m1 = opaque_minus_one();
+  r0 = __builtin_fmaf(float(hh[0]), m1, x0);
+  r1 = __builtin_fmaf(float(hh[1]), m1, x1);
 #endif
   const hf2 l = hf2{_Float16(r0), _Float16(r1)};
   hi = hb;
@@ -594,7 +605,7 @@ __device__ __forceinline__ u4 in2_operand(float x0r, float x1r, float rstd) {
   const hp2 rh = __builtin_amdgcn_cvt_pkrtz(rstd, 0.f);
   const unsigned rhb = __builtin_bit_cast(unsigned, rh);
   float rr;                                                                        // rstd - fp16(rstd), exact
-  rr = rstd - float(__builtin_bit_cast(hf2, rh)[0]);
+  rr = __builtin_fmaf(float(__builtin_bit_cast(hf2, rh)[0]), opaque_minus_one(), rstd);
   const hf2 rl = hf2{_Float16(rr), _Float16(0.f)};
   const unsigned hr = (rhb & 0xFFFFu) | (__builtin_bit_cast(unsigned, rl) << 16);  // r_h | r_l
   return u4{h, l, hr, 0x3C003C00u};
