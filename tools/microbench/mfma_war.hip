@@ -127,6 +127,43 @@ __global__ __launch_bounds__(512) void kp(const u4* A, const u4* B, unsigned* ba
   if (n1) atomicAdd(&bad[V * 128 + 64 + lane], n1);
 }
 
+// ... write-after-read on SrcC (distinct from vDst) and write-after-write on vDst: a vector write W wait states behind the instruction
+#define CBODY(NOPS, VICTIM, JUNK)                                                                            \
+  asm volatile("v_mov_b32 v40, %1\n\tv_mov_b32 v41, %2\n\tv_mov_b32 v42, %3\n\tv_mov_b32 v43, %4\n\t"        \
+               "v_mov_b32 v44, %5\n\tv_mov_b32 v45, %6\n\tv_mov_b32 v46, %7\n\tv_mov_b32 v47, %8\n\t"        \
+               "v_mov_b32 v52, 1.0\n\tv_mov_b32 v53, 2.0\n\tv_mov_b32 v54, 4.0\n\tv_mov_b32 v55, 0.5\n\t"    \
+               "v_mov_b32 v48, 0\n\tv_mov_b32 v49, 0\n\tv_mov_b32 v50, 0\n\tv_mov_b32 v51, 0\n\t"            \
+               "s_nop 7\n\ts_nop 7\n\t"                                                                     \
+               "v_mfma_f32_16x16x32_f16 v[48:51], v[40:43], v[44:47], v[52:55]\n\t" NOPS                       \
+               "v_mov_b32 " VICTIM ", " JUNK "\n\t"                                                          \
+               "s_nop 15\n\ts_nop 15\n\t"                                                                   \
+               "v_mov_b32 %0, v48\n\t"                                                                      \
+               : "=v"(got)                                                                                   \
+               : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w)              \
+               : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56");
+template <int V>
+__global__ __launch_bounds__(512) void kc(const u4* A, const u4* B, unsigned* bad, int rounds) {
+  const int lane = threadIdx.x & 63;
+  unsigned n = 0;
+  for (int r = 0; r < rounds; ++r) {
+    const u4 a = A[(r * 64 + lane) & 4095], b = B[(r * 97 + lane) & 4095];
+    float want, got;
+    CBODY("s_nop 15\n\ts_nop 15\n\t", "v56", "0")                    // (a bystander register: the clean product)
+    want = got;
+    if (V == 0) { CBODY("", "v52", "0x42c80000") }                    // SrcC register 0, junk 100.0
+    if (V == 1) { CBODY("s_nop 1\n\t", "v52", "0x42c80000") }
+    if (V == 2) { CBODY("s_nop 3\n\t", "v52", "0x42c80000") }
+    if (V == 3) { CBODY("s_nop 7\n\t", "v52", "0x42c80000") }
+    if (V == 4) { CBODY("s_nop 11\n\t", "v52", "0x42c80000") }
+    if (V == 5) { CBODY("", "v48", "0x42c80000") }                    // vDst register 0: the product must still win
+    if (V == 6) { CBODY("s_nop 3\n\t", "v48", "0x42c80000") }
+    if (V == 7) { CBODY("s_nop 7\n\t", "v48", "0x42c80000") }
+    if (V == 8) { CBODY("s_nop 11\n\t", "v48", "0x42c80000") }
+    n += __float_as_uint(want) != __float_as_uint(got);
+  }
+  if (n) atomicAdd(&bad[V * 64 + lane], n);
+}
+
 int main() {
   std::vector<u4> a(4096), b(4096);
   uint64_t s = 88172645463325252ull;
@@ -176,5 +213,17 @@ int main() {
       for (int l = 0; l < 64; ++l) if (bad[v * 128 + e * 64 + l]) { tot += bad[v * 128 + e * 64 + l]; ++lanes; if (first < 0) first = l; last = l; }
       std::printf("packed read of D0:D1, %2d wait states, element %d: %10u stale of %.0f, in %d lanes (%d..%d)\n", pw[v], e, tot, per_lane * 64, lanes, first, last);
     }
+  hipMemset(dbad, 0, 10 * 64 * 4);
+#define RUNC(V) kc<V><<<1024, 512>>>(dA, dB, dbad, rounds);
+  RUNC(0) RUNC(1) RUNC(2) RUNC(3) RUNC(4) RUNC(5) RUNC(6) RUNC(7) RUNC(8)
+  hipDeviceSynchronize();
+  hipMemcpy(bad.data(), dbad, 2560, hipMemcpyDeviceToHost);
+  const char* cn[9] = {"SrcC reg 0, +0 wait", "SrcC reg 0, +2 wait", "SrcC reg 0, +4 wait", "SrcC reg 0, +8 wait", "SrcC reg 0, +12 wait",
+                       "vDst reg 0, +0 wait", "vDst reg 0, +4 wait", "vDst reg 0, +8 wait", "vDst reg 0, +12 wait"};
+  for (int v = 0; v < 9; ++v) {
+    unsigned tot = 0; int lanes = 0, first = -1, last = -1;
+    for (int l = 0; l < 64; ++l) if (bad[v * 64 + l]) { tot += bad[v * 64 + l]; ++lanes; if (first < 0) first = l; last = l; }
+    std::printf("vector write to %-22s: %10u wrong D0 words of %.0f, in %d lanes (%d..%d)\n", cn[v], tot, per_lane * 64, lanes, first, last);
+  }
   return 0;
 }
