@@ -377,6 +377,35 @@ def test_identical_encoder_backward_calls_are_bitwise_identical(dev):
             del w2, r
 
 
+def test_whole_training_step_repeated_is_bitwise_identical(dev):
+    """the whole training step (forward with tapes, decoder / aggregator / encoder backward, train-mode dropout) six times on one batch
+    of 32 scenes x 96 agents with the same keys: the same loss bits, trajectories and gradient words every time -- covers the decoder's
+    reverse sweep and the training forward, which the two tape-level tests above do not call"""
+    from trajsde_amd import runtime
+    from trajsde_amd.synth import synth
+    K, T = 6, 20
+    batch = synth(S=32, n=96, L=24, F=T, box=120.0, seed=19, mixed_source=True, history_dropout=0.2).to(dev)
+    y0 = batch.y.clone()
+    model, cfg = H.build_model(K, T, 2.0, init_seed=4)
+    H.perturb_parameters(model, 78)
+    model = model.to(dev).train()
+    ref = None
+    for call in range(6):
+        model.zero_grad(set_to_none=True)
+        batch.y = y0
+        loss = model.training_step(batch, 0, noise=runtime.NoiseSpec(seed=7, dropout_seed=8))
+        loss.backward()
+        torch.cuda.synchronize()
+        cur = (loss.detach().clone(), model.last_output["loc"].clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        if ref is None:
+            ref = cur
+            assert len(cur[2]) > 200 and all(bool(torch.isfinite(g).all()) for g in cur[2].values())
+            continue
+        assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]), call
+        bad = [n for n in ref[2] if not torch.equal(cur[2][n], ref[2][n])]
+        assert not bad, (call, bad[:6])
+
+
 @pytest.mark.parametrize("log2_scale", [-40, -20, 12])
 def test_gradients_scale_with_the_loss_weights(log2_scale, dev):
     """size-independent property of the backward: it is linear in the loss weights.  The 16-bit matrix products of the backward see

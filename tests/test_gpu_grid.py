@@ -282,6 +282,36 @@ def test_vanilla_training_step_in_train_mode_with_the_reference_dropout(dev):
         model.encoder._rt.encoder_grid_forward(batch.to(dev), None)          # train mode without a key is refused, never silently eval
 
 
+def test_vanilla_training_step_repeated_is_bitwise_identical(dev):
+    """the vanilla variant's whole training step (grid encoder with its temporal transformer, aggregator, MLP decoder; train mode, dropout
+    0.1) six times on one batch of 24 scenes x 64 agents with the same keys: the same loss bits, the same gradient words, the same
+    output -- the reproducibility check of tests/test_gpu_backward.py *_bitwise_identical for the entry points only this variant has"""
+    from trajsde_amd import runtime
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    from trajsde_amd.synth import synth
+    K, T = 6, 30
+    batch = synth(S=24, n=64, L=24, F=T, box=120.0, seed=17, mixed_source=True, history_dropout=0.2).to(dev)
+    y0 = batch.y.clone()
+    model = PredictionModel(**_cfg_drop(K, T, 8, 4), init_seed=3)
+    H.perturb_parameters(model, 77)
+    model = model.to(dev).train()
+    ref = None
+    for call in range(6):
+        model.zero_grad(set_to_none=True)
+        batch.y = y0
+        loss = model.training_step(batch, 0, noise=runtime.NoiseSpec(seed=5, dropout_seed=6))
+        loss.backward()
+        torch.cuda.synchronize()
+        cur = (loss.detach().clone(), model.last_output["loc"].clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        if ref is None:
+            ref = cur
+            assert len(cur[2]) > 100 and all(bool(torch.isfinite(g).all()) for g in cur[2].values())
+            continue
+        assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]), call
+        bad = [n for n in ref[2] if not torch.equal(cur[2][n], ref[2][n])]
+        assert not bad, (call, bad[:6])
+
+
 def test_vanilla_training_step_matches_end_to_end_autograd_and_trains(dev):
     from trajsde_amd import driver
     from trajsde_amd.models.model_base_mix import PredictionModel
