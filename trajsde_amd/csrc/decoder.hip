@@ -242,13 +242,21 @@ int trajsde_decoder_forward(int32_t N, int num_modes, int future_steps, const fl
   static const int dthreads = []() { const char* v = getenv("TRAJSDE_THREADS_DECODE"); const int t = v ? atoi(v) : 768; return (t >= 64 && t <= 768 && t % 64 == 0) ? t : 768; }();
   static const bool x6 = []() { const char* e = getenv("TRAJSDE_DECODE_FP32"); return !(e && atoi(e) != 0); }();
   // <=512 threads: the 256-VGPR build (no spills, 2 waves/SIMD); above: the 168-VGPR build (3 waves/SIMD)
-#define TS_DECODE(X6, MAXT, IMG, OFF)                                                                                          \
-  TS_LAUNCH((k_sde_decode<X6, MAXT>), pick_grid(ntiles, dthreads / 64), dthreads, (IMG::SIZE + (dthreads / 64) * 128) * 4, stream, blob + OFF, y0, rows, \
+  // every wave adds a 128-float slab (the step's time-conditioned biases) behind the weight image: as many waves as the 160 KB hold
+  // (the bf16x6 build's image is 1.5x the fp16x3 one: 9 waves there)
+  auto fit = [&](int image_floats) {
+    int t = dthreads;
+    while (t > 64 && (image_floats + (t / 64) * 128) * 4 > 160 * 1024) t -= 64;
+    return t;
+  };
+#define TS_DECODE(X6, MAXT, IMG, OFF, DT)                                                                                      \
+  TS_LAUNCH((k_sde_decode<X6, MAXT>), pick_grid(ntiles, (DT) / 64), (DT), (IMG::SIZE + ((DT) / 64) * 128) * 4, stream, blob + OFF, y0, rows, \
             future_steps, n_euler, step_table, out_table, min_scale, to_arg(noise), loc, state_bf16() ? 1 : 0)
-  if (x6 && dthreads <= 512) TS_DECODE(true, 512, DecSdeL6, DecBlob::SDE6);
-  else if (x6) TS_DECODE(true, 768, DecSdeL6, DecBlob::SDE6);
-  else if (dthreads <= 512) TS_DECODE(false, 512, DecSdeL, DecBlob::SDE);
-  else TS_DECODE(false, 768, DecSdeL, DecBlob::SDE);
+  const int dt6 = fit(DecSdeL6::SIZE), dt1 = fit(DecSdeL::SIZE);
+  if (x6 && dt6 <= 512) TS_DECODE(true, 512, DecSdeL6, DecBlob::SDE6, dt6);
+  else if (x6) TS_DECODE(true, 768, DecSdeL6, DecBlob::SDE6, dt6);
+  else if (dt1 <= 512) TS_DECODE(false, 512, DecSdeL, DecBlob::SDE, dt1);
+  else TS_DECODE(false, 768, DecSdeL, DecBlob::SDE, dt1);
 #undef TS_DECODE
   return TRAJSDE_OK;
 }
