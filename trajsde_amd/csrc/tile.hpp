@@ -90,8 +90,8 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 #if TSDE_SPLIT_H3
 // fp16x3: x = h + l with h = fp16(x) (round toward zero, v_cvt_pkrtz_f16_f32) and l = fp16(x - h): 22 significant bits,
-// the residual x - h is exact in fp32 (v_fma_mix_f32 straight from the packed half) and rounded to nearest.  a*b ~= a_h b_h +
-// a_h b_l + a_l b_h (three v_mfma_f32_16x16x32_f16; the dropped a_l b_l is 2^-22 relative).  2 VALU per value to split
+// the residual x - h is exact in fp32 and rounded to nearest (split_pair below).  a*b ~= a_h b_h +
+// a_h b_l + a_l b_h (three v_mfma_f32_16x16x32_f16; the dropped a_l b_l is 2^-22 relative).  1.5 VALU per value to split
 // against 5.5 for three bf16 pieces, and half the matrix instructions.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
