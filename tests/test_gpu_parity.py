@@ -214,9 +214,11 @@ def _full_size_properties(dev, name, scenes, oracle_scenes=None, seed=4242):
     assert torch.isfinite(o_big["loc"]).all() and torch.isfinite(o_big["pi"]).all()
     assert float(o_big["loc"][..., 2:].min()) > cfg["decoder"]["kwargs"]["min_scale"]
     assert tuple(o_big["loc"].shape) == (K, S * n, T, 4) and tuple(o_big["pi"].shape) == (S * n, K)
-    # the same forward again: the same bits (millions of tiles -- a timing-dependent low-order error shows up here, not on fixtures)
-    o_again = gpu(H.clone_batch(big).to(dev), noise=global_noise_spec(seed, range(S), counts, K, device=dev))
-    assert torch.equal(o_again["loc"], o_big["loc"]) and torch.equal(o_again["pi"], o_big["pi"])
+    # the same forward eight more times: the same bits (millions of tiles -- a timing-dependent low-order error shows up here, not on
+    # fixtures)
+    for _ in range(8):
+        o_again = gpu(H.clone_batch(big).to(dev), noise=global_noise_spec(seed, range(S), counts, K, device=dev))
+        assert torch.equal(o_again["loc"], o_big["loc"]) and torch.equal(o_again["pi"], o_big["pi"])
     for s in scenes:
         lo, hi = s * n, (s + 1) * n
         one = _scene_of(big, s, n, L)
