@@ -164,6 +164,46 @@ __global__ __launch_bounds__(512) void kc(const u4* A, const u4* B, unsigned* ba
   if (n) atomicAdd(&bad[V * 64 + lane], n);
 }
 
+// ... read-after-write INTO the instruction: SrcC registers 0:1 written by a packed (or a plain) multiply W wait states in front of it.
+// A = 0, so D = C: a stale read returns the old C (3.0) instead of the product (lane-dependent).
+#define SBODY(PROD, NOPS)                                                                                    \
+  asm volatile("v_mov_b32 v40, 0\n\tv_mov_b32 v41, 0\n\tv_mov_b32 v42, 0\n\tv_mov_b32 v43, 0\n\t"            \
+               "v_mov_b32 v44, %2\n\tv_mov_b32 v45, %3\n\tv_mov_b32 v46, %4\n\tv_mov_b32 v47, %5\n\t"        \
+               "v_mov_b32 v52, 0x40400000\n\tv_mov_b32 v53, 0x40400000\n\tv_mov_b32 v54, 0\n\tv_mov_b32 v55, 0\n\t" \
+               "v_mov_b32 v56, %6\n\tv_mov_b32 v57, %7\n\tv_mov_b32 v58, 2.0\n\tv_mov_b32 v59, 2.0\n\t"      \
+               "s_nop 7\n\ts_nop 7\n\t" PROD NOPS                                                           \
+               "v_mfma_f32_16x16x32_f16 v[48:51], v[40:43], v[44:47], v[52:55]\n\t"                            \
+               "s_nop 15\n\ts_nop 15\n\t"                                                                   \
+               "v_mov_b32 %0, v48\n\tv_mov_b32 %1, v49\n\t"                                                  \
+               : "=v"(g0), "=v"(g1)                                                                          \
+               : "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(x0), "v"(x1)                                    \
+               : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+#define PK "v_pk_mul_f32 v[52:53], v[56:57], v[58:59]\n\t"
+#define PL "v_mul_f32 v52, v56, v58\n\tv_mul_f32 v53, v57, v59\n\t"
+template <int V>
+__global__ __launch_bounds__(512) void ks(const u4* A, const u4* B, unsigned* bad, int rounds) {
+  const int lane = threadIdx.x & 63;
+  unsigned n0 = 0, n1 = 0;
+  for (int r = 0; r < rounds; ++r) {
+    const u4 b = B[(r * 97 + lane) & 4095];
+    const float x0 = float(lane + r % 7) + 0.25f, x1 = float(2 * lane + r % 5) + 0.5f;
+    float g0, g1;
+    if (V == 0) { SBODY(PK, "") }
+    if (V == 1) { SBODY(PK, "s_nop 0\n\t") }
+    if (V == 2) { SBODY(PK, "s_nop 1\n\t") }
+    if (V == 3) { SBODY(PK, "s_nop 2\n\t") }
+    if (V == 4) { SBODY(PK, "s_nop 4\n\t") }
+    if (V == 5) { SBODY(PL, "") }
+    if (V == 6) { SBODY(PL, "s_nop 0\n\t") }
+    if (V == 7) { SBODY(PL, "s_nop 1\n\t") }
+    if (V == 8) { SBODY(PL, "s_nop 2\n\t") }
+    n0 += g0 != 2.0f * x0;
+    n1 += g1 != 2.0f * x1;
+  }
+  if (n0) atomicAdd(&bad[V * 64 + lane], n0);
+  if (n1) atomicAdd(&bad[V * 64 + lane], n1 << 16);
+}
+
 int main() {
   std::vector<u4> a(4096), b(4096);
   uint64_t s = 88172645463325252ull;
@@ -224,6 +264,18 @@ int main() {
     unsigned tot = 0; int lanes = 0, first = -1, last = -1;
     for (int l = 0; l < 64; ++l) if (bad[v * 64 + l]) { tot += bad[v * 64 + l]; ++lanes; if (first < 0) first = l; last = l; }
     std::printf("vector write to %-22s: %10u wrong D0 words of %.0f, in %d lanes (%d..%d)\n", cn[v], tot, per_lane * 64, lanes, first, last);
+  }
+  hipMemset(dbad, 0, 10 * 64 * 4);
+#define RUNS(V) ks<V><<<1024, 512>>>(dA, dB, dbad, 40);
+  RUNS(0) RUNS(1) RUNS(2) RUNS(3) RUNS(4) RUNS(5) RUNS(6) RUNS(7) RUNS(8)
+  hipDeviceSynchronize();
+  hipMemcpy(bad.data(), dbad, 2560, hipMemcpyDeviceToHost);
+  const char* sn[9] = {"packed multiply, +0 wait", "packed multiply, +1 wait", "packed multiply, +2 wait", "packed multiply, +3 wait", "packed multiply, +5 wait",
+                       "two plain multiplies, +0 wait (1 for the first)", "two plain multiplies, +1 wait", "two plain multiplies, +2 wait", "two plain multiplies, +3 wait"};
+  for (int v = 0; v < 9; ++v) {
+    unsigned t0 = 0, t1 = 0; int first = -1, last = -1;
+    for (int l = 0; l < 64; ++l) if (bad[v * 64 + l]) { t0 += bad[v * 64 + l] & 0xFFFF; t1 += bad[v * 64 + l] >> 16; if (first < 0) first = l; last = l; }
+    std::printf("SrcC 0:1 written by %-48s: stale C0 %8u, stale C1 %8u of %d each, lanes %d..%d\n", sn[v], t0, t1, 1024 * 8 * 40 * 64, first, last);
   }
   return 0;
 }
