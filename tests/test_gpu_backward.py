@@ -597,6 +597,50 @@ def test_checkpoint_resume_retraces_the_uninterrupted_run(dev, tmp_path):
     assert set(ref_style["state_dict"]) == set(a.state_dict())           # loads into the reference model key for key
 
 
+def test_pipelined_training_loop_is_the_plain_loop(dev):
+    """driver.train prepares batch i + 1 (device copy, rotation, graph stage with its host synchronisation) on a side stream while
+    step i runs and reads each loss one step late: same losses in the same order, same log calls, same parameters bit for bit as
+    the plain loop (`model.pipeline_training = False`), over batches of different sizes"""
+    from trajsde_amd import driver
+    from trajsde_amd.synth import synth
+    base = [synth(S=2 + (k % 2), n=9 + 3 * k, L=6, F=20, box=70.0, seed=60 + k, mixed_source=True, history_dropout=0.2) for k in range(4)]
+
+    def per_epoch(epoch):
+        for b in base:
+            yield H.clone_batch(b).to(dev)                # (under the side stream in the pipelined loop)
+
+    from trajsde_amd import runtime
+    prefetched = []
+    stock = runtime.prefetch_graph
+
+    def counting(data, *args, **kw):
+        assert torch.cuda.current_stream(dev) != torch.cuda.default_stream(dev)      # on the side stream
+        prefetched.append(int(data["x"].shape[0]))
+        return stock(data, *args, **kw)
+
+    def run(pipelined):
+        m, _ = H.build_model(3, 20, 2.0, init_seed=31)
+        m.lr, m.weight_decay, m.T_max = 1e-3, 1e-4, 4
+        m = m.to(dev)
+        m.pipeline_training = pipelined
+        calls = []
+        hist = driver.train(m, per_epoch, epochs=2, seed=9, log=lambda e, i, loss, parts: calls.append((e, i, loss, sorted(parts))))
+        torch.cuda.synchronize()
+        return m, hist, calls
+    runtime.prefetch_graph = counting
+    try:
+        a, hist_a, calls_a = run(True)
+        assert prefetched == [int(b_["x"].shape[0]) for b_ in base] * 2              # every batch went through the side stream, in order
+        b, hist_b, calls_b = run(False)
+        assert len(prefetched) == 8                                                   # ... and none in the plain loop
+    finally:
+        runtime.prefetch_graph = stock
+    assert len(hist_a) == 8 and hist_a == hist_b and calls_a == calls_b
+    assert [c[:2] for c in calls_a] == [(e, i) for e in range(2) for i in range(4)]
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p, q), n
+
+
 @pytest.mark.parametrize("scale", [1e-7, 1e3])
 def test_backward_is_linear_in_the_upstream_gradient_over_many_binades(scale, dev):
     """the adjoint products run in split precision on fp16 pieces (tile.hpp linear_adj): each adjoint row is scaled by a

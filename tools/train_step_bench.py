@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--config", default="config2")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pipeline", action="store_true",
+                    help="as driver.train runs it: every step on a fresh copy of the batch, the NEXT step's copy rotated and run "
+                         "through the graph stage on the side stream right after this step was enqueued (runtime.prefetch_graph)")
     a = ap.parse_args()
     spec = CONFIGS[a.config]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,12 +41,31 @@ def main():
     batch = synth(**spec["synth"]).to(dev)
     y0 = batch.y.clone()
 
+    from trajsde_amd import runtime
+    from trajsde_amd.data import TemporalData
+    side = runtime.side_stream(dev)
+    base = {k: v for k, v in batch.as_dict().items() if not k.startswith("_")}
+    base["y"] = y0
+    nxt = [None]
+
+    def fresh(i):                                      # under the side stream: device copies of the batch, then rotation + graph stage
+        with torch.cuda.stream(side):
+            b = TemporalData(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in base.items()})
+            model.prefetch_graph(b, NoiseSpec(seed=100 + i))
+        return b
+
     def step(i):
         flat.zero()
-        batch.y = y0                                   # forward rotates y in place (MODEL:83-84)
-        loss = model.training_step(batch, i, noise=NoiseSpec(seed=100 + i))
+        if a.pipeline:
+            cur = nxt[0] if nxt[0] is not None else fresh(i)
+        else:
+            cur = batch
+            batch.y = y0                               # forward rotates y in place (MODEL:83-84)
+        loss = model.training_step(cur, i, noise=NoiseSpec(seed=100 + i))
         loss.backward()
         flat.step()
+        if a.pipeline:
+            nxt[0] = fresh(i + 1)
         return loss
 
     for i in range(a.warmup):
@@ -57,12 +79,14 @@ def main():
     ms = (time.perf_counter() - t0) / a.steps * 1e3
     torch.cuda.reset_peak_memory_stats()
     _lib.lib().trajsde_profile_mode(2)
+    nxt[0] = None
+    was_pipelined, a.pipeline = bool(a.pipeline), False
     step(999)
     torch.cuda.synchronize()
     table = _lib.profile_report()
     _lib.lib().trajsde_profile_mode(0)
     rows = sorted(((v[1], k, v[0]) for k, v in table.items()), reverse=True)
-    print(json.dumps({"config": a.config, "scenes": spec["synth"]["S"], "ms_per_train_step": ms, "host_enqueue_ms": enq,
+    print(json.dumps({"config": a.config, "pipelined": was_pipelined, "scenes": spec["synth"]["S"], "ms_per_train_step": ms, "host_enqueue_ms": enq,
                       "scenes_per_s": spec["synth"]["S"] / ms * 1e3, "loss": float(loss),
                       "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
     # roofline of the HBM-bound weight-gradient launch: the three embedding problems of every edge list (AA, AL, global)

@@ -28,6 +28,7 @@ import torch
 import yaml
 
 from trajsde_amd.models.model_base_mix_sde import resolve_class
+from trajsde_amd import runtime
 from trajsde_amd.runtime import NoiseSpec
 from trajsde_amd.synth import CONFIGS, synth
 
@@ -322,21 +323,51 @@ def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None, ckpt_p
     rank = torch.distributed.get_rank() if dist_on else 0
     rank0 = rank == 0
     history = []
+    # The loop is pipelined by one step on the host side: batch i + 1 is fetched, moved to the device, rotated and run through the
+    # graph stage on a side stream right after step i has been enqueued (runtime.prefetch_graph: the step's one host synchronisation
+    # then waits for a few small kernels instead of draining the whole step), and the loss of step i is read -- a synchronisation
+    # too -- only after step i + 1 has been enqueued.  Values, order of the log calls and checkpoints are those of the plain loop.
+    pipelined = bool(getattr(model, "pipeline_training", True)) and hasattr(model, "prefetch_graph") and model.device.type == "cuda"
+    side = runtime.side_stream(model.device) if pipelined else None
+
+    def noise_of(step_):     # every rank draws its own Philox streams (rank folded into the key); rank 0's are those of a single-GPU run
+        return NoiseSpec(seed=seed + step_ + RANK_SEED_STRIDE * rank)
+
+    def fetch(it, step_):
+        if not pipelined:
+            return next(it, None)
+        with torch.cuda.stream(side):
+            nxt = next(it, None)
+            if nxt is not None:
+                model.prefetch_graph(nxt, noise_of(step_))
+        return nxt
+
+    def settle(pending):
+        if pending is not None:
+            loss_t, epoch_, i_, parts = pending
+            history.append(float(loss_t))
+            if log:
+                log(epoch_, i_, history[-1], parts)
+
     for epoch in range(first_epoch, epochs):
         batches = batches_per_epoch(epoch)
         if dist_on:
             assert_equal_step_counts(batches)
-        for i, batch in enumerate(batches):
+        it = iter(batches)
+        batch, i, pending = fetch(it, step), 0, None
+        while batch is not None:
             flat.zero()
-            # every rank draws its own Philox streams (rank folded into the key); rank 0's are those of a single-GPU run
-            loss = model.training_step(batch, i, noise=NoiseSpec(seed=seed + step + RANK_SEED_STRIDE * rank))
+            loss = model.training_step(batch, i, noise=noise_of(step))
             loss.backward()
             flat.all_reduce_mean()
             flat.step()
-            history.append(float(loss.detach()))
-            if log:
-                log(epoch, i, history[-1], model.last_losses)
+            mine = (loss.detach(), epoch, i, dict(getattr(model, "last_losses", None) or {}))
             step += 1
+            batch = fetch(it, step)
+            settle(pending)
+            pending = mine
+            i += 1
+        settle(pending)
         scheduler.step()
         if hasattr(model, "check_range"):
             model.check_range()

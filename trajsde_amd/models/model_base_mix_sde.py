@@ -153,10 +153,11 @@ class PredictionModelSDENet(LightningHooks):
         ood = bool(getattr(self, "ood", False))                              # test.py --ood injects this flag (test.py:45-46)
         noise = runtime.NoiseSpec.resolve(noise)
         if self.rotate:
-            rotate_mat, y_rot = runtime.rotate_inputs(data)          # MODEL:76-85
-            if y_rot is not None:
-                data.y = y_rot
-            data["rotate_mat"] = rotate_mat
+            if not runtime.consume_rotation(data):
+                rotate_mat, y_rot = runtime.rotate_inputs(data)          # MODEL:76-85
+                if y_rot is not None:
+                    data.y = y_rot
+                data["rotate_mat"] = rotate_mat
         else:
             raise NotImplementedError("rotate=False is not built (shipped config: rotate: true, CFG:18)")
         prepared = None
@@ -205,13 +206,20 @@ class PredictionModelSDENet(LightningHooks):
             reached |= {f"{stage}.{n}" for n in getattr(self, stage)._rt.param_names(sid)}
         return [p for n, p in self.named_parameters() if n in reached]
 
+    def prefetch_graph(self, data, noise: "runtime.NoiseSpec") -> None:
+        """prepare `data` for the training_step that will follow with the same `noise`: rotation + graph stage on the side stream
+        (runtime.prefetch_graph; driver.train calls it for batch i + 1 right after it has enqueued step i)"""
+        enc = self.encoder
+        runtime.prefetch_graph(data, float(enc.local_radius), int(enc.historical_steps), runtime.NoiseSpec.resolve(noise))
+
     def _forward_stages(self, data, noise, keep_tapes: bool = False):
         """forward() that also hands back the two stage boundaries the backward entry points need; with `keep_tapes` the
         encoder and the aggregator run their tape-keeping forward and the tapes are returned too"""
-        rotate_mat, y_rot = runtime.rotate_inputs(data)
-        if y_rot is not None:
-            data.y = y_rot
-        data["rotate_mat"] = rotate_mat
+        if not runtime.consume_rotation(data):               # (done ahead of time by prefetch_graph)
+            rotate_mat, y_rot = runtime.rotate_inputs(data)
+            if y_rot is not None:
+                data.y = y_rot
+            data["rotate_mat"] = rotate_mat
         enc_tape = agg_tape = None
         if keep_tapes:
             (local_embed, diff_in, diff_out, label_in, label_out), enc_tape = self.encoder._rt.encoder_forward_train(data, noise)

@@ -203,6 +203,53 @@ def rotate_inputs(data) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     return rot, y_rot
 
 
+ROTATED_KEY = "_trajsde_rotated"          # set by prefetch_graph: MODEL:76-85 has been applied to this batch already, once
+_SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """the stream next batches are prepared on while the current step runs (one per device)"""
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+def prefetch_graph(data, radius: float, H: int, noise: "NoiseSpec", fake_agents: bool = True) -> None:
+    """Rotation (MODEL:76-85) and graph stage of a batch the training loop will use NEXT, on the side stream -- call it under
+    `torch.cuda.stream(side_stream(dev))`, with the batch's tensors produced on that stream as well (driver.train moves the next
+    batch to the device there).  The graph stage holds the one host synchronisation of a training step (the list lengths size the
+    tapes): taken here it waits for a few small kernels on the side stream while the main stream still holds milliseconds of the
+    current step, and the next `training_step` starts enqueueing at once -- taken inside the step the GPU idles from the last
+    optimizer kernel until the host has woken up and launched again.  Everything made here is handed to the main stream (event +
+    allocator bookkeeping); `training_step` finds the rotation marked done and the graph cached on the batch."""
+    dev = data["x"].device
+    side = torch.cuda.current_stream(dev)
+    main = torch.cuda.default_stream(dev)
+    if side == main:
+        raise _lib.TrajsdeError("prefetch_graph must run under torch.cuda.stream(runtime.side_stream(device))")
+    rot, y_rot = rotate_inputs(data)
+    if y_rot is not None:
+        data.y = y_rot
+    data["rotate_mat"] = rot
+    data[ROTATED_KEY] = True
+    gc = GraphContext.get(data, radius, H, noise, fake_agents=fake_agents, exact=True)
+    done = torch.cuda.Event()
+    done.record(side)
+    main.wait_event(done)
+    for t in list(data.as_dict().values()) + [gc.ws, gc.edges_ws, gc.rot] + list(gc._keep):
+        if torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(main)                       # freed while main-stream kernels still read it: not handed out again before they finish
+
+
+def consume_rotation(data) -> bool:
+    """True once for a batch that prefetch_graph has rotated already (the caller then skips MODEL:76-85)"""
+    if ROTATED_KEY in data:
+        del data[ROTATED_KEY]
+        return True
+    return False
+
+
 def edge_snapshots(data, historical_steps: int) -> None:
     """The encoder's side effect on the batch (ENC:88-99, 107-110): `data['edge_index_{t}']` = the edges of the EXTENDED
     edge list (edge_index plus the in-edges of the target agents re-pointed at their fake copies, node ids N..N+A-1) whose
