@@ -312,6 +312,45 @@ def test_vanilla_training_step_repeated_is_bitwise_identical(dev):
         assert not bad, (call, bad[:6])
 
 
+def test_vanilla_pipelined_training_loop_is_the_plain_loop(dev):
+    """driver.train over the vanilla variant, next batch prepared on the side stream (this variant's graph stage: no fake agents, no
+    noise) against the plain loop: the same losses and parameters bit for bit"""
+    from trajsde_amd import driver, runtime
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    from trajsde_amd.synth import synth
+    K, T = 3, 12
+    base = [synth(S=2 + (k % 2), n=8 + 3 * k, L=6, F=T, box=70.0, seed=40 + k, mixed_source=True, history_dropout=0.2) for k in range(3)]
+
+    def per_epoch(epoch):
+        for b in base:
+            yield H.clone_batch(b).to(dev)
+    prefetched, stock = [], runtime.prefetch_graph
+
+    def counting(data, *args, **kw):
+        prefetched.append(int(data["x"].shape[0]))
+        return stock(data, *args, **kw)
+
+    def run(pipelined):
+        m = PredictionModel(**_cfg_drop(K, T, 4, 2), init_seed=5)
+        m.lr, m.weight_decay, m.T_max = 1e-3, 1e-4, 4
+        m = m.to(dev)
+        m.pipeline_training = pipelined
+        hist = driver.train(m, per_epoch, epochs=2, seed=3)
+        torch.cuda.synchronize()
+        return m, hist
+    runtime.prefetch_graph = counting
+    try:
+        a, hist_a = run(True)
+        assert len(prefetched) == 6
+        b, hist_b = run(False)
+        assert len(prefetched) == 6
+    finally:
+        runtime.prefetch_graph = stock
+    assert len(hist_a) == 6 and hist_a == hist_b
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p, q), n
+
+
 def test_vanilla_training_step_matches_end_to_end_autograd_and_trains(dev):
     from trajsde_amd import driver
     from trajsde_amd.models.model_base_mix import PredictionModel

@@ -93,13 +93,20 @@ class PredictionModel(LightningHooks):
             noise = runtime.NoiseSpec.resolve(noise)
         if not self.rotate:
             raise NotImplementedError("rotate=False is not built (shipped config: rotate: true)")
-        rotate_mat, y_rot = runtime.rotate_inputs(data)
-        if y_rot is not None:
-            data.y = y_rot
-        data["rotate_mat"] = rotate_mat
+        if not runtime.consume_rotation(data):               # (done ahead of time by prefetch_graph)
+            rotate_mat, y_rot = runtime.rotate_inputs(data)
+            if y_rot is not None:
+                data.y = y_rot
+            data["rotate_mat"] = rotate_mat
         local_embed = self.encoder(data=data, noise=noise)
         global_embed = self.aggregator(data=data, local_embed=local_embed, noise=noise)
         return self.decoder(data=data, local_embed=local_embed, global_embed=global_embed)
+
+    def prefetch_graph(self, data, noise: Optional["runtime.NoiseSpec"] = None) -> None:
+        """rotation + graph stage of the batch the training loop uses next, on the side stream (runtime.prefetch_graph; this variant's
+        graph has no fake agents and does not depend on the step's noise)"""
+        enc = self.encoder
+        runtime.prefetch_graph(data, float(enc.local_radius), int(enc.historical_steps), runtime.NoiseSpec(seed=0), fake_agents=False)
 
     def params_with_gradient(self):
         from trajsde_amd import _lib
