@@ -4,6 +4,7 @@ O=$R/gpurun_out/r3train
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/tools/train_step_bench.py > $O/train_step.log 2>&1
+python3 $R/tools/train_step_bench.py --pipeline > $O/train_step_pipelined.log 2>&1
 python3 $R/tools/train_step_bench.py --config config4 > $O/train_step_config4.log 2>&1
 TRAJSDE_WGRAD_F32=1 TRAJSDE_IMMEDIATE_SUMS=1 TRAJSDE_RECUR_LEGACY=1 python3 $R/tools/train_step_bench.py > $O/train_step_round_start_forms.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kst -- python3 $R/tools/train_step_bench.py --steps 3 --warmup 1 > $O/kst.log 2>&1
