@@ -88,3 +88,21 @@ def test_build_hook_post_check_passes_on_the_built_library():
     """__graft_entry__.build()'s own check after compiling (it once compared against a stale ABI literal)"""
     import __graft_entry__ as g
     g.check_loaded()
+
+
+def test_backward_tile_kernels_compile_without_spills_and_with_the_correctness_flag(tmp_path):
+    """The builds whose results were not bit-reproducible were built with the SLP vectoriser on, and the kernels
+    that misbehaved -- the embedding-backward tile kernels of csrc/node_bwd.hip -- are exactly the ones that then spill registers.  The flag
+    must stay in the build, and every kernel of that file must keep compiling without scratch memory."""
+    import subprocess
+    from trajsde_amd import build
+    assert "-fno-slp-vectorize" in build.FLAGS
+    out = tmp_path / "node_bwd.s"
+    src = os.path.join(H.ROOT, "trajsde_amd", "csrc", "node_bwd.hip")
+    flags = [f for f in build.FLAGS if f != "-fPIC"]
+    subprocess.check_call([build.HIPCC, *flags, "--cuda-device-only", "-S", "-o", str(out), src], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN4tsde\w+):.*?; ScratchSize: (\d+)", text, flags=re.S | re.M)
+    assert len(kernels) >= 10
+    spilled = [(name[:60], int(sz)) for name, sz in kernels if int(sz) > 0]
+    assert not spilled, spilled

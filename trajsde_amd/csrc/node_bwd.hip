@@ -279,8 +279,11 @@ __device__ __forceinline__ void branch_fwd(f4 (&xh)[4], f4 (&act)[4], float& rst
 // ATTN: d emb is not read from `demb` but built here from the attention backward's per-edge scalars (bwd.hpp EdgeAttnGrad):
 //   d emb_e = Wk^T (ED_e,h q[dst_e]) + Wv^T (EA_e,h dagg[dst_e])        (h = the head of each feature)
 // -- two more transposed products per tile instead of a [E,64] row written by one kernel and read by this one.
+#ifndef TSDE_TAIL_BOUNDS             // experiments: 768 caps the registers at 168 and forces spills
+#define TSDE_TAIL_BOUNDS 512
+#endif
 template <bool ATTN>
-__global__ __launch_bounds__(512) void k_edge_embed_bwd_tail(const float* __restrict__ img, const float* __restrict__ geom,
+__global__ __launch_bounds__(TSDE_TAIL_BOUNDS) void k_edge_embed_bwd_tail(const float* __restrict__ img, const float* __restrict__ geom,
                                                              const float* __restrict__ demb, EdgeAttnGrad ag, int64_t E,
                                                              float* __restrict__ S, float* __restrict__ DEP, float* __restrict__ DSP,
                                                              float* __restrict__ vpart) {
