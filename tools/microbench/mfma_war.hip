@@ -204,6 +204,56 @@ __global__ __launch_bounds__(512) void ks(const u4* A, const u4* B, unsigned* ba
   if (n1) atomicAdd(&bad[V * 64 + lane], n1 << 16);
 }
 
+// ... packed fp32 instructions among themselves and next to plain ones, no wait states, behind a matrix instruction in flight:
+// producer -> consumer pairs (plain -> packed, packed -> plain, packed -> packed), every lane checked against the exact product
+#define VBODY(SEQ)                                                                                           \
+  asm volatile("v_mov_b32 v40, %2\n\tv_mov_b32 v41, %3\n\tv_mov_b32 v42, %4\n\tv_mov_b32 v43, %5\n\t"        \
+               "v_mov_b32 v44, %2\n\tv_mov_b32 v45, %3\n\tv_mov_b32 v46, %4\n\tv_mov_b32 v47, %5\n\t"        \
+               "v_mov_b32 v48, 0\n\tv_mov_b32 v49, 0\n\tv_mov_b32 v50, 0\n\tv_mov_b32 v51, 0\n\t"            \
+               "v_mov_b32 v56, %6\n\tv_mov_b32 v57, %7\n\tv_mov_b32 v58, 2.0\n\tv_mov_b32 v59, 4.0\n\t"      \
+               "v_mov_b32 v60, 0\n\tv_mov_b32 v61, 0\n\tv_mov_b32 v62, 0\n\tv_mov_b32 v63, 0\n\t"            \
+               "s_nop 7\n\t"                                                                                \
+               "v_mfma_f32_16x16x32_f16 v[48:51], v[40:43], v[44:47], v[48:51]\n\t" SEQ                       \
+               "s_nop 15\n\ts_nop 15\n\t"                                                                   \
+               "v_mov_b32 %0, v62\n\tv_mov_b32 %1, v63\n\t"                                                  \
+               : "=v"(g0), "=v"(g1)                                                                          \
+               : "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(x0), "v"(x1)                                    \
+               : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+template <int V>
+__global__ __launch_bounds__(512) void kv(const u4* A, const u4* B, unsigned* bad, int rounds) {
+  const int lane = threadIdx.x & 63;
+  unsigned n0 = 0, n1 = 0;
+  for (int r = 0; r < rounds; ++r) {
+    const u4 b = B[(r * 97 + lane) & 4095];
+    const float x0 = float(lane + r % 7) + 0.25f, x1 = float(2 * lane + r % 5) + 0.5f;
+    float g0, g1, w0, w1;
+    if (V == 0) {   // plain -> packed: (x0 * 2, x1 * 4) then packed (.., ..) * (2, 4)
+      VBODY("v_mul_f32 v60, v56, v58\n\tv_mul_f32 v61, v57, v59\n\tv_pk_mul_f32 v[62:63], v[60:61], v[58:59]\n\t")
+      w0 = x0 * 4.f; w1 = x1 * 16.f;
+    }
+    if (V == 1) {   // packed -> plain
+      VBODY("v_pk_mul_f32 v[60:61], v[56:57], v[58:59]\n\tv_mul_f32 v62, v60, v58\n\tv_mul_f32 v63, v61, v59\n\t")
+      w0 = x0 * 4.f; w1 = x1 * 16.f;
+    }
+    if (V == 2) {   // packed -> packed
+      VBODY("v_pk_mul_f32 v[60:61], v[56:57], v[58:59]\n\tv_pk_mul_f32 v[62:63], v[60:61], v[58:59]\n\t")
+      w0 = x0 * 4.f; w1 = x1 * 16.f;
+    }
+    if (V == 3) {   // packed -> packed fma with op_sel_hi broadcast (what the adjoint scaling compiles to)
+      VBODY("v_pk_mul_f32 v[60:61], v[56:57], v[58:59]\n\tv_pk_fma_f32 v[62:63], v[60:61], v[58:59], 0 op_sel_hi:[1,0,0]\n\t")
+      w0 = x0 * 4.f; w1 = x1 * 8.f;
+    }
+    if (V == 4) {   // packed mov shuffle of a packed result: v62 = v61, v63 = v60
+      VBODY("v_pk_mul_f32 v[60:61], v[56:57], v[58:59]\n\tv_pk_mov_b32 v[62:63], v[60:61], v[60:61] op_sel:[1,0]\n\t")
+      w0 = x1 * 4.f; w1 = x0 * 2.f;
+    }
+    n0 += g0 != w0;
+    n1 += g1 != w1;
+  }
+  if (n0) atomicAdd(&bad[V * 64 + lane], n0);
+  if (n1) atomicAdd(&bad[V * 64 + lane], n1 << 16);
+}
+
 int main() {
   std::vector<u4> a(4096), b(4096);
   uint64_t s = 88172645463325252ull;
@@ -276,6 +326,17 @@ int main() {
     unsigned t0 = 0, t1 = 0; int first = -1, last = -1;
     for (int l = 0; l < 64; ++l) if (bad[v * 64 + l]) { t0 += bad[v * 64 + l] & 0xFFFF; t1 += bad[v * 64 + l] >> 16; if (first < 0) first = l; last = l; }
     std::printf("SrcC 0:1 written by %-48s: stale C0 %8u, stale C1 %8u of %d each, lanes %d..%d\n", sn[v], t0, t1, 1024 * 8 * 40 * 64, first, last);
+  }
+  hipMemset(dbad, 0, 10 * 64 * 4);
+#define RUNV(V) kv<V><<<1024, 512>>>(dA, dB, dbad, 40);
+  RUNV(0) RUNV(1) RUNV(2) RUNV(3) RUNV(4)
+  hipDeviceSynchronize();
+  hipMemcpy(bad.data(), dbad, 2560, hipMemcpyDeviceToHost);
+  const char* vn[5] = {"plain -> packed", "packed -> plain", "packed -> packed", "packed -> packed fma (op_sel_hi)", "packed -> v_pk_mov_b32 (op_sel)"};
+  for (int v = 0; v < 5; ++v) {
+    unsigned t0 = 0, t1 = 0;
+    for (int l = 0; l < 64; ++l) { t0 += bad[v * 64 + l] & 0xFFFF; t1 += bad[v * 64 + l] >> 16; }
+    std::printf("back to back, behind a matrix instruction: %-36s wrong element 0 %8u, element 1 %8u of %d each\n", vn[v], t0, t1, 1024 * 8 * 40 * 64);
   }
   return 0;
 }
