@@ -336,10 +336,11 @@ def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None, ckpt_p
     def fetch(it, step_):
         if not pipelined:
             return next(it, None)
+        main = torch.cuda.current_stream(model.device)        # the stream the steps run on: what is prepared is handed to it
         with torch.cuda.stream(side):
             nxt = next(it, None)
             if nxt is not None:
-                model.prefetch_graph(nxt, noise_of(step_))
+                model.prefetch_graph(nxt, noise_of(step_), main_stream=main)
         return nxt
 
     def settle(pending):

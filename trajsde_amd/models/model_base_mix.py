@@ -102,11 +102,12 @@ class PredictionModel(LightningHooks):
         global_embed = self.aggregator(data=data, local_embed=local_embed, noise=noise)
         return self.decoder(data=data, local_embed=local_embed, global_embed=global_embed)
 
-    def prefetch_graph(self, data, noise: Optional["runtime.NoiseSpec"] = None) -> None:
+    def prefetch_graph(self, data, noise: Optional["runtime.NoiseSpec"] = None, main_stream=None) -> None:
         """rotation + graph stage of the batch the training loop uses next, on the side stream (runtime.prefetch_graph; this variant's
         graph has no fake agents and does not depend on the step's noise)"""
         enc = self.encoder
-        runtime.prefetch_graph(data, float(enc.local_radius), int(enc.historical_steps), runtime.NoiseSpec(seed=0), fake_agents=False)
+        runtime.prefetch_graph(data, float(enc.local_radius), int(enc.historical_steps), runtime.NoiseSpec(seed=0), fake_agents=False,
+                               main_stream=main_stream)
 
     def params_with_gradient(self):
         from trajsde_amd import _lib

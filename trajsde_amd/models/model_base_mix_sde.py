@@ -206,11 +206,12 @@ class PredictionModelSDENet(LightningHooks):
             reached |= {f"{stage}.{n}" for n in getattr(self, stage)._rt.param_names(sid)}
         return [p for n, p in self.named_parameters() if n in reached]
 
-    def prefetch_graph(self, data, noise: "runtime.NoiseSpec") -> None:
+    def prefetch_graph(self, data, noise: "runtime.NoiseSpec", main_stream=None) -> None:
         """prepare `data` for the training_step that will follow with the same `noise`: rotation + graph stage on the side stream
         (runtime.prefetch_graph; driver.train calls it for batch i + 1 right after it has enqueued step i)"""
         enc = self.encoder
-        runtime.prefetch_graph(data, float(enc.local_radius), int(enc.historical_steps), runtime.NoiseSpec.resolve(noise))
+        runtime.prefetch_graph(data, float(enc.local_radius), int(enc.historical_steps), runtime.NoiseSpec.resolve(noise),
+                               main_stream=main_stream)
 
     def _forward_stages(self, data, noise, keep_tapes: bool = False):
         """forward() that also hands back the two stage boundaries the backward entry points need; with `keep_tapes` the

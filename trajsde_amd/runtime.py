@@ -215,7 +215,7 @@ def side_stream(device) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[key]
 
 
-def prefetch_graph(data, radius: float, H: int, noise: "NoiseSpec", fake_agents: bool = True) -> None:
+def prefetch_graph(data, radius: float, H: int, noise: "NoiseSpec", fake_agents: bool = True, main_stream=None) -> None:
     """Rotation (MODEL:76-85) and graph stage of a batch the training loop will use NEXT, on the side stream -- call it under
     `torch.cuda.stream(side_stream(dev))`, with the batch's tensors produced on that stream as well (driver.train moves the next
     batch to the device there).  The graph stage holds the one host synchronisation of a training step (the list lengths size the
@@ -225,7 +225,7 @@ def prefetch_graph(data, radius: float, H: int, noise: "NoiseSpec", fake_agents:
     allocator bookkeeping); `training_step` finds the rotation marked done and the graph cached on the batch."""
     dev = data["x"].device
     side = torch.cuda.current_stream(dev)
-    main = torch.cuda.default_stream(dev)
+    main = main_stream if main_stream is not None else torch.cuda.default_stream(dev)      # the stream the training step runs on
     if side == main:
         raise _lib.TrajsdeError("prefetch_graph must run under torch.cuda.stream(runtime.side_stream(device))")
     rot, y_rot = rotate_inputs(data)
