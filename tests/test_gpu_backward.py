@@ -597,6 +597,46 @@ def test_checkpoint_resume_retraces_the_uninterrupted_run(dev, tmp_path):
     assert set(ref_style["state_dict"]) == set(a.state_dict())           # loads into the reference model key for key
 
 
+def test_prefetched_batch_gives_the_forward_of_the_plain_batch(dev):
+    """runtime.prefetch_graph on a side stream (rotation + graph stage ahead of time), then the model's forward in eval mode and a
+    training step: the outputs, loss and gradients of the same calls on an untouched copy of the batch, bit for bit; the rotation is
+    applied once (the marker is consumed); on the stream the step runs on the call is refused"""
+    from trajsde_amd import runtime
+    from trajsde_amd.synth import synth
+    base = synth(S=3, n=14, L=6, F=20, box=70.0, seed=88, mixed_source=True, history_dropout=0.2)
+    model, _ = H.build_model(3, 20, 2.0, init_seed=12)
+    model = model.to(dev)
+    side = runtime.side_stream(dev)
+
+    def fresh(prefetch, noise):
+        if not prefetch:
+            return H.clone_batch(base).to(dev)
+        with torch.cuda.stream(side):
+            b = H.clone_batch(base).to(dev)
+            model.prefetch_graph(b, noise, main_stream=torch.cuda.default_stream(dev))
+        assert runtime.ROTATED_KEY in b
+        return b
+    noise = runtime.NoiseSpec(seed=33, dropout_seed=34)
+    model.eval()
+    with torch.no_grad():
+        plain, pre = fresh(False, noise), fresh(True, noise)
+        o_plain, o_pre = model(plain, noise=noise), model(pre, noise=noise)
+    assert runtime.ROTATED_KEY not in pre and torch.equal(pre.y, plain.y) and torch.equal(pre["rotate_mat"], plain["rotate_mat"])
+    assert torch.equal(o_pre["loc"], o_plain["loc"]) and torch.equal(o_pre["pi"], o_plain["pi"])
+    model.train()
+    grads = []
+    for prefetch in (False, True):
+        model.zero_grad(set_to_none=True)
+        loss = model.training_step(fresh(prefetch, noise), 0, noise=noise)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append((loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(grads[0][0], grads[1][0])
+    assert all(torch.equal(grads[0][1][n], grads[1][1][n]) for n in grads[0][1])
+    with pytest.raises(Exception, match="side_stream"):
+        model.prefetch_graph(H.clone_batch(base).to(dev), noise)          # not under the side stream
+
+
 def test_pipelined_training_loop_is_the_plain_loop(dev):
     """driver.train prepares batch i + 1 (device copy, rotation, graph stage with its host synchronisation) on a side stream while
     step i runs and reads each loss one step late: same losses in the same order, same log calls, same parameters bit for bit as
