@@ -255,7 +255,8 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
   stage_blob(lds, img_g, EL::LDS_SIZE);
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
-  const int64_t nstreams = (E + C - 1) / C;
+  const StreamMap smap = stream_map(C);
+  const int64_t nstreams = stream_count(E, C);
   const int64_t wid = xcd_block() * waves + wave;          // xcd_grid launch: consecutive streams (same snapshot, same scene) share an L2
   if (wid * (16 * NT) >= nstreams) return;                 // whole wave beyond the list (uniform)
   if (NT == 2 && ((wave >> 2) & 1)) {                      // see k_edge_kv: start every other wave of a SIMD half a tile late
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
   for (int t = 0; t < NT; ++t) {
     seg_reset(S[t]);
     sid[t] = wid * (16 * NT) + 16 * t + L.n;
-    base_e[t] = sid[t] * C;
+    base_e[t] = stream_base(smap, sid[t]);
     cur[t] = -1;
     rank0[t] = 0;
   }
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
 #else
   NoStamps st;
 #endif
-  for (int it = 0; it < C; ++it) {
+  const int Cw = stream_length(smap, wid * (16 * NT));     // a wave's 16 NT streams are equally long
+  for (int it = 0; it < Cw; ++it) {
     keep_lds_reads_here();
     f4 ge[NT];
     int d[NT];
@@ -560,7 +562,8 @@ __global__ __launch_bounds__(512) void k_edge_attn2p(const float* __restrict__ i
   stage_blob(lds, img_g, EL::LDS_SIZE);
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
-  const int64_t nstreams = (E + C - 1) / C;
+  const StreamMap smap = stream_map(C);
+  const int64_t nstreams = stream_count(E, C);
   const int64_t wid = xcd_block() * waves + wave;
   if (wid * (16 * NT) >= nstreams) return;
   SegState S[NT];
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(512) void k_edge_attn2p(const float* __restrict__ i
   for (int t = 0; t < NT; ++t) {
     seg_reset(S[t]);
     sid[t] = wid * (16 * NT) + 16 * t + L.n;
-    base_e[t] = sid[t] * C;
+    base_e[t] = stream_base(smap, sid[t]);
     cur[t] = -1;
     const int64_t c = base_e[t] < E ? base_e[t] : E - 1;
     ng[t] = *reinterpret_cast<const f4*>(geom + 4 * c);
@@ -583,10 +586,11 @@ __global__ __launch_bounds__(512) void k_edge_attn2p(const float* __restrict__ i
   // ---- the vector stages of tile t, as atoms -------------------------------------------------------------------------------------
   // adv: edge `nit` of the tile's stream enters: its geometry (loaded one edge ahead), the next edge's loads, and -- when the
   // row's target changes -- the record of the finished segment part and the new target's query row (k_edge_attn2)
+  const int Cw = stream_length(smap, wid * (16 * NT));     // a wave's 16 NT streams are equally long
   auto adv = [&](auto TT, int nit) {
     constexpr int t = decltype(TT)::value;
     const int64_t e = base_e[t] + nit;
-    T[t].ok = nit < C && e < E;
+    T[t].ok = nit < Cw && e < E;
     T[t].ge = ng[t];
     T[t].d = nd[t];
     asm volatile("" : "+v"(T[t].ge), "+v"(T[t].d));         // the previous loads are consumed here (see k_edge_attn2)
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(512) void k_edge_attn2p(const float* __restrict__ i
   adv(T1{}, 0);
   v1(T1{}, std::integral_constant<int, 0>{});
   v1(T1{}, std::integral_constant<int, 1>{});
-  for (int it = 0; it < C; ++it) {
+  for (int it = 0; it < Cw; ++it) {
     keep_lds_reads_here();
     // A.V1 | B.M1
     pipe_cluster_in2<2>(T[1], lds + EL::A_F, lds + EL::B_F, L.lane, [&](auto J) { v1(T0{}, J); });
@@ -759,7 +763,8 @@ __global__ __launch_bounds__(256) void k_seg_merge(const int32_t* __restrict__ s
   const int beg = segptr[node], end = segptr[node + 1];
   float out = 0.f, m_out = 0.f, inv_out = 0.f;
   if (end > beg) {
-    const int c0 = beg / C, c1 = (end - 1) / C;
+    const StreamMap smap = stream_map(C);
+    const int c0 = int(stream_of(smap, beg)), c1 = int(stream_of(smap, end - 1));
     // index of this feature's (m, s) inside a record: by lane group and tile quad (k_edge_attn2), or by 8-feature slot (k_edge_attn3)
     const int ms = rec_layout ? (lane >> 3) : 4 * ((lane >> 2) & 3) + (lane >> 4);
     const float* r = rec + (node + c0) * SEG_REC;
@@ -1140,7 +1145,8 @@ __global__ __launch_bounds__(512) void k_node_update(const float* __restrict__ i
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) a[jt] = f4{0.f, 0.f, 0.f, 0.f};
       if (end > beg) {
-        const int c0 = beg / C, c1 = (end - 1) / C;
+        const StreamMap smap = stream_map(C);
+        const int c0 = int(stream_of(smap, beg)), c1 = int(stream_of(smap, end - 1));
         const float* rr = mg.rec + (r + c0) * SEG_REC;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) a[jt] = *reinterpret_cast<const f4*>(rr + 16 * jt + 4 * L.g);

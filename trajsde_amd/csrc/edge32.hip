@@ -196,10 +196,11 @@ __global__ __launch_bounds__(512) void k_edge_attn3(const float* __restrict__ im
   stage_blob(lds, img_g, EL::LDS_SIZE);
   const int lane = threadIdx.x & 63, n = lane & 31, hh = lane >> 5;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
-  const int64_t nstreams = (E + C - 1) / C;
+  const StreamMap smap = stream_map(C);
+  const int64_t nstreams = stream_count(E, C);
   const int64_t wid = xcd_block() * waves + wave;          // xcd_grid launch: consecutive streams share an L2
   if (wid * 32 >= nstreams) return;                        // whole wave beyond the list (uniform)
-  const int64_t sid = wid * 32 + n, base_e = sid * C;      // this lane's row: its stream and the stream's first edge
+  const int64_t sid = wid * 32 + n, base_e = stream_base(smap, sid);      // this lane's row: its stream and the stream's first edge
   SegState32 S;
   seg_reset32(S);
   int cur = -1, rank0 = 0;                                 // current target; DROP: first edge of that target (mask counter = rank)
@@ -219,10 +220,13 @@ __global__ __launch_bounds__(512) void k_edge_attn3(const float* __restrict__ im
     if (DROP) nrank = segptr[nd];
   }
   if (PP && (wave & 4)) phase_sync();                      // the second wave of every SIMD runs one phase behind (phase_sync)
-  for (int it = 0; it < C; ++it) {
+  // every wave walks the LONGER stream length: the phase barriers of the ping-pong form count iterations, and a wave whose streams
+  // are the shorter ones (kernels.hpp StreamMap) idles through the rest with its rows masked
+  const int Cw = stream_length(smap, wid * 32);
+  for (int it = 0; it < smap.Co; ++it) {
     keep_lds_reads_here();
     const int64_t e = base_e + it;
-    const bool ok = e < E;
+    const bool ok = it < Cw && e < E;
     const f4 ge = ng;
     const int d = nd;
     if (ok && d != cur) {                                  // the row's target changes: its finished segment part leaves

@@ -23,7 +23,7 @@ constexpr int SEG_REC = 96;                       // acc[64] | m[16] | s[16]
 constexpr int SEG_STREAMS_512 = 256 * 8 * 32;     // 256 CUs x 8 waves x 32 rows: every wave of a resident 512-thread grid owns 32 streams
 struct AttnPlan {
   int C;                                          // edges per stream
-  int64_t nstreams;                               // ceil(E / C)
+  int64_t nstreams;                               // stream_count(E, C): whole blocks of 256
   int64_t rec_slots(int64_t targets) const { return targets + nstreams + 1; }
 };
 // the list length of a launch: known on the host (dev == null), or only an upper bound `E` with the true value on the device
@@ -39,6 +39,40 @@ __device__ __forceinline__ int stream_len(const EdgeCount& c, int64_t E, int C_h
   const int C = int((E + c.streams_target - 1) / c.streams_target);
   return C < 1 ? 1 : C;
 }
+// Streams are NOT equally long.  The list is cut into blocks of 256 streams and 256 C edges -- one workgroup of the fused edge attention
+// (8 waves x 32 rows) --, and inside a block the first 128 streams (the four waves that reach their SIMDs first) are Co = 2 C - Cy long,
+// the last 128 (the waves that share those SIMDs as the younger ones) Cy ~ 3/4 C.  A SIMD serves its older wave first (DESIGN section 5,
+// finding 2): with equal streams the older waves of the one resident round finish at 2/3 of the kernel's time and the younger ones run the
+// last third alone; giving the older waves 5/8 of the edges makes both finish together (-4.5 % on the kernel; 60 % / 88 % for the
+// younger streams measured worse).  Everything that maps edges to streams goes through these three functions.
+struct StreamMap {
+  int C, Co, Cy;
+};
+__host__ __device__ __forceinline__ StreamMap stream_map(int C) {
+#ifdef TSDE_EQUAL_STREAMS
+  return StreamMap{C, C, C};
+#else
+#ifndef TSDE_STREAM_SHORT_PCT
+#define TSDE_STREAM_SHORT_PCT 75
+#endif
+  int Cy = (TSDE_STREAM_SHORT_PCT * C + 50) / 100;
+  Cy = Cy < 1 ? 1 : (Cy > C ? C : Cy);
+  return StreamMap{C, 2 * C - Cy, Cy};
+#endif
+}
+__host__ __device__ __forceinline__ int64_t stream_count(int64_t E, int C) {      // whole blocks: some streams of the last one are empty
+  const int64_t per_block = int64_t(256) * C;
+  return (E + per_block - 1) / per_block * 256;
+}
+__device__ __forceinline__ int64_t stream_base(const StreamMap& m, int64_t s) {   // first edge of stream s
+  const int r = int(s & 255);
+  return (s >> 8) * (int64_t(256) * m.C) + (r < 128 ? int64_t(r) * m.Co : int64_t(128) * m.Co + int64_t(r - 128) * m.Cy);
+}
+__device__ __forceinline__ int stream_length(const StreamMap& m, int64_t s) { return (s & 255) < 128 ? m.Co : m.Cy; }
+__device__ __forceinline__ int64_t stream_of(const StreamMap& m, int64_t e) {     // the stream that holds edge e
+  const int64_t per_block = int64_t(256) * m.C, blk = e / per_block, r = e - blk * per_block, half = int64_t(128) * m.Co;
+  return blk * 256 + (r < half ? r / m.Co : 128 + (r - half) / m.Cy);
+}
 // The records of the fused edge attention (16-row-tile layout) merged by the kernel that consumes the aggregate (k_node_update)
 // instead of by k_seg_merge: rec == nullptr means "read the agg rows".  cv: the per-target constant of the v rows (EdgeL6F::CV).
 struct SegMerge {
@@ -53,7 +87,7 @@ inline AttnPlan attn_plan(int64_t E, int streams_target = SEG_STREAMS_512) {
   AttnPlan p;
   p.C = int((E + streams_target - 1) / streams_target);
   if (p.C < 1) p.C = 1;
-  p.nstreams = (E + p.C - 1) / p.C;
+  p.nstreams = stream_count(E, p.C);
   return p;
 }
 template <int NT, bool DROP, bool SAVE, int LIST>
