@@ -153,13 +153,14 @@ template __global__ void k_edge_kv2<768>(const float*, const float*, const int32
 // logits (288 B per edge, written once and read once: 2 x 2 GB per forward at 32 scenes x 256 agents) never reach HBM.
 //
 // Layout ("one edge stream per tile row").  The compacted edge list is sorted by target.  It is cut into `nstreams` chunks
-// of exactly C consecutive edges (the last one shorter); row n of a wave's tile walks chunk `stream(n)` front to back, one
+// of consecutive edges -- 2C - Cy or Cy of them, by the stream's place in its block of 256 (kernels.hpp StreamMap: the waves a SIMD
+// serves first get the longer ones) --; row n of a wave's tile walks chunk `stream(n)` front to back, one
 // edge per tile iteration.  A tile iteration is the same 16-row matrix work as before (embedding, lin_k | lin_v), but its 16
 // rows are 16 DIFFERENT streams -- so the online softmax of a row is lane-local: lane (n, g) owns features 16jt+4g+c of row n,
 // which belong to head 2jt + (g>>1), and keeps the running (m, s) of those heads and the running weighted sum of its 16 value
 // features in registers across iterations.  No cross-lane reduction beyond the per-head dot product that the logits always
-// needed, no segmented scan, no atomics.  Every stream has the same length, so all rows of all waves run the same number of
-// iterations: balanced by construction, whatever the in-degree distribution.
+// needed, no segmented scan, no atomics.  The 32 streams of a wave have the same length, so all its rows run the same number of
+// iterations, whatever the in-degree distribution.
 //
 // When a row's target changes (and at the end of its chunk) the row flushes one RECORD -- acc[64] | m[16] | s[16], 384 B -- to
 // slot (target + stream): along the edge list either the target or the stream advances between consecutive records, so the
