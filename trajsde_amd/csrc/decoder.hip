@@ -92,7 +92,14 @@ __global__ __launch_bounds__(MAXT) void k_sde_decode(const float* __restrict__ b
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (rows + 15) / 16;
-  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+  // Tiles are dealt in blocks: workgroup b owns a contiguous share of them and hands them to its waves in rounds, wave 0 first -- so when
+  // the share is not a multiple of the wave count, the extra tiles go to the waves with the lowest index, the ones that reach their SIMDs
+  // first and are served first (findings 2 and 9).  A grid-stride deal gives those tiles to whole workgroups instead.
+  const int64_t share = ntiles / gridDim.x, extra = ntiles % gridDim.x;
+  const int64_t first = int64_t(blockIdx.x) * share + (int64_t(blockIdx.x) < extra ? int64_t(blockIdx.x) : extra);
+  const int64_t mine = share + (int64_t(blockIdx.x) < extra ? 1 : 0);
+  for (int64_t p = wave; p < mine; p += waves) {
+    const int64_t tile = first + p;
     const int64_t row = tile * 16 + L.n;
     const int64_t r = row < rows ? row : rows - 1;
     f4 y[4], prev[4];
