@@ -18,6 +18,140 @@ def test_library_exports_every_declared_symbol(repo_root):
     assert lib.trajsde_abi_version() == _lib.ABI_VERSION == 9
 
 
+# ---- prototype-level check: names alone would let an argument added on one side only slip through ----------
+_STRUCTS = {"trajsde_batch": "Batch", "trajsde_graph": "Graph", "trajsde_noise": "Noise", "trajsde_dropout": "Dropout"}
+
+
+def _header_prototypes(text):
+    """{name: (return type, [parameter type strings])} of every `trajsde_*` function the header declares (comments stripped)"""
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z_0-9 ]*?[ \*]+)\b(trajsde_[a-z_0-9]+)\s*\(([^()]*)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        params = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?[\* ])([A-Za-z_][A-Za-z_0-9]*)$", a)                 # type, then the parameter's name
+                params.append((mm.group(1) if mm else a).strip())
+        protos[name] = (ret, params)
+    return protos
+
+
+def _ctypes_class(t):
+    """what a ctypes entry says about an argument: ('struct', name) | ('ptr',) | ('scalar', C spelling)"""
+    import ctypes as C
+    from trajsde_amd import _lib
+    scal = {C.c_int: "int", C.c_int32: "int32_t", C.c_int64: "int64_t", C.c_float: "float", C.c_uint64: "uint64_t",
+            C.c_uint32: "uint32_t"}
+    if C.c_int32 is C.c_int:                       # same object on this platform: `int` and `int32_t` are one C type as well
+        scal[C.c_int] = "int"
+    if t in (C.c_void_p, C.c_char_p):
+        return ("ptr",)
+    if t in scal:
+        return ("scalar", scal[t])
+    if hasattr(t, "_type_"):                       # POINTER(x)
+        inner = t._type_
+        for cname, pyname in _STRUCTS.items():
+            if inner is getattr(_lib, pyname):
+                return ("struct", cname)
+        return ("ptr",)
+    raise AssertionError(f"unmapped ctypes type {t}")
+
+
+def _check_against_header(signatures, protos):
+    """Python-side comparison: argument COUNTS, scalar-vs-pointer classes and which struct a struct pointer points at."""
+    problems = []
+    for name, (res, args) in signatures.items():
+        ret, params = protos[name]
+        if len(params) != len(args):
+            problems.append(f"{name}: header has {len(params)} parameters, ctypes {len(args)}")
+            continue
+        for i, (ptype, ctype) in enumerate(zip(params, args)):
+            cls = _ctypes_class(ctype)
+            is_ptr = "*" in ptype
+            base = re.sub(r"\bconst\b|\*", " ", ptype).split()
+            base = base[0] if base else ""
+            if cls[0] == "scalar":
+                same_int = {cls[1], base} <= {"int", "int32_t"}
+                if is_ptr or (base != cls[1] and not same_int):
+                    problems.append(f"{name} arg {i}: header `{ptype}`, ctypes {cls[1]}")
+            elif cls[0] == "struct":
+                if not is_ptr or base != cls[1]:
+                    problems.append(f"{name} arg {i}: header `{ptype}`, ctypes POINTER({cls[1]})")
+            else:
+                if not is_ptr or base in _STRUCTS:
+                    problems.append(f"{name} arg {i}: header `{ptype}`, ctypes void pointer")
+    return problems
+
+
+def _prototype_tu(signatures, protos):
+    """A C translation unit that includes the header and assigns every entry point to a function pointer of the type the ctypes
+    table implies: scalars spelled from the ctypes entry, pointers spelled as the header spells them (ctypes cannot say more
+    about a pointer than that it is one).  gcc -Werror=incompatible-pointer-types then rejects a differing count or scalar."""
+    import ctypes as C
+    out = ['#include "trajsde_hip.h"', ""]
+    ret_of = {C.c_char_p: "const char*", C.c_int: "int", C.c_int64: "int64_t", C.c_float: "float"}
+    for name, (res, args) in signatures.items():
+        _, params = protos[name]
+        spelled = []
+        for i, ctype in enumerate(args):
+            cls = _ctypes_class(ctype)
+            if cls[0] == "scalar":
+                spelled.append(cls[1])
+            elif cls[0] == "struct":
+                hdr = params[i] if i < len(params) else ""
+                spelled.append(("const " if "const" in hdr else "") + cls[1] + "*")
+            else:
+                spelled.append(params[i] if i < len(params) and "*" in params[i] else "void*")
+        out.append(f"static {ret_of[res]} (*const check_{name})({', '.join(spelled) or 'void'}) = {name};")
+    out.append("int main(void) { return 0; }")
+    return "\n".join(out) + "\n"
+
+
+def _compile_tu(tu_text, tmp_path, repo_root, tag):
+    import subprocess
+    src = tmp_path / f"abi_{tag}.c"
+    src.write_text(tu_text)
+    return subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-Werror=incompatible-pointer-types", "-Werror=int-conversion",
+                           "-Wno-unused-variable", "-I", os.path.join(repo_root, "include"), str(src)],
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def test_ctypes_signatures_match_the_header_prototypes(repo_root, tmp_path):
+    """every `_lib.SIGNATURES` entry against the PROTOTYPE in include/trajsde_hip.h: argument count, scalar types
+    (int / int32_t / int64_t / float ...), pointer-ness and pointed-to struct -- compared in Python and by the C compiler"""
+    from trajsde_amd import _lib
+    header = open(os.path.join(repo_root, "include", "trajsde_hip.h")).read()
+    protos = _header_prototypes(header)
+    assert set(protos) == set(_lib.SIGNATURES)
+    assert _check_against_header(_lib.SIGNATURES, protos) == []
+    r = _compile_tu(_prototype_tu(_lib.SIGNATURES, protos), tmp_path, repo_root, "ok")
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_the_prototype_check_fails_when_one_side_changes(repo_root, tmp_path):
+    """teeth of the check above: an argument added, dropped or retyped on the ctypes side only must be caught by BOTH legs"""
+    import ctypes as C
+    from trajsde_amd import _lib
+    header = open(os.path.join(repo_root, "include", "trajsde_hip.h")).read()
+    protos = _header_prototypes(header)
+    res, args = _lib.SIGNATURES["trajsde_decoder_forward"]
+    edits = {"extra argument": list(args) + [C.c_int], "dropped argument": list(args)[:-1],
+             "int64 where the header says float": [C.c_int64 if a is C.c_float else a for a in args],
+             "int32 where the header says int64": [C.c_int32 if a is C.c_int64 else a for a in args]}
+    for what, new_args in edits.items():
+        sig = dict(_lib.SIGNATURES)
+        sig["trajsde_decoder_forward"] = (res, new_args)
+        assert _check_against_header(sig, protos), what
+        assert _compile_tu(_prototype_tu(sig, protos), tmp_path, repo_root, "bad").returncode != 0, what
+    sig = dict(_lib.SIGNATURES)                    # a struct pointer of the wrong struct (both are pointers: only the class check sees it)
+    r2, a2 = sig["trajsde_encoder_ws_bytes"]
+    sig["trajsde_encoder_ws_bytes"] = (r2, [a2[1], a2[0]])
+    assert _check_against_header(sig, protos)
+    assert _compile_tu(_prototype_tu(sig, protos), tmp_path, repo_root, "bad2").returncode != 0
+
+
 def test_param_tables_match_state_dict():
     from trajsde_amd import _lib
     lib = _lib.lib()
@@ -96,7 +230,7 @@ def test_backward_tile_kernels_compile_without_spills_and_with_the_correctness_f
     must stay in the build, and every kernel of that file must keep compiling without scratch memory."""
     import subprocess
     from trajsde_amd import build
-    assert "-fno-slp-vectorize" in build.FLAGS
+    assert "-fno-slp-vectorize" in build.FLAGS and "-DTSDE_NO_SLP=1" in build.FLAGS
     out = tmp_path / "node_bwd.s"
     src = os.path.join(H.ROOT, "trajsde_amd", "csrc", "node_bwd.hip")
     flags = [f for f in build.FLAGS if f != "-fPIC"]

@@ -325,3 +325,92 @@ def test_data_fed_training_on_two_ranks_with_an_odd_scene_count(tmp_path):
             cs.append(np.array([float(_scene_tag(ids) % 9973), 0.0, 1.0]))
         want -= np.mean(cs, axis=0)
     np.testing.assert_allclose(got[0][4][[0, 2]], want[[0, 2]], rtol=1e-6)
+
+
+def _ddp_worker(rank, world, port, q, attach_trainer):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        torch.set_num_threads(1)
+        model, _ = H.build_model(K, T, MAXT, init_seed=3)
+        reached = [n for n, _ in model.named_parameters() if not n.startswith(("decoder.pi.", "decoder.scale."))]
+
+        def fake_loss_and_gradients(data, noise, w_l2, w_diff):                # stands in for the HIP forward + backward entry points
+            model.last_output = {"loc": torch.zeros(K, 4, T, 4)}
+            model.last_losses = {"L2": torch.tensor(1.0), "DiffBCE": torch.tensor(0.5)}
+            sd = dict(model.named_parameters())
+            return torch.tensor(1.5), {n: sd[n].detach() * float(rank + 1) for n in reached}
+
+        model._loss_and_gradients = fake_loss_and_gradients
+        if attach_trainer:
+            model._trainer_stub = types.SimpleNamespace(world_size=world)    # what Lightning's DDP strategy attaches: Trainer.world_size
+        direct = model._direct_accumulation()
+        ddp = DDP(model, find_unused_parameters=True)                          # (pi / scale heads get no gradient, as under the reference)
+
+        class _Step(torch.nn.Module):                                          # Lightning's DDP wrapper forwards to training_step
+            def __init__(self, m):
+                super().__init__()
+                self.m = m
+
+        batch = types.SimpleNamespace(y=torch.zeros(1))
+        errors, grads = [], None
+        orig_forward = model.forward
+        model.forward = lambda *a, **kw: model.training_step(batch, 0, noise=None)
+        try:
+            for step in range(2):
+                for p in model.parameters():
+                    p.grad = None
+                loss = ddp()
+                loss.backward()
+                if step == 0:
+                    sd = dict(model.named_parameters())
+                    grads = {n: sd[n].grad.clone() for n in reached[:3]}
+        except RuntimeError as e:
+            errors.append(str(e)[:200])
+        finally:
+            model.forward = orig_forward
+        sd = dict(model.named_parameters())
+        q.put((rank, direct, errors, None if grads is None else {n: (g / sd[n].detach()).mean().item() for n, g in grads.items()}))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_path_loss_under_a_multi_rank_trainer_feeds_the_ddp_reducer():
+    """under Lightning's DDP strategy the module is wrapped in torch DDP, whose reducer only sees gradients
+    that arrive through autograd.  With a Trainer of world size 2 attached, `_PathLoss` must therefore NOT write `.grad` itself:
+    the two ranks' gradients (1x and 2x the parameters here) come out averaged (1.5x) and a second step does not raise."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, direct, errors, ratios in got:
+        assert direct is False
+        assert errors == [], errors
+        for n, r in ratios.items():
+            assert abs(r - 1.5) < 1e-5, (n, r)
+
+
+def test_direct_accumulation_is_kept_without_a_multi_rank_trainer():
+    import types
+    model, _ = H.build_model(K, T, MAXT, init_seed=3)
+    assert model._direct_accumulation() is True                                # driver.train: no Trainer, flat-bucket all-reduce
+    model._trainer_stub = types.SimpleNamespace(world_size=1)
+    assert model._direct_accumulation() is True
+    model._trainer_stub = types.SimpleNamespace(world_size=4)
+    assert model._direct_accumulation() is False
+    model._trainer_stub = None
+    model.direct_grad_accumulation = False
+    assert model._direct_accumulation() is False

@@ -1,6 +1,6 @@
 """Instruction histogram of the loops of one kernel in a gfx950 assembly listing.
 
-    hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 --cuda-device-only -S -o /tmp/attn.s trajsde_amd/csrc/attn.hip
+    hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -DTSDE_NO_SLP=1 -std=c++17 --cuda-device-only -S -o /tmp/attn.s trajsde_amd/csrc/attn.hip
     python tools/isa_loop_histogram.py /tmp/attn.s k_edge_attn2ILi512ELb0ELb0E
 
 Prints, per backward-branch loop of the kernel, the number of VALU / matrix / LDS / scalar / memory instructions in the loop

@@ -2,7 +2,7 @@
 (the write-after-read window of v_mfma_*_16x16x32: see csrc/tile.hpp split_pair).  Prints every such pair with the number of instructions
 and of s_nop wait states between them.
 
-    hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 --cuda-device-only -S -o /tmp/x.s trajsde_amd/csrc/node_bwd.hip
+    hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -DTSDE_NO_SLP=1 -std=c++17 --cuda-device-only -S -o /tmp/x.s trajsde_amd/csrc/node_bwd.hip
     python tools/isa_mfma_war_scan.py /tmp/x.s [max distance in instructions, default 6]"""
 import re
 import sys

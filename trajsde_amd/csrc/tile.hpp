@@ -19,6 +19,13 @@
 
 #include "layouts.hpp"   // TSDE_SPLIT_H3
 
+// Correctness guard (trajsde_amd/build.py): built with the SLP vectoriser on, identical launches of the
+// backward tile kernels disagree in their low-order bits.  The build passes -fno-slp-vectorize together with -DTSDE_NO_SLP=1; a
+// recipe that forgets the pair stops here instead of shipping a library whose results are not reproducible.
+#if !defined(TSDE_NO_SLP) || !TSDE_NO_SLP
+#error "build trajsde csrc with -fno-slp-vectorize -DTSDE_NO_SLP=1 (python -m trajsde_amd.build): see csrc/tile.hpp split_pair"
+#endif
+
 namespace tsde {
 
 typedef float f4 __attribute__((ext_vector_type(4)));

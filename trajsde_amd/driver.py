@@ -22,6 +22,7 @@ import argparse
 import inspect
 import json
 import os
+import sys
 from typing import Iterable, Optional
 
 import torch
@@ -165,6 +166,7 @@ class FlatTraining:
             self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=model.scheduler_step, gamma=model.scheduler_gamma)
         else:
             self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=model.T_max, eta_min=0.0)
+        model.optimizer, model.scheduler = self.optimizer, self.scheduler      # `current_lr()` (the 'lr' log of MODEL:113) reads the live schedule
 
     def zero(self) -> None:
         self.grads.zero()
@@ -251,6 +253,7 @@ class PlainTraining:
 
     def __init__(self, model) -> None:
         (self.optimizer,), (self.scheduler,) = model.configure_optimizers()
+        model.optimizer, model.scheduler = self.optimizer, self.scheduler
         self.grads = FlatGrads(model.params_with_gradient())
         model._grad_sink = self.grads
 
@@ -488,16 +491,21 @@ def main() -> None:
         batches = datamodule_batches(cfg, dev, rank, world, args.nu_dir, args.argo_dir)
     else:
         batches = synthetic_batches(args.synthetic, args.batches, dev, rank, world)
-    res = evaluate(model, batches)                                                    # metric states all-reduce in compute()
-    if rank == 0 and args.ckpt is not None:
-        model.result_ckpt_path = args.ckpt                                            # test_epoch_end (MODEL:150-165): the result
-        model.test_epoch_end([])                                                      # JSON next to the tested checkpoint
+    res = evaluate(model, batches)                                                    # metric states all-reduce in compute(): every rank
     if rank == 0:
         text = json.dumps(res)
+        print(text)                                                                   # first: nothing below can lose the numbers
         if args.out:
             with open(args.out, "w") as f:
                 f.write(text)
-        print(text)
+        if args.ckpt is not None:
+            # test_epoch_end's side file (MODEL:150-165), the result JSON next to the tested checkpoint, from the values already
+            # reduced above -- no second compute() on one rank (its all-reduces would have no partner on the others)
+            model.result_ckpt_path = args.ckpt
+            try:
+                model.write_results(dict(res))
+            except OSError as e:
+                print(f"warning: result file next to the checkpoint not written ({e})", file=sys.stderr)
     if world > 1:
         dist.destroy_process_group()
 

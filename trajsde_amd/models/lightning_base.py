@@ -58,7 +58,32 @@ class LightningHooks(ModuleBase):
         except Exception:
             return getattr(self, "_trainer_stub", None)
 
+    def _trainer_world_size(self) -> int:
+        """ranks of the attached Trainer's strategy (1 without a Trainer)"""
+        tr = self._attached_trainer()
+        if tr is None:
+            return 1
+        for name in ("world_size", "num_devices"):
+            try:
+                n = int(getattr(tr, name))
+            except Exception:
+                continue
+            if n > 1:
+                return n
+        return 1
+
+    def _direct_accumulation(self) -> bool:
+        """May the path loss write `.grad` itself (no gradient THROUGH autograd, so no per-parameter hook fires)?  Not under a
+        Trainer that runs more than one rank: Lightning's DDP strategy wraps the module in torch DDP, whose reducer learns of a
+        gradient from the AccumulateGrad hook of each parameter -- without them the ranks train unsynchronised or the reducer
+        raises 'expected to have finished reduction' on the second step.  There the gradients are returned through autograd.
+        (`driver.train` has no Trainer: it all-reduces the flat gradient buffer itself.)"""
+        if not bool(getattr(self, "direct_grad_accumulation", True)):
+            return False
+        return self._trainer_world_size() <= 1
+
     def current_lr(self):
+        """MODEL:113 logs `scheduler.get_lr()[0]`; the driver's training handles point `self.scheduler` at the live schedule"""
         sch = getattr(self, "scheduler", None)
         if sch is None:
             return None
@@ -83,8 +108,16 @@ class LightningHooks(ModuleBase):
         return os.path.join(out_dir, f"result_{ck.stem}.json")
 
     def test_epoch_end(self, outputs=None) -> None:
-        """the metric dump `test.py` leaves next to the checkpoint: {metric module name: value}"""
+        """the metric dump `test.py` leaves next to the checkpoint: {metric module name: value}.  `compute()` all-reduces the
+        metric states, so EVERY rank calls this (as Lightning calls the hook on every rank); rank 0 writes the file."""
         metrics = {name: float(m.compute()) for name, m in zip(self.metric_names, self.metrics_vl)}
+        self.write_results(metrics)
+
+    def write_results(self, metrics: dict) -> None:
+        """already reduced metric values -> the result JSON (no collective in here; rank 0 only)"""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+            return
         with open(self.results_path(), "w") as f:
             json.dump(metrics, f)
 

@@ -41,36 +41,12 @@ class _PathLoss(torch.autograd.Function):
     def forward(ctx, model, data, noise, w_l2, w_diff, *params):
         """`w_l2`: the weight of the regression loss -- L2, or LaplaceNLLLoss when the model is configured with it"""
         with torch.no_grad():
-            enc_rt, agg_rt, dec_rt = model.encoder._rt, model.aggregator._rt, model.decoder._rt
-            reg = model._regression_loss()
-            # one forward per step: the encoder and aggregator run their tape-keeping forward, the backward entry points
-            # then walk those tapes instead of recomputing the stage (runtime.*_forward_train)
-            out, local, glob, enc_tape, agg_tape = model._forward_stages(data, noise, keep_tapes=True)
-            if reg[0] == "LaplaceNLLLoss":
-                dec = dec_rt.decoder_nll_backward(data, local, glob, out, noise, eps=reg[1])
-            else:
-                dec = dec_rt.decoder_l2_backward(data, local, glob, out, noise)
-            d_glob, d_local = dec["d_global_embed"], dec["d_local_embed"]
-            if w_l2 != 1.0:
-                d_glob, d_local = d_glob * w_l2, d_local * w_l2
-            agg = agg_rt.aggregator_backward(data, local, d_glob, noise, tape=agg_tape)
-            del agg_tape
-            enc = enc_rt.encoder_backward(data, d_local + agg["d_local_embed"], noise, diff_weight=w_diff, tape=enc_tape)
-            del enc_tape
-            by_name = {}
-            for n, g in dec["grads"].items():
-                by_name["decoder." + n] = g if w_l2 == 1.0 else g * w_l2
-            for n, g in agg["grads"].items():
-                by_name["aggregator." + n] = g
-            for n, g in enc["grads"].items():
-                by_name["encoder." + n] = g
+            loss, by_name = model._loss_and_gradients(data, noise, w_l2, w_diff)
             ctx.grads = [by_name.get(n) for n in model._param_names]          # None: no path from these losses
-            ctx.direct = bool(getattr(model, "direct_grad_accumulation", True))
+            ctx.direct = model._direct_accumulation()
             ctx.params = params if ctx.direct else None
             ctx.sink = getattr(model, "_grad_sink", None) if ctx.direct else None
-            model.last_output = out
-            model.last_losses = {reg[0]: dec["loss"].detach(), "DiffBCE": enc["diff_loss"].detach() / w_diff if w_diff else None}
-            return (w_l2 * dec["loss"] + enc["diff_loss"]).clone()
+            return loss
 
     @staticmethod
     def backward(ctx, g):
@@ -205,6 +181,36 @@ class PredictionModelSDENet(LightningHooks):
                            ("decoder", dec_stage)):
             reached |= {f"{stage}.{n}" for n in getattr(self, stage)._rt.param_names(sid)}
         return [p for n, p in self.named_parameters() if n in reached]
+
+    def _loss_and_gradients(self, data, noise, w_l2: float, w_diff: float):
+        """the HIP forward and, right behind it, the three stage backward entry points of the C-ABI (decoder -> aggregator ->
+        encoder): (weighted loss, {parameter name: gradient}).  Sets `last_output` / `last_losses` like the reference's step."""
+        enc_rt, agg_rt, dec_rt = self.encoder._rt, self.aggregator._rt, self.decoder._rt
+        reg = self._regression_loss()
+        # one forward per step: the encoder and aggregator run their tape-keeping forward, the backward entry points
+        # then walk those tapes instead of recomputing the stage (runtime.*_forward_train)
+        out, local, glob, enc_tape, agg_tape = self._forward_stages(data, noise, keep_tapes=True)
+        if reg[0] == "LaplaceNLLLoss":
+            dec = dec_rt.decoder_nll_backward(data, local, glob, out, noise, eps=reg[1])
+        else:
+            dec = dec_rt.decoder_l2_backward(data, local, glob, out, noise)
+        d_glob, d_local = dec["d_global_embed"], dec["d_local_embed"]
+        if w_l2 != 1.0:
+            d_glob, d_local = d_glob * w_l2, d_local * w_l2
+        agg = agg_rt.aggregator_backward(data, local, d_glob, noise, tape=agg_tape)
+        del agg_tape
+        enc = enc_rt.encoder_backward(data, d_local + agg["d_local_embed"], noise, diff_weight=w_diff, tape=enc_tape)
+        del enc_tape
+        by_name = {}
+        for n, g in dec["grads"].items():
+            by_name["decoder." + n] = g if w_l2 == 1.0 else g * w_l2
+        for n, g in agg["grads"].items():
+            by_name["aggregator." + n] = g
+        for n, g in enc["grads"].items():
+            by_name["encoder." + n] = g
+        self.last_output = out
+        self.last_losses = {reg[0]: dec["loss"].detach(), "DiffBCE": enc["diff_loss"].detach() / w_diff if w_diff else None}
+        return (w_l2 * dec["loss"] + enc["diff_loss"]).clone(), by_name
 
     def prefetch_graph(self, data, noise: "runtime.NoiseSpec", main_stream=None) -> None:
         """prepare `data` for the training_step that will follow with the same `noise`: rotation + graph stage on the side stream

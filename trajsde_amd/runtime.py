@@ -204,15 +204,15 @@ def rotate_inputs(data) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
 
 
 ROTATED_KEY = "_trajsde_rotated"          # set by prefetch_graph: MODEL:76-85 has been applied to this batch already, once
-_SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
+_PREFETCH_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
 
 
 def side_stream(device) -> "torch.cuda.Stream":
     """the stream next batches are prepared on while the current step runs (one per device)"""
     key = str(device)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
+    if key not in _PREFETCH_STREAMS:
+        _PREFETCH_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _PREFETCH_STREAMS[key]
 
 
 def prefetch_graph(data, radius: float, H: int, noise: "NoiseSpec", fake_agents: bool = True, main_stream=None) -> None:
@@ -237,9 +237,21 @@ def prefetch_graph(data, radius: float, H: int, noise: "NoiseSpec", fake_agents:
     done = torch.cuda.Event()
     done.record(side)
     main.wait_event(done)
-    for t in list(data.as_dict().values()) + [gc.ws, gc.edges_ws, gc.rot] + list(gc._keep):
-        if torch.is_tensor(t) and t.is_cuda:
+    for t in _tensors_in(list(data.as_dict().values()) + [gc.ws, gc.edges_ws, gc.rot] + list(gc._keep)):
+        if t.is_cuda:
             t.record_stream(main)                       # freed while main-stream kernels still read it: not handed out again before they finish
+
+
+def _tensors_in(obj):
+    """every tensor inside nested lists / tuples / dicts (batch fields may hold containers of tensors)"""
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_in(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_in(v)
 
 
 def consume_rotation(data) -> bool:
