@@ -9,7 +9,8 @@ obj=/tmp/trajsde_variant_$name; mkdir -p $obj $root/trajsde_amd/variants
 pids=()
 for src in $root/trajsde_amd/csrc/*.hip; do
   b=$(basename $src .hip)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -DTSDE_NO_SLP=1 -std=c++17 -fPIC -Wall -Wno-unused-function $flags -c $src -o $obj/$b.o &
+  extra=""; [ $b = recur ] && extra="-mllvm -amdgpu-mfma-vgpr-form"      # trajsde_amd/build.py PER_FILE_FLAGS
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -DTSDE_NO_SLP=1 -std=c++17 -fPIC -Wall -Wno-unused-function $extra $flags -c $src -o $obj/$b.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done

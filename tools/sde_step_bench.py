@@ -20,6 +20,27 @@ from trajsde_amd import _lib  # noqa: E402
 from trajsde_amd.schedule import decoder_schedule  # noqa: E402
 
 
+def make_runner(rows):
+    """run(i): 20 launches of trajsde_sde_step on `rows` rows (tools/phase_stamps.py)"""
+    dev = torch.device("cuda:0")
+    model, cfg = H.build_model(6, 20, 2.0, init_seed=0)
+    model = model.to(dev)
+    blob = model.decoder._rt.blob()
+    L = _lib.lib()
+    sched = decoder_schedule(20, 2.0)
+    tab = np.ascontiguousarray(sched.step_table())
+    y = [torch.randn(rows, 64, device=dev), torch.empty(rows, 64, device=dev)]
+    noise = _lib.Noise(C.c_uint64(7), None, None)
+
+    def run(i):
+        st = torch.cuda.current_stream().cuda_stream
+        for k in range(20):
+            e = tab[k % sched.n_euler].ctypes.data_as(C.POINTER(C.c_float))
+            _lib.check(L.trajsde_sde_step(rows, blob.data_ptr(), y[k & 1].data_ptr(), y[(k + 1) & 1].data_ptr(), e, k, C.byref(noise), st))
+        run.keep = (model, blob, y)
+    return run
+
+
 def main():
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 6 * 8192        # K*N of BASELINE config 2
     dev = torch.device("cuda:0")

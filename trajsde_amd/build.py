@@ -27,6 +27,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-DTSDE_NO_SLP=1"
 if os.environ.get("TRAJSDE_SPLIT", "fp16x3") == "bf16x6":
     FLAGS.append("-DTSDE_SPLIT_H3=0")
 FLAGS += os.environ.get("TRAJSDE_CXXFLAGS", "").split()       # experiments: extra -D switches of the kernels
+# recur.hip: the cooperative recurrence keeps its 256 weight registers per lane in the accumulation registers (pin_agpr) and needs the
+# products' accumulators in ordinary registers for that -- the compiler's other choice runs every product through a[0:3] (recur.hip)
+PER_FILE_FLAGS = {"recur.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def sources():
@@ -49,7 +52,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in sources():
         obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        procs.append((src, subprocess.Popen([HIPCC, *FLAGS, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        extra = PER_FILE_FLAGS.get(os.path.basename(src), [])
+        procs.append((src, subprocess.Popen([HIPCC, *FLAGS, *extra, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:

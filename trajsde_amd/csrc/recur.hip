@@ -10,9 +10,15 @@
 #include "philox.hpp"
 #include "range.hpp"
 #include "sde_funcs.hpp"
+#include "stamps.hpp"
 #include "tile.hpp"
 
+TSDE_STAMP_TABLE(recur, 16)     // diagnostic builds: [2p] work of phase p+1, [2p+1] its barrier, [14] top of the iteration (noise, biases)
+
 namespace tsde {
+#ifndef TSDE_STAMPS
+static unsigned long long* const g_stamps_recur = nullptr;
+#endif
 
 __global__ __launch_bounds__(512) void k_enc_sde_step(const float* __restrict__ img_g, const float* __restrict__ h_in,
                                                       const float* __restrict__ hidden0, int Nt, float dt, float sq, float sn,
@@ -157,6 +163,22 @@ __device__ __forceinline__ void slice_mma(f4& acc, const WSlice& w, const Opnd& 
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, x1, acc, 0, 0, 0);
   }
 }
+// the same product for the T tiles of a workgroup at once, the tiles' chains interleaved instruction by instruction: a chain on ONE
+// accumulator issues a matrix instruction every ~27 cycles, T independent chains one every ~16 (tools/microbench/coexec.hip).  Per
+// accumulator the order of the products is that of slice_mma: same bits.
+template <int T>
+__device__ __forceinline__ void slice_mma_n(f4 (&acc)[T], const WSlice& w, const Opnd (&x)[T]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const h8 a1 = __builtin_bit_cast(h8, w.p[0][ks]), a2 = __builtin_bit_cast(h8, w.p[1][ks]);
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(h8, x[t].hi[ks]), acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(h8, x[t].lo[ks]), acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(h8, x[t].hi[ks]), acc[t], 0, 0, 0);
+  }
+}
 #else
 struct WSlice {   // one wave's 16 output rows of a 64x64 matrix: 4 k-chunks of A fragments
   f4 q[4];
@@ -224,6 +246,35 @@ __device__ __forceinline__ f4 vec_slice(const float* v, int w, int g) { return *
 __device__ __forceinline__ f4 tanh4(f4 a) { return f4{fast_tanh(a[0]), fast_tanh(a[1]), fast_tanh(a[2]), fast_tanh(a[3])}; }
 __device__ __forceinline__ f4 sigm4(f4 a) { return f4{fast_sigmoid(a[0]), fast_sigmoid(a[1]), fast_sigmoid(a[2]), fast_sigmoid(a[3])}; }
 
+// Register files (round 4).  The sixteen weight slices are 256 registers per lane -- all of the wave's ACCUMULATION registers
+// (a0 .. a255) and nothing else: they are written there once (pin_agpr) and the matrix instructions read them in place as their A
+// operand.  That needs the accumulators of the products in ordinary registers, which this file asks of the compiler
+// (build.py PER_FILE_FLAGS: -mllvm -amdgpu-mfma-vgpr-form).  Before, the compiler kept the slices in ordinary registers, spilled
+// what did not fit into a4 .. a255, copied every spilled slice back (v_accvgpr_read) in front of each use -- 120 copies per tile
+// and iteration -- and ran EVERY product of every tile through the one accumulator a[0:3], with four v_accvgpr_write before and
+// four v_accvgpr_read behind each: the tiles of a workgroup could not overlap at all (0.083 / 0.144 / 0.212 / 0.267 ms for 1 / 2 /
+// 3 / 4 tiles per workgroup: linear).
+__device__ __forceinline__ unsigned pin_agpr1(unsigned v) {
+  unsigned r;
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(v));
+  return r;
+}
+#if TSDE_SPLIT_H3
+__device__ __forceinline__ WSlice pin_agpr(const WSlice& s) {
+  WSlice r;
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      r.p[pl][ks] = u4{pin_agpr1(s.p[pl][ks][0]), pin_agpr1(s.p[pl][ks][1]), pin_agpr1(s.p[pl][ks][2]), pin_agpr1(s.p[pl][ks][3])};
+  return r;
+}
+#else
+__device__ __forceinline__ WSlice pin_agpr(const WSlice& s) { return s; }
+#endif
+
+enum : int { SRC_NUS = 0, SRC_ARGO = 1, SRC_MIXED = 2 };     // diffusion net(s) a workgroup's tiles need (ENC:470-482)
+
 template <int TW, bool SAVE>
 __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict__ sde_img, const float* __restrict__ gru_img,
                                                         const float* __restrict__ coop6, const float* __restrict__ h0, const float* __restrict__ aa_out,
@@ -236,13 +287,11 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const Lane L;
   const int w = threadIdx.x >> 6;
-  const int64_t ntiles = (int64_t(Nt) + 15) / 16;
-  // tiles of this workgroup: blockIdx.x + k * gridDim.x, k < TW.  TW is a compile-time constant so that the per-phase code of
-  // the TW tiles is straight-line and the scheduler interleaves their LDS reads, splits and matrix chains (a runtime tile
-  // count put every tile behind its own branch: one dependency chain at a time on a one-wave-per-SIMD kernel); tiles past
-  // the end of the rows are computed on clamped rows and never stored (inb)
+  // tiles of this workgroup: blockIdx.x * TW + k, k < TW -- consecutive rows, so a workgroup's tiles are rows of one scene (one
+  // source, one diffusion net) except where a scene boundary or the fake agents' rows fall inside.  TW is a compile-time constant so
+  // that the per-phase code of the TW tiles is straight-line and the scheduler interleaves their LDS reads, splits and matrix chains;
+  // tiles past the end of the rows are computed on clamped rows and never stored (inb)
   constexpr int T = TW;
-  (void)ntiles;
   (void)tiles_per_wg;
   constexpr int PER = COOP_TILE + 5 * COOP_OT;                  // per tile: the fp32 state + five operand tiles
   auto Yb = [&](int k) { return lds + k * PER; };                                   // hidden state, fp32 (the update reads its own slice)
@@ -251,7 +300,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
   auto Bb = [&](int k) { return lds + k * PER + COOP_TILE + 2 * COOP_OT; };
   auto Cb = [&](int k) { return lds + k * PER + COOP_TILE + 3 * COOP_OT; };
   auto Xb = [&](int k) { return lds + k * PER + COOP_TILE + 4 * COOP_OT; };         // x_t tile of the step, each wave brings a quarter
-  float* GP = lds + tiles_per_wg * PER;                         // [tile][wave][16]
+  float* GP = lds + T * PER;                                    // [tile][wave][16]
 
   // ---- register-resident weights: this wave's slice of every matrix
   const float* F = sde_img + EncSdeL::F;
@@ -260,7 +309,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
   using G = EncGruL;
 #if TSDE_SPLIT_H3
   using C6 = EncCoopL6;
-  auto sl = [&](int m) { return load_slice(coop6 + m * MAT64X6, w, L.lane); };
+  auto sl = [&](int m) { return pin_agpr(load_slice(coop6 + m * MAT64X6, w, L.lane)); };
   const WSlice wf0 = sl(C6::F0), wf2 = sl(C6::F2), wf4 = sl(C6::F4), wn0 = sl(C6::N0), wn2 = sl(C6::N2), wa0 = sl(C6::A0), wa2 = sl(C6::A2);
   const WSlice wuh = sl(C6::UH), wrh = sl(C6::RH), wux = sl(C6::UX), wrx = sl(C6::RX), wu2 = sl(C6::U2), wr2 = sl(C6::R2);
   const WSlice wnx = sl(C6::NX), wnh = sl(C6::NH), wn2g = sl(C6::N2G);
@@ -274,30 +323,60 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
   const WSlice wnx = load_slice(gru_img + G::WN_X, w, L.lane), wnh = load_slice(gru_img + G::WN_H, w, L.lane);
   const WSlice wn2g = load_slice(gru_img + G::WN2, w, L.lane);
 #endif
+  // ---- the bias / head vectors: copied to LDS once, read where they are used (a wave-uniform 16-byte read per 16 lanes; held in
+  //      registers for the whole launch they are 84 of the 256 ordinary registers and the three-tile form spills)
+  enum : int { V_FB0, V_FWS, V_FWC, V_NB0, V_NWS, V_NWC, V_AB0, V_AWS, V_AWC, V_FB2, V_FB4, V_NB2, V_AB2, V_NW4, V_AW4, V_GBU, V_GBR,
+               V_GBU2, V_GBR2, V_GBN0, V_GBN2, V_COUNT };
+  static_assert(V_COUNT == COOP_BIAS_VECS, "kernels.hpp coop_lds_floats");
+  float* BV = lds + T * PER + T * 64;
+  {
+    const float* src[V_COUNT] = {F + DriftL::B0, F + DriftL::WS, F + DriftL::WC, GN + DiffL::B0, GN + DiffL::WS, GN + DiffL::WC,
+                                 GA + DiffL::B0, GA + DiffL::WS, GA + DiffL::WC, F + DriftL::B2, F + DriftL::B4, GN + DiffL::B2,
+                                 GA + DiffL::B2, GN + DiffL::W4, GA + DiffL::W4, gru_img + G::BUR, gru_img + G::BUR + 64,
+                                 gru_img + G::BU2, gru_img + G::BR2, gru_img + G::BN0, gru_img + G::BN2};
+    if (threadIdx.x < 64) {
+#pragma unroll
+      for (int v = 0; v < V_COUNT; ++v) BV[v * 64 + threadIdx.x] = src[v][threadIdx.x];
+    }
+  }
+  auto bias = [&](int v) { return *reinterpret_cast<const f4*>(BV + v * 64 + 16 * w + 4 * L.g); };
+  const float n_b4 = GN[DiffL::B4], a_b4 = GA[DiffL::B4];
 
   // ---- per-tile row bookkeeping and the initial state
   int64_t rowk[COOP_TMAX];
   bool inb[COOP_TMAX], is_nus[COOP_TMAX];
   int eosk[COOP_TMAX], slotk[COOP_TMAX], origk[COOP_TMAX];
-  unsigned long long nusmask[COOP_TMAX];
+  uint32_t ridk[COOP_TMAX];
+  bool all_nus = true, all_argo = true;
 #pragma unroll
   for (int k = 0; k < COOP_TMAX; ++k) {
     if (k < T) {
-      const int64_t row = (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * 16 + L.n;
+      const int64_t row = (int64_t(blockIdx.x) * T + k) * 16 + L.n;
       inb[k] = row < Nt;
       rowk[k] = inb[k] ? row : Nt - 1;
       is_nus[k] = nus[rowk[k]] != 0;
-      nusmask[k] = __ballot(is_nus[k]);
+      const unsigned long long m = __ballot(is_nus[k]);
+      all_nus = all_nus && m == ~0ull;
+      all_argo = all_argo && m == 0ull;
       eosk[k] = eos[rowk[k]];
       slotk[k] = pick_slot[rowk[k]];
       origk[k] = orig[rowk[k]];
+      ridk[k] = na.row_ids ? uint32_t(na.row_ids[rowk[k]]) : uint32_t(rowk[k]);
       const f4 y = h0 ? vec_slice(h0, w, L.g) : f4{0.f, 0.f, 0.f, 0.f};      // same initial vector for every row (ENC:78 / :257)
       range_note(absmax4(y), RS_ENC_STATE);
       lds_write_slice(Yb(k), y, w, L);
       opnd_write(Ys(k), y, w, L);
     }
   }
+  // which diffusion net(s) the workgroup's rows use: uniform over the workgroup (every wave looks at the same rows), decided once,
+  // so the phases below branch once per phase instead of once per tile
+  const int src_kind = __builtin_amdgcn_readfirstlane(all_nus ? SRC_NUS : (all_argo ? SRC_ARGO : SRC_MIXED));
+  const bool injected = na.z != nullptr;
+  const uint64_t nkey = injected ? 0ull : noise_key(na);
   __syncthreads();
+  PhaseClock<16> clk;                                      // (diagnostic builds only: stamps.hpp)
+  clk.start();
+  float m_state = 0.f, m_input = 0.f;                      // fp16 range guard (range.hpp): running maxima, noted once behind the loop
 
   for (int idx = 0; idx < H; ++idx) {
     const int t = H - 1 - idx;
@@ -308,178 +387,240 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
       if (SAVE && inb[k]) *reinterpret_cast<f4*>(slab + (int64_t(idx) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g) = v;
     };
     // first-layer biases with the (sin t, cos t) columns folded in
-    const f4 bf0 = vec_slice(F + DriftL::B0, w, L.g) + vec_slice(F + DriftL::WS, w, L.g) * sn + vec_slice(F + DriftL::WC, w, L.g) * cs;
-    const f4 bn0 = vec_slice(GN + DiffL::B0, w, L.g) + vec_slice(GN + DiffL::WS, w, L.g) * sn + vec_slice(GN + DiffL::WC, w, L.g) * cs;
-    const f4 ba0 = vec_slice(GA + DiffL::B0, w, L.g) + vec_slice(GA + DiffL::WS, w, L.g) * sn + vec_slice(GA + DiffL::WC, w, L.g) * cs;
-    f4 xq[COOP_TMAX];                                        // this wave's quarter of the x_t rows: loaded in P1, to LDS in P3
-    // ---- P1: first layers of f and g
+    const f4 bf0 = bias(V_FB0) + bias(V_FWS) * sn + bias(V_FWC) * cs;
+    const f4 bn0 = bias(V_NB0) + bias(V_NWS) * sn + bias(V_NWC) * cs;
+    const f4 ba0 = bias(V_AB0) + bias(V_AWS) * sn + bias(V_AWC) * cs;
+    bool validk[COOP_TMAX];                                  // maski = actors_mask[:, t] (ENC:176): asked for here, used in P7
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
-      if (k < T) {
-        {                                                      // in flight early; fp32 or bf16 storage (tile.hpp)
-          const int64_t at = (int64_t(t) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g;
-          xq[k] = aa_bf16 ? widen4(*reinterpret_cast<const bf4*>(reinterpret_cast<const __bf16*>(aa_out) + at))
-                          : *reinterpret_cast<const f4*>(aa_out + at);
-        }
-        const Opnd y = opnd_read(Ys(k), L);
-        if (SAVE) keep(tp.HIN, k, *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g));
-        f4 a = bf0;
-        slice_mma(a, wf0, y);
-        a = tanh4(a);
-        keep(tp.H1, k, a);
-        opnd_write(Ab(k), a, w, L);
-        f4 gsel;
-        if (nusmask[k] == ~0ull) { gsel = bn0; slice_mma(gsel, wn0, y); }
-        else if (nusmask[k] == 0ull) { gsel = ba0; slice_mma(gsel, wa0, y); }
-        else {
-          f4 gn = bn0, ga = ba0;
-          slice_mma(gn, wn0, y);
-          slice_mma(ga, wa0, y);
-          gsel = is_nus[k] ? gn : ga;
-        }
-        gsel = tanh4(gsel);
-        keep(tp.G1, k, gsel);
-        opnd_write(Bb(k), gsel, w, L);
+      if (k < T) validk[k] = !pad[int64_t(origk[k]) * TT + t];
+    f4 xq[COOP_TMAX];                                        // this wave's quarter of the x_t rows: loaded here, to LDS in P3
+    f4 zq[COOP_TMAX];                                        // the step's normals for this wave's 16 channels (used in P3)
+#pragma unroll
+    for (int k = 0; k < COOP_TMAX; ++k)
+      if (k < T) {                                           // in flight early; fp32 or bf16 storage (tile.hpp)
+        const int64_t at = (int64_t(t) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g;
+        xq[k] = aa_bf16 ? widen4(*reinterpret_cast<const bf4*>(reinterpret_cast<const __bf16*>(aa_out) + at))
+                        : *reinterpret_cast<const f4*>(aa_out + at);
       }
+    if (injected) {
+#pragma unroll
+      for (int k = 0; k < COOP_TMAX; ++k)
+        if (k < T) zq[k] = *reinterpret_cast<const f4*>(na.z + (int64_t(noise_step0 + idx) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g);
+    } else {
+      // independent of the state: issued first, it fills the waits of the first phases
+#pragma unroll
+      for (int k = 0; k < COOP_TMAX; ++k)
+        if (k < T) zq[k] = philox_normal4(nkey, STREAM_ENCODER, uint32_t(noise_step0 + idx), ridk[k], uint32_t(4 * w + L.g));
+    }
+#define TS_TILES _Pragma("unroll") for (int k = 0; k < T; ++k)
+    auto state_slice = [&](int k) { return *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g); };
+    clk.mark(14);
+    // ---- P1: first layers of f and g.  Every phase has the same shape: the tiles' operand reads, then the products with the
+    //      tiles' chains interleaved (slice_mma_n), then the pointwise tails and the exchange stores
+    {
+      Opnd y[T];
+      f4 a[T], g[T];
+      TS_TILES y[k] = opnd_read(Ys(k), L);
+      TS_TILES a[k] = bf0;
+      slice_mma_n<T>(a, wf0, y);
+      if (src_kind == SRC_NUS) {
+        TS_TILES g[k] = bn0;
+        slice_mma_n<T>(g, wn0, y);
+      } else if (src_kind == SRC_ARGO) {
+        TS_TILES g[k] = ba0;
+        slice_mma_n<T>(g, wa0, y);
+      } else {
+        f4 g2[T];
+        TS_TILES { g[k] = bn0; g2[k] = ba0; }
+        slice_mma_n<T>(g, wn0, y);
+        slice_mma_n<T>(g2, wa0, y);
+        TS_TILES g[k] = is_nus[k] ? g[k] : g2[k];
+      }
+      TS_TILES {
+        if (SAVE) keep(tp.HIN, k, state_slice(k));
+        a[k] = tanh4(a[k]);
+        keep(tp.H1, k, a[k]);
+        opnd_write(Ab(k), a[k], w, L);
+        g[k] = tanh4(g[k]);
+        keep(tp.G1, k, g[k]);
+        opnd_write(Bb(k), g[k], w, L);
+      }
+    }
+    clk.mark(0);
     __syncthreads();
+    clk.mark(1);
     // ---- P2: second layers; partial dot of the diffusion head
-#pragma unroll
-    for (int k = 0; k < COOP_TMAX; ++k)
-      if (k < T) {
-        const Opnd f1 = opnd_read(Ab(k), L), g1 = opnd_read(Bb(k), L);
-        f4 a = vec_slice(F + DriftL::B2, w, L.g);
-        slice_mma(a, wf2, f1);
-        a = tanh4(a);
-        keep(tp.H2, k, a);
-        opnd_write(Cb(k), a, w, L);
-        f4 g2;
-        float part;
-        auto head = [&](const f4& h2, const float* img) {
-          const f4 wv = vec_slice(img + DiffL::W4, w, L.g);
-          return row_sum(h2[0] * wv[0] + h2[1] * wv[1] + h2[2] * wv[2] + h2[3] * wv[3]);
-        };
-        if (nusmask[k] == ~0ull) { g2 = vec_slice(GN + DiffL::B2, w, L.g); slice_mma(g2, wn2, g1); g2 = tanh4(g2); part = head(g2, GN); }
-        else if (nusmask[k] == 0ull) { g2 = vec_slice(GA + DiffL::B2, w, L.g); slice_mma(g2, wa2, g1); g2 = tanh4(g2); part = head(g2, GA); }
-        else {
-          f4 gn = vec_slice(GN + DiffL::B2, w, L.g), ga = vec_slice(GA + DiffL::B2, w, L.g);
-          slice_mma(gn, wn2, g1);
-          slice_mma(ga, wa2, g1);
-          gn = tanh4(gn);
-          ga = tanh4(ga);
-          const float pn = head(gn, GN), pa = head(ga, GA);
-          part = is_nus[k] ? pn : pa;
-          g2 = is_nus[k] ? gn : ga;
+    {
+      Opnd f1[T], g1[T];
+      f4 a[T], g[T];
+      float part[T];
+      auto head = [&](const f4& h2, const f4& wv) { return row_sum(h2[0] * wv[0] + h2[1] * wv[1] + h2[2] * wv[2] + h2[3] * wv[3]); };
+      TS_TILES { f1[k] = opnd_read(Ab(k), L); g1[k] = opnd_read(Bb(k), L); }
+      TS_TILES a[k] = bias(V_FB2);
+      slice_mma_n<T>(a, wf2, f1);
+      if (src_kind == SRC_NUS) {
+        TS_TILES g[k] = bias(V_NB2);
+        slice_mma_n<T>(g, wn2, g1);
+        TS_TILES { g[k] = tanh4(g[k]); part[k] = head(g[k], bias(V_NW4)); }
+      } else if (src_kind == SRC_ARGO) {
+        TS_TILES g[k] = bias(V_AB2);
+        slice_mma_n<T>(g, wa2, g1);
+        TS_TILES { g[k] = tanh4(g[k]); part[k] = head(g[k], bias(V_AW4)); }
+      } else {
+        f4 g2[T];
+        TS_TILES { g[k] = bias(V_NB2); g2[k] = bias(V_AB2); }
+        slice_mma_n<T>(g, wn2, g1);
+        slice_mma_n<T>(g2, wa2, g1);
+        TS_TILES {
+          g[k] = tanh4(g[k]);
+          g2[k] = tanh4(g2[k]);
+          const float pn = head(g[k], bias(V_NW4)), pa = head(g2[k], bias(V_AW4));
+          part[k] = is_nus[k] ? pn : pa;
+          g[k] = is_nus[k] ? g[k] : g2[k];
         }
-        keep(tp.G2, k, g2);
-        if (L.g == 0) GP[(k * 4 + w) * 16 + L.n] = part;
       }
+      TS_TILES {
+        a[k] = tanh4(a[k]);
+        keep(tp.H2, k, a[k]);
+        opnd_write(Cb(k), a[k], w, L);
+        keep(tp.G2, k, g[k]);
+        if (L.g == 0) GP[(k * 4 + w) * 16 + L.n] = part[k];
+      }
+    }
+    clk.mark(2);
     __syncthreads();
+    clk.mark(3);
     // ---- P3: drift output, diffusion scalar, Euler-Maruyama update of this wave's 16 state channels
-#pragma unroll
-    for (int k = 0; k < COOP_TMAX; ++k)
-      if (k < T) {
-        const Opnd f2 = opnd_read(Cb(k), L);
-        f4 f = vec_slice(F + DriftL::B4, w, L.g);
-        slice_mma(f, wf4, f2);
-        const float b4 = is_nus[k] ? GN[DiffL::B4] : GA[DiffL::B4];
+    {
+      Opnd f2[T];
+      f4 f[T];
+      TS_TILES f2[k] = opnd_read(Cb(k), L);
+      TS_TILES f[k] = bias(V_FB4);
+      slice_mma_n<T>(f, wf4, f2);
+      float gsk[T];
+      TS_TILES {
+        const float b4 = is_nus[k] ? n_b4 : a_b4;
         const float gs = fast_sigmoid(GP[(k * 4 + 0) * 16 + L.n] + GP[(k * 4 + 1) * 16 + L.n] + GP[(k * 4 + 2) * 16 + L.n] +
                                       GP[(k * 4 + 3) * 16 + L.n] + b4);
-        f4 z;
-        if (na.z != nullptr) z = *reinterpret_cast<const f4*>(na.z + (int64_t(noise_step0 + idx) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g);
-        else z = philox_normal4(noise_key(na), STREAM_ENCODER, uint32_t(noise_step0 + idx),
-                                na.row_ids ? uint32_t(na.row_ids[rowk[k]]) : uint32_t(rowk[k]), uint32_t(4 * w + L.g));
-        f4 y = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
+        const f4 z = zq[k];
+        f4 y = state_slice(k);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) y[c] = (y[c] + f[c] * dt) + gs * (z[c] * sq);       // SDEINT:483
+        for (int c = 0; c < 4; ++c) y[c] = (y[c] + f[k][c] * dt) + gs * (z[c] * sq);       // SDEINT:483
         keep(tp.HODE, k, y);
         keep(tp.XS, k, xq[k]);
         if (SAVE && inb[k] && w == 0 && L.g == 0) tp.GS[int64_t(idx) * Nt + rowk[k]] = gs;
-        range_note(absmax4(y), RS_ENC_STATE);                                             // operands of the GRU's split products
-        range_note(absmax4(xq[k]), RS_ENC_INPUT);
+        m_state = fmaxf(m_state, absmax4(y));                                             // operands of the GRU's split products
+        m_input = fmaxf(m_input, absmax4(xq[k]));
         lds_write_slice(Yb(k), y, w, L);                                                  // Y now holds h' (all P1 reads are behind two barriers)
         opnd_write(Ys(k), y, w, L);
         opnd_write(Xb(k), xq[k], w, L);
+        gsk[k] = gs;
+      }
+      TS_TILES
         if (diff_pick != nullptr && inb[k] && slotk[k] >= 0 && eosk[k] == idx)
-          *reinterpret_cast<f4*>(diff_pick + int64_t(slotk[k]) * 64 + 16 * w + 4 * L.g) = f4{gs, gs, gs, gs};
-      }
+          *reinterpret_cast<f4*>(diff_pick + int64_t(slotk[k]) * 64 + 16 * w + 4 * L.g) = f4{gsk[k], gsk[k], gsk[k], gsk[k]};
+    }
+    clk.mark(4);
     __syncthreads();
+    clk.mark(5);
     // ---- P4: GRU gates, first layers (y_concat = [h', x])
-#pragma unroll
-    for (int k = 0; k < COOP_TMAX; ++k)
-      if (k < T) {
-        const Opnd hp = opnd_read(Ys(k), L);
-        const Opnd xin = opnd_read(Xb(k), L);
-        f4 u1 = vec_slice(gru_img + G::BUR, w, L.g), r1 = vec_slice(gru_img + G::BUR + 64, w, L.g);
-        slice_mma(u1, wuh, hp);
-        slice_mma(u1, wux, xin);
-        slice_mma(r1, wrh, hp);
-        slice_mma(r1, wrx, xin);
-        u1 = tanh4(u1);
-        r1 = tanh4(r1);
-        keep(tp.U1, k, u1);
-        keep(tp.R1, k, r1);
-        opnd_write(Ab(k), u1, w, L);
-        opnd_write(Bb(k), r1, w, L);
+    {
+      Opnd hp[T], xin[T];
+      f4 u1[T], r1[T];
+      TS_TILES { hp[k] = opnd_read(Ys(k), L); xin[k] = opnd_read(Xb(k), L); }
+      TS_TILES { u1[k] = bias(V_GBU); r1[k] = bias(V_GBR); }
+      slice_mma_n<T>(u1, wuh, hp);
+      slice_mma_n<T>(r1, wrh, hp);
+      slice_mma_n<T>(u1, wux, xin);
+      slice_mma_n<T>(r1, wrx, xin);
+      TS_TILES {
+        u1[k] = tanh4(u1[k]);
+        r1[k] = tanh4(r1[k]);
+        keep(tp.U1, k, u1[k]);
+        keep(tp.R1, k, r1[k]);
+        opnd_write(Ab(k), u1[k], w, L);
+        opnd_write(Bb(k), r1[k], w, L);
       }
+    }
+    clk.mark(6);
     __syncthreads();
+    clk.mark(7);
     // ---- P5: gates; reset * h'
-    f4 ug[COOP_TMAX];
-#pragma unroll
-    for (int k = 0; k < COOP_TMAX; ++k)
-      if (k < T) {
-        const Opnd u1 = opnd_read(Ab(k), L), r1 = opnd_read(Bb(k), L);
-        f4 u = vec_slice(gru_img + G::BU2, w, L.g), r = vec_slice(gru_img + G::BR2, w, L.g);
-        slice_mma(u, wu2, u1);
-        slice_mma(r, wr2, r1);
-        ug[k] = sigm4(u);
-        const f4 hs = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
-        r = sigm4(r);
-        const f4 rhs = r * hs;
+    f4 ug[T];
+    {
+      Opnd u1[T], r1[T];
+      f4 r[T];
+      TS_TILES { u1[k] = opnd_read(Ab(k), L); r1[k] = opnd_read(Bb(k), L); }
+      TS_TILES { ug[k] = bias(V_GBU2); r[k] = bias(V_GBR2); }
+      slice_mma_n<T>(ug, wu2, u1);
+      slice_mma_n<T>(r, wr2, r1);
+      TS_TILES {
+        ug[k] = sigm4(ug[k]);
+        const f4 hs = state_slice(k);
+        r[k] = sigm4(r[k]);
+        const f4 rhs = r[k] * hs;
         keep(tp.UU, k, ug[k]);
-        keep(tp.RR, k, r);
+        keep(tp.RR, k, r[k]);
         keep(tp.RH, k, rhs);
         opnd_write(Cb(k), rhs, w, L);
       }
+    }
+    clk.mark(8);
     __syncthreads();
+    clk.mark(9);
     // ---- P6: candidate state, first layer (combined = [x, r*h'])
-#pragma unroll
-    for (int k = 0; k < COOP_TMAX; ++k)
-      if (k < T) {
-        const Opnd rh = opnd_read(Cb(k), L);
-        const Opnd xin = opnd_read(Xb(k), L);              // the x_t tile again (not kept live across the phases)
-        f4 n1 = vec_slice(gru_img + G::BN0, w, L.g);
-        slice_mma(n1, wnx, xin);
-        slice_mma(n1, wnh, rh);
-        n1 = tanh4(n1);
-        keep(tp.N1, k, n1);
-        opnd_write(Ab(k), n1, w, L);
+    {
+      Opnd rh[T], xin[T];
+      f4 n1[T];
+      TS_TILES { xin[k] = opnd_read(Xb(k), L); rh[k] = opnd_read(Cb(k), L); }       // the x_t tile again (not kept live across the phases)
+      TS_TILES n1[k] = bias(V_GBN0);
+      slice_mma_n<T>(n1, wnx, xin);
+      slice_mma_n<T>(n1, wnh, rh);
+      TS_TILES {
+        n1[k] = tanh4(n1[k]);
+        keep(tp.N1, k, n1[k]);
+        opnd_write(Ab(k), n1[k], w, L);
       }
+    }
+    clk.mark(10);
     __syncthreads();
+    clk.mark(11);
     // ---- P7: candidate state, second layer; gated blend; masked update; picks
-#pragma unroll
-    for (int k = 0; k < COOP_TMAX; ++k)
-      if (k < T) {
-        const Opnd n1 = opnd_read(Ab(k), L);
-        f4 nw = vec_slice(gru_img + G::BN2, w, L.g);
-        slice_mma(nw, wn2g, n1);
-        keep(tp.NW, k, nw);
-        f4 hs = *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g);
-        const bool valid = !pad[int64_t(origk[k]) * TT + t];
+    {
+      Opnd n1[T];
+      f4 nw[T];
+      TS_TILES n1[k] = opnd_read(Ab(k), L);
+      TS_TILES nw[k] = bias(V_GBN2);
+      slice_mma_n<T>(nw, wn2g, n1);
+      TS_TILES {
+        keep(tp.NW, k, nw[k]);
+        f4 hs = state_slice(k);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float hn = (1.0f - ug[k][c]) * nw[c] + ug[k][c] * hs[c];
-          hs[c] = valid ? hn : hs[c];
+          const float hn = (1.0f - ug[k][c]) * nw[k][c] + ug[k][c] * hs[c];
+          hs[c] = validk[k] ? hn : hs[c];
         }
         lds_write_slice(Yb(k), hs, w, L);
         opnd_write(Ys(k), hs, w, L);
+        nw[k] = hs;
+      }
+      TS_TILES {                                             // the rare stores behind the tiles' straight-line work
         const int64_t row = rowk[k];
         if (inb[k] && row < N) {
-          if (eosk[k] == idx) *reinterpret_cast<f4*>(kept + row * 64 + 16 * w + 4 * L.g) = hs;
-          if (latent_ys != nullptr) *reinterpret_cast<f4*>(latent_ys + (int64_t(idx) * N + row) * 64 + 16 * w + 4 * L.g) = hs;
+          if (eosk[k] == idx) *reinterpret_cast<f4*>(kept + row * 64 + 16 * w + 4 * L.g) = nw[k];
+          if (latent_ys != nullptr) *reinterpret_cast<f4*>(latent_ys + (int64_t(idx) * N + row) * 64 + 16 * w + 4 * L.g) = nw[k];
         }
       }
+    }
+#undef TS_TILES
+    clk.mark(12);
     __syncthreads();
+    clk.mark(13);
   }
+  range_note(m_state, RS_ENC_STATE);
+  range_note(m_input, RS_ENC_INPUT);
+  if (!SAVE && w == 0 && L.lane == 0) clk.flush(g_stamps_recur, (unsigned long long)(H) * T);
 }
 
 #define TS_COOP_INST(TW, SV)                                                                                                      \
@@ -523,7 +664,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_bwd_coop(RecurBwdCoopArgs a) 
   const int Nt = a.Nt, N = a.N, H = a.H;
   using G = GruBwdL;
   using S = EncSdeBwdL;
-  auto sl = [&](const float* img, int off) { return load_slice(img + off, w, L.lane); };
+  auto sl = [&](const float* img, int off) { return pin_agpr(load_slice(img + off, w, L.lane)); };   // (see k_enc_recur_coop: 256 accumulation registers)
   const WSlice wn2 = sl(a.gru_t, G::WN2T), wnx = sl(a.gru_t, G::WNXT), wnh = sl(a.gru_t, G::WNHT), wu2 = sl(a.gru_t, G::WU2T), wr2 = sl(a.gru_t, G::WR2T);
   const WSlice wuh = sl(a.gru_t, G::UHT), wrh = sl(a.gru_t, G::RHT), wux = sl(a.gru_t, G::UXT), wrx = sl(a.gru_t, G::RXT);
   const WSlice wf0 = sl(a.sde_t, S::F_W0T), wf2 = sl(a.sde_t, S::F_W2T), wf4 = sl(a.sde_t, S::F_W4T);
