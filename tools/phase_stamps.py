@@ -20,8 +20,9 @@ TABLES = {
                                       "P3 drift out, EM update", "  barrier", "P4 GRU gates first layers", "  barrier",
                                       "P5 gates, r*h", "  barrier", "P6 candidate first layer", "  barrier",
                                       "P7 candidate out, blend", "  barrier", "top: x_t loads, noise, biases", "-"]),
-    "sde_step": (8, "tile-steps", ["state load + noise", "first layers (128x64) + tanh", "second layers + tanh", "drift out + head + sigmoid",
-                                   "update + store", "-", "-", "-"]),
+    "sde_step": (8, "tile-steps", ["wait for the state rows", "noise: Philox + Box-Muller (16 normals / lane)",
+                                   "first layers: split + 48 matrix instr.", "32 tanh / lane", "drift: layer 2 + tanh + layer 3",
+                                   "diffusion: layer 2 + tanh + head + sigmoid", "update + store", "-"]),
 }
 
 

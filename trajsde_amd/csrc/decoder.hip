@@ -15,9 +15,15 @@
 #include "philox.hpp"
 #include "range.hpp"
 #include "sde_funcs.hpp"
+#include "stamps.hpp"
 #include "tile.hpp"
 
+TSDE_STAMP_TABLE(sde_step, 8)   // diagnostic builds (tools/phase_stamps.py): phases of one tile-step of k_sde_step
+
 namespace tsde {
+#ifndef TSDE_STAMPS
+static unsigned long long* const g_stamps_sde_step = nullptr;
+#endif
 
 // Linear(64,64)-LN-ReLU-Linear(64,2) head on state s -> (o0, o1)
 __device__ __forceinline__ void head_eval(float& o0, float& o1, const f4 (&s)[4], const float* img, const Lane& L) {
@@ -167,6 +173,13 @@ __global__ __launch_bounds__(MAXT) void k_sde_decode(const float* __restrict__ b
 }
 
 // step-granular variant: one Euler-Maruyama step, state read from and written to HBM (no heads)
+//
+// Round 4: the in-kernel phase clocks (tools/phase_stamps.py sde_step) showed a wave spending 31 % of a tile-step waiting for its 16
+// state rows -- the load was issued at the top of the iteration and needed at once -- so the rows of a wave's NEXT tile now travel
+// while it computes the current one: by LDS-DMA (global_load_lds_dwordx4, no registers: the kernel sits at 115 of the 128 registers
+// that four waves per SIMD allow) into a 4 KB slot per wave, 16-byte chunks XOR-swizzled by the row so that the transfer reads four
+// whole rows per instruction and the lanes' ds_read_b128 of "row on lane" find their chunks in distinct banks.
+constexpr int SDE_STEP_SLOT = 16 * 64;                      // floats per wave: one 16 x 64 tile
 template <bool X6>
 __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blob, const float* __restrict__ y_in,
                                                    float* __restrict__ y_out, int64_t rows, float dt, float sq, float sn,
@@ -184,17 +197,63 @@ __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blo
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int64_t ntiles = (rows + 15) / 16;
-  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
-    const int64_t row = tile * 16 + L.n;
-    keep_lds_reads_here();
-    const int64_t r = row < rows ? row : rows - 1;
-    f4 y[4], f[4], z[4];
-    load_row_st(y, y_in, r, L.g, st_bf16 != 0);
+  PhaseClock<8> clk;                                       // (diagnostic builds only: stamps.hpp)
+  clk.start();
+  unsigned long long units = 0;
+  (void)units;
+  // one tile-step on the state rows in y: (row < rows: the row exists and is stored)
+  // (plain_noise: Philox keyed by the kernel argument and the row index itself -- no loads, so nothing in the step waits on the
+  //  vector-memory counter and the transfer of the next tile stays in flight; the other noise forms take the loop at the bottom)
+  const uint64_t key0 = na.seed;
+  auto noise_of = [&](f4 (&z)[4], int64_t r, bool plain_noise) {
+    if (plain_noise) {
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) z[jt] = philox_normal4(key0, STREAM_DECODER, uint32_t(step), uint32_t(r), uint32_t(4 * jt + L.g));
+    } else {
+      noise_row(z, na, STREAM_DECODER, step, r, rows, L.g);
+    }
+  };
+  auto tile_step = [&](f4 (&y)[4], int64_t row, int64_t r, bool store_all, bool plain_noise) {
+    f4 f[4], z[4];
     range_note(absmax<4>(y), RS_DEC_STATE);
     float gs;
 #if TSDE_SPLIT_H3
     if constexpr (X6) {
+#ifdef TSDE_STAMPS
+      // the phases of sde_fg_eval spelled out between the clock's marks (same calls, same order)
+      using DD = DecSdeL6;
+      noise_of(z, r, plain_noise);
+      asm volatile("" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
+      clk.mark(1);                                            // [1] Philox + Box-Muller: 16 normals per lane
+      f4 h[8];
+#pragma unroll
+      for (int jo = 0; jo < 8; ++jo) h[jo] = *reinterpret_cast<const f4*>(tb + 16 * jo + 4 * L.g);
+      linear_acc_x6<8, 4>(h, y, lds + DD::W0FG, L.lane);
+      asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]));
+      clk.mark(2);                                            // [2] first layers: split of the state + 48 matrix instructions
+      tanh_prescaled_<8>(h);
+      asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]));
+      clk.mark(3);                                            // [3] 32 tanh per lane
+      const f4 hf[4] = {h[0], h[1], h[2], h[3]}, hg[4] = {h[4], h[5], h[6], h[7]};
+      f4 h2[4];
+      linear_x6<4, 4>(h2, hf, lds + DD::F_W2, lds + DD::F_B2, L);
+      tanh_prescaled_<4>(h2);
+      linear_x6<4, 4>(f, h2, lds + DD::F_W4, lds + DD::F_B4, L);
+      asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+      clk.mark(4);                                            // [4] drift: second layer + tanh + output layer (48 matrix instructions)
+      linear_x6<4, 4>(h2, hg, lds + DD::G_W2, lds + DD::G_B2, L);
+      tanh_prescaled_<4>(h2);
+      gs = fast_sigmoid(row_dot(h2, lds + DD::G_W4, L.g) + lds[DD::G_B4]);
+      asm volatile("" : "+v"(gs));
+      clk.mark(5);                                            // [5] diffusion: second layer + tanh + head dot + sigmoid
+      em_update(y, f, gs, z, dt, sq);
+      if (store_all || row < rows) store_row_st(y, y_out, row, L.g, st_bf16 != 0);
+      clk.mark(6);                                            // [6] update + store
+      ++units;
+      return;
+#else
       sde_fg_eval(f, gs, y, lds, tb, L);
+#endif
     } else
 #else
     if constexpr (X6) {
@@ -206,10 +265,82 @@ __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blo
       drift_eval(f, y, lds + DL::F, sn, cs, L);
       gs = diff_eval(y, lds + DL::G, sn, cs, L);
     }
-    noise_row(z, na, STREAM_DECODER, step, r, rows, L.g);
+    noise_of(z, r, plain_noise);
     em_update(y, f, gs, z, dt, sq);
-    if (row < rows) store_row_st(y, y_out, row, L.g, st_bf16 != 0);
+    if (store_all || row < rows) store_row_st(y, y_out, row, L.g, st_bf16 != 0);
+  };
+  const int64_t stride = int64_t(gridDim.x) * waves;
+  int64_t tile = int64_t(blockIdx.x) * waves + wave;
+#if TSDE_SPLIT_H3
+  if (X6 && st_bf16 == 0 && na.z == nullptr && na.row_ids == nullptr && na.seed_dev == nullptr) {
+    // ---- full tiles (all 16 rows exist), the next one in flight while this one is computed
+    const int64_t full = rows / 16;
+    float* slot = lds + DL::LOC + 128 + wave * SDE_STEP_SLOT;
+    const unsigned slot_addr = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)slot)));
+    // lane l of transfer q brings chunk (l & 15) ^ rr of row rr = 4 q + (l >> 4), which lands at slot + 1024 q + 16 l bytes = chunk
+    // position (l & 15) of row rr: position p of row rr holds chunk p ^ rr
+    const int rr0 = L.lane >> 4, pc = L.lane & 15;
+    auto send = [&](int64_t t) {
+      const float* base = y_in + t * (16 * 64);
+      const float* s0 = base + (rr0 + 0) * 64 + 4 * (pc ^ (rr0 + 0));
+      const float* s1 = base + (rr0 + 4) * 64 + 4 * (pc ^ (rr0 + 4));
+      const float* s2 = base + (rr0 + 8) * 64 + 4 * (pc ^ (rr0 + 8));
+      const float* s3 = base + (rr0 + 12) * 64 + 4 * (pc ^ (rr0 + 12));
+      unsigned m0_keep;
+      asm volatile("s_mov_b32 %0, m0\n\t"
+                   "s_mov_b32 m0, %5\n\t"
+                   "s_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, off\n\t"
+                   "s_add_u32 m0, m0, 0x400\n\t"
+                   "s_nop 0\n\t"
+                   "global_load_lds_dwordx4 %2, off\n\t"
+                   "s_add_u32 m0, m0, 0x400\n\t"
+                   "s_nop 0\n\t"
+                   "global_load_lds_dwordx4 %3, off\n\t"
+                   "s_add_u32 m0, m0, 0x400\n\t"
+                   "s_nop 0\n\t"
+                   "global_load_lds_dwordx4 %4, off\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(m0_keep)
+                   : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "s"(slot_addr)
+                   : "memory", "scc");
+    };
+    bool first = true;
+    if (tile < full) send(tile);
+    for (; tile < full; tile += stride) {
+      keep_lds_reads_here();
+      // the four transfers of this tile are the oldest vector-memory operations in flight; behind them sit at most the four row
+      // stores of the previous tile (vmcnt counts in issue order), so "all but four" means the tile has landed
+      if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      first = false;
+      f4 y[4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) y[jt] = *reinterpret_cast<const f4*>(slot + L.n * 64 + 4 * ((4 * jt + L.g) ^ L.n));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]) : : "memory");   // the slot is free again
+      clk.mark(0);                                              // [0] waiting for the state rows (and the loop overhead)
+      if (tile + stride < full) send(tile + stride);
+      const int64_t row = tile * 16 + L.n;
+      tile_step(y, row, row, true, true);
+    }
   }
+#endif
+  // ---- the last, partial tile (and every tile of the forms without the transfer): rows asked for where they are used
+  for (; tile < ntiles; tile += stride) {
+    const int64_t row = tile * 16 + L.n;
+    keep_lds_reads_here();
+    const int64_t r = row < rows ? row : rows - 1;
+    f4 y[4];
+    load_row_st(y, y_in, r, L.g, st_bf16 != 0);
+#ifdef TSDE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    clk.mark(0);
+#endif
+    tile_step(y, row, r, false, false);
+  }
+#ifdef TSDE_STAMPS
+  if ((wave & 3) == 0 && L.lane == 0) clk.flush(g_stamps_sde_step, units);
+#endif
 }
 
 int pick_grid(int64_t ntiles, int waves_per_wg) {
@@ -275,7 +406,7 @@ int trajsde_sde_step(int32_t rows, const float* blob, const float* y_in, float* 
   const int64_t ntiles = (int64_t(rows) + 15) / 16;
   static const bool x6 = []() { const char* v = getenv("TRAJSDE_DECODE_FP32"); return !(v && atoi(v) != 0); }();
   if (x6)
-    TS_LAUNCH(k_sde_step<true>, pick_grid(ntiles, 16), 1024, (DecSdeL6::LOC + 128) * 4, stream, blob + DecBlob::SDE6, y_in, y_out, int64_t(rows), e[1],
+    TS_LAUNCH(k_sde_step<true>, pick_grid(ntiles, 16), 1024, (DecSdeL6::LOC + 128 + 16 * SDE_STEP_SLOT) * 4, stream, blob + DecBlob::SDE6, y_in, y_out, int64_t(rows), e[1],
               e[2], e[3], e[4], step, to_arg(noise), state_bf16() ? 1 : 0);
   else
     TS_LAUNCH(k_sde_step<false>, pick_grid(ntiles, 16), 1024, DecSdeL::LOC * 4, stream, blob + DecBlob::SDE, y_in, y_out, int64_t(rows), e[1],

@@ -49,12 +49,15 @@ struct PackJobs {
 };
 
 // dst[i] (+)= src[i]
-__device__ __forceinline__ void k_pack_vec(int i, const float* __restrict__ src, float* __restrict__ dst, int n, int accumulate) {
-  if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
+// (`scale_bits`: the bit pattern of an fp32 factor applied to the packed element, 0 = none -- Packer::scale: a constant of the
+//  consuming kernel's arithmetic folded into the image, e.g. the 2 / ln 2 of tanh(x) = 1 - 2 / (2^(x 2 / ln 2) + 1))
+__device__ __forceinline__ float pack_scaled(float x, int scale_bits) { return scale_bits ? x * __int_as_float(scale_bits) : x; }
+__device__ __forceinline__ void k_pack_vec(int i, const float* __restrict__ src, float* __restrict__ dst, int n, int accumulate, int scale_bits) {
+  if (i < n) dst[i] = accumulate ? dst[i] + pack_scaled(src[i], scale_bits) : pack_scaled(src[i], scale_bits);
 }
 // dst[r] = src[r*ld + col]
-__device__ __forceinline__ void k_pack_col(int i, const float* __restrict__ src, float* __restrict__ dst, int rows, int ld, int col) {
-  if (i < rows) dst[i] = src[i * ld + col];
+__device__ __forceinline__ void k_pack_col(int i, const float* __restrict__ src, float* __restrict__ dst, int rows, int ld, int col, int scale_bits) {
+  if (i < rows) dst[i] = pack_scaled(src[i * ld + col], scale_bits);
 }
 // MFMA fragment order: dst[((jo*JTI + q)*64 + lane)*4 + c] = W[16jo + (lane&15)][col0 + 16q + 4(lane>>4) + c]
 __device__ __forceinline__ void k_pack_mat(int i, const float* __restrict__ src, float* __restrict__ dst, int jto, int jti, int ld, int col0) {
@@ -107,11 +110,11 @@ __device__ __forceinline__ void store_split(float x, unsigned short* __restrict_
 // split-precision pieces: dst (16-bit) [jo][s][piece][lane][8]; element j of lane (i,g) in k-step s is the piece-th
 // truncation piece of W[16jo + i][col0 + 32s + 16(j>>2) + 4g + (j&3)]   (tile.hpp linear_acc_x6)
 __device__ __forceinline__ void k_pack_mat6(int i, const float* __restrict__ src, unsigned short* __restrict__ dst, int jto, int ks,
-                                            int ld, int col0) {
+                                            int ld, int col0, int scale_bits) {
   const int per_plane = jto * ks * 512;
   if (i >= per_plane) return;
   const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % ks, jo = (i >> 9) / ks;
-  const float x = src[(16 * jo + (lane & 15)) * ld + col0 + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)];
+  const float x = pack_scaled(src[(16 * jo + (lane & 15)) * ld + col0 + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)], scale_bits);
   store_split(x, dst, i, per_plane);
 }
 
@@ -257,12 +260,12 @@ __global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= J.count) return;
   switch (J.kind) {
-    case PK_VEC: k_pack_vec(i, J.src, J.dst, J.count, J.p0); break;
-    case PK_COL: k_pack_col(i, J.src, J.dst, J.count, J.p0, J.p1); break;
+    case PK_VEC: k_pack_vec(i, J.src, J.dst, J.count, J.p0, J.p1); break;
+    case PK_COL: k_pack_col(i, J.src, J.dst, J.count, J.p0, J.p1, J.p2); break;
     case PK_MAT: k_pack_mat(i, J.src, J.dst, J.p0, J.p1, J.p2, J.p3); break;
     case PK_MAT_PAD: k_pack_mat_pad(i, J.src, J.dst, J.p0, J.p1, J.p2, J.p3); break;
     case PK_MATT: k_pack_matT(i, J.src, J.dst, J.p0, J.p1, J.p2, J.p3, J.p4); break;
-    case PK_MAT6: k_pack_mat6(i, J.src, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1, J.p2, J.p3); break;
+    case PK_MAT6: k_pack_mat6(i, J.src, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1, J.p2, J.p3, J.p4); break;
     case PK_MAT6_STACK2: k_pack_mat6_stack2(i, J.src, J.src2, J.src3, reinterpret_cast<unsigned short*>(J.dst)); break;
     case PK_MAT6_CENTRED: k_pack_mat6_centred(i, J.src, reinterpret_cast<unsigned short*>(J.dst)); break;
     case PK_VEC_CENTRED: k_pack_vec_centred(i, J.src, J.src2, J.dst); break;
@@ -276,6 +279,8 @@ __global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
 
 struct Packer {
   bool dry;
+  float scale = 0.f;                       // != 0: vec / col / mat6 multiply what they pack by it (pack_scaled); recipes set and clear it
+  int scale_bits() const { return scale != 0.f ? __builtin_bit_cast(int, scale) : 0; }
   std::vector<PackJob> jobs;               // wet: filled by the recipe, launched once by trajsde_pack_weights
   void emit(int kind, int count, const float* s, float* d, int p0 = 0, int p1 = 0, int p2 = 0, int p3 = 0, int p4 = 0,
             const float* s2 = nullptr, int pass = 0) {
@@ -297,7 +302,7 @@ struct Packer {
     if (TSDE_SPLIT_H3) split_raw(s, d, jto, jti, ld, col0, rows_valid, true);
     else emit(PK_MATT, jto * jti * 256, s, d, jto, jti, ld, col0, rows_valid);
   }
-  void mat6_raw(const float* s, float* d, int jto, int ks, int ld, int col0) { emit(PK_MAT6, jto * ks * 512, s, d, jto, ks, ld, col0); }
+  void mat6_raw(const float* s, float* d, int jto, int ks, int ld, int col0) { emit(PK_MAT6, jto * ks * 512, s, d, jto, ks, ld, col0, scale_bits()); }
   std::vector<std::string> names;          // dry: collected in order of first use
   const float* const* params = nullptr;    // wet
   float* blob = nullptr;
@@ -317,12 +322,12 @@ struct Packer {
   void vec(const std::string& n, int dst, int count, bool accumulate = false) {
     const float* s = src(n);
     if (dry) return;
-    emit(PK_VEC, count, s, blob + dst, accumulate ? 1 : 0, 0, 0, 0, 0, nullptr, accumulate ? 1 : 0);
+    emit(PK_VEC, count, s, blob + dst, accumulate ? 1 : 0, scale_bits(), 0, 0, 0, nullptr, accumulate ? 1 : 0);
   }
   void col(const std::string& n, int dst, int rows, int ld, int c) {
     const float* s = src(n);
     if (dry) return;
-    emit(PK_COL, rows, s, blob + dst, ld, c);
+    emit(PK_COL, rows, s, blob + dst, ld, c, scale_bits());
   }
   // rows x cols sub-matrix starting at column col0 of a row-major [rows x ld] weight
   void mat(const std::string& n, int dst, int rows, int cols, int ld, int col0 = 0) {
@@ -757,6 +762,8 @@ static void recipe_decoder(Packer& P) {
     using D = DecSdeL6;
     const int d = DecBlob::SDE6;
     const std::string f = "lsde_func.f_func.net.", g = "lsde_func.g_func.net.";
+    // the four layers in front of a tanh carry its 2 / ln 2 (tile.hpp TANH_PRESCALE, tanh_prescaled): one multiply less per tanh
+    P.scale = TANH_PRESCALE;
     P.mat6(f + "0.weight", d + D::W0FG, 64, 64, 66, 0);                 // jo-major planes: the two row blocks concatenate
     P.mat6(g + "0.weight", d + D::W0FG + MAT64X6, 64, 64, 66, 0);
     P.vec(f + "0.bias", d + D::B0FG, 64);
@@ -767,10 +774,11 @@ static void recipe_decoder(Packer& P) {
     P.col(g + "0.weight", d + D::WCFG + 64, 64, 66, 65);
     P.mat6(f + "2.weight", d + D::F_W2, 64, 64, 64);
     P.vec(f + "2.bias", d + D::F_B2, 64);
-    P.mat6(f + "4.weight", d + D::F_W4, 64, 64, 64);
-    P.vec(f + "4.bias", d + D::F_B4, 64);
     P.mat6(g + "2.weight", d + D::G_W2, 64, 64, 64);
     P.vec(g + "2.bias", d + D::G_B2, 64);
+    P.scale = 0.f;
+    P.mat6(f + "4.weight", d + D::F_W4, 64, 64, 64);
+    P.vec(f + "4.bias", d + D::F_B4, 64);
     P.vec(g + "4.weight", d + D::G_W4, 64);
     P.vec(g + "4.bias", d + D::G_B4, 1);
   }

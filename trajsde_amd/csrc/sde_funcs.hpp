@@ -91,18 +91,19 @@ __device__ __forceinline__ void sde_time_bias(float* tb, const float* img, float
 }
 __device__ __forceinline__ void sde_fg_eval(f4 (&f)[4], float& gs, const f4 (&y)[4], const float* img, const float* tb, const Lane& L) {
   using DD = DecSdeL6;
+  // (the image's four layers in front of a tanh are packed times 2 / ln 2: tanh_prescaled)
   f4 h[8];
 #pragma unroll
   for (int jo = 0; jo < 8; ++jo) h[jo] = *reinterpret_cast<const f4*>(tb + 16 * jo + 4 * L.g);
   linear_acc_x6<8, 4>(h, y, img + DD::W0FG, L.lane);
-  tanh_<8>(h);
+  tanh_prescaled_<8>(h);
   const f4 hf[4] = {h[0], h[1], h[2], h[3]}, hg[4] = {h[4], h[5], h[6], h[7]};
   f4 h2[4];
   linear_x6<4, 4>(h2, hf, img + DD::F_W2, img + DD::F_B2, L);
-  tanh_<4>(h2);
+  tanh_prescaled_<4>(h2);
   linear_x6<4, 4>(f, h2, img + DD::F_W4, img + DD::F_B4, L);
   linear_x6<4, 4>(h2, hg, img + DD::G_W2, img + DD::G_B2, L);
-  tanh_<4>(h2);
+  tanh_prescaled_<4>(h2);
   gs = fast_sigmoid(row_dot(h2, img + DD::G_W4, L.g) + img[DD::G_B4]);
 }
 #endif

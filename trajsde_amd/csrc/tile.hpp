@@ -541,6 +541,11 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+// tanh of a pre-activation that arrives ALREADY multiplied by 2 / ln 2 (the layer in front of it was packed with that factor:
+// pack.hip Packer::scale): v_exp_f32, add, v_rcp_f32, fma -- the multiply of fast_tanh is gone (64 of ~890 vector instructions of an
+// SDE tile-step)
+constexpr float TANH_PRESCALE = 2.8853900817779268f;
+__device__ __forceinline__ float tanh_prescaled(float u) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(u) + 1.0f); }
 
 template <int JT>
 __device__ __forceinline__ void relu(f4 (&a)[JT]) {
@@ -555,6 +560,13 @@ __device__ __forceinline__ void tanh_(f4 (&a)[JT]) {
   for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
     for (int c = 0; c < 4; ++c) a[jt][c] = fast_tanh(a[jt][c]);
+}
+template <int JT>
+__device__ __forceinline__ void tanh_prescaled_(f4 (&a)[JT]) {
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[jt][c] = tanh_prescaled(a[jt][c]);
 }
 template <int JT>
 __device__ __forceinline__ void sigmoid_(f4 (&a)[JT]) {
