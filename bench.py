@@ -89,7 +89,7 @@ def build_cfg(spec):
 
 def cpu_baseline(model, cfg, spec, gpu_loc_fn):
     """Oracle timed on the host cores (BASELINE.md section 3 protocol): CPU_SAMPLE_SCENES scene(s) of the workload's
-    generator, per thread count 2 warm-ups + the median of 5 timed forwards; also the 'minADE match' leg: GPU vs oracle
+    generator, per thread count 1 warm-up + the median of 3 timed forwards; also the 'minADE match' leg: GPU vs oracle
     on that very sample with the same Philox seed."""
     import numpy as np
     import torch
@@ -112,11 +112,11 @@ def cpu_baseline(model, cfg, spec, gpu_loc_fn):
             continue
         torch.set_num_threads(nt)
         times = []
-        for i in range(7):
+        for i in range(4):                                  # one warm-up + three timed forwards per thread count (~8 s in all)
             t0 = time.perf_counter()
             out = restate.forward(P, cfg, batch, restate.PhiloxNoise(seed))
             times.append(time.perf_counter() - t0)
-        table[nt] = float(np.median(times[2:]))
+        table[nt] = float(np.median(times[1:]))
     torch.set_num_threads(all_threads)
     best_nt = min(table, key=table.get)
     med = table[best_nt]
@@ -136,7 +136,7 @@ def cpu_baseline(model, cfg, spec, gpu_loc_fn):
              "tolerance": 1e-4}
     base = {"value": CPU_SAMPLE_SCENES / med, "unit": "scenes/s", "cores": best_nt, "kind": "port",
             "sample": f"{CPU_SAMPLE_SCENES} scene x {skw['n']} agents of {WORKLOAD} (same generator and seed, K=6, 20 steps), "
-                      f"oracle/restate.py (bit-exact restatement of the reference), 2 warm-ups + median of 5 timed forwards per "
+                      f"oracle/restate.py (bit-exact restatement of the reference), 1 warm-up + median of 3 timed forwards per "
                       f"thread count, best = {best_nt} threads at {med:.3f} s/forward, torch {torch.__version__} fp32, "
                       f"host: {cpu_model()}, {os.cpu_count()} logical cores",
             "scenes_per_s_by_threads": {str(k): CPU_SAMPLE_SCENES / v for k, v in table.items()}}
@@ -323,7 +323,8 @@ def main():
                          "windows_ms": [1e3 * w for w in w1], "what": "the same steps on one HIP stream per GPU"},
         }
         if world > 1:                                                         # world-1-only legs: say so instead of leaving the keys out
-            for k in ("cpu_baseline", "minade_match", "graph_replay", "config2_64x128", "roofline_sde_step", "train_step"):
+            for k in ("cpu_baseline", "minade_match", "graph_replay", "config2_64x128", "config3_argo_t30", "roofline_sde_step", "train_step",
+                      "config4_train"):
                 line[k] = "n/a (N>1): measured by the N=1 run"
         if not args.no_cpu_baseline and world == 1:
             def gpu_fn(b_cpu, seed):
@@ -378,6 +379,68 @@ def main():
                                           "workload": "BASELINE configs[1]: 64 scenes x 128 agents, K=6, 20 SDE steps",
                                           "aa_edges_per_step": int(w2l.e_aa()), "streams_per_gpu": n_streams, "windows_ms": [1e3 * w for w in w2]}
                 del w2l
+            # BASELINE configs[2] (Argoverse-shaped: 32 scenes x 48 agents, 150 lanes, K=6, T=30 -> 31 Euler steps incl. the solver's
+            # micro-step): forward throughput, and minADE / minFDE of one of its scenes against the oracle on the same Philox seed
+            try:
+                c3 = CONFIGS["config3"]
+                m3 = PredictionModelSDENet(**build_cfg(c3), init_seed=0).eval().to(dev)
+                skw3 = dict(c3["synth"])
+                cpu3 = synth(**skw3)
+                b3s, y3s = [], []
+                for st in streams:
+                    with torch.cuda.stream(st):
+                        b = cpu3.to(dev)
+                        b3s.append(b)
+                        y3s.append(b.y.clone())
+                torch.cuda.synchronize()
+
+                def step3(i):
+                    k = i % n_streams
+                    with torch.cuda.stream(streams[k]):
+                        b3s[k].y = y3s[k]
+                        m3(b3s[k], noise=NoiseSpec(seed=30_000 + i))
+                for i in range(2 * n_streams):
+                    step3(i)
+                w3 = []
+                for w in range(3):
+                    sync_all()
+                    t0 = time.perf_counter()
+                    for i in range(args.steps):
+                        step3(100 + w * args.steps + i)
+                    sync_all()
+                    w3.append(time.perf_counter() - t0)
+                el3 = float(np.median(w3))
+                entry = {"value": skw3["S"] * args.steps / el3, "ms_per_step": 1e3 * el3 / args.steps, "unit": "scenes/s",
+                         "workload": "BASELINE configs[2] shape: 32 scenes x 48 agents, 150 lanes, K=6, T=30 (31 Euler steps), source = Argoverse; "
+                                     "synthetic stand-in for the Argoverse val split (no preprocessed data in the image)",
+                         "streams_per_gpu": n_streams, "windows_ms": [1e3 * w for w in w3]}
+                if not args.no_cpu_baseline:
+                    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                    import restate
+                    from trajsde_amd.metrics import ADE_T, FDE_T
+                    one = synth(**dict(skw3, S=1))
+                    P3 = {k: v.detach().cpu().clone() for k, v in m3.state_dict().items()}
+                    want = restate.forward(P3, build_cfg(c3), one, restate.PhiloxNoise(4321))
+                    bg = one.to(dev)
+                    got = m3(bg, noise=NoiseSpec(seed=4321))
+                    idx = one["agent_index"]
+                    vals = {}
+                    for name, (loc, mask, y) in (("gpu", (got["loc"].cpu(), got["reg_mask"].cpu(), bg.y.cpu())),
+                                                 ("cpu", (want["loc"], want["reg_mask"], want["y"]))):
+                        last = loc.shape[2] - 1
+                        ade, fde = ADE_T("Argoverse", [last, last]), FDE_T("Argoverse", [last, last])
+                        a = (loc[:, idx, :, :2], y[idx], mask[idx], one["source"])
+                        ade.update(*a)
+                        fde.update(*a)
+                        vals[name] = (float(ade.compute()), float(fde.compute()))
+                    entry["minade_match"] = {"minADE_gpu": vals["gpu"][0], "minADE_cpu_oracle": vals["cpu"][0], "minFDE_gpu": vals["gpu"][1],
+                                             "minFDE_cpu_oracle": vals["cpu"][1],
+                                             "max_abs_loc_diff": float((got["loc"].cpu() - want["loc"]).abs().max()), "tolerance": 1e-4,
+                                             "sample": "one 48-agent scene of the same generator, Philox seed 4321"}
+                line["config3_argo_t30"] = entry
+                del m3, b3s, y3s
+            except Exception as e:
+                line["config3_argo_t30"] = {"error": repr(e)[:300]}
         # the step-granular decoder SDE step (state round-trips HBM every Euler step: SURVEY 8(d)'s 512 B / path-step
         # variant) in both views: algorithmic HBM GB/s -- the figure the north star names -- and the FLOP/s beside it
         try:
@@ -416,16 +479,17 @@ def main():
         except Exception as e:
             line["roofline_sde_step"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_train_step:
-        # secondary figure (not `value`): the training step of BASELINE configs[1] -- forward + L2/DiffBCE + the three
-        # stage backward calls + AdamW, reported next to the inference metric
-        try:
+        # secondary figures (not `value`): the training step -- forward + L2/DiffBCE + the three stage backward calls + AdamW
+        #  -- at BASELINE configs[1] (64 x 128, K=6, T=20) and at the shape of configs[3], the shipped
+        # training recipe (128 scenes x 48 agents per GPU, K=10, T=60, mixed sources: CFG:9-22,106)
+        def train_figure(name, what):
             from trajsde_amd.driver import FlatTraining
-            twl = Workload(SECONDARY)
-            tspec = CONFIGS[SECONDARY]
-            tmodel = PredictionModelSDENet(**build_cfg(tspec), init_seed=0).to(dev).train()
-            flat = FlatTraining(tmodel)                                       # the training loop's handle (driver.train)
             from trajsde_amd import runtime
             from trajsde_amd.data import TemporalData
+            twl = Workload(name)
+            tspec = CONFIGS[name]
+            tmodel = PredictionModelSDENet(**build_cfg(tspec), init_seed=0).to(dev).train()
+            flat = FlatTraining(tmodel)                                       # the training loop's handle (driver.train)
             tb = twl.batches[0]
             tbase = {k: v for k, v in tb.as_dict().items() if not k.startswith("_")}
             tbase["y"] = twl.y0s[0]
@@ -451,14 +515,19 @@ def main():
                 tstep(2 + i)
             torch.cuda.synchronize()
             tms = (time.perf_counter() - t0) / 8 * 1e3
-            line["train_step"] = {"ms_per_step": tms, "scenes_per_s": tspec["synth"]["S"] / tms * 1e3, "steps": 8,
-                                  "workload": "BASELINE configs[1]: 64 scenes x 128 agents, K=6, 20 SDE steps",
-                                  "what": "training_step + backward (HIP backward kernels of all three stages) + AdamW, fp32 gradients, a fresh "
-                                          "copy of the batch per step, the loop of driver.train (next batch's graph stage on a side stream)",
-                                  "loss_L2": float(tmodel.last_losses["L2"]), "loss_DiffBCE": float(tmodel.last_losses["DiffBCE"])}
-            del twl, tmodel
-        except Exception as e:                                              # never let the secondary figure cost the main line
-            line["train_step"] = {"error": repr(e)[:300]}
+            return {"ms_per_step": tms, "scenes_per_s": tspec["synth"]["S"] / tms * 1e3, "steps": 8, "workload": what,
+                    "what": "training_step + backward (HIP backward kernels of all three stages) + AdamW, fp32 gradients, a fresh "
+                            "copy of the batch per step, the loop of driver.train (next batch's graph stage on a side stream)",
+                    "loss_L2": float(tmodel.last_losses["L2"]), "loss_DiffBCE": float(tmodel.last_losses["DiffBCE"]),
+                    "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+        for key, name, what in (("train_step", SECONDARY, "BASELINE configs[1]: 64 scenes x 128 agents, K=6, 20 SDE steps"),
+                                ("config4_train", "config4", "BASELINE configs[3] shape per GPU: 128 scenes x 48 agents, 150 lanes, K=10, T=60 "
+                                                             "(61 Euler steps), mixed nuScenes / Argoverse sources, dropout 0.1")):
+            try:
+                line[key] = train_figure(name, what)
+            except Exception as e:                                          # never let a secondary figure cost the main line
+                line[key] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
     if rank == 0 and args.kernel_table:
         lib.trajsde_profile_mode(2)
         with torch.no_grad():

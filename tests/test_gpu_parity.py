@@ -515,6 +515,7 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
                       ("one_tile", {"TRAJSDE_EDGE_PAIR": "0"}),
                       ("two_kernel", {"TRAJSDE_ATTN_FUSED": "0"}),
                       ("fused_one_tile", {"TRAJSDE_FUSED_TILES": "1"}),
+                      ("gattn_mm", {"TRAJSDE_GATTN_MM": "1"}),
                       ("pipelined", {"TRAJSDE_EDGE_PIPE": "1"}),
                       ("tile32", {"TRAJSDE_EDGE_TILE": "32"}),
                       ("tile32_pingpong", {"TRAJSDE_EDGE_TILE": "32", "TRAJSDE_EDGE_PINGPONG": "1"}),
@@ -530,6 +531,8 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
         assert H.maxdiff(outs["split"][key], outs["two_kernel"][key]) <= 2e-5, key
         assert torch.equal(outs["two_kernel"][key], outs["one_tile"][key]), key        # two tiles per wave: the same bits
         assert torch.equal(outs["split"][key], outs["fused_one_tile"][key]), key         # 16 waves x 1 tile: the same streams, the same bits
+        # the global attention on the matrix cores (gattn.hip): logits and weighted sums as split products over 16-edge tiles
+        assert H.maxdiff(outs["split"][key], outs["gattn_mm"][key]) <= 2e-5, key
         assert torch.equal(outs["split"][key], outs["pipelined"][key]), key              # k_edge_attn2p: the tiles one stage apart, the same bits
         # the fused edge attention on 32x32x16 matrix tiles (edge32.hip): other fragment order, same algebra; with and without the
         # phase barriers between the two waves of a SIMD: the same bits

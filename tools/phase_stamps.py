@@ -20,6 +20,9 @@ TABLES = {
                                       "P3 drift out, EM update", "  barrier", "P4 GRU gates first layers", "  barrier",
                                       "P5 gates, r*h", "  barrier", "P6 candidate first layer", "  barrier",
                                       "P7 candidate out, blend", "  barrier", "top: x_t loads, noise, biases", "-"]),
+    "gattn": (8, "16-edge tiles", ["issue the loads of the tiles ahead", "wait for this tile's rel / k_node rows", "splits + stage writes",
+                                   "P1: fragment reads + 12 matrix instr.", "softmax", "P2: splits + 16 matrix instr.", "loop overhead",
+                                   "per-target epilogue (W_ve, store)"]),
     "sde_step": (8, "tile-steps", ["wait for the state rows", "noise: Philox + Box-Muller (16 normals / lane)",
                                    "first layers: split + 48 matrix instr.", "32 tanh / lane", "drift: layer 2 + tanh + layer 3",
                                    "diffusion: layer 2 + tanh + head + sigmoid", "update + store", "-"]),

@@ -102,6 +102,10 @@ int64_t fused_rec_floats(int64_t E, bool exact, int64_t targets);
 int fused_edge_attention(const char* tag, bool dominant, const float* img, const float* geom, const int32_t* dst, const float* q,
                          const EdgeCount& ec, const int32_t* segptr, int64_t R, float* rec, float* agg, int heads, hipStream_t st,
                          const DropArg& drop, float* emb_out = nullptr, float* stats = nullptr, SegMerge* defer = nullptr);
+// the same attention on the matrix cores (gattn.hip): inference, 8 heads, fp32 rows, no dropout; an alternative, TRAJSDE_GATTN_MM=1 selects it
+bool gattn_mm_enabled();
+int launch_global_attn_mm(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
+                          const float* vn, int64_t N, float* agg, hipStream_t st);
 // launch the instantiation selected by (heads, bf16 state storage, dropout)
 #define TS_GLOBAL_ATTN(heads, bf16, drop, ...)                                                                       \
   do {                                                                                                              \

@@ -519,7 +519,11 @@ static int aggregator_forward_impl(const trajsde_batch* b, const trajsde_graph* 
     if (fused) {
       // one wave per target: logits, softmax and aggregation in one pass over the rel rows (no per-edge GEMM)
       TS_REQUIRE(N < (1 << 23), "aggregator_forward: node rows are addressed with 32-bit byte offsets (N < 2^23)");
-      TS_GLOBAL_ATTN(num_heads, state_bf16(), drop, xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, static_cast<float*>(nullptr));
+      if (num_heads == 8 && !state_bf16() && drop.p == 0.f && gattn_mm_enabled()) {
+        if (int rc = launch_global_attn_mm(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, st)) return rc;
+      } else {
+        TS_GLOBAL_ATTN(num_heads, state_bf16(), drop, xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, static_cast<float*>(nullptr));
+      }
       if (int rc = update_ffn(im, w.agg, w.xn, x, N, w.x1, w.xn2, out, st, drop)) return rc;
       x = out;
       continue;
