@@ -825,6 +825,38 @@ def test_flat_training_is_the_per_parameter_adamw_bit_for_bit(dev):
         assert na == nb and torch.equal(pa.detach(), pb.detach()), na
 
 
+def test_early_gradient_slice_leaves_the_gradients_of_the_plain_step(dev):
+    """the two-slice gradient all-reduce of the multi-rank loop (driver.FlatGrads.early_reduce: the decoder + aggregator block is
+    accumulated -- and, with more than one rank, sent to the all-reduce on a side stream -- between the aggregator and the encoder
+    backward calls): on one rank the flat gradient buffer must end up bit for bit as without it, step after step"""
+    from trajsde_amd import driver
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    batch = synth(S=2, n=10, L=5, F=6, box=50.0, seed=22, mixed_source=True).to(dev)
+    y0 = batch.y.clone()
+    flats = []
+    for early in (False, True):
+        m, _ = H.build_model(3, 6, 0.5, init_seed=9)
+        m.lr, m.weight_decay, m.T_max = 1e-3, 1e-4, 4
+        m = m.to(dev).train()
+        ft = driver.FlatTraining(m)
+        ft.grads.early_enabled = early
+        hist = []
+        for i in range(2):
+            ft.zero()
+            batch.y = y0
+            m.training_step(batch, i, noise=NoiseSpec(seed=50 + i)).backward()
+            if early:
+                assert ft.grads._early is not None and ft.grads._early[1] > 0          # a proper tail block went early
+            ft.all_reduce_mean()                                                          # one rank: nothing to reduce, state reset
+            assert ft.grads._early is None
+            hist.append(ft.grads.flat.clone())
+            ft.step()
+        flats.append(hist)
+    for a, b in zip(*flats):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0
+
+
 def _oracle_nll_grads(model, cfg, batch_cpu, local, glob, y_rot, seed, eps):
     import restate
     from trajsde_amd.schedule import decoder_schedule

@@ -414,3 +414,86 @@ def test_direct_accumulation_is_kept_without_a_multi_rank_trainer():
     model._trainer_stub = None
     model.direct_grad_accumulation = False
     assert model._direct_accumulation() is False
+
+
+def _early_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from trajsde_amd.driver import FlatGrads
+        torch.set_num_threads(1)
+        g = torch.Generator().manual_seed(7)
+        shapes = {"encoder": [(5, 3), (7,), (4, 4)], "aggregator": [(6,), (2, 8)], "decoder": [(3, 3), (9,)]}
+        names, params = [], []
+        for st in ("encoder", "aggregator", "decoder"):
+            for i, sh in enumerate(shapes[st]):
+                names.append(f"{st}.{i}")
+                params.append(torch.nn.Parameter(torch.randn(*sh, generator=g)))
+
+        def stage_grads(step):               # what the stage backward entry points hand over: views of one flat buffer per stage
+            out = {}
+            gg = torch.Generator().manual_seed(100 * rank + step)
+            for st in ("encoder", "aggregator", "decoder"):
+                mine = [(n, p) for n, p in zip(names, params) if n.startswith(st)]
+                buf = torch.randn(sum(p.numel() for _, p in mine), generator=gg) * (1e-3 if st == "encoder" else 1.0)
+                off = 0
+                for n, p in mine:
+                    out[n] = buf[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+            return out
+
+        res = {}
+        for mode in ("plain", "early"):
+            fg = FlatGrads(params)
+            hist = []
+            for step in range(3):
+                fg.zero()
+                grads = stage_grads(step)
+                one = torch.ones(())
+                if mode == "early":
+                    sub = [n for n in names if not n.startswith("encoder")]
+                    assert fg.early_reduce([params[names.index(n)] for n in sub], [grads[n] for n in sub])
+                assert fg.accumulate(params, [grads[n] for n in names], one)
+                fg.all_reduce_mean()
+                hist.append(fg.flat.clone())
+            res[mode] = torch.stack(hist).numpy()
+        q.put((rank, res))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_slice_gradient_all_reduce_equals_the_one_piece_form():
+    """the decoder + aggregator block of the flat gradient buffer is all-reduced while the encoder backward runs
+    (FlatGrads.early_reduce), the encoder block afterwards.  On two gloo ranks the averaged buffer must equal the one-piece
+    all-reduce BIT FOR BIT, step after step, and both ranks must hold the same bits."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_early_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, res in got:
+        assert np.array_equal(res["plain"], res["early"])
+        assert np.abs(res["plain"]).max() > 0
+    assert np.array_equal(got[0][1]["early"], got[1][1]["early"])
+
+
+def test_early_reduce_refuses_a_block_that_is_not_contiguous():
+    from trajsde_amd.driver import FlatGrads
+    ps = [torch.nn.Parameter(torch.zeros(3)) for _ in range(4)]
+    fg = FlatGrads(ps)
+    buf = torch.ones(6)
+    assert fg.early_reduce([ps[0], ps[2]], [buf[:3], buf[3:]]) is False           # not one block of the flat buffer
+    assert fg._early is None
+    assert fg.early_reduce([ps[2], ps[3]], [buf[:3], buf[3:]]) is True
+    with pytest.raises(RuntimeError):
+        fg.accumulate(ps, [None, buf[:3], buf[:3], buf[3:]], torch.ones(()))      # ps[0] has no gradient: does not add up

@@ -92,6 +92,54 @@ class FlatGrads:
 
     def zero(self) -> None:
         self.flat.zero_()
+        self._early = None
+
+    # ---- the gradient all-reduce in two slices, the first one under the encoder backward ----
+    # The stage backward entry points run decoder -> aggregator -> encoder; the decoder's and the aggregator's gradients are final
+    # when the encoder backward -- two thirds of the backward's time -- is only being enqueued.  `early_reduce` (called by the path
+    # loss between the two, when `early_enabled`) adds those gradients into their block of `flat` and starts that block's
+    # all-reduce on a side stream; `accumulate` later skips what is already in, and `all_reduce_mean` reduces the rest and waits.
+    # Element by element the sums are those of the one-piece collective (the same two-operand additions on two ranks; a ring sums
+    # every element over the ranks in the same order whatever the piece it travels in): bit-equal in the gloo test.
+    early_enabled = False
+    _early = None
+
+    def _block_of(self, params, grads):
+        """(ids, lo, hi) of the parameters among `params` that hold a gradient, if they form ONE block of `flat`"""
+        have = {id(p) for p, g in zip(params, grads) if g is not None}
+        idx = [i for i, p in enumerate(self.params) if id(p) in have]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            return None
+        lo = self.offsets[idx[0]]
+        hi = self.offsets[idx[-1]] + self.params[idx[-1]].numel()
+        return have, lo, hi
+
+    def early_reduce(self, params, grads) -> bool:
+        """accumulate the given (final) gradients with scale 1 and start the all-reduce of their block.  The caller guarantees
+        that `backward()` will be called with a unit gradient (driver.train does: it never scales the loss)."""
+        import torch.distributed as dist
+        blk = self._block_of(params, grads)
+        if blk is None or self._early is not None:
+            return False
+        ids, lo, hi = blk
+        sub_p = [p for p in params if id(p) in ids]
+        sub_g = [g for p, g in zip(params, grads) if id(p) in ids]
+        one = torch.ones((), device=self.flat.device, dtype=self.flat.dtype)
+        if not self._accumulate_runs(sub_p, sub_g, one):
+            return False
+        work = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            piece = self.flat[lo:hi]
+            if self.flat.is_cuda:
+                main = torch.cuda.current_stream(self.flat.device)
+                side = runtime.side_stream(self.flat.device)
+                side.wait_stream(main)                       # the block is complete on the main stream up to here
+                with torch.cuda.stream(side):
+                    work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)
+            else:
+                work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)
+        self._early = (ids, lo, hi, work)
+        return True
 
     def accumulate(self, params, grads, scale) -> bool:
         """`.grad += scale * g` for all parameters at once, when the gradients arrive as views of a few flat buffers (what the
@@ -100,19 +148,33 @@ class FlatGrads:
         `flat` that buffer's parameters cover -- six launches a step instead of ~250 slice pairs walked by multi-tensor kernels.
         `params` / `grads`: parallel lists (a gradient may be None); `scale`: 0-dim tensor.  Returns False, having done
         nothing, whenever the layout is not that simple (the caller then accumulates parameter by parameter)."""
-        by_id = {id(p): g for p, g in zip(params, grads) if g is not None}
-        if len(by_id) != len(self.params):
+        done = self._early[0] if self._early is not None else ()
+        pairs = [(p, g) for p, g in zip(params, grads) if g is not None and id(p) not in done]
+        if len(pairs) + len(done) != len(self.params):
+            if self._early is not None:
+                raise RuntimeError("FlatGrads: gradients reduced early do not add up with the rest to the parameter list")
             return False
+        ok = self._accumulate_runs([p for p, _ in pairs], [g for _, g in pairs], scale)
+        if not ok and self._early is not None:
+            raise RuntimeError("FlatGrads: a block was reduced early but the rest of the gradients is not in flat-buffer layout")
+        return ok
+
+    def _accumulate_runs(self, params, grads, scale) -> bool:
+        by_id = {id(p): g for p, g in zip(params, grads) if g is not None}
         runs = []                                        # (source flat, first offset in self.flat, [(offset in source, numel)])
         for p, view, off in zip(self.params, self.views, self.offsets):
             g = by_id.get(id(p))
-            if g is None or p.grad is not view or g._base is None or not g.is_contiguous() or g.numel() != p.numel() \
+            if g is None:
+                continue
+            if p.grad is not view or g._base is None or not g.is_contiguous() or g.numel() != p.numel() \
                     or g.dtype != self.flat.dtype or g._base.dim() != 1:
                 return False
             if not runs or runs[-1][0] is not g._base:
                 if any(r[0] is g._base for r in runs):
                     return False                         # a source buffer's parameters are not one block of `flat`
                 runs.append((g._base, off, []))
+            elif off != runs[-1][1] + sum(n for _, n in runs[-1][2]):
+                return False                             # ... or not contiguous in it
             runs[-1][2].append((g.storage_offset() - g._base.storage_offset(), p.numel()))
         for src, first, pieces in runs:
             key = (first, src.numel(), tuple(pieces))
@@ -127,9 +189,21 @@ class FlatGrads:
 
     def all_reduce_mean(self) -> None:
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            self._early = None
+            return
+        if self._early is None:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
+        else:
+            _, lo, hi, work = self._early
+            if lo > 0:
+                dist.all_reduce(self.flat[:lo], op=dist.ReduceOp.SUM)
+            if hi < self.flat.numel():
+                dist.all_reduce(self.flat[hi:], op=dist.ReduceOp.SUM)
+            if work is not None:
+                work.wait()                              # (CUDA: the current stream waits for the side stream's collective)
+            self._early = None
+        self.flat.div_(dist.get_world_size())
 
 
 class FlatTraining:
@@ -323,6 +397,9 @@ def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None, ckpt_p
         scheduler.load_state_dict(state["lr_schedulers"][0])
         first_epoch, step = int(state["epoch"]) + 1, int(state["global_step"])
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    # two-slice gradient all-reduce, the decoder + aggregator slice under the encoder backward (FlatGrads.early_reduce); this loop
+    # never scales the loss, which is what the early slice assumes.  `model.overlap_grad_allreduce = False` keeps the one-piece form
+    flat.grads.early_enabled = dist_on and bool(getattr(model, "overlap_grad_allreduce", True))
     rank = torch.distributed.get_rank() if dist_on else 0
     rank0 = rank == 0
     history = []

@@ -199,13 +199,27 @@ class PredictionModelSDENet(LightningHooks):
             d_glob, d_local = d_glob * w_l2, d_local * w_l2
         agg = agg_rt.aggregator_backward(data, local, d_glob, noise, tape=agg_tape)
         del agg_tape
+        # multi-rank training loop (driver.train): the decoder's and aggregator's gradients are final -- their slice of the flat
+        # gradient buffer goes to the all-reduce now, on a side stream, under the encoder backward (driver.FlatGrads.early_reduce)
+        sink = getattr(self, "_grad_sink", None)
+        early = {}
+        if sink is not None and getattr(sink, "early_enabled", False) and self._direct_accumulation():
+            for n, g in dec["grads"].items():
+                early["decoder." + n] = g if w_l2 == 1.0 else g * w_l2
+            for n, g in agg["grads"].items():
+                early["aggregator." + n] = g
+            named = dict(self.named_parameters())
+            ps = [named[n] for n in early]
+            if not sink.early_reduce(ps, [early[n] for n in early]):
+                early = {}
         enc = enc_rt.encoder_backward(data, d_local + agg["d_local_embed"], noise, diff_weight=w_diff, tape=enc_tape)
         del enc_tape
-        by_name = {}
-        for n, g in dec["grads"].items():
-            by_name["decoder." + n] = g if w_l2 == 1.0 else g * w_l2
-        for n, g in agg["grads"].items():
-            by_name["aggregator." + n] = g
+        by_name = dict(early)
+        if not early:
+            for n, g in dec["grads"].items():
+                by_name["decoder." + n] = g if w_l2 == 1.0 else g * w_l2
+            for n, g in agg["grads"].items():
+                by_name["aggregator." + n] = g
         for n, g in enc["grads"].items():
             by_name["encoder." + n] = g
         self.last_output = out
