@@ -4,6 +4,7 @@ pinned against the reference by the golden vectors).  Tolerances are relative to
 gradient tensor: fp32 sums over ~1e5 rows on both sides."""
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -309,6 +310,57 @@ def test_full_size_training_step_agrees_between_kernel_forms(dev):
         if not zero_by_symmetry and (abs(norm - o_norm) > tol or abs(proj - o_proj) > tol * 8):
             bad.append((n, norm, o_norm, proj, o_proj))
     print("largest difference between the kernel forms, relative to the gradient's norm:", worst)
+    assert not bad, bad[:6]
+
+
+def test_full_size_config4_training_step(dev):
+    """BASELINE configs[3] at its per-GPU shape (synth.CONFIGS["config4"]: 128 scenes x 48 agents, 150 lanes, K=10, T=60 -> 61 Euler
+    steps, mixed sources, dropout 0.1 -- the shipped training recipe, CFG:9-22,106): the whole training step runs, the loss and every
+    reached gradient are finite and the step repeats bit for bit; and ONE of its scenes alone is differentiated by float64 autograd
+    over the oracle with the same Philox noise and dropout masks: loss to 1e-5, every gradient to 2e-4 of its largest entry."""
+    import restate
+    from trajsde_amd import runtime
+    from trajsde_amd.synth import CONFIGS, synth
+    spec = CONFIGS["config4"]
+    K, T = spec["num_modes"], spec["future_steps"]
+    model, cfg = H.build_model(K, T, spec["max_fut_t"], init_seed=0)
+    model.loss_weights = [1.0, 0.5]
+    model = model.to(dev).train()
+    big = synth(**spec["synth"])
+    digests = []
+    for _ in range(2):
+        for p_ in model.parameters():
+            p_.grad = None
+        loss = model.training_step(H.clone_batch(big).to(dev), 0, noise=runtime.NoiseSpec(seed=61))
+        loss.backward()
+        torch.cuda.synchronize()
+        assert np.isfinite(float(loss))
+        reached = model.params_with_gradient()
+        assert len(reached) >= 240 and all(p_.grad is not None and bool(torch.isfinite(p_.grad).all()) for p_ in reached)
+        digests.append((float(loss), [p_.grad.clone() for p_ in reached]))
+    assert digests[0][0] == digests[1][0] and all(torch.equal(a, b) for a, b in zip(digests[0][1], digests[1][1]))
+    from trajsde_amd import _lib
+    _lib.check_range()
+    # one scene of the same generator against the oracle
+    one = synth(**dict(spec["synth"], S=1))
+    for p_ in model.parameters():
+        p_.grad = None
+    loss = model.training_step(H.clone_batch(one).to(dev), 0, noise=runtime.NoiseSpec(seed=62))
+    loss.backward()
+    torch.cuda.synchronize()
+    want_loss, want = _oracle_full_grads(model, cfg, one, 62, 1.0, 0.5, drop=restate.PhiloxDropout(62, 0.1))
+    assert abs(float(loss) - want_loss) <= 1e-5 * max(1.0, abs(want_loss))
+    reached = {id(p_) for p_ in model.params_with_gradient()}
+    bad = []
+    for n, p_ in model.named_parameters():
+        if id(p_) not in reached:
+            continue
+        w = want[n]
+        scale = float(w.abs().max())
+        err = float((p_.grad.cpu().double() - w).abs().max())
+        zero_by_symmetry = n.endswith("lin_k.bias") or n.endswith("lin_k_node.bias") or n.endswith("lin_k_edge.bias")
+        if (err > 5e-5 or scale > 5e-5) if zero_by_symmetry else (err > REL * scale + 1e-7):
+            bad.append((n, err, scale))
     assert not bad, bad[:6]
 
 

@@ -247,6 +247,13 @@ def test_full_size_config2_properties(dev):
     _full_size_properties(dev, "config2", scenes=(0, 37))
 
 
+def test_full_size_config3_properties(dev):
+    """BASELINE configs[2] at its full shape (synth.CONFIGS["config3"]: 32 Argoverse-sourced scenes x 48 agents, 150 lanes, K=6,
+    T=30 -> 31 Euler steps with the solver's micro-step; the synthetic stand-in for the Argoverse val split, CFG:88-96): finite /
+    scale checks, eight bit-identical repeats, two scenes re-run alone (<= 1e-5) and against the oracle (<= 1e-4)"""
+    _full_size_properties(dev, "config3", scenes=(0, 17))
+
+
 def test_full_size_metric256_properties(dev):
     """the workload `bench.py`'s `value` is quoted on (synth.CONFIGS["metric256"]: 32 scenes x 256 agents, K=6, 20 SDE steps,
     the shape BASELINE.json's metric names): finite / scale checks on the whole batch, two scenes re-run alone with the same
