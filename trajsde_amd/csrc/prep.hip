@@ -4,11 +4,10 @@
 //   ENC:73-74,103 nus_mask;  ENC:88-103 fake copies of the target agents (x + 2*randn, duplicated in-edges)
 //   ENC:107-118   21 x subgraph(valid at t) + DistanceDropEdge(radius) (UTIL:83-92)
 //   AGG:41-51     subgraph(valid at t=H-1), relative pose;   ENC:198 radius drop on lane-actor edges
-// Instead of materialising 21 boolean-masked edge lists, edges are sorted once by target (hipcub radix
-// sort -> CSR), every (t, edge) candidate gets a 1-byte flag, one prefix sum gives the compacted position
+// Instead of materialising 21 boolean-masked edge lists, edges are sorted once by target (counting sort
+// -> CSR), every (t, edge) candidate gets a 1-byte flag, one prefix sum gives the compacted position
 // of every survivor, and the segment pointer of snapshot node (t, i) is read off the same prefix sum.
 // The compacted lists carry the pre-rotated 2-d geometry the edge kernels consume (16 B per edge).
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -252,7 +251,7 @@ __device__ __forceinline__ void fake_x_body(int idx /* one thread per (k, quad o
 //                  ballot of the survivors -- 8 H bytes per 64 candidates x H.  The rows of the fake agents alias their actors'
 //                  (same positions, same padding), so their candidates are the same bits.
 //   k_aa_count     one thread per snapshot node (t, i): popcounts of its row's stretch of the ballots -> segment lengths; a prefix
-//                  sum (hipcub) turns them into the segment pointers.
+//                  sum (k_scan_chained) turns them into the segment pointers.
 //   k_aa_fill      one wave per extended node: for every t the survivors of the row are handed to the lanes by rank (lane r takes the
 //                  r-th set bit of the row's ballots), so a segment's records are computed and written 64 at a time, contiguously
 //                  -- the pass is as long as the output, not as long as the candidate list.
@@ -530,13 +529,95 @@ __global__ void k_collect_counts(int64_t n_aa, int E, int E_al, const int32_t* _
   }
 }
 
-// flags are bytes; scan them as int32 (an accumulator of the input type would wrap at 256)
-struct ByteToInt {
-  __host__ __device__ __forceinline__ int32_t operator()(const uint8_t& v) const { return int32_t(v); }
-};
-using FlagIter = hipcub::TransformInputIterator<int32_t, ByteToInt, const uint8_t*>;
-static hipError_t scan_flags(void* tmp, size_t& tmp_bytes, const uint8_t* flags, int32_t* out, int n, hipStream_t st) {
-  return hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, FlagIter(flags, ByteToInt()), out, n, st);
+// ---- exclusive prefix sums of the graph stage: one launch each, no library.  (Rounds 1-3 called hipcub::DeviceScan: two launches
+// per scan -- init_lookback_scan_state + the scan -- and rocPRIM on the hot path for what are 8 K .. 2 M element scans.)
+// "Chained scan with decoupled look-back": a workgroup takes a ticket (so that a workgroup only ever waits for workgroups that have
+// already started), scans its chunk in registers, publishes its sum, then walks back over the published words of its predecessors
+// -- a wave looks at 64 of them at a time -- until it meets one that carries a complete prefix; it then publishes its own.  One
+// 64-bit word per workgroup holds (state << 32 | value), read and written with agent-scope atomics; the words and the ticket are
+// zeroed by the memset that already clears the degree counters (PrepWs::zeroed).  Values are counts < 2^31.
+constexpr int SCAN_MAX_BLOCKS = 512;
+constexpr int SCAN_WORDS = SCAN_MAX_BLOCKS + 1;            // per scan instance: the ticket + one word per workgroup
+constexpr int SCAN_INSTANCES = 5;                          // agent-agent segments, global flags, lane flags, the two CSR row pointers
+template <typename IN, int PER>                            // PER elements per thread, PER x 1024 per workgroup
+__global__ __launch_bounds__(1024) void k_scan_chained(const IN* __restrict__ in, int32_t* __restrict__ out, int n,
+                                                       unsigned long long* __restrict__ st) {
+  __shared__ int32_t wsum[16];
+  __shared__ int s_bid;
+  __shared__ int32_t s_prefix;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) s_bid = int(__hip_atomic_fetch_add(&st[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  __syncthreads();
+  const int b = s_bid;
+  const int64_t first = (int64_t(b) * 1024 + t) * PER;
+  int32_t v[PER];
+  int32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    v[i] = first + i < n ? int32_t(in[first + i]) : 0;
+    s += v[i];
+  }
+  int32_t inc = s;                                          // inclusive scan of the threads' sums inside the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int32_t o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  int32_t wbase = 0;
+  for (int w = 0; w < wv; ++w) wbase += wsum[w];
+  if (wv == 0) {
+    int32_t total = lane < 16 ? wsum[lane] : 0;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) total += __shfl_xor(total, d);
+    total = __shfl(total, 0);
+    unsigned long long* words = st + 1;
+    if (lane == 0)
+      __hip_atomic_store(&words[b], ((b == 0 ? 2ull : 1ull) << 32) | (unsigned long long)(unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int32_t prefix = 0;
+    if (b > 0) {
+      int j = b - 1;
+      for (long spins = 0;; ++spins) {
+        if (spins > (1L << 28)) __builtin_trap();          // a predecessor never published: fail loudly, never hang
+        const int k = j - lane;
+        const unsigned long long w = k >= 0 ? __hip_atomic_load(&words[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 32);
+        const unsigned flag = unsigned(w >> 32);
+        const unsigned long long done = __ballot(flag == 2u), none = __ballot(flag == 0u);
+        const int upto = done ? __builtin_ctzll(done) : 63;    // the nearest predecessor with a complete prefix ends the walk
+        const unsigned long long need = upto == 63 ? ~0ull : ((1ull << (upto + 1)) - 1);
+        if (none & need) continue;                         // one of the words we need is not there yet: look again
+        int32_t part = lane <= upto ? int32_t(unsigned(w)) : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) part += __shfl_xor(part, d);
+        prefix += part;
+        if (done) break;
+        j -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(&words[b], (2ull << 32) | (unsigned long long)(unsigned)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_prefix = prefix;
+  }
+  __syncthreads();
+  int32_t run = s_prefix + wbase + inc - s;                 // exclusive prefix of this thread's first element
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    if (first + i < n) out[first + i] = run;
+    run += v[i];
+  }
+}
+// out[i] = sum of in[0 .. i), i < n; `st`: this scan's SCAN_WORDS zeroed words; in == out is allowed
+template <typename IN>
+static int scan_exclusive(const IN* in, int32_t* out, int64_t n, unsigned long long* st, hipStream_t stream) {
+  TS_REQUIRE(n <= int64_t(SCAN_MAX_BLOCKS) * 65536, "graph stage: more than 33 M elements in a prefix sum");
+  const int64_t per = (n + int64_t(SCAN_MAX_BLOCKS) * 1024 - 1) / (int64_t(SCAN_MAX_BLOCKS) * 1024);      // smallest class that needs <= 512 workgroups
+  if (per <= 8) k_scan_chained<IN, 8><<<cdiv(n, 8 * 1024), 1024, 0, stream>>>(in, out, int(n), st);
+  else if (per <= 16) k_scan_chained<IN, 16><<<cdiv(n, 16 * 1024), 1024, 0, stream>>>(in, out, int(n), st);
+  else if (per <= 32) k_scan_chained<IN, 32><<<cdiv(n, 32 * 1024), 1024, 0, stream>>>(in, out, int(n), st);
+  else k_scan_chained<IN, 64><<<cdiv(n, 64 * 1024), 1024, 0, stream>>>(in, out, int(n), st);
+  TS_LAUNCH_CHECK("k_scan_chained");
+  return TRAJSDE_OK;
 }
 
 // phase-1 workspace layout, derived from the batch sizes alone (so both phases agree on it)
@@ -549,15 +630,19 @@ struct PrepWs {
   uint32_t* vmask;               // per actor: bit t = valid at history step t
   unsigned long long* bal;       // [ceil(E / 64)][H]: survivors of 64 consecutive CSR positions at step t (k_aa_ballots)
   float *x_fake, *lane_feat;
-  void* cub_tmp;
-  int64_t cub_bytes, n_aa;
+  unsigned long long* scan_st;   // SCAN_INSTANCES x SCAN_WORDS zeroed words (k_scan_chained), directly behind the degree counters
+  int64_t zeroed_bytes, n_aa;
   int64_t total;
   bool ok;
   PrepWs(const trajsde_batch* b, void* ws, int64_t ws_bytes) {
     Carver c(ws, ws_bytes);
     const int64_t N = b->N, A = b->A, E = b->E, Nt = N + A, H = b->H, Ea = b->E_al;
     n_aa = H * Nt;
-    deg = c.take<int32_t>(2 * (N + 1)); la_deg = deg + (N + 1);          // both degree arrays: one memset (graph_prepare)
+    // both degree arrays and the scans' state words: ONE block, one memset (graph_prepare)
+    const int64_t deg_ints = (2 * (N + 1) + 1) / 2 * 2;
+    deg = c.take<int32_t>(deg_ints + 2 * int64_t(SCAN_INSTANCES) * SCAN_WORDS); la_deg = deg + (N + 1);
+    scan_st = reinterpret_cast<unsigned long long*>(deg + deg_ints);
+    zeroed_bytes = (deg_ints + 2 * int64_t(SCAN_INSTANCES) * SCAN_WORDS) * int64_t(sizeof(int32_t));
     rowptr = c.take<int32_t>(N + 1);
     csr_src = c.take<int32_t>(E + 1); csr_dst = c.take<int32_t>(E + 1);
     orig = c.take<int32_t>(Nt); eos = c.take<int32_t>(Nt); pick_slot = c.take<int32_t>(Nt); counts = c.take<int32_t>(8);
@@ -569,11 +654,6 @@ struct PrepWs {
     x_fake = c.take<float>(A * H * 2 + 4); lane_feat = c.take<float>(int64_t(b->L) * 2 + 4);
     vmask = c.take<uint32_t>(N + 1);
     bal = c.take<unsigned long long>(((E + 63) / 64 + 1) * H);
-    size_t s1 = 0, s2 = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, s1, (int32_t*)nullptr, (int32_t*)nullptr, int(n_aa + 1), (hipStream_t)0);
-    (void)scan_flags(nullptr, s2, nullptr, nullptr, int((E > Ea ? E : Ea) + 1), (hipStream_t)0);
-    cub_bytes = int64_t(s1 > s2 ? s1 : s2) + 256;
-    cub_tmp = c.take<uint8_t>(cub_bytes);
     total = c.off + 256;
     ok = c.ok;
   }
@@ -638,13 +718,12 @@ __global__ __launch_bounds__(1024) void k_scan_small(const int32_t* __restrict__
 // (deg arrives zeroed)
 // dst_out (or null): the target of every CSR position (the row it lies in), for the passes that walk positions, not rows
 static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* rowptr, int32_t* out, int64_t* lane_pack,
-                     void* cub_tmp, int64_t cub_bytes, hipStream_t st, int32_t* dst_out = nullptr) {
+                     unsigned long long* scan_words, hipStream_t st, int32_t* dst_out = nullptr) {
   if (E > 0) k_degree<<<cdiv(E, 256), 256, 0, st>>>(ei, E, deg);
   if (N + 1 <= 32768) {
     k_scan_small<<<1, 1024, 0, st>>>(deg, rowptr, N + 1);
-  } else {
-    size_t tmp = size_t(cub_bytes);
-    TS_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, deg, rowptr, N + 1, st));
+  } else if (int rc = scan_exclusive(deg, rowptr, int64_t(N) + 1, scan_words, st)) {
+    return rc;
   }
   if (E > 0 && lane_pack == nullptr) {
     k_scatter<<<cdiv(E, 256), 256, 0, st>>>(ei, E, rowptr, deg, out, 0);
@@ -697,10 +776,10 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
   NoiseArg na{0, nullptr, nullptr};
   if (fake_noise) { na.seed = fake_noise->seed; na.z = fake_noise->z; na.row_ids = fake_noise->row_ids; na.seed_dev = fake_noise->seed_dev; }
 
-  TS_HIP(hipMemsetAsync(w.deg, 0, size_t(2) * (N + 1) * sizeof(int32_t), st));       // actor and lane degree counters
+  TS_HIP(hipMemsetAsync(w.deg, 0, size_t(w.zeroed_bytes), st));       // actor and lane degree counters, the scans' state words
   {
     ProfScope ps("build_csr[actors]", st);
-    if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.csr_src, nullptr, w.cub_tmp, w.cub_bytes, st, w.csr_dst)) return rc;
+    if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.csr_src, nullptr, w.scan_st + 3 * SCAN_WORDS, st, w.csr_dst)) return rc;
   }
   {
     InputPassArgs ia;
@@ -726,24 +805,15 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
   }
   { ProfScope ps("k_aa_count", st);
   k_aa_count<<<cdiv(int64_t(H) * Nt, 256), 256, 0, st>>>(Nt, H, w.rowptr, w.orig, w.bal, w.aa_segptr); }
-  {
-    size_t tmp = size_t(w.cub_bytes);
-    TS_HIP(hipcub::DeviceScan::ExclusiveSum(w.cub_tmp, tmp, w.aa_segptr, w.aa_segptr, int(w.n_aa + 1), st));
-  }
-  {
-    size_t tmp = size_t(w.cub_bytes);
-    TS_HIP(scan_flags(w.cub_tmp, tmp, w.flags_g, w.cpos_g, E + 1, st));
-  }
+  if (int rc = scan_exclusive(w.aa_segptr, w.aa_segptr, w.n_aa + 1, w.scan_st + 0 * SCAN_WORDS, st)) return rc;
+  if (int rc = scan_exclusive(w.flags_g, w.cpos_g, int64_t(E) + 1, w.scan_st + 1 * SCAN_WORDS, st)) return rc;
   // lane-actor edges grouped by actor
   {
     ProfScope ps("build_csr[lanes]", st);
-    if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_eid, w.la_pack, w.cub_tmp, w.cub_bytes, st, w.la_actor)) return rc;
+    if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_eid, w.la_pack, w.scan_st + 4 * SCAN_WORDS, st, w.la_actor)) return rc;
   }
   k_la_flags<<<cdiv(Ea + 1, 256), 256, 0, st>>>(Ea, w.la_eid, b->lane_actor_vectors, radius, w.flags_la);
-  {
-    size_t tmp = size_t(w.cub_bytes);
-    TS_HIP(scan_flags(w.cub_tmp, tmp, w.flags_la, w.cpos_la, Ea + 1, st));
-  }
+  if (int rc = scan_exclusive(w.flags_la, w.cpos_la, int64_t(Ea) + 1, w.scan_st + 2 * SCAN_WORDS, st)) return rc;
   k_collect_counts<<<cdiv(N + 1, 256), 256, 0, st>>>(w.n_aa, E, Ea, w.aa_segptr, w.cpos_g, w.cpos_la, radius, w.counts, N, w.rowptr, w.la_rowptr,
                                                      w.g_segptr, w.la_segptr);
   TS_LAUNCH_CHECK("graph_prepare kernels");
