@@ -117,6 +117,21 @@ def _oracle_aggregator_grads(model, cfg, batch_cpu, local, d_glob, heads=8):
     return grads, local.grad
 
 
+def _aggregator_point_away_from_relu_kinks(model, cfg, batch_cpu, local, d_glob, heads=8):
+    """(local', oracle grads, oracle d_local) with local' = local or local nudged by a few 1e-5: a point where the oracle's own
+    gradients do not move when the input moves by 2e-6.  At a point where some ReLU input of the interactor's FFNs lies within
+    rounding of zero, the two one-sided gradients differ by that unit's whole contribution and float32 summation order picks the
+    side -- the kernels and the oracle then legitimately disagree by percents (seen in round 4: a 1.4e-6 change of the encoder's
+    output put layer 1's FFN of this test's point on such a kink; any 1e-6 nudge of `local` brought the agreement back to 7e-7)."""
+    for eps in (0.0, 1e-5, 2e-5, 4e-5, 8e-5):
+        loc = (local * (1.0 + eps)).contiguous()
+        want, d_local = _oracle_aggregator_grads(model, cfg, batch_cpu, loc, d_glob, heads)
+        _, d_near = _oracle_aggregator_grads(model, cfg, batch_cpu, loc * (1.0 + 2e-6), d_glob, heads)
+        if _rel(d_near, d_local) <= 5e-5:
+            return loc, want, d_local
+    raise AssertionError("no kink-free point near the test input")
+
+
 @pytest.mark.parametrize("S,n,K,heads,kw", [
     (3, 20, 4, 8, dict(mixed_source=True, history_dropout=0.3)),
     (2, 33, 2, 8, dict(source=1)),
@@ -606,9 +621,9 @@ def test_aggregator_backward_is_bitwise_reproducible_and_handles_asymmetric_grap
         data.y, data["rotate_mat"] = y_rot, rot
         local, *_ = model.encoder(data=data, noise=noise)
         d_glob = torch.randn(K, local.shape[0], 64, generator=g)
+        local, want, d_local = _aggregator_point_away_from_relu_kinks(model, cfg, batch, local, d_glob)
         a = model.aggregator._rt.aggregator_backward(data, local, d_glob.to(dev))
         b = model.aggregator._rt.aggregator_backward(data, local, d_glob.to(dev))
-        want, d_local = _oracle_aggregator_grads(model, cfg, batch, local, d_glob)
         assert _rel(a["d_local_embed"], d_local) <= REL
         for k in ("global_interactor_layers.0.lin_k_node.weight", "global_interactor_layers.2.lin_v_node.weight", "rel_embed.aggr_embed.2.weight"):
             assert _rel(a["grads"][k], want[k]) <= REL, (asymmetric, k)

@@ -627,9 +627,11 @@ static void recipe_encoder(Packer& P) {
   {  // the same matrices once more as split-precision images for k_enc_recur_coop
     using C = EncCoopL6;
     auto at = [](int m) { return B::COOP6 + m * MAT64X6; };
+    // the layers in front of a tanh carry its 2 / ln 2, those in front of a sigmoid its -1 / ln 2 (tile.hpp tanh_prescaled /
+    // sigmoid_prescaled: one multiply less per activation); k_enc_recur_coop scales the matching biases when it copies them to LDS
+    P.scale = TANH_PRESCALE;
     P.mat6("lsde_func.f_func.net.0.weight", at(C::F0), 64, 64, 66, 0);
     P.mat6("lsde_func.f_func.net.2.weight", at(C::F2), 64, 64, 64);
-    P.mat6("lsde_func.f_func.net.4.weight", at(C::F4), 64, 64, 64);
     P.mat6("lsde_func.g_nus.net.0.weight", at(C::N0), 64, 64, 66, 0);
     P.mat6("lsde_func.g_nus.net.2.weight", at(C::N2), 64, 64, 64);
     P.mat6("lsde_func.g_argo.net.0.weight", at(C::A0), 64, 64, 66, 0);
@@ -638,10 +640,13 @@ static void recipe_encoder(Packer& P) {
     P.mat6("gru_unit.reset_gate.0.weight", at(C::RH), 64, 64, 128, 0);
     P.mat6("gru_unit.update_gate.0.weight", at(C::UX), 64, 64, 128, 64);
     P.mat6("gru_unit.reset_gate.0.weight", at(C::RX), 64, 64, 128, 64);
-    P.mat6("gru_unit.update_gate.2.weight", at(C::U2), 64, 64, 64);
-    P.mat6("gru_unit.reset_gate.2.weight", at(C::R2), 64, 64, 64);
     P.mat6("gru_unit.new_state_net.0.weight", at(C::NX), 64, 64, 128, 0);
     P.mat6("gru_unit.new_state_net.0.weight", at(C::NH), 64, 64, 128, 64);
+    P.scale = SIGMOID_PRESCALE;
+    P.mat6("gru_unit.update_gate.2.weight", at(C::U2), 64, 64, 64);
+    P.mat6("gru_unit.reset_gate.2.weight", at(C::R2), 64, 64, 64);
+    P.scale = 0.f;
+    P.mat6("lsde_func.f_func.net.4.weight", at(C::F4), 64, 64, 64);
     P.mat6("gru_unit.new_state_net.2.weight", at(C::N2G), 64, 64, 64);
   }
 }

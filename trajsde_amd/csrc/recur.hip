@@ -245,6 +245,15 @@ __device__ __forceinline__ Opnd opnd_read(const float* tile, const Lane& L) {
 __device__ __forceinline__ f4 vec_slice(const float* v, int w, int g) { return *reinterpret_cast<const f4*>(v + 16 * w + 4 * g); }
 __device__ __forceinline__ f4 tanh4(f4 a) { return f4{fast_tanh(a[0]), fast_tanh(a[1]), fast_tanh(a[2]), fast_tanh(a[3])}; }
 __device__ __forceinline__ f4 sigm4(f4 a) { return f4{fast_sigmoid(a[0]), fast_sigmoid(a[1]), fast_sigmoid(a[2]), fast_sigmoid(a[3])}; }
+// the cooperative kernel's activations: its layers arrive pre-multiplied by the activation's constant (pack.hip EncCoopL6) in the
+// fp16x3 build; in the bf16x6 build, where it reads the plain fp32 fragments, these are the ordinary forms
+#if TSDE_SPLIT_H3
+__device__ __forceinline__ f4 tanhp4(f4 a) { return f4{tanh_prescaled(a[0]), tanh_prescaled(a[1]), tanh_prescaled(a[2]), tanh_prescaled(a[3])}; }
+__device__ __forceinline__ f4 sigmp4(f4 a) { return f4{sigmoid_prescaled(a[0]), sigmoid_prescaled(a[1]), sigmoid_prescaled(a[2]), sigmoid_prescaled(a[3])}; }
+#else
+__device__ __forceinline__ f4 tanhp4(f4 a) { return tanh4(a); }
+__device__ __forceinline__ f4 sigmp4(f4 a) { return sigm4(a); }
+#endif
 
 // Register files (round 4).  The sixteen weight slices are 256 registers per lane -- all of the wave's ACCUMULATION registers
 // (a0 .. a255) and nothing else: they are written there once (pin_agpr) and the matrix instructions read them in place as their A
@@ -334,9 +343,16 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
                                  GA + DiffL::B0, GA + DiffL::WS, GA + DiffL::WC, F + DriftL::B2, F + DriftL::B4, GN + DiffL::B2,
                                  GA + DiffL::B2, GN + DiffL::W4, GA + DiffL::W4, gru_img + G::BUR, gru_img + G::BUR + 64,
                                  gru_img + G::BU2, gru_img + G::BR2, gru_img + G::BN0, gru_img + G::BN2};
+    // (the EncCoopL6 matrices in front of a tanh / a sigmoid are packed times TANH_PRESCALE / SIGMOID_PRESCALE: their biases follow)
+#if TSDE_SPLIT_H3
+    constexpr float TP = TANH_PRESCALE, SP = SIGMOID_PRESCALE;
+#else
+    constexpr float TP = 1.f, SP = 1.f;
+#endif
+    const float mul[V_COUNT] = {TP, TP, TP, TP, TP, TP, TP, TP, TP, TP, 1.f, TP, TP, 1.f, 1.f, TP, TP, SP, SP, TP, 1.f};
     if (threadIdx.x < 64) {
 #pragma unroll
-      for (int v = 0; v < V_COUNT; ++v) BV[v * 64 + threadIdx.x] = src[v][threadIdx.x];
+      for (int v = 0; v < V_COUNT; ++v) BV[v * 64 + threadIdx.x] = src[v][threadIdx.x] * mul[v];
     }
   }
   auto bias = [&](int v) { return *reinterpret_cast<const f4*>(BV + v * 64 + 16 * w + 4 * L.g); };
@@ -439,10 +455,10 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
       }
       TS_TILES {
         if (SAVE) keep(tp.HIN, k, state_slice(k));
-        a[k] = tanh4(a[k]);
+        a[k] = tanhp4(a[k]);
         keep(tp.H1, k, a[k]);
         opnd_write(Ab(k), a[k], w, L);
-        g[k] = tanh4(g[k]);
+        g[k] = tanhp4(g[k]);
         keep(tp.G1, k, g[k]);
         opnd_write(Bb(k), g[k], w, L);
       }
@@ -462,26 +478,26 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
       if (src_kind == SRC_NUS) {
         TS_TILES g[k] = bias(V_NB2);
         slice_mma_n<T>(g, wn2, g1);
-        TS_TILES { g[k] = tanh4(g[k]); part[k] = head(g[k], bias(V_NW4)); }
+        TS_TILES { g[k] = tanhp4(g[k]); part[k] = head(g[k], bias(V_NW4)); }
       } else if (src_kind == SRC_ARGO) {
         TS_TILES g[k] = bias(V_AB2);
         slice_mma_n<T>(g, wa2, g1);
-        TS_TILES { g[k] = tanh4(g[k]); part[k] = head(g[k], bias(V_AW4)); }
+        TS_TILES { g[k] = tanhp4(g[k]); part[k] = head(g[k], bias(V_AW4)); }
       } else {
         f4 g2[T];
         TS_TILES { g[k] = bias(V_NB2); g2[k] = bias(V_AB2); }
         slice_mma_n<T>(g, wn2, g1);
         slice_mma_n<T>(g2, wa2, g1);
         TS_TILES {
-          g[k] = tanh4(g[k]);
-          g2[k] = tanh4(g2[k]);
+          g[k] = tanhp4(g[k]);
+          g2[k] = tanhp4(g2[k]);
           const float pn = head(g[k], bias(V_NW4)), pa = head(g2[k], bias(V_AW4));
           part[k] = is_nus[k] ? pn : pa;
           g[k] = is_nus[k] ? g[k] : g2[k];
         }
       }
       TS_TILES {
-        a[k] = tanh4(a[k]);
+        a[k] = tanhp4(a[k]);
         keep(tp.H2, k, a[k]);
         opnd_write(Cb(k), a[k], w, L);
         keep(tp.G2, k, g[k]);
@@ -535,8 +551,8 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
       slice_mma_n<T>(u1, wux, xin);
       slice_mma_n<T>(r1, wrx, xin);
       TS_TILES {
-        u1[k] = tanh4(u1[k]);
-        r1[k] = tanh4(r1[k]);
+        u1[k] = tanhp4(u1[k]);
+        r1[k] = tanhp4(r1[k]);
         keep(tp.U1, k, u1[k]);
         keep(tp.R1, k, r1[k]);
         opnd_write(Ab(k), u1[k], w, L);
@@ -556,9 +572,9 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
       slice_mma_n<T>(ug, wu2, u1);
       slice_mma_n<T>(r, wr2, r1);
       TS_TILES {
-        ug[k] = sigm4(ug[k]);
+        ug[k] = sigmp4(ug[k]);
         const f4 hs = state_slice(k);
-        r[k] = sigm4(r[k]);
+        r[k] = sigmp4(r[k]);
         const f4 rhs = r[k] * hs;
         keep(tp.UU, k, ug[k]);
         keep(tp.RR, k, r[k]);
@@ -578,7 +594,7 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
       slice_mma_n<T>(n1, wnx, xin);
       slice_mma_n<T>(n1, wnh, rh);
       TS_TILES {
-        n1[k] = tanh4(n1[k]);
+        n1[k] = tanhp4(n1[k]);
         keep(tp.N1, k, n1[k]);
         opnd_write(Ab(k), n1[k], w, L);
       }

@@ -561,6 +561,9 @@ __device__ __forceinline__ void tanh_(f4 (&a)[JT]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) a[jt][c] = fast_tanh(a[jt][c]);
 }
+// sigmoid of a pre-activation that arrives multiplied by -1 / ln 2: 1 / (1 + 2^u)
+constexpr float SIGMOID_PRESCALE = -1.4426950408889634f;
+__device__ __forceinline__ float sigmoid_prescaled(float u) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u)); }
 template <int JT>
 __device__ __forceinline__ void tanh_prescaled_(f4 (&a)[JT]) {
 #pragma unroll
