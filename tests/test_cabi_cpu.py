@@ -16,6 +16,13 @@ def test_library_exports_every_declared_symbol(repo_root):
     for name in declared:
         assert hasattr(lib, name)
     assert lib.trajsde_abi_version() == _lib.ABI_VERSION == 9
+    # the library of the alternative kernel forms (tests and A/B tools load it through TRAJSDE_LIB) speaks the same ABI
+    import ctypes
+    alt = ctypes.CDLL(_lib.ALT_LIB_PATH)
+    for name in declared:
+        assert hasattr(alt, name), name
+    assert alt.trajsde_abi_version() == _lib.ABI_VERSION
+    assert os.path.getsize(_lib.LIB_PATH) < os.path.getsize(_lib.ALT_LIB_PATH)      # the product library carries one form of every kernel
 
 
 # ---- prototype-level check: names alone would let an argument added on one side only slip through ----------
@@ -240,3 +247,45 @@ def test_backward_tile_kernels_compile_without_spills_and_with_the_correctness_f
     assert len(kernels) >= 10
     spilled = [(name[:60], int(sz)) for name, sz in kernels if int(sz) > 0]
     assert not spilled, spilled
+
+
+def test_shipped_isa_carries_no_slp_packed_fp32_arithmetic(tmp_path):
+    """ISA guard for DESIGN section 5 item 8.  With the SLP vectoriser on, the compiler pairs the fp32 arithmetic around
+    the matrix products into v_pk_fma_f32 on register pairs it shuffles together with v_pk_mov_b32, and identical launches of the
+    backward tile kernels then disagree in their low-order bits.  The mechanism is not pinned down, so the build is fenced three
+    ways: the flag (-fno-slp-vectorize), the macro the sources demand (-DTSDE_NO_SLP=1, csrc/tile.hpp #error), and THIS check of
+    what the compiler actually emitted: no translation unit with matrix instructions may contain v_pk_mov_b32 (the register-pair
+    shuffles only the vectoriser needs), and the backward units -- where the irreproducible tiles were -- no v_pk_fma_f32 either
+    (the f4 arithmetic written out in the sources compiles to v_pk_mul_f32 / v_pk_add_f32 there, which the shipped, bit-reproducible
+    build does contain: 200 + 40 in node_bwd.hip, against 489 + 1099 and 850 v_pk_fma_f32 with the vectoriser on; the forward
+    units hold a few dozen v_pk_fma_f32 from explicit f4 multiply-adds and are checked for bit-identical repeats on the GPU).  A
+    compiler upgrade that packs this arithmetic by another route fails here instead of silently on the GPU."""
+    import subprocess
+    from trajsde_amd import build
+    flags = [f for f in build.FLAGS if f != "-fPIC"]
+    offenders, seen_mfma = {}, 0
+    procs = []
+    for src in build.sources():
+        name = os.path.basename(src)
+        if name in ("prep.hip", "pack.hip"):                 # no matrix instructions: index work and weight packing
+            continue
+        out = tmp_path / (name[:-4] + ".s")
+        extra = build.PER_FILE_FLAGS.get(name, [])
+        procs.append((name, out, subprocess.Popen([build.HIPCC, *flags, *extra, "--cuda-device-only", "-S", "-o", str(out), src],
+                                                  stderr=subprocess.DEVNULL)))
+    for name, out, p in procs:
+        assert p.wait() == 0, name
+        text = out.read_text()
+        seen_mfma += text.count("v_mfma_")
+        ops = ("v_pk_fma_f32", "v_pk_mov_b32") if name.endswith("_bwd.hip") else ("v_pk_mov_b32",)
+        bad = {op: text.count(op) for op in ops if text.count(op)}
+        if bad:
+            offenders[name] = bad
+    assert seen_mfma > 3000                                   # the scan really looked at the matrix kernels
+    assert not offenders, offenders
+    # teeth: the same scan of one backward unit built WITH the vectoriser finds the instructions
+    src = os.path.join(H.ROOT, "trajsde_amd", "csrc", "node_bwd.hip")
+    out = tmp_path / "node_bwd_slp.s"
+    slp_flags = [f for f in flags if f != "-fno-slp-vectorize"]
+    subprocess.check_call([build.HIPCC, *slp_flags, "--cuda-device-only", "-S", "-o", str(out), src], stderr=subprocess.DEVNULL)
+    assert out.read_text().count("v_pk_fma_f32") > 100

@@ -528,8 +528,15 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
                       ("tile32_pingpong", {"TRAJSDE_EDGE_TILE": "32", "TRAJSDE_EDGE_PINGPONG": "1"}),
                       ("fallbacks", {"TRAJSDE_RECUR_LEGACY": "1", "TRAJSDE_GLOBAL_UNFUSED": "1", "TRAJSDE_NODE_FP32": "0"})):
         path = str(tmp_path / (mode + ".pt"))
+        if mode in ("fused_one_tile", "gattn_mm", "pipelined", "tile32", "tile32_pingpong"):
+            from trajsde_amd import _lib              # alternative kernel forms: not in the product library (trajsde_amd/build.py)
+            env = dict(env, TRAJSDE_LIB=_lib.ALT_LIB_PATH)
         subprocess.run([sys.executable, "-c", script, path], check=True, env={**os.environ, **env}, timeout=600)
         outs[mode] = torch.load(path)
+    # ... and the product library refuses a switch whose kernel it does not carry instead of silently running the default
+    r = subprocess.run([sys.executable, "-c", script, str(tmp_path / "refused.pt")], env={**os.environ, "TRAJSDE_EDGE_TILE": "32"},
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "libtrajsde_alt.so" in r.stderr
     for key in ("loc", "pi", "diff_in", "diff_out"):
         assert H.maxdiff(outs["split"][key], outs["fp32"][key]) <= 2e-5, key
         assert H.maxdiff(outs["split"][key], outs["fallbacks"][key]) <= 2e-5, key      # two-launch recurrence, unfused global attention, two-half FFN

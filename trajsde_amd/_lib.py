@@ -6,6 +6,9 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRAJSDE_LIB") or os.path.join(HERE, "libtrajsde_hip.so")   # TRAJSDE_LIB: another build of the same ABI (A/B runs)
+# the alternative kernel forms kept as cross-checks (TRAJSDE_EDGE_TILE=32, TRAJSDE_EDGE_PIPE, TRAJSDE_FUSED_TILES, TRAJSDE_GATTN_MM):
+# a second library of the same ABI that the tests selecting them load through TRAJSDE_LIB (trajsde_amd/build.py)
+ALT_LIB_PATH = os.path.join(HERE, "variants", "libtrajsde_alt.so")
 
 STAGE_ENCODER, STAGE_AGGREGATOR, STAGE_DECODER, STAGE_DECODER_BWD, STAGE_AGGREGATOR_BWD, STAGE_ENCODER_BWD = 0, 1, 2, 3, 4, 5
 STAGE_ENCODER_GRID, STAGE_DECODER_MLP, STAGE_DECODER_MLP_BWD, STAGE_ENCODER_GRID_BWD = 6, 7, 8, 9

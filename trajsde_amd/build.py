@@ -10,6 +10,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtrajsde_hip.so")
+# The product library carries ONE form of every kernel (-DTSDE_PRODUCT).  The measured-slower alternative forms that are kept as
+# cross-checks -- the 32x32x16 edge attention (edge32.hip), the software-pipelined and the one-tile edge attention, the matrix-core
+# global attention (gattn.hip) -- are compiled into a second library of the same C-ABI, loaded (TRAJSDE_LIB) by the tests and A/B
+# tools that select them with their TRAJSDE_* switches; the product library refuses those switches.
+ALT_LIB = os.path.join(HERE, "variants", "libtrajsde_alt.so")
+ALT_SOURCES = ("attn.hip", "edge32.hip", "gattn.hip", "stages.hip")     # the units TSDE_PRODUCT changes
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize is a CORRECTNESS flag here, not a tuning one.  With the SLP vectoriser on, the compiler pairs the fp32 arithmetic
 # around the matrix products into packed instructions (v_pk_fma_f32 / v_pk_mul_f32 on register pairs shuffled together by v_pk_mov_b32),
@@ -37,7 +43,7 @@ def sources():
 
 
 def _stale() -> bool:
-    if not os.path.isfile(LIB):
+    if not os.path.isfile(LIB) or not os.path.isfile(ALT_LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "trajsde_hip.h")]
@@ -47,13 +53,22 @@ def _stale() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
-    objs = []
+    objs, alt_objs = [], []
     procs = []
     for src in sources():
-        obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ".o")
+        name = os.path.basename(src)
+        extra = PER_FILE_FLAGS.get(name, [])
+        obj = os.path.join(CSRC, name[:-4] + ".o")
         objs.append(obj)
-        extra = PER_FILE_FLAGS.get(os.path.basename(src), [])
-        procs.append((src, subprocess.Popen([HIPCC, *FLAGS, *extra, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        procs.append((src, subprocess.Popen([HIPCC, *FLAGS, "-DTSDE_PRODUCT=1", *extra, "-c", src, "-o", obj], stdout=subprocess.PIPE,
+                                            stderr=subprocess.STDOUT)))
+        if name in ALT_SOURCES:                              # the same unit with the alternative forms compiled in
+            alt = os.path.join(CSRC, name[:-4] + ".alt.o")
+            alt_objs.append(alt)
+            procs.append((src, subprocess.Popen([HIPCC, *FLAGS, *extra, "-c", src, "-o", alt], stdout=subprocess.PIPE,
+                                                stderr=subprocess.STDOUT)))
+        else:
+            alt_objs.append(obj)
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
@@ -61,8 +76,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose and out.strip():
             print(out.decode())
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    os.makedirs(os.path.dirname(ALT_LIB), exist_ok=True)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", ALT_LIB, *alt_objs])
     if verbose:
-        print(f"built {LIB}")
+        print(f"built {LIB}\nbuilt {ALT_LIB}")
     return LIB
 
 

@@ -444,8 +444,10 @@ namespace tsde {
 #endif
 template __global__ void k_edge_attn2<2, false, false, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<2, false, false, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+#ifndef TSDE_PRODUCT        // alternative forms: trajsde_amd/variants/libtrajsde_alt.so only (edge32.hip)
 template __global__ void k_edge_attn2<1, false, false, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<1, false, false, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+#endif
 template __global__ void k_edge_attn2<2, true, false, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<2, true, false, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<2, false, true, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
@@ -453,6 +455,7 @@ template __global__ void k_edge_attn2<2, false, true, 1>(const float*, const flo
 template __global__ void k_edge_attn2<2, true, true, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 template __global__ void k_edge_attn2<2, true, true, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 // ------------------------------------------------------------------------------------------------ pipelined form
+#ifndef TSDE_PRODUCT        // alternative form: trajsde_amd/variants/libtrajsde_alt.so only (edge32.hip)
 // k_edge_attn2p: the inference kernel above (same streams, same records, the same arithmetic per edge: bit-identical) with the
 // vector work of one tile issued BETWEEN the matrix instructions of the other, by construction.
 //
@@ -745,6 +748,7 @@ __global__ __launch_bounds__(512) void k_edge_attn2p(const float* __restrict__ i
 }
 template __global__ void k_edge_attn2p<0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int);
 template __global__ void k_edge_attn2p<1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int);
+#endif  // TSDE_PRODUCT
 #endif   // TSDE_SPLIT_H3
 
 

@@ -13,6 +13,10 @@
 // of k-step s = 2 jo_in + jp is fed from registers a[jo_in][8 jp + jj], i.e. input feature 32 jo_in + 8 (2 jp + (jj >> 2)) + 4 hh +
 // (jj & 3); pack.hip PK_MAT32 writes the weight fragments in that order.  A row lives on 2 lanes instead of 4: LayerNorm and
 // per-head reductions are one v_permlane32_swap; a lane holds half of each of the 8 heads (4 heads: a quarter of each).
+// (Not in the product library: this file compiles to nothing under -DTSDE_PRODUCT.  The measured-slower alternative kernel forms --
+//  this one, k_edge_attn2p, the one-tile instantiations of k_edge_attn2, gattn.hip -- live in trajsde_amd/variants/libtrajsde_alt.so,
+//  which the tests that cross-check them load through TRAJSDE_LIB: trajsde_amd/build.py.)
+#ifndef TSDE_PRODUCT
 #include "common.hpp"
 #include "kernels.hpp"
 #include "layouts.hpp"
@@ -327,3 +331,5 @@ template __global__ void k_edge_attn3<true, true, false>(const float*, const flo
 #endif   // TSDE_SPLIT_H3
 
 }  // namespace tsde
+
+#endif  // TSDE_PRODUCT

@@ -31,7 +31,7 @@ namespace tsde {
 static unsigned long long* const g_stamps_gattn = nullptr;
 #endif
 
-#if TSDE_SPLIT_H3
+#if TSDE_SPLIT_H3 && !defined(TSDE_PRODUCT)
 constexpr int GA_PITCH = 272;                // bytes per staged row of one plane: 128 halves + 16 B (ds_read_b128 of 16 rows: distinct banks)
 constexpr int GA_PLANE = 16 * GA_PITCH;      // one fp16 plane of one 16-edge tile
 constexpr float GA_LAZY = 8.0f;              // the running maximum follows a pair's maximum only past this margin
@@ -326,10 +326,14 @@ int launch_global_attn_mm(const float* img, const int32_t* segptr, const int32_t
   return TRAJSDE_OK;
 }
 #else
-bool gattn_mm_enabled() { return false; }
+bool gattn_mm_enabled() {        // asked for in a build that does not carry it: say so at the launch instead of running something else
+  static const bool v = []() { const char* e = getenv("TRAJSDE_GATTN_MM"); return e && atoi(e) != 0; }();
+  return v;
+}
 int launch_global_attn_mm(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, int64_t, float*,
                           hipStream_t) {
-  return fail(TRAJSDE_ERR_UNSUPPORTED, "the matrix-core global attention exists in the fp16x3 build only");
+  return fail(TRAJSDE_ERR_UNSUPPORTED, "the matrix-core global attention is an alternative form of the fp16x3 build: load "
+                                       "trajsde_amd/variants/libtrajsde_alt.so (TRAJSDE_LIB) for TRAJSDE_GATTN_MM=1");
 }
 #endif
 

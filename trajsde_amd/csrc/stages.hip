@@ -149,6 +149,13 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
     (void)grid; (void)lds; (void)threads;
     return fail(TRAJSDE_ERR_UNSUPPORTED, "the fused edge attention (and with it the training forward) exists in the fp16x3 build only");
 #else
+#ifdef TSDE_PRODUCT
+    // the product library carries the default form only; a switch that asks for an alternative one is refused, not ignored
+    TS_REQUIRE(!edge_tile32() && !edge_pipe() && !fused_one_tile(),
+               "TRAJSDE_EDGE_TILE / TRAJSDE_EDGE_PIPE / TRAJSDE_FUSED_TILES select alternative kernel forms that live in "
+               "trajsde_amd/variants/libtrajsde_alt.so: point TRAJSDE_LIB at it");
+    {
+#else
     if (edge_tile32()) {
 #if TSDE_SPLIT_H3
       if (d && sv) TS_EA3(true, true);
@@ -164,6 +171,7 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
       if (dominant) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<1, false, false, 0>), grid, 1024, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out);
       else TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<1, false, false, 1>), grid, 1024, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out);
     } else {
+#endif
       if (d && sv) TS_EA2(2, true, true);
       else if (d) TS_EA2(2, true, false);
       else if (sv) TS_EA2(2, false, true);
