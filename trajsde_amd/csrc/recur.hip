@@ -419,16 +419,6 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
         xq[k] = aa_bf16 ? widen4(*reinterpret_cast<const bf4*>(reinterpret_cast<const __bf16*>(aa_out) + at))
                         : *reinterpret_cast<const f4*>(aa_out + at);
       }
-    if (injected) {
-#pragma unroll
-      for (int k = 0; k < COOP_TMAX; ++k)
-        if (k < T) zq[k] = *reinterpret_cast<const f4*>(na.z + (int64_t(noise_step0 + idx) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g);
-    } else {
-      // independent of the state: issued first, it fills the waits of the first phases
-#pragma unroll
-      for (int k = 0; k < COOP_TMAX; ++k)
-        if (k < T) zq[k] = philox_normal4(nkey, STREAM_ENCODER, uint32_t(noise_step0 + idx), ridk[k], uint32_t(4 * w + L.g));
-    }
 #define TS_TILES _Pragma("unroll") for (int k = 0; k < T; ++k)
     auto state_slice = [&](int k) { return *reinterpret_cast<const f4*>(Yb(k) + L.n * COOP_RS + 16 * w + 4 * L.g); };
     clk.mark(14);
@@ -452,6 +442,13 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
         slice_mma_n<T>(g, wn0, y);
         slice_mma_n<T>(g2, wa0, y);
         TS_TILES g[k] = is_nus[k] ? g[k] : g2[k];
+      }
+      // the step's normals: independent of the state, so they are computed HERE, in the shadow of the matrix instructions just
+      // issued (a lone wave per SIMD overlaps nothing else with them), not ahead of the phase
+      if (injected) {
+        TS_TILES zq[k] = *reinterpret_cast<const f4*>(na.z + (int64_t(noise_step0 + idx) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g);
+      } else {
+        TS_TILES zq[k] = philox_normal4(nkey, STREAM_ENCODER, uint32_t(noise_step0 + idx), ridk[k], uint32_t(4 * w + L.g));
       }
       TS_TILES {
         if (SAVE) keep(tp.HIN, k, state_slice(k));
