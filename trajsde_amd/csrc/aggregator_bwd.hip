@@ -407,6 +407,12 @@ template <typename DropOf>
 static int aggregator_tape(const trajsde_batch* b, const trajsde_graph* g, const float* blob_fwd, int nl, int num_heads,
                            const float* local_embed, AggBwdWs& w, DropOf drop_of, hipStream_t st) {
   const int64_t N = b->N, E = g->E_g, ntiles = (N + 15) / 16, etiles = (E + 15) / 16;
+#if TSDE_SPLIT_H3
+  if (E > 0 && rel_embed_fused())
+    TS_LAUNCH_TAG("k_edge_embed<true>", false, k_edge_embed2, tile_grid((E + 31) / 32, 1024, edge_embed2_lds(1024)), 1024, edge_embed2_lds(1024), st,
+                  blob_fwd + AggBlob::REL6G, g->g_geom, EdgeCount{E, nullptr, 0}, w.rel, 0);
+  else
+#endif
   if (E > 0)
     TS_LAUNCH(k_edge_embed<true>, tile_grid(etiles, 1024, EdgeL6::EMB_SIZE * 4), 1024, EdgeL6::EMB_SIZE * 4, st, blob_fwd + AggBlob::REL6,
               g->g_geom, EdgeCount{E, nullptr, 0}, w.rel, 0);

@@ -817,6 +817,69 @@ __global__ __launch_bounds__(1024) void k_edge_embed(const float* __restrict__ i
   }
 }
 
+#if TSDE_SPLIT_H3
+// The same embedding with the machinery of the fused edge attention (round 4): two 16-edge tiles per wave share every weight
+// fragment, the two Linear(2,64)+LN first layers are one matrix instruction per 16 features, the matrices are feature-centred so a
+// LayerNorm is one variance reduction (attn_common.hpp edge_embed_fused_n on the EdgeL6G image); the last LayerNorm's gamma / beta
+// are applied here, the rows go out in the state storage type.  Per row the arithmetic is that of the agent-agent kernel's
+// embedding, not bit for bit that of k_edge_embed (other summation order inside the LayerNorms): the backward's recomputation
+// (EdgeL6 image) differs from either by rounding, as it always did from the fused forward.
+constexpr int EMB2_STAGE = 16 * 68;                       // floats of a wave's store tile (kernels.hpp edge_embed2_lds)
+__global__ __launch_bounds__(1024) void k_edge_embed2(const float* __restrict__ img_g, const float* __restrict__ geom, EdgeCount ec,
+                                                     float* __restrict__ emb_out, int st_bf16) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using E = EdgeL6G;
+  const int64_t n_edges = edge_count(ec);
+  stage_blob(lds, img_g, E::SIZE);
+  float* const stg = lds + E::SIZE;                         // [wave][16 rows][68]: the store tiles
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t npairs = (n_edges + 31) / 32;
+  for (int64_t pair = int64_t(blockIdx.x) * waves + wave; pair < npairs; pair += int64_t(gridDim.x) * waves) {
+    keep_lds_reads_here();
+    int64_t e[2];
+    f4 ge[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      e[t] = pair * 32 + 16 * t + L.n;
+      ge[t] = *reinterpret_cast<const f4*>(geom + 4 * (e[t] < n_edges ? e[t] : n_edges - 1));
+    }
+    f4 nrm[2][4];
+    NoStamps st;
+    edge_embed_fused_n<2, NoStamps, E>(nrm, ge, lds, L, st);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const f4 ga = *reinterpret_cast<const f4*>(lds + E::AG3 + 16 * jt + 4 * L.g);
+        const f4 be = *reinterpret_cast<const f4*>(lds + E::AE3 + 16 * jt + 4 * L.g);
+        nrm[t][jt] = nrm[t][jt] * ga + be;
+      }
+      if (st_bf16 != 0) {                                    // bf16 rows (128 B): stored from the row-on-lane registers as before
+        if (e[t] < n_edges) store_row_st(nrm[t], emb_out, e[t], L.g, true);
+      } else {
+        // fp32 rows leave through a wave-private LDS tile: written "row on lane" (a store instruction from this layout touches 16 rows,
+        // 64 bytes of each), read back with 16 lanes per row, so that every global store instruction writes four WHOLE consecutive rows
+        // (1 KB contiguous): the rows are 535 MB per forward and the scattered form cost 0.047 of the kernel's 0.187 ms
+        float* tile = stg + wave * EMB2_STAGE;
+        __builtin_amdgcn_wave_barrier();                      // the previous tile's reads are done (same wave, in order)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(tile + L.n * 68 + 16 * jt + 4 * L.g) = nrm[t][jt];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int64_t row0 = pair * 32 + 16 * t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * q + (L.lane >> 4);
+          const f4 v = *reinterpret_cast<const f4*>(tile + r * 68 + 4 * (L.lane & 15));
+          if (row0 + r < n_edges) *reinterpret_cast<f4*>(emb_out + (row0 + r) * 64 + 4 * (L.lane & 15)) = v;
+        }
+      }
+    }
+  }
+}
+#endif
+
 // global layer: k = k_node[src] + lin_k_edge(rel), v = v_node[src] + lin_v_edge(rel)  (AGG:108-117)
 // The kernel is latency-bound (ids -> dependent row gathers -> little compute), so it is software-pipelined by
 // hand: while tile i is on the matrix cores, the rows of tile i+1 are in flight and the ids of tile i+2 are loading.

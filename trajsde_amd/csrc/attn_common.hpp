@@ -102,9 +102,8 @@ __device__ __forceinline__ void edge_embed2_x6(f4 (&emb0)[4], f4 (&emb1)[4], con
 struct NoStamps {
   __device__ __forceinline__ void mark(int) {}
 };
-template <int NT, class ST>
+template <int NT, class ST, class E = EdgeL6F>
 __device__ __forceinline__ void edge_embed_fused_n(f4 (&nrm)[NT][4], const f4 (&ge)[NT], const float* lds, const Lane& L, ST& st) {
-  using E = EdgeL6F;
   f4 a[NT][4], s[NT][4];
 #if TSDE_SPLIT_H3 && !defined(TSDE_IN2_VALU)
   // the two first layers on the matrix cores (layouts.hpp IN2F): 4 matrix instructions per tile and branch instead of 48 fma

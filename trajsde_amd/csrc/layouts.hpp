@@ -100,6 +100,20 @@ struct EdgeL6F {
     SIZE = CV_END
   };
 };
+// the embedding part of EdgeL6F alone (the global interactor's relative-pose embedding, attn.hip k_edge_embed2): the same centred
+// matrices and matrix-core first layers, no key / value image; AG3 | AE3 are applied by the kernel (its output IS the LayerNorm's)
+struct EdgeL6G {
+  enum : int {
+    S_END = 0,
+    TS_FIELD(A_E, 64, S), TS_FIELD(B_E, 64, A_E),
+    TS_FIELD(WA3, MAT64X6, B_E), TS_FIELD(WB3, MAT64X6, WA3), TS_FIELD(B3, 64, WB3),
+    TS_FIELD(AG0, 64, B3), TS_FIELD(AE0, 64, AG0), TS_FIELD(W2, MAT64X6, AE0), TS_FIELD(B2, 64, W2),
+    TS_FIELD(AG3, 64, B2), TS_FIELD(AE3, 64, AG3),
+    TS_FIELD(A_C, In2L::SIZE, AE3), TS_FIELD(B_C, In2L::SIZE, A_C),
+    TS_FIELD(A_F, IN2F, B_C), TS_FIELD(B_F, IN2F, A_F),
+    SIZE = B_F_END
+  };
+};
 struct GEdgeL6 {
   enum : int { S_END = 0, TS_FIELD(WKV, 2 * MAT64X6, S), TS_FIELD(BKV, 128, WKV), SIZE = BKV_END };
 };
@@ -261,7 +275,8 @@ struct AggLayerL {
 struct AggBlob {
   static constexpr int REL = 0;
   static constexpr int REL6 = EdgeL::EMB_SIZE;
-  static constexpr int layer(int i) { return EdgeL::EMB_SIZE + EdgeL6::EMB_SIZE + i * AggLayerL::SIZE; }
+  static constexpr int REL6G = REL6 + EdgeL6::EMB_SIZE;                         // the fused form's image (EdgeL6G)
+  static constexpr int layer(int i) { return REL6G + EdgeL6G::SIZE + i * AggLayerL::SIZE; }
   static constexpr int norm(int nl) { return layer(nl); }                       // gamma | beta
   static constexpr int proj(int nl, int k) { return norm(nl) + 128 + k * (MAT64 + 64); }  // W_k frag | b_k
   static constexpr int size(int nl, int K) { return proj(nl, K); }

@@ -462,6 +462,31 @@ static void recipe_edge_fused(Packer& P, const std::string& p, const std::string
   P.emit(PK_AFFINE, 64, wv, d + E::CV, 0, 0, 0, 0, 0, e3);
   P.jobs.back().src3 = bv;
 }
+// the embedding half of recipe_edge_fused on the EdgeL6G image (no key / value part): the global interactor's rel_embed
+static void recipe_edge_fused_embed(Packer& P, const std::string& p, int base) {
+  using E = EdgeL6G;
+  const float* wa = P.src(p + ".module_list.0.3.weight");
+  const float* wb = P.src(p + ".module_list.1.3.weight");
+  const float* ba = P.src(p + ".module_list.0.3.bias");
+  const float* bb = P.src(p + ".module_list.1.3.bias");
+  const float* w2 = P.src(p + ".aggr_embed.2.weight");
+  const float* b2 = P.src(p + ".aggr_embed.2.bias");
+  P.vec(p + ".module_list.0.1.bias", base + E::A_E, 64);
+  P.vec(p + ".module_list.1.1.bias", base + E::B_E, 64);
+  P.ln2(p + ".module_list.0", base + E::A_C);
+  P.ln2(p + ".module_list.1", base + E::B_C);
+  P.in2f(p + ".module_list.0", base + E::A_C, base + E::A_F);
+  P.in2f(p + ".module_list.1", base + E::B_C, base + E::B_F);
+  P.ln(p + ".aggr_embed.0", base + E::AG0, base + E::AE0);
+  P.ln(p + ".aggr_embed.3", base + E::AG3, base + E::AE3);
+  if (P.dry) return;
+  float* d = P.blob + base;
+  P.emit(PK_MAT6_CENTRED, 4 * 2 * 512, wa, d + E::WA3);
+  P.emit(PK_MAT6_CENTRED, 4 * 2 * 512, wb, d + E::WB3);
+  P.emit(PK_MAT6_CENTRED, 4 * 2 * 512, w2, d + E::W2);
+  P.emit(PK_VEC_CENTRED, 64, ba, d + E::B3, 0, 0, 0, 0, 0, bb);
+  P.emit(PK_VEC_CENTRED, 64, b2, d + E::B2);
+}
 static void pack_kv6(Packer& P, const std::string& k, const std::string& v, int w, int b) {
   const float* wk = P.src(k + ".weight");
   const float* wv = P.src(v + ".weight");
@@ -706,6 +731,9 @@ static void recipe_decoder_mlp(Packer& P, int T) {
 static void recipe_aggregator(Packer& P, int nl, int K) {
   recipe_edge_embed(P, "rel_embed", AggBlob::REL);
   recipe_edge_embed6(P, "rel_embed", AggBlob::REL6);
+#if TSDE_SPLIT_H3
+  recipe_edge_fused_embed(P, "rel_embed", AggBlob::REL6G);
+#endif
   for (int i = 0; i < nl; ++i) {
     const std::string p = "global_interactor_layers." + std::to_string(i);
     const int b = AggBlob::layer(i);

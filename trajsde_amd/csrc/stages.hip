@@ -192,6 +192,10 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
   return TRAJSDE_OK;
 }
 bool attn_fused_enabled() { return attn_fused(); }
+bool rel_embed_fused() {            // TRAJSDE_REL_EMBED_FUSED=0: the one-tile kernel on the plain split image (A/B runs)
+  static const bool v = []() { const char* e = getenv("TRAJSDE_REL_EMBED_FUSED"); return !(e && atoi(e) == 0); }();
+  return v;
+}
 int64_t fused_rec_floats(int64_t E, bool exact, int64_t targets) { return fused_rec_slots(E, exact, targets) * SEG_REC; }
 
 }  // namespace tsde
@@ -458,6 +462,12 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
 static int aggregator_rel_embed(const trajsde_batch* b, const trajsde_graph* g, const float* blob, AggWs& w, hipStream_t st) {
   const int64_t E = g->E_g, etiles = (E + 15) / 16;
   if (E > 0) {
+#if TSDE_SPLIT_H3
+    if (edge_x6() && rel_embed_fused())                     // two tiles per wave on the centred image (attn.hip k_edge_embed2)
+      TS_LAUNCH_TAG("k_edge_embed<true>", false, k_edge_embed2, tile_grid((E + 31) / 32, 1024, edge_embed2_lds(1024)), 1024, edge_embed2_lds(1024), st,
+                    blob + AggBlob::REL6G, g->g_geom, count_of(g, 2, E), w.rel, state_bf16() ? 1 : 0);
+    else
+#endif
     if (edge_x6())
       TS_LAUNCH(k_edge_embed<true>, tile_grid(etiles, threads_edge(), EdgeL6::EMB_SIZE * 4), threads_edge(), EdgeL6::EMB_SIZE * 4, st,
                 blob + AggBlob::REL6, g->g_geom, count_of(g, 2, E), w.rel, state_bf16() ? 1 : 0);
