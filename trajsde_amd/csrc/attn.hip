@@ -824,7 +824,6 @@ __global__ __launch_bounds__(1024) void k_edge_embed(const float* __restrict__ i
 // are applied here, the rows go out in the state storage type.  Per row the arithmetic is that of the agent-agent kernel's
 // embedding, not bit for bit that of k_edge_embed (other summation order inside the LayerNorms): the backward's recomputation
 // (EdgeL6 image) differs from either by rounding, as it always did from the fused forward.
-constexpr int EMB2_STAGE = 16 * 68;                       // floats of a wave's store tile (kernels.hpp edge_embed2_lds)
 __global__ __launch_bounds__(1024) void k_edge_embed2(const float* __restrict__ img_g, const float* __restrict__ geom, EdgeCount ec,
                                                      float* __restrict__ emb_out, int st_bf16) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -858,22 +857,8 @@ __global__ __launch_bounds__(1024) void k_edge_embed2(const float* __restrict__ 
       if (st_bf16 != 0) {                                    // bf16 rows (128 B): stored from the row-on-lane registers as before
         if (e[t] < n_edges) store_row_st(nrm[t], emb_out, e[t], L.g, true);
       } else {
-        // fp32 rows leave through a wave-private LDS tile: written "row on lane" (a store instruction from this layout touches 16 rows,
-        // 64 bytes of each), read back with 16 lanes per row, so that every global store instruction writes four WHOLE consecutive rows
-        // (1 KB contiguous): the rows are 535 MB per forward and the scattered form cost 0.047 of the kernel's 0.187 ms
-        float* tile = stg + wave * EMB2_STAGE;
-        __builtin_amdgcn_wave_barrier();                      // the previous tile's reads are done (same wave, in order)
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(tile + L.n * 68 + 16 * jt + 4 * L.g) = nrm[t][jt];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int64_t row0 = pair * 32 + 16 * t;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = 4 * q + (L.lane >> 4);
-          const f4 v = *reinterpret_cast<const f4*>(tile + r * 68 + 4 * (L.lane & 15));
-          if (row0 + r < n_edges) *reinterpret_cast<f4*>(emb_out + (row0 + r) * 64 + 4 * (L.lane & 15)) = v;
-        }
+        // fp32 rows leave as whole rows through the wave's LDS tile (tile.hpp store_tile_rows): they are 535 MB per forward
+        store_tile_rows(stg + wave * ROWSTAGE, nrm[t], emb_out, pair * 32 + 16 * t, n_edges, L);
       }
     }
   }

@@ -142,7 +142,7 @@ __global__ void k_edge_attn3(const float* img, const float* geom, const int32_t*
 template <bool X6>
 __global__ void k_edge_embed(const float* img, const float* geom, EdgeCount ec, float* emb_out, int st_bf16);
 bool rel_embed_fused();
-constexpr int edge_embed2_lds(int threads) { return (EdgeL6G::SIZE + (threads / 64) * 16 * 68) * 4; }   // image + one store tile per wave
+constexpr int edge_embed2_lds(int threads) { return (EdgeL6G::SIZE + (threads / 64) * ROWSTAGE) * 4; }   // image + one store tile per wave
 __global__ void k_edge_embed2(const float* img, const float* geom, EdgeCount ec, float* emb_out, int st_bf16);   // fp16x3 build: the fused form
 template <bool X6>
 __global__ void k_global_edge(const float* img, const float* rel, const int32_t* src, const int32_t* dst, const float* q,
