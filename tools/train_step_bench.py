@@ -95,12 +95,12 @@ def main():
     edges = cnt["E_aa"] + cnt["E_la"] + cnt["E_g"]
     if "k_wgrad[edge-embed]" in table:
         n, ms_w = table["k_wgrad[edge-embed]"][0], table["k_wgrad[edge-embed]"][1]
-        by = edges * (512 + 2 * 272)
+        by = edges * (512 + 272)                       # (round 4: the two branch problems share one read of their delta rows)
         print(json.dumps({"roofline_k_wgrad_edge_embed": {"bound": "hbm", "algorithmic_bytes_per_step": by, "ms_per_step": ms_w, "launches": n,
                                                           "achieved_GBps": by / (ms_w * 1e-3) * 1e-9, "peak_GBps": 8000.0,
                                                           "frac": by / (ms_w * 1e-3) * 1e-9 / 8000.0,
                                                           "rows": {"E_aa": cnt["E_aa"], "E_la": cnt["E_la"], "E_g": cnt["E_g"]},
-                                                          "bytes_per_row": "(d e_pre, s) 2 x 256 B + 2 x (d s_pre 256 B + geometry 16 B)"}}))
+                                                          "bytes_per_row": "(d e_pre, s) 2 x 256 B + (d s_pre 256 B + geometry 16 B) read once for both branches"}}))
     tot = sum(r[0] for r in rows)
     print(f"kernel time of one step (HIP events, serial): {tot:.2f} ms")
     for ms_k, name, n in rows[:28]:

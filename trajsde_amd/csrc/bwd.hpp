@@ -69,6 +69,7 @@ struct WgradBatch {
   int add(const float* delta, int ldd, const float* a, int lda, float* W, int ldw, int col0, float* bias, int time_cols);
   int add_in2(const float* delta, int ldd, const float* geom, int pair, const float* in2, const float* beta, float* W, int ldw, float* bias);
   int flush();
+  int flush_edge();           // the edge embedding's three problems (decoder_bwd.hip k_wgrad6_edge); falls back to flush()
 };
 // W[o*ldw + col0 + i] = sum_r delta[r*ldd + o] * a[r*lda + i]  (o, i < 64);  bias[o] = sum_r delta[r*ldd + o] (or null)
 int run_wgrad(const WgradCtx& c, const float* delta, int ldd, const float* a, int lda, int64_t R, int64_t rows_per_group, float* W,

@@ -581,7 +581,7 @@ int edge_embed_backward(const float* img, const float* geom, const float* demb, 
     if (int rc = wb.add(sc.DEP, 64, sc.S, 64, gr.w2, 64, 0, gr.b2, 0)) return rc;
     if (int rc = wb.add_in2(sc.DSP, 64, geom, 0, img + EdgeL6::A_C, img + EdgeL6::A_E, gr.wa3, 64, gr.ba3)) return rc;
     if (int rc = wb.add_in2(sc.DSP, 64, geom, 1, img + EdgeL6::B_C, img + EdgeL6::B_E, gr.wb3, 64, gr.bb3)) return rc;
-    if (int rc = wb.flush()) return rc;
+    if (int rc = wb.flush_edge()) return rc;
   }
   for (int br = 0; br < 2; ++br) {
     vp = vpart_slab(sc.vpart, int64_t(gb) * 4, 320);
