@@ -875,7 +875,16 @@ __global__ __launch_bounds__(256) void k_reduce_partials(WgradJobs jobs, const f
   const int j = blockIdx.x * 32 + lane;
   float s = 0.f, ws = 0.f, wc = 0.f;
   if (j < 4096) {
-    for (int p = sl; p < P; p += 8) s += part[int64_t(p) * 4096 + j];
+    int p = sl;                                         // four loads in flight; the additions in the order of the plain loop
+    for (; p + 24 < P; p += 32) {
+      const float v0 = part[int64_t(p) * 4096 + j], v1 = part[int64_t(p + 8) * 4096 + j];
+      const float v2 = part[int64_t(p + 16) * 4096 + j], v3 = part[int64_t(p + 24) * 4096 + j];
+      s += v0;
+      s += v1;
+      s += v2;
+      s += v3;
+    }
+    for (; p < P; p += 8) s += part[int64_t(p) * 4096 + j];
   } else if (j < 4096 + 64) {
     const int o = j - 4096;
     for (int p = sl; p < P; p += 8) {
@@ -959,7 +968,16 @@ __global__ __launch_bounds__(256) void k_reduce_partials_q(ReduceJobs jobs, cons
   const int j = blockIdx.x * 32 + lane;
   float s = 0.f, ws = 0.f, wc = 0.f;
   if (j < 4096) {
-    for (int p = sl; p < P; p += 8) s += part[int64_t(p) * 4096 + j];
+    int p = sl;                                         // four loads in flight; the additions in the order of the plain loop
+    for (; p + 24 < P; p += 32) {
+      const float v0 = part[int64_t(p) * 4096 + j], v1 = part[int64_t(p + 8) * 4096 + j];
+      const float v2 = part[int64_t(p + 16) * 4096 + j], v3 = part[int64_t(p + 24) * 4096 + j];
+      s += v0;
+      s += v1;
+      s += v2;
+      s += v3;
+    }
+    for (; p < P; p += 8) s += part[int64_t(p) * 4096 + j];
   } else if (j < 4096 + 64 && (bias || time_cols)) {
     const int o = j - 4096;
     for (int p = sl; p < P; p += 8) {
@@ -1151,6 +1169,8 @@ int WgradBatch::add_in2(const float* delta, int ldd, const float* geom, int pair
 #endif
 static int launch_wgrad(const char* tag, const WgradJobs& sub, int64_t R, int64_t rows_per_group, int chunk, int cpg, int P, float* part, float* cs,
                         hipStream_t st) {
+  static const bool trace = getenv("TRAJSDE_WGRAD_TRACE") != nullptr;       // one line per launch: its shape
+  if (trace) fprintf(stderr, "wgrad %s: R=%lld jobs=%d P=%d chunk=%d groups=%lld\n", tag, (long long)R, sub.n, P, chunk, (long long)((R + rows_per_group - 1) / rows_per_group));
 #if TSDE_SPLIT_H3
   if (!wgrad_f32()) {
     TS_LAUNCH_TAG(tag, false, k_wgrad6, dim3(P, sub.n), 256, 32768 + 64, st, sub, R, rows_per_group, chunk, cpg, P, part, cs);
@@ -1187,6 +1207,13 @@ int WgradBatch::flush() {
     // the chip's 4 x 256 resident workgroups per problem), not at whatever a doubling of the chunk happens to give
     const int64_t per_group = want_parts / groups > 0 ? want_parts / groups : 1;
     chunk = ((rows_per_group + per_group - 1) / per_group + 63) / 64 * 64;
+  } else if (groups == 1) {
+    // a short problem (the aggregator's node-level layers: 8 192 rows at 64 x 128): 512-row chunks leave 16 workgroups a problem, each
+    // walking 8 blocks one after the other on a mostly idle chip -- shorter chunks, up to one resident round of workgroups
+    static const int min_chunk = []() { const char* e = getenv("TRAJSDE_WGRAD_MIN_CHUNK"); const int v = e ? atoi(e) : 128; return v < 64 ? 64 : (v + 63) / 64 * 64; }();
+    const int64_t fill = ((R + one_round - 1) / one_round + 63) / 64 * 64;
+    const int64_t shorter = fill > min_chunk ? fill : min_chunk;
+    if (shorter < chunk) chunk = shorter;
   }
   const int cpg = int((rows_per_group + chunk - 1) / chunk);
   const int P = cpg * groups;

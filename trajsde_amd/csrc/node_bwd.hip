@@ -489,7 +489,10 @@ __global__ __launch_bounds__(256) void k_headwise_outer_t(const float* __restric
   }
 }
 int run_headwise_outer(const WgradCtx& wc, const float* X, const float* Y, int64_t N, float* W, int heads) {
-  const int S = N >= 65536 ? 256 : (N >= 4096 ? 32 : (N >= 256 ? 8 : 1));
+  // slices: a workgroup keeps 32 rows in flight and waits on memory between rounds -- few rounds a workgroup (8 192 rows: 32 slices
+  // 0.34 ms for the ten launches of a 64 x 128 step, 128 slices 0.28)
+  static const int s_env = []() { const char* e = getenv("TRAJSDE_HEADWISE_SLICES"); return e ? atoi(e) : 0; }();
+  const int S = s_env > 0 && N >= 4096 ? s_env : (N >= 65536 ? 256 : (N >= 4096 ? 128 : (N >= 256 ? 8 : 1)));
   if (int64_t(S) > wc.cap) return fail(TRAJSDE_ERR_WORKSPACE, "headwise_outer: partial buffer too small");
   ReduceQueue* rq = active_reduce_queue();
   if (rq && rq->part != wc.part) rq = nullptr;
