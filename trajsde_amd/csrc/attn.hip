@@ -225,6 +225,10 @@ __device__ __forceinline__ void seg_update(SegState& S, const f4& lg, const f4 (
     S.m[jt] = mn;
     S.s[jt] = fmaf(S.s[jt], sc, ex);
     const float exk = ex * keep[jt];
+    // (The compiler picks v_fmac here -- result in the addend's register -- and copies the 16 sums of a tile back to their loop registers
+    //  at every back-edge: 32 v_mov an iteration.  The three-address v_fma_f32 written in assembly removes them but needs an s_nop in
+    //  front -- `sc` comes straight from v_exp_f32 and the compiler inserts no wait state for a reader it cannot see into; without it the
+    //  sums were wrong, caught by the golden parity test -- and measured 0.795 against 0.782 ms on one box: not kept.)
 #pragma unroll
     for (int c = 0; c < 4; ++c) S.acc[jt][c] = fmaf(S.acc[jt][c], sc, exk * v[jt][c]);
   }
@@ -243,11 +247,14 @@ __device__ __forceinline__ void seg_flush(const SegState& S, float* __restrict__
 // matrix instructions, accumulators in AGPRs -- 0.575 ms per launch against 0.47 ms; 4 waves x 2 tiles 0.60 ms.)
 // LIST (0: agent-agent, 1: agent-lane) only names the instantiation, so that a kernel trace lists the two launches of a forward
 // -- 6.85 M edges and 0.2 M edges on the metric workload -- separately.
-template <int NT, bool DROP, bool SAVE, int LIST>
+// H8: the head count is the compile-time 8 of the shipped configurations (the launch passes 8): with it a run-time value the logits of
+// every 16 features end in a branch on it, eight a tile pair, and the scheduler cannot move anything across them.
+template <int NT, bool DROP, bool SAVE, int LIST, bool H8>
 __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restrict__ img_g, const float* __restrict__ geom,
                                                           const int32_t* __restrict__ dst, const float* __restrict__ q, EdgeCount ec, int C_host,
-                                                          float* __restrict__ rec, int heads, const int32_t* __restrict__ segptr, DropArg drop,
+                                                          float* __restrict__ rec, int heads_arg, const int32_t* __restrict__ segptr, DropArg drop,
                                                           float* __restrict__ emb_out) {
+  const int heads = H8 ? 8 : heads_arg;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using EL = EdgeL6F;
   const int64_t E = edge_count(ec);
@@ -320,9 +327,12 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (ok[t] && d[t] != cur[t]) {                       // the row's target changes: its finished segment part leaves
+      // The row's target changes: its finished segment part leaves.  The state is NOT reset inside the branch -- only its running
+      // maxima go to -inf, by a select outside it: the next update then scales s and the sums by exp(-inf) = 0 itself (seg_update),
+      // and the 24 state registers of a tile stay out of the branch's merge (24 zero moves + 24 copies a tile and iteration before).
+      const bool chg = ok[t] && d[t] != cur[t];
+      if (chg) {
         if (cur[t] >= 0) seg_flush(S[t], rec, int64_t(cur[t]) + sid[t], L.g);
-        seg_reset(S[t]);
         cur[t] = d[t];
         if (DROP) rank0[t] = segptr[d[t]];
         // the new target's query row goes from L2 straight into the lane's LDS slots (global_load_lds_dwordx4: lane l's 16 bytes land
@@ -352,6 +362,8 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
                      : "v"(qrow), "v"(qrow + 16), "v"(qrow + 32), "v"(qrow + 48), "s"(slot)
                      : "memory", "scc");
       }
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) S[t].m[jt] = chg ? -INFINITY : S[t].m[jt];
     }
     st.mark(0);                                            // loads, target changes (record flush, query row)
     f4 emb[NT][4], kv[NT][8];
@@ -442,18 +454,26 @@ extern "C" int trajsde_debug_edge_wg(unsigned long long* host2048) {
 }
 namespace tsde {
 #endif
-template __global__ void k_edge_attn2<2, false, false, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<2, false, false, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, false, 0, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, false, 0, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, false, 1, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, false, 1, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 #ifndef TSDE_PRODUCT        // alternative forms: trajsde_amd/variants/libtrajsde_alt.so only (edge32.hip)
-template __global__ void k_edge_attn2<1, false, false, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<1, false, false, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<1, false, false, 0, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<1, false, false, 1, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 #endif
-template __global__ void k_edge_attn2<2, true, false, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<2, true, false, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<2, false, true, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<2, false, true, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<2, true, true, 0>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
-template __global__ void k_edge_attn2<2, true, true, 1>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, false, 0, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, false, 0, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, false, 1, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, false, 1, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, true, 0, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, true, 0, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, true, 1, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, false, true, 1, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, true, 0, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, true, 0, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, true, 1, false>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
+template __global__ void k_edge_attn2<2, true, true, 1, true>(const float*, const float*, const int32_t*, const float*, EdgeCount, int, float*, int, const int32_t*, DropArg, float*);
 // ------------------------------------------------------------------------------------------------ pipelined form
 #ifndef TSDE_PRODUCT        // alternative form: trajsde_amd/variants/libtrajsde_alt.so only (edge32.hip)
 // k_edge_attn2p: the inference kernel above (same streams, same records, the same arithmetic per edge: bit-identical) with the

@@ -90,7 +90,7 @@ inline AttnPlan attn_plan(int64_t E, int streams_target = SEG_STREAMS_512) {
   p.nstreams = stream_count(E, p.C);
   return p;
 }
-template <int NT, bool DROP, bool SAVE, int LIST>
+template <int NT, bool DROP, bool SAVE, int LIST, bool H8>
 __global__ void k_edge_attn2(const float* img, const float* geom, const int32_t* dst, const float* q, EdgeCount ec, int C, float* rec, int heads,
                              const int32_t* segptr, DropArg drop, float* emb_out);
 template <int LIST>

@@ -142,7 +142,8 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
     const int grid = xcd_grid((streams + per_wg - 1) / per_wg);
     const int lds = (EdgeL6F::LDS_SIZE + 256 * 64) * 4;                      // weight image + the parked query rows of 256 streams (64 KB)
     const bool d = drop.p > 0.f, sv = emb_out != nullptr;
-#define TS_EA2L(N_, D_, S_, L_) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<N_, D_, S_, L_>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
+#define TS_EA2H(N_, D_, S_, L_, H_) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<N_, D_, S_, L_, H_>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
+#define TS_EA2L(N_, D_, S_, L_) do { if (heads == 8) TS_EA2H(N_, D_, S_, L_, true); else TS_EA2H(N_, D_, S_, L_, false); } while (0)
 #define TS_EA2(N_, D_, S_) do { if (dominant) TS_EA2L(N_, D_, S_, 0); else TS_EA2L(N_, D_, S_, 1); } while (0)
 #define TS_EA3(D_, S_) if (edge_pingpong()) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn3<D_, S_, true>), grid, threads, lds, st, img + EdgeL6F::SIZE, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out); else TS_LAUNCH_TAG(tag, dominant, (k_edge_attn3<D_, S_, false>), grid, threads, lds, st, img + EdgeL6F::SIZE, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out)
 #if !TSDE_SPLIT_H3
@@ -168,8 +169,8 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
       if (dominant) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2p<0>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads);
       else TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2p<1>), grid, threads, lds, st, img, geom, dst, q, ec, pl.C, rec, heads);
     } else if (fused_one_tile() && !d && !sv) {
-      if (dominant) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<1, false, false, 0>), grid, 1024, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out);
-      else TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<1, false, false, 1>), grid, 1024, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out);
+      if (dominant) TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<1, false, false, 0, false>), grid, 1024, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out);
+      else TS_LAUNCH_TAG(tag, dominant, (k_edge_attn2<1, false, false, 1, false>), grid, 1024, lds, st, img, geom, dst, q, ec, pl.C, rec, heads, segptr, drop, emb_out);
     } else {
 #endif
       if (d && sv) TS_EA2(2, true, true);
