@@ -221,16 +221,23 @@ __device__ __forceinline__ void opnd_write(float* tile, const f4& v, int w, cons
   split_pair(v[2], v[3], h1, l1);
   uint2* base = reinterpret_cast<uint2*>(tile);
   const int ks = w >> 1, half = w & 1;
-  base[((0 * 2 + ks) * 64 + L.lane) * 2 + half] = uint2{h0, h1};
-  base[((1 * 2 + ks) * 64 + L.lane) * 2 + half] = uint2{l0, l1};
+  // [piece][k-step][half][lane] in 8-byte units: a wave's 64 stores are 512 contiguous bytes.  (Round 3 kept the two halves of a lane's
+  // fragment side by side -- one 16-byte read for the consumer, but lanes 16 bytes apart storing 8: every store a 2-way bank conflict, the
+  // only LDS conflicts of the forward)  The consumer's two 8-byte reads are one ds_read2_b64.
+  base[((0 * 2 + ks) * 2 + half) * 64 + L.lane] = uint2{h0, h1};
+  base[((1 * 2 + ks) * 2 + half) * 64 + L.lane] = uint2{l0, l1};
 }
 __device__ __forceinline__ Opnd opnd_read(const float* tile, const Lane& L) {
-  const u4* b = reinterpret_cast<const u4*>(tile);
+  const uint2* b = reinterpret_cast<const uint2*>(tile);
   Opnd o;
-  o.hi[0] = b[0 * 64 + L.lane];
-  o.hi[1] = b[1 * 64 + L.lane];
-  o.lo[0] = b[2 * 64 + L.lane];
-  o.lo[1] = b[3 * 64 + L.lane];
+  auto frag = [&](int pk) {
+    const uint2 x = b[(pk * 2 + 0) * 64 + L.lane], y = b[(pk * 2 + 1) * 64 + L.lane];
+    return u4{x.x, x.y, y.x, y.y};
+  };
+  o.hi[0] = frag(0);
+  o.hi[1] = frag(1);
+  o.lo[0] = frag(2);
+  o.lo[1] = frag(3);
   return o;
 }
 #else
