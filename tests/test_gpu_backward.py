@@ -293,8 +293,9 @@ def test_full_size_training_step_agrees_between_kernel_forms(dev):
     """BASELINE configs[1] (64 scenes x 128 agents: 3.4 M agent-agent edges, 4.55 M embedding rows) is far beyond what the float64 oracle
     can differentiate, so the full-size check is a cross-check: the same training step in two child processes, once with this round's
     kernel forms (k_wgrad6 on block-scaled 16-bit products, deferred sums, the cooperative recurrence kernels) and once with the forms
-    they replaced (exact fp32 weight-gradient products, one reduction per batch, one tile per wave: TRAJSDE_WGRAD_F32 /
-    TRAJSDE_IMMEDIATE_SUMS / TRAJSDE_RECUR_LEGACY).  Same loss to 1e-6, every one of the 252 - 8 gradients finite and equal in norm and in
+    they replaced (exact fp32 weight-gradient products, one reduction per batch, one tile per wave, the encoders' attention backward on the
+    vector pipe, the edge embedding's three weight-gradient problems apart: TRAJSDE_WGRAD_F32 / TRAJSDE_IMMEDIATE_SUMS / TRAJSDE_RECUR_LEGACY /
+    TRAJSDE_ROWS_BWD_MM=0 / TRAJSDE_WGRAD_EDGE_PAIR=0).  Same loss to 1e-6, every one of the 252 - 8 gradients finite and equal in norm and in
     a seeded +-1 projection to 2e-5 of its norm."""
     import json
     import subprocess
@@ -307,7 +308,8 @@ def test_full_size_training_step_agrees_between_kernel_forms(dev):
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads(r.stdout.strip().splitlines()[-1])
     new = run({})
-    old = run({"TRAJSDE_WGRAD_F32": "1", "TRAJSDE_IMMEDIATE_SUMS": "1", "TRAJSDE_RECUR_LEGACY": "1"})
+    old = run({"TRAJSDE_WGRAD_F32": "1", "TRAJSDE_IMMEDIATE_SUMS": "1", "TRAJSDE_RECUR_LEGACY": "1", "TRAJSDE_ROWS_BWD_MM": "0",
+               "TRAJSDE_WGRAD_EDGE_PAIR": "0"})
     # the deferred sums with areas so small that they are summed early many times per entry point (and one batch of partials does not
     # fit at all): the same kernels in the same order per problem -> bit-identical digests
     tight = run({"TRAJSDE_REDUCE_CAP": "600", "TRAJSDE_VPART_ARENA": "300000"})

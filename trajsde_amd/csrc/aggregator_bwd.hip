@@ -272,7 +272,192 @@ int run_gattn_drel(hipStream_t st, int heads, int nl, bool from_rows, const Drel
   return TRAJSDE_OK;
 }
 
+// ---- k_gattn_bwd<8, false> on the fp32 matrix cores (round 4).  The kernel above spends 64 of its ~95 vector instructions per edge on
+// multiply-adds: p = rel_e . U_h, t = rel_e . Z_h (16 columns for the 8 heads) and RL_h += dlogit rel_e, SS_h += alpha rel_e (16 rows).
+// Both are tile products -- [16 edges x 64] x [64 x 16] and [16 x 16 edges] x [16 edges x 64] -- and v_mfma_f32_16x16x4_f32 does them in
+// exact fp32 products with no operand split: 32 matrix instructions (1 024 pipe cycles) per 16 edges instead of 1 024 vector
+// multiply-adds (4 096 issue cycles).  One wave per target, tiles of 16 of its edges:
+//   * the tile's rows are loaded once, whole rows per 16 lanes (lane (kk, n), register r: row 4 kk + r, columns 4n..4n+3) -- which IS the
+//     B operand of the second product under the column order 4n + b -- and pass through a wave-private LDS tile to become the A operand
+//     of the first (row on lane: lane (e, kk) holds columns 16 kk .. 16 kk + 15; the contraction runs in that order on both sides);
+//   * the first product's result -- lane (j, q) holds edges 4q + i of column j -- is where the softmax scalars are computed (columns j < 8
+//     are the logits' p of head j, j >= 8 the t of head j - 8: partner lanes swap by a row rotation of 8), and their results
+//     W[e][j] = (dlogit | alpha d) sit exactly where the second product's A operand wants them (row j, contraction index 4q + i): no
+//     shuffle between the two products.
+// Same inputs, outputs and per-edge scalars as the vector form; the sums run in another order (tolerances of the gradient tests).
+// Persistent: one workgroup of 16 waves per CU, every wave walks its own targets.  What a target needs before its first tile -- the B
+// operand [U | Z], 128 multiply-adds per lane over 128 weights that depend on the lane alone -- comes from an LDS image of lin_k_edge |
+// lin_v_edge in the lanes' order (measured: the same weights re-read from L1 / L2 per target, as the vector form does, cost 0.6 of this
+// kernel's 1.1 ms; the tile loop itself 0.1).
+constexpr int RMM_WAVES = 16;
+constexpr int RMM_TP = 68;                                         // padded row of a wave's staging tile / of the plain weight copy
+constexpr int RMM_WIMG = 8192, RMM_WK = 64 * RMM_TP;              // floats: swizzled [Wke | Wve] image, plain Wke rows
+constexpr int RMM_PER_WAVE = 16 * RMM_TP + 8 * RMM_TP;            // staging tile + the eight RL rows of the d q epilogue
+constexpr int rows_mm_lds_bytes() { return (RMM_WIMG + RMM_WK + RMM_WAVES * RMM_PER_WAVE) * 4; }
+template <bool DROP>
+__global__ __launch_bounds__(64 * RMM_WAVES) void k_edge_rows_bwd_mm(const float* __restrict__ img, const int32_t* __restrict__ segptr,
+                                                                     const float* __restrict__ rel, const float* __restrict__ q,
+                                                                     const float* __restrict__ agg, const float* __restrict__ dagg,
+                                                                     const float* __restrict__ stats, int64_t N, float* __restrict__ DQ,
+                                                                     float* __restrict__ RL, float* __restrict__ SS,
+                                                                     float* __restrict__ DAGGM, float* __restrict__ EA,
+                                                                     float* __restrict__ ED, DropArg drop) {
+  constexpr int HEADS = 8;
+  constexpr float INV = INV_SQRT_DH;
+  constexpr int TP = RMM_TP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const wimg = lds;                                         // [d][kk][v4][j][4]: W_(j<8 ? k : v)[8 (j&7) + d][16 kk + 4 v4 + e]
+  float* const wk = lds + RMM_WIMG;                                // Wke[d][c], rows padded to TP
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* const tile = lds + RMM_WIMG + RMM_WK + wv * RMM_PER_WAVE;
+  float* const sb = tile + 16 * TP;                                // [8][TP]
+  const int c16 = lane & 15, q4 = lane >> 4, hd = c16 & 7;
+  const bool lo8 = c16 < 8;
+  {
+    const float* wke = img + GAttnL::WKE;
+    const float* wve = img + GAttnL::WVE;
+    for (int i = threadIdx.x; i < RMM_WIMG / 4; i += blockDim.x) {  // one f4 of the image per step
+      const int j = i & 15, v4 = (i >> 4) & 3, kk = (i >> 6) & 3, d = i >> 8;
+      const float* src = (j < 8 ? wke : wve) + (8 * (j & 7) + d) * 64 + 16 * kk + 4 * v4;
+      *reinterpret_cast<f4*>(wimg + 4 * i) = *reinterpret_cast<const f4*>(src);
+    }
+    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
+      const int row = i >> 4, c4 = i & 15;
+      *reinterpret_cast<f4*>(wk + row * TP + 4 * c4) = *reinterpret_cast<const f4*>(wke + row * 64 + 4 * c4);
+    }
+  }
+  __syncthreads();
+  const float bke = img[GAttnL::BKE + lane], bve = img[GAttnL::BVE + lane];
+  const int64_t stride = int64_t(gridDim.x) * RMM_WAVES;
+  for (int64_t node = int64_t(blockIdx.x) * RMM_WAVES + wv; node < N; node += stride) {
+    // per-head constants, first in the "lane = channel" layout (lanes 8h .. 8h+7 hold head h), then handed to the lanes of column hd
+    const float ql = q[node * 64 + lane];
+    const float da = dagg[node * 64 + lane];
+    const float ag = agg[node * 64 + lane];
+    const float m = stats[(node * HEADS + hd) * 2], inv = stats[(node * HEADS + hd) * 2 + 1];
+    const int beg = segptr[node], end = segptr[node + 1];
+    f4 nx[4];
+    auto fetch = [&](int e0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = e0 + 4 * q4 + r;
+        const int ec = e < end ? e : end - 1;
+        nx[r] = *reinterpret_cast<const f4*>(rel + int64_t(ec) * 64 + 4 * c16);
+      }
+    };
+    if (beg < end) fetch(beg);
+    const float cb = __shfl(head_sum_n<HEADS>(ql * bke), 8 * hd);
+    const float cz = __shfl(head_sum_n<HEADS>(da * bve), 8 * hd);
+    const float dlt = __shfl(head_sum_n<HEADS>(da * ag), 8 * hd);
+    // B operand of the first product: lane (kk = q4, j = c16) holds column j of [U | Z] at rows 16 kk + s
+    float uz[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) uz[s] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const float qd = __shfl(ql, 8 * hd + d), dd = __shfl(da, 8 * hd + d);
+      const float x = lo8 ? qd : dd;
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) {
+        const f4 wr = *reinterpret_cast<const f4*>(wimg + (((d * 4 + q4) * 4 + v4) * 16 + c16) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) uz[4 * v4 + e] = fmaf(wr[e], x, uz[4 * v4 + e]);
+      }
+    }
+    f4 R[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) R[b] = f4{0.f, 0.f, 0.f, 0.f};
+    float sal = 0.f, sad = 0.f;
+    for (int e0 = beg; e0 < end; e0 += 16) {
+      f4 rw[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rw[r] = nx[r];
+      if (e0 + 16 < end) fetch(e0 + 16);
+      __builtin_amdgcn_wave_barrier();                             // the previous readers of the tile are done (same wave, in order)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<f4*>(tile + (4 * q4 + r) * TP + 4 * c16) = rw[r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      f4 a[4];
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) a[v4] = *reinterpret_cast<const f4*>(tile + c16 * TP + 16 * q4 + 4 * v4);
+      f4 P0 = f4{0.f, 0.f, 0.f, 0.f}, P1 = P0;                       // two chains: a matrix instruction waits for its accumulator
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) {
+        P0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][0], uz[4 * v4 + 0], P0, 0, 0, 0);
+        P1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][1], uz[4 * v4 + 1], P1, 0, 0, 0);
+        P0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][2], uz[4 * v4 + 2], P0, 0, 0, 0);
+        P1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][3], uz[4 * v4 + 3], P1, 0, 0, 0);
+      }
+      f4 W;
+      uint32_t mine = 0u;
+      if (DROP) {                                                  // lane (x, r) draws the block of edge x and keeps word r (heads 2r, 2r+1)
+        uint32_t w[4];
+        philox_words(drop.seed, drop_stream(drop, DK_ATTN), uint32_t(e0 - beg) + uint32_t(c16), uint32_t(node), 0u, w);
+        mine = q4 == 0 ? w[0] : (q4 == 1 ? w[1] : (q4 == 2 ? w[2] : w[3]));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = e0 + 4 * q4 + i;
+        const float x = P0[i] + P1[i];
+        const float y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));   // row_ror:8 -- column j ^ 8
+        const float p = lo8 ? x : y, t = lo8 ? y : x;
+        float kp = 1.f;
+        if (DROP) {
+          const uint32_t word = uint32_t(__shfl(int(mine), 16 * (hd >> 1) + 4 * q4 + i));
+          kp = drop_pick(word, hd & 1, drop);
+        }
+        const float lg = (p + cb) * INV;
+        const float alpha = e < end ? fast_exp(lg - m) * inv : 0.f;
+        const float alk = alpha * kp;
+        const float dal = (t + cz) * kp;
+        const float dls = alpha * (dal - dlt) * INV;
+        sal += alpha;
+        sad += alk;
+        W[i] = lo8 ? dls : alk;
+        if (e < end) (lo8 ? ED : EA)[int64_t(e) * HEADS + hd] = W[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) R[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[i], rw[i][b], R[b], 0, 0, 0);
+    }
+    // lane (n, q) holds rows 4q + i' of the 16 x 64 sums at columns 4n .. 4n+3: rows 0-7 are RL of heads 0-7, rows 8-15 SS
+    __builtin_amdgcn_wave_barrier();                               // (the previous target's epilogue reads of sb are done)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f4 rv = f4{R[0][i], R[1][i], R[2][i], R[3][i]};
+      const int row = 4 * q4 + i;
+      if (row < 8) *reinterpret_cast<f4*>(sb + row * TP + 4 * c16) = rv;
+      *reinterpret_cast<f4*>((row < 8 ? RL : SS) + (node * HEADS + (row & 7)) * 64 + 4 * c16) = rv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // d q[d] = Wke[d] . RL_head(d)   (lane = channel d from here on)
+    const int h = lane >> 3;
+    float dq = 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+      const f4 wr = *reinterpret_cast<const f4*>(wk + lane * TP + 4 * k4);
+      const f4 rv = *reinterpret_cast<const f4*>(sb + h * TP + 4 * k4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dq = fmaf(wr[e], rv[e], dq);
+    }
+    // sum_e alpha (d_e) of head h: every lane of column hd holds a part (its edges 4q + i); columns hd and hd + 8 hold the same
+    float sw = DROP ? sad : sal;
+    sw = xor32_sum(xor16_sum(sw));
+    const float swh = __shfl(sw, h);
+    DQ[node * 64 + lane] = dq;
+    DAGGM[node * 64 + lane] = da * swh;                            // lin_v_edge.bias sees sum_e alpha d_e (= 1 without dropout)
+  }
+}
+
 // the encoders' attention backward over stored embedding rows (NODE = false), see bwd.hpp
+// TRAJSDE_ROWS_BWD_MM=0: the vector form (k_gattn_bwd<8, false>) for A/B runs and cross-checks
+static bool rows_bwd_mm() {
+  static const bool on = []() { const char* e = getenv("TRAJSDE_ROWS_BWD_MM"); return !(e && e[0] == '0'); }();
+  return on;
+}
 int run_edge_attn_bwd(hipStream_t st, int heads, const float* img, const int32_t* segptr, const float* emb, const float* q, const float* agg,
                       const float* dagg, const float* stats, int64_t R, float* DQ, float* RL, float* SS, float* DAGGM, float* EA, float* ED,
                       const DropArg& drop) {
@@ -282,7 +467,12 @@ int run_edge_attn_bwd(hipStream_t st, int heads, const float* img, const int32_t
   if (heads == 4)
     TS_LAUNCH_TAG("k_edge_attn_rows_bwd<4>", false, (k_gattn_bwd<4, false>), xcd_grid(cdiv(R, 4)), 256, 0, st, img, segptr, ns, emb, q, nf, nf, agg, dagg, stats,
                   R, DQ, nw, nw, RL, SS, DAGGM, EA, ED, nw, ns, drop);
-  else
+  else if (rows_bwd_mm()) {
+    // one workgroup per CU (its LDS image fills most of one); fewer when the targets do not fill them
+    const int grid = int(std::min<int64_t>(256, cdiv(R, RMM_WAVES)));
+    if (drop.p > 0.f) TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<true>), grid, 64 * RMM_WAVES, rows_mm_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop);
+    else TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<false>), grid, 64 * RMM_WAVES, rows_mm_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop);
+  } else
     TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_gattn_bwd<8, false>), xcd_grid(cdiv(R, 4)), 256, 0, st, img, segptr, ns, emb, q, nf, nf, agg, dagg, stats,
                   R, DQ, nw, nw, RL, SS, DAGGM, EA, ED, nw, ns, drop);
   return TRAJSDE_OK;
