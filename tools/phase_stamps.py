@@ -23,6 +23,9 @@ TABLES = {
     "gattn": (8, "16-edge tiles", ["issue the loads of the tiles ahead", "wait for this tile's rel / k_node rows", "splits + stage writes",
                                    "P1: fragment reads + 12 matrix instr.", "softmax", "P2: splits + 16 matrix instr.", "loop overhead",
                                    "per-target epilogue (W_ve, store)"]),
+    "gmf": (8, "16-edge tiles", ["wait for the rel rows, stage", "first product (16 matrix instr.)", "wait for key rows, node logits",
+                                 "softmax scalars", "rescale", "second product (16 matrix instr.)", "wait for value rows, node sums",
+                                 "per-target prologue / epilogue"]),
     "sde_step": (8, "tile-steps", ["wait for the state rows", "noise: Philox + Box-Muller (16 normals / lane)",
                                    "first layers: split + 48 matrix instr.", "32 tanh / lane", "drift: layer 2 + tanh + layer 3",
                                    "diffusion: layer 2 + tanh + head + sigmoid", "update + store", "-"]),

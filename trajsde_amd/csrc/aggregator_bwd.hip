@@ -614,7 +614,10 @@ static int aggregator_tape(const trajsde_batch* b, const trajsde_graph* g, const
     {
       const DropArg dl = drop_of(l);
       TS_REQUIRE(N < (1 << 23), "aggregator_forward_train: node rows are addressed with 32-bit byte offsets (N < 2^23)");
-      TS_GLOBAL_ATTN(num_heads, false, dl, xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N, w.agg[l], w.stats[l]);
+      if (num_heads == 8 && gattn_f32mm_enabled()) {
+        if (int rc = launch_global_attn_mf(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N, w.agg[l], w.stats[l], dl, st)) return rc;
+      } else
+        TS_GLOBAL_ATTN(num_heads, false, dl, xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N, w.agg[l], w.stats[l]);
     }
     TS_LAUNCH(k_node_update<true>, tile_grid(ntiles, 512, UpdL6::SIZE * 4), 512, UpdL6::SIZE * 4, st, lb + AggLayerL::UPD6, w.agg[l], w.xn[l], x,
               N, w.x1[l], w.xn2[l], drop_of(l), no_merge());

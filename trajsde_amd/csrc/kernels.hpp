@@ -104,6 +104,10 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
                          const DropArg& drop, float* emb_out = nullptr, float* stats = nullptr, SegMerge* defer = nullptr);
 // the same attention on the matrix cores (gattn.hip): inference, 8 heads, fp32 rows, no dropout; an alternative, TRAJSDE_GATTN_MM=1 selects it
 bool gattn_mm_enabled();
+// gattn_f32.hip: the same attention with its rel-row products on the fp32 matrix cores (8 heads, fp32 rows)
+bool gattn_f32mm_enabled();
+int launch_global_attn_mf(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
+                          const float* vn, int64_t N, float* agg, float* stats, const DropArg& drop, hipStream_t st);
 int launch_global_attn_mm(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
                           const float* vn, int64_t N, float* agg, hipStream_t st);
 // launch the instantiation selected by (heads, bf16 state storage, dropout)
