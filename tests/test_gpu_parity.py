@@ -523,6 +523,7 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
                       ("two_kernel", {"TRAJSDE_ATTN_FUSED": "0"}),
                       ("fused_one_tile", {"TRAJSDE_FUSED_TILES": "1"}),
                       ("gattn_mm", {"TRAJSDE_GATTN_MM": "1"}),
+                      ("gattn_vector", {"TRAJSDE_GATTN_F32MM": "0"}),
                       ("pipelined", {"TRAJSDE_EDGE_PIPE": "1"}),
                       ("tile32", {"TRAJSDE_EDGE_TILE": "32"}),
                       ("tile32_pingpong", {"TRAJSDE_EDGE_TILE": "32", "TRAJSDE_EDGE_PINGPONG": "1"}),
@@ -547,6 +548,8 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
         assert torch.equal(outs["split"][key], outs["fused_one_tile"][key]), key         # 16 waves x 1 tile: the same streams, the same bits
         # the global attention on the matrix cores (gattn.hip): logits and weighted sums as split products over 16-edge tiles
         assert H.maxdiff(outs["split"][key], outs["gattn_mm"][key]) <= 2e-5, key
+        # the default global attention (gattn_f32.hip: fp32 matrix instructions) against the vector form it replaced (attn.hip k_global_attn)
+        assert H.maxdiff(outs["split"][key], outs["gattn_vector"][key]) <= 2e-5, key
         assert torch.equal(outs["split"][key], outs["pipelined"][key]), key              # k_edge_attn2p: the tiles one stage apart, the same bits
         # the fused edge attention on 32x32x16 matrix tiles (edge32.hip): other fragment order, same algebra; with and without the
         # phase barriers between the two waves of a SIMD: the same bits
