@@ -29,6 +29,8 @@
 
 namespace tsde {
 
+static bool rows_bwd_mm();
+
 // NODE = false: attention over edge rows alone (the AA / AL encoders: k = lin_k(emb_e), v = lin_v(emb_e), `rel` = the stored
 // embedding rows): no kn / vn / src, nothing to scatter; UZ may be null (k_gattn_drel then rebuilds U, Z from q and dagg).
 template <int HEADS, bool NODE>
@@ -452,6 +454,259 @@ __global__ __launch_bounds__(64 * RMM_WAVES) void k_edge_rows_bwd_mm(const float
   }
 }
 
+// ---- k_gattn_bwd<8, true> (the global interactor's attention backward) in the same form: the rel-row products of a 16-edge tile on the
+// fp32 matrix cores, what belongs to the gathered node rows -- q_h . k_node[src]_h, dagg_h . v_node[src]_h and d q += dlogit k_node[src] --
+// on the vector pipe over the rows as they are loaded (whole rows per 16 lanes: lane (kk, n), register r: the source of edge 4 kk + r,
+// columns 4n .. 4n+3, half a head; gattn_f32.hip k_global_attn_mf is the forward twin).  Workgroups of 8 waves, one per CU; the rel rows of
+// tile t+2 are requested when tile t is staged, the value rows of t+1 once t's node dots are done, its key rows once t's d q sums are.
+constexpr int GBM_WAVES = 8;
+constexpr int GBM_PER_WAVE = 16 * RMM_TP + 16 * 16 + 16 * 8 + 16 * 8 + 3 * 64;   // staging tile (RL rows at the end) | node dots | dlogit | alpha d | d q node part, q, dagg
+constexpr int gattn_bwd_mm_lds_bytes() { return (RMM_WIMG + RMM_WK + GBM_WAVES * GBM_PER_WAVE) * 4; }
+template <bool DROP>
+__global__ __launch_bounds__(64 * GBM_WAVES) void k_gattn_bwd_mm(const float* __restrict__ img, const int32_t* __restrict__ segptr,
+                                                                 const int32_t* __restrict__ src, const float* __restrict__ rel,
+                                                                 const float* __restrict__ q, const float* __restrict__ kn,
+                                                                 const float* __restrict__ vn, const float* __restrict__ agg,
+                                                                 const float* __restrict__ dagg, const float* __restrict__ stats, int64_t N,
+                                                                 float* __restrict__ DQ, float* __restrict__ DKN, float* __restrict__ DVN,
+                                                                 float* __restrict__ RL, float* __restrict__ SS, float* __restrict__ DAGGM,
+                                                                 float* __restrict__ EA, float* __restrict__ ED, float* __restrict__ UZ,
+                                                                 const int32_t* __restrict__ asym, DropArg drop) {
+  constexpr int HEADS = 8;
+  constexpr float INV = INV_SQRT_DH;
+  constexpr int TP = RMM_TP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const wimg = lds;                                         // [d][kk][v4][j][4]: W_(j<8 ? k : v)[8 (j&7) + d][16 kk + 4 v4 + e]
+  float* const wk = lds + RMM_WIMG;                                // Wke[d][c], rows padded to TP
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* const tile = lds + RMM_WIMG + RMM_WK + wv * GBM_PER_WAVE;
+  float* const pnt = tile + 16 * TP;                               // [16 edges][16]: node part of p (heads 0-7) | of t (8-15)
+  float* const wtd = pnt + 256;                                    // [16 edges][8 heads]: dlogit / sqrt(dh)
+  float* const wta = wtd + 128;                                    // [16 edges][8 heads]: alpha d
+  float* const nsum = wta + 128;                                   // [64]: node part of d q
+  float* const qsm = nsum + 64;                                    // [64] q row | [64] dagg row
+  const int c16 = lane & 15, q4 = lane >> 4, hd = c16 & 7;
+  const bool lo8 = c16 < 8;
+  {
+    const float* wke = img + GAttnL::WKE;
+    const float* wve = img + GAttnL::WVE;
+    for (int i = threadIdx.x; i < RMM_WIMG / 4; i += blockDim.x) {
+      const int j = i & 15, v4 = (i >> 4) & 3, kk = (i >> 6) & 3, d = i >> 8;
+      const float* sp = (j < 8 ? wke : wve) + (8 * (j & 7) + d) * 64 + 16 * kk + 4 * v4;
+      *reinterpret_cast<f4*>(wimg + 4 * i) = *reinterpret_cast<const f4*>(sp);
+    }
+    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
+      const int row = i >> 4, c4 = i & 15;
+      *reinterpret_cast<f4*>(wk + row * TP + 4 * c4) = *reinterpret_cast<const f4*>(wke + row * 64 + 4 * c4);
+    }
+  }
+  __syncthreads();
+  const float bve = img[GAttnL::BVE + lane];
+  const bool scatter = *asym != 0;
+  const int64_t stride = int64_t(gridDim.x) * GBM_WAVES;
+  for (int64_t node = int64_t(blockIdx.x) * GBM_WAVES + wv; node < N; node += stride) {
+    const float ql = q[node * 64 + lane];
+    const float da = dagg[node * 64 + lane];
+    const float ag = agg[node * 64 + lane];
+    const float m = stats[(node * HEADS + hd) * 2], inv = stats[(node * HEADS + hd) * 2 + 1];
+    const int beg = segptr[node], end = segptr[node + 1];
+    const int last = end > beg ? end - 1 : beg;                    // (an empty segment loads row `beg` of the next target, or nothing is used of it)
+    auto src_at = [&](int (&dst)[4], int e0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = e0 + 4 * q4 + r;
+        dst[r] = end > beg ? src[e < end ? e : last] : 0;
+      }
+    };
+    auto rel_load = [&](f4 (&dst)[4], int e0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = e0 + 4 * q4 + r;
+        dst[r] = *reinterpret_cast<const f4*>(rel + int64_t(e < end ? e : last) * 64 + 4 * c16);
+      }
+    };
+    auto row_load = [&](f4 (&dst)[4], const float* __restrict__ base, const int (&sidx)[4]) {    // four whole rows per instruction
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[r] = *reinterpret_cast<const f4*>(base + int64_t(sidx[r]) * 64 + 4 * c16);
+    };
+    int s_cur[4], s_next[4];
+    f4 nxa[4], nxb[4], kr[4], vr[4];
+    if (end > beg) {                                               // (uniform)
+      src_at(s_cur, beg);
+      src_at(s_next, beg + 16);
+      rel_load(nxa, beg);
+      row_load(kr, kn, s_cur);
+      row_load(vr, vn, s_cur);
+      rel_load(nxb, beg + 16);
+    }
+    const float cz = __shfl(head_sum_n<HEADS>(da * bve), 8 * hd);
+    const float dlt = __shfl(head_sum_n<HEADS>(da * ag), 8 * hd);
+    // B operand of the first product: lane (kk = q4, j = c16) holds column j of [U | Z] at rows 16 kk + s; it is also what k_gattn_drel reads
+    float uz[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) uz[s] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const float qd = __shfl(ql, 8 * hd + d), dd = __shfl(da, 8 * hd + d);
+      const float x = lo8 ? qd : dd;
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) {
+        const f4 wr = *reinterpret_cast<const f4*>(wimg + (((d * 4 + q4) * 4 + v4) * 16 + c16) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) uz[4 * v4 + e] = fmaf(wr[e], x, uz[4 * v4 + e]);
+      }
+    }
+    if (UZ != nullptr) {
+      float* up = UZ + ((node * HEADS + hd) * 2 + (lo8 ? 0 : 1)) * 64 + 16 * q4;
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) *reinterpret_cast<f4*>(up + 4 * v4) = f4{uz[4 * v4], uz[4 * v4 + 1], uz[4 * v4 + 2], uz[4 * v4 + 3]};
+    }
+    __builtin_amdgcn_wave_barrier();                               // (the previous target's readers of the wave's LDS are done)
+    qsm[lane] = ql;
+    qsm[64 + lane] = da;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const f4 qn = *reinterpret_cast<const f4*>(qsm + 4 * c16);      // the query's / the incoming gradient's columns 4n .. 4n+3
+    const f4 dn = *reinterpret_cast<const f4*>(qsm + 64 + 4 * c16);
+    f4 R[4], accq = f4{0.f, 0.f, 0.f, 0.f};                          // accq: columns 4n .. 4n+3 of sum_e dlogit k_node[src], this lane row's edges
+#pragma unroll
+    for (int b = 0; b < 4; ++b) R[b] = f4{0.f, 0.f, 0.f, 0.f};
+    float sal = 0.f, sad = 0.f;
+    auto tile_step = [&](f4 (&nx)[4], int e0) {
+      int s_after[4];
+      src_at(s_after, e0 + 32);
+      __builtin_amdgcn_wave_barrier();                             // the previous readers of the wave's LDS are done (same wave, in order)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<f4*>(tile + (4 * q4 + r) * TP + 4 * c16) = nx[r];
+      rel_load(nx, e0 + 32);                                       // two tiles ahead, into the registers just staged
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      f4 P0 = f4{0.f, 0.f, 0.f, 0.f}, P1 = P0;                       // two chains: a matrix instruction waits for its accumulator
+      {
+        f4 a[4];
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) a[v4] = *reinterpret_cast<const f4*>(tile + c16 * TP + 16 * q4 + 4 * v4);
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+          P0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][0], uz[4 * v4 + 0], P0, 0, 0, 0);
+          P1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][1], uz[4 * v4 + 1], P1, 0, 0, 0);
+          P0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][2], uz[4 * v4 + 2], P0, 0, 0, 0);
+          P1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][3], uz[4 * v4 + 3], P1, 0, 0, 0);
+        }
+      }
+      // node parts of p and t: edge 4 q4 + r, head n >> 1 -- this lane's four columns and its neighbour's (lane ^ 1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = qn[0] * kr[r][0], t = dn[0] * vr[r][0];
+#pragma unroll
+        for (int e = 1; e < 4; ++e) {
+          p = fmaf(qn[e], kr[r][e], p);
+          t = fmaf(dn[e], vr[r][e], t);
+        }
+        p += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xf, 0xf, false));
+        pnt[(4 * q4 + r) * 16 + (c16 >> 1) + 8 * (c16 & 1)] = (c16 & 1) ? t : p;
+      }
+      row_load(vr, vn, s_next);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      uint32_t mine = 0u;
+      if (DROP) {                                                  // lane (x, r) draws the block of edge x and keeps word r (heads 2r, 2r+1)
+        uint32_t w[4];
+        philox_words(drop.seed, drop_stream(drop, DK_ATTN), uint32_t(e0 - beg) + uint32_t(c16), uint32_t(node), 0u, w);
+        mine = q4 == 0 ? w[0] : (q4 == 1 ? w[1] : (q4 == 2 ? w[2] : w[3]));
+      }
+      f4 W;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = e0 + 4 * q4 + i;
+        const float x = (P0[i] + P1[i]) + pnt[(4 * q4 + i) * 16 + c16];
+        const float y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));   // row_ror:8 -- column j ^ 8
+        const float p = lo8 ? x : y, t = lo8 ? y : x;
+        float kp = 1.f;
+        if (DROP) {
+          const uint32_t word = uint32_t(__shfl(int(mine), 16 * (hd >> 1) + 4 * q4 + i));
+          kp = drop_pick(word, hd & 1, drop);
+        }
+        const float lg = p * INV;                                  // (the key bias q_h . bke_h is not part of the node form: attn.hip)
+        const float alpha = e < end ? fast_exp(lg - m) * inv : 0.f;
+        const float alk = alpha * kp;
+        const float dal = (t + cz) * kp;
+        const float dls = alpha * (dal - dlt) * INV;
+        sal += alpha;
+        sad += alk;
+        W[i] = lo8 ? dls : alk;
+        (lo8 ? wtd : wta)[(4 * q4 + i) * 8 + hd] = W[i];
+        if (e < end) (lo8 ? ED : EA)[int64_t(e) * HEADS + hd] = W[i];
+      }
+      {
+        f4 rw[4];                                                  // the tile's rows again, whole rows per 16 lanes: B operand under the column order 4n + b
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rw[r] = *reinterpret_cast<const f4*>(tile + (4 * q4 + r) * TP + 4 * c16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) R[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[i], rw[i][b], R[b], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // node part of d q: sum_e dlogit_h k_node[src]; an asymmetric edge list scatters the source rows' gradients here (float atomics)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float wd = wtd[(4 * q4 + r) * 8 + (c16 >> 1)];
+        accq += kr[r] * wd;
+        if (scatter && e0 + 4 * q4 + r < end) {
+          const float wa = wta[(4 * q4 + r) * 8 + (c16 >> 1)];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            atomicAdd(DKN + int64_t(s_cur[r]) * 64 + 4 * c16 + e, wd * qn[e]);
+            atomicAdd(DVN + int64_t(s_cur[r]) * 64 + 4 * c16 + e, wa * dn[e]);
+          }
+        }
+      }
+      row_load(kr, kn, s_next);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s_cur[r] = s_next[r];
+        s_next[r] = s_after[r];
+      }
+    };
+    for (int e0 = beg; e0 < end; e0 += 32) {
+      tile_step(nxa, e0);
+      if (e0 + 16 < end) tile_step(nxb, e0 + 16);
+    }
+    // lane (n, q) holds rows 4q + i' of the 16 x 64 sums at columns 4n .. 4n+3: rows 0-7 are RL of heads 0-7, rows 8-15 SS
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f4 rv = f4{R[0][i], R[1][i], R[2][i], R[3][i]};
+      const int row = 4 * q4 + i;
+      if (row < 8) *reinterpret_cast<f4*>(tile + row * TP + 4 * c16) = rv;
+      *reinterpret_cast<f4*>((row < 8 ? RL : SS) + (node * HEADS + (row & 7)) * 64 + 4 * c16) = rv;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) accq[e] = xor32_sum(xor16_sum(accq[e]));      // the four lane rows' edges
+    if (q4 == 0) *reinterpret_cast<f4*>(nsum + 4 * c16) = accq;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // d q[d] = sum_e dlogit k_node[src][d] + Wke[d] . RL_head(d)   (lane = channel d from here on)
+    const int h = lane >> 3;
+    float dq = nsum[lane];
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+      const f4 wr = *reinterpret_cast<const f4*>(wk + lane * TP + 4 * k4);
+      const f4 rv = *reinterpret_cast<const f4*>(tile + h * TP + 4 * k4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dq = fmaf(wr[e], rv[e], dq);
+    }
+    float sw = DROP ? sad : sal;
+    sw = xor32_sum(xor16_sum(sw));
+    const float swh = __shfl(sw, h);
+    DQ[node * 64 + lane] = dq;
+    DAGGM[node * 64 + lane] = da * swh;                            // lin_v_edge.bias sees sum_e alpha d_e (= 1 without dropout)
+  }
+}
+
 // the encoders' attention backward over stored embedding rows (NODE = false), see bwd.hpp
 // TRAJSDE_ROWS_BWD_MM=0: the vector form (k_gattn_bwd<8, false>) for A/B runs and cross-checks
 static bool rows_bwd_mm() {
@@ -762,6 +1017,16 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
       TS_LAUNCH(k_gattn_src_bwd<4>, xcd_grid(cdiv(N, 4)), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA[l], w.ED[l], w.q[l], w.dagg, N, w.DKN, w.DVN,
                 w.asym);
     } else {
+      if (rows_bwd_mm()) {                                           // the matrix-core form (TRAJSDE_ROWS_BWD_MM=0: the vector form)
+        const int grid_mm = int(std::min<int64_t>(256, cdiv(N, GBM_WAVES)));
+        const DropArg dl = drop_of(l);
+        if (dl.p > 0.f)
+          TS_LAUNCH_TAG("(k_gattn_bwd<8, true>)", false, (k_gattn_bwd_mm<true>), grid_mm, 64 * GBM_WAVES, gattn_bwd_mm_lds_bytes(), st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l],
+                        w.vn[l], w.agg[l], w.dagg, w.stats[l], N, w.DQ, w.DKN, w.DVN, w.RL, w.SS, w.DAGGM, w.EA[l], w.ED[l], w.UZ[l], w.asym, dl);
+        else
+          TS_LAUNCH_TAG("(k_gattn_bwd<8, true>)", false, (k_gattn_bwd_mm<false>), grid_mm, 64 * GBM_WAVES, gattn_bwd_mm_lds_bytes(), st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l],
+                        w.vn[l], w.agg[l], w.dagg, w.stats[l], N, w.DQ, w.DKN, w.DVN, w.RL, w.SS, w.DAGGM, w.EA[l], w.ED[l], w.UZ[l], w.asym, dl);
+      } else
       TS_LAUNCH((k_gattn_bwd<8, true>), xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
                 w.agg[l], w.dagg, w.stats[l], N, w.DQ, w.DKN, w.DVN, w.RL, w.SS, w.DAGGM, w.EA[l], w.ED[l], w.UZ[l], w.asym, drop_of(l));
       TS_LAUNCH(k_gattn_src_bwd<8>, xcd_grid(cdiv(N, 4)), 256, 0, st, g->g_segptr, g->g_src, w.REV, w.EA[l], w.ED[l], w.q[l], w.dagg, N, w.DKN, w.DVN,
