@@ -654,7 +654,8 @@ __global__ __launch_bounds__(64 * GBM_WAVES) void k_gattn_bwd_mm(const float* __
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float wd = wtd[(4 * q4 + r) * 8 + (c16 >> 1)];
-        accq += kr[r] * wd;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accq[e] = fmaf(kr[r][e], wd, accq[e]);      // (element by element: no packed fp32 arithmetic in the backward files, tests/test_cabi_cpu.py)
         if (scatter && e0 + 4 * q4 + r < end) {
           const float wa = wta[(4 * q4 + r) * 8 + (c16 >> 1)];
 #pragma unroll
