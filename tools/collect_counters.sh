@@ -1,12 +1,12 @@
 #!/bin/bash
-# Collect the round's profiler evidence on the GPU box (run from the repo root; writes gpurun_out/$ROUND/, default r03):
+# Collect the round's profiler evidence on the GPU box (run from the repo root; writes gpurun_out/$ROUND/, default r04):
 #   kernel-trace stats of the bench command (1 stream and default), SQ / TCC counter passes of the same command (--streams 1)
 #   and of the step-granular SDE step at 786 432 rows.  Counter passes are separate runs with --kernel-trace only
 #   (MI355X_MICROARCH.md: 8 SQ slots per pass; FETCH_SIZE and WRITE_SIZE do not fit one pass).
 #   bash tools/collect_counters.sh
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/${ROUND:-r03}
+O=$R/gpurun_out/${ROUND:-r04}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py --steps 20 --warmup 3 --windows 1 --no-cpu-baseline --no-train-step --no-secondary"

@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r3train
+O=$R/gpurun_out/r4train
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/tools/train_step_bench.py > $O/train_step.log 2>&1
