@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       clk.mark(0);                                                 // wait for the tile's rel rows, stage them
-      f4 P0 = f4{0.f, 0.f, 0.f, 0.f}, P1 = P0;                       // two chains: a matrix instruction waits for its accumulator
+      f4 P0 = f4{0.f, 0.f, 0.f, 0.f}, P1 = P0, P2 = P0, P3 = P0;     // four chains: a matrix instruction waits for its accumulator
       {
         f4 a[4];
 #pragma unroll
@@ -157,10 +157,11 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
         for (int v4 = 0; v4 < 4; ++v4) {
           P0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][0], uz[4 * v4 + 0], P0, 0, 0, 0);
           P1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][1], uz[4 * v4 + 1], P1, 0, 0, 0);
-          P0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][2], uz[4 * v4 + 2], P0, 0, 0, 0);
-          P1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][3], uz[4 * v4 + 3], P1, 0, 0, 0);
+          P2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][2], uz[4 * v4 + 2], P2, 0, 0, 0);
+          P3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][3], uz[4 * v4 + 3], P3, 0, 0, 0);
         }
       }
+      P0 = (P0 + P1) + (P2 + P3);
       clk.mark(1);                                                 // first product
       // node part of the logits: edge 4 q4 + r, head n >> 1 -- this lane's four columns and its neighbour's (lane ^ 1)
 #pragma unroll
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int e = e0 + 4 * q4 + i;
-        const float p = (P0[i] + P1[i]) + pnt[(4 * q4 + i) * 8 + hd];
+        const float p = P0[i] + pnt[(4 * q4 + i) * 8 + hd];
         lg[i] = e < end ? p : -INFINITY;
         cm = fmaxf(cm, lg[i]);
       }
@@ -211,8 +212,10 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
         if (lo8) wt[(4 * q4 + i) * 8 + hd] = ex;
       }
       clk.mark(3);                                                 // softmax scalars
-      // the sums so far shrink by the factor of their row's head: rows 4 q4 + i' of S (lane row q4), heads 2 q4, 2 q4 + 1 of the node sums
-      {
+      // The sums so far shrink by the factor of their row's head: rows 4 q4 + i' of S (lane row q4), head n >> 1 of the node sums.  Only in
+      // a tile that raised some head's maximum (the first ones of a target, as a rule): the factors are exactly 1 otherwise, and the five
+      // cross-lane reads + 20 multiplies sit on the wave's dependent chain between the two products.
+      if (__builtin_amdgcn_ballot_w64(sc != 1.0f) != 0ull) {        // (uniform)
         float sr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) sr[i] = __shfl(sc, (4 * q4 + i) & 7);
