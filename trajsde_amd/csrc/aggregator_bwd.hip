@@ -870,7 +870,7 @@ static int aggregator_tape(const trajsde_batch* b, const trajsde_graph* g, const
     {
       const DropArg dl = drop_of(l);
       TS_REQUIRE(N < (1 << 23), "aggregator_forward_train: node rows are addressed with 32-bit byte offsets (N < 2^23)");
-      if (num_heads == 8 && gattn_f32mm_enabled()) {
+      if (num_heads == 8 && gattn_f32mm_enabled() && g->E_g > 0) {
         if (int rc = launch_global_attn_mf(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N, w.agg[l], w.stats[l], dl, st)) return rc;
       } else
         TS_GLOBAL_ATTN(num_heads, false, dl, xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l], N, w.agg[l], w.stats[l]);

@@ -540,7 +540,7 @@ static int aggregator_forward_impl(const trajsde_batch* b, const trajsde_graph* 
       TS_REQUIRE(N < (1 << 23), "aggregator_forward: node rows are addressed with 32-bit byte offsets (N < 2^23)");
       if (num_heads == 8 && !state_bf16() && drop.p == 0.f && gattn_mm_enabled()) {
         if (int rc = launch_global_attn_mm(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, st)) return rc;
-      } else if (num_heads == 8 && !state_bf16() && gattn_f32mm_enabled()) {
+      } else if (num_heads == 8 && !state_bf16() && gattn_f32mm_enabled() && E > 0) {
         if (int rc = launch_global_attn_mf(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, nullptr, drop, st)) return rc;
       } else {
         TS_GLOBAL_ATTN(num_heads, state_bf16(), drop, xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, static_cast<float*>(nullptr));
