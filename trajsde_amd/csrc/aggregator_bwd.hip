@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64 * GBM_WAVES) void k_gattn_bwd_mm(const float* __
   const float bve = img[GAttnL::BVE + lane];
   const bool scatter = *asym != 0;
   const int64_t stride = int64_t(gridDim.x) * GBM_WAVES;
-  for (int64_t node = int64_t(blockIdx.x) * GBM_WAVES + wv; node < N; node += stride) {
+  for (int64_t node = xcd_block() * GBM_WAVES + wv; node < N; node += stride) {        // (xcd_block: a scene's node rows through one L2, gattn_f32.hip)
     const float ql = q[node * 64 + lane];
     const float da = dagg[node * 64 + lane];
     const float ag = agg[node * 64 + lane];
@@ -1019,7 +1019,7 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
                 w.asym);
     } else {
       if (rows_bwd_mm()) {                                           // the matrix-core form (TRAJSDE_ROWS_BWD_MM=0: the vector form)
-        const int grid_mm = int(std::min<int64_t>(256, cdiv(N, GBM_WAVES)));
+        const int grid_mm = xcd_grid(std::min<int64_t>(256, cdiv(N, GBM_WAVES)));
         const DropArg dl = drop_of(l);
         if (dl.p > 0.f)
           TS_LAUNCH_TAG("(k_gattn_bwd<8, true>)", false, (k_gattn_bwd_mm<true>), grid_mm, 64 * GBM_WAVES, gattn_bwd_mm_lds_bytes(), st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l],

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
   PhaseClock<8> clk;                                               // diagnostic builds only (stamps.hpp, tools/phase_stamps.py gmf)
   clk.start();
   unsigned long long tiles_done = 0;
-  for (int64_t node = int64_t(blockIdx.x) * GMF_WAVES + wv; node < N; node += stride) {
+  // xcd_block(): the workgroups of one XCD walk consecutive targets, so a round of them gathers one scene's node rows through ONE L2
+  // (dealt by blockIdx, a scene's 256 targets were spread over all eight: every L2 had to hold the node rows of every scene in flight)
+  for (int64_t node = xcd_block() * GMF_WAVES + wv; node < N; node += stride) {
     // the logits' 1 / sqrt(dh) is folded into the query; the key bias q_h . bke_h shifts every logit of a (target, head) alike: dropped
     const float ql = q[node * 64 + lane] * INV;
     const int beg = segptr[node], end = segptr[node + 1];
@@ -293,7 +295,7 @@ int launch_global_attn_mf(const float* img, const int32_t* segptr, const int32_t
                           const float* vn, int64_t N, float* agg, float* stats, const DropArg& drop, hipStream_t st) {
   if (N <= 0) return TRAJSDE_OK;
   const int64_t wgs = (N + GMF_WAVES - 1) / GMF_WAVES;
-  const int grid = int(wgs < 256 ? wgs : 256);                     // one workgroup per CU; fewer when the targets do not fill them
+  const int grid = xcd_grid(wgs < 256 ? wgs : 256);                // one workgroup per CU; fewer when the targets do not fill them (a multiple of 8: xcd_block)
   if (drop.p > 0.f) TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn_mf<true>), grid, 64 * GMF_WAVES, gmf_lds_bytes(), st, img, segptr, src, rel, q, kn, vn, N, agg, stats, drop);
   else TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn_mf<false>), grid, 64 * GMF_WAVES, gmf_lds_bytes(), st, img, segptr, src, rel, q, kn, vn, N, agg, stats, drop);
   return TRAJSDE_OK;
