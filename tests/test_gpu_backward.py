@@ -854,11 +854,17 @@ def test_training_forward_keeps_a_tape_the_backward_walks(train_mode, dev):
         assert torch.equal(a_with["grads"][k], a_without["grads"][k]), k
 
 
-def test_flat_training_is_the_per_parameter_adamw_bit_for_bit(dev):
+@pytest.mark.parametrize("foreach", [True, False])
+def test_flat_training_is_the_per_parameter_adamw_bit_for_bit(foreach, dev):
     """driver.FlatTraining runs AdamW over ONE tensor that every optimised parameter is a slice of; AdamW is element-wise, so
     three training steps end on exactly the parameters of torch's per-parameter AdamW over the same model -- and the weight
     images are re-packed although the slices' version counters never move (StageParams.touch).  The flat side also takes its
-    gradients through FlatGrads.accumulate (six launches), the other side parameter by parameter: the same bits."""
+    gradients through FlatGrads.accumulate (six launches), the other side parameter by parameter: the same bits.
+    `foreach=True` (model.adamw_foreach): torch's multi-tensor AdamW on both sides: the same bits.  `foreach=False` (the default of
+    FlatTraining since round 4: the multi-tensor kernels cut one tensor into ten workgroups, 0.33 ms a step): the same formula in the
+    plain element-wise kernels, which round some operations differently: gradients still bit-equal at step 0, after three steps
+    98 % of every parameter's elements within 2e-6 of its scale and none further than the three steps themselves (AdamW turns a
+    noise-level gradient of either sign into a step of size lr)."""
     from trajsde_amd import driver
     from trajsde_amd.runtime import NoiseSpec
     from trajsde_amd.synth import synth
@@ -874,6 +880,7 @@ def test_flat_training_is_the_per_parameter_adamw_bit_for_bit(dev):
     (opt,), _ = a.configure_optimizers()
     fa = driver.FlatGrads(a.params_with_gradient())
     b = make()
+    b.adamw_foreach = foreach
     fb = driver.FlatTraining(b)
     assert b._grad_sink is fb.grads and not hasattr(a, "_grad_sink")
     losses = []
@@ -885,13 +892,27 @@ def test_flat_training_is_the_per_parameter_adamw_bit_for_bit(dev):
             loss.backward()
             if m is b:
                 assert len(fb.grads._gather) == 3                    # the three stage buffers went through accumulate()
-                assert torch.equal(fb.grads.flat, fa.flat)           # ... and left the gradients of the per-parameter route
+                if foreach or i == 0:
+                    assert torch.equal(fb.grads.flat, fa.flat)       # ... and left the gradients of the per-parameter route
             step()
             losses.append(float(loss.detach()))
-    assert losses[0::2] == losses[1::2]                    # same losses step by step: the re-packed weights were the updated ones
+    if foreach:
+        assert losses[0::2] == losses[1::2]                # same losses step by step: the re-packed weights were the updated ones
+    else:
+        assert losses[0] == losses[1] and all(abs(x - y) <= 1e-5 * abs(x) for x, y in zip(losses[0::2], losses[1::2]))
     assert losses[0] != losses[4]                          # ... and they did change
     for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
-        assert na == nb and torch.equal(pa.detach(), pb.detach()), na
+        assert na == nb
+        if foreach:
+            assert torch.equal(pa.detach(), pb.detach()), na
+        elif not (na.endswith("lin_k.bias") or na.endswith("lin_k_node.bias") or na.endswith("lin_k_edge.bias")):
+            # (a key bias shifts every logit of a target alike: its gradient is rounding noise, and AdamW turns noise of either sign
+            #  into a step of size lr -- not comparable once the parameters differ in the last place)
+            # ... and the same holds element by element wherever a gradient is at the noise level: bounded by the three steps of size lr,
+            # and rare
+            diff = (pa.detach() - pb.detach()).abs()
+            assert float(diff.max()) <= 3.5 * a.lr, na
+            assert float((diff > 2e-6 * max(1.0, float(pa.detach().abs().max()))).float().mean()) <= 0.02, na
 
 
 def test_early_gradient_slice_leaves_the_gradients_of_the_plain_step(dev):

@@ -233,9 +233,14 @@ class FlatTraining:
         self.flat_param.grad = self.grads.flat
         model._grad_sink = self.grads                        # the path loss hands its gradients over in a few launches (accumulate)
         self._stages = [m for m in model.modules() if hasattr(m, "touch")]
-        # (torch's single-kernel `fused=True` form is no gain here: its multi-tensor launch cuts ONE tensor into 64 K-element
-        # chunks, eight workgroups for this model, 109 us against 64 us for the six launches of the default form)
-        self.optimizer = torch.optim.AdamW([self.flat_param], lr=model.lr, weight_decay=model.weight_decay)
+        # foreach=False: torch's multi-tensor ("foreach", the default on a GPU) and `fused=True` forms cut ONE tensor into 64 K-element
+        # chunks -- ten workgroups for this model: nine launches of 25-55 us each, 0.33 ms of a 10 ms step (kernel trace, round 4); the
+        # plain element-wise form spreads the same arithmetic over the chip (~5 us a launch).  Same operations element by element: the
+        # per-parameter AdamW and this one agree to the last place or two (tests/test_gpu_backward.py::test_flat_training_is_...)
+        # (the two forms round differently in the last place: `model.adamw_foreach = True` restores the multi-tensor form, which ends on
+        #  the very bits of `AdamW(model.parameters())` as the reference constructs it, MODEL:205)
+        self.optimizer = torch.optim.AdamW([self.flat_param], lr=model.lr, weight_decay=model.weight_decay,
+                                           foreach=bool(getattr(model, "adamw_foreach", False)))
         if hasattr(model, "scheduler_step"):
             self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=model.scheduler_step, gamma=model.scheduler_gamma)
         else:
