@@ -259,6 +259,63 @@ __global__ __launch_bounds__(256) void k_gattn_drel(DrelArgs a, const int32_t* _
   }
 }
 
+// The same sum as a tile product on the fp32 matrix cores (round 4; 8 heads, U / Z from UZ): DREL[16 edges x 64] = S[16 x 16 NL] . UZ[16 NL x 64],
+// S = the edges' (ED | EA) scalars of the NL layers, contraction index k = 16 l + 8 type + h.  One wave per target: its 16 NL x 64 block of
+// UZ is loaded once (lane (kk, n): rows 4 s + kk, columns 4n .. 4n+3 -- the B operand under the column order 4n + b), a tile's scalars are
+// 4 NL dword loads per lane (lane (e, kk): heads kk and 4 + kk of every (layer, type)), and the result leaves as whole rows (lane (n, q):
+// edges 4q + i, columns 4n .. 4n+3).  48 multiply-adds + 48 lane reads per edge and lane on the vector pipe became 3 matrix instructions.
+template <int NL>
+__global__ __launch_bounds__(256) void k_gattn_drel_mm(DrelArgs a, const int32_t* __restrict__ segptr, int64_t N, float* __restrict__ DREL,
+                                                       int accumulate) {
+  constexpr int HEADS = 8;
+  const int lane = threadIdx.x & 63;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int64_t node = xcd_block() * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (node >= N) return;
+  // B operand: step s = 4 l + 2 type + hh covers k = 16 l + 8 type + 4 hh + kk, i.e. head 4 hh + kk of (layer l, type)
+  f4 uz[4 * NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l)
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+        uz[4 * l + 2 * ty + hh] = *reinterpret_cast<const f4*>(a.UZ[l] + ((node * HEADS + 4 * hh + q4) * 2 + ty) * 64 + 4 * c16);
+  const int beg = segptr[node], end = segptr[node + 1];
+  for (int e0 = beg; e0 < end; e0 += 16) {
+    const int e = e0 + c16, ec = e < end ? e : end - 1;
+    float sv[4 * NL];                                            // A operand: lane (e = c16, kk = q4), step s: S[e][16 l + 8 type + 4 hh + kk]
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        sv[4 * l + 0 + hh] = a.ED[l][int64_t(ec) * HEADS + 4 * hh + q4];      // type 0: ED multiplies U
+        sv[4 * l + 2 + hh] = a.EA[l][int64_t(ec) * HEADS + 4 * hh + q4];      // type 1: EA multiplies Z
+      }
+    f4 D[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) D[b] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4 * NL; ++s)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) D[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[s], uz[s][b], D[b], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int er = e0 + 4 * q4 + i;
+      if (er < end) {
+        float* out = DREL + int64_t(er) * 64 + 4 * c16;
+        f4 v = f4{D[0][i], D[1][i], D[2][i], D[3][i]};
+        if (accumulate) {
+          const f4 old = *reinterpret_cast<const f4*>(out);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = old[c] + v[c];
+        }
+        *reinterpret_cast<f4*>(out) = v;
+      }
+    }
+  }
+}
+
 int run_gattn_drel(hipStream_t st, int heads, int nl, bool from_rows, const DrelArgs& da, const int32_t* segptr, int64_t N, float* DREL,
                    int accumulate) {
 #define TS_DREL(H_, N_, F_) TS_LAUNCH((k_gattn_drel<H_, N_, F_>), xcd_grid(cdiv(N, 4)), 256, 0, st, da, segptr, N, DREL, accumulate)
@@ -267,6 +324,10 @@ int run_gattn_drel(hipStream_t st, int heads, int nl, bool from_rows, const Drel
     else TS_DREL(8, 1, true);
   } else if (heads == 4) {
     switch (nl) { case 1: TS_DREL(4, 1, false); break; case 2: TS_DREL(4, 2, false); break; case 3: TS_DREL(4, 3, false); break; default: TS_DREL(4, 4, false); }
+  } else if (rows_bwd_mm()) {                                    // the matrix-core form (TRAJSDE_ROWS_BWD_MM=0: the vector form)
+#define TS_DREL_MM(N_) TS_LAUNCH_TAG("(k_gattn_drel<8, " #N_ ", false>)", false, (k_gattn_drel_mm<N_>), xcd_grid(cdiv(N, 4)), 256, 0, st, da, segptr, N, DREL, accumulate)
+    switch (nl) { case 1: TS_DREL_MM(1); break; case 2: TS_DREL_MM(2); break; case 3: TS_DREL_MM(3); break; default: TS_DREL_MM(4); }
+#undef TS_DREL_MM
   } else {
     switch (nl) { case 1: TS_DREL(8, 1, false); break; case 2: TS_DREL(8, 2, false); break; case 3: TS_DREL(8, 3, false); break; default: TS_DREL(8, 4, false); }
   }
