@@ -23,6 +23,9 @@ TABLES = {
     "gattn": (8, "16-edge tiles", ["issue the loads of the tiles ahead", "wait for this tile's rel / k_node rows", "splits + stage writes",
                                    "P1: fragment reads + 12 matrix instr.", "softmax", "P2: splits + 16 matrix instr.", "loop overhead",
                                    "per-target epilogue (W_ve, store)"]),
+    "tail": (8, "16-edge tiles", ["request the loads (geometry, target rows, scalars)", "first layers of the two branches", "two products, LayerNorm, ReLU",
+                                  "third product, LayerNorm", "d emb: two adjoint products on the target rows", "LayerNorm backwards, W2^T adjoint, mask",
+                                  "three slabs out (whole rows)", "-"]),
     "gmf": (8, "16-edge tiles", ["wait for the rel rows, stage", "first product (16 matrix instr.)", "wait for key rows, node logits",
                                  "softmax scalars", "rescale", "second product (16 matrix instr.)", "wait for value rows, node sums",
                                  "per-target prologue / epilogue"]),
@@ -65,6 +68,34 @@ def forward_runner():
     return run
 
 
+def train_runner():
+    """one training step (forward + backward) at 64 x 128 agents per call: the backward kernels' tables (tail)"""
+    import yaml
+    from trajsde_amd import driver
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import CONFIGS, synth
+    spec = CONFIGS[os.environ.get("WORKLOAD", "config2")]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "trajsde_amd/configs/mi355x_sde_encoder_decoder.yml")) as f:
+        cfg = yaml.safe_load(f)
+    K, T = spec["num_modes"], spec["future_steps"]
+    cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)
+    cfg["aggregator"]["kwargs"]["num_modes"] = K
+    cfg["decoder"]["kwargs"].update(num_modes=K, future_steps=T, max_fut_t=spec["max_fut_t"])
+    dev = torch.device("cuda:0")
+    model = driver.build_model(cfg, None, dev, init_seed=0).train()
+    flat = driver.FlatTraining(model)
+    batch = synth(**spec["synth"]).to(dev)
+    y0 = batch.y.clone()
+
+    def run(i):
+        flat.zero()
+        batch.y = y0
+        model.training_step(batch, i, noise=NoiseSpec(seed=100 + i)).backward()
+    run.keep = (model, flat)
+    return run
+
+
 def sde_step_runner():
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import sde_step_bench
@@ -75,7 +106,7 @@ def main(name):
     from trajsde_amd import _lib
     lib = _lib.lib()
     n, unit, labels = TABLES[name]
-    run = sde_step_runner() if name == "sde_step" else forward_runner()
+    run = sde_step_runner() if name == "sde_step" else (train_runner() if name == "tail" else forward_runner())
     for i in range(3):
         run(i)
     torch.cuda.synchronize()

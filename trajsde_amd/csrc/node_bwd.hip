@@ -16,7 +16,10 @@
 #include "dropout.hpp"
 #include "layouts.hpp"
 #include "tile.hpp"
+#include "stamps.hpp"
 #include "tile_bwd.hpp"
+
+TSDE_STAMP_TABLE(tail, 8)
 
 namespace tsde {
 
@@ -301,31 +304,50 @@ __global__ __launch_bounds__(TSDE_TAIL_BOUNDS) void k_edge_embed_bwd_tail(const 
   const int64_t ntiles = (E + 15) / 16;
   f4 dg3[4], db3[4], dg0[4], db0[4];
   zero4(dg3); zero4(db3); zero4(dg0); zero4(db0);
-  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+  PhaseClock<8> clk;                                      // diagnostic builds only (stamps.hpp, tools/phase_stamps.py tail)
+  clk.start();
+  unsigned long long tiles_done = 0;
+  // (ATTN) the tile's targets are read ONE TILE AHEAD: the target index is the address of the q / dagg rows, and left at the top of its own
+  // tile that dependent pair of latencies was 22 % of the kernel (in-kernel phase clocks, tools/phase_stamps.py tail: 3 900 of 18 150
+  // cycles a tile).
+  const int64_t tstride = int64_t(gridDim.x) * waves;
+  int tgt_next = 0;                                       // (the geometry record too would be 4 registers more: 2 spilled at 256, measured slower)
+  if (ATTN) {
+    const int64_t e0 = (int64_t(blockIdx.x) * waves + wave) * 16 + L.n;
+    tgt_next = ag.dst[e0 < E ? e0 : E - 1];
+  }
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += tstride) {
     keep_lds_reads_here();
+    ++tiles_done;
     const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
     const f4 ge = *reinterpret_cast<const f4*>(geom + 4 * ec);
+    const int tgt_now = tgt_next;
+    if (ATTN) {
+      const int64_t en = (tile + tstride) * 16 + L.n;
+      tgt_next = ag.dst[en < E ? en : E - 1];
+    }
     f4 xh[4], a0[4], b0[4], sp[4], s[4], ep[4], d[4];
     // ATTN: the target's q / dagg rows and the edge's scalars are requested HERE, ahead of the forward recompute that does not
     // need them (index -> row is two dependent latencies; left where they are used, they stalled every tile at two waves per SIMD)
     f4 qv[4], gv[4], d0, a0_, d1, a1_;
     if (!ATTN) load_row(d, demb, ec, L.g);
     if (ATTN) {
-      const int tgt = ag.dst[ec];
+      const int tgt = tgt_now;
       load_row(qv, ag.q, tgt, L.g);
       load_row(gv, ag.dagg, tgt, L.g);
+      // (the second halves by an address, not by `d1 = d0; if (8 heads) load`: copying a register that a load is still writing made the
+      //  wave wait right here for every load it had just requested -- 24 % of the kernel in its phase clocks, round 4)
+      const int half2 = ag.heads == 8 ? 4 : 0;
       d0 = *reinterpret_cast<const f4*>(ag.ED + ec * ag.heads);
       a0_ = *reinterpret_cast<const f4*>(ag.EA + ec * ag.heads);
-      d1 = d0;
-      a1_ = a0_;
-      if (ag.heads == 8) {
-        d1 = *reinterpret_cast<const f4*>(ag.ED + ec * 8 + 4);
-        a1_ = *reinterpret_cast<const f4*>(ag.EA + ec * 8 + 4);
-      }
+      d1 = *reinterpret_cast<const f4*>(ag.ED + ec * ag.heads + half2);
+      a1_ = *reinterpret_cast<const f4*>(ag.EA + ec * ag.heads + half2);
     }
+    clk.mark(0);                                          // loads requested
     float r_;
     branch_fwd(xh, a0, r_, ge[0], ge[1], lds + EL::A_W0, lds + EL::A_B0, lds + EL::A_G, lds + EL::A_E, L);
     branch_fwd(xh, b0, r_, ge[2], ge[3], lds + EL::B_W0, lds + EL::B_B0, lds + EL::B_G, lds + EL::B_E, L);
+    clk.mark(1);                                          // first layers of the two branches
     load_vec<4>(sp, lds + EL::B3, L.g);
     linear_acc_x6<4, 4>(sp, a0, lds + EL::WA3, L.lane);
     linear_acc_x6<4, 4>(sp, b0, lds + EL::WB3, L.lane);
@@ -342,8 +364,10 @@ __global__ __launch_bounds__(TSDE_TAIL_BOUNDS) void k_edge_embed_bwd_tail(const 
         s[jt][c] = fmaxf(pre, 0.f);
       }
     }
+    clk.mark(2);                                          // two products, LayerNorm, ReLU
     linear_x6<4, 4>(ep, s, lds + EL::W2, lds + EL::B2, L);
     const float rs3 = ln_normalize(ep);                   // ep = e_hat
+    clk.mark(3);                                          // third product, LayerNorm
     if (ATTN) {
       // lane group g holds the features of heads 2jt + (g >> 1) (8 heads) or jt (4 heads)
       const int odd = L.g >> 1;
@@ -370,6 +394,7 @@ __global__ __launch_bounds__(TSDE_TAIL_BOUNDS) void k_edge_embed_bwd_tail(const 
       linear_adj<4, 4>(d, dv, lds + EdgeBwdL::WA3T + MAT64, L);
     }
     if (e >= E) zero4(d);
+    clk.mark(4);                                          // d emb from the attention scalars: two adjoint products (ATTN) / the row load
     ln_backward(d, ep, rs3, lds + EL::AG3, L.g, dg3, db3);   // d := d ep
     f4 t[4];
     linear_t(t, d, lds + EdgeBwdL::W2T, L);
@@ -379,12 +404,17 @@ __global__ __launch_bounds__(TSDE_TAIL_BOUNDS) void k_edge_embed_bwd_tail(const 
       for (int c = 0; c < 4; ++c)
         if (!pos[4 * jt + c]) t[jt][c] = 0.f;
     ln_backward(t, sp, rs0, lds + EL::AG0, L.g, dg0, db0);   // t := d sp
+    clk.mark(5);                                          // LayerNorm backwards, W2^T adjoint, ReLU mask
     // the three slabs leave as whole rows (tile.hpp store_tile_rows; with store_row they were 0.36 of this kernel's 1.3 ms per step)
     float* stile = lds + stage_off + wave * ROWSTAGE;
     store_tile_rows(stile, s, S, tile * 16, E, L);
     store_tile_rows(stile, d, DEP, tile * 16, E, L);
     store_tile_rows(stile, t, DSP, tile * 16, E, L);
+    clk.mark(6);                                          // three slabs out
   }
+#ifdef TSDE_STAMPS
+  if (ATTN && L.lane == 0 && (wave == 0 || wave == 5)) clk.flush(g_stamps_tail, tiles_done);
+#endif
   float* vp = vpart + int64_t(blockIdx.x * waves + wave) * 256;
   flush_vec(dg3, vp, L);
   flush_vec(db3, vp + 64, L);
@@ -413,15 +443,31 @@ __global__ __launch_bounds__(256) void k_edge_embed_bwd_branch(const float* __re
   const int64_t ntiles = (E + 15) / 16;
   f4 dg[4], db[4], dwx[4], dwy[4], dbb[4];
   zero4(dg); zero4(db); zero4(dwx); zero4(dwy); zero4(dbb);
-  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
+  // geometry record and gradient row of the NEXT tile are requested while this one is computed (the tail kernel's phase clocks showed
+  // what a tile pays for loads requested at its own top)
+  const int64_t tstride = int64_t(gridDim.x) * waves;
+  f4 ge_next, d_next[4];
+  {
+    const int64_t t0 = int64_t(blockIdx.x) * waves + wave;
+    const int64_t e0 = t0 * 16 + L.n, ec0 = e0 < E ? e0 : E - 1;
+    ge_next = *reinterpret_cast<const f4*>(geom + 4 * ec0);
+    load_row(d_next, DSP, ec0, L.g);
+  }
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += tstride) {
     keep_lds_reads_here();
-    const int64_t e = tile * 16 + L.n, ec = e < E ? e : E - 1;
-    const f4 ge = *reinterpret_cast<const f4*>(geom + 4 * ec);
-    const float i0 = BR ? ge[2] : ge[0], i1 = BR ? ge[3] : ge[1];
+    const int64_t e = tile * 16 + L.n;
+    const f4 ge = ge_next;
     f4 xh[4], act[4], d[4], t[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) d[jt] = d_next[jt];
+    {
+      const int64_t en = (tile + tstride) * 16 + L.n, enc = en < E ? en : E - 1;
+      ge_next = *reinterpret_cast<const f4*>(geom + 4 * enc);
+      load_row(d_next, DSP, enc, L.g);
+    }
+    const float i0 = BR ? ge[2] : ge[0], i1 = BR ? ge[3] : ge[1];
     float rstd;
     branch_fwd(xh, act, rstd, i0, i1, lds + W0, lds + B0_, lds + G_, lds + E_, L);
-    load_row(d, DSP, ec, L.g);
     if (e >= E) zero4(d);
     linear_t(t, d, lds + EL::WA3, L);
 #pragma unroll
