@@ -309,7 +309,7 @@ def test_full_size_training_step_agrees_between_kernel_forms(dev):
         return json.loads(r.stdout.strip().splitlines()[-1])
     new = run({})
     old = run({"TRAJSDE_WGRAD_F32": "1", "TRAJSDE_IMMEDIATE_SUMS": "1", "TRAJSDE_RECUR_LEGACY": "1", "TRAJSDE_ROWS_BWD_MM": "0",
-               "TRAJSDE_WGRAD_EDGE_PAIR": "0"})
+               "TRAJSDE_WGRAD_EDGE_PAIR": "0", "TRAJSDE_ROWS_BWD_FUSEW": "0"})
     # the deferred sums with areas so small that they are summed early many times per entry point (and one batch of partials does not
     # fit at all): the same kernels in the same order per problem -> bit-identical digests
     tight = run({"TRAJSDE_REDUCE_CAP": "600", "TRAJSDE_VPART_ARENA": "300000"})

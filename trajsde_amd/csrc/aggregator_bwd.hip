@@ -357,23 +357,41 @@ constexpr int RMM_TP = 68;                                         // padded row
 constexpr int RMM_WIMG = 8192, RMM_WK = 64 * RMM_TP;              // floats: swizzled [Wke | Wve] image, plain Wke rows
 constexpr int RMM_PER_WAVE = 16 * RMM_TP + 8 * RMM_TP;            // staging tile + the eight RL rows of the d q epilogue
 constexpr int rows_mm_lds_bytes() { return (RMM_WIMG + RMM_WK + RMM_WAVES * RMM_PER_WAVE) * 4; }
-template <bool DROP>
-__global__ __launch_bounds__(64 * RMM_WAVES) void k_edge_rows_bwd_mm(const float* __restrict__ img, const int32_t* __restrict__ segptr,
+// FUSEW: the lin_k / lin_v weight gradients -- head-wise outer products q_h (x) RL_h, dagg_h (x) SS_h summed over the targets -- are
+// accumulated HERE, per wave, in 128 registers (lane = column c: GW[matrix][head][half][i] = dW[8 h + 4 half + i][c]) by 32
+// `v_mfma_f32_4x4x1_16B_f32` per target (sixteen 4 x 4 outer products an instruction: a = four entries of q_h, b = four of RL_h), instead of
+// RL / SS going to HBM (4 KB a target: 671 MB written and read again by k_headwise_outer at 64 x 128).  Workgroups of 8 waves then (the
+// accumulators double the registers); a workgroup's eight partial sums are added in wave order through LDS at the end (fixed order:
+// reproducible) and leave as ONE pair of 64 x 64 partials per workgroup, summed by the deferred reduce like any other weight gradient.
+constexpr int RMMF_WAVES = 8;
+constexpr int RMMF_PER_WAVE = 16 * RMM_TP + 16 * RMM_TP + 128;      // staging tile + the sixteen RL | SS rows + q | dagg
+constexpr int rows_mmf_lds_bytes() { return (RMM_WIMG + RMM_WK + RMMF_WAVES * RMMF_PER_WAVE + 2 * 4096) * 4; }
+template <bool DROP, bool FUSEW>
+__global__ __launch_bounds__(64 * (FUSEW ? RMMF_WAVES : RMM_WAVES)) void k_edge_rows_bwd_mm(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                                      const float* __restrict__ rel, const float* __restrict__ q,
                                                                      const float* __restrict__ agg, const float* __restrict__ dagg,
                                                                      const float* __restrict__ stats, int64_t N, float* __restrict__ DQ,
                                                                      float* __restrict__ RL, float* __restrict__ SS,
                                                                      float* __restrict__ DAGGM, float* __restrict__ EA,
-                                                                     float* __restrict__ ED, DropArg drop) {
+                                                                     float* __restrict__ ED, DropArg drop, float* __restrict__ wpart) {
   constexpr int HEADS = 8;
   constexpr float INV = INV_SQRT_DH;
   constexpr int TP = RMM_TP;
+  constexpr int WAVES = FUSEW ? RMMF_WAVES : RMM_WAVES, PER_WAVE = FUSEW ? RMMF_PER_WAVE : RMM_PER_WAVE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const wimg = lds;                                         // [d][kk][v4][j][4]: W_(j<8 ? k : v)[8 (j&7) + d][16 kk + 4 v4 + e]
   float* const wk = lds + RMM_WIMG;                                // Wke[d][c], rows padded to TP
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* const tile = lds + RMM_WIMG + RMM_WK + wv * RMM_PER_WAVE;
-  float* const sb = tile + 16 * TP;                                // [8][TP]
+  float* const tile = lds + RMM_WIMG + RMM_WK + wv * PER_WAVE;
+  float* const sb = tile + 16 * TP;                                // [8][TP] (FUSEW: [16][TP], the SS rows too)
+  float* const xsm = sb + 16 * TP;                                 // FUSEW: [64] q | [64] dagg of the current target
+  f4 GW[FUSEW ? 2 : 1][FUSEW ? 8 : 1][FUSEW ? 2 : 1];
+#pragma unroll
+  for (int a_ = 0; a_ < (FUSEW ? 2 : 1); ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < (FUSEW ? 8 : 1); ++b_)
+#pragma unroll
+      for (int c_ = 0; c_ < (FUSEW ? 2 : 1); ++c_) GW[a_][b_][c_] = f4{0.f, 0.f, 0.f, 0.f};
   const int c16 = lane & 15, q4 = lane >> 4, hd = c16 & 7;
   const bool lo8 = c16 < 8;
   {
@@ -391,12 +409,17 @@ __global__ __launch_bounds__(64 * RMM_WAVES) void k_edge_rows_bwd_mm(const float
   }
   __syncthreads();
   const float bke = img[GAttnL::BKE + lane], bve = img[GAttnL::BVE + lane];
-  const int64_t stride = int64_t(gridDim.x) * RMM_WAVES;
-  for (int64_t node = int64_t(blockIdx.x) * RMM_WAVES + wv; node < N; node += stride) {
+  const int64_t stride = int64_t(gridDim.x) * WAVES;
+  for (int64_t node = int64_t(blockIdx.x) * WAVES + wv; node < N; node += stride) {
     // per-head constants, first in the "lane = channel" layout (lanes 8h .. 8h+7 hold head h), then handed to the lanes of column hd
     const float ql = q[node * 64 + lane];
     const float da = dagg[node * 64 + lane];
     const float ag = agg[node * 64 + lane];
+    if (FUSEW) {
+      __builtin_amdgcn_wave_barrier();                             // (the previous target's readers are done)
+      xsm[lane] = ql;
+      xsm[64 + lane] = da;
+    }
     const float m = stats[(node * HEADS + hd) * 2], inv = stats[(node * HEADS + hd) * 2 + 1];
     const int beg = segptr[node], end = segptr[node + 1];
     f4 nx[4];
@@ -491,11 +514,25 @@ __global__ __launch_bounds__(64 * RMM_WAVES) void k_edge_rows_bwd_mm(const float
     for (int i = 0; i < 4; ++i) {
       const f4 rv = f4{R[0][i], R[1][i], R[2][i], R[3][i]};
       const int row = 4 * q4 + i;
-      if (row < 8) *reinterpret_cast<f4*>(sb + row * TP + 4 * c16) = rv;
-      *reinterpret_cast<f4*>((row < 8 ? RL : SS) + (node * HEADS + (row & 7)) * 64 + 4 * c16) = rv;
+      if (FUSEW || row < 8) *reinterpret_cast<f4*>(sb + row * TP + 4 * c16) = rv;
+      if (!FUSEW) *reinterpret_cast<f4*>((row < 8 ? RL : SS) + (node * HEADS + (row & 7)) * 64 + 4 * c16) = rv;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (FUSEW) {
+      // dW[8 h + 4 half + i][c] += x[8 h + 4 half + i] * row_h[c]: block b = c >> 2 of the instruction's sixteen, lane = c
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+          const float bv = sb[(8 * mt + hh) * TP + lane];
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const float av = xsm[64 * mt + 8 * hh + 4 * hf + (lane & 3)];
+            GW[mt][hh][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, GW[mt][hh][hf], 0, 0, 0);
+          }
+        }
+    }
     // d q[d] = Wke[d] . RL_head(d)   (lane = channel d from here on)
     const int h = lane >> 3;
     float dq = 0.f;
@@ -512,6 +549,31 @@ __global__ __launch_bounds__(64 * RMM_WAVES) void k_edge_rows_bwd_mm(const float
     const float swh = __shfl(sw, h);
     DQ[node * 64 + lane] = dq;
     DAGGM[node * 64 + lane] = da * swh;                            // lin_v_edge.bias sees sum_e alpha d_e (= 1 without dropout)
+  }
+  if (FUSEW) {
+    // the workgroup's partial: its waves add their registers into one LDS block in wave order, then it leaves as 2 x 4096 floats
+    float* const acc = lds + RMM_WIMG + RMM_WK + WAVES * PER_WAVE;
+    for (int w = 0; w < WAVES; ++w) {
+      __syncthreads();
+      if (wv == w) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int hh = 0; hh < 8; ++hh)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                float* pa = acc + mt * 4096 + (8 * hh + 4 * hf + i) * 64 + lane;
+                *pa = w == 0 ? GW[mt][hh][hf][i] : *pa + GW[mt][hh][hf][i];
+              }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * 1024; i += blockDim.x) {
+      const int mt = i >> 10, k = i & 1023;
+      *reinterpret_cast<f4*>(wpart + (int64_t(mt) * gridDim.x + blockIdx.x) * 4096 + 4 * k) = *reinterpret_cast<const f4*>(acc + mt * 4096 + 4 * k);
+    }
   }
 }
 
@@ -775,20 +837,41 @@ static bool rows_bwd_mm() {
   static const bool on = []() { const char* e = getenv("TRAJSDE_ROWS_BWD_MM"); return !(e && e[0] == '0'); }();
   return on;
 }
+// TRAJSDE_ROWS_BWD_FUSEW=0: RL / SS through HBM and k_headwise_outer, as before round 4's fused form
+static bool rows_bwd_fusew() {
+  static const bool on = []() { const char* e = getenv("TRAJSDE_ROWS_BWD_FUSEW"); return !(e && e[0] == '0'); }();
+  return on;
+}
 int run_edge_attn_bwd(hipStream_t st, int heads, const float* img, const int32_t* segptr, const float* emb, const float* q, const float* agg,
                       const float* dagg, const float* stats, int64_t R, float* DQ, float* RL, float* SS, float* DAGGM, float* EA, float* ED,
-                      const DropArg& drop) {
+                      const DropArg& drop, const WgradCtx* wc, float* wk, float* wv, bool* weights_done) {
   const int32_t* ns = nullptr;
   const float* nf = nullptr;
   float* nw = nullptr;
+  if (weights_done) *weights_done = false;
   if (heads == 4)
     TS_LAUNCH_TAG("k_edge_attn_rows_bwd<4>", false, (k_gattn_bwd<4, false>), xcd_grid(cdiv(R, 4)), 256, 0, st, img, segptr, ns, emb, q, nf, nf, agg, dagg, stats,
                   R, DQ, nw, nw, RL, SS, DAGGM, EA, ED, nw, ns, drop);
   else if (rows_bwd_mm()) {
+    ReduceQueue* rq = active_reduce_queue();
+    const int gridf = int(std::min<int64_t>(256, cdiv(R, RMMF_WAVES)));
+    if (rq && wc && rq->part == wc->part && wk && wv && weights_done && rows_bwd_fusew() && R > 0 && rq->cap >= 2 * int64_t(gridf)) {
+      // the weight gradients of lin_k / lin_v accumulated inside the kernel: one pair of partials per workgroup, summed with the deferred sums
+      int rc = TRAJSDE_OK;
+      const int64_t base = rq->take(2 * int64_t(gridf), &rc);
+      if (rc) return rc;
+      float* wpart = wc->part + base * 4096;
+      if (drop.p > 0.f) TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<true, true>), gridf, 64 * RMMF_WAVES, rows_mmf_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop, wpart);
+      else TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<false, true>), gridf, 64 * RMMF_WAVES, rows_mmf_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop, wpart);
+      rq->jobs.push_back(ReduceJob{wk, nullptr, base, gridf, 1, 64, 0, 0});
+      rq->jobs.push_back(ReduceJob{wv, nullptr, base + gridf, gridf, 1, 64, 0, 0});
+      *weights_done = true;
+      return TRAJSDE_OK;
+    }
     // one workgroup per CU (its LDS image fills most of one); fewer when the targets do not fill them
     const int grid = int(std::min<int64_t>(256, cdiv(R, RMM_WAVES)));
-    if (drop.p > 0.f) TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<true>), grid, 64 * RMM_WAVES, rows_mm_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop);
-    else TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<false>), grid, 64 * RMM_WAVES, rows_mm_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop);
+    if (drop.p > 0.f) TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<true, false>), grid, 64 * RMM_WAVES, rows_mm_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop, nw);
+    else TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<false, false>), grid, 64 * RMM_WAVES, rows_mm_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop, nw);
   } else
     TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_gattn_bwd<8, false>), xcd_grid(cdiv(R, 4)), 256, 0, st, img, segptr, ns, emb, q, nf, nf, agg, dagg, stats,
                   R, DQ, nw, nw, RL, SS, DAGGM, EA, ED, nw, ns, drop);
