@@ -410,6 +410,27 @@ __global__ __launch_bounds__(64 * (FUSEW ? RMMF_WAVES : RMM_WAVES)) void k_edge_
   __syncthreads();
   const float bke = img[GAttnL::BKE + lane], bve = img[GAttnL::BVE + lane];
   const int64_t stride = int64_t(gridDim.x) * WAVES;
+  // The first tile of the NEXT target is requested before the current target's epilogue, into the row registers its last tile has just
+  // freed (the segment bounds of the next target a whole target ahead): a target is two tiles on average, and its first rows used to wait
+  // for segptr -> address -> HBM at the top of every target.
+  f4 nx[4];
+  int beg_next = 0, end_next = 0;
+  auto fetch_rows = [&](int e0, int end_) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = e0 + 4 * q4 + r;
+      const int ec = e < end_ ? e : end_ - 1;
+      nx[r] = *reinterpret_cast<const f4*>(rel + int64_t(ec) * 64 + 4 * c16);
+    }
+  };
+  {
+    const int64_t n0 = int64_t(blockIdx.x) * WAVES + wv;
+    if (n0 < N) {
+      beg_next = segptr[n0];
+      end_next = segptr[n0 + 1];
+      if (beg_next < end_next) fetch_rows(beg_next, end_next);
+    }
+  }
   for (int64_t node = int64_t(blockIdx.x) * WAVES + wv; node < N; node += stride) {
     // per-head constants, first in the "lane = channel" layout (lanes 8h .. 8h+7 hold head h), then handed to the lanes of column hd
     const float ql = q[node * 64 + lane];
@@ -421,17 +442,13 @@ __global__ __launch_bounds__(64 * (FUSEW ? RMMF_WAVES : RMM_WAVES)) void k_edge_
       xsm[64 + lane] = da;
     }
     const float m = stats[(node * HEADS + hd) * 2], inv = stats[(node * HEADS + hd) * 2 + 1];
-    const int beg = segptr[node], end = segptr[node + 1];
-    f4 nx[4];
-    auto fetch = [&](int e0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int e = e0 + 4 * q4 + r;
-        const int ec = e < end ? e : end - 1;
-        nx[r] = *reinterpret_cast<const f4*>(rel + int64_t(ec) * 64 + 4 * c16);
-      }
-    };
-    if (beg < end) fetch(beg);
+    const int beg = beg_next, end = end_next;
+    {
+      const int64_t nn = node + stride < N ? node + stride : node;  // (uniform; the last target reads its own bounds again)
+      beg_next = segptr[nn];
+      end_next = segptr[nn + 1];
+    }
+    auto fetch = [&](int e0) { fetch_rows(e0, end); };
     const float cb = __shfl(head_sum_n<HEADS>(ql * bke), 8 * hd);
     const float cz = __shfl(head_sum_n<HEADS>(da * bve), 8 * hd);
     const float dlt = __shfl(head_sum_n<HEADS>(da * ag), 8 * hd);
@@ -455,13 +472,10 @@ __global__ __launch_bounds__(64 * (FUSEW ? RMMF_WAVES : RMM_WAVES)) void k_edge_
     for (int b = 0; b < 4; ++b) R[b] = f4{0.f, 0.f, 0.f, 0.f};
     float sal = 0.f, sad = 0.f;
     for (int e0 = beg; e0 < end; e0 += 16) {
-      f4 rw[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) rw[r] = nx[r];
-      if (e0 + 16 < end) fetch(e0 + 16);
       __builtin_amdgcn_wave_barrier();                             // the previous readers of the tile are done (same wave, in order)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) *reinterpret_cast<f4*>(tile + (4 * q4 + r) * TP + 4 * c16) = rw[r];
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<f4*>(tile + (4 * q4 + r) * TP + 4 * c16) = nx[r];
+      if (e0 + 16 < end) fetch(e0 + 16);                           // the next tile's rows, into the registers just staged
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       f4 a[4];
@@ -503,11 +517,17 @@ __global__ __launch_bounds__(64 * (FUSEW ? RMMF_WAVES : RMM_WAVES)) void k_edge_
         W[i] = lo8 ? dls : alk;
         if (e < end) (lo8 ? ED : EA)[int64_t(e) * HEADS + hd] = W[i];
       }
+      {
+        f4 rw[4];                                                  // the tile's rows again, whole rows per 16 lanes: B operand under the column order 4n + b
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 4; ++r) rw[r] = *reinterpret_cast<const f4*>(tile + (4 * q4 + r) * TP + 4 * c16);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) R[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[i], rw[i][b], R[b], 0, 0, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) R[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[i], rw[i][b], R[b], 0, 0, 0);
+      }
     }
+    if (node + stride < N && beg_next < end_next) fetch_rows(beg_next, end_next);      // the next target's first tile, under this epilogue
     // lane (n, q) holds rows 4q + i' of the 16 x 64 sums at columns 4n .. 4n+3: rows 0-7 are RL of heads 0-7, rows 8-15 SS
     __builtin_amdgcn_wave_barrier();                               // (the previous target's epilogue reads of sb are done)
 #pragma unroll
