@@ -365,7 +365,7 @@ constexpr int rows_mm_lds_bytes() { return (RMM_WIMG + RMM_WK + RMM_WAVES * RMM_
 // reproducible) and leave as ONE pair of 64 x 64 partials per workgroup, summed by the deferred reduce like any other weight gradient.
 constexpr int RMMF_WAVES = 8;
 constexpr int RMMF_PER_WAVE = 16 * RMM_TP + 16 * RMM_TP + 128;      // staging tile + the sixteen RL | SS rows + q | dagg
-constexpr int rows_mmf_lds_bytes() { return (RMM_WIMG + RMM_WK + RMMF_WAVES * RMMF_PER_WAVE + 2 * 4096) * 4; }
+constexpr int rows_mmf_lds_bytes() { return (RMM_WIMG + RMM_WK + RMMF_WAVES * RMMF_PER_WAVE + 2 * 4096 + 64) * 4; }
 template <bool DROP, bool FUSEW>
 __global__ __launch_bounds__(64 * (FUSEW ? RMMF_WAVES : RMM_WAVES)) void k_edge_rows_bwd_mm(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                                      const float* __restrict__ rel, const float* __restrict__ q,
@@ -373,7 +373,8 @@ __global__ __launch_bounds__(64 * (FUSEW ? RMMF_WAVES : RMM_WAVES)) void k_edge_
                                                                      const float* __restrict__ stats, int64_t N, float* __restrict__ DQ,
                                                                      float* __restrict__ RL, float* __restrict__ SS,
                                                                      float* __restrict__ DAGGM, float* __restrict__ EA,
-                                                                     float* __restrict__ ED, DropArg drop, float* __restrict__ wpart) {
+                                                                     float* __restrict__ ED, DropArg drop, float* __restrict__ wpart,
+                                                                     float* __restrict__ wcs) {
   constexpr int HEADS = 8;
   constexpr float INV = INV_SQRT_DH;
   constexpr int TP = RMM_TP;
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(64 * (FUSEW ? RMMF_WAVES : RMM_WAVES)) void k_edge_
   float* const sb = tile + 16 * TP;                                // [8][TP] (FUSEW: [16][TP], the SS rows too)
   float* const xsm = sb + 16 * TP;                                 // FUSEW: [64] q | [64] dagg of the current target
   f4 GW[FUSEW ? 2 : 1][FUSEW ? 8 : 1][FUSEW ? 2 : 1];
+  float gbv = 0.f;                                                 // FUSEW: lin_v.bias gradient, lane = channel (sum over the wave's targets of dagg * sum_e alpha d)
 #pragma unroll
   for (int a_ = 0; a_ < (FUSEW ? 2 : 1); ++a_)
 #pragma unroll
@@ -568,7 +570,8 @@ __global__ __launch_bounds__(64 * (FUSEW ? RMMF_WAVES : RMM_WAVES)) void k_edge_
     sw = xor32_sum(xor16_sum(sw));
     const float swh = __shfl(sw, h);
     DQ[node * 64 + lane] = dq;
-    DAGGM[node * 64 + lane] = da * swh;                            // lin_v_edge.bias sees sum_e alpha d_e (= 1 without dropout)
+    if (FUSEW) gbv += da * swh;                                    // lin_v_edge.bias sees sum_e alpha d_e (= 1 without dropout)
+    else DAGGM[node * 64 + lane] = da * swh;
   }
   if (FUSEW) {
     // the workgroup's partial: its waves add their registers into one LDS block in wave order, then it leaves as 2 x 4096 floats
@@ -587,9 +590,12 @@ __global__ __launch_bounds__(64 * (FUSEW ? RMMF_WAVES : RMM_WAVES)) void k_edge_
                 float* pa = acc + mt * 4096 + (8 * hh + 4 * hf + i) * 64 + lane;
                 *pa = w == 0 ? GW[mt][hh][hf][i] : *pa + GW[mt][hh][hf][i];
               }
+        float* pb = acc + 2 * 4096 + lane;
+        *pb = w == 0 ? gbv : *pb + gbv;
       }
     }
     __syncthreads();
+    if (threadIdx.x < 64) wcs[(int64_t(gridDim.x) + blockIdx.x) * 64 + threadIdx.x] = acc[2 * 4096 + threadIdx.x];      // the cs slot of the lin_v partial
     for (int i = threadIdx.x; i < 2 * 1024; i += blockDim.x) {
       const int mt = i >> 10, k = i & 1023;
       *reinterpret_cast<f4*>(wpart + (int64_t(mt) * gridDim.x + blockIdx.x) * 4096 + 4 * k) = *reinterpret_cast<const f4*>(acc + mt * 4096 + 4 * k);
@@ -864,7 +870,7 @@ static bool rows_bwd_fusew() {
 }
 int run_edge_attn_bwd(hipStream_t st, int heads, const float* img, const int32_t* segptr, const float* emb, const float* q, const float* agg,
                       const float* dagg, const float* stats, int64_t R, float* DQ, float* RL, float* SS, float* DAGGM, float* EA, float* ED,
-                      const DropArg& drop, const WgradCtx* wc, float* wk, float* wv, bool* weights_done) {
+                      const DropArg& drop, const WgradCtx* wc, float* wk, float* wv, float* bv, bool* weights_done) {
   const int32_t* ns = nullptr;
   const float* nf = nullptr;
   float* nw = nullptr;
@@ -875,23 +881,24 @@ int run_edge_attn_bwd(hipStream_t st, int heads, const float* img, const int32_t
   else if (rows_bwd_mm()) {
     ReduceQueue* rq = active_reduce_queue();
     const int gridf = int(std::min<int64_t>(256, cdiv(R, RMMF_WAVES)));
-    if (rq && wc && rq->part == wc->part && wk && wv && weights_done && rows_bwd_fusew() && R > 0 && rq->cap >= 2 * int64_t(gridf)) {
+    if (rq && wc && rq->part == wc->part && wk && wv && bv && weights_done && rows_bwd_fusew() && R > 0 && rq->cap >= 2 * int64_t(gridf)) {
       // the weight gradients of lin_k / lin_v accumulated inside the kernel: one pair of partials per workgroup, summed with the deferred sums
       int rc = TRAJSDE_OK;
       const int64_t base = rq->take(2 * int64_t(gridf), &rc);
       if (rc) return rc;
       float* wpart = wc->part + base * 4096;
-      if (drop.p > 0.f) TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<true, true>), gridf, 64 * RMMF_WAVES, rows_mmf_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop, wpart);
-      else TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<false, true>), gridf, 64 * RMMF_WAVES, rows_mmf_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop, wpart);
+      float* wcs = wc->cs + base * 64;                               // (the lin_v partials' column-sum slots carry the bias gradient)
+      if (drop.p > 0.f) TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<true, true>), gridf, 64 * RMMF_WAVES, rows_mmf_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop, wpart, wcs);
+      else TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<false, true>), gridf, 64 * RMMF_WAVES, rows_mmf_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop, wpart, wcs);
       rq->jobs.push_back(ReduceJob{wk, nullptr, base, gridf, 1, 64, 0, 0});
-      rq->jobs.push_back(ReduceJob{wv, nullptr, base + gridf, gridf, 1, 64, 0, 0});
+      rq->jobs.push_back(ReduceJob{wv, bv, base + gridf, gridf, 1, 64, 0, 0});      // bias = sum of the cs slots: d lin_v.bias
       *weights_done = true;
       return TRAJSDE_OK;
     }
     // one workgroup per CU (its LDS image fills most of one); fewer when the targets do not fill them
     const int grid = int(std::min<int64_t>(256, cdiv(R, RMM_WAVES)));
-    if (drop.p > 0.f) TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<true, false>), grid, 64 * RMM_WAVES, rows_mm_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop, nw);
-    else TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<false, false>), grid, 64 * RMM_WAVES, rows_mm_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop, nw);
+    if (drop.p > 0.f) TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<true, false>), grid, 64 * RMM_WAVES, rows_mm_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop, nw, nw);
+    else TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_edge_rows_bwd_mm<false, false>), grid, 64 * RMM_WAVES, rows_mm_lds_bytes(), st, img, segptr, emb, q, agg, dagg, stats, R, DQ, RL, SS, DAGGM, EA, ED, drop, nw, nw);
   } else
     TS_LAUNCH_TAG("k_edge_attn_rows_bwd<8>", false, (k_gattn_bwd<8, false>), xcd_grid(cdiv(R, 4)), 256, 0, st, img, segptr, ns, emb, q, nf, nf, agg, dagg, stats,
                   R, DQ, nw, nw, RL, SS, DAGGM, EA, ED, nw, ns, drop);

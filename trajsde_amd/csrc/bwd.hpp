@@ -209,9 +209,10 @@ int run_gattn_drel(hipStream_t st, int heads, int nl, bool from_rows, const Drel
 // with q / dagg), DAGGM [R,64] (column sum = lin_v bias gradient) and the per-edge scalars EA / ED [E,heads]
 int run_edge_attn_bwd(hipStream_t st, int heads, const float* img, const int32_t* segptr, const float* emb, const float* q, const float* agg,
                       const float* dagg, const float* stats, int64_t R, float* DQ, float* RL, float* SS, float* DAGGM, float* EA, float* ED,
-                      const DropArg& drop, const WgradCtx* wc = nullptr, float* wk = nullptr, float* wv = nullptr, bool* weights_done = nullptr);
+                      const DropArg& drop, const WgradCtx* wc = nullptr, float* wk = nullptr, float* wv = nullptr, float* bv = nullptr,
+                      bool* weights_done = nullptr);
 // (wc / wk / wv / weights_done: the kernel may accumulate the lin_k / lin_v weight gradients itself -- *weights_done then tells the caller to
-//  skip its two run_headwise_outer calls; RL / SS are not written in that case)
+//  skip its two run_headwise_outer calls and the column sum of DAGGM (lin_v.bias); RL / SS / DAGGM are not written in that case)
 
 // ---- TemporalEncoder backward kernels (grid_bwd.hip)
 __global__ void k_tr_final_bwd(const float* norm, const float* x, const float* dtout, int N, float* DX, float* vpart);

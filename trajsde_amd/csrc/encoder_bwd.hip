@@ -703,14 +703,15 @@ int run_attn_chain(const AttnChain& c, const float* dout, EncBwdWs& w, const Wgr
   // so no [E,64] row of k, v, d k, d v or d emb is ever written.  A target without edges gets DQ = 0, RL = SS = 0 from the kernel.
   bool weights_done = false;
   if (int rc = run_edge_attn_bwd(st, c.heads, c.img_attn, c.segptr, c.emb, c.q, c.tp.agg, w.dagg, c.stats, R, w.DQ, w.RL, w.SS, w.DAGGM,
-                                 w.EA, w.ED, c.drop, &wc, wk, wv, &weights_done))
+                                 w.EA, w.ED, c.drop, &wc, wk, wv, bv, &weights_done))
     return rc;
   if (!weights_done) {
     if (int rc = run_headwise_outer(wc, c.q, w.RL, R, wk, c.heads)) return rc;
     if (int rc = run_headwise_outer(wc, w.dagg, w.SS, R, wv, c.heads)) return rc;
   }
   TS_HIP(hipMemsetAsync(bk, 0, 64 * sizeof(float), st));
-  if (int rc = run_colsum_tall(st, w.DAGGM, R, 64, 64, bv, w.nb.vpart)) return rc;
+  if (!weights_done)
+    if (int rc = run_colsum_tall(st, w.DAGGM, R, 64, 64, bv, w.nb.vpart)) return rc;
   if (E > 0) {
     const EdgeAttnGrad ag{c.dst, c.q, w.dagg, w.EA, w.ED, c.img_kvt, c.heads};
     // the embedding rows were last read by the attention backward above: their slab becomes the embedding backward's S slab
