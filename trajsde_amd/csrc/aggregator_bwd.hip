@@ -941,12 +941,21 @@ __global__ __launch_bounds__(256) void k_gattn_src_bwd(const int32_t* __restrict
   if (node >= N || *asym != 0) return;                     // asymmetric list: k_gattn_bwd scattered the rows with atomics
   float dk = 0.f, dv = 0.f;
   const int beg = segptr[node], end = segptr[node + 1];
-  for (int e0 = beg; e0 < end; e0 += 8) {                  // 8 edges per round trip; indices loaded coalesced, used as scalars
-    const int ec = e0 + (lane & 7) < end ? e0 + (lane & 7) : end - 1;
-    const int rv = REV[ec], sv = src[ec];
-    float a[8], d[8], qv[8], gv[8];
+  // 16 edges per round trip (the wave does nothing but wait for them: one target per wave, a handful of registers), their indices loaded
+  // coalesced ONE ROUND AHEAD and used as scalars; same summation order as one edge at a time
+  auto idx_at = [&](int e0, int& rv, int& sv) {
+    const int ec = e0 + (lane & 15) < end ? e0 + (lane & 15) : end - 1;
+    rv = REV[ec];
+    sv = src[ec];
+  };
+  int rv_n = 0, sv_n = 0;
+  if (beg < end) idx_at(beg, rv_n, sv_n);
+  for (int e0 = beg; e0 < end; e0 += 16) {
+    const int rv = rv_n, sv = sv_n;
+    idx_at(e0 + 16 < end ? e0 + 16 : e0, rv_n, sv_n);
+    float a[16], d[16], qv[16], gv[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const int e = __builtin_amdgcn_readlane(rv, u), i = __builtin_amdgcn_readlane(sv, u);
       a[u] = (EA + int64_t(e) * HEADS)[h];
       d[u] = (ED + int64_t(e) * HEADS)[h];
@@ -954,8 +963,8 @@ __global__ __launch_bounds__(256) void k_gattn_src_bwd(const int32_t* __restrict
       gv[u] = (dagg + int64_t(i) * 64)[lane];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (e0 + u < end) {                                  // same summation order as one edge at a time
+    for (int u = 0; u < 16; ++u)
+      if (e0 + u < end) {
         dk = fmaf(d[u], qv[u], dk);
         dv = fmaf(a[u], gv[u], dv);
       }
