@@ -143,6 +143,58 @@ def cpu_baseline(model, cfg, spec, gpu_loc_fn):
     return base, match
 
 
+def strict24_child(args) -> int:
+    """The headline workload on the strict-precision library (variants/libtrajsde_strict24.so: bf16x6 split, 24-bit operands, same
+    C-ABI), in a process of its own because a process holds ONE build of the library.  Prints one JSON object."""
+    import numpy as np
+    import torch
+    from trajsde_amd import _lib
+    from trajsde_amd.models.model_base_mix_sde import PredictionModelSDENet
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import CONFIGS, synth
+    lib = _lib.lib()
+    assert lib.trajsde_split_products() == 6, "the strict-precision child must run the bf16x6 library"
+    dev = torch.device("cuda", 0)
+    spec = CONFIGS[args.workload]
+    model = PredictionModelSDENet(**build_cfg(spec), init_seed=0).eval().to(dev)
+    n_streams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    cpu = synth(**spec["synth"])
+    batches, y0s = [], []
+    for st in streams:
+        with torch.cuda.stream(st):
+            b = cpu.to(dev)
+            batches.append(b)
+            y0s.append(b.y.clone())
+    torch.cuda.synchronize()
+
+    def step(i):
+        k = i % n_streams
+        with torch.cuda.stream(streams[k]), torch.no_grad():
+            batches[k].y = y0s[k]
+            model(batches[k], noise=NoiseSpec(seed=10_000 + i))
+    for i in range(2 * n_streams):
+        step(i)
+    wins = []
+    for w in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(100 + w * args.steps + i)
+        torch.cuda.synchronize()
+        wins.append(time.perf_counter() - t0)
+    el = float(np.median(wins))
+    _lib.check_range()
+    sample = synth(**dict(spec["synth"], S=CPU_SAMPLE_SCENES)).to(dev)
+    with torch.no_grad():
+        loc = model(sample, noise=NoiseSpec(seed=1234))["loc"].cpu().numpy()
+    ref = np.load(args.strict24_child)
+    print(json.dumps({"value": spec["synth"]["S"] * args.steps / el, "ms_per_step": 1e3 * el / args.steps, "unit": "scenes/s",
+                      "max_abs_loc_diff": float(np.abs(loc - ref).max()), "windows_ms": [1e3 * w for w in wins],
+                      "steps": args.steps, "streams_per_gpu": n_streams, "split_products": 6}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,7 +208,12 @@ def main():
     ap.add_argument("--kernel-table", action="store_true", help="extra untimed pass timing every kernel (stderr)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the secondary training-step figure")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1-stream / 64x128 / SDE-step side figures")
+    ap.add_argument("--strict24-child", default=None, metavar="NPY",
+                    help="(internal) run as the child that times the 24-bit-operand library (TRAJSDE_LIB set by the parent) and "
+                         "compares its trajectories with the parent's, saved in NPY")
     args = ap.parse_args()
+    if args.strict24_child:
+        sys.exit(strict24_child(args))
 
     if (args.gpus > 1 or os.environ.get("TRAJSDE_BENCH_SPAWN") == "1") and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))                 # nothing above this line has touched the GPU or loaded the HIP library
@@ -323,9 +380,8 @@ def main():
                          "windows_ms": [1e3 * w for w in w1], "what": "the same steps on one HIP stream per GPU"},
         }
         if world > 1:                                                         # world-1-only legs: say so instead of leaving the keys out
-            for k in ("cpu_baseline", "minade_match", "graph_replay", "config2_64x128", "config3_argo_t30", "roofline_sde_step", "train_step",
-                      "config4_train"):
-                line[k] = "n/a (N>1): measured by the N=1 run"
+            for k in ("cpu_baseline", "minade_match", "graph_replay", "config2_64x128", "config3_argo_t30", "roofline_sde_step", "strict24", "train_step"):
+                line[k] = "n/a (N>1): measured by the N=1 run"                   # (config4_train / train_scaling ARE measured under N>1)
         if not args.no_cpu_baseline and world == 1:
             def gpu_fn(b_cpu, seed):
                 b = b_cpu.to(dev)
@@ -441,6 +497,38 @@ def main():
                 del m3, b3s, y3s
             except Exception as e:
                 line["config3_argo_t30"] = {"error": repr(e)[:300]}
+        # The strict-precision twin: the same workload on the 24-bit-operand build of the library (bf16x6 split,
+        # variants/libtrajsde_strict24.so), in a CHILD process -- one process holds one build -- and its trajectories on the
+        # CPU-baseline sample (same generator, Philox seed 1234) against this process's fp16x3 ones
+        if split_products == 3 and rank == 0:
+            try:
+                import tempfile
+                from trajsde_amd import build as build_mod
+                if not os.path.isfile(build_mod.STRICT_LIB):
+                    raise FileNotFoundError(build_mod.STRICT_LIB + " (python -m trajsde_amd.build)")
+                sample = synth(**dict(spec["synth"], S=CPU_SAMPLE_SCENES)).to(dev)
+                with torch.no_grad():
+                    loc0 = model(sample, noise=NoiseSpec(seed=1234))["loc"].cpu().numpy()
+                with tempfile.TemporaryDirectory() as td:
+                    npy = os.path.join(td, "loc_fp16x3.npy")
+                    np.save(npy, loc0)
+                    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TRAJSDE_BENCH_SPAWN",
+                                                                            "TRAJSDE_BENCH_FORCE_DIST")}
+                    env["TRAJSDE_LIB"] = build_mod.STRICT_LIB
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--strict24-child", npy, "--steps", str(min(args.steps, 10)),
+                                        "--streams", str(n_streams), "--workload", args.workload], env=env, timeout=600,
+                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError(r.stderr[-300:])
+                st = json.loads(r.stdout.strip().splitlines()[-1])
+                st["dtype"] = DTYPE[6]
+                st["ratio_to_value"] = st["value"] / line["value"]
+                st["what"] = ("the headline workload on variants/libtrajsde_strict24.so (TRAJSDE_SPLIT=bf16x6: three bf16 pieces, six products, "
+                              "24-bit operands), timed in a child process; max_abs_loc_diff: its trajectories against the fp16x3 build's on "
+                              "the CPU-baseline sample, same Philox seed")
+                line["strict24"] = st
+            except Exception as e:
+                line["strict24"] = {"error": repr(e)[:300]}
         # the step-granular decoder SDE step (state round-trips HBM every Euler step: SURVEY 8(d)'s 512 B / path-step
         # variant) in both views: algorithmic HBM GB/s -- the figure the north star names -- and the FLOP/s beside it
         try:
@@ -478,53 +566,103 @@ def main():
                                              "side of it; the fused decoder (the product path) never writes the state at all")
         except Exception as e:
             line["roofline_sde_step"] = {"error": repr(e)[:300]}
-    if rank == 0 and world == 1 and not args.no_train_step:
-        # secondary figures (not `value`): the training step -- forward + L2/DiffBCE + the three stage backward calls + AdamW
-        #  -- at BASELINE configs[1] (64 x 128, K=6, T=20) and at the shape of configs[3], the shipped
-        # training recipe (128 scenes x 48 agents per GPU, K=10, T=60, mixed sources: CFG:9-22,106)
-        def train_figure(name, what):
-            from trajsde_amd.driver import FlatTraining
-            from trajsde_amd import runtime
-            from trajsde_amd.data import TemporalData
-            twl = Workload(name)
-            tspec = CONFIGS[name]
-            tmodel = PredictionModelSDENet(**build_cfg(tspec), init_seed=0).to(dev).train()
-            flat = FlatTraining(tmodel)                                       # the training loop's handle (driver.train)
-            tb = twl.batches[0]
-            tbase = {k: v for k, v in tb.as_dict().items() if not k.startswith("_")}
-            tbase["y"] = twl.y0s[0]
-            tside = runtime.side_stream(dev)
+    # secondary figures (not `value`): the training step -- forward + L2/DiffBCE + the three stage backward calls + AdamW
+    #  -- at BASELINE configs[1] (64 x 128, K=6, T=20) and at the shape of configs[3], the shipped
+    # training recipe (128 scenes x 48 agents per GPU, K=10, T=60, mixed sources: CFG:9-22,106)
+    def train_figure(name, what, collective=False, steps=8):
+        """`collective`: the multi-rank loop of driver.train -- every rank its own scenes, the flat gradient buffer averaged by the
+        ONE all-reduce of the design (FlatGrads: decoder + aggregator slice early on the collective stream under the
+        encoder backward, the rest after it) -- timed with and without the collective, max over ranks"""
+        from trajsde_amd.driver import FlatTraining
+        from trajsde_amd import runtime
+        from trajsde_amd.data import TemporalData
+        twl = Workload(name)
+        tspec = CONFIGS[name]
+        tmodel = PredictionModelSDENet(**build_cfg(tspec), init_seed=0).to(dev).train()
+        flat = FlatTraining(tmodel)                                       # the training loop's handle (driver.train)
+        tb = twl.batches[0]
+        tbase = {k: v for k, v in tb.as_dict().items() if not k.startswith("_")}
+        tbase["y"] = twl.y0s[0]
+        tside = runtime.side_stream(dev)
+        early_ok = flat.grads.early_plan({id(p): n for n, p in tmodel.named_parameters()})
+        flat.grads.force_collective = bool(collective) and world == 1     # one forced-dist rank still issues the RCCL launches
 
-            def tfresh(i):                  # the loop of driver.train: the next step's copy of the batch, rotated and through the graph
-                with torch.cuda.stream(tside):                                # stage (one host synchronisation) on the side stream
-                    b = TemporalData(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in tbase.items()})
-                    tmodel.prefetch_graph(b, NoiseSpec(seed=5000 + i))
-                return b
-            tnext = [tfresh(0)]
+        def tfresh(i):                  # the loop of driver.train: the next step's copy of the batch, rotated and through the graph
+            with torch.cuda.stream(tside):                                # stage (one host synchronisation) on the side stream
+                b = TemporalData(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in tbase.items()})
+                tmodel.prefetch_graph(b, NoiseSpec(seed=5000 + 100_000 * rank + i))
+            return b
+        tnext = [tfresh(0)]
 
-            def tstep(i):
-                flat.zero()
-                tmodel.training_step(tnext[0], i, noise=NoiseSpec(seed=5000 + i)).backward()
-                flat.step()
-                tnext[0] = tfresh(i + 1)
-            for i in range(2):                                                 # optimizer state, allocator pools
-                tstep(i)
-            torch.cuda.synchronize()
+        def tstep(i, reduce_):
+            flat.zero()
+            tmodel.training_step(tnext[0], i, noise=NoiseSpec(seed=5000 + 100_000 * rank + i)).backward()
+            if reduce_:
+                flat.all_reduce_mean()
+            flat.step()
+            tnext[0] = tfresh(i + 1)
+
+        def timed(first, reduce_):
+            flat.grads.early_enabled = bool(reduce_ and early_ok)
+            for i in range(2):                                             # optimizer state, allocator pools, communicator warm-up
+                tstep(first + i, reduce_)
+            sync_all()
             t0 = time.perf_counter()
-            for i in range(8):
-                tstep(2 + i)
-            torch.cuda.synchronize()
-            tms = (time.perf_counter() - t0) / 8 * 1e3
-            return {"ms_per_step": tms, "scenes_per_s": tspec["synth"]["S"] / tms * 1e3, "steps": 8, "workload": what,
-                    "what": "training_step + backward (HIP backward kernels of all three stages) + AdamW, fp32 gradients, a fresh "
-                            "copy of the batch per step, the loop of driver.train (next batch's graph stage on a side stream)",
-                    "loss_L2": float(tmodel.last_losses["L2"]), "loss_DiffBCE": float(tmodel.last_losses["DiffBCE"]),
-                    "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+            for i in range(steps):
+                tstep(first + 2 + i, reduce_)
+            sync_all()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return el / steps * 1e3
+        tms = timed(0, bool(collective))
+        S = tspec["synth"]["S"]
+        fig = {"ms_per_step": tms, "scenes_per_s": world * S / tms * 1e3, "steps": steps, "workload": what,
+               "what": "training_step + backward (HIP backward kernels of all three stages) + AdamW, fp32 gradients, a fresh "
+                       "copy of the batch per step, the loop of driver.train (next batch's graph stage on a side stream)"
+                       + ("; every rank its own scenes, gradients averaged over the ranks by RCCL" if collective else ""),
+               "loss_L2": float(tmodel.last_losses["L2"]), "loss_DiffBCE": float(tmodel.last_losses["DiffBCE"]),
+               "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+        scaling = None
+        if collective:
+            t_off = timed(100, False)                                     # the same steps with no collective at all
+            scaling = {"ms_per_step": tms, "ms_per_step_without_collective": t_off, "allreduce_exposed_ms": tms - t_off,
+                       "bytes": int(flat.grads.flat.numel()) * 4, "overlap": bool(early_ok),
+                       "early_slice_bytes": (int(flat.grads.flat.numel()) - _encoder_floats(tmodel, flat)) * 4 if early_ok else 0,
+                       "ranks": world, "scenes_per_s": world * S / tms * 1e3, "steps": steps,
+                       "collective": "ONE all-reduce(sum) of the flat fp32 gradient buffer per step over RCCL, in two slices: decoder + "
+                                     "aggregator block on the collective stream under the encoder backward, encoder block after it "
+                                     "(driver.FlatGrads.early_reduce / all_reduce_mean; train.py:35,54, CFG:106)",
+                       "note": "max over ranks, barrier + synchronize on both sides; with one rank (forced dist) the collectives are "
+                               "one-rank RCCL launches: the stream choreography is exercised, the wire is not"}
+        flat.grads.force_collective = False
+        return fig, scaling
+
+    def _encoder_floats(tmodel, flat):
+        enc = {id(p) for n, p in tmodel.named_parameters() if n.startswith("encoder.")}
+        return sum(p.numel() for p in flat.grads.params if id(p) in enc)
+
+    if not args.no_train_step and dist is not None:
+        # N > 1 (or one forced-dist rank): the shipped training recipe's shape per rank with the design's one collective in the step
+        try:
+            fig, scaling = train_figure("config4", "BASELINE configs[3] shape per GPU: 128 scenes x 48 agents, 150 lanes, K=10, T=60 "
+                                                   "(61 Euler steps), mixed nuScenes / Argoverse sources, dropout 0.1", collective=True)
+            if rank == 0:
+                line["config4_train"] = fig
+                line["train_scaling"] = scaling
+        except Exception as e:
+            if rank == 0:
+                line["config4_train"] = {"error": repr(e)[:300]}
+                line["train_scaling"] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and dist is None and not args.no_train_step:
         for key, name, what in (("train_step", SECONDARY, "BASELINE configs[1]: 64 scenes x 128 agents, K=6, 20 SDE steps"),
                                 ("config4_train", "config4", "BASELINE configs[3] shape per GPU: 128 scenes x 48 agents, 150 lanes, K=10, T=60 "
                                                              "(61 Euler steps), mixed nuScenes / Argoverse sources, dropout 0.1")):
             try:
-                line[key] = train_figure(name, what)
+                line[key] = train_figure(name, what)[0]
             except Exception as e:                                          # never let a secondary figure cost the main line
                 line[key] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()

@@ -309,7 +309,7 @@ def test_bench_spawned_rank_runs_the_rccl_path(tmp_path):
     env.update(TRAJSDE_BENCH_SPAWN="1", TRAJSDE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--windows", "1",
-                        "--no-cpu-baseline", "--no-secondary", "--no-train-step"], env=env, timeout=900,
+                        "--no-cpu-baseline", "--no-secondary"], env=env, timeout=900,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -317,6 +317,14 @@ def test_bench_spawned_rank_runs_the_rccl_path(tmp_path):
     assert line["steps"] == 2 and line["value"] > 0 and line["unit"] == "scenes/s"
     assert line["roofline"]["streams"] == 1 and 0.0 < line["roofline"]["frac"] < 1.0
     assert line["roofline_corun"]["launches"] >= 2
+    # the training leg of the N > 1 bench: driver.train's step at the configs[3] shape with the design's one
+    # collective -- the two-slice gradient all-reduce -- issued over RCCL (one-rank communicator here), with and without it
+    ts = line["train_scaling"]
+    assert "error" not in ts, ts
+    assert ts["ranks"] == 1 and ts["overlap"] is True and ts["bytes"] > 4 * 500_000 and 0 < ts["early_slice_bytes"] < ts["bytes"]
+    assert ts["ms_per_step"] > 0 and ts["ms_per_step_without_collective"] > 0
+    assert abs(ts["allreduce_exposed_ms"] - (ts["ms_per_step"] - ts["ms_per_step_without_collective"])) < 1e-9
+    assert line["config4_train"]["ms_per_step"] == ts["ms_per_step"] and line["config4_train"]["loss_L2"] > 0
 
 
 def test_dense_scene_1024_agents(dev):

@@ -497,3 +497,53 @@ def test_early_reduce_refuses_a_block_that_is_not_contiguous():
     assert fg.early_reduce([ps[2], ps[3]], [buf[:3], buf[3:]]) is True
     with pytest.raises(RuntimeError):
         fg.accumulate(ps, [None, buf[:3], buf[:3], buf[3:]], torch.ones(()))      # ps[0] has no gradient: does not add up
+
+
+def test_early_slice_serves_one_backward_per_zero_and_says_so():
+    """with a block reduced early, a second micro-batch before zero() used to lose its decoder + aggregator
+    gradients silently (accumulate skipped the ids that were 'done').  Now both the second early_reduce and the second accumulate
+    raise; after zero() the cycle starts again."""
+    from trajsde_amd.driver import FlatGrads
+    ps = [torch.nn.Parameter(torch.zeros(3)) for _ in range(4)]
+    fg = FlatGrads(ps)
+    buf = torch.ones(12)
+    g = [buf[0:3], buf[3:6], buf[6:9], buf[9:12]]
+    one = torch.ones(())
+    fg.zero()
+    assert fg.early_reduce(ps[2:], g[2:]) is True
+    assert fg.accumulate(ps, g, one) is True
+    assert torch.equal(fg.flat, torch.ones(12))
+    with pytest.raises(RuntimeError, match="second backward"):
+        fg.accumulate(ps, g, one)
+    with pytest.raises(RuntimeError, match="already reduced"):
+        fg.early_reduce(ps[2:], g[2:])
+    assert torch.equal(fg.flat, torch.ones(12))                                    # nothing half-added by the refused calls
+    fg.all_reduce_mean()
+    fg.zero()
+    assert fg.early_reduce(ps[2:], g[2:]) is True and fg.accumulate(ps, g, one) is True
+    # without the early slice two micro-batches accumulate as ever
+    fg.zero()
+    assert fg.accumulate(ps, g, one) and fg.accumulate(ps, g, one)
+    assert torch.equal(fg.flat, 2 * torch.ones(12))
+
+
+def test_early_slice_with_a_frozen_parameter_in_the_block():
+    """a frozen decoder / aggregator parameter is not in the flat buffer; the gradients the stage backward
+    still hands over for it must neither break the block test nor the count in accumulate, and the early-or-plain decision is a
+    static property of the parameter list (early_plan), the same on every rank"""
+    from trajsde_amd.driver import FlatGrads
+    ps = [torch.nn.Parameter(torch.zeros(3)) for _ in range(5)]
+    ps[3].requires_grad_(False)
+    names = {id(p): n for p, n in zip(ps, ("encoder.a", "encoder.b", "aggregator.a", "aggregator.frozen", "decoder.a"))}
+    fg = FlatGrads(ps)
+    assert len(fg.params) == 4 and fg.early_plan(names) is True
+    buf = torch.arange(15.0)
+    g = [buf[3 * i:3 * i + 3] for i in range(5)]
+    fg.zero()
+    assert fg.early_reduce(ps[2:], g[2:]) is True                                  # the frozen one's gradient is simply not taken
+    assert fg.accumulate(ps, g, torch.ones(())) is True
+    want = torch.cat([g[0], g[1], g[2], g[4]])
+    assert torch.equal(fg.flat, want)
+    # a layout where the would-be early block is cut in two by an encoder parameter: plain form, decided up front
+    names2 = {id(p): n for p, n in zip(ps, ("aggregator.a", "encoder.a", "decoder.a", "decoder.frozen", "decoder.b"))}
+    assert FlatGrads(ps).early_plan(names2) is False

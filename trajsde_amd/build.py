@@ -16,6 +16,10 @@ LIB = os.path.join(HERE, "libtrajsde_hip.so")
 # tools that select them with their TRAJSDE_* switches; the product library refuses those switches.
 ALT_LIB = os.path.join(HERE, "variants", "libtrajsde_alt.so")
 ALT_SOURCES = ("attn.hip", "edge32.hip", "gattn.hip", "stages.hip")     # the units TSDE_PRODUCT changes
+# The strict-precision twin: the product library with 24-bit operands (three bf16 pieces, six products: -DTSDE_SPLIT_H3=0), same
+# C-ABI.  bench.py times it in a child process (`strict24` key of the bench line) so that the headline's precision asterisk --
+# fp16x3 operands are 22-bit -- always has a current number beside it.  Not built when TRAJSDE_SPLIT already selects bf16x6.
+STRICT_LIB = os.path.join(HERE, "variants", "libtrajsde_strict24.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize is a CORRECTNESS flag here, not a tuning one.  With the SLP vectoriser on, the compiler pairs the fp32 arithmetic
 # around the matrix products into packed instructions (v_pk_fma_f32 / v_pk_mul_f32 on register pairs shuffled together by v_pk_mov_b32),
@@ -36,14 +40,39 @@ FLAGS += os.environ.get("TRAJSDE_CXXFLAGS", "").split()       # experiments: ext
 # recur.hip: the cooperative recurrence keeps its 256 weight registers per lane in the accumulation registers (pin_agpr) and needs the
 # products' accumulators in ordinary registers for that -- the compiler's other choice runs every product through a[0:3] (recur.hip)
 PER_FILE_FLAGS = {"recur.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+_PROBED = {}
+
+
+def usable_flags(flags):
+    """`flags` if this hipcc accepts them, else [] with a warning.  The per-file options are INTERNAL LLVM options (`-mllvm ...`):
+    a ROCm that renames or drops one must not fail the whole build -- the kernels stay correct without it, only slower (the
+    compiler then routes every product of recur.hip through a[0:3])."""
+    key = tuple(flags)
+    if key not in _PROBED:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "probe.hip")
+            with open(src, "w") as f:
+                f.write("#include <hip/hip_runtime.h>\n__global__ void trajsde_flag_probe() {}\n")
+            r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", *flags, "-c", src, "-o", os.path.join(d, "probe.o")],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        _PROBED[key] = r.returncode == 0
+        if not _PROBED[key]:
+            print(f"[trajsde_amd.build] warning: {HIPCC} rejects {' '.join(flags)} -- building without it (slower recurrence, same results):\n"
+                  + r.stdout.decode()[-400:], file=sys.stderr)
+    return list(flags) if _PROBED[key] else []
 
 
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _want_strict() -> bool:
+    return "-DTSDE_SPLIT_H3=0" not in FLAGS and os.environ.get("TRAJSDE_BUILD_STRICT24", "1") != "0"
+
+
 def _stale() -> bool:
-    if not os.path.isfile(LIB) or not os.path.isfile(ALT_LIB):
+    if not os.path.isfile(LIB) or not os.path.isfile(ALT_LIB) or (_want_strict() and not os.path.isfile(STRICT_LIB)):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "trajsde_hip.h")]
@@ -53,11 +82,12 @@ def _stale() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
-    objs, alt_objs = [], []
+    objs, alt_objs, strict_objs = [], [], []
     procs = []
+    strict = _want_strict()
     for src in sources():
         name = os.path.basename(src)
-        extra = PER_FILE_FLAGS.get(name, [])
+        extra = usable_flags(PER_FILE_FLAGS[name]) if (name in PER_FILE_FLAGS and "-DTSDE_SPLIT_H3=0" not in FLAGS) else []
         obj = os.path.join(CSRC, name[:-4] + ".o")
         objs.append(obj)
         procs.append((src, subprocess.Popen([HIPCC, *FLAGS, "-DTSDE_PRODUCT=1", *extra, "-c", src, "-o", obj], stdout=subprocess.PIPE,
@@ -69,6 +99,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
                                                 stderr=subprocess.STDOUT)))
         else:
             alt_objs.append(obj)
+        if strict:                                           # every unit again with the bf16x6 split
+            sobj = os.path.join(CSRC, name[:-4] + ".s24.o")
+            strict_objs.append(sobj)
+            # (without the per-file options: the bf16x6 recurrence pins nothing in the accumulation registers, and this compiler
+            #  crashes on its fp32 matrix instructions under -amdgpu-mfma-vgpr-form)
+            procs.append((src, subprocess.Popen([HIPCC, *FLAGS, "-DTSDE_SPLIT_H3=0", "-DTSDE_PRODUCT=1", "-c", src, "-o", sobj],
+                                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
@@ -78,9 +115,45 @@ def build(force: bool = False, verbose: bool = True) -> str:
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
     os.makedirs(os.path.dirname(ALT_LIB), exist_ok=True)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", ALT_LIB, *alt_objs])
+    if strict:
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", STRICT_LIB, *strict_objs])
     if verbose:
-        print(f"built {LIB}\nbuilt {ALT_LIB}")
+        print(f"built {LIB}\nbuilt {ALT_LIB}" + (f"\nbuilt {STRICT_LIB}" if strict else ""))
     return LIB
+
+
+def build_sanitized(out_lib: str, obj_dir: str) -> str:
+    """The product library once more with the HOST side under AddressSanitizer + UndefinedBehaviorSanitizer (device code
+    unsanitised: -fno-gpu-sanitize; GPU ASan is not available on this pool).  For the CPU suite (tests/test_cabi_cpu.py): the
+    size queries, argument checks, job tables and workspace carving of the entry points run on the host and can be driven
+    without a GPU.  Load it in a process started with LD_PRELOAD=<asan_runtime()>."""
+    os.makedirs(obj_dir, exist_ok=True)
+    san = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-shared-libsan"]
+    procs, objs = [], []
+    for src in sources():
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".san.o")
+        objs.append(obj)
+        procs.append((src, subprocess.Popen([HIPCC, *FLAGS, "-DTSDE_PRODUCT=1", *san, "-c", src, "-o", obj], stdout=subprocess.PIPE,
+                                            stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc (sanitized) failed on {src}:\n{out.decode()[-3000:]}")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *san, "-o", out_lib, *objs])
+    return out_lib
+
+
+def asan_runtime() -> str:
+    """path of the shared AddressSanitizer runtime of the compiler that built build_sanitized()'s library"""
+    out = subprocess.check_output([os.path.join(os.path.dirname(os.path.realpath(HIPCC)), "..", "lib", "llvm", "bin", "clang++"),
+                                   "-print-file-name=libclang_rt.asan-x86_64.so"]).decode().strip()
+    if not os.path.isfile(out):
+        import glob
+        hits = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+        if not hits:
+            raise FileNotFoundError("libclang_rt.asan-x86_64.so")
+        out = hits[0]
+    return out
 
 
 if __name__ == "__main__":

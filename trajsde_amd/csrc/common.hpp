@@ -44,20 +44,26 @@ inline int current_device() {
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 // bump allocator over a caller-provided workspace
+// (addresses are formed in integer arithmetic: the size queries carve from a null base, and pointer arithmetic on a null pointer
+//  is undefined behaviour -- found by the sanitizer build of the host side, tests/test_cabi_cpu.py)
 struct Carver {
-  char* base;
+  uintptr_t base;
   int64_t size, off;
   bool ok;
-  Carver(void* p, int64_t n) : base(static_cast<char*>(p)), size(n), off(0), ok(true) {}
+  Carver(void* p, int64_t n) : base(reinterpret_cast<uintptr_t>(p)), size(n), off(0), ok(true) {}
   template <typename T>
   T* take(int64_t count) {
     off = align_up(off, 256);
-    T* p = reinterpret_cast<T*>(base + off);
+    T* p = reinterpret_cast<T*>(base + uintptr_t(off));
     off += count * int64_t(sizeof(T));
-    if (base != nullptr && off > size) ok = false;
+    if (base != 0 && off > size) ok = false;
     return p;
   }
 };
+
+// p + n in integer arithmetic (workspace layouts are also computed from a null base by the size queries)
+template <typename T>
+inline T* ptr_add(T* p, int64_t n) { return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + uintptr_t(n) * sizeof(T)); }
 
 inline int cdiv(int64_t a, int64_t b) { return int((a + b - 1) / b); }
 // XCD-aware workgroup order.  The dispatcher deals workgroups round-robin to the 8 XCDs (workgroup b runs on XCD b % 8) and

@@ -640,8 +640,8 @@ struct PrepWs {
     n_aa = H * Nt;
     // both degree arrays and the scans' state words: ONE block, one memset (graph_prepare)
     const int64_t deg_ints = (2 * (N + 1) + 1) / 2 * 2;
-    deg = c.take<int32_t>(deg_ints + 2 * int64_t(SCAN_INSTANCES) * SCAN_WORDS); la_deg = deg + (N + 1);
-    scan_st = reinterpret_cast<unsigned long long*>(deg + deg_ints);
+    deg = c.take<int32_t>(deg_ints + 2 * int64_t(SCAN_INSTANCES) * SCAN_WORDS); la_deg = ptr_add(deg, N + 1);
+    scan_st = reinterpret_cast<unsigned long long*>(ptr_add(deg, deg_ints));
     zeroed_bytes = (deg_ints + 2 * int64_t(SCAN_INSTANCES) * SCAN_WORDS) * int64_t(sizeof(int32_t));
     rowptr = c.take<int32_t>(N + 1);
     csr_src = c.take<int32_t>(E + 1); csr_dst = c.take<int32_t>(E + 1);
@@ -667,9 +667,10 @@ struct EdgeWs {
   EdgeWs(const trajsde_batch* b, const trajsde_graph* g, void* ws, int64_t ws_bytes) {
     Carver c(ws, ws_bytes);
     (void)b;
-    aa_geom = c.take<float>(4 * int64_t(g->E_aa) + 4); aa_dst = c.take<int32_t>(g->E_aa + 1); aa_src = c.take<int32_t>(g->E_aa + 1);
-    g_geom = c.take<float>(4 * int64_t(g->E_g) + 4); g_src = c.take<int32_t>(g->E_g + 1); g_dst = c.take<int32_t>(g->E_g + 1);
-    la_geom = c.take<float>(4 * int64_t(g->E_la) + 4); la_dst = c.take<int32_t>(g->E_la + 1); la_lane = c.take<int32_t>(g->E_la + 1);
+    const int64_t Eaa = g->E_aa, Eg = g->E_g, Ela = g->E_la;            // (int64: E + 1 overflows int32 at the bound the ABI admits)
+    aa_geom = c.take<float>(4 * Eaa + 4); aa_dst = c.take<int32_t>(Eaa + 1); aa_src = c.take<int32_t>(Eaa + 1);
+    g_geom = c.take<float>(4 * Eg + 4); g_src = c.take<int32_t>(Eg + 1); g_dst = c.take<int32_t>(Eg + 1);
+    la_geom = c.take<float>(4 * Ela + 4); la_dst = c.take<int32_t>(Ela + 1); la_lane = c.take<int32_t>(Ela + 1);
     total = c.off + 256;
     ok = c.ok;
   }

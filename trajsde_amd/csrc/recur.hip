@@ -199,6 +199,16 @@ __device__ __forceinline__ void slice_mma(f4& acc, const WSlice& w, const Opnd& 
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.q[q][c], x.q[q][c], acc, 0, 0, 0);
 }
+// (the T tiles' chains interleaved, as in the fp16x3 build; per accumulator the order of slice_mma)
+template <int T>
+__device__ __forceinline__ void slice_mma_n(f4 (&acc)[T], const WSlice& w, const Opnd (&x)[T]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.q[q][c], x[t].q[q][c], acc[t], 0, 0, 0);
+}
 #endif
 // full 16x64 activation tile from LDS as B operands / one wave's 16-feature slice to LDS
 __device__ __forceinline__ void lds_read_tile(f4 (&in)[4], const float* tile, const Lane& L) {

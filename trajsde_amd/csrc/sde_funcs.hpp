@@ -84,7 +84,8 @@ __device__ __forceinline__ float diff_eval_x6(const f4 (&y)[4], const float* img
 // Drift and diffusion on the fp16x3 decoder image (layouts.hpp DecSdeL6).  The two first layers are ONE 128x64 product on one
 // split of the state (the heads do the same, decoder.hip head_pair_eval); `tb` = their 128 time-conditioned biases
 // b + s sin t + c cos t, which are constants of an Euler step: computed once per step into LDS (sde_time_bias), not once per tile.
-// Per output the arithmetic and its order are those of drift_eval_x6 / diff_eval_x6: same bits.
+// Per output the products and their order are those of drift_eval_x6 / diff_eval_x6, but NOT the same bits since round 4: the
+// image's layers in front of a tanh / sigmoid are packed times 2 / ln 2 (-1 / ln 2), which moves the activation's last place.
 __device__ __forceinline__ void sde_time_bias(float* tb, const float* img, float sn, float cs, int i /* 0..127 */) {
   using DD = DecSdeL6;
   tb[i] = fmaf(img[DD::WCFG + i], cs, fmaf(img[DD::WSFG + i], sn, img[DD::B0FG + i]));

@@ -93,20 +93,40 @@ class FlatGrads:
     def zero(self) -> None:
         self.flat.zero_()
         self._early = None
+        self._early_taken = False
 
     # ---- the gradient all-reduce in two slices, the first one under the encoder backward ----
     # The stage backward entry points run decoder -> aggregator -> encoder; the decoder's and the aggregator's gradients are final
     # when the encoder backward -- two thirds of the backward's time -- is only being enqueued.  `early_reduce` (called by the path
     # loss between the two, when `early_enabled`) adds those gradients into their block of `flat` and starts that block's
-    # all-reduce on a side stream; `accumulate` later skips what is already in, and `all_reduce_mean` reduces the rest and waits.
-    # Element by element the sums are those of the one-piece collective (the same two-operand additions on two ranks; a ring sums
-    # every element over the ranks in the same order whatever the piece it travels in): bit-equal in the gloo test.
+    # all-reduce on the collective stream; `accumulate` later skips what is already in, and `all_reduce_mean` reduces the rest and
+    # waits.  On two ranks every element is the same two-operand sum whatever piece it travels in (bit-equal in the gloo test);
+    # on larger rings the position of an element inside its piece picks the rank that starts its sum, so the two forms may then
+    # differ in the last place -- like any change of bucket size under torch DDP.
+    #
+    # Protocol, per zero(): at most ONE early_reduce, then ONE accumulate, then all_reduce_mean.  Gradient accumulation over
+    # micro-batches does not fit that (the early block would be reduced before the later micro-batches are in it): a second
+    # early_reduce or a second accumulate before zero() RAISES instead of dropping gradients.  The early block also assumes that
+    # backward() arrives with a unit gradient (driver.train never scales the loss).
     early_enabled = False
     _early = None
+    _early_taken = False
+    # bench.py / tests: issue the collectives with ONE rank too (an RCCL all-reduce over a one-rank communicator is a real launch on
+    # the collective stream), so the stream choreography below is exercised on a one-GPU box
+    force_collective = False
+
+    def _dist(self):
+        """torch.distributed when a collective is due (more than one rank, or `force_collective`), else None"""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collective):
+            return dist
+        return None
 
     def _block_of(self, params, grads):
-        """(ids, lo, hi) of the parameters among `params` that hold a gradient, if they form ONE block of `flat`"""
-        have = {id(p) for p, g in zip(params, grads) if g is not None}
+        """(ids, lo, hi) of the parameters among `params` that hold a gradient AND are in this buffer (frozen parameters and
+        parameters the losses do not reach are not), if they form ONE block of `flat`"""
+        own = {id(p) for p in self.params}
+        have = {id(p) for p, g in zip(params, grads) if g is not None and id(p) in own}
         idx = [i for i, p in enumerate(self.params) if id(p) in have]
         if not idx or idx != list(range(idx[0], idx[-1] + 1)):
             return None
@@ -114,12 +134,22 @@ class FlatGrads:
         hi = self.offsets[idx[-1]] + self.params[idx[-1]].numel()
         return have, lo, hi
 
+    def early_plan(self, names_of_params: dict, prefixes=("decoder.", "aggregator.")) -> bool:
+        """Decided ONCE, from static properties (the parameter list and its names), whether the early slice applies: the
+        parameters under `prefixes` that are in this buffer must form one block of it.  Every rank holds the same model, so
+        every rank decides alike -- the sequence of collectives can not differ between ranks.  `names_of_params`: id -> name."""
+        sub = [p for p in self.params if names_of_params.get(id(p), "").startswith(tuple(prefixes))]
+        return bool(sub) and self._block_of(sub, [True] * len(sub)) is not None
+
     def early_reduce(self, params, grads) -> bool:
         """accumulate the given (final) gradients with scale 1 and start the all-reduce of their block.  The caller guarantees
-        that `backward()` will be called with a unit gradient (driver.train does: it never scales the loss)."""
-        import torch.distributed as dist
+        that `backward()` will be called with a unit gradient (driver.train does: it never scales the loss).  False (nothing
+        done) when the gradients are not one block of the buffer in flat-buffer layout -- a static property of the model."""
+        if self._early is not None:
+            raise RuntimeError("FlatGrads.early_reduce: a block of this buffer was already reduced since zero() -- the early slice "
+                               "serves ONE backward per zero(); switch `early_enabled` off for gradient accumulation over micro-batches")
         blk = self._block_of(params, grads)
-        if blk is None or self._early is not None:
+        if blk is None:
             return False
         ids, lo, hi = blk
         sub_p = [p for p in params if id(p) in ids]
@@ -128,17 +158,19 @@ class FlatGrads:
         if not self._accumulate_runs(sub_p, sub_g, one):
             return False
         work = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist = self._dist()
+        if dist is not None:
             piece = self.flat[lo:hi]
             if self.flat.is_cuda:
                 main = torch.cuda.current_stream(self.flat.device)
-                side = runtime.side_stream(self.flat.device)
-                side.wait_stream(main)                       # the block is complete on the main stream up to here
-                with torch.cuda.stream(side):
+                coll = runtime.collective_stream(self.flat.device)   # its own stream: not queued behind the next batch's prefetch
+                coll.wait_stream(main)                       # the block is complete on the main stream up to here
+                with torch.cuda.stream(coll):
                     work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)
             else:
                 work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)
         self._early = (ids, lo, hi, work)
+        self._early_taken = False
         return True
 
     def accumulate(self, params, grads, scale) -> bool:
@@ -148,8 +180,15 @@ class FlatGrads:
         `flat` that buffer's parameters cover -- six launches a step instead of ~250 slice pairs walked by multi-tensor kernels.
         `params` / `grads`: parallel lists (a gradient may be None); `scale`: 0-dim tensor.  Returns False, having done
         nothing, whenever the layout is not that simple (the caller then accumulates parameter by parameter)."""
-        done = self._early[0] if self._early is not None else ()
-        pairs = [(p, g) for p, g in zip(params, grads) if g is not None and id(p) not in done]
+        own = {id(p) for p in self.params}
+        if self._early is not None:
+            if self._early_taken:
+                raise RuntimeError("FlatGrads.accumulate: second backward since zero() while a block was reduced early -- its "
+                                   "gradients for that block would be dropped; switch `early_enabled` off for gradient accumulation")
+            done = self._early[0]
+        else:
+            done = ()
+        pairs = [(p, g) for p, g in zip(params, grads) if g is not None and id(p) in own and id(p) not in done]
         if len(pairs) + len(done) != len(self.params):
             if self._early is not None:
                 raise RuntimeError("FlatGrads: gradients reduced early do not add up with the rest to the parameter list")
@@ -157,6 +196,8 @@ class FlatGrads:
         ok = self._accumulate_runs([p for p, _ in pairs], [g for _, g in pairs], scale)
         if not ok and self._early is not None:
             raise RuntimeError("FlatGrads: a block was reduced early but the rest of the gradients is not in flat-buffer layout")
+        if ok and self._early is not None:
+            self._early_taken = True
         return ok
 
     def _accumulate_runs(self, params, grads, scale) -> bool:
@@ -188,8 +229,8 @@ class FlatGrads:
         return True
 
     def all_reduce_mean(self) -> None:
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        dist = self._dist()
+        if dist is None:
             self._early = None
             return
         if self._early is None:
@@ -201,9 +242,10 @@ class FlatGrads:
             if hi < self.flat.numel():
                 dist.all_reduce(self.flat[hi:], op=dist.ReduceOp.SUM)
             if work is not None:
-                work.wait()                              # (CUDA: the current stream waits for the side stream's collective)
+                work.wait()                              # (CUDA: the current stream waits for the collective stream's all-reduce)
             self._early = None
-        self.flat.div_(dist.get_world_size())
+        if dist.get_world_size() > 1:
+            self.flat.div_(dist.get_world_size())
 
 
 class FlatTraining:
@@ -352,6 +394,11 @@ class PlainTraining:
         self.optimizer.load_state_dict(sd)
 
 
+def rank_is_zero() -> bool:
+    d = torch.distributed
+    return not (d.is_available() and d.is_initialized()) or d.get_rank() == 0
+
+
 RANK_SEED_STRIDE = 1_000_003          # noise seeds of rank r: base + step + r * stride (distinct streams per rank)
 
 
@@ -404,7 +451,16 @@ def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None, ckpt_p
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
     # two-slice gradient all-reduce, the decoder + aggregator slice under the encoder backward (FlatGrads.early_reduce); this loop
     # never scales the loss, which is what the early slice assumes.  `model.overlap_grad_allreduce = False` keeps the one-piece form
-    flat.grads.early_enabled = dist_on and bool(getattr(model, "overlap_grad_allreduce", True))
+    # Early or one-piece is decided HERE, once, from the parameter list (FlatGrads.early_plan) -- never per step from the gradients --
+    # so every rank issues the same sequence of collectives.
+    flat.grads.early_enabled = (dist_on and bool(getattr(model, "overlap_grad_allreduce", True))
+                                and flat.grads.early_plan({id(p): n for n, p in model.named_parameters()}))
+    if rank_is_zero() and log:
+        form = "multi-tensor (foreach: the bits of the reference's AdamW(model.parameters()))" if getattr(model, "adamw_foreach", False) \
+            else "element-wise over one flat tensor (last-place differences from torch's multi-tensor AdamW; model.adamw_foreach=True restores it)"
+        print(f"[trajsde_amd.driver] AdamW form: {form}; gradient all-reduce: "
+              f"{'two slices, decoder+aggregator early' if flat.grads.early_enabled else ('one piece' if dist_on else 'none (one rank)')}",
+              file=sys.stderr)
     rank = torch.distributed.get_rank() if dist_on else 0
     rank0 = rank == 0
     history = []

@@ -215,6 +215,18 @@ def side_stream(device) -> "torch.cuda.Stream":
     return _PREFETCH_STREAMS[key]
 
 
+_COLLECTIVE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
+
+
+def collective_stream(device) -> "torch.cuda.Stream":
+    """the stream the early slice of the gradient all-reduce runs on (driver.FlatGrads.early_reduce), one per device and NOT the
+    prefetch stream: the collective must neither queue behind the next batch's graph stage nor hold that stage back"""
+    key = str(device)
+    if key not in _COLLECTIVE_STREAMS:
+        _COLLECTIVE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _COLLECTIVE_STREAMS[key]
+
+
 def prefetch_graph(data, radius: float, H: int, noise: "NoiseSpec", fake_agents: bool = True, main_stream=None) -> None:
     """Rotation (MODEL:76-85) and graph stage of a batch the training loop will use NEXT, on the side stream -- call it under
     `torch.cuda.stream(side_stream(dev))`, with the batch's tensors produced on that stream as well (driver.train moves the next
