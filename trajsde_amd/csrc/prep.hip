@@ -37,44 +37,127 @@ __global__ void k_rotate(const float* __restrict__ ang, int N, const float* __re
     }
 }
 
-// ---------------------------------------------------------------------------------------------- CSR by target
+// ---------------------------------------------------------------------------------------------- the graph stage in six launches
+// (round 5; rounds 1-4 issued 22 launches of a few microseconds each: 0.36 ms of a 2.55 ms one-stream forward.)
+//   memset        degree counters, tickets and look-back words
+//   k_prep_first  block ranges: target-degree histograms of the actor and the lane-actor edge lists (integer atomics), extended-node
+//                 table, fake agents' inputs, validity masks + TIME-MAJOR copies of positions / inputs, lane features; the workgroup
+//                 that finishes LAST turns both histograms into row pointers and fills the agents' slots
+//   k_scatter2    counting-sort scatter of both lists
+//   k_row_sort2   canonical (ascending) order of every CSR row of both lists; the keep-flags of the global-interactor edges (AGG:41)
+//                 and of the lane-actor edges (ENC:198) are written as the sorted rows are stored
+//   k_aa_count    the survivor counts of every snapshot node (t, i)
+//   k_scan_multi  the prefix sums over the counts and the two flag arrays as ONE launch of chained scans; the workgroup that finishes
+//                 last derives the segment pointers of the global / lane lists and the list lengths
+//   k_graph_fill  trajsde_graph_compact: block ranges -- the agent-agent snapshot records, the global list, the lane list
+// Every result is bit for bit what the 22-launch form produced (integer work; the geometry expressions are the same).
+
+// "the workgroup that finishes last continues": every workgroup waits until its own writes have been performed, takes a number, and
+// the one that draws the last number reads what the others left.  NO device-wide fence: on this chip an agent-scope release is a
+// write-back of the XCD's whole L2 (measured: 0.96 ms for the 10 K workgroups of the first launch).  Instead, everything a tail reads
+// from other workgroups of its launch is written with agent-scope atomics / write-through stores (store_through) and read with
+// agent-scope loads (coherent_load): those are performed at the device's point of coherence; `s_waitcnt vmcnt(0)` is what tells a wave
+// that its own have been (it is the wait an agent-scope release ends with; a WORKGROUP-scope release fence compiles to no wait at
+// all for global memory in this execution mode, and with it a tail read degree counters that were still on their way).
+// (the numbers are drawn from 16 counters, the 16 draws that complete a counter from a 17th: 1 500 returning atomics on ONE address
+//  are served one after the other)
+constexpr int DONE_WAYS = 16;
+__device__ __forceinline__ bool last_block_done(unsigned int* counters /* DONE_WAYS + 1, zeroed */, unsigned int total) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned way = blockIdx.x % DONE_WAYS;
+    const unsigned quota = total / DONE_WAYS + (way < total % DONE_WAYS ? 1u : 0u);        // blocks b with b % DONE_WAYS == way
+    int last = 0;
+    if (__hip_atomic_fetch_add(&counters[way], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == quota) {
+      unsigned ways_used = total < unsigned(DONE_WAYS) ? total : unsigned(DONE_WAYS);
+      last = __hip_atomic_fetch_add(&counters[DONE_WAYS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == ways_used;
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+// agent-scope (sc1) loads as ordinary buffer loads -- the compiler schedules them and counts their waits, several stay in flight; an
+// atomic load per element serialised the tails (0.15 ms for the 8 K-entry row pointers)
+struct CoherentI32 {
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ explicit CoherentI32(const int32_t* base)
+      : rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(base), 0, 0xFFFFFFFF, 0x00020000)) {}
+  __device__ __forceinline__ int32_t operator[](int i) const { return __builtin_amdgcn_raw_buffer_load_b32(rs, i * 4, 0, 16 /* sc1 */); }
+};
+__device__ __forceinline__ void store_through(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // counting sort on the target id (deterministic counts via integer atomics), then every row is put into canonical
-// order (ascending source / edge id) by an in-LDS bitonic sort, so the result does not depend on atomic arrival
+// order (ascending source / edge id) by a register / in-LDS bitonic sort, so the result does not depend on atomic arrival
 // order -- nor on the order of the input edge list.
-__global__ void k_degree(const int64_t* __restrict__ ei, int E, int32_t* __restrict__ deg) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < E) atomicAdd(&deg[int(ei[int64_t(E) + e])], 1);                 // row 1 = target
+constexpr int EPT = 16;     // edges per thread of the histogram / scatter passes: their index loads and atomics in flight together
+__device__ __forceinline__ void degree_body(int blk, const int64_t* __restrict__ ei, int E, int32_t* __restrict__ deg) {
+  int d[EPT];
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {
+    const int e = (blk * EPT + u) * 256 + int(threadIdx.x);
+    d[u] = e < E ? int(ei[int64_t(E) + e]) : -1;                           // row 1 = target
+  }
+#pragma unroll
+  for (int u = 0; u < EPT; ++u)
+    if (d[u] >= 0) atomicAdd(&deg[d[u]], 1);
 }
 // a row's slots are handed out by counting its degree back down (any order: the rows are sorted afterwards), so no copy of the
 // row pointers is needed as a cursor
-__global__ void k_scatter(const int64_t* __restrict__ ei, int E, const int32_t* __restrict__ rowptr, int32_t* __restrict__ deg,
-                          int32_t* __restrict__ out, int store_edge_id) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const int d = int(ei[int64_t(E) + e]);
-  const int p = rowptr[d] + atomicSub(&deg[d], 1) - 1;
-  out[p] = store_edge_id ? e : int32_t(ei[e]);                             // row 0 = source
+__device__ __forceinline__ void scatter_body(int blk, const int64_t* __restrict__ ei, int E, const int32_t* __restrict__ rowptr,
+                                             int32_t* __restrict__ deg, int32_t* __restrict__ out) {
+  int d[EPT], p[EPT], src[EPT];
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {
+    const int e = (blk * EPT + u) * 256 + int(threadIdx.x);
+    d[u] = e < E ? int(ei[int64_t(E) + e]) : -1;
+    src[u] = e < E ? int32_t(ei[e]) : 0;                                   // row 0 = source
+  }
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) p[u] = d[u] >= 0 ? rowptr[d[u]] + atomicSub(&deg[d[u]], 1) - 1 : -1;
+#pragma unroll
+  for (int u = 0; u < EPT; ++u)
+    if (p[u] >= 0) out[p[u]] = src[u];
 }
 // lane-actor edges: value = (lane id << 32) | edge id, so that rows sort by lane first (canonical under permutations
 // of the input list) and the edge id is still at hand for the vector lookup
-__global__ void k_scatter_lane(const int64_t* __restrict__ lai, int E, const int32_t* __restrict__ rowptr, int32_t* __restrict__ deg,
-                               int64_t* __restrict__ out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const int d = int(lai[int64_t(E) + e]);
-  const int p = rowptr[d] + atomicSub(&deg[d], 1) - 1;
-  out[p] = (lai[e] << 32) | int64_t(e);
+__device__ __forceinline__ void scatter_lane_body(int blk, const int64_t* __restrict__ lai, int E, const int32_t* __restrict__ rowptr,
+                                                  int32_t* __restrict__ deg, int64_t* __restrict__ out) {
+  int d[EPT], p[EPT];
+  int64_t key[EPT];
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {
+    const int e = (blk * EPT + u) * 256 + int(threadIdx.x);
+    d[u] = e < E ? int(lai[int64_t(E) + e]) : -1;
+    key[u] = e < E ? ((lai[e] << 32) | int64_t(e)) : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) p[u] = d[u] >= 0 ? rowptr[d[u]] + atomicSub(&deg[d[u]], 1) - 1 : -1;
+#pragma unroll
+  for (int u = 0; u < EPT; ++u)
+    if (p[u] >= 0) out[p[u]] = key[u];
+}
+__global__ __launch_bounds__(256) void k_scatter2(const int64_t* __restrict__ ei, int E, const int32_t* __restrict__ rowptr, int32_t* __restrict__ deg,
+                                                  int32_t* __restrict__ csr_src, int nb_a, const int64_t* __restrict__ lai, int Ea,
+                                                  const int32_t* __restrict__ la_rowptr, int32_t* __restrict__ la_deg, int64_t* __restrict__ la_pack) {
+  const int blk = blockIdx.x;
+  if (blk < nb_a) scatter_body(blk, ei, E, rowptr, deg, csr_src);
+  else scatter_lane_body(blk - nb_a, lai, Ea, la_rowptr, la_deg, la_pack);
 }
 // ascending sort of the long CSR rows (more than 256 entries; second phase of k_row_sort), one workgroup per row (grid-stride).
 // Rows of up to 4096 entries: bitonic network in LDS on the row padded to a power of two with +inf.  Longer rows: in place in global memory with the "flip" form of the network
 // (first sub-step of stage k pairs i with i ^ (k - 1), the others i with i ^ j), in which EVERY compare-exchange puts the
 // minimum at the lower index -- so the virtual +inf padding above the row's end never moves and a pair whose upper index lies
 // beyond the row is a no-op: correct for any row length without materialising the padding.
-template <typename T>
-__device__ __forceinline__ void sort_long_rows(const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals, T* buf /* LDS, 4096 */,
-                                               int32_t* __restrict__ low_out, int32_t* __restrict__ row_out) {
+// `emit(position, sorted value, row)`: called once for every position as its final value is stored (the keep-flags of the two lists)
+template <typename T, typename EMIT>
+__device__ __forceinline__ void sort_long_rows(int vblk, int vgrid, const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals,
+                                               T* buf /* LDS, 4096 */, int32_t* __restrict__ low_out, int32_t* __restrict__ row_out,
+                                               const EMIT& emit) {
   const T INF = sizeof(T) == 8 ? T(INT64_MAX) : T(INT32_MAX);
-  for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+  for (int row = vblk; row < n_rows; row += vgrid) {
     const int beg = rowptr[row], n = rowptr[row + 1] - beg;
     if (n <= 256) continue;                                 // (sorted by a wave in the first phase)
     if (row_out != nullptr)
@@ -102,6 +185,7 @@ __device__ __forceinline__ void sort_long_rows(const int32_t* __restrict__ rowpt
       for (int i = threadIdx.x; i < n; i += blockDim.x) {
         vals[beg + i] = buf[i];
         if (low_out != nullptr) low_out[beg + i] = int32_t(int64_t(buf[i]) & 0xFFFFFFFFll);
+        emit(beg + i, buf[i], row);
       }
       __syncthreads();
     } else {
@@ -122,8 +206,10 @@ __device__ __forceinline__ void sort_long_rows(const int32_t* __restrict__ rowpt
           __threadfence_block();
           __syncthreads();
         }
-      if (low_out != nullptr)
-        for (int i = threadIdx.x; i < n; i += blockDim.x) low_out[beg + i] = int32_t(int64_t(a[i]) & 0xFFFFFFFFll);
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (low_out != nullptr) low_out[beg + i] = int32_t(int64_t(a[i]) & 0xFFFFFFFFll);
+        emit(beg + i, a[i], row);
+      }
     }
   }
 }
@@ -142,15 +228,15 @@ __device__ __forceinline__ T lane_xor(T v, int mask) {
     return T(__shfl_xor(int(v), mask));
   }
 }
-template <typename T>
-__global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals,
-                                                  int32_t* __restrict__ low_out /* or null: the low words of the sorted values (edge ids of packed lane keys) */,
-                                                  int32_t* __restrict__ row_out /* or null: the row of every position (its target) */) {
-  __shared__ T buf[4096];
+template <typename T, typename EMIT>
+__device__ __forceinline__ void row_sort_part(int vblk, int vgrid, const int32_t* __restrict__ rowptr, int n_rows, T* __restrict__ vals,
+                                              int32_t* __restrict__ low_out /* or null: the low words of the sorted values (edge ids of packed lane keys) */,
+                                              int32_t* __restrict__ row_out /* or null: the row of every position (its target) */,
+                                              T* buf /* LDS, 4096 */, const EMIT& emit) {
   constexpr int EPL = 4, PMAX = 64 * EPL;
   const T INF = sizeof(T) == 8 ? T(INT64_MAX) : T(INT32_MAX);
   const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
-  for (int row = blockIdx.x * waves + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * waves) {
+  for (int row = vblk * waves + (threadIdx.x >> 6); row < n_rows; row += vgrid * waves) {
     const int beg = rowptr[row], n = rowptr[row + 1] - beg;
     if (n > PMAX) continue;
     if (row_out != nullptr) {
@@ -159,7 +245,11 @@ __global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ ro
         if (64 * r + lane < n) row_out[beg + 64 * r + lane] = row;
     }
     if (n <= 1) {
-      if (n == 1 && low_out != nullptr && lane == 0) low_out[beg] = int32_t(int64_t(vals[beg]) & 0xFFFFFFFFll);
+      if (n == 1 && lane == 0) {
+        const T v0 = vals[beg];
+        if (low_out != nullptr) low_out[beg] = int32_t(int64_t(v0) & 0xFFFFFFFFll);
+        emit(beg, v0, row);
+      }
       continue;
     }
     T v[EPL];
@@ -200,16 +290,30 @@ __global__ __launch_bounds__(256) void k_row_sort(const int32_t* __restrict__ ro
       if (EPL * lane + r < n) {
         vals[beg + EPL * lane + r] = v[r];
         if (low_out != nullptr) low_out[beg + EPL * lane + r] = int32_t(int64_t(v[r]) & 0xFFFFFFFFll);
+        emit(beg + EPL * lane + r, v[r], row);
       }
   }
-  sort_long_rows<T>(rowptr, n_rows, vals, buf, low_out, row_out);    // rows of more than 256 entries, a workgroup per row
+  sort_long_rows<T>(vblk, vgrid, rowptr, n_rows, vals, buf, low_out, row_out, emit);    // rows of more than 256 entries, a workgroup per row
 }
 
-// per extended node: original actor, source mask, recurrence iteration to keep; slots of the agent rows
+// per extended node: original actor, source mask, recurrence iteration to keep; slots of the agent rows.  pick_slot of a real actor is
+// the index k of the agent entry that names it (-1: none; the LAST such k should agent_index repeat an actor), found by a scan over
+// agent_index staged through LDS -- no second pass that overrides the table, so no ordering between workgroups is needed
 __device__ __forceinline__ void ext_nodes_body(int i, int N, int A, int H, const int64_t* __restrict__ agent_index,
                                                const int64_t* __restrict__ batch, const int64_t* __restrict__ source,
                                                const uint8_t* __restrict__ bos, int32_t* __restrict__ orig, uint8_t* __restrict__ nus,
                                                int32_t* __restrict__ eos, int32_t* __restrict__ pick_slot) {
+  __shared__ int32_t s_agents[256];
+  int slot = -1;
+  for (int k0 = 0; k0 < A; k0 += 256) {                               // (uniform loop: every thread of the workgroup takes part)
+    __syncthreads();
+    s_agents[threadIdx.x] = k0 + int(threadIdx.x) < A ? int32_t(agent_index[k0 + threadIdx.x]) : -1;
+    __syncthreads();
+    const int m = A - k0 < 256 ? A - k0 : 256;
+    if (i < N)
+      for (int k = 0; k < m; ++k)
+        if (s_agents[k] == i) slot = k0 + k;
+  }
   if (i >= N + A) return;
   const int o = i < N ? i : int(agent_index[i - N]);
   orig[i] = o;
@@ -218,11 +322,7 @@ __device__ __forceinline__ void ext_nodes_body(int i, int N, int A, int H, const
   for (int t = H - 1; t >= 0; --t)
     if (bos[int64_t(o) * H + t]) first = t;
   eos[i] = (H - 1) - first;                                          // ENC:187 (ref_time = H-1)
-  pick_slot[i] = i < N ? -1 : A + (i - N);
-}
-__global__ void k_agent_slots(int A, const int64_t* __restrict__ agent_index, int32_t* __restrict__ pick_slot) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < A) pick_slot[agent_index[k]] = k;
+  pick_slot[i] = i < N ? slot : A + (i - N);
 }
 
 // x_fake[k,t,:] = x[agent_k,t,:] + 2*z   (ENC:94-95)
@@ -246,17 +346,7 @@ __device__ __forceinline__ void fake_x_body(int idx /* one thread per (k, quad o
 
 // ---------------------------------------------------------------------------------------------- 21 snapshots
 // The agent-agent list of snapshot t keeps the in-edge (j -> i) when both ends are valid at t (ENC:108) and closer than the
-// radius (UTIL:88).  Three steps, none of which evaluates a candidate twice or leaves lanes idle on non-survivors:
-//   k_aa_ballots   a wave tests 64 consecutive CSR positions (in-edges of REAL actors) at every t and stores, per t, the 64-bit
-//                  ballot of the survivors -- 8 H bytes per 64 candidates x H.  The rows of the fake agents alias their actors'
-//                  (same positions, same padding), so their candidates are the same bits.
-//   k_aa_count     one thread per snapshot node (t, i): popcounts of its row's stretch of the ballots -> segment lengths; a prefix
-//                  sum (k_scan_chained) turns them into the segment pointers.
-//   k_aa_fill      one wave per extended node: for every t the survivors of the row are handed to the lanes by rank (lane r takes the
-//                  r-th set bit of the row's ballots), so a segment's records are computed and written 64 at a time, contiguously
-//                  -- the pass is as long as the output, not as long as the candidate list.
-// Results are identical to evaluating every (t, in-edge) candidate in row order: same predicate, same order (ascending CSR
-// position = ascending sender), same arithmetic for the geometry.
+// radius (UTIL:88).  The list is ordered (t, target, sender): k_aa_build below.
 // The reference's test is  sqrt(dx^2 + dy^2) < radius  in float32 (UTIL:88).  sqrtf is correctly rounded and monotone, so that is
 // exactly  dx^2 + dy^2 < T  with T the smallest float whose square root reaches the radius (radius2_threshold, host): same
 // survivors for every input, without a 25-instruction IEEE square root per candidate.
@@ -286,169 +376,27 @@ __device__ __forceinline__ void valid_mask_body(int i, int N, int H, int TT, con
   for (int t = 0; t < 32; ++t) m |= uint32_t(t < H && !v[t]) << t;
   vmask[i] = m;
 }
-
-// A wave owns 64 consecutive CSR positions.  Phase 1, lane = (candidate, t) the way the rows lie in memory: the senders' position
-// rows are read coalesced (64 / H rows of 8 H bytes per instruction; one lane per candidate looping over t would make every load
-// a 64-line gather) and parked in wave-private LDS.  Phase 2, lane = candidate: for every t the lane tests its pair (sender row
-// from LDS, target row from the one or two rows the block's candidates share) and the wave's ballot IS the stored word.
-__global__ __launch_bounds__(256) void k_aa_ballots(int E, int H, int TT, const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_dst,
-                                                    const uint32_t* __restrict__ vmask, const float* __restrict__ pos, float thr2,
-                                                    unsigned long long* __restrict__ bal) {
-  extern __shared__ __attribute__((aligned(16))) float2 rows[];                            // [4 waves][64 rows][H | 1]: odd stride, 2-way LDS conflicts at most
-  const int AA_ROW = H | 1;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t blk = xcd_block() * (blockDim.x >> 6) + wv;                               // 64 consecutive CSR positions (xcd_grid launch)
-  if (blk * 64 >= E) return;                                                               // (uniform)
-  const int per = 64 / H, j = lane / H, t = lane - j * H;
-  const float2* pos2 = reinterpret_cast<const float2*>(pos);
-  const int64_t pl = blk * 64 + lane;
-  const bool live = pl < E;
-  const int s_all = live ? csr_src[pl] : 0, o_all = live ? csr_dst[pl] : 0;
-  const uint32_t m = live ? (vmask[s_all] & vmask[o_all]) : 0u;
-  float2* mine_rows = rows + wv * 64 * AA_ROW;
-  for (int q0 = 0; q0 < 64; q0 += 8 * per) {                                               // eight row groups in flight
-    float2 v[8];
+// time-major copies of the history positions and inputs ([H][N] float2): snapshot t of a scene's actors is then 8 N_scene contiguous
+// bytes (k_aa_build stages it in LDS) instead of one 8-byte piece out of every 8 TT-byte row
+__device__ __forceinline__ void time_major_body(int blk, int N, int H, int TT, const float* __restrict__ pos,
+                                                const float* __restrict__ x, float2* __restrict__ pos_t, float2* __restrict__ x_t) {
+  float2 pv[4], xv[4];
+  int ii[4], tt[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int q = q0 + u * per + j;
-      const int su = __shfl(s_all, q & 63);
-      v[u] = pos2[int64_t(su) * TT + t];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int q = q0 + u * per + j;
-      if (j < per && q < 64) mine_rows[q * AA_ROW + t] = v[u];
-    }
+  for (int u = 0; u < 4; ++u) {
+    const int idx = (blk * 4 + u) * 256 + int(threadIdx.x);              // = i * H + t
+    const bool live = idx < N * H;
+    ii[u] = live ? idx / H : -1;
+    tt[u] = live ? idx - ii[u] * H : 0;
+    pv[u] = live ? reinterpret_cast<const float2*>(pos)[int64_t(ii[u]) * TT + tt[u]] : float2{0.f, 0.f};
+    xv[u] = live ? reinterpret_cast<const float2*>(x)[int64_t(ii[u]) * H + tt[u]] : float2{0.f, 0.f};
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  const float2* pd = pos2 + int64_t(o_all) * TT;
-  unsigned long long mine = 0;
-  for (int t0 = 0; t0 < H; t0 += 8) {
-    float2 d[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) d[u] = pd[t0 + u < H ? t0 + u : H - 1];                     // one or two distinct rows per wave: broadcast
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int tt = t0 + u;
-      if (tt >= H) break;                                                                  // (uniform)
-      const float2 q = mine_rows[lane * AA_ROW + tt];
-      const bool ok = ((m >> tt) & 1u) && within_radius2(q.x - d[u].x, q.y - d[u].y, thr2);
-      const unsigned long long B = __ballot(ok);
-      if (lane == tt) mine = B;
+  for (int u = 0; u < 4; ++u)
+    if (ii[u] >= 0) {
+      pos_t[int64_t(tt[u]) * N + ii[u]] = pv[u];
+      x_t[int64_t(tt[u]) * N + ii[u]] = xv[u];
     }
-  }
-  if (lane < H) bal[blk * H + lane] = mine;
-}
-
-// bits [lo, hi) of a 64-bit word
-__device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
-  const unsigned long long upto_hi = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
-  return upto_hi & ~((1ull << lo) - 1ull);
-}
-// the part of ballot block b that belongs to the CSR row [beg, end)
-__device__ __forceinline__ unsigned long long row_part(int b, int beg, int end) {
-  const int lo = beg > 64 * b ? beg - 64 * b : 0, hi = end < 64 * b + 64 ? end - 64 * b : 64;
-  return bit_range(lo, hi);
-}
-
-__global__ void k_aa_count(int Nt, int H, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ orig,
-                           const unsigned long long* __restrict__ bal, int32_t* __restrict__ cnt) {
-  const int64_t id = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;                       // = t * Nt + node
-  if (id >= int64_t(H) * Nt) return;
-  if (id == 0) cnt[int64_t(H) * Nt] = 0;                                                   // the scan's extra element (total at the end)
-  const int t = int(id / Nt), node = int(id - int64_t(t) * Nt), o = orig[node];
-  const int beg = rowptr[o], end = rowptr[o + 1];
-  int c = 0;
-  if (end > beg)
-    for (int b = beg >> 6; b <= (end - 1) >> 6; ++b) c += __popcll(bal[int64_t(b) * H + t] & row_part(b, beg, end));
-  cnt[id] = c;
-}
-
-// index of the r-th (0-based) set bit of w (r < popcount(w))
-__device__ __forceinline__ int nth_set_bit(unsigned long long w, int r) {
-  int posn = 0;
-#pragma unroll
-  for (int width = 32; width >= 1; width >>= 1) {
-    const int c = __popcll((w >> posn) & ((1ull << width) - 1ull));
-    if (r >= c) { r -= c; posn += width; }
-  }
-  return posn;
-}
-
-__global__ __launch_bounds__(256) void k_aa_fill(int N, int Nt, int H, int TT, const int32_t* __restrict__ rowptr,
-                                                 const int32_t* __restrict__ csr_src, const int32_t* __restrict__ orig,
-                                                 const unsigned long long* __restrict__ bal, const int32_t* __restrict__ segptr,
-                                                 const float* __restrict__ pos, const float* __restrict__ x, const float* __restrict__ rot,
-                                                 int32_t* __restrict__ aa_dst, int32_t* __restrict__ aa_src, float* __restrict__ geom) {
-  // one wave per extended node; for every t its survivors are handed out to the lanes by rank (lane r takes the r-th set bit of
-  // the row's ballots), so the records of segment (t, node) are written 64 at a time, contiguously
-  const int lane = threadIdx.x & 63;
-  const int node = __builtin_amdgcn_readfirstlane(int(xcd_block() * (blockDim.x >> 6) + (threadIdx.x >> 6)));   // xcd_grid launch
-  (void)N;
-  if (node >= Nt) return;
-  const int o = orig[node];
-  const int beg = rowptr[o], end = rowptr[o + 1];
-  if (end <= beg) return;
-  const int b0 = beg >> 6, b1 = (end - 1) >> 6;
-  const f4 R = *reinterpret_cast<const f4*>(rot + 4 * o);
-  const float2* pd_row = reinterpret_cast<const float2*>(pos) + int64_t(o) * TT;
-  for (int t = blockIdx.y; t < H; t += gridDim.y) {                        // gridDim.y waves share a node's snapshots: more gathers in flight
-    const int seg = t * Nt + node;
-    const int base = segptr[seg], n = segptr[seg + 1] - base;
-    if (n == 0) continue;                                                  // (uniform)
-    const float2 pd = pd_row[t];
-    for (int c0 = 0; c0 < n; c0 += 64) {
-      const int r = c0 + lane;
-      unsigned long long selw = 0;
-      int selb = b0, rr = 0, cum = 0;
-      for (int b = b0; b <= b1; ++b) {                                     // the row's ballot words are wave-uniform
-        const unsigned long long w = bal[int64_t(b) * H + t] & row_part(b, beg, end);
-        const int c = __popcll(w);
-        if (r >= cum && r < cum + c) { selw = w; selb = b; rr = r - cum; }
-        cum += c;
-        if (cum >= c0 + 64) break;                                         // (uniform) every lane of this chunk is served
-      }
-      if (r < n) {
-        const int sdr = csr_src[64 * selb + nth_set_bit(selw, rr)];        // senders are real actors
-        const float2 ps = reinterpret_cast<const float2*>(pos)[int64_t(sdr) * TT + t];
-        const float dx = ps.x - pd.x, dy = ps.y - pd.y;
-        const float x0 = x[(int64_t(sdr) * H + t) * 2], x1 = x[(int64_t(sdr) * H + t) * 2 + 1];
-        const f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
-        const int64_t k = int64_t(base) + r;
-        *reinterpret_cast<f4*>(geom + 4 * k) = g;
-        aa_dst[k] = seg;
-        if (aa_src != nullptr) aa_src[k] = sdr;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------- global / lane edges
-// global interactor edges: both endpoints valid at the reference step (AGG:41)
-__global__ void k_g_flags(int E, int TT, int tref, const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_dst,
-                          const uint8_t* __restrict__ pad, uint8_t* __restrict__ flags) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p > E) return;
-  uint8_t keep = 0;
-  if (p < E) keep = !pad[int64_t(csr_src[p]) * TT + tref] && !pad[int64_t(csr_dst[p]) * TT + tref];   // csr_dst: written by the row sort
-  flags[p] = keep;
-}
-__global__ void k_g_compact(int E, int TT, int tref, const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_dst,
-                            const float* __restrict__ pos, const float* __restrict__ rot, const float* __restrict__ ang,
-                            const uint8_t* __restrict__ flags, const int32_t* __restrict__ cpos, int32_t* __restrict__ g_src,
-                            int32_t* __restrict__ g_dst, float* __restrict__ geom) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= E || !flags[p]) return;
-  const int s = csr_src[p], i = csr_dst[p], q = cpos[p];
-  const f4 R = *reinterpret_cast<const f4*>(rot + 4 * i);
-  const float dx = pos[(int64_t(s) * TT + tref) * 2] - pos[(int64_t(i) * TT + tref) * 2];
-  const float dy = pos[(int64_t(s) * TT + tref) * 2 + 1] - pos[(int64_t(i) * TT + tref) * 2 + 1];
-  const float th = ang[s] - ang[i];                                                          // AGG:48-50
-  f4 g = {dx * R[0] + dy * R[2], dx * R[1] + dy * R[3], cosf(th), sinf(th)};
-  *reinterpret_cast<f4*>(geom + 4 * int64_t(q)) = g;
-  g_src[q] = s;
-  g_dst[q] = i;
 }
 
 // lane feature (ENC:68-71); torch's negative index wraps when a lane is fully padded
@@ -462,75 +410,121 @@ __device__ __forceinline__ void lane_feat_body(int l, int L, int P, const float*
   feat[2 * l] = lp[(int64_t(l) * P + last) * 2] - lp[int64_t(l) * P * 2];
   feat[2 * l + 1] = lp[(int64_t(l) * P + last) * 2 + 1] - lp[int64_t(l) * P * 2 + 1];
 }
-// The four per-input passes that depend on nothing but the batch -- extended-node table, fake agents' inputs, per-actor validity
-// masks, lane features -- as ONE launch: blocks [0, b1) / [b1, b2) / [b2, b3) / [b3, ..) take one pass each (a 71-kernel forward
-// spends 5 % of its time in launches of a few microseconds).
-struct InputPassArgs {
-  int N, A, H, TT, L, P, b1, b2, b3;
-  const int64_t *agent_index, *batch, *source;
-  const uint8_t *bos, *pad;
-  const float *x, *lane_pos, *lane_pad;
-  int32_t *orig, *eos, *pick_slot;
-  uint8_t* nus;
-  float *x_fake, *lane_feat;
-  uint32_t* vmask;
-  NoiseArg na;
-};
-__global__ __launch_bounds__(256) void k_input_passes(const InputPassArgs a) {
-  const int blk = blockIdx.x;
-  if (blk < a.b1) ext_nodes_body(blk * 256 + threadIdx.x, a.N, a.A, a.H, a.agent_index, a.batch, a.source, a.bos, a.orig, a.nus, a.eos, a.pick_slot);
-  else if (blk < a.b2) fake_x_body((blk - a.b1) * 256 + threadIdx.x, a.A, a.H, a.x, a.agent_index, a.na, a.x_fake);
-  else if (blk < a.b3) valid_mask_body((blk - a.b2) * 256 + threadIdx.x, a.N, a.H, a.TT, a.pad, a.vmask);
-  else lane_feat_body((blk - a.b3) * 256 + threadIdx.x, a.L, a.P, a.lane_pos, a.lane_pad, a.lane_feat);
-}
-__global__ void k_la_flags(int E_al, const int32_t* __restrict__ eid, const float* __restrict__ vec, float radius, uint8_t* __restrict__ flags) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p > E_al) return;
-  uint8_t keep = 0;
-  if (p < E_al) {                                          // (the actor of every position: written by the row sort)
-    const float vx = vec[2 * int64_t(eid[p])], vy = vec[2 * int64_t(eid[p]) + 1];
-    keep = sqrtf(norm2_sq(vx, vy)) < radius;                                                  // ENC:198
-  }
-  flags[p] = keep;
-}
-__global__ void k_la_compact(int E_al, const int32_t* __restrict__ actor, const int32_t* __restrict__ eid,
-                             const int64_t* __restrict__ la_index, const float* __restrict__ vec,
-                             const float* __restrict__ lane_feat, const float* __restrict__ rot,
-                             const uint8_t* __restrict__ flags, const int32_t* __restrict__ cpos, int32_t* __restrict__ la_dst,
-                             int32_t* __restrict__ la_lane, float* __restrict__ geom) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= E_al || !flags[p]) return;
-  const int i = actor[p], e = eid[p], q = cpos[p];
-  const int lane = int(la_index[e]);                                   // row 0 of lane_actor_index
-  const f4 R = *reinterpret_cast<const f4*>(rot + 4 * i);
-  const float fx = lane_feat[2 * lane], fy = lane_feat[2 * lane + 1], vx = vec[2 * int64_t(e)], vy = vec[2 * int64_t(e) + 1];
-  f4 g = {fx * R[0] + fy * R[2], fx * R[1] + fy * R[3], vx * R[0] + vy * R[2], vx * R[1] + vy * R[3]};   // ENC:763-764
-  *reinterpret_cast<f4*>(geom + 4 * int64_t(q)) = g;
-  la_dst[q] = i;
-  if (la_lane != nullptr) la_lane[q] = lane;
-}
-// the last launch of the graph stage: the segment pointers of the global and lane lists (positions of the row starts among the
-// survivors) and the three list lengths
-__global__ void k_collect_counts(int64_t n_aa, int E, int E_al, const int32_t* __restrict__ aa_segptr, const int32_t* __restrict__ cpos_g,
-                                 const int32_t* __restrict__ cpos_la, float radius, int32_t* __restrict__ counts, int N,
-                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ la_rowptr, int32_t* __restrict__ g_segptr,
-                                 int32_t* __restrict__ la_segptr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i <= N) {
-    g_segptr[i] = cpos_g[rowptr[i]];
-    la_segptr[i] = cpos_la[la_rowptr[i]];
-  }
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    counts[0] = 0;
-    reinterpret_cast<float*>(counts)[4] = radius;
-    counts[1] = aa_segptr[n_aa];
-    counts[2] = cpos_g[E];
-    counts[3] = cpos_la[E_al];
+
+// exclusive prefix sums of TWO count arrays of n entries by one workgroup of 256 threads (the row pointers of the two CSRs: n = N + 1),
+// 8 192 entries per round -- 32 consecutive entries per thread, all requested before the first is used; the counts were formed by other
+// workgroups' atomics: read coherently
+__device__ __forceinline__ void block_scan_two(const int32_t* __restrict__ in0, int32_t* __restrict__ out0, const int32_t* __restrict__ in1,
+                                               int32_t* __restrict__ out1, int n) {
+  __shared__ int32_t s_w[2][4];
+  __shared__ int32_t s_carry[2];
+  constexpr int PT = 32;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t < 2) s_carry[t] = 0;
+  __syncthreads();
+  const CoherentI32 c0(in0), c1(in1);
+  for (int base = 0; base < n; base += 256 * PT) {
+    int32_t v[2][PT], sum[2] = {0, 0};
+#pragma unroll
+    for (int c = 0; c < PT; ++c) {
+      const int i = base + PT * t + c;
+      v[0][c] = i < n ? c0[i] : 0;
+      v[1][c] = i < n ? c1[i] : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < PT; ++c) {
+      sum[0] += v[0][c];
+      sum[1] += v[1][c];
+    }
+    int32_t inc[2] = {sum[0], sum[1]};
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int32_t o0 = __shfl_up(inc[0], d), o1 = __shfl_up(inc[1], d);
+      if (lane >= d) { inc[0] += o0; inc[1] += o1; }
+    }
+    if (lane == 63) { s_w[0][wv] = inc[0]; s_w[1][wv] = inc[1]; }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int32_t run = s_carry[a] + inc[a] - sum[a];
+      for (int w = 0; w < wv; ++w) run += s_w[a][w];
+      int32_t* out = a ? out1 : out0;
+#pragma unroll
+      for (int c = 0; c < PT; ++c) {
+        const int i = base + PT * t + c;
+        if (i < n) out[i] = run;
+        run += v[a][c];
+      }
+    }
+    __syncthreads();
+    if (t < 2) s_carry[t] += s_w[t][0] + s_w[t][1] + s_w[t][2] + s_w[t][3];
+    __syncthreads();
   }
 }
 
-// ---- exclusive prefix sums of the graph stage: one launch each, no library.  (Rounds 1-3 called hipcub::DeviceScan: two launches
-// per scan -- init_lookback_scan_state + the scan -- and rocPRIM on the hot path for what are 8 K .. 2 M element scans.)
+// First launch of the graph stage: every per-input pass that depends on nothing but the batch, as block ranges of one launch --
+// [0, b0) actor-edge degrees, [b0, b1) lane-edge degrees, [b1, b2) extended-node table, [b2, b3) fake agents' inputs, [b3, b4) validity
+// masks, [b4, b5) time-major copies, [b5, ..) lane features -- and, by the workgroup that finishes last, both CSR row pointers
+// (exclusive scans of the degree histograms, which are formed by agent-scope atomics: see last_block_done).
+struct FirstPassArgs {
+  int N, A, H, TT, L, P, E, Ea, b0, b1, b2, b3, b4, b5, blocks;
+  const int64_t *edge_index, *lane_actor_index, *agent_index, *batch, *source;
+  const uint8_t *bos, *pad;
+  const float *x, *pos, *lane_pos, *lane_pad;
+  int32_t *deg, *la_deg, *rowptr, *la_rowptr, *orig, *eos, *pick_slot;
+  uint8_t* nus;
+  float *x_fake, *lane_feat;
+  float2 *pos_t, *x_t;
+  uint32_t* vmask;
+  unsigned int* done;
+  NoiseArg na;
+};
+__global__ __launch_bounds__(256) void k_prep_first(const FirstPassArgs a) {
+  const int blk = blockIdx.x, i = threadIdx.x;
+  if (blk < a.b0) degree_body(blk, a.edge_index, a.E, a.deg);
+  else if (blk < a.b1) degree_body(blk - a.b0, a.lane_actor_index, a.Ea, a.la_deg);
+  else if (blk < a.b2) ext_nodes_body((blk - a.b1) * 256 + i, a.N, a.A, a.H, a.agent_index, a.batch, a.source, a.bos, a.orig, a.nus, a.eos, a.pick_slot);
+  else if (blk < a.b3) fake_x_body((blk - a.b2) * 256 + i, a.A, a.H, a.x, a.agent_index, a.na, a.x_fake);
+  else if (blk < a.b4) valid_mask_body((blk - a.b3) * 256 + i, a.N, a.H, a.TT, a.pad, a.vmask);
+  else if (blk < a.b5) time_major_body(blk - a.b4, a.N, a.H, a.TT, a.pos, a.x, a.pos_t, a.x_t);
+  else lane_feat_body((blk - a.b5) * 256 + i, a.L, a.P, a.lane_pos, a.lane_pad, a.lane_feat);
+  if (!last_block_done(a.done, unsigned(a.blocks))) return;
+  block_scan_two(a.deg, a.rowptr, a.la_deg, a.la_rowptr, a.N + 1);
+}
+
+// Canonical order of both CSRs in one launch: blocks [0, nb_a) sort the actor rows (values = senders; also names the target of every
+// position, csr_dst, and writes the keep-flag of the global-interactor edge at that position: both ends valid at the reference step,
+// AGG:41), the rest sort the lane rows (values = lane << 32 | edge id; writes the edge ids, the actor of every position and the
+// keep-flag of the lane-actor edge: |vector| < radius, ENC:198).  flags[E] (the scans' extra element) is zero.
+__global__ __launch_bounds__(256) void k_row_sort2(int N, int nb_a, int nb_l, const int32_t* __restrict__ rowptr, int32_t* __restrict__ csr_src,
+                                                   int32_t* __restrict__ csr_dst, const uint32_t* __restrict__ vmask, int tref, int E,
+                                                   uint8_t* __restrict__ flags_g, const int32_t* __restrict__ la_rowptr,
+                                                   int64_t* __restrict__ la_pack, int32_t* __restrict__ la_eid, int32_t* __restrict__ la_actor,
+                                                   const float* __restrict__ vec, float radius, int Ea, uint8_t* __restrict__ flags_la) {
+  __shared__ int64_t buf[4096];
+  const int blk = blockIdx.x;
+  if (blk == 0 && threadIdx.x == 0) {
+    flags_g[E] = 0;
+    flags_la[Ea] = 0;
+  }
+  if (blk < nb_a) {
+    if (E <= 0) return;
+    auto emit = [&](int p, int32_t sender, int row) { flags_g[p] = uint8_t((vmask[sender] >> tref) & (vmask[row] >> tref) & 1u); };
+    row_sort_part<int32_t>(blk, nb_a, rowptr, N, csr_src, nullptr, csr_dst, reinterpret_cast<int32_t*>(buf), emit);
+  } else {
+    if (Ea <= 0) return;
+    auto emit = [&](int p, int64_t packed, int row) {
+      (void)row;
+      const int64_t e = packed & 0xFFFFFFFFll;
+      flags_la[p] = uint8_t(sqrtf(norm2_sq(vec[2 * e], vec[2 * e + 1])) < radius);                    // ENC:198
+    };
+    row_sort_part<int64_t>(blk - nb_a, nb_l, la_rowptr, N, la_pack, la_eid, la_actor, buf, emit);
+  }
+}
+
+// ---- exclusive prefix sums of the graph stage: one launch for all of them, no library.  (Rounds 1-3 called hipcub::DeviceScan: two
+// launches per scan -- init_lookback_scan_state + the scan -- and rocPRIM on the hot path for what are 8 K .. 2 M element scans; round 4
+// one launch per scan.)
 // "Chained scan with decoupled look-back": a workgroup takes a ticket (so that a workgroup only ever waits for workgroups that have
 // already started), scans its chunk in registers, publishes its sum, then walks back over the published words of its predecessors
 // -- a wave looks at 64 of them at a time -- until it meets one that carries a complete prefix; it then publishes its own.  One
@@ -538,15 +532,56 @@ __global__ void k_collect_counts(int64_t n_aa, int E, int E_al, const int32_t* _
 // zeroed by the memset that already clears the degree counters (PrepWs::zeroed).  Values are counts < 2^31.
 constexpr int SCAN_MAX_BLOCKS = 512;
 constexpr int SCAN_WORDS = SCAN_MAX_BLOCKS + 1;            // per scan instance: the ticket + one word per workgroup
-constexpr int SCAN_INSTANCES = 5;                          // agent-agent segments, global flags, lane flags, the two CSR row pointers
-template <typename IN, int PER>                            // PER elements per thread, PER x 1024 per workgroup
-__global__ __launch_bounds__(1024) void k_scan_chained(const IN* __restrict__ in, int32_t* __restrict__ out, int n,
-                                                       unsigned long long* __restrict__ st) {
+constexpr int SCAN_INSTANCES = 3;                          // agent-agent segments, global flags, lane flags
+// wave 0 of workgroup `b` (in ticket order): publish `total`, return the sum of the totals of workgroups 0 .. b-1
+__device__ __forceinline__ int32_t lookback_prefix(unsigned long long* __restrict__ words, int b, int32_t total, int lane) {
+  if (lane == 0)
+    __hip_atomic_store(&words[b], ((b == 0 ? 2ull : 1ull) << 32) | (unsigned long long)(unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int32_t prefix = 0;
+  if (b > 0) {
+    int j = b - 1;
+    for (long spins = 0;; ++spins) {
+      if (spins > (1L << 28)) __builtin_trap();          // a predecessor never published: fail loudly, never hang
+      const int k = j - lane;
+      const unsigned long long w = k >= 0 ? __hip_atomic_load(&words[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 32);
+      const unsigned flag = unsigned(w >> 32);
+      const unsigned long long done = __ballot(flag == 2u), none = __ballot(flag == 0u);
+      const int upto = done ? __builtin_ctzll(done) : 63;    // the nearest predecessor with a complete prefix ends the walk
+      const unsigned long long need = upto == 63 ? ~0ull : ((1ull << (upto + 1)) - 1);
+      if (none & need) continue;                         // one of the words we need is not there yet: look again
+      int32_t part = lane <= upto ? int32_t(unsigned(w)) : 0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) part += __shfl_xor(part, d);
+      prefix += part;
+      if (done) break;
+      j -= 64;
+    }
+    if (lane == 0)
+      __hip_atomic_store(&words[b], (2ull << 32) | (unsigned long long)(unsigned)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return prefix;
+}
+struct ScanJob {
+  const void* in;          // int32 (u8 == 0) or uint8 (u8 == 1) counts
+  int32_t* out;            // out[i] = sum of in[0 .. i), i < n; in == out is allowed
+  int n, u8, blocks;
+  unsigned long long* st;  // this scan's SCAN_WORDS zeroed words
+};
+struct ScanMultiArgs {
+  ScanJob j[3];
+  int njobs, blocks;
+};
+template <int PER>                                         // PER elements per thread, PER x 1024 per workgroup
+__global__ __launch_bounds__(1024) void k_scan_multi(const ScanMultiArgs a) {
   __shared__ int32_t wsum[16];
   __shared__ int s_bid;
   __shared__ int32_t s_prefix;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  if (t == 0) s_bid = int(__hip_atomic_fetch_add(&st[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  int blk = blockIdx.x, q = 0;
+  while (q + 1 < a.njobs && blk >= a.j[q].blocks) { blk -= a.j[q].blocks; ++q; }
+  const ScanJob& job = a.j[q];
+  const int n = job.n;
+  if (t == 0) s_bid = int(__hip_atomic_fetch_add(&job.st[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   __syncthreads();
   const int b = s_bid;
   const int64_t first = (int64_t(b) * 1024 + t) * PER;
@@ -554,7 +589,7 @@ __global__ __launch_bounds__(1024) void k_scan_chained(const IN* __restrict__ in
   int32_t s = 0;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    v[i] = first + i < n ? int32_t(in[first + i]) : 0;
+    v[i] = first + i < n ? (job.u8 ? int32_t(static_cast<const uint8_t*>(job.in)[first + i]) : static_cast<const int32_t*>(job.in)[first + i]) : 0;
     s += v[i];
   }
   int32_t inc = s;                                          // inclusive scan of the threads' sums inside the wave
@@ -572,52 +607,292 @@ __global__ __launch_bounds__(1024) void k_scan_chained(const IN* __restrict__ in
 #pragma unroll
     for (int d = 1; d < 16; d <<= 1) total += __shfl_xor(total, d);
     total = __shfl(total, 0);
-    unsigned long long* words = st + 1;
-    if (lane == 0)
-      __hip_atomic_store(&words[b], ((b == 0 ? 2ull : 1ull) << 32) | (unsigned long long)(unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int32_t prefix = 0;
-    if (b > 0) {
-      int j = b - 1;
-      for (long spins = 0;; ++spins) {
-        if (spins > (1L << 28)) __builtin_trap();          // a predecessor never published: fail loudly, never hang
-        const int k = j - lane;
-        const unsigned long long w = k >= 0 ? __hip_atomic_load(&words[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 32);
-        const unsigned flag = unsigned(w >> 32);
-        const unsigned long long done = __ballot(flag == 2u), none = __ballot(flag == 0u);
-        const int upto = done ? __builtin_ctzll(done) : 63;    // the nearest predecessor with a complete prefix ends the walk
-        const unsigned long long need = upto == 63 ? ~0ull : ((1ull << (upto + 1)) - 1);
-        if (none & need) continue;                         // one of the words we need is not there yet: look again
-        int32_t part = lane <= upto ? int32_t(unsigned(w)) : 0;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) part += __shfl_xor(part, d);
-        prefix += part;
-        if (done) break;
-        j -= 64;
-      }
-      if (lane == 0)
-        __hip_atomic_store(&words[b], (2ull << 32) | (unsigned long long)(unsigned)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const int32_t prefix = lookback_prefix(job.st + 1, b, total, lane);
     if (lane == 0) s_prefix = prefix;
   }
   __syncthreads();
   int32_t run = s_prefix + wbase + inc - s;                 // exclusive prefix of this thread's first element
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    if (first + i < n) out[first + i] = run;
+    if (first + i < n) job.out[first + i] = run;
     run += v[i];
   }
 }
-// out[i] = sum of in[0 .. i), i < n; `st`: this scan's SCAN_WORDS zeroed words; in == out is allowed
-template <typename IN>
-static int scan_exclusive(const IN* in, int32_t* out, int64_t n, unsigned long long* st, hipStream_t stream) {
-  TS_REQUIRE(n <= int64_t(SCAN_MAX_BLOCKS) * 65536, "graph stage: more than 33 M elements in a prefix sum");
-  const int64_t per = (n + int64_t(SCAN_MAX_BLOCKS) * 1024 - 1) / (int64_t(SCAN_MAX_BLOCKS) * 1024);      // smallest class that needs <= 512 workgroups
-  if (per <= 8) k_scan_chained<IN, 8><<<cdiv(n, 8 * 1024), 1024, 0, stream>>>(in, out, int(n), st);
-  else if (per <= 16) k_scan_chained<IN, 16><<<cdiv(n, 16 * 1024), 1024, 0, stream>>>(in, out, int(n), st);
-  else if (per <= 32) k_scan_chained<IN, 32><<<cdiv(n, 32 * 1024), 1024, 0, stream>>>(in, out, int(n), st);
-  else k_scan_chained<IN, 64><<<cdiv(n, 64 * 1024), 1024, 0, stream>>>(in, out, int(n), st);
-  TS_LAUNCH_CHECK("k_scan_chained");
-  return TRAJSDE_OK;
+// The segment pointers of the global and lane lists (positions of the row starts among the survivors) and the list lengths: read off
+// the finished prefix sums, so in a LATER launch -- k_collect_counts behind the scans when the host wants the lengths (exact graphs),
+// else the first workgroups of k_graph_fill.  (A "last workgroup of the scan launch" tail was built first: it needs every scan output
+// written through to the point of coherence, 2.8 M four-byte transactions, and cost more than this launch.)
+struct CollectArgs {
+  int64_t n_aa;
+  int E, Ea, N;
+  const int32_t *aa_segptr, *cpos_g, *cpos_la, *rowptr, *la_rowptr;
+  int32_t *g_segptr, *la_segptr, *counts;
+  float radius, thr2;
+  int radius_dev;            // the radius is already in counts[4] (left there by k_aa_count): keep it
+};
+__device__ __forceinline__ void collect_body(int i, const CollectArgs& a) {
+  if (i <= a.N) {
+    a.g_segptr[i] = a.cpos_g[a.rowptr[i]];
+    a.la_segptr[i] = a.cpos_la[a.la_rowptr[i]];
+  }
+  if (i == 0) {
+    a.counts[0] = 0;
+    a.counts[1] = a.aa_segptr[a.n_aa];
+    a.counts[2] = a.cpos_g[a.E];
+    a.counts[3] = a.cpos_la[a.Ea];
+    if (!a.radius_dev) reinterpret_cast<float*>(a.counts)[4] = a.radius;
+  }
+}
+__global__ void k_collect_counts(const CollectArgs a) { collect_body(blockIdx.x * blockDim.x + threadIdx.x, a); }
+
+// ---- the agent-agent snapshot lists.  ONE WAVE PER EXTENDED NODE, ALL HISTORY STEPS, twice:
+//   k_aa_count   lane = candidate (the node's CSR row: the in-edges of its actor; the fake agents' rows alias their actors'), 64 x 4
+//                candidates in registers at a time; per step t the candidates' positions come from the TIME-MAJOR copy (the senders of a
+//                row are ascending, mostly consecutive actor ids: one step's positions of 64 candidates are ~512 contiguous bytes) --
+//                seven steps' loads in flight together; survivor test (both ends valid at t, closer than the radius); the wave's ballot
+//                IS the stored word: bal[(row chunk)][t], 8 bytes per 64 candidates and step, and lane t ends up with the count of (t, node).
+//   (k_scan_multi turns the counts into the segment pointers)
+//   fill         (blocks of k_graph_fill) lane = OUTPUT record: per step the r-th survivor of the row is found from the row's ballot
+//                words (prefetched into registers for all steps: one coalesced load), so records are computed and written 64 at a
+//                time, contiguously -- no lane idles on a non-survivor and no store instruction is issued for a handful of lanes.
+// What a wave needs for all steps -- segment starts, the target's own positions, the ballot words -- is fetched once, before the
+// step loop.  Results equal evaluating every (t, in-edge) candidate in row order: same predicate, same order (ascending CSR position =
+// ascending sender), same arithmetic for the geometry.
+// History.  Rounds 2-4: ballots over 64 consecutive CSR positions with 168-byte position-row gathers (76 us) + count (7 us) + fill with
+// one wave per (node, 3 steps) (76 us) at 32 x 256 agents.  Tried this round and dropped, all bit-identical: a workgroup per (step,
+// 16 nodes) with the scene's snapshot staged in LDS -- seven dependent round trips a workgroup (count 54 us, fill 110 us); step groups
+// with the candidates in registers and NaN-poisoned staging so that the test is subtract-square-add-compare (count 47 us, fill
+// 190 us: four sparse store pairs per (row, step), three waves per SIMD behind 33 KB of LDS); and count + decoupled look-back + fill in
+// ONE pass (0.29 ms: a look-back window is 64 workgroups per round trip to the point of coherence, so the prefix advances 64
+// workgroups per ~2 us however many run).
+// Records are (x_j R_i | (pos_j - pos_i) R_i) (ENC:584-585) + the target's snapshot node; order: t, node, ascending sender.
+struct AaArgs {
+  int N, Nt, H;
+  float radius, thr2;                      // radius test: dx^2 + dy^2 < thr2 ...
+  int thr2_dev;                            // ... or read from counts[5] (trajsde_graph_compact does not get the radius)
+  const int32_t *rowptr, *csr_src, *orig;
+  const uint32_t* vmask;
+  const float2 *pos_t, *x_t;
+  const float* rot;
+  int32_t* segptr;
+  int32_t* counts;
+  unsigned long long* bal;                 // [row chunk][H]; the chunks of row o start at (rowptr[o] >> 6) + o
+  int32_t *aa_dst, *aa_src;
+  float* geom;
+};
+// first ballot slot of a row: rows' chunk counts ceil(deg / 64) <= floor(deg / 64) + 1 fit between consecutive starts
+__device__ __forceinline__ int64_t bal_base(int row_start, int o) { return int64_t(row_start >> 6) + o; }
+// index of the r-th (0-based) set bit of w (r < popcount(w))
+__device__ __forceinline__ int nth_set_bit(unsigned long long w, int r) {
+  int posn = 0;
+#pragma unroll
+  for (int width = 32; width >= 1; width >>= 1) {
+    const int c = __popcll((w >> posn) & ((1ull << width) - 1ull));
+    if (r >= c) { r -= c; posn += width; }
+  }
+  return posn;
+}
+constexpr int AA_CG = 4, AA_SG = 7;        // candidates: 64 x AA_CG in registers; steps: AA_SG loads in flight per chunk
+__global__ __launch_bounds__(256) void k_aa_count(const AaArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int N = a.N, Nt = a.Nt, H = a.H;
+  // a wave = (node, group of AA_SG steps); xcd_grid launch: a scene's nodes share an L2
+  const int wid = __builtin_amdgcn_readfirstlane(int(xcd_block() * 4 + (threadIdx.x >> 6)));
+  const int groups = (H + AA_SG - 1) / AA_SG, node = wid / groups, t0 = (wid - node * groups) * AA_SG;
+  if (wid == 0 && lane == 0) {
+    a.segptr[int64_t(H) * Nt] = 0;                                         // the scan's extra element (total at the end)
+    reinterpret_cast<float*>(a.counts)[4] = a.radius;
+    reinterpret_cast<float*>(a.counts)[5] = a.thr2;                        // the threshold the counts are formed with: the fill reads it here
+  }
+  if (node >= Nt) return;
+  const int o = node < N ? node : __builtin_amdgcn_readfirstlane(a.orig[node]);
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[o]), end = __builtin_amdgcn_readfirstlane(a.rowptr[o + 1]);
+  const uint32_t vo = __builtin_amdgcn_readfirstlane(a.vmask[o]);
+  const int chunks = (end - beg + 63) >> 6;
+  const int64_t bbase = bal_base(beg, o);
+  const float thr2 = a.thr2;
+  int mycnt = 0;                                                           // lane t: survivors of (t, node)
+  for (int c0 = 0; c0 < chunks; c0 += AA_CG) {
+    int s[AA_CG];
+    uint32_t m[AA_CG];
+#pragma unroll
+    for (int u = 0; u < AA_CG; ++u) {
+      const int p = beg + 64 * (c0 + u) + lane;
+      s[u] = p < end ? a.csr_src[p] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < AA_CG; ++u) {
+      m[u] = s[u] >= 0 ? (a.vmask[s[u]] & vo) : 0u;                        // steps at which both ends are valid
+      s[u] = s[u] >= 0 ? s[u] : 0;
+    }
+    unsigned long long mine[AA_CG];
+#pragma unroll
+    for (int u = 0; u < AA_CG; ++u) mine[u] = 0ull;
+    {
+      float2 ps[AA_CG][AA_SG], pd[AA_SG];
+#pragma unroll
+      for (int q = 0; q < AA_SG; ++q) {
+        const int t = t0 + q < H ? t0 + q : H - 1;
+        pd[q] = a.pos_t[int64_t(t) * N + o];
+#pragma unroll
+        for (int u = 0; u < AA_CG; ++u) ps[u][q] = a.pos_t[int64_t(t) * N + s[u]];
+      }
+#pragma unroll
+      for (int q = 0; q < AA_SG; ++q) {
+        const int t = t0 + q;
+        if (t >= H) break;                                                 // (uniform)
+#pragma unroll
+        for (int u = 0; u < AA_CG; ++u) {
+          const bool ok = ((m[u] >> t) & 1u) && within_radius2(ps[u][q].x - pd[q].x, ps[u][q].y - pd[q].y, thr2);
+          const unsigned long long B = __ballot(ok);
+          mine[u] = lane == t ? B : mine[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < AA_CG; ++u)
+      if (c0 + u < chunks && lane >= t0 && lane < t0 + AA_SG && lane < H) {
+        if (node < N) a.bal[(bbase + c0 + u) * H + lane] = mine[u];        // (a fake agent's row is its actor's: those words are the actor's)
+        mycnt += __popcll(mine[u]);
+      }
+  }
+  if (lane >= t0 && lane < t0 + AA_SG && lane < H) a.segptr[int64_t(lane) * Nt + node] = mycnt;
+}
+// the records of one extended node (all steps), one wave
+__device__ __forceinline__ void aa_fill_node(const AaArgs& a, int node, int part, int parts, int lane) {
+  const int N = a.N, Nt = a.Nt, H = a.H;
+  const int o = node < N ? node : __builtin_amdgcn_readfirstlane(a.orig[node]);
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[o]), end = __builtin_amdgcn_readfirstlane(a.rowptr[o + 1]);
+  if (end <= beg) return;
+  const int chunks = (end - beg + 63) >> 6;
+  const unsigned long long* __restrict__ words = a.bal + bal_base(beg, o) * H;     // [chunk][H] of this row
+  // per step, lane t: segment start and length, the target's position
+  int base_l = 0, n_l = 0;
+  float2 pd_l = {0.f, 0.f};
+  if (lane < H) {
+    base_l = a.segptr[int64_t(lane) * Nt + node];
+    n_l = a.segptr[int64_t(lane) * Nt + node + 1] - base_l;
+    pd_l = a.pos_t[int64_t(lane) * N + o];
+  }
+  // the row's ballot words for all steps, two per lane (rows of up to 128 / H chunks; longer rows read them as they go)
+  const int nw = chunks * H;
+  const bool in_regs = nw <= 128;
+  unsigned long long w0 = 0ull, w1 = 0ull;
+  if (in_regs) {
+    if (lane < nw) w0 = words[lane];
+    if (64 + lane < nw) w1 = words[64 + lane];
+  }
+  const f4 R = *reinterpret_cast<const f4*>(a.rot + 4 * o);
+  auto word = [&](int c, int t) -> unsigned long long {                    // (uniform arguments, uniform result)
+    if (in_regs) {
+      const int i = c * H + t;
+      const unsigned long long src = i < 64 ? w0 : w1;
+      const unsigned lo_ = __builtin_amdgcn_readlane(unsigned(src), i & 63), hi_ = __builtin_amdgcn_readlane(unsigned(src >> 32), i & 63);
+      return (static_cast<unsigned long long>(hi_) << 32) | lo_;
+    }
+    return words[int64_t(c) * H + t];
+  };
+  for (int t = part; t < H; t += parts) {                                  // `parts` waves share a node's steps: more gathers in flight
+    const int n = __builtin_amdgcn_readlane(n_l, t);
+    if (n == 0) continue;                                                  // (uniform)
+    const int64_t base = __builtin_amdgcn_readlane(base_l, t);
+    const float pdx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pd_l.x), t));
+    const float pdy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pd_l.y), t));
+    const float2* __restrict__ pos_t = a.pos_t + int64_t(t) * N;
+    const float2* __restrict__ x_t = a.x_t + int64_t(t) * N;
+    const int seg = t * Nt + node;
+    for (int r0 = 0; r0 < n; r0 += 64) {
+      const int r = r0 + lane;
+      unsigned long long selw = 0ull;
+      int selc = 0, rr = 0, cum = 0;
+      for (int c = 0; c < chunks; ++c) {                                   // the row's ballot words are wave-uniform
+        const unsigned long long w = word(c, t);
+        const int cc = __popcll(w);
+        if (r >= cum && r < cum + cc) { selw = w; selc = c; rr = r - cum; }
+        cum += cc;
+        if (cum >= r0 + 64) break;                                         // (uniform) every lane of this round is served
+      }
+      if (r < n) {
+        const int sdr = a.csr_src[beg + 64 * selc + nth_set_bit(selw, rr)];     // senders are real actors
+        const float2 ps = pos_t[sdr], xs = x_t[sdr];
+        const float dx = ps.x - pdx, dy = ps.y - pdy;
+        const float x0 = xs.x, x1 = xs.y;
+        const f4 g = {x0 * R[0] + x1 * R[2], x0 * R[1] + x1 * R[3], dx * R[0] + dy * R[2], dx * R[1] + dy * R[3]};   // v @ R_i (ENC:584-585)
+        const int64_t k = base + r;
+        *reinterpret_cast<f4*>(a.geom + 4 * k) = g;
+        a.aa_dst[k] = seg;
+        if (a.aa_src != nullptr) a.aa_src[k] = sdr;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- global / lane edges
+// global interactor edges: both endpoints valid at the reference step (AGG:41); relative pose AGG:42-50
+__device__ __forceinline__ void g_compact_body(int p, int E, int TT, int tref, const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_dst,
+                                               const float* __restrict__ pos, const float* __restrict__ rot, const float* __restrict__ ang,
+                                               const uint8_t* __restrict__ flags, const int32_t* __restrict__ cpos, int32_t* __restrict__ g_src,
+                                               int32_t* __restrict__ g_dst, float* __restrict__ geom) {
+  if (p >= E || !flags[p]) return;
+  const int s = csr_src[p], i = csr_dst[p], q = cpos[p];
+  const f4 R = *reinterpret_cast<const f4*>(rot + 4 * i);
+  const float dx = pos[(int64_t(s) * TT + tref) * 2] - pos[(int64_t(i) * TT + tref) * 2];
+  const float dy = pos[(int64_t(s) * TT + tref) * 2 + 1] - pos[(int64_t(i) * TT + tref) * 2 + 1];
+  const float th = ang[s] - ang[i];                                                          // AGG:48-50
+  f4 g = {dx * R[0] + dy * R[2], dx * R[1] + dy * R[3], cosf(th), sinf(th)};
+  *reinterpret_cast<f4*>(geom + 4 * int64_t(q)) = g;
+  g_src[q] = s;
+  g_dst[q] = i;
+}
+__device__ __forceinline__ void la_compact_body(int p, int E_al, const int32_t* __restrict__ actor, const int32_t* __restrict__ eid,
+                                                const int64_t* __restrict__ la_index, const float* __restrict__ vec,
+                                                const float* __restrict__ lane_feat, const float* __restrict__ rot,
+                                                const uint8_t* __restrict__ flags, const int32_t* __restrict__ cpos, int32_t* __restrict__ la_dst,
+                                                int32_t* __restrict__ la_lane, float* __restrict__ geom) {
+  if (p >= E_al || !flags[p]) return;
+  const int i = actor[p], e = eid[p], q = cpos[p];
+  const int lane = int(la_index[e]);                                   // row 0 of lane_actor_index
+  const f4 R = *reinterpret_cast<const f4*>(rot + 4 * i);
+  const float fx = lane_feat[2 * lane], fy = lane_feat[2 * lane + 1], vx = vec[2 * int64_t(e)], vy = vec[2 * int64_t(e) + 1];
+  f4 g = {fx * R[0] + fy * R[2], fx * R[1] + fy * R[3], vx * R[0] + vy * R[2], vx * R[1] + vy * R[3]};   // ENC:763-764
+  *reinterpret_cast<f4*>(geom + 4 * int64_t(q)) = g;
+  la_dst[q] = i;
+  if (la_lane != nullptr) la_lane[q] = lane;
+}
+// The launch of trajsde_graph_compact: blocks [0, nb_g) the global list, [nb_g, nb_g + nb_l) the lane list, the rest the agent-agent
+// records
+struct FillArgs {
+  AaArgs aa;
+  CollectArgs col;
+  int nb_c;                  // sync-free graphs: the blocks that read the segment pointers / lengths off the prefix sums (else 0)
+  int nb_g, nb_l, nb_a, parts;
+  int E, TT, tref, Ea;
+  const int32_t *csr_src, *csr_dst, *cpos_g, *la_actor, *la_eid, *cpos_la;
+  const float *pos, *rot, *ang, *vec, *lane_feat;
+  const uint8_t *flags_g, *flags_la;
+  const int64_t* la_index;
+  int32_t *g_src, *g_dst, *la_dst, *la_lane;
+  float *g_geom, *la_geom;
+};
+__global__ __launch_bounds__(256) void k_graph_fill(const FillArgs f) {
+  int blk = blockIdx.x;
+  if (blk < f.nb_c) {
+    collect_body(blk * 256 + threadIdx.x, f.col);
+    return;
+  }
+  blk -= f.nb_c;
+  if (blk < f.nb_g) {
+    g_compact_body(blk * 256 + threadIdx.x, f.E, f.TT, f.tref, f.csr_src, f.csr_dst, f.pos, f.rot, f.ang, f.flags_g, f.cpos_g, f.g_src, f.g_dst, f.g_geom);
+  } else if (blk < f.nb_g + f.nb_l) {
+    la_compact_body((blk - f.nb_g) * 256 + threadIdx.x, f.Ea, f.la_actor, f.la_eid, f.la_index, f.vec, f.lane_feat, f.rot, f.flags_la, f.cpos_la,
+                    f.la_dst, f.la_lane, f.la_geom);
+  } else {
+    // (XCD-aware order inside the range: nb_a is a multiple of 8; consecutive nodes -- one scene -- go to one XCD's L2)
+    const int ab = blk - f.nb_g - f.nb_l, logical = (ab & 7) * (f.nb_a >> 3) + (ab >> 3);
+    const int wid = __builtin_amdgcn_readfirstlane(logical * 4 + int(threadIdx.x >> 6));
+    const int node = wid / f.parts, part = wid - node * f.parts;
+    if (node < f.aa.Nt) aa_fill_node(f.aa, node, part, f.parts, threadIdx.x & 63);
+  }
 }
 
 // phase-1 workspace layout, derived from the batch sizes alone (so both phases agree on it)
@@ -628,21 +903,26 @@ struct PrepWs {
   int32_t *aa_segptr, *g_segptr, *la_segptr, *cpos_g, *cpos_la;
   uint8_t *nus, *flags_g, *flags_la;
   uint32_t* vmask;               // per actor: bit t = valid at history step t
-  unsigned long long* bal;       // [ceil(E / 64)][H]: survivors of 64 consecutive CSR positions at step t (k_aa_ballots)
+  float2 *pos_t, *x_t;           // [H][N] time-major copies of positions[:, :H] and x
+  unsigned long long* bal;       // [row chunk][H]: survivors of 64 candidates of a CSR row at step t (k_aa_count)
   float *x_fake, *lane_feat;
-  unsigned long long* scan_st;   // SCAN_INSTANCES x SCAN_WORDS zeroed words (k_scan_chained), directly behind the degree counters
-  int64_t zeroed_bytes, n_aa;
+  unsigned long long* scan_st;   // SCAN_INSTANCES x SCAN_WORDS zeroed words (k_scan_multi), directly behind the degree counters
+  unsigned int* done;            // DONE_WAYS + 1 zeroed "workgroups finished" counters (last_block_done)
+  int64_t zeroed_bytes, n_aa, aa_blocks;
   int64_t total;
   bool ok;
   PrepWs(const trajsde_batch* b, void* ws, int64_t ws_bytes) {
     Carver c(ws, ws_bytes);
     const int64_t N = b->N, A = b->A, E = b->E, Nt = N + A, H = b->H, Ea = b->E_al;
     n_aa = H * Nt;
-    // both degree arrays and the scans' state words: ONE block, one memset (graph_prepare)
+    aa_blocks = xcd_grid((Nt * ((H + 6) / 7) + 3) / 4);                    // k_aa_count: one wave per (extended node, group of AA_SG = 7 steps)
+    // both degree arrays, the scans' and the look-back's state words, the finish counters: ONE block, one memset (graph_prepare)
     const int64_t deg_ints = (2 * (N + 1) + 1) / 2 * 2;
-    deg = c.take<int32_t>(deg_ints + 2 * int64_t(SCAN_INSTANCES) * SCAN_WORDS); la_deg = ptr_add(deg, N + 1);
+    const int64_t st_words = int64_t(SCAN_INSTANCES) * SCAN_WORDS + (DONE_WAYS + 2) / 2 + 1;
+    deg = c.take<int32_t>(deg_ints + 2 * st_words); la_deg = ptr_add(deg, N + 1);
     scan_st = reinterpret_cast<unsigned long long*>(ptr_add(deg, deg_ints));
-    zeroed_bytes = (deg_ints + 2 * int64_t(SCAN_INSTANCES) * SCAN_WORDS) * int64_t(sizeof(int32_t));
+    done = reinterpret_cast<unsigned int*>(ptr_add(scan_st, int64_t(SCAN_INSTANCES) * SCAN_WORDS));
+    zeroed_bytes = (deg_ints + 2 * st_words) * int64_t(sizeof(int32_t));
     rowptr = c.take<int32_t>(N + 1);
     csr_src = c.take<int32_t>(E + 1); csr_dst = c.take<int32_t>(E + 1);
     orig = c.take<int32_t>(Nt); eos = c.take<int32_t>(Nt); pick_slot = c.take<int32_t>(Nt); counts = c.take<int32_t>(8);
@@ -653,7 +933,8 @@ struct PrepWs {
     nus = c.take<uint8_t>(Nt); flags_g = c.take<uint8_t>(E + 1); flags_la = c.take<uint8_t>(Ea + 1);
     x_fake = c.take<float>(A * H * 2 + 4); lane_feat = c.take<float>(int64_t(b->L) * 2 + 4);
     vmask = c.take<uint32_t>(N + 1);
-    bal = c.take<unsigned long long>(((E + 63) / 64 + 1) * H);
+    pos_t = c.take<float2>(H * N + 1); x_t = c.take<float2>(H * N + 1);
+    bal = c.take<unsigned long long>(((E >> 6) + N + 2) * H);
     total = c.off + 256;
     ok = c.ok;
   }
@@ -690,51 +971,21 @@ static int check_batch(const trajsde_batch* b) {
   return TRAJSDE_OK;
 }
 
-// CSR by target: degree histogram -> exclusive scan -> scatter -> canonical row order
-// exclusive prefix sum of up to 32 768 int32 by ONE workgroup (the row pointers of a batch: N + 1 counts) -- one launch of a few
-// microseconds where the device-wide scan is two
-__global__ __launch_bounds__(1024) void k_scan_small(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n) {
-  __shared__ int32_t wsum[16];
-  const int per = (n + 1023) / 1024, t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int beg = t * per, end = beg + per < n ? beg + per : n;
-  int32_t s = 0;
-  for (int i = beg; i < end; ++i) s += in[i];
-  int32_t inc = s;                                          // inclusive scan of the threads' sums inside the wave
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int32_t o = __shfl_up(inc, d);
-    if (lane >= d) inc += o;
-  }
-  if (lane == 63) wsum[wv] = inc;
-  __syncthreads();
-  int32_t base = 0;
-  for (int w = 0; w < wv; ++w) base += wsum[w];
-  int32_t run = base + inc - s;                             // exclusive prefix of this thread's first element
-  for (int i = beg; i < end; ++i) {
-    const int32_t v = in[i];
-    out[i] = run;
-    run += v;
-  }
+static CollectArgs collect_args(const trajsde_batch* b, const PrepWs& w, float radius) {
+  CollectArgs c;
+  c.n_aa = w.n_aa; c.E = b->E; c.Ea = b->E_al; c.N = b->N;
+  c.aa_segptr = w.aa_segptr; c.cpos_g = w.cpos_g; c.cpos_la = w.cpos_la; c.rowptr = w.rowptr; c.la_rowptr = w.la_rowptr;
+  c.g_segptr = w.g_segptr; c.la_segptr = w.la_segptr; c.counts = w.counts; c.radius = radius; c.thr2 = 0.f; c.radius_dev = 0;
+  return c;
 }
-// (deg arrives zeroed)
-// dst_out (or null): the target of every CSR position (the row it lies in), for the passes that walk positions, not rows
-static int build_csr(const int64_t* ei, int E, int N, int32_t* deg, int32_t* rowptr, int32_t* out, int64_t* lane_pack,
-                     unsigned long long* scan_words, hipStream_t st, int32_t* dst_out = nullptr) {
-  if (E > 0) k_degree<<<cdiv(E, 256), 256, 0, st>>>(ei, E, deg);
-  if (N + 1 <= 32768) {
-    k_scan_small<<<1, 1024, 0, st>>>(deg, rowptr, N + 1);
-  } else if (int rc = scan_exclusive(deg, rowptr, int64_t(N) + 1, scan_words, st)) {
-    return rc;
-  }
-  if (E > 0 && lane_pack == nullptr) {
-    k_scatter<<<cdiv(E, 256), 256, 0, st>>>(ei, E, rowptr, deg, out, 0);
-    k_row_sort<int32_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, out, nullptr, dst_out);
-  } else if (E > 0) {
-    k_scatter_lane<<<cdiv(E, 256), 256, 0, st>>>(ei, E, rowptr, deg, lane_pack);
-    k_row_sort<int64_t><<<cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192, 256, 0, st>>>(rowptr, N, lane_pack, out, dst_out);   // also writes the edge ids
-  }
-  TS_LAUNCH_CHECK("build_csr");
-  return TRAJSDE_OK;
+static AaArgs aa_args(const trajsde_batch* b, const PrepWs& w, const float* rot, float radius) {
+  AaArgs a;
+  a.N = b->N; a.Nt = b->N + b->A; a.H = b->H;
+  a.radius = radius; a.thr2 = radius2_threshold(radius); a.thr2_dev = 0;
+  a.rowptr = w.rowptr; a.csr_src = w.csr_src; a.orig = w.orig; a.vmask = w.vmask; a.pos_t = w.pos_t; a.x_t = w.x_t; a.rot = rot;
+  a.segptr = w.aa_segptr; a.counts = w.counts; a.bal = w.bal;
+  a.aa_dst = nullptr; a.aa_src = nullptr; a.geom = nullptr;
+  return a;
 }
 
 }  // namespace tsde
@@ -777,46 +1028,73 @@ static int graph_prepare(const trajsde_batch* b, const float* rot, float radius,
   NoiseArg na{0, nullptr, nullptr};
   if (fake_noise) { na.seed = fake_noise->seed; na.z = fake_noise->z; na.row_ids = fake_noise->row_ids; na.seed_dev = fake_noise->seed_dev; }
 
-  TS_HIP(hipMemsetAsync(w.deg, 0, size_t(w.zeroed_bytes), st));       // actor and lane degree counters, the scans' state words
+  TS_HIP(hipMemsetAsync(w.deg, 0, size_t(w.zeroed_bytes), st));       // degree counters, scan / look-back state words, finish counters
+  const int tref = H - 1;
   {
-    ProfScope ps("build_csr[actors]", st);
-    if (int rc = build_csr(b->edge_index, E, N, w.deg, w.rowptr, w.csr_src, nullptr, w.scan_st + 3 * SCAN_WORDS, st, w.csr_dst)) return rc;
+    ProfScope ps("k_prep_first", st);
+    FirstPassArgs fa;
+    fa.N = N; fa.A = A; fa.H = H; fa.TT = TT; fa.L = b->L; fa.P = b->lane_pts; fa.E = E; fa.Ea = Ea;
+    fa.b0 = cdiv(E, 256 * EPT);
+    fa.b1 = fa.b0 + cdiv(Ea, 256 * EPT);
+    fa.b2 = fa.b1 + cdiv(Nt, 256);
+    fa.b3 = fa.b2 + (A > 0 ? cdiv(A * ((2 * H + 3) / 4), 256) : 0);
+    fa.b4 = fa.b3 + cdiv(N, 256);
+    fa.b5 = fa.b4 + cdiv(int64_t(N) * H, 1024);
+    fa.blocks = fa.b5 + (b->L > 0 ? cdiv(b->L, 256) : 0);
+    fa.edge_index = b->edge_index; fa.lane_actor_index = b->lane_actor_index; fa.agent_index = b->agent_index; fa.batch = b->batch;
+    fa.source = b->source; fa.bos = b->bos_mask; fa.pad = b->padding_mask; fa.x = b->x; fa.pos = b->positions;
+    fa.lane_pos = b->lane_positions; fa.lane_pad = b->lane_paddings;
+    fa.deg = w.deg; fa.la_deg = w.la_deg; fa.rowptr = w.rowptr; fa.la_rowptr = w.la_rowptr; fa.orig = w.orig; fa.eos = w.eos;
+    fa.pick_slot = w.pick_slot; fa.nus = w.nus; fa.x_fake = w.x_fake; fa.lane_feat = w.lane_feat; fa.pos_t = w.pos_t; fa.x_t = w.x_t;
+    fa.vmask = w.vmask; fa.done = w.done + 0; fa.na = na;
+    k_prep_first<<<fa.blocks, 256, 0, st>>>(fa);
+  }
+  if (E > 0 || Ea > 0) {
+    ProfScope ps("k_scatter2", st);
+    const int nb_a = cdiv(E, 256 * EPT);
+    k_scatter2<<<nb_a + cdiv(Ea, 256 * EPT), 256, 0, st>>>(b->edge_index, E, w.rowptr, w.deg, w.csr_src, nb_a, b->lane_actor_index, Ea, w.la_rowptr,
+                                                     w.la_deg, w.la_pack);
   }
   {
-    InputPassArgs ia;
-    ia.N = N; ia.A = A; ia.H = H; ia.TT = TT; ia.L = b->L; ia.P = b->lane_pts;
-    ia.b1 = cdiv(Nt, 256);
-    ia.b2 = ia.b1 + (A > 0 ? cdiv(A * ((2 * H + 3) / 4), 256) : 0);
-    ia.b3 = ia.b2 + (E > 0 ? cdiv(N, 256) : 0);
-    const int blocks = ia.b3 + (b->L > 0 ? cdiv(b->L, 256) : 0);
-    ia.agent_index = b->agent_index; ia.batch = b->batch; ia.source = b->source; ia.bos = b->bos_mask; ia.pad = b->padding_mask;
-    ia.x = b->x; ia.lane_pos = b->lane_positions; ia.lane_pad = b->lane_paddings;
-    ia.orig = w.orig; ia.eos = w.eos; ia.pick_slot = w.pick_slot; ia.nus = w.nus; ia.x_fake = w.x_fake; ia.lane_feat = w.lane_feat;
-    ia.vmask = w.vmask; ia.na = na;
-    k_input_passes<<<blocks, 256, 0, st>>>(ia);
+    ProfScope ps("k_row_sort2", st);
+    const int per_list = cdiv(N, 4) < 8192 ? cdiv(N, 4) : 8192;
+    k_row_sort2<<<2 * per_list, 256, 0, st>>>(N, per_list, per_list, w.rowptr, w.csr_src, w.csr_dst, w.vmask, tref, E, w.flags_g, w.la_rowptr,
+                                              w.la_pack, w.la_eid, w.la_actor, b->lane_actor_vectors, radius, Ea, w.flags_la);
   }
-  if (A > 0) k_agent_slots<<<cdiv(A, 256), 256, 0, st>>>(A, b->agent_index, w.pick_slot);    // after the table: overrides its -1 entries
-  // global interactor edges (also names the target of every CSR position: csr_dst)
-  k_g_flags<<<cdiv(E + 1, 256), 256, 0, st>>>(E, TT, H - 1, w.csr_src, w.csr_dst, b->padding_mask, w.flags_g);
-  // 21 snapshots: survivor ballots -> segment lengths -> prefix sum -> segment pointers
-  if (E > 0) {
-    const int lds_b = 4 * 64 * (H | 1) * int(sizeof(float2));              // (67 KB at H = 32: TS_LAUNCH raises the dynamic-LDS limit)
-    TS_LAUNCH(k_aa_ballots, xcd_grid(cdiv(cdiv(E, 64), 4)), 256, lds_b, st, E, H, TT, w.csr_src, w.csr_dst, w.vmask, b->positions, radius2_threshold(radius),
-              w.bal);
-  }
-  { ProfScope ps("k_aa_count", st);
-  k_aa_count<<<cdiv(int64_t(H) * Nt, 256), 256, 0, st>>>(Nt, H, w.rowptr, w.orig, w.bal, w.aa_segptr); }
-  if (int rc = scan_exclusive(w.aa_segptr, w.aa_segptr, w.n_aa + 1, w.scan_st + 0 * SCAN_WORDS, st)) return rc;
-  if (int rc = scan_exclusive(w.flags_g, w.cpos_g, int64_t(E) + 1, w.scan_st + 1 * SCAN_WORDS, st)) return rc;
-  // lane-actor edges grouped by actor
   {
-    ProfScope ps("build_csr[lanes]", st);
-    if (int rc = build_csr(b->lane_actor_index, Ea, N, w.la_deg, w.la_rowptr, w.la_eid, w.la_pack, w.scan_st + 4 * SCAN_WORDS, st, w.la_actor)) return rc;
+    ProfScope ps("k_aa_count", st);
+    const AaArgs aa = aa_args(b, w, rot, radius);
+    k_aa_count<<<int(w.aa_blocks), 256, 0, st>>>(aa);
   }
-  k_la_flags<<<cdiv(Ea + 1, 256), 256, 0, st>>>(Ea, w.la_eid, b->lane_actor_vectors, radius, w.flags_la);
-  if (int rc = scan_exclusive(w.flags_la, w.cpos_la, int64_t(Ea) + 1, w.scan_st + 2 * SCAN_WORDS, st)) return rc;
-  k_collect_counts<<<cdiv(N + 1, 256), 256, 0, st>>>(w.n_aa, E, Ea, w.aa_segptr, w.cpos_g, w.cpos_la, radius, w.counts, N, w.rowptr, w.la_rowptr,
-                                                     w.g_segptr, w.la_segptr);
+  {
+    ProfScope ps("k_scan_multi", st);
+    ScanMultiArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    int64_t nmax = 0;
+    auto add = [&](const void* in, int32_t* out_, int64_t n, int u8, int inst) {
+      ScanJob& j = sa.j[sa.njobs++];
+      j.in = in; j.out = out_; j.n = int(n); j.u8 = u8; j.st = w.scan_st + int64_t(inst) * SCAN_WORDS;
+      nmax = std::max(nmax, n);
+    };
+    add(w.aa_segptr, w.aa_segptr, w.n_aa + 1, 0, 0);
+    add(w.flags_g, w.cpos_g, int64_t(E) + 1, 1, 1);
+    add(w.flags_la, w.cpos_la, int64_t(Ea) + 1, 1, 2);
+    TS_REQUIRE(nmax <= int64_t(SCAN_MAX_BLOCKS) * 65536, "graph stage: more than 33 M elements in a prefix sum");
+    const int64_t per = (nmax + int64_t(SCAN_MAX_BLOCKS) * 1024 - 1) / (int64_t(SCAN_MAX_BLOCKS) * 1024);      // smallest class that needs <= 512 workgroups
+    const int PER = per <= 8 ? 8 : (per <= 16 ? 16 : (per <= 32 ? 32 : 64));
+    for (int q = 0; q < sa.njobs; ++q) {
+      sa.j[q].blocks = cdiv(sa.j[q].n, PER * 1024);
+      sa.blocks += sa.j[q].blocks;
+    }
+    if (PER == 8) k_scan_multi<8><<<sa.blocks, 1024, 0, st>>>(sa);
+    else if (PER == 16) k_scan_multi<16><<<sa.blocks, 1024, 0, st>>>(sa);
+    else if (PER == 32) k_scan_multi<32><<<sa.blocks, 1024, 0, st>>>(sa);
+    else k_scan_multi<64><<<sa.blocks, 1024, 0, st>>>(sa);
+  }
+  if (sync) {                                           // the host wants the lengths now: read them off the prefix sums
+    ProfScope ps("k_collect_counts", st);
+    k_collect_counts<<<cdiv(N + 1, 256), 256, 0, st>>>(collect_args(b, w, radius));
+  }
   TS_LAUNCH_CHECK("graph_prepare kernels");
   int32_t h[4] = {0, 0, 0, 0};
   if (sync) {
@@ -862,18 +1140,32 @@ int trajsde_graph_compact(const trajsde_batch* b, const float* rot, void* ws, in
   EdgeWs e(b, out, edges_ws, edges_ws_bytes);
   if (!w.ok || !e.ok) return fail(TRAJSDE_ERR_WORKSPACE, "graph_compact: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  const int N = b->N, A = b->A, E = b->E, H = b->H, TT = b->TT, Ea = b->E_al, Nt = N + A;
+  const int E = b->E, H = b->H, TT = b->TT, Ea = b->E_al;
   const bool want_src = g_export_senders.load() != 0;                      // sender ids are for checking the index work only
-  { ProfScope ps("k_aa_fill", st);
-  static const int fill_parts = []() { const char* e = getenv("TRAJSDE_FILL_PARTS"); const int v = e ? atoi(e) : 7; return v >= 1 && v <= 32 ? v : 7; }();   // 94 us at 1, 80 at 3, 79 at 7, 84 at 21 (32 x 256 agents)
-  k_aa_fill<<<dim3(xcd_grid(cdiv(Nt, 4)), fill_parts), 256, 0, st>>>(N, Nt, H, TT, w.rowptr, w.csr_src, w.orig, w.bal, w.aa_segptr, b->positions, b->x, rot, e.aa_dst,
-                                   want_src ? e.aa_src : nullptr, e.aa_geom); }
-  if (E > 0)
-    k_g_compact<<<cdiv(E, 256), 256, 0, st>>>(E, TT, H - 1, w.csr_src, w.csr_dst, b->positions, rot, b->rotate_angles, w.flags_g,
-                                              w.cpos_g, e.g_src, e.g_dst, e.g_geom);
-  if (Ea > 0)
-    k_la_compact<<<cdiv(Ea, 256), 256, 0, st>>>(Ea, w.la_actor, w.la_eid, b->lane_actor_index, b->lane_actor_vectors, w.lane_feat,
-                                                rot, w.flags_la, w.cpos_la, e.la_dst, want_src ? e.la_lane : nullptr, e.la_geom);
+  {
+    ProfScope ps("k_graph_fill", st);
+    FillArgs f;
+    f.aa = aa_args(b, w, rot, 0.f);
+    f.aa.aa_dst = e.aa_dst; f.aa.aa_src = want_src ? e.aa_src : nullptr; f.aa.geom = e.aa_geom;
+    f.nb_g = cdiv(E, 256); f.nb_l = cdiv(Ea, 256);
+    f.E = E; f.TT = TT; f.tref = H - 1; f.Ea = Ea;
+    f.csr_src = w.csr_src; f.csr_dst = w.csr_dst; f.cpos_g = w.cpos_g; f.la_actor = w.la_actor; f.la_eid = w.la_eid; f.cpos_la = w.cpos_la;
+    f.pos = b->positions; f.rot = rot; f.ang = b->rotate_angles; f.vec = b->lane_actor_vectors; f.lane_feat = w.lane_feat;
+    f.flags_g = w.flags_g; f.flags_la = w.flags_la; f.la_index = b->lane_actor_index;
+    f.g_src = e.g_src; f.g_dst = e.g_dst; f.la_dst = e.la_dst; f.la_lane = want_src ? e.la_lane : nullptr;
+    f.g_geom = e.g_geom; f.la_geom = e.la_geom;
+    // sync-free graphs: nobody has read the segment pointers / lengths off the prefix sums yet (the radius those workgroups also
+    // record is the one trajsde_graph_prepare left in the count block for exactly this)
+    f.col = collect_args(b, w, 0.f);
+    f.col.radius_dev = 1;
+    f.nb_c = out->exact ? 0 : cdiv(b->N + 1, 256);
+    const bool aa_work = E > 0 && out->E_aa > 0;
+    static const int fill_parts = []() { const char* e = getenv("TRAJSDE_FILL_PARTS"); const int v = e ? atoi(e) : 3; return v >= 1 && v <= 32 ? v : 3; }();
+    f.parts = fill_parts;
+    f.nb_a = xcd_grid(cdiv(int64_t(b->N + b->A) * f.parts, 4));
+    const int blocks = f.nb_c + f.nb_g + f.nb_l + (aa_work ? f.nb_a : 0);
+    if (blocks > 0) k_graph_fill<<<blocks, 256, 0, st>>>(f);
+  }
   TS_LAUNCH_CHECK("graph_compact kernels");
   out->aa_geom = e.aa_geom; out->aa_dst = e.aa_dst;
   out->aa_src = want_src ? e.aa_src : nullptr; out->la_lane = want_src ? e.la_lane : nullptr;
