@@ -93,6 +93,7 @@ class FlatGrads:
     def zero(self) -> None:
         self.flat.zero_()
         self._early = None
+        self._early_prefixes = None
         self._early_taken = False
 
     # ---- the gradient all-reduce in two slices, the first one under the encoder backward ----
@@ -157,19 +158,9 @@ class FlatGrads:
         one = torch.ones((), device=self.flat.device, dtype=self.flat.dtype)
         if not self._accumulate_runs(sub_p, sub_g, one):
             return False
-        work = None
-        dist = self._dist()
-        if dist is not None:
-            piece = self.flat[lo:hi]
-            if self.flat.is_cuda:
-                main = torch.cuda.current_stream(self.flat.device)
-                coll = runtime.collective_stream(self.flat.device)   # its own stream: not queued behind the next batch's prefetch
-                coll.wait_stream(main)                       # the block is complete on the main stream up to here
-                with torch.cuda.stream(coll):
-                    work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)
-            else:
-                work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)
+        work = self._start_early_collective(lo, hi)
         self._early = (ids, lo, hi, work)
+        self._early_prefixes = None
         self._early_taken = False
         return True
 
@@ -199,6 +190,110 @@ class FlatGrads:
         if ok and self._early is not None:
             self._early_taken = True
         return ok
+
+    # ---- the same two entry points over WHOLE stage buffers ("bundles": (name prefix, runtime.GradBuffers, multiplier)) -------------
+    # A stage's gradients arrive as one flat tensor with a static layout, and the parameters of a stage are one stretch of this
+    # buffer: the gather index of a (stage, layout) pair is derived once, from names alone, and every later step is ONE
+    # index_select + addcmul per stage -- no per-parameter view is ever made, none is walked (0.5 ms of host time a step).
+    # Needs the parameters' names (`names`: id -> dotted name, set by FlatTraining / PlainTraining); False = not applicable.
+    names = None
+
+    def _bundle_plan(self, prefix, gb):
+        """(first offset in `flat`, gather index into gb.flat, ids of the parameters covered) or None if they are not one block"""
+        key = ("bundle", prefix, id(gb.layout))
+        plan = self._gather.get(key)
+        if plan is None:
+            if self.names is None:
+                return None
+            lay = gb.layout
+            idx, pieces, ids = [], [], []
+            for i, p in enumerate(self.params):
+                name = self.names.get(id(p), "")
+                if not name.startswith(prefix):
+                    continue
+                j = lay.index.get(name[len(prefix):])
+                if j is None or lay.sizes[j] != p.numel() or p.grad is not self.views[i]:
+                    return None
+                idx.append(i)
+                pieces.append((lay.offs[j], lay.sizes[j]))
+                ids.append(id(p))
+            if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+                return None
+            gather = torch.cat([torch.arange(o, o + n, dtype=torch.int64) for o, n in pieces]).to(self.flat.device)
+            plan = (self.offsets[idx[0]], gather, frozenset(ids))
+            self._gather[key] = plan
+        return plan
+
+    def _apply_bundle(self, plan, gb, scale) -> None:
+        first, gather, _ = plan
+        self.flat[first:first + gather.numel()].addcmul_(gb.flat.index_select(0, gather), scale)
+
+    def early_reduce_bundles(self, bundles) -> bool:
+        """early_reduce over whole stage buffers (decoder + aggregator); same protocol"""
+        if self._early is not None:
+            raise RuntimeError("FlatGrads.early_reduce: a block of this buffer was already reduced since zero() -- the early slice "
+                               "serves ONE backward per zero(); switch `early_enabled` off for gradient accumulation over micro-batches")
+        if self.flat.dtype != torch.float32:
+            return False
+        plans = [self._bundle_plan(prefix, gb) for prefix, gb, _ in bundles]
+        if not plans or any(pl is None for pl in plans):
+            return False
+        spans = sorted((pl[0], pl[0] + pl[1].numel()) for pl in plans)
+        if any(a[1] != b[0] for a, b in zip(spans, spans[1:])):
+            return False                                     # the stages' blocks are not adjacent: not one slice of the buffer
+        lo, hi = spans[0][0], spans[-1][1]
+        one = torch.ones((), device=self.flat.device, dtype=self.flat.dtype)
+        for pl, (_, gb, mult) in zip(plans, bundles):
+            self._apply_bundle(pl, gb, one if mult == 1.0 else one * mult)
+        self._early = (frozenset().union(*[pl[2] for pl in plans]), lo, hi, self._start_early_collective(lo, hi))
+        self._early_prefixes = tuple(prefix for prefix, _, _ in bundles)
+        self._early_taken = False
+        return True
+
+    def accumulate_bundles(self, bundles, scale) -> bool:
+        """accumulate over whole stage buffers; False (nothing done) when the layout does not allow it"""
+        if self.flat.dtype != torch.float32:
+            return False
+        early = ()
+        if self._early is not None:
+            if self._early_taken:
+                raise RuntimeError("FlatGrads.accumulate: second backward since zero() while a block was reduced early -- its "
+                                   "gradients for that block would be dropped; switch `early_enabled` off for gradient accumulation")
+            early = getattr(self, "_early_prefixes", None)
+            if early is None:
+                return False                                 # the early block went in through the per-parameter route: finish there
+        todo = [(prefix, gb, mult) for prefix, gb, mult in bundles if prefix not in early]
+        plans = [self._bundle_plan(prefix, gb) for prefix, gb, _ in todo]
+        if any(pl is None for pl in plans):
+            if self._early is not None:
+                raise RuntimeError("FlatGrads: a block was reduced early but the rest of the gradients is not in flat-buffer layout")
+            return False
+        covered = sum(len(pl[2]) for pl in plans) + (len(self._early[0]) if self._early is not None else 0)
+        if covered != len(self.params):
+            if self._early is not None:
+                raise RuntimeError("FlatGrads: gradients reduced early do not add up with the rest to the parameter list")
+            return False
+        for pl, (_, gb, mult) in zip(plans, todo):
+            self._apply_bundle(pl, gb, scale if mult == 1.0 else scale * mult)
+        if self._early is not None:
+            self._early_taken = True
+        return True
+
+    def _start_early_collective(self, lo, hi):
+        """the all-reduce of flat[lo:hi] on the collective stream (None: no collective due)"""
+        work = None
+        dist = self._dist()
+        if dist is not None:
+            piece = self.flat[lo:hi]
+            if self.flat.is_cuda:
+                main = torch.cuda.current_stream(self.flat.device)
+                coll = runtime.collective_stream(self.flat.device)   # its own stream: not queued behind the next batch's prefetch
+                coll.wait_stream(main)                       # the block is complete on the main stream up to here
+                with torch.cuda.stream(coll):
+                    work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)
+            else:
+                work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)
+        return work
 
     def _accumulate_runs(self, params, grads, scale) -> bool:
         by_id = {id(p): g for p, g in zip(params, grads) if g is not None}
@@ -272,6 +367,7 @@ class FlatTraining:
         self._all_params = [p for _, p in self._named]       # the order of `AdamW(self.parameters())` (MODEL:205)
         self._index = {id(p): i for i, p in enumerate(self._all_params)}
         self.grads = FlatGrads(params)                       # p.grad: slices of one gradient buffer, in the same order
+        self.grads.names = {id(p): n for n, p in self._named}
         self.flat_param.grad = self.grads.flat
         model._grad_sink = self.grads                        # the path loss hands its gradients over in a few launches (accumulate)
         self._stages = [m for m in model.modules() if hasattr(m, "touch")]
@@ -376,6 +472,7 @@ class PlainTraining:
         (self.optimizer,), (self.scheduler,) = model.configure_optimizers()
         model.optimizer, model.scheduler = self.optimizer, self.scheduler
         self.grads = FlatGrads(model.params_with_gradient())
+        self.grads.names = {id(p): n for n, p in model.named_parameters()}
         model._grad_sink = self.grads
 
     def zero(self) -> None:

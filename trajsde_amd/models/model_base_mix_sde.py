@@ -31,6 +31,24 @@ def resolve_class(file_path: str, module_name: str):
     return getattr(SourceFileLoader(module_name, path).load_module(module_name), module_name)
 
 
+class GradSet:
+    """the three stages' gradient buffers of one training step: (name prefix, runtime.GradBuffers, multiplier) each.  The training
+    loop's sink takes them whole (driver.FlatGrads.accumulate_bundles); `by_name()` spells them out per parameter for everyone else."""
+
+    def __init__(self) -> None:
+        self.bundles = []
+
+    def add(self, prefix: str, grads, mult: float = 1.0) -> None:
+        self.bundles.append((prefix, grads, float(mult)))
+
+    def by_name(self) -> dict:
+        out = {}
+        for prefix, grads, mult in self.bundles:
+            for n, g in grads.items():
+                out[prefix + n] = g if mult == 1.0 else g * mult
+        return out
+
+
 class _PathLoss(torch.autograd.Function):
     """loss = sum_i w_i * loss_i over the configured {L2, DiffBCE} set as ONE autograd node whose inputs are the model
     parameters: forward runs the HIP forward and, right behind it, the three stage backward entry points of the
@@ -41,27 +59,41 @@ class _PathLoss(torch.autograd.Function):
     def forward(ctx, model, data, noise, w_l2, w_diff, *params):
         """`w_l2`: the weight of the regression loss -- L2, or LaplaceNLLLoss when the model is configured with it"""
         with torch.no_grad():
-            loss, by_name = model._loss_and_gradients(data, noise, w_l2, w_diff)
-            ctx.grads = [by_name.get(n) for n in model._param_names]          # None: no path from these losses
+            loss, gs = model._loss_and_gradients(data, noise, w_l2, w_diff)
             ctx.direct = model._direct_accumulation()
-            ctx.params = params if ctx.direct else None
             ctx.sink = getattr(model, "_grad_sink", None) if ctx.direct else None
+            ctx.n_inputs = len(params)
+            ctx.model = model
+            # the training loop's sink takes whole stage buffers: no per-parameter tensor is made for it
+            ctx.gradset = gs if (isinstance(gs, GradSet) and ctx.sink is not None and hasattr(ctx.sink, "accumulate_bundles")) else None
+            ctx.grads = None if ctx.gradset is not None else _PathLoss._spell_out(model, gs)
             return loss
 
     @staticmethod
+    def _spell_out(model, gs):
+        by_name = gs.by_name() if isinstance(gs, GradSet) else gs        # (a plain {name: gradient} dict is accepted too)
+        return [by_name.get(n) for n in model._param_names]               # None: no path from these losses
+
+    @staticmethod
     def backward(ctx, g):
+        nothing = (None,) * (5 + ctx.n_inputs)
+        if ctx.gradset is not None:
+            if ctx.sink.accumulate_bundles(ctx.gradset.bundles, g):
+                return nothing
+            ctx.grads = _PathLoss._spell_out(ctx.model, ctx.gradset)       # (a layout the sink does not take whole)
         have = [x for x in ctx.grads if x is not None]
         if ctx.direct:
             # Leaf accumulation done here in two fused launches instead of one AccumulateGrad node (an add kernel and ~5 us of
             # host time) per parameter: `.grad += g * grad`, or `.grad = ...` where there is none yet -- what autograd's
             # accumulation would have left.  The parameters then receive no gradient THROUGH autograd, so per-parameter
             # hooks (torch DDP's reducer) do not fire: `model.direct_grad_accumulation = False` restores the plain route.
+            params = [p for _, p in ctx.model.named_parameters()]
             sink = ctx.sink                                                  # driver.FlatGrads: all of it in six launches
-            if sink is not None and sink.accumulate(ctx.params, ctx.grads, g):
-                return (None,) * (5 + len(ctx.grads))
+            if sink is not None and sink.accumulate(params, ctx.grads, g):
+                return nothing
             torch._foreach_mul_(have, g)                                     # our own buffers, fresh every step
             dst, src = [], []
-            for p, x in zip(ctx.params, ctx.grads):
+            for p, x in zip(params, ctx.grads):
                 if x is None or not p.requires_grad:
                     continue
                 if p.grad is None:
@@ -71,7 +103,7 @@ class _PathLoss(torch.autograd.Function):
                     src.append(x)
             if dst:
                 torch._foreach_add_(dst, src)
-            return (None,) * (5 + len(ctx.grads))
+            return nothing
         scaled = iter(torch._foreach_mul(have, g))                          # a handful of fused launches, not one per tensor
         return (None, None, None, None, None) + tuple(None if x is None else next(scaled) for x in ctx.grads)
 
@@ -186,6 +218,16 @@ class PredictionModelSDENet(LightningHooks):
         """the HIP forward and, right behind it, the three stage backward entry points of the C-ABI (decoder -> aggregator ->
         encoder): (weighted loss, {parameter name: gradient}).  Sets `last_output` / `last_losses` like the reference's step."""
         enc_rt, agg_rt, dec_rt = self.encoder._rt, self.aggregator._rt, self.decoder._rt
+        for rt in (enc_rt, agg_rt, dec_rt):                   # no parameter changes inside this call: one stamp walk per stage
+            rt.pin_stamp()
+        try:
+            return self._loss_and_gradients_pinned(data, noise, w_l2, w_diff)
+        finally:
+            for rt in (enc_rt, agg_rt, dec_rt):
+                rt.unpin_stamp()
+
+    def _loss_and_gradients_pinned(self, data, noise, w_l2: float, w_diff: float):
+        enc_rt, agg_rt, dec_rt = self.encoder._rt, self.aggregator._rt, self.decoder._rt
         reg = self._regression_loss()
         # one forward per step: the encoder and aggregator run their tape-keeping forward, the backward entry points
         # then walk those tapes instead of recomputing the stage (runtime.*_forward_train)
@@ -200,31 +242,22 @@ class PredictionModelSDENet(LightningHooks):
         agg = agg_rt.aggregator_backward(data, local, d_glob, noise, tape=agg_tape)
         del agg_tape
         # multi-rank training loop (driver.train): the decoder's and aggregator's gradients are final -- their slice of the flat
-        # gradient buffer goes to the all-reduce now, on a side stream, under the encoder backward (driver.FlatGrads.early_reduce)
+        # gradient buffer goes to the all-reduce now, on the collective stream, under the encoder backward (driver.FlatGrads)
+        gs = GradSet()
+        gs.add("decoder.", dec["grads"], w_l2)
+        gs.add("aggregator.", agg["grads"])
         sink = getattr(self, "_grad_sink", None)
-        early = {}
         if sink is not None and getattr(sink, "early_enabled", False) and self._direct_accumulation():
-            for n, g in dec["grads"].items():
-                early["decoder." + n] = g if w_l2 == 1.0 else g * w_l2
-            for n, g in agg["grads"].items():
-                early["aggregator." + n] = g
-            named = dict(self.named_parameters())
-            ps = [named[n] for n in early]
-            if not sink.early_reduce(ps, [early[n] for n in early]):
-                early = {}
+            if not (hasattr(sink, "early_reduce_bundles") and sink.early_reduce_bundles(gs.bundles)):
+                early = gs.by_name()                                         # (a sink without the whole-buffer entry points)
+                named = dict(self.named_parameters())
+                sink.early_reduce([named[n] for n in early], [early[n] for n in early])
         enc = enc_rt.encoder_backward(data, d_local + agg["d_local_embed"], noise, diff_weight=w_diff, tape=enc_tape)
         del enc_tape
-        by_name = dict(early)
-        if not early:
-            for n, g in dec["grads"].items():
-                by_name["decoder." + n] = g if w_l2 == 1.0 else g * w_l2
-            for n, g in agg["grads"].items():
-                by_name["aggregator." + n] = g
-        for n, g in enc["grads"].items():
-            by_name["encoder." + n] = g
+        gs.add("encoder.", enc["grads"])
         self.last_output = out
         self.last_losses = {reg[0]: dec["loss"].detach(), "DiffBCE": enc["diff_loss"].detach() / w_diff if w_diff else None}
-        return (w_l2 * dec["loss"] + enc["diff_loss"]).clone(), by_name
+        return (w_l2 * dec["loss"] + enc["diff_loss"]).clone(), gs
 
     def prefetch_graph(self, data, noise: "runtime.NoiseSpec", main_stream=None) -> None:
         """prepare `data` for the training_step that will follow with the same `noise`: rotation + graph stage on the side stream
@@ -275,7 +308,19 @@ class PredictionModelSDENet(LightningHooks):
         noise = runtime.NoiseSpec.resolve(noise)
         if not hasattr(self, "_param_names"):
             self._param_names = [n for n, _ in self.named_parameters()]
-        params = [p for _, p in self.named_parameters()]
+        direct = self._direct_accumulation()
+        # (named_parameters() walks the ~270 modules of the tree: once per step on the autograd route, not at all on the direct one,
+        #  whose single input is looked up once)
+        one = self.__dict__.get("_one_param")               # (kept out of nn.Module's parameter registry: plain instance dict)
+        if direct and one is not None and one.requires_grad:
+            params = [one]
+        else:
+            params = [p for _, p in self.named_parameters()]
+        if direct:
+            # the gradients do not travel through autograd (`.grad` is written directly): ONE parameter as the node's input is
+            # enough to make the loss differentiable, and 250 fewer inputs are 250 fewer edges for the engine to walk every step
+            params = [p for p in params if p.requires_grad][:1]
+            self.__dict__["_one_param"] = params[0] if params else None
         loss = _PathLoss.apply(self, data, noise, float(weights[reg_name]), float(weights.get("DiffBCE", 0.0)), *params)
         n_rows = int(self.last_output["loc"].size(1))
         for name in self.loss_names:                                          # MODEL:112: one entry per configured loss

@@ -150,8 +150,13 @@ class ParamTree(nn.Module):
         if slots is None:
             slots = [(mod._parameters, leaf) for mod in self.modules() for leaf in mod._parameters]
             self.__dict__["_stamp_slots"] = slots
-        s = self.__dict__.get("_touched", 0)
+        s = 0
         for d, leaf in slots:
             p = d[leaf]
             s = (s * 1000003 + p._version + (p.data_ptr() & 0xFFFF)) & 0xFFFFFFFFFFFF
-        return s
+        self.__dict__["_walk_stamp"] = s                      # versions and addresses alone (runtime.StageRuntime keys its pointer tables by it)
+        return (s * 1000003 + self.__dict__.get("_touched", 0)) & 0xFFFFFFFFFFFF
+
+    def walk_stamp(self) -> int:
+        """the part of the last version_stamp() that does not move on touch(): same value = same tensors at the same addresses"""
+        return self.__dict__.get("_walk_stamp", -1)

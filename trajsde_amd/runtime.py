@@ -1,5 +1,6 @@
 """Host-side runtime of the stage modules: weight packing, workspaces, noise selection and the ctypes
 calls into libtrajsde_hip.so.  PyTorch is used for device memory and streams only."""
+import collections.abc
 import ctypes as C
 import itertools
 import os
@@ -315,6 +316,51 @@ _TABLES_DEV: Dict[tuple, torch.Tensor] = {}          # device copies of the host
 
 
 
+class GradLayout:
+    """names / shapes / offsets of a *_BWD stage's gradient buffers inside their flat tensor -- static per stage"""
+
+    def __init__(self, names, shapes) -> None:
+        self.names, self.shapes = list(names), list(shapes)
+        self.sizes = [int(np.prod(sh)) if len(sh) else 1 for sh in self.shapes]
+        # 16-byte aligned slices: kernels store float4 rows into some of them
+        self.offs, total = [], 0
+        for sz in self.sizes:
+            self.offs.append(total)
+            total += (sz + 3) // 4 * 4
+        self.total = total
+        self.index = {n: i for i, n in enumerate(self.names)}
+        self.byte_offs = np.asarray(self.offs, dtype=np.uint64) * np.uint64(4)
+
+
+class GradBuffers(collections.abc.Mapping):
+    """The zero-initialised gradient buffers of a *_BWD stage: ONE flat tensor (one fill instead of one per parameter), keyed and
+    ordered like the stage's parameter names.  A read-only mapping name -> view; the views are made when they are asked for -- the
+    training loop's sink (driver.FlatGrads.accumulate_bundles) adds the flat tensor into its own in one gather and never asks
+    (creating ~250 views a step was 0.25 ms of host time, and walking them again in the sink as much)."""
+
+    def __init__(self, flat: torch.Tensor, layout: GradLayout) -> None:
+        self.flat, self.layout, self._views = flat, layout, {}
+
+    def __getitem__(self, name: str) -> torch.Tensor:
+        v = self._views.get(name)
+        if v is None:
+            lay = self.layout
+            i = lay.index[name]
+            v = self._views[name] = self.flat[lay.offs[i]:lay.offs[i] + lay.sizes[i]].view(lay.shapes[i])
+        return v
+
+    def __iter__(self):
+        return iter(self.layout.names)
+
+    def __len__(self) -> int:
+        return len(self.layout.names)
+
+    def pointer_array(self):
+        """(ctypes pointer to the void* array the C-ABI takes, keep-alive object): base address + static byte offsets"""
+        ptrs = self.layout.byte_offs + np.uint64(self.flat.data_ptr())
+        return ptrs.ctypes.data_as(C.POINTER(C.c_void_p)), ptrs
+
+
 class StageRuntime:
     """Per-stage glue owned by a stage module (encoder / aggregator / decoder)."""
 
@@ -344,53 +390,75 @@ class StageRuntime:
             self._names[stage_id] = [L.trajsde_param_name(stage_id, i, nl, K).decode() for i in range(n)]
         return self._names[stage_id]
 
-    def _grad_buffers(self, stage_id: int) -> Dict[str, torch.Tensor]:
+    def _first_param(self) -> torch.Tensor:
+        """one parameter of the module (its device is the stage's); looked up through the cached slot, not `next(m.parameters())`
+        -- that generator walks the module tree, 0.1 ms a call and nine calls a training step"""
+        names = self.param_names()
+        return self.module.p(names[0]) if names else next(self.module.parameters())
+
+    def _grad_buffers(self, stage_id: int) -> "GradBuffers":
         """zero-initialised gradient buffers of a *_BWD stage as views of ONE flat tensor (one fill instead of one per
         parameter), keyed and ordered like param_names(stage_id)"""
         m = self.module
         lay = self._grad_layouts.get(stage_id) if hasattr(self, "_grad_layouts") else None
         if lay is None:                                                     # names / shapes / offsets do not change: computed once
             names = self.param_names(stage_id)
-            shapes = [tuple(m.p(n).shape) for n in names]
-            sizes = [int(np.prod(sh)) if len(sh) else 1 for sh in shapes]
-            # 16-byte aligned slices: kernels store float4 rows into some of them
-            offs, total = [], 0
-            for sz in sizes:
-                offs.append(total)
-                total += (sz + 3) // 4 * 4
-            lay = (names, shapes, sizes, offs, total)
+            lay = GradLayout(names, [tuple(m.p(n).shape) for n in names])
             if not hasattr(self, "_grad_layouts"):
                 self._grad_layouts = {}
             self._grad_layouts[stage_id] = lay
-        names, shapes, sizes, offs, total = lay
-        first = next(m.parameters())
-        flat = torch.zeros(total, device=first.device, dtype=torch.float32)
-        return {n: flat[o:o + sz].view(sh) for n, o, sz, sh in zip(names, offs, sizes, shapes)}
+        first = self._first_param()
+        return GradBuffers(torch.zeros(lay.total, device=first.device, dtype=torch.float32), lay)
+
+    # the parameters do not change between the forward and the backward calls of ONE training step: the path loss pins the stamp
+    # for that stretch (pin_stamp / unpin_stamp), so the nine blob() lookups of a step walk the parameter list once per stage
+    _pinned_stamp = None
+
+    def pin_stamp(self) -> None:
+        self._pinned_stamp = None
+        self._pinned_stamp = self._stamp()
+
+    def unpin_stamp(self) -> None:
+        self._pinned_stamp = None
+
+    def _stamp(self):
+        if self._pinned_stamp is not None:
+            return self._pinned_stamp
+        return (self.module.version_stamp(), str(self._first_param().device))
 
     def blob(self, stage_id: Optional[int] = None) -> torch.Tensor:
         """Packed LDS images of this stage's weights (`stage_id`: the forward images by default, or the
         stage's backward images); re-packed whenever a parameter changed."""
         m = self.module
         stage_id = self.stage_id if stage_id is None else stage_id
-        first = next(m.parameters())
+        first = self._first_param()
         _require_gpu(first, f"{self.stage} parameters")
-        stamp = (m.version_stamp(), str(first.device))
+        stamp = self._stamp()
         cached = self._blobs.get(stage_id)
         if cached is None or stamp != cached[1]:
             L = _lib.lib()
             nl, K = self._dims()
-            names = self.param_names(stage_id)
-            tensors = []
-            for n in names:
-                p = m.p(n)
-                if p.dtype != torch.float32 or not p.is_contiguous() or p.device != first.device:
-                    raise _lib.TrajsdeError(f"parameter {self.stage}.{n} must be contiguous fp32 on {first.device}")
-                tensors.append(p)
-            n_floats = L.trajsde_blob_floats(stage_id, nl, K)
+            # the table of parameter addresses is rebuilt (and the tensors re-checked) only when a tensor was replaced or moved:
+            # an optimizer step through the flat alias (touch()) re-packs from the same addresses
+            walk = m.walk_stamp() if hasattr(m, "walk_stamp") else None
+            tab = self._ptr_tables.get(stage_id) if hasattr(self, "_ptr_tables") else None
+            if tab is None or walk is None or tab[0] != (walk, str(first.device)):
+                names = self.param_names(stage_id)
+                tensors = []
+                for n in names:
+                    p = m.p(n)
+                    if p.dtype != torch.float32 or not p.is_contiguous() or p.device != first.device:
+                        raise _lib.TrajsdeError(f"parameter {self.stage}.{n} must be contiguous fp32 on {first.device}")
+                    tensors.append(p)
+                arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+                tab = ((walk, str(first.device)), arr, len(tensors), int(L.trajsde_blob_floats(stage_id, nl, K)))
+                if not hasattr(self, "_ptr_tables"):
+                    self._ptr_tables = {}
+                self._ptr_tables[stage_id] = tab
+            _, arr, n_tensors, n_floats = tab
             blob = torch.empty(n_floats, device=first.device, dtype=torch.float32)
-            arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
             with torch.cuda.device(first.device):
-                _lib.check(L.trajsde_pack_weights(stage_id, nl, K, arr, len(tensors), blob.data_ptr(), n_floats, _stream()),
+                _lib.check(L.trajsde_pack_weights(stage_id, nl, K, arr, n_tensors, blob.data_ptr(), n_floats, _stream()),
                            "trajsde_pack_weights")
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
@@ -474,7 +542,7 @@ class StageRuntime:
         stage = _lib.STAGE_DECODER_BWD if nll_eps is None else _lib.STAGE_DECODER_NLL_BWD
         names = self.param_names(stage)
         grads = self._grad_buffers(stage)
-        arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
+        arr, _keep = grads.pointer_array()
         loss = torch.empty(1, device=dev, dtype=torch.float32)
         best = torch.empty(N, device=dev, dtype=torch.int32)
         d_local = torch.empty(N, D, device=dev, dtype=torch.float32)
@@ -588,7 +656,7 @@ class StageRuntime:
             tab_dev = _TABLES_DEV[(id(tab), str(dev))] = torch.from_numpy(tab).to(dev)
         names = self.param_names(_lib.STAGE_ENCODER_BWD)
         grads = self._grad_buffers(_lib.STAGE_ENCODER_BWD)
-        arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
+        arr, _keep = grads.pointer_array()
         loss = torch.empty(1, device=dev, dtype=torch.float32)
         d_lat = torch.empty(N, D, device=dev, dtype=torch.float32) if want_boundaries else None
         d_aa = torch.empty(H, Nt, D, device=dev, dtype=torch.float32) if want_boundaries else None
@@ -765,7 +833,7 @@ class StageRuntime:
             raise _lib.TrajsdeError(f"d_local must be [{N},{D}]")
         names = self.param_names(_lib.STAGE_ENCODER_GRID_BWD)
         grads = self._grad_buffers(_lib.STAGE_ENCODER_GRID_BWD)
-        arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
+        arr, _keep = grads.pointer_array()
         ws_bytes = L.trajsde_encoder_grid_backward_ws_bytes(C.byref(gc.batch), C.byref(gc.graph), nl)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         with torch.cuda.device(dev):
@@ -832,7 +900,7 @@ class StageRuntime:
             raise _lib.TrajsdeError(f"d_global must be [{K},{N},{D}]")
         names = self.param_names(_lib.STAGE_AGGREGATOR_BWD)
         grads = self._grad_buffers(_lib.STAGE_AGGREGATOR_BWD)
-        arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
+        arr, _keep = grads.pointer_array()
         d_local = torch.empty(N, D, device=dev, dtype=torch.float32)
         if tape is not None:
             ws, ws_bytes = tape
@@ -865,7 +933,7 @@ class StageRuntime:
         L = _lib.lib()
         names = self.param_names(_lib.STAGE_DECODER_MLP_BWD)
         grads = self._grad_buffers(_lib.STAGE_DECODER_MLP_BWD)
-        arr = (C.c_void_p * len(names))(*[grads[n].data_ptr() for n in names])
+        arr, _keep = grads.pointer_array()
         loss = torch.empty(1, device=dev, dtype=torch.float32)
         best = torch.empty(N, device=dev, dtype=torch.int32)
         d_local = torch.empty(N, D, device=dev, dtype=torch.float32)
