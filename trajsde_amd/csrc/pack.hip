@@ -3,6 +3,7 @@
 // yields the ordered parameter names (trajsde_param_name), run "wet" it launches the pack kernels.
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1189,35 +1190,111 @@ int64_t trajsde_blob_floats(int stage, int num_layers, int num_modes) {
   return fail(TRAJSDE_ERR_INVALID, "unknown stage");
 }
 
+}  // extern "C"
+namespace {
+struct PackLaunch {
+  PackJobs tab;
+  int n, max_count;
+};
+struct PackPlan {
+  int stage, nl, K;
+  int64_t need_floats;
+  std::vector<const float*> params;
+  std::vector<PackLaunch> tables;          // built against a stand-in blob address (pack_standin_blob): re-based per call
+  int standin = 0;                         // which stand-in range (one that holds none of the parameters)
+};
+// an address range no allocation lives in (2^44 .. 2^44 + blob size): the recipe's `blob + offset` arithmetic stays ordinary pointer
+// arithmetic on a non-null base, and what points into the blob is recognisable afterwards
+float* pack_standin_blob(int slot = 0) { return reinterpret_cast<float*>(uintptr_t(1) << (44 - slot)); }
+// the launch tables of one stage's packing: the recipe run against `params`, destinations relative to a null blob
+void build_pack_tables(int stage, int num_layers, int num_modes, const std::vector<std::string>& names, const float* const* params,
+                       std::vector<PackLaunch>& out, int standin) {
+  Packer wet{false};
+  wet.names = names;
+  wet.params = params;
+  wet.blob = pack_standin_blob(standin);
+  wet.stream = nullptr;
+  run_recipe(wet, stage, num_layers, num_modes);
+  for (int pass = 0; pass < 2; ++pass) {
+    PackLaunch cur;
+    cur.n = cur.max_count = 0;
+    for (const PackJob& j : wet.jobs) {
+      if (j.pass != pass) continue;
+      cur.tab.j[cur.n++] = j;
+      cur.max_count = j.count > cur.max_count ? j.count : cur.max_count;
+      if (cur.n == PACK_JOBS_PER_LAUNCH) {
+        out.push_back(cur);
+        cur.n = cur.max_count = 0;
+      }
+    }
+    if (cur.n) out.push_back(cur);
+  }
+}
+}  // namespace
+extern "C" {
+
 int trajsde_pack_weights(int stage, int num_layers, int num_modes, const float* const* params, int n_params,
                          float* blob, int64_t blob_floats, void* stream) {
   TS_REQUIRE(params && blob, "pack_weights: null pointer");
-  Packer dry{true};
-  if (!run_recipe(dry, stage, num_layers, num_modes)) return fail(TRAJSDE_ERR_INVALID, "unknown stage");
-  TS_REQUIRE(n_params == int(dry.names.size()), "pack_weights: parameter count does not match trajsde_param_count");
-  TS_REQUIRE(blob_floats >= trajsde_blob_floats(stage, num_layers, num_modes), "pack_weights: blob too small");
-  for (int i = 0; i < n_params; ++i) TS_REQUIRE(params[i] != nullptr, "pack_weights: null parameter " + dry.names[i]);
-  TS_HIP(hipMemsetAsync(blob, 0, size_t(blob_floats) * sizeof(float), static_cast<hipStream_t>(stream)));
-  Packer wet{false};
-  wet.names = dry.names;
-  wet.params = params;
-  wet.blob = blob;
-  wet.stream = static_cast<hipStream_t>(stream);
-  run_recipe(wet, stage, num_layers, num_modes);
-  for (int pass = 0; pass < 2; ++pass) {
-    PackJobs tab;
-    int n = 0, max_count = 0;
-    auto launch = [&] {
-      if (n) k_pack_jobs<<<dim3(cdiv(max_count, 256), n), 256, 0, wet.stream>>>(tab);
-      n = max_count = 0;
-    };
-    for (const PackJob& j : wet.jobs) {
-      if (j.pass != pass) continue;
-      tab.j[n++] = j;
-      max_count = j.count > max_count ? j.count : max_count;
-      if (n == PACK_JOBS_PER_LAUNCH) launch();
+  TS_REQUIRE(n_params >= 0 && n_params < (1 << 20), "pack_weights: bad parameter count");
+  // A training loop re-packs six blobs after every optimizer step from the SAME parameter addresses: the launch tables of a
+  // (stage, sizes, parameter addresses) triple are built once -- two runs of the recipe, whose name lookups are a linear search over
+  // ~130 strings each, were ~0.1 ms of host time a call -- and re-used with the destination re-based onto this call's blob.
+  static std::mutex mu;
+  static std::vector<PackPlan> plans;
+  PackPlan plan_copy;
+  bool hit = false;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const PackPlan& pl : plans)
+      if (pl.stage == stage && pl.nl == num_layers && pl.K == num_modes && int(pl.params.size()) == n_params &&
+          std::equal(pl.params.begin(), pl.params.end(), params)) {
+        plan_copy = pl;
+        hit = true;
+        break;
+      }
+  }
+  if (!hit) {
+    Packer dry{true};
+    if (!run_recipe(dry, stage, num_layers, num_modes)) return fail(TRAJSDE_ERR_INVALID, "unknown stage");
+    TS_REQUIRE(n_params == int(dry.names.size()), "pack_weights: parameter count does not match trajsde_param_count");
+    for (int i = 0; i < n_params; ++i) TS_REQUIRE(params[i] != nullptr, "pack_weights: null parameter " + dry.names[i]);
+    plan_copy.stage = stage; plan_copy.nl = num_layers; plan_copy.K = num_modes;
+    plan_copy.params.assign(params, params + n_params);
+    plan_copy.need_floats = trajsde_blob_floats(stage, num_layers, num_modes);
+    for (int slot = 0; slot < 8; ++slot) {                // a stand-in range that no parameter lives in
+      const uintptr_t lo = reinterpret_cast<uintptr_t>(pack_standin_blob(slot)), hi = lo + uintptr_t(plan_copy.need_floats) * sizeof(float);
+      bool clash = false;
+      for (int i = 0; i < n_params; ++i) {
+        const uintptr_t u = reinterpret_cast<uintptr_t>(params[i]);
+        clash = clash || (u + (uintptr_t(1) << 32) >= lo && u < hi);
+      }
+      plan_copy.standin = slot;
+      if (!clash) break;
     }
-    launch();
+    build_pack_tables(stage, num_layers, num_modes, dry.names, params, plan_copy.tables, plan_copy.standin);
+    std::lock_guard<std::mutex> lk(mu);
+    if (plans.size() >= 64) plans.clear();
+    plans.push_back(plan_copy);
+  }
+  TS_REQUIRE(blob_floats >= plan_copy.need_floats, "pack_weights: blob too small");
+  TS_HIP(hipMemsetAsync(blob, 0, size_t(blob_floats) * sizeof(float), static_cast<hipStream_t>(stream)));
+  // every address inside the stand-in blob -- destinations, and the sources of second-pass jobs that read first-pass results --
+  // moves onto this call's blob
+  const uintptr_t F = reinterpret_cast<uintptr_t>(pack_standin_blob(plan_copy.standin)), Fend = F + uintptr_t(plan_copy.need_floats) * sizeof(float);
+  auto rebase = [&](const float* q) -> const float* {
+    const uintptr_t u = reinterpret_cast<uintptr_t>(q);
+    return (u >= F && u < Fend) ? blob + (u - F) / sizeof(float) : q;
+  };
+  for (PackLaunch& t : plan_copy.tables) {
+    for (int q = 0; q < t.n; ++q) {
+      PackJob& j = t.tab.j[q];
+      j.dst = const_cast<float*>(rebase(j.dst));
+      j.src = rebase(j.src);
+      j.src2 = rebase(j.src2);
+      j.src3 = rebase(j.src3);
+    }
+    k_pack_jobs<<<dim3(cdiv(t.max_count, 256), t.n), 256, 0, static_cast<hipStream_t>(stream)>>>(t.tab);
   }
   TS_LAUNCH_CHECK("pack");
   return TRAJSDE_OK;
