@@ -246,7 +246,13 @@ def prefetch_graph(data, radius: float, H: int, noise: "NoiseSpec", fake_agents:
         data.y = y_rot
     data["rotate_mat"] = rot
     data[ROTATED_KEY] = True
-    gc = GraphContext.get(data, radius, H, noise, fake_agents=fake_agents, exact=True)
+    # The list lengths (the step's one host read-back) are NOT waited for here: the graph is built in its sync-free form -- lengths on
+    # the device, lists sized by their bounds -- and made exact at the top of the step that uses it, by a read issued on THIS stream
+    # (GraphContext.make_exact honours `count_stream`), which by then has long drained.  Waiting here cost the loop 0.3-0.7 ms a
+    # step: the side stream's few kernels share the chip with the step that was just enqueued.  Lists past SYNC_FREE_MAX_BYTES take
+    # the synchronising form as ever.
+    gc = GraphContext.get(data, radius, H, noise, fake_agents=fake_agents, exact=not sync_free())
+    gc.count_stream = side
     done = torch.cuda.Event()
     done.record(side)
     main.wait_event(done)
@@ -1038,7 +1044,12 @@ class GraphContext:
         g = self.graph
         if g.exact:
             return {"E_aa": g.E_aa, "E_g": g.E_g, "E_la": g.E_la}
-        c = self._i32(self.ws, g.counts, 4).tolist()
+        st = getattr(self, "count_stream", None)
+        if st is not None:                    # built on a side stream (prefetch_graph): read there -- a read on the current stream
+            with torch.cuda.stream(st):       # would wait for everything queued on it, i.e. for the whole previous training step
+                c = self._i32(self.ws, g.counts, 4).tolist()
+        else:
+            c = self._i32(self.ws, g.counts, 4).tolist()
         return {"E_aa": c[1], "E_g": c[2], "E_la": c[3]}
 
     def make_exact(self) -> "GraphContext":
