@@ -492,6 +492,82 @@ __global__ __launch_bounds__(256) void k_edge_embed_bwd_branch(const float* __re
   flush_vec(dwy, vp + 192, L);
   flush_vec(dbb, vp + 256, L);
 }
+// Both branches in ONE pass over the d sp rows (round 5, an alternative: TRAJSDE_BRANCH_FUSED=1, measured slower -- see
+// edge_embed_backward): the two kernels above read the same 256-byte row each, 1.15 GB twice per 64 x 128 training step.  Here a tile's
+// row is loaded once and goes through branch A then branch B (the same device functions in the same order: per branch the arithmetic
+// is that of k_edge_embed_bwd_branch<BR>); 160 accumulator registers per lane, so one wave per SIMD.  vpart: [branch][wave][320].
+__global__ __launch_bounds__(256) void k_edge_embed_bwd_branch2(const float* __restrict__ img, const float* __restrict__ geom,
+                                                                const float* __restrict__ DSP, int64_t E, float* __restrict__ vpartA,
+                                                                float* __restrict__ vpartB) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using EL = EdgeL;
+  for (int i = threadIdx.x; i < EL::WA3; i += blockDim.x) lds[i] = img[i];
+  for (int i = threadIdx.x; i < MAT64; i += blockDim.x) {
+    lds[EL::WA3 + i] = img[EdgeBwdL::WA3T + i];
+    lds[EL::WA3 + MAT64 + i] = img[EdgeBwdL::WB3T + i];
+  }
+  __syncthreads();
+  const Lane L;
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int64_t ntiles = (E + 15) / 16;
+  f4 dg[2][4], db[2][4], dwx[2][4], dwy[2][4], dbb[2][4];
+#pragma unroll
+  for (int br = 0; br < 2; ++br) { zero4(dg[br]); zero4(db[br]); zero4(dwx[br]); zero4(dwy[br]); zero4(dbb[br]); }
+  const int64_t tstride = int64_t(gridDim.x) * waves;
+  f4 ge_next, d_next[4];
+  {
+    const int64_t t0 = int64_t(blockIdx.x) * waves + wave;
+    const int64_t e0 = t0 * 16 + L.n, ec0 = e0 < E ? e0 : E - 1;
+    ge_next = *reinterpret_cast<const f4*>(geom + 4 * ec0);
+    load_row(d_next, DSP, ec0, L.g);
+  }
+  for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += tstride) {
+    keep_lds_reads_here();
+    const int64_t e = tile * 16 + L.n;
+    const f4 ge = ge_next;
+    f4 d[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) d[jt] = d_next[jt];
+    {
+      const int64_t en = (tile + tstride) * 16 + L.n, enc = en < E ? en : E - 1;
+      ge_next = *reinterpret_cast<const f4*>(geom + 4 * enc);
+      load_row(d_next, DSP, enc, L.g);
+    }
+    if (e >= E) zero4(d);
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+      const int W0 = br ? EL::B_W0 : EL::A_W0, B0_ = br ? EL::B_B0 : EL::A_B0, G_ = br ? EL::B_G : EL::A_G, E_ = br ? EL::B_E : EL::A_E;
+      const float i0 = br ? ge[2] : ge[0], i1 = br ? ge[3] : ge[1];
+      f4 xh[4], act[4], t[4];
+      float rstd;
+      branch_fwd(xh, act, rstd, i0, i1, lds + W0, lds + B0_, lds + G_, lds + E_, L);
+      linear_t(t, d, lds + EL::WA3 + br * MAT64, L);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (!(act[jt][c] > 0.f)) t[jt][c] = 0.f;
+      ln_backward(t, xh, rstd, lds + G_, L.g, dg[br], db[br]);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          dwx[br][jt][c] = fmaf(t[jt][c], i0, dwx[br][jt][c]);
+          dwy[br][jt][c] = fmaf(t[jt][c], i1, dwy[br][jt][c]);
+          dbb[br][jt][c] += t[jt][c];
+        }
+    }
+  }
+#pragma unroll
+  for (int br = 0; br < 2; ++br) {
+    float* vp = (br ? vpartB : vpartA) + int64_t(blockIdx.x * waves + wave) * 320;
+    flush_vec(dg[br], vp, L);
+    flush_vec(db[br], vp + 64, L);
+    flush_vec(dwx[br], vp + 128, L);
+    flush_vec(dwy[br], vp + 192, L);
+    flush_vec(dbb[br], vp + 256, L);
+  }
+}
 template __global__ void k_edge_embed_bwd_branch<0>(const float*, const float*, const float*, int64_t, float*);
 template __global__ void k_edge_embed_bwd_branch<1>(const float*, const float*, const float*, int64_t, float*);
 
@@ -632,22 +708,41 @@ int edge_embed_backward(const float* img, const float* geom, const float* demb, 
     if (int rc = wb.add_in2(sc.DSP, 64, geom, 1, img + EdgeL6::B_C, img + EdgeL6::B_E, gr.wb3, 64, gr.bb3)) return rc;
     if (int rc = wb.flush_edge()) return rc;
   }
-  for (int br = 0; br < 2; ++br) {
-    vp = vpart_slab(sc.vpart, int64_t(gb) * 4, 320);
-    if (br == 0) TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, img, geom, sc.DSP, E, vp);
-    else TS_LAUNCH(k_edge_embed_bwd_branch<1>, gb, 256, lds_br, st, img, geom, sc.DSP, E, vp);
-    float* g_ = br ? gr.b_g : gr.a_g;
-    float* e_ = br ? gr.b_e : gr.a_e;
-    float* w0 = br ? gr.b_w0 : gr.a_w0;
-    float* b0 = br ? gr.b_b0 : gr.a_b0;
-    {
-      ColsumBatch cb(st, gb * 4, 320);
+  {
+    // TRAJSDE_BRANCH_FUSED=1: both branches in one pass over the d sp rows (k_edge_embed_bwd_branch2).  Measured (64 x 128 step, one
+    // box, alternating): 1.047 ms against 0.379 + 0.367 = 0.746 ms for the two one-branch kernels -- at one wave per SIMD (296
+    // registers) the pass is bound by its dependent chain, not by the rows it saves reading.  Off by default; kept as the record.
+    static const bool fused = []() { const char* e = getenv("TRAJSDE_BRANCH_FUSED"); return e && atoi(e) == 1; }();
+    const int lds_br2 = (EdgeL::WA3 + 2 * MAT64) * 4;
+    const int g2 = fused ? vec_grid(ntiles, 256, lds_br2) : gb;
+    auto sums = [&](int br, float* vp, int g) -> int {
+      float* g_ = br ? gr.b_g : gr.a_g;
+      float* e_ = br ? gr.b_e : gr.a_e;
+      float* w0 = br ? gr.b_w0 : gr.a_w0;
+      float* b0 = br ? gr.b_b0 : gr.a_b0;
+      ColsumBatch cb(st, g * 4, 320);
       cb.add(vp, 64, g_);
       cb.add(vp + 64, 64, e_);
       cb.add(vp + 128, 64, w0, 2);        // [64,2] weight, column 0
       cb.add(vp + 192, 64, w0 + 1, 2);    // column 1
       cb.add(vp + 256, 64, b0);
-      if (int rc = cb.flush()) return rc;
+      return cb.flush();
+    };
+    float* vps[2] = {nullptr, nullptr};
+    if (fused) {
+      for (int br = 0; br < 2; ++br) vps[br] = vpart_slab(sc.vpart, int64_t(g2) * 4, 320);
+    }
+    if (fused && vps[0] != vps[1]) {      // (two slabs of their own: not the shared fallback slab twice)
+      TS_LAUNCH(k_edge_embed_bwd_branch2, g2, 256, lds_br2, st, img, geom, sc.DSP, E, vps[0], vps[1]);
+      for (int br = 0; br < 2; ++br)
+        if (int rc = sums(br, vps[br], g2)) return rc;
+    } else {
+      for (int br = 0; br < 2; ++br) {
+        float* vp = vpart_slab(sc.vpart, int64_t(gb) * 4, 320);
+        if (br == 0) TS_LAUNCH(k_edge_embed_bwd_branch<0>, gb, 256, lds_br, st, img, geom, sc.DSP, E, vp);
+        else TS_LAUNCH(k_edge_embed_bwd_branch<1>, gb, 256, lds_br, st, img, geom, sc.DSP, E, vp);
+        if (int rc = sums(br, vp, gb)) return rc;
+      }
     }
   }
   return TRAJSDE_OK;
