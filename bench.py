@@ -351,7 +351,7 @@ def main():
         roof = edge_roofline(iso_n, iso_ms, e_aa, 1)                          # the kernel alone (one stream): what profiles/ reproduces
         roof_corun = edge_roofline(n_launch, total_ms, e_aa, n_streams)       # inside the timed multi-stream region
         roof["traffic"] = None                                                # HBM bytes per launch are a PMC quantity: not measurable in this run
-        for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+        for tname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.isfile(tpath):
                 with open(tpath) as f:

@@ -59,7 +59,7 @@ def main():
             e = tab[k % sched.n_euler].ctypes.data_as(C.POINTER(C.c_float))
             _lib.check(L.trajsde_sde_step(rows, blob.data_ptr(), y[k & 1].data_ptr(), y[(k + 1) & 1].data_ptr(), e, k, C.byref(noise), st))
 
-    run(20)
+    run(int(os.environ.get("SDE_STEP_WARMUP", "500")))          # the clock ramps over the first ~100 launches: time a warmed chip
     torch.cuda.synchronize()
     beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 200

@@ -177,7 +177,10 @@ constexpr int COOP_TILE = 16 * COOP_RS;
 // LDS floats of the cooperative recurrence for `tiles` row tiles per workgroup: per tile the fp32 state + five operand tiles
 // (1024 floats each as pre-split fp16 planes in the fp16x3 build, a padded fp32 tile otherwise: recur.hip) + 64 partial sums
 constexpr int COOP_BIAS_VECS = 21;                            // + the bias / head vectors of the three nets and the GRU unit (recur.hip BV)
-constexpr int coop_lds_floats(int tiles) { return tiles * (COOP_TILE + 5 * (TSDE_SPLIT_H3 ? 1024 : COOP_TILE)) + tiles * 64 + COOP_BIAS_VECS * 64; }
+// + the three time-conditioned first-layer biases of every step (32 steps x 3 x 64: recur.hip BT)
+constexpr int coop_lds_floats(int tiles) {
+  return tiles * (COOP_TILE + 5 * (TSDE_SPLIT_H3 ? 1024 : COOP_TILE)) + tiles * 64 + COOP_BIAS_VECS * 64 + 32 * 3 * 64;
+}
 struct StepTab {                                              // per-iteration (dt, sqrt_h, sin t0, cos t0), H <= 32
   float dt[32], sq[32], sn[32], cs[32];
 };

@@ -374,6 +374,24 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
   }
   auto bias = [&](int v) { return *reinterpret_cast<const f4*>(BV + v * 64 + 16 * w + 4 * L.g); };
   const float n_b4 = GN[DiffL::B4], a_b4 = GA[DiffL::B4];
+  // the first-layer biases with the (sin t, cos t) columns folded in depend on the step alone: all H x 3 of them are formed here, once
+  // (the step loop's top used to read nine vectors and form them: with the step table's scalar loads that was 17 % of a step, round 4's
+  // phase clocks)
+  float* BT = BV + V_COUNT * 64;                               // [H][3][64]
+  if (threadIdx.x < 192) {
+    const int net = threadIdx.x >> 6, c = threadIdx.x & 63;
+    const float* base = net == 0 ? F + DriftL::B0 : (net == 1 ? GN + DiffL::B0 : GA + DiffL::B0);
+    const float* ws_ = net == 0 ? F + DriftL::WS : (net == 1 ? GN + DiffL::WS : GA + DiffL::WS);
+    const float* wc_ = net == 0 ? F + DriftL::WC : (net == 1 ? GN + DiffL::WC : GA + DiffL::WC);
+#if TSDE_SPLIT_H3
+    constexpr float TPB = TANH_PRESCALE;
+#else
+    constexpr float TPB = 1.f;
+#endif
+    const float b = base[c] * TPB, s_ = ws_[c] * TPB, c_ = wc_[c] * TPB;
+    for (int i = 0; i < H; ++i) BT[(i * 3 + net) * 64 + c] = fmaf(c_, tab.cs[i], fmaf(s_, tab.sn[i], b));
+  }
+  auto step_bias = [&](int idx, int net) { return *reinterpret_cast<const f4*>(BT + (idx * 3 + net) * 64 + 16 * w + 4 * L.g); };
 
   // ---- per-tile row bookkeeping and the initial state
   int64_t rowk[COOP_TMAX];
@@ -413,16 +431,14 @@ __global__ __launch_bounds__(256) void k_enc_recur_coop(const float* __restrict_
 
   for (int idx = 0; idx < H; ++idx) {
     const int t = H - 1 - idx;
-    const float dt = tab.dt[idx], sq = tab.sq[idx], sn = tab.sn[idx], cs = tab.cs[idx];
+    const float dt = tab.dt[idx], sq = tab.sq[idx];
     // SAVE (the training forward): this wave's 16 channels of every activation the backward reads go to the tape slabs
     // [H][Nt][64] of csrc/encoder_bwd.hip (what k_enc_recur_save wrote one tile per wave) -- fire-and-forget stores
     auto keep = [&](float* slab, int k, const f4& v) {
       if (SAVE && inb[k]) *reinterpret_cast<f4*>(slab + (int64_t(idx) * Nt + rowk[k]) * 64 + 16 * w + 4 * L.g) = v;
     };
-    // first-layer biases with the (sin t, cos t) columns folded in
-    const f4 bf0 = bias(V_FB0) + bias(V_FWS) * sn + bias(V_FWC) * cs;
-    const f4 bn0 = bias(V_NB0) + bias(V_NWS) * sn + bias(V_NWC) * cs;
-    const f4 ba0 = bias(V_AB0) + bias(V_AWS) * sn + bias(V_AWC) * cs;
+    // first-layer biases with the (sin t, cos t) columns folded in (BT above)
+    const f4 bf0 = step_bias(idx, 0), bn0 = step_bias(idx, 1), ba0 = step_bias(idx, 2);
     bool validk[COOP_TMAX];                                  // maski = actors_mask[:, t] (ENC:176): asked for here, used in P7
 #pragma unroll
     for (int k = 0; k < COOP_TMAX; ++k)
