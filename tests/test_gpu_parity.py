@@ -532,12 +532,13 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
                       ("fused_one_tile", {"TRAJSDE_FUSED_TILES": "1"}),
                       ("gattn_mm", {"TRAJSDE_GATTN_MM": "1"}),
                       ("gattn_vector", {"TRAJSDE_GATTN_F32MM": "0"}),
+                      ("gattn_two_tiles", {"TRAJSDE_GMF_TILES": "2"}),
                       ("pipelined", {"TRAJSDE_EDGE_PIPE": "1"}),
                       ("tile32", {"TRAJSDE_EDGE_TILE": "32"}),
                       ("tile32_pingpong", {"TRAJSDE_EDGE_TILE": "32", "TRAJSDE_EDGE_PINGPONG": "1"}),
                       ("fallbacks", {"TRAJSDE_RECUR_LEGACY": "1", "TRAJSDE_GLOBAL_UNFUSED": "1", "TRAJSDE_NODE_FP32": "0"})):
         path = str(tmp_path / (mode + ".pt"))
-        if mode in ("fused_one_tile", "gattn_mm", "pipelined", "tile32", "tile32_pingpong"):
+        if mode in ("fused_one_tile", "gattn_mm", "gattn_two_tiles", "pipelined", "tile32", "tile32_pingpong"):
             from trajsde_amd import _lib              # alternative kernel forms: not in the product library (trajsde_amd/build.py)
             env = dict(env, TRAJSDE_LIB=_lib.ALT_LIB_PATH)
         subprocess.run([sys.executable, "-c", script, path], check=True, env={**os.environ, **env}, timeout=600)
@@ -558,6 +559,8 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
         assert H.maxdiff(outs["split"][key], outs["gattn_mm"][key]) <= 2e-5, key
         # the default global attention (gattn_f32.hip: fp32 matrix instructions) against the vector form it replaced (attn.hip k_global_attn)
         assert H.maxdiff(outs["split"][key], outs["gattn_vector"][key]) <= 2e-5, key
+        # ... and against its 32-edges-a-step form (k_global_attn_mf2: two tiles of a target through every phase together)
+        assert H.maxdiff(outs["split"][key], outs["gattn_two_tiles"][key]) <= 2e-5, key
         assert torch.equal(outs["split"][key], outs["pipelined"][key]), key              # k_edge_attn2p: the tiles one stage apart, the same bits
         # the fused edge attention on 32x32x16 matrix tiles (edge32.hip): other fragment order, same algebra; with and without the
         # phase barriers between the two waves of a SIMD: the same bits

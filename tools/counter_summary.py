@@ -67,7 +67,8 @@ def table(title, cmd, data, order_key="SQ_WAVE_CYCLES", top=14):
 def main():
     root, md_path, json_path = sys.argv[1:4]
     fwd, sde, stress = collect(root, "pmc_fwd_"), collect(root, "pmc_sde_"), collect(root, "pmc_stress_")
-    lines = ["# SQ / TCC counters, round 3 build (fp16x3 split precision, fused edge attention with matrix-core first layers, Philox4x32-7)", ""]
+    lines = [f"# SQ / TCC counters, {os.environ.get('ROUND', 'this')} build (fp16x3 split precision, fused edge attention with matrix-core first "
+             "layers, Philox4x32-7)", ""]
     lines += table("forward, 32 scenes x 256 agents, K=6, 20 steps, one stream",
                    "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --windows 1 "
                    "--no-cpu-baseline --no-train-step --no-secondary --streams 1   (one pass per counter set)", fwd)

@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libtrajsde_hip.so")
 # global attention (gattn.hip) -- are compiled into a second library of the same C-ABI, loaded (TRAJSDE_LIB) by the tests and A/B
 # tools that select them with their TRAJSDE_* switches; the product library refuses those switches.
 ALT_LIB = os.path.join(HERE, "variants", "libtrajsde_alt.so")
-ALT_SOURCES = ("attn.hip", "edge32.hip", "gattn.hip", "stages.hip")     # the units TSDE_PRODUCT changes
+ALT_SOURCES = ("attn.hip", "edge32.hip", "gattn.hip", "gattn_f32.hip", "stages.hip")     # the units TSDE_PRODUCT changes
 # The strict-precision twin: the product library with 24-bit operands (three bf16 pieces, six products: -DTSDE_SPLIT_H3=0), same
 # C-ABI.  bench.py times it in a child process (`strict24` key of the bench line) so that the headline's precision asterisk --
 # fp16x3 operands are 22-bit -- always has a current number beside it.  Not built when TRAJSDE_SPLIT already selects bf16x6.

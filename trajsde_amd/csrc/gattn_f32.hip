@@ -286,6 +286,269 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
 #endif
 }
 
+#ifndef TSDE_PRODUCT        // alternative form: trajsde_amd/variants/libtrajsde_alt.so only (TRAJSDE_GMF_TILES=2)
+// ---- the same kernel over 32 edges a step (round 5).  The phase clocks of the kernel above say 70 % of a 16-edge tile is waiting at the
+// three places its dependent chain touches memory, and the ablations say the waits are the chain, not the bytes: stage -> product ->
+// scalars -> product -> node sums, ~5 300 cycles with nothing of its own to overlap at two waves per SIMD.  A third wave per SIMD does
+// not fit (213 registers; through an LDS ring instead of registers the tiles in flight are 18 KB a wave).  So the chain is made to carry
+// twice the edges: two consecutive tiles of the SAME target go through every phase together -- they share the target's state (m, s, R,
+// node sums, U), only the tile-local values double -- and each wait is paid once per 32 edges.  Per edge and head the arithmetic is
+// that of the one-tile form except for the order in which a head's maximum is raised (one rescale per 32 edges instead of two) and
+// the grouping of the sums: parity against the oracle at the same tolerance, not bit-identical to the one-tile form.
+// MEASURED (32 x 256 agents, one box, alternating): 0.541-0.547 ms for the three layers against 0.525-0.530 for the one-tile form --
+// 3 % SLOWER at 256 registers.  Twice the edges per dependent chain buy nothing, so the chain is not what bounds the kernel either:
+// what remains is pipe time -- 32 fp32 matrix instructions of 32 cycles (1 024 cycles of the SIMD's matrix pipe) and ~290 vector
+// instructions (~1 300 cycles) per 16 edges and wave, served to two waves with little co-execution (DESIGN.md section 5 "Round 5").
+constexpr int GMF2_PER_WAVE = 2 * 16 * GMF_TP + 32 * 8 + 32 * 8 + 64 + 64;
+constexpr int gmf2_lds_bytes() { return (GMF_WIMG + GMF_WV + GMF_WAVES * GMF2_PER_WAVE) * 4; }
+template <bool DROP>
+__global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf2(const float* __restrict__ img, const int32_t* __restrict__ segptr,
+                                                                    const int32_t* __restrict__ src, const float* __restrict__ rel,
+                                                                    const float* __restrict__ q, const float* __restrict__ kn,
+                                                                    const float* __restrict__ vn, int64_t N, float* __restrict__ agg,
+                                                                    float* __restrict__ stats, DropArg drop) {
+  constexpr int HEADS = 8;
+  constexpr float INV = INV_SQRT_DH;
+  constexpr int TP = GMF_TP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const wimg = lds;
+  float* const wvp = lds + GMF_WIMG;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* const tile = lds + GMF_WIMG + GMF_WV + wv * GMF2_PER_WAVE;   // [2][16][TP]
+  float* const pnt = tile + 32 * TP;                               // [32 edges][8 heads]: node part of the logits
+  float* const wt = pnt + 256;                                     // [32 edges][8 heads]: the step's softmax weights
+  float* const nsum = wt + 256;
+  float* const qsm = nsum + 64;
+  const int c16 = lane & 15, q4 = lane >> 4, hd = c16 & 7;
+  const bool lo8 = c16 < 8;
+  {
+    const float* wke = img + GAttnL::WKE;
+    const float* wve = img + GAttnL::WVE;
+    for (int i = threadIdx.x; i < GMF_WIMG / 4; i += blockDim.x) {
+      const int j = i & 7, v4 = (i >> 3) & 3, kk = (i >> 5) & 3, d = i >> 7;
+      *reinterpret_cast<f4*>(wimg + 4 * i) = *reinterpret_cast<const f4*>(wke + (8 * j + d) * 64 + 16 * kk + 4 * v4);
+    }
+    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
+      const int row = i >> 4, c4 = i & 15;
+      *reinterpret_cast<f4*>(wvp + row * TP + 4 * c4) = *reinterpret_cast<const f4*>(wve + row * 64 + 4 * c4);
+    }
+  }
+  __syncthreads();
+  const float bve = img[GAttnL::BVE + lane];
+  const int64_t stride = int64_t(gridDim.x) * GMF_WAVES;
+  for (int64_t node = xcd_block() * GMF_WAVES + wv; node < N; node += stride) {
+    const float ql = q[node * 64 + lane] * INV;
+    const int beg = segptr[node], end = segptr[node + 1];
+    if (end <= beg) {                                              // (uniform) no edge: the aggregate is zero
+      agg[node * 64 + lane] = 0.f;
+      if (stats != nullptr && lo8 && q4 == 0) *reinterpret_cast<float2*>(stats + (node * HEADS + hd) * 2) = float2{-INFINITY, 1.0f / 1e-16f};
+      continue;
+    }
+    auto src_at = [&](int (&dst)[4], int e0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = e0 + 4 * q4 + r;
+        dst[r] = src[e < end ? e : end - 1];
+      }
+    };
+    auto rel_load = [&](f4 (&dst)[4], int e0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = e0 + 4 * q4 + r;
+        dst[r] = *reinterpret_cast<const f4*>(rel + int64_t(e < end ? e : end - 1) * 64 + 4 * c16);
+      }
+    };
+    auto row_load = [&](f4 (&dst)[4], const float* __restrict__ base, const int (&sidx)[4]) {    // four whole rows per instruction
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[r] = *reinterpret_cast<const f4*>(base + int64_t(sidx[r]) * 64 + 4 * c16);
+    };
+    // in flight per wave: the rel rows of the NEXT step's two tiles (nx), the key and value rows of THIS step's two tiles (kr, vr),
+    // the sources of the next step's tiles (sn)
+    int sn[2][4];
+    f4 nx[2][4], kr[2][4], vr[2][4];
+    {
+      int s0[2][4];
+      src_at(s0[0], beg);
+      src_at(s0[1], beg + 16);
+      src_at(sn[0], beg + 32);
+      src_at(sn[1], beg + 48);
+      rel_load(nx[0], beg);
+      rel_load(nx[1], beg + 16);
+      row_load(kr[0], kn, s0[0]);
+      row_load(kr[1], kn, s0[1]);
+      row_load(vr[0], vn, s0[0]);
+      row_load(vr[1], vn, s0[1]);
+    }
+    float uz[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) uz[s] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const float qs = __shfl(ql, 8 * hd + d);
+      const float qd = lo8 ? qs : 0.f;
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) {
+        const f4 wr = *reinterpret_cast<const f4*>(wimg + (((d * 4 + q4) * 4 + v4) * 8 + hd) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) uz[4 * v4 + e] = fmaf(wr[e], qd, uz[4 * v4 + e]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    qsm[lane] = ql;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const f4 qn = *reinterpret_cast<const f4*>(qsm + 4 * c16);
+    f4 R[4], accn = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) R[b] = f4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, s = 0.f, sk = 0.f;
+    for (int e0 = beg; e0 < end; e0 += 32) {
+      __builtin_amdgcn_wave_barrier();                             // the previous readers of the wave's LDS are done (same wave, in order)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<f4*>(tile + (16 * u + 4 * q4 + r) * TP + 4 * c16) = nx[u][r];
+      rel_load(nx[0], e0 + 32);                                    // the next step's tiles, into the registers just staged
+      rel_load(nx[1], e0 + 48);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // first product, both tiles: eight independent accumulator chains
+      f4 P[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f4 P0 = f4{0.f, 0.f, 0.f, 0.f}, P1 = P0, P2 = P0, P3 = P0;
+        f4 a[4];
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) a[v4] = *reinterpret_cast<const f4*>(tile + (16 * u + c16) * TP + 16 * q4 + 4 * v4);
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+          P0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][0], uz[4 * v4 + 0], P0, 0, 0, 0);
+          P1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][1], uz[4 * v4 + 1], P1, 0, 0, 0);
+          P2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][2], uz[4 * v4 + 2], P2, 0, 0, 0);
+          P3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v4][3], uz[4 * v4 + 3], P3, 0, 0, 0);
+        }
+        P[u] = (P0 + P1) + (P2 + P3);
+      }
+      // node part of the logits, both tiles
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = qn[0] * kr[u][r][0];
+#pragma unroll
+          for (int e = 1; e < 4; ++e) p = fmaf(qn[e], kr[u][r][e], p);
+          p += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+          if ((c16 & 1) == 0) pnt[(16 * u + 4 * q4 + r) * 8 + (c16 >> 1)] = p;
+        }
+      row_load(kr[0], kn, sn[0]);
+      row_load(kr[1], kn, sn[1]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      uint32_t mine[2] = {0u, 0u};
+      if (DROP) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          uint32_t w[4];
+          philox_words(drop.seed, drop_stream(drop, DK_ATTN), uint32_t(e0 + 16 * u - beg) + uint32_t(c16), uint32_t(node), 0u, w);
+          mine[u] = q4 == 0 ? w[0] : (q4 == 1 ? w[1] : (q4 == 2 ? w[2] : w[3]));
+        }
+      }
+      // lane (j = c16, q4): logits of head j for the edges 16 u + 4 q4 + i of the step
+      f4 lg[2];
+      float cm = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = e0 + 16 * u + 4 * q4 + i;
+          const float p = P[u][i] + pnt[(16 * u + 4 * q4 + i) * 8 + hd];
+          lg[u][i] = e < end ? p : -INFINITY;
+          cm = fmaxf(cm, lg[u][i]);
+        }
+      cm = row_max(cm);
+      const float mn = fmaxf(m, cm);
+      const float sc = fast_exp(m - mn);
+      m = mn;
+      s *= sc;
+      sk *= sc;
+      f4 W[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float ex = fast_exp(lg[u][i] - m);
+          s += ex;
+          if (DROP) {
+            const uint32_t word = uint32_t(__shfl(int(mine[u]), 16 * (hd >> 1) + 4 * q4 + i));
+            ex *= drop_pick(word, hd & 1, drop);
+          }
+          sk += ex;
+          W[u][i] = lo8 ? ex : 0.f;
+          if (lo8) wt[(16 * u + 4 * q4 + i) * 8 + hd] = ex;
+        }
+      if (__builtin_amdgcn_ballot_w64(sc != 1.0f) != 0ull) {        // (uniform)
+        float sr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sr[i] = __shfl(sc, (4 * q4 + i) & 7);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) R[b][i] *= sr[i];
+        accn *= __shfl(sc, c16 >> 1);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f4 rw[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rw[r] = *reinterpret_cast<const f4*>(tile + (16 * u + 4 * q4 + r) * TP + 4 * c16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) R[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u][i], rw[i][b], R[b], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accn += vr[u][r] * wt[(16 * u + 4 * q4 + r) * 8 + (c16 >> 1)];
+      row_load(vr[0], vn, sn[0]);
+      row_load(vr[1], vn, sn[1]);
+      src_at(sn[0], e0 + 64);
+      src_at(sn[1], e0 + 80);
+    }
+    s = xor32_sum(xor16_sum(s));
+    sk = xor32_sum(xor16_sum(sk));
+    const float inv = 1.0f / (s + 1e-16f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * q4 + i;
+      const float ri = __shfl(inv, row & 7);
+      if (row < 8) *reinterpret_cast<f4*>(tile + row * TP + 4 * c16) = f4{R[0][i] * ri, R[1][i] * ri, R[2][i] * ri, R[3][i] * ri};
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) accn[e] = xor32_sum(xor16_sum(accn[e]));
+    if (q4 == 0) *reinterpret_cast<f4*>(nsum + 4 * c16) = accn;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int h = lane >> 3;
+    const float invh = __shfl(inv, h), skh = __shfl(sk, h);
+    float out = fmaf(bve, skh * invh, nsum[lane] * invh);
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+      const f4 wr = *reinterpret_cast<const f4*>(wvp + lane * TP + 4 * k4);
+      const f4 sv = *reinterpret_cast<const f4*>(tile + h * TP + 4 * k4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out = fmaf(wr[e], sv[e], out);
+    }
+    agg[node * 64 + lane] = out;
+    if (stats != nullptr && lo8 && q4 == 0) *reinterpret_cast<float2*>(stats + (node * HEADS + hd) * 2) = float2{m, inv};
+  }
+}
+
+#endif  // TSDE_PRODUCT
+
 // TRAJSDE_GATTN_F32MM=0: the vector form (attn.hip k_global_attn) for A/B runs and cross-checks
 bool gattn_f32mm_enabled() {
   static const bool on = []() { const char* e = getenv("TRAJSDE_GATTN_F32MM"); return !(e && e[0] == '0'); }();
@@ -296,6 +559,17 @@ int launch_global_attn_mf(const float* img, const int32_t* segptr, const int32_t
   if (N <= 0) return TRAJSDE_OK;
   const int64_t wgs = (N + GMF_WAVES - 1) / GMF_WAVES;
   const int grid = xcd_grid(wgs < 256 ? wgs : 256);                // one workgroup per CU; fewer when the targets do not fill them (a multiple of 8: xcd_block)
+  // TRAJSDE_GMF_TILES=2: 32 edges a step (k_global_attn_mf2)
+  static const bool two = []() { const char* e = getenv("TRAJSDE_GMF_TILES"); return e && atoi(e) == 2; }();
+#ifdef TSDE_PRODUCT
+  TS_REQUIRE(!two, "TRAJSDE_GMF_TILES selects an alternative kernel form that lives in trajsde_amd/variants/libtrajsde_alt.so: point TRAJSDE_LIB at it");
+#else
+  if (two) {
+    if (drop.p > 0.f) TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn_mf2<true>), grid, 64 * GMF_WAVES, gmf2_lds_bytes(), st, img, segptr, src, rel, q, kn, vn, N, agg, stats, drop);
+    else TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn_mf2<false>), grid, 64 * GMF_WAVES, gmf2_lds_bytes(), st, img, segptr, src, rel, q, kn, vn, N, agg, stats, drop);
+    return TRAJSDE_OK;
+  }
+#endif
   if (drop.p > 0.f) TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn_mf<true>), grid, 64 * GMF_WAVES, gmf_lds_bytes(), st, img, segptr, src, rel, q, kn, vn, N, agg, stats, drop);
   else TS_LAUNCH_TAG("k_global_attn<8>", false, (k_global_attn_mf<false>), grid, 64 * GMF_WAVES, gmf_lds_bytes(), st, img, segptr, src, rel, q, kn, vn, N, agg, stats, drop);
   return TRAJSDE_OK;
