@@ -355,3 +355,102 @@ def test_squared_radius_threshold_selects_exactly_the_sqrt_survivors():
         for d2 in (near, far):
             assert np.array_equal(np.sqrt(d2, dtype=np.float32) < r, d2 < T), radius
     assert L.trajsde_radius2_threshold(0.0) == 0.0 and L.trajsde_radius2_threshold(-1.0) == 0.0
+
+
+def _bundle_fixture(seed=0):
+    """a toy model's parameters (three 'stages'), a FlatGrads over the ones that train, and one GradBuffers per stage whose layout
+    holds MORE names than the model trains (what the *_BWD stages hand back: every parameter the kernels differentiate)"""
+    import torch
+    from trajsde_amd.driver import FlatGrads
+    from trajsde_amd.runtime import GradBuffers, GradLayout
+    g = torch.Generator().manual_seed(seed)
+    shapes = {"encoder.": [("a.weight", (5, 3)), ("a.bias", (5,)), ("tok", (1, 7))],
+              "aggregator.": [("l.0.weight", (4, 4)), ("l.0.bias", (4,))],
+              "decoder.": [("h.weight", (2, 6)), ("h.bias", (2,)), ("pi.weight", (3, 3))]}
+    named, bundles = [], []
+    for prefix, items in shapes.items():
+        for n, sh in items:
+            named.append((prefix + n, torch.nn.Parameter(torch.randn(*sh, generator=g))))
+        lay = GradLayout([n for n, _ in items], [sh for _, sh in items])
+        flat = torch.randn(lay.total, generator=g)
+        bundles.append((prefix, GradBuffers(flat, lay), 1.0))
+    trained = [p for n, p in named if n != "decoder.pi.weight"]          # the losses do not reach the pi head
+    fg = FlatGrads(trained)
+    fg.names = {id(p): n for n, p in named}
+    return named, trained, fg, bundles
+
+
+def test_grad_buffers_is_a_lazy_read_only_mapping():
+    import torch
+    named, trained, fg, bundles = _bundle_fixture()
+    prefix, gb, _ = bundles[0]
+    assert list(gb) == ["a.weight", "a.bias", "tok"] and len(gb) == 3 and "tok" in gb and gb._views == {}
+    v = gb["a.bias"]
+    assert v.shape == (5,) and v._base is gb.flat and list(gb._views) == ["a.bias"]         # made on first access, only that one
+    assert gb["a.bias"] is v
+    assert {k: tuple(t.shape) for k, t in gb.items()} == {"a.weight": (5, 3), "a.bias": (5,), "tok": (1, 7)}
+    lay = gb.layout
+    assert all(o % 4 == 0 for o in lay.offs) and lay.total % 4 == 0                          # 16-byte aligned slices
+    arr, keep = gb.pointer_array()
+    assert [arr[i] for i in range(3)] == [gb.flat.data_ptr() + 4 * o for o in lay.offs]
+    assert torch.equal(dict(gb)["tok"], gb["tok"])
+
+
+def test_whole_stage_buffers_accumulate_like_the_per_parameter_route():
+    """driver.FlatGrads.accumulate_bundles (one cached gather per stage buffer, no per-parameter view) must leave exactly what
+    accumulate() leaves when it is handed the same gradients parameter by parameter -- with a multiplier on one stage, a parameter
+    the losses do not reach, and twice in a row (gradient accumulation without the early slice)"""
+    import torch
+    named, trained, fg, bundles = _bundle_fixture(3)
+    bundles[2] = (bundles[2][0], bundles[2][1], 0.5)                                       # decoder gradients times w_l2
+    scale = torch.tensor(2.0)
+    fg.zero()
+    assert fg.accumulate_bundles(bundles, scale) and fg.accumulate_bundles(bundles, scale)
+    got = fg.flat.clone()
+    assert len(fg._gather) == 3                                                              # one plan per stage, cached
+    ref_named, ref_trained, ref, _ = _bundle_fixture(3)
+    by_name = {}
+    for prefix, gb, mult in bundles:
+        for n, t in gb.items():
+            by_name[prefix + n] = t if mult == 1.0 else t * mult
+    ref.zero()
+    params = [p for _, p in ref_named]
+    grads = [by_name[n] for n, _ in ref_named]
+    for _ in range(2):
+        ok = ref.accumulate(params, grads, scale)
+        if not ok:                                                                          # (scaled copies are not views of a flat buffer:
+            for p, g_ in zip(params, grads):                                                #  the per-parameter fallback of _PathLoss.backward)
+                if p.grad is not None and id(p) in {id(q) for q in ref.params}:
+                    p.grad.add_(g_ * scale)
+    assert torch.allclose(got, ref.flat, rtol=0, atol=1e-6) and float(got.abs().max()) > 0
+    # without names the whole-buffer route says so and does nothing
+    fg2 = _bundle_fixture(3)[2]
+    fg2.names = None
+    fg2.zero()
+    assert fg2.accumulate_bundles(bundles, scale) is False and float(fg2.flat.abs().max()) == 0.0
+
+
+def test_early_slice_over_whole_stage_buffers_follows_the_protocol():
+    import pytest
+    import torch
+    named, trained, fg, bundles = _bundle_fixture(5)
+    one = torch.ones(())
+    fg.zero()
+    assert fg.early_plan({id(p): n for n, p in named}) is True
+    assert fg.early_reduce_bundles(bundles[1:]) is True                                     # aggregator + decoder: adjacent blocks, one slice
+    lo, hi = fg._early[1], fg._early[2]
+    assert lo == sum(p.numel() for n, p in named if n.startswith("encoder.")) and hi == fg.flat.numel()
+    assert float(fg.flat[:lo].abs().max()) == 0.0 and float(fg.flat[lo:].abs().max()) > 0
+    assert fg.accumulate_bundles(bundles, one) is True                                      # the encoder's block; the early ones are skipped
+    full = _bundle_fixture(5)[2]
+    full.zero()
+    assert full.accumulate_bundles(bundles, one)
+    assert torch.equal(fg.flat, full.flat)
+    with pytest.raises(RuntimeError, match="second backward"):
+        fg.accumulate_bundles(bundles, one)
+    with pytest.raises(RuntimeError, match="already reduced"):
+        fg.early_reduce_bundles(bundles[1:])
+    fg.all_reduce_mean()
+    fg.zero()
+    assert fg.early_reduce_bundles([bundles[0], bundles[2]]) is False                       # encoder + decoder: not adjacent in the buffer
+    assert fg._early is None and float(fg.flat.abs().max()) == 0.0

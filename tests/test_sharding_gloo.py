@@ -442,18 +442,40 @@ def _early_worker(rank, world, port, q):
                     off += p.numel()
             return out
 
+        def stage_bundles(step):             # the same numbers as whole stage buffers (runtime.GradBuffers), what the training loop hands over
+            from trajsde_amd.runtime import GradBuffers, GradLayout
+            gg = torch.Generator().manual_seed(100 * rank + step)
+            out = []
+            for st in ("encoder", "aggregator", "decoder"):
+                mine = [(n, p) for n, p in zip(names, params) if n.startswith(st)]
+                buf = torch.randn(sum(p.numel() for _, p in mine), generator=gg) * (1e-3 if st == "encoder" else 1.0)
+                lay = GradLayout([n[len(st) + 1:] for n, _ in mine], [tuple(p.shape) for _, p in mine])
+                flat = torch.zeros(lay.total)
+                off = 0
+                for (n, p), o, sz in zip(mine, lay.offs, lay.sizes):
+                    flat[o:o + sz] = buf[off:off + sz]
+                    off += sz
+                out.append((st + ".", GradBuffers(flat, lay), 1.0))
+            return out
+
         res = {}
-        for mode in ("plain", "early"):
+        for mode in ("plain", "early", "bundles"):
             fg = FlatGrads(params)
+            fg.names = {id(p): n for n, p in zip(names, params)}
             hist = []
             for step in range(3):
                 fg.zero()
                 grads = stage_grads(step)
                 one = torch.ones(())
-                if mode == "early":
-                    sub = [n for n in names if not n.startswith("encoder")]
-                    assert fg.early_reduce([params[names.index(n)] for n in sub], [grads[n] for n in sub])
-                assert fg.accumulate(params, [grads[n] for n in names], one)
+                if mode == "bundles":
+                    bundles = stage_bundles(step)
+                    assert fg.early_reduce_bundles(bundles[1:])
+                    assert fg.accumulate_bundles(bundles, one)
+                else:
+                    if mode == "early":
+                        sub = [n for n in names if not n.startswith("encoder")]
+                        assert fg.early_reduce([params[names.index(n)] for n in sub], [grads[n] for n in sub])
+                    assert fg.accumulate(params, [grads[n] for n in names], one)
                 fg.all_reduce_mean()
                 hist.append(fg.flat.clone())
             res[mode] = torch.stack(hist).numpy()
@@ -483,6 +505,7 @@ def test_two_slice_gradient_all_reduce_equals_the_one_piece_form():
         assert p.exitcode == 0
     for rank, res in got:
         assert np.array_equal(res["plain"], res["early"])
+        assert np.array_equal(res["plain"], res["bundles"])               # ... and the whole-stage-buffer entry points
         assert np.abs(res["plain"]).max() > 0
     assert np.array_equal(got[0][1]["early"], got[1][1]["early"])
 

@@ -361,6 +361,9 @@ class GradBuffers(collections.abc.Mapping):
     def __len__(self) -> int:
         return len(self.layout.names)
 
+    def __contains__(self, name) -> bool:
+        return name in self.layout.index
+
     def pointer_array(self):
         """(ctypes pointer to the void* array the C-ABI takes, keep-alive object): base address + static byte offsets"""
         ptrs = self.layout.byte_offs + np.uint64(self.flat.data_ptr())
