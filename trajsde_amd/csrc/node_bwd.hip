@@ -293,8 +293,7 @@ __global__ __launch_bounds__(TSDE_TAIL_BOUNDS) void k_edge_embed_bwd_tail(const 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_blob(lds, img, EdgeBwdL::WA3T);                   // forward image + W2^T
   if (ATTN) {                                             // lin_k^T | lin_v^T behind it
-    for (int i = threadIdx.x; i < 2 * MAT64 / 4; i += blockDim.x)
-      reinterpret_cast<f4*>(lds + EdgeBwdL::WA3T)[i] = reinterpret_cast<const f4*>(ag.wkvt)[i];
+    stage_copy(lds + EdgeBwdL::WA3T, ag.wkvt, 2 * MAT64);
     __syncthreads();
   }
   using EL = EdgeL6;                                     // split-precision recompute, fp32 transposes for the gradients
@@ -432,11 +431,9 @@ __global__ __launch_bounds__(256) void k_edge_embed_bwd_branch(const float* __re
   using EL = EdgeL;
   constexpr int W0 = BR ? EL::B_W0 : EL::A_W0, B0_ = BR ? EL::B_B0 : EL::A_B0, G_ = BR ? EL::B_G : EL::A_G, E_ = BR ? EL::B_E : EL::A_E;
   // stage the input-embedding vectors and this branch's transposed matrix only
-  for (int i = threadIdx.x; i < EL::WA3; i += blockDim.x) lds[i] = img[i];
-  {
-    const float* src = img + (BR ? EdgeBwdL::WB3T : EdgeBwdL::WA3T);
-    for (int i = threadIdx.x; i < MAT64; i += blockDim.x) lds[EL::WA3 + i] = src[i];
-  }
+  static_assert(EL::WA3 % 4 == 0 && EdgeBwdL::WA3T % 4 == 0 && EdgeBwdL::WB3T % 4 == 0, "16-byte staging");
+  stage_copy(lds, img, EL::WA3);
+  stage_copy(lds + EL::WA3, img + (BR ? EdgeBwdL::WB3T : EdgeBwdL::WA3T), MAT64);
   __syncthreads();
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -501,11 +498,9 @@ __global__ __launch_bounds__(256) void k_edge_embed_bwd_branch2(const float* __r
                                                                 float* __restrict__ vpartB) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using EL = EdgeL;
-  for (int i = threadIdx.x; i < EL::WA3; i += blockDim.x) lds[i] = img[i];
-  for (int i = threadIdx.x; i < MAT64; i += blockDim.x) {
-    lds[EL::WA3 + i] = img[EdgeBwdL::WA3T + i];
-    lds[EL::WA3 + MAT64 + i] = img[EdgeBwdL::WB3T + i];
-  }
+  stage_copy(lds, img, EL::WA3);
+  stage_copy(lds + EL::WA3, img + EdgeBwdL::WA3T, MAT64);
+  stage_copy(lds + EL::WA3 + MAT64, img + EdgeBwdL::WB3T, MAT64);
   __syncthreads();
   const Lane L;
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;

@@ -734,11 +734,32 @@ __device__ __forceinline__ float load_elem_st(const void* base, int64_t idx, boo
 // ds_reads next to their MFMAs (no instruction is emitted).
 __device__ __forceinline__ void keep_lds_reads_here() { asm volatile("" ::: "memory"); }
 
-// stage a packed weight blob into LDS (whole workgroup), then barrier
-__device__ __forceinline__ void stage_blob(float* lds, const float* blob, int n_floats) {
+// stage a packed weight blob into LDS (whole workgroup), then barrier.  EIGHT loads of a thread are requested before the first is
+// stored: written as `for (i ..) dst[i] = src[i]` the compiler emitted load, wait, store per iteration -- a 128 KB image staged by
+// 512 threads was 16 global-memory latencies in a row, ~10 us at the head of EVERY launch of every tile kernel (a 512-tile k_ffn
+// launch took 14 us for 2 us of work; round 5, seen in the listing).
+// (stage_copy: the copy alone -- n_floats a multiple of 4, both sides 16-byte aligned; no barrier)
+__device__ __forceinline__ void stage_copy(float* lds, const float* blob, int n_floats) {
   const f4* src = reinterpret_cast<const f4*>(blob);
   f4* dst = reinterpret_cast<f4*>(lds);
-  for (int i = threadIdx.x; i < (n_floats >> 2); i += blockDim.x) dst[i] = src[i];
+  const int n4 = n_floats >> 2, step = blockDim.x;
+  int i = threadIdx.x;
+  for (; i + 7 * step < n4; i += 8 * step) {
+    f4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[i + u * step];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dst[i + u * step] = v[u];
+  }
+  for (; i + step < n4; i += 2 * step) {
+    const f4 a = src[i], b = src[i + step];
+    dst[i] = a;
+    dst[i + step] = b;
+  }
+  for (; i < n4; i += step) dst[i] = src[i];
+}
+__device__ __forceinline__ void stage_blob(float* lds, const float* blob, int n_floats) {
+  stage_copy(lds, blob, n_floats);
   __syncthreads();
 }
 
