@@ -47,7 +47,7 @@ __global__ void k_colsum(ColsumJobs jobs, int64_t rows, int stride);
 // ---- pieces of the SDE decoder backward reused by the MLP decoder backward (decoder_bwd.hip)
 struct InitV { enum : int { DGAM = 0, DBET = 64, SIZE = 128 }; };               // per-wave vector slots of k_dec_init_bwd
 __global__ void k_l2_wta(const float* loc, const float* y, const uint8_t* mask, int N, int K, int T, int32_t* best, float* minsum,
-                         int32_t* cnt);
+                         int32_t* cnt, int KP);
 __global__ void k_l2_finalize(const float* minsum, const int32_t* cnt, int N, float* scal);
 __global__ void k_init_sel(const float* img, const float* local, const float* global, const int32_t* best, int N, float* y0, float* gsel);
 __global__ void k_dec_init_bwd(const float* img, const float* local, const float* gsel, const float* DY0, const int32_t* best, int N,

@@ -294,7 +294,12 @@ int trajsde_mlp_decoder_l2_backward(int32_t N, int num_modes, int future_steps, 
   const int ntiles = (N + 15) / 16;
   const float* init_img = blob_bwd + MlpDecBwdBlob::INIT;
   const WgradCtx wc{st, w.part, w.cs, nullptr, w.parts};
-  TS_LAUNCH(k_l2_wta, cdiv(N, 256), 256, 0, st, loc, y, reg_mask, N, K, T, w.best, w.minsum, w.cnt);
+  {
+    TS_REQUIRE(K >= 1 && K <= 256, "mlp decoder backward: 1 <= num_modes <= 256");
+    int KP = 1;
+    while (KP < K) KP <<= 1;
+    TS_LAUNCH(k_l2_wta, cdiv(N, 256 / KP), 256, 0, st, loc, y, reg_mask, N, K, T, w.best, w.minsum, w.cnt, KP);
+  }
   TS_LAUNCH(k_l2_finalize, 1, 1024, 0, st, w.minsum, w.cnt, N, w.scal);
   TS_HIP(hipMemcpyAsync(loss, w.scal, sizeof(float), hipMemcpyDeviceToDevice, st));
   if (best_mode) TS_HIP(hipMemcpyAsync(best_mode, w.best, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st));

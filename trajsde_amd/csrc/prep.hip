@@ -22,19 +22,23 @@
 
 namespace tsde {
 
+// one thread per (actor, future step) -- a thread per actor walked its F steps one dependent load at a time: 16 us a forward
 __global__ void k_rotate(const float* __restrict__ ang, int N, const float* __restrict__ y, int F,
                          float* __restrict__ rot, float* __restrict__ y_rot) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
+  const int per = F > 0 && y != nullptr ? F : 1;
+  const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= int64_t(N) * per) return;
+  const int i = int(idx / per), t = int(idx - int64_t(i) * per);
   const float s = sinf(ang[i]), c = cosf(ang[i]);
-  f4 r = {c, -s, s, c};
-  *reinterpret_cast<f4*>(rot + 4 * i) = r;
-  if (y != nullptr)
-    for (int t = 0; t < F; ++t) {
-      const float a = y[(int64_t(i) * F + t) * 2], b = y[(int64_t(i) * F + t) * 2 + 1];
-      y_rot[(int64_t(i) * F + t) * 2] = a * c + b * s;        // [a b] @ [[c,-s],[s,c]]
-      y_rot[(int64_t(i) * F + t) * 2 + 1] = b * c - a * s;
-    }
+  if (t == 0) {
+    f4 r = {c, -s, s, c};
+    *reinterpret_cast<f4*>(rot + 4 * i) = r;
+  }
+  if (y != nullptr && F > 0) {
+    const float a = y[(int64_t(i) * F + t) * 2], b = y[(int64_t(i) * F + t) * 2 + 1];
+    y_rot[(int64_t(i) * F + t) * 2] = a * c + b * s;        // [a b] @ [[c,-s],[s,c]]
+    y_rot[(int64_t(i) * F + t) * 2 + 1] = b * c - a * s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- the graph stage in six launches
@@ -319,8 +323,14 @@ __device__ __forceinline__ void ext_nodes_body(int i, int N, int A, int H, const
   orig[i] = o;
   nus[i] = (i < N ? source[batch[i]] : source[i - N]) == 0;        // ENC:73-74, 103
   int first = 0;                                                     // torch.argmax of an all-false row is 0
-  for (int t = H - 1; t >= 0; --t)
-    if (bos[int64_t(o) * H + t]) first = t;
+  {
+    uint8_t bv[32];                                                  // all H <= 32 bytes requested before the first is looked at
+#pragma unroll
+    for (int t = 0; t < 32; ++t) bv[t] = bos[int64_t(o) * H + (t < H ? t : H - 1)];
+#pragma unroll
+    for (int t = 31; t >= 0; --t)
+      if (t < H && bv[t]) first = t;
+  }
   eos[i] = (H - 1) - first;                                          // ENC:187 (ref_time = H-1)
   pick_slot[i] = i < N ? slot : A + (i - N);
 }
@@ -404,7 +414,14 @@ __device__ __forceinline__ void lane_feat_body(int l, int L, int P, const float*
                                                float* __restrict__ feat) {
   if (l >= L) return;
   float len = 0.f;
-  for (int j = 0; j < P; ++j) len += 1.0f - pad[int64_t(l) * P + j];
+  for (int j0 = 0; j0 < P; j0 += 8) {                                // eight paddings in flight, summed in order
+    float pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pv[u] = pad[int64_t(l) * P + (j0 + u < P ? j0 + u : P - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (j0 + u < P) len += 1.0f - pv[u];
+  }
   int last = int(len - 1.0f);
   if (last < 0) last += P;
   feat[2 * l] = lp[(int64_t(l) * P + last) * 2] - lp[int64_t(l) * P * 2];
@@ -1006,7 +1023,7 @@ int trajsde_export_senders(int on) {
 int trajsde_rotate(const float* rotate_angles, int32_t N, const float* y, int32_t F, float* rotate_mat, float* y_rot, void* stream) {
   TS_REQUIRE(rotate_angles && rotate_mat && N > 0, "rotate: bad argument");
   TS_REQUIRE(y == nullptr || y_rot != nullptr, "rotate: y given without y_rot");
-  k_rotate<<<cdiv(N, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(rotate_angles, N, y, F, rotate_mat, y_rot);
+  k_rotate<<<cdiv(int64_t(N) * (y != nullptr && F > 0 ? F : 1), 256), 256, 0, static_cast<hipStream_t>(stream)>>>(rotate_angles, N, y, F, rotate_mat, y_rot);
   TS_LAUNCH_CHECK("k_rotate");
   return TRAJSDE_OK;
 }
