@@ -103,7 +103,7 @@ def main():
                                                           "bytes_per_row": "(d e_pre, s) 2 x 256 B + (d s_pre 256 B + geometry 16 B) read once for both branches"}}))
     tot = sum(r[0] for r in rows)
     print(f"kernel time of one step (HIP events, serial): {tot:.2f} ms")
-    for ms_k, name, n in rows[:28]:
+    for ms_k, name, n in rows[:int(os.environ.get("TSB_ROWS", "28"))]:
         print(f"  {ms_k:8.3f} ms  x{n:<4d} {name}")
 
 

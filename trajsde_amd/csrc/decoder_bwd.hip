@@ -920,7 +920,14 @@ __global__ __launch_bounds__(256) void k_reduce_partials(WgradJobs jobs, const f
   const int j = blockIdx.x * 32 + lane;
   float s = 0.f, ws = 0.f, wc = 0.f;
   if (j < 4096) {
-    int p = sl;                                         // four loads in flight; the additions in the order of the plain loop
+    int p = sl;                                         // sixteen loads in flight; the additions in the order of the plain loop
+    for (; p + 120 < P; p += 128) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = part[int64_t(p + 8 * u) * 4096 + j];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
     for (; p + 24 < P; p += 32) {
       const float v0 = part[int64_t(p) * 4096 + j], v1 = part[int64_t(p + 8) * 4096 + j];
       const float v2 = part[int64_t(p + 16) * 4096 + j], v3 = part[int64_t(p + 24) * 4096 + j];
@@ -932,13 +939,22 @@ __global__ __launch_bounds__(256) void k_reduce_partials(WgradJobs jobs, const f
     for (; p < P; p += 8) s += part[int64_t(p) * 4096 + j];
   } else if (j < 4096 + 64) {
     const int o = j - 4096;
-    for (int p = sl; p < P; p += 8) {
-      const float v = cs[int64_t(p) * 64 + o];
-      s += v;
-      if (time_cols) {
-        const int k = p / chunks_per_group;
-        ws = fmaf(step_tab[k * 8 + 3], v, ws);
-        wc = fmaf(step_tab[k * 8 + 4], v, wc);
+    // (eight partials in flight, consumed in the order of the plain loop: these 64 threads a problem walked P / 8 dependent loads
+    //  and were the launch's critical path)
+    for (int p0 = sl; p0 < P; p0 += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p0 + 8 * u < P ? cs[int64_t(p0 + 8 * u) * 64 + o] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + 8 * u;
+        if (p >= P) break;
+        s += v[u];
+        if (time_cols) {
+          const int k = p / chunks_per_group;
+          ws = fmaf(step_tab[k * 8 + 3], v[u], ws);
+          wc = fmaf(step_tab[k * 8 + 4], v[u], wc);
+        }
       }
     }
   }
@@ -1013,7 +1029,14 @@ __global__ __launch_bounds__(256) void k_reduce_partials_q(ReduceJobs jobs, cons
   const int j = blockIdx.x * 32 + lane;
   float s = 0.f, ws = 0.f, wc = 0.f;
   if (j < 4096) {
-    int p = sl;                                         // four loads in flight; the additions in the order of the plain loop
+    int p = sl;                                         // sixteen loads in flight; the additions in the order of the plain loop
+    for (; p + 120 < P; p += 128) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = part[int64_t(p + 8 * u) * 4096 + j];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
     for (; p + 24 < P; p += 32) {
       const float v0 = part[int64_t(p) * 4096 + j], v1 = part[int64_t(p + 8) * 4096 + j];
       const float v2 = part[int64_t(p + 16) * 4096 + j], v3 = part[int64_t(p + 24) * 4096 + j];
@@ -1025,13 +1048,22 @@ __global__ __launch_bounds__(256) void k_reduce_partials_q(ReduceJobs jobs, cons
     for (; p < P; p += 8) s += part[int64_t(p) * 4096 + j];
   } else if (j < 4096 + 64 && (bias || time_cols)) {
     const int o = j - 4096;
-    for (int p = sl; p < P; p += 8) {
-      const float v = cs[int64_t(p) * 64 + o];
-      s += v;
-      if (time_cols) {
-        const int k = p / chunks_per_group;
-        ws = fmaf(step_tab[k * 8 + 3], v, ws);
-        wc = fmaf(step_tab[k * 8 + 4], v, wc);
+    // (eight partials in flight, consumed in the order of the plain loop: these 64 threads a problem walked P / 8 dependent loads
+    //  and were the launch's critical path)
+    for (int p0 = sl; p0 < P; p0 += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p0 + 8 * u < P ? cs[int64_t(p0 + 8 * u) * 64 + o] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + 8 * u;
+        if (p >= P) break;
+        s += v[u];
+        if (time_cols) {
+          const int k = p / chunks_per_group;
+          ws = fmaf(step_tab[k * 8 + 3], v[u], ws);
+          wc = fmaf(step_tab[k * 8 + 4], v[u], wc);
+        }
       }
     }
   }
