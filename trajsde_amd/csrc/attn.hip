@@ -304,6 +304,7 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
   NoStamps st;
 #endif
   const int Cw = stream_length(smap, wid * (16 * NT));     // a wave's 16 NT streams are equally long
+  prioritize_younger_half();
   for (int it = 0; it < Cw; ++it) {
     keep_lds_reads_here();
     f4 ge[NT];

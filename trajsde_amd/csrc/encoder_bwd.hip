@@ -498,7 +498,21 @@ __global__ __launch_bounds__(1024) void k_rowscale_colsum(const float* __restric
   const int c = threadIdx.x & 63, sub = threadIdx.x >> 6;
   const int64_t per = (R + gridDim.x - 1) / gridDim.x, lo = int64_t(blockIdx.x) * per, hi = lo + per < R ? lo + per : R;
   float acc = 0.f, ss = 0.f;
-  for (int64_t r = lo + sub; r < hi; r += 16) {
+  int64_t r = lo + sub;
+  for (; r + 112 < hi; r += 128) {                       // eight rows in flight, consumed in the order of the plain loop
+    float sv[8], av[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      sv[u] = s[r + 16 * u];
+      av[u] = A[(r + 16 * u) * 64 + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc = fmaf(sv[u], av[u], acc);
+      ss += sv[u];
+    }
+  }
+  for (; r < hi; r += 16) {
     const float sv = s[r];
     acc = fmaf(sv, A[r * 64 + c], acc);
     ss += sv;

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
   PhaseClock<8> clk;                                               // diagnostic builds only (stamps.hpp, tools/phase_stamps.py gmf)
   clk.start();
   unsigned long long tiles_done = 0;
+  prioritize_younger_half();
   // xcd_block(): the workgroups of one XCD walk consecutive targets, so a round of them gathers one scene's node rows through ONE L2
   // (dealt by blockIdx, a scene's 256 targets were spread over all eight: every L2 had to hold the node rows of every scene in flight)
   for (int64_t node = xcd_block() * GMF_WAVES + wv; node < N; node += stride) {

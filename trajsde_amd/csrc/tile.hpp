@@ -734,6 +734,20 @@ __device__ __forceinline__ float load_elem_st(const void* base, int64_t idx, boo
 // ds_reads next to their MFMAs (no instruction is emitted).
 __device__ __forceinline__ void keep_lds_reads_here() { asm volatile("" ::: "memory"); }
 
+// Static priority for the second-dispatched half of a workgroup's waves (MI355X_MICROARCH.md "Two waves per SIMD", item 4): the two
+// waves of a SIMD are arbitrated by priority, then age, and the younger one loses every contested slot; one s_setprio 1 for that half
+// before the main loop (no per-phase flips) hands it the older half's timing.  The guard must be a SCALAR comparison (readfirstlane):
+// on a vector condition the compiler makes the scalar instruction unconditional.  -DTSDE_PRIO_YOUNG=1 (A/B: profiles/r05_ab_runs.md).
+#ifndef TSDE_PRIO_YOUNG
+#define TSDE_PRIO_YOUNG 0
+#endif
+__device__ __forceinline__ void prioritize_younger_half() {
+#if TSDE_PRIO_YOUNG
+  const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), half = __builtin_amdgcn_readfirstlane(int(blockDim.x >> 7));
+  if (wave >= half) __builtin_amdgcn_s_setprio(1);
+#endif
+}
+
 // stage a packed weight blob into LDS (whole workgroup), then barrier.  EIGHT loads of a thread are requested before the first is
 // stored: written as `for (i ..) dst[i] = src[i]` the compiler emitted load, wait, store per iteration -- a 128 KB image staged by
 // 512 threads was 16 global-memory latencies in a row, ~10 us at the head of EVERY launch of every tile kernel (a 512-tile k_ffn
