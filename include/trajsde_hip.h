@@ -82,6 +82,44 @@ int64_t trajsde_blob_floats(int stage, int num_layers, int num_modes);
 int trajsde_pack_weights(int stage, int num_layers, int num_modes, const float* const* params, int n_params,
                          float* blob, int64_t blob_floats, void* stream);
 
+/* The weight images of SEVERAL stages in three launches over one job table in device memory (ABI 10).  A training step re-packs
+ * every image after the optimizer step (the reference's modules read their nn.Parameters directly, MODEL:104-115: packing is this
+ * library's cost, so it is kept to one call): zero the blobs | first-pass jobs | second-pass jobs.  The merged table is built when
+ * the arguments are first seen, written to `table_host` (PINNED host memory) and copied to `table_dev` on `stream`; while the item
+ * list, the parameter addresses, the blob addresses and `table_dev` stay the same, later calls only launch.  `fresh` != 0 forces
+ * the upload (the caller re-allocated or wrote `table_dev`).  Both tables hold trajsde_pack_many_table_bytes(items, n) bytes, are
+ * owned by the caller and must not be written by it while calls with these arguments continue.  Blobs: distinct, 16-byte aligned.
+ * The images are bit-identical to those of n calls of trajsde_pack_weights. */
+typedef struct {
+  int32_t stage, num_layers, num_modes, n_params;
+  const float* const* params; /* n_params device pointers in the order of trajsde_param_name(stage, ...) */
+  float* blob;                /* >= trajsde_blob_floats(stage, ...) floats */
+  int64_t blob_floats;
+} trajsde_pack_item;
+int64_t trajsde_pack_many_table_bytes(const trajsde_pack_item* items, int n);
+int trajsde_pack_weights_many(const trajsde_pack_item* items, int n, void* table_host, void* table_dev, int64_t table_bytes,
+                              int fresh, void* stream);
+
+/* ---- the end of a training step (ABI 10): two element-wise launches in place of ~14 ------------------------------------------
+ * trajsde_grad_gather_add: dst[i] += src[index[i]] * (scale[0] * mult) for up to 8 (dst, src, index) items in ONE launch -- the
+ * stage backward calls hand back their gradients as one buffer per stage in the order of trajsde_param_name; the training loop keeps
+ * one flat gradient tensor in the order of model.parameters() (what `loss.backward()` fills through autograd in the reference,
+ * MODEL:104-115).  `scale`: a device scalar (the incoming gradient of the loss) or NULL for 1.
+ * trajsde_adamw_step: torch.optim.AdamW's single-tensor update (MODEL:204-207; amsgrad and maximize off) over n elements in one
+ * launch, operation by operation as torch/optim/adamw.py performs it; the caller forms the scalars as torch does:
+ *   decay = 1 - lr * weight_decay, w1 = 1 - beta1, w2 = 1 - beta2, inv_bias2_sqrt = 1 / sqrt(1 - beta2^step) (in double, then
+ *   rounded: torch divides a tensor by a host scalar that way), neg_step = -(lr / (1 - beta1^step)), step counted from 1. */
+typedef struct {
+  float* dst;
+  const float* src;
+  const int64_t* index;
+  int64_t n;
+  float mult;
+} trajsde_gather_item;
+int trajsde_grad_gather_add(const trajsde_gather_item* items, int n_items, const float* scale, void* stream);
+int trajsde_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float decay, float w1,
+                       float beta2, float w2, float inv_bias2_sqrt, float eps, float neg_step, void* stream);
+
 /* ---- the batch ------------------------------------------------------------ */
 typedef struct {
   int32_t N;            /* actors                                   */

@@ -132,6 +132,38 @@ for stage in range(0, 11):
             rc(L.trajsde_pack_weights(stage, nl, K, arr, n_given, fake(9), floats, stream))
         arr[n // 2] = None
         rc(L.trajsde_pack_weights(stage, nl, K, arr, n, fake(9), nf, stream))
+# the merged table of several stages (host side: plans, re-basing, the table written to the caller's pinned buffer)
+sets = [[(0, 3, 6), (5, 3, 6), (1, 3, 6), (4, 3, 6), (2, 3, 6), (3, 3, 6)], [(0, 3, 6), (1, 4, 10), (10, 3, 6)], [(6, 3, 6), (7, 30, 6)], [(99, 1, 1)]]
+for entries in sets:
+    items = (_lib.PackItem * len(entries))()
+    keep = []
+    for k, (it, (stage, nl, K)) in enumerate(zip(items, entries)):
+        n = max(L.trajsde_param_count(stage, nl, K), 0)
+        arr = (C.c_void_p * max(n, 1))(*[fake(300 + 200 * k + i) for i in range(max(n, 1))])
+        keep.append(arr)
+        it.stage, it.num_layers, it.num_modes, it.n_params = stage, nl, K, n
+        it.params, it.blob, it.blob_floats = C.cast(arr, C.c_void_p), fake(40 + k), max(L.trajsde_blob_floats(stage, nl, K), 0)
+    need = rc(L.trajsde_pack_many_table_bytes(items, len(entries)))
+    host = C.create_string_buffer(max(need, 64))
+    for nbytes, fresh in ((max(need, 0), 1), (max(need, 0), 0), (max(need - 1, 0), 0)):
+        rc(L.trajsde_pack_weights_many(items, len(entries), host, fake(60), nbytes, fresh, stream))
+    if len(entries) > 1:
+        items[1].blob = items[0].blob                      # two items on one blob: refused
+        rc(L.trajsde_pack_weights_many(items, len(entries), host, fake(60), max(need, 0), 0, stream))
+rc(L.trajsde_pack_many_table_bytes(None, 1))
+rc(L.trajsde_pack_weights_many(None, 1, None, None, 0, 0, stream))
+# the step's closing launches: argument checks
+gi = (_lib.GatherItem * 9)()
+for k in range(9):
+    gi[k].dst, gi[k].src, gi[k].index, gi[k].n, gi[k].mult = fake(70), fake(71), fake(72), 100 * k, 1.0
+for n_items in (0, 1, 8, 9):
+    rc(L.trajsde_grad_gather_add(gi, n_items, None, stream))
+gi[1].n = -1
+rc(L.trajsde_grad_gather_add(gi, 2, fake(73), stream))
+rc(L.trajsde_grad_gather_add(None, 1, None, stream))
+for n_el, b2 in ((0, 31.6), (1000, 31.6), (1001, 0.0), (1001, float('inf')), (-1, 31.6)):
+    rc(L.trajsde_adamw_step(fake(80), fake(81), fake(82), fake(83), n_el, 0.99, 0.1, 0.999, 0.001, b2, 1e-8, -1e-3, stream))
+rc(L.trajsde_adamw_step(None, fake(81), fake(82), fake(83), 10, 0.99, 0.1, 0.999, 0.001, 31.6, 1e-8, -1e-3, stream))
 rc(L.trajsde_rotate(fake(1), 100, None, 0, fake(2), None, stream))
 rc(L.trajsde_rotate(None, 100, fake(3), 20, fake(2), fake(4), stream))
 rc(L.trajsde_sde_step(0, fake(1), fake(2), fake(3), None, 0, C.byref(nz), stream))

@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol(repo_root):
     lib = _lib.lib()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.trajsde_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.trajsde_abi_version() == _lib.ABI_VERSION == 10
     # the library of the alternative kernel forms (tests and A/B tools load it through TRAJSDE_LIB) speaks the same ABI
     import ctypes
     alt = ctypes.CDLL(_lib.ALT_LIB_PATH)
@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol(repo_root):
 
 
 # ---- prototype-level check: names alone would let an argument added on one side only slip through ----------
-_STRUCTS = {"trajsde_batch": "Batch", "trajsde_graph": "Graph", "trajsde_noise": "Noise", "trajsde_dropout": "Dropout"}
+_STRUCTS = {"trajsde_batch": "Batch", "trajsde_graph": "Graph", "trajsde_noise": "Noise", "trajsde_dropout": "Dropout",
+            "trajsde_pack_item": "PackItem", "trajsde_gather_item": "GatherItem"}
 
 
 def _header_prototypes(text):

@@ -15,11 +15,12 @@ STAGE_ENCODER_GRID, STAGE_DECODER_MLP, STAGE_DECODER_MLP_BWD, STAGE_ENCODER_GRID
 STAGE_DECODER_NLL_BWD = 10
 
 
-ABI_VERSION = 9          # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4);
+ABI_VERSION = 10         # trajsde_graph grew aa_src / la_lane (2); trajsde_dropout arguments (3); training tapes (4);
                          # device-side list lengths + trajsde_graph_prepare_async (5); encoder tape / scratch split (6);
                          # trajsde_noise.seed_dev: Philox key read on the device (7); trajsde_aggregator_prepare /
                          # _forward_prepared: the relative-pose embedding as a call of its own (8);
-                         # trajsde_encoder_grid_forward_train / _backward_train: dropout of the vanilla encoder (9)
+                         # trajsde_encoder_grid_forward_train / _backward_train: dropout of the vanilla encoder (9);
+                         # trajsde_pack_weights_many, trajsde_grad_gather_add, trajsde_adamw_step: a training step's small launches (10)
 
 
 class TrajsdeError(RuntimeError):
@@ -52,6 +53,15 @@ class Graph(C.Structure):
                 ("aa_src", C.c_void_p), ("la_lane", C.c_void_p), ("counts", C.c_void_p), ("exact", C.c_int32)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("stage", C.c_int32), ("num_layers", C.c_int32), ("num_modes", C.c_int32), ("n_params", C.c_int32),
+                ("params", C.c_void_p), ("blob", C.c_void_p), ("blob_floats", C.c_int64)]
+
+
+class GatherItem(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("index", C.c_void_p), ("n", C.c_int64), ("mult", C.c_float)]
+
+
 _lib: Optional[C.CDLL] = None
 
 # every symbol include/trajsde_hip.h declares: (restype, argtypes)
@@ -67,6 +77,10 @@ SIGNATURES = {
     "trajsde_param_name": (C.c_char_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "trajsde_blob_floats": (I64, [C.c_int, C.c_int, C.c_int]),
     "trajsde_pack_weights": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(P), C.c_int, P, I64, P]),
+    "trajsde_pack_many_table_bytes": (I64, [C.POINTER(PackItem), C.c_int]),
+    "trajsde_pack_weights_many": (C.c_int, [C.POINTER(PackItem), C.c_int, P, P, I64, C.c_int, P]),
+    "trajsde_grad_gather_add": (C.c_int, [C.POINTER(GatherItem), C.c_int, P, P]),
+    "trajsde_adamw_step": (C.c_int, [P, P, P, P, I64, F32, F32, F32, F32, F32, F32, F32, P]),
     "trajsde_rotate": (C.c_int, [P, I32, P, I32, P, P, P]),
     "trajsde_graph_ws_bytes": (I64, [C.POINTER(Batch)]),
     "trajsde_graph_prepare": (C.c_int, [C.POINTER(Batch), P, F32, C.POINTER(Noise), P, I64, C.POINTER(Graph), P]),

@@ -1190,8 +1190,13 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     TS_REQUIRE(!missing, "aggregator_backward: parameter table lacks an entry of " + p);
     const NodeBlockTape tp{w.agg[l], w.xn[l], w.x1[l], w.xn2[l]};
     if (int rc = node_block_backward(lb + AggLayerBwdL::NODE, tp, dcur, N, w.nb, wc, gr, w.dagg, w.dxn, st, drop_of(l))) return rc;
-    TS_HIP(hipMemsetAsync(w.DKN, 0, size_t(N) * 64 * sizeof(float), st));
-    TS_HIP(hipMemsetAsync(w.DVN, 0, size_t(N) * 64 * sizeof(float), st));
+    // (carved one behind the other: one fill when nothing sits between them)
+    if (w.DVN >= w.DKN + N * 64 && w.DVN - w.DKN < N * 64 + 1024) {
+      TS_HIP(hipMemsetAsync(w.DKN, 0, size_t(w.DVN - w.DKN + N * 64) * sizeof(float), st));
+    } else {
+      TS_HIP(hipMemsetAsync(w.DKN, 0, size_t(N) * 64 * sizeof(float), st));
+      TS_HIP(hipMemsetAsync(w.DVN, 0, size_t(N) * 64 * sizeof(float), st));
+    }
     if (num_heads == 4) {
       TS_LAUNCH((k_gattn_bwd<4, true>), xcd_grid(cdiv(N, 4)), 256, 0, st, lb + AggLayerBwdL::ATTN, g->g_segptr, g->g_src, w.rel, w.q[l], w.kn[l], w.vn[l],
                 w.agg[l], w.dagg, w.stats[l], N, w.DQ, w.DKN, w.DVN, w.RL, w.SS, w.DAGGM, w.EA[l], w.ED[l], w.UZ[l], w.asym, drop_of(l));

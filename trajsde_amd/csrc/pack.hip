@@ -255,11 +255,8 @@ __device__ __forceinline__ void k_pack_in2f(int i, const float* __restrict__ in2
   dst[i] = __builtin_bit_cast(unsigned short, low ? l : h);
 }
 
-// one thread per element; blockIdx.y = job
-__global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
-  const PackJob& J = jobs.j[blockIdx.y];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= J.count) return;
+// element i of job J
+__device__ __forceinline__ void pack_element(const PackJob& J, int i) {
   switch (J.kind) {
     case PK_VEC: k_pack_vec(i, J.src, J.dst, J.count, J.p0, J.p1); break;
     case PK_COL: k_pack_col(i, J.src, J.dst, J.count, J.p0, J.p1, J.p2); break;
@@ -276,6 +273,31 @@ __global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
     case PK_IN2F: k_pack_in2f(i, J.src, J.src2, reinterpret_cast<unsigned short*>(J.dst)); break;
     case PK_SPLIT: k_pack_split(i, J.src, reinterpret_cast<unsigned short*>(J.dst), J.p0, J.p1, J.p2, J.p3, J.p4 & 0x3FFFFFFF, J.p4 >> 30); break;
   }
+}
+
+// one thread per element; blockIdx.y = job
+__global__ __launch_bounds__(256) void k_pack_jobs(const PackJobs jobs) {
+  const PackJob& J = jobs.j[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= J.count) return;
+  pack_element(J, i);
+}
+
+// The same over a job table in DEVICE memory (trajsde_pack_weights_many: the tables of all the stages of a training step, uploaded
+// once and re-used while the parameter and blob addresses stay): jobs [first, first + gridDim.y).
+__global__ __launch_bounds__(256) void k_pack_jobs_table(const PackJob* __restrict__ table, int first) {
+  const PackJob J = table[first + blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= J.count) return;
+  pack_element(J, i);
+}
+// blobs to zero: job q = (dst, count); gridDim.x workgroups stride over a blob in float4 steps
+__global__ __launch_bounds__(256) void k_pack_zero_table(const PackJob* __restrict__ table) {
+  const PackJob J = table[blockIdx.y];
+  float* __restrict__ d = J.dst;
+  const int n4 = J.count >> 2;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) reinterpret_cast<float4*>(d)[i] = float4{0.f, 0.f, 0.f, 0.f};
+  if (blockIdx.x == 0 && int(threadIdx.x) < (J.count & 3)) d[4 * n4 + threadIdx.x] = 0.f;
 }
 
 struct Packer {
@@ -1157,7 +1179,7 @@ int trajsde_range_status(int reset, uint32_t* sites_out, void* stream) {
   msg += " -- the results of the affected launches are not valid; rebuild with TRAJSDE_SPLIT=bf16x6 for fp32's exponent range";
   return tsde::fail(TRAJSDE_ERR_UNSUPPORTED, msg);
 }
-int trajsde_abi_version(void) { return 9; }
+int trajsde_abi_version(void) { return 10; }
 
 int trajsde_param_count(int stage, int num_layers, int num_modes) {
   Packer P{true};
@@ -1201,6 +1223,7 @@ struct PackPlan {
   int64_t need_floats;
   std::vector<const float*> params;
   std::vector<PackLaunch> tables;          // built against a stand-in blob address (pack_standin_blob): re-based per call
+  std::vector<PackJob> jobs;               // the same jobs as one list (trajsde_pack_weights_many merges the stages' lists)
   int standin = 0;                         // which stand-in range (one that holds none of the parameters)
 };
 // an address range no allocation lives in (2^44 .. 2^44 + blob size): the recipe's `blob + offset` arithmetic stays ordinary pointer
@@ -1208,13 +1231,14 @@ struct PackPlan {
 float* pack_standin_blob(int slot = 0) { return reinterpret_cast<float*>(uintptr_t(1) << (44 - slot)); }
 // the launch tables of one stage's packing: the recipe run against `params`, destinations relative to a null blob
 void build_pack_tables(int stage, int num_layers, int num_modes, const std::vector<std::string>& names, const float* const* params,
-                       std::vector<PackLaunch>& out, int standin) {
+                       std::vector<PackLaunch>& out, std::vector<PackJob>& flat, int standin) {
   Packer wet{false};
   wet.names = names;
   wet.params = params;
   wet.blob = pack_standin_blob(standin);
   wet.stream = nullptr;
   run_recipe(wet, stage, num_layers, num_modes);
+  flat = wet.jobs;
   for (int pass = 0; pass < 2; ++pass) {
     PackLaunch cur;
     cur.n = cur.max_count = 0;
@@ -1230,6 +1254,97 @@ void build_pack_tables(int stage, int num_layers, int num_modes, const std::vect
     if (cur.n) out.push_back(cur);
   }
 }
+
+// A training loop re-packs its blobs after every optimizer step from the SAME parameter addresses: the launch tables of a
+// (stage, sizes, parameter addresses) triple are built once -- two runs of the recipe, whose name lookups are a linear search over
+// ~130 strings each, were ~0.1 ms of host time a call -- and re-used with the destination re-based onto the call's blob.
+std::mutex& plan_mutex() {
+  static std::mutex mu;
+  return mu;
+}
+int get_pack_plan(int stage, int num_layers, int num_modes, const float* const* params, int n_params, PackPlan& plan_copy) {
+  static std::vector<PackPlan> plans;
+  {
+    std::lock_guard<std::mutex> lk(plan_mutex());
+    for (const PackPlan& pl : plans)
+      if (pl.stage == stage && pl.nl == num_layers && pl.K == num_modes && int(pl.params.size()) == n_params &&
+          std::equal(pl.params.begin(), pl.params.end(), params)) {
+        plan_copy = pl;
+        return TRAJSDE_OK;
+      }
+  }
+  Packer dry{true};
+  if (!run_recipe(dry, stage, num_layers, num_modes)) return fail(TRAJSDE_ERR_INVALID, "unknown stage");
+  TS_REQUIRE(n_params == int(dry.names.size()), "pack_weights: parameter count does not match trajsde_param_count");
+  for (int i = 0; i < n_params; ++i) TS_REQUIRE(params[i] != nullptr, "pack_weights: null parameter " + dry.names[i]);
+  plan_copy = PackPlan();
+  plan_copy.stage = stage; plan_copy.nl = num_layers; plan_copy.K = num_modes;
+  plan_copy.params.assign(params, params + n_params);
+  plan_copy.need_floats = trajsde_blob_floats(stage, num_layers, num_modes);
+  for (int slot = 0; slot < 8; ++slot) {                // a stand-in range that no parameter lives in
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(pack_standin_blob(slot)), hi = lo + uintptr_t(plan_copy.need_floats) * sizeof(float);
+    bool clash = false;
+    for (int i = 0; i < n_params; ++i) {
+      const uintptr_t u = reinterpret_cast<uintptr_t>(params[i]);
+      clash = clash || (u + (uintptr_t(1) << 32) >= lo && u < hi);
+    }
+    plan_copy.standin = slot;
+    if (!clash) break;
+  }
+  build_pack_tables(stage, num_layers, num_modes, dry.names, params, plan_copy.tables, plan_copy.jobs, plan_copy.standin);
+  std::lock_guard<std::mutex> lk(plan_mutex());
+  if (plans.size() >= 64) plans.clear();
+  plans.push_back(plan_copy);
+  return TRAJSDE_OK;
+}
+// every address inside the plan's stand-in blob -- destinations, and the sources of second-pass jobs that read first-pass results --
+// moves onto `blob`
+void rebase_job(PackJob& j, const PackPlan& pl, float* blob) {
+  const uintptr_t F = reinterpret_cast<uintptr_t>(pack_standin_blob(pl.standin)), Fend = F + uintptr_t(pl.need_floats) * sizeof(float);
+  auto rebase = [&](const float* q) -> const float* {
+    const uintptr_t u = reinterpret_cast<uintptr_t>(q);
+    return (u >= F && u < Fend) ? blob + (u - F) / sizeof(float) : q;
+  };
+  j.dst = const_cast<float*>(rebase(j.dst));
+  j.src = rebase(j.src);
+  j.src2 = rebase(j.src2);
+  j.src3 = rebase(j.src3);
+}
+
+// number of jobs of a stage's recipe (independent of the addresses): the recipe run wet over made-up parameter addresses
+int pack_job_count(int stage, int num_layers, int num_modes) {
+  Packer dry{true};
+  if (!run_recipe(dry, stage, num_layers, num_modes)) return -1;
+  std::vector<const float*> fake(dry.names.size());
+  for (size_t i = 0; i < fake.size(); ++i) fake[i] = reinterpret_cast<const float*>((uintptr_t(1) << 40) + (uintptr_t(i) << 28));
+  Packer wet{false};
+  wet.names = dry.names;
+  wet.params = fake.data();
+  wet.blob = pack_standin_blob(0);
+  run_recipe(wet, stage, num_layers, num_modes);
+  return int(wet.jobs.size());
+}
+
+// the merged table of several stages (trajsde_pack_weights_many), as last uploaded to `table_dev`
+struct ManyPlan {
+  std::vector<trajsde_pack_item> items;
+  std::vector<std::vector<const float*>> params;
+  void* table_dev = nullptr;
+  std::vector<PackJob> table;              // [zero jobs | first-pass jobs | second-pass jobs]
+  int n_zero = 0, n0 = 0, max0 = 0, n1 = 0, max1 = 0;
+  uint64_t serial = 0;
+  bool matches(const trajsde_pack_item* it, int n, void* dev) const {
+    if (int(items.size()) != n || dev != table_dev) return false;
+    for (int i = 0; i < n; ++i) {
+      const trajsde_pack_item& a = items[i];
+      if (a.stage != it[i].stage || a.num_layers != it[i].num_layers || a.num_modes != it[i].num_modes || a.n_params != it[i].n_params ||
+          a.blob != it[i].blob || a.blob_floats != it[i].blob_floats)
+        return false;
+      if (!std::equal(params[i].begin(), params[i].end(), it[i].params)) return false;
+    }
+    return true;
+  }
+};
 }  // namespace
 extern "C" {
 
@@ -1237,66 +1352,134 @@ int trajsde_pack_weights(int stage, int num_layers, int num_modes, const float* 
                          float* blob, int64_t blob_floats, void* stream) {
   TS_REQUIRE(params && blob, "pack_weights: null pointer");
   TS_REQUIRE(n_params >= 0 && n_params < (1 << 20), "pack_weights: bad parameter count");
-  // A training loop re-packs six blobs after every optimizer step from the SAME parameter addresses: the launch tables of a
-  // (stage, sizes, parameter addresses) triple are built once -- two runs of the recipe, whose name lookups are a linear search over
-  // ~130 strings each, were ~0.1 ms of host time a call -- and re-used with the destination re-based onto this call's blob.
-  static std::mutex mu;
-  static std::vector<PackPlan> plans;
   PackPlan plan_copy;
-  bool hit = false;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    for (const PackPlan& pl : plans)
-      if (pl.stage == stage && pl.nl == num_layers && pl.K == num_modes && int(pl.params.size()) == n_params &&
-          std::equal(pl.params.begin(), pl.params.end(), params)) {
-        plan_copy = pl;
-        hit = true;
-        break;
-      }
-  }
-  if (!hit) {
-    Packer dry{true};
-    if (!run_recipe(dry, stage, num_layers, num_modes)) return fail(TRAJSDE_ERR_INVALID, "unknown stage");
-    TS_REQUIRE(n_params == int(dry.names.size()), "pack_weights: parameter count does not match trajsde_param_count");
-    for (int i = 0; i < n_params; ++i) TS_REQUIRE(params[i] != nullptr, "pack_weights: null parameter " + dry.names[i]);
-    plan_copy.stage = stage; plan_copy.nl = num_layers; plan_copy.K = num_modes;
-    plan_copy.params.assign(params, params + n_params);
-    plan_copy.need_floats = trajsde_blob_floats(stage, num_layers, num_modes);
-    for (int slot = 0; slot < 8; ++slot) {                // a stand-in range that no parameter lives in
-      const uintptr_t lo = reinterpret_cast<uintptr_t>(pack_standin_blob(slot)), hi = lo + uintptr_t(plan_copy.need_floats) * sizeof(float);
-      bool clash = false;
-      for (int i = 0; i < n_params; ++i) {
-        const uintptr_t u = reinterpret_cast<uintptr_t>(params[i]);
-        clash = clash || (u + (uintptr_t(1) << 32) >= lo && u < hi);
-      }
-      plan_copy.standin = slot;
-      if (!clash) break;
-    }
-    build_pack_tables(stage, num_layers, num_modes, dry.names, params, plan_copy.tables, plan_copy.standin);
-    std::lock_guard<std::mutex> lk(mu);
-    if (plans.size() >= 64) plans.clear();
-    plans.push_back(plan_copy);
-  }
+  if (int rc = get_pack_plan(stage, num_layers, num_modes, params, n_params, plan_copy)) return rc;
   TS_REQUIRE(blob_floats >= plan_copy.need_floats, "pack_weights: blob too small");
   TS_HIP(hipMemsetAsync(blob, 0, size_t(blob_floats) * sizeof(float), static_cast<hipStream_t>(stream)));
-  // every address inside the stand-in blob -- destinations, and the sources of second-pass jobs that read first-pass results --
-  // moves onto this call's blob
-  const uintptr_t F = reinterpret_cast<uintptr_t>(pack_standin_blob(plan_copy.standin)), Fend = F + uintptr_t(plan_copy.need_floats) * sizeof(float);
-  auto rebase = [&](const float* q) -> const float* {
-    const uintptr_t u = reinterpret_cast<uintptr_t>(q);
-    return (u >= F && u < Fend) ? blob + (u - F) / sizeof(float) : q;
-  };
   for (PackLaunch& t : plan_copy.tables) {
-    for (int q = 0; q < t.n; ++q) {
-      PackJob& j = t.tab.j[q];
-      j.dst = const_cast<float*>(rebase(j.dst));
-      j.src = rebase(j.src);
-      j.src2 = rebase(j.src2);
-      j.src3 = rebase(j.src3);
-    }
+    for (int q = 0; q < t.n; ++q) rebase_job(t.tab.j[q], plan_copy, blob);
     k_pack_jobs<<<dim3(cdiv(t.max_count, 256), t.n), 256, 0, static_cast<hipStream_t>(stream)>>>(t.tab);
   }
   TS_LAUNCH_CHECK("pack");
+  return TRAJSDE_OK;
+}
+
+int64_t trajsde_pack_many_table_bytes(const trajsde_pack_item* items, int n) {
+  if (!items || n < 0 || n > 64) return -1;
+  int64_t jobs = 0;
+  for (int i = 0; i < n; ++i) {
+    const int c = pack_job_count(items[i].stage, items[i].num_layers, items[i].num_modes);
+    if (c < 0) return -1;
+    jobs += c + 1;                                         // + the blob's zero job
+  }
+  return jobs * int64_t(sizeof(PackJob));
+}
+
+// The weight images of SEVERAL stages in three launches (zero the blobs | first-pass jobs | second-pass jobs) over ONE job table in
+// device memory: a training step re-packs six blobs (three stages, forward and backward images) after every optimizer step, which
+// through trajsde_pack_weights is 26 launches and 6 fills of ~5 us each.  The merged table is built when the arguments are first seen,
+// written to `table_host` (pinned host memory of the caller) and copied to `table_dev` on `stream`; while the stage list, parameter
+// addresses, blob addresses and `table_dev` stay the same, later calls only launch.  `fresh` != 0 forces the upload (the caller
+// re-allocated or wrote `table_dev`).  Both tables: trajsde_pack_many_table_bytes(items, n) bytes, owned by the caller, not to be
+// written by it while calls with these arguments continue.  Results: bit-identical to n calls of trajsde_pack_weights.
+int trajsde_pack_weights_many(const trajsde_pack_item* items, int n, void* table_host, void* table_dev, int64_t table_bytes, int fresh,
+                              void* stream) {
+  TS_REQUIRE(items && table_host && table_dev, "pack_weights_many: null pointer");
+  TS_REQUIRE(n > 0 && n <= 64, "pack_weights_many: bad stage count");
+  for (int i = 0; i < n; ++i) {
+    TS_REQUIRE(items[i].params && items[i].blob, "pack_weights_many: null pointer in an item");
+    TS_REQUIRE(items[i].n_params >= 0 && items[i].n_params < (1 << 20), "pack_weights_many: bad parameter count");
+    for (int k = 0; k < i; ++k) TS_REQUIRE(items[k].blob != items[i].blob, "pack_weights_many: two items share a blob");
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static std::mutex mu;
+  static std::vector<ManyPlan> plans;
+  static uint64_t next_serial = 1;
+  static std::vector<std::pair<void*, uint64_t>> resident;       // table_dev -> serial of the plan it holds
+  struct { int n_zero, n0, max0, n1, max1; uint64_t serial; int64_t bytes; } run{};
+  bool upload = fresh != 0;
+  auto note = [&](const ManyPlan& pl) {
+    run.n_zero = pl.n_zero; run.n0 = pl.n0; run.max0 = pl.max0; run.n1 = pl.n1; run.max1 = pl.max1; run.serial = pl.serial;
+    run.bytes = int64_t(pl.table.size()) * int64_t(sizeof(PackJob));
+  };
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const ManyPlan& pl : plans)
+      if (pl.matches(items, n, table_dev)) note(pl);
+  }
+  if (run.serial == 0) {
+    ManyPlan mp;
+    mp.items.assign(items, items + n);
+    mp.table_dev = table_dev;
+    std::vector<PackJob> zero, p0, p1;
+    for (int i = 0; i < n; ++i) {
+      const trajsde_pack_item& it = items[i];
+      PackPlan pl;
+      if (int rc = get_pack_plan(it.stage, it.num_layers, it.num_modes, it.params, it.n_params, pl)) return rc;
+      TS_REQUIRE(it.blob_floats >= pl.need_floats, "pack_weights_many: blob too small");
+      TS_REQUIRE(it.blob_floats < (int64_t(1) << 31), "pack_weights_many: blob too large");
+      TS_REQUIRE((reinterpret_cast<uintptr_t>(it.blob) & 15) == 0, "pack_weights_many: blob must be 16-byte aligned");
+      mp.params.emplace_back(it.params, it.params + it.n_params);
+      mp.items[i].params = nullptr;                                   // (the key holds its own copy of the addresses)
+      PackJob z{};
+      z.count = int(it.blob_floats);
+      z.dst = it.blob;
+      zero.push_back(z);
+      for (PackJob j : pl.jobs) {
+        rebase_job(j, pl, it.blob);
+        (j.pass == 0 ? p0 : p1).push_back(j);
+      }
+    }
+    mp.n_zero = int(zero.size());
+    mp.n0 = int(p0.size());
+    mp.n1 = int(p1.size());
+    for (const PackJob& j : p0) mp.max0 = j.count > mp.max0 ? j.count : mp.max0;
+    for (const PackJob& j : p1) mp.max1 = j.count > mp.max1 ? j.count : mp.max1;
+    mp.table = zero;
+    mp.table.insert(mp.table.end(), p0.begin(), p0.end());
+    mp.table.insert(mp.table.end(), p1.begin(), p1.end());
+    TS_REQUIRE(mp.n0 < 65536 && mp.n1 < 65536, "pack_weights_many: too many jobs for one launch");
+    std::lock_guard<std::mutex> lk(mu);
+    mp.serial = next_serial++;
+    if (plans.size() >= 16) plans.clear();
+    plans.push_back(mp);
+    note(mp);
+    upload = true;
+  }
+  TS_REQUIRE(table_bytes >= run.bytes, "pack_weights_many: table too small (trajsde_pack_many_table_bytes)");
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    bool seen = false;
+    for (auto& r : resident)
+      if (r.first == table_dev) {
+        seen = true;
+        upload = upload || r.second != run.serial;
+        r.second = run.serial;
+      }
+    if (!seen) {
+      if (resident.size() >= 64) resident.clear();
+      resident.emplace_back(table_dev, run.serial);
+      upload = true;
+    }
+  }
+  if (upload) {
+    // (rare) `table_host` may still be the source of an earlier upload on this stream
+    TS_HIP(hipStreamSynchronize(st));
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      const ManyPlan* src = nullptr;
+      for (const ManyPlan& pl : plans)
+        if (pl.serial == run.serial) src = &pl;
+      TS_REQUIRE(src != nullptr, "pack_weights_many: plan evicted while in use");
+      std::memcpy(table_host, src->table.data(), size_t(run.bytes));
+    }
+    TS_HIP(hipMemcpyAsync(table_dev, table_host, size_t(run.bytes), hipMemcpyHostToDevice, st));
+  }
+  const PackJob* tab = static_cast<const PackJob*>(table_dev);
+  k_pack_zero_table<<<dim3(32, run.n_zero), 256, 0, st>>>(tab);
+  if (run.n0) k_pack_jobs_table<<<dim3(cdiv(run.max0, 256), run.n0), 256, 0, st>>>(tab, run.n_zero);
+  if (run.n1) k_pack_jobs_table<<<dim3(cdiv(run.max1, 256), run.n1), 256, 0, st>>>(tab, run.n_zero + run.n0);
+  TS_LAUNCH_CHECK("pack_many");
   return TRAJSDE_OK;
 }
 

@@ -228,6 +228,24 @@ class FlatGrads:
         first, gather, _ = plan
         self.flat[first:first + gather.numel()].addcmul_(gb.flat.index_select(0, gather), scale)
 
+    def _apply_bundles(self, plans, bundles, scale) -> None:
+        """flat[block] += stage buffer[gather] * (scale * mult) for every (plan, (prefix, buffers, mult)); on a GPU all of them in ONE
+        launch (trajsde_grad_gather_add) -- two element-wise launches per stage otherwise.  `scale`: a 0-dim tensor or None for 1"""
+        gpu = runtime.single_call_forms() and self.flat.is_cuda and all(gb.flat.is_cuda and gb.flat.dtype == torch.float32 and gb.flat.is_contiguous() for _, gb, _ in bundles)
+        if gpu and (scale is None or (scale.is_cuda and scale.dtype == torch.float32 and scale.numel() == 1)) and 0 < len(plans) <= 8:
+            from trajsde_amd import _lib
+            items = (_lib.GatherItem * len(plans))()
+            base = self.flat.data_ptr()
+            for it, (first, gather, _), (_, gb, mult) in zip(items, plans, bundles):
+                it.dst, it.src, it.index, it.n, it.mult = base + 4 * first, gb.flat.data_ptr(), gather.data_ptr(), gather.numel(), float(mult)
+            with torch.cuda.device(self.flat.device):
+                _lib.check(_lib.lib().trajsde_grad_gather_add(items, len(plans), None if scale is None else scale.data_ptr(),
+                                                              torch.cuda.current_stream().cuda_stream), "trajsde_grad_gather_add")
+            return
+        one = torch.ones((), device=self.flat.device, dtype=self.flat.dtype) if scale is None else scale
+        for pl, (_, gb, mult) in zip(plans, bundles):
+            self._apply_bundle(pl, gb, one if mult == 1.0 else one * mult)
+
     def early_reduce_bundles(self, bundles) -> bool:
         """early_reduce over whole stage buffers (decoder + aggregator); same protocol"""
         if self._early is not None:
@@ -242,9 +260,7 @@ class FlatGrads:
         if any(a[1] != b[0] for a, b in zip(spans, spans[1:])):
             return False                                     # the stages' blocks are not adjacent: not one slice of the buffer
         lo, hi = spans[0][0], spans[-1][1]
-        one = torch.ones((), device=self.flat.device, dtype=self.flat.dtype)
-        for pl, (_, gb, mult) in zip(plans, bundles):
-            self._apply_bundle(pl, gb, one if mult == 1.0 else one * mult)
+        self._apply_bundles(plans, bundles, None)
         self._early = (frozenset().union(*[pl[2] for pl in plans]), lo, hi, self._start_early_collective(lo, hi))
         self._early_prefixes = tuple(prefix for prefix, _, _ in bundles)
         self._early_taken = False
@@ -273,8 +289,7 @@ class FlatGrads:
             if self._early is not None:
                 raise RuntimeError("FlatGrads: gradients reduced early do not add up with the rest to the parameter list")
             return False
-        for pl, (_, gb, mult) in zip(plans, todo):
-            self._apply_bundle(pl, gb, scale if mult == 1.0 else scale * mult)
+        self._apply_bundles(plans, todo, scale)
         if self._early is not None:
             self._early_taken = True
         return True
@@ -343,6 +358,57 @@ class FlatGrads:
             self.flat.div_(dist.get_world_size())
 
 
+class FlatAdamW(torch.optim.AdamW):
+    """torch.optim.AdamW whose step over a contiguous fp32 GPU tensor is ONE launch (trajsde_adamw_step: the operations of torch's
+    single-tensor form in torch's order, its scalars formed here as torch forms them) instead of nine element-wise ones -- 2 MB of
+    parameters make each of them ~5 us of GPU time and ~15 us of host time, however little they compute.  State (`step`, `exp_avg`,
+    `exp_avg_sq`), param_groups, state_dict and the lr schedulers are torch's own; anything the launch does not cover (amsgrad,
+    maximize, capturable, a CPU tensor, another dtype) goes to torch's step unchanged."""
+
+    def _fast(self, group) -> bool:
+        if group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("fused") or group.get("differentiable"):
+            return False
+        if torch.is_tensor(group["lr"]) or torch.is_tensor(group["betas"][0]) or torch.is_tensor(group["betas"][1]):
+            return False
+        for p in group["params"]:
+            g = p.grad
+            if g is None:
+                continue
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.dtype == torch.float32 and g.is_contiguous()
+                    and not g.is_sparse and g.device == p.device):
+                return False
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if not all(self._fast(g) for g in self.param_groups):
+            return super().step(closure)
+        from trajsde_amd import _lib
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        for group in self.param_groups:
+            lr, (beta1, beta2), eps, wd = group["lr"], group["betas"], group["eps"], group["weight_decay"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                state = self.state[p]
+                if len(state) == 0:                                          # as torch's _init_group
+                    state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["step"] += 1
+                step = float(state["step"])
+                bias1, bias2 = 1 - beta1 ** step, 1 - beta2 ** step
+                with torch.cuda.device(p.device):
+                    _lib.check(L.trajsde_adamw_step(p.data_ptr(), p.grad.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
+                                                    p.numel(), 1 - lr * wd, 1 - beta1, beta2, 1 - beta2, 1.0 / (bias2 ** 0.5), eps, -(lr / bias1),
+                                                    torch.cuda.current_stream().cuda_stream), "trajsde_adamw_step")
+        return loss
+
+
 class FlatTraining:
     """One flat parameter tensor, one flat gradient tensor.  The parameters the losses reach are re-pointed at slices of a
     single buffer, and the model's optimizer (AdamW, MODEL:204-207) runs over that ONE tensor: the same update element by
@@ -377,8 +443,10 @@ class FlatTraining:
         # per-parameter AdamW and this one agree to the last place or two (tests/test_gpu_backward.py::test_flat_training_is_...)
         # (the two forms round differently in the last place: `model.adamw_foreach = True` restores the multi-tensor form, which ends on
         #  the very bits of `AdamW(model.parameters())` as the reference constructs it, MODEL:205)
-        self.optimizer = torch.optim.AdamW([self.flat_param], lr=model.lr, weight_decay=model.weight_decay,
-                                           foreach=bool(getattr(model, "adamw_foreach", False)))
+        # (on a GPU the element-wise form is one launch: FlatAdamW)
+        adamw = torch.optim.AdamW if getattr(model, "adamw_foreach", False) or not runtime.single_call_forms() else FlatAdamW
+        self.optimizer = adamw([self.flat_param], lr=model.lr, weight_decay=model.weight_decay,
+                               foreach=bool(getattr(model, "adamw_foreach", False)))
         if hasattr(model, "scheduler_step"):
             self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=model.scheduler_step, gamma=model.scheduler_gamma)
         else:

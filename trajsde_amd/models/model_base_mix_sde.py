@@ -221,10 +221,24 @@ class PredictionModelSDENet(LightningHooks):
         for rt in (enc_rt, agg_rt, dec_rt):                   # no parameter changes inside this call: one stamp walk per stage
             rt.pin_stamp()
         try:
+            if runtime.single_call_forms():
+                self._step_pack_set().refresh()               # the six weight images of the step in one call (runtime.PackSet)
             return self._loss_and_gradients_pinned(data, noise, w_l2, w_diff)
         finally:
             for rt in (enc_rt, agg_rt, dec_rt):
                 rt.unpin_stamp()
+
+    def _step_pack_set(self) -> "runtime.PackSet":
+        """forward and backward images of the three stages, as one packing call per optimizer step"""
+        from trajsde_amd import _lib
+        dec_stage = _lib.STAGE_DECODER_NLL_BWD if self._regression_loss()[0] == "LaplaceNLLLoss" else _lib.STAGE_DECODER_BWD
+        ps = self.__dict__.get("_pack_set_obj")
+        if ps is None or ps.entries[-1][1] != dec_stage:
+            enc_rt, agg_rt, dec_rt = self.encoder._rt, self.aggregator._rt, self.decoder._rt
+            ps = runtime.PackSet([(enc_rt, _lib.STAGE_ENCODER), (enc_rt, _lib.STAGE_ENCODER_BWD), (agg_rt, _lib.STAGE_AGGREGATOR),
+                                  (agg_rt, _lib.STAGE_AGGREGATOR_BWD), (dec_rt, _lib.STAGE_DECODER), (dec_rt, dec_stage)])
+            self.__dict__["_pack_set_obj"] = ps
+        return ps
 
     def _loss_and_gradients_pinned(self, data, noise, w_l2: float, w_diff: float):
         enc_rt, agg_rt, dec_rt = self.encoder._rt, self.aggregator._rt, self.decoder._rt

@@ -370,6 +370,71 @@ class GradBuffers(collections.abc.Mapping):
         return ptrs.ctypes.data_as(C.POINTER(C.c_void_p)), ptrs
 
 
+def single_call_forms() -> bool:
+    """TRAJSDE_STEP_SINGLE_CALLS=0: a training step packs its weight images stage by stage, gathers its gradients and runs AdamW through
+    torch's element-wise launches, as before ABI 10 (same results bit for bit: tests/test_gpu_step_launches.py) -- the A/B switch of
+    profiles/r05_ab_runs.md"""
+    return os.environ.get("TRAJSDE_STEP_SINGLE_CALLS", "1") != "0"
+
+
+class PackSet:
+    """The weight images of several (StageRuntime, stage id) pairs packed by ONE call (trajsde_pack_weights_many: three launches
+    over a job table that stays on the device).  A training step re-packs six images after every optimizer step -- 26 launches and 6
+    fills of ~5 us through `StageRuntime.blob()` one stage at a time; `refresh()` at the top of the step leaves every `blob()` call
+    of the step a cache hit.  The blobs are allocated once and re-packed in place: what reads them is ordered behind the pack on the
+    packing stream, or behind its event on any other."""
+
+    def __init__(self, entries) -> None:
+        self.entries = list(entries)                 # [(StageRuntime, stage id)]
+        self._blobs = None
+        self._items = None
+        self._tables = None                          # (pinned host table, device table, bytes)
+        self._tab_ids = None
+        self._fresh = 1
+
+    def refresh(self) -> None:
+        stamps = [rt._stamp() for rt, _ in self.entries]
+        if self._blobs is not None:
+            for (rt, sid), stamp, blob in zip(self.entries, stamps, self._blobs):
+                cached = rt._blobs.get(sid)
+                if cached is None or cached[1] != stamp or cached[0] is not blob:
+                    break
+            else:
+                return                               # every image is current
+        L = _lib.lib()
+        first = self.entries[0][0]._first_param()
+        _require_gpu(first, "parameters")
+        dev = first.device
+        tabs = [rt._param_table(sid) for rt, sid in self.entries]
+        if self._blobs is None or any(b.device != dev for b in self._blobs):
+            self._blobs = [torch.empty(t[3], device=dev, dtype=torch.float32) for t in tabs]
+            self._items = None
+        if self._items is None or any(a is not b for a, b in zip(self._tab_ids, tabs)):
+            items = (_lib.PackItem * len(tabs))()
+            for it, (rt, sid), t, blob in zip(items, self.entries, tabs, self._blobs):
+                nl, K = rt._dims()
+                it.stage, it.num_layers, it.num_modes, it.n_params = sid, nl, K, t[2]
+                it.params = C.cast(t[1], C.c_void_p)
+                it.blob, it.blob_floats = blob.data_ptr(), t[3]
+            need = int(L.trajsde_pack_many_table_bytes(items, len(tabs)))
+            if need < 0:
+                raise _lib.TrajsdeError("trajsde_pack_many_table_bytes: unknown stage")
+            if self._tables is None or self._tables[2] < need or self._tables[1].device != dev:
+                self._tables = (torch.empty(need, dtype=torch.uint8).pin_memory(), torch.empty(need, dtype=torch.uint8, device=dev), need)
+                self._fresh = 1
+            self._items, self._tab_ids = items, tabs
+        host, table, nbytes = self._tables
+        with torch.cuda.device(dev):
+            _lib.check(L.trajsde_pack_weights_many(self._items, len(self.entries), host.data_ptr(), table.data_ptr(), nbytes, self._fresh,
+                                                   _stream()), "trajsde_pack_weights_many")
+            self._fresh = 0
+            ev = torch.cuda.Event()
+            cur = torch.cuda.current_stream()
+            ev.record(cur)
+        for (rt, sid), stamp, blob in zip(self.entries, stamps, self._blobs):
+            rt._blobs[sid] = (blob, stamp, ev, cur.cuda_stream)
+
+
 class StageRuntime:
     """Per-stage glue owned by a stage module (encoder / aggregator / decoder)."""
 
@@ -435,6 +500,31 @@ class StageRuntime:
             return self._pinned_stamp
         return (self.module.version_stamp(), str(self._first_param().device))
 
+    def _param_table(self, stage_id: int):
+        """(identity, ctypes array of the parameter addresses, count, blob floats) of a stage's packing -- rebuilt (and the tensors
+        re-checked) only when a tensor was replaced or moved: an optimizer step through the flat alias (touch()) re-packs from the
+        same addresses"""
+        m = self.module
+        first = self._first_param()
+        walk = m.walk_stamp() if hasattr(m, "walk_stamp") else None
+        tab = self._ptr_tables.get(stage_id) if hasattr(self, "_ptr_tables") else None
+        if tab is None or walk is None or tab[0] != (walk, str(first.device)):
+            L = _lib.lib()
+            nl, K = self._dims()
+            names = self.param_names(stage_id)
+            tensors = []
+            for n in names:
+                p = m.p(n)
+                if p.dtype != torch.float32 or not p.is_contiguous() or p.device != first.device:
+                    raise _lib.TrajsdeError(f"parameter {self.stage}.{n} must be contiguous fp32 on {first.device}")
+                tensors.append(p)
+            arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+            tab = ((walk, str(first.device)), arr, len(tensors), int(L.trajsde_blob_floats(stage_id, nl, K)))
+            if not hasattr(self, "_ptr_tables"):
+                self._ptr_tables = {}
+            self._ptr_tables[stage_id] = tab
+        return tab
+
     def blob(self, stage_id: Optional[int] = None) -> torch.Tensor:
         """Packed LDS images of this stage's weights (`stage_id`: the forward images by default, or the
         stage's backward images); re-packed whenever a parameter changed."""
@@ -447,24 +537,7 @@ class StageRuntime:
         if cached is None or stamp != cached[1]:
             L = _lib.lib()
             nl, K = self._dims()
-            # the table of parameter addresses is rebuilt (and the tensors re-checked) only when a tensor was replaced or moved:
-            # an optimizer step through the flat alias (touch()) re-packs from the same addresses
-            walk = m.walk_stamp() if hasattr(m, "walk_stamp") else None
-            tab = self._ptr_tables.get(stage_id) if hasattr(self, "_ptr_tables") else None
-            if tab is None or walk is None or tab[0] != (walk, str(first.device)):
-                names = self.param_names(stage_id)
-                tensors = []
-                for n in names:
-                    p = m.p(n)
-                    if p.dtype != torch.float32 or not p.is_contiguous() or p.device != first.device:
-                        raise _lib.TrajsdeError(f"parameter {self.stage}.{n} must be contiguous fp32 on {first.device}")
-                    tensors.append(p)
-                arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
-                tab = ((walk, str(first.device)), arr, len(tensors), int(L.trajsde_blob_floats(stage_id, nl, K)))
-                if not hasattr(self, "_ptr_tables"):
-                    self._ptr_tables = {}
-                self._ptr_tables[stage_id] = tab
-            _, arr, n_tensors, n_floats = tab
+            _, arr, n_tensors, n_floats = self._param_table(stage_id)
             blob = torch.empty(n_floats, device=first.device, dtype=torch.float32)
             with torch.cuda.device(first.device):
                 _lib.check(L.trajsde_pack_weights(stage_id, nl, K, arr, n_tensors, blob.data_ptr(), n_floats, _stream()),
