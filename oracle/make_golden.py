@@ -29,16 +29,20 @@ CASES = {
     "nus_k1_t5": (dict(S=1, n=12, L=8, F=5, box=60.0, seed=12, nus_sparsity=True, source=0), 1, 5, 0.5, 1, 102),
     "argo_k6_t30": (dict(S=3, n=10, L=8, F=30, box=120.0, seed=13, source=1, history_dropout=0.3), 6, 30, 3.0, 2, 103),
     "shipped_k10_t60": (dict(S=2, n=8, L=6, F=60, box=90.0, seed=14, mixed_source=True, history_dropout=0.3), 10, 60, 6.0, 3, 104),
+    # `uncertain: False` (DEC:56, DEC:100-101): the decoder without its scale head, loc [K, N, T, 2]
+    "plain_k3_t12": (dict(S=2, n=9, L=5, F=12, box=80.0, seed=16, mixed_source=True, history_dropout=0.3), 3, 12, 1.2, 6, 106, False),
 }
 
 
-def our_cfg(num_modes, future_steps, max_fut_t):
+def our_cfg(num_modes, future_steps, max_fut_t, uncertain=True):
     import yaml
     with open(os.path.join(ROOT, "trajsde_amd/configs/mi355x_sde_encoder_decoder.yml")) as f:
         cfg = yaml.safe_load(f)
     cfg["model_specific"]["kwargs"].update(num_modes=num_modes, future_steps=future_steps)
     cfg["aggregator"]["kwargs"]["num_modes"] = num_modes
     cfg["decoder"]["kwargs"].update(num_modes=num_modes, future_steps=future_steps, max_fut_t=max_fut_t)
+    if not uncertain:
+        cfg["decoder"]["kwargs"]["uncertain"] = False
     return cfg
 
 
@@ -91,11 +95,14 @@ def make_ood(name):
 
 
 def make(name):
-    skw, K, T, max_t, init_seed, noise_seed = CASES[name]
+    skw, K, T, max_t, init_seed, noise_seed = CASES[name][:6]
+    uncertain = CASES[name][6] if len(CASES[name]) > 6 else True
     batch = synth(**skw)
-    ours = PredictionModelSDENet(**our_cfg(K, T, max_t), init_seed=init_seed)
+    ours = PredictionModelSDENet(**our_cfg(K, T, max_t, uncertain), init_seed=init_seed)
     sd = {k: v.detach().clone() for k, v in ours.state_dict().items()}
-    ref = R.build_reference_model(R.load_reference_cfg(num_modes=K, future_steps=T, max_fut_t=max_t))
+    rcfg = R.load_reference_cfg(num_modes=K, future_steps=T, max_fut_t=max_t)
+    rcfg["decoder"]["kwargs"]["uncertain"] = uncertain
+    ref = R.build_reference_model(rcfg)
     ref.load_state_dict(sd)                                   # key-for-key: the state_dict contract of App. C
 
     N, A = batch.num_nodes, batch["agent_index"].numel()
@@ -118,6 +125,9 @@ def make(name):
     fx["meta.init_seed"], fx["meta.noise_seed"] = init_seed, noise_seed
     fx["meta.state_checksum"] = state_checksum(sd)
     fx["meta.n_euler"] = sched.n_euler
+    if not uncertain:
+        fx["meta.uncertain"] = 0
+        assert out["loc"].shape[-1] == 2 and not any(k.startswith("decoder.scale") for k in sd)
     for k in ("loc", "pi", "reg_mask", "diff_in", "diff_out", "label_in", "label_out"):
         fx[f"out.{k}"] = out[k].numpy()
     fx["out.y_rot"] = data.y.numpy()

@@ -28,6 +28,8 @@ CASES = {
     "grid_k10_t60_h4": (dict(S=2, n=7, L=5, F=60, box=90.0, seed=21, mixed_source=True, history_dropout=0.4), 10, 60, 4, 4, 0),
     "grid_k3_t12_h4": (dict(S=3, n=9, L=6, F=12, box=70.0, seed=22, source=0, nus_sparsity=True), 3, 12, 4, 2, 1),
     "grid_k6_t30_h8": (dict(S=2, n=11, L=4, F=30, box=110.0, seed=23, source=1, history_dropout=0.3), 6, 30, 8, 3, 2),
+    # `uncertain: False` (dec_hivt_nusargo_grid.py:31, :58-59): no scale head, loc [K, N, T, 2]
+    "grid_plain_k3_t12_h4": (dict(S=2, n=8, L=5, F=12, box=80.0, seed=24, mixed_source=True, history_dropout=0.3), 3, 12, 4, 2, 3, False),
 }
 
 
@@ -40,8 +42,10 @@ def torch1_transformer_encoder_forward(self, src, mask=None, src_key_padding_mas
     return output if self.norm is None else self.norm(output)
 
 
-def edit(cfg, K, T, heads, layers):
+def edit(cfg, K, T, heads, layers, uncertain=True):
     cfg = copy.deepcopy(cfg)
+    if not uncertain:
+        cfg["decoder"]["kwargs"]["uncertain"] = False
     cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)
     cfg["encoder"]["kwargs"].update(num_heads=heads, num_temporal_layers=layers)
     cfg["aggregator"]["kwargs"].update(num_modes=K, num_heads=heads)
@@ -54,14 +58,15 @@ def state_checksum(sd):
 
 
 def make(name):
-    skw, K, T, heads, layers, init_seed = CASES[name]
+    skw, K, T, heads, layers, init_seed = CASES[name][:6]
+    uncertain = CASES[name][6] if len(CASES[name]) > 6 else True
     batch = synth(**skw)
     with open(os.path.join(ROOT, "trajsde_amd/configs/mi355x_trmenc_mlpdec.yml")) as f:
-        ours_cfg = edit(yaml.safe_load(f), K, T, heads, layers)
+        ours_cfg = edit(yaml.safe_load(f), K, T, heads, layers, uncertain)
     ours = PredictionModel(**ours_cfg, init_seed=init_seed)
     sd = {k: v.detach().clone() for k, v in ours.state_dict().items()}
     with open(os.path.join(R.REFERENCE_ROOT, REF_CFG)) as f:
-        ref_cfg = edit(yaml.safe_load(f), K, T, heads, layers)
+        ref_cfg = edit(yaml.safe_load(f), K, T, heads, layers, uncertain)
     ref = R.build_reference_model(ref_cfg)
     ref.load_state_dict(sd)                                   # key-for-key, buffers included
     caps = {}
@@ -85,6 +90,9 @@ def make(name):
     fx = {f"in.{k}": v.numpy() for k, v in batch.as_dict().items() if torch.is_tensor(v)}
     fx.update({"meta.num_modes": K, "meta.future_steps": T, "meta.num_heads": heads, "meta.num_temporal_layers": layers,
                "meta.init_seed": init_seed, "meta.state_checksum": state_checksum(sd)})
+    if not uncertain:
+        fx["meta.uncertain"] = 0
+        assert out["loc"].shape[-1] == 2 and not any(k.startswith("decoder.scale") for k in sd)
     for k in ("loc", "pi", "reg_mask"):
         fx[f"out.{k}"] = out[k].numpy()
     fx["out.y_rot"] = data.y.numpy()

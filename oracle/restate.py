@@ -405,10 +405,13 @@ def sde_decoder(P, cfg, batch, local_embed, global_embed, noise, dec_sched, want
     pi = _lin(P, pre + ".pi.3", F.relu(_ln(P, pre + ".pi.1", _lin(P, pre + ".pi.0", torch.cat((loc_exp, global_embed), -1)))))
     pi = pi.squeeze(-1).t()
     loc = _lin(P, pre + ".decoder.3", F.relu(_ln(P, pre + ".decoder.1", _lin(P, pre + ".decoder.0", sol))))
-    sc = _lin(P, pre + ".scale.3", F.relu(_ln(P, pre + ".scale.1", _lin(P, pre + ".scale.0", sol))))
-    sc = F.elu(sc, alpha=1.0) + 1.0 + cfg["min_scale"]
-    out = {"loc": torch.cat((loc.view(K, N, T, 2), sc.view(K, N, T, 2)), -1), "pi": pi,
-           "reg_mask": ~batch["padding_mask"][:, -T:]}
+    if pre + ".scale.0.weight" in P:                                            # DEC:96-99 (`uncertain: True`)
+        sc = _lin(P, pre + ".scale.3", F.relu(_ln(P, pre + ".scale.1", _lin(P, pre + ".scale.0", sol))))
+        sc = F.elu(sc, alpha=1.0) + 1.0 + cfg["min_scale"]
+        loc = torch.cat((loc.view(K, N, T, 2), sc.view(K, N, T, 2)), -1)
+    else:                                                                       # DEC:100-101: no scale head, loc [K, N, T, 2]
+        loc = loc.view(K, N, T, 2)
+    out = {"loc": loc, "pi": pi, "reg_mask": ~batch["padding_mask"][:, -T:]}
     if want_intermediates:
         out["y0"] = sol.new_tensor([])  # placeholder so keys are stable
         out["sol"] = sol

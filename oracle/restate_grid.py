@@ -124,6 +124,8 @@ def mlp_decoder(P, cfg, batch, local_embed, global_embed):
     pi = _lin(P, pre + ".pi.6", F.relu(_ln(P, pre + ".pi.4", _lin(P, pre + ".pi.3", h)))).squeeze(-1).t()
     out = F.relu(_ln(P, pre + ".aggr_embed.1", _lin(P, pre + ".aggr_embed.0", torch.cat((global_embed, loc_exp), -1))))
     loc = _lin(P, pre + ".loc.3", F.relu(_ln(P, pre + ".loc.1", _lin(P, pre + ".loc.0", out)))).view(K, N, T, 2)
+    if pre + ".scale.0.weight" not in P:                                        # GDEC:58-59 (`uncertain: False`): no scale head
+        return {"loc": loc, "pi": pi, "reg_mask": ~batch["padding_mask"][:, -T:]}
     sc = _lin(P, pre + ".scale.3", F.relu(_ln(P, pre + ".scale.1", _lin(P, pre + ".scale.0", out))))
     sc = F.elu(sc, alpha=1.0).view(K, N, T, 2) + 1.0 + cfg["min_scale"]
     return {"loc": torch.cat((loc, sc), -1), "pi": pi, "reg_mask": ~batch["padding_mask"][:, -T:]}

@@ -10,12 +10,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
 
 
-def our_cfg(num_modes, future_steps, max_fut_t):
+def our_cfg(num_modes, future_steps, max_fut_t, uncertain=True):
     with open(os.path.join(ROOT, "trajsde_amd/configs/mi355x_sde_encoder_decoder.yml")) as f:
         cfg = yaml.safe_load(f)
     cfg["model_specific"]["kwargs"].update(num_modes=num_modes, future_steps=future_steps)
     cfg["aggregator"]["kwargs"]["num_modes"] = num_modes
     cfg["decoder"]["kwargs"].update(num_modes=num_modes, future_steps=future_steps, max_fut_t=max_fut_t)
+    if not uncertain:                                          # DEC:56: the decoder without its scale head
+        cfg["decoder"]["kwargs"]["uncertain"] = False
     return cfg
 
 
@@ -32,12 +34,14 @@ def load_fixture(name):
 
 def build_model(meta_or_K, T=None, max_t=None, init_seed=0):
     from trajsde_amd.models.model_base_mix_sde import PredictionModelSDENet
+    uncertain = True
     if isinstance(meta_or_K, dict):
         m = meta_or_K
         K, T, max_t, init_seed = int(m["num_modes"]), int(m["future_steps"]), float(m["max_fut_t"]), int(m["init_seed"])
+        uncertain = bool(int(m.get("uncertain", 1)))
     else:
         K = meta_or_K
-    cfg = our_cfg(K, T, max_t)
+    cfg = our_cfg(K, T, max_t, uncertain)
     return PredictionModelSDENet(**cfg, init_seed=init_seed).eval(), cfg
 
 
@@ -217,9 +221,11 @@ def check_grads_against_train_fixture(got, grads, digests, rel):
     return bad
 
 
-def grid_cfg(K, T, heads, layers, dropout=0.0):
+def grid_cfg(K, T, heads, layers, dropout=0.0, uncertain=True):
     with open(os.path.join(ROOT, "trajsde_amd/configs/mi355x_trmenc_mlpdec.yml")) as f:
         cfg = yaml.safe_load(f)
+    if not uncertain:
+        cfg["decoder"]["kwargs"]["uncertain"] = False
     cfg["encoder"]["kwargs"]["dropout"] = dropout
     cfg["aggregator"]["kwargs"]["dropout"] = dropout
     cfg["model_specific"]["kwargs"].update(num_modes=K, future_steps=T)

@@ -45,15 +45,26 @@ def test_vanilla_forward_matches_reference_golden(name, dev):
     z = np.load(os.path.join(H.ROOT, "tests", "golden_grid", name + ".npz"))
     batch = TemporalData(**{k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in.")})
     K, T, heads, layers = (int(z["meta." + k]) for k in ("num_modes", "future_steps", "num_heads", "num_temporal_layers"))
-    model = PredictionModel(**_cfg(K, T, heads, layers), init_seed=int(z["meta.init_seed"])).eval().to(dev)
+    cfg = _cfg(K, T, heads, layers)
+    plain = "meta.uncertain" in z.files and int(z["meta.uncertain"]) == 0
+    if plain:                                                    # dec_hivt_nusargo_grid.py:31: the decoder without its scale head
+        cfg["decoder"]["kwargs"]["uncertain"] = False
+    model = PredictionModel(**cfg, init_seed=int(z["meta.init_seed"])).eval().to(dev)
+    assert plain == (not any(k.startswith("decoder.scale") for k in model.state_dict()))
     data = batch.to(dev)
     with torch.no_grad():
         out = model(data)
+    assert out["loc"].shape[-1] == (2 if plain else 4)
     for k in ("loc", "pi"):
         assert H.maxdiff(out[k].cpu(), torch.from_numpy(z["out." + k])) <= TOL, k
     assert torch.equal(out["reg_mask"].cpu(), torch.from_numpy(z["out.reg_mask"]))
-    assert H.maxdiff(out["local_embed"].cpu(), torch.from_numpy(z["mid.local_embed"])) <= TOL
-    assert H.maxdiff(out["global_embed"].cpu(), torch.from_numpy(z["mid.global_embed"])) <= TOL
+    if plain:                                                    # (the reference returns the embeddings with `uncertain: True` only, :56-59)
+        assert "local_embed" not in out and "global_embed" not in out
+        with pytest.raises(NotImplementedError):
+            model.train().training_step(batch.to(dev), 0)
+    else:
+        assert H.maxdiff(out["local_embed"].cpu(), torch.from_numpy(z["mid.local_embed"])) <= TOL
+        assert H.maxdiff(out["global_embed"].cpu(), torch.from_numpy(z["mid.global_embed"])) <= TOL
     assert H.maxdiff(data.y.cpu(), torch.from_numpy(z["out.y_rot"])) <= 1e-5
 
 

@@ -31,6 +31,9 @@ def test_forward_matches_reference_golden(name, dev):
     model.encoder.capture_intermediates = True
     data = batch.to(dev)
     o = model(data, noise=NoiseSpec(seed=int(meta["noise_seed"])))
+    plain = int(meta.get("uncertain", 1)) == 0                            # DEC:56, DEC:100-101: no scale head, loc [K, N, T, 2]
+    assert o["loc"].shape[-1] == (2 if plain else 4) == out["loc"].shape[-1]
+    assert plain == (not any(k.startswith("decoder.scale") for k in model.state_dict()))
     assert H.maxdiff(o["loc"].cpu(), out["loc"]) <= TOL
     assert H.maxdiff(o["pi"].cpu(), out["pi"]) <= TOL
     assert torch.equal(o["reg_mask"].cpu(), out["reg_mask"])
@@ -41,6 +44,9 @@ def test_forward_matches_reference_golden(name, dev):
     im = model.encoder.last_intermediates
     assert H.maxdiff(im["aa_out"].cpu(), mid["aa_out"]) <= TOL
     assert H.maxdiff(im["latent_ys"].cpu(), mid["latent_ys"]) <= TOL
+    if plain:              # the reference's losses chunk loc | scale out of four channels (losses/L2.py:12): training without the head is refused
+        with pytest.raises(NotImplementedError):
+            model.train().training_step(batch.to(dev), 0, noise=NoiseSpec(seed=1))
 
 
 @pytest.mark.parametrize("name", H.GOLDEN)

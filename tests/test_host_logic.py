@@ -454,3 +454,28 @@ def test_early_slice_over_whole_stage_buffers_follows_the_protocol():
     fg.zero()
     assert fg.early_reduce_bundles([bundles[0], bundles[2]]) is False                       # encoder + decoder: not adjacent in the buffer
     assert fg._early is None and float(fg.flat.abs().max()) == 0.0
+
+
+def test_decoders_without_the_scale_head_keep_the_reference_state_dict():
+    """`uncertain: False` (DEC:56, dec_hivt_nusargo_grid.py:31): the reference's decoders have no `scale.*` tensors -- neither have
+    ours (state_dict, parameters()); the weight packer's recipe still finds zero stand-ins under those names, they follow `.to()`
+    and consume nothing of the init stream (the heads after `scale` initialise as in a model that never had it)"""
+    import helpers as H
+    from trajsde_amd.models.model_base_mix import PredictionModel
+    full, _ = H.build_model(3, 12, 1.2, init_seed=6)
+    plain, _ = H.build_model({"num_modes": 3, "future_steps": 12, "max_fut_t": 1.2, "init_seed": 6, "uncertain": 0})
+    sd_full, sd_plain = full.state_dict(), plain.state_dict()
+    assert set(sd_full) - set(sd_plain) == {k for k in sd_full if k.startswith("decoder.scale.")} != set()
+    assert not set(sd_plain) - set(sd_full)
+    assert not any("absent" in k for k in sd_plain) and not any("absent" in n for n, _ in plain.named_parameters())
+    dec = plain.decoder
+    for leaf, shape in ((".0.weight", (64, 64)), (".0.bias", (64,)), (".1.weight", (64,)), (".3.weight", (2, 64)), (".3.bias", (2,))):
+        t = dec.p("scale" + leaf)
+        assert tuple(t.shape) == shape == tuple(full.decoder.p("scale" + leaf).shape) and float(t.abs().max()) == 0.0
+    assert torch.equal(sd_plain["decoder.aggr_embed.0.weight"], sd_full["decoder.aggr_embed.0.weight"])
+    assert not torch.equal(sd_plain["decoder.pi.0.weight"], sd_full["decoder.pi.0.weight"])      # (the stream moved up by one head)
+    assert dec.p("scale.0.weight").dtype == torch.float32 and dec.to(torch.float64).p("scale.0.weight").dtype == torch.float64
+    cfg = H.grid_cfg(3, 12, 4, 2, uncertain=False)
+    vanilla = PredictionModel(**cfg, init_seed=1)
+    assert not any(k.startswith("decoder.scale") for k in vanilla.state_dict())
+    assert tuple(vanilla.decoder.p("scale.3.weight").shape) == (24, 64)

@@ -69,6 +69,8 @@ def test_vanilla_restatement_matches_reference_golden(name):
     cfg["encoder"]["kwargs"].update(num_heads=heads, num_temporal_layers=layers)
     cfg["aggregator"]["kwargs"].update(num_modes=K, num_heads=heads)
     cfg["decoder"]["kwargs"].update(num_modes=K, future_steps=T)
+    if "meta.uncertain" in z.files and int(z["meta.uncertain"]) == 0:      # the decoder without its scale head (GDEC:31, :58-59)
+        cfg["decoder"]["kwargs"]["uncertain"] = False
     model = PredictionModel(**cfg, init_seed=int(z["meta.init_seed"]))
     sd = model.state_dict()
     assert abs(sum(float(v.double().abs().sum()) for v in sd.values() if torch.isfinite(v).all()) - float(z["meta.state_checksum"])) < 1e-6 * float(z["meta.state_checksum"])

@@ -15,12 +15,15 @@ class MLPDecoder(ParamTree):
             setattr(self, key, value)
         self.input_size, self.hidden_size = self.global_channels, self.local_channels
         d, t = self.hidden_size, self.future_steps
-        if d != 64 or self.input_size != 64 or not self.uncertain or not 0 < t <= 64:
-            raise NotImplementedError("kernels are specialised for 64 channels, uncertain=True, future_steps <= 64")
+        if d != 64 or self.input_size != 64 or not 0 < t <= 64:
+            raise NotImplementedError("kernels are specialised for 64 channels, future_steps <= 64")
         self.linear("aggr_embed.0", d, self.input_size + d)
         self.layernorm("aggr_embed.1", d)
         self.head("loc", d, d, 2 * t)
-        self.head("scale", d, d, 2 * t)
+        if self.uncertain:
+            self.head("scale", d, d, 2 * t)
+        else:                                                    # dec_hivt_nusargo_grid.py:31: no scale head, 'loc' [K, N, T, 2] (:58-59)
+            self.absent_head("scale", d, d, 2 * t)
         self.linear("pi.0", d, d + self.input_size)
         self.layernorm("pi.1", d)
         self.linear("pi.3", d, d)

@@ -137,6 +137,9 @@ class PredictionModel(LightningHooks):
             self.apply_ts_drop(data)
         if self.loss_names != ["L2"]:
             raise NotImplementedError(f"training_step differentiates L2 through the HIP kernels; configured: {self.loss_names}")
+        if not getattr(self.decoder, "uncertain", True):      # (losses/L2.py:12 chunks loc | scale out of four channels: see the SDE model)
+            raise NotImplementedError("training with `uncertain: False` is not built: the reference's L2 regresses x against both targets "
+                                      "on a two-channel output (losses/L2.py:12)")
         if data.y is None:
             raise ValueError("training_step needs targets (data.y)")
         noise = runtime.NoiseSpec.resolve(noise)

@@ -311,6 +311,12 @@ class PredictionModelSDENet(LightningHooks):
         is refused rather than silently differentiated elsewhere."""
         if not self.rotate:
             raise NotImplementedError("rotate=False is not built (shipped config: rotate: true, CFG:18)")
+        if not getattr(self.decoder, "uncertain", True):
+            # losses/L2.py:12 and losses/laplace_nll_loss.py:28 take `loc, scale = output['loc'].chunk(2, dim=-1)`: on the
+            # two-channel output of `uncertain: False` that makes `loc` the x coordinate alone, broadcast against BOTH target
+            # coordinates -- the reference's losses are only meaningful with the scale head.  Inference is supported.
+            raise NotImplementedError("training with `uncertain: False` is not built: the reference's own losses chunk loc | scale out of "
+                                      "FOUR channels (losses/L2.py:12); on the two-channel output they regress x against both targets")
         weights = dict(zip(self.loss_names, self.loss_weights))
         unknown = set(self.loss_names) - {"L2", "LaplaceNLLLoss", "DiffBCE"}
         reg_name = self._regression_loss()[0]

@@ -50,17 +50,35 @@ class ParamTree(nn.Module):
         self.__dict__.pop("_p_slots", None)
         return p
 
+    def absent(self, path: str, shape) -> None:
+        """A tensor the reference's module does NOT have under this configuration (e.g. the decoder's `scale` head with
+        `uncertain: False`, DEC:56 / dec_hivt_nusargo_grid.py:31) but the weight packer's recipe names: a zero stand-in held as a
+        NON-persistent buffer -- it follows `.to()`, is in neither `state_dict()` nor `parameters()`, and `p(path)` resolves to it."""
+        name = "_absent_" + path.replace(".", "_")
+        self.register_buffer(name, torch.zeros(shape), persistent=False)
+        self.__dict__.setdefault("_absent_paths", {})[path] = name
+        self.__dict__.pop("_p_slots", None)
+
+    def absent_head(self, path: str, in_f: int, d: int, out_f: int) -> None:
+        for leaf, shape in ((".0.weight", (d, in_f)), (".0.bias", (d,)), (".1.weight", (d,)), (".1.bias", (d,)),
+                            (".3.weight", (out_f, d)), (".3.bias", (out_f,))):
+            self.absent(path + leaf, shape)
+
     def p(self, path: str) -> nn.Parameter:
         slots = self.__dict__.get("_p_slots")                               # path -> (container dict, leaf): survives re-assignment
         if slots is None:
             slots = self.__dict__["_p_slots"] = {}
         hit = slots.get(path)
         if hit is None:
-            mod: nn.Module = self
-            parts = path.split(".")
-            for q in parts[:-1]:
-                mod = mod._modules[q]
-            hit = slots[path] = (mod._parameters, parts[-1])
+            absent = self.__dict__.get("_absent_paths", {})
+            if path in absent:
+                hit = slots[path] = (self._buffers, absent[path])
+            else:
+                mod: nn.Module = self
+                parts = path.split(".")
+                for q in parts[:-1]:
+                    mod = mod._modules[q]
+                hit = slots[path] = (mod._parameters, parts[-1])
         return hit[0][hit[1]]
 
     # -- initialisers ---------------------------------------------------------------------------

@@ -377,6 +377,22 @@ def single_call_forms() -> bool:
     return os.environ.get("TRAJSDE_STEP_SINGLE_CALLS", "1") != "0"
 
 
+def _drop_scale_channels(module, out: dict) -> None:
+    """`uncertain: False` (DEC:100-101, dec_hivt_nusargo_grid.py:58-59): 'loc' is [K, N, T, 2].  The kernels always evaluate both
+    heads into [K, N, T, 4] (the absent scale head is a zero stand-in, params.ParamTree.absent); the four-channel tensor stays
+    under a private key for the backward entry points, which index it"""
+    if not getattr(module, "uncertain", True):
+        out["_loc4"] = out["loc"]
+        out["loc"] = out["loc"][..., :2].contiguous()
+
+
+def _loc4(out: dict) -> torch.Tensor:
+    loc = out.get("_loc4", out["loc"])
+    if loc.shape[-1] != 4:
+        raise _lib.TrajsdeError("the decoder backward needs the forward's own output dict (its [K, N, T, 4] locations)")
+    return loc.contiguous()
+
+
 class PackSet:
     """The weight images of several (StageRuntime, stage id) pairs packed by ONE call (trajsde_pack_weights_many: three launches
     over a job table that stays on the device).  A training step re-packs six images after every optimizer step -- 26 launches and 6
@@ -586,6 +602,7 @@ class StageRuntime:
                                                  out_tab.data_ptr(), float(m.min_scale), C.byref(cn), ws.data_ptr(), ws_bytes,
                                                  loc.data_ptr(), pi.data_ptr(), _stream()), "trajsde_decoder_forward")
         out = {"loc": loc, "pi": pi, "reg_mask": ~data["padding_mask"][:, -T:]}          # DEC:104
+        _drop_scale_channels(m, out)
         return out
 
     def decoder_nll_backward(self, data, local_embed: torch.Tensor, global_embed: torch.Tensor, out: Dict[str, torch.Tensor],
@@ -609,6 +626,9 @@ class StageRuntime:
         m = self.module
         if noise is None:
             raise _lib.TrajsdeError("decoder_l2_backward needs the NoiseSpec of the forward pass (seed or z_dec)")
+        if nll_eps is not None and not getattr(m, "uncertain", True):
+            raise _lib.TrajsdeError("LaplaceNLLLoss needs the decoder's scale head: `uncertain: False` has none (DEC:56, "
+                                    "losses/laplace_nll_loss.py:28 chunks loc | scale out of four channels)")
         _require_gpu(local_embed, "local_embed")
         dev = local_embed.device
         K, T = int(m.num_modes), int(m.future_steps)
@@ -632,7 +652,7 @@ class StageRuntime:
         cn = noise.c_noise(noise.z_dec, noise.dec_row_ids)
         head = (N, K, T, self.blob().data_ptr(), self.blob(stage).data_ptr(),
                 local_embed.contiguous().data_ptr(), global_embed.contiguous().data_ptr(), step_tab.data_ptr(), sched.n_euler,
-                out_tab.data_ptr(), C.byref(cn), out["loc"].contiguous().data_ptr(), y.data_ptr(), mask.data_ptr())
+                out_tab.data_ptr(), C.byref(cn), _loc4(out).data_ptr(), y.data_ptr(), mask.data_ptr())
         with torch.cuda.device(dev):
             if nll_eps is None:
                 ws_bytes = L.trajsde_decoder_backward_ws_bytes(N, K, T, sched.n_euler)
@@ -943,8 +963,11 @@ class StageRuntime:
                                                      global_embed.contiguous().data_ptr(), float(m.min_scale), ws.data_ptr(),
                                                      ws_bytes, loc.data_ptr(), pi.data_ptr(), _stream()),
                        "trajsde_mlp_decoder_forward")
-        return {"loc": loc, "pi": pi, "local_embed": local_embed, "global_embed": global_embed,
-                "reg_mask": ~data["padding_mask"][:, -T:]}
+        out = {"loc": loc, "pi": pi, "reg_mask": ~data["padding_mask"][:, -T:]}
+        if getattr(m, "uncertain", True):                    # (the reference returns the embeddings on this branch only, :56-57)
+            out["local_embed"], out["global_embed"] = local_embed, global_embed
+        _drop_scale_channels(m, out)
+        return out
 
 
     def aggregator_forward_train(self, data, local_embed: torch.Tensor, noise: Optional[NoiseSpec] = None):
@@ -1025,7 +1048,7 @@ class StageRuntime:
         with torch.cuda.device(dev):
             _lib.check(L.trajsde_mlp_decoder_l2_backward(
                 N, K, T, self.blob(_lib.STAGE_DECODER_MLP_BWD).data_ptr(), local_embed.contiguous().data_ptr(),
-                global_embed.contiguous().data_ptr(), out["loc"].contiguous().data_ptr(), y.data_ptr(), mask.data_ptr(), ws.data_ptr(),
+                global_embed.contiguous().data_ptr(), _loc4(out).data_ptr(), y.data_ptr(), mask.data_ptr(), ws.data_ptr(),
                 ws_bytes, loss.data_ptr(), best.data_ptr(), arr, len(names), d_local.data_ptr(), d_global.data_ptr(), _stream()),
                 "trajsde_mlp_decoder_l2_backward")
         return {"loss": loss[0], "best_mode": best, "grads": grads, "d_local_embed": d_local, "d_global_embed": d_global}
