@@ -292,7 +292,8 @@ __global__ __launch_bounds__(256) void k_gattn_drel_mm(DrelArgs a, const int32_t
         sv[4 * l + 0 + hh] = a.ED[l][int64_t(ec) * HEADS + 4 * hh + q4];      // type 0: ED multiplies U
         sv[4 * l + 2 + hh] = a.EA[l][int64_t(ec) * HEADS + 4 * hh + q4];      // type 1: EA multiplies Z
       }
-    f4 D[4];
+    __builtin_amdgcn_sched_barrier(0);                            // all 4 NL loads requested before the first product waits for one
+    f4 D[4];                                                      // (the scheduler otherwise recycles two registers: 2 loads in flight)
 #pragma unroll
     for (int b = 0; b < 4; ++b) D[b] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1221,7 +1222,7 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     if (int rc = run_headwise_outer(wc, w.q[l], w.RL, N, wke, num_heads)) return rc;
     if (int rc = run_headwise_outer(wc, w.dagg, w.SS, N, wve, num_heads)) return rc;
     TS_HIP(hipMemsetAsync(bke, 0, 64 * sizeof(float), st));          // a key bias shifts every logit of a target alike
-    if (int rc = run_colsum(st, w.DAGGM, N, 64, 64, bve)) return rc;
+    if (int rc = run_colsum_tall(st, w.DAGGM, N, 64, 64, bve, w.nb.vpart)) return rc;    // (one workgroup over N rows was 30 us at N = 8 192)
     const int gp = vec_grid(ntiles, 256, ProjBwdL<3>::SIZE * 4);
     float* const vp = vpart_slab(w.nb.vpart, int64_t(gp) * 4, 128);
     TS_LAUNCH(k_node_proj_bwd<3>, gp, 256, ProjBwdL<3>::SIZE * 4, st, lb + AggLayerBwdL::PROJ, x_in, w.nb.dx1, w.dxn, w.DQ, w.DKN, w.DVN, N,

@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(1024) void k_colsum_slices(const float* __restrict_
   }
 }
 int run_colsum_tall(hipStream_t st, const float* src, int64_t rows, int stride, int n, float* dst, float* scratch /* 256 x n floats */) {
-  if (rows < 16384) return run_colsum(st, src, rows, stride, n, dst, 1);
+  if (rows < 2048) return run_colsum(st, src, rows, stride, n, dst, 1);      // (a single workgroup streams a short slab fast enough)
   const int slices = 256;
   TS_LAUNCH(k_colsum_slices, dim3(cdiv(n, 64), slices), 1024, 0, st, src, rows, stride, n, scratch);
   return run_colsum(st, scratch, slices, n, n, dst, 1);

@@ -98,33 +98,50 @@ __global__ __launch_bounds__(256) void k_aa_center_bwd_tail(const float* __restr
   flush_vec(db4, vp + 192, L);
 }
 
-// d bos_token[t][c] = sum over the rows (t, i) that took the token of dcentre; one workgroup per t.  Few rows take the token
-// (an actor's first valid step), so each wave scans its contiguous share of the rows 64 at a time for the flag and only then
-// loads the flagged rows, in ascending order (fixed summation order).
+// d bos_token[t][c] = sum over the rows (t, i) that took the token of dcentre; BOS_SLICES workgroups per t, each over a contiguous
+// slice of the rows (most actors are valid from the first step on, so t = 0 holds most of the flagged rows: one workgroup per t left
+// that one walking ~5 000 rows while twenty others idled), partial sums to `part[slice][t][64]`, added in slice order by a column
+// sum.  Few rows take the token at t > 0, so each wave scans its contiguous share of the rows 64 at a time for the flag and only
+// then loads the flagged rows, in ascending order (fixed summation order).
+constexpr int BOS_SLICES = 8;
 __global__ __launch_bounds__(1024) void k_bos_grad(const float* __restrict__ dcenter, const uint8_t* __restrict__ bos,
-                                                   const int32_t* __restrict__ orig, int Nt, int H, float* __restrict__ dtok) {
+                                                   const int32_t* __restrict__ orig, int Nt, int H, float* __restrict__ partial) {
   __shared__ float red[16][64];
-  const int t = blockIdx.x, c = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int per = (((Nt + 15) / 16) + 63) & ~63;
-  const int r0 = part * per, r1 = r0 + per < Nt ? r0 + per : Nt;
+  const int t = blockIdx.x, slice = blockIdx.y, c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int per = (((Nt + 16 * BOS_SLICES - 1) / (16 * BOS_SLICES)) + 63) & ~63;
+  const int lo = (slice * 16 + part) * per;
+  const int r0 = lo < Nt ? lo : Nt, r1 = r0 + per < Nt ? r0 + per : Nt;
   float s = 0.f;
-  for (int base = r0; base < r1; base += 64) {
-    const int i = base + c;
-    const bool f = i < r1 && bos[int64_t(orig[i]) * H + t] != 0;
-    unsigned long long m = __ballot(f);
-    while (m) {                                              // eight flagged rows in flight, added in ascending order
-      float v[8];
+  // the flags of eight 64-row groups at a time: their `orig` loads, then their flag loads, are requested together (two dependent
+  // round trips per eight groups instead of two per group: 21 workgroups on the whole chip pay full latency for each)
+  for (int base0 = r0; base0 < r1; base0 += 512) {
+    int o[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        v[k] = 0.f;
-        if (m) {
-          const int b = __ffsll(m) - 1;
-          m &= m - 1;
-          v[k] = dcenter[(int64_t(t) * Nt + base + b) * 64 + c];
+    for (int k = 0; k < 8; ++k) {
+      const int i = base0 + 64 * k + c;
+      o[k] = i < r1 ? orig[i] : -1;
+    }
+    uint8_t fl[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fl[k] = o[k] >= 0 ? bos[int64_t(o[k]) * H + t] : uint8_t(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int base = base0 + 64 * k;
+      unsigned long long m = __ballot(fl[k] != 0);
+      while (m) {                                            // eight flagged rows in flight, added in ascending order
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          v[q] = 0.f;
+          if (m) {
+            const int b = __ffsll(m) - 1;
+            m &= m - 1;
+            v[q] = dcenter[(int64_t(t) * Nt + base + b) * 64 + c];
+          }
         }
-      }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s += v[k];
+        for (int q = 0; q < 8; ++q) s += v[q];
+      }
     }
   }
   red[part][c] = s;
@@ -132,7 +149,7 @@ __global__ __launch_bounds__(1024) void k_bos_grad(const float* __restrict__ dce
   if (part == 0) {
     float u = 0.f;
     for (int p = 0; p < 16; ++p) u += red[p][c];
-    dtok[t * 64 + c] = u;
+    partial[(int64_t(slice) * H + t) * 64 + c] = u;
   }
 }
 
@@ -789,8 +806,9 @@ int aa_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, const fl
     cb.add(vp + 256, 64, b0);
     if (int rc = cb.flush()) return rc;
   }
-  TS_LAUNCH(k_bos_grad, H, 1024, 0, st, w.DCENTER, b->bos_mask, g->orig, Nt, H, tok);
-  return TRAJSDE_OK;
+  // (the shared slab is free here: every vector sum of this call that fell back to it has run)
+  TS_LAUNCH(k_bos_grad, dim3(H, BOS_SLICES), 1024, 0, st, w.DCENTER, b->bos_mask, g->orig, Nt, H, w.nb.vpart);
+  return run_colsum(st, w.nb.vpart, BOS_SLICES, H * 64, H * 64, tok);
 }
 
 }  // namespace
@@ -1028,7 +1046,7 @@ int trajsde_encoder_backward(const trajsde_batch* b, const trajsde_graph* g, con
     }
     const float* dh = w.dhA;
     // iteration 0 started from the learned initial state, broadcast to every row (ENC:78)
-    if (int rc = run_colsum(st, dh, Nt, 64, 64, G("hidden"))) return rc;
+    if (int rc = run_colsum_tall(st, dh, Nt, 64, 64, G("hidden"), w.nb.vpart)) return rc;
     const std::string lf = "lsde_func.", gu = "gru_unit.";
     struct WG { const float* d; const float* a; const char* w; const char* bias; int ldw, col0, tc; };
     const WG jobs[] = {
