@@ -1142,9 +1142,9 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
   (void)etiles;
 
   // ---- multihead_proj + final norm
-  for (int k = 0; k < K; ++k)
-    TS_LAUNCH(k_lin_t_acc, tile_grid(ntiles, 256, MAT64 * 4), 256, MAT64 * 4, st, blob_bwd + AggBwdBlob::proj(nl, k),
-              d_global + int64_t(k) * N * 64, N, w.dxn, k > 0 ? 1 : 0);
+  if (K > 0)                                                    // d xn = sum_k W_k^T d global_k: one launch, the sum in registers
+    TS_LAUNCH(k_lin_t_sum, unsigned(ntiles > 0 ? (ntiles + 3) / 4 : 1), 256, 2 * MAT64 * 4, st, blob_bwd + AggBwdBlob::proj(nl, 0),
+              int64_t(AggBwdBlob::proj(nl, 1) - AggBwdBlob::proj(nl, 0)), d_global, N * 64, K, N, w.dxn);
   {
     const int gp = vec_grid(ntiles, 256, ProjBwdL<0>::SIZE * 4);
     float* const vp = vpart_slab(w.nb.vpart, int64_t(gp) * 4, 128);

@@ -159,6 +159,7 @@ __global__ void k_node_proj_bwd(const float* img, const float* x, const float* d
 template <int BR>
 __global__ void k_edge_embed_bwd_branch(const float* img, const float* geom, const float* DSP, int64_t E, float* vpart);
 __global__ void k_lin_t_acc(const float* wt, const float* d, int64_t R, float* out, int accumulate);
+__global__ void k_lin_t_sum(const float* wt, int64_t wt_stride, const float* d, int64_t d_stride, int K, int64_t R, float* out);
 
 constexpr int64_t VPART_FLOATS = int64_t(2048) * 4 * 320;     // per-wave vector partials of the widest kernel at the largest grid
 

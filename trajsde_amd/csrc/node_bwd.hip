@@ -260,6 +260,35 @@ __global__ __launch_bounds__(256) void k_lin_t_acc(const float* __restrict__ wt,
   }
 }
 
+// out = sum_k W_k^T d_k over K transposed images `wt + k * wt_stride` and K row blocks `d + k * d_stride` (the aggregator's
+// multihead_proj: K = num_modes launches of k_lin_t_acc, each reading and re-writing `out`, were 6-10 launches of ~6 us for 2 MB of
+// rows).  One tile per wave, its sum kept in registers over k (same order of additions: the same bits); image k + 1 is copied into
+// the other half of the LDS while image k is in use.
+__global__ __launch_bounds__(256) void k_lin_t_sum(const float* __restrict__ wt, int64_t wt_stride, const float* __restrict__ d,
+                                                   int64_t d_stride, int K, int64_t R, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const Lane L;
+  const int wave = threadIdx.x >> 6;
+  const int64_t tile = int64_t(blockIdx.x) * (blockDim.x >> 6) + wave, ntiles = (R + 15) / 16;
+  const bool live = tile < ntiles;
+  const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
+  f4 t[4];
+  zero4(t);
+  stage_blob(lds, wt, MAT64);
+  for (int k = 0; k < K; ++k) {
+    const float* cur = lds + (k & 1) * MAT64;
+    if (k + 1 < K) stage_copy(lds + ((k + 1) & 1) * MAT64, wt + int64_t(k + 1) * wt_stride, MAT64);
+    if (live) {
+      keep_lds_reads_here();
+      f4 a[4];
+      load_row(a, d + int64_t(k) * d_stride, r, L.g);
+      linear_adj<4, 4>(t, a, cur, L);
+    }
+    __syncthreads();
+  }
+  if (live && row < R) store_row(t, out, row, L.g);
+}
+
 // ------------------------------------------------------------------ MultipleInputEmbedding backward (EMB:62-70)
 // forward: a0 = relu(LN(A_W0 in0 + b)), b0 likewise from in1; sp = WA3 a0 + WB3 b0 + b3; s = relu(LN0(sp));
 //          ep = W2 s + b2; emb = LN3(ep).
