@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void k_node_proj_bwd(const float* __restrict__
   for (int64_t tile = int64_t(blockIdx.x) * waves + wave; tile < ntiles; tile += int64_t(gridDim.x) * waves) {
     keep_lds_reads_here();
     const int64_t row = tile * 16 + L.n, r = row < R ? row : R - 1;
-    f4 t[4], d[4], xh[4], dq[NQ > 0 ? NQ : 1][4], dr[4];
+    f4 t[4], xh[4], dq[NQ > 0 ? NQ : 1][4], dr[4];
     if (dxn_part) load_row(t, dxn_part, r, L.g);
     else zero4(t);
     // every row of the tile is requested before the first product (they used to be loaded one product at a time)
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(TSDE_TAIL_BOUNDS) void k_edge_embed_bwd_tail(const 
   zero4(dg3); zero4(db3); zero4(dg0); zero4(db0);
   PhaseClock<8> clk;                                      // diagnostic builds only (stamps.hpp, tools/phase_stamps.py tail)
   clk.start();
-  unsigned long long tiles_done = 0;
+  [[maybe_unused]] unsigned long long tiles_done = 0;          // (read by the phase clocks when they are compiled in)
   // (ATTN) the tile's targets are read ONE TILE AHEAD: the target index is the address of the q / dagg rows, and left at the top of its own
   // tile that dependent pair of latencies was 22 % of the kernel (in-kernel phase clocks, tools/phase_stamps.py tail: 3 900 of 18 150
   // cycles a tile).
