@@ -105,10 +105,12 @@ int trajsde_pack_weights_many(const trajsde_pack_item* items, int n, void* table
  * stage backward calls hand back their gradients as one buffer per stage in the order of trajsde_param_name; the training loop keeps
  * one flat gradient tensor in the order of model.parameters() (what `loss.backward()` fills through autograd in the reference,
  * MODEL:104-115).  `scale`: a device scalar (the incoming gradient of the loss) or NULL for 1.
- * trajsde_adamw_step: torch.optim.AdamW's single-tensor update (MODEL:204-207; amsgrad and maximize off) over n elements in one
- * launch, operation by operation as torch/optim/adamw.py performs it; the caller forms the scalars as torch does:
- *   decay = 1 - lr * weight_decay, w1 = 1 - beta1, w2 = 1 - beta2, inv_bias2_sqrt = 1 / sqrt(1 - beta2^step) (in double, then
- *   rounded: torch divides a tensor by a host scalar that way), neg_step = -(lr / (1 - beta1^step)), step counted from 1. */
+ * trajsde_adamw_step: torch.optim.AdamW's update (MODEL:204-207; amsgrad and maximize off) over n elements in one launch, operation by
+ * operation as torch/optim/adam.py performs it; the caller forms the scalars as torch does: decay = 1 - lr * weight_decay,
+ * w1 = 1 - beta1, w2 = 1 - beta2, neg_step = -(lr / (1 - beta1^step)), step counted from 1, and
+ *   divide = 1, bias2 = sqrt(1 - beta2^step):      the multi-tensor form (`foreach=True`: what AdamW(model.parameters()) runs on a GPU),
+ *   divide = 0, bias2 = 1 / sqrt(1 - beta2^step):  the single-tensor form (`foreach=False`; reciprocal formed in double, then rounded)
+ * -- the two differ in that one operation (a true division against a product with the reciprocal) and each is reproduced bit for bit. */
 typedef struct {
   float* dst;
   const float* src;
@@ -118,7 +120,7 @@ typedef struct {
 } trajsde_gather_item;
 int trajsde_grad_gather_add(const trajsde_gather_item* items, int n_items, const float* scale, void* stream);
 int trajsde_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float decay, float w1,
-                       float beta2, float w2, float inv_bias2_sqrt, float eps, float neg_step, void* stream);
+                       float beta2, float w2, float bias2, int divide, float eps, float neg_step, void* stream);
 
 /* ---- the batch ------------------------------------------------------------ */
 typedef struct {

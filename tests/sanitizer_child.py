@@ -162,8 +162,8 @@ gi[1].n = -1
 rc(L.trajsde_grad_gather_add(gi, 2, fake(73), stream))
 rc(L.trajsde_grad_gather_add(None, 1, None, stream))
 for n_el, b2 in ((0, 31.6), (1000, 31.6), (1001, 0.0), (1001, float('inf')), (-1, 31.6)):
-    rc(L.trajsde_adamw_step(fake(80), fake(81), fake(82), fake(83), n_el, 0.99, 0.1, 0.999, 0.001, b2, 1e-8, -1e-3, stream))
-rc(L.trajsde_adamw_step(None, fake(81), fake(82), fake(83), 10, 0.99, 0.1, 0.999, 0.001, 31.6, 1e-8, -1e-3, stream))
+    rc(L.trajsde_adamw_step(fake(80), fake(81), fake(82), fake(83), n_el, 0.99, 0.1, 0.999, 0.001, b2, n_el & 1, 1e-8, -1e-3, stream))
+rc(L.trajsde_adamw_step(None, fake(81), fake(82), fake(83), 10, 0.99, 0.1, 0.999, 0.001, 31.6, 0, 1e-8, -1e-3, stream))
 rc(L.trajsde_rotate(fake(1), 100, None, 0, fake(2), None, stream))
 rc(L.trajsde_rotate(None, 100, fake(3), 20, fake(2), fake(4), stream))
 rc(L.trajsde_sde_step(0, fake(1), fake(2), fake(3), None, 0, C.byref(nz), stream))

@@ -854,20 +854,23 @@ def test_training_forward_keeps_a_tape_the_backward_walks(train_mode, dev):
         assert torch.equal(a_with["grads"][k], a_without["grads"][k]), k
 
 
-@pytest.mark.parametrize("foreach", [True, False])
-def test_flat_training_is_the_per_parameter_adamw_bit_for_bit(foreach, dev):
+@pytest.mark.parametrize("route", ["one_launch", "torch_foreach", "one_launch_single_form"])
+def test_flat_training_is_the_per_parameter_adamw_bit_for_bit(route, dev):
     """driver.FlatTraining runs AdamW over ONE tensor that every optimised parameter is a slice of; AdamW is element-wise, so
-    three training steps end on exactly the parameters of torch's per-parameter AdamW over the same model -- and the weight
-    images are re-packed although the slices' version counters never move (StageParams.touch).  The flat side also takes its
-    gradients through FlatGrads.accumulate (six launches), the other side parameter by parameter: the same bits.
-    `foreach=True` (model.adamw_foreach): torch's multi-tensor AdamW on both sides: the same bits.  `foreach=False` (the default of
-    FlatTraining since round 4: the multi-tensor kernels cut one tensor into ten workgroups, 0.33 ms a step): the same formula in the
-    plain element-wise kernels, which round some operations differently: gradients still bit-equal at step 0, after three steps
-    98 % of every parameter's elements within 2e-6 of its scale and none further than the three steps themselves (AdamW turns a
-    noise-level gradient of either sign into a step of size lr)."""
+    three training steps end on exactly the parameters of torch's per-parameter AdamW over the same model -- the reference's
+    `AdamW(self.parameters())`, MODEL:205, which on a GPU is torch's multi-tensor implementation -- and the weight images are re-packed
+    although the slices' version counters never move (StageParams.touch).  The flat side also takes its gradients through
+    FlatGrads.accumulate_bundles (one launch), the other side parameter by parameter: the same bits.
+    "one_launch" (the default: driver.FlatAdamW, trajsde_adamw_step with the multi-tensor form's roundings) and "torch_foreach"
+    (model.adamw_foreach: torch's own multi-tensor kernels over the flat tensor): the same bits as the per-parameter optimizer.
+    "one_launch_single_form" (model.adamw_form = "single": the roundings of torch's foreach=False, the default of round 4): one
+    operation rounds differently -- gradients still bit-equal at step 0, after three steps 98 % of every parameter's elements within
+    2e-6 of its scale and none further than the three steps themselves (AdamW turns a noise-level gradient of either sign into a
+    step of size lr)."""
     from trajsde_amd import driver
     from trajsde_amd.runtime import NoiseSpec
     from trajsde_amd.synth import synth
+    exact = route != "one_launch_single_form"
     batch = synth(S=2, n=10, L=5, F=6, box=50.0, seed=21, mixed_source=True).to(dev)
     y0 = batch.y.clone()
 
@@ -880,8 +883,12 @@ def test_flat_training_is_the_per_parameter_adamw_bit_for_bit(foreach, dev):
     (opt,), _ = a.configure_optimizers()
     fa = driver.FlatGrads(a.params_with_gradient())
     b = make()
-    b.adamw_foreach = foreach
+    if route == "torch_foreach":
+        b.adamw_foreach = True
+    elif route == "one_launch_single_form":
+        b.adamw_form = "single"
     fb = driver.FlatTraining(b)
+    assert isinstance(fb.optimizer, driver.FlatAdamW) == (route != "torch_foreach")
     assert b._grad_sink is fb.grads and not hasattr(a, "_grad_sink")
     losses = []
     for i in range(3):
@@ -891,19 +898,19 @@ def test_flat_training_is_the_per_parameter_adamw_bit_for_bit(foreach, dev):
             loss = m.training_step(batch, i, noise=NoiseSpec(seed=40 + i))
             loss.backward()
             if m is b:
-                assert len(fb.grads._gather) == 3                    # the three stage buffers went through accumulate()
-                if foreach or i == 0:
+                assert len(fb.grads._gather) == 3                    # the three stage buffers went through accumulate_bundles()
+                if exact or i == 0:
                     assert torch.equal(fb.grads.flat, fa.flat)       # ... and left the gradients of the per-parameter route
             step()
             losses.append(float(loss.detach()))
-    if foreach:
+    if exact:
         assert losses[0::2] == losses[1::2]                # same losses step by step: the re-packed weights were the updated ones
     else:
         assert losses[0] == losses[1] and all(abs(x - y) <= 1e-5 * abs(x) for x, y in zip(losses[0::2], losses[1::2]))
     assert losses[0] != losses[4]                          # ... and they did change
     for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
         assert na == nb
-        if foreach:
+        if exact:
             assert torch.equal(pa.detach(), pb.detach()), na
         elif not (na.endswith("lin_k.bias") or na.endswith("lin_k_node.bias") or na.endswith("lin_k_edge.bias")):
             # (a key bias shifts every logit of a target alike: its gradient is rounding noise, and AdamW turns noise of either sign

@@ -98,18 +98,21 @@ def test_training_step_packs_once_and_matches_the_per_stage_route(dev):
         assert torch.equal(out[0][1][n], out[1][1][n]), n
 
 
+@pytest.mark.parametrize("form", ["foreach", "single"])
 @pytest.mark.parametrize("n", [1, 7, 1000, 530_001])
-def test_adamw_launch_is_torch_adamw_element_by_element(n, dev):
-    """five steps of driver.FlatAdamW against torch.optim.AdamW(foreach=False) -- the form FlatTraining used before -- from the same
-    parameters, gradients and schedule: parameters and both moments bit-identical after every step (the kernel performs torch's
-    operations in torch's order with torch's roundings); state_dict interchangeable"""
+def test_adamw_launch_is_torch_adamw_element_by_element(n, form, dev):
+    """five steps of driver.FlatAdamW against torch.optim.AdamW from the same parameters, gradients and schedule: parameters and both
+    moments bit-identical after every step (the kernel performs torch's operations in torch's order with torch's roundings).
+    form "foreach": torch's multi-tensor implementation -- what `AdamW(model.parameters())` of MODEL:205 runs on a GPU -- which divides
+    sqrt(exp_avg_sq) by sqrt(1 - beta2^step); form "single": `foreach=False`, which multiplies by the reciprocal.  state_dict
+    interchangeable"""
     from trajsde_amd import driver
     g = torch.Generator(device="cpu").manual_seed(n)
     p0 = torch.randn(n, generator=g)
     pa = torch.nn.Parameter(p0.clone().to(dev))
     pb = torch.nn.Parameter(p0.clone().to(dev))
-    a = torch.optim.AdamW([pa], lr=3e-3, weight_decay=1e-2, foreach=False)
-    b = driver.FlatAdamW([pb], lr=3e-3, weight_decay=1e-2, foreach=False)
+    a = torch.optim.AdamW([pa], lr=3e-3, weight_decay=1e-2, foreach=form == "foreach")
+    b = driver.FlatAdamW([pb], lr=3e-3, weight_decay=1e-2, form=form)
     sa = torch.optim.lr_scheduler.CosineAnnealingLR(a, T_max=4, eta_min=0.0)
     sb = torch.optim.lr_scheduler.CosineAnnealingLR(b, T_max=4, eta_min=0.0)
     for step in range(5):
@@ -121,14 +124,14 @@ def test_adamw_launch_is_torch_adamw_element_by_element(n, dev):
         b.step()
         sa.step()
         sb.step()
-        assert torch.equal(pa.detach(), pb.detach()), (step, float((pa - pb).abs().max()))
+        assert torch.equal(pa.detach(), pb.detach()), (step, float((pa.detach() - pb.detach()).abs().max()))
         for key in ("exp_avg", "exp_avg_sq"):
             assert torch.equal(a.state[pa][key], b.state[pb][key]), (step, key)
         assert float(a.state[pa]["step"]) == float(b.state[pb]["step"]) == step + 1
     # either optimizer resumes the other's checkpoint
-    c = torch.optim.AdamW([torch.nn.Parameter(pb.detach().clone())], lr=3e-3, weight_decay=1e-2, foreach=False)
+    c = torch.optim.AdamW([torch.nn.Parameter(pb.detach().clone())], lr=3e-3, weight_decay=1e-2, foreach=form == "foreach")
     c.load_state_dict(b.state_dict())
-    d = driver.FlatAdamW([torch.nn.Parameter(pa.detach().clone())], lr=3e-3, weight_decay=1e-2)
+    d = driver.FlatAdamW([torch.nn.Parameter(pa.detach().clone())], lr=3e-3, weight_decay=1e-2, form=form)
     d.load_state_dict(a.state_dict())
     grad = torch.randn(n, generator=g).to(dev)
     for opt in (c, d):
@@ -143,8 +146,9 @@ def test_adamw_launch_leaves_unsupported_forms_to_torch(dev):
     for kwargs, device in (({"amsgrad": True}, dev), ({}, torch.device("cpu"))):
         p0 = torch.randn(33)
         pa, pb = torch.nn.Parameter(p0.clone().to(device)), torch.nn.Parameter(p0.clone().to(device))
-        a = torch.optim.AdamW([pa], lr=1e-2, foreach=False, **kwargs)
-        b = driver.FlatAdamW([pb], lr=1e-2, foreach=False, **kwargs)
+        a = torch.optim.AdamW([pa], lr=1e-2, **kwargs)                   # torch's own choice of implementation (`foreach=None`) ...
+        b = driver.FlatAdamW([pb], lr=1e-2, **kwargs)                    # ... which is what the default form leaves to it
+        assert b.param_groups[0]["foreach"] is None and driver.FlatAdamW([torch.nn.Parameter(p0.clone())], form="single").param_groups[0]["foreach"] is False
         for _ in range(2):
             g = torch.randn(33).to(device)
             pa.grad, pb.grad = g.clone(), g.clone()

@@ -80,7 +80,7 @@ SIGNATURES = {
     "trajsde_pack_many_table_bytes": (I64, [C.POINTER(PackItem), C.c_int]),
     "trajsde_pack_weights_many": (C.c_int, [C.POINTER(PackItem), C.c_int, P, P, I64, C.c_int, P]),
     "trajsde_grad_gather_add": (C.c_int, [C.POINTER(GatherItem), C.c_int, P, P]),
-    "trajsde_adamw_step": (C.c_int, [P, P, P, P, I64, F32, F32, F32, F32, F32, F32, F32, P]),
+    "trajsde_adamw_step": (C.c_int, [P, P, P, P, I64, F32, F32, F32, F32, F32, C.c_int, F32, F32, P]),
     "trajsde_rotate": (C.c_int, [P, I32, P, I32, P, P, P]),
     "trajsde_graph_ws_bytes": (I64, [C.POINTER(Batch)]),
     "trajsde_graph_prepare": (C.c_int, [C.POINTER(Batch), P, F32, C.POINTER(Noise), P, I64, C.POINTER(Graph), P]),

@@ -32,16 +32,20 @@ __global__ __launch_bounds__(256) void k_grad_gather_add(const GatherItems items
 //   param.mul_(1 - lr * weight_decay)                                    decay
 //   exp_avg.lerp_(grad, 1 - beta1)                                       w1   (|w| < 0.5: a + w (b - a), ATen/native/Lerp.h)
 //   exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)         beta2, w2
-//   denom = (exp_avg_sq.sqrt() / sqrt(1 - beta2^step)).add_(eps)         inv_bias2_sqrt, eps  (torch divides a tensor by a host
-//                                                                        scalar as a product with the scalar's reciprocal, formed in
-//                                                                        double and rounded to fp32: measured, tools/scratch)
+//   denom = (exp_avg_sq.sqrt() / sqrt(1 - beta2^step)).add_(eps)         bias2, eps  (torch divides a tensor by a host scalar as a
+//                                                                        product with the scalar's reciprocal, formed in double and
+//                                                                        rounded to fp32: `divide` = 0, bias2 = that reciprocal)
+// The multi-tensor form (`foreach=True`, what AdamW(model.parameters()) runs on a GPU: MODEL:205) differs in ONE operation: its
+// _foreach_div_ by the scalar list is a true division (`divide` = 1, bias2 = sqrt(1 - beta2^step) itself).  Measured on this torch,
+// element by element over 2e5 values: both forms reproduced exactly (tests/test_gpu_step_launches.py).
 //   param.addcdiv_(exp_avg, denom, value=-(lr / (1 - beta1^step)))       neg_step
 struct AdamScalars {
-  float decay, w1, beta2, w2, inv_bias2_sqrt, eps, neg_step;
+  float decay, w1, beta2, w2, bias2, eps, neg_step;
 };
 // (each torch op rounds its result to fp32; inside one op the multiply-add is fused, as hipcc contracts it in torch's kernels.  Written
 //  with contraction OFF and the fused operations spelled out: the __f*_rn spellings are plain operators to this compiler and were
 //  contracted across the op boundaries; __fsqrt_rn is the bare 1-ulp v_sqrt_f32, sqrtf the correctly rounded sequence torch uses)
+template <bool DIVIDE>
 __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, const AdamScalars& c) {
 #pragma clang fp contract(off)
   p = p * c.decay;
@@ -50,11 +54,12 @@ __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v,
   v = v * c.beta2;
   const float gg = g * g;
   v = __builtin_fmaf(c.w2, gg, v);                                     // addcmul: a + value * (b * c)
-  float denom = sqrtf(v) * c.inv_bias2_sqrt;
+  float denom = DIVIDE ? sqrtf(v) / c.bias2 : sqrtf(v) * c.bias2;
   denom = denom + c.eps;
   const float q = m / denom;
   p = __builtin_fmaf(c.neg_step, q, p);
 }
+template <bool DIVIDE>
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
                                                float* __restrict__ exp_avg_sq, int64_t n, AdamScalars c, int vec) {
   const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
@@ -66,17 +71,17 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ param, const 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float pk = p[k], mk = m[k], vk = v[k];
-        adamw_one(pk, g[k], mk, vk, c);
+        adamw_one<DIVIDE>(pk, g[k], mk, vk, c);
         p[k] = pk; m[k] = mk; v[k] = vk;
       }
       *reinterpret_cast<f4*>(param + i) = p;
       *reinterpret_cast<f4*>(exp_avg + i) = m;
       *reinterpret_cast<f4*>(exp_avg_sq + i) = v;
     } else {
-      for (int64_t j = i; j < n; ++j) adamw_one(param[j], grad[j], exp_avg[j], exp_avg_sq[j], c);
+      for (int64_t j = i; j < n; ++j) adamw_one<DIVIDE>(param[j], grad[j], exp_avg[j], exp_avg_sq[j], c);
     }
   } else if (t < n) {
-    adamw_one(param[t], grad[t], exp_avg[t], exp_avg_sq[t], c);
+    adamw_one<DIVIDE>(param[t], grad[t], exp_avg[t], exp_avg_sq[t], c);
   }
 }
 
@@ -105,18 +110,19 @@ int trajsde_grad_gather_add(const trajsde_gather_item* items, int n_items, const
 }
 
 int trajsde_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float decay, float w1,
-                       float beta2, float w2, float inv_bias2_sqrt, float eps, float neg_step, void* stream) {
+                       float beta2, float w2, float bias2, int divide, float eps, float neg_step, void* stream) {
   TS_REQUIRE(param && grad && exp_avg && exp_avg_sq, "adamw_step: null pointer");
   TS_REQUIRE(n >= 0, "adamw_step: negative length");
-  TS_REQUIRE(inv_bias2_sqrt > 0.f && inv_bias2_sqrt < 3.0e38f, "adamw_step: 1 / sqrt(1 - beta2^step) must be positive and finite (step >= 1)");
+  TS_REQUIRE(bias2 > 0.f && bias2 < 3.0e38f, "adamw_step: the bias-correction scalar must be positive and finite (step >= 1)");
   if (n == 0) return TRAJSDE_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const uintptr_t all = reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
                         reinterpret_cast<uintptr_t>(exp_avg_sq);
   const int vec = (all & 15) == 0;
   const int64_t threads = vec ? (n + 3) / 4 : n;
-  const AdamScalars c{decay, w1, beta2, w2, inv_bias2_sqrt, eps, neg_step};
-  TS_LAUNCH(k_adamw, dim3(unsigned((threads + 255) / 256)), 256, 0, st, param, grad, exp_avg, exp_avg_sq, n, c, vec);
+  const AdamScalars c{decay, w1, beta2, w2, bias2, eps, neg_step};
+  if (divide) TS_LAUNCH(k_adamw<true>, dim3(unsigned((threads + 255) / 256)), 256, 0, st, param, grad, exp_avg, exp_avg_sq, n, c, vec);
+  else TS_LAUNCH(k_adamw<false>, dim3(unsigned((threads + 255) / 256)), 256, 0, st, param, grad, exp_avg, exp_avg_sq, n, c, vec);
   return TRAJSDE_OK;
 }
 

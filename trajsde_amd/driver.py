@@ -359,11 +359,23 @@ class FlatGrads:
 
 
 class FlatAdamW(torch.optim.AdamW):
-    """torch.optim.AdamW whose step over a contiguous fp32 GPU tensor is ONE launch (trajsde_adamw_step: the operations of torch's
-    single-tensor form in torch's order, its scalars formed here as torch forms them) instead of nine element-wise ones -- 2 MB of
-    parameters make each of them ~5 us of GPU time and ~15 us of host time, however little they compute.  State (`step`, `exp_avg`,
-    `exp_avg_sq`), param_groups, state_dict and the lr schedulers are torch's own; anything the launch does not cover (amsgrad,
+    """torch.optim.AdamW whose step over a contiguous fp32 GPU tensor is ONE launch (trajsde_adamw_step: torch's operations in torch's
+    order, its scalars formed here as torch forms them) instead of nine element-wise ones -- 2 MB of parameters make each of them ~5 us
+    of GPU time and ~15 us of host time, however little they compute.  `form`: whose roundings the launch reproduces, bit for bit --
+    "foreach" (default): torch's multi-tensor implementation, i.e. what `AdamW(model.parameters())` of MODEL:205 runs on a GPU;
+    "single": the single-tensor implementation (`foreach=False`).  The two differ in one operation (exp_avg_sq.sqrt() divided by
+    sqrt(1 - beta2^step): a true division in the multi-tensor form, a product with the reciprocal in the other).  State (`step`,
+    `exp_avg`, `exp_avg_sq`), param_groups, state_dict and the lr schedulers are torch's own; anything the launch does not cover (amsgrad,
     maximize, capturable, a CPU tensor, another dtype) goes to torch's step unchanged."""
+
+    def __init__(self, params, *args, form: str = "foreach", **kwargs) -> None:
+        if form not in ("foreach", "single"):
+            raise ValueError(f"FlatAdamW form {form!r}: 'foreach' or 'single'")
+        self.form = form
+        # what torch runs where the launch does not apply, and what a checkpoint's param_groups say: the multi-tensor form is torch's
+        # own choice on a GPU when `foreach` is None (the reference's `AdamW(model.parameters())` stores None), the other is False
+        kwargs.setdefault("foreach", None if form == "foreach" else False)
+        super().__init__(params, *args, **kwargs)
 
     def _fast(self, group) -> bool:
         if group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("fused") or group.get("differentiable"):
@@ -403,8 +415,10 @@ class FlatAdamW(torch.optim.AdamW):
                 step = float(state["step"])
                 bias1, bias2 = 1 - beta1 ** step, 1 - beta2 ** step
                 with torch.cuda.device(p.device):
+                    divide = self.form == "foreach"
                     _lib.check(L.trajsde_adamw_step(p.data_ptr(), p.grad.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
-                                                    p.numel(), 1 - lr * wd, 1 - beta1, beta2, 1 - beta2, 1.0 / (bias2 ** 0.5), eps, -(lr / bias1),
+                                                    p.numel(), 1 - lr * wd, 1 - beta1, beta2, 1 - beta2,
+                                                    bias2 ** 0.5 if divide else 1.0 / (bias2 ** 0.5), int(divide), eps, -(lr / bias1),
                                                     torch.cuda.current_stream().cuda_stream), "trajsde_adamw_step")
         return loss
 
@@ -437,16 +451,19 @@ class FlatTraining:
         self.flat_param.grad = self.grads.flat
         model._grad_sink = self.grads                        # the path loss hands its gradients over in a few launches (accumulate)
         self._stages = [m for m in model.modules() if hasattr(m, "touch")]
-        # foreach=False: torch's multi-tensor ("foreach", the default on a GPU) and `fused=True` forms cut ONE tensor into 64 K-element
-        # chunks -- ten workgroups for this model: nine launches of 25-55 us each, 0.33 ms of a 10 ms step (kernel trace, round 4); the
-        # plain element-wise form spreads the same arithmetic over the chip (~5 us a launch).  Same operations element by element: the
-        # per-parameter AdamW and this one agree to the last place or two (tests/test_gpu_backward.py::test_flat_training_is_...)
-        # (the two forms round differently in the last place: `model.adamw_foreach = True` restores the multi-tensor form, which ends on
-        #  the very bits of `AdamW(model.parameters())` as the reference constructs it, MODEL:205)
-        # (on a GPU the element-wise form is one launch: FlatAdamW)
-        adamw = torch.optim.AdamW if getattr(model, "adamw_foreach", False) or not runtime.single_call_forms() else FlatAdamW
-        self.optimizer = adamw([self.flat_param], lr=model.lr, weight_decay=model.weight_decay,
-                               foreach=bool(getattr(model, "adamw_foreach", False)))
+        # The optimizer over the ONE tensor.  torch's multi-tensor ("foreach", the default on a GPU) and `fused=True` forms cut one
+        # tensor into 64 K-element chunks -- ten workgroups for this model: nine launches of 25-55 us each, 0.33 ms of a 10 ms step (kernel
+        # trace, round 4) -- and its single-tensor form is nine chip-wide launches of ~5 us.  FlatAdamW does the update in ONE launch and
+        # ends on the very bits of the multi-tensor form, i.e. of `AdamW(model.parameters())` as the reference constructs it (MODEL:205;
+        # tests/test_gpu_backward.py::test_flat_training_is_the_per_parameter_adamw_bit_for_bit, tests/test_gpu_step_launches.py).
+        # `model.adamw_foreach = True`: torch's own multi-tensor implementation; `model.adamw_form = "single"`: the roundings of torch's
+        # `foreach=False` (what this loop ran in round 4: a product with a reciprocal where the multi-tensor form divides).
+        if getattr(model, "adamw_foreach", False) or not runtime.single_call_forms():
+            self.optimizer = torch.optim.AdamW([self.flat_param], lr=model.lr, weight_decay=model.weight_decay,
+                                               foreach=bool(getattr(model, "adamw_foreach", False)))
+        else:
+            self.optimizer = FlatAdamW([self.flat_param], lr=model.lr, weight_decay=model.weight_decay,
+                                       form=str(getattr(model, "adamw_form", "foreach")))
         if hasattr(model, "scheduler_step"):
             self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=model.scheduler_step, gamma=model.scheduler_gamma)
         else:
@@ -621,8 +638,12 @@ def train(model, batches_per_epoch, epochs: int, seed: int = 0, log=None, ckpt_p
     flat.grads.early_enabled = (dist_on and bool(getattr(model, "overlap_grad_allreduce", True))
                                 and flat.grads.early_plan({id(p): n for n, p in model.named_parameters()}))
     if rank_is_zero() and log:
-        form = "multi-tensor (foreach: the bits of the reference's AdamW(model.parameters()))" if getattr(model, "adamw_foreach", False) \
-            else "element-wise over one flat tensor (last-place differences from torch's multi-tensor AdamW; model.adamw_foreach=True restores it)"
+        opt = getattr(flat, "optimizer", None)
+        if isinstance(opt, FlatAdamW):
+            form = ("one launch over the flat tensor, the bits of torch's multi-tensor AdamW = the reference's AdamW(model.parameters())"
+                    if opt.form == "foreach" else "one launch over the flat tensor, the bits of torch's single-tensor AdamW (foreach=False)")
+        else:
+            form = "torch's multi-tensor AdamW (foreach)" if getattr(model, "adamw_foreach", False) else "torch's / the model's own optimizer"
         print(f"[trajsde_amd.driver] AdamW form: {form}; gradient all-reduce: "
               f"{'two slices, decoder+aggregator early' if flat.grads.early_enabled else ('one piece' if dist_on else 'none (one rank)')}",
               file=sys.stderr)
