@@ -420,6 +420,71 @@ def test_compacted_edge_lists_equal_the_oracle_edge_sets_exactly(S, n, L, kw, de
         assert bool((src[1:][same] >= src[:-1][same]).all())                       # senders ascending inside a row
 
 
+def _random_graph_cases(count, seed):
+    """seeded shapes for the sweep below: scene counts, scene sizes (down to one actor), lane counts, box sizes from "everyone sees
+    everyone" to "nobody sees anybody", every generator option, shuffled / duplicated / pruned input edge lists"""
+    import random
+    rnd = random.Random(seed)
+    cases = []
+    for i in range(count):
+        kw = {}
+        if rnd.random() < 0.5:
+            kw["mixed_source"] = True
+        elif rnd.random() < 0.5:
+            kw["source"] = rnd.choice([0, 1])
+        if rnd.random() < 0.6:
+            kw["history_dropout"] = rnd.choice([0.1, 0.4, 0.8])
+        if rnd.random() < 0.4 and kw.get("source", 0) != 1:
+            kw["nus_sparsity"] = True
+        cases.append((rnd.choice([1, 2, 3, 5]), rnd.choice([1, 2, 3, 7, 16, 17, 40, 65, 90]), rnd.choice([1, 2, 5, 11]),
+                      rnd.choice([20.0, 60.0, 150.0, 600.0]), rnd.choice(["as is", "shuffled", "duplicated", "pruned"]), 1000 + i, kw))
+    return cases
+
+
+@pytest.mark.parametrize("S,n,L,box,edges,seed,kw", _random_graph_cases(24, 11))
+def test_graph_stage_on_randomised_shapes_equals_the_oracle_lists(S, n, L, box, edges, seed, kw, dev):
+    """the graph stage (rewritten in round 5: seven launches) over a seeded sweep of shapes: the three compacted lists equal the
+    oracle's as multisets, rows canonical, segment pointers the CSR of the targets -- in the exact form (lengths read back) AND in the
+    sync-free form the inference forward uses (lengths stay on the device): the two forwards give the same trajectories"""
+    from trajsde_amd.runtime import NoiseSpec
+    from trajsde_amd.synth import synth
+    K, T = 2, 5
+    batch = synth(S=S, n=n, L=L, F=T, box=box, seed=seed, **kw)
+    g = torch.Generator().manual_seed(seed)
+    ei = batch["edge_index"]
+    if ei.shape[1] > 0:
+        if edges == "duplicated":
+            ei = torch.cat([ei, ei[:, : max(1, ei.shape[1] // 7)]], dim=1)
+        if edges == "pruned":
+            ei = ei[:, torch.rand(ei.shape[1], generator=g) < 0.6]
+        if edges != "as is":
+            ei = ei[:, torch.randperm(ei.shape[1], generator=g)]
+        batch["edge_index"] = ei.contiguous()
+    model, cfg = H.build_model(K, T, 0.5, init_seed=2)
+    want = H.oracle_forward(model, cfg, batch, noise_seed=seed)
+    model = model.to(dev)
+    model.encoder.capture_intermediates = True                        # the exact form, lists exported
+    o = model(batch.to(dev), noise=NoiseSpec(seed=seed))
+    im = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in model.encoder.last_intermediates.items()}
+    N, A = batch.num_nodes, batch["agent_index"].numel()
+    Nt = N + A
+    t_of = torch.div(im["aa_dst"], Nt, rounding_mode="floor")
+    assert torch.equal(_sorted_cols(t_of * Nt + im["aa_src"], im["aa_dst"]), _sorted_cols(*want["aa_edge_list"]))
+    assert torch.equal(_sorted_cols(im["g_src"], im["g_dst"]), _sorted_cols(*want["g_edge_list"]))
+    assert torch.equal(_sorted_cols(im["la_lane"], im["la_dst"]), _sorted_cols(*want["al_edge_list"]))
+    for dst, src, segptr, rows in ((im["aa_dst"], im["aa_src"], im["aa_segptr"], 21 * Nt), (im["g_dst"], im["g_src"], im["g_segptr"], N),
+                                   (im["la_dst"], im["la_lane"], im["la_segptr"], N)):
+        assert segptr.numel() == rows + 1 and int(segptr[0]) == 0 and int(segptr[-1]) == dst.numel()
+        assert torch.equal(segptr[1:] - segptr[:-1], torch.bincount(dst.to(torch.int64), minlength=rows).to(torch.int32))
+        assert bool((dst[1:] >= dst[:-1]).all())
+        same = dst[1:] == dst[:-1]
+        assert bool((src[1:][same] >= src[:-1][same]).all())
+    assert H.maxdiff(o["loc"].cpu(), want["loc"]) <= TOL and H.maxdiff(o["pi"].cpu(), want["pi"]) <= TOL
+    model.encoder.capture_intermediates = False                       # the inference forward: sync-free where the build supports it
+    o2 = model(batch.to(dev), noise=NoiseSpec(seed=seed))
+    assert torch.equal(o2["loc"], o["loc"]) and torch.equal(o2["pi"], o["pi"])
+
+
 def test_csr_rows_longer_than_the_lds_sort_buffer(dev):
     """a target with more than 4096 in-edges (and an actor near more than 4096 lanes) takes the global-memory path of the
     canonical row sort; the row length is not a power of two"""
