@@ -1190,7 +1190,8 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
     float* qkv_b[3] = {G(p + ".lin_q_node.bias"), G(p + ".lin_k_node.bias"), G(p + ".lin_v_node.bias")};
     TS_REQUIRE(!missing, "aggregator_backward: parameter table lacks an entry of " + p);
     const NodeBlockTape tp{w.agg[l], w.xn[l], w.x1[l], w.xn2[l]};
-    if (int rc = node_block_backward(lb + AggLayerBwdL::NODE, tp, dcur, N, w.nb, wc, gr, w.dagg, w.dxn, st, drop_of(l))) return rc;
+    WgradBatch wb(wc, N, N);                                       // the layer's seven N-row problems in one launch (gated update + q, k, v)
+    if (int rc = node_block_backward(lb + AggLayerBwdL::NODE, tp, dcur, N, w.nb, wc, gr, w.dagg, w.dxn, st, drop_of(l), &wb)) return rc;
     // (carved one behind the other: one fill when nothing sits between them)
     if (w.DVN >= w.DKN + N * 64 && w.DVN - w.DKN < N * 64 + 1024) {
       TS_HIP(hipMemsetAsync(w.DKN, 0, size_t(w.DVN - w.DKN + N * 64) * sizeof(float), st));
@@ -1234,7 +1235,6 @@ int trajsde_aggregator_backward_heads(const trajsde_batch* b, const trajsde_grap
       if (int rc = cb.flush()) return rc;
     }
     const float* dps[3] = {w.DQ, w.DKN, w.DVN};
-    WgradBatch wb(wc, N, N);
     for (int j = 0; j < 3; ++j)
       if (int rc = wb.add(dps[j], 64, w.xn[l], 64, qkv_w[j], 64, 0, qkv_b[j], 0)) return rc;
     if (int rc = wb.flush()) return rc;

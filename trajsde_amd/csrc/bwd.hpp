@@ -172,7 +172,7 @@ struct NodeBlockGrads {                                                         
 // writes dagg, dxn (the block's contribution to d xn) and sc.dx1 (= d x1, also the residual gradient of x)
 int node_block_backward(const float* img /*NodeBlockBwdL*/, const NodeBlockTape& tp, const float* dout, int64_t R,
                         const NodeBlockScratch& sc, const WgradCtx& wc, const NodeBlockGrads& gr, float* dagg, float* dxn,
-                        hipStream_t st, const DropArg& drop);
+                        hipStream_t st, const DropArg& drop, WgradBatch* defer = nullptr);
 
 // the FFN half alone (TemporalEncoderLayer: linear1 / linear2 / norm2); uses gr.w1, b1, w2, b2, n2g, n2b only
 int ffn_block_backward(const float* img_a /*FfnBwdAL*/, const float* img_b /*FfnBwdBL*/, const float* xn2, const float* x1,

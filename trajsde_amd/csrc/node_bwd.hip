@@ -687,8 +687,14 @@ int ffn_block_backward(const float* img_a, const float* img_b, const float* xn2,
   return wb.flush();
 }
 
+// `defer`: a batch of the caller over the same R rows that takes the gated update's four weight-gradient problems instead of a launch of
+// their own.  Only for a caller whose later kernels leave sc.UPD / DGP / DS / dx1 / H alone until it flushes: the AGGREGATOR's layers
+// do (seven N-row problems in one launch); the ENCODER's blocks do NOT -- their attention backward keeps its per-target sums in the
+// same memory as sc.H (encoder_bwd.hip EncBwdWs: RL = nb.H), which under dropout holds the masked d x1 rows of the out_proj problem
+// (tried: test_full_size_training_step_agrees_between_kernel_forms caught it at once)
 int node_block_backward(const float* img, const NodeBlockTape& tp, const float* dout, int64_t R, const NodeBlockScratch& sc,
-                        const WgradCtx& wc, const NodeBlockGrads& gr, float* dagg, float* dxn, hipStream_t st, const DropArg& drop) {
+                        const WgradCtx& wc, const NodeBlockGrads& gr, float* dagg, float* dxn, hipStream_t st, const DropArg& drop,
+                        WgradBatch* defer) {
   const int64_t ntiles = (R + 15) / 16;
   const int gu = tile_grid(ntiles, 256, UpdBwdL::SIZE * 4);
   if (int rc = ffn_block_backward(img + NodeBlockBwdL::FFN_A, img + NodeBlockBwdL::FFN_B, tp.xn2, tp.x1, dout, R, sc, wc, gr, st, drop)) return rc;
@@ -696,12 +702,13 @@ int node_block_backward(const float* img, const NodeBlockTape& tp, const float* 
   const float* dx1m = drop.p > 0.f ? sc.H : sc.dx1;
   TS_LAUNCH(k_upd_bwd, gu, 256, UpdBwdL::SIZE * 4, st, img + NodeBlockBwdL::UPD, sc.dx1, tp.agg, tp.xn, R, sc.UPD, sc.DGP, sc.DS, dagg, dxn, sc.H,
             drop);
-  WgradBatch wb(wc, R, R);
+  WgradBatch own(wc, R, R);
+  WgradBatch& wb = defer ? *defer : own;
   if (int rc = wb.add(dx1m, 64, sc.UPD, 64, gr.w_out, 64, 0, gr.b_out, 0)) return rc;
   if (int rc = wb.add(sc.DGP, 64, tp.agg, 64, gr.w_ih, 64, 0, gr.b_ih, 0)) return rc;
   if (int rc = wb.add(sc.DGP, 64, tp.xn, 64, gr.w_hh, 64, 0, gr.b_hh, 0)) return rc;
   if (int rc = wb.add(sc.DS, 64, tp.xn, 64, gr.w_self, 64, 0, gr.b_self, 0)) return rc;
-  return wb.flush();
+  return defer ? TRAJSDE_OK : own.flush();
 }
 
 int edge_embed_backward(const float* img, const float* geom, const float* demb, int64_t E, const EdgeEmbedScratch& sc,
