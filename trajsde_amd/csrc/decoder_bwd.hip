@@ -374,7 +374,7 @@ __global__ __launch_bounds__(128) void k_head_bwd(const float* __restrict__ img,
 // ------------------------------------------------------------------ reverse sweep through the Euler-Maruyama steps
 struct SweepV { enum : int { DV4 = 0, DC4 = 64, SIZE = 68 }; };
 
-__global__ __launch_bounds__(128) void k_sde_bwd(const float* __restrict__ img, const int32_t* __restrict__ best, int N, int K, int T,
+__global__ __launch_bounds__(128, 2) void k_sde_bwd(const float* __restrict__ img, const int32_t* __restrict__ best, int N, int K, int T,
                                                  int n_euler, const float* __restrict__ step_tab, const float* __restrict__ out_tab,
                                                  NoiseArg na, const float* __restrict__ H1, const float* __restrict__ H2,
                                                  const float* __restrict__ G1, const float* __restrict__ G2,
@@ -399,9 +399,32 @@ __global__ __launch_bounds__(128) void k_sde_bwd(const float* __restrict__ img, 
     f4 dy[4];                                             // dL/dy_{k+1} on entry of iteration k
     zero4(dy);
     int o = T - 1;
+    // The saved activation tiles of an iteration used to be loaded right where they are consumed, behind a matrix product they do
+    // not depend on: four exposed round trips to HBM per iteration of a kernel that runs one wave per SIMD on a third of the chip (384
+    // tiles at 128 x 48 agents).  Now the two that are consumed FIRST (the last layers' activations) and the diffusion value are
+    // requested one iteration ahead (32 registers), the other two at the top of their iteration, a matrix product ahead of their use.
+    f4 nh2[4], ng2[4];
+    float ngs;
+    {
+      const int k0 = n_euler - 1;
+      load_row(nh2, H2 + k0 * slab, i, L.g);
+      load_row(ng2, G2 + k0 * slab, i, L.g);
+      ngs = GS[int64_t(k0) * N + i];
+    }
     for (int k = n_euler - 1; k >= 0; --k) {
       keep_lds_reads_here();
       const float dt = step_tab[k * 8 + 1], sq = step_tab[k * 8 + 2];
+      f4 ah2[4], ah1[4], ag2[4], ag1[4];
+      load_row(ah1, H1 + k * slab, i, L.g);
+      load_row(ag1, G1 + k * slab, i, L.g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) { ah2[jt] = nh2[jt]; ag2[jt] = ng2[jt]; }
+      const float gs = ngs;
+      if (k > 0) {
+        load_row(nh2, H2 + (k - 1) * slab, i, L.g);
+        load_row(ng2, G2 + (k - 1) * slab, i, L.g);
+        ngs = GS[int64_t(k - 1) * N + i];
+      }
       // outputs interpolated between y_k and y_{k+1}: s_o = w0 y_k + w1 y_{k+1}
       f4 dprev[4];
       zero4(dprev);
@@ -418,7 +441,7 @@ __global__ __launch_bounds__(128) void k_sde_bwd(const float* __restrict__ img, 
           }
         --o;
       }
-      f4 a[4], d[4], t[4];
+      f4 d[4], t[4];
       // ---- drift net: y' gets f*dt
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
@@ -426,18 +449,16 @@ __global__ __launch_bounds__(128) void k_sde_bwd(const float* __restrict__ img, 
         for (int c = 0; c < 4; ++c) d[jt][c] = dt * dy[jt][c];
       if (live) store_row(d, DF + k * slab, row, L.g);
       linear_t(t, d, lds + SweepL::F_W4T, L);
-      load_row(a, H2 + k * slab, i, L.g);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - a[jt][c] * a[jt][c]);
+        for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - ah2[jt][c] * ah2[jt][c]);
       if (live) store_row(d, DH2 + k * slab, row, L.g);
       linear_t(t, d, lds + SweepL::F_W2T, L);
-      load_row(a, H1 + k * slab, i, L.g);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - a[jt][c] * a[jt][c]);
+        for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - ah1[jt][c] * ah1[jt][c]);
       if (live) store_row(d, DH1 + k * slab, row, L.g);
       f4 dyn[4];                                          // dL/dy_k being assembled
 #pragma unroll
@@ -451,16 +472,14 @@ __global__ __launch_bounds__(128) void k_sde_bwd(const float* __restrict__ img, 
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int c = 0; c < 4; ++c) cdot = fmaf(z[jt][c] * sq, dy[jt][c], cdot);
-      const float gs = GS[int64_t(k) * N + i];
       const float dgp = row_sum(cdot) * gs * (1.0f - gs);
-      load_row(a, G2 + k * slab, i, L.g);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
         const f4 w4 = *reinterpret_cast<const f4*>(lds + SweepL::G_W4 + 16 * jt + 4 * L.g);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          if (live) dv4[jt][c] = fmaf(dgp, a[jt][c], dv4[jt][c]);
-          d[jt][c] = dgp * w4[c] * (1.0f - a[jt][c] * a[jt][c]);
+          if (live) dv4[jt][c] = fmaf(dgp, ag2[jt][c], dv4[jt][c]);
+          d[jt][c] = dgp * w4[c] * (1.0f - ag2[jt][c] * ag2[jt][c]);
         }
       }
       if (live) {
@@ -468,11 +487,10 @@ __global__ __launch_bounds__(128) void k_sde_bwd(const float* __restrict__ img, 
         store_row(d, DG2 + k * slab, row, L.g);
       }
       linear_t(t, d, lds + SweepL::G_W2T, L);
-      load_row(a, G1 + k * slab, i, L.g);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - a[jt][c] * a[jt][c]);
+        for (int c = 0; c < 4; ++c) d[jt][c] = t[jt][c] * (1.0f - ag1[jt][c] * ag1[jt][c]);
       if (live) store_row(d, DG1 + k * slab, row, L.g);
       linear_adj<4, 4>(dyn, d, lds + SweepL::G_W0T, L);
 #pragma unroll
