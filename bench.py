@@ -604,12 +604,14 @@ def main():
 
         def timed(first, reduce_):
             flat.grads.early_enabled = bool(reduce_ and early_ok)
-            for i in range(2):                                             # optimizer state, allocator pools, communicator warm-up
+            for i in range(4):                                             # optimizer state, allocator pools (a pipelined loop's block sizes
+                                                                           # take more than two steps to settle: a late hipMalloc inside the
+                                                                           # timed window was a 45 ms outlier in 2 of ~20 runs), communicator
                 tstep(first + i, reduce_)
             sync_all()
             t0 = time.perf_counter()
             for i in range(steps):
-                tstep(first + 2 + i, reduce_)
+                tstep(first + 4 + i, reduce_)
             sync_all()
             el = time.perf_counter() - t0
             if dist is not None:

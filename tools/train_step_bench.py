@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="config2")
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--pipeline", action="store_true",
                     help="as driver.train runs it: every step on a fresh copy of the batch, the NEXT step's copy rotated and run "
                          "through the graph stage on the side stream right after this step was enqueued (runtime.prefetch_graph)")
