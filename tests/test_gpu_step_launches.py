@@ -2,7 +2,6 @@
 (trajsde_pack_weights_many), the stage gradient buffers gathered into the flat gradient tensor by one launch
 (trajsde_grad_gather_add), AdamW over the flat parameter tensor in one launch (trajsde_adamw_step).  Each against what it replaces:
 the per-stage packing call, torch's index_select + addcmul_, torch.optim.AdamW's single-tensor form (MODEL:204-207)."""
-import ctypes as C
 
 import pytest
 import torch
