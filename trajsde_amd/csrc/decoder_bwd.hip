@@ -28,6 +28,7 @@
 #include "tile.hpp"
 #include "tile_bwd.hpp"
 #include "bwd.hpp"
+#include "kernels.hpp"
 
 namespace tsde {
 
@@ -1592,6 +1593,15 @@ static int decoder_backward_impl(bool nll, float eps, float min_scale, int32_t N
   const float* init_img = blob_bwd + DecBwdBlob::INIT;
   TS_LAUNCH(k_init_sel, bwd_grid(ntiles), BWD_THREADS, InitBwdL::AE_END * 4, st, init_img, local_embed, global_embed, w.best, N,
             w.states, w.gsel);
+#if TSDE_SPLIT_H3
+  // the cooperative form (recur.hip k_sde_replay_coop: four waves a tile, the fused forward kernel's own image); TRAJSDE_REPLAY_COOP=0:
+  // the one-wave kernel of this file
+  static const bool replay_coop = []() { const char* e = getenv("TRAJSDE_REPLAY_COOP"); return !(e && e[0] == '0'); }();
+  if (replay_coop)
+    TS_LAUNCH_TAG("k_sde_replay", false, k_sde_replay_coop, ntiles < 8192 ? ntiles : 8192, 256, SDE_REPLAY_COOP_LDS_BYTES, st,
+                  blob_fwd + DecBlob::SDE6, w.best, N, K, n_euler, step_table, na, w.states, w.H1, w.H2, w.G1, w.G2, w.GS);
+  else
+#endif
   TS_LAUNCH(k_sde_replay, bwd_grid(ntiles), BWD_THREADS, DecSdeL::LOC * 4, st, blob_fwd + DecBlob::SDE, w.best, N, K, n_euler,
             step_table, na, w.states, w.H1, w.H2, w.G1, w.G2, w.GS);
 

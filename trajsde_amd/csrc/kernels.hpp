@@ -209,6 +209,10 @@ constexpr int COOP_BWD_TILES = 6;                                 // operand til
 constexpr int coop_bwd_lds_floats(int tiles) { return tiles * (COOP_BWD_TILES * (TSDE_SPLIT_H3 ? 1024 : COOP_TILE) + 128); }
 template <int TW>
 __global__ void k_enc_recur_bwd_coop(RecurBwdCoopArgs a);
+// the decoder backward's forward replay in the cooperative form (recur.hip k_sde_replay_coop; fp16x3 build).  LDS: four operand tiles + 64 floats
+constexpr int SDE_REPLAY_COOP_LDS_BYTES = (4 * 1024 + 64) * 4;
+__global__ void k_sde_replay_coop(const float* img, const int32_t* best, int N, int K, int n_euler, const float* step_tab, NoiseArg na,
+                                  float* states, float* H1, float* H2, float* G1, float* G2, float* GS);
 // vanilla HiVT variant (grid.hip)
 __global__ void k_tr_prep(const float* aa_out, const uint8_t* pad, const float* tok, int N, int TT, float* X);
 template <int HEADS, bool DROP>

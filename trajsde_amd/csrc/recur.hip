@@ -929,6 +929,120 @@ template __global__ void k_enc_recur_bwd_coop<2>(RecurBwdCoopArgs);
 template __global__ void k_enc_recur_bwd_coop<3>(RecurBwdCoopArgs);
 template __global__ void k_enc_recur_bwd_coop<4>(RecurBwdCoopArgs);
 
+// ------------------------------------------------------------------------------------------------------------------
+// The decoder backward's forward REPLAY of the winning paths in the cooperative form (decoder_bwd.hip k_sde_replay is the one-wave
+// form).  Only N paths are replayed -- 384 row tiles at 128 x 48 agents, a third of the chip's SIMDs with one wave each -- and an
+// iteration of the one-wave kernel is ~4.5 us of ONE wave's issue slots (64 tanh, 16 normals, five operand splits per lane beside 120
+// matrix instructions) 61 times over.  Here the four waves of a workgroup share a tile as in the recurrence above: wave w produces
+// channels [16w, 16w + 16) of every layer of BOTH nets (its slices of the five matrices stay in registers), the activations that feed
+// a product travel as pre-split operand tiles through the LDS, the diffusion head's dot product as four partial sums.  Three barriers
+// an iteration.  The matrices are the fused forward kernel's own image (DecSdeL6: layers in front of a tanh packed times 2 / ln 2,
+// first layers of drift and diffusion stacked), and per output the products run in the fused kernel's order: the replayed drift,
+// activations and states are the forward's own to the bit; the diffusion value sums its 64 terms in another order.
+#if TSDE_SPLIT_H3
+__global__ __launch_bounds__(256) void k_sde_replay_coop(const float* __restrict__ img, const int32_t* __restrict__ best, int N, int K,
+                                                         int n_euler, const float* __restrict__ step_tab, NoiseArg na,
+                                                         float* __restrict__ states, float* __restrict__ H1, float* __restrict__ H2,
+                                                         float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ GS) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using DD = DecSdeL6;
+  float* const Yop = lds;                                  // operand tiles: the state, first-layer activations of f / g, f's second
+  float* const Af = lds + COOP_OT;
+  float* const Ag = lds + 2 * COOP_OT;
+  float* const Bf = lds + 3 * COOP_OT;
+  float* const dotp = lds + 4 * COOP_OT;                   // [wave][16 rows]: partial dots of the diffusion head
+  const Lane L;
+  const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const WSlice w0f = load_slice(img + DD::W0FG, w, L.lane), w0g = load_slice(img + DD::W0FG, 4 + w, L.lane);
+  const WSlice w2f = load_slice(img + DD::F_W2, w, L.lane), w4f = load_slice(img + DD::F_W4, w, L.lane);
+  const WSlice w2g = load_slice(img + DD::G_W2, w, L.lane);
+  const int ch = 16 * w + 4 * L.g;                          // this lane's four channels of its row
+  const f4 b0f = *reinterpret_cast<const f4*>(img + DD::B0FG + ch), b0g = *reinterpret_cast<const f4*>(img + DD::B0FG + 64 + ch);
+  const f4 wsf = *reinterpret_cast<const f4*>(img + DD::WSFG + ch), wsg = *reinterpret_cast<const f4*>(img + DD::WSFG + 64 + ch);
+  const f4 wcf = *reinterpret_cast<const f4*>(img + DD::WCFG + ch), wcg = *reinterpret_cast<const f4*>(img + DD::WCFG + 64 + ch);
+  const f4 b2f = vec_slice(img + DD::F_B2, w, L.g), b4f = vec_slice(img + DD::F_B4, w, L.g), b2g = vec_slice(img + DD::G_B2, w, L.g);
+  const f4 w4g = vec_slice(img + DD::G_W4, w, L.g);
+  const float b4g = img[DD::G_B4];
+  const int ntiles = (N + 15) / 16;
+  const int64_t slab = int64_t(N) * D;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row = tile * 16 + L.n;
+    const bool live = row < N;
+    const int i = live ? row : N - 1;
+    const int64_t r = int64_t(best[i]) * N + i;
+    const uint32_t rid = na.row_ids ? uint32_t(na.row_ids[r]) : uint32_t(r);
+    f4 y = *reinterpret_cast<const f4*>(states + int64_t(i) * D + ch);
+    __syncthreads();                                       // the previous tile's readers of the operand tiles are done
+    opnd_write(Yop, y, w, L);
+    for (int k = 0; k < n_euler; ++k) {
+      const float dt = step_tab[k * 8 + 1], sq = step_tab[k * 8 + 2], sn = step_tab[k * 8 + 3], cs = step_tab[k * 8 + 4];
+      // the iteration's normals for this wave's 16 channels: vector work that needs nothing, first
+      f4 z;
+      if (na.z != nullptr) z = *reinterpret_cast<const f4*>(na.z + (int64_t(k) * N * K + r) * D + ch);
+      else z = philox_normal4(noise_key(na), STREAM_DECODER, uint32_t(k), rid, uint32_t(4 * w + L.g));
+      __syncthreads();                                     // y of this iteration is in Yop
+      // ---- first layers of both nets on one read of the state
+      f4 h1, g1;
+      {
+        const Opnd oy = opnd_read(Yop, L);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          h1[c] = fmaf(wcf[c], cs, fmaf(wsf[c], sn, b0f[c]));
+          g1[c] = fmaf(wcg[c], cs, fmaf(wsg[c], sn, b0g[c]));
+        }
+        slice_mma(h1, w0f, oy);
+        slice_mma(g1, w0g, oy);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          h1[c] = tanh_prescaled(h1[c]);
+          g1[c] = tanh_prescaled(g1[c]);
+        }
+      }
+      opnd_write(Af, h1, w, L);
+      opnd_write(Ag, g1, w, L);
+      if (live) {
+        *reinterpret_cast<f4*>(H1 + k * slab + int64_t(row) * D + ch) = h1;
+        *reinterpret_cast<f4*>(G1 + k * slab + int64_t(row) * D + ch) = g1;
+      }
+      __syncthreads();
+      // ---- second layers; the diffusion head's partial dot over this wave's channels
+      f4 h2 = b2f, g2 = b2g;
+      slice_mma(h2, w2f, opnd_read(Af, L));
+      slice_mma(g2, w2g, opnd_read(Ag, L));
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        h2[c] = tanh_prescaled(h2[c]);
+        g2[c] = tanh_prescaled(g2[c]);
+      }
+      opnd_write(Bf, h2, w, L);
+      {
+        float pd = g2[0] * w4g[0];
+#pragma unroll
+        for (int c = 1; c < 4; ++c) pd = fmaf(g2[c], w4g[c], pd);
+        pd = row_sum(pd);                                  // over the four lanes of the row: this wave's 16 channels
+        if (L.g == 0) dotp[16 * w + L.n] = pd;
+      }
+      if (live) {
+        *reinterpret_cast<f4*>(H2 + k * slab + int64_t(row) * D + ch) = h2;
+        *reinterpret_cast<f4*>(G2 + k * slab + int64_t(row) * D + ch) = g2;
+      }
+      __syncthreads();
+      // ---- drift output, diffusion value, the Euler-Maruyama step on this wave's channels (sde_funcs.hpp em_update)
+      f4 f = b4f;
+      slice_mma(f, w4f, opnd_read(Bf, L));
+      const float gs = fast_sigmoid(((dotp[L.n] + dotp[16 + L.n]) + (dotp[32 + L.n] + dotp[48 + L.n])) + b4g);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) y[c] = (y[c] + f[c] * dt) + gs * (z[c] * sq);
+      opnd_write(Yop, y, w, L);                            // (its readers of this iteration passed two barriers ago)
+      if (live) {
+        *reinterpret_cast<f4*>(states + (k + 1) * slab + int64_t(row) * D + ch) = y;
+        if (w == 0 && L.g == 0) GS[int64_t(k) * N + row] = gs;
+      }
+    }
+  }
+}
+#endif
+
 // forward_ood (ENC:311-313): outs [S,N,64] -> mean over samples [N,64] and std(0).mean(-1) [N] (unbiased std)
 __global__ __launch_bounds__(256) void k_ood_stats(const float* __restrict__ samples, int S, int N, float* __restrict__ mean,
                                                    float* __restrict__ stds) {
