@@ -1637,11 +1637,25 @@ static int decoder_backward_impl(bool nll, float eps, float min_scale, int32_t N
   }
 
   const int sweep_grid = bwd_grid(ntiles);
-  vp = vpart_slab(w.vpart, int64_t(sweep_grid) * waves, SweepV::SIZE);
-  TS_LAUNCH(k_sde_bwd, sweep_grid, BWD_THREADS, SweepL::SIZE * 4, st, blob_bwd + DecBwdBlob::SWEEP, w.best, N, K, T, n_euler, step_table,
-            out_table, na, w.H1, w.H2, w.G1, w.G2, w.GS, w.DS, w.DH1, w.DH2, w.DF, w.DG1, w.DG2, w.DY0, vp);
+  static_assert(SweepV::SIZE == SDE_SWEEP_V_FLOATS && SweepV::DV4 == 0 && SweepV::DC4 == 64, "recur.hip k_sde_bwd_coop writes this row");
+#if TSDE_SPLIT_H3
+  // the cooperative form (recur.hip k_sde_bwd_coop: four waves a tile); TRAJSDE_SWEEP_COOP=0: the one-wave kernel of this file
+  static const bool sweep_coop = []() { const char* e = getenv("TRAJSDE_SWEEP_COOP"); return !(e && e[0] == '0'); }();
+#else
+  const bool sweep_coop = false;
+#endif
+  const int sweep_rows = sweep_coop ? (ntiles < 8192 ? ntiles : 8192) : sweep_grid * waves;
+  vp = vpart_slab(w.vpart, sweep_rows, SweepV::SIZE);
+  if (sweep_coop) {
+    const SdeBwdCoopArgs ca{blob_bwd + DecBwdBlob::SWEEP, w.best, N, K, T, n_euler, step_table, out_table, na, w.H1, w.H2, w.G1, w.G2, w.GS,
+                            w.DS, w.DH1, w.DH2, w.DF, w.DG1, w.DG2, w.DY0, vp};
+    TS_LAUNCH_TAG("k_sde_bwd", false, k_sde_bwd_coop, sweep_rows, 256, SDE_BWD_COOP_LDS_BYTES + (8 * n_euler + 4 * T) * 4, st, ca);
+  } else {
+    TS_LAUNCH(k_sde_bwd, sweep_grid, BWD_THREADS, SweepL::SIZE * 4, st, blob_bwd + DecBwdBlob::SWEEP, w.best, N, K, T, n_euler, step_table,
+              out_table, na, w.H1, w.H2, w.G1, w.G2, w.GS, w.DS, w.DH1, w.DH2, w.DF, w.DG1, w.DG2, w.DY0, vp);
+  }
   {
-    ColsumBatch cb(st, sweep_grid * waves, SweepV::SIZE);
+    ColsumBatch cb(st, sweep_rows, SweepV::SIZE);
     cb.add(vp + SweepV::DV4, 64, grads[G4W]);
     cb.add(vp + SweepV::DC4, 1, grads[G4B]);
     if (int rc = cb.flush()) return rc;

@@ -213,6 +213,20 @@ __global__ void k_enc_recur_bwd_coop(RecurBwdCoopArgs a);
 constexpr int SDE_REPLAY_COOP_LDS_BYTES = (4 * 1024 + 64) * 4;
 __global__ void k_sde_replay_coop(const float* img, const int32_t* best, int N, int K, int n_euler, const float* step_tab, NoiseArg na,
                                   float* states, float* H1, float* H2, float* G1, float* G2, float* GS);
+// the decoder's reverse sweep in the cooperative form (recur.hip k_sde_bwd_coop; fp16x3 build).  LDS: five operand tiles + 128 floats;
+// vpart: one row of SDE_SWEEP_V_FLOATS per workgroup (d diffusion.4.weight [64], its bias at [64])
+constexpr int SDE_SWEEP_V_FLOATS = 68;
+constexpr int SDE_BWD_COOP_LDS_BYTES = (5 * 1024 + 128) * 4;
+struct SdeBwdCoopArgs {
+  const float* img;                 // SweepL
+  const int32_t* best;
+  int N, K, T, n_euler;
+  const float *step_tab, *out_tab;
+  NoiseArg na;
+  const float *H1, *H2, *G1, *G2, *GS, *DS;
+  float *DH1, *DH2, *DF, *DG1, *DG2, *DY0, *vpart;     // vpart: one row of SweepV::SIZE floats per WORKGROUP
+};
+__global__ void k_sde_bwd_coop(SdeBwdCoopArgs a);
 // vanilla HiVT variant (grid.hip)
 __global__ void k_tr_prep(const float* aa_out, const uint8_t* pad, const float* tok, int N, int TT, float* X);
 template <int HEADS, bool DROP>

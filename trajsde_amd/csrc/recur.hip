@@ -929,6 +929,12 @@ template __global__ void k_enc_recur_bwd_coop<2>(RecurBwdCoopArgs);
 template __global__ void k_enc_recur_bwd_coop<3>(RecurBwdCoopArgs);
 template __global__ void k_enc_recur_bwd_coop<4>(RecurBwdCoopArgs);
 
+// A workgroup barrier that orders LDS traffic ONLY.  `__syncthreads()` also drains every outstanding global load and store of the wave
+// (s_waitcnt vmcnt(0)) -- at each barrier: a saved tile requested an iteration ahead would be waited for at the very next barrier, and
+// every stored slab row at the one after its store.  The two decoder kernels below exchange data through the LDS alone (what a wave
+// reads from global memory was written by earlier launches or by itself), so their barriers wait for the LDS counter and nothing else.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ------------------------------------------------------------------------------------------------------------------
 // The decoder backward's forward REPLAY of the winning paths in the cooperative form (decoder_bwd.hip k_sde_replay is the one-wave
 // form).  Only N paths are replayed -- 384 row tiles at 128 x 48 agents, a third of the chip's SIMDs with one wave each -- and an
@@ -965,6 +971,7 @@ __global__ __launch_bounds__(256) void k_sde_replay_coop(const float* __restrict
   const float b4g = img[DD::G_B4];
   const int ntiles = (N + 15) / 16;
   const int64_t slab = int64_t(N) * D;
+  const uint64_t key = noise_key(na);                      // (read once: through `seed_dev` it is a load, and it was one per iteration)
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row = tile * 16 + L.n;
     const bool live = row < N;
@@ -972,15 +979,15 @@ __global__ __launch_bounds__(256) void k_sde_replay_coop(const float* __restrict
     const int64_t r = int64_t(best[i]) * N + i;
     const uint32_t rid = na.row_ids ? uint32_t(na.row_ids[r]) : uint32_t(r);
     f4 y = *reinterpret_cast<const f4*>(states + int64_t(i) * D + ch);
-    __syncthreads();                                       // the previous tile's readers of the operand tiles are done
+    lds_barrier();                                       // the previous tile's readers of the operand tiles are done
     opnd_write(Yop, y, w, L);
     for (int k = 0; k < n_euler; ++k) {
       const float dt = step_tab[k * 8 + 1], sq = step_tab[k * 8 + 2], sn = step_tab[k * 8 + 3], cs = step_tab[k * 8 + 4];
       // the iteration's normals for this wave's 16 channels: vector work that needs nothing, first
       f4 z;
       if (na.z != nullptr) z = *reinterpret_cast<const f4*>(na.z + (int64_t(k) * N * K + r) * D + ch);
-      else z = philox_normal4(noise_key(na), STREAM_DECODER, uint32_t(k), rid, uint32_t(4 * w + L.g));
-      __syncthreads();                                     // y of this iteration is in Yop
+      else z = philox_normal4(key, STREAM_DECODER, uint32_t(k), rid, uint32_t(4 * w + L.g));
+      lds_barrier();                                     // y of this iteration is in Yop
       // ---- first layers of both nets on one read of the state
       f4 h1, g1;
       {
@@ -1004,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_sde_replay_coop(const float* __restrict
         *reinterpret_cast<f4*>(H1 + k * slab + int64_t(row) * D + ch) = h1;
         *reinterpret_cast<f4*>(G1 + k * slab + int64_t(row) * D + ch) = g1;
       }
-      __syncthreads();
+      lds_barrier();
       // ---- second layers; the diffusion head's partial dot over this wave's channels
       f4 h2 = b2f, g2 = b2g;
       slice_mma(h2, w2f, opnd_read(Af, L));
@@ -1026,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_sde_replay_coop(const float* __restrict
         *reinterpret_cast<f4*>(H2 + k * slab + int64_t(row) * D + ch) = h2;
         *reinterpret_cast<f4*>(G2 + k * slab + int64_t(row) * D + ch) = g2;
       }
-      __syncthreads();
+      lds_barrier();
       // ---- drift output, diffusion value, the Euler-Maruyama step on this wave's channels (sde_funcs.hpp em_update)
       f4 f = b4f;
       slice_mma(f, w4f, opnd_read(Bf, L));
@@ -1041,6 +1048,190 @@ __global__ __launch_bounds__(256) void k_sde_replay_coop(const float* __restrict
     }
   }
 }
+
+// The decoder's REVERSE SWEEP through the Euler-Maruyama steps in the same cooperative form (decoder_bwd.hip k_sde_bwd is the one-wave
+// form: 5.5 us an iteration on one wave a tile).  Wave w owns channels [16w, 16w + 16) of every delta; its slices of the five TRANSPOSED
+// matrices (SweepL) stay in registers; deltas that feed a product travel as pre-split operand tiles.  Deltas span many binades and fp16
+// has five exponent bits, so -- as in k_enc_recur_bwd_coop -- a row is normalised ONCE per iteration by the power of two of the largest
+// magnitude of the gradient entering it (everything the iteration computes for the row is linear in that gradient); the factor comes
+// off again at every store and where the products rejoin d y.  Four barriers an iteration:
+//   B0 row magnitudes, partial dots of the diffusion scalar | B1 d f -> drift.4^T input | B2 d h2, d g2 | B3 d h1, d g1 | (first layers^T -> d y)
+// Same stored deltas as the one-wave kernel up to the rounding of one shared scale per row instead of one per product.
+__global__ __launch_bounds__(256) void k_sde_bwd_coop(const SdeBwdCoopArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using SL = SweepL;
+  auto Tb = [&](int i) { return lds + i * COOP_OT; };      // operand tiles 0..4
+  float* const MX = lds + 5 * COOP_OT;                      // [wave][16]: row magnitudes
+  float* const CD = MX + 64;                                // [wave][16]: partial dots z sqrt(h) . d y
+  // the step and output tables, once, into the LDS: read through the argument struct they are VECTOR loads from global memory (the
+  // compiler cannot prove that the kernel's own stores leave them alone), and the `while` over the output steps below made one or two of
+  // them, dependent, per iteration -- a round trip to L2 each on a chain that has nothing else to do
+  float* const stab = CD + 64;                              // [n_euler][8]
+  float* const otab = stab + 8 * a.n_euler;                 // [T][4]
+  for (int q = threadIdx.x; q < 8 * a.n_euler; q += blockDim.x) stab[q] = a.step_tab[q];
+  for (int q = threadIdx.x; q < 4 * a.T; q += blockDim.x) otab[q] = a.out_tab[q];
+  const Lane L;
+  const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const WSlice wf4 = load_slice(a.img + SL::F_W4T, w, L.lane), wf2 = load_slice(a.img + SL::F_W2T, w, L.lane);
+  const WSlice wf0 = load_slice(a.img + SL::F_W0T, w, L.lane), wg2 = load_slice(a.img + SL::G_W2T, w, L.lane);
+  const WSlice wg0 = load_slice(a.img + SL::G_W0T, w, L.lane);
+  const f4 w4g = vec_slice(a.img + SL::G_W4, w, L.g);
+  const int ch = 16 * w + 4 * L.g;
+  const int N = a.N, n_euler = a.n_euler;
+  const int ntiles = (N + 15) / 16;
+  const int64_t slab = int64_t(N) * D;
+  f4 dv4 = f4{0.f, 0.f, 0.f, 0.f};
+  float dc4 = 0.f;
+  const uint64_t key = noise_key(a.na);
+  __syncthreads();                                          // the tables are staged
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row = tile * 16 + L.n;
+    const bool live = row < N;
+    const int i = live ? row : N - 1;
+    const int64_t r = int64_t(a.best[i]) * N + i;
+    const uint32_t rid = a.na.row_ids ? uint32_t(a.na.row_ids[r]) : uint32_t(r);
+    auto at = [&](const float* slabs, int k) { return *reinterpret_cast<const f4*>(slabs + k * slab + int64_t(i) * D + ch); };
+    f4 dy = f4{0.f, 0.f, 0.f, 0.f};                         // dL/dy_{k+1} on entry of iteration k (this wave's channels)
+    int o = a.T - 1;
+    // saved activations, and the head gradient of the next output step: requested one iteration ahead
+    f4 nh2 = at(a.H2, n_euler - 1), nh1 = at(a.H1, n_euler - 1), ng2 = at(a.G2, n_euler - 1), ng1 = at(a.G1, n_euler - 1);
+    float ngs = a.GS[int64_t(n_euler - 1) * N + i];
+    f4 nds = o >= 0 ? at(a.DS, o) : f4{0.f, 0.f, 0.f, 0.f};
+    for (int k = n_euler - 1; k >= 0; --k) {
+      const float dt = stab[k * 8 + 1], sq = stab[k * 8 + 2];
+      const f4 h2 = nh2, h1 = nh1, g2 = ng2, g1 = ng1;
+      const float gs = ngs;
+      // (injected normals are a load: it goes in FRONT of the look-ahead requests -- the memory counter is in order, and a value asked
+      //  for after them could only be waited for together with them)
+      f4 z;
+      if (a.na.z != nullptr) z = *reinterpret_cast<const f4*>(a.na.z + (int64_t(k) * N * a.K + r) * D + ch);
+      else z = philox_normal4(key, STREAM_DECODER, uint32_t(k), rid, uint32_t(4 * w + L.g));
+      if (k > 0) {
+        nh2 = at(a.H2, k - 1); nh1 = at(a.H1, k - 1); ng2 = at(a.G2, k - 1); ng1 = at(a.G1, k - 1);
+        ngs = a.GS[int64_t(k - 1) * N + i];
+      }
+      // outputs interpolated between y_k and y_{k+1}: s_o = w0 y_k + w1 y_{k+1}
+      f4 dprev = f4{0.f, 0.f, 0.f, 0.f};
+      // (the FIRST output of a step is taken outside the loop: inside it, the request for the next output's rows is followed by the
+      //  loop's back edge, where the compiler must assume the rows are used at once and waits for them -- and, the memory counter being
+      //  in order, for everything requested before them: the whole look-ahead above, every iteration)
+      if (o >= 0 && int(otab[o * 4]) == k + 1) {
+        const float w0 = otab[o * 4 + 1], w1 = otab[o * 4 + 2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          dy[c] = fmaf(w1, nds[c], dy[c]);                   // (DS rows of output o: asked for an iteration ago)
+          dprev[c] = fmaf(w0, nds[c], dprev[c]);
+        }
+        --o;
+        while (o >= 0 && int(otab[o * 4]) == k + 1) {        // further outputs inside the same Euler step: not in the shipped schedules
+          const float v0 = otab[o * 4 + 1], v1 = otab[o * 4 + 2];
+          const f4 ds = at(a.DS, o);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            dy[c] = fmaf(v1, ds[c], dy[c]);
+            dprev[c] = fmaf(v0, ds[c], dprev[c]);
+          }
+          --o;
+        }
+        if (o >= 0) nds = at(a.DS, o);
+      }
+      // ---- B0: the row's magnitude and the diffusion scalar's dot product, this wave's share
+      {
+        const float m = row_max(fmaxf(fmaxf(fabsf(dy[0]), fabsf(dy[1])), fmaxf(fabsf(dy[2]), fabsf(dy[3]))));
+        float cd = (z[0] * sq) * dy[0];
+#pragma unroll
+        for (int c = 1; c < 4; ++c) cd = fmaf(z[c] * sq, dy[c], cd);
+        cd = row_sum(cd);
+        if (L.g == 0) {
+          MX[16 * w + L.n] = m;
+          CD[16 * w + L.n] = cd;
+        }
+      }
+      lds_barrier();
+      const unsigned e = __float_as_uint(fmaxf(fmaxf(MX[L.n], MX[16 + L.n]), fmaxf(MX[32 + L.n], MX[48 + L.n]))) & 0x7F800000u;   // 0: an all-zero row
+      const float up = __uint_as_float(0x7F000000u - e), down = __uint_as_float(e);
+      const float cdot = (CD[L.n] + CD[16 + L.n]) + (CD[32 + L.n] + CD[48 + L.n]);
+      // ---- B1: drift net: y' gets f dt
+      {
+        f4 d;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = dt * dy[c];
+        if (live) *reinterpret_cast<f4*>(a.DF + k * slab + int64_t(row) * D + ch) = d;
+        opnd_write(Tb(0), d * up, w, L);
+      }
+      lds_barrier();
+      // ---- B2: drift.4^T; the diffusion head (64 -> 1, sigmoid): y' gets g (z sqrt(h)), g one scalar per row
+      {
+        const f4 t = zero_mma(wf4, opnd_read(Tb(0), L));
+        f4 d;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = t[c] * (1.0f - h2[c] * h2[c]);
+        if (live) *reinterpret_cast<f4*>(a.DH2 + k * slab + int64_t(row) * D + ch) = d * down;
+        opnd_write(Tb(1), d, w, L);
+        const float dgp = cdot * gs * (1.0f - gs);
+        const float dgps = dgp * up;
+        f4 dg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (live) dv4[c] = fmaf(dgp, g2[c], dv4[c]);
+          dg[c] = dgps * w4g[c] * (1.0f - g2[c] * g2[c]);
+        }
+        if (live && w == 0) dc4 += dgp;
+        if (live) *reinterpret_cast<f4*>(a.DG2 + k * slab + int64_t(row) * D + ch) = dg * down;
+        opnd_write(Tb(2), dg, w, L);
+      }
+      lds_barrier();
+      // ---- B3: drift.2^T, diffusion.2^T
+      {
+        const f4 t = zero_mma(wf2, opnd_read(Tb(1), L));
+        const f4 u = zero_mma(wg2, opnd_read(Tb(2), L));
+        f4 d, dg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          d[c] = t[c] * (1.0f - h1[c] * h1[c]);
+          dg[c] = u[c] * (1.0f - g1[c] * g1[c]);
+        }
+        if (live) {
+          *reinterpret_cast<f4*>(a.DH1 + k * slab + int64_t(row) * D + ch) = d * down;
+          *reinterpret_cast<f4*>(a.DG1 + k * slab + int64_t(row) * D + ch) = dg * down;
+        }
+        opnd_write(Tb(3), d, w, L);
+        opnd_write(Tb(4), dg, w, L);
+      }
+      lds_barrier();
+      // ---- first layers^T (the 64 state columns of the 66-wide inputs) -> d y_k, true scale.  No barrier behind it: the next writes
+      //      to the tiles it reads (3, 4) come three barriers later.
+      {
+        f4 adj = zero_mma(wf0, opnd_read(Tb(3), L));
+        slice_mma(adj, wg0, opnd_read(Tb(4), L));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dy[c] = fmaf(adj[c], down, dy[c] + dprev[c]);
+      }
+    }
+    if (live) *reinterpret_cast<f4*>(a.DY0 + int64_t(row) * D + ch) = dy;
+  }
+  // this workgroup's row of vector partials: d diffusion.4.weight (this wave's 16 channels, summed over the rows) and its bias
+  float* vp = a.vpart + int64_t(blockIdx.x) * SDE_SWEEP_V_FLOATS;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float x = dv4[c];
+    x += __shfl_xor(x, 1);
+    x += __shfl_xor(x, 2);
+    x += __shfl_xor(x, 4);
+    x += __shfl_xor(x, 8);
+    dv4[c] = x;
+  }
+  if (L.n == 0) *reinterpret_cast<f4*>(vp + ch) = dv4;
+  if (w == 0) {
+    float x = L.g == 0 ? dc4 : 0.f;
+    x += __shfl_xor(x, 1);
+    x += __shfl_xor(x, 2);
+    x += __shfl_xor(x, 4);
+    x += __shfl_xor(x, 8);
+    if (L.lane == 0) vp[64] = x;
+  }
+}
+
 #endif
 
 // forward_ood (ENC:311-313): outs [S,N,64] -> mean over samples [N,64] and std(0).mean(-1) [N] (unbiased std)
