@@ -132,6 +132,13 @@ __global__ __launch_bounds__(512) void k_enc_gru_step(const float* __restrict__ 
 //   * bf16x6 build: plain fp32 fragments of the stage blob (three planes would not fit the register file).
 // (COOP_TMAX, COOP_RS, COOP_TILE and StepTab are declared in kernels.hpp)
 
+// A workgroup barrier that orders LDS traffic ONLY.  `__syncthreads()` also drains every outstanding global load and store of the wave
+// (s_waitcnt vmcnt(0)) -- at each barrier: a saved tile requested an iteration ahead would be waited for at the very next barrier, and
+// every stored slab row at the one after its store.  The two decoder kernels at the end of this file exchange data through the LDS alone (what a wave
+// reads from global memory was written by earlier launches or by itself), so their barriers wait for the LDS counter and nothing else.  (Tried in the two recurrence kernels as well: no change -- their loads are
+// requested a phase ahead and have arrived by the phase's barrier.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #if TSDE_SPLIT_H3
 struct WSlice {   // one wave's 16 output rows of a 64x64 matrix: [plane][k-step] fp16x8 A fragments
   u4 p[2][2];
@@ -928,12 +935,6 @@ template __global__ void k_enc_recur_bwd_coop<1>(RecurBwdCoopArgs);
 template __global__ void k_enc_recur_bwd_coop<2>(RecurBwdCoopArgs);
 template __global__ void k_enc_recur_bwd_coop<3>(RecurBwdCoopArgs);
 template __global__ void k_enc_recur_bwd_coop<4>(RecurBwdCoopArgs);
-
-// A workgroup barrier that orders LDS traffic ONLY.  `__syncthreads()` also drains every outstanding global load and store of the wave
-// (s_waitcnt vmcnt(0)) -- at each barrier: a saved tile requested an iteration ahead would be waited for at the very next barrier, and
-// every stored slab row at the one after its store.  The two decoder kernels below exchange data through the LDS alone (what a wave
-// reads from global memory was written by earlier launches or by itself), so their barriers wait for the LDS counter and nothing else.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // The decoder backward's forward REPLAY of the winning paths in the cooperative form (decoder_bwd.hip k_sde_replay is the one-wave
