@@ -294,8 +294,9 @@ def test_full_size_training_step_agrees_between_kernel_forms(dev):
     can differentiate, so the full-size check is a cross-check: the same training step in two child processes, once with this round's
     kernel forms (k_wgrad6 on block-scaled 16-bit products, deferred sums, the cooperative recurrence kernels) and once with the forms
     they replaced (exact fp32 weight-gradient products, one reduction per batch, one tile per wave, the encoders' attention backward on the
-    vector pipe, the edge embedding's three weight-gradient problems apart: TRAJSDE_WGRAD_F32 / TRAJSDE_IMMEDIATE_SUMS / TRAJSDE_RECUR_LEGACY /
-    TRAJSDE_ROWS_BWD_MM=0 / TRAJSDE_WGRAD_EDGE_PAIR=0).  Same loss to 1e-6, every one of the 252 - 8 gradients finite and equal in norm and in
+    vector pipe, the edge embedding's three weight-gradient problems apart, the decoder's replay and reverse sweep one wave a tile:
+    TRAJSDE_WGRAD_F32 / TRAJSDE_IMMEDIATE_SUMS / TRAJSDE_RECUR_LEGACY / TRAJSDE_ROWS_BWD_MM=0 / TRAJSDE_WGRAD_EDGE_PAIR=0 / TRAJSDE_REPLAY_COOP=0 /
+    TRAJSDE_SWEEP_COOP=0).  Same loss to 1e-6, every one of the 252 - 8 gradients finite and equal in norm and in
     a seeded +-1 projection to 2e-5 of its norm."""
     import json
     import subprocess
@@ -309,7 +310,8 @@ def test_full_size_training_step_agrees_between_kernel_forms(dev):
         return json.loads(r.stdout.strip().splitlines()[-1])
     new = run({})
     old = run({"TRAJSDE_WGRAD_F32": "1", "TRAJSDE_IMMEDIATE_SUMS": "1", "TRAJSDE_RECUR_LEGACY": "1", "TRAJSDE_ROWS_BWD_MM": "0",
-               "TRAJSDE_WGRAD_EDGE_PAIR": "0", "TRAJSDE_ROWS_BWD_FUSEW": "0"})
+               "TRAJSDE_WGRAD_EDGE_PAIR": "0", "TRAJSDE_ROWS_BWD_FUSEW": "0",
+               "TRAJSDE_REPLAY_COOP": "0", "TRAJSDE_SWEEP_COOP": "0"})       # (round 5: the decoder's sweeps one wave a tile)
     # the deferred sums with areas so small that they are summed early many times per entry point (and one batch of partials does not
     # fit at all): the same kernels in the same order per problem -> bit-identical digests
     tight = run({"TRAJSDE_REDUCE_CAP": "600", "TRAJSDE_VPART_ARENA": "300000"})
