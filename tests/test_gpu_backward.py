@@ -286,6 +286,42 @@ def test_decoder_backward_is_deterministic_and_checks_arguments(dev):
         model.decoder._rt.decoder_l2_backward(data, local, glob, out, noise)
 
 
+def test_decoder_backward_with_injected_normals_equals_the_seeded_run(dev):
+    """the decoder's forward and backward fed with the normals the in-kernel generator would have drawn (host twin of the Philox
+    stream, NoiseSpec.z_dec): the same winning modes, and trajectories, loss and gradients equal to the seeded run's to 1e-4 of each
+    tensor's largest entry -- the injected path of the replay / reverse-sweep kernels indexes its rows like the generator keys its
+    counters (a shifted row or step would change every gradient by order one)"""
+    import numpy as np
+    from trajsde_amd import philox, runtime
+    from trajsde_amd.schedule import decoder_schedule
+    from trajsde_amd.synth import synth
+    K, T, seed = 3, 20, 11
+    batch = synth(S=2, n=19, L=5, F=T, box=80.0, seed=8, mixed_source=True, history_dropout=0.3)
+    model, _ = H.build_model(K, T, 2.0, init_seed=6)
+    model = model.to(dev)
+    data = batch.to(dev)
+    rot, y_rot = runtime.rotate_inputs(data)
+    data.y, data["rotate_mat"] = y_rot, rot
+    local, *_ = model.encoder(data=data, noise=runtime.NoiseSpec(seed=seed))
+    glob = model.aggregator(data=data, local_embed=local)
+    N = batch.num_nodes
+    sched = decoder_schedule(T, 2.0)
+    z = torch.from_numpy(np.stack([philox.normals(seed, philox.STREAM_DECODER, k, np.arange(K * N), 64) for k in range(sched.n_euler)])).to(dev)
+    res = []
+    for noise in (runtime.NoiseSpec(seed=seed), runtime.NoiseSpec(seed=0, z_dec=z)):
+        out = model.decoder(data=data, local_embed=local, global_embed=glob, noise=noise)
+        res.append((out, model.decoder._rt.decoder_l2_backward(data, local, glob, out, noise)))
+    (o_a, a), (o_b, b) = res
+    # (the host twin's normals and the kernels' agree to the last place or two -- numpy's log / cos against the device's --, not in it)
+    assert H.maxdiff(o_a["loc"], o_b["loc"]) <= 1e-5 and abs(float(a["loss"]) - float(b["loss"])) <= 1e-6 * max(1.0, abs(float(a["loss"])))
+    assert torch.equal(a["best_mode"], b["best_mode"])
+    for x, y in ((a["d_local_embed"], b["d_local_embed"]), (a["d_global_embed"], b["d_global_embed"])):
+        assert H.maxdiff(x, y) <= 1e-4 * max(float(x.abs().max()), 1e-12)
+    for k in a["grads"]:
+        ref = float(a["grads"][k].abs().max())
+        assert H.maxdiff(a["grads"][k], b["grads"][k]) <= 1e-4 * max(ref, 1e-9), (k, ref)
+
+
 _oracle_full_grads = H.oracle_full_grads
 
 
