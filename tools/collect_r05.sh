@@ -18,6 +18,7 @@ rm -rf $O/kstr
 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 $R/tools/train_step_bench.py --steps 3 --warmup 2 > $O/kt.log 2>&1
 python3 $R/tools/step_timeline.py $O/kt --full > $O/train_step_timeline.txt 2>&1      # every launch of one step in start order
 rm -rf $O/kt
+python3 $R/tools/train_loop_stalls.py > $O/train_loop_stalls.log 2>/dev/null
 python3 $R/tools/graph_stage_bench.py > $O/graph_stage.log 2>&1
 python3 $R/tools/graph_stage_bench.py --exact >> $O/graph_stage.log 2>&1
 python3 $R/tools/graph_stage_bench.py --workload config2 >> $O/graph_stage.log 2>&1
