@@ -183,11 +183,17 @@ struct PhaseStamps {
     last = __builtin_amdgcn_s_memtime();
     real0 = __builtin_amdgcn_s_memrealtime();
   }
+#ifdef TSDE_EDGE_STAMPS_LIGHT      // the loop as a whole only (no stamp inside the body: the shipped stream, undisturbed): cycles and clock
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void finish() { acc[0] = __builtin_amdgcn_s_memtime() - last; }
+#else
   __device__ __forceinline__ void mark(int i) {
     const unsigned long long t = __builtin_amdgcn_s_memtime();
     acc[i] += t - last;
     last = t;
   }
+  __device__ __forceinline__ void finish() {}
+#endif
 };
 #endif
 struct SegState {
@@ -201,21 +207,69 @@ __device__ __forceinline__ void seg_reset(SegState& S) {
 }
 // per-head logits of the 16 rows of a tile: lane (n, g) gets, for jt = 0..3, the logit of the head its features 16jt+4g+c
 // belong to (8 heads: head 2jt + (g>>1), completed by the partner lane group g^1; 4 heads: head jt, all four groups)
+// Round 6: the running softmax of the fused kernel works in LOG2 units -- the logit scale carries log2(e), so a weight is 2^(l - m)
+// with no multiply in front of v_exp_f32 (two per head group and edge before); a record's maxima go out in natural units again
+// (seg_flush), so its readers (k_seg_merge, k_node_update, the training tape) are unchanged.
+constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
+__device__ __forceinline__ float logit_scale(int heads) {
+  return (heads == 4 ? 0.25f : INV_SQRT_DH) * (TSDE_R6_SOFTMAX ? LOG2E_F : 1.0f);
+}
+// the logit of head group jt of a tile's 16 rows
+__device__ __forceinline__ float head_logit1(const f4& qv, const f4& k, int heads) {
+  float p = qv[0] * k[0];
+#pragma unroll
+  for (int c = 1; c < 4; ++c) p = fmaf(qv[c], k[c], p);
+  p = xor16_sum(p);
+  if (heads == 4) p = xor32_sum(p);
+  return p * logit_scale(heads);
+}
 __device__ __forceinline__ f4 head_logits(const f4 (&qv)[4], const f4 (&k)[4], int heads) {
   f4 lg;
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    float p = qv[jt][0] * k[jt][0];
-#pragma unroll
-    for (int c = 1; c < 4; ++c) p = fmaf(qv[jt][c], k[jt][c], p);
-    p = xor16_sum(p);
-    if (heads == 4) p = xor32_sum(p);
-    lg[jt] = p * (heads == 4 ? 0.25f : INV_SQRT_DH);
-  }
+  for (int jt = 0; jt < 4; ++jt) lg[jt] = head_logit1(qv[jt], k[jt], heads);
   return lg;
 }
 // `keep`: attention dropout (ENC:592): the softmax is normalised over ALL edges (s), the weighted sum takes the kept ones
 // scaled by 1/(1-p); f4{1,1,1,1} when dropout is off
+#if TSDE_R6_SOFTMAX
+// fmaxf() costs three instructions here: the compiler quiets both inputs first (v_max x, x) because it cannot know that neither is a
+// signalling NaN.  The plain instruction: both inputs come from ordinary vector instructions (selects, multiplies), its result
+// goes to subtractions -- no matrix or transcendental result is involved, so no wait state the compiler would have to see.
+__device__ __forceinline__ float max_plain(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// The update in three parts, so that a kernel can run the first two before the value rows exist (k_edge_attn2: inside the lin_v product):
+// front: new maximum, scale of the old sums, weight of the edge, running sum;  scale: sums *= sc;  add: sums += w v.
+// The sums are updated IN PLACE (multiply, then fma into the same register): written fma(sum, sc, w v) the compiler picked the
+// two-address v_fmac with the product as the addend and copied all 16 sums of a tile back at every back-edge (32 v_mov an iteration).
+__device__ __forceinline__ void seg_front1(SegState& S, int jt, float lg, float keep, float& sc, float& exk) {
+  const float mn = max_plain(S.m[jt], lg);
+  sc = __builtin_amdgcn_exp2f(S.m[jt] - mn);               // first edge of a segment: 2^(-inf) = 0
+  const float ex = __builtin_amdgcn_exp2f(lg - mn);
+  S.m[jt] = mn;
+  S.s[jt] = fmaf(S.s[jt], sc, ex);
+  exk = ex * keep;
+}
+__device__ __forceinline__ void seg_scale1(SegState& S, int jt, float sc) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) S.acc[jt][c] *= sc;
+}
+__device__ __forceinline__ void seg_add1(SegState& S, int jt, float exk, const f4& v) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) S.acc[jt][c] = fmaf(exk, v[c], S.acc[jt][c]);
+}
+__device__ __forceinline__ void seg_update(SegState& S, const f4& lg, const f4 (&v)[4], const f4& keep) {
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    float sc, exk;
+    seg_front1(S, jt, lg[jt], keep[jt], sc, exk);
+    seg_scale1(S, jt, sc);
+    seg_add1(S, jt, exk, v[jt]);
+  }
+}
+#else
 __device__ __forceinline__ void seg_update(SegState& S, const f4& lg, const f4 (&v)[4], const f4& keep) {
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
@@ -233,11 +287,12 @@ __device__ __forceinline__ void seg_update(SegState& S, const f4& lg, const f4 (
     for (int c = 0; c < 4; ++c) S.acc[jt][c] = fmaf(S.acc[jt][c], sc, exk * v[jt][c]);
   }
 }
+#endif
 __device__ __forceinline__ void seg_flush(const SegState& S, float* __restrict__ rec, int64_t slot, int g) {
   float* r = rec + slot * SEG_REC;
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<f4*>(r + 16 * jt + 4 * g) = S.acc[jt];
-  *reinterpret_cast<f4*>(r + 64 + 4 * g) = S.m;           // m / s of lane group g at [4g + jt]
+  *reinterpret_cast<f4*>(r + 64 + 4 * g) = TSDE_R6_SOFTMAX ? S.m * LN2_F : S.m;      // m / s of lane group g at [4g + jt]; maxima in natural units
   *reinterpret_cast<f4*>(r + 80 + 4 * g) = S.s;
 }
 
@@ -367,6 +422,137 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
       for (int jt = 0; jt < 4; ++jt) S[t].m[jt] = chg ? -INFINITY : S[t].m[jt];
     }
     st.mark(0);                                            // loads, target changes (record flush, query row)
+#if TSDE_R6_ATOMS && TSDE_R6_SOFTMAX
+    // ---- round 6: the same arithmetic per edge (products, LayerNorms and softmax element for element those of the round-5 stream,
+    // edge_embed_fused_n + linear_acc_x6_n + seg_update), re-ordered so that a wave's matrix instructions have vector work beside them:
+    //   * both first layers of both tiles are 8 NT matrix instructions back to back (round 5: each instruction followed by the ~8
+    //     wait states of its result's first reader, 16 times an iteration);
+    //   * the ReLU + operand split of branch B issues between the matrix instructions of the W_A product;
+    //   * lin_k is finished before lin_v starts (k-rows first: same order per accumulator), and the logits, the new maxima, the two
+    //     exponentials and the rescaling of the running sums of one (tile, head group) issue inside each step of the lin_v product;
+    //     behind it only sums += w v is left.
+    {
+      u4 opA[NT], opB[NT];
+      {
+        float xa[NT], xb[NT], xc[NT], xd[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          xa[t] = ge[t][0];
+          xb[t] = ge[t][1];
+          xc[t] = ge[t][2];
+          xd[t] = ge[t][3];
+        }
+        in2_operands_n<NT>(opA, xa, xb, lds + EL::A_C);
+        in2_operands_n<NT>(opB, xc, xd, lds + EL::B_C);
+      }
+      f4 ya[NT][4], yb[NT][4];
+      in2_mfma_raw_n<NT>(ya, opA, lds + EL::A_F, L.lane);
+      in2_mfma_raw_n<NT>(yb, opB, lds + EL::B_F, L.lane);
+      __builtin_amdgcn_sched_barrier(0);
+      st.mark(1);
+      u4 xh[NT][2], xl[NT][2], bh[NT][2], bl[NT][2];
+      f4 sm[NT][4];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) relu_split_kstep(ya[t][2 * ks], ya[t][2 * ks + 1], xh[t][ks], xl[t][ks]);
+        load_vec<4>(sm[t], lds + EL::B3, L.g);
+      }
+      product_x6_n<NT, 4>(sm, xh, xl, lds + EL::WA3, L.lane, [&](auto I) {
+        constexpr int i = decltype(I)::value, per = 8 / (2 * NT);       // 2 NT atoms (tile, k-step) over the 8 steps
+        if constexpr (i % per == per - 1) {
+          constexpr int a = i / per, t = a >> 1, ks = a & 1;
+          relu_split_kstep(yb[t][2 * ks], yb[t][2 * ks + 1], bh[t][ks], bl[t][ks]);
+        }
+      });
+      st.mark(2);
+      st.mark(3);
+      product_x6_n<NT, 4>(sm, bh, bl, lds + EL::WB3, L.lane, NoAtoms{});
+      st.mark(4);
+      float r[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) r[t] = centred_rstd(sm[t]);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const f4 ga = *reinterpret_cast<const f4*>(lds + EL::AG0 + 16 * jt + 4 * L.g);
+        const f4 be = *reinterpret_cast<const f4*>(lds + EL::AE0 + 16 * jt + 4 * L.g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sm[t][jt][c] = fmaxf(fmaf(sm[t][jt][c] * r[t], ga[c], be[c]), 0.f);
+      }
+      split_rows_n<NT>(xh, xl, sm);
+      f4 emb[NT][4];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) load_vec<4>(emb[t], lds + EL::B2, L.g);
+      st.mark(5);
+      product_x6_n<NT, 4>(emb, xh, xl, lds + EL::W2, L.lane, NoAtoms{});
+      st.mark(6);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float q4 = centred_rstd(emb[t]);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) emb[t][jt][c] *= q4;     // (y - mean) * rstd of the last LayerNorm; gamma / beta live downstream
+      }
+      st.mark(7);
+      if (SAVE) {                                            // the tape holds the embedding rows proper
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          f4 tr[4];
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt) {
+            const f4 ga = *reinterpret_cast<const f4*>(lds + EL::AG3 + 16 * jt + 4 * L.g);
+            const f4 be = *reinterpret_cast<const f4*>(lds + EL::AE3 + 16 * jt + 4 * L.g);
+            tr[jt] = emb[t][jt] * ga + be;
+          }
+          if (ok[t]) store_row(tr, emb_out, base_e[t] + it, L.g);
+        }
+      }
+      split_rows_n<NT>(xh, xl, emb);
+      // k / v without their constant parts (EdgeL6F): q . CK shifts all logits of a (target, head) alike, and sum_e alpha_e CV = CV
+      // is added by k_seg_merge.  With attention dropout the kept weights do not sum to one, so v carries CV here.
+      f4 kk[NT][4], vv[NT][4], keep[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          kk[t][jt] = f4{0.f, 0.f, 0.f, 0.f};
+          vv[t][jt] = DROP ? *reinterpret_cast<const f4*>(img_g + EL::CV + 16 * jt + 4 * L.g) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+        keep[t] = DROP ? drop_attn_row(drop, uint32_t(d[t]), uint32_t(int(base_e[t] + it) - rank0[t]), L.g, heads) : one4;
+      }
+      product_x6_n<NT, 4>(kk, xh, xl, lds + EL::WKV, L.lane, NoAtoms{});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the query rows sent to LDS at the top of the iteration have landed
+      f4 sc[NT], exk[NT];
+      product_x6_n<NT, 4>(vv, xh, xl, lds + EL::WKV + 4 * 2 * 512, L.lane, [&](auto I) {
+        constexpr int i = decltype(I)::value, per = 8 / (4 * NT);       // 4 NT atoms (tile, head group) over the 8 steps
+        if constexpr (i % per == per - 1) {
+          constexpr int a = i / per, t = a >> 2, jt = a & 3;
+          const f4 qv = *reinterpret_cast<const f4*>(qs + ((4 * t + jt) * 64 + L.lane) * 4);
+          float lg = head_logit1(qv, kk[t][jt], heads);
+          // Branch-free: a row beyond the list (the tail of the last stream; rows of streams >= nstreams) enters with logit -inf --
+          // weight 2^(-inf) = 0, running maximum and scale unchanged.  A row that never had an edge turns its state into NaNs
+          // (2^(-inf + inf)); it is never flushed (cur < 0).
+          if (!ok[t]) lg = -INFINITY;
+          float sc1, exk1;
+          seg_front1(S[t], jt, lg, keep[t][jt], sc1, exk1);
+          seg_scale1(S[t], jt, sc1);
+          sc[t][jt] = sc1;
+          exk[t][jt] = exk1;
+        }
+      });
+      st.mark(8);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) seg_add1(S[t], jt, exk[t][jt], vv[t][jt]);
+      (void)sc;
+    }
+    st.mark(9);                                            // the rest of the online softmax
+#else
+    st.mark(0);                                            // loads, target changes (record flush, query row)
     f4 emb[NT][4], kv[NT][8];
     edge_embed_fused_n<NT>(emb, ge, lds, L, st);            // (y - mean) * rstd of the last LayerNorm; gamma / beta live downstream
     if (SAVE) {                                            // the tape holds the embedding rows proper
@@ -412,11 +598,13 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
       seg_update(S[t], lg, vv, DROP ? drop_attn_row(drop, uint32_t(d[t]), uint32_t(int(base_e[t] + it) - rank0[t]), L.g, heads) : one4);
     }
     st.mark(9);                                            // logits + online softmax
+#endif
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t)
     if (cur[t] >= 0) seg_flush(S[t], rec, int64_t(cur[t]) + sid[t], L.g);
 #ifdef TSDE_EDGE_STAMPS
+  st.finish();
   if (LIST == 0 && !DROP && !SAVE && (wave == 0 || wave == 5) && L.lane == 0) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) atomicAdd(&g_edge_stamps[i], st.acc[i]);
@@ -717,7 +905,7 @@ __global__ __launch_bounds__(512) void k_edge_attn2p(const float* __restrict__ i
       for (int c = 1; c < 4; ++c) p = fmaf(qv[c], T[t].kv[j][c], p);
       p = xor16_sum(p);
       if (heads == 4) p = xor32_sum(p);
-      lg5[t][j] = p * (heads == 4 ? 0.25f : INV_SQRT_DH);
+      lg5[t][j] = p * logit_scale(heads);
     } else {
       f4 lg = lg5[t];
       if (!T[t].ok) lg = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};

@@ -16,8 +16,27 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "layouts.hpp"   // TSDE_SPLIT_H3
+
+// round-6 forms of the edge attention's stream (A/B switches of tools/build_variant.sh; all on by default):
+//   TSDE_R6_SOFTMAX  logits in log2 units (2^x without the pre-multiply), one v_max per head group, sums updated in place
+//   TSDE_R6_IN2      first layers: operand packed by v_fma_mixhi, all 16 matrix instructions of a tile pair back to back
+//   TSDE_R6_ATOMS    vector work issued between the matrix instructions of the W_A and lin_v products
+#ifndef TSDE_R6_SOFTMAX
+#define TSDE_R6_SOFTMAX 1
+#endif
+#ifndef TSDE_R6_IN2
+#define TSDE_R6_IN2 1
+#endif
+#ifndef TSDE_R6_ATOMS
+#define TSDE_R6_ATOMS 1
+#endif
+//   TSDE_R6_SPLIT    operand split: low pieces by v_fma_mix_f32 + v_cvt_pkrtz (half-rate) instead of v_fma_mixlo/hi_f16 (quarter-rate)
+#ifndef TSDE_R6_SPLIT
+#define TSDE_R6_SPLIT 1
+#endif
 
 // Correctness guard (trajsde_amd/build.py): built with the SLP vectoriser on, identical launches of the
 // backward tile kernels disagree in their low-order bits.  The build passes -fno-slp-vectorize together with -DTSDE_NO_SLP=1; a
@@ -144,9 +163,18 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
   r0 = __builtin_fmaf(float(hh[0]), m1, x0);
   r1 = __builtin_fmaf(float(hh[1]), m1, x1);
 #endif
+#if TSDE_R6_SPLIT
+  // Round 6 (tools/microbench/vissue.hip): v_fma_mixlo_f16 / v_fma_mixhi_f16 are QUARTER-rate instructions on this chip -- 8 cycles
+  // of the SIMD each, alone or beside a second wave, like v_exp_f32 -- while v_fma_mix_f32 (fp32 result) and v_cvt_pkrtz_f16_f32 take 4.
+  // The residuals stay fp32 (two v_fma_mix_f32) and are packed by a second v_cvt_pkrtz: 16 cycles per pair instead of 20.  The low
+  // piece is then the residual TRUNCATED to 11 bits instead of rounded: x - (hi + lo) < 2^-22 |x| either way (22-bit operands).
+  hi = hb;
+  lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+#else
   const hf2 l = hf2{_Float16(r0), _Float16(r1)};
   hi = hb;
   lo = __builtin_bit_cast(unsigned, l);
+#endif
 }
 // The 8 values of one k-step
 __device__ __forceinline__ void split_kstep(const f4& qa, const f4& qb, u4& hi, u4& lo) {
@@ -296,6 +324,70 @@ __device__ __forceinline__ void linear_acc_x6_n(f4 (&acc)[NT][JT_OUT], const f4 
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t][jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(h8, xh[t][s]), acc[t][jo], 0, 0, 0);
   }
+}
+
+// ---- round 6: the same products with the operand split and the matrix steps as separate calls, so that a kernel can hand the steps
+// independent vector work ("atoms") to issue in the shadow of the matrix instructions.  A wave's stream is in order: a vector stage
+// that sits between two products runs with the matrix pipe idle, whereas up to two vector instructions per matrix instruction issued
+// BETWEEN them cost nothing (tools/microbench/coexec.hip modes 18 / 19: 48 x (mfma + 2 fma) = 14.9 cycles per group).
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for_(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_<N, F, I + 1>(static_cast<F&&>(f));
+  }
+}
+struct NoAtoms {
+  template <class I>
+  __device__ __forceinline__ void operator()(I) const {}
+};
+// operand pieces of NT tiles (the split of linear_acc_x6_n, element for element)
+template <int NT>
+__device__ __forceinline__ void split_rows_n(u4 (&xh)[NT][2], u4 (&xl)[NT][2], const f4 (&in)[NT][4]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) split_kstep(in[t][2 * s], in[t][2 * s + 1], xh[t][s], xl[t][s]);
+}
+// ReLU (as an integer max on the bits of a matrix result: in2_mfma_relu_n) + split of one k-step of one tile
+__device__ __forceinline__ void relu_split_kstep(const f4& ya, const f4& yb, u4& hi, u4& lo) {
+  f4 r0, r1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r0[k] = __int_as_float(max(__float_as_int(ya[k]), 0));
+    r1[k] = __int_as_float(max(__float_as_int(yb[k]), 0));
+  }
+  split_kstep(r0, r1, hi, lo);
+}
+// acc[t][jo] += W x_t over the two k-steps (64 inputs), jo = 0 .. JT_OUT-1, steps in the order of linear_acc_x6_n (k-step major), every
+// fragment pair read one step ahead and feeding 3 NT matrix instructions; after the matrix instructions of step i the caller's
+// atoms(i) -- the compiler may move them among that step's matrix instructions, not across the step's fence.  Same bits as
+// linear_acc_x6_n per accumulator.
+template <int NT, int JT_OUT, class Atoms>
+__device__ __forceinline__ void product_x6_n(f4 (&acc)[NT][JT_OUT], const u4 (&xh)[NT][2], const u4 (&xl)[NT][2], const float* w, int lane,
+                                             Atoms&& atoms) {
+  constexpr int KS = 2, STEPS = KS * JT_OUT;
+  u4 f1[2], f2[2];
+  f1[0] = *reinterpret_cast<const u4*>(w + lane * 4);
+  f2[0] = *reinterpret_cast<const u4*>(w + lane * 4 + 256);
+  static_for_<STEPS>([&](auto I) {
+    constexpr int i = decltype(I)::value, s = i / JT_OUT, jo = i % JT_OUT;
+    if constexpr (i + 1 < STEPS) {
+      constexpr int s2 = (i + 1) / JT_OUT, jo2 = (i + 1) % JT_OUT;
+      const float* p = w + (jo2 * KS + s2) * 512 + lane * 4;
+      f1[(i + 1) & 1] = *reinterpret_cast<const u4*>(p);
+      f2[(i + 1) & 1] = *reinterpret_cast<const u4*>(p + 256);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const h8 a1 = __builtin_bit_cast(h8, f1[i & 1]), a2 = __builtin_bit_cast(h8, f2[i & 1]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(h8, xh[t][s]), acc[t][jo], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(h8, xl[t][s]), acc[t][jo], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][jo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(h8, xh[t][s]), acc[t][jo], 0, 0, 0);
+    atoms(I);
+  });
 }
 #else
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
@@ -480,9 +572,19 @@ __device__ __forceinline__ void linear_adj(f4 (&acc)[JT_OUT], const f4 (&d)[JT_I
 // 1/sqrt(x) for the LayerNorms (x = var + eps >= 1e-5): v_rsq_f32 plus one Newton step, 5 instructions with one
 // transcendental -- `1.0f / sqrtf(x)` expands to the IEEE sqrt and division sequences, ~25 instructions per call,
 // which was 15 % of the VALU stream of the edge kernel.  Within 1 ulp of the correctly rounded value.
+// Round 6: the Newton step is gone.  v_rsq_f32 is specified to 1 ulp; the step bought the last half ulp of a factor whose consumers are
+// 22-bit operands (2^-22), for four more vector instructions per LayerNorm row (32 an iteration of the edge kernel, whose SIMDs are
+// bound by the instructions they issue: profiles/r06_edge_issue_model.md).  -DTSDE_R6_RSQ=0 restores it.
+#ifndef TSDE_R6_RSQ
+#define TSDE_R6_RSQ 1
+#endif
 __device__ __forceinline__ float rsqrt_nr(float x) {
   const float y = __builtin_amdgcn_rsqf(x);
+#if TSDE_R6_RSQ
+  return y;
+#else
   return y * fmaf(-0.5f * x * y, y, 1.5f);
+#endif
 }
 
 template <int JT>
@@ -625,12 +727,21 @@ __device__ __forceinline__ u4 in2_operand(float x0r, float x1r, float rstd) {
   unsigned h, l;
   split_pair(x0r, x1r, h, l);
   const hp2 rh = __builtin_amdgcn_cvt_pkrtz(rstd, 0.f);
+#if TSDE_R6_IN2
+  // r_h | r_l: the low piece rounded straight into the high half of the register that holds r_h (v_fma_mixhi_f16 keeps the low
+  // half): no mask, no shift-or (round 5: v_and + v_lshl_or per operand)
+  hf2 hr2 = __builtin_bit_cast(hf2, rh);
+  const float rr = __builtin_fmaf(float(hr2[0]), opaque_minus_one(), rstd);        // rstd - fp16(rstd), exact
+  hr2[1] = _Float16(rr);
+  return u4{h, l, __builtin_bit_cast(unsigned, hr2), 0x3C003C00u};
+#else
   const unsigned rhb = __builtin_bit_cast(unsigned, rh);
   float rr;                                                                        // rstd - fp16(rstd), exact
   rr = __builtin_fmaf(float(__builtin_bit_cast(hf2, rh)[0]), opaque_minus_one(), rstd);
   const hf2 rl = hf2{_Float16(rr), _Float16(0.f)};
   const unsigned hr = (rhb & 0xFFFFu) | (__builtin_bit_cast(unsigned, rl) << 16);  // r_h | r_l
   return u4{h, l, hr, 0x3C003C00u};
+#endif
 }
 // ... and ReLU(LayerNorm(Linear(2,64)(x))) of NT row tiles: 4 fragments read once, 4 NT matrix instructions, 16 NT max
 template <int NT>
@@ -663,6 +774,17 @@ __device__ __forceinline__ void in2_mfma_relu_n(f4 (&out)[NT][4], const u4 (&b)[
 #pragma unroll
       for (int k = 0; k < 4; ++k) out[t][jt][k] = __int_as_float(max(__float_as_int(y[k]), 0));
     }
+  }
+}
+// the 4 NT matrix instructions of one first layer alone, back to back (results before the ReLU): a kernel that has other work for the
+// ~8 wait states between a matrix instruction and the first reader of its result issues all of a tile pair's first layers at once
+template <int NT>
+__device__ __forceinline__ void in2_mfma_raw_n(f4 (&y)[NT][4], const u4 (&b)[NT], const float* frag, int lane) {
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(frag + jt * 256 + lane * 4));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) y[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, b[t]), f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
   }
 }
 #endif
