@@ -603,6 +603,7 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
                       ("fused_one_tile", {"TRAJSDE_FUSED_TILES": "1"}),
                       ("gattn_mm", {"TRAJSDE_GATTN_MM": "1"}),
                       ("gattn_vector", {"TRAJSDE_GATTN_F32MM": "0"}),
+                      ("rel_split", {"TRAJSDE_REL_SPLIT": "1"}),
                       ("gattn_two_tiles", {"TRAJSDE_GMF_TILES": "2"}),
                       ("pipelined", {"TRAJSDE_EDGE_PIPE": "1"}),
                       ("tile32", {"TRAJSDE_EDGE_TILE": "32"}),
@@ -630,6 +631,8 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
         assert H.maxdiff(outs["split"][key], outs["gattn_mm"][key]) <= 2e-5, key
         # the default global attention (gattn_f32.hip: fp32 matrix instructions) against the vector form it replaced (attn.hip k_global_attn)
         assert H.maxdiff(outs["split"][key], outs["gattn_vector"][key]) <= 2e-5, key
+        # ... against the fp16x3 form on rel rows that their writer stored as split operand pieces (gattn_h3.hip: round 6, product library)
+        assert H.maxdiff(outs["split"][key], outs["rel_split"][key]) <= 2e-5, key
         # ... and against its 32-edges-a-step form (k_global_attn_mf2: two tiles of a target through every phase together)
         assert H.maxdiff(outs["split"][key], outs["gattn_two_tiles"][key]) <= 2e-5, key
         assert torch.equal(outs["split"][key], outs["pipelined"][key]), key              # k_edge_attn2p: the tiles one stage apart, the same bits

@@ -317,7 +317,12 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
   if (E <= 0) return;                                      // (only reachable when the count lives on the device)
   stage_blob(lds, img_g, EL::LDS_SIZE);
   const Lane L;
+#if TSDE_R6_TOP
+  // (the wave index as a SCALAR: with it the stream length below is one, and the loop counter and its back-edge are scalar instructions)
+  const int waves = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+#else
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+#endif
   const StreamMap smap = stream_map(C);
   const int64_t nstreams = stream_count(E, C);
   const int64_t wid = xcd_block() * waves + wave;          // xcd_grid launch: consecutive streams (same snapshot, same scene) share an L2
@@ -346,12 +351,31 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
   // with the current ones, and nothing would cover that round trip
   f4 ng[NT];
   int nd[NT];
+#if TSDE_R6_TOP
+  // Round 6: the edge walk in 32-bit arithmetic.  geometry / targets are read through buffer descriptors whose extent is the list
+  // (a read past it returns zeros: no index clamp), at byte offsets that advance by 16 / 4 an iteration: two additions and one
+  // compare a tile, where the 64-bit form spent ~12 vector instructions a tile (adds, compares, selects, address pairs).
+  // (host side: fused_edge_attention refuses lists of 2^28 edges or more)
+  const __amdgpu_buffer_rsrc_t geom_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(geom), 0, int(unsigned(E) * 16u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(dst), 0, int(unsigned(E) * 4u), 0x00020000);
+  unsigned goff[NT], doff[NT];                             // byte offsets of the row's current edge in the two lists
+  const unsigned E16 = unsigned(E) * 16u;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const unsigned e0 = unsigned(base_e[t] < E ? base_e[t] : E);
+    goff[t] = e0 * 16u;
+    doff[t] = e0 * 4u;
+    ng[t] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(geom_rs, int(goff[t]), 0, 0));
+    nd[t] = int(__builtin_amdgcn_raw_buffer_load_b32(dst_rs, int(doff[t]), 0, 0));
+  }
+#else
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int64_t c = base_e[t] < E ? base_e[t] : E - 1;
     ng[t] = *reinterpret_cast<const f4*>(geom + 4 * c);
     nd[t] = dst[c];
   }
+#endif
 #ifdef TSDE_EDGE_STAMPS
   PhaseStamps st;
   st.start();
@@ -367,7 +391,11 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
     bool ok[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+#if TSDE_R6_TOP
+      ok[t] = goff[t] < E16;                               // only the last stream is short; streams >= nstreams are empty
+#else
       ok[t] = base_e[t] + it < E;                          // only the last stream is short; streams >= nstreams are empty
+#endif
       ge[t] = ng[t];
       d[t] = nd[t];
       // the loads of the previous iteration are consumed HERE, before this iteration issues anything: the compiler's counted
@@ -376,10 +404,17 @@ __global__ __launch_bounds__(1024 / NT) void k_edge_attn2(const float* __restric
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+#if TSDE_R6_TOP
+      goff[t] += 16u;                                      // (one past a stream's end: loaded, never used; past the list: zeros)
+      doff[t] += 4u;
+      ng[t] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(geom_rs, int(goff[t]), 0, 0));
+      nd[t] = int(__builtin_amdgcn_raw_buffer_load_b32(dst_rs, int(doff[t]), 0, 0));
+#else
       const int64_t e = base_e[t] + it;
       const int64_t c = e + 1 < E ? e + 1 : E - 1;         // (one past a stream's end: loaded, never used)
       ng[t] = *reinterpret_cast<const f4*>(geom + 4 * c);
       nd[t] = dst[c];
+#endif
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1063,7 +1098,11 @@ __global__ __launch_bounds__(1024) void k_edge_embed2(const float* __restrict__ 
         const f4 be = *reinterpret_cast<const f4*>(lds + E::AE3 + 16 * jt + 4 * L.g);
         nrm[t][jt] = nrm[t][jt] * ga + be;
       }
-      if (st_bf16 != 0) {                                    // bf16 rows (128 B): stored from the row-on-lane registers as before
+      if (st_bf16 == 2) {
+        // split-precision image (gattn_h3.hip): the row as fp16 hi[64] | fp16 lo[64] -- the operand pieces its three readers would
+        // otherwise each form again -- through the same LDS tile, whole rows out
+        store_tile_rows_split(stg + wave * ROWSTAGE, nrm[t], emb_out, pair * 32 + 16 * t, n_edges, L);
+      } else if (st_bf16 != 0) {                             // bf16 rows (128 B): stored from the row-on-lane registers as before
         if (e[t] < n_edges) store_row_st(nrm[t], emb_out, e[t], L.g, true);
       } else {
         // fp32 rows leave as whole rows through the wave's LDS tile (tile.hpp store_tile_rows): they are 535 MB per forward

@@ -1,0 +1,361 @@
+// gattn_h3.hip -- the fused global attention of a GlobalInteractorLayer (reference models/aggregators/agg_hivt.py:92-135; AGG:101-117) on
+// the fp16x3 matrix cores, reading relative-pose rows that their PRODUCER already stored as split-precision operand pieces (round 6).
+//
+// Why.  The global interactor is 28 % of the one-stream forward and its attention (three layers) most of that.  The default kernel
+// (gattn_f32.hip) multiplies on the fp32 matrix instruction -- 32 x v_mfma_f32_16x16x4_f32 = 1 024 cycles of the matrix pipe per 16
+// edges -- because the fp16x3 form (gattn.hip, round 4) had to split every rel row twice inside the kernel (once per product, in two
+// different pairings): 128 values a lane and tile, at what tools/microbench/vissue.hip now shows to be 10 SIMD cycles a value.  The
+// rel rows are written once per forward (attn.hip k_edge_embed2) and read by three layers: the split belongs to the writer.
+//
+// Image.  A rel row is 256 bytes either way: fp32[64], or here  fp16 hi[64] | fp16 lo[64]  with hi = fp16(x) toward zero and lo =
+// fp16(x - hi) (tile.hpp split_pair): `TRAJSDE_REL_SPLIT`, inference with fp32 state only (training keeps fp32 rows: its backward
+// kernels read them; bf16 state storage keeps bf16 rows).
+//
+// Kernel.  One wave per target, 16 in-edges a tile, the algebra and the hand-offs of gattn.hip:
+//   P1   logits [16 edges x 8 heads]  = [rel_e | k_node[src_e]] (K = 128) . W1         W1 = [U ; Q]: U_h = Wke_h^T q_h, Q = q masked to its head
+//   P2   O [8 heads x 128]           += alpha^T [heads x 16 edges] . [rel_e | v_node[src_e]]
+// The tile's 16 rel rows are loaded whole (16 B a lane, 16 lanes a row, two tiles ahead) and parked in a wave-private 4 KB LDS tile
+// whose 16-byte chunks are XOR-swizzled by the row (chunk c of row r at position c ^ r: every access below is conflict-free):
+//   * P1's A operand is the tile read back with an EDGE on a lane -- ds_read_b128 of chunk 8 p + 4 s + g (plane p, k-step s): the eight
+//     consecutive features 32 s + 8 g .. of piece p;
+//   * P2's B operand contracts over EDGES, the index the rows are not contiguous in: ds_read_b64_tr_b16 hands lane i of a 16-lane group
+//     column i (feature 16 cb + i) of the group's four rows (edges 4 g .. 4 g + 3) -- the high pieces in k-slots 0 .. 3, the low pieces
+//     in 4 .. 7 of one K = 32 instruction, against the weights' piece repeated in both halves (gattn.hip: all four terms of the split
+//     product in two instructions).
+// No vector instruction touches a rel value.  The gathered node rows (k_node, v_node: 2 MB a layer, L2-resident) stay fp32 and are split
+// here as in gattn.hip.
+#include "attn_common.hpp"
+#include "common.hpp"
+#include "kernels.hpp"
+#include "layouts.hpp"
+#include "stamps.hpp"
+#include "tile.hpp"
+
+TSDE_STAMP_TABLE(gh3, 8)        // diagnostic builds (tools/phase_stamps.py gh3): phases of one 16-edge tile of k_global_attn_h3
+
+namespace tsde {
+#ifndef TSDE_STAMPS
+static unsigned long long* const g_stamps_gh3 = nullptr;
+#endif
+
+#if TSDE_SPLIT_H3
+constexpr int H3_KPITCH = 144;               // bytes per staged k_node row of one plane: 64 halves + 16 B (ds_read_b128 of 16 rows: distinct banks)
+constexpr int H3_KPLANE = 16 * H3_KPITCH;
+constexpr float H3_LAZY = 8.0f;              // the running maximum follows a tile's maximum only past this margin (gattn.hip)
+
+// (timing experiments only: -DTSDE_H3_EXP=1 every gathered node row is row (index & 3), =2 every rel row is one of the segment's first 4)
+#if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 1)
+#define H3_EXP_NODE(i) ((i) & 3)
+#else
+#define H3_EXP_NODE(i) (i)
+#endif
+#if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 2)
+#define H3_EXP_REL(i) ((i) & 3)
+#else
+#define H3_EXP_REL(i) (i)
+#endif
+struct H3Rows {                              // what a lane brings for one tile, one kind of row: edges 4g .. 4g+3, 16 bytes of each
+  f4 x[4];
+};
+typedef short s4v __attribute__((ext_vector_type(4)));
+
+#ifndef TSDE_H3_OCC
+#define TSDE_H3_OCC 2
+#endif
+__global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float* __restrict__ img, const int32_t* __restrict__ segptr,
+                                                                     const int32_t* __restrict__ src, const float* __restrict__ rel,
+                                                                     const float* __restrict__ q, const float* __restrict__ kn,
+                                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ agg) {
+  __shared__ __attribute__((aligned(16))) char reltile[4][16 * 256];        // [wave][row][16 chunks of 16 B, swizzled]
+  __shared__ __attribute__((aligned(16))) char kstage[4][2][H3_KPLANE];     // [wave][plane][16 rows]
+  __shared__ __attribute__((aligned(16))) float sbuf[4][8][64 + 4];
+  __shared__ __attribute__((aligned(16))) float qbuf[4][64];
+  __shared__ __attribute__((aligned(16))) float obuf[4][64];
+  __shared__ float hbuf[4][16];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nn = lane & 15, g = lane >> 4;
+  const int64_t node = xcd_block() * 4 + wv;                 // launched with xcd_grid(): a scene's targets share an L2
+  const int64_t nc = node < N ? node : N - 1;
+  const float* wke = img + GAttnL::WKE;
+  const float* wve = img + GAttnL::WVE;
+  // ---- W1 as B operand: lane (head nn, g), step s, slot j = W1[32 s + 8 g + j][nn]; columns 8 .. 15 are zero
+  const float ql = q[nc * 64 + lane] * INV_SQRT_DH;          // the logits' 1 / sqrt(dh) rides in the query
+  qbuf[wv][lane] = ql;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  u4 b1h[4], b1l[4];
+  {
+    const int hh = nn & 7;
+    f4 qa = *reinterpret_cast<const f4*>(&qbuf[wv][8 * hh]), qb = *reinterpret_cast<const f4*>(&qbuf[wv][8 * hh + 4]);
+    if (nn >= 8) qa = qb = f4{0.f, 0.f, 0.f, 0.f};
+    f4 w[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) w[s][0] = w[s][1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {                            // U_h[c] = sum over the head's 8 dims of Wke[d][c] q[d]
+      const float qd = d < 4 ? qa[d] : qb[d - 4];
+      const float* row = wke + (8 * hh + d) * 64 + 8 * g;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        w[s][0] += *reinterpret_cast<const f4*>(row + 32 * s) * qd;
+        w[s][1] += *reinterpret_cast<const f4*>(row + 32 * s + 4) * qd;
+      }
+    }
+    split_kstep(w[0][0], w[0][1], b1h[0], b1l[0]);
+    split_kstep(w[1][0], w[1][1], b1h[1], b1l[1]);
+    // k_node part: slot (s, g, j) is node feature d = 32 (s - 2) + 8 g + j, which belongs to head 4 (s - 2) + g
+    const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+    split_kstep(nn == g ? qa : z, nn == g ? qb : z, b1h[2], b1l[2]);
+    split_kstep(nn == 4 + g ? qa : z, nn == 4 + g ? qb : z, b1h[3], b1l[3]);
+  }
+  const int beg = segptr[nc], end = node < N ? segptr[nc + 1] : beg;
+  char* const rt = &reltile[wv][0];
+  char* const ks = &kstage[wv][0][0];
+  f4 O[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) O[c] = f4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, spart = 0.f;
+  PhaseClock<8> clk;                                         // (diagnostic builds only: stamps.hpp)
+  clk.start();
+  unsigned long long units = 0;
+  (void)units;
+
+  // (buffer loads: descriptor base in SGPRs + a 32-bit byte offset per lane; the rel descriptor starts at the target's segment, node rows
+  //  are addressed from row 0: N < 2^23 is checked on the host)
+  const __amdgpu_buffer_rsrc_t rs_rel = row_rsrc(rel + int64_t(beg) * 64), rs_kn = row_rsrc(kn), rs_vn = row_rsrc(vn);
+  const __amdgpu_buffer_rsrc_t rs_src = row_rsrc(reinterpret_cast<const float*>(src + beg));
+  auto row4 = [&](__amdgpu_buffer_rsrc_t rs, int row) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, row * 256 + 16 * nn, 0, 0));
+  };
+  const int deg = end - beg, lim = deg - 1 - 4 * g;
+  auto fetch_idx = [&](int (&sidx)[4], int e0) {
+    const int o = e0 - beg;                                  // uniform
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sidx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_src, (min(o + j, lim) + 4 * g) * 4, 0, 0);
+  };
+  auto fetch_rel = [&](H3Rows& R, int e0) {                  // chunk nn of the rows 4g .. 4g+3: the stored pieces, as they are
+    const int o = e0 - beg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) R.x[j] = row4(rs_rel, H3_EXP_REL(min(o + j, lim) + 4 * g));
+  };
+  auto fetch_kv = [&](H3Rows& K, H3Rows& V, const int (&sidx)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) K.x[j] = row4(rs_kn, H3_EXP_NODE(sidx[j]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) V.x[j] = row4(rs_vn, H3_EXP_NODE(sidx[j]));
+  };
+  // per-lane LDS addresses of the tile's fragments (bytes into the wave's rel tile)
+  int a1off[2][2];                                           // P1: [plane][k-step]: row nn, chunk 8 p + 4 s + g
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a1off[p][s] = nn * 256 + 16 * ((8 * p + 4 * s + g) ^ nn);
+  const int trow = 4 * g + (nn >> 2), tpp = nn & 3;           // P2: this lane addresses row trow, columns 4 tpp .. 4 tpp + 3 of a 16-column block
+  auto tile_step = [&](const H3Rows& RR, const H3Rows& KK, const H3Rows& VV, int e0) {
+    __builtin_amdgcn_wave_barrier();                          // the previous tile's fragment reads are done (same wave, in order)
+#ifdef TSDE_STAMPS
+    clk.mark(0);                                              // [0] issuing the loads of the tiles ahead
+    {
+      f4 t0 = RR.x[0], t1 = RR.x[3], t2 = KK.x[0], t3 = KK.x[3];
+      asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+    }
+    clk.mark(1);                                              // [1] waiting for this tile's rel / k_node rows
+#endif
+    // ---- rel rows -> the swizzled tile, as stored; k_node rows -> the stage, split here (an edge per row)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * g + j;
+      *reinterpret_cast<f4*>(rt + r * 256 + 16 * (nn ^ r)) = RR.x[j];
+      char* rowp = ks + r * H3_KPITCH + 8 * nn;
+      unsigned h0, l0, h1, l1;
+      split_pair(KK.x[j][0], KK.x[j][1], h0, l0);
+      split_pair(KK.x[j][2], KK.x[j][3], h1, l1);
+      *reinterpret_cast<uint2*>(rowp) = uint2{h0, h1};
+      *reinterpret_cast<uint2*>(rowp + H3_KPLANE) = uint2{l0, l1};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    clk.mark(2);                                              // [2] stage writes (+ k_node split)
+    // ---- P1: the tile's logits, lane (head nn, g): edges 4g .. 4g+3.  Three chains, one per term of the split product (gattn.hip)
+    f4 lg;
+    {
+      f4 t0 = f4{0.f, 0.f, 0.f, 0.f}, t1 = t0, t2 = t0;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {                           // the rel half of K
+        const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(rt + a1off[0][s]));
+        const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(rt + a1off[1][s]));
+        const h8 bh = __builtin_bit_cast(h8, b1h[s]), bl = __builtin_bit_cast(h8, b1l[s]);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, t1, 0, 0, 0);
+        t2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t2, 0, 0, 0);
+      }
+      const char* frag = ks + nn * H3_KPITCH + 16 * g;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {                           // the k_node half
+        const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(frag + 64 * s));
+        const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(frag + 64 * s + H3_KPLANE));
+        const h8 bh = __builtin_bit_cast(h8, b1h[2 + s]), bl = __builtin_bit_cast(h8, b1l[2 + s]);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, t1, 0, 0, 0);
+        t2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t2, 0, 0, 0);
+      }
+      lg = t0 + (t1 + t2);
+    }
+#ifdef TSDE_STAMPS
+    asm volatile("" : "+v"(lg));
+    clk.mark(3);                                              // [3] P1: fragment reads + 12 matrix instructions
+#endif
+    // ---- online softmax of this lane's head over the tile's 16 edges
+    float cm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (e0 + 4 * g + r >= end) lg[r] = -INFINITY;
+      cm = fmaxf(cm, lg[r]);
+    }
+    cm = row_max(cm);                                         // over the four lane groups: the head's 16 edges
+    if (__builtin_amdgcn_ballot_w64(cm > m + H3_LAZY) != 0ull) {
+      const float mn = fmaxf(m, cm);
+      const float sc = fast_exp(m - mn);                      // m = -inf on the first tile -> 0
+      m = mn;
+      spart *= sc;
+      // the accumulators hold heads 4g + r in their registers: fetch those heads' factors from the lanes that own them
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sr = __shfl(sc, 4 * g + r);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) O[c][r] *= sr;
+      }
+    }
+    f4 ex;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ex[r] = fast_exp(lg[r] - m);                            // masked edges: exp(-inf) = 0
+      spart += ex[r];
+    }
+#ifdef TSDE_STAMPS
+    asm volatile("" : "+v"(ex));
+    clk.mark(4);                                              // [4] softmax
+#endif
+    // ---- P2 over the tile's 16 edges with K = 32 instructions (gattn.hip): B carries the rows' high pieces in slots 0..3 and their low
+    //      pieces in 4..7, A one piece of the weights in both halves
+    unsigned eh0, el0, eh1, el1;
+    split_pair(ex[0], ex[1], eh0, el0);
+    split_pair(ex[2], ex[3], eh1, el1);
+    const h8 a2h = __builtin_bit_cast(h8, u4{eh0, eh1, eh0, eh1}), a2l = __builtin_bit_cast(h8, u4{el0, el1, el0, el1});
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {                          // rel columns 16 cb + nn, straight from the tile: the transposing read
+      const int idh = 2 * cb + (tpp >> 1), idl = 8 + idh;
+      const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s4v*)(rt + trow * 256 + 16 * (idh ^ trow) + 8 * (tpp & 1)));
+      const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s4v*)(rt + trow * 256 + 16 * (idl ^ trow) + 8 * (tpp & 1)));
+      const uint2 hw = __builtin_bit_cast(uint2, hi), lw = __builtin_bit_cast(uint2, lo);
+      const h8 br = __builtin_bit_cast(h8, u4{hw.x, hw.y, lw.x, lw.y});
+      O[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h, br, O[cb], 0, 0, 0);
+      O[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2l, br, O[cb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                             // v_node columns 4 nn + c, split here (pairs of edges)
+      unsigned h0, l0, h1, l1;
+      split_pair(VV.x[0][c], VV.x[1][c], h0, l0);
+      split_pair(VV.x[2][c], VV.x[3][c], h1, l1);
+      const h8 bv = __builtin_bit_cast(h8, u4{h0, h1, l0, l1});
+      O[4 + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h, bv, O[4 + c], 0, 0, 0);
+      O[4 + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2l, bv, O[4 + c], 0, 0, 0);
+    }
+#ifdef TSDE_STAMPS
+    asm volatile("" : "+v"(O[0]), "+v"(O[7]));
+    clk.mark(5);                                              // [5] P2: transposing reads, v split, 16 matrix instructions
+    ++units;
+#endif
+  };
+  // The pipeline of gattn.hip: rel rows two tiles ahead (the HBM stream: three register sets), k_node / v_node rows one tile ahead (gathers
+  // that mostly hit the L2: two sets), source indices of tile i + 3.  Every fetch is UNCONDITIONAL (offsets clamp to the segment's last row)
+  // so that the compiler's counted waits stay counted.
+  H3Rows R[3], K[2], V[2];
+  int idx[2][4];
+  auto tile_at = [&](int i) { return beg + 16 * i; };
+  if (beg < end) {
+    fetch_idx(idx[0], tile_at(0));
+    fetch_idx(idx[1], tile_at(1));
+    fetch_rel(R[0], tile_at(0));
+    fetch_rel(R[1], tile_at(1));
+    fetch_kv(K[0], V[0], idx[0]);
+    fetch_idx(idx[0], tile_at(2));
+    for (int i0 = 0; tile_at(i0) < end; i0 += 6) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int i = i0 + u;
+        fetch_rel(R[(u + 2) % 3], tile_at(i + 2));
+        fetch_kv(K[(u + 1) % 2], V[(u + 1) % 2], idx[(u + 1) % 2]);
+        fetch_idx(idx[(u + 1) % 2], tile_at(i + 3));
+        if (tile_at(i) < end) tile_step(R[u % 3], K[u % 2], V[u % 2], tile_at(i));
+      }
+    }
+  }
+  clk.mark(6);
+  // ---- per target: normalise, lin_v_edge on the aggregated rel rows, store
+  const float s = row_sum(spart);                             // lanes (head nn, every g): the head's sum
+  const float inv = 1.0f / (s + 1e-16f);                      // PyG softmax denominator
+  if (g == 0 && nn < 8) {
+    hbuf[wv][nn] = inv;
+    hbuf[wv][8 + nn] = s * inv;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (g < 2) {                                                // S_h[16 cb + nn] of the heads 4g + r -> sbuf, normalised
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float iv = hbuf[wv][4 * g + r];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) sbuf[wv][4 * g + r][16 * cb + nn] = O[cb][r] * iv;
+    }
+  }
+  if (g == (nn >> 3)) {                                       // sum_e alpha v_node of node features 4 nn + c: head nn >> 1
+    const int r = (nn >> 1) & 3;
+    f4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = r == 0 ? O[4 + c][0] : (r == 1 ? O[4 + c][1] : (r == 2 ? O[4 + c][2] : O[4 + c][3]));
+    *reinterpret_cast<f4*>(&obuf[wv][4 * nn]) = o * hbuf[wv][nn >> 1];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int h = lane >> 3;
+  float out = fmaf(img[GAttnL::BVE + lane], hbuf[wv][8 + h], obuf[wv][lane]);
+#pragma unroll
+  for (int k4 = 0; k4 < 16; ++k4) {
+    const f4 wr = *reinterpret_cast<const f4*>(wve + lane * 64 + 4 * k4);
+    const f4 sv = *reinterpret_cast<const f4*>(&sbuf[wv][h][4 * k4]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out = fmaf(wr[e], sv[e], out);
+  }
+  if (node < N) agg[node * 64 + lane] = out;
+#ifdef TSDE_STAMPS
+  clk.mark(7);                                                // [7] the per-target epilogue ([6]: loop overhead)
+  if (lane == 0) clk.flush(g_stamps_gh3, units);
+#endif
+}
+
+// OFF by default -- measured (profiles/r06_ab_runs.md, 32 x 256 agents, one box): 170.7 us a layer against 168.2 us for the fp32-matrix
+// kernel (gattn_f32.hip) plus 5 us for the writer's split epilogue.  With a matrix part 5x shorter (28 x 16 cycles instead of 32 x 32)
+// and no vector instruction on a rel value the time does not move: neither pipe bounds this kernel.  What does, by ablation
+// (-DTSDE_H3_EXP): every row served from the cache 128 us (memory: 26 %); the rest is the tile's dependent chain (stage -> product ->
+// softmax -> product, ~1 100 cycles of issue in ~4 000) at the two waves per SIMD that 256 registers allow.  TRAJSDE_REL_SPLIT=1 selects it.
+bool rel_split_enabled() {
+  static const bool v = []() { const char* e = getenv("TRAJSDE_REL_SPLIT"); return e && atoi(e) != 0; }();
+  return v;
+}
+int launch_global_attn_h3(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
+                          const float* vn, int64_t N, float* agg, hipStream_t st) {
+  TS_LAUNCH_TAG("k_global_attn<8>", false, k_global_attn_h3, xcd_grid(cdiv(N, 4)), 256, 0, st, img, segptr, src, rel, q, kn, vn, N, agg);
+  return TRAJSDE_OK;
+}
+#else
+bool rel_split_enabled() { return false; }
+int launch_global_attn_h3(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, int64_t, float*,
+                          hipStream_t) {
+  return fail(TRAJSDE_ERR_UNSUPPORTED, "the split-image global attention exists in the fp16x3 build only");
+}
+#endif
+
+}  // namespace tsde

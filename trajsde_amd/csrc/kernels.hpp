@@ -53,7 +53,7 @@ __host__ __device__ __forceinline__ StreamMap stream_map(int C) {
   return StreamMap{C, C, C};
 #else
 #ifndef TSDE_STREAM_SHORT_PCT
-#define TSDE_STREAM_SHORT_PCT 75
+#define TSDE_STREAM_SHORT_PCT 70
 #endif
   int Cy = (TSDE_STREAM_SHORT_PCT * C + 50) / 100;
   Cy = Cy < 1 ? 1 : (Cy > C ? C : Cy);
@@ -104,6 +104,10 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
                          const DropArg& drop, float* emb_out = nullptr, float* stats = nullptr, SegMerge* defer = nullptr);
 // the same attention on the matrix cores (gattn.hip): inference, 8 heads, fp32 rows, no dropout; an alternative, TRAJSDE_GATTN_MM=1 selects it
 bool gattn_mm_enabled();
+// gattn_h3.hip: the same attention as fp16x3 products on rel rows stored split by their producer (inference, 8 heads, fp32 state)
+bool rel_split_enabled();
+int launch_global_attn_h3(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
+                          const float* vn, int64_t N, float* agg, hipStream_t st);
 // gattn_f32.hip: the same attention with its rel-row products on the fp32 matrix cores (8 heads, fp32 rows)
 bool gattn_f32mm_enabled();
 int launch_global_attn_mf(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,

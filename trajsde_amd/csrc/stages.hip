@@ -134,6 +134,8 @@ int fused_edge_attention(const char* tag, bool dominant, const float* img, const
                          const DropArg& drop, float* emb_out, float* stats, SegMerge* defer) {
   const int64_t E = ec.E;
   const AttnPlan pl = fused_plan(E);
+  // (k_edge_attn2 walks the list at 32-bit byte offsets through buffer descriptors: 16 B of geometry per edge)
+  TS_REQUIRE(E < (int64_t(1) << 28), "fused edge attention: an edge list of 2^28 or more entries exceeds its 32-bit byte offsets; split the batch");
   if (E > 0) {
     const int threads = fused_threads();
     // a bounded list: enough waves for the most streams any E' <= E cuts into; the ones beyond the true count leave at once
@@ -460,13 +462,22 @@ int trajsde_aggregator_forward(const trajsde_batch* b, const trajsde_graph* g, c
 }
 
 // relative-pose embedding of every global edge (AGG:42-51), once for the layers: depends on the graph stage alone
-static int aggregator_rel_embed(const trajsde_batch* b, const trajsde_graph* g, const float* blob, AggWs& w, hipStream_t st) {
+// The rel rows of an INFERENCE forward are stored as split-precision operand pieces (fp16 hi | lo, the same 256 bytes) when their
+// readers are the split-image attention (gattn_h3.hip): 8 heads, fp32 state, no dropout, the default kernel forms.
+static bool rel_split_possible() {
+#if TSDE_SPLIT_H3
+  return rel_split_enabled() && !state_bf16() && edge_x6() && rel_embed_fused() && global_fused_env() && !gattn_mm_enabled();
+#else
+  return false;
+#endif
+}
+static int aggregator_rel_embed(const trajsde_batch* b, const trajsde_graph* g, const float* blob, AggWs& w, hipStream_t st, bool split) {
   const int64_t E = g->E_g, etiles = (E + 15) / 16;
   if (E > 0) {
 #if TSDE_SPLIT_H3
     if (edge_x6() && rel_embed_fused())                     // two tiles per wave on the centred image (attn.hip k_edge_embed2)
       TS_LAUNCH_TAG("k_edge_embed<true>", false, k_edge_embed2, tile_grid((E + 31) / 32, 1024, edge_embed2_lds(1024)), 1024, edge_embed2_lds(1024), st,
-                    blob + AggBlob::REL6G, g->g_geom, count_of(g, 2, E), w.rel, state_bf16() ? 1 : 0);
+                    blob + AggBlob::REL6G, g->g_geom, count_of(g, 2, E), w.rel, split ? 2 : (state_bf16() ? 1 : 0));
     else
 #endif
     if (edge_x6())
@@ -489,7 +500,8 @@ int trajsde_aggregator_prepare(const trajsde_batch* b, const trajsde_graph* g, c
   TS_REQUIRE(g->g_src && g->g_segptr, "aggregator_prepare: graph not compacted (call trajsde_graph_compact)");
   AggWs w(b, g, ws, ws_bytes);
   if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "aggregator_prepare: workspace too small");
-  return aggregator_rel_embed(b, g, blob, w, static_cast<hipStream_t>(stream_));
+  // (the layers' caller may turn out to need fp32 rows -- 4 heads, dropout --: aggregator_forward_impl then forms them again)
+  return aggregator_rel_embed(b, g, blob, w, static_cast<hipStream_t>(stream_), rel_split_possible());
 }
 
 static int aggregator_forward_impl(const trajsde_batch* b, const trajsde_graph* g, const float* blob, int num_layers, int num_modes,
@@ -520,8 +532,9 @@ static int aggregator_forward_impl(const trajsde_batch* b, const trajsde_graph* 
   if (!w.ok) return fail(TRAJSDE_ERR_WORKSPACE, "aggregator_forward: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int64_t N = b->N, E = g->E_g, ntiles = (N + 15) / 16, etiles = (E + 15) / 16;
-  if (!rel_ready)
-    if (int rc = aggregator_rel_embed(b, g, blob, w, st)) return rc;
+  const bool split = rel_split_possible() && num_heads == 8 && (!dropout || dropout->p == 0.f) && E > 0;
+  if (!rel_ready || split != rel_split_possible())
+    if (int rc = aggregator_rel_embed(b, g, blob, w, st, split)) return rc;
   const float* x = local_embed;
   float* bufs[2] = {w.xa, w.xb};
   for (int i = 0; i < num_layers; ++i) {
@@ -538,7 +551,9 @@ static int aggregator_forward_impl(const trajsde_batch* b, const trajsde_graph* 
     if (fused) {
       // one wave per target: logits, softmax and aggregation in one pass over the rel rows (no per-edge GEMM)
       TS_REQUIRE(N < (1 << 23), "aggregator_forward: node rows are addressed with 32-bit byte offsets (N < 2^23)");
-      if (num_heads == 8 && !state_bf16() && drop.p == 0.f && gattn_mm_enabled()) {
+      if (split) {
+        if (int rc = launch_global_attn_h3(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, st)) return rc;
+      } else if (num_heads == 8 && !state_bf16() && drop.p == 0.f && gattn_mm_enabled()) {
         if (int rc = launch_global_attn_mm(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, st)) return rc;
       } else if (num_heads == 8 && !state_bf16() && gattn_f32mm_enabled() && E > 0) {
         if (int rc = launch_global_attn_mf(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, nullptr, drop, st)) return rc;

@@ -33,6 +33,10 @@
 #ifndef TSDE_R6_ATOMS
 #define TSDE_R6_ATOMS 1
 #endif
+//   TSDE_R6_TOP      edge walk of the fused attention in 32-bit arithmetic through buffer descriptors, scalar loop counter
+#ifndef TSDE_R6_TOP
+#define TSDE_R6_TOP 1
+#endif
 //   TSDE_R6_SPLIT    operand split: low pieces by v_fma_mix_f32 + v_cvt_pkrtz (half-rate) instead of v_fma_mixlo/hi_f16 (quarter-rate)
 #ifndef TSDE_R6_SPLIT
 #define TSDE_R6_SPLIT 1
@@ -733,7 +737,11 @@ __device__ __forceinline__ u4 in2_operand(float x0r, float x1r, float rstd) {
   hf2 hr2 = __builtin_bit_cast(hf2, rh);
   const float rr = __builtin_fmaf(float(hr2[0]), opaque_minus_one(), rstd);        // rstd - fp16(rstd), exact
   hr2[1] = _Float16(rr);
-  return u4{h, l, __builtin_bit_cast(unsigned, hr2), 0x3C003C00u};
+  // (the constant word through an opaque VECTOR register: with a literal there the compiler materialises the whole 128-bit tuple from
+  //  scalar registers -- two v_mov_b64 -- and then overwrites three of its words, five moves per operand, twenty an iteration)
+  unsigned ones = 0x3C003C00u;
+  asm("" : "+v"(ones));
+  return u4{h, l, __builtin_bit_cast(unsigned, hr2), ones};
 #else
   const unsigned rhb = __builtin_bit_cast(unsigned, rh);
   float rr;                                                                        // rstd - fp16(rstd), exact
@@ -821,6 +829,32 @@ __device__ __forceinline__ void store_tile_rows(float* tile, const f4 (&a)[4], f
     if (row0 + r < nrows) *reinterpret_cast<f4*>(out + (row0 + r) * 64 + 4 * (L.lane & 15)) = v;
   }
 }
+
+#if TSDE_SPLIT_H3
+// The same tile as SPLIT-PRECISION rows: row r = fp16 hi[64] | fp16 lo[64] (256 bytes, like the fp32 row), hi / lo the operand pieces of
+// split_pair.  Lane (n, g) holds features 16 jt + 4 g + c of row n: 8 bytes of each plane per jt.
+__device__ __forceinline__ void store_tile_rows_split(float* tile, const f4 (&a)[4], float* __restrict__ out, int64_t row0, int64_t nrows,
+                                                      const Lane& L) {
+  __builtin_amdgcn_wave_barrier();                            // the tile's previous readers are done (same wave, in order)
+  unsigned* const t = reinterpret_cast<unsigned*>(tile);
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    unsigned h0, l0, h1, l1;
+    split_pair(a[jt][0], a[jt][1], h0, l0);
+    split_pair(a[jt][2], a[jt][3], h1, l1);
+    *reinterpret_cast<uint2*>(t + L.n * 68 + 8 * jt + 2 * L.g) = uint2{h0, h1};
+    *reinterpret_cast<uint2*>(t + L.n * 68 + 32 + 8 * jt + 2 * L.g) = uint2{l0, l1};
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 4 * q + (L.lane >> 4);
+    const f4 v = *reinterpret_cast<const f4*>(tile + r * 68 + 4 * (L.lane & 15));
+    if (row0 + r < nrows) *reinterpret_cast<f4*>(out + (row0 + r) * 64 + 4 * (L.lane & 15)) = v;
+  }
+}
+#endif
 
 // ---- "hidden state stored bf16 between kernels" (BASELINE configs[4]): the same [rows][64] activations with 2-byte elements.
 // Arithmetic stays fp32 in registers; a row is rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32) when it is stored and
