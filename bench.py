@@ -547,16 +547,18 @@ def main():
                         e = tab[k % tab.shape[0]].ctypes.data_as(C.POINTER(C.c_float))
                         src, dst = (ya, yb) if k % 2 == 0 else (yb, ya)
                         _lib.check(lib.trajsde_sde_step(rows, dblob.data_ptr(), src.data_ptr(), dst.data_ptr(), e, k, C.byref(nz), cur))
-                sde_steps(20)
+                # 500 warm-up launches (~75 ms): the chip's clock ramps over the first few hundred launches of a burst, and a figure taken
+                # after 20 read 0.29-0.31 of the HBM peak where the warmed kernel does 0.33-0.36 (profiles/r05_sde_step_floor.md section 1)
+                sde_steps(500)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                sde_steps(100)
+                sde_steps(400)
                 e1.record()
                 torch.cuda.synchronize()
-                sms = e0.elapsed_time(e1) / 100
+                sms = e0.elapsed_time(e1) / 400
                 gbs, tfl = rows * 512 / (sms * 1e-3) / 1e9, rows * 41.8e3 / (sms * 1e-3) / 1e12
-                views[label] = {"rows": rows, "avg_launch_ms": sms,
+                views[label] = {"rows": rows, "avg_launch_ms": sms, "launches": 400, "warmup_launches": 500,
                                 "hbm_view": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_path_step": 512},
                                 "flop_view": {"achieved": tfl, "peak": peak_fp32_equiv, "unit": "TFLOP/s", "frac": tfl / peak_fp32_equiv,
                                               "flop_per_path_step": 41.8e3}}

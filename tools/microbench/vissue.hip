@@ -70,6 +70,14 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define I_FMAF16(i) "v_fma_f16 %" #i ", %" #i ", %16, %17\n\t"
 #define I_BITOP3(i) "v_bitop3_b32 %" #i ", %" #i ", %16, %17 bitop3:0x80\n\t"
 #define I_MAXIMUM3(i) "v_maximum3_f32 %" #i ", %" #i ", %16, %17\n\t"
+#define I_MULHI(i) "v_mul_hi_u32 %" #i ", %" #i ", %16\n\t"
+#define I_SIN(i) "v_sin_f32_e32 %" #i ", %" #i "\n\t"
+#define I_LOG(i) "v_log_f32_e32 %" #i ", %" #i "\n\t"
+#define I_SQRT(i) "v_sqrt_f32_e32 %" #i ", %" #i "\n\t"
+#define I_CVTU(i) "v_cvt_f32_u32_e32 %" #i ", %" #i "\n\t"
+#define I_LSHR(i) "v_lshrrev_b32_e32 %" #i ", 9, %" #i "\n\t"
+#define I_ALIGNBIT(i) "v_alignbit_b32 %" #i ", %" #i ", %16, 7\n\t"
+#define I_MULU24(i) "v_mul_u32_u24_e32 %" #i ", %16, %" #i "\n\t"
 #define I_ACCW(i) "v_accvgpr_write_b32 a" #i ", %" #i "\n\t"
 #define I_DSREAD(i) "ds_read_b128 %" #i ", %8\n\t"
 
@@ -80,8 +88,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 enum Kind { K_FMA, K_MUL32, K_FMAC32, K_LIT, K_FMAAK, K_MIXLO, K_PKRTZ, K_MAXI, K_MAXF, K_EXP, K_RSQ, K_CND, K_MOV, K_PERM16, K_CHAIN, K_CHAIN2,
             K_NOP, K_AND, K_SUB, K_PKMAXH, K_PKADDH, K_PKFMAH, K_CVT32_16, K_CVT16_32, K_PACK, K_PERM, K_LSHLOR, K_BFI, K_MED3, K_MAX3, K_MIXF32, K_MIXHI,
-            K_ADDU, K_LSHL, K_XOR, K_MULLO, K_PKBF16, K_RCP, K_DOT2C, K_LDEXP, K_CMP, K_CNDVCC, K_MINF, K_MAXU, K_FMAF16, K_BITOP3, K_MAXIMUM3, K_PKMULF32,
-            K_PKFMAF32, K_PKADDF32, K_COUNT };
+            K_ADDU, K_LSHL, K_XOR, K_MULLO, K_PKBF16, K_RCP, K_DOT2C, K_LDEXP, K_CMP, K_CNDVCC, K_MINF, K_MAXU, K_FMAF16, K_BITOP3, K_MAXIMUM3, K_MULHI, K_SIN, K_LOG, K_SQRT, K_CVTU, K_LSHR, K_ALIGNBIT, K_MULU24, K_MAD64,
+            K_LSHLADD64, K_PKMULF32, K_PKFMAF32, K_PKADDF32, K_COUNT };
 static const char* KIND_NAME[] = {"v_fma_f32 (VOP3, 8 B)", "v_mul_f32_e32 (VOP2, 4 B)", "v_fmac_f32_e32 (4 B, 16 chains)", "v_add_f32 + literal (8 B)",
                                   "v_fmaak_f32 (literal, 8 B)", "v_fma_mixlo_f16", "v_cvt_pkrtz_f16_f32", "v_max_i32_e32", "v_max_f32_e32",
                                   "v_exp_f32", "v_rsq_f32", "v_cndmask_b32_e64 (SGPR mask)", "v_mov_b32", "v_permlane16_swap", "v_fma_f32, ONE chain",
@@ -89,7 +97,8 @@ static const char* KIND_NAME[] = {"v_fma_f32 (VOP3, 8 B)", "v_mul_f32_e32 (VOP2,
                                   "v_cvt_f32_f16", "v_cvt_f16_f32", "v_pack_b32_f16", "v_perm_b32", "v_lshl_or_b32", "v_bfi_b32", "v_med3_f32", "v_max3_f32",
                                   "v_fma_mix_f32", "v_fma_mixhi_f16", "v_add_u32", "v_lshlrev_b32", "v_xor_b32", "v_mul_lo_u32", "v_cvt_pk_bf16_f32", "v_rcp_f32",
                                   "v_dot2c_f32_f16", "v_ldexp_f32", "v_cmp_gt_f32 (vcc)", "v_cndmask_b32_e32 (vcc)", "v_min_f32", "v_max_u32", "v_fma_f16",
-                                  "v_bitop3_b32", "v_maximum3_f32", "v_pk_mul_f32 (per 2 values)", "v_pk_fma_f32 (per 2 values)", "v_pk_add_f32 (per 2 values)"};
+                                  "v_bitop3_b32", "v_maximum3_f32", "v_mul_hi_u32", "v_sin_f32", "v_log_f32", "v_sqrt_f32", "v_cvt_f32_u32", "v_lshrrev_b32",
+                                  "v_alignbit_b32", "v_mul_u32_u24", "v_mad_u64_u32 (8 pairs)", "v_lshl_add_u64 (8 pairs)", "v_pk_mul_f32 (per 2 values)", "v_pk_fma_f32 (per 2 values)", "v_pk_add_f32 (per 2 values)"};
 
 template <int KIND, bool BIG>
 __device__ __forceinline__ void body(float (&x)[16], float m, float c) {
@@ -141,6 +150,32 @@ __device__ __forceinline__ void body(float (&x)[16], float m, float c) {
   else if constexpr (KIND == K_FMAF16) EMIT(I_FMAF16);
   else if constexpr (KIND == K_BITOP3) EMIT(I_BITOP3);
   else if constexpr (KIND == K_MAXIMUM3) EMIT(I_MAXIMUM3);
+  else if constexpr (KIND == K_MULHI) EMIT(I_MULHI);
+  else if constexpr (KIND == K_SIN) EMIT(I_SIN);
+  else if constexpr (KIND == K_LOG) EMIT(I_LOG);
+  else if constexpr (KIND == K_SQRT) EMIT(I_SQRT);
+  else if constexpr (KIND == K_CVTU) EMIT(I_CVTU);
+  else if constexpr (KIND == K_LSHR) EMIT(I_LSHR);
+  else if constexpr (KIND == K_ALIGNBIT) EMIT(I_ALIGNBIT);
+  else if constexpr (KIND == K_MULU24) EMIT(I_MULU24);
+  else if constexpr (KIND == K_MAD64 || KIND == K_LSHLADD64) {
+    // 64-bit results on 8 register pairs: 96 (768) instructions per call
+    typedef unsigned long long u64t;
+    u64t y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = (u64t(__float_as_uint(x[2 * i])) << 32) | __float_as_uint(x[2 * i + 1]);
+    const unsigned mu = __float_as_uint(m);
+#define Q_MAD(i) "v_mad_u64_u32 %" #i ", s[2:3], %8, %8, %" #i "\n\t"
+#define Q_LSA(i) "v_lshl_add_u64 %" #i ", %" #i ", 2, %" #i "\n\t"
+#define QR8(I) I(0) I(1) I(2) I(3) I(4) I(5) I(6) I(7)
+#define Q12(I) QR8(I) QR8(I) QR8(I) QR8(I) QR8(I) QR8(I) QR8(I) QR8(I) QR8(I) QR8(I) QR8(I) QR8(I)
+#define Q96(I) Q12(I) Q12(I) Q12(I) Q12(I) Q12(I) Q12(I) Q12(I) Q12(I)
+#define OUTQ "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7])
+    if constexpr (KIND == K_MAD64) { if (BIG) asm volatile(Q96(Q_MAD) : OUTQ : "v"(mu) : "s2", "s3"); else asm volatile(Q12(Q_MAD) : OUTQ : "v"(mu) : "s2", "s3"); }
+    else { if (BIG) asm volatile(Q96(Q_LSA) : OUTQ : "v"(mu)); else asm volatile(Q12(Q_LSA) : OUTQ : "v"(mu)); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[2 * i] = __uint_as_float(unsigned(y[i] >> 32)); x[2 * i + 1] = __uint_as_float(unsigned(y[i])); }
+  }
   else if constexpr (KIND == K_PKMULF32 || KIND == K_PKFMAF32 || KIND == K_PKADDF32) {
     // packed fp32 on 8 register pairs: 96 (768) instructions = 192 (1 536) values per call, so the columns read "per two values"
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -231,7 +266,7 @@ static double run(int threads, int iters, float* out, unsigned long long* cyc, i
 template <int KIND>
 static void kind_rows(float* out, unsigned long long* cyc, int nblocks) {
   const int it_s = 400, it_b = 50;                       // 192 x 400 = 1536 x 50 instructions per wave
-  const double n = ((KIND == K_PKMULF32 || KIND == K_PKFMAF32 || KIND == K_PKADDF32) ? 96.0 : (KIND == K_CHAIN2 ? 384.0 : 192.0)) * it_s;
+  const double n = ((KIND == K_PKMULF32 || KIND == K_PKFMAF32 || KIND == K_PKADDF32 || KIND == K_MAD64 || KIND == K_LSHLADD64) ? 96.0 : (KIND == K_CHAIN2 ? 384.0 : 192.0)) * it_s;
   const double one_s = run<KIND, false, 0>(256, it_s, out, cyc, nblocks, 0), two_s = run<KIND, false, 0>(512, it_s, out, cyc, nblocks, 5);
   const double one_b = run<KIND, true, 0>(256, it_b, out, cyc, nblocks, 0), two_b = run<KIND, true, 0>(512, it_b, out, cyc, nblocks, 5);
   const double beside = run<KIND, false, 1>(512, it_s, out, cyc, nblocks, 5);

@@ -219,8 +219,14 @@ __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blo
     float gs;
 #if TSDE_SPLIT_H3
     if constexpr (X6) {
-#ifdef TSDE_STAMPS
+#if defined(TSDE_STAMPS) || (defined(TSDE_SDE_ALIGN) && TSDE_SDE_ALIGN >= 2)
       // the phases of sde_fg_eval spelled out between the clock's marks (same calls, same order)
+      // (-DTSDE_SDE_ALIGN=2, a timing experiment of round 6: a workgroup barrier at every mark, so that the four waves of a SIMD run their
+      //  vector-only phases together and their matrix phases together -- profiles/r06_sde_step_floor.md)
+#if defined(TSDE_SDE_ALIGN) && TSDE_SDE_ALIGN >= 2 && !defined(TSDE_STAMPS)
+      struct { __device__ __forceinline__ void mark(int) { __builtin_amdgcn_s_barrier(); } } clk;
+      unsigned long long units = 0;
+#endif
       using DD = DecSdeL6;
       noise_of(z, r, plain_noise);
       asm volatile("" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
@@ -307,8 +313,18 @@ __global__ __launch_bounds__(1024) void k_sde_step(const float* __restrict__ blo
     };
     bool first = true;
     if (tile < full) send(tile);
+#if defined(TSDE_SDE_ALIGN) && TSDE_SDE_ALIGN >= 1
+    // timing experiment (round 6): every wave of the workgroup takes its tile-step at the same time.  (Waves of one workgroup may differ
+    // by one iteration; the tail of the list is then NOT processed by the short ones' partners: results are wrong, timings are what this is for.)
+    const int64_t iters_wg = (full - int64_t(blockIdx.x) * waves + stride - 1) / stride;      // of the workgroup's first wave
+    for (int64_t it_ = 0; it_ < iters_wg; ++it_, tile += stride) {
+      __builtin_amdgcn_s_barrier();
+      if (tile >= full) continue;
+      keep_lds_reads_here();
+#else
     for (; tile < full; tile += stride) {
       keep_lds_reads_here();
+#endif
       // the four transfers of this tile are the oldest vector-memory operations in flight; behind them sit at most the four row
       // stores of the previous tile (vmcnt counts in issue order), so "all but four" means the tile has landed
       if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
