@@ -231,6 +231,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if rank != 0:
         os.dup2(2, 1)       # only rank 0 owns stdout (the JSON line); anything other ranks' libraries print goes to stderr
+    # N ranks share one host: each is confined to its share of the cores and torch's thread pool capped to it, before any GPU call
+    from trajsde_amd.shard import pin_rank_to_cores
+    host_share = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     rccl_ranks = None
     if world > 1 or os.environ.get("TRAJSDE_BENCH_FORCE_DIST") == "1":      # the latter: exercise the RCCL path with one rank
         import torch.distributed as dist
@@ -371,7 +374,8 @@ def main():
                                    f"SDE decoder), synth({', '.join(f'{k}={v}' for k, v in spec['synth'].items())})",
                        "scenes_per_gpu": wl.scenes, "agents_per_scene": wl.skw["n"], "num_modes": spec["num_modes"],
                        "future_steps": spec["future_steps"], "aa_edges_per_step": int(e_aa), "parallelism": f"scene-shard x{world}",
-                       "streams_per_gpu": n_streams, "rccl_ranks_seen": rccl_ranks, "sync_free_forward": bool(runtime_mod.sync_free())},
+                       "streams_per_gpu": n_streams, "rccl_ranks_seen": rccl_ranks, "sync_free_forward": bool(runtime_mod.sync_free()),
+                       "host_cores_rank0": host_share},
             "timing": {"windows_ms": [1e3 * w for w in windows], "reported": "median window", "steps_per_window": args.steps,
                        "untimed_warmup_steps_run": warm_steps},
             "roofline": roof,
@@ -505,7 +509,7 @@ def main():
                 import tempfile
                 from trajsde_amd import build as build_mod
                 if not os.path.isfile(build_mod.STRICT_LIB):
-                    raise FileNotFoundError(build_mod.STRICT_LIB + " (python -m trajsde_amd.build)")
+                    raise FileNotFoundError(build_mod.STRICT_LIB + " (python -m trajsde_amd.build --strict, or __graft_entry__.build())")
                 sample = synth(**dict(spec["synth"], S=CPU_SAMPLE_SCENES)).to(dev)
                 with torch.no_grad():
                     loc0 = model(sample, noise=NoiseSpec(seed=1234))["loc"].cpu().numpy()
@@ -594,7 +598,32 @@ def main():
                 b = TemporalData(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in tbase.items()})
                 tmodel.prefetch_graph(b, NoiseSpec(seed=5000 + 100_000 * rank + i))
             return b
-        tnext = [tfresh(0)]
+        def all_ranks_ok(ok, stage):
+            """A rank that failed must not leave the others inside a collective it will never join: every rank reports, all of them
+            leave together (the flag's own all-reduce is the only collective a failed rank still takes part in)."""
+            if dist is None or world == 1:
+                return ok
+            flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and ok:
+                raise RuntimeError(f"train_figure({name}): another rank failed during {stage}; this rank leaves the leg with it")
+            return ok
+
+        # set-up and ONE step without any collective first: allocation failures and layout refusals show up here, on their own rank
+        err = None
+        try:
+            tnext = [tfresh(0)]
+            flat.grads.early_enabled = False
+            flat.zero()
+            tmodel.training_step(tnext[0], 0, noise=NoiseSpec(seed=5000 + 100_000 * rank)).backward()
+            flat.step()
+            tnext[0] = tfresh(1)
+            torch.cuda.synchronize()
+        except Exception as e:        # noqa: BLE001 -- reported below, after the other ranks know
+            err = e
+        all_ranks_ok(err is None, "the collective-free first step")
+        if err is not None:
+            raise err
 
         def tstep(i, reduce_):
             flat.zero()
@@ -621,7 +650,17 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el = float(t.item())
             return el / steps * 1e3
-        tms = timed(0, bool(collective))
+        try:
+            tms = timed(0, bool(collective))
+        except Exception:
+            # inside the collective loop there is no point at which the other ranks could be told: they sit in an all-reduce this rank
+            # will never join.  Leave hard, so that the launcher tears the job down at once instead of after the RCCL watchdog's minutes.
+            if collective and dist is not None and world > 1:
+                import traceback
+                traceback.print_exc()
+                sys.stderr.flush()
+                os._exit(3)
+            raise
         S = tspec["synth"]["S"]
         fig = {"ms_per_step": tms, "scenes_per_s": world * S / tms * 1e3, "steps": steps, "workload": what,
                "what": "training_step + backward (HIP backward kernels of all three stages) + AdamW, fp32 gradients, a fresh "

@@ -1,5 +1,8 @@
 """CPU suite: host-side mirrors of the reference interface (losses, metrics, collate, schedule helpers) against the
 formulas of the reference, evaluated on the oracle's outputs."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -479,3 +482,36 @@ def test_decoders_without_the_scale_head_keep_the_reference_state_dict():
     vanilla = PredictionModel(**cfg, init_seed=1)
     assert not any(k.startswith("decoder.scale") for k in vanilla.state_dict())
     assert tuple(vanilla.decoder.p("scale.3.weight").shape) == (24, 64)
+
+
+def test_ranks_of_a_node_get_disjoint_core_shares_and_capped_thread_pools():
+    """shard.core_share / pin_rank_to_cores: eight ranks on one host each keep a contiguous share of the cores,
+    every core belongs to exactly one rank, and the process really is confined (checked in child processes: the affinity of a
+    process is not something a test should change for its own interpreter)"""
+    import subprocess
+    import sys
+    from trajsde_amd.shard import core_share
+    cores = list(range(3, 3 + 61))                                          # 61 usable cores starting at an offset, 8 ranks
+    shares = [core_share(cores, r, 8) for r in range(8)]
+    assert sorted(sum(shares, [])) == cores
+    assert {len(s) for s in shares} == {7, 8} and all(s == list(range(s[0], s[0] + len(s))) for s in shares)
+    assert core_share(cores, 0, 1) == cores
+    assert [core_share([5, 9], r, 4) for r in range(4)] == [[5], [9], [5], [9]]      # fewer cores than ranks: shared round-robin
+    avail = sorted(os.sched_getaffinity(0))
+    code = ("import os, json, sys; sys.path.insert(0, %r)\n"
+            "from trajsde_amd.shard import pin_rank_to_cores\n"
+            "import torch\n"
+            "info = pin_rank_to_cores()\n"
+            "print(json.dumps([info, sorted(os.sched_getaffinity(0)), torch.get_num_threads()]))\n") % H.ROOT
+    seen = []
+    for r in range(2):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="2", WORLD_SIZE="2")
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        info, aff, nt = json.loads(out.stdout.strip().splitlines()[-1])
+        assert aff == core_share(avail, r, 2) and info["pinned"] and nt == max(1, min(len(aff), 16)) == info["torch_threads"]
+        seen += aff
+    assert sorted(seen) == avail if len(avail) >= 2 else True
+    one = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LOCAL_RANK="0", LOCAL_WORLD_SIZE="1", WORLD_SIZE="1"),
+                         capture_output=True, text=True, timeout=120)
+    assert json.loads(one.stdout.strip().splitlines()[-1])[0]["pinned"] is False          # single-rank runs are left alone

@@ -570,3 +570,110 @@ def test_early_slice_with_a_frozen_parameter_in_the_block():
     # a layout where the would-be early block is cut in two by an encoder parameter: plain form, decided up front
     names2 = {id(p): n for p, n in zip(ps, ("aggregator.a", "encoder.a", "decoder.a", "decoder.frozen", "decoder.b"))}
     assert FlatGrads(ps).early_plan(names2) is False
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# cost-balanced dealing of a step's scenes (SceneLoader(balance="cost"))
+class _SizedScenes(list):
+    """a dataset of bare scenes whose sizes are skewed like a real split's (6 .. 69 actors, 0 .. 39 lane segments)"""
+
+    def __init__(self, n=96, seed=5):
+        g = torch.Generator().manual_seed(seed)
+        ns = torch.randint(6, 70, (n,), generator=g).tolist()
+        ls = torch.randint(0, 40, (n,), generator=g).tolist()
+        super().__init__({"x": torch.zeros(a, 2), "lane_vectors": torch.zeros(b, 2), "sid": i} for i, (a, b) in enumerate(zip(ns, ls)))
+
+
+def _scene_grad(i):
+    """an integer-valued 'gradient' of scene i: sums of these are exact in fp32 in any order, so the all-reduced average of a step
+    must equal the single-process one bit for bit whichever rank computed which scene"""
+    return torch.tensor([float((7 * i + 3) % 101), float((i * i) % 53), 1.0])
+
+
+def _balance_worker(rank, world, port, q, balance):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from trajsde_amd.dataset import SceneLoader
+        torch.set_num_threads(1)
+        ds = _SizedScenes()
+        ld = SceneLoader(ds, batch_size=8, shuffle=True, seed=11, rank=rank, world_size=world, balance=balance)
+        w = torch.zeros(3)
+        steps = []
+        for epoch in range(2):
+            ld.set_epoch(epoch)
+            ids, B = ld.scene_ids(), ld.batch_size
+            for lo in range(0, len(ids), B):
+                chunk = ids[lo:lo + B]
+                g = torch.stack([_scene_grad(i) for i in chunk]).sum(0)
+                dist.all_reduce(g)                                          # the step's one collective: sum, then the mean over ranks
+                w -= g / world
+                steps.append(chunk)
+        q.put((rank, steps, [ld.step_costs() for _ in range(1)][0], w.numpy()))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("balance", ["round_robin", "cost"])
+def test_cost_balanced_dealing_levels_the_ranks_and_keeps_the_averaged_gradient(balance):
+    """two gloo ranks over 96 scenes of skewed sizes, 8 scenes a rank and step: with balance="cost" every step's scenes are the ones
+    round-robin would give it (same steps, same averaged gradient -- bit-equal to the single-process sums), dealt so that the
+    heaviest rank of a step carries <= 1.05 of the mean; round-robin on the same data is measurably worse"""
+    from trajsde_amd.dataset import SceneLoader
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_balance_worker, args=(r, world, port, q, balance)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ds = _SizedScenes()
+    # the single-process run: per step the union of the ranks' scenes in round-robin's grouping, averaged over the world size
+    want, ref = torch.zeros(3), SceneLoader(ds, batch_size=8, shuffle=True, seed=11)
+    n_steps = len(got[0][1])
+    assert n_steps == len(got[1][1]) == 2 * (96 // 16)
+    k = 0
+    for epoch in range(2):
+        ref.set_epoch(epoch)
+        order = ref._order()
+        for lo in range(0, len(order), 16):
+            group = order[lo:lo + 16]
+            assert sorted(got[0][1][k] + got[1][1][k]) == sorted(group)       # the same scenes per step, whoever computes them
+            want -= torch.stack([_scene_grad(i) for i in group]).sum(0) / world
+            k += 1
+    for g in got:
+        assert np.array_equal(g[3], want.numpy())                            # bit-equal: replicas and the single-process sums
+    costs = np.array([g[2] for g in got])                                     # [rank][step of the last epoch]
+    ratio = float((costs.max(0) / costs.mean(0)).max())
+    if balance == "cost":
+        assert ratio <= 1.05, ratio
+    else:
+        assert ratio > 1.05, ratio                                            # what the option is for: round-robin leaves the ranks uneven
+
+
+def test_cost_balance_at_eight_ranks_and_the_shard_index_costs(tmp_path):
+    """the deal at the node's width (8 ranks, 16 scenes a rank and step): max / mean <= 1.05 per step, every scene once; and
+    nuArgoDataset.scene_costs() reads n^2 + lanes from the shards' pointer tables without materialising a scene"""
+    from trajsde_amd.dataset import SceneLoader, nuArgoDataset
+    ds = _SizedScenes(n=256, seed=9)
+    loaders = [SceneLoader(ds, 16, shuffle=True, seed=1, rank=r, world_size=8, balance="cost") for r in range(8)]
+    costs = np.array([ld.step_costs() for ld in loaders])
+    assert float((costs.max(0) / costs.mean(0)).max()) <= 1.05
+    assert sorted(sum((ld.scene_ids() for ld in loaders), [])) == list(range(256))
+    rr = np.array([SceneLoader(ds, 16, shuffle=True, seed=1, rank=r, world_size=8).step_costs() for r in range(8)])
+    assert float((rr.max(0) / rr.mean(0)).max()) > 1.2
+    nu, argo, n = _fixture_scene_roots(str(tmp_path))
+    real = nuArgoDataset("train", None, None, nu, argo)
+    got = real.scene_costs()
+    assert len(got) == n == len(real)
+    for i in range(n):
+        sc = real._raw(i)
+        assert got[i] == float(sc["x"].shape[0]) ** 2 + float(sc["lane_vectors"].shape[0])

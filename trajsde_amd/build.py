@@ -68,57 +68,94 @@ def sources():
 
 
 def _want_strict() -> bool:
-    return "-DTSDE_SPLIT_H3=0" not in FLAGS and os.environ.get("TRAJSDE_BUILD_STRICT24", "1") != "0"
+    """the strict-precision twin is a product of `build_strict()` (bench.py's `strict24` leg, __graft_entry__.build()) -- not of every
+    import: it compiles every unit a third time for an artefact only the bench uses.  TRAJSDE_BUILD_STRICT24=1 puts it back into build()."""
+    return "-DTSDE_SPLIT_H3=0" not in FLAGS and os.environ.get("TRAJSDE_BUILD_STRICT24", "0") == "1"
+
+
+def _deps():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".o")] + [os.path.join(os.path.dirname(HERE), "include", "trajsde_hip.h")]
 
 
 def _stale() -> bool:
-    if not os.path.isfile(LIB) or not os.path.isfile(ALT_LIB) or (_want_strict() and not os.path.isfile(STRICT_LIB)):
+    if not os.path.isfile(LIB) or not os.path.isfile(ALT_LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "trajsde_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps())
+
+
+def _run_all(jobs, what="hipcc"):
+    """run the compile commands, at most one per host core at a time (three builds of every unit started at once took ~3x the
+    peak host memory of one)"""
+    limit = max(2, os.cpu_count() or 2)
+    pending, running, outputs = list(jobs), [], []
+    while pending or running:
+        while pending and len(running) < limit:
+            src, cmd = pending.pop(0)
+            running.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        src, p = running.pop(0)
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            for _, q in running:
+                q.kill()
+            raise RuntimeError(f"{what} failed on {src}:\n{out.decode()}")
+        outputs.append(out)
+    return outputs
+
+
+def _unit_flags(name):
+    return usable_flags(PER_FILE_FLAGS[name]) if (name in PER_FILE_FLAGS and "-DTSDE_SPLIT_H3=0" not in FLAGS) else []
+
+
+def build_strict(force: bool = False, verbose: bool = True) -> str:
+    """variants/libtrajsde_strict24.so: the product library with 24-bit operands (three bf16 pieces, six products), same C-ABI"""
+    if "-DTSDE_SPLIT_H3=0" in FLAGS:
+        raise RuntimeError("TRAJSDE_SPLIT=bf16x6 already builds the main library strict")
+    if not force and os.path.isfile(STRICT_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(STRICT_LIB) for d in _deps()):
+        return STRICT_LIB
+    jobs, objs = [], []
+    for src in sources():
+        sobj = os.path.join(CSRC, os.path.basename(src)[:-4] + ".s24.o")
+        objs.append(sobj)
+        # (without the per-file options: the bf16x6 recurrence pins nothing in the accumulation registers, and this compiler
+        #  crashes on its fp32 matrix instructions under -amdgpu-mfma-vgpr-form)
+        jobs.append((src, [HIPCC, *FLAGS, "-DTSDE_SPLIT_H3=0", "-DTSDE_PRODUCT=1", "-c", src, "-o", sobj]))
+    for out in _run_all(jobs):
+        if verbose and out.strip():
+            print(out.decode())
+    os.makedirs(os.path.dirname(STRICT_LIB), exist_ok=True)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", STRICT_LIB, *objs])
+    if verbose:
+        print(f"built {STRICT_LIB}")
+    return STRICT_LIB
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
-    objs, alt_objs, strict_objs = [], [], []
-    procs = []
-    strict = _want_strict()
+    objs, alt_objs, jobs = [], [], []
     for src in sources():
         name = os.path.basename(src)
-        extra = usable_flags(PER_FILE_FLAGS[name]) if (name in PER_FILE_FLAGS and "-DTSDE_SPLIT_H3=0" not in FLAGS) else []
+        extra = _unit_flags(name)
         obj = os.path.join(CSRC, name[:-4] + ".o")
         objs.append(obj)
-        procs.append((src, subprocess.Popen([HIPCC, *FLAGS, "-DTSDE_PRODUCT=1", *extra, "-c", src, "-o", obj], stdout=subprocess.PIPE,
-                                            stderr=subprocess.STDOUT)))
+        jobs.append((src, [HIPCC, *FLAGS, "-DTSDE_PRODUCT=1", *extra, "-c", src, "-o", obj]))
         if name in ALT_SOURCES:                              # the same unit with the alternative forms compiled in
             alt = os.path.join(CSRC, name[:-4] + ".alt.o")
             alt_objs.append(alt)
-            procs.append((src, subprocess.Popen([HIPCC, *FLAGS, *extra, "-c", src, "-o", alt], stdout=subprocess.PIPE,
-                                                stderr=subprocess.STDOUT)))
+            jobs.append((src, [HIPCC, *FLAGS, *extra, "-c", src, "-o", alt]))
         else:
             alt_objs.append(obj)
-        if strict:                                           # every unit again with the bf16x6 split
-            sobj = os.path.join(CSRC, name[:-4] + ".s24.o")
-            strict_objs.append(sobj)
-            # (without the per-file options: the bf16x6 recurrence pins nothing in the accumulation registers, and this compiler
-            #  crashes on its fp32 matrix instructions under -amdgpu-mfma-vgpr-form)
-            procs.append((src, subprocess.Popen([HIPCC, *FLAGS, "-DTSDE_SPLIT_H3=0", "-DTSDE_PRODUCT=1", "-c", src, "-o", sobj],
-                                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+    for out in _run_all(jobs):
         if verbose and out.strip():
             print(out.decode())
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
     os.makedirs(os.path.dirname(ALT_LIB), exist_ok=True)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", ALT_LIB, *alt_objs])
-    if strict:
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", STRICT_LIB, *strict_objs])
     if verbose:
-        print(f"built {LIB}\nbuilt {ALT_LIB}" + (f"\nbuilt {STRICT_LIB}" if strict else ""))
+        print(f"built {LIB}\nbuilt {ALT_LIB}")
+    if _want_strict():
+        build_strict(force=True, verbose=verbose)
     return LIB
 
 
@@ -129,16 +166,12 @@ def build_sanitized(out_lib: str, obj_dir: str) -> str:
     without a GPU.  Load it in a process started with LD_PRELOAD=<asan_runtime()>."""
     os.makedirs(obj_dir, exist_ok=True)
     san = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-shared-libsan"]
-    procs, objs = [], []
+    jobs, objs = [], []
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".san.o")
         objs.append(obj)
-        procs.append((src, subprocess.Popen([HIPCC, *FLAGS, "-DTSDE_PRODUCT=1", *san, "-c", src, "-o", obj], stdout=subprocess.PIPE,
-                                            stderr=subprocess.STDOUT)))
-    for src, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError(f"hipcc (sanitized) failed on {src}:\n{out.decode()[-3000:]}")
+        jobs.append((src, [HIPCC, *FLAGS, "-DTSDE_PRODUCT=1", *san, "-c", src, "-o", obj]))
+    _run_all(jobs, "hipcc (sanitized)")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *san, "-o", out_lib, *objs])
     return out_lib
 
@@ -158,3 +191,5 @@ def asan_runtime() -> str:
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--strict" in sys.argv or "--all" in sys.argv:
+        build_strict(force="--force" in sys.argv)

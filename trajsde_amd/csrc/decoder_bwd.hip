@@ -1640,16 +1640,25 @@ static int decoder_backward_impl(bool nll, float eps, float min_scale, int32_t N
   static_assert(SweepV::SIZE == SDE_SWEEP_V_FLOATS && SweepV::DV4 == 0 && SweepV::DC4 == 64, "recur.hip k_sde_bwd_coop writes this row");
 #if TSDE_SPLIT_H3
   // the cooperative form (recur.hip k_sde_bwd_coop: four waves a tile); TRAJSDE_SWEEP_COOP=0: the one-wave kernel of this file
-  static const bool sweep_coop = []() { const char* e = getenv("TRAJSDE_SWEEP_COOP"); return !(e && e[0] == '0'); }();
+  static const bool sweep_coop_env = []() { const char* e = getenv("TRAJSDE_SWEEP_COOP"); return !(e && e[0] == '0'); }();
+  bool sweep_coop = sweep_coop_env;
 #else
-  const bool sweep_coop = false;
+  bool sweep_coop = false;
 #endif
-  const int sweep_rows = sweep_coop ? (ntiles < 8192 ? ntiles : 8192) : sweep_grid * waves;
+  // (the cooperative kernel writes one SweepV row per workgroup: when vpart_slab() falls back to the workspace's shared slab -- no
+  //  deferred sums active, or the arena full -- that slab bounds the rows; and its tables live in dynamic LDS, so a schedule too long
+  //  for it takes the one-wave kernel, whose tables stay in global memory)
+  constexpr int64_t SHARED_VPART_FLOATS = int64_t(256) * (BWD_THREADS / 64) * 512;       // DecBwdWs: w.vpart
+  constexpr int64_t SWEEP_ROWS_MAX = SHARED_VPART_FLOATS / SweepV::SIZE < 8192 ? SHARED_VPART_FLOATS / SweepV::SIZE : 8192;
+  const int64_t coop_lds = int64_t(SDE_BWD_COOP_LDS_BYTES) + int64_t(8 * n_euler + 4 * T) * 4;
+  if (sweep_coop && coop_lds > 150 * 1024) sweep_coop = false;
+  const int sweep_rows = sweep_coop ? int(ntiles < SWEEP_ROWS_MAX ? ntiles : SWEEP_ROWS_MAX) : sweep_grid * waves;
+  TS_REQUIRE(int64_t(sweep_rows) * SweepV::SIZE <= SHARED_VPART_FLOATS, "decoder backward: the sweep's partial rows exceed the shared slab");
   vp = vpart_slab(w.vpart, sweep_rows, SweepV::SIZE);
   if (sweep_coop) {
     const SdeBwdCoopArgs ca{blob_bwd + DecBwdBlob::SWEEP, w.best, N, K, T, n_euler, step_table, out_table, na, w.H1, w.H2, w.G1, w.G2, w.GS,
                             w.DS, w.DH1, w.DH2, w.DF, w.DG1, w.DG2, w.DY0, vp};
-    TS_LAUNCH_TAG("k_sde_bwd", false, k_sde_bwd_coop, sweep_rows, 256, SDE_BWD_COOP_LDS_BYTES + (8 * n_euler + 4 * T) * 4, st, ca);
+    TS_LAUNCH_TAG("k_sde_bwd", false, k_sde_bwd_coop, sweep_rows, 256, int(coop_lds), st, ca);
   } else {
     TS_LAUNCH(k_sde_bwd, sweep_grid, BWD_THREADS, SweepL::SIZE * 4, st, blob_bwd + DecBwdBlob::SWEEP, w.best, N, K, T, n_euler, step_table,
               out_table, na, w.H1, w.H2, w.G1, w.G2, w.GS, w.DS, w.DH1, w.DH2, w.DF, w.DG1, w.DG2, w.DY0, vp);

@@ -106,6 +106,16 @@ class nuArgoDataset(torch.utils.data.Dataset):
     def __getitem__(self, idx: int) -> TemporalData:
         return self.get(idx)
 
+    def scene_costs(self) -> List[float]:
+        """what a scene costs a training step, from the shards' pointer tables alone: n^2 (the agent-agent candidate pairs of every
+        history step and the fully connected global graph both grow with it: SURVEY.md 8(e)) + its lane segments.  Read by
+        SceneLoader(balance="cost")."""
+        out: List[float] = []
+        for st in self.stores:
+            n, lanes = st.extents("x"), st.extents("lane_vectors")
+            out += [float(a) * float(a) + float(b) for a, b in zip(n, lanes)]
+        return out
+
     def _raw(self, idx: int) -> Dict[str, object]:
         which = 0 if idx < self._starts[1] else 1
         return self.stores[which].scene(idx - self._starts[which])
@@ -175,20 +185,48 @@ class SceneLoader:
     on a side stream one batch ahead of the consumer."""
 
     def __init__(self, dataset, batch_size: int, shuffle: bool = False, device: Optional[str] = None,
-                 rank: int = 0, world_size: int = 1, seed: int = 0, drop_last: bool = False, even: bool = True):
+                 rank: int = 0, world_size: int = 1, seed: int = 0, drop_last: bool = False, even: bool = True,
+                 balance: str = "round_robin"):
         """`even` (default): every rank gets the same number of scenes -- the order is padded by wrapping around to a
         multiple of world_size, like torch's DistributedSampler that Lightning installs for the reference (train.py:54) --
         so that every rank runs the same number of steps and the per-step gradient all-reduce cannot be left waiting.
-        Evaluation loaders pass even=False: no per-step collective there, and no scene is counted twice in the metrics."""
+        Evaluation loaders pass even=False: no per-step collective there, and no scene is counted twice in the metrics.
+
+        `balance`: "round_robin" (default: rank r takes every world_size-th scene of the order -- the DistributedSampler rule the
+        reference trains under) or "cost": the SAME scenes per step, dealt so that the ranks' work is level.  A step's cost grows
+        with the sum of n^2 over its scenes, and every step ends in a gradient all-reduce that waits for the heaviest rank; with
+        "cost" the world_size * batch_size scenes of a step are dealt greedily, heaviest first, to the rank with the least work so
+        far that still has a free slot (LPT with equal scene counts).  Same steps per rank, same scenes per step as round-robin:
+        the averaged gradient of a step is over the same scenes, only who computes which changes."""
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
         self.device = torch.device(device) if device is not None else None
         self.rank, self.world_size, self.seed, self.drop_last, self.even = rank, world_size, seed, drop_last, even
+        if balance not in ("round_robin", "cost"):
+            raise ValueError(f"SceneLoader: balance must be 'round_robin' or 'cost', not {balance!r}")
+        self.balance = balance
+        self._costs: Optional[List[float]] = None
         self.epoch = 0
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = epoch
 
-    def scene_ids(self) -> List[int]:
+    def scene_costs(self) -> List[float]:
+        """cost of every scene of the dataset (cached): the dataset's own `scene_costs()` where it has one (nuArgoDataset reads
+        the shard index), else n^2 + lane segments from the scenes themselves, loaded once"""
+        if self._costs is None:
+            if hasattr(self.dataset, "scene_costs"):
+                self._costs = [float(c) for c in self.dataset.scene_costs()]
+            else:
+                def one(sc):
+                    n = int(sc["x"].shape[0])
+                    lv = sc["lane_vectors"] if "lane_vectors" in sc else None
+                    return float(n * n + (int(lv.shape[0]) if lv is not None else 0))
+                self._costs = [one(self.dataset[i]) for i in range(len(self.dataset))]
+            if len(self._costs) != len(self.dataset):
+                raise ValueError("scene_costs(): one cost per scene expected")
+        return self._costs
+
+    def _order(self) -> List[int]:
         n = len(self.dataset)
         if self.shuffle:
             g = torch.Generator().manual_seed(self.seed + self.epoch)
@@ -198,7 +236,30 @@ class SceneLoader:
         if self.even and self.world_size > 1 and n % self.world_size:
             pad = self.world_size - n % self.world_size
             order += (order * (pad // max(n, 1) + 1))[:pad]
-        return order[self.rank::self.world_size]
+        return order
+
+    def scene_ids(self) -> List[int]:
+        order, W = self._order(), self.world_size
+        if self.balance != "cost" or W == 1:
+            return order[self.rank::W]
+        cost, mine = self.scene_costs(), []
+        per_step = W * self.batch_size
+        for lo in range(0, len(order), per_step):
+            group = order[lo:lo + per_step]
+            cap = [len(group) // W + (1 if r < len(group) % W else 0) for r in range(W)]     # what round-robin would hand out
+            load, taken = [0.0] * W, [[] for _ in range(W)]
+            # heaviest first; ties by position, so that every rank computes the same deal
+            for pos in sorted(range(len(group)), key=lambda p: (-cost[group[p]], p)):
+                r = min((r for r in range(W) if len(taken[r]) < cap[r]), key=lambda r: (load[r], r))
+                taken[r].append(pos)
+                load[r] += cost[group[pos]]
+            mine += [group[p] for p in sorted(taken[self.rank])]
+        return mine
+
+    def step_costs(self) -> List[float]:
+        """this rank's cost of every step of the epoch (diagnostics, tests)"""
+        ids, cost = self.scene_ids(), self.scene_costs()
+        return [sum(cost[i] for i in ids[lo:lo + self.batch_size]) for lo in range(0, len(ids), self.batch_size)]
 
     def __len__(self) -> int:
         n = len(self.scene_ids())
@@ -275,7 +336,9 @@ class DataModuleNuArgoMix:
             self.test_dataset = mk("val", self.test_dataset_args)     # Datamodule_nuargo_mix.py:31
 
     def _loader(self, ds, bs, shuffle, even):
-        return SceneLoader(ds, bs, shuffle=shuffle, device=self.device, rank=self.rank, world_size=self.world_size, even=even)
+        # `balance` (YAML kwarg of the data module, default "round_robin"): SceneLoader's dealing rule for the train loader
+        return SceneLoader(ds, bs, shuffle=shuffle, device=self.device, rank=self.rank, world_size=self.world_size, even=even,
+                           balance=getattr(self, "balance", "round_robin") if even else "round_robin")
 
     def train_dataloader(self):
         return self._loader(self.train_dataset, self.train_batch_size, self.shuffle, True)     # equal step counts per rank

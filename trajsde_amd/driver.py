@@ -779,6 +779,8 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
+        from trajsde_amd.shard import pin_rank_to_cores
+        pin_rank_to_cores(local_rank)                        # this rank's share of the host cores, torch's pool capped to it
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -167,6 +167,11 @@ class RelPrefetch:
 
 _SYNC_FREE = os.environ.get("TRAJSDE_SYNC_FREE", "1") != "0"
 SYNC_FREE_MAX_BYTES = 4 << 30
+# ... and for the training loop's prefetched graphs: TWO batches are alive at once there and the bound-sized lists keep their size
+# after make_exact() (at 32 x 256 agents ~2 GB a batch where the exact build needs ~160 MB), so the prefetch path gets half the cap
+# -- at most 2 x 2 GB of the 288 GB reserved by it (the shipped training shapes need 0.3-1.0 GB) -- and beyond it takes the
+# synchronising form: its one host read then waits on the side stream, which is what the form was before round 5
+PREFETCH_SYNC_FREE_MAX_BYTES = 2 << 30
 
 
 def set_sync_free(on: bool) -> bool:
@@ -249,9 +254,9 @@ def prefetch_graph(data, radius: float, H: int, noise: "NoiseSpec", fake_agents:
     # The list lengths (the step's one host read-back) are NOT waited for here: the graph is built in its sync-free form -- lengths on
     # the device, lists sized by their bounds -- and made exact at the top of the step that uses it, by a read issued on THIS stream
     # (GraphContext.make_exact honours `count_stream`), which by then has long drained.  Waiting here cost the loop 0.3-0.7 ms a
-    # step: the side stream's few kernels share the chip with the step that was just enqueued.  Lists past SYNC_FREE_MAX_BYTES take
-    # the synchronising form as ever.
-    gc = GraphContext.get(data, radius, H, noise, fake_agents=fake_agents, exact=not sync_free())
+    # step: the side stream's few kernels share the chip with the step that was just enqueued.  Lists past
+    # PREFETCH_SYNC_FREE_MAX_BYTES (two batches are alive in this loop, and bound-sized lists keep their size) take the synchronising form.
+    gc = GraphContext.get(data, radius, H, noise, fake_agents=fake_agents, exact=not sync_free(), sync_free_cap=PREFETCH_SYNC_FREE_MAX_BYTES)
     gc.count_stream = side
     done = torch.cuda.Event()
     done.record(side)
@@ -441,6 +446,17 @@ class PackSet:
             self._items, self._tab_ids = items, tabs
         host, table, nbytes = self._tables
         with torch.cuda.device(dev):
+            # the images are re-packed IN PLACE: streams that read them since the last pack (StageRuntime.blob records them) may still
+            # have kernels queued on the old contents -- the pack waits for what they hold now
+            packing = torch.cuda.current_stream()
+            for rt, sid in self.entries:
+                for sid_, readers in list(rt._readers.items()):
+                    if sid_ != sid:
+                        continue
+                    for handle, stream in readers.items():
+                        if handle != packing.cuda_stream:
+                            packing.wait_stream(stream)
+                    readers.clear()
             _lib.check(L.trajsde_pack_weights_many(self._items, len(self.entries), host.data_ptr(), table.data_ptr(), nbytes, self._fresh,
                                                    _stream()), "trajsde_pack_weights_many")
             self._fresh = 0
@@ -462,6 +478,7 @@ class StageRuntime:
         self.stage = stage
         self.stage_id = self.STAGE_ID[stage]
         self._blobs: Dict[int, tuple] = {}          # stage id -> (blob, parameter stamp, pack-done event, packing stream)
+        self._readers: Dict[int, dict] = {}         # stage id -> {stream handle: stream} that read the image from another stream
         self._names: Dict[int, list] = {}
 
     # ---------------------------------------------------------------- weights
@@ -562,13 +579,16 @@ class StageRuntime:
                 ev.record(torch.cuda.current_stream())
             self._blobs[stage_id] = (blob, stamp, ev, torch.cuda.current_stream(first.device).cuda_stream)
         blob, stamp_, ev, packed_on = self._blobs[stage_id]
+        cur = torch.cuda.current_stream(first.device)
+        if cur.cuda_stream != packed_on:
+            # a reader on another stream (multi-stream inference, a validation stream beside the training loop): remembered, so that an
+            # IN-PLACE re-pack of this image (PackSet.refresh) is ordered behind what the stream still has queued on it
+            self._readers.setdefault(stage_id, {})[cur.cuda_stream] = cur
         if ev is not None:
             if ev.query():
                 self._blobs[stage_id] = (blob, stamp_, None, packed_on)        # pack finished: nothing left to order against
-            else:
-                cur = torch.cuda.current_stream(first.device)
-                if cur.cuda_stream != packed_on:
-                    cur.wait_event(ev)      # packed on another stream (multi-stream drivers): order the reads behind the pack
+            elif cur.cuda_stream != packed_on:
+                cur.wait_event(ev)          # packed on another stream (multi-stream drivers): order the reads behind the pack
         return blob
 
     def packs_complete(self) -> None:
@@ -1063,7 +1083,7 @@ class GraphContext:
     _DEVICE_KEY_TOKENS = itertools.count(1)
 
     def __init__(self, data, radius: float, H: int, noise: Optional[NoiseSpec], fake_agents: bool = True,
-                 exact: bool = True) -> None:
+                 exact: bool = True, sync_free_cap: Optional[int] = None) -> None:
         L = _lib.lib()
         self.fake_agents = fake_agents
         x = data["x"]
@@ -1119,7 +1139,8 @@ class GraphContext:
             b = self.batch
             # ... and the agent-agent list is allocated for the bound 2 H E (24 B per slot): past SYNC_FREE_MAX_BYTES the
             # one synchronisation is the better deal (8 scenes x 1024 agents would reserve 8 GB for 90 MB of edges)
-            if not exact and (2 * b.H * b.E >= 2 ** 31 - 2 or 24 * 2 * b.H * b.E > SYNC_FREE_MAX_BYTES):
+            cap = SYNC_FREE_MAX_BYTES if sync_free_cap is None else int(sync_free_cap)
+            if not exact and (2 * b.H * b.E >= 2 ** 31 - 2 or 24 * 2 * b.H * b.E > cap):
                 exact = True
             prepare = L.trajsde_graph_prepare if exact else L.trajsde_graph_prepare_async
             _lib.check(prepare(C.byref(self.batch), self.rot.data_ptr(), float(radius), C.byref(cn),
@@ -1195,7 +1216,7 @@ class GraphContext:
 
     @classmethod
     def get(cls, data, radius: Optional[float], H: int, noise: Optional[NoiseSpec], fake_agents: bool = True,
-            want_senders: bool = False, exact: Optional[bool] = True) -> "GraphContext":
+            want_senders: bool = False, exact: Optional[bool] = True, sync_free_cap: Optional[int] = None) -> "GraphContext":
         """`exact`: True -- the caller's entry point needs the list lengths on the host (training, backward, OOD, vanilla
         variant, captures); False -- build sync-free if a build is needed; None -- take whatever the encoder left."""
         gc = data[cls.KEY] if cls.KEY in data else None
@@ -1213,7 +1234,8 @@ class GraphContext:
         if gc is None or (key is not None and getattr(gc, "build_key", None) != key):
             # the encoder (which owns the radius and the fake-agent noise) builds; the aggregator and the backward
             # entry points of the same step (same noise) reuse
-            gc = cls(data, cls.DEFAULT_RADIUS if radius is None else radius, H, noise, fake_agents, exact=exact is not False)
+            gc = cls(data, cls.DEFAULT_RADIUS if radius is None else radius, H, noise, fake_agents, exact=exact is not False,
+                     sync_free_cap=sync_free_cap)
             gc.build_key = key
             data[cls.KEY] = gc
         if exact:

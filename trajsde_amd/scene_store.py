@@ -115,6 +115,14 @@ class SceneShard:
     def __len__(self) -> int:
         return self.num_scenes
 
+    def extents(self, key: str) -> List[int]:
+        """rows of the ragged field `key` per scene, from the shard's pointer table alone (no scene is materialised); zeros
+        for scenes that do not carry the field"""
+        ptr = self._ptr.get(key)
+        if ptr is None:
+            return [0] * self.num_scenes
+        return [ptr[i + 1] - ptr[i] for i in range(self.num_scenes)]
+
     @property
     def keys(self) -> List[str]:
         return list(self._data) + list(self._strings)
@@ -147,6 +155,9 @@ class SceneStore:
 
     def __len__(self) -> int:
         return self._starts[-1]
+
+    def extents(self, key: str) -> List[int]:
+        return [e for s in self.shards for e in s.extents(key)]
 
     def scene(self, i: int) -> Dict[str, object]:
         if not 0 <= i < len(self):
