@@ -1597,7 +1597,9 @@ __global__ __launch_bounds__(512) void k_ffn6(const float* __restrict__ img_g, c
 }
 
 // xn = norm1(x); NQ stacked projections of xn (AL: q; global layer: q, k_node, v_node)
-template <int NQ>
+// SPLITKV (round 6, gattn_h3.hip): the second and third projection (k_node, v_node of a global layer) leave as split-precision rows
+// -- fp16 hi[64] | fp16 lo[64], the same 256 bytes -- for the attention kernel that multiplies them on the fp16 matrix cores
+template <int NQ, bool SPLITKV>
 __global__ __launch_bounds__(512) void k_node_proj(const float* __restrict__ img_g, const float* __restrict__ x, int64_t R,
                                                    float* __restrict__ xn_out, float* __restrict__ p0, float* __restrict__ p1,
                                                    float* __restrict__ p2) {
@@ -1619,6 +1621,22 @@ __global__ __launch_bounds__(512) void k_node_proj(const float* __restrict__ img
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       f4 t4[4] = {pr[4 * j], pr[4 * j + 1], pr[4 * j + 2], pr[4 * j + 3]};
+#if TSDE_SPLIT_H3
+      if (SPLITKV && j > 0) {
+        if (row < R) {
+          char* o = reinterpret_cast<char*>(outs[j] + row * 64);
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt) {
+            unsigned h0, l0, h1, l1;
+            split_pair(t4[jt][0], t4[jt][1], h0, l0);
+            split_pair(t4[jt][2], t4[jt][3], h1, l1);
+            *reinterpret_cast<uint2*>(o + 32 * jt + 8 * L.g) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(o + 128 + 32 * jt + 8 * L.g) = uint2{l0, l1};
+          }
+        }
+        continue;
+      }
+#endif
       if (row < R) store_row(t4, outs[j], row, L.g);
     }
   }
@@ -1653,7 +1671,8 @@ template __global__ void k_global_edge<false>(const float*, const float*, const 
 template __global__ void k_global_edge<true>(const float*, const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, int64_t, float*, float*);
 template __global__ void k_node_update<false>(const float*, const float*, const float*, const float*, int64_t, float*, float*, DropArg, SegMerge);
 template __global__ void k_node_update<true>(const float*, const float*, const float*, const float*, int64_t, float*, float*, DropArg, SegMerge);
-template __global__ void k_node_proj<1>(const float*, const float*, int64_t, float*, float*, float*, float*);
-template __global__ void k_node_proj<3>(const float*, const float*, int64_t, float*, float*, float*, float*);
+template __global__ void k_node_proj<1, false>(const float*, const float*, int64_t, float*, float*, float*, float*);
+template __global__ void k_node_proj<3, false>(const float*, const float*, int64_t, float*, float*, float*, float*);
+template __global__ void k_node_proj<3, true>(const float*, const float*, int64_t, float*, float*, float*, float*);
 
 }  // namespace tsde

@@ -39,8 +39,6 @@ static unsigned long long* const g_stamps_gh3 = nullptr;
 #endif
 
 #if TSDE_SPLIT_H3
-constexpr int H3_KPITCH = 144;               // bytes per staged k_node row of one plane: 64 halves + 16 B (ds_read_b128 of 16 rows: distinct banks)
-constexpr int H3_KPLANE = 16 * H3_KPITCH;
 constexpr float H3_LAZY = 8.0f;              // the running maximum follows a tile's maximum only past this margin (gattn.hip)
 
 // (timing experiments only: -DTSDE_H3_EXP=1 every gathered node row is row (index & 3), =2 every rel row is one of the segment's first 4)
@@ -59,6 +57,14 @@ struct H3Rows {                              // what a lane brings for one tile,
 };
 typedef short s4v __attribute__((ext_vector_type(4)));
 
+// Second form (round 6, after the first one measured on par with the fp32-matrix kernel and the ablations said "latency, not pipes"):
+// the same products with the REGISTER budget of three waves per SIMD.  k_node / v_node rows arrive split like the rel rows (their
+// writer k_node_proj_split stores fp16 hi | lo), so no vector instruction splits anything but the 16 softmax weights of a tile; every
+// row kind takes the same road -- 16 B a lane from memory, ds_write_b128 into a swizzled LDS tile, fragment reads -- and holds registers
+// only while in flight: rel two tiles ahead in two sets, k / v one tile ahead in one set each (re-requested as soon as the set has been
+// parked).  The k tile and the v tile share one LDS region (k is read by the first product, v written behind it); the per-target
+// operand W1 lives in LDS as well (4 KB: columns 8 .. 15 of the logits mirror 0 .. 7, nothing reads them).
+constexpr int H3_WAVE_LDS = 4096 + 4096 + 4096 + (64 + 64 + 16) * 4;       // rel tile | k / v tile | W1 | q, node sums, head scalars
 #ifndef TSDE_H3_OCC
 #define TSDE_H3_OCC 2
 #endif
@@ -66,28 +72,28 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
                                                                      const int32_t* __restrict__ src, const float* __restrict__ rel,
                                                                      const float* __restrict__ q, const float* __restrict__ kn,
                                                                      const float* __restrict__ vn, int64_t N, float* __restrict__ agg) {
-  __shared__ __attribute__((aligned(16))) char reltile[4][16 * 256];        // [wave][row][16 chunks of 16 B, swizzled]
-  __shared__ __attribute__((aligned(16))) char kstage[4][2][H3_KPLANE];     // [wave][plane][16 rows]
-  __shared__ __attribute__((aligned(16))) float sbuf[4][8][64 + 4];
-  __shared__ __attribute__((aligned(16))) float qbuf[4][64];
-  __shared__ __attribute__((aligned(16))) float obuf[4][64];
-  __shared__ float hbuf[4][16];
+  __shared__ __attribute__((aligned(16))) char wave_lds[4][H3_WAVE_LDS];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nn = lane & 15, g = lane >> 4;
+  char* const rt = &wave_lds[wv][0];                         // [16 rows][16 chunks of 16 B]: chunk c of row r at position c ^ r
+  char* const kvt = rt + 4096;                               // the same image for the k_node rows, then for the v_node rows
+  char* const w1 = rt + 8192;                                // [k-step 4][piece 2][g 4][head 8][16 B]
+  float* const qbuf = reinterpret_cast<float*>(rt + 12288);
+  float* const obuf = qbuf + 64;
+  float* const hbuf = obuf + 64;
+  float (*const sbuf)[68] = reinterpret_cast<float (*)[68]>(rt);   // the epilogue's S_h rows: over the rel tile, which is free by then
   const int64_t node = xcd_block() * 4 + wv;                 // launched with xcd_grid(): a scene's targets share an L2
   const int64_t nc = node < N ? node : N - 1;
   const float* wke = img + GAttnL::WKE;
   const float* wve = img + GAttnL::WVE;
-  // ---- W1 as B operand: lane (head nn, g), step s, slot j = W1[32 s + 8 g + j][nn]; columns 8 .. 15 are zero
+  // ---- W1 as B operand: lane (head nn & 7, g), step s, slot j = W1[32 s + 8 g + j][head]
   const float ql = q[nc * 64 + lane] * INV_SQRT_DH;          // the logits' 1 / sqrt(dh) rides in the query
-  qbuf[wv][lane] = ql;
+  qbuf[lane] = ql;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  u4 b1h[4], b1l[4];
   {
     const int hh = nn & 7;
-    f4 qa = *reinterpret_cast<const f4*>(&qbuf[wv][8 * hh]), qb = *reinterpret_cast<const f4*>(&qbuf[wv][8 * hh + 4]);
-    if (nn >= 8) qa = qb = f4{0.f, 0.f, 0.f, 0.f};
+    const f4 qa = *reinterpret_cast<const f4*>(&qbuf[8 * hh]), qb = *reinterpret_cast<const f4*>(&qbuf[8 * hh + 4]);
     f4 w[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) w[s][0] = w[s][1] = f4{0.f, 0.f, 0.f, 0.f};
@@ -101,16 +107,23 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
         w[s][1] += *reinterpret_cast<const f4*>(row + 32 * s + 4) * qd;
       }
     }
-    split_kstep(w[0][0], w[0][1], b1h[0], b1l[0]);
-    split_kstep(w[1][0], w[1][1], b1h[1], b1l[1]);
+    u4 bh[4], bl[4];
+    split_kstep(w[0][0], w[0][1], bh[0], bl[0]);
+    split_kstep(w[1][0], w[1][1], bh[1], bl[1]);
     // k_node part: slot (s, g, j) is node feature d = 32 (s - 2) + 8 g + j, which belongs to head 4 (s - 2) + g
     const f4 z = f4{0.f, 0.f, 0.f, 0.f};
-    split_kstep(nn == g ? qa : z, nn == g ? qb : z, b1h[2], b1l[2]);
-    split_kstep(nn == 4 + g ? qa : z, nn == 4 + g ? qb : z, b1h[3], b1l[3]);
+    split_kstep(hh == g ? qa : z, hh == g ? qb : z, bh[2], bl[2]);
+    split_kstep(hh == 4 + g ? qa : z, hh == 4 + g ? qb : z, bh[3], bl[3]);
+    if (nn < 8) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        *reinterpret_cast<u4*>(w1 + (((2 * s + 0) * 4 + g) * 8 + hh) * 16) = bh[s];
+        *reinterpret_cast<u4*>(w1 + (((2 * s + 1) * 4 + g) * 8 + hh) * 16) = bl[s];
+      }
+    }
   }
+  const int w1off = (g * 8 + (nn & 7)) * 16;                 // + (2 s + piece) * 512
   const int beg = segptr[nc], end = node < N ? segptr[nc + 1] : beg;
-  char* const rt = &reltile[wv][0];
-  char* const ks = &kstage[wv][0][0];
   f4 O[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) O[c] = f4{0.f, 0.f, 0.f, 0.f};
@@ -138,73 +151,62 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
 #pragma unroll
     for (int j = 0; j < 4; ++j) R.x[j] = row4(rs_rel, H3_EXP_REL(min(o + j, lim) + 4 * g));
   };
-  auto fetch_kv = [&](H3Rows& K, H3Rows& V, const int (&sidx)[4]) {
+  auto fetch_rows = [&](H3Rows& X, __amdgpu_buffer_rsrc_t rs, const int (&sidx)[4]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) K.x[j] = row4(rs_kn, H3_EXP_NODE(sidx[j]));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) V.x[j] = row4(rs_vn, H3_EXP_NODE(sidx[j]));
+    for (int j = 0; j < 4; ++j) X.x[j] = row4(rs, H3_EXP_NODE(sidx[j]));
   };
-  // per-lane LDS addresses of the tile's fragments (bytes into the wave's rel tile)
-  int a1off[2][2];                                           // P1: [plane][k-step]: row nn, chunk 8 p + 4 s + g
+  auto park = [&](char* tile, const H3Rows& X) {             // rows 4g .. 4g+3, chunk nn -> position nn ^ row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * g + j;
+      *reinterpret_cast<f4*>(tile + r * 256 + 16 * (nn ^ r)) = X.x[j];
+    }
+  };
+  // per-lane LDS offsets of the fragments (bytes into a tile)
+  int a1off[2][2];                                           // A operand of P1: [piece][k-step]: row nn, chunk 8 p + 4 s + g
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int s = 0; s < 2; ++s) a1off[p][s] = nn * 256 + 16 * ((8 * p + 4 * s + g) ^ nn);
-  const int trow = 4 * g + (nn >> 2), tpp = nn & 3;           // P2: this lane addresses row trow, columns 4 tpp .. 4 tpp + 3 of a 16-column block
-  auto tile_step = [&](const H3Rows& RR, const H3Rows& KK, const H3Rows& VV, int e0) {
+  const int trow = 4 * g + (nn >> 2), tpp = nn & 3;           // B operand of P2: this lane addresses row trow, columns 4 tpp .. of a 16-column block
+  auto troff = [&](int piece, int cb) { return trow * 256 + 16 * ((8 * piece + 2 * cb + (tpp >> 1)) ^ trow) + 8 * (tpp & 1); };
+
+  H3Rows R[2], K, V;
+  int idx[2][4];
+  auto tile_at = [&](int i) { return beg + 16 * i; };
+  auto tile_step = [&](int i, int u) {                        // u = i & 1 (a constant after unrolling)
+    const int e0 = tile_at(i);
     __builtin_amdgcn_wave_barrier();                          // the previous tile's fragment reads are done (same wave, in order)
-#ifdef TSDE_STAMPS
-    clk.mark(0);                                              // [0] issuing the loads of the tiles ahead
-    {
-      f4 t0 = RR.x[0], t1 = RR.x[3], t2 = KK.x[0], t3 = KK.x[3];
-      asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
-    }
-    clk.mark(1);                                              // [1] waiting for this tile's rel / k_node rows
-#endif
-    // ---- rel rows -> the swizzled tile, as stored; k_node rows -> the stage, split here (an edge per row)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = 4 * g + j;
-      *reinterpret_cast<f4*>(rt + r * 256 + 16 * (nn ^ r)) = RR.x[j];
-      char* rowp = ks + r * H3_KPITCH + 8 * nn;
-      unsigned h0, l0, h1, l1;
-      split_pair(KK.x[j][0], KK.x[j][1], h0, l0);
-      split_pair(KK.x[j][2], KK.x[j][3], h1, l1);
-      *reinterpret_cast<uint2*>(rowp) = uint2{h0, h1};
-      *reinterpret_cast<uint2*>(rowp + H3_KPLANE) = uint2{l0, l1};
-    }
+    clk.mark(0);                                              // [0] loop overhead
+    park(rt, R[u]);
+    park(kvt, K);
+    clk.mark(1);                                              // [1] waiting for this tile's rel / k rows, parking them
+    fetch_rel(R[u], tile_at(i + 2));                          // into the set just parked: two tiles ahead
+    fetch_rows(K, rs_kn, idx[u ^ 1]);                         // the next tile's k rows (its indices came two steps ago)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    clk.mark(2);                                              // [2] stage writes (+ k_node split)
-    // ---- P1: the tile's logits, lane (head nn, g): edges 4g .. 4g+3.  Three chains, one per term of the split product (gattn.hip)
+    // ---- P1: the tile's logits, lane (head nn & 7, g): edges 4g .. 4g+3.  Three chains, one per term of the split product (gattn.hip)
     f4 lg;
     {
       f4 t0 = f4{0.f, 0.f, 0.f, 0.f}, t1 = t0, t2 = t0;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {                           // the rel half of K
-        const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(rt + a1off[0][s]));
-        const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(rt + a1off[1][s]));
-        const h8 bh = __builtin_bit_cast(h8, b1h[s]), bl = __builtin_bit_cast(h8, b1l[s]);
-        t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t0, 0, 0, 0);
-        t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, t1, 0, 0, 0);
-        t2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t2, 0, 0, 0);
-      }
-      const char* frag = ks + nn * H3_KPITCH + 16 * g;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {                           // the k_node half
-        const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(frag + 64 * s));
-        const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(frag + 64 * s + H3_KPLANE));
-        const h8 bh = __builtin_bit_cast(h8, b1h[2 + s]), bl = __builtin_bit_cast(h8, b1l[2 + s]);
+      for (int s = 0; s < 4; ++s) {                           // k-steps 0, 1: the rel half of K; 2, 3: the k_node half
+        const char* tile = s < 2 ? rt : kvt;
+        const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(tile + a1off[0][s & 1]));
+        const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(tile + a1off[1][s & 1]));
+        const h8 bh = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(w1 + (2 * s + 0) * 512 + w1off));
+        const h8 bl = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(w1 + (2 * s + 1) * 512 + w1off));
         t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t0, 0, 0, 0);
         t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, t1, 0, 0, 0);
         t2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t2, 0, 0, 0);
       }
       lg = t0 + (t1 + t2);
     }
-#ifdef TSDE_STAMPS
-    asm volatile("" : "+v"(lg));
-    clk.mark(3);                                              // [3] P1: fragment reads + 12 matrix instructions
-#endif
+    __builtin_amdgcn_wave_barrier();                          // the k fragments have been read: the region takes the v rows
+    clk.mark(2);                                              // [2] P1: fragment reads + 12 matrix instructions
+    park(kvt, V);
+    fetch_rows(V, rs_vn, idx[u ^ 1]);                         // the next tile's v rows ...
+    fetch_idx(idx[u ^ 1], tile_at(i + 3));                    // ... and the indices of the tile after the next two
     // ---- online softmax of this lane's head over the tile's 16 edges
     float cm = -INFINITY;
 #pragma unroll
@@ -232,106 +234,90 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
       ex[r] = fast_exp(lg[r] - m);                            // masked edges: exp(-inf) = 0
       spart += ex[r];
     }
-#ifdef TSDE_STAMPS
-    asm volatile("" : "+v"(ex));
-    clk.mark(4);                                              // [4] softmax
-#endif
-    // ---- P2 over the tile's 16 edges with K = 32 instructions (gattn.hip): B carries the rows' high pieces in slots 0..3 and their low
-    //      pieces in 4..7, A one piece of the weights in both halves
     unsigned eh0, el0, eh1, el1;
     split_pair(ex[0], ex[1], eh0, el0);
     split_pair(ex[2], ex[3], eh1, el1);
     const h8 a2h = __builtin_bit_cast(h8, u4{eh0, eh1, eh0, eh1}), a2l = __builtin_bit_cast(h8, u4{el0, el1, el0, el1});
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    clk.mark(3);                                              // [3] v rows parked, softmax, the weights' split
+    // ---- P2 over the tile's 16 edges with K = 32 instructions (gattn.hip): B carries the rows' high pieces in slots 0..3 and their low
+    //      pieces in 4..7 -- the transposing read hands lane i column 16 cb + i of the lane group's four rows --, A one piece of the weights
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {                          // rel columns 16 cb + nn, straight from the tile: the transposing read
-      const int idh = 2 * cb + (tpp >> 1), idl = 8 + idh;
-      const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) s4v*)(rt + trow * 256 + 16 * (idh ^ trow) + 8 * (tpp & 1)));
-      const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) s4v*)(rt + trow * 256 + 16 * (idl ^ trow) + 8 * (tpp & 1)));
+    for (int c = 0; c < 8; ++c) {
+      const char* tile = c < 4 ? rt : kvt;
+      const int cb = c & 3;
+      const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(tile + troff(0, cb)));
+      const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(tile + troff(1, cb)));
       const uint2 hw = __builtin_bit_cast(uint2, hi), lw = __builtin_bit_cast(uint2, lo);
       const h8 br = __builtin_bit_cast(h8, u4{hw.x, hw.y, lw.x, lw.y});
-      O[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h, br, O[cb], 0, 0, 0);
-      O[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2l, br, O[cb], 0, 0, 0);
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {                             // v_node columns 4 nn + c, split here (pairs of edges)
-      unsigned h0, l0, h1, l1;
-      split_pair(VV.x[0][c], VV.x[1][c], h0, l0);
-      split_pair(VV.x[2][c], VV.x[3][c], h1, l1);
-      const h8 bv = __builtin_bit_cast(h8, u4{h0, h1, l0, l1});
-      O[4 + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h, bv, O[4 + c], 0, 0, 0);
-      O[4 + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2l, bv, O[4 + c], 0, 0, 0);
+      O[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h, br, O[c], 0, 0, 0);
+      O[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2l, br, O[c], 0, 0, 0);
     }
 #ifdef TSDE_STAMPS
     asm volatile("" : "+v"(O[0]), "+v"(O[7]));
-    clk.mark(5);                                              // [5] P2: transposing reads, v split, 16 matrix instructions
+    clk.mark(4);                                              // [4] P2: 16 transposing reads, 16 matrix instructions
     ++units;
 #endif
   };
-  // The pipeline of gattn.hip: rel rows two tiles ahead (the HBM stream: three register sets), k_node / v_node rows one tile ahead (gathers
-  // that mostly hit the L2: two sets), source indices of tile i + 3.  Every fetch is UNCONDITIONAL (offsets clamp to the segment's last row)
-  // so that the compiler's counted waits stay counted.
-  H3Rows R[3], K[2], V[2];
-  int idx[2][4];
-  auto tile_at = [&](int i) { return beg + 16 * i; };
+  // Every fetch is UNCONDITIONAL (offsets clamp to the segment's last row) so that the compiler's counted waits stay counted.
   if (beg < end) {
     fetch_idx(idx[0], tile_at(0));
     fetch_idx(idx[1], tile_at(1));
     fetch_rel(R[0], tile_at(0));
     fetch_rel(R[1], tile_at(1));
-    fetch_kv(K[0], V[0], idx[0]);
+    fetch_rows(K, rs_kn, idx[0]);
+    fetch_rows(V, rs_vn, idx[0]);
     fetch_idx(idx[0], tile_at(2));
-    for (int i0 = 0; tile_at(i0) < end; i0 += 6) {
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int i = i0 + u;
-        fetch_rel(R[(u + 2) % 3], tile_at(i + 2));
-        fetch_kv(K[(u + 1) % 2], V[(u + 1) % 2], idx[(u + 1) % 2]);
-        fetch_idx(idx[(u + 1) % 2], tile_at(i + 3));
-        if (tile_at(i) < end) tile_step(R[u % 3], K[u % 2], V[u % 2], tile_at(i));
-      }
+    for (int i0 = 0; tile_at(i0) < end; i0 += 2) {
+      tile_step(i0, 0);
+      if (tile_at(i0 + 1) < end) tile_step(i0 + 1, 1);
+      else break;
     }
   }
-  clk.mark(6);
+  clk.mark(5);
+  __builtin_amdgcn_wave_barrier();                            // the last tile's reads of the rel tile are done: sbuf takes its place
   // ---- per target: normalise, lin_v_edge on the aggregated rel rows, store
-  const float s = row_sum(spart);                             // lanes (head nn, every g): the head's sum
+  const float s = row_sum(spart);                             // lanes (head nn & 7, every g): the head's sum
   const float inv = 1.0f / (s + 1e-16f);                      // PyG softmax denominator
   if (g == 0 && nn < 8) {
-    hbuf[wv][nn] = inv;
-    hbuf[wv][8 + nn] = s * inv;
+    hbuf[nn] = inv;
+    hbuf[8 + nn] = s * inv;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if (g < 2) {                                                // S_h[16 cb + nn] of the heads 4g + r -> sbuf, normalised
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float iv = hbuf[wv][4 * g + r];
+      const float iv = hbuf[4 * g + r];
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) sbuf[wv][4 * g + r][16 * cb + nn] = O[cb][r] * iv;
+      for (int cb = 0; cb < 4; ++cb) sbuf[4 * g + r][16 * cb + nn] = O[cb][r] * iv;
     }
   }
-  if (g == (nn >> 3)) {                                       // sum_e alpha v_node of node features 4 nn + c: head nn >> 1
-    const int r = (nn >> 1) & 3;
-    f4 o;
+  // sum_e alpha v_node of node feature f = 16 cb + nn: head f >> 3 = 2 cb + (nn >> 3), held by lane group (f >> 3) >> 2, register (f >> 3) & 3
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = r == 0 ? O[4 + c][0] : (r == 1 ? O[4 + c][1] : (r == 2 ? O[4 + c][2] : O[4 + c][3]));
-    *reinterpret_cast<f4*>(&obuf[wv][4 * nn]) = o * hbuf[wv][nn >> 1];
+  for (int cb = 0; cb < 4; ++cb) {
+    const int head = 2 * cb + (nn >> 3);
+    if (g == (head >> 2)) {
+      const int r = head & 3;
+      const float o = r == 0 ? O[4 + cb][0] : (r == 1 ? O[4 + cb][1] : (r == 2 ? O[4 + cb][2] : O[4 + cb][3]));
+      obuf[16 * cb + nn] = o * hbuf[head];
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int h = lane >> 3;
-  float out = fmaf(img[GAttnL::BVE + lane], hbuf[wv][8 + h], obuf[wv][lane]);
+  float out = fmaf(img[GAttnL::BVE + lane], hbuf[8 + h], obuf[lane]);
 #pragma unroll
   for (int k4 = 0; k4 < 16; ++k4) {
     const f4 wr = *reinterpret_cast<const f4*>(wve + lane * 64 + 4 * k4);
-    const f4 sv = *reinterpret_cast<const f4*>(&sbuf[wv][h][4 * k4]);
+    const f4 sv = *reinterpret_cast<const f4*>(&sbuf[h][4 * k4]);
 #pragma unroll
     for (int e = 0; e < 4; ++e) out = fmaf(wr[e], sv[e], out);
   }
   if (node < N) agg[node * 64 + lane] = out;
 #ifdef TSDE_STAMPS
-  clk.mark(7);                                                // [7] the per-target epilogue ([6]: loop overhead)
+  clk.mark(6);                                                // [6] the per-target epilogue ([5]: loop exit)
   if (lane == 0) clk.flush(g_stamps_gh3, units);
 #endif
 }

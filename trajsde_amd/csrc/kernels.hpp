@@ -164,7 +164,7 @@ __global__ void k_node_update(const float* img, const float* agg, const float* x
                               SegMerge mg);
 __global__ void k_ffn6(const float* img, const float* x1, const float* xn2, int64_t R, float* out, DropArg drop);
 __global__ void k_ffn(const float* img, const float* x1, const float* xn2, int64_t R, float* out, DropArg drop, int out_bf16);
-template <int NQ>
+template <int NQ, bool SPLITKV = false>
 __global__ void k_node_proj(const float* img, const float* x, int64_t R, float* xn_out, float* p0, float* p1, float* p2);
 __global__ void k_mode_proj(const float* norm_g, const float* proj_g, const float* x, int64_t N, float* out);
 

@@ -539,8 +539,12 @@ static int aggregator_forward_impl(const trajsde_batch* b, const trajsde_graph* 
   float* bufs[2] = {w.xa, w.xb};
   for (int i = 0; i < num_layers; ++i) {
     const float* lb = blob + AggBlob::layer(i);
-    TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
-              w.xn, w.q, w.kn, w.vn);
+    if (split)                                               // k_node / v_node rows leave split like the rel rows (gattn_h3.hip)
+      TS_LAUNCH((k_node_proj<3, true>), tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
+                w.xn, w.q, w.kn, w.vn);
+    else
+      TS_LAUNCH(k_node_proj<3>, tile_grid(ntiles, 512, NodeProjL<3>::SIZE * 4), 512, NodeProjL<3>::SIZE * 4, st, lb + AggLayerL::QKV, x, N,
+                w.xn, w.q, w.kn, w.vn);
     float* out = bufs[i & 1];
     const NodeImgs im{lb + AggLayerL::UPD, lb + AggLayerL::FFN, lb + AggLayerL::UPD6, lb + AggLayerL::FFN6};
     const bool fused = global_fused_env() || num_heads != 8;           // the unfused edge kernel exists for 8 heads only
