@@ -441,6 +441,35 @@ def _random_graph_cases(count, seed):
     return cases
 
 
+@pytest.mark.gpu
+def test_scene_cached_global_attention_leaves_large_scenes_to_the_gathering_kernel(dev, tmp_path):
+    """TRAJSDE_REL_SPLIT=2 (gattn_h3.hip k_global_attn_sc): a scene's k_node / v_node rows are parked in LDS, which holds 256 actors;
+    a batch that mixes a 20-actor scene with a 270-actor one must come out the same -- the large scene's targets are taken by the
+    gathering kernel launched beside it -- as the default forward"""
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import sys, torch; sys.path[:0] = [%r, %r]\n"
+        "import helpers as H\n"
+        "from trajsde_amd.data import collate\n"
+        "from trajsde_amd.runtime import NoiseSpec\n"
+        "from trajsde_amd.synth import synth\n"
+        "m, cfg = H.build_model(6, 20, 2.0, init_seed=2)\n"
+        "b = collate([synth(S=1, n=20, L=8, F=20, box=90.0, seed=9), synth(S=1, n=270, L=8, F=20, box=200.0, seed=10),\n"
+        "             synth(S=1, n=33, L=8, F=20, box=90.0, seed=11)])\n"
+        "o = m.to('cuda')(b.to('cuda'), noise=NoiseSpec(seed=6))\n"
+        "torch.save({k: v.cpu() for k, v in o.items()}, sys.argv[1])\n") % (H.ROOT, os.path.join(H.ROOT, "tests"))
+    outs = {}
+    for mode, env in (("default", {}), ("scene_cache", {"TRAJSDE_REL_SPLIT": "2"}), ("split", {"TRAJSDE_REL_SPLIT": "1"})):
+        path = str(tmp_path / (mode + ".pt"))
+        subprocess.run([sys.executable, "-c", script, path], check=True, env={**os.environ, **env}, timeout=600)
+        outs[mode] = torch.load(path)
+    for key in ("loc", "pi", "diff_in", "diff_out"):
+        assert H.maxdiff(outs["default"][key], outs["scene_cache"][key]) <= 2e-5, key
+        assert H.maxdiff(outs["default"][key], outs["split"][key]) <= 2e-5, key
+
+
 @pytest.mark.parametrize("S,n,L,box,edges,seed,kw", _random_graph_cases(24, 11))
 def test_graph_stage_on_randomised_shapes_equals_the_oracle_lists(S, n, L, box, edges, seed, kw, dev):
     """the graph stage (rewritten in round 5: seven launches) over a seeded sweep of shapes: the three compacted lists equal the
@@ -604,6 +633,7 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
                       ("gattn_mm", {"TRAJSDE_GATTN_MM": "1"}),
                       ("gattn_vector", {"TRAJSDE_GATTN_F32MM": "0"}),
                       ("rel_split", {"TRAJSDE_REL_SPLIT": "1"}),
+                      ("rel_split_scene_cache", {"TRAJSDE_REL_SPLIT": "2"}),
                       ("gattn_two_tiles", {"TRAJSDE_GMF_TILES": "2"}),
                       ("pipelined", {"TRAJSDE_EDGE_PIPE": "1"}),
                       ("tile32", {"TRAJSDE_EDGE_TILE": "32"}),
@@ -633,6 +663,8 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
         assert H.maxdiff(outs["split"][key], outs["gattn_vector"][key]) <= 2e-5, key
         # ... against the fp16x3 form on rel rows that their writer stored as split operand pieces (gattn_h3.hip: round 6, product library)
         assert H.maxdiff(outs["split"][key], outs["rel_split"][key]) <= 2e-5, key
+        # ... and its scene-cached form (k_global_attn_sc: a scene's k_node / v_node rows resident in LDS)
+        assert H.maxdiff(outs["split"][key], outs["rel_split_scene_cache"][key]) <= 2e-5, key
         # ... and against its 32-edges-a-step form (k_global_attn_mf2: two tiles of a target through every phase together)
         assert H.maxdiff(outs["split"][key], outs["gattn_two_tiles"][key]) <= 2e-5, key
         assert torch.equal(outs["split"][key], outs["pipelined"][key]), key              # k_edge_attn2p: the tiles one stage apart, the same bits

@@ -1,0 +1,82 @@
+// relstream.hip -- what the chip delivers to the global attention's rel-row stream with the compute removed.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/microbench/relstream tools/microbench/relstream.hip && tools/microbench/relstream
+// 8192 segments of 255 rows x 256 B (535 MB, the rel rows of 32 scenes x 256 agents), read once per launch:
+//   mode 0   every wave grid-strides over the whole buffer, 16 B a lane (the ideal stream)
+//   mode 1   one wave per segment, its 16-row tiles in order: 4 loads (4 KB) per tile, DEPTH tiles requested ahead of the one consumed
+//            (the consumer: a dependent add into a register -- no LDS, no matrix work), WAVES waves per workgroup, OCC workgroups per CU
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_ideal(const f4* __restrict__ p, size_t n4, float* out) {
+  f4 acc = f4{0, 0, 0, 0};
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += size_t(gridDim.x) * blockDim.x) acc += p[i];
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = 1.f;
+}
+
+// OCC workgroups per CU, enforced by LDS: each workgroup declares 160 KB / OCC (minus a margin) and touches it
+template <int DEPTH, int THREADS, int OCC>
+__global__ __launch_bounds__(THREADS) void k_seg(const float* __restrict__ rel, int nseg, int rows, float* out) {
+  __shared__ float pad[(160 * 1024 / OCC - 2048) / 4];
+  if (rows < 0) pad[threadIdx.x] = 1.f;                       // (never: keeps the array)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nn = lane & 15, g = lane >> 4;
+  const int seg = blockIdx.x * (THREADS / 64) + wv;
+  if (seg >= nseg) return;
+  const float* base = rel + size_t(seg) * rows * 64;
+  const int ntiles = (rows + 15) / 16;
+  f4 R[DEPTH][4];
+  auto fetch = [&](f4 (&r)[4], int t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int row = 16 * t + 4 * g + j;
+      row = row < rows ? row : rows - 1;
+      r[j] = *reinterpret_cast<const f4*>(base + size_t(row) * 64 + 4 * nn);
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) fetch(R[d], d);
+  f4 acc = f4{0, 0, 0, 0};
+  for (int t0 = 0; t0 < ntiles; t0 += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      if (t0 + d < ntiles) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += R[d][j];
+        fetch(R[d], t0 + d + DEPTH < ntiles ? t0 + d + DEPTH : ntiles - 1);
+      }
+    }
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = pad[lane];
+}
+
+template <class F>
+static double time_ms(F f, int reps = 20) {
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  f(); f();
+  hipEventRecord(a);
+  for (int i = 0; i < reps; ++i) f();
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  return ms / reps;
+}
+
+int main() {
+  const int nseg = 8192, rows = 255;
+  const size_t bytes = size_t(nseg) * rows * 256;
+  float *rel, *out;
+  hipMalloc(&rel, bytes); hipMalloc(&out, 16);
+  hipMemset(rel, 0x3c, bytes);
+  printf("# %zu MB in %d segments of %d rows\n", bytes >> 20, nseg, rows);
+  double ms = time_ms([&] { k_ideal<<<256 * 8, 256>>>(reinterpret_cast<const f4*>(rel), bytes / 16, out); });
+  printf("ideal grid-stride stream                         %7.1f us  %5.2f TB/s\n", ms * 1e3, bytes / ms / 1e9);
+#define SEG(D, T, O) ms = time_ms([&] { k_seg<D, T, O><<<(nseg + T / 64 - 1) / (T / 64), T>>>(rel, nseg, rows, out); }); \
+  printf("wave per segment, depth %d, %d waves/WG, %d WG/CU   %7.1f us  %5.2f TB/s\n", D, T / 64, O, ms * 1e3, bytes / ms / 1e9);
+  SEG(1, 256, 2) SEG(2, 256, 2) SEG(3, 256, 2) SEG(4, 256, 2) SEG(8, 256, 2)
+  SEG(1, 256, 3) SEG(2, 256, 3) SEG(4, 256, 3)
+  SEG(1, 256, 4) SEG(2, 256, 4) SEG(4, 256, 4) SEG(2, 256, 8)
+  SEG(2, 512, 1) SEG(4, 512, 1)
+  return 0;
+}

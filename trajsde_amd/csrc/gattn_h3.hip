@@ -71,7 +71,9 @@ constexpr int H3_WAVE_LDS = 4096 + 4096 + 4096 + (64 + 64 + 16) * 4;       // re
 __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                                      const int32_t* __restrict__ src, const float* __restrict__ rel,
                                                                      const float* __restrict__ q, const float* __restrict__ kn,
-                                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ agg) {
+                                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ agg,
+                                                                     const int64_t* __restrict__ scene_of, const int32_t* __restrict__ scene_ptr,
+                                                                     int skip_cap) {
   __shared__ __attribute__((aligned(16))) char wave_lds[4][H3_WAVE_LDS];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nn = lane & 15, g = lane >> 4;
@@ -84,6 +86,10 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
   float (*const sbuf)[68] = reinterpret_cast<float (*)[68]>(rt);   // the epilogue's S_h rows: over the rel tile, which is free by then
   const int64_t node = xcd_block() * 4 + wv;                 // launched with xcd_grid(): a scene's targets share an L2
   const int64_t nc = node < N ? node : N - 1;
+  if (scene_of != nullptr) {                                 // beside k_global_attn_sc: only the targets of scenes too large for its cache
+    const int sc = int(scene_of[nc]);
+    if (scene_ptr[sc + 1] - scene_ptr[sc] <= skip_cap) return;   // (uniform per wave)
+  }
   const float* wke = img + GAttnL::WKE;
   const float* wve = img + GAttnL::WVE;
   // ---- W1 as B operand: lane (head nn & 7, g), step s, slot j = W1[32 s + 8 g + j][head]
@@ -171,31 +177,44 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
   const int trow = 4 * g + (nn >> 2), tpp = nn & 3;           // B operand of P2: this lane addresses row trow, columns 4 tpp .. of a 16-column block
   auto troff = [&](int piece, int cb) { return trow * 256 + 16 * ((8 * piece + 2 * cb + (tpp >> 1)) ^ trow) + 8 * (tpp & 1); };
 
-  H3Rows R[2], K, V;
+#ifndef TSDE_H3_PF
+#define TSDE_H3_PF 2
+#endif
+  constexpr int PF = TSDE_H3_PF;                              // tiles the rel rows travel ahead of their use (register sets)
+  H3Rows R[PF], K, V;
   int idx[2][4];
   auto tile_at = [&](int i) { return beg + 16 * i; };
-  auto tile_step = [&](int i, int u) {                        // u = i & 1 (a constant after unrolling)
+  auto tile_step = [&](int i, auto U_, auto V_) {             // u = i % PF, v = i & 1: compile-time (the register sets must stay registers)
+    constexpr int u = decltype(U_)::value, v = decltype(V_)::value;
     const int e0 = tile_at(i);
     __builtin_amdgcn_wave_barrier();                          // the previous tile's fragment reads are done (same wave, in order)
     clk.mark(0);                                              // [0] loop overhead
     park(rt, R[u]);
     park(kvt, K);
     clk.mark(1);                                              // [1] waiting for this tile's rel / k rows, parking them
-    fetch_rel(R[u], tile_at(i + 2));                          // into the set just parked: two tiles ahead
-    fetch_rows(K, rs_kn, idx[u ^ 1]);                         // the next tile's k rows (its indices came two steps ago)
+    fetch_rel(R[u], tile_at(i + PF));                         // into the set just parked: PF tiles ahead
+    fetch_rows(K, rs_kn, idx[v ^ 1]);                         // the next tile's k rows (its indices came two steps ago)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- P1: the tile's logits, lane (head nn & 7, g): edges 4g .. 4g+3.  Three chains, one per term of the split product (gattn.hip)
     f4 lg;
     {
       f4 t0 = f4{0.f, 0.f, 0.f, 0.f}, t1 = t0, t2 = t0;
+      // (every fragment of the product requested before its first matrix instruction: see k_global_attn_sc)
+      u4 fa[4][2], fb[4][2];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {                           // k-steps 0, 1: the rel half of K; 2, 3: the k_node half
         const char* tile = s < 2 ? rt : kvt;
-        const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(tile + a1off[0][s & 1]));
-        const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(tile + a1off[1][s & 1]));
-        const h8 bh = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(w1 + (2 * s + 0) * 512 + w1off));
-        const h8 bl = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(w1 + (2 * s + 1) * 512 + w1off));
+        fa[s][0] = *reinterpret_cast<const u4*>(tile + a1off[0][s & 1]);
+        fa[s][1] = *reinterpret_cast<const u4*>(tile + a1off[1][s & 1]);
+        fb[s][0] = *reinterpret_cast<const u4*>(w1 + (2 * s + 0) * 512 + w1off);
+        fb[s][1] = *reinterpret_cast<const u4*>(w1 + (2 * s + 1) * 512 + w1off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const h8 ah = __builtin_bit_cast(h8, fa[s][0]), al = __builtin_bit_cast(h8, fa[s][1]);
+        const h8 bh = __builtin_bit_cast(h8, fb[s][0]), bl = __builtin_bit_cast(h8, fb[s][1]);
         t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t0, 0, 0, 0);
         t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, t1, 0, 0, 0);
         t2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t2, 0, 0, 0);
@@ -205,8 +224,8 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
     __builtin_amdgcn_wave_barrier();                          // the k fragments have been read: the region takes the v rows
     clk.mark(2);                                              // [2] P1: fragment reads + 12 matrix instructions
     park(kvt, V);
-    fetch_rows(V, rs_vn, idx[u ^ 1]);                         // the next tile's v rows ...
-    fetch_idx(idx[u ^ 1], tile_at(i + 3));                    // ... and the indices of the tile after the next two
+    fetch_rows(V, rs_vn, idx[v ^ 1]);                         // the next tile's v rows ...
+    fetch_idx(idx[v ^ 1], tile_at(i + 3));                    // ... and the indices of the tile after the next two
     // ---- online softmax of this lane's head over the tile's 16 edges
     float cm = -INFINITY;
 #pragma unroll
@@ -243,16 +262,24 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
     clk.mark(3);                                              // [3] v rows parked, softmax, the weights' split
     // ---- P2 over the tile's 16 edges with K = 32 instructions (gattn.hip): B carries the rows' high pieces in slots 0..3 and their low
     //      pieces in 4..7 -- the transposing read hands lane i column 16 cb + i of the lane group's four rows --, A one piece of the weights
+    s4v fh[8], fl[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const char* tile = c < 4 ? rt : kvt;
       const int cb = c & 3;
-      const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(tile + troff(0, cb)));
-      const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(tile + troff(1, cb)));
-      const uint2 hw = __builtin_bit_cast(uint2, hi), lw = __builtin_bit_cast(uint2, lo);
-      const h8 br = __builtin_bit_cast(h8, u4{hw.x, hw.y, lw.x, lw.y});
-      O[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h, br, O[c], 0, 0, 0);
-      O[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2l, br, O[c], 0, 0, 0);
+      fh[c] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(tile + troff(0, cb)));
+      fl[c] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(tile + troff(1, cb)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint2 hw = __builtin_bit_cast(uint2, fh[c]), lw = __builtin_bit_cast(uint2, fl[c]);
+      O[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h, __builtin_bit_cast(h8, u4{hw.x, hw.y, lw.x, lw.y}), O[c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint2 hw = __builtin_bit_cast(uint2, fh[c]), lw = __builtin_bit_cast(uint2, fl[c]);
+      O[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2l, __builtin_bit_cast(h8, u4{hw.x, hw.y, lw.x, lw.y}), O[c], 0, 0, 0);
     }
 #ifdef TSDE_STAMPS
     asm volatile("" : "+v"(O[0]), "+v"(O[7]));
@@ -264,15 +291,22 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
   if (beg < end) {
     fetch_idx(idx[0], tile_at(0));
     fetch_idx(idx[1], tile_at(1));
-    fetch_rel(R[0], tile_at(0));
-    fetch_rel(R[1], tile_at(1));
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch_rel(R[u], tile_at(u));
     fetch_rows(K, rs_kn, idx[0]);
     fetch_rows(V, rs_vn, idx[0]);
     fetch_idx(idx[0], tile_at(2));
-    for (int i0 = 0; tile_at(i0) < end; i0 += 2) {
-      tile_step(i0, 0);
-      if (tile_at(i0 + 1) < end) tile_step(i0 + 1, 1);
-      else break;
+    constexpr int UN = (PF % 2 == 0) ? PF : 2 * PF;           // a trip of the loop: every set index a compile-time constant
+    for (int i0 = 0; tile_at(i0) < end; i0 += UN) {
+      bool done = false;
+      static_for_<UN>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        if (!done) {
+          if (tile_at(i0 + j) < end) tile_step(i0 + j, std::integral_constant<int, j % PF>{}, std::integral_constant<int, (j & 1)>{});
+          else done = true;
+        }
+      });
+      if (done) break;
     }
   }
   clk.mark(5);
@@ -322,22 +356,398 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
 #endif
 }
 
-// OFF by default -- measured (profiles/r06_ab_runs.md, 32 x 256 agents, one box): 170.7 us a layer against 168.2 us for the fp32-matrix
-// kernel (gattn_f32.hip) plus 5 us for the writer's split epilogue.  With a matrix part 5x shorter (28 x 16 cycles instead of 32 x 32)
-// and no vector instruction on a rel value the time does not move: neither pipe bounds this kernel.  What does, by ablation
-// (-DTSDE_H3_EXP): every row served from the cache 128 us (memory: 26 %); the rest is the tile's dependent chain (stage -> product ->
-// softmax -> product, ~1 100 cycles of issue in ~4 000) at the two waves per SIMD that 256 registers allow.  TRAJSDE_REL_SPLIT=1 selects it.
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Third form (round 6): the node rows of a SCENE resident in LDS.  What the two forms above and the fp32-matrix kernel have in common
+// is 12 KB through the CU per 16 edges -- 4 KB of rel rows that are genuinely streamed and 8 KB of gathered k_node / v_node rows that the
+// 255 other targets of the scene gather as well (every edge of the global graph joins two actors of one scene: AGG:41, the collated
+// `edge_index` of complete per-scene graphs) -- through L1, the registers and an LDS tile: ~450 of the ~500 CU cycles a tile takes.
+// Here a workgroup owns up to 32 consecutive targets of ONE scene and parks that scene's k_node / v_node rows (split, swizzled: 512 B a
+// node, 128 KB for 256 nodes) once; a tile's key fragments and the transposed value fragments are then read straight from the cache at
+// the rows its source indices name, and only the rel rows travel.  8 waves, two per SIMD: 160 KB = cache + eight 4 KB rel tiles, the
+// per-target scratch (query, head scalars, S rows) aliases a wave's rel tile outside its tile loop, W1 stays in registers.
+// Scenes with more than SC_CAP actors are left to k_global_attn_h3 (launched beside this kernel with the complementary guard).
+constexpr int SC_CAP = 256, SC_CH = 32, SC_WAVES = 8, SC_CHUNKS = SC_CAP / SC_CH;
+#ifndef TSDE_SC_SKIP
+#define TSDE_SC_SKIP 0          // timing experiments: 1 no first product, 2 no softmax, 4 no second product, 8 no parking (wrong results)
+#endif
+constexpr int SC_LDS_BYTES = SC_CAP * 512 + SC_WAVES * 4096;
+
+// scene_ptr[s] = first node of scene s (batch ids ascending, as collate builds them), scene_ptr[A] = N
+__global__ void k_scene_ptr(const int64_t* __restrict__ scene_of, int N, int A, int32_t* __restrict__ scene_ptr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > N) return;
+  const int64_t cur = i < N ? scene_of[i] : A, prev = i > 0 ? scene_of[i - 1] : -1;
+  for (int64_t sidx = prev + 1; sidx <= cur; ++sidx) scene_ptr[sidx] = i;      // (empty scenes, if any, get empty ranges)
+}
+
+__global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* __restrict__ img, const int32_t* __restrict__ segptr,
+                                                                  const int32_t* __restrict__ src, const float* __restrict__ rel,
+                                                                  const float* __restrict__ q, const float* __restrict__ kn,
+                                                                  const float* __restrict__ vn, int64_t N, int A,
+                                                                  const int32_t* __restrict__ scene_ptr, float* __restrict__ agg) {
+  extern __shared__ __attribute__((aligned(16))) char sc_lds[];
+  char* const kc = sc_lds;                                   // [node][16 chunks]: chunk c of node r at position c ^ (r & 15)
+  char* const vc = sc_lds + SC_CAP * 256;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nn = lane & 15, g = lane >> 4;
+  char* const rt = sc_lds + SC_CAP * 512 + wv * 4096;       // the wave's rel tile; outside the tile loop: its per-target scratch
+  float* const qbuf = reinterpret_cast<float*>(rt + 2304);
+  float* const obuf = qbuf + 64;
+  float* const hbuf = obuf + 64;
+  float (*const sbuf)[68] = reinterpret_cast<float (*)[68]>(rt);
+  const float* wke = img + GAttnL::WKE;
+  const float* wve = img + GAttnL::WVE;
+  const int n_units = A * SC_CHUNKS;
+  PhaseClock<8> clk;                                         // (diagnostic builds only: stamps.hpp; table shared with k_global_attn_h3)
+  clk.start();
+  unsigned long long units = 0;
+  (void)units;
+  for (int unit = int(xcd_block()); unit < n_units; unit += gridDim.x) {
+    const int sc = unit / SC_CHUNKS, chunk = unit % SC_CHUNKS;
+    const int ps = scene_ptr[sc], pe = scene_ptr[sc + 1], ns = pe - ps;
+    if (ns > SC_CAP || chunk * SC_CH >= ns) continue;        // (uniform) left to the gathering kernel / no such chunk
+    __syncthreads();                                         // the previous unit's readers of the cache are done
+    {
+      // the scene's rows -> the cache: thread i takes 16-byte chunk (i & 15) of row (i >> 4), eight requests in flight
+      const f4* ks = reinterpret_cast<const f4*>(kn + int64_t(ps) * 64);
+      const f4* vs = reinterpret_cast<const f4*>(vn + int64_t(ps) * 64);
+      const int total = ns * 16;
+      for (int i0 = threadIdx.x; i0 < total; i0 += 4 * blockDim.x) {
+        f4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * blockDim.x;
+          if (i < total) { a[u] = ks[i]; b[u] = vs[i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * blockDim.x;
+          if (i < total) {
+            const int r = i >> 4, c = i & 15, off = r * 256 + 16 * (c ^ (r & 15));
+            *reinterpret_cast<f4*>(kc + off) = a[u];
+            *reinterpret_cast<f4*>(vc + off) = b[u];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int t_end = min(ps + (chunk + 1) * SC_CH, pe);
+    for (int node = ps + chunk * SC_CH + wv; node < t_end; node += SC_WAVES) {
+      __builtin_amdgcn_wave_barrier();
+      // ---- W1 as B operand: lane (head nn & 7, g), step s, slot j = W1[32 s + 8 g + j][head]; columns 8 .. 15 mirror 0 .. 7 (never read)
+      const float ql = q[int64_t(node) * 64 + lane] * INV_SQRT_DH;
+      qbuf[lane] = ql;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      u4 b1h[4], b1l[4];
+      {
+        const int hh = nn & 7;
+        const f4 qa = *reinterpret_cast<const f4*>(&qbuf[8 * hh]), qb = *reinterpret_cast<const f4*>(&qbuf[8 * hh + 4]);
+        f4 w[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) w[s][0] = w[s][1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const float qd = d < 4 ? qa[d] : qb[d - 4];
+          const float* row = wke + (8 * hh + d) * 64 + 8 * g;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            w[s][0] += *reinterpret_cast<const f4*>(row + 32 * s) * qd;
+            w[s][1] += *reinterpret_cast<const f4*>(row + 32 * s + 4) * qd;
+          }
+        }
+        split_kstep(w[0][0], w[0][1], b1h[0], b1l[0]);
+        split_kstep(w[1][0], w[1][1], b1h[1], b1l[1]);
+        const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+        split_kstep(hh == g ? qa : z, hh == g ? qb : z, b1h[2], b1l[2]);
+        split_kstep(hh == 4 + g ? qa : z, hh == 4 + g ? qb : z, b1h[3], b1l[3]);
+      }
+      __builtin_amdgcn_wave_barrier();                        // qbuf has been read: the region is the rel tile again
+      const int beg = segptr[node], end = segptr[node + 1];
+      f4 O[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) O[c] = f4{0.f, 0.f, 0.f, 0.f};
+      float m = -INFINITY, spart = 0.f;
+      const __amdgpu_buffer_rsrc_t rs_rel = row_rsrc(rel + int64_t(beg) * 64);
+      const __amdgpu_buffer_rsrc_t rs_src = row_rsrc(reinterpret_cast<const float*>(src + beg));
+#if defined(TSDE_SC_EXP) && TSDE_SC_EXP == 1                   // (timing experiment: no tiles at all -- what a target costs by itself)
+      const int deg = 0;
+#elif defined(TSDE_SC_EXP) && TSDE_SC_EXP == 2                 // (timing experiment: one tile per target)
+      const int deg = min(end - beg, 16);
+#else
+      const int deg = end - beg;
+#endif
+      const int limR = deg - 1 - 4 * g;
+      auto fetch_rel = [&](H3Rows& R, int o) {               // o: the tile's first edge, relative to the segment
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          R.x[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_rel, (min(o + j, limR) + 4 * g) * 256 + 16 * nn, 0, 0));
+      };
+      // the cache rows a lane addresses: as an edge-on-a-lane reader (edge nn) and as a transposing reader (edge 4g + (nn >> 2))
+      auto fetch_src = [&](int& sa, int& st_, int o) {
+        sa = __builtin_amdgcn_raw_buffer_load_b32(rs_src, min(o + nn, deg - 1) * 4, 0, 0);
+        st_ = __builtin_amdgcn_raw_buffer_load_b32(rs_src, min(o + 4 * g + (nn >> 2), deg - 1) * 4, 0, 0);
+      };
+      int a1off[2][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) a1off[p][s] = nn * 256 + 16 * ((8 * p + 4 * s + g) ^ nn);
+      const int trow = 4 * g + (nn >> 2), tpp = nn & 3;
+#ifndef TSDE_SC_PF
+#define TSDE_SC_PF 2
+#endif
+      constexpr int SPF = TSDE_SC_PF;                         // tiles the rel rows (and the source indices) travel ahead
+      H3Rows R[SPF];
+      int sA[SPF], sT[SPF];
+      auto tile_step = [&](int i, auto U_) {
+        constexpr int u = decltype(U_)::value;
+        const int o = 16 * i;
+        __builtin_amdgcn_wave_barrier();                      // the previous tile's fragment reads are done (same wave, in order)
+        clk.mark(0);                                          // [0] loop overhead
+#ifdef TSDE_STAMPS
+        { f4 t0 = R[u].x[0], t1 = R[u].x[3]; int t2 = sA[u], t3 = sT[u]; asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3)); }
+        clk.mark(1);                                          // [1] waiting for this tile's rel rows / source indices
+#endif
+        if (TSDE_SC_SKIP & 8) {
+          f4 t = R[u].x[0] + R[u].x[1] + R[u].x[2] + R[u].x[3];
+          if (t[0] == 1234.5f) *reinterpret_cast<f4*>(rt) = t;
+        } else
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          *reinterpret_cast<f4*>(rt + r * 256 + 16 * (nn ^ r)) = R[u].x[j];
+        }
+        const int ra = sA[u] - ps, rv = sT[u] - ps;           // this tile's cache rows (scene-local)
+        fetch_rel(R[u], o + 16 * SPF);
+        fetch_src(sA[u], sT[u], o + 16 * SPF);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        clk.mark(2);                                          // [2] parking, requests of the tiles ahead
+        // ---- P1: the tile's logits, lane (head nn & 7, g): edges 4g .. 4g+3
+        // (ALL fragment reads of a product are requested before its first matrix instruction, and kept there by a scheduling fence:
+        //  left to itself the compiler reads a fragment, waits, multiplies, reads the next -- twenty LDS round trips in a row per tile,
+        //  ~3 500 of a tile's ~5 000 cycles at two waves per SIMD; this chain, not the memory system (tools/microbench/relstream.hip:
+        //  the same rel stream alone runs at 5.3 TB/s with eight waves per CU) and not either pipe, was the 165 us of every form)
+        f4 lg;
+        {
+          f4 t0 = f4{0.f, 0.f, 0.f, 0.f}, t1 = t0, t2 = t0;
+          const char* krow = kc + ra * 256;
+          const int rk = ra & 15;
+          u4 fa[4][2];
+          if (TSDE_SC_SKIP & 1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fa[s][0] = fa[s][1] = u4{unsigned(ra), unsigned(o), 0u, 0u};
+          } else
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            fa[s][0] = *reinterpret_cast<const u4*>(rt + a1off[0][s]);
+            fa[s][1] = *reinterpret_cast<const u4*>(rt + a1off[1][s]);
+            fa[2 + s][0] = *reinterpret_cast<const u4*>(krow + 16 * ((4 * s + g) ^ rk));
+            fa[2 + s][1] = *reinterpret_cast<const u4*>(krow + 16 * ((8 + 4 * s + g) ^ rk));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (TSDE_SC_SKIP & 1) {
+            t0 = __builtin_bit_cast(f4, fa[0][0]) + __builtin_bit_cast(f4, b1h[0]) + __builtin_bit_cast(f4, b1l[3]);
+          } else
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const h8 ah = __builtin_bit_cast(h8, fa[s][0]), al = __builtin_bit_cast(h8, fa[s][1]);
+            const h8 bh = __builtin_bit_cast(h8, b1h[s]), bl = __builtin_bit_cast(h8, b1l[s]);
+            t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, t1, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t2, 0, 0, 0);
+          }
+          lg = t0 + (t1 + t2);
+        }
+#ifdef TSDE_STAMPS
+        asm volatile("" : "+v"(lg));
+        clk.mark(3);                                          // [3] P1
+#endif
+        // ---- online softmax of this lane's head over the tile's 16 edges
+        float cm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (o + 4 * g + r >= deg) lg[r] = -INFINITY;
+          cm = fmaxf(cm, lg[r]);
+        }
+        if (!(TSDE_SC_SKIP & 2)) cm = row_max(cm);
+        if (!(TSDE_SC_SKIP & 2) && __builtin_amdgcn_ballot_w64(cm > m + H3_LAZY) != 0ull) {
+          const float mn = fmaxf(m, cm);
+          const float sc_ = fast_exp(m - mn);
+          m = mn;
+          spart *= sc_;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sr = __shfl(sc_, 4 * g + r);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) O[c][r] *= sr;
+          }
+        }
+        f4 ex;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ex[r] = fast_exp(lg[r] - m);
+          spart += ex[r];
+        }
+        unsigned eh0, el0, eh1, el1;
+        split_pair(ex[0], ex[1], eh0, el0);
+        split_pair(ex[2], ex[3], eh1, el1);
+        const h8 a2h = __builtin_bit_cast(h8, u4{eh0, eh1, eh0, eh1}), a2l = __builtin_bit_cast(h8, u4{el0, el1, el0, el1});
+#ifdef TSDE_STAMPS
+        asm volatile("" : "+v"(ex));
+        clk.mark(4);                                          // [4] softmax
+#endif
+        // ---- P2: rel columns from the tile, v_node columns from the cache, both by the transposing read
+        const char* vrow = vc + rv * 256;
+        const int rvk = rv & 15;
+        s4v fh[8], fl[8];
+        if (TSDE_SC_SKIP & 4) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) O[c] += ex * float(rv + c);
+        } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int cb = c & 3, idh = 2 * cb + (tpp >> 1);
+          const char* ph = c < 4 ? rt + trow * 256 + 16 * (idh ^ trow) : vrow + 16 * (idh ^ rvk);
+          const char* pl = c < 4 ? rt + trow * 256 + 16 * ((8 + idh) ^ trow) : vrow + 16 * ((8 + idh) ^ rvk);
+          fh[c] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ph + 8 * (tpp & 1)));
+          fl[c] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(pl + 8 * (tpp & 1)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (the two instructions on one accumulator are a chain: all eight first terms, then all eight second ones)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const uint2 hw = __builtin_bit_cast(uint2, fh[c]), lw = __builtin_bit_cast(uint2, fl[c]);
+          O[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h, __builtin_bit_cast(h8, u4{hw.x, hw.y, lw.x, lw.y}), O[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const uint2 hw = __builtin_bit_cast(uint2, fh[c]), lw = __builtin_bit_cast(uint2, fl[c]);
+          O[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2l, __builtin_bit_cast(h8, u4{hw.x, hw.y, lw.x, lw.y}), O[c], 0, 0, 0);
+        }
+        }
+#ifdef TSDE_STAMPS
+        asm volatile("" : "+v"(O[0]), "+v"(O[7]));
+        clk.mark(5);                                          // [5] P2
+        ++units;
+#endif
+      };
+      if (deg > 0) {
+#pragma unroll
+        for (int u = 0; u < SPF; ++u) {
+          fetch_rel(R[u], 16 * u);
+          fetch_src(sA[u], sT[u], 16 * u);
+        }
+        for (int i0 = 0; 16 * i0 < deg; i0 += SPF) {
+          bool done = false;
+          static_for_<SPF>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            if (!done) {
+              if (16 * (i0 + j) < deg) tile_step(i0 + j, J);
+              else done = true;
+            }
+          });
+          if (done) break;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                        // the last tile's reads are done: the region is scratch again
+      // ---- per target: normalise, lin_v_edge on the aggregated rel rows, store (k_global_attn_h3's epilogue)
+      const float ssum = row_sum(spart);
+      const float inv = 1.0f / (ssum + 1e-16f);
+      if (g == 0 && nn < 8) {
+        hbuf[nn] = inv;
+        hbuf[8 + nn] = ssum * inv;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (g < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float iv = hbuf[4 * g + r];
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) sbuf[4 * g + r][16 * cb + nn] = O[cb][r] * iv;
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const int head = 2 * cb + (nn >> 3);
+        if (g == (head >> 2)) {
+          const int r = head & 3;
+          const float o = r == 0 ? O[4 + cb][0] : (r == 1 ? O[4 + cb][1] : (r == 2 ? O[4 + cb][2] : O[4 + cb][3]));
+          obuf[16 * cb + nn] = o * hbuf[head];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int h = lane >> 3;
+      float out = fmaf(img[GAttnL::BVE + lane], hbuf[8 + h], obuf[lane]);
+#pragma unroll
+      for (int k4 = 0; k4 < 16; ++k4) {
+        const f4 wr = *reinterpret_cast<const f4*>(wve + lane * 64 + 4 * k4);
+        const f4 sv = *reinterpret_cast<const f4*>(&sbuf[h][4 * k4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out = fmaf(wr[e], sv[e], out);
+      }
+      agg[int64_t(node) * 64 + lane] = deg > 0 ? out : 0.f;
+      clk.mark(6);                                            // [6] per-target prologue + epilogue (and the unit's staging)
+    }
+  }
+#ifdef TSDE_STAMPS
+  if (lane == 0 && (wv == 0 || wv == 5)) clk.flush(g_stamps_gh3, units);
+#endif
+}
+
+// OFF by default.  Measured (profiles/r06_ab_runs.md, 32 x 256 agents, rocprofv3 kernel stats, one box):
+//   k_global_attn_mf (fp32 matrix instruction, the default)   164-165 us a layer
+//   k_global_attn_h3, first form (256 registers)              170.7
+//   k_global_attn_h3, this form, two / three waves per SIMD    158.8 / 180 (12 spilled registers)
+//   k_global_attn_sc (node rows of a scene resident in LDS)    183-186
+// plus 5 us for k_edge_embed2's split epilogue and 3 x 1.7 us for k_node_proj's: 486 against 495 us a forward for the best form, which is
+// not worth a second default path.  What the forms have in common, by ablation (-DTSDE_H3_EXP, -DTSDE_SC_SKIP, -DTSDE_SC_EXP;
+// tools/microbench/relstream.hip): the rel stream alone, one wave per target at eight waves per CU, needs 100 us (5.3 TB/s); a target's
+// own prologue / epilogue (W1 from Wke, the W_ve product: dependent global reads) 23 us a layer; and the tile's work -- first product 46,
+// second 18, softmax 7 us -- ADDS to that instead of hiding under it (sc with every phase skipped: 126 us; with all of them: 186).
+// Neither a 5x shorter matrix part, nor 128 fewer split values a lane and tile, nor a third wave per SIMD, nor the node rows out of an
+// LDS cache (12 KB -> 4 KB through L1 per tile), nor rel rows three or four tiles ahead, nor every fragment read issued before its
+// product's first matrix instruction moved the sum.  TRAJSDE_REL_SPLIT=1 selects this kernel, =2 the scene-cached one.
 bool rel_split_enabled() {
   static const bool v = []() { const char* e = getenv("TRAJSDE_REL_SPLIT"); return e && atoi(e) != 0; }();
   return v;
 }
 int launch_global_attn_h3(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
                           const float* vn, int64_t N, float* agg, hipStream_t st) {
-  TS_LAUNCH_TAG("k_global_attn<8>", false, k_global_attn_h3, xcd_grid(cdiv(N, 4)), 256, 0, st, img, segptr, src, rel, q, kn, vn, N, agg);
+  TS_LAUNCH_TAG("k_global_attn<8>", false, k_global_attn_h3, xcd_grid(cdiv(N, 4)), 256, 0, st, img, segptr, src, rel, q, kn, vn, N, agg,
+                static_cast<const int64_t*>(nullptr), static_cast<const int32_t*>(nullptr), 0);
+  return TRAJSDE_OK;
+}
+// TRAJSDE_REL_SPLIT=2: the scene-cached form, with the gathering form beside it for scenes beyond the cache
+bool rel_split_scene_cache() {
+  static const bool v = []() { const char* e = getenv("TRAJSDE_REL_SPLIT"); return e && atoi(e) == 2; }();
+  return v;
+}
+int launch_scene_ptr(const int64_t* scene_of, int N, int A, int32_t* scene_ptr, hipStream_t st) {
+  TS_LAUNCH(k_scene_ptr, cdiv(int64_t(N) + 1, 256), 256, 0, st, scene_of, N, A, scene_ptr);
+  return TRAJSDE_OK;
+}
+int launch_global_attn_sc(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
+                          const float* vn, int64_t N, int A, const int64_t* scene_of, const int32_t* scene_ptr, float* agg, hipStream_t st) {
+  const int units = A * SC_CHUNKS;
+  TS_LAUNCH_TAG("k_global_attn<8>", false, k_global_attn_sc, xcd_grid(units < 256 ? units : 256), 64 * SC_WAVES, SC_LDS_BYTES, st, img, segptr, src, rel,
+                q, kn, vn, N, A, scene_ptr, agg);
+  // the targets of scenes larger than the cache (none in the shipped configurations: the launch returns at its first branch)
+  TS_LAUNCH_TAG("k_global_attn<8>[big scenes]", false, k_global_attn_h3, xcd_grid(cdiv(N, 4)), 256, 0, st, img, segptr, src, rel, q, kn, vn, N, agg,
+                scene_of, scene_ptr, SC_CAP);
   return TRAJSDE_OK;
 }
 #else
 bool rel_split_enabled() { return false; }
+bool rel_split_scene_cache() { return false; }
+int launch_scene_ptr(const int64_t*, int, int, int32_t*, hipStream_t) { return fail(TRAJSDE_ERR_UNSUPPORTED, "fp16x3 build only"); }
+int launch_global_attn_sc(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, int64_t, int,
+                          const int64_t*, const int32_t*, float*, hipStream_t) {
+  return fail(TRAJSDE_ERR_UNSUPPORTED, "the split-image global attention exists in the fp16x3 build only");
+}
 int launch_global_attn_h3(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, int64_t, float*,
                           hipStream_t) {
   return fail(TRAJSDE_ERR_UNSUPPORTED, "the split-image global attention exists in the fp16x3 build only");
