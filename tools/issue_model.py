@@ -11,6 +11,10 @@ For every backward-branch loop of the kernel (or the N-th largest) it prints the
   pipe      SIMD cycles of the vector PIPE: 2 per full-rate instruction (two or more waves interleave them), 4 and 8 for the others;
   port      SIMD cycles of the shared issue port per wave: the vector pipe cycles above + `mfma-hold` cycles per matrix instruction
             (vissue "V wave beside an M wave": a 16x16x32 instruction takes ~5.2 cycles of its partner's issue).
+  pair      SIMD cycles of one iteration of BOTH waves of a two-wave SIMD as vissue's "both alternate 48 mfma / 192 V" mode runs them:
+            2 x matrix pipe + 2 x sum of what a vector instruction of each kind ADDS to the matrix pipe there ((alternate - 1536) / 384:
+            1.35 full-rate, 2.68 half-rate, 6.97 quarter-rate): two free-running waves that alternate matrix and vector phases overlap
+            that much and no more, whatever the kind -- the empirical floor of a two-wave kernel with this instruction mix.
 The matrix pipe itself (16 cycles per 16x16x32, 32 per 16x16x4 f32 / 32x32x16) is printed beside them: with W waves per SIMD a loop
 iteration of all W waves cannot take less than max(W * matrix pipe, W * port)."""
 import collections
@@ -101,6 +105,8 @@ def main():
         print(f"  lone wave, issue         {lone_v + pipe_m + other:8.0f}   (vector {lone_v:.0f} + matrix pipe {pipe_m} + LDS / memory issue {other:.0f})")
         print(f"  vector pipe (>= 2 waves) {pipe_v:8.0f}")
         print(f"  issue port (>= 2 waves)  {pipe_v + hold * cls['mfma'] + other:8.0f}   (vector pipe + {hold} x matrix + LDS / memory issue)")
+        add_v = 1.35 * cls["v2"] + 2.68 * cls["v4"] + 6.97 * cls["v8"] + 2.7 * cls["v16"]
+        print(f"  pair, alternating waves  {2 * pipe_m + 2 * add_v:8.0f}   (2 x matrix pipe {2 * pipe_m} + 2 x vector additions {add_v:.0f}; both waves of a two-wave SIMD)")
         top = sorted(ops.items(), key=lambda kv: -kv[1])[:28]
         print("  " + ", ".join(f"{n} {o}[{c}]" for (c, o), n in top))
 
