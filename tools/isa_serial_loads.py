@@ -3,7 +3,7 @@
     hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -DTSDE_NO_SLP=1 -std=c++17 --cuda-device-only -S -o /tmp/x.s trajsde_amd/csrc/x.hip
     python tools/isa_serial_loads.py /tmp/x.s [...]
 
-`for (i ..) dst[i] = f(src[i])` compiles to load, s_waitcnt vmcnt(0), use, branch (DESIGN.md section 5 "Round 5"): however independent the
+`for (i ..) dst[i] = f(src[i])` compiles to load, s_waitcnt vmcnt(0), use, branch (HISTORY.md section 5 "Round 5"): however independent the
 iterations are, each costs a round trip to L2 / HBM.  For every innermost backward-branch loop the scan reports the number of vector-memory
 loads in the body and the largest number of them requested before a `s_waitcnt vmcnt(n)` that waits for (nearly) all of them; loops with one or
 two loads in flight and no matrix instructions are listed first -- candidates for requesting a batch of loads before the first use."""

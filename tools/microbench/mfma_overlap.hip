@@ -1,7 +1,7 @@
 // v_mfma_f32_16x16x32_f16 with its destination ON TOP of SrcA (or SrcB): the register allocator does this for the second product of
 //   D1 = A x B1;   A <- A x B2 + D1
 // when registers are tight (csrc/node_bwd.hip k_edge_embed_bwd_tail at a 128-register cap is the only kernel of the library where it
-// happens -- and the one whose results were not reproducible).  Is the overlap safe on this hardware?
+// happens -- and the one whose results were not reproducible, HISTORY.md section 5 item 8).  Is the overlap safe on this hardware?
 //   hipcc --offload-arch=gfx950 -O3 mfma_overlap.hip -o mfma_overlap && ./mfma_overlap
 // Each variant: the pair above with a separate destination (reference) and with the overlap, all four result registers of all lanes compared,
 // 2 and 3 waves per SIMD all doing the same, 200 rounds per wave.

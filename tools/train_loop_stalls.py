@@ -3,7 +3,7 @@
 
     python tools/train_loop_stalls.py [--config config4] [--steps 400]
 
-Finding of round 5: no collection worth the name; the host runs ahead until a few thousand launches are in flight
+Finding of round 5 (HISTORY.md section 7 "Round 5"): no collection worth the name; the host runs ahead until a few thousand launches are in flight
 (2 200 ... 6 300 by run) and is then held for 11-16 ms at a time -- back-pressure, which costs nothing while the GPU has queued work."""
 import argparse
 import gc

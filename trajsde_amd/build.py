@@ -29,7 +29,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # (forward +-0, training step -2 %).  The mechanism is not pinned down: the simple hazards measure as the compiler assumes
 # (tools/microbench/mfma_war.hip: results readable 7 wait states behind the instruction, also by packed reads; operands free at once).
 # (It is also what lets the operand split compile to three instructions per pair: csrc/tile.hpp split_pair.)
-# Guards: tests/test_gpu_backward.py *_bitwise_identical, test_full_size_training_step_agrees_between_kernel_forms.  DESIGN.md section 5.
+# Guards: tests/test_gpu_backward.py *_bitwise_identical, test_full_size_training_step_agrees_between_kernel_forms.  HISTORY.md section 5.
 # -DTSDE_NO_SLP=1 ties the sources to the flag: csrc/tile.hpp refuses to compile without it, so no other build recipe
 # (a user's HIPCC line, an IDE, a future setup.py) can produce the library with the vectoriser on by accident.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-DTSDE_NO_SLP=1", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, TSDE_GA_OCC) void k_global_attn_mm(const float
 
 bool gattn_mm_enabled() {
   // OFF by default: measured at 32 x 256 agents it is on par with the lane-per-feature kernel, not ahead of it (0.177 against 0.167-0.170
-  // ms per layer; 0.144 with every rel row served from the cache) -- DESIGN.md section 5, round 4.  TRAJSDE_GATTN_MM=1 selects it.
+  // ms per layer; 0.144 with every rel row served from the cache) -- HISTORY.md section 5, round 4.  TRAJSDE_GATTN_MM=1 selects it.
   static const bool v = []() { const char* e = getenv("TRAJSDE_GATTN_MM"); return e && atoi(e) != 0; }();
   return v;
 }

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
 // MEASURED (32 x 256 agents, one box, alternating): 0.541-0.547 ms for the three layers against 0.525-0.530 for the one-tile form --
 // 3 % SLOWER at 256 registers.  Twice the edges per dependent chain buy nothing, so the chain is not what bounds the kernel either:
 // what remains is pipe time -- 32 fp32 matrix instructions of 32 cycles (1 024 cycles of the SIMD's matrix pipe) and ~290 vector
-// instructions (~1 300 cycles) per 16 edges and wave, served to two waves with little co-execution (DESIGN.md section 5 "Round 5").
+// instructions (~1 300 cycles) per 16 edges and wave, served to two waves with little co-execution (HISTORY.md section 5 "Round 5").
 constexpr int GMF2_PER_WAVE = 2 * 16 * GMF_TP + 32 * 8 + 32 * 8 + 64 + 64;
 constexpr int gmf2_lds_bytes() { return (GMF_WIMG + GMF_WV + GMF_WAVES * GMF2_PER_WAVE) * 4; }
 template <bool DROP>

@@ -31,7 +31,7 @@ static int fused_threads() {                 // TRAJSDE_FUSED_THREADS=256: one w
 static bool merge_in_update() { static const bool v = []() { const char* e = getenv("TRAJSDE_MERGE_KERNEL"); return !(e && atoi(e) != 0); }(); return v; }
 // TRAJSDE_EDGE_PIPE=1: the software-pipelined form of the fused edge attention (k_edge_attn2p: the wave's two tiles one stage apart,
 // vector work issued between the other tile's matrix instructions; bit-identical) for inference.  Measured slower than the lockstep
-// form (0.87 against 0.81 ms per launch; one wave per SIMD 1.12 against 0.98) -- DESIGN.md section 5 -- so it is an alternative.
+// form (0.87 against 0.81 ms per launch; one wave per SIMD 1.12 against 0.98) -- HISTORY.md section 5 -- so it is an alternative.
 static bool edge_pipe() { static const bool v = []() { const char* e = getenv("TRAJSDE_EDGE_PIPE"); return e && atoi(e) == 1; }(); return v; }
 static bool fused_one_tile() { static const bool v = []() { const char* e = getenv("TRAJSDE_FUSED_TILES"); return e && atoi(e) == 1; }(); return v; }
 static bool edge_pingpong() { static const bool v = []() { const char* e = getenv("TRAJSDE_EDGE_PINGPONG"); return e && atoi(e) != 0; }(); return v; }

@@ -42,7 +42,7 @@
 #define TSDE_R6_SPLIT 1
 #endif
 
-// Correctness guard (trajsde_amd/build.py): built with the SLP vectoriser on, identical launches of the
+// Correctness guard (HISTORY.md section 5 item 8, trajsde_amd/build.py): built with the SLP vectoriser on, identical launches of the
 // backward tile kernels disagree in their low-order bits.  The build passes -fno-slp-vectorize together with -DTSDE_NO_SLP=1; a
 // recipe that forgets the pair stops here instead of shipping a library whose results are not reproducible.
 #if !defined(TSDE_NO_SLP) || !TSDE_NO_SLP

@@ -137,7 +137,7 @@ def set_state_storage(kind: str) -> str:
 
 # Off by default: measured on the metric workload (32 x 256 agents) the one-stream forward gains 0.6 % (2.781 against 2.798 ms)
 # and the three-stream headline loses 1.2 % -- the recurrence's four waves per CU hold the whole register file of their SIMDs
-# (512 registers each), so the embedding kernel only finds room on the CUs the recurrence leaves empty.
+# (512 registers each), so the embedding kernel only finds room on the CUs the recurrence leaves empty (HISTORY.md section 5).
 _OVERLAP_REL = os.environ.get("TRAJSDE_OVERLAP_REL", "0") != "0"
 _SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
 
