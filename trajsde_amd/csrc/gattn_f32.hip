@@ -32,6 +32,9 @@ constexpr int GMF_WIMG = 4096, GMF_WV = 64 * GMF_TP;               // floats: Wk
 constexpr int GMF_PER_WAVE = 16 * GMF_TP + 16 * 8 + 16 * 8 + 64 + 64;   // staging tile (reused for S at the end) | node logits | weights | node sums | query
 constexpr int gmf_lds_bytes() { return (GMF_WIMG + GMF_WV + GMF_WAVES * GMF_PER_WAVE) * 4; }
 
+#ifndef TSDE_GMF_ORDER
+#define TSDE_GMF_ORDER 1         // 1: key / value rows in two register sets, requested in the order they are needed (k_global_attn_mf)
+#endif
 template <bool DROP>
 __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                                    const int32_t* __restrict__ src, const float* __restrict__ rel,
@@ -105,14 +108,24 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
       for (int r = 0; r < 4; ++r) dst[r] = *reinterpret_cast<const f4*>(base + int64_t(sidx[r]) * 64 + 4 * c16);
     };
     int s_next[4];
-    f4 nxa[4], nxb[4], kr[4], vr[4];                               // rel rows of the even / odd tiles: two tiles in flight per wave
+    f4 nxa[4], nxb[4];                                             // rel rows of the even / odd tiles: two tiles in flight per wave
+#if TSDE_GMF_ORDER
+    // (round 6) The memory counter is IN ORDER: a wait for a request also waits for everything requested before it.  With one set of key /
+    // value rows, re-requested where the set falls free (behind the rel rows of two tiles ahead), the waits for them pulled the rel
+    // look-ahead in.  Two sets each, the next tile's rows requested at the TOP of a tile and BEFORE the rel rows of two tiles ahead: every
+    // wait of a tile leaves the younger requests in flight.
+    f4 kra[4], vra[4], krb[4], vrb[4];
+#else
+    f4 kra[4], vra[4];
+    f4 (&krb)[4] = kra, (&vrb)[4] = vra;
+#endif
     {
       int s0[4];
       src_at(s0, beg);
       src_at(s_next, beg + 16);
       rel_load(nxa, beg);
-      row_load(kr, kn, s0);
-      row_load(vr, vn, s0);
+      row_load(kra, kn, s0);
+      row_load(vra, vn, s0);
       rel_load(nxb, beg + 16);
     }
     // B operand of the first product: lane (kk = q4, j = c16 < 8) holds U_j at rows 16 kk + s (columns 8-15 stay zero)
@@ -140,14 +153,18 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
     for (int b = 0; b < 4; ++b) R[b] = f4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, s = 0.f, sk = 0.f;                        // of head hd; s, sk: this lane's edges 4 q4 + i only
     clk.mark(7);                                                   // per-target prologue (and the previous target's epilogue)
-    auto tile_step = [&](f4 (&nx)[4], int e0) {
+    auto tile_step = [&](f4 (&nx)[4], f4 (&kr)[4], f4 (&vr)[4], f4 (&krn)[4], f4 (&vrn)[4], int e0) {
       ++tiles_done;
       int s_after[4];
       src_at(s_after, e0 + 32);
       __builtin_amdgcn_wave_barrier();                             // the previous readers of the wave's LDS are done (same wave, in order)
 #pragma unroll
       for (int r = 0; r < 4; ++r) *reinterpret_cast<f4*>(tile + (4 * q4 + r) * TP + 4 * c16) = nx[r];
-      rel_load(nx, e0 + 32);                                       // two tiles ahead, into the registers just staged
+#if TSDE_GMF_ORDER
+      row_load(krn, kn, s_next);                                   // the next tile's key and value rows, into the other set ...
+      row_load(vrn, vn, s_next);
+#endif
+      rel_load(nx, e0 + 32);                                       // ... then two tiles ahead, into the registers just staged
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       clk.mark(0);                                                 // wait for the tile's rel rows, stage them
@@ -175,7 +192,9 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
         p += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
         if ((c16 & 1) == 0) pnt[(4 * q4 + r) * 8 + (c16 >> 1)] = p;
       }
+#if !TSDE_GMF_ORDER
       row_load(kr, kn, s_next);
+#endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       clk.mark(2);                                                 // wait for the key rows, node logits
@@ -243,14 +262,16 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
       clk.mark(5);                                                 // second product
 #pragma unroll
       for (int r = 0; r < 4; ++r) accn += vr[r] * wt[(4 * q4 + r) * 8 + (c16 >> 1)];      // node part of the aggregate
+#if !TSDE_GMF_ORDER
       row_load(vr, vn, s_next);
+#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) s_next[r] = s_after[r];
       clk.mark(6);                                                 // wait for the value rows, node sums
     };
     for (int e0 = beg; e0 < end; e0 += 32) {
-      tile_step(nxa, e0);
-      if (e0 + 16 < end) tile_step(nxb, e0 + 16);
+      tile_step(nxa, kra, vra, krb, vrb, e0);
+      if (e0 + 16 < end) tile_step(nxb, krb, vrb, kra, vra, e0 + 16);
     }
     // ---- per target: S_h / (s_h + 1e-16) to LDS (the staging tile is free), node sums over the 16 edge lanes, lin_v_edge
     s = xor32_sum(xor16_sum(s));

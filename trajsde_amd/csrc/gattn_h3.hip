@@ -64,7 +64,11 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 // only while in flight: rel two tiles ahead in two sets, k / v one tile ahead in one set each (re-requested as soon as the set has been
 // parked).  The k tile and the v tile share one LDS region (k is read by the first product, v written behind it); the per-target
 // operand W1 lives in LDS as well (4 KB: columns 8 .. 15 of the logits mirror 0 .. 7, nothing reads them).
-constexpr int H3_WAVE_LDS = 4096 + 4096 + 4096 + (64 + 64 + 16) * 4;       // rel tile | k / v tile | W1 | q, node sums, head scalars
+#ifndef TSDE_H3_ORDER
+#define TSDE_H3_ORDER 1         // 1: k and v tiles of their own, a step's requests in the order they are needed (below); 0: the first order
+#endif
+constexpr int H3_KV_TILES = TSDE_H3_ORDER ? 2 : 1;
+constexpr int H3_WAVE_LDS = 4096 + 4096 * H3_KV_TILES + 4096 + (64 + 64 + 16) * 4;       // rel tile | k tile (| v tile) | W1 | q, node sums, head scalars
 #ifndef TSDE_H3_OCC
 #define TSDE_H3_OCC 2
 #endif
@@ -78,9 +82,10 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nn = lane & 15, g = lane >> 4;
   char* const rt = &wave_lds[wv][0];                         // [16 rows][16 chunks of 16 B]: chunk c of row r at position c ^ r
-  char* const kvt = rt + 4096;                               // the same image for the k_node rows, then for the v_node rows
-  char* const w1 = rt + 8192;                                // [k-step 4][piece 2][g 4][head 8][16 B]
-  float* const qbuf = reinterpret_cast<float*>(rt + 12288);
+  char* const kvt = rt + 4096;                               // the same image for the k_node rows, then (first order) for the v_node rows
+  char* const vt = rt + 4096 * H3_KV_TILES;                  // the v_node rows' tile (the k tile in the first order)
+  char* const w1 = vt + 4096;                                // [k-step 4][piece 2][g 4][head 8][16 B]
+  float* const qbuf = reinterpret_cast<float*>(w1 + 4096);
   float* const obuf = qbuf + 64;
   float* const hbuf = obuf + 64;
   float (*const sbuf)[68] = reinterpret_cast<float (*)[68]>(rt);   // the epilogue's S_h rows: over the rel tile, which is free by then
@@ -191,9 +196,23 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
     clk.mark(0);                                              // [0] loop overhead
     park(rt, R[u]);
     park(kvt, K);
+#if TSDE_H3_ORDER
+    // The memory counter is IN ORDER: a wait for a request also waits for everything requested before it.  In the first order the next
+    // tile's k rows were requested right behind the rel rows of PF tiles ahead and its v rows half a tile later, so the waits for them
+    // at the next tile pulled the whole rel look-ahead in: PF tiles of look-ahead behaved like one.  Here a step requests what is
+    // needed FIRST first -- next tile's k rows, its v rows, then the rel rows PF tiles ahead, then the indices three ahead -- so every
+    // wait leaves the younger requests in flight.  Costs a v tile of its own (the v rows are parked at the top, beside the k rows).
+    park(vt, V);
+    clk.mark(1);                                              // [1] waiting for this tile's rel / k / v rows, parking them
+    fetch_rows(K, rs_kn, idx[v ^ 1]);                         // the next tile's k and v rows (their indices came two steps ago)
+    fetch_rows(V, rs_vn, idx[v ^ 1]);
+    fetch_rel(R[u], tile_at(i + PF));                         // into the set just parked: PF tiles ahead
+    fetch_idx(idx[v ^ 1], tile_at(i + 3));                    // the indices of the tile after the next two
+#else
     clk.mark(1);                                              // [1] waiting for this tile's rel / k rows, parking them
     fetch_rel(R[u], tile_at(i + PF));                         // into the set just parked: PF tiles ahead
     fetch_rows(K, rs_kn, idx[v ^ 1]);                         // the next tile's k rows (its indices came two steps ago)
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- P1: the tile's logits, lane (head nn & 7, g): edges 4g .. 4g+3.  Three chains, one per term of the split product (gattn.hip)
@@ -223,9 +242,11 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
     }
     __builtin_amdgcn_wave_barrier();                          // the k fragments have been read: the region takes the v rows
     clk.mark(2);                                              // [2] P1: fragment reads + 12 matrix instructions
+#if !TSDE_H3_ORDER
     park(kvt, V);
     fetch_rows(V, rs_vn, idx[v ^ 1]);                         // the next tile's v rows ...
     fetch_idx(idx[v ^ 1], tile_at(i + 3));                    // ... and the indices of the tile after the next two
+#endif
     // ---- online softmax of this lane's head over the tile's 16 edges
     float cm = -INFINITY;
 #pragma unroll
@@ -265,7 +286,7 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
     s4v fh[8], fl[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const char* tile = c < 4 ? rt : kvt;
+      const char* tile = c < 4 ? rt : vt;
       const int cb = c & 3;
       fh[c] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(tile + troff(0, cb)));
       fl[c] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(tile + troff(1, cb)));
