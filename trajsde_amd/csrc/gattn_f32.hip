@@ -33,7 +33,7 @@ constexpr int GMF_PER_WAVE = 16 * GMF_TP + 16 * 8 + 16 * 8 + 64 + 64;   // stagi
 constexpr int gmf_lds_bytes() { return (GMF_WIMG + GMF_WV + GMF_WAVES * GMF_PER_WAVE) * 4; }
 
 #ifndef TSDE_GMF_ORDER
-#define TSDE_GMF_ORDER 1         // 1: key / value rows in two register sets, requested in the order they are needed (k_global_attn_mf)
+#define TSDE_GMF_ORDER 0         // 1: key / value rows in two register sets, requested in the order they are needed (measured: slower)
 #endif
 template <bool DROP>
 __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* __restrict__ img, const int32_t* __restrict__ segptr,
@@ -110,10 +110,11 @@ __global__ __launch_bounds__(64 * GMF_WAVES) void k_global_attn_mf(const float* 
     int s_next[4];
     f4 nxa[4], nxb[4];                                             // rel rows of the even / odd tiles: two tiles in flight per wave
 #if TSDE_GMF_ORDER
-    // (round 6) The memory counter is IN ORDER: a wait for a request also waits for everything requested before it.  With one set of key /
-    // value rows, re-requested where the set falls free (behind the rel rows of two tiles ahead), the waits for them pulled the rel
-    // look-ahead in.  Two sets each, the next tile's rows requested at the TOP of a tile and BEFORE the rel rows of two tiles ahead: every
-    // wait of a tile leaves the younger requests in flight.
+    // EXPERIMENT (round 6, -DTSDE_GMF_ORDER=1; measured, SLOWER: 168.8 / 169.8 us a layer against 165.1 / 165.6 on one box, 236 registers
+    // against 213).  The memory counter is in order: a wait for a request also waits for everything requested before it.  With one set of
+    // key / value rows, re-requested where the set falls free (behind the rel rows of two tiles ahead), the waits for them pull the rel
+    // look-ahead in.  Here: two sets each, the next tile's rows requested at the TOP of a tile and BEFORE the rel rows of two tiles ahead,
+    // so that every wait of a tile leaves the younger requests in flight.  It does not pay: the look-ahead is not what bounds the kernel.
     f4 kra[4], vra[4], krb[4], vrb[4];
 #else
     f4 kra[4], vra[4];

@@ -65,7 +65,7 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 // parked).  The k tile and the v tile share one LDS region (k is read by the first product, v written behind it); the per-target
 // operand W1 lives in LDS as well (4 KB: columns 8 .. 15 of the logits mirror 0 .. 7, nothing reads them).
 #ifndef TSDE_H3_ORDER
-#define TSDE_H3_ORDER 1         // 1: k and v tiles of their own, a step's requests in the order they are needed (below); 0: the first order
+#define TSDE_H3_ORDER 0         // 1: k and v tiles of their own, a step's requests in the order they are needed (below: measured, not faster); 0: the shipped order
 #endif
 constexpr int H3_KV_TILES = TSDE_H3_ORDER ? 2 : 1;
 constexpr int H3_WAVE_LDS = 4096 + 4096 * H3_KV_TILES + 4096 + (64 + 64 + 16) * 4;       // rel tile | k tile (| v tile) | W1 | q, node sums, head scalars
@@ -197,11 +197,13 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
     park(rt, R[u]);
     park(kvt, K);
 #if TSDE_H3_ORDER
-    // The memory counter is IN ORDER: a wait for a request also waits for everything requested before it.  In the first order the next
-    // tile's k rows were requested right behind the rel rows of PF tiles ahead and its v rows half a tile later, so the waits for them
-    // at the next tile pulled the whole rel look-ahead in: PF tiles of look-ahead behaved like one.  Here a step requests what is
-    // needed FIRST first -- next tile's k rows, its v rows, then the rel rows PF tiles ahead, then the indices three ahead -- so every
-    // wait leaves the younger requests in flight.  Costs a v tile of its own (the v rows are parked at the top, beside the k rows).
+    // EXPERIMENT (-DTSDE_H3_ORDER=1; measured, NOT faster).  The memory counter is in order: a wait for a request also waits for
+    // everything requested before it.  In the shipped order the next tile's k rows are requested right behind the rel rows of PF tiles
+    // ahead and its v rows half a tile later, so the waits for them at the next tile pull the rel look-ahead in.  Here a step requests
+    // what is needed FIRST first -- next tile's k rows, its v rows, then the rel rows PF tiles ahead, then the indices three ahead --
+    // so every wait leaves the younger requests in flight (costs a v tile of its own).  One box, alternating: 161.2 / 161.3 us a layer
+    // against 158.2 / 159.4 shipped; with PF = 3 / 4 on top 160.8-162.0 / 162.1-162.9.  So neither the depth nor the order of the
+    // look-ahead bounds this kernel: the hypothesis that the in-order counter is what stops the tile arithmetic from hiding is refuted.
     park(vt, V);
     clk.mark(1);                                              // [1] waiting for this tile's rel / k / v rows, parking them
     fetch_rows(K, rs_kn, idx[v ^ 1]);                         // the next tile's k and v rows (their indices came two steps ago)
