@@ -549,9 +549,9 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
         clk.mark(2);                                          // [2] parking, requests of the tiles ahead
         // ---- P1: the tile's logits, lane (head nn & 7, g): edges 4g .. 4g+3
         // (ALL fragment reads of a product are requested before its first matrix instruction, and kept there by a scheduling fence:
-        //  left to itself the compiler reads a fragment, waits, multiplies, reads the next -- twenty LDS round trips in a row per tile,
-        //  ~3 500 of a tile's ~5 000 cycles at two waves per SIMD; this chain, not the memory system (tools/microbench/relstream.hip:
-        //  the same rel stream alone runs at 5.3 TB/s with eight waves per CU) and not either pipe, was the 165 us of every form)
+        //  left to itself the compiler reads a fragment, waits, multiplies, reads the next -- twenty LDS round trips in a row per tile.
+        //  Measured: worth 1 % in k_global_attn_h3 (160.4 -> 158.8 us a layer), nothing here (183 -> 186): this kernel keeps W1 in
+        //  registers and spills ~106 of them at 256 with or without the fence -- one reason it is the slowest of the three forms.)
         f4 lg;
         {
           f4 t0 = f4{0.f, 0.f, 0.f, 0.f}, t1 = t0, t2 = t0;
