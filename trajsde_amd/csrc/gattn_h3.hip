@@ -42,6 +42,12 @@ static unsigned long long* const g_stamps_gh3 = nullptr;
 constexpr float H3_LAZY = 8.0f;              // the running maximum follows a tile's maximum only past this margin (gattn.hip)
 
 // (timing experiments only: -DTSDE_H3_EXP=1 every gathered node row is row (index & 3), =2 every rel row is one of the segment's first 4)
+// (=4: a tile's softmax and second product use the previous tile's logits: the dataflow of a software pipeline; =8: no scheduling fences)
+#if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 8)
+#define H3_FENCE() ((void)0)
+#else
+#define H3_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 1)
 #define H3_EXP_NODE(i) ((i) & 3)
 #else
@@ -188,6 +194,9 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
   constexpr int PF = TSDE_H3_PF;                              // tiles the rel rows travel ahead of their use (register sets)
   H3Rows R[PF], K, V;
   int idx[2][4];
+#if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 4)
+  f4 lg_prev = f4{0.f, 0.f, 0.f, 0.f};      // (timing experiment: a tile's softmax uses the PREVIOUS tile's logits -- the dataflow of a software pipeline)
+#endif
   auto tile_at = [&](int i) { return beg + 16 * i; };
   auto tile_step = [&](int i, auto U_, auto V_) {             // u = i % PF, v = i & 1: compile-time (the register sets must stay registers)
     constexpr int u = decltype(U_)::value, v = decltype(V_)::value;
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
         fb[s][0] = *reinterpret_cast<const u4*>(w1 + (2 * s + 0) * 512 + w1off);
         fb[s][1] = *reinterpret_cast<const u4*>(w1 + (2 * s + 1) * 512 + w1off);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      H3_FENCE();
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const h8 ah = __builtin_bit_cast(h8, fa[s][0]), al = __builtin_bit_cast(h8, fa[s][1]);
@@ -241,6 +250,9 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
         t2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t2, 0, 0, 0);
       }
       lg = t0 + (t1 + t2);
+#if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 4)
+      { const f4 tmp = lg; lg = lg_prev; lg_prev = tmp; }
+#endif
     }
     __builtin_amdgcn_wave_barrier();                          // the k fragments have been read: the region takes the v rows
     clk.mark(2);                                              // [2] P1: fragment reads + 12 matrix instructions
@@ -293,7 +305,7 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
       fh[c] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(tile + troff(0, cb)));
       fl[c] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(tile + troff(1, cb)));
     }
-    __builtin_amdgcn_sched_barrier(0);
+    H3_FENCE();
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const uint2 hw = __builtin_bit_cast(uint2, fh[c]), lw = __builtin_bit_cast(uint2, fl[c]);
