@@ -42,7 +42,8 @@ static unsigned long long* const g_stamps_gh3 = nullptr;
 constexpr float H3_LAZY = 8.0f;              // the running maximum follows a tile's maximum only past this margin (gattn.hip)
 
 // (timing experiments only: -DTSDE_H3_EXP=1 every gathered node row is row (index & 3), =2 every rel row is one of the segment's first 4)
-// (=4: a tile's softmax and second product use the previous tile's logits: the dataflow of a software pipeline; =8: no scheduling fences)
+// (=4: a tile's softmax and second product use the previous tile's logits: the dataflow of a software pipeline; =8: no scheduling fences;
+//  =16: one workgroup per CU, i.e. one wave per SIMD; =32: W1 fragments kept in registers (results right); =64: no k tile in LDS)
 #if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 8)
 #define H3_FENCE() ((void)0)
 #else
@@ -84,7 +85,11 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
                                                                      const float* __restrict__ vn, int64_t N, float* __restrict__ agg,
                                                                      const int64_t* __restrict__ scene_of, const int32_t* __restrict__ scene_ptr,
                                                                      int skip_cap) {
+#if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 16)              // (timing experiment: one workgroup per CU -- the LDS of a second one is taken)
+  __shared__ __attribute__((aligned(16))) char wave_lds[4][H3_WAVE_LDS + 12288];
+#else
   __shared__ __attribute__((aligned(16))) char wave_lds[4][H3_WAVE_LDS];
+#endif
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nn = lane & 15, g = lane >> 4;
   char* const rt = &wave_lds[wv][0];                         // [16 rows][16 chunks of 16 B]: chunk c of row r at position c ^ r
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
   qbuf[lane] = ql;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  u4 bh[4], bl[4];                                           // this lane's W1 fragments (what it reads back from `w1` below: lane nn computes those of head nn & 7)
   {
     const int hh = nn & 7;
     const f4 qa = *reinterpret_cast<const f4*>(&qbuf[8 * hh]), qb = *reinterpret_cast<const f4*>(&qbuf[8 * hh + 4]);
@@ -124,7 +130,6 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
         w[s][1] += *reinterpret_cast<const f4*>(row + 32 * s + 4) * qd;
       }
     }
-    u4 bh[4], bl[4];
     split_kstep(w[0][0], w[0][1], bh[0], bl[0]);
     split_kstep(w[1][0], w[1][1], bh[1], bl[1]);
     // k_node part: slot (s, g, j) is node feature d = 32 (s - 2) + 8 g + j, which belongs to head 4 (s - 2) + g
@@ -204,7 +209,11 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
     __builtin_amdgcn_wave_barrier();                          // the previous tile's fragment reads are done (same wave, in order)
     clk.mark(0);                                              // [0] loop overhead
     park(rt, R[u]);
+#if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 64)
+    asm volatile("" :: "v"(K.x[0]), "v"(K.x[1]), "v"(K.x[2]), "v"(K.x[3]));      // (the rows still arrive)
+#else
     park(kvt, K);
+#endif
 #if TSDE_H3_ORDER
     // EXPERIMENT (-DTSDE_H3_ORDER=1; measured, NOT faster).  The memory counter is in order: a wait for a request also waits for
     // everything requested before it.  In the shipped order the next tile's k rows are requested right behind the rel rows of PF tiles
@@ -234,11 +243,20 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
       u4 fa[4][2], fb[4][2];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {                           // k-steps 0, 1: the rel half of K; 2, 3: the k_node half
+#if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 64)                 // (timing only: the k_node half reads the rel fragments again -- no k tile traffic)
+        const char* tile = rt;
+#else
         const char* tile = s < 2 ? rt : kvt;
+#endif
         fa[s][0] = *reinterpret_cast<const u4*>(tile + a1off[0][s & 1]);
         fa[s][1] = *reinterpret_cast<const u4*>(tile + a1off[1][s & 1]);
+#if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 32)                 // (W1 from the registers that computed it: 4 KB of LDS reads a tile less)
+        fb[s][0] = bh[s];
+        fb[s][1] = bl[s];
+#else
         fb[s][0] = *reinterpret_cast<const u4*>(w1 + (2 * s + 0) * 512 + w1off);
         fb[s][1] = *reinterpret_cast<const u4*>(w1 + (2 * s + 1) * 512 + w1off);
+#endif
       }
       H3_FENCE();
 #pragma unroll
