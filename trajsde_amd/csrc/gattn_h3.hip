@@ -76,6 +76,50 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 #endif
 constexpr int H3_KV_TILES = TSDE_H3_ORDER ? 2 : 1;
 constexpr int H3_WAVE_LDS = 4096 + 4096 * H3_KV_TILES + 4096 + (64 + 64 + 16) * 4;       // rel tile | k tile (| v tile) | W1 | q, node sums, head scalars
+// -DTSDE_H3_ASMLD=1: the tile loop's row / index requests are issued from inline assembly and waited for by hand.  Reason (the listing of
+// the builtin form): the compiler's own waits in this loop are `s_waitcnt vmcnt(12)` before the rel rows are parked and `vmcnt(0)` before
+// the k rows are -- it drains EVERY outstanding request once a tile, so the rel rows "PF tiles ahead" have always arrived one tile
+// after they were requested, whatever PF and whatever the order of the requests.  Requests the compiler cannot see are not waited for
+// by it; the counts below are those of the request order written in tile_step (listing checked: vmcnt(28) / (8) / (12) a tile at PF = 2,
+// 16 for the first tile).  MEASURED (one box, alternating, parity tests green): 158.0 / 156.9 us a layer against 157.3 / 157.9 with the
+// compiler's waits; PF = 3: 159.0 / 158.1; PF = 4: 158.7 / 159.5.  So even with the look-ahead really in flight the layer takes what it
+// took: the rows were never what a tile waits for.  Kept as a switch (default off) because it is the clean form of that experiment.
+#ifndef TSDE_H3_ASMLD
+#define TSDE_H3_ASMLD 0
+#endif
+typedef int h3_rsrc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h3_rsrc h3_rsrc_words(const void* base) {      // raw buffer descriptor in four scalar registers (attn_common.hpp row_rsrc)
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  h3_rsrc r;
+  r.x = __builtin_amdgcn_readfirstlane(int(uint32_t(a)));
+  r.y = __builtin_amdgcn_readfirstlane(int(uint32_t(a >> 32) & 0xFFFFu));
+  r.z = -1;
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ f4 h3_asm_load128(h3_rsrc rs, int off) {
+  f4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(rs));
+  return v;
+}
+__device__ __forceinline__ int h3_asm_load32(h3_rsrc rs, int off) {
+  int v;
+  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(rs));
+  return v;
+}
+// at most N requests of this wave still outstanding.  No "memory" clobber (with one the compiler drains every counter around each of
+// these statements and keeps the row registers in scratch): the wait is tied to the registers it releases -- their readers cannot be
+// moved in front of it -- and volatile statements keep their order among themselves
+template <int N>
+__device__ __forceinline__ void h3_wait_vm(f4& a, f4& b, f4& c, f4& d) {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void h3_wait_vm(int& a, int& b, int& c, int& d) {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
 #ifndef TSDE_H3_OCC
 #define TSDE_H3_OCC 2
 #endif
@@ -159,25 +203,55 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
   //  are addressed from row 0: N < 2^23 is checked on the host)
   const __amdgpu_buffer_rsrc_t rs_rel = row_rsrc(rel + int64_t(beg) * 64), rs_kn = row_rsrc(kn), rs_vn = row_rsrc(vn);
   const __amdgpu_buffer_rsrc_t rs_src = row_rsrc(reinterpret_cast<const float*>(src + beg));
-  auto row4 = [&](__amdgpu_buffer_rsrc_t rs, int row) {
+#if TSDE_H3_ASMLD
+  const h3_rsrc as_rel = h3_rsrc_words(rel + int64_t(beg) * 64), as_kn = h3_rsrc_words(kn), as_vn = h3_rsrc_words(vn);
+  const h3_rsrc as_src = h3_rsrc_words(src + beg);
+  auto row4 = [&](__amdgpu_buffer_rsrc_t rs, int row) __attribute__((always_inline)) {
+    (void)rs;
+    return f4{0.f, 0.f, 0.f, 0.f};
+  };
+#else
+  auto row4 = [&](__amdgpu_buffer_rsrc_t rs, int row) __attribute__((always_inline)) {
     return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, row * 256 + 16 * nn, 0, 0));
   };
+#endif
   const int deg = end - beg, lim = deg - 1 - 4 * g;
   auto fetch_idx = [&](int (&sidx)[4], int e0) {
     const int o = e0 - beg;                                  // uniform
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sidx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_src, (min(o + j, lim) + 4 * g) * 4, 0, 0);
+    for (int j = 0; j < 4; ++j) {
+#if TSDE_H3_ASMLD
+      sidx[j] = h3_asm_load32(as_src, (min(o + j, lim) + 4 * g) * 4);
+#else
+      sidx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_src, (min(o + j, lim) + 4 * g) * 4, 0, 0);
+#endif
+    }
   };
-  auto fetch_rel = [&](H3Rows& R, int e0) {                  // chunk nn of the rows 4g .. 4g+3: the stored pieces, as they are
+  auto fetch_rel = [&](H3Rows& R, int e0) __attribute__((always_inline)) {                  // chunk nn of the rows 4g .. 4g+3: the stored pieces, as they are
     const int o = e0 - beg;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) R.x[j] = row4(rs_rel, H3_EXP_REL(min(o + j, lim) + 4 * g));
+    for (int j = 0; j < 4; ++j) {
+#if TSDE_H3_ASMLD
+      R.x[j] = h3_asm_load128(as_rel, H3_EXP_REL(min(o + j, lim) + 4 * g) * 256 + 16 * nn);
+#else
+      R.x[j] = row4(rs_rel, H3_EXP_REL(min(o + j, lim) + 4 * g));
+#endif
+    }
   };
+#if TSDE_H3_ASMLD
+  auto fetch_rows = [&](H3Rows& X, h3_rsrc rs, const int (&sidx)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) X.x[j] = h3_asm_load128(rs, H3_EXP_NODE(sidx[j]) * 256 + 16 * nn);
+  };
+#define rs_kn as_kn
+#define rs_vn as_vn
+#else
   auto fetch_rows = [&](H3Rows& X, __amdgpu_buffer_rsrc_t rs, const int (&sidx)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) X.x[j] = row4(rs, H3_EXP_NODE(sidx[j]));
   };
-  auto park = [&](char* tile, const H3Rows& X) {             // rows 4g .. 4g+3, chunk nn -> position nn ^ row
+#endif
+  auto park = [&](char* tile, const H3Rows& X) __attribute__((always_inline)) {             // rows 4g .. 4g+3, chunk nn -> position nn ^ row
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = 4 * g + j;
@@ -191,7 +265,7 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
 #pragma unroll
     for (int s = 0; s < 2; ++s) a1off[p][s] = nn * 256 + 16 * ((8 * p + 4 * s + g) ^ nn);
   const int trow = 4 * g + (nn >> 2), tpp = nn & 3;           // B operand of P2: this lane addresses row trow, columns 4 tpp .. of a 16-column block
-  auto troff = [&](int piece, int cb) { return trow * 256 + 16 * ((8 * piece + 2 * cb + (tpp >> 1)) ^ trow) + 8 * (tpp & 1); };
+  auto troff = [&](int piece, int cb) __attribute__((always_inline)) { return trow * 256 + 16 * ((8 * piece + 2 * cb + (tpp >> 1)) ^ trow) + 8 * (tpp & 1); };
 
 #ifndef TSDE_H3_PF
 #define TSDE_H3_PF 2
@@ -202,13 +276,24 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
 #if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 4)
   f4 lg_prev = f4{0.f, 0.f, 0.f, 0.f};      // (timing experiment: a tile's softmax uses the PREVIOUS tile's logits -- the dataflow of a software pipeline)
 #endif
-  auto tile_at = [&](int i) { return beg + 16 * i; };
-  auto tile_step = [&](int i, auto U_, auto V_) {             // u = i % PF, v = i & 1: compile-time (the register sets must stay registers)
+  auto tile_at = [&](int i) __attribute__((always_inline)) { return beg + 16 * i; };
+  auto tile_step = [&](int i, auto U_, auto V_, auto W_) __attribute__((always_inline)) {     // u = i % PF, v = i & 1: compile-time (the register sets must stay registers)
     constexpr int u = decltype(U_)::value, v = decltype(V_)::value;
+    // W_: how many requests may still be outstanding when this tile's rel rows are needed.  The request order of a tile is rel (PF ahead),
+    // k (next tile) | v (next tile), indices (three ahead) -- 16 a tile -- so in the steady state rel rows requested PF tiles ago have
+    // 12 + 16 (PF - 1) younger requests behind them; in the first tiles of a target the prologue's order decides (see the loop below)
+    constexpr int wait_rel = decltype(W_)::value;
+    (void)wait_rel;
     const int e0 = tile_at(i);
     __builtin_amdgcn_wave_barrier();                          // the previous tile's fragment reads are done (same wave, in order)
     clk.mark(0);                                              // [0] loop overhead
+#if TSDE_H3_ASMLD
+    h3_wait_vm<wait_rel>(R[u].x[0], R[u].x[1], R[u].x[2], R[u].x[3]);
+#endif
     park(rt, R[u]);
+#if TSDE_H3_ASMLD
+    h3_wait_vm<8>(K.x[0], K.x[1], K.x[2], K.x[3]);            // this tile's k rows: its v rows and the indices two ahead stay in flight
+#endif
 #if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 64)
     asm volatile("" :: "v"(K.x[0]), "v"(K.x[1]), "v"(K.x[2]), "v"(K.x[3]));      // (the rows still arrive)
 #else
@@ -275,6 +360,9 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
     __builtin_amdgcn_wave_barrier();                          // the k fragments have been read: the region takes the v rows
     clk.mark(2);                                              // [2] P1: fragment reads + 12 matrix instructions
 #if !TSDE_H3_ORDER
+#if TSDE_H3_ASMLD
+    h3_wait_vm<12>(V.x[0], V.x[1], V.x[2], V.x[3]);           // this tile's v rows: younger are the indices, the rel rows PF ahead, the next k rows
+#endif
     park(kvt, V);
     fetch_rows(V, rs_vn, idx[v ^ 1]);                         // the next tile's v rows ...
     fetch_idx(idx[v ^ 1], tile_at(i + 3));                    // ... and the indices of the tile after the next two
@@ -346,21 +434,40 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
     fetch_idx(idx[1], tile_at(1));
 #pragma unroll
     for (int u = 0; u < PF; ++u) fetch_rel(R[u], tile_at(u));
+#if TSDE_H3_ASMLD
+    h3_wait_vm<4 + 4 * PF>(idx[0][0], idx[0][1], idx[0][2], idx[0][3]);      // the first tile's indices: the second tile's and the rel rows stay in flight
+#endif
     fetch_rows(K, rs_kn, idx[0]);
     fetch_rows(V, rs_vn, idx[0]);
     fetch_idx(idx[0], tile_at(2));
     constexpr int UN = (PF % 2 == 0) ? PF : 2 * PF;           // a trip of the loop: every set index a compile-time constant
-    for (int i0 = 0; tile_at(i0) < end; i0 += UN) {
+    // one trip = UN tiles.  In the FIRST trip the tiles 0 .. PF - 2 find the prologue's request order behind their rel rows: the later rel
+    // sets, k, v and indices of the prologue (4 (PF - 1 - j) + 12) and 16 a tile since; from tile PF - 1 on the steady count holds
+    auto trip = [&](int i0, auto FIRST_) __attribute__((always_inline)) {
       bool done = false;
-      static_for_<UN>([&](auto J) {
+      static_for_<UN>([&](auto J) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
+        constexpr int steady = 12 + 16 * (PF - 1);
+        constexpr int w = (decltype(FIRST_)::value && j < PF - 1) ? 4 * (PF - 1 - j) + 12 + 16 * j : steady;
         if (!done) {
-          if (tile_at(i0 + j) < end) tile_step(i0 + j, std::integral_constant<int, j % PF>{}, std::integral_constant<int, (j & 1)>{});
+          if (tile_at(i0 + j) < end)
+            tile_step(i0 + j, std::integral_constant<int, j % PF>{}, std::integral_constant<int, (j & 1)>{}, std::integral_constant<int, w>{});
           else done = true;
         }
       });
-      if (done) break;
-    }
+      return done;
+    };
+    if (!trip(0, std::true_type{}))
+      for (int i0 = UN; tile_at(i0) < end; i0 += UN)
+        if (trip(i0, std::false_type{})) break;
+#if TSDE_H3_ASMLD
+    // the look-ahead of the last tiles: nothing may land in a register after this
+    static_for_<PF>([&](auto U) { h3_wait_vm<0>(R[decltype(U)::value].x[0], R[decltype(U)::value].x[1], R[decltype(U)::value].x[2], R[decltype(U)::value].x[3]); });
+    h3_wait_vm<0>(K.x[0], K.x[1], K.x[2], K.x[3]);
+    h3_wait_vm<0>(V.x[0], V.x[1], V.x[2], V.x[3]);
+    h3_wait_vm<0>(idx[0][0], idx[0][1], idx[0][2], idx[0][3]);
+    h3_wait_vm<0>(idx[1][0], idx[1][1], idx[1][2], idx[1][3]);
+#endif
   }
   clk.mark(5);
   __builtin_amdgcn_wave_barrier();                            // the last tile's reads of the rel tile are done: sbuf takes its place
