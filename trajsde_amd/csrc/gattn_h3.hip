@@ -123,6 +123,9 @@ __device__ __forceinline__ void h3_wait_vm(int& a, int& b, int& c, int& d) {
 #ifndef TSDE_H3_OCC
 #define TSDE_H3_OCC 2
 #endif
+#ifndef TSDE_H3_SKIP
+#define TSDE_H3_SKIP 0          // timing experiments (wrong results): 1 no first product, 2 no softmax reductions, 4 no second product, 8 no parking
+#endif
 __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                                      const int32_t* __restrict__ src, const float* __restrict__ rel,
                                                                      const float* __restrict__ q, const float* __restrict__ kn,
@@ -252,11 +255,16 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
   };
 #endif
   auto park = [&](char* tile, const H3Rows& X) __attribute__((always_inline)) {             // rows 4g .. 4g+3, chunk nn -> position nn ^ row
+#if TSDE_H3_SKIP & 8                                           // (timing only: the rows arrive but are not written to the LDS)
+    (void)tile;
+    asm volatile("" :: "v"(X.x[0]), "v"(X.x[1]), "v"(X.x[2]), "v"(X.x[3]));
+#else
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = 4 * g + j;
       *reinterpret_cast<f4*>(tile + r * 256 + 16 * (nn ^ r)) = X.x[j];
     }
+#endif
   };
   // per-lane LDS offsets of the fragments (bytes into a tile)
   int a1off[2][2];                                           // A operand of P1: [piece][k-step]: row nn, chunk 8 p + 4 s + g
@@ -344,6 +352,9 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
 #endif
       }
       H3_FENCE();
+#if TSDE_H3_SKIP & 1                                           // (timing only: no first product -- its fragment reads are dead code too)
+      t0 = f4{float(e0), float(i), float(nn), float(g)};
+#else
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const h8 ah = __builtin_bit_cast(h8, fa[s][0]), al = __builtin_bit_cast(h8, fa[s][1]);
@@ -352,6 +363,7 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
         t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, t1, 0, 0, 0);
         t2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t2, 0, 0, 0);
       }
+#endif
       lg = t0 + (t1 + t2);
 #if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 4)
       { const f4 tmp = lg; lg = lg_prev; lg_prev = tmp; }
@@ -374,8 +386,10 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
       if (e0 + 4 * g + r >= end) lg[r] = -INFINITY;
       cm = fmaxf(cm, lg[r]);
     }
+#if !(TSDE_H3_SKIP & 2)                                        // (timing only, bit 2: no cross-lane maximum, no rescaling)
     cm = row_max(cm);                                         // over the four lane groups: the head's 16 edges
-    if (__builtin_amdgcn_ballot_w64(cm > m + H3_LAZY) != 0ull) {
+#endif
+    if (!(TSDE_H3_SKIP & 2) && __builtin_amdgcn_ballot_w64(cm > m + H3_LAZY) != 0ull) {
       const float mn = fmaxf(m, cm);
       const float sc = fast_exp(m - mn);                      // m = -inf on the first tile -> 0
       m = mn;
@@ -403,6 +417,11 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
     clk.mark(3);                                              // [3] v rows parked, softmax, the weights' split
     // ---- P2 over the tile's 16 edges with K = 32 instructions (gattn.hip): B carries the rows' high pieces in slots 0..3 and their low
     //      pieces in 4..7 -- the transposing read hands lane i column 16 cb + i of the lane group's four rows --, A one piece of the weights
+#if TSDE_H3_SKIP & 4                                           // (timing only: no second product, no transposing reads)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) O[c] += ex * float(c + 1);
+    (void)a2h; (void)a2l;
+#else
     s4v fh[8], fl[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -422,6 +441,7 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
       const uint2 hw = __builtin_bit_cast(uint2, fh[c]), lw = __builtin_bit_cast(uint2, fl[c]);
       O[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2l, __builtin_bit_cast(h8, u4{hw.x, hw.y, lw.x, lw.y}), O[c], 0, 0, 0);
     }
+#endif
 #ifdef TSDE_STAMPS
     asm volatile("" : "+v"(O[0]), "+v"(O[7]));
     clk.mark(4);                                              // [4] P2: 16 transposing reads, 16 matrix instructions
@@ -592,8 +612,60 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
     }
     __syncthreads();
     const int t_end = min(ps + (chunk + 1) * SC_CH, pe);
-    for (int node = ps + chunk * SC_CH + wv; node < t_end; node += SC_WAVES) {
+    // Per-target state of the stream (segment, descriptors) and the register sets of the rows in flight live OUTSIDE the target loop: the
+    // first tiles of the NEXT target are requested before the current target's epilogue (open_target), so a target does not start cold
+    int deg = 0, limR = 0;
+    __amdgpu_buffer_rsrc_t rs_rel = row_rsrc(rel), rs_src = row_rsrc(reinterpret_cast<const float*>(src));
+    auto fetch_rel = [&](H3Rows& R, int o) {                 // o: the tile's first edge, relative to the segment
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        R.x[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_rel, (min(o + j, limR) + 4 * g) * 256 + 16 * nn, 0, 0));
+    };
+    // the cache rows a lane addresses: as an edge-on-a-lane reader (edge nn) and as a transposing reader (edge 4g + (nn >> 2))
+    auto fetch_src = [&](int& sa, int& st_, int o) {
+      sa = __builtin_amdgcn_raw_buffer_load_b32(rs_src, min(o + nn, deg - 1) * 4, 0, 0);
+      st_ = __builtin_amdgcn_raw_buffer_load_b32(rs_src, min(o + 4 * g + (nn >> 2), deg - 1) * 4, 0, 0);
+    };
+    int a1off[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) a1off[p][s] = nn * 256 + 16 * ((8 * p + 4 * s + g) ^ nn);
+    const int trow = 4 * g + (nn >> 2), tpp = nn & 3;
+#ifndef TSDE_SC_PF
+#define TSDE_SC_PF 2
+#endif
+    constexpr int SPF = TSDE_SC_PF;                           // tiles the rel rows (and the source indices) travel ahead
+    H3Rows R[SPF];
+    int sA[SPF], sT[SPF];
+    auto open_target = [&](int nd) {                         // the target's segment; its first tiles' rows and indices on their way
+      const int beg = segptr[nd], end = segptr[nd + 1];
+      rs_rel = row_rsrc(rel + int64_t(beg) * 64);
+      rs_src = row_rsrc(reinterpret_cast<const float*>(src + beg));
+#if defined(TSDE_SC_EXP) && TSDE_SC_EXP == 1                   // (timing experiment: no tiles at all -- what a target costs by itself)
+      deg = 0 * (end - beg);
+#elif defined(TSDE_SC_EXP) && TSDE_SC_EXP == 2                 // (timing experiment: one tile per target)
+      deg = min(end - beg, 16);
+#else
+      deg = end - beg;
+#endif
+      limR = deg - 1 - 4 * g;
+      if (deg > 0) {
+#pragma unroll
+        for (int u = 0; u < SPF; ++u) {
+          fetch_rel(R[u], 16 * u);
+          fetch_src(sA[u], sT[u], 16 * u);
+        }
+      }
+    };
+    const int node0 = ps + chunk * SC_CH + wv;
+    if (node0 < t_end) open_target(node0);
+    for (int node = node0; node < t_end; node += SC_WAVES) {
       __builtin_amdgcn_wave_barrier();
+      f4 O[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) O[c] = f4{0.f, 0.f, 0.f, 0.f};
+      float m = -INFINITY, spart = 0.f;
       // ---- W1 as B operand: lane (head nn & 7, g), step s, slot j = W1[32 s + 8 g + j][head]; columns 8 .. 15 mirror 0 .. 7 (never read)
       const float ql = q[int64_t(node) * 64 + lane] * INV_SQRT_DH;
       qbuf[lane] = ql;
@@ -606,9 +678,9 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
         f4 w[2][2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) w[s][0] = w[s][1] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 2      // (NOT the full unroll: 32 row loads in flight at once spilled 106 registers into the tile loop -- 183 us a layer against 147)
         for (int d = 0; d < 8; ++d) {
-          const float qd = d < 4 ? qa[d] : qb[d - 4];
+          const float qd = d < 4 ? qa[d & 3] : qb[d & 3];
           const float* row = wke + (8 * hh + d) * 64 + 8 * g;
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
@@ -623,43 +695,6 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
         split_kstep(hh == 4 + g ? qa : z, hh == 4 + g ? qb : z, b1h[3], b1l[3]);
       }
       __builtin_amdgcn_wave_barrier();                        // qbuf has been read: the region is the rel tile again
-      const int beg = segptr[node], end = segptr[node + 1];
-      f4 O[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) O[c] = f4{0.f, 0.f, 0.f, 0.f};
-      float m = -INFINITY, spart = 0.f;
-      const __amdgpu_buffer_rsrc_t rs_rel = row_rsrc(rel + int64_t(beg) * 64);
-      const __amdgpu_buffer_rsrc_t rs_src = row_rsrc(reinterpret_cast<const float*>(src + beg));
-#if defined(TSDE_SC_EXP) && TSDE_SC_EXP == 1                   // (timing experiment: no tiles at all -- what a target costs by itself)
-      const int deg = 0;
-#elif defined(TSDE_SC_EXP) && TSDE_SC_EXP == 2                 // (timing experiment: one tile per target)
-      const int deg = min(end - beg, 16);
-#else
-      const int deg = end - beg;
-#endif
-      const int limR = deg - 1 - 4 * g;
-      auto fetch_rel = [&](H3Rows& R, int o) {               // o: the tile's first edge, relative to the segment
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          R.x[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_rel, (min(o + j, limR) + 4 * g) * 256 + 16 * nn, 0, 0));
-      };
-      // the cache rows a lane addresses: as an edge-on-a-lane reader (edge nn) and as a transposing reader (edge 4g + (nn >> 2))
-      auto fetch_src = [&](int& sa, int& st_, int o) {
-        sa = __builtin_amdgcn_raw_buffer_load_b32(rs_src, min(o + nn, deg - 1) * 4, 0, 0);
-        st_ = __builtin_amdgcn_raw_buffer_load_b32(rs_src, min(o + 4 * g + (nn >> 2), deg - 1) * 4, 0, 0);
-      };
-      int a1off[2][2];
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) a1off[p][s] = nn * 256 + 16 * ((8 * p + 4 * s + g) ^ nn);
-      const int trow = 4 * g + (nn >> 2), tpp = nn & 3;
-#ifndef TSDE_SC_PF
-#define TSDE_SC_PF 2
-#endif
-      constexpr int SPF = TSDE_SC_PF;                         // tiles the rel rows (and the source indices) travel ahead
-      H3Rows R[SPF];
-      int sA[SPF], sT[SPF];
       auto tile_step = [&](int i, auto U_) {
         constexpr int u = decltype(U_)::value;
         const int o = 16 * i;
@@ -794,11 +829,6 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
 #endif
       };
       if (deg > 0) {
-#pragma unroll
-        for (int u = 0; u < SPF; ++u) {
-          fetch_rel(R[u], 16 * u);
-          fetch_src(sA[u], sT[u], 16 * u);
-        }
         for (int i0 = 0; 16 * i0 < deg; i0 += SPF) {
           bool done = false;
           static_for_<SPF>([&](auto J) {
@@ -812,6 +842,8 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
         }
       }
       __builtin_amdgcn_wave_barrier();                        // the last tile's reads are done: the region is scratch again
+      const int deg_done = deg;
+      if (node + SC_WAVES < t_end) open_target(node + SC_WAVES);      // (the row sets are free: the next target's first tiles leave now)
       // ---- per target: normalise, lin_v_edge on the aggregated rel rows, store (k_global_attn_h3's epilogue)
       const float ssum = row_sum(spart);
       const float inv = 1.0f / (ssum + 1e-16f);
@@ -849,7 +881,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
 #pragma unroll
         for (int e = 0; e < 4; ++e) out = fmaf(wr[e], sv[e], out);
       }
-      agg[int64_t(node) * 64 + lane] = deg > 0 ? out : 0.f;
+      agg[int64_t(node) * 64 + lane] = deg_done > 0 ? out : 0.f;
       clk.mark(6);                                            // [6] per-target prologue + epilogue (and the unit's staging)
     }
   }
