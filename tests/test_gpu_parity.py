@@ -443,9 +443,10 @@ def _random_graph_cases(count, seed):
 
 @pytest.mark.gpu
 def test_scene_cached_global_attention_leaves_large_scenes_to_the_gathering_kernel(dev, tmp_path):
-    """TRAJSDE_REL_SPLIT=2 (gattn_h3.hip k_global_attn_sc): a scene's k_node / v_node rows are parked in LDS, which holds 256 actors;
-    a batch that mixes a 20-actor scene with a 270-actor one must come out the same -- the large scene's targets are taken by the
-    gathering kernel launched beside it -- as the default forward"""
+    """the default global attention (gattn_h3.hip k_global_attn_sc, TRAJSDE_REL_SPLIT=2) parks a scene's k_node / v_node rows in LDS,
+    which holds 256 actors; a batch that mixes a 20-actor scene with a 270-actor one must come out the same -- the large scene's
+    targets are taken by the gathering kernel launched beside it -- as with the fp32-matrix kernel (=0) and the gathering kernel
+    alone (=1)"""
     import os
     import subprocess
     import sys
@@ -461,7 +462,7 @@ def test_scene_cached_global_attention_leaves_large_scenes_to_the_gathering_kern
         "o = m.to('cuda')(b.to('cuda'), noise=NoiseSpec(seed=6))\n"
         "torch.save({k: v.cpu() for k, v in o.items()}, sys.argv[1])\n") % (H.ROOT, os.path.join(H.ROOT, "tests"))
     outs = {}
-    for mode, env in (("default", {}), ("scene_cache", {"TRAJSDE_REL_SPLIT": "2"}), ("split", {"TRAJSDE_REL_SPLIT": "1"})):
+    for mode, env in (("default", {"TRAJSDE_REL_SPLIT": "0"}), ("scene_cache", {}), ("split", {"TRAJSDE_REL_SPLIT": "1"})):
         path = str(tmp_path / (mode + ".pt"))
         subprocess.run([sys.executable, "-c", script, path], check=True, env={**os.environ, **env}, timeout=600)
         outs[mode] = torch.load(path)
@@ -631,10 +632,11 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
                       ("two_kernel", {"TRAJSDE_ATTN_FUSED": "0"}),
                       ("fused_one_tile", {"TRAJSDE_FUSED_TILES": "1"}),
                       ("gattn_mm", {"TRAJSDE_GATTN_MM": "1"}),
-                      ("gattn_vector", {"TRAJSDE_GATTN_F32MM": "0"}),
+                      ("gattn_vector", {"TRAJSDE_GATTN_F32MM": "0", "TRAJSDE_REL_SPLIT": "0"}),
+                      ("gattn_f32", {"TRAJSDE_REL_SPLIT": "0"}),
                       ("rel_split", {"TRAJSDE_REL_SPLIT": "1"}),
                       ("rel_split_scene_cache", {"TRAJSDE_REL_SPLIT": "2"}),
-                      ("gattn_two_tiles", {"TRAJSDE_GMF_TILES": "2"}),
+                      ("gattn_two_tiles", {"TRAJSDE_GMF_TILES": "2", "TRAJSDE_REL_SPLIT": "0"}),
                       ("pipelined", {"TRAJSDE_EDGE_PIPE": "1"}),
                       ("tile32", {"TRAJSDE_EDGE_TILE": "32"}),
                       ("tile32_pingpong", {"TRAJSDE_EDGE_TILE": "32", "TRAJSDE_EDGE_PINGPONG": "1"}),
@@ -659,12 +661,16 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
         assert torch.equal(outs["split"][key], outs["fused_one_tile"][key]), key         # 16 waves x 1 tile: the same streams, the same bits
         # the global attention on the matrix cores (gattn.hip): logits and weighted sums as split products over 16-edge tiles
         assert H.maxdiff(outs["split"][key], outs["gattn_mm"][key]) <= 2e-5, key
-        # the default global attention (gattn_f32.hip: fp32 matrix instructions) against the vector form it replaced (attn.hip k_global_attn)
-        assert H.maxdiff(outs["split"][key], outs["gattn_vector"][key]) <= 2e-5, key
-        # ... against the fp16x3 form on rel rows that their writer stored as split operand pieces (gattn_h3.hip: round 6, product library)
+        # the fp32-matrix global attention (gattn_f32.hip) against the vector form it replaced (attn.hip k_global_attn)
+        assert H.maxdiff(outs["gattn_f32"][key], outs["gattn_vector"][key]) <= 2e-5, key
+        # the default global attention since the end of round 6 (gattn_h3.hip k_global_attn_sc: fp16x3 products on rel / node rows that
+        # their writers store as split operand pieces, a scene's k_node / v_node rows resident in LDS) against the fp32-matrix kernel on
+        # fp32 rows it replaced (gattn_f32.hip k_global_attn_mf) ...
+        assert H.maxdiff(outs["split"][key], outs["gattn_f32"][key]) <= 2e-5, key
+        # ... against the gathering form on the same rows (k_global_attn_h3: what scenes beyond the cache take)
         assert H.maxdiff(outs["split"][key], outs["rel_split"][key]) <= 2e-5, key
-        # ... and its scene-cached form (k_global_attn_sc: a scene's k_node / v_node rows resident in LDS)
-        assert H.maxdiff(outs["split"][key], outs["rel_split_scene_cache"][key]) <= 2e-5, key
+        # ... and the explicit switch is the default
+        assert torch.equal(outs["split"][key], outs["rel_split_scene_cache"][key]), key
         # ... and against its 32-edges-a-step form (k_global_attn_mf2: two tiles of a target through every phase together)
         assert H.maxdiff(outs["split"][key], outs["gattn_two_tiles"][key]) <= 2e-5, key
         assert torch.equal(outs["split"][key], outs["pipelined"][key]), key              # k_edge_attn2p: the tiles one stage apart, the same bits

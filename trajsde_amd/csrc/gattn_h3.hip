@@ -903,10 +903,13 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
 // Neither a 5x shorter matrix part, nor 128 fewer split values a lane and tile, nor a third wave per SIMD, nor the node rows out of an
 // LDS cache (12 KB -> 4 KB through L1 per tile), nor rel rows three or four tiles ahead, nor every fragment read issued before its
 // product's first matrix instruction moved the sum.  TRAJSDE_REL_SPLIT=1 selects this kernel, =2 the scene-cached one.
-bool rel_split_enabled() {
-  static const bool v = []() { const char* e = getenv("TRAJSDE_REL_SPLIT"); return e && atoi(e) != 0; }();
+// Default since the end of round 6: 2 (the scene-cached kernel, with the gathering one beside it for scenes beyond the cache); 1 selects
+// the gathering kernel alone, 0 the fp32-matrix kernel on fp32 rows (k_global_attn_mf, the default until then).
+static int rel_split_mode() {
+  static const int v = []() { const char* e = getenv("TRAJSDE_REL_SPLIT"); return e ? atoi(e) : 2; }();
   return v;
 }
+bool rel_split_enabled() { return rel_split_mode() != 0; }
 int launch_global_attn_h3(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
                           const float* vn, int64_t N, float* agg, hipStream_t st) {
   TS_LAUNCH_TAG("k_global_attn<8>", false, k_global_attn_h3, xcd_grid(cdiv(N, 4)), 256, 0, st, img, segptr, src, rel, q, kn, vn, N, agg,
@@ -914,10 +917,7 @@ int launch_global_attn_h3(const float* img, const int32_t* segptr, const int32_t
   return TRAJSDE_OK;
 }
 // TRAJSDE_REL_SPLIT=2: the scene-cached form, with the gathering form beside it for scenes beyond the cache
-bool rel_split_scene_cache() {
-  static const bool v = []() { const char* e = getenv("TRAJSDE_REL_SPLIT"); return e && atoi(e) == 2; }();
-  return v;
-}
+bool rel_split_scene_cache() { return rel_split_mode() == 2; }
 int launch_scene_ptr(const int64_t* scene_of, int N, int A, int32_t* scene_ptr, hipStream_t st) {
   TS_LAUNCH(k_scene_ptr, cdiv(int64_t(N) + 1, 256), 256, 0, st, scene_of, N, A, scene_ptr);
   return TRAJSDE_OK;

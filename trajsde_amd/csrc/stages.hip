@@ -555,9 +555,9 @@ static int aggregator_forward_impl(const trajsde_batch* b, const trajsde_graph* 
     if (fused) {
       // one wave per target: logits, softmax and aggregation in one pass over the rel rows (no per-edge GEMM)
       TS_REQUIRE(N < (1 << 23), "aggregator_forward: node rows are addressed with 32-bit byte offsets (N < 2^23)");
-      if (split && rel_split_scene_cache()) {
+      // (the scene-cached form needs the batch vector and room for the scene pointers; without them the gathering form serves alone)
+      if (split && rel_split_scene_cache() && b->batch != nullptr && b->A > 0 && b->A + 2 <= E * 8 + 8) {      // (A = scenes: 0 without fake agents)
         int32_t* scene_ptr = reinterpret_cast<int32_t*>(w.logits);        // (the unfused path's per-edge logits: idle in this form)
-        TS_REQUIRE(b->A + 2 <= E * 8 + 8 && b->batch != nullptr, "aggregator_forward: scene-cached attention needs the batch vector");
         if (i == 0)
           if (int rc = launch_scene_ptr(b->batch, b->N, b->A, scene_ptr, st)) return rc;
         if (int rc = launch_global_attn_sc(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, b->A, b->batch, scene_ptr, w.agg, st))
