@@ -50,6 +50,56 @@ __global__ __launch_bounds__(THREADS) void k_seg(const float* __restrict__ rel, 
   if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = pad[lane];
 }
 
+
+// mode 2: the structure of the global attention kernels around the same stream -- THINK dependent fmas a tile between consuming a tile and
+// requesting the next (the tile's arithmetic), persistent workgroups of 8 waves that take TPW targets a wave one after the other
+// (k_global_attn_sc / _mf) or one wave per target (k_global_attn_h3), the workgroups of an XCD on consecutive targets or dealt round-robin,
+// and a stagger: wave w idles w * STAG fmas before its first tile, so that the waves of a CU do not request and think in phase
+template <int DEPTH, int THINK, int TPW, bool XCD, int STAG>
+__global__ __launch_bounds__(512) void k_struct(const float* __restrict__ rel, int nseg, int rows, float* out) {
+  __shared__ float pad[(160 * 1024 - 2048) / 4];
+  if (rows < 0) pad[threadIdx.x] = 1.f;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nn = lane & 15, g = lane >> 4;
+  // 256 workgroups; XCD: workgroup b runs on XCD b & 7 (round-robin dispatch) and takes block (b & 7) * 32 + (b >> 3) of targets
+  const int blk = XCD ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  f4 acc = f4{0, 0, 0, 0};
+  float chain = float(lane);
+  for (int s = 0; s < STAG * wv; ++s) chain = __builtin_fmaf(chain, 1.0000001f, 1e-9f);
+  for (int k = 0; k < TPW; ++k) {
+    const int seg = blk * (8 * TPW) + k * 8 + wv;
+    if (seg >= nseg) break;
+    const float* base = rel + size_t(seg) * rows * 64;
+    const int ntiles = (rows + 15) / 16;
+    f4 R[DEPTH][4];
+    auto fetch = [&](f4 (&r)[4], int t) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int row = 16 * t + 4 * g + j;
+        row = row < rows ? row : rows - 1;
+        r[j] = *reinterpret_cast<const f4*>(base + size_t(row) * 64 + 4 * nn);
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) fetch(R[d], d);
+    for (int t0 = 0; t0 < ntiles; t0 += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        if (t0 + d < ntiles) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc += R[d][j];
+          chain += acc[0];
+          fetch(R[d], t0 + d + DEPTH < ntiles ? t0 + d + DEPTH : ntiles - 1);       // (as in the kernels: the set is re-requested BEFORE the tile's arithmetic)
+          asm volatile("" : "+v"(chain));
+#pragma unroll 8
+          for (int s = 0; s < THINK; ++s) chain = __builtin_fmaf(chain, 1.0000001f, 1e-9f);      // ~4 cycles each for a lone wave
+          asm volatile("" : "+v"(chain));
+        }
+      }
+    }
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] + chain == 12345.678f) out[0] = pad[lane];
+}
+
 template <class F>
 static double time_ms(F f, int reps = 20) {
   hipEvent_t a, b;
@@ -78,5 +128,11 @@ int main() {
   SEG(1, 256, 3) SEG(2, 256, 3) SEG(4, 256, 3)
   SEG(1, 256, 4) SEG(2, 256, 4) SEG(4, 256, 4) SEG(2, 256, 8)
   SEG(2, 512, 1) SEG(4, 512, 1)
+#define STR(D, TH, TPW, X, SG) ms = time_ms([&] { k_struct<D, TH, TPW, X, SG><<<nseg / (8 * TPW), 512>>>(rel, nseg, rows, out); }); \
+  printf("8-wave workgroups, %d targets a wave, depth %d, think %4d fmas, xcd-contiguous %d, stagger %4d   %7.1f us  %5.2f TB/s\n", TPW, D, TH, int(X), SG, ms * 1e3, bytes / ms / 1e9);
+  STR(2, 0, 4, false, 0) STR(2, 0, 4, true, 0) STR(2, 0, 1, false, 0)
+  STR(2, 128, 4, false, 0) STR(2, 256, 4, false, 0) STR(2, 512, 4, false, 0) STR(2, 512, 4, true, 0)
+  STR(4, 512, 4, false, 0) STR(2, 512, 4, false, 128) STR(2, 512, 4, false, 1024) STR(2, 512, 1, false, 0) STR(4, 512, 1, false, 0)
+  STR(2, 1024, 4, false, 0) STR(4, 1024, 4, false, 0)
   return 0;
 }

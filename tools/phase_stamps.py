@@ -23,9 +23,9 @@ TABLES = {
     "gattn": (8, "16-edge tiles", ["issue the loads of the tiles ahead", "wait for this tile's rel / k_node rows", "splits + stage writes",
                                    "P1: fragment reads + 12 matrix instr.", "softmax", "P2: splits + 16 matrix instr.", "loop overhead",
                                    "per-target epilogue (W_ve, store)"]),
-    "gh3": (8, "16-edge tiles", ["loop overhead", "wait for this tile's rel / k rows, park them", "P1: fragment reads + 12 matrix instr. (+ requests)",
-                                 "wait for the v rows, park them; softmax; split of the weights", "P2: 16 transposing reads + 16 matrix instr.",
-                                 "loop exit", "per-target epilogue (W_ve, store)", "-"]),
+    "gh3": (8, "16-edge tiles", ["loop overhead", "wait for this tile's rows (sc: rel rows + indices)", "h3: P1 | sc: parking + requests of the tiles ahead",
+                                 "h3: v rows, softmax, split | sc: P1", "h3: P2 | sc: softmax", "h3: loop exit | sc: P2",
+                                 "per-target prologue + epilogue (sc: and the unit's staging)", "-"]),
     "tail": (8, "16-edge tiles", ["request the loads (geometry, target rows, scalars)", "first layers of the two branches", "two products, LayerNorm, ReLU",
                                   "third product, LayerNorm", "d emb: two adjoint products on the target rows", "LayerNorm backwards, W2^T adjoint, mask",
                                   "three slabs out (whole rows)", "-"]),

@@ -62,6 +62,13 @@ constexpr float H3_LAZY = 8.0f;              // the running maximum follows a ti
 struct H3Rows {                              // what a lane brings for one tile, one kind of row: edges 4g .. 4g+3, 16 bytes of each
   f4 x[4];
 };
+// (k_global_attn_sc) at most N requests of this wave outstanding; tied to the registers it releases (see h3_wait_vm)
+template <int N>
+__device__ __forceinline__ void sc_wait_vm(H3Rows& R, int& a, int& b) {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(R.x[0]), "+v"(R.x[1]), "+v"(R.x[2]), "+v"(R.x[3]), "+v"(a), "+v"(b) : "n"(N));
+}
+
 typedef short s4v __attribute__((ext_vector_type(4)));
 
 // Second form (round 6, after the first one measured on par with the fp32-matrix kernel and the ablations said "latency, not pipes"):
@@ -551,6 +558,11 @@ constexpr int SC_CAP = 256, SC_CH = 32, SC_WAVES = 8, SC_CHUNKS = SC_CAP / SC_CH
 #define TSDE_SC_SKIP 0          // timing experiments: 1 no first product, 2 no softmax, 4 no second product, 8 no parking (wrong results)
 #endif
 constexpr int SC_LDS_BYTES = SC_CAP * 512 + SC_WAVES * 4096;
+// The tile loop's row / index requests from inline assembly, waited for by hand (h3_asm_load*, above): the compiler's own wait in this
+// loop is `s_waitcnt vmcnt(0)` at the loop latch -- every request drained once a trip, the rows "two tiles ahead" included.
+#ifndef TSDE_SC_ASMLD
+#define TSDE_SC_ASMLD 1
+#endif
 
 // scene_ptr[s] = first node of scene s (batch ids ascending, as collate builds them), scene_ptr[A] = N
 __global__ void k_scene_ptr(const int64_t* __restrict__ scene_of, int N, int A, int32_t* __restrict__ scene_ptr) {
@@ -586,6 +598,74 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
     const int sc = unit / SC_CHUNKS, chunk = unit % SC_CHUNKS;
     const int ps = scene_ptr[sc], pe = scene_ptr[sc + 1], ns = pe - ps;
     if (ns > SC_CAP || chunk * SC_CH >= ns) continue;        // (uniform) left to the gathering kernel / no such chunk
+    const int t_end = min(ps + (chunk + 1) * SC_CH, pe);
+    // Per-target state of the stream (segment, descriptors) and the register sets of the rows in flight live OUTSIDE the target loop: the
+    // first tiles of the NEXT target are requested before the current target's epilogue (open_target), and those of the unit's FIRST
+    // target before the scene's rows are copied into the cache, so no target starts cold
+    int deg = 0, limR = 0;
+#if TSDE_SC_ASMLD
+    h3_rsrc rs_rel = h3_rsrc_words(rel), rs_src = h3_rsrc_words(src);
+    auto fetch_rel = [&](H3Rows& R, int o) __attribute__((always_inline)) {      // o: the tile's first edge, relative to the segment
+#pragma unroll
+      for (int j = 0; j < 4; ++j) R.x[j] = h3_asm_load128(rs_rel, (min(o + j, limR) + 4 * g) * 256 + 16 * nn);
+    };
+    // the cache rows a lane addresses: as an edge-on-a-lane reader (edge nn) and as a transposing reader (edge 4g + (nn >> 2))
+    auto fetch_src = [&](int& sa, int& st_, int o) __attribute__((always_inline)) {
+      sa = h3_asm_load32(rs_src, min(o + nn, deg - 1) * 4);
+      st_ = h3_asm_load32(rs_src, min(o + 4 * g + (nn >> 2), deg - 1) * 4);
+    };
+#else
+    __amdgpu_buffer_rsrc_t rs_rel = row_rsrc(rel), rs_src = row_rsrc(reinterpret_cast<const float*>(src));
+    auto fetch_rel = [&](H3Rows& R, int o) {                 // o: the tile's first edge, relative to the segment
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        R.x[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_rel, (min(o + j, limR) + 4 * g) * 256 + 16 * nn, 0, 0));
+    };
+    // the cache rows a lane addresses: as an edge-on-a-lane reader (edge nn) and as a transposing reader (edge 4g + (nn >> 2))
+    auto fetch_src = [&](int& sa, int& st_, int o) {
+      sa = __builtin_amdgcn_raw_buffer_load_b32(rs_src, min(o + nn, deg - 1) * 4, 0, 0);
+      st_ = __builtin_amdgcn_raw_buffer_load_b32(rs_src, min(o + 4 * g + (nn >> 2), deg - 1) * 4, 0, 0);
+    };
+#endif
+    int a1off[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) a1off[p][s] = nn * 256 + 16 * ((8 * p + 4 * s + g) ^ nn);
+    const int trow = 4 * g + (nn >> 2), tpp = nn & 3;
+#ifndef TSDE_SC_PF
+#define TSDE_SC_PF 2
+#endif
+    constexpr int SPF = TSDE_SC_PF;                           // tiles the rel rows (and the source indices) travel ahead
+    H3Rows R[SPF];
+    int sA[SPF], sT[SPF];
+    auto open_target = [&](int nd) __attribute__((always_inline)) {      // the target's segment; its first tiles' rows and indices on their way
+      const int beg = segptr[nd], end = segptr[nd + 1];
+#if TSDE_SC_ASMLD
+      rs_rel = h3_rsrc_words(rel + int64_t(beg) * 64);
+      rs_src = h3_rsrc_words(src + beg);
+#else
+      rs_rel = row_rsrc(rel + int64_t(beg) * 64);
+      rs_src = row_rsrc(reinterpret_cast<const float*>(src + beg));
+#endif
+#if defined(TSDE_SC_EXP) && TSDE_SC_EXP == 1                   // (timing experiment: no tiles at all -- what a target costs by itself)
+      deg = 0 * (end - beg);
+#elif defined(TSDE_SC_EXP) && TSDE_SC_EXP == 2                 // (timing experiment: one tile per target)
+      deg = min(end - beg, 16);
+#else
+      deg = end - beg;
+#endif
+      limR = deg - 1 - 4 * g;
+      if (deg > 0) {
+#pragma unroll
+        for (int u = 0; u < SPF; ++u) {
+          fetch_rel(R[u], 16 * u);
+          fetch_src(sA[u], sT[u], 16 * u);
+        }
+      }
+    };
+    const int node0 = ps + chunk * SC_CH + wv;
+    if (node0 < t_end) open_target(node0);
     __syncthreads();                                         // the previous unit's readers of the cache are done
     {
       // the scene's rows -> the cache: thread i takes 16-byte chunk (i & 15) of row (i >> 4), eight requests in flight
@@ -611,55 +691,6 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
       }
     }
     __syncthreads();
-    const int t_end = min(ps + (chunk + 1) * SC_CH, pe);
-    // Per-target state of the stream (segment, descriptors) and the register sets of the rows in flight live OUTSIDE the target loop: the
-    // first tiles of the NEXT target are requested before the current target's epilogue (open_target), so a target does not start cold
-    int deg = 0, limR = 0;
-    __amdgpu_buffer_rsrc_t rs_rel = row_rsrc(rel), rs_src = row_rsrc(reinterpret_cast<const float*>(src));
-    auto fetch_rel = [&](H3Rows& R, int o) {                 // o: the tile's first edge, relative to the segment
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        R.x[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_rel, (min(o + j, limR) + 4 * g) * 256 + 16 * nn, 0, 0));
-    };
-    // the cache rows a lane addresses: as an edge-on-a-lane reader (edge nn) and as a transposing reader (edge 4g + (nn >> 2))
-    auto fetch_src = [&](int& sa, int& st_, int o) {
-      sa = __builtin_amdgcn_raw_buffer_load_b32(rs_src, min(o + nn, deg - 1) * 4, 0, 0);
-      st_ = __builtin_amdgcn_raw_buffer_load_b32(rs_src, min(o + 4 * g + (nn >> 2), deg - 1) * 4, 0, 0);
-    };
-    int a1off[2][2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) a1off[p][s] = nn * 256 + 16 * ((8 * p + 4 * s + g) ^ nn);
-    const int trow = 4 * g + (nn >> 2), tpp = nn & 3;
-#ifndef TSDE_SC_PF
-#define TSDE_SC_PF 2
-#endif
-    constexpr int SPF = TSDE_SC_PF;                           // tiles the rel rows (and the source indices) travel ahead
-    H3Rows R[SPF];
-    int sA[SPF], sT[SPF];
-    auto open_target = [&](int nd) {                         // the target's segment; its first tiles' rows and indices on their way
-      const int beg = segptr[nd], end = segptr[nd + 1];
-      rs_rel = row_rsrc(rel + int64_t(beg) * 64);
-      rs_src = row_rsrc(reinterpret_cast<const float*>(src + beg));
-#if defined(TSDE_SC_EXP) && TSDE_SC_EXP == 1                   // (timing experiment: no tiles at all -- what a target costs by itself)
-      deg = 0 * (end - beg);
-#elif defined(TSDE_SC_EXP) && TSDE_SC_EXP == 2                 // (timing experiment: one tile per target)
-      deg = min(end - beg, 16);
-#else
-      deg = end - beg;
-#endif
-      limR = deg - 1 - 4 * g;
-      if (deg > 0) {
-#pragma unroll
-        for (int u = 0; u < SPF; ++u) {
-          fetch_rel(R[u], 16 * u);
-          fetch_src(sA[u], sT[u], 16 * u);
-        }
-      }
-    };
-    const int node0 = ps + chunk * SC_CH + wv;
-    if (node0 < t_end) open_target(node0);
     for (int node = node0; node < t_end; node += SC_WAVES) {
       __builtin_amdgcn_wave_barrier();
       f4 O[8];
@@ -681,7 +712,11 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
 #pragma unroll 2      // (NOT the full unroll: 32 row loads in flight at once spilled 106 registers into the tile loop -- 183 us a layer against 147)
         for (int d = 0; d < 8; ++d) {
           const float qd = d < 4 ? qa[d & 3] : qb[d & 3];
+#if defined(TSDE_SC_EXP) && TSDE_SC_EXP == 3                   // (timing experiment: the per-target weight rows from four cache lines)
+          const float* row = wke + (d & 1) * 64 + 8 * (g & 1);
+#else
           const float* row = wke + (8 * hh + d) * 64 + 8 * g;
+#endif
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             w[s][0] += *reinterpret_cast<const f4*>(row + 32 * s) * qd;
@@ -695,11 +730,17 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
         split_kstep(hh == 4 + g ? qa : z, hh == 4 + g ? qb : z, b1h[3], b1l[3]);
       }
       __builtin_amdgcn_wave_barrier();                        // qbuf has been read: the region is the rel tile again
-      auto tile_step = [&](int i, auto U_) {
+      auto tile_step = [&](int i, auto U_) __attribute__((always_inline)) {
         constexpr int u = decltype(U_)::value;
         const int o = 16 * i;
         __builtin_amdgcn_wave_barrier();                      // the previous tile's fragment reads are done (same wave, in order)
         clk.mark(0);                                          // [0] loop overhead
+#if TSDE_SC_ASMLD
+        // six requests a tile (four row pieces, two indices), issued SPF tiles ahead in tile order -- by open_target for a target's first
+        // SPF tiles, by the step below afterwards: behind this tile's requests there are those of the SPF - 1 tiles after it (and
+        // whatever the compiler issued since: its presence only makes this wait stricter, never laxer)
+        sc_wait_vm<6 * (SPF - 1)>(R[u], sA[u], sT[u]);
+#endif
 #ifdef TSDE_STAMPS
         { f4 t0 = R[u].x[0], t1 = R[u].x[3]; int t2 = sA[u], t3 = sT[u]; asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3)); }
         clk.mark(1);                                          // [1] waiting for this tile's rel rows / source indices
@@ -831,7 +872,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
       if (deg > 0) {
         for (int i0 = 0; 16 * i0 < deg; i0 += SPF) {
           bool done = false;
-          static_for_<SPF>([&](auto J) {
+          static_for_<SPF>([&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
             if (!done) {
               if (16 * (i0 + j) < deg) tile_step(i0 + j, J);
@@ -843,6 +884,11 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
       }
       __builtin_amdgcn_wave_barrier();                        // the last tile's reads are done: the region is scratch again
       const int deg_done = deg;
+#if TSDE_SC_ASMLD
+      // the clamped look-ahead of the last tiles: nothing of it may land in a register set that is about to be requested into again
+#pragma unroll
+      for (int u = 0; u < SPF; ++u) sc_wait_vm<0>(R[u], sA[u], sT[u]);
+#endif
       if (node + SC_WAVES < t_end) open_target(node + SC_WAVES);      // (the row sets are free: the next target's first tiles leave now)
       // ---- per target: normalise, lin_v_edge on the aggregated rel rows, store (k_global_attn_h3's epilogue)
       const float ssum = row_sum(spart);
@@ -876,7 +922,11 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
       float out = fmaf(img[GAttnL::BVE + lane], hbuf[8 + h], obuf[lane]);
 #pragma unroll
       for (int k4 = 0; k4 < 16; ++k4) {
+#if defined(TSDE_SC_EXP) && TSDE_SC_EXP == 3
+        const f4 wr = *reinterpret_cast<const f4*>(wve + (lane & 1) * 64 + 4 * (k4 & 3));
+#else
         const f4 wr = *reinterpret_cast<const f4*>(wve + lane * 64 + 4 * k4);
+#endif
         const f4 sv = *reinterpret_cast<const f4*>(&sbuf[h][4 * k4]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) out = fmaf(wr[e], sv[e], out);
