@@ -90,7 +90,8 @@ constexpr int H3_WAVE_LDS = 4096 + 4096 * H3_KV_TILES + 4096 + (64 + 64 + 16) * 
 // by it; the counts below are those of the request order written in tile_step (listing checked: vmcnt(28) / (8) / (12) a tile at PF = 2,
 // 16 for the first tile).  MEASURED (one box, alternating, parity tests green): 158.0 / 156.9 us a layer against 157.3 / 157.9 with the
 // compiler's waits; PF = 3: 159.0 / 158.1; PF = 4: 158.7 / 159.5.  So even with the look-ahead really in flight the layer takes what it
-// took: the rows were never what a tile waits for.  Kept as a switch (default off) because it is the clean form of that experiment.
+// took: the rows were never what a tile waits for.  Kept as a switch (default off) for the record of that experiment -- and UNSAFE as a
+// product form: see TSDE_SC_ASMLD (a register the compiler believes loaded may be copied by it before the hand-written wait).
 #ifndef TSDE_H3_ASMLD
 #define TSDE_H3_ASMLD 0
 #endif
@@ -558,10 +559,14 @@ constexpr int SC_CAP = 256, SC_CH = 32, SC_WAVES = 8, SC_CHUNKS = SC_CAP / SC_CH
 #define TSDE_SC_SKIP 0          // timing experiments: 1 no first product, 2 no softmax, 4 no second product, 8 no parking (wrong results)
 #endif
 constexpr int SC_LDS_BYTES = SC_CAP * 512 + SC_WAVES * 4096;
-// The tile loop's row / index requests from inline assembly, waited for by hand (h3_asm_load*, above): the compiler's own wait in this
-// loop is `s_waitcnt vmcnt(0)` at the loop latch -- every request drained once a trip, the rows "two tiles ahead" included.
+// -DTSDE_SC_ASMLD=1: the tile loop's row / index requests from inline assembly, waited for by hand (h3_asm_load*, above), because the
+// compiler's own wait in this loop is `s_waitcnt vmcnt(0)` at the loop latch -- every request drained once a trip, the rows "two tiles
+// ahead" included.  UNSAFE, kept for the record only: 139 against 142 us a layer, but the full GPU suite fails with it (18 tests, results
+// that differ run to run).  A value the compiler believes to be in a register the moment the assembly statement has been issued may be
+// COPIED by it before the hand-written wait (the listing shows such a move of an index register at the loop head): the copy reads the
+// register before the request has landed.  (Longer straight-line trips, the safe way to fewer drains, spill: see the tile loop.)
 #ifndef TSDE_SC_ASMLD
-#define TSDE_SC_ASMLD 1
+#define TSDE_SC_ASMLD 0
 #endif
 
 // scene_ptr[s] = first node of scene s (batch ids ascending, as collate builds them), scene_ptr[A] = N
@@ -870,6 +875,9 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
 #endif
       };
       if (deg > 0) {
+        // (Tried: trips of 4 / 8 tiles as straight-line code, so that the compiler's drain at the loop latch -- `s_waitcnt vmcnt(0)`: it does
+        //  not carry request counts around a back edge -- comes once per 4 / 8 tiles instead of once per SPF.  Inside such a trip its
+        //  waits are exact (vmcnt(13) .. (8)), but the longer schedule spills 20 registers: 164 us a layer against 142.)
         for (int i0 = 0; 16 * i0 < deg; i0 += SPF) {
           bool done = false;
           static_for_<SPF>([&](auto J) __attribute__((always_inline)) {
