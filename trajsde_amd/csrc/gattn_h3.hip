@@ -877,7 +877,8 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
       if (deg > 0) {
         // (Tried: trips of 4 / 8 tiles as straight-line code, so that the compiler's drain at the loop latch -- `s_waitcnt vmcnt(0)`: it does
         //  not carry request counts around a back edge -- comes once per 4 / 8 tiles instead of once per SPF.  Inside such a trip its
-        //  waits are exact (vmcnt(13) .. (8)), but the longer schedule spills 20 registers: 164 us a layer against 142.)
+        //  waits are exact (vmcnt(13) .. (8)), yet the layer takes 157 / 164 us against 142, with or without scheduling fences between the
+        //  tiles; the 20 registers it spills are spilled in the cache fill, not here.)
         for (int i0 = 0; 16 * i0 < deg; i0 += SPF) {
           bool done = false;
           static_for_<SPF>([&](auto J) __attribute__((always_inline)) {
