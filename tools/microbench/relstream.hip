@@ -55,8 +55,8 @@ __global__ __launch_bounds__(THREADS) void k_seg(const float* __restrict__ rel, 
 // requesting the next (the tile's arithmetic), persistent workgroups of 8 waves that take TPW targets a wave one after the other
 // (k_global_attn_sc / _mf) or one wave per target (k_global_attn_h3), the workgroups of an XCD on consecutive targets or dealt round-robin,
 // and a stagger: wave w idles w * STAG fmas before its first tile, so that the waves of a CU do not request and think in phase
-template <int DEPTH, int THINK, int TPW, bool XCD, int STAG>
-__global__ __launch_bounds__(512) void k_struct(const float* __restrict__ rel, int nseg, int rows, float* out) {
+template <int DEPTH, int THINK, int TPW, bool XCD, int STAG, int IDX = 0>
+__global__ __launch_bounds__(512) void k_struct(const float* __restrict__ rel, int nseg, int rows, float* out, const int* __restrict__ idxs = nullptr) {
   __shared__ float pad[(160 * 1024 - 2048) / 4];
   if (rows < 0) pad[threadIdx.x] = 1.f;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nn = lane & 15, g = lane >> 4;
@@ -71,24 +71,32 @@ __global__ __launch_bounds__(512) void k_struct(const float* __restrict__ rel, i
     const float* base = rel + size_t(seg) * rows * 64;
     const int ntiles = (rows + 15) / 16;
     f4 R[DEPTH][4];
-    auto fetch = [&](f4 (&r)[4], int t) {
+    int IA[DEPTH], IB[DEPTH];
+    const int* ib = idxs + size_t(seg) * rows;
+    auto fetch = [&](f4 (&r)[4], int& ia, int& ibv, int t) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int row = 16 * t + 4 * g + j;
         row = row < rows ? row : rows - 1;
         r[j] = *reinterpret_cast<const f4*>(base + size_t(row) * 64 + 4 * nn);
       }
+      if (IDX) {                                               // the two source-index loads of a tile (k_global_attn_sc fetch_src)
+        int e0 = 16 * t + nn, e1 = 16 * t + 4 * g + (nn >> 2);
+        ia = ib[e0 < rows ? e0 : rows - 1];
+        ibv = ib[e1 < rows ? e1 : rows - 1];
+      }
     };
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) fetch(R[d], d);
+    for (int d = 0; d < DEPTH; ++d) fetch(R[d], IA[d], IB[d], d);
     for (int t0 = 0; t0 < ntiles; t0 += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
         if (t0 + d < ntiles) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc += R[d][j];
+          if (IDX) acc[1] += float(IA[d] + IB[d]);
           chain += acc[0];
-          fetch(R[d], t0 + d + DEPTH < ntiles ? t0 + d + DEPTH : ntiles - 1);       // (as in the kernels: the set is re-requested BEFORE the tile's arithmetic)
+          fetch(R[d], IA[d], IB[d], t0 + d + DEPTH < ntiles ? t0 + d + DEPTH : ntiles - 1);       // (as in the kernels: the set is re-requested BEFORE the tile's arithmetic)
           asm volatile("" : "+v"(chain));
 #pragma unroll 8
           for (int s = 0; s < THINK; ++s) chain = __builtin_fmaf(chain, 1.0000001f, 1e-9f);      // ~4 cycles each for a lone wave
@@ -118,6 +126,7 @@ int main() {
   const size_t bytes = size_t(nseg) * rows * 256;
   float *rel, *out;
   hipMalloc(&rel, bytes); hipMalloc(&out, 16);
+  int* idxs; hipMalloc(&idxs, size_t(nseg) * rows * 4); hipMemset(idxs, 0, size_t(nseg) * rows * 4);
   hipMemset(rel, 0x3c, bytes);
   printf("# %zu MB in %d segments of %d rows\n", bytes >> 20, nseg, rows);
   double ms = time_ms([&] { k_ideal<<<256 * 8, 256>>>(reinterpret_cast<const f4*>(rel), bytes / 16, out); });
@@ -134,5 +143,8 @@ int main() {
   STR(2, 128, 4, false, 0) STR(2, 256, 4, false, 0) STR(2, 512, 4, false, 0) STR(2, 512, 4, true, 0)
   STR(4, 512, 4, false, 0) STR(2, 512, 4, false, 128) STR(2, 512, 4, false, 1024) STR(2, 512, 1, false, 0) STR(4, 512, 1, false, 0)
   STR(2, 1024, 4, false, 0) STR(4, 1024, 4, false, 0)
+#define STRI(D, TH, TPW) ms = time_ms([&] { k_struct<D, TH, TPW, true, 0, 1><<<nseg / (8 * TPW), 512>>>(rel, nseg, rows, out, idxs); }); \
+  printf("8-wave workgroups, %d targets a wave, depth %d, think %4d fmas, xcd-contiguous 1, + two index loads a tile   %7.1f us  %5.2f TB/s\n", TPW, D, TH, ms * 1e3, bytes / ms / 1e9);
+  STRI(2, 0, 4) STRI(2, 128, 4) STRI(2, 256, 4)
   return 0;
 }
