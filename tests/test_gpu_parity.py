@@ -636,7 +636,6 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
                       ("gattn_f32", {"TRAJSDE_REL_SPLIT": "0"}),
                       ("rel_split", {"TRAJSDE_REL_SPLIT": "1"}),
                       ("rel_split_scene_cache", {"TRAJSDE_REL_SPLIT": "2"}),
-                      ("gattn_u", {"TRAJSDE_GATTN_U": "1"}),
                       ("gattn_two_tiles", {"TRAJSDE_GMF_TILES": "2", "TRAJSDE_REL_SPLIT": "0"}),
                       ("pipelined", {"TRAJSDE_EDGE_PIPE": "1"}),
                       ("tile32", {"TRAJSDE_EDGE_TILE": "32"}),
@@ -672,8 +671,6 @@ def test_alternative_kernel_paths_agree(dev, tmp_path):
         assert H.maxdiff(outs["split"][key], outs["rel_split"][key]) <= 2e-5, key
         # ... and the explicit switch is the default
         assert torch.equal(outs["split"][key], outs["rel_split_scene_cache"][key]), key
-        # ... also with the per-target operand formed by a kernel of its own (k_gattn_u: the same sums in the same order)
-        assert torch.equal(outs["split"][key], outs["gattn_u"][key]), key
         # ... and against its 32-edges-a-step form (k_global_attn_mf2: two tiles of a target through every phase together)
         assert H.maxdiff(outs["split"][key], outs["gattn_two_tiles"][key]) <= 2e-5, key
         assert torch.equal(outs["split"][key], outs["pipelined"][key]), key              # k_edge_attn2p: the tiles one stage apart, the same bits

@@ -568,6 +568,9 @@ constexpr int SC_LDS_BYTES = SC_CAP * 512 + SC_WAVES * 4096;
 #ifndef TSDE_SC_ASMLD
 #define TSDE_SC_ASMLD 0
 #endif
+#ifndef TSDE_SC_W1_UNROLL
+#define TSDE_SC_W1_UNROLL 4
+#endif
 
 // scene_ptr[s] = first node of scene s (batch ids ascending, as collate builds them), scene_ptr[A] = N
 __global__ void k_scene_ptr(const int64_t* __restrict__ scene_of, int N, int A, int32_t* __restrict__ scene_ptr) {
@@ -577,67 +580,11 @@ __global__ void k_scene_ptr(const int64_t* __restrict__ scene_of, int N, int A, 
   for (int64_t sidx = prev + 1; sidx <= cur; ++sidx) scene_ptr[sidx] = i;      // (empty scenes, if any, get empty ranges)
 }
 
-// The per-target operand of the first product, formed ONCE per target by a kernel of its own instead of at the head of every target's
-// stream: U_h = Wke_h^T q_h / sqrt(dh) as the split B fragments the attention kernel's lanes hold -- [target][piece 2][k-step 2][g 4][head 8]
-// chunks of 16 B, 2 KB a target.  In the attention kernel this was 32 dependent weight-row loads (16 KB of Wke through L1) and ~4 us at the
-// head of each of a wave's four targets, with every wave of the chip in that phase at the same time (one tile per target: 55.7 us a layer
-// of 140); now it is four 16-byte loads a lane, requested with the target's first tiles.  Wke lives in this kernel's LDS.
-__global__ __launch_bounds__(256) void k_gattn_u(const float* __restrict__ img, const float* __restrict__ q, int64_t N, char* __restrict__ ufrag) {
-  constexpr int WP = 68;                                     // padded row: the eight heads' rows a wave reads together are 8 x 256 B apart
-  __shared__ __attribute__((aligned(16))) float wl[64 * WP];
-  const float* wke = img + GAttnL::WKE;
-  for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x)
-    *reinterpret_cast<f4*>(wl + (i >> 4) * WP + 4 * (i & 15)) = reinterpret_cast<const f4*>(wke)[i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nn = lane & 15, g = lane >> 4, hh = nn & 7;
-  constexpr int UB = 8;                                       // targets a wave takes at a time: their query values are requested together
-  const int64_t stride = int64_t(gridDim.x) * 4;
-  for (int64_t t0 = int64_t(blockIdx.x) * 4 + wv; t0 < N; t0 += stride * UB) {
-    f4 qa[UB], qb[UB];
-#pragma unroll
-    for (int k = 0; k < UB; ++k) {
-      const int64_t t = t0 + k * stride, tc = t < N ? t : N - 1;
-      qa[k] = *reinterpret_cast<const f4*>(q + tc * 64 + 8 * hh);
-      qb[k] = *reinterpret_cast<const f4*>(q + tc * 64 + 8 * hh + 4);
-    }
-#pragma unroll
-    for (int k = 0; k < UB; ++k) {
-      const int64_t t = t0 + k * stride;
-      const f4 a = qa[k] * INV_SQRT_DH, b = qb[k] * INV_SQRT_DH;
-      f4 w[2][2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) w[s][0] = w[s][1] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int d = 0; d < 8; ++d) {                            // the attention kernel's own order of the sum: the same bits
-        const float qd = d < 4 ? a[d] : b[d - 4];
-        const float* row = wl + (8 * hh + d) * WP + 8 * g;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          w[s][0] += *reinterpret_cast<const f4*>(row + 32 * s) * qd;
-          w[s][1] += *reinterpret_cast<const f4*>(row + 32 * s + 4) * qd;
-        }
-      }
-      u4 bh[2], bl[2];
-      split_kstep(w[0][0], w[0][1], bh[0], bl[0]);
-      split_kstep(w[1][0], w[1][1], bh[1], bl[1]);
-      if (nn < 8 && t < N) {
-        char* u = ufrag + t * 2048;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          *reinterpret_cast<u4*>(u + (((0 * 2 + s) * 4 + g) * 8 + hh) * 16) = bh[s];
-          *reinterpret_cast<u4*>(u + (((1 * 2 + s) * 4 + g) * 8 + hh) * 16) = bl[s];
-        }
-      }
-    }
-  }
-}
-
 __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* __restrict__ img, const int32_t* __restrict__ segptr,
                                                                   const int32_t* __restrict__ src, const float* __restrict__ rel,
                                                                   const float* __restrict__ q, const float* __restrict__ kn,
                                                                   const float* __restrict__ vn, int64_t N, int A,
-                                                                  const int32_t* __restrict__ scene_ptr, float* __restrict__ agg,
-                                                                  const char* __restrict__ ufrag) {
+                                                                  const int32_t* __restrict__ scene_ptr, float* __restrict__ agg) {
   extern __shared__ __attribute__((aligned(16))) char sc_lds[];
   char* const kc = sc_lds;                                   // [node][16 chunks]: chunk c of node r at position c ^ (r & 15)
   char* const vc = sc_lds + SC_CAP * 256;
@@ -700,21 +647,8 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
     constexpr int SPF = TSDE_SC_PF;                           // tiles the rel rows (and the source indices) travel ahead
     H3Rows R[SPF];
     int sA[SPF], sT[SPF];
-    u4 b1h[4], b1l[4];                                        // W1 as B operand: lane (head nn & 7, g), step s, slot j = W1[32 s + 8 g + j][head]
-    f4 qa_n = f4{0.f, 0.f, 0.f, 0.f}, qb_n = qa_n;            // the target's query values of head nn & 7 (the k_node half of W1)
     auto open_target = [&](int nd) __attribute__((always_inline)) {      // the target's segment; its first tiles' rows and indices on their way
       const int beg = segptr[nd], end = segptr[nd + 1];
-      if (ufrag != nullptr) {                                  // (uniform) the operand formed by k_gattn_u: four chunks a lane + the query values
-        const char* u = ufrag + int64_t(nd) * 2048;
-        const int hh = nn & 7;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          b1h[s] = *reinterpret_cast<const u4*>(u + (((0 * 2 + s) * 4 + g) * 8 + hh) * 16);
-          b1l[s] = *reinterpret_cast<const u4*>(u + (((1 * 2 + s) * 4 + g) * 8 + hh) * 16);
-        }
-        qa_n = *reinterpret_cast<const f4*>(q + int64_t(nd) * 64 + 8 * hh);
-        qb_n = *reinterpret_cast<const f4*>(q + int64_t(nd) * 64 + 8 * hh + 4);
-      }
 #if TSDE_SC_ASMLD
       rs_rel = h3_rsrc_words(rel + int64_t(beg) * 64);
       rs_src = h3_rsrc_words(src + beg);
@@ -772,24 +706,18 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
       for (int c = 0; c < 8; ++c) O[c] = f4{0.f, 0.f, 0.f, 0.f};
       float m = -INFINITY, spart = 0.f;
       // ---- W1 as B operand: lane (head nn & 7, g), step s, slot j = W1[32 s + 8 g + j][head]; columns 8 .. 15 mirror 0 .. 7 (never read)
-      if (ufrag != nullptr) {                                  // (uniform) the rel half arrived with open_target; the k_node half from the query values
-        const int hh = nn & 7;
-        const f4 qa = qa_n * INV_SQRT_DH, qb = qb_n * INV_SQRT_DH;
-        const f4 z = f4{0.f, 0.f, 0.f, 0.f};
-        split_kstep(hh == g ? qa : z, hh == g ? qb : z, b1h[2], b1l[2]);
-        split_kstep(hh == 4 + g ? qa : z, hh == 4 + g ? qb : z, b1h[3], b1l[3]);
-      } else {
       const float ql = q[int64_t(node) * 64 + lane] * INV_SQRT_DH;
       qbuf[lane] = ql;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      u4 b1h[4], b1l[4];
       {
         const int hh = nn & 7;
         const f4 qa = *reinterpret_cast<const f4*>(&qbuf[8 * hh]), qb = *reinterpret_cast<const f4*>(&qbuf[8 * hh + 4]);
         f4 w[2][2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) w[s][0] = w[s][1] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2      // (NOT the full unroll: 32 row loads in flight at once spilled 106 registers into the tile loop -- 183 us a layer against 147)
+#pragma unroll TSDE_SC_W1_UNROLL      // (rounds of row loads; the full unroll -- 32 in flight at once -- spilled 106 registers into the tile loop in the first form of this kernel: 183 us a layer against 147)
         for (int d = 0; d < 8; ++d) {
           const float qd = d < 4 ? qa[d & 3] : qb[d & 3];
 #if defined(TSDE_SC_EXP) && TSDE_SC_EXP == 3                   // (timing experiment: the per-target weight rows from four cache lines)
@@ -808,7 +736,6 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
         const f4 z = f4{0.f, 0.f, 0.f, 0.f};
         split_kstep(hh == g ? qa : z, hh == g ? qb : z, b1h[2], b1l[2]);
         split_kstep(hh == 4 + g ? qa : z, hh == 4 + g ? qb : z, b1h[3], b1l[3]);
-      }
       }
       __builtin_amdgcn_wave_barrier();                        // qbuf has been read: the region is the rel tile again
       auto tile_step = [&](int i, auto U_) __attribute__((always_inline)) {
@@ -1058,13 +985,10 @@ int launch_scene_ptr(const int64_t* scene_of, int N, int A, int32_t* scene_ptr, 
   return TRAJSDE_OK;
 }
 int launch_global_attn_sc(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
-                          const float* vn, int64_t N, int A, const int64_t* scene_of, const int32_t* scene_ptr, float* agg, char* ufrag,
-                          hipStream_t st) {
+                          const float* vn, int64_t N, int A, const int64_t* scene_of, const int32_t* scene_ptr, float* agg, hipStream_t st) {
   const int units = A * SC_CHUNKS;
-  if (ufrag != nullptr)                                      // (room for 2 KB a target in an idle buffer: stages.hip) the targets' operands, once
-    TS_LAUNCH(k_gattn_u, int(N < 1024 ? (N + 3) / 4 : 256), 256, 0, st, img, q, N, ufrag);
   TS_LAUNCH_TAG("k_global_attn<8>", false, k_global_attn_sc, xcd_grid(units < 256 ? units : 256), 64 * SC_WAVES, SC_LDS_BYTES, st, img, segptr, src, rel,
-                q, kn, vn, N, A, scene_ptr, agg, static_cast<const char*>(ufrag));
+                q, kn, vn, N, A, scene_ptr, agg);
   // the targets of scenes larger than the cache (none in the shipped configurations: the launch returns at its first branch)
   TS_LAUNCH_TAG("k_global_attn<8>[big scenes]", false, k_global_attn_h3, xcd_grid(cdiv(N, 4)), 256, 0, st, img, segptr, src, rel, q, kn, vn, N, agg,
                 scene_of, scene_ptr, SC_CAP);
@@ -1075,7 +999,7 @@ bool rel_split_enabled() { return false; }
 bool rel_split_scene_cache() { return false; }
 int launch_scene_ptr(const int64_t*, int, int, int32_t*, hipStream_t) { return fail(TRAJSDE_ERR_UNSUPPORTED, "fp16x3 build only"); }
 int launch_global_attn_sc(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, int64_t, int,
-                          const int64_t*, const int32_t*, float*, char*, hipStream_t) {
+                          const int64_t*, const int32_t*, float*, hipStream_t) {
   return fail(TRAJSDE_ERR_UNSUPPORTED, "the split-image global attention exists in the fp16x3 build only");
 }
 int launch_global_attn_h3(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, int64_t, float*,

@@ -111,8 +111,7 @@ int launch_global_attn_h3(const float* img, const int32_t* segptr, const int32_t
 bool rel_split_scene_cache();
 int launch_scene_ptr(const int64_t* scene_of, int N, int A, int32_t* scene_ptr, hipStream_t st);
 int launch_global_attn_sc(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
-                          const float* vn, int64_t N, int A, const int64_t* scene_of, const int32_t* scene_ptr, float* agg, char* ufrag,
-                          hipStream_t st);      // ufrag: N x 2 KB for the targets' operands (k_gattn_u), or null: formed inside the kernel
+                          const float* vn, int64_t N, int A, const int64_t* scene_of, const int32_t* scene_ptr, float* agg, hipStream_t st);
 // gattn_f32.hip: the same attention with its rel-row products on the fp32 matrix cores (8 heads, fp32 rows)
 bool gattn_f32mm_enabled();
 int launch_global_attn_mf(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,

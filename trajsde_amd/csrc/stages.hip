@@ -560,12 +560,7 @@ static int aggregator_forward_impl(const trajsde_batch* b, const trajsde_graph* 
         int32_t* scene_ptr = reinterpret_cast<int32_t*>(w.logits);        // (the unfused path's per-edge logits: idle in this form)
         if (i == 0)
           if (int rc = launch_scene_ptr(b->batch, b->N, b->A, scene_ptr, st)) return rc;
-        // TRAJSDE_GATTN_U=1: the targets' first-product operands formed once by a kernel of their own (k_gattn_u), 2 KB each, in the unfused
-        // path's per-edge v rows (idle here) when they fit.  Measured: k_global_attn_sc 141 -> 133.5 us a layer, the extra launch 11 us
-        // (as much as k_node_proj<3>: launch + staging of a weight image): one stream 2.263 against 2.253 ms, three streams equal.  Off.
-        static const bool u_kernel = []() { const char* e = getenv("TRAJSDE_GATTN_U"); return e && atoi(e) != 0; }();
-        char* ufrag = u_kernel && N * 512 <= E * 64 ? reinterpret_cast<char*>(w.v) : nullptr;
-        if (int rc = launch_global_attn_sc(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, b->A, b->batch, scene_ptr, w.agg, ufrag, st))
+        if (int rc = launch_global_attn_sc(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, b->A, b->batch, scene_ptr, w.agg, st))
           return rc;
       } else if (split) {
         if (int rc = launch_global_attn_h3(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, w.agg, st)) return rc;
