@@ -471,6 +471,35 @@ def test_scene_cached_global_attention_leaves_large_scenes_to_the_gathering_kern
         assert H.maxdiff(outs["default"][key], outs["split"][key]) <= 2e-5, key
 
 
+@pytest.mark.gpu
+def test_scene_cached_global_attention_stands_down_for_edges_that_join_two_scenes(dev, tmp_path):
+    """the scene-cached kernel reads a target's senders out of ITS scene's rows in LDS: right for the reference's collated graphs (every
+    global edge joins two actors of one scene), wrong for an edge list that joins two scenes -- which the reference would accept.  Such a
+    batch is detected on the device (k_scene_ptr) and handed to the gathering kernel whole: same trajectories as the fp32-matrix kernel"""
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import sys, torch; sys.path[:0] = [%r, %r]\n"
+        "import helpers as H\n"
+        "from trajsde_amd.runtime import NoiseSpec\n"
+        "from trajsde_amd.synth import synth\n"
+        "m, cfg = H.build_model(6, 20, 2.0, init_seed=2)\n"
+        "b = synth(S=3, n=24, L=8, F=20, box=90.0, seed=9, mixed_source=True)\n"
+        "extra = torch.tensor([[1, 30, 5, 60], [30, 1, 60, 5]], dtype=b['edge_index'].dtype)      # actors of scenes 0 / 1 and 0 / 2\n"
+        "b['edge_index'] = torch.cat([b['edge_index'], extra], dim=1).contiguous()\n"
+        "o = m.to('cuda')(b.to('cuda'), noise=NoiseSpec(seed=6))\n"
+        "torch.save({k: v.cpu() for k, v in o.items()}, sys.argv[1])\n") % (H.ROOT, os.path.join(H.ROOT, "tests"))
+    outs = {}
+    for mode, env in (("default", {}), ("fp32_matrix", {"TRAJSDE_REL_SPLIT": "0"}), ("gathering", {"TRAJSDE_REL_SPLIT": "1"})):
+        path = str(tmp_path / (mode + ".pt"))
+        subprocess.run([sys.executable, "-c", script, path], check=True, env={**os.environ, **env}, timeout=600)
+        outs[mode] = torch.load(path)
+    for key in ("loc", "pi", "diff_in", "diff_out"):
+        assert H.maxdiff(outs["default"][key], outs["fp32_matrix"][key]) <= 2e-5, key
+        assert torch.equal(outs["default"][key], outs["gathering"][key]), key      # the gathering kernel took every target
+
+
 @pytest.mark.parametrize("S,n,L,box,edges,seed,kw", _random_graph_cases(24, 11))
 def test_graph_stage_on_randomised_shapes_equals_the_oracle_lists(S, n, L, box, edges, seed, kw, dev):
     """the graph stage (rewritten in round 5: seven launches) over a seeded sweep of shapes: the three compacted lists equal the

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
                                                                      const float* __restrict__ q, const float* __restrict__ kn,
                                                                      const float* __restrict__ vn, int64_t N, float* __restrict__ agg,
                                                                      const int64_t* __restrict__ scene_of, const int32_t* __restrict__ scene_ptr,
-                                                                     int skip_cap) {
+                                                                     int skip_cap, int skip_flag) {
 #if defined(TSDE_H3_EXP) && (TSDE_H3_EXP & 16)              // (timing experiment: one workgroup per CU -- the LDS of a second one is taken)
   __shared__ __attribute__((aligned(16))) char wave_lds[4][H3_WAVE_LDS + 12288];
 #else
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, TSDE_H3_OCC) void k_global_attn_h3(const float
   const int64_t nc = node < N ? node : N - 1;
   if (scene_of != nullptr) {                                 // beside k_global_attn_sc: only the targets of scenes too large for its cache
     const int sc = int(scene_of[nc]);
-    if (scene_ptr[sc + 1] - scene_ptr[sc] <= skip_cap) return;   // (uniform per wave)
+    if (scene_ptr[skip_flag] == 0 && scene_ptr[sc + 1] - scene_ptr[sc] <= skip_cap) return;   // (uniform per wave; flag: k_scene_ptr)
   }
   const float* wke = img + GAttnL::WKE;
   const float* wve = img + GAttnL::WVE;
@@ -572,12 +572,23 @@ constexpr int SC_LDS_BYTES = SC_CAP * 512 + SC_WAVES * 4096;
 #define TSDE_SC_W1_UNROLL 4
 #endif
 
-// scene_ptr[s] = first node of scene s (batch ids ascending, as collate builds them), scene_ptr[A] = N
-__global__ void k_scene_ptr(const int64_t* __restrict__ scene_of, int N, int A, int32_t* __restrict__ scene_ptr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// scene_ptr[s] = first node of scene s (batch ids ascending, as collate builds them), scene_ptr[A] = N; scene_ptr[A + 1] (zeroed by the
+// launcher) becomes non-zero when the batch is NOT what the scene cache assumes -- scene ids that do not ascend over the nodes, or a
+// global edge that joins two scenes (the reference's collated graphs never do: AGG:41, the per-scene complete graphs of the data set).
+// The scene-cached kernel then does nothing and the gathering kernel beside it takes every target: a graph the reference would accept
+// is never computed wrongly, only more slowly.
+__global__ void k_scene_ptr(const int64_t* __restrict__ scene_of, int N, int A, const int32_t* __restrict__ esrc,
+                            const int32_t* __restrict__ edst, const int32_t* __restrict__ segptr, int32_t* __restrict__ scene_ptr) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t E = segptr[N];                               // the list's true length (the host may only know a bound: sync-free graphs)
+  if (i < E && scene_of[esrc[i]] != scene_of[edst[i]]) scene_ptr[A + 1] = 1;
   if (i > N) return;
   const int64_t cur = i < N ? scene_of[i] : A, prev = i > 0 ? scene_of[i - 1] : -1;
-  for (int64_t sidx = prev + 1; sidx <= cur; ++sidx) scene_ptr[sidx] = i;      // (empty scenes, if any, get empty ranges)
+  if (cur < prev || cur > A || prev < -1) {
+    scene_ptr[A + 1] = 1;
+    return;
+  }
+  for (int64_t sidx = prev + 1; sidx <= cur; ++sidx) scene_ptr[sidx] = int32_t(i);      // (empty scenes, if any, get empty ranges)
 }
 
 __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* __restrict__ img, const int32_t* __restrict__ segptr,
@@ -598,6 +609,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void k_global_attn_sc(const float* _
   const float* wke = img + GAttnL::WKE;
   const float* wve = img + GAttnL::WVE;
   const int n_units = A * SC_CHUNKS;
+  if (scene_ptr[A + 1] != 0) return;                         // (uniform) not a batch of self-contained scenes: k_scene_ptr
   PhaseClock<8> clk;                                         // (diagnostic builds only: stamps.hpp; table shared with k_global_attn_h3)
   clk.start();
   unsigned long long units = 0;
@@ -975,13 +987,16 @@ bool rel_split_enabled() { return rel_split_mode() != 0; }
 int launch_global_attn_h3(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
                           const float* vn, int64_t N, float* agg, hipStream_t st) {
   TS_LAUNCH_TAG("k_global_attn<8>", false, k_global_attn_h3, xcd_grid(cdiv(N, 4)), 256, 0, st, img, segptr, src, rel, q, kn, vn, N, agg,
-                static_cast<const int64_t*>(nullptr), static_cast<const int32_t*>(nullptr), 0);
+                static_cast<const int64_t*>(nullptr), static_cast<const int32_t*>(nullptr), 0, 0);
   return TRAJSDE_OK;
 }
 // TRAJSDE_REL_SPLIT=2: the scene-cached form, with the gathering form beside it for scenes beyond the cache
 bool rel_split_scene_cache() { return rel_split_mode() == 2; }
-int launch_scene_ptr(const int64_t* scene_of, int N, int A, int32_t* scene_ptr, hipStream_t st) {
-  TS_LAUNCH(k_scene_ptr, cdiv(int64_t(N) + 1, 256), 256, 0, st, scene_of, N, A, scene_ptr);
+int launch_scene_ptr(const int64_t* scene_of, int N, int A, const int32_t* esrc, const int32_t* edst, const int32_t* segptr, int64_t E_bound,
+                     int32_t* scene_ptr, hipStream_t st) {
+  TS_HIP(hipMemsetAsync(scene_ptr + A + 1, 0, sizeof(int32_t), st));
+  const int64_t n = E_bound > int64_t(N) + 1 ? E_bound : int64_t(N) + 1;
+  TS_LAUNCH(k_scene_ptr, cdiv(n, 256), 256, 0, st, scene_of, N, A, esrc, edst, segptr, scene_ptr);
   return TRAJSDE_OK;
 }
 int launch_global_attn_sc(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
@@ -991,13 +1006,13 @@ int launch_global_attn_sc(const float* img, const int32_t* segptr, const int32_t
                 q, kn, vn, N, A, scene_ptr, agg);
   // the targets of scenes larger than the cache (none in the shipped configurations: the launch returns at its first branch)
   TS_LAUNCH_TAG("k_global_attn<8>[big scenes]", false, k_global_attn_h3, xcd_grid(cdiv(N, 4)), 256, 0, st, img, segptr, src, rel, q, kn, vn, N, agg,
-                scene_of, scene_ptr, SC_CAP);
+                scene_of, scene_ptr, SC_CAP, A + 1);
   return TRAJSDE_OK;
 }
 #else
 bool rel_split_enabled() { return false; }
 bool rel_split_scene_cache() { return false; }
-int launch_scene_ptr(const int64_t*, int, int, int32_t*, hipStream_t) { return fail(TRAJSDE_ERR_UNSUPPORTED, "fp16x3 build only"); }
+int launch_scene_ptr(const int64_t*, int, int, const int32_t*, const int32_t*, const int32_t*, int64_t, int32_t*, hipStream_t) { return fail(TRAJSDE_ERR_UNSUPPORTED, "fp16x3 build only"); }
 int launch_global_attn_sc(const float*, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, int64_t, int,
                           const int64_t*, const int32_t*, float*, hipStream_t) {
   return fail(TRAJSDE_ERR_UNSUPPORTED, "the split-image global attention exists in the fp16x3 build only");

@@ -109,7 +109,8 @@ bool rel_split_enabled();
 int launch_global_attn_h3(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
                           const float* vn, int64_t N, float* agg, hipStream_t st);
 bool rel_split_scene_cache();
-int launch_scene_ptr(const int64_t* scene_of, int N, int A, int32_t* scene_ptr, hipStream_t st);
+int launch_scene_ptr(const int64_t* scene_of, int N, int A, const int32_t* esrc, const int32_t* edst, const int32_t* segptr, int64_t E_bound,
+                     int32_t* scene_ptr, hipStream_t st);
 int launch_global_attn_sc(const float* img, const int32_t* segptr, const int32_t* src, const float* rel, const float* q, const float* kn,
                           const float* vn, int64_t N, int A, const int64_t* scene_of, const int32_t* scene_ptr, float* agg, hipStream_t st);
 // gattn_f32.hip: the same attention with its rel-row products on the fp32 matrix cores (8 heads, fp32 rows)

@@ -559,7 +559,7 @@ static int aggregator_forward_impl(const trajsde_batch* b, const trajsde_graph* 
       if (split && rel_split_scene_cache() && b->batch != nullptr && b->A > 0 && b->A + 2 <= E * 8 + 8) {      // (A = scenes: 0 without fake agents)
         int32_t* scene_ptr = reinterpret_cast<int32_t*>(w.logits);        // (the unfused path's per-edge logits: idle in this form)
         if (i == 0)
-          if (int rc = launch_scene_ptr(b->batch, b->N, b->A, scene_ptr, st)) return rc;
+          if (int rc = launch_scene_ptr(b->batch, b->N, b->A, g->g_src, g->g_dst, g->g_segptr, E, scene_ptr, st)) return rc;
         if (int rc = launch_global_attn_sc(lb + AggLayerL::ATTN, g->g_segptr, g->g_src, w.rel, w.q, w.kn, w.vn, N, b->A, b->batch, scene_ptr, w.agg, st))
           return rc;
       } else if (split) {
